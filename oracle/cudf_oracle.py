@@ -1,0 +1,579 @@
+"""CPU oracle for the cudf hot path (sort / hash-join / groupby / scan / reduce / hash).
+
+TEST INFRASTRUCTURE ONLY.  Nothing under ``cudf_amd/`` may import this module: only
+``tests/``, ``__graft_entry__.smoke()`` and ``bench.py``'s ``cpu_baseline`` leg do, and there
+only as the checker.  The product path is the HIP library behind ``include/cudf_amd/gx.h``.
+
+Every function is a NumPy restatement of the *observable* semantics of the reference
+(rapidsai/cudf @ 26.10) for the hot path, citing the reference file:line it follows.  The
+digit passes / hash-table loops of the reference live in third-party CCCL (cub) and
+cuCollections (cuco), which are NOT vendored under /root/reference (pinned only through
+rapids-cmake's versions.json for release 26.10); their *results* are pinned here through
+
+  * the reference's own golden vectors (tests/golden/reference_vectors.py, transcribed from
+    cpp/tests/{sort,join,groupby,reductions}/*), checked in tests/test_oracle_golden.py, and
+  * the published MurmurHash3_x86_32 known-answer vectors (SMHasher), same test file.
+
+The reference itself (libcudf) cannot be built or imported in this environment (needs nvcc,
+CCCL, cuco, rmm and an NVIDIA GPU), so there is no ``oracle/_ref``.
+"""
+from __future__ import annotations
+
+import math
+from typing import Optional, Sequence, Tuple
+
+import numpy as np
+
+JOIN_NO_MATCH = np.int32(-(2**31))  # cpp/include/cudf/join/join.hpp:72  (JoinNoMatch = INT32_MIN)
+
+# ----------------------------------------------------------------------------------------------
+# helpers
+# ----------------------------------------------------------------------------------------------
+
+
+def _is_float(a: np.ndarray) -> bool:
+    return a.dtype.kind == "f"
+
+
+def sortable_bits(values: np.ndarray) -> np.ndarray:
+    """Map fixed-width values to unsigned integers whose unsigned order is the cudf order.
+
+    ints: two's complement sign flip (what cub's radix twiddle does; call site
+    cpp/src/sort/sort_radix.cu:69-76).  floats: IEEE total-order flip with -0.0 == +0.0 and every
+    NaN mapped to the maximum (NaN sorts after +Inf, all NaNs equivalent:
+    cpp/include/cudf/detail/row_operator/common_utils.cuh:157-169; radix NaN rule
+    cpp/src/sort/sort_radix.cu:36-45).
+    """
+    v = np.ascontiguousarray(values)
+    nbits = v.dtype.itemsize * 8
+    u = np.dtype(f"u{v.dtype.itemsize}")
+    if v.dtype.kind == "b":
+        return v.astype(np.uint8)
+    if v.dtype.kind == "u":
+        return v.copy()
+    if v.dtype.kind == "i":
+        return v.view(u) ^ u.type(1 << (nbits - 1))
+    if v.dtype.kind == "f":
+        bits = v.view(u).copy()
+        sign = u.type(1 << (nbits - 1))
+        bits[bits == sign] = 0  # -0.0 -> +0.0
+        neg = (bits & sign) != 0
+        out = np.where(neg, ~bits, bits | sign)
+        out[np.isnan(v)] = u.type(~u.type(0))
+        return out.astype(u)
+    raise TypeError(f"unsupported dtype {v.dtype}")
+
+
+def _stable_argsort_unsigned(keys: np.ndarray) -> np.ndarray:
+    return np.argsort(keys, kind="stable")
+
+
+# ----------------------------------------------------------------------------------------------
+# sort  
+# ----------------------------------------------------------------------------------------------
+
+
+def sorted_order(
+    values: np.ndarray,
+    valid: Optional[np.ndarray] = None,
+    ascending: bool = True,
+    null_before: bool = True,
+) -> np.ndarray:
+    """cudf::sorted_order / stable_sorted_order of ONE column -> int32 row indices.
+
+    No nulls: the radix path (cpp/src/sort/sorted_order_radix.cu:63-96,124-137): stable
+    LSD sort of (key, iota); for floats the key is the pair (isnan*(idx+1), f)
+    (:37-48), so ascending puts NaNs last in index order and DESCENDING puts them first in
+    *reverse* index order (cub SortPairsDescending on the composite key).
+    With nulls: the comparator path (cpp/src/sort/sort_column_impl.cuh:35-57): nulls are all
+    equivalent, placed by null_order and flipped when descending (:42-45); NaNs equivalent and
+    greater than every number; our implementation is always stable (the unstable entry point
+    permits any tie order, stable_sorted_order requires this one).
+    """
+    v = np.asarray(values)
+    n = v.shape[0]
+    idx = np.arange(n, dtype=np.int64)
+    if valid is not None and not bool(np.all(valid)):
+        valid = np.asarray(valid, dtype=bool)
+        nulls = idx[~valid]
+        good = idx[valid]
+        bits = sortable_bits(v[valid])
+        if not ascending:
+            bits = ~bits
+        order_valid = good[_stable_argsort_unsigned(bits)]
+        nulls_first = null_before if ascending else (not null_before)
+        out = np.concatenate([nulls, order_valid] if nulls_first else [order_valid, nulls])
+        return out.astype(np.int32)
+    bits = sortable_bits(v)
+    if ascending:
+        return _stable_argsort_unsigned(bits).astype(np.int32)
+    order = _stable_argsort_unsigned(~bits)
+    if _is_float(v):
+        nan_count = int(np.isnan(v).sum())
+        if nan_count > 1:  # composite key (idx+1, f) descending => NaN block in reverse index order
+            order[:nan_count] = order[:nan_count][::-1]
+    return order.astype(np.int32)
+
+
+def sort_keys(values: np.ndarray, ascending: bool = True) -> np.ndarray:
+    """cudf::sort of a single non-null fixed-width column (cpp/src/sort/sort.cu:52-67 ->
+    sort_radix, cpp/src/sort/sort_radix.cu:151-161).  Bit-exact output incl. -0.0/NaN payloads."""
+    return np.asarray(values)[sorted_order(values, None, ascending)]
+
+
+def sort_by_key(values: Sequence[np.ndarray], keys: np.ndarray, key_valid=None, ascending=True,
+                null_before=True):
+    """cudf::sort_by_key = gather(values, sorted_order(keys)) (cpp/src/sort/sort.cu:31-50)."""
+    order = sorted_order(keys, key_valid, ascending, null_before)
+    return [np.asarray(c)[order] for c in values]
+
+
+def gather(values: np.ndarray, gather_map: np.ndarray) -> np.ndarray:
+    """out[i] = in[map[i]] (cpp/include/cudf/detail/gather.cuh:108-131)."""
+    return np.asarray(values)[np.asarray(gather_map, dtype=np.int64)]
+
+
+# ----------------------------------------------------------------------------------------------
+# hashing
+# ----------------------------------------------------------------------------------------------
+
+_M32 = 0xFFFFFFFF
+
+
+def _rotl32(x: np.ndarray, r: int) -> np.ndarray:
+    x = x & _M32
+    return ((x << r) | (x >> (32 - r))) & _M32
+
+
+def murmur3_32_bytes(data: bytes, seed: int = 0) -> int:
+    """Published MurmurHash3_x86_32 (Appleby, SMHasher) for arbitrary bytes: scalar KAT helper."""
+    c1, c2 = 0xCC9E2D51, 0x1B873593
+    h = seed & _M32
+    nblocks = len(data) // 4
+    for i in range(nblocks):
+        k = int.from_bytes(data[4 * i : 4 * i + 4], "little")
+        k = (k * c1) & _M32
+        k = ((k << 15) | (k >> 17)) & _M32
+        k = (k * c2) & _M32
+        h ^= k
+        h = ((h << 13) | (h >> 19)) & _M32
+        h = (h * 5 + 0xE6546B64) & _M32
+    tail = data[4 * nblocks :]
+    k = 0
+    if len(tail) >= 3:
+        k ^= tail[2] << 16
+    if len(tail) >= 2:
+        k ^= tail[1] << 8
+    if len(tail) >= 1:
+        k ^= tail[0]
+        k = (k * c1) & _M32
+        k = ((k << 15) | (k >> 17)) & _M32
+        k = (k * c2) & _M32
+        h ^= k
+    h ^= len(data)
+    h ^= h >> 16
+    h = (h * 0x85EBCA6B) & _M32
+    h ^= h >> 13
+    h = (h * 0xC2B2AE35) & _M32
+    h ^= h >> 16
+    return h
+
+
+def murmur3_32(values: np.ndarray, seed: int = 0, valid: Optional[np.ndarray] = None) -> np.ndarray:
+    """Vectorised cudf::hashing::detail::MurmurHash3_x86_32<T> over a fixed-width column.
+
+    cpp/include/cudf/hashing/detail/murmurhash3_x86_32.cuh:22-67: hash of the element's bytes
+    (4 or 8 byte types here; bool hashes as one uint8 byte), floats first normalised (NaN ->
+    canonical quiet NaN, -0.0 -> +0.0: cpp/include/cudf/hashing/detail/hash_functions.cuh
+    normalize_nans_and_zeros); null elements hash to UINT32_MAX
+    (cpp/include/cudf/detail/row_operator/primitive_row_operators.cuh:207-268).
+    """
+    v = np.ascontiguousarray(values)
+    if v.dtype.kind == "f":
+        v = v.copy()
+        v[np.isnan(v)] = np.nan  # canonical quiet NaN
+        v[v == 0] = 0.0
+    if v.dtype.kind == "b":
+        v = v.astype(np.uint8)
+    size = v.dtype.itemsize
+    raw = v.view(np.uint8).reshape(-1, size)
+    c1, c2 = np.uint64(0xCC9E2D51), np.uint64(0x1B873593)
+    h = np.full(v.shape[0], seed & _M32, dtype=np.uint64)
+    nblocks = size // 4
+    if nblocks:
+        words = np.ascontiguousarray(raw[:, : 4 * nblocks]).view("<u4").reshape(-1, nblocks)
+        for b in range(nblocks):
+            k = words[:, b].astype(np.uint64)
+            k = (k * c1) & _M32
+            k = _rotl32(k, 15)
+            k = (k * c2) & _M32
+            h ^= k
+            h = _rotl32(h, 13)
+            h = (h * np.uint64(5) + np.uint64(0xE6546B64)) & _M32
+    tail = size - 4 * nblocks
+    if tail:
+        k = np.zeros(v.shape[0], dtype=np.uint64)
+        for t in range(tail - 1, -1, -1):
+            k ^= raw[:, 4 * nblocks + t].astype(np.uint64) << np.uint64(8 * t)
+        k = (k * c1) & _M32
+        k = _rotl32(k, 15)
+        k = (k * c2) & _M32
+        h ^= k
+    h ^= np.uint64(size)
+    h ^= h >> np.uint64(16)
+    h = (h * np.uint64(0x85EBCA6B)) & _M32
+    h ^= h >> np.uint64(13)
+    h = (h * np.uint64(0xC2B2AE35)) & _M32
+    h ^= h >> np.uint64(16)
+    out = h.astype(np.uint32)
+    if valid is not None:
+        out = np.where(np.asarray(valid, dtype=bool), out, np.uint32(0xFFFFFFFF))
+    return out
+
+
+def hash_combine(lhs: np.ndarray, rhs: np.ndarray) -> np.ndarray:
+    """cpp/include/cudf/hashing/detail/hashing.hpp:83-86 (boost-style 32-bit combine)."""
+    l = lhs.astype(np.uint64)
+    r = rhs.astype(np.uint64)
+    return ((l ^ ((r + np.uint64(0x9E3779B9) + (l << np.uint64(6)) + (l >> np.uint64(2))) & _M32))
+            & _M32).astype(np.uint32)
+
+
+def row_hash(columns: Sequence[np.ndarray], valids: Optional[Sequence] = None, seed: int = 0) -> np.ndarray:
+    """Row hash used by join/groupby/partition for primitive keys
+    (cpp/include/cudf/detail/row_operator/primitive_row_operators.cuh:247-268): the first
+    column's element hash seeds the fold; later columns are folded with hash_combine."""
+    valids = valids or [None] * len(columns)
+    h = murmur3_32(columns[0], seed, valids[0])
+    for c, m in zip(columns[1:], valids[1:]):
+        h = hash_combine(h, murmur3_32(c, seed, m))
+    return h
+
+
+def hash_partition(key_columns: Sequence[np.ndarray], num_partitions: int, seed: int = 0,
+                   valids=None) -> Tuple[np.ndarray, np.ndarray]:
+    """cudf::hash_partition (cpp/src/partitioning/partitioning.cu:53-92,568-660): partition id =
+    row_hash % P (``& (P-1)`` when P is a power of two -- same value); rows keep their relative
+    order inside a partition.  Returns (gather order, offsets[P+1])."""
+    h = row_hash(key_columns, valids, seed)
+    pid = (h % np.uint32(num_partitions)).astype(np.int64)
+    order = np.argsort(pid, kind="stable").astype(np.int32)
+    counts = np.bincount(pid, minlength=num_partitions)
+    offsets = np.concatenate([[0], np.cumsum(counts)]).astype(np.int32)
+    return order, offsets
+
+
+# ----------------------------------------------------------------------------------------------
+# hash join
+# ----------------------------------------------------------------------------------------------
+
+
+def _join_key(v: np.ndarray) -> np.ndarray:
+    """Equality classes of the join/groupby row comparator: NaN == NaN, -0.0 == +0.0
+    (cpp/include/cudf/detail/row_operator/common_utils.cuh:215-220)."""
+    v = np.asarray(v)
+    if v.dtype.kind == "f":
+        v = v.copy()
+        v[np.isnan(v)] = np.nan
+        v[v == 0] = 0.0
+        return v.view(np.dtype(f"u{v.dtype.itemsize}"))
+    return v
+
+
+def _factorize_rows(lcols, rcols):
+    """Dense ids for rows of two tables so that equal rows (across tables) share an id."""
+    nl = len(lcols[0])
+    combo = None
+    for lc, rc in zip(lcols, rcols):
+        both = np.concatenate([_join_key(lc), _join_key(rc)])
+        _, inv = np.unique(both, return_inverse=True)
+        combo = inv if combo is None else np.unique(
+            np.stack([combo, inv], axis=1), axis=0, return_inverse=True)[1].reshape(-1)
+    return combo[:nl], combo[nl:]
+
+
+def inner_join(left_cols, right_cols, left_valids=None, right_valids=None,
+               nulls_equal: bool = True) -> Tuple[np.ndarray, np.ndarray]:
+    """cudf::inner_join (cpp/include/cudf/join/join.hpp:127-166; cpp/src/join/join.cu:27-60):
+    every (left_idx, right_idx) whose key rows compare equal; a row with a null in any key
+    column matches only rows null in the same columns and only when nulls_equal
+    (cpp/src/join/hash_join/hash_join.cu:77-84).  The reference's pair order is unspecified
+    (join.hpp:131-134), so the oracle returns pairs sorted by (left, right) -- the canonical form
+    the reference's own tests compare in (cpp/tests/join/join_tests.cpp:1186-1210)."""
+    if not isinstance(left_cols, (list, tuple)):
+        left_cols, right_cols = [left_cols], [right_cols]
+    left_cols = [np.asarray(c) for c in left_cols]
+    right_cols = [np.asarray(c) for c in right_cols]
+    nl, nr = len(left_cols[0]), len(right_cols[0])
+    if nl == 0 or nr == 0:
+        return np.empty(0, np.int32), np.empty(0, np.int32)
+    lv = [np.ones(nl, bool) if m is None else np.asarray(m, bool)
+          for m in (left_valids or [None] * len(left_cols))]
+    rv = [np.ones(nr, bool) if m is None else np.asarray(m, bool)
+          for m in (right_valids or [None] * len(right_cols))]
+    # null elements: canonical value 0 plus the validity bit as an extra key column
+    lcols = [np.where(m, c, c.dtype.type(0)) for c, m in zip(left_cols, lv)] + [m.astype(np.uint8) for m in lv]
+    rcols = [np.where(m, c, c.dtype.type(0)) for c, m in zip(right_cols, rv)] + [m.astype(np.uint8) for m in rv]
+    lid, rid = _factorize_rows(lcols, rcols)
+    l_ok = np.ones(nl, bool)
+    r_ok = np.ones(nr, bool)
+    if not nulls_equal:
+        for m in lv:
+            l_ok &= m
+        for m in rv:
+            r_ok &= m
+    lidx = np.nonzero(l_ok)[0]
+    ridx = np.nonzero(r_ok)[0]
+    lid, rid = lid[lidx], rid[ridx]
+    r_order = np.argsort(rid, kind="stable")
+    rid_sorted = rid[r_order]
+    lo = np.searchsorted(rid_sorted, lid, "left")
+    hi = np.searchsorted(rid_sorted, lid, "right")
+    cnt = hi - lo
+    total = int(cnt.sum())
+    out_l = np.repeat(lidx, cnt)
+    starts = np.repeat(lo, cnt)
+    within = np.arange(total) - np.repeat(np.cumsum(cnt) - cnt, cnt)
+    out_r = ridx[r_order[starts + within]]
+    order = np.lexsort((out_r, out_l))
+    return out_l[order].astype(np.int32), out_r[order].astype(np.int32)
+
+
+def canonical_pairs(left_idx, right_idx) -> Tuple[np.ndarray, np.ndarray]:
+    """Sort a join result into the canonical (left, right) order used for comparison."""
+    l = np.asarray(left_idx).astype(np.int64)
+    r = np.asarray(right_idx).astype(np.int64)
+    order = np.lexsort((r, l))
+    return l[order].astype(np.int32), r[order].astype(np.int32)
+
+
+def left_join(left_cols, right_cols, left_valids=None, right_valids=None, nulls_equal=True):
+    """cudf::left_join: inner pairs + (l, JoinNoMatch) for unmatched left rows
+    (cpp/src/join/join.cu:62-85, cpp/src/join/join_utils.cu:45-60)."""
+    l, r = inner_join(left_cols, right_cols, left_valids, right_valids, nulls_equal)
+    lc = left_cols if isinstance(left_cols, (list, tuple)) else [left_cols]
+    nl = len(lc[0])
+    matched = np.zeros(nl, bool)
+    matched[l] = True
+    un = np.nonzero(~matched)[0].astype(np.int32)
+    return canonical_pairs(np.concatenate([l, un]),
+                           np.concatenate([r, np.full(len(un), JOIN_NO_MATCH, np.int32)]))
+
+
+def full_join(left_cols, right_cols, left_valids=None, right_valids=None, nulls_equal=True):
+    """cudf::full_join: left join + (JoinNoMatch, r) for unmatched right rows
+    (cpp/src/join/join_utils.cu:86-157)."""
+    l, r = left_join(left_cols, right_cols, left_valids, right_valids, nulls_equal)
+    rc = right_cols if isinstance(right_cols, (list, tuple)) else [right_cols]
+    nr = len(rc[0])
+    matched = np.zeros(nr, bool)
+    matched[r[r != JOIN_NO_MATCH]] = True
+    un = np.nonzero(~matched)[0].astype(np.int32)
+    return canonical_pairs(np.concatenate([l, np.full(len(un), JOIN_NO_MATCH, np.int32)]),
+                           np.concatenate([r, un]))
+
+
+# ----------------------------------------------------------------------------------------------
+# groupby
+# ----------------------------------------------------------------------------------------------
+
+
+def _exact_group_sums(labels: np.ndarray, values: np.ndarray, ngroups: int) -> np.ndarray:
+    """Correctly rounded float64 sum per group (math.fsum): the parity target for f64 SUM/MEAN
+    (north_star: within 1 ulp).  The reference's own sum is an unordered relaxed atomic add
+    (cpp/include/cudf/detail/utilities/device_atomics.cuh:57-62), i.e. any summation order."""
+    order = np.argsort(labels, kind="stable")
+    sv = values[order].astype(np.float64)
+    bounds = np.searchsorted(labels[order], np.arange(ngroups + 1))
+    out = np.empty(ngroups, np.float64)
+    for g in range(ngroups):
+        out[g] = math.fsum(sv[bounds[g] : bounds[g + 1]])
+    return out
+
+
+def groupby_agg(keys: np.ndarray, values: np.ndarray, aggs: Sequence[str],
+                keys_valid=None, values_valid=None, exact: bool = True):
+    """cudf::groupby::groupby(keys, null_policy::EXCLUDE).aggregate(...) for one key column and
+    one values column (cpp/src/groupby/groupby.cu:220-237, hash path cpp/src/groupby/hash/*).
+
+    Returns (unique_keys_sorted, {agg: (result, result_valid)}) with groups in ascending key
+    order -- the canonical order the reference's tests compare in
+    (cpp/tests/groupby/groupby_test_util.cpp:37-49,80-89).
+    Result types (cpp/include/cudf/detail/aggregation/aggregation.hpp:879-1001): SUM of integers
+    -> int64 (wraps mod 2^64), SUM of floats -> same float type (f64 here), COUNT_* -> int32,
+    MEAN -> float64, MIN/MAX -> input type.  Rows whose key is null are dropped
+    (cpp/src/groupby/hash/compute_groupby.cu:62-66); a group with no valid value gives a null
+    SUM/MEAN/MIN/MAX and COUNT_VALID 0 (cpp/src/groupby/hash/output_utils.cu:68-70).
+    """
+    keys = np.asarray(keys)
+    values = np.asarray(values)
+    n = keys.shape[0]
+    kv = np.ones(n, bool) if keys_valid is None else np.asarray(keys_valid, bool)
+    vv = np.ones(n, bool) if values_valid is None else np.asarray(values_valid, bool)
+    keys, values, vv = keys[kv], values[kv], vv[kv]
+    uniq, labels = np.unique(_join_key(keys), return_inverse=True)
+    labels = labels.reshape(-1)
+    g = len(uniq)
+    first = np.full(g, -1, np.int64)
+    # representative key value: first occurrence (matters only for -0.0/NaN payloads)
+    order = np.argsort(labels, kind="stable")
+    if len(order):
+        bounds = np.searchsorted(labels[order], np.arange(g))
+        first = order[bounds]
+    out_keys = keys[first] if g else keys[:0]
+    count_valid = np.bincount(labels[vv], minlength=g).astype(np.int32)
+    count_all = np.bincount(labels, minlength=g).astype(np.int32)
+    res = {}
+    has = count_valid > 0
+    for a in aggs:
+        if a == "count_valid":
+            res[a] = (count_valid, np.ones(g, bool))
+        elif a == "count_all":
+            res[a] = (count_all, np.ones(g, bool))
+        elif a in ("sum", "mean"):
+            if values.dtype.kind == "f":
+                if exact:
+                    s = _exact_group_sums(labels[vv], values[vv].astype(np.float64), g)
+                else:
+                    s = np.bincount(labels[vv], weights=values[vv].astype(np.float64), minlength=g)
+                s = s.astype(values.dtype) if a == "sum" else s
+            else:
+                acc = np.zeros(g, np.uint64)
+                np.add.at(acc, labels[vv], values[vv].astype(np.int64).view(np.uint64))
+                s = acc.view(np.int64)
+            if a == "sum":
+                res[a] = (s, has.copy())
+            else:
+                # MEAN = SUM / COUNT_VALID in double (hash_compound_agg_finalizer.cu:92-133)
+                with np.errstate(divide="ignore", invalid="ignore"):
+                    if values.dtype.kind == "f":
+                        m = s.astype(np.float64) / count_valid
+                    else:
+                        m = s.astype(np.float64) / count_valid
+                res[a] = (np.where(has, m, 0.0), has.copy())
+        elif a in ("min", "max"):
+            fill = values[vv]
+            lab = labels[vv]
+            out = np.zeros(g, values.dtype)
+            if len(fill):
+                o2 = np.lexsort((sortable_bits(fill), lab))
+                b = np.searchsorted(lab[o2], np.arange(g + 1))
+                sel = np.where(has, b[:-1] if a == "min" else np.maximum(b[1:] - 1, 0), 0)
+                out = np.where(has, fill[o2][np.minimum(sel, len(fill) - 1)], 0).astype(values.dtype)
+            res[a] = (out, has.copy())
+        else:
+            raise ValueError(a)
+    return out_keys, res
+
+
+def groupby_scan_sum(keys: np.ndarray, values: np.ndarray, keys_valid=None, values_valid=None):
+    """groupby::scan with SUM (cpp/src/groupby/groupby.cu:240-259 -> sort path
+    cpp/src/groupby/sort/scan.cpp:214-238, sort_helper.cu:73-162, group_scan_util.cuh:77-133):
+    keys come out sorted (stable), values are the per-group inclusive prefix sum in that order;
+    integer inputs accumulate in int64; null values stay null and are skipped."""
+    keys = np.asarray(keys)
+    values = np.asarray(values)
+    n = len(keys)
+    kv = np.ones(n, bool) if keys_valid is None else np.asarray(keys_valid, bool)
+    vv = np.ones(n, bool) if values_valid is None else np.asarray(values_valid, bool)
+    keep = np.nonzero(kv)[0]
+    order = keep[np.argsort(sortable_bits(keys[keep]), kind="stable")]
+    sk = keys[order]
+    sv = values[order]
+    svv = vv[order]
+    acc_t = np.float64 if values.dtype.kind == "f" else np.int64
+    x = np.where(svv, sv, 0).astype(acc_t)
+    out = np.empty(len(x), acc_t)
+    if len(x):
+        newgrp = np.concatenate([[True], _join_key(sk)[1:] != _join_key(sk)[:-1]])
+        starts = np.nonzero(newgrp)[0]
+        ends = np.append(starts[1:], len(x))
+        for s, e in zip(starts, ends):
+            if acc_t is np.int64:
+                out[s:e] = np.cumsum(x[s:e].view(np.uint64)).view(np.int64)
+            else:
+                out[s:e] = np.cumsum(x[s:e])
+    return sk, out, svv
+
+
+# ----------------------------------------------------------------------------------------------
+# reduce / scan
+# ----------------------------------------------------------------------------------------------
+
+
+def reduce(values: np.ndarray, op: str, valid=None, out_dtype=None):
+    """cudf::reduce (cpp/src/reductions/reductions.cpp:484-507, simple.cuh:47-85): nulls skipped;
+    returns (value, is_valid); is_valid False iff there is no valid element; computed in
+    out_dtype (ints wrap)."""
+    v = np.asarray(values)
+    m = np.ones(len(v), bool) if valid is None else np.asarray(valid, bool)
+    x = v[m]
+    out_dtype = np.dtype(out_dtype or v.dtype)
+    if len(x) == 0:
+        return out_dtype.type(0), False
+    if op == "sum":
+        if out_dtype.kind == "f":
+            return out_dtype.type(math.fsum(x.astype(np.float64))), True
+        return x.astype(out_dtype).sum(dtype=out_dtype), True
+    if op == "min":
+        return x[np.argmin(sortable_bits(x))].astype(out_dtype), True
+    if op == "max":
+        return x[np.argmax(sortable_bits(x))].astype(out_dtype), True
+    if op == "mean":
+        return np.float64(math.fsum(x.astype(np.float64)) / len(x)), True
+    raise ValueError(op)
+
+
+def scan(values: np.ndarray, op: str = "sum", inclusive: bool = True, valid=None,
+         null_include: bool = False):
+    """cudf::scan (cpp/src/reductions/scan/scan.cpp:13-54, scan_inclusive.cu:36-240,
+    scan_exclusive.cu): output dtype == input dtype (ints wrap); null_policy EXCLUDE: nulls are
+    replaced by the identity and stay null in the output (mask copied); INCLUDE: everything from
+    the first null on is null (mask_scan :36-61).  Returns (values, valid mask)."""
+    v = np.asarray(values)
+    n = len(v)
+    m = np.ones(n, bool) if valid is None else np.asarray(valid, bool)
+    dt = v.dtype
+    if op == "sum":
+        ident = dt.type(0)
+        f = np.cumsum
+    elif op == "min":
+        ident = dt.type(np.inf) if dt.kind == "f" else np.iinfo(dt).max
+        f = np.minimum.accumulate
+    elif op == "max":
+        ident = dt.type(-np.inf) if dt.kind == "f" else np.iinfo(dt).min
+        f = np.maximum.accumulate
+    elif op == "product":
+        ident = dt.type(1)
+        f = np.cumprod
+    else:
+        raise ValueError(op)
+    x = np.where(m, v, ident).astype(dt)
+    with np.errstate(over="ignore"):
+        inc = f(x, dtype=dt) if op in ("sum", "product") else f(x)
+    if inclusive:
+        out = inc
+    else:
+        out = np.concatenate([[ident], inc[:-1]]).astype(dt) if n else inc
+    if null_include:
+        first_null = int(np.argmin(m)) if not m.all() else n
+        pos = min(n, first_null + (0 if inclusive else 1))
+        om = np.arange(n) < pos
+    else:
+        om = m.copy()
+    return out, om
+
+
+# ----------------------------------------------------------------------------------------------
+# ulp distance helper for float parity (tolerance stated in the tests)
+# ----------------------------------------------------------------------------------------------
+
+
+def ulp_diff(a: np.ndarray, b: np.ndarray) -> np.ndarray:
+    a = np.asarray(a, np.float64)
+    b = np.asarray(b, np.float64)
+    ia = a.view(np.int64).copy()
+    ib = b.view(np.int64).copy()
+    ia = np.where(ia < 0, np.int64(-(2**63)) - ia, ia)
+    ib = np.where(ib < 0, np.int64(-(2**63)) - ib, ib)
+    return np.abs(ia - ib)

@@ -1,0 +1,227 @@
+"""Golden vectors transcribed (inputs / expected literals only) from the reference's own tests.
+
+Every entry cites the reference test file:line (relative to /root/reference/cpp/tests).  These
+pin the CPU oracle (tests/test_oracle_golden.py) and are replayed through the HIP path
+(tests/test_gpu_golden.py).  ``N`` marks a null element; masks use 1 = valid.
+String key columns of the reference tests are transcribed as small integer codes
+("s0"->0, "s1"->1, ...) because only their equality classes matter to the join.
+"""
+import numpy as np
+
+NaN = float("nan")
+Inf = float("inf")
+NO_MATCH = -(2**31)  # JoinNoMatch, include/cudf/join/join.hpp:72
+
+# ---------------------------------------------------------------------------------------------
+# sort
+# ---------------------------------------------------------------------------------------------
+SORT = [
+    # sort/stable_sort_tests.cpp:88-104  StableSort.SingleColumnNoNull (radix fast path)
+    dict(name="stable_single_nonull_signed", dtype="int64", values=[7, 1, -2, 5, 1, 0, 1, -2, 0, 5],
+         valid=None, ascending=True, null_before=True, expected=[2, 7, 5, 8, 1, 4, 6, 3, 9, 0],
+         compare="indices"),
+    dict(name="stable_single_nonull_int32", dtype="int32", values=[7, 1, -2, 5, 1, 0, 1, -2, 0, 5],
+         valid=None, ascending=True, null_before=True, expected=[2, 7, 5, 8, 1, 4, 6, 3, 9, 0],
+         compare="indices"),
+    dict(name="stable_single_nonull_f64", dtype="float64", values=[7, 1, -2, 5, 1, 0, 1, -2, 0, 5],
+         valid=None, ascending=True, null_before=True, expected=[2, 7, 5, 8, 1, 4, 6, 3, 9, 0],
+         compare="indices"),
+    # unsigned: -2 wraps to the maximum
+    dict(name="stable_single_nonull_unsigned", dtype="uint32",
+         values=[7, 1, 2**32 - 2, 5, 1, 0, 1, 2**32 - 2, 0, 5],
+         valid=None, ascending=True, null_before=True, expected=[5, 8, 1, 4, 6, 3, 9, 0, 2, 7],
+         compare="indices"),
+    dict(name="stable_single_nonull_uint64", dtype="uint64",
+         values=[7, 1, 2**64 - 2, 5, 1, 0, 1, 2**64 - 2, 0, 5],
+         valid=None, ascending=True, null_before=True, expected=[5, 8, 1, 4, 6, 3, 9, 0, 2, 7],
+         compare="indices"),
+    # sort/stable_sort_tests.cpp:106-123  StableSort.SingleColumnWithNull -- the reference compares
+    # the GATHERED table (run_stable_sort_test :20-31), so null rows are interchangeable.
+    dict(name="stable_single_withnull_signed", dtype="int64", values=[7, 1, -2, 5, 1, 0, 1, -2, 0, 5],
+         valid=[1, 1, 0, 0, 1, 0, 1, 0, 1, 0], ascending=True, null_before=True,
+         expected=[2, 7, 5, 3, 9, 8, 1, 4, 6, 0], compare="gathered"),
+    dict(name="stable_single_withnull_unsigned", dtype="uint32",
+         values=[7, 1, 2**32 - 2, 5, 1, 0, 1, 2**32 - 2, 0, 5],
+         valid=[1, 1, 0, 0, 1, 0, 1, 0, 1, 0], ascending=True, null_before=True,
+         expected=[5, 3, 9, 2, 7, 8, 1, 4, 6, 0], compare="gathered"),
+    # sort/sort_test.cpp:1068-1083  SortDouble.InfinityAndNan (sorted_order, default order)
+    dict(name="double_inf_nan", dtype="float64",
+         values=[-0.0, -NaN, -NaN, NaN, Inf, -Inf, 7.0, 5.0, 6.0, NaN, Inf, -Inf, -NaN, -NaN, -0.0],
+         valid=None, ascending=True, null_before=True,
+         expected=[5, 11, 0, 14, 7, 8, 6, 4, 10, 1, 2, 3, 9, 12, 13], compare="indices"),
+    # sort/stable_sort_tests.cpp:278-289  same input through stable_sorted_order
+    dict(name="double_inf_nan_f32", dtype="float32",
+         values=[-0.0, -NaN, -NaN, NaN, Inf, -Inf, 7.0, 5.0, 6.0, NaN, Inf, -Inf, -NaN, -NaN, -0.0],
+         valid=None, ascending=True, null_before=True,
+         expected=[5, 11, 0, 14, 7, 8, 6, 4, 10, 1, 2, 3, 9, 12, 13], compare="indices"),
+]
+
+# ---------------------------------------------------------------------------------------------
+# hash join.  left/right: list of key columns (each a list, None = null element);
+# expected_rows: multiset of (left payload..., right payload...) rows of the reference's gold
+# table restricted to the integer payload columns; or expected_pairs: (left_idx, right_idx).
+# ---------------------------------------------------------------------------------------------
+N = None
+JOIN = [
+    # join/join_tests.cpp:1163-1237  InnerJoinNoNulls, single key column (both null_equality values)
+    dict(name="inner_nonulls_single", dtype="int32",
+         left=[[3, 1, 2, 0, 2]], right=[[2, 2, 0, 4, 3]],
+         left_payload=[[3, 1, 2, 0, 2], [0, 1, 2, 4, 1]], right_payload=[[2, 2, 0, 4, 3], [1, 0, 1, 2, 1]],
+         expected_rows=[(3, 0, 3, 1), (2, 2, 2, 1), (2, 2, 2, 0), (0, 4, 0, 1), (2, 1, 2, 1), (2, 1, 2, 0)],
+         nulls_equal=[True, False]),
+    # same test, two key columns (second is the string column, coded)
+    dict(name="inner_nonulls_multi", dtype="int32",
+         left=[[3, 1, 2, 0, 2], [1, 1, 0, 4, 0]], right=[[2, 2, 0, 4, 3], [1, 0, 1, 2, 1]],
+         left_payload=[[3, 1, 2, 0, 2], [0, 1, 2, 4, 1]], right_payload=[[2, 2, 0, 4, 3], [1, 0, 1, 2, 1]],
+         expected_rows=[(3, 0, 3, 1), (2, 2, 2, 0), (2, 1, 2, 0)],
+         nulls_equal=[True, False]),
+    # join/join_tests.cpp:1239-1283  InnerJoinWithNulls: left string key has a null at row 2
+    dict(name="inner_withnulls", dtype="int32",
+         left=[[3, 1, 2, 0, 2], [1, 1, N, 4, 0]], right=[[2, 2, 0, 4, 3], [1, 0, 1, 2, 1]],
+         left_payload=[[3, 1, 2, 0, 2], [0, 1, 2, 4, 1]], right_payload=[[2, 2, 0, 4, 3]],
+         expected_rows=[(3, 0, 3), (2, 1, 2)],
+         nulls_equal=[True]),
+    # join/join_tests.cpp:1421-1500  InnerJoinOnNulls: nulls on both sides; EQUAL -> 2 rows, UNEQUAL -> 1
+    dict(name="inner_onnulls_equal", dtype="int32",
+         left=[[3, 1, 2, 0, 2], [1, 1, N, 4, 0]], right=[[2, 2, 0, 4, 3], [1, N, 1, 2, 1]],
+         left_payload=[[3, 1, 2, 0, 2], [0, 1, 2, 4, 1]], right_payload=[[2, 2, 0, 4, 3], [1, 0, 1, 2, 1]],
+         expected_rows=[(3, 0, 3, 1), (2, 2, 2, 0)],
+         nulls_equal=[True]),
+    dict(name="inner_onnulls_unequal", dtype="int32",
+         left=[[3, 1, 2, 0, 2], [1, 1, N, 4, 0]], right=[[2, 2, 0, 4, 3], [1, N, 1, 2, 1]],
+         left_payload=[[3, 1, 2, 0, 2], [0, 1, 2, 4, 1]], right_payload=[[2, 2, 0, 4, 3], [1, 0, 1, 2, 1]],
+         expected_rows=[(3, 0, 3, 1)],
+         nulls_equal=[False]),
+    # join/join_tests.cpp:1906-1940  EqualValuesInnerJoin
+    dict(name="equal_values", dtype="int32",
+         left=[[0, 0], [0, 0]], right=[[0, 0], [0, 0]],
+         expected_pairs=[(0, 0), (0, 1), (1, 0), (1, 1)], nulls_equal=[True]),
+    # join/join_tests.cpp:2010-2038  InnerJoinCornerCase (int64)
+    dict(name="corner_case", dtype="int64",
+         left=[[4, 1, 3, 2, 2, 2, 2]], right=[[2]],
+         expected_pairs=[(3, 0), (4, 0), (5, 0), (6, 0)], nulls_equal=[True]),
+    # join/join_tests.cpp:2040-2123  HashJoinSequentialProbes (build t1 once, probe three tables)
+    dict(name="sequential_probe_inner", dtype="int32",
+         left=[[3, 1, 2, 0, 2], [1, 1, 0, 4, 0]], right=[[2, 2, 0, 4, 3], [1, 0, 1, 2, 1]],
+         expected_pairs=[(2, 1), (4, 1), (0, 4)], expected_size=3, nulls_equal=[True]),
+    dict(name="sequential_probe_left", dtype="int32", how="left",
+         left=[[3, 1, 2, 0, 3], [0, 1, 2, 4, 1]], right=[[2, 2, 0, 4, 3], [1, 0, 1, 2, 1]],
+         expected_pairs=[(0, NO_MATCH), (1, NO_MATCH), (2, NO_MATCH), (3, NO_MATCH), (4, 4)],
+         expected_size=5, nulls_equal=[True]),
+    dict(name="sequential_probe_full", dtype="int32", how="full",
+         left=[[3, 1, 2, 0, 3], [0, 1, 2, 4, 1]], right=[[2, 2, 0, 4, 3], [1, 0, 1, 2, 1]],
+         expected_pairs=[(0, NO_MATCH), (1, NO_MATCH), (2, NO_MATCH), (3, NO_MATCH), (4, 4),
+                         (NO_MATCH, 0), (NO_MATCH, 1), (NO_MATCH, 2), (NO_MATCH, 3)],
+         expected_size=9, nulls_equal=[True]),
+]
+
+# ---------------------------------------------------------------------------------------------
+# groupby (keys int32; results compared after sorting by key)
+# ---------------------------------------------------------------------------------------------
+_K_BASIC = [1, 2, 3, 1, 2, 2, 1, 3, 3, 2]
+_V_BASIC = [0, 1, 2, 3, 4, 5, 6, 7, 8, 9]
+_K_NULL = [1, 2, 3, 1, 2, 2, 1, 3, 3, 2, 4]
+_KM_NULL = [1, 1, 1, 1, 1, 1, 1, 0, 1, 1, 1]
+_V_NULL = [0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 4]
+_VM_NULL = [0, 1, 1, 1, 1, 0, 1, 1, 1, 1, 0]
+
+GROUPBY = [
+    # groupby/sum_tests.cpp:68-80 basic (integral V -> int64; float V -> V)
+    dict(name="sum_basic", keys=_K_BASIC, vals=_V_BASIC, agg="sum",
+         expect_keys=[1, 2, 3], expect=[9, 19, 17], expect_valid=[1, 1, 1]),
+    # groupby/count_tests.cpp:21-41
+    dict(name="count_basic", keys=_K_BASIC, vals=_V_BASIC, agg="count_valid",
+         expect_keys=[1, 2, 3], expect=[3, 4, 3], expect_valid=[1, 1, 1]),
+    # groupby/mean_tests.cpp:37-56
+    dict(name="mean_basic", keys=_K_BASIC, vals=_V_BASIC, agg="mean",
+         expect_keys=[1, 2, 3], expect=[3.0, 19.0 / 4, 17.0 / 3], expect_valid=[1, 1, 1]),
+    # groupby/sum_tests.cpp:82-94 empty input
+    dict(name="sum_empty", keys=[], vals=[], agg="sum", expect_keys=[], expect=[], expect_valid=[]),
+    # groupby/sum_tests.cpp:96-108 all keys null -> empty result
+    dict(name="sum_zero_valid_keys", keys=[1, 2, 3], keys_valid=[0, 0, 0], vals=[3, 4, 5], agg="sum",
+         expect_keys=[], expect=[], expect_valid=[]),
+    # groupby/sum_tests.cpp:110-122 all values null -> one group, null sum
+    dict(name="sum_zero_valid_values", keys=[1, 1, 1], vals=[3, 4, 5], vals_valid=[0, 0, 0], agg="sum",
+         expect_keys=[1], expect=[0], expect_valid=[0]),
+    # groupby/sum_tests.cpp:124-145 null keys and values
+    dict(name="sum_null_keys_values", keys=_K_NULL, keys_valid=_KM_NULL, vals=_V_NULL, vals_valid=_VM_NULL,
+         agg="sum", expect_keys=[1, 2, 3, 4], expect=[9, 14, 10, 0], expect_valid=[1, 1, 1, 0]),
+    # groupby/count_tests.cpp:103-132
+    dict(name="count_valid_null_keys_values", keys=_K_NULL, keys_valid=_KM_NULL, vals=_V_NULL,
+         vals_valid=_VM_NULL, agg="count_valid", expect_keys=[1, 2, 3, 4], expect=[2, 3, 2, 0],
+         expect_valid=[1, 1, 1, 1]),
+    dict(name="count_all_null_keys_values", keys=_K_NULL, keys_valid=_KM_NULL, vals=_V_NULL,
+         vals_valid=_VM_NULL, agg="count_all", expect_keys=[1, 2, 3, 4], expect=[3, 4, 2, 1],
+         expect_valid=[1, 1, 1, 1]),
+    # groupby/mean_tests.cpp:102-128
+    dict(name="mean_null_keys_values", keys=_K_NULL, keys_valid=_KM_NULL, vals=_V_NULL, vals_valid=_VM_NULL,
+         agg="mean", expect_keys=[1, 2, 3, 4], expect=[4.5, 14.0 / 3, 5.0, 0.0], expect_valid=[1, 1, 1, 0]),
+    # groupby/sum_tests.cpp:167-188 int32 overflow accumulates in int64
+    dict(name="sum_overflow_int32", keys=[0, 0], vals=[-2147483648, -2147483648], vals_dtype="int32",
+         agg="sum", expect_keys=[0], expect=[-4294967296], expect_valid=[1]),
+]
+
+GROUPBY_SCAN = [
+    # groupby/sum_scan_tests.cpp:33-48 basic
+    dict(name="sum_scan_basic", keys=_K_BASIC, vals=_V_BASIC,
+         expect_keys=[1, 1, 1, 2, 2, 2, 2, 3, 3, 3], expect=[0, 3, 9, 1, 5, 10, 19, 2, 9, 17],
+         expect_valid=[1] * 10),
+    # groupby/sum_scan_tests.cpp:118-139 null keys and values
+    dict(name="sum_scan_null_keys_values", keys=_K_NULL, keys_valid=_KM_NULL, vals=_V_NULL,
+         vals_valid=_VM_NULL, expect_keys=[1, 1, 1, 2, 2, 2, 2, 3, 3, 4],
+         expect=[-1, 3, 9, 1, 5, -1, 14, 2, 10, -1], expect_valid=[0, 1, 1, 1, 1, 0, 1, 1, 1, 0]),
+]
+
+# ---------------------------------------------------------------------------------------------
+# column scan / reduce  (reductions/scan_tests.cpp:164-213; typed over every numeric type)
+# ---------------------------------------------------------------------------------------------
+_SCAN_IN = [5, 4, 6, 0, 1, 6, 5, 3]
+_SCAN_MASK = [1, 1, 1, 0, 1, 1, 1, 1]
+SCAN = [
+    dict(name="sum_inclusive_nonulls", op="sum", inclusive=True, values=_SCAN_IN, valid=None,
+         null_include=False, expect=[5, 9, 15, 15, 16, 22, 27, 30], expect_valid=[1] * 8),   # :164-172
+    dict(name="sum_exclusive_nonulls", op="sum", inclusive=False, values=_SCAN_IN, valid=None,
+         null_include=False, expect=[0, 5, 9, 15, 15, 16, 22, 27], expect_valid=[1] * 8),    # :175-185
+    dict(name="sum_inclusive_nulls_exclude", op="sum", inclusive=True, values=_SCAN_IN, valid=_SCAN_MASK,
+         null_include=False, expect=[5, 9, 15, 15, 16, 22, 27, 30], expect_valid=_SCAN_MASK),  # :188-199
+    dict(name="sum_inclusive_nulls_include", op="sum", inclusive=True, values=_SCAN_IN, valid=_SCAN_MASK,
+         null_include=True, expect=[5, 9, 15, 0, 0, 0, 0, 0], expect_valid=[1, 1, 1, 0, 0, 0, 0, 0]),  # :202-213
+]
+
+# Published MurmurHash3_x86_32 known-answer vectors (Appleby's SMHasher reference implementation;
+# the reference delegates the body to cuco::murmurhash3_32,
+# include/cudf/hashing/detail/murmurhash3_x86_32.cuh:16,45).  (bytes, seed, digest)
+MURMUR3_KAT = [
+    (b"", 0, 0x00000000),
+    (b"", 1, 0x514E28B7),
+    (b"", 0xFFFFFFFF, 0x81F16F39),
+    (b"\x00\x00\x00\x00", 0, 0x2362F9DE),
+    (b"\xff\xff\xff\xff", 0, 0x76293B50),
+    (b"\x21\x43\x65\x87", 0, 0xF55B516B),
+    (b"\x21\x43\x65\x87", 0x5082EDEE, 0x2362F9DE),
+    (b"\x21\x43\x65", 0, 0x7E4A8634),
+    (b"\x21\x43", 0, 0xA0F7B07A),
+    (b"\x21", 0, 0x72661CF4),
+    (b"aaaa", 0x9747B28C, 0x5A97808A),
+    (b"Hello, world!", 0x9747B28C, 0x24884CBA),
+    (b"The quick brown fox jumps over the lazy dog", 0x9747B28C, 0x2FA826CD),
+    (b"abc", 0, 0xB3DD93FA),
+    (b"abcdbcdecdefdefgefghfghighijhijkijkljklmklmnlmnomnopnopq", 0, 0xEE925B90),
+]
+
+
+def col(values, dtype, valid=None):
+    """Build (np.ndarray values, bool mask or None) with None elements turned into nulls."""
+    vals = [0 if v is None else v for v in values]
+    mask = None
+    if any(v is None for v in values):
+        mask = np.array([v is not None for v in values], dtype=bool)
+    if valid is not None:
+        m2 = np.array(valid, dtype=bool)
+        mask = m2 if mask is None else (mask & m2)
+    dt = np.dtype(dtype)
+    if dt.kind == "u":
+        arr = np.array(vals, dtype=object).astype(dt) if vals else np.array([], dt)
+    else:
+        arr = np.array(vals, dtype=dt)
+    return arr, mask

@@ -1,0 +1,171 @@
+"""Pins the CPU oracle (oracle/) against the reference's own golden vectors and the published
+MurmurHash3 KATs.  CPU only."""
+import math
+
+import numpy as np
+import pytest
+
+from oracle import c_oracle
+from oracle import cudf_oracle as orc
+from tests.golden import reference_vectors as gv
+
+
+@pytest.mark.parametrize("case", gv.SORT, ids=lambda c: c["name"])
+def test_sort_golden(case):
+    vals, mask = gv.col(case["values"], case["dtype"], case["valid"])
+    got = orc.sorted_order(vals, mask, case["ascending"], case["null_before"])
+    exp = np.array(case["expected"], np.int32)
+    if case["compare"] == "indices":
+        np.testing.assert_array_equal(got, exp)
+    else:  # the reference compares gather(input, expected) with the sorted table: nulls interchangeable
+        m = np.ones(len(vals), bool) if mask is None else mask
+        np.testing.assert_array_equal(m[got], m[exp])
+        np.testing.assert_array_equal(vals[got][m[got]], vals[exp][m[exp]])
+    if mask is None:
+        # keys-only sort is bit-identical to gathering through the order
+        out = orc.sort_keys(vals, case["ascending"])
+        assert out.tobytes() == vals[exp].tobytes()
+
+
+def _cols(lists, dtype):
+    cols, masks = [], []
+    for c in lists:
+        a, m = gv.col(c, dtype)
+        cols.append(a)
+        masks.append(m)
+    return cols, masks
+
+
+@pytest.mark.parametrize("case", gv.JOIN, ids=lambda c: c["name"])
+def test_join_golden(case):
+    lc, lm = _cols(case["left"], case["dtype"])
+    rc, rm = _cols(case["right"], case["dtype"])
+    fn = {"inner": orc.inner_join, "left": orc.left_join, "full": orc.full_join}[case.get("how", "inner")]
+    for eq in case["nulls_equal"]:
+        l, r = fn(lc, rc, lm, rm, eq)
+        if "expected_size" in case:
+            assert len(l) == case["expected_size"]
+        if "expected_pairs" in case:
+            assert sorted(zip(l.tolist(), r.tolist())) == sorted(case["expected_pairs"])
+        else:
+            lp = [np.array(c) for c in case["left_payload"]]
+            rp = [np.array(c) for c in case["right_payload"]]
+            rows = sorted(tuple(int(c[i]) for c in lp) + tuple(int(c[j]) for c in rp)
+                          for i, j in zip(l, r))
+            assert rows == sorted(case["expected_rows"])
+
+
+@pytest.mark.parametrize("vdtype", ["int32", "int64", "float64"])
+@pytest.mark.parametrize("case", gv.GROUPBY, ids=lambda c: c["name"])
+def test_groupby_golden(case, vdtype):
+    vdtype = case.get("vals_dtype", vdtype)
+    keys, km = gv.col(case["keys"], "int32", case.get("keys_valid"))
+    vals, vm = gv.col(case["vals"], vdtype, case.get("vals_valid"))
+    out_keys, res = orc.groupby_agg(keys, vals, [case["agg"]], km, vm)
+    r, rv = res[case["agg"]]
+    np.testing.assert_array_equal(out_keys, np.array(case["expect_keys"], np.int32))
+    ev = np.array(case["expect_valid"], bool)
+    np.testing.assert_array_equal(rv, ev)
+    exp = np.array(case["expect"])
+    if case["agg"] == "sum":
+        assert r.dtype == (np.int64 if np.dtype(vdtype).kind == "i" else np.dtype(vdtype))
+    if case["agg"].startswith("count"):
+        assert r.dtype == np.int32
+    if case["agg"] == "mean":
+        assert r.dtype == np.float64
+        assert np.all(orc.ulp_diff(r[ev], exp[ev].astype(np.float64)) <= 1)
+    else:
+        np.testing.assert_array_equal(r[ev], exp[ev].astype(r.dtype))
+
+
+@pytest.mark.parametrize("vdtype", ["int32", "int64", "float64"])
+@pytest.mark.parametrize("case", gv.GROUPBY_SCAN, ids=lambda c: c["name"])
+def test_groupby_scan_golden(case, vdtype):
+    keys, km = gv.col(case["keys"], "int32", case.get("keys_valid"))
+    vals, vm = gv.col(case["vals"], vdtype, case.get("vals_valid"))
+    sk, out, ov = orc.groupby_scan_sum(keys, vals, km, vm)
+    np.testing.assert_array_equal(sk, np.array(case["expect_keys"], np.int32))
+    ev = np.array(case["expect_valid"], bool)
+    np.testing.assert_array_equal(ov, ev)
+    np.testing.assert_array_equal(out[ev], np.array(case["expect"])[ev].astype(out.dtype))
+
+
+@pytest.mark.parametrize("dtype", ["int8", "int32", "int64", "uint32", "float32", "float64"])
+@pytest.mark.parametrize("case", gv.SCAN, ids=lambda c: c["name"])
+def test_scan_golden(case, dtype):
+    vals, mask = gv.col(case["values"], dtype, case["valid"])
+    out, om = orc.scan(vals, case["op"], case["inclusive"], mask, case["null_include"])
+    ev = np.array(case["expect_valid"], bool)
+    assert out.dtype == np.dtype(dtype)
+    np.testing.assert_array_equal(om, ev)
+    np.testing.assert_array_equal(out[ev], np.array(case["expect"])[ev].astype(dtype))
+
+
+def test_murmur3_published_kat():
+    for data, seed, digest in gv.MURMUR3_KAT:
+        assert orc.murmur3_32_bytes(data, seed) == digest, (data, seed)
+
+
+def test_murmur3_vector_matches_scalar_and_c():
+    rng = np.random.default_rng(5)
+    for dt in (np.int32, np.uint32, np.int64, np.uint64, np.float32, np.float64):
+        if np.dtype(dt).kind == "f":
+            v = rng.standard_normal(257).astype(dt)
+        else:
+            info = np.iinfo(dt)
+            v = rng.integers(info.min, info.max, 257, dtype=dt, endpoint=True)
+        for seed in (0, 619):
+            h = orc.murmur3_32(v, seed)
+            ref = [orc.murmur3_32_bytes(x.tobytes(), seed) for x in v]
+            np.testing.assert_array_equal(h, np.array(ref, np.uint32))
+            np.testing.assert_array_equal(c_oracle.murmur3(v.view(f"u{v.dtype.itemsize}"), seed), h)
+    # float normalisation: -0.0 == +0.0, every NaN payload hashes alike; nulls -> UINT32_MAX
+    f = np.array([0.0, -0.0, np.nan, -np.nan], np.float64)
+    h = orc.murmur3_32(f)
+    assert h[0] == h[1] and h[2] == h[3]
+    assert orc.murmur3_32(np.array([5], np.int32), valid=np.array([False]))[0] == 0xFFFFFFFF
+
+
+def test_c_oracle_matches_numpy_oracle():
+    rng = np.random.default_rng(11)
+    v = rng.integers(-2**63, 2**63 - 1, 100_003, dtype=np.int64)
+    v[::7] = v[3]  # duplicates
+    for desc in (False, True):
+        assert c_oracle.sort_i64(v, desc).tobytes() == orc.sort_keys(v, not desc).tobytes()
+        np.testing.assert_array_equal(c_oracle.sorted_order_i64(v, desc), orc.sorted_order(v, None, not desc))
+    build = rng.permutation(20_000).astype(np.int64)[:5000] * 3
+    probe = rng.integers(0, 60_000, 40_000).astype(np.int64)
+    probe[:100] = build[:100]
+    build2 = np.concatenate([build, build[:50]])  # duplicates on the build side
+    l, r = c_oracle.inner_join_i64(probe, build2)
+    l, r = orc.canonical_pairs(l, r)
+    ol, orr = orc.inner_join(probe, build2)
+    np.testing.assert_array_equal(l, ol)
+    np.testing.assert_array_equal(r, orr)
+    keys = rng.integers(0, 1000, 200_000).astype(np.int32)
+    vals = rng.random(200_000)
+    s, c = c_oracle.groupby_dense_sum_count(keys, vals, 1000)
+    ok, res = orc.groupby_agg(keys, vals, ["sum", "count_valid"])
+    np.testing.assert_array_equal(ok, np.arange(1000, dtype=np.int32))
+    np.testing.assert_array_equal(c, res["count_valid"][0])
+    assert np.all(orc.ulp_diff(s, res["sum"][0]) <= 1)  # tolerance: 1 ulp (north_star)
+    x = rng.integers(-2**62, 2**62, 1000, dtype=np.int64)
+    np.testing.assert_array_equal(c_oracle.inclusive_sum_i64(x), orc.scan(x, "sum")[0])
+
+
+def test_descending_float_nan_block_reversed():
+    # cub SortPairsDescending on the composite key (isnan*(idx+1), f): NaNs first, highest idx first
+    v = np.array([1.0, np.nan, 3.0, np.nan, -np.inf, np.nan], np.float64)
+    np.testing.assert_array_equal(orc.sorted_order(v, None, ascending=False), [5, 3, 1, 2, 0, 4])
+
+
+def test_hash_partition_oracle_properties():
+    rng = np.random.default_rng(3)
+    k = rng.integers(0, 1000, 5000).astype(np.int64)
+    for p in (1, 3, 8):
+        order, offs = orc.hash_partition([k], p)
+        assert offs[0] == 0 and offs[-1] == len(k) and len(offs) == p + 1
+        pid = orc.murmur3_32(k) % np.uint32(p)
+        for q in range(p):
+            seg = order[offs[q]:offs[q + 1]]
+            assert np.all(pid[seg] == q) and np.all(np.diff(seg) > 0)
