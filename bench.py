@@ -1,0 +1,263 @@
+#!/usr/bin/env python
+"""bench.py -- BASELINE.json's metric on MI355X: rows/s + achieved HBM GB/s of the hot path.
+
+  python bench.py --gpus N --steps K --warmup W [--workload sort|sorted_order|join|groupby]
+                  [--rows R] [--cpu-baseline/--no-cpu-baseline]
+
+A "step" is one pass of the hot path over one batch of synthetic input already resident in HBM
+(generated on the device by a counter-based RNG, so no PCIe traffic inside or outside the timed
+region).  Default workload = BASELINE.json configs[1]: 1e9-row int64 radix sort (cudf::sort) on
+one GPU.  N > 1: one process per GPU (torch.distributed / RCCL for the barrier only); the path
+shards by rows with no data-path collective, each rank sorts its own shard  -> "scaling": "weak".
+
+Rank 0 prints ONE JSON line (contract in the task statement) with two extra objects:
+  roofline     -- dominant kernel (the radix scatter pass): algorithmic bytes per launch
+                  (16 B/row = read 8 + write 8) / average launch duration measured
+                  live with HIP events on the launch stream (gx_sort_profile); peak = 8.0 TB/s HBM3E.
+  cpu_baseline -- the CPU oracle ("port": oracle/oracle.c LSD radix sort, 1 thread) timed on the
+                  host on a bounded sample of the same workload.
+"""
+import argparse
+import ctypes
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec (MI355X_MICROARCH.md); measured copy ceiling 6290 GB/s
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=5)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--workload", default="sort", choices=["sort", "sorted_order", "join", "groupby"])
+    ap.add_argument("--rows", type=float, default=1e9)
+    ap.add_argument("--algo", type=int, default=0, help="sort algorithm knob (0 onesweep, 1 three-kernel)")
+    ap.add_argument("--cpu-baseline", dest="cpu", action="store_true", default=True)
+    ap.add_argument("--no-cpu-baseline", dest="cpu", action="store_false")
+    ap.add_argument("--cpu-rows", type=float, default=3e7)
+    return ap.parse_args()
+
+
+def cpu_baseline_sort(rows):
+    """oracle ("port") timed on the host: single-thread LSD radix sort in C + pandas for context."""
+    import numpy as np
+    from oracle import c_oracle
+    n = int(rows)
+    rng = np.random.default_rng(42)
+    v = rng.integers(-2**63, 2**63 - 1, n, dtype=np.int64)
+    t0 = time.perf_counter()
+    out = c_oracle.sort_i64(v)
+    dt = time.perf_counter() - t0
+    assert out[0] <= out[n // 2] <= out[-1]
+    extra = {}
+    try:
+        import pandas as pd
+        m = min(n, 10_000_000)
+        df = pd.DataFrame({"a": v[:m]})
+        t0 = time.perf_counter()
+        df.sort_values("a", kind="stable")
+        extra["pandas_sort_values_rows_per_s"] = m / (time.perf_counter() - t0)
+        extra["pandas_rows"] = m
+    except Exception as e:  # pandas is context only
+        extra["pandas_error"] = repr(e)
+    return {"value": n / dt, "unit": "rows/s", "cores": 1, "kind": "port",
+            "sample": f"{n} uniform int64 rows (seed 42), oracle/oracle.c orc_sort_i64 (8-pass LSD radix, 1 thread)",
+            "host_cpus": os.cpu_count(), **extra}
+
+
+def cpu_baseline_join(rows):
+    import numpy as np
+    from oracle import c_oracle
+    n = int(rows)
+    rng = np.random.default_rng(12345)
+    build = rng.permutation(n // 5).astype(np.int64)[: n // 10]
+    probe = rng.integers(0, n // 3, n).astype(np.int64)
+    t0 = time.perf_counter()
+    l, r = c_oracle.inner_join_i64(probe, build)
+    dt = time.perf_counter() - t0
+    return {"value": n / dt, "unit": "rows/s", "cores": 1, "kind": "port",
+            "sample": f"probe {n} x build {len(build)} int64 rows, oracle/oracle.c orc_inner_join_i64 (count+retrieve)",
+            "host_cpus": os.cpu_count(), "matches": int(len(l))}
+
+
+def cpu_baseline_groupby(rows):
+    import numpy as np
+    from oracle import c_oracle
+    n = int(rows)
+    rng = np.random.default_rng(7)
+    k = rng.integers(0, 1_000_000, n).astype(np.int32)
+    v = rng.random(n)
+    t0 = time.perf_counter()
+    c_oracle.groupby_dense_sum_count(k, v, 1_000_000)
+    dt = time.perf_counter() - t0
+    return {"value": n / dt, "unit": "rows/s", "cores": 1, "kind": "port",
+            "sample": f"{n} rows, 1e6 int32 groups, f64 sum+count, oracle/oracle.c orc_groupby_dense_sum_count",
+            "host_cpus": os.cpu_count()}
+
+
+def main():
+    args = parse()
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    import numpy as np
+    import torch
+    import torch.distributed as dist
+    torch.cuda.set_device(local)
+    if world > 1:
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+    from cudf_amd import Column, ops, _lib as L
+    from cudf_amd.column import device_bytes, ptr, stream_ptr
+
+    lib = L.lib
+    n = int(args.rows)
+    lib.gx_sort_set_algorithm(args.algo)
+    stream = stream_ptr()
+
+    def barrier():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    roofline = None
+    extra = {}
+    if args.workload in ("sort", "sorted_order"):
+        keys = ops.random_column(np.int64, n, seed=42 + rank)
+        pairs = args.workload == "sorted_order"
+        out = Column.empty(np.int32 if pairs else np.int64, n)
+        nb = ctypes.c_size_t(0)
+        if pairs:
+            fn = lambda tmp, nbp: lib.gx_sorted_order(keys.gx, keys.data_ptr, None, n, 0, 0, 1, out.data_ptr, tmp, nbp, stream)
+        else:
+            fn = lambda tmp, nbp: lib.gx_sort_keys(keys.gx, keys.data_ptr, out.data_ptr, n, 0, tmp, nbp, stream)
+        L.check(fn(None, ctypes.byref(nb)), "size query")
+        tmp = device_bytes(nb.value)
+        step = lambda: L.check(fn(ptr(tmp), ctypes.byref(nb)), "sort")
+        bytes_per_row_pass = 24 if pairs else 16   # read key(+idx) + write key(+idx)
+        model_bytes_row = 200 if pairs else 136    # 8-pass LSD model
+        workload = f"{n:.0e}-row int64 " + ("sorted_order (radix sort pairs, int32 payload)" if pairs else "radix sort (cudf::sort, keys only)")
+        unit_rows = n
+    elif args.workload == "join":
+        nb_rows = max(1, n // 10)
+        # build: distinct keys (a permutation-like bijection of iota), probe: 30% hit rate
+        # (cpp/benchmarks/join/generate_input_tables.cu:24-103: unique build keys, selectivity 0.3)
+        bk = Column.empty(np.int64, nb_rows)
+        bkt = bk.data[: nb_rows * 8].view(torch.int64)
+        torch.manual_seed(12345 + rank)
+        bkt.copy_(torch.randperm(nb_rows, device="cuda") * 3 + 1)  # distinct keys {3i+1}, shuffled
+        pk = ops.random_column(np.int64, n, seed=67890 + rank, lo=0, hi=int(nb_rows / 0.3))
+        pk.data[: n * 8].view(torch.int64).mul_(3).add_(1)          # hits a build key w.p. 0.3
+        hj = ops.HashJoin(bk)
+        lo = Column.empty(np.int32, n)
+        ro = Column.empty(np.int32, n)
+        cur = torch.zeros(1, dtype=torch.int64, device="cuda")
+
+        def step():
+            cur.zero_()
+            L.check(lib.gx_join_probe(8, pk.data_ptr, None, n, ptr(hj.table), hj.table_bytes, 0, lo.data_ptr,
+                                      ro.data_ptr, n, ptr(cur), stream), "probe")
+        workload = f"{n:.0e}-row int64 probe x {nb_rows:.0e}-row build inner hash join (probe phase timed)"
+        unit_rows = n
+    else:  # groupby
+        gk = ops.random_column(np.int32, n, seed=7 + rank, lo=0, hi=1_000_000)
+        gv = ops.random_column(np.float64, n, seed=8 + rank)
+        mg = 1 << 20
+        ok, osum = Column.empty(np.int32, mg), Column.empty(np.float64, mg)
+        ocv = Column.empty(np.int32, mg)
+        ng = torch.zeros(1, dtype=torch.int64, device="cuda")
+        nb = ctypes.c_size_t(0)
+        fn = lambda tmp, nbp: lib.gx_groupby_sum_count(gk.gx, gk.data_ptr, None, gv.gx, gv.data_ptr, None, n, mg,
+                                                       ok.data_ptr, osum.data_ptr, ocv.data_ptr, None, ptr(ng), tmp, nbp, stream)
+        L.check(fn(None, ctypes.byref(nb)), "size query")
+        tmp = device_bytes(nb.value)
+        step = lambda: L.check(fn(ptr(tmp), ctypes.byref(nb)), "groupby")
+        workload = f"{n:.0e}-row groupby(int32 key, 1e6 groups).agg(float64 sum,count)"
+        unit_rows = n
+
+    for _ in range(args.warmup):
+        step()
+    if args.workload in ("sort", "sorted_order"):
+        lib.gx_sort_profile(1)
+    barrier()
+    t0 = time.perf_counter()
+    pass_ms_acc, hist_ms_acc, launches = 0.0, 0.0, 0
+    for _ in range(args.steps):
+        step()
+        if args.workload in ("sort", "sorted_order"):
+            # reading the events waits for this step only; it is part of the timed region
+            h = ctypes.c_float()
+            p = (ctypes.c_float * 8)()
+            k = ctypes.c_int()
+            L.check(lib.gx_sort_profile_read(ctypes.byref(h), p, ctypes.byref(k)), "profile_read")
+            act = [x for x in list(p)[: k.value] if x > 0.05]  # skipped passes exit in microseconds
+            pass_ms_acc += sum(act)
+            launches += len(act)
+            hist_ms_acc += h.value
+    barrier()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([dt], device="cuda", dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+    ms_per_step = dt / args.steps * 1e3
+
+    # correctness guard on the timed output (device-side, cheap): sorted + same multiset
+    if args.workload == "sort":
+        cin, cout = ops.checksum(keys), ops.checksum(out)
+        assert cout[2] == 0 and cin[:2] == cout[:2], "sort output invalid"
+        st = ctypes.c_int(0)
+        lib.gx_sort_status(ptr(tmp), ctypes.byref(st), stream)
+        assert st.value == 0, "look-back timed out"
+    if args.workload in ("sort", "sorted_order") and launches:
+        avg_ms = pass_ms_acc / launches
+        achieved = bytes_per_row_pass * n / (avg_ms * 1e-3) / 1e9
+        roofline = {"bound": "hbm", "kernel": "k_radix_pass (one 8-bit digit scatter pass)", "achieved": achieved,
+                    "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                    "algorithmic_bytes_per_launch": bytes_per_row_pass * n, "avg_launch_ms": avg_ms,
+                    "launches_per_step": launches / args.steps,
+                    "hist_kernel_ms": hist_ms_acc / args.steps,
+                    "whole_sort_model_GBps": model_bytes_row * n / (ms_per_step * 1e-3) / 1e9,
+                    "whole_sort_model_frac": model_bytes_row * n / (ms_per_step * 1e-3) / 1e9 / HBM_PEAK_GBS}
+    elif args.workload == "join":
+        matches = int(cur.item())
+        algb = 24 * n + 16 * matches
+        ach = algb / (ms_per_step * 1e-3) / 1e9
+        roofline = {"bound": "hbm", "kernel": "k_probe", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                    "frac": ach / HBM_PEAK_GBS, "traffic": None, "algorithmic_bytes_per_launch": algb,
+                    "avg_launch_ms": ms_per_step, "matches": matches}
+    elif args.workload == "groupby":
+        ach = 12 * n / (ms_per_step * 1e-3) / 1e9
+        roofline = {"bound": "hbm", "kernel": "k_aggregate", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                    "frac": ach / HBM_PEAK_GBS, "traffic": None, "algorithmic_bytes_per_launch": 12 * n,
+                    "avg_launch_ms": ms_per_step, "groups": int(ng.item())}
+
+    if rank == 0:
+        cpu = None
+        if args.cpu and world == 1:
+            cpu = {"sort": cpu_baseline_sort, "sorted_order": cpu_baseline_sort, "join": cpu_baseline_join,
+                   "groupby": cpu_baseline_groupby}[args.workload](args.cpu_rows)
+        line = {
+            "metric": "rows/sec + achieved HBM GB/s: 1e9-row int64 sort & hash-join, 1/2/4/8 GPU",
+            "value": unit_rows * world / (dt / args.steps), "unit": "rows/s", "n_gpus": world, "steps": args.steps,
+            "warmup": args.warmup, "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": {"sort": "int64", "sorted_order": "int64", "join": "int64", "groupby": "f64"}[args.workload],
+            "data": "synthetic",
+            "config": {"workload": workload, "rows_per_gpu": n, "algo": args.algo,
+                       "parallelism": f"row shards x{world}, no data-path collective"},
+            "roofline": roofline, "cpu_baseline": cpu,
+        }
+        line.update(extra)
+        print(json.dumps(line), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

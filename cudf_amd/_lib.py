@@ -1,0 +1,74 @@
+"""ctypes binding of the C ABI in include/cudf_amd/gx.h.
+
+The product path REQUIRES the HIP library: importing this module raises if
+cudf_amd/libcudf_amd.so is missing (build it with ``python scripts/build_ext.py``); there is no CPU
+fallback anywhere in the package.
+"""
+import ctypes
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libcudf_amd.so")
+
+if not os.path.exists(LIB_PATH):
+    raise ImportError(
+        f"{LIB_PATH} not found: the HIP extension is mandatory (no CPU fallback). "
+        "Run `python scripts/build_ext.py` (needs hipcc).")
+
+lib = ctypes.CDLL(LIB_PATH)
+
+_p = ctypes.c_void_p
+_i64 = ctypes.c_int64
+_i = ctypes.c_int
+_sz = ctypes.POINTER(ctypes.c_size_t)
+
+# dtype codes (== cudf::type_id)
+INT8, INT16, INT32, INT64, UINT8, UINT16, UINT32, UINT64, FLOAT32, FLOAT64, BOOL8 = range(1, 12)
+OP_SUM, OP_PRODUCT, OP_MIN, OP_MAX, OP_COUNT_VALID, OP_COUNT_ALL = 0, 1, 2, 3, 4, 5
+OP_MEAN = 10
+
+_PROTOS = {
+    "gx_version": (ctypes.c_char_p, []),
+    "gx_dtype_size": (_i, [_i]),
+    "gx_sort_keys": (_i, [_i, _p, _p, _i64, _i, _p, _sz, _p]),
+    "gx_sort_pairs": (_i, [_i, _p, _p, _p, _p, _i64, _i, _p, _sz, _p]),
+    "gx_sorted_order": (_i, [_i, _p, _p, _i64, _i64, _i, _i, _p, _p, _sz, _p]),
+    "gx_sort_status": (_i, [_p, ctypes.POINTER(_i), _p]),
+    "gx_sort_set_algorithm": (None, [_i]),
+    "gx_sort_profile": (_i, [_i]),
+    "gx_sort_profile_read": (_i, [ctypes.POINTER(ctypes.c_float), ctypes.POINTER(ctypes.c_float), ctypes.POINTER(_i)]),
+    "gx_gather": (_i, [_i, _p, _p, _i64, _p, _i64, _i, _p, _p, _p]),
+    "gx_bitmask_set": (_i, [_p, _i64, _i64, _i, _p]),
+    "gx_bitmask_count": (_i, [_p, _i64, _i64, _p, _p]),
+    "gx_bitmask_and": (_i, [ctypes.POINTER(_p), _i, _i64, _p, _p, _p]),
+    "gx_bitmask_first_unset": (_i, [_p, _i64, _p, _p]),
+    "gx_murmur3_32": (_i, [_i, _p, _p, _i64, ctypes.c_uint32, _i, _p, _p]),
+    "gx_hash_partition_map": (_i, [_p, _i64, _i, _p, _p, _p, _sz, _p]),
+    "gx_join_table_bytes": (ctypes.c_size_t, [_i, _i64, ctypes.c_double]),
+    "gx_join_build": (_i, [_i, _p, _p, _i64, _p, ctypes.c_size_t, ctypes.c_double, _p]),
+    "gx_join_count": (_i, [_i, _p, _p, _i64, _p, ctypes.c_size_t, _p, _p]),
+    "gx_join_probe": (_i, [_i, _p, _p, _i64, _p, ctypes.c_size_t, _i, _p, _p, _i64, _p, _p]),
+    "gx_groupby_sum_count": (_i, [_i, _p, _p, _i, _p, _p, _i64, _i64, _p, _p, _p, _p, _p, _p, _sz, _p]),
+    "gx_segmented_scan": (_i, [_i, _p, _i, _p, _p, _i64, _i, _p, _p, _sz, _p]),
+    "gx_reduce": (_i, [_i, _p, _p, _i64, _i, _i, _p, _p, _p, _sz, _p]),
+    "gx_scan": (_i, [_i, _p, _p, _i64, _i, _i, _p, _p, _sz, _p]),
+    "gx_fill_random": (_i, [_i, _p, _i64, ctypes.c_uint64, _i64, _i64, _p]),
+    "gx_sequence_i32": (_i, [_p, _i64, ctypes.c_int32, _p]),
+    "gx_checksum": (_i, [_i, _p, _i64, _i, _p, _p]),
+}
+
+for _name, (_res, _args) in _PROTOS.items():
+    _f = getattr(lib, _name)  # AttributeError here == the library does not export the ABI
+    _f.restype = _res
+    _f.argtypes = _args
+
+EXPORTED = tuple(_PROTOS)
+
+
+class GxError(RuntimeError):
+    pass
+
+
+def check(rc, what=""):
+    if rc != 0:
+        raise GxError(f"{what} failed with code {rc}" + (" (hipError)" if rc > 0 else ""))

@@ -1,0 +1,259 @@
+// gx_common.hpp -- device/host helpers shared by the gfx950 kernels of libcudf_amd.
+// wave = 64 lanes everywhere (CDNA4); no rocPRIM/hipCUB/thrust in the product.
+#pragma once
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "../../include/cudf_amd/gx.h"
+
+#define GX_WAVE 64
+
+#define GX_HIP_TRY(expr)                           \
+  do {                                             \
+    hipError_t _e = (expr);                        \
+    if (_e != hipSuccess) return (int)_e;          \
+  } while (0)
+
+#define GX_LAUNCH_CHECK()                          \
+  do {                                             \
+    hipError_t _e = hipGetLastError();             \
+    if (_e != hipSuccess) return (int)_e;          \
+  } while (0)
+
+namespace gx {
+
+__host__ __device__ static inline size_t align_up(size_t x, size_t a) { return (x + a - 1) / a * a; }
+__host__ __device__ static inline int64_t div_up(int64_t a, int64_t b) { return (a + b - 1) / b; }
+
+// carve helper for caller-provided scratch
+struct Carver {
+  char* base;
+  size_t off;
+  explicit Carver(void* p) : base(static_cast<char*>(p)), off(0) {}
+  template <typename T>
+  T* take(size_t count)
+  {
+    off       = align_up(off, 256);
+    T* r      = base ? reinterpret_cast<T*>(base + off) : nullptr;
+    off += count * sizeof(T);
+    return r;
+  }
+  size_t total() const { return align_up(off, 256); }
+};
+
+// ---------------------------------------------------------------- device primitives
+__device__ __forceinline__ unsigned lane_id()
+{
+  return __builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u));
+}
+__device__ __forceinline__ uint64_t lanemask_lt() { return (1ull << lane_id()) - 1ull; }
+__device__ __forceinline__ uint64_t ballot(bool p) { return __builtin_amdgcn_ballot_w64(p); }
+
+// cross-lane moves for any trivially copyable type (moved as 32-bit words)
+template <typename T, typename F>
+__device__ __forceinline__ T shfl_words(T v, F f)
+{
+  static_assert(sizeof(T) % 4 == 0, "shuffle payload must be a multiple of 4 bytes");
+  uint32_t w[sizeof(T) / 4];
+  __builtin_memcpy(w, &v, sizeof(T));
+#pragma unroll
+  for (unsigned k = 0; k < sizeof(T) / 4; ++k) w[k] = f(w[k]);
+  T r;
+  __builtin_memcpy(&r, w, sizeof(T));
+  return r;
+}
+template <typename T>
+__device__ __forceinline__ T shfl_up(T v, unsigned delta)
+{
+  return shfl_words(v, [delta](uint32_t x) { return (uint32_t)__shfl_up((int)x, delta, GX_WAVE); });
+}
+template <typename T>
+__device__ __forceinline__ T shfl(T v, int src)
+{
+  return shfl_words(v, [src](uint32_t x) { return (uint32_t)__shfl((int)x, src, GX_WAVE); });
+}
+template <typename T>
+__device__ __forceinline__ T shfl_xor(T v, int m)
+{
+  return shfl_words(v, [m](uint32_t x) { return (uint32_t)__shfl_xor((int)x, m, GX_WAVE); });
+}
+
+struct SumOp {
+  template <typename T>
+  __device__ __forceinline__ T operator()(T a, T b) const { return a + b; }
+};
+struct MinOp {
+  template <typename T>
+  __device__ __forceinline__ T operator()(T a, T b) const { return b < a ? b : a; }
+};
+struct MaxOp {
+  template <typename T>
+  __device__ __forceinline__ T operator()(T a, T b) const { return a < b ? b : a; }
+};
+struct ProdOp {
+  template <typename T>
+  __device__ __forceinline__ T operator()(T a, T b) const { return a * b; }
+};
+
+// inclusive scan across the 64 lanes of a wave (Hillis-Steele on shuffles; log2(64)=6 steps)
+template <typename T, typename Op>
+__device__ __forceinline__ T wave_inclusive_scan(T v, Op op)
+{
+  const unsigned l = lane_id();
+#pragma unroll
+  for (int d = 1; d < GX_WAVE; d <<= 1) {
+    T o = shfl_up(v, d);
+    if (l >= (unsigned)d) v = op(o, v);
+  }
+  return v;
+}
+
+template <typename T, typename Op>
+__device__ __forceinline__ T wave_reduce(T v, Op op)
+{
+#pragma unroll
+  for (int d = GX_WAVE / 2; d >= 1; d >>= 1) v = op(v, shfl_xor(v, d));
+  return v;
+}
+
+// Block-wide exclusive scan of one value per thread.  `lds` needs BT/64 + 1 elements of T.
+// Every thread of the block must call it.  Returns the exclusive prefix; *total (optional) the
+// block aggregate.  Association order is fixed (lane order inside a wave, wave order across), so
+// floating-point results are deterministic.
+template <int BT, typename T, typename Op>
+__device__ __forceinline__ T block_exclusive_scan(T v, T identity, Op op, T* lds, T* total)
+{
+  constexpr int NW = BT / GX_WAVE;
+  const unsigned l = lane_id();
+  const unsigned w = threadIdx.x / GX_WAVE;
+  T inc            = wave_inclusive_scan(v, op);
+  if (l == GX_WAVE - 1) lds[w] = inc;
+  __syncthreads();
+  if (w == 0) {
+    T x = (l < NW) ? lds[l] : identity;
+    T s = wave_inclusive_scan(x, op);
+    if (l < NW) lds[l] = s;  // inclusive over waves
+  }
+  __syncthreads();
+  T wave_prefix = (w == 0) ? identity : lds[w - 1];
+  T exc         = shfl_up(inc, 1);
+  if (l == 0) exc = identity;
+  if (total) *total = lds[NW - 1];
+  T r = op(wave_prefix, exc);
+  __syncthreads();  // lds may be reused by the caller
+  return r;
+}
+
+// bits -> unsigned key whose unsigned order is the cudf order (KIND 0 unsigned, 1 signed, 2 float).
+//  signed: sign flip.  float: -0.0 -> +0.0, NaN -> all ones (after +Inf; all NaNs equivalent),
+//  then the IEEE total-order flip.  desc_mask (0 or ~0) reverses the order.  Equal sortable bits
+//  <=> equivalent under the row comparator (NaN == NaN, -0 == +0).
+enum KeyKind { K_UNSIGNED = 0, K_SIGNED = 1, K_FLOAT = 2 };
+template <typename U, int KIND>
+__host__ __device__ __forceinline__ U to_sortable(U bits, U desc_mask)
+{
+  constexpr U SIGN = U(U(1) << (sizeof(U) * 8 - 1));
+  if (KIND == K_SIGNED) {
+    bits ^= SIGN;
+  } else if (KIND == K_FLOAT) {
+    constexpr U EXP = (sizeof(U) == 8) ? U(0x7FF0000000000000ull) : U(0x7F800000u);
+    const U mag     = bits & U(~SIGN);
+    if (mag > EXP) {
+      bits = U(~U(0));
+    } else {
+      if (mag == 0) bits = 0;
+      bits ^= (bits & SIGN) ? U(~U(0)) : SIGN;
+    }
+  }
+  return bits ^ desc_mask;
+}
+
+// splitmix64: counter-based generator for synthetic data and checksums
+__host__ __device__ __forceinline__ uint64_t splitmix64(uint64_t x)
+{
+  x += 0x9E3779B97F4A7C15ull;
+  x = (x ^ (x >> 30)) * 0xBF58476D1CE4E5B9ull;
+  x = (x ^ (x >> 27)) * 0x94D049BB133111EBull;
+  return x ^ (x >> 31);
+}
+
+// validity bitmap: LSB-first bits in uint32 words, 1 = valid (cudf/utilities/bit.hpp:47-61)
+__device__ __forceinline__ bool bit_is_set(const uint32_t* mask, int64_t i)
+{
+  return (mask[i >> 5] >> (i & 31)) & 1u;
+}
+__device__ __forceinline__ bool row_valid(const uint32_t* mask, int64_t i)
+{
+  return mask == nullptr || bit_is_set(mask, i);
+}
+
+// MurmurHash3_x86_32 finaliser / block (published algorithm; the reference delegates to
+// cuco::murmurhash3_32: include/cudf/hashing/detail/murmurhash3_x86_32.cuh:16,45)
+__host__ __device__ __forceinline__ uint32_t rotl32(uint32_t x, int r) { return (x << r) | (x >> (32 - r)); }
+__host__ __device__ __forceinline__ uint32_t fmix32(uint32_t h)
+{
+  h ^= h >> 16;
+  h *= 0x85ebca6bu;
+  h ^= h >> 13;
+  h *= 0xc2b2ae35u;
+  h ^= h >> 16;
+  return h;
+}
+__host__ __device__ __forceinline__ uint32_t mm3_block(uint32_t h, uint32_t k)
+{
+  k *= 0xcc9e2d51u;
+  k = rotl32(k, 15);
+  k *= 0x1b873593u;
+  h ^= k;
+  h = rotl32(h, 13);
+  return h * 5u + 0xe6546b64u;
+}
+__host__ __device__ __forceinline__ uint32_t murmur3_u32(uint32_t v, uint32_t seed)
+{
+  return fmix32(mm3_block(seed, v) ^ 4u);
+}
+__host__ __device__ __forceinline__ uint32_t murmur3_u64(uint64_t v, uint32_t seed)
+{
+  uint32_t h = mm3_block(seed, (uint32_t)v);
+  h          = mm3_block(h, (uint32_t)(v >> 32));
+  return fmix32(h ^ 8u);
+}
+// tail-only variants for 1- and 2-byte elements
+__host__ __device__ __forceinline__ uint32_t murmur3_tail(uint32_t k, uint32_t len, uint32_t seed)
+{
+  k *= 0xcc9e2d51u;
+  k = rotl32(k, 15);
+  k *= 0x1b873593u;
+  return fmix32((seed ^ k) ^ len);
+}
+__host__ __device__ __forceinline__ uint32_t hash_combine32(uint32_t lhs, uint32_t rhs)
+{
+  return lhs ^ (rhs + 0x9e3779b9u + (lhs << 6) + (lhs >> 2));
+}
+
+// XCD-aware tile mapping: the dispatcher is observed to place block b on XCD b % 8
+// (MI355X_MICROARCH.md, "Workgroup dispatch").  Give each XCD a contiguous range of tiles so
+// neighbouring tiles share an L2 (speed only; correctness never depends on it).
+__device__ __forceinline__ int64_t xcd_swizzle(int64_t bid, int64_t nblocks)
+{
+  constexpr int64_t NXCD = 8;
+  const int64_t full     = nblocks / NXCD * NXCD;
+  if (bid >= full) return bid;  // ragged tail keeps its index
+  const int64_t per = full / NXCD;
+  return (bid % NXCD) * per + bid / NXCD;
+}
+
+typedef __attribute__((address_space(1))) unsigned long long gu64;
+typedef __attribute__((address_space(1))) unsigned int gu32;
+
+__device__ __forceinline__ void store_agent_u64(unsigned long long* p, unsigned long long v)
+{
+  __hip_atomic_store((gu64*)p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ unsigned long long load_agent_u64(const unsigned long long* p)
+{
+  return __hip_atomic_load((gu64*)p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
+}  // namespace gx

@@ -1,0 +1,215 @@
+// gx_gather.hip -- gather of fixed-width columns (+ validity) and validity-bitmap utilities.
+//
+// gather replaces cudf::detail::gather (include/cudf/detail/gather.cuh:108-131 for data,
+// :506-577 gather_bitmask kernel).  HBM-bound: reads 4 B of map + one random element, writes one
+// coalesced element; the output bitmap is assembled with one wave64 ballot per 64 rows.
+#include "gx_common.hpp"
+
+namespace gx {
+
+constexpr int GATHER_BT = 256;
+
+template <typename T, bool HAS_VALID>
+__global__ void __launch_bounds__(GATHER_BT) k_gather(const T* __restrict__ src,
+                                                      const uint32_t* __restrict__ src_valid, int64_t src_rows,
+                                                      const int32_t* __restrict__ map, int64_t n, int nullify_oob,
+                                                      T* __restrict__ out, uint32_t* __restrict__ out_valid)
+{
+  // n rounded up to a multiple of 64 so every wave covers an aligned 64-row span of the bitmap
+  const int64_t n64    = (n + 63) & ~int64_t(63);
+  const int64_t stride = (int64_t)gridDim.x * GATHER_BT;
+  for (int64_t i = (int64_t)blockIdx.x * GATHER_BT + threadIdx.x; i < n64; i += stride) {
+    bool ok = false;
+    if (i < n) {
+      const int64_t m = map[i];
+      const bool inb  = !nullify_oob || (m >= 0 && m < src_rows);
+      T v             = T(0);
+      if (inb) {
+        v  = src[m];
+        ok = !HAS_VALID || src_valid == nullptr || bit_is_set(src_valid, m);
+      }
+      out[i] = v;
+    }
+    if (HAS_VALID) {
+      const uint64_t b = ballot(ok);
+      if (lane_id() == 0) {
+        const int64_t w = i >> 5;  // i is a multiple of 64 here
+        out_valid[w]     = (uint32_t)b;
+        if (w + 1 < ((n + 31) >> 5)) out_valid[w + 1] = (uint32_t)(b >> 32);
+      }
+    }
+  }
+}
+
+template <typename T>
+int gather_launch(const void* src, const uint32_t* src_valid, int64_t src_rows, const int32_t* map, int64_t n,
+                  int nullify_oob, void* out, uint32_t* out_valid, hipStream_t s)
+{
+  int64_t blocks = div_up(n, GATHER_BT * 4);
+  if (blocks > 8192) blocks = 8192;
+  if (blocks < 1) blocks = 1;
+  if (out_valid)
+    hipLaunchKernelGGL((k_gather<T, true>), dim3((unsigned)blocks), dim3(GATHER_BT), 0, s,
+                       static_cast<const T*>(src), src_valid, src_rows, map, n, nullify_oob, static_cast<T*>(out),
+                       out_valid);
+  else
+    hipLaunchKernelGGL((k_gather<T, false>), dim3((unsigned)blocks), dim3(GATHER_BT), 0, s,
+                       static_cast<const T*>(src), src_valid, src_rows, map, n, nullify_oob, static_cast<T*>(out),
+                       out_valid);
+  GX_LAUNCH_CHECK();
+  return 0;
+}
+
+// ---------------------------------------------------------------- bitmask kernels
+__device__ __forceinline__ uint32_t word_range_mask(int64_t w, int64_t begin_bit, int64_t end_bit)
+{
+  const int64_t lo = w * 32, hi = lo + 32;
+  if (hi <= begin_bit || lo >= end_bit) return 0u;
+  uint32_t m = 0xFFFFFFFFu;
+  if (begin_bit > lo) m &= 0xFFFFFFFFu << (begin_bit - lo);
+  if (end_bit < hi) m &= 0xFFFFFFFFu >> (hi - end_bit);
+  return m;
+}
+
+__global__ void __launch_bounds__(256) k_bitmask_set(uint32_t* mask, int64_t begin_bit, int64_t end_bit, int valid)
+{
+  const int64_t w0 = begin_bit >> 5, w1 = (end_bit + 31) >> 5;
+  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  for (int64_t w = w0 + (int64_t)blockIdx.x * blockDim.x + threadIdx.x; w < w1; w += stride) {
+    const uint32_t m = word_range_mask(w, begin_bit, end_bit);
+    if (m == 0xFFFFFFFFu)
+      mask[w] = valid ? 0xFFFFFFFFu : 0u;
+    else if (m)
+      mask[w] = valid ? (mask[w] | m) : (mask[w] & ~m);
+  }
+}
+
+struct MaskList {
+  const uint32_t* m[16];
+  int count;
+};
+
+// out = AND of masks (null entries skipped); optional popcount of [0, nbits)
+__global__ void __launch_bounds__(256) k_bitmask_and_count(MaskList ml, int64_t begin_bit, int64_t end_bit,
+                                                           uint32_t* out, unsigned long long* count)
+{
+  const int64_t w0 = begin_bit >> 5, w1 = (end_bit + 31) >> 5;
+  const int64_t stride    = (int64_t)gridDim.x * blockDim.x;
+  unsigned long long pops = 0;
+  for (int64_t w = w0 + (int64_t)blockIdx.x * blockDim.x + threadIdx.x; w < w1; w += stride) {
+    uint32_t v = 0xFFFFFFFFu;
+    for (int k = 0; k < ml.count; ++k)
+      if (ml.m[k]) v &= ml.m[k][w];
+    if (out) out[w] = v;
+    pops += __builtin_popcount(v & word_range_mask(w, begin_bit, end_bit));
+  }
+  if (count) {
+    pops = wave_reduce(pops, SumOp());
+    if (lane_id() == 0 && pops) atomicAdd(count, pops);
+  }
+}
+
+__global__ void k_set_u64(unsigned long long* p, unsigned long long v) { *p = v; }
+
+__global__ void __launch_bounds__(256) k_first_unset(const uint32_t* mask, int64_t nbits, unsigned long long* pos)
+{
+  const int64_t nw     = (nbits + 31) >> 5;
+  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  unsigned long long best = (unsigned long long)nbits;
+  for (int64_t w = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; w < nw; w += stride) {
+    const uint32_t inv = ~mask[w] & word_range_mask(w, 0, nbits);
+    if (inv) {
+      const unsigned long long p = (unsigned long long)(w * 32 + __builtin_ctz(inv));
+      if (p < best) best = p;
+      break;  // later words of this thread are larger
+    }
+  }
+  best = wave_reduce(best, MinOp());
+  if (lane_id() == 0 && best < (unsigned long long)nbits) atomicMin(pos, best);
+}
+
+static inline unsigned word_grid(int64_t nwords)
+{
+  int64_t b = div_up(nwords, 256 * 4);
+  if (b > 4096) b = 4096;
+  if (b < 1) b = 1;
+  return (unsigned)b;
+}
+
+}  // namespace gx
+
+extern "C" {
+
+int gx_gather(int elem_size, const void* src, const uint32_t* src_valid, int64_t src_rows, const int32_t* map,
+              int64_t n, int nullify_oob, void* out, uint32_t* out_valid, gx_stream_t s)
+{
+  if (n < 0 || src_rows < 0) return GX_EINVAL;
+  if (n == 0) return 0;
+  if (!map || !out || (!src && src_rows > 0)) return GX_EINVAL;
+  switch (elem_size) {
+    case 1: return gx::gather_launch<uint8_t>(src, src_valid, src_rows, map, n, nullify_oob, out, out_valid, s);
+    case 2: return gx::gather_launch<uint16_t>(src, src_valid, src_rows, map, n, nullify_oob, out, out_valid, s);
+    case 4: return gx::gather_launch<uint32_t>(src, src_valid, src_rows, map, n, nullify_oob, out, out_valid, s);
+    case 8: return gx::gather_launch<uint64_t>(src, src_valid, src_rows, map, n, nullify_oob, out, out_valid, s);
+    default: return GX_EDTYPE;
+  }
+}
+
+int gx_bitmask_set(uint32_t* mask, int64_t begin_bit, int64_t end_bit, int valid, gx_stream_t s)
+{
+  if (begin_bit < 0 || end_bit < begin_bit) return GX_EINVAL;
+  if (end_bit == begin_bit) return 0;
+  if (!mask) return GX_EINVAL;
+  const int64_t nw = ((end_bit + 31) >> 5) - (begin_bit >> 5);
+  hipLaunchKernelGGL(gx::k_bitmask_set, dim3(gx::word_grid(nw)), dim3(256), 0, s, mask, begin_bit, end_bit, valid);
+  GX_LAUNCH_CHECK();
+  return 0;
+}
+
+int gx_bitmask_count(const uint32_t* mask, int64_t begin_bit, int64_t end_bit, int64_t* count_dev, gx_stream_t s)
+{
+  if (begin_bit < 0 || end_bit < begin_bit || !count_dev) return GX_EINVAL;
+  GX_HIP_TRY(hipMemsetAsync(count_dev, 0, sizeof(int64_t), s));
+  if (end_bit == begin_bit) return 0;
+  if (!mask) return GX_EINVAL;
+  gx::MaskList ml{};
+  ml.m[0]  = mask;
+  ml.count = 1;
+  const int64_t nw = ((end_bit + 31) >> 5) - (begin_bit >> 5);
+  hipLaunchKernelGGL(gx::k_bitmask_and_count, dim3(gx::word_grid(nw)), dim3(256), 0, s, ml, begin_bit, end_bit,
+                     (uint32_t*)nullptr, reinterpret_cast<unsigned long long*>(count_dev));
+  GX_LAUNCH_CHECK();
+  return 0;
+}
+
+int gx_bitmask_and(const uint32_t* const* masks_host, int nmasks, int64_t nbits, uint32_t* out, int64_t* count_dev,
+                   gx_stream_t s)
+{
+  if (nmasks < 0 || nmasks > 16 || nbits < 0 || (nmasks > 0 && !masks_host)) return GX_EINVAL;
+  if (count_dev) GX_HIP_TRY(hipMemsetAsync(count_dev, 0, sizeof(int64_t), s));
+  if (nbits == 0) return 0;
+  if (!out && !count_dev) return GX_EINVAL;
+  gx::MaskList ml{};
+  ml.count = nmasks;
+  for (int k = 0; k < nmasks; ++k) ml.m[k] = masks_host[k];
+  const int64_t nw = (nbits + 31) >> 5;
+  hipLaunchKernelGGL(gx::k_bitmask_and_count, dim3(gx::word_grid(nw)), dim3(256), 0, s, ml, (int64_t)0, nbits, out,
+                     reinterpret_cast<unsigned long long*>(count_dev));
+  GX_LAUNCH_CHECK();
+  return 0;
+}
+
+int gx_bitmask_first_unset(const uint32_t* mask, int64_t nbits, int64_t* pos_dev, gx_stream_t s)
+{
+  if (nbits < 0 || !pos_dev) return GX_EINVAL;
+  hipLaunchKernelGGL(gx::k_set_u64, dim3(1), dim3(1), 0, s, reinterpret_cast<unsigned long long*>(pos_dev),
+                     (unsigned long long)nbits);
+  if (nbits == 0 || !mask) return 0;
+  const int64_t nw = (nbits + 31) >> 5;
+  hipLaunchKernelGGL(gx::k_first_unset, dim3(gx::word_grid(nw)), dim3(256), 0, s, mask, nbits,
+                     reinterpret_cast<unsigned long long*>(pos_dev));
+  GX_LAUNCH_CHECK();
+  return 0;
+}
+
+}  // extern "C"

@@ -1,0 +1,314 @@
+// gx_join.hip -- hash join build / count / probe for gfx950 (single 4- or 8-byte key column).
+//
+// Replaces the cuco::static_multiset the reference builds over {murmur3(row), row}
+// (cpp/src/join/hash_join/hash_join.cu:62-99,112-148; hash_join_impl.cuh:50-57) and its
+// count / retrieve probes (size_impl.cuh:26-62, retrieve_impl.cuh:28-113).
+//
+// MI355X-first differences (DESIGN.md "hash join"):
+//   * slots hold the KEY itself ({key,row}: 16 B for 8-byte keys, 8 B for 4-byte keys), so a probe
+//     is one random line fetch -- no second random read of the build column to verify equality
+//     (the reference compares hashes in the slot, then dereferences the row: dispatch.cuh:58-75);
+//   * power-of-two capacity, Fibonacci hash, linear probing: a chain stays inside one 128-B line;
+//   * probe output is reserved with ONE atomic per 4096-row workgroup chunk (a single HBM-side
+//     cursor word saturates near 88 atomics/us on this chip), and pairs leave in wave-contiguous
+//     runs; the reference flushes per warp (partitioned_retrieve_kernels.cuh:57-211).
+// Result order is unspecified (cpp/include/cudf/join/join.hpp:131-134).
+#include "gx_common.hpp"
+
+namespace gx {
+namespace join {
+
+constexpr int JBT  = 256;
+constexpr int JRPT = 16;  // probe rows per thread
+constexpr int JCHUNK = JBT * JRPT;
+constexpr int32_t EMPTY_ROW = -1;
+constexpr int32_t NO_MATCH  = INT32_MIN;  // cudf::JoinNoMatch (include/cudf/join/join.hpp:72)
+
+struct alignas(256) TableHeader {
+  uint64_t capacity;  // slots, power of two
+  uint32_t log2cap;
+  uint32_t key_size;
+  int64_t build_rows;
+};
+
+template <typename K>
+struct Slot;
+template <>
+struct alignas(16) Slot<uint64_t> {
+  uint64_t key;
+  int32_t row;
+  int32_t pad;
+};
+template <>
+struct alignas(8) Slot<uint32_t> {
+  uint32_t key;
+  int32_t row;
+};
+
+static inline uint32_t log2_capacity(int64_t build_rows, double load_factor)
+{
+  if (!(load_factor > 0.0) || load_factor > 1.0) load_factor = 0.5;  // CUCO_DESIRED_LOAD_FACTOR
+  double want  = (double)(build_rows < 1 ? 1 : build_rows) / load_factor + 1.0;  // never completely full
+  uint32_t lg  = 4;
+  while ((double)(1ull << lg) < want) ++lg;
+  return lg;
+}
+
+template <typename K>
+__device__ __forceinline__ uint64_t slot_of(K key, uint32_t log2cap)
+{
+  return ((uint64_t)key * 0x9E3779B97F4A7C15ull) >> (64 - log2cap);
+}
+
+template <typename K>
+__device__ __forceinline__ void load_slot(const Slot<K>* s, K& key, int32_t& row);
+template <>
+__device__ __forceinline__ void load_slot<uint64_t>(const Slot<uint64_t>* s, uint64_t& key, int32_t& row)
+{
+  const uint4 v = *reinterpret_cast<const uint4*>(s);  // one 16-B load
+  key           = ((uint64_t)v.y << 32) | v.x;
+  row           = (int32_t)v.z;
+}
+template <>
+__device__ __forceinline__ void load_slot<uint32_t>(const Slot<uint32_t>* s, uint32_t& key, int32_t& row)
+{
+  const uint2 v = *reinterpret_cast<const uint2*>(s);
+  key           = v.x;
+  row           = (int32_t)v.y;
+}
+
+template <typename K>
+__global__ void __launch_bounds__(JBT) k_build(const K* __restrict__ keys, const uint32_t* __restrict__ valid,
+                                               int64_t n, Slot<K>* slots, uint32_t log2cap)
+{
+  const uint64_t mask  = (1ull << log2cap) - 1;
+  const int64_t stride = (int64_t)gridDim.x * JBT;
+  for (int64_t i = (int64_t)blockIdx.x * JBT + threadIdx.x; i < n; i += stride) {
+    if (valid && !bit_is_set(valid, i)) continue;  // null build rows are never inserted
+    const K key = keys[i];
+    uint64_t h  = slot_of<K>(key, log2cap);
+    for (;;) {
+      const int32_t old = atomicCAS(&slots[h].row, EMPTY_ROW, (int32_t)i);
+      if (old == EMPTY_ROW) {
+        slots[h].key = key;  // nobody reads keys before the build kernel has finished
+        break;
+      }
+      h = (h + 1) & mask;
+    }
+  }
+}
+
+// walk the chain of `key`: count matches, remember the first one
+template <typename K>
+__device__ __forceinline__ uint32_t chain_count(const Slot<K>* slots, uint64_t mask, uint32_t log2cap, K key,
+                                                int32_t& first)
+{
+  uint32_t c = 0;
+  uint64_t h = slot_of<K>(key, log2cap);
+  for (;;) {
+    K k;
+    int32_t r;
+    load_slot<K>(&slots[h], k, r);
+    if (r == EMPTY_ROW) break;
+    if (k == key) {
+      if (c == 0) first = r;
+      ++c;
+    }
+    h = (h + 1) & mask;
+  }
+  return c;
+}
+
+template <typename K, bool WRITE>
+__global__ void __launch_bounds__(JBT) k_probe(const K* __restrict__ keys, const uint32_t* __restrict__ valid,
+                                               int64_t n, const Slot<K>* __restrict__ slots, uint32_t log2cap,
+                                               int left_outer, int32_t* __restrict__ out_probe,
+                                               int32_t* __restrict__ out_build, int64_t capacity,
+                                               unsigned long long* cursor)
+{
+  constexpr int NWJ = JBT / GX_WAVE;
+  __shared__ unsigned long long s_wave_tot[NWJ];
+  __shared__ unsigned long long s_base;
+  const uint64_t mask   = (1ull << log2cap) - 1;
+  const unsigned lane   = lane_id();
+  const unsigned w      = threadIdx.x / GX_WAVE;
+  const int64_t nchunks = div_up(n, (int64_t)JCHUNK);
+  for (int64_t chunk = blockIdx.x; chunk < nchunks; chunk += gridDim.x) {
+    const int64_t wbase = chunk * JCHUNK + (int64_t)w * (JRPT * GX_WAVE) + lane;
+    uint32_t cnt[JRPT];
+    int32_t first[JRPT];
+    uint32_t wave_total = 0;
+#pragma unroll
+    for (int j = 0; j < JRPT; ++j) {
+      const int64_t i = wbase + j * GX_WAVE;
+      cnt[j]          = 0;
+      first[j]        = NO_MATCH;
+      if (i < n) {
+        if (!valid || bit_is_set(valid, i)) cnt[j] = chain_count<K>(slots, mask, log2cap, keys[i], first[j]);
+        if (left_outer && cnt[j] == 0) cnt[j] = 1;  // (i, JoinNoMatch); first[j] already NO_MATCH
+      }
+    }
+    if (!WRITE) {
+#pragma unroll
+      for (int j = 0; j < JRPT; ++j) wave_total += cnt[j];
+      wave_total = wave_reduce(wave_total, SumOp());
+      if (lane == 0 && wave_total) atomicAdd(cursor, (unsigned long long)wave_total);
+      continue;
+    }
+    // ---- per-lane exclusive offsets inside the wave, row-major over j
+    uint32_t off[JRPT];
+#pragma unroll
+    for (int j = 0; j < JRPT; ++j) {
+      uint32_t inc;
+      if (ballot(cnt[j] > 1) == 0) {  // at most one match per row in this wave-row: one ballot
+        const uint64_t b = ballot(cnt[j] == 1);
+        off[j]           = wave_total + (uint32_t)__builtin_popcountll(b & lanemask_lt());
+        inc              = (uint32_t)__builtin_popcountll(b);
+      } else {
+        const uint32_t s = wave_inclusive_scan(cnt[j], SumOp());
+        off[j]           = wave_total + s - cnt[j];
+        inc              = shfl(s, GX_WAVE - 1);
+      }
+      wave_total += inc;
+    }
+    // ---- one reservation per workgroup chunk
+    if (lane == 0) s_wave_tot[w] = wave_total;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+      unsigned long long tot = 0;
+      for (int k = 0; k < NWJ; ++k) {
+        const unsigned long long t = s_wave_tot[k];
+        s_wave_tot[k]              = tot;
+        tot += t;
+      }
+      s_base = tot ? atomicAdd(cursor, tot) : 0ull;
+    }
+    __syncthreads();
+    const unsigned long long wave_base = s_base + s_wave_tot[w];
+#pragma unroll
+    for (int j = 0; j < JRPT; ++j) {
+      const int64_t i = wbase + j * GX_WAVE;
+      if (cnt[j] == 0) continue;
+      unsigned long long pos = wave_base + off[j];
+      if (cnt[j] == 1) {
+        if ((int64_t)pos < capacity) {
+          out_probe[pos] = (int32_t)i;
+          out_build[pos] = first[j];
+        }
+      } else {  // duplicate build keys: walk the chain again (lines are cache-resident)
+        const K key = keys[i];
+        uint64_t h  = slot_of<K>(key, log2cap);
+        for (;;) {
+          K k;
+          int32_t r;
+          load_slot<K>(&slots[h], k, r);
+          if (r == EMPTY_ROW) break;
+          if (k == key) {
+            if ((int64_t)pos < capacity) {
+              out_probe[pos] = (int32_t)i;
+              out_build[pos] = r;
+            }
+            ++pos;
+          }
+          h = (h + 1) & mask;
+        }
+      }
+    }
+    __syncthreads();  // s_wave_tot / s_base reused by the next chunk
+  }
+}
+
+template <typename K>
+int build_impl(const void* keys, const uint32_t* valid, int64_t n, void* table, size_t table_bytes,
+               double load_factor, hipStream_t s)
+{
+  const uint32_t lg = log2_capacity(n, load_factor);
+  const size_t need = sizeof(TableHeader) + (sizeof(Slot<K>) << lg);
+  if (table_bytes < need) return GX_ETMP;
+  char* base = static_cast<char*>(table);
+  GX_HIP_TRY(hipMemsetAsync(base + sizeof(TableHeader), 0xFF, sizeof(Slot<K>) << lg, s));
+  if (n > 0) {
+    int64_t blocks = div_up(n, JBT * 4);
+    if (blocks > 8192) blocks = 8192;
+    hipLaunchKernelGGL((k_build<K>), dim3((unsigned)blocks), dim3(JBT), 0, s, static_cast<const K*>(keys), valid, n,
+                       reinterpret_cast<Slot<K>*>(base + sizeof(TableHeader)), lg);
+    GX_LAUNCH_CHECK();
+  }
+  return 0;
+}
+
+template <typename K, bool WRITE>
+int probe_impl(const void* keys, const uint32_t* valid, int64_t n, const void* table, size_t table_bytes,
+               uint32_t lg, int left_outer, int32_t* out_probe, int32_t* out_build, int64_t capacity,
+               int64_t* cursor, hipStream_t s)
+{
+  const size_t need = sizeof(TableHeader) + (sizeof(Slot<K>) << lg);
+  if (table_bytes < need) return GX_ETMP;
+  if (n == 0) return 0;
+  int64_t blocks = div_up(n, JCHUNK);
+  if (blocks > 256 * 16) blocks = 256 * 16;
+  const char* base = static_cast<const char*>(table);
+  hipLaunchKernelGGL((k_probe<K, WRITE>), dim3((unsigned)blocks), dim3(JBT), 0, s, static_cast<const K*>(keys), valid,
+                     n, reinterpret_cast<const Slot<K>*>(base + sizeof(TableHeader)), lg, left_outer, out_probe,
+                     out_build, capacity, reinterpret_cast<unsigned long long*>(cursor));
+  GX_LAUNCH_CHECK();
+  return 0;
+}
+
+}  // namespace join
+}  // namespace gx
+
+extern "C" {
+
+size_t gx_join_table_bytes(int key_size, int64_t build_rows, double load_factor)
+{
+  if (key_size != 4 && key_size != 8) return 0;
+  const uint32_t lg = gx::join::log2_capacity(build_rows, load_factor);
+  return sizeof(gx::join::TableHeader) + ((size_t)(key_size == 8 ? 16 : 8) << lg);
+}
+
+int gx_join_build(int key_size, const void* build_keys, const uint32_t* build_valid, int64_t build_rows,
+                  void* table, size_t table_bytes, double load_factor, gx_stream_t s)
+{
+  if (build_rows < 0 || !table || (build_rows > 0 && !build_keys)) return GX_EINVAL;
+  if (key_size == 8) return gx::join::build_impl<uint64_t>(build_keys, build_valid, build_rows, table, table_bytes, load_factor, s);
+  if (key_size == 4) return gx::join::build_impl<uint32_t>(build_keys, build_valid, build_rows, table, table_bytes, load_factor, s);
+  return GX_EDTYPE;
+}
+
+// capacity (log2) is recomputed from the table size so the table blob needs no host round trip
+static uint32_t gx_join_log2_from_bytes(int key_size, size_t table_bytes)
+{
+  const size_t slot = key_size == 8 ? 16 : 8;
+  size_t slots      = (table_bytes - sizeof(gx::join::TableHeader)) / slot;
+  uint32_t lg       = 0;
+  while ((2ull << lg) <= slots) ++lg;
+  return lg;
+}
+
+int gx_join_count(int key_size, const void* probe_keys, const uint32_t* probe_valid, int64_t probe_rows,
+                  const void* table, size_t table_bytes, int64_t* count_dev, gx_stream_t s)
+{
+  if (probe_rows < 0 || !table || !count_dev || (probe_rows > 0 && !probe_keys)) return GX_EINVAL;
+  if (table_bytes <= sizeof(gx::join::TableHeader)) return GX_ETMP;
+  GX_HIP_TRY(hipMemsetAsync(count_dev, 0, sizeof(int64_t), s));
+  const uint32_t lg = gx_join_log2_from_bytes(key_size, table_bytes);
+  if (key_size == 8) return gx::join::probe_impl<uint64_t, false>(probe_keys, probe_valid, probe_rows, table, table_bytes, lg, 0, nullptr, nullptr, 0, count_dev, s);
+  if (key_size == 4) return gx::join::probe_impl<uint32_t, false>(probe_keys, probe_valid, probe_rows, table, table_bytes, lg, 0, nullptr, nullptr, 0, count_dev, s);
+  return GX_EDTYPE;
+}
+
+int gx_join_probe(int key_size, const void* probe_keys, const uint32_t* probe_valid, int64_t probe_rows,
+                  const void* table, size_t table_bytes, int left_outer, int32_t* out_probe_idx,
+                  int32_t* out_build_idx, int64_t capacity, int64_t* cursor_dev, gx_stream_t s)
+{
+  if (probe_rows < 0 || capacity < 0 || !table || !cursor_dev || (probe_rows > 0 && !probe_keys)) return GX_EINVAL;
+  if (capacity > 0 && (!out_probe_idx || !out_build_idx)) return GX_EINVAL;
+  if (table_bytes <= sizeof(gx::join::TableHeader)) return GX_ETMP;
+  const uint32_t lg = gx_join_log2_from_bytes(key_size, table_bytes);
+  if (key_size == 8) return gx::join::probe_impl<uint64_t, true>(probe_keys, probe_valid, probe_rows, table, table_bytes, lg, left_outer, out_probe_idx, out_build_idx, capacity, cursor_dev, s);
+  if (key_size == 4) return gx::join::probe_impl<uint32_t, true>(probe_keys, probe_valid, probe_rows, table, table_bytes, lg, left_outer, out_probe_idx, out_build_idx, capacity, cursor_dev, s);
+  return GX_EDTYPE;
+}
+
+}  // extern "C"

@@ -1,0 +1,424 @@
+// gx_reduce_scan.hip -- cudf::reduce / cudf::scan / groupby::scan kernels' C ABI.
+//
+// reduce replaces cub::DeviceReduce::Reduce (cpp/include/cudf/reduction/detail/reduction.cuh:46-83),
+// scan replaces thrust::inclusive_scan / exclusive_scan (cpp/src/reductions/scan/
+// scan_inclusive.cu:76-89, scan_exclusive.cu), segmented scan replaces
+// thrust::inclusive_scan_by_key (cpp/src/groupby/sort/group_scan_util.cuh:109-130).
+//
+// float SUM accumulates in double-double (error-free two_sum), so the rounded result is the
+// correctly rounded exact sum in all but pathological cases and is bit-reproducible (fixed
+// association order of gx_scan.hpp) -- north_star asks <= 1 ulp; integer SUM/PRODUCT wrap mod 2^64
+// exactly like the reference's integer arithmetic.
+#include <limits>
+#include <type_traits>
+
+#include "gx_common.hpp"
+#include "gx_scan.hpp"
+
+namespace gx {
+namespace rs {
+
+// ---------------------------------------------------------------- double-double accumulator
+struct DD {
+  double hi, lo;
+  __host__ __device__ explicit operator double() const { return hi + lo; }
+  __host__ __device__ explicit operator float() const { return (float)(hi + lo); }
+};
+struct DDSum {
+  __device__ __forceinline__ DD operator()(DD a, DD b) const
+  {
+    // two_sum(a.hi, b.hi)
+    const double s  = a.hi + b.hi;
+    const double bb = s - a.hi;
+    double e        = (a.hi - (s - bb)) + (b.hi - bb);
+    e += a.lo + b.lo;
+    // fast_two_sum(s, e)
+    const double hi = s + e;
+    const double lo = e - (hi - s);
+    return DD{hi, lo};
+  }
+};
+
+template <typename InT>
+struct DDLoader {
+  const InT* in;
+  const uint32_t* valid;
+  __device__ __forceinline__ DD operator()(int64_t i) const
+  {
+    if (valid && !bit_is_set(valid, i)) return DD{0.0, 0.0};
+    return DD{(double)in[i], 0.0};
+  }
+};
+
+// ---------------------------------------------------------------- segmented (by-key) element
+template <typename T>
+struct Seg {
+  T v;
+  uint32_t f;  // 1 = this element starts a new key run
+  uint32_t pad;
+  __host__ __device__ explicit operator double() const { return (double)v; }
+  __host__ __device__ explicit operator float() const { return (float)v; }
+  __host__ __device__ explicit operator long long() const { return (long long)v; }
+  __host__ __device__ explicit operator long() const { return (long)v; }
+  __host__ __device__ explicit operator int() const { return (int)v; }
+  __host__ __device__ explicit operator short() const { return (short)v; }
+  __host__ __device__ explicit operator signed char() const { return (signed char)v; }
+  __host__ __device__ explicit operator unsigned long long() const { return (unsigned long long)v; }
+  __host__ __device__ explicit operator unsigned long() const { return (unsigned long)v; }
+  __host__ __device__ explicit operator unsigned int() const { return (unsigned int)v; }
+  __host__ __device__ explicit operator unsigned short() const { return (unsigned short)v; }
+  __host__ __device__ explicit operator unsigned char() const { return (unsigned char)v; }
+};
+template <typename T, typename Op>
+struct SegOp {
+  Op op;
+  __device__ __forceinline__ Seg<T> operator()(Seg<T> a, Seg<T> b) const
+  {
+    return Seg<T>{b.f ? b.v : op(a.v, b.v), a.f | b.f, 0u};
+  }
+};
+template <typename InT, typename AccT>
+struct SegLoader {
+  const InT* in;
+  const uint32_t* valid;
+  const uint8_t* heads;
+  AccT identity;
+  __device__ __forceinline__ Seg<AccT> operator()(int64_t i) const
+  {
+    const AccT v = (valid && !bit_is_set(valid, i)) ? identity : static_cast<AccT>(in[i]);
+    return Seg<AccT>{v, heads[i], 0u};
+  }
+};
+
+template <typename U, int KIND>
+__global__ void __launch_bounds__(256) k_run_heads(const U* __restrict__ keys, int64_t n, uint8_t* __restrict__ heads)
+{
+  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
+    heads[i] = (i == 0 || to_sortable<U, KIND>(keys[i], U(0)) != to_sortable<U, KIND>(keys[i - 1], U(0))) ? 1 : 0;
+  }
+}
+
+template <typename U, int KIND>
+int heads_launch(const void* keys, int64_t n, uint8_t* heads, hipStream_t s)
+{
+  int64_t blocks = div_up(n, 256 * 8);
+  if (blocks > 4096) blocks = 4096;
+  hipLaunchKernelGGL((k_run_heads<U, KIND>), dim3((unsigned)blocks), dim3(256), 0, s, static_cast<const U*>(keys), n,
+                     heads);
+  GX_LAUNCH_CHECK();
+  return 0;
+}
+
+static int heads_dispatch(int key_dtype, const void* keys, int64_t n, uint8_t* heads, hipStream_t s)
+{
+  switch (key_dtype) {
+    case GX_INT8: return heads_launch<uint8_t, K_SIGNED>(keys, n, heads, s);
+    case GX_BOOL8:
+    case GX_UINT8: return heads_launch<uint8_t, K_UNSIGNED>(keys, n, heads, s);
+    case GX_INT16: return heads_launch<uint16_t, K_SIGNED>(keys, n, heads, s);
+    case GX_UINT16: return heads_launch<uint16_t, K_UNSIGNED>(keys, n, heads, s);
+    case GX_INT32: return heads_launch<uint32_t, K_SIGNED>(keys, n, heads, s);
+    case GX_UINT32: return heads_launch<uint32_t, K_UNSIGNED>(keys, n, heads, s);
+    case GX_FLOAT32: return heads_launch<uint32_t, K_FLOAT>(keys, n, heads, s);
+    case GX_INT64: return heads_launch<uint64_t, K_SIGNED>(keys, n, heads, s);
+    case GX_UINT64: return heads_launch<uint64_t, K_UNSIGNED>(keys, n, heads, s);
+    case GX_FLOAT64: return heads_launch<uint64_t, K_FLOAT>(keys, n, heads, s);
+    default: return GX_EDTYPE;
+  }
+}
+
+// ---------------------------------------------------------------- identities
+template <typename T>
+struct Limits;
+#define GX_LIMITS(T, LO, HI)                                   \
+  template <>                                                  \
+  struct Limits<T> {                                           \
+    static constexpr T lowest() { return LO; }                 \
+    static constexpr T highest() { return HI; }                \
+  };
+GX_LIMITS(int64_t, INT64_MIN, INT64_MAX)
+GX_LIMITS(uint64_t, 0ull, UINT64_MAX)
+GX_LIMITS(double, -__builtin_huge_val(), __builtin_huge_val())
+#undef GX_LIMITS
+
+// result conversion: partials[nc] (AccT) -> *out in out_dtype
+__global__ void k_set_i64(int64_t* p, int64_t v) { *p = v; }
+
+template <typename AccT>
+__device__ __forceinline__ void store_as(AccT r, int out_dtype, void* out)
+{
+  switch (out_dtype) {
+    case GX_INT8: *static_cast<int8_t*>(out) = static_cast<int8_t>(r); break;
+    case GX_BOOL8:
+    case GX_UINT8: *static_cast<uint8_t*>(out) = static_cast<uint8_t>(r); break;
+    case GX_INT16: *static_cast<int16_t*>(out) = static_cast<int16_t>(r); break;
+    case GX_UINT16: *static_cast<uint16_t*>(out) = static_cast<uint16_t>(r); break;
+    case GX_INT32: *static_cast<int32_t*>(out) = static_cast<int32_t>(r); break;
+    case GX_UINT32: *static_cast<uint32_t*>(out) = static_cast<uint32_t>(r); break;
+    case GX_INT64: *static_cast<int64_t*>(out) = static_cast<int64_t>(r); break;
+    case GX_UINT64: *static_cast<uint64_t*>(out) = static_cast<uint64_t>(r); break;
+    case GX_FLOAT32: *static_cast<float*>(out) = static_cast<float>(r); break;
+    case GX_FLOAT64: *static_cast<double*>(out) = static_cast<double>(r); break;
+    default: break;
+  }
+}
+template <typename AccT>
+__global__ void k_store_result(const AccT* res, int out_dtype, void* out)
+{
+  store_as<AccT>(*res, out_dtype, out);
+}
+template <>
+__global__ void k_store_result<DD>(const DD* res, int out_dtype, void* out)
+{
+  store_as<double>(res->hi + res->lo, out_dtype, out);
+}
+
+template <typename InT, typename AccT, typename Op>
+int reduce_typed(const void* in, const uint32_t* valid, int64_t n, AccT identity, Op op, int out_dtype, void* out,
+                 void* tmp, size_t* tmp_bytes, hipStream_t s)
+{
+  Carver c(tmp);
+  AccT* partials = c.take<AccT>(scan::partials_count(n));
+  if (!tmp) {
+    *tmp_bytes = c.total();
+    return 0;
+  }
+  if (*tmp_bytes < c.total()) return GX_ETMP;
+  scan::PlainLoader<InT, AccT> ld{static_cast<const InT*>(in), valid, identity};
+  int rc = scan::device_reduce<AccT>(ld, n, identity, op, partials, s);
+  if (rc) return rc;
+  hipLaunchKernelGGL((k_store_result<AccT>), dim3(1), dim3(1), 0, s, partials + scan::num_chunks(n), out_dtype, out);
+  GX_LAUNCH_CHECK();
+  return 0;
+}
+
+template <typename InT>
+int reduce_dd(const void* in, const uint32_t* valid, int64_t n, int out_dtype, void* out, void* tmp,
+              size_t* tmp_bytes, hipStream_t s)
+{
+  Carver c(tmp);
+  DD* partials = c.take<DD>(scan::partials_count(n));
+  if (!tmp) {
+    *tmp_bytes = c.total();
+    return 0;
+  }
+  if (*tmp_bytes < c.total()) return GX_ETMP;
+  DDLoader<InT> ld{static_cast<const InT*>(in), valid};
+  int rc = scan::device_reduce<DD>(ld, n, DD{0.0, 0.0}, DDSum(), partials, s);
+  if (rc) return rc;
+  hipLaunchKernelGGL((k_store_result<DD>), dim3(1), dim3(1), 0, s, partials + scan::num_chunks(n), out_dtype, out);
+  GX_LAUNCH_CHECK();
+  return 0;
+}
+
+// integers: SUM/PRODUCT in uint64 (wrap == two's complement), MIN/MAX in int64 or uint64
+template <typename InT, bool SIGNED>
+int reduce_int(const void* in, const uint32_t* valid, int64_t n, int op, int out_dtype, void* out, void* tmp,
+               size_t* tmp_bytes, hipStream_t s)
+{
+  using W = typename std::conditional<SIGNED, int64_t, uint64_t>::type;
+  switch (op) {
+    case GX_OP_SUM: return reduce_typed<InT, uint64_t>(in, valid, n, uint64_t(0), SumOp(), out_dtype, out, tmp, tmp_bytes, s);
+    case GX_OP_PRODUCT: return reduce_typed<InT, uint64_t>(in, valid, n, uint64_t(1), ProdOp(), out_dtype, out, tmp, tmp_bytes, s);
+    case GX_OP_MIN: return reduce_typed<InT, W>(in, valid, n, Limits<W>::highest(), MinOp(), out_dtype, out, tmp, tmp_bytes, s);
+    case GX_OP_MAX: return reduce_typed<InT, W>(in, valid, n, Limits<W>::lowest(), MaxOp(), out_dtype, out, tmp, tmp_bytes, s);
+    default: return GX_EINVAL;
+  }
+}
+template <typename InT>
+int reduce_float(const void* in, const uint32_t* valid, int64_t n, int op, int out_dtype, void* out, void* tmp,
+                 size_t* tmp_bytes, hipStream_t s)
+{
+  switch (op) {
+    case GX_OP_SUM: return reduce_dd<InT>(in, valid, n, out_dtype, out, tmp, tmp_bytes, s);
+    case GX_OP_PRODUCT: return reduce_typed<InT, double>(in, valid, n, 1.0, ProdOp(), out_dtype, out, tmp, tmp_bytes, s);
+    case GX_OP_MIN: return reduce_typed<InT, double>(in, valid, n, Limits<double>::highest(), MinOp(), out_dtype, out, tmp, tmp_bytes, s);
+    case GX_OP_MAX: return reduce_typed<InT, double>(in, valid, n, Limits<double>::lowest(), MaxOp(), out_dtype, out, tmp, tmp_bytes, s);
+    default: return GX_EINVAL;
+  }
+}
+
+// ---------------------------------------------------------------- column scan
+template <typename InT, typename AccT, typename Op>
+int scan_typed(const void* in, const uint32_t* valid, int64_t n, AccT identity, Op op, int inclusive, void* out,
+               void* tmp, size_t* tmp_bytes, hipStream_t s)
+{
+  Carver c(tmp);
+  AccT* partials = c.take<AccT>(scan::partials_count(n));
+  if (!tmp) {
+    *tmp_bytes = c.total();
+    return 0;
+  }
+  if (*tmp_bytes < c.total()) return GX_ETMP;
+  scan::PlainLoader<InT, AccT> ld{static_cast<const InT*>(in), valid, identity};
+  return scan::device_scan<AccT, InT>(ld, n, identity, op, inclusive != 0, static_cast<InT*>(out), partials, s);
+}
+template <typename InT>
+int scan_dd(const void* in, const uint32_t* valid, int64_t n, int inclusive, void* out, void* tmp, size_t* tmp_bytes,
+            hipStream_t s)
+{
+  Carver c(tmp);
+  DD* partials = c.take<DD>(scan::partials_count(n));
+  if (!tmp) {
+    *tmp_bytes = c.total();
+    return 0;
+  }
+  if (*tmp_bytes < c.total()) return GX_ETMP;
+  DDLoader<InT> ld{static_cast<const InT*>(in), valid};
+  return scan::device_scan<DD, InT>(ld, n, DD{0.0, 0.0}, DDSum(), inclusive != 0, static_cast<InT*>(out), partials, s);
+}
+template <typename InT, bool SIGNED>
+int scan_int(const void* in, const uint32_t* valid, int64_t n, int op, int inclusive, void* out, void* tmp,
+             size_t* tmp_bytes, hipStream_t s)
+{
+  using W = typename std::conditional<SIGNED, int64_t, uint64_t>::type;
+  switch (op) {
+    case GX_OP_SUM: return scan_typed<InT, uint64_t>(in, valid, n, uint64_t(0), SumOp(), inclusive, out, tmp, tmp_bytes, s);
+    case GX_OP_PRODUCT: return scan_typed<InT, uint64_t>(in, valid, n, uint64_t(1), ProdOp(), inclusive, out, tmp, tmp_bytes, s);
+    case GX_OP_MIN: return scan_typed<InT, W>(in, valid, n, (W)std::numeric_limits<InT>::max(), MinOp(), inclusive, out, tmp, tmp_bytes, s);
+    case GX_OP_MAX: return scan_typed<InT, W>(in, valid, n, (W)std::numeric_limits<InT>::lowest(), MaxOp(), inclusive, out, tmp, tmp_bytes, s);
+    default: return GX_EINVAL;
+  }
+}
+template <typename InT>
+int scan_float(const void* in, const uint32_t* valid, int64_t n, int op, int inclusive, void* out, void* tmp,
+               size_t* tmp_bytes, hipStream_t s)
+{
+  switch (op) {
+    case GX_OP_SUM: return scan_dd<InT>(in, valid, n, inclusive, out, tmp, tmp_bytes, s);
+    case GX_OP_PRODUCT: return scan_typed<InT, double>(in, valid, n, 1.0, ProdOp(), inclusive, out, tmp, tmp_bytes, s);
+    case GX_OP_MIN: return scan_typed<InT, double>(in, valid, n, Limits<double>::highest(), MinOp(), inclusive, out, tmp, tmp_bytes, s);
+    case GX_OP_MAX: return scan_typed<InT, double>(in, valid, n, Limits<double>::lowest(), MaxOp(), inclusive, out, tmp, tmp_bytes, s);
+    default: return GX_EINVAL;
+  }
+}
+
+// ---------------------------------------------------------------- segmented scan
+template <typename InT, typename AccT, typename OutT, typename Op>
+int seg_typed(const void* vals, const uint32_t* valid, const uint8_t* heads, int64_t n, AccT identity, Op op,
+              void* out, Seg<AccT>* partials, hipStream_t s)
+{
+  SegLoader<InT, AccT> ld{static_cast<const InT*>(vals), valid, heads, identity};
+  return scan::device_scan<Seg<AccT>, OutT>(ld, n, Seg<AccT>{identity, 0u, 0u}, SegOp<AccT, Op>{op}, true,
+                                            static_cast<OutT*>(out), partials, s);
+}
+
+// integer SUM accumulates and returns int64 (cpp/src/groupby/sort/group_scan_util.cuh:85-95);
+// MIN/MAX return the input type
+template <typename InT, bool SIGNED>
+int seg_int(const void* vals, const uint32_t* valid, const uint8_t* heads, int64_t n, int op, void* out,
+            void* partials, hipStream_t s)
+{
+  using W = typename std::conditional<SIGNED, int64_t, uint64_t>::type;
+  switch (op) {
+    case GX_OP_SUM: return seg_typed<InT, int64_t, int64_t>(vals, valid, heads, n, int64_t(0), SumOp(), out, static_cast<Seg<int64_t>*>(partials), s);
+    case GX_OP_MIN: return seg_typed<InT, W, InT>(vals, valid, heads, n, (W)std::numeric_limits<InT>::max(), MinOp(), out, static_cast<Seg<W>*>(partials), s);
+    case GX_OP_MAX: return seg_typed<InT, W, InT>(vals, valid, heads, n, (W)std::numeric_limits<InT>::lowest(), MaxOp(), out, static_cast<Seg<W>*>(partials), s);
+    default: return GX_EINVAL;
+  }
+}
+template <typename InT>
+int seg_float(const void* vals, const uint32_t* valid, const uint8_t* heads, int64_t n, int op, void* out,
+              void* partials, hipStream_t s)
+{
+  switch (op) {
+    case GX_OP_SUM: return seg_typed<InT, double, InT>(vals, valid, heads, n, 0.0, SumOp(), out, static_cast<Seg<double>*>(partials), s);
+    case GX_OP_MIN: return seg_typed<InT, double, InT>(vals, valid, heads, n, Limits<double>::highest(), MinOp(), out, static_cast<Seg<double>*>(partials), s);
+    case GX_OP_MAX: return seg_typed<InT, double, InT>(vals, valid, heads, n, Limits<double>::lowest(), MaxOp(), out, static_cast<Seg<double>*>(partials), s);
+    default: return GX_EINVAL;
+  }
+}
+
+}  // namespace rs
+}  // namespace gx
+
+extern "C" {
+
+int gx_reduce(int in_dtype, const void* in, const uint32_t* valid, int64_t n, int op, int out_dtype, void* out_dev,
+              int64_t* valid_count_dev, void* tmp, size_t* tmp_bytes, gx_stream_t s)
+{
+  using namespace gx::rs;
+  if (n < 0 || !tmp_bytes) return GX_EINVAL;
+  if (tmp && (!out_dev || (n > 0 && !in))) return GX_EINVAL;
+  if (tmp && valid_count_dev) {
+    if (valid) {
+      int rc = gx_bitmask_count(valid, 0, n, valid_count_dev, s);
+      if (rc) return rc;
+    } else {
+      hipLaunchKernelGGL(gx::rs::k_set_i64, dim3(1), dim3(1), 0, s, valid_count_dev, n);
+    }
+  }
+  switch (in_dtype) {
+    case GX_INT8: return reduce_int<int8_t, true>(in, valid, n, op, out_dtype, out_dev, tmp, tmp_bytes, s);
+    case GX_INT16: return reduce_int<int16_t, true>(in, valid, n, op, out_dtype, out_dev, tmp, tmp_bytes, s);
+    case GX_INT32: return reduce_int<int32_t, true>(in, valid, n, op, out_dtype, out_dev, tmp, tmp_bytes, s);
+    case GX_INT64: return reduce_int<int64_t, true>(in, valid, n, op, out_dtype, out_dev, tmp, tmp_bytes, s);
+    case GX_BOOL8:
+    case GX_UINT8: return reduce_int<uint8_t, false>(in, valid, n, op, out_dtype, out_dev, tmp, tmp_bytes, s);
+    case GX_UINT16: return reduce_int<uint16_t, false>(in, valid, n, op, out_dtype, out_dev, tmp, tmp_bytes, s);
+    case GX_UINT32: return reduce_int<uint32_t, false>(in, valid, n, op, out_dtype, out_dev, tmp, tmp_bytes, s);
+    case GX_UINT64: return reduce_int<uint64_t, false>(in, valid, n, op, out_dtype, out_dev, tmp, tmp_bytes, s);
+    case GX_FLOAT32: return reduce_float<float>(in, valid, n, op, out_dtype, out_dev, tmp, tmp_bytes, s);
+    case GX_FLOAT64: return reduce_float<double>(in, valid, n, op, out_dtype, out_dev, tmp, tmp_bytes, s);
+    default: return GX_EDTYPE;
+  }
+}
+
+int gx_scan(int dtype, const void* in, const uint32_t* valid, int64_t n, int op, int inclusive, void* out, void* tmp,
+            size_t* tmp_bytes, gx_stream_t s)
+{
+  using namespace gx::rs;
+  if (n < 0 || !tmp_bytes) return GX_EINVAL;
+  if (tmp && n > 0 && (!in || !out)) return GX_EINVAL;
+  switch (dtype) {
+    case GX_INT8: return scan_int<int8_t, true>(in, valid, n, op, inclusive, out, tmp, tmp_bytes, s);
+    case GX_INT16: return scan_int<int16_t, true>(in, valid, n, op, inclusive, out, tmp, tmp_bytes, s);
+    case GX_INT32: return scan_int<int32_t, true>(in, valid, n, op, inclusive, out, tmp, tmp_bytes, s);
+    case GX_INT64: return scan_int<int64_t, true>(in, valid, n, op, inclusive, out, tmp, tmp_bytes, s);
+    case GX_BOOL8:
+    case GX_UINT8: return scan_int<uint8_t, false>(in, valid, n, op, inclusive, out, tmp, tmp_bytes, s);
+    case GX_UINT16: return scan_int<uint16_t, false>(in, valid, n, op, inclusive, out, tmp, tmp_bytes, s);
+    case GX_UINT32: return scan_int<uint32_t, false>(in, valid, n, op, inclusive, out, tmp, tmp_bytes, s);
+    case GX_UINT64: return scan_int<uint64_t, false>(in, valid, n, op, inclusive, out, tmp, tmp_bytes, s);
+    case GX_FLOAT32: return scan_float<float>(in, valid, n, op, inclusive, out, tmp, tmp_bytes, s);
+    case GX_FLOAT64: return scan_float<double>(in, valid, n, op, inclusive, out, tmp, tmp_bytes, s);
+    default: return GX_EDTYPE;
+  }
+}
+
+int gx_segmented_scan(int key_dtype, const void* sorted_keys, int val_dtype, const void* vals,
+                      const uint32_t* vals_valid, int64_t n, int op, void* out, void* tmp, size_t* tmp_bytes,
+                      gx_stream_t s)
+{
+  using namespace gx::rs;
+  if (n < 0 || !tmp_bytes) return GX_EINVAL;
+  gx::Carver c(tmp);
+  uint8_t* heads = c.take<uint8_t>((size_t)n);
+  char* partials = c.take<char>(gx::scan::partials_count(n) * sizeof(Seg<double>));
+  if (!tmp) {
+    *tmp_bytes = c.total();
+    return 0;
+  }
+  if (*tmp_bytes < c.total()) return GX_ETMP;
+  if (n == 0) return 0;
+  if (!sorted_keys || !vals || !out) return GX_EINVAL;
+  int rc = heads_dispatch(key_dtype, sorted_keys, n, heads, s);
+  if (rc) return rc;
+  switch (val_dtype) {
+    case GX_INT8: return seg_int<int8_t, true>(vals, vals_valid, heads, n, op, out, partials, s);
+    case GX_INT16: return seg_int<int16_t, true>(vals, vals_valid, heads, n, op, out, partials, s);
+    case GX_INT32: return seg_int<int32_t, true>(vals, vals_valid, heads, n, op, out, partials, s);
+    case GX_INT64: return seg_int<int64_t, true>(vals, vals_valid, heads, n, op, out, partials, s);
+    case GX_BOOL8:
+    case GX_UINT8: return seg_int<uint8_t, false>(vals, vals_valid, heads, n, op, out, partials, s);
+    case GX_UINT16: return seg_int<uint16_t, false>(vals, vals_valid, heads, n, op, out, partials, s);
+    case GX_UINT32: return seg_int<uint32_t, false>(vals, vals_valid, heads, n, op, out, partials, s);
+    case GX_UINT64: return seg_int<uint64_t, false>(vals, vals_valid, heads, n, op, out, partials, s);
+    case GX_FLOAT32: return seg_float<float>(vals, vals_valid, heads, n, op, out, partials, s);
+    case GX_FLOAT64: return seg_float<double>(vals, vals_valid, heads, n, op, out, partials, s);
+    default: return GX_EDTYPE;
+  }
+}
+
+}  // extern "C"

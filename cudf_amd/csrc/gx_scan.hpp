@@ -1,0 +1,147 @@
+// gx_scan.hpp -- device-wide scan / reduce building blocks (reduce-then-scan, three launches).
+//
+// Fixed association order (item order inside a thread, lane order, wave order, chunk order), so
+// floating-point results are bit-reproducible run to run -- the reason the f64 paths use this
+// form rather than a decoupled look-back chain, whose association depends on timing.
+// Traffic: reduce pass reads N, apply pass reads N and writes N  (3 x sizeof(T) per element).
+#pragma once
+
+#include "gx_common.hpp"
+
+namespace gx {
+namespace scan {
+
+constexpr int SCAN_BT  = 256;
+constexpr int SCAN_IPT = 16;
+constexpr int SCAN_CHUNK = SCAN_BT * SCAN_IPT;
+
+// Loader: element i -> value of the scan's accumulator type (handles nulls / casts).
+template <typename InT, typename AccT>
+struct PlainLoader {
+  const InT* in;
+  const uint32_t* valid;
+  AccT identity;
+  __device__ __forceinline__ AccT operator()(int64_t i) const
+  {
+    if (valid && !bit_is_set(valid, i)) return identity;
+    return static_cast<AccT>(in[i]);
+  }
+};
+
+// chunk-striped access: thread t owns items [t*IPT, (t+1)*IPT) of its chunk, so the sequential
+// order inside a thread is the element order (needed for a deterministic, ordered scan).
+template <typename AccT, typename Op, typename Loader>
+__global__ void __launch_bounds__(SCAN_BT) k_chunk_reduce(Loader load, int64_t n, AccT identity, Op op,
+                                                          AccT* partials, const int* skip)
+{
+  if (skip && *skip) return;
+  __shared__ AccT s_tmp[SCAN_BT / GX_WAVE + 1];
+  const int64_t chunk = blockIdx.x;
+  const int64_t base  = chunk * SCAN_CHUNK + (int64_t)threadIdx.x * SCAN_IPT;
+  AccT acc            = identity;
+#pragma unroll
+  for (int k = 0; k < SCAN_IPT; ++k) {
+    const int64_t i = base + k;
+    if (i < n) acc = op(acc, load(i));
+  }
+  AccT total;
+  block_exclusive_scan<SCAN_BT>(acc, identity, op, s_tmp, &total);
+  if (threadIdx.x == 0) partials[chunk] = total;
+}
+
+// single block: exclusive scan of the chunk partials in place; partials[np] = grand total
+template <typename AccT, typename Op>
+__global__ void __launch_bounds__(1024) k_partials_scan(AccT* partials, int64_t np, AccT identity, Op op,
+                                                        const int* skip)
+{
+  if (skip && *skip) return;
+  __shared__ AccT s_tmp[1024 / GX_WAVE + 1];
+  __shared__ AccT s_carry;
+  if (threadIdx.x == 0) s_carry = identity;
+  __syncthreads();
+  for (int64_t base = 0; base < np; base += 1024) {
+    const int64_t i = base + threadIdx.x;
+    AccT v          = (i < np) ? partials[i] : identity;
+    AccT total;
+    AccT exc   = block_exclusive_scan<1024>(v, identity, op, s_tmp, &total);
+    AccT carry = s_carry;
+    if (i < np) partials[i] = op(carry, exc);
+    __syncthreads();
+    if (threadIdx.x == 0) s_carry = op(carry, total);
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) partials[np] = s_carry;
+}
+
+template <typename AccT, typename OutT, typename Op, typename Loader, bool INCLUSIVE>
+__global__ void __launch_bounds__(SCAN_BT) k_chunk_scan(Loader load, int64_t n, AccT identity, Op op,
+                                                        const AccT* partials, OutT* out, const int* skip)
+{
+  if (skip && *skip) return;
+  __shared__ AccT s_tmp[SCAN_BT / GX_WAVE + 1];
+  const int64_t chunk = blockIdx.x;
+  const int64_t base  = chunk * SCAN_CHUNK + (int64_t)threadIdx.x * SCAN_IPT;
+  AccT v[SCAN_IPT];
+  AccT acc = identity;
+#pragma unroll
+  for (int k = 0; k < SCAN_IPT; ++k) {
+    const int64_t i = base + k;
+    v[k]            = (i < n) ? load(i) : identity;
+    acc             = op(acc, v[k]);
+  }
+  AccT exc     = block_exclusive_scan<SCAN_BT>(acc, identity, op, s_tmp, (AccT*)nullptr);
+  AccT running = op(partials[chunk], exc);
+#pragma unroll
+  for (int k = 0; k < SCAN_IPT; ++k) {
+    const int64_t i = base + k;
+    if (INCLUSIVE) {
+      running = op(running, v[k]);
+      if (i < n) out[i] = static_cast<OutT>(running);
+    } else {
+      if (i < n) out[i] = static_cast<OutT>(running);
+      running = op(running, v[k]);
+    }
+  }
+}
+
+static inline int64_t num_chunks(int64_t n) { return n > 0 ? div_up(n, SCAN_CHUNK) : 0; }
+// scratch elements of AccT needed for a scan over n elements
+static inline size_t partials_count(int64_t n) { return (size_t)num_chunks(n) + 1; }
+
+// out may alias the loader's input (each chunk is fully loaded before it is written).
+template <typename AccT, typename OutT, typename Op, typename Loader>
+int device_scan(Loader load, int64_t n, AccT identity, Op op, bool inclusive, OutT* out, AccT* partials,
+                hipStream_t stream, const int* skip = nullptr)
+{
+  if (n <= 0) return 0;
+  const int64_t nc = num_chunks(n);
+  hipLaunchKernelGGL((k_chunk_reduce<AccT, Op, Loader>), dim3((unsigned)nc), dim3(SCAN_BT), 0, stream, load, n,
+                     identity, op, partials, skip);
+  hipLaunchKernelGGL((k_partials_scan<AccT, Op>), dim3(1), dim3(1024), 0, stream, partials, nc, identity, op,
+                     skip);
+  if (inclusive)
+    hipLaunchKernelGGL((k_chunk_scan<AccT, OutT, Op, Loader, true>), dim3((unsigned)nc), dim3(SCAN_BT), 0,
+                       stream, load, n, identity, op, partials, out, skip);
+  else
+    hipLaunchKernelGGL((k_chunk_scan<AccT, OutT, Op, Loader, false>), dim3((unsigned)nc), dim3(SCAN_BT), 0,
+                       stream, load, n, identity, op, partials, out, skip);
+  GX_LAUNCH_CHECK();
+  return 0;
+}
+
+// device-wide reduce: partials[nc] receives the result (as AccT)
+template <typename AccT, typename Op, typename Loader>
+int device_reduce(Loader load, int64_t n, AccT identity, Op op, AccT* partials, hipStream_t stream)
+{
+  const int64_t nc = num_chunks(n);
+  if (nc > 0)
+    hipLaunchKernelGGL((k_chunk_reduce<AccT, Op, Loader>), dim3((unsigned)nc), dim3(SCAN_BT), 0, stream, load,
+                       n, identity, op, partials, (const int*)nullptr);
+  hipLaunchKernelGGL((k_partials_scan<AccT, Op>), dim3(1), dim3(1024), 0, stream, partials, nc, identity, op,
+                     (const int*)nullptr);
+  GX_LAUNCH_CHECK();
+  return 0;
+}
+
+}  // namespace scan
+}  // namespace gx

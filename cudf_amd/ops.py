@@ -1,0 +1,349 @@
+"""Host-side mirror of the libcudf operator interface for the hot path, over the C ABI.
+
+Function names / argument meaning / error behaviour follow pylibcudf's thin wrappers
+(python/pylibcudf/pylibcudf/{sorting.pyx:37-613, join.pyx:63-108, groupby.pyx:89,
+reduce.pyx:48-157, copying.pyx gather}) which bind the C++ API named in SURVEY.md section 8b.
+Every function here only validates, allocates (torch as the device allocator) and calls
+``libcudf_amd.so``; there is no CPU implementation to fall back to.
+"""
+from __future__ import annotations
+
+import ctypes
+from typing import List, Optional, Sequence, Tuple
+
+import numpy as np
+import torch
+
+from . import _lib as L
+from .column import Column, device_bytes, gx_dtype, ptr, stream_ptr, bitmask_words
+
+JOIN_NO_MATCH = -(2**31)  # cudf::JoinNoMatch
+
+_lib = L.lib
+
+
+def _query(fn, *args):
+    """Run the tmp==NULL size query of a gx_* entry point; returns required bytes."""
+    nbytes = ctypes.c_size_t(0)
+    L.check(fn(*args, None, ctypes.byref(nbytes), stream_ptr()), fn.__name__ + " (size query)")
+    return nbytes.value
+
+
+def _run(fn, *args):
+    nbytes = _query(fn, *args)
+    tmp = device_bytes(nbytes)
+    nb = ctypes.c_size_t(nbytes)
+    L.check(fn(*args, ptr(tmp), ctypes.byref(nb), stream_ptr()), fn.__name__)
+    return tmp
+
+
+def _check_sort_status(tmp: torch.Tensor):
+    """Fail loudly if the device-side look-back protocol reported a timeout (never expected)."""
+    st = ctypes.c_int(0)
+    L.check(_lib.gx_sort_status(ptr(tmp), ctypes.byref(st), stream_ptr()), "gx_sort_status")
+    if st.value != 0:
+        raise L.GxError(f"radix sort look-back timed out (status {st.value})")
+
+
+def _dev_i64(value: int = 0) -> torch.Tensor:
+    return torch.full((1,), value, dtype=torch.int64, device="cuda")
+
+
+# ------------------------------------------------------------------------------------------------
+# sorting  (cudf::sort / sorted_order / stable_sorted_order / sort_by_key: sorting.hpp:44-163)
+# ------------------------------------------------------------------------------------------------
+
+def sort(col: Column, ascending: bool = True, null_before: bool = True) -> Column:
+    """cudf::sort of a one-column table (src/sort/sort.cu:52-67).  No nulls: keys-only radix sort;
+    with nulls: sort_by_key(input, input) like the reference's general path (:31-50)."""
+    if col.has_nulls():
+        order = sorted_order(col, ascending, null_before)
+        return gather(col, order)
+    out = Column.empty(col.dtype, col.size)
+    tmp = _run(_lib.gx_sort_keys, col.gx, col.data_ptr, out.data_ptr, col.size, int(not ascending))
+    _check_sort_status(tmp)
+    return out
+
+
+def sorted_order(col: Column, ascending: bool = True, null_before: bool = True) -> Column:
+    """cudf::sorted_order == stable_sorted_order for one column (always stable here)."""
+    out = Column.empty(np.int32, col.size)
+    valid = col.mask_ptr if col.has_nulls() else None
+    tmp = _run(_lib.gx_sorted_order, col.gx, col.data_ptr, valid, col.size, col.null_count if valid else 0,
+               int(not ascending), int(null_before), out.data_ptr)
+    if not valid:
+        _check_sort_status(tmp)  # plan header sits at the start of the scratch on the radix path
+    return out
+
+
+stable_sorted_order = sorted_order
+
+
+def sort_by_key(values: Sequence[Column], keys: Column, ascending: bool = True,
+                null_before: bool = True) -> List[Column]:
+    """cudf::sort_by_key: gather(values, sorted_order(keys)) (src/sort/sort.cu:31-50)."""
+    for v in values:
+        if v.size != keys.size:
+            raise RuntimeError("Mismatch in number of rows for values and keys")  # sort.cu:39
+    order = sorted_order(keys, ascending, null_before)
+    return [gather(v, order) for v in values]
+
+
+def gather(col: Column, gather_map: Column, nullify_out_of_bounds: bool = False) -> Column:
+    """cudf::gather for a fixed-width column (copying.hpp; detail/gather.cuh:108-131,506-577)."""
+    if gather_map.dtype != np.int32:
+        raise TypeError("gather map must be INT32")
+    n = gather_map.size
+    need_mask = col.mask is not None or nullify_out_of_bounds
+    out = Column.empty(col.dtype, n, nullable=need_mask)
+    L.check(_lib.gx_gather(col.dtype.itemsize, col.data_ptr, col.mask_ptr, col.size, gather_map.data_ptr, n,
+                           int(nullify_out_of_bounds), out.data_ptr, out.mask_ptr, stream_ptr()), "gx_gather")
+    if need_mask:
+        out.null_count = n - bitmask_count(out.mask, n)
+    return out
+
+
+def bitmask_count(mask: torch.Tensor, nbits: int) -> int:
+    cnt = _dev_i64()
+    L.check(_lib.gx_bitmask_count(ptr(mask), 0, nbits, ptr(cnt), stream_ptr()), "gx_bitmask_count")
+    return int(cnt.item())
+
+
+# ------------------------------------------------------------------------------------------------
+# hashing / partitioning
+# ------------------------------------------------------------------------------------------------
+
+def murmurhash3_x86_32(cols: Sequence[Column], seed: int = 0) -> Column:
+    """cudf::hashing::murmurhash3_x86_32 row hash of fixed-width columns."""
+    n = cols[0].size
+    out = Column.empty(np.uint32, n)
+    for k, c in enumerate(cols):
+        L.check(_lib.gx_murmur3_32(c.gx, c.data_ptr, c.mask_ptr if c.has_nulls() else None, n, seed, int(k > 0),
+                                   out.data_ptr, stream_ptr()), "gx_murmur3_32")
+    return out
+
+
+def hash_partition_map(key_cols: Sequence[Column], num_partitions: int, seed: int = 0) -> Tuple[Column, np.ndarray]:
+    """cudf::hash_partition in index form: (gather map, offsets[num_partitions+1])."""
+    h = murmurhash3_x86_32(key_cols, seed)
+    n = h.size
+    out_map = Column.empty(np.int32, n)
+    offs = torch.empty(num_partitions + 1, dtype=torch.int32, device="cuda")
+    _run(_lib.gx_hash_partition_map, h.data_ptr, n, num_partitions, out_map.data_ptr, ptr(offs))
+    return out_map, offs.cpu().numpy()
+
+
+# ------------------------------------------------------------------------------------------------
+# hash join  (cudf::hash_join / cudf::inner_join: join/hash_join.hpp:70-444, join/join.hpp:160-166)
+# ------------------------------------------------------------------------------------------------
+
+def _join_key(col: Column) -> Column:
+    if col.dtype.itemsize not in (4, 8):
+        raise TypeError("join key must be a 4- or 8-byte fixed-width column")  # data_type_error
+    return col
+
+
+class HashJoin:
+    """cudf::hash_join: build once on `right`, probe many (hash_join.hpp:95-125).  The object
+    views the build column: keep it alive (hash_join.hpp:83-84)."""
+
+    def __init__(self, right: Column, nulls_equal: bool = True, load_factor: float = 0.5):
+        if not (0.0 < load_factor <= 1.0):
+            raise ValueError("Invalid load factor: must be greater than 0 and less than or equal to 1.")
+        self.build = _join_key(right)
+        self.nulls_equal = nulls_equal
+        self.key_size = right.dtype.itemsize
+        self.load_factor = load_factor
+        self.table_bytes = _lib.gx_join_table_bytes(self.key_size, right.size, load_factor)
+        self.table = device_bytes(self.table_bytes)
+        valid = right.mask_ptr if right.has_nulls() else None
+        L.check(_lib.gx_join_build(self.key_size, right.data_ptr, valid, right.size, ptr(self.table),
+                                   self.table_bytes, load_factor, stream_ptr()), "gx_join_build")
+
+    def _check(self, left: Column):
+        if left.dtype != self.build.dtype:
+            raise TypeError("Mismatch in joining column data types")  # hash_join.cu:56-58
+
+    def inner_join_size(self, left: Column) -> int:
+        self._check(left)
+        if left.size == 0 or self.build.size == 0:
+            return 0
+        cnt = _dev_i64()
+        valid = left.mask_ptr if left.has_nulls() else None
+        L.check(_lib.gx_join_count(self.key_size, left.data_ptr, valid, left.size, ptr(self.table),
+                                   self.table_bytes, ptr(cnt), stream_ptr()), "gx_join_count")
+        total = int(cnt.item())
+        if self.nulls_equal:
+            total += left.null_count * self.build.null_count if left.has_nulls() and self.build.has_nulls() else 0
+        return total
+
+    def _probe(self, left: Column, capacity: int, left_outer: bool):
+        lo = Column.empty(np.int32, capacity)
+        ro = Column.empty(np.int32, capacity)
+        cur = _dev_i64()
+        valid = left.mask_ptr if left.has_nulls() else None
+        L.check(_lib.gx_join_probe(self.key_size, left.data_ptr, valid, left.size, ptr(self.table), self.table_bytes,
+                                   int(left_outer), lo.data_ptr, ro.data_ptr, capacity, ptr(cur), stream_ptr()),
+                "gx_join_probe")
+        return lo, ro, int(cur.item())
+
+    def inner_join(self, left: Column, output_size: Optional[int] = None) -> Tuple[Column, Column]:
+        """(left_indices, right_indices), order unspecified (join.hpp:131-134)."""
+        self._check(left)
+        if left.size == 0 or self.build.size == 0:  # trivial joins (hash_join.cu:32-45)
+            return Column.empty(np.int32, 0), Column.empty(np.int32, 0)
+        # optimistic single pass: with distinct build keys (the common PK-FK case) matches <= probe
+        # rows; 288 GB of HBM makes that allocation cheaper than the reference's count pass
+        capacity = output_size if output_size is not None else left.size
+        lo, ro, total = self._probe(left, capacity, False)
+        if total > capacity:  # duplicate build keys blew the guess: size is now known exactly
+            lo, ro, total = self._probe(left, total, False)
+        lo.size = ro.size = total
+        if self.nulls_equal and left.has_nulls() and self.build.has_nulls():
+            lo, ro = _append_null_cross(lo, ro, left, self.build)
+        return lo, ro
+
+    def left_join(self, left: Column) -> Tuple[Column, Column]:
+        self._check(left)
+        if left.size == 0:
+            return Column.empty(np.int32, 0), Column.empty(np.int32, 0)
+        lo, ro, total = self._probe(left, left.size, True)
+        if total > left.size:
+            lo, ro, total = self._probe(left, total, True)
+        lo.size = ro.size = total
+        return lo, ro
+
+
+def _append_null_cross(lo: Column, ro: Column, left: Column, right: Column):
+    """null_equality::EQUAL for a single nullable key: every null left row matches every null
+    right row.  Rare path, assembled with torch index ops on the device."""
+    lv = torch.from_numpy(~left.valid_numpy()).cuda().nonzero().flatten().to(torch.int32)
+    rv = torch.from_numpy(~right.valid_numpy()).cuda().nonzero().flatten().to(torch.int32)
+    # the null left rows were emitted by nobody (probe skips them): add the cross product
+    cl = lv.repeat_interleave(len(rv))
+    cr = rv.repeat(len(lv))
+    a = torch.cat([lo.data[: lo.size * 4].view(torch.int32), cl])
+    b = torch.cat([ro.data[: ro.size * 4].view(torch.int32), cr])
+    n = a.numel()
+    return (Column(a.view(torch.uint8), np.int32, n), Column(b.view(torch.uint8), np.int32, n))
+
+
+def inner_join(left: Column, right: Column, nulls_equal: bool = True) -> Tuple[Column, Column]:
+    """cudf::inner_join (src/join/join.cu:27-60): build on the smaller side, swap the pair back."""
+    if left.dtype != right.dtype:
+        raise TypeError("Mismatch in joining column data types")
+    if right.size > left.size:
+        hj = HashJoin(left, nulls_equal)
+        r, l = hj.inner_join(right)
+        return l, r
+    return HashJoin(right, nulls_equal).inner_join(left)
+
+
+def left_join(left: Column, right: Column, nulls_equal: bool = True) -> Tuple[Column, Column]:
+    if left.dtype != right.dtype:
+        raise TypeError("Mismatch in joining column data types")
+    return HashJoin(right, nulls_equal).left_join(left)
+
+
+# ------------------------------------------------------------------------------------------------
+# groupby  (cudf::groupby::groupby::aggregate / scan: groupby.hpp:89-240)
+# ------------------------------------------------------------------------------------------------
+
+def groupby_sum_count(keys: Column, values: Column, max_groups_hint: int = 1 << 20):
+    """Hash groupby with SUM + COUNT_VALID + COUNT_ALL of one values column.
+    Returns (keys, sum, count_valid, count_all) columns in unspecified group order."""
+    if keys.size != values.size:
+        raise RuntimeError("Size mismatch between request values and groupby keys.")  # groupby.cu:230
+    if keys.dtype.itemsize not in (4, 8) or keys.dtype.kind not in "iu":
+        raise TypeError("groupby key must be a 32/64-bit integer column")
+    n = keys.size
+    sum_dt = np.dtype(values.dtype if values.dtype.kind == "f" else np.int64)
+    max_groups = max(1, min(n, max_groups_hint))
+    while True:
+        ok = Column.empty(keys.dtype, max_groups)
+        osum = Column.empty(sum_dt, max_groups)
+        ocv = Column.empty(np.int32, max_groups)
+        oca = Column.empty(np.int32, max_groups)
+        ng = _dev_i64()
+        _run(_lib.gx_groupby_sum_count, keys.gx, keys.data_ptr, keys.mask_ptr if keys.has_nulls() else None,
+             values.gx, values.data_ptr, values.mask_ptr if values.has_nulls() else None, n, max_groups,
+             ok.data_ptr, osum.data_ptr, ocv.data_ptr, oca.data_ptr, ptr(ng))
+        g = int(ng.item())
+        if 0 <= g <= max_groups:
+            break
+        if max_groups >= n:
+            raise RuntimeError("groupby table overflow")
+        max_groups = min(n, max_groups * 8)
+    for c in (ok, osum, ocv, oca):
+        c.size = g
+    return ok, osum, ocv, oca
+
+
+def groupby_scan(sorted_keys: Column, values: Column, op: str = "sum") -> Column:
+    """Segmented inclusive scan over already-sorted keys (groupby::scan's value pass)."""
+    opc = {"sum": L.OP_SUM, "min": L.OP_MIN, "max": L.OP_MAX}[op]
+    out_dt = (np.int64 if values.dtype.kind in "iub" else values.dtype) if op == "sum" else values.dtype
+    out = Column.empty(out_dt, values.size)
+    _run(_lib.gx_segmented_scan, sorted_keys.gx, sorted_keys.data_ptr, values.gx, values.data_ptr,
+         values.mask_ptr if values.has_nulls() else None, values.size, opc, out.data_ptr)
+    return out
+
+
+# ------------------------------------------------------------------------------------------------
+# reduce / scan  (cudf::reduce / cudf::scan: reduction.hpp:60-65,229-235)
+# ------------------------------------------------------------------------------------------------
+_OPS = {"sum": L.OP_SUM, "product": L.OP_PRODUCT, "min": L.OP_MIN, "max": L.OP_MAX}
+
+
+def reduce(col: Column, op: str, out_dtype=None):
+    """cudf::reduce -> (python scalar, is_valid).  Invalid iff no valid element
+    (reductions.cpp; simple.cuh:47-85)."""
+    if out_dtype is None:
+        if op in ("sum", "product"):
+            out_dtype = np.float64 if col.dtype.kind == "f" else (np.uint64 if col.dtype.kind == "u" else np.int64)
+        else:
+            out_dtype = col.dtype
+    out_dtype = np.dtype(out_dtype)
+    out = Column.empty(out_dtype, 1)
+    cnt = _dev_i64()
+    _run(_lib.gx_reduce, col.gx, col.data_ptr, col.mask_ptr if col.has_nulls() else None, col.size, _OPS[op],
+         gx_dtype(out_dtype), out.data_ptr, ptr(cnt))
+    valid = int(cnt.item()) > 0
+    return out.to_numpy()[0], valid
+
+
+def scan(col: Column, op: str = "sum", inclusive: bool = True, null_include: bool = False) -> Column:
+    """cudf::scan; output dtype == input dtype; mask handling of scan_inclusive.cu:198-216."""
+    out = Column.empty(col.dtype, col.size)
+    valid = col.mask_ptr if col.has_nulls() else None
+    _run(_lib.gx_scan, col.gx, col.data_ptr, valid, col.size, _OPS[op], int(inclusive), out.data_ptr)
+    if col.has_nulls():
+        if null_include:  # everything from the first null on is null (mask_scan :36-61)
+            pos = _dev_i64()
+            L.check(_lib.gx_bitmask_first_unset(col.mask_ptr, col.size, ptr(pos), stream_ptr()), "first_unset")
+            first = min(col.size, int(pos.item()) + (0 if inclusive else 1))
+            out.mask = torch.zeros(bitmask_words(col.size), dtype=torch.int32, device="cuda")
+            L.check(_lib.gx_bitmask_set(ptr(out.mask), 0, first, 1, stream_ptr()), "bitmask_set")
+            out.null_count = col.size - first
+        else:
+            out.mask = col.mask.clone()
+            out.null_count = col.null_count
+    return out
+
+
+# ------------------------------------------------------------------------------------------------
+# synthetic data / checks (bench + tests)
+# ------------------------------------------------------------------------------------------------
+
+def random_column(dtype, n: int, seed: int, lo: int = 0, hi: int = 0) -> Column:
+    out = Column.empty(dtype, n)
+    L.check(_lib.gx_fill_random(out.gx, out.data_ptr, n, seed, lo, hi, stream_ptr()), "gx_fill_random")
+    return out
+
+
+def checksum(col: Column, descending: bool = False):
+    """(sum, xor, sortedness violations) computed on the device."""
+    res = torch.zeros(3, dtype=torch.int64, device="cuda")
+    L.check(_lib.gx_checksum(col.gx, col.data_ptr, col.size, int(descending), ptr(res), stream_ptr()), "gx_checksum")
+    r = res.cpu().numpy().view(np.uint64)
+    return int(r[0]), int(r[1]), int(r[2])

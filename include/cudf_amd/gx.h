@@ -1,0 +1,254 @@
+/*
+ * gx.h -- the C ABI of libcudf_amd (MI355X / gfx950 kernel layer).
+ *
+ * This is the drop-in boundary for the cudf hot path: plain pointers and sizes, no C++ types,
+ * no torch types.  Everything above it (include/cudf/ C++ API mirror, the Python ctypes
+ * wrapper) only allocates, validates and throws; everything below it is hand-written HIP.
+ *
+ * Conventions (all entry points):
+ *   - return 0 on success, a positive hipError_t value on a runtime failure, a negative
+ *     GX_E* code on misuse;
+ *   - every pointer is a DEVICE pointer unless the parameter is documented "host";
+ *   - work is enqueued on `stream` and is asynchronous w.r.t. the host unless the entry point
+ *     returns a host value (documented per function);
+ *   - entry points never allocate: scratch comes from the caller through the cub-style query
+ *     convention (tmp == NULL  ->  *tmp_bytes is set to the required size and nothing runs),
+ *     mirroring the reference's call sites, e.g. cpp/src/sort/sort_radix.cu:67-71;
+ *   - row counts are int64_t here; the cudf::size_type (int32) limit is enforced one layer up
+ *     (cpp/include/cudf/types.hpp:76).
+ *
+ * Each declaration cites the reference interface it replaces (paths relative to
+ * /root/reference/cpp).
+ */
+#ifndef CUDF_AMD_GX_H
+#define CUDF_AMD_GX_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct ihipStream_t* gx_stream_t; /* == hipStream_t */
+
+/* element types: numeric values match cudf::type_id (include/cudf/types.hpp:184-216) */
+enum gx_dtype {
+  GX_INT8    = 1,
+  GX_INT16   = 2,
+  GX_INT32   = 3,
+  GX_INT64   = 4,
+  GX_UINT8   = 5,
+  GX_UINT16  = 6,
+  GX_UINT32  = 7,
+  GX_UINT64  = 8,
+  GX_FLOAT32 = 9,
+  GX_FLOAT64 = 10,
+  GX_BOOL8   = 11
+};
+
+enum gx_error {
+  GX_SUCCESS       = 0,
+  GX_EINVAL        = -1, /* bad argument (null pointer, negative size, aliasing) */
+  GX_EDTYPE        = -2, /* dtype not supported by this entry point */
+  GX_ETMP          = -3, /* scratch buffer too small */
+  GX_EINTERNAL     = -4, /* device-side protocol failure reported by gx_sort_status */
+  GX_EOVERFLOW     = -5  /* output does not fit the caller's capacity */
+};
+
+/* reduce / scan / groupby operator codes: match cudf::aggregation::Kind for the kinds we
+ * implement (include/cudf/aggregation.hpp:84-130) */
+enum gx_op {
+  GX_OP_SUM         = 0,
+  GX_OP_PRODUCT     = 1,
+  GX_OP_MIN         = 2,
+  GX_OP_MAX         = 3,
+  GX_OP_COUNT_VALID = 4,
+  GX_OP_COUNT_ALL   = 5,
+  GX_OP_MEAN        = 10
+};
+
+const char* gx_version(void);
+/* size in bytes of one element of `dtype`, 0 if unknown */
+int gx_dtype_size(int dtype);
+
+/* ------------------------------------------------------------------------------------------
+ * Radix sort.
+ * Replaces cub::DeviceRadixSort::SortKeys[Descending] as called at src/sort/sort_radix.cu:69-76
+ * (and the float path :80-119): stable LSD radix sort of a fixed-width column without nulls,
+ * begin_bit = 0, end_bit = 8*sizeof(T).  Floats: -0.0 == +0.0 (input order kept), NaNs after
+ * +Inf in input order (descending: NaNs first, reverse input order -- the composite-key rule of
+ * sort_radix.cu:36-45).  `in` and `out` must not alias.
+ * ------------------------------------------------------------------------------------------ */
+int gx_sort_keys(int dtype, const void* in, void* out, int64_t n, int descending,
+                 void* tmp, size_t* tmp_bytes, gx_stream_t stream);
+
+/* Replaces cub::DeviceRadixSort::SortPairs[Descending] as called at
+ * src/sort/sorted_order_radix.cu:83-94,125-135.  vals_in == NULL means iota (what
+ * thrust::sequence writes at :70-73).  keys_out may be NULL (sorted keys are then kept only in
+ * scratch, as the reference discards them: :67). */
+int gx_sort_pairs(int key_dtype, const void* keys_in, void* keys_out, const int32_t* vals_in,
+                  int32_t* vals_out, int64_t n, int descending, void* tmp, size_t* tmp_bytes,
+                  gx_stream_t stream);
+
+/* cudf::sorted_order / stable_sorted_order of one column (include/cudf/sorting.hpp:44-64;
+ * src/sort/sort_column.cu:22-44, stable_sort_column.cu:22-46, sort_column_impl.cuh:35-57).
+ * valid == NULL: radix path above.  Otherwise `valid` is an Arrow validity bitmap (LSB-first,
+ * 1 = valid, bit 0 = row 0): null rows are placed first when (nulls_before XOR descending) --
+ * the flip of sort_column_impl.cuh:42-45 -- in input order, valid rows are radix sorted (stable,
+ * NaN greater than every number and equivalent to each other in BOTH directions: the comparator
+ * path, include/cudf/detail/row_operator/common_utils.cuh:157-169).  null_count is the host-side
+ * null count the column_view carries (include/cudf/column/column_view.hpp null_count()). */
+int gx_sorted_order(int dtype, const void* keys, const uint32_t* valid, int64_t n, int64_t null_count,
+                    int descending, int nulls_before, int32_t* out_indices, void* tmp, size_t* tmp_bytes,
+                    gx_stream_t stream);
+
+/* Copies the device-side status word of the last sort that used `tmp` to *status_host
+ * (0 = ok).  Synchronises `stream`.  A non-zero status means a look-back spin timed out. */
+int gx_sort_status(const void* tmp, int* status_host, gx_stream_t stream);
+
+/* Tuning / A-B knob (process-wide): 0 = onesweep (decoupled look-back, default),
+ * 1 = three-kernel passes (tile histogram + scan + scatter; no inter-workgroup communication). */
+void gx_sort_set_algorithm(int algo);
+
+/* Measurement hooks (bench.py's roofline leg): when enabled, every sort records HIP events on
+ * the caller's stream around the histogram launch and around each pass's launch(es);
+ * gx_sort_profile_read waits for the last sort and returns the durations in milliseconds
+ * (pass_ms has room for 8 entries; skipped passes report the few microseconds of their early
+ * exit). */
+int gx_sort_profile(int enable);
+int gx_sort_profile_read(float* hist_ms, float* pass_ms, int* npass);
+
+/* ------------------------------------------------------------------------------------------
+ * Gather.  Replaces cudf::detail::gather for fixed-width columns
+ * (include/cudf/detail/gather.cuh:108-131 data, :506-577 validity): out[i] = in[map[i]].
+ * elem_size in {1,2,4,8}.  map entries must be in [0, src_rows) (bounds_policy::DONT_CHECK);
+ * entries equal to INT32_MIN (JoinNoMatch) produce a null/zero row when nullify_oob != 0.
+ * src_valid/out_valid may be NULL (no validity handled).
+ * ------------------------------------------------------------------------------------------ */
+int gx_gather(int elem_size, const void* src, const uint32_t* src_valid, int64_t src_rows,
+              const int32_t* map, int64_t n, int nullify_oob, void* out, uint32_t* out_valid,
+              gx_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------
+ * Validity bitmaps.  Replace src/bitmask/null_mask.cu:152 (set), :339-409 (count),
+ * include/cudf/detail/null_mask.cuh:68 (bitmask_and).
+ * ------------------------------------------------------------------------------------------ */
+int gx_bitmask_set(uint32_t* mask, int64_t begin_bit, int64_t end_bit, int valid, gx_stream_t stream);
+/* *count_dev (device int64) = number of set bits in [begin_bit, end_bit) */
+int gx_bitmask_count(const uint32_t* mask, int64_t begin_bit, int64_t end_bit, int64_t* count_dev,
+                     gx_stream_t stream);
+/* out = AND of `nmasks` bitmaps (host array of device pointers; NULL entries = all valid),
+ * nbits bits each; *count_dev (optional) = set bits of the result */
+int gx_bitmask_and(const uint32_t* const* masks_host, int nmasks, int64_t nbits, uint32_t* out,
+                   int64_t* count_dev, gx_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------
+ * Hashing / partitioning.
+ * gx_murmur3_32: cudf::hashing::detail::MurmurHash3_x86_32<T>
+ * (include/cudf/hashing/detail/murmurhash3_x86_32.cuh:22-67), null -> UINT32_MAX, and the
+ * column fold of primitive_row_operators.cuh:247-268: combine == 0 writes out[i] = hash(x[i]),
+ * combine != 0 writes out[i] = hash_combine(out[i], hash(x[i])) (hashing.hpp:83-86).
+ * ------------------------------------------------------------------------------------------ */
+int gx_murmur3_32(int dtype, const void* in, const uint32_t* valid, int64_t n, uint32_t seed,
+                  int combine, uint32_t* out, gx_stream_t stream);
+
+/* cudf::hash_partition (include/cudf/partitioning.hpp:103-110; src/partitioning/partitioning.cu:
+ * 53-92,120-360,568-660) reduced to its index form: from row hashes, a stable gather map that
+ * groups rows by partition (hash % num_partitions) plus num_partitions+1 int32 offsets.
+ * The caller gathers every column through the map (gx_gather). */
+int gx_hash_partition_map(const uint32_t* row_hash, int64_t n, int num_partitions,
+                          int32_t* out_map, int32_t* out_offsets, void* tmp, size_t* tmp_bytes,
+                          gx_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------
+ * Hash join (single fixed-width key column of 4 or 8 bytes; multi-column keys are packed or
+ * hashed by the layer above -- see include/cudf/join/).
+ * Replaces cudf::detail::hash_join build (src/join/hash_join/hash_join.cu:62-99,112-148 ->
+ * cuco::static_multiset::insert) and probe (src/join/hash_join/retrieve_impl.cuh:28-113,
+ * size_impl.cuh:26-62 -> cuco count / retrieve).
+ *
+ * The table is an open-addressing multiset of {key, row} slots sized by gx_join_table_bytes;
+ * build rows whose validity bit is 0 are skipped (null_equality::UNEQUAL semantics of
+ * hash_join.cu:77-84; for EQUAL the caller maps nulls to a reserved key -- see DESIGN.md).
+ * ------------------------------------------------------------------------------------------ */
+size_t gx_join_table_bytes(int key_size, int64_t build_rows, double load_factor);
+int gx_join_build(int key_size, const void* build_keys, const uint32_t* build_valid,
+                  int64_t build_rows, void* table, size_t table_bytes, double load_factor,
+                  gx_stream_t stream);
+/* Number of matches: *count_dev (device int64).  probe_valid NULL = all valid. */
+int gx_join_count(int key_size, const void* probe_keys, const uint32_t* probe_valid,
+                  int64_t probe_rows, const void* table, size_t table_bytes, int64_t* count_dev,
+                  gx_stream_t stream);
+/* Emits pairs (probe_idx, build_idx) in unspecified order (include/cudf/join/join.hpp:131-134)
+ * through a device cursor *cursor_dev (must be zeroed by the caller); pairs beyond `capacity`
+ * are counted but not written (caller compares the cursor with capacity).
+ * left_outer != 0: probe rows without a match emit (probe_idx, INT32_MIN) -- cudf::left_join
+ * (src/join/join.cu:62-85). */
+int gx_join_probe(int key_size, const void* probe_keys, const uint32_t* probe_valid,
+                  int64_t probe_rows, const void* table, size_t table_bytes, int left_outer,
+                  int32_t* out_probe_idx, int32_t* out_build_idx, int64_t capacity,
+                  int64_t* cursor_dev, gx_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------
+ * Groupby, hash path (single int32/int64 key column; values int32/int64/float32/float64).
+ * Replaces src/groupby/hash/compute_groupby.cu:50-155 + compute_global_memory_aggs.cuh:123-157:
+ * distinct keys (unspecified order) and per-group SUM / COUNT_VALID / COUNT_ALL / MIN / MAX.
+ * float sums are accumulated in 128-bit fixed point (exact, order independent, bit-reproducible)
+ * and rounded once: see DESIGN.md "groupby".  Outputs have capacity `max_groups`; *ngroups_dev
+ * (device int64) receives the group count.  Rows with key validity 0 are dropped
+ * (null_policy::EXCLUDE, compute_groupby.cu:62-66).
+ * ------------------------------------------------------------------------------------------ */
+int gx_groupby_sum_count(int key_dtype, const void* keys, const uint32_t* keys_valid,
+                         int val_dtype, const void* vals, const uint32_t* vals_valid, int64_t n,
+                         int64_t max_groups, void* out_keys, void* out_sum /* f64 or i64 */,
+                         int32_t* out_count_valid, int32_t* out_count_all, int64_t* ngroups_dev,
+                         void* tmp, size_t* tmp_bytes, gx_stream_t stream);
+
+/* Segmented inclusive scan over sorted group labels: replaces thrust::inclusive_scan_by_key at
+ * src/groupby/sort/group_scan_util.cuh:109-130 (groupby::scan SUM/MIN/MAX).  keys are the
+ * (already sorted) key column; out[i] = op over the rows of the same key run up to i.
+ * Null values (vals_valid bit 0) contribute the identity. Integer SUM accumulates in int64. */
+int gx_segmented_scan(int key_dtype, const void* sorted_keys, int val_dtype, const void* vals,
+                      const uint32_t* vals_valid, int64_t n, int op, void* out, void* tmp,
+                      size_t* tmp_bytes, gx_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------
+ * Column reduce / scan.
+ * gx_reduce replaces cub::DeviceReduce::Reduce at include/cudf/reduction/detail/reduction.cuh:
+ * 46-83 (cudf::reduce SUM/MIN/MAX/PRODUCT; nulls skipped).  Result written to *out_dev in
+ * `out_dtype` (GX_INT64, GX_UINT64 or GX_FLOAT64 for SUM/PRODUCT; in_dtype for MIN/MAX);
+ * *valid_count_dev (device int64, optional) = number of valid inputs.
+ * gx_scan replaces thrust::inclusive_scan / exclusive_scan at
+ * src/reductions/scan/scan_inclusive.cu:76-89 and scan_exclusive.cu; output dtype == input
+ * dtype (ints wrap); nulls contribute the identity (null_policy handling of the mask is done by
+ * the caller: scan_inclusive.cu:198-216).
+ * ------------------------------------------------------------------------------------------ */
+int gx_reduce(int in_dtype, const void* in, const uint32_t* valid, int64_t n, int op,
+              int out_dtype, void* out_dev, int64_t* valid_count_dev, void* tmp, size_t* tmp_bytes,
+              gx_stream_t stream);
+int gx_scan(int dtype, const void* in, const uint32_t* valid, int64_t n, int op, int inclusive,
+            void* out, void* tmp, size_t* tmp_bytes, gx_stream_t stream);
+
+/* index of the first 0 bit in [0,nbits) or nbits: *pos_dev (device int64).  Used for the
+ * null_policy::INCLUDE scan mask (scan_inclusive.cu:44-53 thrust::find_if_not). */
+int gx_bitmask_first_unset(const uint32_t* mask, int64_t nbits, int64_t* pos_dev, gx_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------
+ * Synthetic data (bench / tests): counter-based generator so that 1e9-row inputs never cross
+ * PCIe.  out[i] = splitmix64(seed + i) mapped to the dtype; `lo`,`hi` bound integer outputs
+ * when hi > lo (uniform in [lo, hi)), floats are uniform in [0,1).
+ * ------------------------------------------------------------------------------------------ */
+int gx_fill_random(int dtype, void* out, int64_t n, uint64_t seed, int64_t lo, int64_t hi,
+                   gx_stream_t stream);
+/* iota: out[i] = start + i (int32) */
+int gx_sequence_i32(int32_t* out, int64_t n, int32_t start, gx_stream_t stream);
+/* order-independent 64-bit checksum of a column (sum and xor of splitmix64(element)) and a
+ * sortedness violation count in the column's cudf order: res_dev[0]=sum, [1]=xor, [2]=violations */
+int gx_checksum(int dtype, const void* in, int64_t n, int descending, uint64_t* res_dev,
+                gx_stream_t stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* CUDF_AMD_GX_H */

@@ -1,0 +1,222 @@
+"""GPU parity: hash join / groupby through the C ABI vs the CPU oracle and the reference's goldens."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+from oracle import cudf_oracle as orc
+from tests.golden import reference_vectors as gv
+
+
+@pytest.fixture(scope="module")
+def gx():
+    import torch
+    assert torch.cuda.is_available()
+    import cudf_amd
+    from cudf_amd import Column, ops
+    return Column, ops
+
+
+def _pairs(l, r):
+    return orc.canonical_pairs(l.to_numpy(), r.to_numpy())
+
+
+@pytest.mark.parametrize("dtype", ["int64", "int32", "uint64", "uint32"])
+def test_inner_join_matches_oracle(gx, dtype):
+    Column, ops = gx
+    rng = np.random.default_rng(1)
+    for nl, nr, dup in [(0, 5, False), (5, 0, False), (1, 1, False), (1000, 300, False), (70_000, 9_000, True),
+                        (9_000, 70_000, True), (300_001, 100_003, False)]:
+        if nr:
+            right = rng.permutation(max(nr * 3, 1))[:nr].astype(dtype)
+            if dup and nr > 10:
+                right[: nr // 10] = right[nr // 2: nr // 2 + nr // 10]  # duplicate build keys
+        else:
+            right = np.empty(0, dtype)
+        left = rng.integers(0, max(nr * 4, 1), nl).astype(dtype)
+        l, r = ops.inner_join(Column.from_numpy(left), Column.from_numpy(right))
+        gl, gr = _pairs(l, r)
+        el, er = orc.inner_join(left, right)
+        np.testing.assert_array_equal(gl, el, err_msg=f"{dtype} {nl}x{nr}")
+        np.testing.assert_array_equal(gr, er)
+
+
+def test_hash_join_class_sequential_probes_and_sizes(gx):
+    Column, ops = gx
+    rng = np.random.default_rng(2)
+    build = (rng.permutation(50_000)[:20_000] * 7).astype(np.int64)
+    hj = ops.HashJoin(Column.from_numpy(build), load_factor=0.5)
+    for seed in range(3):
+        probe = np.random.default_rng(seed).integers(0, 400_000, 60_000).astype(np.int64)
+        pc = Column.from_numpy(probe)
+        el, er = orc.inner_join(probe, build)
+        assert hj.inner_join_size(pc) == len(el)
+        l, r = hj.inner_join(pc)
+        gl, gr = _pairs(l, r)
+        np.testing.assert_array_equal(gl, el)
+        np.testing.assert_array_equal(gr, er)
+        # exact output_size supplied by the caller (hash_join.hpp:145-150)
+        l2, r2 = hj.inner_join(pc, output_size=len(el))
+        assert _pairs(l2, r2)[0].tolist() == el.tolist()
+        ll, lr = hj.left_join(pc)
+        xl, xr = orc.left_join(probe, build)
+        gl, gr = _pairs(ll, lr)
+        np.testing.assert_array_equal(gl, xl)
+        np.testing.assert_array_equal(gr, xr)
+    with pytest.raises(TypeError):
+        hj.inner_join(Column.from_numpy(np.zeros(3, np.int32)))
+    with pytest.raises(ValueError):
+        ops.HashJoin(Column.from_numpy(build), load_factor=0.0)
+
+
+@pytest.mark.parametrize("nulls_equal", [True, False])
+def test_join_with_nulls(gx, nulls_equal):
+    Column, ops = gx
+    rng = np.random.default_rng(3)
+    left = rng.integers(0, 50, 2000).astype(np.int64)
+    right = rng.integers(0, 50, 300).astype(np.int64)
+    lv = rng.random(2000) > 0.1
+    rv = rng.random(300) > 0.1
+    l, r = ops.inner_join(Column.from_numpy(left, lv), Column.from_numpy(right, rv), nulls_equal)
+    gl, gr = _pairs(l, r)
+    el, er = orc.inner_join([left], [right], [lv], [rv], nulls_equal)
+    np.testing.assert_array_equal(gl, el)
+    np.testing.assert_array_equal(gr, er)
+
+
+@pytest.mark.parametrize("case", [c for c in gv.JOIN if len(c["left"]) == 1 and c.get("how", "inner") == "inner"],
+                         ids=lambda c: c["name"])
+def test_reference_golden_join_single_key(gx, case):
+    Column, ops = gx
+    (lc, lm), (rc, rm) = gv.col(case["left"][0], case["dtype"]), gv.col(case["right"][0], case["dtype"])
+    for eq in case["nulls_equal"]:
+        l, r = ops.inner_join(Column.from_numpy(lc, lm), Column.from_numpy(rc, rm), eq)
+        l, r = l.to_numpy(), r.to_numpy()
+        if "expected_pairs" in case:
+            assert sorted(zip(l.tolist(), r.tolist())) == sorted(case["expected_pairs"])
+        else:
+            lp = [np.array(c) for c in case["left_payload"]]
+            rp = [np.array(c) for c in case["right_payload"]]
+            rows = sorted(tuple(int(c[i]) for c in lp) + tuple(int(c[j]) for c in rp) for i, j in zip(l, r))
+            assert rows == sorted(case["expected_rows"])
+
+
+def test_join_large_properties(gx):
+    """Size-independent checks at 2e7 x 2e6: every emitted pair has equal keys, count equals the
+    oracle-free closed form (distinct build keys, known hit set)."""
+    import torch
+    Column, ops = gx
+    nb, n = 2_000_000, 20_000_000
+    bk = Column.empty(np.int64, nb)
+    bkt = bk.data[: nb * 8].view(torch.int64)
+    bkt.copy_(torch.randperm(nb, device="cuda") * 3 + 1)
+    pk = ops.random_column(np.int64, n, seed=5, lo=0, hi=int(nb / 0.3))
+    pkt = pk.data[: n * 8].view(torch.int64)
+    pkt.mul_(3).add_(1)
+    l, r = ops.inner_join(pk, bk)
+    li = l.data[: l.size * 4].view(torch.int32).long()
+    ri = r.data[: r.size * 4].view(torch.int32).long()
+    assert bool((pkt[li] == bkt[ri]).all())
+    expected = int((pkt < 3 * nb).sum().item())  # key 3u+1 with u < nb is present exactly once
+    assert l.size == expected
+    assert int(torch.unique(li).numel()) == expected  # each probe row at most once
+
+
+@pytest.mark.parametrize("vdtype", ["float64", "float32", "int32", "int64"])
+@pytest.mark.parametrize("kdtype", ["int32", "int64"])
+def test_groupby_sum_count_matches_oracle(gx, kdtype, vdtype):
+    Column, ops = gx
+    rng = np.random.default_rng(4)
+    for n, g in [(0, 1), (1, 1), (1000, 7), (200_000, 1000), (300_000, 150_000)]:
+        keys = rng.integers(-g // 2, g // 2 + 1, n).astype(kdtype)
+        if n > 10:
+            keys[:3] = -1  # the reserved-slot key of the int64 table
+        if np.dtype(vdtype).kind == "f":
+            vals = (rng.random(n) * 1000 - 300).astype(vdtype)
+        else:
+            vals = rng.integers(-2**31, 2**31 - 1, n).astype(vdtype)
+        kv = rng.random(n) > 0.05
+        vv = rng.random(n) > 0.2
+        k, s, cv, ca = ops.groupby_sum_count(Column.from_numpy(keys, kv), Column.from_numpy(vals, vv), max_groups_hint=64)
+        o = np.argsort(k.to_numpy(), kind="stable")
+        ek, res = orc.groupby_agg(keys, vals, ["sum", "count_valid", "count_all"], kv, vv)
+        np.testing.assert_array_equal(k.to_numpy()[o], ek)
+        np.testing.assert_array_equal(cv.to_numpy()[o], res["count_valid"][0])
+        np.testing.assert_array_equal(ca.to_numpy()[o], res["count_all"][0])
+        es, ev = res["sum"]
+        got = s.to_numpy()[o]
+        if np.dtype(vdtype).kind == "f":
+            assert got.dtype == np.dtype(vdtype)
+            if vdtype == "float64":
+                assert np.all(orc.ulp_diff(got[ev], es[ev]) <= 1), "f64 SUM must be within 1 ulp of the exact sum"
+            else:
+                np.testing.assert_allclose(got[ev], es[ev], rtol=2e-7)
+        else:
+            assert got.dtype == np.int64
+            np.testing.assert_array_equal(got[ev], es[ev])
+
+
+@pytest.mark.parametrize("vdtype", ["int32", "int64", "float64"])
+@pytest.mark.parametrize("case", [c for c in gv.GROUPBY if c["agg"] in ("sum", "count_valid", "count_all", "mean")],
+                         ids=lambda c: c["name"])
+def test_reference_golden_groupby(gx, case, vdtype):
+    Column, ops = gx
+    vdtype = case.get("vals_dtype", vdtype)
+    keys, km = gv.col(case["keys"], "int32", case.get("keys_valid"))
+    vals, vm = gv.col(case["vals"], vdtype, case.get("vals_valid"))
+    k, s, cv, ca = ops.groupby_sum_count(Column.from_numpy(keys, km), Column.from_numpy(vals, vm))
+    o = np.argsort(k.to_numpy(), kind="stable")
+    np.testing.assert_array_equal(k.to_numpy()[o], np.array(case["expect_keys"], np.int32))
+    ev = np.array(case["expect_valid"], bool)
+    exp = np.array(case["expect"])
+    cvn = cv.to_numpy()[o]
+    if case["agg"] == "sum":
+        np.testing.assert_array_equal(cvn > 0, ev)
+        np.testing.assert_array_equal(s.to_numpy()[o][ev], exp[ev].astype(s.dtype))
+    elif case["agg"] == "count_valid":
+        np.testing.assert_array_equal(cvn, exp)
+    elif case["agg"] == "count_all":
+        np.testing.assert_array_equal(ca.to_numpy()[o], exp)
+    else:  # MEAN = SUM / COUNT_VALID in double (hash_compound_agg_finalizer.cu:92-133)
+        np.testing.assert_array_equal(cvn > 0, ev)
+        mean = s.to_numpy()[o][ev].astype(np.float64) / cvn[ev]
+        assert np.all(orc.ulp_diff(mean, exp[ev].astype(np.float64)) <= 1)
+
+
+@pytest.mark.parametrize("vdtype", ["int32", "int64", "float64"])
+@pytest.mark.parametrize("case", gv.GROUPBY_SCAN, ids=lambda c: c["name"])
+def test_reference_golden_groupby_scan(gx, case, vdtype):
+    Column, ops = gx
+    keys, km = gv.col(case["keys"], "int32", case.get("keys_valid"))
+    vals, vm = gv.col(case["vals"], vdtype, case.get("vals_valid"))
+    keep = np.ones(len(keys), bool) if km is None else km
+    kc = Column.from_numpy(keys[keep])
+    vc = Column.from_numpy(vals[keep], None if vm is None else vm[keep])
+    order = ops.sorted_order(kc)                      # sort_helper.cu:73-118 stable_sorted_order(keys)
+    sk, sv = ops.gather(kc, order), ops.gather(vc, order)
+    out = ops.groupby_scan(sk, sv, "sum")
+    np.testing.assert_array_equal(sk.to_numpy(), np.array(case["expect_keys"], np.int32))
+    ev = np.array(case["expect_valid"], bool)
+    if sv.mask is not None:
+        np.testing.assert_array_equal(sv.valid_numpy(), ev)
+    np.testing.assert_array_equal(out.to_numpy()[ev], np.array(case["expect"])[ev].astype(out.dtype))
+
+
+def test_groupby_scan_matches_oracle(gx):
+    Column, ops = gx
+    rng = np.random.default_rng(8)
+    n = 150_000
+    keys = rng.integers(0, 300, n).astype(np.int64)
+    for vdtype in ("int32", "float64"):
+        vals = (rng.random(n) * 100).astype(vdtype)
+        vv = rng.random(n) > 0.1
+        kc = Column.from_numpy(keys)
+        order = ops.sorted_order(kc)
+        sk, sv = ops.gather(kc, order), ops.gather(Column.from_numpy(vals, vv), order)
+        out = ops.groupby_scan(sk, sv, "sum").to_numpy()
+        ek, eo, ev = orc.groupby_scan_sum(keys, vals, None, vv)
+        np.testing.assert_array_equal(sk.to_numpy(), ek)
+        if vdtype == "int32":
+            np.testing.assert_array_equal(out[ev], eo[ev])
+        else:
+            np.testing.assert_allclose(out[ev], eo[ev], rtol=1e-12)

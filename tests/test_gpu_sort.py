@@ -1,0 +1,156 @@
+"""GPU parity: radix sort / sorted_order / gather through the C ABI vs the CPU oracle."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+from oracle import cudf_oracle as orc
+from tests.golden import reference_vectors as gv
+
+
+@pytest.fixture(scope="module")
+def gx():
+    import torch
+    assert torch.cuda.is_available()
+    import cudf_amd
+    from cudf_amd import Column, ops
+    return Column, ops
+
+
+def _rand(dtype, n, rng, lowcard=False):
+    dt = np.dtype(dtype)
+    if dt.kind == "f":
+        v = rng.standard_normal(n).astype(dt)
+        if n > 16:
+            v[rng.integers(0, n, n // 50 + 1)] = np.nan
+            v[rng.integers(0, n, n // 50 + 1)] = -np.nan
+            v[rng.integers(0, n, n // 50 + 1)] = 0.0
+            v[rng.integers(0, n, n // 50 + 1)] = -0.0
+            v[rng.integers(0, n, n // 100 + 1)] = np.inf
+            v[rng.integers(0, n, n // 100 + 1)] = -np.inf
+        return v
+    info = np.iinfo(dt)
+    if lowcard:
+        return rng.integers(100, 10000, n).astype(dt) if dt.itemsize > 1 else rng.integers(0, 7, n).astype(dt)
+    return rng.integers(info.min, info.max, n, dtype=dt, endpoint=True)
+
+
+DTYPES = ["int8", "uint8", "int16", "uint16", "int32", "uint32", "int64", "uint64", "float32", "float64"]
+SIZES = [0, 1, 2, 63, 64, 65, 1000, 8191, 8192, 8193, 100_003, 1_000_003]
+
+
+@pytest.mark.parametrize("algo", [0, 1])
+@pytest.mark.parametrize("dtype", DTYPES)
+def test_sort_keys_matches_oracle(gx, dtype, algo):
+    Column, ops = gx
+    from cudf_amd import _lib
+    _lib.lib.gx_sort_set_algorithm(algo)
+    try:
+        rng = np.random.default_rng(42)
+        for n in SIZES:
+            for lowcard in (False, True):
+                v = _rand(dtype, n, rng, lowcard)
+                for asc in (True, False):
+                    got = ops.sort(Column.from_numpy(v), ascending=asc).to_numpy()
+                    exp = orc.sort_keys(v, asc)
+                    assert got.tobytes() == exp.tobytes(), (dtype, n, lowcard, asc, algo)
+    finally:
+        _lib.lib.gx_sort_set_algorithm(0)
+
+
+@pytest.mark.parametrize("algo", [0, 1])
+@pytest.mark.parametrize("dtype", ["int32", "int64", "uint64", "float32", "float64", "int8", "uint16"])
+def test_sorted_order_matches_oracle(gx, dtype, algo):
+    Column, ops = gx
+    from cudf_amd import _lib
+    _lib.lib.gx_sort_set_algorithm(algo)
+    try:
+        rng = np.random.default_rng(7)
+        for n in [0, 1, 65, 5121, 10_240, 200_001]:
+            v = _rand(dtype, n, rng, lowcard=True)  # many ties: stability is observable
+            for asc in (True, False):
+                got = ops.sorted_order(Column.from_numpy(v), ascending=asc).to_numpy()
+                np.testing.assert_array_equal(got, orc.sorted_order(v, None, asc), err_msg=f"{dtype} {n} {asc}")
+    finally:
+        _lib.lib.gx_sort_set_algorithm(0)
+
+
+@pytest.mark.parametrize("dtype", ["int32", "int64", "float64", "uint8"])
+def test_sorted_order_with_nulls(gx, dtype):
+    Column, ops = gx
+    rng = np.random.default_rng(9)
+    for n in [1, 10, 1000, 70_001]:
+        v = _rand(dtype, n, rng, lowcard=True)
+        valid = rng.random(n) > 0.3
+        if n == 10:
+            valid[:] = False  # all null
+        for asc in (True, False):
+            for before in (True, False):
+                got = ops.sorted_order(Column.from_numpy(v, valid), asc, before).to_numpy()
+                exp = orc.sorted_order(v, valid, asc, before)
+                np.testing.assert_array_equal(got, exp, err_msg=f"{dtype} {n} asc={asc} before={before}")
+
+
+@pytest.mark.parametrize("case", gv.SORT, ids=lambda c: c["name"])
+def test_reference_golden_sort(gx, case):
+    Column, ops = gx
+    vals, mask = gv.col(case["values"], case["dtype"], case["valid"])
+    got = ops.sorted_order(Column.from_numpy(vals, mask), case["ascending"], case["null_before"]).to_numpy()
+    exp = np.array(case["expected"], np.int32)
+    if case["compare"] == "indices":
+        np.testing.assert_array_equal(got, exp)
+    else:
+        m = np.ones(len(vals), bool) if mask is None else mask
+        np.testing.assert_array_equal(m[got], m[exp])
+        np.testing.assert_array_equal(vals[got][m[got]], vals[exp][m[exp]])
+    if mask is None:
+        assert ops.sort(Column.from_numpy(vals), case["ascending"]).to_numpy().tobytes() == vals[exp].tobytes()
+
+
+def test_sort_by_key_and_gather(gx):
+    Column, ops = gx
+    rng = np.random.default_rng(3)
+    n = 50_000
+    keys = rng.integers(0, 500, n).astype(np.int64)
+    pay = rng.standard_normal(n)
+    pvalid = rng.random(n) > 0.1
+    out = ops.sort_by_key([Column.from_numpy(pay, pvalid), Column.from_numpy(keys)], Column.from_numpy(keys))
+    order = orc.sorted_order(keys)
+    np.testing.assert_array_equal(out[1].to_numpy(), keys[order])
+    np.testing.assert_array_equal(out[0].valid_numpy(), pvalid[order])
+    got = out[0].to_numpy()
+    np.testing.assert_array_equal(got[pvalid[order]], pay[order][pvalid[order]])
+    assert out[0].null_count == int((~pvalid).sum())
+    # JoinNoMatch entries become nulls under the NULLIFY policy
+    gm = np.array([3, -2**31, 0, n - 1, -2**31], np.int32)
+    g = ops.gather(Column.from_numpy(keys), Column.from_numpy(gm), nullify_out_of_bounds=True)
+    np.testing.assert_array_equal(g.valid_numpy(), [True, False, True, True, False])
+    np.testing.assert_array_equal(g.to_numpy()[[0, 2, 3]], keys[[3, 0, n - 1]])
+    with pytest.raises(RuntimeError, match="Mismatch in number of rows"):
+        ops.sort_by_key([Column.from_numpy(pay[:10])], Column.from_numpy(keys))
+
+
+def test_sort_large_properties(gx):
+    """Size-independent properties at a size the oracle does not run at: sortedness, permutation
+    checksum (sum and xor of splitmix64(element)), idempotence."""
+    Column, ops = gx
+    n = 50_000_000
+    col = ops.random_column(np.int64, n, seed=42)
+    s_in = ops.checksum(col)
+    out = ops.sort(col)
+    s_out = ops.checksum(out)
+    assert s_out[2] == 0
+    assert s_in[:2] == s_out[:2]
+    again = ops.sort(out)
+    assert ops.checksum(again) == s_out
+    desc = ops.sort(col, ascending=False)
+    cd = ops.checksum(desc, descending=True)
+    assert cd[2] == 0 and cd[:2] == s_in[:2]
+    # argsort: gather(col, order) == sorted
+    order = ops.sorted_order(col)
+    g = ops.gather(col, order)
+    assert ops.checksum(g) == s_out
+    import torch
+    o = order.data[: n * 4].view(torch.int32).to(torch.int64)
+    assert int(torch.bincount(o[: 1_000_000] % 1024).sum()) == 1_000_000
+    assert int(o.sum().item()) == n * (n - 1) // 2  # a permutation of iota
