@@ -72,7 +72,8 @@ def test_reference_golden_scan(gx, case, dtype):
     out = ops.scan(Column.from_numpy(vals, mask), case["op"], case["inclusive"], case["null_include"])
     ev = np.array(case["expect_valid"], bool)
     if mask is not None:
-        np.testing.assert_array_equal(out.valid_numpy(), ev)
+        gm = out.valid_numpy()
+        np.testing.assert_array_equal(np.ones(len(vals), bool) if gm is None else gm, ev)
     np.testing.assert_array_equal(out.to_numpy()[ev], np.array(case["expect"])[ev].astype(dtype))
 
 
