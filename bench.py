@@ -37,10 +37,13 @@ def parse():
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--workload", default="sort", choices=["sort", "sorted_order", "join", "groupby"])
     ap.add_argument("--rows", type=float, default=1e9)
-    ap.add_argument("--algo", type=int, default=0, help="sort algorithm knob (0 onesweep, 1 three-kernel)")
+    ap.add_argument("--algo", type=int, default=0,
+                    help="sort knob: 0 onesweep/windowed look-back, 1 three-kernel, 2 onesweep/one-tile look-back")
+    ap.add_argument("--gb-algo", type=int, default=0, help="groupby knob: 0 auto, 1 global table, 2 LDS-partitioned")
+    ap.add_argument("--gb-split", type=int, default=1)
     ap.add_argument("--cpu-baseline", dest="cpu", action="store_true", default=True)
     ap.add_argument("--no-cpu-baseline", dest="cpu", action="store_false")
-    ap.add_argument("--cpu-rows", type=float, default=3e7)
+    ap.add_argument("--cpu-rows", type=float, default=0, help="rows of the CPU-baseline sample (0 = per-workload default)")
     return ap.parse_args()
 
 
@@ -118,6 +121,7 @@ def main():
     lib = L.lib
     n = int(args.rows)
     lib.gx_sort_set_algorithm(args.algo)
+    lib.gx_groupby_set_algorithm(args.gb_algo, args.gb_split)
     stream = stream_ptr()
 
     def barrier():
@@ -241,15 +245,17 @@ def main():
     if rank == 0:
         cpu = None
         if args.cpu and world == 1:
+            # bounded sample: ~10-30 s of single-thread CPU work
+            cpu_rows = args.cpu_rows or {"sort": 1e8, "sorted_order": 1e8, "join": 5e7, "groupby": 2e8}[args.workload]
             cpu = {"sort": cpu_baseline_sort, "sorted_order": cpu_baseline_sort, "join": cpu_baseline_join,
-                   "groupby": cpu_baseline_groupby}[args.workload](args.cpu_rows)
+                   "groupby": cpu_baseline_groupby}[args.workload](cpu_rows)
         line = {
             "metric": "rows/sec + achieved HBM GB/s: 1e9-row int64 sort & hash-join, 1/2/4/8 GPU",
             "value": unit_rows * world / (dt / args.steps), "unit": "rows/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": {"sort": "int64", "sorted_order": "int64", "join": "int64", "groupby": "f64"}[args.workload],
             "data": "synthetic",
-            "config": {"workload": workload, "rows_per_gpu": n, "algo": args.algo,
+            "config": {"workload": workload, "rows_per_gpu": n, "algo": args.algo, "gb_algo": args.gb_algo,
                        "parallelism": f"row shards x{world}, no data-path collective"},
             "roofline": roofline, "cpu_baseline": cpu,
         }

@@ -156,11 +156,405 @@ __global__ void __launch_bounds__(GBT) k_compact(const unsigned long long* __res
   }
 }
 
+
+// ------------------------------------------------------------------------------------------------
+// Partitioned path (large inputs): the chip has 256 x 160 KiB = 40 MiB of LDS, more than the
+// accumulators of a million groups, but a row must reach the CU that owns its group.  So:
+//   1. k_part_hist     read the keys once (4-8 B/row), histogram of the top 8 hash bits;
+//   2. k_part_scatter  one radix-partition pass of (key, value) rows into 256 hash partitions
+//                      (tile ranked with LDS atomics, re-ordered in LDS so that every partition
+//                      leaves the tile as one contiguous run, global space reserved with one atomic
+//                      per (tile, partition)); order inside a partition is irrelevant for groupby;
+//   3. k_part_aggregate one 1024-thread workgroup per partition owns an open-addressing table in
+//                      LDS ({key, count, sum, compensation} per group) and streams its rows through
+//                      LDS atomics (ds_add_rtn_f64 with the same two_sum compensation as above);
+//                      at the end the few thousand groups of the partition are merged into the
+//                      global table, which also takes any row the LDS table could not hold
+//                      (more distinct keys than slots): correctness never depends on the fit.
+// HBM traffic: sizeof(K) + 3*(sizeof(K)+sizeof(V)) per row against the algorithmic
+// sizeof(K)+sizeof(V), but every access is streaming; the global-atomic path above does ~4 random
+// memory-side atomics per row instead.
+// ------------------------------------------------------------------------------------------------
+constexpr int NPART  = 256;
+constexpr int PBT    = 512;          // scatter workgroup
+constexpr int PRPT   = 16;           // rows per thread -> 8192-row tiles
+constexpr int PTILE  = PBT * PRPT;
+constexpr int ABT    = 1024;         // aggregate workgroup
+constexpr int LDS_BUDGET = 160 * 1024 - 2048;
+
+// The scatter pass reserves output space per (row range, partition): the input tiles are split
+// into NRANGE contiguous ranges, range r is processed by the workgroups the dispatcher places on
+// XCD r (xcd_swizzle; placement is a speed assumption only), and partition p is the concatenation
+// of its NRANGE regions.  All writes to one region then come from one XCD, so the partial 128-B
+// lines at the ends of neighbouring tiles' runs meet in that XCD's L2 and leave as full lines; with
+// a single cursor per partition neighbouring runs come from different XCDs, whose L2s are not
+// coherent, and every boundary line is written back twice as a masked partial line.
+constexpr int NRANGE = 8;
+
+struct PartPlan {
+  unsigned long long count[NRANGE][NPART];   // rows per (range, partition) (null keys excluded)
+  unsigned long long cursor[NRANGE][NPART];  // scatter cursors (start at the region offset)
+  unsigned long long offset[NPART + 1];      // partition starts
+};
+
+template <typename K>
+__device__ __forceinline__ uint64_t part_hash(K key)
+{
+  return stored_key<K>(key) * 0x9E3779B97F4A7C15ull;
+}
+
+// tiles of PTILE rows; range r = tiles [r*per, (r+1)*per), the last range takes the remainder
+__host__ __device__ static inline int64_t range_tiles(int64_t n) { return div_up(n, (int64_t)PBT * PRPT) / NRANGE; }
+
+template <typename K>
+__global__ void __launch_bounds__(256) k_part_hist(const K* __restrict__ keys, const uint32_t* __restrict__ kvalid,
+                                                   int64_t n, PartPlan* plan, int nrange)
+{
+  __shared__ uint32_t s_h[NPART];
+  s_h[threadIdx.x] = 0;
+  __syncthreads();
+  const int r          = blockIdx.x % NRANGE;  // block b -> XCD b % 8 reads the rows it will scatter
+  const int64_t jb     = blockIdx.x / NRANGE;
+  const int64_t nb     = gridDim.x / NRANGE;
+  const int64_t per    = range_tiles(n) * PTILE;
+  const int64_t rbegin = (int64_t)r * per;
+  const int64_t rend   = (r == NRANGE - 1) ? n : rbegin + per;
+  constexpr int U      = 8;
+  const int64_t stride = nb * 256 * U;
+  for (int64_t i0 = rbegin + jb * 256 * U + threadIdx.x; i0 < rend; i0 += stride) {
+    K k[U];
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const int64_t i = i0 + (int64_t)u * 256;
+      k[u]            = (i < rend) ? keys[i] : K(0);
+    }
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const int64_t i = i0 + (int64_t)u * 256;
+      if (i < rend && (!kvalid || bit_is_set(kvalid, i))) atomicAdd(&s_h[part_hash<K>(k[u]) >> 56], 1u);
+    }
+  }
+  __syncthreads();
+  const uint32_t c = s_h[threadIdx.x];
+  if (c) atomicAdd(&plan->count[nrange == 1 ? 0 : r][threadIdx.x], (unsigned long long)c);
+}
+
+__global__ void __launch_bounds__(NPART) k_part_offsets(PartPlan* plan)
+{
+  __shared__ unsigned long long s_tmp[NPART / GX_WAVE + 1];
+  unsigned long long c = 0;
+  for (int r = 0; r < NRANGE; ++r) c += plan->count[r][threadIdx.x];
+  unsigned long long total;
+  unsigned long long run = block_exclusive_scan<NPART>(c, 0ull, SumOp(), s_tmp, &total);
+  plan->offset[threadIdx.x] = run;
+  for (int r = 0; r < NRANGE; ++r) {
+    plan->cursor[r][threadIdx.x] = run;
+    run += plan->count[r][threadIdx.x];
+  }
+  if (threadIdx.x == 0) plan->offset[NPART] = total;
+}
+
+template <typename K, typename V, bool HAS_VV>
+__global__ void __launch_bounds__(PBT) k_part_scatter(const K* __restrict__ keys, const uint32_t* __restrict__ kvalid,
+                                                      const V* __restrict__ vals, const uint32_t* __restrict__ vvalid,
+                                                      int64_t n, PartPlan* plan, K* __restrict__ pkeys,
+                                                      V* __restrict__ pvals, uint8_t* __restrict__ pflags, int nrange)
+{
+  constexpr int ESZ = sizeof(K) > sizeof(V) ? sizeof(K) : sizeof(V);
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  char* s_buf       = smem;                                             // PTILE * ESZ
+  uint8_t* s_bin    = reinterpret_cast<uint8_t*>(smem + (size_t)PTILE * ESZ);  // PTILE
+  uint8_t* s_flag   = s_bin + PTILE;                                    // PTILE (HAS_VV)
+  uint32_t* s_cnt   = reinterpret_cast<uint32_t*>(s_flag + (HAS_VV ? PTILE : 0));  // NPART
+  uint32_t* s_start = s_cnt + NPART;                                    // NPART
+  unsigned long long* s_delta = reinterpret_cast<unsigned long long*>(s_start + NPART);  // NPART
+  uint32_t* s_scan  = reinterpret_cast<uint32_t*>(s_delta + NPART);     // 16
+  __shared__ uint32_t s_total;
+
+  const unsigned tid = threadIdx.x;
+  const int64_t tile = nrange == 1 ? (int64_t)blockIdx.x : xcd_swizzle(blockIdx.x, gridDim.x);
+  const int64_t rper = range_tiles(n);
+  const int range    = nrange == 1 ? 0 : ((rper > 0 && tile / rper < NRANGE - 1) ? (int)(tile / rper) : NRANGE - 1);
+  const int64_t base = tile * PTILE;
+  const int nvalid   = (int)((n - base < (int64_t)PTILE) ? (n - base) : (int64_t)PTILE);
+  if (tid < NPART) s_cnt[tid] = 0;
+  K key[PRPT];
+  V val[PRPT];
+  uint8_t vflag[PRPT];
+  bool live[PRPT];
+#pragma unroll
+  for (int j = 0; j < PRPT; ++j) {
+    const int idx   = j * PBT + (int)tid;
+    const int64_t i = base + idx;
+    live[j]         = idx < nvalid && (!kvalid || bit_is_set(kvalid, i));
+    key[j]          = (idx < nvalid) ? keys[i] : K(0);
+    val[j]          = (idx < nvalid) ? vals[i] : V(0);
+    vflag[j]        = HAS_VV ? (uint8_t)((idx < nvalid) && bit_is_set(vvalid, i)) : (uint8_t)1;
+  }
+  __syncthreads();
+  uint32_t rank[PRPT];
+  uint32_t part[PRPT];
+#pragma unroll
+  for (int j = 0; j < PRPT; ++j) {
+    part[j] = (uint32_t)(part_hash<K>(key[j]) >> 56);
+    rank[j] = live[j] ? atomicAdd(&s_cnt[part[j]], 1u) : 0u;
+  }
+  __syncthreads();
+  const uint32_t c  = (tid < NPART) ? s_cnt[tid] : 0u;
+  uint32_t total;
+  const uint32_t st = block_exclusive_scan<PBT>(c, 0u, SumOp(), s_scan, &total);
+  if (tid < NPART) {
+    s_start[tid] = st;
+    unsigned long long g = 0;
+    if (c) g = atomicAdd(&plan->cursor[range][tid], (unsigned long long)c);
+    s_delta[tid] = g - st;
+  }
+  if (tid == 0) s_total = total;
+  __syncthreads();
+  const int ntot = (int)s_total;
+  // ---- values (and flags, partition ids) through LDS
+  V* s_v = reinterpret_cast<V*>(s_buf);
+#pragma unroll
+  for (int j = 0; j < PRPT; ++j) {
+    if (live[j]) {
+      const uint32_t pos = s_start[part[j]] + rank[j];
+      s_v[pos]           = val[j];
+      s_bin[pos]         = (uint8_t)part[j];
+      if (HAS_VV) s_flag[pos] = vflag[j];
+    }
+  }
+  __syncthreads();
+#pragma unroll
+  for (int j = 0; j < PRPT; ++j) {
+    const int i = j * PBT + (int)tid;
+    if (i < ntot) {
+      const unsigned long long dst = s_delta[s_bin[i]] + (unsigned long long)i;
+      pvals[dst]                   = s_v[i];
+      if (HAS_VV) pflags[dst] = s_flag[i];
+    }
+  }
+  __syncthreads();
+  // ---- keys through the same buffer
+  K* s_k = reinterpret_cast<K*>(s_buf);
+#pragma unroll
+  for (int j = 0; j < PRPT; ++j) {
+    if (live[j]) s_k[s_start[part[j]] + rank[j]] = key[j];
+  }
+  __syncthreads();
+#pragma unroll
+  for (int j = 0; j < PRPT; ++j) {
+    const int i = j * PBT + (int)tid;
+    if (i < ntot) pkeys[s_delta[s_bin[i]] + (unsigned long long)i] = s_k[i];
+  }
+}
+
+template <typename K, bool HAS_VV>
+constexpr int lds_slots()
+{
+  // per slot: key + count_valid + sum + comp (+ count_all)
+  constexpr int slot = (int)sizeof(K) + 4 + 8 + 8 + (HAS_VV ? 4 : 0);
+  return (LDS_BUDGET / slot) / 256 * 256;
+}
+
+template <typename V, bool IS_FLOAT>
+struct LdsAcc;
+template <typename V>
+struct LdsAcc<V, true> {
+  static __device__ __forceinline__ void add(double* sum, double* comp, int g, V v)
+  {
+    const double x   = (double)v;
+    const double old = atomicAdd(&sum[g], x);  // ds_add_rtn_f64
+    const double s   = old + x;
+    const double bb  = s - old;
+    const double err = (old - (s - bb)) + (x - bb);
+    if (err != 0.0) atomicAdd(&comp[g], err);
+  }
+};
+template <typename V>
+struct LdsAcc<V, false> {
+  static __device__ __forceinline__ void add(double* sum, double*, int g, V v)
+  {
+    atomicAdd(reinterpret_cast<unsigned long long*>(sum) + g, (unsigned long long)(long long)v);
+  }
+};
+
+// merge one partially aggregated group into the global accumulators
+template <bool IS_FLOAT>
+__device__ __forceinline__ void global_merge(double* sum, double* comp, int64_t g, double psum, double pcomp)
+{
+  if (IS_FLOAT) {
+    const double old = atomicAdd(&sum[g], psum);
+    const double s   = old + psum;
+    const double bb  = s - old;
+    const double err = ((old - (s - bb)) + (psum - bb)) + pcomp;
+    if (err != 0.0) atomicAdd(&comp[g], err);
+  } else {
+    unsigned long long u;
+    __builtin_memcpy(&u, &psum, 8);
+    atomicAdd(reinterpret_cast<unsigned long long*>(sum) + g, u);
+  }
+}
+
+template <typename K, typename V, bool IS_FLOAT, bool HAS_VV>
+__global__ void __launch_bounds__(ABT) k_part_aggregate(const K* __restrict__ pkeys, const V* __restrict__ pvals,
+                                                        const uint8_t* __restrict__ pflags, const PartPlan* plan,
+                                                        int nsplit, unsigned long long* table, uint32_t log2cap,
+                                                        double* sum, double* comp, uint32_t* cnt_valid,
+                                                        uint32_t* cnt_all, GbState* st)
+{
+  constexpr int S     = lds_slots<K, HAS_VV>();
+  constexpr K EMPTYK  = K(~K(0));   // rows with this key use the dedicated slot S
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  double* l_sum    = reinterpret_cast<double*>(smem);            // S + 1
+  double* l_comp   = l_sum + (S + 1);                             // S + 1
+  K* l_key         = reinterpret_cast<K*>(l_comp + (S + 1));      // S + 1 (+1 pad)
+  uint32_t* l_cv   = reinterpret_cast<uint32_t*>(l_key + (S + 2));  // S + 1
+  uint32_t* l_ca   = l_cv + (S + 1);                              // S + 1 (HAS_VV)
+  __shared__ uint32_t s_nkeys;
+  __shared__ uint32_t s_special;
+
+  const unsigned tid = threadIdx.x;
+  for (int i = tid; i <= S; i += ABT) {
+    l_sum[i]  = 0.0;
+    l_comp[i] = 0.0;
+    l_key[i]  = EMPTYK;
+    l_cv[i]   = 0;
+    if (HAS_VV) l_ca[i] = 0;
+  }
+  if (tid == 0) {
+    s_nkeys   = 0;
+    s_special = 0;
+  }
+  __syncthreads();
+
+  const int part  = blockIdx.x / nsplit;
+  const int split = blockIdx.x % nsplit;
+  const unsigned long long p0 = plan->offset[part], p1 = plan->offset[part + 1];
+  const unsigned long long len = p1 - p0;
+  const unsigned long long per = (len + nsplit - 1) / nsplit;
+  const unsigned long long r0  = p0 + per * split < p1 ? p0 + per * split : p1;
+  const unsigned long long r1  = r0 + per < p1 ? r0 + per : p1;
+  constexpr uint32_t MAXKEYS = (uint32_t)(S - S / 8);  // stop inserting new keys above 87.5 % load
+
+  constexpr int U = 8;
+  for (unsigned long long i0 = r0 + tid; i0 < r1; i0 += (unsigned long long)ABT * U) {
+    K k[U];
+    V v[U];
+    uint8_t f[U];
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const unsigned long long i = i0 + (unsigned long long)u * ABT;
+      const bool in              = i < r1;
+      k[u]                       = in ? pkeys[i] : K(0);
+      v[u]                       = in ? pvals[i] : V(0);
+      f[u]                       = HAS_VV ? (in ? pflags[i] : (uint8_t)0) : (uint8_t)1;
+    }
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const unsigned long long i = i0 + (unsigned long long)u * ABT;
+      if (i >= r1) continue;
+      const K key = k[u];
+      int slot    = -1;
+      if (key == EMPTYK) {
+        slot      = S;
+        s_special = 1u;  // benign race: every writer stores 1
+      } else {
+        uint32_t h = (uint32_t)(((part_hash<K>(key) >> 24) & 0xFFFFFFFFull) * (uint64_t)S >> 32);
+        for (int probes = 0; probes < S; ++probes) {
+          K cur = l_key[h];
+          if (cur == EMPTYK) {
+            if (s_nkeys >= MAXKEYS) break;  // table (nearly) full: this row goes to the global table
+            cur = atomicCAS(&l_key[h], EMPTYK, key);
+            if (cur == EMPTYK) {
+              atomicAdd(&s_nkeys, 1u);
+              slot = (int)h;
+              break;
+            }
+          }
+          if (cur == key) {
+            slot = (int)h;
+            break;
+          }
+          h = (h + 1 == (uint32_t)S) ? 0u : h + 1;
+        }
+      }
+      if (slot >= 0) {
+        if (HAS_VV) atomicAdd(&l_ca[slot], 1u);
+        if (f[u]) {
+          LdsAcc<V, IS_FLOAT>::add(l_sum, l_comp, slot, v[u]);
+          atomicAdd(&l_cv[slot], 1u);
+        }
+      } else {
+        const int64_t g = find_or_insert<K>(table, log2cap, key, st);
+        if (g >= 0) {
+          if (cnt_all) atomicAdd(&cnt_all[g], 1u);
+          if (f[u]) {
+            Acc<V, IS_FLOAT>::add(sum, comp, g, v[u]);
+            atomicAdd(&cnt_valid[g], 1u);
+          }
+        }
+      }
+    }
+  }
+  __syncthreads();
+  // ---- merge this workgroup's groups into the global table
+  for (int i = tid; i <= S; i += ABT) {
+    const K key = l_key[i];
+    const bool occ = (i < S) ? (key != EMPTYK) : (s_special != 0u);
+    if (!occ) continue;
+    const int64_t g = find_or_insert<K>(table, log2cap, (i < S) ? key : EMPTYK, st);
+    if (g < 0) continue;
+    const uint32_t cv = l_cv[i];
+    if (cnt_all) atomicAdd(&cnt_all[g], HAS_VV ? l_ca[i] : cv);
+    if (cv) {
+      atomicAdd(&cnt_valid[g], cv);
+      global_merge<IS_FLOAT>(sum, comp, g, l_sum[i], l_comp[i]);
+    }
+  }
+}
+
 static inline uint32_t log2_cap(int64_t max_groups)
 {
   uint32_t lg = 6;
   while ((1ull << lg) < (unsigned long long)(max_groups < 1 ? 1 : max_groups) * 2ull) ++lg;
   return lg;
+}
+
+static int g_gb_algorithm = 0;  // 0 auto, 1 global-atomic table only, 2 partitioned whenever possible
+static int g_gb_nsplit    = 1;
+static int g_gb_nrange    = NRANGE;  // 1 = single cursor per partition (A/B measurement)
+constexpr int64_t PART_MIN_ROWS = 1 << 19;
+
+template <typename K, typename V, bool IS_FLOAT, bool HAS_VV>
+int launch_partitioned(const K* keys, const uint32_t* kvalid, const V* vals, const uint32_t* vvalid, int64_t n,
+                       PartPlan* plan, K* pkeys, V* pvals, uint8_t* pflags, unsigned long long* table, uint32_t lg,
+                       double* sum, double* comp, uint32_t* cv, uint32_t* ca, GbState* st, hipStream_t s)
+{
+  GX_HIP_TRY(hipMemsetAsync(plan, 0, sizeof(PartPlan), s));
+  int64_t hb = div_up(n, 256 * 8 * 4 * NRANGE);
+  if (hb > 256) hb = 256;
+  if (hb < 1) hb = 1;
+  hipLaunchKernelGGL((k_part_hist<K>), dim3((unsigned)(hb * NRANGE)), dim3(256), 0, s, keys, kvalid, n, plan, g_gb_nrange);
+  hipLaunchKernelGGL(k_part_offsets, dim3(1), dim3(NPART), 0, s, plan);
+  constexpr int ESZ      = sizeof(K) > sizeof(V) ? sizeof(K) : sizeof(V);
+  constexpr size_t lds_s = (size_t)PTILE * ESZ + PTILE + (HAS_VV ? PTILE : 0) + NPART * 4 * 2 + NPART * 8 + 64;
+  auto ks                = k_part_scatter<K, V, HAS_VV>;
+  constexpr int S        = lds_slots<K, HAS_VV>();
+  constexpr size_t lds_a = (size_t)(S + 1) * 16 + (size_t)(S + 2) * sizeof(K) + (size_t)(S + 1) * 4 * (HAS_VV ? 2 : 1);
+  auto ka                = k_part_aggregate<K, V, IS_FLOAT, HAS_VV>;
+  static bool attr_set   = false;
+  if (!attr_set) {
+    GX_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(ks), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_s));
+    GX_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(ka), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_a));
+    attr_set = true;
+  }
+  hipLaunchKernelGGL(ks, dim3((unsigned)div_up(n, PTILE)), dim3(PBT), lds_s, s, keys, kvalid, vals, vvalid, n, plan,
+                     pkeys, pvals, pflags, g_gb_nrange);
+  const int nsplit = g_gb_nsplit;
+  hipLaunchKernelGGL(ka, dim3((unsigned)(NPART * nsplit)), dim3(ABT), lds_a, s, pkeys, pvals, pflags, plan, nsplit,
+                     table, lg, sum, comp, cv, ca, st);
+  GX_LAUNCH_CHECK();
+  return 0;
 }
 
 template <typename K, typename V, bool IS_FLOAT>
@@ -170,6 +564,9 @@ int groupby_impl(const void* keys, const uint32_t* kvalid, const void* vals, con
 {
   const uint32_t lg  = log2_cap(max_groups);
   const uint64_t cap = 1ull << lg;
+  // the partitioned path needs a values column and pays off only on large inputs
+  const bool partitioned = vals != nullptr && g_gb_algorithm != 1 && n > 0 &&
+                           (g_gb_algorithm == 2 || n >= PART_MIN_ROWS);
   Carver c(tmp);
   GbState* st               = c.take<GbState>(1);
   unsigned long long* table = c.take<unsigned long long>(cap);
@@ -179,6 +576,11 @@ int groupby_impl(const void* keys, const uint32_t* kvalid, const void* vals, con
   uint32_t* ca              = c.take<uint32_t>(cap + 1);
   uint32_t* pos             = c.take<uint32_t>(cap + 1);
   uint32_t* partials        = c.take<uint32_t>(scan::partials_count(cap + 1));
+  // the size query cannot see `vals` (callers pass the same arguments, so it can): keep both layouts equal
+  PartPlan* plan  = c.take<PartPlan>(1);
+  K* pkeys        = partitioned ? c.take<K>((size_t)n) : nullptr;
+  V* pvals        = partitioned ? c.take<V>((size_t)n) : nullptr;
+  uint8_t* pflags = (partitioned && vvalid) ? c.take<uint8_t>((size_t)n) : nullptr;
   if (!tmp) {
     *tmp_bytes = c.total();
     return 0;
@@ -186,7 +588,18 @@ int groupby_impl(const void* keys, const uint32_t* kvalid, const void* vals, con
   if (*tmp_bytes < c.total()) return GX_ETMP;
   // one memset covers state, table and accumulators (they are contiguous up to `pos`)
   GX_HIP_TRY(hipMemsetAsync(tmp, 0, (size_t)(reinterpret_cast<char*>(pos) - static_cast<char*>(tmp)), s));
-  if (n > 0) {
+  if (partitioned) {
+    int rc;
+    if (vvalid)
+      rc = launch_partitioned<K, V, IS_FLOAT, true>(static_cast<const K*>(keys), kvalid, static_cast<const V*>(vals),
+                                                    vvalid, n, plan, pkeys, pvals, pflags, table, lg, sum, comp, cv,
+                                                    out_ca ? ca : nullptr, st, s);
+    else
+      rc = launch_partitioned<K, V, IS_FLOAT, false>(static_cast<const K*>(keys), kvalid, static_cast<const V*>(vals),
+                                                     vvalid, n, plan, pkeys, pvals, pflags, table, lg, sum, comp, cv,
+                                                     out_ca ? ca : nullptr, st, s);
+    if (rc) return rc;
+  } else if (n > 0) {
     int64_t blocks = div_up(n, GBT * 8);
     if (blocks > 256 * 16) blocks = 256 * 16;
     hipLaunchKernelGGL((k_aggregate<K, V, IS_FLOAT>), dim3((unsigned)blocks), dim3(GBT), 0, s,
@@ -252,6 +665,14 @@ int gx_groupby_sum_count(int key_dtype, const void* keys, const uint32_t* keys_v
                                             out_sum, out_count_valid, out_count_all, ngroups_dev, tmp, tmp_bytes, s);
     default: return GX_EDTYPE;
   }
+}
+
+void gx_groupby_set_algorithm(int algo, int nsplit)
+{
+  gx::gb::g_gb_nrange    = (algo & 16) ? 1 : gx::gb::NRANGE;  // +16: single-cursor scatter (A/B measurement)
+  algo &= 15;
+  gx::gb::g_gb_algorithm = (algo >= 0 && algo <= 2) ? algo : 0;
+  gx::gb::g_gb_nsplit    = (nsplit >= 1 && nsplit <= 16) ? nsplit : 1;
 }
 
 }  // extern "C"

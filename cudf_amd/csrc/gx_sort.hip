@@ -133,6 +133,7 @@ struct PassArgs {
   int64_t n;
   int64_t ntiles;
   int pass;
+  int order_mode;  // experiment knob for the LBW == 0 kernel: 0 XCD-swizzled blockIdx, 1 plain blockIdx, 2 ticket
   uint64_t desc_mask;
 };
 
@@ -143,9 +144,15 @@ __device__ __forceinline__ unsigned long long pack_status(unsigned flag, unsigne
   return ((unsigned long long)flag << 62) | ((unsigned long long)epoch << 32) | value;
 }
 
-template <typename KeyT, int KIND, bool HAS_VAL, int KPT, bool LOOKBACK>
+// LBW: look-back window (0 = no look-back: offsets were precomputed by algorithm 1).  A thread owns
+// one bin and inspects LBW predecessor tiles per round with LBW independent loads in flight: a
+// status hop costs a memory-side round trip (~1.5-2.5 us under streaming load, the per-XCD L2s do
+// not share lines), and a one-tile-per-hop walk settles into a regime where every tile walks
+// ~10 predecessors (DESIGN.md "look-back regime"); the window bounds the walk to ~1-2 rounds.
+template <typename KeyT, int KIND, bool HAS_VAL, int KPT, int LBW>
 __global__ void __launch_bounds__(BT) k_radix_pass(PassArgs a)
 {
+  constexpr bool LOOKBACK = LBW > 0;
   constexpr int TILE = BT * KPT;
   extern __shared__ __attribute__((aligned(16))) char smem[];
   KeyT* s_keys       = reinterpret_cast<KeyT*>(smem);
@@ -176,8 +183,12 @@ __global__ void __launch_bounds__(BT) k_radix_pass(PassArgs a)
     if (tid == 0) s_misc[0] = atomicAdd(&plan->tickets[pass], 1u);
     __syncthreads();
     tile = s_misc[0];
+  } else if (a.order_mode == 2) {
+    if (tid == 0) s_misc[0] = atomicAdd(&plan->tickets[pass], 1u);
+    __syncthreads();
+    tile = s_misc[0];
   } else {
-    tile = xcd_swizzle(blockIdx.x, gridDim.x);
+    tile = a.order_mode == 1 ? (int64_t)blockIdx.x : xcd_swizzle(blockIdx.x, gridDim.x);
   }
   const int64_t base = tile * TILE;
   const int nvalid   = (int)((a.n - base < (int64_t)TILE) ? (a.n - base) : (int64_t)TILE);
@@ -270,21 +281,34 @@ __global__ void __launch_bounds__(BT) k_radix_pass(PassArgs a)
       uint32_t prefix = 0;
       if (tile > 0) {
         int64_t p = tile - 1;
-        for (;;) {
-          unsigned long long v = load_agent_u64(&a.status[p * BINS + tid]);
-          uint32_t spins       = 0;
-          while ((v >> 62) == 0 || ((unsigned)(v >> 32) & 0xFFu) != epoch) {
-            if (++spins > SPIN_LIMIT) {
-              atomicExch(&plan->status, 1);
-              v = pack_status(2u, epoch, 0u);
-              break;
-            }
-            __builtin_amdgcn_s_sleep(2);
-            v = load_agent_u64(&a.status[p * BINS + tid]);
+        bool done = false;
+        while (!done) {
+          constexpr int WN = LBW > 0 ? LBW : 1;
+          unsigned long long v[WN];
+#pragma unroll
+          for (int k = 0; k < LBW; ++k) {
+            const int64_t q = p - k;
+            v[k]            = (q >= 0) ? load_agent_u64(&a.status[q * BINS + tid]) : pack_status(2u, epoch, 0u);
           }
-          prefix += (uint32_t)v;
-          if ((v >> 62) == 2u) break;
-          --p;
+#pragma unroll
+          for (int k = 0; k < LBW; ++k) {
+            if (!done) {
+              unsigned long long x = v[k];
+              uint32_t spins       = 0;
+              while ((x >> 62) == 0 || ((unsigned)(x >> 32) & 0xFFu) != epoch) {
+                if (++spins > SPIN_LIMIT) {
+                  atomicExch(&plan->status, 1);
+                  x = pack_status(2u, epoch, 0u);
+                  break;
+                }
+                __builtin_amdgcn_s_sleep(2);
+                x = load_agent_u64(&a.status[(p - k) * BINS + tid]);
+              }
+              prefix += (uint32_t)x;
+              if ((x >> 62) == 2u) done = true;
+            }
+          }
+          p -= LBW;
         }
         store_agent_u64(&a.status[tile * BINS + tid], pack_status(2u, epoch, prefix + pub_count));
       }
@@ -397,6 +421,7 @@ __global__ void __launch_bounds__(256) k_reverse_nan_block(KeyT* keys, uint32_t*
 }
 
 static int g_algorithm = 0;
+static int g_order_mode = 0;
 
 // optional per-launch timing with HIP events on the caller's stream (bench.py's roofline leg)
 struct Profile {
@@ -440,7 +465,7 @@ int sort_impl(const void* keys_in, void* keys_out, const int32_t* vals_in, int32
   unsigned long long* status = nullptr;
   uint32_t* tile_hist        = nullptr;
   uint32_t* partials         = nullptr;
-  if (algo == 0) {
+  if (algo != 1) {
     status = c.take<unsigned long long>((size_t)ntiles * BINS);
   } else {
     tile_hist = c.take<uint32_t>((size_t)ntiles * BINS);
@@ -459,7 +484,7 @@ int sort_impl(const void* keys_in, void* keys_out, const int32_t* vals_in, int32
 
   GX_HIP_TRY(hipMemsetAsync(plan, 0, sizeof(SortPlan), stream));
   if (n == 0) return 0;
-  if (algo == 0) GX_HIP_TRY(hipMemsetAsync(status, 0, (size_t)ntiles * BINS * sizeof(unsigned long long), stream));
+  if (algo != 1) GX_HIP_TRY(hipMemsetAsync(status, 0, (size_t)ntiles * BINS * sizeof(unsigned long long), stream));
 
   const KeyT desc_mask = descending ? KeyT(~KeyT(0)) : KeyT(0);
   g_prof.npass = NPASS;
@@ -487,13 +512,16 @@ int sort_impl(const void* keys_in, void* keys_out, const int32_t* vals_in, int32
   a.n         = n;
   a.ntiles    = ntiles;
   a.desc_mask = (uint64_t)desc_mask;
+  a.order_mode = g_order_mode;
 
   constexpr size_t lds = pass_lds_bytes<KeyT, HAS_VAL, KPT>();
-  auto kern_lb         = k_radix_pass<KeyT, KIND, HAS_VAL, KPT, true>;
-  auto kern_pre        = k_radix_pass<KeyT, KIND, HAS_VAL, KPT, false>;
+  auto kern_lb         = (algo == 2) ? k_radix_pass<KeyT, KIND, HAS_VAL, KPT, 1> : k_radix_pass<KeyT, KIND, HAS_VAL, KPT, 8>;
+  auto kern_pre        = k_radix_pass<KeyT, KIND, HAS_VAL, KPT, 0>;
   static bool attr_set = false;  // per template instantiation
   if (!attr_set) {
-    GX_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(kern_lb),
+    GX_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(k_radix_pass<KeyT, KIND, HAS_VAL, KPT, 8>),
+                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    GX_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(k_radix_pass<KeyT, KIND, HAS_VAL, KPT, 1>),
                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     GX_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(kern_pre),
                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
@@ -502,7 +530,7 @@ int sort_impl(const void* keys_in, void* keys_out, const int32_t* vals_in, int32
   for (int pass = 0; pass < NPASS; ++pass) {
     a.pass = pass;
     prof_mark(2 + 2 * pass, stream);
-    if (algo == 0) {
+    if (algo != 1) {
       hipLaunchKernelGGL(kern_lb, dim3((unsigned)ntiles), dim3(BT), lds, stream, a);
     } else {
       hipLaunchKernelGGL((k_tile_hist<KeyT, KIND, KPT>), dim3((unsigned)ntiles), dim3(BT), 0, stream, a, tile_hist);
@@ -646,7 +674,13 @@ int gx_sorted_order(int dtype, const void* keys, const uint32_t* valid, int64_t 
   }
 }
 
-void gx_sort_set_algorithm(int algo) { gx::sort::g_algorithm = algo ? 1 : 0; }
+void gx_sort_set_algorithm(int algo)
+{
+  // algo 1 + 16*m: three-kernel passes with tile order m (measurement only: 1 plain blockIdx, 2 ticket)
+  gx::sort::g_order_mode = (algo >> 4) & 3;
+  algo &= 15;
+  gx::sort::g_algorithm = (algo >= 0 && algo <= 2) ? algo : 0;
+}
 
 int gx_sort_profile(int enable)
 {

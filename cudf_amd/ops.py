@@ -317,11 +317,11 @@ def scan(col: Column, op: str = "sum", inclusive: bool = True, null_include: boo
     out = Column.empty(col.dtype, col.size)
     valid = col.mask_ptr if col.has_nulls() else None
     _run(_lib.gx_scan, col.gx, col.data_ptr, valid, col.size, _OPS[op], int(inclusive), out.data_ptr)
-    if col.has_nulls():
+    if col.mask is not None:  # nullable input -> nullable output, even when no bit happens to be 0
         if null_include:  # everything from the first null on is null (mask_scan :36-61)
             pos = _dev_i64()
             L.check(_lib.gx_bitmask_first_unset(col.mask_ptr, col.size, ptr(pos), stream_ptr()), "first_unset")
-            first = min(col.size, int(pos.item()) + (0 if inclusive else 1))
+            first = min(col.size, int(pos.item()) + (0 if inclusive else 1)) if col.has_nulls() else col.size
             out.mask = torch.zeros(bitmask_words(col.size), dtype=torch.int32, device="cuda")
             L.check(_lib.gx_bitmask_set(ptr(out.mask), 0, first, 1, stream_ptr()), "bitmask_set")
             out.null_count = col.size - first

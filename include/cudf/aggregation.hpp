@@ -1,0 +1,82 @@
+// cudf/aggregation.hpp -- aggregation descriptors and their factories
+// (reference: cpp/include/cudf/aggregation.hpp:73-330).  The Kind enumerators keep the reference's
+// order so integer values stay interchangeable; the hot path implements SUM, PRODUCT, MIN, MAX,
+// COUNT_VALID, COUNT_ALL and MEAN (others throw cudf::logic_error where they are used).
+#pragma once
+#include <cudf/types.hpp>
+#include <cudf/utilities/error.hpp>
+
+#include <memory>
+
+namespace cudf {
+
+class aggregation {
+ public:
+  enum Kind {
+    SUM, SUM_WITH_OVERFLOW, PRODUCT, MIN, MAX, COUNT_VALID, COUNT_ALL, ANY, ALL, SUM_OF_SQUARES, MEAN, M2, VARIANCE,
+    STD, MEDIAN, QUANTILE, ARGMAX, ARGMIN, NUNIQUE, NTH_ELEMENT, ROW_NUMBER, EWMA, RANK, COLLECT_LIST, COLLECT_SET,
+    LEAD, LAG, PTX, CUDA, HOST_UDF, MERGE_LISTS, MERGE_SETS, MERGE_M2, COVARIANCE, CORRELATION, TDIGEST,
+    MERGE_TDIGEST, HISTOGRAM, MERGE_HISTOGRAM, BITWISE_AGG, TOP_K, INVALID
+  };
+
+  aggregation() : kind{Kind::INVALID} { CUDF_FAIL("No-parameter aggregation constructor should never be called"); }
+  explicit aggregation(aggregation::Kind a) : kind{a} {}
+  virtual ~aggregation() = default;
+  Kind kind;
+  [[nodiscard]] virtual bool is_equal(aggregation const& other) const { return kind == other.kind; }
+  [[nodiscard]] virtual std::size_t do_hash() const { return static_cast<std::size_t>(kind); }
+  [[nodiscard]] virtual std::unique_ptr<aggregation> clone() const { return std::make_unique<aggregation>(kind); }
+};
+
+class rolling_aggregation : public virtual aggregation {};
+class groupby_aggregation : public virtual aggregation {};
+class groupby_scan_aggregation : public virtual aggregation {};
+class reduce_aggregation : public virtual aggregation {};
+class scan_aggregation : public virtual aggregation {};
+class segmented_reduce_aggregation : public virtual aggregation {};
+
+namespace detail {
+// one concrete type usable through every API-facing base (the reference derives one class per
+// kind from the bases it is legal for: cpp/include/cudf/detail/aggregation/aggregation.hpp)
+class simple_aggregation final : public groupby_aggregation,
+                                 public groupby_scan_aggregation,
+                                 public reduce_aggregation,
+                                 public scan_aggregation,
+                                 public segmented_reduce_aggregation,
+                                 public rolling_aggregation {
+ public:
+  explicit simple_aggregation(aggregation::Kind k) : aggregation(k) {}
+  [[nodiscard]] std::unique_ptr<aggregation> clone() const override
+  {
+    return std::unique_ptr<aggregation>(static_cast<groupby_aggregation*>(new simple_aggregation(kind)));
+  }
+};
+template <typename Base>
+std::unique_ptr<Base> make_simple(aggregation::Kind k)
+{
+  return std::unique_ptr<Base>(static_cast<Base*>(new simple_aggregation(k)));
+}
+template <>
+inline std::unique_ptr<aggregation> make_simple<aggregation>(aggregation::Kind k)
+{
+  return std::unique_ptr<aggregation>(static_cast<groupby_aggregation*>(new simple_aggregation(k)));
+}
+}  // namespace detail
+
+template <typename Base = aggregation>
+std::unique_ptr<Base> make_sum_aggregation() { return detail::make_simple<Base>(aggregation::SUM); }
+template <typename Base = aggregation>
+std::unique_ptr<Base> make_product_aggregation() { return detail::make_simple<Base>(aggregation::PRODUCT); }
+template <typename Base = aggregation>
+std::unique_ptr<Base> make_min_aggregation() { return detail::make_simple<Base>(aggregation::MIN); }
+template <typename Base = aggregation>
+std::unique_ptr<Base> make_max_aggregation() { return detail::make_simple<Base>(aggregation::MAX); }
+template <typename Base = aggregation>
+std::unique_ptr<Base> make_count_aggregation(null_policy null_handling = null_policy::EXCLUDE)
+{
+  return detail::make_simple<Base>(null_handling == null_policy::INCLUDE ? aggregation::COUNT_ALL : aggregation::COUNT_VALID);
+}
+template <typename Base = aggregation>
+std::unique_ptr<Base> make_mean_aggregation() { return detail::make_simple<Base>(aggregation::MEAN); }
+
+}  // namespace cudf

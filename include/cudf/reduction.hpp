@@ -1,0 +1,27 @@
+// cudf/reduction.hpp -- column reduce / scan (reference: cpp/include/cudf/reduction.hpp:60-65,
+// 124-130,229-235; impl cpp/src/reductions/reductions.cpp:484-507, scan/scan.cpp:13-54).
+#pragma once
+#include <cudf/aggregation.hpp>
+#include <cudf/column/column.hpp>
+#include <cudf/scalar/scalar.hpp>
+#include <cudf/types.hpp>
+
+#include <memory>
+
+namespace cudf {
+
+// column -> scalar of `output_type`; nulls are skipped; the result is invalid when there is no
+// valid element.  SUM/PRODUCT compute in output_type (INT64, UINT64 or FLOAT64 here), MIN/MAX
+// require output_type == col.type().
+std::unique_ptr<scalar> reduce(column_view const& col, reduce_aggregation const& agg, data_type output_type,
+                               rmm::cuda_stream_view stream      = cudf::get_default_stream(),
+                               rmm::device_async_resource_ref mr = cudf::get_current_device_resource_ref());
+
+// prefix SUM / MIN / MAX / PRODUCT; output type == input type (integers wrap).
+// null_policy::EXCLUDE: nulls are skipped and stay null; INCLUDE: the first null poisons the rest.
+std::unique_ptr<column> scan(column_view const& input, scan_aggregation const& agg, scan_type inclusive,
+                             null_policy null_handling         = null_policy::EXCLUDE,
+                             rmm::cuda_stream_view stream      = cudf::get_default_stream(),
+                             rmm::device_async_resource_ref mr = cudf::get_current_device_resource_ref());
+
+}  // namespace cudf

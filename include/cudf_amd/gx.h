@@ -107,8 +107,10 @@ int gx_sorted_order(int dtype, const void* keys, const uint32_t* valid, int64_t 
  * (0 = ok).  Synchronises `stream`.  A non-zero status means a look-back spin timed out. */
 int gx_sort_status(const void* tmp, int* status_host, gx_stream_t stream);
 
-/* Tuning / A-B knob (process-wide): 0 = onesweep (decoupled look-back, default),
- * 1 = three-kernel passes (tile histogram + scan + scatter; no inter-workgroup communication). */
+/* Tuning / A-B knob (process-wide): 0 = onesweep (decoupled look-back, 8-tile look-back window,
+ * default), 1 = three-kernel passes (tile histogram + scan + scatter; no inter-workgroup
+ * communication), 2 = onesweep with a one-tile-per-hop look-back (the textbook form; slower on
+ * this chip, kept for A/B measurements). */
 void gx_sort_set_algorithm(int algo);
 
 /* Measurement hooks (bench.py's roofline leg): when enabled, every sort records HIP events on
@@ -204,6 +206,12 @@ int gx_groupby_sum_count(int key_dtype, const void* keys, const uint32_t* keys_v
                          int64_t max_groups, void* out_keys, void* out_sum /* f64 or i64 */,
                          int32_t* out_count_valid, int32_t* out_count_all, int64_t* ngroups_dev,
                          void* tmp, size_t* tmp_bytes, gx_stream_t stream);
+
+/* Tuning / A-B knob (process-wide).  algo: 0 = auto (hash-partition rows into 256 LDS-sized
+ * partitions and aggregate each in one workgroup's LDS when n >= 2^19, else the global-atomic
+ * table), 1 = global-atomic table only, 2 = partitioned for every n > 0.  nsplit: workgroups per
+ * partition in the LDS aggregation kernel (1..16). */
+void gx_groupby_set_algorithm(int algo, int nsplit);
 
 /* Segmented inclusive scan over sorted group labels: replaces thrust::inclusive_scan_by_key at
  * src/groupby/sort/group_scan_util.cuh:109-130 (groupby::scan SUM/MIN/MAX).  keys are the

@@ -554,7 +554,7 @@ def scan(values: np.ndarray, op: str = "sum", inclusive: bool = True, valid=None
     if inclusive:
         out = inc
     else:
-        out = np.concatenate([[ident], inc[:-1]]).astype(dt) if n else inc
+        out = np.concatenate([np.array([ident], dt), inc[:-1]]) if n else inc  # typed identity: no float64 promotion
     if null_include:
         first_null = int(np.argmin(m)) if not m.all() else n
         pos = min(n, first_null + (0 if inclusive else 1))

@@ -122,9 +122,19 @@ def test_join_large_properties(gx):
     assert int(torch.unique(li).numel()) == expected  # each probe row at most once
 
 
+@pytest.fixture(params=[1, 2], ids=["global_table", "lds_partitioned"])
+def gb_algo(request):
+    """Both groupby kernels families must give the same answers: 1 = global-atomic table,
+    2 = hash-partition + per-partition LDS tables (forced for every n > 0)."""
+    from cudf_amd import _lib
+    _lib.lib.gx_groupby_set_algorithm(request.param, 1)
+    yield request.param
+    _lib.lib.gx_groupby_set_algorithm(0, 1)
+
+
 @pytest.mark.parametrize("vdtype", ["float64", "float32", "int32", "int64"])
 @pytest.mark.parametrize("kdtype", ["int32", "int64"])
-def test_groupby_sum_count_matches_oracle(gx, kdtype, vdtype):
+def test_groupby_sum_count_matches_oracle(gx, kdtype, vdtype, gb_algo):
     Column, ops = gx
     rng = np.random.default_rng(4)
     for n, g in [(0, 1), (1, 1), (1000, 7), (200_000, 1000), (300_000, 150_000)]:
@@ -156,10 +166,51 @@ def test_groupby_sum_count_matches_oracle(gx, kdtype, vdtype):
             np.testing.assert_array_equal(got[ev], es[ev])
 
 
+@pytest.mark.parametrize("nsplit", [1, 3])
+@pytest.mark.parametrize("nulls", [False, True])
+def test_groupby_partitioned_large(gx, nulls, nsplit):
+    """The auto path at sizes where the LDS-partitioned kernels run (n >= 2^19): few groups (every
+    partition fits its LDS table), ~8k groups per partition (LDS tables fill up: rows spill to the
+    global table and the partial sums merge), the all-ones key (dedicated LDS slot) and a hot key."""
+    Column, ops = gx
+    from cudf_amd import _lib
+    _lib.lib.gx_groupby_set_algorithm(0, nsplit)
+    try:
+        rng = np.random.default_rng(11)
+        for n, g, kdtype in [(1_500_000, 50_000, "int32"), (2_500_000, 2_000_000, "int32"), (1_200_000, 300_000, "int64")]:
+            keys = rng.integers(-g // 2, g // 2, n).astype(kdtype)
+            keys[::97] = -1
+            keys[5::3] = 12345 if n < 2_000_000 else keys[5::3]
+            vals = rng.random(n) * 2000.0 - 700.0
+            kv = (rng.random(n) > 0.03) if nulls else None
+            vv = (rng.random(n) > 0.15) if nulls else None
+            k, s, cv, ca = ops.groupby_sum_count(Column.from_numpy(keys, kv), Column.from_numpy(vals, vv),
+                                                 max_groups_hint=1 << 21)
+            o = np.argsort(k.to_numpy(), kind="stable")
+            ek, res = orc.groupby_agg(keys, vals, ["sum", "count_valid", "count_all"], kv, vv)
+            np.testing.assert_array_equal(k.to_numpy()[o], ek)
+            np.testing.assert_array_equal(cv.to_numpy()[o], res["count_valid"][0])
+            np.testing.assert_array_equal(ca.to_numpy()[o], res["count_all"][0])
+            es, ev = res["sum"]
+            assert np.all(orc.ulp_diff(s.to_numpy()[o][ev], es[ev]) <= 1)
+        # integer values: exact, wrapping int64 sums
+        n = 1_000_000
+        keys = rng.integers(0, 70_000, n).astype(np.int32)
+        vals = rng.integers(-2**62, 2**62, n).astype(np.int64)
+        k, s, cv, ca = ops.groupby_sum_count(Column.from_numpy(keys), Column.from_numpy(vals))
+        o = np.argsort(k.to_numpy(), kind="stable")
+        ek, res = orc.groupby_agg(keys, vals, ["sum", "count_valid"])
+        np.testing.assert_array_equal(k.to_numpy()[o], ek)
+        np.testing.assert_array_equal(s.to_numpy()[o], res["sum"][0])
+        np.testing.assert_array_equal(cv.to_numpy()[o], res["count_valid"][0])
+    finally:
+        _lib.lib.gx_groupby_set_algorithm(0, 1)
+
+
 @pytest.mark.parametrize("vdtype", ["int32", "int64", "float64"])
 @pytest.mark.parametrize("case", [c for c in gv.GROUPBY if c["agg"] in ("sum", "count_valid", "count_all", "mean")],
                          ids=lambda c: c["name"])
-def test_reference_golden_groupby(gx, case, vdtype):
+def test_reference_golden_groupby(gx, case, vdtype, gb_algo):
     Column, ops = gx
     vdtype = case.get("vals_dtype", vdtype)
     keys, km = gv.col(case["keys"], "int32", case.get("keys_valid"))

@@ -39,7 +39,7 @@ DTYPES = ["int8", "uint8", "int16", "uint16", "int32", "uint32", "int64", "uint6
 SIZES = [0, 1, 2, 63, 64, 65, 1000, 8191, 8192, 8193, 100_003, 1_000_003]
 
 
-@pytest.mark.parametrize("algo", [0, 1])
+@pytest.mark.parametrize("algo", [0, 1, 2])
 @pytest.mark.parametrize("dtype", DTYPES)
 def test_sort_keys_matches_oracle(gx, dtype, algo):
     Column, ops = gx
@@ -58,7 +58,7 @@ def test_sort_keys_matches_oracle(gx, dtype, algo):
         _lib.lib.gx_sort_set_algorithm(0)
 
 
-@pytest.mark.parametrize("algo", [0, 1])
+@pytest.mark.parametrize("algo", [0, 1, 2])
 @pytest.mark.parametrize("dtype", ["int32", "int64", "uint64", "float32", "float64", "int8", "uint16"])
 def test_sorted_order_matches_oracle(gx, dtype, algo):
     Column, ops = gx
