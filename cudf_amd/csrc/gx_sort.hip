@@ -35,6 +35,7 @@ struct SortPlan {
   int32_t pass_src[MAX_PASSES];  // buffer selector: 0 = input, 1 = output (A), 2 = scratch (B)
   int32_t pass_dst[MAX_PASSES];
   uint32_t tickets[MAX_PASSES];
+  uint32_t pool_next[MAX_PASSES][8];  // persistent kernel: takes per XCD pool
   int32_t num_active;
   int32_t status;  // 0 ok, 1 look-back spin timed out
 };
@@ -130,6 +131,8 @@ struct PassArgs {
   SortPlan* plan;
   unsigned long long* status;  // [ntiles][256] look-back granules (algorithm 0)
   const uint32_t* tile_off;    // [256][ntiles] absolute offsets (algorithm 1)
+  uint32_t* batch_base;        // [MAX_PASSES][8][nbatch] first ticket of a pool batch, +1 (0 = unpublished)
+  int64_t nbatch;
   int64_t n;
   int64_t ntiles;
   int pass;
@@ -144,15 +147,75 @@ __device__ __forceinline__ unsigned long long pack_status(unsigned flag, unsigne
   return ((unsigned long long)flag << 62) | ((unsigned long long)epoch << 32) | value;
 }
 
+// XCD id of the executing CU (HW_REG_XCC_ID, bits 3:0).  Used for L2 affinity only.
+__device__ __forceinline__ unsigned xcc_id() { return __builtin_amdgcn_s_getreg(20 | (0 << 6) | (3 << 11)) & 7u; }
+
+typedef __attribute__((address_space(1))) unsigned int gu32_t;
+__device__ __forceinline__ void store_agent_u32(uint32_t* p, uint32_t v)
+{
+  __hip_atomic_store((gu32_t*)p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ uint32_t load_agent_u32(const uint32_t* p)
+{
+  return __hip_atomic_load((gu32_t*)p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
+constexpr int POOL_BATCH = 8;  // consecutive tickets an XCD pool reserves at a time
+
+// Tile hand-out of the persistent kernel.  Tickets are still a single global sequence (so the
+// look-back's forward-progress argument is the usual one: a tile is owned by a running workgroup
+// before any later ticket is), but they are drawn in batches of POOL_BATCH by per-XCD pools:
+// the k-th take of pool x (atomicAdd on pool_next[x]) is ticket base[x][k / B] + k % B, where the
+// take with k % B == 0 reserves the batch from the global counter -- after the previous batch of the
+// same pool has been published, so that a pool hands out increasing tickets -- and publishes its
+// base.  Neighbouring tiles therefore run on the same XCD at about the same time, and the partial
+// 128-B lines where their output runs meet are merged in that XCD's L2 instead of leaving two
+// non-coherent L2s as masked partial writes (measured on the scatter alone: 3.5 ms per 1e9-key pass
+// with XCD-contiguous tiles, 4.0 ms with arrival-order tickets, 5.7 ms with tiles dealt round-robin).
+// A take never waits on tile processing: the first take of a batch reserves and publishes at once
+// (it waits only for the previous batch's publication, which is equally prompt), and the others
+// read the published base when they need the ticket.  A workgroup resolves its pending take after
+// it has finished its current tile, so no workgroup ever holds an unprocessed tile while it waits.
+__device__ __forceinline__ uint32_t pool_take(const PassArgs& a, SortPlan* plan, int pass, unsigned xcc)
+{
+  const uint32_t k = atomicAdd(&plan->pool_next[pass][xcc], 1u);
+  if (k % POOL_BATCH == 0) {
+    const uint32_t j = k / POOL_BATCH;
+    uint32_t* slot   = a.batch_base + ((int64_t)pass * 8 + xcc) * a.nbatch + j;
+    uint32_t spins   = 0;
+    if (j > 0) {
+      while (load_agent_u32(slot - 1) == 0u) {
+        if (++spins > SPIN_LIMIT) { atomicExch(&plan->status, 2); break; }
+        __builtin_amdgcn_s_sleep(1);
+      }
+    }
+    store_agent_u32(slot, atomicAdd(&plan->tickets[pass], (uint32_t)POOL_BATCH) + 1u);
+  }
+  return k;
+}
+// the ticket of take k, or -1 when the sequence is exhausted (tickets only grow: once past the
+// end, every later take of every pool is too)
+__device__ __forceinline__ int64_t pool_resolve(const PassArgs& a, SortPlan* plan, int pass, unsigned xcc, uint32_t k)
+{
+  const uint32_t j = k / POOL_BATCH, wi = k % POOL_BATCH;
+  const uint32_t* slot = a.batch_base + ((int64_t)pass * 8 + xcc) * a.nbatch + j;
+  uint32_t base1, spins = 0;
+  while ((base1 = load_agent_u32(slot)) == 0u) {
+    if (++spins > SPIN_LIMIT) { atomicExch(&plan->status, 2); return -1; }
+    __builtin_amdgcn_s_sleep(1);
+  }
+  const int64_t t = (int64_t)(base1 - 1u) + wi;
+  return t < a.ntiles ? t : -1;
+}
+
 // LBW: look-back window (0 = no look-back: offsets were precomputed by algorithm 1).  A thread owns
-// one bin and inspects LBW predecessor tiles per round with LBW independent loads in flight: a
-// status hop costs a memory-side round trip (~1.5-2.5 us under streaming load, the per-XCD L2s do
-// not share lines), and a one-tile-per-hop walk settles into a regime where every tile walks
-// ~10 predecessors (DESIGN.md "look-back regime"); the window bounds the walk to ~1-2 rounds.
-template <typename KeyT, int KIND, bool HAS_VAL, int KPT, int LBW>
-__global__ void __launch_bounds__(BT) k_radix_pass(PassArgs a)
+// one bin and inspects LBW predecessor tiles per round with LBW independent loads in flight.
+// PERSIST: workgroups loop over tiles handed out by pool_take/pool_resolve (2 workgroups per CU).
+template <typename KeyT, int KIND, bool HAS_VAL, int KPT, int LBW, bool PERSIST>
+__global__ void __launch_bounds__(BT, 4) k_radix_pass(PassArgs a)
 {
   constexpr bool LOOKBACK = LBW > 0;
+  static_assert(!PERSIST || LOOKBACK, "the persistent kernel is the look-back kernel");
   constexpr int TILE = BT * KPT;
   extern __shared__ __attribute__((aligned(16))) char smem[];
   KeyT* s_keys       = reinterpret_cast<KeyT*>(smem);
@@ -178,18 +241,27 @@ __global__ void __launch_bounds__(BT) k_radix_pass(PassArgs a)
   const unsigned w       = tid / GX_WAVE;
   const unsigned epoch   = (unsigned)pass + 1u;
 
+  const unsigned xcc = PERSIST ? xcc_id() : 0u;
+  uint32_t k_next    = 0;  // thread 0: pending pool take (the tile after the current one)
   int64_t tile;
-  if (LOOKBACK) {
-    if (tid == 0) s_misc[0] = atomicAdd(&plan->tickets[pass], 1u);
+  if (PERSIST) {
+    if (tid == 0) {
+      const uint32_t k0                 = pool_take(a, plan, pass, xcc);
+      reinterpret_cast<int*>(s_misc)[0] = (int)pool_resolve(a, plan, pass, xcc, k0);
+    }
     __syncthreads();
-    tile = s_misc[0];
-  } else if (a.order_mode == 2) {
+    tile = reinterpret_cast<int*>(s_misc)[0];
+  } else if (LOOKBACK || a.order_mode == 2) {
     if (tid == 0) s_misc[0] = atomicAdd(&plan->tickets[pass], 1u);
     __syncthreads();
     tile = s_misc[0];
   } else {
     tile = a.order_mode == 1 ? (int64_t)blockIdx.x : xcd_swizzle(blockIdx.x, gridDim.x);
   }
+  while (tile >= 0) {
+  // the take for the next tile is issued now (its round trip overlaps this tile's key loads) and
+  // resolved after this tile has been written out
+  if (PERSIST && tid == 0) k_next = pool_take(a, plan, pass, xcc);
   const int64_t base = tile * TILE;
   const int nvalid   = (int)((a.n - base < (int64_t)TILE) ? (a.n - base) : (int64_t)TILE);
 
@@ -332,6 +404,12 @@ __global__ void __launch_bounds__(BT) k_radix_pass(PassArgs a)
       if (HAS_VAL) vout[dst] = s_vals[i];
     }
   }
+  if (!PERSIST) break;
+  __syncthreads();  // every read of this tile's LDS state is done
+  if (tid == 0) reinterpret_cast<int*>(s_misc)[0] = (int)pool_resolve(a, plan, pass, xcc, k_next);
+  __syncthreads();
+  tile = reinterpret_cast<int*>(s_misc)[0];
+  }  // while (tile >= 0)
 }
 
 // algorithm 1: per-tile histogram of the current digit -> tile_hist[bin][tile]
@@ -422,6 +500,7 @@ __global__ void __launch_bounds__(256) k_reverse_nan_block(KeyT* keys, uint32_t*
 
 static int g_algorithm = 0;
 static int g_order_mode = 0;
+static int g_persist_blocks = 512;  // persistent look-back kernel: 2 workgroups x 256 CUs
 
 // optional per-launch timing with HIP events on the caller's stream (bench.py's roofline leg)
 struct Profile {
@@ -465,8 +544,12 @@ int sort_impl(const void* keys_in, void* keys_out, const int32_t* vals_in, int32
   unsigned long long* status = nullptr;
   uint32_t* tile_hist        = nullptr;
   uint32_t* partials         = nullptr;
+  const int64_t pblocks = ntiles < g_persist_blocks ? ntiles : (int64_t)g_persist_blocks;
+  const int64_t nbatch  = (ntiles + 2 * pblocks) / POOL_BATCH + 8;
+  uint32_t* batch_base  = nullptr;
   if (algo != 1) {
-    status = c.take<unsigned long long>((size_t)ntiles * BINS);
+    status     = c.take<unsigned long long>((size_t)ntiles * BINS);
+    batch_base = c.take<uint32_t>((size_t)MAX_PASSES * 8 * nbatch);  // right behind status: one memset
   } else {
     tile_hist = c.take<uint32_t>((size_t)ntiles * BINS);
     partials  = c.take<uint32_t>(scan::partials_count(ntiles * BINS));
@@ -484,7 +567,9 @@ int sort_impl(const void* keys_in, void* keys_out, const int32_t* vals_in, int32
 
   GX_HIP_TRY(hipMemsetAsync(plan, 0, sizeof(SortPlan), stream));
   if (n == 0) return 0;
-  if (algo != 1) GX_HIP_TRY(hipMemsetAsync(status, 0, (size_t)ntiles * BINS * sizeof(unsigned long long), stream));
+  if (algo != 1)
+    GX_HIP_TRY(hipMemsetAsync(status, 0, (size_t)(reinterpret_cast<char*>(batch_base + (size_t)MAX_PASSES * 8 * nbatch) -
+                                                   reinterpret_cast<char*>(status)), stream));
 
   const KeyT desc_mask = descending ? KeyT(~KeyT(0)) : KeyT(0);
   g_prof.npass = NPASS;
@@ -508,20 +593,22 @@ int sort_impl(const void* keys_in, void* keys_out, const int32_t* vals_in, int32
   a.vbuf[2]   = vb;
   a.plan      = plan;
   a.status    = status;
-  a.tile_off  = tile_hist;
+  a.tile_off   = tile_hist;
+  a.batch_base = batch_base;
+  a.nbatch     = nbatch;
   a.n         = n;
   a.ntiles    = ntiles;
   a.desc_mask = (uint64_t)desc_mask;
   a.order_mode = g_order_mode;
 
   constexpr size_t lds = pass_lds_bytes<KeyT, HAS_VAL, KPT>();
-  auto kern_lb         = (algo == 2) ? k_radix_pass<KeyT, KIND, HAS_VAL, KPT, 1> : k_radix_pass<KeyT, KIND, HAS_VAL, KPT, 8>;
-  auto kern_pre        = k_radix_pass<KeyT, KIND, HAS_VAL, KPT, 0>;
+  auto kern_lb         = (algo == 2) ? k_radix_pass<KeyT, KIND, HAS_VAL, KPT, 4, false> : k_radix_pass<KeyT, KIND, HAS_VAL, KPT, 4, true>;
+  auto kern_pre        = k_radix_pass<KeyT, KIND, HAS_VAL, KPT, 0, false>;
   static bool attr_set = false;  // per template instantiation
   if (!attr_set) {
-    GX_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(k_radix_pass<KeyT, KIND, HAS_VAL, KPT, 8>),
+    GX_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(k_radix_pass<KeyT, KIND, HAS_VAL, KPT, 4, true>),
                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    GX_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(k_radix_pass<KeyT, KIND, HAS_VAL, KPT, 1>),
+    GX_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(k_radix_pass<KeyT, KIND, HAS_VAL, KPT, 4, false>),
                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     GX_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(kern_pre),
                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
@@ -531,7 +618,7 @@ int sort_impl(const void* keys_in, void* keys_out, const int32_t* vals_in, int32
     a.pass = pass;
     prof_mark(2 + 2 * pass, stream);
     if (algo != 1) {
-      hipLaunchKernelGGL(kern_lb, dim3((unsigned)ntiles), dim3(BT), lds, stream, a);
+      hipLaunchKernelGGL(kern_lb, dim3((unsigned)(algo == 2 ? ntiles : pblocks)), dim3(BT), lds, stream, a);
     } else {
       hipLaunchKernelGGL((k_tile_hist<KeyT, KIND, KPT>), dim3((unsigned)ntiles), dim3(BT), 0, stream, a, tile_hist);
       scan::PlainLoader<uint32_t, uint32_t> ld{tile_hist, nullptr, 0u};
