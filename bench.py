@@ -41,6 +41,7 @@ def parse():
                     help="sort knob: 0 onesweep/windowed look-back, 1 three-kernel, 2 onesweep/one-tile look-back")
     ap.add_argument("--gb-algo", type=int, default=0, help="groupby knob: 0 auto, 1 global table, 2 LDS-partitioned")
     ap.add_argument("--gb-split", type=int, default=1)
+    ap.add_argument("--no-hybrid", action="store_true", help="sort: disable the hybrid MSD path (LSD passes only)")
     ap.add_argument("--cpu-baseline", dest="cpu", action="store_true", default=True)
     ap.add_argument("--no-cpu-baseline", dest="cpu", action="store_false")
     ap.add_argument("--cpu-rows", type=float, default=0, help="rows of the CPU-baseline sample (0 = per-workload default)")
@@ -122,6 +123,7 @@ def main():
     n = int(args.rows)
     lib.gx_sort_set_algorithm(args.algo)
     lib.gx_groupby_set_algorithm(args.gb_algo, args.gb_split)
+    lib.gx_sort_set_hybrid(0 if args.no_hybrid else 1)
     stream = stream_ptr()
 
     def barrier():
@@ -192,6 +194,7 @@ def main():
     barrier()
     t0 = time.perf_counter()
     pass_ms_acc, hist_ms_acc, launches = 0.0, 0.0, 0
+    hyb_acc, hyb_n = [0.0, 0.0, 0.0, 0.0], 0
     for _ in range(args.steps):
         step()
         if args.workload in ("sort", "sorted_order"):
@@ -204,6 +207,11 @@ def main():
             pass_ms_acc += sum(act)
             launches += len(act)
             hist_ms_acc += h.value
+            h4 = (ctypes.c_float * 4)()
+            if lib.gx_sort_profile_read_hybrid(h4) == 0:
+                for i in range(4):
+                    hyb_acc[i] += h4[i]
+                hyb_n += 1
     barrier()
     dt = time.perf_counter() - t0
     if world > 1:
@@ -219,7 +227,31 @@ def main():
         st = ctypes.c_int(0)
         lib.gx_sort_status(ptr(tmp), ctypes.byref(st), stream)
         assert st.value == 0, "look-back timed out"
-    if args.workload in ("sort", "sorted_order") and launches:
+    sort_info = None
+    if args.workload in ("sort", "sorted_order"):
+        info = (ctypes.c_int32 * 8)()
+        lib.gx_sort_info(ptr(tmp), info, stream)
+        sort_info = dict(zip(["hybrid_attempted", "hybrid_used", "d1", "shift2", "bits2", "lds_passes", "max_cell",
+                              "lsd_passes"], list(info)))
+    if args.workload == "sort" and sort_info and sort_info["hybrid_used"] and hyb_n:
+        # hybrid MSD path: per-kernel algorithmic bytes: partition passes and the local
+        # sort read 8 + write 8 B/row, the joint histogram reads 8 B/row
+        ms = [x / hyb_n for x in hyb_acc]
+        names = ["k_msd_pass level 0 (8-bit partition, 8 XCD chains)", "k_hist2+k_plan2 (joint histogram)",
+                 "k_msd_pass level 1 (partition inside buckets)", "k_local_sort (LDS sort of <=16384-key cells)"]
+        bpr = [16, 8, 16, 16]
+        dom = max(range(4), key=lambda i: ms[i])
+        achieved = bpr[dom] * n / (ms[dom] * 1e-3) / 1e9
+        roofline = {"bound": "hbm", "kernel": names[dom], "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                    "frac": achieved / HBM_PEAK_GBS, "traffic": None, "algorithmic_bytes_per_launch": bpr[dom] * n,
+                    "avg_launch_ms": ms[dom], "launches_per_step": 1.0,
+                    "kernels_ms": dict(zip(names, ms)), "kernels_GBps": {k: b * n / (m * 1e-3) / 1e9 for k, b, m in zip(names, bpr, ms)},
+                    "hist_kernel_ms": hist_ms_acc / args.steps,
+                    "path_bytes_per_row": 64, "path_GBps": 64 * n / (ms_per_step * 1e-3) / 1e9,
+                    "whole_sort_model_GBps": model_bytes_row * n / (ms_per_step * 1e-3) / 1e9,
+                    "whole_sort_model_frac": model_bytes_row * n / (ms_per_step * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                    "sort_info": sort_info}
+    elif args.workload in ("sort", "sorted_order") and launches:
         avg_ms = pass_ms_acc / launches
         achieved = bytes_per_row_pass * n / (avg_ms * 1e-3) / 1e9
         roofline = {"bound": "hbm", "kernel": "k_radix_pass (one 8-bit digit scatter pass)", "achieved": achieved,
@@ -228,7 +260,8 @@ def main():
                     "launches_per_step": launches / args.steps,
                     "hist_kernel_ms": hist_ms_acc / args.steps,
                     "whole_sort_model_GBps": model_bytes_row * n / (ms_per_step * 1e-3) / 1e9,
-                    "whole_sort_model_frac": model_bytes_row * n / (ms_per_step * 1e-3) / 1e9 / HBM_PEAK_GBS}
+                    "whole_sort_model_frac": model_bytes_row * n / (ms_per_step * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                    "sort_info": sort_info}
     elif args.workload == "join":
         matches = int(cur.item())
         algb = 24 * n + 16 * matches

@@ -79,6 +79,26 @@ __device__ __forceinline__ T shfl_xor(T v, int m)
   return shfl_words(v, [m](uint32_t x) { return (uint32_t)__shfl_xor((int)x, m, GX_WAVE); });
 }
 
+// Wave-wide match on an 8-bit digit: for every lane, the lanes holding the same digit.  Returns the
+// number of such lanes below this one (the stable rank inside the wave) and their total count.
+// One ballot per digit bit; the per-lane 64-bit mask update m &= (bit ? v : ~v) is ONE gfx950
+// v_bitop3_b32 per half (truth table 0x90: a & ~(b ^ c) with c = 0 / ~0 from the lane's bit), which
+// halves the VALU work of the and/xor/cndmask sequence the compiler emits for the generic form.
+// `active` = ballot of the lanes that take part (others must pass live == false).
+__device__ __forceinline__ void match_rank8(uint32_t d, bool live, uint64_t active, uint32_t& lower, uint32_t& count)
+{
+  uint32_t m_lo = (uint32_t)active, m_hi = (uint32_t)(active >> 32);
+#pragma unroll
+  for (int b = 0; b < 8; ++b) {
+    const int beta   = __builtin_amdgcn_sbfe(d, b, 1);  // 0 or -1
+    const uint64_t v = ballot(live && beta != 0);
+    m_lo             = __builtin_amdgcn_bitop3_b32(m_lo, (uint32_t)v, (uint32_t)beta, 0x90);
+    m_hi             = __builtin_amdgcn_bitop3_b32(m_hi, (uint32_t)(v >> 32), (uint32_t)beta, 0x90);
+  }
+  lower = __builtin_amdgcn_mbcnt_hi(m_hi, __builtin_amdgcn_mbcnt_lo(m_lo, 0u));
+  count = (uint32_t)__builtin_popcount(m_lo) + (uint32_t)__builtin_popcount(m_hi);
+}
+
 struct SumOp {
   template <typename T>
   __device__ __forceinline__ T operator()(T a, T b) const { return a + b; }

@@ -17,6 +17,7 @@
 //   * algorithm 1 (A/B knob, no inter-workgroup communication): per pass a tile-histogram
 //     kernel + device scan + the same scatter kernel reading precomputed offsets.
 #include "gx_common.hpp"
+#include <cstdlib>
 #include "gx_scan.hpp"
 
 namespace gx {
@@ -26,6 +27,45 @@ constexpr int BINS       = 256;
 constexpr int MAX_PASSES = 8;
 constexpr int BT         = 512;  // threads per workgroup (8 waves)
 constexpr int NW         = BT / GX_WAVE;
+constexpr int NRANGE     = 8;    // input ranges == XCDs: each gets its own look-back chain (hybrid level 0)
+
+// Hybrid MSD sort (64-bit keys, keys only, n >= 2^22): two stable MSD partition passes bring every
+// cell (= keys sharing their top 8 + bits2 active bits) down to at most LOCAL_MAX keys, then ONE
+// kernel sorts each cell on all remaining bits inside LDS.  HBM traffic: 8 (histogram) + 16 + 8
+// (joint histogram) + 16 + 16 = 64 B/row instead of 8 + 8 x 16 = 136 B/row for the 8-pass LSD.
+// Whether every cell fits is decided ON THE DEVICE after the joint histogram (k_plan2); when one
+// does not (skewed keys) the hybrid kernels turn into no-ops and the LSD passes below run instead.
+constexpr int LOCAL_MAX  = 16384;
+constexpr int LS_BT      = 1024;
+constexpr int LS_KPT     = LOCAL_MAX / LS_BT;
+constexpr int LS_NW      = LS_BT / GX_WAVE;
+
+struct HybridPlan {
+  int32_t attempt;  // k_plan: the hybrid path is being tried
+  int32_t ok;       // k_plan2: every cell fits -> LSD passes are skipped, local sort runs
+  int32_t d1;       // byte index of the level-0 digit (most significant non-constant byte)
+  int32_t shift2, bits2;  // level-1 digit: bits [shift2, shift2 + bits2)
+  int32_t nlocal;         // LDS passes of the local sort
+  int32_t lshift[MAX_PASSES], lbits[MAX_PASSES];
+  uint32_t list_tile0[2][NRANGE + 1];  // first global tile of each list
+  uint32_t seg_tile0[2][BINS + 1];     // first global tile of each segment (level 0: NRANGE segments)
+  uint32_t seg_start[2][BINS], seg_count[2][BINS];
+  uint32_t max_cell;
+  uint32_t rhist[NRANGE][MAX_PASSES][BINS];  // range-resolved digit histograms (k_hist_all)
+};
+
+// Every word that workgroups update with atomics lives on its own 128-B line, away from the
+// read-only plan: a device-scope atomic drops its line from the L2s, so a counter that shares a
+// line with fields every workgroup reads turns those reads into memory-side round trips queued
+// behind the atomics.
+struct alignas(128) Counter {
+  uint32_t v;
+  uint32_t pad[31];
+};
+struct SortCounters {
+  Counter tickets[MAX_PASSES];  // LSD passes
+  Counter ctr[2][NRANGE];       // hybrid: tile tickets per level and per XCD list
+};
 
 // Device-resident plan, first bytes of the caller's scratch.
 struct SortPlan {
@@ -34,10 +74,10 @@ struct SortPlan {
   int32_t pass_skip[MAX_PASSES];
   int32_t pass_src[MAX_PASSES];  // buffer selector: 0 = input, 1 = output (A), 2 = scratch (B)
   int32_t pass_dst[MAX_PASSES];
-  uint32_t tickets[MAX_PASSES];
-  uint32_t pool_next[MAX_PASSES][8];  // persistent kernel: takes per XCD pool
   int32_t num_active;
-  int32_t status;  // 0 ok, 1 look-back spin timed out
+  int32_t status;  // 0 ok, 1 look-back spin timed out, 3 hybrid bookkeeping mismatch
+  HybridPlan hy;
+  SortCounters cnt;
 };
 
 // ------------------------------------------------------------------------------------------
@@ -45,26 +85,31 @@ struct SortPlan {
 // ------------------------------------------------------------------------------------------
 template <typename KeyT, int KIND>
 __global__ void __launch_bounds__(BT) k_hist_all(const KeyT* __restrict__ in, int64_t n, KeyT desc_mask,
-                                                 SortPlan* plan)
+                                                 SortPlan* plan, int64_t range_rows)
 {
+  // block b histograms rows of input range b % NRANGE (range r = rows [r, r+1) * range_rows); k_plan
+  // sums the ranges.  The hybrid's first partition pass runs one look-back chain per range.
+  const int range      = blockIdx.x % NRANGE;
+  const int64_t rbegin = (int64_t)range * range_rows < n ? (int64_t)range * range_rows : n;
+  const int64_t rend   = (range == NRANGE - 1) ? n : (rbegin + range_rows < n ? rbegin + range_rows : n);
   constexpr int NPASS = sizeof(KeyT);
   __shared__ uint32_t s_hist[NPASS * BINS];
   for (int i = threadIdx.x; i < NPASS * BINS; i += BT) s_hist[i] = 0;
   __syncthreads();
   const unsigned lane  = lane_id();
   constexpr int UNROLL = 4;  // independent loads in flight per lane (>= 32 KiB per CU at full occupancy)
-  const int64_t stride = (int64_t)gridDim.x * BT * UNROLL;
-  for (int64_t i0 = (int64_t)blockIdx.x * BT * UNROLL + threadIdx.x; i0 < n; i0 += stride) {
+  const int64_t stride = (int64_t)(gridDim.x / NRANGE) * BT * UNROLL;
+  for (int64_t i0 = rbegin + (int64_t)(blockIdx.x / NRANGE) * BT * UNROLL + threadIdx.x; i0 < rend; i0 += stride) {
     KeyT raw[UNROLL];
 #pragma unroll
     for (int u = 0; u < UNROLL; ++u) {
       const int64_t i = i0 + (int64_t)u * BT;
-      raw[u]          = (i < n) ? in[i] : KeyT(0);
+      raw[u]          = (i < rend) ? in[i] : KeyT(0);
     }
 #pragma unroll
     for (int u = 0; u < UNROLL; ++u) {
       const int64_t i = i0 + (int64_t)u * BT;
-      if (i < n) {
+      if (i < rend) {
         const KeyT k          = to_sortable<KeyT, KIND>(raw[u], desc_mask);
         const uint64_t active = ballot(true);
         const int leader      = __builtin_ctzll(active);
@@ -84,18 +129,21 @@ __global__ void __launch_bounds__(BT) k_hist_all(const KeyT* __restrict__ in, in
   __syncthreads();
   for (int i = threadIdx.x; i < NPASS * BINS; i += BT) {
     const uint32_t c = s_hist[i];
-    if (c) atomicAdd(&plan->hist[i / BINS][i % BINS], c);
+    if (c) atomicAdd(&plan->hy.rhist[range][i / BINS][i % BINS], c);
   }
 }
 
 // one block of 256 threads
-__global__ void __launch_bounds__(BINS) k_plan(SortPlan* plan, int npass, int64_t n)
+__global__ void __launch_bounds__(BINS) k_plan(SortPlan* plan, int npass, int64_t n, int try_hybrid, int64_t range_rows,
+                                               int tile_rows, uint32_t* base1)
 {
   __shared__ uint32_t s_tmp[BINS / GX_WAVE + 1];
   __shared__ int s_skip[MAX_PASSES];
   const int t = threadIdx.x;
   for (int p = 0; p < npass; ++p) {
-    const uint32_t c = plan->hist[p][t];
+    uint32_t c = 0;
+    for (int r = 0; r < NRANGE; ++r) c += plan->hy.rhist[r][p][t];
+    plan->hist[p][t] = c;
     const int triv   = __syncthreads_or(c == (uint32_t)n);
     uint32_t exc     = block_exclusive_scan<BINS>(c, 0u, SumOp(), s_tmp, (uint32_t*)nullptr);
     plan->gbin[p][t] = exc;
@@ -119,6 +167,53 @@ __global__ void __launch_bounds__(BINS) k_plan(SortPlan* plan, int npass, int64_
       plan->pass_dst[p] = dst;
       prev_dst          = dst;
     }
+    // ---- hybrid: digits and level-0 (range) segments
+    HybridPlan& hy = plan->hy;
+    int d1 = -1, nact = 0;
+    for (int p = npass - 1; p >= 0; --p)
+      if (!s_skip[p]) {
+        if (d1 < 0) d1 = p;
+        ++nact;
+      }
+    hy.attempt = (try_hybrid && nact >= 3 && d1 >= 2) ? 1 : 0;
+    if (hy.attempt) {
+      int B = 8;  // total MSD bits: cells of about 12k keys
+      while (B < 16 && ((double)n / (double)(1ull << B)) > 12288.0) ++B;
+      if (B < 9) B = 9;
+      hy.d1     = d1;
+      hy.bits2  = B - 8;
+      hy.shift2 = 8 * d1 - hy.bits2;
+      int nl    = 0;
+      for (int sft = 0; sft < hy.shift2; sft += 8) {
+        const int bits = hy.shift2 - sft < 8 ? hy.shift2 - sft : 8;
+        if (bits == 8 && s_skip[sft / 8]) continue;  // constant byte: nothing to sort on
+        hy.lshift[nl] = sft;
+        hy.lbits[nl]  = bits;
+        ++nl;
+      }
+      hy.nlocal = nl;
+      uint32_t tiles = 0;
+      for (int r = 0; r < NRANGE; ++r) {
+        const int64_t b = (int64_t)r * range_rows < n ? (int64_t)r * range_rows : n;
+        const int64_t e = (r == NRANGE - 1) ? n : (b + range_rows < n ? b + range_rows : n);
+        hy.seg_start[0][r]  = (uint32_t)b;
+        hy.seg_count[0][r]  = (uint32_t)(e - b);
+        hy.seg_tile0[0][r]  = tiles;
+        hy.list_tile0[0][r] = tiles;
+        tiles += (uint32_t)((e - b + tile_rows - 1) / tile_rows);
+      }
+      hy.seg_tile0[0][NRANGE]  = tiles;
+      hy.list_tile0[0][NRANGE] = tiles;
+    }
+  }
+  __syncthreads();
+  if (plan->hy.attempt) {  // level-0 output base of bin t for every input range
+    const int d1 = plan->hy.d1;
+    uint32_t run = plan->gbin[d1][t];
+    for (int r = 0; r < NRANGE; ++r) {
+      base1[r * BINS + t] = run;
+      run += plan->hy.rhist[r][d1][t];
+    }
   }
 }
 
@@ -131,8 +226,6 @@ struct PassArgs {
   SortPlan* plan;
   unsigned long long* status;  // [ntiles][256] look-back granules (algorithm 0)
   const uint32_t* tile_off;    // [256][ntiles] absolute offsets (algorithm 1)
-  uint32_t* batch_base;        // [MAX_PASSES][8][nbatch] first ticket of a pool batch, +1 (0 = unpublished)
-  int64_t nbatch;
   int64_t n;
   int64_t ntiles;
   int pass;
@@ -147,75 +240,15 @@ __device__ __forceinline__ unsigned long long pack_status(unsigned flag, unsigne
   return ((unsigned long long)flag << 62) | ((unsigned long long)epoch << 32) | value;
 }
 
-// XCD id of the executing CU (HW_REG_XCC_ID, bits 3:0).  Used for L2 affinity only.
-__device__ __forceinline__ unsigned xcc_id() { return __builtin_amdgcn_s_getreg(20 | (0 << 6) | (3 << 11)) & 7u; }
-
-typedef __attribute__((address_space(1))) unsigned int gu32_t;
-__device__ __forceinline__ void store_agent_u32(uint32_t* p, uint32_t v)
-{
-  __hip_atomic_store((gu32_t*)p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-}
-__device__ __forceinline__ uint32_t load_agent_u32(const uint32_t* p)
-{
-  return __hip_atomic_load((gu32_t*)p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-}
-
-constexpr int POOL_BATCH = 8;  // consecutive tickets an XCD pool reserves at a time
-
-// Tile hand-out of the persistent kernel.  Tickets are still a single global sequence (so the
-// look-back's forward-progress argument is the usual one: a tile is owned by a running workgroup
-// before any later ticket is), but they are drawn in batches of POOL_BATCH by per-XCD pools:
-// the k-th take of pool x (atomicAdd on pool_next[x]) is ticket base[x][k / B] + k % B, where the
-// take with k % B == 0 reserves the batch from the global counter -- after the previous batch of the
-// same pool has been published, so that a pool hands out increasing tickets -- and publishes its
-// base.  Neighbouring tiles therefore run on the same XCD at about the same time, and the partial
-// 128-B lines where their output runs meet are merged in that XCD's L2 instead of leaving two
-// non-coherent L2s as masked partial writes (measured on the scatter alone: 3.5 ms per 1e9-key pass
-// with XCD-contiguous tiles, 4.0 ms with arrival-order tickets, 5.7 ms with tiles dealt round-robin).
-// A take never waits on tile processing: the first take of a batch reserves and publishes at once
-// (it waits only for the previous batch's publication, which is equally prompt), and the others
-// read the published base when they need the ticket.  A workgroup resolves its pending take after
-// it has finished its current tile, so no workgroup ever holds an unprocessed tile while it waits.
-__device__ __forceinline__ uint32_t pool_take(const PassArgs& a, SortPlan* plan, int pass, unsigned xcc)
-{
-  const uint32_t k = atomicAdd(&plan->pool_next[pass][xcc], 1u);
-  if (k % POOL_BATCH == 0) {
-    const uint32_t j = k / POOL_BATCH;
-    uint32_t* slot   = a.batch_base + ((int64_t)pass * 8 + xcc) * a.nbatch + j;
-    uint32_t spins   = 0;
-    if (j > 0) {
-      while (load_agent_u32(slot - 1) == 0u) {
-        if (++spins > SPIN_LIMIT) { atomicExch(&plan->status, 2); break; }
-        __builtin_amdgcn_s_sleep(1);
-      }
-    }
-    store_agent_u32(slot, atomicAdd(&plan->tickets[pass], (uint32_t)POOL_BATCH) + 1u);
-  }
-  return k;
-}
-// the ticket of take k, or -1 when the sequence is exhausted (tickets only grow: once past the
-// end, every later take of every pool is too)
-__device__ __forceinline__ int64_t pool_resolve(const PassArgs& a, SortPlan* plan, int pass, unsigned xcc, uint32_t k)
-{
-  const uint32_t j = k / POOL_BATCH, wi = k % POOL_BATCH;
-  const uint32_t* slot = a.batch_base + ((int64_t)pass * 8 + xcc) * a.nbatch + j;
-  uint32_t base1, spins = 0;
-  while ((base1 = load_agent_u32(slot)) == 0u) {
-    if (++spins > SPIN_LIMIT) { atomicExch(&plan->status, 2); return -1; }
-    __builtin_amdgcn_s_sleep(1);
-  }
-  const int64_t t = (int64_t)(base1 - 1u) + wi;
-  return t < a.ntiles ? t : -1;
-}
-
 // LBW: look-back window (0 = no look-back: offsets were precomputed by algorithm 1).  A thread owns
-// one bin and inspects LBW predecessor tiles per round with LBW independent loads in flight.
-// PERSIST: workgroups loop over tiles handed out by pool_take/pool_resolve (2 workgroups per CU).
-template <typename KeyT, int KIND, bool HAS_VAL, int KPT, int LBW, bool PERSIST>
+// one bin and inspects LBW predecessor tiles per round with LBW independent loads in flight: a
+// status hop costs a memory-side round trip (~1.5-2.5 us under streaming load, the per-XCD L2s do
+// not share lines), and a one-tile-per-hop walk settles into a regime where every tile walks
+// ~10 predecessors (DESIGN.md "look-back regime"); the window bounds the walk to ~1-2 rounds.
+template <typename KeyT, int KIND, bool HAS_VAL, int KPT, int LBW>
 __global__ void __launch_bounds__(BT, 4) k_radix_pass(PassArgs a)
 {
   constexpr bool LOOKBACK = LBW > 0;
-  static_assert(!PERSIST || LOOKBACK, "the persistent kernel is the look-back kernel");
   constexpr int TILE = BT * KPT;
   extern __shared__ __attribute__((aligned(16))) char smem[];
   KeyT* s_keys       = reinterpret_cast<KeyT*>(smem);
@@ -241,27 +274,18 @@ __global__ void __launch_bounds__(BT, 4) k_radix_pass(PassArgs a)
   const unsigned w       = tid / GX_WAVE;
   const unsigned epoch   = (unsigned)pass + 1u;
 
-  const unsigned xcc = PERSIST ? xcc_id() : 0u;
-  uint32_t k_next    = 0;  // thread 0: pending pool take (the tile after the current one)
   int64_t tile;
-  if (PERSIST) {
-    if (tid == 0) {
-      const uint32_t k0                 = pool_take(a, plan, pass, xcc);
-      reinterpret_cast<int*>(s_misc)[0] = (int)pool_resolve(a, plan, pass, xcc, k0);
-    }
+  if (LOOKBACK) {
+    if (tid == 0) s_misc[0] = atomicAdd(&plan->cnt.tickets[pass].v, 1u);
     __syncthreads();
-    tile = reinterpret_cast<int*>(s_misc)[0];
-  } else if (LOOKBACK || a.order_mode == 2) {
-    if (tid == 0) s_misc[0] = atomicAdd(&plan->tickets[pass], 1u);
+    tile = s_misc[0];
+  } else if (a.order_mode == 2) {
+    if (tid == 0) s_misc[0] = atomicAdd(&plan->cnt.tickets[pass].v, 1u);
     __syncthreads();
     tile = s_misc[0];
   } else {
     tile = a.order_mode == 1 ? (int64_t)blockIdx.x : xcd_swizzle(blockIdx.x, gridDim.x);
   }
-  while (tile >= 0) {
-  // the take for the next tile is issued now (its round trip overlaps this tile's key loads) and
-  // resolved after this tile has been written out
-  if (PERSIST && tid == 0) k_next = pool_take(a, plan, pass, xcc);
   const int64_t base = tile * TILE;
   const int nvalid   = (int)((a.n - base < (int64_t)TILE) ? (a.n - base) : (int64_t)TILE);
 
@@ -293,22 +317,15 @@ __global__ void __launch_bounds__(BT, 4) k_radix_pass(PassArgs a)
 
   // ---- stable ranking inside the wave: ballot match on the 8 digit bits, count lower lanes
   uint32_t packed[KPT];  // digit << 16 | rank inside (wave, digit)
-  const uint64_t lt = lanemask_lt();
 #pragma unroll
   for (int j = 0; j < KPT; ++j) {
     const int idx = wbase + j * GX_WAVE;
     uint32_t d    = (uint32_t)(to_sortable<KeyT, KIND>(key[j], desc_mask) >> shift) & 0xFFu;
     if (idx >= nvalid) d = BINS - 1;  // padding sorts last (it is also last in input order)
-    uint64_t m = ~0ull;
-#pragma unroll
-    for (int b = 0; b < 8; ++b) {
-      const bool bit   = (d >> b) & 1u;
-      const uint64_t v = ballot(bit);
-      m &= bit ? v : ~v;
-    }
-    const uint32_t lower = (uint32_t)__builtin_popcountll(m & lt);
-    const uint32_t prev  = my_hist[d];
-    if (lower == 0) my_hist[d] = prev + (uint32_t)__builtin_popcountll(m);
+    uint32_t lower, cnt;
+    match_rank8(d, true, ~0ull, lower, cnt);
+    const uint32_t prev = my_hist[d];
+    if (lower == 0) my_hist[d] = prev + cnt;
     packed[j] = (d << 16) | (prev + lower);
   }
   __syncthreads();
@@ -404,12 +421,6 @@ __global__ void __launch_bounds__(BT, 4) k_radix_pass(PassArgs a)
       if (HAS_VAL) vout[dst] = s_vals[i];
     }
   }
-  if (!PERSIST) break;
-  __syncthreads();  // every read of this tile's LDS state is done
-  if (tid == 0) reinterpret_cast<int*>(s_misc)[0] = (int)pool_resolve(a, plan, pass, xcc, k_next);
-  __syncthreads();
-  tile = reinterpret_cast<int*>(s_misc)[0];
-  }  // while (tile >= 0)
 }
 
 // algorithm 1: per-tile histogram of the current digit -> tile_hist[bin][tile]
@@ -498,9 +509,427 @@ __global__ void __launch_bounds__(256) k_reverse_nan_block(KeyT* keys, uint32_t*
   }
 }
 
+// ==========================================================================================
+// Hybrid MSD sort kernels
+// ==========================================================================================
+__device__ __forceinline__ unsigned xcc_id() { return __builtin_amdgcn_s_getreg(20 | (0 << 6) | (3 << 11)) & 7u; }
+
+struct MsdArgs {
+  const void* in;
+  void* out;
+  SortPlan* plan;
+  unsigned long long* status;  // [tiles][256] look-back granules, epoch = level + 1
+  const uint32_t* base;        // [segments][256] output position of each bin of each segment
+  int64_t n;
+  int level;
+  int exp;  // experiment bits (GX_EXP environment variable)
+  uint64_t desc_mask;
+};
+
+// One stable partition pass of the hybrid sort: k_radix_pass's tile body (wave64 ballot ranking,
+// LDS reorder, decoupled look-back, coalesced write-out) over SEGMENTS.  A segment is a contiguous
+// piece of the input with its own output bases and its own look-back chain: level 0 = the NRANGE
+// input ranges (bases from the range-resolved histogram), level 1 = the 256 buckets of level 0
+// (bases from the joint histogram).  Chains never cross segments, so tiles are handed out per XCD:
+// list x (range x; buckets 32x..32x+31) has its own ticket counter, served first by the workgroups
+// running on XCD x (HW_REG_XCC_ID) and by anyone once their own list is drained.  Neighbouring
+// tiles thus share an L2, where the partial 128-B lines at the seams of their output runs merge
+// (the per-XCD L2s are not coherent; see DESIGN.md "XCD-local write combining").  Correctness
+// needs no placement assumption: within a list tickets are handed out in order, so every
+// predecessor a tile can wait for is already owned by a running workgroup.
+template <typename KeyT, int KIND, int KPT, int LBW>
+__global__ void __launch_bounds__(BT, 4) k_msd_pass(MsdArgs a)
+{
+  constexpr int TILE = BT * KPT;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  KeyT* s_keys       = reinterpret_cast<KeyT*>(smem);
+  uint32_t* s_whist  = reinterpret_cast<uint32_t*>(smem + (size_t)TILE * sizeof(KeyT));  // [NW][256]
+  uint32_t* s_gdelta = s_whist + NW * BINS;                                              // [256]
+  uint32_t* s_scan   = s_gdelta + BINS;                                                  // [16]
+  uint32_t* s_misc   = s_scan + 16;                                                      // [4]
+
+  SortPlan* plan = a.plan;
+  HybridPlan& hy = plan->hy;
+  const int lvl  = a.level;
+  if (!hy.attempt || (lvl == 1 && !hy.ok)) return;
+  const KeyT* kin      = static_cast<const KeyT*>(a.in);
+  KeyT* kout           = static_cast<KeyT*>(a.out);
+  const KeyT desc_mask = (KeyT)a.desc_mask;
+  const int shift      = lvl == 0 ? 8 * hy.d1 : hy.shift2;
+  const uint32_t dmask = lvl == 0 ? 0xFFu : ((1u << hy.bits2) - 1u);
+  const int nseg       = lvl == 0 ? NRANGE : BINS;
+  const unsigned tid   = threadIdx.x;
+  const unsigned lane  = lane_id();
+  const unsigned w     = tid / GX_WAVE;
+  const unsigned epoch = 9u + (unsigned)lvl;  // LSD passes use 1..8 on the same status array
+
+  // ---- take a tile: own XCD's list first, then the others
+  if (tid == 0) {
+    const unsigned x = ((a.exp & 1) && lvl == 1) ? 0u : ((a.exp & 2) ? (blockIdx.x % NRANGE) : xcc_id());
+    uint32_t g       = 0xFFFFFFFFu;
+    for (int i = 0; i < NRANGE; ++i) {
+      const unsigned y   = (x + i) % NRANGE;
+      const uint32_t ntl = hy.list_tile0[lvl][y + 1] - hy.list_tile0[lvl][y];
+      if (ntl == 0) continue;
+      const uint32_t t = atomicAdd(&plan->cnt.ctr[lvl][y].v, 1u);
+      if (t < ntl) {
+        g = hy.list_tile0[lvl][y] + t;
+        break;
+      }
+    }
+    s_misc[0] = g;
+  }
+  __syncthreads();
+  {
+    // segment of global tile g: the one whose tile interval contains it (one table entry per thread)
+    const uint32_t g = s_misc[0];
+    if (g != 0xFFFFFFFFu && (int)tid < nseg) {
+      const uint32_t lo = hy.seg_tile0[lvl][tid], hi = hy.seg_tile0[lvl][tid + 1];
+      if (lo <= g && g < hi) {
+        s_misc[1] = tid;
+        s_misc[2] = g - lo;
+      }
+    }
+  }
+  __syncthreads();
+  const uint32_t gtile = s_misc[0];
+  if (gtile == 0xFFFFFFFFu) return;
+  const uint32_t seg   = s_misc[1];
+  const uint32_t jt    = s_misc[2];
+  const int64_t base   = (int64_t)hy.seg_start[lvl][seg] + (int64_t)jt * TILE;
+  const int64_t remain = (int64_t)hy.seg_count[lvl][seg] - (int64_t)jt * TILE;
+  const int nvalid     = (int)(remain < (int64_t)TILE ? remain : (int64_t)TILE);
+
+  // ---- load (wave-striped)
+  KeyT key[KPT];
+  const int wbase = (int)w * (KPT * GX_WAVE) + (int)lane;
+  if (nvalid == TILE) {
+#pragma unroll
+    for (int j = 0; j < KPT; ++j) key[j] = kin[base + wbase + j * GX_WAVE];
+  } else {
+#pragma unroll
+    for (int j = 0; j < KPT; ++j) {
+      const int idx = wbase + j * GX_WAVE;
+      key[j]        = (idx < nvalid) ? kin[base + idx] : KeyT(0);
+    }
+  }
+  uint32_t* my_hist = s_whist + w * BINS;
+#pragma unroll
+  for (int k = 0; k < BINS / GX_WAVE; ++k) my_hist[lane + k * GX_WAVE] = 0;
+
+  uint32_t packed[KPT];
+#pragma unroll
+  for (int j = 0; j < KPT; ++j) {
+    const int idx = wbase + j * GX_WAVE;
+    uint32_t d    = (uint32_t)(to_sortable<KeyT, KIND>(key[j], desc_mask) >> shift) & dmask;
+    if (idx >= nvalid) d = BINS - 1;  // padding sorts last (it is also last in input order)
+    uint32_t lower, cnt;
+    match_rank8(d, true, ~0ull, lower, cnt);
+    const uint32_t prev = my_hist[d];
+    if (lower == 0) my_hist[d] = prev + cnt;
+    packed[j] = (d << 16) | (prev + lower);
+  }
+  __syncthreads();
+
+  uint32_t tile_count = 0;
+  if (tid < BINS) {
+    uint32_t sum = 0;
+#pragma unroll
+    for (int w2 = 0; w2 < NW; ++w2) {
+      const uint32_t c         = s_whist[w2 * BINS + tid];
+      s_whist[w2 * BINS + tid] = sum;
+      sum += c;
+    }
+    tile_count = sum;
+  }
+  uint32_t pub_count = tile_count;
+  if (tid == BINS - 1) pub_count -= (uint32_t)(TILE - nvalid);
+  if (tid < BINS) {
+    store_agent_u64(&a.status[(int64_t)gtile * BINS + tid], pack_status(jt == 0 ? 2u : 1u, epoch, pub_count));
+  }
+  const uint32_t bin_start = block_exclusive_scan<BT>(tile_count, 0u, SumOp(), s_scan, (uint32_t*)nullptr);
+  if (tid < BINS) {
+#pragma unroll
+    for (int w2 = 0; w2 < NW; ++w2) s_whist[w2 * BINS + tid] += bin_start;
+  }
+  __syncthreads();
+
+#pragma unroll
+  for (int j = 0; j < KPT; ++j) {
+    const uint32_t d   = packed[j] >> 16;
+    const uint32_t pos = my_hist[d] + (packed[j] & 0xFFFFu);
+    s_keys[pos]        = key[j];
+  }
+
+  if (tid < BINS) {
+    uint32_t prefix = 0;
+    if (jt > 0) {
+      int64_t p = (int64_t)gtile - 1;  // predecessors of the same segment have consecutive tile ids
+      bool done = false;
+      while (!done) {
+        unsigned long long v[LBW];
+#pragma unroll
+        for (int k = 0; k < LBW; ++k) {
+          const int64_t q = p - k;
+          v[k]            = (q >= 0) ? load_agent_u64(&a.status[q * BINS + tid]) : pack_status(2u, epoch, 0u);
+        }
+#pragma unroll
+        for (int k = 0; k < LBW; ++k) {
+          if (!done) {
+            unsigned long long x = v[k];
+            uint32_t spins       = 0;
+            while ((x >> 62) == 0 || ((unsigned)(x >> 32) & 0xFFu) != epoch) {
+              if (++spins > SPIN_LIMIT) {
+                atomicExch(&plan->status, 1);
+                x = pack_status(2u, epoch, 0u);
+                break;
+              }
+              __builtin_amdgcn_s_sleep(2);
+              x = load_agent_u64(&a.status[(p - k) * BINS + tid]);
+            }
+            prefix += (uint32_t)x;
+            if ((x >> 62) == 2u) done = true;
+          }
+        }
+        p -= LBW;
+      }
+      store_agent_u64(&a.status[(int64_t)gtile * BINS + tid], pack_status(2u, epoch, prefix + pub_count));
+    }
+    s_gdelta[tid] = a.base[seg * BINS + tid] + prefix - bin_start;
+  }
+  __syncthreads();
+
+#pragma unroll
+  for (int j = 0; j < KPT; ++j) {
+    const int i = j * BT + (int)tid;
+    if (i < nvalid) {
+      const KeyT k       = s_keys[i];
+      const uint32_t d   = (uint32_t)(to_sortable<KeyT, KIND>(k, desc_mask) >> shift) & dmask;
+      kout[s_gdelta[d] + (uint32_t)i] = k;
+    }
+  }
+}
+
+// Joint histogram hist2[d1 digit][level-1 digit] over the level-0 output, which is sorted by the
+// d1 digit: a 4096-key tile almost always holds ONE d1 value, so the workgroup keeps a 256-bin LDS
+// histogram for the current bucket and flushes it when the bucket changes; the <= 255 tiles that
+// straddle a bucket boundary use global atomics per key.
+constexpr int H2_BT = 256, H2_KPT = 16, H2_TILE = H2_BT * H2_KPT;
+template <typename KeyT, int KIND>
+__global__ void __launch_bounds__(H2_BT) k_hist2(const KeyT* __restrict__ in, int64_t n, KeyT desc_mask, SortPlan* plan,
+                                                 uint32_t* hist2)
+{
+  HybridPlan& hy = plan->hy;
+  if (!hy.attempt) return;
+  __shared__ uint32_t s_h[BINS];
+  const int shift1     = 8 * hy.d1;
+  const int shift2     = hy.shift2;
+  const uint32_t mask2 = (1u << hy.bits2) - 1u;
+  const int64_t ntile  = div_up(n, H2_TILE);
+  const int64_t per    = div_up(ntile, gridDim.x);
+  const int64_t t0     = (int64_t)blockIdx.x * per;
+  const int64_t t1     = t0 + per < ntile ? t0 + per : ntile;
+  s_h[threadIdx.x]     = 0;
+  int cur              = -1;
+  __syncthreads();
+  for (int64_t t = t0; t < t1; ++t) {
+    const int64_t base = t * H2_TILE;
+    const int64_t last = base + H2_TILE <= n ? base + H2_TILE - 1 : n - 1;
+    const int afirst   = (int)((to_sortable<KeyT, KIND>(in[base], desc_mask) >> shift1) & 0xFFu);
+    const int alast    = (int)((to_sortable<KeyT, KIND>(in[last], desc_mask) >> shift1) & 0xFFu);
+    KeyT k[H2_KPT];
+#pragma unroll
+    for (int j = 0; j < H2_KPT; ++j) {
+      const int64_t i = base + j * H2_BT + threadIdx.x;
+      k[j]            = (i < n) ? in[i] : KeyT(0);
+    }
+    if (afirst == alast) {  // uniform branch
+      if (afirst != cur) {
+        __syncthreads();
+        if (cur >= 0) {
+          const uint32_t c = s_h[threadIdx.x];
+          if (c) atomicAdd(&hist2[cur * BINS + threadIdx.x], c);
+        }
+        s_h[threadIdx.x] = 0;
+        cur              = afirst;
+        __syncthreads();
+      }
+#pragma unroll
+      for (int j = 0; j < H2_KPT; ++j) {
+        const int64_t i = base + j * H2_BT + threadIdx.x;
+        if (i < n) atomicAdd(&s_h[(uint32_t)(to_sortable<KeyT, KIND>(k[j], desc_mask) >> shift2) & mask2], 1u);
+      }
+    } else {
+#pragma unroll
+      for (int j = 0; j < H2_KPT; ++j) {
+        const int64_t i = base + j * H2_BT + threadIdx.x;
+        if (i < n) {
+          const KeyT sk = to_sortable<KeyT, KIND>(k[j], desc_mask);
+          atomicAdd(&hist2[((uint32_t)(sk >> shift1) & 0xFFu) * BINS + ((uint32_t)(sk >> shift2) & mask2)], 1u);
+        }
+      }
+    }
+  }
+  __syncthreads();
+  if (cur >= 0) {
+    const uint32_t c = s_h[threadIdx.x];
+    if (c) atomicAdd(&hist2[cur * BINS + threadIdx.x], c);
+  }
+}
+
+// one block of 256 threads: thread b owns level-0 bucket b
+__global__ void __launch_bounds__(BINS) k_plan2(SortPlan* plan, const uint32_t* hist2, uint32_t* base2, int tile_rows,
+                                                int npass)
+{
+  HybridPlan& hy = plan->hy;
+  if (!hy.attempt) return;
+  __shared__ uint32_t s_tmp[BINS / GX_WAVE + 1];
+  const int b          = threadIdx.x;
+  const int d1         = hy.d1;
+  const uint32_t start = plan->gbin[d1][b];
+  const uint32_t count = plan->hist[d1][b];
+  const int nb2        = 1 << hy.bits2;
+  uint32_t run = start, mx = 0;
+  for (int d2 = 0; d2 < nb2; ++d2) {
+    const uint32_t c     = hist2[b * BINS + d2];
+    base2[b * BINS + d2] = run;
+    run += c;
+    mx = c > mx ? c : mx;
+  }
+  const int bad   = __syncthreads_or(run - start != count);
+  const uint32_t m = wave_reduce(mx, MaxOp());
+  if (lane_id() == 0) s_tmp[b / GX_WAVE] = m;
+  __syncthreads();
+  uint32_t maxcell = 0;
+  for (int k = 0; k < BINS / GX_WAVE; ++k) maxcell = s_tmp[k] > maxcell ? s_tmp[k] : maxcell;
+  __syncthreads();
+  const uint32_t tiles = (count + (uint32_t)tile_rows - 1) / (uint32_t)tile_rows;
+  uint32_t total;
+  const uint32_t t0 = block_exclusive_scan<BINS>(tiles, 0u, SumOp(), s_tmp, &total);
+  hy.seg_start[1][b] = start;
+  hy.seg_count[1][b] = count;
+  hy.seg_tile0[1][b] = t0;
+  if (b % (BINS / NRANGE) == 0) hy.list_tile0[1][b / (BINS / NRANGE)] = t0;
+  if (b == 0) {
+    hy.seg_tile0[1][BINS]    = total;
+    hy.list_tile0[1][NRANGE] = total;
+    hy.max_cell              = maxcell;
+    if (bad) atomicExch(&plan->status, 3);
+    const int ok = (!bad && maxcell <= (uint32_t)LOCAL_MAX) ? 1 : 0;
+    hy.ok        = ok;
+    if (ok) {  // the LSD passes and the copy-only finalizer become no-ops
+      for (int p = 0; p < npass; ++p) plan->pass_skip[p] = 1;
+      plan->num_active = -1;
+    }
+  }
+}
+
+// Sort one cell (<= LOCAL_MAX keys sharing all bits above shift2) on its remaining bits inside LDS:
+// nlocal stable 8-bit counting passes, keys resident in registers between the LDS exchanges, one
+// HBM read and one HBM write of the cell in total.
+template <typename KeyT, int KIND>
+__global__ void __launch_bounds__(LS_BT) k_local_sort(const KeyT* __restrict__ in, KeyT* __restrict__ out, KeyT desc_mask,
+                                                      SortPlan* plan, const uint32_t* __restrict__ hist2,
+                                                      const uint32_t* __restrict__ base2)
+{
+  HybridPlan& hy = plan->hy;
+  if (!hy.attempt || !hy.ok) return;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  KeyT* s_keys      = reinterpret_cast<KeyT*>(smem);                                           // LOCAL_MAX
+  uint32_t* s_whist = reinterpret_cast<uint32_t*>(smem + (size_t)LOCAL_MAX * sizeof(KeyT));   // [LS_NW][256]
+  uint32_t* s_scan  = s_whist + LS_NW * BINS;                                                 // [32]
+  const int bits2   = hy.bits2;
+  if (blockIdx.x >= ((unsigned)BINS << bits2)) return;
+  const uint32_t b  = blockIdx.x >> bits2;
+  const uint32_t d2 = blockIdx.x & ((1u << bits2) - 1u);
+  const uint32_t m  = hist2[b * BINS + d2];
+  if (m == 0) return;
+  const int64_t start = base2[b * BINS + d2];
+  const unsigned tid  = threadIdx.x;
+  const unsigned lane = lane_id();
+  const unsigned w    = tid / GX_WAVE;
+  const int wbase     = (int)w * (LS_KPT * GX_WAVE) + (int)lane;
+  const int nlocal    = hy.nlocal;
+
+  KeyT key[LS_KPT];
+#pragma unroll
+  for (int j = 0; j < LS_KPT; ++j) {
+    const int idx = wbase + j * GX_WAVE;
+    key[j]        = ((uint32_t)idx < m) ? in[start + idx] : KeyT(0);
+  }
+  uint32_t* my_hist = s_whist + w * BINS;
+  for (int lp = 0; lp < nlocal; ++lp) {
+    const int shift      = hy.lshift[lp];
+    const uint32_t dmask = (1u << hy.lbits[lp]) - 1u;
+#pragma unroll
+    for (int k = 0; k < BINS / GX_WAVE; ++k) my_hist[lane + k * GX_WAVE] = 0;
+    uint32_t packed[LS_KPT];
+#pragma unroll
+    for (int j = 0; j < LS_KPT; ++j) {
+      const int idx     = wbase + j * GX_WAVE;
+      const bool live   = (uint32_t)idx < m;
+      const uint64_t act = ballot(live);
+      packed[j]         = 0;
+      if (act == 0) continue;  // wave-uniform
+      const uint32_t d = (uint32_t)(to_sortable<KeyT, KIND>(key[j], desc_mask) >> shift) & dmask;
+      uint32_t lower, cnt;
+      match_rank8(d, live, act, lower, cnt);
+      if (live) {
+        const uint32_t prev = my_hist[d];
+        if (lower == 0) my_hist[d] = prev + cnt;
+        packed[j] = (d << 16) | (prev + lower);
+      }
+    }
+    __syncthreads();
+    uint32_t tile_count = 0;
+    if (tid < BINS) {
+      uint32_t sum = 0;
+#pragma unroll
+      for (int w2 = 0; w2 < LS_NW; ++w2) {
+        const uint32_t c         = s_whist[w2 * BINS + tid];
+        s_whist[w2 * BINS + tid] = sum;
+        sum += c;
+      }
+      tile_count = sum;
+    }
+    const uint32_t bin_start = block_exclusive_scan<LS_BT>(tile_count, 0u, SumOp(), s_scan, (uint32_t*)nullptr);
+    if (tid < BINS) {
+#pragma unroll
+      for (int w2 = 0; w2 < LS_NW; ++w2) s_whist[w2 * BINS + tid] += bin_start;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int j = 0; j < LS_KPT; ++j) {
+      const int idx = wbase + j * GX_WAVE;
+      if ((uint32_t)idx < m) s_keys[my_hist[packed[j] >> 16] + (packed[j] & 0xFFFFu)] = key[j];
+    }
+    __syncthreads();
+    if (lp + 1 < nlocal) {
+#pragma unroll
+      for (int j = 0; j < LS_KPT; ++j) {
+        const int idx = wbase + j * GX_WAVE;
+        key[j]        = ((uint32_t)idx < m) ? s_keys[idx] : KeyT(0);
+      }
+      __syncthreads();  // the next pass rewrites s_whist / s_keys
+    }
+  }
+  if (nlocal == 0) {  // nothing left to sort on: the cell is a copy
+#pragma unroll
+    for (int j = 0; j < LS_KPT; ++j) {
+      const int idx = wbase + j * GX_WAVE;
+      if ((uint32_t)idx < m) out[start + idx] = key[j];
+    }
+    return;
+  }
+#pragma unroll
+  for (int j = 0; j < LS_KPT; ++j) {
+    const int i = j * LS_BT + (int)tid;
+    if ((uint32_t)i < m) out[start + i] = s_keys[i];
+  }
+}
+
 static int g_algorithm = 0;
 static int g_order_mode = 0;
-static int g_persist_blocks = 512;  // persistent look-back kernel: 2 workgroups x 256 CUs
 
 // optional per-launch timing with HIP events on the caller's stream (bench.py's roofline leg)
 struct Profile {
@@ -508,12 +937,19 @@ struct Profile {
   bool created = false;
   int npass    = 0;
   hipEvent_t ev[2 * MAX_PASSES + 2];
+  hipEvent_t hev[5];  // hybrid: before msd0, hist2, msd1, local sort, after
+  bool hybrid_marked = false;
 };
 static Profile g_prof;
 static inline void prof_mark(int idx, hipStream_t s)
 {
   if (g_prof.enabled) (void)hipEventRecord(g_prof.ev[idx], s);
 }
+static inline void prof_mark_h(int idx, hipStream_t s)
+{
+  if (g_prof.enabled) (void)hipEventRecord(g_prof.hev[idx], s);
+}
+static int g_hybrid = 1;  // 0 disables the hybrid MSD path (A/B knob)
 
 template <typename KeyT>
 constexpr int kpt_for(bool has_val)
@@ -544,12 +980,13 @@ int sort_impl(const void* keys_in, void* keys_out, const int32_t* vals_in, int32
   unsigned long long* status = nullptr;
   uint32_t* tile_hist        = nullptr;
   uint32_t* partials         = nullptr;
-  const int64_t pblocks = ntiles < g_persist_blocks ? ntiles : (int64_t)g_persist_blocks;
-  const int64_t nbatch  = (ntiles + 2 * pblocks) / POOL_BATCH + 8;
-  uint32_t* batch_base  = nullptr;
+  const bool try_hybrid = sizeof(KeyT) == 8 && !HAS_VAL && algo == 0 && g_hybrid && n >= (1ll << 22);
+  uint32_t* base1 = c.take<uint32_t>((size_t)NRANGE * BINS);
+  uint32_t* hist2 = try_hybrid ? c.take<uint32_t>((size_t)2 * BINS * BINS) : nullptr;  // hist2 | base2
+  uint32_t* base2 = try_hybrid ? hist2 + BINS * BINS : nullptr;
+  const int64_t status_tiles = ntiles + BINS + 2 * NRANGE;  // segment tails add at most one tile each
   if (algo != 1) {
-    status     = c.take<unsigned long long>((size_t)ntiles * BINS);
-    batch_base = c.take<uint32_t>((size_t)MAX_PASSES * 8 * nbatch);  // right behind status: one memset
+    status = c.take<unsigned long long>((size_t)status_tiles * BINS);
   } else {
     tile_hist = c.take<uint32_t>((size_t)ntiles * BINS);
     partials  = c.take<uint32_t>(scan::partials_count(ntiles * BINS));
@@ -567,9 +1004,9 @@ int sort_impl(const void* keys_in, void* keys_out, const int32_t* vals_in, int32
 
   GX_HIP_TRY(hipMemsetAsync(plan, 0, sizeof(SortPlan), stream));
   if (n == 0) return 0;
-  if (algo != 1)
-    GX_HIP_TRY(hipMemsetAsync(status, 0, (size_t)(reinterpret_cast<char*>(batch_base + (size_t)MAX_PASSES * 8 * nbatch) -
-                                                   reinterpret_cast<char*>(status)), stream));
+  if (algo != 1) GX_HIP_TRY(hipMemsetAsync(status, 0, (size_t)status_tiles * BINS * sizeof(unsigned long long), stream));
+  if (try_hybrid) GX_HIP_TRY(hipMemsetAsync(hist2, 0, (size_t)2 * BINS * BINS * sizeof(uint32_t), stream));
+  const int64_t range_rows = div_up(ntiles, NRANGE) * TILE;
 
   const KeyT desc_mask = descending ? KeyT(~KeyT(0)) : KeyT(0);
   g_prof.npass = NPASS;
@@ -577,12 +1014,57 @@ int sort_impl(const void* keys_in, void* keys_out, const int32_t* vals_in, int32
   {
     int64_t blocks = div_up(n, (int64_t)BT * 8);
     if (blocks > 2048) blocks = 2048;
-    if (blocks < 1) blocks = 1;
+    blocks = div_up(blocks, NRANGE) * NRANGE;  // block b serves input range b % NRANGE
     hipLaunchKernelGGL((k_hist_all<KeyT, KIND>), dim3((unsigned)blocks), dim3(BT), 0, stream,
-                       static_cast<const KeyT*>(keys_in), n, desc_mask, plan);
-    hipLaunchKernelGGL(k_plan, dim3(1), dim3(BINS), 0, stream, plan, NPASS, n);
+                       static_cast<const KeyT*>(keys_in), n, desc_mask, plan, range_rows);
+    hipLaunchKernelGGL(k_plan, dim3(1), dim3(BINS), 0, stream, plan, NPASS, n, try_hybrid ? 1 : 0, range_rows, TILE,
+                       base1);
   }
   prof_mark(1, stream);
+  g_prof.hybrid_marked = false;
+  if constexpr (sizeof(KeyT) == 8 && !HAS_VAL) {
+    if (try_hybrid) {
+      // hybrid MSD path: every kernel below is a no-op unless the device-side plan enables it
+      constexpr size_t lds_m = (size_t)TILE * sizeof(KeyT) + (size_t)(NW * BINS + BINS + 16 + 4) * 4;
+      constexpr size_t lds_l = (size_t)LOCAL_MAX * sizeof(KeyT) + (size_t)(LS_NW * BINS + 32) * 4;
+      auto kmsd              = k_msd_pass<KeyT, KIND, KPT, 4>;
+      auto kloc              = k_local_sort<KeyT, KIND>;
+      static bool hattr_set  = false;
+      if (!hattr_set) {
+        GX_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(kmsd), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_m));
+        GX_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(kloc), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_l));
+        hattr_set = true;
+      }
+      KeyT* bufA = keys_out ? static_cast<KeyT*>(keys_out) : ka_scratch;
+      KeyT* bufB = kb_scratch;
+      MsdArgs m;
+      m.plan      = plan;
+      m.status    = status;
+      m.n         = n;
+      m.desc_mask = (uint64_t)desc_mask;
+      m.in        = keys_in;
+      m.out       = bufA;
+      m.base      = base1;
+      m.level     = 0;
+      m.exp       = getenv("GX_EXP") ? atoi(getenv("GX_EXP")) : 0;
+      prof_mark_h(0, stream);
+      hipLaunchKernelGGL(kmsd, dim3((unsigned)(ntiles + NRANGE)), dim3(BT), lds_m, stream, m);
+      prof_mark_h(1, stream);
+      hipLaunchKernelGGL((k_hist2<KeyT, KIND>), dim3(2048), dim3(H2_BT), 0, stream, bufA, n, desc_mask, plan, hist2);
+      hipLaunchKernelGGL(k_plan2, dim3(1), dim3(BINS), 0, stream, plan, hist2, base2, TILE, NPASS);
+      prof_mark_h(2, stream);
+      m.in    = bufA;
+      m.out   = bufB;
+      m.base  = base2;
+      m.level = 1;
+      hipLaunchKernelGGL(kmsd, dim3((unsigned)(ntiles + BINS + NRANGE)), dim3(BT), lds_m, stream, m);
+      prof_mark_h(3, stream);
+      hipLaunchKernelGGL(kloc, dim3((unsigned)(BINS * BINS)), dim3(LS_BT), lds_l, stream, bufB, bufA, desc_mask, plan,
+                         hist2, base2);
+      prof_mark_h(4, stream);
+      g_prof.hybrid_marked = g_prof.enabled;
+    }
+  }
 
   PassArgs a;
   a.kbuf[0]   = const_cast<void*>(keys_in);
@@ -593,22 +1075,20 @@ int sort_impl(const void* keys_in, void* keys_out, const int32_t* vals_in, int32
   a.vbuf[2]   = vb;
   a.plan      = plan;
   a.status    = status;
-  a.tile_off   = tile_hist;
-  a.batch_base = batch_base;
-  a.nbatch     = nbatch;
+  a.tile_off  = tile_hist;
   a.n         = n;
   a.ntiles    = ntiles;
   a.desc_mask = (uint64_t)desc_mask;
   a.order_mode = g_order_mode;
 
   constexpr size_t lds = pass_lds_bytes<KeyT, HAS_VAL, KPT>();
-  auto kern_lb         = (algo == 2) ? k_radix_pass<KeyT, KIND, HAS_VAL, KPT, 4, false> : k_radix_pass<KeyT, KIND, HAS_VAL, KPT, 4, true>;
-  auto kern_pre        = k_radix_pass<KeyT, KIND, HAS_VAL, KPT, 0, false>;
+  auto kern_lb         = (algo == 2) ? k_radix_pass<KeyT, KIND, HAS_VAL, KPT, 1> : k_radix_pass<KeyT, KIND, HAS_VAL, KPT, 4>;
+  auto kern_pre        = k_radix_pass<KeyT, KIND, HAS_VAL, KPT, 0>;
   static bool attr_set = false;  // per template instantiation
   if (!attr_set) {
-    GX_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(k_radix_pass<KeyT, KIND, HAS_VAL, KPT, 4, true>),
+    GX_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(k_radix_pass<KeyT, KIND, HAS_VAL, KPT, 4>),
                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    GX_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(k_radix_pass<KeyT, KIND, HAS_VAL, KPT, 4, false>),
+    GX_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(k_radix_pass<KeyT, KIND, HAS_VAL, KPT, 1>),
                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     GX_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(kern_pre),
                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
@@ -618,7 +1098,7 @@ int sort_impl(const void* keys_in, void* keys_out, const int32_t* vals_in, int32
     a.pass = pass;
     prof_mark(2 + 2 * pass, stream);
     if (algo != 1) {
-      hipLaunchKernelGGL(kern_lb, dim3((unsigned)(algo == 2 ? ntiles : pblocks)), dim3(BT), lds, stream, a);
+      hipLaunchKernelGGL(kern_lb, dim3((unsigned)ntiles), dim3(BT), lds, stream, a);
     } else {
       hipLaunchKernelGGL((k_tile_hist<KeyT, KIND, KPT>), dim3((unsigned)ntiles), dim3(BT), 0, stream, a, tile_hist);
       scan::PlainLoader<uint32_t, uint32_t> ld{tile_hist, nullptr, 0u};
@@ -774,6 +1254,7 @@ int gx_sort_profile(int enable)
   auto& p = gx::sort::g_prof;
   if (enable && !p.created) {
     for (auto& e : p.ev) GX_HIP_TRY(hipEventCreate(&e));
+    for (auto& e : p.hev) GX_HIP_TRY(hipEventCreate(&e));
     p.created = true;
   }
   p.enabled = enable != 0;
@@ -788,6 +1269,30 @@ int gx_sort_profile_read(float* hist_ms, float* pass_ms, int* npass)
   GX_HIP_TRY(hipEventSynchronize(p.ev[3 + 2 * (p.npass - 1)]));
   GX_HIP_TRY(hipEventElapsedTime(hist_ms, p.ev[0], p.ev[1]));
   for (int i = 0; i < p.npass; ++i) GX_HIP_TRY(hipEventElapsedTime(&pass_ms[i], p.ev[2 + 2 * i], p.ev[3 + 2 * i]));
+  return 0;
+}
+
+int gx_sort_profile_read_hybrid(float* ms4)
+{
+  auto& p = gx::sort::g_prof;
+  if (!p.created || !ms4) return GX_EINVAL;
+  if (!p.hybrid_marked) return GX_EINVAL;
+  GX_HIP_TRY(hipEventSynchronize(p.hev[4]));
+  for (int i = 0; i < 4; ++i) GX_HIP_TRY(hipEventElapsedTime(&ms4[i], p.hev[i], p.hev[i + 1]));
+  return 0;
+}
+
+void gx_sort_set_hybrid(int enable) { gx::sort::g_hybrid = enable ? 1 : 0; }
+
+int gx_sort_info(const void* tmp, int32_t* info8_host, gx_stream_t stream)
+{
+  if (!tmp || !info8_host) return GX_EINVAL;
+  const auto* plan = static_cast<const gx::sort::SortPlan*>(tmp);
+  // attempt, ok, d1, shift2, bits2, nlocal are the first six int32 of HybridPlan
+  GX_HIP_TRY(hipMemcpyAsync(info8_host, &plan->hy, 6 * sizeof(int32_t), hipMemcpyDeviceToHost, stream));
+  GX_HIP_TRY(hipMemcpyAsync(info8_host + 6, &plan->hy.max_cell, sizeof(int32_t), hipMemcpyDeviceToHost, stream));
+  GX_HIP_TRY(hipMemcpyAsync(info8_host + 7, &plan->num_active, sizeof(int32_t), hipMemcpyDeviceToHost, stream));
+  GX_HIP_TRY(hipStreamSynchronize(stream));
   return 0;
 }
 

@@ -120,6 +120,20 @@ void gx_sort_set_algorithm(int algo);
  * exit). */
 int gx_sort_profile(int enable);
 int gx_sort_profile_read(float* hist_ms, float* pass_ms, int* npass);
+/* durations of the hybrid path's kernels of the last profiled sort, in milliseconds:
+ * ms4 = {level-0 partition pass, joint histogram + plan, level-1 partition pass, LDS local sort}.
+ * GX_EINVAL when the last sort did not enqueue the hybrid path. */
+int gx_sort_profile_read_hybrid(float* ms4);
+
+/* Hybrid MSD path (64-bit keys, keys only, n >= 2^22): two stable 8-bit-class partition passes,
+ * then one kernel that sorts every cell of <= 16384 keys on its remaining bits inside LDS
+ * (64 B/row of HBM traffic instead of 136).  Enabled by default; the device falls back to the LSD
+ * passes by itself when a cell does not fit (skewed keys).  0 disables it (A/B measurements). */
+void gx_sort_set_hybrid(int enable);
+/* info8_host (host, 8 x int32) = {hybrid attempted, hybrid used, d1, shift2, bits2, LDS passes,
+ * largest cell, active LSD passes (-1 when the hybrid path produced the output)} of the last sort
+ * that used `tmp`.  Synchronises `stream`. */
+int gx_sort_info(const void* tmp, int32_t* info8_host, gx_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------
  * Gather.  Replaces cudf::detail::gather for fixed-width columns

@@ -154,3 +154,77 @@ def test_sort_large_properties(gx):
     o = order.data[: n * 4].view(torch.int32).to(torch.int64)
     assert int(torch.bincount(o[: 1_000_000] % 1024).sum()) == 1_000_000
     assert int(o.sum().item()) == n * (n - 1) // 2  # a permutation of iota
+
+
+def _sort_info(ops_mod, col, ascending=True):
+    """Run gx_sort_keys directly so the scratch (and the device-side plan in it) can be inspected."""
+    import ctypes
+    from cudf_amd import _lib as L
+    from cudf_amd.column import Column, device_bytes, ptr, stream_ptr
+    out = Column.empty(col.dtype, col.size)
+    nb = ctypes.c_size_t(0)
+    args = (col.gx, col.data_ptr, out.data_ptr, col.size, int(not ascending))
+    L.check(L.lib.gx_sort_keys(*args, None, ctypes.byref(nb), stream_ptr()), "query")
+    tmp = device_bytes(nb.value)
+    L.check(L.lib.gx_sort_keys(*args, ptr(tmp), ctypes.byref(nb), stream_ptr()), "sort")
+    info = (ctypes.c_int32 * 8)()
+    L.check(L.lib.gx_sort_info(ptr(tmp), info, stream_ptr()), "info")
+    st = ctypes.c_int(0)
+    L.check(L.lib.gx_sort_status(ptr(tmp), ctypes.byref(st), stream_ptr()), "status")
+    assert st.value == 0
+    return out.to_numpy(), list(info)
+
+
+@pytest.mark.parametrize("dtype", ["int64", "uint64", "float64"])
+def test_hybrid_msd_sort_matches_oracle(gx, dtype):
+    """64-bit keys-only sorts of >= 2^22 rows take the hybrid MSD path (two partition passes + LDS
+    local sort); skewed inputs must fall back to the LSD passes on the device.  Bit-exact either way."""
+    Column, ops = gx
+    rng = np.random.default_rng(77)
+    n = (1 << 22) + 12_345
+
+    def spread(m):
+        # keys whose leading bits are uniform (for doubles: random bit patterns, incl. NaNs/Infs/-0.0)
+        if dtype == "float64":
+            return rng.integers(-2**63, 2**63 - 1, m, dtype=np.int64).view(np.float64)
+        return _rand(dtype, m, rng, False)
+
+    for asc in (True, False):
+        v = spread(n)
+        got, info = _sort_info(ops, Column.from_numpy(v), asc)
+        assert got.tobytes() == orc.sort_keys(v, asc).tobytes(), (dtype, asc, info)
+        assert info[0] == 1 and info[1] == 1, f"uniform keys must use the hybrid path: {info}"
+        assert 0 < info[6] <= 16384
+    # larger: 9+ bits at level 1, several tiles per bucket
+    n = 20_000_000
+    v = spread(n)
+    got, info = _sort_info(ops, Column.from_numpy(v))
+    assert got.tobytes() == orc.sort_keys(v, True).tobytes()
+    assert info[1] == 1
+    # skew: a third of the keys in one narrow cluster -> one cell overflows -> device-side fallback
+    v = spread(6_000_000)
+    if dtype == "float64":
+        v[::3] = 1.0 + rng.random(len(v[::3])) * 1e-9
+    else:
+        v[::3] = (rng.integers(0, 1 << 20, len(v[::3])) + (1 << 40)).astype(dtype)
+    got, info = _sort_info(ops, Column.from_numpy(v))
+    assert got.tobytes() == orc.sort_keys(v, True).tobytes()
+    assert info[0] == 1 and info[1] == 0 and info[6] > 16384, f"expected the LSD fallback: {info}"
+    # low-entropy keys (two active bytes): hybrid is not attempted
+    v = _rand(dtype, 5_000_000, rng, True) if dtype != "float64" else np.floor(rng.random(5_000_000) * 50)
+    got, info = _sort_info(ops, Column.from_numpy(v))
+    assert got.tobytes() == orc.sort_keys(v, True).tobytes()
+
+
+def test_hybrid_knob_off_uses_lsd(gx):
+    Column, ops = gx
+    from cudf_amd import _lib
+    rng = np.random.default_rng(78)
+    v = rng.integers(-2**63, 2**63 - 1, 5_000_000, dtype=np.int64)
+    _lib.lib.gx_sort_set_hybrid(0)
+    try:
+        got, info = _sort_info(ops, Column.from_numpy(v))
+    finally:
+        _lib.lib.gx_sort_set_hybrid(1)
+    assert got.tobytes() == np.sort(v).tobytes()
+    assert info[0] == 0 and info[7] == 8
