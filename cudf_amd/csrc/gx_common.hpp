@@ -99,6 +99,59 @@ __device__ __forceinline__ void match_rank8(uint32_t d, bool live, uint64_t acti
   count = (uint32_t)__builtin_popcount(m_lo) + (uint32_t)__builtin_popcount(m_hi);
 }
 
+// ---- in-wave bitonic sort of 64-bit keys (one or two keys per lane), ascending over
+// element index e = r * 64 + lane.  "Flip" form of the network: every compare-exchange keeps the
+// minimum in the lower element, so the only per-step state is a constant lane mask.  Lane moves:
+// xor 1/2/3 = DPP quad_perm, xor 7 / 15 = DPP row_half_mirror / row_mirror (VALU, no LDS traffic);
+// larger distances go through ds_bpermute.
+template <int M>
+__device__ __forceinline__ uint32_t lane_xor32(uint32_t v)
+{
+  if constexpr (M == 1) return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0xB1, 0xF, 0xF, false);
+  else if constexpr (M == 2) return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x4E, 0xF, 0xF, false);
+  else if constexpr (M == 3) return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x1B, 0xF, 0xF, false);
+  else if constexpr (M == 7) return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x141, 0xF, 0xF, false);
+  else if constexpr (M == 15) return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x140, 0xF, 0xF, false);
+  else return (uint32_t)__builtin_amdgcn_ds_bpermute((int)((lane_id() ^ (unsigned)M) << 2), (int)v);
+}
+template <int M>
+__device__ __forceinline__ uint64_t lane_xor64(uint64_t v)
+{
+  return ((uint64_t)lane_xor32<M>((uint32_t)(v >> 32)) << 32) | lane_xor32<M>((uint32_t)v);
+}
+// compare-exchange with the lane at distance xor M; LOWBIT: lanes with (lane & LOWBIT) == 0 keep the minimum
+template <int M, int LOWBIT>
+__device__ __forceinline__ void cmpx(uint64_t& k)
+{
+  const uint64_t o   = lane_xor64<M>(k);
+  const bool keepmin = (lane_id() & (unsigned)LOWBIT) == 0;
+  k                  = ((k < o) == keepmin) ? k : o;
+}
+__device__ __forceinline__ void wave_bitonic64(uint64_t& k)
+{
+  cmpx<1, 1>(k);
+  cmpx<3, 2>(k); cmpx<1, 1>(k);
+  cmpx<7, 4>(k); cmpx<2, 2>(k); cmpx<1, 1>(k);
+  cmpx<15, 8>(k); cmpx<4, 4>(k); cmpx<2, 2>(k); cmpx<1, 1>(k);
+  cmpx<31, 16>(k); cmpx<8, 8>(k); cmpx<4, 4>(k); cmpx<2, 2>(k); cmpx<1, 1>(k);
+  cmpx<63, 32>(k); cmpx<16, 16>(k); cmpx<8, 8>(k); cmpx<4, 4>(k); cmpx<2, 2>(k); cmpx<1, 1>(k);
+}
+__device__ __forceinline__ void wave_halfclean64(uint64_t& k)
+{
+  cmpx<32, 32>(k); cmpx<16, 16>(k); cmpx<8, 8>(k); cmpx<4, 4>(k); cmpx<2, 2>(k); cmpx<1, 1>(k);
+}
+// 128 keys: k0 = elements 0..63, k1 = elements 64..127
+__device__ __forceinline__ void wave_bitonic128(uint64_t& k0, uint64_t& k1)
+{
+  wave_bitonic64(k0);
+  wave_bitonic64(k1);
+  const uint64_t o1 = lane_xor64<63>(k1), o0 = lane_xor64<63>(k0);  // element e pairs with e ^ 127
+  k0 = k0 < o1 ? k0 : o1;
+  k1 = k1 < o0 ? o0 : k1;
+  wave_halfclean64(k0);
+  wave_halfclean64(k1);
+}
+
 struct SumOp {
   template <typename T>
   __device__ __forceinline__ T operator()(T a, T b) const { return a + b; }

@@ -857,6 +857,66 @@ __global__ void __launch_bounds__(LS_BT) k_local_sort(const KeyT* __restrict__ i
     const int idx = wbase + j * GX_WAVE;
     key[j]        = ((uint32_t)idx < m) ? in[start + idx] : KeyT(0);
   }
+  // ---- fast path (integer keys): ONE unstable 8-bit MSD split in LDS on the byte below the
+  // level-1 digit (LDS atomics, no ballots), then every <=128-key sub-bucket is sorted on the full
+  // key by one wave's in-register bitonic network.  Equal integer keys are indistinguishable, so
+  // stability is not needed; floats (-0.0 == +0.0 must keep input order) and cells with a
+  // sub-bucket above 128 keys take the stable LSD passes below.
+  if (KIND != K_FLOAT && nlocal > 0) {
+    uint32_t* s_cnt   = s_whist;          // [256] counts, then exclusive starts
+    uint32_t* s_start = s_whist + BINS;   // [256]
+    const int sshift  = hy.shift2 - 8;    // >= 0: d1 >= 2 and bits2 <= 8
+    if (tid < BINS) s_cnt[tid] = 0;
+    __syncthreads();
+    uint32_t rank[LS_KPT];
+#pragma unroll
+    for (int j = 0; j < LS_KPT; ++j) {
+      const int idx = wbase + j * GX_WAVE;
+      key[j]        = to_sortable<KeyT, KIND>(key[j], desc_mask);  // an involution for integer kinds
+      rank[j]       = 0;
+      if ((uint32_t)idx < m) rank[j] = atomicAdd(&s_cnt[(uint32_t)(key[j] >> sshift) & 0xFFu], 1u);
+    }
+    __syncthreads();
+    const uint32_t c   = tid < BINS ? s_cnt[tid] : 0u;
+    const int too_big  = __syncthreads_or(c > 128u);
+    if (!too_big) {
+      const uint32_t st = block_exclusive_scan<LS_BT>(c, 0u, SumOp(), s_scan, (uint32_t*)nullptr);
+      if (tid < BINS) s_start[tid] = st;
+      __syncthreads();
+#pragma unroll
+      for (int j = 0; j < LS_KPT; ++j) {
+        const int idx = wbase + j * GX_WAVE;
+        if ((uint32_t)idx < m) s_keys[s_start[(uint32_t)(key[j] >> sshift) & 0xFFu] + rank[j]] = key[j];
+      }
+      __syncthreads();
+      for (int sb = (int)w; sb < BINS; sb += LS_NW) {
+        const uint32_t cnt = s_cnt[sb], o = s_start[sb];
+        if (cnt <= 1) continue;
+        if (cnt <= 64) {
+          uint64_t k0 = lane < cnt ? (uint64_t)s_keys[o + lane] : ~0ull;
+          wave_bitonic64(k0);
+          if (lane < cnt) s_keys[o + lane] = (KeyT)k0;
+        } else {
+          uint64_t k0 = (uint64_t)s_keys[o + lane];
+          uint64_t k1 = lane + 64 < cnt ? (uint64_t)s_keys[o + 64 + lane] : ~0ull;
+          wave_bitonic128(k0, k1);
+          s_keys[o + lane] = (KeyT)k0;
+          if (lane + 64 < cnt) s_keys[o + 64 + lane] = (KeyT)k1;
+        }
+      }
+      __syncthreads();
+#pragma unroll
+      for (int j = 0; j < LS_KPT; ++j) {
+        const int i = j * LS_BT + (int)tid;
+        if ((uint32_t)i < m) out[start + i] = to_sortable<KeyT, KIND>(s_keys[i], desc_mask);
+      }
+      return;
+    }
+    // undo the transform and fall through to the stable passes
+#pragma unroll
+    for (int j = 0; j < LS_KPT; ++j) key[j] = to_sortable<KeyT, KIND>(key[j], desc_mask);
+    __syncthreads();
+  }
   uint32_t* my_hist = s_whist + w * BINS;
   for (int lp = 0; lp < nlocal; ++lp) {
     const int shift      = hy.lshift[lp];
