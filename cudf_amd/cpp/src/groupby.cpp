@@ -1,0 +1,239 @@
+// cudf::groupby::groupby::aggregate / scan over the C ABI.
+// reference: cpp/src/groupby/groupby.cu:40-71,220-259; hash path cpp/src/groupby/hash/*;
+// scan path cpp/src/groupby/sort/{scan.cpp:214-238, sort_helper.cu:73-162, group_scan_util.cuh:77-133}.
+#include "common.hpp"
+
+#include <cudf/column/column_factories.hpp>
+#include <cudf/copying.hpp>
+#include <cudf/groupby.hpp>
+#include <cudf/sorting.hpp>
+
+#include <algorithm>
+#include <cstdio>
+#include <cstdlib>
+
+namespace cudf {
+namespace groupby {
+namespace {
+
+struct hash_agg_out {
+  std::unique_ptr<column> keys, sum, count_valid, count_all;
+};
+
+data_type sum_type(data_type v)
+{
+  // SUM target types (cpp/include/cudf/detail/aggregation/aggregation.hpp:949-970): integers -> INT64,
+  // floats keep their type
+  return is_floating_point(v) ? v : data_type{type_id::INT64};
+}
+
+// one gx_groupby_sum_count call, retried with a larger table when the group estimate was too small
+hash_agg_out hash_aggregate(column_view const& keys, column_view const& vals, rmm::cuda_stream_view stream,
+                            rmm::device_async_resource_ref mr)
+{
+  auto const n = keys.size();
+  rmm::device_buffer kh, vh;
+  auto const* kmask = keys.has_nulls() ? detail::rebased_mask(keys, kh, stream) : nullptr;
+  auto const* vmask = vals.has_nulls() ? detail::rebased_mask(vals, vh, stream) : nullptr;
+  int64_t max_groups = std::max<int64_t>(1, std::min<int64_t>(n, int64_t{1} << 20));
+  rmm::device_buffer ng{sizeof(int64_t), stream};
+  for (;;) {
+    hash_agg_out o;
+    auto const g = static_cast<size_type>(max_groups);
+    o.keys        = make_fixed_width_column(keys.type(), g, mask_state::UNALLOCATED, stream, mr);
+    o.sum         = make_fixed_width_column(sum_type(vals.type()), g, mask_state::UNALLOCATED, stream, mr);
+    o.count_valid = make_fixed_width_column(data_type{type_id::INT32}, g, mask_state::UNALLOCATED, stream, mr);
+    o.count_all   = make_fixed_width_column(data_type{type_id::INT32}, g, mask_state::UNALLOCATED, stream, mr);
+    detail::run_with_scratch(
+      [&](void* t, std::size_t* b) {
+        return gx_groupby_sum_count(detail::gx_type(keys.type()), detail::row0(keys), kmask, detail::gx_type(vals.type()),
+                                    detail::row0(vals), vmask, n, max_groups, o.keys->mutable_view().head<void>(),
+                                    o.sum->mutable_view().head<void>(), o.count_valid->mutable_view().head<int32_t>(),
+                                    o.count_all->mutable_view().head<int32_t>(), static_cast<int64_t*>(ng.data()), t, b,
+                                    detail::gxs(stream));
+      },
+      "groupby aggregate", stream);
+    auto const groups = detail::read_i64(static_cast<int64_t const*>(ng.data()), stream);
+    if (getenv("CUDF_AMD_DEBUG")) std::fprintf(stderr, "hash_aggregate: n=%d max_groups=%ld groups=%ld\n", (int)n, (long)max_groups, (long)groups);
+    if (groups >= 0 && groups <= max_groups) {
+      // trim the columns to the group count (buffers keep their capacity)
+      auto trim = [&](std::unique_ptr<column>& c) {
+        auto type     = c->type();
+        auto contents = c->release();
+        c = std::make_unique<column>(type, static_cast<size_type>(groups), std::move(*contents.data), rmm::device_buffer{}, 0);
+      };
+      trim(o.keys);
+      trim(o.sum);
+      trim(o.count_valid);
+      trim(o.count_all);
+      return o;
+    }
+    CUDF_EXPECTS(max_groups < n, "groupby: group table overflow");
+    max_groups = std::min<int64_t>(n, max_groups * 8);
+  }
+}
+
+// permute `c` by an INT32 map (same length)
+std::unique_ptr<column> permute(column_view const& c, column_view const& map, rmm::cuda_stream_view stream,
+                                rmm::device_async_resource_ref mr)
+{
+  auto t = cudf::gather(table_view{{c}}, map, out_of_bounds_policy::DONT_CHECK, stream, mr);
+  return std::move(t->release().front());
+}
+
+}  // namespace
+
+groupby::~groupby() = default;
+
+groupby::groupby(table_view const& keys, null_policy null_handling, sorted keys_are_sorted,
+                 std::vector<order> const& column_order, std::vector<null_order> const& null_precedence)
+  : _keys{keys},
+    _include_null_keys{null_handling},
+    _keys_are_sorted{keys_are_sorted},
+    _column_order{column_order},
+    _null_precedence{null_precedence}
+{
+}
+
+std::pair<std::unique_ptr<table>, std::vector<aggregation_result>> groupby::aggregate(
+  std::span<aggregation_request const> requests, rmm::cuda_stream_view stream, rmm::device_async_resource_ref mr)
+{
+  CUDF_EXPECTS(std::all_of(requests.begin(), requests.end(),
+                           [this](auto const& r) { return r.values.size() == _keys.num_rows(); }),
+               "Size mismatch between request values and groupby keys.", std::invalid_argument);
+  CUDF_EXPECTS(_keys.num_columns() == 1, "multi-column groupby keys are not supported on this path yet");
+  auto const& keys = _keys.column(0);
+  CUDF_EXPECTS(keys.type().id() == type_id::INT32 || keys.type().id() == type_id::INT64 ||
+                 keys.type().id() == type_id::UINT32 || keys.type().id() == type_id::UINT64,
+               "groupby key must be a 32/64-bit integer column on this path", cudf::data_type_error);
+  CUDF_EXPECTS(_include_null_keys == null_policy::EXCLUDE || !keys.has_nulls(),
+               "null_policy::INCLUDE with null keys is not supported on this path yet");
+
+  std::vector<aggregation_result> results(requests.size());
+  std::unique_ptr<column> out_keys;
+  bool const canonical = requests.size() > 1;  // several hash passes: bring every result into key order
+
+  if (_keys.num_rows() == 0 || requests.empty()) {  // empty input -> empty keys + typed empty results (groupby.cu:234)
+    for (std::size_t i = 0; i < requests.size(); ++i)
+      for (auto const& agg : requests[i].aggregations) {
+        data_type t = requests[i].values.type();
+        if (agg->kind == aggregation::SUM) t = sum_type(t);
+        if (agg->kind == aggregation::COUNT_VALID || agg->kind == aggregation::COUNT_ALL) t = data_type{type_id::INT32};
+        if (agg->kind == aggregation::MEAN) t = data_type{type_id::FLOAT64};
+        results[i].results.emplace_back(make_empty_column(t));
+      }
+    if (requests.empty() && _keys.num_rows() > 0) {
+      // keys only: aggregate a dummy count to obtain the distinct keys
+      auto o   = hash_aggregate(keys, keys, stream, mr);
+      out_keys = std::move(o.keys);
+    } else {
+      out_keys = make_empty_column(keys.type());
+    }
+    std::vector<std::unique_ptr<column>> kc;
+    kc.emplace_back(std::move(out_keys));
+    return {std::make_unique<table>(std::move(kc)), std::move(results)};
+  }
+
+  for (std::size_t i = 0; i < requests.size(); ++i) {
+    auto const& req = requests[i];
+    for (auto const& agg : req.aggregations)
+      CUDF_EXPECTS(agg->kind == aggregation::SUM || agg->kind == aggregation::COUNT_VALID ||
+                     agg->kind == aggregation::COUNT_ALL || agg->kind == aggregation::MEAN,
+                   "groupby aggregation kind not implemented on this path (SUM, COUNT, MEAN are)");
+    auto o = hash_aggregate(keys, req.values, stream, mr);
+    std::unique_ptr<column> order;
+    if (canonical) order = cudf::sorted_order(table_view{{o.keys->view()}}, {}, {}, stream);
+    auto fin = [&](std::unique_ptr<column> c) {
+      return canonical ? permute(c->view(), order->view(), stream, mr) : std::move(c);
+    };
+    auto const g = o.keys->size();
+    // validity of SUM / MEAN: groups without a valid value are null
+    auto validity = [&](size_type& nulls) {
+      rmm::device_buffer mask = create_null_mask(g, mask_state::ALL_VALID, stream, mr);
+      rmm::device_buffer cnt{sizeof(int64_t), stream};
+      detail::gx_check(gx_valid_from_counts(o.count_valid->view().head<int32_t>(), g, static_cast<uint32_t*>(mask.data()),
+                                            static_cast<int64_t*>(cnt.data()), detail::gxs(stream)),
+                       "groupby validity");
+      nulls = static_cast<size_type>(detail::read_i64(static_cast<int64_t const*>(cnt.data()), stream));
+      return mask;
+    };
+    for (auto const& agg : req.aggregations) {
+      switch (agg->kind) {
+        case aggregation::SUM: {
+          auto c = std::make_unique<column>(o.sum->view(), stream, mr);
+          size_type nulls = 0;
+          auto mask       = validity(nulls);
+          if (nulls > 0) c->set_null_mask(std::move(mask), nulls);
+          results[i].results.emplace_back(fin(std::move(c)));
+          break;
+        }
+        case aggregation::COUNT_VALID: results[i].results.emplace_back(fin(std::make_unique<column>(o.count_valid->view(), stream, mr))); break;
+        case aggregation::COUNT_ALL: results[i].results.emplace_back(fin(std::make_unique<column>(o.count_all->view(), stream, mr))); break;
+        case aggregation::MEAN: {
+          auto c = make_fixed_width_column(data_type{type_id::FLOAT64}, g, mask_state::UNALLOCATED, stream, mr);
+          detail::gx_check(gx_mean_from_sum(detail::gx_type(o.sum->type()), o.sum->view().head<void>(),
+                                            o.count_valid->view().head<int32_t>(), g, c->mutable_view().head<double>(),
+                                            detail::gxs(stream)),
+                           "groupby mean");
+          size_type nulls = 0;
+          auto mask       = validity(nulls);
+          if (nulls > 0) c->set_null_mask(std::move(mask), nulls);
+          results[i].results.emplace_back(fin(std::move(c)));
+          break;
+        }
+        default: break;
+      }
+    }
+    if (!out_keys) out_keys = fin(std::move(o.keys));
+    stream.synchronize();  // per-request temporaries are released here
+  }
+  std::vector<std::unique_ptr<column>> kc;
+  kc.emplace_back(std::move(out_keys));
+  return {std::make_unique<table>(std::move(kc)), std::move(results)};
+}
+
+std::pair<std::unique_ptr<table>, std::vector<aggregation_result>> groupby::scan(
+  std::span<scan_request const> requests, rmm::cuda_stream_view stream, rmm::device_async_resource_ref mr)
+{
+  CUDF_EXPECTS(std::all_of(requests.begin(), requests.end(),
+                           [this](auto const& r) { return r.values.size() == _keys.num_rows(); }),
+               "Size mismatch between request values and groupby keys.", std::invalid_argument);
+  CUDF_EXPECTS(_keys.num_columns() == 1, "multi-column groupby keys are not supported on this path yet");
+  auto const& keys = _keys.column(0);
+  std::vector<aggregation_result> results(requests.size());
+  // sort helper: stable order of the keys, nulls AFTER (sort_helper.cu:92-94); null keys are dropped
+  auto order       = cudf::stable_sorted_order(_keys, {}, {null_order::AFTER}, stream);
+  auto const kept  = _include_null_keys == null_policy::EXCLUDE ? keys.size() - keys.null_count() : keys.size();
+  column_view omap{data_type{type_id::INT32}, kept, order->view().head<void>(), nullptr, 0};
+  auto sorted_keys = cudf::gather(_keys, omap, out_of_bounds_policy::DONT_CHECK, stream, mr);
+  column_view const sk = sorted_keys->view().column(0);  // by value: view() is a temporary
+  for (std::size_t i = 0; i < requests.size(); ++i) {
+    auto vals = cudf::gather(table_view{{requests[i].values}}, omap, out_of_bounds_policy::DONT_CHECK, stream, mr);
+    column_view const sv = vals->view().column(0);
+    for (auto const& agg : requests[i].aggregations) {
+      int op = -1;
+      if (agg->kind == aggregation::SUM) op = GX_OP_SUM;
+      if (agg->kind == aggregation::MIN) op = GX_OP_MIN;
+      if (agg->kind == aggregation::MAX) op = GX_OP_MAX;
+      CUDF_EXPECTS(op >= 0, "groupby scan kind not implemented on this path (SUM, MIN, MAX are)");
+      data_type const ot = (op == GX_OP_SUM) ? sum_type(sv.type()) : sv.type();
+      auto out = make_fixed_width_column(ot, kept, mask_state::UNALLOCATED, stream, mr);
+      detail::run_with_scratch(
+        [&](void* t, std::size_t* b) {
+          return gx_segmented_scan(detail::gx_type(sk.type()), detail::row0(sk), detail::gx_type(sv.type()), detail::row0(sv),
+                                   sv.has_nulls() ? sv.null_mask() : nullptr, kept, op, out->mutable_view().head<void>(), t, b,
+                                   detail::gxs(stream));
+        },
+        "groupby scan", stream);
+      if (sv.nullable()) {  // null rows stay null
+        out->set_null_mask(rmm::device_buffer{sv.null_mask(), bitmask_allocation_size_bytes(kept), stream, mr}, sv.null_count());
+      }
+      results[i].results.emplace_back(std::move(out));
+    }
+    stream.synchronize();
+  }
+  return {std::move(sorted_keys), std::move(results)};
+}
+
+}  // namespace groupby
+}  // namespace cudf

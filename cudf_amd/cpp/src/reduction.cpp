@@ -1,0 +1,157 @@
+// cudf::reduce / cudf::scan and the hashing entry points over the C ABI.
+// reference: cpp/src/reductions/reductions.cpp:484-507, simple.cuh:47-85, scan/scan.cpp:13-54,
+// scan/scan_inclusive.cu:36-240; cpp/src/hash/murmurhash3_x86_32.cu; cpp/src/partitioning/partitioning.cu:568-660.
+#include "common.hpp"
+
+#include <cudf/column/column_factories.hpp>
+#include <cudf/copying.hpp>
+#include <cudf/hashing.hpp>
+#include <cudf/reduction.hpp>
+
+namespace cudf {
+namespace {
+
+int gx_op_of(aggregation::Kind k)
+{
+  switch (k) {
+    case aggregation::SUM: return GX_OP_SUM;
+    case aggregation::PRODUCT: return GX_OP_PRODUCT;
+    case aggregation::MIN: return GX_OP_MIN;
+    case aggregation::MAX: return GX_OP_MAX;
+    default: CUDF_FAIL("aggregation kind not implemented on this path (SUM, PRODUCT, MIN, MAX are)");
+  }
+}
+
+template <typename T>
+std::unique_ptr<scalar> make_result(void const* dev_value, bool valid, rmm::cuda_stream_view stream,
+                                    rmm::device_async_resource_ref mr)
+{
+  auto s = std::make_unique<numeric_scalar<T>>(T{}, valid, stream, mr);
+  CUDF_CUDA_TRY(hipMemcpyAsync(s->data(), dev_value, sizeof(T), hipMemcpyDeviceToDevice, stream.value()));
+  stream.synchronize();
+  return s;
+}
+
+}  // namespace
+
+std::unique_ptr<scalar> reduce(column_view const& col, reduce_aggregation const& agg, data_type output_type,
+                               rmm::cuda_stream_view stream, rmm::device_async_resource_ref mr)
+{
+  int const op = gx_op_of(agg.kind);
+  CUDF_EXPECTS(is_fixed_width(col.type()), "reduce: only fixed-width columns are supported on this path", cudf::data_type_error);
+  if (op == GX_OP_MIN || op == GX_OP_MAX)
+    CUDF_EXPECTS(output_type == col.type(), "min/max reduction output type must match the input type", cudf::data_type_error);
+  rmm::device_buffer holder;
+  auto const* mask = col.has_nulls() ? detail::rebased_mask(col, holder, stream) : nullptr;
+  rmm::device_buffer value{16, stream}, cnt{sizeof(int64_t), stream};
+  detail::run_with_scratch(
+    [&](void* t, std::size_t* b) {
+      return gx_reduce(detail::gx_type(col.type()), detail::row0(col), mask, col.size(), op, detail::gx_type(output_type),
+                       value.data(), static_cast<int64_t*>(cnt.data()), t, b, detail::gxs(stream));
+    },
+    "reduce", stream);
+  bool const valid = detail::read_i64(static_cast<int64_t const*>(cnt.data()), stream) > 0;
+  switch (output_type.id()) {
+    case type_id::INT8: return make_result<int8_t>(value.data(), valid, stream, mr);
+    case type_id::INT16: return make_result<int16_t>(value.data(), valid, stream, mr);
+    case type_id::INT32: return make_result<int32_t>(value.data(), valid, stream, mr);
+    case type_id::INT64: return make_result<int64_t>(value.data(), valid, stream, mr);
+    case type_id::UINT8: return make_result<uint8_t>(value.data(), valid, stream, mr);
+    case type_id::UINT16: return make_result<uint16_t>(value.data(), valid, stream, mr);
+    case type_id::UINT32: return make_result<uint32_t>(value.data(), valid, stream, mr);
+    case type_id::UINT64: return make_result<uint64_t>(value.data(), valid, stream, mr);
+    case type_id::FLOAT32: return make_result<float>(value.data(), valid, stream, mr);
+    case type_id::FLOAT64: return make_result<double>(value.data(), valid, stream, mr);
+    default: CUDF_FAIL("reduce: unsupported output type");
+  }
+}
+
+std::unique_ptr<column> scan(column_view const& input, scan_aggregation const& agg, scan_type inclusive,
+                             null_policy null_handling, rmm::cuda_stream_view stream, rmm::device_async_resource_ref mr)
+{
+  int const op = gx_op_of(agg.kind);
+  CUDF_EXPECTS(is_fixed_width(input.type()), "scan: only fixed-width columns are supported on this path", cudf::data_type_error);
+  auto const n = input.size();
+  auto out     = make_fixed_width_column(input.type(), n, mask_state::UNALLOCATED, stream, mr);
+  if (n == 0) return out;
+  rmm::device_buffer holder;
+  auto const* mask = input.has_nulls() ? detail::rebased_mask(input, holder, stream) : nullptr;
+  detail::run_with_scratch(
+    [&](void* t, std::size_t* b) {
+      return gx_scan(detail::gx_type(input.type()), detail::row0(input), mask, n, op, inclusive == scan_type::INCLUSIVE ? 1 : 0,
+                     out->mutable_view().head<void>(), t, b, detail::gxs(stream));
+    },
+    "scan", stream);
+  if (input.nullable()) {
+    if (null_handling == null_policy::EXCLUDE) {  // nulls stay null (scan_inclusive.cu:198-216)
+      rmm::device_buffer h2;
+      auto const* m = detail::rebased_mask(input, h2, stream);
+      out->set_null_mask(rmm::device_buffer{m, bitmask_allocation_size_bytes(n), stream, mr}, input.null_count());
+      stream.synchronize();
+    } else {  // the first null poisons the rest (mask_scan :36-61)
+      size_type first = n;
+      if (input.has_nulls()) {
+        rmm::device_buffer pos{sizeof(int64_t), stream};
+        detail::gx_check(gx_bitmask_first_unset(mask, n, static_cast<int64_t*>(pos.data()), detail::gxs(stream)), "first_unset");
+        auto const p = detail::read_i64(static_cast<int64_t const*>(pos.data()), stream);
+        first        = static_cast<size_type>(std::min<int64_t>(n, p + (inclusive == scan_type::INCLUSIVE ? 0 : 1)));
+      }
+      auto m = create_null_mask(n, mask_state::ALL_NULL, stream, mr);
+      set_null_mask(static_cast<bitmask_type*>(m.data()), 0, first, true, stream);
+      out->set_null_mask(std::move(m), n - first);
+    }
+  }
+  return out;
+}
+
+namespace hashing {
+std::unique_ptr<column> murmurhash3_x86_32(table_view const& input, uint32_t seed, rmm::cuda_stream_view stream,
+                                           rmm::device_async_resource_ref mr)
+{
+  auto const n = input.num_rows();
+  auto out     = make_numeric_column(data_type{type_id::UINT32}, n, mask_state::UNALLOCATED, stream, mr);
+  if (n == 0 || input.num_columns() == 0) return out;
+  int k = 0;
+  for (auto const& c : input) {
+    rmm::device_buffer holder;
+    auto const* mask = c.has_nulls() ? detail::rebased_mask(c, holder, stream) : nullptr;
+    detail::gx_check(gx_murmur3_32(detail::gx_type(c.type()), detail::row0(c), mask, n, seed, k > 0 ? 1 : 0,
+                                   out->mutable_view().head<uint32_t>(), detail::gxs(stream)),
+                     "murmurhash3_x86_32");
+    stream.synchronize();
+    ++k;
+  }
+  return out;
+}
+}  // namespace hashing
+
+std::pair<std::unique_ptr<table>, std::vector<size_type>> hash_partition(table_view const& input,
+                                                                         std::vector<size_type> const& columns_to_hash,
+                                                                         int num_partitions, hash_id hash_function,
+                                                                         uint32_t seed, rmm::cuda_stream_view stream,
+                                                                         rmm::device_async_resource_ref mr)
+{
+  CUDF_EXPECTS(hash_function == hash_id::HASH_MURMUR3, "only HASH_MURMUR3 is implemented on this path");
+  CUDF_EXPECTS(num_partitions > 0, "num_partitions must be positive", std::invalid_argument);
+  auto const n = input.num_rows();
+  std::vector<size_type> offsets(num_partitions, 0);
+  if (n == 0 || columns_to_hash.empty()) return {std::make_unique<table>(input, stream, mr), offsets};
+  auto h = hashing::murmurhash3_x86_32(input.select(columns_to_hash), seed, stream);
+  rmm::device_uvector<int32_t> map(n, stream), offs(num_partitions + 1, stream);
+  detail::run_with_scratch(
+    [&](void* t, std::size_t* b) {
+      return gx_hash_partition_map(h->view().head<uint32_t>(), n, num_partitions, map.data(), offs.data(), t, b,
+                                   detail::gxs(stream));
+    },
+    "hash_partition", stream);
+  std::vector<int32_t> host_offs(num_partitions + 1);
+  CUDF_CUDA_TRY(hipMemcpyAsync(host_offs.data(), offs.data(), host_offs.size() * 4, hipMemcpyDeviceToHost, stream.value()));
+  stream.synchronize();
+  for (int p = 0; p < num_partitions; ++p) offsets[p] = host_offs[p];
+  column_view mapv{data_type{type_id::INT32}, n, map.data(), nullptr, 0};
+  auto out = gather(input, mapv, out_of_bounds_policy::DONT_CHECK, stream, mr);
+  stream.synchronize();
+  return {std::move(out), offsets};
+}
+
+}  // namespace cudf

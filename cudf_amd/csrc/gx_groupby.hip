@@ -676,3 +676,76 @@ void gx_groupby_set_algorithm(int algo, int nsplit)
 }
 
 }  // extern "C"
+
+// ------------------------------------------------------------------------------------------------
+// result finalizers used by the host layer (cudf::groupby::aggregate): validity of SUM/MEAN from
+// COUNT_VALID (cpp/src/groupby/hash/output_utils.cu:68-70: a group with no valid value is null) and
+// MEAN = SUM / COUNT_VALID in double (hash_compound_agg_finalizer.cu:92-133).
+// ------------------------------------------------------------------------------------------------
+namespace gx {
+namespace gb {
+
+__global__ void __launch_bounds__(256) k_valid_from_counts(const int32_t* __restrict__ counts, int64_t n,
+                                                           uint32_t* mask, unsigned long long* nulls)
+{
+  const int64_t nwords = (n + 31) / 32;
+  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  unsigned long long local = 0;
+  for (int64_t wi = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; wi < nwords; wi += stride) {
+    uint32_t bits = 0;
+    for (int b = 0; b < 32; ++b) {
+      const int64_t i = wi * 32 + b;
+      if (i < n) {
+        if (counts[i] > 0) bits |= 1u << b; else ++local;
+      }
+    }
+    mask[wi] = bits;
+  }
+  local = wave_reduce(local, SumOp());
+  if (lane_id() == 0 && local) atomicAdd(nulls, local);
+}
+
+template <typename S>
+__global__ void __launch_bounds__(256) k_mean(const S* __restrict__ sum, const int32_t* __restrict__ cnt, int64_t n,
+                                              double* out)
+{
+  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride)
+    out[i] = cnt[i] > 0 ? (double)sum[i] / (double)cnt[i] : 0.0;
+}
+
+}  // namespace gb
+}  // namespace gx
+
+extern "C" {
+
+int gx_valid_from_counts(const int32_t* counts, int64_t n, uint32_t* mask_out, int64_t* null_count_dev, gx_stream_t s)
+{
+  if (n < 0 || (n > 0 && (!counts || !mask_out)) || !null_count_dev) return GX_EINVAL;
+  GX_HIP_TRY(hipMemsetAsync(null_count_dev, 0, sizeof(int64_t), s));
+  if (n == 0) return 0;
+  int64_t blocks = gx::div_up(gx::div_up(n, 32), 256);
+  if (blocks > 2048) blocks = 2048;
+  hipLaunchKernelGGL(gx::gb::k_valid_from_counts, dim3((unsigned)blocks), dim3(256), 0, s, counts, n, mask_out,
+                     reinterpret_cast<unsigned long long*>(null_count_dev));
+  GX_LAUNCH_CHECK();
+  return 0;
+}
+
+int gx_mean_from_sum(int sum_dtype, const void* sum, const int32_t* count, int64_t n, double* out, gx_stream_t s)
+{
+  if (n < 0 || (n > 0 && (!sum || !count || !out))) return GX_EINVAL;
+  if (n == 0) return 0;
+  int64_t blocks = gx::div_up(n, 256 * 4);
+  if (blocks > 4096) blocks = 4096;
+  switch (sum_dtype) {
+    case GX_INT64: hipLaunchKernelGGL((gx::gb::k_mean<int64_t>), dim3((unsigned)blocks), dim3(256), 0, s, static_cast<const int64_t*>(sum), count, n, out); break;
+    case GX_FLOAT64: hipLaunchKernelGGL((gx::gb::k_mean<double>), dim3((unsigned)blocks), dim3(256), 0, s, static_cast<const double*>(sum), count, n, out); break;
+    case GX_FLOAT32: hipLaunchKernelGGL((gx::gb::k_mean<float>), dim3((unsigned)blocks), dim3(256), 0, s, static_cast<const float*>(sum), count, n, out); break;
+    default: return GX_EDTYPE;
+  }
+  GX_LAUNCH_CHECK();
+  return 0;
+}
+
+}  // extern "C"

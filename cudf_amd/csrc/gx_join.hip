@@ -312,3 +312,80 @@ int gx_join_probe(int key_size, const void* probe_keys, const uint32_t* probe_va
 }
 
 }  // extern "C"
+
+// ------------------------------------------------------------------------------------------------
+// full join complement: build rows that no probe row matched, as (JoinNoMatch, build_row) pairs
+// appended behind a left-join result (cpp/src/join/join_utils.cu:86-157 get_left_join_indices_complement).
+// ------------------------------------------------------------------------------------------------
+namespace gx {
+namespace join {
+
+__global__ void __launch_bounds__(256) k_mark_matched(const int32_t* __restrict__ build_idx, int64_t n,
+                                                      uint32_t* matched_bits)
+{
+  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
+    const int32_t r = build_idx[i];
+    if (r >= 0) atomicOr(&matched_bits[r >> 5], 1u << (r & 31));
+  }
+}
+
+__global__ void __launch_bounds__(256) k_emit_unmatched(const uint32_t* __restrict__ matched_bits, int64_t build_rows,
+                                                        int32_t* out_probe, int32_t* out_build, int64_t capacity,
+                                                        unsigned long long* cursor)
+{
+  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  for (int64_t i0 = (int64_t)blockIdx.x * blockDim.x; i0 < build_rows; i0 += stride) {
+    const int64_t i  = i0 + threadIdx.x;
+    const bool un    = i < build_rows && !((matched_bits[i >> 5] >> (i & 31)) & 1u);
+    const uint64_t b = ballot(un);
+    if (b == 0) continue;
+    unsigned long long base = 0;
+    if (lane_id() == (unsigned)__builtin_ctzll(b)) base = atomicAdd(cursor, (unsigned long long)__builtin_popcountll(b));
+    base = shfl(base, __builtin_ctzll(b));
+    if (un) {
+      const unsigned long long pos = base + (unsigned long long)__builtin_popcountll(b & lanemask_lt());
+      if ((int64_t)pos < capacity) {
+        out_probe[pos] = NO_MATCH;
+        out_build[pos] = (int32_t)i;
+      }
+    }
+  }
+}
+
+}  // namespace join
+}  // namespace gx
+
+extern "C" {
+
+/* tmp: (build_rows + 31) / 32 uint32 words (query with tmp == NULL).  *cursor_dev must hold the number
+ * of pairs already in out_* (the left-join result); unmatched build rows are appended from there. */
+int gx_join_complement(const int32_t* build_idx, int64_t n, int64_t build_rows, int32_t* out_probe_idx,
+                       int32_t* out_build_idx, int64_t capacity, int64_t* cursor_dev, void* tmp, size_t* tmp_bytes,
+                       gx_stream_t s)
+{
+  if (n < 0 || build_rows < 0 || !tmp_bytes) return GX_EINVAL;
+  const size_t need = gx::align_up((size_t)((build_rows + 31) / 32) * 4 + 4, 256);
+  if (!tmp) {
+    *tmp_bytes = need;
+    return 0;
+  }
+  if (*tmp_bytes < need) return GX_ETMP;
+  if (!cursor_dev) return GX_EINVAL;
+  GX_HIP_TRY(hipMemsetAsync(tmp, 0, need, s));
+  if (n > 0) {
+    int64_t blocks = gx::div_up(n, 256 * 8);
+    if (blocks > 4096) blocks = 4096;
+    hipLaunchKernelGGL(gx::join::k_mark_matched, dim3((unsigned)blocks), dim3(256), 0, s, build_idx, n, static_cast<uint32_t*>(tmp));
+  }
+  if (build_rows > 0) {
+    int64_t blocks = gx::div_up(build_rows, 256 * 4);
+    if (blocks > 4096) blocks = 4096;
+    hipLaunchKernelGGL(gx::join::k_emit_unmatched, dim3((unsigned)blocks), dim3(256), 0, s, static_cast<const uint32_t*>(tmp),
+                       build_rows, out_probe_idx, out_build_idx, capacity, reinterpret_cast<unsigned long long*>(cursor_dev));
+  }
+  GX_LAUNCH_CHECK();
+  return 0;
+}
+
+}  // extern "C"

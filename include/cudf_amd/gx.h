@@ -206,6 +206,14 @@ int gx_join_probe(int key_size, const void* probe_keys, const uint32_t* probe_va
                   int32_t* out_probe_idx, int32_t* out_build_idx, int64_t capacity,
                   int64_t* cursor_dev, gx_stream_t stream);
 
+/* cudf::full_join's complement step (src/join/join_utils.cu:86-157): appends (JoinNoMatch, r) for
+ * every build row r in [0, build_rows) that does not occur in build_idx[0..n) to the pair arrays,
+ * starting at *cursor_dev (device int64: pairs already present, updated to the new total; pairs
+ * beyond `capacity` are counted but not written).  tmp: cub-style query. */
+int gx_join_complement(const int32_t* build_idx, int64_t n, int64_t build_rows, int32_t* out_probe_idx,
+                       int32_t* out_build_idx, int64_t capacity, int64_t* cursor_dev, void* tmp,
+                       size_t* tmp_bytes, gx_stream_t stream);
+
 /* ------------------------------------------------------------------------------------------
  * Groupby, hash path (single int32/int64 key column; values int32/int64/float32/float64).
  * Replaces src/groupby/hash/compute_groupby.cu:50-155 + compute_global_memory_aggs.cuh:123-157:
@@ -226,6 +234,16 @@ int gx_groupby_sum_count(int key_dtype, const void* keys, const uint32_t* keys_v
  * table), 1 = global-atomic table only, 2 = partitioned for every n > 0.  nsplit: workgroups per
  * partition in the LDS aggregation kernel (1..16). */
 void gx_groupby_set_algorithm(int algo, int nsplit);
+
+/* Result finalizers of cudf::groupby::aggregate: (a) validity bitmap of SUM / MEAN results from
+ * COUNT_VALID -- a group without a valid value is null (src/groupby/hash/output_utils.cu:68-70);
+ * *null_count_dev (device int64) receives the number of null groups; mask_out needs
+ * (n + 31) / 32 words.  (b) MEAN = SUM / COUNT_VALID computed in double
+ * (src/groupby/hash/hash_compound_agg_finalizer.cu:92-133); sum_dtype in {INT64, FLOAT64, FLOAT32}. */
+int gx_valid_from_counts(const int32_t* counts, int64_t n, uint32_t* mask_out, int64_t* null_count_dev,
+                         gx_stream_t stream);
+int gx_mean_from_sum(int sum_dtype, const void* sum, const int32_t* count, int64_t n, double* out,
+                     gx_stream_t stream);
 
 /* Segmented inclusive scan over sorted group labels: replaces thrust::inclusive_scan_by_key at
  * src/groupby/sort/group_scan_util.cuh:109-130 (groupby::scan SUM/MIN/MAX).  keys are the

@@ -6,6 +6,7 @@
 #include <rmm/cuda_stream_view.hpp>
 
 #include <cstddef>
+#include <cstdlib>
 #include <new>
 
 namespace rmm {
@@ -42,10 +43,34 @@ class hip_async_memory_resource final : public device_memory_resource {
   }
 };
 
+// plain hipMalloc / hipFree; deallocation waits for the stream so the block cannot be reused under
+// work that is still in flight
+class hip_memory_resource final : public device_memory_resource {
+  void* do_allocate(std::size_t bytes, cuda_stream_view) override
+  {
+    void* p = nullptr;
+    if (hipMalloc(&p, bytes) != hipSuccess) throw std::bad_alloc();
+    return p;
+  }
+  void do_deallocate(void* p, std::size_t, cuda_stream_view stream) noexcept override
+  {
+    (void)hipStreamSynchronize(stream.value());
+    (void)hipFree(p);
+  }
+};
+
+// CUDF_AMD_ALLOC=async selects the stream-ordered pool (hipMallocAsync); the default is plain
+// hipMalloc: on ROCm 7.2 blocks recycled by the stream-ordered pool were observed to lose
+// host-to-device copies issued right after re-allocation (tests/cpp reproduces it with the pool).
 inline device_memory_resource* get_default_resource()
 {
-  static hip_async_memory_resource r;
-  return &r;
+  static hip_async_memory_resource pool;
+  static hip_memory_resource plain;
+  static bool const use_pool = [] {
+    char const* e = std::getenv("CUDF_AMD_ALLOC");
+    return e != nullptr && e[0] == 'a';
+  }();
+  return use_pool ? static_cast<device_memory_resource*>(&pool) : static_cast<device_memory_resource*>(&plain);
 }
 
 }  // namespace mr

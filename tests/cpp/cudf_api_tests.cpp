@@ -1,0 +1,497 @@
+// C++ API parity tests: drive the drop-in through the reference's own interface (cudf::sort,
+// cudf::hash_join, cudf::groupby::groupby, cudf::reduce, cudf::scan ...) with the literal vectors of
+// the reference's gtest suites (file:line cited per case).  No gtest in this image: a minimal
+// harness.  Needs a GPU; run by tests/test_gpu_cpp_api.py.
+#include <cudf/aggregation.hpp>
+#include <cudf/column/column_factories.hpp>
+#include <cudf/copying.hpp>
+#include <cudf/groupby.hpp>
+#include <cudf/hashing.hpp>
+#include <cudf/join/hash_join.hpp>
+#include <cudf/join/join.hpp>
+#include <cudf/reduction.hpp>
+#include <cudf/sorting.hpp>
+
+#include <execinfo.h>
+#include <signal.h>
+#include <unistd.h>
+
+#include <algorithm>
+#include <cmath>
+#include <cstdio>
+#include <functional>
+#include <limits>
+#include <numeric>
+#include <random>
+#include <string>
+#include <vector>
+
+using namespace cudf;
+static int g_failed = 0, g_run = 0;
+#define CHECK(cond)                                                                   \
+  do {                                                                                \
+    if (!(cond)) {                                                                    \
+      std::printf("    CHECK failed %s:%d: %s\n", __FILE__, __LINE__, #cond);         \
+      throw std::runtime_error("check failed");                                       \
+    }                                                                                 \
+  } while (0)
+
+template <typename T>
+std::unique_ptr<column> make_col(std::vector<T> const& v, std::vector<int> const& valid = {})
+{
+  auto const n = static_cast<size_type>(v.size());
+  rmm::device_buffer data{v.data(), v.size() * sizeof(T), get_default_stream()};
+  rmm::device_buffer mask{};
+  size_type nulls = 0;
+  if (!valid.empty()) {
+    std::vector<bitmask_type> w(bitmask_allocation_size_bytes(n) / 4, 0u);
+    for (size_type i = 0; i < n; ++i) {
+      if (valid[i]) w[i / 32] |= 1u << (i % 32); else ++nulls;
+    }
+    mask = rmm::device_buffer{w.data(), w.size() * 4, get_default_stream()};
+  }
+  get_default_stream().synchronize();
+  return std::make_unique<column>(data_type{type_to_id<T>()}, n, std::move(data), std::move(mask), nulls);
+}
+
+template <typename T>
+std::vector<T> to_host(column_view const& c)
+{
+  std::vector<T> h(c.size());
+  if (c.size()) (void)hipMemcpy(h.data(), c.data<T>(), h.size() * sizeof(T), hipMemcpyDeviceToHost);
+  return h;
+}
+std::vector<int> valid_host(column_view const& c)
+{
+  std::vector<int> v(c.size(), 1);
+  if (!c.nullable()) return v;
+  std::vector<bitmask_type> w(num_bitmask_words(c.size() + c.offset()));
+  (void)hipMemcpy(w.data(), c.null_mask(), w.size() * 4, hipMemcpyDeviceToHost);
+  for (size_type i = 0; i < c.size(); ++i) v[i] = (w[(i + c.offset()) / 32] >> ((i + c.offset()) % 32)) & 1;
+  return v;
+}
+template <typename T>
+std::vector<T> to_host(rmm::device_uvector<T> const& c)
+{
+  std::vector<T> h(c.size());
+  if (c.size()) (void)hipMemcpy(h.data(), c.data(), h.size() * sizeof(T), hipMemcpyDeviceToHost);
+  return h;
+}
+using pairs_t = std::vector<std::pair<int, int>>;
+pairs_t sorted_pairs(join_result const& r)
+{
+  auto l = to_host(*r.first);
+  auto rr = to_host(*r.second);
+  pairs_t p;
+  for (std::size_t i = 0; i < l.size(); ++i) p.emplace_back(l[i], rr[i]);
+  std::sort(p.begin(), p.end());
+  return p;
+}
+template <typename Exc, typename F>
+bool throws(F&& f)
+{
+  try {
+    f();
+  } catch (Exc const&) {
+    return true;
+  } catch (...) {
+    return false;
+  }
+  return false;
+}
+void run(char const* name, std::function<void()> f)
+{
+  ++g_run;
+  try {
+    f();
+    std::printf("[ OK ] %s\n", name);
+  } catch (std::exception const& e) {
+    ++g_failed;
+    std::printf("[FAIL] %s: %s\n", name, e.what());
+  }
+}
+
+
+static void dbg_h2d(char const* where)
+{
+  std::vector<int32_t> kv(300000);
+  for (std::size_t i = 0; i < kv.size(); ++i) kv[i] = (int32_t)(i % 5000) + 1;
+  auto c  = make_col<int32_t>(kv);
+  auto h0 = to_host<int32_t>(c->view());
+  std::size_t bad = 0;
+  for (std::size_t i = 0; i < kv.size(); ++i) bad += h0[i] != kv[i];
+  std::printf("  dbg[%s] make_col: bad %zu first %d ptr %p\n", where, bad, h0[0], c->view().head<void>());
+  (void)hipMemcpy(const_cast<void*>(c->view().head<void>()), kv.data(), kv.size() * 4, hipMemcpyHostToDevice);
+  h0  = to_host<int32_t>(c->view());
+  bad = 0;
+  for (std::size_t i = 0; i < kv.size(); ++i) bad += h0[i] != kv[i];
+  std::printf("  dbg[%s] after sync hipMemcpy: bad %zu\n", where, bad);
+  rmm::device_buffer raw{kv.data(), kv.size() * 4, get_default_stream()};
+  get_default_stream().synchronize();
+  std::vector<int32_t> h1(kv.size());
+  (void)hipMemcpy(h1.data(), raw.data(), kv.size() * 4, hipMemcpyDeviceToHost);
+  bad = 0;
+  for (std::size_t i = 0; i < kv.size(); ++i) bad += h1[i] != kv[i];
+  std::printf("  dbg[%s] raw device_buffer: bad %zu ptr %p\n", where, bad, raw.data());
+}
+
+static void on_segv(int sig)
+{
+  void* frames[64];
+  int const n = backtrace(frames, 64);
+  backtrace_symbols_fd(frames, n, STDERR_FILENO);
+  _exit(128 + sig);
+}
+
+int main()
+{
+  setvbuf(stdout, nullptr, _IONBF, 0);
+  signal(SIGSEGV, on_segv);
+  int ndev = 0;
+  if (hipGetDeviceCount(&ndev) != hipSuccess || ndev == 0) {
+    std::printf("no GPU\n");
+    return 77;
+  }
+  if (getenv("CUDF_AMD_DEBUG")) dbg_h2d("start");
+  constexpr double NaN = std::numeric_limits<double>::quiet_NaN();
+  constexpr double Inf = std::numeric_limits<double>::infinity();
+
+  // ---- sort: cpp/tests/sort/stable_sort_tests.cpp:88-123
+  run("sorted_order single column no nulls (stable_sort_tests.cpp:88-104)", [] {
+    auto c = make_col<int32_t>({7, 1, -2, 5, 1, 0, 1, -2, 0, 5});
+    auto o = stable_sorted_order(table_view{{c->view()}});
+    CHECK((to_host<int32_t>(o->view()) == std::vector<int32_t>{2, 7, 5, 8, 1, 4, 6, 3, 9, 0}));
+    auto u = make_col<uint32_t>({7, 1, (uint32_t)-2, 5, 1, 0, 1, (uint32_t)-2, 0, 5});
+    auto o2 = sorted_order(table_view{{u->view()}});
+    CHECK((to_host<int32_t>(o2->view()) == std::vector<int32_t>{5, 8, 1, 4, 6, 3, 9, 0, 2, 7}));
+    CHECK(o->type().id() == type_id::INT32 && !o->nullable());
+  });
+  run("sorted_order with nulls BEFORE (stable_sort_tests.cpp:106-123)", [] {
+    auto c = make_col<int64_t>({7, 1, -2, 5, 1, 0, 1, -2, 0, 5}, {1, 1, 0, 0, 1, 0, 1, 0, 1, 0});
+    auto o = stable_sorted_order(table_view{{c->view()}}, {order::ASCENDING}, {null_order::BEFORE});
+    // the reference compares the GATHERED table (run_stable_sort_test :20-31): null rows are interchangeable
+    auto h = to_host<int32_t>(o->view());
+    std::vector<int32_t> nulls(h.begin(), h.begin() + 5), rest(h.begin() + 5, h.end());
+    std::sort(nulls.begin(), nulls.end());
+    CHECK((nulls == std::vector<int32_t>{2, 3, 5, 7, 9}));
+    CHECK((rest == std::vector<int32_t>{8, 1, 4, 6, 0}));
+  });
+  run("sorted_order floats: NaN / Inf / -0.0 (sort_test.cpp:1071-1083)", [&] {
+    auto c = make_col<double>({-0.0, -NaN, -NaN, NaN, Inf, -Inf, 7, 5, 6, NaN, Inf, -Inf, -NaN, -NaN, -0.0});
+    auto o = sorted_order(table_view{{c->view()}});
+    CHECK((to_host<int32_t>(o->view()) == std::vector<int32_t>{5, 11, 0, 14, 7, 8, 6, 4, 10, 1, 2, 3, 9, 12, 13}));
+  });
+  run("multi-column sorted_order {ASC, DESC} (sort_test.cpp:148-175, numeric columns)", [] {
+    auto c1 = make_col<int32_t>({5, 4, 3, 5, 8});
+    auto c3 = make_col<int32_t>({10, 40, 70, 5, 2});
+    auto o  = sorted_order(table_view{{c1->view(), c3->view()}}, {order::ASCENDING, order::DESCENDING});
+    CHECK((to_host<int32_t>(o->view()) == std::vector<int32_t>{2, 1, 0, 3, 4}));
+  });
+  run("multi-column with nulls AFTER (sort_test.cpp:50-84, numeric columns)", [] {
+    auto c1 = make_col<int32_t>({5, 4, 3, 5, 8, 5}, {1, 1, 0, 1, 1, 1});
+    auto c3 = make_col<int32_t>({10, 40, 70, 5, 2, 10}, {1, 1, 0, 1, 1, 1});
+    auto o  = sorted_order(table_view{{c1->view(), c3->view()}}, {order::ASCENDING, order::DESCENDING},
+                           {null_order::AFTER, null_order::AFTER});
+    // col1 asc: 4(1) 5(0,3,5) 8(4) null(2); among the 5s col3 desc: 10(0),10(5),5(3) -> stable 0,5,3
+    CHECK((to_host<int32_t>(o->view()) == std::vector<int32_t>{1, 0, 5, 3, 4, 2}));
+  });
+  run("sort / sort_by_key / error messages (sort.cu:31-67, sort_impl.cuh:45)", [] {
+    std::mt19937_64 rng(1);
+    std::vector<int64_t> v(100003);
+    for (auto& x : v) x = (int64_t)rng();
+    auto c   = make_col<int64_t>(v);
+    auto out = sort(table_view{{c->view()}}, {order::DESCENDING});
+    std::sort(v.begin(), v.end(), std::greater<int64_t>());
+    CHECK(to_host<int64_t>(out->view().column(0)) == v);
+    auto k  = make_col<int32_t>({3, 1, 2});
+    auto pv = make_col<double>({30., 10., 20.});
+    auto sb = sort_by_key(table_view{{pv->view()}}, table_view{{k->view()}});
+    CHECK((to_host<double>(sb->view().column(0)) == std::vector<double>{10., 20., 30.}));
+    auto k2 = make_col<int32_t>({3, 1});
+    CHECK(throws<std::logic_error>([&] { sort_by_key(table_view{{pv->view()}}, table_view{{k2->view()}}); }));
+    CHECK(throws<std::logic_error>([&] { sorted_order(table_view{{k->view()}}, {order::ASCENDING, order::ASCENDING}); }));
+    auto e = sorted_order(table_view{});
+    CHECK(e->size() == 0 && e->type().id() == type_id::INT32);
+  });
+
+  // ---- join: cpp/tests/join/join_tests.cpp:1163-1237, 2040-2123 (single key column forms)
+  run("inner_join / left_join / full_join single key (join_tests.cpp:1163-1237)", [] {
+    auto l = make_col<int32_t>({3, 1, 2, 0, 2});
+    auto r = make_col<int32_t>({2, 2, 0, 4, 3});
+    auto ij = inner_join(table_view{{l->view()}}, table_view{{r->view()}});
+    CHECK((sorted_pairs(ij) == pairs_t{{0, 4}, {2, 0}, {2, 1}, {3, 2}, {4, 0}, {4, 1}}));
+    auto lj = left_join(table_view{{l->view()}}, table_view{{r->view()}});
+    CHECK((sorted_pairs(lj) == pairs_t{{0, 4}, {1, JoinNoMatch}, {2, 0}, {2, 1}, {3, 2}, {4, 0}, {4, 1}}));
+    auto fj = full_join(table_view{{l->view()}}, table_view{{r->view()}});
+    CHECK((sorted_pairs(fj) == pairs_t{{JoinNoMatch, 3}, {0, 4}, {1, JoinNoMatch}, {2, 0}, {2, 1}, {3, 2}, {4, 0}, {4, 1}}));
+  });
+  run("hash_join object: sequential probes, sizes, errors (join_tests.cpp:2040-2123; hash_join.cu:49-58)", [] {
+    auto b = make_col<int64_t>({2, 2, 0, 4, 3});
+    for (double lf : {0.5, 1.0}) {
+      hash_join hj{table_view{{b->view()}}, nullable_join::NO, null_equality::EQUAL, lf};
+      auto p1 = make_col<int64_t>({3, 1, 2, 0, 2});
+      CHECK(hj.inner_join_size(table_view{{p1->view()}}) == 6);
+      CHECK(sorted_pairs(hj.inner_join(table_view{{p1->view()}})).size() == 6);
+      auto p2 = make_col<int64_t>({9, 9, 9, 0, 3});
+      CHECK((sorted_pairs(hj.inner_join(table_view{{p2->view()}}, 2)) == pairs_t{{3, 2}, {4, 4}}));
+      CHECK(hj.left_join_size(table_view{{p2->view()}}) == 5);
+      CHECK(hj.full_join_size(table_view{{p2->view()}}) == 8);
+      auto pn = make_col<int64_t>({1, 2}, {1, 0});
+      CHECK(throws<std::invalid_argument>([&] { (void)hj.inner_join(table_view{{pn->view()}}); }));
+      auto pt = make_col<int32_t>({1, 2});
+      CHECK(throws<cudf::data_type_error>([&] { (void)hj.inner_join(table_view{{pt->view()}}); }));
+    }
+    CHECK(throws<std::invalid_argument>([&] { hash_join hj{table_view{}, null_equality::EQUAL}; }));
+    CHECK(throws<std::invalid_argument>([&] { hash_join hj{table_view{{b->view()}}, nullable_join::NO, null_equality::EQUAL, 0.0}; }));
+  });
+  run("join on nulls, both null_equality values (join_tests.cpp:1421-...)", [] {
+    auto l = make_col<int32_t>({1, 2, 0, 7}, {1, 1, 0, 1});
+    auto r = make_col<int32_t>({2, 0, 9, 0}, {1, 0, 1, 0});
+    auto eq = inner_join(table_view{{l->view()}}, table_view{{r->view()}}, null_equality::EQUAL);
+    CHECK((sorted_pairs(eq) == pairs_t{{1, 0}, {2, 1}, {2, 3}}));
+    auto ne = inner_join(table_view{{l->view()}}, table_view{{r->view()}}, null_equality::UNEQUAL);
+    CHECK((sorted_pairs(ne) == pairs_t{{1, 0}}));
+    auto e  = make_col<int32_t>({});
+    auto em = inner_join(table_view{{l->view()}}, table_view{{e->view()}});
+    CHECK(em.first->size() == 0 && em.second->size() == 0);
+    auto le = left_join(table_view{{l->view()}}, table_view{{e->view()}});
+    CHECK((sorted_pairs(le) == pairs_t{{0, JoinNoMatch}, {1, JoinNoMatch}, {2, JoinNoMatch}, {3, JoinNoMatch}}));
+  });
+  run("large join: build on the smaller side, pair orientation kept (join.cu:49-59)", [] {
+    std::mt19937 rng(3);
+    std::vector<int64_t> big(200000), small(5000);
+    for (auto& x : big) x = rng() % 20000;
+    for (std::size_t i = 0; i < small.size(); ++i) small[i] = (int64_t)i * 3;
+    auto cb = make_col<int64_t>(big);
+    auto cs = make_col<int64_t>(small);
+    auto a  = sorted_pairs(inner_join(table_view{{cs->view()}}, table_view{{cb->view()}}));  // left = small
+    std::size_t expect = 0;
+    for (auto x : big) expect += (x % 3 == 0 && x / 3 < 5000);
+    CHECK(a.size() == expect);
+    for (auto const& p : a) CHECK(small[p.first] == big[p.second]);
+  });
+
+  // ---- groupby: cpp/tests/groupby/{sum,count,mean}_tests.cpp, sum_scan_tests.cpp
+  auto by_key = [](table const& keys, std::vector<std::unique_ptr<column>> const& res) {
+    auto k = to_host<int32_t>(keys.view().column(0));
+    std::vector<int> idx(k.size());
+    std::iota(idx.begin(), idx.end(), 0);
+    std::sort(idx.begin(), idx.end(), [&](int a, int b) { return k[a] < k[b]; });
+    return std::make_pair(k, idx);
+  };
+  run("groupby SUM/COUNT/MEAN basic (sum_tests.cpp:68-80, count_tests.cpp:21-41, mean_tests.cpp:37-56)", [&] {
+    auto keys = make_col<int32_t>({1, 2, 3, 1, 2, 2, 1, 3, 3, 2});
+    auto vals = make_col<int32_t>({0, 1, 2, 3, 4, 5, 6, 7, 8, 9});
+    groupby::groupby gb{table_view{{keys->view()}}};
+    std::vector<groupby::aggregation_request> reqs(1);
+    reqs[0].values = vals->view();
+    reqs[0].aggregations.push_back(make_sum_aggregation<groupby_aggregation>());
+    reqs[0].aggregations.push_back(make_count_aggregation<groupby_aggregation>());
+    reqs[0].aggregations.push_back(make_mean_aggregation<groupby_aggregation>());
+    auto [k, res] = gb.aggregate(reqs);
+    auto [kh, idx] = by_key(*k, res[0].results);
+    CHECK(kh.size() == 3);
+    auto s = to_host<int64_t>(res[0].results[0]->view());
+    auto c = to_host<int32_t>(res[0].results[1]->view());
+    auto m = to_host<double>(res[0].results[2]->view());
+    CHECK(res[0].results[0]->type().id() == type_id::INT64);
+    int64_t es[] = {9, 19, 17};
+    int32_t ec[] = {3, 4, 3};
+    double em[]  = {3., 19. / 4, 17. / 3};
+    for (int g = 0; g < 3; ++g) {
+      CHECK(kh[idx[g]] == g + 1 && s[idx[g]] == es[g] && c[idx[g]] == ec[g] && m[idx[g]] == em[g]);
+    }
+  });
+  run("groupby with null keys and values (sum_tests.cpp:124-145, count_tests.cpp:103-132, mean_tests.cpp:102-128)", [&] {
+    auto keys = make_col<int32_t>({1, 2, 3, 1, 2, 2, 1, 3, 3, 2, 4}, {1, 1, 1, 1, 1, 1, 1, 0, 1, 1, 1});
+    auto vals = make_col<double>({0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 4}, {0, 1, 1, 1, 1, 0, 1, 1, 1, 1, 0});
+    groupby::groupby gb{table_view{{keys->view()}}};
+    std::vector<groupby::aggregation_request> reqs(1);
+    reqs[0].values = vals->view();
+    reqs[0].aggregations.push_back(make_sum_aggregation<groupby_aggregation>());
+    reqs[0].aggregations.push_back(make_count_aggregation<groupby_aggregation>());
+    reqs[0].aggregations.push_back(make_count_aggregation<groupby_aggregation>(null_policy::INCLUDE));
+    reqs[0].aggregations.push_back(make_mean_aggregation<groupby_aggregation>());
+    auto [k, res] = gb.aggregate(reqs);
+    auto [kh, idx] = by_key(*k, res[0].results);
+    CHECK(kh.size() == 4);
+    auto s  = to_host<double>(res[0].results[0]->view());
+    auto sv = valid_host(res[0].results[0]->view());
+    auto cv = to_host<int32_t>(res[0].results[1]->view());
+    auto ca = to_host<int32_t>(res[0].results[2]->view());
+    auto m  = to_host<double>(res[0].results[3]->view());
+    auto mv = valid_host(res[0].results[3]->view());
+    double es[] = {9, 14, 10, 0};
+    int ev[]    = {1, 1, 1, 0};
+    int ecv[]   = {2, 3, 2, 0};
+    int eca[]   = {3, 4, 2, 1};
+    double em[] = {4.5, 14. / 3, 5., 0};
+    for (int g = 0; g < 4; ++g) {
+      int i = idx[g];
+      CHECK(kh[i] == g + 1 && sv[i] == ev[g] && mv[i] == ev[g] && cv[i] == ecv[g] && ca[i] == eca[g]);
+      if (ev[g]) CHECK(s[i] == es[g] && m[i] == em[g]);
+    }
+    CHECK(res[0].results[0]->null_count() == 1);
+  });
+  run("groupby edge cases: empty input, all-null keys, size mismatch, int32 sum does not wrap (sum_tests.cpp:82-108,167-188)", [&] {
+    auto ek = make_col<int32_t>({});
+    auto ev = make_col<int32_t>({});
+    groupby::groupby gb0{table_view{{ek->view()}}};
+    std::vector<groupby::aggregation_request> r0(1);
+    r0[0].values = ev->view();
+    r0[0].aggregations.push_back(make_sum_aggregation<groupby_aggregation>());
+    auto [k0, res0] = gb0.aggregate(r0);
+    CHECK(k0->num_rows() == 0 && res0[0].results[0]->size() == 0 && res0[0].results[0]->type().id() == type_id::INT64);
+    auto nk = make_col<int32_t>({1, 2, 3}, {0, 0, 0});
+    auto nv = make_col<int32_t>({3, 4, 5});
+    groupby::groupby gb1{table_view{{nk->view()}}};
+    std::vector<groupby::aggregation_request> r1(1);
+    r1[0].values = nv->view();
+    r1[0].aggregations.push_back(make_sum_aggregation<groupby_aggregation>());
+    auto [k1, res1] = gb1.aggregate(r1);
+    CHECK(k1->num_rows() == 0);
+    auto sv = make_col<int32_t>({1, 2});
+    std::vector<groupby::aggregation_request> r2(1);
+    r2[0].values = sv->view();
+    r2[0].aggregations.push_back(make_sum_aggregation<groupby_aggregation>());
+    CHECK(throws<std::logic_error>([&] { (void)gb1.aggregate(r2); }));
+    auto ok = make_col<int32_t>({0, 0});
+    auto ov = make_col<int32_t>({std::numeric_limits<int32_t>::min(), std::numeric_limits<int32_t>::min()});
+    groupby::groupby gb3{table_view{{ok->view()}}};
+    std::vector<groupby::aggregation_request> r3(1);
+    r3[0].values = ov->view();
+    r3[0].aggregations.push_back(make_sum_aggregation<groupby_aggregation>());
+    auto [k3, res3] = gb3.aggregate(r3);
+    CHECK(to_host<int64_t>(res3[0].results[0]->view())[0] == -4294967296ll);
+  });
+  if (getenv("CUDF_AMD_DEBUG")) dbg_h2d("before two requests");
+  run("groupby two requests give consistently ordered results", [&] {
+    std::mt19937 rng(5);
+    std::vector<int32_t> kv(300000);
+    std::vector<double> a(kv.size()), b(kv.size());
+    for (std::size_t i = 0; i < kv.size(); ++i) {
+      kv[i] = rng() % 5000;
+      a[i]  = (double)(rng() % 1000);
+      b[i]  = (double)(rng() % 7);
+    }
+    auto keys = make_col<int32_t>(kv);
+    { auto h0 = to_host<int32_t>(keys->view()); std::printf("    after make_col: %d %d %d ptr %p\n", h0[0], h0[1], h0[2], keys->view().head<void>()); }
+    auto ca = make_col<double>(a);
+    auto cb = make_col<double>(b);
+    { auto h0 = to_host<int32_t>(keys->view()); std::printf("    after 3 cols: %d %d %d; a ptr %p b ptr %p\n", h0[0], h0[1], h0[2], ca->view().head<void>(), cb->view().head<void>()); }
+    groupby::groupby gb{table_view{{keys->view()}}};
+    std::vector<groupby::aggregation_request> reqs(2);
+    reqs[0].values = ca->view();
+    reqs[0].aggregations.push_back(make_sum_aggregation<groupby_aggregation>());
+    reqs[1].values = cb->view();
+    reqs[1].aggregations.push_back(make_sum_aggregation<groupby_aggregation>());
+    auto [k, res] = gb.aggregate(reqs);
+    auto kh = to_host<int32_t>(k->view().column(0));
+    auto sa = to_host<double>(res[0].results[0]->view());
+    auto sb = to_host<double>(res[1].results[0]->view());
+    std::vector<double> ea(5000, 0.), eb(5000, 0.);
+    for (std::size_t i = 0; i < kv.size(); ++i) {
+      ea[kv[i]] += a[i];
+      eb[kv[i]] += b[i];
+    }
+    if (kh.size() != 5000) {
+      auto mn = reduce(keys->view(), *make_min_aggregation<reduce_aggregation>(), data_type{type_id::INT32});
+      auto mx = reduce(keys->view(), *make_max_aggregation<reduce_aggregation>(), data_type{type_id::INT32});
+      std::printf("    groups: %zu sums %zu %zu; key[0]=%d sum=%g; device keys min %d max %d; host kv[0..2]=%d %d %d\n", kh.size(),
+                  sa.size(), sb.size(), kh[0], sa[0], static_cast<numeric_scalar<int32_t>&>(*mn).value(),
+                  static_cast<numeric_scalar<int32_t>&>(*mx).value(), kv[0], kv[1], kv[2]);
+    }
+    CHECK(kh.size() == 5000);
+    for (std::size_t g = 0; g < kh.size(); ++g) CHECK(sa[g] == ea[kh[g]] && sb[g] == eb[kh[g]]);  // small integers: exact
+  });
+  run("groupby SUM scan (sum_scan_tests.cpp:33-48,118-139)", [&] {
+    auto keys = make_col<int32_t>({1, 2, 3, 1, 2, 2, 1, 3, 3, 2});
+    auto vals = make_col<int32_t>({0, 1, 2, 3, 4, 5, 6, 7, 8, 9});
+    groupby::groupby gb{table_view{{keys->view()}}};
+    std::vector<groupby::scan_request> reqs(1);
+    reqs[0].values = vals->view();
+    reqs[0].aggregations.push_back(make_sum_aggregation<groupby_scan_aggregation>());
+    auto [k, res] = gb.scan(reqs);
+    CHECK((to_host<int32_t>(k->view().column(0)) == std::vector<int32_t>{1, 1, 1, 2, 2, 2, 2, 3, 3, 3}));
+    CHECK((to_host<int64_t>(res[0].results[0]->view()) == std::vector<int64_t>{0, 3, 9, 1, 5, 10, 19, 2, 9, 17}));
+    auto k2 = make_col<int32_t>({1, 2, 3, 1, 2, 2, 1, 3, 3, 2, 4}, {1, 1, 1, 1, 1, 1, 1, 0, 1, 1, 1});
+    auto v2 = make_col<int32_t>({0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 4}, {0, 1, 1, 1, 1, 0, 1, 1, 1, 1, 0});
+    groupby::groupby gb2{table_view{{k2->view()}}};
+    std::vector<groupby::scan_request> r2(1);
+    r2[0].values = v2->view();
+    r2[0].aggregations.push_back(make_sum_aggregation<groupby_scan_aggregation>());
+    auto [kk, rr] = gb2.scan(r2);
+    CHECK((to_host<int32_t>(kk->view().column(0)) == std::vector<int32_t>{1, 1, 1, 2, 2, 2, 2, 3, 3, 4}));
+    auto o = to_host<int64_t>(rr[0].results[0]->view());
+    auto v = valid_host(rr[0].results[0]->view());
+    int64_t e[] = {0, 3, 9, 1, 5, 0, 14, 2, 10, 0};
+    int ev[]    = {0, 1, 1, 1, 1, 0, 1, 1, 1, 0};
+    for (int i = 0; i < 10; ++i) {
+      CHECK(v[i] == ev[i]);
+      if (ev[i]) CHECK(o[i] == e[i]);
+    }
+  });
+
+  // ---- reduce / scan: cpp/tests/reductions/{reduction_tests.cpp,scan_tests.cpp}
+  run("reduce SUM/MIN/MAX with nulls; all-null -> invalid scalar", [] {
+    auto c = make_col<int32_t>({6, -14, 13, 64, 0, -13, -20, 45}, {1, 0, 1, 1, 1, 1, 0, 1});
+    auto s = reduce(c->view(), *make_sum_aggregation<reduce_aggregation>(), data_type{type_id::INT64});
+    CHECK(s->is_valid() && static_cast<numeric_scalar<int64_t>&>(*s).value() == 6 + 13 + 64 + 0 - 13 + 45);
+    auto mn = reduce(c->view(), *make_min_aggregation<reduce_aggregation>(), data_type{type_id::INT32});
+    auto mx = reduce(c->view(), *make_max_aggregation<reduce_aggregation>(), data_type{type_id::INT32});
+    CHECK(static_cast<numeric_scalar<int32_t>&>(*mn).value() == -13 && static_cast<numeric_scalar<int32_t>&>(*mx).value() == 64);
+    auto n = make_col<double>({1., 2.}, {0, 0});
+    auto sn = reduce(n->view(), *make_sum_aggregation<reduce_aggregation>(), data_type{type_id::FLOAT64});
+    CHECK(!sn->is_valid());
+    CHECK(throws<cudf::data_type_error>([&] { (void)reduce(c->view(), *make_min_aggregation<reduce_aggregation>(), data_type{type_id::INT64}); }));
+  });
+  run("scan inclusive / exclusive, null policies (scan_inclusive.cu:36-61,198-216)", [] {
+    auto c = make_col<int32_t>({1, 2, 3, 4, 5}, {1, 1, 0, 1, 1});
+    auto inc = scan(c->view(), *make_sum_aggregation<scan_aggregation>(), scan_type::INCLUSIVE);
+    auto h = to_host<int32_t>(inc->view());
+    auto v = valid_host(inc->view());
+    CHECK(h[0] == 1 && h[1] == 3 && h[3] == 7 && h[4] == 12 && (v == std::vector<int>{1, 1, 0, 1, 1}));
+    auto exc = scan(c->view(), *make_sum_aggregation<scan_aggregation>(), scan_type::EXCLUSIVE);
+    auto he = to_host<int32_t>(exc->view());
+    CHECK(he[0] == 0 && he[1] == 1 && he[3] == 3 && he[4] == 7);
+    auto poison = scan(c->view(), *make_max_aggregation<scan_aggregation>(), scan_type::INCLUSIVE, null_policy::INCLUDE);
+    CHECK((valid_host(poison->view()) == std::vector<int>{1, 1, 0, 0, 0}));
+    auto w = make_col<int8_t>({100, 100, 100});
+    auto ws = scan(w->view(), *make_sum_aggregation<scan_aggregation>(), scan_type::INCLUSIVE);
+    CHECK(to_host<int8_t>(ws->view())[2] == (int8_t)(300 & 0xFF));  // output dtype == input dtype, wraps
+  });
+
+  // ---- hashing / partitioning / gather / data model
+  run("murmurhash3_x86_32 + hash_partition (murmurhash3_x86_32_test.cpp; partitioning.hpp:103-110)", [] {
+    auto c = make_col<int32_t>({0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11});
+    auto h = hashing::murmurhash3_x86_32(table_view{{c->view()}});
+    auto hh = to_host<uint32_t>(h->view());
+    auto [t, offs] = hash_partition(table_view{{c->view()}}, {0}, 4);
+    auto out = to_host<int32_t>(t->view().column(0));
+    CHECK(offs.size() == 4 && offs[0] == 0 && t->num_rows() == 12);
+    for (int p = 0; p < 4; ++p) {
+      int e = p + 1 < 4 ? offs[p + 1] : 12;
+      for (int i = offs[p]; i < e; ++i) CHECK((int)(hh[out[i]] % 4) == p);
+    }
+    auto sorted = out;
+    std::sort(sorted.begin(), sorted.end());
+    CHECK((sorted == to_host<int32_t>(c->view())));
+  });
+  run("gather NULLIFY / column & table ownership (gather.cuh:506-577, column.hpp:248-269)", [] {
+    auto c = make_col<double>({1., 2., 3.}, {1, 0, 1});
+    auto m = make_col<int32_t>({2, JoinNoMatch, 1, 0});
+    auto g = gather(table_view{{c->view()}}, m->view(), out_of_bounds_policy::NULLIFY);
+    CHECK((valid_host(g->view().column(0)) == std::vector<int>{1, 0, 0, 1}));
+    CHECK(g->get_column(0).null_count() == 2);
+    column copy{*c};
+    CHECK(copy.size() == 3 && copy.null_count() == 1);
+    auto contents = copy.release();
+    CHECK(copy.size() == 0 && copy.type().id() == type_id::EMPTY && contents.data->size() == 24);
+    CHECK(throws<cudf::logic_error>([&] { table_view bad{{c->view(), m->view()}}; }));
+    column_view sl{c->type(), 2, c->view().head<void>(), c->view().null_mask(), 1, 1};
+    CHECK(sl.null_count(0, 2) == 1 && sl.data<double>() == c->view().data<double>() + 1);
+  });
+
+  std::printf("%d run, %d failed\n", g_run, g_failed);
+  return g_failed ? 1 : 0;
+}
