@@ -7,8 +7,10 @@
 A "step" is one pass of the hot path over one batch of synthetic input already resident in HBM
 (generated on the device by a counter-based RNG, so no PCIe traffic inside or outside the timed
 region).  Default workload = BASELINE.json configs[1]: 1e9-row int64 radix sort (cudf::sort) on
-one GPU.  N > 1: one process per GPU (torch.distributed / RCCL for the barrier only); the path
-shards by rows with no data-path collective, each rank sorts its own shard  -> "scaling": "weak".
+one GPU.  N > 1: one process per GPU (torch.distributed / RCCL over xGMI), every rank holds a shard
+of `--rows` rows and the step is the DISTRIBUTED operator of cudf_amd/distributed.py (sample sort /
+hash-partitioned join / pre-aggregated groupby: one all-to-all exchange each, no all-reduce) ->
+"scaling": "weak", value = rows of all ranks / max-over-ranks time.
 
 Rank 0 prints ONE JSON line (contract in the task statement) with two extra objects:
   roofline     -- dominant kernel (the radix scatter pass): algorithmic bytes per launch
@@ -134,6 +136,30 @@ def main():
 
     roofline = None
     extra = {}
+    dist_step = None
+    if world > 1:
+        # distributed operators: same synthetic shards, one all-to-all exchange per step
+        from cudf_amd import distributed as D
+        local_ops = D.HipLocalOps()
+
+        def as_tensor(col, dt):
+            return col.data[: col.size * col.dtype.itemsize].view(dt)
+        if args.workload in ("sort", "sorted_order"):
+            dkeys = as_tensor(ops.random_column(np.int64, n, seed=42 + rank), torch.int64)
+            dist_step = lambda: D.distributed_sort(dkeys, local=local_ops)
+            dist_name = f"{n:.0e}-row-per-GPU int64 distributed sort (local sort, splitters, all-to-all, local sort)"
+        elif args.workload == "join":
+            nbr = max(1, n // 10)
+            torch.manual_seed(12345 + rank)
+            dbk = (torch.randperm(nbr, device="cuda") + rank * nbr) * 3 + 1           # globally distinct build keys
+            dpk = as_tensor(ops.random_column(np.int64, n, seed=67890 + rank, lo=0, hi=int(nbr * world / 0.3)), torch.int64) * 3 + 1
+            dist_step = lambda: D.distributed_inner_join(dpk, dbk, local=local_ops)
+            dist_name = f"{n:.0e}-row-per-GPU probe x {nbr:.0e} build distributed inner join (hash partition, all-to-all, local join)"
+        else:
+            dgk = as_tensor(ops.random_column(np.int32, n, seed=7 + rank, lo=0, hi=1_000_000), torch.int32)
+            dgv = as_tensor(ops.random_column(np.float64, n, seed=8 + rank), torch.float64)
+            dist_step = lambda: D.distributed_groupby_sum_count(dgk, dgv, local=local_ops)
+            dist_name = f"{n:.0e}-row-per-GPU groupby(int32 key, 1e6 groups).agg(f64 sum,count), partials exchanged"
     if args.workload in ("sort", "sorted_order"):
         keys = ops.random_column(np.int64, n, seed=42 + rank)
         pairs = args.workload == "sorted_order"
@@ -187,6 +213,10 @@ def main():
         workload = f"{n:.0e}-row groupby(int32 key, 1e6 groups).agg(float64 sum,count)"
         unit_rows = n
 
+    single_step = step
+    if dist_step is not None:
+        step = dist_step
+        workload = dist_name
     for _ in range(args.warmup):
         step()
     if args.workload in ("sort", "sorted_order"):
@@ -197,7 +227,7 @@ def main():
     hyb_acc, hyb_n = [0.0, 0.0, 0.0, 0.0], 0
     for _ in range(args.steps):
         step()
-        if args.workload in ("sort", "sorted_order"):
+        if args.workload in ("sort", "sorted_order") and dist_step is None:
             # reading the events waits for this step only; it is part of the timed region
             h = ctypes.c_float()
             p = (ctypes.c_float * 8)()
@@ -221,14 +251,38 @@ def main():
     ms_per_step = dt / args.steps * 1e3
 
     # correctness guard on the timed output (device-side, cheap): sorted + same multiset
-    if args.workload == "sort":
+    if dist_step is not None:
+        if args.workload in ("sort", "sorted_order"):
+            res = dist_step()
+            assert bool((res[1:] >= res[:-1]).all()), "distributed sort: shard not sorted"
+            tot = torch.tensor([res.numel()], device="cuda", dtype=torch.int64)
+            dist.all_reduce(tot)
+            assert int(tot.item()) == n * world, "distributed sort lost rows"
+            del res
+        if args.workload == "sort":
+            # roofline of the dominant LOCAL kernel: one profiled single-GPU sort of this rank's shard,
+            # outside the timed region
+            single_step()
+            h = ctypes.c_float()
+            p8 = (ctypes.c_float * 8)()
+            k = ctypes.c_int()
+            L.check(lib.gx_sort_profile_read(ctypes.byref(h), p8, ctypes.byref(k)), "profile_read")
+            act = [x for x in list(p8)[: k.value] if x > 0.05]
+            pass_ms_acc, launches, hist_ms_acc = sum(act), len(act), h.value * args.steps
+            h4 = (ctypes.c_float * 4)()
+            if lib.gx_sort_profile_read_hybrid(h4) == 0:
+                hyb_acc, hyb_n = list(h4), 1
+    elif args.workload == "sort":
         cin, cout = ops.checksum(keys), ops.checksum(out)
         assert cout[2] == 0 and cin[:2] == cout[:2], "sort output invalid"
         st = ctypes.c_int(0)
         lib.gx_sort_status(ptr(tmp), ctypes.byref(st), stream)
         assert st.value == 0, "look-back timed out"
     sort_info = None
-    if args.workload in ("sort", "sorted_order"):
+    local_sort_ms = ms_per_step  # duration the whole-sort model figures refer to
+    if dist_step is not None and args.workload == "sort":
+        local_sort_ms = hist_ms_acc / args.steps + (sum(hyb_acc) if hyb_n else pass_ms_acc)
+    if args.workload in ("sort", "sorted_order") and (dist_step is None or args.workload == "sort"):
         info = (ctypes.c_int32 * 8)()
         lib.gx_sort_info(ptr(tmp), info, stream)
         sort_info = dict(zip(["hybrid_attempted", "hybrid_used", "d1", "shift2", "bits2", "lds_passes", "max_cell",
@@ -247,9 +301,9 @@ def main():
                     "avg_launch_ms": ms[dom], "launches_per_step": 1.0,
                     "kernels_ms": dict(zip(names, ms)), "kernels_GBps": {k: b * n / (m * 1e-3) / 1e9 for k, b, m in zip(names, bpr, ms)},
                     "hist_kernel_ms": hist_ms_acc / args.steps,
-                    "path_bytes_per_row": 64, "path_GBps": 64 * n / (ms_per_step * 1e-3) / 1e9,
-                    "whole_sort_model_GBps": model_bytes_row * n / (ms_per_step * 1e-3) / 1e9,
-                    "whole_sort_model_frac": model_bytes_row * n / (ms_per_step * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                    "path_bytes_per_row": 64, "path_GBps": 64 * n / (local_sort_ms * 1e-3) / 1e9,
+                    "whole_sort_model_GBps": model_bytes_row * n / (local_sort_ms * 1e-3) / 1e9,
+                    "whole_sort_model_frac": model_bytes_row * n / (local_sort_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
                     "sort_info": sort_info}
     elif args.workload in ("sort", "sorted_order") and launches:
         avg_ms = pass_ms_acc / launches
@@ -259,9 +313,11 @@ def main():
                     "algorithmic_bytes_per_launch": bytes_per_row_pass * n, "avg_launch_ms": avg_ms,
                     "launches_per_step": launches / args.steps,
                     "hist_kernel_ms": hist_ms_acc / args.steps,
-                    "whole_sort_model_GBps": model_bytes_row * n / (ms_per_step * 1e-3) / 1e9,
-                    "whole_sort_model_frac": model_bytes_row * n / (ms_per_step * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                    "whole_sort_model_GBps": model_bytes_row * n / (local_sort_ms * 1e-3) / 1e9,
+                    "whole_sort_model_frac": model_bytes_row * n / (local_sort_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
                     "sort_info": sort_info}
+    elif dist_step is not None:
+        roofline = None  # distributed join / groupby: see the N=1 lines for the kernels' rooflines
     elif args.workload == "join":
         matches = int(cur.item())
         algb = 24 * n + 16 * matches
@@ -289,7 +345,8 @@ def main():
             "vs_baseline": None, "dtype": {"sort": "int64", "sorted_order": "int64", "join": "int64", "groupby": "f64"}[args.workload],
             "data": "synthetic",
             "config": {"workload": workload, "rows_per_gpu": n, "algo": args.algo, "gb_algo": args.gb_algo,
-                       "parallelism": f"row shards x{world}, no data-path collective"},
+                       "parallelism": (f"{world} ranks, row shards, one all-to-all exchange per step (RCCL over xGMI)"
+                                       if world > 1 else "1 GPU")},
             "roofline": roofline, "cpu_baseline": cpu,
         }
         line.update(extra)

@@ -1,0 +1,187 @@
+"""One-process-per-GPU forms of the hot path: torch.distributed over RCCL on
+MI355X (backend "nccl"), gloo in the CPU tests.
+
+Each function takes this rank's SHARD and returns this rank's shard of the result.  The data path
+has exactly one exchange step per operation -- an all-to-all over the xGMI mesh (point-to-point
+links, so the full mesh keeps all 7 links of a GPU busy; a ring all-reduce would be per-link
+bound) -- preceded by an all-gather of a few scalars (counts / splitters).  Reference analogues:
+cudf::hash_partition + the rapidsmpf shuffler (cpp/libcudf_streaming/src/partition_utils.cpp:72-117),
+cudf_polars' sample -> allgather boundaries -> shuffle -> local sort
+(python/cudf_polars/cudf_polars/streaming/actor_graph/collectives/sort.py) and its piecewise
+groupby (streaming/groupby.py:411-437).
+
+The local work goes through a `LocalOps` object.  The product implementation (`HipLocalOps`) calls
+the HIP kernels through cudf_amd.ops; the CPU tests inject a NumPy implementation of the same
+interface (tests/cpu_local_ops.py) to exercise the exchange logic with gloo -- this module itself
+never touches the oracle.
+"""
+from __future__ import annotations
+
+from typing import List, Optional, Sequence, Tuple
+
+import numpy as np
+import torch
+import torch.distributed as dist
+
+
+# ------------------------------------------------------------------------------------------------
+# local kernels behind an interface
+# ------------------------------------------------------------------------------------------------
+class HipLocalOps:
+    """Local operators on CUDA tensors, implemented by libcudf_amd.so (no CPU path)."""
+
+    def __init__(self):
+        from . import ops  # raises if the HIP library is missing
+        from .column import Column
+        self._ops = ops
+        self._Column = Column
+
+    def _col(self, t: torch.Tensor):
+        t = t.contiguous()
+        return self._Column(t.view(torch.uint8).reshape(-1), np.dtype(str(t.dtype).replace("torch.", "")), t.numel())
+
+    @staticmethod
+    def _tensor(col, dtype: torch.dtype) -> torch.Tensor:
+        return col.data[: col.size * col.dtype.itemsize].view(dtype)
+
+    def sort(self, keys: torch.Tensor) -> torch.Tensor:
+        return self._tensor(self._ops.sort(self._col(keys)), keys.dtype)
+
+    def hash_partition(self, keys: torch.Tensor, nparts: int) -> Tuple[torch.Tensor, List[int]]:
+        """(int32 gather map grouping rows by murmur3(key) % nparts, nparts+1 offsets)"""
+        m, offs = self._ops.hash_partition_map([self._col(keys)], nparts)
+        return self._tensor(m, torch.int32), [int(x) for x in offs]
+
+    def gather(self, values: torch.Tensor, gather_map: torch.Tensor) -> torch.Tensor:
+        out = self._ops.gather(self._col(values), self._col(gather_map))
+        return self._tensor(out, values.dtype)
+
+    def inner_join(self, left: torch.Tensor, right: torch.Tensor) -> Tuple[torch.Tensor, torch.Tensor]:
+        li, ri = self._ops.inner_join(self._col(left), self._col(right))
+        return self._tensor(li, torch.int32), self._tensor(ri, torch.int32)
+
+    def groupby_sum_count(self, keys: torch.Tensor, vals: torch.Tensor):
+        k, s, cv, _ = self._ops.groupby_sum_count(self._col(keys), self._col(vals))
+        sdt = vals.dtype if vals.dtype.is_floating_point else torch.int64
+        return self._tensor(k, keys.dtype), self._tensor(s, sdt), self._tensor(cv, torch.int32)
+
+
+# ------------------------------------------------------------------------------------------------
+# exchange primitives
+# ------------------------------------------------------------------------------------------------
+def _world(group) -> Tuple[int, int]:
+    return dist.get_rank(group), dist.get_world_size(group)
+
+
+def exchange_counts(send_counts: Sequence[int], device, group=None) -> List[int]:
+    """all-to-all of one int64 per peer: recv_counts[j] = what rank j sends to me."""
+    _, world = _world(group)
+    s = torch.tensor(list(send_counts), dtype=torch.int64, device=device)
+    r = torch.empty(world, dtype=torch.int64, device=device)
+    dist.all_to_all_single(r, s, group=group)
+    return [int(x) for x in r.cpu()]
+
+
+def all_to_all_rows(data: torch.Tensor, send_counts: Sequence[int], recv_counts: Sequence[int], group=None) -> torch.Tensor:
+    """Rows [sum(send_counts[:j]), +send_counts[j]) of `data` go to rank j; returns the rows received,
+    ordered by source rank.  One collective on the full xGMI mesh."""
+    out = torch.empty(int(sum(recv_counts)), dtype=data.dtype, device=data.device)
+    dist.all_to_all_single(out, data.contiguous(), output_split_sizes=list(recv_counts),
+                           input_split_sizes=list(send_counts), group=group)
+    return out
+
+
+def _offsets_to_counts(offsets: Sequence[int]) -> List[int]:
+    return [int(offsets[i + 1] - offsets[i]) for i in range(len(offsets) - 1)]
+
+
+# ------------------------------------------------------------------------------------------------
+# distributed operators
+# ------------------------------------------------------------------------------------------------
+def distributed_sort(keys: torch.Tensor, local: Optional[object] = None, group=None, samples_per_rank: int = 64) -> torch.Tensor:
+    """Global sort of the concatenation of all ranks' shards; rank r returns the r-th range, so the
+    concatenation of the results in rank order is sorted.  sample sort: local sort -> regular samples
+    -> all-gather -> common splitters -> contiguous slices of the sorted shard -> all-to-all ->
+    local sort of the received runs."""
+    local = local or HipLocalOps()
+    rank, world = _world(group)
+    if world == 1:
+        return local.sort(keys)
+    s = local.sort(keys)
+    n = s.numel()
+    # regular samples of the sorted shard (empty shards contribute the dtype's max so they never split)
+    if n > 0:
+        pos = torch.linspace(0, n - 1, samples_per_rank, device=s.device).round().to(torch.int64)
+        mine = s[pos]
+    else:
+        fill = torch.finfo(s.dtype).max if s.dtype.is_floating_point else torch.iinfo(s.dtype).max
+        mine = torch.full((samples_per_rank,), fill, dtype=s.dtype, device=s.device)
+    gathered = [torch.empty_like(mine) for _ in range(world)]
+    dist.all_gather(gathered, mine, group=group)
+    allsamp = local.sort(torch.cat(gathered))
+    cut = torch.arange(1, world, device=s.device) * samples_per_rank
+    splitters = allsamp[cut]                                  # world-1 values, identical on every rank
+    bounds = torch.searchsorted(s, splitters, right=False)    # first index >= splitter
+    edges = [0] + [int(x) for x in bounds.cpu()] + [n]
+    send = _offsets_to_counts(edges)
+    recv = exchange_counts(send, s.device, group)
+    got = all_to_all_rows(s, send, recv, group)
+    return local.sort(got)
+
+
+def distributed_inner_join(left: torch.Tensor, right: torch.Tensor, local: Optional[object] = None, group=None
+                           ) -> Tuple[torch.Tensor, torch.Tensor]:
+    """Inner equi-join of the concatenations of all ranks' `left` and `right` key shards.
+    Returns this rank's share of the result as (global_left_row, global_right_row) int64 tensors,
+    where a global row id = (offset of the owning rank's shard) + local row.  Both sides are
+    hash-partitioned with murmur3 % world (cudf::hash_partition's rule), exchanged once, joined
+    locally; outputs stay sharded."""
+    local = local or HipLocalOps()
+    rank, world = _world(group)
+    dev = left.device
+
+    def shard_offset(n: int) -> int:
+        sizes = [torch.empty(1, dtype=torch.int64, device=dev) for _ in range(world)]
+        dist.all_gather(sizes, torch.tensor([n], dtype=torch.int64, device=dev), group=group)
+        return int(sum(int(x) for x in sizes[:rank]))
+
+    def shuffle(keys: torch.Tensor) -> Tuple[torch.Tensor, torch.Tensor]:
+        base = shard_offset(keys.numel())
+        if world == 1:
+            return keys, torch.arange(keys.numel(), dtype=torch.int64, device=dev)
+        gmap, offs = local.hash_partition(keys, world)
+        send = _offsets_to_counts(offs)
+        recv = exchange_counts(send, dev, group)
+        pk = local.gather(keys, gmap)
+        gid = gmap.to(torch.int64) + base                      # global id of every partitioned row
+        return all_to_all_rows(pk, send, recv, group), all_to_all_rows(gid, send, recv, group)
+
+    lk, lid = shuffle(left)
+    rk, rid = shuffle(right)
+    li, ri = local.inner_join(lk, rk)
+    return local.gather(lid, li), local.gather(rid, ri)
+
+
+def distributed_groupby_sum_count(keys: torch.Tensor, vals: torch.Tensor, local: Optional[object] = None, group=None):
+    """groupby(keys).agg(sum, count) over all ranks' shards.  Pre-aggregate locally (<= #groups rows),
+    hash-partition the partials, one all-to-all, merge.  Every group ends on exactly one rank.
+    Returns (keys, sum, count) for the groups this rank owns (count as int64)."""
+    local = local or HipLocalOps()
+    rank, world = _world(group)
+    k, s, c = local.groupby_sum_count(keys, vals)
+    c = c.to(torch.int64)
+    if world == 1:
+        return k, s, c
+    gmap, offs = local.hash_partition(k, world)
+    send = _offsets_to_counts(offs)
+    recv = exchange_counts(send, k.device, group)
+    rk = all_to_all_rows(local.gather(k, gmap), send, recv, group)
+    rs = all_to_all_rows(local.gather(s, gmap), send, recv, group)
+    rc = all_to_all_rows(local.gather(c, gmap), send, recv, group)
+    # merge: sum of partial sums, sum of partial counts (two passes of the same kernel)
+    mk, ms, _ = local.groupby_sum_count(rk, rs)
+    mk2, mc, _ = local.groupby_sum_count(rk, rc)
+    # bring the count column into the key order of the sum column
+    o1 = torch.argsort(mk)
+    o2 = torch.argsort(mk2)
+    return mk[o1], ms[o1], mc[o2]

@@ -1,0 +1,31 @@
+"""TEST-ONLY NumPy implementation of cudf_amd.distributed's LocalOps interface, so the exchange
+logic (counts all-to-all, splitters, all_to_all_single with uneven splits, global row ids) can run
+under gloo on CPU tensors.  The product never imports this file."""
+import numpy as np
+import torch
+
+from oracle import cudf_oracle as orc
+
+
+class NumpyLocalOps:
+    def sort(self, keys):
+        return torch.from_numpy(np.sort(keys.numpy(), kind="stable"))
+
+    def hash_partition(self, keys, nparts):
+        h = orc.murmur3_32(keys.numpy())
+        part = (h % np.uint32(nparts)).astype(np.int64)
+        gmap = np.argsort(part, kind="stable").astype(np.int32)
+        counts = np.bincount(part, minlength=nparts)
+        offs = np.concatenate([[0], np.cumsum(counts)])
+        return torch.from_numpy(gmap), [int(x) for x in offs]
+
+    def gather(self, values, gather_map):
+        return values[gather_map.to(torch.int64)]
+
+    def inner_join(self, left, right):
+        l, r = orc.inner_join(left.numpy(), right.numpy())
+        return torch.from_numpy(l.astype(np.int32)), torch.from_numpy(r.astype(np.int32))
+
+    def groupby_sum_count(self, keys, vals):
+        k, res = orc.groupby_agg(keys.numpy(), vals.numpy(), ["sum", "count_valid"], exact=False)
+        return torch.from_numpy(k), torch.from_numpy(res["sum"][0]), torch.from_numpy(res["count_valid"][0])
