@@ -43,6 +43,7 @@ def parse():
                     help="sort knob: 0 onesweep/windowed look-back, 1 three-kernel, 2 onesweep/one-tile look-back")
     ap.add_argument("--gb-algo", type=int, default=0, help="groupby knob: 0 auto, 1 global table, 2 LDS-partitioned")
     ap.add_argument("--gb-split", type=int, default=1)
+    ap.add_argument("--no-partitioned-join", action="store_true", help="join: probe the table directly")
     ap.add_argument("--no-hybrid", action="store_true", help="sort: disable the hybrid MSD path (LSD passes only)")
     ap.add_argument("--cpu-baseline", dest="cpu", action="store_true", default=True)
     ap.add_argument("--no-cpu-baseline", dest="cpu", action="store_false")
@@ -191,10 +192,22 @@ def main():
         ro = Column.empty(np.int32, n)
         cur = torch.zeros(1, dtype=torch.int64, device="cuda")
 
+        part_bits = lib.gx_join_partition_bits(8, hj.table_bytes) if not args.no_partitioned_join else 0
+        extra["join_partition_bits"] = part_bits
+        jnb = ctypes.c_size_t(0)
+        if part_bits:
+            L.check(lib.gx_join_probe_partitioned(8, pk.data_ptr, n, ptr(hj.table), hj.table_bytes, 0, lo.data_ptr,
+                                                  ro.data_ptr, n, ptr(cur), None, ctypes.byref(jnb), stream), "query")
+            jtmp = device_bytes(jnb.value)
+
         def step():
             cur.zero_()
-            L.check(lib.gx_join_probe(8, pk.data_ptr, None, n, ptr(hj.table), hj.table_bytes, 0, lo.data_ptr,
-                                      ro.data_ptr, n, ptr(cur), stream), "probe")
+            if part_bits:
+                L.check(lib.gx_join_probe_partitioned(8, pk.data_ptr, n, ptr(hj.table), hj.table_bytes, 0, lo.data_ptr,
+                                                      ro.data_ptr, n, ptr(cur), ptr(jtmp), ctypes.byref(jnb), stream), "probe")
+            else:
+                L.check(lib.gx_join_probe(8, pk.data_ptr, None, n, ptr(hj.table), hj.table_bytes, 0, lo.data_ptr,
+                                          ro.data_ptr, n, ptr(cur), stream), "probe")
         workload = f"{n:.0e}-row int64 probe x {nb_rows:.0e}-row build inner hash join (probe phase timed)"
         unit_rows = n
     else:  # groupby
@@ -322,7 +335,7 @@ def main():
         matches = int(cur.item())
         algb = 24 * n + 16 * matches
         ach = algb / (ms_per_step * 1e-3) / 1e9
-        roofline = {"bound": "hbm", "kernel": "k_probe", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+        roofline = {"bound": "hbm", "kernel": "k_pj_hist+k_pj_scatter+k_pj_probe (partitioned probe)" if extra.get("join_partition_bits") else "k_probe", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                     "frac": ach / HBM_PEAK_GBS, "traffic": None, "algorithmic_bytes_per_launch": algb,
                     "avg_launch_ms": ms_per_step, "matches": matches}
     elif args.workload == "groupby":

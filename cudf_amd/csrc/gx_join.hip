@@ -14,6 +14,7 @@
 //     runs; the reference flushes per warp (partitioned_retrieve_kernels.cuh:57-211).
 // Result order is unspecified (cpp/include/cudf/join/join.hpp:131-134).
 #include "gx_common.hpp"
+#include <cstdlib>
 
 namespace gx {
 namespace join {
@@ -218,6 +219,395 @@ __global__ void __launch_bounds__(JBT) k_probe(const K* __restrict__ keys, const
   }
 }
 
+// ------------------------------------------------------------------------------------------------
+// Partitioned probe (large probes against tables far beyond the L2s).
+// The table is addressed by the TOP bits of key * phi, so its slots [p, p+1) * capacity / P already
+// form P sub-tables selected by the top log2(P) hash bits.  P is chosen so that a sub-table is about
+// 2 MiB -- half of one XCD's L2.  The probe rows are first radix-partitioned on those bits (one
+// streaming pass: LDS-atomic ranking, LDS reorder, space reserved per (XCD range, partition) so the
+// short runs of neighbouring tiles merge in one L2), then probed partition by partition with the
+// workgroups of XCD x taking the partitions of list x in order: all of them hammer the same 2 MiB
+// sub-table at the same time, so after the first touch every probe is an L2 hit instead of a random
+// HBM sector read.  Traffic: 8 + 12 (partition) + 12 + 8/match (probe) B/row, all streaming.
+// ------------------------------------------------------------------------------------------------
+constexpr int PJ_MAXP  = 4096;
+constexpr int PJ_BT    = 512;
+constexpr int PJ_RPT   = 8;
+constexpr int PJ_TILE  = PJ_BT * PJ_RPT;  // 4096 rows: the range split of the input is defined on these tiles
+constexpr int PJ_NR    = 8;               // XCD ranges
+constexpr int PJ_CHUNK = 8192;            // probe rows per output reservation
+
+struct alignas(128) PjCounter {
+  unsigned int v;
+  unsigned int pad[31];
+};
+struct PjPlan {
+  unsigned long long count[PJ_NR][PJ_MAXP];   // rows per (range, partition)
+  unsigned long long cursor[PJ_NR][PJ_MAXP];  // scatter cursors
+  unsigned long long offset[PJ_MAXP + 1];     // partition starts
+  unsigned int chunk0[PJ_MAXP + 1];           // first probe chunk of each partition (partitions in list order)
+  unsigned int list_chunk0[PJ_NR + 1];
+  PjCounter ticket[PJ_NR];                    // chunk tickets per XCD list, each on its own line
+};
+
+__device__ __forceinline__ unsigned pj_xcc() { return __builtin_amdgcn_s_getreg(20 | (0 << 6) | (3 << 11)) & 7u; }
+__host__ __device__ static inline int64_t pj_range_tiles(int64_t n) { return div_up(n, (int64_t)PJ_TILE) / PJ_NR; }
+
+template <typename K>
+__global__ void __launch_bounds__(256) k_pj_hist(const K* __restrict__ keys, int64_t n, PjPlan* plan, int pbits)
+{
+  __shared__ unsigned int s_h[PJ_MAXP];
+  const int P = 1 << pbits;
+  for (int i = threadIdx.x; i < P; i += 256) s_h[i] = 0;
+  __syncthreads();
+  const int r          = blockIdx.x % PJ_NR;
+  const int64_t jb     = blockIdx.x / PJ_NR;
+  const int64_t nb     = gridDim.x / PJ_NR;
+  const int64_t per    = pj_range_tiles(n) * PJ_TILE;
+  const int64_t rbegin = (int64_t)r * per;
+  const int64_t rend   = (r == PJ_NR - 1) ? n : rbegin + per;
+  constexpr int U      = 8;
+  const int64_t stride = nb * 256 * U;
+  for (int64_t i0 = rbegin + jb * 256 * U + threadIdx.x; i0 < rend; i0 += stride) {
+    K k[U];
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const int64_t i = i0 + (int64_t)u * 256;
+      k[u]            = (i < rend) ? keys[i] : K(0);
+    }
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const int64_t i = i0 + (int64_t)u * 256;
+      if (i < rend) atomicAdd(&s_h[slot_of<K>(k[u], (uint32_t)pbits)], 1u);
+    }
+  }
+  __syncthreads();
+  for (int i = threadIdx.x; i < P; i += 256) {
+    const unsigned int c = s_h[i];
+    if (c) atomicAdd(&plan->count[r][i], (unsigned long long)c);
+  }
+}
+
+// one block of 1024 threads: offsets, cursors, probe-chunk numbering (partitions of list x = [x, x+1) * P / 8)
+__global__ void __launch_bounds__(1024) k_pj_offsets(PjPlan* plan, int pbits)
+{
+  __shared__ unsigned long long s_tmp[1024 / GX_WAVE + 1];
+  __shared__ unsigned long long s_carry;
+  __shared__ unsigned int s_ccarry;
+  const int P = 1 << pbits;
+  if (threadIdx.x == 0) {
+    s_carry  = 0;
+    s_ccarry = 0;
+  }
+  __syncthreads();
+  for (int base = 0; base < P; base += 1024) {
+    const int p = base + threadIdx.x;
+    unsigned long long c = 0;
+    if (p < P)
+      for (int r = 0; r < PJ_NR; ++r) c += plan->count[r][p];
+    unsigned long long total;
+    unsigned long long run = block_exclusive_scan<1024>(c, 0ull, SumOp(), s_tmp, &total) + s_carry;
+    const unsigned int nch = (unsigned int)((c + PJ_CHUNK - 1) / PJ_CHUNK);
+    unsigned long long ctotal;
+    const unsigned int ch0 = (unsigned int)block_exclusive_scan<1024>((unsigned long long)nch, 0ull, SumOp(), s_tmp, &ctotal) + s_ccarry;
+    if (p < P) {
+      plan->offset[p] = run;
+      plan->chunk0[p] = ch0;
+      if (p % (P / PJ_NR) == 0) plan->list_chunk0[p / (P / PJ_NR)] = ch0;
+      for (int r = 0; r < PJ_NR; ++r) {
+        plan->cursor[r][p] = run;
+        run += plan->count[r][p];
+      }
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+      s_carry += total;
+      s_ccarry += (unsigned int)ctotal;
+    }
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) {
+    plan->offset[P]           = s_carry;
+    plan->chunk0[P]           = s_ccarry;
+    plan->list_chunk0[PJ_NR]  = s_ccarry;
+  }
+}
+
+template <typename K, int RPT>
+__global__ void __launch_bounds__(PJ_BT) k_pj_scatter(const K* __restrict__ keys, int64_t n, PjPlan* plan, int pbits,
+                                                      K* __restrict__ pkeys, int32_t* __restrict__ pidx)
+{
+  constexpr int PJ_RPT  = RPT;
+  constexpr int PJ_TILE = PJ_BT * RPT;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  K* s_k               = reinterpret_cast<K*>(smem);                                     // PJ_TILE (reused for idx)
+  unsigned short* s_bin = reinterpret_cast<unsigned short*>(smem + (size_t)PJ_TILE * sizeof(K));  // PJ_TILE
+  unsigned int* s_cnt  = reinterpret_cast<unsigned int*>(s_bin + PJ_TILE);               // P
+  unsigned int* s_start = s_cnt + (1 << pbits);                                          // P
+  unsigned long long* s_delta = reinterpret_cast<unsigned long long*>(s_start + (1 << pbits));  // P
+  __shared__ unsigned int s_scan[PJ_BT / GX_WAVE + 1];
+  __shared__ unsigned int s_carry;
+
+  const int P         = 1 << pbits;
+  const unsigned tid  = threadIdx.x;
+  const int64_t tile  = xcd_swizzle(blockIdx.x, gridDim.x);
+  const int64_t base  = tile * PJ_TILE;
+  const int64_t rrows = pj_range_tiles(n) * gx::join::PJ_TILE;  // rows per input range (k_pj_hist's split)
+  const int range     = (rrows > 0 && base / rrows < PJ_NR - 1) ? (int)(base / rrows) : PJ_NR - 1;
+  const int nvalid    = (int)((n - base < (int64_t)PJ_TILE) ? (n - base) : (int64_t)PJ_TILE);
+  for (int i = tid; i < P; i += PJ_BT) s_cnt[i] = 0;
+  if (tid == 0) s_carry = 0;
+  K key[PJ_RPT];
+#pragma unroll
+  for (int j = 0; j < PJ_RPT; ++j) {
+    const int idx = j * PJ_BT + (int)tid;
+    key[j]        = (idx < nvalid) ? __builtin_nontemporal_load(&keys[base + idx]) : K(0);
+  }
+  __syncthreads();
+  unsigned int rank[PJ_RPT], part[PJ_RPT];
+#pragma unroll
+  for (int j = 0; j < PJ_RPT; ++j) {
+    const int idx = j * PJ_BT + (int)tid;
+    part[j]       = (unsigned int)slot_of<K>(key[j], (uint32_t)pbits);
+    rank[j]       = (idx < nvalid) ? atomicAdd(&s_cnt[part[j]], 1u) : 0u;
+  }
+  __syncthreads();
+  // exclusive scan of the P counts (P may exceed the block: strips of PJ_BT)
+  for (int b0 = 0; b0 < P; b0 += PJ_BT) {
+    const int b          = b0 + (int)tid;
+    const unsigned int c = b < P ? s_cnt[b] : 0u;
+    unsigned int total;
+    const unsigned int st = block_exclusive_scan<PJ_BT>(c, 0u, SumOp(), s_scan, &total) + s_carry;
+    if (b < P) {
+      s_start[b] = st;
+      unsigned long long g = 0;
+      if (c) g = atomicAdd(&plan->cursor[range][b], (unsigned long long)c);
+      s_delta[b] = g - st;
+    }
+    __syncthreads();
+    if (tid == 0) s_carry += total;
+    __syncthreads();
+  }
+  // keys through LDS
+#pragma unroll
+  for (int j = 0; j < PJ_RPT; ++j) {
+    const int idx = j * PJ_BT + (int)tid;
+    if (idx < nvalid) {
+      const unsigned int pos = s_start[part[j]] + rank[j];
+      s_k[pos]               = key[j];
+      s_bin[pos]             = (unsigned short)part[j];
+    }
+  }
+  __syncthreads();
+#pragma unroll
+  for (int j = 0; j < PJ_RPT; ++j) {
+    const int i = j * PJ_BT + (int)tid;
+    if (i < nvalid) pkeys[s_delta[s_bin[i]] + (unsigned long long)i] = s_k[i];
+  }
+  __syncthreads();
+  // row indices through the same buffer
+  int32_t* s_i = reinterpret_cast<int32_t*>(smem);
+#pragma unroll
+  for (int j = 0; j < PJ_RPT; ++j) {
+    const int idx = j * PJ_BT + (int)tid;
+    if (idx < nvalid) s_i[s_start[part[j]] + rank[j]] = (int32_t)(base + idx);
+  }
+  __syncthreads();
+#pragma unroll
+  for (int j = 0; j < PJ_RPT; ++j) {
+    const int i = j * PJ_BT + (int)tid;
+    if (i < nvalid) pidx[s_delta[s_bin[i]] + (unsigned long long)i] = s_i[i];
+  }
+}
+
+template <typename K>
+__global__ void __launch_bounds__(PJ_BT) k_pj_probe(const K* __restrict__ pkeys, const int32_t* __restrict__ pidx,
+                                                    PjPlan* plan, int pbits, const Slot<K>* __restrict__ slots,
+                                                    uint32_t log2cap, int left_outer, int32_t* __restrict__ out_probe,
+                                                    int32_t* __restrict__ out_build, int64_t capacity,
+                                                    unsigned long long* cursor)
+{
+  constexpr int NWJ  = PJ_BT / GX_WAVE;
+  constexpr int RPT  = PJ_CHUNK / PJ_BT;  // 16
+  __shared__ unsigned long long s_wave_tot[NWJ];
+  __shared__ unsigned long long s_base;
+  __shared__ unsigned int s_misc[4];
+  const int P        = 1 << pbits;
+  const int LISTP    = P / PJ_NR;
+  const uint64_t mask = (1ull << log2cap) - 1;
+  const unsigned tid  = threadIdx.x;
+  const unsigned lane = lane_id();
+  const unsigned w    = tid / GX_WAVE;
+
+  // ---- take a chunk: own XCD's list first
+  if (tid == 0) {
+    const unsigned x = pj_xcc();
+    unsigned int g   = 0xFFFFFFFFu;
+    for (int i = 0; i < PJ_NR; ++i) {
+      const unsigned y       = (x + i) % PJ_NR;
+      const unsigned int nch = plan->list_chunk0[y + 1] - plan->list_chunk0[y];
+      if (nch == 0) continue;
+      const unsigned int t = atomicAdd(&plan->ticket[y].v, 1u);
+      if (t < nch) {
+        g         = plan->list_chunk0[y] + t;
+        s_misc[1] = y;
+        break;
+      }
+    }
+    s_misc[0] = g;
+  }
+  __syncthreads();
+  const unsigned int g = s_misc[0];
+  if (g == 0xFFFFFFFFu) return;
+  {  // partition of chunk g inside its list: one table entry per thread (LISTP <= 512)
+    const unsigned y = s_misc[1];
+    for (int e = (int)tid; e < LISTP; e += PJ_BT) {
+      const int p           = (int)y * LISTP + e;
+      const unsigned int lo = plan->chunk0[p], hi = plan->chunk0[p + 1];
+      if (lo <= g && g < hi) {
+        s_misc[2] = (unsigned int)p;
+        s_misc[3] = g - lo;
+      }
+    }
+  }
+  __syncthreads();
+  const unsigned int part = s_misc[2];
+  const unsigned long long p0 = plan->offset[part], p1 = plan->offset[part + 1];
+  const unsigned long long c0 = p0 + (unsigned long long)s_misc[3] * PJ_CHUNK;
+  const unsigned long long c1 = c0 + PJ_CHUNK < p1 ? c0 + PJ_CHUNK : p1;
+
+  const unsigned long long wbase = c0 + (unsigned long long)w * (RPT * GX_WAVE) + lane;
+  uint32_t cnt[RPT];
+  int32_t first[RPT], row[RPT];
+  uint32_t wave_total = 0;
+#pragma unroll
+  for (int j = 0; j < RPT; ++j) {
+    const unsigned long long i = wbase + (unsigned long long)j * GX_WAVE;
+    cnt[j]   = 0;
+    first[j] = NO_MATCH;
+    row[j]   = 0;
+    if (i < c1) {
+      row[j] = __builtin_nontemporal_load(&pidx[i]);
+      cnt[j] = chain_count<K>(slots, mask, log2cap, __builtin_nontemporal_load(&pkeys[i]), first[j]);
+      if (left_outer && cnt[j] == 0) cnt[j] = 1;
+    }
+  }
+  uint32_t off[RPT];
+#pragma unroll
+  for (int j = 0; j < RPT; ++j) {
+    uint32_t inc;
+    if (ballot(cnt[j] > 1) == 0) {
+      const uint64_t b = ballot(cnt[j] == 1);
+      off[j]           = wave_total + (uint32_t)__builtin_popcountll(b & lanemask_lt());
+      inc              = (uint32_t)__builtin_popcountll(b);
+    } else {
+      const uint32_t sc = wave_inclusive_scan(cnt[j], SumOp());
+      off[j]            = wave_total + sc - cnt[j];
+      inc               = shfl(sc, GX_WAVE - 1);
+    }
+    wave_total += inc;
+  }
+  if (lane == 0) s_wave_tot[w] = wave_total;
+  __syncthreads();
+  if (tid == 0) {
+    unsigned long long tot = 0;
+    for (int k = 0; k < NWJ; ++k) {
+      const unsigned long long t = s_wave_tot[k];
+      s_wave_tot[k]              = tot;
+      tot += t;
+    }
+    s_base = tot ? atomicAdd(cursor, tot) : 0ull;
+  }
+  __syncthreads();
+  const unsigned long long wave_base = s_base + s_wave_tot[w];
+#pragma unroll
+  for (int j = 0; j < RPT; ++j) {
+    if (cnt[j] == 0) continue;
+    unsigned long long pos = wave_base + off[j];
+    if (cnt[j] == 1) {
+      if ((int64_t)pos < capacity) {
+        __builtin_nontemporal_store(row[j], &out_probe[pos]);
+        __builtin_nontemporal_store(first[j], &out_build[pos]);
+      }
+    } else {
+      const unsigned long long i = wbase + (unsigned long long)j * GX_WAVE;
+      const K key = pkeys[i];
+      uint64_t h  = slot_of<K>(key, log2cap);
+      for (;;) {
+        K k;
+        int32_t r;
+        load_slot<K>(&slots[h], k, r);
+        if (r == EMPTY_ROW) break;
+        if (k == key) {
+          if ((int64_t)pos < capacity) {
+            out_probe[pos] = row[j];
+            out_build[pos] = r;
+          }
+          ++pos;
+        }
+        h = (h + 1) & mask;
+      }
+    }
+  }
+}
+
+static inline int pj_bits(uint32_t log2cap, int slot_bytes)
+{
+  // sub-table of about 2 MiB: P = table bytes / 2 MiB
+  int lg_table = (int)log2cap + (slot_bytes == 16 ? 4 : 3);
+  int pb       = lg_table - 21;
+  if (getenv("GX_PJ_SUB")) pb = lg_table - atoi(getenv("GX_PJ_SUB"));  // experiment: log2 of the sub-table bytes
+  if (pb < 3) pb = 0;  // small tables: the direct probe is already cache resident
+  if (pb > 12) pb = 12;
+  return pb;
+}
+
+template <typename K>
+int probe_partitioned_impl(const void* keys, int64_t n, const void* table, size_t table_bytes, uint32_t lg,
+                           int left_outer, int32_t* out_probe, int32_t* out_build, int64_t capacity, int64_t* cursor,
+                           void* tmp, size_t* tmp_bytes, hipStream_t s)
+{
+  const int pbits = pj_bits(lg, (int)sizeof(Slot<K>));
+  Carver c(tmp);
+  PjPlan* plan   = c.take<PjPlan>(1);
+  K* pkeys       = c.take<K>((size_t)n);
+  int32_t* pidx  = c.take<int32_t>((size_t)n);
+  if (!tmp) {
+    *tmp_bytes = c.total();
+    return 0;
+  }
+  if (*tmp_bytes < c.total()) return GX_ETMP;
+  const size_t need = sizeof(TableHeader) + (sizeof(Slot<K>) << lg);
+  if (table_bytes < need) return GX_ETMP;
+  if (n == 0) return 0;
+  const Slot<K>* slots = reinterpret_cast<const Slot<K>*>(static_cast<const char*>(table) + sizeof(TableHeader));
+  if (pbits == 0) return GX_EINVAL;  // caller should use gx_join_probe
+  GX_HIP_TRY(hipMemsetAsync(plan, 0, sizeof(PjPlan), s));
+  int64_t hb = div_up(n, 256 * 8 * 4 * PJ_NR);
+  if (hb > 256) hb = 256;
+  if (hb < 1) hb = 1;
+  hipLaunchKernelGGL((k_pj_hist<K>), dim3((unsigned)(hb * PJ_NR)), dim3(256), 0, s, static_cast<const K*>(keys), n, plan, pbits);
+  hipLaunchKernelGGL(k_pj_offsets, dim3(1), dim3(1024), 0, s, plan, pbits);
+  const int rpt            = getenv("GX_PJ_RPT") ? atoi(getenv("GX_PJ_RPT")) : 8;
+  const size_t tile_rows   = (size_t)PJ_BT * (rpt == 16 ? 16 : 8);
+  const size_t lds_max     = (size_t)PJ_BT * 16 * sizeof(K) + (size_t)PJ_BT * 16 * 2 + (size_t)PJ_MAXP * (4 + 4 + 8);
+  const size_t lds         = tile_rows * sizeof(K) + tile_rows * 2 + ((size_t)16 << pbits);
+  auto ks                  = rpt == 16 ? k_pj_scatter<K, 16> : k_pj_scatter<K, 8>;
+  static bool attr_set = false;
+  if (!attr_set) {
+    GX_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(k_pj_scatter<K, 8>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_max));
+    GX_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(k_pj_scatter<K, 16>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_max));
+    attr_set = true;
+  }
+  hipLaunchKernelGGL(ks, dim3((unsigned)div_up(n, (int64_t)tile_rows)), dim3(PJ_BT), lds, s, static_cast<const K*>(keys), n, plan, pbits,
+                     pkeys, pidx);
+  const int64_t max_chunks = div_up(n, PJ_CHUNK) + (1 << pbits);
+  hipLaunchKernelGGL((k_pj_probe<K>), dim3((unsigned)max_chunks), dim3(PJ_BT), 0, s, pkeys, pidx, plan, pbits, slots, lg,
+                     left_outer, out_probe, out_build, capacity, reinterpret_cast<unsigned long long*>(cursor));
+  GX_LAUNCH_CHECK();
+  return 0;
+}
+
 template <typename K>
 int build_impl(const void* keys, const uint32_t* valid, int64_t n, void* table, size_t table_bytes,
                double load_factor, hipStream_t s)
@@ -309,6 +699,31 @@ int gx_join_probe(int key_size, const void* probe_keys, const uint32_t* probe_va
   if (key_size == 8) return gx::join::probe_impl<uint64_t, true>(probe_keys, probe_valid, probe_rows, table, table_bytes, lg, left_outer, out_probe_idx, out_build_idx, capacity, cursor_dev, s);
   if (key_size == 4) return gx::join::probe_impl<uint32_t, true>(probe_keys, probe_valid, probe_rows, table, table_bytes, lg, left_outer, out_probe_idx, out_build_idx, capacity, cursor_dev, s);
   return GX_EDTYPE;
+}
+
+
+/* see gx.h */
+int gx_join_probe_partitioned(int key_size, const void* probe_keys, int64_t probe_rows, const void* table,
+                              size_t table_bytes, int left_outer, int32_t* out_probe_idx, int32_t* out_build_idx,
+                              int64_t capacity, int64_t* cursor_dev, void* tmp, size_t* tmp_bytes, gx_stream_t s)
+{
+  if (probe_rows < 0 || capacity < 0 || !table || !tmp_bytes || (probe_rows > 0 && !probe_keys)) return GX_EINVAL;
+  if (tmp && (!cursor_dev || (capacity > 0 && (!out_probe_idx || !out_build_idx)))) return GX_EINVAL;
+  if (table_bytes <= sizeof(gx::join::TableHeader)) return GX_ETMP;
+  const uint32_t lg = gx_join_log2_from_bytes(key_size, table_bytes);
+  if (key_size == 8)
+    return gx::join::probe_partitioned_impl<uint64_t>(probe_keys, probe_rows, table, table_bytes, lg, left_outer, out_probe_idx,
+                                                      out_build_idx, capacity, cursor_dev, tmp, tmp_bytes, s);
+  if (key_size == 4)
+    return gx::join::probe_partitioned_impl<uint32_t>(probe_keys, probe_rows, table, table_bytes, lg, left_outer, out_probe_idx,
+                                                      out_build_idx, capacity, cursor_dev, tmp, tmp_bytes, s);
+  return GX_EDTYPE;
+}
+
+int gx_join_partition_bits(int key_size, size_t table_bytes)
+{
+  if ((key_size != 4 && key_size != 8) || table_bytes <= sizeof(gx::join::TableHeader)) return 0;
+  return gx::join::pj_bits(gx_join_log2_from_bytes(key_size, table_bytes), key_size == 8 ? 16 : 8);
 }
 
 }  // extern "C"

@@ -98,6 +98,9 @@ def _offsets_to_counts(offsets: Sequence[int]) -> List[int]:
 # ------------------------------------------------------------------------------------------------
 # distributed operators
 # ------------------------------------------------------------------------------------------------
+_FORCE_EXCHANGE = False  # tests: take the partition + all-to-all path even when world == 1
+
+
 def distributed_sort(keys: torch.Tensor, local: Optional[object] = None, group=None, samples_per_rank: int = 64) -> torch.Tensor:
     """Global sort of the concatenation of all ranks' shards; rank r returns the r-th range, so the
     concatenation of the results in rank order is sorted.  sample sort: local sort -> regular samples
@@ -105,7 +108,7 @@ def distributed_sort(keys: torch.Tensor, local: Optional[object] = None, group=N
     local sort of the received runs."""
     local = local or HipLocalOps()
     rank, world = _world(group)
-    if world == 1:
+    if world == 1 and not _FORCE_EXCHANGE:
         return local.sort(keys)
     s = local.sort(keys)
     n = s.numel()
@@ -147,7 +150,7 @@ def distributed_inner_join(left: torch.Tensor, right: torch.Tensor, local: Optio
 
     def shuffle(keys: torch.Tensor) -> Tuple[torch.Tensor, torch.Tensor]:
         base = shard_offset(keys.numel())
-        if world == 1:
+        if world == 1 and not _FORCE_EXCHANGE:
             return keys, torch.arange(keys.numel(), dtype=torch.int64, device=dev)
         gmap, offs = local.hash_partition(keys, world)
         send = _offsets_to_counts(offs)
@@ -170,7 +173,7 @@ def distributed_groupby_sum_count(keys: torch.Tensor, vals: torch.Tensor, local:
     rank, world = _world(group)
     k, s, c = local.groupby_sum_count(keys, vals)
     c = c.to(torch.int64)
-    if world == 1:
+    if world == 1 and not _FORCE_EXCHANGE:
         return k, s, c
     gmap, offs = local.hash_partition(k, world)
     send = _offsets_to_counts(offs)

@@ -177,11 +177,19 @@ class HashJoin:
             total += left.null_count * self.build.null_count if left.has_nulls() and self.build.has_nulls() else 0
         return total
 
+    PARTITIONED_MIN_ROWS = 1 << 22
+
     def _probe(self, left: Column, capacity: int, left_outer: bool):
         lo = Column.empty(np.int32, capacity)
         ro = Column.empty(np.int32, capacity)
         cur = _dev_i64()
         valid = left.mask_ptr if left.has_nulls() else None
+        if (valid is None and left.size >= self.PARTITIONED_MIN_ROWS
+                and _lib.gx_join_partition_bits(self.key_size, self.table_bytes) > 0):
+            # large probe against a table far beyond the L2s: partition the probe rows first
+            _run(_lib.gx_join_probe_partitioned, self.key_size, left.data_ptr, left.size, ptr(self.table),
+                 self.table_bytes, int(left_outer), lo.data_ptr, ro.data_ptr, capacity, ptr(cur))
+            return lo, ro, int(cur.item())
         L.check(_lib.gx_join_probe(self.key_size, left.data_ptr, valid, left.size, ptr(self.table), self.table_bytes,
                                    int(left_outer), lo.data_ptr, ro.data_ptr, capacity, ptr(cur), stream_ptr()),
                 "gx_join_probe")

@@ -206,6 +206,19 @@ int gx_join_probe(int key_size, const void* probe_keys, const uint32_t* probe_va
                   int32_t* out_probe_idx, int32_t* out_build_idx, int64_t capacity,
                   int64_t* cursor_dev, gx_stream_t stream);
 
+/* Partitioned form of gx_join_probe for large probes (no probe nulls) against tables far beyond the
+ * L2s: the probe rows are radix-partitioned on the table's top hash bits (one streaming pass), then
+ * probed partition by partition with XCD-affine scheduling so that each ~2 MiB sub-table is L2
+ * resident while it is probed.  Same outputs and cursor convention as gx_join_probe (pair order
+ * unspecified).  cub-style scratch query.  GX_EINVAL when the table is too small to partition
+ * (gx_join_partition_bits() == 0): use gx_join_probe. */
+int gx_join_probe_partitioned(int key_size, const void* probe_keys, int64_t probe_rows, const void* table,
+                              size_t table_bytes, int left_outer, int32_t* out_probe_idx,
+                              int32_t* out_build_idx, int64_t capacity, int64_t* cursor_dev, void* tmp,
+                              size_t* tmp_bytes, gx_stream_t stream);
+/* log2 of the number of partitions the partitioned probe uses for this table; 0 = not partitionable */
+int gx_join_partition_bits(int key_size, size_t table_bytes);
+
 /* cudf::full_join's complement step (src/join/join_utils.cu:86-157): appends (JoinNoMatch, r) for
  * every build row r in [0, build_rows) that does not occur in build_idx[0..n) to the pair arrays,
  * starting at *cursor_dev (device int64: pairs already present, updated to the new total; pairs

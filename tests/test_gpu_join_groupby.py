@@ -101,6 +101,43 @@ def test_reference_golden_join_single_key(gx, case):
             assert rows == sorted(case["expected_rows"])
 
 
+@pytest.mark.parametrize("dtype", ["int64", "int32"])
+def test_partitioned_probe_matches_direct_probe(gx, dtype):
+    """Large probes against tables beyond the L2s take the partitioned probe (radix-partition on the
+    table's top hash bits, XCD-affine probe); it must produce the same pair multiset as the direct
+    probe and as the oracle, incl. duplicate build keys and left-outer rows."""
+    import ctypes
+    import torch
+    Column, ops = gx
+    from cudf_amd import _lib as L
+    from cudf_amd.column import device_bytes, ptr, stream_ptr
+    rng = np.random.default_rng(21)
+    nb, npr = 1_200_000, (1 << 22) + 777
+    build = rng.permutation(3 * nb)[:nb].astype(dtype)
+    build[:1000] = build[5000:6000]                      # duplicate build keys
+    probe = rng.integers(0, 4 * nb, npr).astype(dtype)
+    hj = ops.HashJoin(Column.from_numpy(build))
+    assert L.lib.gx_join_partition_bits(hj.key_size, hj.table_bytes) >= 3
+    pc = Column.from_numpy(probe)
+    l, r = hj.inner_join(pc)                              # partitioned (n >= 2^22, no nulls)
+    gl, gr = _pairs(l, r)
+    el, er = orc.inner_join(probe, build)
+    np.testing.assert_array_equal(gl, el)
+    np.testing.assert_array_equal(gr, er)
+    # direct probe of the same table, for the left-outer form
+    old = ops.HashJoin.PARTITIONED_MIN_ROWS
+    try:
+        ops.HashJoin.PARTITIONED_MIN_ROWS = 1 << 62
+        dl, dr = hj.left_join(pc)
+    finally:
+        ops.HashJoin.PARTITIONED_MIN_ROWS = old
+    pl, pr = hj.left_join(pc)
+    a = _pairs(dl, dr)
+    b = _pairs(pl, pr)
+    np.testing.assert_array_equal(a[0], b[0])
+    np.testing.assert_array_equal(a[1], b[1])
+
+
 def test_join_large_properties(gx):
     """Size-independent checks at 2e7 x 2e6: every emitted pair has equal keys, count equals the
     oracle-free closed form (distinct build keys, known hit set)."""
