@@ -344,6 +344,16 @@ def main():
                     "frac": ach / HBM_PEAK_GBS, "traffic": None, "algorithmic_bytes_per_launch": 12 * n,
                     "avg_launch_ms": ms_per_step, "groups": int(ng.item())}
 
+    # HBM bytes of the dominant kernel from the committed PMC passes (same command, 1e9 rows)
+    if roofline is not None and n == 1_000_000_000:
+        try:
+            tr = json.load(open(os.path.join(ROOT, "profiles", "r1_pmc_traffic_1e9.json")))
+            for key, v in tr["kernels"].items():
+                if roofline["kernel"].startswith(key):
+                    roofline["traffic"] = v["hbm_bytes_per_launch"]
+                    roofline["traffic_source"] = tr["source"] + "; " + tr["correction"]
+        except (OSError, KeyError, ValueError):
+            pass
     if rank == 0:
         cpu = None
         if args.cpu and world == 1:

@@ -7,5 +7,6 @@ include/cudf_amd/gx.h).  There is NO CPU fallback: a missing library is an Impor
 from . import _lib  # noqa: F401  (raises if the HIP library is missing)
 from .column import Column  # noqa: F401
 from . import ops  # noqa: F401
+from .dataframe import DataFrame  # noqa: F401
 
 __version__ = "0.1.0"

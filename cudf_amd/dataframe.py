@@ -1,0 +1,152 @@
+"""Thin pandas-like wrapper over the hot path (the cudf.DataFrame surface of the reference, reduced
+to the methods that land on it): sort_values, merge, groupby(...).agg.
+
+reference: python/cudf/cudf/core/dataframe.py (sort_values -> core/_internals/sorting.py ->
+pylibcudf.sorting.sorted_order + gather; merge -> core/join/join.py -> pylibcudf.join.inner_join /
+left_join + gather; groupby(...).agg -> core/groupby/groupby.py -> pylibcudf.groupby.aggregate).
+Columns are fixed-width numeric; data moves host<->device only in from_pandas / to_pandas.
+"""
+from __future__ import annotations
+
+from typing import Dict, List, Optional, Sequence, Union
+
+import numpy as np
+
+from . import ops
+from .column import Column
+
+
+class DataFrame:
+    def __init__(self, data: Optional[Dict[str, Union[Column, np.ndarray, Sequence]]] = None):
+        self._cols: Dict[str, Column] = {}
+        for name, v in (data or {}).items():
+            self[name] = v
+
+    # ---- construction / export
+    @classmethod
+    def from_pandas(cls, pdf) -> "DataFrame":
+        df = cls()
+        for name in pdf.columns:
+            s = pdf[name]
+            if s.isna().any():
+                valid = ~s.isna().to_numpy()
+                vals = s.fillna(0).to_numpy()
+                df._cols[str(name)] = Column.from_numpy(vals, valid)
+            else:
+                df._cols[str(name)] = Column.from_numpy(s.to_numpy())
+        return df
+
+    def to_pandas(self):
+        import pandas as pd
+        out = {}
+        for name, c in self._cols.items():
+            v = c.to_numpy()
+            if c.has_nulls():
+                m = c.valid_numpy()
+                v = v.astype(np.float64) if v.dtype.kind != "f" else v.copy()
+                v[~m] = np.nan
+            out[name] = v
+        return pd.DataFrame(out)
+
+    # ---- dict-like
+    def __setitem__(self, name: str, value):
+        col = value if isinstance(value, Column) else Column.from_numpy(np.asarray(value))
+        if self._cols and len(col) != len(self):
+            raise ValueError("Length of values does not match length of index")
+        self._cols[name] = col
+
+    def __getitem__(self, name: str) -> Column:
+        return self._cols[name]
+
+    def __len__(self) -> int:
+        return next(iter(self._cols.values())).size if self._cols else 0
+
+    @property
+    def columns(self) -> List[str]:
+        return list(self._cols)
+
+    def _take(self, gather_map: Column, nullify: bool = False) -> "DataFrame":
+        out = DataFrame()
+        for name, c in self._cols.items():
+            out._cols[name] = ops.gather(c, gather_map, nullify_out_of_bounds=nullify)
+        return out
+
+    # ---- the hot path
+    def sort_values(self, by: Union[str, Sequence[str]], ascending: Union[bool, Sequence[bool]] = True,
+                    na_position: str = "last") -> "DataFrame":
+        """Stable sort by one or more key columns (pandas semantics: NaN/nulls last by default).
+        Several keys = LSD over the key columns with stable sorts, as cudf::sorted_order does."""
+        keys = [by] if isinstance(by, str) else list(by)
+        asc = [ascending] * len(keys) if isinstance(ascending, bool) else list(ascending)
+        if len(asc) != len(keys):
+            raise ValueError("Length of ascending must match the number of sort keys")
+        if na_position not in ("first", "last"):
+            raise ValueError("invalid na_position")
+        order = None
+        for name, a in reversed(list(zip(keys, asc))):
+            col = self._cols[name] if order is None else ops.gather(self._cols[name], order)
+            # NullOrder mapping of core/_internals/sorting.py:83-90: null_before = asc ^ (na == "last")
+            null_before = a ^ (na_position == "last")
+            perm = ops.sorted_order(col, ascending=a, null_before=null_before)
+            order = perm if order is None else ops.gather(order, perm)
+        return self._take(order)
+
+    def merge(self, right: "DataFrame", on: str, how: str = "inner", suffixes=("_x", "_y")) -> "DataFrame":
+        """Equi-join on one key column; how in {"inner", "left"}.  Row order is unspecified (as in
+        cudf); callers that need an order sort afterwards."""
+        if how not in ("inner", "left"):
+            raise NotImplementedError(f"merge(how={how!r}) is not on this path yet")
+        lk, rk = self._cols[on], right._cols[on]
+        if how == "inner":
+            li, ri = ops.inner_join(lk, rk, nulls_equal=False)
+        else:
+            li, ri = ops.left_join(lk, rk, nulls_equal=False)
+        out = DataFrame()
+        out._cols[on] = ops.gather(lk, li)
+        for name, c in self._cols.items():
+            if name != on:
+                out._cols[name + (suffixes[0] if name in right._cols else "")] = ops.gather(c, li)
+        for name, c in right._cols.items():
+            if name != on:
+                out._cols[name + (suffixes[1] if name in self._cols else "")] = ops.gather(c, ri, nullify_out_of_bounds=(how == "left"))
+        return out
+
+    def groupby(self, by: str) -> "GroupBy":
+        return GroupBy(self, by)
+
+
+class GroupBy:
+    _SUPPORTED = ("sum", "count", "mean")
+
+    def __init__(self, df: DataFrame, by: str):
+        self._df, self._by = df, by
+
+    def agg(self, spec: Dict[str, Union[str, Sequence[str]]]) -> DataFrame:
+        """{value column: "sum" | "count" | "mean" | [..]} -> one row per group, sorted by key
+        (pandas' default sort=True).  Null keys are dropped (dropna=True), null values are skipped."""
+        keys = self._df[self._by]
+        out = DataFrame()
+        first = True
+        for name, fns in spec.items():
+            fns = [fns] if isinstance(fns, str) else list(fns)
+            for f in fns:
+                if f not in self._SUPPORTED:
+                    raise NotImplementedError(f"groupby aggregation {f!r} is not on this path yet")
+            k, s, cv, _ = ops.groupby_sum_count(keys, self._df[name])
+            order = ops.sorted_order(k)
+            if first:
+                out._cols[self._by] = ops.gather(k, order)
+                first = False
+            s, cv = ops.gather(s, order), ops.gather(cv, order)
+            for f in fns:
+                label = name if len(fns) == 1 and len(spec) >= 1 and all(isinstance(v, str) for v in spec.values()) else f"{name}_{f}"
+                if f == "sum":
+                    out._cols[label] = s
+                elif f == "count":
+                    out._cols[label] = cv
+                else:
+                    sn, cn = s.to_numpy().astype(np.float64), cv.to_numpy()
+                    with np.errstate(divide="ignore", invalid="ignore"):
+                        m = sn / cn
+                    out._cols[label] = Column.from_numpy(np.where(cn > 0, m, 0.0), cn > 0)
+        return out
