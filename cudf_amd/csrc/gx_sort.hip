@@ -538,7 +538,7 @@ struct MsdArgs {
 // needs no placement assumption: within a list tickets are handed out in order, so every
 // predecessor a tile can wait for is already owned by a running workgroup.
 template <typename KeyT, int KIND, int KPT, int LBW>
-__global__ void __launch_bounds__(BT, 4) k_msd_pass(MsdArgs a)
+__global__ void __launch_bounds__(BT, (KPT <= 8 ? 8 : (KPT <= 12 ? 6 : 4))) k_msd_pass(MsdArgs a)
 {
   constexpr int TILE = BT * KPT;
   extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -613,52 +613,76 @@ __global__ void __launch_bounds__(BT, 4) k_msd_pass(MsdArgs a)
       key[j]        = (idx < nvalid) ? kin[base + idx] : KeyT(0);
     }
   }
+  // Ranking inside the tile.  Integer keys: equal keys are indistinguishable, so the partition need
+  // not be stable -- one returning LDS atomic per key on a 256-entry counter array replaces the
+  // 8-ballot match.  Floats keep the stable wave-match ranking (-0.0 == +0.0 must keep input order).
+  constexpr bool STABLE = KIND == K_FLOAT;
   uint32_t* my_hist = s_whist + w * BINS;
-#pragma unroll
-  for (int k = 0; k < BINS / GX_WAVE; ++k) my_hist[lane + k * GX_WAVE] = 0;
-
   uint32_t packed[KPT];
-#pragma unroll
-  for (int j = 0; j < KPT; ++j) {
-    const int idx = wbase + j * GX_WAVE;
-    uint32_t d    = (uint32_t)(to_sortable<KeyT, KIND>(key[j], desc_mask) >> shift) & dmask;
-    if (idx >= nvalid) d = BINS - 1;  // padding sorts last (it is also last in input order)
-    uint32_t lower, cnt;
-    match_rank8(d, true, ~0ull, lower, cnt);
-    const uint32_t prev = my_hist[d];
-    if (lower == 0) my_hist[d] = prev + cnt;
-    packed[j] = (d << 16) | (prev + lower);
-  }
-  __syncthreads();
-
   uint32_t tile_count = 0;
-  if (tid < BINS) {
-    uint32_t sum = 0;
+  if (STABLE) {
 #pragma unroll
-    for (int w2 = 0; w2 < NW; ++w2) {
-      const uint32_t c         = s_whist[w2 * BINS + tid];
-      s_whist[w2 * BINS + tid] = sum;
-      sum += c;
+    for (int k = 0; k < BINS / GX_WAVE; ++k) my_hist[lane + k * GX_WAVE] = 0;
+#pragma unroll
+    for (int j = 0; j < KPT; ++j) {
+      const int idx = wbase + j * GX_WAVE;
+      uint32_t d    = (uint32_t)(to_sortable<KeyT, KIND>(key[j], desc_mask) >> shift) & dmask;
+      if (idx >= nvalid) d = BINS - 1;  // padding sorts last (it is also last in input order)
+      uint32_t lower, cnt;
+      match_rank8(d, true, ~0ull, lower, cnt);
+      const uint32_t prev = my_hist[d];
+      if (lower == 0) my_hist[d] = prev + cnt;
+      packed[j] = (d << 16) | (prev + lower);
     }
-    tile_count = sum;
+    __syncthreads();
+    if (tid < BINS) {
+      uint32_t sum = 0;
+#pragma unroll
+      for (int w2 = 0; w2 < NW; ++w2) {
+        const uint32_t c         = s_whist[w2 * BINS + tid];
+        s_whist[w2 * BINS + tid] = sum;
+        sum += c;
+      }
+      tile_count = sum;
+    }
+  } else {
+    if (tid < BINS) s_whist[tid] = 0;
+    __syncthreads();
+#pragma unroll
+    for (int j = 0; j < KPT; ++j) {
+      const int idx    = wbase + j * GX_WAVE;
+      const uint32_t d = (uint32_t)(to_sortable<KeyT, KIND>(key[j], desc_mask) >> shift) & dmask;
+      uint32_t r       = 0;
+      if (idx < nvalid) r = atomicAdd(&s_whist[d], 1u);
+      packed[j] = (d << 16) | r;
+    }
+    __syncthreads();
+    if (tid < BINS) tile_count = s_whist[tid];
   }
   uint32_t pub_count = tile_count;
-  if (tid == BINS - 1) pub_count -= (uint32_t)(TILE - nvalid);
+  if (STABLE && tid == BINS - 1) pub_count -= (uint32_t)(TILE - nvalid);
   if (tid < BINS) {
     store_agent_u64(&a.status[(int64_t)gtile * BINS + tid], pack_status(jt == 0 ? 2u : 1u, epoch, pub_count));
   }
   const uint32_t bin_start = block_exclusive_scan<BT>(tile_count, 0u, SumOp(), s_scan, (uint32_t*)nullptr);
   if (tid < BINS) {
+    if (STABLE) {
 #pragma unroll
-    for (int w2 = 0; w2 < NW; ++w2) s_whist[w2 * BINS + tid] += bin_start;
+      for (int w2 = 0; w2 < NW; ++w2) s_whist[w2 * BINS + tid] += bin_start;
+    } else {
+      s_whist[BINS + tid] = bin_start;  // row 1: bin starts (row 0 holds the counts)
+    }
   }
   __syncthreads();
 
 #pragma unroll
   for (int j = 0; j < KPT; ++j) {
-    const uint32_t d   = packed[j] >> 16;
-    const uint32_t pos = my_hist[d] + (packed[j] & 0xFFFFu);
-    s_keys[pos]        = key[j];
+    const uint32_t d = packed[j] >> 16;
+    if (STABLE) {
+      s_keys[my_hist[d] + (packed[j] & 0xFFFFu)] = key[j];
+    } else if (wbase + j * GX_WAVE < nvalid) {
+      s_keys[s_whist[BINS + d] + (packed[j] & 0xFFFFu)] = key[j];
+    }
   }
 
   if (tid < BINS) {
@@ -1010,6 +1034,7 @@ static inline void prof_mark_h(int idx, hipStream_t s)
   if (g_prof.enabled) (void)hipEventRecord(g_prof.hev[idx], s);
 }
 static int g_hybrid = 1;  // 0 disables the hybrid MSD path (A/B knob)
+static int g_msd_kpt = getenv("GX_MSD_KPT") ? atoi(getenv("GX_MSD_KPT")) : 16;  // keys per thread of the partition passes (8, 12, 16)
 
 template <typename KeyT>
 constexpr int kpt_for(bool has_val)
@@ -1044,7 +1069,9 @@ int sort_impl(const void* keys_in, void* keys_out, const int32_t* vals_in, int32
   uint32_t* base1 = c.take<uint32_t>((size_t)NRANGE * BINS);
   uint32_t* hist2 = try_hybrid ? c.take<uint32_t>((size_t)2 * BINS * BINS) : nullptr;  // hist2 | base2
   uint32_t* base2 = try_hybrid ? hist2 + BINS * BINS : nullptr;
-  const int64_t status_tiles = ntiles + BINS + 2 * NRANGE;  // segment tails add at most one tile each
+  const int64_t msd_tile     = (int64_t)BT * g_msd_kpt;  // tile of the hybrid partition passes
+  const int64_t msd_ntiles   = n > 0 ? div_up(n, msd_tile) : 0;
+  const int64_t status_tiles = (msd_ntiles > ntiles ? msd_ntiles : ntiles) + BINS + 2 * NRANGE;  // segment tails add at most one tile each
   if (algo != 1) {
     status = c.take<unsigned long long>((size_t)status_tiles * BINS);
   } else {
@@ -1066,7 +1093,7 @@ int sort_impl(const void* keys_in, void* keys_out, const int32_t* vals_in, int32
   if (n == 0) return 0;
   if (algo != 1) GX_HIP_TRY(hipMemsetAsync(status, 0, (size_t)status_tiles * BINS * sizeof(unsigned long long), stream));
   if (try_hybrid) GX_HIP_TRY(hipMemsetAsync(hist2, 0, (size_t)2 * BINS * BINS * sizeof(uint32_t), stream));
-  const int64_t range_rows = div_up(ntiles, NRANGE) * TILE;
+  const int64_t range_rows = try_hybrid ? div_up(msd_ntiles, NRANGE) * msd_tile : div_up(ntiles, NRANGE) * TILE;
 
   const KeyT desc_mask = descending ? KeyT(~KeyT(0)) : KeyT(0);
   g_prof.npass = NPASS;
@@ -1077,21 +1104,25 @@ int sort_impl(const void* keys_in, void* keys_out, const int32_t* vals_in, int32
     blocks = div_up(blocks, NRANGE) * NRANGE;  // block b serves input range b % NRANGE
     hipLaunchKernelGGL((k_hist_all<KeyT, KIND>), dim3((unsigned)blocks), dim3(BT), 0, stream,
                        static_cast<const KeyT*>(keys_in), n, desc_mask, plan, range_rows);
-    hipLaunchKernelGGL(k_plan, dim3(1), dim3(BINS), 0, stream, plan, NPASS, n, try_hybrid ? 1 : 0, range_rows, TILE,
-                       base1);
+    hipLaunchKernelGGL(k_plan, dim3(1), dim3(BINS), 0, stream, plan, NPASS, n, try_hybrid ? 1 : 0, range_rows,
+                       try_hybrid ? (int)msd_tile : TILE, base1);
   }
   prof_mark(1, stream);
   g_prof.hybrid_marked = false;
   if constexpr (sizeof(KeyT) == 8 && !HAS_VAL) {
     if (try_hybrid) {
       // hybrid MSD path: every kernel below is a no-op unless the device-side plan enables it
-      constexpr size_t lds_m = (size_t)TILE * sizeof(KeyT) + (size_t)(NW * BINS + BINS + 16 + 4) * 4;
       constexpr size_t lds_l = (size_t)LOCAL_MAX * sizeof(KeyT) + (size_t)(LS_NW * BINS + 32) * 4;
-      auto kmsd              = k_msd_pass<KeyT, KIND, KPT, 4>;
+      const int mkpt         = g_msd_kpt;
+      const size_t lds_m     = (size_t)BT * mkpt * sizeof(KeyT) + (size_t)(NW * BINS + BINS + 16 + 4) * 4;
+      auto kmsd              = mkpt == 8 ? k_msd_pass<KeyT, KIND, 8, 4> : (mkpt == 12 ? k_msd_pass<KeyT, KIND, 12, 4> : k_msd_pass<KeyT, KIND, 16, 4>);
       auto kloc              = k_local_sort<KeyT, KIND>;
       static bool hattr_set  = false;
       if (!hattr_set) {
-        GX_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(kmsd), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_m));
+        constexpr size_t lds_mmax = (size_t)BT * 16 * sizeof(KeyT) + (size_t)(NW * BINS + BINS + 16 + 4) * 4;
+        GX_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(k_msd_pass<KeyT, KIND, 8, 4>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_mmax));
+        GX_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(k_msd_pass<KeyT, KIND, 12, 4>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_mmax));
+        GX_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(k_msd_pass<KeyT, KIND, 16, 4>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_mmax));
         GX_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(kloc), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_l));
         hattr_set = true;
       }
@@ -1108,16 +1139,16 @@ int sort_impl(const void* keys_in, void* keys_out, const int32_t* vals_in, int32
       m.level     = 0;
       m.exp       = getenv("GX_EXP") ? atoi(getenv("GX_EXP")) : 0;
       prof_mark_h(0, stream);
-      hipLaunchKernelGGL(kmsd, dim3((unsigned)(ntiles + NRANGE)), dim3(BT), lds_m, stream, m);
+      hipLaunchKernelGGL(kmsd, dim3((unsigned)(msd_ntiles + NRANGE)), dim3(BT), lds_m, stream, m);
       prof_mark_h(1, stream);
       hipLaunchKernelGGL((k_hist2<KeyT, KIND>), dim3(2048), dim3(H2_BT), 0, stream, bufA, n, desc_mask, plan, hist2);
-      hipLaunchKernelGGL(k_plan2, dim3(1), dim3(BINS), 0, stream, plan, hist2, base2, TILE, NPASS);
+      hipLaunchKernelGGL(k_plan2, dim3(1), dim3(BINS), 0, stream, plan, hist2, base2, (int)msd_tile, NPASS);
       prof_mark_h(2, stream);
       m.in    = bufA;
       m.out   = bufB;
       m.base  = base2;
       m.level = 1;
-      hipLaunchKernelGGL(kmsd, dim3((unsigned)(ntiles + BINS + NRANGE)), dim3(BT), lds_m, stream, m);
+      hipLaunchKernelGGL(kmsd, dim3((unsigned)(msd_ntiles + BINS + NRANGE)), dim3(BT), lds_m, stream, m);
       prof_mark_h(3, stream);
       hipLaunchKernelGGL(kloc, dim3((unsigned)(BINS * BINS)), dim3(LS_BT), lds_l, stream, bufB, bufA, desc_mask, plan,
                          hist2, base2);
