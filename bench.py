@@ -71,6 +71,13 @@ def cpu_baseline_sort(rows):
         df.sort_values("a", kind="stable")
         extra["pandas_sort_values_rows_per_s"] = m / (time.perf_counter() - t0)
         extra["pandas_rows"] = m
+        import pyarrow as pa
+        import pyarrow.compute as pc
+        arr = pa.array(v[:m])
+        t0 = time.perf_counter()
+        pc.sort_indices(arr)
+        extra["pyarrow_sort_indices_rows_per_s"] = m / (time.perf_counter() - t0)
+        extra["pyarrow_threads"] = pa.cpu_count()
     except Exception as e:  # pandas is context only
         extra["pandas_error"] = repr(e)
     return {"value": n / dt, "unit": "rows/s", "cores": 1, "kind": "port",
@@ -88,9 +95,21 @@ def cpu_baseline_join(rows):
     t0 = time.perf_counter()
     l, r = c_oracle.inner_join_i64(probe, build)
     dt = time.perf_counter() - t0
+    extra = {}
+    try:
+        import pandas as pd
+        m = min(n, 10_000_000)
+        lp = pd.DataFrame({"k": probe[:m]})
+        rp = pd.DataFrame({"k": build, "r": np.arange(len(build))})
+        t0 = time.perf_counter()
+        lp.merge(rp, on="k", how="inner")
+        extra["pandas_merge_rows_per_s"] = m / (time.perf_counter() - t0)
+        extra["pandas_rows"] = m
+    except Exception as e:  # context only
+        extra["pandas_error"] = repr(e)
     return {"value": n / dt, "unit": "rows/s", "cores": 1, "kind": "port",
             "sample": f"probe {n} x build {len(build)} int64 rows, oracle/oracle.c orc_inner_join_i64 (count+retrieve)",
-            "host_cpus": os.cpu_count(), "matches": int(len(l))}
+            "host_cpus": os.cpu_count(), "matches": int(len(l)), **extra}
 
 
 def cpu_baseline_groupby(rows):
@@ -103,9 +122,20 @@ def cpu_baseline_groupby(rows):
     t0 = time.perf_counter()
     c_oracle.groupby_dense_sum_count(k, v, 1_000_000)
     dt = time.perf_counter() - t0
+    extra = {}
+    try:
+        import pandas as pd
+        m = min(n, 20_000_000)
+        df = pd.DataFrame({"k": k[:m], "v": v[:m]})
+        t0 = time.perf_counter()
+        df.groupby("k", sort=False).agg(s=("v", "sum"), c=("v", "count"))
+        extra["pandas_groupby_rows_per_s"] = m / (time.perf_counter() - t0)
+        extra["pandas_rows"] = m
+    except Exception as e:  # context only
+        extra["pandas_error"] = repr(e)
     return {"value": n / dt, "unit": "rows/s", "cores": 1, "kind": "port",
             "sample": f"{n} rows, 1e6 int32 groups, f64 sum+count, oracle/oracle.c orc_groupby_dense_sum_count",
-            "host_cpus": os.cpu_count()}
+            "host_cpus": os.cpu_count(), **extra}
 
 
 def main():
