@@ -330,13 +330,13 @@ def main():
         lib.gx_sort_info(ptr(tmp), info, stream)
         sort_info = dict(zip(["hybrid_attempted", "hybrid_used", "d1", "shift2", "bits2", "lds_passes", "max_cell",
                               "lsd_passes"], list(info)))
-    if args.workload == "sort" and sort_info and sort_info["hybrid_used"] and hyb_n:
+    if args.workload in ("sort", "sorted_order") and sort_info and sort_info["hybrid_used"] and hyb_n:
         # hybrid MSD path: per-kernel algorithmic bytes: partition passes and the local
         # sort read 8 + write 8 B/row, the joint histogram reads 8 B/row
         ms = [x / hyb_n for x in hyb_acc]
         names = ["k_msd_pass level 0 (8-bit partition, 8 XCD chains)", "k_hist2+k_plan2 (joint histogram)",
                  "k_msd_pass level 1 (partition inside buckets)", "k_local_sort (LDS sort of <=16384-key cells)"]
-        bpr = [16, 8, 16, 16]
+        bpr = [20, 8, 24, 24] if args.workload == "sorted_order" else [16, 8, 16, 16]  # pairs carry a 4-B index
         dom = max(range(4), key=lambda i: ms[i])
         achieved = bpr[dom] * n / (ms[dom] * 1e-3) / 1e9
         roofline = {"bound": "hbm", "kernel": names[dom], "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
@@ -344,7 +344,7 @@ def main():
                     "avg_launch_ms": ms[dom], "launches_per_step": 1.0,
                     "kernels_ms": dict(zip(names, ms)), "kernels_GBps": {k: b * n / (m * 1e-3) / 1e9 for k, b, m in zip(names, bpr, ms)},
                     "hist_kernel_ms": hist_ms_acc / args.steps,
-                    "path_bytes_per_row": 64, "path_GBps": 64 * n / (local_sort_ms * 1e-3) / 1e9,
+                    "path_bytes_per_row": 8 + sum(bpr), "path_GBps": (8 + sum(bpr)) * n / (local_sort_ms * 1e-3) / 1e9,
                     "whole_sort_model_GBps": model_bytes_row * n / (local_sort_ms * 1e-3) / 1e9,
                     "whole_sort_model_frac": model_bytes_row * n / (local_sort_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
                     "sort_info": sort_info}

@@ -135,7 +135,7 @@ __global__ void __launch_bounds__(BT) k_hist_all(const KeyT* __restrict__ in, in
 
 // one block of 256 threads
 __global__ void __launch_bounds__(BINS) k_plan(SortPlan* plan, int npass, int64_t n, int try_hybrid, int64_t range_rows,
-                                               int tile_rows, uint32_t* base1)
+                                               int tile_rows, uint32_t* base1, int pairs)
 {
   __shared__ uint32_t s_tmp[BINS / GX_WAVE + 1];
   __shared__ int s_skip[MAX_PASSES];
@@ -192,6 +192,7 @@ __global__ void __launch_bounds__(BINS) k_plan(SortPlan* plan, int npass, int64_
         ++nl;
       }
       hy.nlocal = nl;
+      if (pairs && hy.shift2 + 14 > 64) hy.attempt = 0;  // k_local_sort packs (low key bits, position) into 64 bits
       uint32_t tiles = 0;
       for (int r = 0; r < NRANGE; ++r) {
         const int64_t b = (int64_t)r * range_rows < n ? (int64_t)r * range_rows : n;
@@ -517,6 +518,8 @@ __device__ __forceinline__ unsigned xcc_id() { return __builtin_amdgcn_s_getreg(
 struct MsdArgs {
   const void* in;
   void* out;
+  const uint32_t* vin;  // payload (row index); NULL at level 0 = iota
+  uint32_t* vout;
   SortPlan* plan;
   unsigned long long* status;  // [tiles][256] look-back granules, epoch = level + 1
   const uint32_t* base;        // [segments][256] output position of each bin of each segment
@@ -537,13 +540,14 @@ struct MsdArgs {
 // (the per-XCD L2s are not coherent; see DESIGN.md "XCD-local write combining").  Correctness
 // needs no placement assumption: within a list tickets are handed out in order, so every
 // predecessor a tile can wait for is already owned by a running workgroup.
-template <typename KeyT, int KIND, int KPT, int LBW>
+template <typename KeyT, int KIND, bool HAS_VAL, int KPT, int LBW>
 __global__ void __launch_bounds__(BT, (KPT <= 8 ? 8 : (KPT <= 12 ? 6 : 4))) k_msd_pass(MsdArgs a)
 {
   constexpr int TILE = BT * KPT;
   extern __shared__ __attribute__((aligned(16))) char smem[];
   KeyT* s_keys       = reinterpret_cast<KeyT*>(smem);
-  uint32_t* s_whist  = reinterpret_cast<uint32_t*>(smem + (size_t)TILE * sizeof(KeyT));  // [NW][256]
+  uint32_t* s_vals   = reinterpret_cast<uint32_t*>(smem + (size_t)TILE * sizeof(KeyT));  // [TILE] (HAS_VAL)
+  uint32_t* s_whist  = s_vals + (HAS_VAL ? TILE : 0);                                    // [NW][256]
   uint32_t* s_gdelta = s_whist + NW * BINS;                                              // [256]
   uint32_t* s_scan   = s_gdelta + BINS;                                                  // [16]
   uint32_t* s_misc   = s_scan + 16;                                                      // [4]
@@ -554,6 +558,8 @@ __global__ void __launch_bounds__(BT, (KPT <= 8 ? 8 : (KPT <= 12 ? 6 : 4))) k_ms
   if (!hy.attempt || (lvl == 1 && !hy.ok)) return;
   const KeyT* kin      = static_cast<const KeyT*>(a.in);
   KeyT* kout           = static_cast<KeyT*>(a.out);
+  const uint32_t* vin  = a.vin;
+  uint32_t* vout       = a.vout;
   const KeyT desc_mask = (KeyT)a.desc_mask;
   const int shift      = lvl == 0 ? 8 * hy.d1 : hy.shift2;
   const uint32_t dmask = lvl == 0 ? 0xFFu : ((1u << hy.bits2) - 1u);
@@ -602,6 +608,7 @@ __global__ void __launch_bounds__(BT, (KPT <= 8 ? 8 : (KPT <= 12 ? 6 : 4))) k_ms
 
   // ---- load (wave-striped)
   KeyT key[KPT];
+  uint32_t val[HAS_VAL ? KPT : 1];
   const int wbase = (int)w * (KPT * GX_WAVE) + (int)lane;
   if (nvalid == TILE) {
 #pragma unroll
@@ -613,10 +620,17 @@ __global__ void __launch_bounds__(BT, (KPT <= 8 ? 8 : (KPT <= 12 ? 6 : 4))) k_ms
       key[j]        = (idx < nvalid) ? kin[base + idx] : KeyT(0);
     }
   }
+  if (HAS_VAL) {
+#pragma unroll
+    for (int j = 0; j < KPT; ++j) {
+      const int idx = wbase + j * GX_WAVE;
+      val[j]        = (idx < nvalid) ? (vin ? vin[base + idx] : (uint32_t)(base + idx)) : 0u;
+    }
+  }
   // Ranking inside the tile.  Integer keys: equal keys are indistinguishable, so the partition need
   // not be stable -- one returning LDS atomic per key on a 256-entry counter array replaces the
   // 8-ballot match.  Floats keep the stable wave-match ranking (-0.0 == +0.0 must keep input order).
-  constexpr bool STABLE = KIND == K_FLOAT;
+  constexpr bool STABLE = KIND == K_FLOAT || HAS_VAL;  // pairs: the row index breaks ties downstream only if cells keep input order
   uint32_t* my_hist = s_whist + w * BINS;
   uint32_t packed[KPT];
   uint32_t tile_count = 0;
@@ -679,7 +693,9 @@ __global__ void __launch_bounds__(BT, (KPT <= 8 ? 8 : (KPT <= 12 ? 6 : 4))) k_ms
   for (int j = 0; j < KPT; ++j) {
     const uint32_t d = packed[j] >> 16;
     if (STABLE) {
-      s_keys[my_hist[d] + (packed[j] & 0xFFFFu)] = key[j];
+      const uint32_t pos = my_hist[d] + (packed[j] & 0xFFFFu);
+      s_keys[pos]        = key[j];
+      if (HAS_VAL) s_vals[pos] = val[j];
     } else if (wbase + j * GX_WAVE < nvalid) {
       s_keys[s_whist[BINS + d] + (packed[j] & 0xFFFFu)] = key[j];
     }
@@ -729,7 +745,9 @@ __global__ void __launch_bounds__(BT, (KPT <= 8 ? 8 : (KPT <= 12 ? 6 : 4))) k_ms
     if (i < nvalid) {
       const KeyT k       = s_keys[i];
       const uint32_t d   = (uint32_t)(to_sortable<KeyT, KIND>(k, desc_mask) >> shift) & dmask;
-      kout[s_gdelta[d] + (uint32_t)i] = k;
+      const uint32_t dst = s_gdelta[d] + (uint32_t)i;
+      kout[dst]          = k;
+      if (HAS_VAL) vout[dst] = s_vals[i];
     }
   }
 }
@@ -851,13 +869,84 @@ __global__ void __launch_bounds__(BINS) k_plan2(SortPlan* plan, const uint32_t* 
 // Sort one cell (<= LOCAL_MAX keys sharing all bits above shift2) on its remaining bits inside LDS:
 // nlocal stable 8-bit counting passes, keys resident in registers between the LDS exchanges, one
 // HBM read and one HBM write of the cell in total.
-template <typename KeyT, int KIND>
-__global__ void __launch_bounds__(LS_BT) k_local_sort(const KeyT* __restrict__ in, KeyT* __restrict__ out, KeyT desc_mask,
-                                                      SortPlan* plan, const uint32_t* __restrict__ hist2,
-                                                      const uint32_t* __restrict__ base2)
+// PAIRS (sorted_order: key + row index, index payload = iota at level 0): the cell's keys share all
+// bits above shift2, and the stable partition passes left the cell in input order, so the word
+// (low shift2 bits of the sortable key) << 14 | (position in the cell) is a distinct 64-bit key whose
+// order is the stable order of the pairs.  Only these words go through LDS; the sorted positions
+// then gather the original key and index of the cell (L2-resident: the cell was just read).
+constexpr int LS_POS_BITS = 14;  // LOCAL_MAX == 1 << 14
+
+// PAIRS write-out: the sorted words hold the position of each row inside the cell in their low 14
+// bits.  Integer keys are rebuilt from the word (cell prefix | low bits, the transform is an
+// involution); float keys (-0.0 / NaN payloads are not recoverable) and the row indices are staged
+// through the now free LDS buffer so that every HBM access stays coalesced.
+template <typename KeyT, int KIND, bool HAS_VAL>
+__device__ __forceinline__ void pairs_write_out(KeyT* s_keys, const KeyT* __restrict__ in, KeyT* __restrict__ out,
+                                                const uint32_t* __restrict__ vin, uint32_t* __restrict__ vout,
+                                                int64_t start, uint32_t m, int shift2, KeyT desc_mask)
 {
+  const unsigned tid = threadIdx.x;
+  const KeyT lowmask = (KeyT(1) << shift2) - KeyT(1);
+  const KeyT hi      = to_sortable<KeyT, KIND>(in[start], desc_mask) & ~lowmask;  // shared by the whole cell
+  uint32_t pos[LS_KPT];
+#pragma unroll
+  for (int j = 0; j < LS_KPT; ++j) {
+    const int i = j * LS_BT + (int)tid;
+    pos[j]      = 0;
+    if ((uint32_t)i < m) {
+      const KeyT wd = s_keys[i];
+      pos[j]        = (uint32_t)wd & ((1u << LS_POS_BITS) - 1u);
+      if (KIND != K_FLOAT) out[start + i] = to_sortable<KeyT, KIND>(hi | ((wd >> LS_POS_BITS) & lowmask), desc_mask);
+    }
+  }
+  __syncthreads();
+  if (KIND == K_FLOAT) {
+#pragma unroll
+    for (int j = 0; j < LS_KPT; ++j) {
+      const int i = j * LS_BT + (int)tid;
+      if ((uint32_t)i < m) s_keys[i] = in[start + i];
+    }
+    __syncthreads();
+#pragma unroll
+    for (int j = 0; j < LS_KPT; ++j) {
+      const int i = j * LS_BT + (int)tid;
+      if ((uint32_t)i < m) out[start + i] = s_keys[pos[j]];
+    }
+    __syncthreads();
+  }
+  if (!HAS_VAL) return;
+  uint32_t* s_idx = reinterpret_cast<uint32_t*>(s_keys);
+#pragma unroll
+  for (int j = 0; j < LS_KPT; ++j) {
+    const int i = j * LS_BT + (int)tid;
+    if ((uint32_t)i < m) s_idx[i] = vin[start + i];
+  }
+  __syncthreads();
+#pragma unroll
+  for (int j = 0; j < LS_KPT; ++j) {
+    const int i = j * LS_BT + (int)tid;
+    if ((uint32_t)i < m) vout[start + i] = s_idx[pos[j]];
+  }
+}
+
+template <typename KeyT, int KIND, bool HAS_VAL>
+__global__ void __launch_bounds__(LS_BT) k_local_sort(const KeyT* __restrict__ in, KeyT* __restrict__ out,
+                                                      const uint32_t* __restrict__ vin, uint32_t* __restrict__ vout,
+                                                      KeyT desc_mask_in, SortPlan* plan,
+                                                      const uint32_t* __restrict__ hist2, const uint32_t* __restrict__ base2)
+{
+  // PAIRS = the packed-word mode: pairs, and float keys (whose -0.0 == +0.0 ties must keep input order
+  // and whose original bits cannot be rebuilt from the sortable form)
+  // (floats whose remaining bits do not leave room for the position keep plain keys and take the
+  // stable passes; k_plan never attempts the hybrid path for pairs in that case)
+  constexpr bool CAN_PACK = HAS_VAL || KIND == K_FLOAT;
   HybridPlan& hy = plan->hy;
   if (!hy.attempt || !hy.ok) return;
+  const bool PAIRS     = CAN_PACK && (hy.shift2 + LS_POS_BITS <= 64);
+  const KeyT desc_mask = desc_mask_in;
+  const int pos_shift  = PAIRS ? LS_POS_BITS : 0;
+  // sortable form of a register word: packed words already are, plain keys go through the transform
+  auto sortable = [&](KeyT x) -> KeyT { return PAIRS ? x : to_sortable<KeyT, KIND>(x, desc_mask); };
   extern __shared__ __attribute__((aligned(16))) char smem[];
   KeyT* s_keys      = reinterpret_cast<KeyT*>(smem);                                           // LOCAL_MAX
   uint32_t* s_whist = reinterpret_cast<uint32_t*>(smem + (size_t)LOCAL_MAX * sizeof(KeyT));   // [LS_NW][256]
@@ -880,23 +969,27 @@ __global__ void __launch_bounds__(LS_BT) k_local_sort(const KeyT* __restrict__ i
   for (int j = 0; j < LS_KPT; ++j) {
     const int idx = wbase + j * GX_WAVE;
     key[j]        = ((uint32_t)idx < m) ? in[start + idx] : KeyT(0);
+    if (PAIRS) {
+      const KeyT sk = to_sortable<KeyT, KIND>(key[j], desc_mask_in);
+      key[j]        = ((sk & ((KeyT(1) << hy.shift2) - KeyT(1))) << LS_POS_BITS) | (KeyT)idx;
+    }
   }
   // ---- fast path (integer keys): ONE unstable 8-bit MSD split in LDS on the byte below the
   // level-1 digit (LDS atomics, no ballots), then every <=128-key sub-bucket is sorted on the full
   // key by one wave's in-register bitonic network.  Equal integer keys are indistinguishable, so
   // stability is not needed; floats (-0.0 == +0.0 must keep input order) and cells with a
   // sub-bucket above 128 keys take the stable LSD passes below.
-  if (KIND != K_FLOAT && nlocal > 0) {
+  if ((PAIRS || KIND != K_FLOAT) && nlocal > 0) {
     uint32_t* s_cnt   = s_whist;          // [256] counts, then exclusive starts
     uint32_t* s_start = s_whist + BINS;   // [256]
-    const int sshift  = hy.shift2 - 8;    // >= 0: d1 >= 2 and bits2 <= 8
+    const int sshift  = hy.shift2 - 8 + pos_shift;  // shift2 >= 8: d1 >= 2 and bits2 <= 8
     if (tid < BINS) s_cnt[tid] = 0;
     __syncthreads();
     uint32_t rank[LS_KPT];
 #pragma unroll
     for (int j = 0; j < LS_KPT; ++j) {
       const int idx = wbase + j * GX_WAVE;
-      key[j]        = to_sortable<KeyT, KIND>(key[j], desc_mask);  // an involution for integer kinds
+      key[j]        = sortable(key[j]);  // an involution for integer kinds
       rank[j]       = 0;
       if ((uint32_t)idx < m) rank[j] = atomicAdd(&s_cnt[(uint32_t)(key[j] >> sshift) & 0xFFu], 1u);
     }
@@ -929,21 +1022,25 @@ __global__ void __launch_bounds__(LS_BT) k_local_sort(const KeyT* __restrict__ i
         }
       }
       __syncthreads();
+      if (PAIRS) {
+        pairs_write_out<KeyT, KIND, HAS_VAL>(s_keys, in, out, vin, vout, start, m, hy.shift2, desc_mask_in);
+        return;
+      }
 #pragma unroll
       for (int j = 0; j < LS_KPT; ++j) {
         const int i = j * LS_BT + (int)tid;
-        if ((uint32_t)i < m) out[start + i] = to_sortable<KeyT, KIND>(s_keys[i], desc_mask);
+        if ((uint32_t)i < m) out[start + i] = to_sortable<KeyT, KIND>(s_keys[i], desc_mask);  // integer kinds only
       }
       return;
     }
     // undo the transform and fall through to the stable passes
 #pragma unroll
-    for (int j = 0; j < LS_KPT; ++j) key[j] = to_sortable<KeyT, KIND>(key[j], desc_mask);
+    for (int j = 0; j < LS_KPT; ++j) key[j] = sortable(key[j]);
     __syncthreads();
   }
   uint32_t* my_hist = s_whist + w * BINS;
   for (int lp = 0; lp < nlocal; ++lp) {
-    const int shift      = hy.lshift[lp];
+    const int shift      = hy.lshift[lp] + pos_shift;
     const uint32_t dmask = (1u << hy.lbits[lp]) - 1u;
 #pragma unroll
     for (int k = 0; k < BINS / GX_WAVE; ++k) my_hist[lane + k * GX_WAVE] = 0;
@@ -955,7 +1052,7 @@ __global__ void __launch_bounds__(LS_BT) k_local_sort(const KeyT* __restrict__ i
       const uint64_t act = ballot(live);
       packed[j]         = 0;
       if (act == 0) continue;  // wave-uniform
-      const uint32_t d = (uint32_t)(to_sortable<KeyT, KIND>(key[j], desc_mask) >> shift) & dmask;
+      const uint32_t d = (uint32_t)(sortable(key[j]) >> shift) & dmask;
       uint32_t lower, cnt;
       match_rank8(d, live, act, lower, cnt);
       if (live) {
@@ -1001,8 +1098,19 @@ __global__ void __launch_bounds__(LS_BT) k_local_sort(const KeyT* __restrict__ i
 #pragma unroll
     for (int j = 0; j < LS_KPT; ++j) {
       const int idx = wbase + j * GX_WAVE;
-      if ((uint32_t)idx < m) out[start + idx] = key[j];
+      if ((uint32_t)idx < m) {
+        if (PAIRS) {
+          out[start + idx] = in[start + idx];
+          if (HAS_VAL) vout[start + idx] = vin[start + idx];
+        } else {
+          out[start + idx] = key[j];
+        }
+      }
     }
+    return;
+  }
+  if (PAIRS) {
+    pairs_write_out<KeyT, KIND, HAS_VAL>(s_keys, in, out, vin, vout, start, m, hy.shift2, desc_mask_in);
     return;
   }
 #pragma unroll
@@ -1065,11 +1173,14 @@ int sort_impl(const void* keys_in, void* keys_out, const int32_t* vals_in, int32
   unsigned long long* status = nullptr;
   uint32_t* tile_hist        = nullptr;
   uint32_t* partials         = nullptr;
-  const bool try_hybrid = sizeof(KeyT) == 8 && !HAS_VAL && algo == 0 && g_hybrid && n >= (1ll << 22);
+  // hybrid MSD path: 64-bit keys; pairs only with the iota payload (sorted_order), whose value is the
+  // tie-break the packed local sort relies on
+  const bool try_hybrid = sizeof(KeyT) == 8 && (!HAS_VAL || vals_in == nullptr) && algo == 0 && g_hybrid && n >= (1ll << 22);
+  const int hyb_kpt     = HAS_VAL ? 10 : g_msd_kpt;
   uint32_t* base1 = c.take<uint32_t>((size_t)NRANGE * BINS);
   uint32_t* hist2 = try_hybrid ? c.take<uint32_t>((size_t)2 * BINS * BINS) : nullptr;  // hist2 | base2
   uint32_t* base2 = try_hybrid ? hist2 + BINS * BINS : nullptr;
-  const int64_t msd_tile     = (int64_t)BT * g_msd_kpt;  // tile of the hybrid partition passes
+  const int64_t msd_tile     = (int64_t)BT * hyb_kpt;  // tile of the hybrid partition passes
   const int64_t msd_ntiles   = n > 0 ? div_up(n, msd_tile) : 0;
   const int64_t status_tiles = (msd_ntiles > ntiles ? msd_ntiles : ntiles) + BINS + 2 * NRANGE;  // segment tails add at most one tile each
   if (algo != 1) {
@@ -1105,30 +1216,37 @@ int sort_impl(const void* keys_in, void* keys_out, const int32_t* vals_in, int32
     hipLaunchKernelGGL((k_hist_all<KeyT, KIND>), dim3((unsigned)blocks), dim3(BT), 0, stream,
                        static_cast<const KeyT*>(keys_in), n, desc_mask, plan, range_rows);
     hipLaunchKernelGGL(k_plan, dim3(1), dim3(BINS), 0, stream, plan, NPASS, n, try_hybrid ? 1 : 0, range_rows,
-                       try_hybrid ? (int)msd_tile : TILE, base1);
+                       try_hybrid ? (int)msd_tile : TILE, base1, HAS_VAL ? 1 : 0);
   }
   prof_mark(1, stream);
   g_prof.hybrid_marked = false;
-  if constexpr (sizeof(KeyT) == 8 && !HAS_VAL) {
+  if constexpr (sizeof(KeyT) == 8) {
     if (try_hybrid) {
       // hybrid MSD path: every kernel below is a no-op unless the device-side plan enables it
       constexpr size_t lds_l = (size_t)LOCAL_MAX * sizeof(KeyT) + (size_t)(LS_NW * BINS + 32) * 4;
-      const int mkpt         = g_msd_kpt;
-      const size_t lds_m     = (size_t)BT * mkpt * sizeof(KeyT) + (size_t)(NW * BINS + BINS + 16 + 4) * 4;
-      auto kmsd              = mkpt == 8 ? k_msd_pass<KeyT, KIND, 8, 4> : (mkpt == 12 ? k_msd_pass<KeyT, KIND, 12, 4> : k_msd_pass<KeyT, KIND, 16, 4>);
-      auto kloc              = k_local_sort<KeyT, KIND>;
-      static bool hattr_set  = false;
+      constexpr size_t pay   = HAS_VAL ? 4 : 0;
+      const size_t lds_m     = (size_t)BT * hyb_kpt * (sizeof(KeyT) + pay) + (size_t)(NW * BINS + BINS + 16 + 4) * 4;
+      auto kmsd = HAS_VAL ? k_msd_pass<KeyT, KIND, HAS_VAL, 10, 4>
+                          : (hyb_kpt == 8 ? k_msd_pass<KeyT, KIND, HAS_VAL, 8, 4>
+                                          : (hyb_kpt == 12 ? k_msd_pass<KeyT, KIND, HAS_VAL, 12, 4> : k_msd_pass<KeyT, KIND, HAS_VAL, 16, 4>));
+      auto kloc             = k_local_sort<KeyT, KIND, HAS_VAL>;
+      static bool hattr_set = false;
       if (!hattr_set) {
-        constexpr size_t lds_mmax = (size_t)BT * 16 * sizeof(KeyT) + (size_t)(NW * BINS + BINS + 16 + 4) * 4;
-        GX_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(k_msd_pass<KeyT, KIND, 8, 4>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_mmax));
-        GX_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(k_msd_pass<KeyT, KIND, 12, 4>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_mmax));
-        GX_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(k_msd_pass<KeyT, KIND, 16, 4>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_mmax));
+        constexpr size_t lds_mmax = (size_t)BT * 16 * (sizeof(KeyT) + pay) + (size_t)(NW * BINS + BINS + 16 + 4) * 4;
+        GX_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(k_msd_pass<KeyT, KIND, HAS_VAL, 8, 4>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_mmax));
+        GX_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(k_msd_pass<KeyT, KIND, HAS_VAL, 10, 4>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_mmax));
+        GX_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(k_msd_pass<KeyT, KIND, HAS_VAL, 12, 4>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_mmax));
+        GX_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(k_msd_pass<KeyT, KIND, HAS_VAL, 16, 4>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_mmax));
         GX_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(kloc), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_l));
         hattr_set = true;
       }
       KeyT* bufA = keys_out ? static_cast<KeyT*>(keys_out) : ka_scratch;
       KeyT* bufB = kb_scratch;
+      uint32_t* valA = reinterpret_cast<uint32_t*>(vals_out);
+      uint32_t* valB = vb;
       MsdArgs m;
+      m.vin  = nullptr;  // iota
+      m.vout = valA;
       m.plan      = plan;
       m.status    = status;
       m.n         = n;
@@ -1146,12 +1264,14 @@ int sort_impl(const void* keys_in, void* keys_out, const int32_t* vals_in, int32
       prof_mark_h(2, stream);
       m.in    = bufA;
       m.out   = bufB;
+      m.vin   = valA;
+      m.vout  = valB;
       m.base  = base2;
       m.level = 1;
       hipLaunchKernelGGL(kmsd, dim3((unsigned)(msd_ntiles + BINS + NRANGE)), dim3(BT), lds_m, stream, m);
       prof_mark_h(3, stream);
-      hipLaunchKernelGGL(kloc, dim3((unsigned)(BINS * BINS)), dim3(LS_BT), lds_l, stream, bufB, bufA, desc_mask, plan,
-                         hist2, base2);
+      hipLaunchKernelGGL(kloc, dim3((unsigned)(BINS * BINS)), dim3(LS_BT), lds_l, stream, bufB, bufA, valB, valA, desc_mask,
+                         plan, hist2, base2);
       prof_mark_h(4, stream);
       g_prof.hybrid_marked = g_prof.enabled;
     }

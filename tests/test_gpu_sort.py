@@ -228,3 +228,28 @@ def test_hybrid_knob_off_uses_lsd(gx):
         _lib.lib.gx_sort_set_hybrid(1)
     assert got.tobytes() == np.sort(v).tobytes()
     assert info[0] == 0 and info[7] == 8
+
+
+@pytest.mark.parametrize("dtype", ["int64", "float64", "uint64"])
+def test_hybrid_sorted_order_is_stable(gx, dtype):
+    """sorted_order (key + iota payload) of >= 2^22 rows takes the hybrid path with the packed
+    (low key bits, position) local sort: ties must come out in input order, both directions."""
+    Column, ops = gx
+    rng = np.random.default_rng(91)
+    n = (1 << 22) + 4321
+    if dtype == "float64":
+        v = rng.integers(-2**63, 2**63 - 1, n, dtype=np.int64).view(np.float64)
+        v[::1000] = 0.0
+        v[1::1000] = -0.0
+    else:
+        v = _rand(dtype, n, rng, False)
+    v[::7] = v[3]                       # a heavy duplicate: ties across many tiles of one cell
+    v[5::11] = v[5]
+    for asc in (True, False):
+        got = ops.sorted_order(Column.from_numpy(v), ascending=asc).to_numpy()
+        np.testing.assert_array_equal(got, orc.sorted_order(v, None, asc), err_msg=f"{dtype} asc={asc}")
+    # larger, no heavy duplicates: 8 level-1 bits, full cells
+    n = 20_000_000
+    v = rng.integers(-2**63, 2**63 - 1, n, dtype=np.int64).view(np.dtype(dtype)) if dtype != "uint64" else _rand(dtype, n, rng, False)
+    got = ops.sorted_order(Column.from_numpy(v)).to_numpy()
+    np.testing.assert_array_equal(got, orc.sorted_order(v, None, True))
