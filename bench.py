@@ -37,7 +37,7 @@ def parse():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--warmup", type=int, default=2)
-    ap.add_argument("--workload", default="sort", choices=["sort", "sorted_order", "join", "groupby"])
+    ap.add_argument("--workload", default="sort", choices=["sort", "sorted_order", "join", "groupby", "reduce", "scan", "gather"])
     ap.add_argument("--rows", type=float, default=1e9)
     ap.add_argument("--algo", type=int, default=0,
                     help="sort knob: 0 onesweep/windowed look-back, 1 three-kernel, 2 onesweep/one-tile look-back")
@@ -240,6 +240,33 @@ def main():
                                           ro.data_ptr, n, ptr(cur), stream), "probe")
         workload = f"{n:.0e}-row int64 probe x {nb_rows:.0e}-row build inner hash join (probe phase timed)"
         unit_rows = n
+    elif args.workload in ("reduce", "scan", "gather"):
+        # single streaming kernels of the path: f64 SUM reduce, int64 inclusive
+        # SUM scan, 8-byte gather through a random int32 map
+        src = ops.random_column(np.float64 if args.workload == "reduce" else np.int64, n, seed=11 + rank)
+        nb = ctypes.c_size_t(0)
+        if args.workload == "reduce":
+            res = Column.empty(np.float64, 1)
+            cnt = torch.zeros(1, dtype=torch.int64, device="cuda")
+            fn = lambda tmp, nbp: lib.gx_reduce(src.gx, src.data_ptr, None, n, L.OP_SUM, L.FLOAT64, res.data_ptr, ptr(cnt), tmp, nbp, stream)
+            bpr_simple, kname = 8, "gx_reduce f64 SUM (k_chunk_reduce)"
+        elif args.workload == "scan":
+            dst = Column.empty(np.int64, n)
+            fn = lambda tmp, nbp: lib.gx_scan(src.gx, src.data_ptr, None, n, L.OP_SUM, 1, dst.data_ptr, tmp, nbp, stream)
+            bpr_simple, kname = 16, "gx_scan int64 inclusive SUM (reduce-then-scan, 3 launches; 24 B/row moved)"
+        else:
+            gm = ops.random_column(np.int32, n, seed=13 + rank, lo=0, hi=n)
+            dst = Column.empty(np.int64, n)
+            fn = None
+            bpr_simple, kname = 20, "gx_gather 8-byte rows through a uniform random int32 map"
+        if fn is not None:
+            L.check(fn(None, ctypes.byref(nb)), "size query")
+            tmp = device_bytes(nb.value)
+            step = lambda: L.check(fn(ptr(tmp), ctypes.byref(nb)), args.workload)
+        else:
+            step = lambda: L.check(lib.gx_gather(8, src.data_ptr, None, n, gm.data_ptr, n, 0, dst.data_ptr, None, stream), "gather")
+        workload = f"{n:.0e}-row {kname}"
+        unit_rows = n
     else:  # groupby
         gk = ops.random_column(np.int32, n, seed=7 + rank, lo=0, hi=1_000_000)
         gv = ops.random_column(np.float64, n, seed=8 + rank)
@@ -368,6 +395,11 @@ def main():
         roofline = {"bound": "hbm", "kernel": "k_pj_hist+k_pj_scatter+k_pj_probe (partitioned probe)" if extra.get("join_partition_bits") else "k_probe", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                     "frac": ach / HBM_PEAK_GBS, "traffic": None, "algorithmic_bytes_per_launch": algb,
                     "avg_launch_ms": ms_per_step, "matches": matches}
+    elif args.workload in ("reduce", "scan", "gather"):
+        ach = bpr_simple * n / (ms_per_step * 1e-3) / 1e9
+        roofline = {"bound": "hbm", "kernel": kname, "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                    "frac": ach / HBM_PEAK_GBS, "traffic": None, "algorithmic_bytes_per_launch": bpr_simple * n,
+                    "avg_launch_ms": ms_per_step}
     elif args.workload == "groupby":
         ach = 12 * n / (ms_per_step * 1e-3) / 1e9
         roofline = {"bound": "hbm", "kernel": "k_aggregate", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",
@@ -388,14 +420,16 @@ def main():
         cpu = None
         if args.cpu and world == 1:
             # bounded sample: ~10-30 s of single-thread CPU work
-            cpu_rows = args.cpu_rows or {"sort": 1e8, "sorted_order": 1e8, "join": 5e7, "groupby": 2e8}[args.workload]
-            cpu = {"sort": cpu_baseline_sort, "sorted_order": cpu_baseline_sort, "join": cpu_baseline_join,
-                   "groupby": cpu_baseline_groupby}[args.workload](cpu_rows)
+            cpu_rows = args.cpu_rows or {"sort": 1e8, "sorted_order": 1e8, "join": 5e7, "groupby": 2e8}.get(args.workload, 1e8)
+            fnc = {"sort": cpu_baseline_sort, "sorted_order": cpu_baseline_sort, "join": cpu_baseline_join,
+                   "groupby": cpu_baseline_groupby}.get(args.workload)
+            cpu = fnc(cpu_rows) if fnc else None
         line = {
             "metric": "rows/sec + achieved HBM GB/s: 1e9-row int64 sort & hash-join, 1/2/4/8 GPU",
             "value": unit_rows * world / (dt / args.steps), "unit": "rows/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "weak",
-            "vs_baseline": None, "dtype": {"sort": "int64", "sorted_order": "int64", "join": "int64", "groupby": "f64"}[args.workload],
+            "vs_baseline": None, "dtype": {"sort": "int64", "sorted_order": "int64", "join": "int64", "groupby": "f64", "reduce": "f64",
+                                          "scan": "int64", "gather": "int64"}[args.workload],
             "data": "synthetic",
             "config": {"workload": workload, "rows_per_gpu": n, "algo": args.algo, "gb_algo": args.gb_algo,
                        "parallelism": (f"{world} ranks, row shards, one all-to-all exchange per step (RCCL over xGMI)"

@@ -1,6 +1,6 @@
 // gx_scan.hpp -- device-wide scan / reduce building blocks (reduce-then-scan, three launches).
 //
-// Fixed association order (item order inside a thread, lane order, wave order, chunk order), so
+// Fixed association order (lane order inside a row, row order, wave order, chunk order), so
 // floating-point results are bit-reproducible run to run -- the reason the f64 paths use this
 // form rather than a decoupled look-back chain, whose association depends on timing.
 // Traffic: reduce pass reads N, apply pass reads N and writes N  (3 x sizeof(T) per element).
@@ -28,25 +28,52 @@ struct PlainLoader {
   }
 };
 
-// chunk-striped access: thread t owns items [t*IPT, (t+1)*IPT) of its chunk, so the sequential
-// order inside a thread is the element order (needed for a deterministic, ordered scan).
-template <typename AccT, typename Op, typename Loader>
+// Access pattern: wave w of a chunk owns the contiguous run [w, w+1) * 64 * IPT of it and walks it
+// in IPT rows of 64 consecutive items, lane l taking item row * 64 + l -- every load and store is a
+// fully coalesced 64-lane access (the earlier thread-contiguous layout had each lane on its own
+// cache line: 0.6 TB/s).  Order is kept for non-commutative operators: rows are combined in
+// order, lanes inside a row by an inclusive wave scan, waves in order.
+// ORDERED = false (commutative operators: cudf::reduce): every lane folds its own column of the rows,
+// then one ordered wave fold -- IPT + 6 operator applications per lane instead of 7 * IPT.
+template <typename AccT, typename Op, typename Loader, bool ORDERED = true>
 __global__ void __launch_bounds__(SCAN_BT) k_chunk_reduce(Loader load, int64_t n, AccT identity, Op op,
                                                           AccT* partials, const int* skip)
 {
   if (skip && *skip) return;
-  __shared__ AccT s_tmp[SCAN_BT / GX_WAVE + 1];
+  constexpr int NWV = SCAN_BT / GX_WAVE;
+  __shared__ AccT s_w[NWV];
+  const unsigned l    = lane_id();
+  const unsigned w    = threadIdx.x / GX_WAVE;
   const int64_t chunk = blockIdx.x;
-  const int64_t base  = chunk * SCAN_CHUNK + (int64_t)threadIdx.x * SCAN_IPT;
-  AccT acc            = identity;
+  const int64_t base  = chunk * SCAN_CHUNK + (int64_t)w * (GX_WAVE * SCAN_IPT) + l;
+  AccT carry          = identity;
+  if (ORDERED) {
+#pragma unroll 4
+    for (int k = 0; k < SCAN_IPT; ++k) {
+      const int64_t i = base + (int64_t)k * GX_WAVE;
+      const AccT v    = (i < n) ? load(i) : identity;
+      const AccT inc  = wave_inclusive_scan(v, op);
+      carry           = op(carry, shfl(inc, GX_WAVE - 1));
+    }
+  } else {
+    AccT v[SCAN_IPT];
 #pragma unroll
-  for (int k = 0; k < SCAN_IPT; ++k) {
-    const int64_t i = base + k;
-    if (i < n) acc = op(acc, load(i));
+    for (int k = 0; k < SCAN_IPT; ++k) {
+      const int64_t i = base + (int64_t)k * GX_WAVE;
+      v[k]            = (i < n) ? load(i) : identity;
+    }
+#pragma unroll
+    for (int k = 0; k < SCAN_IPT; ++k) carry = op(carry, v[k]);
+    carry = shfl(wave_inclusive_scan(carry, op), GX_WAVE - 1);
   }
-  AccT total;
-  block_exclusive_scan<SCAN_BT>(acc, identity, op, s_tmp, &total);
-  if (threadIdx.x == 0) partials[chunk] = total;
+  if (l == 0) s_w[w] = carry;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    AccT t = s_w[0];
+#pragma unroll
+    for (int k = 1; k < NWV; ++k) t = op(t, s_w[k]);
+    partials[chunk] = t;
+  }
 }
 
 // single block: exclusive scan of the chunk partials in place; partials[np] = grand total
@@ -78,29 +105,36 @@ __global__ void __launch_bounds__(SCAN_BT) k_chunk_scan(Loader load, int64_t n, 
                                                         const AccT* partials, OutT* out, const int* skip)
 {
   if (skip && *skip) return;
-  __shared__ AccT s_tmp[SCAN_BT / GX_WAVE + 1];
+  constexpr int NWV = SCAN_BT / GX_WAVE;
+  __shared__ AccT s_w[NWV];
+  const unsigned l    = lane_id();
+  const unsigned w    = threadIdx.x / GX_WAVE;
   const int64_t chunk = blockIdx.x;
-  const int64_t base  = chunk * SCAN_CHUNK + (int64_t)threadIdx.x * SCAN_IPT;
-  AccT v[SCAN_IPT];
-  AccT acc = identity;
+  const int64_t base  = chunk * SCAN_CHUNK + (int64_t)w * (GX_WAVE * SCAN_IPT) + l;
+  AccT inc[SCAN_IPT];  // inclusive scan of each row inside the wave
+  AccT carry = identity;
 #pragma unroll
   for (int k = 0; k < SCAN_IPT; ++k) {
-    const int64_t i = base + k;
-    v[k]            = (i < n) ? load(i) : identity;
-    acc             = op(acc, v[k]);
+    const int64_t i = base + (int64_t)k * GX_WAVE;
+    const AccT v    = (i < n) ? load(i) : identity;
+    inc[k]          = wave_inclusive_scan(v, op);
+    carry           = op(carry, shfl(inc[k], GX_WAVE - 1));
   }
-  AccT exc     = block_exclusive_scan<SCAN_BT>(acc, identity, op, s_tmp, (AccT*)nullptr);
-  AccT running = op(partials[chunk], exc);
+  if (l == 0) s_w[w] = carry;
+  __syncthreads();
+  AccT run = partials[chunk];  // everything before this chunk, then the waves before this one
+  for (unsigned k = 0; k < w; ++k) run = op(run, s_w[k]);
 #pragma unroll
   for (int k = 0; k < SCAN_IPT; ++k) {
-    const int64_t i = base + k;
+    const int64_t i = base + (int64_t)k * GX_WAVE;
     if (INCLUSIVE) {
-      running = op(running, v[k]);
-      if (i < n) out[i] = static_cast<OutT>(running);
+      if (i < n) out[i] = static_cast<OutT>(op(run, inc[k]));
     } else {
-      if (i < n) out[i] = static_cast<OutT>(running);
-      running = op(running, v[k]);
+      AccT ex = shfl_up(inc[k], 1);
+      if (l == 0) ex = identity;
+      if (i < n) out[i] = static_cast<OutT>(op(run, ex));
     }
+    run = op(run, shfl(inc[k], GX_WAVE - 1));
   }
 }
 
@@ -135,7 +169,7 @@ int device_reduce(Loader load, int64_t n, AccT identity, Op op, AccT* partials, 
 {
   const int64_t nc = num_chunks(n);
   if (nc > 0)
-    hipLaunchKernelGGL((k_chunk_reduce<AccT, Op, Loader>), dim3((unsigned)nc), dim3(SCAN_BT), 0, stream, load,
+    hipLaunchKernelGGL((k_chunk_reduce<AccT, Op, Loader, false>), dim3((unsigned)nc), dim3(SCAN_BT), 0, stream, load,
                        n, identity, op, partials, (const int*)nullptr);
   hipLaunchKernelGGL((k_partials_scan<AccT, Op>), dim3(1), dim3(1024), 0, stream, partials, nc, identity, op,
                      (const int*)nullptr);
