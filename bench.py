@@ -420,7 +420,7 @@ def main():
         cpu = None
         if args.cpu and world == 1:
             # bounded sample: ~10-30 s of single-thread CPU work
-            cpu_rows = args.cpu_rows or {"sort": 1e8, "sorted_order": 1e8, "join": 5e7, "groupby": 2e8}.get(args.workload, 1e8)
+            cpu_rows = args.cpu_rows or {"sort": 5e8, "sorted_order": 5e8, "join": 2e8, "groupby": 5e8}.get(args.workload, 1e8)
             fnc = {"sort": cpu_baseline_sort, "sorted_order": cpu_baseline_sort, "join": cpu_baseline_join,
                    "groupby": cpu_baseline_groupby}.get(args.workload)
             cpu = fnc(cpu_rows) if fnc else None

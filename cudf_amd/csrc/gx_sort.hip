@@ -234,6 +234,7 @@ struct PassArgs {
   uint64_t desc_mask;
 };
 
+constexpr int PASS_TPB = 8;  // tickets per workgroup of the MULTI form of k_radix_pass
 constexpr uint32_t SPIN_LIMIT = 1u << 22;  // ~seconds; only a broken forward-progress chain gets here
 
 __device__ __forceinline__ unsigned long long pack_status(unsigned flag, unsigned epoch, uint32_t value)
@@ -246,7 +247,10 @@ __device__ __forceinline__ unsigned long long pack_status(unsigned flag, unsigne
 // status hop costs a memory-side round trip (~1.5-2.5 us under streaming load, the per-XCD L2s do
 // not share lines), and a one-tile-per-hop walk settles into a regime where every tile walks
 // ~10 predecessors (DESIGN.md "look-back regime"); the window bounds the walk to ~1-2 rounds.
-template <typename KeyT, int KIND, bool HAS_VAL, int KPT, int LBW>
+// MULTI: the workgroup handles PASS_TPB consecutive tickets.  Used for the LSD passes that are enqueued
+// behind a hybrid attempt: when the attempt succeeds they are no-ops, and the cost of a no-op launch
+// is proportional to its grid (51 us for 122k single-tile workgroups at 1e9 keys).
+template <typename KeyT, int KIND, bool HAS_VAL, int KPT, int LBW, bool MULTI = false>
 __global__ void __launch_bounds__(BT, 4) k_radix_pass(PassArgs a)
 {
   constexpr bool LOOKBACK = LBW > 0;
@@ -275,11 +279,13 @@ __global__ void __launch_bounds__(BT, 4) k_radix_pass(PassArgs a)
   const unsigned w       = tid / GX_WAVE;
   const unsigned epoch   = (unsigned)pass + 1u;
 
+  for (int it = 0; it < (MULTI ? PASS_TPB : 1); ++it) {
   int64_t tile;
   if (LOOKBACK) {
     if (tid == 0) s_misc[0] = atomicAdd(&plan->cnt.tickets[pass].v, 1u);
     __syncthreads();
     tile = s_misc[0];
+    if (MULTI && tile >= a.ntiles) return;  // tickets only grow
   } else if (a.order_mode == 2) {
     if (tid == 0) s_misc[0] = atomicAdd(&plan->cnt.tickets[pass].v, 1u);
     __syncthreads();
@@ -422,6 +428,8 @@ __global__ void __launch_bounds__(BT, 4) k_radix_pass(PassArgs a)
       if (HAS_VAL) vout[dst] = s_vals[i];
     }
   }
+  if (MULTI) __syncthreads();  // the next tile reuses the LDS
+  }  // tiles of this workgroup
 }
 
 // algorithm 1: per-tile histogram of the current digit -> tile_hist[bin][tile]
@@ -1293,13 +1301,16 @@ int sort_impl(const void* keys_in, void* keys_out, const int32_t* vals_in, int32
   a.order_mode = g_order_mode;
 
   constexpr size_t lds = pass_lds_bytes<KeyT, HAS_VAL, KPT>();
-  auto kern_lb         = (algo == 2) ? k_radix_pass<KeyT, KIND, HAS_VAL, KPT, 1> : k_radix_pass<KeyT, KIND, HAS_VAL, KPT, 4>;
+  auto kern_lb         = (algo == 2) ? k_radix_pass<KeyT, KIND, HAS_VAL, KPT, 1>
+                                       : (try_hybrid ? k_radix_pass<KeyT, KIND, HAS_VAL, KPT, 4, true> : k_radix_pass<KeyT, KIND, HAS_VAL, KPT, 4>);
   auto kern_pre        = k_radix_pass<KeyT, KIND, HAS_VAL, KPT, 0>;
   static bool attr_set = false;  // per template instantiation
   if (!attr_set) {
     GX_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(k_radix_pass<KeyT, KIND, HAS_VAL, KPT, 4>),
                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     GX_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(k_radix_pass<KeyT, KIND, HAS_VAL, KPT, 1>),
+                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    GX_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(k_radix_pass<KeyT, KIND, HAS_VAL, KPT, 4, true>),
                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     GX_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(kern_pre),
                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
@@ -1309,7 +1320,8 @@ int sort_impl(const void* keys_in, void* keys_out, const int32_t* vals_in, int32
     a.pass = pass;
     prof_mark(2 + 2 * pass, stream);
     if (algo != 1) {
-      hipLaunchKernelGGL(kern_lb, dim3((unsigned)ntiles), dim3(BT), lds, stream, a);
+      const int64_t lb_grid = (try_hybrid && algo != 2) ? div_up(ntiles, PASS_TPB) : ntiles;
+      hipLaunchKernelGGL(kern_lb, dim3((unsigned)lb_grid), dim3(BT), lds, stream, a);
     } else {
       hipLaunchKernelGGL((k_tile_hist<KeyT, KIND, KPT>), dim3((unsigned)ntiles), dim3(BT), 0, stream, a, tile_hist);
       scan::PlainLoader<uint32_t, uint32_t> ld{tile_hist, nullptr, 0u};

@@ -2,7 +2,8 @@
 
 Every entry cites the reference test file:line (relative to /root/reference/cpp/tests).  These
 pin the CPU oracle (tests/test_oracle_golden.py) and are replayed through the HIP path
-(tests/test_gpu_golden.py).  ``N`` marks a null element; masks use 1 = valid.
+(the test_reference_golden_* cases of tests/test_gpu_sort.py, tests/test_gpu_join_groupby.py,
+tests/test_gpu_reduce_scan_hash.py and tests/cpp/cudf_api_tests.cpp).  ``N`` marks a null element; masks use 1 = valid.
 String key columns of the reference tests are transcribed as small integer codes
 ("s0"->0, "s1"->1, ...) because only their equality classes matter to the join.
 """
