@@ -941,7 +941,8 @@ template <typename KeyT, int KIND, bool HAS_VAL>
 __global__ void __launch_bounds__(LS_BT) k_local_sort(const KeyT* __restrict__ in, KeyT* __restrict__ out,
                                                       const uint32_t* __restrict__ vin, uint32_t* __restrict__ vout,
                                                       KeyT desc_mask_in, SortPlan* plan,
-                                                      const uint32_t* __restrict__ hist2, const uint32_t* __restrict__ base2)
+                                                      const uint32_t* __restrict__ hist2, const uint32_t* __restrict__ base2,
+                                                      int exp = 0)
 {
   // PAIRS = the packed-word mode: pairs, and float keys (whose -0.0 == +0.0 ties must keep input order
   // and whose original bits cannot be rebuilt from the sortable form)
@@ -999,7 +1000,7 @@ __global__ void __launch_bounds__(LS_BT) k_local_sort(const KeyT* __restrict__ i
       const int idx = wbase + j * GX_WAVE;
       key[j]        = sortable(key[j]);  // an involution for integer kinds
       rank[j]       = 0;
-      if ((uint32_t)idx < m) rank[j] = atomicAdd(&s_cnt[(uint32_t)(key[j] >> sshift) & 0xFFu], 1u);
+      if ((uint32_t)idx < m) rank[j] = (exp & 8) ? (uint32_t)(idx >> 8) : atomicAdd(&s_cnt[(uint32_t)(key[j] >> sshift) & 0xFFu], 1u);  // ablation 8: no atomics
     }
     __syncthreads();
     const uint32_t c   = tid < BINS ? s_cnt[tid] : 0u;
@@ -1015,6 +1016,7 @@ __global__ void __launch_bounds__(LS_BT) k_local_sort(const KeyT* __restrict__ i
       }
       __syncthreads();
       for (int sb = (int)w; sb < BINS; sb += LS_NW) {
+        if (exp & 4) break;  // ablation: no sorting networks
         const uint32_t cnt = s_cnt[sb], o = s_start[sb];
         if (cnt <= 1) continue;
         if (cnt <= 64) {
@@ -1279,7 +1281,7 @@ int sort_impl(const void* keys_in, void* keys_out, const int32_t* vals_in, int32
       hipLaunchKernelGGL(kmsd, dim3((unsigned)(msd_ntiles + BINS + NRANGE)), dim3(BT), lds_m, stream, m);
       prof_mark_h(3, stream);
       hipLaunchKernelGGL(kloc, dim3((unsigned)(BINS * BINS)), dim3(LS_BT), lds_l, stream, bufB, bufA, valB, valA, desc_mask,
-                         plan, hist2, base2);
+                         plan, hist2, base2, m.exp);
       prof_mark_h(4, stream);
       g_prof.hybrid_marked = g_prof.enabled;
     }
