@@ -73,6 +73,53 @@ hash_agg_out hash_aggregate(column_view const& keys, column_view const& vals, rm
   }
 }
 
+struct hash_minmax_out {
+  std::unique_ptr<column> keys, mn, mx, count_valid;
+};
+
+hash_minmax_out hash_minmax(column_view const& keys, column_view const& vals, rmm::cuda_stream_view stream,
+                            rmm::device_async_resource_ref mr)
+{
+  auto const n = keys.size();
+  rmm::device_buffer kh, vh;
+  auto const* kmask = keys.has_nulls() ? detail::rebased_mask(keys, kh, stream) : nullptr;
+  auto const* vmask = vals.has_nulls() ? detail::rebased_mask(vals, vh, stream) : nullptr;
+  int64_t max_groups = std::max<int64_t>(1, std::min<int64_t>(n, int64_t{1} << 20));
+  rmm::device_buffer ng{sizeof(int64_t), stream};
+  for (;;) {
+    hash_minmax_out o;
+    auto const g  = static_cast<size_type>(max_groups);
+    o.keys        = make_fixed_width_column(keys.type(), g, mask_state::UNALLOCATED, stream, mr);
+    o.mn          = make_fixed_width_column(vals.type(), g, mask_state::UNALLOCATED, stream, mr);
+    o.mx          = make_fixed_width_column(vals.type(), g, mask_state::UNALLOCATED, stream, mr);
+    o.count_valid = make_fixed_width_column(data_type{type_id::INT32}, g, mask_state::UNALLOCATED, stream, mr);
+    detail::run_with_scratch(
+      [&](void* t, std::size_t* b) {
+        return gx_groupby_min_max(detail::gx_type(keys.type()), detail::row0(keys), kmask, detail::gx_type(vals.type()),
+                                  detail::row0(vals), vmask, n, max_groups, o.keys->mutable_view().head<void>(),
+                                  o.mn->mutable_view().head<void>(), o.mx->mutable_view().head<void>(),
+                                  o.count_valid->mutable_view().head<int32_t>(), static_cast<int64_t*>(ng.data()), t, b,
+                                  detail::gxs(stream));
+      },
+      "groupby min/max", stream);
+    auto const groups = detail::read_i64(static_cast<int64_t const*>(ng.data()), stream);
+    if (groups >= 0 && groups <= max_groups) {
+      auto trim = [&](std::unique_ptr<column>& c) {
+        auto type     = c->type();
+        auto contents = c->release();
+        c = std::make_unique<column>(type, static_cast<size_type>(groups), std::move(*contents.data), rmm::device_buffer{}, 0);
+      };
+      trim(o.keys);
+      trim(o.mn);
+      trim(o.mx);
+      trim(o.count_valid);
+      return o;
+    }
+    CUDF_EXPECTS(max_groups < n, "groupby: group table overflow");
+    max_groups = std::min<int64_t>(n, max_groups * 8);
+  }
+}
+
 // permute `c` by an INT32 map (same length)
 std::unique_ptr<column> permute(column_view const& c, column_view const& map, rmm::cuda_stream_view stream,
                                 rmm::device_async_resource_ref mr)
@@ -111,7 +158,20 @@ std::pair<std::unique_ptr<table>, std::vector<aggregation_result>> groupby::aggr
 
   std::vector<aggregation_result> results(requests.size());
   std::unique_ptr<column> out_keys;
-  bool const canonical = requests.size() > 1;  // several hash passes: bring every result into key order
+  auto needs_sum = [](aggregation::Kind k) {
+    return k == aggregation::SUM || k == aggregation::COUNT_VALID || k == aggregation::COUNT_ALL || k == aggregation::MEAN;
+  };
+  auto needs_mm = [](aggregation::Kind k) { return k == aggregation::MIN || k == aggregation::MAX; };
+  std::size_t passes = 0;  // hash passes over the keys: more than one -> bring every result into key order
+  for (auto const& r : requests) {
+    bool a = false, b = false;
+    for (auto const& agg : r.aggregations) {
+      a = a || needs_sum(agg->kind);
+      b = b || needs_mm(agg->kind);
+    }
+    passes += (a ? 1 : 0) + (b ? 1 : 0);
+  }
+  bool const canonical = passes > 1;
 
   if (_keys.num_rows() == 0 || requests.empty()) {  // empty input -> empty keys + typed empty results (groupby.cu:234)
     for (std::size_t i = 0; i < requests.size(); ++i)
@@ -120,6 +180,7 @@ std::pair<std::unique_ptr<table>, std::vector<aggregation_result>> groupby::aggr
         if (agg->kind == aggregation::SUM) t = sum_type(t);
         if (agg->kind == aggregation::COUNT_VALID || agg->kind == aggregation::COUNT_ALL) t = data_type{type_id::INT32};
         if (agg->kind == aggregation::MEAN) t = data_type{type_id::FLOAT64};
+        // MIN / MAX keep the values' type
         results[i].results.emplace_back(make_empty_column(t));
       }
     if (requests.empty() && _keys.num_rows() > 0) {
@@ -136,15 +197,34 @@ std::pair<std::unique_ptr<table>, std::vector<aggregation_result>> groupby::aggr
 
   for (std::size_t i = 0; i < requests.size(); ++i) {
     auto const& req = requests[i];
-    for (auto const& agg : req.aggregations)
-      CUDF_EXPECTS(agg->kind == aggregation::SUM || agg->kind == aggregation::COUNT_VALID ||
-                     agg->kind == aggregation::COUNT_ALL || agg->kind == aggregation::MEAN,
-                   "groupby aggregation kind not implemented on this path (SUM, COUNT, MEAN are)");
-    auto o = hash_aggregate(keys, req.values, stream, mr);
-    std::unique_ptr<column> order;
-    if (canonical) order = cudf::sorted_order(table_view{{o.keys->view()}}, {}, {}, stream);
+    bool want_sum = false, want_mm = false;
+    for (auto const& agg : req.aggregations) {
+      CUDF_EXPECTS(needs_sum(agg->kind) || needs_mm(agg->kind),
+                   "groupby aggregation kind not implemented on this path (SUM, COUNT, MEAN, MIN, MAX are)");
+      want_sum = want_sum || needs_sum(agg->kind);
+      want_mm  = want_mm || needs_mm(agg->kind);
+    }
+    hash_agg_out o;
+    hash_minmax_out mm;
+    std::unique_ptr<column> order, mm_order;
+    if (want_sum || !want_mm) {
+      o = hash_aggregate(keys, req.values, stream, mr);
+      if (canonical) order = cudf::sorted_order(table_view{{o.keys->view()}}, {}, {}, stream);
+    }
+    if (want_mm) {
+      mm = hash_minmax(keys, req.values, stream, mr);
+      if (canonical) mm_order = cudf::sorted_order(table_view{{mm.keys->view()}}, {}, {}, stream);
+      if (!o.keys) {  // only MIN / MAX requested: this pass provides keys and validity
+        o.keys        = std::make_unique<column>(mm.keys->view(), stream, mr);
+        o.count_valid = std::make_unique<column>(mm.count_valid->view(), stream, mr);
+        if (canonical) order = std::make_unique<column>(mm_order->view(), stream, mr);
+      }
+    }
     auto fin = [&](std::unique_ptr<column> c) {
       return canonical ? permute(c->view(), order->view(), stream, mr) : std::move(c);
+    };
+    auto fin_mm = [&](std::unique_ptr<column> c) {
+      return canonical ? permute(c->view(), mm_order->view(), stream, mr) : std::move(c);
     };
     auto const g = o.keys->size();
     // validity of SUM / MEAN: groups without a valid value are null
@@ -179,6 +259,22 @@ std::pair<std::unique_ptr<table>, std::vector<aggregation_result>> groupby::aggr
           auto mask       = validity(nulls);
           if (nulls > 0) c->set_null_mask(std::move(mask), nulls);
           results[i].results.emplace_back(fin(std::move(c)));
+          break;
+        }
+        case aggregation::MIN:
+        case aggregation::MAX: {
+          auto const& src = agg->kind == aggregation::MIN ? mm.mn : mm.mx;
+          auto c          = std::make_unique<column>(src->view(), stream, mr);
+          // validity from THIS pass's counts (its group order)
+          rmm::device_buffer mask = create_null_mask(c->size(), mask_state::ALL_VALID, stream, mr);
+          rmm::device_buffer cnt{sizeof(int64_t), stream};
+          detail::gx_check(gx_valid_from_counts(mm.count_valid->view().head<int32_t>(), c->size(),
+                                                static_cast<uint32_t*>(mask.data()), static_cast<int64_t*>(cnt.data()),
+                                                detail::gxs(stream)),
+                           "groupby validity");
+          auto const nulls = static_cast<size_type>(detail::read_i64(static_cast<int64_t const*>(cnt.data()), stream));
+          if (nulls > 0) c->set_null_mask(std::move(mask), nulls);
+          results[i].results.emplace_back(fin_mm(std::move(c)));
           break;
         }
         default: break;

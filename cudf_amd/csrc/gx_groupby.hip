@@ -12,6 +12,8 @@
 // result is within 1 ulp of the correctly rounded sum regardless of the order in which the
 // atomics land (the reference's plain relaxed atomic add -- device_atomics.cuh:57-62 -- drifts by
 // sqrt(rows per group) ulps).  integer SUM: 64-bit wrapping atomics (exact).
+#include <type_traits>
+
 #include "gx_common.hpp"
 #include "gx_scan.hpp"
 
@@ -746,6 +748,192 @@ int gx_mean_from_sum(int sum_dtype, const void* sum, const int32_t* count, int64
   }
   GX_LAUNCH_CHECK();
   return 0;
+}
+
+}  // extern "C"
+
+// ------------------------------------------------------------------------------------------------
+// groupby MIN / MAX (cpp/src/groupby/hash/global_memory_aggregator.cuh:18-238: atomic min/max per
+// group).  Values are widened to a 64-bit word whose unsigned order is the value order (sign flip
+// for signed integers, the IEEE total-order flip for floats with -0.0 -> +0.0 and every NaN above
+// +Inf, the row comparator's order: include/cudf/detail/row_operator/common_utils.cuh:157-169), so one
+// native 64-bit unsigned atomic min / max per row serves every value type.  Global-table path only.
+// ------------------------------------------------------------------------------------------------
+namespace gx {
+namespace gb {
+
+template <typename V>
+__device__ __forceinline__ unsigned long long mm_encode(V v)
+{
+  if constexpr (sizeof(V) == 8 && !std::is_integral<V>::value) {
+    unsigned long long b;
+    __builtin_memcpy(&b, &v, 8);
+    return to_sortable<unsigned long long, K_FLOAT>(b, 0ull);
+  } else if constexpr (!std::is_integral<V>::value) {
+    const double d = (double)v;  // float -> double is exact and order preserving
+    unsigned long long b;
+    __builtin_memcpy(&b, &d, 8);
+    return to_sortable<unsigned long long, K_FLOAT>(b, 0ull);
+  } else if constexpr (std::is_signed<V>::value) {
+    return (unsigned long long)(long long)v ^ 0x8000000000000000ull;
+  } else {
+    return (unsigned long long)v;
+  }
+}
+template <typename V>
+__device__ __forceinline__ V mm_decode(unsigned long long s)
+{
+  if constexpr (!std::is_integral<V>::value) {
+    const unsigned long long b = (s & 0x8000000000000000ull) ? (s ^ 0x8000000000000000ull) : ~s;
+    double d;
+    __builtin_memcpy(&d, &b, 8);
+    return (V)d;
+  } else if constexpr (std::is_signed<V>::value) {
+    return (V)(long long)(s ^ 0x8000000000000000ull);
+  } else {
+    return (V)s;
+  }
+}
+
+template <typename K, typename V>
+__global__ void __launch_bounds__(GBT) k_minmax(const K* __restrict__ keys, const uint32_t* __restrict__ kvalid,
+                                                const V* __restrict__ vals, const uint32_t* __restrict__ vvalid, int64_t n,
+                                                unsigned long long* table, uint32_t log2cap, unsigned long long* mn,
+                                                unsigned long long* mx, uint32_t* cnt_valid, GbState* st)
+{
+  const int64_t stride = (int64_t)gridDim.x * GBT;
+  for (int64_t i = (int64_t)blockIdx.x * GBT + threadIdx.x; i < n; i += stride) {
+    if (kvalid && !bit_is_set(kvalid, i)) continue;
+    const int64_t g = find_or_insert<K>(table, log2cap, keys[i], st);
+    if (g < 0) continue;
+    if (!vvalid || bit_is_set(vvalid, i)) {
+      const unsigned long long e = mm_encode<V>(vals[i]);
+      atomicMin(&mn[g], e);
+      atomicMax(&mx[g], e);
+      atomicAdd(&cnt_valid[g], 1u);
+    }
+  }
+}
+
+template <typename K, typename V>
+__global__ void __launch_bounds__(GBT) k_minmax_compact(const unsigned long long* __restrict__ table, uint64_t cap,
+                                                        const uint32_t* __restrict__ pos, const uint32_t* __restrict__ total,
+                                                        const unsigned long long* __restrict__ mn,
+                                                        const unsigned long long* __restrict__ mx,
+                                                        const uint32_t* __restrict__ cnt_valid, const GbState* st,
+                                                        int64_t max_groups, K* out_keys, V* out_min, V* out_max,
+                                                        int32_t* out_cv, long long* ngroups)
+{
+  const int64_t stride = (int64_t)gridDim.x * GBT;
+  for (int64_t i = (int64_t)blockIdx.x * GBT + threadIdx.x; i <= (int64_t)cap; i += stride) {
+    bool occ;
+    K key;
+    if ((uint64_t)i < cap) {
+      const unsigned long long s = table[i];
+      occ                        = s != 0ull;
+      key                        = (K)(s - 1ull);
+    } else {
+      occ = st->special_used != 0ull;
+      key = (K)(~0ull);
+    }
+    if (!occ) continue;
+    const int64_t p = pos[i];
+    if (p >= max_groups) continue;
+    out_keys[p] = key;
+    const bool has = cnt_valid[i] > 0;
+    if (out_min) out_min[p] = has ? mm_decode<V>(mn[i]) : V(0);
+    if (out_max) out_max[p] = has ? mm_decode<V>(mx[i]) : V(0);
+    if (out_cv) out_cv[p] = (int32_t)cnt_valid[i];
+  }
+  if (blockIdx.x == 0 && threadIdx.x == 0) *ngroups = st->overflow ? -1ll : (long long)*total;
+}
+
+template <typename K, typename V>
+int minmax_impl(const void* keys, const uint32_t* kvalid, const void* vals, const uint32_t* vvalid, int64_t n,
+                int64_t max_groups, void* out_keys, void* out_min, void* out_max, int32_t* out_cv, int64_t* ngroups,
+                void* tmp, size_t* tmp_bytes, hipStream_t s)
+{
+  const uint32_t lg  = log2_cap(max_groups);
+  const uint64_t cap = 1ull << lg;
+  Carver c(tmp);
+  GbState* st               = c.take<GbState>(1);
+  unsigned long long* table = c.take<unsigned long long>(cap);
+  uint32_t* cv              = c.take<uint32_t>(cap + 1);
+  unsigned long long* mx    = c.take<unsigned long long>(cap + 1);  // zero-initialised with the block above
+  unsigned long long* mn    = c.take<unsigned long long>(cap + 1);  // all-ones
+  uint32_t* pos             = c.take<uint32_t>(cap + 1);
+  uint32_t* partials        = c.take<uint32_t>(scan::partials_count(cap + 1));
+  if (!tmp) {
+    *tmp_bytes = c.total();
+    return 0;
+  }
+  if (*tmp_bytes < c.total()) return GX_ETMP;
+  GX_HIP_TRY(hipMemsetAsync(tmp, 0, (size_t)(reinterpret_cast<char*>(mn) - static_cast<char*>(tmp)), s));
+  GX_HIP_TRY(hipMemsetAsync(mn, 0xFF, (cap + 1) * sizeof(unsigned long long), s));
+  if (n > 0) {
+    int64_t blocks = div_up(n, GBT * 8);
+    if (blocks > 256 * 16) blocks = 256 * 16;
+    hipLaunchKernelGGL((k_minmax<K, V>), dim3((unsigned)blocks), dim3(GBT), 0, s, static_cast<const K*>(keys), kvalid,
+                       static_cast<const V*>(vals), vvalid, n, table, lg, mn, mx, cv, st);
+  }
+  OccLoader ld{table, cap, st};
+  int rc = scan::device_scan<uint32_t, uint32_t>(ld, (int64_t)cap + 1, 0u, SumOp(), false, pos, partials, s);
+  if (rc) return rc;
+  int64_t blocks = div_up((int64_t)cap + 1, GBT * 4);
+  if (blocks > 4096) blocks = 4096;
+  hipLaunchKernelGGL((k_minmax_compact<K, V>), dim3((unsigned)blocks), dim3(GBT), 0, s, table, cap, pos,
+                     partials + scan::num_chunks((int64_t)cap + 1), mn, mx, cv, st, max_groups, static_cast<K*>(out_keys),
+                     static_cast<V*>(out_min), static_cast<V*>(out_max), out_cv, reinterpret_cast<long long*>(ngroups));
+  GX_LAUNCH_CHECK();
+  return 0;
+}
+
+template <typename K>
+int minmax_dispatch(int val_dtype, const void* keys, const uint32_t* kvalid, const void* vals, const uint32_t* vvalid,
+                    int64_t n, int64_t max_groups, void* out_keys, void* out_min, void* out_max, int32_t* out_cv,
+                    int64_t* ngroups, void* tmp, size_t* tmp_bytes, hipStream_t s)
+{
+#define GX_MM(V) return minmax_impl<K, V>(keys, kvalid, vals, vvalid, n, max_groups, out_keys, out_min, out_max, out_cv, ngroups, tmp, tmp_bytes, s)
+  switch (val_dtype) {
+    case GX_INT8: GX_MM(int8_t);
+    case GX_INT16: GX_MM(int16_t);
+    case GX_INT32: GX_MM(int32_t);
+    case GX_INT64: GX_MM(int64_t);
+    case GX_BOOL8:
+    case GX_UINT8: GX_MM(uint8_t);
+    case GX_UINT16: GX_MM(uint16_t);
+    case GX_UINT32: GX_MM(uint32_t);
+    case GX_UINT64: GX_MM(uint64_t);
+    case GX_FLOAT32: GX_MM(float);
+    case GX_FLOAT64: GX_MM(double);
+    default: return GX_EDTYPE;
+  }
+#undef GX_MM
+}
+
+}  // namespace gb
+}  // namespace gx
+
+extern "C" {
+
+int gx_groupby_min_max(int key_dtype, const void* keys, const uint32_t* keys_valid, int val_dtype, const void* vals,
+                       const uint32_t* vals_valid, int64_t n, int64_t max_groups, void* out_keys, void* out_min,
+                       void* out_max, int32_t* out_count_valid, int64_t* ngroups_dev, void* tmp, size_t* tmp_bytes,
+                       gx_stream_t s)
+{
+  if (n < 0 || max_groups < 0 || !tmp_bytes) return GX_EINVAL;
+  if (tmp && (!ngroups_dev || (n > 0 && (!keys || !vals)) || (max_groups > 0 && !out_keys))) return GX_EINVAL;
+  switch (key_dtype) {
+    case GX_INT32:
+    case GX_UINT32:
+      return gx::gb::minmax_dispatch<uint32_t>(val_dtype, keys, keys_valid, vals, vals_valid, n, max_groups, out_keys, out_min,
+                                               out_max, out_count_valid, ngroups_dev, tmp, tmp_bytes, s);
+    case GX_INT64:
+    case GX_UINT64:
+      return gx::gb::minmax_dispatch<uint64_t>(val_dtype, keys, keys_valid, vals, vals_valid, n, max_groups, out_keys, out_min,
+                                               out_max, out_count_valid, ngroups_dev, tmp, tmp_bytes, s);
+    default: return GX_EDTYPE;
+  }
 }
 
 }  // extern "C"

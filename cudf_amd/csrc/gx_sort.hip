@@ -1175,6 +1175,7 @@ int sort_impl(const void* keys_in, void* keys_out, const int32_t* vals_in, int32
   constexpr int TILE  = BT * KPT;
   constexpr int NPASS = sizeof(KeyT);
   if (n < 0 || tmp_bytes == nullptr) return GX_EINVAL;
+  if (n > 0x7FFFFFFFll) return GX_EINVAL;  // offsets are 32-bit: cudf::size_type rows (types.hpp:76)
   const int64_t ntiles = n > 0 ? div_up(n, TILE) : 0;
   const int algo       = g_algorithm;
 

@@ -116,13 +116,13 @@ class DataFrame:
 
 
 class GroupBy:
-    _SUPPORTED = ("sum", "count", "mean")
+    _SUPPORTED = ("sum", "count", "mean", "min", "max")
 
     def __init__(self, df: DataFrame, by: str):
         self._df, self._by = df, by
 
     def agg(self, spec: Dict[str, Union[str, Sequence[str]]]) -> DataFrame:
-        """{value column: "sum" | "count" | "mean" | [..]} -> one row per group, sorted by key
+        """{value column: "sum" | "count" | "mean" | "min" | "max" | [..]} -> one row per group, sorted by key
         (pandas' default sort=True).  Null keys are dropped (dropna=True), null values are skipped."""
         keys = self._df[self._by]
         out = DataFrame()
@@ -138,12 +138,23 @@ class GroupBy:
                 out._cols[self._by] = ops.gather(k, order)
                 first = False
             s, cv = ops.gather(s, order), ops.gather(cv, order)
+            mn = mx = None
+            if any(f in ("min", "max") for f in fns):
+                k2, mn, mx, cv2 = ops.groupby_min_max(keys, self._df[name])
+                o2 = ops.sorted_order(k2)
+                valid = ops.gather(cv2, o2).to_numpy() > 0
+                mn = Column.from_numpy(ops.gather(mn, o2).to_numpy(), valid)
+                mx = Column.from_numpy(ops.gather(mx, o2).to_numpy(), valid)
             for f in fns:
                 label = name if len(fns) == 1 and len(spec) >= 1 and all(isinstance(v, str) for v in spec.values()) else f"{name}_{f}"
                 if f == "sum":
                     out._cols[label] = s
                 elif f == "count":
                     out._cols[label] = cv
+                elif f == "min":
+                    out._cols[label] = mn
+                elif f == "max":
+                    out._cols[label] = mx
                 else:
                     sn, cn = s.to_numpy().astype(np.float64), cv.to_numpy()
                     with np.errstate(divide="ignore", invalid="ignore"):

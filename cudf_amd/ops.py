@@ -287,6 +287,34 @@ def groupby_sum_count(keys: Column, values: Column, max_groups_hint: int = 1 << 
     return ok, osum, ocv, oca
 
 
+def groupby_min_max(keys: Column, values: Column, max_groups_hint: int = 1 << 20):
+    """Hash groupby MIN + MAX + COUNT_VALID of one values column -> (keys, min, max, count_valid);
+    min/max have the values' dtype and are meaningful where count_valid > 0."""
+    if keys.size != values.size:
+        raise RuntimeError("Size mismatch between request values and groupby keys.")
+    if keys.dtype.itemsize not in (4, 8) or keys.dtype.kind not in "iu":
+        raise TypeError("groupby key must be a 32/64-bit integer column")
+    n = keys.size
+    max_groups = max(1, min(n, max_groups_hint))
+    while True:
+        ok = Column.empty(keys.dtype, max_groups)
+        omin, omax = Column.empty(values.dtype, max_groups), Column.empty(values.dtype, max_groups)
+        ocv = Column.empty(np.int32, max_groups)
+        ng = _dev_i64()
+        _run(_lib.gx_groupby_min_max, keys.gx, keys.data_ptr, keys.mask_ptr if keys.has_nulls() else None,
+             values.gx, values.data_ptr, values.mask_ptr if values.has_nulls() else None, n, max_groups,
+             ok.data_ptr, omin.data_ptr, omax.data_ptr, ocv.data_ptr, ptr(ng))
+        g = int(ng.item())
+        if 0 <= g <= max_groups:
+            break
+        if max_groups >= n:
+            raise RuntimeError("groupby table overflow")
+        max_groups = min(n, max_groups * 8)
+    for c in (ok, omin, omax, ocv):
+        c.size = g
+    return ok, omin, omax, ocv
+
+
 def groupby_scan(sorted_keys: Column, values: Column, op: str = "sum") -> Column:
     """Segmented inclusive scan over already-sorted keys (groupby::scan's value pass)."""
     opc = {"sum": L.OP_SUM, "min": L.OP_MIN, "max": L.OP_MAX}[op]

@@ -242,6 +242,15 @@ int gx_groupby_sum_count(int key_dtype, const void* keys, const uint32_t* keys_v
                          int32_t* out_count_valid, int32_t* out_count_all, int64_t* ngroups_dev,
                          void* tmp, size_t* tmp_bytes, gx_stream_t stream);
 
+/* Groupby MIN / MAX of one value column (src/groupby/hash/global_memory_aggregator.cuh:18-238):
+ * same conventions as gx_groupby_sum_count; out_min / out_max have the VALUE dtype (either may be
+ * NULL); a group without a valid value has count 0 and an unspecified min/max (the caller nulls it).
+ * Floats: -0.0 == +0.0, NaN greater than every number (the row comparator's order). */
+int gx_groupby_min_max(int key_dtype, const void* keys, const uint32_t* keys_valid, int val_dtype,
+                       const void* vals, const uint32_t* vals_valid, int64_t n, int64_t max_groups,
+                       void* out_keys, void* out_min, void* out_max, int32_t* out_count_valid,
+                       int64_t* ngroups_dev, void* tmp, size_t* tmp_bytes, gx_stream_t stream);
+
 /* Tuning / A-B knob (process-wide).  algo: 0 = auto (hash-partition rows into 256 LDS-sized
  * partitions and aggregate each in one workgroup's LDS when n >= 2^19, else the global-atomic
  * table), 1 = global-atomic table only, 2 = partitioned for every n > 0.  nsplit: workgroups per

@@ -404,6 +404,40 @@ int main()
     CHECK(kh.size() == 5000);
     for (std::size_t g = 0; g < kh.size(); ++g) CHECK(sa[g] == ea[kh[g]] && sb[g] == eb[kh[g]]);  // small integers: exact
   });
+  run("groupby MIN / MAX incl. null group, mixed with SUM (min_tests.cpp:37-120, max_tests.cpp:37-120)", [&] {
+    auto keys = make_col<int32_t>({1, 2, 3, 1, 2, 2, 1, 3, 3, 2});
+    auto vals = make_col<double>({0, 1, 2, 3, 4, 5, 6, 7, 8, 9});
+    groupby::groupby gb{table_view{{keys->view()}}};
+    std::vector<groupby::aggregation_request> reqs(1);
+    reqs[0].values = vals->view();
+    reqs[0].aggregations.push_back(make_min_aggregation<groupby_aggregation>());
+    reqs[0].aggregations.push_back(make_max_aggregation<groupby_aggregation>());
+    reqs[0].aggregations.push_back(make_sum_aggregation<groupby_aggregation>());
+    auto [k, res] = gb.aggregate(reqs);
+    CHECK((to_host<int32_t>(k->view().column(0)) == std::vector<int32_t>{1, 2, 3}));  // two hash passes -> key order
+    CHECK((to_host<double>(res[0].results[0]->view()) == std::vector<double>{0, 1, 2}));
+    CHECK((to_host<double>(res[0].results[1]->view()) == std::vector<double>{6, 9, 8}));
+    CHECK((to_host<double>(res[0].results[2]->view()) == std::vector<double>{9, 19, 17}));
+    auto k2 = make_col<int32_t>({1, 2, 3, 1, 2, 2, 1, 3, 3, 2, 4}, {1, 1, 1, 1, 1, 1, 1, 0, 1, 1, 1});
+    auto v2 = make_col<int32_t>({0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 4}, {0, 1, 1, 1, 1, 0, 1, 1, 1, 1, 0});
+    groupby::groupby gb2{table_view{{k2->view()}}};
+    std::vector<groupby::aggregation_request> r2(1);
+    r2[0].values = v2->view();
+    r2[0].aggregations.push_back(make_min_aggregation<groupby_aggregation>());
+    r2[0].aggregations.push_back(make_max_aggregation<groupby_aggregation>());
+    auto [kk, rr] = gb2.aggregate(r2);
+    auto [kh, idx] = by_key(*kk, rr[0].results);
+    auto mn = to_host<int32_t>(rr[0].results[0]->view());
+    auto mx = to_host<int32_t>(rr[0].results[1]->view());
+    auto vv = valid_host(rr[0].results[0]->view());
+    int emn[] = {3, 1, 2, 0}, emx[] = {6, 9, 8, 0}, ev[] = {1, 1, 1, 0};
+    CHECK(kh.size() == 4 && rr[0].results[0]->type().id() == type_id::INT32);
+    for (int g = 0; g < 4; ++g) {
+      int i = idx[g];
+      CHECK(kh[i] == g + 1 && vv[i] == ev[g]);
+      if (ev[g]) CHECK(mn[i] == emn[g] && mx[i] == emx[g]);
+    }
+  });
   run("groupby SUM scan (sum_scan_tests.cpp:33-48,118-139)", [&] {
     auto keys = make_col<int32_t>({1, 2, 3, 1, 2, 2, 1, 3, 3, 2});
     auto vals = make_col<int32_t>({0, 1, 2, 3, 4, 5, 6, 7, 8, 9});

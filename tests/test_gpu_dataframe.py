@@ -44,8 +44,12 @@ def test_groupby_agg_matches_pandas(DF):
     rng = np.random.default_rng(2)
     n = 700_000  # >= 2^19: the LDS-partitioned kernels
     pdf = pd.DataFrame({"k": rng.integers(0, 20_000, n).astype(np.int32), "v": rng.random(n), "w": rng.integers(-1000, 1000, n)})
-    exp = pdf.groupby("k").agg(v_sum=("v", "sum"), v_count=("v", "count"), v_mean=("v", "mean"), w_sum=("w", "sum")).reset_index()
-    got = DF.from_pandas(pdf).groupby("k").agg({"v": ["sum", "count", "mean"], "w": ["sum"]}).to_pandas()
+    exp = pdf.groupby("k").agg(v_sum=("v", "sum"), v_count=("v", "count"), v_mean=("v", "mean"), v_min=("v", "min"),
+                               v_max=("v", "max"), w_sum=("w", "sum"), w_min=("w", "min")).reset_index()
+    got = DF.from_pandas(pdf).groupby("k").agg({"v": ["sum", "count", "mean", "min", "max"], "w": ["sum", "min"]}).to_pandas()
+    np.testing.assert_array_equal(got["v_min"], exp["v_min"])
+    np.testing.assert_array_equal(got["v_max"], exp["v_max"])
+    np.testing.assert_array_equal(got["w_min"], exp["w_min"])
     np.testing.assert_array_equal(got["k"], exp["k"])
     np.testing.assert_allclose(got["v_sum"], exp["v_sum"], rtol=1e-13)
     np.testing.assert_array_equal(got["v_count"], exp["v_count"])

@@ -244,6 +244,35 @@ def test_groupby_partitioned_large(gx, nulls, nsplit):
         _lib.lib.gx_groupby_set_algorithm(0, 1)
 
 
+@pytest.mark.parametrize("vdtype", ["float64", "float32", "int32", "int64", "uint8", "int16"])
+@pytest.mark.parametrize("kdtype", ["int32", "int64"])
+def test_groupby_min_max_matches_oracle(gx, kdtype, vdtype):
+    Column, ops = gx
+    rng = np.random.default_rng(14)
+    for n, g in [(0, 1), (1, 1), (1000, 7), (250_000, 3000)]:
+        keys = rng.integers(-g // 2, g // 2 + 1, n).astype(kdtype)
+        if np.dtype(vdtype).kind == "f":
+            vals = (rng.random(n) * 2000 - 1000).astype(vdtype)
+            if n > 100:
+                vals[::50] = -0.0
+                vals[1::97] = np.inf
+        else:
+            info = np.iinfo(vdtype)
+            vals = rng.integers(info.min, info.max, n, dtype=vdtype, endpoint=True)
+        kv = rng.random(n) > 0.05
+        vv = rng.random(n) > 0.3
+        k, mn, mx, cv = ops.groupby_min_max(Column.from_numpy(keys, kv), Column.from_numpy(vals, vv), max_groups_hint=64)
+        o = np.argsort(k.to_numpy(), kind="stable")
+        ek, res = orc.groupby_agg(keys, vals, ["min", "max", "count_valid"], kv, vv)
+        np.testing.assert_array_equal(k.to_numpy()[o], ek)
+        np.testing.assert_array_equal(cv.to_numpy()[o], res["count_valid"][0])
+        emn, ev = res["min"]
+        emx, _ = res["max"]
+        assert mn.dtype == np.dtype(vdtype)
+        np.testing.assert_array_equal(mn.to_numpy()[o][ev], emn[ev])   # -0.0 == +0.0 under array_equal
+        np.testing.assert_array_equal(mx.to_numpy()[o][ev], emx[ev])
+
+
 @pytest.mark.parametrize("vdtype", ["int32", "int64", "float64"])
 @pytest.mark.parametrize("case", [c for c in gv.GROUPBY if c["agg"] in ("sum", "count_valid", "count_all", "mean")],
                          ids=lambda c: c["name"])
