@@ -114,7 +114,8 @@ def distributed_sort(keys: torch.Tensor, local: Optional[object] = None, group=N
     n = s.numel()
     # regular samples of the sorted shard (empty shards contribute the dtype's max so they never split)
     if n > 0:
-        pos = torch.linspace(0, n - 1, samples_per_rank, device=s.device).round().to(torch.int64)
+        # integer arithmetic: float32 cannot represent n - 1 for n ~ 1e9 (it would round to n)
+        pos = (torch.arange(samples_per_rank, dtype=torch.int64, device=s.device) * (n - 1)) // max(samples_per_rank - 1, 1)
         mine = s[pos]
     else:
         fill = torch.finfo(s.dtype).max if s.dtype.is_floating_point else torch.iinfo(s.dtype).max
