@@ -674,9 +674,8 @@ __global__ void __launch_bounds__(BT, (KPT <= 8 ? 8 : (KPT <= 12 ? 6 : 4))) k_ms
     for (int j = 0; j < KPT; ++j) {
       const int idx    = wbase + j * GX_WAVE;
       const uint32_t d = (uint32_t)(to_sortable<KeyT, KIND>(key[j], desc_mask) >> shift) & dmask;
-      uint32_t r       = 0;
-      if (idx < nvalid) r = atomicAdd(&s_whist[d], 1u);
-      packed[j] = (d << 16) | r;
+      const uint32_t r = lds_rank(s_whist, d, idx < nvalid);
+      packed[j]        = (d << 16) | r;
     }
     __syncthreads();
     if (tid < BINS) tile_count = s_whist[tid];
@@ -999,8 +998,8 @@ __global__ void __launch_bounds__(LS_BT) k_local_sort(const KeyT* __restrict__ i
     for (int j = 0; j < LS_KPT; ++j) {
       const int idx = wbase + j * GX_WAVE;
       key[j]        = sortable(key[j]);  // an involution for integer kinds
-      rank[j]       = 0;
-      if ((uint32_t)idx < m) rank[j] = (exp & 8) ? (uint32_t)(idx >> 8) : atomicAdd(&s_cnt[(uint32_t)(key[j] >> sshift) & 0xFFu], 1u);  // ablation 8: no atomics
+      rank[j]       = (exp & 8) ? (uint32_t)(idx >> 8)  // ablation 8: no atomics
+                                : lds_rank(s_cnt, (uint32_t)(key[j] >> sshift) & 0xFFu, (uint32_t)idx < m);
     }
     __syncthreads();
     const uint32_t c   = tid < BINS ? s_cnt[tid] : 0u;

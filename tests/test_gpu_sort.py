@@ -253,3 +253,17 @@ def test_hybrid_sorted_order_is_stable(gx, dtype):
     v = rng.integers(-2**63, 2**63 - 1, n, dtype=np.int64).view(np.dtype(dtype)) if dtype != "uint64" else _rand(dtype, n, rng, False)
     got = ops.sorted_order(Column.from_numpy(v)).to_numpy()
     np.testing.assert_array_equal(got, orc.sorted_order(v, None, True))
+
+
+def test_hybrid_sort_presorted_and_few_values(gx):
+    """Inputs whose waves hit a single bin (already sorted, reverse sorted, a handful of distinct
+    values spread over the top bits) exercise the wave-uniform ranking path."""
+    Column, ops = gx
+    rng = np.random.default_rng(5)
+    n = 6_000_000
+    base = np.sort(rng.integers(-2**63, 2**63 - 1, n, dtype=np.int64))
+    for v in (base, base[::-1].copy()):
+        got, info = _sort_info(ops, Column.from_numpy(v))
+        assert got.tobytes() == base.tobytes() and info[1] == 1, info
+        order = ops.sorted_order(Column.from_numpy(v)).to_numpy()
+        np.testing.assert_array_equal(order, np.argsort(v, kind="stable"))
