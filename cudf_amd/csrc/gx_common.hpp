@@ -236,6 +236,76 @@ __device__ __forceinline__ T block_exclusive_scan(T v, T identity, Op op, T* lds
   return r;
 }
 
+// ---- sub-bucket sort without a sorting network.  `cnt` <= 128 keys that agree on every bit above
+// `sh + 8`: (1) wave-private 256-bin counting split on byte [sh, sh+8) (one returning LDS atomic per
+// key, an exclusive scan of the 256 counters held four per lane), which leaves only keys with the
+// same byte adjacent and possibly out of order; (2) when no bin holds more than four keys -- the
+// common case: cnt / 256 keys per bin on average -- four phases of odd-even transposition, two
+// consecutive elements per lane (even phase in-lane, odd phase through DPP wave shifts), finish the
+// job.  ~75 VALU per sub-bucket against ~250 (64 keys) to ~650 (128 keys) for the bitonic network.
+// Returns false (keys untouched) when a bin is too full; the caller falls back to the network.
+__device__ __forceinline__ uint64_t dpp_wave_shl1_u64(uint64_t v, uint64_t fill)
+{  // lane i receives lane i+1; lane 63 receives `fill`
+  const int lo = __builtin_amdgcn_update_dpp((int)(uint32_t)fill, (int)(uint32_t)v, 0x130, 0xF, 0xF, false);
+  const int hi = __builtin_amdgcn_update_dpp((int)(uint32_t)(fill >> 32), (int)(uint32_t)(v >> 32), 0x130, 0xF, 0xF, false);
+  return ((uint64_t)(uint32_t)hi << 32) | (uint32_t)lo;
+}
+__device__ __forceinline__ uint64_t dpp_wave_shr1_u64(uint64_t v, uint64_t fill)
+{  // lane i receives lane i-1; lane 0 receives `fill`
+  const int lo = __builtin_amdgcn_update_dpp((int)(uint32_t)fill, (int)(uint32_t)v, 0x138, 0xF, 0xF, false);
+  const int hi = __builtin_amdgcn_update_dpp((int)(uint32_t)(fill >> 32), (int)(uint32_t)(v >> 32), 0x138, 0xF, 0xF, false);
+  return ((uint64_t)(uint32_t)hi << 32) | (uint32_t)lo;
+}
+__device__ __forceinline__ bool wave_split_sort(uint64_t* keys, uint32_t cnt, uint32_t* cw /* 256 wave-private counters, 16-B aligned */,
+                                                int sh)
+{
+  const unsigned lane = lane_id();
+  const uint32_t e0 = 2 * lane, e1 = 2 * lane + 1;
+  uint64_t k0 = e0 < cnt ? keys[e0] : ~0ull;
+  uint64_t k1 = e1 < cnt ? keys[e1] : ~0ull;
+  uint4* cw4  = reinterpret_cast<uint4*>(cw);
+  cw4[lane]   = make_uint4(0u, 0u, 0u, 0u);
+  const uint32_t b0 = (uint32_t)(k0 >> sh) & 0xFFu, b1 = (uint32_t)(k1 >> sh) & 0xFFu;
+  const uint32_t r0 = e0 < cnt ? atomicAdd(&cw[b0], 1u) : 0u;
+  const uint32_t r1 = e1 < cnt ? atomicAdd(&cw[b1], 1u) : 0u;
+  uint4 c = cw4[lane];
+  uint32_t mx = c.x > c.y ? c.x : c.y;
+  mx          = c.z > mx ? c.z : mx;
+  mx          = c.w > mx ? c.w : mx;
+  if (ballot(mx > 4u) != 0) return false;  // wave-uniform
+  const uint32_t sum = c.x + c.y + c.z + c.w;
+  const uint32_t inc = wave_inclusive_scan(sum, SumOp());
+  uint32_t run       = inc - sum;
+  uint4 st;
+  st.x = run; run += c.x;
+  st.y = run; run += c.y;
+  st.z = run; run += c.z;
+  st.w = run;
+  cw4[lane] = st;
+  if (e0 < cnt) keys[cw[b0] + r0] = k0;
+  if (e1 < cnt) keys[cw[b1] + r1] = k1;
+  k0 = e0 < cnt ? keys[e0] : ~0ull;
+  k1 = e1 < cnt ? keys[e1] : ~0ull;
+#pragma unroll
+  for (int ph = 0; ph < 2; ++ph) {
+    {  // even phase: (2l, 2l+1) inside the lane
+      const bool sw     = k1 < k0;
+      const uint64_t lo = sw ? k1 : k0, hi = sw ? k0 : k1;
+      k0 = lo;
+      k1 = hi;
+    }
+    {  // odd phase: (2l+1, 2l+2): lane l's k1 with lane l+1's k0
+      const uint64_t nxt = dpp_wave_shl1_u64(k0, ~0ull);  // k0 of lane + 1
+      const uint64_t prv = dpp_wave_shr1_u64(k1, 0ull);   // k1 of lane - 1
+      k1                 = nxt < k1 ? nxt : k1;
+      k0                 = prv > k0 ? prv : k0;
+    }
+  }
+  if (e0 < cnt) keys[e0] = k0;
+  if (e1 < cnt) keys[e1] = k1;
+  return true;
+}
+
 // bits -> unsigned key whose unsigned order is the cudf order (KIND 0 unsigned, 1 signed, 2 float).
 //  signed: sign flip.  float: -0.0 -> +0.0, NaN -> all ones (after +Inf; all NaNs equivalent),
 //  then the IEEE total-order flip.  desc_mask (0 or ~0) reverses the order.  Equal sortable bits

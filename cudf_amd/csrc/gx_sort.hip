@@ -971,6 +971,7 @@ __global__ void __launch_bounds__(LS_BT) k_local_sort(const KeyT* __restrict__ i
   const unsigned w    = tid / GX_WAVE;
   const int wbase     = (int)w * (LS_KPT * GX_WAVE) + (int)lane;
   const int nlocal    = hy.nlocal;
+  uint32_t* my_hist   = s_whist + w * BINS;  // this wave's 256 counters
 
   KeyT key[LS_KPT];
 #pragma unroll
@@ -988,8 +989,8 @@ __global__ void __launch_bounds__(LS_BT) k_local_sort(const KeyT* __restrict__ i
   // stability is not needed; floats (-0.0 == +0.0 must keep input order) and cells with a
   // sub-bucket above 128 keys take the stable LSD passes below.
   if ((PAIRS || KIND != K_FLOAT) && nlocal > 0) {
-    uint32_t* s_cnt   = s_whist;          // [256] counts, then exclusive starts
-    uint32_t* s_start = s_whist + BINS;   // [256]
+    uint32_t* s_cnt   = s_scan + 32;          // [256] sub-bucket counts (own area: the wave rows of s_whist serve wave_split_sort)
+    uint32_t* s_start = s_scan + 32 + BINS;   // [256] exclusive starts
     const int sshift  = hy.shift2 - 8 + pos_shift;  // shift2 >= 8: d1 >= 2 and bits2 <= 8
     if (tid < BINS) s_cnt[tid] = 0;
     __syncthreads();
@@ -1018,6 +1019,10 @@ __global__ void __launch_bounds__(LS_BT) k_local_sort(const KeyT* __restrict__ i
         if (exp & 4) break;  // ablation: no sorting networks
         const uint32_t cnt = s_cnt[sb], o = s_start[sb];
         if (cnt <= 1) continue;
+        // counting split on the next byte + odd-even clean-up; the network only when a bin is crowded
+        if (sshift >= 8 && !(exp & 16) &&
+            wave_split_sort(reinterpret_cast<uint64_t*>(s_keys + o), cnt, my_hist, sshift - 8))
+          continue;
         if (cnt <= 64) {
           uint64_t k0 = lane < cnt ? (uint64_t)s_keys[o + lane] : ~0ull;
           wave_bitonic64(k0);
@@ -1047,7 +1052,6 @@ __global__ void __launch_bounds__(LS_BT) k_local_sort(const KeyT* __restrict__ i
     for (int j = 0; j < LS_KPT; ++j) key[j] = sortable(key[j]);
     __syncthreads();
   }
-  uint32_t* my_hist = s_whist + w * BINS;
   for (int lp = 0; lp < nlocal; ++lp) {
     const int shift      = hy.lshift[lp] + pos_shift;
     const uint32_t dmask = (1u << hy.lbits[lp]) - 1u;
@@ -1233,7 +1237,7 @@ int sort_impl(const void* keys_in, void* keys_out, const int32_t* vals_in, int32
   if constexpr (sizeof(KeyT) == 8) {
     if (try_hybrid) {
       // hybrid MSD path: every kernel below is a no-op unless the device-side plan enables it
-      constexpr size_t lds_l = (size_t)LOCAL_MAX * sizeof(KeyT) + (size_t)(LS_NW * BINS + 32) * 4;
+      constexpr size_t lds_l = (size_t)LOCAL_MAX * sizeof(KeyT) + (size_t)(LS_NW * BINS + 32 + 2 * BINS) * 4;
       constexpr size_t pay   = HAS_VAL ? 4 : 0;
       const size_t lds_m     = (size_t)BT * hyb_kpt * (sizeof(KeyT) + pay) + (size_t)(NW * BINS + BINS + 16 + 4) * 4;
       auto kmsd = HAS_VAL ? k_msd_pass<KeyT, KIND, HAS_VAL, 10, 4>
