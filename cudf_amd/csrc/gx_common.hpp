@@ -256,13 +256,15 @@ __device__ __forceinline__ uint64_t dpp_wave_shr1_u64(uint64_t v, uint64_t fill)
   const int hi = __builtin_amdgcn_update_dpp((int)(uint32_t)(fill >> 32), (int)(uint32_t)(v >> 32), 0x138, 0xF, 0xF, false);
   return ((uint64_t)(uint32_t)hi << 32) | (uint32_t)lo;
 }
+// On success the sorted keys are returned in registers, lane l holding elements 2l (k0) and 2l+1 (k1);
+// the caller stores them (to LDS or straight to global memory).
 __device__ __forceinline__ bool wave_split_sort(uint64_t* keys, uint32_t cnt, uint32_t* cw /* 256 wave-private counters, 16-B aligned */,
-                                                int sh)
+                                                int sh, uint64_t& k0, uint64_t& k1)
 {
   const unsigned lane = lane_id();
   const uint32_t e0 = 2 * lane, e1 = 2 * lane + 1;
-  uint64_t k0 = e0 < cnt ? keys[e0] : ~0ull;
-  uint64_t k1 = e1 < cnt ? keys[e1] : ~0ull;
+  k0 = e0 < cnt ? keys[e0] : ~0ull;
+  k1 = e1 < cnt ? keys[e1] : ~0ull;
   uint4* cw4  = reinterpret_cast<uint4*>(cw);
   cw4[lane]   = make_uint4(0u, 0u, 0u, 0u);
   const uint32_t b0 = (uint32_t)(k0 >> sh) & 0xFFu, b1 = (uint32_t)(k1 >> sh) & 0xFFu;
@@ -301,8 +303,6 @@ __device__ __forceinline__ bool wave_split_sort(uint64_t* keys, uint32_t cnt, ui
       k0                 = prv > k0 ? prv : k0;
     }
   }
-  if (e0 < cnt) keys[e0] = k0;
-  if (e1 < cnt) keys[e1] = k1;
   return true;
 }
 

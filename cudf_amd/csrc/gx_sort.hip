@@ -1019,20 +1019,46 @@ __global__ void __launch_bounds__(LS_BT) k_local_sort(const KeyT* __restrict__ i
         if (exp & 4) break;  // ablation: no sorting networks
         const uint32_t cnt = s_cnt[sb], o = s_start[sb];
         if (cnt <= 1) continue;
-        // counting split on the next byte + odd-even clean-up; the network only when a bin is crowded
-        if (sshift >= 8 && !(exp & 16) &&
-            wave_split_sort(reinterpret_cast<uint64_t*>(s_keys + o), cnt, my_hist, sshift - 8))
+        // counting split on the next byte + odd-even clean-up; the network only when a bin is crowded.
+        // Plain integer keys leave straight from the registers (1 KiB per wave and sub-bucket); packed
+        // words go back to LDS for the gathering write-out.
+        KeyT* sub = s_keys + o;
+        uint64_t k0, k1;
+        if (sshift >= 8 && !(exp & 16) && wave_split_sort(reinterpret_cast<uint64_t*>(sub), cnt, my_hist, sshift - 8, k0, k1)) {
+          const uint32_t e0 = 2 * lane, e1 = 2 * lane + 1;
+          if (PAIRS) {
+            if (e0 < cnt) sub[e0] = (KeyT)k0;
+            if (e1 < cnt) sub[e1] = (KeyT)k1;
+          } else {
+            if (e0 < cnt) out[start + o + e0] = to_sortable<KeyT, KIND>((KeyT)k0, desc_mask);
+            if (e1 < cnt) out[start + o + e1] = to_sortable<KeyT, KIND>((KeyT)k1, desc_mask);
+          }
           continue;
+        }
         if (cnt <= 64) {
-          uint64_t k0 = lane < cnt ? (uint64_t)s_keys[o + lane] : ~0ull;
+          k0 = lane < cnt ? (uint64_t)sub[lane] : ~0ull;
           wave_bitonic64(k0);
-          if (lane < cnt) s_keys[o + lane] = (KeyT)k0;
+          if (lane < cnt) {
+            if (PAIRS) sub[lane] = (KeyT)k0; else out[start + o + lane] = to_sortable<KeyT, KIND>((KeyT)k0, desc_mask);
+          }
         } else {
-          uint64_t k0 = (uint64_t)s_keys[o + lane];
-          uint64_t k1 = lane + 64 < cnt ? (uint64_t)s_keys[o + 64 + lane] : ~0ull;
+          k0 = (uint64_t)sub[lane];
+          k1 = lane + 64 < cnt ? (uint64_t)sub[64 + lane] : ~0ull;
           wave_bitonic128(k0, k1);
-          s_keys[o + lane] = (KeyT)k0;
-          if (lane + 64 < cnt) s_keys[o + 64 + lane] = (KeyT)k1;
+          if (PAIRS) {
+            sub[lane] = (KeyT)k0;
+            if (lane + 64 < cnt) sub[64 + lane] = (KeyT)k1;
+          } else {
+            out[start + o + lane] = to_sortable<KeyT, KIND>((KeyT)k0, desc_mask);
+            if (lane + 64 < cnt) out[start + o + 64 + lane] = to_sortable<KeyT, KIND>((KeyT)k1, desc_mask);
+          }
+        }
+      }
+      if (!PAIRS) {
+        // sub-buckets of 0 or 1 keys were skipped by the loop above: they leave here
+        if (!(exp & 4)) {
+          if (tid < BINS && s_cnt[tid] == 1) out[start + s_start[tid]] = to_sortable<KeyT, KIND>(s_keys[s_start[tid]], desc_mask);
+          return;
         }
       }
       __syncthreads();
