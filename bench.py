@@ -217,7 +217,12 @@ def main():
         bkt.copy_(torch.randperm(nb_rows, device="cuda") * 3 + 1)  # distinct keys {3i+1}, shuffled
         pk = ops.random_column(np.int64, n, seed=67890 + rank, lo=0, hi=int(nb_rows / 0.3))
         pk.data[: n * 8].view(torch.int64).mul_(3).add_(1)          # hits a build key w.p. 0.3
+        hj = ops.HashJoin(bk)  # warm-up build (allocations, module load)
+        torch.cuda.synchronize()
+        tb = time.perf_counter()
         hj = ops.HashJoin(bk)
+        torch.cuda.synchronize()
+        extra["join_build_ms"] = (time.perf_counter() - tb) * 1e3  # build of the 1e8-row side (not in `value`)
         lo = Column.empty(np.int32, n)
         ro = Column.empty(np.int32, n)
         cur = torch.zeros(1, dtype=torch.int64, device="cuda")

@@ -56,6 +56,7 @@ _PROTOS = {
     "gx_valid_from_counts": (_i, [_p, _i64, _p, _p, _p]),
     "gx_mean_from_sum": (_i, [_i, _p, _p, _i64, _p, _p]),
     "gx_join_probe_partitioned": (_i, [_i, _p, _i64, _p, ctypes.c_size_t, _i, _p, _p, _i64, _p, _p, _sz, _p]),
+    "gx_join_build_partitioned": (_i, [_i, _p, _i64, _p, ctypes.c_size_t, ctypes.c_double, _p, _sz, _p]),
     "gx_join_partition_bits": (_i, [_i, ctypes.c_size_t]),
     "gx_join_complement": (_i, [_p, _i64, _i64, _p, _p, _i64, _p, _p, _sz, _p]),
     "gx_groupby_set_algorithm": (None, [_i, _i]),

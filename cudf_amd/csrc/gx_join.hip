@@ -551,6 +551,99 @@ __global__ void __launch_bounds__(PJ_BT) k_pj_probe(const K* __restrict__ pkeys,
   }
 }
 
+// Partitioned build: the build rows go through the same partition pass, then each chunk inserts into
+// the ~2 MiB sub-table its partition maps to while the other workgroups of the XCD insert into the
+// same one -- the CAS and the 16-B slot write hit L2 instead of scattering over the whole table
+// (k_build wrote 9.6 GB to HBM for 1.6 GB of slots at 1e8 rows).
+template <typename K>
+__global__ void __launch_bounds__(PJ_BT) k_pj_build(const K* __restrict__ pkeys, const int32_t* __restrict__ pidx,
+                                                    PjPlan* plan, int pbits, Slot<K>* __restrict__ slots, uint32_t log2cap)
+{
+  constexpr int RPT = PJ_CHUNK / PJ_BT;
+  __shared__ unsigned int s_misc[4];
+  const int P         = 1 << pbits;
+  const int LISTP     = P / PJ_NR;
+  const uint64_t mask = (1ull << log2cap) - 1;
+  const unsigned tid  = threadIdx.x;
+  if (tid == 0) {
+    const unsigned x = pj_xcc();
+    unsigned int g   = 0xFFFFFFFFu;
+    for (int i = 0; i < PJ_NR; ++i) {
+      const unsigned y       = (x + i) % PJ_NR;
+      const unsigned int nch = plan->list_chunk0[y + 1] - plan->list_chunk0[y];
+      if (nch == 0) continue;
+      const unsigned int t = atomicAdd(&plan->ticket[y].v, 1u);
+      if (t < nch) {
+        g         = plan->list_chunk0[y] + t;
+        s_misc[1] = y;
+        break;
+      }
+    }
+    s_misc[0] = g;
+  }
+  __syncthreads();
+  const unsigned int g = s_misc[0];
+  if (g == 0xFFFFFFFFu) return;
+  {
+    const unsigned y = s_misc[1];
+    for (int e = (int)tid; e < LISTP; e += PJ_BT) {
+      const int p           = (int)y * LISTP + e;
+      const unsigned int lo = plan->chunk0[p], hi = plan->chunk0[p + 1];
+      if (lo <= g && g < hi) {
+        s_misc[2] = (unsigned int)p;
+        s_misc[3] = g - lo;
+      }
+    }
+  }
+  __syncthreads();
+  const unsigned int part = s_misc[2];
+  const unsigned long long p0 = plan->offset[part], p1 = plan->offset[part + 1];
+  const unsigned long long c0 = p0 + (unsigned long long)s_misc[3] * PJ_CHUNK;
+  const unsigned long long c1 = c0 + PJ_CHUNK < p1 ? c0 + PJ_CHUNK : p1;
+#pragma unroll 4
+  for (int j = 0; j < RPT; ++j) {
+    const unsigned long long i = c0 + (unsigned long long)j * PJ_BT + tid;
+    if (i >= c1) continue;
+    const K key       = pkeys[i];
+    const int32_t row = pidx[i];
+    uint64_t h        = slot_of<K>(key, log2cap);
+    for (;;) {
+      const int32_t old = atomicCAS(&slots[h].row, EMPTY_ROW, row);
+      if (old == EMPTY_ROW) {
+        slots[h].key = key;
+        break;
+      }
+      h = (h + 1) & mask;
+    }
+  }
+}
+
+// the partition pass shared by the partitioned probe and build
+template <typename K>
+int pj_partition(const K* keys, int64_t n, int pbits, PjPlan* plan, K* pkeys, int32_t* pidx, hipStream_t s)
+{
+  GX_HIP_TRY(hipMemsetAsync(plan, 0, sizeof(PjPlan), s));
+  int64_t hb = div_up(n, 256 * 8 * 4 * PJ_NR);
+  if (hb > 256) hb = 256;
+  if (hb < 1) hb = 1;
+  hipLaunchKernelGGL((k_pj_hist<K>), dim3((unsigned)(hb * PJ_NR)), dim3(256), 0, s, keys, n, plan, pbits);
+  hipLaunchKernelGGL(k_pj_offsets, dim3(1), dim3(1024), 0, s, plan, pbits);
+  const int rpt            = getenv("GX_PJ_RPT") ? atoi(getenv("GX_PJ_RPT")) : 8;
+  const size_t tile_rows   = (size_t)PJ_BT * (rpt == 16 ? 16 : 8);
+  const size_t lds_max     = (size_t)PJ_BT * 16 * sizeof(K) + (size_t)PJ_BT * 16 * 2 + (size_t)PJ_MAXP * (4 + 4 + 8);
+  const size_t lds         = tile_rows * sizeof(K) + tile_rows * 2 + ((size_t)16 << pbits);
+  auto ks                  = rpt == 16 ? k_pj_scatter<K, 16> : k_pj_scatter<K, 8>;
+  static bool attr_set     = false;
+  if (!attr_set) {
+    GX_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(k_pj_scatter<K, 8>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_max));
+    GX_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(k_pj_scatter<K, 16>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_max));
+    attr_set = true;
+  }
+  hipLaunchKernelGGL(ks, dim3((unsigned)div_up(n, (int64_t)tile_rows)), dim3(PJ_BT), lds, s, keys, n, plan, pbits, pkeys, pidx);
+  GX_LAUNCH_CHECK();
+  return 0;
+}
+
 static inline int pj_bits(uint32_t log2cap, int slot_bytes)
 {
   // sub-table of about 2 MiB: P = table bytes / 2 MiB
@@ -582,28 +675,43 @@ int probe_partitioned_impl(const void* keys, int64_t n, const void* table, size_
   if (n == 0) return 0;
   const Slot<K>* slots = reinterpret_cast<const Slot<K>*>(static_cast<const char*>(table) + sizeof(TableHeader));
   if (pbits == 0) return GX_EINVAL;  // caller should use gx_join_probe
-  GX_HIP_TRY(hipMemsetAsync(plan, 0, sizeof(PjPlan), s));
-  int64_t hb = div_up(n, 256 * 8 * 4 * PJ_NR);
-  if (hb > 256) hb = 256;
-  if (hb < 1) hb = 1;
-  hipLaunchKernelGGL((k_pj_hist<K>), dim3((unsigned)(hb * PJ_NR)), dim3(256), 0, s, static_cast<const K*>(keys), n, plan, pbits);
-  hipLaunchKernelGGL(k_pj_offsets, dim3(1), dim3(1024), 0, s, plan, pbits);
-  const int rpt            = getenv("GX_PJ_RPT") ? atoi(getenv("GX_PJ_RPT")) : 8;
-  const size_t tile_rows   = (size_t)PJ_BT * (rpt == 16 ? 16 : 8);
-  const size_t lds_max     = (size_t)PJ_BT * 16 * sizeof(K) + (size_t)PJ_BT * 16 * 2 + (size_t)PJ_MAXP * (4 + 4 + 8);
-  const size_t lds         = tile_rows * sizeof(K) + tile_rows * 2 + ((size_t)16 << pbits);
-  auto ks                  = rpt == 16 ? k_pj_scatter<K, 16> : k_pj_scatter<K, 8>;
-  static bool attr_set = false;
-  if (!attr_set) {
-    GX_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(k_pj_scatter<K, 8>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_max));
-    GX_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(k_pj_scatter<K, 16>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_max));
-    attr_set = true;
+  {
+    int rc = pj_partition<K>(static_cast<const K*>(keys), n, pbits, plan, pkeys, pidx, s);
+    if (rc) return rc;
   }
-  hipLaunchKernelGGL(ks, dim3((unsigned)div_up(n, (int64_t)tile_rows)), dim3(PJ_BT), lds, s, static_cast<const K*>(keys), n, plan, pbits,
-                     pkeys, pidx);
   const int64_t max_chunks = div_up(n, PJ_CHUNK) + (1 << pbits);
   hipLaunchKernelGGL((k_pj_probe<K>), dim3((unsigned)max_chunks), dim3(PJ_BT), 0, s, pkeys, pidx, plan, pbits, slots, lg,
                      left_outer, out_probe, out_build, capacity, reinterpret_cast<unsigned long long*>(cursor));
+  GX_LAUNCH_CHECK();
+  return 0;
+}
+
+template <typename K>
+int build_partitioned_impl(const void* keys, int64_t n, void* table, size_t table_bytes, double load_factor, void* tmp,
+                           size_t* tmp_bytes, hipStream_t s)
+{
+  const uint32_t lg = log2_capacity(n, load_factor);
+  const int pbits   = pj_bits(lg, (int)sizeof(Slot<K>));
+  Carver c(tmp);
+  PjPlan* plan  = c.take<PjPlan>(1);
+  K* pkeys      = c.take<K>((size_t)n);
+  int32_t* pidx = c.take<int32_t>((size_t)n);
+  if (!tmp) {
+    *tmp_bytes = c.total();
+    return 0;
+  }
+  if (*tmp_bytes < c.total()) return GX_ETMP;
+  const size_t need = sizeof(TableHeader) + (sizeof(Slot<K>) << lg);
+  if (table_bytes < need) return GX_ETMP;
+  if (pbits == 0) return GX_EINVAL;
+  char* base = static_cast<char*>(table);
+  GX_HIP_TRY(hipMemsetAsync(base + sizeof(TableHeader), 0xFF, sizeof(Slot<K>) << lg, s));
+  if (n == 0) return 0;
+  int rc = pj_partition<K>(static_cast<const K*>(keys), n, pbits, plan, pkeys, pidx, s);
+  if (rc) return rc;
+  const int64_t max_chunks = div_up(n, PJ_CHUNK) + (1 << pbits);
+  hipLaunchKernelGGL((k_pj_build<K>), dim3((unsigned)max_chunks), dim3(PJ_BT), 0, s, pkeys, pidx, plan, pbits,
+                     reinterpret_cast<Slot<K>*>(base + sizeof(TableHeader)), lg);
   GX_LAUNCH_CHECK();
   return 0;
 }
@@ -724,6 +832,17 @@ int gx_join_partition_bits(int key_size, size_t table_bytes)
 {
   if ((key_size != 4 && key_size != 8) || table_bytes <= sizeof(gx::join::TableHeader)) return 0;
   return gx::join::pj_bits(gx_join_log2_from_bytes(key_size, table_bytes), key_size == 8 ? 16 : 8);
+}
+
+
+/* see gx.h */
+int gx_join_build_partitioned(int key_size, const void* build_keys, int64_t build_rows, void* table, size_t table_bytes,
+                              double load_factor, void* tmp, size_t* tmp_bytes, gx_stream_t s)
+{
+  if (build_rows < 0 || !table || !tmp_bytes || (build_rows > 0 && !build_keys)) return GX_EINVAL;
+  if (key_size == 8) return gx::join::build_partitioned_impl<uint64_t>(build_keys, build_rows, table, table_bytes, load_factor, tmp, tmp_bytes, s);
+  if (key_size == 4) return gx::join::build_partitioned_impl<uint32_t>(build_keys, build_rows, table, table_bytes, load_factor, tmp, tmp_bytes, s);
+  return GX_EDTYPE;
 }
 
 }  // extern "C"

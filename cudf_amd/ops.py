@@ -157,8 +157,14 @@ class HashJoin:
         self.table_bytes = _lib.gx_join_table_bytes(self.key_size, right.size, load_factor)
         self.table = device_bytes(self.table_bytes)
         valid = right.mask_ptr if right.has_nulls() else None
-        L.check(_lib.gx_join_build(self.key_size, right.data_ptr, valid, right.size, ptr(self.table),
-                                   self.table_bytes, load_factor, stream_ptr()), "gx_join_build")
+        if (valid is None and right.size >= (1 << 20)
+                and _lib.gx_join_partition_bits(self.key_size, self.table_bytes) > 0):
+            # large build side: partition the rows first so the inserts hit L2-resident sub-tables
+            _run(_lib.gx_join_build_partitioned, self.key_size, right.data_ptr, right.size, ptr(self.table),
+                 self.table_bytes, load_factor)
+        else:
+            L.check(_lib.gx_join_build(self.key_size, right.data_ptr, valid, right.size, ptr(self.table),
+                                       self.table_bytes, load_factor, stream_ptr()), "gx_join_build")
 
     def _check(self, left: Column):
         if left.dtype != self.build.dtype:

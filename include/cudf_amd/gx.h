@@ -216,6 +216,14 @@ int gx_join_probe_partitioned(int key_size, const void* probe_keys, int64_t prob
                               size_t table_bytes, int left_outer, int32_t* out_probe_idx,
                               int32_t* out_build_idx, int64_t capacity, int64_t* cursor_dev, void* tmp,
                               size_t* tmp_bytes, gx_stream_t stream);
+/* Partitioned form of gx_join_build for large build sides without nulls: the rows are radix-
+ * partitioned on the table's top hash bits, then inserted partition by partition so that the CAS
+ * and slot writes of concurrently running workgroups fall into one L2-resident ~2 MiB sub-table.
+ * Produces the same table as gx_join_build (slot positions may differ among equal hashes).
+ * cub-style scratch query.  GX_EINVAL when the table is too small to partition. */
+int gx_join_build_partitioned(int key_size, const void* build_keys, int64_t build_rows, void* table,
+                              size_t table_bytes, double load_factor, void* tmp, size_t* tmp_bytes,
+                              gx_stream_t stream);
 /* log2 of the number of partitions the partitioned probe uses for this table; 0 = not partitionable */
 int gx_join_partition_bits(int key_size, size_t table_bytes);
 
