@@ -78,6 +78,45 @@ __device__ __forceinline__ void load_slot<uint32_t>(const Slot<uint32_t>* s, uin
   row           = (int32_t)v.y;
 }
 
+// 4-bit tag per slot, two per byte, stored behind the slots: 0 = empty slot, 1..15 = hash bits of the
+// resident key just below the slot-index bits.  The partitioned probe keeps the tags of its ~128 k-slot
+// sub-table in LDS and walks the probe chain THERE; only a tag match costs an L2 request.
+constexpr int PJ_SUB_LOG2 = 17;  // slots per sub-table of the partitioned probe (64 KiB of tags)
+template <typename K>
+__device__ __forceinline__ uint32_t tag_of(K key, uint32_t log2cap)
+{
+  const uint32_t t = (uint32_t)(((uint64_t)key * 0x9E3779B97F4A7C15ull) >> (60 - log2cap)) & 15u;
+  return t ? t : 8u;
+}
+template <typename K>
+__global__ void __launch_bounds__(256) k_tags(const Slot<K>* __restrict__ slots, uint64_t cap, uint32_t log2cap,
+                                              uint8_t* __restrict__ tags)
+{
+  const int64_t stride = (int64_t)gridDim.x * 256;
+  for (int64_t b = (int64_t)blockIdx.x * 256 + threadIdx.x; b < (int64_t)(cap / 2); b += stride) {
+    K k0, k1;
+    int32_t r0, r1;
+    load_slot<K>(&slots[2 * b], k0, r0);
+    load_slot<K>(&slots[2 * b + 1], k1, r1);
+    const uint32_t t0 = r0 == EMPTY_ROW ? 0u : tag_of<K>(k0, log2cap);
+    const uint32_t t1 = r1 == EMPTY_ROW ? 0u : tag_of<K>(k1, log2cap);
+    tags[b] = (uint8_t)(t0 | (t1 << 4));
+  }
+}
+template <typename K>
+static int launch_tags(void* table, uint32_t lg, hipStream_t s)
+{
+  char* base     = static_cast<char*>(table);
+  auto* slots    = reinterpret_cast<const Slot<K>*>(base + sizeof(TableHeader));
+  uint8_t* tags  = reinterpret_cast<uint8_t*>(base + sizeof(TableHeader) + (sizeof(Slot<K>) << lg));
+  int64_t blocks = div_up((int64_t)((1ull << lg) / 2), 256 * 8);
+  if (blocks > 4096) blocks = 4096;
+  if (blocks < 1) blocks = 1;
+  hipLaunchKernelGGL((k_tags<K>), dim3((unsigned)blocks), dim3(256), 0, s, slots, 1ull << lg, lg, tags);
+  GX_LAUNCH_CHECK();
+  return 0;
+}
+
 template <typename K>
 __global__ void __launch_bounds__(JBT) k_build(const K* __restrict__ keys, const uint32_t* __restrict__ valid,
                                                int64_t n, Slot<K>* slots, uint32_t log2cap)
@@ -289,7 +328,7 @@ __global__ void __launch_bounds__(256) k_pj_hist(const K* __restrict__ keys, int
 }
 
 // one block of 1024 threads: offsets, cursors, probe-chunk numbering (partitions of list x = [x, x+1) * P / 8)
-__global__ void __launch_bounds__(1024) k_pj_offsets(PjPlan* plan, int pbits)
+__global__ void __launch_bounds__(1024) k_pj_offsets(PjPlan* plan, int pbits, unsigned int chunk_rows)
 {
   __shared__ unsigned long long s_tmp[1024 / GX_WAVE + 1];
   __shared__ unsigned long long s_carry;
@@ -307,7 +346,7 @@ __global__ void __launch_bounds__(1024) k_pj_offsets(PjPlan* plan, int pbits)
       for (int r = 0; r < PJ_NR; ++r) c += plan->count[r][p];
     unsigned long long total;
     unsigned long long run = block_exclusive_scan<1024>(c, 0ull, SumOp(), s_tmp, &total) + s_carry;
-    const unsigned int nch = (unsigned int)((c + PJ_CHUNK - 1) / PJ_CHUNK);
+    const unsigned int nch = (unsigned int)((c + chunk_rows - 1) / chunk_rows);
     unsigned long long ctotal;
     const unsigned int ch0 = (unsigned int)block_exclusive_scan<1024>((unsigned long long)nch, 0ull, SumOp(), s_tmp, &ctotal) + s_ccarry;
     if (p < P) {
@@ -551,6 +590,250 @@ __global__ void __launch_bounds__(PJ_BT) k_pj_probe(const K* __restrict__ pkeys,
   }
 }
 
+// ---- the partitioned probe on LDS tags ------------------------------------------------------------
+// The 8 tags of local slots [li, li+8) of the chain (one ds_read2_b32 + v_alignbit): `cand` gets a
+// flag at the top bit of every nibble that carries `tagpat`'s tag and lies before the first empty
+// slot; returns true when an empty slot ends the chain inside the window.  Nibble-zero detection is
+// the carry-free form ((x & 7..7) + 7..7 | x), exact for every nibble.
+__device__ __forceinline__ bool scan_tags8(const uint32_t* s_tagw, uint32_t li, uint32_t tagpat, uint32_t& cand)
+{
+  const uint32_t w0 = s_tagw[li >> 3], w1 = s_tagw[(li >> 3) + 1];
+  const uint32_t x  = __builtin_amdgcn_alignbit(w1, w0, (li & 7u) * 4u);
+  const uint32_t y  = x ^ tagpat;
+  const uint32_t z  = ~(((x & 0x77777777u) + 0x77777777u) | x) & 0x88888888u;  // empty slots
+  const uint32_t m  = ~(((y & 0x77777777u) + 0x77777777u) | y) & 0x88888888u;  // tag matches
+  cand              = m & ((z & (0u - z)) - 1u);                                 // ... below the first empty one
+  return z != 0;
+}
+
+// A workgroup takes `chunk_rows` (a multiple of PJ_CHUNK) rows of ONE partition, copies the 64 KiB of
+// tags of that partition's sub-table into LDS once, and probes PJ_CHUNK rows at a time: (A) every
+// lane runs its rows' chains on the LDS tags up to the first tag match, (B) the candidate slots of
+// all its rows are fetched together -- independent L2 requests in flight instead of one dependent
+// request per chain step -- (C) keys are compared and the chains resume (duplicates, tag collisions).
+// A probe row that misses usually costs no L2 request at all.
+template <typename K>
+__global__ void __launch_bounds__(PJ_BT, 4)
+k_pj_probe_tags(const K* __restrict__ pkeys, const int32_t* __restrict__ pidx, PjPlan* plan, int pbits,
+                const Slot<K>* __restrict__ slots, uint32_t log2cap, int left_outer, int32_t* __restrict__ out_probe,
+                int32_t* __restrict__ out_build, int64_t capacity, unsigned long long* cursor, unsigned int chunk_rows)
+{
+  constexpr int NWJ      = PJ_BT / GX_WAVE;
+  constexpr int RPT      = PJ_CHUNK / PJ_BT;  // 16
+  constexpr int HB       = 8;                 // rows whose slot fetches are batched
+  constexpr uint32_t SUB = 1u << PJ_SUB_LOG2;
+  __shared__ unsigned long long s_wave_tot[NWJ];
+  __shared__ unsigned long long s_base;
+  __shared__ unsigned int s_misc[4];
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  uint8_t* s_tags        = reinterpret_cast<uint8_t*>(smem);
+  const uint32_t* s_tagw = reinterpret_cast<const uint32_t*>(smem);
+  const int P         = 1 << pbits;
+  const int LISTP     = P / PJ_NR;
+  const uint64_t mask = (1ull << log2cap) - 1;
+  const unsigned tid  = threadIdx.x;
+  const unsigned lane = lane_id();
+  const unsigned w    = tid / GX_WAVE;
+
+  if (tid == 0) {  // take a chunk: own XCD's list first
+    const unsigned x = pj_xcc();
+    unsigned int g   = 0xFFFFFFFFu;
+    for (int i = 0; i < PJ_NR; ++i) {
+      const unsigned y       = (x + i) % PJ_NR;
+      const unsigned int nch = plan->list_chunk0[y + 1] - plan->list_chunk0[y];
+      if (nch == 0) continue;
+      const unsigned int t = atomicAdd(&plan->ticket[y].v, 1u);
+      if (t < nch) {
+        g         = plan->list_chunk0[y] + t;
+        s_misc[1] = y;
+        break;
+      }
+    }
+    s_misc[0] = g;
+  }
+  __syncthreads();
+  const unsigned int g = s_misc[0];
+  if (g == 0xFFFFFFFFu) return;
+  {
+    const unsigned y = s_misc[1];
+    for (int e = (int)tid; e < LISTP; e += PJ_BT) {
+      const int p           = (int)y * LISTP + e;
+      const unsigned int lo = plan->chunk0[p], hi = plan->chunk0[p + 1];
+      if (lo <= g && g < hi) {
+        s_misc[2] = (unsigned int)p;
+        s_misc[3] = g - lo;
+      }
+    }
+  }
+  __syncthreads();
+  const unsigned int part     = s_misc[2];
+  const unsigned long long p0 = plan->offset[part], p1 = plan->offset[part + 1];
+  const unsigned long long c0 = p0 + (unsigned long long)s_misc[3] * chunk_rows;
+  const unsigned long long c1 = c0 + chunk_rows < p1 ? c0 + chunk_rows : p1;
+  const uint64_t sub_base     = (uint64_t)part << PJ_SUB_LOG2;
+  {
+    const uint8_t* gtags = reinterpret_cast<const uint8_t*>(slots + (mask + 1)) + (sub_base >> 1);
+    const uint4* src     = reinterpret_cast<const uint4*>(gtags);
+    uint4* dst           = reinterpret_cast<uint4*>(s_tags);
+    for (uint32_t i = tid; i < SUB / 2 / 16; i += PJ_BT) dst[i] = src[i];
+  }
+  __syncthreads();
+
+  for (unsigned long long sc0 = c0; sc0 < c1; sc0 += PJ_CHUNK) {
+    const unsigned long long sc1   = sc0 + PJ_CHUNK < c1 ? sc0 + PJ_CHUNK : c1;
+    const unsigned long long wbase = sc0 + (unsigned long long)w * (RPT * GX_WAVE) + lane;
+    uint32_t cnt[RPT];
+    int32_t first[RPT];
+#pragma unroll
+    for (int h = 0; h < RPT; h += HB) {
+      K key[HB];
+      uint32_t li[HB], cand[HB];
+      uint32_t active = 0, ended = 0;
+      // finish a chain on the slots themselves (it leaves the sub-table: a handful of rows per partition)
+      auto finish_global = [&](int j, uint64_t gs) {
+        for (;;) {
+          K k;
+          int32_t r;
+          load_slot<K>(&slots[gs & mask], k, r);
+          if (r == EMPTY_ROW) break;
+          if (k == key[j]) {
+            if (cnt[h + j] == 0) first[h + j] = r;
+            ++cnt[h + j];
+          }
+          ++gs;
+        }
+      };
+#pragma unroll
+      for (int j = 0; j < HB; ++j) {
+        const unsigned long long i = wbase + (unsigned long long)(h + j) * GX_WAVE;
+        cnt[h + j]   = 0;
+        first[h + j] = NO_MATCH;
+        key[j]       = K(0);
+        li[j]        = 0;
+        cand[j]      = 0;
+        if (i < sc1) {
+          key[j]              = __builtin_nontemporal_load(&pkeys[i]);
+          const uint64_t prod = (uint64_t)key[j] * 0x9E3779B97F4A7C15ull;
+          li[j]               = (uint32_t)((prod >> (64 - log2cap)) - sub_base);
+          uint32_t t          = (uint32_t)(prod >> (60 - log2cap)) & 15u;
+          t                   = t ? t : 8u;
+          if (li[j] > SUB - 8) {
+            finish_global(j, sub_base + li[j]);
+          } else {
+            const bool e = scan_tags8(s_tagw, li[j], t * 0x11111111u, cand[j]);
+            if (e) ended |= 1u << j;
+            if (cand[j] || !e) active |= 1u << j;
+          }
+        }
+      }
+      while (active) {
+        K k[HB];
+        int32_t r[HB];
+#pragma unroll
+        for (int j = 0; j < HB; ++j) {  // candidate slots of all rows, in flight together
+          k[j] = K(0);
+          r[j] = EMPTY_ROW;
+          if (ballot((active >> j) & 1u) == 0) continue;  // wave-uniform: nobody left on row j
+          if ((active & (1u << j)) && cand[j]) {
+            load_slot<K>(&slots[sub_base + li[j] + ((uint32_t)__builtin_ctz(cand[j]) >> 2)], k[j], r[j]);
+          }
+        }
+#pragma unroll
+        for (int j = 0; j < HB; ++j) {
+          if (ballot((active >> j) & 1u) == 0) continue;
+          if (!(active & (1u << j))) continue;
+          if (cand[j]) {
+            if (k[j] == key[j]) {
+              if (cnt[h + j] == 0) first[h + j] = r[j];
+              ++cnt[h + j];
+            }
+            cand[j] &= cand[j] - 1;
+          }
+          if (cand[j] == 0) {
+            if (ended & (1u << j)) {
+              active &= ~(1u << j);
+            } else {  // the chain runs on: next 8 slots
+              li[j] += 8;
+              if (li[j] > SUB - 8) {
+                finish_global(j, sub_base + li[j]);
+                active &= ~(1u << j);
+              } else {
+                const bool e = scan_tags8(s_tagw, li[j], tag_of<K>(key[j], log2cap) * 0x11111111u, cand[j]);
+                if (e) {
+                  ended |= 1u << j;
+                  if (cand[j] == 0) active &= ~(1u << j);
+                }
+              }
+            }
+          }
+        }
+      }
+    }
+    uint32_t off[RPT];
+    uint32_t wave_total = 0;
+#pragma unroll
+    for (int j = 0; j < RPT; ++j) {
+      const unsigned long long i = wbase + (unsigned long long)j * GX_WAVE;
+      if (left_outer && cnt[j] == 0 && i < sc1) cnt[j] = 1;
+      uint32_t inc;
+      if (ballot(cnt[j] > 1) == 0) {
+        const uint64_t b = ballot(cnt[j] == 1);
+        off[j]           = wave_total + (uint32_t)__builtin_popcountll(b & lanemask_lt());
+        inc              = (uint32_t)__builtin_popcountll(b);
+      } else {
+        const uint32_t sc = wave_inclusive_scan(cnt[j], SumOp());
+        off[j]            = wave_total + sc - cnt[j];
+        inc               = shfl(sc, GX_WAVE - 1);
+      }
+      wave_total += inc;
+    }
+    if (lane == 0) s_wave_tot[w] = wave_total;
+    __syncthreads();
+    if (tid == 0) {
+      unsigned long long tot = 0;
+      for (int k = 0; k < NWJ; ++k) {
+        const unsigned long long t = s_wave_tot[k];
+        s_wave_tot[k]              = tot;
+        tot += t;
+      }
+      s_base = tot ? atomicAdd(cursor, tot) : 0ull;  // one reservation per PJ_CHUNK rows (per wave: measured 30 % slower)
+    }
+    __syncthreads();
+    const unsigned long long wave_base = s_base + s_wave_tot[w];
+#pragma unroll
+    for (int j = 0; j < RPT; ++j) {
+      if (cnt[j] == 0) continue;
+      const unsigned long long i = wbase + (unsigned long long)j * GX_WAVE;
+      unsigned long long pos     = wave_base + off[j];
+      const int32_t row          = __builtin_nontemporal_load(&pidx[i]);
+      if (cnt[j] == 1) {
+        if ((int64_t)pos < capacity) {
+          __builtin_nontemporal_store(row, &out_probe[pos]);
+          __builtin_nontemporal_store(first[j], &out_build[pos]);
+        }
+      } else {
+        const K key = pkeys[i];
+        uint64_t hh = slot_of<K>(key, log2cap);
+        for (;;) {
+          K k;
+          int32_t r;
+          load_slot<K>(&slots[hh], k, r);
+          if (r == EMPTY_ROW) break;
+          if (k == key) {
+            if ((int64_t)pos < capacity) {
+              out_probe[pos] = row;
+              out_build[pos] = r;
+            }
+            ++pos;
+          }
+          hh = (hh + 1) & mask;
+        }
+      }
+    }
+    __syncthreads();  // s_wave_tot / s_base are reused by the next PJ_CHUNK rows
+  }
+}
+
 // Partitioned build: the build rows go through the same partition pass, then each chunk inserts into
 // the ~2 MiB sub-table its partition maps to while the other workgroups of the XCD insert into the
 // same one -- the CAS and the 16-B slot write hit L2 instead of scattering over the whole table
@@ -620,14 +903,14 @@ __global__ void __launch_bounds__(PJ_BT) k_pj_build(const K* __restrict__ pkeys,
 
 // the partition pass shared by the partitioned probe and build
 template <typename K>
-int pj_partition(const K* keys, int64_t n, int pbits, PjPlan* plan, K* pkeys, int32_t* pidx, hipStream_t s)
+int pj_partition(const K* keys, int64_t n, int pbits, PjPlan* plan, K* pkeys, int32_t* pidx, unsigned int chunk_rows, hipStream_t s)
 {
   GX_HIP_TRY(hipMemsetAsync(plan, 0, sizeof(PjPlan), s));
   int64_t hb = div_up(n, 256 * 8 * 4 * PJ_NR);
   if (hb > 256) hb = 256;
   if (hb < 1) hb = 1;
   hipLaunchKernelGGL((k_pj_hist<K>), dim3((unsigned)(hb * PJ_NR)), dim3(256), 0, s, keys, n, plan, pbits);
-  hipLaunchKernelGGL(k_pj_offsets, dim3(1), dim3(1024), 0, s, plan, pbits);
+  hipLaunchKernelGGL(k_pj_offsets, dim3(1), dim3(1024), 0, s, plan, pbits, chunk_rows);
   const int rpt            = getenv("GX_PJ_RPT") ? atoi(getenv("GX_PJ_RPT")) : 8;
   const size_t tile_rows   = (size_t)PJ_BT * (rpt == 16 ? 16 : 8);
   const size_t lds_max     = (size_t)PJ_BT * 16 * sizeof(K) + (size_t)PJ_BT * 16 * 2 + (size_t)PJ_MAXP * (4 + 4 + 8);
@@ -647,9 +930,8 @@ int pj_partition(const K* keys, int64_t n, int pbits, PjPlan* plan, K* pkeys, in
 static inline int pj_bits(uint32_t log2cap, int slot_bytes)
 {
   // sub-table of about 2 MiB: P = table bytes / 2 MiB
-  int lg_table = (int)log2cap + (slot_bytes == 16 ? 4 : 3);
-  int pb       = lg_table - 21;
-  if (getenv("GX_PJ_SUB")) pb = lg_table - atoi(getenv("GX_PJ_SUB"));  // experiment: log2 of the sub-table bytes
+  (void)slot_bytes;
+  int pb = (int)log2cap - PJ_SUB_LOG2;  // sub-table = 2^17 slots: 2 MiB of 16-B slots, 64 KiB of tags
   if (pb < 3) pb = 0;  // small tables: the direct probe is already cache resident
   if (pb > 12) pb = 12;
   return pb;
@@ -670,18 +952,37 @@ int probe_partitioned_impl(const void* keys, int64_t n, const void* table, size_
     return 0;
   }
   if (*tmp_bytes < c.total()) return GX_ETMP;
-  const size_t need = sizeof(TableHeader) + (sizeof(Slot<K>) << lg);
+  const size_t need = sizeof(TableHeader) + (sizeof(Slot<K>) << lg) + ((size_t)1 << lg) / 2;
   if (table_bytes < need) return GX_ETMP;
   if (n == 0) return 0;
   const Slot<K>* slots = reinterpret_cast<const Slot<K>*>(static_cast<const char*>(table) + sizeof(TableHeader));
   if (pbits == 0) return GX_EINVAL;  // caller should use gx_join_probe
+  const bool use_tags = !getenv("GX_PJ_NOTAGS");
+  // the tag probe amortises its 64 KiB tag copy over several PJ_CHUNKs of the same partition
+  unsigned int chunk_rows = PJ_CHUNK;
+  if (use_tags) {
+    const int mult = getenv("GX_PJ_SC") ? atoi(getenv("GX_PJ_SC")) : 8;
+    chunk_rows     = PJ_CHUNK * (unsigned)(mult < 1 ? 1 : mult);
+    while (chunk_rows > PJ_CHUNK && div_up(n, (int64_t)chunk_rows) < 4096) chunk_rows /= 2;  // keep >> 512 workgroups
+  }
   {
-    int rc = pj_partition<K>(static_cast<const K*>(keys), n, pbits, plan, pkeys, pidx, s);
+    int rc = pj_partition<K>(static_cast<const K*>(keys), n, pbits, plan, pkeys, pidx, chunk_rows, s);
     if (rc) return rc;
   }
-  const int64_t max_chunks = div_up(n, PJ_CHUNK) + (1 << pbits);
-  hipLaunchKernelGGL((k_pj_probe<K>), dim3((unsigned)max_chunks), dim3(PJ_BT), 0, s, pkeys, pidx, plan, pbits, slots, lg,
-                     left_outer, out_probe, out_build, capacity, reinterpret_cast<unsigned long long*>(cursor));
+  const int64_t max_chunks = div_up(n, (int64_t)chunk_rows) + (1 << pbits);
+  if (use_tags) {
+    constexpr size_t lds_t = (size_t)1 << (PJ_SUB_LOG2 - 1);
+    static bool tattr_set  = false;
+    if (!tattr_set) {
+      GX_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(k_pj_probe_tags<K>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_t));
+      tattr_set = true;
+    }
+    hipLaunchKernelGGL((k_pj_probe_tags<K>), dim3((unsigned)max_chunks), dim3(PJ_BT), lds_t, s, pkeys, pidx, plan, pbits, slots, lg,
+                       left_outer, out_probe, out_build, capacity, reinterpret_cast<unsigned long long*>(cursor), chunk_rows);
+  } else {
+    hipLaunchKernelGGL((k_pj_probe<K>), dim3((unsigned)max_chunks), dim3(PJ_BT), 0, s, pkeys, pidx, plan, pbits, slots, lg,
+                       left_outer, out_probe, out_build, capacity, reinterpret_cast<unsigned long long*>(cursor));
+  }
   GX_LAUNCH_CHECK();
   return 0;
 }
@@ -701,19 +1002,19 @@ int build_partitioned_impl(const void* keys, int64_t n, void* table, size_t tabl
     return 0;
   }
   if (*tmp_bytes < c.total()) return GX_ETMP;
-  const size_t need = sizeof(TableHeader) + (sizeof(Slot<K>) << lg);
+  const size_t need = sizeof(TableHeader) + (sizeof(Slot<K>) << lg) + ((size_t)1 << lg) / 2;
   if (table_bytes < need) return GX_ETMP;
   if (pbits == 0) return GX_EINVAL;
   char* base = static_cast<char*>(table);
   GX_HIP_TRY(hipMemsetAsync(base + sizeof(TableHeader), 0xFF, sizeof(Slot<K>) << lg, s));
-  if (n == 0) return 0;
-  int rc = pj_partition<K>(static_cast<const K*>(keys), n, pbits, plan, pkeys, pidx, s);
+  if (n == 0) return launch_tags<K>(table, lg, s);
+  int rc = pj_partition<K>(static_cast<const K*>(keys), n, pbits, plan, pkeys, pidx, PJ_CHUNK, s);
   if (rc) return rc;
   const int64_t max_chunks = div_up(n, PJ_CHUNK) + (1 << pbits);
   hipLaunchKernelGGL((k_pj_build<K>), dim3((unsigned)max_chunks), dim3(PJ_BT), 0, s, pkeys, pidx, plan, pbits,
                      reinterpret_cast<Slot<K>*>(base + sizeof(TableHeader)), lg);
   GX_LAUNCH_CHECK();
-  return 0;
+  return launch_tags<K>(table, lg, s);
 }
 
 template <typename K>
@@ -721,7 +1022,7 @@ int build_impl(const void* keys, const uint32_t* valid, int64_t n, void* table, 
                double load_factor, hipStream_t s)
 {
   const uint32_t lg = log2_capacity(n, load_factor);
-  const size_t need = sizeof(TableHeader) + (sizeof(Slot<K>) << lg);
+  const size_t need = sizeof(TableHeader) + (sizeof(Slot<K>) << lg) + ((size_t)1 << lg) / 2;
   if (table_bytes < need) return GX_ETMP;
   char* base = static_cast<char*>(table);
   GX_HIP_TRY(hipMemsetAsync(base + sizeof(TableHeader), 0xFF, sizeof(Slot<K>) << lg, s));
@@ -732,7 +1033,7 @@ int build_impl(const void* keys, const uint32_t* valid, int64_t n, void* table, 
                        reinterpret_cast<Slot<K>*>(base + sizeof(TableHeader)), lg);
     GX_LAUNCH_CHECK();
   }
-  return 0;
+  return launch_tags<K>(table, lg, s);
 }
 
 template <typename K, bool WRITE>
@@ -762,7 +1063,7 @@ size_t gx_join_table_bytes(int key_size, int64_t build_rows, double load_factor)
 {
   if (key_size != 4 && key_size != 8) return 0;
   const uint32_t lg = gx::join::log2_capacity(build_rows, load_factor);
-  return sizeof(gx::join::TableHeader) + ((size_t)(key_size == 8 ? 16 : 8) << lg);
+  return sizeof(gx::join::TableHeader) + ((size_t)(key_size == 8 ? 16 : 8) << lg) + ((size_t)1 << lg) / 2;  // slots + 4-bit tags
 }
 
 int gx_join_build(int key_size, const void* build_keys, const uint32_t* build_valid, int64_t build_rows,

@@ -184,7 +184,9 @@ int gx_hash_partition_map(const uint32_t* row_hash, int64_t n, int num_partition
  * cuco::static_multiset::insert) and probe (src/join/hash_join/retrieve_impl.cuh:28-113,
  * size_impl.cuh:26-62 -> cuco count / retrieve).
  *
- * The table is an open-addressing multiset of {key, row} slots sized by gx_join_table_bytes;
+ * The table is an open-addressing multiset of {key, row} slots followed by one 4-bit tag per slot
+ * (0 = empty, else hash bits; the partitioned probe walks chains on the tags in LDS), sized by
+ * gx_join_table_bytes = 256 + slots * (slot bytes + 1/2);
  * build rows whose validity bit is 0 are skipped (null_equality::UNEQUAL semantics of
  * hash_join.cu:77-84; for EQUAL the caller maps nulls to a reserved key -- see DESIGN.md).
  * ------------------------------------------------------------------------------------------ */

@@ -1,21 +1,22 @@
 #!/bin/bash
 set -u
 mkdir -p gpurun_out
-export TMPDIR=/tmp
 O=gpurun_out
 L=$O/run23.log
 : > $L
-timeout 900 python -m pytest tests/test_gpu_join_groupby.py tests/test_gpu_dataframe.py tests/test_gpu_distributed.py -m gpu -x -q > $O/pytest_gpu23.log 2>&1
-echo "pytest exit $?" | tee -a $L
-tail -5 $O/pytest_gpu23.log | tee -a $L
-(cd /tmp && timeout 600 rocprofv3 --kernel-trace --stats -d "$GRAFT_REPO_ROOT/$O/prof_join23" -o join23 -- python "$GRAFT_REPO_ROOT/bench.py" --workload join --rows 1e9 --steps 2 --warmup 1 --no-cpu-baseline) >> $L 2>&1
-db=$(find $O/prof_join23 -name "*.db" | head -1)
-[ -n "$db" ] && python scripts/rocprof_summary.py "$db" "round 1 run 23: rocprofv3 --kernel-trace --stats -- python bench.py --workload join --rows 1e9 --steps 2 --warmup 1" > $O/r1_run23_join_kernel_stats.txt
-find $O/prof_join23 -name "*.db" -delete
-grep -E "^# round|k_pj|k_probe|k_build" $O/r1_run23_join_kernel_stats.txt | cut -c1-170
+timeout 900 python -m pytest tests/test_gpu_join_groupby.py tests/test_cpp_api.py -m gpu -x -q > $O/pytest_gpu23.log 2>&1
+echo "pytest join exit $?" | tee -a $L
+tail -12 $O/pytest_gpu23.log | tee -a $L
+python bench.py --workload join --rows 1e9 --steps 3 --warmup 1 --no-cpu-baseline >> $L 2>&1
+GX_PJ_NOTAGS=1 python bench.py --workload join --rows 1e9 --steps 3 --warmup 1 --no-cpu-baseline >> $L 2>&1
+cd /tmp && export TMPDIR=/tmp
+rocprofv3 --kernel-trace --stats -d $GRAFT_REPO_ROOT/$O/prof23 -o join -- python $GRAFT_REPO_ROOT/bench.py --workload join --rows 1e9 --steps 3 --warmup 1 --no-cpu-baseline > /dev/null 2>&1
+cd $GRAFT_REPO_ROOT
+python scripts/rocprof_summary.py $O/prof23 > $O/prof23_summary.txt 2>&1
+head -20 $O/prof23_summary.txt | tee -a $L
 grep -h '"metric"' $L | python -c "
 import sys, json
 for l in sys.stdin:
-    d = json.loads(l)
-    print('join ms', round(d['ms_per_step'],2), 'Grows/s', round(d['value']/1e9,2), 'build_ms', round(d.get('join_build_ms',0),2))
+    d = json.loads(l); r = d['roofline']
+    print(d['config']['workload'][:60], '| ms', round(d['ms_per_step'],2), '| Grows/s', round(d['value']/1e9,2), '|', r['kernel'][:30], round(r['avg_launch_ms'],2), d.get('join_build_ms'))
 "

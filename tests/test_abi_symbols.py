@@ -33,6 +33,7 @@ def test_pure_host_entry_points():
     assert [_lib.lib.gx_dtype_size(d) for d in range(1, 12)] == [1, 2, 4, 8, 1, 2, 4, 8, 4, 8, 1]
     # table sizing is host arithmetic: power-of-two slots, load factor <= requested
     b8 = _lib.lib.gx_join_table_bytes(8, 1000, 0.5)
-    assert (b8 - 256) % 16 == 0 and (b8 - 256) // 16 == 2048
-    assert _lib.lib.gx_join_table_bytes(4, 1000, 0.5) == 256 + 8 * 2048
+    # header + slots + one 4-bit tag per slot
+    assert b8 == 256 + 16 * 2048 + 2048 // 2
+    assert _lib.lib.gx_join_table_bytes(4, 1000, 0.5) == 256 + 8 * 2048 + 2048 // 2
     assert _lib.lib.gx_join_table_bytes(3, 1000, 0.5) == 0

@@ -138,6 +138,39 @@ def test_partitioned_probe_matches_direct_probe(gx, dtype):
     np.testing.assert_array_equal(a[1], b[1])
 
 
+@pytest.mark.parametrize("dtype", ["int64", "int32"])
+def test_partitioned_probe_chains_cross_subtables(gx, dtype):
+    """The partitioned probe walks collision chains on 4-bit tags held in LDS, one 2^17-slot sub-table
+    per workgroup.  Build keys that hash to the LAST slots of a sub-table, each duplicated many times,
+    force chains across the sub-table edge (and around the end of the table): same pairs as the oracle."""
+    Column, ops = gx
+    from cudf_amd import _lib as L
+    rng = np.random.default_rng(33)
+    nb, npr = 1_500_000, (1 << 22) + 5
+    ksz = np.dtype(dtype).itemsize
+    tb = L.lib.gx_join_table_bytes(ksz, nb, 0.5)
+    lg = int(np.log2((tb - 256) // (16 if ksz == 8 else 8)))
+    cand = np.arange(1, 3_000_000, dtype=np.uint64)
+    with np.errstate(over="ignore"):
+        slot = (cand * np.uint64(0x9E3779B97F4A7C15)) >> np.uint64(64 - lg)
+    edge = cand[(slot & np.uint64((1 << 17) - 1)) >= np.uint64((1 << 17) - 3)]     # last 3 slots of a sub-table
+    last = cand[slot >= np.uint64((1 << lg) - 2)]                                  # last slots of the table
+    hot = np.concatenate([edge[:40], last[:2]]).astype(dtype)
+    assert hot.size >= 20
+    base = rng.permutation(3_000_000)[: nb - 60 * hot.size].astype(dtype)
+    build = np.concatenate([base, np.repeat(hot, 60)])
+    rng.shuffle(build)
+    probe = rng.integers(0, 4_000_000, npr).astype(dtype)
+    probe[:: 1000] = hot[np.arange(probe[::1000].size) % hot.size]                 # make sure the hot keys are probed
+    hj = ops.HashJoin(Column.from_numpy(build))
+    assert hj.table_bytes == tb and L.lib.gx_join_partition_bits(ksz, tb) >= 3
+    l, r = hj.inner_join(Column.from_numpy(probe))
+    gl, gr = _pairs(l, r)
+    el, er = orc.inner_join(probe, build)
+    np.testing.assert_array_equal(gl, el)
+    np.testing.assert_array_equal(gr, er)
+
+
 def test_join_large_properties(gx):
     """Size-independent checks at 2e7 x 2e6: every emitted pair has equal keys, count equals the
     oracle-free closed form (distinct build keys, known hit set)."""
