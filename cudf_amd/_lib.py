@@ -58,6 +58,12 @@ _PROTOS = {
     "gx_join_probe_partitioned": (_i, [_i, _p, _i64, _p, ctypes.c_size_t, _i, _p, _p, _i64, _p, _p, _sz, _p]),
     "gx_join_build_partitioned": (_i, [_i, _p, _i64, _p, ctypes.c_size_t, ctypes.c_double, _p, _sz, _p]),
     "gx_join_partition_bits": (_i, [_i, ctypes.c_size_t]),
+    "gx_bitmask_copy": (_i, [_p, _i64, _p, _i64, _i64, _p]),
+    "gx_pack_keys": (_i, [_i, _p, _p, _i64, _p, _p]),
+    "gx_dense_rank": (_i, [_i, _p, _p, _i64, _i64, _p, _p, _p, _p, _sz, _p]),
+    "gx_fill_nulls": (_i, [_i, _p, _p, _i64, ctypes.c_uint64, _p]),
+    "gx_join_lookup": (_i, [_i, _p, _p, _i64, _p, ctypes.c_size_t, _p, _p]),
+    "gx_join_filter": (_i, [_i, _p, _p, _i64, _p, ctypes.c_size_t, _i, _i, _p, _p, _p, _sz, _p]),
     "gx_join_complement": (_i, [_p, _i64, _i64, _p, _p, _i64, _p, _p, _sz, _p]),
     "gx_groupby_set_algorithm": (None, [_i, _i]),
     "gx_segmented_scan": (_i, [_i, _p, _i, _p, _p, _i64, _i, _p, _p, _sz, _p]),

@@ -45,19 +45,11 @@ bitmask_type const* rebased_mask(column_view const& c, rmm::device_buffer& holde
   if (!c.nullable()) return nullptr;
   if (c.offset() == 0) return c.null_mask();
   if (c.offset() % 32 == 0) return c.null_mask() + c.offset() / 32;  // word aligned: plain pointer shift
-  // unaligned slice: host round trip (slices of nullable columns are off the hot path)
-  auto const words_in = num_bitmask_words(c.offset() + c.size());
-  std::vector<bitmask_type> h(words_in);
-  CUDF_CUDA_TRY(hipMemcpyAsync(h.data(), c.null_mask(), words_in * sizeof(bitmask_type), hipMemcpyDeviceToHost,
-                               stream.value()));
-  stream.synchronize();
-  std::vector<bitmask_type> o(bitmask_allocation_size_bytes(c.size()) / sizeof(bitmask_type), 0u);
-  for (size_type i = 0; i < c.size(); ++i) {
-    auto const s = c.offset() + i;
-    if ((h[s / 32] >> (s % 32)) & 1u) o[i / 32] |= (1u << (i % 32));
-  }
-  holder = rmm::device_buffer{o.data(), o.size() * sizeof(bitmask_type), stream};
-  stream.synchronize();
+  // unaligned slice: the bits are re-based on the device (cudf::copy_bitmask, null_mask.cu:357-390)
+  holder = rmm::device_buffer{bitmask_allocation_size_bytes(c.size()), stream};
+  CUDF_CUDA_TRY(hipMemsetAsync(holder.data(), 0, holder.size(), stream.value()));
+  gx_check(gx_bitmask_copy(static_cast<uint32_t*>(holder.data()), 0, c.null_mask(), c.offset(), c.size(), gxs(stream)),
+           "copy_bitmask");
   return static_cast<bitmask_type const*>(holder.data());
 }
 

@@ -2,6 +2,7 @@
 // reference: cpp/src/groupby/groupby.cu:40-71,220-259; hash path cpp/src/groupby/hash/*;
 // scan path cpp/src/groupby/sort/{scan.cpp:214-238, sort_helper.cu:73-162, group_scan_util.cuh:77-133}.
 #include "common.hpp"
+#include "row_encoding.hpp"
 
 #include <cudf/column/column_factories.hpp>
 #include <cudf/copying.hpp>
@@ -148,13 +149,36 @@ std::pair<std::unique_ptr<table>, std::vector<aggregation_result>> groupby::aggr
   CUDF_EXPECTS(std::all_of(requests.begin(), requests.end(),
                            [this](auto const& r) { return r.values.size() == _keys.num_rows(); }),
                "Size mismatch between request values and groupby keys.", std::invalid_argument);
-  CUDF_EXPECTS(_keys.num_columns() == 1, "multi-column groupby keys are not supported on this path yet");
-  auto const& keys = _keys.column(0);
-  CUDF_EXPECTS(keys.type().id() == type_id::INT32 || keys.type().id() == type_id::INT64 ||
-                 keys.type().id() == type_id::UINT32 || keys.type().id() == type_id::UINT64,
-               "groupby key must be a 32/64-bit integer column on this path", cudf::data_type_error);
-  CUDF_EXPECTS(_include_null_keys == null_policy::EXCLUDE || !keys.has_nulls(),
+  CUDF_EXPECTS(_keys.num_columns() >= 1, "groupby needs at least one key column");
+  CUDF_EXPECTS(_include_null_keys == null_policy::EXCLUDE || !cudf::has_nulls(_keys),
                "null_policy::INCLUDE with null keys is not supported on this path yet");
+  // One 32/64-bit integer key column goes to the hash kernels as it is; anything else (several columns,
+  // floats, narrow types) is first encoded into dense INT32 row ids (gx_dense_rank), aggregated by id, and
+  // the key columns are gathered back through the first row of every id.
+  auto const k0      = _keys.column(0).type().id();
+  bool const encoded = !(_keys.num_columns() == 1 && (k0 == type_id::INT32 || k0 == type_id::INT64 ||
+                                                      k0 == type_id::UINT32 || k0 == type_id::UINT64));
+  detail::dense_rank_result enc;
+  column_view keys = _keys.column(0);
+  if (encoded && _keys.num_rows() > 0) {
+    enc  = detail::dense_row_ids(_keys, stream);
+    keys = enc.ids->view();
+  }
+  // unique ids (in whatever order the hash pass produced) -> the key columns
+  auto decode_keys = [&](std::unique_ptr<column> ids) {
+    if (!encoded) {
+      std::vector<std::unique_ptr<column>> kc;
+      kc.emplace_back(std::move(ids));
+      return std::make_unique<table>(std::move(kc));
+    }
+    if (_keys.num_rows() == 0 || ids->size() == 0) {
+      std::vector<std::unique_ptr<column>> kc;
+      for (auto const& c : _keys) kc.emplace_back(make_empty_column(c.type()));
+      return std::make_unique<table>(std::move(kc));
+    }
+    auto rows = cudf::gather(table_view{{enc.rep->view()}}, ids->view(), out_of_bounds_policy::DONT_CHECK, stream);
+    return cudf::gather(_keys, rows->get_column(0).view(), out_of_bounds_policy::DONT_CHECK, stream, mr);
+  };
 
   std::vector<aggregation_result> results(requests.size());
   std::unique_ptr<column> out_keys;
@@ -190,9 +214,7 @@ std::pair<std::unique_ptr<table>, std::vector<aggregation_result>> groupby::aggr
     } else {
       out_keys = make_empty_column(keys.type());
     }
-    std::vector<std::unique_ptr<column>> kc;
-    kc.emplace_back(std::move(out_keys));
-    return {std::make_unique<table>(std::move(kc)), std::move(results)};
+    return {decode_keys(std::move(out_keys)), std::move(results)};
   }
 
   for (std::size_t i = 0; i < requests.size(); ++i) {
@@ -283,9 +305,7 @@ std::pair<std::unique_ptr<table>, std::vector<aggregation_result>> groupby::aggr
     if (!out_keys) out_keys = fin(std::move(o.keys));
     stream.synchronize();  // per-request temporaries are released here
   }
-  std::vector<std::unique_ptr<column>> kc;
-  kc.emplace_back(std::move(out_keys));
-  return {std::make_unique<table>(std::move(kc)), std::move(results)};
+  return {decode_keys(std::move(out_keys)), std::move(results)};
 }
 
 std::pair<std::unique_ptr<table>, std::vector<aggregation_result>> groupby::scan(

@@ -2,7 +2,10 @@
 // reference: cpp/src/join/hash_join/hash_join.cu:32-198, cpp/src/join/join.cu:27-124,
 // cpp/src/join/join_utils.cu:45-157.
 #include "common.hpp"
+#include "row_encoding.hpp"
 
+#include <cudf/join/distinct_hash_join.hpp>
+#include <cudf/join/filtered_join.hpp>
 #include <cudf/join/hash_join.hpp>
 #include <cudf/join/join.hpp>
 
@@ -47,27 +50,54 @@ class hash_join_impl {
     CUDF_EXPECTS(0 != build.num_columns(), "Hash join build table is empty", std::invalid_argument);
     CUDF_EXPECTS(load_factor > 0 && load_factor <= 1,
                  "Invalid load factor: must be greater than 0 and less than or equal to 1.", std::invalid_argument);
-    CUDF_EXPECTS(build.num_columns() == 1, "multi-column join keys are not supported on this path yet");
-    auto const& key = build.column(0);
+    // one fixed-width key per row: the column itself (4/8-byte integers), else the row encoding
+    auto const& c0    = build.column(0);
+    bool const direct = build.num_columns() == 1 && (size_of(c0.type()) == 4 || size_of(c0.type()) == 8) &&
+                        !is_floating_point(c0.type());
+    if (direct) {
+      _key = c0;
+    } else {
+      _enc = std::make_unique<row_encoder>(build, _nulls_equal, stream);
+      _key = _enc->build_keys();
+    }
+    auto const& key = _key;
     _key_size       = static_cast<int>(size_of(key.type()));
-    CUDF_EXPECTS(_key_size == 4 || _key_size == 8, "join key must be a 4- or 8-byte fixed-width column", cudf::data_type_error);
     if (build.num_rows() == 0) return;
     _table_bytes = gx_join_table_bytes(_key_size, key.size(), load_factor);
     _table       = rmm::device_buffer{_table_bytes, stream};
     rmm::device_buffer holder;
     auto const* mask = key.has_nulls() ? rebased_mask(key, holder, stream) : nullptr;
-    gx_check(gx_join_build(_key_size, row0(key), mask, key.size(), _table.data(), _table_bytes, load_factor, gxs(stream)),
-             "hash_join build");
+    if (mask == nullptr && key.size() >= (1 << 20) && gx_join_partition_bits(_key_size, _table_bytes) > 0) {
+      // large build side: rows are partitioned first so that the inserts hit L2-resident sub-tables
+      run_with_scratch(
+        [&](void* t, std::size_t* b) {
+          return gx_join_build_partitioned(_key_size, row0(key), key.size(), _table.data(), _table_bytes, load_factor, t, b,
+                                           gxs(stream));
+        },
+        "hash_join build", stream);
+    } else {
+      gx_check(gx_join_build(_key_size, row0(key), mask, key.size(), _table.data(), _table_bytes, load_factor, gxs(stream)),
+               "hash_join build");
+    }
     _build_nulls = null_rows(key, stream);
     stream.synchronize();
+  }
+
+  // the probe table's key column in the build side's key space (owner keeps an encoded column alive)
+  column_view probe_key(table_view const& probe, std::unique_ptr<column>& owner, rmm::cuda_stream_view stream) const
+  {
+    if (!_enc) return probe.column(0);
+    owner = _enc->encode(probe, stream);
+    return owner->view();
   }
 
   void check_probe(table_view const& probe) const
   {
     CUDF_EXPECTS(probe.num_columns() == _build.num_columns(), "Mismatch in number of columns to be joined on",
                  std::invalid_argument);
-    CUDF_EXPECTS(probe.column(0).type() == _build.column(0).type(), "Mismatch in joining column data types",
-                 cudf::data_type_error);
+    for (size_type i = 0; i < probe.num_columns(); ++i)
+      CUDF_EXPECTS(probe.column(i).type() == _build.column(i).type(), "Mismatch in joining column data types",
+                   cudf::data_type_error);
     CUDF_EXPECTS(_has_nulls || !cudf::has_nulls(probe), "Probe table has nulls while build table was not hashed with null check.",
                  std::invalid_argument);
   }
@@ -77,7 +107,8 @@ class hash_join_impl {
                          rmm::cuda_stream_view stream, rmm::device_async_resource_ref mr) const
   {
     check_probe(probe);
-    auto const& pk = probe.column(0);
+    std::unique_ptr<column> owner;
+    auto const pk = probe_key(probe, owner, stream);
     rmm::device_buffer holder;
     auto const* pmask = pk.has_nulls() ? rebased_mask(pk, holder, stream) : nullptr;
     std::vector<size_type> pnulls = _nulls_equal ? null_rows(pk, stream) : std::vector<size_type>{};
@@ -93,10 +124,21 @@ class hash_join_impl {
       l = std::make_unique<rmm::device_uvector<size_type>>(capacity, stream, mr);
       r = std::make_unique<rmm::device_uvector<size_type>>(capacity, stream, mr);
       CUDF_CUDA_TRY(hipMemsetAsync(cursor.data(), 0, sizeof(int64_t), stream.value()));
-      gx_check(gx_join_probe(_key_size, row0(pk), pmask, pk.size(), _table.data(), _table_bytes, left_outer ? 1 : 0,
-                             l->data(), r->data(), static_cast<int64_t>(capacity), static_cast<int64_t*>(cursor.data()),
-                             gxs(stream)),
-               "hash_join probe");
+      if (pmask == nullptr && pk.size() >= (1 << 22) && gx_join_partition_bits(_key_size, _table_bytes) > 0) {
+        // large probe against a table far beyond the L2s: partitioned probe (chains run on LDS tags)
+        run_with_scratch(
+          [&](void* t, std::size_t* b) {
+            return gx_join_probe_partitioned(_key_size, row0(pk), pk.size(), _table.data(), _table_bytes, left_outer ? 1 : 0,
+                                             l->data(), r->data(), static_cast<int64_t>(capacity),
+                                             static_cast<int64_t*>(cursor.data()), t, b, gxs(stream));
+          },
+          "hash_join probe", stream);
+      } else {
+        gx_check(gx_join_probe(_key_size, row0(pk), pmask, pk.size(), _table.data(), _table_bytes, left_outer ? 1 : 0,
+                               l->data(), r->data(), static_cast<int64_t>(capacity), static_cast<int64_t*>(cursor.data()),
+                               gxs(stream)),
+                 "hash_join probe");
+      }
       total = read_i64(static_cast<int64_t const*>(cursor.data()), stream);
       if (static_cast<std::size_t>(total) + cross <= capacity) break;
       capacity = static_cast<std::size_t>(total) + cross;  // duplicate build keys: exact size now known
@@ -147,7 +189,7 @@ class hash_join_impl {
       stream.synchronize();
       return {std::move(l), std::move(r)};
     }
-    CUDF_EXPECTS(!(_nulls_equal && probe.column(0).has_nulls() && !_build_nulls.empty()),
+    CUDF_EXPECTS(!(_nulls_equal && !_enc && probe.column(0).has_nulls() && !_build_nulls.empty()),
                  "left/full join with null keys on both sides under null_equality::EQUAL is not supported on this path yet");
     return probe_join(probe, true, output_size, stream, mr);
   }
@@ -185,7 +227,8 @@ class hash_join_impl {
   {
     check_probe(probe);
     if (probe.num_rows() == 0 || _build.num_rows() == 0) return 0;
-    auto const& pk = probe.column(0);
+    std::unique_ptr<column> owner;
+    auto const pk = probe_key(probe, owner, stream);
     rmm::device_buffer holder;
     auto const* pmask = pk.has_nulls() ? rebased_mask(pk, holder, stream) : nullptr;
     rmm::device_buffer cnt{sizeof(int64_t), stream};
@@ -197,6 +240,61 @@ class hash_join_impl {
     return total;
   }
 
+  // cudf::filtered_join: ascending rows of `probe` with (anti: without) a match
+  map_ptr semi_anti(table_view const& probe, bool anti, rmm::cuda_stream_view stream, rmm::device_async_resource_ref mr) const
+  {
+    auto const n = probe.num_rows();
+    if (n == 0) return std::make_unique<rmm::device_uvector<size_type>>(0, stream, mr);
+    if (_build.num_rows() == 0 || _build.num_columns() == 0) {  // nothing can match
+      auto out = std::make_unique<rmm::device_uvector<size_type>>(anti ? n : 0, stream, mr);
+      if (anti) gx_check(gx_sequence_i32(out->data(), n, 0, gxs(stream)), "sequence");
+      return out;
+    }
+    check_probe(probe);
+    std::unique_ptr<column> owner;
+    auto const pk = probe_key(probe, owner, stream);
+    rmm::device_buffer holder;
+    auto const* pmask = pk.has_nulls() ? rebased_mask(pk, holder, stream) : nullptr;
+    auto out          = std::make_unique<rmm::device_uvector<size_type>>(n, stream, mr);
+    rmm::device_buffer cnt{sizeof(int64_t), stream};
+    int const null_matches = (_nulls_equal && !_build_nulls.empty()) ? 1 : 0;
+    run_with_scratch(
+      [&](void* t, std::size_t* b) {
+        return gx_join_filter(_key_size, row0(pk), pmask, n, _table.data(), _table_bytes, anti ? 1 : 0, null_matches,
+                              out->data(), static_cast<int64_t*>(cnt.data()), t, b, gxs(stream));
+      },
+      "filtered_join", stream);
+    out->shrink(static_cast<std::size_t>(read_i64(static_cast<int64_t const*>(cnt.data()), stream)));
+    return out;
+  }
+
+  // cudf::distinct_hash_join::left_join: the build row of every probe row, JoinNoMatch where none
+  map_ptr lookup(table_view const& probe, rmm::cuda_stream_view stream, rmm::device_async_resource_ref mr) const
+  {
+    auto const n = probe.num_rows();
+    auto out     = std::make_unique<rmm::device_uvector<size_type>>(n, stream, mr);
+    if (n == 0) return out;
+    if (_build.num_rows() == 0) {
+      std::vector<size_type> nm(n, JoinNoMatch);
+      CUDF_CUDA_TRY(hipMemcpyAsync(out->data(), nm.data(), n * sizeof(size_type), hipMemcpyHostToDevice, stream.value()));
+      stream.synchronize();
+      return out;
+    }
+    check_probe(probe);
+    std::unique_ptr<column> owner;
+    auto const pk = probe_key(probe, owner, stream);
+    rmm::device_buffer holder;
+    auto const* pmask = pk.has_nulls() ? rebased_mask(pk, holder, stream) : nullptr;
+    gx_check(gx_join_lookup(_key_size, row0(pk), pmask, n, _table.data(), _table_bytes, out->data(), gxs(stream)),
+             "distinct_hash_join lookup");
+    if (pmask && _nulls_equal && !_build_nulls.empty())  // null == null: the (single) null build row
+      gx_check(gx_fill_nulls(4, out->data(), pmask, n, static_cast<uint64_t>(static_cast<uint32_t>(_build_nulls.front())),
+                             gxs(stream)),
+               "distinct_hash_join null rows");
+    stream.synchronize();
+    return out;
+  }
+
   [[nodiscard]] size_type build_rows() const { return _build.num_rows(); }
 
  private:
@@ -204,6 +302,8 @@ class hash_join_impl {
   bool _has_nulls;
   bool _nulls_equal;
   double _load_factor;
+  std::unique_ptr<row_encoder> _enc{};
+  column_view _key{};
   int _key_size{0};
   std::size_t _table_bytes{0};
   rmm::device_buffer _table{};
@@ -252,6 +352,62 @@ std::size_t hash_join::full_join_size(table_view const& probe, rmm::cuda_stream_
                                       rmm::device_async_resource_ref mr) const
 {
   return _impl->full_join(probe, {}, stream, mr).first->size();
+}
+
+// ---- cudf::filtered_join (include/cudf/join/filtered_join.hpp:51-144; src/join/filtered_join/filtered_join.cu)
+filtered_join::~filtered_join() = default;
+filtered_join::filtered_join(table_view const& right, null_equality compare_nulls, rmm::cuda_stream_view stream)
+  : filtered_join(right, compare_nulls, 0.5, stream)
+{
+}
+filtered_join::filtered_join(table_view const& right, null_equality compare_nulls, double load_factor,
+                             rmm::cuda_stream_view stream)
+{
+  CUDF_EXPECTS(load_factor > 0 && load_factor <= 1,
+               "Invalid load factor: must be greater than 0 and less than or equal to 1.", std::invalid_argument);
+  _right_rows = right.num_rows();
+  // an empty right table (no columns or no rows) matches nothing (semi_anti_join_tests.cpp:357-421)
+  if (right.num_columns() > 0 && right.num_rows() > 0)
+    _impl = std::make_unique<detail::hash_join_impl const>(right, nullable_join::YES, compare_nulls, load_factor, stream);
+}
+std::unique_ptr<rmm::device_uvector<size_type>> filtered_join::semi_join(table_view const& left, rmm::cuda_stream_view stream,
+                                                                         rmm::device_async_resource_ref mr) const
+{
+  if (!_impl) return std::make_unique<rmm::device_uvector<size_type>>(0, stream, mr);
+  return _impl->semi_anti(left, false, stream, mr);
+}
+std::unique_ptr<rmm::device_uvector<size_type>> filtered_join::anti_join(table_view const& left, rmm::cuda_stream_view stream,
+                                                                         rmm::device_async_resource_ref mr) const
+{
+  if (!_impl) {  // every left row
+    auto const n = left.num_rows();
+    auto out     = std::make_unique<rmm::device_uvector<size_type>>(n, stream, mr);
+    if (n) detail::gx_check(gx_sequence_i32(out->data(), n, 0, detail::gxs(stream)), "sequence");
+    return out;
+  }
+  return _impl->semi_anti(left, true, stream, mr);
+}
+
+// ---- cudf::distinct_hash_join (include/cudf/join/distinct_hash_join.hpp:50-124; src/join/distinct_hash_join.cu)
+distinct_hash_join::~distinct_hash_join() = default;
+distinct_hash_join::distinct_hash_join(table_view const& right, null_equality compare_nulls, double load_factor,
+                                       rmm::cuda_stream_view stream)
+{
+  CUDF_EXPECTS(load_factor > 0 && load_factor <= 1,
+               "Invalid load factor: must be greater than 0 and less than or equal to 1.", std::invalid_argument);
+  CUDF_EXPECTS(0 != right.num_columns(), "Hash join build table is empty", std::invalid_argument);
+  _impl = std::make_unique<detail::hash_join_impl const>(right, nullable_join::YES, compare_nulls, load_factor, stream);
+}
+join_result distinct_hash_join::inner_join(table_view const& left, rmm::cuda_stream_view stream,
+                                           rmm::device_async_resource_ref mr) const
+{
+  return _impl->inner_join(left, {}, stream, mr);
+}
+std::unique_ptr<rmm::device_uvector<size_type>> distinct_hash_join::left_join(table_view const& left,
+                                                                              rmm::cuda_stream_view stream,
+                                                                              rmm::device_async_resource_ref mr) const
+{
+  return _impl->lookup(left, stream, mr);
 }
 
 join_result inner_join(table_view const& left_keys, table_view const& right_keys, null_equality compare_nulls,

@@ -128,6 +128,38 @@ __global__ void __launch_bounds__(256) k_first_unset(const uint32_t* mask, int64
   if (lane_id() == 0 && best < (unsigned long long)nbits) atomicMin(pos, best);
 }
 
+// dst bits [dst_begin, dst_begin + nbits) = src bits [src_begin, src_begin + nbits) (src == NULL: all 1).
+// One thread per destination word; fully covered words are plain stores, the (at most two) edge words
+// merge under a mask with atomics so that neighbouring copies into the same word compose.
+__global__ void __launch_bounds__(256) k_bitmask_copy(uint32_t* __restrict__ dst, int64_t dst_begin,
+                                                      const uint32_t* __restrict__ src, int64_t src_begin, int64_t nbits)
+{
+  const int64_t w0     = dst_begin >> 5;
+  const int64_t w1     = (dst_begin + nbits + 31) >> 5;
+  const int64_t stride = (int64_t)gridDim.x * 256;
+  for (int64_t w = w0 + (int64_t)blockIdx.x * 256 + threadIdx.x; w < w1; w += stride) {
+    const int64_t lo = (w << 5) > dst_begin ? (w << 5) : dst_begin;                                  // first dst bit of this word
+    const int64_t hi = ((w + 1) << 5) < dst_begin + nbits ? ((w + 1) << 5) : dst_begin + nbits;      // one past the last
+    const uint32_t m = (hi - lo == 32) ? 0xFFFFFFFFu : (((1u << (hi - lo)) - 1u) << (lo & 31));
+    uint32_t v       = 0xFFFFFFFFu;
+    if (src) {
+      const int64_t sb  = src_begin + (lo - dst_begin);  // source bit that lands on dst bit `lo`
+      const int64_t sw  = sb >> 5;
+      const unsigned sh = (unsigned)(sb & 31);
+      const int64_t send = (src_begin + nbits + 31) >> 5;
+      uint64_t two = src[sw];
+      if (sh && sw + 1 < send) two |= (uint64_t)src[sw + 1] << 32;
+      v = (uint32_t)(two >> sh) << (lo & 31);
+    }
+    if (m == 0xFFFFFFFFu) {
+      dst[w] = v;
+    } else {
+      atomicAnd(&dst[w], ~m);
+      atomicOr(&dst[w], v & m);
+    }
+  }
+}
+
 static inline unsigned word_grid(int64_t nwords)
 {
   int64_t b = div_up(nwords, 256 * 4);
@@ -195,6 +227,18 @@ int gx_bitmask_and(const uint32_t* const* masks_host, int nmasks, int64_t nbits,
   const int64_t nw = (nbits + 31) >> 5;
   hipLaunchKernelGGL(gx::k_bitmask_and_count, dim3(gx::word_grid(nw)), dim3(256), 0, s, ml, (int64_t)0, nbits, out,
                      reinterpret_cast<unsigned long long*>(count_dev));
+  GX_LAUNCH_CHECK();
+  return 0;
+}
+
+int gx_bitmask_copy(uint32_t* dst, int64_t dst_begin_bit, const uint32_t* src, int64_t src_begin_bit, int64_t nbits,
+                    gx_stream_t s)
+{
+  if (nbits < 0 || dst_begin_bit < 0 || src_begin_bit < 0 || (nbits > 0 && !dst)) return GX_EINVAL;
+  if (nbits == 0) return 0;
+  const int64_t nw = ((dst_begin_bit + nbits + 31) >> 5) - (dst_begin_bit >> 5);
+  hipLaunchKernelGGL(gx::k_bitmask_copy, dim3(gx::word_grid(nw)), dim3(256), 0, s, dst, dst_begin_bit, src, src_begin_bit,
+                     nbits);
   GX_LAUNCH_CHECK();
   return 0;
 }

@@ -14,6 +14,7 @@
 //     runs; the reference flushes per warp (partitioned_retrieve_kernels.cuh:57-211).
 // Result order is unspecified (cpp/include/cudf/join/join.hpp:131-134).
 #include "gx_common.hpp"
+#include "gx_scan.hpp"
 #include <cstdlib>
 
 namespace gx {
@@ -256,6 +257,139 @@ __global__ void __launch_bounds__(JBT) k_probe(const K* __restrict__ keys, const
     }
     __syncthreads();  // s_wave_tot / s_base reused by the next chunk
   }
+}
+
+// ------------------------------------------------------------------------------------------------
+// lookup / contains: the probe forms that need no output reservation.
+//   k_lookup   : out[i] = first build row with probe key i, or JoinNoMatch -- a left join against
+//                DISTINCT build keys (cudf::distinct_hash_join::left_join returns exactly this vector,
+//                distinct_hash_join.hpp:111-116), and the row -> group map of the compound groupby
+//                aggregations.
+//   k_contains : one bit per probe row (any match), plus the number of set bits per 4096-row chunk;
+//   k_emit_selected turns the bits into the ascending list of selected rows -- the reference's
+//                contains map + thrust::copy_if of filtered_join::semi_anti_join
+//                (src/join/filtered_join/filtered_join.cu:124-156), so the order matches it too.
+// ------------------------------------------------------------------------------------------------
+template <typename K>
+__device__ __forceinline__ int32_t chain_first(const Slot<K>* slots, uint64_t mask, uint32_t log2cap, K key)
+{
+  uint64_t h = slot_of<K>(key, log2cap);
+  for (;;) {
+    K k;
+    int32_t r;
+    load_slot<K>(&slots[h], k, r);
+    if (r == EMPTY_ROW) return NO_MATCH;
+    if (k == key) return r;
+    h = (h + 1) & mask;
+  }
+}
+
+template <typename K>
+__global__ void __launch_bounds__(256) k_lookup(const K* __restrict__ keys, const uint32_t* __restrict__ valid, int64_t n,
+                                                const Slot<K>* __restrict__ slots, uint32_t log2cap,
+                                                int32_t* __restrict__ out)
+{
+  const uint64_t mask  = (1ull << log2cap) - 1;
+  const int64_t stride = (int64_t)gridDim.x * 256;
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += stride) {
+    int32_t r = NO_MATCH;
+    if (!valid || bit_is_set(valid, i)) r = chain_first<K>(slots, mask, log2cap, keys[i]);
+    out[i] = r;
+  }
+}
+
+constexpr int SEL_CHUNK = 4096;  // rows per chunk of the ordered selection (256 threads x 16 wave-rows of 64)
+
+// bits[i] = (row i has a match) != invert ; null probe rows count as matching iff null_matches
+template <typename K>
+__global__ void __launch_bounds__(256) k_contains(const K* __restrict__ keys, const uint32_t* __restrict__ valid, int64_t n,
+                                                  const Slot<K>* __restrict__ slots, uint32_t log2cap, int invert,
+                                                  int null_matches, uint64_t* __restrict__ bits,
+                                                  long long* __restrict__ chunk_count)
+{
+  __shared__ unsigned int s_cnt;
+  const uint64_t mask = (1ull << log2cap) - 1;
+  const unsigned lane = lane_id();
+  const unsigned w    = threadIdx.x / GX_WAVE;
+  if (threadIdx.x == 0) s_cnt = 0;
+  __syncthreads();
+  const int64_t base = (int64_t)blockIdx.x * SEL_CHUNK;
+  unsigned int mine  = 0;
+  for (int k = 0; k < SEL_CHUNK / 256; ++k) {
+    const int64_t i = base + (int64_t)(k * 4 + w) * GX_WAVE + lane;  // wave w takes wave-rows w, w+4, ...
+    bool sel        = false;
+    if (i < n) {
+      const bool ok = !valid || bit_is_set(valid, i);
+      const bool m  = ok ? chain_first<K>(slots, mask, log2cap, keys[i]) != NO_MATCH : (null_matches != 0);
+      sel           = m != (invert != 0);
+    }
+    const uint64_t b = ballot(sel);
+    if (lane == 0 && base + (int64_t)(k * 4 + w) * GX_WAVE < n) {
+      bits[(base >> 6) + (k * 4 + w)] = b;
+      mine += (unsigned int)__builtin_popcountll(b);
+    }
+  }
+  if (lane == 0 && mine) atomicAdd(&s_cnt, mine);
+  __syncthreads();
+  if (threadIdx.x == 0) chunk_count[blockIdx.x] = s_cnt;
+}
+
+__global__ void __launch_bounds__(256) k_emit_selected(const uint64_t* __restrict__ bits, int64_t n,
+                                                       const long long* __restrict__ chunk_start,
+                                                       int32_t* __restrict__ out, long long* count_out, int64_t nchunks)
+{
+  __shared__ unsigned int s_row[SEL_CHUNK / GX_WAVE + 1];
+  const int64_t base   = (int64_t)blockIdx.x * SEL_CHUNK;
+  const int64_t nwords = div_up(n, (int64_t)GX_WAVE);
+  // exclusive popcount scan of the chunk's 64 words (one wave does it)
+  if (threadIdx.x < GX_WAVE) {
+    const int64_t wi     = (base >> 6) + threadIdx.x;
+    const unsigned int c = wi < nwords ? (unsigned int)__builtin_popcountll(bits[wi]) : 0u;
+    const unsigned int s = wave_inclusive_scan(c, SumOp());
+    s_row[threadIdx.x]   = s - c;
+  }
+  __syncthreads();
+  const unsigned lane      = lane_id();
+  const unsigned w         = threadIdx.x / GX_WAVE;
+  const long long start    = chunk_start[blockIdx.x];
+  for (int k = w; k < SEL_CHUNK / GX_WAVE; k += 256 / GX_WAVE) {
+    const int64_t wi = (base >> 6) + k;
+    if (wi >= nwords) break;
+    const uint64_t b = bits[wi];
+    if ((b >> lane) & 1ull) out[start + s_row[k] + __builtin_popcountll(b & lanemask_lt())] = (int32_t)(base + (int64_t)k * GX_WAVE + lane);
+  }
+  if (blockIdx.x == 0 && threadIdx.x == 0 && count_out) *count_out = chunk_start[nchunks];
+}
+
+template <typename K>
+int filter_impl(const void* keys, const uint32_t* valid, int64_t n, const void* table, size_t table_bytes, uint32_t lg,
+                int anti, int null_matches, int32_t* out_idx, int64_t* count_dev, void* tmp, size_t* tmp_bytes,
+                hipStream_t s)
+{
+  const int64_t nchunks = div_up(n, (int64_t)SEL_CHUNK);
+  Carver c(tmp);
+  uint64_t* bits  = c.take<uint64_t>((size_t)div_up(n, (int64_t)GX_WAVE) + 1);
+  long long* part = c.take<long long>((size_t)nchunks + 1);
+  if (!tmp) {
+    *tmp_bytes = c.total();
+    return 0;
+  }
+  if (*tmp_bytes < c.total()) return GX_ETMP;
+  const size_t need = sizeof(TableHeader) + (sizeof(Slot<K>) << lg);
+  if (table_bytes < need) return GX_ETMP;
+  if (n == 0) {
+    if (count_dev) GX_HIP_TRY(hipMemsetAsync(count_dev, 0, sizeof(int64_t), s));
+    return 0;
+  }
+  const Slot<K>* slots = reinterpret_cast<const Slot<K>*>(static_cast<const char*>(table) + sizeof(TableHeader));
+  hipLaunchKernelGGL((k_contains<K>), dim3((unsigned)nchunks), dim3(256), 0, s, static_cast<const K*>(keys), valid, n, slots,
+                     lg, anti, null_matches, bits, part);
+  hipLaunchKernelGGL((scan::k_partials_scan<long long, SumOp>), dim3(1), dim3(1024), 0, s, part, nchunks, 0ll, SumOp(),
+                     (const int*)nullptr);
+  hipLaunchKernelGGL(k_emit_selected, dim3((unsigned)nchunks), dim3(256), 0, s, bits, n, part, out_idx,
+                     reinterpret_cast<long long*>(count_dev), nchunks);
+  GX_LAUNCH_CHECK();
+  return 0;
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -1126,6 +1260,47 @@ int gx_join_probe_partitioned(int key_size, const void* probe_keys, int64_t prob
   if (key_size == 4)
     return gx::join::probe_partitioned_impl<uint32_t>(probe_keys, probe_rows, table, table_bytes, lg, left_outer, out_probe_idx,
                                                       out_build_idx, capacity, cursor_dev, tmp, tmp_bytes, s);
+  return GX_EDTYPE;
+}
+
+int gx_join_lookup(int key_size, const void* probe_keys, const uint32_t* probe_valid, int64_t probe_rows,
+                   const void* table, size_t table_bytes, int32_t* out_build_idx, gx_stream_t s)
+{
+  if (probe_rows < 0 || (probe_rows > 0 && (!probe_keys || !out_build_idx)) || !table) return GX_EINVAL;
+  if (table_bytes <= sizeof(gx::join::TableHeader)) return GX_ETMP;
+  if (probe_rows == 0) return 0;
+  const uint32_t lg = gx_join_log2_from_bytes(key_size, table_bytes);
+  int64_t blocks    = gx::div_up(probe_rows, (int64_t)256 * 4);
+  if (blocks > 16384) blocks = 16384;
+  const char* base = static_cast<const char*>(table) + sizeof(gx::join::TableHeader);
+  if (key_size == 8)
+    hipLaunchKernelGGL((gx::join::k_lookup<uint64_t>), dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)s,
+                       static_cast<const uint64_t*>(probe_keys), probe_valid, probe_rows,
+                       reinterpret_cast<const gx::join::Slot<uint64_t>*>(base), lg, out_build_idx);
+  else if (key_size == 4)
+    hipLaunchKernelGGL((gx::join::k_lookup<uint32_t>), dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)s,
+                       static_cast<const uint32_t*>(probe_keys), probe_valid, probe_rows,
+                       reinterpret_cast<const gx::join::Slot<uint32_t>*>(base), lg, out_build_idx);
+  else
+    return GX_EDTYPE;
+  GX_LAUNCH_CHECK();
+  return 0;
+}
+
+int gx_join_filter(int key_size, const void* probe_keys, const uint32_t* probe_valid, int64_t probe_rows,
+                   const void* table, size_t table_bytes, int anti, int null_matches, int32_t* out_probe_idx,
+                   int64_t* count_dev, void* tmp, size_t* tmp_bytes, gx_stream_t s)
+{
+  if (!tmp_bytes || probe_rows < 0) return GX_EINVAL;
+  if (tmp && (!table || !count_dev || (probe_rows > 0 && (!probe_keys || !out_probe_idx)))) return GX_EINVAL;
+  if (tmp && table_bytes <= sizeof(gx::join::TableHeader)) return GX_ETMP;
+  const uint32_t lg = tmp ? gx_join_log2_from_bytes(key_size, table_bytes) : 0;
+  if (key_size == 8)
+    return gx::join::filter_impl<uint64_t>(probe_keys, probe_valid, probe_rows, table, table_bytes, lg, anti, null_matches,
+                                           out_probe_idx, count_dev, tmp, tmp_bytes, (hipStream_t)s);
+  if (key_size == 4)
+    return gx::join::filter_impl<uint32_t>(probe_keys, probe_valid, probe_rows, table, table_bytes, lg, anti, null_matches,
+                                           out_probe_idx, count_dev, tmp, tmp_bytes, (hipStream_t)s);
   return GX_EDTYPE;
 }
 

@@ -91,40 +91,56 @@ class DataFrame:
             order = perm if order is None else ops.gather(order, perm)
         return self._take(order)
 
-    def merge(self, right: "DataFrame", on: str, how: str = "inner", suffixes=("_x", "_y")) -> "DataFrame":
-        """Equi-join on one key column; how in {"inner", "left"}.  Row order is unspecified (as in
-        cudf); callers that need an order sort afterwards."""
-        if how not in ("inner", "left"):
+    def merge(self, right: "DataFrame", on: Union[str, Sequence[str]], how: str = "inner",
+              suffixes=("_x", "_y")) -> "DataFrame":
+        """Equi-join on one or several key columns; how in {"inner", "left", "leftsemi", "leftanti"}.
+        Row order is unspecified for inner / left (as in cudf); leftsemi / leftanti keep the left order."""
+        if how not in ("inner", "left", "leftsemi", "leftanti"):
             raise NotImplementedError(f"merge(how={how!r}) is not on this path yet")
-        lk, rk = self._cols[on], right._cols[on]
+        on = [on] if isinstance(on, str) else list(on)
+        lt, rt = [self._cols[k] for k in on], [right._cols[k] for k in on]
+        if how in ("leftsemi", "leftanti"):
+            if len(on) == 1:
+                lk, rk = lt[0], rt[0]
+            else:
+                lk, rk = ops.encode_rows([lt, rt], nulls_equal=False)
+            fn = ops.left_semi_join if how == "leftsemi" else ops.left_anti_join
+            return self._take(fn(lk, rk, nulls_equal=False))
         if how == "inner":
-            li, ri = ops.inner_join(lk, rk, nulls_equal=False)
+            li, ri = ops.inner_join_tables(lt, rt, nulls_equal=False)
         else:
-            li, ri = ops.left_join(lk, rk, nulls_equal=False)
+            li, ri = ops.left_join_tables(lt, rt, nulls_equal=False)
         out = DataFrame()
-        out._cols[on] = ops.gather(lk, li)
+        for k, c in zip(on, lt):
+            out._cols[k] = ops.gather(c, li)
         for name, c in self._cols.items():
-            if name != on:
+            if name not in on:
                 out._cols[name + (suffixes[0] if name in right._cols else "")] = ops.gather(c, li)
         for name, c in right._cols.items():
-            if name != on:
+            if name not in on:
                 out._cols[name + (suffixes[1] if name in self._cols else "")] = ops.gather(c, ri, nullify_out_of_bounds=(how == "left"))
         return out
 
-    def groupby(self, by: str) -> "GroupBy":
+    def groupby(self, by: Union[str, Sequence[str]]) -> "GroupBy":
         return GroupBy(self, by)
 
 
 class GroupBy:
     _SUPPORTED = ("sum", "count", "mean", "min", "max")
 
-    def __init__(self, df: DataFrame, by: str):
-        self._df, self._by = df, by
+    def __init__(self, df: DataFrame, by: Union[str, Sequence[str]]):
+        self._df, self._by = df, ([by] if isinstance(by, str) else list(by))
 
     def agg(self, spec: Dict[str, Union[str, Sequence[str]]]) -> DataFrame:
         """{value column: "sum" | "count" | "mean" | "min" | "max" | [..]} -> one row per group, sorted by key
         (pandas' default sort=True).  Null keys are dropped (dropna=True), null values are skipped."""
-        keys = self._df[self._by]
+        by = self._by
+        k0 = self._df[by[0]]
+        rep = None
+        if len(by) == 1 and k0.dtype.kind in "iu" and k0.dtype.itemsize in (4, 8):
+            keys = k0
+        else:  # several key columns / floats / narrow types: dense row ids, ascending in key order
+            keys, rep, _ = ops.groupby_keys_tables([self._df[b] for b in by])
         out = DataFrame()
         first = True
         for name, fns in spec.items():
@@ -135,7 +151,13 @@ class GroupBy:
             k, s, cv, _ = ops.groupby_sum_count(keys, self._df[name])
             order = ops.sorted_order(k)
             if first:
-                out._cols[self._by] = ops.gather(k, order)
+                kk = ops.gather(k, order)
+                if rep is None:
+                    out._cols[by[0]] = kk
+                else:
+                    rows = ops.gather(rep, kk)
+                    for b in by:
+                        out._cols[b] = ops.gather(self._df[b], rows)
                 first = False
             s, cv = ops.gather(s, order), ops.gather(cv, order)
             mn = mx = None

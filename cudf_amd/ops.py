@@ -228,6 +228,55 @@ class HashJoin:
         return lo, ro
 
 
+    def lookup(self, left: Column) -> Column:
+        """cudf::distinct_hash_join::left_join (distinct_hash_join.hpp:96-116): for DISTINCT build keys,
+        the build row matching each left row, in left order, JoinNoMatch (INT32_MIN) where there is none.
+        (With duplicate build keys it returns one of the matching rows.)"""
+        self._check(left)
+        out = Column.empty(np.int32, left.size)
+        if left.size == 0:
+            return out
+        if self.build.size == 0:
+            out.data[: left.size * 4].view(torch.int32).fill_(-(2 ** 31))
+            return out
+        valid = left.mask_ptr if left.has_nulls() else None
+        L.check(_lib.gx_join_lookup(self.key_size, left.data_ptr, valid, left.size, ptr(self.table), self.table_bytes,
+                                    out.data_ptr, stream_ptr()), "gx_join_lookup")
+        if self.nulls_equal and left.has_nulls() and self.build.has_nulls():
+            # null == null: every null left row matches the (single, keys are distinct) null build row
+            rv = int(np.nonzero(~self.build.valid_numpy())[0][0])
+            lv = torch.from_numpy(~left.valid_numpy()).cuda()
+            out.data[: left.size * 4].view(torch.int32)[lv] = rv
+        return out
+
+    def _filter(self, left: Column, anti: bool) -> Column:
+        self._check(left)
+        out = Column.empty(np.int32, left.size)
+        if left.size == 0:
+            return out
+        if self.build.size == 0:  # nothing can match
+            if anti:
+                out.data[: left.size * 4].view(torch.int32).copy_(torch.arange(left.size, dtype=torch.int32, device="cuda"))
+            else:
+                out.size = 0
+            return out
+        cnt = _dev_i64()
+        valid = left.mask_ptr if left.has_nulls() else None
+        null_matches = int(self.nulls_equal and self.build.has_nulls())
+        _run(_lib.gx_join_filter, self.key_size, left.data_ptr, valid, left.size, ptr(self.table), self.table_bytes,
+             int(anti), null_matches, out.data_ptr, ptr(cnt))
+        out.size = int(cnt.item())
+        return out
+
+    def semi_join(self, left: Column) -> Column:
+        """cudf::filtered_join::semi_join (filtered_join.hpp:96-116): ascending left rows with a match."""
+        return self._filter(left, False)
+
+    def anti_join(self, left: Column) -> Column:
+        """cudf::filtered_join::anti_join (filtered_join.hpp:118-139): ascending left rows without a match."""
+        return self._filter(left, True)
+
+
 def _append_null_cross(lo: Column, ro: Column, left: Column, right: Column):
     """null_equality::EQUAL for a single nullable key: every null left row matches every null
     right row.  Rare path, assembled with torch index ops on the device."""
@@ -253,10 +302,177 @@ def inner_join(left: Column, right: Column, nulls_equal: bool = True) -> Tuple[C
     return HashJoin(right, nulls_equal).inner_join(left)
 
 
+def left_semi_join(left: Column, right: Column, nulls_equal: bool = True) -> Column:
+    if left.dtype != right.dtype:
+        raise TypeError("Mismatch in joining column data types")
+    return HashJoin(right, nulls_equal).semi_join(left)
+
+
+def left_anti_join(left: Column, right: Column, nulls_equal: bool = True) -> Column:
+    if left.dtype != right.dtype:
+        raise TypeError("Mismatch in joining column data types")
+    return HashJoin(right, nulls_equal).anti_join(left)
+
+
 def left_join(left: Column, right: Column, nulls_equal: bool = True) -> Tuple[Column, Column]:
     if left.dtype != right.dtype:
         raise TypeError("Mismatch in joining column data types")
     return HashJoin(right, nulls_equal).left_join(left)
+
+
+# ------------------------------------------------------------------------------------------------
+# multi-column keys: rows -> one fixed-width key  (gx_pack_keys / gx_dense_rank; the reference compares
+# whole rows inside its hash tables: detail/row_operator/primitive_row_operators.cuh:207-274)
+# ------------------------------------------------------------------------------------------------
+
+def pack_keys(cols: Sequence[Column]) -> Column:
+    """Concatenate columns whose widths sum to <= 8 bytes into one uint64 key column (no nulls)."""
+    n = cols[0].size
+    out = Column.empty(np.uint64, n)
+    ptrs = (ctypes.c_void_p * len(cols))(*[c.data_ptr.value or 0 for c in cols])
+    dts = (ctypes.c_int * len(cols))(*[c.gx for c in cols])
+    L.check(_lib.gx_pack_keys(len(cols), ptrs, dts, n, out.data_ptr, stream_ptr()), "gx_pack_keys")
+    return out
+
+
+def dense_rank(col: Column):
+    """(ids int32 column, first row of every id, number of ids): equal values share an id, null == null
+    has its own id (last), ids ascend with the value."""
+    n = col.size
+    ids, rep = Column.empty(np.int32, n), Column.empty(np.int32, n)
+    ng = _dev_i64()
+    _run(_lib.gx_dense_rank, col.gx, col.data_ptr, col.mask_ptr if col.has_nulls() else None, n,
+         col.null_count if col.has_nulls() else 0, ids.data_ptr, rep.data_ptr, ptr(ng))
+    g = int(ng.item())
+    rep.size = g
+    return ids, rep, g
+
+
+def _and_masks(cols: Sequence[Column], n: int):
+    """(mask words tensor or None, null count) of the AND of the columns' validity."""
+    masks = [c for c in cols if c.has_nulls()]
+    if not masks:
+        return None, 0
+    out = torch.zeros(bitmask_words(n), dtype=torch.int32, device="cuda")
+    arr = (ctypes.c_void_p * len(masks))(*[c.mask_ptr.value for c in masks])
+    cnt = _dev_i64()
+    L.check(_lib.gx_bitmask_and(arr, len(masks), n, ptr(out), ptr(cnt), stream_ptr()), "gx_bitmask_and")
+    return out, n - int(cnt.item())
+
+
+def concat_columns(a: Column, b: Column) -> Column:
+    """cudf::concatenate of two columns of one type (data memcpy + gx_bitmask_copy for the validity)."""
+    if a.dtype != b.dtype:
+        raise TypeError("Mismatch in joining column data types")
+    n = a.size + b.size
+    if n > 2**31 - 1:
+        raise OverflowError("concatenated key columns exceed cudf::size_type")
+    w = a.dtype.itemsize
+    out = Column.empty(a.dtype, n, nullable=a.has_nulls() or b.has_nulls())
+    out.data[: a.size * w].copy_(a.data[: a.size * w])
+    out.data[a.size * w: n * w].copy_(b.data[: b.size * w])
+    if out.mask is not None:
+        L.check(_lib.gx_bitmask_copy(ptr(out.mask), 0, a.mask_ptr if a.has_nulls() else None, 0, a.size, stream_ptr()),
+                "gx_bitmask_copy")
+        L.check(_lib.gx_bitmask_copy(ptr(out.mask), a.size, b.mask_ptr if b.has_nulls() else None, 0, b.size,
+                                     stream_ptr()), "gx_bitmask_copy")
+        out.null_count = a.null_count + b.null_count
+    return out
+
+
+def _slice_rows(col: Column, begin: int, end: int) -> Column:
+    """Rows [begin, end) of a column WITHOUT nulls as a new column sharing no storage."""
+    w = col.dtype.itemsize
+    out = Column.empty(col.dtype, end - begin)
+    out.data[: (end - begin) * w].copy_(col.data[begin * w: end * w])
+    return out
+
+
+def encode_rows(tables: Sequence[Sequence[Column]], nulls_equal: bool = True, dense: bool = False):
+    """Encode the rows of 1 or 2 tables (same schema) into ONE key column per table such that two rows
+    get equal keys iff they compare equal column by column (null == null, NaN == NaN, -0.0 == +0.0).
+    Rows holding a null are marked null in the result when nulls_equal is False (they can then match
+    nothing).  dense=True (one table): keys are dense int32 ids; also returns (first row per id, #ids).
+
+    Path 1 (widths sum to <= 8 bytes, no nulls): gx_pack_keys, exact, one streaming pass.
+    Path 2: every column -> dense ids over the CONCATENATION of the tables (so ids agree across them),
+    then (ids so far, next column's ids) pairs are packed and ranked again."""
+    ncols = len(tables[0])
+    for t in tables[1:]:
+        if len(t) != ncols:
+            raise ValueError("Mismatch in number of columns to be joined on")
+        for a, b in zip(tables[0], t):
+            if a.dtype != b.dtype:
+                raise TypeError("Mismatch in joining column data types")
+    sizes = [t[0].size for t in tables]
+    any_nulls = any(c.has_nulls() for t in tables for c in t)
+    width = sum(c.dtype.itemsize for c in tables[0])
+    if width <= 8 and not any_nulls and not dense:
+        return [pack_keys(t) for t in tables]
+    # ---- one tall table
+    if len(tables) == 2:
+        cols = [concat_columns(a, b) for a, b in zip(tables[0], tables[1])]
+    else:
+        cols = list(tables[0])
+    n = cols[0].size
+    if width <= 8 and not any_nulls:
+        ids, rep, g = dense_rank(pack_keys(cols))
+    else:
+        def as32(c):  # a column the pair-packing can take as it is: 4 bytes, no nulls, bitwise equality
+            return c if (c.dtype.itemsize == 4 and not c.has_nulls() and c.dtype.kind in "iu") else dense_rank(c)[0]
+        cur = None
+        ids = rep = None
+        g = 0
+        for k, c in enumerate(cols):
+            if cur is None:
+                if ncols == 1:
+                    ids, rep, g = dense_rank(c)
+                cur = as32(c) if ncols > 1 else ids
+                continue
+            pair = pack_keys([cur, as32(c)])
+            if k == ncols - 1 and not dense:
+                ids = pair           # the last packing need not be dense
+            else:
+                ids, rep, g = dense_rank(pair)
+                cur = ids
+    mask, nulls = (None, 0) if nulls_equal else _and_masks(cols, n)
+    outs = []
+    begin = 0
+    for sz in sizes:
+        o = _slice_rows(ids, begin, begin + sz) if len(sizes) > 1 else ids
+        if mask is not None:
+            words = torch.zeros(bitmask_words(sz), dtype=torch.int32, device="cuda")
+            L.check(_lib.gx_bitmask_copy(ptr(words), 0, ptr(mask), begin, sz, stream_ptr()), "gx_bitmask_copy")
+            cnt = _dev_i64()
+            L.check(_lib.gx_bitmask_count(ptr(words), 0, sz, ptr(cnt), stream_ptr()), "gx_bitmask_count")
+            o.mask, o.null_count = words, sz - int(cnt.item())
+        outs.append(o)
+        begin += sz
+    if dense:
+        return outs[0], rep, g
+    return outs
+
+
+def inner_join_tables(left: Sequence[Column], right: Sequence[Column], nulls_equal: bool = True):
+    """cudf::inner_join on key TABLES (join.hpp:160-166): rows are encoded, then the single-key join."""
+    if len(left) == 1 and len(right) == 1:
+        return inner_join(left[0], right[0], nulls_equal)
+    lk, rk = encode_rows([left, right], nulls_equal)
+    return inner_join(lk, rk, nulls_equal)
+
+
+def left_join_tables(left: Sequence[Column], right: Sequence[Column], nulls_equal: bool = True):
+    if len(left) == 1 and len(right) == 1:
+        return left_join(left[0], right[0], nulls_equal)
+    lk, rk = encode_rows([left, right], nulls_equal)
+    return left_join(lk, rk, nulls_equal)
+
+
+def groupby_keys_tables(keys: Sequence[Column]):
+    """Multi-column groupby keys -> (dense int32 id column with the rows holding a null key marked
+    null, first row of every id, number of ids): aggregate by id, gather the key columns by first row."""
+    ids, rep, g = encode_rows([keys], nulls_equal=False, dense=True)
+    return ids, rep, g
 
 
 # ------------------------------------------------------------------------------------------------
@@ -291,6 +507,21 @@ def groupby_sum_count(keys: Column, values: Column, max_groups_hint: int = 1 << 
     for c in (ok, osum, ocv, oca):
         c.size = g
     return ok, osum, ocv, oca
+
+
+def groupby_sum_count_tables(keys: Sequence[Column], values: Column):
+    """groupby(keys = several columns).agg(SUM, COUNT_VALID, COUNT_ALL): rows -> dense ids
+    (gx_dense_rank), aggregate by id, gather the key columns by the first row of every id.
+    Returns ([key columns], sum, count_valid, count_all); rows with a null in any key are dropped."""
+    if len(keys) == 1 and keys[0].dtype.itemsize in (4, 8) and keys[0].dtype.kind in "iu":
+        k, s, cv, ca = groupby_sum_count(keys[0], values)
+        return [k], s, cv, ca
+    if keys[0].size != values.size:
+        raise RuntimeError("Size mismatch between request values and groupby keys.")
+    ids, rep, g = groupby_keys_tables(keys)
+    ok, s, cv, ca = groupby_sum_count(ids, values, max_groups_hint=max(g, 1))
+    rows = gather(rep, ok)  # id -> its first row
+    return [gather(k, rows) for k in keys], s, cv, ca
 
 
 def groupby_min_max(keys: Column, values: Column, max_groups_hint: int = 1 << 20):

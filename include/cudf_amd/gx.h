@@ -154,6 +154,11 @@ int gx_bitmask_set(uint32_t* mask, int64_t begin_bit, int64_t end_bit, int valid
 /* *count_dev (device int64) = number of set bits in [begin_bit, end_bit) */
 int gx_bitmask_count(const uint32_t* mask, int64_t begin_bit, int64_t end_bit, int64_t* count_dev,
                      gx_stream_t stream);
+/* dst bits [dst_begin_bit, +nbits) = src bits [src_begin_bit, +nbits); src == NULL writes 1s.  The
+ * building block of cudf::copy_bitmask (src/bitmask/null_mask.cu:357-390) and concatenate_masks
+ * (src/copying/concatenate.cu:111-170); bits of dst outside the range are preserved. */
+int gx_bitmask_copy(uint32_t* dst, int64_t dst_begin_bit, const uint32_t* src, int64_t src_begin_bit,
+                    int64_t nbits, gx_stream_t stream);
 /* out = AND of `nmasks` bitmaps (host array of device pointers; NULL entries = all valid),
  * nbits bits each; *count_dev (optional) = set bits of the result */
 int gx_bitmask_and(const uint32_t* const* masks_host, int nmasks, int64_t nbits, uint32_t* out,
@@ -176,6 +181,31 @@ int gx_murmur3_32(int dtype, const void* in, const uint32_t* valid, int64_t n, u
 int gx_hash_partition_map(const uint32_t* row_hash, int64_t n, int num_partitions,
                           int32_t* out_map, int32_t* out_offsets, void* tmp, size_t* tmp_bytes,
                           gx_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------
+ * Row-key encoding for multi-column join / groupby keys.  The reference hashes and compares whole
+ * rows inside its tables (include/cudf/detail/row_operator/primitive_row_operators.cuh:95-163,
+ * 207-274); here a row is encoded into ONE fixed-width key first (cf. the reference's own
+ * include/cudf/join/key_remapping.hpp) and the single-key kernels below do the rest.
+ *
+ * gx_pack_keys: out[i] = the ncols (<= 8) column values of row i concatenated into a uint64 (column 0
+ *   most significant; widths must sum to <= 8 bytes, else GX_EINVAL).  FLOAT32/64 columns are
+ *   normalised (-0.0 -> +0.0, every NaN -> one NaN): the row comparator's equality classes
+ *   (detail/row_operator/common_utils.cuh:215-220).  `cols` / `dtypes` are HOST arrays.
+ * gx_dense_rank: out_ids[i] in [0, G) with equal values sharing an id (null == null has its own id,
+ *   floats compared as above), ids ascending with the value, nulls last; out_rep[g] (optional, n
+ *   entries) = the smallest row of id g; *out_ngroups_dev = G.  sorted_order + adjacent difference +
+ *   scan + scatter.  cub-style scratch query.
+ * ------------------------------------------------------------------------------------------ */
+int gx_pack_keys(int ncols, const void* const* cols, const int* dtypes, int64_t n, uint64_t* out,
+                 gx_stream_t stream);
+int gx_dense_rank(int dtype, const void* keys, const uint32_t* valid, int64_t n, int64_t null_count,
+                  int32_t* out_ids, int32_t* out_rep, int64_t* out_ngroups_dev, void* tmp,
+                  size_t* tmp_bytes, gx_stream_t stream);
+/* data[i] = value_bits (low elem_size bytes) for every row whose validity bit is 0 -- cudf::replace_nulls
+ * with a scalar (src/replace/nulls.cu), in place; valid == NULL: no-op. */
+int gx_fill_nulls(int elem_size, void* data, const uint32_t* valid, int64_t n, uint64_t value_bits,
+                  gx_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------
  * Hash join (single fixed-width key column of 4 or 8 bytes; multi-column keys are packed or
@@ -228,6 +258,22 @@ int gx_join_build_partitioned(int key_size, const void* build_keys, int64_t buil
                               gx_stream_t stream);
 /* log2 of the number of partitions the partitioned probe uses for this table; 0 = not partitionable */
 int gx_join_partition_bits(int key_size, size_t table_bytes);
+
+/* out_build_idx[i] = the first build row whose key equals probe key i, or INT32_MIN (JoinNoMatch) --
+ * the left join against DISTINCT build keys, in probe order and without an output reservation:
+ * cudf::distinct_hash_join::left_join (include/cudf/join/distinct_hash_join.hpp:111-116,
+ * src/join/distinct_hash_join.cu).  Null probe rows (validity bit 0) get JoinNoMatch. */
+int gx_join_lookup(int key_size, const void* probe_keys, const uint32_t* probe_valid, int64_t probe_rows,
+                   const void* table, size_t table_bytes, int32_t* out_build_idx, gx_stream_t stream);
+/* Left semi (anti == 0) / left anti (anti != 0) join: the ASCENDING list of probe rows that have
+ * (have no) match in the table, *count_dev = its length -- the contains map + stable copy_if of
+ * cudf::filtered_join::semi_join / anti_join (src/join/filtered_join/filtered_join.cu:124-156).
+ * Null probe rows count as matching iff null_matches != 0 (null_equality::EQUAL and the build side
+ * holds a null).  out_probe_idx needs room for probe_rows entries.  cub-style scratch query. */
+int gx_join_filter(int key_size, const void* probe_keys, const uint32_t* probe_valid, int64_t probe_rows,
+                   const void* table, size_t table_bytes, int anti, int null_matches,
+                   int32_t* out_probe_idx, int64_t* count_dev, void* tmp, size_t* tmp_bytes,
+                   gx_stream_t stream);
 
 /* cudf::full_join's complement step (src/join/join_utils.cu:86-157): appends (JoinNoMatch, r) for
  * every build row r in [0, build_rows) that does not occur in build_idx[0..n) to the pair arrays,

@@ -373,6 +373,35 @@ def full_join(left_cols, right_cols, left_valids=None, right_valids=None, nulls_
                            np.concatenate([r, un]))
 
 
+def semi_join(left_cols, right_cols, left_valids=None, right_valids=None, nulls_equal=True) -> np.ndarray:
+    """cudf::filtered_join::semi_join: ascending indices of the left rows that have at least one
+    match in right (contains map + stable copy_if: cpp/src/join/filtered_join/filtered_join.cu:124-156;
+    include/cudf/join/filtered_join.hpp:96-116)."""
+    l, _ = inner_join(left_cols, right_cols, left_valids, right_valids, nulls_equal)
+    return np.unique(l).astype(np.int32)
+
+
+def anti_join(left_cols, right_cols, left_valids=None, right_valids=None, nulls_equal=True) -> np.ndarray:
+    """cudf::filtered_join::anti_join: ascending indices of the left rows with no match in right
+    (filtered_join.hpp:118-139); with an empty right table every left row."""
+    lc = left_cols if isinstance(left_cols, (list, tuple)) else [left_cols]
+    nl = len(lc[0])
+    keep = np.ones(nl, bool)
+    keep[semi_join(left_cols, right_cols, left_valids, right_valids, nulls_equal)] = False
+    return np.nonzero(keep)[0].astype(np.int32)
+
+
+def distinct_left_join(left_cols, right_cols, left_valids=None, right_valids=None, nulls_equal=True) -> np.ndarray:
+    """cudf::distinct_hash_join::left_join (include/cudf/join/distinct_hash_join.hpp:96-116): right
+    holds distinct keys; result[i] = the right row matching left row i, or JoinNoMatch."""
+    lc = left_cols if isinstance(left_cols, (list, tuple)) else [left_cols]
+    nl = len(lc[0])
+    l, r = inner_join(left_cols, right_cols, left_valids, right_valids, nulls_equal)
+    out = np.full(nl, JOIN_NO_MATCH, np.int32)
+    out[l] = r
+    return out
+
+
 # ----------------------------------------------------------------------------------------------
 # groupby (SURVEY §8 a10-a12)
 # ----------------------------------------------------------------------------------------------

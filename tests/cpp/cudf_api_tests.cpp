@@ -7,6 +7,8 @@
 #include <cudf/copying.hpp>
 #include <cudf/groupby.hpp>
 #include <cudf/hashing.hpp>
+#include <cudf/join/distinct_hash_join.hpp>
+#include <cudf/join/filtered_join.hpp>
 #include <cudf/join/hash_join.hpp>
 #include <cudf/join/join.hpp>
 #include <cudf/reduction.hpp>
@@ -279,6 +281,136 @@ int main()
     std::sort(idx.begin(), idx.end(), [&](int a, int b) { return k[a] < k[b]; });
     return std::make_pair(k, idx);
   };
+  run("filtered_join semi / anti (semi_anti_join_tests.cpp:119-136,357-421)", [] {
+    auto l = make_col<int32_t>({0, 1, 2});
+    auto r = make_col<int32_t>({0, 1, 3});
+    filtered_join fj{table_view{{r->view()}}, null_equality::EQUAL, get_default_stream()};
+    CHECK((to_host(*fj.semi_join(table_view{{l->view()}})) == std::vector<size_type>{0, 1}));
+    CHECK((to_host(*fj.anti_join(table_view{{l->view()}})) == std::vector<size_type>{2}));
+    // empty right table (no columns): semi -> nothing, anti -> every left row; empty left -> nothing
+    filtered_join fe{table_view{}, null_equality::EQUAL, get_default_stream()};
+    CHECK(fe.semi_join(table_view{{l->view()}})->size() == 0);
+    CHECK((to_host(*fe.anti_join(table_view{{l->view()}})) == std::vector<size_type>{0, 1, 2}));
+    auto e = make_col<int32_t>({});
+    CHECK(fj.semi_join(table_view{{e->view()}})->size() == 0);
+    CHECK(fj.anti_join(table_view{{e->view()}})->size() == 0);
+    CHECK(throws<std::invalid_argument>([&] { filtered_join bad{table_view{{r->view()}}, null_equality::EQUAL, 0.0, get_default_stream()}; }));
+    // nulls: a null left row matches a null right row only under EQUAL
+    auto ln = make_col<int64_t>({5, 7, 9, 1}, {1, 0, 1, 1});
+    auto rn = make_col<int64_t>({9, 4, 5}, {1, 0, 1});
+    filtered_join feq{table_view{{rn->view()}}, null_equality::EQUAL, get_default_stream()};
+    CHECK((to_host(*feq.semi_join(table_view{{ln->view()}})) == std::vector<size_type>{0, 1, 2}));
+    CHECK((to_host(*feq.anti_join(table_view{{ln->view()}})) == std::vector<size_type>{3}));
+    filtered_join fne{table_view{{rn->view()}}, null_equality::UNEQUAL, get_default_stream()};
+    CHECK((to_host(*fne.semi_join(table_view{{ln->view()}})) == std::vector<size_type>{0, 2}));
+    CHECK((to_host(*fne.anti_join(table_view{{ln->view()}})) == std::vector<size_type>{1, 3}));
+    // two key columns
+    auto l0 = make_col<int32_t>({3, 1, 2, 0, 3}), l1 = make_col<int32_t>({0, 1, 2, 4, 1});
+    auto r0 = make_col<int32_t>({2, 2, 0, 4, 3}), r1 = make_col<int32_t>({1, 0, 1, 2, 1});
+    filtered_join f2{table_view{{r0->view(), r1->view()}}, null_equality::EQUAL, get_default_stream()};
+    CHECK((to_host(*f2.semi_join(table_view{{l0->view(), l1->view()}})) == std::vector<size_type>{4}));
+    CHECK((to_host(*f2.anti_join(table_view{{l0->view(), l1->view()}})) == std::vector<size_type>{0, 1, 2, 3}));
+  });
+  run("distinct_hash_join (distinct_join_tests.cpp:74-93,185-225,541-575,614-649)", [] {
+    // IntegerInnerJoin: right = 0..2023, left = 0,2,...,4046
+    std::vector<int32_t> rv(2024), lv(2024);
+    std::iota(rv.begin(), rv.end(), 0);
+    for (int i = 0; i < 2024; ++i) lv[i] = 2 * i;
+    auto r = make_col<int32_t>(rv);
+    auto l = make_col<int32_t>(lv);
+    distinct_hash_join dj{table_view{{r->view()}}};
+    auto p = sorted_pairs(dj.inner_join(table_view{{l->view()}}));
+    CHECK(p.size() == 1012);
+    for (int i = 0; i < 1012; ++i) CHECK(p[i].first == i && p[i].second == 2 * i);
+    // PrimitiveLeftJoinNoNulls: two int32 key columns
+    auto l0 = make_col<int32_t>({3, 1, 2, 0, 3}), l1 = make_col<int32_t>({0, 1, 2, 4, 1});
+    auto r0 = make_col<int32_t>({2, 2, 0, 4, 3}), r1 = make_col<int32_t>({1, 0, 1, 2, 1});
+    distinct_hash_join d2{table_view{{r0->view(), r1->view()}}};
+    CHECK((to_host(*d2.left_join(table_view{{l0->view(), l1->view()}})) ==
+           std::vector<size_type>{JoinNoMatch, JoinNoMatch, JoinNoMatch, JoinNoMatch, 4}));
+    // PrimitiveLeftJoinWithNulls: the left second key is null at row 2
+    auto m0 = make_col<int32_t>({3, 1, 2, 0, 2}), m1 = make_col<int32_t>({1, 1, -1, 4, 0}, {1, 1, 0, 1, 1});
+    CHECK((to_host(*d2.left_join(table_view{{m0->view(), m1->view()}})) ==
+           std::vector<size_type>{4, JoinNoMatch, JoinNoMatch, JoinNoMatch, 1}));
+    // PrimitiveInnerJoinNoNulls: three int32 key columns (12 bytes: the dictionary encoding)
+    auto a0 = make_col<int32_t>({1, 2, 3, 4, 5}), a1 = make_col<int32_t>({0, 0, 3, 4, 5}), a2 = make_col<int32_t>({9, 9, 9, 9, 9});
+    auto b0 = make_col<int32_t>({1, 2, 3, 4, 9}), b1 = make_col<int32_t>({0, 0, 0, 4, 4}), b2 = make_col<int32_t>({9, 9, 9, 0, 9});
+    distinct_hash_join d3{table_view{{a0->view(), a1->view(), a2->view()}}};
+    CHECK((sorted_pairs(d3.inner_join(table_view{{b0->view(), b1->view(), b2->view()}})) == pairs_t{{0, 0}, {1, 1}}));
+    CHECK(throws<std::invalid_argument>([&] { distinct_hash_join bad{table_view{{r->view()}}, null_equality::EQUAL, 1.5}; }));
+    CHECK(throws<std::invalid_argument>([&] { distinct_hash_join bad{table_view{}}; }));
+  });
+  run("multi-column join keys (join_tests.cpp:1163-1283,1421-1500: numeric key columns)", [] {
+    auto l0 = make_col<int32_t>({3, 1, 2, 0, 2}), l1 = make_col<int32_t>({1, 1, 0, 4, 0});
+    auto r0 = make_col<int32_t>({2, 2, 0, 4, 3}), r1 = make_col<int32_t>({1, 0, 1, 2, 1});
+    table_view L{{l0->view(), l1->view()}}, R{{r0->view(), r1->view()}};
+    CHECK((sorted_pairs(inner_join(L, R)) == pairs_t{{0, 4}, {2, 1}, {4, 1}}));
+    CHECK((sorted_pairs(left_join(L, R)) == pairs_t{{0, 4}, {1, JoinNoMatch}, {2, 1}, {3, JoinNoMatch}, {4, 1}}));
+    CHECK(full_join(L, R).first->size() == 8);  // 5 left rows + right rows 0, 2, 3 unmatched
+    // InnerJoinOnNulls: nulls on both sides of the second key; EQUAL -> 2 pairs, UNEQUAL -> 1
+    auto ln = make_col<int32_t>({1, 1, 0, 4, 0}, {1, 1, 0, 1, 1});
+    auto rn = make_col<int32_t>({1, 0, 1, 2, 1}, {1, 0, 1, 1, 1});
+    table_view LN{{l0->view(), ln->view()}}, RN{{r0->view(), rn->view()}};
+    CHECK((sorted_pairs(inner_join(LN, RN, null_equality::EQUAL)) == pairs_t{{0, 4}, {2, 1}}));
+    CHECK((sorted_pairs(inner_join(LN, RN, null_equality::UNEQUAL)) == pairs_t{{0, 4}}));
+    // wide keys (int64, float64 with NaN / -0.0, int16): 18 bytes per row
+    auto w0 = make_col<int64_t>({10, 10, 20, 20, 30});
+    auto w1 = make_col<double>({0.0, std::nan(""), 1.5, -0.0, 2.0});
+    auto w2 = make_col<int16_t>({1, 2, 3, 4, 5});
+    auto v0 = make_col<int64_t>({20, 10, 10, 30});
+    auto v1 = make_col<double>({0.0, -std::nan(""), -0.0, 2.5});
+    auto v2 = make_col<int16_t>({4, 2, 1, 5});
+    table_view W{{w0->view(), w1->view(), w2->view()}}, V{{v0->view(), v1->view(), v2->view()}};
+    CHECK((sorted_pairs(inner_join(W, V)) == pairs_t{{0, 2}, {1, 1}, {3, 0}}));   // -0.0 == 0.0, NaN == NaN
+    CHECK(throws<cudf::data_type_error>([&] { (void)inner_join(W, table_view{{v0->view(), v1->view(), v0->view()}}); }));
+    CHECK(throws<std::invalid_argument>([&] {
+      hash_join hj{V, null_equality::EQUAL};
+      (void)hj.inner_join(table_view{{w0->view()}});
+    }));
+  });
+  run("groupby key types and multi-column keys (keys_tests.cpp:25-41 typed over int8..double)", [&] {
+    auto check_keys = [&](auto tag) {
+      using K = decltype(tag);
+      auto keys = make_col<K>({1, 2, 3, 1, 2, 2, 1, 3, 3, 2});
+      auto vals = make_col<int32_t>({0, 1, 2, 3, 4, 5, 6, 7, 8, 9});
+      groupby::groupby gb{table_view{{keys->view()}}};
+      std::vector<groupby::aggregation_request> reqs(1);
+      reqs[0].values = vals->view();
+      reqs[0].aggregations.emplace_back(make_count_aggregation<groupby_aggregation>());
+      reqs[0].aggregations.emplace_back(make_sum_aggregation<groupby_aggregation>());
+      auto [k, res] = gb.aggregate(reqs);
+      auto order    = sorted_order(k->view());
+      auto ks       = gather(k->view(), order->view());
+      auto cs       = gather(table_view{{res[0].results[0]->view(), res[0].results[1]->view()}}, order->view());
+      CHECK((to_host<K>(ks->get_column(0).view()) == std::vector<K>{1, 2, 3}));
+      CHECK((to_host<int32_t>(cs->get_column(0).view()) == std::vector<int32_t>{3, 4, 3}));
+      CHECK((to_host<int64_t>(cs->get_column(1).view()) == std::vector<int64_t>{9, 19, 17}));
+    };
+    check_keys(int8_t{});
+    check_keys(int16_t{});
+    check_keys(int32_t{});
+    check_keys(int64_t{});
+    check_keys(float{});
+    check_keys(double{});
+    // two key columns, a null in the second drops the row (null_policy::EXCLUDE)
+    auto k0   = make_col<int32_t>({1, 1, 2, 2, 1, 2, 1});
+    auto k1   = make_col<int64_t>({7, 8, 7, 7, 7, 9, 8}, {1, 1, 1, 1, 1, 0, 1});
+    auto vals = make_col<double>({1.0, 2.0, 3.0, 4.0, 5.0, 6.0, 7.0});
+    groupby::groupby gb{table_view{{k0->view(), k1->view()}}};
+    std::vector<groupby::aggregation_request> reqs(1);
+    reqs[0].values = vals->view();
+    reqs[0].aggregations.emplace_back(make_sum_aggregation<groupby_aggregation>());
+    reqs[0].aggregations.emplace_back(make_max_aggregation<groupby_aggregation>());
+    auto [k, res] = gb.aggregate(reqs);
+    CHECK(k->num_columns() == 2 && k->num_rows() == 3);
+    auto order = sorted_order(k->view());
+    auto ks    = gather(k->view(), order->view());
+    auto rs    = gather(table_view{{res[0].results[0]->view(), res[0].results[1]->view()}}, order->view());
+    CHECK((to_host<int32_t>(ks->get_column(0).view()) == std::vector<int32_t>{1, 1, 2}));
+    CHECK((to_host<int64_t>(ks->get_column(1).view()) == std::vector<int64_t>{7, 8, 7}));
+    CHECK((to_host<double>(rs->get_column(0).view()) == std::vector<double>{6.0, 9.0, 7.0}));
+    CHECK((to_host<double>(rs->get_column(1).view()) == std::vector<double>{5.0, 7.0, 4.0}));
+  });
   run("groupby SUM/COUNT/MEAN basic (sum_tests.cpp:68-80, count_tests.cpp:21-41, mean_tests.cpp:37-56)", [&] {
     auto keys = make_col<int32_t>({1, 2, 3, 1, 2, 2, 1, 3, 3, 2});
     auto vals = make_col<int32_t>({0, 1, 2, 3, 4, 5, 6, 7, 8, 9});

@@ -117,6 +117,47 @@ JOIN = [
 ]
 
 # ---------------------------------------------------------------------------------------------
+# semi / anti join (cudf::filtered_join) and distinct_hash_join.  expected = ascending left row
+# indices (semi/anti) or the right row per left row (distinct left join, NO_MATCH where none).
+# ---------------------------------------------------------------------------------------------
+SEMI_ANTI = [
+    # join/semi_anti_join_tests.cpp:119-136  TestSimple (result table {0, 1} = left rows 0, 1)
+    dict(name="semi_simple", dtype="int32", how="semi", left=[[0, 1, 2]], right=[[0, 1, 3]],
+         expected=[0, 1], nulls_equal=True),
+    # join/semi_anti_join_tests.cpp:357-388  AntiJoinEmptyTables: empty right -> every left row; empty left -> none
+    dict(name="anti_empty_right", dtype="int32", how="anti", left=[[0, 1, 2]], right=[[]],
+         expected=[0, 1, 2], nulls_equal=True),
+    dict(name="anti_empty_left", dtype="int32", how="anti", left=[[]], right=[[0, 1, 2]],
+         expected=[], nulls_equal=True),
+    # join/semi_anti_join_tests.cpp:390-421  SemiJoinEmptyTables
+    dict(name="semi_empty_right", dtype="int32", how="semi", left=[[0, 1, 2]], right=[[]],
+         expected=[], nulls_equal=True),
+    dict(name="semi_empty_left", dtype="int32", how="semi", left=[[]], right=[[0, 1, 2]],
+         expected=[], nulls_equal=True),
+]
+
+DISTINCT_JOIN = [
+    # join/distinct_join_tests.cpp:74-93  IntegerInnerJoin: right = 0..2023, left = 0,2,..,4046 -> the
+    # 1012 left rows with value < 2024 match right row == value
+    dict(name="distinct_integer_inner", dtype="int32", how="inner",
+         left=[list(range(0, 4048, 2))], right=[list(range(2024))],
+         expected_pairs=[(i, 2 * i) for i in range(1012)]),
+    # join/distinct_join_tests.cpp:541-575  PrimitiveLeftJoinNoNulls (two int32 key columns)
+    dict(name="distinct_left_nonulls", dtype="int32", how="left",
+         left=[[3, 1, 2, 0, 3], [0, 1, 2, 4, 1]], right=[[2, 2, 0, 4, 3], [1, 0, 1, 2, 1]],
+         expected=[NO_MATCH, NO_MATCH, NO_MATCH, NO_MATCH, 4]),
+    # join/distinct_join_tests.cpp:614-649  PrimitiveLeftJoinWithNulls (left second key null at row 2)
+    dict(name="distinct_left_withnulls", dtype="int32", how="left",
+         left=[[3, 1, 2, 0, 2], [1, 1, N, 4, 0]], right=[[2, 2, 0, 4, 3], [1, 0, 1, 2, 1]],
+         expected=[4, NO_MATCH, NO_MATCH, NO_MATCH, 1]),
+    # join/distinct_join_tests.cpp:185-225  PrimitiveInnerJoinNoNulls (three int32 key columns; the test's
+    # first table is the build/right side)
+    dict(name="distinct_inner_3col", dtype="int32", how="inner",
+         left=[[1, 2, 3, 4, 9], [0, 0, 0, 4, 4], [9, 9, 9, 0, 9]], right=[[1, 2, 3, 4, 5], [0, 0, 3, 4, 5], [9, 9, 9, 9, 9]],
+         expected_pairs=[(0, 0), (1, 1)]),
+]
+
+# ---------------------------------------------------------------------------------------------
 # groupby (keys int32; results compared after sorting by key)
 # ---------------------------------------------------------------------------------------------
 _K_BASIC = [1, 2, 3, 1, 2, 2, 1, 3, 3, 2]

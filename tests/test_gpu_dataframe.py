@@ -55,3 +55,49 @@ def test_groupby_agg_matches_pandas(DF):
     np.testing.assert_array_equal(got["v_count"], exp["v_count"])
     np.testing.assert_allclose(got["v_mean"], exp["v_mean"], rtol=1e-13)
     np.testing.assert_array_equal(got["w_sum"], exp["w_sum"])
+
+
+@pytest.mark.parametrize("how", ["inner", "left"])
+def test_merge_on_two_keys_matches_pandas(DF, how):
+    import pandas as pd
+    rng = np.random.default_rng(3)
+    n = 60_000
+    left = pd.DataFrame({"a": rng.integers(0, 40, n).astype(np.int32), "b": rng.integers(0, 300, n), "x": rng.random(n)})
+    right = pd.DataFrame({"a": rng.integers(0, 40, 5000).astype(np.int32), "b": rng.integers(0, 300, 5000),
+                          "y": rng.integers(0, 100, 5000).astype(np.int64)}).drop_duplicates(["a", "b"])
+    exp = left.merge(right, on=["a", "b"], how=how).sort_values(["a", "b", "x"]).reset_index(drop=True)
+    got = (DF.from_pandas(left).merge(DF.from_pandas(right), on=["a", "b"], how=how).to_pandas()
+           .sort_values(["a", "b", "x"]).reset_index(drop=True))
+    pd.testing.assert_frame_equal(got[exp.columns], exp, check_dtype=False)
+
+
+def test_semi_anti_merge_matches_pandas(DF):
+    import pandas as pd
+    rng = np.random.default_rng(4)
+    left = pd.DataFrame({"k": rng.integers(0, 5000, 50_000), "j": rng.integers(0, 3, 50_000).astype(np.int32), "x": rng.random(50_000)})
+    right = pd.DataFrame({"k": rng.permutation(8000)[:3000], "j": rng.integers(0, 3, 3000).astype(np.int32)})
+    g = DF.from_pandas(left)
+    for on in ("k", ["k", "j"]):
+        keys = [on] if isinstance(on, str) else on
+        m = left.merge(right[keys].drop_duplicates(), on=keys, how="left", indicator=True)["_merge"].to_numpy() == "both"
+        semi = g.merge(DF.from_pandas(right), on=on, how="leftsemi").to_pandas()
+        anti = g.merge(DF.from_pandas(right), on=on, how="leftanti").to_pandas()
+        pd.testing.assert_frame_equal(semi, left[m].reset_index(drop=True), check_dtype=False)   # left order kept
+        pd.testing.assert_frame_equal(anti, left[~m].reset_index(drop=True), check_dtype=False)
+
+
+def test_groupby_on_two_keys_and_float_key_matches_pandas(DF):
+    import pandas as pd
+    rng = np.random.default_rng(5)
+    n = 300_000
+    pdf = pd.DataFrame({"a": rng.integers(0, 30, n).astype(np.int16), "b": rng.integers(-5, 5, n), "f": rng.integers(0, 9, n) / 4,
+                        "v": rng.random(n), "w": rng.integers(-1000, 1000, n)})
+    for by in (["a", "b"], ["f"], ["b", "f", "a"]):
+        exp = pdf.groupby(by).agg(v_sum=("v", "sum"), v_max=("v", "max"), w_sum=("w", "sum"), w_count=("w", "count")).reset_index()
+        got = DF.from_pandas(pdf).groupby(by).agg({"v": ["sum", "max"], "w": ["sum", "count"]}).to_pandas()
+        for b in by:
+            np.testing.assert_array_equal(got[b], exp[b])
+        np.testing.assert_allclose(got["v_sum"], exp["v_sum"], rtol=1e-13)
+        np.testing.assert_array_equal(got["v_max"], exp["v_max"])
+        np.testing.assert_array_equal(got["w_sum"], exp["w_sum"])
+        np.testing.assert_array_equal(got["w_count"], exp["w_count"])

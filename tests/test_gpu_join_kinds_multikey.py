@@ -1,0 +1,295 @@
+"""GPU parity: semi / anti / distinct joins, row-key encoding (pack / dense rank) and multi-column join /
+groupby keys through the C ABI, vs the CPU oracle and the reference's golden vectors."""
+import ctypes
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+from oracle import cudf_oracle as orc
+from tests.golden import reference_vectors as gv
+
+NO_MATCH = gv.NO_MATCH
+
+
+@pytest.fixture(scope="module")
+def gx():
+    import torch
+    assert torch.cuda.is_available()
+    import cudf_amd
+    from cudf_amd import Column, ops
+    return Column, ops
+
+
+def _cols(Column, lists, dtype):
+    out = []
+    for c in lists:
+        a, m = gv.col(c, dtype)
+        out.append(Column.from_numpy(a, m))
+    return out
+
+
+def _np_cols(lists, dtype):
+    cols, masks = [], []
+    for c in lists:
+        a, m = gv.col(c, dtype)
+        cols.append(a)
+        masks.append(m)
+    return cols, masks
+
+
+# ------------------------------------------------------------------------------------------------
+# semi / anti / distinct
+# ------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("case", gv.SEMI_ANTI, ids=lambda c: c["name"])
+def test_reference_golden_semi_anti(gx, case):
+    Column, ops = gx
+    (l,), (r,) = _cols(Column, case["left"], case["dtype"]), _cols(Column, case["right"], case["dtype"])
+    fn = ops.left_semi_join if case["how"] == "semi" else ops.left_anti_join
+    got = fn(l, r, case["nulls_equal"])
+    assert got.dtype == np.int32 and got.to_numpy().tolist() == case["expected"]
+
+
+@pytest.mark.parametrize("dtype", ["int64", "int32"])
+@pytest.mark.parametrize("nulls_equal", [True, False])
+def test_semi_anti_match_oracle(gx, dtype, nulls_equal):
+    """Ascending left rows with / without a match; null probe rows match only a null build row and only
+    under null_equality::EQUAL (filtered_join.cu:124-156)."""
+    Column, ops = gx
+    rng = np.random.default_rng(5)
+    for nl, nr, nulls in [(1, 1, False), (5000, 700, False), (5000, 700, True), (300_001, 50_000, True), (4097, 3, False)]:
+        right = rng.integers(0, nr * 2 + 1, nr).astype(dtype)
+        left = rng.integers(0, nr * 4 + 1, nl).astype(dtype)
+        lv = rng.random(nl) > 0.2 if nulls else None
+        rv = rng.random(nr) > 0.2 if nulls else None
+        hj = ops.HashJoin(Column.from_numpy(right, rv), nulls_equal)
+        lc = Column.from_numpy(left, lv)
+        semi, anti = hj.semi_join(lc).to_numpy(), hj.anti_join(lc).to_numpy()
+        es = orc.semi_join([left], [right], [lv], [rv], nulls_equal)
+        ea = orc.anti_join([left], [right], [lv], [rv], nulls_equal)
+        np.testing.assert_array_equal(semi, es)
+        np.testing.assert_array_equal(anti, ea)
+        assert len(semi) + len(anti) == nl
+
+
+def test_semi_anti_large_properties(gx):
+    """2e7 probe rows: semi + anti partition the rows, both ascending, semi keys all present."""
+    import torch
+    Column, ops = gx
+    nb, n = 1_000_000, 20_000_000
+    bk = Column.empty(np.int64, nb)
+    bkt = bk.data[: nb * 8].view(torch.int64)
+    bkt.copy_(torch.randperm(nb, device="cuda") * 2)          # even keys 0 .. 2nb-2
+    pk = ops.random_column(np.int64, n, seed=9, lo=0, hi=4 * nb)
+    pkt = pk.data[: n * 8].view(torch.int64)
+    hj = ops.HashJoin(bk)
+    semi, anti = hj.semi_join(pk), hj.anti_join(pk)
+    st = semi.data[: semi.size * 4].view(torch.int32).long()
+    at = anti.data[: anti.size * 4].view(torch.int32).long()
+    assert semi.size + anti.size == n
+    assert bool((st[1:] > st[:-1]).all()) and bool((at[1:] > at[:-1]).all())
+    hit = (pkt % 2 == 0) & (pkt < 2 * nb)
+    assert semi.size == int(hit.sum().item())
+    assert bool(hit[st].all()) and not bool(hit[at].any())
+
+
+@pytest.mark.parametrize("case", gv.DISTINCT_JOIN, ids=lambda c: c["name"])
+def test_reference_golden_distinct_join(gx, case):
+    Column, ops = gx
+    left, right = _cols(Column, case["left"], case["dtype"]), _cols(Column, case["right"], case["dtype"])
+    if len(left) > 1:
+        lk, rk = ops.encode_rows([left, right], True)
+    else:
+        lk, rk = left[0], right[0]
+    hj = ops.HashJoin(rk)
+    if case["how"] == "inner":
+        l, r = hj.inner_join(lk)
+        assert sorted(zip(l.to_numpy().tolist(), r.to_numpy().tolist())) == sorted(case["expected_pairs"])
+    else:
+        assert hj.lookup(lk).to_numpy().tolist() == case["expected"]
+
+
+def test_lookup_matches_oracle(gx):
+    Column, ops = gx
+    rng = np.random.default_rng(6)
+    right = rng.permutation(400_000)[:100_000].astype(np.int64)      # distinct
+    left = rng.integers(0, 400_000, 250_001).astype(np.int64)
+    lv = rng.random(left.size) > 0.1
+    rv = np.ones(right.size, bool)
+    rv[17] = False                                                  # one null build row
+    for eq in (True, False):
+        hj = ops.HashJoin(Column.from_numpy(right, rv), eq)
+        got = hj.lookup(Column.from_numpy(left, lv)).to_numpy()
+        np.testing.assert_array_equal(got, orc.distinct_left_join([left], [right], [lv], [rv], eq))
+
+
+# ------------------------------------------------------------------------------------------------
+# building blocks: bitmask copy, pack, dense rank
+# ------------------------------------------------------------------------------------------------
+def test_bitmask_copy(gx):
+    import torch
+    from cudf_amd import _lib as L
+    from cudf_amd.column import pack_mask, unpack_mask, ptr, stream_ptr
+    rng = np.random.default_rng(7)
+    for nbits, doff, soff in [(1, 0, 0), (31, 1, 0), (32, 0, 0), (33, 31, 5), (1000, 77, 13), (100_003, 4096, 31), (64, 32, 32), (5, 30, 29)]:
+        src = rng.random(soff + nbits) > 0.5
+        dst = rng.random(doff + nbits + 70) > 0.5
+        d = torch.from_numpy(pack_mask(dst).view(np.int32).copy()).cuda()
+        s = torch.from_numpy(pack_mask(src).view(np.int32).copy()).cuda()
+        assert L.lib.gx_bitmask_copy(ptr(d), doff, ptr(s), soff, nbits, stream_ptr()) == 0
+        exp = dst.copy()
+        exp[doff:doff + nbits] = src[soff:soff + nbits]
+        np.testing.assert_array_equal(unpack_mask(d.cpu().numpy().view(np.uint32), len(dst)), exp)
+        # src == NULL writes ones
+        assert L.lib.gx_bitmask_copy(ptr(d), doff, None, 0, nbits, stream_ptr()) == 0
+        exp[doff:doff + nbits] = True
+        np.testing.assert_array_equal(unpack_mask(d.cpu().numpy().view(np.uint32), len(dst)), exp)
+
+
+def test_pack_keys(gx):
+    Column, ops = gx
+    rng = np.random.default_rng(8)
+    n = 100_003
+    a = rng.integers(-2**31, 2**31, n).astype(np.int32)
+    b = rng.integers(0, 2**16, n).astype(np.uint16)
+    c = rng.integers(-128, 128, n).astype(np.int8)
+    got = ops.pack_keys([Column.from_numpy(a), Column.from_numpy(b), Column.from_numpy(c)]).to_numpy()
+    exp = (a.view(np.uint32).astype(np.uint64) << np.uint64(24)) | (b.astype(np.uint64) << np.uint64(8)) | c.view(np.uint8).astype(np.uint64)
+    np.testing.assert_array_equal(got, exp)
+    # floats are normalised: -0.0 == +0.0, every NaN == NaN
+    f = np.array([0.0, -0.0, np.nan, -np.nan, 1.5, np.float32("inf")], np.float32)
+    g = ops.pack_keys([Column.from_numpy(f), Column.from_numpy(np.arange(6, dtype=np.int32) * 0)]).to_numpy()
+    assert g[0] == g[1] and g[2] == g[3] and len(set(g.tolist())) == 4
+    from cudf_amd import _lib as L
+    cols = [Column.from_numpy(np.zeros(4, np.int64)), Column.from_numpy(np.zeros(4, np.int32))]
+    with pytest.raises(L.GxError):
+        ops.pack_keys(cols)                                         # 12 bytes do not fit
+
+
+@pytest.mark.parametrize("dtype", ["int64", "int32", "uint64", "float64", "float32", "int16", "uint8"])
+def test_dense_rank(gx, dtype):
+    Column, ops = gx
+    rng = np.random.default_rng(9)
+    for n, nulls in [(1, False), (1000, False), (1000, True), (200_003, True), ((1 << 22) + 3, False)]:
+        if np.dtype(dtype).kind == "f":
+            v = rng.integers(-50, 50, n).astype(dtype) / 4
+            if n > 10:
+                v[3], v[7], v[8], v[9] = np.nan, -np.nan, 0.0, -0.0
+        else:
+            info = np.iinfo(dtype)
+            v = rng.integers(max(info.min, -300), min(info.max, 300) + 1, n).astype(dtype)
+        valid = rng.random(n) > 0.15 if nulls else None
+        ids, rep, g = ops.dense_rank(Column.from_numpy(v, valid))
+        ids, rep = ids.to_numpy(), rep.to_numpy()
+        ok = np.ones(n, bool) if valid is None else valid
+        if np.dtype(dtype).kind == "f":                              # equality classes: NaN == NaN, -0.0 == +0.0
+            canon = v.copy()
+            canon[np.isnan(canon)] = np.nan
+            canon[canon == 0] = 0.0
+            sk = orc.sortable_bits(canon)                             # ascending, NaN after +Inf
+        else:
+            sk = v
+        uniq, inv = np.unique(sk[ok], return_inverse=True)
+        exp = np.full(n, len(uniq), np.int64)                         # nulls: one id after every value
+        exp[ok] = inv.reshape(-1)
+        np.testing.assert_array_equal(ids, exp.astype(np.int32))
+        assert g == len(uniq) + (0 if ok.all() else 1)
+        first = np.full(g, n, np.int64)                               # smallest row of every id
+        np.minimum.at(first, exp, np.arange(n))
+        np.testing.assert_array_equal(rep, first.astype(np.int32))
+
+
+# ------------------------------------------------------------------------------------------------
+# multi-column keys
+# ------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("case", [c for c in gv.JOIN if c.get("how", "inner") in ("inner", "left")], ids=lambda c: c["name"])
+def test_reference_golden_join_tables(gx, case):
+    """Every inner / left golden of join_tests.cpp, single- and multi-column keys, through the row encoding."""
+    Column, ops = gx
+    fn = ops.inner_join_tables if case.get("how", "inner") == "inner" else ops.left_join_tables
+    for eq in case["nulls_equal"]:
+        l, r = fn(_cols(Column, case["left"], case["dtype"]), _cols(Column, case["right"], case["dtype"]), eq)
+        l, r = l.to_numpy(), r.to_numpy()
+        if "expected_size" in case:
+            assert len(l) == case["expected_size"]
+        if "expected_pairs" in case:
+            assert sorted(zip(l.tolist(), r.tolist())) == sorted(case["expected_pairs"])
+        else:
+            lp = [np.array(c) for c in case["left_payload"]]
+            rp = [np.array(c) for c in case["right_payload"]]
+            rows = sorted(tuple(int(c[i]) for c in lp) + tuple(int(c[j]) for c in rp) for i, j in zip(l, r))
+            assert rows == sorted(case["expected_rows"])
+
+
+@pytest.mark.parametrize("schema", [("int32", "int32"), ("int64", "int32"), ("int64", "int64", "int64"),
+                                    ("int16", "uint8", "int32"), ("float64", "int32"), ("int32", "float32", "int64")],
+                         ids=lambda s: "-".join(s))
+@pytest.mark.parametrize("nulls", [False, True])
+@pytest.mark.parametrize("nulls_equal", [True, False])
+def test_multi_column_join_matches_oracle(gx, schema, nulls, nulls_equal):
+    Column, ops = gx
+    rng = np.random.default_rng(10)
+    nl, nr = 20_011, 3_001
+
+    def table(n):
+        cols, masks = [], []
+        for dt in schema:
+            if np.dtype(dt).kind == "f":
+                v = rng.integers(-3, 4, n).astype(dt) / 2
+                v[rng.random(n) < 0.05] = np.nan
+                v[rng.random(n) < 0.05] = -0.0
+            else:
+                v = rng.integers(0, 6, n).astype(dt)
+            cols.append(v)
+            masks.append(rng.random(n) > 0.1 if nulls else None)
+        return cols, masks
+
+    (lc, lm), (rc, rm) = table(nl), table(nr)
+    L = [Column.from_numpy(c, m) for c, m in zip(lc, lm)]
+    R = [Column.from_numpy(c, m) for c, m in zip(rc, rm)]
+    l, r = ops.inner_join_tables(L, R, nulls_equal)
+    gl, gr = orc.canonical_pairs(l.to_numpy(), r.to_numpy())
+    el, er = orc.inner_join(lc, rc, lm, rm, nulls_equal)
+    np.testing.assert_array_equal(gl, el)
+    np.testing.assert_array_equal(gr, er)
+    l, r = ops.left_join_tables(L, R, nulls_equal)
+    gl, gr = orc.canonical_pairs(l.to_numpy(), r.to_numpy())
+    el, er = orc.left_join(lc, rc, lm, rm, nulls_equal)
+    np.testing.assert_array_equal(gl, el)
+    np.testing.assert_array_equal(gr, er)
+
+
+@pytest.mark.parametrize("schema", [("int32", "int32"), ("int64", "int16"), ("int64", "int64", "int32"), ("float64", "int8")],
+                         ids=lambda s: "-".join(s))
+@pytest.mark.parametrize("nulls", [False, True])
+def test_multi_column_groupby(gx, schema, nulls):
+    """groupby on several key columns: ids from the row encoding, SUM / COUNT per id, keys gathered by
+    the first row of every id; rows with a null in any key column are dropped (null_policy::EXCLUDE)."""
+    Column, ops = gx
+    rng = np.random.default_rng(11)
+    n = 150_007
+    cols, masks = [], []
+    for dt in schema:
+        v = (rng.integers(-2, 3, n).astype(dt) / 2) if np.dtype(dt).kind == "f" else rng.integers(0, 9, n).astype(dt)
+        cols.append(v)
+        masks.append(rng.random(n) > 0.05 if nulls else None)
+    vals = rng.integers(-1000, 1000, n).astype(np.int64)
+    K = [Column.from_numpy(c, m) for c, m in zip(cols, masks)]
+    out_keys, s, cv, ca = ops.groupby_sum_count_tables(K, Column.from_numpy(vals))
+    got = {}
+    ks = [k.to_numpy() for k in out_keys]
+    for i in range(s.size):
+        got[tuple(float(k[i]) for k in ks)] = (int(s.to_numpy()[i]), int(cv.to_numpy()[i]), int(ca.to_numpy()[i]))
+    ok = np.ones(n, bool)
+    for m in masks:
+        if m is not None:
+            ok &= m
+    exp = {}
+    for i in np.nonzero(ok)[0]:
+        key = tuple(float(c[i]) + 0.0 for c in cols)
+        a = exp.setdefault(key, [0, 0, 0])
+        a[0] += int(vals[i])
+        a[1] += 1
+        a[2] += 1
+    assert got == {k: tuple(v) for k, v in exp.items()}

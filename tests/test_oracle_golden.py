@@ -55,6 +55,26 @@ def test_join_golden(case):
             assert rows == sorted(case["expected_rows"])
 
 
+@pytest.mark.parametrize("case", gv.SEMI_ANTI, ids=lambda c: c["name"])
+def test_semi_anti_golden(case):
+    lc, lm = _cols(case["left"], case["dtype"])
+    rc, rm = _cols(case["right"], case["dtype"])
+    fn = orc.semi_join if case["how"] == "semi" else orc.anti_join
+    got = fn(lc, rc, lm, rm, case["nulls_equal"])
+    assert got.dtype == np.int32 and got.tolist() == case["expected"]
+
+
+@pytest.mark.parametrize("case", gv.DISTINCT_JOIN, ids=lambda c: c["name"])
+def test_distinct_join_golden(case):
+    lc, lm = _cols(case["left"], case["dtype"])
+    rc, rm = _cols(case["right"], case["dtype"])
+    if case["how"] == "inner":
+        l, r = orc.inner_join(lc, rc, lm, rm, True)
+        assert sorted(zip(l.tolist(), r.tolist())) == sorted(case["expected_pairs"])
+    else:
+        assert orc.distinct_left_join(lc, rc, lm, rm, True).tolist() == case["expected"]
+
+
 @pytest.mark.parametrize("vdtype", ["int32", "int64", "float64"])
 @pytest.mark.parametrize("case", gv.GROUPBY, ids=lambda c: c["name"])
 def test_groupby_golden(case, vdtype):
