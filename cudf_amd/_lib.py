@@ -61,6 +61,9 @@ _PROTOS = {
     "gx_bitmask_copy": (_i, [_p, _i64, _p, _i64, _i64, _p]),
     "gx_pack_keys": (_i, [_i, _p, _p, _i64, _p, _p]),
     "gx_dense_rank": (_i, [_i, _p, _p, _i64, _i64, _p, _p, _p, _p, _sz, _p]),
+    "gx_square": (_i, [_i, _p, _i64, _p, _p]),
+    "gx_var_from_sums": (_i, [_i, _p, _p, _p, _i64, _i, _i, _p, _p, _p, _p]),
+    "gx_groupby_arg_select": (_i, [_i, _p, _p, _p, _i64, _p, _i64, _p, _p]),
     "gx_fill_nulls": (_i, [_i, _p, _p, _i64, ctypes.c_uint64, _p]),
     "gx_join_lookup": (_i, [_i, _p, _p, _i64, _p, ctypes.c_size_t, _p, _p]),
     "gx_join_filter": (_i, [_i, _p, _p, _i64, _p, ctypes.c_size_t, _i, _i, _p, _p, _p, _sz, _p]),

@@ -185,15 +185,22 @@ std::pair<std::unique_ptr<table>, std::vector<aggregation_result>> groupby::aggr
   auto needs_sum = [](aggregation::Kind k) {
     return k == aggregation::SUM || k == aggregation::COUNT_VALID || k == aggregation::COUNT_ALL || k == aggregation::MEAN;
   };
-  auto needs_mm = [](aggregation::Kind k) { return k == aggregation::MIN || k == aggregation::MAX; };
+  auto needs_mm  = [](aggregation::Kind k) {
+    return k == aggregation::MIN || k == aggregation::MAX || k == aggregation::ARGMIN || k == aggregation::ARGMAX;
+  };
+  // SUM_OF_SQUARES / M2 / VARIANCE / STD: the SUM pass plus a second SUM pass over the squared values
+  auto needs_sq = [](aggregation::Kind k) {
+    return k == aggregation::SUM_OF_SQUARES || k == aggregation::M2 || k == aggregation::VARIANCE || k == aggregation::STD;
+  };
   std::size_t passes = 0;  // hash passes over the keys: more than one -> bring every result into key order
   for (auto const& r : requests) {
-    bool a = false, b = false;
+    bool a = false, b = false, c = false;
     for (auto const& agg : r.aggregations) {
-      a = a || needs_sum(agg->kind);
+      a = a || needs_sum(agg->kind) || needs_sq(agg->kind);
       b = b || needs_mm(agg->kind);
+      c = c || needs_sq(agg->kind);
     }
-    passes += (a ? 1 : 0) + (b ? 1 : 0);
+    passes += (a ? 1 : 0) + (b ? 1 : 0) + (c ? 1 : 0);
   }
   bool const canonical = passes > 1;
 
@@ -203,7 +210,11 @@ std::pair<std::unique_ptr<table>, std::vector<aggregation_result>> groupby::aggr
         data_type t = requests[i].values.type();
         if (agg->kind == aggregation::SUM) t = sum_type(t);
         if (agg->kind == aggregation::COUNT_VALID || agg->kind == aggregation::COUNT_ALL) t = data_type{type_id::INT32};
-        if (agg->kind == aggregation::MEAN) t = data_type{type_id::FLOAT64};
+        if (agg->kind == aggregation::MEAN || agg->kind == aggregation::M2 || agg->kind == aggregation::VARIANCE ||
+            agg->kind == aggregation::STD)
+          t = data_type{type_id::FLOAT64};
+        if (agg->kind == aggregation::SUM_OF_SQUARES) t = sum_type(t);
+        if (agg->kind == aggregation::ARGMIN || agg->kind == aggregation::ARGMAX) t = data_type{type_id::INT32};
         // MIN / MAX keep the values' type
         results[i].results.emplace_back(make_empty_column(t));
       }
@@ -219,19 +230,35 @@ std::pair<std::unique_ptr<table>, std::vector<aggregation_result>> groupby::aggr
 
   for (std::size_t i = 0; i < requests.size(); ++i) {
     auto const& req = requests[i];
-    bool want_sum = false, want_mm = false;
+    bool want_sum = false, want_mm = false, want_sq = false, want_arg = false;
     for (auto const& agg : req.aggregations) {
-      CUDF_EXPECTS(needs_sum(agg->kind) || needs_mm(agg->kind),
-                   "groupby aggregation kind not implemented on this path (SUM, COUNT, MEAN, MIN, MAX are)");
-      want_sum = want_sum || needs_sum(agg->kind);
+      CUDF_EXPECTS(needs_sum(agg->kind) || needs_mm(agg->kind) || needs_sq(agg->kind),
+                   "groupby aggregation kind not implemented on this path (SUM, COUNT, MEAN, MIN, MAX, ARGMIN, ARGMAX, "
+                   "SUM_OF_SQUARES, M2, VARIANCE, STD are)");
+      want_sum = want_sum || needs_sum(agg->kind) || needs_sq(agg->kind);
       want_mm  = want_mm || needs_mm(agg->kind);
+      want_sq  = want_sq || needs_sq(agg->kind);
+      want_arg = want_arg || agg->kind == aggregation::ARGMIN || agg->kind == aggregation::ARGMAX;
     }
-    hash_agg_out o;
+    hash_agg_out o, q;
     hash_minmax_out mm;
-    std::unique_ptr<column> order, mm_order;
+    std::unique_ptr<column> order, mm_order, sq_order, group_of_row;
     if (want_sum || !want_mm) {
       o = hash_aggregate(keys, req.values, stream, mr);
       if (canonical) order = cudf::sorted_order(table_view{{o.keys->view()}}, {}, {}, stream);
+    }
+    if (want_sq) {  // second SUM pass over the squared values (same validity): SUM_OF_SQUARES
+      auto const& v = req.values;
+      auto sq       = make_fixed_width_column(sum_type(v.type()), v.size(), mask_state::UNALLOCATED, stream);
+      detail::gx_check(gx_square(detail::gx_type(v.type()), detail::row0(v), v.size(), sq->mutable_view().head<void>(),
+                                 detail::gxs(stream)),
+                       "groupby sum of squares");
+      // the squares start at row 0; the validity is the values' (re-based when the view is sliced)
+      rmm::device_buffer holder;
+      auto const* m = v.has_nulls() ? detail::rebased_mask(v, holder, stream) : nullptr;
+      column_view sqv{sq->type(), v.size(), sq->view().head<void>(), m, m ? v.null_count() : 0};
+      q        = hash_aggregate(keys, sqv, stream, mr);
+      sq_order = cudf::sorted_order(table_view{{q.keys->view()}}, {}, {}, stream);  // passes >= 2: canonical is set
     }
     if (want_mm) {
       mm = hash_minmax(keys, req.values, stream, mr);
@@ -240,6 +267,22 @@ std::pair<std::unique_ptr<table>, std::vector<aggregation_result>> groupby::aggr
         o.keys        = std::make_unique<column>(mm.keys->view(), stream, mr);
         o.count_valid = std::make_unique<column>(mm.count_valid->view(), stream, mr);
         if (canonical) order = std::make_unique<column>(mm_order->view(), stream, mr);
+      }
+      if (want_arg && mm.keys->size() > 0) {
+        // row -> position of its key among this pass's groups: a lookup table over the distinct keys
+        auto const ksz    = static_cast<int>(size_of(keys.type()));
+        auto const tbytes = gx_join_table_bytes(ksz, mm.keys->size(), 0.5);
+        rmm::device_buffer table{tbytes, stream};
+        detail::gx_check(gx_join_build(ksz, mm.keys->view().head<void>(), nullptr, mm.keys->size(), table.data(), tbytes, 0.5,
+                                       detail::gxs(stream)),
+                         "groupby argmin/argmax dictionary");
+        group_of_row = make_fixed_width_column(data_type{type_id::INT32}, keys.size(), mask_state::UNALLOCATED, stream);
+        rmm::device_buffer kh;
+        auto const* kmask = keys.has_nulls() ? detail::rebased_mask(keys, kh, stream) : nullptr;
+        detail::gx_check(gx_join_lookup(ksz, detail::row0(keys), kmask, keys.size(), table.data(), tbytes,
+                                        group_of_row->mutable_view().head<int32_t>(), detail::gxs(stream)),
+                         "groupby argmin/argmax lookup");
+        stream.synchronize();  // table / kh
       }
     }
     auto fin = [&](std::unique_ptr<column> c) {
@@ -281,6 +324,67 @@ std::pair<std::unique_ptr<table>, std::vector<aggregation_result>> groupby::aggr
           auto mask       = validity(nulls);
           if (nulls > 0) c->set_null_mask(std::move(mask), nulls);
           results[i].results.emplace_back(fin(std::move(c)));
+          break;
+        }
+        case aggregation::SUM_OF_SQUARES: {
+          auto c = permute(q.sum->view(), sq_order->view(), stream, mr);  // already in key order
+          rmm::device_buffer mask = create_null_mask(c->size(), mask_state::ALL_VALID, stream, mr);
+          rmm::device_buffer cnt{sizeof(int64_t), stream};
+          auto cv = permute(q.count_valid->view(), sq_order->view(), stream, mr);
+          detail::gx_check(gx_valid_from_counts(cv->view().head<int32_t>(), c->size(), static_cast<uint32_t*>(mask.data()),
+                                                static_cast<int64_t*>(cnt.data()), detail::gxs(stream)),
+                           "groupby validity");
+          auto const nulls = static_cast<size_type>(detail::read_i64(static_cast<int64_t const*>(cnt.data()), stream));
+          if (nulls > 0) c->set_null_mask(std::move(mask), nulls);
+          results[i].results.emplace_back(std::move(c));
+          break;
+        }
+        case aggregation::M2:
+        case aggregation::VARIANCE:
+        case aggregation::STD: {
+          // both passes brought into key order, then M2 = sum_sqr - sum^2/count etc. (m2_var_std.cu:44-61,153-190)
+          auto ssum = permute(q.sum->view(), sq_order->view(), stream, mr);
+          auto sum  = permute(o.sum->view(), order->view(), stream, mr);
+          auto cv   = permute(o.count_valid->view(), order->view(), stream, mr);
+          auto c    = make_fixed_width_column(data_type{type_id::FLOAT64}, g, mask_state::UNALLOCATED, stream, mr);
+          rmm::device_buffer mask = create_null_mask(g, mask_state::ALL_VALID, stream, mr);
+          rmm::device_buffer cnt{sizeof(int64_t), stream};
+          int ddof = 1;
+          if (auto const* sv = dynamic_cast<detail::std_var_aggregation const*>(agg.get())) ddof = sv->_ddof;
+          int const mode = agg->kind == aggregation::M2 ? 0 : (agg->kind == aggregation::VARIANCE ? 1 : 2);
+          detail::gx_check(gx_var_from_sums(detail::gx_type(sum->type()), ssum->view().head<void>(), sum->view().head<void>(),
+                                            cv->view().head<int32_t>(), g, ddof, mode, c->mutable_view().head<double>(),
+                                            static_cast<uint32_t*>(mask.data()), static_cast<int64_t*>(cnt.data()),
+                                            detail::gxs(stream)),
+                           "groupby variance");
+          auto const nulls = static_cast<size_type>(detail::read_i64(static_cast<int64_t const*>(cnt.data()), stream));
+          if (nulls > 0) c->set_null_mask(std::move(mask), nulls);
+          results[i].results.emplace_back(std::move(c));  // already in key order
+          break;
+        }
+        case aggregation::ARGMIN:
+        case aggregation::ARGMAX: {
+          auto const& target = agg->kind == aggregation::ARGMIN ? mm.mn : mm.mx;
+          auto const gm      = mm.keys->size();
+          auto c             = make_fixed_width_column(data_type{type_id::INT32}, gm, mask_state::UNALLOCATED, stream, mr);
+          if (gm > 0) {
+            rmm::device_buffer vh;
+            auto const* vmask = req.values.has_nulls() ? detail::rebased_mask(req.values, vh, stream) : nullptr;
+            detail::gx_check(gx_groupby_arg_select(detail::gx_type(req.values.type()), detail::row0(req.values), vmask,
+                                                   group_of_row->view().head<int32_t>(), keys.size(),
+                                                   target->view().head<void>(), gm, c->mutable_view().head<int32_t>(),
+                                                   detail::gxs(stream)),
+                             "groupby argmin/argmax");
+            stream.synchronize();  // vh
+          }
+          rmm::device_buffer mask = create_null_mask(gm, mask_state::ALL_VALID, stream, mr);
+          rmm::device_buffer cnt{sizeof(int64_t), stream};
+          detail::gx_check(gx_valid_from_counts(mm.count_valid->view().head<int32_t>(), gm, static_cast<uint32_t*>(mask.data()),
+                                                static_cast<int64_t*>(cnt.data()), detail::gxs(stream)),
+                           "groupby validity");
+          auto const nulls = static_cast<size_type>(detail::read_i64(static_cast<int64_t const*>(cnt.data()), stream));
+          if (nulls > 0) c->set_null_mask(std::move(mask), nulls);
+          results[i].results.emplace_back(fin_mm(std::move(c)));
           break;
         }
         case aggregation::MIN:

@@ -937,3 +937,185 @@ int gx_groupby_min_max(int key_dtype, const void* keys, const uint32_t* keys_val
 }
 
 }  // extern "C"
+
+// ------------------------------------------------------------------------------------------------
+// Compound aggregations on top of the passes above.
+//   SUM_OF_SQUARES / M2 / VARIANCE / STD (hash path of the reference: SUM_OF_SQUARES is a single-pass
+//   aggregation, M2 = sum_sqr - sum * sum / count, VAR = M2 / (count - ddof), STD = sqrt(VAR), null when
+//   count - ddof <= 0: cpp/src/groupby/common/m2_var_std.cu:44-61,153-190,
+//   cpp/src/groupby/hash/hash_compound_agg_finalizer.cu:135-186).  gx_square produces the squared values
+//   in the SUM accumulator type (integers -> int64, wrapping like the reference's int64 accumulator;
+//   floats keep their type); the caller sums them with gx_groupby_sum_count.
+//   ARGMIN / ARGMAX: the row of the group's MIN / MAX value.  gx_groupby_arg_select takes the row -> group
+//   map (gx_join_lookup on the output keys) and the per-group target value and keeps the SMALLEST row
+//   whose value equals the target (floats: NaN == NaN, -0.0 == +0.0, the order MIN / MAX used).
+// ------------------------------------------------------------------------------------------------
+namespace gx {
+namespace gb {
+
+template <typename V, typename S>
+__global__ void __launch_bounds__(256) k_square(const V* __restrict__ in, int64_t n, S* __restrict__ out)
+{
+  const int64_t stride = (int64_t)gridDim.x * 256;
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += stride) {
+    if constexpr (std::is_integral<S>::value) {
+      const unsigned long long x = (unsigned long long)(long long)in[i];  // wraps mod 2^64 like an int64 accumulator
+      out[i]                     = (S)(x * x);
+    } else {
+      const S x = (S)in[i];
+      out[i]    = x * x;
+    }
+  }
+}
+
+// mode 0: M2, 1: VARIANCE, 2: STD
+template <typename S>
+__global__ void __launch_bounds__(256) k_var(const S* __restrict__ sumsq, const S* __restrict__ sum,
+                                             const int32_t* __restrict__ cnt, int64_t n, int ddof, int mode,
+                                             double* __restrict__ out, uint32_t* __restrict__ mask, unsigned long long* nulls)
+{
+  const int64_t stride = (int64_t)gridDim.x * 256;
+  const int64_t nround = div_up(n, (int64_t)64) * 64;  // whole waves: the ballot below needs every lane
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < nround; i += stride) {
+    bool ok  = false;
+    double r = 0.0;
+    if (i < n) {
+      const int32_t c = cnt[i];
+      if (c > 0) {
+        const double ss = (double)sumsq[i], sm = (double)sum[i];
+        const double m2 = ss - sm * sm / (double)c;
+        if (mode == 0) {
+          r  = m2;
+          ok = true;
+        } else if (c - ddof > 0) {
+          r  = m2 / (double)(c - ddof);
+          if (mode == 2) r = sqrt(r);
+          ok = true;
+        }
+      } else if (mode == 0) {
+        ok = true;  // M2 of an empty group is 0 and valid (m2_var_std.cu:52-53)
+      }
+      out[i] = r;
+    }
+    const uint64_t b = ballot(ok);
+    if (lane_id() == 0 && i < n) {
+      mask[i >> 5]       = (uint32_t)b;
+      if (i + 32 < n) mask[(i >> 5) + 1] = (uint32_t)(b >> 32);
+      const int64_t rows = (n - i) < 64 ? (n - i) : 64;
+      const int bad      = (int)rows - __builtin_popcountll(b);
+      if (bad) atomicAdd(nulls, (unsigned long long)bad);
+    }
+  }
+}
+
+template <typename V>
+__device__ __forceinline__ bool same_value(V a, V b)
+{
+  if constexpr (std::is_floating_point<V>::value) return a == b || (a != a && b != b);
+  return a == b;
+}
+
+template <typename V>
+__global__ void __launch_bounds__(256) k_arg_select(const V* __restrict__ vals, const uint32_t* __restrict__ valid,
+                                                    const int32_t* __restrict__ gid, int64_t n,
+                                                    const V* __restrict__ target, int32_t* __restrict__ out)
+{
+  const int64_t stride = (int64_t)gridDim.x * 256;
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += stride) {
+    const int32_t g = gid[i];
+    if (g < 0) continue;                                // null / dropped key
+    if (valid && !bit_is_set(valid, i)) continue;       // null value
+    if (same_value<V>(vals[i], target[g])) atomicMin(&out[g], (int32_t)i);
+  }
+}
+
+template <typename V>
+int arg_select_impl(const void* vals, const uint32_t* valid, const int32_t* gid, int64_t n, const void* target, int64_t g,
+                    int32_t* out, hipStream_t s)
+{
+  GX_HIP_TRY(hipMemsetAsync(out, 0x7F, (size_t)g * sizeof(int32_t), s));  // 0x7F7F7F7F: above every row index in use
+  if (n == 0) return 0;
+  int64_t blocks = div_up(n, (int64_t)256 * 4);
+  if (blocks > 16384) blocks = 16384;
+  hipLaunchKernelGGL((k_arg_select<V>), dim3((unsigned)blocks), dim3(256), 0, s, static_cast<const V*>(vals), valid, gid, n,
+                     static_cast<const V*>(target), out);
+  GX_LAUNCH_CHECK();
+  return 0;
+}
+
+}  // namespace gb
+}  // namespace gx
+
+extern "C" {
+
+int gx_square(int dtype, const void* in, int64_t n, void* out, gx_stream_t s)
+{
+  if (n < 0 || (n > 0 && (!in || !out))) return GX_EINVAL;
+  if (n == 0) return 0;
+  int64_t blocks = gx::div_up(n, (int64_t)256 * 8);
+  if (blocks > 16384) blocks = 16384;
+#define GX_SQ(V, S) hipLaunchKernelGGL((gx::gb::k_square<V, S>), dim3((unsigned)blocks), dim3(256), 0, s, static_cast<const V*>(in), n, static_cast<S*>(out)); break
+  switch (dtype) {
+    case GX_INT8: GX_SQ(int8_t, int64_t);
+    case GX_INT16: GX_SQ(int16_t, int64_t);
+    case GX_INT32: GX_SQ(int32_t, int64_t);
+    case GX_INT64: GX_SQ(int64_t, int64_t);
+    case GX_BOOL8:
+    case GX_UINT8: GX_SQ(uint8_t, int64_t);
+    case GX_UINT16: GX_SQ(uint16_t, int64_t);
+    case GX_UINT32: GX_SQ(uint32_t, int64_t);
+    case GX_UINT64: GX_SQ(uint64_t, int64_t);
+    case GX_FLOAT32: GX_SQ(float, float);
+    case GX_FLOAT64: GX_SQ(double, double);
+    default: return GX_EDTYPE;
+  }
+#undef GX_SQ
+  GX_LAUNCH_CHECK();
+  return 0;
+}
+
+int gx_var_from_sums(int sum_dtype, const void* sum_sqr, const void* sum, const int32_t* count, int64_t n, int ddof, int mode,
+                     double* out, uint32_t* mask_out, int64_t* null_count_dev, gx_stream_t s)
+{
+  if (n < 0 || mode < 0 || mode > 2 || !null_count_dev) return GX_EINVAL;
+  if (n > 0 && (!sum_sqr || !sum || !count || !out || !mask_out)) return GX_EINVAL;
+  GX_HIP_TRY(hipMemsetAsync(null_count_dev, 0, sizeof(int64_t), s));
+  if (n == 0) return 0;
+  int64_t blocks = gx::div_up(n, (int64_t)256);
+  if (blocks > 4096) blocks = 4096;
+  auto* nulls = reinterpret_cast<unsigned long long*>(null_count_dev);
+  switch (sum_dtype) {
+    case GX_INT64: hipLaunchKernelGGL((gx::gb::k_var<int64_t>), dim3((unsigned)blocks), dim3(256), 0, s, static_cast<const int64_t*>(sum_sqr), static_cast<const int64_t*>(sum), count, n, ddof, mode, out, mask_out, nulls); break;
+    case GX_FLOAT64: hipLaunchKernelGGL((gx::gb::k_var<double>), dim3((unsigned)blocks), dim3(256), 0, s, static_cast<const double*>(sum_sqr), static_cast<const double*>(sum), count, n, ddof, mode, out, mask_out, nulls); break;
+    case GX_FLOAT32: hipLaunchKernelGGL((gx::gb::k_var<float>), dim3((unsigned)blocks), dim3(256), 0, s, static_cast<const float*>(sum_sqr), static_cast<const float*>(sum), count, n, ddof, mode, out, mask_out, nulls); break;
+    default: return GX_EDTYPE;
+  }
+  GX_LAUNCH_CHECK();
+  return 0;
+}
+
+int gx_groupby_arg_select(int val_dtype, const void* vals, const uint32_t* vals_valid, const int32_t* group_of_row, int64_t n,
+                          const void* target, int64_t num_groups, int32_t* out_rows, gx_stream_t s)
+{
+  if (n < 0 || num_groups < 0 || (n > 0 && (!vals || !group_of_row)) || (num_groups > 0 && (!target || !out_rows)))
+    return GX_EINVAL;
+  if (num_groups == 0) return 0;
+#define GX_AS(V) return gx::gb::arg_select_impl<V>(vals, vals_valid, group_of_row, n, target, num_groups, out_rows, s)
+  switch (val_dtype) {
+    case GX_INT8: GX_AS(int8_t);
+    case GX_INT16: GX_AS(int16_t);
+    case GX_INT32: GX_AS(int32_t);
+    case GX_INT64: GX_AS(int64_t);
+    case GX_BOOL8:
+    case GX_UINT8: GX_AS(uint8_t);
+    case GX_UINT16: GX_AS(uint16_t);
+    case GX_UINT32: GX_AS(uint32_t);
+    case GX_UINT64: GX_AS(uint64_t);
+    case GX_FLOAT32: GX_AS(float);
+    case GX_FLOAT64: GX_AS(double);
+    default: return GX_EDTYPE;
+  }
+#undef GX_AS
+}
+
+}  // extern "C"

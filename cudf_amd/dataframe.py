@@ -126,13 +126,13 @@ class DataFrame:
 
 
 class GroupBy:
-    _SUPPORTED = ("sum", "count", "mean", "min", "max")
+    _SUPPORTED = ("sum", "count", "mean", "min", "max", "var", "std")
 
     def __init__(self, df: DataFrame, by: Union[str, Sequence[str]]):
         self._df, self._by = df, ([by] if isinstance(by, str) else list(by))
 
     def agg(self, spec: Dict[str, Union[str, Sequence[str]]]) -> DataFrame:
-        """{value column: "sum" | "count" | "mean" | "min" | "max" | [..]} -> one row per group, sorted by key
+        """{value column: "sum" | "count" | "mean" | "min" | "max" | "var" | "std" | [..]} -> one row per group, sorted by key
         (pandas' default sort=True).  Null keys are dropped (dropna=True), null values are skipped."""
         by = self._by
         k0 = self._df[by[0]]
@@ -167,6 +167,9 @@ class GroupBy:
                 valid = ops.gather(cv2, o2).to_numpy() > 0
                 mn = Column.from_numpy(ops.gather(mn, o2).to_numpy(), valid)
                 mx = Column.from_numpy(ops.gather(mx, o2).to_numpy(), valid)
+            var = std = None
+            if any(f in ("var", "std") for f in fns):  # ddof = 1, groups come back in ascending key order
+                _, var, std, _, _ = ops.groupby_var_std(keys, self._df[name])
             for f in fns:
                 label = name if len(fns) == 1 and len(spec) >= 1 and all(isinstance(v, str) for v in spec.values()) else f"{name}_{f}"
                 if f == "sum":
@@ -177,6 +180,10 @@ class GroupBy:
                     out._cols[label] = mn
                 elif f == "max":
                     out._cols[label] = mx
+                elif f == "var":
+                    out._cols[label] = var
+                elif f == "std":
+                    out._cols[label] = std
                 else:
                     sn, cn = s.to_numpy().astype(np.float64), cv.to_numpy()
                     with np.errstate(divide="ignore", invalid="ignore"):

@@ -552,6 +552,51 @@ def groupby_min_max(keys: Column, values: Column, max_groups_hint: int = 1 << 20
     return ok, omin, omax, ocv
 
 
+def _sum_dtype(dt) -> np.dtype:
+    return np.dtype(dt if np.dtype(dt).kind == "f" else np.int64)
+
+
+def groupby_var_std(keys: Column, values: Column, ddof: int = 1):
+    """groupby VARIANCE / STD / M2 the way the reference's hash path computes them: SUM, COUNT_VALID and
+    SUM_OF_SQUARES per group, then M2 = sum_sqr - sum^2/count, VAR = M2/(count - ddof), STD = sqrt(VAR)
+    (src/groupby/common/m2_var_std.cu:44-61,153-190).  Returns (keys, var, std, m2, count_valid) with
+    the groups in ascending key order; var / std are null where count - ddof <= 0."""
+    n = keys.size
+    k, s, cv, _ = groupby_sum_count(keys, values)
+    sq = Column(device_bytes(n * _sum_dtype(values.dtype).itemsize), _sum_dtype(values.dtype), n, values.mask,
+                values.null_count)
+    L.check(_lib.gx_square(values.gx, values.data_ptr, n, sq.data_ptr, stream_ptr()), "gx_square")
+    k2, ss, _, _ = groupby_sum_count(keys, sq)
+    o1, o2 = sorted_order(k), sorted_order(k2)  # the two hash passes emit the groups in their own orders
+    k, s, cv, ss = gather(k, o1), gather(s, o1), gather(cv, o1), gather(ss, o2)
+    g = k.size
+    outs = []
+    for mode in (1, 2, 0):
+        o = Column.empty(np.float64, g, nullable=True)
+        cnt = _dev_i64()
+        L.check(_lib.gx_var_from_sums(s.gx, ss.data_ptr, s.data_ptr, cv.data_ptr, g, int(ddof), mode, o.data_ptr,
+                                      o.mask_ptr, ptr(cnt), stream_ptr()), "gx_var_from_sums")
+        o.null_count = int(cnt.item())
+        outs.append(o)
+    return k, outs[0], outs[1], outs[2], cv
+
+
+def groupby_argmin_argmax(keys: Column, values: Column):
+    """groupby ARGMIN / ARGMAX: (keys, argmin, argmax, count_valid); the row index (INT32) of each group's
+    MIN / MAX value -- the smallest such row on ties; meaningful where count_valid > 0."""
+    k, mn, mx, cv = groupby_min_max(keys, values)
+    g = k.size
+    amin, amax = Column.empty(np.int32, g), Column.empty(np.int32, g)
+    if g == 0:
+        return k, amin, amax, cv
+    gid = HashJoin(k).lookup(keys)  # row -> position of its key in k (negative for null keys)
+    valid = values.mask_ptr if values.has_nulls() else None
+    for target, out in ((mn, amin), (mx, amax)):
+        L.check(_lib.gx_groupby_arg_select(values.gx, values.data_ptr, valid, gid.data_ptr, keys.size, target.data_ptr, g,
+                                           out.data_ptr, stream_ptr()), "gx_groupby_arg_select")
+    return k, amin, amax, cv
+
+
 def groupby_scan(sorted_keys: Column, values: Column, op: str = "sum") -> Column:
     """Segmented inclusive scan over already-sorted keys (groupby::scan's value pass)."""
     opc = {"sum": L.OP_SUM, "min": L.OP_MIN, "max": L.OP_MAX}[op]

@@ -51,6 +51,37 @@ class simple_aggregation final : public groupby_aggregation,
     return std::unique_ptr<aggregation>(static_cast<groupby_aggregation*>(new simple_aggregation(kind)));
   }
 };
+// VARIANCE / STD carry the delta degrees of freedom (reference: detail/aggregation/aggregation.hpp
+// std_var_aggregation, _ddof)
+class std_var_aggregation final : public groupby_aggregation,
+                                  public reduce_aggregation,
+                                  public segmented_reduce_aggregation,
+                                  public rolling_aggregation {
+ public:
+  std_var_aggregation(aggregation::Kind k, size_type ddof) : aggregation(k), _ddof{ddof} {}
+  size_type _ddof;
+  [[nodiscard]] bool is_equal(aggregation const& other) const override
+  {
+    auto const* o = dynamic_cast<std_var_aggregation const*>(&other);
+    return o != nullptr && o->kind == kind && o->_ddof == _ddof;
+  }
+  [[nodiscard]] std::size_t do_hash() const override { return static_cast<std::size_t>(kind) * 31u + static_cast<std::size_t>(_ddof); }
+  [[nodiscard]] std::unique_ptr<aggregation> clone() const override
+  {
+    return std::unique_ptr<aggregation>(static_cast<groupby_aggregation*>(new std_var_aggregation(kind, _ddof)));
+  }
+};
+template <typename Base>
+std::unique_ptr<Base> make_std_var(aggregation::Kind k, size_type ddof)
+{
+  return std::unique_ptr<Base>(static_cast<Base*>(new std_var_aggregation(k, ddof)));
+}
+template <>
+inline std::unique_ptr<aggregation> make_std_var<aggregation>(aggregation::Kind k, size_type ddof)
+{
+  return std::unique_ptr<aggregation>(static_cast<groupby_aggregation*>(new std_var_aggregation(k, ddof)));
+}
+
 template <typename Base>
 std::unique_ptr<Base> make_simple(aggregation::Kind k)
 {
@@ -78,5 +109,19 @@ std::unique_ptr<Base> make_count_aggregation(null_policy null_handling = null_po
 }
 template <typename Base = aggregation>
 std::unique_ptr<Base> make_mean_aggregation() { return detail::make_simple<Base>(aggregation::MEAN); }
+// include/cudf/aggregation.hpp:335-375 of the reference: SUM_OF_SQUARES, M2, VARIANCE(ddof = 1), STD(ddof = 1)
+template <typename Base = aggregation>
+std::unique_ptr<Base> make_sum_of_squares_aggregation() { return detail::make_simple<Base>(aggregation::SUM_OF_SQUARES); }
+template <typename Base = aggregation>
+std::unique_ptr<Base> make_m2_aggregation() { return detail::make_simple<Base>(aggregation::M2); }
+template <typename Base = aggregation>
+std::unique_ptr<Base> make_variance_aggregation(size_type ddof = 1) { return detail::make_std_var<Base>(aggregation::VARIANCE, ddof); }
+template <typename Base = aggregation>
+std::unique_ptr<Base> make_std_aggregation(size_type ddof = 1) { return detail::make_std_var<Base>(aggregation::STD, ddof); }
+// ARGMAX / ARGMIN: row index (size_type) of the group's maximum / minimum (aggregation.hpp:430-446)
+template <typename Base = aggregation>
+std::unique_ptr<Base> make_argmax_aggregation() { return detail::make_simple<Base>(aggregation::ARGMAX); }
+template <typename Base = aggregation>
+std::unique_ptr<Base> make_argmin_aggregation() { return detail::make_simple<Base>(aggregation::ARGMIN); }
 
 }  // namespace cudf

@@ -307,6 +307,25 @@ int gx_groupby_min_max(int key_dtype, const void* keys, const uint32_t* keys_val
                        void* out_keys, void* out_min, void* out_max, int32_t* out_count_valid,
                        int64_t* ngroups_dev, void* tmp, size_t* tmp_bytes, gx_stream_t stream);
 
+/* Compound groupby aggregations on top of gx_groupby_sum_count / gx_groupby_min_max.
+ * gx_square: out[i] = in[i]^2 in the SUM accumulator type of `dtype` (integers -> int64 wrapping mod
+ *   2^64, FLOAT32/64 keep their type): the values of the reference's single-pass SUM_OF_SQUARES
+ *   (include/cudf/detail/aggregation/aggregation.hpp:944-954), summed by gx_groupby_sum_count.
+ * gx_var_from_sums: mode 0 M2 = sum_sqr - sum^2/count (valid for every group), 1 VARIANCE = M2/(count-ddof),
+ *   2 STD = sqrt(VARIANCE); null where count == 0 or count - ddof <= 0
+ *   (src/groupby/common/m2_var_std.cu:44-61,153-190; hash_compound_agg_finalizer.cu:135-186).
+ *   sum_dtype GX_INT64 / GX_FLOAT64 / GX_FLOAT32; mask_out holds ceil(n/32) words; *null_count_dev = nulls.
+ * gx_groupby_arg_select: ARGMIN / ARGMAX (global_memory_aggregator.cuh: ARGMIN/ARGMAX updates): out_rows[g] =
+ *   the smallest row i with group_of_row[i] == g, a valid value and vals[i] == target[g] (target = the
+ *   group's MIN or MAX; floats NaN == NaN); 0x7F7F7F7F where the group has no valid value. */
+int gx_square(int dtype, const void* in, int64_t n, void* out, gx_stream_t stream);
+int gx_var_from_sums(int sum_dtype, const void* sum_sqr, const void* sum, const int32_t* count, int64_t n,
+                     int ddof, int mode, double* out, uint32_t* mask_out, int64_t* null_count_dev,
+                     gx_stream_t stream);
+int gx_groupby_arg_select(int val_dtype, const void* vals, const uint32_t* vals_valid,
+                          const int32_t* group_of_row, int64_t n, const void* target, int64_t num_groups,
+                          int32_t* out_rows, gx_stream_t stream);
+
 /* Tuning / A-B knob (process-wide).  algo: 0 = auto (hash-partition rows into 256 LDS-sized
  * partitions and aggregate each in one workgroup's LDS when n >= 2^19, else the global-atomic
  * table), 1 = global-atomic table only, 2 = partitioned for every n > 0.  nsplit: workgroups per

@@ -421,7 +421,7 @@ def _exact_group_sums(labels: np.ndarray, values: np.ndarray, ngroups: int) -> n
 
 
 def groupby_agg(keys: np.ndarray, values: np.ndarray, aggs: Sequence[str],
-                keys_valid=None, values_valid=None, exact: bool = True):
+                keys_valid=None, values_valid=None, exact: bool = True, ddof: int = 1):
     """cudf::groupby::groupby(keys, null_policy::EXCLUDE).aggregate(...) for one key column and
     one values column (cpp/src/groupby/groupby.cu:220-237, hash path cpp/src/groupby/hash/*).
 
@@ -480,6 +480,53 @@ def groupby_agg(keys: np.ndarray, values: np.ndarray, aggs: Sequence[str],
                     else:
                         m = s.astype(np.float64) / count_valid
                 res[a] = (np.where(has, m, 0.0), has.copy())
+        elif a in ("var", "std", "m2"):
+            # hash path of the reference: SUM_OF_SQUARES + SUM + COUNT_VALID, then
+            # M2 = sum_sqr - sum*sum/count, VAR = M2/(count - ddof), STD = sqrt(VAR); null when
+            # count - ddof <= 0 (cpp/src/groupby/common/m2_var_std.cu:44-61,153-190).  Integer
+            # sums (and sums of squares) are int64 and wrap.
+            if values.dtype.kind == "f":
+                v64 = values[vv].astype(np.float64)
+                if exact:
+                    sm = _exact_group_sums(labels[vv], v64, g)
+                    ss = _exact_group_sums(labels[vv], v64 * v64, g)
+                else:
+                    sm = np.bincount(labels[vv], weights=v64, minlength=g)
+                    ss = np.bincount(labels[vv], weights=v64 * v64, minlength=g)
+            else:
+                acc = np.zeros(g, np.uint64)
+                np.add.at(acc, labels[vv], values[vv].astype(np.int64).view(np.uint64))
+                sm = acc.view(np.int64).astype(np.float64)
+                acc2 = np.zeros(g, np.uint64)
+                x = values[vv].astype(np.int64).view(np.uint64)
+                np.add.at(acc2, labels[vv], x * x)
+                ss = acc2.view(np.int64).astype(np.float64)
+            with np.errstate(divide="ignore", invalid="ignore"):
+                cnt = count_valid.astype(np.float64)
+                m2 = np.where(has, ss - sm * sm / cnt, 0.0)
+                df = count_valid - ddof
+                ok = has & (df > 0)
+                var = np.where(ok, m2 / np.where(ok, df, 1), 0.0)
+            if a == "m2":
+                res[a] = (m2, np.ones(g, bool))
+            elif a == "var":
+                res[a] = (var, ok)
+            else:
+                res[a] = (np.sqrt(var), ok)
+        elif a in ("argmin", "argmax"):
+            # row index (in the ORIGINAL table) of the group's MIN / MAX; smallest row on ties
+            rows = np.nonzero(kv)[0][vv]
+            fill = values[vv]
+            lab = labels[vv]
+            out = np.zeros(g, np.int32)
+            if len(fill):
+                sb = sortable_bits(fill)
+                if a == "argmax":
+                    sb = ~sb
+                o2 = np.lexsort((rows, sb, lab))
+                b = np.searchsorted(lab[o2], np.arange(g))
+                out = np.where(has, rows[o2][np.minimum(b, len(fill) - 1)], 0).astype(np.int32)
+            res[a] = (out, has.copy())
         elif a in ("min", "max"):
             fill = values[vv]
             lab = labels[vv]

@@ -570,6 +570,93 @@ int main()
       if (ev[g]) CHECK(mn[i] == emn[g] && mx[i] == emx[g]);
     }
   });
+  run("groupby VARIANCE / STD / M2 / ARGMIN / ARGMAX (var_tests.cpp:24-137, std_tests.cpp:24-134, argmin_tests.cpp:23-108, argmax_tests.cpp:22-107)", [&] {
+    auto run_one = [&](column_view keys, column_view vals, std::unique_ptr<groupby_aggregation> agg) {
+      groupby::groupby gb{table_view{{keys}}};
+      std::vector<groupby::aggregation_request> reqs(1);
+      reqs[0].values = vals;
+      reqs[0].aggregations.emplace_back(std::move(agg));
+      auto [k, res] = gb.aggregate(reqs);
+      auto order    = sorted_order(k->view());
+      auto ks       = gather(k->view(), order->view());
+      auto rs       = gather(table_view{{res[0].results[0]->view()}}, order->view());
+      return std::pair{std::move(ks), std::move(rs)};
+    };
+    auto near = [](std::vector<double> const& a, std::vector<double> const& b, std::vector<int> const& valid) {
+      if (a.size() != b.size()) return false;
+      for (std::size_t i = 0; i < a.size(); ++i)
+        if (valid[i] && std::fabs(a[i] - b[i]) > 1e-12 * std::max(1.0, std::fabs(b[i]))) return false;
+      return true;
+    };
+    auto keys = make_col<int32_t>({1, 2, 3, 1, 2, 2, 1, 3, 3, 2});
+    for (int t = 0; t < 3; ++t) {  // value types int32, int64, double
+      std::unique_ptr<column> vals = t == 0   ? make_col<int32_t>({0, 1, 2, 3, 4, 5, 6, 7, 8, 9})
+                                     : t == 1 ? make_col<int64_t>({0, 1, 2, 3, 4, 5, 6, 7, 8, 9})
+                                              : make_col<double>({0, 1, 2, 3, 4, 5, 6, 7, 8, 9});
+      auto [k, r] = run_one(keys->view(), vals->view(), make_variance_aggregation<groupby_aggregation>());
+      CHECK((to_host<int32_t>(k->get_column(0).view()) == std::vector<int32_t>{1, 2, 3}));
+      CHECK(r->get_column(0).type().id() == type_id::FLOAT64);
+      CHECK(near(to_host<double>(r->get_column(0).view()), {9.0, 131.0 / 12, 31.0 / 3}, {1, 1, 1}));
+      auto [k2, r2] = run_one(keys->view(), vals->view(), make_std_aggregation<groupby_aggregation>());
+      CHECK(near(to_host<double>(r2->get_column(0).view()), {3.0, std::sqrt(131.0 / 12), std::sqrt(31.0 / 3)}, {1, 1, 1}));
+      auto [k3, r3] = run_one(keys->view(), vals->view(), make_m2_aggregation<groupby_aggregation>());
+      CHECK(near(to_host<double>(r3->get_column(0).view()), {18.0, 131.0 / 4, 62.0 / 3}, {1, 1, 1}));
+    }
+    // null keys and values; ddof = 1 and 2
+    auto kn = make_col<int32_t>({1, 2, 3, 1, 2, 2, 1, 3, 3, 2, 4}, {1, 1, 1, 1, 1, 1, 1, 0, 1, 1, 1});
+    auto vn = make_col<int64_t>({0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 3}, {0, 1, 1, 1, 1, 0, 1, 1, 1, 1, 1});
+    {
+      auto [k, r] = run_one(kn->view(), vn->view(), make_variance_aggregation<groupby_aggregation>());
+      CHECK((to_host<int32_t>(k->get_column(0).view()) == std::vector<int32_t>{1, 2, 3, 4}));
+      CHECK((valid_host(r->get_column(0).view()) == std::vector<int>{1, 1, 1, 0}));
+      CHECK(near(to_host<double>(r->get_column(0).view()), {4.5, 49.0 / 3, 18.0, 0.0}, {1, 1, 1, 0}));
+      auto [k2, r2] = run_one(kn->view(), vn->view(), make_variance_aggregation<groupby_aggregation>(2));
+      CHECK((valid_host(r2->get_column(0).view()) == std::vector<int>{0, 1, 0, 0}));
+      CHECK(near(to_host<double>(r2->get_column(0).view()), {0.0, 98.0 / 3, 0.0, 0.0}, {0, 1, 0, 0}));
+      auto [k3, r3] = run_one(kn->view(), vn->view(), make_std_aggregation<groupby_aggregation>());
+      CHECK(near(to_host<double>(r3->get_column(0).view()), {3 / std::sqrt(2.0), 7 / std::sqrt(3.0), 3 * std::sqrt(2.0), 0.0}, {1, 1, 1, 0}));
+    }
+    // ARGMIN / ARGMAX
+    auto va = make_col<int32_t>({9, 8, 7, 6, 5, 4, 3, 2, 1, 0});
+    {
+      auto [k, r] = run_one(keys->view(), va->view(), make_argmin_aggregation<groupby_aggregation>());
+      CHECK(r->get_column(0).type().id() == type_id::INT32);
+      CHECK((to_host<int32_t>(r->get_column(0).view()) == std::vector<int32_t>{6, 9, 8}));
+      auto [k2, r2] = run_one(keys->view(), va->view(), make_argmax_aggregation<groupby_aggregation>());
+      CHECK((to_host<int32_t>(r2->get_column(0).view()) == std::vector<int32_t>{0, 1, 2}));
+    }
+    {
+      auto vb = make_col<double>({9, 8, 7, 6, 5, 4, 3, 2, 1, 0, 4}, {1, 1, 1, 1, 1, 0, 0, 1, 1, 1, 0});
+      auto [k, r] = run_one(kn->view(), vb->view(), make_argmin_aggregation<groupby_aggregation>());
+      CHECK((to_host<int32_t>(k->get_column(0).view()) == std::vector<int32_t>{1, 2, 3, 4}));
+      CHECK((valid_host(r->get_column(0).view()) == std::vector<int>{1, 1, 1, 0}));
+      auto h = to_host<int32_t>(r->get_column(0).view());
+      CHECK(h[0] == 3 && h[1] == 9 && h[2] == 8);
+      auto kx = make_col<int32_t>({1, 2, 3, 1, 2, 2, 1, 3, 3, 2, 4}, {1, 1, 0, 1, 1, 1, 1, 1, 1, 1, 1});
+      auto vx = make_col<int64_t>({9, 8, 7, 6, 5, 4, 3, 2, 1, 0, 4}, {0, 0, 1, 1, 1, 1, 1, 1, 1, 1, 0});
+      auto [k2, r2] = run_one(kx->view(), vx->view(), make_argmax_aggregation<groupby_aggregation>());
+      CHECK((valid_host(r2->get_column(0).view()) == std::vector<int>{1, 1, 1, 0}));
+      auto h2 = to_host<int32_t>(r2->get_column(0).view());
+      CHECK(h2[0] == 3 && h2[1] == 4 && h2[2] == 7);
+    }
+    // all of them in one request, mixed with SUM: every result in the same (key) order
+    {
+      auto vals = make_col<double>({0, 1, 2, 3, 4, 5, 6, 7, 8, 9});
+      groupby::groupby gb{table_view{{keys->view()}}};
+      std::vector<groupby::aggregation_request> reqs(1);
+      reqs[0].values = vals->view();
+      reqs[0].aggregations.emplace_back(make_sum_aggregation<groupby_aggregation>());
+      reqs[0].aggregations.emplace_back(make_variance_aggregation<groupby_aggregation>());
+      reqs[0].aggregations.emplace_back(make_argmax_aggregation<groupby_aggregation>());
+      reqs[0].aggregations.emplace_back(make_sum_of_squares_aggregation<groupby_aggregation>());
+      auto [k, res] = gb.aggregate(reqs);
+      CHECK((to_host<int32_t>(k->get_column(0).view()) == std::vector<int32_t>{1, 2, 3}));
+      CHECK((to_host<double>(res[0].results[0]->view()) == std::vector<double>{9, 19, 17}));
+      CHECK(near(to_host<double>(res[0].results[1]->view()), {9.0, 131.0 / 12, 31.0 / 3}, {1, 1, 1}));
+      CHECK((to_host<int32_t>(res[0].results[2]->view()) == std::vector<int32_t>{6, 9, 8}));
+      CHECK((to_host<double>(res[0].results[3]->view()) == std::vector<double>{45, 123, 117}));
+    }
+  });
   run("groupby SUM scan (sum_scan_tests.cpp:33-48,118-139)", [&] {
     auto keys = make_col<int32_t>({1, 2, 3, 1, 2, 2, 1, 3, 3, 2});
     auto vals = make_col<int32_t>({0, 1, 2, 3, 4, 5, 6, 7, 8, 9});

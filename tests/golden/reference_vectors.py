@@ -201,6 +201,36 @@ GROUPBY = [
     # groupby/sum_tests.cpp:167-188 int32 overflow accumulates in int64
     dict(name="sum_overflow_int32", keys=[0, 0], vals=[-2147483648, -2147483648], vals_dtype="int32",
          agg="sum", expect_keys=[0], expect=[-4294967296], expect_valid=[1]),
+    # groupby/var_tests.cpp:24-42 basic; :92-113 null keys and values; :115-137 ddof = 2
+    dict(name="var_basic", keys=_K_BASIC, vals=_V_BASIC, agg="var",
+         expect_keys=[1, 2, 3], expect=[9.0, 131.0 / 12, 31.0 / 3], expect_valid=[1, 1, 1]),
+    dict(name="var_null_keys_values", keys=_K_NULL, keys_valid=_KM_NULL, vals=[0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 3],
+         vals_valid=[0, 1, 1, 1, 1, 0, 1, 1, 1, 1, 1], agg="var",
+         expect_keys=[1, 2, 3, 4], expect=[4.5, 49.0 / 3, 18.0, 0.0], expect_valid=[1, 1, 1, 0]),
+    dict(name="var_ddof2", keys=_K_NULL, keys_valid=_KM_NULL, vals=[0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 3],
+         vals_valid=[0, 1, 1, 1, 1, 0, 1, 1, 1, 1, 1], agg="var", ddof=2,
+         expect_keys=[1, 2, 3, 4], expect=[0.0, 98.0 / 3, 0.0, 0.0], expect_valid=[0, 1, 0, 0]),
+    # groupby/std_tests.cpp:24-42 basic; :92-112 null keys and values; :114-134 ddof = 2
+    dict(name="std_basic", keys=_K_BASIC, vals=_V_BASIC, agg="std",
+         expect_keys=[1, 2, 3], expect=[3.0, (131.0 / 12) ** 0.5, (31.0 / 3) ** 0.5], expect_valid=[1, 1, 1]),
+    dict(name="std_null_keys_values", keys=_K_NULL, keys_valid=_KM_NULL, vals=[0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 3],
+         vals_valid=[0, 1, 1, 1, 1, 0, 1, 1, 1, 1, 1], agg="std",
+         expect_keys=[1, 2, 3, 4], expect=[3 / 2 ** 0.5, 7 / 3 ** 0.5, 3 * 2 ** 0.5, 0.0], expect_valid=[1, 1, 1, 0]),
+    dict(name="std_ddof2", keys=_K_NULL, keys_valid=_KM_NULL, vals=[0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 3],
+         vals_valid=[0, 1, 1, 1, 1, 0, 1, 1, 1, 1, 1], agg="std", ddof=2,
+         expect_keys=[1, 2, 3, 4], expect=[0.0, 7 * (2.0 / 3) ** 0.5, 0.0, 0.0], expect_valid=[0, 1, 0, 0]),
+    # groupby/argmin_tests.cpp:23-41 basic, :83-108 null keys and values
+    dict(name="argmin_basic", keys=_K_BASIC, vals=[9, 8, 7, 6, 5, 4, 3, 2, 1, 0], agg="argmin",
+         expect_keys=[1, 2, 3], expect=[6, 9, 8], expect_valid=[1, 1, 1]),
+    dict(name="argmin_null_keys_values", keys=_K_NULL, keys_valid=_KM_NULL, vals=[9, 8, 7, 6, 5, 4, 3, 2, 1, 0, 4],
+         vals_valid=[1, 1, 1, 1, 1, 0, 0, 1, 1, 1, 0], agg="argmin",
+         expect_keys=[1, 2, 3, 4], expect=[3, 9, 8, 0], expect_valid=[1, 1, 1, 0]),
+    # groupby/argmax_tests.cpp:22-40 basic, :82-107 null keys and values (the null key is row 2 here)
+    dict(name="argmax_basic", keys=_K_BASIC, vals=[9, 8, 7, 6, 5, 4, 3, 2, 1, 0], agg="argmax",
+         expect_keys=[1, 2, 3], expect=[0, 1, 2], expect_valid=[1, 1, 1]),
+    dict(name="argmax_null_keys_values", keys=_K_NULL, keys_valid=[1, 1, 0, 1, 1, 1, 1, 1, 1, 1, 1],
+         vals=[9, 8, 7, 6, 5, 4, 3, 2, 1, 0, 4], vals_valid=[0, 0, 1, 1, 1, 1, 1, 1, 1, 1, 0], agg="argmax",
+         expect_keys=[1, 2, 3, 4], expect=[3, 4, 7, 0], expect_valid=[1, 1, 1, 0]),
 ]
 
 GROUPBY_SCAN = [

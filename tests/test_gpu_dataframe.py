@@ -93,8 +93,11 @@ def test_groupby_on_two_keys_and_float_key_matches_pandas(DF):
     pdf = pd.DataFrame({"a": rng.integers(0, 30, n).astype(np.int16), "b": rng.integers(-5, 5, n), "f": rng.integers(0, 9, n) / 4,
                         "v": rng.random(n), "w": rng.integers(-1000, 1000, n)})
     for by in (["a", "b"], ["f"], ["b", "f", "a"]):
-        exp = pdf.groupby(by).agg(v_sum=("v", "sum"), v_max=("v", "max"), w_sum=("w", "sum"), w_count=("w", "count")).reset_index()
-        got = DF.from_pandas(pdf).groupby(by).agg({"v": ["sum", "max"], "w": ["sum", "count"]}).to_pandas()
+        exp = pdf.groupby(by).agg(v_sum=("v", "sum"), v_max=("v", "max"), w_sum=("w", "sum"), w_count=("w", "count"),
+                                  w_var=("w", "var"), v_std=("v", "std")).reset_index()
+        got = DF.from_pandas(pdf).groupby(by).agg({"v": ["sum", "max", "std"], "w": ["sum", "count", "var"]}).to_pandas()
+        np.testing.assert_allclose(got["w_var"], exp["w_var"], rtol=1e-9)
+        np.testing.assert_allclose(got["v_std"], exp["v_std"], rtol=1e-7)
         for b in by:
             np.testing.assert_array_equal(got[b], exp[b])
         np.testing.assert_allclose(got["v_sum"], exp["v_sum"], rtol=1e-13)

@@ -294,3 +294,71 @@ def test_multi_column_groupby(gx, schema, nulls):
         a[1] += 1
         a[2] += 1
     assert got == {k: tuple(v) for k, v in exp.items()}
+
+
+# ------------------------------------------------------------------------------------------------
+# compound groupby aggregations: VARIANCE / STD / M2, ARGMIN / ARGMAX
+# ------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("vdtype", ["int32", "int64", "float64"])
+@pytest.mark.parametrize("case", [c for c in gv.GROUPBY if c["agg"] in ("var", "std", "argmin", "argmax")], ids=lambda c: c["name"])
+def test_reference_golden_groupby_compound(gx, case, vdtype):
+    Column, ops = gx
+    keys, km = gv.col(case["keys"], "int32", case.get("keys_valid"))
+    vals, vm = gv.col(case["vals"], vdtype, case.get("vals_valid"))
+    K, V = Column.from_numpy(keys, km), Column.from_numpy(vals, vm)
+    ev = np.array(case["expect_valid"], bool)
+    exp = np.array(case["expect"])
+    if case["agg"] in ("var", "std"):
+        k, var, std, m2, cv = ops.groupby_var_std(K, V, ddof=case.get("ddof", 1))
+        np.testing.assert_array_equal(k.to_numpy(), np.array(case["expect_keys"], np.int32))
+        r = var if case["agg"] == "var" else std
+        np.testing.assert_array_equal(r.valid_numpy() if r.mask is not None and r.null_count else np.ones(r.size, bool), ev)
+        assert r.dtype == np.float64
+        assert np.all(orc.ulp_diff(r.to_numpy()[ev], exp[ev].astype(np.float64)) <= 1)
+    else:
+        k, amin, amax, cv = ops.groupby_argmin_argmax(K, V)
+        o = np.argsort(k.to_numpy(), kind="stable")
+        np.testing.assert_array_equal(k.to_numpy()[o], np.array(case["expect_keys"], np.int32))
+        np.testing.assert_array_equal(cv.to_numpy()[o] > 0, ev)
+        r = (amin if case["agg"] == "argmin" else amax).to_numpy()[o]
+        assert r.dtype == np.int32
+        np.testing.assert_array_equal(r[ev], exp[ev])
+
+
+@pytest.mark.parametrize("vdtype", ["int8", "int64", "uint32", "float32", "float64"])
+@pytest.mark.parametrize("nulls", [False, True])
+def test_groupby_compound_matches_oracle(gx, vdtype, nulls):
+    """700 k rows (the LDS-partitioned sum path), many ties for ARGMIN / ARGMAX (smallest row wins), NaN and
+    -0.0 among the float values; integer VAR is bit-exact (int64 sums, the same double formula), float
+    VAR is compared relative to the sum of squares (the formula cancels)."""
+    Column, ops = gx
+    rng = np.random.default_rng(12)
+    n = 700_001
+    keys = rng.integers(0, 5000, n).astype(np.int64)
+    if np.dtype(vdtype).kind == "f":
+        vals = (rng.integers(-40, 40, n) / 8).astype(vdtype)
+        vals[rng.random(n) < 0.01] = -0.0
+    else:
+        info = np.iinfo(vdtype)
+        vals = rng.integers(max(info.min, -100), min(info.max, 100) + 1, n).astype(vdtype)
+    kv = rng.random(n) > 0.05 if nulls else None
+    vv = rng.random(n) > 0.2 if nulls else None
+    K, V = Column.from_numpy(keys, kv), Column.from_numpy(vals, vv)
+    ek, res = orc.groupby_agg(keys, vals, ["var", "std", "m2", "argmin", "argmax", "count_valid"], kv, vv, exact=False)
+    k, var, std, m2, cv = ops.groupby_var_std(K, V)
+    np.testing.assert_array_equal(k.to_numpy(), ek)
+    np.testing.assert_array_equal(cv.to_numpy(), res["count_valid"][0])
+    for got, name in ((var, "var"), (std, "std"), (m2, "m2")):
+        e, ev = res[name]
+        gvalid = got.valid_numpy() if got.null_count else np.ones(got.size, bool)
+        np.testing.assert_array_equal(gvalid, ev)
+        if np.dtype(vdtype).kind in "iu":
+            np.testing.assert_array_equal(got.to_numpy()[ev], e[ev])
+        else:
+            np.testing.assert_allclose(got.to_numpy()[ev], e[ev], rtol=1e-9, atol=1e-9)
+    k2, amin, amax, cv2 = ops.groupby_argmin_argmax(K, V)
+    o = np.argsort(k2.to_numpy(), kind="stable")
+    np.testing.assert_array_equal(k2.to_numpy()[o], ek)
+    ev = res["argmin"][1]
+    np.testing.assert_array_equal(amin.to_numpy()[o][ev], res["argmin"][0][ev])
+    np.testing.assert_array_equal(amax.to_numpy()[o][ev], res["argmax"][0][ev])

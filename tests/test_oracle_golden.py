@@ -81,7 +81,7 @@ def test_groupby_golden(case, vdtype):
     vdtype = case.get("vals_dtype", vdtype)
     keys, km = gv.col(case["keys"], "int32", case.get("keys_valid"))
     vals, vm = gv.col(case["vals"], vdtype, case.get("vals_valid"))
-    out_keys, res = orc.groupby_agg(keys, vals, [case["agg"]], km, vm)
+    out_keys, res = orc.groupby_agg(keys, vals, [case["agg"]], km, vm, ddof=case.get("ddof", 1))
     r, rv = res[case["agg"]]
     np.testing.assert_array_equal(out_keys, np.array(case["expect_keys"], np.int32))
     ev = np.array(case["expect_valid"], bool)
@@ -91,7 +91,9 @@ def test_groupby_golden(case, vdtype):
         assert r.dtype == (np.int64 if np.dtype(vdtype).kind == "i" else np.dtype(vdtype))
     if case["agg"].startswith("count"):
         assert r.dtype == np.int32
-    if case["agg"] == "mean":
+    if case["agg"].startswith("arg"):
+        assert r.dtype == np.int32
+    if case["agg"] in ("mean", "var", "std"):
         assert r.dtype == np.float64
         assert np.all(orc.ulp_diff(r[ev], exp[ev].astype(np.float64)) <= 1)
     else:
