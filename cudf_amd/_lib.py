@@ -7,6 +7,11 @@ fallback anywhere in the package.
 import ctypes
 import os
 
+# PyTorch's HIP runtime must be in the process BEFORE libcudf_amd.so is loaded: the kernels are handed
+# torch's device pointers and streams, so both have to bind to the same libamdhip64 instance (loading the
+# library first pulls in /opt/rocm's copy, torch then brings its own, and launches fail with hipErrorNoDevice).
+import torch  # noqa: F401,E402
+
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libcudf_amd.so")
 

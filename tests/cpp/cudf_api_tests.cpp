@@ -7,6 +7,7 @@
 #include <cudf/copying.hpp>
 #include <cudf/groupby.hpp>
 #include <cudf/hashing.hpp>
+#include <cudf/interop.hpp>
 #include <cudf/join/distinct_hash_join.hpp>
 #include <cudf/join/filtered_join.hpp>
 #include <cudf/join/hash_join.hpp>
@@ -729,6 +730,60 @@ int main()
     auto sorted = out;
     std::sort(sorted.begin(), sorted.end());
     CHECK((sorted == to_host<int32_t>(c->view())));
+  });
+  run("Arrow C Device Data Interface round trip (interop.hpp:477-606,838-885)", [] {
+    std::vector<std::unique_ptr<column>> cols;
+    cols.emplace_back(make_col<int64_t>({5, -3, 9, 0, 7}));
+    cols.emplace_back(make_col<double>({0.5, 1.5, 2.5, 3.5, 4.5}, {1, 0, 1, 1, 0}));
+    cols.emplace_back(make_col<uint16_t>({1, 2, 3, 4, 5}));
+    table t{std::move(cols)};
+    std::vector<column_metadata> meta{{"a"}, {"b"}, {"c"}};
+    auto schema = to_arrow_schema(t.view(), meta);
+    CHECK(std::string{schema->format} == "+s" && schema->n_children == 3);
+    CHECK(std::string{schema->children[0]->format} == "l" && std::string{schema->children[0]->name} == "a");
+    CHECK(std::string{schema->children[1]->format} == "g" && (schema->children[1]->flags & ARROW_FLAG_NULLABLE));
+    CHECK(std::string{schema->children[2]->format} == "S" && !(schema->children[2]->flags & ARROW_FLAG_NULLABLE));
+    auto dev = to_arrow_device(std::move(t));
+    CHECK(dev->device_type == ARROW_DEVICE_ROCM && dev->sync_event != nullptr);
+    CHECK(dev->array.length == 5 && dev->array.n_children == 3 && dev->array.n_buffers == 1);
+    CHECK(dev->array.children[1]->null_count == 2 && dev->array.children[1]->n_buffers == 2);
+    CHECK(dev->array.children[0]->buffers[0] == nullptr && dev->array.children[0]->buffers[1] != nullptr);
+    // import: zero-copy views over the exported buffers
+    auto tv = from_arrow_device(schema.get(), dev.get());
+    CHECK(tv->num_columns() == 3 && tv->num_rows() == 5);
+    CHECK(tv->column(0).head<void>() == dev->array.children[0]->buffers[1]);
+    CHECK((to_host<int64_t>(tv->column(0)) == std::vector<int64_t>{5, -3, 9, 0, 7}));
+    CHECK((valid_host(tv->column(1)) == std::vector<int>{1, 0, 1, 1, 0}) && tv->column(1).null_count() == 2);
+    CHECK((to_host<uint16_t>(tv->column(2)) == std::vector<uint16_t>{1, 2, 3, 4, 5}));
+    // the imported view feeds the hot path directly
+    auto order = sorted_order(table_view{{tv->column(0)}});
+    CHECK((to_host<int32_t>(order->view()) == std::vector<int32_t>{1, 3, 0, 4, 2}));
+    // a single column, null_count left to the consumer (-1), and a sliced (offset) non-owning export
+    auto c  = make_col<int32_t>({10, 20, 30, 40, 50, 60}, {1, 1, 0, 1, 0, 1});
+    column_view sliced{c->type(), 4, c->view().head<void>(), c->view().null_mask(), 2, 1};
+    auto dcol = to_arrow_device(sliced);
+    CHECK(dcol->array.offset == 1 && dcol->array.length == 4);
+    dcol->array.null_count = -1;
+    ArrowSchema cs{};
+    cs.format = "i";
+    auto cv = from_arrow_device_column(&cs, dcol.get());
+    CHECK(cv->size() == 4 && cv->offset() == 1 && cv->null_count() == 2);
+    CHECK((to_host<int32_t>(*cv) == std::vector<int32_t>{20, 30, 40, 50}));
+    CHECK((valid_host(*cv) == std::vector<int>{1, 0, 1, 0}));
+    // errors
+    CHECK(throws<std::invalid_argument>([&] { (void)from_arrow_device(nullptr, dev.get()); }));
+    CHECK(throws<cudf::data_type_error>([&] { (void)from_arrow_device(&cs, dcol.get()); }));  // not a struct
+    ArrowDeviceArray host_side = *dcol;
+    host_side.device_type      = ARROW_DEVICE_CPU;
+    host_side.sync_event       = nullptr;
+    CHECK(throws<std::invalid_argument>([&] { (void)from_arrow_device_column(&cs, &host_side); }));
+    ArrowSchema bad{};
+    bad.format = "u";  // utf8 string
+    CHECK(throws<cudf::data_type_error>([&] { (void)from_arrow_device_column(&bad, dcol.get()); }));
+    auto b8 = make_col<uint8_t>({1, 0});
+    column_view b{data_type{type_id::BOOL8}, 2, b8->view().head<void>(), nullptr, 0};  // Arrow packs booleans into bits
+    CHECK(throws<cudf::data_type_error>([&] { (void)to_arrow_device(b); }));
+    CHECK(throws<std::invalid_argument>([&] { (void)to_arrow_schema(table_view{{c->view()}}, std::vector<column_metadata>{}); }));
   });
   run("gather NULLIFY / column & table ownership (gather.cuh:506-577, column.hpp:248-269)", [] {
     auto c = make_col<double>({1., 2., 3.}, {1, 0, 1});
