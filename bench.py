@@ -45,6 +45,9 @@ def parse():
     ap.add_argument("--gb-split", type=int, default=1)
     ap.add_argument("--no-partitioned-join", action="store_true", help="join: probe the table directly")
     ap.add_argument("--no-hybrid", action="store_true", help="sort: disable the hybrid MSD path (LSD passes only)")
+    ap.add_argument("--key-range", type=int, nargs=2, default=None, metavar=("LO", "HI"),
+                    help="sort: keys uniform in [LO, HI) instead of the full int64 range (the reference's own "
+                         "benchmark distribution is 100 10001: benchmarks/sort/sort.cpp:24-26)")
     ap.add_argument("--cpu-baseline", dest="cpu", action="store_true", default=True)
     ap.add_argument("--no-cpu-baseline", dest="cpu", action="store_false")
     ap.add_argument("--cpu-rows", type=float, default=0, help="rows of the CPU-baseline sample (0 = per-workload default)")
@@ -192,7 +195,10 @@ def main():
             dist_step = lambda: D.distributed_groupby_sum_count(dgk, dgv, local=local_ops)
             dist_name = f"{n:.0e}-row-per-GPU groupby(int32 key, 1e6 groups).agg(f64 sum,count), partials exchanged"
     if args.workload in ("sort", "sorted_order"):
-        keys = ops.random_column(np.int64, n, seed=42 + rank)
+        if args.key_range:
+            keys = ops.random_column(np.int64, n, seed=42 + rank, lo=args.key_range[0], hi=args.key_range[1])
+        else:
+            keys = ops.random_column(np.int64, n, seed=42 + rank)
         pairs = args.workload == "sorted_order"
         out = Column.empty(np.int32 if pairs else np.int64, n)
         nb = ctypes.c_size_t(0)
@@ -206,6 +212,8 @@ def main():
         bytes_per_row_pass = 24 if pairs else 16   # read key(+idx) + write key(+idx)
         model_bytes_row = 200 if pairs else 136    # 8-pass LSD model
         workload = f"{n:.0e}-row int64 " + ("sorted_order (radix sort pairs, int32 payload)" if pairs else "radix sort (cudf::sort, keys only)")
+        if args.key_range:
+            workload += f", keys uniform in [{args.key_range[0]}, {args.key_range[1]})"
         unit_rows = n
     elif args.workload == "join":
         nb_rows = max(1, n // 10)

@@ -376,9 +376,29 @@ def full_join(left_cols, right_cols, left_valids=None, right_valids=None, nulls_
 def semi_join(left_cols, right_cols, left_valids=None, right_valids=None, nulls_equal=True) -> np.ndarray:
     """cudf::filtered_join::semi_join: ascending indices of the left rows that have at least one
     match in right (contains map + stable copy_if: cpp/src/join/filtered_join/filtered_join.cu:124-156;
-    include/cudf/join/filtered_join.hpp:96-116)."""
-    l, _ = inner_join(left_cols, right_cols, left_valids, right_valids, nulls_equal)
-    return np.unique(l).astype(np.int32)
+    include/cudf/join/filtered_join.hpp:96-116).  Same row equality as inner_join, without
+    materialising the pairs (null x null would be a cross product)."""
+    if not isinstance(left_cols, (list, tuple)):
+        left_cols, right_cols = [left_cols], [right_cols]
+    left_cols = [np.asarray(c) for c in left_cols]
+    right_cols = [np.asarray(c) for c in right_cols]
+    nl, nr = len(left_cols[0]), len(right_cols[0])
+    if nl == 0 or nr == 0:
+        return np.empty(0, np.int32)
+    lv = [np.ones(nl, bool) if m is None else np.asarray(m, bool) for m in (left_valids or [None] * len(left_cols))]
+    rv = [np.ones(nr, bool) if m is None else np.asarray(m, bool) for m in (right_valids or [None] * len(right_cols))]
+    lcols = [np.where(m, c, c.dtype.type(0)) for c, m in zip(left_cols, lv)] + [m.astype(np.uint8) for m in lv]
+    rcols = [np.where(m, c, c.dtype.type(0)) for c, m in zip(right_cols, rv)] + [m.astype(np.uint8) for m in rv]
+    lid, rid = _factorize_rows(lcols, rcols)
+    l_ok = np.ones(nl, bool)
+    r_ok = np.ones(nr, bool)
+    if not nulls_equal:
+        for m in lv:
+            l_ok &= m
+        for m in rv:
+            r_ok &= m
+    hit = l_ok & np.isin(lid, rid[r_ok])
+    return np.nonzero(hit)[0].astype(np.int32)
 
 
 def anti_join(left_cols, right_cols, left_valids=None, right_valids=None, nulls_equal=True) -> np.ndarray:
