@@ -3,7 +3,7 @@ set -u
 mkdir -p gpurun_out
 export TMPDIR=/tmp
 O=gpurun_out
-L=$O/run28.log
+L=$O/runNN.log
 : > $L
 pmc() { # name, counters, args...
   local name=$1; shift
@@ -19,7 +19,7 @@ for r in csv.DictReader(open(sys.argv[1])):
     if "k_pj" in r["Kernel_Name"]:
         print("%-34s %-22s %12.6g" % (r["Kernel_Name"][:34], r["Counter_Name"], float(r["Counter_Value"])))
 PY
-done > $O/pmc28_summary.txt 2>&1
+done > $O/pmcNN_summary.txt 2>&1
 find $O/pmc_p_* -name "*.csv" -size +2M -delete
-cat $O/pmc28_summary.txt
+cat $O/pmcNN_summary.txt
 tail -5 $L

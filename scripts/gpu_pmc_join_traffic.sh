@@ -3,7 +3,7 @@ set -u
 mkdir -p gpurun_out
 export TMPDIR=/tmp
 O=gpurun_out
-L=$O/run21.log
+L=$O/runNN.log
 : > $L
 pmc() { # name, counters, args...
   local name=$1; shift
@@ -20,6 +20,6 @@ for r in csv.DictReader(open(sys.argv[1])):
     if "k_pj" in r["Kernel_Name"] or "k_build" in r["Kernel_Name"]:
         print("%-34s %-14s %12.6g" % (r["Kernel_Name"][:34], r["Counter_Name"], float(r["Counter_Value"])))
 PY
-done > $O/pmc21_summary.txt 2>&1
+done > $O/pmcNN_summary.txt 2>&1
 find $O/pmc_j_* -name "*.csv" -size +2M -delete
-cat $O/pmc21_summary.txt
+cat $O/pmcNN_summary.txt
