@@ -65,6 +65,43 @@ class HipLocalOps:
         sdt = vals.dtype if vals.dtype.is_floating_point else torch.int64
         return self._tensor(k, keys.dtype), self._tensor(s, sdt), self._tensor(cv, torch.int32)
 
+    def reduce(self, values: torch.Tensor, op: str) -> torch.Tensor:
+        """1-element tensor: cudf::reduce of the shard in the accumulator type (int64 / float64 for
+        sum and product, the input type for min / max); the operator's identity for an empty shard."""
+        acc = _acc_dtype(values.dtype, op)
+        if values.numel() == 0:
+            return torch.tensor([_identity(acc, op)], dtype=acc, device=values.device)
+        v, _ = self._ops.reduce(self._col(values), op, out_dtype=np.dtype(str(acc).replace("torch.", "")))
+        return torch.tensor([v.item()], dtype=acc, device=values.device)
+
+    def scan(self, values: torch.Tensor, op: str, inclusive: bool) -> torch.Tensor:
+        return self._tensor(self._ops.scan(self._col(values), op, inclusive), values.dtype)
+
+
+def _acc_dtype(dtype: torch.dtype, op: str) -> torch.dtype:
+    if op in ("sum", "product"):
+        return torch.float64 if dtype.is_floating_point else torch.int64
+    return dtype
+
+
+def _identity(dtype: torch.dtype, op: str):
+    if op == "sum":
+        return 0
+    if op == "product":
+        return 1
+    if dtype.is_floating_point:
+        return float("inf") if op == "min" else float("-inf")
+    info = torch.iinfo(dtype)
+    return info.max if op == "min" else info.min
+
+
+def _combine(a: torch.Tensor, b: torch.Tensor, op: str) -> torch.Tensor:
+    if op == "sum":
+        return a + b
+    if op == "product":
+        return a * b
+    return torch.minimum(a, b) if op == "min" else torch.maximum(a, b)
+
 
 # ------------------------------------------------------------------------------------------------
 # exchange primitives
@@ -189,3 +226,54 @@ def distributed_groupby_sum_count(keys: torch.Tensor, vals: torch.Tensor, local:
     o1 = torch.argsort(mk)
     o2 = torch.argsort(mk2)
     return mk[o1], ms[o1], mc[o2]
+
+
+def _gather_partials(part: torch.Tensor, group=None) -> List[torch.Tensor]:
+    _, world = _world(group)
+    parts = [torch.empty_like(part) for _ in range(world)]
+    dist.all_gather(parts, part, group=group)
+    return parts
+
+
+def distributed_reduce(values: torch.Tensor, op: str = "sum", local: Optional[object] = None, group=None):
+    """cudf::reduce over the concatenation of all ranks' shards (SURVEY.md 8e: an all-gather of one
+    partial per GPU).  Every rank returns the same Python scalar; partials are folded in rank order, so
+    the floating-point result does not depend on which rank asks."""
+    local = local or HipLocalOps()
+    parts = _gather_partials(local.reduce(values, op), group)
+    acc = parts[0]
+    for p in parts[1:]:
+        acc = _combine(acc, p, op)
+    return acc.item()
+
+
+def distributed_scan(values: torch.Tensor, op: str = "sum", inclusive: bool = True, local: Optional[object] = None,
+                     group=None) -> torch.Tensor:
+    """cudf::scan over the concatenation of all ranks' shards in rank order; rank r returns its shard of
+    the result (same dtype as the input: integers wrap like the single-GPU scan).  One all-gather of the
+    shard totals; the exclusive prefix of the totals of the ranks before this one is folded into the
+    shard's first element, so the local scan kernel produces the global values in its one pass
+    (the input is restored afterwards)."""
+    local = local or HipLocalOps()
+    rank, _ = _world(group)
+    dt = values.dtype
+    total = local.reduce(values, op)
+    if op in ("sum", "product") and not dt.is_floating_point:
+        total = total.to(dt)  # wrap to the scan's element type: (a + b) mod 2^w is associative
+    elif dt.is_floating_point:
+        total = total.to(dt)
+    parts = _gather_partials(total, group)
+    if rank == 0 or values.numel() == 0:
+        return local.scan(values, op, inclusive)
+    prefix = parts[0]
+    for p in parts[1:rank]:
+        prefix = _combine(prefix, p, op)
+    first = values[:1].clone()
+    values[:1] = _combine(prefix, first, op)
+    try:
+        out = local.scan(values, op, inclusive)
+    finally:
+        values[:1] = first
+    if not inclusive:
+        out[:1] = prefix  # an exclusive scan starts at the identity: here at everything before this shard
+    return out

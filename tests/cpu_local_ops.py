@@ -29,3 +29,20 @@ class NumpyLocalOps:
     def groupby_sum_count(self, keys, vals):
         k, res = orc.groupby_agg(keys.numpy(), vals.numpy(), ["sum", "count_valid"], exact=False)
         return torch.from_numpy(k), torch.from_numpy(res["sum"][0]), torch.from_numpy(res["count_valid"][0])
+
+    def reduce(self, values, op):
+        v = values.numpy()
+        acc = {"sum": np.float64 if v.dtype.kind == "f" else np.int64,
+               "product": np.float64 if v.dtype.kind == "f" else np.int64}.get(op, v.dtype)
+        if v.size == 0:
+            ident = {"sum": 0, "product": 1}.get(op)
+            if ident is None:
+                lim = np.finfo(v.dtype) if v.dtype.kind == "f" else np.iinfo(v.dtype)
+                ident = (np.inf if v.dtype.kind == "f" else lim.max) if op == "min" else (-np.inf if v.dtype.kind == "f" else lim.min)
+            return torch.from_numpy(np.array([ident], dtype=acc))
+        r, _ = orc.reduce(v, op, None, np.dtype(acc))
+        return torch.from_numpy(np.array([r], dtype=acc))
+
+    def scan(self, values, op, inclusive):
+        out, _ = orc.scan(values.numpy(), op, inclusive)
+        return torch.from_numpy(out)

@@ -30,6 +30,12 @@ def _shards(rank, world, what):
         left = rng.integers(0, 3000, 4000 + 500 * rank).astype(np.int64)
         right = (rng.permutation(4000)[: 1500 + 100 * rank]).astype(np.int64)
         return left, right
+    if what.startswith("scan") or what.startswith("reduce"):
+        n = [4001, 0, 2500][rank % 3]                           # rank 1 is empty on purpose
+        dt = what.split(":")[2]
+        if dt == "int32":
+            return rng.integers(-2**31, 2**31, n).astype(np.int32)   # wraps
+        return rng.integers(-1000, 1000, n).astype(dt)            # exact in float64
     keys = rng.integers(0, 700, 20000 + 1000 * rank).astype(np.int32)
     vals = rng.integers(0, 100, len(keys)).astype(np.float64)  # small integers: sums are exact in any order
     return keys, vals
@@ -53,6 +59,17 @@ def _worker(rank, world, port, what, outdir):
         l, r = _shards(rank, world, what)
         gl, gr = D.distributed_inner_join(torch.from_numpy(l), torch.from_numpy(r), local=local)
         np.save(os.path.join(outdir, f"join_{rank}.npy"), np.stack([gl.numpy(), gr.numpy()]))
+    elif what.startswith("scan"):
+        _, op, dt, inc = what.split(":")
+        v = _shards(rank, world, what)
+        keep = v.copy()
+        out = D.distributed_scan(torch.from_numpy(v), op, inc == "inc", local=local)
+        assert np.array_equal(v, keep)                          # the input is restored
+        np.save(os.path.join(outdir, f"scan_{rank}.npy"), out.numpy())
+    elif what.startswith("reduce"):
+        _, op, dt = what.split(":")
+        r = D.distributed_reduce(torch.from_numpy(_shards(rank, world, what)), op, local=local)
+        np.save(os.path.join(outdir, f"reduce_{rank}.npy"), np.array([r]))
     else:
         k, v = _shards(rank, world, what)
         gk, gs, gc = D.distributed_groupby_sum_count(torch.from_numpy(k), torch.from_numpy(v), local=local)
@@ -103,3 +120,30 @@ def test_distributed_groupby_gloo(world, tmp_path):
     np.testing.assert_array_equal(res[0][o], uk.astype(np.float64))      # every group exactly once
     np.testing.assert_array_equal(res[1][o], np.bincount(keys, weights=vals)[uk])
     np.testing.assert_array_equal(res[2][o], np.bincount(keys)[uk].astype(np.float64))
+
+
+@pytest.mark.parametrize("world", [2, 3])
+@pytest.mark.parametrize("op,dt,inc", [("sum", "int64", "inc"), ("sum", "int32", "exc"), ("sum", "float64", "inc"),
+                                       ("min", "int64", "inc"), ("max", "float64", "exc")])
+def test_distributed_scan_gloo(world, op, dt, inc, tmp_path):
+    from oracle import cudf_oracle as orc
+    what = f"scan:{op}:{dt}:{inc}"
+    _run(world, what, tmp_path)
+    got = np.concatenate([np.load(tmp_path / f"scan_{r}.npy") for r in range(world)])
+    full = np.concatenate([_shards(r, world, what) for r in range(world)])
+    exp, _ = orc.scan(full, op, inc == "inc")
+    assert got.dtype == np.dtype(dt)
+    np.testing.assert_array_equal(got, exp)
+
+
+@pytest.mark.parametrize("world", [2, 3])
+@pytest.mark.parametrize("op,dt", [("sum", "int64"), ("sum", "float64"), ("min", "int64"), ("max", "float64")])
+def test_distributed_reduce_gloo(world, op, dt, tmp_path):
+    from oracle import cudf_oracle as orc
+    what = f"reduce:{op}:{dt}"
+    _run(world, what, tmp_path)
+    res = [np.load(tmp_path / f"reduce_{r}.npy")[0] for r in range(world)]
+    full = np.concatenate([_shards(r, world, what) for r in range(world)])
+    exp, _ = orc.reduce(full, op, None, np.float64 if (dt == "float64" and op == "sum") else (np.int64 if op == "sum" else None))
+    assert all(r == res[0] for r in res)                       # every rank returns the same scalar
+    assert res[0] == exp

@@ -46,3 +46,21 @@ def test_distributed_ops_single_rank_rccl(pg):
     np.testing.assert_array_equal(k.cpu().numpy(), uk)
     np.testing.assert_array_equal(s.cpu().numpy(), np.bincount(gk, weights=gv)[uk])
     np.testing.assert_array_equal(c.cpu().numpy(), np.bincount(gk)[uk])
+
+
+def test_distributed_reduce_scan_single_rank_rccl(pg):
+    """reduce = all-gather of one partial per GPU, scan = exclusive prefix of the shard
+    totals; here with the HIP LocalOps on the 1-rank RCCL group (the multi-rank folding runs under gloo)."""
+    import torch
+    D = pg
+    rng = np.random.default_rng(4)
+    v = rng.integers(-1000, 1000, 300_001).astype(np.int64)
+    t = torch.from_numpy(v).cuda()
+    assert D.distributed_reduce(t, "sum") == int(v.sum())
+    assert D.distributed_reduce(t, "min") == int(v.min()) and D.distributed_reduce(t, "max") == int(v.max())
+    f = (v / 4).astype(np.float64)
+    assert D.distributed_reduce(torch.from_numpy(f).cuda(), "sum") == float(f.sum())   # quarters: exact
+    np.testing.assert_array_equal(D.distributed_scan(t, "sum", True).cpu().numpy(), np.cumsum(v))
+    ex = D.distributed_scan(t, "max", False).cpu().numpy()
+    np.testing.assert_array_equal(ex[1:], np.maximum.accumulate(v)[:-1])
+    assert D.distributed_reduce(t[:0], "sum") == 0
