@@ -201,6 +201,21 @@ GROUPBY = [
     # groupby/sum_tests.cpp:167-188 int32 overflow accumulates in int64
     dict(name="sum_overflow_int32", keys=[0, 0], vals=[-2147483648, -2147483648], vals_dtype="int32",
          agg="sum", expect_keys=[0], expect=[-4294967296], expect_valid=[1]),
+    # groupby/min_tests.cpp:26-42 basic, :98-120 null keys and values; :497-516 -inf among the values
+    dict(name="min_basic", keys=_K_BASIC, vals=_V_BASIC, agg="min",
+         expect_keys=[1, 2, 3], expect=[0, 1, 2], expect_valid=[1, 1, 1]),
+    dict(name="min_null_keys_values", keys=_K_NULL, keys_valid=_KM_NULL, vals=_V_NULL, vals_valid=_VM_NULL, agg="min",
+         expect_keys=[1, 2, 3, 4], expect=[3, 1, 2, 0], expect_valid=[1, 1, 1, 0]),
+    dict(name="min_with_infinity", keys=[1, 2, 1, 2], vals=[1.0, 1.0, float("-inf"), 2.0], vals_dtype="float64", agg="min",
+         expect_keys=[1, 2], expect=[float("-inf"), 1.0], expect_valid=[1, 1]),
+    # groupby/max_tests.cpp:30-46 basic, :102-123 null keys and values; :505-523 +inf among the values
+    dict(name="max_basic", keys=_K_BASIC, vals=_V_BASIC, agg="max",
+         expect_keys=[1, 2, 3], expect=[6, 9, 8], expect_valid=[1, 1, 1]),
+    dict(name="max_null_keys_values", keys=_K_NULL, keys_valid=_KM_NULL, vals=_V_NULL,
+         vals_valid=[1, 1, 1, 1, 1, 1, 0, 1, 1, 0, 0], agg="max",
+         expect_keys=[1, 2, 3, 4], expect=[3, 5, 8, 0], expect_valid=[1, 1, 1, 0]),
+    dict(name="max_with_infinity", keys=[1, 2, 1, 2], vals=[1.0, 1.0, float("inf"), 2.0], vals_dtype="float64", agg="max",
+         expect_keys=[1, 2], expect=[float("inf"), 2.0], expect_valid=[1, 1]),
     # groupby/var_tests.cpp:24-42 basic; :92-113 null keys and values; :115-137 ddof = 2
     dict(name="var_basic", keys=_K_BASIC, vals=_V_BASIC, agg="var",
          expect_keys=[1, 2, 3], expect=[9.0, 131.0 / 12, 31.0 / 3], expect_valid=[1, 1, 1]),

@@ -300,9 +300,11 @@ def test_multi_column_groupby(gx, schema, nulls):
 # compound groupby aggregations: VARIANCE / STD / M2, ARGMIN / ARGMAX
 # ------------------------------------------------------------------------------------------------
 @pytest.mark.parametrize("vdtype", ["int32", "int64", "float64"])
-@pytest.mark.parametrize("case", [c for c in gv.GROUPBY if c["agg"] in ("var", "std", "argmin", "argmax")], ids=lambda c: c["name"])
+@pytest.mark.parametrize("case", [c for c in gv.GROUPBY if c["agg"] in ("var", "std", "argmin", "argmax", "min", "max")],
+                         ids=lambda c: c["name"])
 def test_reference_golden_groupby_compound(gx, case, vdtype):
     Column, ops = gx
+    vdtype = case.get("vals_dtype", vdtype)
     keys, km = gv.col(case["keys"], "int32", case.get("keys_valid"))
     vals, vm = gv.col(case["vals"], vdtype, case.get("vals_valid"))
     K, V = Column.from_numpy(keys, km), Column.from_numpy(vals, vm)
@@ -315,6 +317,14 @@ def test_reference_golden_groupby_compound(gx, case, vdtype):
         np.testing.assert_array_equal(r.valid_numpy() if r.mask is not None and r.null_count else np.ones(r.size, bool), ev)
         assert r.dtype == np.float64
         assert np.all(orc.ulp_diff(r.to_numpy()[ev], exp[ev].astype(np.float64)) <= 1)
+    elif case["agg"] in ("min", "max"):
+        k, mn, mx, cv = ops.groupby_min_max(K, V)
+        o = np.argsort(k.to_numpy(), kind="stable")
+        np.testing.assert_array_equal(k.to_numpy()[o], np.array(case["expect_keys"], np.int32))
+        np.testing.assert_array_equal(cv.to_numpy()[o] > 0, ev)
+        r = (mn if case["agg"] == "min" else mx).to_numpy()[o]
+        assert r.dtype == np.dtype(vdtype)                     # MIN / MAX keep the values' type
+        np.testing.assert_array_equal(r[ev], exp[ev].astype(vdtype))
     else:
         k, amin, amax, cv = ops.groupby_argmin_argmax(K, V)
         o = np.argsort(k.to_numpy(), kind="stable")
