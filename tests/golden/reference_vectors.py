@@ -275,6 +275,26 @@ SCAN = [
          null_include=True, expect=[5, 9, 15, 0, 0, 0, 0, 0], expect_valid=[1, 1, 1, 0, 0, 0, 0, 0]),  # :202-213
 ]
 
+# ---------------------------------------------------------------------------------------------
+# column reduce (reductions/reduction_tests.cpp; the expected values are what the tests' own
+# std::accumulate / std::min_element over the literal inputs give; typed over the numeric types)
+# ---------------------------------------------------------------------------------------------
+REDUCE = [
+    # reduction_tests.cpp:330-368  SumReductionTest.Sum
+    dict(name="sum", op="sum", values=[6, -14, 13, 64, 0, -13, -20, 45], valid=None, expect=81, expect_valid=True),
+    dict(name="sum_nulls", op="sum", values=[6, -14, 13, 64, 0, -13, -20, 45], valid=[1, 1, 0, 0, 1, 1, 1, 1], expect=4,
+         expect_valid=True),
+    # reduction_tests.cpp:122-200  MinMaxReductionTest.MinMaxReductions
+    dict(name="min", op="min", values=[5, 0, -120, -111, 0, 64, 63, 99, 123, -16], valid=None, expect=-120, expect_valid=True),
+    dict(name="max", op="max", values=[5, 0, -120, -111, 0, 64, 63, 99, 123, -16], valid=None, expect=123, expect_valid=True),
+    dict(name="min_nulls", op="min", values=[5, 0, -120, -111, 0, 64, 63, 99, 123, -16],
+         valid=[1, 1, 0, 1, 1, 1, 0, 1, 0, 1], expect=-111, expect_valid=True),
+    dict(name="max_nulls", op="max", values=[5, 0, -120, -111, 0, 64, 63, 99, 123, -16],
+         valid=[1, 1, 0, 1, 1, 1, 0, 1, 0, 1], expect=99, expect_valid=True),
+    # reduction_tests.cpp:999-1013  all_null_output: the result scalar is invalid
+    dict(name="sum_all_null", op="sum", values=[1, 2, 3], valid=[0, 0, 0], expect=0, expect_valid=False),
+]
+
 # Published MurmurHash3_x86_32 known-answer vectors (Appleby's SMHasher reference implementation;
 # the reference delegates the body to cuco::murmurhash3_32,
 # include/cudf/hashing/detail/murmurhash3_x86_32.cuh:16,45).  (bytes, seed, digest)

@@ -101,6 +101,17 @@ def test_reduce_matches_oracle(gx, dtype):
                     assert got == exp, (dtype, n, op, got, exp)
 
 
+@pytest.mark.parametrize("dtype", ["int8", "int32", "int64", "float32", "float64"])
+@pytest.mark.parametrize("case", gv.REDUCE, ids=lambda c: c["name"])
+def test_reference_golden_reduce(gx, case, dtype):
+    Column, ops = gx
+    vals, mask = gv.col(case["values"], dtype, case["valid"])
+    got, ok = ops.reduce(Column.from_numpy(vals, mask), case["op"])
+    assert ok == case["expect_valid"]
+    if ok:
+        assert got == case["expect"]
+
+
 @pytest.mark.parametrize("dtype", ["int8", "uint8", "int16", "int32", "uint32", "int64", "uint64", "float32", "float64", "bool"])
 def test_murmur3_matches_oracle(gx, dtype):
     Column, ops = gx

@@ -191,3 +191,14 @@ def test_hash_partition_oracle_properties():
         for q in range(p):
             seg = order[offs[q]:offs[q + 1]]
             assert np.all(pid[seg] == q) and np.all(np.diff(seg) > 0)
+
+
+@pytest.mark.parametrize("dtype", ["int8", "int32", "int64", "float32", "float64"])
+@pytest.mark.parametrize("case", gv.REDUCE, ids=lambda c: c["name"])
+def test_reduce_golden(case, dtype):
+    vals, mask = gv.col(case["values"], dtype, case["valid"])
+    out_dtype = (np.float64 if np.dtype(dtype).kind == "f" else np.int64) if case["op"] == "sum" else None
+    r, ok = orc.reduce(vals, case["op"], mask, out_dtype)
+    assert ok == case["expect_valid"]
+    if ok:
+        assert r == case["expect"]
