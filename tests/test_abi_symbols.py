@@ -37,3 +37,24 @@ def test_pure_host_entry_points():
     assert b8 == 256 + 16 * 2048 + 2048 // 2
     assert _lib.lib.gx_join_table_bytes(4, 1000, 0.5) == 256 + 8 * 2048 + 2048 // 2
     assert _lib.lib.gx_join_table_bytes(3, 1000, 0.5) == 0
+
+
+def test_public_headers_compile_clean(tmp_path):
+    """The drop-in boundary is a C header: gx.h must compile as C99 (-pedantic), and the cudf:: API headers
+    as C++20 with -Wall -Wextra, without a GPU and without warnings."""
+    import glob
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    inc = ["-I" + os.path.join(root, "include"), "-I/opt/rocm/include"]
+    c = tmp_path / "abi.c"
+    c.write_text("#include <cudf_amd/gx.h>\nint main(void) { return gx_dtype_size(GX_INT64) == 8 ? 0 : 1; }\n")
+    r = subprocess.run(["gcc", "-std=c99", "-Wall", "-Wextra", "-pedantic", "-Werror", "-fsyntax-only", *inc, str(c)],
+                       capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
+    hdrs = sorted(os.path.relpath(h, os.path.join(root, "include"))
+                  for h in glob.glob(os.path.join(root, "include", "cudf", "**", "*.hpp"), recursive=True))
+    cpp = tmp_path / "api.cpp"
+    cpp.write_text("".join(f"#include <{h}>\n" for h in hdrs) + "int main() { return 0; }\n")
+    r = subprocess.run(["g++", "-std=c++20", "-Wall", "-Wextra", "-Werror", "-D__HIP_PLATFORM_AMD__", "-fsyntax-only", *inc, str(cpp)],
+                       capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr[-3000:]
