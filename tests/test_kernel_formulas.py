@@ -1,0 +1,131 @@
+"""CPU checks of the bit-level formulas the HIP kernels rely on, restated in Python and compared with
+brute force.  They do not run the kernels (the -m gpu tests do); they pin the arithmetic the kernels
+were derived from, so a future edit of a constant or a shift can be checked without a GPU.
+
+  * scan_tags8 (cudf_amd/csrc/gx_join.hip): the 4-bit slot tags of the partitioned hash-join probe --
+    carry-free zero-nibble detection, "tag matches before the first empty slot";
+  * k_bitmask_copy (cudf_amd/csrc/gx_gather.hip): funnel shift + edge-word masks of the offset bitmap copy;
+  * normalise_float / gx_pack_keys (cudf_amd/csrc/gx_rank.hip): float equality classes and key packing;
+  * mm_encode order (cudf_amd/csrc/gx_groupby.hip) == oracle.sortable_bits order for floats.
+"""
+import numpy as np
+
+from oracle import cudf_oracle as orc
+
+M32 = 0xFFFFFFFF
+
+
+def _scan_tags8(w0, w1, li, tagpat):
+    """Python transcription of scan_tags8: returns (cand mask, chain_ends_in_window)."""
+    two = (w1 << 32) | w0
+    x = (two >> ((li & 7) * 4)) & M32                               # v_alignbit_b32(w1, w0, shift)
+    y = x ^ tagpat
+    z = ~(((x & 0x77777777) + 0x77777777) | x) & 0x88888888 & M32
+    m = ~(((y & 0x77777777) + 0x77777777) | y) & 0x88888888 & M32
+    cand = m & (((z & (-z & M32)) - 1) & M32)
+    return cand, z != 0
+
+
+def test_scan_tags8_matches_bruteforce():
+    rng = np.random.default_rng(0)
+    for _ in range(20000):
+        tags = rng.integers(0, 16, 16)
+        if rng.random() < 0.5:
+            tags[rng.integers(0, 16, rng.integers(0, 6))] = 0      # some empty slots
+        w0 = sum(int(t) << (4 * i) for i, t in enumerate(tags[:8]))
+        w1 = sum(int(t) << (4 * i) for i, t in enumerate(tags[8:]))
+        li = int(rng.integers(0, 8))
+        tag = int(rng.integers(1, 16))
+        cand, ended = _scan_tags8(w0, w1, li, tag * 0x11111111)
+        window = tags[li:li + 8]
+        exp_cand, exp_ended = 0, False
+        for i, t in enumerate(window):
+            if t == 0:
+                exp_ended = True
+                break
+            if t == tag:
+                exp_cand |= 0x8 << (4 * i)                          # flag = top bit of the nibble
+        assert cand == exp_cand and ended == exp_ended
+
+
+def test_bitmask_copy_word_formula():
+    """dst word = funnel(src[sw], src[sw + 1]) >> sh, masked at the two edge words."""
+    rng = np.random.default_rng(1)
+    for _ in range(300):
+        nbits = int(rng.integers(1, 200))
+        doff, soff = int(rng.integers(0, 70)), int(rng.integers(0, 70))
+        src = rng.random(soff + nbits) > 0.5
+        dst = rng.random(doff + nbits + 40) > 0.5
+        def words(bits):  # LSB-first uint32 words, padded with two spare words
+            padded = np.zeros(((len(bits) + 31) // 32 + 2) * 32, bool)
+            padded[: len(bits)] = bits
+            return np.packbits(padded, bitorder="little").view(np.uint32).astype(np.uint64)
+        sw, dw = words(src), words(dst)
+        send = (soff + nbits + 31) >> 5
+        for w in range(doff >> 5, (doff + nbits + 31) >> 5):
+            lo, hi = max(w << 5, doff), min((w + 1) << 5, doff + nbits)
+            mask = 0xFFFFFFFF if hi - lo == 32 else (((1 << (hi - lo)) - 1) << (lo & 31))
+            sb = soff + (lo - doff)
+            two = int(sw[sb >> 5])
+            if (sb & 31) and (sb >> 5) + 1 < send:
+                two |= int(sw[(sb >> 5) + 1]) << 32
+            v = ((two >> (sb & 31)) << (lo & 31)) & M32
+            dw[w] = (int(dw[w]) & ~mask & M32) | (v & mask)
+        got = np.unpackbits(dw.astype(np.uint32).view(np.uint8), bitorder="little")[: len(dst)].astype(bool)
+        exp = dst.copy()
+        exp[doff:doff + nbits] = src[soff:soff + nbits]
+        np.testing.assert_array_equal(got, exp)
+
+
+def _normalise(bits, size):
+    if size == 4:
+        x = bits & 0x7FFFFFFF
+        return 0 if x == 0 else (0x7FC00000 if x > 0x7F800000 else bits)
+    x = bits & 0x7FFFFFFFFFFFFFFF
+    return 0 if x == 0 else (0x7FF8000000000000 if x > 0x7FF0000000000000 else bits)
+
+
+def test_float_normalisation_gives_the_row_comparators_equality_classes():
+    """normalise_float(a) == normalise_float(b)  <=>  a == b or both NaN  (so -0.0 == +0.0, NaN == NaN)."""
+    for dt, size in ((np.float32, 4), (np.float64, 8)):
+        u = np.uint32 if size == 4 else np.uint64
+        vals = np.array([0.0, -0.0, 1.0, -1.0, np.inf, -np.inf, np.nan, -np.nan, 1e-40, -1e-40, 3.5], dt)
+        bits = vals.view(u)
+        extra = np.array([0x7FC00001, 0xFFC12345], np.uint32) if size == 4 else np.array([0x7FF8000000000001, 0xFFF0000000000001], np.uint64)
+        vals = np.concatenate([vals, extra.view(dt)])
+        bits = np.concatenate([bits, extra])
+        for a, ba in zip(vals, bits):
+            for b, bb in zip(vals, bits):
+                same = (a == b) or (np.isnan(a) and np.isnan(b))
+                assert (_normalise(int(ba), size) == _normalise(int(bb), size)) == bool(same)
+        # and the oracle's join key uses the same classes
+        k = orc._join_key(vals)
+        for i in range(len(vals)):
+            for j in range(len(vals)):
+                assert (k[i] == k[j]) == (_normalise(int(bits[i]), size) == _normalise(int(bits[j]), size))
+
+
+def test_pack_keys_layout():
+    """column 0 most significant; widths sum to <= 8 bytes; equality of packed words == equality of rows."""
+    rng = np.random.default_rng(2)
+    a = rng.integers(-5, 5, 200).astype(np.int32)
+    b = rng.integers(0, 4, 200).astype(np.uint16)
+    c = rng.integers(-3, 3, 200).astype(np.int8)
+    packed = (a.view(np.uint32).astype(np.uint64) << np.uint64(24)) | (b.astype(np.uint64) << np.uint64(8)) | c.view(np.uint8).astype(np.uint64)
+    rows = list(zip(a.tolist(), b.tolist(), c.tolist()))
+    for i in range(0, 200, 7):
+        for j in range(200):
+            assert (packed[i] == packed[j]) == (rows[i] == rows[j])
+
+
+def test_minmax_word_order_is_the_sort_order():
+    """gx_groupby_min_max widens values to 64-bit words whose unsigned order is the value order (sign flip for
+    integers, IEEE total-order flip with -0.0 -> +0.0 and NaN above +Inf for floats): the same map as
+    oracle.sortable_bits, which the sort goldens pin."""
+    f = np.array([-np.inf, -3.5, -0.0, 0.0, 1e-300, 2.0, np.inf, np.nan], np.float64)
+    sb = orc.sortable_bits(f)
+    assert sb[2] == sb[3]                                            # -0.0 == +0.0
+    assert all(sb[i] <= sb[i + 1] for i in range(len(sb) - 1)) and sb[-1] == np.uint64(2**64 - 1)
+    i = np.array([-2**63, -1, 0, 1, 2**63 - 1], np.int64)
+    si = orc.sortable_bits(i)
+    assert all(si[k] < si[k + 1] for k in range(len(si) - 1))
