@@ -129,3 +129,34 @@ def test_minmax_word_order_is_the_sort_order():
     i = np.array([-2**63, -1, 0, 1, 2**63 - 1], np.int64)
     si = orc.sortable_bits(i)
     assert all(si[k] < si[k + 1] for k in range(len(si) - 1))
+
+
+def test_split_sort_four_transposition_phases_suffice():
+    """wave_split_sort (gx_common.hpp): after the counting split on one byte every bin holds <= 4 keys and
+    the bins are in order; the kernel then runs even, odd, even, odd compare-exchange phases over the
+    whole wave (element pairs (2l, 2l+1), then (2l+1, 2l+2)).  Exhaustively: every arrangement of bins of
+    1..4 keys, at either alignment, in every internal order, comes out sorted."""
+    import itertools
+
+    def phases(a):
+        a = list(a)
+        for _ in range(2):
+            for i in range(0, len(a) - 1, 2):      # even phase
+                if a[i + 1] < a[i]:
+                    a[i], a[i + 1] = a[i + 1], a[i]
+            for i in range(1, len(a) - 1, 2):      # odd phase
+                if a[i + 1] < a[i]:
+                    a[i], a[i + 1] = a[i + 1], a[i]
+        return a
+
+    checked = 0
+    for lead in (0, 1):                            # a 1-key bin in front shifts the alignment
+        for sizes in itertools.product((1, 2, 3, 4), repeat=3):
+            bins = ([[0]] if lead else []) + [list(range(10 * (b + 1), 10 * (b + 1) + s)) for b, s in enumerate(sizes)]
+            for perm in itertools.product(*[itertools.permutations(b) for b in bins]):
+                arr = [x for b in perm for x in b]
+                assert phases(arr) == sorted(arr)
+                checked += 1
+    assert checked > 10000
+    # and five keys in one bin are NOT always sorted by four phases: the kernel's "any bin > 4 -> network" guard
+    assert any(phases(p) != sorted(p) for p in itertools.permutations(range(5)))
