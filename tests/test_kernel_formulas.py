@@ -160,3 +160,69 @@ def test_split_sort_four_transposition_phases_suffice():
     assert checked > 10000
     # and five keys in one bin are NOT always sorted by four phases: the kernel's "any bin > 4 -> network" guard
     assert any(phases(p) != sorted(p) for p in itertools.permutations(range(5)))
+
+
+def _network_steps(name):
+    """The (xor distance, low-bit) compare-exchange steps of a wave network, parsed from gx_common.hpp."""
+    import os
+    import re
+    src = open(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "cudf_amd", "csrc", "gx_common.hpp")).read()
+    body = re.search(r"void " + name + r"\(uint64_t& k\)\s*\{(.*?)\n\}", src, re.S).group(1)
+    return [(int(m), int(l)) for m, l in re.findall(r"cmpx<(\d+),\s*(\d+)>", body)]
+
+
+def _run_network(keys, steps):
+    k = list(keys)
+    for m, lowbit in steps:                      # cmpx<M, LOWBIT>: lane ^ M is the partner, lanes with (lane & LOWBIT) == 0 keep the minimum
+        nk = list(k)
+        for lane in range(64):
+            o = k[lane ^ m]
+            keepmin = (lane & lowbit) == 0
+            nk[lane] = k[lane] if ((k[lane] < o) == keepmin) else o
+        k = nk
+    return k
+
+
+def test_wave_bitonic_networks_sort():
+    """wave_bitonic64 sorts any 64 keys; wave_halfclean64 sorts any bitonic-merged half (checked through
+    wave_bitonic128's construction: two sorted 64-runs, element e paired with e ^ 127, then half-cleaners)."""
+    rng = np.random.default_rng(3)
+    s64 = _network_steps("wave_bitonic64")
+    hc = _network_steps("wave_halfclean64")
+    assert len(s64) == 21 and len(hc) == 6
+    for trial in range(300):
+        if trial % 3 == 0:
+            keys = rng.integers(0, 2, 64).tolist()                  # 0-1 inputs (zero-one principle, sampled)
+        elif trial % 3 == 1:
+            keys = rng.integers(0, 5, 64).tolist()                  # many duplicates
+        else:
+            keys = rng.integers(0, 2**63, 64).tolist()
+        assert _run_network(keys, s64) == sorted(keys)
+    for trial in range(200):
+        keys = rng.integers(0, 50 if trial % 2 else 2**62, 128).tolist()
+        k0, k1 = _run_network(keys[:64], s64), _run_network(keys[64:], s64)
+        o1, o0 = [k1[l ^ 63] for l in range(64)], [k0[l ^ 63] for l in range(64)]
+        k0 = [min(a, b) for a, b in zip(k0, o1)]
+        k1 = [max(a, b) for a, b in zip(k1, o0)]
+        assert _run_network(k0, hc) + _run_network(k1, hc) == sorted(keys)
+
+
+def test_match_rank8_bitop3_truth_table():
+    """match_rank8: m &= (bit ? v : ~v) per digit bit, as v_bitop3_b32 with truth table 0x90 (index = a*4 + b*2 + c,
+    c = the lane's bit replicated): the surviving mask is exactly the lanes with the same digit."""
+    tt = 0x90
+    bitop3 = lambda a, b, c: sum((((tt >> ((((a >> i) & 1) << 2) | (((b >> i) & 1) << 1) | ((c >> i) & 1))) & 1) << i) for i in range(64))
+    rng = np.random.default_rng(4)
+    for _ in range(60):
+        digits = rng.integers(0, rng.integers(1, 40), 64)
+        live = rng.random(64) > 0.2
+        active = sum(1 << l for l in range(64) if live[l])
+        for lane in np.nonzero(live)[0][:16]:
+            m = active
+            for b in range(8):
+                beta = -((int(digits[lane]) >> b) & 1) & (2**64 - 1)               # 0 or all ones
+                v = sum(1 << l for l in range(64) if live[l] and (int(digits[l]) >> b) & 1)
+                m = bitop3(m, v, beta)
+            same = [l for l in range(64) if live[l] and digits[l] == digits[lane]]
+            assert m == sum(1 << l for l in same)
+            assert bin(m & ((1 << int(lane)) - 1)).count("1") == sum(1 for l in same if l < lane)   # stable rank
