@@ -226,3 +226,42 @@ def test_match_rank8_bitop3_truth_table():
             same = [l for l in range(64) if live[l] and digits[l] == digits[lane]]
             assert m == sum(1 << l for l in same)
             assert bin(m & ((1 << int(lane)) - 1)).count("1") == sum(1 for l in same if l < lane)   # stable rank
+
+
+def test_compensated_atomic_sum_is_order_independent_to_one_ulp():
+    """gx_groupby float SUM: every add is a RETURNING atomic, the thread recomputes the rounding error of
+    that add from the returned old value (two_sum) and adds it to a compensation word; the result is
+    sum + comp.  Modelled here with Python floats: whatever order the adds land in -- also for values of
+    wildly different magnitude and sign -- the result stays within 1 ulp of the correctly rounded sum
+    (math.fsum), while the plain running sum drifts."""
+    import math
+    rng = np.random.default_rng(5)
+
+    def model(values):
+        s = 0.0
+        comp = 0.0
+        for v in values:
+            old = s
+            s = old + v                      # the atomic add; `old` is what ds_add_rtn_f64 / global atomic returns
+            bb = s - old                     # two_sum: exact error of old + v
+            err = (old - (s - bb)) + (v - bb)
+            comp += err                      # second atomic, on the compensation word
+        return s + comp, s
+
+    worst_plain = 0
+    for case in range(12):
+        n = 20000
+        if case % 3 == 0:
+            v = rng.random(n)
+        elif case % 3 == 1:
+            v = rng.standard_normal(n) * 10.0 ** rng.integers(-8, 8, n)       # 16 orders of magnitude, both signs
+        else:
+            v = np.concatenate([rng.random(n // 2) * 1e12, -rng.random(n // 2) * 1e12, rng.random(10)])
+        exact = math.fsum(v.tolist())
+        for _ in range(3):
+            order = rng.permutation(len(v))
+            got, plain = model(v[order].tolist())
+            ulps = abs(got - exact) / math.ulp(exact) if exact != 0 else abs(got)
+            assert ulps <= 1.0, (case, ulps)
+            worst_plain = max(worst_plain, abs(plain - exact) / math.ulp(exact))
+    assert worst_plain > 1.0                 # the uncompensated sum is NOT within 1 ulp on these inputs
