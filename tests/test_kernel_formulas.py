@@ -265,3 +265,63 @@ def test_compensated_atomic_sum_is_order_independent_to_one_ulp():
             assert ulps <= 1.0, (case, ulps)
             worst_plain = max(worst_plain, abs(plain - exact) / math.ulp(exact))
     assert worst_plain > 1.0                 # the uncompensated sum is NOT within 1 ulp on these inputs
+
+
+def test_decoupled_lookback_protocol_model():
+    """The partition passes' tile hand-off (gx_sort.hip k_radix_pass / k_msd_pass): a tile publishes
+    {flag 1 = aggregate | 2 = inclusive, epoch, count} in ONE 8-byte granule, walks back over its
+    predecessors in windows of LBW granules (loaded as a batch, re-read while a granule is empty or carries
+    another epoch), adds aggregates until it meets an inclusive value, then publishes its own inclusive
+    value.  The status array is NOT cleared between passes: the epoch makes stale granules invisible.
+    Modelled with random interleavings at single load / store granularity, tiles started in ticket order."""
+    import random
+    LBW = 4
+
+    def tile_program(tile, epoch, count, status, result):
+        # publish the aggregate (tile 0 publishes an inclusive value straight away)
+        status[tile] = (2 if tile == 0 else 1, epoch, count)
+        yield
+        prefix = 0
+        if tile > 0:
+            p, done = tile - 1, False
+            while not done:
+                window = []
+                for k in range(LBW):                       # batch of loads
+                    q = p - k
+                    window.append(status[q] if q >= 0 else (2, epoch, 0))
+                    yield
+                for k in range(LBW):
+                    if done:
+                        break
+                    x = window[k]
+                    while x[0] == 0 or x[1] != epoch:      # empty or stale: spin on this granule
+                        yield
+                        x = status[p - k]
+                    prefix += x[2]
+                    if x[0] == 2:
+                        done = True
+                p -= LBW
+            status[tile] = (2, epoch, prefix + count)
+            yield
+        result[tile] = prefix
+
+    rnd = random.Random(7)
+    for trial in range(60):
+        ntiles = rnd.randint(1, 40)
+        status = [(0, 0, 0)] * 40                          # reused across epochs, never cleared
+        for epoch in range(1, 5):
+            counts = [rnd.randint(0, 1000) for _ in range(ntiles)]
+            result = [None] * ntiles
+            running, started = [], 0
+            while started < ntiles or running:
+                # tickets: the next tile may start at any time, but only in index order
+                if started < ntiles and (not running or rnd.random() < 0.3):
+                    running.append(tile_program(started, epoch, counts[started], status, result))
+                    started += 1
+                    continue
+                g = rnd.choice(running)
+                try:
+                    next(g)
+                except StopIteration:
+                    running.remove(g)
+            assert result == [sum(counts[:t]) for t in range(ntiles)], (trial, epoch)
