@@ -325,3 +325,45 @@ def test_decoupled_lookback_protocol_model():
                 except StopIteration:
                     running.remove(g)
             assert result == [sum(counts[:t]) for t in range(ntiles)], (trial, epoch)
+
+
+def test_row_encoding_refinement_algorithm():
+    """Multi-column keys (ops.encode_rows / cpp row_encoding.cpp): every column -> dense ids, then
+    (ids so far, next column's ids) pairs are packed into 64 bits and ranked again.  Restated with NumPy:
+    the final ids are the dense rank of the ROWS in lexicographic order (so sorting by id sorts by key,
+    equal rows share an id, null == null as its own last value per column), and the first row of every id
+    is the smallest row index of the group."""
+    rng = np.random.default_rng(8)
+
+    def dense_rank(values, valid=None):          # what gx_dense_rank returns: ids ascending with the value, nulls last
+        n = len(values)
+        ok = np.ones(n, bool) if valid is None else valid
+        uniq, inv = np.unique(values[ok], return_inverse=True)
+        ids = np.full(n, len(uniq), np.int64)
+        ids[ok] = inv.reshape(-1)
+        return ids
+
+    for trial in range(30):
+        n = int(rng.integers(1, 400))
+        ncols = int(rng.integers(1, 5))
+        cols = [rng.integers(-3, 4, n).astype(rng.choice([np.int8, np.int32, np.int64])) for _ in range(ncols)]
+        valids = [rng.random(n) > 0.15 if rng.random() < 0.5 else None for _ in range(ncols)]
+        cur = None
+        for c, v in zip(cols, valids):
+            ids = dense_rank(c, v)
+            if cur is None:
+                cur = ids
+            else:
+                pair = (cur.astype(np.uint64) << np.uint64(32)) | ids.astype(np.uint64)      # gx_pack_keys of two int32 ids
+                cur = dense_rank(pair)
+        # brute force: rows as tuples with null -> (1, 0) after every value (0, v)
+        rows = [tuple((1, 0) if (v is not None and not v[i]) else (0, int(c[i])) for c, v in zip(cols, valids)) for i in range(n)]
+        order = sorted(set(rows))
+        exp = np.array([order.index(r) for r in rows])
+        np.testing.assert_array_equal(cur, exp)
+        first = {}
+        for i, r in enumerate(rows):
+            first.setdefault(r, i)
+        rep = np.full(len(order), n)
+        np.minimum.at(rep, cur, np.arange(n))
+        assert [first[r] for r in order] == rep.tolist()
