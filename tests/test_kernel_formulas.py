@@ -367,3 +367,87 @@ def test_row_encoding_refinement_algorithm():
         rep = np.full(len(order), n)
         np.minimum.at(rep, cur, np.arange(n))
         assert [first[r] for r in order] == rep.tolist()
+
+
+def test_dictionary_row_encoder_model():
+    """cpp/src/row_encoding.cpp (cudf::hash_join builds once, probes many): per-column dictionaries learnt
+    from the BUILD table, probe values looked up (unseen -> JoinNoMatch = INT32_MIN, null -> the build side's
+    null id when nulls compare equal and it has one), (id, id) pairs packed and looked up again.  Restated with
+    NumPy and checked against brute-force row equality for inner-join pairs, both null_equality values."""
+    rng = np.random.default_rng(9)
+    NO = -(2**31)
+
+    def rank(values, valid):
+        ok = np.ones(len(values), bool) if valid is None else valid
+        uniq = np.unique(values[ok])
+        ids = np.full(len(values), len(uniq), np.int64)
+        ids[ok] = np.searchsorted(uniq, values[ok])
+        return ids, uniq, (len(uniq) if not ok.all() else -1)         # ids, dictionary, null id
+
+    def lookup(uniq, values, valid, null_id, nulls_equal):
+        ok = np.ones(len(values), bool) if valid is None else valid
+        pos = np.searchsorted(uniq, values)
+        hit = ok & (pos < len(uniq)) & (uniq[np.minimum(pos, len(uniq) - 1)] == values) if len(uniq) else np.zeros(len(values), bool)
+        ids = np.where(hit, pos, NO).astype(np.int64)
+        if nulls_equal and null_id >= 0:
+            ids[~ok] = null_id
+        return ids
+
+    pack = lambda a, b: ((a.astype(np.int64) & 0xFFFFFFFF).astype(np.uint64) << np.uint64(32)) | (b.astype(np.int64) & 0xFFFFFFFF).astype(np.uint64)
+
+    for trial in range(40):
+        ncols = int(rng.integers(2, 5))
+        nb, npr = int(rng.integers(1, 60)), int(rng.integers(1, 120))
+        nulls_equal = bool(trial % 2)
+        build = [rng.integers(0, 4, nb) for _ in range(ncols)]
+        probe = [rng.integers(-1, 5, npr) for _ in range(ncols)]          # -1 and 4 never occur on the build side
+        bval = [rng.random(nb) > 0.2 if rng.random() < 0.6 else None for _ in range(ncols)]
+        pval = [rng.random(npr) > 0.2 if rng.random() < 0.6 else None for _ in range(ncols)]
+        # ---- build side: dictionaries per column and per inner pair level
+        col_dict, pair_dict, cur = [], [], None
+        for k in range(ncols):
+            ids, uniq, null_id = rank(build[k], bval[k])
+            col_dict.append((uniq, null_id))
+            if k == 0:
+                cur = ids
+                continue
+            pair = pack(cur, ids)
+            if k == ncols - 1:
+                bkey = pair
+            else:
+                pid, puniq, _ = rank(pair, None)
+                pair_dict.append(puniq)
+                cur = pid
+        # ---- probe side
+        cur = None
+        for k in range(ncols):
+            ids = lookup(col_dict[k][0], probe[k], pval[k], col_dict[k][1], nulls_equal)
+            if k == 0:
+                cur = ids
+                continue
+            pair = pack(cur, ids)
+            if k == ncols - 1:
+                pkey = pair
+            else:
+                cur = lookup(pair_dict[k - 1], pair, None, -1, nulls_equal)
+        b_ok = np.ones(nb, bool)
+        p_ok = np.ones(npr, bool)
+        if not nulls_equal:                                               # rows holding a null match nothing
+            for v in bval:
+                if v is not None:
+                    b_ok &= v
+            for v in pval:
+                if v is not None:
+                    p_ok &= v
+        got = sorted((i, j) for i in range(npr) for j in range(nb) if p_ok[i] and b_ok[j] and pkey[i] == bkey[j])
+
+        def row(cols, vals, i):
+            return tuple(None if (v is not None and not v[i]) else int(c[i]) for c, v in zip(cols, vals))
+        exp = []
+        for i in range(npr):
+            ri = row(probe, pval, i)
+            for j in range(nb):
+                rj = row(build, bval, j)
+                if ri == rj and (nulls_equal or None not in ri):
+                    exp.append((i, j))
+        assert got == sorted(exp), (trial, nulls_equal)
