@@ -58,3 +58,41 @@ def test_public_headers_compile_clean(tmp_path):
     r = subprocess.run(["g++", "-std=c++20", "-Wall", "-Wextra", "-Werror", "-D__HIP_PLATFORM_AMD__", "-fsyntax-only", *inc, str(cpp)],
                        capture_output=True, text=True)
     assert r.returncode == 0, r.stderr[-3000:]
+
+
+def test_join_table_sizing_round_trips_through_the_blob_size():
+    """The join table blob is header + slots + 4-bit tags; the probe entry points recover log2(capacity) from
+    the blob size alone (no host round trip).  Host arithmetic, checked here for every capacity 2^4..2^33 and
+    both slot widths: gx_join_partition_bits = log2(capacity) - 17 (2^17-slot sub-tables), 0 below 2^20, max 12."""
+    from cudf_amd import _lib
+    lib = _lib.lib
+    for key_size, slot in ((8, 16), (4, 8)):
+        for lf in (0.5, 1.0, 0.3):
+            for rows in [0, 1, 7, 8, 9, 1000, 2**17, 2**19 - 1, 2**19, 2**20, 10**8, 10**9, 2**31 - 1]:
+                want = max(rows, 1) / lf + 1.0
+                lg = 4
+                while float(1 << lg) < want:
+                    lg += 1
+                nbytes = lib.gx_join_table_bytes(key_size, rows, lf)
+                assert nbytes == 256 + (slot << lg) + (1 << lg) // 2, (key_size, lf, rows)
+                pb = lg - 17
+                pb = 0 if pb < 3 else min(pb, 12)
+                assert lib.gx_join_partition_bits(key_size, nbytes) == pb, (key_size, lf, rows, lg)
+
+
+def test_partition_of_a_key_is_the_top_bits_of_its_slot():
+    """Partitioned join: slot = (key * phi) >> (64 - log2cap), partition = (key * phi) >> (64 - pbits) with
+    pbits = log2cap - 17, so partition p owns exactly the slots [p, p + 1) << 17 -- the sub-table whose tags a
+    workgroup keeps in LDS; the tag is the 4 bits just below the slot index (0 remapped to 8)."""
+    import numpy as np
+    rng = np.random.default_rng(0)
+    keys = rng.integers(0, 2**63, 5000, dtype=np.int64).astype(np.uint64)
+    phi = np.uint64(0x9E3779B97F4A7C15)
+    with np.errstate(over="ignore"):
+        prod = keys * phi
+    for lg in (20, 24, 28, 29):
+        slot = prod >> np.uint64(64 - lg)
+        part = prod >> np.uint64(64 - (lg - 17))
+        assert np.array_equal(slot >> np.uint64(17), part)
+        tag = (prod >> np.uint64(60 - lg)) & np.uint64(15)
+        assert np.array_equal(tag, ((prod >> np.uint64(64 - lg - 4)) & np.uint64(15)))   # next 4 bits below the slot index
