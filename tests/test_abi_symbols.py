@@ -96,3 +96,45 @@ def test_partition_of_a_key_is_the_top_bits_of_its_slot():
         assert np.array_equal(slot >> np.uint64(17), part)
         tag = (prod >> np.uint64(60 - lg)) & np.uint64(15)
         assert np.array_equal(tag, ((prod >> np.uint64(64 - lg - 4)) & np.uint64(15)))   # next 4 bits below the slot index
+
+
+def test_scratch_queries_and_argument_checks_without_a_gpu():
+    """Every data-path entry point follows the cub convention (tmp == NULL -> *tmp_bytes): the query is pure
+    host arithmetic, so it must work here; sizes grow with n; bad arguments come back as gx_error codes
+    (GX_EINVAL -1, GX_EDTYPE -2) before anything touches the device."""
+    import ctypes
+    from cudf_amd import _lib as L
+    lib = L.lib
+    nb = ctypes.c_size_t(0)
+
+    def q(name, *args):
+        nb.value = 0
+        rc = getattr(lib, name)(*args, None, ctypes.byref(nb), None)
+        return rc, nb.value
+
+    queries = {
+        "gx_sort_keys": lambda n: q("gx_sort_keys", L.INT64, None, None, n, 0),
+        "gx_sort_pairs": lambda n: q("gx_sort_pairs", L.INT64, None, None, None, None, n, 0),
+        "gx_sorted_order": lambda n: q("gx_sorted_order", L.FLOAT64, None, None, n, 0, 0, 1, None),
+        "gx_groupby_sum_count": lambda n: q("gx_groupby_sum_count", L.INT32, None, None, L.FLOAT64, None, None, n, 1 << 20, None, None, None, None, None),
+        "gx_groupby_min_max": lambda n: q("gx_groupby_min_max", L.INT64, None, None, L.INT32, None, None, n, 1 << 20, None, None, None, None, None),
+        "gx_reduce": lambda n: q("gx_reduce", L.FLOAT64, None, None, n, L.OP_SUM, L.FLOAT64, None, None),
+        "gx_scan": lambda n: q("gx_scan", L.INT64, None, None, n, L.OP_SUM, 1, None),
+        "gx_join_filter": lambda n: q("gx_join_filter", 8, None, None, n, None, 0, 0, 0, None, None),
+        "gx_dense_rank": lambda n: q("gx_dense_rank", L.UINT64, None, None, n, 0, None, None, None),
+    }
+    for name, fn in queries.items():
+        sizes = []
+        for n in (0, 1000, 10**6, 10**9):
+            rc, b = fn(n)
+            assert rc == 0, (name, n, rc)
+            sizes.append(b)
+        assert sizes == sorted(sizes) and sizes[-1] > 0, (name, sizes)
+    # the 1e9-row keys-only sort: two key buffers worth of scratch (ping-pong + look-back granules), not more
+    assert 16e9 < queries["gx_sort_keys"](10**9)[1] < 16.5e9
+    assert q("gx_sort_keys", 99, None, None, 10, 0)[0] == -2                 # GX_EDTYPE
+    assert q("gx_sort_keys", L.INT64, None, None, -1, 0)[0] == -1            # GX_EINVAL
+    assert q("gx_sort_keys", L.INT64, None, None, 2**31, 0)[0] == -1         # more than size_type rows
+    assert q("gx_dense_rank", L.INT64, None, None, 10, 11, None, None, None)[0] == -1   # null_count > n
+    assert lib.gx_pack_keys(0, None, None, 0, None, None) == -1
+    assert lib.gx_join_table_bytes(3, 1000, 0.5) == 0
