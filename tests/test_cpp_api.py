@@ -37,6 +37,16 @@ def test_host_library_exports_the_cudf_api():
         assert s in und
 
 
+def test_host_side_validation():
+    """tests/cpp/cudf_host_tests: constructor / argument checks, aggregation objects and the Arrow schema export --
+    everything the C++ surface decides before its first device call -- run without a GPU."""
+    _build()
+    r = subprocess.run([os.path.join(ROOT, "tests", "cpp", "cudf_host_tests")], capture_output=True, text=True, timeout=120)
+    print(r.stdout[-3000:])
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-2000:]
+    assert "0 failed" in r.stdout
+
+
 @pytest.mark.gpu
 def test_cpp_api_against_reference_vectors():
     _build()
