@@ -451,3 +451,68 @@ def test_dictionary_row_encoder_model():
                 if ri == rj and (nulls_equal or None not in ri):
                     exp.append((i, j))
         assert got == sorted(exp), (trial, nulls_equal)
+
+
+def test_xcd_lists_with_stealing_make_progress_with_few_resident_workgroups():
+    """Hybrid sort levels / partitioned join: tiles are grouped in 8 lists (one per XCD), every list has its own
+    ticket counter and its own look-back chain; a workgroup takes a ticket from the list of the XCD it runs on
+    and steals from the others when its own is exhausted.  Placement is only a performance hint: because a tile's
+    predecessors in its chain always hold EARLIER tickets of the same list, they are already running (or done)
+    when the tile starts, so the chain cannot wait on a tile nobody has started -- even when only a handful of
+    workgroups are resident.  Modelled with W resident slots, random XCD placement and random interleaving."""
+    import random
+    rnd = random.Random(11)
+
+    def worker(xcd, tickets, lists, status, result, counts):
+        # take a tile: own list first, then the others (pj_xcc() + i) % 8
+        tile = None
+        for i in range(8):
+            y = (xcd + i) % 8
+            if tickets[y] < len(lists[y]):
+                tile = (y, tickets[y])
+                tickets[y] += 1
+                break
+        if tile is None:
+            return
+        y, t = tile
+        yield
+        status[y][t] = (2 if t == 0 else 1, counts[y][t])
+        yield
+        prefix = 0
+        p = t - 1
+        while t > 0:
+            x = status[y][p]
+            while x[0] == 0:                    # predecessor has not published yet: spin (it IS running)
+                yield
+                x = status[y][p]
+            prefix += x[1]
+            if x[0] == 2:
+                break
+            p -= 1
+        if t > 0:
+            status[y][t] = (2, prefix + counts[y][t])
+        result[y][t] = prefix
+        yield
+
+    for trial in range(40):
+        W = rnd.randint(1, 6)                   # resident workgroups (far fewer than tiles)
+        lists = [list(range(rnd.randint(0, 12))) for _ in range(8)]
+        counts = [[rnd.randint(0, 99) for _ in l] for l in lists]
+        status = [[(0, 0)] * len(l) for l in lists]
+        result = [[None] * len(l) for l in lists]
+        tickets = [0] * 8
+        total = sum(len(l) for l in lists)
+        launched, running, steps = 0, [], 0
+        while launched < total + W or running:  # the grid has a few spare workgroups that find nothing to do
+            while len(running) < W and launched < total + W:
+                running.append(worker(rnd.randrange(8), tickets, lists, status, result, counts))
+                launched += 1
+            g = rnd.choice(running)
+            try:
+                next(g)
+            except StopIteration:
+                running.remove(g)
+            steps += 1
+            assert steps < 200000, "no progress"
+        for y in range(8):
+            assert result[y] == [sum(counts[y][:t]) for t in range(len(lists[y]))]
