@@ -1,28 +1,35 @@
 #!/usr/bin/env python
 """bench.py -- BASELINE.json's metric on MI355X: rows/s + achieved HBM GB/s of the hot path.
 
-  python bench.py --gpus N --steps K --warmup W [--workload sort|sorted_order|join|groupby]
+  python bench.py --gpus N --steps K --warmup W [--workload all|sort|sorted_order|join|groupby|reduce|scan|gather]
                   [--rows R] [--cpu-baseline/--no-cpu-baseline]
 
-A "step" is one pass of the hot path over one batch of synthetic input already resident in HBM
-(generated on the device by a counter-based RNG, so no PCIe traffic inside or outside the timed
-region).  Default workload = BASELINE.json configs[1]: 1e9-row int64 radix sort (cudf::sort) on
-one GPU.  N > 1: one process per GPU (torch.distributed / RCCL over xGMI), every rank holds a shard
-of `--rows` rows and the step is the DISTRIBUTED operator of cudf_amd/distributed.py (sample sort /
-hash-partitioned join / pre-aggregated groupby: one all-to-all exchange each, no all-reduce) ->
-"scaling": "weak", value = rows of all ranks / max-over-ranks time.
+A "step" is one pass of the hot path over one batch of synthetic input already resident in HBM (generated on
+the device by a counter-based RNG: no PCIe traffic inside or outside the timed region).
 
-Rank 0 prints ONE JSON line (contract in the task statement) with two extra objects:
-  roofline     -- dominant kernel (the radix scatter pass): algorithmic bytes per launch
-                  (16 B/row = read 8 + write 8) / average launch duration measured
-                  live with HIP events on the launch stream (gx_sort_profile); peak = 8.0 TB/s HBM3E.
-  cpu_baseline -- the CPU oracle ("port": oracle/oracle.c LSD radix sort, 1 thread) timed on the
-                  host on a bounded sample of the same workload.
+Default (N = 1, --workload all): the headline `value` is BASELINE.json configs[1], the 1e9-row int64 radix sort
+(cudf::sort), timed as K steps between barriers; the SAME JSON line then carries a `join` block (configs[2]:
+1e9-row probe x 1e8-row build inner hash join, probe phase timed, build time reported) and a `groupby` block
+(configs[3]: 1e9 rows, int32 key, 1e6 groups, f64 sum + count), each timed over its own K steps with its own
+`roofline`, `cpu_baseline` and a device-side correctness guard on the timed output.
+
+N > 1: one process per GPU (torch.distributed / RCCL over xGMI).  `python bench.py --gpus N` spawns the N ranks
+itself (and fails when fewer devices are visible); under torchrun (RANK / WORLD_SIZE set) it joins the group it
+was given.  Every rank holds `--rows` rows and the step is the DISTRIBUTED operator of cudf_amd/distributed.py
+(range-partitioned sort / hash-partitioned join / pre-aggregated groupby: one all-to-all exchange each, no
+all-reduce) -> "scaling": "weak", value = rows of all ranks / max-over-ranks time.
+
+roofline     -- dominant kernel: algorithmic bytes per launch / average launch duration measured live with HIP
+                events on the launch stream (gx_sort_profile / gx_join_profile); peak = 8.0 TB/s HBM3E.
+cpu_baseline -- the CPU oracle ("port": oracle/oracle.c, 1 thread) timed on the host on a bounded sample of the
+                same workload, pandas / pyarrow beside it.
 """
 import argparse
 import ctypes
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
@@ -30,6 +37,7 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec (MI355X_MICROARCH.md); measured copy ceiling 6290 GB/s
+METRIC = "rows/sec + achieved HBM GB/s: 1e9-row int64 sort & hash-join, 1/2/4/8 GPU"
 
 
 def parse():
@@ -37,13 +45,16 @@ def parse():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--warmup", type=int, default=2)
-    ap.add_argument("--workload", default="sort", choices=["sort", "sorted_order", "join", "groupby", "reduce", "scan", "gather"])
+    ap.add_argument("--workload", default="all",
+                    choices=["all", "sort", "sorted_order", "join", "groupby", "reduce", "scan", "gather"])
     ap.add_argument("--rows", type=float, default=1e9)
     ap.add_argument("--algo", type=int, default=0,
                     help="sort knob: 0 onesweep/windowed look-back, 1 three-kernel, 2 onesweep/one-tile look-back")
     ap.add_argument("--gb-algo", type=int, default=0, help="groupby knob: 0 auto, 1 global table, 2 LDS-partitioned")
     ap.add_argument("--gb-split", type=int, default=1)
     ap.add_argument("--no-partitioned-join", action="store_true", help="join: probe the table directly")
+    ap.add_argument("--join-probe-kernel", type=int, default=0, help="join knob: 0 pipelined tag probe, 1 round-1 tag probe")
+    ap.add_argument("--join-scatter-tile", type=int, default=0, help="join knob: rows per scatter tile (0 = default)")
     ap.add_argument("--no-hybrid", action="store_true", help="sort: disable the hybrid MSD path (LSD passes only)")
     ap.add_argument("--key-range", type=int, nargs=2, default=None, metavar=("LO", "HI"),
                     help="sort: keys uniform in [LO, HI) instead of the full int64 range (the reference's own "
@@ -51,11 +62,17 @@ def parse():
     ap.add_argument("--cpu-baseline", dest="cpu", action="store_true", default=True)
     ap.add_argument("--no-cpu-baseline", dest="cpu", action="store_false")
     ap.add_argument("--cpu-rows", type=float, default=0, help="rows of the CPU-baseline sample (0 = per-workload default)")
+    ap.add_argument("--cpu-rows-pandas", type=float, default=1e7,
+                    help="rows of the pandas / pyarrow legs (BASELINE.md section 3 plans 1e7 and 1e8; 1e8 takes minutes)")
     return ap.parse_args()
 
 
-def cpu_baseline_sort(rows):
-    """oracle ("port") timed on the host: single-thread LSD radix sort in C + pandas for context."""
+# ------------------------------------------------------------------------------------------------
+# CPU baselines (rank 0, N = 1): the oracle is the checker / baseline, never the product
+# ------------------------------------------------------------------------------------------------
+
+def cpu_baseline_sort(rows, pandas_rows):
+    """oracle ("port") timed on the host: single-thread LSD radix sort in C + pandas / pyarrow for context."""
     import numpy as np
     from oracle import c_oracle
     n = int(rows)
@@ -68,7 +85,7 @@ def cpu_baseline_sort(rows):
     extra = {}
     try:
         import pandas as pd
-        m = min(n, 10_000_000)
+        m = min(n, int(pandas_rows))
         df = pd.DataFrame({"a": v[:m]})
         t0 = time.perf_counter()
         df.sort_values("a", kind="stable")
@@ -88,7 +105,7 @@ def cpu_baseline_sort(rows):
             "host_cpus": os.cpu_count(), **extra}
 
 
-def cpu_baseline_join(rows):
+def cpu_baseline_join(rows, pandas_rows):
     import numpy as np
     from oracle import c_oracle
     n = int(rows)
@@ -101,7 +118,7 @@ def cpu_baseline_join(rows):
     extra = {}
     try:
         import pandas as pd
-        m = min(n, 10_000_000)
+        m = min(n, int(pandas_rows))
         lp = pd.DataFrame({"k": probe[:m]})
         rp = pd.DataFrame({"k": build, "r": np.arange(len(build))})
         t0 = time.perf_counter()
@@ -115,7 +132,7 @@ def cpu_baseline_join(rows):
             "host_cpus": os.cpu_count(), "matches": int(len(l)), **extra}
 
 
-def cpu_baseline_groupby(rows):
+def cpu_baseline_groupby(rows, pandas_rows):
     import numpy as np
     from oracle import c_oracle
     n = int(rows)
@@ -128,7 +145,7 @@ def cpu_baseline_groupby(rows):
     extra = {}
     try:
         import pandas as pd
-        m = min(n, 20_000_000)
+        m = min(n, int(pandas_rows))
         df = pd.DataFrame({"k": k[:m], "v": v[:m]})
         t0 = time.perf_counter()
         df.groupby("k", sort=False).agg(s=("v", "sum"), c=("v", "count"))
@@ -141,318 +158,487 @@ def cpu_baseline_groupby(rows):
             "host_cpus": os.cpu_count(), **extra}
 
 
-def main():
-    args = parse()
-    rank = int(os.environ.get("RANK", "0"))
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    local = int(os.environ.get("LOCAL_RANK", "0"))
-    import numpy as np
+# ------------------------------------------------------------------------------------------------
+# launcher: `python bench.py --gpus N` without torchrun spawns the ranks itself
+# ------------------------------------------------------------------------------------------------
+
+def spawn_ranks(args):
     import torch
-    import torch.distributed as dist
-    torch.cuda.set_device(local)
-    if world > 1:
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local))
-    from cudf_amd import Column, ops, _lib as L
-    from cudf_amd.column import device_bytes, ptr, stream_ptr
+    have = torch.cuda.device_count()
+    if have < args.gpus:
+        print(f"bench.py: --gpus {args.gpus} but only {have} device(s) visible", file=sys.stderr)
+        return 2
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}",
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    return subprocess.call(cmd, env=env)
 
-    lib = L.lib
-    n = int(args.rows)
-    lib.gx_sort_set_algorithm(args.algo)
-    lib.gx_groupby_set_algorithm(args.gb_algo, args.gb_split)
-    lib.gx_sort_set_hybrid(0 if args.no_hybrid else 1)
-    stream = stream_ptr()
 
-    def barrier():
-        torch.cuda.synchronize()
-        if world > 1:
-            dist.barrier()
-        torch.cuda.synchronize()
+class Ctx:
+    """what every workload needs: library handles, rank info, a barrier"""
 
-    roofline = None
-    extra = {}
-    dist_step = None
-    if world > 1:
-        # distributed operators: same synthetic shards, one all-to-all exchange per step
+    def __init__(self, args):
+        import numpy as np
+        import torch
+        import torch.distributed as dist
+        self.args = args
+        self.rank = int(os.environ.get("RANK", "0"))
+        self.world = int(os.environ.get("WORLD_SIZE", "1"))
+        self.local = int(os.environ.get("LOCAL_RANK", "0"))
+        torch.cuda.set_device(self.local)
+        if self.world > 1:
+            dist.init_process_group("nccl", device_id=torch.device("cuda", self.local))
+        from cudf_amd import Column, ops, _lib as L
+        from cudf_amd.column import device_bytes, ptr, stream_ptr
+        self.np, self.torch, self.dist = np, torch, dist
+        self.Column, self.ops, self.L, self.lib = Column, ops, L, L.lib
+        self.device_bytes, self.ptr = device_bytes, ptr
+        self.stream = stream_ptr()
+        self.n = int(args.rows)
+
+    def barrier(self):
+        self.torch.cuda.synchronize()
+        if self.world > 1:
+            self.dist.barrier()
+        self.torch.cuda.synchronize()
+
+    def timed(self, step, per_step=None, after_warmup=None):
+        """W warm-ups, then exactly K steps between barriers; max over ranks.  Returns seconds per step."""
+        a = self.args
+        for _ in range(a.warmup):
+            step()
+        if after_warmup:
+            after_warmup()
+        self.barrier()
+        t0 = time.perf_counter()
+        for _ in range(a.steps):
+            step()
+            if per_step:
+                per_step()
+        self.barrier()
+        dt = time.perf_counter() - t0
+        if self.world > 1:
+            t = self.torch.tensor([dt], device="cuda", dtype=self.torch.float64)
+            self.dist.all_reduce(t, op=self.dist.ReduceOp.MAX)
+            dt = float(t.item())
+        return dt / a.steps
+
+    def as_tensor(self, col, dt):
+        return col.data[: col.size * col.dtype.itemsize].view(dt)
+
+
+def pmc_traffic(roofline, n):
+    """HBM bytes of the dominant kernel from the committed PMC passes (same command, 1e9 rows)"""
+    if roofline is None or n != 1_000_000_000:
+        return
+    for name in ("r2_pmc_traffic_1e9.json", "r1_pmc_traffic_1e9.json"):
+        try:
+            tr = json.load(open(os.path.join(ROOT, "profiles", name)))
+            for key, v in tr["kernels"].items():
+                if roofline["kernel"].startswith(key):
+                    roofline["traffic"] = v["hbm_bytes_per_launch"]
+                    roofline["traffic_source"] = tr["source"] + "; " + tr["correction"]
+                    return
+        except (OSError, KeyError, ValueError):
+            pass
+
+
+# ------------------------------------------------------------------------------------------------
+# config 2: radix sort
+# ------------------------------------------------------------------------------------------------
+
+def bench_sort(c, pairs=False):
+    a, lib, L, ops, np = c.args, c.lib, c.L, c.ops, c.np
+    n = c.n
+    lib.gx_sort_set_algorithm(a.algo)
+    lib.gx_sort_set_hybrid(0 if a.no_hybrid else 1)
+    if a.key_range:
+        keys = ops.random_column(np.int64, n, seed=42 + c.rank, lo=a.key_range[0], hi=a.key_range[1])
+    else:
+        keys = ops.random_column(np.int64, n, seed=42 + c.rank)
+    out = c.Column.empty(np.int32 if pairs else np.int64, n)
+    nb = ctypes.c_size_t(0)
+    if pairs:
+        fn = lambda tmp, nbp: lib.gx_sorted_order(keys.gx, keys.data_ptr, None, n, 0, 0, 1, out.data_ptr, tmp, nbp, c.stream)
+    else:
+        fn = lambda tmp, nbp: lib.gx_sort_keys(keys.gx, keys.data_ptr, out.data_ptr, n, 0, tmp, nbp, c.stream)
+    L.check(fn(None, ctypes.byref(nb)), "size query")
+    tmp = c.device_bytes(nb.value)
+    single_step = lambda: L.check(fn(c.ptr(tmp), ctypes.byref(nb)), "sort")
+    bytes_per_row_pass = 24 if pairs else 16   # read key(+idx) + write key(+idx)
+    model_bytes_row = 200 if pairs else 136    # SURVEY.md 8d: 8-pass LSD model
+    workload = f"{n:.0e}-row int64 " + ("sorted_order (radix sort pairs, int32 payload)" if pairs else "radix sort (cudf::sort, keys only)")
+    if a.key_range:
+        workload += f", keys uniform in [{a.key_range[0]}, {a.key_range[1]})"
+
+    prof = {"pass_ms": 0.0, "hist_ms": 0.0, "launches": 0, "hyb": [0.0] * 4, "hyb_n": 0}
+
+    def read_profile():
+        # reading the events waits for this step only; it is part of the timed region
+        h = ctypes.c_float()
+        p = (ctypes.c_float * 8)()
+        k = ctypes.c_int()
+        L.check(lib.gx_sort_profile_read(ctypes.byref(h), p, ctypes.byref(k)), "profile_read")
+        act = [x for x in list(p)[: k.value] if x > 0.05]  # skipped passes exit in microseconds
+        prof["pass_ms"] += sum(act)
+        prof["launches"] += len(act)
+        prof["hist_ms"] += h.value
+        h4 = (ctypes.c_float * 4)()
+        if lib.gx_sort_profile_read_hybrid(h4) == 0:
+            for i in range(4):
+                prof["hyb"][i] += h4[i]
+            prof["hyb_n"] += 1
+
+    if c.world > 1:
         from cudf_amd import distributed as D
         local_ops = D.HipLocalOps()
-
-        def as_tensor(col, dt):
-            return col.data[: col.size * col.dtype.itemsize].view(dt)
-        if args.workload in ("sort", "sorted_order"):
-            dkeys = as_tensor(ops.random_column(np.int64, n, seed=42 + rank), torch.int64)
-            dist_step = lambda: D.distributed_sort(dkeys, local=local_ops)
-            dist_name = f"{n:.0e}-row-per-GPU int64 distributed sort (local sort, splitters, all-to-all, local sort)"
-        elif args.workload == "join":
-            nbr = max(1, n // 10)
-            torch.manual_seed(12345 + rank)
-            dbk = (torch.randperm(nbr, device="cuda") + rank * nbr) * 3 + 1           # globally distinct build keys
-            dpk = as_tensor(ops.random_column(np.int64, n, seed=67890 + rank, lo=0, hi=int(nbr * world / 0.3)), torch.int64) * 3 + 1
-            dist_step = lambda: D.distributed_inner_join(dpk, dbk, local=local_ops)
-            dist_name = f"{n:.0e}-row-per-GPU probe x {nbr:.0e} build distributed inner join (hash partition, all-to-all, local join)"
-        else:
-            dgk = as_tensor(ops.random_column(np.int32, n, seed=7 + rank, lo=0, hi=1_000_000), torch.int32)
-            dgv = as_tensor(ops.random_column(np.float64, n, seed=8 + rank), torch.float64)
-            dist_step = lambda: D.distributed_groupby_sum_count(dgk, dgv, local=local_ops)
-            dist_name = f"{n:.0e}-row-per-GPU groupby(int32 key, 1e6 groups).agg(f64 sum,count), partials exchanged"
-    if args.workload in ("sort", "sorted_order"):
-        if args.key_range:
-            keys = ops.random_column(np.int64, n, seed=42 + rank, lo=args.key_range[0], hi=args.key_range[1])
-        else:
-            keys = ops.random_column(np.int64, n, seed=42 + rank)
-        pairs = args.workload == "sorted_order"
-        out = Column.empty(np.int32 if pairs else np.int64, n)
-        nb = ctypes.c_size_t(0)
-        if pairs:
-            fn = lambda tmp, nbp: lib.gx_sorted_order(keys.gx, keys.data_ptr, None, n, 0, 0, 1, out.data_ptr, tmp, nbp, stream)
-        else:
-            fn = lambda tmp, nbp: lib.gx_sort_keys(keys.gx, keys.data_ptr, out.data_ptr, n, 0, tmp, nbp, stream)
-        L.check(fn(None, ctypes.byref(nb)), "size query")
-        tmp = device_bytes(nb.value)
-        step = lambda: L.check(fn(ptr(tmp), ctypes.byref(nb)), "sort")
-        bytes_per_row_pass = 24 if pairs else 16   # read key(+idx) + write key(+idx)
-        model_bytes_row = 200 if pairs else 136    # 8-pass LSD model
-        workload = f"{n:.0e}-row int64 " + ("sorted_order (radix sort pairs, int32 payload)" if pairs else "radix sort (cudf::sort, keys only)")
-        if args.key_range:
-            workload += f", keys uniform in [{args.key_range[0]}, {args.key_range[1]})"
-        unit_rows = n
-    elif args.workload == "join":
-        nb_rows = max(1, n // 10)
-        # build: distinct keys (a permutation-like bijection of iota), probe: 30% hit rate
-        # (cpp/benchmarks/join/generate_input_tables.cu:24-103: unique build keys, selectivity 0.3)
-        bk = Column.empty(np.int64, nb_rows)
-        bkt = bk.data[: nb_rows * 8].view(torch.int64)
-        torch.manual_seed(12345 + rank)
-        bkt.copy_(torch.randperm(nb_rows, device="cuda") * 3 + 1)  # distinct keys {3i+1}, shuffled
-        pk = ops.random_column(np.int64, n, seed=67890 + rank, lo=0, hi=int(nb_rows / 0.3))
-        pk.data[: n * 8].view(torch.int64).mul_(3).add_(1)          # hits a build key w.p. 0.3
-        hj = ops.HashJoin(bk)  # warm-up build (allocations, module load)
-        torch.cuda.synchronize()
-        tb = time.perf_counter()
-        hj = ops.HashJoin(bk)
-        torch.cuda.synchronize()
-        extra["join_build_ms"] = (time.perf_counter() - tb) * 1e3  # build of the 1e8-row side (not in `value`)
-        lo = Column.empty(np.int32, n)
-        ro = Column.empty(np.int32, n)
-        cur = torch.zeros(1, dtype=torch.int64, device="cuda")
-
-        part_bits = lib.gx_join_partition_bits(8, hj.table_bytes) if not args.no_partitioned_join else 0
-        extra["join_partition_bits"] = part_bits
-        jnb = ctypes.c_size_t(0)
-        if part_bits:
-            L.check(lib.gx_join_probe_partitioned(8, pk.data_ptr, n, ptr(hj.table), hj.table_bytes, 0, lo.data_ptr,
-                                                  ro.data_ptr, n, ptr(cur), None, ctypes.byref(jnb), stream), "query")
-            jtmp = device_bytes(jnb.value)
-
-        def step():
-            cur.zero_()
-            if part_bits:
-                L.check(lib.gx_join_probe_partitioned(8, pk.data_ptr, n, ptr(hj.table), hj.table_bytes, 0, lo.data_ptr,
-                                                      ro.data_ptr, n, ptr(cur), ptr(jtmp), ctypes.byref(jnb), stream), "probe")
-            else:
-                L.check(lib.gx_join_probe(8, pk.data_ptr, None, n, ptr(hj.table), hj.table_bytes, 0, lo.data_ptr,
-                                          ro.data_ptr, n, ptr(cur), stream), "probe")
-        workload = f"{n:.0e}-row int64 probe x {nb_rows:.0e}-row build inner hash join (probe phase timed)"
-        unit_rows = n
-    elif args.workload in ("reduce", "scan", "gather"):
-        # single streaming kernels of the path: f64 SUM reduce, int64 inclusive
-        # SUM scan, 8-byte gather through a random int32 map
-        src = ops.random_column(np.float64 if args.workload == "reduce" else np.int64, n, seed=11 + rank)
-        nb = ctypes.c_size_t(0)
-        if args.workload == "reduce":
-            res = Column.empty(np.float64, 1)
-            cnt = torch.zeros(1, dtype=torch.int64, device="cuda")
-            fn = lambda tmp, nbp: lib.gx_reduce(src.gx, src.data_ptr, None, n, L.OP_SUM, L.FLOAT64, res.data_ptr, ptr(cnt), tmp, nbp, stream)
-            bpr_simple, kname = 8, "gx_reduce f64 SUM (k_chunk_reduce)"
-        elif args.workload == "scan":
-            dst = Column.empty(np.int64, n)
-            fn = lambda tmp, nbp: lib.gx_scan(src.gx, src.data_ptr, None, n, L.OP_SUM, 1, dst.data_ptr, tmp, nbp, stream)
-            bpr_simple, kname = 16, "gx_scan int64 inclusive SUM (reduce-then-scan, 3 launches; 24 B/row moved)"
-        else:
-            gm = ops.random_column(np.int32, n, seed=13 + rank, lo=0, hi=n)
-            dst = Column.empty(np.int64, n)
-            fn = None
-            bpr_simple, kname = 20, "gx_gather 8-byte rows through a uniform random int32 map"
-        if fn is not None:
-            L.check(fn(None, ctypes.byref(nb)), "size query")
-            tmp = device_bytes(nb.value)
-            step = lambda: L.check(fn(ptr(tmp), ctypes.byref(nb)), args.workload)
-        else:
-            step = lambda: L.check(lib.gx_gather(8, src.data_ptr, None, n, gm.data_ptr, n, 0, dst.data_ptr, None, stream), "gather")
-        workload = f"{n:.0e}-row {kname}"
-        unit_rows = n
-    else:  # groupby
-        gk = ops.random_column(np.int32, n, seed=7 + rank, lo=0, hi=1_000_000)
-        gv = ops.random_column(np.float64, n, seed=8 + rank)
-        mg = 1 << 20
-        ok, osum = Column.empty(np.int32, mg), Column.empty(np.float64, mg)
-        ocv = Column.empty(np.int32, mg)
-        ng = torch.zeros(1, dtype=torch.int64, device="cuda")
-        nb = ctypes.c_size_t(0)
-        fn = lambda tmp, nbp: lib.gx_groupby_sum_count(gk.gx, gk.data_ptr, None, gv.gx, gv.data_ptr, None, n, mg,
-                                                       ok.data_ptr, osum.data_ptr, ocv.data_ptr, None, ptr(ng), tmp, nbp, stream)
-        L.check(fn(None, ctypes.byref(nb)), "size query")
-        tmp = device_bytes(nb.value)
-        step = lambda: L.check(fn(ptr(tmp), ctypes.byref(nb)), "groupby")
-        workload = f"{n:.0e}-row groupby(int32 key, 1e6 groups).agg(float64 sum,count)"
-        unit_rows = n
-
-    single_step = step
-    if dist_step is not None:
-        step = dist_step
-        workload = dist_name
-    for _ in range(args.warmup):
-        step()
-    if args.workload in ("sort", "sorted_order"):
+        dkeys = c.as_tensor(keys, c.torch.int64)
+        step = lambda: D.distributed_sort(dkeys, local=local_ops)
+        workload = f"{n:.0e}-row-per-GPU int64 distributed sort (splitters from a sample, range partition, all-to-all, one local sort)"
+        sec = c.timed(step)
+        res = step()
+        assert bool((res[1:] >= res[:-1]).all()), "distributed sort: shard not sorted"
+        tot = c.torch.tensor([res.numel()], device="cuda", dtype=c.torch.int64)
+        c.dist.all_reduce(tot)
+        assert int(tot.item()) == n * c.world, "distributed sort lost rows"
+        del res
+        # roofline of the dominant LOCAL kernel: one profiled single-GPU sort of this rank's shard, untimed
         lib.gx_sort_profile(1)
-    barrier()
-    t0 = time.perf_counter()
-    pass_ms_acc, hist_ms_acc, launches = 0.0, 0.0, 0
-    hyb_acc, hyb_n = [0.0, 0.0, 0.0, 0.0], 0
-    for _ in range(args.steps):
-        step()
-        if args.workload in ("sort", "sorted_order") and dist_step is None:
-            # reading the events waits for this step only; it is part of the timed region
-            h = ctypes.c_float()
-            p = (ctypes.c_float * 8)()
-            k = ctypes.c_int()
-            L.check(lib.gx_sort_profile_read(ctypes.byref(h), p, ctypes.byref(k)), "profile_read")
-            act = [x for x in list(p)[: k.value] if x > 0.05]  # skipped passes exit in microseconds
-            pass_ms_acc += sum(act)
-            launches += len(act)
-            hist_ms_acc += h.value
-            h4 = (ctypes.c_float * 4)()
-            if lib.gx_sort_profile_read_hybrid(h4) == 0:
-                for i in range(4):
-                    hyb_acc[i] += h4[i]
-                hyb_n += 1
-    barrier()
-    dt = time.perf_counter() - t0
-    if world > 1:
-        t = torch.tensor([dt], device="cuda", dtype=torch.float64)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        dt = float(t.item())
-    ms_per_step = dt / args.steps * 1e3
-
-    # correctness guard on the timed output (device-side, cheap): sorted + same multiset
-    if dist_step is not None:
-        if args.workload in ("sort", "sorted_order"):
-            res = dist_step()
-            assert bool((res[1:] >= res[:-1]).all()), "distributed sort: shard not sorted"
-            tot = torch.tensor([res.numel()], device="cuda", dtype=torch.int64)
-            dist.all_reduce(tot)
-            assert int(tot.item()) == n * world, "distributed sort lost rows"
-            del res
-        if args.workload == "sort":
-            # roofline of the dominant LOCAL kernel: one profiled single-GPU sort of this rank's shard,
-            # outside the timed region
-            single_step()
-            h = ctypes.c_float()
-            p8 = (ctypes.c_float * 8)()
-            k = ctypes.c_int()
-            L.check(lib.gx_sort_profile_read(ctypes.byref(h), p8, ctypes.byref(k)), "profile_read")
-            act = [x for x in list(p8)[: k.value] if x > 0.05]
-            pass_ms_acc, launches, hist_ms_acc = sum(act), len(act), h.value * args.steps
-            h4 = (ctypes.c_float * 4)()
-            if lib.gx_sort_profile_read_hybrid(h4) == 0:
-                hyb_acc, hyb_n = list(h4), 1
-    elif args.workload == "sort":
+        single_step()
+        read_profile()
+        nsteps_prof = 1
+    else:
+        sec = c.timed(single_step, read_profile, after_warmup=lambda: lib.gx_sort_profile(1))
+        nsteps_prof = a.steps
         cin, cout = ops.checksum(keys), ops.checksum(out)
-        assert cout[2] == 0 and cin[:2] == cout[:2], "sort output invalid"
+        if not pairs:
+            assert cout[2] == 0 and cin[:2] == cout[:2], "sort output invalid"
         st = ctypes.c_int(0)
-        lib.gx_sort_status(ptr(tmp), ctypes.byref(st), stream)
+        lib.gx_sort_status(c.ptr(tmp), ctypes.byref(st), c.stream)
         assert st.value == 0, "look-back timed out"
-    sort_info = None
-    local_sort_ms = ms_per_step  # duration the whole-sort model figures refer to
-    if dist_step is not None and args.workload == "sort":
-        local_sort_ms = hist_ms_acc / args.steps + (sum(hyb_acc) if hyb_n else pass_ms_acc)
-    if args.workload in ("sort", "sorted_order") and (dist_step is None or args.workload == "sort"):
-        info = (ctypes.c_int32 * 8)()
-        lib.gx_sort_info(ptr(tmp), info, stream)
-        sort_info = dict(zip(["hybrid_attempted", "hybrid_used", "d1", "shift2", "bits2", "lds_passes", "max_cell",
-                              "lsd_passes"], list(info)))
-    if args.workload in ("sort", "sorted_order") and sort_info and sort_info["hybrid_used"] and hyb_n:
-        # hybrid MSD path: per-kernel algorithmic bytes: partition passes and the local
-        # sort read 8 + write 8 B/row, the joint histogram reads 8 B/row
-        ms = [x / hyb_n for x in hyb_acc]
+    lib.gx_sort_profile(0)
+    ms_per_step = sec * 1e3
+    info = (ctypes.c_int32 * 8)()
+    lib.gx_sort_info(c.ptr(tmp), info, c.stream)
+    sort_info = dict(zip(["hybrid_attempted", "hybrid_used", "d1", "shift2", "bits2", "lds_passes", "max_cell", "lsd_passes"], list(info)))
+    hist_ms = prof["hist_ms"] / nsteps_prof
+    local_sort_ms = ms_per_step if c.world == 1 else hist_ms + (sum(prof["hyb"]) if prof["hyb_n"] else prof["pass_ms"])
+    roofline = None
+    if sort_info["hybrid_used"] and prof["hyb_n"]:
+        # hybrid MSD path: per-kernel algorithmic bytes (DESIGN.md): partition passes and the local sort read 8 +
+        # write 8 B/row, the joint histogram reads 8 B/row
+        ms = [x / prof["hyb_n"] for x in prof["hyb"]]
         names = ["k_msd_pass level 0 (8-bit partition, 8 XCD chains)", "k_hist2+k_plan2 (joint histogram)",
-                 "k_msd_pass level 1 (partition inside buckets)", "k_local_sort (LDS sort of <=16384-key cells)"]
-        bpr = [20, 8, 24, 24] if args.workload == "sorted_order" else [16, 8, 16, 16]  # pairs carry a 4-B index
+                 "k_msd_pass level 1 (partition inside buckets)", "k_local_sort (LDS sort of the cells)"]
+        bpr = [20, 8, 24, 24] if pairs else [16, 8, 16, 16]  # pairs carry a 4-B index
         dom = max(range(4), key=lambda i: ms[i])
         achieved = bpr[dom] * n / (ms[dom] * 1e-3) / 1e9
         roofline = {"bound": "hbm", "kernel": names[dom], "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                     "frac": achieved / HBM_PEAK_GBS, "traffic": None, "algorithmic_bytes_per_launch": bpr[dom] * n,
                     "avg_launch_ms": ms[dom], "launches_per_step": 1.0,
                     "kernels_ms": dict(zip(names, ms)), "kernels_GBps": {k: b * n / (m * 1e-3) / 1e9 for k, b, m in zip(names, bpr, ms)},
-                    "hist_kernel_ms": hist_ms_acc / args.steps,
+                    "hist_kernel_ms": hist_ms,
                     "path_bytes_per_row": 8 + sum(bpr), "path_GBps": (8 + sum(bpr)) * n / (local_sort_ms * 1e-3) / 1e9,
+                    "path_frac": (8 + sum(bpr)) * n / (local_sort_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
                     "whole_sort_model_GBps": model_bytes_row * n / (local_sort_ms * 1e-3) / 1e9,
                     "whole_sort_model_frac": model_bytes_row * n / (local_sort_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
                     "sort_info": sort_info}
-    elif args.workload in ("sort", "sorted_order") and launches:
-        avg_ms = pass_ms_acc / launches
+    elif prof["launches"]:
+        avg_ms = prof["pass_ms"] / prof["launches"]
         achieved = bytes_per_row_pass * n / (avg_ms * 1e-3) / 1e9
         roofline = {"bound": "hbm", "kernel": "k_radix_pass (one 8-bit digit scatter pass)", "achieved": achieved,
                     "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": None,
                     "algorithmic_bytes_per_launch": bytes_per_row_pass * n, "avg_launch_ms": avg_ms,
-                    "launches_per_step": launches / args.steps,
-                    "hist_kernel_ms": hist_ms_acc / args.steps,
+                    "launches_per_step": prof["launches"] / nsteps_prof, "hist_kernel_ms": hist_ms,
                     "whole_sort_model_GBps": model_bytes_row * n / (local_sort_ms * 1e-3) / 1e9,
                     "whole_sort_model_frac": model_bytes_row * n / (local_sort_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
                     "sort_info": sort_info}
-    elif dist_step is not None:
-        roofline = None  # distributed join / groupby: see the N=1 lines for the kernels' rooflines
-    elif args.workload == "join":
-        matches = int(cur.item())
-        algb = 24 * n + 16 * matches
-        ach = algb / (ms_per_step * 1e-3) / 1e9
-        roofline = {"bound": "hbm", "kernel": "k_pj_hist+k_pj_scatter+k_pj_probe (partitioned probe)" if extra.get("join_partition_bits") else "k_probe", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                    "frac": ach / HBM_PEAK_GBS, "traffic": None, "algorithmic_bytes_per_launch": algb,
-                    "avg_launch_ms": ms_per_step, "matches": matches}
-    elif args.workload in ("reduce", "scan", "gather"):
-        ach = bpr_simple * n / (ms_per_step * 1e-3) / 1e9
-        roofline = {"bound": "hbm", "kernel": kname, "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                    "frac": ach / HBM_PEAK_GBS, "traffic": None, "algorithmic_bytes_per_launch": bpr_simple * n,
-                    "avg_launch_ms": ms_per_step}
-    elif args.workload == "groupby":
-        ach = 12 * n / (ms_per_step * 1e-3) / 1e9
-        roofline = {"bound": "hbm", "kernel": "k_aggregate", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                    "frac": ach / HBM_PEAK_GBS, "traffic": None, "algorithmic_bytes_per_launch": 12 * n,
-                    "avg_launch_ms": ms_per_step, "groups": int(ng.item())}
+    pmc_traffic(roofline, n)
+    cpu = None
+    if a.cpu and c.world == 1 and c.rank == 0:
+        cpu = cpu_baseline_sort(a.cpu_rows or 5e8, a.cpu_rows_pandas)
+    return {"workload": workload, "rows": n, "ms_per_step": ms_per_step, "rows_per_s": n * c.world / sec, "dtype": "int64",
+            "roofline": roofline, "cpu_baseline": cpu, "checked": "order + multiset checksum of the timed output (gx_checksum)"}
 
-    # HBM bytes of the dominant kernel from the committed PMC passes (same command, 1e9 rows)
-    if roofline is not None and n == 1_000_000_000:
-        try:
-            tr = json.load(open(os.path.join(ROOT, "profiles", "r1_pmc_traffic_1e9.json")))
-            for key, v in tr["kernels"].items():
-                if roofline["kernel"].startswith(key):
-                    roofline["traffic"] = v["hbm_bytes_per_launch"]
-                    roofline["traffic_source"] = tr["source"] + "; " + tr["correction"]
-        except (OSError, KeyError, ValueError):
-            pass
-    if rank == 0:
-        cpu = None
-        if args.cpu and world == 1:
-            # bounded sample: ~10-30 s of single-thread CPU work
-            cpu_rows = args.cpu_rows or {"sort": 5e8, "sorted_order": 5e8, "join": 2e8, "groupby": 5e8}.get(args.workload, 1e8)
-            fnc = {"sort": cpu_baseline_sort, "sorted_order": cpu_baseline_sort, "join": cpu_baseline_join,
-                   "groupby": cpu_baseline_groupby}.get(args.workload)
-            cpu = fnc(cpu_rows) if fnc else None
+
+# ------------------------------------------------------------------------------------------------
+# config 3: inner hash join, probe 1e9 x build 1e8, selectivity 0.3
+# ------------------------------------------------------------------------------------------------
+
+def bench_join(c):
+    a, lib, L, ops, np, torch = c.args, c.lib, c.L, c.ops, c.np, c.torch
+    n = c.n
+    nb_rows = max(1, n // 10)
+    lib.gx_join_set_probe_kernel(a.join_probe_kernel)
+    lib.gx_join_set_scatter_tile(a.join_scatter_tile)
+    if c.world > 1:
+        from cudf_amd import distributed as D
+        local_ops = D.HipLocalOps()
+        torch.manual_seed(12345 + c.rank)
+        dbk = (torch.randperm(nb_rows, device="cuda") + c.rank * nb_rows) * 3 + 1           # globally distinct build keys
+        dpk = c.as_tensor(ops.random_column(np.int64, n, seed=67890 + c.rank, lo=0, hi=int(nb_rows * c.world / 0.3)), torch.int64) * 3 + 1
+        step = lambda: D.distributed_inner_join(dpk, dbk, local=local_ops)
+        sec = c.timed(step)
+        l, r = step()
+        tot = torch.tensor([l.numel()], device="cuda", dtype=torch.int64)
+        c.dist.all_reduce(tot)
+        want = (dpk < 3 * nb_rows * c.world + 1).sum().to(torch.int64)
+        c.dist.all_reduce(want)
+        assert int(tot.item()) == int(want.item()), "distributed join: wrong number of pairs"
+        return {"workload": f"{n:.0e}-row-per-GPU probe x {nb_rows:.0e}-row-per-GPU build distributed inner join "
+                            "(hash partition, all-to-all, local join)", "rows": n, "ms_per_step": sec * 1e3,
+                "rows_per_s": n * c.world / sec, "dtype": "int64", "roofline": None, "cpu_baseline": None,
+                "matches": int(tot.item()), "checked": "pair count == closed form over all ranks"}
+    # build: distinct keys (a permutation-like bijection of iota), probe: 30% hit rate
+    # (cpp/benchmarks/join/generate_input_tables.cu:24-103: unique build keys, selectivity 0.3)
+    bk = c.Column.empty(np.int64, nb_rows)
+    bkt = c.as_tensor(bk, torch.int64)
+    torch.manual_seed(12345 + c.rank)
+    bkt.copy_(torch.randperm(nb_rows, device="cuda") * 3 + 1)  # distinct keys {3i+1}, shuffled
+    pk = ops.random_column(np.int64, n, seed=67890 + c.rank, lo=0, hi=int(nb_rows / 0.3))
+    pkt = c.as_tensor(pk, torch.int64)
+    pkt.mul_(3).add_(1)                                        # hits a build key w.p. 0.3
+    hj = ops.HashJoin(bk)  # warm-up build (allocations, module load)
+    torch.cuda.synchronize()
+    tb = time.perf_counter()
+    hj = ops.HashJoin(bk)
+    torch.cuda.synchronize()
+    build_ms = (time.perf_counter() - tb) * 1e3  # build of the 1e8-row side (not in `rows_per_s`)
+    lo = c.Column.empty(np.int32, n)
+    ro = c.Column.empty(np.int32, n)
+    cur = torch.zeros(1, dtype=torch.int64, device="cuda")
+    part_bits = lib.gx_join_partition_bits(8, hj.table_bytes) if not a.no_partitioned_join else 0
+    jnb = ctypes.c_size_t(0)
+    if part_bits:
+        L.check(lib.gx_join_probe_partitioned(8, pk.data_ptr, n, c.ptr(hj.table), hj.table_bytes, 0, lo.data_ptr,
+                                              ro.data_ptr, n, c.ptr(cur), None, ctypes.byref(jnb), c.stream), "query")
+        jtmp = c.device_bytes(jnb.value)
+
+    def step():
+        cur.zero_()
+        if part_bits:
+            L.check(lib.gx_join_probe_partitioned(8, pk.data_ptr, n, c.ptr(hj.table), hj.table_bytes, 0, lo.data_ptr,
+                                                  ro.data_ptr, n, c.ptr(cur), c.ptr(jtmp), ctypes.byref(jnb), c.stream), "probe")
+        else:
+            L.check(lib.gx_join_probe(8, pk.data_ptr, None, n, c.ptr(hj.table), hj.table_bytes, 0, lo.data_ptr,
+                                      ro.data_ptr, n, c.ptr(cur), c.stream), "probe")
+
+    kms = [0.0, 0.0, 0.0]
+    kn = [0]
+
+    def read_profile():
+        ms3 = (ctypes.c_float * 3)()
+        if part_bits and lib.gx_join_profile_read(ms3) == 0:
+            for i in range(3):
+                kms[i] += ms3[i]
+            kn[0] += 1
+
+    sec = c.timed(step, read_profile, after_warmup=lambda: lib.gx_join_profile(1))
+    lib.gx_join_profile(0)
+    ms_per_step = sec * 1e3
+    # ---- guard on the timed output: the number of pairs is the closed form, every pair joins equal keys, and
+    # the probe rows that appear are exactly the matching rows (sum and sum of squares of their indices)
+    matches = int(cur.item())
+    hit = pkt < (3 * nb_rows + 1)
+    want = int(hit.sum().item())
+    assert matches == want, f"join: {matches} pairs, closed form {want}"
+    lt = c.as_tensor(lo, torch.int32)[:matches].to(torch.int64)
+    rt = c.as_tensor(ro, torch.int32)[:matches].to(torch.int64)
+    assert bool((pkt[lt] == bkt[rt]).all()), "join: a pair joins unequal keys"
+    rows = torch.nonzero(hit).flatten()
+    assert int(lt.sum().item()) == int(rows.sum().item()), "join: wrong set of probe rows (sum)"
+    assert int((lt * lt).sum().item()) == int((rows * rows).sum().item()), "join: wrong set of probe rows (sum of squares)"
+    del lt, rt, rows, hit
+    algb = 24 * n + 16 * matches   # SURVEY.md 8d: 24 B/probe row + 16 B/match
+    ach = algb / (ms_per_step * 1e-3) / 1e9
+    roofline = {"bound": "hbm", "kernel": "partitioned probe (k_pj_hist + k_pj_scatter + k_pj_probe_pipe)" if part_bits else "k_probe",
+                "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS, "traffic": None,
+                "algorithmic_bytes_per_launch": algb, "avg_launch_ms": ms_per_step, "matches": matches,
+                "model": "24 B/probe row + 16 B/match (SURVEY.md 8d); whole probe phase = 3 launches"}
+    if kn[0]:
+        ms = [x / kn[0] for x in kms]
+        names = ["k_pj_hist+k_pj_offsets (partition histogram)", "k_pj_scatter (partition (key,row) by table hash)",
+                 "k_pj_probe (tag probe of partition-resident sub-tables)"]
+        kb = [8 * n, 20 * n, 12 * n + 8 * matches]   # bytes each launch must move: keys | keys + (key,row) | (key,row) + pairs
+        dom = max(range(3), key=lambda i: ms[i])
+        roofline["kernels_ms"] = dict(zip(names, ms))
+        roofline["kernels_GBps"] = {k: b / (m * 1e-3) / 1e9 for k, b, m in zip(names, kb, ms)}
+        roofline["dominant_kernel"] = {"kernel": names[dom], "algorithmic_bytes_per_launch": kb[dom], "avg_launch_ms": ms[dom],
+                                       "achieved": kb[dom] / (ms[dom] * 1e-3) / 1e9,
+                                       "frac": kb[dom] / (ms[dom] * 1e-3) / 1e9 / HBM_PEAK_GBS}
+        roofline["path_bytes"] = sum(kb)
+        roofline["path_GBps"] = sum(kb) / (ms_per_step * 1e-3) / 1e9
+    cpu = None
+    if a.cpu and c.rank == 0:
+        cpu = cpu_baseline_join(a.cpu_rows or 1e8, a.cpu_rows_pandas)
+    return {"workload": f"{n:.0e}-row int64 probe x {nb_rows:.0e}-row build inner hash join (probe phase timed)", "rows": n,
+            "ms_per_step": ms_per_step, "rows_per_s": n / sec, "dtype": "int64", "build_ms": build_ms,
+            "partition_bits": part_bits, "roofline": roofline, "cpu_baseline": cpu,
+            "checked": "pairs == closed form; every pair joins equal keys; sum / sum of squares of the matched probe rows"}
+
+
+# ------------------------------------------------------------------------------------------------
+# config 4: groupby(int32 key, 1e6 groups).agg(f64 sum, count)
+# ------------------------------------------------------------------------------------------------
+
+def bench_groupby(c):
+    a, lib, L, ops, np, torch = c.args, c.lib, c.L, c.ops, c.np, c.torch
+    n = c.n
+    lib.gx_groupby_set_algorithm(a.gb_algo, a.gb_split)
+    gk = ops.random_column(np.int32, n, seed=7 + c.rank, lo=0, hi=1_000_000)
+    gv = ops.random_column(np.float64, n, seed=8 + c.rank)
+    if c.world > 1:
+        from cudf_amd import distributed as D
+        local_ops = D.HipLocalOps()
+        dgk, dgv = c.as_tensor(gk, torch.int32), c.as_tensor(gv, torch.float64)
+        step = lambda: D.distributed_groupby_sum_count(dgk, dgv, local=local_ops)
+        sec = c.timed(step)
+        k, s, cnt = step()
+        tot = cnt.sum().to(torch.int64)
+        c.dist.all_reduce(tot)
+        assert int(tot.item()) == n * c.world, "distributed groupby: counts do not add up"
+        return {"workload": f"{n:.0e}-row-per-GPU groupby(int32 key, 1e6 groups).agg(f64 sum,count), partials exchanged",
+                "rows": n, "ms_per_step": sec * 1e3, "rows_per_s": n * c.world / sec, "dtype": "f64", "roofline": None,
+                "cpu_baseline": None, "checked": "sum of counts == rows over all ranks"}
+    mg = 1 << 20
+    ok, osum = c.Column.empty(np.int32, mg), c.Column.empty(np.float64, mg)
+    ocv = c.Column.empty(np.int32, mg)
+    ng = torch.zeros(1, dtype=torch.int64, device="cuda")
+    nb = ctypes.c_size_t(0)
+    fn = lambda tmp, nbp: lib.gx_groupby_sum_count(gk.gx, gk.data_ptr, None, gv.gx, gv.data_ptr, None, n, mg,
+                                                   ok.data_ptr, osum.data_ptr, ocv.data_ptr, None, c.ptr(ng), tmp, nbp, c.stream)
+    L.check(fn(None, ctypes.byref(nb)), "size query")
+    tmp = c.device_bytes(nb.value)
+    step = lambda: L.check(fn(c.ptr(tmp), ctypes.byref(nb)), "groupby")
+    sec = c.timed(step)
+    ms_per_step = sec * 1e3
+    # ---- guard: counts add up to n, keys are distinct and in range, and sampled groups match a direct
+    # device-side recomputation (count exact, f64 sum to 1e-11 relative: the kernel's own bar is 1 ulp)
+    groups = int(ng.item())
+    kt = c.as_tensor(ok, torch.int32)[:groups]
+    st = c.as_tensor(osum, torch.float64)[:groups]
+    ct = c.as_tensor(ocv, torch.int32)[:groups]
+    assert int(ct.to(torch.int64).sum().item()) == n, "groupby: counts do not add up to the row count"
+    assert int(kt.min().item()) >= 0 and int(kt.max().item()) < 1_000_000, "groupby: key out of range"
+    assert int(torch.unique(kt).numel()) == groups, "groupby: duplicate group keys"
+    gkt, gvt = c.as_tensor(gk, torch.int32), c.as_tensor(gv, torch.float64)
+    total_ref = float(gvt.sum().item())
+    assert abs(float(st.sum().item()) - total_ref) <= 1e-9 * abs(total_ref), "groupby: sums do not add up"
+    for gi in (0, groups // 3, groups - 1):
+        key = int(kt[gi].item())
+        sel = gkt == key
+        assert int(sel.sum().item()) == int(ct[gi].item()), "groupby: sampled group count differs"
+        ref = float(gvt[sel].sum().item())
+        assert abs(float(st[gi].item()) - ref) <= 1e-11 * max(1.0, abs(ref)), "groupby: sampled group sum differs"
+    ach = 12 * n / (ms_per_step * 1e-3) / 1e9
+    roofline = {"bound": "hbm", "kernel": "k_part_hist + k_part_scatter + k_part_aggregate (LDS-partitioned groupby)",
+                "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS, "traffic": None,
+                "algorithmic_bytes_per_launch": 12 * n, "avg_launch_ms": ms_per_step, "groups": groups,
+                "model": "12 B/row (4-B key + 8-B value read once; SURVEY.md 8d)"}
+    cpu = None
+    if a.cpu and c.rank == 0:
+        cpu = cpu_baseline_groupby(a.cpu_rows or 3e8, a.cpu_rows_pandas)
+    return {"workload": f"{n:.0e}-row groupby(int32 key, 1e6 groups).agg(float64 sum,count)", "rows": n,
+            "ms_per_step": ms_per_step, "rows_per_s": n / sec, "dtype": "f64", "roofline": roofline, "cpu_baseline": cpu,
+            "checked": "sum(count) == rows; distinct in-range keys; total and 3 sampled groups recomputed on the device"}
+
+
+# ------------------------------------------------------------------------------------------------
+# streaming primitives (SURVEY 8a rows a13-a15)
+# ------------------------------------------------------------------------------------------------
+
+def bench_stream(c, which):
+    a, lib, L, ops, np, torch = c.args, c.lib, c.L, c.ops, c.np, c.torch
+    n = c.n
+    src = ops.random_column(np.float64 if which == "reduce" else np.int64, n, seed=11 + c.rank)
+    nb = ctypes.c_size_t(0)
+    fn = None
+    if which == "reduce":
+        res = c.Column.empty(np.float64, 1)
+        cnt = torch.zeros(1, dtype=torch.int64, device="cuda")
+        fn = lambda tmp, nbp: lib.gx_reduce(src.gx, src.data_ptr, None, n, L.OP_SUM, L.FLOAT64, res.data_ptr, c.ptr(cnt), tmp, nbp, c.stream)
+        bpr, kname = 8, "gx_reduce f64 SUM"
+    elif which == "scan":
+        dst = c.Column.empty(np.int64, n)
+        fn = lambda tmp, nbp: lib.gx_scan(src.gx, src.data_ptr, None, n, L.OP_SUM, 1, dst.data_ptr, tmp, nbp, c.stream)
+        bpr, kname = 16, "gx_scan int64 inclusive SUM"
+    else:
+        gm = ops.random_column(np.int32, n, seed=13 + c.rank, lo=0, hi=n)
+        dst = c.Column.empty(np.int64, n)
+        bpr, kname = 20, "gx_gather 8-byte rows through a uniform random int32 map"
+    if fn is not None:
+        L.check(fn(None, ctypes.byref(nb)), "size query")
+        tmp = c.device_bytes(nb.value)
+        step = lambda: L.check(fn(c.ptr(tmp), ctypes.byref(nb)), which)
+    else:
+        step = lambda: L.check(lib.gx_gather(8, src.data_ptr, None, n, gm.data_ptr, n, 0, dst.data_ptr, None, c.stream), "gather")
+    sec = c.timed(step)
+    checked = None
+    if which == "reduce":
+        ref = float(c.as_tensor(src, torch.float64).sum().item())
+        got = float(res.to_numpy()[0])
+        assert abs(got - ref) <= 1e-9 * abs(ref) + 1e-3, "reduce: sum differs from the device recomputation"
+        checked = "sum vs torch.sum of the same column"
+    elif which == "scan":
+        s, d = c.as_tensor(src, torch.int64), c.as_tensor(dst, torch.int64)
+        assert int(d[-1].item()) == int(s.sum().item()), "scan: last element is not the wrapped total"
+        i = n // 2
+        assert int(d[i].item()) - int(d[i - 1].item()) == int(s[i].item()), "scan: adjacent difference differs"
+        checked = "last element == wrapped total; adjacent difference at n/2"
+    ach = bpr * n / sec / 1e9
+    roofline = {"bound": "hbm", "kernel": kname, "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS,
+                "traffic": None, "algorithmic_bytes_per_launch": bpr * n, "avg_launch_ms": sec * 1e3}
+    return {"workload": f"{n:.0e}-row {kname}", "rows": n, "ms_per_step": sec * 1e3, "rows_per_s": n * c.world / sec,
+            "dtype": "f64" if which == "reduce" else "int64", "roofline": roofline, "cpu_baseline": None, "checked": checked}
+
+
+def main():
+    args = parse()
+    if args.gpus > 1 and "RANK" not in os.environ:
+        sys.exit(spawn_ranks(args))
+    c = Ctx(args)
+    if c.world != max(1, args.gpus) and c.rank == 0:
+        print(f"bench.py: note: --gpus {args.gpus} but the process group has {c.world} rank(s); n_gpus reports the group", file=sys.stderr)
+    wl = args.workload
+    blocks = {}
+    if wl in ("all", "sort", "sorted_order"):
+        head = bench_sort(c, pairs=(wl == "sorted_order"))
+        if wl == "all":
+            c.torch.cuda.empty_cache()
+            blocks["join"] = bench_join(c)
+            c.torch.cuda.empty_cache()
+            blocks["groupby"] = bench_groupby(c)
+    elif wl == "join":
+        head = bench_join(c)
+    elif wl == "groupby":
+        head = bench_groupby(c)
+    else:
+        head = bench_stream(c, wl)
+    if c.rank == 0:
         line = {
-            "metric": "rows/sec + achieved HBM GB/s: 1e9-row int64 sort & hash-join, 1/2/4/8 GPU",
-            "value": unit_rows * world / (dt / args.steps), "unit": "rows/s", "n_gpus": world, "steps": args.steps,
-            "warmup": args.warmup, "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "weak",
-            "vs_baseline": None, "dtype": {"sort": "int64", "sorted_order": "int64", "join": "int64", "groupby": "f64", "reduce": "f64",
-                                          "scan": "int64", "gather": "int64"}[args.workload],
-            "data": "synthetic",
-            "config": {"workload": workload, "rows_per_gpu": n, "algo": args.algo, "gb_algo": args.gb_algo,
-                       "parallelism": (f"{world} ranks, row shards, one all-to-all exchange per step (RCCL over xGMI)"
-                                       if world > 1 else "1 GPU")},
-            "roofline": roofline, "cpu_baseline": cpu,
+            "metric": METRIC, "value": head["rows_per_s"], "unit": "rows/s", "n_gpus": c.world, "steps": args.steps,
+            "warmup": args.warmup, "ms_per_step": head["ms_per_step"], "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": head["dtype"], "data": "synthetic",
+            "config": {"workload": head["workload"], "rows_per_gpu": c.n, "algo": args.algo, "gb_algo": args.gb_algo,
+                       "parallelism": (f"{c.world} ranks, row shards, one all-to-all exchange per step (RCCL over xGMI)"
+                                       if c.world > 1 else "1 GPU")},
+            "roofline": head["roofline"], "cpu_baseline": head["cpu_baseline"], "checked": head.get("checked"),
         }
-        line.update(extra)
+        for k in ("build_ms", "partition_bits", "matches"):
+            if k in head:
+                line["join_" + k] = head[k]
+        for name, b in blocks.items():
+            line[name] = {"config": {"workload": b["workload"]}, "value": b["rows_per_s"], "unit": "rows/s",
+                          "ms_per_step": b["ms_per_step"], "steps": args.steps, "warmup": args.warmup, "dtype": b["dtype"],
+                          "roofline": b["roofline"], "cpu_baseline": b["cpu_baseline"], "checked": b.get("checked"),
+                          **({"build_ms": b["build_ms"], "partition_bits": b["partition_bits"]} if "build_ms" in b else {})}
         print(json.dumps(line), flush=True)
-    if world > 1:
-        dist.destroy_process_group()
+    if c.world > 1:
+        c.dist.destroy_process_group()
 
 
 if __name__ == "__main__":

@@ -63,6 +63,10 @@ _PROTOS = {
     "gx_join_probe_partitioned": (_i, [_i, _p, _i64, _p, ctypes.c_size_t, _i, _p, _p, _i64, _p, _p, _sz, _p]),
     "gx_join_build_partitioned": (_i, [_i, _p, _i64, _p, ctypes.c_size_t, ctypes.c_double, _p, _sz, _p]),
     "gx_join_partition_bits": (_i, [_i, ctypes.c_size_t]),
+    "gx_join_profile": (_i, [_i]),
+    "gx_join_profile_read": (_i, [ctypes.POINTER(ctypes.c_float)]),
+    "gx_join_set_scatter_tile": (None, [_i]),
+    "gx_join_set_probe_kernel": (None, [_i]),
     "gx_bitmask_copy": (_i, [_p, _i64, _p, _i64, _i64, _p]),
     "gx_pack_keys": (_i, [_i, _p, _p, _i64, _p, _p]),
     "gx_dense_rank": (_i, [_i, _p, _p, _i64, _i64, _p, _p, _p, _p, _sz, _p]),

@@ -405,8 +405,6 @@ int filter_impl(const void* keys, const uint32_t* valid, int64_t n, const void* 
 // ------------------------------------------------------------------------------------------------
 constexpr int PJ_MAXP  = 4096;
 constexpr int PJ_BT    = 512;
-constexpr int PJ_RPT   = 8;
-constexpr int PJ_TILE  = PJ_BT * PJ_RPT;  // 4096 rows: the range split of the input is defined on these tiles
 constexpr int PJ_NR    = 8;               // XCD ranges
 constexpr int PJ_CHUNK = 8192;            // probe rows per output reservation
 
@@ -424,10 +422,11 @@ struct PjPlan {
 };
 
 __device__ __forceinline__ unsigned pj_xcc() { return __builtin_amdgcn_s_getreg(20 | (0 << 6) | (3 << 11)) & 7u; }
-__host__ __device__ static inline int64_t pj_range_tiles(int64_t n) { return div_up(n, (int64_t)PJ_TILE) / PJ_NR; }
+// rows per XCD range of the input: a whole number of scatter tiles, so that no tile straddles two ranges
+static inline int64_t pj_range_rows(int64_t n, int64_t tile_rows) { return div_up(n, tile_rows) / PJ_NR * tile_rows; }
 
 template <typename K>
-__global__ void __launch_bounds__(256) k_pj_hist(const K* __restrict__ keys, int64_t n, PjPlan* plan, int pbits)
+__global__ void __launch_bounds__(256) k_pj_hist(const K* __restrict__ keys, int64_t n, PjPlan* plan, int pbits, int64_t rrows)
 {
   __shared__ unsigned int s_h[PJ_MAXP];
   const int P = 1 << pbits;
@@ -436,9 +435,8 @@ __global__ void __launch_bounds__(256) k_pj_hist(const K* __restrict__ keys, int
   const int r          = blockIdx.x % PJ_NR;
   const int64_t jb     = blockIdx.x / PJ_NR;
   const int64_t nb     = gridDim.x / PJ_NR;
-  const int64_t per    = pj_range_tiles(n) * PJ_TILE;
-  const int64_t rbegin = (int64_t)r * per;
-  const int64_t rend   = (r == PJ_NR - 1) ? n : rbegin + per;
+  const int64_t rbegin = (int64_t)r * rrows;
+  const int64_t rend   = (r == PJ_NR - 1) ? n : rbegin + rrows;
   constexpr int U      = 8;
   const int64_t stride = nb * 256 * U;
   for (int64_t i0 = rbegin + jb * 256 * U + threadIdx.x; i0 < rend; i0 += stride) {
@@ -506,56 +504,59 @@ __global__ void __launch_bounds__(1024) k_pj_offsets(PjPlan* plan, int pbits, un
   }
 }
 
-template <typename K, int RPT>
-__global__ void __launch_bounds__(PJ_BT) k_pj_scatter(const K* __restrict__ keys, int64_t n, PjPlan* plan, int pbits,
-                                                      K* __restrict__ pkeys, int32_t* __restrict__ pidx)
+// Scatter of the partition pass.  A workgroup of BTt threads ranks a tile of BTt * RPT rows with LDS atomics,
+// reorders the keys in LDS so that every partition leaves as one contiguous run, then sends the row indices
+// through the same buffer.  The partition of an element is recomputed from its key at write-out (one 64-bit
+// multiply) instead of being staged: the whole LDS budget goes to rows, and a tile of 16384 rows gives runs
+// of 8 rows (64 B of keys) at P = 2048 where the 4096-row tile of round 1 gave 2.
+template <typename K, int RPT, int BTt>
+__global__ void __launch_bounds__(BTt) k_pj_scatter(const K* __restrict__ keys, int64_t n, PjPlan* plan, int pbits,
+                                                    int64_t rrows, K* __restrict__ pkeys, int32_t* __restrict__ pidx)
 {
-  constexpr int PJ_RPT  = RPT;
-  constexpr int PJ_TILE = PJ_BT * RPT;
+  constexpr int TILE = BTt * RPT;
   extern __shared__ __attribute__((aligned(16))) char smem[];
-  K* s_k               = reinterpret_cast<K*>(smem);                                     // PJ_TILE (reused for idx)
-  unsigned short* s_bin = reinterpret_cast<unsigned short*>(smem + (size_t)PJ_TILE * sizeof(K));  // PJ_TILE
-  unsigned int* s_cnt  = reinterpret_cast<unsigned int*>(s_bin + PJ_TILE);               // P
-  unsigned int* s_start = s_cnt + (1 << pbits);                                          // P
-  unsigned long long* s_delta = reinterpret_cast<unsigned long long*>(s_start + (1 << pbits));  // P
-  __shared__ unsigned int s_scan[PJ_BT / GX_WAVE + 1];
+  K* s_k                = reinterpret_cast<K*>(smem);                                  // TILE (reused for idx)
+  unsigned int* s_cnt   = reinterpret_cast<unsigned int*>(smem + (size_t)TILE * sizeof(K));  // P
+  unsigned int* s_start = s_cnt + (1 << pbits);                                        // P
+  unsigned int* s_delta = s_start + (1 << pbits);                                      // P: global position - tile position (mod 2^32)
+  __shared__ unsigned int s_scan[BTt / GX_WAVE + 1];
   __shared__ unsigned int s_carry;
 
   const int P         = 1 << pbits;
   const unsigned tid  = threadIdx.x;
   const int64_t tile  = xcd_swizzle(blockIdx.x, gridDim.x);
-  const int64_t base  = tile * PJ_TILE;
-  const int64_t rrows = pj_range_tiles(n) * gx::join::PJ_TILE;  // rows per input range (k_pj_hist's split)
+  const int64_t base  = tile * TILE;
   const int range     = (rrows > 0 && base / rrows < PJ_NR - 1) ? (int)(base / rrows) : PJ_NR - 1;
-  const int nvalid    = (int)((n - base < (int64_t)PJ_TILE) ? (n - base) : (int64_t)PJ_TILE);
-  for (int i = tid; i < P; i += PJ_BT) s_cnt[i] = 0;
+  const int nvalid    = (int)((n - base < (int64_t)TILE) ? (n - base) : (int64_t)TILE);
+  for (int i = tid; i < P; i += BTt) s_cnt[i] = 0;
   if (tid == 0) s_carry = 0;
-  K key[PJ_RPT];
+  K key[RPT];
 #pragma unroll
-  for (int j = 0; j < PJ_RPT; ++j) {
-    const int idx = j * PJ_BT + (int)tid;
+  for (int j = 0; j < RPT; ++j) {
+    const int idx = j * BTt + (int)tid;
     key[j]        = (idx < nvalid) ? __builtin_nontemporal_load(&keys[base + idx]) : K(0);
   }
   __syncthreads();
-  unsigned int rank[PJ_RPT], part[PJ_RPT];
+  unsigned int packed[RPT];  // partition << 16 | rank inside (tile, partition)
 #pragma unroll
-  for (int j = 0; j < PJ_RPT; ++j) {
-    const int idx = j * PJ_BT + (int)tid;
-    part[j]       = (unsigned int)slot_of<K>(key[j], (uint32_t)pbits);
-    rank[j]       = (idx < nvalid) ? atomicAdd(&s_cnt[part[j]], 1u) : 0u;
+  for (int j = 0; j < RPT; ++j) {
+    const int idx           = j * BTt + (int)tid;
+    const unsigned int part = (unsigned int)slot_of<K>(key[j], (uint32_t)pbits);
+    const unsigned int rank = (idx < nvalid) ? atomicAdd(&s_cnt[part], 1u) : 0u;
+    packed[j]               = (part << 16) | rank;
   }
   __syncthreads();
-  // exclusive scan of the P counts (P may exceed the block: strips of PJ_BT)
-  for (int b0 = 0; b0 < P; b0 += PJ_BT) {
+  // exclusive scan of the P counts (P may exceed the block: strips of BTt)
+  for (int b0 = 0; b0 < P; b0 += BTt) {
     const int b          = b0 + (int)tid;
     const unsigned int c = b < P ? s_cnt[b] : 0u;
     unsigned int total;
-    const unsigned int st = block_exclusive_scan<PJ_BT>(c, 0u, SumOp(), s_scan, &total) + s_carry;
+    const unsigned int st = block_exclusive_scan<BTt>(c, 0u, SumOp(), s_scan, &total) + s_carry;
     if (b < P) {
       s_start[b] = st;
       unsigned long long g = 0;
       if (c) g = atomicAdd(&plan->cursor[range][b], (unsigned long long)c);
-      s_delta[b] = g - st;
+      s_delta[b] = (unsigned int)g - st;
     }
     __syncthreads();
     if (tid == 0) s_carry += total;
@@ -563,33 +564,35 @@ __global__ void __launch_bounds__(PJ_BT) k_pj_scatter(const K* __restrict__ keys
   }
   // keys through LDS
 #pragma unroll
-  for (int j = 0; j < PJ_RPT; ++j) {
-    const int idx = j * PJ_BT + (int)tid;
-    if (idx < nvalid) {
-      const unsigned int pos = s_start[part[j]] + rank[j];
-      s_k[pos]               = key[j];
-      s_bin[pos]             = (unsigned short)part[j];
-    }
+  for (int j = 0; j < RPT; ++j) {
+    const int idx = j * BTt + (int)tid;
+    if (idx < nvalid) s_k[s_start[packed[j] >> 16] + (packed[j] & 0xFFFFu)] = key[j];
   }
   __syncthreads();
+  unsigned short obin[RPT];  // partition of the element this thread writes out
 #pragma unroll
-  for (int j = 0; j < PJ_RPT; ++j) {
-    const int i = j * PJ_BT + (int)tid;
-    if (i < nvalid) pkeys[s_delta[s_bin[i]] + (unsigned long long)i] = s_k[i];
+  for (int j = 0; j < RPT; ++j) {
+    const int i = j * BTt + (int)tid;
+    obin[j]     = 0;
+    if (i < nvalid) {
+      const K k = s_k[i];
+      obin[j]   = (unsigned short)slot_of<K>(k, (uint32_t)pbits);
+      pkeys[(unsigned int)(s_delta[obin[j]] + (unsigned int)i)] = k;
+    }
   }
   __syncthreads();
   // row indices through the same buffer
   int32_t* s_i = reinterpret_cast<int32_t*>(smem);
 #pragma unroll
-  for (int j = 0; j < PJ_RPT; ++j) {
-    const int idx = j * PJ_BT + (int)tid;
-    if (idx < nvalid) s_i[s_start[part[j]] + rank[j]] = (int32_t)(base + idx);
+  for (int j = 0; j < RPT; ++j) {
+    const int idx = j * BTt + (int)tid;
+    if (idx < nvalid) s_i[s_start[packed[j] >> 16] + (packed[j] & 0xFFFFu)] = (int32_t)(base + idx);
   }
   __syncthreads();
 #pragma unroll
-  for (int j = 0; j < PJ_RPT; ++j) {
-    const int i = j * PJ_BT + (int)tid;
-    if (i < nvalid) pidx[s_delta[s_bin[i]] + (unsigned long long)i] = s_i[i];
+  for (int j = 0; j < RPT; ++j) {
+    const int i = j * BTt + (int)tid;
+    if (i < nvalid) pidx[(unsigned int)(s_delta[obin[j]] + (unsigned int)i)] = s_i[i];
   }
 }
 
@@ -968,6 +971,355 @@ k_pj_probe_tags(const K* __restrict__ pkeys, const int32_t* __restrict__ pidx, P
   }
 }
 
+// ---- software-pipelined tag probe ---------------------------------------------------------------------
+// k_pj_probe_tags waits for every memory level in turn (keys from HBM, then slots from L2, then the output
+// cursor, then the row ids from HBM) with 16 waves per CU to hide it: 85 % of its wave cycles were parked on
+// s_waitcnt (profiles/r1_run28_pmc_join_sq.txt).  Here ONE 1024-thread workgroup per CU owns the 64 KiB of
+// tags, the rest of the LDS stages the output, and a trip of the loop runs three stages of three different
+// 3840-row pieces of the chunk on 15 probe waves:
+//   S1(t)   issue the (key, row id) loads of piece t                           -> consumed one trip later
+//   S2(t-1) keys arrived: run the chain heads on the LDS tags, issue the slot load of the first candidate
+//           (unconditionally, lanes without a candidate read one shared dummy slot: a conditional load would
+//           make the compiler wait for it on the spot)
+//   S3(t-2) slots arrived: compare, finish the (rare) longer chains, append the matches to LDS staging
+//           buffer (t-2) % 3 at positions handed out by an LDS counter;
+//   after the trip's ONE barrier the probe waves send the staged pairs of piece t-3 to HBM as two fully
+//   coalesced streams, while the 16th wave -- which probes nothing -- reserves the output of piece t-2 with one
+//   device atomic and parks the result for the next trip.  Nothing a probe wave does in a trip waits for a
+//   memory operation issued in the same trip, except the rare chain continuations.
+constexpr int PP_BT    = 1024;
+constexpr int PP_PW    = PP_BT / GX_WAVE - 1;       // 15 probe waves
+constexpr int PP_R     = 4;                         // rows per thread and piece
+constexpr int PP_ROWS  = PP_PW * GX_WAVE * PP_R;    // 3840 rows per piece; also the capacity of a staging buffer
+struct Raw3 {  // the 12 bytes of a 16-B slot that matter: a 4th dword in flight would be a register the compiler may reuse early
+  uint32_t x, y, z;
+};
+template <typename K> struct SlotRaw;
+template <> struct SlotRaw<uint64_t> { typedef Raw3 type; };
+template <> struct SlotRaw<uint32_t> { typedef uint2 type; };
+__device__ __forceinline__ void unpack_slot(const Raw3& v, uint64_t& key, int32_t& row)
+{
+  key = ((uint64_t)v.y << 32) | v.x;
+  row = (int32_t)v.z;
+}
+__device__ __forceinline__ void unpack_slot(const uint2& v, uint32_t& key, int32_t& row)
+{
+  key = v.x;
+  row = (int32_t)v.y;
+}
+
+template <typename K>
+__global__ void __launch_bounds__(PP_BT)
+k_pj_probe_pipe(const K* __restrict__ pkeys, const int32_t* __restrict__ pidx, PjPlan* plan, int pbits,
+                const Slot<K>* __restrict__ slots, uint32_t log2cap, int left_outer, int32_t* __restrict__ out_probe,
+                int32_t* __restrict__ out_build, int64_t capacity, unsigned long long* cursor, unsigned int chunk_rows)
+{
+  typedef typename SlotRaw<K>::type Raw;
+  constexpr uint32_t SUB = 1u << PJ_SUB_LOG2;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const uint32_t* s_tagw = reinterpret_cast<const uint32_t*>(smem);                       // 64 KiB of tags
+  int32_t* s_sidx        = reinterpret_cast<int32_t*>(smem + (SUB >> 1));                  // [3][PP_ROWS] staged probe rows
+  int32_t* s_sfirst      = s_sidx + 3 * PP_ROWS;                                           // [3][PP_ROWS] staged build rows
+  __shared__ unsigned int s_cnt[8];           // pairs staged by piece (it & 7)
+  __shared__ unsigned long long s_base[3];    // output position of staging buffer (it % 3)
+  __shared__ unsigned int s_misc[4];
+  const int P         = 1 << pbits;
+  const int LISTP     = P / PJ_NR;
+  const uint64_t mask = (1ull << log2cap) - 1;
+  const unsigned tid  = threadIdx.x;
+  const unsigned lane = lane_id();
+  const unsigned w    = tid / GX_WAVE;
+
+  if (tid == 0) {  // take a chunk: own XCD's list first
+    const unsigned x = pj_xcc();
+    unsigned int g   = 0xFFFFFFFFu;
+    for (int i = 0; i < PJ_NR; ++i) {
+      const unsigned y       = (x + i) % PJ_NR;
+      const unsigned int nch = plan->list_chunk0[y + 1] - plan->list_chunk0[y];
+      if (nch == 0) continue;
+      const unsigned int t = atomicAdd(&plan->ticket[y].v, 1u);
+      if (t < nch) {
+        g         = plan->list_chunk0[y] + t;
+        s_misc[1] = y;
+        break;
+      }
+    }
+    s_misc[0] = g;
+  }
+  if (tid < 8) s_cnt[tid] = 0;
+  __syncthreads();
+  const unsigned int g = s_misc[0];
+  if (g == 0xFFFFFFFFu) return;
+  {
+    const unsigned y = s_misc[1];
+    for (int e = (int)tid; e < LISTP; e += PP_BT) {
+      const int p           = (int)y * LISTP + e;
+      const unsigned int lo = plan->chunk0[p], hi = plan->chunk0[p + 1];
+      if (lo <= g && g < hi) {
+        s_misc[2] = (unsigned int)p;
+        s_misc[3] = g - lo;
+      }
+    }
+  }
+  __syncthreads();
+  const unsigned int part     = s_misc[2];
+  const unsigned long long p0 = plan->offset[part], p1 = plan->offset[part + 1];
+  const unsigned long long c0 = p0 + (unsigned long long)s_misc[3] * chunk_rows;
+  const unsigned long long c1 = c0 + chunk_rows < p1 ? c0 + chunk_rows : p1;
+  const uint64_t sub_base     = (uint64_t)part << PJ_SUB_LOG2;
+  {
+    const uint8_t* gtags = reinterpret_cast<const uint8_t*>(slots + (mask + 1)) + (sub_base >> 1);
+    const uint4* src     = reinterpret_cast<const uint4*>(gtags);
+    uint4* dst           = reinterpret_cast<uint4*>(smem);
+    for (uint32_t i = tid; i < SUB / 2 / 16; i += PP_BT) dst[i] = src[i];
+  }
+  __syncthreads();
+
+  const int npieces = (int)((c1 - c0 + PP_ROWS - 1) / PP_ROWS);
+
+  if (w == PP_PW) {
+    // ------------------------------------------------------------------ service wave: output reservations
+    unsigned long long pending = 0;
+    for (int t = 0; t < npieces + 3; ++t) {
+      const int itf = t - 3, it3 = t - 2;
+      if (lane == 0 && itf >= 0 && itf < npieces) s_base[(unsigned)itf % 3u] = pending;
+      __syncthreads();  // X(t)
+      if (lane == 0) {
+        if (it3 >= 0 && it3 < npieces) {
+          unsigned int c = s_cnt[(unsigned)it3 & 7u];
+          c              = c < (unsigned)PP_ROWS ? c : (unsigned)PP_ROWS;
+          pending        = c ? atomicAdd(cursor, (unsigned long long)c) : 0ull;
+        }
+        s_cnt[(unsigned)(t + 2) & 7u] = 0;  // counter of piece t+2 (staged in trip t+4); its last user, piece t-6, left in trip t-3
+      }
+    }
+    return;
+  }
+
+  // ---------------------------------------------------------------------- probe waves
+  const Slot<K>* dummy = slots + sub_base;  // what lanes without a candidate read: one line for the whole wave
+  K kA[PP_R];                // S1 -> S2
+  int32_t iA[PP_R];
+  K kB[PP_R];                // S2 -> S3
+  int32_t iB[PP_R];
+  uint32_t li[PP_R], cand[PP_R];
+  Raw sv[PP_R];              // first candidate slot, in flight from S2 to S3
+  uint32_t fl = 0;           // per row j: bit j = live row, bit 4+j = chain ended inside the scanned window, bit 8+j = chain left the LDS window
+#pragma unroll
+  for (int j = 0; j < PP_R; ++j) {
+    kA[j] = kB[j] = K(0);
+    iA[j] = iB[j] = 0;
+    li[j] = cand[j] = 0;
+    sv[j] = Raw{};
+  }
+
+  for (int t = 0; t < npieces + 3; ++t) {
+    // ---------------- S3(t-2): compare, finish chains, stage the matches
+    const int it3 = t - 2;
+    if (it3 >= 0 && it3 < npieces) {
+      const unsigned buf = (unsigned)it3 % 3u;
+      uint32_t m[PP_R];
+      int32_t first[PP_R];
+      K sk[PP_R];
+      int32_t sr[PP_R];
+      uint32_t active = 0, ended = (fl >> 4) & 15u;
+#pragma unroll
+      for (int j = 0; j < PP_R; ++j) {
+        m[j]     = 0;
+        first[j] = NO_MATCH;
+        unpack_slot(sv[j], sk[j], sr[j]);
+        if (!((fl >> j) & 1u)) continue;
+        if ((fl >> (8 + j)) & 1u) {  // chain starts in the last slots of the sub-table: walk the slots themselves
+          uint64_t gs = sub_base + li[j];
+          for (;;) {
+            K k;
+            int32_t r;
+            load_slot<K>(&slots[gs & mask], k, r);
+            if (r == EMPTY_ROW) break;
+            if (k == kB[j]) {
+              if (m[j] == 0) first[j] = r;
+              ++m[j];
+            }
+            ++gs;
+          }
+        } else if (cand[j] || !((ended >> j) & 1u)) {
+          active |= 1u << j;
+        }
+      }
+      bool preloaded = true;  // the first candidate of every row was fetched by S2
+      while (active) {
+        if (!preloaded) {
+#pragma unroll
+          for (int j = 0; j < PP_R; ++j) {
+            if (ballot((active >> j) & 1u) == 0) continue;
+            if ((active & (1u << j)) && cand[j])
+              load_slot<K>(&slots[sub_base + li[j] + ((uint32_t)__builtin_ctz(cand[j]) >> 2)], sk[j], sr[j]);
+          }
+        }
+        preloaded = false;
+#pragma unroll
+        for (int j = 0; j < PP_R; ++j) {
+          if (ballot((active >> j) & 1u) == 0) continue;
+          if (!(active & (1u << j))) continue;
+          if (cand[j]) {
+            if (sk[j] == kB[j]) {  // a tagged slot is never empty
+              if (m[j] == 0) first[j] = sr[j];
+              ++m[j];
+            }
+            cand[j] &= cand[j] - 1;
+          }
+          if (cand[j] == 0) {
+            if (ended & (1u << j)) {
+              active &= ~(1u << j);
+            } else {  // the chain runs on: next 8 slots
+              li[j] += 8;
+              if (li[j] > SUB - 8) {
+                uint64_t gs = sub_base + li[j];
+                for (;;) {
+                  K k;
+                  int32_t r;
+                  load_slot<K>(&slots[gs & mask], k, r);
+                  if (r == EMPTY_ROW) break;
+                  if (k == kB[j]) {
+                    if (m[j] == 0) first[j] = r;
+                    ++m[j];
+                  }
+                  ++gs;
+                }
+                active &= ~(1u << j);
+              } else {
+                const bool e = scan_tags8(s_tagw, li[j], tag_of<K>(kB[j], log2cap) * 0x11111111u, cand[j]);
+                if (e) {
+                  ended |= 1u << j;
+                  if (cand[j] == 0) active &= ~(1u << j);
+                }
+              }
+            }
+          }
+        }
+      }
+      // ---- stage: pairs of this piece go to s_sidx / s_sfirst [buf] at positions handed out by an LDS counter
+#pragma unroll
+      for (int j = 0; j < PP_R; ++j) {
+        const bool live = (fl >> j) & 1u;
+        if (left_outer && live && m[j] == 0) m[j] = 1;  // (row, JoinNoMatch); first[j] is NO_MATCH
+        uint32_t off, tot;
+        if (ballot(m[j] > 1) == 0) {
+          const uint64_t b = ballot(m[j] == 1);
+          if (b == 0) continue;
+          off = (uint32_t)__builtin_popcountll(b & lanemask_lt());
+          tot = (uint32_t)__builtin_popcountll(b);
+        } else {
+          const uint32_t sc = wave_inclusive_scan(m[j], SumOp());
+          off               = sc - m[j];
+          tot               = shfl(sc, GX_WAVE - 1);
+        }
+        uint32_t wbase = 0;
+        if (lane == 0) wbase = atomicAdd(&s_cnt[(unsigned)it3 & 7u], tot);
+        wbase = (uint32_t)__builtin_amdgcn_readfirstlane((int)wbase);
+        if (m[j] == 0) continue;
+        const uint32_t pos = wbase + off;
+        if (m[j] == 1) {
+          if (pos < (uint32_t)PP_ROWS) {
+            s_sidx[buf * PP_ROWS + pos]   = iB[j];
+            s_sfirst[buf * PP_ROWS + pos] = first[j];
+          } else {  // staging full (duplicate build keys): reserve and write directly
+            const unsigned long long gp = atomicAdd(cursor, 1ull);
+            if ((int64_t)gp < capacity) {
+              out_probe[gp] = iB[j];
+              out_build[gp] = first[j];
+            }
+          }
+        } else {  // duplicate build keys: walk the chain again (lines are cache-resident)
+          const uint32_t room   = pos < (uint32_t)PP_ROWS ? (uint32_t)PP_ROWS - pos : 0u;
+          const uint32_t staged = room < m[j] ? room : m[j];
+          unsigned long long gp = 0;
+          if (staged < m[j]) gp = atomicAdd(cursor, (unsigned long long)(m[j] - staged));
+          uint32_t seen = 0;
+          uint64_t hh   = slot_of<K>(kB[j], log2cap);
+          for (;;) {
+            K k;
+            int32_t r;
+            load_slot<K>(&slots[hh], k, r);
+            if (r == EMPTY_ROW) break;
+            if (k == kB[j]) {
+              if (seen < staged) {
+                s_sidx[buf * PP_ROWS + pos + seen]   = iB[j];
+                s_sfirst[buf * PP_ROWS + pos + seen] = r;
+              } else {
+                if ((int64_t)gp < capacity) {
+                  out_probe[gp] = iB[j];
+                  out_build[gp] = r;
+                }
+                ++gp;
+              }
+              ++seen;
+            }
+            hh = (hh + 1) & mask;
+          }
+        }
+      }
+    }
+    // ---------------- S2(t-1): chain heads on the LDS tags, first candidate slot in flight
+    const int it2 = t - 1;
+    fl            = 0;
+    if (it2 >= 0 && it2 < npieces) {
+      const unsigned long long pb = c0 + (unsigned long long)it2 * PP_ROWS + (unsigned long long)w * (PP_R * GX_WAVE) + lane;
+#pragma unroll
+      for (int j = 0; j < PP_R; ++j) {
+        kB[j]   = kA[j];
+        iB[j]   = iA[j];
+        cand[j] = 0;
+        li[j]   = 0;
+        if (pb + (unsigned long long)j * GX_WAVE < c1) {
+          fl |= 1u << j;
+          const uint64_t prod = (uint64_t)kB[j] * 0x9E3779B97F4A7C15ull;
+          li[j]               = (uint32_t)((prod >> (64 - log2cap)) - sub_base);
+          uint32_t tg         = (uint32_t)(prod >> (60 - log2cap)) & 15u;
+          tg                  = tg ? tg : 8u;
+          if (li[j] > SUB - 8) {
+            fl |= 1u << (8 + j);
+          } else if (scan_tags8(s_tagw, li[j], tg * 0x11111111u, cand[j])) {
+            fl |= 1u << (4 + j);
+          }
+        }
+      }
+#pragma unroll
+      for (int j = 0; j < PP_R; ++j) {
+        const Slot<K>* sp = cand[j] ? slots + (sub_base + li[j] + ((uint32_t)__builtin_ctz(cand[j]) >> 2)) : dummy;
+        sv[j]             = *reinterpret_cast<const Raw*>(sp);
+      }
+    }
+    // ---------------- S1(t): loads of the next piece
+    if (t < npieces) {
+      const unsigned long long pb = c0 + (unsigned long long)t * PP_ROWS + (unsigned long long)w * (PP_R * GX_WAVE) + lane;
+#pragma unroll
+      for (int j = 0; j < PP_R; ++j) {
+        const unsigned long long i  = pb + (unsigned long long)j * GX_WAVE;
+        const unsigned long long ic = i < c1 ? i : c0;  // clamped: the load is unconditional, dead rows are masked by `fl`
+        kA[j] = __builtin_nontemporal_load(&pkeys[ic]);
+        iA[j] = __builtin_nontemporal_load(&pidx[ic]);
+      }
+    }
+    __syncthreads();  // X(t): staging of piece t-2 complete, s_base of piece t-3 visible
+    // ---------------- flush of piece t-3: two coalesced streams
+    const int itf = t - 3;
+    if (itf >= 0 && itf < npieces) {
+      const unsigned buf          = (unsigned)itf % 3u;
+      unsigned int c              = s_cnt[(unsigned)itf & 7u];
+      c                           = c < (unsigned)PP_ROWS ? c : (unsigned)PP_ROWS;
+      const unsigned long long gb = s_base[buf];
+      for (unsigned int i = tid; i < c; i += PP_PW * GX_WAVE) {
+        const unsigned long long gp = gb + i;
+        if ((int64_t)gp < capacity) {
+          __builtin_nontemporal_store(s_sidx[buf * PP_ROWS + i], &out_probe[gp]);
+          __builtin_nontemporal_store(s_sfirst[buf * PP_ROWS + i], &out_build[gp]);
+        }
+      }
+    }
+  }
+}
+
 // Partitioned build: the build rows go through the same partition pass, then each chunk inserts into
 // the ~2 MiB sub-table its partition maps to while the other workgroups of the XCD insert into the
 // same one -- the CAS and the 16-B slot write hit L2 instead of scattering over the whole table
@@ -1035,28 +1387,54 @@ __global__ void __launch_bounds__(PJ_BT) k_pj_build(const K* __restrict__ pkeys,
   }
 }
 
+// optional per-kernel timing of the partitioned probe with HIP events on the caller's stream (bench.py)
+struct JoinProfile {
+  bool enabled = false, created = false, marked = false;
+  hipEvent_t ev[4];  // before hist | before scatter | before probe | after probe
+};
+static JoinProfile g_jprof;
+static inline void jprof_mark(int i, hipStream_t s)
+{
+  if (g_jprof.enabled) (void)hipEventRecord(g_jprof.ev[i], s);
+}
+static int g_pj_probe = 0; // probe kernel: 0 = default (software-pipelined tag probe), 1 = round-1 tag probe (A/B knob)
+static int g_pj_tile = 0;  // scatter tile rows: 0 = default, else 4096 / 8192 / 16384 (A/B knob)
+
 // the partition pass shared by the partitioned probe and build
 template <typename K>
-int pj_partition(const K* keys, int64_t n, int pbits, PjPlan* plan, K* pkeys, int32_t* pidx, unsigned int chunk_rows, hipStream_t s)
+int pj_partition(const K* keys, int64_t n, int pbits, PjPlan* plan, K* pkeys, int32_t* pidx, unsigned int chunk_rows, hipStream_t s,
+                 bool profile = false)
 {
   GX_HIP_TRY(hipMemsetAsync(plan, 0, sizeof(PjPlan), s));
+  // tile: as many rows as the LDS holds next to the three P-entry arrays (160 KiB per CU)
+  int tile_rows = g_pj_tile ? g_pj_tile : 16384;
+  while (tile_rows > 4096 && (size_t)tile_rows * sizeof(K) + ((size_t)12 << pbits) + 256 > (size_t)160 * 1024) tile_rows /= 2;
+  if (n <= 4 * (int64_t)tile_rows * 256) tile_rows = 4096;  // small inputs: more, smaller workgroups
+  const int64_t rrows = pj_range_rows(n, tile_rows);
+  if (profile) jprof_mark(0, s);
   int64_t hb = div_up(n, 256 * 8 * 4 * PJ_NR);
   if (hb > 256) hb = 256;
   if (hb < 1) hb = 1;
-  hipLaunchKernelGGL((k_pj_hist<K>), dim3((unsigned)(hb * PJ_NR)), dim3(256), 0, s, keys, n, plan, pbits);
+  hipLaunchKernelGGL((k_pj_hist<K>), dim3((unsigned)(hb * PJ_NR)), dim3(256), 0, s, keys, n, plan, pbits, rrows);
   hipLaunchKernelGGL(k_pj_offsets, dim3(1), dim3(1024), 0, s, plan, pbits, chunk_rows);
-  const int rpt            = getenv("GX_PJ_RPT") ? atoi(getenv("GX_PJ_RPT")) : 8;
-  const size_t tile_rows   = (size_t)PJ_BT * (rpt == 16 ? 16 : 8);
-  const size_t lds_max     = (size_t)PJ_BT * 16 * sizeof(K) + (size_t)PJ_BT * 16 * 2 + (size_t)PJ_MAXP * (4 + 4 + 8);
-  const size_t lds         = tile_rows * sizeof(K) + tile_rows * 2 + ((size_t)16 << pbits);
-  auto ks                  = rpt == 16 ? k_pj_scatter<K, 16> : k_pj_scatter<K, 8>;
-  static bool attr_set     = false;
+  if (profile) jprof_mark(1, s);
+  const size_t lds = (size_t)tile_rows * sizeof(K) + ((size_t)12 << pbits);
+  auto k4          = k_pj_scatter<K, 8, 512>;
+  auto k8          = k_pj_scatter<K, 16, 512>;
+  auto k16         = k_pj_scatter<K, 16, 1024>;
+  static bool attr_set = false;
   if (!attr_set) {
-    GX_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(k_pj_scatter<K, 8>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_max));
-    GX_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(k_pj_scatter<K, 16>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_max));
+    const int lds_max = 160 * 1024 - 256;
+    GX_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(k4), hipFuncAttributeMaxDynamicSharedMemorySize, lds_max));
+    GX_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(k8), hipFuncAttributeMaxDynamicSharedMemorySize, lds_max));
+    GX_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(k16), hipFuncAttributeMaxDynamicSharedMemorySize, lds_max));
     attr_set = true;
   }
-  hipLaunchKernelGGL(ks, dim3((unsigned)div_up(n, (int64_t)tile_rows)), dim3(PJ_BT), lds, s, keys, n, plan, pbits, pkeys, pidx);
+  const unsigned grid = (unsigned)div_up(n, (int64_t)tile_rows);
+  if (tile_rows == 16384) hipLaunchKernelGGL(k16, dim3(grid), dim3(1024), lds, s, keys, n, plan, pbits, rrows, pkeys, pidx);
+  else if (tile_rows == 8192) hipLaunchKernelGGL(k8, dim3(grid), dim3(512), lds, s, keys, n, plan, pbits, rrows, pkeys, pidx);
+  else hipLaunchKernelGGL(k4, dim3(grid), dim3(512), lds, s, keys, n, plan, pbits, rrows, pkeys, pidx);
+  if (profile) jprof_mark(2, s);
   GX_LAUNCH_CHECK();
   return 0;
 }
@@ -1092,19 +1470,29 @@ int probe_partitioned_impl(const void* keys, int64_t n, const void* table, size_
   const Slot<K>* slots = reinterpret_cast<const Slot<K>*>(static_cast<const char*>(table) + sizeof(TableHeader));
   if (pbits == 0) return GX_EINVAL;  // caller should use gx_join_probe
   const bool use_tags = !getenv("GX_PJ_NOTAGS");
+  const bool use_pipe = use_tags && g_pj_probe != 1;
   // the tag probe amortises its 64 KiB tag copy over several PJ_CHUNKs of the same partition
   unsigned int chunk_rows = PJ_CHUNK;
   if (use_tags) {
     const int mult = getenv("GX_PJ_SC") ? atoi(getenv("GX_PJ_SC")) : 8;
-    chunk_rows     = PJ_CHUNK * (unsigned)(mult < 1 ? 1 : mult);
-    while (chunk_rows > PJ_CHUNK && div_up(n, (int64_t)chunk_rows) < 4096) chunk_rows /= 2;  // keep >> 512 workgroups
+    chunk_rows     = PJ_CHUNK * (unsigned)(mult < 1 ? 1 : mult) * (use_pipe ? 2u : 1u);
+    while (chunk_rows > PJ_CHUNK && div_up(n, (int64_t)chunk_rows) < (use_pipe ? 2048 : 4096)) chunk_rows /= 2;  // keep >> 256 (512) workgroups
   }
   {
-    int rc = pj_partition<K>(static_cast<const K*>(keys), n, pbits, plan, pkeys, pidx, chunk_rows, s);
+    int rc = pj_partition<K>(static_cast<const K*>(keys), n, pbits, plan, pkeys, pidx, chunk_rows, s, true);
     if (rc) return rc;
   }
   const int64_t max_chunks = div_up(n, (int64_t)chunk_rows) + (1 << pbits);
-  if (use_tags) {
+  if (use_pipe) {
+    constexpr size_t lds_p = ((size_t)1 << (PJ_SUB_LOG2 - 1)) + (size_t)6 * PP_ROWS * sizeof(int32_t);
+    static bool pattr_set  = false;
+    if (!pattr_set) {
+      GX_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(k_pj_probe_pipe<K>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_p));
+      pattr_set = true;
+    }
+    hipLaunchKernelGGL((k_pj_probe_pipe<K>), dim3((unsigned)max_chunks), dim3(PP_BT), lds_p, s, pkeys, pidx, plan, pbits, slots, lg,
+                       left_outer, out_probe, out_build, capacity, reinterpret_cast<unsigned long long*>(cursor), chunk_rows);
+  } else if (use_tags) {
     constexpr size_t lds_t = (size_t)1 << (PJ_SUB_LOG2 - 1);
     static bool tattr_set  = false;
     if (!tattr_set) {
@@ -1117,6 +1505,8 @@ int probe_partitioned_impl(const void* keys, int64_t n, const void* table, size_
     hipLaunchKernelGGL((k_pj_probe<K>), dim3((unsigned)max_chunks), dim3(PJ_BT), 0, s, pkeys, pidx, plan, pbits, slots, lg,
                        left_outer, out_probe, out_build, capacity, reinterpret_cast<unsigned long long*>(cursor));
   }
+  jprof_mark(3, s);
+  g_jprof.marked = g_jprof.enabled;
   GX_LAUNCH_CHECK();
   return 0;
 }
@@ -1302,6 +1692,33 @@ int gx_join_filter(int key_size, const void* probe_keys, const uint32_t* probe_v
     return gx::join::filter_impl<uint32_t>(probe_keys, probe_valid, probe_rows, table, table_bytes, lg, anti, null_matches,
                                            out_probe_idx, count_dev, tmp, tmp_bytes, (hipStream_t)s);
   return GX_EDTYPE;
+}
+
+int gx_join_profile(int enable)
+{
+  auto& p = gx::join::g_jprof;
+  if (enable && !p.created) {
+    for (auto& e : p.ev) GX_HIP_TRY(hipEventCreate(&e));
+    p.created = true;
+  }
+  p.enabled = enable != 0;
+  return 0;
+}
+
+int gx_join_profile_read(float* ms3)
+{
+  auto& p = gx::join::g_jprof;
+  if (!p.created || !p.marked || !ms3) return GX_EINVAL;
+  GX_HIP_TRY(hipEventSynchronize(p.ev[3]));
+  for (int i = 0; i < 3; ++i) GX_HIP_TRY(hipEventElapsedTime(&ms3[i], p.ev[i], p.ev[i + 1]));
+  return 0;
+}
+
+void gx_join_set_probe_kernel(int which) { gx::join::g_pj_probe = which == 1 ? 1 : 0; }
+
+void gx_join_set_scatter_tile(int rows)
+{
+  gx::join::g_pj_tile = (rows == 4096 || rows == 8192 || rows == 16384) ? rows : 0;
 }
 
 int gx_join_partition_bits(int key_size, size_t table_bytes)

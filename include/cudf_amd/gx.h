@@ -258,6 +258,16 @@ int gx_join_build_partitioned(int key_size, const void* build_keys, int64_t buil
                               gx_stream_t stream);
 /* log2 of the number of partitions the partitioned probe uses for this table; 0 = not partitionable */
 int gx_join_partition_bits(int key_size, size_t table_bytes);
+/* Measurement hooks (bench.py's roofline leg), like gx_sort_profile: when enabled, every partitioned probe
+ * records HIP events on the caller's stream; gx_join_profile_read waits for the last one and returns
+ * ms3 = {partition histogram + offsets, scatter of (key, row) into partitions, probe} in milliseconds. */
+int gx_join_profile(int enable);
+int gx_join_profile_read(float* ms3);
+/* A/B knob (process-wide): rows per workgroup tile of the partition scatter (4096, 8192, 16384; 0 = default:
+ * the largest that fits the LDS next to the per-partition counters). */
+void gx_join_set_scatter_tile(int rows);
+/* A/B knob (process-wide): 0 = software-pipelined tag probe (default), 1 = the round-1 tag probe. */
+void gx_join_set_probe_kernel(int which);
 
 /* out_build_idx[i] = the first build row whose key equals probe key i, or INT32_MIN (JoinNoMatch) --
  * the left join against DISTINCT build keys, in probe order and without an output reservation:
