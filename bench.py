@@ -56,6 +56,7 @@ def parse():
     ap.add_argument("--join-probe-kernel", type=int, default=0, help="join knob: 0 pipelined tag probe, 1 round-1 tag probe")
     ap.add_argument("--join-scatter-tile", type=int, default=0, help="join knob: rows per scatter tile (0 = default)")
     ap.add_argument("--no-hybrid", action="store_true", help="sort: disable the hybrid MSD path (LSD passes only)")
+    ap.add_argument("--sort-cell", type=int, default=0, help="sort knob: local-sort cell capacity (0 auto, 8192, 16384)")
     ap.add_argument("--key-range", type=int, nargs=2, default=None, metavar=("LO", "HI"),
                     help="sort: keys uniform in [LO, HI) instead of the full int64 range (the reference's own "
                          "benchmark distribution is 100 10001: benchmarks/sort/sort.cpp:24-26)")
@@ -256,6 +257,7 @@ def bench_sort(c, pairs=False):
     n = c.n
     lib.gx_sort_set_algorithm(a.algo)
     lib.gx_sort_set_hybrid(0 if a.no_hybrid else 1)
+    lib.gx_sort_set_cell(a.sort_cell)
     if a.key_range:
         keys = ops.random_column(np.int64, n, seed=42 + c.rank, lo=a.key_range[0], hi=a.key_range[1])
     else:
@@ -324,7 +326,7 @@ def bench_sort(c, pairs=False):
     ms_per_step = sec * 1e3
     info = (ctypes.c_int32 * 8)()
     lib.gx_sort_info(c.ptr(tmp), info, c.stream)
-    sort_info = dict(zip(["hybrid_attempted", "hybrid_used", "d1", "shift2", "bits2", "lds_passes", "max_cell", "lsd_passes"], list(info)))
+    sort_info = dict(zip(["hybrid_attempted", "hybrid_used", "shift0", "shift2", "bits2", "lds_passes", "max_cell", "lsd_passes"], list(info)))
     hist_ms = prof["hist_ms"] / nsteps_prof
     local_sort_ms = ms_per_step if c.world == 1 else hist_ms + (sum(prof["hyb"]) if prof["hyb_n"] else prof["pass_ms"])
     roofline = None
@@ -333,7 +335,8 @@ def bench_sort(c, pairs=False):
         # write 8 B/row, the joint histogram reads 8 B/row
         ms = [x / prof["hyb_n"] for x in prof["hyb"]]
         names = ["k_msd_pass level 0 (8-bit partition, 8 XCD chains)", "k_hist2+k_plan2 (joint histogram)",
-                 "k_msd_pass level 1 (partition inside buckets)", "k_local_sort (LDS sort of the cells)"]
+                 f"k_msd_pass level 1 ({sort_info['bits2']}-bit partition inside buckets)",
+                 "k_local_sort (LDS sort of the cells)"]
         bpr = [20, 8, 24, 24] if pairs else [16, 8, 16, 16]  # pairs carry a 4-B index
         dom = max(range(4), key=lambda i: ms[i])
         achieved = bpr[dom] * n / (ms[dom] * 1e-3) / 1e9

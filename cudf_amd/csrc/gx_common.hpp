@@ -85,11 +85,12 @@ __device__ __forceinline__ T shfl_xor(T v, int m)
 // v_bitop3_b32 per half (truth table 0x90: a & ~(b ^ c) with c = 0 / ~0 from the lane's bit), which
 // halves the VALU work of the and/xor/cndmask sequence the compiler emits for the generic form.
 // `active` = ballot of the lanes that take part (others must pass live == false).
-__device__ __forceinline__ void match_rank8(uint32_t d, bool live, uint64_t active, uint32_t& lower, uint32_t& count)
+template <int NBITS>
+__device__ __forceinline__ void match_rank(uint32_t d, bool live, uint64_t active, uint32_t& lower, uint32_t& count)
 {
   uint32_t m_lo = (uint32_t)active, m_hi = (uint32_t)(active >> 32);
 #pragma unroll
-  for (int b = 0; b < 8; ++b) {
+  for (int b = 0; b < NBITS; ++b) {
     const int beta   = __builtin_amdgcn_sbfe(d, b, 1);  // 0 or -1
     const uint64_t v = ballot(live && beta != 0);
     m_lo             = __builtin_amdgcn_bitop3_b32(m_lo, (uint32_t)v, (uint32_t)beta, 0x90);
@@ -97,6 +98,11 @@ __device__ __forceinline__ void match_rank8(uint32_t d, bool live, uint64_t acti
   }
   lower = __builtin_amdgcn_mbcnt_hi(m_hi, __builtin_amdgcn_mbcnt_lo(m_lo, 0u));
   count = (uint32_t)__builtin_popcount(m_lo) + (uint32_t)__builtin_popcount(m_hi);
+}
+
+__device__ __forceinline__ void match_rank8(uint32_t d, bool live, uint64_t active, uint32_t& lower, uint32_t& count)
+{
+  match_rank<8>(d, live, active, lower, count);
 }
 
 // ---- in-wave bitonic sort of 64-bit keys (one or two keys per lane), ascending over

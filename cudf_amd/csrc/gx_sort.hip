@@ -29,29 +29,38 @@ constexpr int BT         = 512;  // threads per workgroup (8 waves)
 constexpr int NW         = BT / GX_WAVE;
 constexpr int NRANGE     = 8;    // input ranges == XCDs: each gets its own look-back chain (hybrid level 0)
 
-// Hybrid MSD sort (64-bit keys, keys only, n >= 2^22): two stable MSD partition passes bring every
-// cell (= keys sharing their top 8 + bits2 active bits) down to at most LOCAL_MAX keys, then ONE
-// kernel sorts each cell on all remaining bits inside LDS.  HBM traffic: 8 (histogram) + 16 + 8
-// (joint histogram) + 16 + 16 = 64 B/row instead of 8 + 8 x 16 = 136 B/row for the 8-pass LSD.
-// Whether every cell fits is decided ON THE DEVICE after the joint histogram (k_plan2); when one
-// does not (skewed keys) the hybrid kernels turn into no-ops and the LSD passes below run instead.
-constexpr int LOCAL_MAX  = 16384;
-constexpr int LS_BT      = 1024;
-constexpr int LS_KPT     = LOCAL_MAX / LS_BT;
-constexpr int LS_NW      = LS_BT / GX_WAVE;
+// Hybrid MSD sort (64-bit keys, n >= 2^22): two MSD partition passes bring every cell (= keys sharing
+// all bits above shift2) down to at most one LDS-resident cell, then ONE kernel sorts each cell on all
+// remaining bits inside LDS.  HBM traffic: 8 (histogram) + 16 + 8 (joint histogram) + 16 + 16 = 64 B/row
+// instead of 8 + 8 x 16 = 136 B/row for the 8-pass LSD.
+//   * digits are BIT granular: an up-front pass reduces the OR of the keys and the OR of their complements
+//     (a bit varies iff it is set in both) next to a speculative histogram of the top byte; level 0 takes the
+//     8 bits below the highest varying bit, so keys confined to a range that is not byte aligned (a rank's
+//     shard of a distributed sort, timestamps, n a few per cent above a power of two) stay on this path;
+//   * level 1 takes the next `bits2` <= 9 bits.  Keys-only sorts use cells of <= 8192 keys (64 KiB): two
+//     local-sort workgroups share a CU, so one cell's loads and stores overlap the other's LDS work;
+//     pairs / larger n use 16384-key cells (one workgroup per CU), the round-1 configuration.
+// Whether every cell fits is decided ON THE DEVICE after the joint histogram (k_plan2); when one does not
+// (skewed keys) the hybrid kernels turn into no-ops and the LSD passes below run instead.
+constexpr int NB2MAX     = 512;  // level-1 bins (<= 9 bits)
 
 struct HybridPlan {
-  int32_t attempt;  // k_plan: the hybrid path is being tried
+  int32_t attempt;  // k_hy_plan: the hybrid path is being tried
   int32_t ok;       // k_plan2: every cell fits -> LSD passes are skipped, local sort runs
-  int32_t d1;       // byte index of the level-0 digit (most significant non-constant byte)
+  int32_t shift0;   // level-0 digit: bits [shift0, shift0 + 8) of the sortable key
   int32_t shift2, bits2;  // level-1 digit: bits [shift2, shift2 + bits2)
-  int32_t nlocal;         // LDS passes of the local sort
+  int32_t nlocal;         // LDS passes of the local sort's stable fallback
   int32_t lshift[MAX_PASSES], lbits[MAX_PASSES];
+  int32_t need_hist;      // the speculative top-byte histogram is not the level-0 digit: k_hy_hist<false> runs
+  int32_t cell_max;       // capacity of a local-sort cell (8192 or 16384)
+  unsigned long long or_mask, nor_mask;  // OR of the sortable keys / of their complements
   uint32_t list_tile0[2][NRANGE + 1];  // first global tile of each list
   uint32_t seg_tile0[2][BINS + 1];     // first global tile of each segment (level 0: NRANGE segments)
   uint32_t seg_start[2][BINS], seg_count[2][BINS];
   uint32_t max_cell;
-  uint32_t rhist[NRANGE][MAX_PASSES][BINS];  // range-resolved digit histograms (k_hist_all)
+  uint32_t hist0[BINS], gbin0[BINS];   // level-0 digit histogram of the whole column and its exclusive scan
+  uint32_t rh0[NRANGE][BINS];          // range-resolved level-0 histogram
+  uint32_t rhist[NRANGE][MAX_PASSES][BINS];  // range-resolved byte histograms (k_hist_all, LSD path)
 };
 
 // Every word that workgroups update with atomics lives on its own 128-B line, away from the
@@ -89,6 +98,7 @@ __global__ void __launch_bounds__(BT) k_hist_all(const KeyT* __restrict__ in, in
 {
   // block b histograms rows of input range b % NRANGE (range r = rows [r, r+1) * range_rows); k_plan
   // sums the ranges.  The hybrid's first partition pass runs one look-back chain per range.
+  if (plan->hy.ok) return;  // the hybrid path sorted the column: no LSD pass will run
   const int range      = blockIdx.x % NRANGE;
   const int64_t rbegin = (int64_t)range * range_rows < n ? (int64_t)range * range_rows : n;
   const int64_t rend   = (range == NRANGE - 1) ? n : (rbegin + range_rows < n ? rbegin + range_rows : n);
@@ -133,12 +143,165 @@ __global__ void __launch_bounds__(BT) k_hist_all(const KeyT* __restrict__ in, in
   }
 }
 
-// one block of 256 threads
-__global__ void __launch_bounds__(BINS) k_plan(SortPlan* plan, int npass, int64_t n, int try_hybrid, int64_t range_rows,
-                                               int tile_rows, uint32_t* base1, int pairs)
+// ------------------------------------------------------------------------------------------
+// hybrid path, up-front pass: ONE read of the keys (8 B/row) with one LDS atomic per key.
+//   SPEC = true : OR of the sortable keys and OR of their complements (a bit varies over the column iff it is
+//                 set in both) + range-resolved histogram of the TOP byte -- the level-0 digit of any column
+//                 whose top bit varies (full-range integers, mixed-sign doubles);
+//   SPEC = false: range-resolved histogram of the bit-granular level-0 digit k_hy_plan chose; runs only when
+//                 that is not the top byte (hy.need_hist), otherwise exits at once.
+// Block b histograms rows of input range b % NRANGE (range r = rows [r, r+1) * range_rows): the first
+// partition pass runs one look-back chain per range.
+// ------------------------------------------------------------------------------------------
+template <typename KeyT, int KIND, bool SPEC>
+__global__ void __launch_bounds__(BT) k_hy_hist(const KeyT* __restrict__ in, int64_t n, KeyT desc_mask, SortPlan* plan,
+                                                int64_t range_rows)
+{
+  HybridPlan& hy = plan->hy;
+  if (!SPEC && !(hy.attempt && hy.need_hist)) return;
+  const int shift      = SPEC ? (int)(8 * sizeof(KeyT) - 8) : hy.shift0;
+  const int range      = blockIdx.x % NRANGE;
+  const int64_t rbegin = (int64_t)range * range_rows < n ? (int64_t)range * range_rows : n;
+  const int64_t rend   = (range == NRANGE - 1) ? n : (rbegin + range_rows < n ? rbegin + range_rows : n);
+  __shared__ uint32_t s_hist[BINS];
+  __shared__ unsigned long long s_red[2 * NW];
+  for (int i = threadIdx.x; i < BINS; i += BT) s_hist[i] = 0;
+  __syncthreads();
+  const unsigned lane  = lane_id();
+  constexpr int UNROLL = 8;  // independent 8-byte loads in flight per lane
+  const int64_t stride = (int64_t)(gridDim.x / NRANGE) * BT * UNROLL;
+  KeyT vor = 0, vnor = 0;
+  for (int64_t i0 = rbegin + (int64_t)(blockIdx.x / NRANGE) * BT * UNROLL + threadIdx.x; i0 < rend; i0 += stride) {
+    KeyT raw[UNROLL];
+#pragma unroll
+    for (int u = 0; u < UNROLL; ++u) {
+      const int64_t i = i0 + (int64_t)u * BT;
+      raw[u]          = (i < rend) ? in[i] : KeyT(0);
+    }
+#pragma unroll
+    for (int u = 0; u < UNROLL; ++u) {
+      const int64_t i = i0 + (int64_t)u * BT;
+      if (i < rend) {
+        const KeyT k = to_sortable<KeyT, KIND>(raw[u], desc_mask);
+        if (SPEC) {
+          vor |= k;
+          vnor |= (KeyT)~k;
+        }
+        const uint64_t active = ballot(true);
+        const int leader      = __builtin_ctzll(active);
+        const uint32_t d      = (uint32_t)(k >> shift) & 0xFFu;
+        const uint32_t d0     = __builtin_amdgcn_readfirstlane(d);
+        if (ballot(d == d0) == active) {  // whole wave hits one bin: one add instead of 64 conflicts
+          if ((int)lane == leader) atomicAdd(&s_hist[d0], (uint32_t)__builtin_popcountll(active));
+        } else {
+          atomicAdd(&s_hist[d], 1u);
+        }
+      }
+    }
+  }
+  if (SPEC) {
+    const unsigned long long wo = wave_reduce((unsigned long long)vor, [](unsigned long long x, unsigned long long y) { return x | y; });
+    const unsigned long long wn = wave_reduce((unsigned long long)vnor, [](unsigned long long x, unsigned long long y) { return x | y; });
+    if (lane == 0) {
+      s_red[threadIdx.x / GX_WAVE]      = wo;
+      s_red[NW + threadIdx.x / GX_WAVE] = wn;
+    }
+  }
+  __syncthreads();
+  if (SPEC && threadIdx.x == 0) {
+    unsigned long long o = 0, no = 0;
+    for (int k = 0; k < NW; ++k) {
+      o |= s_red[k];
+      no |= s_red[NW + k];
+    }
+    atomicOr(&hy.or_mask, o);
+    atomicOr(&hy.nor_mask, no);
+  }
+  for (int i = threadIdx.x; i < BINS; i += BT) {
+    const uint32_t c = s_hist[i];
+    if (c) atomicAdd(&hy.rh0[range][i], c);
+  }
+}
+
+// One block of 256 threads.  STAGE 0 (after k_hy_hist<SPEC>): digits from the varying-bit mask.  STAGE 1 (after
+// k_hy_hist<!SPEC>): level-0 histogram totals, bin bases per input range, level-0 segment tables.
+__global__ void __launch_bounds__(BINS) k_hy_plan(SortPlan* plan, int stage, int key_bits, int64_t n, int bits2, int cell_max,
+                                                  int pos_bits, int64_t range_rows, int tile_rows, uint32_t* base1)
+{
+  __shared__ uint32_t s_tmp[BINS / GX_WAVE + 1];
+  HybridPlan& hy = plan->hy;
+  const int t    = threadIdx.x;
+  if (stage == 0) {
+    const unsigned long long V = hy.or_mask & hy.nor_mask;  // bits that differ somewhere in the column
+    if (V == 0) {
+      if (t == 0) hy.attempt = 0;
+      return;
+    }
+    const int top    = 63 - __builtin_clzll(V);
+    const int shift0 = top - 7;
+    const int shift2 = shift0 - bits2;
+    // the local sort splits a cell on >= 7 further bits in LDS; packed (key bits, position) words must fit 64 bits
+    const bool ok = shift2 >= 8 && (pos_bits == 0 || shift2 + pos_bits <= 64);
+    const bool spec_ok = shift0 == key_bits - 8;
+    if (!ok) {
+      if (t == 0) hy.attempt = 0;
+      return;
+    }
+    if (!spec_ok) {  // the speculative histogram is of the wrong digit: k_hy_hist<false> refills rh0
+      for (int r = 0; r < NRANGE; ++r) hy.rh0[r][t] = 0;
+    }
+    if (t == 0) {
+      hy.attempt   = 1;
+      hy.shift0    = shift0;
+      hy.bits2     = bits2;
+      hy.shift2    = shift2;
+      hy.cell_max  = cell_max;
+      hy.need_hist = spec_ok ? 0 : 1;
+      int nl       = 0;
+      for (int sft = 0; sft < shift2; sft += 8) {
+        const int bits = shift2 - sft < 8 ? shift2 - sft : 8;
+        if (bits == 8 && ((V >> sft) & 0xFFull) == 0) continue;  // constant byte: nothing to sort on
+        hy.lshift[nl] = sft;
+        hy.lbits[nl]  = bits;
+        ++nl;
+      }
+      hy.nlocal = nl;
+    }
+    return;
+  }
+  if (!hy.attempt) return;
+  uint32_t c = 0;
+  for (int r = 0; r < NRANGE; ++r) c += hy.rh0[r][t];
+  const uint32_t exc = block_exclusive_scan<BINS>(c, 0u, SumOp(), s_tmp, (uint32_t*)nullptr);
+  hy.hist0[t] = c;
+  hy.gbin0[t] = exc;
+  uint32_t run = exc;
+  for (int r = 0; r < NRANGE; ++r) {  // level-0 output base of bin t for every input range
+    base1[r * NB2MAX + t] = run;
+    run += hy.rh0[r][t];
+  }
+  if (t == 0) {
+    uint32_t tiles = 0;
+    for (int r = 0; r < NRANGE; ++r) {
+      const int64_t b = (int64_t)r * range_rows < n ? (int64_t)r * range_rows : n;
+      const int64_t e = (r == NRANGE - 1) ? n : (b + range_rows < n ? b + range_rows : n);
+      hy.seg_start[0][r]  = (uint32_t)b;
+      hy.seg_count[0][r]  = (uint32_t)(e - b);
+      hy.seg_tile0[0][r]  = tiles;
+      hy.list_tile0[0][r] = tiles;
+      tiles += (uint32_t)((e - b + tile_rows - 1) / tile_rows);
+    }
+    hy.seg_tile0[0][NRANGE]  = tiles;
+    hy.list_tile0[0][NRANGE] = tiles;
+  }
+}
+
+// one block of 256 threads: plan of the LSD passes
+__global__ void __launch_bounds__(BINS) k_plan(SortPlan* plan, int npass, int64_t n)
 {
   __shared__ uint32_t s_tmp[BINS / GX_WAVE + 1];
   __shared__ int s_skip[MAX_PASSES];
+  if (plan->hy.ok) return;  // the hybrid path sorted the column (k_plan2 marked every pass as skipped)
   const int t = threadIdx.x;
   for (int p = 0; p < npass; ++p) {
     uint32_t c = 0;
@@ -166,54 +329,6 @@ __global__ void __launch_bounds__(BINS) k_plan(SortPlan* plan, int npass, int64_
       plan->pass_src[p] = (i == 1) ? 0 : prev_dst;
       plan->pass_dst[p] = dst;
       prev_dst          = dst;
-    }
-    // ---- hybrid: digits and level-0 (range) segments
-    HybridPlan& hy = plan->hy;
-    int d1 = -1, nact = 0;
-    for (int p = npass - 1; p >= 0; --p)
-      if (!s_skip[p]) {
-        if (d1 < 0) d1 = p;
-        ++nact;
-      }
-    hy.attempt = (try_hybrid && nact >= 3 && d1 >= 2) ? 1 : 0;
-    if (hy.attempt) {
-      int B = 8;  // total MSD bits: cells of about 12k keys
-      while (B < 16 && ((double)n / (double)(1ull << B)) > 12288.0) ++B;
-      if (B < 9) B = 9;
-      hy.d1     = d1;
-      hy.bits2  = B - 8;
-      hy.shift2 = 8 * d1 - hy.bits2;
-      int nl    = 0;
-      for (int sft = 0; sft < hy.shift2; sft += 8) {
-        const int bits = hy.shift2 - sft < 8 ? hy.shift2 - sft : 8;
-        if (bits == 8 && s_skip[sft / 8]) continue;  // constant byte: nothing to sort on
-        hy.lshift[nl] = sft;
-        hy.lbits[nl]  = bits;
-        ++nl;
-      }
-      hy.nlocal = nl;
-      if (pairs && hy.shift2 + 14 > 64) hy.attempt = 0;  // k_local_sort packs (low key bits, position) into 64 bits
-      uint32_t tiles = 0;
-      for (int r = 0; r < NRANGE; ++r) {
-        const int64_t b = (int64_t)r * range_rows < n ? (int64_t)r * range_rows : n;
-        const int64_t e = (r == NRANGE - 1) ? n : (b + range_rows < n ? b + range_rows : n);
-        hy.seg_start[0][r]  = (uint32_t)b;
-        hy.seg_count[0][r]  = (uint32_t)(e - b);
-        hy.seg_tile0[0][r]  = tiles;
-        hy.list_tile0[0][r] = tiles;
-        tiles += (uint32_t)((e - b + tile_rows - 1) / tile_rows);
-      }
-      hy.seg_tile0[0][NRANGE]  = tiles;
-      hy.list_tile0[0][NRANGE] = tiles;
-    }
-  }
-  __syncthreads();
-  if (plan->hy.attempt) {  // level-0 output base of bin t for every input range
-    const int d1 = plan->hy.d1;
-    uint32_t run = plan->gbin[d1][t];
-    for (int r = 0; r < NRANGE; ++r) {
-      base1[r * BINS + t] = run;
-      run += plan->hy.rhist[r][d1][t];
     }
   }
 }
@@ -548,16 +663,24 @@ struct MsdArgs {
 // (the per-XCD L2s are not coherent; see DESIGN.md "XCD-local write combining").  Correctness
 // needs no placement assumption: within a list tickets are handed out in order, so every
 // predecessor a tile can wait for is already owned by a running workgroup.
-template <typename KeyT, int KIND, bool HAS_VAL, int KPT, int LBW>
+template <typename KeyT, int KIND, bool HAS_VAL, int KPT, int LBW, int NBL>
 __global__ void __launch_bounds__(BT, (KPT <= 8 ? 8 : (KPT <= 12 ? 6 : 4))) k_msd_pass(MsdArgs a)
 {
   constexpr int TILE = BT * KPT;
+  constexpr int NB   = 1 << NBL;  // bins of this pass: 256 (level 0, level 1 up to 8 bits) or 512 (9-bit level 1)
+  static_assert(NB <= BT, "one thread per bin");
+  // Ranking inside the tile.  Integer keys: equal keys are indistinguishable, so the partition need not be
+  // stable -- one returning LDS atomic per key on an NB-entry counter array replaces the ballot match.
+  // Floats keep the stable wave-match ranking (-0.0 == +0.0 must keep input order); pairs too: the row index
+  // breaks ties downstream only if cells keep input order.
+  constexpr bool STABLE = KIND == K_FLOAT || HAS_VAL;
+  constexpr int WROWS   = STABLE ? NW : 2;  // rows of s_whist: per-wave counters, or {counts, bin starts}
   extern __shared__ __attribute__((aligned(16))) char smem[];
   KeyT* s_keys       = reinterpret_cast<KeyT*>(smem);
   uint32_t* s_vals   = reinterpret_cast<uint32_t*>(smem + (size_t)TILE * sizeof(KeyT));  // [TILE] (HAS_VAL)
-  uint32_t* s_whist  = s_vals + (HAS_VAL ? TILE : 0);                                    // [NW][256]
-  uint32_t* s_gdelta = s_whist + NW * BINS;                                              // [256]
-  uint32_t* s_scan   = s_gdelta + BINS;                                                  // [16]
+  uint32_t* s_whist  = s_vals + (HAS_VAL ? TILE : 0);                                    // [NW][NB]
+  uint32_t* s_gdelta = s_whist + WROWS * NB;                                             // [NB]
+  uint32_t* s_scan   = s_gdelta + NB;                                                    // [16]
   uint32_t* s_misc   = s_scan + 16;                                                      // [4]
 
   SortPlan* plan = a.plan;
@@ -569,7 +692,7 @@ __global__ void __launch_bounds__(BT, (KPT <= 8 ? 8 : (KPT <= 12 ? 6 : 4))) k_ms
   const uint32_t* vin  = a.vin;
   uint32_t* vout       = a.vout;
   const KeyT desc_mask = (KeyT)a.desc_mask;
-  const int shift      = lvl == 0 ? 8 * hy.d1 : hy.shift2;
+  const int shift      = lvl == 0 ? hy.shift0 : hy.shift2;
   const uint32_t dmask = lvl == 0 ? 0xFFu : ((1u << hy.bits2) - 1u);
   const int nseg       = lvl == 0 ? NRANGE : BINS;
   const unsigned tid   = threadIdx.x;
@@ -635,40 +758,36 @@ __global__ void __launch_bounds__(BT, (KPT <= 8 ? 8 : (KPT <= 12 ? 6 : 4))) k_ms
       val[j]        = (idx < nvalid) ? (vin ? vin[base + idx] : (uint32_t)(base + idx)) : 0u;
     }
   }
-  // Ranking inside the tile.  Integer keys: equal keys are indistinguishable, so the partition need
-  // not be stable -- one returning LDS atomic per key on a 256-entry counter array replaces the
-  // 8-ballot match.  Floats keep the stable wave-match ranking (-0.0 == +0.0 must keep input order).
-  constexpr bool STABLE = KIND == K_FLOAT || HAS_VAL;  // pairs: the row index breaks ties downstream only if cells keep input order
-  uint32_t* my_hist = s_whist + w * BINS;
+  uint32_t* my_hist = s_whist + w * NB;
   uint32_t packed[KPT];
   uint32_t tile_count = 0;
   if (STABLE) {
 #pragma unroll
-    for (int k = 0; k < BINS / GX_WAVE; ++k) my_hist[lane + k * GX_WAVE] = 0;
+    for (int k = 0; k < NB / GX_WAVE; ++k) my_hist[lane + k * GX_WAVE] = 0;
 #pragma unroll
     for (int j = 0; j < KPT; ++j) {
       const int idx = wbase + j * GX_WAVE;
       uint32_t d    = (uint32_t)(to_sortable<KeyT, KIND>(key[j], desc_mask) >> shift) & dmask;
-      if (idx >= nvalid) d = BINS - 1;  // padding sorts last (it is also last in input order)
+      if (idx >= nvalid) d = NB - 1;  // padding sorts last (it is also last in input order)
       uint32_t lower, cnt;
-      match_rank8(d, true, ~0ull, lower, cnt);
+      match_rank<NBL>(d, true, ~0ull, lower, cnt);
       const uint32_t prev = my_hist[d];
       if (lower == 0) my_hist[d] = prev + cnt;
       packed[j] = (d << 16) | (prev + lower);
     }
     __syncthreads();
-    if (tid < BINS) {
+    if (tid < NB) {
       uint32_t sum = 0;
 #pragma unroll
       for (int w2 = 0; w2 < NW; ++w2) {
-        const uint32_t c         = s_whist[w2 * BINS + tid];
-        s_whist[w2 * BINS + tid] = sum;
+        const uint32_t c       = s_whist[w2 * NB + tid];
+        s_whist[w2 * NB + tid] = sum;
         sum += c;
       }
       tile_count = sum;
     }
   } else {
-    if (tid < BINS) s_whist[tid] = 0;
+    if (tid < NB) s_whist[tid] = 0;
     __syncthreads();
 #pragma unroll
     for (int j = 0; j < KPT; ++j) {
@@ -678,20 +797,20 @@ __global__ void __launch_bounds__(BT, (KPT <= 8 ? 8 : (KPT <= 12 ? 6 : 4))) k_ms
       packed[j]        = (d << 16) | r;
     }
     __syncthreads();
-    if (tid < BINS) tile_count = s_whist[tid];
+    if (tid < NB) tile_count = s_whist[tid];
   }
   uint32_t pub_count = tile_count;
-  if (STABLE && tid == BINS - 1) pub_count -= (uint32_t)(TILE - nvalid);
-  if (tid < BINS) {
-    store_agent_u64(&a.status[(int64_t)gtile * BINS + tid], pack_status(jt == 0 ? 2u : 1u, epoch, pub_count));
+  if (STABLE && tid == NB - 1) pub_count -= (uint32_t)(TILE - nvalid);
+  if (tid < NB) {
+    store_agent_u64(&a.status[(int64_t)gtile * NB + tid], pack_status(jt == 0 ? 2u : 1u, epoch, pub_count));
   }
   const uint32_t bin_start = block_exclusive_scan<BT>(tile_count, 0u, SumOp(), s_scan, (uint32_t*)nullptr);
-  if (tid < BINS) {
+  if (tid < NB) {
     if (STABLE) {
 #pragma unroll
-      for (int w2 = 0; w2 < NW; ++w2) s_whist[w2 * BINS + tid] += bin_start;
+      for (int w2 = 0; w2 < NW; ++w2) s_whist[w2 * NB + tid] += bin_start;
     } else {
-      s_whist[BINS + tid] = bin_start;  // row 1: bin starts (row 0 holds the counts)
+      s_whist[NB + tid] = bin_start;  // row 1: bin starts (row 0 holds the counts)
     }
   }
   __syncthreads();
@@ -704,11 +823,11 @@ __global__ void __launch_bounds__(BT, (KPT <= 8 ? 8 : (KPT <= 12 ? 6 : 4))) k_ms
       s_keys[pos]        = key[j];
       if (HAS_VAL) s_vals[pos] = val[j];
     } else if (wbase + j * GX_WAVE < nvalid) {
-      s_keys[s_whist[BINS + d] + (packed[j] & 0xFFFFu)] = key[j];
+      s_keys[s_whist[NB + d] + (packed[j] & 0xFFFFu)] = key[j];
     }
   }
 
-  if (tid < BINS) {
+  if (tid < NB) {
     uint32_t prefix = 0;
     if (jt > 0) {
       int64_t p = (int64_t)gtile - 1;  // predecessors of the same segment have consecutive tile ids
@@ -718,7 +837,7 @@ __global__ void __launch_bounds__(BT, (KPT <= 8 ? 8 : (KPT <= 12 ? 6 : 4))) k_ms
 #pragma unroll
         for (int k = 0; k < LBW; ++k) {
           const int64_t q = p - k;
-          v[k]            = (q >= 0) ? load_agent_u64(&a.status[q * BINS + tid]) : pack_status(2u, epoch, 0u);
+          v[k]            = (q >= 0) ? load_agent_u64(&a.status[q * NB + tid]) : pack_status(2u, epoch, 0u);
         }
 #pragma unroll
         for (int k = 0; k < LBW; ++k) {
@@ -732,7 +851,7 @@ __global__ void __launch_bounds__(BT, (KPT <= 8 ? 8 : (KPT <= 12 ? 6 : 4))) k_ms
                 break;
               }
               __builtin_amdgcn_s_sleep(2);
-              x = load_agent_u64(&a.status[(p - k) * BINS + tid]);
+              x = load_agent_u64(&a.status[(p - k) * NB + tid]);
             }
             prefix += (uint32_t)x;
             if ((x >> 62) == 2u) done = true;
@@ -740,9 +859,9 @@ __global__ void __launch_bounds__(BT, (KPT <= 8 ? 8 : (KPT <= 12 ? 6 : 4))) k_ms
         }
         p -= LBW;
       }
-      store_agent_u64(&a.status[(int64_t)gtile * BINS + tid], pack_status(2u, epoch, prefix + pub_count));
+      store_agent_u64(&a.status[(int64_t)gtile * NB + tid], pack_status(2u, epoch, prefix + pub_count));
     }
-    s_gdelta[tid] = a.base[seg * BINS + tid] + prefix - bin_start;
+    s_gdelta[tid] = a.base[seg * NB2MAX + tid] + prefix - bin_start;
   }
   __syncthreads();
 
@@ -759,10 +878,10 @@ __global__ void __launch_bounds__(BT, (KPT <= 8 ? 8 : (KPT <= 12 ? 6 : 4))) k_ms
   }
 }
 
-// Joint histogram hist2[d1 digit][level-1 digit] over the level-0 output, which is sorted by the
-// d1 digit: a 4096-key tile almost always holds ONE d1 value, so the workgroup keeps a 256-bin LDS
-// histogram for the current bucket and flushes it when the bucket changes; the <= 255 tiles that
-// straddle a bucket boundary use global atomics per key.
+// Joint histogram hist2[level-0 digit][level-1 digit] over the level-0 output, which is sorted by the
+// level-0 digit: a 4096-key tile almost always holds ONE bucket, so the workgroup keeps an LDS histogram for
+// the current bucket and flushes it when the bucket changes; the <= 255 tiles that straddle a bucket
+// boundary use global atomics per key.
 constexpr int H2_BT = 256, H2_KPT = 16, H2_TILE = H2_BT * H2_KPT;
 template <typename KeyT, int KIND>
 __global__ void __launch_bounds__(H2_BT) k_hist2(const KeyT* __restrict__ in, int64_t n, KeyT desc_mask, SortPlan* plan,
@@ -770,16 +889,23 @@ __global__ void __launch_bounds__(H2_BT) k_hist2(const KeyT* __restrict__ in, in
 {
   HybridPlan& hy = plan->hy;
   if (!hy.attempt) return;
-  __shared__ uint32_t s_h[BINS];
-  const int shift1     = 8 * hy.d1;
+  __shared__ uint32_t s_h[NB2MAX];
+  const int shift1     = hy.shift0;
   const int shift2     = hy.shift2;
   const uint32_t mask2 = (1u << hy.bits2) - 1u;
   const int64_t ntile  = div_up(n, H2_TILE);
   const int64_t per    = div_up(ntile, gridDim.x);
   const int64_t t0     = (int64_t)blockIdx.x * per;
   const int64_t t1     = t0 + per < ntile ? t0 + per : ntile;
-  s_h[threadIdx.x]     = 0;
-  int cur              = -1;
+  auto flush = [&](int cur) {
+    for (int i = threadIdx.x; i < NB2MAX; i += H2_BT) {
+      const uint32_t c = s_h[i];
+      if (c && cur >= 0) atomicAdd(&hist2[cur * NB2MAX + i], c);
+      s_h[i] = 0;
+    }
+  };
+  int cur = -1;
+  flush(-1);
   __syncthreads();
   for (int64_t t = t0; t < t1; ++t) {
     const int64_t base = t * H2_TILE;
@@ -795,12 +921,8 @@ __global__ void __launch_bounds__(H2_BT) k_hist2(const KeyT* __restrict__ in, in
     if (afirst == alast) {  // uniform branch
       if (afirst != cur) {
         __syncthreads();
-        if (cur >= 0) {
-          const uint32_t c = s_h[threadIdx.x];
-          if (c) atomicAdd(&hist2[cur * BINS + threadIdx.x], c);
-        }
-        s_h[threadIdx.x] = 0;
-        cur              = afirst;
+        flush(cur);
+        cur = afirst;
         __syncthreads();
       }
 #pragma unroll
@@ -814,16 +936,13 @@ __global__ void __launch_bounds__(H2_BT) k_hist2(const KeyT* __restrict__ in, in
         const int64_t i = base + j * H2_BT + threadIdx.x;
         if (i < n) {
           const KeyT sk = to_sortable<KeyT, KIND>(k[j], desc_mask);
-          atomicAdd(&hist2[((uint32_t)(sk >> shift1) & 0xFFu) * BINS + ((uint32_t)(sk >> shift2) & mask2)], 1u);
+          atomicAdd(&hist2[((uint32_t)(sk >> shift1) & 0xFFu) * NB2MAX + ((uint32_t)(sk >> shift2) & mask2)], 1u);
         }
       }
     }
   }
   __syncthreads();
-  if (cur >= 0) {
-    const uint32_t c = s_h[threadIdx.x];
-    if (c) atomicAdd(&hist2[cur * BINS + threadIdx.x], c);
-  }
+  flush(cur);
 }
 
 // one block of 256 threads: thread b owns level-0 bucket b
@@ -834,14 +953,13 @@ __global__ void __launch_bounds__(BINS) k_plan2(SortPlan* plan, const uint32_t* 
   if (!hy.attempt) return;
   __shared__ uint32_t s_tmp[BINS / GX_WAVE + 1];
   const int b          = threadIdx.x;
-  const int d1         = hy.d1;
-  const uint32_t start = plan->gbin[d1][b];
-  const uint32_t count = plan->hist[d1][b];
+  const uint32_t start = hy.gbin0[b];
+  const uint32_t count = hy.hist0[b];
   const int nb2        = 1 << hy.bits2;
   uint32_t run = start, mx = 0;
   for (int d2 = 0; d2 < nb2; ++d2) {
-    const uint32_t c     = hist2[b * BINS + d2];
-    base2[b * BINS + d2] = run;
+    const uint32_t c       = hist2[b * NB2MAX + d2];
+    base2[b * NB2MAX + d2] = run;
     run += c;
     mx = c > mx ? c : mx;
   }
@@ -864,7 +982,7 @@ __global__ void __launch_bounds__(BINS) k_plan2(SortPlan* plan, const uint32_t* 
     hy.list_tile0[1][NRANGE] = total;
     hy.max_cell              = maxcell;
     if (bad) atomicExch(&plan->status, 3);
-    const int ok = (!bad && maxcell <= (uint32_t)LOCAL_MAX) ? 1 : 0;
+    const int ok = (!bad && maxcell <= (uint32_t)hy.cell_max) ? 1 : 0;
     hy.ok        = ok;
     if (ok) {  // the LSD passes and the copy-only finalizer become no-ops
       for (int p = 0; p < npass; ++p) plan->pass_skip[p] = 1;
@@ -873,7 +991,7 @@ __global__ void __launch_bounds__(BINS) k_plan2(SortPlan* plan, const uint32_t* 
   }
 }
 
-// Sort one cell (<= LOCAL_MAX keys sharing all bits above shift2) on its remaining bits inside LDS:
+// Sort one cell (<= 1 << CL2 keys sharing all bits above shift2) on its remaining bits inside LDS:
 // nlocal stable 8-bit counting passes, keys resident in registers between the LDS exchanges, one
 // HBM read and one HBM write of the cell in total.
 // PAIRS (sorted_order: key + row index, index payload = iota at level 0): the cell's keys share all
@@ -881,17 +999,18 @@ __global__ void __launch_bounds__(BINS) k_plan2(SortPlan* plan, const uint32_t* 
 // (low shift2 bits of the sortable key) << 14 | (position in the cell) is a distinct 64-bit key whose
 // order is the stable order of the pairs.  Only these words go through LDS; the sorted positions
 // then gather the original key and index of the cell (L2-resident: the cell was just read).
-constexpr int LS_POS_BITS = 14;  // LOCAL_MAX == 1 << 14
+// (the position field of a packed word has CL2 bits: cells hold at most 1 << CL2 keys)
 
 // PAIRS write-out: the sorted words hold the position of each row inside the cell in their low 14
 // bits.  Integer keys are rebuilt from the word (cell prefix | low bits, the transform is an
 // involution); float keys (-0.0 / NaN payloads are not recoverable) and the row indices are staged
 // through the now free LDS buffer so that every HBM access stays coalesced.
-template <typename KeyT, int KIND, bool HAS_VAL>
+template <typename KeyT, int KIND, bool HAS_VAL, int CL2>
 __device__ __forceinline__ void pairs_write_out(KeyT* s_keys, const KeyT* __restrict__ in, KeyT* __restrict__ out,
                                                 const uint32_t* __restrict__ vin, uint32_t* __restrict__ vout,
                                                 int64_t start, uint32_t m, int shift2, KeyT desc_mask)
 {
+  constexpr int LS_KPT = 16, LS_BT = (1 << CL2) / LS_KPT, LS_POS_BITS = CL2;
   const unsigned tid = threadIdx.x;
   const KeyT lowmask = (KeyT(1) << shift2) - KeyT(1);
   const KeyT hi      = to_sortable<KeyT, KIND>(in[start], desc_mask) & ~lowmask;  // shared by the whole cell
@@ -936,8 +1055,8 @@ __device__ __forceinline__ void pairs_write_out(KeyT* s_keys, const KeyT* __rest
   }
 }
 
-template <typename KeyT, int KIND, bool HAS_VAL>
-__global__ void __launch_bounds__(LS_BT) k_local_sort(const KeyT* __restrict__ in, KeyT* __restrict__ out,
+template <typename KeyT, int KIND, bool HAS_VAL, int CL2>
+__global__ void __launch_bounds__((1 << CL2) / 16, 4) k_local_sort(const KeyT* __restrict__ in, KeyT* __restrict__ out,
                                                       const uint32_t* __restrict__ vin, uint32_t* __restrict__ vout,
                                                       KeyT desc_mask_in, SortPlan* plan,
                                                       const uint32_t* __restrict__ hist2, const uint32_t* __restrict__ base2,
@@ -947,10 +1066,12 @@ __global__ void __launch_bounds__(LS_BT) k_local_sort(const KeyT* __restrict__ i
   // and whose original bits cannot be rebuilt from the sortable form)
   // (floats whose remaining bits do not leave room for the position keep plain keys and take the
   // stable passes; k_plan never attempts the hybrid path for pairs in that case)
+  constexpr int LOCAL_MAX = 1 << CL2, LS_KPT = 16, LS_BT = LOCAL_MAX / LS_KPT, LS_NW = LS_BT / GX_WAVE, LS_POS_BITS = CL2;
+  constexpr int SB = CL2 - 6, NSB = 1 << SB;  // LDS split into NSB sub-buckets of ~64 keys
   constexpr bool CAN_PACK = HAS_VAL || KIND == K_FLOAT;
   HybridPlan& hy = plan->hy;
   if (!hy.attempt || !hy.ok) return;
-  const bool PAIRS     = CAN_PACK && (hy.shift2 + LS_POS_BITS <= 64);
+  const bool PAIRS     = CAN_PACK && (hy.shift2 + LS_POS_BITS <= 64);  // k_hy_plan never attempts pairs otherwise
   const KeyT desc_mask = desc_mask_in;
   const int pos_shift  = PAIRS ? LS_POS_BITS : 0;
   // sortable form of a register word: packed words already are, plain keys go through the transform
@@ -963,9 +1084,9 @@ __global__ void __launch_bounds__(LS_BT) k_local_sort(const KeyT* __restrict__ i
   if (blockIdx.x >= ((unsigned)BINS << bits2)) return;
   const uint32_t b  = blockIdx.x >> bits2;
   const uint32_t d2 = blockIdx.x & ((1u << bits2) - 1u);
-  const uint32_t m  = hist2[b * BINS + d2];
+  const uint32_t m  = hist2[b * NB2MAX + d2];
   if (m == 0) return;
-  const int64_t start = base2[b * BINS + d2];
+  const int64_t start = base2[b * NB2MAX + d2];
   const unsigned tid  = threadIdx.x;
   const unsigned lane = lane_id();
   const unsigned w    = tid / GX_WAVE;
@@ -989,10 +1110,10 @@ __global__ void __launch_bounds__(LS_BT) k_local_sort(const KeyT* __restrict__ i
   // stability is not needed; floats (-0.0 == +0.0 must keep input order) and cells with a
   // sub-bucket above 128 keys take the stable LSD passes below.
   if ((PAIRS || KIND != K_FLOAT) && nlocal > 0) {
-    uint32_t* s_cnt   = s_scan + 32;          // [256] sub-bucket counts (own area: the wave rows of s_whist serve wave_split_sort)
-    uint32_t* s_start = s_scan + 32 + BINS;   // [256] exclusive starts
-    const int sshift  = hy.shift2 - 8 + pos_shift;  // shift2 >= 8: d1 >= 2 and bits2 <= 8
-    if (tid < BINS) s_cnt[tid] = 0;
+    uint32_t* s_cnt   = s_scan + 32;          // [NSB] sub-bucket counts (own area: the wave rows of s_whist serve wave_split_sort)
+    uint32_t* s_start = s_scan + 32 + BINS;   // [NSB] exclusive starts
+    const int sshift  = hy.shift2 - SB + pos_shift;  // shift2 >= 8 (k_hy_plan)
+    if (tid < NSB) s_cnt[tid] = 0;
     __syncthreads();
     uint32_t rank[LS_KPT];
 #pragma unroll
@@ -1000,22 +1121,22 @@ __global__ void __launch_bounds__(LS_BT) k_local_sort(const KeyT* __restrict__ i
       const int idx = wbase + j * GX_WAVE;
       key[j]        = sortable(key[j]);  // an involution for integer kinds
       rank[j]       = (exp & 8) ? (uint32_t)(idx >> 8)  // ablation 8: no atomics
-                                : lds_rank(s_cnt, (uint32_t)(key[j] >> sshift) & 0xFFu, (uint32_t)idx < m);
+                                : lds_rank(s_cnt, (uint32_t)(key[j] >> sshift) & (uint32_t)(NSB - 1), (uint32_t)idx < m);
     }
     __syncthreads();
-    const uint32_t c   = tid < BINS ? s_cnt[tid] : 0u;
+    const uint32_t c   = tid < NSB ? s_cnt[tid] : 0u;
     const int too_big  = __syncthreads_or(c > 128u);
     if (!too_big) {
       const uint32_t st = block_exclusive_scan<LS_BT>(c, 0u, SumOp(), s_scan, (uint32_t*)nullptr);
-      if (tid < BINS) s_start[tid] = st;
+      if (tid < NSB) s_start[tid] = st;
       __syncthreads();
 #pragma unroll
       for (int j = 0; j < LS_KPT; ++j) {
         const int idx = wbase + j * GX_WAVE;
-        if ((uint32_t)idx < m) s_keys[s_start[(uint32_t)(key[j] >> sshift) & 0xFFu] + rank[j]] = key[j];
+        if ((uint32_t)idx < m) s_keys[s_start[(uint32_t)(key[j] >> sshift) & (uint32_t)(NSB - 1)] + rank[j]] = key[j];
       }
       __syncthreads();
-      for (int sb = (int)w; sb < BINS; sb += LS_NW) {
+      for (int sb = (int)w; sb < NSB; sb += LS_NW) {
         if (exp & 4) break;  // ablation: no sorting networks
         const uint32_t cnt = s_cnt[sb], o = s_start[sb];
         if (cnt <= 1) continue;
@@ -1057,13 +1178,13 @@ __global__ void __launch_bounds__(LS_BT) k_local_sort(const KeyT* __restrict__ i
       if (!PAIRS) {
         // sub-buckets of 0 or 1 keys were skipped by the loop above: they leave here
         if (!(exp & 4)) {
-          if (tid < BINS && s_cnt[tid] == 1) out[start + s_start[tid]] = to_sortable<KeyT, KIND>(s_keys[s_start[tid]], desc_mask);
+          if (tid < NSB && s_cnt[tid] == 1) out[start + s_start[tid]] = to_sortable<KeyT, KIND>(s_keys[s_start[tid]], desc_mask);
           return;
         }
       }
       __syncthreads();
       if (PAIRS) {
-        pairs_write_out<KeyT, KIND, HAS_VAL>(s_keys, in, out, vin, vout, start, m, hy.shift2, desc_mask_in);
+        pairs_write_out<KeyT, KIND, HAS_VAL, CL2>(s_keys, in, out, vin, vout, start, m, hy.shift2, desc_mask_in);
         return;
       }
 #pragma unroll
@@ -1149,7 +1270,7 @@ __global__ void __launch_bounds__(LS_BT) k_local_sort(const KeyT* __restrict__ i
     return;
   }
   if (PAIRS) {
-    pairs_write_out<KeyT, KIND, HAS_VAL>(s_keys, in, out, vin, vout, start, m, hy.shift2, desc_mask_in);
+    pairs_write_out<KeyT, KIND, HAS_VAL, CL2>(s_keys, in, out, vin, vout, start, m, hy.shift2, desc_mask_in);
     return;
   }
 #pragma unroll
@@ -1196,6 +1317,34 @@ constexpr size_t pass_lds_bytes()
          (size_t)(NW * BINS + BINS + 16 + 4) * 4;
 }
 
+// hybrid configuration: a pure function of (n, key kind, payload, knobs), so the scratch query and the run agree
+struct HybridCfg {
+  bool on;
+  int cl2;    // log2 of the local-sort cell capacity (13 or 14)
+  int bits2;  // level-1 bits (1..9)
+  int kpt;    // keys per thread of the partition passes
+};
+static int g_cell = 0;  // A/B knob: 0 = auto, 8192 / 16384 = force the local-sort cell capacity
+template <typename KeyT, int KIND, bool HAS_VAL>
+static HybridCfg hybrid_cfg(int64_t n, bool iota_payload, int algo)
+{
+  HybridCfg c{false, 14, 8, HAS_VAL ? 10 : g_msd_kpt};
+  if (sizeof(KeyT) != 8 || (HAS_VAL && !iota_payload) || algo != 0 || !g_hybrid || n < (1ll << 22)) return c;
+  // 8192-key cells (two local-sort workgroups per CU) for integer keys-only sorts while 2^17 cells suffice;
+  // floats and pairs sort packed (key bits, position) words through 16384-key cells as in round 1
+  const bool small_ok = !HAS_VAL && KIND != K_FLOAT;
+  c.cl2 = (small_ok && g_cell != 16384 && (double)n / (double)(1 << 17) <= 0.955 * 8192.0) ? 13 : 14;
+  if (g_cell == 8192 && small_ok) c.cl2 = 13;
+  const double cell = (double)(1 << c.cl2);
+  const int maxb2   = (small_ok && c.cl2 == 13) ? 9 : 8;
+  int B = 9;
+  while (B < 8 + maxb2 && (double)n / (double)(1ull << B) > 0.955 * cell) ++B;
+  if ((double)n / (double)(1ull << B) > 0.97 * cell) return c;  // cells would overflow: LSD passes
+  c.bits2 = B - 8;
+  c.on    = true;
+  return c;
+}
+
 template <typename KeyT, int KIND, bool HAS_VAL>
 int sort_impl(const void* keys_in, void* keys_out, const int32_t* vals_in, int32_t* vals_out, int64_t n,
               int descending, bool radix_nan_rule, void* tmp, size_t* tmp_bytes, hipStream_t stream)
@@ -1215,16 +1364,19 @@ int sort_impl(const void* keys_in, void* keys_out, const int32_t* vals_in, int32
   uint32_t* partials         = nullptr;
   // hybrid MSD path: 64-bit keys; pairs only with the iota payload (sorted_order), whose value is the
   // tie-break the packed local sort relies on
-  const bool try_hybrid = sizeof(KeyT) == 8 && (!HAS_VAL || vals_in == nullptr) && algo == 0 && g_hybrid && n >= (1ll << 22);
-  const int hyb_kpt     = HAS_VAL ? 10 : g_msd_kpt;
-  uint32_t* base1 = c.take<uint32_t>((size_t)NRANGE * BINS);
-  uint32_t* hist2 = try_hybrid ? c.take<uint32_t>((size_t)2 * BINS * BINS) : nullptr;  // hist2 | base2
-  uint32_t* base2 = try_hybrid ? hist2 + BINS * BINS : nullptr;
+  const HybridCfg hc    = hybrid_cfg<KeyT, KIND, HAS_VAL>(n, vals_in == nullptr, algo);
+  const bool try_hybrid = hc.on;
+  const int hyb_kpt     = hc.kpt;
+  const int nb1         = hc.bits2 > 8 ? NB2MAX : BINS;  // bins (and look-back granules per tile) of the level-1 pass
+  uint32_t* base1 = c.take<uint32_t>((size_t)NRANGE * NB2MAX);
+  uint32_t* hist2 = try_hybrid ? c.take<uint32_t>((size_t)2 * BINS * NB2MAX) : nullptr;  // hist2 | base2
+  uint32_t* base2 = try_hybrid ? hist2 + BINS * NB2MAX : nullptr;
   const int64_t msd_tile     = (int64_t)BT * hyb_kpt;  // tile of the hybrid partition passes
   const int64_t msd_ntiles   = n > 0 ? div_up(n, msd_tile) : 0;
   const int64_t status_tiles = (msd_ntiles > ntiles ? msd_ntiles : ntiles) + BINS + 2 * NRANGE;  // segment tails add at most one tile each
+  const size_t status_words  = (size_t)status_tiles * (try_hybrid ? nb1 : BINS);
   if (algo != 1) {
-    status = c.take<unsigned long long>((size_t)status_tiles * BINS);
+    status = c.take<unsigned long long>(status_words);
   } else {
     tile_hist = c.take<uint32_t>((size_t)ntiles * BINS);
     partials  = c.take<uint32_t>(scan::partials_count(ntiles * BINS));
@@ -1242,44 +1394,68 @@ int sort_impl(const void* keys_in, void* keys_out, const int32_t* vals_in, int32
 
   GX_HIP_TRY(hipMemsetAsync(plan, 0, sizeof(SortPlan), stream));
   if (n == 0) return 0;
-  if (algo != 1) GX_HIP_TRY(hipMemsetAsync(status, 0, (size_t)status_tiles * BINS * sizeof(unsigned long long), stream));
-  if (try_hybrid) GX_HIP_TRY(hipMemsetAsync(hist2, 0, (size_t)2 * BINS * BINS * sizeof(uint32_t), stream));
+  if (algo != 1) GX_HIP_TRY(hipMemsetAsync(status, 0, status_words * sizeof(unsigned long long), stream));
+  if (try_hybrid) GX_HIP_TRY(hipMemsetAsync(hist2, 0, (size_t)2 * BINS * NB2MAX * sizeof(uint32_t), stream));
   const int64_t range_rows = try_hybrid ? div_up(msd_ntiles, NRANGE) * msd_tile : div_up(ntiles, NRANGE) * TILE;
 
   const KeyT desc_mask = descending ? KeyT(~KeyT(0)) : KeyT(0);
   g_prof.npass = NPASS;
+  int64_t hblocks = div_up(n, (int64_t)BT * 8);
+  if (hblocks > 2048) hblocks = 2048;
+  hblocks = div_up(hblocks, NRANGE) * NRANGE;  // block b serves input range b % NRANGE
   prof_mark(0, stream);
-  {
-    int64_t blocks = div_up(n, (int64_t)BT * 8);
-    if (blocks > 2048) blocks = 2048;
-    blocks = div_up(blocks, NRANGE) * NRANGE;  // block b serves input range b % NRANGE
-    hipLaunchKernelGGL((k_hist_all<KeyT, KIND>), dim3((unsigned)blocks), dim3(BT), 0, stream,
-                       static_cast<const KeyT*>(keys_in), n, desc_mask, plan, range_rows);
-    hipLaunchKernelGGL(k_plan, dim3(1), dim3(BINS), 0, stream, plan, NPASS, n, try_hybrid ? 1 : 0, range_rows,
-                       try_hybrid ? (int)msd_tile : TILE, base1, HAS_VAL ? 1 : 0);
-  }
-  prof_mark(1, stream);
   g_prof.hybrid_marked = false;
   if constexpr (sizeof(KeyT) == 8) {
     if (try_hybrid) {
       // hybrid MSD path: every kernel below is a no-op unless the device-side plan enables it
-      constexpr size_t lds_l = (size_t)LOCAL_MAX * sizeof(KeyT) + (size_t)(LS_NW * BINS + 32 + 2 * BINS) * 4;
       constexpr size_t pay   = HAS_VAL ? 4 : 0;
-      const size_t lds_m     = (size_t)BT * hyb_kpt * (sizeof(KeyT) + pay) + (size_t)(NW * BINS + BINS + 16 + 4) * 4;
-      auto kmsd = HAS_VAL ? k_msd_pass<KeyT, KIND, HAS_VAL, 10, 4>
-                          : (hyb_kpt == 8 ? k_msd_pass<KeyT, KIND, HAS_VAL, 8, 4>
-                                          : (hyb_kpt == 12 ? k_msd_pass<KeyT, KIND, HAS_VAL, 12, 4> : k_msd_pass<KeyT, KIND, HAS_VAL, 16, 4>));
-      auto kloc             = k_local_sort<KeyT, KIND, HAS_VAL>;
+      constexpr bool STABLE  = KIND == K_FLOAT || HAS_VAL;
+      constexpr bool SMALLOK = !HAS_VAL && KIND != K_FLOAT;  // 8192-key cells and the 9-bit level 1 exist for these
+      auto lds_msd = [&](int kpt, int nb) { return (size_t)BT * kpt * (sizeof(KeyT) + pay) + (size_t)((STABLE ? NW : 2) * nb + nb + 16 + 4) * 4; };
+      auto lds_loc = [&](int cl2) { return ((size_t)sizeof(KeyT) << cl2) + (size_t)(((1 << cl2) / 16 / GX_WAVE) * BINS + 32 + 2 * BINS) * 4; };
+      typedef void (*MsdK)(MsdArgs);
+      MsdK kmsd0 = HAS_VAL ? (MsdK)k_msd_pass<KeyT, KIND, HAS_VAL, 10, 4, 8>
+                           : (hyb_kpt == 8 ? (MsdK)k_msd_pass<KeyT, KIND, HAS_VAL, 8, 4, 8>
+                                           : (hyb_kpt == 12 ? (MsdK)k_msd_pass<KeyT, KIND, HAS_VAL, 12, 4, 8> : (MsdK)k_msd_pass<KeyT, KIND, HAS_VAL, 16, 4, 8>));
+      MsdK kmsd1 = kmsd0;
+      auto kloc  = k_local_sort<KeyT, KIND, HAS_VAL, 14>;
+      int ls_bt  = (1 << 14) / 16;
       static bool hattr_set = false;
       if (!hattr_set) {
-        constexpr size_t lds_mmax = (size_t)BT * 16 * (sizeof(KeyT) + pay) + (size_t)(NW * BINS + BINS + 16 + 4) * 4;
-        GX_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(k_msd_pass<KeyT, KIND, HAS_VAL, 8, 4>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_mmax));
-        GX_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(k_msd_pass<KeyT, KIND, HAS_VAL, 10, 4>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_mmax));
-        GX_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(k_msd_pass<KeyT, KIND, HAS_VAL, 12, 4>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_mmax));
-        GX_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(k_msd_pass<KeyT, KIND, HAS_VAL, 16, 4>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_mmax));
-        GX_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(kloc), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_l));
+        const int lds_mmax = (int)lds_msd(16, BINS);
+        GX_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(k_msd_pass<KeyT, KIND, HAS_VAL, 8, 4, 8>), hipFuncAttributeMaxDynamicSharedMemorySize, lds_mmax));
+        GX_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(k_msd_pass<KeyT, KIND, HAS_VAL, 10, 4, 8>), hipFuncAttributeMaxDynamicSharedMemorySize, lds_mmax));
+        GX_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(k_msd_pass<KeyT, KIND, HAS_VAL, 12, 4, 8>), hipFuncAttributeMaxDynamicSharedMemorySize, lds_mmax));
+        GX_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(k_msd_pass<KeyT, KIND, HAS_VAL, 16, 4, 8>), hipFuncAttributeMaxDynamicSharedMemorySize, lds_mmax));
+        GX_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(kloc), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_loc(14)));
+        if constexpr (SMALLOK) {
+          GX_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(k_msd_pass<KeyT, KIND, HAS_VAL, 16, 4, 9>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_msd(16, NB2MAX)));
+          GX_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(k_local_sort<KeyT, KIND, HAS_VAL, 13>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_loc(13)));
+        }
         hattr_set = true;
       }
+      int kpt1 = hyb_kpt;
+      if constexpr (SMALLOK) {
+        if (hc.bits2 > 8) {
+          kmsd1 = (MsdK)k_msd_pass<KeyT, KIND, HAS_VAL, 16, 4, 9>;
+          kpt1  = 16;
+        }
+        if (hc.cl2 == 13) {
+          kloc  = k_local_sort<KeyT, KIND, HAS_VAL, 13>;
+          ls_bt = (1 << 13) / 16;
+        }
+      }
+      if (kpt1 != hyb_kpt) return GX_EINTERNAL;  // the 9-bit pass exists for 16 keys per thread only (g_msd_kpt knob)
+      // ---- up-front: varying bits + level-0 histogram (one read of the keys), plan
+      hipLaunchKernelGGL((k_hy_hist<KeyT, KIND, true>), dim3((unsigned)hblocks), dim3(BT), 0, stream,
+                         static_cast<const KeyT*>(keys_in), n, desc_mask, plan, range_rows);
+      hipLaunchKernelGGL(k_hy_plan, dim3(1), dim3(BINS), 0, stream, plan, 0, (int)(8 * sizeof(KeyT)), n, hc.bits2, 1 << hc.cl2,
+                         (HAS_VAL || KIND == K_FLOAT) ? hc.cl2 : 0, range_rows, (int)msd_tile, base1);
+      hipLaunchKernelGGL((k_hy_hist<KeyT, KIND, false>), dim3((unsigned)hblocks), dim3(BT), 0, stream,
+                         static_cast<const KeyT*>(keys_in), n, desc_mask, plan, range_rows);
+      hipLaunchKernelGGL(k_hy_plan, dim3(1), dim3(BINS), 0, stream, plan, 1, (int)(8 * sizeof(KeyT)), n, hc.bits2, 1 << hc.cl2,
+                         (HAS_VAL || KIND == K_FLOAT) ? hc.cl2 : 0, range_rows, (int)msd_tile, base1);
+      prof_mark(1, stream);
       KeyT* bufA = keys_out ? static_cast<KeyT*>(keys_out) : ka_scratch;
       KeyT* bufB = kb_scratch;
       uint32_t* valA = reinterpret_cast<uint32_t*>(vals_out);
@@ -1297,7 +1473,7 @@ int sort_impl(const void* keys_in, void* keys_out, const int32_t* vals_in, int32
       m.level     = 0;
       m.exp       = getenv("GX_EXP") ? atoi(getenv("GX_EXP")) : 0;
       prof_mark_h(0, stream);
-      hipLaunchKernelGGL(kmsd, dim3((unsigned)(msd_ntiles + NRANGE)), dim3(BT), lds_m, stream, m);
+      hipLaunchKernelGGL(kmsd0, dim3((unsigned)(msd_ntiles + NRANGE)), dim3(BT), lds_msd(hyb_kpt, BINS), stream, m);
       prof_mark_h(1, stream);
       hipLaunchKernelGGL((k_hist2<KeyT, KIND>), dim3(2048), dim3(H2_BT), 0, stream, bufA, n, desc_mask, plan, hist2);
       hipLaunchKernelGGL(k_plan2, dim3(1), dim3(BINS), 0, stream, plan, hist2, base2, (int)msd_tile, NPASS);
@@ -1308,14 +1484,19 @@ int sort_impl(const void* keys_in, void* keys_out, const int32_t* vals_in, int32
       m.vout  = valB;
       m.base  = base2;
       m.level = 1;
-      hipLaunchKernelGGL(kmsd, dim3((unsigned)(msd_ntiles + BINS + NRANGE)), dim3(BT), lds_m, stream, m);
+      hipLaunchKernelGGL(kmsd1, dim3((unsigned)(msd_ntiles + BINS + NRANGE)), dim3(BT), lds_msd(hyb_kpt, nb1), stream, m);
       prof_mark_h(3, stream);
-      hipLaunchKernelGGL(kloc, dim3((unsigned)(BINS * BINS)), dim3(LS_BT), lds_l, stream, bufB, bufA, valB, valA, desc_mask,
+      hipLaunchKernelGGL(kloc, dim3((unsigned)(BINS << hc.bits2)), dim3(ls_bt), lds_loc(hc.cl2), stream, bufB, bufA, valB, valA, desc_mask,
                          plan, hist2, base2, m.exp);
       prof_mark_h(4, stream);
       g_prof.hybrid_marked = g_prof.enabled;
     }
   }
+  // LSD path: byte histograms + plan (no-ops when the hybrid path has sorted the column)
+  hipLaunchKernelGGL((k_hist_all<KeyT, KIND>), dim3((unsigned)hblocks), dim3(BT), 0, stream,
+                     static_cast<const KeyT*>(keys_in), n, desc_mask, plan, range_rows);
+  hipLaunchKernelGGL(k_plan, dim3(1), dim3(BINS), 0, stream, plan, NPASS, n);
+  if (!try_hybrid) prof_mark(1, stream);
 
   PassArgs a;
   a.kbuf[0]   = const_cast<void*>(keys_in);
@@ -1539,11 +1720,13 @@ int gx_sort_profile_read_hybrid(float* ms4)
 
 void gx_sort_set_hybrid(int enable) { gx::sort::g_hybrid = enable ? 1 : 0; }
 
+void gx_sort_set_cell(int keys) { gx::sort::g_cell = (keys == 8192 || keys == 16384) ? keys : 0; }
+
 int gx_sort_info(const void* tmp, int32_t* info8_host, gx_stream_t stream)
 {
   if (!tmp || !info8_host) return GX_EINVAL;
   const auto* plan = static_cast<const gx::sort::SortPlan*>(tmp);
-  // attempt, ok, d1, shift2, bits2, nlocal are the first six int32 of HybridPlan
+  // attempt, ok, shift0, shift2, bits2, nlocal are the first six int32 of HybridPlan
   GX_HIP_TRY(hipMemcpyAsync(info8_host, &plan->hy, 6 * sizeof(int32_t), hipMemcpyDeviceToHost, stream));
   GX_HIP_TRY(hipMemcpyAsync(info8_host + 6, &plan->hy.max_cell, sizeof(int32_t), hipMemcpyDeviceToHost, stream));
   GX_HIP_TRY(hipMemcpyAsync(info8_host + 7, &plan->num_active, sizeof(int32_t), hipMemcpyDeviceToHost, stream));

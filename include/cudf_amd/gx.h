@@ -125,11 +125,16 @@ int gx_sort_profile_read(float* hist_ms, float* pass_ms, int* npass);
  * GX_EINVAL when the last sort did not enqueue the hybrid path. */
 int gx_sort_profile_read_hybrid(float* ms4);
 
-/* Hybrid MSD path (64-bit keys, keys only, n >= 2^22): two stable 8-bit-class partition passes,
- * then one kernel that sorts every cell of <= 16384 keys on its remaining bits inside LDS
- * (64 B/row of HBM traffic instead of 136).  Enabled by default; the device falls back to the LSD
- * passes by itself when a cell does not fit (skewed keys).  0 disables it (A/B measurements). */
+/* Hybrid MSD path (64-bit keys, n >= 2^22): an up-front pass finds the varying bits and histograms the
+ * level-0 digit (the 8 bits below the highest varying bit), two partition passes (8 + up to 9 bits), then one
+ * kernel that sorts every cell of <= 8192 / 16384 keys on its remaining bits inside LDS (64 B/row of HBM
+ * traffic instead of 136).  Enabled by default; the device falls back to the LSD passes by itself when a cell
+ * does not fit (skewed keys).  0 disables it (A/B measurements). */
 void gx_sort_set_hybrid(int enable);
+/* A/B knob (process-wide): capacity of a local-sort cell of the hybrid path.  0 = auto (8192-key cells, two
+ * workgroups per CU and a 9-bit second partition level, for integer keys-only sorts of up to ~1.02e9 rows;
+ * 16384-key cells otherwise), 8192 / 16384 = force where the key kind allows it. */
+void gx_sort_set_cell(int keys);
 /* info8_host (host, 8 x int32) = {hybrid attempted, hybrid used, d1, shift2, bits2, LDS passes,
  * largest cell, active LSD passes (-1 when the hybrid path produced the output)} of the last sort
  * that used `tmp`.  Synchronises `stream`. */

@@ -131,7 +131,8 @@ def test_scratch_queries_and_argument_checks_without_a_gpu():
             sizes.append(b)
         assert sizes == sorted(sizes) and sizes[-1] > 0, (name, sizes)
     # the 1e9-row keys-only sort: two key buffers worth of scratch (ping-pong + look-back granules), not more
-    assert 16e9 < queries["gx_sort_keys"](10**9)[1] < 16.5e9
+    # (the 9-bit second level keeps 512 eight-byte granules per 8192-key tile: 0.5 GB)
+    assert 16e9 < queries["gx_sort_keys"](10**9)[1] < 16.6e9
     assert q("gx_sort_keys", 99, None, None, 10, 0)[0] == -2                 # GX_EDTYPE
     assert q("gx_sort_keys", L.INT64, None, None, -1, 0)[0] == -1            # GX_EINVAL
     assert q("gx_sort_keys", L.INT64, None, None, 2**31, 0)[0] == -1         # more than size_type rows
