@@ -113,8 +113,8 @@ class hash_join_impl {
     auto const* pmask = pk.has_nulls() ? rebased_mask(pk, holder, stream) : nullptr;
     std::vector<size_type> pnulls = _nulls_equal ? null_rows(pk, stream) : std::vector<size_type>{};
     std::size_t const cross = _nulls_equal ? pnulls.size() * _build_nulls.size() : 0;
-    // with nulls EQUAL a null probe row that has a null partner must not also emit (i, NoMatch)
-    bool const suppress_null_nomatch = left_outer && cross > 0;
+    // with nulls EQUAL a null probe row that has a null partner must not also emit (i, NoMatch): flag bit 1
+    int const outer_flags = left_outer ? (cross > 0 ? 3 : 1) : 0;
 
     std::size_t capacity = output_size.value_or(static_cast<std::size_t>(pk.size())) + cross;
     rmm::device_buffer cursor{sizeof(int64_t), stream};
@@ -128,13 +128,13 @@ class hash_join_impl {
         // large probe against a table far beyond the L2s: partitioned probe (chains run on LDS tags)
         run_with_scratch(
           [&](void* t, std::size_t* b) {
-            return gx_join_probe_partitioned(_key_size, row0(pk), pk.size(), _table.data(), _table_bytes, left_outer ? 1 : 0,
+            return gx_join_probe_partitioned(_key_size, row0(pk), pk.size(), _table.data(), _table_bytes, outer_flags & 1,
                                              l->data(), r->data(), static_cast<int64_t>(capacity),
                                              static_cast<int64_t*>(cursor.data()), t, b, gxs(stream));
           },
           "hash_join probe", stream);
       } else {
-        gx_check(gx_join_probe(_key_size, row0(pk), pmask, pk.size(), _table.data(), _table_bytes, left_outer ? 1 : 0,
+        gx_check(gx_join_probe(_key_size, row0(pk), pmask, pk.size(), _table.data(), _table_bytes, outer_flags,
                                l->data(), r->data(), static_cast<int64_t>(capacity), static_cast<int64_t*>(cursor.data()),
                                gxs(stream)),
                  "hash_join probe");
@@ -158,7 +158,6 @@ class hash_join_impl {
       stream.synchronize();
       n += cross;
     }
-    (void)suppress_null_nomatch;  // the kernel skips null probe rows only for inner joins; see left_join below
     l->shrink(n);
     r->shrink(n);
     return {std::move(l), std::move(r)};
@@ -189,8 +188,6 @@ class hash_join_impl {
       stream.synchronize();
       return {std::move(l), std::move(r)};
     }
-    CUDF_EXPECTS(!(_nulls_equal && !_enc && probe.column(0).has_nulls() && !_build_nulls.empty()),
-                 "left/full join with null keys on both sides under null_equality::EQUAL is not supported on this path yet");
     return probe_join(probe, true, output_size, stream, mr);
   }
 

@@ -49,8 +49,13 @@ __device__ __forceinline__ int64_t find_or_insert(unsigned long long* table, uin
     st->special_used = 1ull;
     return (int64_t)cap;
   }
+  // Once the table has overflowed the result is discarded (the caller retries with a larger table): stop probing.
+  // A chain is cut after 2^16 slots: at the load factor the caller sizes for (<= 0.5) no legitimate chain comes
+  // near that, and a full table would otherwise cost every new key a walk over all of its slots.
+  if (*reinterpret_cast<volatile unsigned long long*>(&st->overflow) != 0ull) return -1;
+  const uint64_t limit = cap < 65536ull ? cap : 65536ull;
   uint64_t h = gb_hash(s, log2cap);
-  for (uint64_t probes = 0; probes < cap; ++probes) {
+  for (uint64_t probes = 0; probes < limit; ++probes) {
     unsigned long long cur = table[h];
     if (cur == 0ull) {
       cur = atomicCAS(&table[h], 0ull, s);

@@ -185,8 +185,11 @@ __global__ void __launch_bounds__(JBT) k_probe(const K* __restrict__ keys, const
       cnt[j]          = 0;
       first[j]        = NO_MATCH;
       if (i < n) {
-        if (!valid || bit_is_set(valid, i)) cnt[j] = chain_count<K>(slots, mask, log2cap, keys[i], first[j]);
-        if (left_outer && cnt[j] == 0) cnt[j] = 1;  // (i, JoinNoMatch); first[j] already NO_MATCH
+        const bool ok = !valid || bit_is_set(valid, i);
+        if (ok) cnt[j] = chain_count<K>(slots, mask, log2cap, keys[i], first[j]);
+        // (i, JoinNoMatch); first[j] already NO_MATCH.  left_outer bit 1: a null probe row emits nothing -- its
+        // partners are the null build rows, which the caller appends (null == null)
+        if ((left_outer & 1) && cnt[j] == 0 && (ok || !(left_outer & 2))) cnt[j] = 1;
       }
     }
     if (!WRITE) {

@@ -240,7 +240,8 @@ __global__ void __launch_bounds__(BINS) k_hy_plan(SortPlan* plan, int stage, int
     const int top    = 63 - __builtin_clzll(V);
     const int shift0 = top - 7;
     const int shift2 = shift0 - bits2;
-    // the local sort splits a cell on >= 7 further bits in LDS; packed (key bits, position) words must fit 64 bits
+    // the local sort splits a cell on >= 7 further bits in LDS; the packed (key bits, position) words of a pairs
+    // sort must fit 64 bits (float keys-only sorts fall back to plain keys + stable LDS passes by themselves)
     const bool ok = shift2 >= 8 && (pos_bits == 0 || shift2 + pos_bits <= 64);
     const bool spec_ok = shift0 == key_bits - 8;
     if (!ok) {
@@ -1336,7 +1337,7 @@ static HybridCfg hybrid_cfg(int64_t n, bool iota_payload, int algo)
   c.cl2 = (small_ok && g_cell != 16384 && (double)n / (double)(1 << 17) <= 0.955 * 8192.0) ? 13 : 14;
   if (g_cell == 8192 && small_ok) c.cl2 = 13;
   const double cell = (double)(1 << c.cl2);
-  const int maxb2   = (small_ok && c.cl2 == 13) ? 9 : 8;
+  const int maxb2   = small_ok ? 9 : 8;  // the 9-bit level-1 pass exists for integer keys-only sorts
   int B = 9;
   while (B < 8 + maxb2 && (double)n / (double)(1ull << B) > 0.955 * cell) ++B;
   if ((double)n / (double)(1ull << B) > 0.97 * cell) return c;  // cells would overflow: LSD passes
@@ -1450,11 +1451,11 @@ int sort_impl(const void* keys_in, void* keys_out, const int32_t* vals_in, int32
       hipLaunchKernelGGL((k_hy_hist<KeyT, KIND, true>), dim3((unsigned)hblocks), dim3(BT), 0, stream,
                          static_cast<const KeyT*>(keys_in), n, desc_mask, plan, range_rows);
       hipLaunchKernelGGL(k_hy_plan, dim3(1), dim3(BINS), 0, stream, plan, 0, (int)(8 * sizeof(KeyT)), n, hc.bits2, 1 << hc.cl2,
-                         (HAS_VAL || KIND == K_FLOAT) ? hc.cl2 : 0, range_rows, (int)msd_tile, base1);
+                         HAS_VAL ? hc.cl2 : 0, range_rows, (int)msd_tile, base1);
       hipLaunchKernelGGL((k_hy_hist<KeyT, KIND, false>), dim3((unsigned)hblocks), dim3(BT), 0, stream,
                          static_cast<const KeyT*>(keys_in), n, desc_mask, plan, range_rows);
       hipLaunchKernelGGL(k_hy_plan, dim3(1), dim3(BINS), 0, stream, plan, 1, (int)(8 * sizeof(KeyT)), n, hc.bits2, 1 << hc.cl2,
-                         (HAS_VAL || KIND == K_FLOAT) ? hc.cl2 : 0, range_rows, (int)msd_tile, base1);
+                         HAS_VAL ? hc.cl2 : 0, range_rows, (int)msd_tile, base1);
       prof_mark(1, stream);
       KeyT* bufA = keys_out ? static_cast<KeyT*>(keys_out) : ka_scratch;
       KeyT* bufB = kb_scratch;

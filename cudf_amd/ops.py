@@ -140,6 +140,12 @@ def hash_partition_map(key_cols: Sequence[Column], num_partitions: int, seed: in
 def _join_key(col: Column) -> Column:
     if col.dtype.itemsize not in (4, 8):
         raise TypeError("join key must be a 4- or 8-byte fixed-width column")  # data_type_error
+    if col.dtype.kind == "f":
+        # row equality of the reference: -0.0 == +0.0 and NaN == NaN whatever the payload
+        # (detail/row_operator/common_utils.cuh:215-220); gx_pack_keys normalises both, the table compares bits
+        key = pack_keys([col])
+        key.mask, key.null_count = col.mask, col.null_count
+        return key
     return col
 
 
@@ -150,7 +156,8 @@ class HashJoin:
     def __init__(self, right: Column, nulls_equal: bool = True, load_factor: float = 0.5):
         if not (0.0 < load_factor <= 1.0):
             raise ValueError("Invalid load factor: must be greater than 0 and less than or equal to 1.")
-        self.build = _join_key(right)
+        self.build_dtype = right.dtype
+        self.build = right = _join_key(right)
         self.nulls_equal = nulls_equal
         self.key_size = right.dtype.itemsize
         self.load_factor = load_factor
@@ -166,12 +173,14 @@ class HashJoin:
             L.check(_lib.gx_join_build(self.key_size, right.data_ptr, valid, right.size, ptr(self.table),
                                        self.table_bytes, load_factor, stream_ptr()), "gx_join_build")
 
-    def _check(self, left: Column):
-        if left.dtype != self.build.dtype:
-            raise TypeError("Mismatch in joining column data types")  # hash_join.cu:56-58
+    def _check(self, left: Column) -> Column:
+        """type check (hash_join.cu:56-58); returns the probe column in the table's key space"""
+        if left.dtype != self.build_dtype:
+            raise TypeError("Mismatch in joining column data types")
+        return _join_key(left) if left.size else left
 
     def inner_join_size(self, left: Column) -> int:
-        self._check(left)
+        left = self._check(left)
         if left.size == 0 or self.build.size == 0:
             return 0
         cnt = _dev_i64()
@@ -185,7 +194,8 @@ class HashJoin:
 
     PARTITIONED_MIN_ROWS = 1 << 22
 
-    def _probe(self, left: Column, capacity: int, left_outer: bool):
+    def _probe(self, left: Column, capacity: int, left_outer: int):
+        """left_outer: gx_join_probe's flags (bit 0 left outer, bit 1 null probe rows emit nothing)"""
         lo = Column.empty(np.int32, capacity)
         ro = Column.empty(np.int32, capacity)
         cur = _dev_i64()
@@ -194,7 +204,7 @@ class HashJoin:
                 and _lib.gx_join_partition_bits(self.key_size, self.table_bytes) > 0):
             # large probe against a table far beyond the L2s: partition the probe rows first
             _run(_lib.gx_join_probe_partitioned, self.key_size, left.data_ptr, left.size, ptr(self.table),
-                 self.table_bytes, int(left_outer), lo.data_ptr, ro.data_ptr, capacity, ptr(cur))
+                 self.table_bytes, int(left_outer) & 1, lo.data_ptr, ro.data_ptr, capacity, ptr(cur))
             return lo, ro, int(cur.item())
         L.check(_lib.gx_join_probe(self.key_size, left.data_ptr, valid, left.size, ptr(self.table), self.table_bytes,
                                    int(left_outer), lo.data_ptr, ro.data_ptr, capacity, ptr(cur), stream_ptr()),
@@ -203,7 +213,7 @@ class HashJoin:
 
     def inner_join(self, left: Column, output_size: Optional[int] = None) -> Tuple[Column, Column]:
         """(left_indices, right_indices), order unspecified (join.hpp:131-134)."""
-        self._check(left)
+        left = self._check(left)
         if left.size == 0 or self.build.size == 0:  # trivial joins (hash_join.cu:32-45)
             return Column.empty(np.int32, 0), Column.empty(np.int32, 0)
         # optimistic single pass: with distinct build keys (the common PK-FK case) matches <= probe
@@ -218,13 +228,18 @@ class HashJoin:
         return lo, ro
 
     def left_join(self, left: Column) -> Tuple[Column, Column]:
-        self._check(left)
+        left = self._check(left)
         if left.size == 0:
             return Column.empty(np.int32, 0), Column.empty(np.int32, 0)
-        lo, ro, total = self._probe(left, left.size, True)
+        # null == null (hash_join.cu:77-84): a null left row matches every null build row instead of (i, JoinNoMatch)
+        cross = self.nulls_equal and left.has_nulls() and self.build.has_nulls()
+        flags = 3 if cross else 1
+        lo, ro, total = self._probe(left, left.size, flags)
         if total > left.size:
-            lo, ro, total = self._probe(left, total, True)
+            lo, ro, total = self._probe(left, total, flags)
         lo.size = ro.size = total
+        if cross:
+            lo, ro = _append_null_cross(lo, ro, left, self.build)
         return lo, ro
 
 
@@ -232,7 +247,7 @@ class HashJoin:
         """cudf::distinct_hash_join::left_join (distinct_hash_join.hpp:96-116): for DISTINCT build keys,
         the build row matching each left row, in left order, JoinNoMatch (INT32_MIN) where there is none.
         (With duplicate build keys it returns one of the matching rows.)"""
-        self._check(left)
+        left = self._check(left)
         out = Column.empty(np.int32, left.size)
         if left.size == 0:
             return out
@@ -250,7 +265,7 @@ class HashJoin:
         return out
 
     def _filter(self, left: Column, anti: bool) -> Column:
-        self._check(left)
+        left = self._check(left)
         out = Column.empty(np.int32, left.size)
         if left.size == 0:
             return out

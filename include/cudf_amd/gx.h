@@ -236,8 +236,10 @@ int gx_join_count(int key_size, const void* probe_keys, const uint32_t* probe_va
 /* Emits pairs (probe_idx, build_idx) in unspecified order (include/cudf/join/join.hpp:131-134)
  * through a device cursor *cursor_dev (must be zeroed by the caller); pairs beyond `capacity`
  * are counted but not written (caller compares the cursor with capacity).
- * left_outer != 0: probe rows without a match emit (probe_idx, INT32_MIN) -- cudf::left_join
- * (src/join/join.cu:62-85). */
+ * left_outer bit 0: probe rows without a match emit (probe_idx, INT32_MIN) -- cudf::left_join
+ * (src/join/join.cu:62-85).  left_outer bit 1 (with bit 0): NULL probe rows emit nothing -- under
+ * null_equality::EQUAL with null build rows present their partners are those rows, which the caller appends
+ * (hash_join.cu:77-84). */
 int gx_join_probe(int key_size, const void* probe_keys, const uint32_t* probe_valid,
                   int64_t probe_rows, const void* table, size_t table_bytes, int left_outer,
                   int32_t* out_probe_idx, int32_t* out_build_idx, int64_t capacity,

@@ -341,6 +341,30 @@ int main()
     CHECK(throws<std::invalid_argument>([&] { distinct_hash_join bad{table_view{{r->view()}}, null_equality::EQUAL, 1.5}; }));
     CHECK(throws<std::invalid_argument>([&] { distinct_hash_join bad{table_view{}}; }));
   });
+  run("left / full join, one nullable key column, nulls on BOTH sides (hash_join.cu:77-84; ADVICE r1)", [] {
+    // EQUAL: null left rows 1 and 4 pair with null right rows 0 and 3 and do NOT also appear as (row, NoMatch);
+    // UNEQUAL: they match nothing.  Same expectation through the direct path (int32), the normalising encoder
+    // (float64) and the dictionary encoder (int16).
+    auto check = [](auto tag) {
+      using T = decltype(tag);
+      auto l = make_col<T>({3, 9, 2, 7, 9}, {1, 0, 1, 1, 0});
+      auto r = make_col<T>({9, 2, 3, 9, 2}, {0, 1, 1, 0, 1});
+      table_view L{{l->view()}}, R{{r->view()}};
+      pairs_t const eq{{0, 2}, {1, 0}, {1, 3}, {2, 1}, {2, 4}, {3, JoinNoMatch}, {4, 0}, {4, 3}};
+      pairs_t const ne{{0, 2}, {1, JoinNoMatch}, {2, 1}, {2, 4}, {3, JoinNoMatch}, {4, JoinNoMatch}};
+      CHECK((sorted_pairs(left_join(L, R, null_equality::EQUAL)) == eq));
+      CHECK((sorted_pairs(left_join(L, R, null_equality::UNEQUAL)) == ne));
+      CHECK(full_join(L, R, null_equality::EQUAL).first->size() == eq.size());        // every right row is matched
+      CHECK(full_join(L, R, null_equality::UNEQUAL).first->size() == ne.size() + 2);  // + null right rows 0 and 3
+      hash_join hj{R, null_equality::EQUAL};
+      CHECK(hj.left_join_size(L) == eq.size());
+      CHECK(hj.inner_join_size(L) == 7);
+    };
+    check(int32_t{});
+    check(double{});
+    check(int16_t{});
+    check(int64_t{});
+  });
   run("multi-column join keys (join_tests.cpp:1163-1283,1421-1500: numeric key columns)", [] {
     auto l0 = make_col<int32_t>({3, 1, 2, 0, 2}), l1 = make_col<int32_t>({1, 1, 0, 4, 0});
     auto r0 = make_col<int32_t>({2, 2, 0, 4, 3}), r1 = make_col<int32_t>({1, 0, 1, 2, 1});

@@ -372,3 +372,34 @@ def test_groupby_compound_matches_oracle(gx, vdtype, nulls):
     ev = res["argmin"][1]
     np.testing.assert_array_equal(amin.to_numpy()[o][ev], res["argmin"][0][ev])
     np.testing.assert_array_equal(amax.to_numpy()[o][ev], res["argmax"][0][ev])
+
+
+@pytest.mark.parametrize("dtype", ["int64", "int32", "float64", "float32"])
+@pytest.mark.parametrize("nulls_equal", [True, False])
+def test_single_key_left_join_with_nulls_on_both_sides(gx, dtype, nulls_equal):
+    """null_equality::EQUAL: a null left row matches every null build row and must NOT also appear as
+    (row, JoinNoMatch) (cpp/src/join/hash_join/hash_join.cu:77-84); UNEQUAL: it matches nothing.  Float keys:
+    -0.0 == +0.0 and NaN == NaN whatever the payload (row_operator/common_utils.cuh:215-220)."""
+    Column, ops = gx
+    rng = np.random.default_rng(31)
+    nl, nr = 10_007, 2_003
+    if np.dtype(dtype).kind == "f":
+        lv = (rng.integers(-4, 5, nl) / 2).astype(dtype)
+        rv = (rng.integers(-4, 5, nr) / 2).astype(dtype)
+        lv[rng.random(nl) < 0.05] = np.nan
+        rv[rng.random(nr) < 0.05] = -np.nan
+        lv[rng.random(nl) < 0.05] = -0.0
+    else:
+        lv = rng.integers(0, 40, nl).astype(dtype)
+        rv = rng.integers(0, 40, nr).astype(dtype)
+    lm, rm = rng.random(nl) > 0.1, rng.random(nr) > 0.2
+    l, r = ops.left_join(Column.from_numpy(lv, lm), Column.from_numpy(rv, rm), nulls_equal)
+    gl, gr = orc.canonical_pairs(l.to_numpy(), r.to_numpy())
+    el, er = orc.left_join(lv, rv, lm, rm, nulls_equal)
+    np.testing.assert_array_equal(gl, el)
+    np.testing.assert_array_equal(gr, er)
+    l, r = ops.inner_join(Column.from_numpy(lv, lm), Column.from_numpy(rv, rm), nulls_equal)
+    gl, gr = orc.canonical_pairs(l.to_numpy(), r.to_numpy())
+    el, er = orc.inner_join(lv, rv, lm, rm, nulls_equal)
+    np.testing.assert_array_equal(gl, el)
+    np.testing.assert_array_equal(gr, er)

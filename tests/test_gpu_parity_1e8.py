@@ -1,0 +1,108 @@
+"""GPU parity at BASELINE scale (oracle parity at N in {1e3, 1e6, 1e8}): 1e8-row sort, 1e8 x 4e7 join
+(P = 1024 partitions: the partitioned build, the 16384-row scatter tiles and the pipelined tag probe) and 1e8-row
+groupby (LDS-partitioned path, once with every partition fitting its LDS table and once spilling) against the plain-C
+oracle (oracle/oracle.c), through the C ABI.  The small-size cases live in the other test_gpu_* files."""
+import math
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+from oracle import c_oracle
+from oracle import cudf_oracle as orc
+
+N = 100_000_000
+
+
+@pytest.fixture(scope="module")
+def gx():
+    import torch
+    assert torch.cuda.is_available()
+    import cudf_amd  # noqa: F401
+    from cudf_amd import Column, ops
+    return Column, ops
+
+
+def _mix(l, r):
+    """order-independent fingerprint of a multiset of (left, right) pairs: sum and xor of a 64-bit mix"""
+    x = (l.astype(np.uint64) << np.uint64(32)) | r.astype(np.uint32).astype(np.uint64)
+    with np.errstate(over="ignore"):
+        x = (x ^ (x >> np.uint64(30))) * np.uint64(0xBF58476D1CE4E5B9)
+        x = (x ^ (x >> np.uint64(27))) * np.uint64(0x94D049BB133111EB)
+        x = x ^ (x >> np.uint64(31))
+        return int(x.sum(dtype=np.uint64)), int(np.bitwise_xor.reduce(x))
+
+
+def test_sort_1e8_matches_c_oracle(gx):
+    Column, ops = gx
+    rng = np.random.default_rng(42)
+    v = rng.integers(-2**63, 2**63 - 1, N, dtype=np.int64)
+    want = c_oracle.sort_i64(v)
+    got = ops.sort(Column.from_numpy(v)).to_numpy()
+    assert got.tobytes() == want.tobytes()
+    # keys confined to a range that is not byte aligned (a rank's shard of a distributed sort): still bit-exact
+    w = (v >> 5) + (1 << 40)
+    got = ops.sort(Column.from_numpy(w), ascending=False).to_numpy()
+    assert got.tobytes() == c_oracle.sort_i64(w, descending=True).tobytes()
+    # sorted_order: the stable permutation
+    order = ops.sorted_order(Column.from_numpy(v)).to_numpy()
+    np.testing.assert_array_equal(order, c_oracle.sorted_order_i64(v))
+
+
+def test_join_1e8_x_4e7_matches_c_oracle(gx):
+    Column, ops = gx
+    from cudf_amd import _lib
+    rng = np.random.default_rng(12345)
+    nb = 40_000_000
+    build = (rng.permutation(nb).astype(np.int64) * 3 + 1)                       # distinct keys, shuffled
+    probe = rng.integers(0, int(nb / 0.3), N).astype(np.int64) * 3 + 1          # selectivity 0.3
+    probe[::1000] = build[7]                                                     # a hot key
+    hj = ops.HashJoin(Column.from_numpy(build))
+    assert _lib.lib.gx_join_partition_bits(8, hj.table_bytes) >= 10, "the test must run P >= 1024 partitions"
+    l, r = hj.inner_join(Column.from_numpy(probe))
+    gl, gr = l.to_numpy(), r.to_numpy()
+    el, er = c_oracle.inner_join_i64(probe, build)
+    assert len(gl) == len(el)
+    assert _mix(gl, gr) == _mix(el, er)
+    assert np.array_equal(probe[gl], build[gr])
+    assert hj.inner_join_size(Column.from_numpy(probe)) == len(el)
+    # duplicate build keys (every 16th key twice): the optimistic single pass overflows its guess and re-runs
+    build2 = np.concatenate([build, build[::16]])
+    l, r = ops.HashJoin(Column.from_numpy(build2)).inner_join(Column.from_numpy(probe[: N // 4]))
+    el, er = c_oracle.inner_join_i64(probe[: N // 4], build2)
+    assert len(l.to_numpy()) == len(el)
+    assert _mix(l.to_numpy(), r.to_numpy()) == _mix(el, er)
+
+
+@pytest.mark.parametrize("ngroups", [1_000_000, 4_000_000], ids=["fits_lds_tables", "spills_lds_tables"])
+def test_groupby_1e8_matches_c_oracle(gx, ngroups):
+    Column, ops = gx
+    rng = np.random.default_rng(7)
+    k = rng.integers(0, ngroups, N).astype(np.int32)
+    vi = rng.integers(0, 1 << 20, N).astype(np.float64)      # integer-valued doubles: every order of summation is exact
+    gk, gs, gcv, _ = ops.groupby_sum_count(Column.from_numpy(k), Column.from_numpy(vi), max_groups_hint=ngroups)
+    o = np.argsort(gk.to_numpy())
+    es, ec = c_oracle.groupby_dense_sum_count(k, vi, ngroups)
+    present = ec > 0
+    np.testing.assert_array_equal(gk.to_numpy()[o], np.nonzero(present)[0].astype(np.int32))
+    np.testing.assert_array_equal(gcv.to_numpy()[o], ec[present])
+    assert gs.to_numpy()[o].tobytes() == es[present].tobytes()
+    # uniform [0, 1) values: 1 ulp of the correctly rounded sum (math.fsum) on sampled groups, 1e-12 relative everywhere
+    vf = rng.random(N)
+    gk, gs, gcv, _ = ops.groupby_sum_count(Column.from_numpy(k), Column.from_numpy(vf), max_groups_hint=ngroups)
+    o = np.argsort(gk.to_numpy())
+    es, ec = c_oracle.groupby_dense_sum_count(k, vf, ngroups)
+    got = gs.to_numpy()[o]
+    np.testing.assert_allclose(got, es[present], rtol=1e-12)
+    keys_sorted = gk.to_numpy()[o]
+    sample = rng.choice(len(keys_sorted), 300, replace=False)
+    sel = np.isin(k, keys_sorted[sample])
+    ks, vs = k[sel], vf[sel]
+    order = np.argsort(ks, kind="stable")
+    ks, vs = ks[order], vs[order]
+    bounds = np.flatnonzero(np.diff(ks)) + 1
+    for grp_k, grp_v in zip(np.split(ks, bounds), np.split(vs, bounds)):
+        exact = math.fsum(grp_v.tolist())
+        g = got[np.searchsorted(keys_sorted, grp_k[0])]
+        assert orc.ulp_diff(np.array([g]), np.array([exact]))[0] <= 1, (int(grp_k[0]), g, exact)
