@@ -334,16 +334,16 @@ def bench_sort(c, pairs=False):
         # hybrid MSD path: per-kernel algorithmic bytes: partition passes and the local sort read 8 +
         # write 8 B/row, the joint histogram reads 8 B/row
         ms = [x / prof["hyb_n"] for x in prof["hyb"]]
-        names = ["k_msd_pass level 0 (8-bit partition, 8 XCD chains)", "k_hist2+k_plan2 (joint histogram)",
-                 f"k_msd_pass level 1 ({sort_info['bits2']}-bit partition inside buckets)",
-                 "k_local_sort (LDS sort of the cells)"]
-        bpr = [20, 8, 24, 24] if pairs else [16, 8, 16, 16]  # pairs carry a 4-B index
+        names = ["k_msd_pass level 0 (8-bit partition, 8 XCD chains)",
+                 f"k_msd_pass level 1 ({sort_info['bits2']}-bit partition inside buckets, padded cell slots)",
+                 "k_plan2 (cell starts, one block)", "k_local_sort (LDS sort of the cells)"]
+        bpr = [20, 24, 0, 24] if pairs else [16, 16, 0, 16]  # pairs carry a 4-B index
         dom = max(range(4), key=lambda i: ms[i])
         achieved = bpr[dom] * n / (ms[dom] * 1e-3) / 1e9
         roofline = {"bound": "hbm", "kernel": names[dom], "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                     "frac": achieved / HBM_PEAK_GBS, "traffic": None, "algorithmic_bytes_per_launch": bpr[dom] * n,
                     "avg_launch_ms": ms[dom], "launches_per_step": 1.0,
-                    "kernels_ms": dict(zip(names, ms)), "kernels_GBps": {k: b * n / (m * 1e-3) / 1e9 for k, b, m in zip(names, bpr, ms)},
+                    "kernels_ms": dict(zip(names, ms)), "kernels_GBps": {k: b * n / (m * 1e-3) / 1e9 for k, b, m in zip(names, bpr, ms) if b},
                     "hist_kernel_ms": hist_ms,
                     "path_bytes_per_row": 8 + sum(bpr), "path_GBps": (8 + sum(bpr)) * n / (local_sort_ms * 1e-3) / 1e9,
                     "path_frac": (8 + sum(bpr)) * n / (local_sort_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,

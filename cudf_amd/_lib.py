@@ -79,6 +79,12 @@ _PROTOS = {
     "gx_join_filter": (_i, [_i, _p, _p, _i64, _p, ctypes.c_size_t, _i, _i, _p, _p, _p, _sz, _p]),
     "gx_join_complement": (_i, [_p, _i64, _i64, _p, _p, _i64, _p, _p, _sz, _p]),
     "gx_groupby_set_algorithm": (None, [_i, _i]),
+    "gx_group_heads": (_i, [_i, _p, _p, _p, _i64, _i, _p, _p]),
+    "gx_group_offsets": (_i, [_p, _i64, _p, _p, _p, _p, _p, _sz, _p]),
+    "gx_segmented_reduce": (_i, [_i, _p, _p, _p, _p, _i64, _i, _p, _p, _p, _sz, _p]),
+    "gx_segmented_shift": (_i, [_i, _p, _p, _p, _i64, _i64, ctypes.c_uint64, _i, _p, _p, _p]),
+    "gx_segmented_fill_nulls": (_i, [_i, _p, _p, _p, _i64, _i, _p, _p, _p, _sz, _p]),
+    "gx_rank_from_groups": (_i, [_p, _p, _p, _i64, _i, ctypes.c_double, _i, _p, _p, _p]),
     "gx_segmented_scan": (_i, [_i, _p, _i, _p, _p, _i64, _i, _p, _p, _sz, _p]),
     "gx_reduce": (_i, [_i, _p, _p, _i64, _i, _i, _p, _p, _p, _sz, _p]),
     "gx_scan": (_i, [_i, _p, _p, _i64, _i, _i, _p, _p, _sz, _p]),

@@ -330,6 +330,137 @@ int seg_float(const void* vals, const uint32_t* valid, const uint8_t* heads, int
   }
 }
 
+// ---------------------------------------------------------------- segmented reduce (sort-path groupby)
+// One result per key run instead of one per row: the same reduce-then-scan over (value, head flag) elements,
+// carrying the number of valid values as a third field, with the last pass storing only where a run ENDS
+// (at out[label]).  Replaces thrust::reduce_by_key of the reference's sort-based aggregations
+// (cpp/src/groupby/sort/group_single_pass_reduction_util.cuh:133-200, group_count.cu:25-89).  Fixed
+// association order; float SUM in double-double, so results are bit-reproducible and within 1 ulp.
+template <typename T>
+struct SegC {
+  T v;
+  uint32_t f;  // 1 = this element starts a new key run
+  uint32_t c;  // valid values folded into v
+};
+template <typename T, typename Op>
+struct SegCOp {
+  Op op;
+  __device__ __forceinline__ SegC<T> operator()(SegC<T> a, SegC<T> b) const
+  {
+    return SegC<T>{b.f ? b.v : op(a.v, b.v), a.f | b.f, b.f ? b.c : a.c + b.c};
+  }
+};
+template <typename AccT>
+struct AccFrom {
+  template <typename X>
+  static __device__ __forceinline__ AccT of(X x) { return static_cast<AccT>(x); }
+};
+template <>
+struct AccFrom<DD> {
+  template <typename X>
+  static __device__ __forceinline__ DD of(X x) { return DD{(double)x, 0.0}; }
+};
+template <typename InT, typename AccT>
+struct SegCLoader {
+  const InT* in;
+  const uint32_t* valid;
+  const uint8_t* heads;
+  AccT identity;
+  __device__ __forceinline__ SegC<AccT> operator()(int64_t i) const
+  {
+    const bool ok = !valid || bit_is_set(valid, i);
+    return SegC<AccT>{(ok && in) ? AccFrom<AccT>::of(in[i]) : identity, heads[i], ok ? 1u : 0u};
+  }
+};
+
+template <typename AccT, typename OutT, typename Op, typename Loader>
+__global__ void __launch_bounds__(scan::SCAN_BT) k_chunk_segreduce(Loader load, int64_t n, SegC<AccT> identity, SegCOp<AccT, Op> op,
+                                                                   const SegC<AccT>* partials, const uint8_t* __restrict__ heads,
+                                                                   const int32_t* __restrict__ labels, OutT* __restrict__ out,
+                                                                   int32_t* __restrict__ out_cnt)
+{
+  using namespace scan;
+  constexpr int NWV = SCAN_BT / GX_WAVE;
+  __shared__ SegC<AccT> s_w[NWV];
+  const unsigned l    = lane_id();
+  const unsigned w    = threadIdx.x / GX_WAVE;
+  const int64_t chunk = blockIdx.x;
+  const int64_t base  = chunk * SCAN_CHUNK + (int64_t)w * (GX_WAVE * SCAN_IPT) + l;
+  SegC<AccT> inc[SCAN_IPT];
+  SegC<AccT> carry = identity;
+#pragma unroll
+  for (int k = 0; k < SCAN_IPT; ++k) {
+    const int64_t i    = base + (int64_t)k * GX_WAVE;
+    const SegC<AccT> v = (i < n) ? load(i) : identity;
+    inc[k]             = wave_inclusive_scan(v, op);
+    carry              = op(carry, shfl(inc[k], GX_WAVE - 1));
+  }
+  if (l == 0) s_w[w] = carry;
+  __syncthreads();
+  SegC<AccT> run = partials[chunk];
+  for (unsigned k = 0; k < w; ++k) run = op(run, s_w[k]);
+#pragma unroll
+  for (int k = 0; k < SCAN_IPT; ++k) {
+    const int64_t i = base + (int64_t)k * GX_WAVE;
+    if (i < n && (i + 1 == n || heads[i + 1])) {  // last row of its run
+      const SegC<AccT> r = op(run, inc[k]);
+      const int32_t g    = labels[i];
+      if (out) out[g] = static_cast<OutT>(r.v);
+      if (out_cnt) out_cnt[g] = (int32_t)r.c;
+    }
+    run = op(run, shfl(inc[k], GX_WAVE - 1));
+  }
+}
+
+template <typename InT, typename AccT, typename OutT, typename Op>
+int segreduce_typed(const void* vals, const uint32_t* valid, const uint8_t* heads, const int32_t* labels, int64_t n,
+                    AccT identity, Op op, void* out, int32_t* out_cnt, void* partials_raw, hipStream_t s)
+{
+  using E = SegC<AccT>;
+  E* partials = static_cast<E*>(partials_raw);
+  SegCLoader<InT, AccT> ld{static_cast<const InT*>(vals), valid, heads, identity};
+  const E ident{identity, 0u, 0u};
+  const SegCOp<AccT, Op> sop{op};
+  const int64_t nc = scan::num_chunks(n);
+  hipLaunchKernelGGL((scan::k_chunk_reduce<E, SegCOp<AccT, Op>, SegCLoader<InT, AccT>>), dim3((unsigned)nc), dim3(scan::SCAN_BT), 0, s,
+                     ld, n, ident, sop, partials, (const int*)nullptr);
+  hipLaunchKernelGGL((scan::k_partials_scan<E, SegCOp<AccT, Op>>), dim3(1), dim3(1024), 0, s, partials, nc, ident, sop,
+                     (const int*)nullptr);
+  hipLaunchKernelGGL((k_chunk_segreduce<AccT, OutT, Op, SegCLoader<InT, AccT>>), dim3((unsigned)nc), dim3(scan::SCAN_BT), 0, s, ld, n,
+                     ident, sop, partials, heads, labels, static_cast<OutT*>(out), out_cnt);
+  GX_LAUNCH_CHECK();
+  return 0;
+}
+
+// integers: SUM / PRODUCT accumulate and return int64 (aggregation.hpp:949-970); MIN / MAX return the input type
+template <typename InT, bool SIGNED>
+int segreduce_int(const void* vals, const uint32_t* valid, const uint8_t* heads, const int32_t* labels, int64_t n, int op,
+                  void* out, int32_t* out_cnt, void* partials, hipStream_t s)
+{
+  using W = typename std::conditional<SIGNED, int64_t, uint64_t>::type;
+  switch (op) {
+    case GX_OP_COUNT_VALID:
+    case GX_OP_SUM: return segreduce_typed<InT, int64_t, int64_t>(vals, valid, heads, labels, n, int64_t(0), SumOp(), out, out_cnt, partials, s);
+    case GX_OP_PRODUCT: return segreduce_typed<InT, uint64_t, int64_t>(vals, valid, heads, labels, n, uint64_t(1), ProdOp(), out, out_cnt, partials, s);
+    case GX_OP_MIN: return segreduce_typed<InT, W, InT>(vals, valid, heads, labels, n, (W)std::numeric_limits<InT>::max(), MinOp(), out, out_cnt, partials, s);
+    case GX_OP_MAX: return segreduce_typed<InT, W, InT>(vals, valid, heads, labels, n, (W)std::numeric_limits<InT>::lowest(), MaxOp(), out, out_cnt, partials, s);
+    default: return GX_EINVAL;
+  }
+}
+template <typename InT>
+int segreduce_float(const void* vals, const uint32_t* valid, const uint8_t* heads, const int32_t* labels, int64_t n, int op,
+                    void* out, int32_t* out_cnt, void* partials, hipStream_t s)
+{
+  switch (op) {
+    case GX_OP_COUNT_VALID:
+    case GX_OP_SUM: return segreduce_typed<InT, DD, InT>(vals, valid, heads, labels, n, DD{0.0, 0.0}, DDSum(), out, out_cnt, partials, s);
+    case GX_OP_PRODUCT: return segreduce_typed<InT, double, InT>(vals, valid, heads, labels, n, 1.0, ProdOp(), out, out_cnt, partials, s);
+    case GX_OP_MIN: return segreduce_typed<InT, double, InT>(vals, valid, heads, labels, n, Limits<double>::highest(), MinOp(), out, out_cnt, partials, s);
+    case GX_OP_MAX: return segreduce_typed<InT, double, InT>(vals, valid, heads, labels, n, Limits<double>::lowest(), MaxOp(), out, out_cnt, partials, s);
+    default: return GX_EINVAL;
+  }
+}
+
 }  // namespace rs
 }  // namespace gx
 
@@ -417,6 +548,43 @@ int gx_segmented_scan(int key_dtype, const void* sorted_keys, int val_dtype, con
     case GX_UINT64: return seg_int<uint64_t, false>(vals, vals_valid, heads, n, op, out, partials, s);
     case GX_FLOAT32: return seg_float<float>(vals, vals_valid, heads, n, op, out, partials, s);
     case GX_FLOAT64: return seg_float<double>(vals, vals_valid, heads, n, op, out, partials, s);
+    default: return GX_EDTYPE;
+  }
+}
+
+/* see gx.h */
+int gx_segmented_reduce(int val_dtype, const void* vals, const uint32_t* vals_valid, const uint8_t* heads, const int32_t* labels,
+                        int64_t n, int op, void* out, int32_t* out_count_valid, void* tmp, size_t* tmp_bytes, gx_stream_t s)
+{
+  using namespace gx::rs;
+  if (n < 0 || !tmp_bytes) return GX_EINVAL;
+  gx::Carver c(tmp);
+  char* partials = c.take<char>(gx::scan::partials_count(n) * sizeof(SegC<DD>));
+  if (!tmp) {
+    *tmp_bytes = c.total();
+    return 0;
+  }
+  if (*tmp_bytes < c.total()) return GX_ETMP;
+  if (n == 0) return 0;
+  if (!heads || !labels || (!out && !out_count_valid)) return GX_EINVAL;
+  if (op == GX_OP_COUNT_VALID) {
+    out = nullptr;  // counts only; the values are not read
+    if (!out_count_valid) return GX_EINVAL;
+    return segreduce_int<int32_t, true>(nullptr, vals_valid, heads, labels, n, op, nullptr, out_count_valid, partials, s);
+  }
+  if (!vals) return GX_EINVAL;
+  switch (val_dtype) {
+    case GX_INT8: return segreduce_int<int8_t, true>(vals, vals_valid, heads, labels, n, op, out, out_count_valid, partials, s);
+    case GX_INT16: return segreduce_int<int16_t, true>(vals, vals_valid, heads, labels, n, op, out, out_count_valid, partials, s);
+    case GX_INT32: return segreduce_int<int32_t, true>(vals, vals_valid, heads, labels, n, op, out, out_count_valid, partials, s);
+    case GX_INT64: return segreduce_int<int64_t, true>(vals, vals_valid, heads, labels, n, op, out, out_count_valid, partials, s);
+    case GX_BOOL8:
+    case GX_UINT8: return segreduce_int<uint8_t, false>(vals, vals_valid, heads, labels, n, op, out, out_count_valid, partials, s);
+    case GX_UINT16: return segreduce_int<uint16_t, false>(vals, vals_valid, heads, labels, n, op, out, out_count_valid, partials, s);
+    case GX_UINT32: return segreduce_int<uint32_t, false>(vals, vals_valid, heads, labels, n, op, out, out_count_valid, partials, s);
+    case GX_UINT64: return segreduce_int<uint64_t, false>(vals, vals_valid, heads, labels, n, op, out, out_count_valid, partials, s);
+    case GX_FLOAT32: return segreduce_float<float>(vals, vals_valid, heads, labels, n, op, out, out_count_valid, partials, s);
+    case GX_FLOAT64: return segreduce_float<double>(vals, vals_valid, heads, labels, n, op, out, out_count_valid, partials, s);
     default: return GX_EDTYPE;
   }
 }

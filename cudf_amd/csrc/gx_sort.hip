@@ -53,6 +53,7 @@ struct HybridPlan {
   int32_t lshift[MAX_PASSES], lbits[MAX_PASSES];
   int32_t need_hist;      // the speculative top-byte histogram is not the level-0 digit: k_hy_hist<false> runs
   int32_t cell_max;       // capacity of a local-sort cell (8192 or 16384)
+  int32_t overflow;       // level 1: a cell outgrew its slot (skewed keys) -> LSD fallback
   unsigned long long or_mask, nor_mask;  // OR of the sortable keys / of their complements
   uint32_t list_tile0[2][NRANGE + 1];  // first global tile of each list
   uint32_t seg_tile0[2][BINS + 1];     // first global tile of each segment (level 0: NRANGE segments)
@@ -280,6 +281,19 @@ __global__ void __launch_bounds__(BINS) k_hy_plan(SortPlan* plan, int stage, int
   for (int r = 0; r < NRANGE; ++r) {  // level-0 output base of bin t for every input range
     base1[r * NB2MAX + t] = run;
     run += hy.rh0[r][t];
+  }
+  {  // level 1: bucket t is one segment with its own look-back chain; lists of 32 buckets per XCD
+    const uint32_t tiles1 = (c + (uint32_t)tile_rows - 1) / (uint32_t)tile_rows;
+    uint32_t total1;
+    const uint32_t t0 = block_exclusive_scan<BINS>(tiles1, 0u, SumOp(), s_tmp, &total1);
+    hy.seg_start[1][t] = exc;
+    hy.seg_count[1][t] = c;
+    hy.seg_tile0[1][t] = t0;
+    if (t % (BINS / NRANGE) == 0) hy.list_tile0[1][t / (BINS / NRANGE)] = t0;
+    if (t == 0) {
+      hy.seg_tile0[1][BINS]    = total1;
+      hy.list_tile0[1][NRANGE] = total1;
+    }
   }
   if (t == 0) {
     uint32_t tiles = 0;
@@ -646,7 +660,9 @@ struct MsdArgs {
   uint32_t* vout;
   SortPlan* plan;
   unsigned long long* status;  // [tiles][256] look-back granules, epoch = level + 1
-  const uint32_t* base;        // [segments][256] output position of each bin of each segment
+  const uint32_t* base;        // level 0: [ranges][NB2MAX] output position of each bin of each input range
+  uint32_t* cellcount;         // level 1: [256][NB2MAX] keys per cell, written by the last tile of each bucket
+  uint32_t cellcap;            // level 1: every cell owns a slot of this many keys in the output buffer
   int64_t n;
   int level;
   int exp;  // experiment bits (GX_EXP environment variable)
@@ -681,13 +697,14 @@ __global__ void __launch_bounds__(BT, (KPT <= 8 ? 8 : (KPT <= 12 ? 6 : 4))) k_ms
   uint32_t* s_vals   = reinterpret_cast<uint32_t*>(smem + (size_t)TILE * sizeof(KeyT));  // [TILE] (HAS_VAL)
   uint32_t* s_whist  = s_vals + (HAS_VAL ? TILE : 0);                                    // [NW][NB]
   uint32_t* s_gdelta = s_whist + WROWS * NB;                                             // [NB]
-  uint32_t* s_scan   = s_gdelta + NB;                                                    // [16]
+  uint32_t* s_limit  = s_gdelta + NB;                                                    // [NB] end of each bin's output slot
+  uint32_t* s_scan   = s_limit + NB;                                                     // [16]
   uint32_t* s_misc   = s_scan + 16;                                                      // [4]
 
   SortPlan* plan = a.plan;
   HybridPlan& hy = plan->hy;
   const int lvl  = a.level;
-  if (!hy.attempt || (lvl == 1 && !hy.ok)) return;
+  if (!hy.attempt) return;
   const KeyT* kin      = static_cast<const KeyT*>(a.in);
   KeyT* kout           = static_cast<KeyT*>(a.out);
   const uint32_t* vin  = a.vin;
@@ -862,7 +879,24 @@ __global__ void __launch_bounds__(BT, (KPT <= 8 ? 8 : (KPT <= 12 ? 6 : 4))) k_ms
       }
       store_agent_u64(&a.status[(int64_t)gtile * NB + tid], pack_status(2u, epoch, prefix + pub_count));
     }
-    s_gdelta[tid] = a.base[seg * NB2MAX + tid] + prefix - bin_start;
+    uint32_t gb, lim = 0xFFFFFFFFu;
+    if (lvl == 0) {
+      gb = a.base[seg * NB2MAX + tid];
+    } else {
+      // Level 1 needs no histogram: cell (bucket, bin) owns a fixed slot of `cellcap` keys, this tile's keys go
+      // behind those of the bucket's earlier tiles (the look-back prefix), and the bucket's last tile leaves the
+      // cell sizes behind for k_plan2.  A cell that outgrows its slot (skewed keys) is cut off and flagged: the
+      // LSD passes then sort the column instead.
+      const bool live = tid < (1u << hy.bits2);
+      gb              = live ? ((seg << hy.bits2) + tid) * a.cellcap : 0u;
+      lim             = live ? gb + a.cellcap : 0u;
+      if (live) {
+        if (prefix + pub_count > a.cellcap) atomicExch(&hy.overflow, 1);
+        if (gtile + 1 == hy.seg_tile0[1][seg + 1]) a.cellcount[seg * NB2MAX + tid] = prefix + pub_count;
+      }
+    }
+    s_limit[tid]  = lim;
+    s_gdelta[tid] = gb + prefix - bin_start;
   }
   __syncthreads();
 
@@ -873,82 +907,18 @@ __global__ void __launch_bounds__(BT, (KPT <= 8 ? 8 : (KPT <= 12 ? 6 : 4))) k_ms
       const KeyT k       = s_keys[i];
       const uint32_t d   = (uint32_t)(to_sortable<KeyT, KIND>(k, desc_mask) >> shift) & dmask;
       const uint32_t dst = s_gdelta[d] + (uint32_t)i;
-      kout[dst]          = k;
-      if (HAS_VAL) vout[dst] = s_vals[i];
+      if (dst < s_limit[d]) {
+        kout[dst] = k;
+        if (HAS_VAL) vout[dst] = s_vals[i];
+      }
     }
   }
 }
 
-// Joint histogram hist2[level-0 digit][level-1 digit] over the level-0 output, which is sorted by the
-// level-0 digit: a 4096-key tile almost always holds ONE bucket, so the workgroup keeps an LDS histogram for
-// the current bucket and flushes it when the bucket changes; the <= 255 tiles that straddle a bucket
-// boundary use global atomics per key.
-constexpr int H2_BT = 256, H2_KPT = 16, H2_TILE = H2_BT * H2_KPT;
-template <typename KeyT, int KIND>
-__global__ void __launch_bounds__(H2_BT) k_hist2(const KeyT* __restrict__ in, int64_t n, KeyT desc_mask, SortPlan* plan,
-                                                 uint32_t* hist2)
-{
-  HybridPlan& hy = plan->hy;
-  if (!hy.attempt) return;
-  __shared__ uint32_t s_h[NB2MAX];
-  const int shift1     = hy.shift0;
-  const int shift2     = hy.shift2;
-  const uint32_t mask2 = (1u << hy.bits2) - 1u;
-  const int64_t ntile  = div_up(n, H2_TILE);
-  const int64_t per    = div_up(ntile, gridDim.x);
-  const int64_t t0     = (int64_t)blockIdx.x * per;
-  const int64_t t1     = t0 + per < ntile ? t0 + per : ntile;
-  auto flush = [&](int cur) {
-    for (int i = threadIdx.x; i < NB2MAX; i += H2_BT) {
-      const uint32_t c = s_h[i];
-      if (c && cur >= 0) atomicAdd(&hist2[cur * NB2MAX + i], c);
-      s_h[i] = 0;
-    }
-  };
-  int cur = -1;
-  flush(-1);
-  __syncthreads();
-  for (int64_t t = t0; t < t1; ++t) {
-    const int64_t base = t * H2_TILE;
-    const int64_t last = base + H2_TILE <= n ? base + H2_TILE - 1 : n - 1;
-    const int afirst   = (int)((to_sortable<KeyT, KIND>(in[base], desc_mask) >> shift1) & 0xFFu);
-    const int alast    = (int)((to_sortable<KeyT, KIND>(in[last], desc_mask) >> shift1) & 0xFFu);
-    KeyT k[H2_KPT];
-#pragma unroll
-    for (int j = 0; j < H2_KPT; ++j) {
-      const int64_t i = base + j * H2_BT + threadIdx.x;
-      k[j]            = (i < n) ? in[i] : KeyT(0);
-    }
-    if (afirst == alast) {  // uniform branch
-      if (afirst != cur) {
-        __syncthreads();
-        flush(cur);
-        cur = afirst;
-        __syncthreads();
-      }
-#pragma unroll
-      for (int j = 0; j < H2_KPT; ++j) {
-        const int64_t i = base + j * H2_BT + threadIdx.x;
-        if (i < n) atomicAdd(&s_h[(uint32_t)(to_sortable<KeyT, KIND>(k[j], desc_mask) >> shift2) & mask2], 1u);
-      }
-    } else {
-#pragma unroll
-      for (int j = 0; j < H2_KPT; ++j) {
-        const int64_t i = base + j * H2_BT + threadIdx.x;
-        if (i < n) {
-          const KeyT sk = to_sortable<KeyT, KIND>(k[j], desc_mask);
-          atomicAdd(&hist2[((uint32_t)(sk >> shift1) & 0xFFu) * NB2MAX + ((uint32_t)(sk >> shift2) & mask2)], 1u);
-        }
-      }
-    }
-  }
-  __syncthreads();
-  flush(cur);
-}
-
-// one block of 256 threads: thread b owns level-0 bucket b
-__global__ void __launch_bounds__(BINS) k_plan2(SortPlan* plan, const uint32_t* hist2, uint32_t* base2, int tile_rows,
-                                                int npass)
+// one block of 256 threads, after the level-1 pass: thread b owns level-0 bucket b.  Cell sizes -> output
+// position of every cell (cells in key order), largest cell, and the verdict: the local sort runs iff no cell
+// outgrew its slot and the cell sizes add up.
+__global__ void __launch_bounds__(BINS) k_plan2(SortPlan* plan, const uint32_t* cellcount, uint32_t* cellstart, int npass)
 {
   HybridPlan& hy = plan->hy;
   if (!hy.attempt) return;
@@ -959,31 +929,22 @@ __global__ void __launch_bounds__(BINS) k_plan2(SortPlan* plan, const uint32_t* 
   const int nb2        = 1 << hy.bits2;
   uint32_t run = start, mx = 0;
   for (int d2 = 0; d2 < nb2; ++d2) {
-    const uint32_t c       = hist2[b * NB2MAX + d2];
-    base2[b * NB2MAX + d2] = run;
+    const uint32_t c           = cellcount[b * NB2MAX + d2];
+    cellstart[b * NB2MAX + d2] = run;
     run += c;
     mx = c > mx ? c : mx;
   }
-  const int bad   = __syncthreads_or(run - start != count);
-  const uint32_t m = wave_reduce(mx, MaxOp());
+  const int overflow = hy.overflow;
+  const int bad      = __syncthreads_or(!overflow && run - start != count);
+  const uint32_t m   = wave_reduce(mx, MaxOp());
   if (lane_id() == 0) s_tmp[b / GX_WAVE] = m;
   __syncthreads();
   uint32_t maxcell = 0;
   for (int k = 0; k < BINS / GX_WAVE; ++k) maxcell = s_tmp[k] > maxcell ? s_tmp[k] : maxcell;
-  __syncthreads();
-  const uint32_t tiles = (count + (uint32_t)tile_rows - 1) / (uint32_t)tile_rows;
-  uint32_t total;
-  const uint32_t t0 = block_exclusive_scan<BINS>(tiles, 0u, SumOp(), s_tmp, &total);
-  hy.seg_start[1][b] = start;
-  hy.seg_count[1][b] = count;
-  hy.seg_tile0[1][b] = t0;
-  if (b % (BINS / NRANGE) == 0) hy.list_tile0[1][b / (BINS / NRANGE)] = t0;
   if (b == 0) {
-    hy.seg_tile0[1][BINS]    = total;
-    hy.list_tile0[1][NRANGE] = total;
-    hy.max_cell              = maxcell;
+    hy.max_cell = maxcell;
     if (bad) atomicExch(&plan->status, 3);
-    const int ok = (!bad && maxcell <= (uint32_t)hy.cell_max) ? 1 : 0;
+    const int ok = (!bad && !overflow && maxcell <= (uint32_t)hy.cell_max) ? 1 : 0;
     hy.ok        = ok;
     if (ok) {  // the LSD passes and the copy-only finalizer become no-ops
       for (int p = 0; p < npass; ++p) plan->pass_skip[p] = 1;
@@ -1007,10 +968,13 @@ __global__ void __launch_bounds__(BINS) k_plan2(SortPlan* plan, const uint32_t* 
 // involution); float keys (-0.0 / NaN payloads are not recoverable) and the row indices are staged
 // through the now free LDS buffer so that every HBM access stays coalesced.
 template <typename KeyT, int KIND, bool HAS_VAL, int CL2>
-__device__ __forceinline__ void pairs_write_out(KeyT* s_keys, const KeyT* __restrict__ in, KeyT* __restrict__ out,
-                                                const uint32_t* __restrict__ vin, uint32_t* __restrict__ vout,
+__device__ __forceinline__ void pairs_write_out(KeyT* s_keys, const KeyT* __restrict__ in_cell, KeyT* __restrict__ out,
+                                                const uint32_t* __restrict__ vin_cell, uint32_t* __restrict__ vout,
                                                 int64_t start, uint32_t m, int shift2, KeyT desc_mask)
 {
+  // in_cell / vin_cell point at the cell's slot; out / vout are indexed from `start`
+  const KeyT* in      = in_cell - start;
+  const uint32_t* vin = vin_cell ? vin_cell - start : nullptr;
   constexpr int LS_KPT = 16, LS_BT = (1 << CL2) / LS_KPT, LS_POS_BITS = CL2;
   const unsigned tid = threadIdx.x;
   const KeyT lowmask = (KeyT(1) << shift2) - KeyT(1);
@@ -1057,8 +1021,8 @@ __device__ __forceinline__ void pairs_write_out(KeyT* s_keys, const KeyT* __rest
 }
 
 template <typename KeyT, int KIND, bool HAS_VAL, int CL2>
-__global__ void __launch_bounds__((1 << CL2) / 16, 4) k_local_sort(const KeyT* __restrict__ in, KeyT* __restrict__ out,
-                                                      const uint32_t* __restrict__ vin, uint32_t* __restrict__ vout,
+__global__ void __launch_bounds__((1 << CL2) / 16, 4) k_local_sort(const KeyT* in, KeyT* __restrict__ out,
+                                                      const uint32_t* vin, uint32_t* __restrict__ vout,
                                                       KeyT desc_mask_in, SortPlan* plan,
                                                       const uint32_t* __restrict__ hist2, const uint32_t* __restrict__ base2,
                                                       int exp = 0)
@@ -1085,9 +1049,11 @@ __global__ void __launch_bounds__((1 << CL2) / 16, 4) k_local_sort(const KeyT* _
   if (blockIdx.x >= ((unsigned)BINS << bits2)) return;
   const uint32_t b  = blockIdx.x >> bits2;
   const uint32_t d2 = blockIdx.x & ((1u << bits2) - 1u);
-  const uint32_t m  = hist2[b * NB2MAX + d2];
+  const uint32_t m  = hist2[b * NB2MAX + d2];  // cell size (level-1 pass), output position (k_plan2)
   if (m == 0) return;
   const int64_t start = base2[b * NB2MAX + d2];
+  in += (int64_t)blockIdx.x * LOCAL_MAX - start;  // the cell sits in its slot of the padded level-1 buffer
+  if (HAS_VAL) vin += (int64_t)blockIdx.x * LOCAL_MAX - start;
   const unsigned tid  = threadIdx.x;
   const unsigned lane = lane_id();
   const unsigned w    = tid / GX_WAVE;
@@ -1185,7 +1151,7 @@ __global__ void __launch_bounds__((1 << CL2) / 16, 4) k_local_sort(const KeyT* _
       }
       __syncthreads();
       if (PAIRS) {
-        pairs_write_out<KeyT, KIND, HAS_VAL, CL2>(s_keys, in, out, vin, vout, start, m, hy.shift2, desc_mask_in);
+        pairs_write_out<KeyT, KIND, HAS_VAL, CL2>(s_keys, in + start, out, HAS_VAL ? vin + start : nullptr, vout, start, m, hy.shift2, desc_mask_in);
         return;
       }
 #pragma unroll
@@ -1271,7 +1237,7 @@ __global__ void __launch_bounds__((1 << CL2) / 16, 4) k_local_sort(const KeyT* _
     return;
   }
   if (PAIRS) {
-    pairs_write_out<KeyT, KIND, HAS_VAL, CL2>(s_keys, in, out, vin, vout, start, m, hy.shift2, desc_mask_in);
+    pairs_write_out<KeyT, KIND, HAS_VAL, CL2>(s_keys, in + start, out, HAS_VAL ? vin + start : nullptr, vout, start, m, hy.shift2, desc_mask_in);
     return;
   }
 #pragma unroll
@@ -1370,7 +1336,7 @@ int sort_impl(const void* keys_in, void* keys_out, const int32_t* vals_in, int32
   const int hyb_kpt     = hc.kpt;
   const int nb1         = hc.bits2 > 8 ? NB2MAX : BINS;  // bins (and look-back granules per tile) of the level-1 pass
   uint32_t* base1 = c.take<uint32_t>((size_t)NRANGE * NB2MAX);
-  uint32_t* hist2 = try_hybrid ? c.take<uint32_t>((size_t)2 * BINS * NB2MAX) : nullptr;  // hist2 | base2
+  uint32_t* hist2 = try_hybrid ? c.take<uint32_t>((size_t)2 * BINS * NB2MAX) : nullptr;  // cell sizes | cell output positions
   uint32_t* base2 = try_hybrid ? hist2 + BINS * NB2MAX : nullptr;
   const int64_t msd_tile     = (int64_t)BT * hyb_kpt;  // tile of the hybrid partition passes
   const int64_t msd_ntiles   = n > 0 ? div_up(n, msd_tile) : 0;
@@ -1382,9 +1348,13 @@ int sort_impl(const void* keys_in, void* keys_out, const int32_t* vals_in, int32
     tile_hist = c.take<uint32_t>((size_t)ntiles * BINS);
     partials  = c.take<uint32_t>(scan::partials_count(ntiles * BINS));
   }
-  KeyT* kb_scratch = c.take<KeyT>((size_t)n);
+  // the level-1 pass writes every cell into its own slot of 1 << cl2 keys (no joint histogram pass): the
+  // ping-pong scratch holds (256 << bits2) slots when that exceeds n
+  const size_t padded = try_hybrid ? ((size_t)BINS << hc.bits2) << hc.cl2 : 0;
+  const size_t nb_buf = padded > (size_t)n ? padded : (size_t)n;
+  KeyT* kb_scratch = c.take<KeyT>(nb_buf);
   KeyT* ka_scratch = keys_out ? nullptr : c.take<KeyT>((size_t)n);
-  uint32_t* vb     = HAS_VAL ? c.take<uint32_t>((size_t)n) : nullptr;
+  uint32_t* vb     = HAS_VAL ? c.take<uint32_t>(nb_buf) : nullptr;
   if (tmp == nullptr) {
     *tmp_bytes = c.total();
     return 0;
@@ -1412,7 +1382,7 @@ int sort_impl(const void* keys_in, void* keys_out, const int32_t* vals_in, int32
       constexpr size_t pay   = HAS_VAL ? 4 : 0;
       constexpr bool STABLE  = KIND == K_FLOAT || HAS_VAL;
       constexpr bool SMALLOK = !HAS_VAL && KIND != K_FLOAT;  // 8192-key cells and the 9-bit level 1 exist for these
-      auto lds_msd = [&](int kpt, int nb) { return (size_t)BT * kpt * (sizeof(KeyT) + pay) + (size_t)((STABLE ? NW : 2) * nb + nb + 16 + 4) * 4; };
+      auto lds_msd = [&](int kpt, int nb) { return (size_t)BT * kpt * (sizeof(KeyT) + pay) + (size_t)((STABLE ? NW : 2) * nb + 2 * nb + 16 + 4) * 4; };
       auto lds_loc = [&](int cl2) { return ((size_t)sizeof(KeyT) << cl2) + (size_t)(((1 << cl2) / 16 / GX_WAVE) * BINS + 32 + 2 * BINS) * 4; };
       typedef void (*MsdK)(MsdArgs);
       MsdK kmsd0 = HAS_VAL ? (MsdK)k_msd_pass<KeyT, KIND, HAS_VAL, 10, 4, 8>
@@ -1473,19 +1443,19 @@ int sort_impl(const void* keys_in, void* keys_out, const int32_t* vals_in, int32
       m.base      = base1;
       m.level     = 0;
       m.exp       = getenv("GX_EXP") ? atoi(getenv("GX_EXP")) : 0;
+      m.cellcount = hist2;
+      m.cellcap   = 1u << hc.cl2;
       prof_mark_h(0, stream);
       hipLaunchKernelGGL(kmsd0, dim3((unsigned)(msd_ntiles + NRANGE)), dim3(BT), lds_msd(hyb_kpt, BINS), stream, m);
       prof_mark_h(1, stream);
-      hipLaunchKernelGGL((k_hist2<KeyT, KIND>), dim3(2048), dim3(H2_BT), 0, stream, bufA, n, desc_mask, plan, hist2);
-      hipLaunchKernelGGL(k_plan2, dim3(1), dim3(BINS), 0, stream, plan, hist2, base2, (int)msd_tile, NPASS);
-      prof_mark_h(2, stream);
       m.in    = bufA;
       m.out   = bufB;
       m.vin   = valA;
       m.vout  = valB;
-      m.base  = base2;
       m.level = 1;
       hipLaunchKernelGGL(kmsd1, dim3((unsigned)(msd_ntiles + BINS + NRANGE)), dim3(BT), lds_msd(hyb_kpt, nb1), stream, m);
+      prof_mark_h(2, stream);
+      hipLaunchKernelGGL(k_plan2, dim3(1), dim3(BINS), 0, stream, plan, hist2, base2, NPASS);
       prof_mark_h(3, stream);
       hipLaunchKernelGGL(kloc, dim3((unsigned)(BINS << hc.bits2)), dim3(ls_bt), lds_loc(hc.cl2), stream, bufB, bufA, valB, valA, desc_mask,
                          plan, hist2, base2, m.exp);

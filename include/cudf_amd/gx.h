@@ -121,7 +121,7 @@ void gx_sort_set_algorithm(int algo);
 int gx_sort_profile(int enable);
 int gx_sort_profile_read(float* hist_ms, float* pass_ms, int* npass);
 /* durations of the hybrid path's kernels of the last profiled sort, in milliseconds:
- * ms4 = {level-0 partition pass, joint histogram + plan, level-1 partition pass, LDS local sort}.
+ * ms4 = {level-0 partition pass, level-1 partition pass, cell plan (one block), LDS local sort}.
  * GX_EINVAL when the last sort did not enqueue the hybrid path. */
 int gx_sort_profile_read_hybrid(float* ms4);
 
@@ -342,6 +342,45 @@ int gx_var_from_sums(int sum_dtype, const void* sum_sqr, const void* sum, const 
 int gx_groupby_arg_select(int val_dtype, const void* vals, const uint32_t* vals_valid,
                           const int32_t* group_of_row, int64_t n, const void* target, int64_t num_groups,
                           int32_t* out_rows, gx_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------
+ * Sort-based groupby building blocks: rows that are (or have been brought, through `order`) in key order.
+ * Replace compute_group_offsets / label_segments (cpp/src/groupby/sort/sort_helper.cu:151-214),
+ * thrust::reduce_by_key of the sort-path aggregations (sort/group_single_pass_reduction_util.cuh:133-200,
+ * sort/group_count.cu:25-89), segmented_shift (groupby.cu:306-346), group_replace_nulls
+ * (sort/group_replace_nulls.cu) and the rank scans of cpp/src/sort/rank.cu:60-330.
+ *
+ * gx_group_heads: heads[i] = 1 iff row order[i] differs from row order[i - 1] in this column (order NULL =
+ *   identity; heads[0] = 1; null == null, NaN == NaN, -0.0 == +0.0); combine != 0 ORs into `heads`, so a key
+ *   TABLE is one call per column.
+ * gx_group_offsets: labels[i] = group of sorted row i, offsets[g] = first sorted row of group g,
+ *   offsets[ngroups] = n (capacity n + 1), sizes (optional, capacity n) = rows per group; *ngroups_dev.
+ * gx_segmented_reduce: one value per group at out[label] -- op GX_OP_SUM / PRODUCT (integers -> INT64, floats
+ *   keep their type; float SUM in double-double: <= 1 ulp, order-independent), MIN / MAX (input type),
+ *   COUNT_VALID (out NULL); out_count_valid (optional) = valid values per group.  `vals` are in sorted order.
+ * gx_segmented_shift: out[i] = in[i - offset] when that row is in the same group, else the fill value
+ *   (fill_valid == 0: null); out_valid (optional) holds ceil(n/64)*2 words.
+ * gx_segmented_fill_nulls: replace_policy PRECEDING (backward == 0) / FOLLOWING: a null takes the nearest valid
+ *   value of its group before / after it, or stays null.
+ * gx_rank_from_groups: scatter ranks to out[order[i]]: method 0 FIRST, 1 AVERAGE, 2 MIN, 3 MAX, 4 DENSE
+ *   (rank_method, cpp/include/cudf/aggregation.hpp:91-98); scale > 0 = percentage (rank / scale, or
+ *   (rank - 1) / (scale - 1) when one_normalized); exactly one of out_i32 / out_f64.
+ * ------------------------------------------------------------------------------------------ */
+int gx_group_heads(int dtype, const void* col, const uint32_t* valid, const int32_t* order, int64_t n, int combine,
+                   uint8_t* heads, gx_stream_t stream);
+int gx_group_offsets(const uint8_t* heads, int64_t n, int32_t* labels, int32_t* offsets, int32_t* sizes,
+                     int64_t* ngroups_dev, void* tmp, size_t* tmp_bytes, gx_stream_t stream);
+int gx_segmented_reduce(int val_dtype, const void* vals, const uint32_t* vals_valid, const uint8_t* heads,
+                        const int32_t* labels, int64_t n, int op, void* out, int32_t* out_count_valid, void* tmp,
+                        size_t* tmp_bytes, gx_stream_t stream);
+int gx_segmented_shift(int elem_size, const void* in, const uint32_t* in_valid, const int32_t* labels, int64_t n,
+                       int64_t offset, uint64_t fill_bits, int fill_valid, void* out, uint32_t* out_valid,
+                       gx_stream_t stream);
+int gx_segmented_fill_nulls(int elem_size, const void* in, const uint32_t* in_valid, const uint8_t* heads, int64_t n,
+                            int backward, void* out, uint32_t* out_valid, void* tmp, size_t* tmp_bytes,
+                            gx_stream_t stream);
+int gx_rank_from_groups(const int32_t* order, const int32_t* labels, const int32_t* offsets, int64_t n, int method,
+                        double scale, int one_normalized, int32_t* out_i32, double* out_f64, gx_stream_t stream);
 
 /* Tuning / A-B knob (process-wide).  algo: 0 = auto (hash-partition rows into 256 LDS-sized
  * partitions and aggregate each in one workgroup's LDS when n >= 2^19, else the global-atomic

@@ -395,11 +395,11 @@ def test_single_key_left_join_with_nulls_on_both_sides(gx, dtype, nulls_equal):
     lm, rm = rng.random(nl) > 0.1, rng.random(nr) > 0.2
     l, r = ops.left_join(Column.from_numpy(lv, lm), Column.from_numpy(rv, rm), nulls_equal)
     gl, gr = orc.canonical_pairs(l.to_numpy(), r.to_numpy())
-    el, er = orc.left_join(lv, rv, lm, rm, nulls_equal)
+    el, er = orc.left_join([lv], [rv], [lm], [rm], nulls_equal)
     np.testing.assert_array_equal(gl, el)
     np.testing.assert_array_equal(gr, er)
     l, r = ops.inner_join(Column.from_numpy(lv, lm), Column.from_numpy(rv, rm), nulls_equal)
     gl, gr = orc.canonical_pairs(l.to_numpy(), r.to_numpy())
-    el, er = orc.inner_join(lv, rv, lm, rm, nulls_equal)
+    el, er = orc.inner_join([lv], [rv], [lm], [rm], nulls_equal)
     np.testing.assert_array_equal(gl, el)
     np.testing.assert_array_equal(gr, er)
