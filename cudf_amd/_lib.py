@@ -85,6 +85,7 @@ _PROTOS = {
     "gx_segmented_shift": (_i, [_i, _p, _p, _p, _i64, _i64, ctypes.c_uint64, _i, _p, _p, _p]),
     "gx_segmented_fill_nulls": (_i, [_i, _p, _p, _p, _i64, _i, _p, _p, _p, _sz, _p]),
     "gx_rank_from_groups": (_i, [_p, _p, _p, _i64, _i, ctypes.c_double, _i, _p, _p, _p]),
+    "gx_segment_ids": (_i, [_p, _i64, _i64, _p, _p]),
     "gx_segmented_scan": (_i, [_i, _p, _i, _p, _p, _i64, _i, _p, _p, _sz, _p]),
     "gx_reduce": (_i, [_i, _p, _p, _i64, _i, _i, _p, _p, _p, _sz, _p]),
     "gx_scan": (_i, [_i, _p, _p, _i64, _i, _i, _p, _p, _sz, _p]),

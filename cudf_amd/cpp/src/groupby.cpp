@@ -3,6 +3,7 @@
 // scan path cpp/src/groupby/sort/{scan.cpp:214-238, sort_helper.cu:73-162, group_scan_util.cuh:77-133}.
 #include "common.hpp"
 #include "row_encoding.hpp"
+#include "sort_helper.hpp"
 
 #include <cudf/column/column_factories.hpp>
 #include <cudf/copying.hpp>
@@ -55,7 +56,6 @@ hash_agg_out hash_aggregate(column_view const& keys, column_view const& vals, rm
       },
       "groupby aggregate", stream);
     auto const groups = detail::read_i64(static_cast<int64_t const*>(ng.data()), stream);
-    if (getenv("CUDF_AMD_DEBUG")) std::fprintf(stderr, "hash_aggregate: n=%d max_groups=%ld groups=%ld\n", (int)n, (long)max_groups, (long)groups);
     if (groups >= 0 && groups <= max_groups) {
       // trim the columns to the group count (buffers keep their capacity)
       auto trim = [&](std::unique_ptr<column>& c) {
@@ -150,8 +150,13 @@ std::pair<std::unique_ptr<table>, std::vector<aggregation_result>> groupby::aggr
                            [this](auto const& r) { return r.values.size() == _keys.num_rows(); }),
                "Size mismatch between request values and groupby keys.", std::invalid_argument);
   CUDF_EXPECTS(_keys.num_columns() >= 1, "groupby needs at least one key column");
-  CUDF_EXPECTS(_include_null_keys == null_policy::EXCLUDE || !cudf::has_nulls(_keys),
-               "null_policy::INCLUDE with null keys is not supported on this path yet");
+  // groupby.cu:54-71 dispatch_aggregation: hash-based only when the keys are not pre-sorted and every aggregation is one
+  // the hash kernels implement; here also when no null key has to be KEPT (the hash tables drop null keys).
+  bool sort_path = _keys_are_sorted == sorted::YES || (_include_null_keys == null_policy::INCLUDE && cudf::has_nulls(_keys));
+  for (auto const& r : requests)
+    for (auto const& agg : r.aggregations)
+      sort_path = sort_path || agg->kind == aggregation::PRODUCT || agg->kind == aggregation::NTH_ELEMENT;
+  if (sort_path && _keys.num_rows() > 0 && !requests.empty()) return sort_aggregate(requests, stream, mr);
   // One 32/64-bit integer key column goes to the hash kernels as it is; anything else (several columns,
   // floats, narrow types) is first encoded into dense INT32 row ids (gx_dense_rank), aggregated by id, and
   // the key columns are gathered back through the first row of every id.
@@ -418,18 +423,21 @@ std::pair<std::unique_ptr<table>, std::vector<aggregation_result>> groupby::scan
   CUDF_EXPECTS(std::all_of(requests.begin(), requests.end(),
                            [this](auto const& r) { return r.values.size() == _keys.num_rows(); }),
                "Size mismatch between request values and groupby keys.", std::invalid_argument);
-  CUDF_EXPECTS(_keys.num_columns() == 1, "multi-column groupby keys are not supported on this path yet");
-  auto const& keys = _keys.column(0);
+  // sort helper: stable order of the keys (skipped when they are pre-sorted), nulls AFTER (sort_helper.cu:92-94);
+  // null keys are dropped under null_policy::EXCLUDE.  Any number of key columns.
+  auto& h           = helper();
+  auto const kept   = h.num_keys(stream);
+  auto const* labels = h.group_labels(stream);
   std::vector<aggregation_result> results(requests.size());
-  // sort helper: stable order of the keys, nulls AFTER (sort_helper.cu:92-94); null keys are dropped
-  auto order       = cudf::stable_sorted_order(_keys, {}, {null_order::AFTER}, stream);
-  auto const kept  = _include_null_keys == null_policy::EXCLUDE ? keys.size() - keys.null_count() : keys.size();
-  column_view omap{data_type{type_id::INT32}, kept, order->view().head<void>(), nullptr, 0};
-  auto sorted_keys = cudf::gather(_keys, omap, out_of_bounds_policy::DONT_CHECK, stream, mr);
-  column_view const sk = sorted_keys->view().column(0);  // by value: view() is a temporary
   for (std::size_t i = 0; i < requests.size(); ++i) {
-    auto vals = cudf::gather(table_view{{requests[i].values}}, omap, out_of_bounds_policy::DONT_CHECK, stream, mr);
-    column_view const sv = vals->view().column(0);
+    std::unique_ptr<column> owner;
+    column_view sv = requests[i].values;
+    if (!h.is_presorted()) {
+      owner = h.grouped_values(requests[i].values, stream, mr);
+      sv    = owner->view();
+    }
+    rmm::device_buffer vh;
+    auto const* vmask = sv.has_nulls() ? detail::rebased_mask(sv, vh, stream) : nullptr;
     for (auto const& agg : requests[i].aggregations) {
       int op = -1;
       if (agg->kind == aggregation::SUM) op = GX_OP_SUM;
@@ -438,21 +446,26 @@ std::pair<std::unique_ptr<table>, std::vector<aggregation_result>> groupby::scan
       CUDF_EXPECTS(op >= 0, "groupby scan kind not implemented on this path (SUM, MIN, MAX are)");
       data_type const ot = (op == GX_OP_SUM) ? sum_type(sv.type()) : sv.type();
       auto out = make_fixed_width_column(ot, kept, mask_state::UNALLOCATED, stream, mr);
-      detail::run_with_scratch(
-        [&](void* t, std::size_t* b) {
-          return gx_segmented_scan(detail::gx_type(sk.type()), detail::row0(sk), detail::gx_type(sv.type()), detail::row0(sv),
-                                   sv.has_nulls() ? sv.null_mask() : nullptr, kept, op, out->mutable_view().head<void>(), t, b,
-                                   detail::gxs(stream));
-        },
-        "groupby scan", stream);
-      if (sv.nullable()) {  // null rows stay null
-        out->set_null_mask(rmm::device_buffer{sv.null_mask(), bitmask_allocation_size_bytes(kept), stream, mr}, sv.null_count());
+      if (kept > 0)
+        detail::run_with_scratch(
+          [&](void* t, std::size_t* b) {
+            // the group labels stand in for the keys: an INT32 "key" column whose runs are the groups
+            return gx_segmented_scan(GX_INT32, labels, detail::gx_type(sv.type()), detail::row0(sv), vmask, kept, op,
+                                     out->mutable_view().head<void>(), t, b, detail::gxs(stream));
+          },
+          "groupby scan", stream);
+      if (sv.nullable() && kept > 0) {  // null rows stay null
+        rmm::device_buffer m{bitmask_allocation_size_bytes(kept), stream, mr};
+        CUDF_CUDA_TRY(hipMemsetAsync(m.data(), 0, m.size(), stream.value()));
+        detail::gx_check(gx_bitmask_copy(static_cast<uint32_t*>(m.data()), 0, sv.null_mask(), sv.offset(), kept, detail::gxs(stream)),
+                         "groupby scan validity");
+        out->set_null_mask(std::move(m), sv.null_count());
       }
       results[i].results.emplace_back(std::move(out));
     }
     stream.synchronize();
   }
-  return {std::move(sorted_keys), std::move(results)};
+  return {h.sorted_keys(stream, mr), std::move(results)};
 }
 
 }  // namespace groupby

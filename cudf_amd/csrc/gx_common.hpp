@@ -312,6 +312,116 @@ __device__ __forceinline__ bool wave_split_sort(uint64_t* keys, uint32_t cnt, ui
   return true;
 }
 
+// Inclusive +-scan of one uint32 per lane over the wave with DPP row shifts and row broadcasts (gfx9 family:
+// row_shr:1/2/4/8 inside each row of 16 lanes, row_bcast:15 into rows 1 and 3, row_bcast:31 into rows 2 and 3):
+// 6 VALU steps, no LDS crossbar round trips (the __shfl_up form costs one ds_bpermute + wait per step).
+__device__ __forceinline__ uint32_t wave_inclusive_sum_dpp(uint32_t v)
+{
+  v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x111, 0xF, 0xF, false);
+  v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x112, 0xF, 0xF, false);
+  v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x114, 0xF, 0xF, false);
+  v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x118, 0xF, 0xF, false);
+  v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x142, 0xA, 0xF, false);
+  v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x143, 0xC, 0xF, false);
+  return v;
+}
+
+// wave_split_sort for TWO sub-buckets at once (A and B, each <= 128 keys): the two dependency chains -- zero the
+// counters, rank with returning LDS atomics, scan, scatter, read back, odd-even clean-up -- are issued interleaved,
+// so each LDS round trip of one hides behind the other's.  The 256 counters of a sub-bucket are 16-bit halves of
+// 128 words (counts <= 128), which fits both arrays into the wave's 1 KiB counter row `cw`.  Returns bit 0 / bit 1
+// = A / B sorted into (a0, a1) / (b0, b1), lane l holding elements 2l and 2l + 1; a sub-bucket whose bit is clear
+// had a bin with more than four keys and is untouched in LDS (the caller falls back to the network).
+// cntB == 0: only A is processed.
+__device__ __forceinline__ unsigned wave_split_sort_x2(uint64_t* keysA, uint32_t cntA, uint64_t* keysB, uint32_t cntB,
+                                                       uint32_t* cw /* 256 words, 16-B aligned */, int sh, uint64_t& a0,
+                                                       uint64_t& a1, uint64_t& b0, uint64_t& b1)
+{
+  const unsigned lane = lane_id();
+  const uint32_t e0 = 2 * lane, e1 = 2 * lane + 1;
+  uint32_t* cwA = cw;
+  uint32_t* cwB = cw + 128;
+  a0 = e0 < cntA ? keysA[e0] : ~0ull;
+  a1 = e1 < cntA ? keysA[e1] : ~0ull;
+  b0 = e0 < cntB ? keysB[e0] : ~0ull;
+  b1 = e1 < cntB ? keysB[e1] : ~0ull;
+  reinterpret_cast<uint2*>(cwA)[lane] = make_uint2(0u, 0u);
+  reinterpret_cast<uint2*>(cwB)[lane] = make_uint2(0u, 0u);
+  const uint32_t ba0 = (uint32_t)(a0 >> sh) & 0xFFu, ba1 = (uint32_t)(a1 >> sh) & 0xFFu;
+  const uint32_t bb0 = (uint32_t)(b0 >> sh) & 0xFFu, bb1 = (uint32_t)(b1 >> sh) & 0xFFu;
+  // rank inside the bin: old value of the bin's 16-bit half
+  uint32_t ra0 = 0, ra1 = 0, rb0 = 0, rb1 = 0;
+  if (e0 < cntA) ra0 = atomicAdd(&cwA[ba0 >> 1], 1u << (16 * (ba0 & 1)));
+  if (e0 < cntB) rb0 = atomicAdd(&cwB[bb0 >> 1], 1u << (16 * (bb0 & 1)));
+  if (e1 < cntA) ra1 = atomicAdd(&cwA[ba1 >> 1], 1u << (16 * (ba1 & 1)));
+  if (e1 < cntB) rb1 = atomicAdd(&cwB[bb1 >> 1], 1u << (16 * (bb1 & 1)));
+  ra0 = (ra0 >> (16 * (ba0 & 1))) & 0xFFFFu;
+  ra1 = (ra1 >> (16 * (ba1 & 1))) & 0xFFFFu;
+  rb0 = (rb0 >> (16 * (bb0 & 1))) & 0xFFFFu;
+  rb1 = (rb1 >> (16 * (bb1 & 1))) & 0xFFFFu;
+  const uint2 ca = reinterpret_cast<uint2*>(cwA)[lane];  // bins 4l .. 4l + 3
+  const uint2 cb = reinterpret_cast<uint2*>(cwB)[lane];
+  const uint32_t ca0 = ca.x & 0xFFFFu, ca1 = ca.x >> 16, ca2 = ca.y & 0xFFFFu, ca3 = ca.y >> 16;
+  const uint32_t cb0 = cb.x & 0xFFFFu, cb1 = cb.x >> 16, cb2 = cb.y & 0xFFFFu, cb3 = cb.y >> 16;
+  uint32_t mxa = ca0 > ca1 ? ca0 : ca1, mxb = cb0 > cb1 ? cb0 : cb1;
+  mxa = ca2 > mxa ? ca2 : mxa;
+  mxb = cb2 > mxb ? cb2 : mxb;
+  mxa = ca3 > mxa ? ca3 : mxa;
+  mxb = cb3 > mxb ? cb3 : mxb;
+  const bool okA = cntA > 0 && ballot(mxa > 4u) == 0;  // wave-uniform
+  const bool okB = cntB > 0 && ballot(mxb > 4u) == 0;
+  const uint32_t suma = ca0 + ca1 + ca2 + ca3, sumb = cb0 + cb1 + cb2 + cb3;
+  uint32_t runa = wave_inclusive_sum_dpp(suma) - suma;
+  uint32_t runb = wave_inclusive_sum_dpp(sumb) - sumb;
+  uint2 sa, sb2;
+  sa.x = runa | ((runa + ca0) << 16);
+  runa += ca0 + ca1;
+  sa.y = runa | ((runa + ca2) << 16);
+  sb2.x = runb | ((runb + cb0) << 16);
+  runb += cb0 + cb1;
+  sb2.y = runb | ((runb + cb2) << 16);
+  if (okA) reinterpret_cast<uint2*>(cwA)[lane] = sa;
+  if (okB) reinterpret_cast<uint2*>(cwB)[lane] = sb2;
+  if (okA) {
+    if (e0 < cntA) keysA[((cwA[ba0 >> 1] >> (16 * (ba0 & 1))) & 0xFFFFu) + ra0] = a0;
+    if (e1 < cntA) keysA[((cwA[ba1 >> 1] >> (16 * (ba1 & 1))) & 0xFFFFu) + ra1] = a1;
+  }
+  if (okB) {
+    if (e0 < cntB) keysB[((cwB[bb0 >> 1] >> (16 * (bb0 & 1))) & 0xFFFFu) + rb0] = b0;
+    if (e1 < cntB) keysB[((cwB[bb1 >> 1] >> (16 * (bb1 & 1))) & 0xFFFFu) + rb1] = b1;
+  }
+  if (okA) {
+    a0 = e0 < cntA ? keysA[e0] : ~0ull;
+    a1 = e1 < cntA ? keysA[e1] : ~0ull;
+  }
+  if (okB) {
+    b0 = e0 < cntB ? keysB[e0] : ~0ull;
+    b1 = e1 < cntB ? keysB[e1] : ~0ull;
+  }
+#pragma unroll
+  for (int ph = 0; ph < 2; ++ph) {
+    {  // even phase: (2l, 2l+1) inside the lane
+      const bool swa     = a1 < a0;
+      const uint64_t loa = swa ? a1 : a0, hia = swa ? a0 : a1;
+      a0 = loa;
+      a1 = hia;
+      const bool swb     = b1 < b0;
+      const uint64_t lob = swb ? b1 : b0, hib = swb ? b0 : b1;
+      b0 = lob;
+      b1 = hib;
+    }
+    {  // odd phase: (2l+1, 2l+2): lane l's k1 with lane l+1's k0
+      const uint64_t nxa = dpp_wave_shl1_u64(a0, ~0ull), pva = dpp_wave_shr1_u64(a1, 0ull);
+      const uint64_t nxb = dpp_wave_shl1_u64(b0, ~0ull), pvb = dpp_wave_shr1_u64(b1, 0ull);
+      a1 = nxa < a1 ? nxa : a1;
+      a0 = pva > a0 ? pva : a0;
+      b1 = nxb < b1 ? nxb : b1;
+      b0 = pvb > b0 ? pvb : b0;
+    }
+  }
+  return (okA ? 1u : 0u) | (okB ? 2u : 0u);
+}
+
 // bits -> unsigned key whose unsigned order is the cudf order (KIND 0 unsigned, 1 signed, 2 float).
 //  signed: sign flip.  float: -0.0 -> +0.0, NaN -> all ones (after +Inf; all NaNs equivalent),
 //  then the IEEE total-order flip.  desc_mask (0 or ~0) reverses the order.  Equal sortable bits

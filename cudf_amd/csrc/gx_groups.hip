@@ -166,7 +166,7 @@ __global__ void __launch_bounds__(256) k_rank(const int32_t* __restrict__ order,
 {
   const int64_t stride = (int64_t)gridDim.x * 256;
   for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += stride) {
-    const int32_t g = labels[i];
+    const int32_t g = method == 0 ? 0 : labels[i];
     double r;
     switch (method) {
       case 0: r = (double)(i + 1); break;
@@ -178,6 +178,27 @@ __global__ void __launch_bounds__(256) k_rank(const int32_t* __restrict__ order,
     if (scale > 0.0) r = one_normalized ? (scale > 1.0 ? (r - 1.0) / (scale - 1.0) : 0.0) : r / scale;
     const int32_t row = order ? order[i] : (int32_t)i;
     if (out_f64) out_f64[row] = r; else out_i32[row] = (int32_t)r;
+  }
+}
+
+// ---- segment id of every row for a segmented sort (cpp/src/sort/segmented_sort_impl.cuh:178-203): rows of segment
+// [offsets[j], offsets[j+1]) get offsets[j+1]; rows before the first / from the last offset on get unique ascending ids
+// (their own index / index + 1), so they keep their place.
+__global__ void __launch_bounds__(256) k_segment_ids(const int32_t* __restrict__ offsets, int64_t noff, int64_t n,
+                                                     int32_t* __restrict__ ids)
+{
+  const int64_t stride = (int64_t)gridDim.x * 256;
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += stride) {
+    int64_t lo = 0, hi = noff;  // first offset > i
+    while (lo < hi) {
+      const int64_t mid = (lo + hi) / 2;
+      if ((int64_t)offsets[mid] <= i) lo = mid + 1; else hi = mid;
+    }
+    int32_t id;
+    if (lo == 0) id = (int32_t)i;                  // before the first segment (or no offsets at all)
+    else if (lo < noff) id = offsets[lo];          // inside segment lo - 1
+    else id = (int32_t)i + 1;                      // from the last offset on
+    ids[i] = id;
   }
 }
 
@@ -305,10 +326,20 @@ int gx_rank_from_groups(const int32_t* order, const int32_t* labels, const int32
                         int one_normalized, int32_t* out_i32, double* out_f64, gx_stream_t s)
 {
   using namespace gx::grp;
-  if (n < 0 || method < 0 || method > 4 || (n > 0 && (!labels || !offsets || (!out_i32 && !out_f64)))) return GX_EINVAL;
+  if (n < 0 || method < 0 || method > 4 || (n > 0 && ((method != 0 && (!labels || !offsets)) || (!out_i32 && !out_f64)))) return GX_EINVAL;
   if (n == 0) return 0;
   hipLaunchKernelGGL(k_rank, dim3(grid_for(n)), dim3(256), 0, s, order, labels, offsets, n, method, scale, one_normalized, out_i32,
                      out_f64);
+  GX_LAUNCH_CHECK();
+  return 0;
+}
+
+int gx_segment_ids(const int32_t* offsets, int64_t num_offsets, int64_t num_rows, int32_t* ids, gx_stream_t s)
+{
+  using namespace gx::grp;
+  if (num_offsets < 0 || num_rows < 0 || (num_rows > 0 && !ids) || (num_offsets > 0 && !offsets)) return GX_EINVAL;
+  if (num_rows == 0) return 0;
+  hipLaunchKernelGGL(k_segment_ids, dim3(grid_for(num_rows)), dim3(256), 0, s, offsets, num_offsets, num_rows, ids);
   GX_LAUNCH_CHECK();
   return 0;
 }

@@ -54,6 +54,8 @@ struct HybridPlan {
   int32_t need_hist;      // the speculative top-byte histogram is not the level-0 digit: k_hy_hist<false> runs
   int32_t cell_max;       // capacity of a local-sort cell (8192 or 16384)
   int32_t overflow;       // level 1: a cell outgrew its slot (skewed keys) -> LSD fallback
+  int32_t bad;            // k_plan2: the cell sizes of a bucket do not add up to the bucket (protocol failure)
+  uint32_t plan2_done;    // k_plan2: buckets finished (the last one decides)
   unsigned long long or_mask, nor_mask;  // OR of the sortable keys / of their complements
   uint32_t list_tile0[2][NRANGE + 1];  // first global tile of each list
   uint32_t seg_tile0[2][BINS + 1];     // first global tile of each segment (level 0: NRANGE segments)
@@ -915,40 +917,53 @@ __global__ void __launch_bounds__(BT, (KPT <= 8 ? 8 : (KPT <= 12 ? 6 : 4))) k_ms
   }
 }
 
-// one block of 256 threads, after the level-1 pass: thread b owns level-0 bucket b.  Cell sizes -> output
-// position of every cell (cells in key order), largest cell, and the verdict: the local sort runs iff no cell
-// outgrew its slot and the cell sizes add up.
-__global__ void __launch_bounds__(BINS) k_plan2(SortPlan* plan, const uint32_t* cellcount, uint32_t* cellstart, int npass)
+// After the level-1 pass, one wave per level-0 bucket: cell sizes -> output position of every cell (cells in key
+// order: a bucket starts at its histogram offset), largest cell; the bucket that finishes last gives the verdict:
+// the local sort runs iff no cell outgrew its slot and the cell sizes add up.
+__global__ void __launch_bounds__(GX_WAVE) k_plan2(SortPlan* plan, const uint32_t* __restrict__ cellcount,
+                                                   uint32_t* __restrict__ cellstart, int npass)
 {
   HybridPlan& hy = plan->hy;
   if (!hy.attempt) return;
-  __shared__ uint32_t s_tmp[BINS / GX_WAVE + 1];
-  const int b          = threadIdx.x;
+  constexpr int PER    = NB2MAX / GX_WAVE;  // 8 consecutive cells per lane
+  const int b          = blockIdx.x;
+  const unsigned lane  = lane_id();
   const uint32_t start = hy.gbin0[b];
   const uint32_t count = hy.hist0[b];
   const int nb2        = 1 << hy.bits2;
-  uint32_t run = start, mx = 0;
-  for (int d2 = 0; d2 < nb2; ++d2) {
-    const uint32_t c           = cellcount[b * NB2MAX + d2];
-    cellstart[b * NB2MAX + d2] = run;
-    run += c;
-    mx = c > mx ? c : mx;
+  uint32_t c[PER], sum = 0, mx = 0;
+#pragma unroll
+  for (int k = 0; k < PER; ++k) {
+    const int d2 = (int)lane * PER + k;
+    c[k]         = d2 < nb2 ? cellcount[b * NB2MAX + d2] : 0u;
+    sum += c[k];
+    mx = c[k] > mx ? c[k] : mx;
   }
-  const int overflow = hy.overflow;
-  const int bad      = __syncthreads_or(!overflow && run - start != count);
-  const uint32_t m   = wave_reduce(mx, MaxOp());
-  if (lane_id() == 0) s_tmp[b / GX_WAVE] = m;
-  __syncthreads();
-  uint32_t maxcell = 0;
-  for (int k = 0; k < BINS / GX_WAVE; ++k) maxcell = s_tmp[k] > maxcell ? s_tmp[k] : maxcell;
-  if (b == 0) {
-    hy.max_cell = maxcell;
-    if (bad) atomicExch(&plan->status, 3);
-    const int ok = (!bad && !overflow && maxcell <= (uint32_t)hy.cell_max) ? 1 : 0;
-    hy.ok        = ok;
-    if (ok) {  // the LSD passes and the copy-only finalizer become no-ops
-      for (int p = 0; p < npass; ++p) plan->pass_skip[p] = 1;
-      plan->num_active = -1;
+  const uint32_t inc = wave_inclusive_sum_dpp(sum);
+  uint32_t run       = start + inc - sum;
+#pragma unroll
+  for (int k = 0; k < PER; ++k) {
+    const int d2 = (int)lane * PER + k;
+    if (d2 < nb2) cellstart[b * NB2MAX + d2] = run;
+    run += c[k];
+  }
+  const uint32_t total = shfl(inc, GX_WAVE - 1);
+  mx                   = wave_reduce(mx, MaxOp());
+  if (lane == 0) {
+    atomicMax(&hy.max_cell, mx);
+    if (total != count) atomicExch(&hy.bad, 1);
+    __threadfence();
+    if (atomicAdd(&hy.plan2_done, 1u) == (uint32_t)BINS - 1u) {  // every bucket is in
+      const int overflow     = atomicAdd(&hy.overflow, 0);
+      const int bad          = !overflow && atomicAdd(&hy.bad, 0);
+      const uint32_t maxcell = atomicMax(&hy.max_cell, 0u);
+      if (bad) atomicExch(&plan->status, 3);
+      const int ok = (!bad && !overflow && maxcell <= (uint32_t)hy.cell_max) ? 1 : 0;
+      hy.ok        = ok;
+      if (ok) {  // the LSD passes and the copy-only finalizer become no-ops
+        for (int p = 0; p < npass; ++p) plan->pass_skip[p] = 1;
+        plan->num_active = -1;
+      }
     }
   }
 }
@@ -1103,26 +1118,21 @@ __global__ void __launch_bounds__((1 << CL2) / 16, 4) k_local_sort(const KeyT* i
         if ((uint32_t)idx < m) s_keys[s_start[(uint32_t)(key[j] >> sshift) & (uint32_t)(NSB - 1)] + rank[j]] = key[j];
       }
       __syncthreads();
-      for (int sb = (int)w; sb < NSB; sb += LS_NW) {
-        if (exp & 4) break;  // ablation: no sorting networks
-        const uint32_t cnt = s_cnt[sb], o = s_start[sb];
-        if (cnt <= 1) continue;
-        // counting split on the next byte + odd-even clean-up; the network only when a bin is crowded.
-        // Plain integer keys leave straight from the registers (1 KiB per wave and sub-bucket); packed
-        // words go back to LDS for the gathering write-out.
-        KeyT* sub = s_keys + o;
-        uint64_t k0, k1;
-        if (sshift >= 8 && !(exp & 16) && wave_split_sort(reinterpret_cast<uint64_t*>(sub), cnt, my_hist, sshift - 8, k0, k1)) {
-          const uint32_t e0 = 2 * lane, e1 = 2 * lane + 1;
-          if (PAIRS) {
-            if (e0 < cnt) sub[e0] = (KeyT)k0;
-            if (e1 < cnt) sub[e1] = (KeyT)k1;
-          } else {
-            if (e0 < cnt) out[start + o + e0] = to_sortable<KeyT, KIND>((KeyT)k0, desc_mask);
-            if (e1 < cnt) out[start + o + e1] = to_sortable<KeyT, KIND>((KeyT)k1, desc_mask);
-          }
-          continue;
+      // sorted sub-bucket in registers (lane l: elements 2l, 2l + 1) -> LDS (packed words: the gathering write-out
+      // needs them) or straight to HBM (plain integer keys: 1 KiB per wave and sub-bucket)
+      auto emit2 = [&](KeyT* sub, uint32_t cnt, uint32_t o, uint64_t k0, uint64_t k1) {
+        const uint32_t e0 = 2 * lane, e1 = 2 * lane + 1;
+        if (PAIRS) {
+          if (e0 < cnt) sub[e0] = (KeyT)k0;
+          if (e1 < cnt) sub[e1] = (KeyT)k1;
+        } else {
+          if (e0 < cnt) out[start + o + e0] = to_sortable<KeyT, KIND>((KeyT)k0, desc_mask);
+          if (e1 < cnt) out[start + o + e1] = to_sortable<KeyT, KIND>((KeyT)k1, desc_mask);
         }
+      };
+      // crowded bin (or too few bits left for a counting split): the in-register bitonic network
+      auto network = [&](KeyT* sub, uint32_t cnt, uint32_t o) {
+        uint64_t k0, k1;
         if (cnt <= 64) {
           k0 = lane < cnt ? (uint64_t)sub[lane] : ~0ull;
           wave_bitonic64(k0);
@@ -1141,6 +1151,27 @@ __global__ void __launch_bounds__((1 << CL2) / 16, 4) k_local_sort(const KeyT* i
             if (lane + 64 < cnt) out[start + o + 64 + lane] = to_sortable<KeyT, KIND>((KeyT)k1, desc_mask);
           }
         }
+      };
+      // every wave takes its sub-buckets two at a time: counting split on the next byte + odd-even clean-up for
+      // both, their LDS round trips interleaved (wave_split_sort_x2)
+      for (int sb = (int)w; sb < NSB; sb += 2 * LS_NW) {
+        if (exp & 4) break;  // ablation: no sorting step
+        const int sbB       = sb + LS_NW;
+        const uint32_t cntA = s_cnt[sb], oA = s_start[sb];
+        const uint32_t cntB = sbB < NSB ? s_cnt[sbB] : 0u, oB = sbB < NSB ? s_start[sbB] : 0u;
+        const bool doA = cntA > 1, doB = cntB > 1;
+        if (!doA && !doB) continue;
+        KeyT* subA = s_keys + oA;
+        KeyT* subB = s_keys + oB;
+        unsigned okm = 0;
+        uint64_t a0 = 0, a1 = 0, b0 = 0, b1 = 0;
+        if (sshift >= 8 && !(exp & 16))
+          okm = wave_split_sort_x2(reinterpret_cast<uint64_t*>(subA), doA ? cntA : 0u, reinterpret_cast<uint64_t*>(subB),
+                                   doB ? cntB : 0u, my_hist, sshift - 8, a0, a1, b0, b1);
+        if (okm & 1u) emit2(subA, cntA, oA, a0, a1);
+        else if (doA) network(subA, cntA, oA);
+        if (okm & 2u) emit2(subB, cntB, oB, b0, b1);
+        else if (doB) network(subB, cntB, oB);
       }
       if (!PAIRS) {
         // sub-buckets of 0 or 1 keys were skipped by the loop above: they leave here
@@ -1455,7 +1486,7 @@ int sort_impl(const void* keys_in, void* keys_out, const int32_t* vals_in, int32
       m.level = 1;
       hipLaunchKernelGGL(kmsd1, dim3((unsigned)(msd_ntiles + BINS + NRANGE)), dim3(BT), lds_msd(hyb_kpt, nb1), stream, m);
       prof_mark_h(2, stream);
-      hipLaunchKernelGGL(k_plan2, dim3(1), dim3(BINS), 0, stream, plan, hist2, base2, NPASS);
+      hipLaunchKernelGGL(k_plan2, dim3(BINS), dim3(GX_WAVE), 0, stream, plan, hist2, base2, NPASS);
       prof_mark_h(3, stream);
       hipLaunchKernelGGL(kloc, dim3((unsigned)(BINS << hc.bits2)), dim3(ls_bt), lds_loc(hc.cl2), stream, bufB, bufA, valB, valA, desc_mask,
                          plan, hist2, base2, m.exp);

@@ -1,7 +1,8 @@
 // cudf/aggregation.hpp -- aggregation descriptors and their factories
 // (reference: cpp/include/cudf/aggregation.hpp:73-330).  The Kind enumerators keep the reference's
-// order so integer values stay interchangeable; the hot path implements SUM, PRODUCT, MIN, MAX,
-// COUNT_VALID, COUNT_ALL and MEAN (others throw cudf::logic_error where they are used).
+// order so integer values stay interchangeable; the hot path implements SUM, PRODUCT, MIN, MAX, COUNT_VALID,
+// COUNT_ALL, MEAN, SUM_OF_SQUARES, M2, VARIANCE, STD, ARGMIN, ARGMAX and (sort path) NTH_ELEMENT; others throw
+// cudf::logic_error where they are used.
 #pragma once
 #include <cudf/types.hpp>
 #include <cudf/utilities/error.hpp>
@@ -71,6 +72,25 @@ class std_var_aggregation final : public groupby_aggregation,
     return std::unique_ptr<aggregation>(static_cast<groupby_aggregation*>(new std_var_aggregation(kind, _ddof)));
   }
 };
+// NTH_ELEMENT carries the index and the null handling (reference: detail/aggregation/aggregation.hpp
+// nth_element_aggregation, _n / _null_handling); sort-path only -- the reference's tests use it to force that path
+class nth_element_aggregation final : public groupby_aggregation, public reduce_aggregation, public rolling_aggregation {
+ public:
+  nth_element_aggregation(size_type n, null_policy null_handling) : aggregation(aggregation::NTH_ELEMENT), _n{n}, _null_handling{null_handling} {}
+  size_type _n;
+  null_policy _null_handling;
+  [[nodiscard]] bool is_equal(aggregation const& other) const override
+  {
+    auto const* o = dynamic_cast<nth_element_aggregation const*>(&other);
+    return o != nullptr && o->_n == _n && o->_null_handling == _null_handling;
+  }
+  [[nodiscard]] std::size_t do_hash() const override { return static_cast<std::size_t>(kind) * 31u + static_cast<std::size_t>(_n); }
+  [[nodiscard]] std::unique_ptr<aggregation> clone() const override
+  {
+    return std::unique_ptr<aggregation>(static_cast<groupby_aggregation*>(new nth_element_aggregation(_n, _null_handling)));
+  }
+};
+
 template <typename Base>
 std::unique_ptr<Base> make_std_var(aggregation::Kind k, size_type ddof)
 {
@@ -118,6 +138,17 @@ template <typename Base = aggregation>
 std::unique_ptr<Base> make_variance_aggregation(size_type ddof = 1) { return detail::make_std_var<Base>(aggregation::VARIANCE, ddof); }
 template <typename Base = aggregation>
 std::unique_ptr<Base> make_std_aggregation(size_type ddof = 1) { return detail::make_std_var<Base>(aggregation::STD, ddof); }
+// NTH_ELEMENT: the n-th value of each group, negative n from the end (aggregation.hpp:448-470)
+template <typename Base = aggregation>
+std::unique_ptr<Base> make_nth_element_aggregation(size_type n, null_policy null_handling = null_policy::INCLUDE)
+{
+  return std::unique_ptr<Base>(static_cast<Base*>(new detail::nth_element_aggregation(n, null_handling)));
+}
+template <>
+inline std::unique_ptr<aggregation> make_nth_element_aggregation<aggregation>(size_type n, null_policy null_handling)
+{
+  return std::unique_ptr<aggregation>(static_cast<groupby_aggregation*>(new detail::nth_element_aggregation(n, null_handling)));
+}
 // ARGMAX / ARGMIN: row index (size_type) of the group's maximum / minimum (aggregation.hpp:430-446)
 template <typename Base = aggregation>
 std::unique_ptr<Base> make_argmax_aggregation() { return detail::make_simple<Base>(aggregation::ARGMAX); }

@@ -4,10 +4,13 @@
 #pragma once
 #include <cudf/aggregation.hpp>
 #include <cudf/column/column.hpp>
+#include <cudf/replace.hpp>
+#include <cudf/scalar/scalar.hpp>
 #include <cudf/table/table.hpp>
 #include <cudf/table/table_view.hpp>
 #include <cudf/types.hpp>
 
+#include <functional>
 #include <memory>
 #include <span>
 #include <utility>
@@ -15,6 +18,10 @@
 
 namespace cudf {
 namespace groupby {
+
+namespace sort_impl {
+class sort_groupby_helper;  // the reference's detail::sort::sort_groupby_helper (detail/groupby/sort_helper.hpp)
+}
 
 struct aggregation_request {
   column_view values;                                              // the elements to aggregate
@@ -44,6 +51,8 @@ class groupby {
 
   // {unique keys (unspecified order), one aggregation_result per request}
   // throws cudf::logic_error "Size mismatch between request values and groupby keys."
+  // Hash-based unless the keys are pre-sorted (sorted::YES), null keys are to be kept (null_policy::INCLUDE) or an
+  // aggregation needs the sort path (PRODUCT): then sort-based, keys come out sorted (groupby.cu:54-71).
   std::pair<std::unique_ptr<table>, std::vector<aggregation_result>> aggregate(
     std::span<aggregation_request const> requests, rmm::cuda_stream_view stream = cudf::get_default_stream(),
     rmm::device_async_resource_ref mr = cudf::get_current_device_resource_ref());
@@ -53,12 +62,39 @@ class groupby {
     std::span<scan_request const> requests, rmm::cuda_stream_view stream = cudf::get_default_stream(),
     rmm::device_async_resource_ref mr = cudf::get_current_device_resource_ref());
 
+  // every column of `values` shifted by its offset INSIDE its group, filled with the scalar where no row exists;
+  // {sorted keys, shifted values} (groupby.hpp:242-300)
+  std::pair<std::unique_ptr<table>, std::unique_ptr<table>> shift(
+    table_view const& values, std::span<size_type const> offsets,
+    std::vector<std::reference_wrapper<scalar const>> const& fill_values,
+    rmm::cuda_stream_view stream = cudf::get_default_stream(),
+    rmm::device_async_resource_ref mr = cudf::get_current_device_resource_ref());
+
+  struct groups {
+    std::unique_ptr<table> keys;     // grouped keys (every kept row, sorted)
+    std::vector<size_type> offsets;  // group offsets (num_groups + 1)
+    std::unique_ptr<table> values;   // grouped values (when values were given)
+  };
+  groups get_groups(cudf::table_view values = {}, rmm::cuda_stream_view stream = cudf::get_default_stream(),
+                    rmm::device_async_resource_ref mr = cudf::get_current_device_resource_ref());
+
+  // nulls replaced by the preceding / following valid value of the same group; {sorted keys, replaced values}
+  std::pair<std::unique_ptr<table>, std::unique_ptr<table>> replace_nulls(
+    table_view const& values, std::span<cudf::replace_policy const> replace_policies,
+    rmm::cuda_stream_view stream = cudf::get_default_stream(),
+    rmm::device_async_resource_ref mr = cudf::get_current_device_resource_ref());
+
  private:
   table_view _keys;
   null_policy _include_null_keys{null_policy::EXCLUDE};
   sorted _keys_are_sorted{sorted::NO};
   std::vector<order> _column_order{};
   std::vector<null_order> _null_precedence{};
+  std::unique_ptr<sort_impl::sort_groupby_helper> _helper;  // built on first use by the sort-based paths
+  sort_impl::sort_groupby_helper& helper();
+
+  std::pair<std::unique_ptr<table>, std::vector<aggregation_result>> sort_aggregate(
+    std::span<aggregation_request const> requests, rmm::cuda_stream_view stream, rmm::device_async_resource_ref mr);
 };
 
 }  // namespace groupby

@@ -20,6 +20,9 @@ class scalar {
   [[nodiscard]] data_type type() const noexcept { return _type; }
   void set_valid_async(bool is_valid, rmm::cuda_stream_view stream = cudf::get_default_stream());
   [[nodiscard]] bool is_valid(rmm::cuda_stream_view stream = cudf::get_default_stream()) const;
+  // device address of the value bytes of a fixed-width scalar (NULL for other scalars): what type-erased callers
+  // such as groupby::shift's fill values read
+  [[nodiscard]] virtual void const* device_value_ptr() const noexcept { return nullptr; }
   bool* validity_data() { return static_cast<bool*>(_is_valid.data()); }
   [[nodiscard]] bool const* validity_data() const { return static_cast<bool const*>(_is_valid.data()); }
 
@@ -56,6 +59,7 @@ class fixed_width_scalar : public scalar {
   }
   T* data() { return static_cast<T*>(_data.data()); }
   [[nodiscard]] T const* data() const { return static_cast<T const*>(_data.data()); }
+  [[nodiscard]] void const* device_value_ptr() const noexcept override { return _data.data(); }
 
  protected:
   rmm::device_buffer _data;

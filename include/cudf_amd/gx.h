@@ -381,6 +381,9 @@ int gx_segmented_fill_nulls(int elem_size, const void* in, const uint32_t* in_va
                             gx_stream_t stream);
 int gx_rank_from_groups(const int32_t* order, const int32_t* labels, const int32_t* offsets, int64_t n, int method,
                         double scale, int one_normalized, int32_t* out_i32, double* out_f64, gx_stream_t stream);
+/* Segment id of every row for cudf::segmented_sorted_order (cpp/src/sort/segmented_sort_impl.cuh:178-203): rows of
+ * segment [offsets[j], offsets[j+1]) get offsets[j+1]; rows outside every segment get unique ascending ids. */
+int gx_segment_ids(const int32_t* offsets, int64_t num_offsets, int64_t num_rows, int32_t* ids, gx_stream_t stream);
 
 /* Tuning / A-B knob (process-wide).  algo: 0 = auto (hash-partition rows into 256 LDS-sized
  * partitions and aggregate each in one workgroup's LDS when n >= 2^19, else the global-atomic

@@ -710,6 +710,264 @@ int main()
     }
   });
 
+  run("rank: FIRST / DENSE / MIN / MAX / AVERAGE, keep / top / bottom, percentage (rank_test.cpp:60-430)", [] {
+    auto col1 = make_col<int32_t>({5, 4, 3, 5, 8, 5});
+    auto col2 = make_col<int32_t>({5, 4, 3, 5, 8, 5}, {1, 1, 0, 1, 1, 1});
+    using V   = std::vector<int32_t>;
+    using D   = std::vector<double>;
+    auto ri   = [](column_view c, rank_method m, order o, null_policy np, null_order no) {
+      return to_host<int32_t>(rank(c, m, o, np, no, false)->view());
+    };
+    auto rd = [](column_view c, rank_method m, order o, null_policy np, null_order no, bool pct) {
+      return to_host<double>(rank(c, m, o, np, no, pct)->view());
+    };
+    auto const A = order::ASCENDING, Dn = order::DESCENDING;
+    auto const EX = null_policy::EXCLUDE, IN = null_policy::INCLUDE;
+    auto const AF = null_order::AFTER, BE = null_order::BEFORE;
+    CHECK((ri(col1->view(), rank_method::FIRST, A, EX, AF) == V{3, 2, 1, 4, 6, 5}));
+    {  // keep: the null row stays null, the others are ranked among themselves
+      auto r = rank(col2->view(), rank_method::FIRST, A, EX, AF, false);
+      CHECK((valid_host(r->view()) == std::vector<int>{1, 1, 0, 1, 1, 1}));
+      auto h = to_host<int32_t>(r->view());
+      CHECK(h[0] == 2 && h[1] == 1 && h[3] == 3 && h[4] == 5 && h[5] == 4);
+    }
+    CHECK((ri(col2->view(), rank_method::FIRST, A, IN, BE) == V{3, 2, 1, 4, 6, 5}));   // first_asc_top
+    CHECK((ri(col2->view(), rank_method::FIRST, A, IN, AF) == V{2, 1, 6, 3, 5, 4}));   // first_asc_bottom
+    CHECK((ri(col1->view(), rank_method::FIRST, Dn, EX, BE) == V{2, 5, 6, 3, 1, 4}));  // first_desc_keep
+    CHECK((ri(col1->view(), rank_method::DENSE, A, EX, AF) == V{3, 2, 1, 3, 4, 3}));   // dense_asc_keep
+    CHECK((ri(col1->view(), rank_method::MIN, A, EX, AF) == V{3, 2, 1, 3, 6, 3}));     // min_asc_keep
+    CHECK((ri(col1->view(), rank_method::MAX, A, EX, AF) == V{5, 2, 1, 5, 6, 5}));     // max_asc_keep
+    CHECK((rd(col1->view(), rank_method::AVERAGE, A, EX, AF, false) == D{4, 2, 1, 4, 6, 4}));  // average_asc_keep
+    CHECK((rd(col1->view(), rank_method::DENSE, A, EX, AF, true) == D{0.75, 0.5, 0.25, 0.75, 1., 0.75}));  // dense_asc_keep_pct
+    CHECK((rd(col1->view(), rank_method::MIN, Dn, EX, BE, true) == D{1.0 / 3.0, 5.0 / 6.0, 1., 1.0 / 3.0, 1.0 / 6.0, 1.0 / 3.0}));
+    {  // min_desc_keep_pct with the null row: divided by the 5 ranked rows
+      auto r = rank(col2->view(), rank_method::MIN, Dn, EX, BE, true);
+      auto h = to_host<double>(r->view());
+      CHECK((valid_host(r->view()) == std::vector<int>{1, 1, 0, 1, 1, 1}));
+      CHECK(h[0] == 0.4 && h[1] == 1. && h[3] == 0.4 && h[4] == 0.2 && h[5] == 0.4);
+    }
+    {  // dense percentage with a null: 3 distinct ranked values
+      auto h = to_host<double>(rank(col2->view(), rank_method::DENSE, A, EX, AF, true)->view());
+      CHECK(h[0] == 2.0 / 3.0 && h[1] == 1.0 / 3.0 && h[4] == 1.);
+    }
+  });
+  run("top_k / top_k_order (top_k.cu:118-165) and segmented sorts (segmented_sort_tests.cpp:70-157)", [] {
+    auto c = make_col<int64_t>({7, -3, 12, 5, 12, 0, 9});
+    CHECK((to_host<int64_t>(top_k(c->view(), 3)->view()) == std::vector<int64_t>{12, 12, 9}));
+    CHECK((to_host<int32_t>(top_k_order(c->view(), 3)->view()) == std::vector<int32_t>{2, 4, 6}));
+    CHECK((to_host<int64_t>(top_k(c->view(), 2, order::ASCENDING)->view()) == std::vector<int64_t>{-3, 0}));
+    CHECK(top_k(c->view(), 0)->size() == 0 && top_k(c->view(), 100)->size() == 7);
+    auto cn = make_col<double>({1.5, 9.0, 2.5, 7.0}, {1, 0, 1, 1});  // the null never makes the top
+    CHECK((to_host<double>(top_k(cn->view(), 2)->view()) == std::vector<double>{7.0, 2.5}));
+    CHECK(throws<std::invalid_argument>([&] { (void)top_k(c->view(), -1); }));
+    // segments             {0   1   2} {3   4} {5} {6   7   8   9  10}{11  12}{13}{14  15}
+    auto col1 = make_col<int32_t>({10, 36, 14, 32, 49, 23, 10, 34, 12, 45, 12, 37, 43, 26, 21, 16});
+    auto col2 = make_col<int32_t>({10, 63, 41, 23, 94, 32, 10, 43, 21, 54, 22, 73, 34, 62, 12, 61});
+    auto segs = make_col<int32_t>({0, 3, 5, 5, 5, 6, 11, 13, 14, 16});
+    table_view in1{{col1->view()}}, in2{{col1->view(), col2->view()}};
+    using V = std::vector<int32_t>;
+    CHECK((to_host<int32_t>(segmented_sort_by_key(in1, in1, segs->view(), {order::ASCENDING})->view().column(0)) ==
+           V{10, 14, 36, 32, 49, 23, 10, 12, 12, 34, 45, 37, 43, 26, 16, 21}));
+    CHECK((to_host<int32_t>(segmented_sort_by_key(in1, in1, segs->view(), {order::DESCENDING})->view().column(0)) ==
+           V{36, 14, 10, 49, 32, 23, 45, 34, 12, 12, 10, 43, 37, 26, 21, 16}));
+    auto r2 = segmented_sort_by_key(in2, in2, segs->view(), {order::ASCENDING, order::DESCENDING});
+    CHECK((to_host<int32_t>(r2->view().column(1)) == V{10, 41, 63, 23, 94, 32, 10, 22, 21, 43, 54, 73, 34, 62, 61, 12}));
+    // offsets that do not cover every row: the rows outside keep their place (segmented_sort_impl.cuh:190-196)
+    auto part = make_col<int32_t>({3, 7});
+    CHECK((to_host<int32_t>(segmented_sorted_order(in1, part->view())->view()) ==
+           V{0, 1, 2, 6, 5, 3, 4, 7, 8, 9, 10, 11, 12, 13, 14, 15}));
+    // nulls inside segments, both precedences (segmented_sort_tests.cpp:106-130)
+    auto n1 = make_col<int32_t>({1, 3, 2, 4, 5, 23, 6, 8, 7, 9, 7, 37, 43, 26, 21, 16}, {1, 1, 0, 1, 1, 1, 1, 1, 1, 0, 1, 1, 1, 1, 1, 1});
+    table_view inn{{n1->view()}};
+    auto aa = segmented_sort_by_key(inn, inn, segs->view(), {}, {null_order::AFTER});
+    CHECK((valid_host(aa->view().column(0)) == std::vector<int>{1, 1, 0, 1, 1, 1, 1, 1, 1, 1, 0, 1, 1, 1, 1, 1}));
+    auto ha = to_host<int32_t>(aa->view().column(0));
+    CHECK(ha[0] == 1 && ha[1] == 3 && ha[6] == 6 && ha[7] == 7 && ha[8] == 7 && ha[9] == 8 && ha[14] == 16 && ha[15] == 21);
+    auto ab = segmented_sort_by_key(inn, inn, segs->view(), {}, {null_order::BEFORE});
+    CHECK((valid_host(ab->view().column(0)) == std::vector<int>{0, 1, 1, 1, 1, 1, 0, 1, 1, 1, 1, 1, 1, 1, 1, 1}));
+  });
+
+  // ---- sort-based groupby: the reference's tests force this path with an extra NTH_ELEMENT(0) request
+  // (groupby_test_util.cpp:60-64); with it the keys come out SORTED and are compared without re-sorting (:77-80)
+  run("sort-path groupby: SUM/COUNT/MIN/MAX/MEAN/PRODUCT, keys sorted (sum_tests.cpp:68-80, count_tests.cpp:21-41, min/max_tests.cpp:37-57, force_use_sort_impl::YES)", [&] {
+    auto keys = make_col<int32_t>({1, 2, 3, 1, 2, 2, 1, 3, 3, 2});
+    auto vals = make_col<int32_t>({0, 1, 2, 3, 4, 5, 6, 7, 8, 9});
+    groupby::groupby gb{table_view{{keys->view()}}};
+    std::vector<groupby::aggregation_request> reqs(1);
+    reqs[0].values = vals->view();
+    reqs[0].aggregations.push_back(make_sum_aggregation<groupby_aggregation>());
+    reqs[0].aggregations.push_back(make_count_aggregation<groupby_aggregation>());
+    reqs[0].aggregations.push_back(make_min_aggregation<groupby_aggregation>());
+    reqs[0].aggregations.push_back(make_max_aggregation<groupby_aggregation>());
+    reqs[0].aggregations.push_back(make_mean_aggregation<groupby_aggregation>());
+    reqs[0].aggregations.push_back(make_product_aggregation<groupby_aggregation>());
+    reqs[0].aggregations.push_back(make_nth_element_aggregation<groupby_aggregation>(0));
+    reqs[0].aggregations.push_back(make_nth_element_aggregation<groupby_aggregation>(-1));
+    reqs[0].aggregations.push_back(make_argmax_aggregation<groupby_aggregation>());
+    reqs[0].aggregations.push_back(make_variance_aggregation<groupby_aggregation>());
+    auto [k, res] = gb.aggregate(reqs);
+    CHECK((to_host<int32_t>(k->view().column(0)) == std::vector<int32_t>{1, 2, 3}));
+    auto const& r = res[0].results;
+    CHECK(r[0]->type().id() == type_id::INT64 && r[5]->type().id() == type_id::INT64);
+    CHECK((to_host<int64_t>(r[0]->view()) == std::vector<int64_t>{9, 19, 17}));
+    CHECK((to_host<int32_t>(r[1]->view()) == std::vector<int32_t>{3, 4, 3}));
+    CHECK((to_host<int32_t>(r[2]->view()) == std::vector<int32_t>{0, 1, 2}));
+    CHECK((to_host<int32_t>(r[3]->view()) == std::vector<int32_t>{6, 9, 8}));
+    CHECK((to_host<double>(r[4]->view()) == std::vector<double>{3., 19. / 4, 17. / 3}));
+    CHECK((to_host<int64_t>(r[5]->view()) == std::vector<int64_t>{0, 180, 112}));
+    CHECK((to_host<int32_t>(r[6]->view()) == std::vector<int32_t>{0, 1, 2}));   // first value of each group
+    CHECK((to_host<int32_t>(r[7]->view()) == std::vector<int32_t>{6, 9, 8}));   // last value of each group
+    CHECK((to_host<int32_t>(r[8]->view()) == std::vector<int32_t>{6, 9, 8}));   // ARGMAX: row index of the maximum
+    CHECK((to_host<double>(r[9]->view()) == std::vector<double>{9., 131. / 12, 31. / 3}));  // var_tests.cpp:37-57
+    // double SUM through the segmented reduce (double-double accumulation): exact on these values
+    auto dv = make_col<double>({0.1, 1.5, 2.25, 3.0, 4.5, 5.125, 6.0, 7.5, 8.0, 9.75});
+    std::vector<groupby::aggregation_request> r2(1);
+    r2[0].values = dv->view();
+    r2[0].aggregations.push_back(make_sum_aggregation<groupby_aggregation>());
+    r2[0].aggregations.push_back(make_nth_element_aggregation<groupby_aggregation>(0));
+    auto [k2, res2] = gb.aggregate(r2);
+    CHECK((to_host<double>(res2[0].results[0]->view()) == std::vector<double>{0.1 + 3.0 + 6.0, 1.5 + 4.5 + 5.125 + 9.75, 2.25 + 7.5 + 8.0}));
+  });
+  run("sort-path groupby with null keys and values (sum_tests.cpp:124-145, count_tests.cpp:103-132, max_tests.cpp:100-120)", [&] {
+    auto keys = make_col<int32_t>({1, 2, 3, 1, 2, 2, 1, 3, 3, 2, 4}, {1, 1, 1, 1, 1, 1, 1, 0, 1, 1, 1});
+    auto vals = make_col<double>({0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 4}, {0, 1, 1, 1, 1, 0, 1, 1, 1, 1, 0});
+    groupby::groupby gb{table_view{{keys->view()}}};
+    std::vector<groupby::aggregation_request> reqs(1);
+    reqs[0].values = vals->view();
+    reqs[0].aggregations.push_back(make_sum_aggregation<groupby_aggregation>());
+    reqs[0].aggregations.push_back(make_count_aggregation<groupby_aggregation>());
+    reqs[0].aggregations.push_back(make_count_aggregation<groupby_aggregation>(null_policy::INCLUDE));
+    reqs[0].aggregations.push_back(make_max_aggregation<groupby_aggregation>());
+    reqs[0].aggregations.push_back(make_nth_element_aggregation<groupby_aggregation>(0));
+    auto [k, res] = gb.aggregate(reqs);
+    CHECK((to_host<int32_t>(k->view().column(0)) == std::vector<int32_t>{1, 2, 3, 4}));
+    auto const& r = res[0].results;
+    auto s = to_host<double>(r[0]->view());
+    CHECK((valid_host(r[0]->view()) == std::vector<int>{1, 1, 1, 0}));
+    CHECK(s[0] == 9. && s[1] == 14. && s[2] == 10.);
+    CHECK((to_host<int32_t>(r[1]->view()) == std::vector<int32_t>{2, 3, 2, 0}));
+    CHECK((to_host<int32_t>(r[2]->view()) == std::vector<int32_t>{3, 4, 2, 1}));
+    auto mx = to_host<double>(r[3]->view());
+    CHECK((valid_host(r[3]->view()) == std::vector<int>{1, 1, 1, 0}));
+    CHECK(mx[0] == 6. && mx[1] == 9. && mx[2] == 8.);
+  });
+  run("pre-sorted keys: sorted::YES, descending, nullable, nulls kept (keys_tests.cpp:109-203)", [&] {
+    auto sum_of = [&](std::unique_ptr<column> const& keys, std::unique_ptr<column> const& vals, null_policy np,
+                      std::vector<order> const& ord = {}) {
+      groupby::groupby gb{table_view{{keys->view()}}, np, sorted::YES, ord, {null_order::BEFORE}};
+      std::vector<groupby::aggregation_request> reqs(1);
+      reqs[0].values = vals->view();
+      reqs[0].aggregations.push_back(make_sum_aggregation<groupby_aggregation>());
+      return gb.aggregate(reqs);
+    };
+    auto vals = make_col<int32_t>({0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 4});
+    {
+      auto keys     = make_col<int32_t>({1, 1, 1, 2, 2, 2, 2, 3, 3, 3, 4});
+      auto [k, res] = sum_of(keys, vals, null_policy::EXCLUDE);
+      CHECK((to_host<int32_t>(k->view().column(0)) == std::vector<int32_t>{1, 2, 3, 4}));
+      CHECK((to_host<int64_t>(res[0].results[0]->view()) == std::vector<int64_t>{3, 18, 24, 4}));
+    }
+    {
+      auto keys     = make_col<int32_t>({4, 3, 3, 3, 2, 2, 2, 2, 1, 1, 1});
+      auto [k, res] = sum_of(keys, vals, null_policy::EXCLUDE, {order::DESCENDING});
+      CHECK((to_host<int32_t>(k->view().column(0)) == std::vector<int32_t>{4, 3, 2, 1}));
+      CHECK((to_host<int64_t>(res[0].results[0]->view()) == std::vector<int64_t>{0, 6, 22, 21}));
+    }
+    {  // nulls to exclude: the helper re-sorts (sort_helper.cu:47-54)
+      auto keys     = make_col<int32_t>({1, 1, 1, 2, 2, 2, 2, 3, 3, 3, 4}, {1, 1, 1, 0, 1, 1, 1, 0, 1, 1, 1});
+      auto [k, res] = sum_of(keys, vals, null_policy::EXCLUDE);
+      CHECK((to_host<int32_t>(k->view().column(0)) == std::vector<int32_t>{1, 2, 3, 4}));
+      CHECK(k->view().column(0).null_count() == 0);
+      CHECK((to_host<int64_t>(res[0].results[0]->view()) == std::vector<int64_t>{3, 15, 17, 4}));
+    }
+    {  // nulls kept: every run of adjacent equal rows (null == null) is a group
+      auto keys     = make_col<int32_t>({1, 1, 1, 2, 2, 2, 2, 3, 3, 3, 4}, {1, 1, 1, 0, 0, 1, 1, 0, 1, 1, 1});
+      auto [k, res] = sum_of(keys, vals, null_policy::INCLUDE);
+      CHECK((valid_host(k->view().column(0)) == std::vector<int>{1, 0, 1, 0, 1, 1}));
+      auto kh = to_host<int32_t>(k->view().column(0));
+      CHECK(kh[0] == 1 && kh[2] == 2 && kh[4] == 3 && kh[5] == 4);
+      CHECK((to_host<int64_t>(res[0].results[0]->view()) == std::vector<int64_t>{3, 7, 11, 7, 17, 4}));
+    }
+    {  // unsorted keys with nulls KEPT (null_policy::INCLUDE, keys_tests.cpp:86-107): the null key is a group
+      auto keys = make_col<int32_t>({1, 2, 3, 1, 2, 2, 1, 3, 3, 2, 4}, {1, 1, 1, 1, 1, 1, 1, 0, 1, 1, 1});
+      groupby::groupby gb{table_view{{keys->view()}}, null_policy::INCLUDE};
+      std::vector<groupby::aggregation_request> reqs(1);
+      reqs[0].values = vals->view();
+      reqs[0].aggregations.push_back(make_sum_aggregation<groupby_aggregation>());
+      auto [k, res] = gb.aggregate(reqs);
+      CHECK((valid_host(k->view().column(0)) == std::vector<int>{1, 1, 1, 1, 0}));   // nulls AFTER (sort_helper.cu:92-94)
+      auto kh = to_host<int32_t>(k->view().column(0));
+      CHECK(kh[0] == 1 && kh[1] == 2 && kh[2] == 3 && kh[3] == 4);
+      CHECK((to_host<int64_t>(res[0].results[0]->view()) == std::vector<int64_t>{9, 19, 10, 4, 7}));
+    }
+    {  // groupby::scan on pre-sorted keys skips the sort (two key columns)
+      auto k0 = make_col<int32_t>({1, 1, 1, 2, 2, 3});
+      auto k1 = make_col<int64_t>({5, 5, 6, 6, 6, 6});
+      auto v  = make_col<int32_t>({1, 2, 3, 4, 5, 6});
+      groupby::groupby gb{table_view{{k0->view(), k1->view()}}, null_policy::EXCLUDE, sorted::YES};
+      std::vector<groupby::scan_request> reqs(1);
+      reqs[0].values = v->view();
+      reqs[0].aggregations.push_back(make_sum_aggregation<groupby_scan_aggregation>());
+      auto [k, res] = gb.scan(reqs);
+      CHECK((to_host<int64_t>(res[0].results[0]->view()) == std::vector<int64_t>{1, 3, 3, 4, 9, 6}));
+      CHECK((to_host<int64_t>(k->view().column(1)) == std::vector<int64_t>{5, 5, 6, 6, 6, 6}));
+    }
+  });
+  run("groupby::get_groups / shift / replace_nulls (group_shift / shift_tests.cpp:34-140, replace_nulls_tests.cpp:40-105, groupby.cu:261-362)", [&] {
+    auto key = make_col<int32_t>({1, 2, 1, 2, 2, 1, 1, 2, 1, 2, 1, 2, 1});
+    auto val = make_col<int32_t>({3, 4, 5, 6, 7, 8, 9, 0, 1, 2, 3, 4, 5});
+    groupby::groupby gb{table_view{{key->view()}}};
+    auto grp = gb.get_groups(table_view{{val->view()}});
+    CHECK((grp.offsets == std::vector<size_type>{0, 7, 13}));
+    CHECK((to_host<int32_t>(grp.keys->view().column(0)) == std::vector<int32_t>{1, 1, 1, 1, 1, 1, 1, 2, 2, 2, 2, 2, 2}));
+    CHECK((to_host<int32_t>(grp.values->view().column(0)) == std::vector<int32_t>{3, 5, 8, 9, 1, 3, 5, 4, 6, 7, 0, 2, 4}));
+    // forward shift by 3, valid fill 42 (ForwardShiftWithoutNull_ValidScalar)
+    numeric_scalar<int32_t> fill{42};
+    std::vector<size_type> off{3};
+    auto [sk, sv] = gb.shift(table_view{{val->view()}}, off, {fill});
+    CHECK((to_host<int32_t>(sv->view().column(0)) == std::vector<int32_t>{42, 42, 42, 3, 5, 8, 9, 42, 42, 42, 4, 6, 7}));
+    CHECK(sv->view().column(0).null_count() == 0);
+    // backward shift by 1, null fill (BackwardShiftWithoutNull_NullScalar)
+    auto key2 = make_col<int32_t>({1, 2, 1, 2, 2, 1, 1});
+    auto val2 = make_col<int32_t>({3, 4, 5, 6, 7, 8, 9});
+    groupby::groupby gb2{table_view{{key2->view()}}};
+    numeric_scalar<int32_t> nullfill{0, false};
+    std::vector<size_type> off2{-1};
+    auto [sk2, sv2] = gb2.shift(table_view{{val2->view()}}, off2, {nullfill});
+    auto h2 = to_host<int32_t>(sv2->view().column(0));
+    CHECK((valid_host(sv2->view().column(0)) == std::vector<int>{1, 1, 1, 0, 1, 1, 0}));
+    CHECK(h2[0] == 5 && h2[1] == 8 && h2[2] == 9 && h2[4] == 6 && h2[5] == 7);
+    // forward shift with nulls in the values (ForwardShiftWithNull_ValidScalar)
+    auto val3 = make_col<int32_t>({3, 4, 5, 6, 7, 8, 9, 0, 1, 2, 3, 4, 5}, {1, 0, 1, 0, 1, 0, 0, 1, 0, 1, 1, 0, 1});
+    auto [sk3, sv3] = gb.shift(table_view{{val3->view()}}, off, {fill});
+    CHECK((valid_host(sv3->view().column(0)) == std::vector<int>{1, 1, 1, 1, 1, 0, 0, 1, 1, 1, 0, 0, 1}));
+    auto h3 = to_host<int32_t>(sv3->view().column(0));
+    CHECK(h3[0] == 42 && h3[3] == 3 && h3[4] == 5 && h3[7] == 42 && h3[12] == 7);
+    // replace_nulls: PrecedingFill / FollowingFill / leading and trailing nulls
+    auto rk = make_col<int32_t>({0, 1, 0, 1, 0, 1});
+    auto rv = make_col<int32_t>({42, 7, 24, 10, 1, 1000}, {1, 1, 1, 0, 0, 0});
+    groupby::groupby gbr{table_view{{rk->view()}}};
+    std::vector<replace_policy> pol{replace_policy::PRECEDING};
+    auto [pk, pv] = gbr.replace_nulls(table_view{{rv->view()}}, pol);
+    CHECK((to_host<int32_t>(pk->view().column(0)) == std::vector<int32_t>{0, 0, 0, 1, 1, 1}));
+    CHECK((to_host<int32_t>(pv->view().column(0)) == std::vector<int32_t>{42, 24, 24, 7, 7, 7}));
+    CHECK(pv->view().column(0).null_count() == 0);
+    auto fk = make_col<int32_t>({0, 0, 1, 1, 0, 1, 1, 1});
+    auto fv = make_col<int32_t>({2, 4, 8, 16, 32, 64, 128, 256}, {1, 0, 1, 0, 1, 0, 1, 1});
+    groupby::groupby gbf{table_view{{fk->view()}}};
+    std::vector<replace_policy> polf{replace_policy::FOLLOWING};
+    auto [qk, qv] = gbf.replace_nulls(table_view{{fv->view()}}, polf);
+    CHECK((to_host<int32_t>(qv->view().column(0)) == std::vector<int32_t>{2, 32, 32, 8, 128, 128, 128, 256}));
+    auto tv = make_col<int32_t>({2, 4, 8, 16, 32, 64, 128, 256}, {1, 0, 0, 0, 0, 1, 0, 0});
+    auto [tk, tvv] = gbf.replace_nulls(table_view{{tv->view()}}, polf);
+    CHECK((valid_host(tvv->view().column(0)) == std::vector<int>{1, 0, 0, 1, 1, 1, 0, 0}));
+    auto th = to_host<int32_t>(tvv->view().column(0));
+    CHECK(th[0] == 2 && th[3] == 64 && th[4] == 64 && th[5] == 64);
+    auto lv = make_col<int32_t>({42, 7, 24, 10, 1, 1000}, {0, 0, 1, 0, 0, 0});
+    auto [lk, lvv] = gbr.replace_nulls(table_view{{lv->view()}}, pol);
+    CHECK((valid_host(lvv->view().column(0)) == std::vector<int>{0, 1, 1, 0, 0, 0}));
+  });
+
   // ---- reduce / scan: cpp/tests/reductions/{reduction_tests.cpp,scan_tests.cpp}
   run("reduce SUM/MIN/MAX with nulls; all-null -> invalid scalar", [] {
     auto c = make_col<int32_t>({6, -14, 13, 64, 0, -13, -20, 45}, {1, 0, 1, 1, 1, 1, 0, 1});
