@@ -8,7 +8,10 @@
 #include <cudf/join/filtered_join.hpp>
 #include <cudf/join/hash_join.hpp>
 #include <cudf/join/join.hpp>
+#include <cudf/null_mask.hpp>
 
+#include <algorithm>
+#include <stdexcept>
 #include <vector>
 
 namespace cudf {
@@ -292,6 +295,58 @@ class hash_join_impl {
     return out;
   }
 
+  // matches per probe row (at least `min_count`): *_join_match_context
+  std::unique_ptr<rmm::device_uvector<size_type>> match_counts(table_view const& probe, size_type min_count,
+                                                               rmm::cuda_stream_view stream, rmm::device_async_resource_ref mr) const
+  {
+    check_probe(probe);
+    auto const n = probe.num_rows();
+    auto counts  = std::make_unique<rmm::device_uvector<size_type>>(n, stream, mr);
+    if (n == 0) return counts;
+    if (_build.num_rows() == 0) {
+      std::vector<size_type> h(n, min_count);
+      CUDF_CUDA_TRY(hipMemcpyAsync(counts->data(), h.data(), n * sizeof(size_type), hipMemcpyHostToDevice, stream.value()));
+      stream.synchronize();
+      return counts;
+    }
+    std::unique_ptr<column> owner;
+    auto const pk = probe_key(probe, owner, stream);
+    rmm::device_buffer holder;
+    auto const* pmask = pk.has_nulls() ? rebased_mask(pk, holder, stream) : nullptr;
+    gx_check(gx_join_count_rows(_key_size, row0(pk), pmask, n, _table.data(), _table_bytes, min_count, counts->data(), gxs(stream)),
+             "hash_join match counts");
+    if (pmask && _nulls_equal && !_build_nulls.empty()) {  // null == null: a null probe row matches every null build row
+      auto const c = std::max<size_type>(min_count, static_cast<size_type>(_build_nulls.size()));
+      gx_check(gx_fill_nulls(4, counts->data(), pmask, n, static_cast<uint64_t>(static_cast<uint32_t>(c)), gxs(stream)),
+               "hash_join match counts of null rows");
+    }
+    stream.synchronize();
+    return counts;
+  }
+
+  // one chunk [start, end) of the context's left table; left indices refer to the whole table
+  join_result partitioned_join(join_partition_context const& ctx, bool left_outer, rmm::cuda_stream_view stream,
+                               rmm::device_async_resource_ref mr) const
+  {
+    CUDF_EXPECTS(ctx.left_table_context != nullptr, "partitioned join: missing match context", std::invalid_argument);
+    auto const& left = ctx.left_table_context->_left_table;
+    auto const start = ctx.left_start_idx, end = ctx.left_end_idx;
+    CUDF_EXPECTS(0 <= start && start <= end && end <= left.num_rows(), "partitioned join: chunk out of range", std::out_of_range);
+    if (start == end) return empty_result(stream, mr);
+    std::vector<column_view> cols;
+    for (auto const& c : left) {
+      size_type nulls = 0;
+      if (c.nullable() && c.null_count() > 0) nulls = cudf::null_count(c.null_mask(), c.offset() + start, c.offset() + end, stream);
+      cols.emplace_back(c.type(), end - start, c.head<void>(), c.null_mask(), nulls, c.offset() + start);
+    }
+    table_view chunk{cols};
+    join_result res = left_outer ? left_join(chunk, {}, stream, mr)
+                                 : ((_build.num_rows() == 0) ? empty_result(stream, mr) : probe_join(chunk, false, {}, stream, mr));
+    gx_check(gx_add_i32(res.first->data(), static_cast<int64_t>(res.first->size()), start, gxs(stream)), "partitioned join: re-base");
+    stream.synchronize();
+    return res;
+  }
+
   [[nodiscard]] size_type build_rows() const { return _build.num_rows(); }
 
  private:
@@ -349,6 +404,80 @@ std::size_t hash_join::full_join_size(table_view const& probe, rmm::cuda_stream_
                                       rmm::device_async_resource_ref mr) const
 {
   return _impl->full_join(probe, {}, stream, mr).first->size();
+}
+
+join_match_context hash_join::inner_join_match_context(table_view const& left, rmm::cuda_stream_view stream,
+                                                       rmm::device_async_resource_ref mr) const
+{
+  return join_match_context{left, _impl->match_counts(left, 0, stream, mr)};
+}
+join_match_context hash_join::left_join_match_context(table_view const& left, rmm::cuda_stream_view stream,
+                                                      rmm::device_async_resource_ref mr) const
+{
+  return join_match_context{left, _impl->match_counts(left, 1, stream, mr)};  // an unmatched row still emits one pair
+}
+join_match_context hash_join::full_join_match_context(table_view const& left, rmm::cuda_stream_view stream,
+                                                      rmm::device_async_resource_ref mr) const
+{
+  return join_match_context{left, _impl->match_counts(left, 1, stream, mr)};
+}
+join_result hash_join::partitioned_inner_join(join_partition_context const& context, rmm::cuda_stream_view stream,
+                                              rmm::device_async_resource_ref mr) const
+{
+  return _impl->partitioned_join(context, false, stream, mr);
+}
+join_result hash_join::partitioned_left_join(join_partition_context const& context, rmm::cuda_stream_view stream,
+                                             rmm::device_async_resource_ref mr) const
+{
+  return _impl->partitioned_join(context, true, stream, mr);
+}
+join_result hash_join::partitioned_full_join(join_partition_context const& context, rmm::cuda_stream_view stream,
+                                             rmm::device_async_resource_ref mr) const
+{
+  return _impl->partitioned_join(context, true, stream, mr);  // the unmatched right rows come from finalize
+}
+// hash_join.hpp:420-440 / join_utils.cu:86-157: concatenate the chunks, append (JoinNoMatch, r) for every right row no
+// chunk matched
+join_result hash_join::finalize_partitioned_full_join(host_span<device_span<size_type const> const> left_partials,
+                                                      host_span<device_span<size_type const> const> right_partials,
+                                                      size_type left_table_num_rows, size_type right_table_num_rows,
+                                                      rmm::cuda_stream_view stream, rmm::device_async_resource_ref mr)
+{
+  (void)left_table_num_rows;
+  CUDF_EXPECTS(left_partials.size() == right_partials.size(), "finalize_partitioned_full_join: partial counts differ",
+               std::invalid_argument);
+  std::size_t total = 0;
+  for (std::size_t i = 0; i < left_partials.size(); ++i) {
+    CUDF_EXPECTS(left_partials[i].size() == right_partials[i].size(), "finalize_partitioned_full_join: partial sizes differ",
+                 std::invalid_argument);
+    total += left_partials[i].size();
+  }
+  auto const cap = total + static_cast<std::size_t>(right_table_num_rows);
+  auto l = std::make_unique<rmm::device_uvector<size_type>>(cap, stream, mr);
+  auto r = std::make_unique<rmm::device_uvector<size_type>>(cap, stream, mr);
+  std::size_t at = 0;
+  for (std::size_t i = 0; i < left_partials.size(); ++i) {
+    auto const n = left_partials[i].size();
+    if (n == 0) continue;
+    CUDF_CUDA_TRY(hipMemcpyAsync(l->data() + at, left_partials[i].data(), n * sizeof(size_type), hipMemcpyDeviceToDevice, stream.value()));
+    CUDF_CUDA_TRY(hipMemcpyAsync(r->data() + at, right_partials[i].data(), n * sizeof(size_type), hipMemcpyDeviceToDevice, stream.value()));
+    at += n;
+  }
+  rmm::device_buffer cursor{sizeof(int64_t), stream};
+  int64_t const start = static_cast<int64_t>(total);
+  CUDF_CUDA_TRY(hipMemcpyAsync(cursor.data(), &start, sizeof(int64_t), hipMemcpyHostToDevice, stream.value()));
+  stream.synchronize();
+  if (right_table_num_rows > 0)
+    detail::run_with_scratch(
+      [&](void* t, std::size_t* b) {
+        return gx_join_complement(r->data(), static_cast<int64_t>(total), right_table_num_rows, l->data(), r->data(),
+                                  static_cast<int64_t>(cap), static_cast<int64_t*>(cursor.data()), t, b, detail::gxs(stream));
+      },
+      "finalize_partitioned_full_join", stream);
+  auto const n = detail::read_i64(static_cast<int64_t const*>(cursor.data()), stream);
+  l->shrink(static_cast<std::size_t>(n));
+  r->shrink(static_cast<std::size_t>(n));
+  return {std::move(l), std::move(r)};
 }
 
 // ---- cudf::filtered_join (include/cudf/join/filtered_join.hpp:51-144; src/join/filtered_join/filtered_join.cu)

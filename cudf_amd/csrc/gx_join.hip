@@ -301,6 +301,29 @@ __global__ void __launch_bounds__(256) k_lookup(const K* __restrict__ keys, cons
   }
 }
 
+// matches per probe row (cudf::hash_join::{inner,left,full}_join_match_context: hash_join.hpp:259-340; the
+// reference's per-row count pass of size_impl.cuh:26-62): counts[i] = max(min_count, #build rows with key i)
+template <typename K>
+__global__ void __launch_bounds__(256) k_count_rows(const K* __restrict__ keys, const uint32_t* __restrict__ valid, int64_t n,
+                                                    const Slot<K>* __restrict__ slots, uint32_t log2cap, int32_t min_count,
+                                                    int32_t* __restrict__ counts)
+{
+  const uint64_t mask  = (1ull << log2cap) - 1;
+  const int64_t stride = (int64_t)gridDim.x * 256;
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += stride) {
+    int32_t c = 0, first;
+    if (!valid || bit_is_set(valid, i)) c = (int32_t)chain_count<K>(slots, mask, log2cap, keys[i], first);
+    counts[i] = c < min_count ? min_count : c;
+  }
+}
+
+__global__ void __launch_bounds__(256) k_add_i32(int32_t* __restrict__ data, int64_t n, int32_t value)
+{
+  const int64_t stride = (int64_t)gridDim.x * 256;
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += stride)
+    if (data[i] != NO_MATCH) data[i] += value;
+}
+
 constexpr int SEL_CHUNK = 4096;  // rows per chunk of the ordered selection (256 threads x 16 wave-rows of 64)
 
 // bits[i] = (row i has a match) != invert ; null probe rows count as matching iff null_matches
@@ -1695,6 +1718,41 @@ int gx_join_filter(int key_size, const void* probe_keys, const uint32_t* probe_v
     return gx::join::filter_impl<uint32_t>(probe_keys, probe_valid, probe_rows, table, table_bytes, lg, anti, null_matches,
                                            out_probe_idx, count_dev, tmp, tmp_bytes, (hipStream_t)s);
   return GX_EDTYPE;
+}
+
+int gx_join_count_rows(int key_size, const void* probe_keys, const uint32_t* probe_valid, int64_t probe_rows, const void* table,
+                       size_t table_bytes, int32_t min_count, int32_t* counts, gx_stream_t s)
+{
+  if (probe_rows < 0 || !table || (probe_rows > 0 && (!probe_keys || !counts))) return GX_EINVAL;
+  if (table_bytes <= sizeof(gx::join::TableHeader)) return GX_ETMP;
+  if (probe_rows == 0) return 0;
+  const uint32_t lg = gx_join_log2_from_bytes(key_size, table_bytes);
+  int64_t blocks    = gx::div_up(probe_rows, (int64_t)256 * 4);
+  if (blocks > 16384) blocks = 16384;
+  const char* base = static_cast<const char*>(table) + sizeof(gx::join::TableHeader);
+  if (key_size == 8)
+    hipLaunchKernelGGL((gx::join::k_count_rows<uint64_t>), dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)s,
+                       static_cast<const uint64_t*>(probe_keys), probe_valid, probe_rows,
+                       reinterpret_cast<const gx::join::Slot<uint64_t>*>(base), lg, min_count, counts);
+  else if (key_size == 4)
+    hipLaunchKernelGGL((gx::join::k_count_rows<uint32_t>), dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)s,
+                       static_cast<const uint32_t*>(probe_keys), probe_valid, probe_rows,
+                       reinterpret_cast<const gx::join::Slot<uint32_t>*>(base), lg, min_count, counts);
+  else
+    return GX_EDTYPE;
+  GX_LAUNCH_CHECK();
+  return 0;
+}
+
+int gx_add_i32(int32_t* data, int64_t n, int32_t value, gx_stream_t s)
+{
+  if (n < 0 || (n > 0 && !data)) return GX_EINVAL;
+  if (n == 0 || value == 0) return 0;
+  int64_t blocks = gx::div_up(n, (int64_t)256 * 8);
+  if (blocks > 8192) blocks = 8192;
+  hipLaunchKernelGGL(gx::join::k_add_i32, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)s, data, n, value);
+  GX_LAUNCH_CHECK();
+  return 0;
 }
 
 int gx_join_profile(int enable)

@@ -4,6 +4,7 @@
 // are const and may be called concurrently from several host threads on distinct streams.
 #pragma once
 #include <cudf/join/join.hpp>
+#include <cudf/utilities/span.hpp>
 
 #include <cstddef>
 #include <memory>
@@ -50,6 +51,33 @@ class hash_join {
   [[nodiscard]] std::size_t full_join_size(table_view const& probe,
                                            rmm::cuda_stream_view stream      = cudf::get_default_stream(),
                                            rmm::device_async_resource_ref mr = cudf::get_current_device_resource_ref()) const;
+
+  // Chunked joins for outputs beyond size_type (hash_join.hpp:259-440): the match context holds the number of
+  // matches of every left row (left / full: at least 1), from which the caller cuts the left table into chunks whose
+  // output fits; partitioned_*_join joins one chunk and returns indices into the WHOLE left table.  A full join is
+  // its left-join chunks plus the unmatched right rows, appended by finalize_partitioned_full_join.
+  [[nodiscard]] join_match_context inner_join_match_context(
+    table_view const& left, rmm::cuda_stream_view stream = cudf::get_default_stream(),
+    rmm::device_async_resource_ref mr = cudf::get_current_device_resource_ref()) const;
+  [[nodiscard]] join_match_context left_join_match_context(
+    table_view const& left, rmm::cuda_stream_view stream = cudf::get_default_stream(),
+    rmm::device_async_resource_ref mr = cudf::get_current_device_resource_ref()) const;
+  [[nodiscard]] join_match_context full_join_match_context(
+    table_view const& left, rmm::cuda_stream_view stream = cudf::get_default_stream(),
+    rmm::device_async_resource_ref mr = cudf::get_current_device_resource_ref()) const;
+  [[nodiscard]] join_result partitioned_inner_join(
+    join_partition_context const& context, rmm::cuda_stream_view stream = cudf::get_default_stream(),
+    rmm::device_async_resource_ref mr = cudf::get_current_device_resource_ref()) const;
+  [[nodiscard]] join_result partitioned_left_join(
+    join_partition_context const& context, rmm::cuda_stream_view stream = cudf::get_default_stream(),
+    rmm::device_async_resource_ref mr = cudf::get_current_device_resource_ref()) const;
+  [[nodiscard]] join_result partitioned_full_join(
+    join_partition_context const& context, rmm::cuda_stream_view stream = cudf::get_default_stream(),
+    rmm::device_async_resource_ref mr = cudf::get_current_device_resource_ref()) const;
+  [[nodiscard]] static join_result finalize_partitioned_full_join(
+    host_span<device_span<size_type const> const> left_partials, host_span<device_span<size_type const> const> right_partials,
+    size_type left_table_num_rows, size_type right_table_num_rows, rmm::cuda_stream_view stream = cudf::get_default_stream(),
+    rmm::device_async_resource_ref mr = cudf::get_current_device_resource_ref());
 
  private:
   std::unique_ptr<detail::hash_join_impl const> _impl;

@@ -263,6 +263,14 @@ int gx_join_probe_partitioned(int key_size, const void* probe_keys, int64_t prob
 int gx_join_build_partitioned(int key_size, const void* build_keys, int64_t build_rows, void* table,
                               size_t table_bytes, double load_factor, void* tmp, size_t* tmp_bytes,
                               gx_stream_t stream);
+/* Matches per probe row: counts[i] = max(min_count, number of build rows whose key equals probe key i); null probe
+ * rows count 0.  The per-row form of gx_join_count behind cudf::hash_join::*_join_match_context
+ * (cpp/include/cudf/join/hash_join.hpp:259-340; cpp/src/join/hash_join/size_impl.cuh:26-62). */
+int gx_join_count_rows(int key_size, const void* probe_keys, const uint32_t* probe_valid, int64_t probe_rows,
+                       const void* table, size_t table_bytes, int32_t min_count, int32_t* counts, gx_stream_t stream);
+/* data[i] += value wherever data[i] != INT32_MIN (JoinNoMatch): re-bases the probe indices of a chunk of a
+ * partitioned join (hash_join.hpp:352-440) onto the whole left table. */
+int gx_add_i32(int32_t* data, int64_t n, int32_t value, gx_stream_t stream);
 /* log2 of the number of partitions the partitioned probe uses for this table; 0 = not partitionable */
 int gx_join_partition_bits(int key_size, size_t table_bytes);
 /* Measurement hooks (bench.py's roofline leg), like gx_sort_profile: when enabled, every partitioned probe
