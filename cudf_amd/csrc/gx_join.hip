@@ -1000,19 +1000,25 @@ k_pj_probe_tags(const K* __restrict__ pkeys, const int32_t* __restrict__ pidx, P
 // ---- software-pipelined tag probe ---------------------------------------------------------------------
 // k_pj_probe_tags waits for every memory level in turn (keys from HBM, then slots from L2, then the output
 // cursor, then the row ids from HBM) with 16 waves per CU to hide it: 85 % of its wave cycles were parked on
-// s_waitcnt (profiles/r1_run28_pmc_join_sq.txt).  Here ONE 1024-thread workgroup per CU owns the 64 KiB of
-// tags, the rest of the LDS stages the output, and a trip of the loop runs three stages of three different
-// 3840-row pieces of the chunk on 15 probe waves:
+// s_waitcnt (profiles/r1_run28_pmc_join_sq.txt).  Here ONE persistent 1024-thread workgroup per CU keeps 64 KiB
+// of tags in LDS, the rest of the LDS stages the output, and a trip of the loop runs three stages of three
+// different 3840-row PIECES on 15 probe waves:
 //   S1(t)   issue the (key, row id) loads of piece t                           -> consumed one trip later
 //   S2(t-1) keys arrived: run the chain heads on the LDS tags, issue the slot load of the first candidate
 //           (unconditionally, lanes without a candidate read one shared dummy slot: a conditional load would
 //           make the compiler wait for it on the spot)
-//   S3(t-2) slots arrived: compare, finish the (rare) longer chains, append the matches to LDS staging
-//           buffer (t-2) % 3 at positions handed out by an LDS counter;
+//   S3(t-2) slots arrived: compare, finish the (rare) longer chains on the tags in global memory, append the
+//           matches to LDS staging buffer (t-2) % 3 at positions handed out by an LDS counter;
 //   after the trip's ONE barrier the probe waves send the staged pairs of piece t-3 to HBM as two fully
 //   coalesced streams, while the 16th wave -- which probes nothing -- reserves the output of piece t-2 with one
-//   device atomic and parks the result for the next trip.  Nothing a probe wave does in a trip waits for a
-//   memory operation issued in the same trip, except the rare chain continuations.
+//   device atomic, takes the ticket of piece t+2 and resolves it to (partition, rows), all for later trips.
+// Nothing a probe wave does in a trip waits for a memory operation issued in the same trip, except the rare
+// chain continuations.
+// Pieces are handed out per XCD list in partition order, so the 32 workgroups of an XCD work on the SAME
+// partition (or the next one) at any time: its 2 MiB of slots stay in that XCD's L2.  (With 131072-row chunks,
+// the first version of this kernel, the workgroups of an XCD were spread over ~8 partitions = 16 MiB of slots:
+// 347 M L2 misses, 40 GB fetched for 12 GB of input -- profiles/r2_run6_pmc_join_traffic.txt.)  A workgroup
+// reloads its tags when its next piece belongs to another partition; the pipeline never drains in between.
 constexpr int PP_BT    = 1024;
 constexpr int PP_PW    = PP_BT / GX_WAVE - 1;       // 15 probe waves
 constexpr int PP_R     = 4;                         // rows per thread and piece
@@ -1033,12 +1039,29 @@ __device__ __forceinline__ void unpack_slot(const uint2& v, uint32_t& key, int32
   key = v.x;
   row = (int32_t)v.y;
 }
+struct PpPiece {
+  unsigned long long c0, c1;  // rows [c0, c1) of the partitioned probe arrays
+  unsigned int part;          // their partition
+  unsigned int valid;         // 0: no piece left -- the pipeline drains
+};
+// scan_tags8 on the tags in GLOBAL memory (chain continuations): `tagw` = the sub-table's tag words
+__device__ __forceinline__ bool scan_tags8_global(const uint32_t* tagw, uint32_t li, uint32_t tagpat, uint32_t& cand)
+{
+  const uint32_t w0 = tagw[li >> 3];
+  const uint32_t w1 = (li & 7u) ? tagw[(li >> 3) + 1] : 0u;  // unused when the window is word aligned (also the table's last word)
+  const uint32_t x  = __builtin_amdgcn_alignbit(w1, w0, (li & 7u) * 4u);
+  const uint32_t y  = x ^ tagpat;
+  const uint32_t z  = ~(((x & 0x77777777u) + 0x77777777u) | x) & 0x88888888u;
+  const uint32_t m  = ~(((y & 0x77777777u) + 0x77777777u) | y) & 0x88888888u;
+  cand              = m & ((z & (0u - z)) - 1u);
+  return z != 0;
+}
 
 template <typename K>
 __global__ void __launch_bounds__(PP_BT)
 k_pj_probe_pipe(const K* __restrict__ pkeys, const int32_t* __restrict__ pidx, PjPlan* plan, int pbits,
                 const Slot<K>* __restrict__ slots, uint32_t log2cap, int left_outer, int32_t* __restrict__ out_probe,
-                int32_t* __restrict__ out_build, int64_t capacity, unsigned long long* cursor, unsigned int chunk_rows)
+                int32_t* __restrict__ out_build, int64_t capacity, unsigned long long* cursor)
 {
   typedef typename SlotRaw<K>::type Raw;
   constexpr uint32_t SUB = 1u << PJ_SUB_LOG2;
@@ -1048,70 +1071,96 @@ k_pj_probe_pipe(const K* __restrict__ pkeys, const int32_t* __restrict__ pidx, P
   int32_t* s_sfirst      = s_sidx + 3 * PP_ROWS;                                           // [3][PP_ROWS] staged build rows
   __shared__ unsigned int s_cnt[8];           // pairs staged by piece (it & 7)
   __shared__ unsigned long long s_base[3];    // output position of staging buffer (it % 3)
-  __shared__ unsigned int s_misc[4];
+  __shared__ PpPiece s_piece[4];              // piece of trip (t & 3), resolved two trips ahead by the service wave
   const int P         = 1 << pbits;
   const int LISTP     = P / PJ_NR;
   const uint64_t mask = (1ull << log2cap) - 1;
   const unsigned tid  = threadIdx.x;
   const unsigned lane = lane_id();
   const unsigned w    = tid / GX_WAVE;
+  const uint8_t* gtags = reinterpret_cast<const uint8_t*>(slots + (mask + 1));
 
-  if (tid == 0) {  // take a chunk: own XCD's list first
-    const unsigned x = pj_xcc();
-    unsigned int g   = 0xFFFFFFFFu;
-    for (int i = 0; i < PJ_NR; ++i) {
-      const unsigned y       = (x + i) % PJ_NR;
-      const unsigned int nch = plan->list_chunk0[y + 1] - plan->list_chunk0[y];
-      if (nch == 0) continue;
-      const unsigned int t = atomicAdd(&plan->ticket[y].v, 1u);
-      if (t < nch) {
-        g         = plan->list_chunk0[y] + t;
-        s_misc[1] = y;
-        break;
-      }
-    }
-    s_misc[0] = g;
-  }
   if (tid < 8) s_cnt[tid] = 0;
-  __syncthreads();
-  const unsigned int g = s_misc[0];
-  if (g == 0xFFFFFFFFu) return;
-  {
-    const unsigned y = s_misc[1];
-    for (int e = (int)tid; e < LISTP; e += PP_BT) {
-      const int p           = (int)y * LISTP + e;
-      const unsigned int lo = plan->chunk0[p], hi = plan->chunk0[p + 1];
-      if (lo <= g && g < hi) {
-        s_misc[2] = (unsigned int)p;
-        s_misc[3] = g - lo;
-      }
-    }
-  }
-  __syncthreads();
-  const unsigned int part     = s_misc[2];
-  const unsigned long long p0 = plan->offset[part], p1 = plan->offset[part + 1];
-  const unsigned long long c0 = p0 + (unsigned long long)s_misc[3] * chunk_rows;
-  const unsigned long long c1 = c0 + chunk_rows < p1 ? c0 + chunk_rows : p1;
-  const uint64_t sub_base     = (uint64_t)part << PJ_SUB_LOG2;
-  {
-    const uint8_t* gtags = reinterpret_cast<const uint8_t*>(slots + (mask + 1)) + (sub_base >> 1);
-    const uint4* src     = reinterpret_cast<const uint4*>(gtags);
-    uint4* dst           = reinterpret_cast<uint4*>(smem);
-    for (uint32_t i = tid; i < SUB / 2 / 16; i += PP_BT) dst[i] = src[i];
-  }
-  __syncthreads();
-
-  const int npieces = (int)((c1 - c0 + PP_ROWS - 1) / PP_ROWS);
 
   if (w == PP_PW) {
-    // ------------------------------------------------------------------ service wave: output reservations
-    unsigned long long pending = 0;
-    for (int t = 0; t < npieces + 3; ++t) {
-      const int itf = t - 3, it3 = t - 2;
-      if (lane == 0 && itf >= 0 && itf < npieces) s_base[(unsigned)itf % 3u] = pending;
-      __syncthreads();  // X(t)
+    // ------------------------------------------------------------------ service wave: tickets and reservations
+    // tickets: own XCD's list first, then the others; a list that has run dry stays dry
+    const unsigned x0 = pj_xcc();
+    unsigned ylist    = 0;  // lists tried so far
+    auto take_piece = [&](PpPiece& pc) {
+      pc.valid = 0;
+      pc.c0 = pc.c1 = 0;
+      pc.part = 0;
+      unsigned int g = 0xFFFFFFFFu, y = 0;
       if (lane == 0) {
-        if (it3 >= 0 && it3 < npieces) {
+        while (ylist < PJ_NR) {
+          y                      = (x0 + ylist) % PJ_NR;
+          const unsigned int nch = plan->list_chunk0[y + 1] - plan->list_chunk0[y];
+          if (nch) {
+            const unsigned int t = atomicAdd(&plan->ticket[y].v, 1u);
+            if (t < nch) {
+              g = plan->list_chunk0[y] + t;
+              break;
+            }
+          }
+          ++ylist;
+        }
+      }
+      g     = (unsigned int)__builtin_amdgcn_readfirstlane((int)g);
+      y     = (unsigned int)__builtin_amdgcn_readfirstlane((int)y);
+      ylist = (unsigned int)__builtin_amdgcn_readfirstlane((int)ylist);
+      if (g == 0xFFFFFFFFu) return;
+      // partition of piece g inside list y: the one whose piece interval contains it (LISTP <= 512 entries, 64 lanes)
+      unsigned int part = 0, loc = 0;
+      bool hit = false;
+      for (int e = (int)lane; e < LISTP; e += GX_WAVE) {
+        const int p           = (int)y * LISTP + e;
+        const unsigned int lo = plan->chunk0[p], hi = plan->chunk0[p + 1];
+        if (lo <= g && g < hi) {
+          part = (unsigned int)p;
+          loc  = g - lo;
+          hit  = true;
+        }
+      }
+      const uint64_t hb = ballot(hit);
+      const int src     = __builtin_ctzll(hb);
+      part              = shfl(part, src);
+      loc               = shfl(loc, src);
+      const unsigned long long p0 = plan->offset[part], p1 = plan->offset[part + 1];
+      pc.c0    = p0 + (unsigned long long)loc * PP_ROWS;
+      pc.c1    = pc.c0 + PP_ROWS < p1 ? pc.c0 + PP_ROWS : p1;
+      pc.part  = part;
+      pc.valid = 1;
+    };
+    PpPiece pc;
+    take_piece(pc);
+    if (lane == 0) s_piece[0] = pc;
+    take_piece(pc);
+    if (lane == 0) s_piece[1] = pc;
+    __syncthreads();  // prologue barrier
+    unsigned long long pending = 0;
+    int done_at = -1;
+    unsigned int partC = 0;
+    bool tags_loaded   = false;
+    for (int t = 0;; ++t) {
+      const int itf = t - 3, it3 = t - 2;
+      if (t >= 1) {  // R(t): the probe waves reload their tags when the piece entering S2 belongs to another partition
+        const PpPiece pa = s_piece[(t - 1) & 3];
+        if (pa.valid && (!tags_loaded || pa.part != partC)) {
+          partC       = pa.part;
+          tags_loaded = true;
+          __syncthreads();
+        }
+      }
+      if (done_at < 0 && !s_piece[t & 3].valid) done_at = t;  // same test as the probe waves make
+      if (lane == 0 && itf >= 0) s_base[(unsigned)itf % 3u] = pending;
+      // piece t + 2, for the S1 of two trips from now (its slot in the ring was read last in trip t - 2)
+      take_piece(pc);
+      if (lane == 0) s_piece[(t + 2) & 3] = pc;
+      __syncthreads();  // X(t)
+      if (done_at >= 0 && t >= done_at + 3) break;
+      if (lane == 0) {
+        if (it3 >= 0) {
           unsigned int c = s_cnt[(unsigned)it3 & 7u];
           c              = c < (unsigned)PP_ROWS ? c : (unsigned)PP_ROWS;
           pending        = c ? atomicAdd(cursor, (unsigned long long)c) : 0ull;
@@ -1123,7 +1172,7 @@ k_pj_probe_pipe(const K* __restrict__ pkeys, const int32_t* __restrict__ pidx, P
   }
 
   // ---------------------------------------------------------------------- probe waves
-  const Slot<K>* dummy = slots + sub_base;  // what lanes without a candidate read: one line for the whole wave
+  __syncthreads();  // prologue barrier: pieces 0 and 1 are resolved
   K kA[PP_R];                // S1 -> S2
   int32_t iA[PP_R];
   K kB[PP_R];                // S2 -> S3
@@ -1131,6 +1180,10 @@ k_pj_probe_pipe(const K* __restrict__ pkeys, const int32_t* __restrict__ pidx, P
   uint32_t li[PP_R], cand[PP_R];
   Raw sv[PP_R];              // first candidate slot, in flight from S2 to S3
   uint32_t fl = 0;           // per row j: bit j = live row, bit 4+j = chain ended inside the scanned window, bit 8+j = chain left the LDS window
+  uint32_t partA = 0, partB = 0, partC = 0;     // partition of the piece in S1->S2, S2->S3 (this trip's S3), and of the LDS tags
+  bool tags_loaded = false;
+  unsigned long long cA0 = 0, cA1 = 0;          // row range of the piece loaded by the last S1
+  bool validA = false, validB = false;          // a piece sits between S1 and S2 / between S2 and S3
 #pragma unroll
   for (int j = 0; j < PP_R; ++j) {
     kA[j] = kB[j] = K(0);
@@ -1138,12 +1191,15 @@ k_pj_probe_pipe(const K* __restrict__ pkeys, const int32_t* __restrict__ pidx, P
     li[j] = cand[j] = 0;
     sv[j] = Raw{};
   }
+  int done_at = -1;
 
-  for (int t = 0; t < npieces + 3; ++t) {
+  for (int t = 0;; ++t) {
     // ---------------- S3(t-2): compare, finish chains, stage the matches
     const int it3 = t - 2;
-    if (it3 >= 0 && it3 < npieces) {
-      const unsigned buf = (unsigned)it3 % 3u;
+    if (validB) {
+      const unsigned buf       = (unsigned)it3 % 3u;
+      const uint64_t sub_base  = (uint64_t)partB << PJ_SUB_LOG2;
+      const uint32_t* gtagw    = reinterpret_cast<const uint32_t*>(gtags + (sub_base >> 1));
       uint32_t m[PP_R];
       int32_t first[PP_R];
       K sk[PP_R];
@@ -1197,7 +1253,7 @@ k_pj_probe_pipe(const K* __restrict__ pkeys, const int32_t* __restrict__ pidx, P
           if (cand[j] == 0) {
             if (ended & (1u << j)) {
               active &= ~(1u << j);
-            } else {  // the chain runs on: next 8 slots
+            } else {  // the chain runs on: next 8 slots (tags from global memory: the LDS may hold another partition's)
               li[j] += 8;
               if (li[j] > SUB - 8) {
                 uint64_t gs = sub_base + li[j];
@@ -1214,7 +1270,7 @@ k_pj_probe_pipe(const K* __restrict__ pkeys, const int32_t* __restrict__ pidx, P
                 }
                 active &= ~(1u << j);
               } else {
-                const bool e = scan_tags8(s_tagw, li[j], tag_of<K>(kB[j], log2cap) * 0x11111111u, cand[j]);
+                const bool e = scan_tags8_global(gtagw, li[j], tag_of<K>(kB[j], log2cap) * 0x11111111u, cand[j]);
                 if (e) {
                   ended |= 1u << j;
                   if (cand[j] == 0) active &= ~(1u << j);
@@ -1231,10 +1287,10 @@ k_pj_probe_pipe(const K* __restrict__ pkeys, const int32_t* __restrict__ pidx, P
         if (left_outer && live && m[j] == 0) m[j] = 1;  // (row, JoinNoMatch); first[j] is NO_MATCH
         uint32_t off, tot;
         if (ballot(m[j] > 1) == 0) {
-          const uint64_t b = ballot(m[j] == 1);
-          if (b == 0) continue;
-          off = (uint32_t)__builtin_popcountll(b & lanemask_lt());
-          tot = (uint32_t)__builtin_popcountll(b);
+          const uint64_t bb = ballot(m[j] == 1);
+          if (bb == 0) continue;
+          off = (uint32_t)__builtin_popcountll(bb & lanemask_lt());
+          tot = (uint32_t)__builtin_popcountll(bb);
         } else {
           const uint32_t sc = wave_inclusive_scan(m[j], SumOp());
           off               = sc - m[j];
@@ -1286,18 +1342,31 @@ k_pj_probe_pipe(const K* __restrict__ pkeys, const int32_t* __restrict__ pidx, P
         }
       }
     }
+    // ---------------- tags of the partition S2 is about to probe (workgroup-uniform branch; the S2 of the previous
+    // trip finished before X(t-1), S3 does not read the LDS tags)
+    if (validA && (!tags_loaded || partA != partC)) {
+      const uint4* src = reinterpret_cast<const uint4*>(gtags + (((uint64_t)partA << PJ_SUB_LOG2) >> 1));
+      uint4* dst       = reinterpret_cast<uint4*>(smem);
+      for (uint32_t i = tid; i < SUB / 2 / 16; i += PP_PW * GX_WAVE) dst[i] = src[i];
+      partC       = partA;
+      tags_loaded = true;
+      __syncthreads();  // R(t): every probe wave's share of the tags is in place (the service wave joins this barrier)
+    }
     // ---------------- S2(t-1): chain heads on the LDS tags, first candidate slot in flight
-    const int it2 = t - 1;
-    fl            = 0;
-    if (it2 >= 0 && it2 < npieces) {
-      const unsigned long long pb = c0 + (unsigned long long)it2 * PP_ROWS + (unsigned long long)w * (PP_R * GX_WAVE) + lane;
+    fl     = 0;
+    validB = validA;
+    partB  = partA;
+    if (validA) {
+      const uint64_t sub_base = (uint64_t)partA << PJ_SUB_LOG2;
+      const Slot<K>* dummy    = slots + sub_base;  // what lanes without a candidate read: one line for the whole wave
+      const unsigned long long pb = cA0 + (unsigned long long)w * (PP_R * GX_WAVE) + lane;
 #pragma unroll
       for (int j = 0; j < PP_R; ++j) {
         kB[j]   = kA[j];
         iB[j]   = iA[j];
         cand[j] = 0;
         li[j]   = 0;
-        if (pb + (unsigned long long)j * GX_WAVE < c1) {
+        if (pb + (unsigned long long)j * GX_WAVE < cA1) {
           fl |= 1u << j;
           const uint64_t prod = (uint64_t)kB[j] * 0x9E3779B97F4A7C15ull;
           li[j]               = (uint32_t)((prod >> (64 - log2cap)) - sub_base);
@@ -1317,20 +1386,29 @@ k_pj_probe_pipe(const K* __restrict__ pkeys, const int32_t* __restrict__ pidx, P
       }
     }
     // ---------------- S1(t): loads of the next piece
-    if (t < npieces) {
-      const unsigned long long pb = c0 + (unsigned long long)t * PP_ROWS + (unsigned long long)w * (PP_R * GX_WAVE) + lane;
+    {
+      const PpPiece pc = s_piece[t & 3];
+      validA           = pc.valid != 0;
+      if (done_at < 0 && !validA) done_at = t;
+      if (validA) {
+        partA = pc.part;
+        cA0   = pc.c0;
+        cA1   = pc.c1;
+        const unsigned long long pb = cA0 + (unsigned long long)w * (PP_R * GX_WAVE) + lane;
 #pragma unroll
-      for (int j = 0; j < PP_R; ++j) {
-        const unsigned long long i  = pb + (unsigned long long)j * GX_WAVE;
-        const unsigned long long ic = i < c1 ? i : c0;  // clamped: the load is unconditional, dead rows are masked by `fl`
-        kA[j] = __builtin_nontemporal_load(&pkeys[ic]);
-        iA[j] = __builtin_nontemporal_load(&pidx[ic]);
+        for (int j = 0; j < PP_R; ++j) {
+          const unsigned long long i  = pb + (unsigned long long)j * GX_WAVE;
+          const unsigned long long ic = i < cA1 ? i : cA0;  // clamped: the load is unconditional, dead rows are masked by `fl`
+          kA[j] = __builtin_nontemporal_load(&pkeys[ic]);
+          iA[j] = __builtin_nontemporal_load(&pidx[ic]);
+        }
       }
     }
     __syncthreads();  // X(t): staging of piece t-2 complete, s_base of piece t-3 visible
+    if (done_at >= 0 && t >= done_at + 3) break;
     // ---------------- flush of piece t-3: two coalesced streams
     const int itf = t - 3;
-    if (itf >= 0 && itf < npieces) {
+    if (itf >= 0) {
       const unsigned buf          = (unsigned)itf % 3u;
       unsigned int c              = s_cnt[(unsigned)itf & 7u];
       c                           = c < (unsigned)PP_ROWS ? c : (unsigned)PP_ROWS;
@@ -1501,8 +1579,9 @@ int probe_partitioned_impl(const void* keys, int64_t n, const void* table, size_
   unsigned int chunk_rows = PJ_CHUNK;
   if (use_tags) {
     const int mult = getenv("GX_PJ_SC") ? atoi(getenv("GX_PJ_SC")) : 8;
-    chunk_rows     = PJ_CHUNK * (unsigned)(mult < 1 ? 1 : mult) * (use_pipe ? 2u : 1u);
-    while (chunk_rows > PJ_CHUNK && div_up(n, (int64_t)chunk_rows) < (use_pipe ? 2048 : 4096)) chunk_rows /= 2;  // keep >> 256 (512) workgroups
+    chunk_rows     = PJ_CHUNK * (unsigned)(mult < 1 ? 1 : mult);
+    while (chunk_rows > PJ_CHUNK && div_up(n, (int64_t)chunk_rows) < 4096) chunk_rows /= 2;  // keep >> 512 workgroups
+    if (use_pipe) chunk_rows = PP_ROWS;  // the persistent probe takes tickets per 3840-row piece
   }
   {
     int rc = pj_partition<K>(static_cast<const K*>(keys), n, pbits, plan, pkeys, pidx, chunk_rows, s, true);
@@ -1512,12 +1591,19 @@ int probe_partitioned_impl(const void* keys, int64_t n, const void* table, size_
   if (use_pipe) {
     constexpr size_t lds_p = ((size_t)1 << (PJ_SUB_LOG2 - 1)) + (size_t)6 * PP_ROWS * sizeof(int32_t);
     static bool pattr_set  = false;
+    static int num_cus     = 0;
     if (!pattr_set) {
       GX_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(k_pj_probe_pipe<K>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_p));
+      int dev = 0;
+      GX_HIP_TRY(hipGetDevice(&dev));
+      GX_HIP_TRY(hipDeviceGetAttribute(&num_cus, hipDeviceAttributeMultiprocessorCount, dev));
       pattr_set = true;
     }
-    hipLaunchKernelGGL((k_pj_probe_pipe<K>), dim3((unsigned)max_chunks), dim3(PP_BT), lds_p, s, pkeys, pidx, plan, pbits, slots, lg,
-                       left_outer, out_probe, out_build, capacity, reinterpret_cast<unsigned long long*>(cursor), chunk_rows);
+    // persistent workgroups, one per CU (the LDS admits no second one); pieces come from per-XCD tickets
+    int64_t grid = num_cus > 0 ? num_cus : 256;
+    if (grid > max_chunks) grid = max_chunks;
+    hipLaunchKernelGGL((k_pj_probe_pipe<K>), dim3((unsigned)grid), dim3(PP_BT), lds_p, s, pkeys, pidx, plan, pbits, slots, lg,
+                       left_outer, out_probe, out_build, capacity, reinterpret_cast<unsigned long long*>(cursor));
   } else if (use_tags) {
     constexpr size_t lds_t = (size_t)1 << (PJ_SUB_LOG2 - 1);
     static bool tattr_set  = false;

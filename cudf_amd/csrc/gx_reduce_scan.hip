@@ -188,7 +188,7 @@ int reduce_typed(const void* in, const uint32_t* valid, int64_t n, AccT identity
   scan::PlainLoader<InT, AccT> ld{static_cast<const InT*>(in), valid, identity};
   int rc = scan::device_reduce<AccT>(ld, n, identity, op, partials, s);
   if (rc) return rc;
-  hipLaunchKernelGGL((k_store_result<AccT>), dim3(1), dim3(1), 0, s, partials + scan::num_chunks(n), out_dtype, out);
+  hipLaunchKernelGGL((k_store_result<AccT>), dim3(1), dim3(1), 0, s, partials + scan::reduce_blocks(n), out_dtype, out);
   GX_LAUNCH_CHECK();
   return 0;
 }
@@ -207,7 +207,7 @@ int reduce_dd(const void* in, const uint32_t* valid, int64_t n, int out_dtype, v
   DDLoader<InT> ld{static_cast<const InT*>(in), valid};
   int rc = scan::device_reduce<DD>(ld, n, DD{0.0, 0.0}, DDSum(), partials, s);
   if (rc) return rc;
-  hipLaunchKernelGGL((k_store_result<DD>), dim3(1), dim3(1), 0, s, partials + scan::num_chunks(n), out_dtype, out);
+  hipLaunchKernelGGL((k_store_result<DD>), dim3(1), dim3(1), 0, s, partials + scan::reduce_blocks(n), out_dtype, out);
   GX_LAUNCH_CHECK();
   return 0;
 }
