@@ -451,8 +451,40 @@ __device__ __forceinline__ unsigned pj_xcc() { return __builtin_amdgcn_s_getreg(
 // rows per XCD range of the input: a whole number of scatter tiles, so that no tile straddles two ranges
 static inline int64_t pj_range_rows(int64_t n, int64_t tile_rows) { return div_up(n, tile_rows) / PJ_NR * tile_rows; }
 
+// Which partition a key goes to.  TableTop: the top bits of the table hash -- partition p owns slots [p, p+1) << 17 of
+// the join table (the partitioned probe / build).  AltHash: top bits of a SECOND multiplicative hash, independent of
+// the table's slot bits (the rank a row is sent to in the distributed join: the rows of one rank must still spread
+// over the whole local table).  Range: number of splitters <= key in sort order (the distributed sort's exchange).
 template <typename K>
-__global__ void __launch_bounds__(256) k_pj_hist(const K* __restrict__ keys, int64_t n, PjPlan* plan, int pbits, int64_t rrows)
+struct TableTop {
+  int pbits;
+  __device__ __forceinline__ unsigned int operator()(K key) const { return (unsigned int)slot_of<K>(key, (uint32_t)pbits); }
+};
+template <typename K>
+struct AltHash {
+  int pbits;
+  __device__ __forceinline__ unsigned int operator()(K key) const
+  {
+    return pbits ? (unsigned int)(((uint64_t)key * 0xD6E8FEB86659FD93ull) >> (64 - pbits)) : 0u;
+  }
+};
+constexpr int PJ_MAX_SPLIT = 15;
+template <typename K, int KIND>
+struct RangeSplit {
+  K split[PJ_MAX_SPLIT];  // sortable form, ascending
+  int nsplit;
+  __device__ __forceinline__ unsigned int operator()(K key) const
+  {
+    const K sk     = to_sortable<K, KIND>(key, K(0));
+    unsigned int d = 0;
+#pragma unroll
+    for (int i = 0; i < PJ_MAX_SPLIT; ++i) d += (i < nsplit && split[i] <= sk) ? 1u : 0u;
+    return d;
+  }
+};
+
+template <typename K, typename F>
+__global__ void __launch_bounds__(256) k_pj_hist(const K* __restrict__ keys, int64_t n, PjPlan* plan, int pbits, int64_t rrows, F part_of)
 {
   __shared__ unsigned int s_h[PJ_MAXP];
   const int P = 1 << pbits;
@@ -475,7 +507,7 @@ __global__ void __launch_bounds__(256) k_pj_hist(const K* __restrict__ keys, int
 #pragma unroll
     for (int u = 0; u < U; ++u) {
       const int64_t i = i0 + (int64_t)u * 256;
-      if (i < rend) atomicAdd(&s_h[slot_of<K>(k[u], (uint32_t)pbits)], 1u);
+      if (i < rend) atomicAdd(&s_h[part_of(k[u])], 1u);
     }
   }
   __syncthreads();
@@ -535,9 +567,9 @@ __global__ void __launch_bounds__(1024) k_pj_offsets(PjPlan* plan, int pbits, un
 // through the same buffer.  The partition of an element is recomputed from its key at write-out (one 64-bit
 // multiply) instead of being staged: the whole LDS budget goes to rows, and a tile of 16384 rows gives runs
 // of 8 rows (64 B of keys) at P = 2048 where the 4096-row tile of round 1 gave 2.
-template <typename K, int RPT, int BTt>
+template <typename K, int RPT, int BTt, typename F>
 __global__ void __launch_bounds__(BTt) k_pj_scatter(const K* __restrict__ keys, int64_t n, PjPlan* plan, int pbits,
-                                                    int64_t rrows, K* __restrict__ pkeys, int32_t* __restrict__ pidx)
+                                                    int64_t rrows, K* __restrict__ pkeys, int32_t* __restrict__ pidx, F part_of)
 {
   constexpr int TILE = BTt * RPT;
   extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -567,7 +599,7 @@ __global__ void __launch_bounds__(BTt) k_pj_scatter(const K* __restrict__ keys, 
 #pragma unroll
   for (int j = 0; j < RPT; ++j) {
     const int idx           = j * BTt + (int)tid;
-    const unsigned int part = (unsigned int)slot_of<K>(key[j], (uint32_t)pbits);
+    const unsigned int part = part_of(key[j]);
     const unsigned int rank = (idx < nvalid) ? atomicAdd(&s_cnt[part], 1u) : 0u;
     packed[j]               = (part << 16) | rank;
   }
@@ -602,10 +634,11 @@ __global__ void __launch_bounds__(BTt) k_pj_scatter(const K* __restrict__ keys, 
     obin[j]     = 0;
     if (i < nvalid) {
       const K k = s_k[i];
-      obin[j]   = (unsigned short)slot_of<K>(k, (uint32_t)pbits);
+      obin[j]   = (unsigned short)part_of(k);
       pkeys[(unsigned int)(s_delta[obin[j]] + (unsigned int)i)] = k;
     }
   }
+  if (pidx == nullptr) return;  // keys only (range partition of a sort)
   __syncthreads();
   // row indices through the same buffer
   int32_t* s_i = reinterpret_cast<int32_t*>(smem);
@@ -1504,10 +1537,10 @@ static inline void jprof_mark(int i, hipStream_t s)
 static int g_pj_probe = 0; // probe kernel: 0 = default (software-pipelined tag probe), 1 = round-1 tag probe (A/B knob)
 static int g_pj_tile = 0;  // scatter tile rows: 0 = default, else 4096 / 8192 / 16384 (A/B knob)
 
-// the partition pass shared by the partitioned probe and build
-template <typename K>
-int pj_partition(const K* keys, int64_t n, int pbits, PjPlan* plan, K* pkeys, int32_t* pidx, unsigned int chunk_rows, hipStream_t s,
-                 bool profile = false)
+// the partition pass shared by the partitioned probe and build (F = TableTop) and by gx_partition_rows
+template <typename K, typename F>
+int pj_partition_fn(const K* keys, int64_t n, int pbits, PjPlan* plan, K* pkeys, int32_t* pidx, unsigned int chunk_rows, hipStream_t s,
+                    F part_of, bool profile = false)
 {
   GX_HIP_TRY(hipMemsetAsync(plan, 0, sizeof(PjPlan), s));
   // tile: as many rows as the LDS holds next to the three P-entry arrays (160 KiB per CU)
@@ -1519,14 +1552,14 @@ int pj_partition(const K* keys, int64_t n, int pbits, PjPlan* plan, K* pkeys, in
   int64_t hb = div_up(n, 256 * 8 * 4 * PJ_NR);
   if (hb > 256) hb = 256;
   if (hb < 1) hb = 1;
-  hipLaunchKernelGGL((k_pj_hist<K>), dim3((unsigned)(hb * PJ_NR)), dim3(256), 0, s, keys, n, plan, pbits, rrows);
+  hipLaunchKernelGGL((k_pj_hist<K, F>), dim3((unsigned)(hb * PJ_NR)), dim3(256), 0, s, keys, n, plan, pbits, rrows, part_of);
   hipLaunchKernelGGL(k_pj_offsets, dim3(1), dim3(1024), 0, s, plan, pbits, chunk_rows);
   if (profile) jprof_mark(1, s);
   const size_t lds = (size_t)tile_rows * sizeof(K) + ((size_t)12 << pbits);
-  auto k4          = k_pj_scatter<K, 8, 512>;
-  auto k8          = k_pj_scatter<K, 16, 512>;
-  auto k16         = k_pj_scatter<K, 16, 1024>;
-  static bool attr_set = false;
+  auto k4          = k_pj_scatter<K, 8, 512, F>;
+  auto k8          = k_pj_scatter<K, 16, 512, F>;
+  auto k16         = k_pj_scatter<K, 16, 1024, F>;
+  static bool attr_set = false;  // per instantiation
   if (!attr_set) {
     const int lds_max = 160 * 1024 - 256;
     GX_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(k4), hipFuncAttributeMaxDynamicSharedMemorySize, lds_max));
@@ -1535,10 +1568,65 @@ int pj_partition(const K* keys, int64_t n, int pbits, PjPlan* plan, K* pkeys, in
     attr_set = true;
   }
   const unsigned grid = (unsigned)div_up(n, (int64_t)tile_rows);
-  if (tile_rows == 16384) hipLaunchKernelGGL(k16, dim3(grid), dim3(1024), lds, s, keys, n, plan, pbits, rrows, pkeys, pidx);
-  else if (tile_rows == 8192) hipLaunchKernelGGL(k8, dim3(grid), dim3(512), lds, s, keys, n, plan, pbits, rrows, pkeys, pidx);
-  else hipLaunchKernelGGL(k4, dim3(grid), dim3(512), lds, s, keys, n, plan, pbits, rrows, pkeys, pidx);
+  if (tile_rows == 16384) hipLaunchKernelGGL(k16, dim3(grid), dim3(1024), lds, s, keys, n, plan, pbits, rrows, pkeys, pidx, part_of);
+  else if (tile_rows == 8192) hipLaunchKernelGGL(k8, dim3(grid), dim3(512), lds, s, keys, n, plan, pbits, rrows, pkeys, pidx, part_of);
+  else hipLaunchKernelGGL(k4, dim3(grid), dim3(512), lds, s, keys, n, plan, pbits, rrows, pkeys, pidx, part_of);
   if (profile) jprof_mark(2, s);
+  GX_LAUNCH_CHECK();
+  return 0;
+}
+template <typename K>
+int pj_partition(const K* keys, int64_t n, int pbits, PjPlan* plan, K* pkeys, int32_t* pidx, unsigned int chunk_rows, hipStream_t s,
+                 bool profile = false)
+{
+  return pj_partition_fn<K, TableTop<K>>(keys, n, pbits, plan, pkeys, pidx, chunk_rows, s, TableTop<K>{pbits}, profile);
+}
+
+// partition starts as int64, for the caller of gx_partition_rows
+__global__ void k_pj_export_offsets(const PjPlan* plan, int nparts, long long* out)
+{
+  for (int i = threadIdx.x; i <= nparts; i += blockDim.x) out[i] = (long long)plan->offset[i];
+}
+
+template <typename K>
+int partition_rows_hash(const void* keys, int64_t n, int pbits, int nparts, void* out_keys, int32_t* out_rows, int64_t* offsets,
+                        void* tmp, size_t* tmp_bytes, hipStream_t s)
+{
+  Carver c(tmp);
+  PjPlan* plan = c.take<PjPlan>(1);
+  if (!tmp) {
+    *tmp_bytes = c.total();
+    return 0;
+  }
+  if (*tmp_bytes < c.total()) return GX_ETMP;
+  int rc = pj_partition_fn<K, AltHash<K>>(static_cast<const K*>(keys), n, pbits < 3 ? 3 : pbits, plan, static_cast<K*>(out_keys), out_rows,
+                                          PJ_CHUNK, s, AltHash<K>{pbits});
+  if (rc) return rc;
+  hipLaunchKernelGGL(k_pj_export_offsets, dim3(1), dim3(256), 0, s, plan, nparts, reinterpret_cast<long long*>(offsets));
+  GX_LAUNCH_CHECK();
+  return 0;
+}
+template <typename K, int KIND>
+int partition_rows_range(const void* keys, int64_t n, int nparts, const void* splitters_host, void* out_keys, int32_t* out_rows,
+                         int64_t* offsets, void* tmp, size_t* tmp_bytes, hipStream_t s)
+{
+  Carver c(tmp);
+  PjPlan* plan = c.take<PjPlan>(1);
+  if (!tmp) {
+    *tmp_bytes = c.total();
+    return 0;
+  }
+  if (*tmp_bytes < c.total()) return GX_ETMP;
+  RangeSplit<K, KIND> f;
+  f.nsplit = nparts - 1;
+  for (int i = 0; i < PJ_MAX_SPLIT; ++i)
+    f.split[i] = i < f.nsplit ? to_sortable<K, KIND>(static_cast<const K*>(splitters_host)[i], K(0)) : K(0);
+  int pbits = 3;
+  while ((1 << pbits) < nparts) ++pbits;
+  int rc = pj_partition_fn<K, RangeSplit<K, KIND>>(static_cast<const K*>(keys), n, pbits, plan, static_cast<K*>(out_keys), out_rows, PJ_CHUNK,
+                                                   s, f);
+  if (rc) return rc;
+  hipLaunchKernelGGL(k_pj_export_offsets, dim3(1), dim3(256), 0, s, plan, nparts, reinterpret_cast<long long*>(offsets));
   GX_LAUNCH_CHECK();
   return 0;
 }
@@ -1804,6 +1892,35 @@ int gx_join_filter(int key_size, const void* probe_keys, const uint32_t* probe_v
     return gx::join::filter_impl<uint32_t>(probe_keys, probe_valid, probe_rows, table, table_bytes, lg, anti, null_matches,
                                            out_probe_idx, count_dev, tmp, tmp_bytes, (hipStream_t)s);
   return GX_EDTYPE;
+}
+
+/* see gx.h */
+int gx_partition_rows(int key_dtype, const void* keys, int64_t n, int mode, int nparts, const void* splitters_host, void* out_keys,
+                      int32_t* out_rows, int64_t* offsets_dev, void* tmp, size_t* tmp_bytes, gx_stream_t s)
+{
+  using namespace gx;
+  using namespace gx::join;
+  if (n < 0 || nparts < 1 || nparts > PJ_MAX_SPLIT + 1 || !tmp_bytes || (mode != 0 && mode != 1)) return GX_EINVAL;
+  if (tmp && (!offsets_dev || (n > 0 && (!keys || !out_keys)) || (mode == 1 && nparts > 1 && !splitters_host))) return GX_EINVAL;
+  if (mode == 0) {
+    if (nparts & (nparts - 1)) return GX_EINVAL;  // hash mode: a power of two ranks
+    int pbits = 0;
+    while ((1 << pbits) < nparts) ++pbits;
+    switch (gx_dtype_size(key_dtype)) {
+      case 8: return partition_rows_hash<uint64_t>(keys, n, pbits, nparts, out_keys, out_rows, offsets_dev, tmp, tmp_bytes, s);
+      case 4: return partition_rows_hash<uint32_t>(keys, n, pbits, nparts, out_keys, out_rows, offsets_dev, tmp, tmp_bytes, s);
+      default: return GX_EDTYPE;
+    }
+  }
+  switch (key_dtype) {
+    case GX_INT64: return partition_rows_range<uint64_t, K_SIGNED>(keys, n, nparts, splitters_host, out_keys, out_rows, offsets_dev, tmp, tmp_bytes, s);
+    case GX_UINT64: return partition_rows_range<uint64_t, K_UNSIGNED>(keys, n, nparts, splitters_host, out_keys, out_rows, offsets_dev, tmp, tmp_bytes, s);
+    case GX_FLOAT64: return partition_rows_range<uint64_t, K_FLOAT>(keys, n, nparts, splitters_host, out_keys, out_rows, offsets_dev, tmp, tmp_bytes, s);
+    case GX_INT32: return partition_rows_range<uint32_t, K_SIGNED>(keys, n, nparts, splitters_host, out_keys, out_rows, offsets_dev, tmp, tmp_bytes, s);
+    case GX_UINT32: return partition_rows_range<uint32_t, K_UNSIGNED>(keys, n, nparts, splitters_host, out_keys, out_rows, offsets_dev, tmp, tmp_bytes, s);
+    case GX_FLOAT32: return partition_rows_range<uint32_t, K_FLOAT>(keys, n, nparts, splitters_host, out_keys, out_rows, offsets_dev, tmp, tmp_bytes, s);
+    default: return GX_EDTYPE;
+  }
 }
 
 int gx_join_count_rows(int key_size, const void* probe_keys, const uint32_t* probe_valid, int64_t probe_rows, const void* table,

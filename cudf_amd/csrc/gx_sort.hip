@@ -671,23 +671,23 @@ struct MsdArgs {
   uint64_t desc_mask;
 };
 
-// One partition pass of the hybrid sort: k_radix_pass's tile body (ranking in LDS, LDS reorder, decoupled
-// look-back, coalesced write-out) over SEGMENTS.  A segment is a contiguous piece of the input with its own
-// output bases and its own look-back chain: level 0 = the NRANGE input ranges (bases from the range-resolved
-// histogram), level 1 = the 256 buckets of level 0 (every cell owns a fixed slot; the look-back prefix is the
-// position inside it).  Chains never cross segments, so tiles are handed out per XCD: list x (range x; buckets
-// 32x..32x+31) has its own ticket counter, served first by the workgroups running on XCD x (HW_REG_XCC_ID) and
-// by anyone once their own list is drained.  Neighbouring tiles thus share an L2, where the partial 128-B lines
-// at the seams of their output runs merge (the per-XCD L2s are not coherent; see DESIGN.md "XCD-local write
-// combining").  Correctness needs no placement assumption: within a list tickets are handed out in order, so
-// every predecessor a tile can wait for is already owned by a running workgroup.
-// The workgroups are PERSISTENT (two per CU) and software-pipelined: the ticket of the next tile is taken while
-// the bins of the current one look back, and its keys are loaded into registers before the current tile is
-// written out, so every CU always has loads in flight under its stores (the one-tile-per-workgroup form left the
-// memory pipe idle through ranking, look-back and write-out: 66 % of its wave cycles were waits,
-// profiles/r2_run3_pmc_sq_sort.txt).
+// One stable partition pass of the hybrid sort: k_radix_pass's tile body (wave64 ballot ranking,
+// LDS reorder, decoupled look-back, coalesced write-out) over SEGMENTS.  A segment is a contiguous
+// piece of the input with its own output bases and its own look-back chain: level 0 = the NRANGE
+// input ranges (bases from the range-resolved histogram), level 1 = the 256 buckets of level 0
+// (bases from the joint histogram).  Chains never cross segments, so tiles are handed out per XCD:
+// list x (range x; buckets 32x..32x+31) has its own ticket counter, served first by the workgroups
+// running on XCD x (HW_REG_XCC_ID) and by anyone once their own list is drained.  Neighbouring
+// tiles thus share an L2, where the partial 128-B lines at the seams of their output runs merge
+// (the per-XCD L2s are not coherent; see DESIGN.md "XCD-local write combining").  Correctness
+// needs no placement assumption: within a list tickets are handed out in order, so every
+// predecessor a tile can wait for is already owned by a running workgroup.
+// (Measured and dropped in round 2: persistent workgroups that prefetch the next tile's keys into registers during
+// the write-out.  A ticket taken late costs its latency before the write-out barrier (4.98 / 5.20 ms per pass against
+// 4.21 / 4.70), a ticket taken early delays the aggregate its successors look back for (5.34 / 6.31 ms):
+// profiles/r2_run8_bench_sort_persistent.jsonl, r2_run9_bench_persistent_early_ticket.jsonl.)
 template <typename KeyT, int KIND, bool HAS_VAL, int KPT, int LBW, int NBL>
-__global__ void __launch_bounds__(BT, 4) k_msd_pass(MsdArgs a)
+__global__ void __launch_bounds__(BT, (KPT <= 8 ? 8 : (KPT <= 12 ? 6 : 4))) k_msd_pass(MsdArgs a)
 {
   constexpr int TILE = BT * KPT;
   constexpr int NB   = 1 << NBL;  // bins of this pass: 256 (level 0, level 1 up to 8 bits) or 512 (9-bit level 1)
@@ -701,7 +701,7 @@ __global__ void __launch_bounds__(BT, 4) k_msd_pass(MsdArgs a)
   extern __shared__ __attribute__((aligned(16))) char smem[];
   KeyT* s_keys       = reinterpret_cast<KeyT*>(smem);
   uint32_t* s_vals   = reinterpret_cast<uint32_t*>(smem + (size_t)TILE * sizeof(KeyT));  // [TILE] (HAS_VAL)
-  uint32_t* s_whist  = s_vals + (HAS_VAL ? TILE : 0);                                    // [WROWS][NB]
+  uint32_t* s_whist  = s_vals + (HAS_VAL ? TILE : 0);                                    // [NW][NB]
   uint32_t* s_gdelta = s_whist + WROWS * NB;                                             // [NB]
   uint32_t* s_limit  = s_gdelta + NB;                                                    // [NB] end of each bin's output slot
   uint32_t* s_scan   = s_limit + NB;                                                     // [16]
@@ -723,234 +723,201 @@ __global__ void __launch_bounds__(BT, 4) k_msd_pass(MsdArgs a)
   const unsigned lane  = lane_id();
   const unsigned w     = tid / GX_WAVE;
   const unsigned epoch = 9u + (unsigned)lvl;  // LSD passes use 1..8 on the same status array
-  constexpr uint32_t NONE = 0xFFFFFFFFu;
 
-  // a tile ticket: own XCD's list first, then the others
-  const unsigned xhome = ((a.exp & 1) && lvl == 1) ? 0u : ((a.exp & 2) ? (blockIdx.x % NRANGE) : xcc_id());
-  auto take_ticket = [&]() -> uint32_t {
+  // ---- take a tile: own XCD's list first, then the others
+  if (tid == 0) {
+    const unsigned x = ((a.exp & 1) && lvl == 1) ? 0u : ((a.exp & 2) ? (blockIdx.x % NRANGE) : xcc_id());
+    uint32_t g       = 0xFFFFFFFFu;
     for (int i = 0; i < NRANGE; ++i) {
-      const unsigned y   = (xhome + i) % NRANGE;
+      const unsigned y   = (x + i) % NRANGE;
       const uint32_t ntl = hy.list_tile0[lvl][y + 1] - hy.list_tile0[lvl][y];
       if (ntl == 0) continue;
-      if (*reinterpret_cast<volatile uint32_t*>(&plan->cnt.ctr[lvl][y].v) >= ntl) continue;  // dry list: no atomic
       const uint32_t t = atomicAdd(&plan->cnt.ctr[lvl][y].v, 1u);
-      if (t < ntl) return hy.list_tile0[lvl][y] + t;
+      if (t < ntl) {
+        g = hy.list_tile0[lvl][y] + t;
+        break;
+      }
     }
-    return NONE;
-  };
-  // segment of global tile g: the one whose tile interval contains it (one table entry per thread)
-  auto lookup_segment = [&](uint32_t g) {
-    if (g != NONE && (int)tid < nseg) {
+    s_misc[0] = g;
+  }
+  __syncthreads();
+  {
+    // segment of global tile g: the one whose tile interval contains it (one table entry per thread)
+    const uint32_t g = s_misc[0];
+    if (g != 0xFFFFFFFFu && (int)tid < nseg) {
       const uint32_t lo = hy.seg_tile0[lvl][tid], hi = hy.seg_tile0[lvl][tid + 1];
       if (lo <= g && g < hi) {
         s_misc[1] = tid;
         s_misc[2] = g - lo;
       }
     }
-  };
+  }
+  __syncthreads();
+  const uint32_t gtile = s_misc[0];
+  if (gtile == 0xFFFFFFFFu) return;
+  const uint32_t seg   = s_misc[1];
+  const uint32_t jt    = s_misc[2];
+  const int64_t base   = (int64_t)hy.seg_start[lvl][seg] + (int64_t)jt * TILE;
+  const int64_t remain = (int64_t)hy.seg_count[lvl][seg] - (int64_t)jt * TILE;
+  const int nvalid     = (int)(remain < (int64_t)TILE ? remain : (int64_t)TILE);
+
+  // ---- load (wave-striped)
+  KeyT key[KPT];
+  uint32_t val[HAS_VAL ? KPT : 1];
   const int wbase = (int)w * (KPT * GX_WAVE) + (int)lane;
-  KeyT keyN[KPT];  // the next tile's keys, in flight while the current tile is written out
-  uint32_t gN, segN = 0, jtN = 0;
-  int64_t baseN = 0;
-  int nvalidN   = 0;
-  auto describe_next = [&]() {  // after a barrier that published s_misc[0..2]; everything here is wave-uniform (SGPRs)
-    gN = (uint32_t)__builtin_amdgcn_readfirstlane((int)s_misc[0]);
-    if (gN == NONE) return;
-    segN                 = (uint32_t)__builtin_amdgcn_readfirstlane((int)s_misc[1]);
-    jtN                  = (uint32_t)__builtin_amdgcn_readfirstlane((int)s_misc[2]);
-    const uint32_t sst   = (uint32_t)__builtin_amdgcn_readfirstlane((int)hy.seg_start[lvl][segN]);
-    const uint32_t scn   = (uint32_t)__builtin_amdgcn_readfirstlane((int)hy.seg_count[lvl][segN]);
-    baseN                = (int64_t)sst + (int64_t)jtN * TILE;
-    const int64_t remain = (int64_t)scn - (int64_t)jtN * TILE;
-    nvalidN              = (int)(remain < (int64_t)TILE ? remain : (int64_t)TILE);
-  };
-  auto load_next = [&]() {  // wave-striped loads: scalar tile base + ONE per-lane offset register + immediates
-    uint32_t off = (uint32_t)wbase * (uint32_t)sizeof(KeyT);
-    asm volatile("" : "+v"(off));  // opaque: otherwise the 16 per-lane addresses are hoisted out of the tile loop (32 VGPRs, spilled)
-    const char* pb = reinterpret_cast<const char*>(kin + baseN) + off;
-    if (nvalidN == TILE) {
+  if (nvalid == TILE) {
 #pragma unroll
-      for (int j = 0; j < KPT; ++j) keyN[j] = *reinterpret_cast<const KeyT*>(pb + (size_t)j * GX_WAVE * sizeof(KeyT));
-    } else {
+    for (int j = 0; j < KPT; ++j) key[j] = kin[base + wbase + j * GX_WAVE];
+  } else {
 #pragma unroll
-      for (int j = 0; j < KPT; ++j) {
-        const int idx = wbase + j * GX_WAVE;
-        keyN[j]       = (idx < nvalidN) ? *reinterpret_cast<const KeyT*>(pb + (size_t)j * GX_WAVE * sizeof(KeyT)) : KeyT(0);
-      }
+    for (int j = 0; j < KPT; ++j) {
+      const int idx = wbase + j * GX_WAVE;
+      key[j]        = (idx < nvalid) ? kin[base + idx] : KeyT(0);
     }
-  };
-
-  // ---- first tile of this workgroup
-  if (tid == 0) s_misc[0] = take_ticket();
-  __syncthreads();
-  lookup_segment(s_misc[0]);
-  __syncthreads();
-  describe_next();
-  if (gN == NONE) return;
-  load_next();
-
-  for (;;) {
-    const uint32_t gtile = gN, seg = segN, jt = jtN;
-    const int64_t base   = baseN;
-    const int nvalid     = nvalidN;
-    KeyT key[KPT];
+  }
+  if (HAS_VAL) {
 #pragma unroll
-    for (int j = 0; j < KPT; ++j) key[j] = keyN[j];
-    uint32_t val[HAS_VAL ? KPT : 1];
-    if (HAS_VAL) {
-#pragma unroll
-      for (int j = 0; j < KPT; ++j) {
-        const int idx = wbase + j * GX_WAVE;
-        val[j]        = (idx < nvalid) ? (vin ? vin[base + idx] : (uint32_t)(base + idx)) : 0u;
-      }
+    for (int j = 0; j < KPT; ++j) {
+      const int idx = wbase + j * GX_WAVE;
+      val[j]        = (idx < nvalid) ? (vin ? vin[base + idx] : (uint32_t)(base + idx)) : 0u;
     }
-    uint32_t* my_hist = s_whist + w * NB;
-    uint32_t packed[KPT];
-    uint32_t tile_count = 0;
-    if (STABLE) {
+  }
+  uint32_t* my_hist = s_whist + w * NB;
+  uint32_t packed[KPT];
+  uint32_t tile_count = 0;
+  if (STABLE) {
 #pragma unroll
-      for (int k = 0; k < NB / GX_WAVE; ++k) my_hist[lane + k * GX_WAVE] = 0;
+    for (int k = 0; k < NB / GX_WAVE; ++k) my_hist[lane + k * GX_WAVE] = 0;
 #pragma unroll
-      for (int j = 0; j < KPT; ++j) {
-        const int idx = wbase + j * GX_WAVE;
-        uint32_t d    = (uint32_t)(to_sortable<KeyT, KIND>(key[j], desc_mask) >> shift) & dmask;
-        if (idx >= nvalid) d = NB - 1;  // padding sorts last (it is also last in input order)
-        uint32_t lower, cnt;
-        match_rank<NBL>(d, true, ~0ull, lower, cnt);
-        const uint32_t prev = my_hist[d];
-        if (lower == 0) my_hist[d] = prev + cnt;
-        packed[j] = (d << 16) | (prev + lower);
-      }
-      __syncthreads();
-      if (tid < NB) {
-        uint32_t sum = 0;
-#pragma unroll
-        for (int w2 = 0; w2 < NW; ++w2) {
-          const uint32_t c       = s_whist[w2 * NB + tid];
-          s_whist[w2 * NB + tid] = sum;
-          sum += c;
-        }
-        tile_count = sum;
-      }
-    } else {
-      if (tid < NB) s_whist[tid] = 0;
-      __syncthreads();
-#pragma unroll
-      for (int j = 0; j < KPT; ++j) {
-        const int idx    = wbase + j * GX_WAVE;
-        const uint32_t d = (uint32_t)(to_sortable<KeyT, KIND>(key[j], desc_mask) >> shift) & dmask;
-        const uint32_t r = lds_rank(s_whist, d, idx < nvalid);
-        packed[j]        = (d << 16) | r;
-      }
-      __syncthreads();
-      if (tid < NB) tile_count = s_whist[tid];
-    }
-    uint32_t pub_count = tile_count;
-    if (STABLE && tid == NB - 1) pub_count -= (uint32_t)(TILE - nvalid);
-    if (tid < NB) {
-      store_agent_u64(&a.status[(int64_t)gtile * NB + tid], pack_status(jt == 0 ? 2u : 1u, epoch, pub_count));
-    }
-    const uint32_t bin_start = block_exclusive_scan<BT>(tile_count, 0u, SumOp(), s_scan, (uint32_t*)nullptr);
-    if (tid < NB) {
-      if (STABLE) {
-#pragma unroll
-        for (int w2 = 0; w2 < NW; ++w2) s_whist[w2 * NB + tid] += bin_start;
-      } else {
-        s_whist[NB + tid] = bin_start;  // row 1: bin starts (row 0 holds the counts)
-      }
+    for (int j = 0; j < KPT; ++j) {
+      const int idx = wbase + j * GX_WAVE;
+      uint32_t d    = (uint32_t)(to_sortable<KeyT, KIND>(key[j], desc_mask) >> shift) & dmask;
+      if (idx >= nvalid) d = NB - 1;  // padding sorts last (it is also last in input order)
+      uint32_t lower, cnt;
+      match_rank<NBL>(d, true, ~0ull, lower, cnt);
+      const uint32_t prev = my_hist[d];
+      if (lower == 0) my_hist[d] = prev + cnt;
+      packed[j] = (d << 16) | (prev + lower);
     }
     __syncthreads();
-
-#pragma unroll
-    for (int j = 0; j < KPT; ++j) {
-      const uint32_t d = packed[j] >> 16;
-      if (STABLE) {
-        const uint32_t pos = my_hist[d] + (packed[j] & 0xFFFFu);
-        s_keys[pos]        = key[j];
-        if (HAS_VAL) s_vals[pos] = val[j];
-      } else if (wbase + j * GX_WAVE < nvalid) {
-        s_keys[s_whist[NB + d] + (packed[j] & 0xFFFFu)] = key[j];
-      }
-    }
-
-    // the next tile's ticket: taken by the last thread (no bin to look back for when NB < BT) while the bins look back
-    uint32_t next_ticket = NONE;
-    if (tid == BT - 1) next_ticket = take_ticket();
     if (tid < NB) {
-      uint32_t prefix = 0;
-      if (jt > 0) {
-        int64_t p = (int64_t)gtile - 1;  // predecessors of the same segment have consecutive tile ids
-        bool done = false;
-        while (!done) {
-          unsigned long long v[LBW];
+      uint32_t sum = 0;
 #pragma unroll
-          for (int k = 0; k < LBW; ++k) {
-            const int64_t q = p - k;
-            v[k]            = (q >= 0) ? load_agent_u64(&a.status[q * NB + tid]) : pack_status(2u, epoch, 0u);
-          }
-#pragma unroll
-          for (int k = 0; k < LBW; ++k) {
-            if (!done) {
-              unsigned long long x = v[k];
-              uint32_t spins       = 0;
-              while ((x >> 62) == 0 || ((unsigned)(x >> 32) & 0xFFu) != epoch) {
-                if (++spins > SPIN_LIMIT) {
-                  atomicExch(&plan->status, 1);
-                  x = pack_status(2u, epoch, 0u);
-                  break;
-                }
-                __builtin_amdgcn_s_sleep(2);
-                x = load_agent_u64(&a.status[(p - k) * NB + tid]);
-              }
-              prefix += (uint32_t)x;
-              if ((x >> 62) == 2u) done = true;
-            }
-          }
-          p -= LBW;
-        }
-        store_agent_u64(&a.status[(int64_t)gtile * NB + tid], pack_status(2u, epoch, prefix + pub_count));
+      for (int w2 = 0; w2 < NW; ++w2) {
+        const uint32_t c       = s_whist[w2 * NB + tid];
+        s_whist[w2 * NB + tid] = sum;
+        sum += c;
       }
-      uint32_t gb, lim = 0xFFFFFFFFu;
-      if (lvl == 0) {
-        gb = a.base[seg * NB2MAX + tid];
-      } else {
-        // Level 1 needs no histogram: cell (bucket, bin) owns a fixed slot of `cellcap` keys, this tile's keys go
-        // behind those of the bucket's earlier tiles (the look-back prefix), and the bucket's last tile leaves the
-        // cell sizes behind for k_plan2.  A cell that outgrows its slot (skewed keys) is cut off and flagged: the
-        // LSD passes then sort the column instead.
-        const bool live = tid < (1u << hy.bits2);
-        gb              = live ? ((seg << hy.bits2) + tid) * a.cellcap : 0u;
-        lim             = live ? gb + a.cellcap : 0u;
-        if (live) {
-          if (prefix + pub_count > a.cellcap) atomicExch(&hy.overflow, 1);
-          if (gtile + 1 == hy.seg_tile0[1][seg + 1]) a.cellcount[seg * NB2MAX + tid] = prefix + pub_count;
-        }
-      }
-      s_limit[tid]  = lim;
-      s_gdelta[tid] = gb + prefix - bin_start;
+      tile_count = sum;
     }
-    if (tid == BT - 1) s_misc[0] = next_ticket;
-    __syncthreads();  // B1: output offsets and the next ticket are visible
-    lookup_segment(s_misc[0]);
-    __syncthreads();  // B1': ... and its segment
-    describe_next();
-    if (gN != NONE) load_next();  // in flight under the write-out below
-
+  } else {
+    if (tid < NB) s_whist[tid] = 0;
+    __syncthreads();
 #pragma unroll
     for (int j = 0; j < KPT; ++j) {
-      const int i = j * BT + (int)tid;
-      if (i < nvalid) {
-        const KeyT k       = s_keys[i];
-        const uint32_t d   = (uint32_t)(to_sortable<KeyT, KIND>(k, desc_mask) >> shift) & dmask;
-        const uint32_t dst = s_gdelta[d] + (uint32_t)i;
-        if (dst < s_limit[d]) {
-          kout[dst] = k;
-          if (HAS_VAL) vout[dst] = s_vals[i];
+      const int idx    = wbase + j * GX_WAVE;
+      const uint32_t d = (uint32_t)(to_sortable<KeyT, KIND>(key[j], desc_mask) >> shift) & dmask;
+      const uint32_t r = lds_rank(s_whist, d, idx < nvalid);
+      packed[j]        = (d << 16) | r;
+    }
+    __syncthreads();
+    if (tid < NB) tile_count = s_whist[tid];
+  }
+  uint32_t pub_count = tile_count;
+  if (STABLE && tid == NB - 1) pub_count -= (uint32_t)(TILE - nvalid);
+  if (tid < NB) {
+    store_agent_u64(&a.status[(int64_t)gtile * NB + tid], pack_status(jt == 0 ? 2u : 1u, epoch, pub_count));
+  }
+  const uint32_t bin_start = block_exclusive_scan<BT>(tile_count, 0u, SumOp(), s_scan, (uint32_t*)nullptr);
+  if (tid < NB) {
+    if (STABLE) {
+#pragma unroll
+      for (int w2 = 0; w2 < NW; ++w2) s_whist[w2 * NB + tid] += bin_start;
+    } else {
+      s_whist[NB + tid] = bin_start;  // row 1: bin starts (row 0 holds the counts)
+    }
+  }
+  __syncthreads();
+
+#pragma unroll
+  for (int j = 0; j < KPT; ++j) {
+    const uint32_t d = packed[j] >> 16;
+    if (STABLE) {
+      const uint32_t pos = my_hist[d] + (packed[j] & 0xFFFFu);
+      s_keys[pos]        = key[j];
+      if (HAS_VAL) s_vals[pos] = val[j];
+    } else if (wbase + j * GX_WAVE < nvalid) {
+      s_keys[s_whist[NB + d] + (packed[j] & 0xFFFFu)] = key[j];
+    }
+  }
+
+  if (tid < NB) {
+    uint32_t prefix = 0;
+    if (jt > 0) {
+      int64_t p = (int64_t)gtile - 1;  // predecessors of the same segment have consecutive tile ids
+      bool done = false;
+      while (!done) {
+        unsigned long long v[LBW];
+#pragma unroll
+        for (int k = 0; k < LBW; ++k) {
+          const int64_t q = p - k;
+          v[k]            = (q >= 0) ? load_agent_u64(&a.status[q * NB + tid]) : pack_status(2u, epoch, 0u);
         }
+#pragma unroll
+        for (int k = 0; k < LBW; ++k) {
+          if (!done) {
+            unsigned long long x = v[k];
+            uint32_t spins       = 0;
+            while ((x >> 62) == 0 || ((unsigned)(x >> 32) & 0xFFu) != epoch) {
+              if (++spins > SPIN_LIMIT) {
+                atomicExch(&plan->status, 1);
+                x = pack_status(2u, epoch, 0u);
+                break;
+              }
+              __builtin_amdgcn_s_sleep(2);
+              x = load_agent_u64(&a.status[(p - k) * NB + tid]);
+            }
+            prefix += (uint32_t)x;
+            if ((x >> 62) == 2u) done = true;
+          }
+        }
+        p -= LBW;
+      }
+      store_agent_u64(&a.status[(int64_t)gtile * NB + tid], pack_status(2u, epoch, prefix + pub_count));
+    }
+    uint32_t gb, lim = 0xFFFFFFFFu;
+    if (lvl == 0) {
+      gb = a.base[seg * NB2MAX + tid];
+    } else {
+      // Level 1 needs no histogram: cell (bucket, bin) owns a fixed slot of `cellcap` keys, this tile's keys go
+      // behind those of the bucket's earlier tiles (the look-back prefix), and the bucket's last tile leaves the
+      // cell sizes behind for k_plan2.  A cell that outgrows its slot (skewed keys) is cut off and flagged: the
+      // LSD passes then sort the column instead.
+      const bool live = tid < (1u << hy.bits2);
+      gb              = live ? ((seg << hy.bits2) + tid) * a.cellcap : 0u;
+      lim             = live ? gb + a.cellcap : 0u;
+      if (live) {
+        if (prefix + pub_count > a.cellcap) atomicExch(&hy.overflow, 1);
+        if (gtile + 1 == hy.seg_tile0[1][seg + 1]) a.cellcount[seg * NB2MAX + tid] = prefix + pub_count;
       }
     }
-    if (gN == NONE) return;
-    __syncthreads();  // B2: the LDS tile, the counters and s_misc are reused by the next tile
+    s_limit[tid]  = lim;
+    s_gdelta[tid] = gb + prefix - bin_start;
+  }
+  __syncthreads();
+
+#pragma unroll
+  for (int j = 0; j < KPT; ++j) {
+    const int i = j * BT + (int)tid;
+    if (i < nvalid) {
+      const KeyT k       = s_keys[i];
+      const uint32_t d   = (uint32_t)(to_sortable<KeyT, KIND>(k, desc_mask) >> shift) & dmask;
+      const uint32_t dst = s_gdelta[d] + (uint32_t)i;
+      if (dst < s_limit[d]) {
+        kout[dst] = k;
+        if (HAS_VAL) vout[dst] = s_vals[i];
+      }
+    }
   }
 }
 
@@ -1514,23 +1481,14 @@ int sort_impl(const void* keys_in, void* keys_out, const int32_t* vals_in, int32
       m.cellcount = hist2;
       m.cellcap   = 1u << hc.cl2;
       prof_mark_h(0, stream);
-      // persistent workgroups: two per CU (LDS), never more than there are tiles
-      static int num_cus = 0;
-      if (num_cus == 0) {
-        int dev = 0;
-        GX_HIP_TRY(hipGetDevice(&dev));
-        GX_HIP_TRY(hipDeviceGetAttribute(&num_cus, hipDeviceAttributeMultiprocessorCount, dev));
-      }
-      int64_t msd_grid = 2 * (int64_t)(num_cus > 0 ? num_cus : 256);
-      if (msd_grid > msd_ntiles + NRANGE) msd_grid = msd_ntiles + NRANGE;
-      hipLaunchKernelGGL(kmsd0, dim3((unsigned)msd_grid), dim3(BT), lds_msd(hyb_kpt, BINS), stream, m);
+      hipLaunchKernelGGL(kmsd0, dim3((unsigned)(msd_ntiles + NRANGE)), dim3(BT), lds_msd(hyb_kpt, BINS), stream, m);
       prof_mark_h(1, stream);
       m.in    = bufA;
       m.out   = bufB;
       m.vin   = valA;
       m.vout  = valB;
       m.level = 1;
-      hipLaunchKernelGGL(kmsd1, dim3((unsigned)msd_grid), dim3(BT), lds_msd(hyb_kpt, nb1), stream, m);
+      hipLaunchKernelGGL(kmsd1, dim3((unsigned)(msd_ntiles + BINS + NRANGE)), dim3(BT), lds_msd(hyb_kpt, nb1), stream, m);
       prof_mark_h(2, stream);
       hipLaunchKernelGGL(k_plan2, dim3(BINS), dim3(GX_WAVE), 0, stream, plan, hist2, base2, NPASS);
       prof_mark_h(3, stream);

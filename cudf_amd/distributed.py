@@ -47,10 +47,20 @@ class HipLocalOps:
     def sort(self, keys: torch.Tensor) -> torch.Tensor:
         return self._tensor(self._ops.sort(self._col(keys)), keys.dtype)
 
-    def hash_partition(self, keys: torch.Tensor, nparts: int) -> Tuple[torch.Tensor, List[int]]:
-        """(int32 gather map grouping rows by murmur3(key) % nparts, nparts+1 offsets)"""
-        m, offs = self._ops.hash_partition_map([self._col(keys)], nparts)
-        return self._tensor(m, torch.int32), [int(x) for x in offs]
+    def range_partition(self, keys: torch.Tensor, splitters: Sequence) -> Tuple[torch.Tensor, List[int]]:
+        """One pass: keys grouped by destination = number of splitters <= key; (grouped keys, offsets)."""
+        pk, _, offs = self._ops.partition_rows(self._col(keys), len(splitters) + 1, splitters=list(splitters), want_rows=False)
+        return self._tensor(pk, keys.dtype), offs
+
+    def hash_partition_rows(self, keys: torch.Tensor, nparts: int) -> Tuple[torch.Tensor, torch.Tensor, List[int]]:
+        """One pass: (keys grouped by destination rank, their int32 local rows, offsets).  The destination is a hash
+        that is independent of the local join table's slot bits."""
+        if nparts & (nparts - 1):  # not a power of two ranks: murmur3 % nparts through the partition map
+            m, offs = self._ops.hash_partition_map([self._col(keys)], nparts)
+            gm = self._tensor(m, torch.int32)
+            return self.gather(keys, gm), gm, [int(x) for x in offs]
+        pk, rows, offs = self._ops.partition_rows(self._col(keys), nparts)
+        return self._tensor(pk, keys.dtype), self._tensor(rows, torch.int32), offs
 
     def gather(self, values: torch.Tensor, gather_map: torch.Tensor) -> torch.Tensor:
         out = self._ops.gather(self._col(values), self._col(gather_map))
@@ -64,6 +74,12 @@ class HipLocalOps:
         k, s, cv, _ = self._ops.groupby_sum_count(self._col(keys), self._col(vals))
         sdt = vals.dtype if vals.dtype.is_floating_point else torch.int64
         return self._tensor(k, keys.dtype), self._tensor(s, sdt), self._tensor(cv, torch.int32)
+
+    def merge_sum_count(self, keys: torch.Tensor, sums: torch.Tensor, counts: torch.Tensor):
+        """Partial (key, sum, count) rows -> one row per key, keys ascending: ONE grouping (sort the keys, run
+        boundaries) shared by the two segmented reductions."""
+        k, s, c = self._ops.merge_sum_count(self._col(keys), self._col(sums), self._col(counts))
+        return self._tensor(k, keys.dtype), self._tensor(s, sums.dtype), self._tensor(c, torch.int64)
 
     def reduce(self, values: torch.Tensor, op: str) -> torch.Tensor:
         """1-element tensor: cudf::reduce of the shard in the accumulator type (int64 / float64 for
@@ -138,94 +154,116 @@ def _offsets_to_counts(offsets: Sequence[int]) -> List[int]:
 _FORCE_EXCHANGE = False  # tests: take the partition + all-to-all path even when world == 1
 
 
-def distributed_sort(keys: torch.Tensor, local: Optional[object] = None, group=None, samples_per_rank: int = 64) -> torch.Tensor:
+def distributed_sort(keys: torch.Tensor, local: Optional[object] = None, group=None, samples_per_rank: int = 1024) -> torch.Tensor:
     """Global sort of the concatenation of all ranks' shards; rank r returns the r-th range, so the
-    concatenation of the results in rank order is sorted.  sample sort: local sort -> regular samples
-    -> all-gather -> common splitters -> contiguous slices of the sorted shard -> all-to-all ->
-    local sort of the received runs."""
+    concatenation of the results in rank order is sorted.  Sample sort with ONE partition pass and ONE sort per
+    rank: strided sample of the UNSORTED shard -> all-gather -> common splitters -> one range-partition pass
+    into `world` send regions -> all-to-all -> local sort of what arrived
+    (cudf_polars: sample -> allgather boundaries -> shuffle -> local sort, collectives/sort.py)."""
     local = local or HipLocalOps()
     rank, world = _world(group)
     if world == 1 and not _FORCE_EXCHANGE:
         return local.sort(keys)
-    s = local.sort(keys)
-    n = s.numel()
-    # regular samples of the sorted shard (empty shards contribute the dtype's max so they never split)
+    n = keys.numel()
+    # evenly strided sample of the shard as it is (empty shards contribute the dtype's max so they never split)
     if n > 0:
         # integer arithmetic: float32 cannot represent n - 1 for n ~ 1e9 (it would round to n)
-        pos = (torch.arange(samples_per_rank, dtype=torch.int64, device=s.device) * (n - 1)) // max(samples_per_rank - 1, 1)
-        mine = s[pos]
+        pos = (torch.arange(samples_per_rank, dtype=torch.int64, device=keys.device) * (n - 1)) // max(samples_per_rank - 1, 1)
+        mine = keys[pos]
     else:
-        fill = torch.finfo(s.dtype).max if s.dtype.is_floating_point else torch.iinfo(s.dtype).max
-        mine = torch.full((samples_per_rank,), fill, dtype=s.dtype, device=s.device)
+        fill = torch.finfo(keys.dtype).max if keys.dtype.is_floating_point else torch.iinfo(keys.dtype).max
+        mine = torch.full((samples_per_rank,), fill, dtype=keys.dtype, device=keys.device)
     gathered = [torch.empty_like(mine) for _ in range(world)]
     dist.all_gather(gathered, mine, group=group)
     allsamp = local.sort(torch.cat(gathered))
-    cut = torch.arange(1, world, device=s.device) * samples_per_rank
-    splitters = allsamp[cut]                                  # world-1 values, identical on every rank
-    bounds = torch.searchsorted(s, splitters, right=False)    # first index >= splitter
-    edges = [0] + [int(x) for x in bounds.cpu()] + [n]
-    send = _offsets_to_counts(edges)
-    recv = exchange_counts(send, s.device, group)
-    got = all_to_all_rows(s, send, recv, group)
+    cut = torch.arange(1, world, device=keys.device) * samples_per_rank
+    splitters = allsamp[cut].cpu().tolist()                   # world-1 values, identical on every rank
+    pk, offs = local.range_partition(keys, splitters)          # rank j gets keys with j splitters <= key
+    send = _offsets_to_counts(offs)
+    recv = exchange_counts(send, keys.device, group)
+    got = all_to_all_rows(pk, send, recv, group)
     return local.sort(got)
+
+
+def _all_sizes(n: int, device, group) -> List[int]:
+    _, world = _world(group)
+    sizes = [torch.empty(1, dtype=torch.int64, device=device) for _ in range(world)]
+    dist.all_gather(sizes, torch.tensor([n], dtype=torch.int64, device=device), group=group)
+    return [int(x) for x in sizes]
 
 
 def distributed_inner_join(left: torch.Tensor, right: torch.Tensor, local: Optional[object] = None, group=None
                            ) -> Tuple[torch.Tensor, torch.Tensor]:
     """Inner equi-join of the concatenations of all ranks' `left` and `right` key shards.
     Returns this rank's share of the result as (global_left_row, global_right_row) int64 tensors,
-    where a global row id = (offset of the owning rank's shard) + local row.  Both sides are
-    hash-partitioned with murmur3 % world (cudf::hash_partition's rule), exchanged once, joined
-    locally; outputs stay sharded."""
+    where a global row id = (offset of the owning rank's shard) + local row.  Both sides are hash-partitioned in
+    one pass each, exchanged once as (key, int32 local row) = 12 B/row -- the source rank, hence the shard offset, is
+    implied by the receive segment -- and joined locally; outputs stay sharded.  The build side's exchange is in
+    flight while the probe side is partitioned."""
     local = local or HipLocalOps()
     rank, world = _world(group)
     dev = left.device
+    lsizes, rsizes = _all_sizes(left.numel(), dev, group), _all_sizes(right.numel(), dev, group)
 
-    def shard_offset(n: int) -> int:
-        sizes = [torch.empty(1, dtype=torch.int64, device=dev) for _ in range(world)]
-        dist.all_gather(sizes, torch.tensor([n], dtype=torch.int64, device=dev), group=group)
-        return int(sum(int(x) for x in sizes[:rank]))
+    def bases(sizes):
+        out, run = [], 0
+        for x in sizes:
+            out.append(run)
+            run += x
+        return out
 
-    def shuffle(keys: torch.Tensor) -> Tuple[torch.Tensor, torch.Tensor]:
-        base = shard_offset(keys.numel())
-        if world == 1 and not _FORCE_EXCHANGE:
-            return keys, torch.arange(keys.numel(), dtype=torch.int64, device=dev)
-        gmap, offs = local.hash_partition(keys, world)
+    if world == 1 and not _FORCE_EXCHANGE:
+        li, ri = local.inner_join(left, right)
+        return li.to(torch.int64), ri.to(torch.int64)
+
+    def start_exchange(pk, prow, offs):
         send = _offsets_to_counts(offs)
         recv = exchange_counts(send, dev, group)
-        pk = local.gather(keys, gmap)
-        gid = gmap.to(torch.int64) + base                      # global id of every partitioned row
-        return all_to_all_rows(pk, send, recv, group), all_to_all_rows(gid, send, recv, group)
+        ok = torch.empty(int(sum(recv)), dtype=pk.dtype, device=dev)
+        orow = torch.empty(int(sum(recv)), dtype=torch.int32, device=dev)
+        w1 = dist.all_to_all_single(ok, pk.contiguous(), output_split_sizes=list(recv), input_split_sizes=list(send), group=group, async_op=True)
+        w2 = dist.all_to_all_single(orow, prow.contiguous(), output_split_sizes=list(recv), input_split_sizes=list(send), group=group, async_op=True)
+        return ok, orow, recv, (w1, w2)
 
-    lk, lid = shuffle(left)
-    rk, rid = shuffle(right)
-    li, ri = local.inner_join(lk, rk)
-    return local.gather(lid, li), local.gather(rid, ri)
+    def global_ids(rows: torch.Tensor, recv: Sequence[int], base: Sequence[int]) -> torch.Tensor:
+        gid = rows.to(torch.int64)
+        at = 0
+        for j, c in enumerate(recv):        # segment j came from rank j: add that shard's offset
+            if c and base[j]:
+                gid[at:at + c] += base[j]
+            at += c
+        return gid
+
+    rk, rrow, roffs = local.hash_partition_rows(right, world)
+    rkeys, rrows, rrecv, rwork = start_exchange(rk, rrow, roffs)     # build side in flight ...
+    lk, lrow, loffs = local.hash_partition_rows(left, world)        # ... while the probe side is partitioned
+    lkeys, lrows, lrecv, lwork = start_exchange(lk, lrow, loffs)
+    for w in rwork + lwork:
+        w.wait()
+    li, ri = local.inner_join(lkeys, rkeys)
+    lgid = global_ids(lrows, lrecv, bases(lsizes))
+    rgid = global_ids(rrows, rrecv, bases(rsizes))
+    return local.gather(lgid, li), local.gather(rgid, ri)
 
 
 def distributed_groupby_sum_count(keys: torch.Tensor, vals: torch.Tensor, local: Optional[object] = None, group=None):
     """groupby(keys).agg(sum, count) over all ranks' shards.  Pre-aggregate locally (<= #groups rows),
     hash-partition the partials, one all-to-all, merge.  Every group ends on exactly one rank.
-    Returns (keys, sum, count) for the groups this rank owns (count as int64)."""
+    Returns (keys, sum, count) for the groups this rank owns (count as int64), keys ascending after a merge."""
     local = local or HipLocalOps()
     rank, world = _world(group)
     k, s, c = local.groupby_sum_count(keys, vals)
     c = c.to(torch.int64)
     if world == 1 and not _FORCE_EXCHANGE:
         return k, s, c
-    gmap, offs = local.hash_partition(k, world)
+    pk, prow, offs = local.hash_partition_rows(k, world)
     send = _offsets_to_counts(offs)
     recv = exchange_counts(send, k.device, group)
-    rk = all_to_all_rows(local.gather(k, gmap), send, recv, group)
-    rs = all_to_all_rows(local.gather(s, gmap), send, recv, group)
-    rc = all_to_all_rows(local.gather(c, gmap), send, recv, group)
-    # merge: sum of partial sums, sum of partial counts (two passes of the same kernel)
-    mk, ms, _ = local.groupby_sum_count(rk, rs)
-    mk2, mc, _ = local.groupby_sum_count(rk, rc)
-    # bring the count column into the key order of the sum column
-    o1 = torch.argsort(mk)
-    o2 = torch.argsort(mk2)
-    return mk[o1], ms[o1], mc[o2]
+    rk = all_to_all_rows(pk, send, recv, group)
+    rs = all_to_all_rows(local.gather(s, prow), send, recv, group)
+    rc = all_to_all_rows(local.gather(c, prow), send, recv, group)
+    # one grouping of the received partials carries both the sum and the count
+    return local.merge_sum_count(rk, rs, rc)
 
 
 def _gather_partials(part: torch.Tensor, group=None) -> List[torch.Tensor]:
@@ -252,8 +290,7 @@ def distributed_scan(values: torch.Tensor, op: str = "sum", inclusive: bool = Tr
     """cudf::scan over the concatenation of all ranks' shards in rank order; rank r returns its shard of
     the result (same dtype as the input: integers wrap like the single-GPU scan).  One all-gather of the
     shard totals; the exclusive prefix of the totals of the ranks before this one is folded into the
-    shard's first element, so the local scan kernel produces the global values in its one pass
-    (the input is restored afterwards)."""
+    first element of a copy of the shard, so the local scan kernel produces the global values in its one pass."""
     local = local or HipLocalOps()
     rank, _ = _world(group)
     dt = values.dtype
@@ -268,12 +305,11 @@ def distributed_scan(values: torch.Tensor, op: str = "sum", inclusive: bool = Tr
     prefix = parts[0]
     for p in parts[1:rank]:
         prefix = _combine(prefix, p, op)
-    first = values[:1].clone()
-    values[:1] = _combine(prefix, first, op)
-    try:
-        out = local.scan(values, op, inclusive)
-    finally:
-        values[:1] = first
+    # the prefix of the earlier ranks is folded into a COPY of the shard's first element: the caller's tensor is never
+    # written (another stream may be reading it)
+    patched = values.clone()
+    patched[:1] = _combine(prefix, values[:1], op)
+    out = local.scan(patched, op, inclusive)
     if not inclusive:
         out[:1] = prefix  # an exclusive scan starts at the identity: here at everything before this shard
     return out

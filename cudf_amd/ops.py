@@ -133,6 +133,52 @@ def hash_partition_map(key_cols: Sequence[Column], num_partitions: int, seed: in
     return out_map, offs.cpu().numpy()
 
 
+def partition_rows(col: Column, nparts: int, splitters: Optional[Sequence] = None, want_rows: bool = True):
+    """One-pass partition of a key column into `nparts` groups (gx_partition_rows): by a hash that is independent of
+    the join table's slot bits (splitters None; nparts a power of two), or by range (nparts - 1 ascending splitters:
+    destination = number of splitters <= key).  Returns (grouped keys, int32 row indices or None, nparts + 1 offsets).
+    What a rank runs before the all-to-all of the distributed sort / join / groupby
+    (cudf::hash_partition, cpp/src/partitioning/partitioning.cu:568-660)."""
+    n = col.size
+    out = Column.empty(col.dtype, n)
+    rows = Column.empty(np.int32, n) if want_rows else None
+    offs = torch.zeros(nparts + 1, dtype=torch.int64, device="cuda")
+    mode = 0 if splitters is None else 1
+    sp = None
+    if splitters is not None:
+        if len(splitters) != nparts - 1:
+            raise ValueError("range partition needs nparts - 1 splitters")
+        sp_np = np.asarray(list(splitters) + [0], dtype=col.dtype)   # host array the call reads synchronously
+        sp = sp_np.ctypes.data_as(ctypes.c_void_p)
+    _run(_lib.gx_partition_rows, col.gx, col.data_ptr, n, mode, nparts, sp, out.data_ptr, rows.data_ptr if rows is not None else None,
+         ptr(offs))
+    return out, rows, [int(x) for x in offs.cpu()]
+
+
+def merge_sum_count(keys: Column, sums: Column, counts: Column):
+    """Partial (key, sum, count) rows -> one row per distinct key, keys ascending: sorted_order of the keys, run heads
+    and labels once, then two segmented reductions over the same grouping (the sort-based aggregation path:
+    cpp/src/groupby/sort/aggregate.cpp:94-142).  Float sums in double-double (order independent)."""
+    n = keys.size
+    if n == 0:
+        return Column.empty(keys.dtype, 0), Column.empty(sums.dtype, 0), Column.empty(np.int64, 0)
+    order = sorted_order(keys)
+    sk, ss, sc = gather(keys, order), gather(sums, order), gather(counts, order)
+    heads = torch.empty(n, dtype=torch.uint8, device="cuda")
+    L.check(_lib.gx_group_heads(sk.gx, sk.data_ptr, None, None, n, 0, ptr(heads), stream_ptr()), "gx_group_heads")
+    labels = torch.empty(n, dtype=torch.int32, device="cuda")
+    offsets = torch.empty(n + 1, dtype=torch.int32, device="cuda")
+    ng = _dev_i64()
+    _run(_lib.gx_group_offsets, ptr(heads), n, ptr(labels), ptr(offsets), None, ptr(ng))
+    g = int(ng.item())
+    out_s = Column.empty(sums.dtype if sums.dtype.kind == "f" else np.int64, g)
+    out_c = Column.empty(np.int64, g)
+    _run(_lib.gx_segmented_reduce, ss.gx, ss.data_ptr, None, ptr(heads), ptr(labels), n, L.OP_SUM, out_s.data_ptr, None)
+    _run(_lib.gx_segmented_reduce, sc.gx, sc.data_ptr, None, ptr(heads), ptr(labels), n, L.OP_SUM, out_c.data_ptr, None)
+    starts = Column(offsets[:g].contiguous().view(torch.uint8), np.int32, g)
+    return gather(sk, starts), out_s, out_c
+
+
 # ------------------------------------------------------------------------------------------------
 # hash join  (cudf::hash_join / cudf::inner_join: join/hash_join.hpp:70-444, join/join.hpp:160-166)
 # ------------------------------------------------------------------------------------------------

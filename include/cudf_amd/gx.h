@@ -271,6 +271,19 @@ int gx_join_count_rows(int key_size, const void* probe_keys, const uint32_t* pro
 /* data[i] += value wherever data[i] != INT32_MIN (JoinNoMatch): re-bases the probe indices of a chunk of a
  * partitioned join (hash_join.hpp:352-440) onto the whole left table. */
 int gx_add_i32(int32_t* data, int64_t n, int32_t value, gx_stream_t stream);
+/* One-pass partition of rows into `nparts` <= 16 contiguous groups (histogram + LDS-ranked scatter, the partition pass
+ * of the partitioned join): out_keys = the keys grouped by destination (order inside a group unspecified), out_rows
+ * (optional) = their row indices, offsets_dev[nparts + 1] = group starts (device int64).  What a rank runs before the
+ * all-to-all of the distributed operators (cudf::hash_partition, cpp/src/partitioning/partitioning.cu:568-660, feeding
+ * the shuffle of cpp/libcudf_streaming/src/partition_utils.cpp:72-117):
+ *   mode 0  destination = top bits of a multiplicative hash independent of the join table's slot bits (nparts a
+ *           power of two); key_dtype any 4- or 8-byte type (bit patterns are hashed);
+ *   mode 1  destination = number of splitters <= key in cudf sort order; splitters_host = nparts - 1 ascending keys
+ *           of key_dtype in HOST memory (INT32/UINT32/FLOAT32/INT64/UINT64/FLOAT64).
+ * cub-style scratch query. */
+int gx_partition_rows(int key_dtype, const void* keys, int64_t n, int mode, int nparts, const void* splitters_host,
+                      void* out_keys, int32_t* out_rows, int64_t* offsets_dev, void* tmp, size_t* tmp_bytes,
+                      gx_stream_t stream);
 /* log2 of the number of partitions the partitioned probe uses for this table; 0 = not partitionable */
 int gx_join_partition_bits(int key_size, size_t table_bytes);
 /* Measurement hooks (bench.py's roofline leg), like gx_sort_profile: when enabled, every partitioned probe

@@ -13,7 +13,10 @@ CSRC = os.path.join(HERE, "csrc")
 OUT = os.path.join(HERE, "libcudf_amd.so")
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wall", "-Wno-unused-function",
-         "-munsafe-fp-atomics"]  # hardware f64 atomics: all our buffers are coarse-grained device memory
+         "-munsafe-fp-atomics",  # hardware f64 atomics: all our buffers are coarse-grained device memory
+         # a returning atomic issued by ONE lane (tickets, output reservations) must not be followed by an immediate
+         # s_waitcnt: LLVM's atomic optimizer rewrites it into reduce + atomic + readfirstlane and waits on the spot
+         "-mllvm", "-amdgpu-atomic-optimizer-strategy=None"]
 
 
 def _sources():

@@ -19,6 +19,26 @@ class NumpyLocalOps:
         offs = np.concatenate([[0], np.cumsum(counts)])
         return torch.from_numpy(gmap), [int(x) for x in offs]
 
+    def range_partition(self, keys, splitters):
+        k = keys.numpy()
+        dest = np.searchsorted(np.asarray(splitters, dtype=k.dtype), k, side="right") if len(splitters) else np.zeros(len(k), np.int64)
+        order = np.argsort(dest, kind="stable")
+        counts = np.bincount(dest, minlength=len(splitters) + 1)
+        return torch.from_numpy(k[order]), [int(x) for x in np.concatenate([[0], np.cumsum(counts)])]
+
+    def hash_partition_rows(self, keys, nparts):
+        gmap, offs = self.hash_partition(keys, nparts)
+        return keys[gmap.to(torch.int64)], gmap, offs
+
+    def merge_sum_count(self, keys, sums, counts):
+        k, s, c = keys.numpy(), sums.numpy(), counts.numpy()
+        uk, inv = np.unique(k, return_inverse=True)
+        ms = np.zeros(len(uk), s.dtype)
+        mc = np.zeros(len(uk), np.int64)
+        np.add.at(ms, inv, s)
+        np.add.at(mc, inv, c)
+        return torch.from_numpy(uk), torch.from_numpy(ms), torch.from_numpy(mc)
+
     def gather(self, values, gather_map):
         return values[gather_map.to(torch.int64)]
 

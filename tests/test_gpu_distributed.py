@@ -64,3 +64,62 @@ def test_distributed_reduce_scan_single_rank_rccl(pg):
     ex = D.distributed_scan(t, "max", False).cpu().numpy()
     np.testing.assert_array_equal(ex[1:], np.maximum.accumulate(v)[:-1])
     assert D.distributed_reduce(t[:0], "sum") == 0
+
+
+@pytest.mark.parametrize("dtype", ["int64", "uint64", "float64", "int32"])
+def test_partition_rows_range_and_hash(dtype):
+    """gx_partition_rows, the one-pass partition a rank runs before the all-to-all: range mode sends a key to
+    (number of splitters <= key) in cudf sort order; hash mode groups equal keys, returns a permutation and uses
+    bits that are independent of the join table's slot bits."""
+    import torch
+    import cudf_amd  # noqa: F401
+    from cudf_amd import Column, ops
+    rng = np.random.default_rng(8)
+    for n in (0, 1, 1000, 300_007, 5_000_011):
+        if dtype == "float64":
+            v = rng.standard_normal(n) * 1e6
+            if n > 10:
+                v[::97] = -0.0
+                v[5::101] = np.inf
+        elif dtype == "int32":
+            v = rng.integers(-2**31, 2**31 - 1, n).astype(np.int32)
+        else:
+            v = rng.integers(-2**62 if dtype == "int64" else 0, 2**62, n).astype(dtype)
+        col = Column.from_numpy(v)
+        for nparts in (1, 2, 3, 8, 16):
+            sp = np.sort(rng.choice(v, nparts - 1)) if n >= nparts and nparts > 1 else np.zeros(nparts - 1, v.dtype)
+            pk, rows, offs = ops.partition_rows(col, nparts, splitters=sp.tolist(), want_rows=True)
+            got, r = pk.to_numpy(), rows.to_numpy()
+            assert offs[0] == 0 and offs[-1] == n and all(a <= b for a, b in zip(offs, offs[1:]))
+            assert np.array_equal(np.sort(r), np.arange(n))            # a permutation ...
+            assert got.tobytes() == v[r].tobytes()                       # ... that carries the keys
+            dest = np.searchsorted(sp, v, side="right")
+            for j in range(nparts):
+                assert np.all(dest[r[offs[j]:offs[j + 1]]] == j), (dtype, n, nparts, j)
+        if np.dtype(dtype).itemsize == 8 or dtype == "int32":
+            for nparts in (1, 2, 8):
+                pk, rows, offs = ops.partition_rows(col, nparts)
+                got, r = pk.to_numpy(), rows.to_numpy()
+                assert offs[-1] == n and np.array_equal(np.sort(r), np.arange(n)) and got.tobytes() == v[r].tobytes()
+                if n >= 1000 and dtype != "float64":
+                    seen = {}
+                    for j in range(nparts):                               # equal keys land in one group
+                        for k in np.unique(got[offs[j]:offs[j + 1]][:2000]):
+                            assert seen.setdefault(int(k), j) == j
+                    if nparts == 8 and n > 100_000:
+                        sizes = np.diff(offs)
+                        assert sizes.min() > 0.8 * n / 8 and sizes.max() < 1.2 * n / 8, sizes   # balanced
+
+
+def test_merge_sum_count_matches_numpy():
+    import cudf_amd  # noqa: F401
+    from cudf_amd import Column, ops
+    rng = np.random.default_rng(9)
+    k = rng.integers(0, 5000, 40_000).astype(np.int32)
+    s = rng.integers(0, 1000, 40_000).astype(np.float64)
+    c = rng.integers(1, 50, 40_000).astype(np.int64)
+    mk, ms, mc = ops.merge_sum_count(Column.from_numpy(k), Column.from_numpy(s), Column.from_numpy(c))
+    uk = np.unique(k)
+    np.testing.assert_array_equal(mk.to_numpy(), uk)
+    np.testing.assert_array_equal(ms.to_numpy(), np.bincount(k, weights=s)[uk])
+    np.testing.assert_array_equal(mc.to_numpy(), np.bincount(k, weights=c)[uk].astype(np.int64))
