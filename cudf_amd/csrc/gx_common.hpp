@@ -193,16 +193,33 @@ struct ProdOp {
   __device__ __forceinline__ T operator()(T a, T b) const { return a * b; }
 };
 
-// inclusive scan across the 64 lanes of a wave (Hillis-Steele on shuffles; log2(64)=6 steps)
+// DPP lane movement (gfx9 family): every 32-bit word of v moved by the DPP pattern CTRL under row mask RM; lanes the
+// pattern leaves without a source keep their own value.
+template <int CTRL, int RM, typename T>
+__device__ __forceinline__ T dpp_take(T v)
+{
+  return shfl_words(v, [](uint32_t x) { return (uint32_t)__builtin_amdgcn_update_dpp((int)x, (int)x, CTRL, RM, 0xF, false); });
+}
+// value of lane `src` (a compile-time lane) in every lane: v_readlane per word, no LDS crossbar trip
+template <int SRC, typename T>
+__device__ __forceinline__ T read_lane(T v)
+{
+  return shfl_words(v, [](uint32_t x) { return (uint32_t)__builtin_amdgcn_readlane((int)x, SRC); });
+}
+// Inclusive scan across the 64 lanes of a wave: row_shr:1/2/4/8 inside each row of 16 lanes, row_bcast:15 into
+// rows 1 and 3, row_bcast:31 into rows 2 and 3 -- six VALU steps per word.  (The earlier __shfl_up form cost one
+// ds_bpermute per word and step on the LDS pipe all four SIMDs of a CU share.)  Lower lanes are always the LEFT
+// operand, so any associative operator keeps its order.
 template <typename T, typename Op>
 __device__ __forceinline__ T wave_inclusive_scan(T v, Op op)
 {
   const unsigned l = lane_id();
-#pragma unroll
-  for (int d = 1; d < GX_WAVE; d <<= 1) {
-    T o = shfl_up(v, d);
-    if (l >= (unsigned)d) v = op(o, v);
-  }
+  { const T o = dpp_take<0x111, 0xF>(v); if ((l & 15u) >= 1u) v = op(o, v); }
+  { const T o = dpp_take<0x112, 0xF>(v); if ((l & 15u) >= 2u) v = op(o, v); }
+  { const T o = dpp_take<0x114, 0xF>(v); if ((l & 15u) >= 4u) v = op(o, v); }
+  { const T o = dpp_take<0x118, 0xF>(v); if ((l & 15u) >= 8u) v = op(o, v); }
+  { const T o = dpp_take<0x142, 0xA>(v); if (l & 16u) v = op(o, v); }
+  { const T o = dpp_take<0x143, 0xC>(v); if (l >= 32u) v = op(o, v); }
   return v;
 }
 

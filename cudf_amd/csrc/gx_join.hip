@@ -1902,8 +1902,12 @@ int gx_partition_rows(int key_dtype, const void* keys, int64_t n, int mode, int 
   using namespace gx::join;
   if (n < 0 || nparts < 1 || nparts > PJ_MAX_SPLIT + 1 || !tmp_bytes || (mode != 0 && mode != 1)) return GX_EINVAL;
   if (tmp && (!offsets_dev || (n > 0 && (!keys || !out_keys)) || (mode == 1 && nparts > 1 && !splitters_host))) return GX_EINVAL;
+  if (mode == 0 && (nparts & (nparts - 1))) return GX_EINVAL;  // hash mode: a power of two ranks
+  if (tmp && n == 0) {  // nothing to place: every partition is empty
+    GX_HIP_TRY(hipMemsetAsync(offsets_dev, 0, sizeof(int64_t) * (size_t)(nparts + 1), (hipStream_t)s));
+    return 0;
+  }
   if (mode == 0) {
-    if (nparts & (nparts - 1)) return GX_EINVAL;  // hash mode: a power of two ranks
     int pbits = 0;
     while ((1 << pbits) < nparts) ++pbits;
     switch (gx_dtype_size(key_dtype)) {

@@ -268,16 +268,31 @@ int scan_dd(const void* in, const uint32_t* valid, int64_t n, int inclusive, voi
   DDLoader<InT> ld{static_cast<const InT*>(in), valid};
   return scan::device_scan<DD, InT>(ld, n, DD{0.0, 0.0}, DDSum(), inclusive != 0, static_cast<InT*>(out), partials, s);
 }
+// exact commutative operators: the single-pass look-back scan (16 B/row)
+template <typename InT, typename AccT, typename Op>
+int scan_lookback(const void* in, const uint32_t* valid, int64_t n, AccT identity, Op op, int inclusive, void* out, void* tmp,
+                  size_t* tmp_bytes, hipStream_t s)
+{
+  Carver c(tmp);
+  char* scratch = c.take<char>(scan::lookback_bytes(n));
+  if (!tmp) {
+    *tmp_bytes = c.total();
+    return 0;
+  }
+  if (*tmp_bytes < c.total()) return GX_ETMP;
+  scan::PlainLoader<InT, AccT> ld{static_cast<const InT*>(in), valid, identity};
+  return scan::device_scan_lookback<AccT, InT>(ld, n, identity, op, inclusive != 0, static_cast<InT*>(out), scratch, s);
+}
 template <typename InT, bool SIGNED>
 int scan_int(const void* in, const uint32_t* valid, int64_t n, int op, int inclusive, void* out, void* tmp,
              size_t* tmp_bytes, hipStream_t s)
 {
   using W = typename std::conditional<SIGNED, int64_t, uint64_t>::type;
   switch (op) {
-    case GX_OP_SUM: return scan_typed<InT, uint64_t>(in, valid, n, uint64_t(0), SumOp(), inclusive, out, tmp, tmp_bytes, s);
-    case GX_OP_PRODUCT: return scan_typed<InT, uint64_t>(in, valid, n, uint64_t(1), ProdOp(), inclusive, out, tmp, tmp_bytes, s);
-    case GX_OP_MIN: return scan_typed<InT, W>(in, valid, n, (W)std::numeric_limits<InT>::max(), MinOp(), inclusive, out, tmp, tmp_bytes, s);
-    case GX_OP_MAX: return scan_typed<InT, W>(in, valid, n, (W)std::numeric_limits<InT>::lowest(), MaxOp(), inclusive, out, tmp, tmp_bytes, s);
+    case GX_OP_SUM: return scan_lookback<InT, uint64_t>(in, valid, n, uint64_t(0), SumOp(), inclusive, out, tmp, tmp_bytes, s);
+    case GX_OP_PRODUCT: return scan_lookback<InT, uint64_t>(in, valid, n, uint64_t(1), ProdOp(), inclusive, out, tmp, tmp_bytes, s);
+    case GX_OP_MIN: return scan_lookback<InT, W>(in, valid, n, (W)std::numeric_limits<InT>::max(), MinOp(), inclusive, out, tmp, tmp_bytes, s);
+    case GX_OP_MAX: return scan_lookback<InT, W>(in, valid, n, (W)std::numeric_limits<InT>::lowest(), MaxOp(), inclusive, out, tmp, tmp_bytes, s);
     default: return GX_EINVAL;
   }
 }
@@ -288,8 +303,8 @@ int scan_float(const void* in, const uint32_t* valid, int64_t n, int op, int inc
   switch (op) {
     case GX_OP_SUM: return scan_dd<InT>(in, valid, n, inclusive, out, tmp, tmp_bytes, s);
     case GX_OP_PRODUCT: return scan_typed<InT, double>(in, valid, n, 1.0, ProdOp(), inclusive, out, tmp, tmp_bytes, s);
-    case GX_OP_MIN: return scan_typed<InT, double>(in, valid, n, Limits<double>::highest(), MinOp(), inclusive, out, tmp, tmp_bytes, s);
-    case GX_OP_MAX: return scan_typed<InT, double>(in, valid, n, Limits<double>::lowest(), MaxOp(), inclusive, out, tmp, tmp_bytes, s);
+    case GX_OP_MIN: return scan_lookback<InT, double>(in, valid, n, Limits<double>::highest(), MinOp(), inclusive, out, tmp, tmp_bytes, s);
+    case GX_OP_MAX: return scan_lookback<InT, double>(in, valid, n, Limits<double>::lowest(), MaxOp(), inclusive, out, tmp, tmp_bytes, s);
     default: return GX_EINVAL;
   }
 }

@@ -138,7 +138,150 @@ __global__ void __launch_bounds__(SCAN_BT) k_chunk_scan(Loader load, int64_t n, 
   }
 }
 
+// ---- single-pass scan with decoupled look-back, for EXACT commutative operators (integer sum / product, any
+// min / max): 16 B/row instead of the 24 B/row of reduce-then-scan.  Floating-point sums keep the three-launch
+// form above: their result must not depend on which predecessor had published what when a tile looked back.
+// Tiles are handed out by ticket (every predecessor of a running tile is running or done); a tile publishes its
+// aggregate, then folds its predecessors' -- 64 of them per round, one per lane of wave 0 -- up to the nearest
+// inclusive prefix, and publishes its own.  An 8-byte accumulator travels as two 8-byte granules
+// {flag:2 | 32 value bits}: equal non-zero flags in both halves mean both come from the same publication.
+struct LbStatus {
+  unsigned long long lo, hi;
+};
+template <typename AccT>
+__device__ __forceinline__ void lb_publish(LbStatus* st, unsigned flag, AccT v)
+{
+  static_assert(sizeof(AccT) == 8, "look-back scan: 8-byte accumulators");
+  unsigned long long bits;
+  __builtin_memcpy(&bits, &v, 8);
+  store_agent_u64(&st->lo, ((unsigned long long)flag << 62) | (bits & 0xFFFFFFFFull));
+  store_agent_u64(&st->hi, ((unsigned long long)flag << 62) | (bits >> 32));
+}
+template <typename AccT>
+__device__ __forceinline__ unsigned lb_read(const LbStatus* st, AccT& v)
+{
+  unsigned long long l, h;
+  unsigned spins = 0;
+  for (;;) {
+    l = load_agent_u64(&st->lo);
+    h = load_agent_u64(&st->hi);
+    if ((l >> 62) != 0 && (l >> 62) == (h >> 62)) break;
+    if (++spins > (1u << 22)) break;  // a broken chain: give up rather than hang (the result is wrong, tests would tell)
+    __builtin_amdgcn_s_sleep(2);
+  }
+  const unsigned long long bits = (l & 0xFFFFFFFFull) | (h << 32);
+  __builtin_memcpy(&v, &bits, 8);
+  return (unsigned)(l >> 62);
+}
+
+// Tile = 1024 threads x 16 elements: measured on 1e9 uint64 (scripts/xp/xp_scan.hip, profiles/r2_xp_scan.txt) the tile
+// COUNT is what bounds this kernel -- 4096-element tiles 4.5 ms, 8192 3.5 ms, 16384 3.3 ms against a 3.0 ms copy;
+// the ticket atomic, the wave-scan flavour and 16-byte loads each moved it by < 0.1 ms.  The look-back window is 16
+// predecessors per round, not 64: a round waits for the slowest tile in its window (3.8 ms against 4.4 ms at 4096).
+constexpr int LB_BT    = 1024;
+constexpr int LB_CHUNK = LB_BT * SCAN_IPT;
+constexpr int LB_WIN   = 16;
+
+template <typename AccT, typename OutT, typename Op, typename Loader, bool INCLUSIVE>
+__global__ void __launch_bounds__(LB_BT) k_lookback_scan(Loader load, int64_t n, AccT identity, Op op, LbStatus* status,
+                                                         unsigned int* ticket, OutT* out)
+{
+  constexpr int NWV = LB_BT / GX_WAVE;
+  __shared__ AccT s_w[NWV];
+  __shared__ unsigned int s_tile;
+  const unsigned l = lane_id();
+  const unsigned w = threadIdx.x / GX_WAVE;
+  if (threadIdx.x == 0) s_tile = atomicAdd(ticket, 1u);
+  __syncthreads();
+  const int64_t tile = s_tile;
+  const int64_t base = tile * LB_CHUNK + (int64_t)w * (GX_WAVE * SCAN_IPT) + l;
+  AccT inc[SCAN_IPT];  // inclusive scan of each row inside the wave
+  AccT carry = identity;
+#pragma unroll
+  for (int k = 0; k < SCAN_IPT; ++k) {
+    const int64_t i = base + (int64_t)k * GX_WAVE;
+    inc[k]          = (i < n) ? load(i) : identity;
+  }
+#pragma unroll
+  for (int k = 0; k < SCAN_IPT; ++k) {
+    inc[k] = wave_inclusive_scan(inc[k], op);
+    carry  = op(carry, read_lane<GX_WAVE - 1>(inc[k]));
+  }
+  if (l == 0) s_w[w] = carry;
+  __syncthreads();
+  if (w == 0) {
+    // aggregate of the tile: the 16 wave carries, scanned so that every wave finds its own prefix in s_w afterwards
+    AccT wv = l < NWV ? s_w[l] : identity;
+    wv      = wave_inclusive_scan(wv, op);
+    const AccT agg = read_lane<NWV - 1>(wv);
+    AccT ex  = identity;
+    if (tile == 0) {
+      if (l == 0) lb_publish<AccT>(&status[0], 2u, agg);
+    } else {
+      if (l == 0) lb_publish<AccT>(&status[tile], 1u, agg);
+      int64_t pos = tile - 1;
+      for (;;) {
+        const int64_t idx = pos - (int64_t)l;
+        AccT v            = identity;
+        unsigned flag     = 2u;  // before the first tile: an (empty) inclusive prefix
+        if (l >= (unsigned)LB_WIN) flag = 1u;  // outside the window: an empty aggregate
+        else if (idx >= 0) flag = lb_read<AccT>(&status[idx], v);
+        const uint64_t m2 = ballot(flag == 2u);
+        if (m2 != 0) {  // nearest inclusive prefix: fold it and every aggregate nearer than it
+          const unsigned first = (unsigned)__builtin_ctzll(m2);
+          const AccT part      = wave_reduce(l <= first ? v : identity, op);
+          ex                   = op(part, ex);
+          break;
+        }
+        ex = op(wave_reduce(v, op), ex);
+        pos -= LB_WIN;
+      }
+      if (l == 0) lb_publish<AccT>(&status[tile], 2u, op(ex, agg));
+    }
+    // s_w[k] <- everything before wave k of this tile
+    AccT before = shfl_up(wv, 1);
+    if (l == 0) before = identity;
+    if (l < NWV) s_w[l] = op(ex, before);
+  }
+  __syncthreads();
+  AccT run = s_w[w];
+#pragma unroll
+  for (int k = 0; k < SCAN_IPT; ++k) {
+    const int64_t i = base + (int64_t)k * GX_WAVE;
+    if (INCLUSIVE) {
+      if (i < n) out[i] = static_cast<OutT>(op(run, inc[k]));
+    } else {
+      AccT exl = dpp_take<0x138, 0xF>(inc[k]);  // wave_shr:1
+      if (l == 0) exl = identity;
+      if (i < n) out[i] = static_cast<OutT>(op(run, exl));
+    }
+    run = op(run, read_lane<GX_WAVE - 1>(inc[k]));
+  }
+}
+
+static inline int64_t lb_tiles(int64_t n) { return n > 0 ? div_up(n, (int64_t)LB_CHUNK) : 0; }
 static inline int64_t num_chunks(int64_t n) { return n > 0 ? div_up(n, SCAN_CHUNK) : 0; }
+// scratch bytes of the single-pass scan over n elements
+static inline size_t lookback_bytes(int64_t n) { return (size_t)(lb_tiles(n) + 1) * sizeof(LbStatus) + 256; }
+
+// out may alias the loader's input (each tile is fully loaded before it is written).
+template <typename AccT, typename OutT, typename Op, typename Loader>
+int device_scan_lookback(Loader load, int64_t n, AccT identity, Op op, bool inclusive, OutT* out, void* scratch, hipStream_t stream)
+{
+  if (n <= 0) return 0;
+  const int64_t nc = lb_tiles(n);
+  GX_HIP_TRY(hipMemsetAsync(scratch, 0, lookback_bytes(n), stream));
+  unsigned int* ticket = static_cast<unsigned int*>(scratch);
+  LbStatus* status     = reinterpret_cast<LbStatus*>(static_cast<char*>(scratch) + 256);
+  if (inclusive)
+    hipLaunchKernelGGL((k_lookback_scan<AccT, OutT, Op, Loader, true>), dim3((unsigned)nc), dim3(LB_BT), 0, stream, load, n, identity,
+                       op, status, ticket, out);
+  else
+    hipLaunchKernelGGL((k_lookback_scan<AccT, OutT, Op, Loader, false>), dim3((unsigned)nc), dim3(LB_BT), 0, stream, load, n,
+                       identity, op, status, ticket, out);
+  GX_LAUNCH_CHECK();
+  return 0;
+}
 // scratch elements of AccT needed for a scan over n elements
 static inline size_t partials_count(int64_t n) { return (size_t)num_chunks(n) + 1; }
 
