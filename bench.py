@@ -46,7 +46,7 @@ def parse():
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--workload", default="all",
-                    choices=["all", "sort", "sorted_order", "join", "groupby", "reduce", "scan", "gather"])
+                    choices=["all", "sort", "sorted_order", "join", "groupby", "groupby_minmax", "reduce", "scan", "gather"])
     ap.add_argument("--rows", type=float, default=1e9)
     ap.add_argument("--algo", type=int, default=0,
                     help="sort knob: 0 onesweep/windowed look-back, 1 three-kernel, 2 onesweep/one-tile look-back")
@@ -60,6 +60,9 @@ def parse():
     ap.add_argument("--key-range", type=int, nargs=2, default=None, metavar=("LO", "HI"),
                     help="sort: keys uniform in [LO, HI) instead of the full int64 range (the reference's own "
                          "benchmark distribution is 100 10001: benchmarks/sort/sort.cpp:24-26)")
+    ap.add_argument("--through-cpp", action="store_true",
+                    help="also time cudf::sort / hash_join::inner_join / groupby::aggregate through the C++ surface "
+                         "(tests/cpp/cudf_api_bench, default pooled mr) and report the ratio to the C-ABI numbers")
     ap.add_argument("--cpu-baseline", dest="cpu", action="store_true", default=True)
     ap.add_argument("--no-cpu-baseline", dest="cpu", action="store_false")
     ap.add_argument("--cpu-rows", type=float, default=0, help="rows of the CPU-baseline sample (0 = per-workload default)")
@@ -550,6 +553,46 @@ def bench_groupby(c):
             "checked": "sum(count) == rows; distinct in-range keys; total and 3 sampled groups recomputed on the device"}
 
 
+def bench_groupby_minmax(c):
+    """groupby(int32 key, 1e6 groups).agg(f64 min, max): the LDS-partitioned MIN / MAX path (gx_groupby_min_max)"""
+    a, lib, L, ops, np, torch = c.args, c.lib, c.L, c.ops, c.np, c.torch
+    n = c.n
+    lib.gx_groupby_set_algorithm(a.gb_algo, a.gb_split)
+    gk = ops.random_column(np.int32, n, seed=7 + c.rank, lo=0, hi=1_000_000)
+    gv = ops.random_column(np.float64, n, seed=8 + c.rank)
+    mg = 1 << 20
+    ok, omin, omax = c.Column.empty(np.int32, mg), c.Column.empty(np.float64, mg), c.Column.empty(np.float64, mg)
+    ocv = c.Column.empty(np.int32, mg)
+    ng = torch.zeros(1, dtype=torch.int64, device="cuda")
+    nb = ctypes.c_size_t(0)
+    fn = lambda tmp, nbp: lib.gx_groupby_min_max(gk.gx, gk.data_ptr, None, gv.gx, gv.data_ptr, None, n, mg, ok.data_ptr,
+                                                 omin.data_ptr, omax.data_ptr, ocv.data_ptr, c.ptr(ng), tmp, nbp, c.stream)
+    L.check(fn(None, ctypes.byref(nb)), "size query")
+    tmp = c.device_bytes(nb.value)
+    step = lambda: L.check(fn(c.ptr(tmp), ctypes.byref(nb)), "groupby min/max")
+    sec = c.timed(step)
+    groups = int(ng.item())
+    kt = c.as_tensor(ok, torch.int32)[:groups]
+    ct = c.as_tensor(ocv, torch.int32)[:groups]
+    mnt, mxt = c.as_tensor(omin, torch.float64)[:groups], c.as_tensor(omax, torch.float64)[:groups]
+    assert int(ct.to(torch.int64).sum().item()) == n, "groupby min/max: counts do not add up to the row count"
+    assert int(torch.unique(kt).numel()) == groups, "groupby min/max: duplicate group keys"
+    gkt, gvt = c.as_tensor(gk, torch.int32), c.as_tensor(gv, torch.float64)
+    assert float(mnt.min().item()) == float(gvt.min().item()) and float(mxt.max().item()) == float(gvt.max().item())
+    for gi in (0, groups // 3, groups - 1):
+        sel = gkt == int(kt[gi].item())
+        assert float(gvt[sel].min().item()) == float(mnt[gi].item()) and float(gvt[sel].max().item()) == float(mxt[gi].item()), \
+            "groupby min/max: sampled group differs"
+    ach = 12 * n / sec / 1e9
+    roofline = {"bound": "hbm", "kernel": "k_part_hist + k_part_scatter + k_part_minmax (LDS-partitioned groupby MIN/MAX)",
+                "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS, "traffic": None,
+                "algorithmic_bytes_per_launch": 12 * n, "avg_launch_ms": sec * 1e3, "groups": groups,
+                "model": "12 B/row (4-B key + 8-B value read once; SURVEY.md 8d)"}
+    return {"workload": f"{n:.0e}-row groupby(int32 key, 1e6 groups).agg(float64 min,max)", "rows": n, "ms_per_step": sec * 1e3,
+            "rows_per_s": n / sec, "dtype": "f64", "roofline": roofline, "cpu_baseline": None,
+            "checked": "sum(count) == rows; distinct keys; global min / max and 3 sampled groups recomputed on the device"}
+
+
 # ------------------------------------------------------------------------------------------------
 # streaming primitives (SURVEY 8a rows a13-a15)
 # ------------------------------------------------------------------------------------------------
@@ -599,6 +642,26 @@ def bench_stream(c, which):
             "dtype": "f64" if which == "reduce" else "int64", "roofline": roofline, "cpu_baseline": None, "checked": checked}
 
 
+def through_cpp(args, c, sort_ms, join_ms, groupby_ms):
+    """What a caller of include/cudf/*.hpp pays (allocation through the pooled mr, result columns, the size read of
+    the join) next to the C-ABI numbers of this run.  The binary is built by __graft_entry__.build()."""
+    import subprocess
+    exe = os.path.join(ROOT, "tests", "cpp", "cudf_api_bench")
+    if not os.path.exists(exe):
+        raise RuntimeError("tests/cpp/cudf_api_bench is missing: run `python __graft_entry__.py` (build) first")
+    c.torch.cuda.synchronize()
+    c.torch.cuda.empty_cache()
+    out = subprocess.run([exe, str(c.n), str(args.steps), str(args.warmup)], check=True, capture_output=True, text=True,
+                         timeout=1200).stdout.strip().splitlines()[-1]
+    r = json.loads(out)
+    for k, ref in (("sort", sort_ms), ("join_probe", join_ms), ("groupby", groupby_ms)):
+        if ref:
+            r[k + "_vs_c_abi"] = r[k + "_ms"] / ref
+    r["note"] = ("wall-clock per call through the C++ API (allocation of outputs and scratch from the pooled mr included); "
+                 "the C-ABI numbers beside it use caller-owned buffers")
+    return r
+
+
 def main():
     args = parse()
     if args.gpus > 1 and "RANK" not in os.environ:
@@ -619,6 +682,8 @@ def main():
         head = bench_join(c)
     elif wl == "groupby":
         head = bench_groupby(c)
+    elif wl == "groupby_minmax":
+        head = bench_groupby_minmax(c)
     else:
         head = bench_stream(c, wl)
     if c.rank == 0:
@@ -639,6 +704,10 @@ def main():
                           "ms_per_step": b["ms_per_step"], "steps": args.steps, "warmup": args.warmup, "dtype": b["dtype"],
                           "roofline": b["roofline"], "cpu_baseline": b["cpu_baseline"], "checked": b.get("checked"),
                           **({"build_ms": b["build_ms"], "partition_bits": b["partition_bits"]} if "build_ms" in b else {})}
+        if args.through_cpp and c.world == 1:
+            line["through_cpp"] = through_cpp(args, c, head["ms_per_step"] if wl in ("all", "sort") else None,
+                                              (blocks.get("join") or (head if wl == "join" else {})).get("ms_per_step"),
+                                              (blocks.get("groupby") or (head if wl == "groupby" else {})).get("ms_per_step"))
         print(json.dumps(line), flush=True)
     if c.world > 1:
         c.dist.destroy_process_group()

@@ -39,6 +39,7 @@ _PROTOS = {
     "gx_sort_pairs": (_i, [_i, _p, _p, _p, _p, _i64, _i, _p, _sz, _p]),
     "gx_sorted_order": (_i, [_i, _p, _p, _i64, _i64, _i, _i, _p, _p, _sz, _p]),
     "gx_sort_status": (_i, [_p, ctypes.POINTER(_i), _p]),
+    "gx_sort_status_async": (_i, [_p, _p, _p]),
     "gx_sort_set_algorithm": (None, [_i]),
     "gx_sort_profile": (_i, [_i]),
     "gx_sort_profile_read": (_i, [ctypes.POINTER(ctypes.c_float), ctypes.POINTER(ctypes.c_float), ctypes.POINTER(_i)]),
@@ -73,6 +74,9 @@ _PROTOS = {
     "gx_join_set_probe_kernel": (None, [_i]),
     "gx_bitmask_copy": (_i, [_p, _i64, _p, _i64, _i64, _p]),
     "gx_pack_keys": (_i, [_i, _p, _p, _i64, _p, _p]),
+    "gx_hash_rows64": (_i, [_i, _p, _p, _i64, ctypes.c_uint64, _p, _p]),
+    "gx_rows_mismatch_count": (_i, [_i, _p, _p, _p, _p, _p, _i64, _p, _p]),
+    "gx_first_row_of_id": (_i, [_p, _p, _i64, _i64, _p, _p]),
     "gx_dense_rank": (_i, [_i, _p, _p, _i64, _i64, _p, _p, _p, _p, _sz, _p]),
     "gx_square": (_i, [_i, _p, _i64, _p, _p]),
     "gx_var_from_sums": (_i, [_i, _p, _p, _p, _i64, _i, _i, _p, _p, _p, _p]),

@@ -139,7 +139,6 @@ column::column(column_view view, rmm::cuda_stream_view stream, rmm::device_async
     rmm::device_buffer holder;
     auto const* m = detail::rebased_mask(view, holder, stream);
     _null_mask    = rmm::device_buffer{m, bitmask_allocation_size_bytes(view.size()), stream, mr};
-    stream.synchronize();  // `holder` may be the source
   }
 }
 
@@ -364,9 +363,9 @@ std::pair<rmm::device_buffer, size_type> bitmask_and(table_view const& view, rmm
 
 // ------------------------------------------------------------------------------------ scalar
 scalar::scalar(data_type type, bool is_valid, rmm::cuda_stream_view stream, rmm::device_async_resource_ref mr)
-  : _type{type}, _is_valid{&is_valid, 1, stream, mr}
+  : _type{type}, _is_valid{1, stream, mr}
 {
-  stream.synchronize();  // `is_valid` is a parameter
+  set_valid_async(is_valid, stream);  // a memset: no host source, nothing to wait for
 }
 
 void scalar::set_valid_async(bool is_valid, rmm::cuda_stream_view stream)

@@ -287,7 +287,6 @@ std::pair<std::unique_ptr<table>, std::vector<aggregation_result>> groupby::aggr
         detail::gx_check(gx_join_lookup(ksz, detail::row0(keys), kmask, keys.size(), table.data(), tbytes,
                                         group_of_row->mutable_view().head<int32_t>(), detail::gxs(stream)),
                          "groupby argmin/argmax lookup");
-        stream.synchronize();  // table / kh
       }
     }
     auto fin = [&](std::unique_ptr<column> c) {
@@ -380,7 +379,6 @@ std::pair<std::unique_ptr<table>, std::vector<aggregation_result>> groupby::aggr
                                                    target->view().head<void>(), gm, c->mutable_view().head<int32_t>(),
                                                    detail::gxs(stream)),
                              "groupby argmin/argmax");
-            stream.synchronize();  // vh
           }
           rmm::device_buffer mask = create_null_mask(gm, mask_state::ALL_VALID, stream, mr);
           rmm::device_buffer cnt{sizeof(int64_t), stream};
@@ -412,7 +410,6 @@ std::pair<std::unique_ptr<table>, std::vector<aggregation_result>> groupby::aggr
       }
     }
     if (!out_keys) out_keys = fin(std::move(o.keys));
-    stream.synchronize();  // per-request temporaries are released here
   }
   return {decode_keys(std::move(out_keys)), std::move(results)};
 }
@@ -463,7 +460,6 @@ std::pair<std::unique_ptr<table>, std::vector<aggregation_result>> groupby::scan
       }
       results[i].results.emplace_back(std::move(out));
     }
-    stream.synchronize();
   }
   return {h.sorted_keys(stream, mr), std::move(results)};
 }

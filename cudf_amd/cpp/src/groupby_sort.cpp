@@ -63,7 +63,6 @@ column_view sort_groupby_helper::key_sort_order(rmm::cuda_stream_view stream)
     for (auto const& c : _keys) cols.push_back(c);
     precedence.insert(precedence.begin(), null_order::AFTER);
     _order = cudf::stable_sorted_order(table_view{cols}, {}, precedence, stream);
-    stream.synchronize();  // `flag` dies here
   }
   return sliced();
 }
@@ -78,7 +77,6 @@ void sort_groupby_helper::build_groups(rmm::cuda_stream_view stream)
   _heads       = rmm::device_buffer{std::max<std::size_t>(1, n), stream};
   if (n == 0) {
     CUDF_CUDA_TRY(hipMemsetAsync(_offsets.data(), 0, sizeof(int32_t), stream.value()));
-    stream.synchronize();
     _num_groups = 0;
     return;
   }
@@ -343,7 +341,6 @@ std::pair<std::unique_ptr<table>, std::vector<aggregation_result>> groupby::sort
       }
       results[i].results.emplace_back(std::move(out));
     }
-    stream.synchronize();  // per-request temporaries are released here
   }
   return {h.unique_keys(stream, mr), std::move(results)};
 }
@@ -399,7 +396,6 @@ std::pair<std::unique_ptr<table>, std::unique_ptr<table>> groupby::shift(
                                           out->mutable_view().head<void>(), out->mutable_view().null_mask(), detail::gxs(stream)),
                        "groupby shift");
     out->set_null_count(n > 0 ? cudf::null_count(out->view().null_mask(), 0, n, stream) : 0);
-    stream.synchronize();
     results.emplace_back(std::move(out));
   }
   return {h.sorted_keys(stream, mr), std::make_unique<table>(std::move(results))};
@@ -434,7 +430,6 @@ std::pair<std::unique_ptr<table>, std::unique_ptr<table>> groupby::replace_nulls
       },
       "groupby replace_nulls", stream);
     out->set_null_count(cudf::null_count(out->view().null_mask(), 0, n, stream));
-    stream.synchronize();
     results.emplace_back(std::move(out));
   }
   return {h.sorted_keys(stream, mr), std::make_unique<table>(std::move(results))};

@@ -26,6 +26,15 @@ join_result empty_result(rmm::cuda_stream_view stream, rmm::device_async_resourc
           std::make_unique<rmm::device_uvector<size_type>>(0, stream, mr)};
 }
 
+// device int64 cursor <- v, with no host source to outlive the call: the high word by memset, the low one by the
+// sequence kernel (v is a row count: it fits 31 bits)
+void set_cursor_async(rmm::device_buffer& cursor, std::size_t v, rmm::cuda_stream_view stream)
+{
+  CUDF_CUDA_TRY(hipMemsetAsync(cursor.data(), 0, sizeof(int64_t), stream.value()));
+  if (v != 0)
+    detail::gx_check(gx_sequence_i32(static_cast<int32_t*>(cursor.data()), 1, static_cast<int32_t>(v), detail::gxs(stream)), "cursor");
+}
+
 // row indices of the null rows of a nullable column (rare path: host round trip)
 std::vector<size_type> null_rows(column_view const& c, rmm::cuda_stream_view stream)
 {
@@ -83,7 +92,6 @@ class hash_join_impl {
                "hash_join build");
     }
     _build_nulls = null_rows(key, stream);
-    stream.synchronize();
   }
 
   // the probe table's key column in the build side's key space (owner keeps an encoded column alive)
@@ -208,9 +216,7 @@ class hash_join_impl {
       CUDF_CUDA_TRY(hipMemcpyAsync(orr->data(), r->data(), n0 * sizeof(size_type), hipMemcpyDeviceToDevice, stream.value()));
     }
     rmm::device_buffer cursor{sizeof(int64_t), stream};
-    int64_t const start = static_cast<int64_t>(n0);
-    CUDF_CUDA_TRY(hipMemcpyAsync(cursor.data(), &start, sizeof(int64_t), hipMemcpyHostToDevice, stream.value()));
-    stream.synchronize();
+    set_cursor_async(cursor, n0, stream);
     run_with_scratch(
       [&](void* t, std::size_t* b) {
         return gx_join_complement(r->data(), static_cast<int64_t>(n0), nb, ol->data(), orr->data(),
@@ -291,7 +297,6 @@ class hash_join_impl {
       gx_check(gx_fill_nulls(4, out->data(), pmask, n, static_cast<uint64_t>(static_cast<uint32_t>(_build_nulls.front())),
                              gxs(stream)),
                "distinct_hash_join null rows");
-    stream.synchronize();
     return out;
   }
 
@@ -320,7 +325,6 @@ class hash_join_impl {
       gx_check(gx_fill_nulls(4, counts->data(), pmask, n, static_cast<uint64_t>(static_cast<uint32_t>(c)), gxs(stream)),
                "hash_join match counts of null rows");
     }
-    stream.synchronize();
     return counts;
   }
 
@@ -343,7 +347,6 @@ class hash_join_impl {
     join_result res = left_outer ? left_join(chunk, {}, stream, mr)
                                  : ((_build.num_rows() == 0) ? empty_result(stream, mr) : probe_join(chunk, false, {}, stream, mr));
     gx_check(gx_add_i32(res.first->data(), static_cast<int64_t>(res.first->size()), start, gxs(stream)), "partitioned join: re-base");
-    stream.synchronize();
     return res;
   }
 
@@ -464,9 +467,7 @@ join_result hash_join::finalize_partitioned_full_join(host_span<device_span<size
     at += n;
   }
   rmm::device_buffer cursor{sizeof(int64_t), stream};
-  int64_t const start = static_cast<int64_t>(total);
-  CUDF_CUDA_TRY(hipMemcpyAsync(cursor.data(), &start, sizeof(int64_t), hipMemcpyHostToDevice, stream.value()));
-  stream.synchronize();
+  detail::set_cursor_async(cursor, total, stream);
   if (right_table_num_rows > 0)
     detail::run_with_scratch(
       [&](void* t, std::size_t* b) {

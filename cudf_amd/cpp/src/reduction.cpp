@@ -26,9 +26,8 @@ template <typename T>
 std::unique_ptr<scalar> make_result(void const* dev_value, bool valid, rmm::cuda_stream_view stream,
                                     rmm::device_async_resource_ref mr)
 {
-  auto s = std::make_unique<numeric_scalar<T>>(T{}, valid, stream, mr);
+  auto s = std::make_unique<numeric_scalar<T>>(detail::uninitialized_value_t{}, valid, stream, mr);
   CUDF_CUDA_TRY(hipMemcpyAsync(s->data(), dev_value, sizeof(T), hipMemcpyDeviceToDevice, stream.value()));
-  stream.synchronize();
   return s;
 }
 
@@ -87,7 +86,6 @@ std::unique_ptr<column> scan(column_view const& input, scan_aggregation const& a
       rmm::device_buffer h2;
       auto const* m = detail::rebased_mask(input, h2, stream);
       out->set_null_mask(rmm::device_buffer{m, bitmask_allocation_size_bytes(n), stream, mr}, input.null_count());
-      stream.synchronize();
     } else {  // the first null poisons the rest (mask_scan :36-61)
       size_type first = n;
       if (input.has_nulls()) {
@@ -118,7 +116,6 @@ std::unique_ptr<column> murmurhash3_x86_32(table_view const& input, uint32_t see
     detail::gx_check(gx_murmur3_32(detail::gx_type(c.type()), detail::row0(c), mask, n, seed, k > 0 ? 1 : 0,
                                    out->mutable_view().head<uint32_t>(), detail::gxs(stream)),
                      "murmurhash3_x86_32");
-    stream.synchronize();
     ++k;
   }
   return out;
@@ -150,7 +147,6 @@ std::pair<std::unique_ptr<table>, std::vector<size_type>> hash_partition(table_v
   for (int p = 0; p < num_partitions; ++p) offsets[p] = host_offs[p];
   column_view mapv{data_type{type_id::INT32}, n, map.data(), nullptr, 0};
   auto out = gather(input, mapv, out_of_bounds_policy::DONT_CHECK, stream, mr);
-  stream.synchronize();
   return {std::move(out), offsets};
 }
 

@@ -120,7 +120,6 @@ row_encoder::dictionary row_encoder::make_dictionary(column_view const& packed, 
   gx_check(gx_join_build(8, row0(distinct->get_column(0).view()), nullptr, nvalues, d.table.data(), d.table_bytes, 0.5,
                          gxs(stream)),
            "row_encoder dictionary build");
-  stream.synchronize();  // `distinct` dies here
   return d;
 }
 
@@ -161,7 +160,6 @@ row_encoder::row_encoder(table_view const& build, bool nulls_equal, rmm::cuda_st
       auto const* m = rebased_mask(cols[0], holder, stream);
       _build_keys->set_null_mask(rmm::device_buffer{m, bitmask_allocation_size_bytes(cols[0].size()), stream},
                                  cols[0].null_count());
-      stream.synchronize();
     }
     return;
   }
@@ -173,7 +171,6 @@ row_encoder::row_encoder(table_view const& build, bool nulls_equal, rmm::cuda_st
       rmm::device_buffer holder;
       auto const* m = rebased_mask(cols[k], holder, stream);
       packed->set_null_mask(rmm::device_buffer{m, bitmask_allocation_size_bytes(cols[k].size()), stream}, cols[k].null_count());
-      stream.synchronize();
     }
     auto r = dense_rank(packed->view(), stream);
     _col_dict.push_back(make_dictionary(packed->view(), r, cols[k].null_count(), stream));
@@ -213,7 +210,6 @@ std::unique_ptr<column> row_encoder::encode(table_view const& probe, rmm::cuda_s
       rmm::device_buffer holder;
       auto const* m = cols[k].has_nulls() ? rebased_mask(cols[k], holder, stream) : nullptr;
       auto ids      = lookup(_col_dict[k], packed->view(), m, stream);
-      stream.synchronize();  // `holder`
       if (k == 0) {
         cur = std::move(ids);
         continue;

@@ -24,7 +24,6 @@ std::unique_ptr<column> rank(column_view const& input, rank_method method, order
     rmm::device_buffer holder;
     auto const* m = detail::rebased_mask(input, holder, stream);
     rmm::device_buffer mask{m, bitmask_allocation_size_bytes(n), stream, mr};
-    stream.synchronize();
     out->set_null_mask(std::move(mask), input.null_count());
   }
   auto order_col   = cudf::stable_sorted_order(table_view{{input}}, {column_order}, {null_precedence}, stream);
@@ -63,7 +62,6 @@ std::unique_ptr<column> rank(column_view const& input, rank_method method, order
                                        static_cast<int>(method), scale, 0, as_f64 ? nullptr : out->mutable_view().head<int32_t>(),
                                        as_f64 ? out->mutable_view().head<double>() : nullptr, detail::gxs(stream)),
                    "rank");
-  stream.synchronize();  // temporaries
   return out;
 }
 
@@ -78,7 +76,6 @@ std::unique_ptr<column> top_k_order(column_view const& col, size_type k, order t
   auto const kk    = std::min(k, col.size());
   column_view first{data_type{type_id::INT32}, kk, indices->view().head<void>(), nullptr, 0};
   auto out = std::make_unique<column>(first, stream, mr);
-  stream.synchronize();
   return out;
 }
 
@@ -124,7 +121,6 @@ std::unique_ptr<column> segmented_order(table_view const& keys, column_view cons
     prec.insert(prec.end(), null_precedence.begin(), null_precedence.end());
   }
   auto out = cudf::stable_sorted_order(table_view{cols}, ord, prec, stream, mr);
-  stream.synchronize();  // `ids`
   return out;
 }
 }  // namespace

@@ -762,7 +762,8 @@ int gx_mean_from_sum(int sum_dtype, const void* sum, const int32_t* count, int64
 // group).  Values are widened to a 64-bit word whose unsigned order is the value order (sign flip
 // for signed integers, the IEEE total-order flip for floats with -0.0 -> +0.0 and every NaN above
 // +Inf, the row comparator's order: include/cudf/detail/row_operator/common_utils.cuh:157-169), so one
-// native 64-bit unsigned atomic min / max per row serves every value type.  Global-table path only.
+// native 64-bit unsigned atomic min / max per row serves every value type.  Small inputs use the global table
+// directly, large ones the LDS-partitioned path below (k_part_minmax).
 // ------------------------------------------------------------------------------------------------
 namespace gx {
 namespace gb {
@@ -853,6 +854,164 @@ __global__ void __launch_bounds__(GBT) k_minmax_compact(const unsigned long long
   if (blockIdx.x == 0 && threadIdx.x == 0) *ngroups = st->overflow ? -1ll : (long long)*total;
 }
 
+// LDS-partitioned MIN / MAX: the same radix partition of (key, value) rows as the SUM path (k_part_hist /
+// k_part_scatter), then one workgroup per partition folding its rows into an LDS table of {key, min, max, count}
+// with ds_min_u64 / ds_max_u64 on the order-preserving 64-bit encoding; a group reaches the global table once per
+// partition (one find_or_insert + three global atomics) instead of once per row.  Rows that do not fit the LDS
+// table (more than 7/8 of its slots in use) take the global path row by row, as in k_part_aggregate.
+template <typename K, bool HAS_VV>
+constexpr int lds_slots_mm()
+{
+  constexpr int slot = (int)sizeof(K) + 8 + 8 + 4;
+  return (LDS_BUDGET / slot) / 256 * 256;
+}
+
+template <typename K, typename V, bool HAS_VV>
+__global__ void __launch_bounds__(ABT) k_part_minmax(const K* __restrict__ pkeys, const V* __restrict__ pvals,
+                                                     const uint8_t* __restrict__ pflags, const PartPlan* plan, int nsplit,
+                                                     unsigned long long* table, uint32_t log2cap, unsigned long long* mn,
+                                                     unsigned long long* mx, uint32_t* cnt_valid, GbState* st)
+{
+  constexpr int S    = lds_slots_mm<K, HAS_VV>();
+  constexpr K EMPTYK = K(~K(0));  // rows with this key use the dedicated slot S
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  unsigned long long* l_mn = reinterpret_cast<unsigned long long*>(smem);  // S + 1
+  unsigned long long* l_mx = l_mn + (S + 1);                                // S + 1
+  K* l_key                 = reinterpret_cast<K*>(l_mx + (S + 1));          // S + 1 (+1 pad)
+  uint32_t* l_cv           = reinterpret_cast<uint32_t*>(l_key + (S + 2));  // S + 1
+  __shared__ uint32_t s_nkeys;
+  __shared__ uint32_t s_special;
+
+  const unsigned tid = threadIdx.x;
+  for (int i = tid; i <= S; i += ABT) {
+    l_mn[i]  = ~0ull;
+    l_mx[i]  = 0ull;
+    l_key[i] = EMPTYK;
+    l_cv[i]  = 0;
+  }
+  if (tid == 0) {
+    s_nkeys   = 0;
+    s_special = 0;
+  }
+  __syncthreads();
+
+  const int part  = blockIdx.x / nsplit;
+  const int split = blockIdx.x % nsplit;
+  const unsigned long long p0 = plan->offset[part], p1 = plan->offset[part + 1];
+  const unsigned long long len = p1 - p0;
+  const unsigned long long per = (len + nsplit - 1) / nsplit;
+  const unsigned long long r0  = p0 + per * split < p1 ? p0 + per * split : p1;
+  const unsigned long long r1  = r0 + per < p1 ? r0 + per : p1;
+  constexpr uint32_t MAXKEYS   = (uint32_t)(S - S / 8);
+
+  constexpr int U = 8;
+  for (unsigned long long i0 = r0 + tid; i0 < r1; i0 += (unsigned long long)ABT * U) {
+    K k[U];
+    V v[U];
+    uint8_t f[U];
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const unsigned long long i = i0 + (unsigned long long)u * ABT;
+      const bool in              = i < r1;
+      k[u]                       = in ? pkeys[i] : K(0);
+      v[u]                       = in ? pvals[i] : V(0);
+      f[u]                       = HAS_VV ? (in ? pflags[i] : (uint8_t)0) : (uint8_t)1;
+    }
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const unsigned long long i = i0 + (unsigned long long)u * ABT;
+      if (i >= r1) continue;
+      const K key = k[u];
+      int slot    = -1;
+      if (key == EMPTYK) {
+        slot      = S;
+        s_special = 1u;  // benign race: every writer stores 1
+      } else {
+        uint32_t h = (uint32_t)(((part_hash<K>(key) >> 24) & 0xFFFFFFFFull) * (uint64_t)S >> 32);
+        for (int probes = 0; probes < S; ++probes) {
+          K cur = l_key[h];
+          if (cur == EMPTYK) {
+            if (s_nkeys >= MAXKEYS) break;
+            cur = atomicCAS(&l_key[h], EMPTYK, key);
+            if (cur == EMPTYK) {
+              atomicAdd(&s_nkeys, 1u);
+              slot = (int)h;
+              break;
+            }
+          }
+          if (cur == key) {
+            slot = (int)h;
+            break;
+          }
+          h = (h + 1 == (uint32_t)S) ? 0u : h + 1;
+        }
+      }
+      const unsigned long long e = mm_encode<V>(v[u]);
+      if (slot >= 0) {
+        if (f[u]) {
+          atomicMin(&l_mn[slot], e);
+          atomicMax(&l_mx[slot], e);
+          atomicAdd(&l_cv[slot], 1u);
+        }
+      } else {
+        const int64_t g = find_or_insert<K>(table, log2cap, key, st);
+        if (g >= 0 && f[u]) {
+          atomicMin(&mn[g], e);
+          atomicMax(&mx[g], e);
+          atomicAdd(&cnt_valid[g], 1u);
+        }
+      }
+    }
+  }
+  __syncthreads();
+  // ---- merge this workgroup's groups into the global table (a group with only null values still gets its slot)
+  for (int i = tid; i <= S; i += ABT) {
+    const K key    = l_key[i];
+    const bool occ = (i < S) ? (key != EMPTYK) : (s_special != 0u);
+    if (!occ) continue;
+    const int64_t g = find_or_insert<K>(table, log2cap, (i < S) ? key : EMPTYK, st);
+    if (g < 0) continue;
+    const uint32_t cv = l_cv[i];
+    if (cv) {
+      atomicMin(&mn[g], l_mn[i]);
+      atomicMax(&mx[g], l_mx[i]);
+      atomicAdd(&cnt_valid[g], cv);
+    }
+  }
+}
+
+template <typename K, typename V, bool HAS_VV>
+int launch_partitioned_minmax(const K* keys, const uint32_t* kvalid, const V* vals, const uint32_t* vvalid, int64_t n, PartPlan* plan,
+                              K* pkeys, V* pvals, uint8_t* pflags, unsigned long long* table, uint32_t lg, unsigned long long* mn,
+                              unsigned long long* mx, uint32_t* cv, GbState* st, hipStream_t s)
+{
+  GX_HIP_TRY(hipMemsetAsync(plan, 0, sizeof(PartPlan), s));
+  int64_t hb = div_up(n, 256 * 8 * 4 * NRANGE);
+  if (hb > 256) hb = 256;
+  if (hb < 1) hb = 1;
+  hipLaunchKernelGGL((k_part_hist<K>), dim3((unsigned)(hb * NRANGE)), dim3(256), 0, s, keys, kvalid, n, plan, g_gb_nrange);
+  hipLaunchKernelGGL(k_part_offsets, dim3(1), dim3(NPART), 0, s, plan);
+  constexpr int ESZ      = sizeof(K) > sizeof(V) ? sizeof(K) : sizeof(V);
+  constexpr size_t lds_s = (size_t)PTILE * ESZ + PTILE + (HAS_VV ? PTILE : 0) + NPART * 4 * 2 + NPART * 8 + 64;
+  auto ks                = k_part_scatter<K, V, HAS_VV>;
+  constexpr int S        = lds_slots_mm<K, HAS_VV>();
+  constexpr size_t lds_a = (size_t)(S + 1) * 16 + (size_t)(S + 2) * sizeof(K) + (size_t)(S + 1) * 4;
+  auto ka                = k_part_minmax<K, V, HAS_VV>;
+  static bool attr_set   = false;
+  if (!attr_set) {
+    GX_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(ks), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_s));
+    GX_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(ka), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_a));
+    attr_set = true;
+  }
+  hipLaunchKernelGGL(ks, dim3((unsigned)div_up(n, PTILE)), dim3(PBT), lds_s, s, keys, kvalid, vals, vvalid, n, plan, pkeys, pvals,
+                     pflags, g_gb_nrange);
+  const int nsplit = g_gb_nsplit;
+  hipLaunchKernelGGL(ka, dim3((unsigned)(NPART * nsplit)), dim3(ABT), lds_a, s, pkeys, pvals, pflags, plan, nsplit, table, lg, mn, mx,
+                     cv, st);
+  GX_LAUNCH_CHECK();
+  return 0;
+}
+
 template <typename K, typename V>
 int minmax_impl(const void* keys, const uint32_t* kvalid, const void* vals, const uint32_t* vvalid, int64_t n,
                 int64_t max_groups, void* out_keys, void* out_min, void* out_max, int32_t* out_cv, int64_t* ngroups,
@@ -868,6 +1027,13 @@ int minmax_impl(const void* keys, const uint32_t* kvalid, const void* vals, cons
   unsigned long long* mn    = c.take<unsigned long long>(cap + 1);  // all-ones
   uint32_t* pos             = c.take<uint32_t>(cap + 1);
   uint32_t* partials        = c.take<uint32_t>(scan::partials_count(cap + 1));
+  // large inputs: radix-partition the rows and fold each partition in LDS (the scratch layout depends on n only,
+  // so the size query and the call agree)
+  const bool partitioned = g_gb_algorithm != 1 && n > 0 && (g_gb_algorithm == 2 || n >= PART_MIN_ROWS);
+  PartPlan* plan         = c.take<PartPlan>(1);
+  K* pkeys               = partitioned ? c.take<K>((size_t)n) : nullptr;
+  V* pvals               = partitioned ? c.take<V>((size_t)n) : nullptr;
+  uint8_t* pflags        = partitioned ? c.take<uint8_t>((size_t)n) : nullptr;
   if (!tmp) {
     *tmp_bytes = c.total();
     return 0;
@@ -875,7 +1041,16 @@ int minmax_impl(const void* keys, const uint32_t* kvalid, const void* vals, cons
   if (*tmp_bytes < c.total()) return GX_ETMP;
   GX_HIP_TRY(hipMemsetAsync(tmp, 0, (size_t)(reinterpret_cast<char*>(mn) - static_cast<char*>(tmp)), s));
   GX_HIP_TRY(hipMemsetAsync(mn, 0xFF, (cap + 1) * sizeof(unsigned long long), s));
-  if (n > 0) {
+  if (partitioned) {
+    int prc;
+    if (vvalid)
+      prc = launch_partitioned_minmax<K, V, true>(static_cast<const K*>(keys), kvalid, static_cast<const V*>(vals), vvalid, n, plan,
+                                                  pkeys, pvals, pflags, table, lg, mn, mx, cv, st, s);
+    else
+      prc = launch_partitioned_minmax<K, V, false>(static_cast<const K*>(keys), kvalid, static_cast<const V*>(vals), vvalid, n, plan,
+                                                   pkeys, pvals, pflags, table, lg, mn, mx, cv, st, s);
+    if (prc) return prc;
+  } else if (n > 0) {
     int64_t blocks = div_up(n, GBT * 8);
     if (blocks > 256 * 16) blocks = 256 * 16;
     hipLaunchKernelGGL((k_minmax<K, V>), dim3((unsigned)blocks), dim3(GBT), 0, s, static_cast<const K*>(keys), kvalid,

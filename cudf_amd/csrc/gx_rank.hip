@@ -124,6 +124,90 @@ static inline unsigned grid_for(int64_t n)
   return (unsigned)b;
 }
 
+
+// ---- hashed row keys: rows wider than 8 bytes get a 64-bit hash as their join / groupby key, and the result is
+// VERIFIED against the real columns afterwards (k_rows_mismatch): equal rows always hash equal, so a verified result
+// is exact, and the caller falls back to the dense-rank encoding in the (2^-64 per pair) case of a collision.
+// One pass over the key columns instead of one radix sort per column; the reference hashes the row once as well
+// (cpp/include/cudf/detail/row_operator/primitive_row_operators.cuh:247-268) and compares on every probe (:95-163).
+__device__ __forceinline__ uint64_t fmix64(uint64_t x)
+{
+  x ^= x >> 33;
+  x *= 0xFF51AFD7ED558CCDull;
+  x ^= x >> 33;
+  x *= 0xC4CEB9FE1A85EC53ull;
+  x ^= x >> 33;
+  return x;
+}
+__global__ void __launch_bounds__(256) k_hash_rows(PackCols c, int64_t n, uint64_t seed, uint64_t* __restrict__ out)
+{
+  const int64_t stride = (int64_t)gridDim.x * 256;
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += stride) {
+    uint64_t h = seed;
+    for (int k = 0; k < c.ncols; ++k) {
+      uint64_t b = load_bits(c.p[k], c.size[k], i);
+      if (c.is_float[k]) b = normalise_float(b, c.size[k]);
+      h = fmix64(h + 0x9E3779B97F4A7C15ull + b) ^ (h << 1 | h >> 63);
+    }
+    out[i] = h;
+  }
+}
+// pairs (lidx[i], ridx[i]) -- NULL = row i itself; a negative index = no row, skipped -- whose rows differ in a column
+__global__ void __launch_bounds__(256) k_rows_mismatch(PackCols l, PackCols r, const int32_t* __restrict__ lidx,
+                                                       const int32_t* __restrict__ ridx, int64_t npairs, unsigned long long* count)
+{
+  const int64_t stride = (int64_t)gridDim.x * 256;
+  unsigned long long bad = 0;
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < npairs; i += stride) {
+    const int64_t a = lidx ? (int64_t)lidx[i] : i, b = ridx ? (int64_t)ridx[i] : i;
+    if (a < 0 || b < 0) continue;
+    bool diff = false;
+    for (int k = 0; k < l.ncols; ++k) {
+      uint64_t x = load_bits(l.p[k], l.size[k], a), y = load_bits(r.p[k], r.size[k], b);
+      if (l.is_float[k]) {
+        x = normalise_float(x, l.size[k]);
+        y = normalise_float(y, l.size[k]);
+      }
+      diff = diff || x != y;
+    }
+    bad += diff ? 1ull : 0ull;
+  }
+  bad = wave_reduce(bad, SumOp());
+  if (lane_id() == 0 && bad) atomicAdd(count, bad);
+}
+__global__ void __launch_bounds__(256) k_fill_i32(int32_t* __restrict__ out, int64_t n, int32_t v)
+{
+  const int64_t stride = (int64_t)gridDim.x * 256;
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += stride) out[i] = v;
+}
+// rep[id] = the smallest row carrying that id (rows whose validity bit is clear, or whose id is negative, carry none)
+__global__ void __launch_bounds__(256) k_first_row(const int32_t* __restrict__ ids, const uint32_t* __restrict__ valid, int64_t n,
+                                                   int64_t nids, int32_t* __restrict__ rep)
+{
+  const int64_t stride = (int64_t)gridDim.x * 256;
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += stride) {
+    if (valid && !bit_is_set(valid, i)) continue;
+    const int32_t id = ids[i];
+    if (id < 0 || (int64_t)id >= nids) continue;
+    if (rep[id] > (int32_t)i) atomicMin(&rep[id], (int32_t)i);
+  }
+}
+
+static inline int fill_cols(PackCols& c, int ncols, const void* const* cols, const int* dtypes, int64_t n)
+{
+  std::memset(&c, 0, sizeof(c));
+  for (int k = 0; k < ncols; ++k) {
+    const int sz = gx_dtype_size(dtypes[k]);
+    if (sz <= 0) return GX_EDTYPE;
+    if (n > 0 && !cols[k]) return GX_EINVAL;
+    c.p[k]        = cols[k];
+    c.size[k]     = sz;
+    c.is_float[k] = dtypes[k] == GX_FLOAT32 || dtypes[k] == GX_FLOAT64;
+  }
+  c.ncols = ncols;
+  return 0;
+}
+
 }  // namespace rank
 }  // namespace gx
 
@@ -149,6 +233,42 @@ int gx_pack_keys(int ncols, const void* const* cols, const int* dtypes, int64_t 
   c.ncols = ncols;
   if (n == 0) return 0;
   hipLaunchKernelGGL(gx::rank::k_pack, dim3(gx::rank::grid_for(n)), dim3(256), 0, s, c, n, out);
+  GX_LAUNCH_CHECK();
+  return 0;
+}
+
+int gx_hash_rows64(int ncols, const void* const* cols, const int* dtypes, int64_t n, uint64_t seed, uint64_t* out, gx_stream_t s)
+{
+  if (ncols < 1 || ncols > 8 || !cols || !dtypes || n < 0 || (n > 0 && !out)) return GX_EINVAL;
+  gx::rank::PackCols c;
+  if (int rc = gx::rank::fill_cols(c, ncols, cols, dtypes, n)) return rc;
+  if (n == 0) return 0;
+  hipLaunchKernelGGL(gx::rank::k_hash_rows, dim3(gx::rank::grid_for(n)), dim3(256), 0, s, c, n, seed, out);
+  GX_LAUNCH_CHECK();
+  return 0;
+}
+
+int gx_rows_mismatch_count(int ncols, const void* const* lcols, const void* const* rcols, const int* dtypes, const int32_t* lidx,
+                           const int32_t* ridx, int64_t npairs, int64_t* mismatch_dev, gx_stream_t s)
+{
+  if (ncols < 1 || ncols > 8 || !lcols || !rcols || !dtypes || npairs < 0 || !mismatch_dev) return GX_EINVAL;
+  gx::rank::PackCols l, r;
+  if (int rc = gx::rank::fill_cols(l, ncols, lcols, dtypes, npairs)) return rc;
+  if (int rc = gx::rank::fill_cols(r, ncols, rcols, dtypes, npairs)) return rc;
+  GX_HIP_TRY(hipMemsetAsync(mismatch_dev, 0, sizeof(int64_t), s));
+  if (npairs == 0) return 0;
+  hipLaunchKernelGGL(gx::rank::k_rows_mismatch, dim3(gx::rank::grid_for(npairs)), dim3(256), 0, s, l, r, lidx, ridx, npairs,
+                     reinterpret_cast<unsigned long long*>(mismatch_dev));
+  GX_LAUNCH_CHECK();
+  return 0;
+}
+
+int gx_first_row_of_id(const int32_t* ids, const uint32_t* valid, int64_t n, int64_t nids, int32_t* out_rep, gx_stream_t s)
+{
+  if (n < 0 || nids < 0 || (n > 0 && !ids) || (nids > 0 && !out_rep)) return GX_EINVAL;
+  if (nids == 0) return 0;
+  hipLaunchKernelGGL(gx::rank::k_fill_i32, dim3(gx::rank::grid_for(nids)), dim3(256), 0, s, out_rep, nids, INT32_MAX);
+  if (n > 0) hipLaunchKernelGGL(gx::rank::k_first_row, dim3(gx::rank::grid_for(n)), dim3(256), 0, s, ids, valid, n, nids, out_rep);
   GX_LAUNCH_CHECK();
   return 0;
 }

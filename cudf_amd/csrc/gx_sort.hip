@@ -1749,4 +1749,12 @@ int gx_sort_status(const void* tmp, int* status_host, gx_stream_t stream)
   return 0;
 }
 
+int gx_sort_status_async(const void* tmp, int* status_host_pinned, gx_stream_t stream)
+{
+  if (!tmp || !status_host_pinned) return GX_EINVAL;
+  const auto* plan = static_cast<const gx::sort::SortPlan*>(tmp);
+  GX_HIP_TRY(hipMemcpyAsync(status_host_pinned, &plan->status, sizeof(int), hipMemcpyDeviceToHost, stream));
+  return 0;
+}
+
 }  // extern "C"

@@ -37,6 +37,8 @@ class scalar {
 
 namespace detail {
 
+struct uninitialized_value_t {};
+
 template <typename T>
 class fixed_width_scalar : public scalar {
  public:
@@ -69,6 +71,11 @@ class fixed_width_scalar : public scalar {
   {
     stream.synchronize();  // `value` is a parameter: the copy must finish before returning
   }
+  // value left for the caller to fill on `stream` (reduction results: device-to-device, nothing to wait for)
+  fixed_width_scalar(uninitialized_value_t, bool is_valid, rmm::cuda_stream_view stream, rmm::device_async_resource_ref mr)
+    : scalar(data_type{type_to_id<T>()}, is_valid, stream, mr), _data{sizeof(T), stream, mr}
+  {
+  }
 };
 
 }  // namespace detail
@@ -81,6 +88,10 @@ class numeric_scalar : public detail::fixed_width_scalar<T> {
   numeric_scalar(T value, bool is_valid = true, rmm::cuda_stream_view stream = cudf::get_default_stream(),
                  rmm::device_async_resource_ref mr = cudf::get_current_device_resource_ref())
     : detail::fixed_width_scalar<T>(value, is_valid, stream, mr)
+  {
+  }
+  numeric_scalar(detail::uninitialized_value_t u, bool is_valid, rmm::cuda_stream_view stream, rmm::device_async_resource_ref mr)
+    : detail::fixed_width_scalar<T>(u, is_valid, stream, mr)
   {
   }
 };

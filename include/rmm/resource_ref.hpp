@@ -1,7 +1,7 @@
 // rmm::device_async_resource_ref shim: stream-ordered device allocation, the allocator type of
 // every libcudf signature (reference usage: cpp/include/cudf/sorting.hpp:48).
-// Default resource = hipMallocAsync / hipFreeAsync (the HIP stream-ordered pool), sized for
-// 288 GB of HBM3E: nothing here caps the pool.
+// Default resource = mr::pool_memory_resource, a stream-ordered caching arena sized for 288 GB of HBM3E:
+// nothing caps it, blocks go back to the driver only when an allocation fails.
 #pragma once
 #include <rmm/cuda_stream_view.hpp>
 
@@ -59,19 +59,33 @@ class hip_memory_resource final : public device_memory_resource {
   }
 };
 
-// CUDF_AMD_ALLOC=async selects the stream-ordered pool (hipMallocAsync); the default is plain
-// hipMalloc: on ROCm 7.2 blocks recycled by the stream-ordered pool were observed to lose
-// host-to-device copies issued right after re-allocation (tests/cpp reproduces it with the pool).
-inline device_memory_resource* get_default_resource()
-{
-  static hip_async_memory_resource pool;
-  static hip_memory_resource plain;
-  static bool const use_pool = [] {
-    char const* e = std::getenv("CUDF_AMD_ALLOC");
-    return e != nullptr && e[0] == 'a';
-  }();
-  return use_pool ? static_cast<device_memory_resource*>(&pool) : static_cast<device_memory_resource*>(&plain);
-}
+// Stream-ordered caching arena over hipMalloc (defined in libcudf.so, cudf_amd/cpp/src/memory_resource.cpp): a
+// freed block goes to a free list tagged with the stream it was freed on and an event recorded there; the same
+// stream takes it back with no synchronisation at all (stream order), another stream first waits on the event
+// (hipStreamWaitEvent, asynchronous).  hipMalloc / hipFree -- both of which synchronise the device -- are left
+// only on the cold path: a first-time size, or an out-of-memory retry after the cache is emptied.
+class pool_memory_resource final : public device_memory_resource {
+ public:
+  pool_memory_resource();
+  ~pool_memory_resource() override;
+  pool_memory_resource(pool_memory_resource const&)            = delete;
+  pool_memory_resource& operator=(pool_memory_resource const&) = delete;
+  // return every cached block to the driver (synchronises the device)
+  void release();
+  [[nodiscard]] std::size_t cached_bytes() const noexcept;
+  [[nodiscard]] std::size_t driver_allocations() const noexcept;  // hipMalloc calls so far
+
+ private:
+  void* do_allocate(std::size_t bytes, cuda_stream_view stream) override;
+  void do_deallocate(void* p, std::size_t bytes, cuda_stream_view stream) noexcept override;
+  struct impl;
+  impl* impl_;
+};
+
+// The process-wide default: the caching arena.  CUDF_AMD_ALLOC=plain selects hipMalloc / hipFree with a stream
+// synchronisation per free, CUDF_AMD_ALLOC=async the HIP runtime's own stream-ordered pool (hipMallocAsync).
+device_memory_resource* get_default_resource();
+device_memory_resource* set_default_resource(device_memory_resource* r);  // returns the previous one; nullptr restores the built-in
 
 }  // namespace mr
 

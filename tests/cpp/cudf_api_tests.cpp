@@ -14,6 +14,7 @@
 #include <cudf/join/join.hpp>
 #include <cudf/reduction.hpp>
 #include <cudf/sorting.hpp>
+#include <cudf_amd/gx.h>  // gx_sequence_i32: a device fill for the allocator test
 
 #include <execinfo.h>
 #include <signal.h>
@@ -1154,6 +1155,65 @@ int main()
     CHECK(throws<cudf::logic_error>([&] { table_view bad{{c->view(), m->view()}}; }));
     column_view sl{c->type(), 2, c->view().head<void>(), c->view().null_mask(), 1, 1};
     CHECK(sl.null_count(0, 2) == 1 && sl.data<double>() == c->view().data<double>() + 1);
+  });
+
+  run("pool_memory_resource: stream-ordered reuse, cross-stream reuse behind an event, H2D right after a recycle", [] {
+    auto* pool = dynamic_cast<rmm::mr::pool_memory_resource*>(rmm::mr::get_default_resource());
+    if (pool == nullptr) return;  // CUDF_AMD_ALLOC selected another resource
+    // (1) the same request again and again: one driver allocation per distinct size, none afterwards
+    std::vector<int64_t> kv(200000);
+    for (std::size_t i = 0; i < kv.size(); ++i) kv[i] = static_cast<int64_t>((i * 2654435761u) % 1000003) - 500000;
+    auto keys = make_col<int64_t>(kv);
+    auto want = kv;
+    std::sort(want.begin(), want.end());
+    std::size_t after_first = 0;
+    for (int it = 0; it < 4; ++it) {
+      auto out = cudf::sort(table_view{{keys->view()}});
+      CHECK(to_host<int64_t>(out->view().column(0)) == want);
+      if (it == 0) after_first = pool->driver_allocations();
+    }
+    CHECK(pool->driver_allocations() == after_first);
+    // (2) a pageable host-to-device copy into a block that was just recycled (what hipMallocAsync lost on ROCm 7.2)
+    for (int it = 0; it < 6; ++it) {
+      std::vector<int32_t> a(300000);
+      for (std::size_t i = 0; i < a.size(); ++i) a[i] = static_cast<int32_t>(i % 5000) + it;
+      auto c = make_col<int32_t>(a);
+      CHECK(to_host<int32_t>(c->view()) == a);
+      auto s = cudf::sort(table_view{{c->view()}});  // scratch and output come from, and go back to, the pool
+      auto const hs = to_host<int32_t>(s->view().column(0));
+      CHECK(hs.size() == a.size() && std::is_sorted(hs.begin(), hs.end()));
+    }
+    // (3) freed on one stream, taken on another: the taker is ordered behind the last use on the first stream
+    hipStream_t s1, s2;
+    CHECK(hipStreamCreateWithFlags(&s1, hipStreamNonBlocking) == hipSuccess);
+    CHECK(hipStreamCreateWithFlags(&s2, hipStreamNonBlocking) == hipSuccess);
+    std::size_t const n = std::size_t{48} << 20;  // 192 MiB of int32: the fill on s1 is still running when s2 asks
+    for (int it = 0; it < 3; ++it) {
+      void* p1 = nullptr;
+      {
+        rmm::device_buffer b1{n * 4, rmm::cuda_stream_view{s1}};
+        p1 = b1.data();
+        for (int r = 0; r < 4; ++r) CHECK(gx_sequence_i32(static_cast<int32_t*>(b1.data()), (int64_t)n, 1000 + r, s1) == 0);
+      }  // freed on s1 with the fills still queued
+      rmm::device_buffer b2{n * 4, rmm::cuda_stream_view{s2}};
+      CHECK(b2.data() == p1);  // the only cached block of that size
+      CHECK(gx_sequence_i32(static_cast<int32_t*>(b2.data()), (int64_t)n, 7, s2) == 0);
+      std::vector<int32_t> h(n);
+      CHECK(hipMemcpyAsync(h.data(), b2.data(), n * 4, hipMemcpyDeviceToHost, s2) == hipSuccess);
+      CHECK(hipStreamSynchronize(s2) == hipSuccess);
+      CHECK(hipStreamSynchronize(s1) == hipSuccess);
+      bool ok = true;
+      for (std::size_t i = 0; i < n; i += 4097) ok = ok && h[i] == static_cast<int32_t>(7 + i);
+      CHECK(ok && h[n - 1] == static_cast<int32_t>(7 + n - 1));
+    }
+    (void)hipStreamDestroy(s1);
+    (void)hipStreamDestroy(s2);
+    // (4) release() hands everything back; the next request allocates again
+    pool->release();
+    CHECK(pool->cached_bytes() == 0);
+    auto const before = pool->driver_allocations();
+    { rmm::device_buffer b{1 << 20, get_default_stream()}; }
+    CHECK(pool->driver_allocations() == before + 1 && pool->cached_bytes() >= (1u << 20));
   });
 
   std::printf("%d run, %d failed\n", g_run, g_failed);

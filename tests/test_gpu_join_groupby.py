@@ -279,7 +279,7 @@ def test_groupby_partitioned_large(gx, nulls, nsplit):
 
 @pytest.mark.parametrize("vdtype", ["float64", "float32", "int32", "int64", "uint8", "int16"])
 @pytest.mark.parametrize("kdtype", ["int32", "int64"])
-def test_groupby_min_max_matches_oracle(gx, kdtype, vdtype):
+def test_groupby_min_max_matches_oracle(gx, kdtype, vdtype, gb_algo):
     Column, ops = gx
     rng = np.random.default_rng(14)
     for n, g in [(0, 1), (1, 1), (1000, 7), (250_000, 3000)]:
@@ -304,6 +304,48 @@ def test_groupby_min_max_matches_oracle(gx, kdtype, vdtype):
         assert mn.dtype == np.dtype(vdtype)
         np.testing.assert_array_equal(mn.to_numpy()[o][ev], emn[ev])   # -0.0 == +0.0 under array_equal
         np.testing.assert_array_equal(mx.to_numpy()[o][ev], emx[ev])
+
+
+@pytest.mark.parametrize("nsplit", [1, 3])
+@pytest.mark.parametrize("nulls", [False, True])
+def test_groupby_min_max_partitioned_large(gx, nulls, nsplit):
+    """MIN / MAX on the auto path at sizes where the LDS-partitioned kernels run (n >= 2^19): partitions that fit
+    their LDS table, partitions that overflow it (rows spill to the global table), the all-ones key, a hot key,
+    groups whose values are all null, NaN / -0.0 / inf values."""
+    Column, ops = gx
+    from cudf_amd import _lib
+    _lib.lib.gx_groupby_set_algorithm(0, nsplit)
+    try:
+        rng = np.random.default_rng(21)
+        for n, g, kdtype, vdtype in [(1_500_000, 50_000, "int32", "float64"), (2_500_000, 2_000_000, "int32", "int64"),
+                                     (1_200_000, 300_000, "int64", "float32"), (1_000_000, 40_000, "int64", "int16")]:
+            keys = rng.integers(-g // 2, g // 2, n).astype(kdtype)
+            keys[::97] = -1
+            if n < 2_000_000:
+                keys[5::3] = 12345
+            if np.dtype(vdtype).kind == "f":
+                vals = (rng.random(n) * 2000 - 1000).astype(vdtype)
+                vals[::50] = -0.0
+                vals[1::97] = np.inf
+                vals[3::1013] = -np.inf
+            else:
+                info = np.iinfo(vdtype)
+                vals = rng.integers(info.min, info.max, n, dtype=vdtype, endpoint=True)
+            kv = (rng.random(n) > 0.03) if nulls else None
+            vv = (rng.random(n) > 0.4) if nulls else None
+            if nulls:
+                vv[keys == 7] = False                      # a group with only null values keeps its slot, count 0
+            k, mn, mx, cv = ops.groupby_min_max(Column.from_numpy(keys, kv), Column.from_numpy(vals, vv), max_groups_hint=1 << 21)
+            o = np.argsort(k.to_numpy(), kind="stable")
+            ek, res = orc.groupby_agg(keys, vals, ["min", "max", "count_valid"], kv, vv)
+            np.testing.assert_array_equal(k.to_numpy()[o], ek)
+            np.testing.assert_array_equal(cv.to_numpy()[o], res["count_valid"][0])
+            emn, ev = res["min"]
+            emx, _ = res["max"]
+            np.testing.assert_array_equal(mn.to_numpy()[o][ev], emn[ev])
+            np.testing.assert_array_equal(mx.to_numpy()[o][ev], emx[ev])
+    finally:
+        _lib.lib.gx_groupby_set_algorithm(0, 1)
 
 
 @pytest.mark.parametrize("vdtype", ["int32", "int64", "float64"])
