@@ -46,7 +46,7 @@ def parse():
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--workload", default="all",
-                    choices=["all", "sort", "sorted_order", "join", "groupby", "groupby_minmax", "reduce", "scan", "gather"])
+                    choices=["all", "sort", "sorted_order", "join", "groupby", "groupby_minmax", "join_multikey", "groupby_multikey", "reduce", "scan", "gather"])
     ap.add_argument("--rows", type=float, default=1e9)
     ap.add_argument("--algo", type=int, default=0,
                     help="sort knob: 0 onesweep/windowed look-back, 1 three-kernel, 2 onesweep/one-tile look-back")
@@ -593,6 +593,81 @@ def bench_groupby_minmax(c):
             "checked": "sum(count) == rows; distinct keys; global min / max and 3 sampled groups recomputed on the device"}
 
 
+def bench_multikey(c, which):
+    """Two int64 key columns (16-byte rows): the hash-and-verify row keys (gx_hash_rows64 + the single-key kernels +
+    gx_rows_mismatch_count) against nothing but their own roofline -- the earlier encoding ran one radix sort per key
+    column.  join: 1e8-row build side hashed and built once (untimed, like the single-key line), timed = hash the
+    probe rows, partitioned probe, certify the pairs.  groupby: timed = ids (hash, distinct keys + first rows, lookup,
+    certify) + SUM/COUNT by id + gather of the group keys."""
+    a, lib, L, ops, np, torch = c.args, c.lib, c.L, c.ops, c.np, c.torch
+    n = c.n
+    if which == "join_multikey":
+        nb_rows = max(1, n // 10)
+        b0 = c.Column.empty(np.int64, nb_rows)
+        torch.manual_seed(4242)
+        c.as_tensor(b0, torch.int64).copy_(torch.randperm(nb_rows, device="cuda"))          # distinct first column
+        b1 = ops.random_column(np.int64, nb_rows, seed=5, lo=0, hi=1 << 40)
+        p0 = ops.random_column(np.int64, n, seed=6, lo=0, hi=int(nb_rows / 0.3))          # 30 % of the probe rows hit ...
+        p0t, b0t, b1t = c.as_tensor(p0, torch.int64), c.as_tensor(b0, torch.int64), c.as_tensor(b1, torch.int64)
+        p1 = c.Column.empty(np.int64, n)
+        p1t = c.as_tensor(p1, torch.int64)
+        inv = torch.empty(nb_rows, dtype=torch.int64, device="cuda")
+        inv[b0t] = torch.arange(nb_rows, device="cuda")
+        hit = p0t < nb_rows
+        p1t.fill_(-1)
+        p1t[hit] = b1t[inv[p0t[hit]]]                                                        # ... with BOTH columns equal
+        half = hit & ((p0t & 1) == 1)
+        p1t[half] += 1                                                                       # odd keys: second column differs
+        expected = int((hit & ~half).sum().item())
+        del inv, hit, half
+        bk = ops.hash_rows64([b0, b1])
+        hj = ops.HashJoin(bk)
+        res = {}
+
+        def step():
+            pk = ops.hash_rows64([p0, p1])
+            l, r = hj.inner_join(pk)
+            res["bad"] = ops.rows_mismatch_count([p0, p1], [b0, b1], l, r, l.size)
+            res["pairs"] = l.size
+        sec = c.timed(step)
+        assert res["bad"] == 0 and res["pairs"] == expected, (res, expected)
+        bpr = 16 + 8 + 20                      # read 2 keys, write the hash; the single-key join's 20 B/row model
+        kname = "gx_hash_rows64 + partitioned probe + gx_rows_mismatch_count (2 x int64 keys)"
+        wl = f"{n:.0e}-row probe x {nb_rows:.0e}-row build inner join on 2 int64 key columns"
+        checked = "pair count == closed form (rows equal in both columns); every pair certified column by column"
+    else:
+        k0 = ops.random_column(np.int64, n, seed=21, lo=0, hi=1000)
+        k1 = ops.random_column(np.int64, n, seed=22, lo=0, hi=1000)                         # 1e6 (k0, k1) groups
+        gv = ops.random_column(np.float64, n, seed=23)
+        res = {}
+
+        def step():
+            keys, sm, cv, _ = ops.groupby_sum_count_tables([k0, k1], gv)
+            res["out"] = (keys, sm, cv)
+        sec = c.timed(step)
+        keys, sm, cv = res["out"]
+        g = sm.size
+        assert g == 1_000_000 or n < 20_000_000, g
+        assert int(c.as_tensor(cv, torch.int32)[:g].to(torch.int64).sum().item()) == n
+        kt0, kt1 = c.as_tensor(keys[0], torch.int64)[:g], c.as_tensor(keys[1], torch.int64)[:g]
+        assert int(torch.unique(kt0 * 1000 + kt1).numel()) == g, "duplicate group keys"
+        t0, t1, tv = c.as_tensor(k0, torch.int64), c.as_tensor(k1, torch.int64), c.as_tensor(gv, torch.float64)
+        for gi in (0, g // 2, g - 1):
+            sel = (t0 == int(kt0[gi].item())) & (t1 == int(kt1[gi].item()))
+            ref = float(tv[sel].sum().item())
+            assert abs(float(c.as_tensor(sm, torch.float64)[gi].item()) - ref) <= 1e-11 * max(1.0, abs(ref))
+        bpr = 16 + 8
+        kname = "gx_hash_rows64 + hash ids + LDS-partitioned groupby (2 x int64 keys)"
+        wl = f"{n:.0e}-row groupby(2 int64 key columns, 1e6 groups).agg(float64 sum,count)"
+        checked = "sum(count) == rows; distinct key pairs; 3 sampled groups recomputed on the device"
+    ach = bpr * n / sec / 1e9
+    roofline = {"bound": "hbm", "kernel": kname, "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS,
+                "traffic": None, "algorithmic_bytes_per_launch": bpr * n, "avg_launch_ms": sec * 1e3,
+                "model": f"{bpr} B/row: the key and value columns read once" + (", 8-B hash written, 20 B/row single-key join" if which == "join_multikey" else "")}
+    return {"workload": wl, "rows": n, "ms_per_step": sec * 1e3, "rows_per_s": n / sec, "dtype": "int64", "roofline": roofline,
+            "cpu_baseline": None, "checked": checked}
+
+
 # ------------------------------------------------------------------------------------------------
 # streaming primitives (SURVEY 8a rows a13-a15)
 # ------------------------------------------------------------------------------------------------
@@ -684,6 +759,8 @@ def main():
         head = bench_groupby(c)
     elif wl == "groupby_minmax":
         head = bench_groupby_minmax(c)
+    elif wl in ("join_multikey", "groupby_multikey"):
+        head = bench_multikey(c, wl)
     else:
         head = bench_stream(c, wl)
     if c.rank == 0:

@@ -74,9 +74,9 @@ _PROTOS = {
     "gx_join_set_probe_kernel": (None, [_i]),
     "gx_bitmask_copy": (_i, [_p, _i64, _p, _i64, _i64, _p]),
     "gx_pack_keys": (_i, [_i, _p, _p, _i64, _p, _p]),
+    "gx_unpack_keys": (_i, [_i, _p, _p, _i64, _p, _p]),
     "gx_hash_rows64": (_i, [_i, _p, _p, _i64, ctypes.c_uint64, _p, _p]),
     "gx_rows_mismatch_count": (_i, [_i, _p, _p, _p, _p, _p, _i64, _p, _p]),
-    "gx_first_row_of_id": (_i, [_p, _p, _i64, _i64, _p, _p]),
     "gx_dense_rank": (_i, [_i, _p, _p, _i64, _i64, _p, _p, _p, _p, _sz, _p]),
     "gx_square": (_i, [_i, _p, _i64, _p, _p]),
     "gx_var_from_sums": (_i, [_i, _p, _p, _p, _i64, _i, _i, _p, _p, _p, _p]),

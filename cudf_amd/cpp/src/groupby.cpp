@@ -143,8 +143,22 @@ groupby::groupby(table_view const& keys, null_policy null_handling, sorted keys_
 {
 }
 
+namespace {
+struct row_key_collision {};  // two different key rows shared a 64-bit hash: thrown by decode_keys, caught by aggregate
+}  // namespace
+
 std::pair<std::unique_ptr<table>, std::vector<aggregation_result>> groupby::aggregate(
   std::span<aggregation_request const> requests, rmm::cuda_stream_view stream, rmm::device_async_resource_ref mr)
+{
+  try {
+    return aggregate_impl(requests, false, stream, mr);
+  } catch (row_key_collision const&) {
+    return aggregate_impl(requests, true, stream, mr);
+  }
+}
+
+std::pair<std::unique_ptr<table>, std::vector<aggregation_result>> groupby::aggregate_impl(
+  std::span<aggregation_request const> requests, bool exact_keys, rmm::cuda_stream_view stream, rmm::device_async_resource_ref mr)
 {
   CUDF_EXPECTS(std::all_of(requests.begin(), requests.end(),
                            [this](auto const& r) { return r.values.size() == _keys.num_rows(); }),
@@ -157,17 +171,25 @@ std::pair<std::unique_ptr<table>, std::vector<aggregation_result>> groupby::aggr
     for (auto const& agg : r.aggregations)
       sort_path = sort_path || agg->kind == aggregation::PRODUCT || agg->kind == aggregation::NTH_ELEMENT;
   if (sort_path && _keys.num_rows() > 0 && !requests.empty()) return sort_aggregate(requests, stream, mr);
-  // One 32/64-bit integer key column goes to the hash kernels as it is; anything else (several columns,
-  // floats, narrow types) is first encoded into dense INT32 row ids (gx_dense_rank), aggregated by id, and
-  // the key columns are gathered back through the first row of every id.
+  // One 32/64-bit integer key column goes to the hash kernels as it is; anything else (several columns, floats,
+  // narrow types) becomes ONE 8-byte row key first (detail::row_keys: the packed values, or a 64-bit row hash whose
+  // result is certified against the key columns), and the key columns come back from the distinct row keys.
+  // exact_keys (the retry after a hash collision, or more than 8 key columns): dense INT32 row ids
+  // (gx_dense_rank, one radix sort per column), aggregated by id, keys gathered through the first row of every id.
   auto const k0      = _keys.column(0).type().id();
   bool const encoded = !(_keys.num_columns() == 1 && (k0 == type_id::INT32 || k0 == type_id::INT64 ||
                                                       k0 == type_id::UINT32 || k0 == type_id::UINT64));
   detail::dense_rank_result enc;
+  std::unique_ptr<detail::row_keys> rk;
   column_view keys = _keys.column(0);
   if (encoded && _keys.num_rows() > 0) {
-    enc  = detail::dense_row_ids(_keys, stream);
-    keys = enc.ids->view();
+    if (!exact_keys && _keys.num_columns() <= 8) {
+      rk   = std::make_unique<detail::row_keys>(_keys, stream);
+      keys = rk->view();
+    } else {
+      enc  = detail::dense_row_ids(_keys, stream);
+      keys = enc.ids->view();
+    }
   }
   // unique ids (in whatever order the hash pass produced) -> the key columns
   auto decode_keys = [&](std::unique_ptr<column> ids) {
@@ -180,6 +202,11 @@ std::pair<std::unique_ptr<table>, std::vector<aggregation_result>> groupby::aggr
       std::vector<std::unique_ptr<column>> kc;
       for (auto const& c : _keys) kc.emplace_back(make_empty_column(c.type()));
       return std::make_unique<table>(std::move(kc));
+    }
+    if (rk) {
+      auto kt = rk->key_columns(ids->view(), stream, mr);
+      if (!kt) throw row_key_collision{};
+      return kt;
     }
     auto rows = cudf::gather(table_view{{enc.rep->view()}}, ids->view(), out_of_bounds_policy::DONT_CHECK, stream);
     return cudf::gather(_keys, rows->get_column(0).view(), out_of_bounds_policy::DONT_CHECK, stream, mr);

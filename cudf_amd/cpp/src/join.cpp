@@ -11,6 +11,7 @@
 #include <cudf/null_mask.hpp>
 
 #include <algorithm>
+#include <mutex>
 #include <stdexcept>
 #include <vector>
 
@@ -54,8 +55,10 @@ std::vector<size_type> null_rows(column_view const& c, rmm::cuda_stream_view str
 
 class hash_join_impl {
  public:
+  // allow_hash: rows wider than 8 bytes may be keyed by their 64-bit hash (row_encoder); pair-producing probes then
+  // certify their output against the key columns, everything else goes through exact()
   hash_join_impl(table_view const& build, nullable_join has_nulls, null_equality compare_nulls, double load_factor,
-                 rmm::cuda_stream_view stream)
+                 rmm::cuda_stream_view stream, bool allow_hash = true)
     : _build{build}, _has_nulls{has_nulls == nullable_join::YES}, _nulls_equal{compare_nulls == null_equality::EQUAL},
       _load_factor{load_factor}
   {
@@ -69,7 +72,7 @@ class hash_join_impl {
     if (direct) {
       _key = c0;
     } else {
-      _enc = std::make_unique<row_encoder>(build, _nulls_equal, stream);
+      _enc = std::make_unique<row_encoder>(build, _nulls_equal, stream, allow_hash);
       _key = _enc->build_keys();
     }
     auto const& key = _key;
@@ -92,6 +95,19 @@ class hash_join_impl {
                "hash_join build");
     }
     _build_nulls = null_rows(key, stream);
+  }
+
+  [[nodiscard]] bool hashed() const { return _enc && _enc->hashed(); }
+  // The exactly-encoded twin of a hashed table, built on first use: the operations that only COUNT matches cannot
+  // be certified pair by pair, and a pair-producing probe lands here after a 64-bit collision.
+  hash_join_impl const& exact(rmm::cuda_stream_view stream) const
+  {
+    std::lock_guard<std::mutex> lock(_exact_mutex);
+    if (!_exact)
+      _exact = std::make_unique<hash_join_impl const>(_build, _has_nulls ? nullable_join::YES : nullable_join::NO,
+                                                      _nulls_equal ? null_equality::EQUAL : null_equality::UNEQUAL, _load_factor,
+                                                      stream, false);
+    return *_exact;
   }
 
   // the probe table's key column in the build side's key space (owner keeps an encoded column alive)
@@ -171,6 +187,8 @@ class hash_join_impl {
     }
     l->shrink(n);
     r->shrink(n);
+    if (hashed() && n > 0 && count_row_mismatches(probe, _build, l->data(), r->data(), n, stream) != 0)
+      return exact(stream).probe_join(probe, left_outer, output_size, stream, mr);  // a 64-bit collision
     return {std::move(l), std::move(r)};
   }
 
@@ -232,6 +250,7 @@ class hash_join_impl {
   std::size_t inner_join_size(table_view const& probe, rmm::cuda_stream_view stream) const
   {
     check_probe(probe);
+    if (hashed()) return exact(stream).inner_join_size(probe, stream);
     if (probe.num_rows() == 0 || _build.num_rows() == 0) return 0;
     std::unique_ptr<column> owner;
     auto const pk = probe_key(probe, owner, stream);
@@ -257,6 +276,7 @@ class hash_join_impl {
       return out;
     }
     check_probe(probe);
+    if (hashed()) return exact(stream).semi_anti(probe, anti, stream, mr);  // "has a match" cannot be certified pair by pair
     std::unique_ptr<column> owner;
     auto const pk = probe_key(probe, owner, stream);
     rmm::device_buffer holder;
@@ -297,6 +317,8 @@ class hash_join_impl {
       gx_check(gx_fill_nulls(4, out->data(), pmask, n, static_cast<uint64_t>(static_cast<uint32_t>(_build_nulls.front())),
                              gxs(stream)),
                "distinct_hash_join null rows");
+    if (hashed() && count_row_mismatches(probe, _build, nullptr, out->data(), static_cast<std::size_t>(n), stream) != 0)
+      return exact(stream).lookup(probe, stream, mr);  // a 64-bit collision
     return out;
   }
 
@@ -305,6 +327,7 @@ class hash_join_impl {
                                                                rmm::cuda_stream_view stream, rmm::device_async_resource_ref mr) const
   {
     check_probe(probe);
+    if (hashed()) return exact(stream).match_counts(probe, min_count, stream, mr);
     auto const n = probe.num_rows();
     auto counts  = std::make_unique<rmm::device_uvector<size_type>>(n, stream, mr);
     if (n == 0) return counts;
@@ -358,6 +381,8 @@ class hash_join_impl {
   bool _nulls_equal;
   double _load_factor;
   std::unique_ptr<row_encoder> _enc{};
+  mutable std::mutex _exact_mutex{};
+  mutable std::unique_ptr<hash_join_impl const> _exact{};
   column_view _key{};
   int _key_size{0};
   std::size_t _table_bytes{0};
@@ -495,7 +520,8 @@ filtered_join::filtered_join(table_view const& right, null_equality compare_null
   _right_rows = right.num_rows();
   // an empty right table (no columns or no rows) matches nothing (semi_anti_join_tests.cpp:357-421)
   if (right.num_columns() > 0 && right.num_rows() > 0)
-    _impl = std::make_unique<detail::hash_join_impl const>(right, nullable_join::YES, compare_nulls, load_factor, stream);
+    _impl = std::make_unique<detail::hash_join_impl const>(right, nullable_join::YES, compare_nulls, load_factor, stream,
+                                                                  false);  // semi / anti results cannot be certified pair by pair: exact keys
 }
 std::unique_ptr<rmm::device_uvector<size_type>> filtered_join::semi_join(table_view const& left, rmm::cuda_stream_view stream,
                                                                          rmm::device_async_resource_ref mr) const

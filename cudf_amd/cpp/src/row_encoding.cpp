@@ -4,6 +4,7 @@
 #include <cudf/column/column_factories.hpp>
 #include <cudf/copying.hpp>
 #include <cudf/null_mask.hpp>
+#include <cudf/sorting.hpp>
 
 namespace cudf {
 namespace detail {
@@ -43,6 +44,40 @@ std::unique_ptr<column> pack_columns(std::vector<column_view> const& cols, rmm::
                         out->mutable_view().data<uint64_t>(), gxs(stream)),
            "pack_keys");
   return out;
+}
+
+std::unique_ptr<column> hash_columns(std::vector<column_view> const& cols, rmm::cuda_stream_view stream)
+{
+  CUDF_EXPECTS(!cols.empty() && cols.size() <= 8, "hash_columns: 1 to 8 key columns");
+  auto const n = cols.front().size();
+  auto out     = make_numeric_column(data_type{type_id::UINT64}, n, mask_state::UNALLOCATED, stream);
+  std::vector<void const*> ptrs;
+  std::vector<int> dts;
+  for (auto const& c : cols) {
+    ptrs.push_back(row0(c));
+    dts.push_back(gx_type(c.type()));
+  }
+  gx_check(gx_hash_rows64(static_cast<int>(cols.size()), ptrs.data(), dts.data(), n, 0, out->mutable_view().data<uint64_t>(),
+                          gxs(stream)),
+           "hash_rows64");
+  return out;
+}
+
+int64_t count_row_mismatches(table_view const& left, table_view const& right, size_type const* lidx, size_type const* ridx,
+                             std::size_t npairs, rmm::cuda_stream_view stream)
+{
+  std::vector<void const*> lp, rp;
+  std::vector<int> dts;
+  for (size_type k = 0; k < left.num_columns(); ++k) {
+    lp.push_back(row0(left.column(k)));
+    rp.push_back(row0(right.column(k)));
+    dts.push_back(gx_type(left.column(k).type()));
+  }
+  rmm::device_buffer cnt{sizeof(int64_t), stream};
+  gx_check(gx_rows_mismatch_count(left.num_columns(), lp.data(), rp.data(), dts.data(), lidx, ridx, static_cast<int64_t>(npairs),
+                                  static_cast<int64_t*>(cnt.data()), gxs(stream)),
+           "rows_mismatch_count");
+  return read_i64(static_cast<int64_t const*>(cnt.data()), stream);
 }
 
 dense_rank_result dense_rank(column_view const& col, rmm::cuda_stream_view stream)
@@ -102,6 +137,76 @@ dense_rank_result dense_row_ids(table_view const& keys, rmm::cuda_stream_view st
   return r;
 }
 
+// ------------------------------------------------------------------------------------------ row keys
+row_keys::row_keys(table_view const& keys, rmm::cuda_stream_view stream) : _keys{keys}
+{
+  CUDF_EXPECTS(keys.num_columns() >= 1 && keys.num_columns() <= 8, "row_keys: 1 to 8 key columns");
+  std::size_t width = 0;
+  for (auto const& c : keys) {
+    width += size_of(c.type());
+    _bare.push_back(without_mask(c));
+  }
+  _exact = width <= 8;
+  _col   = _exact ? pack_columns(_bare, stream) : hash_columns(_bare, stream);
+  if (cudf::has_nulls(keys)) {
+    auto [mask, nc] = and_of_masks(keys, stream);
+    _col->set_null_mask(std::move(mask), nc);
+  }
+}
+
+std::unique_ptr<table> row_keys::key_columns(column_view const& distinct, rmm::cuda_stream_view stream,
+                                             rmm::device_async_resource_ref mr) const
+{
+  auto const g = distinct.size();
+  std::vector<std::unique_ptr<column>> out;
+  if (_exact || g == 0) {
+    std::vector<void*> ptrs;
+    std::vector<int> dts;
+    for (auto const& c : _keys) {
+      out.emplace_back(make_fixed_width_column(c.type(), g, mask_state::UNALLOCATED, stream, mr));
+      ptrs.push_back(out.back()->mutable_view().head<void>());
+      dts.push_back(gx_type(c.type()));
+    }
+    if (g > 0)
+      gx_check(gx_unpack_keys(_keys.num_columns(), ptrs.data(), dts.data(), g, distinct.head<uint64_t>() + distinct.offset(),
+                              gxs(stream)),
+               "unpack_keys");
+    return std::make_unique<table>(std::move(out));
+  }
+  // hashed keys: per key column one streaming groupby MIN + MAX by hash.  MIN == MAX in every group and column <=> all
+  // rows of a group carry the same key values (returned as the group's keys) <=> no two different rows shared a hash.
+  auto const* kmask = _col->view().null_mask();
+  auto const n      = _keys.num_rows();
+  std::vector<std::unique_ptr<column>> mns, mxs;
+  rmm::device_buffer ng{sizeof(int64_t), stream};
+  for (auto const& c : _bare) {
+    auto hk = make_numeric_column(data_type{type_id::UINT64}, g, mask_state::UNALLOCATED, stream);
+    auto mn = make_fixed_width_column(c.type(), g, mask_state::UNALLOCATED, stream);
+    auto mx = make_fixed_width_column(c.type(), g, mask_state::UNALLOCATED, stream);
+    run_with_scratch(
+      [&](void* t, std::size_t* b) {
+        return gx_groupby_min_max(GX_UINT64, _col->view().head<void>(), kmask, gx_type(c.type()), row0(c), nullptr, n, g,
+                                  hk->mutable_view().head<void>(), mn->mutable_view().head<void>(), mx->mutable_view().head<void>(),
+                                  nullptr, static_cast<int64_t*>(ng.data()), t, b, gxs(stream));
+      },
+      "row keys: key column", stream);
+    if (read_i64(static_cast<int64_t const*>(ng.data()), stream) != g) return nullptr;
+    auto order = cudf::sorted_order(table_view{{hk->view()}}, {}, {}, stream);  // ascending-hash order
+    auto t     = cudf::gather(table_view{{mn->view(), mx->view()}}, order->view(), out_of_bounds_policy::DONT_CHECK, stream);
+    auto cols  = t->release();
+    mns.emplace_back(std::move(cols[0]));
+    mxs.emplace_back(std::move(cols[1]));
+  }
+  std::vector<column_view> mnv, mxv;
+  for (auto const& c : mns) mnv.push_back(c->view());
+  for (auto const& c : mxs) mxv.push_back(c->view());
+  if (count_row_mismatches(table_view{mnv}, table_view{mxv}, nullptr, nullptr, static_cast<std::size_t>(g), stream) != 0) return nullptr;
+  // ascending-hash position of every entry of `distinct`: the inverse of its sorted order
+  auto order = cudf::sorted_order(table_view{{distinct}}, {}, {}, stream);
+  auto back  = cudf::sorted_order(table_view{{order->view()}}, {}, {}, stream);
+  return cudf::gather(table_view{mnv}, back->view(), out_of_bounds_policy::DONT_CHECK, stream, mr);
+}
+
 // ------------------------------------------------------------------------------------------ encoder
 row_encoder::~row_encoder() = default;
 
@@ -139,7 +244,8 @@ std::unique_ptr<column> row_encoder::lookup(dictionary const& d, column_view con
   return ids;
 }
 
-row_encoder::row_encoder(table_view const& build, bool nulls_equal, rmm::cuda_stream_view stream) : _nulls_equal{nulls_equal}
+row_encoder::row_encoder(table_view const& build, bool nulls_equal, rmm::cuda_stream_view stream, bool allow_hash)
+  : _nulls_equal{nulls_equal}
 {
   std::size_t width = 0;
   for (auto const& c : build) {
@@ -160,6 +266,19 @@ row_encoder::row_encoder(table_view const& build, bool nulls_equal, rmm::cuda_st
       auto const* m = rebased_mask(cols[0], holder, stream);
       _build_keys->set_null_mask(rmm::device_buffer{m, bitmask_allocation_size_bytes(cols[0].size()), stream},
                                  cols[0].null_count());
+    }
+    return;
+  }
+  if (allow_hash && ncols <= 8 && (!nulls || !_nulls_equal)) {
+    // wider rows: the 64-bit row hash is the key (one pass over the columns); rows holding a null match nothing under
+    // null != null and are not inserted.  With null == null and nulls on the build side the exact encoding below runs.
+    _hashed = true;
+    std::vector<column_view> bare;
+    for (auto const& c : cols) bare.push_back(without_mask(c));
+    _build_keys = hash_columns(bare, stream);
+    if (nulls) {
+      auto [mask, nc] = and_of_masks(build, stream);
+      _build_keys->set_null_mask(std::move(mask), nc);
     }
     return;
   }
@@ -199,10 +318,10 @@ std::unique_ptr<column> row_encoder::encode(table_view const& probe, rmm::cuda_s
   std::vector<column_view> cols(probe.begin(), probe.end());
   bool const nulls = cudf::has_nulls(probe);
   std::unique_ptr<column> out;
-  if (_pack_only) {
+  if (_pack_only || _hashed) {
     std::vector<column_view> bare;
     for (auto const& c : cols) bare.push_back(without_mask(c));
-    out = pack_columns(bare, stream);
+    out = _hashed ? hash_columns(bare, stream) : pack_columns(bare, stream);
   } else {
     std::unique_ptr<column> cur;
     for (size_type k = 0; k < ncols; ++k) {
@@ -221,7 +340,7 @@ std::unique_ptr<column> row_encoder::encode(table_view const& probe, rmm::cuda_s
   }
   // validity of the encoded key: a single column keeps its own; several columns: rows holding a null can
   // match nothing when the build side has no nulls (pack-only) or when nulls compare unequal
-  if (nulls && (_pack_only || !_nulls_equal)) {
+  if (nulls && (_pack_only || _hashed || !_nulls_equal)) {  // hashed + null == null: the build side has no nulls
     auto [mask, nc] = and_of_masks(probe, stream);
     out->set_null_mask(std::move(mask), nc);
   }

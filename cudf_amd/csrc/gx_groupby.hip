@@ -405,7 +405,7 @@ __device__ __forceinline__ void global_merge(double* sum, double* comp, int64_t 
 template <typename K, typename V, bool IS_FLOAT, bool HAS_VV>
 __global__ void __launch_bounds__(ABT) k_part_aggregate(const K* __restrict__ pkeys, const V* __restrict__ pvals,
                                                         const uint8_t* __restrict__ pflags, const PartPlan* plan,
-                                                        int nsplit, unsigned long long* table, uint32_t log2cap,
+                                                        int nsplit, int nsub, unsigned long long* table, uint32_t log2cap,
                                                         double* sum, double* comp, uint32_t* cnt_valid,
                                                         uint32_t* cnt_all, GbState* st)
 {
@@ -434,8 +434,11 @@ __global__ void __launch_bounds__(ABT) k_part_aggregate(const K* __restrict__ pk
   }
   __syncthreads();
 
-  const int part  = blockIdx.x / nsplit;
-  const int split = blockIdx.x % nsplit;
+  // nsub > 1: the keys of a partition are dealt to nsub workgroups by hash bits the partition and the LDS slot do
+  // not use; each reads the whole slice and keeps its own keys, so its LDS table sees 1/nsub of the groups
+  const int sub   = (int)(blockIdx.x % (unsigned)nsub);
+  const int part  = (int)(blockIdx.x / (unsigned)nsub) / nsplit;
+  const int split = (int)(blockIdx.x / (unsigned)nsub) % nsplit;
   const unsigned long long p0 = plan->offset[part], p1 = plan->offset[part + 1];
   const unsigned long long len = p1 - p0;
   const unsigned long long per = (len + nsplit - 1) / nsplit;
@@ -461,6 +464,7 @@ __global__ void __launch_bounds__(ABT) k_part_aggregate(const K* __restrict__ pk
       const unsigned long long i = i0 + (unsigned long long)u * ABT;
       if (i >= r1) continue;
       const K key = k[u];
+      if (nsub > 1 && (int)((part_hash<K>(key) >> 16) & (uint64_t)(nsub - 1)) != sub) continue;
       int slot    = -1;
       if (key == EMPTYK) {
         slot      = S;
@@ -527,6 +531,19 @@ static inline uint32_t log2_cap(int64_t max_groups)
   return lg;
 }
 
+// Workgroups per (partition, split) of the LDS aggregation: enough that the groups one LDS table has to hold stay
+// under ~65 % of its slots.  Linear probing with keys that hash like random numbers (row hashes, sparse ids) grows
+// long chains beyond that -- measured at 1e6 groups / 1e9 rows: 3.4 ms for dense integer keys (Fibonacci hashing
+// spreads consecutive integers almost perfectly), 24.5 ms for uniformly random 64-bit keys at 69 % load
+// (profiles/r2_xp_minmax_matrix.txt) -- and beyond 7/8 the rows spill to the global table one by one.
+static inline int lds_nsub(int64_t max_groups, int lds_slots)
+{
+  const double per_part = (double)(max_groups < 1 ? 1 : max_groups) / NPART;
+  int nsub = 1;
+  while (nsub < 16 && per_part / nsub > 0.65 * lds_slots) nsub *= 2;
+  return nsub;
+}
+
 static int g_gb_algorithm = 0;  // 0 auto, 1 global-atomic table only, 2 partitioned whenever possible
 static int g_gb_nsplit    = 1;
 static int g_gb_nrange    = NRANGE;  // 1 = single cursor per partition (A/B measurement)
@@ -535,7 +552,7 @@ constexpr int64_t PART_MIN_ROWS = 1 << 19;
 template <typename K, typename V, bool IS_FLOAT, bool HAS_VV>
 int launch_partitioned(const K* keys, const uint32_t* kvalid, const V* vals, const uint32_t* vvalid, int64_t n,
                        PartPlan* plan, K* pkeys, V* pvals, uint8_t* pflags, unsigned long long* table, uint32_t lg,
-                       double* sum, double* comp, uint32_t* cv, uint32_t* ca, GbState* st, hipStream_t s)
+                       double* sum, double* comp, uint32_t* cv, uint32_t* ca, GbState* st, int64_t max_groups, hipStream_t s)
 {
   GX_HIP_TRY(hipMemsetAsync(plan, 0, sizeof(PartPlan), s));
   int64_t hb = div_up(n, 256 * 8 * 4 * NRANGE);
@@ -558,7 +575,8 @@ int launch_partitioned(const K* keys, const uint32_t* kvalid, const V* vals, con
   hipLaunchKernelGGL(ks, dim3((unsigned)div_up(n, PTILE)), dim3(PBT), lds_s, s, keys, kvalid, vals, vvalid, n, plan,
                      pkeys, pvals, pflags, g_gb_nrange);
   const int nsplit = g_gb_nsplit;
-  hipLaunchKernelGGL(ka, dim3((unsigned)(NPART * nsplit)), dim3(ABT), lds_a, s, pkeys, pvals, pflags, plan, nsplit,
+  const int nsub   = lds_nsub(max_groups, S);
+  hipLaunchKernelGGL(ka, dim3((unsigned)(NPART * nsplit * nsub)), dim3(ABT), lds_a, s, pkeys, pvals, pflags, plan, nsplit, nsub,
                      table, lg, sum, comp, cv, ca, st);
   GX_LAUNCH_CHECK();
   return 0;
@@ -600,11 +618,11 @@ int groupby_impl(const void* keys, const uint32_t* kvalid, const void* vals, con
     if (vvalid)
       rc = launch_partitioned<K, V, IS_FLOAT, true>(static_cast<const K*>(keys), kvalid, static_cast<const V*>(vals),
                                                     vvalid, n, plan, pkeys, pvals, pflags, table, lg, sum, comp, cv,
-                                                    out_ca ? ca : nullptr, st, s);
+                                                    out_ca ? ca : nullptr, st, max_groups, s);
     else
       rc = launch_partitioned<K, V, IS_FLOAT, false>(static_cast<const K*>(keys), kvalid, static_cast<const V*>(vals),
                                                      vvalid, n, plan, pkeys, pvals, pflags, table, lg, sum, comp, cv,
-                                                     out_ca ? ca : nullptr, st, s);
+                                                     out_ca ? ca : nullptr, st, max_groups, s);
     if (rc) return rc;
   } else if (n > 0) {
     int64_t blocks = div_up(n, GBT * 8);
@@ -868,7 +886,7 @@ constexpr int lds_slots_mm()
 
 template <typename K, typename V, bool HAS_VV>
 __global__ void __launch_bounds__(ABT) k_part_minmax(const K* __restrict__ pkeys, const V* __restrict__ pvals,
-                                                     const uint8_t* __restrict__ pflags, const PartPlan* plan, int nsplit,
+                                                     const uint8_t* __restrict__ pflags, const PartPlan* plan, int nsplit, int nsub,
                                                      unsigned long long* table, uint32_t log2cap, unsigned long long* mn,
                                                      unsigned long long* mx, uint32_t* cnt_valid, GbState* st)
 {
@@ -895,8 +913,11 @@ __global__ void __launch_bounds__(ABT) k_part_minmax(const K* __restrict__ pkeys
   }
   __syncthreads();
 
-  const int part  = blockIdx.x / nsplit;
-  const int split = blockIdx.x % nsplit;
+  // nsub > 1: the keys of a partition are dealt to nsub workgroups by hash bits the partition and the LDS slot do
+  // not use; each reads the whole slice and keeps its own keys, so its LDS table sees 1/nsub of the groups
+  const int sub   = (int)(blockIdx.x % (unsigned)nsub);
+  const int part  = (int)(blockIdx.x / (unsigned)nsub) / nsplit;
+  const int split = (int)(blockIdx.x / (unsigned)nsub) % nsplit;
   const unsigned long long p0 = plan->offset[part], p1 = plan->offset[part + 1];
   const unsigned long long len = p1 - p0;
   const unsigned long long per = (len + nsplit - 1) / nsplit;
@@ -922,6 +943,7 @@ __global__ void __launch_bounds__(ABT) k_part_minmax(const K* __restrict__ pkeys
       const unsigned long long i = i0 + (unsigned long long)u * ABT;
       if (i >= r1) continue;
       const K key = k[u];
+      if (nsub > 1 && (int)((part_hash<K>(key) >> 16) & (uint64_t)(nsub - 1)) != sub) continue;
       int slot    = -1;
       if (key == EMPTYK) {
         slot      = S;
@@ -983,7 +1005,7 @@ __global__ void __launch_bounds__(ABT) k_part_minmax(const K* __restrict__ pkeys
 template <typename K, typename V, bool HAS_VV>
 int launch_partitioned_minmax(const K* keys, const uint32_t* kvalid, const V* vals, const uint32_t* vvalid, int64_t n, PartPlan* plan,
                               K* pkeys, V* pvals, uint8_t* pflags, unsigned long long* table, uint32_t lg, unsigned long long* mn,
-                              unsigned long long* mx, uint32_t* cv, GbState* st, hipStream_t s)
+                              unsigned long long* mx, uint32_t* cv, GbState* st, int64_t max_groups, hipStream_t s)
 {
   GX_HIP_TRY(hipMemsetAsync(plan, 0, sizeof(PartPlan), s));
   int64_t hb = div_up(n, 256 * 8 * 4 * NRANGE);
@@ -1006,8 +1028,9 @@ int launch_partitioned_minmax(const K* keys, const uint32_t* kvalid, const V* va
   hipLaunchKernelGGL(ks, dim3((unsigned)div_up(n, PTILE)), dim3(PBT), lds_s, s, keys, kvalid, vals, vvalid, n, plan, pkeys, pvals,
                      pflags, g_gb_nrange);
   const int nsplit = g_gb_nsplit;
-  hipLaunchKernelGGL(ka, dim3((unsigned)(NPART * nsplit)), dim3(ABT), lds_a, s, pkeys, pvals, pflags, plan, nsplit, table, lg, mn, mx,
-                     cv, st);
+  const int nsub   = lds_nsub(max_groups, S);
+  hipLaunchKernelGGL(ka, dim3((unsigned)(NPART * nsplit * nsub)), dim3(ABT), lds_a, s, pkeys, pvals, pflags, plan, nsplit, nsub, table,
+                     lg, mn, mx, cv, st);
   GX_LAUNCH_CHECK();
   return 0;
 }
@@ -1045,10 +1068,10 @@ int minmax_impl(const void* keys, const uint32_t* kvalid, const void* vals, cons
     int prc;
     if (vvalid)
       prc = launch_partitioned_minmax<K, V, true>(static_cast<const K*>(keys), kvalid, static_cast<const V*>(vals), vvalid, n, plan,
-                                                  pkeys, pvals, pflags, table, lg, mn, mx, cv, st, s);
+                                                  pkeys, pvals, pflags, table, lg, mn, mx, cv, st, max_groups, s);
     else
       prc = launch_partitioned_minmax<K, V, false>(static_cast<const K*>(keys), kvalid, static_cast<const V*>(vals), vvalid, n, plan,
-                                                   pkeys, pvals, pflags, table, lg, mn, mx, cv, st, s);
+                                                   pkeys, pvals, pflags, table, lg, mn, mx, cv, st, max_groups, s);
     if (prc) return prc;
   } else if (n > 0) {
     int64_t blocks = div_up(n, GBT * 8);

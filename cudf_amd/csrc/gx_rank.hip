@@ -125,6 +125,30 @@ static inline unsigned grid_for(int64_t n)
 }
 
 
+// inverse of k_pack: column k of row i = bits [shift_k, shift_k + 8 size_k) of packed[i]
+struct UnpackCols {
+  void* p[8];
+  int size[8];
+  int shift[8];
+  int ncols;
+};
+__global__ void __launch_bounds__(256) k_unpack(UnpackCols c, int64_t n, const uint64_t* __restrict__ packed)
+{
+  const int64_t stride = (int64_t)gridDim.x * 256;
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += stride) {
+    const uint64_t v = packed[i];
+    for (int k = 0; k < c.ncols; ++k) {
+      const uint64_t b = v >> c.shift[k];
+      switch (c.size[k]) {
+        case 1: static_cast<uint8_t*>(c.p[k])[i] = (uint8_t)b; break;
+        case 2: static_cast<uint16_t*>(c.p[k])[i] = (uint16_t)b; break;
+        case 4: static_cast<uint32_t*>(c.p[k])[i] = (uint32_t)b; break;
+        default: static_cast<uint64_t*>(c.p[k])[i] = b; break;
+      }
+    }
+  }
+}
+
 // ---- hashed row keys: rows wider than 8 bytes get a 64-bit hash as their join / groupby key, and the result is
 // VERIFIED against the real columns afterwards (k_rows_mismatch): equal rows always hash equal, so a verified result
 // is exact, and the caller falls back to the dense-rank encoding in the (2^-64 per pair) case of a collision.
@@ -175,24 +199,6 @@ __global__ void __launch_bounds__(256) k_rows_mismatch(PackCols l, PackCols r, c
   bad = wave_reduce(bad, SumOp());
   if (lane_id() == 0 && bad) atomicAdd(count, bad);
 }
-__global__ void __launch_bounds__(256) k_fill_i32(int32_t* __restrict__ out, int64_t n, int32_t v)
-{
-  const int64_t stride = (int64_t)gridDim.x * 256;
-  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += stride) out[i] = v;
-}
-// rep[id] = the smallest row carrying that id (rows whose validity bit is clear, or whose id is negative, carry none)
-__global__ void __launch_bounds__(256) k_first_row(const int32_t* __restrict__ ids, const uint32_t* __restrict__ valid, int64_t n,
-                                                   int64_t nids, int32_t* __restrict__ rep)
-{
-  const int64_t stride = (int64_t)gridDim.x * 256;
-  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += stride) {
-    if (valid && !bit_is_set(valid, i)) continue;
-    const int32_t id = ids[i];
-    if (id < 0 || (int64_t)id >= nids) continue;
-    if (rep[id] > (int32_t)i) atomicMin(&rep[id], (int32_t)i);
-  }
-}
-
 static inline int fill_cols(PackCols& c, int ncols, const void* const* cols, const int* dtypes, int64_t n)
 {
   std::memset(&c, 0, sizeof(c));
@@ -237,6 +243,29 @@ int gx_pack_keys(int ncols, const void* const* cols, const int* dtypes, int64_t 
   return 0;
 }
 
+int gx_unpack_keys(int ncols, void* const* out_cols, const int* dtypes, int64_t n, const uint64_t* packed, gx_stream_t s)
+{
+  if (ncols < 1 || ncols > 8 || !out_cols || !dtypes || n < 0 || (n > 0 && !packed)) return GX_EINVAL;
+  gx::rank::UnpackCols c;
+  std::memset(&c, 0, sizeof(c));
+  int bits = 0;
+  for (int k = ncols - 1; k >= 0; --k) {  // the layout of gx_pack_keys: first column most significant
+    const int sz = gx_dtype_size(dtypes[k]);
+    if (sz <= 0) return GX_EDTYPE;
+    if (n > 0 && !out_cols[k]) return GX_EINVAL;
+    c.p[k]     = out_cols[k];
+    c.size[k]  = sz;
+    c.shift[k] = bits;
+    bits += sz * 8;
+  }
+  if (bits > 64) return GX_EINVAL;
+  c.ncols = ncols;
+  if (n == 0) return 0;
+  hipLaunchKernelGGL(gx::rank::k_unpack, dim3(gx::rank::grid_for(n)), dim3(256), 0, s, c, n, packed);
+  GX_LAUNCH_CHECK();
+  return 0;
+}
+
 int gx_hash_rows64(int ncols, const void* const* cols, const int* dtypes, int64_t n, uint64_t seed, uint64_t* out, gx_stream_t s)
 {
   if (ncols < 1 || ncols > 8 || !cols || !dtypes || n < 0 || (n > 0 && !out)) return GX_EINVAL;
@@ -259,16 +288,6 @@ int gx_rows_mismatch_count(int ncols, const void* const* lcols, const void* cons
   if (npairs == 0) return 0;
   hipLaunchKernelGGL(gx::rank::k_rows_mismatch, dim3(gx::rank::grid_for(npairs)), dim3(256), 0, s, l, r, lidx, ridx, npairs,
                      reinterpret_cast<unsigned long long*>(mismatch_dev));
-  GX_LAUNCH_CHECK();
-  return 0;
-}
-
-int gx_first_row_of_id(const int32_t* ids, const uint32_t* valid, int64_t n, int64_t nids, int32_t* out_rep, gx_stream_t s)
-{
-  if (n < 0 || nids < 0 || (n > 0 && !ids) || (nids > 0 && !out_rep)) return GX_EINVAL;
-  if (nids == 0) return 0;
-  hipLaunchKernelGGL(gx::rank::k_fill_i32, dim3(gx::rank::grid_for(nids)), dim3(256), 0, s, out_rep, nids, INT32_MAX);
-  if (n > 0) hipLaunchKernelGGL(gx::rank::k_first_row, dim3(gx::rank::grid_for(n)), dim3(256), 0, s, ids, valid, n, nids, out_rep);
   GX_LAUNCH_CHECK();
   return 0;
 }

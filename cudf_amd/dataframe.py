@@ -11,9 +11,13 @@ from __future__ import annotations
 from typing import Dict, List, Optional, Sequence, Union
 
 import numpy as np
+import torch
 
+from . import _lib as L
 from . import ops
-from .column import Column
+from .column import Column, bitmask_words, ptr, stream_ptr
+
+_lib = L.lib
 
 
 class DataFrame:
@@ -125,22 +129,47 @@ class DataFrame:
         return GroupBy(self, by)
 
 
+def _valid_from_counts(counts: Column):
+    """(validity words, null count) of per-group results from COUNT_VALID: a group without a valid value is null
+    (src/groupby/hash/output_utils.cu:68-70); None when every group has one"""
+    n = counts.size
+    words = torch.zeros(bitmask_words(n), dtype=torch.int32, device="cuda")
+    nulls = torch.zeros(1, dtype=torch.int64, device="cuda")
+    L.check(_lib.gx_valid_from_counts(counts.data_ptr, n, ptr(words), ptr(nulls), stream_ptr()), "gx_valid_from_counts")
+    k = int(nulls.item())
+    return (words, k) if k else (None, 0)
+
+
+def _lexicographic_order(cols: Sequence[Column]) -> Column:
+    """stable order of the rows by (cols[0], cols[1], ...): LSD over the columns with the stable radix argsort"""
+    order = None
+    for c in reversed(list(cols)):
+        if order is None:
+            order = ops.sorted_order(c)
+        else:
+            order = ops.gather(order, ops.sorted_order(ops.gather(c, order)))
+    return order
+
+
 class GroupBy:
     _SUPPORTED = ("sum", "count", "mean", "min", "max", "var", "std")
 
     def __init__(self, df: DataFrame, by: Union[str, Sequence[str]]):
         self._df, self._by = df, ([by] if isinstance(by, str) else list(by))
 
-    def agg(self, spec: Dict[str, Union[str, Sequence[str]]]) -> DataFrame:
+    def agg(self, spec: Dict[str, Union[str, Sequence[str]]], _exact: bool = False) -> DataFrame:
         """{value column: "sum" | "count" | "mean" | "min" | "max" | "var" | "std" | [..]} -> one row per group, sorted by key
         (pandas' default sort=True).  Null keys are dropped (dropna=True), null values are skipped."""
         by = self._by
         k0 = self._df[by[0]]
-        rep = None
+        rep = rk = None
         if len(by) == 1 and k0.dtype.kind in "iu" and k0.dtype.itemsize in (4, 8):
             keys = k0
-        else:  # several key columns / floats / narrow types: dense row ids, ascending in key order
+        elif _exact or len(by) > 8:  # exact encoding: dense row ids, one radix sort per key column
             keys, rep, _ = ops.groupby_keys_tables([self._df[b] for b in by])
+        else:  # several key columns / floats / narrow types: one 8-byte row key (packed values or row hash)
+            rk = ops.RowKeys([self._df[b] for b in by])
+            keys = rk.col
         out = DataFrame()
         first = True
         for name, fns in spec.items():
@@ -152,7 +181,13 @@ class GroupBy:
             order = ops.sorted_order(k)
             if first:
                 kk = ops.gather(k, order)
-                if rep is None:
+                if rk is not None:
+                    kc = rk.key_columns(kk)
+                    if kc is None:  # two different rows shared a 64-bit hash: start over with the exact encoding
+                        return self.agg(spec, _exact=True)
+                    for b, c in zip(by, kc):
+                        out._cols[b] = c
+                elif rep is None:
                     out._cols[by[0]] = kk
                 else:
                     rows = ops.gather(rep, kk)
@@ -164,9 +199,9 @@ class GroupBy:
             if any(f in ("min", "max") for f in fns):
                 k2, mn, mx, cv2 = ops.groupby_min_max(keys, self._df[name])
                 o2 = ops.sorted_order(k2)
-                valid = ops.gather(cv2, o2).to_numpy() > 0
-                mn = Column.from_numpy(ops.gather(mn, o2).to_numpy(), valid)
-                mx = Column.from_numpy(ops.gather(mx, o2).to_numpy(), valid)
+                mn, mx, cv2 = ops.gather(mn, o2), ops.gather(mx, o2), ops.gather(cv2, o2)
+                mn.mask, mn.null_count = _valid_from_counts(cv2)    # a group without a valid value is null
+                mx.mask, mx.null_count = mn.mask, mn.null_count
             var = std = None
             if any(f in ("var", "std") for f in fns):  # ddof = 1, groups come back in ascending key order
                 _, var, std, _, _ = ops.groupby_var_std(keys, self._df[name])
@@ -184,9 +219,14 @@ class GroupBy:
                     out._cols[label] = var
                 elif f == "std":
                     out._cols[label] = std
-                else:
-                    sn, cn = s.to_numpy().astype(np.float64), cv.to_numpy()
-                    with np.errstate(divide="ignore", invalid="ignore"):
-                        m = sn / cn
-                    out._cols[label] = Column.from_numpy(np.where(cn > 0, m, 0.0), cn > 0)
+                else:  # MEAN = SUM / COUNT_VALID in double, on the device (hash_compound_agg_finalizer.cu:92-133)
+                    m = Column.empty(np.float64, s.size)
+                    L.check(_lib.gx_mean_from_sum(s.gx, s.data_ptr, cv.data_ptr, s.size, m.data_ptr, stream_ptr()), "gx_mean_from_sum")
+                    m.mask, m.null_count = _valid_from_counts(cv)
+                    out._cols[label] = m
+        if (rep is not None or rk is not None) and len(out._cols):
+            # results are in row-key order, pandas sorts by the key columns: order the (few) groups once
+            perm = _lexicographic_order([out._cols[b] for b in by])
+            for name in list(out._cols):
+                out._cols[name] = ops.gather(out._cols[name], perm)
         return out

@@ -396,6 +396,74 @@ def pack_keys(cols: Sequence[Column]) -> Column:
     return out
 
 
+def _col_ptrs(cols: Sequence[Column]):
+    return ((ctypes.c_void_p * len(cols))(*[c.data_ptr.value or 0 for c in cols]), (ctypes.c_int * len(cols))(*[c.gx for c in cols]))
+
+
+def hash_rows64(cols: Sequence[Column], seed: int = 0) -> Column:
+    """One uint64 hash per row of the key columns (floats normalised: -0.0 == +0.0, NaN == NaN).  Equal rows hash
+    equal; a result obtained through the hashes is certified by rows_mismatch_count == 0."""
+    n = cols[0].size
+    out = Column.empty(np.uint64, n)
+    ptrs, dts = _col_ptrs(cols)
+    L.check(_lib.gx_hash_rows64(len(cols), ptrs, dts, n, seed, out.data_ptr, stream_ptr()), "gx_hash_rows64")
+    return out
+
+
+def rows_mismatch_count(lcols: Sequence[Column], rcols: Sequence[Column], lidx: Optional[Column], ridx: Optional[Column],
+                        npairs: int) -> int:
+    """Number of pairs (lidx[i], ridx[i]) -- None = row i, negative = no row -- whose rows differ in some column."""
+    lp, dts = _col_ptrs(lcols)
+    rp, _ = _col_ptrs(rcols)
+    cnt = _dev_i64()
+    L.check(_lib.gx_rows_mismatch_count(len(lcols), lp, rp, dts, lidx.data_ptr if lidx is not None else None,
+                                        ridx.data_ptr if ridx is not None else None, npairs, ptr(cnt), stream_ptr()),
+            "gx_rows_mismatch_count")
+    return int(cnt.item())
+
+
+class RowKeys:
+    """ONE 8-byte key per row of a multi-column key table, for the single-key groupby kernels, without sorting:
+    the packed column values when their widths sum to <= 8 bytes (exact), else a 64-bit row hash.  Rows holding a
+    null key get a null key (they belong to no group: null_policy::EXCLUDE).  key_columns() turns the distinct keys
+    of a result back into key columns and -- for hashed keys -- certifies that no two different rows shared a hash."""
+
+    def __init__(self, cols: Sequence[Column]):
+        self.cols = list(cols)
+        n = self.cols[0].size
+        self.bare = [Column(c.data, c.dtype, c.size) for c in self.cols]
+        self.exact = sum(c.dtype.itemsize for c in self.cols) <= 8
+        self.col = pack_keys(self.bare) if self.exact else hash_rows64(self.bare)
+        self.col.mask, self.col.null_count = _and_masks(self.cols, n)
+
+    def key_columns(self, distinct: Column) -> Optional[List[Column]]:
+        """Key columns of the groups whose row keys are `distinct` (in that order).  Packed keys are unpacked.  Hashed
+        keys: per key column one streaming groupby MIN + MAX by hash; MIN == MAX in every group and column means every
+        row of a group carries the same key values (the values returned), i.e. no 64-bit collision; None otherwise
+        (the caller then encodes through gx_dense_rank)."""
+        g = distinct.size
+        if self.exact:
+            outs = [Column.empty(c.dtype, g) for c in self.cols]
+            ptrs = (ctypes.c_void_p * len(outs))(*[c.data_ptr.value or 0 for c in outs])
+            dts = (ctypes.c_int * len(outs))(*[c.gx for c in outs])
+            L.check(_lib.gx_unpack_keys(len(outs), ptrs, dts, g, distinct.data_ptr, stream_ptr()), "gx_unpack_keys")
+            return outs
+        if g == 0:
+            return [Column.empty(c.dtype, 0) for c in self.cols]
+        mns, mxs = [], []
+        for c in self.bare:
+            hk, mn, mx, _ = groupby_min_max(self.col, c, max_groups_hint=g)
+            if hk.size != g:
+                return None
+            o = sorted_order(hk)                                   # ascending-hash order
+            mns.append(gather(mn, o))
+            mxs.append(gather(mx, o))
+        if rows_mismatch_count(mns, mxs, None, None, g) != 0:
+            return None
+        back = sorted_order(sorted_order(distinct))                # ascending-hash position of every entry of `distinct`
+        return [gather(m, back) for m in mns]
+
+
 def dense_rank(col: Column):
     """(ids int32 column, first row of every id, number of ids): equal values share an id, null == null
     has its own id (last), ids ascend with the value."""
@@ -514,10 +582,40 @@ def encode_rows(tables: Sequence[Sequence[Column]], nulls_equal: bool = True, de
     return outs
 
 
+def _hashed_join(left: Sequence[Column], right: Sequence[Column], nulls_equal: bool, join):
+    """Rows wider than 8 bytes: join on a 64-bit row hash (one pass over the key columns per side), then compare the
+    real columns of every emitted pair.  Equal rows always hash equal, so no pair is missing; a pair that fails the
+    comparison is a 64-bit collision and sends the call to the exact encoding (None).  With nulls the fast path
+    needs null != null (a row holding a null matches nothing: its hash is marked null)."""
+    if len(left) != len(right):
+        raise ValueError("Mismatch in number of columns to be joined on")
+    for a, b in zip(left, right):
+        if a.dtype != b.dtype:
+            raise TypeError("Mismatch in joining column data types")
+    width = sum(c.dtype.itemsize for c in left)
+    any_nulls = any(c.has_nulls() for c in list(left) + list(right))
+    if width <= 8 or (any_nulls and nulls_equal):
+        return None
+    keys = []
+    for t in (left, right):
+        bare = [Column(c.data, c.dtype, c.size) for c in t]
+        k = hash_rows64(bare)
+        k.mask, k.null_count = _and_masks(t, t[0].size)
+        keys.append((k, bare))
+    (lk, lbare), (rk, rbare) = keys
+    l, r = join(lk, rk, False)
+    if rows_mismatch_count(lbare, rbare, l, r, l.size) != 0:
+        return None
+    return l, r
+
+
 def inner_join_tables(left: Sequence[Column], right: Sequence[Column], nulls_equal: bool = True):
     """cudf::inner_join on key TABLES (join.hpp:160-166): rows are encoded, then the single-key join."""
     if len(left) == 1 and len(right) == 1:
         return inner_join(left[0], right[0], nulls_equal)
+    res = _hashed_join(left, right, nulls_equal, inner_join)
+    if res is not None:
+        return res
     lk, rk = encode_rows([left, right], nulls_equal)
     return inner_join(lk, rk, nulls_equal)
 
@@ -525,13 +623,17 @@ def inner_join_tables(left: Sequence[Column], right: Sequence[Column], nulls_equ
 def left_join_tables(left: Sequence[Column], right: Sequence[Column], nulls_equal: bool = True):
     if len(left) == 1 and len(right) == 1:
         return left_join(left[0], right[0], nulls_equal)
+    res = _hashed_join(left, right, nulls_equal, left_join)
+    if res is not None:
+        return res
     lk, rk = encode_rows([left, right], nulls_equal)
     return left_join(lk, rk, nulls_equal)
 
 
 def groupby_keys_tables(keys: Sequence[Column]):
-    """Multi-column groupby keys -> (dense int32 id column with the rows holding a null key marked
-    null, first row of every id, number of ids): aggregate by id, gather the key columns by first row."""
+    """Multi-column groupby keys, exact encoding -> (dense int32 id column with the rows holding a null key marked
+    null, first row of every id, number of ids): aggregate by id, gather the key columns by first row.  One radix
+    sort per key column (gx_dense_rank); the operators use RowKeys (one hash pass) and come here on a collision."""
     ids, rep, g = encode_rows([keys], nulls_equal=False, dense=True)
     return ids, rep, g
 
@@ -570,15 +672,22 @@ def groupby_sum_count(keys: Column, values: Column, max_groups_hint: int = 1 << 
     return ok, osum, ocv, oca
 
 
-def groupby_sum_count_tables(keys: Sequence[Column], values: Column):
-    """groupby(keys = several columns).agg(SUM, COUNT_VALID, COUNT_ALL): rows -> dense ids
-    (gx_dense_rank), aggregate by id, gather the key columns by the first row of every id.
-    Returns ([key columns], sum, count_valid, count_all); rows with a null in any key are dropped."""
+def groupby_sum_count_tables(keys: Sequence[Column], values: Column, exact: bool = False):
+    """groupby(keys = several columns).agg(SUM, COUNT_VALID, COUNT_ALL): the rows' 8-byte keys (RowKeys: packed values
+    or row hash) go through the single-key hash groupby; the key columns come back from the distinct keys.
+    exact=True, or a 64-bit collision: dense ids (gx_dense_rank), aggregate by id, gather the key columns by the
+    first row of every id.  Returns ([key columns], sum, count_valid, count_all); rows with a null in any key are dropped."""
     if len(keys) == 1 and keys[0].dtype.itemsize in (4, 8) and keys[0].dtype.kind in "iu":
         k, s, cv, ca = groupby_sum_count(keys[0], values)
         return [k], s, cv, ca
     if keys[0].size != values.size:
         raise RuntimeError("Size mismatch between request values and groupby keys.")
+    if not exact and len(keys) <= 8:
+        rk = RowKeys(keys)
+        hk, s, cv, ca = groupby_sum_count(rk.col, values)
+        kc = rk.key_columns(hk)
+        if kc is not None:
+            return kc, s, cv, ca
     ids, rep, g = groupby_keys_tables(keys)
     ok, s, cv, ca = groupby_sum_count(ids, values, max_groups_hint=max(g, 1))
     rows = gather(rep, ok)  # id -> its first row

@@ -95,6 +95,10 @@ class groupby {
 
   std::pair<std::unique_ptr<table>, std::vector<aggregation_result>> sort_aggregate(
     std::span<aggregation_request const> requests, rmm::cuda_stream_view stream, rmm::device_async_resource_ref mr);
+  // exact_keys: encode multi-column keys through dense ranks instead of 8-byte row keys (the retry after a hash collision)
+  std::pair<std::unique_ptr<table>, std::vector<aggregation_result>> aggregate_impl(
+    std::span<aggregation_request const> requests, bool exact_keys, rmm::cuda_stream_view stream,
+    rmm::device_async_resource_ref mr);
 };
 
 }  // namespace groupby

@@ -208,6 +208,10 @@ int gx_hash_partition_map(const uint32_t* row_hash, int64_t n, int num_partition
  * ------------------------------------------------------------------------------------------ */
 int gx_pack_keys(int ncols, const void* const* cols, const int* dtypes, int64_t n, uint64_t* out,
                  gx_stream_t stream);
+/* gx_unpack_keys: the inverse of gx_pack_keys -- out_cols[k][i] = column k of packed[i] (float columns come back
+ * normalised: +0.0 for either zero, one NaN).  Turns the distinct packed keys of a groupby back into key columns. */
+int gx_unpack_keys(int ncols, void* const* out_cols, const int* dtypes, int64_t n, const uint64_t* packed,
+                   gx_stream_t stream);
 /* Rows wider than 8 bytes: hash-and-verify.  gx_hash_rows64: out[i] = a 64-bit hash of the ncols (<= 8) column
  *   values of row i (floats normalised as in gx_pack_keys; equal rows hash equal); the single-key join / groupby
  *   kernels then run on the hashes, one pass over the key columns instead of one radix sort per column -- the
@@ -215,16 +219,12 @@ int gx_pack_keys(int ncols, const void* const* cols, const int* dtypes, int64_t 
  * gx_rows_mismatch_count: *mismatch_dev = the number of pairs (lidx[i], ridx[i]) -- NULL index array = row i
  *   itself, a negative index = no row, skipped -- whose rows differ in some column (the row equality the reference
  *   evaluates inside its probe, primitive_row_operators.cuh:95-163).  0 certifies a result obtained through the
- *   hashes as exact; otherwise (a 64-bit collision) the caller re-runs through gx_dense_rank.
- * gx_first_row_of_id: out_rep[g] = the smallest row i with ids[i] == g (rows whose validity bit is clear or whose
- *   id is outside [0, nids) carry none; an id no row carries gets INT32_MAX). */
+ *   hashes as exact; otherwise (a 64-bit collision) the caller re-runs through gx_dense_rank. */
 int gx_hash_rows64(int ncols, const void* const* cols, const int* dtypes, int64_t n, uint64_t seed, uint64_t* out,
                    gx_stream_t stream);
 int gx_rows_mismatch_count(int ncols, const void* const* lcols, const void* const* rcols, const int* dtypes,
                            const int32_t* lidx, const int32_t* ridx, int64_t npairs, int64_t* mismatch_dev,
                            gx_stream_t stream);
-int gx_first_row_of_id(const int32_t* ids, const uint32_t* valid, int64_t n, int64_t nids, int32_t* out_rep,
-                       gx_stream_t stream);
 int gx_dense_rank(int dtype, const void* keys, const uint32_t* valid, int64_t n, int64_t null_count,
                   int32_t* out_ids, int32_t* out_rep, int64_t* out_ngroups_dev, void* tmp,
                   size_t* tmp_bytes, gx_stream_t stream);

@@ -296,6 +296,67 @@ def test_multi_column_groupby(gx, schema, nulls):
     assert got == {k: tuple(v) for k, v in exp.items()}
 
 
+def test_hashed_row_keys_large_and_collision_fallback(gx, monkeypatch):
+    """Rows wider than 8 bytes are keyed by a 64-bit row hash and the result is certified against the key columns
+    (gx_hash_rows64 / gx_rows_mismatch_count).  (1) 2 x int64 keys at a few million rows against the oracle, join
+    and groupby; (2) the certificate: equal tables have no mismatch, a perturbed row is counted; (3) a reported
+    mismatch (a 64-bit collision, simulated) sends both operators down the exact dense-rank path: same answers."""
+    Column, ops = gx
+    rng = np.random.default_rng(77)
+    nl, nr = 3_000_017, 400_003
+    ra = rng.integers(-2**62, 2**62, nr, dtype=np.int64)
+    rb = rng.integers(0, 5, nr).astype(np.int64)
+    pick = rng.integers(0, nr, nl)
+    la, lb = ra[pick].copy(), rb[pick].copy()
+    miss = rng.random(nl) < 0.6
+    lb[miss] += 7                                            # same first column, different second: no match
+    L = [Column.from_numpy(la), Column.from_numpy(lb)]
+    R = [Column.from_numpy(ra), Column.from_numpy(rb)]
+    el, er = orc.inner_join([la, lb], [ra, rb], [None, None], [None, None], True)
+
+    def check_join():
+        l, r = ops.inner_join_tables(L, R)
+        gl, gr = orc.canonical_pairs(l.to_numpy(), r.to_numpy())
+        np.testing.assert_array_equal(gl, el)
+        np.testing.assert_array_equal(gr, er)
+        l, r = ops.left_join_tables(L, R)
+        assert l.size == len(el) + int(np.count_nonzero(~np.isin(np.arange(nl), el)))
+
+    def check_groupby():
+        vals = rng.integers(-1000, 1000, nl).astype(np.int64)
+        keys, s, cv, _ = ops.groupby_sum_count_tables(L, Column.from_numpy(vals))
+        ka, kb = keys[0].to_numpy(), keys[1].to_numpy()
+        o = np.lexsort((kb, ka))
+        packed = np.stack([la, lb], 1)
+        uk, inv = np.unique(packed, axis=0, return_inverse=True)
+        es = np.zeros(len(uk), np.int64)
+        np.add.at(es, inv.ravel(), vals)
+        np.testing.assert_array_equal(np.stack([ka[o], kb[o]], 1), uk)
+        np.testing.assert_array_equal(s.to_numpy()[o], es)
+        np.testing.assert_array_equal(cv.to_numpy()[o], np.bincount(inv.ravel(), minlength=len(uk)))
+
+    check_join()
+    check_groupby()
+    # (2) the certificate itself
+    iota = Column.from_numpy(np.arange(nr, dtype=np.int32))
+    assert ops.rows_mismatch_count(R, R, None, iota, nr) == 0
+    rb2 = rb.copy()
+    rb2[[5, 77, nr - 1]] += 1
+    assert ops.rows_mismatch_count(R, [R[0], Column.from_numpy(rb2)], None, None, nr) == 3
+    skip = np.arange(nr, dtype=np.int32)
+    skip[5] = -1                                             # a negative index = no row: not compared
+    assert ops.rows_mismatch_count(R, [R[0], Column.from_numpy(rb2)], None, Column.from_numpy(skip), nr) == 2
+    h1, h2 = ops.hash_rows64(R).to_numpy(), ops.hash_rows64([R[0], Column.from_numpy(rb2)]).to_numpy()
+    assert np.count_nonzero(h1 != h2) == 3 and len(np.unique(h1)) >= len(np.unique(np.stack([ra, rb], 1), axis=0)) - 1
+    # (3) simulated collision: the exact path must take over
+    calls = []
+    real = ops.rows_mismatch_count
+    monkeypatch.setattr(ops, "rows_mismatch_count", lambda *a: (calls.append(1), real(*a) + 1)[1])
+    check_join()
+    check_groupby()
+    assert len(calls) >= 3
+
+
 # ------------------------------------------------------------------------------------------------
 # compound groupby aggregations: VARIANCE / STD / M2, ARGMIN / ARGMAX
 # ------------------------------------------------------------------------------------------------
