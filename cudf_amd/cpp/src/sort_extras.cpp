@@ -1,6 +1,6 @@
 // cudf::rank, cudf::top_k / top_k_order and the segmented sorts over the C ABI: all of them are a sorted_order plus one
 // streaming kernel (group boundaries in sorted order, rank scatter, segment ids).
-// reference: cpp/src/sort/rank.cu:60-380, cpp/src/sort/top_k.cu:118-165, cpp/src/sort/segmented_sort_impl.cuh:178-330.
+// reference: cpp/src/sort/rank.cu:59-369, cpp/src/sort/top_k.cu:118-165, cpp/src/sort/segmented_sort_impl.cuh:152-324.
 #include "common.hpp"
 
 #include <cudf/column/column_factories.hpp>
