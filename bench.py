@@ -242,11 +242,12 @@ def pmc_traffic(roofline, n):
     for name in ("r2_pmc_traffic_1e9.json", "r1_pmc_traffic_1e9.json"):
         try:
             tr = json.load(open(os.path.join(ROOT, "profiles", name)))
-            for key, v in tr["kernels"].items():
-                if roofline["kernel"].startswith(key):
-                    roofline["traffic"] = v["hbm_bytes_per_launch"]
-                    roofline["traffic_source"] = tr["source"] + "; " + tr["correction"]
-                    return
+            hits = [k for k in tr["kernels"] if roofline["kernel"].startswith(k)]
+            if hits:
+                key = max(hits, key=len)  # "k_part_hist + k_part_scatter + ..." over "k_part_hist"
+                roofline["traffic"] = tr["kernels"][key]["hbm_bytes_per_launch"]
+                roofline["traffic_source"] = tr["source"] + "; " + tr["correction"]
+                return
         except (OSError, KeyError, ValueError):
             pass
 
@@ -478,6 +479,7 @@ def bench_join(c):
                                        "frac": kb[dom] / (ms[dom] * 1e-3) / 1e9 / HBM_PEAK_GBS}
         roofline["path_bytes"] = sum(kb)
         roofline["path_GBps"] = sum(kb) / (ms_per_step * 1e-3) / 1e9
+    pmc_traffic(roofline, n)
     cpu = None
     if a.cpu and c.rank == 0:
         cpu = cpu_baseline_join(a.cpu_rows or 1e8, a.cpu_rows_pandas)
@@ -545,6 +547,7 @@ def bench_groupby(c):
                 "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS, "traffic": None,
                 "algorithmic_bytes_per_launch": 12 * n, "avg_launch_ms": ms_per_step, "groups": groups,
                 "model": "12 B/row (4-B key + 8-B value read once; SURVEY.md 8d)"}
+    pmc_traffic(roofline, n)
     cpu = None
     if a.cpu and c.rank == 0:
         cpu = cpu_baseline_groupby(a.cpu_rows or 3e8, a.cpu_rows_pandas)
