@@ -31,8 +31,9 @@ constexpr int NRANGE     = 8;    // input ranges == XCDs: each gets its own look
 
 // Hybrid MSD sort (64-bit keys, n >= 2^22): two MSD partition passes bring every cell (= keys sharing
 // all bits above shift2) down to at most one LDS-resident cell, then ONE kernel sorts each cell on all
-// remaining bits inside LDS.  HBM traffic: 8 (histogram) + 16 + 8 (joint histogram) + 16 + 16 = 64 B/row
-// instead of 8 + 8 x 16 = 136 B/row for the 8-pass LSD.
+// remaining bits inside LDS.  HBM traffic: 8 (mask + histogram) + 16 + 16 + 16 = 56 B/row instead of
+// 8 + 8 x 16 = 136 B/row for the 8-pass LSD (round 1 also read the bucketed keys once more for a joint
+// bucket x digit histogram; level 1 now writes into padded cell slots and needs none).
 //   * digits are BIT granular: an up-front pass reduces the OR of the keys and the OR of their complements
 //     (a bit varies iff it is set in both) next to a speculative histogram of the top byte; level 0 takes the
 //     8 bits below the highest varying bit, so keys confined to a range that is not byte aligned (a rank's
@@ -40,8 +41,9 @@ constexpr int NRANGE     = 8;    // input ranges == XCDs: each gets its own look
 //   * level 1 takes the next `bits2` <= 9 bits.  Keys-only sorts use cells of <= 8192 keys (64 KiB): two
 //     local-sort workgroups share a CU, so one cell's loads and stores overlap the other's LDS work;
 //     pairs / larger n use 16384-key cells (one workgroup per CU), the round-1 configuration.
-// Whether every cell fits is decided ON THE DEVICE after the joint histogram (k_plan2); when one does not
-// (skewed keys) the hybrid kernels turn into no-ops and the LSD passes below run instead.
+// Whether every cell fits is decided ON THE DEVICE (level 1 raises hy.overflow when a cell outgrows its slot,
+// k_plan2 checks the cell counts); when one does not (skewed keys) the remaining hybrid kernels turn into
+// no-ops and the LSD passes below run instead.
 constexpr int NB2MAX     = 512;  // level-1 bins (<= 9 bits)
 
 struct HybridPlan {
@@ -667,7 +669,7 @@ struct MsdArgs {
   uint32_t cellcap;            // level 1: every cell owns a slot of this many keys in the output buffer
   int64_t n;
   int level;
-  int exp;  // experiment bits (GX_EXP environment variable)
+  int exp;  // experiment bits (A/B knob of the XCD placement; 0 in production)
   uint64_t desc_mask;
 };
 
@@ -675,7 +677,8 @@ struct MsdArgs {
 // LDS reorder, decoupled look-back, coalesced write-out) over SEGMENTS.  A segment is a contiguous
 // piece of the input with its own output bases and its own look-back chain: level 0 = the NRANGE
 // input ranges (bases from the range-resolved histogram), level 1 = the 256 buckets of level 0
-// (bases from the joint histogram).  Chains never cross segments, so tiles are handed out per XCD:
+// (each (bucket, digit) cell has its own fixed-capacity slot; the position inside it is the look-back
+// prefix).  Chains never cross segments, so tiles are handed out per XCD:
 // list x (range x; buckets 32x..32x+31) has its own ticket counter, served first by the workgroups
 // running on XCD x (HW_REG_XCC_ID) and by anyone once their own list is drained.  Neighbouring
 // tiles thus share an L2, where the partial 128-B lines at the seams of their output runs merge
@@ -1304,7 +1307,7 @@ static inline void prof_mark_h(int idx, hipStream_t s)
   if (g_prof.enabled) (void)hipEventRecord(g_prof.hev[idx], s);
 }
 static int g_hybrid = 1;  // 0 disables the hybrid MSD path (A/B knob)
-static int g_msd_kpt = getenv("GX_MSD_KPT") ? atoi(getenv("GX_MSD_KPT")) : 16;  // keys per thread of the partition passes (8, 12, 16)
+static int g_msd_kpt = 16;  // keys per thread of the partition passes (8 and 12 measured slower: 5.7 / 4.7 vs 4.0 ms)
 
 template <typename KeyT>
 constexpr int kpt_for(bool has_val)
@@ -1477,7 +1480,7 @@ int sort_impl(const void* keys_in, void* keys_out, const int32_t* vals_in, int32
       m.out       = bufA;
       m.base      = base1;
       m.level     = 0;
-      m.exp       = getenv("GX_EXP") ? atoi(getenv("GX_EXP")) : 0;
+      m.exp       = 0;
       m.cellcount = hist2;
       m.cellcap   = 1u << hc.cl2;
       prof_mark_h(0, stream);
