@@ -166,7 +166,10 @@ __device__ __forceinline__ unsigned lb_read(const LbStatus* st, AccT& v)
     l = load_agent_u64(&st->lo);
     h = load_agent_u64(&st->hi);
     if ((l >> 62) != 0 && (l >> 62) == (h >> 62)) break;
-    if (++spins > (1u << 22)) break;  // a broken chain: give up rather than hang (the result is wrong, tests would tell)
+    // A chain cannot break by construction (tickets: every predecessor is running or done).  If one ever does, fail
+    // LOUDLY: the trap aborts the kernel and the error surfaces at the caller's next synchronisation, instead of
+    // a silently wrong scan or a hang.
+    if (++spins > (1u << 24)) __builtin_trap();
     __builtin_amdgcn_s_sleep(2);
   }
   const unsigned long long bits = (l & 0xFFFFFFFFull) | (h << 32);
