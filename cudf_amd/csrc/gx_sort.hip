@@ -688,7 +688,12 @@ struct MsdArgs {
 // (Measured and dropped in round 2: persistent workgroups that prefetch the next tile's keys into registers during
 // the write-out.  A ticket taken late costs its latency before the write-out barrier (4.98 / 5.20 ms per pass against
 // 4.21 / 4.70), a ticket taken early delays the aggregate its successors look back for (5.34 / 6.31 ms):
-// profiles/r2_run8_bench_sort_persistent.jsonl, r2_run9_bench_persistent_early_ticket.jsonl.)
+// profiles/r2_run8_bench_sort_persistent.jsonl, r2_run9_bench_persistent_early_ticket.jsonl.
+// Also measured and dropped: issuing the first look-back window's status loads right after publishing the tile's own
+// counts, so that they travel during the scan and the LDS reorder (the loads do stay in flight across the barriers:
+// no s_waitcnt in between).  4.81 / 5.44 ms per pass against 4.2 / 4.7: words read that early are mostly not
+// published yet, so the window is read twice, and the eight extra registers do not come for free
+// (profiles/r2_run20_bench_sort_lookback_prefetch.jsonl).)
 template <typename KeyT, int KIND, bool HAS_VAL, int KPT, int LBW, int NBL>
 __global__ void __launch_bounds__(BT, (KPT <= 8 ? 8 : (KPT <= 12 ? 6 : 4))) k_msd_pass(MsdArgs a)
 {

@@ -87,6 +87,19 @@ int main(int argc, char** argv)
     table_view bt{{bk->view()}}, pt{{pk->view()}};
     std::unique_ptr<hash_join> hj;
     build_ms = time_steps(1, 2, [&] { hj = std::make_unique<hash_join>(bt, null_equality::EQUAL); });
+    if (std::getenv("CUDF_API_BENCH_TRACE")) {  // per-call view of the build: host time of the call, then time until idle
+      for (int i = 0; i < 6; ++i) {
+        auto const a0 = pool ? pool->driver_allocations() : 0;
+        double const t0 = now_ms();
+        if (i >= 3) hj.reset();  // the last three: free the old table before building the new one
+        hj = std::make_unique<hash_join>(bt, null_equality::EQUAL);
+        double const t1 = now_ms();
+        HIP_OK(hipDeviceSynchronize());
+        double const t2 = now_ms();
+        std::fprintf(stderr, "build %d: call %.3f ms, until idle %.3f ms, driver allocations +%zu\n", i, t1 - t0, t2 - t1,
+                     (pool ? pool->driver_allocations() : 0) - a0);
+      }
+    }
     probe_ms = time_steps(warmup, steps, [&] {
       auto res = hj->inner_join(pt);
       pairs    = res.first->size();
