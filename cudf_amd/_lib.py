@@ -46,6 +46,7 @@ _PROTOS = {
     "gx_sort_profile_read_hybrid": (_i, [ctypes.POINTER(ctypes.c_float)]),
     "gx_sort_set_hybrid": (None, [_i]),
     "gx_sort_set_cell": (None, [_i]),
+    "gx_sort_set_lookback": (None, [_i]),
     "gx_sort_info": (_i, [_p, ctypes.POINTER(ctypes.c_int32), _p]),
     "gx_gather": (_i, [_i, _p, _p, _i64, _p, _i64, _i, _p, _p, _p]),
     "gx_bitmask_set": (_i, [_p, _i64, _i64, _i, _p]),

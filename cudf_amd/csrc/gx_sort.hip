@@ -1312,6 +1312,7 @@ static inline void prof_mark_h(int idx, hipStream_t s)
   if (g_prof.enabled) (void)hipEventRecord(g_prof.hev[idx], s);
 }
 static int g_hybrid = 1;  // 0 disables the hybrid MSD path (A/B knob)
+static int g_lbw    = 4;  // predecessors per look-back round of the hybrid partition passes (A/B knob: 4, 8, 16)
 static int g_msd_kpt = 16;  // keys per thread of the partition passes (8 and 12 measured slower: 5.7 / 4.7 vs 4.0 ms)
 
 template <typename KeyT>
@@ -1453,6 +1454,19 @@ int sort_impl(const void* keys_in, void* keys_out, const int32_t* vals_in, int32
         if (hc.bits2 > 8) {
           kmsd1 = (MsdK)k_msd_pass<KeyT, KIND, HAS_VAL, 16, 4, 9>;
           kpt1  = 16;
+        }
+        if (g_lbw != 4 && hyb_kpt == 16) {  // A/B knob: predecessors examined per look-back round
+          static bool lattr_set = false;
+          if (!lattr_set) {
+            GX_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(k_msd_pass<KeyT, KIND, HAS_VAL, 16, 8, 8>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_msd(16, BINS)));
+            GX_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(k_msd_pass<KeyT, KIND, HAS_VAL, 16, 16, 8>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_msd(16, BINS)));
+            GX_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(k_msd_pass<KeyT, KIND, HAS_VAL, 16, 8, 9>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_msd(16, NB2MAX)));
+            GX_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(k_msd_pass<KeyT, KIND, HAS_VAL, 16, 16, 9>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_msd(16, NB2MAX)));
+            lattr_set = true;
+          }
+          kmsd0 = g_lbw == 8 ? (MsdK)k_msd_pass<KeyT, KIND, HAS_VAL, 16, 8, 8> : (MsdK)k_msd_pass<KeyT, KIND, HAS_VAL, 16, 16, 8>;
+          if (hc.bits2 > 8) kmsd1 = g_lbw == 8 ? (MsdK)k_msd_pass<KeyT, KIND, HAS_VAL, 16, 8, 9> : (MsdK)k_msd_pass<KeyT, KIND, HAS_VAL, 16, 16, 9>;
+          else kmsd1 = kmsd0;
         }
         if (hc.cl2 == 13) {
           kloc  = k_local_sort<KeyT, KIND, HAS_VAL, 13>;
@@ -1733,6 +1747,8 @@ int gx_sort_profile_read_hybrid(float* ms4)
 }
 
 void gx_sort_set_hybrid(int enable) { gx::sort::g_hybrid = enable ? 1 : 0; }
+
+void gx_sort_set_lookback(int window) { gx::sort::g_lbw = (window == 8 || window == 16) ? window : 4; }
 
 void gx_sort_set_cell(int keys) { gx::sort::g_cell = (keys == 8192 || keys == 16384) ? keys : 0; }
 
