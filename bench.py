@@ -57,7 +57,7 @@ def parse():
     ap.add_argument("--join-scatter-tile", type=int, default=0, help="join knob: rows per scatter tile (0 = default)")
     ap.add_argument("--no-hybrid", action="store_true", help="sort: disable the hybrid MSD path (LSD passes only)")
     ap.add_argument("--sort-cell", type=int, default=0, help="sort knob: local-sort cell capacity (0 auto, 8192, 16384)")
-    ap.add_argument("--sort-lbw", type=int, default=4, help="sort knob: predecessors per look-back round of the partition passes (4, 8, 16)")
+    ap.add_argument("--sort-lbw", type=int, default=16, help="sort knob: predecessors per look-back round of the partition passes (4, 8, 16)")
     ap.add_argument("--key-range", type=int, nargs=2, default=None, metavar=("LO", "HI"),
                     help="sort: keys uniform in [LO, HI) instead of the full int64 range (the reference's own "
                          "benchmark distribution is 100 10001: benchmarks/sort/sort.cpp:24-26)")

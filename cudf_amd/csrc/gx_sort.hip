@@ -1312,7 +1312,8 @@ static inline void prof_mark_h(int idx, hipStream_t s)
   if (g_prof.enabled) (void)hipEventRecord(g_prof.hev[idx], s);
 }
 static int g_hybrid = 1;  // 0 disables the hybrid MSD path (A/B knob)
-static int g_lbw    = 4;  // predecessors per look-back round of the hybrid partition passes (A/B knob: 4, 8, 16)
+static int g_lbw    = 16;  // predecessors per look-back round of the keys-only hybrid partition passes (knob: 4, 8, 16;
+                           // 16 measured 2-3 % ahead of 4: profiles/r2_run21_bench_sort_lookback_window.jsonl)
 static int g_msd_kpt = 16;  // keys per thread of the partition passes (8 and 12 measured slower: 5.7 / 4.7 vs 4.0 ms)
 
 template <typename KeyT>
@@ -1748,7 +1749,7 @@ int gx_sort_profile_read_hybrid(float* ms4)
 
 void gx_sort_set_hybrid(int enable) { gx::sort::g_hybrid = enable ? 1 : 0; }
 
-void gx_sort_set_lookback(int window) { gx::sort::g_lbw = (window == 8 || window == 16) ? window : 4; }
+void gx_sort_set_lookback(int window) { gx::sort::g_lbw = (window == 4 || window == 8) ? window : 16; }
 
 void gx_sort_set_cell(int keys) { gx::sort::g_cell = (keys == 8192 || keys == 16384) ? keys : 0; }
 

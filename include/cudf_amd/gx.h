@@ -139,8 +139,8 @@ void gx_sort_set_hybrid(int enable);
  * workgroups per CU and a 9-bit second partition level, for integer keys-only sorts of up to ~1.02e9 rows;
  * 16384-key cells otherwise), 8192 / 16384 = force where the key kind allows it. */
 void gx_sort_set_cell(int keys);
-/* A/B knob (process-wide): predecessors a tile of the hybrid partition passes examines per look-back round (4
- * default, 8, 16). */
+/* A/B knob (process-wide): predecessors a tile of the keys-only hybrid partition passes examines per look-back
+ * round (4, 8, 16 = default). */
 void gx_sort_set_lookback(int window);
 /* info8_host (host, 8 x int32) = {hybrid attempted, hybrid used, d1, shift2, bits2, LDS passes,
  * largest cell, active LSD passes (-1 when the hybrid path produced the output)} of the last sort
