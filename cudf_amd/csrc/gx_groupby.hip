@@ -226,19 +226,47 @@ __global__ void __launch_bounds__(256) k_part_hist(const K* __restrict__ keys, c
   const int64_t per    = range_tiles(n) * PTILE;
   const int64_t rbegin = (int64_t)r * per;
   const int64_t rend   = (r == NRANGE - 1) ? n : rbegin + per;
-  constexpr int U      = 8;
-  const int64_t stride = nb * 256 * U;
-  for (int64_t i0 = rbegin + jb * 256 * U + threadIdx.x; i0 < rend; i0 += stride) {
-    K k[U];
+  constexpr int U = 8;
+  constexpr int V = 16 / (int)sizeof(K);  // keys per 16-byte load
+  if (V > 1 && (reinterpret_cast<uintptr_t>(keys) & 15u) == 0) {
+    // 16-byte loads: with 4-byte keys the dword form keeps only half as many bytes in flight per lane as the 8-byte
+    // key form does, and ran at 3.7 TB/s against 6.1 TB/s (range starts are multiples of PTILE: the vectors stay aligned)
+    struct alignas(16) Vec { K k[V]; };
+    const int64_t stride = nb * 256 * U * V;
+    for (int64_t i0 = rbegin + (jb * 256 * U + threadIdx.x) * V; i0 < rend; i0 += stride) {
+      Vec v[U];
 #pragma unroll
-    for (int u = 0; u < U; ++u) {
-      const int64_t i = i0 + (int64_t)u * 256;
-      k[u]            = (i < rend) ? keys[i] : K(0);
+      for (int u = 0; u < U; ++u) {
+        const int64_t i = i0 + (int64_t)u * 256 * V;
+        if (i + V <= rend) {
+          v[u] = *reinterpret_cast<const Vec*>(keys + i);
+        } else {
+#pragma unroll
+          for (int e = 0; e < V; ++e) v[u].k[e] = (i + e < rend) ? keys[i + e] : K(0);
+        }
+      }
+#pragma unroll
+      for (int u = 0; u < U; ++u) {
+        const int64_t i = i0 + (int64_t)u * 256 * V;
+#pragma unroll
+        for (int e = 0; e < V; ++e)
+          if (i + e < rend && (!kvalid || bit_is_set(kvalid, i + e))) atomicAdd(&s_h[part_hash<K>(v[u].k[e]) >> 56], 1u);
+      }
     }
+  } else {
+    const int64_t stride = nb * 256 * U;
+    for (int64_t i0 = rbegin + jb * 256 * U + threadIdx.x; i0 < rend; i0 += stride) {
+      K k[U];
 #pragma unroll
-    for (int u = 0; u < U; ++u) {
-      const int64_t i = i0 + (int64_t)u * 256;
-      if (i < rend && (!kvalid || bit_is_set(kvalid, i))) atomicAdd(&s_h[part_hash<K>(k[u]) >> 56], 1u);
+      for (int u = 0; u < U; ++u) {
+        const int64_t i = i0 + (int64_t)u * 256;
+        k[u]            = (i < rend) ? keys[i] : K(0);
+      }
+#pragma unroll
+      for (int u = 0; u < U; ++u) {
+        const int64_t i = i0 + (int64_t)u * 256;
+        if (i < rend && (!kvalid || bit_is_set(kvalid, i))) atomicAdd(&s_h[part_hash<K>(k[u]) >> 56], 1u);
+      }
     }
   }
   __syncthreads();
