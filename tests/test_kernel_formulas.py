@@ -516,3 +516,113 @@ def test_xcd_lists_with_stealing_make_progress_with_few_resident_workgroups():
             assert steps < 200000, "no progress"
         for y in range(8):
             assert result[y] == [sum(counts[y][:t]) for t in range(len(lists[y]))]
+
+
+def test_hashed_row_keys_certificates_detect_every_collision_and_nothing_else():
+    """The multi-column-key operators key rows by a 64-bit hash and CERTIFY the result.  Model of the
+    two certificates with a deliberately weak hash (so that collisions happen): equal rows hash equal, hence a
+    hashed join never misses a pair and a hashed groupby never splits a group; the join certificate (compare every
+    emitted pair) and the groupby certificate (MIN == MAX of every key column inside every hash group) fire exactly
+    when two DIFFERENT rows share a hash, and when they stay silent the hashed result equals the exact one."""
+    rng = np.random.default_rng(5)
+
+    def weak_hash(cols, bits):
+        h = np.zeros(len(cols[0]), np.uint64)
+        for c in cols:
+            h = (h * np.uint64(1000003) + c.astype(np.uint64) * np.uint64(0x9E3779B97F4A7C15)) & np.uint64((1 << 63) - 1)
+        return h >> np.uint64(63 - bits)
+
+    saw_collision = saw_clean = False
+    for trial in range(60):
+        bits = int(rng.integers(3, 14))
+        n, m = int(rng.integers(1, 300)), int(rng.integers(1, 80))
+        card = int(rng.integers(2, 12))
+        L = [rng.integers(0, card, n), rng.integers(0, card, n)]
+        R = [rng.integers(0, card, m), rng.integers(0, card, m)]
+        # ---- join
+        hl, hr = weak_hash(L, bits), weak_hash(R, bits)
+        hashed = {(i, j) for i in range(n) for j in range(m) if hl[i] == hr[j]}
+        exact = {(i, j) for i in range(n) for j in range(m) if L[0][i] == R[0][j] and L[1][i] == R[1][j]}
+        assert exact <= hashed                                   # no pair can be missing
+        mismatches = sum(1 for (i, j) in hashed if not (L[0][i] == R[0][j] and L[1][i] == R[1][j]))
+        assert (mismatches == 0) == (hashed == exact)            # certificate silent <=> result exact
+        # ---- groupby
+        groups = {}
+        for i in range(n):
+            groups.setdefault(int(hl[i]), []).append(i)
+        cert_ok = all(min(c[i] for i in g) == max(c[i] for i in g) for g in groups.values() for c in L)
+        exact_groups = {}
+        for i in range(n):
+            exact_groups.setdefault((int(L[0][i]), int(L[1][i])), []).append(i)
+        same_partition = sorted(map(tuple, groups.values())) == sorted(map(tuple, exact_groups.values()))
+        assert cert_ok == same_partition
+        if cert_ok:   # the MINs are the group keys
+            assert sorted((min(L[0][i] for i in g), min(L[1][i] for i in g)) for g in groups.values()) == sorted(exact_groups)
+        saw_collision |= not cert_ok or mismatches > 0
+        saw_clean |= cert_ok and mismatches == 0
+    assert saw_collision and saw_clean
+
+
+def test_single_pass_lookback_scan_protocol_model():
+    """gx_scan's single-pass look-back (gx_scan.hpp k_lookback_scan): tiles taken by ticket publish {flag 1, aggregate},
+    fold the LB_WIN nearest predecessors per round up to the nearest {flag 2, inclusive prefix} and publish their own.
+    An accumulator travels as two granules that are written one after the other; a reader accepts a pair only when
+    both carry the same non-zero flag.  Random interleavings of (publish lo, publish hi, read) steps must always give
+    the sequential exclusive prefix, whatever the order tiles make progress in."""
+    rng = np.random.default_rng(9)
+    WIN = 4
+    for trial in range(200):
+        ntiles = int(rng.integers(1, 24))
+        agg = rng.integers(-1000, 1000, ntiles)
+        want = np.concatenate([[0], np.cumsum(agg)[:-1]])
+        lo = [(0, 0)] * ntiles      # (flag, low half)
+        hi = [(0, 0)] * ntiles
+        # per-tile program counters: 0/1 publish aggregate (lo, hi); 2.. look back; final publish prefix (lo, hi)
+        state = [{"pc": 0, "pos": t - 1, "ex": 0, "done": False, "pend": None} for t in range(ntiles)]
+        started = 0                 # tickets: tile t may only start once tiles < t have started
+        got = [None] * ntiles
+        guard = 0
+        while not all(s["done"] for s in state):
+            guard += 1
+            assert guard < 100000
+            runnable = [t for t in range(min(ntiles, started + 1)) if not state[t]["done"]]
+            t = int(rng.choice(runnable))
+            started = max(started, t + 1)
+            s = state[t]
+            first_flag = 2 if t == 0 else 1
+            if s["pc"] == 0:
+                lo[t] = (first_flag, int(agg[t]) & 0xFFFF); s["pc"] = 1
+            elif s["pc"] == 1:
+                hi[t] = (first_flag, int(agg[t]) >> 16); s["pc"] = 2
+                if t == 0:
+                    got[0] = 0; s["done"] = True
+            elif s["pc"] == 2:      # one look-back round (all-or-nothing: a lane spins until its word is consistent)
+                window = [s["pos"] - k for k in range(WIN) if s["pos"] - k >= 0]
+                vals, ok = [], True
+                for q in window:
+                    (fl, l), (fh, h) = lo[q], hi[q]
+                    if fl == 0 or fl != fh:
+                        ok = False; break
+                    vals.append((fl, (h << 16) | l))
+                if not ok:
+                    continue        # spin: try again later
+                done = False
+                for fl, v in vals:
+                    v = v - (1 << 32) if v >= (1 << 31) else v
+                    s["ex"] += v
+                    if fl == 2:
+                        done = True; break
+                if not window:
+                    done = True
+                if done:
+                    s["pc"] = 3
+                else:
+                    s["pos"] -= WIN
+                    if s["pos"] < 0:
+                        s["pc"] = 3
+            elif s["pc"] == 3:
+                lo[t] = (2, int(s["ex"] + agg[t]) & 0xFFFF); s["pc"] = 4
+            else:
+                hi[t] = (2, int(s["ex"] + agg[t]) >> 16)
+                got[t] = s["ex"]; s["done"] = True
+        assert got == [int(x) for x in want], (trial, got, want.tolist())
