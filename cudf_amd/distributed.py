@@ -70,6 +70,15 @@ class HipLocalOps:
         li, ri = self._ops.inner_join(self._col(left), self._col(right))
         return self._tensor(li, torch.int32), self._tensor(ri, torch.int32)
 
+    def join_build(self, right: torch.Tensor):
+        """cudf::hash_join on the local build keys: hashed once, probed many times"""
+        col = self._col(right)
+        return (self._ops.HashJoin(col), col)
+
+    def join_probe(self, table, left: torch.Tensor) -> Tuple[torch.Tensor, torch.Tensor]:
+        li, ri = table[0].inner_join(self._col(left))
+        return self._tensor(li, torch.int32), self._tensor(ri, torch.int32)
+
     def groupby_sum_count(self, keys: torch.Tensor, vals: torch.Tensor):
         k, s, cv, _ = self._ops.groupby_sum_count(self._col(keys), self._col(vals))
         sdt = vals.dtype if vals.dtype.is_floating_point else torch.int64
@@ -244,6 +253,67 @@ def distributed_inner_join(left: torch.Tensor, right: torch.Tensor, local: Optio
     lgid = global_ids(lrows, lrecv, bases(lsizes))
     rgid = global_ids(rrows, rrecv, bases(rsizes))
     return local.gather(lgid, li), local.gather(rgid, ri)
+
+
+class DistributedHashJoin:
+    """cudf::hash_join over sharded tables (hash_join.hpp:70-125: build once, probe many).  The constructor hash-partitions
+    this rank's build keys, exchanges them once (key + int32 local row, 12 B/row) and builds the local hash table over
+    what it received; inner_join() partitions and exchanges only the probe side and probes that table.  Results as in
+    distributed_inner_join: (global probe row, global build row) of this rank's share of the pairs."""
+
+    def __init__(self, right: torch.Tensor, local: Optional[object] = None, group=None):
+        self._local = local or HipLocalOps()
+        self._group = group
+        rank, world = _world(group)
+        dev = right.device
+        rsizes = _all_sizes(right.numel(), dev, group)
+        self._single = world == 1 and not _FORCE_EXCHANGE
+        if self._single:
+            self._table, self._rgid = self._local.join_build(right), None
+            return
+        rk, rrow, roffs = self._local.hash_partition_rows(right, world)
+        send = _offsets_to_counts(roffs)
+        recv = exchange_counts(send, dev, group)
+        rkeys = all_to_all_rows(rk, send, recv, group)
+        rrows = all_to_all_rows(rrow, send, recv, group)
+        self._rgid = _segment_global_ids(rrows, recv, _bases(rsizes))
+        self._table = self._local.join_build(rkeys)
+
+    def inner_join(self, left: torch.Tensor) -> Tuple[torch.Tensor, torch.Tensor]:
+        local, group = self._local, self._group
+        if self._single:
+            li, ri = local.join_probe(self._table, left)
+            return li.to(torch.int64), ri.to(torch.int64)
+        rank, world = _world(group)
+        dev = left.device
+        lsizes = _all_sizes(left.numel(), dev, group)
+        lk, lrow, loffs = local.hash_partition_rows(left, world)
+        send = _offsets_to_counts(loffs)
+        recv = exchange_counts(send, dev, group)
+        lkeys = all_to_all_rows(lk, send, recv, group)
+        lrows = all_to_all_rows(lrow, send, recv, group)
+        li, ri = local.join_probe(self._table, lkeys)
+        lgid = _segment_global_ids(lrows, recv, _bases(lsizes))
+        return local.gather(lgid, li), local.gather(self._rgid, ri)
+
+
+def _bases(sizes: Sequence[int]) -> List[int]:
+    out, run = [], 0
+    for x in sizes:
+        out.append(run)
+        run += x
+    return out
+
+
+def _segment_global_ids(rows: torch.Tensor, recv: Sequence[int], base: Sequence[int]) -> torch.Tensor:
+    """received int32 local rows -> int64 global rows: segment j came from rank j, whose shard starts at base[j]"""
+    gid = rows.to(torch.int64)
+    at = 0
+    for j, c in enumerate(recv):
+        if c and base[j]:
+            gid[at:at + c] += base[j]
+        at += c
+    return gid
 
 
 def distributed_groupby_sum_count(keys: torch.Tensor, vals: torch.Tensor, local: Optional[object] = None, group=None):

@@ -46,6 +46,13 @@ class NumpyLocalOps:
         l, r = orc.inner_join(left.numpy(), right.numpy())
         return torch.from_numpy(l.astype(np.int32)), torch.from_numpy(r.astype(np.int32))
 
+    def join_build(self, right):
+        return right.numpy().copy()
+
+    def join_probe(self, table, left):
+        l, r = orc.inner_join(left.numpy(), table)
+        return torch.from_numpy(l.astype(np.int32)), torch.from_numpy(r.astype(np.int32))
+
     def groupby_sum_count(self, keys, vals):
         k, res = orc.groupby_agg(keys.numpy(), vals.numpy(), ["sum", "count_valid"], exact=False)
         return torch.from_numpy(k), torch.from_numpy(res["sum"][0]), torch.from_numpy(res["count_valid"][0])

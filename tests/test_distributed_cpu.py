@@ -59,6 +59,13 @@ def _worker(rank, world, port, what, outdir):
         l, r = _shards(rank, world, what)
         gl, gr = D.distributed_inner_join(torch.from_numpy(l), torch.from_numpy(r), local=local)
         np.save(os.path.join(outdir, f"join_{rank}.npy"), np.stack([gl.numpy(), gr.numpy()]))
+    elif what == "hashjoin":   # build exchanged and hashed once, probed twice (the second probe: the first half of the shard)
+        l, r = _shards(rank, world, "join")
+        hj = D.DistributedHashJoin(torch.from_numpy(r), local=local)
+        gl, gr = hj.inner_join(torch.from_numpy(l))
+        np.save(os.path.join(outdir, f"hashjoin_{rank}.npy"), np.stack([gl.numpy(), gr.numpy()]))
+        gl2, gr2 = hj.inner_join(torch.from_numpy(l[: len(l) // 2].copy()))
+        np.save(os.path.join(outdir, f"hashjoin2_{rank}.npy"), np.stack([gl2.numpy(), gr2.numpy()]))
     elif what.startswith("scan"):
         _, op, dt, inc = what.split(":")
         v = _shards(rank, world, what)
@@ -92,6 +99,27 @@ def test_distributed_sort_gloo(world, tmp_path):
     for a, b in zip(parts[:-1], parts[1:]):
         if len(a) and len(b):
             assert a[-1] <= b[0]
+
+
+@pytest.mark.parametrize("world", [2, 3])
+def test_distributed_hash_join_builds_once_probes_many_gloo(world, tmp_path):
+    from oracle import cudf_oracle as orc
+    _run(world, "hashjoin", tmp_path)
+    shards = [_shards(r, world, "join") for r in range(world)]
+    left = np.concatenate([s[0] for s in shards])
+    right = np.concatenate([s[1] for s in shards])
+    pairs = np.concatenate([np.load(tmp_path / f"hashjoin_{r}.npy") for r in range(world)], axis=1)
+    el, er = orc.inner_join(left, right)
+    gl, gr = orc.canonical_pairs(pairs[0], pairs[1])
+    np.testing.assert_array_equal(gl, el)
+    np.testing.assert_array_equal(gr, er)
+    # second probe: every rank's first half; global probe ids count positions in the concatenation of the halves
+    halves = [s[0][: len(s[0]) // 2] for s in shards]
+    pairs2 = np.concatenate([np.load(tmp_path / f"hashjoin2_{r}.npy") for r in range(world)], axis=1)
+    el2, er2 = orc.inner_join(np.concatenate(halves), right)
+    gl2, gr2 = orc.canonical_pairs(pairs2[0], pairs2[1])
+    np.testing.assert_array_equal(gl2, el2)
+    np.testing.assert_array_equal(gr2, er2)
 
 
 @pytest.mark.parametrize("world", [2, 3])

@@ -34,6 +34,13 @@ def test_distributed_ops_single_rank_rccl(pg):
     np.testing.assert_array_equal(out.cpu().numpy(), np.sort(keys))
     left = rng.integers(0, 50_000, 200_000).astype(np.int64)
     right = rng.permutation(60_000)[:30_000].astype(np.int64)
+    hj = D.DistributedHashJoin(torch.from_numpy(right).cuda())           # build once ...
+    for sl in (slice(None), slice(0, len(left) // 3)):                   # ... probe twice
+        hl, hr = hj.inner_join(torch.from_numpy(left[sl].copy()).cuda())
+        el_, er_ = orc.inner_join(left[sl], right)
+        a, b = orc.canonical_pairs(hl.cpu().numpy(), hr.cpu().numpy())
+        np.testing.assert_array_equal(a, el_)
+        np.testing.assert_array_equal(b, er_)
     gl, gr = D.distributed_inner_join(torch.from_numpy(left).cuda(), torch.from_numpy(right).cuda())
     el, er = orc.inner_join(left, right)
     cl, cr = orc.canonical_pairs(gl.cpu().numpy(), gr.cpu().numpy())
