@@ -170,7 +170,51 @@ static inline unsigned word_grid(int64_t nwords)
 
 }  // namespace gx
 
+namespace gx {
+// out[j] = rows[idx[j]] + base[segment of idx[j]]: the received (int32 local row) of a sharded join's pair turned into
+// a global int64 row id in one gather -- segment s of the receive buffer came from rank s, whose shard starts at base[s]
+struct SegBases {
+  long long start[17];  // segment s = positions [start[s], start[s + 1])
+  long long base[16];
+  int nseg;
+};
+__global__ void __launch_bounds__(256) k_gather_global_rows(const int32_t* __restrict__ rows, const int32_t* __restrict__ idx, int64_t n,
+                                                            SegBases sb, long long* __restrict__ out)
+{
+  const int64_t stride = (int64_t)gridDim.x * 256;
+  for (int64_t j = (int64_t)blockIdx.x * 256 + threadIdx.x; j < n; j += stride) {
+    const long long i = idx[j];
+    int s             = 0;
+    for (int k = 1; k < sb.nseg; ++k) s += (i >= sb.start[k]) ? 1 : 0;
+    out[j] = (long long)rows[i] + sb.base[s];
+  }
+}
+}  // namespace gx
+
 extern "C" {
+
+int gx_gather_global_rows(const int32_t* rows, int64_t nrows, const int32_t* idx, int64_t n, int nseg, const int64_t* seg_counts_host,
+                          const int64_t* seg_bases_host, int64_t* out, gx_stream_t s)
+{
+  if (n < 0 || nrows < 0 || nseg < 1 || nseg > 16 || !seg_counts_host || !seg_bases_host) return GX_EINVAL;
+  if (n == 0) return 0;
+  if (!rows || !idx || !out) return GX_EINVAL;
+  gx::SegBases sb{};
+  long long run = 0;
+  for (int k = 0; k < nseg; ++k) {
+    sb.start[k] = run;
+    sb.base[k]  = seg_bases_host[k];
+    run += seg_counts_host[k];
+  }
+  sb.start[nseg] = run;
+  sb.nseg        = nseg;
+  if (run != nrows) return GX_EINVAL;
+  int64_t blocks = gx::div_up(n, (int64_t)256 * 4);
+  if (blocks > 16384) blocks = 16384;
+  hipLaunchKernelGGL(gx::k_gather_global_rows, dim3((unsigned)blocks), dim3(256), 0, s, rows, idx, n, sb, reinterpret_cast<long long*>(out));
+  GX_LAUNCH_CHECK();
+  return 0;
+}
 
 int gx_gather(int elem_size, const void* src, const uint32_t* src_valid, int64_t src_rows, const int32_t* map,
               int64_t n, int nullify_oob, void* out, uint32_t* out_valid, gx_stream_t s)

@@ -1546,6 +1546,9 @@ int pj_partition_fn(const K* keys, int64_t n, int pbits, PjPlan* plan, K* pkeys,
   // tile: as many rows as the LDS holds next to the three P-entry arrays (160 KiB per CU)
   int tile_rows = g_pj_tile ? g_pj_tile : 16384;
   while (tile_rows > 4096 && (size_t)tile_rows * sizeof(K) + ((size_t)12 << pbits) + 256 > (size_t)160 * 1024) tile_rows /= 2;
+  // few partitions (the rank split of a sharded sort / join, small join tables): runs are long whatever the tile, so
+  // take the 8192-row tile whose 64 KiB let two workgroups share a CU and overlap each other's load and write phases
+  if (!g_pj_tile && pbits <= 6 && tile_rows > 8192) tile_rows = 8192;
   if (n <= 4 * (int64_t)tile_rows * 256) tile_rows = 4096;  // small inputs: more, smaller workgroups
   const int64_t rrows = pj_range_rows(n, tile_rows);
   if (profile) jprof_mark(0, s);

@@ -70,6 +70,11 @@ class HipLocalOps:
         li, ri = self._ops.inner_join(self._col(left), self._col(right))
         return self._tensor(li, torch.int32), self._tensor(ri, torch.int32)
 
+    def gather_global_rows(self, rows: torch.Tensor, idx: torch.Tensor, recv: Sequence[int], bases: Sequence[int]) -> torch.Tensor:
+        """int64 global row of every selected entry: rows[idx] + the shard offset of the rank its segment came from"""
+        out = self._ops.gather_global_rows(self._col(rows), self._col(idx), recv, bases)
+        return self._tensor(out, torch.int64)
+
     def join_build(self, right: torch.Tensor):
         """cudf::hash_join on the local build keys: hashed once, probed many times"""
         col = self._col(right)
@@ -234,15 +239,6 @@ def distributed_inner_join(left: torch.Tensor, right: torch.Tensor, local: Optio
         w2 = dist.all_to_all_single(orow, prow.contiguous(), output_split_sizes=list(recv), input_split_sizes=list(send), group=group, async_op=True)
         return ok, orow, recv, (w1, w2)
 
-    def global_ids(rows: torch.Tensor, recv: Sequence[int], base: Sequence[int]) -> torch.Tensor:
-        gid = rows.to(torch.int64)
-        at = 0
-        for j, c in enumerate(recv):        # segment j came from rank j: add that shard's offset
-            if c and base[j]:
-                gid[at:at + c] += base[j]
-            at += c
-        return gid
-
     rk, rrow, roffs = local.hash_partition_rows(right, world)
     rkeys, rrows, rrecv, rwork = start_exchange(rk, rrow, roffs)     # build side in flight ...
     lk, lrow, loffs = local.hash_partition_rows(left, world)        # ... while the probe side is partitioned
@@ -250,9 +246,8 @@ def distributed_inner_join(left: torch.Tensor, right: torch.Tensor, local: Optio
     for w in rwork + lwork:
         w.wait()
     li, ri = local.inner_join(lkeys, rkeys)
-    lgid = global_ids(lrows, lrecv, bases(lsizes))
-    rgid = global_ids(rrows, rrecv, bases(rsizes))
-    return local.gather(lgid, li), local.gather(rgid, ri)
+    return (local.gather_global_rows(lrows, li, lrecv, bases(lsizes)),
+            local.gather_global_rows(rrows, ri, rrecv, bases(rsizes)))
 
 
 class DistributedHashJoin:
@@ -269,14 +264,13 @@ class DistributedHashJoin:
         rsizes = _all_sizes(right.numel(), dev, group)
         self._single = world == 1 and not _FORCE_EXCHANGE
         if self._single:
-            self._table, self._rgid = self._local.join_build(right), None
+            self._table = self._local.join_build(right)
             return
         rk, rrow, roffs = self._local.hash_partition_rows(right, world)
         send = _offsets_to_counts(roffs)
         recv = exchange_counts(send, dev, group)
         rkeys = all_to_all_rows(rk, send, recv, group)
-        rrows = all_to_all_rows(rrow, send, recv, group)
-        self._rgid = _segment_global_ids(rrows, recv, _bases(rsizes))
+        self._rrows, self._rrecv, self._rbases = all_to_all_rows(rrow, send, recv, group), list(recv), _bases(rsizes)
         self._table = self._local.join_build(rkeys)
 
     def inner_join(self, left: torch.Tensor) -> Tuple[torch.Tensor, torch.Tensor]:
@@ -293,8 +287,9 @@ class DistributedHashJoin:
         lkeys = all_to_all_rows(lk, send, recv, group)
         lrows = all_to_all_rows(lrow, send, recv, group)
         li, ri = local.join_probe(self._table, lkeys)
-        lgid = _segment_global_ids(lrows, recv, _bases(lsizes))
-        return local.gather(lgid, li), local.gather(self._rgid, ri)
+        # only the rows that joined are translated: (int32 local row, segment) -> int64 global row in one gather each
+        return (local.gather_global_rows(lrows, li, recv, _bases(lsizes)),
+                local.gather_global_rows(self._rrows, ri, self._rrecv, self._rbases))
 
 
 def _bases(sizes: Sequence[int]) -> List[int]:
@@ -303,17 +298,6 @@ def _bases(sizes: Sequence[int]) -> List[int]:
         out.append(run)
         run += x
     return out
-
-
-def _segment_global_ids(rows: torch.Tensor, recv: Sequence[int], base: Sequence[int]) -> torch.Tensor:
-    """received int32 local rows -> int64 global rows: segment j came from rank j, whose shard starts at base[j]"""
-    gid = rows.to(torch.int64)
-    at = 0
-    for j, c in enumerate(recv):
-        if c and base[j]:
-            gid[at:at + c] += base[j]
-        at += c
-    return gid
 
 
 def distributed_groupby_sum_count(keys: torch.Tensor, vals: torch.Tensor, local: Optional[object] = None, group=None):

@@ -103,6 +103,18 @@ def gather(col: Column, gather_map: Column, nullify_out_of_bounds: bool = False)
     return out
 
 
+def gather_global_rows(rows: Column, idx: Column, seg_counts: Sequence[int], seg_bases: Sequence[int]) -> Column:
+    """out[j] = rows[idx[j]] + seg_bases[segment of idx[j]] as int64: received int32 local rows -> global row ids of
+    the join pairs `idx` selects (segment k = the seg_counts[k] entries received from rank k)."""
+    n = idx.size
+    out = Column.empty(np.int64, n)
+    cnt = (ctypes.c_int64 * len(seg_counts))(*[int(x) for x in seg_counts])
+    bas = (ctypes.c_int64 * len(seg_bases))(*[int(x) for x in seg_bases])
+    L.check(_lib.gx_gather_global_rows(rows.data_ptr, rows.size, idx.data_ptr, n, len(seg_counts), cnt, bas, out.data_ptr,
+                                       stream_ptr()), "gx_gather_global_rows")
+    return out
+
+
 def bitmask_count(mask: torch.Tensor, nbits: int) -> int:
     cnt = _dev_i64()
     L.check(_lib.gx_bitmask_count(ptr(mask), 0, nbits, ptr(cnt), stream_ptr()), "gx_bitmask_count")

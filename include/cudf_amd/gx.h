@@ -157,6 +157,12 @@ int gx_sort_info(const void* tmp, int32_t* info8_host, gx_stream_t stream);
 int gx_gather(int elem_size, const void* src, const uint32_t* src_valid, int64_t src_rows,
               const int32_t* map, int64_t n, int nullify_oob, void* out, uint32_t* out_valid,
               gx_stream_t stream);
+/* Sharded joins: out[j] = rows[idx[j]] + seg_bases[s], s = the segment of the receive buffer position idx[j] falls
+ * into (segment k holds seg_counts[k] entries; nseg <= 16 ranks; counts and bases are HOST arrays).  Turns the
+ * (int32 local row) a rank received next to each key into the global int64 row id of a join pair in one gather
+ * (the per-rank split of cudf_polars' shuffle carries the same information as a partition id). */
+int gx_gather_global_rows(const int32_t* rows, int64_t nrows, const int32_t* idx, int64_t n, int nseg,
+                          const int64_t* seg_counts_host, const int64_t* seg_bases_host, int64_t* out, gx_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------
  * Validity bitmaps.  Replace src/bitmask/null_mask.cu:152 (set), :339-409 (count),

@@ -46,6 +46,12 @@ class NumpyLocalOps:
         l, r = orc.inner_join(left.numpy(), right.numpy())
         return torch.from_numpy(l.astype(np.int32)), torch.from_numpy(r.astype(np.int32))
 
+    def gather_global_rows(self, rows, idx, recv, bases):
+        starts = np.concatenate([[0], np.cumsum(recv)])
+        i = idx.numpy().astype(np.int64)
+        seg = np.searchsorted(starts[1:], i, side="right")
+        return torch.from_numpy(rows.numpy().astype(np.int64)[i] + np.asarray(bases, np.int64)[seg])
+
     def join_build(self, right):
         return right.numpy().copy()
 
