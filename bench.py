@@ -36,7 +36,8 @@ import time
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
-HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec (MI355X_MICROARCH.md); measured copy ceiling 6290 GB/s
+HBM_PEAK_GBS = 8000.0   # MI355X HBM3E spec (MI355X_MICROARCH.md)
+HBM_COPY_GBS = 6290.0   # measured copy ceiling (same guide)
 METRIC = "rows/sec + achieved HBM GB/s: 1e9-row int64 sort & hash-join, 1/2/4/8 GPU"
 
 
@@ -797,6 +798,15 @@ def main():
             line["through_cpp"] = through_cpp(args, c, head["ms_per_step"] if wl in ("all", "sort") else None,
                                               (blocks.get("join") or (head if wl == "join" else {})).get("ms_per_step"),
                                               (blocks.get("groupby") or (head if wl == "groupby" else {})).get("ms_per_step"))
+        for r in [line.get("roofline")] + [line[k].get("roofline") for k in ("join", "groupby") if k in line]:
+            if not r:
+                continue
+            # achieved GB/s two ways (model bytes / time, PMC bytes / time), against the 8.0 TB/s spec and
+            # against the 6.29 TB/s copy ceiling measured on this part (MI355X_MICROARCH.md)
+            r["peak_measured_copy"] = HBM_COPY_GBS
+            r["frac_of_measured_copy"] = r["achieved"] / HBM_COPY_GBS
+            if r.get("traffic") and r.get("avg_launch_ms"):
+                r["traffic_GBps"] = r["traffic"] / (r["avg_launch_ms"] * 1e-3) / 1e9
         print(json.dumps(line), flush=True)
     if c.world > 1:
         c.dist.destroy_process_group()
