@@ -467,8 +467,11 @@ std::pair<std::unique_ptr<table>, std::vector<aggregation_result>> groupby::scan
       if (agg->kind == aggregation::SUM) op = GX_OP_SUM;
       if (agg->kind == aggregation::MIN) op = GX_OP_MIN;
       if (agg->kind == aggregation::MAX) op = GX_OP_MAX;
-      CUDF_EXPECTS(op >= 0, "groupby scan kind not implemented on this path (SUM, MIN, MAX are)");
-      data_type const ot = (op == GX_OP_SUM) ? sum_type(sv.type()) : sv.type();
+      if (agg->kind == aggregation::COUNT_VALID) op = GX_OP_COUNT_VALID;
+      if (agg->kind == aggregation::COUNT_ALL) op = GX_OP_COUNT_ALL;
+      CUDF_EXPECTS(op >= 0, "groupby scan kind not implemented on this path (SUM, MIN, MAX, COUNT are)");
+      bool const counting = op == GX_OP_COUNT_VALID || op == GX_OP_COUNT_ALL;  // sort/scan.cpp:113-136: INT32, never null
+      data_type const ot  = counting ? data_type{type_id::INT32} : (op == GX_OP_SUM) ? sum_type(sv.type()) : sv.type();
       auto out = make_fixed_width_column(ot, kept, mask_state::UNALLOCATED, stream, mr);
       if (kept > 0)
         detail::run_with_scratch(
@@ -478,7 +481,7 @@ std::pair<std::unique_ptr<table>, std::vector<aggregation_result>> groupby::scan
                                      out->mutable_view().head<void>(), t, b, detail::gxs(stream));
           },
           "groupby scan", stream);
-      if (sv.nullable() && kept > 0) {  // null rows stay null
+      if (!counting && sv.nullable() && kept > 0) {  // null rows stay null
         rmm::device_buffer m{bitmask_allocation_size_bytes(kept), stream, mr};
         CUDF_CUDA_TRY(hipMemsetAsync(m.data(), 0, m.size(), stream.value()));
         detail::gx_check(gx_bitmask_copy(static_cast<uint32_t*>(m.data()), 0, sv.null_mask(), sv.offset(), kept, detail::gxs(stream)),

@@ -27,13 +27,16 @@ join_result empty_result(rmm::cuda_stream_view stream, rmm::device_async_resourc
           std::make_unique<rmm::device_uvector<size_type>>(0, stream, mr)};
 }
 
-// device int64 cursor <- v, with no host source to outlive the call: the high word by memset, the low one by the
-// sequence kernel (v is a row count: it fits 31 bits)
+// device int64 cursor <- v (the full 64 bits: the pair total of a partitioned join may exceed size_type), with no host
+// source to outlive the call: each 32-bit half is written by the sequence kernel from a by-value argument
 void set_cursor_async(rmm::device_buffer& cursor, std::size_t v, rmm::cuda_stream_view stream)
 {
   CUDF_CUDA_TRY(hipMemsetAsync(cursor.data(), 0, sizeof(int64_t), stream.value()));
-  if (v != 0)
-    detail::gx_check(gx_sequence_i32(static_cast<int32_t*>(cursor.data()), 1, static_cast<int32_t>(v), detail::gxs(stream)), "cursor");
+  auto* w = static_cast<int32_t*>(cursor.data());
+  auto const lo = static_cast<int32_t>(static_cast<uint32_t>(v & 0xFFFFFFFFull));
+  auto const hi = static_cast<int32_t>(static_cast<uint32_t>(v >> 32));
+  if (lo != 0) detail::gx_check(gx_sequence_i32(w, 1, lo, detail::gxs(stream)), "cursor");
+  if (hi != 0) detail::gx_check(gx_sequence_i32(w + 1, 1, hi, detail::gxs(stream)), "cursor");
 }
 
 // row indices of the null rows of a nullable column (rare path: host round trip)
@@ -103,10 +106,14 @@ class hash_join_impl {
   hash_join_impl const& exact(rmm::cuda_stream_view stream) const
   {
     std::lock_guard<std::mutex> lock(_exact_mutex);
-    if (!_exact)
+    if (!_exact) {
       _exact = std::make_unique<hash_join_impl const>(_build, _has_nulls ? nullable_join::YES : nullable_join::NO,
                                                       _nulls_equal ? null_equality::EQUAL : null_equality::UNEQUAL, _load_factor,
                                                       stream, false);
+      // cold path, once per table: probes are const and may come from other threads on other streams
+      // (hash_join.hpp:63-68) -- none of them may see the twin before its build kernels have finished
+      stream.synchronize();
+    }
     return *_exact;
   }
 

@@ -70,6 +70,11 @@ std::unique_ptr<column> top_k_order(column_view const& col, size_type k, order t
 {
   CUDF_EXPECTS(k >= 0, "k must be non-negative", std::invalid_argument);
   if (k == 0 || col.size() == 0) return make_empty_column(data_type{type_id::INT32});
+  if (k >= col.size()) {  // top_k.cu:139-145: every row is in the top -- the identity, matching top_k's copy of the column
+    auto all = make_fixed_width_column(data_type{type_id::INT32}, col.size(), mask_state::UNALLOCATED, stream, mr);
+    detail::gx_check(gx_sequence_i32(all->mutable_view().head<int32_t>(), col.size(), 0, detail::gxs(stream)), "top_k_order");
+    return all;
+  }
   // nulls never make the top (top_k.cu:136-137)
   auto const nulls = topk_order == order::ASCENDING ? null_order::AFTER : null_order::BEFORE;
   auto indices     = cudf::stable_sorted_order(table_view{{col}}, {topk_order}, {nulls}, stream);

@@ -7,75 +7,13 @@
 #include <cudf/copying.hpp>
 #include <cudf/sorting.hpp>
 
-#include <mutex>
-
 namespace cudf {
 namespace {
 
-// Device-side protocol faults (a look-back spin that timed out) without a host round trip per call: the status word
-// of each radix sort is copied -- asynchronously, on the caller's stream -- into a slot of a small pinned ring, and
-// the slots whose copy has completed are examined at the START of the next sort.  A fault therefore surfaces as a
-// cudf::logic_error one call late (or at process exit, on stderr); the sort itself returns as soon as its work is
+// Device-side protocol faults: a look-back spin that loses forward progress traps inside the kernel (gx_sort.hip), so
+// the error belongs to the stream of the call that produced it and surfaces at that stream's next synchronisation as
+// a cudf::cuda_error -- never as a wrong order returned as success.  The sort itself returns as soon as its work is
 // queued, like the reference's (cpp/src/sort/sort.cu:52-89).
-class deferred_sort_status {
- public:
-  static deferred_sort_status& instance()
-  {
-    static deferred_sort_status* d = new deferred_sort_status;  // pinned memory outlives static destruction
-    return *d;
-  }
-  // throw for every finished sort that reported a fault
-  void poll()
-  {
-    std::lock_guard<std::mutex> lock(m_);
-    bool bad = false;
-    for (auto& s : slots_) {
-      if (!s.busy || hipEventQuery(s.done) != hipSuccess) continue;
-      bad    = bad || *s.word != 0;
-      s.busy = false;
-    }
-    (void)hipGetLastError();
-    CUDF_EXPECTS(!bad, "radix sort: device-side protocol failure in an earlier sort on this process");
-  }
-  void note(void const* tmp, rmm::cuda_stream_view stream)
-  {
-    std::lock_guard<std::mutex> lock(m_);
-    if (host_ == nullptr) {
-      CUDF_CUDA_TRY(hipHostMalloc(reinterpret_cast<void**>(&host_), sizeof(int) * SLOTS, hipHostMallocDefault));
-      for (int i = 0; i < SLOTS; ++i) {
-        slots_[i].word = host_ + i;
-        CUDF_CUDA_TRY(hipEventCreateWithFlags(&slots_[i].done, hipEventDisableTiming));
-      }
-    }
-    slot* s = nullptr;
-    for (auto& c : slots_)
-      if (!c.busy) {
-        s = &c;
-        break;
-      }
-    if (s == nullptr) {  // ring full (SLOTS sorts in flight): wait for the oldest
-      s = &slots_[next_victim_++ % SLOTS];
-      CUDF_CUDA_TRY(hipEventSynchronize(s->done));
-      CUDF_EXPECTS(*s->word == 0, "radix sort: device-side protocol failure in an earlier sort on this process");
-    }
-    *s->word = 0;
-    detail::gx_check(gx_sort_status_async(tmp, s->word, detail::gxs(stream)), "sort status");
-    CUDF_CUDA_TRY(hipEventRecord(s->done, stream.value()));
-    s->busy = true;
-  }
-
- private:
-  static constexpr int SLOTS = 64;
-  struct slot {
-    int* word{nullptr};
-    hipEvent_t done{nullptr};
-    bool busy{false};
-  };
-  std::mutex m_;
-  int* host_{nullptr};
-  slot slots_[SLOTS];
-  unsigned next_victim_{0};
-};
 
 void check_order_args(table_view const& input, std::vector<order> const& column_order,
                       std::vector<null_order> const& null_precedence)
@@ -91,19 +29,17 @@ void check_order_args(table_view const& input, std::vector<order> const& column_
 // stable argsort of ONE column into `out` (device int32[n]); out may not alias the column
 void column_sorted_order(column_view const& col, order ord, null_order nulls, int32_t* out, rmm::cuda_stream_view stream)
 {
-  deferred_sort_status::instance().poll();
   rmm::device_buffer mask_holder;
   auto const* mask      = col.has_nulls() ? detail::rebased_mask(col, mask_holder, stream) : nullptr;
   int const dtype       = detail::gx_type(col.type());
   int const descending  = ord == order::DESCENDING ? 1 : 0;
   int const null_before = nulls == null_order::BEFORE ? 1 : 0;
-  auto tmp = detail::run_with_scratch(
+  (void)detail::run_with_scratch(
     [&](void* t, std::size_t* b) {
       return gx_sorted_order(dtype, detail::row0(col), mask, col.size(), mask ? col.null_count() : 0, descending,
                              null_before, out, t, b, detail::gxs(stream));
     },
     "sorted_order", stream);
-  if (!mask) deferred_sort_status::instance().note(tmp.data(), stream);
 }
 
 std::unique_ptr<column> gather_column(column_view const& src, int32_t const* map, size_type n, bool nullify,
@@ -219,17 +155,15 @@ std::unique_ptr<table> sort(table_view const& input, std::vector<order> const& c
   // fast path of sort.cu:57-64: one fixed-width column without nulls -> keys-only radix sort
   if (input.num_columns() == 1 && !input.column(0).has_nulls() && is_fixed_width(input.column(0).type()) &&
       input.num_rows() > 0) {
-    deferred_sort_status::instance().poll();
-    auto const& col = input.column(0);
+      auto const& col = input.column(0);
     auto out        = make_fixed_width_column(col.type(), col.size(), mask_state::UNALLOCATED, stream, mr);
     int const desc  = (!column_order.empty() && column_order[0] == order::DESCENDING) ? 1 : 0;
-    auto tmp        = detail::run_with_scratch(
+    (void)detail::run_with_scratch(
       [&](void* t, std::size_t* b) {
         return gx_sort_keys(detail::gx_type(col.type()), detail::row0(col), out->mutable_view().head<void>(), col.size(),
                             desc, t, b, detail::gxs(stream));
       },
       "sort", stream);
-    deferred_sort_status::instance().note(tmp.data(), stream);
     std::vector<std::unique_ptr<column>> cols;
     cols.emplace_back(std::move(out));
     return std::make_unique<table>(std::move(cols));

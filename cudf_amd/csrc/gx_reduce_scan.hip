@@ -310,6 +310,23 @@ int scan_float(const void* in, const uint32_t* valid, int64_t n, int op, int inc
 }
 
 // ---------------------------------------------------------------- segmented scan
+// COUNT scans (cpp/src/groupby/sort/group_count_scan.cu:24-62): the scanned value is 1 per row (COUNT_ALL) or the
+// row's validity (COUNT_VALID); the values themselves are never read
+struct SegCountLoader {
+  const uint32_t* valid;  // NULL: every row counts
+  const uint8_t* heads;
+  __device__ __forceinline__ Seg<int32_t> operator()(int64_t i) const
+  {
+    return Seg<int32_t>{(valid && !bit_is_set(valid, i)) ? 0 : 1, heads[i], 0u};
+  }
+};
+static int seg_count(const uint32_t* valid, const uint8_t* heads, int64_t n, void* out, void* partials, hipStream_t s)
+{
+  SegCountLoader ld{valid, heads};
+  return scan::device_scan<Seg<int32_t>, int32_t>(ld, n, Seg<int32_t>{0, 0u, 0u}, SegOp<int32_t, SumOp>{SumOp()}, true,
+                                                  static_cast<int32_t*>(out), static_cast<Seg<int32_t>*>(partials), s);
+}
+
 template <typename InT, typename AccT, typename OutT, typename Op>
 int seg_typed(const void* vals, const uint32_t* valid, const uint8_t* heads, int64_t n, AccT identity, Op op,
               void* out, Seg<AccT>* partials, hipStream_t s)
@@ -548,9 +565,11 @@ int gx_segmented_scan(int key_dtype, const void* sorted_keys, int val_dtype, con
   }
   if (*tmp_bytes < c.total()) return GX_ETMP;
   if (n == 0) return 0;
-  if (!sorted_keys || !vals || !out) return GX_EINVAL;
+  const bool counting = op == GX_OP_COUNT_VALID || op == GX_OP_COUNT_ALL;
+  if (!sorted_keys || (!vals && !counting) || !out) return GX_EINVAL;
   int rc = heads_dispatch(key_dtype, sorted_keys, n, heads, s);
   if (rc) return rc;
+  if (counting) return seg_count(op == GX_OP_COUNT_ALL ? nullptr : vals_valid, heads, n, out, partials, s);
   switch (val_dtype) {
     case GX_INT8: return seg_int<int8_t, true>(vals, vals_valid, heads, n, op, out, partials, s);
     case GX_INT16: return seg_int<int16_t, true>(vals, vals_valid, heads, n, op, out, partials, s);

@@ -89,7 +89,7 @@ struct SortPlan {
   int32_t pass_src[MAX_PASSES];  // buffer selector: 0 = input, 1 = output (A), 2 = scratch (B)
   int32_t pass_dst[MAX_PASSES];
   int32_t num_active;
-  int32_t status;  // 0 ok, 1 look-back spin timed out, 3 hybrid bookkeeping mismatch
+  int32_t status;  // 0 ok, 3 hybrid bookkeeping mismatch (the LSD passes then produced the output); a look-back spin that times out traps
   HybridPlan hy;
   SortCounters cnt;
 };
@@ -526,11 +526,7 @@ __global__ void __launch_bounds__(BT, 4) k_radix_pass(PassArgs a)
               unsigned long long x = v[k];
               uint32_t spins       = 0;
               while ((x >> 62) == 0 || ((unsigned)(x >> 32) & 0xFFu) != epoch) {
-                if (++spins > SPIN_LIMIT) {
-                  atomicExch(&plan->status, 1);
-                  x = pack_status(2u, epoch, 0u);
-                  break;
-                }
+                if (++spins > SPIN_LIMIT) __builtin_trap();  // broken forward progress: fail the STREAM, never return a wrong order
                 __builtin_amdgcn_s_sleep(2);
                 x = load_agent_u64(&a.status[(p - k) * BINS + tid]);
               }
@@ -877,11 +873,7 @@ __global__ void __launch_bounds__(BT, (KPT <= 8 ? 8 : (KPT <= 12 ? 6 : 4))) k_ms
             unsigned long long x = v[k];
             uint32_t spins       = 0;
             while ((x >> 62) == 0 || ((unsigned)(x >> 32) & 0xFFu) != epoch) {
-              if (++spins > SPIN_LIMIT) {
-                atomicExch(&plan->status, 1);
-                x = pack_status(2u, epoch, 0u);
-                break;
-              }
+              if (++spins > SPIN_LIMIT) __builtin_trap();  // as above
               __builtin_amdgcn_s_sleep(2);
               x = load_agent_u64(&a.status[(p - k) * NB + tid]);
             }

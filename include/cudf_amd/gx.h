@@ -455,7 +455,9 @@ int gx_mean_from_sum(int sum_dtype, const void* sum, const int32_t* count, int64
 /* Segmented inclusive scan over sorted group labels: replaces thrust::inclusive_scan_by_key at
  * src/groupby/sort/group_scan_util.cuh:109-130 (groupby::scan SUM/MIN/MAX).  keys are the
  * (already sorted) key column; out[i] = op over the rows of the same key run up to i.
- * Null values (vals_valid bit 0) contribute the identity. Integer SUM accumulates in int64. */
+ * Null values (vals_valid bit 0) contribute the identity. Integer SUM accumulates in int64.
+ * op GX_OP_COUNT_VALID / GX_OP_COUNT_ALL (sort/group_count_scan.cu:24-62): out is INT32, out[i] = valid rows (all
+ * rows) of the run up to and including i; `vals` is not read and may be NULL. */
 int gx_segmented_scan(int key_dtype, const void* sorted_keys, int val_dtype, const void* vals,
                       const uint32_t* vals_valid, int64_t n, int op, void* out, void* tmp,
                       size_t* tmp_bytes, gx_stream_t stream);

@@ -593,6 +593,304 @@ def groupby_scan_sum(keys: np.ndarray, values: np.ndarray, keys_valid=None, valu
 
 
 # ----------------------------------------------------------------------------------------------
+# sort-path groupby, groupby::scan COUNT / MIN / MAX, get_groups / shift / replace_nulls  
+# ----------------------------------------------------------------------------------------------
+
+
+def _group_sort(keys, keys_valid=None, include_null_keys=False, keys_sorted=False):
+    """The reference's sort helper (cpp/src/groupby/sort/sort_helper.cu:73-162): the stable order of the key column with
+    nulls AFTER (:92-94) -- rows with a null key are dropped under null_policy::EXCLUDE (pushed to the end and cut off,
+    :113-135) and form the LAST group under INCLUDE -- plus group labels / offsets of the kept rows in that order
+    (:151-214).  Pre-sorted keys (sorted::YES) keep their order.  Returns (order, labels, offsets)."""
+    keys = np.asarray(keys)
+    n = len(keys)
+    kv = np.ones(n, bool) if keys_valid is None else np.asarray(keys_valid, bool)
+    if keys_sorted and (include_null_keys or bool(kv.all())):
+        order = np.arange(n, dtype=np.int64)
+    else:
+        order = sorted_order(keys, kv, True, False).astype(np.int64)  # nulls AFTER
+        if not include_null_keys:
+            order = order[: int(kv.sum())]
+    m = len(order)
+    if m == 0:
+        return order, np.zeros(0, np.int32), np.zeros(1, np.int32)
+    jk = _join_key(keys[order])
+    okv = kv[order]
+    same = (jk[1:] == jk[:-1]) & okv[1:] & okv[:-1]
+    same |= ~okv[1:] & ~okv[:-1]  # null == null: the null keys are one group
+    head = np.concatenate([[True], ~same])
+    labels = (np.cumsum(head) - 1).astype(np.int32)
+    offsets = np.append(np.nonzero(head)[0], m).astype(np.int32)
+    return order, labels, offsets
+
+
+def groupby_sort_agg(keys, values, agg: str, keys_valid=None, values_valid=None, include_null_keys=False,
+                     keys_sorted=False, n_th: int = 0):
+    """cudf::groupby::aggregate on the SORT path (cpp/src/groupby/sort/aggregate.cpp:94-142,276-301,879-903;
+    group_single_pass_reduction_util.cuh:133-200; group_count.cu:25-89; group_nth_element.cu:30-80): keys come out
+    sorted (null key group last), one result per group.  agg in sum / product / min / max / count_valid / count_all /
+    nth.  SUM and PRODUCT of integers are int64 and wrap (aggregation.hpp:949-970), floats keep their type; MIN / MAX
+    keep the input type; a group without a valid value is null (:185-195).  NTH_ELEMENT (null_policy::INCLUDE): the
+    value at group start + n (group end + n for n < 0), null when the group is shorter or the row is null.
+    Returns (unique_keys, unique_keys_valid, result, result_valid); float sums are the correctly rounded ones."""
+    keys, values = np.asarray(keys), np.asarray(values)
+    n = len(keys)
+    kv = np.ones(n, bool) if keys_valid is None else np.asarray(keys_valid, bool)
+    vv = np.ones(n, bool) if values_valid is None else np.asarray(values_valid, bool)
+    order, labels, offsets = _group_sort(keys, kv, include_null_keys, keys_sorted)
+    g = len(offsets) - 1
+    first = order[offsets[:-1]] if g else order[:0]
+    ukeys, ukv = keys[first], kv[first]
+    sv, svv = values[order], vv[order]
+    cnt = np.bincount(labels[svv], minlength=g).astype(np.int32) if g else np.zeros(0, np.int32)
+    has = cnt > 0
+    isf = values.dtype.kind == "f"
+    if agg == "count_valid":
+        return ukeys, ukv, cnt, np.ones(g, bool)
+    if agg == "count_all":
+        return ukeys, ukv, np.diff(offsets).astype(np.int32), np.ones(g, bool)
+    if agg == "nth":
+        sizes = np.diff(offsets)
+        j = np.where(n_th >= 0, n_th, sizes + n_th)
+        ok = (j >= 0) & (j < sizes)
+        pos = np.where(ok, offsets[:-1] + j, 0)
+        out = sv[pos] if g else sv[:0]
+        return ukeys, ukv, out, ok & (svv[pos] if g else ok)
+    if agg == "sum":
+        if isf:
+            out = _exact_group_sums(labels[svv], sv[svv].astype(np.float64), g).astype(values.dtype)
+        else:
+            acc = np.zeros(g, np.uint64)
+            np.add.at(acc, labels[svv], sv[svv].astype(np.int64).view(np.uint64))
+            out = acc.view(np.int64)
+        return ukeys, ukv, out, has
+    if agg == "product":
+        if isf:
+            out = np.ones(g, np.float64)
+            np.multiply.at(out, labels[svv], sv[svv].astype(np.float64))
+            out = out.astype(values.dtype)
+        else:
+            acc = np.ones(g, np.uint64)
+            with np.errstate(over="ignore"):
+                np.multiply.at(acc, labels[svv], sv[svv].astype(np.int64).view(np.uint64))
+            out = acc.view(np.int64)
+        return ukeys, ukv, out, has
+    if agg in ("min", "max"):
+        out = np.zeros(g, values.dtype)
+        fill, lab = sv[svv], labels[svv]
+        if len(fill):
+            o2 = np.lexsort((sortable_bits(fill), lab))
+            b = np.searchsorted(lab[o2], np.arange(g + 1))
+            sel = np.where(has, b[:-1] if agg == "min" else np.maximum(b[1:] - 1, 0), 0)
+            out = np.where(has, fill[o2][np.minimum(sel, len(fill) - 1)], 0).astype(values.dtype)
+        return ukeys, ukv, out, has
+    raise ValueError(agg)
+
+
+def groupby_scan(keys, values, op: str, keys_valid=None, values_valid=None, include_null_keys=False, keys_sorted=False):
+    """groupby::scan (cpp/src/groupby/sort/scan.cpp:60-238): rows in sorted-key order, per-group INCLUSIVE scan.
+    sum / min / max (group_scan_util.cuh:77-133): null values are skipped and stay null, integer SUM in int64;
+    count_valid / count_all (group_count_scan.cu:24-62): INT32, never null, count of valid / all rows so far.
+    Returns (sorted_keys, out, out_valid)."""
+    keys, values = np.asarray(keys), np.asarray(values)
+    n = len(keys)
+    vv = np.ones(n, bool) if values_valid is None else np.asarray(values_valid, bool)
+    order, labels, offsets = _group_sort(keys, keys_valid, include_null_keys, keys_sorted)
+    sk, sv, svv = keys[order], values[order], vv[order]
+    m = len(order)
+    if op in ("count_valid", "count_all"):
+        x = svv.astype(np.int64) if op == "count_valid" else np.ones(m, np.int64)
+        c = np.cumsum(x)
+        base = np.concatenate([[0], c])[offsets[:-1]] if m else c
+        out = (c - base[labels]).astype(np.int32) if m else np.zeros(0, np.int32)
+        return sk, out, np.ones(m, bool)
+    isf = values.dtype.kind == "f"
+    import pandas as pd  # segmented cumulative ops at C speed; the semantics are spelled out above
+    if op == "sum":
+        if isf:  # running sum inside each group, in row order (any association is within the tests' tolerance)
+            out = pd.Series(np.where(svv, sv, 0).astype(np.float64)).groupby(labels).cumsum().to_numpy().astype(values.dtype)
+        else:  # int64, wrapping: global wrapping prefix sum minus the prefix at the group start
+            c = np.cumsum(np.where(svv, sv, 0).astype(np.int64).view(np.uint64))
+            base = np.concatenate([np.zeros(1, np.uint64), c])[offsets[:-1]] if m else c
+            out = (c - base[labels]).view(np.int64) if m else np.zeros(0, np.int64)
+        return sk, out, svv
+    if op in ("min", "max"):
+        if m == 0:
+            return sk, sv.copy(), svv
+        if isf:
+            ident = np.inf if op == "min" else -np.inf
+        else:
+            ident = np.iinfo(values.dtype).max if op == "min" else np.iinfo(values.dtype).min
+        x = pd.Series(np.where(svv, sv, ident))
+        gb = x.groupby(labels)
+        out = (gb.cummin() if op == "min" else gb.cummax()).to_numpy().astype(values.dtype)
+        return sk, out, svv
+    raise ValueError(op)
+
+
+def groupby_get_groups(keys, values, keys_valid=None, include_null_keys=False):
+    """groupby::get_groups (cpp/src/groupby/groupby.cu:261-283): (sorted keys, values gathered in that order, offsets)."""
+    order, _, offsets = _group_sort(keys, keys_valid, include_null_keys)
+    return np.asarray(keys)[order], np.asarray(values)[order], offsets
+
+
+def groupby_shift(keys, values, offset: int, fill=None, keys_valid=None, values_valid=None):
+    """groupby::shift (cpp/src/groupby/groupby.cu:306-346 -> segmented_shift, cpp/src/copying/segmented_shift.cu):
+    in sorted-key order, out[i] = in[i - offset] when that row lies in the same group, else the fill scalar
+    (fill None = null).  Returns (sorted_keys, out, out_valid)."""
+    keys, values = np.asarray(keys), np.asarray(values)
+    n = len(keys)
+    vv = np.ones(n, bool) if values_valid is None else np.asarray(values_valid, bool)
+    order, labels, offsets = _group_sort(keys, keys_valid)
+    sv, svv = values[order], vv[order]
+    m = len(order)
+    idx = np.arange(m, dtype=np.int64) - offset
+    lo, hi = offsets[:-1][labels], offsets[1:][labels]
+    inside = (idx >= lo) & (idx < hi)
+    src = np.clip(idx, 0, max(m - 1, 0))
+    out = np.where(inside, sv[src] if m else sv, values.dtype.type(0 if fill is None else fill))
+    ov = np.where(inside, svv[src] if m else svv, fill is not None)
+    return keys[order], out.astype(values.dtype), ov
+
+
+def groupby_replace_nulls(keys, values, values_valid, following: bool, keys_valid=None):
+    """groupby::replace_nulls (cpp/src/groupby/groupby.cu:285-321, sort/group_replace_nulls.cu): in sorted-key order a
+    null takes the nearest valid value of ITS group before it (PRECEDING) or after it (FOLLOWING), else stays null."""
+    keys, values = np.asarray(keys), np.asarray(values)
+    vv = np.asarray(values_valid, bool)
+    order, labels, offsets = _group_sort(keys, keys_valid)
+    sv, svv = values[order].copy(), vv[order].copy()
+    for s, e in zip(offsets[:-1], offsets[1:]):
+        rng = range(s, e) if not following else range(e - 1, s - 1, -1)
+        last = -1
+        for i in rng:
+            if svv[i]:
+                last = i
+            elif last >= 0:
+                sv[i] = sv[last]
+                svv[i] = True
+    return keys[order], sv, svv
+
+
+# ----------------------------------------------------------------------------------------------
+# rank / top_k / segmented sort  (SURVEY §8 f4)
+# ----------------------------------------------------------------------------------------------
+
+RANK_FIRST, RANK_AVERAGE, RANK_MIN, RANK_MAX, RANK_DENSE = range(5)  # cudf::rank_method (aggregation.hpp:37-43)
+
+
+def rank(values, valid=None, method: int = RANK_FIRST, ascending=True, null_include=False, null_before=False,
+         percentage=False):
+    """cudf::rank (cpp/src/sort/rank.cu:59-369).  Rows are ranked by their 1-based position in the (stable) sorted order
+    of the column -- nulls take part in that order wherever null_precedence puts them (:290-296); rows that compare equal
+    (null == null, NaN == NaN, -0.0 == +0.0: the row equality comparator, :59-97) form a tie group: FIRST = the
+    position itself, MIN / MAX = first / last position of the group, AVERAGE = min + (count - 1) / 2 (:236-257),
+    DENSE = 1 + number of distinct groups before.  null_policy::EXCLUDE: the output carries the input's null mask
+    (:275-284; the masked values are unspecified).  percentage (:343-360): r / count of ranked rows
+    (EXCLUDE: non-null rows), DENSE: r / dense rank of sorted position count - 1.  INT32, or FLOAT64 for AVERAGE /
+    percentage.  Returns (ranks, out_valid)."""
+    v = np.asarray(values)
+    n = len(v)
+    ok = np.ones(n, bool) if valid is None else np.asarray(valid, bool)
+    order = sorted_order(v, ok, ascending, null_before).astype(np.int64)
+    sb = sortable_bits(v)[order]
+    so = ok[order]
+    if n:
+        same = ((sb[1:] == sb[:-1]) & so[1:] & so[:-1]) | (~so[1:] & ~so[:-1])
+        head = np.concatenate([[True], ~same])
+    else:
+        head = np.zeros(0, bool)
+    dense = np.cumsum(head)  # 1-based dense rank in sorted order
+    pos = np.arange(1, n + 1)
+    starts = np.nonzero(head)[0]
+    ends = np.append(starts[1:], n)
+    gid = dense - 1
+    if method == RANK_FIRST:
+        r = pos.astype(np.float64)
+    elif method == RANK_DENSE:
+        r = dense.astype(np.float64)
+    elif method == RANK_MIN:
+        r = (starts[gid] + 1).astype(np.float64)
+    elif method == RANK_MAX:
+        r = ends[gid].astype(np.float64)
+    elif method == RANK_AVERAGE:
+        r = (starts[gid] + 1) + ((ends - starts)[gid] - 1) / 2.0
+    else:
+        raise ValueError(method)
+    if percentage:
+        count = int(ok.sum()) if not null_include else n
+        denom = float(dense[count - 1]) if (method == RANK_DENSE and count > 0) else float(count)
+        with np.errstate(divide="ignore", invalid="ignore"):
+            r = r / denom
+    out = np.empty(n, np.float64)
+    out[order] = r
+    if not (percentage or method == RANK_AVERAGE):
+        out = out.astype(np.int32)
+    return out, (np.ones(n, bool) if null_include else ok.copy())
+
+
+def top_k(values, k: int, descending=True, valid=None):
+    """cudf::top_k / top_k_order (cpp/src/sort/top_k.cu:104-150).  k >= size: the column itself / iota (:112,:139-145).
+    Otherwise the first k rows of the stable sorted order with nulls never making the top (:121-123); the reference's
+    fast path (no nulls, integers: cub::DeviceTopK, :47-74) promises neither order nor tie choice, so the checkable
+    contract is the MULTISET of the k values.  Returns (values in this oracle's order, their rows, valid flags)."""
+    v = np.asarray(values)
+    n = len(v)
+    ok = np.ones(n, bool) if valid is None else np.asarray(valid, bool)
+    if k == 0 or n == 0:
+        return v[:0], np.zeros(0, np.int32), ok[:0]
+    if k >= n:
+        idx = np.arange(n, dtype=np.int32)
+        return v.copy(), idx, ok.copy()
+    idx = sorted_order(v, ok, not descending, descending)[:k]  # ascending: nulls AFTER, descending: nulls BEFORE
+    return v[idx], idx.astype(np.int32), ok[idx]
+
+
+def segmented_sorted_order(key_cols, offsets, valids=None, ascending=None, null_before=None):
+    """cudf::stable_segmented_sorted_order (cpp/src/sort/segmented_sort_impl.cuh:178-203,265-293): every row gets a
+    segment id -- rows of [offsets[j], offsets[j+1]) share one, rows outside every segment each their own, ascending
+    with the row -- and the table (segment id, keys...) is sorted lexicographically and stably.  Defaults: all
+    ASCENDING, nulls BEFORE (sorting.hpp:33-38)."""
+    cols = [np.asarray(c) for c in key_cols]
+    n = len(cols[0])
+    nc = len(cols)
+    valids = [None] * nc if valids is None else valids
+    ascending = [True] * nc if ascending is None else ascending
+    null_before = [True] * nc if null_before is None else null_before
+    offsets = np.asarray(offsets, np.int64)
+    ids = np.arange(n, dtype=np.int64)  # rows outside every segment: unique, in place
+    for j in range(len(offsets) - 1):
+        ids[offsets[j] : offsets[j + 1]] = offsets[j + 1]
+    if len(offsets):
+        ids[: offsets[0]] = np.arange(offsets[0])
+        tail = np.arange(offsets[-1], n)
+        ids[offsets[-1] :] = tail + 1 if len(tail) else tail
+    order = np.arange(n, dtype=np.int64)
+    for c in range(nc - 1, -1, -1):  # LSD over the columns, each pass stable
+        ok = np.ones(n, bool) if valids[c] is None else np.asarray(valids[c], bool)
+        sub = sorted_order(cols[c][order], ok[order], ascending[c], null_before[c]).astype(np.int64)
+        order = order[sub]
+    order = order[np.argsort(ids[order], kind="stable")]
+    return order.astype(np.int32)
+
+
+def join_match_counts(left, right, kind: str = "inner", left_valid=None, right_valid=None, nulls_equal=True):
+    """hash_join::{inner,left,full}_join_match_context (cpp/include/cudf/join/hash_join.hpp:259-340;
+    cpp/src/join/hash_join/size_impl.cuh:26-62): matching right rows per left row; left / full: at least 1 (the row is
+    emitted with JoinNoMatch).  A null left key matches the null right keys iff nulls_equal."""
+    left, right = np.asarray(left), np.asarray(right)
+    lv = np.ones(len(left), bool) if left_valid is None else np.asarray(left_valid, bool)
+    rv = np.ones(len(right), bool) if right_valid is None else np.asarray(right_valid, bool)
+    rk = np.sort(_join_key(right[rv]))
+    lk = _join_key(left)
+    c = (np.searchsorted(rk, lk, "right") - np.searchsorted(rk, lk, "left")).astype(np.int64)
+    c[~lv] = int((~rv).sum()) if nulls_equal else 0
+    if kind in ("left", "full"):
+        c = np.maximum(c, 1)
+    return c.astype(np.int32)
+
+
+# ----------------------------------------------------------------------------------------------
 # reduce / scan (SURVEY §8 a13-a14)
 # ----------------------------------------------------------------------------------------------
 

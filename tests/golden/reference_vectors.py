@@ -332,3 +332,89 @@ def col(values, dtype, valid=None):
     else:
         arr = np.array(vals, dtype=dt)
     return arr, mask
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# sort-path groupby / groupby::scan COUNT / shift / replace_nulls / top_k / segmented sort
+# transcribed from the reference's tests; rank vectors are in rank_vectors.json (make_rank_vectors.py)
+# ---------------------------------------------------------------------------------------------------------------------
+GROUPBY_SORT = [
+    # cpp/tests/groupby/product_tests.cpp:24-45 (basic)
+    dict(name="product_basic", agg="product", keys=_K_BASIC, vals=_V_BASIC, expect_keys=[1, 2, 3], expect=[0, 180, 112],
+         expect_valid=[1, 1, 1]),
+    # cpp/tests/groupby/product_tests.cpp:104-128 (null_keys_and_values)
+    dict(name="product_null_keys_and_values", agg="product", keys=_K_NULL, keys_valid=_KM_NULL,
+         vals=[0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 3], vals_valid=_VM_NULL, expect_keys=[1, 2, 3, 4], expect=[18, 36, 16, 3],
+         expect_valid=[1, 1, 1, 0]),
+    # cpp/tests/groupby/nth_element_tests.cpp:23-48 (basic: n = 0, 1, 2)
+    dict(name="nth0", agg="nth", n=0, keys=_K_BASIC, vals=_V_BASIC, expect_keys=[1, 2, 3], expect=[0, 1, 2], expect_valid=[1, 1, 1]),
+    dict(name="nth1", agg="nth", n=1, keys=_K_BASIC, vals=_V_BASIC, expect_keys=[1, 2, 3], expect=[3, 4, 7], expect_valid=[1, 1, 1]),
+    dict(name="nth2", agg="nth", n=2, keys=_K_BASIC, vals=_V_BASIC, expect_keys=[1, 2, 3], expect=[6, 5, 8], expect_valid=[1, 1, 1]),
+    # cpp/tests/groupby/nth_element_tests.cpp:82-107 (negative: n = -1, -2, -3)
+    dict(name="nth-1", agg="nth", n=-1, keys=_K_BASIC, vals=_V_BASIC, expect_keys=[1, 2, 3], expect=[6, 9, 8], expect_valid=[1, 1, 1]),
+    dict(name="nth-2", agg="nth", n=-2, keys=_K_BASIC, vals=_V_BASIC, expect_keys=[1, 2, 3], expect=[3, 5, 7], expect_valid=[1, 1, 1]),
+    dict(name="nth-3", agg="nth", n=-3, keys=_K_BASIC, vals=_V_BASIC, expect_keys=[1, 2, 3], expect=[0, 4, 2], expect_valid=[1, 1, 1]),
+    # cpp/tests/groupby/nth_element_tests.cpp:157-176, 178-197 (null keys and values; n = 0, n = 2 out of bounds)
+    dict(name="nth0_nulls", agg="nth", n=0, keys=_K_NULL, keys_valid=_KM_NULL, vals=_V_NULL, vals_valid=_VM_NULL,
+         expect_keys=[1, 2, 3, 4], expect=[-1, 1, 2, -1], expect_valid=[0, 1, 1, 0]),
+    dict(name="nth2_nulls_oob", agg="nth", n=2, keys=_K_NULL, keys_valid=_KM_NULL, vals=_V_NULL, vals_valid=_VM_NULL,
+         expect_keys=[1, 2, 3, 4], expect=[6, -1, -1, -1], expect_valid=[1, 0, 0, 0]),
+]
+
+GROUPBY_COUNT_SCAN = [
+    # cpp/tests/groupby/count_scan_tests.cpp:39-60 (basic: both null policies give the same counts)
+    dict(name="basic", keys=_K_BASIC, vals=_V_BASIC, expect_keys=[1, 1, 1, 2, 2, 2, 2, 3, 3, 3],
+         expect_valid_count=[1, 2, 3, 1, 2, 3, 4, 1, 2, 3], expect_all_count=[1, 2, 3, 1, 2, 3, 4, 1, 2, 3]),
+    # cpp/tests/groupby/count_scan_tests.cpp:100-118 (zero_valid_values)
+    dict(name="zero_valid_values", keys=[1, 1, 1], vals=[3, 4, 5], vals_valid=[0, 0, 0], expect_keys=[1, 1, 1],
+         expect_valid_count=[0, 0, 0], expect_all_count=[1, 2, 3]),
+    # cpp/tests/groupby/count_scan_tests.cpp:120-145 (null_keys_and_values)
+    dict(name="null_keys_and_values", keys=_K_NULL, keys_valid=_KM_NULL, vals=_V_NULL, vals_valid=_VM_NULL,
+         expect_keys=[1, 1, 1, 2, 2, 2, 2, 3, 3, 4], expect_valid_count=[0, 1, 2, 1, 2, 2, 3, 1, 2, 0],
+         expect_all_count=[1, 2, 3, 1, 2, 3, 4, 1, 2, 1]),
+]
+
+_SHIFT_K = [1, 2, 1, 2, 2, 1, 1, 2, 1, 2, 1, 2, 1]
+_SHIFT_V = [3, 4, 5, 6, 7, 8, 9, 0, 1, 2, 3, 4, 5]
+GROUPBY_SHIFT = [
+    # cpp/tests/groupby/shift_tests.cpp:64-77 (ForwardShiftWithoutNull_ValidScalar)
+    dict(name="forward3_fill42", keys=_SHIFT_K, vals=_SHIFT_V, offset=3, fill=42,
+         expect=[42, 42, 42, 3, 5, 8, 9, 42, 42, 42, 4, 6, 7], expect_valid=[1] * 13),
+    # cpp/tests/groupby/shift_tests.cpp:79-94 (ForwardShiftWithNull_ValidScalar)
+    dict(name="forward3_nulls_fill42", keys=_SHIFT_K, vals=_SHIFT_V, vals_valid=[1, 0, 1, 0, 1, 0, 0, 1, 0, 1, 1, 0, 1], offset=3, fill=42,
+         expect=[42, 42, 42, 3, 5, -1, -1, 42, 42, 42, -1, -1, 7], expect_valid=[1, 1, 1, 1, 1, 0, 0, 1, 1, 1, 0, 0, 1]),
+    # cpp/tests/groupby/shift_tests.cpp:96-109 (BackwardShiftWithoutNull_NullScalar)
+    dict(name="backward1_nullfill", keys=[1, 2, 1, 2, 2, 1, 1], vals=[3, 4, 5, 6, 7, 8, 9], offset=-1, fill=None,
+         expect=[5, 8, 9, -1, 6, 7, -1], expect_valid=[1, 1, 1, 0, 1, 1, 0]),
+]
+
+GROUPBY_REPLACE_NULLS = [
+    # cpp/tests/groupby/replace_nulls_tests.cpp:40-56 (PrecedingFill)
+    dict(name="preceding", keys=[0, 1, 0, 1, 0, 1], vals=[42, 7, 24, 10, 1, 1000], vals_valid=[1, 1, 1, 0, 0, 0], following=False,
+         expect_keys=[0, 0, 0, 1, 1, 1], expect=[42, 24, 24, 7, 7, 7], expect_valid=[1, 1, 1, 1, 1, 1]),
+    # cpp/tests/groupby/replace_nulls_tests.cpp:58-75 (FollowingFill)
+    dict(name="following", keys=[0, 0, 1, 1, 0, 1, 1, 1], vals=[2, 4, 8, 16, 32, 64, 128, 256], vals_valid=[1, 0, 1, 0, 1, 0, 1, 1],
+         following=True, expect_keys=[0, 0, 0, 1, 1, 1, 1, 1], expect=[2, 32, 32, 8, 128, 128, 128, 256], expect_valid=[1] * 8),
+    # cpp/tests/groupby/replace_nulls_tests.cpp:77-93 (PrecedingFillLeadingNulls)
+    dict(name="preceding_leading_nulls", keys=[0, 1, 0, 1, 0, 1], vals=[42, 7, 24, 10, 1, 1000], vals_valid=[0, 0, 1, 0, 0, 0],
+         following=False, expect_keys=[0, 0, 0, 1, 1, 1], expect=[-1, 24, 24, -1, -1, -1], expect_valid=[0, 1, 1, 0, 0, 0]),
+    # cpp/tests/groupby/replace_nulls_tests.cpp:95-112 (FollowingFillTrailingNulls)
+    dict(name="following_trailing_nulls", keys=[0, 0, 1, 1, 0, 1, 1, 1], vals=[2, 4, 8, 16, 32, 64, 128, 256],
+         vals_valid=[1, 0, 0, 0, 0, 1, 0, 0], following=True, expect_keys=[0, 0, 0, 1, 1, 1, 1, 1],
+         expect=[2, -1, -1, 64, 64, 64, -1, -1], expect_valid=[1, 0, 0, 1, 1, 1, 0, 0]),
+]
+
+# cpp/tests/sort/segmented_sort_tests.cpp:70-104 (NoNull: col1, col2, segments) and :141-157 (partial offsets)
+_SEG_C1 = [10, 36, 14, 32, 49, 23, 10, 34, 12, 45, 12, 37, 43, 26, 21, 16]
+_SEG_C2 = [10, 63, 41, 23, 94, 32, 10, 43, 21, 54, 22, 73, 34, 62, 12, 61]
+_SEG_OFF = [0, 3, 5, 5, 5, 6, 11, 13, 14, 16]
+SEGMENTED_SORT = [
+    dict(name="asc", cols=[_SEG_C1], offsets=_SEG_OFF, ascending=[True],
+         expect_col0=[10, 14, 36, 32, 49, 23, 10, 12, 12, 34, 45, 37, 43, 26, 16, 21]),
+    dict(name="desc", cols=[_SEG_C1], offsets=_SEG_OFF, ascending=[False],
+         expect_col0=[36, 14, 10, 49, 32, 23, 45, 34, 12, 12, 10, 43, 37, 26, 21, 16]),
+    dict(name="two_cols_asc_desc", cols=[_SEG_C1, _SEG_C2], offsets=_SEG_OFF, ascending=[True, False],
+         expect_col1=[10, 41, 63, 23, 94, 32, 10, 22, 21, 43, 54, 73, 34, 62, 61, 12]),
+    dict(name="partial_offsets", cols=[_SEG_C1], offsets=[3, 7], ascending=[True],
+         expect_order=[0, 1, 2, 6, 5, 3, 4, 7, 8, 9, 10, 11, 12, 13, 14, 15]),
+]

@@ -1,6 +1,7 @@
 """Pins the CPU oracle (oracle/) against the reference's own golden vectors and the published
 MurmurHash3 KATs.  CPU only."""
 import math
+import os
 
 import numpy as np
 import pytest
@@ -202,3 +203,108 @@ def test_reduce_golden(case, dtype):
     assert ok == case["expect_valid"]
     if ok:
         assert r == case["expect"]
+
+
+# ---- round 3: the oracle restatements behind the at-scale parity tests of rank / top_k / segmented sort /
+# sort-path groupby / groupby::scan COUNT / shift / replace_nulls are pinned to the reference's own literals
+def test_rank_oracle_matches_every_reference_rank_vector():
+    import json
+    d = json.load(open(os.path.join(os.path.dirname(__file__), "golden", "rank_vectors.json")))
+    assert len(d["cases"]) == 36  # 5 methods x 6 (order, null policy, null order) + 6 percentage cases
+    v = np.array(d["input"], np.int32)
+    m2 = np.array(d["col2_valid"], bool)
+    for c in d["cases"]:
+        for col, valid in (("col1", None), ("col2", m2)):
+            r, ok = orc.rank(v, valid, c["method"], not c["descending"], c["null_include"], c["null_before"], c["percentage"])
+            ev, e = np.array(c[col + "_valid"], bool), np.array(c[col])
+            np.testing.assert_array_equal(ok, ev, err_msg=f"{c['name']} {col} (rank_test.cpp:{c['line']})")
+            np.testing.assert_allclose(r[ev], e[ev], rtol=1e-15, atol=0, err_msg=f"{c['name']} {col}")
+
+
+@pytest.mark.parametrize("case", gv.GROUPBY_SORT, ids=lambda c: c["name"])
+def test_groupby_sort_path_oracle_matches_reference(case):
+    keys, km = gv.col(case["keys"], "int32", case.get("keys_valid"))
+    for vdtype in ("int32", "int64", "float64"):
+        vals, vm = gv.col(case["vals"], vdtype, case.get("vals_valid"))
+        uk, ukv, out, ov = orc.groupby_sort_agg(keys, vals, case["agg"], km, vm, n_th=case.get("n", 0))
+        np.testing.assert_array_equal(uk, np.array(case["expect_keys"], np.int32))
+        ev = np.array(case["expect_valid"], bool)
+        np.testing.assert_array_equal(ov, ev)
+        np.testing.assert_array_equal(out[ev], np.array(case["expect"])[ev].astype(out.dtype))
+        if case["agg"] == "product":  # integers -> int64, floats keep their type (aggregation.hpp:949-970)
+            assert out.dtype == (np.float64 if vdtype == "float64" else np.int64)
+
+
+@pytest.mark.parametrize("case", gv.GROUPBY_COUNT_SCAN, ids=lambda c: c["name"])
+def test_groupby_count_scan_oracle_matches_reference(case):
+    keys, km = gv.col(case["keys"], "int32", case.get("keys_valid"))
+    vals, vm = gv.col(case["vals"], "int32", case.get("vals_valid"))
+    for op, key in (("count_valid", "expect_valid_count"), ("count_all", "expect_all_count")):
+        sk, out, ov = orc.groupby_scan(keys, vals, op, km, vm)
+        np.testing.assert_array_equal(sk, np.array(case["expect_keys"], np.int32))
+        np.testing.assert_array_equal(out, np.array(case[key], np.int32))
+        assert out.dtype == np.int32 and bool(ov.all())
+
+
+@pytest.mark.parametrize("case", gv.GROUPBY_SCAN, ids=lambda c: c["name"])
+def test_general_groupby_scan_oracle_agrees_with_the_sum_scan_vectors(case):
+    keys, km = gv.col(case["keys"], "int32", case.get("keys_valid"))
+    vals, vm = gv.col(case["vals"], "int64", case.get("vals_valid"))
+    sk, out, ov = orc.groupby_scan(keys, vals, "sum", km, vm)
+    np.testing.assert_array_equal(sk, np.array(case["expect_keys"], np.int32))
+    ev = np.array(case["expect_valid"], bool)
+    np.testing.assert_array_equal(ov, ev)
+    np.testing.assert_array_equal(out[ev], np.array(case["expect"])[ev])
+
+
+@pytest.mark.parametrize("case", gv.GROUPBY_SHIFT, ids=lambda c: c["name"])
+def test_groupby_shift_oracle_matches_reference(case):
+    keys, _ = gv.col(case["keys"], "int32")
+    vals, vm = gv.col(case["vals"], "int32", case.get("vals_valid"))
+    _, out, ov = orc.groupby_shift(keys, vals, case["offset"], case["fill"], None, vm)
+    ev = np.array(case["expect_valid"], bool)
+    np.testing.assert_array_equal(ov, ev)
+    np.testing.assert_array_equal(out[ev], np.array(case["expect"], np.int32)[ev])
+
+
+@pytest.mark.parametrize("case", gv.GROUPBY_REPLACE_NULLS, ids=lambda c: c["name"])
+def test_groupby_replace_nulls_oracle_matches_reference(case):
+    keys, _ = gv.col(case["keys"], "int32")
+    vals, vm = gv.col(case["vals"], "int32", case["vals_valid"])
+    sk, out, ov = orc.groupby_replace_nulls(keys, vals, vm, case["following"])
+    np.testing.assert_array_equal(sk, np.array(case["expect_keys"], np.int32))
+    ev = np.array(case["expect_valid"], bool)
+    np.testing.assert_array_equal(ov, ev)
+    np.testing.assert_array_equal(out[ev], np.array(case["expect"], np.int32)[ev])
+
+
+@pytest.mark.parametrize("case", gv.SEGMENTED_SORT, ids=lambda c: c["name"])
+def test_segmented_sort_oracle_matches_reference(case):
+    cols = [np.array(c, np.int32) for c in case["cols"]]
+    order = orc.segmented_sorted_order(cols, case["offsets"], None, case["ascending"], None)
+    if "expect_order" in case:
+        np.testing.assert_array_equal(order, np.array(case["expect_order"], np.int32))
+    if "expect_col0" in case:
+        np.testing.assert_array_equal(cols[0][order], np.array(case["expect_col0"], np.int32))
+    if "expect_col1" in case:
+        np.testing.assert_array_equal(cols[1][order], np.array(case["expect_col1"], np.int32))
+
+
+def test_top_k_and_match_count_oracles_on_the_reference_literals():
+    # cpp/tests/sort/top_k_tests.cpp semantics on the vectors tests/cpp/cudf_api_tests.cpp uses
+    v = np.array([7, -3, 12, 5, 12, 0, 9], np.int64)
+    vals, idx, _ = orc.top_k(v, 3)
+    np.testing.assert_array_equal(vals, [12, 12, 9])
+    np.testing.assert_array_equal(idx, [2, 4, 6])
+    np.testing.assert_array_equal(orc.top_k(v, 2, descending=False)[0], [-3, 0])
+    assert len(orc.top_k(v, 0)[0]) == 0 and len(orc.top_k(v, 100)[0]) == 7
+    np.testing.assert_array_equal(orc.top_k(v, 100)[1], np.arange(7))  # top_k.cu:139-145: k >= size -> iota
+    vn, _, ok = orc.top_k(np.array([1.5, 9.0, 2.5, 7.0]), 2, valid=np.array([1, 0, 1, 1], bool))
+    np.testing.assert_array_equal(vn, [7.0, 2.5])
+    assert bool(ok.all())
+    # match contexts on InnerJoinNoNulls (cpp/tests/join/join_tests.cpp:1163-1237): per-row counts add up to the pairs
+    c = gv.JOIN[0]
+    l, r = np.array(c["left"][0], np.int32), np.array(c["right"][0], np.int32)
+    np.testing.assert_array_equal(orc.join_match_counts(l, r, "inner"), [1, 0, 2, 1, 2])
+    assert int(orc.join_match_counts(l, r, "inner").sum()) == len(c["expected_rows"])
+    np.testing.assert_array_equal(orc.join_match_counts(l, r, "left"), [1, 1, 2, 1, 2])
