@@ -56,6 +56,11 @@ def parse():
     ap.add_argument("--no-partitioned-join", action="store_true", help="join: probe the table directly")
     ap.add_argument("--join-probe-kernel", type=int, default=0, help="join knob: 0 pipelined tag probe, 1 round-1 tag probe")
     ap.add_argument("--join-scatter-tile", type=int, default=0, help="join knob: rows per scatter tile (0 = default)")
+    ap.add_argument("--join-spec", type=int, default=1, help="join knob: 1 hist-free speculative partition (default), 0 round-2 path")
+    ap.add_argument("--join-early-loads", type=int, default=1, help="join knob: pipelined probe requests rows at the top of a trip")
+    ap.add_argument("--join-keys", default="random", choices=["random", "dense"],
+                    help="join: random = SURVEY 8d (build = distinct random 64-bit keys, probe = 30%% drawn from them + 70%% from a "
+                         "disjoint random set); dense = round 2's arithmetic progressions 3i+1 (kept for comparison)")
     ap.add_argument("--no-hybrid", action="store_true", help="sort: disable the hybrid MSD path (LSD passes only)")
     ap.add_argument("--sort-cell", type=int, default=0, help="sort knob: local-sort cell capacity (0 auto, 8192, 16384)")
     ap.add_argument("--sort-lbw", type=int, default=16, help="sort knob: predecessors per look-back round of the partition passes (4, 8, 16)")
@@ -410,15 +415,43 @@ def bench_join(c):
                 "rows": n, "ms_per_step": sec * 1e3, "rows_per_s": n * c.world / sec, "dtype": "int64", "roofline": None,
                 "cpu_baseline": None, "build_ms": build_ms, "partition_bits": None, "matches": int(tot.item()),
                 "checked": "pair count == closed form over all ranks"}
-    # build: distinct keys (a permutation-like bijection of iota), probe: 30% hit rate
-    # (cpp/benchmarks/join/generate_input_tables.cu:24-103: unique build keys, selectivity 0.3)
+    lib.gx_join_set_partition_mode(a.join_spec, a.join_early_loads)
     bk = c.Column.empty(np.int64, nb_rows)
     bkt = c.as_tensor(bk, torch.int64)
     torch.manual_seed(12345 + c.rank)
-    bkt.copy_(torch.randperm(nb_rows, device="cuda") * 3 + 1)  # distinct keys {3i+1}, shuffled
-    pk = ops.random_column(np.int64, n, seed=67890 + c.rank, lo=0, hi=int(nb_rows / 0.3))
-    pkt = c.as_tensor(pk, torch.int64)
-    pkt.mul_(3).add_(1)                                        # hits a build key w.p. 0.3
+    if a.join_keys == "dense":
+        # round 2's keys: arithmetic progressions -- under the table's multiplicative slot hash a low-discrepancy sequence
+        # (near-zero collisions, perfectly even partitions); kept only to show what that flattered
+        bkt.copy_(torch.randperm(nb_rows, device="cuda") * 3 + 1)  # distinct keys {3i+1}, shuffled
+        pk = ops.random_column(np.int64, n, seed=67890 + c.rank, lo=0, hi=int(nb_rows / 0.3))
+        pkt = c.as_tensor(pk, torch.int64)
+        pkt.mul_(3).add_(1)                                        # hits a build key w.p. 0.3
+        is_hit = lambda: pkt < (3 * nb_rows + 1)
+    else:
+        # SURVEY 8d / cpp/benchmarks/join/generate_input_tables.cu:24-103: build = a random permutation of a random SET of
+        # distinct 64-bit keys, probe = selectivity 0.3 drawn uniformly from the build keys, the rest from a disjoint
+        # random set of equal size.  The set is mix64(j), j in [0, 2 * nb_rows): mix64 (the splitmix64 finalizer) is a
+        # bijection of the 64-bit integers, so the values are distinct and look random in every bit; j < nb_rows is the
+        # build set, j >= nb_rows the disjoint one.
+        def lsr_mix64(j):  # logical shifts on int64 tensors: mask off the sign extension
+            x = j
+            x = (x ^ ((x >> 30) & ((1 << 34) - 1))) * (-4658895280553007687)
+            x = (x ^ ((x >> 27) & ((1 << 37) - 1))) * (-7723592293110705685)
+            return x ^ ((x >> 31) & ((1 << 33) - 1))
+
+        bkt.copy_(lsr_mix64(torch.randperm(nb_rows, device="cuda") + (c.rank << 40)))
+        pk = c.Column.empty(np.int64, n)
+        pkt = c.as_tensor(pk, torch.int64)
+        sel = ops.random_column(np.int64, n, seed=67890 + c.rank, lo=0, hi=10)            # < 3: a hit
+        jj = c.as_tensor(ops.random_column(np.int64, n, seed=424242 + c.rank, lo=0, hi=nb_rows), torch.int64)
+        selt = c.as_tensor(sel, torch.int64)
+        jj.add_((selt >= 3).to(torch.int64) * nb_rows).add_(c.rank << 40)
+        hit_mask = selt < 3
+        CH = 1 << 27
+        for s0 in range(0, n, CH):   # in chunks: the mix needs a few temporaries
+            pkt[s0:s0 + CH] = lsr_mix64(jj[s0:s0 + CH])
+        del jj, sel, selt
+        is_hit = lambda: hit_mask
     hj = ops.HashJoin(bk)  # warm-up build (allocations, module load)
     torch.cuda.synchronize()
     tb = time.perf_counter()
@@ -460,7 +493,7 @@ def bench_join(c):
     # ---- guard on the timed output: the number of pairs is the closed form, every pair joins equal keys, and
     # the probe rows that appear are exactly the matching rows (sum and sum of squares of their indices)
     matches = int(cur.item())
-    hit = pkt < (3 * nb_rows + 1)
+    hit = is_hit()
     want = int(hit.sum().item())
     assert matches == want, f"join: {matches} pairs, closed form {want}"
     lt = c.as_tensor(lo, torch.int32)[:matches].to(torch.int64)
@@ -493,7 +526,10 @@ def bench_join(c):
     cpu = None
     if a.cpu and c.rank == 0:
         cpu = cpu_baseline_join(a.cpu_rows or 1e8, a.cpu_rows_pandas)
-    return {"workload": f"{n:.0e}-row int64 probe x {nb_rows:.0e}-row build inner hash join (probe phase timed)", "rows": n,
+    keydesc = ("random distinct 64-bit build keys, probe 30 % from them + 70 % from a disjoint random set (SURVEY 8d)"
+               if a.join_keys == "random" else "dense keys 3i+1 (round-2 distribution)")
+    return {"workload": f"{n:.0e}-row int64 probe x {nb_rows:.0e}-row build inner hash join (probe phase timed), {keydesc}", "rows": n,
+            "join_keys": a.join_keys, "partition_mode": {"speculative": a.join_spec, "early_loads": a.join_early_loads},
             "ms_per_step": ms_per_step, "rows_per_s": n / sec, "dtype": "int64", "build_ms": build_ms,
             "partition_bits": part_bits, "roofline": roofline, "cpu_baseline": cpu,
             "checked": "pairs == closed form; every pair joins equal keys; sum / sum of squares of the matched probe rows"}
@@ -786,14 +822,15 @@ def main():
                                        if c.world > 1 else "1 GPU")},
             "roofline": head["roofline"], "cpu_baseline": head["cpu_baseline"], "checked": head.get("checked"),
         }
-        for k in ("build_ms", "partition_bits", "matches"):
+        for k in ("build_ms", "partition_bits", "matches", "join_keys", "partition_mode"):
             if k in head:
-                line["join_" + k] = head[k]
+                line["join_" + k if not k.startswith("join") else k] = head[k]
         for name, b in blocks.items():
             line[name] = {"config": {"workload": b["workload"]}, "value": b["rows_per_s"], "unit": "rows/s",
                           "ms_per_step": b["ms_per_step"], "steps": args.steps, "warmup": args.warmup, "dtype": b["dtype"],
                           "roofline": b["roofline"], "cpu_baseline": b["cpu_baseline"], "checked": b.get("checked"),
-                          **({"build_ms": b["build_ms"], "partition_bits": b["partition_bits"]} if "build_ms" in b else {})}
+                          **({"build_ms": b["build_ms"], "partition_bits": b["partition_bits"], "join_keys": b.get("join_keys"),
+                              "partition_mode": b.get("partition_mode")} if "build_ms" in b else {})}
         if args.through_cpp and c.world == 1:
             line["through_cpp"] = through_cpp(args, c, head["ms_per_step"] if wl in ("all", "sort") else None,
                                               (blocks.get("join") or (head if wl == "join" else {})).get("ms_per_step"),

@@ -484,8 +484,10 @@ struct RangeSplit {
 };
 
 template <typename K, typename F>
-__global__ void __launch_bounds__(256) k_pj_hist(const K* __restrict__ keys, int64_t n, PjPlan* plan, int pbits, int64_t rrows, F part_of)
+__global__ void __launch_bounds__(256) k_pj_hist(const K* __restrict__ keys, int64_t n, PjPlan* plan, int pbits, int64_t rrows, F part_of,
+                                                 const unsigned int* gate = nullptr)
 {
+  if (gate && *gate == 0) return;  // the exact sequence behind a speculative partition pass that held
   __shared__ unsigned int s_h[PJ_MAXP];
   const int P = 1 << pbits;
   for (int i = threadIdx.x; i < P; i += 256) s_h[i] = 0;
@@ -518,8 +520,9 @@ __global__ void __launch_bounds__(256) k_pj_hist(const K* __restrict__ keys, int
 }
 
 // one block of 1024 threads: offsets, cursors, probe-chunk numbering (partitions of list x = [x, x+1) * P / 8)
-__global__ void __launch_bounds__(1024) k_pj_offsets(PjPlan* plan, int pbits, unsigned int chunk_rows)
+__global__ void __launch_bounds__(1024) k_pj_offsets(PjPlan* plan, int pbits, unsigned int chunk_rows, const unsigned int* gate = nullptr)
 {
+  if (gate && *gate == 0) return;
   __shared__ unsigned long long s_tmp[1024 / GX_WAVE + 1];
   __shared__ unsigned long long s_carry;
   __shared__ unsigned int s_ccarry;
@@ -1524,6 +1527,652 @@ __global__ void __launch_bounds__(PJ_BT) k_pj_build(const K* __restrict__ pkeys,
   }
 }
 
+// ================================================================================================
+// Round 3: the partition pass without its histogram, persistent, and the probe over region tables.
+//
+// (1) No k_pj_hist.  Region e = partition * PJ_NR + range owns a fixed slot of `cap` rows in the partitioned arrays
+//     (cap = mean + 8 sigma of a uniform hash, so a row count that overflows its slot means skewed keys, not bad
+//     luck); a tile adds its count to the region's fill counter and writes behind what the earlier tiles of that
+//     range wrote.  A region that outgrows its slot raises `overflow`: its surplus rows are dropped, k_pj2_offsets
+//     turns the flag into `fallback`, the speculative probe finds no piece to take, and the EXACT sequence -- histogram,
+//     offsets, scatter into exactly sized partitions, probe -- which is enqueued behind it and exits at once
+//     otherwise, produces the result.  No host round trip on either branch (the trick of the sort's level-1 pass).
+//     Saves the 8 B/row histogram read: 1.35 ms of 14.3 at 1e9 rows.
+// (2) Persistent scatter.  One 1024-thread workgroup per CU owns ~130 KiB of LDS, so nothing else is resident to
+//     hide its serial phases; per tile it used to pay the HBM latency of its key loads, two returning device-scope
+//     atomics, the drain of its stores and the launch of its successor (~11 of 27 us).  Now a workgroup walks tiles
+//     v = blockIdx.x + k * gridDim.x (same XCD for every k, so range == XCD as before): the keys of the NEXT tile are
+//     requested as soon as the current ones sit in LDS (their registers are free from there on) and arrive under the
+//     write-out; the fill-counter atomics of ALL bins of a thread are issued together, before the block scan, and are
+//     consumed only after the keys have been moved to LDS.
+// (3) Probe pieces come from a region table (chunk0 per region) instead of per-partition row ranges, so the same
+//     kernel serves the padded regions and the exact partitions; and the loads of a piece are issued at the TOP of a
+//     trip into their own registers (copied into the S1->S2 set at the bottom), which gives HBM a whole trip to
+//     deliver them: the old order left them the barrier, the flush and S3 (~1.5 us) and every trip stalled on them.
+// ================================================================================================
+struct alignas(128) Pj2Plan {
+  unsigned int fill[PJ_MAXP * PJ_NR];        // rows written to region e (device-scope atomics; nothing else on these lines)
+  unsigned int chunk0[PJ_MAXP * PJ_NR + 1];  // first probe piece of region e, regions in (partition, range) order
+  unsigned int list_chunk0[PJ_NR + 1];       // first piece of XCD list y (partitions [y, y + 1) * P / PJ_NR)
+  alignas(128) unsigned int overflow;        // a region outgrew its slot
+  alignas(128) unsigned int fallback;        // set by k_pj2_offsets: the exact sequence must run
+  alignas(128) PjCounter ticket[PJ_NR];
+  PjCounter ticket_exact[PJ_NR];
+};
+
+// rows per region slot: mean + 8 standard deviations of a binomial(range rows, 1/P) count, a multiple of 32 rows
+static inline uint32_t pj2_cap(int64_t n, int pbits)
+{
+  const double mean = (double)n / (double)PJ_NR / (double)(1 << pbits);
+  double cap        = mean + 8.0 * __builtin_sqrt(mean + 1.0) + 64.0;
+  return (uint32_t)((((int64_t)cap + 31) / 32) * 32);
+}
+
+template <typename K, int RPT, int BTt, bool EXACT, typename F>
+__global__ void __launch_bounds__(BTt) k_pj2_scatter(const K* __restrict__ keys, int64_t n, Pj2Plan* plan2, PjPlan* plan, int pbits,
+                                                     int64_t rrows, uint32_t cap, int64_t ntiles, K* __restrict__ pkeys,
+                                                     int32_t* __restrict__ pidx, F part_of)
+{
+  constexpr int TILE = BTt * RPT;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  K* s_k                = reinterpret_cast<K*>(smem);                                        // TILE (reused for the row indices)
+  unsigned int* s_cd    = reinterpret_cast<unsigned int*>(smem + (size_t)TILE * sizeof(K));  // P: counts, then global - tile position
+  unsigned int* s_start = s_cd + (1 << pbits);                                               // P
+  __shared__ unsigned int s_scan[BTt / GX_WAVE + 1];
+  if (EXACT && plan2->fallback == 0) return;  // the speculative pass held: nothing to redo
+  const int P        = 1 << pbits;
+  const unsigned tid = threadIdx.x;
+  const int bpt      = P > BTt ? P / BTt : 1;                 // bins per thread (consecutive)
+  const int b0       = P > BTt ? (int)tid * bpt : (int)tid;   // (threads >= P own no bin when P < BTt)
+  const bool owner   = P > BTt || (int)tid < P;
+
+  K key[RPT];
+  int64_t v = blockIdx.x;
+  if (v >= ntiles) return;
+  int64_t base;
+  int nvalid, range;
+  auto locate = [&](int64_t vv, int64_t& b, int& nv, int& r) {
+    const int64_t tile = xcd_swizzle(vv, ntiles);
+    b                  = tile * TILE;
+    nv                 = (int)((n - b < (int64_t)TILE) ? (n - b) : (int64_t)TILE);
+    r                  = (rrows > 0 && b / rrows < PJ_NR - 1) ? (int)(b / rrows) : PJ_NR - 1;
+  };
+  auto load = [&](int64_t b, int nv) {
+#pragma unroll
+    for (int j = 0; j < RPT; ++j) {
+      const int idx = j * BTt + (int)tid;
+      key[j]        = __builtin_nontemporal_load(&keys[b + (idx < nv ? idx : 0)]);  // unconditional: rows >= nv are masked below
+    }
+  };
+  locate(v, base, nvalid, range);
+  load(base, nvalid);
+  for (;;) {
+    for (int i = tid; i < P; i += BTt) s_cd[i] = 0;
+    __syncthreads();  // also: the previous tile's last LDS reads are done
+    unsigned int packed[RPT];  // partition << 16 | rank inside (tile, partition)
+#pragma unroll
+    for (int j = 0; j < RPT; ++j) {
+      const int idx           = j * BTt + (int)tid;
+      const unsigned int part = part_of(key[j]);
+      const unsigned int rank = (idx < nvalid) ? atomicAdd(&s_cd[part], 1u) : 0u;
+      packed[j]               = (part << 16) | rank;
+    }
+    __syncthreads();
+    // counts of this thread's bins; the fill-counter atomics leave together and stay in flight across the scan
+    unsigned int c[4], g[4];  // bpt <= 4 (P <= 4096, BTt >= 1024 when P > BTt ... checked on the host)
+    unsigned int sum = 0;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      c[k] = (owner && k < bpt) ? s_cd[b0 + k] : 0u;
+      g[k] = 0;
+      sum += c[k];
+    }
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      if (c[k]) {
+        if (EXACT) g[k] = (unsigned int)atomicAdd(&plan->cursor[range][b0 + k], (unsigned long long)c[k]);
+        else g[k] = atomicAdd(&plan2->fill[(b0 + k) * PJ_NR + range], c[k]);
+      }
+    }
+    unsigned int st = block_exclusive_scan<BTt>(sum, 0u, SumOp(), s_scan, (unsigned int*)nullptr);
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      if (owner && k < bpt) s_start[b0 + k] = st;
+      st += c[k];
+    }
+    __syncthreads();
+    // keys through LDS: every partition becomes one contiguous run of the tile.  The position inside the tile is kept
+    // (16 bits, two per register) for the row indices that follow through the same buffer.
+    unsigned int lpos2[RPT / 2];
+#pragma unroll
+    for (int j = 0; j < RPT; ++j) {
+      const int idx        = j * BTt + (int)tid;
+      const unsigned int l = s_start[packed[j] >> 16] + (packed[j] & 0xFFFFu);  // < TILE <= 65536
+      if (idx < nvalid) s_k[l] = key[j];
+      if (j & 1) lpos2[j / 2] |= l << 16; else lpos2[j / 2] = l & 0xFFFFu;
+    }
+    // the key registers are free: request the next tile now, it lands under the write-out
+    const int64_t vn = v + gridDim.x;
+    int64_t nbase    = 0;
+    int nnvalid = 0, nrange = 0;
+    const bool more = vn < ntiles;
+    if (more) {
+      locate(vn, nbase, nnvalid, nrange);
+      load(nbase, nnvalid);
+    }
+    // global position of a run = slot base + rows already there (the atomics have had the scan and the LDS scatter to return)
+    {
+      unsigned int st2 = s_start[owner ? b0 : 0];
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        if (owner && k < bpt) {
+          unsigned int gb = g[k];
+          if (!EXACT) {
+            gb += (unsigned int)((b0 + k) * PJ_NR + range) * cap;
+            if (c[k] && g[k] + c[k] > cap) plan2->overflow = 1u;  // the surplus is dropped below; the exact sequence will run
+          }
+          s_cd[b0 + k] = gb - st2;
+        }
+        st2 += c[k];
+      }
+    }
+    __syncthreads();
+    unsigned int obin2[RPT / 2];  // partition of the element this thread writes out (16 bits each; 0xFFFF: dropped)
+#pragma unroll
+    for (int j = 0; j < RPT; ++j) {
+      const int i     = j * BTt + (int)tid;
+      unsigned int pt = 0xFFFFu;
+      if (i < nvalid) {
+        const K k = s_k[i];
+        pt        = part_of(k);
+        const unsigned int p = s_cd[pt] + (unsigned int)i;
+        if (!EXACT && p >= (unsigned int)(pt * PJ_NR + range + 1) * cap) pt = 0xFFFFu;
+        else pkeys[p] = k;
+      }
+      if (j & 1) obin2[j / 2] |= pt << 16; else obin2[j / 2] = pt;
+    }
+    __syncthreads();
+    // row indices through the same buffer
+    int32_t* s_i = reinterpret_cast<int32_t*>(smem);
+#pragma unroll
+    for (int j = 0; j < RPT; ++j) {
+      const int idx        = j * BTt + (int)tid;
+      const unsigned int l = (j & 1) ? lpos2[j / 2] >> 16 : lpos2[j / 2] & 0xFFFFu;
+      if (idx < nvalid) s_i[l] = (int32_t)(base + idx);
+    }
+    __syncthreads();
+#pragma unroll
+    for (int j = 0; j < RPT; ++j) {
+      const int i           = j * BTt + (int)tid;
+      const unsigned int pt = (j & 1) ? obin2[j / 2] >> 16 : obin2[j / 2] & 0xFFFFu;
+      if (pt != 0xFFFFu) pidx[(unsigned int)(s_cd[pt] + (unsigned int)i)] = s_i[i];
+    }
+    if (!more) break;
+    __syncthreads();  // the row-index write-out reads s_cd / s_i: nobody may start zeroing the counters of the next tile before
+    v      = vn;
+    base   = nbase;
+    nvalid = nnvalid;
+    range  = nrange;
+  }
+}
+
+// After the speculative scatter: piece numbering over the regions, or the verdict "fallback".  One block of 1024 threads,
+// each handling a run of consecutive regions.
+__global__ void __launch_bounds__(1024) k_pj2_offsets(Pj2Plan* plan2, int pbits, uint32_t cap, unsigned int piece_rows)
+{
+  __shared__ unsigned int s_tmp[1024 / GX_WAVE + 1];
+  const int E   = (1 << pbits) * PJ_NR;
+  const int per = E > 1024 ? E / 1024 : 1;
+  const int e0  = (int)threadIdx.x * per;
+  if (plan2->overflow) {  // chunk0 / list_chunk0 stay zero (the plan was cleared): the speculative probe takes no piece
+    if (threadIdx.x == 0) plan2->fallback = 1u;
+    return;
+  }
+  unsigned int sum = 0;
+  for (int k = 0; k < per; ++k) {
+    const int e = e0 + k;
+    if (e < E) {
+      unsigned int c = plan2->fill[e];
+      c              = c < cap ? c : cap;
+      sum += (c + piece_rows - 1) / piece_rows;
+    }
+  }
+  unsigned int total;
+  unsigned int run = block_exclusive_scan<1024>(sum, 0u, SumOp(), s_tmp, &total);
+  const int LISTE  = E / PJ_NR;  // regions per XCD list
+  for (int k = 0; k < per; ++k) {
+    const int e = e0 + k;
+    if (e < E) {
+      plan2->chunk0[e] = run;
+      if (e % LISTE == 0) plan2->list_chunk0[e / LISTE] = run;
+      unsigned int c = plan2->fill[e];
+      c              = c < cap ? c : cap;
+      run += (c + piece_rows - 1) / piece_rows;
+    }
+  }
+  if (threadIdx.x == 0) {
+    plan2->chunk0[E]           = total;
+    plan2->list_chunk0[PJ_NR]  = total;
+  }
+}
+
+// where the pieces of a probe launch come from
+struct PieceTable {
+  const unsigned int* chunk0;        // [regions + 1] first piece of each region
+  const unsigned int* list_chunk0;   // [PJ_NR + 1]
+  PjCounter* ticket;                 // [PJ_NR]
+  const unsigned long long* start;   // exact partitions: row range of region e = [start[e], start[e + 1]); NULL = padded slots
+  const unsigned int* fill;          // padded slots: rows in region e (clamped to cap)
+  unsigned int cap;                  // padded slots: region e starts at e * cap
+  int nr;                            // regions per partition: PJ_NR (padded slots) or 1 (exact partitions)
+};
+
+template <typename K, bool EARLY>
+__global__ void __launch_bounds__(PP_BT)
+k_pj2_probe_pipe(const K* __restrict__ pkeys, const int32_t* __restrict__ pidx, PieceTable pt, int pbits,
+                 const Slot<K>* __restrict__ slots, uint32_t log2cap, int left_outer, int32_t* __restrict__ out_probe,
+                 int32_t* __restrict__ out_build, int64_t capacity, unsigned long long* cursor)
+{
+  typedef typename SlotRaw<K>::type Raw;
+  constexpr uint32_t SUB = 1u << PJ_SUB_LOG2;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const uint32_t* s_tagw = reinterpret_cast<const uint32_t*>(smem);                       // 64 KiB of tags
+  int32_t* s_sidx        = reinterpret_cast<int32_t*>(smem + (SUB >> 1));                  // [3][PP_ROWS] staged probe rows
+  int32_t* s_sfirst      = s_sidx + 3 * PP_ROWS;                                           // [3][PP_ROWS] staged build rows
+  __shared__ unsigned int s_cnt[8];           // pairs staged by piece (it & 7)
+  __shared__ unsigned long long s_base[3];    // output position of staging buffer (it % 3)
+  __shared__ PpPiece s_piece[4];              // piece of trip (t & 3), resolved two trips ahead by the service wave
+  const int P         = 1 << pbits;
+  const int LISTP     = P / PJ_NR;
+  const uint64_t mask = (1ull << log2cap) - 1;
+  const unsigned tid  = threadIdx.x;
+  const unsigned lane = lane_id();
+  const unsigned w    = tid / GX_WAVE;
+  const uint8_t* gtags = reinterpret_cast<const uint8_t*>(slots + (mask + 1));
+
+  if (tid < 8) s_cnt[tid] = 0;
+
+  if (w == PP_PW) {
+    // ------------------------------------------------------------------ service wave: tickets and reservations
+    const unsigned x0 = pj_xcc();
+    unsigned ylist    = 0;  // lists tried so far
+    auto take_piece = [&](PpPiece& pc) {
+      pc.valid = 0;
+      pc.c0 = pc.c1 = 0;
+      pc.part = 0;
+      unsigned int g = 0xFFFFFFFFu, y = 0;
+      if (lane == 0) {
+        while (ylist < PJ_NR) {
+          y                      = (x0 + ylist) % PJ_NR;
+          const unsigned int nch = pt.list_chunk0[y + 1] - pt.list_chunk0[y];
+          if (nch) {
+            const unsigned int t = atomicAdd(&pt.ticket[y].v, 1u);
+            if (t < nch) {
+              g = pt.list_chunk0[y] + t;
+              break;
+            }
+          }
+          ++ylist;
+        }
+      }
+      g     = (unsigned int)__builtin_amdgcn_readfirstlane((int)g);
+      y     = (unsigned int)__builtin_amdgcn_readfirstlane((int)y);
+      ylist = (unsigned int)__builtin_amdgcn_readfirstlane((int)ylist);
+      if (g == 0xFFFFFFFFu) return;
+      // partition of piece g inside list y: the one whose piece interval contains it (LISTP <= 512 entries, 64 lanes)
+      unsigned int part = 0;
+      bool hit = false;
+      for (int e = (int)lane; e < LISTP; e += GX_WAVE) {
+        const int p           = (int)y * LISTP + e;
+        const unsigned int lo = pt.chunk0[p * pt.nr], hi = pt.chunk0[(p + 1) * pt.nr];
+        if (lo <= g && g < hi) {
+          part = (unsigned int)p;
+          hit  = true;
+        }
+      }
+      uint64_t hb = ballot(hit);
+      part        = shfl(part, __builtin_ctzll(hb));
+      // its region inside the partition
+      unsigned int reg = part * (unsigned int)pt.nr, loc = 0;
+      hit = false;
+      if ((int)lane < pt.nr) {
+        const unsigned int e  = part * (unsigned int)pt.nr + lane;
+        const unsigned int lo = pt.chunk0[e], hi = pt.chunk0[e + 1];
+        if (lo <= g && g < hi) {
+          reg = e;
+          loc = g - lo;
+          hit = true;
+        }
+      }
+      hb           = ballot(hit);
+      const int sr = __builtin_ctzll(hb);
+      reg          = shfl(reg, sr);
+      loc          = shfl(loc, sr);
+      unsigned long long r0, r1;
+      if (pt.start) {
+        r0 = pt.start[reg];
+        r1 = pt.start[reg + 1];
+      } else {
+        unsigned int c = pt.fill[reg];
+        c              = c < pt.cap ? c : pt.cap;
+        r0             = (unsigned long long)reg * pt.cap;
+        r1             = r0 + c;
+      }
+      pc.c0    = r0 + (unsigned long long)loc * PP_ROWS;
+      pc.c1    = pc.c0 + PP_ROWS < r1 ? pc.c0 + PP_ROWS : r1;
+      pc.part  = part;
+      pc.valid = 1;
+    };
+    PpPiece pc;
+    take_piece(pc);
+    if (lane == 0) s_piece[0] = pc;
+    take_piece(pc);
+    if (lane == 0) s_piece[1] = pc;
+    __syncthreads();  // prologue barrier
+    unsigned long long pending = 0;
+    int done_at = -1;
+    unsigned int partC = 0;
+    bool tags_loaded   = false;
+    for (int t = 0;; ++t) {
+      const int itf = t - 3, it3 = t - 2;
+      if (t >= 1) {  // R(t): the probe waves reload their tags when the piece entering S2 belongs to another partition
+        const PpPiece pa = s_piece[(t - 1) & 3];
+        if (pa.valid && (!tags_loaded || pa.part != partC)) {
+          partC       = pa.part;
+          tags_loaded = true;
+          __syncthreads();
+        }
+      }
+      if (done_at < 0 && !s_piece[t & 3].valid) done_at = t;  // same test as the probe waves make
+      if (lane == 0 && itf >= 0) s_base[(unsigned)itf % 3u] = pending;
+      take_piece(pc);
+      if (lane == 0) s_piece[(t + 2) & 3] = pc;
+      __syncthreads();  // X(t)
+      if (done_at >= 0 && t >= done_at + 3) break;
+      if (lane == 0) {
+        if (it3 >= 0) {
+          unsigned int c = s_cnt[(unsigned)it3 & 7u];
+          c              = c < (unsigned)PP_ROWS ? c : (unsigned)PP_ROWS;
+          pending        = c ? atomicAdd(cursor, (unsigned long long)c) : 0ull;
+        }
+        s_cnt[(unsigned)(t + 2) & 7u] = 0;
+      }
+    }
+    return;
+  }
+
+  // ---------------------------------------------------------------------- probe waves
+  __syncthreads();  // prologue barrier: pieces 0 and 1 are resolved
+  K kN[PP_R];                // EARLY: loads of trip t, issued at its top
+  int32_t iN[PP_R];
+  K kA[PP_R];                // S1 -> S2
+  int32_t iA[PP_R];
+  K kB[PP_R];                // S2 -> S3
+  int32_t iB[PP_R];
+  uint32_t li[PP_R], cand[PP_R];
+  Raw sv[PP_R];
+  uint32_t fl = 0;
+  uint32_t partA = 0, partB = 0, partC = 0;
+  bool tags_loaded = false;
+  unsigned long long cA0 = 0, cA1 = 0;
+  bool validA = false, validB = false;
+#pragma unroll
+  for (int j = 0; j < PP_R; ++j) {
+    kA[j] = kB[j] = kN[j] = K(0);
+    iA[j] = iB[j] = iN[j] = 0;
+    li[j] = cand[j] = 0;
+    sv[j] = Raw{};
+  }
+  int done_at = -1;
+
+  for (int t = 0;; ++t) {
+    // ---------------- S1(t), EARLY form: request the piece's rows first; they are not looked at before the next trip
+    PpPiece pcur = s_piece[t & 3];
+    if (EARLY && pcur.valid) {
+      const unsigned long long pb = pcur.c0 + (unsigned long long)w * (PP_R * GX_WAVE) + lane;
+#pragma unroll
+      for (int j = 0; j < PP_R; ++j) {
+        const unsigned long long i  = pb + (unsigned long long)j * GX_WAVE;
+        const unsigned long long ic = i < pcur.c1 ? i : pcur.c0;
+        kN[j] = __builtin_nontemporal_load(&pkeys[ic]);
+        iN[j] = __builtin_nontemporal_load(&pidx[ic]);
+      }
+    }
+    // ---------------- S3(t-2): compare, finish chains, stage the matches
+    const int it3 = t - 2;
+    if (validB) {
+      const unsigned buf       = (unsigned)it3 % 3u;
+      const uint64_t sub_base  = (uint64_t)partB << PJ_SUB_LOG2;
+      const uint32_t* gtagw    = reinterpret_cast<const uint32_t*>(gtags + (sub_base >> 1));
+      uint32_t m[PP_R];
+      int32_t first[PP_R];
+      K sk[PP_R];
+      int32_t sr[PP_R];
+      uint32_t active = 0, ended = (fl >> 4) & 15u;
+#pragma unroll
+      for (int j = 0; j < PP_R; ++j) {
+        m[j]     = 0;
+        first[j] = NO_MATCH;
+        unpack_slot(sv[j], sk[j], sr[j]);
+        if (!((fl >> j) & 1u)) continue;
+        if ((fl >> (8 + j)) & 1u) {  // chain starts in the last slots of the sub-table: walk the slots themselves
+          uint64_t gs = sub_base + li[j];
+          for (;;) {
+            K k;
+            int32_t r;
+            load_slot<K>(&slots[gs & mask], k, r);
+            if (r == EMPTY_ROW) break;
+            if (k == kB[j]) {
+              if (m[j] == 0) first[j] = r;
+              ++m[j];
+            }
+            ++gs;
+          }
+        } else if (cand[j] || !((ended >> j) & 1u)) {
+          active |= 1u << j;
+        }
+      }
+      bool preloaded = true;  // the first candidate of every row was fetched by S2
+      while (active) {
+        if (!preloaded) {
+#pragma unroll
+          for (int j = 0; j < PP_R; ++j) {
+            if (ballot((active >> j) & 1u) == 0) continue;
+            if ((active & (1u << j)) && cand[j])
+              load_slot<K>(&slots[sub_base + li[j] + ((uint32_t)__builtin_ctz(cand[j]) >> 2)], sk[j], sr[j]);
+          }
+        }
+        preloaded = false;
+#pragma unroll
+        for (int j = 0; j < PP_R; ++j) {
+          if (ballot((active >> j) & 1u) == 0) continue;
+          if (!(active & (1u << j))) continue;
+          if (cand[j]) {
+            if (sk[j] == kB[j]) {  // a tagged slot is never empty
+              if (m[j] == 0) first[j] = sr[j];
+              ++m[j];
+            }
+            cand[j] &= cand[j] - 1;
+          }
+          if (cand[j] == 0) {
+            if (ended & (1u << j)) {
+              active &= ~(1u << j);
+            } else {  // the chain runs on: next 8 slots (tags from global memory: the LDS may hold another partition's)
+              li[j] += 8;
+              if (li[j] > SUB - 8) {
+                uint64_t gs = sub_base + li[j];
+                for (;;) {
+                  K k;
+                  int32_t r;
+                  load_slot<K>(&slots[gs & mask], k, r);
+                  if (r == EMPTY_ROW) break;
+                  if (k == kB[j]) {
+                    if (m[j] == 0) first[j] = r;
+                    ++m[j];
+                  }
+                  ++gs;
+                }
+                active &= ~(1u << j);
+              } else {
+                const bool e = scan_tags8_global(gtagw, li[j], tag_of<K>(kB[j], log2cap) * 0x11111111u, cand[j]);
+                if (e) {
+                  ended |= 1u << j;
+                  if (cand[j] == 0) active &= ~(1u << j);
+                }
+              }
+            }
+          }
+        }
+      }
+      // ---- stage: pairs of this piece go to s_sidx / s_sfirst [buf] at positions handed out by an LDS counter
+#pragma unroll
+      for (int j = 0; j < PP_R; ++j) {
+        const bool live = (fl >> j) & 1u;
+        if (left_outer && live && m[j] == 0) m[j] = 1;  // (row, JoinNoMatch); first[j] is NO_MATCH
+        uint32_t off, tot;
+        if (ballot(m[j] > 1) == 0) {
+          const uint64_t bb = ballot(m[j] == 1);
+          if (bb == 0) continue;
+          off = (uint32_t)__builtin_popcountll(bb & lanemask_lt());
+          tot = (uint32_t)__builtin_popcountll(bb);
+        } else {
+          const uint32_t sc = wave_inclusive_scan(m[j], SumOp());
+          off               = sc - m[j];
+          tot               = shfl(sc, GX_WAVE - 1);
+        }
+        uint32_t wbase = 0;
+        if (lane == 0) wbase = atomicAdd(&s_cnt[(unsigned)it3 & 7u], tot);
+        wbase = (uint32_t)__builtin_amdgcn_readfirstlane((int)wbase);
+        if (m[j] == 0) continue;
+        const uint32_t pos = wbase + off;
+        if (m[j] == 1) {
+          if (pos < (uint32_t)PP_ROWS) {
+            s_sidx[buf * PP_ROWS + pos]   = iB[j];
+            s_sfirst[buf * PP_ROWS + pos] = first[j];
+          } else {  // staging full (duplicate build keys): reserve and write directly
+            const unsigned long long gp = atomicAdd(cursor, 1ull);
+            if ((int64_t)gp < capacity) {
+              out_probe[gp] = iB[j];
+              out_build[gp] = first[j];
+            }
+          }
+        } else {  // duplicate build keys: walk the chain again (lines are cache-resident)
+          const uint32_t room   = pos < (uint32_t)PP_ROWS ? (uint32_t)PP_ROWS - pos : 0u;
+          const uint32_t staged = room < m[j] ? room : m[j];
+          unsigned long long gp = 0;
+          if (staged < m[j]) gp = atomicAdd(cursor, (unsigned long long)(m[j] - staged));
+          uint32_t seen = 0;
+          uint64_t hh   = slot_of<K>(kB[j], log2cap);
+          for (;;) {
+            K k;
+            int32_t r;
+            load_slot<K>(&slots[hh], k, r);
+            if (r == EMPTY_ROW) break;
+            if (k == kB[j]) {
+              if (seen < staged) {
+                s_sidx[buf * PP_ROWS + pos + seen]   = iB[j];
+                s_sfirst[buf * PP_ROWS + pos + seen] = r;
+              } else {
+                if ((int64_t)gp < capacity) {
+                  out_probe[gp] = iB[j];
+                  out_build[gp] = r;
+                }
+                ++gp;
+              }
+              ++seen;
+            }
+            hh = (hh + 1) & mask;
+          }
+        }
+      }
+    }
+    // ---------------- tags of the partition S2 is about to probe
+    if (validA && (!tags_loaded || partA != partC)) {
+      const uint4* src = reinterpret_cast<const uint4*>(gtags + (((uint64_t)partA << PJ_SUB_LOG2) >> 1));
+      uint4* dst       = reinterpret_cast<uint4*>(smem);
+      for (uint32_t i = tid; i < SUB / 2 / 16; i += PP_PW * GX_WAVE) dst[i] = src[i];
+      partC       = partA;
+      tags_loaded = true;
+      __syncthreads();  // R(t)
+    }
+    // ---------------- S2(t-1): chain heads on the LDS tags, first candidate slot in flight
+    fl     = 0;
+    validB = validA;
+    partB  = partA;
+    if (validA) {
+      const uint64_t sub_base = (uint64_t)partA << PJ_SUB_LOG2;
+      const Slot<K>* dummy    = slots + sub_base;
+      const unsigned long long pb = cA0 + (unsigned long long)w * (PP_R * GX_WAVE) + lane;
+#pragma unroll
+      for (int j = 0; j < PP_R; ++j) {
+        kB[j]   = kA[j];
+        iB[j]   = iA[j];
+        cand[j] = 0;
+        li[j]   = 0;
+        if (pb + (unsigned long long)j * GX_WAVE < cA1) {
+          fl |= 1u << j;
+          const uint64_t prod = (uint64_t)kB[j] * 0x9E3779B97F4A7C15ull;
+          li[j]               = (uint32_t)((prod >> (64 - log2cap)) - sub_base);
+          uint32_t tg         = (uint32_t)(prod >> (60 - log2cap)) & 15u;
+          tg                  = tg ? tg : 8u;
+          if (li[j] > SUB - 8) {
+            fl |= 1u << (8 + j);
+          } else if (scan_tags8(s_tagw, li[j], tg * 0x11111111u, cand[j])) {
+            fl |= 1u << (4 + j);
+          }
+        }
+      }
+#pragma unroll
+      for (int j = 0; j < PP_R; ++j) {
+        const Slot<K>* sp = cand[j] ? slots + (sub_base + li[j] + ((uint32_t)__builtin_ctz(cand[j]) >> 2)) : dummy;
+        sv[j]             = *reinterpret_cast<const Raw*>(sp);
+      }
+    }
+    // ---------------- S1(t): the piece that enters S2 next trip
+    validA = pcur.valid != 0;
+    if (done_at < 0 && !validA) done_at = t;
+    if (validA) {
+      partA = pcur.part;
+      cA0   = pcur.c0;
+      cA1   = pcur.c1;
+      if (!EARLY) {
+        const unsigned long long pb = cA0 + (unsigned long long)w * (PP_R * GX_WAVE) + lane;
+#pragma unroll
+        for (int j = 0; j < PP_R; ++j) {
+          const unsigned long long i  = pb + (unsigned long long)j * GX_WAVE;
+          const unsigned long long ic = i < cA1 ? i : cA0;
+          kA[j] = __builtin_nontemporal_load(&pkeys[ic]);
+          iA[j] = __builtin_nontemporal_load(&pidx[ic]);
+        }
+      }
+    }
+    __syncthreads();  // X(t): staging of piece t-2 complete, s_base of piece t-3 visible
+    if (done_at >= 0 && t >= done_at + 3) break;
+    // ---------------- flush of piece t-3: two coalesced streams
+    const int itf = t - 3;
+    if (itf >= 0) {
+      const unsigned buf          = (unsigned)itf % 3u;
+      unsigned int c              = s_cnt[(unsigned)itf & 7u];
+      c                           = c < (unsigned)PP_ROWS ? c : (unsigned)PP_ROWS;
+      const unsigned long long gb = s_base[buf];
+      for (unsigned int i = tid; i < c; i += PP_PW * GX_WAVE) {
+        const unsigned long long gp = gb + i;
+        if ((int64_t)gp < capacity) {
+          __builtin_nontemporal_store(s_sidx[buf * PP_ROWS + i], &out_probe[gp]);
+          __builtin_nontemporal_store(s_sfirst[buf * PP_ROWS + i], &out_build[gp]);
+        }
+      }
+    }
+    if (EARLY && validA) {  // the rows requested at the top of the trip: into the S1 -> S2 registers
+#pragma unroll
+      for (int j = 0; j < PP_R; ++j) {
+        kA[j] = kN[j];
+        iA[j] = iN[j];
+      }
+    }
+  }
+}
+
 // optional per-kernel timing of the partitioned probe with HIP events on the caller's stream (bench.py)
 struct JoinProfile {
   bool enabled = false, created = false, marked = false;
@@ -1536,6 +2185,7 @@ static inline void jprof_mark(int i, hipStream_t s)
 }
 static int g_pj_probe = 0; // probe kernel: 0 = default (software-pipelined tag probe), 1 = round-1 tag probe (A/B knob)
 static int g_pj_tile = 0;  // scatter tile rows: 0 = default, else 4096 / 8192 / 16384 (A/B knob)
+static int g_pj_probe_early = 1;  // round-3 probe: 1 = rows of a piece requested at the top of the trip (default), 0 = at its end (A/B knob)
 
 // the partition pass shared by the partitioned probe and build (F = TableTop) and by gx_partition_rows
 template <typename K, typename F>
@@ -1555,8 +2205,8 @@ int pj_partition_fn(const K* keys, int64_t n, int pbits, PjPlan* plan, K* pkeys,
   int64_t hb = div_up(n, 256 * 8 * 4 * PJ_NR);
   if (hb > 256) hb = 256;
   if (hb < 1) hb = 1;
-  hipLaunchKernelGGL((k_pj_hist<K, F>), dim3((unsigned)(hb * PJ_NR)), dim3(256), 0, s, keys, n, plan, pbits, rrows, part_of);
-  hipLaunchKernelGGL(k_pj_offsets, dim3(1), dim3(1024), 0, s, plan, pbits, chunk_rows);
+  hipLaunchKernelGGL((k_pj_hist<K, F>), dim3((unsigned)(hb * PJ_NR)), dim3(256), 0, s, keys, n, plan, pbits, rrows, part_of, (const unsigned int*)nullptr);
+  hipLaunchKernelGGL(k_pj_offsets, dim3(1), dim3(1024), 0, s, plan, pbits, chunk_rows, (const unsigned int*)nullptr);
   if (profile) jprof_mark(1, s);
   const size_t lds = (size_t)tile_rows * sizeof(K) + ((size_t)12 << pbits);
   auto k4          = k_pj_scatter<K, 8, 512, F>;
@@ -1644,12 +2294,104 @@ static inline int pj_bits(uint32_t log2cap, int slot_bytes)
   return pb;
 }
 
+// The round-3 probe: speculative hist-free partition (padded regions, persistent scatter) -> probe over the region table,
+// with the exact sequence (histogram, offsets, exact scatter, probe) enqueued behind it and gated on `fallback`.
+static int g_pj_spec = 1;  // A/B knob: 1 = this path where it applies (default), 0 = the round-2 path
+template <typename K>
+static bool pj2_applies(int64_t n, int pbits)
+{
+  const size_t lds = (size_t)16384 * sizeof(K) + ((size_t)8 << pbits) + 512;
+  return g_pj_spec && g_pj_probe == 0 && pbits >= 3 && pbits <= 12 && lds <= (size_t)160 * 1024 && n > 0 &&
+         (g_pj_spec == 2 || n > 4 * (int64_t)16384 * 256);  // 2: forced for any n (tests)
+}
+template <typename K>
+int probe_partitioned_impl2(const K* keys, int64_t n, const Slot<K>* slots, uint32_t lg, int pbits, int left_outer, int32_t* out_probe,
+                            int32_t* out_build, int64_t capacity, int64_t* cursor, void* tmp, size_t* tmp_bytes, hipStream_t s)
+{
+  constexpr int TILE   = 16384;
+  const uint32_t cap   = pj2_cap(n, pbits);
+  const size_t nslots  = ((size_t)PJ_NR << pbits) * cap;
+  const size_t nbuf    = nslots > (size_t)n ? nslots : (size_t)n;
+  Carver c(tmp);
+  Pj2Plan* plan2 = c.take<Pj2Plan>(1);
+  PjPlan* plan   = c.take<PjPlan>(1);
+  K* pkeys       = c.take<K>(nbuf);
+  int32_t* pidx  = c.take<int32_t>(nbuf);
+  if (!tmp) {
+    *tmp_bytes = c.total();
+    return 0;
+  }
+  if (*tmp_bytes < c.total()) return GX_ETMP;
+  typedef TableTop<K> F;
+  const F part_of{pbits};
+  auto kspec  = k_pj2_scatter<K, 16, 1024, false, F>;
+  auto kexact = k_pj2_scatter<K, 16, 1024, true, F>;
+  auto kprobe = g_pj_probe_early ? k_pj2_probe_pipe<K, true> : k_pj2_probe_pipe<K, false>;
+  constexpr size_t lds_p = ((size_t)1 << (PJ_SUB_LOG2 - 1)) + (size_t)6 * PP_ROWS * sizeof(int32_t);
+  const size_t lds_s     = (size_t)TILE * sizeof(K) + ((size_t)8 << pbits);
+  static bool attr_set   = false;  // per instantiation
+  static int num_cus     = 0;
+  if (!attr_set) {
+    const int lds_max = 160 * 1024 - 256;
+    GX_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(kspec), hipFuncAttributeMaxDynamicSharedMemorySize, lds_max));
+    GX_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(kexact), hipFuncAttributeMaxDynamicSharedMemorySize, lds_max));
+    GX_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(k_pj2_probe_pipe<K, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_p));
+    GX_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(k_pj2_probe_pipe<K, false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_p));
+    int dev = 0;
+    GX_HIP_TRY(hipGetDevice(&dev));
+    GX_HIP_TRY(hipDeviceGetAttribute(&num_cus, hipDeviceAttributeMultiprocessorCount, dev));
+    attr_set = true;
+  }
+  const int64_t ntiles = div_up(n, (int64_t)TILE);
+  const int64_t rrows  = pj_range_rows(n, TILE);
+  int64_t grid         = num_cus > 0 ? num_cus : 256;
+  grid                 = grid / PJ_NR * PJ_NR;  // v % 8 must stay the XCD of a workgroup over its whole walk
+  if (grid < PJ_NR) grid = PJ_NR;
+  if (grid > ntiles) grid = ntiles;
+  unsigned long long* cur = reinterpret_cast<unsigned long long*>(cursor);
+  jprof_mark(0, s);
+  GX_HIP_TRY(hipMemsetAsync(plan2, 0, sizeof(Pj2Plan), s));
+  GX_HIP_TRY(hipMemsetAsync(plan, 0, sizeof(PjPlan), s));
+  jprof_mark(1, s);
+  // ---- speculative pass
+  hipLaunchKernelGGL(kspec, dim3((unsigned)grid), dim3(1024), lds_s, s, keys, n, plan2, plan, pbits, rrows, cap, ntiles, pkeys, pidx, part_of);
+  jprof_mark(2, s);
+  hipLaunchKernelGGL(k_pj2_offsets, dim3(1), dim3(1024), 0, s, plan2, pbits, cap, (unsigned int)PP_ROWS);
+  PieceTable pt{plan2->chunk0, plan2->list_chunk0, plan2->ticket, nullptr, plan2->fill, cap, PJ_NR};
+  int64_t pgrid = num_cus > 0 ? num_cus : 256;
+  hipLaunchKernelGGL(kprobe, dim3((unsigned)pgrid), dim3(PP_BT), lds_p, s, pkeys, pidx, pt, pbits, slots, lg, left_outer, out_probe, out_build,
+                     capacity, cur);
+  // ---- exact sequence: every kernel returns at once unless plan2->fallback is set
+  int64_t hb = div_up(n, 256 * 8 * 4 * PJ_NR);
+  if (hb > 256) hb = 256;
+  if (hb < 1) hb = 1;
+  hipLaunchKernelGGL((k_pj_hist<K, F>), dim3((unsigned)(hb * PJ_NR)), dim3(256), 0, s, keys, n, plan, pbits, rrows, part_of, &plan2->fallback);
+  hipLaunchKernelGGL(k_pj_offsets, dim3(1), dim3(1024), 0, s, plan, pbits, (unsigned int)PP_ROWS, &plan2->fallback);
+  hipLaunchKernelGGL(kexact, dim3((unsigned)grid), dim3(1024), lds_s, s, keys, n, plan2, plan, pbits, rrows, cap, ntiles, pkeys, pidx, part_of);
+  PieceTable pe{plan->chunk0, plan->list_chunk0, plan2->ticket_exact, plan->offset, nullptr, 0u, 1};
+  hipLaunchKernelGGL(kprobe, dim3((unsigned)pgrid), dim3(PP_BT), lds_p, s, pkeys, pidx, pe, pbits, slots, lg, left_outer, out_probe, out_build,
+                     capacity, cur);
+  jprof_mark(3, s);
+  g_jprof.marked = g_jprof.enabled;
+  GX_LAUNCH_CHECK();
+  return 0;
+}
+
 template <typename K>
 int probe_partitioned_impl(const void* keys, int64_t n, const void* table, size_t table_bytes, uint32_t lg,
                            int left_outer, int32_t* out_probe, int32_t* out_build, int64_t capacity, int64_t* cursor,
                            void* tmp, size_t* tmp_bytes, hipStream_t s)
 {
   const int pbits = pj_bits(lg, (int)sizeof(Slot<K>));
+  if (pj2_applies<K>(n, pbits)) {
+    if (tmp) {
+      const size_t need = sizeof(TableHeader) + (sizeof(Slot<K>) << lg) + ((size_t)1 << lg) / 2;
+      if (table_bytes < need) return GX_ETMP;
+    }
+    return probe_partitioned_impl2<K>(static_cast<const K*>(keys), n,
+                                      reinterpret_cast<const Slot<K>*>(static_cast<const char*>(table) + sizeof(TableHeader)), lg, pbits,
+                                      left_outer, out_probe, out_build, capacity, cursor, tmp, tmp_bytes, s);
+  }
   Carver c(tmp);
   PjPlan* plan   = c.take<PjPlan>(1);
   K* pkeys       = c.take<K>((size_t)n);
@@ -1986,6 +2728,11 @@ int gx_join_profile_read(float* ms3)
 }
 
 void gx_join_set_probe_kernel(int which) { gx::join::g_pj_probe = which == 1 ? 1 : 0; }
+void gx_join_set_partition_mode(int speculative, int early_loads)
+{
+  gx::join::g_pj_spec        = speculative == 2 ? 2 : (speculative ? 1 : 0);
+  gx::join::g_pj_probe_early = early_loads ? 1 : 0;
+}
 
 void gx_join_set_scatter_tile(int rows)
 {

@@ -326,6 +326,12 @@ int gx_join_profile_read(float* ms3);
 void gx_join_set_scatter_tile(int rows);
 /* A/B knob (process-wide): 0 = software-pipelined tag probe (default), 1 = the round-1 tag probe. */
 void gx_join_set_probe_kernel(int which);
+/* A/B knob (process-wide): speculative = 1 (default) partitions the probe rows WITHOUT a histogram pass into padded
+ * (partition, XCD range) slots with a persistent scatter kernel, falling back on the device to the exact histogram
+ * path when a slot overflows (skewed keys); 0 = always the exact path of round 2; 2 = speculative for every row count
+ * (tests: by default inputs below 1.7e7 rows take the round-2 path).  early_loads = 1 (default): the
+ * pipelined probe requests a piece's rows at the top of a trip instead of at its end. */
+void gx_join_set_partition_mode(int speculative, int early_loads);
 
 /* out_build_idx[i] = the first build row whose key equals probe key i, or INT32_MIN (JoinNoMatch) --
  * the left join against DISTINCT build keys, in probe order and without an output reservation:

@@ -1,0 +1,96 @@
+"""The round-3 partitioned probe: speculative hist-free partition into padded (partition, XCD range)
+slots by a persistent scatter kernel + probe over the region table, against the oracle and against the round-2 exact
+path; and the DEVICE-SIDE FALLBACK: keys skewed enough to overflow a slot must come out right through the exact
+sequence enqueued behind the speculative one (no host round trip on either branch)."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+from oracle import cudf_oracle as orc
+
+
+@pytest.fixture(scope="module")
+def gx():
+    import torch
+    assert torch.cuda.is_available()
+    import cudf_amd  # noqa: F401
+    from cudf_amd import Column, ops, _lib
+    yield Column, ops, _lib
+    _lib.lib.gx_join_set_partition_mode(1, 1)
+
+
+def _pairs(l, r):
+    return orc.canonical_pairs(l.to_numpy(), r.to_numpy())
+
+
+def _inputs(rng, dtype, shape, nb, npr):
+    build = rng.permutation(3 * nb)[:nb].astype(dtype)
+    if shape == "dup_build":
+        build[:5000] = build[20000:25000]
+    probe = rng.integers(0, 4 * nb, npr).astype(dtype)
+    if shape == "hot_key":           # 35 % of the probe rows carry ONE key: its (partition, range) slots overflow
+        probe[rng.random(npr) < 0.35] = build[7]
+    elif shape == "one_partition":   # every probe key hashes into the same partition: all eight of its slots overflow
+        lg = 21
+        cand = np.arange(1, 40_000_000, dtype=np.uint64)
+        with np.errstate(over="ignore"):
+            part = (cand * np.uint64(0x9E3779B97F4A7C15)) >> np.uint64(64 - (lg - 17))
+        pool = cand[part == 3][:200_000].astype(dtype)
+        probe = pool[rng.integers(0, len(pool), npr)]
+        build[: len(pool) // 2] = pool[::2]
+    return build, probe
+
+
+@pytest.mark.parametrize("dtype", ["int64", "int32"])
+@pytest.mark.parametrize("shape", ["uniform", "dup_build", "hot_key", "one_partition"])
+@pytest.mark.parametrize("early", [1, 0])
+def test_speculative_partition_probe_matches_oracle(gx, dtype, shape, early):
+    Column, ops, _lib = gx
+    rng = np.random.default_rng(1234)
+    nb, npr = 600_000, (1 << 22) + 1234          # table 2^21 slots -> 16 partitions
+    build, probe = _inputs(rng, dtype, shape, nb, npr)
+    el, er = orc.inner_join(probe, build)
+    got = {}
+    for spec in (2, 0):                          # 2: the speculative path forced at this (small) size; 0: round-2 exact path
+        _lib.lib.gx_join_set_partition_mode(spec, early)
+        hj = ops.HashJoin(Column.from_numpy(build))
+        assert _lib.lib.gx_join_partition_bits(hj.key_size, hj.table_bytes) >= 3
+        l, r = hj.inner_join(Column.from_numpy(probe))
+        got[spec] = _pairs(l, r)
+        np.testing.assert_array_equal(got[spec][0], el)
+        np.testing.assert_array_equal(got[spec][1], er)
+        if shape in ("uniform", "hot_key"):      # left-outer form: unmatched rows pair with JoinNoMatch
+            pl, pr = hj.left_join(Column.from_numpy(probe))
+            wl, wr = orc.left_join([probe], [build])
+            a, b = _pairs(pl, pr), orc.canonical_pairs(wl, wr)
+            np.testing.assert_array_equal(a[0], b[0])
+            np.testing.assert_array_equal(a[1], b[1])
+    _lib.lib.gx_join_set_partition_mode(1, 1)
+
+
+def test_speculative_partition_probe_default_threshold(gx):
+    """Above the default row threshold (1.7e7 rows) the speculative path is what runs without any knob: uniform keys and a
+    hot key (fallback) against the closed form."""
+    import torch
+    Column, ops, _lib = gx
+    _lib.lib.gx_join_set_partition_mode(1, 1)
+    nb, n = 3_000_000, 30_000_000
+    bk = Column.empty(np.int64, nb)
+    bkt = bk.data[: nb * 8].view(torch.int64)
+    torch.manual_seed(3)
+    bkt.copy_(torch.randperm(nb, device="cuda") * 7 + 3)
+    for hot in (False, True):
+        pk = ops.random_column(np.int64, n, seed=9, lo=0, hi=int(nb / 0.3))
+        pkt = pk.data[: n * 8].view(torch.int64)
+        pkt.mul_(7).add_(3)
+        if hot:
+            pkt[::3] = bkt[11]
+        l, r = ops.HashJoin(bk).inner_join(pk)
+        li = l.data[: l.size * 4].view(torch.int32).long()
+        ri = r.data[: r.size * 4].view(torch.int32).long()
+        assert bool((pkt[li] == bkt[ri]).all())
+        hitrows = torch.nonzero(pkt < 7 * nb).flatten()   # 7u+3 with u < nb is a build key exactly once
+        assert l.size == hitrows.numel()
+        assert int(li.sum().item()) == int(hitrows.sum().item())
+        assert int(torch.unique(li).numel()) == l.size
