@@ -57,7 +57,7 @@ def parse():
     ap.add_argument("--join-probe-kernel", type=int, default=0, help="join knob: 0 pipelined tag probe, 1 round-1 tag probe")
     ap.add_argument("--join-scatter-tile", type=int, default=0, help="join knob: rows per scatter tile (0 = default)")
     ap.add_argument("--join-spec", type=int, default=1, help="join knob: 1 hist-free speculative partition (default), 0 round-2 path")
-    ap.add_argument("--join-early-loads", type=int, default=1, help="join knob: pipelined probe requests rows at the top of a trip")
+    ap.add_argument("--join-early-loads", type=int, default=0, help="join knob: bit 0 pipelined probe requests rows at the top of a trip, bit 1 deferral queue")
     ap.add_argument("--join-keys", default="random", choices=["random", "dense"],
                     help="join: random = SURVEY 8d (build = distinct random 64-bit keys, probe = 30%% drawn from them + 70%% from a "
                          "disjoint random set); dense = round 2's arithmetic progressions 3i+1 (kept for comparison)")

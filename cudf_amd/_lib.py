@@ -50,6 +50,8 @@ _PROTOS = {
     "gx_sort_info": (_i, [_p, ctypes.POINTER(ctypes.c_int32), _p]),
     "gx_gather": (_i, [_i, _p, _p, _i64, _p, _i64, _i, _p, _p, _p]),
     "gx_gather_global_rows": (_i, [_p, _i64, _p, _i64, _i, _p, _p, _p, _p]),
+    "gx_gather_global_rows_dev": (_i, [_p, _i64, _p, _i64, _i, _p, _p, _p]),
+    "gx_widen_i32_i64": (_i, [_p, _i64, _p, _p]),
     "gx_bitmask_set": (_i, [_p, _i64, _i64, _i, _p]),
     "gx_bitmask_count": (_i, [_p, _i64, _i64, _p, _p]),
     "gx_bitmask_and": (_i, [ctypes.POINTER(_p), _i, _i64, _p, _p, _p]),
@@ -65,8 +67,10 @@ _PROTOS = {
     "gx_valid_from_counts": (_i, [_p, _i64, _p, _p, _p]),
     "gx_mean_from_sum": (_i, [_i, _p, _p, _i64, _p, _p]),
     "gx_join_probe_partitioned": (_i, [_i, _p, _i64, _p, ctypes.c_size_t, _i, _p, _p, _i64, _p, _p, _sz, _p]),
+    "gx_join_probe_partitioned_at": (_i, [_i, _p, _i64, ctypes.c_int32, _p, ctypes.c_size_t, _i, _p, _p, _i64, _p, _p, _sz, _p]),
     "gx_join_build_partitioned": (_i, [_i, _p, _i64, _p, ctypes.c_size_t, ctypes.c_double, _p, _sz, _p]),
     "gx_partition_rows": (_i, [_i, _p, _i64, _i, _i, _p, _p, _p, _p, _p, _sz, _p]),
+    "gx_partition_rows_at": (_i, [_i, _p, _i64, ctypes.c_int32, _i, _i, _p, _p, _p, _p, _p, _sz, _p]),
     "gx_join_count_rows": (_i, [_i, _p, _p, _i64, _p, ctypes.c_size_t, ctypes.c_int32, _p, _p]),
     "gx_add_i32": (_i, [_p, _i64, ctypes.c_int32, _p]),
     "gx_join_partition_bits": (_i, [_i, ctypes.c_size_t]),

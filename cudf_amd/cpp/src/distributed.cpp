@@ -1,0 +1,795 @@
+// distributed.cpp -- the sharded operators of include/cudf_amd/gxd.h: host-side C++ over the HIP kernels (gx.h) and RCCL.
+// One process per GPU.  Replaces, for this path, the shuffle of libcudf_streaming (cpp/libcudf_streaming/src/
+// partition_utils.cpp:72-117, partition.cpp:56-80) + rapidsmpf and the collectives of cudf_polars' streaming executor
+// (python/cudf_polars/cudf_polars/streaming/actor_graph/collectives/sort.py, streaming/join.py:58-135,
+// streaming/groupby.py:411-437).
+//
+// Shape of every operator (counts all-gather, then an all-to-all as grouped ncclSend / ncclRecv pairs):
+//   caller's stream : partition chunk 0 | partition chunk 1 | ... | partition chunk C-1 | local operator (chunks)
+//   exchange stream :   wait P0, counts(0), send/recv(0) | wait P1, counts(1), send/recv(1) | ...
+//   host            : enqueues ALL partition passes first, then per chunk waits only for that chunk's count matrix
+//                     (a 64-entry D2H copy) -- the GPU is busy with the later chunks meanwhile.
+// Receive buffers, partition buffers and scratch are slots of a grow-only arena kept by the communicator object.
+#include <cudf_amd/gxd.h>
+
+#include <hip/hip_runtime_api.h>
+#include <rccl/rccl.h>
+
+#include <algorithm>
+#include <chrono>
+#include <cstring>
+#include <functional>
+#include <string>
+#include <vector>
+
+namespace {
+
+thread_local std::string g_err;
+
+int fail(int rc, std::string what)
+{
+  g_err = std::move(what);
+  return rc;
+}
+#define GXD_HIP(expr)                                                                             \
+  do {                                                                                            \
+    hipError_t e_ = (expr);                                                                       \
+    if (e_ != hipSuccess) return fail((int)e_, std::string(#expr) + ": " + hipGetErrorString(e_)); \
+  } while (0)
+#define GXD_NCCL(expr)                                                                                 \
+  do {                                                                                                 \
+    ncclResult_t r_ = (expr);                                                                          \
+    if (r_ != ncclSuccess) return fail(GX_EINTERNAL, std::string(#expr) + ": " + ncclGetErrorString(r_)); \
+  } while (0)
+#define GXD_GX(expr)                                                                 \
+  do {                                                                               \
+    int g_ = (expr);                                                                 \
+    if (g_ != 0) return fail(g_, std::string(#expr) + " returned " + std::to_string(g_)); \
+  } while (0)
+
+double now_ms()
+{
+  return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count();
+}
+
+// grow-only device buffers, one per purpose, reused from call to call
+struct Arena {
+  enum Slot { PART_KEYS, PART_ROWS, RECV_KEYS, RECV_ROWS, TMP, TMP2, OFFS, ALLOFFS, SAMPLE, ALLSAMPLE, PAIR_L, PAIR_R, CURSOR, MISC_A,
+              MISC_B, MISC_C, MISC_D, MISC_E, MISC_F, SEGTAB, NSLOTS };
+  void* p[NSLOTS]      = {};
+  size_t cap[NSLOTS]   = {};
+  // at least `bytes`; the contents are NOT kept
+  int get(int s, size_t bytes, void** out)
+  {
+    if (bytes > cap[s]) {
+      GXD_HIP(hipDeviceSynchronize());  // nothing may still be using the old block
+      if (p[s]) GXD_HIP(hipFree(p[s]));
+      p[s]   = nullptr;
+      cap[s] = 0;
+      size_t want = bytes + bytes / 8 + 4096;
+      GXD_HIP(hipMalloc(&p[s], want));
+      cap[s] = want;
+    }
+    *out = p[s];
+    return 0;
+  }
+  // at least `bytes`, the first `keep` bytes preserved
+  int grow(int s, size_t bytes, size_t keep, void** out)
+  {
+    if (bytes > cap[s]) {
+      GXD_HIP(hipDeviceSynchronize());
+      void* q     = nullptr;
+      size_t want = bytes + bytes / 4 + 4096;
+      GXD_HIP(hipMalloc(&q, want));
+      if (p[s] && keep) GXD_HIP(hipMemcpy(q, p[s], keep, hipMemcpyDeviceToDevice));
+      if (p[s]) GXD_HIP(hipFree(p[s]));
+      p[s]   = q;
+      cap[s] = want;
+    }
+    *out = p[s];
+    return 0;
+  }
+  void release()
+  {
+    for (int s = 0; s < NSLOTS; ++s)
+      if (p[s]) (void)hipFree(p[s]);
+  }
+};
+
+}  // namespace
+
+struct gxd_comm {
+  ncclComm_t comm = nullptr;
+  int rank = 0, world = 1;
+  hipStream_t xs = nullptr;  // exchange stream
+  std::vector<hipEvent_t> evP;  // partition of chunk c done (caller's stream)
+  hipEvent_t evQ = nullptr, evX = nullptr;
+  long long* pinned = nullptr;  // host staging of count matrices / small reads
+  size_t pinned_elems = 0;
+  Arena arena;
+  double ms[3] = {0, 0, 0};
+};
+
+struct gxd_join {
+  gxd_comm* comm = nullptr;
+  int key_size = 8;
+  bool single = false;  // world == 1 without forced exchange: local rows ARE global rows
+  void* table = nullptr;
+  size_t table_bytes = 0;
+  void* keys_keep = nullptr;      // received build keys (the table stores rows, the keys live in its slots; kept for re-builds only)
+  int32_t* rows = nullptr;        // received (int32 local row at the source), chunk-major / source-minor segments
+  int64_t nrows = 0;
+  std::vector<long long> seg_counts, seg_bases;  // per segment: rows, first global row of the source rank's shard
+  void* segtab = nullptr;                          // device copy: [nseg + 1] starts | [nseg] bases
+};
+
+namespace {
+
+constexpr int MAX_WORLD = 16;  // gx_partition_rows splits into <= 16 groups in one pass (PJ_MAX_SPLIT + 1)
+
+int elem_size(int dtype) { return gx_dtype_size(dtype); }
+
+int ensure_events(gxd_comm* c, int chunks)
+{
+  while ((int)c->evP.size() < chunks) {
+    hipEvent_t e;
+    GXD_HIP(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+    c->evP.push_back(e);
+  }
+  return 0;
+}
+
+int ensure_pinned(gxd_comm* c, size_t elems)
+{
+  if (elems > c->pinned_elems) {
+    if (c->pinned) GXD_HIP(hipHostFree(c->pinned));
+    c->pinned = nullptr;
+    GXD_HIP(hipHostMalloc(reinterpret_cast<void**>(&c->pinned), elems * sizeof(long long), hipHostMallocDefault));
+    c->pinned_elems = elems;
+  }
+  return 0;
+}
+
+// all-gather of `count` int64 per rank (device -> device) followed by a copy to pinned host memory; waits for it.
+int allgather_i64_host(gxd_comm* c, const long long* mine_dev, long long* all_dev, int count, long long* host)
+{
+  if (c->world > 1) GXD_NCCL(ncclAllGather(mine_dev, all_dev, (size_t)count, ncclInt64, c->comm, c->xs));
+  else GXD_HIP(hipMemcpyAsync(all_dev, mine_dev, sizeof(long long) * count, hipMemcpyDeviceToDevice, c->xs));
+  GXD_HIP(hipMemcpyAsync(host, all_dev, sizeof(long long) * count * c->world, hipMemcpyDeviceToHost, c->xs));
+  GXD_HIP(hipEventRecord(c->evQ, c->xs));
+  GXD_HIP(hipEventSynchronize(c->evQ));
+  return 0;
+}
+
+// first global row of every rank's shard (exclusive scan of the shard sizes)
+int shard_bases(gxd_comm* c, int64_t n, std::vector<long long>& bases)
+{
+  void *d1, *d2;
+  GXD_GX(c->arena.get(Arena::MISC_E, sizeof(long long), &d1));
+  GXD_GX(c->arena.get(Arena::MISC_F, sizeof(long long) * c->world, &d2));
+  GXD_GX(ensure_pinned(c, (size_t)c->world * (c->world + 2) * 16));
+  long long mine = n;
+  GXD_HIP(hipMemcpyAsync(d1, &mine, sizeof(mine), hipMemcpyHostToDevice, c->xs));
+  GXD_HIP(hipStreamSynchronize(c->xs));  // `mine` is a stack variable
+  GXD_GX(allgather_i64_host(c, static_cast<long long*>(d1), static_cast<long long*>(d2), 1, c->pinned));
+  bases.assign(c->world, 0);
+  long long run = 0;
+  for (int r = 0; r < c->world; ++r) {
+    bases[r] = run;
+    run += c->pinned[r];
+  }
+  return 0;
+}
+
+struct Exchange {
+  int64_t total = 0;                   // rows received
+  int chunks    = 0;
+  std::vector<long long> seg_counts;   // [chunks * world] rows received per (chunk, source rank), in buffer order
+  std::vector<long long> chunk_start;  // [chunks + 1] first received row of each chunk
+};
+
+// Partition `keys` chunk by chunk into `world` destination groups (mode 0 hash / mode 1 range, gx_partition_rows_at), exchange
+// every chunk as soon as it is partitioned, and call on_chunk(c, first received row, rows) when the chunk's rows have been
+// POSTED on the exchange stream (evX is recorded behind them; the callee makes its stream wait for it).
+int partition_exchange(gxd_comm* c, int dtype, const void* keys, int64_t n, int mode, const void* splitters_host, bool want_rows,
+                       int chunks, hipStream_t stream, Exchange* ex, const std::function<int(int, int64_t, int64_t)>& on_chunk)
+{
+  const int W  = c->world;
+  const int es = elem_size(dtype);
+  if (chunks <= 0) chunks = 8;
+  if (n < (int64_t)chunks * (1 << 20)) chunks = (int)std::max<int64_t>(1, n >> 20);  // small shards: fewer, larger chunks
+  const int64_t crows = ((n + chunks - 1) / chunks + 16383) / 16384 * 16384;          // whole scatter tiles per chunk
+  chunks              = n > 0 ? (int)((n + crows - 1) / crows) : 1;
+  ex->chunks          = chunks;
+  ex->seg_counts.assign((size_t)chunks * W, 0);
+  ex->chunk_start.assign((size_t)chunks + 1, 0);
+  GXD_GX(ensure_events(c, chunks));
+  GXD_GX(ensure_pinned(c, (size_t)W * (W + 1) + 64));
+  void *pk, *prow = nullptr, *offs, *alloffs, *tmp;
+  GXD_GX(c->arena.get(Arena::PART_KEYS, (size_t)std::max<int64_t>(n, 1) * es, &pk));
+  if (want_rows) GXD_GX(c->arena.get(Arena::PART_ROWS, (size_t)std::max<int64_t>(n, 1) * 4, &prow));
+  GXD_GX(c->arena.get(Arena::OFFS, sizeof(long long) * (size_t)chunks * (W + 1), &offs));
+  GXD_GX(c->arena.get(Arena::ALLOFFS, sizeof(long long) * (size_t)W * (W + 1), &alloffs));
+  size_t tb = 0;
+  GXD_GX(gx_partition_rows_at(dtype, keys, crows, 0, mode, W, splitters_host, pk, static_cast<int32_t*>(prow), static_cast<int64_t*>(offs),
+                              nullptr, &tb, stream));
+  GXD_GX(c->arena.get(Arena::TMP, tb ? tb : 1, &tmp));
+  const double t0 = now_ms();
+  // ---- every partition pass is enqueued before the first wait
+  for (int k = 0; k < chunks; ++k) {
+    const int64_t c0 = (int64_t)k * crows;
+    const int64_t nc = std::min<int64_t>(crows, n - c0);
+    GXD_GX(gx_partition_rows_at(dtype, static_cast<const char*>(keys) + c0 * es, nc, (int32_t)c0, mode, W, splitters_host,
+                                static_cast<char*>(pk) + c0 * es, want_rows ? static_cast<int32_t*>(prow) + c0 : nullptr,
+                                static_cast<int64_t*>(offs) + (size_t)k * (W + 1), tmp, &tb, stream));
+    GXD_HIP(hipEventRecord(c->evP[k], stream));
+  }
+  c->ms[0] = now_ms() - t0;
+  // ---- exchange, chunk by chunk
+  int64_t rpos      = 0;
+  int64_t recv_cap  = 0;  // elements the receive buffers hold
+  void *rk = nullptr, *rr = nullptr;
+  {
+    const int64_t guess = n + n / 4 + 65536;
+    GXD_GX(c->arena.get(Arena::RECV_KEYS, (size_t)guess * es, &rk));
+    if (want_rows) GXD_GX(c->arena.get(Arena::RECV_ROWS, (size_t)guess * 4, &rr));
+    recv_cap = std::min<int64_t>((int64_t)(c->arena.cap[Arena::RECV_KEYS] / es), want_rows ? (int64_t)(c->arena.cap[Arena::RECV_ROWS] / 4) : INT64_MAX);
+  }
+  double waited = 0;
+  for (int k = 0; k < chunks; ++k) {
+    const int64_t c0 = (int64_t)k * crows;
+    GXD_HIP(hipStreamWaitEvent(c->xs, c->evP[k], 0));
+    const double w0 = now_ms();
+    GXD_GX(allgather_i64_host(c, static_cast<long long*>(offs) + (size_t)k * (W + 1), static_cast<long long*>(alloffs), W + 1, c->pinned));
+    waited += now_ms() - w0;
+    const long long* M = c->pinned;  // M[r * (W + 1) + j] = first row of rank r's group j in its chunk
+    int64_t rtotal     = 0;
+    for (int r = 0; r < W; ++r) rtotal += M[r * (W + 1) + c->rank + 1] - M[r * (W + 1) + c->rank];
+    if (rpos + rtotal > recv_cap) {  // (rare: a skewed split) grow, keeping what has arrived
+      GXD_HIP(hipStreamSynchronize(c->xs));
+      const int64_t want = rpos + rtotal + (rpos + rtotal) / 4;
+      GXD_GX(c->arena.grow(Arena::RECV_KEYS, (size_t)want * es, (size_t)rpos * es, &rk));
+      if (want_rows) GXD_GX(c->arena.grow(Arena::RECV_ROWS, (size_t)want * 4, (size_t)rpos * 4, &rr));
+      recv_cap = want;
+    }
+    ex->chunk_start[k] = rpos;
+    if (W > 1) GXD_NCCL(ncclGroupStart());
+    for (int r = 0; r < W; ++r) {
+      const int64_t so = M[c->rank * (W + 1) + r], sc = M[c->rank * (W + 1) + r + 1] - so;  // what I send to r
+      const int64_t rc = M[r * (W + 1) + c->rank + 1] - M[r * (W + 1) + c->rank];          // what r sends to me
+      ex->seg_counts[(size_t)k * W + r] = rc;
+      const char* sk = static_cast<const char*>(pk) + (c0 + so) * es;
+      char* dk       = static_cast<char*>(rk) + rpos * es;
+      if (r == c->rank) {  // my own group: a device-local copy on the exchange stream
+        if (sc) GXD_HIP(hipMemcpyAsync(dk, sk, (size_t)sc * es, hipMemcpyDeviceToDevice, c->xs));
+        if (want_rows && sc)
+          GXD_HIP(hipMemcpyAsync(static_cast<int32_t*>(rr) + rpos, static_cast<const int32_t*>(prow) + c0 + so, (size_t)sc * 4,
+                                 hipMemcpyDeviceToDevice, c->xs));
+      } else {
+        if (sc) GXD_NCCL(ncclSend(sk, (size_t)sc * es, ncclInt8, r, c->comm, c->xs));
+        if (rc) GXD_NCCL(ncclRecv(dk, (size_t)rc * es, ncclInt8, r, c->comm, c->xs));
+        if (want_rows) {
+          if (sc) GXD_NCCL(ncclSend(static_cast<const int32_t*>(prow) + c0 + so, (size_t)sc, ncclInt32, r, c->comm, c->xs));
+          if (rc) GXD_NCCL(ncclRecv(static_cast<int32_t*>(rr) + rpos, (size_t)rc, ncclInt32, r, c->comm, c->xs));
+        }
+      }
+      rpos += rc;
+    }
+    if (W > 1) GXD_NCCL(ncclGroupEnd());
+    GXD_HIP(hipEventRecord(c->evX, c->xs));
+    if (on_chunk) {
+      int rc2 = on_chunk(k, ex->chunk_start[k], rpos - ex->chunk_start[k]);
+      if (rc2) return rc2;
+    }
+  }
+  ex->chunk_start[chunks] = rpos;
+  ex->total               = rpos;
+  c->ms[1]                = waited;
+  return 0;
+}
+
+template <typename F>
+int with_tmp(gxd_comm* c, int slot, F&& f)
+{
+  size_t b = 0;
+  GXD_GX(f(nullptr, &b));
+  void* t;
+  GXD_GX(c->arena.get(slot, b ? b : 1, &t));
+  GXD_GX(f(t, &b));
+  return 0;
+}
+
+// device table for gx_gather_global_rows_dev: [nseg + 1] int64 starts, then [nseg] int64 bases
+int upload_segtab(gxd_comm* c, const std::vector<long long>& counts, const std::vector<long long>& bases, void* dst, hipStream_t s)
+{
+  const size_t nseg = counts.size();
+  std::vector<long long> h(2 * nseg + 1);
+  long long run = 0;
+  for (size_t i = 0; i < nseg; ++i) {
+    h[i] = run;
+    run += counts[i];
+  }
+  h[nseg] = run;
+  for (size_t i = 0; i < nseg; ++i) h[nseg + 1 + i] = bases[i];
+  GXD_HIP(hipMemcpyAsync(dst, h.data(), h.size() * sizeof(long long), hipMemcpyHostToDevice, s));
+  GXD_HIP(hipStreamSynchronize(s));  // `h` dies here
+  (void)c;
+  return 0;
+}
+
+}  // namespace
+
+extern "C" {
+
+const char* gxd_last_error(void) { return g_err.c_str(); }
+
+int gxd_unique_id(void* id128_host)
+{
+  if (!id128_host) return GX_EINVAL;
+  static_assert(sizeof(ncclUniqueId) == 128, "gxd_unique_id hands out 128 bytes");
+  ncclUniqueId id;
+  GXD_NCCL(ncclGetUniqueId(&id));
+  std::memcpy(id128_host, &id, sizeof(id));
+  return 0;
+}
+
+int gxd_comm_create(const void* id128_host, int world, int rank, gxd_comm** out)
+{
+  if (!id128_host || !out || world < 1 || rank < 0 || rank >= world) return GX_EINVAL;
+  if (world > MAX_WORLD) return fail(GX_EINVAL, "gxd: at most 16 ranks (one partition pass splits into <= 16 groups)");
+  auto* c  = new gxd_comm;
+  c->rank  = rank;
+  c->world = world;
+  ncclUniqueId id;
+  std::memcpy(&id, id128_host, sizeof(id));
+  if (world > 1) {
+    ncclResult_t r = ncclCommInitRank(&c->comm, world, id, rank);
+    if (r != ncclSuccess) {
+      delete c;
+      return fail(GX_EINTERNAL, std::string("ncclCommInitRank: ") + ncclGetErrorString(r));
+    }
+  }
+  GXD_HIP(hipStreamCreateWithFlags(&c->xs, hipStreamNonBlocking));
+  GXD_HIP(hipEventCreateWithFlags(&c->evQ, hipEventDisableTiming));
+  GXD_HIP(hipEventCreateWithFlags(&c->evX, hipEventDisableTiming));
+  *out = c;
+  return 0;
+}
+
+int gxd_comm_destroy(gxd_comm* c)
+{
+  if (!c) return 0;
+  (void)hipDeviceSynchronize();
+  c->arena.release();
+  for (auto e : c->evP) (void)hipEventDestroy(e);
+  if (c->evQ) (void)hipEventDestroy(c->evQ);
+  if (c->evX) (void)hipEventDestroy(c->evX);
+  if (c->pinned) (void)hipHostFree(c->pinned);
+  if (c->xs) (void)hipStreamDestroy(c->xs);
+  if (c->comm) (void)ncclCommDestroy(c->comm);
+  delete c;
+  return 0;
+}
+
+int gxd_comm_rank(const gxd_comm* c) { return c ? c->rank : -1; }
+int gxd_comm_world(const gxd_comm* c) { return c ? c->world : -1; }
+int gxd_last_timing(const gxd_comm* c, double* ms3_host)
+{
+  if (!c || !ms3_host) return GX_EINVAL;
+  for (int i = 0; i < 3; ++i) ms3_host[i] = c->ms[i];
+  return 0;
+}
+
+// ------------------------------------------------------------------------------------------------------------ sort
+int gxd_sort(gxd_comm* c, int dtype, const void* keys, int64_t n, int chunks, int force_exchange, gxd_alloc_fn alloc, void* actx,
+             void** out_keys, int64_t* out_n, gx_stream_t gstream)
+{
+  if (!c || !alloc || !out_keys || !out_n || n < 0 || (n > 0 && !keys)) return GX_EINVAL;
+  const int es = elem_size(dtype);
+  if (es != 4 && es != 8) return GX_EDTYPE;
+  hipStream_t stream = reinterpret_cast<hipStream_t>(gstream);
+  const double t0    = now_ms();
+  const int W        = c->world;
+  *out_keys          = nullptr;
+  *out_n             = 0;
+  if (W == 1 && !force_exchange) {
+    if (n == 0) return 0;
+    void* out = alloc((size_t)n * es, actx);
+    if (!out) return fail(GX_EINVAL, "gxd_sort: allocator returned NULL");
+    GXD_GX(with_tmp(c, Arena::TMP2, [&](void* t, size_t* b) { return gx_sort_keys(dtype, keys, out, n, 0, t, b, gstream); }));
+    GXD_HIP(hipStreamSynchronize(stream));
+    *out_keys = out;
+    *out_n    = n;
+    c->ms[2]  = now_ms() - t0;
+    return 0;
+  }
+  // ---- splitters from an evenly strided sample of every shard (collectives/sort.py: sample -> allgather -> boundaries)
+  constexpr int S = 1024;
+  void *samp, *allsamp, *sorted;
+  GXD_GX(c->arena.get(Arena::SAMPLE, (size_t)S * es, &samp));
+  GXD_GX(c->arena.get(Arena::ALLSAMPLE, (size_t)S * es * W, &allsamp));
+  GXD_GX(c->arena.get(Arena::MISC_A, (size_t)S * es * W, &sorted));
+  GXD_HIP(hipStreamSynchronize(stream));  // the caller's keys are ready from here on for the exchange stream as well
+  if (n >= S) {
+    const int64_t stride = (n - 1) / (S - 1);
+    GXD_HIP(hipMemcpy2DAsync(samp, (size_t)es, keys, (size_t)stride * es, (size_t)es, S, hipMemcpyDeviceToDevice, c->xs));
+  } else {  // tiny or empty shard: cyclic copies of what there is; an empty shard contributes all-ones bit patterns
+    std::vector<char> h((size_t)S * es, (char)0xFF), mine((size_t)std::max<int64_t>(n, 1) * es);
+    if (n > 0) {
+      GXD_HIP(hipMemcpy(mine.data(), keys, (size_t)n * es, hipMemcpyDeviceToHost));
+      for (int i = 0; i < S; ++i) std::memcpy(&h[(size_t)i * es], &mine[(size_t)((int64_t)i * n / S) * es], es);
+    } else if (dtype == GX_INT32 || dtype == GX_INT64 || dtype == GX_FLOAT32 || dtype == GX_FLOAT64) {
+      for (int i = 0; i < S; ++i) h[(size_t)i * es + es - 1] = (char)0x7F;  // INT_MAX / a NaN: sorts last either way
+    }
+    GXD_HIP(hipMemcpy(samp, h.data(), h.size(), hipMemcpyHostToDevice));
+  }
+  if (W > 1) GXD_NCCL(ncclAllGather(samp, allsamp, (size_t)S * es, ncclInt8, c->comm, c->xs));
+  else GXD_HIP(hipMemcpyAsync(allsamp, samp, (size_t)S * es, hipMemcpyDeviceToDevice, c->xs));
+  GXD_GX(with_tmp(c, Arena::TMP2, [&](void* t, size_t* b) {
+    return gx_sort_keys(dtype, allsamp, sorted, (int64_t)S * W, 0, t, b, reinterpret_cast<gx_stream_t>(c->xs));
+  }));
+  std::vector<char> hs((size_t)S * es * W), split((size_t)MAX_WORLD * 8, 0);
+  GXD_HIP(hipMemcpyAsync(hs.data(), sorted, hs.size(), hipMemcpyDeviceToHost, c->xs));
+  GXD_HIP(hipStreamSynchronize(c->xs));
+  for (int r = 1; r < W; ++r) std::memcpy(&split[(size_t)(r - 1) * es], &hs[(size_t)r * S * es], es);
+  // ---- one range-partition pass per chunk, exchange, one local sort
+  Exchange ex;
+  GXD_GX(partition_exchange(c, dtype, keys, n, 1, split.data(), false, chunks, stream, &ex, nullptr));
+  GXD_HIP(hipStreamWaitEvent(stream, c->evX, 0));
+  if (ex.total > 0) {
+    void* out = alloc((size_t)ex.total * es, actx);
+    if (!out) return fail(GX_EINVAL, "gxd_sort: allocator returned NULL");
+    void* rk = c->arena.p[Arena::RECV_KEYS];
+    GXD_GX(with_tmp(c, Arena::TMP2, [&](void* t, size_t* b) { return gx_sort_keys(dtype, rk, out, ex.total, 0, t, b, gstream); }));
+    *out_keys = out;
+  }
+  GXD_HIP(hipStreamSynchronize(stream));
+  *out_n   = ex.total;
+  c->ms[2] = now_ms() - t0;
+  return 0;
+}
+
+// ------------------------------------------------------------------------------------------------------------ join
+int gxd_join_build(gxd_comm* c, int key_dtype, const void* build_keys, int64_t n, int force_exchange, gx_stream_t gstream, gxd_join** out)
+{
+  if (!c || !out || n < 0 || (n > 0 && !build_keys)) return GX_EINVAL;
+  const int ks = elem_size(key_dtype);
+  if (ks != 4 && ks != 8) return GX_EDTYPE;
+  hipStream_t stream = reinterpret_cast<hipStream_t>(gstream);
+  const double t0    = now_ms();
+  auto* j            = new gxd_join;
+  j->comm            = c;
+  j->key_size        = ks;
+  j->single          = c->world == 1 && !force_exchange;
+  const void* tkeys  = build_keys;
+  int64_t tn         = n;
+  if (!j->single) {
+    std::vector<long long> bases;
+    GXD_HIP(hipStreamSynchronize(stream));
+    GXD_GX(shard_bases(c, n, bases));
+    Exchange ex;
+    GXD_GX(partition_exchange(c, key_dtype, build_keys, n, 0, nullptr, true, 4, stream, &ex, nullptr));
+    GXD_HIP(hipStreamWaitEvent(stream, c->evX, 0));
+    GXD_HIP(hipStreamSynchronize(stream));
+    // the received rows stay with the table (the arena's receive buffers are reused by every probe)
+    j->nrows = ex.total;
+    GXD_HIP(hipMalloc(reinterpret_cast<void**>(&j->rows), (size_t)std::max<int64_t>(ex.total, 1) * 4));
+    GXD_HIP(hipMalloc(&j->keys_keep, (size_t)std::max<int64_t>(ex.total, 1) * ks));
+    GXD_HIP(hipMemcpy(j->rows, c->arena.p[Arena::RECV_ROWS], (size_t)ex.total * 4, hipMemcpyDeviceToDevice));
+    GXD_HIP(hipMemcpy(j->keys_keep, c->arena.p[Arena::RECV_KEYS], (size_t)ex.total * ks, hipMemcpyDeviceToDevice));
+    j->seg_counts = ex.seg_counts;
+    j->seg_bases.resize(ex.seg_counts.size());
+    for (size_t i = 0; i < ex.seg_counts.size(); ++i) j->seg_bases[i] = bases[i % c->world];
+    GXD_HIP(hipMalloc(&j->segtab, (2 * j->seg_counts.size() + 1) * sizeof(long long)));
+    GXD_GX(upload_segtab(c, j->seg_counts, j->seg_bases, j->segtab, stream));
+    tkeys = j->keys_keep;
+    tn    = ex.total;
+  }
+  j->table_bytes = gx_join_table_bytes(ks, tn, 0.5);
+  GXD_HIP(hipMalloc(&j->table, j->table_bytes));
+  if (tn >= (1 << 20) && gx_join_partition_bits(ks, j->table_bytes) > 0) {
+    GXD_GX(with_tmp(c, Arena::TMP2, [&](void* t, size_t* b) {
+      return gx_join_build_partitioned(ks, tkeys, tn, j->table, j->table_bytes, 0.5, t, b, gstream);
+    }));
+  } else {
+    GXD_GX(gx_join_build(ks, tkeys, nullptr, tn, j->table, j->table_bytes, 0.5, gstream));
+  }
+  GXD_HIP(hipStreamSynchronize(stream));
+  c->ms[2] = now_ms() - t0;
+  *out     = j;
+  return 0;
+}
+
+int gxd_join_destroy(gxd_join* j)
+{
+  if (!j) return 0;
+  (void)hipDeviceSynchronize();
+  if (j->table) (void)hipFree(j->table);
+  if (j->rows) (void)hipFree(j->rows);
+  if (j->keys_keep) (void)hipFree(j->keys_keep);
+  if (j->segtab) (void)hipFree(j->segtab);
+  delete j;
+  return 0;
+}
+
+int gxd_join_probe(gxd_join* j, const void* probe_keys, int64_t n, int chunks, gxd_alloc_fn alloc, void* actx, int64_t** out_probe_rows,
+                   int64_t** out_build_rows, int64_t* out_pairs, gx_stream_t gstream)
+{
+  if (!j || !alloc || !out_probe_rows || !out_build_rows || !out_pairs || n < 0 || (n > 0 && !probe_keys)) return GX_EINVAL;
+  gxd_comm* c        = j->comm;
+  hipStream_t stream = reinterpret_cast<hipStream_t>(gstream);
+  const int ks       = j->key_size;
+  const int W        = c->world;
+  const double t0    = now_ms();
+  *out_probe_rows = *out_build_rows = nullptr;
+  *out_pairs                        = 0;
+  void* cur;
+  GXD_GX(c->arena.get(Arena::CURSOR, 256, &cur));
+  const int key_dtype    = ks == 8 ? GX_INT64 : GX_INT32;  // bit patterns are hashed / compared
+  const bool partitioned = gx_join_partition_bits(ks, j->table_bytes) > 0;
+
+  auto probe_into = [&](const void* keys, int64_t rows, int32_t row_base, void* pl, void* pr, int64_t cap) -> int {
+    if (rows == 0) return 0;
+    if (partitioned)
+      return with_tmp(c, Arena::TMP2, [&](void* t, size_t* b) {
+        return gx_join_probe_partitioned_at(ks, keys, rows, row_base, j->table, j->table_bytes, 0, static_cast<int32_t*>(pl),
+                                            static_cast<int32_t*>(pr), cap, static_cast<int64_t*>(cur), t, b, gstream);
+      });
+    return gx_join_probe(ks, keys, nullptr, rows, j->table, j->table_bytes, 0, static_cast<int32_t*>(pl), static_cast<int32_t*>(pr), cap,
+                         static_cast<int64_t*>(cur), gstream);
+  };
+  auto read_cursor = [&](long long* v) -> int {
+    GXD_HIP(hipMemcpyAsync(v, cur, sizeof(long long), hipMemcpyDeviceToHost, stream));
+    GXD_HIP(hipStreamSynchronize(stream));
+    return 0;
+  };
+
+  if (j->single) {  // one rank, no exchange: local rows are global rows
+    int64_t cap = std::max<int64_t>(n, 1);
+    long long pairs = 0;
+    for (int attempt = 0; attempt < 2; ++attempt) {
+      void *pl, *pr;
+      GXD_GX(c->arena.get(Arena::PAIR_L, (size_t)cap * 4, &pl));
+      GXD_GX(c->arena.get(Arena::PAIR_R, (size_t)cap * 4, &pr));
+      GXD_HIP(hipMemsetAsync(cur, 0, 8, stream));
+      GXD_GX(probe_into(probe_keys, n, 0, pl, pr, cap));
+      GXD_GX(read_cursor(&pairs));
+      if (pairs <= cap) break;
+      cap = pairs;  // duplicate build keys blew the guess: the size is now known exactly
+    }
+    if (pairs > 0) {
+      auto* ol = static_cast<int64_t*>(alloc((size_t)pairs * 8, actx));
+      auto* orr = static_cast<int64_t*>(alloc((size_t)pairs * 8, actx));
+      if (!ol || !orr) return fail(GX_EINVAL, "gxd_join_probe: allocator returned NULL");
+      GXD_GX(gx_widen_i32_i64(static_cast<const int32_t*>(c->arena.p[Arena::PAIR_L]), pairs, ol, gstream));
+      GXD_GX(gx_widen_i32_i64(static_cast<const int32_t*>(c->arena.p[Arena::PAIR_R]), pairs, orr, gstream));
+      *out_probe_rows = ol;
+      *out_build_rows = orr;
+    }
+    GXD_HIP(hipStreamSynchronize(stream));
+    *out_pairs = pairs;
+    c->ms[2]   = now_ms() - t0;
+    return 0;
+  }
+
+  std::vector<long long> bases;
+  GXD_HIP(hipStreamSynchronize(stream));
+  GXD_GX(shard_bases(c, n, bases));
+  Exchange ex;
+  int64_t pair_cap = 0;
+  void *pl = nullptr, *pr = nullptr;
+  GXD_HIP(hipMemsetAsync(cur, 0, 8, stream));
+  // a chunk is probed as soon as it has been posted: its probe overlaps the exchange of the later chunks
+  auto on_chunk = [&](int k, int64_t first, int64_t rows) -> int {
+    (void)k;
+    if (!partitioned) return 0;  // small tables: one direct probe of everything at the end
+    const int64_t need = first + rows;
+    if (need > pair_cap) {  // pairs <= probe rows unless build keys repeat (checked at the end)
+      const int64_t want = std::max<int64_t>(need + need / 4, n + n / 4 + 65536);
+      GXD_GX(c->arena.grow(Arena::PAIR_L, (size_t)want * 4, (size_t)pair_cap * 4, &pl));
+      GXD_GX(c->arena.grow(Arena::PAIR_R, (size_t)want * 4, (size_t)pair_cap * 4, &pr));
+      pair_cap = want;
+    }
+    GXD_HIP(hipStreamWaitEvent(stream, c->evX, 0));
+    const char* rk = static_cast<const char*>(c->arena.p[Arena::RECV_KEYS]);
+    return probe_into(rk + first * ks, rows, (int32_t)first, pl, pr, pair_cap);
+  };
+  GXD_GX(partition_exchange(c, key_dtype, probe_keys, n, 0, nullptr, true, chunks, stream, &ex, on_chunk));
+  GXD_HIP(hipStreamWaitEvent(stream, c->evX, 0));
+  long long pairs = 0;
+  if (!partitioned) {
+    pair_cap = std::max<int64_t>(ex.total, 1);
+    GXD_GX(c->arena.get(Arena::PAIR_L, (size_t)pair_cap * 4, &pl));
+    GXD_GX(c->arena.get(Arena::PAIR_R, (size_t)pair_cap * 4, &pr));
+    GXD_GX(probe_into(c->arena.p[Arena::RECV_KEYS], ex.total, 0, pl, pr, pair_cap));
+  }
+  GXD_GX(read_cursor(&pairs));
+  if (pairs > pair_cap) {  // duplicate build keys: probe again into buffers of the exact size
+    pair_cap = pairs;
+    GXD_GX(c->arena.get(Arena::PAIR_L, (size_t)pair_cap * 4, &pl));
+    GXD_GX(c->arena.get(Arena::PAIR_R, (size_t)pair_cap * 4, &pr));
+    GXD_HIP(hipMemsetAsync(cur, 0, 8, stream));
+    const char* rk = static_cast<const char*>(c->arena.p[Arena::RECV_KEYS]);
+    if (partitioned) {
+      for (int k = 0; k < ex.chunks; ++k)
+        GXD_GX(probe_into(rk + ex.chunk_start[k] * ks, ex.chunk_start[k + 1] - ex.chunk_start[k], (int32_t)ex.chunk_start[k], pl, pr, pair_cap));
+    } else {
+      GXD_GX(probe_into(rk, ex.total, 0, pl, pr, pair_cap));
+    }
+    GXD_GX(read_cursor(&pairs));
+  }
+  if (pairs > 0) {
+    auto* ol  = static_cast<int64_t*>(alloc((size_t)pairs * 8, actx));
+    auto* orr = static_cast<int64_t*>(alloc((size_t)pairs * 8, actx));
+    if (!ol || !orr) return fail(GX_EINVAL, "gxd_join_probe: allocator returned NULL");
+    // (position in the receive buffer) -> (int32 local row at its source) + (first global row of that source's shard)
+    std::vector<long long> segb(ex.seg_counts.size());
+    for (size_t i = 0; i < segb.size(); ++i) segb[i] = bases[i % W];
+    void* st;
+    GXD_GX(c->arena.get(Arena::SEGTAB, (2 * segb.size() + 1) * sizeof(long long), &st));
+    GXD_GX(upload_segtab(c, ex.seg_counts, segb, st, stream));
+    GXD_GX(gx_gather_global_rows_dev(static_cast<const int32_t*>(c->arena.p[Arena::RECV_ROWS]), ex.total, static_cast<const int32_t*>(pl), pairs,
+                                     (int)segb.size(), static_cast<const int64_t*>(st), ol, gstream));
+    GXD_GX(gx_gather_global_rows_dev(j->rows, j->nrows, static_cast<const int32_t*>(pr), pairs, (int)j->seg_counts.size(),
+                                     static_cast<const int64_t*>(j->segtab), orr, gstream));
+    *out_probe_rows = ol;
+    *out_build_rows = orr;
+  }
+  GXD_HIP(hipStreamSynchronize(stream));
+  *out_pairs = pairs;
+  c->ms[2]   = now_ms() - t0;
+  return 0;
+}
+
+// ------------------------------------------------------------------------------------------------------------ groupby
+int gxd_groupby_sum_count(gxd_comm* c, int key_dtype, const void* keys, int val_dtype, const void* vals, int64_t n, int64_t max_groups,
+                          int force_exchange, gxd_alloc_fn alloc, void* actx, void** out_keys, void** out_sums, int64_t** out_counts,
+                          int64_t* out_groups, gx_stream_t gstream)
+{
+  if (!c || !alloc || !out_keys || !out_sums || !out_counts || !out_groups || n < 0 || (n > 0 && (!keys || !vals))) return GX_EINVAL;
+  const int ks = elem_size(key_dtype);
+  if ((key_dtype != GX_INT32 && key_dtype != GX_INT64)) return GX_EDTYPE;
+  const bool fsum    = val_dtype == GX_FLOAT32 || val_dtype == GX_FLOAT64;
+  const int sum_type = fsum ? GX_FLOAT64 : GX_INT64;
+  if (!fsum && val_dtype != GX_INT32 && val_dtype != GX_INT64) return GX_EDTYPE;
+  hipStream_t stream = reinterpret_cast<hipStream_t>(gstream);
+  const double t0    = now_ms();
+  const int W        = c->world;
+  *out_keys = *out_sums = nullptr;
+  *out_counts           = nullptr;
+  *out_groups           = 0;
+  if (max_groups <= 0) max_groups = std::max<int64_t>(std::min<int64_t>(n, 1 << 20), 1);
+  // ---- local aggregate: at most #groups partial rows leave this rank
+  void *pk, *ps, *pc, *ng;
+  GXD_GX(c->arena.get(Arena::MISC_A, (size_t)max_groups * ks, &pk));
+  GXD_GX(c->arena.get(Arena::MISC_B, (size_t)max_groups * 8, &ps));
+  GXD_GX(c->arena.get(Arena::MISC_C, (size_t)max_groups * 4, &pc));
+  GXD_GX(c->arena.get(Arena::CURSOR, 256, &ng));
+  long long g = 0;
+  for (int attempt = 0; attempt < 2; ++attempt) {
+    GXD_HIP(hipMemsetAsync(ng, 0, 8, stream));
+    if (n > 0)
+      GXD_GX(with_tmp(c, Arena::TMP2, [&](void* t, size_t* b) {
+        return gx_groupby_sum_count(key_dtype, keys, nullptr, val_dtype, vals, nullptr, n, max_groups, pk, ps, static_cast<int32_t*>(pc), nullptr,
+                                    static_cast<int64_t*>(ng), t, b, gstream);
+      }));
+    GXD_HIP(hipMemcpyAsync(&g, ng, 8, hipMemcpyDeviceToHost, stream));
+    GXD_HIP(hipStreamSynchronize(stream));
+    if (g <= max_groups) break;
+    max_groups = g;  // more groups than the caller's bound: the count is exact now
+    GXD_GX(c->arena.get(Arena::MISC_A, (size_t)max_groups * ks, &pk));
+    GXD_GX(c->arena.get(Arena::MISC_B, (size_t)max_groups * 8, &ps));
+    GXD_GX(c->arena.get(Arena::MISC_C, (size_t)max_groups * 4, &pc));
+  }
+  // counts as int64 partials (they are summed again after the exchange)
+  void* pc64;
+  GXD_GX(c->arena.get(Arena::MISC_D, (size_t)std::max<long long>(g, 1) * 8, &pc64));
+  if (g > 0) GXD_GX(gx_widen_i32_i64(static_cast<const int32_t*>(pc), g, static_cast<int64_t*>(pc64), gstream));
+  const void *mk = pk, *msum = ps, *mcnt = pc64;
+  int64_t mrows = g;
+  void *rs = nullptr, *rc = nullptr;
+  if (!(W == 1 && !force_exchange)) {
+    // ---- hash-partition the partial rows, exchange keys + (sum, count) gathered into the same order
+    GXD_HIP(hipStreamSynchronize(stream));
+    Exchange ex;
+    GXD_GX(partition_exchange(c, key_dtype, pk, g, 0, nullptr, true, 1, stream, &ex, nullptr));
+    // the (sum, count) payload rides the SAME split: gather by the partition's row map, then one more grouped exchange
+    void *gs, *gc;
+    GXD_GX(c->arena.get(Arena::MISC_E, (size_t)std::max<long long>(g, 1) * 8, &gs));
+    GXD_GX(c->arena.get(Arena::MISC_F, (size_t)std::max<long long>(g, 1) * 8, &gc));
+    if (g > 0) {
+      const int32_t* prow = static_cast<const int32_t*>(c->arena.p[Arena::PART_ROWS]);
+      GXD_GX(gx_gather(8, ps, nullptr, g, prow, g, 0, gs, nullptr, gstream));
+      GXD_GX(gx_gather(8, pc64, nullptr, g, prow, g, 0, gc, nullptr, gstream));
+    }
+    GXD_HIP(hipEventRecord(c->evP[0], stream));
+    GXD_HIP(hipStreamWaitEvent(c->xs, c->evP[0], 0));
+    GXD_GX(c->arena.get(Arena::PAIR_L, (size_t)std::max<int64_t>(ex.total, 1) * 8, &rs));
+    GXD_GX(c->arena.get(Arena::PAIR_R, (size_t)std::max<int64_t>(ex.total, 1) * 8, &rc));
+    // the count matrix of the single chunk is still in pinned memory (partition_exchange left it there)
+    const long long* M = c->pinned;
+    int64_t rpos = 0;
+    if (W > 1) GXD_NCCL(ncclGroupStart());
+    for (int r = 0; r < W; ++r) {
+      const int64_t so = M[c->rank * (W + 1) + r], sc = M[c->rank * (W + 1) + r + 1] - so;
+      const int64_t rcv = M[r * (W + 1) + c->rank + 1] - M[r * (W + 1) + c->rank];
+      if (r == c->rank) {
+        if (sc) {
+          GXD_HIP(hipMemcpyAsync(static_cast<char*>(rs) + rpos * 8, static_cast<const char*>(gs) + so * 8, (size_t)sc * 8, hipMemcpyDeviceToDevice, c->xs));
+          GXD_HIP(hipMemcpyAsync(static_cast<char*>(rc) + rpos * 8, static_cast<const char*>(gc) + so * 8, (size_t)sc * 8, hipMemcpyDeviceToDevice, c->xs));
+        }
+      } else {
+        if (sc) {
+          GXD_NCCL(ncclSend(static_cast<const char*>(gs) + so * 8, (size_t)sc * 8, ncclInt8, r, c->comm, c->xs));
+          GXD_NCCL(ncclSend(static_cast<const char*>(gc) + so * 8, (size_t)sc * 8, ncclInt8, r, c->comm, c->xs));
+        }
+        if (rcv) {
+          GXD_NCCL(ncclRecv(static_cast<char*>(rs) + rpos * 8, (size_t)rcv * 8, ncclInt8, r, c->comm, c->xs));
+          GXD_NCCL(ncclRecv(static_cast<char*>(rc) + rpos * 8, (size_t)rcv * 8, ncclInt8, r, c->comm, c->xs));
+        }
+      }
+      rpos += rcv;
+    }
+    if (W > 1) GXD_NCCL(ncclGroupEnd());
+    GXD_HIP(hipEventRecord(c->evX, c->xs));
+    GXD_HIP(hipStreamWaitEvent(stream, c->evX, 0));
+    mk    = c->arena.p[Arena::RECV_KEYS];
+    msum  = rs;
+    mcnt  = rc;
+    mrows = ex.total;
+  } else if (g == 0) {
+    c->ms[2] = now_ms() - t0;
+    return 0;
+  }
+  if (mrows == 0) {
+    GXD_HIP(hipStreamSynchronize(stream));
+    c->ms[2] = now_ms() - t0;
+    return 0;
+  }
+  // ---- merge: ONE grouping of the received partials (sorted order, run heads, labels) carries the sum and the count
+  void *order, *sk, *ss, *sc2, *heads, *labels, *offsets;
+  GXD_GX(c->arena.get(Arena::PART_KEYS, (size_t)mrows * 4, &order));
+  GXD_GX(with_tmp(c, Arena::TMP2, [&](void* t, size_t* b) {
+    return gx_sorted_order(key_dtype, mk, nullptr, mrows, 0, 0, 1, static_cast<int32_t*>(order), t, b, gstream);
+  }));
+  GXD_GX(c->arena.get(Arena::SAMPLE, (size_t)mrows * ks, &sk));
+  GXD_GX(c->arena.get(Arena::ALLSAMPLE, (size_t)mrows * 8, &ss));
+  GXD_GX(c->arena.get(Arena::OFFS, (size_t)mrows * 8, &sc2));
+  GXD_GX(gx_gather(ks, mk, nullptr, mrows, static_cast<const int32_t*>(order), mrows, 0, sk, nullptr, gstream));
+  GXD_GX(gx_gather(8, msum, nullptr, mrows, static_cast<const int32_t*>(order), mrows, 0, ss, nullptr, gstream));
+  GXD_GX(gx_gather(8, mcnt, nullptr, mrows, static_cast<const int32_t*>(order), mrows, 0, sc2, nullptr, gstream));
+  GXD_GX(c->arena.get(Arena::ALLOFFS, (size_t)mrows, &heads));
+  GXD_GX(c->arena.get(Arena::PART_ROWS, (size_t)mrows * 4, &labels));
+  GXD_GX(c->arena.get(Arena::SEGTAB, ((size_t)mrows + 1) * 4, &offsets));
+  GXD_GX(gx_group_heads(key_dtype, sk, nullptr, nullptr, mrows, 0, static_cast<uint8_t*>(heads), gstream));
+  GXD_HIP(hipMemsetAsync(ng, 0, 8, stream));
+  GXD_GX(with_tmp(c, Arena::TMP2, [&](void* t, size_t* b) {
+    return gx_group_offsets(static_cast<const uint8_t*>(heads), mrows, static_cast<int32_t*>(labels), static_cast<int32_t*>(offsets), nullptr,
+                            static_cast<int64_t*>(ng), t, b, gstream);
+  }));
+  long long G = 0;
+  GXD_HIP(hipMemcpyAsync(&G, ng, 8, hipMemcpyDeviceToHost, stream));
+  GXD_HIP(hipStreamSynchronize(stream));
+  void* ok = alloc((size_t)G * ks, actx);
+  void* os = alloc((size_t)G * 8, actx);
+  auto* oc = static_cast<int64_t*>(alloc((size_t)G * 8, actx));
+  if (!ok || !os || !oc) return fail(GX_EINVAL, "gxd_groupby_sum_count: allocator returned NULL");
+  GXD_GX(with_tmp(c, Arena::TMP2, [&](void* t, size_t* b) {
+    return gx_segmented_reduce(sum_type, ss, nullptr, static_cast<const uint8_t*>(heads), static_cast<const int32_t*>(labels), mrows, GX_OP_SUM,
+                               os, nullptr, t, b, gstream);
+  }));
+  GXD_GX(with_tmp(c, Arena::TMP2, [&](void* t, size_t* b) {
+    return gx_segmented_reduce(GX_INT64, sc2, nullptr, static_cast<const uint8_t*>(heads), static_cast<const int32_t*>(labels), mrows, GX_OP_SUM,
+                               oc, nullptr, t, b, gstream);
+  }));
+  GXD_GX(gx_gather(ks, sk, nullptr, mrows, static_cast<const int32_t*>(offsets), G, 0, ok, nullptr, gstream));
+  GXD_HIP(hipStreamSynchronize(stream));
+  *out_keys   = ok;
+  *out_sums   = os;
+  *out_counts = oc;
+  *out_groups = G;
+  c->ms[2]    = now_ms() - t0;
+  return 0;
+}
+
+}  // extern "C"

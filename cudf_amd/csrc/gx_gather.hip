@@ -189,9 +189,56 @@ __global__ void __launch_bounds__(256) k_gather_global_rows(const int32_t* __res
     out[j] = (long long)rows[i] + sb.base[s];
   }
 }
+// the same with the segment table in device memory (any number of segments; binary search): tab = [nseg + 1] starts | [nseg] bases
+__global__ void __launch_bounds__(256) k_gather_global_rows_dev(const int32_t* __restrict__ rows, const int32_t* __restrict__ idx, int64_t n,
+                                                                int nseg, const long long* __restrict__ tab, long long* __restrict__ out)
+{
+  const long long* start = tab;
+  const long long* base  = tab + nseg + 1;
+  const int64_t stride   = (int64_t)gridDim.x * 256;
+  for (int64_t j = (int64_t)blockIdx.x * 256 + threadIdx.x; j < n; j += stride) {
+    const long long i = idx[j];
+    int lo = 0, hi = nseg;  // the segment s with start[s] <= i < start[s + 1] (empty segments are skipped by the search)
+    while (hi - lo > 1) {
+      const int mid = (lo + hi) >> 1;
+      if (start[mid] <= i) lo = mid; else hi = mid;
+    }
+    out[j] = (long long)rows[i] + base[lo];
+  }
+}
+__global__ void __launch_bounds__(256) k_widen_i32_i64(const int32_t* __restrict__ in, int64_t n, long long* __restrict__ out)
+{
+  const int64_t stride = (int64_t)gridDim.x * 256;
+  for (int64_t j = (int64_t)blockIdx.x * 256 + threadIdx.x; j < n; j += stride) out[j] = (long long)in[j];
+}
 }  // namespace gx
 
 extern "C" {
+
+int gx_gather_global_rows_dev(const int32_t* rows, int64_t nrows, const int32_t* idx, int64_t n, int nseg, const int64_t* segtab_dev,
+                              int64_t* out, gx_stream_t s)
+{
+  if (n < 0 || nrows < 0 || nseg < 1 || !segtab_dev) return GX_EINVAL;
+  if (n == 0) return 0;
+  if (!rows || !idx || !out) return GX_EINVAL;
+  int64_t blocks = gx::div_up(n, (int64_t)256 * 4);
+  if (blocks > 16384) blocks = 16384;
+  hipLaunchKernelGGL(gx::k_gather_global_rows_dev, dim3((unsigned)blocks), dim3(256), 0, s, rows, idx, n, nseg,
+                     reinterpret_cast<const long long*>(segtab_dev), reinterpret_cast<long long*>(out));
+  GX_LAUNCH_CHECK();
+  return 0;
+}
+
+int gx_widen_i32_i64(const int32_t* in, int64_t n, int64_t* out, gx_stream_t s)
+{
+  if (n < 0 || (n > 0 && (!in || !out))) return GX_EINVAL;
+  if (n == 0) return 0;
+  int64_t blocks = gx::div_up(n, (int64_t)256 * 8);
+  if (blocks > 8192) blocks = 8192;
+  hipLaunchKernelGGL(gx::k_widen_i32_i64, dim3((unsigned)blocks), dim3(256), 0, s, in, n, reinterpret_cast<long long*>(out));
+  GX_LAUNCH_CHECK();
+  return 0;
+}
 
 int gx_gather_global_rows(const int32_t* rows, int64_t nrows, const int32_t* idx, int64_t n, int nseg, const int64_t* seg_counts_host,
                           const int64_t* seg_bases_host, int64_t* out, gx_stream_t s)

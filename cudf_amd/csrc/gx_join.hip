@@ -572,7 +572,8 @@ __global__ void __launch_bounds__(1024) k_pj_offsets(PjPlan* plan, int pbits, un
 // of 8 rows (64 B of keys) at P = 2048 where the 4096-row tile of round 1 gave 2.
 template <typename K, int RPT, int BTt, typename F>
 __global__ void __launch_bounds__(BTt) k_pj_scatter(const K* __restrict__ keys, int64_t n, PjPlan* plan, int pbits,
-                                                    int64_t rrows, K* __restrict__ pkeys, int32_t* __restrict__ pidx, F part_of)
+                                                    int64_t rrows, K* __restrict__ pkeys, int32_t* __restrict__ pidx, F part_of,
+                                                    int32_t row0 = 0)
 {
   constexpr int TILE = BTt * RPT;
   extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -648,7 +649,7 @@ __global__ void __launch_bounds__(BTt) k_pj_scatter(const K* __restrict__ keys, 
 #pragma unroll
   for (int j = 0; j < RPT; ++j) {
     const int idx = j * BTt + (int)tid;
-    if (idx < nvalid) s_i[s_start[packed[j] >> 16] + (packed[j] & 0xFFFFu)] = (int32_t)(base + idx);
+    if (idx < nvalid) s_i[s_start[packed[j] >> 16] + (packed[j] & 0xFFFFu)] = (int32_t)(base + idx) + row0;
   }
   __syncthreads();
 #pragma unroll
@@ -1571,7 +1572,7 @@ static inline uint32_t pj2_cap(int64_t n, int pbits)
 template <typename K, int RPT, int BTt, bool EXACT, typename F>
 __global__ void __launch_bounds__(BTt) k_pj2_scatter(const K* __restrict__ keys, int64_t n, Pj2Plan* plan2, PjPlan* plan, int pbits,
                                                      int64_t rrows, uint32_t cap, int64_t ntiles, K* __restrict__ pkeys,
-                                                     int32_t* __restrict__ pidx, F part_of)
+                                                     int32_t* __restrict__ pidx, F part_of, int32_t row0)
 {
   constexpr int TILE = BTt * RPT;
   extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -1698,7 +1699,7 @@ __global__ void __launch_bounds__(BTt) k_pj2_scatter(const K* __restrict__ keys,
     for (int j = 0; j < RPT; ++j) {
       const int idx        = j * BTt + (int)tid;
       const unsigned int l = (j & 1) ? lpos2[j / 2] >> 16 : lpos2[j / 2] & 0xFFFFu;
-      if (idx < nvalid) s_i[l] = (int32_t)(base + idx);
+      if (idx < nvalid) s_i[l] = (int32_t)(base + idx) + row0;
     }
     __syncthreads();
 #pragma unroll
@@ -1767,7 +1768,24 @@ struct PieceTable {
   int nr;                            // regions per partition: PJ_NR (padded slots) or 1 (exact partitions)
 };
 
-template <typename K, bool EARLY>
+// DEFER: a row whose chain is not settled by its first (preloaded) candidate slot -- another slot carries its tag, or the
+// chain runs past the 8-slot tag window -- used to make its whole wave wait for a second, dependent L2 round trip inside
+// S3.  With keys that hash like random numbers (SURVEY 8d's) about 1 % of the rows are like that, i.e. nearly every
+// wave in every trip (256 rows) stalled once: 8.4 ms against 6.4 ms for round 2's low-discrepancy keys.  Such a row is
+// now parked in a small per-wave LDS queue {key, row, next slot, first match}; lanes 0..q-1 request the next slot of
+// their queue entry right away and look at it in the NEXT trip, where the row is staged like a fifth row of the lane.
+constexpr int PP_TAGPAD = 16;  // bytes of tags of the NEXT sub-table kept behind a sub-table's own: 16-slot windows never leave the LDS
+constexpr int PP_Q = 8;  // queue entries per wave (expected ~2 per trip; a full queue falls back to the in-place walk)
+template <typename K>
+struct alignas(8) PpDefer {
+  K key;
+  uint32_t row_m;  // row index | (first candidate matched) << 31
+  uint32_t wb;     // absolute slot of the row's 16-slot tag window
+  int32_t first;   // build row of the first match
+  uint32_t ended;  // the chain ends inside the window
+  uint64_t cand;   // tag candidates still to look at (bit 4i + 3 = slot i of the window), lowest first
+};
+template <typename K, bool EARLY, bool DEFER>
 __global__ void __launch_bounds__(PP_BT)
 k_pj2_probe_pipe(const K* __restrict__ pkeys, const int32_t* __restrict__ pidx, PieceTable pt, int pbits,
                  const Slot<K>* __restrict__ slots, uint32_t log2cap, int left_outer, int32_t* __restrict__ out_probe,
@@ -1776,12 +1794,13 @@ k_pj2_probe_pipe(const K* __restrict__ pkeys, const int32_t* __restrict__ pidx, 
   typedef typename SlotRaw<K>::type Raw;
   constexpr uint32_t SUB = 1u << PJ_SUB_LOG2;
   extern __shared__ __attribute__((aligned(16))) char smem[];
-  const uint32_t* s_tagw = reinterpret_cast<const uint32_t*>(smem);                       // 64 KiB of tags
-  int32_t* s_sidx        = reinterpret_cast<int32_t*>(smem + (SUB >> 1));                  // [3][PP_ROWS] staged probe rows
+  const uint32_t* s_tagw = reinterpret_cast<const uint32_t*>(smem);                       // 64 KiB of tags + the 32 tags that follow them
+  int32_t* s_sidx        = reinterpret_cast<int32_t*>(smem + (SUB >> 1) + PP_TAGPAD);      // [3][PP_ROWS] staged probe rows
   int32_t* s_sfirst      = s_sidx + 3 * PP_ROWS;                                           // [3][PP_ROWS] staged build rows
   __shared__ unsigned int s_cnt[8];           // pairs staged by piece (it & 7)
   __shared__ unsigned long long s_base[3];    // output position of staging buffer (it % 3)
   __shared__ PpPiece s_piece[4];              // piece of trip (t & 3), resolved two trips ahead by the service wave
+  __shared__ PpDefer<K> s_defer[DEFER ? PP_PW * PP_Q : 1];  // per-wave queues of rows that need another slot
   const int P         = 1 << pbits;
   const int LISTP     = P / PJ_NR;
   const uint64_t mask = (1ull << log2cap) - 1;
@@ -1888,7 +1907,7 @@ k_pj2_probe_pipe(const K* __restrict__ pkeys, const int32_t* __restrict__ pidx, 
       take_piece(pc);
       if (lane == 0) s_piece[(t + 2) & 3] = pc;
       __syncthreads();  // X(t)
-      if (done_at >= 0 && t >= done_at + 3) break;
+      if (done_at >= 0 && t >= done_at + (DEFER ? 4 : 3)) break;  // DEFER: rows parked in the last S3 are staged one trip later
       if (lane == 0) {
         if (it3 >= 0) {
           unsigned int c = s_cnt[(unsigned)it3 & 7u];
@@ -1909,13 +1928,17 @@ k_pj2_probe_pipe(const K* __restrict__ pkeys, const int32_t* __restrict__ pidx, 
   int32_t iA[PP_R];
   K kB[PP_R];                // S2 -> S3
   int32_t iB[PP_R];
-  uint32_t li[PP_R], cand[PP_R];
+  uint32_t li[PP_R];
+  uint64_t cand[PP_R];       // tag candidates of the row's 16-slot window (nibble top bits)
   Raw sv[PP_R];
-  uint32_t fl = 0;
+  uint32_t fl = 0;           // per row j: bit j = live row, bit 4+j = chain ends inside the window
   uint32_t partA = 0, partB = 0, partC = 0;
   bool tags_loaded = false;
   unsigned long long cA0 = 0, cA1 = 0;
   bool validA = false, validB = false;
+  PpDefer<K>* myq = &s_defer[DEFER ? w * PP_Q : 0];
+  uint32_t qn = 0;           // entries of this wave's queue whose next slot is in flight in `qsv` (wave-uniform)
+  Raw qsv = Raw{};
 #pragma unroll
   for (int j = 0; j < PP_R; ++j) {
     kA[j] = kB[j] = kN[j] = K(0);
@@ -1938,96 +1961,158 @@ k_pj2_probe_pipe(const K* __restrict__ pkeys, const int32_t* __restrict__ pidx, 
         iN[j] = __builtin_nontemporal_load(&pidx[ic]);
       }
     }
-    // ---------------- S3(t-2): compare, finish chains, stage the matches
+    // ---------------- S3(t-2): compare, settle or park unsettled rows, stage the matches
     const int it3 = t - 2;
-    if (validB) {
-      const unsigned buf       = (unsigned)it3 % 3u;
-      const uint64_t sub_base  = (uint64_t)partB << PJ_SUB_LOG2;
-      const uint32_t* gtagw    = reinterpret_cast<const uint32_t*>(gtags + (sub_base >> 1));
-      uint32_t m[PP_R];
-      int32_t first[PP_R];
-      K sk[PP_R];
-      int32_t sr[PP_R];
-      uint32_t active = 0, ended = (fl >> 4) & 15u;
-#pragma unroll
-      for (int j = 0; j < PP_R; ++j) {
-        m[j]     = 0;
-        first[j] = NO_MATCH;
-        unpack_slot(sv[j], sk[j], sr[j]);
-        if (!((fl >> j) & 1u)) continue;
-        if ((fl >> (8 + j)) & 1u) {  // chain starts in the last slots of the sub-table: walk the slots themselves
-          uint64_t gs = sub_base + li[j];
-          for (;;) {
+    if (validB || (DEFER && qn)) {
+      const unsigned buf      = (unsigned)it3 % 3u;
+      const uint64_t sub_base = (uint64_t)partB << PJ_SUB_LOG2;
+      const uint32_t* gtagw   = reinterpret_cast<const uint32_t*>(gtags);  // the tags of the WHOLE table, by absolute slot
+      uint32_t m[PP_R + 1];
+      int32_t first[PP_R + 1];
+      // Finish a chain in place (every load waits): the remaining tag candidates of the 8-slot window at absolute slot
+      // `wb`, then further windows on the tags in global memory.  Rare by construction: the first candidate of a row was
+      // preloaded by S2, a parked row's second one by last trip's S3.
+      auto finish = [&](K key, uint64_t wb, uint64_t cnd64, bool ended, uint32_t& mm, int32_t& ff) {
+        const uint32_t tagpat = tag_of<K>(key, log2cap) * 0x11111111u;
+        while (cnd64) {  // what is left of the row's first (16-slot) window
+          K k;
+          int32_t r;
+          load_slot<K>(&slots[(wb + ((uint32_t)__builtin_ctzll(cnd64) >> 2)) & mask], k, r);
+          if (k == key) {  // a tagged slot is never empty
+            if (mm == 0) ff = r;
+            ++mm;
+          }
+          cnd64 &= cnd64 - 1;
+        }
+        wb = (wb + 16) & mask;
+        while (!ended) {  // further windows of 8 slots, tags from global memory
+          if (wb + 8 > mask) {  // the window would wrap around the table's end: walk the slots themselves
+            for (;;) {
+              K k;
+              int32_t r;
+              load_slot<K>(&slots[wb & mask], k, r);
+              if (r == EMPTY_ROW) break;
+              if (k == key) {
+                if (mm == 0) ff = r;
+                ++mm;
+              }
+              ++wb;
+            }
+            break;
+          }
+          uint32_t cnd = 0;
+          ended        = scan_tags8_global(gtagw, (uint32_t)wb, tagpat, cnd);
+          while (cnd) {
             K k;
             int32_t r;
-            load_slot<K>(&slots[gs & mask], k, r);
-            if (r == EMPTY_ROW) break;
-            if (k == kB[j]) {
-              if (m[j] == 0) first[j] = r;
-              ++m[j];
+            load_slot<K>(&slots[wb + ((uint32_t)__builtin_ctz(cnd) >> 2)], k, r);
+            if (k == key) {
+              if (mm == 0) ff = r;
+              ++mm;
             }
-            ++gs;
+            cnd &= cnd - 1;
           }
-        } else if (cand[j] || !((ended >> j) & 1u)) {
-          active |= 1u << j;
+          wb += 8;
+        }
+      };
+      // ---- (0) the rows parked last trip: their second candidate slot has arrived
+      K keyx       = K(0);
+      int32_t idxx = 0;
+      bool livex   = false;
+      m[PP_R]      = 0;
+      first[PP_R]  = NO_MATCH;
+      if (DEFER && qn) {  // wave-uniform
+        if (lane < qn) {
+          const PpDefer<K> e = myq[lane];
+          keyx               = e.key;
+          idxx               = (int32_t)(e.row_m & 0x7FFFFFFFu);
+          livex              = true;
+          if (e.row_m >> 31) {
+            m[PP_R]     = 1;
+            first[PP_R] = e.first;
+          }
+          K k;
+          int32_t r;
+          unpack_slot(qsv, k, r);
+          if (k == keyx) {
+            if (m[PP_R] == 0) first[PP_R] = r;
+            ++m[PP_R];
+          }
+          const uint64_t cnd = e.cand & (e.cand - 1);  // the second candidate is the slot in `qsv`
+          const bool ended   = e.ended != 0;
+          if (cnd || !ended) finish(keyx, e.wb, cnd, ended, m[PP_R], first[PP_R]);  // a third candidate / a 16+ chain: rare
         }
       }
-      bool preloaded = true;  // the first candidate of every row was fetched by S2
-      while (active) {
-        if (!preloaded) {
-#pragma unroll
-          for (int j = 0; j < PP_R; ++j) {
-            if (ballot((active >> j) & 1u) == 0) continue;
-            if ((active & (1u << j)) && cand[j])
-              load_slot<K>(&slots[sub_base + li[j] + ((uint32_t)__builtin_ctz(cand[j]) >> 2)], sk[j], sr[j]);
-          }
-        }
-        preloaded = false;
+      // ---- (1) this trip's rows
+      uint32_t qnew   = 0;  // wave-uniform
+      uint32_t parked = 0;  // rows of this lane that went to the queue: they emit next trip
+      if (validB) {
 #pragma unroll
         for (int j = 0; j < PP_R; ++j) {
-          if (ballot((active >> j) & 1u) == 0) continue;
-          if (!(active & (1u << j))) continue;
-          if (cand[j]) {
-            if (sk[j] == kB[j]) {  // a tagged slot is never empty
-              if (m[j] == 0) first[j] = sr[j];
-              ++m[j];
-            }
-            cand[j] &= cand[j] - 1;
-          }
-          if (cand[j] == 0) {
-            if (ended & (1u << j)) {
-              active &= ~(1u << j);
-            } else {  // the chain runs on: next 8 slots (tags from global memory: the LDS may hold another partition's)
-              li[j] += 8;
-              if (li[j] > SUB - 8) {
-                uint64_t gs = sub_base + li[j];
-                for (;;) {
-                  K k;
-                  int32_t r;
-                  load_slot<K>(&slots[gs & mask], k, r);
-                  if (r == EMPTY_ROW) break;
-                  if (k == kB[j]) {
-                    if (m[j] == 0) first[j] = r;
-                    ++m[j];
-                  }
-                  ++gs;
-                }
-                active &= ~(1u << j);
-              } else {
-                const bool e = scan_tags8_global(gtagw, li[j], tag_of<K>(kB[j], log2cap) * 0x11111111u, cand[j]);
-                if (e) {
-                  ended |= 1u << j;
-                  if (cand[j] == 0) active &= ~(1u << j);
-                }
+          m[j]     = 0;
+          first[j] = NO_MATCH;
+          K sk;
+          int32_t sr;
+          unpack_slot(sv[j], sk, sr);
+          bool more  = false;
+          bool ended = true;
+          if ((fl >> j) & 1u) {
+            ended = (fl >> (4 + j)) & 1u;
+            if (cand[j]) {
+              if (sk == kB[j]) {  // a tagged slot is never empty
+                m[j]     = 1;
+                first[j] = sr;
               }
+              cand[j] &= cand[j] - 1;
             }
+            more = cand[j] != 0 || !ended;
           }
+          const uint64_t mb = ballot(more);
+          if (mb == 0) continue;  // wave-uniform: the common case
+          // park the rows that have another tag candidate in their window (its slot is requested below and looked at next
+          // trip); a chain that merely runs past the window (no candidate left) is finished in place -- rarer still
+          const uint64_t pb = ballot(more && cand[j] != 0);
+          const uint32_t nq = (uint32_t)__builtin_popcountll(pb);
+          const bool fits   = DEFER && nq > 0 && qnew + nq <= (uint32_t)PP_Q;
+          if (fits && more && cand[j] != 0) {
+            PpDefer<K> e;
+            e.key   = kB[j];
+            e.row_m = (uint32_t)iB[j] | (m[j] << 31);
+            e.wb    = (uint32_t)(sub_base + li[j]);
+            e.first = first[j];
+            e.ended = ended ? 1u : 0u;
+            e.cand  = cand[j];
+            myq[qnew + (uint32_t)__builtin_popcountll(pb & lanemask_lt())] = e;
+            m[j] = 0;
+            parked |= 1u << j;
+          } else if (more) {
+            finish(kB[j], sub_base + li[j], cand[j], ended, m[j], first[j]);
+          }
+          if (fits) qnew += nq;
+        }
+      } else {
+#pragma unroll
+        for (int j = 0; j < PP_R; ++j) {
+          m[j]     = 0;
+          first[j] = NO_MATCH;
         }
       }
-      // ---- stage: pairs of this piece go to s_sidx / s_sfirst [buf] at positions handed out by an LDS counter
+      // ---- (2) request the second candidate slot of the rows just parked: looked at in the next trip
+      if (DEFER) {
+        __builtin_amdgcn_wave_barrier();
+        qn = qnew;
+        if (lane < qn) {
+          const PpDefer<K> e = myq[lane];
+          qsv = *reinterpret_cast<const Raw*>(&slots[((uint64_t)e.wb + ((uint32_t)__builtin_ctzll(e.cand) >> 2)) & mask]);
+        }
+      }
+      // ---- (3) stage: pairs go to s_sidx / s_sfirst [buf] at positions handed out by an LDS counter
 #pragma unroll
-      for (int j = 0; j < PP_R; ++j) {
-        const bool live = (fl >> j) & 1u;
+      for (int j = 0; j <= PP_R; ++j) {
+        if (j == PP_R && !DEFER) break;
+        const bool live    = j < PP_R ? (validB && ((fl >> j) & 1u) && !((parked >> j) & 1u)) : livex;
+        const K rkey       = j < PP_R ? kB[j < PP_R ? j : 0] : keyx;
+        const int32_t ridx = j < PP_R ? iB[j < PP_R ? j : 0] : idxx;
         if (left_outer && live && m[j] == 0) m[j] = 1;  // (row, JoinNoMatch); first[j] is NO_MATCH
         uint32_t off, tot;
         if (ballot(m[j] > 1) == 0) {
@@ -2047,12 +2132,12 @@ k_pj2_probe_pipe(const K* __restrict__ pkeys, const int32_t* __restrict__ pidx, 
         const uint32_t pos = wbase + off;
         if (m[j] == 1) {
           if (pos < (uint32_t)PP_ROWS) {
-            s_sidx[buf * PP_ROWS + pos]   = iB[j];
+            s_sidx[buf * PP_ROWS + pos]   = ridx;
             s_sfirst[buf * PP_ROWS + pos] = first[j];
           } else {  // staging full (duplicate build keys): reserve and write directly
             const unsigned long long gp = atomicAdd(cursor, 1ull);
             if ((int64_t)gp < capacity) {
-              out_probe[gp] = iB[j];
+              out_probe[gp] = ridx;
               out_build[gp] = first[j];
             }
           }
@@ -2062,19 +2147,19 @@ k_pj2_probe_pipe(const K* __restrict__ pkeys, const int32_t* __restrict__ pidx, 
           unsigned long long gp = 0;
           if (staged < m[j]) gp = atomicAdd(cursor, (unsigned long long)(m[j] - staged));
           uint32_t seen = 0;
-          uint64_t hh   = slot_of<K>(kB[j], log2cap);
+          uint64_t hh   = slot_of<K>(rkey, log2cap);
           for (;;) {
             K k;
             int32_t r;
             load_slot<K>(&slots[hh], k, r);
             if (r == EMPTY_ROW) break;
-            if (k == kB[j]) {
+            if (k == rkey) {
               if (seen < staged) {
-                s_sidx[buf * PP_ROWS + pos + seen]   = iB[j];
+                s_sidx[buf * PP_ROWS + pos + seen]   = ridx;
                 s_sfirst[buf * PP_ROWS + pos + seen] = r;
               } else {
                 if ((int64_t)gp < capacity) {
-                  out_probe[gp] = iB[j];
+                  out_probe[gp] = ridx;
                   out_build[gp] = r;
                 }
                 ++gp;
@@ -2091,6 +2176,10 @@ k_pj2_probe_pipe(const K* __restrict__ pkeys, const int32_t* __restrict__ pidx, 
       const uint4* src = reinterpret_cast<const uint4*>(gtags + (((uint64_t)partA << PJ_SUB_LOG2) >> 1));
       uint4* dst       = reinterpret_cast<uint4*>(smem);
       for (uint32_t i = tid; i < SUB / 2 / 16; i += PP_PW * GX_WAVE) dst[i] = src[i];
+      if (tid == 0) {  // the 32 tags behind the sub-table's own; behind the LAST sub-table the table wraps to slot 0
+        const bool last = (((uint64_t)partA + 1) << PJ_SUB_LOG2) > mask;
+        dst[SUB / 2 / 16] = last ? *reinterpret_cast<const uint4*>(gtags) : src[SUB / 2 / 16];
+      }
       partC       = partA;
       tags_loaded = true;
       __syncthreads();  // R(t)
@@ -2115,16 +2204,26 @@ k_pj2_probe_pipe(const K* __restrict__ pkeys, const int32_t* __restrict__ pidx, 
           li[j]               = (uint32_t)((prod >> (64 - log2cap)) - sub_base);
           uint32_t tg         = (uint32_t)(prod >> (60 - log2cap)) & 15u;
           tg                  = tg ? tg : 8u;
-          if (li[j] > SUB - 8) {
-            fl |= 1u << (8 + j);
-          } else if (scan_tags8(s_tagw, li[j], tg * 0x11111111u, cand[j])) {
-            fl |= 1u << (4 + j);
-          }
+          // the 16 tags of local slots [li, li + 16): three words, two funnel shifts.  A chain of the table (load <= 0.5)
+          // that is not over after 16 slots is a 1e-5 event; after 8 it is not (3e-3 per row: one stalled wave per trip).
+          const uint32_t tagpat = tg * 0x11111111u;
+          const uint32_t w0 = s_tagw[li[j] >> 3], w1 = s_tagw[(li[j] >> 3) + 1], w2 = s_tagw[(li[j] >> 3) + 2];
+          const uint32_t sh = (li[j] & 7u) * 4u;
+          const uint32_t x0 = __builtin_amdgcn_alignbit(w1, w0, sh), x1 = __builtin_amdgcn_alignbit(w2, w1, sh);
+          const uint32_t y0 = x0 ^ tagpat, y1 = x1 ^ tagpat;
+          const uint32_t z0 = ~(((x0 & 0x77777777u) + 0x77777777u) | x0) & 0x88888888u;  // empty slots
+          const uint32_t z1 = ~(((x1 & 0x77777777u) + 0x77777777u) | x1) & 0x88888888u;
+          const uint32_t m0 = ~(((y0 & 0x77777777u) + 0x77777777u) | y0) & 0x88888888u;  // tag matches
+          const uint32_t m1 = ~(((y1 & 0x77777777u) + 0x77777777u) | y1) & 0x88888888u;
+          const uint32_t c0 = m0 & ((z0 & (0u - z0)) - 1u);                               // ... below the first empty one
+          const uint32_t c1 = z0 ? 0u : (m1 & ((z1 & (0u - z1)) - 1u));
+          cand[j]           = (uint64_t)c0 | ((uint64_t)c1 << 32);
+          if (z0 | z1) fl |= 1u << (4 + j);
         }
       }
 #pragma unroll
       for (int j = 0; j < PP_R; ++j) {
-        const Slot<K>* sp = cand[j] ? slots + (sub_base + li[j] + ((uint32_t)__builtin_ctz(cand[j]) >> 2)) : dummy;
+        const Slot<K>* sp = cand[j] ? slots + ((sub_base + li[j] + ((uint32_t)__builtin_ctzll(cand[j]) >> 2)) & mask) : dummy;
         sv[j]             = *reinterpret_cast<const Raw*>(sp);
       }
     }
@@ -2147,7 +2246,7 @@ k_pj2_probe_pipe(const K* __restrict__ pkeys, const int32_t* __restrict__ pidx, 
       }
     }
     __syncthreads();  // X(t): staging of piece t-2 complete, s_base of piece t-3 visible
-    if (done_at >= 0 && t >= done_at + 3) break;
+    if (done_at >= 0 && t >= done_at + (DEFER ? 4 : 3)) break;
     // ---------------- flush of piece t-3: two coalesced streams
     const int itf = t - 3;
     if (itf >= 0) {
@@ -2185,12 +2284,15 @@ static inline void jprof_mark(int i, hipStream_t s)
 }
 static int g_pj_probe = 0; // probe kernel: 0 = default (software-pipelined tag probe), 1 = round-1 tag probe (A/B knob)
 static int g_pj_tile = 0;  // scatter tile rows: 0 = default, else 4096 / 8192 / 16384 (A/B knob)
-static int g_pj_probe_early = 1;  // round-3 probe: 1 = rows of a piece requested at the top of the trip (default), 0 = at its end (A/B knob)
+static int g_pj_probe_early = 0;  // round-3 probe: 1 = rows of a piece requested at the top of the trip, 0 = at its end (default: with the
+                                  // deferral queue the early form no longer fits 128 VGPRs) (A/B knob)
+static int g_pj_defer = 0;        // round-3 probe: 1 = unsettled rows are parked in a per-wave queue for one trip, 0 = settled in place (default:
+                                  // measured 0.3 ms SLOWER with the queue once the tag window covers 16 slots -- profiles/r3_run4_*) (A/B knob)
 
 // the partition pass shared by the partitioned probe and build (F = TableTop) and by gx_partition_rows
 template <typename K, typename F>
 int pj_partition_fn(const K* keys, int64_t n, int pbits, PjPlan* plan, K* pkeys, int32_t* pidx, unsigned int chunk_rows, hipStream_t s,
-                    F part_of, bool profile = false)
+                    F part_of, bool profile = false, int32_t row0 = 0)
 {
   GX_HIP_TRY(hipMemsetAsync(plan, 0, sizeof(PjPlan), s));
   // tile: as many rows as the LDS holds next to the three P-entry arrays (160 KiB per CU)
@@ -2221,18 +2323,18 @@ int pj_partition_fn(const K* keys, int64_t n, int pbits, PjPlan* plan, K* pkeys,
     attr_set = true;
   }
   const unsigned grid = (unsigned)div_up(n, (int64_t)tile_rows);
-  if (tile_rows == 16384) hipLaunchKernelGGL(k16, dim3(grid), dim3(1024), lds, s, keys, n, plan, pbits, rrows, pkeys, pidx, part_of);
-  else if (tile_rows == 8192) hipLaunchKernelGGL(k8, dim3(grid), dim3(512), lds, s, keys, n, plan, pbits, rrows, pkeys, pidx, part_of);
-  else hipLaunchKernelGGL(k4, dim3(grid), dim3(512), lds, s, keys, n, plan, pbits, rrows, pkeys, pidx, part_of);
+  if (tile_rows == 16384) hipLaunchKernelGGL(k16, dim3(grid), dim3(1024), lds, s, keys, n, plan, pbits, rrows, pkeys, pidx, part_of, row0);
+  else if (tile_rows == 8192) hipLaunchKernelGGL(k8, dim3(grid), dim3(512), lds, s, keys, n, plan, pbits, rrows, pkeys, pidx, part_of, row0);
+  else hipLaunchKernelGGL(k4, dim3(grid), dim3(512), lds, s, keys, n, plan, pbits, rrows, pkeys, pidx, part_of, row0);
   if (profile) jprof_mark(2, s);
   GX_LAUNCH_CHECK();
   return 0;
 }
 template <typename K>
 int pj_partition(const K* keys, int64_t n, int pbits, PjPlan* plan, K* pkeys, int32_t* pidx, unsigned int chunk_rows, hipStream_t s,
-                 bool profile = false)
+                 bool profile = false, int32_t row0 = 0)
 {
-  return pj_partition_fn<K, TableTop<K>>(keys, n, pbits, plan, pkeys, pidx, chunk_rows, s, TableTop<K>{pbits}, profile);
+  return pj_partition_fn<K, TableTop<K>>(keys, n, pbits, plan, pkeys, pidx, chunk_rows, s, TableTop<K>{pbits}, profile, row0);
 }
 
 // partition starts as int64, for the caller of gx_partition_rows
@@ -2243,7 +2345,7 @@ __global__ void k_pj_export_offsets(const PjPlan* plan, int nparts, long long* o
 
 template <typename K>
 int partition_rows_hash(const void* keys, int64_t n, int pbits, int nparts, void* out_keys, int32_t* out_rows, int64_t* offsets,
-                        void* tmp, size_t* tmp_bytes, hipStream_t s)
+                        void* tmp, size_t* tmp_bytes, hipStream_t s, int32_t row0)
 {
   Carver c(tmp);
   PjPlan* plan = c.take<PjPlan>(1);
@@ -2253,7 +2355,7 @@ int partition_rows_hash(const void* keys, int64_t n, int pbits, int nparts, void
   }
   if (*tmp_bytes < c.total()) return GX_ETMP;
   int rc = pj_partition_fn<K, AltHash<K>>(static_cast<const K*>(keys), n, pbits < 3 ? 3 : pbits, plan, static_cast<K*>(out_keys), out_rows,
-                                          PJ_CHUNK, s, AltHash<K>{pbits});
+                                          PJ_CHUNK, s, AltHash<K>{pbits}, false, row0);
   if (rc) return rc;
   hipLaunchKernelGGL(k_pj_export_offsets, dim3(1), dim3(256), 0, s, plan, nparts, reinterpret_cast<long long*>(offsets));
   GX_LAUNCH_CHECK();
@@ -2261,7 +2363,7 @@ int partition_rows_hash(const void* keys, int64_t n, int pbits, int nparts, void
 }
 template <typename K, int KIND>
 int partition_rows_range(const void* keys, int64_t n, int nparts, const void* splitters_host, void* out_keys, int32_t* out_rows,
-                         int64_t* offsets, void* tmp, size_t* tmp_bytes, hipStream_t s)
+                         int64_t* offsets, void* tmp, size_t* tmp_bytes, hipStream_t s, int32_t row0)
 {
   Carver c(tmp);
   PjPlan* plan = c.take<PjPlan>(1);
@@ -2277,7 +2379,7 @@ int partition_rows_range(const void* keys, int64_t n, int nparts, const void* sp
   int pbits = 3;
   while ((1 << pbits) < nparts) ++pbits;
   int rc = pj_partition_fn<K, RangeSplit<K, KIND>>(static_cast<const K*>(keys), n, pbits, plan, static_cast<K*>(out_keys), out_rows, PJ_CHUNK,
-                                                   s, f);
+                                                   s, f, false, row0);
   if (rc) return rc;
   hipLaunchKernelGGL(k_pj_export_offsets, dim3(1), dim3(256), 0, s, plan, nparts, reinterpret_cast<long long*>(offsets));
   GX_LAUNCH_CHECK();
@@ -2306,7 +2408,7 @@ static bool pj2_applies(int64_t n, int pbits)
 }
 template <typename K>
 int probe_partitioned_impl2(const K* keys, int64_t n, const Slot<K>* slots, uint32_t lg, int pbits, int left_outer, int32_t* out_probe,
-                            int32_t* out_build, int64_t capacity, int64_t* cursor, void* tmp, size_t* tmp_bytes, hipStream_t s)
+                            int32_t* out_build, int64_t capacity, int64_t* cursor, void* tmp, size_t* tmp_bytes, hipStream_t s, int32_t row0)
 {
   constexpr int TILE   = 16384;
   const uint32_t cap   = pj2_cap(n, pbits);
@@ -2326,8 +2428,9 @@ int probe_partitioned_impl2(const K* keys, int64_t n, const Slot<K>* slots, uint
   const F part_of{pbits};
   auto kspec  = k_pj2_scatter<K, 16, 1024, false, F>;
   auto kexact = k_pj2_scatter<K, 16, 1024, true, F>;
-  auto kprobe = g_pj_probe_early ? k_pj2_probe_pipe<K, true> : k_pj2_probe_pipe<K, false>;
-  constexpr size_t lds_p = ((size_t)1 << (PJ_SUB_LOG2 - 1)) + (size_t)6 * PP_ROWS * sizeof(int32_t);
+  auto kprobe = g_pj_defer ? (g_pj_probe_early ? k_pj2_probe_pipe<K, true, true> : k_pj2_probe_pipe<K, false, true>)
+                           : (g_pj_probe_early ? k_pj2_probe_pipe<K, true, false> : k_pj2_probe_pipe<K, false, false>);
+  constexpr size_t lds_p = ((size_t)1 << (PJ_SUB_LOG2 - 1)) + PP_TAGPAD + (size_t)6 * PP_ROWS * sizeof(int32_t);
   const size_t lds_s     = (size_t)TILE * sizeof(K) + ((size_t)8 << pbits);
   static bool attr_set   = false;  // per instantiation
   static int num_cus     = 0;
@@ -2335,8 +2438,10 @@ int probe_partitioned_impl2(const K* keys, int64_t n, const Slot<K>* slots, uint
     const int lds_max = 160 * 1024 - 256;
     GX_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(kspec), hipFuncAttributeMaxDynamicSharedMemorySize, lds_max));
     GX_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(kexact), hipFuncAttributeMaxDynamicSharedMemorySize, lds_max));
-    GX_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(k_pj2_probe_pipe<K, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_p));
-    GX_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(k_pj2_probe_pipe<K, false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_p));
+    GX_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(k_pj2_probe_pipe<K, true, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_p));
+    GX_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(k_pj2_probe_pipe<K, false, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_p));
+    GX_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(k_pj2_probe_pipe<K, true, false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_p));
+    GX_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(k_pj2_probe_pipe<K, false, false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_p));
     int dev = 0;
     GX_HIP_TRY(hipGetDevice(&dev));
     GX_HIP_TRY(hipDeviceGetAttribute(&num_cus, hipDeviceAttributeMultiprocessorCount, dev));
@@ -2354,7 +2459,7 @@ int probe_partitioned_impl2(const K* keys, int64_t n, const Slot<K>* slots, uint
   GX_HIP_TRY(hipMemsetAsync(plan, 0, sizeof(PjPlan), s));
   jprof_mark(1, s);
   // ---- speculative pass
-  hipLaunchKernelGGL(kspec, dim3((unsigned)grid), dim3(1024), lds_s, s, keys, n, plan2, plan, pbits, rrows, cap, ntiles, pkeys, pidx, part_of);
+  hipLaunchKernelGGL(kspec, dim3((unsigned)grid), dim3(1024), lds_s, s, keys, n, plan2, plan, pbits, rrows, cap, ntiles, pkeys, pidx, part_of, row0);
   jprof_mark(2, s);
   hipLaunchKernelGGL(k_pj2_offsets, dim3(1), dim3(1024), 0, s, plan2, pbits, cap, (unsigned int)PP_ROWS);
   PieceTable pt{plan2->chunk0, plan2->list_chunk0, plan2->ticket, nullptr, plan2->fill, cap, PJ_NR};
@@ -2367,7 +2472,7 @@ int probe_partitioned_impl2(const K* keys, int64_t n, const Slot<K>* slots, uint
   if (hb < 1) hb = 1;
   hipLaunchKernelGGL((k_pj_hist<K, F>), dim3((unsigned)(hb * PJ_NR)), dim3(256), 0, s, keys, n, plan, pbits, rrows, part_of, &plan2->fallback);
   hipLaunchKernelGGL(k_pj_offsets, dim3(1), dim3(1024), 0, s, plan, pbits, (unsigned int)PP_ROWS, &plan2->fallback);
-  hipLaunchKernelGGL(kexact, dim3((unsigned)grid), dim3(1024), lds_s, s, keys, n, plan2, plan, pbits, rrows, cap, ntiles, pkeys, pidx, part_of);
+  hipLaunchKernelGGL(kexact, dim3((unsigned)grid), dim3(1024), lds_s, s, keys, n, plan2, plan, pbits, rrows, cap, ntiles, pkeys, pidx, part_of, row0);
   PieceTable pe{plan->chunk0, plan->list_chunk0, plan2->ticket_exact, plan->offset, nullptr, 0u, 1};
   hipLaunchKernelGGL(kprobe, dim3((unsigned)pgrid), dim3(PP_BT), lds_p, s, pkeys, pidx, pe, pbits, slots, lg, left_outer, out_probe, out_build,
                      capacity, cur);
@@ -2380,7 +2485,7 @@ int probe_partitioned_impl2(const K* keys, int64_t n, const Slot<K>* slots, uint
 template <typename K>
 int probe_partitioned_impl(const void* keys, int64_t n, const void* table, size_t table_bytes, uint32_t lg,
                            int left_outer, int32_t* out_probe, int32_t* out_build, int64_t capacity, int64_t* cursor,
-                           void* tmp, size_t* tmp_bytes, hipStream_t s)
+                           void* tmp, size_t* tmp_bytes, hipStream_t s, int32_t row0 = 0)
 {
   const int pbits = pj_bits(lg, (int)sizeof(Slot<K>));
   if (pj2_applies<K>(n, pbits)) {
@@ -2390,7 +2495,7 @@ int probe_partitioned_impl(const void* keys, int64_t n, const void* table, size_
     }
     return probe_partitioned_impl2<K>(static_cast<const K*>(keys), n,
                                       reinterpret_cast<const Slot<K>*>(static_cast<const char*>(table) + sizeof(TableHeader)), lg, pbits,
-                                      left_outer, out_probe, out_build, capacity, cursor, tmp, tmp_bytes, s);
+                                      left_outer, out_probe, out_build, capacity, cursor, tmp, tmp_bytes, s, row0);
   }
   Carver c(tmp);
   PjPlan* plan   = c.take<PjPlan>(1);
@@ -2417,7 +2522,7 @@ int probe_partitioned_impl(const void* keys, int64_t n, const void* table, size_
     if (use_pipe) chunk_rows = PP_ROWS;  // the persistent probe takes tickets per 3840-row piece
   }
   {
-    int rc = pj_partition<K>(static_cast<const K*>(keys), n, pbits, plan, pkeys, pidx, chunk_rows, s, true);
+    int rc = pj_partition<K>(static_cast<const K*>(keys), n, pbits, plan, pkeys, pidx, chunk_rows, s, true, row0);
     if (rc) return rc;
   }
   const int64_t max_chunks = div_up(n, (int64_t)chunk_rows) + (1 << pbits);
@@ -2581,9 +2686,9 @@ int gx_join_probe(int key_size, const void* probe_keys, const uint32_t* probe_va
 
 
 /* see gx.h */
-int gx_join_probe_partitioned(int key_size, const void* probe_keys, int64_t probe_rows, const void* table,
-                              size_t table_bytes, int left_outer, int32_t* out_probe_idx, int32_t* out_build_idx,
-                              int64_t capacity, int64_t* cursor_dev, void* tmp, size_t* tmp_bytes, gx_stream_t s)
+int gx_join_probe_partitioned_at(int key_size, const void* probe_keys, int64_t probe_rows, int32_t row_base, const void* table,
+                                 size_t table_bytes, int left_outer, int32_t* out_probe_idx, int32_t* out_build_idx,
+                                 int64_t capacity, int64_t* cursor_dev, void* tmp, size_t* tmp_bytes, gx_stream_t s)
 {
   if (probe_rows < 0 || capacity < 0 || !table || !tmp_bytes || (probe_rows > 0 && !probe_keys)) return GX_EINVAL;
   if (tmp && (!cursor_dev || (capacity > 0 && (!out_probe_idx || !out_build_idx)))) return GX_EINVAL;
@@ -2591,11 +2696,18 @@ int gx_join_probe_partitioned(int key_size, const void* probe_keys, int64_t prob
   const uint32_t lg = gx_join_log2_from_bytes(key_size, table_bytes);
   if (key_size == 8)
     return gx::join::probe_partitioned_impl<uint64_t>(probe_keys, probe_rows, table, table_bytes, lg, left_outer, out_probe_idx,
-                                                      out_build_idx, capacity, cursor_dev, tmp, tmp_bytes, s);
+                                                      out_build_idx, capacity, cursor_dev, tmp, tmp_bytes, s, row_base);
   if (key_size == 4)
     return gx::join::probe_partitioned_impl<uint32_t>(probe_keys, probe_rows, table, table_bytes, lg, left_outer, out_probe_idx,
-                                                      out_build_idx, capacity, cursor_dev, tmp, tmp_bytes, s);
+                                                      out_build_idx, capacity, cursor_dev, tmp, tmp_bytes, s, row_base);
   return GX_EDTYPE;
+}
+int gx_join_probe_partitioned(int key_size, const void* probe_keys, int64_t probe_rows, const void* table,
+                              size_t table_bytes, int left_outer, int32_t* out_probe_idx, int32_t* out_build_idx,
+                              int64_t capacity, int64_t* cursor_dev, void* tmp, size_t* tmp_bytes, gx_stream_t s)
+{
+  return gx_join_probe_partitioned_at(key_size, probe_keys, probe_rows, 0, table, table_bytes, left_outer, out_probe_idx, out_build_idx,
+                                      capacity, cursor_dev, tmp, tmp_bytes, s);
 }
 
 int gx_join_lookup(int key_size, const void* probe_keys, const uint32_t* probe_valid, int64_t probe_rows,
@@ -2643,6 +2755,12 @@ int gx_join_filter(int key_size, const void* probe_keys, const uint32_t* probe_v
 int gx_partition_rows(int key_dtype, const void* keys, int64_t n, int mode, int nparts, const void* splitters_host, void* out_keys,
                       int32_t* out_rows, int64_t* offsets_dev, void* tmp, size_t* tmp_bytes, gx_stream_t s)
 {
+  return gx_partition_rows_at(key_dtype, keys, n, 0, mode, nparts, splitters_host, out_keys, out_rows, offsets_dev, tmp, tmp_bytes, s);
+}
+
+int gx_partition_rows_at(int key_dtype, const void* keys, int64_t n, int32_t row0, int mode, int nparts, const void* splitters_host,
+                         void* out_keys, int32_t* out_rows, int64_t* offsets_dev, void* tmp, size_t* tmp_bytes, gx_stream_t s)
+{
   using namespace gx;
   using namespace gx::join;
   if (n < 0 || nparts < 1 || nparts > PJ_MAX_SPLIT + 1 || !tmp_bytes || (mode != 0 && mode != 1)) return GX_EINVAL;
@@ -2656,18 +2774,18 @@ int gx_partition_rows(int key_dtype, const void* keys, int64_t n, int mode, int 
     int pbits = 0;
     while ((1 << pbits) < nparts) ++pbits;
     switch (gx_dtype_size(key_dtype)) {
-      case 8: return partition_rows_hash<uint64_t>(keys, n, pbits, nparts, out_keys, out_rows, offsets_dev, tmp, tmp_bytes, s);
-      case 4: return partition_rows_hash<uint32_t>(keys, n, pbits, nparts, out_keys, out_rows, offsets_dev, tmp, tmp_bytes, s);
+      case 8: return partition_rows_hash<uint64_t>(keys, n, pbits, nparts, out_keys, out_rows, offsets_dev, tmp, tmp_bytes, s, row0);
+      case 4: return partition_rows_hash<uint32_t>(keys, n, pbits, nparts, out_keys, out_rows, offsets_dev, tmp, tmp_bytes, s, row0);
       default: return GX_EDTYPE;
     }
   }
   switch (key_dtype) {
-    case GX_INT64: return partition_rows_range<uint64_t, K_SIGNED>(keys, n, nparts, splitters_host, out_keys, out_rows, offsets_dev, tmp, tmp_bytes, s);
-    case GX_UINT64: return partition_rows_range<uint64_t, K_UNSIGNED>(keys, n, nparts, splitters_host, out_keys, out_rows, offsets_dev, tmp, tmp_bytes, s);
-    case GX_FLOAT64: return partition_rows_range<uint64_t, K_FLOAT>(keys, n, nparts, splitters_host, out_keys, out_rows, offsets_dev, tmp, tmp_bytes, s);
-    case GX_INT32: return partition_rows_range<uint32_t, K_SIGNED>(keys, n, nparts, splitters_host, out_keys, out_rows, offsets_dev, tmp, tmp_bytes, s);
-    case GX_UINT32: return partition_rows_range<uint32_t, K_UNSIGNED>(keys, n, nparts, splitters_host, out_keys, out_rows, offsets_dev, tmp, tmp_bytes, s);
-    case GX_FLOAT32: return partition_rows_range<uint32_t, K_FLOAT>(keys, n, nparts, splitters_host, out_keys, out_rows, offsets_dev, tmp, tmp_bytes, s);
+    case GX_INT64: return partition_rows_range<uint64_t, K_SIGNED>(keys, n, nparts, splitters_host, out_keys, out_rows, offsets_dev, tmp, tmp_bytes, s, row0);
+    case GX_UINT64: return partition_rows_range<uint64_t, K_UNSIGNED>(keys, n, nparts, splitters_host, out_keys, out_rows, offsets_dev, tmp, tmp_bytes, s, row0);
+    case GX_FLOAT64: return partition_rows_range<uint64_t, K_FLOAT>(keys, n, nparts, splitters_host, out_keys, out_rows, offsets_dev, tmp, tmp_bytes, s, row0);
+    case GX_INT32: return partition_rows_range<uint32_t, K_SIGNED>(keys, n, nparts, splitters_host, out_keys, out_rows, offsets_dev, tmp, tmp_bytes, s, row0);
+    case GX_UINT32: return partition_rows_range<uint32_t, K_UNSIGNED>(keys, n, nparts, splitters_host, out_keys, out_rows, offsets_dev, tmp, tmp_bytes, s, row0);
+    case GX_FLOAT32: return partition_rows_range<uint32_t, K_FLOAT>(keys, n, nparts, splitters_host, out_keys, out_rows, offsets_dev, tmp, tmp_bytes, s, row0);
     default: return GX_EDTYPE;
   }
 }
@@ -2731,7 +2849,8 @@ void gx_join_set_probe_kernel(int which) { gx::join::g_pj_probe = which == 1 ? 1
 void gx_join_set_partition_mode(int speculative, int early_loads)
 {
   gx::join::g_pj_spec        = speculative == 2 ? 2 : (speculative ? 1 : 0);
-  gx::join::g_pj_probe_early = early_loads ? 1 : 0;
+  gx::join::g_pj_probe_early = early_loads & 1;
+  gx::join::g_pj_defer       = (early_loads & 2) ? 1 : 0;  // bit 1 of early_loads: park unsettled rows in the per-wave queue (A/B)
 }
 
 void gx_join_set_scatter_tile(int rows)

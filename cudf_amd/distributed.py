@@ -49,12 +49,19 @@ class HipLocalOps:
 
     def range_partition(self, keys: torch.Tensor, splitters: Sequence) -> Tuple[torch.Tensor, List[int]]:
         """One pass: keys grouped by destination = number of splitters <= key; (grouped keys, offsets)."""
+        if len(splitters) + 1 > self.MAX_PARTS:
+            raise ValueError(f"the one-pass exchange partition supports at most {self.MAX_PARTS} ranks (got {len(splitters) + 1})")
         pk, _, offs = self._ops.partition_rows(self._col(keys), len(splitters) + 1, splitters=list(splitters), want_rows=False)
         return self._tensor(pk, keys.dtype), offs
+
+    MAX_PARTS = 16  # gx_partition_rows splits into <= 16 groups in one pass; gx_gather_global_rows resolves <= 16 segments
 
     def hash_partition_rows(self, keys: torch.Tensor, nparts: int) -> Tuple[torch.Tensor, torch.Tensor, List[int]]:
         """One pass: (keys grouped by destination rank, their int32 local rows, offsets).  The destination is a hash
         that is independent of the local join table's slot bits."""
+        if nparts > self.MAX_PARTS:
+            raise ValueError(f"the one-pass exchange partition supports at most {self.MAX_PARTS} ranks (got {nparts}); "
+                             "run a two-level exchange (node x GPU) above it")
         if nparts & (nparts - 1):  # not a power of two ranks: murmur3 % nparts through the partition map
             m, offs = self._ops.hash_partition_map([self._col(keys)], nparts)
             gm = self._tensor(m, torch.int32)
@@ -167,6 +174,32 @@ def _offsets_to_counts(offsets: Sequence[int]) -> List[int]:
 # ------------------------------------------------------------------------------------------------
 _FORCE_EXCHANGE = False  # tests: take the partition + all-to-all path even when world == 1
 
+# The PRODUCT path on GPUs is C++ over RCCL (include/cudf_amd/gxd.h, cudf_amd/cpp/src/distributed.cpp): chunked partition
+# passes with the exchange of chunk k overlapping the partition of chunk k + 1 and (join) the probe of chunk k - 1, counts by
+# ncclAllGather, rows by grouped ncclSend / ncclRecv, persistent buffers.  The functions below hand CUDA tensors to it whenever no
+# LocalOps object is injected; the torch.distributed implementation that follows is what the gloo tests drive with a NumPy
+# LocalOps, and it documents the exchange logic in 60 lines.
+_COMMS = {}
+
+
+def _gxd_comm(group):
+    from . import gxd
+    key = id(group) if group is not None else 0
+    if key not in _COMMS:
+        _COMMS[key] = gxd.Communicator(group)
+    return _COMMS[key]
+
+
+def close_communicators():
+    """destroy the RCCL communicators this module created (before dist.destroy_process_group)"""
+    for c in _COMMS.values():
+        c.close()
+    _COMMS.clear()
+
+
+def _use_gxd(local, t: torch.Tensor) -> bool:
+    return local is None and t.is_cuda
+
 
 def distributed_sort(keys: torch.Tensor, local: Optional[object] = None, group=None, samples_per_rank: int = 1024) -> torch.Tensor:
     """Global sort of the concatenation of all ranks' shards; rank r returns the r-th range, so the
@@ -174,6 +207,8 @@ def distributed_sort(keys: torch.Tensor, local: Optional[object] = None, group=N
     rank: strided sample of the UNSORTED shard -> all-gather -> common splitters -> one range-partition pass
     into `world` send regions -> all-to-all -> local sort of what arrived
     (cudf_polars: sample -> allgather boundaries -> shuffle -> local sort, collectives/sort.py)."""
+    if _use_gxd(local, keys):
+        return _gxd_comm(group).sort(keys, force_exchange=_FORCE_EXCHANGE)
     local = local or HipLocalOps()
     rank, world = _world(group)
     if world == 1 and not _FORCE_EXCHANGE:
@@ -214,6 +249,13 @@ def distributed_inner_join(left: torch.Tensor, right: torch.Tensor, local: Optio
     one pass each, exchanged once as (key, int32 local row) = 12 B/row -- the source rank, hence the shard offset, is
     implied by the receive segment -- and joined locally; outputs stay sharded.  The build side's exchange is in
     flight while the probe side is partitioned."""
+    if _use_gxd(local, left):
+        from . import gxd
+        hj = gxd.HashJoin(_gxd_comm(group), right, force_exchange=_FORCE_EXCHANGE)
+        try:
+            return hj.inner_join(left)
+        finally:
+            hj.close()
     local = local or HipLocalOps()
     rank, world = _world(group)
     dev = left.device
@@ -257,6 +299,11 @@ class DistributedHashJoin:
     distributed_inner_join: (global probe row, global build row) of this rank's share of the pairs."""
 
     def __init__(self, right: torch.Tensor, local: Optional[object] = None, group=None):
+        self._gxd = None
+        if _use_gxd(local, right):
+            from . import gxd
+            self._gxd = gxd.HashJoin(_gxd_comm(group), right, force_exchange=_FORCE_EXCHANGE)
+            return
         self._local = local or HipLocalOps()
         self._group = group
         rank, world = _world(group)
@@ -274,6 +321,8 @@ class DistributedHashJoin:
         self._table = self._local.join_build(rkeys)
 
     def inner_join(self, left: torch.Tensor) -> Tuple[torch.Tensor, torch.Tensor]:
+        if self._gxd is not None:
+            return self._gxd.inner_join(left)
         local, group = self._local, self._group
         if self._single:
             li, ri = local.join_probe(self._table, left)
@@ -304,6 +353,8 @@ def distributed_groupby_sum_count(keys: torch.Tensor, vals: torch.Tensor, local:
     """groupby(keys).agg(sum, count) over all ranks' shards.  Pre-aggregate locally (<= #groups rows),
     hash-partition the partials, one all-to-all, merge.  Every group ends on exactly one rank.
     Returns (keys, sum, count) for the groups this rank owns (count as int64), keys ascending after a merge."""
+    if _use_gxd(local, keys):
+        return _gxd_comm(group).groupby_sum_count(keys, vals, force_exchange=_FORCE_EXCHANGE)
     local = local or HipLocalOps()
     rank, world = _world(group)
     k, s, c = local.groupby_sum_count(keys, vals)

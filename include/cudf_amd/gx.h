@@ -164,6 +164,13 @@ int gx_gather(int elem_size, const void* src, const uint32_t* src_valid, int64_t
 int gx_gather_global_rows(const int32_t* rows, int64_t nrows, const int32_t* idx, int64_t n, int nseg,
                           const int64_t* seg_counts_host, const int64_t* seg_bases_host, int64_t* out, gx_stream_t stream);
 
+/* The same with the segment table in DEVICE memory and any number of segments (the chunked exchange of gxd.h leaves
+ * chunks x ranks segments): segtab_dev = [nseg + 1] int64 segment starts followed by [nseg] int64 bases. */
+int gx_gather_global_rows_dev(const int32_t* rows, int64_t nrows, const int32_t* idx, int64_t n, int nseg, const int64_t* segtab_dev,
+                              int64_t* out, gx_stream_t stream);
+/* out[i] = in[i] as int64 (row indices / counts leaving the int32 world of cudf::size_type) */
+int gx_widen_i32_i64(const int32_t* in, int64_t n, int64_t* out, gx_stream_t stream);
+
 /* ------------------------------------------------------------------------------------------
  * Validity bitmaps.  Replace src/bitmask/null_mask.cu:152 (set), :339-409 (count),
  * include/cudf/detail/null_mask.cuh:68 (bitmask_and).
@@ -314,6 +321,16 @@ int gx_add_i32(int32_t* data, int64_t n, int32_t value, gx_stream_t stream);
 int gx_partition_rows(int key_dtype, const void* keys, int64_t n, int mode, int nparts, const void* splitters_host,
                       void* out_keys, int32_t* out_rows, int64_t* offsets_dev, void* tmp, size_t* tmp_bytes,
                       gx_stream_t stream);
+/* The same pass over a CHUNK of a shard: out_rows[i] = row_base + (index inside `keys`), so that chunks of one column can be
+ * partitioned (and exchanged) one after the other while the row ids stay those of the whole shard. */
+int gx_partition_rows_at(int key_dtype, const void* keys, int64_t n, int32_t row_base, int mode, int nparts, const void* splitters_host,
+                         void* out_keys, int32_t* out_rows, int64_t* offsets_dev, void* tmp, size_t* tmp_bytes,
+                         gx_stream_t stream);
+/* gx_join_probe_partitioned for a chunk of the probe side: the probe indices written are row_base + (index inside probe_keys);
+ * pairs are appended at *cursor_dev (which the caller zeroes once, before the first chunk). */
+int gx_join_probe_partitioned_at(int key_size, const void* probe_keys, int64_t probe_rows, int32_t row_base, const void* table,
+                                 size_t table_bytes, int left_outer, int32_t* out_probe_idx, int32_t* out_build_idx,
+                                 int64_t capacity, int64_t* cursor_dev, void* tmp, size_t* tmp_bytes, gx_stream_t stream);
 /* log2 of the number of partitions the partitioned probe uses for this table; 0 = not partitionable */
 int gx_join_partition_bits(int key_size, size_t table_bytes);
 /* Measurement hooks (bench.py's roofline leg), like gx_sort_profile: when enabled, every partitioned probe
@@ -329,8 +346,10 @@ void gx_join_set_probe_kernel(int which);
 /* A/B knob (process-wide): speculative = 1 (default) partitions the probe rows WITHOUT a histogram pass into padded
  * (partition, XCD range) slots with a persistent scatter kernel, falling back on the device to the exact histogram
  * path when a slot overflows (skewed keys); 0 = always the exact path of round 2; 2 = speculative for every row count
- * (tests: by default inputs below 1.7e7 rows take the round-2 path).  early_loads = 1 (default): the
- * pipelined probe requests a piece's rows at the top of a trip instead of at its end. */
+ * (tests: by default inputs below 1.7e7 rows take the round-2 path).  early_loads bit 0 (default 0): the
+ * pipelined probe requests a piece's rows at the top of a trip instead of at its end; bit 1 set: rows whose chain is not
+ * settled by their first candidate slot are parked in a per-wave queue for one trip instead of being finished in place (A/B;
+ * default 0: the queue measured slower once the tag window grew to 16 slots). */
 void gx_join_set_partition_mode(int speculative, int early_loads);
 
 /* out_build_idx[i] = the first build row whose key equals probe key i, or INT32_MIN (JoinNoMatch) --

@@ -1,0 +1,77 @@
+/*
+ * gxd.h -- C ABI of the SHARDED operators (one process per GPU, RCCL over xGMI): distributed cudf::sort,
+ * cudf::hash_join (build once / probe many) and groupby SUM + COUNT.  SURVEY.md 8(e); BASELINE config 5.
+ *
+ * What it replaces in the reference: the shuffle of libcudf_streaming (cpp/libcudf_streaming/src/partition_utils.cpp:
+ * 72-117 hash / range partition -> rapidsmpf shuffler -> partition.cpp:56-80 unpack) and the collectives of
+ * cudf_polars' streaming executor (python/cudf_polars/cudf_polars/streaming/actor_graph/collectives/sort.py,
+ * streaming/join.py:58-135, streaming/groupby.py:411-437).  Here each operator is ONE call per rank that
+ *   - partitions the shard in CHUNKS with the HIP kernels of gx.h (gx_partition_rows_at: range split for the sort,
+ *     hash split for join / groupby), all chunks enqueued up front on the caller's stream,
+ *   - exchanges chunk k on a second stream while chunk k+1 is still being partitioned: the count matrix of a chunk
+ *     travels by ncclAllGather, its rows as ONE grouped ncclSend / ncclRecv per peer (the full xGMI mesh: 7 links busy),
+ *     and the host only ever waits for a chunk's counts while the GPU works on the next chunk,
+ *   - runs the local operator on what arrived (join: chunk by chunk, overlapping the exchange of the later chunks).
+ * No all-reduce appears on the data path.  Results stay sharded.
+ *
+ * Conventions: as gx.h (0 = success, negative GX_E*, positive hipError_t; RCCL errors are reported as GX_EINTERNAL with
+ * the text in gxd_last_error()).  Pointers are DEVICE pointers unless named *_host.  RESULT buffers are obtained through
+ * the caller's allocator callback (their size is known only after the exchange); everything else lives in a grow-only
+ * arena owned by the communicator object and is reused from call to call (persistent send / receive buffers).
+ */
+#ifndef CUDF_AMD_GXD_H
+#define CUDF_AMD_GXD_H
+
+#include <cudf_amd/gx.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct gxd_comm gxd_comm; /* an RCCL communicator + exchange stream + persistent buffers */
+typedef struct gxd_join gxd_join; /* the local hash table of a sharded build side */
+
+/* device memory for a result: `bytes` > 0; return NULL on failure.  The caller frees it its own way. */
+typedef void* (*gxd_alloc_fn)(size_t bytes, void* ctx);
+
+/* 128-byte id for gxd_comm_create (ncclGetUniqueId): made by ONE rank, handed to the others out of band */
+int gxd_unique_id(void* id128_host);
+/* ncclCommInitRank on the CURRENT device (collective over all `world` ranks) */
+int gxd_comm_create(const void* id128_host, int world, int rank, gxd_comm** out);
+int gxd_comm_destroy(gxd_comm* comm);
+int gxd_comm_rank(const gxd_comm* comm);
+int gxd_comm_world(const gxd_comm* comm);
+const char* gxd_last_error(void);
+/* milliseconds the last operator call of this communicator spent in: [0] partition kernels, [1] host waits for counts,
+ * [2] whole call (host clock, the stream is synchronised at the end of every operator) */
+int gxd_last_timing(const gxd_comm* comm, double* ms3_host);
+
+/* Global sort of the concatenation of all ranks' shards: rank r receives the r-th range, sorted; the concatenation of the
+ * results in rank order is sorted (sample sort: strided sample -> all-gather -> common splitters -> ONE range-partition
+ * pass per chunk -> exchange -> ONE local sort).  dtype: a 4- or 8-byte numeric gx_dtype.  chunks <= 0: default (8).
+ * force_exchange != 0: take the exchange path even for world == 1 (measurements / tests).
+ * *out_keys (alloc'ed, *out_n elements). */
+int gxd_sort(gxd_comm* comm, int dtype, const void* keys, int64_t n, int chunks, int force_exchange, gxd_alloc_fn alloc,
+             void* alloc_ctx, void** out_keys, int64_t* out_n, gx_stream_t stream);
+
+/* cudf::hash_join over sharded tables.  build: hash-partition this rank's build keys (key + int32 local row = 12 B/row on
+ * the wire), exchange once, build the local table over what arrived.  probe: per chunk partition -> exchange -> local
+ * partitioned probe; every pair comes back as (global probe row, global build row), global row = (first row of the owning
+ * rank's shard) + local row.  key_dtype: an 8- or 4-byte numeric type (bit patterns are compared).  No nulls. */
+int gxd_join_build(gxd_comm* comm, int key_dtype, const void* build_keys, int64_t n, int force_exchange, gx_stream_t stream,
+                   gxd_join** out);
+int gxd_join_probe(gxd_join* table, const void* probe_keys, int64_t n, int chunks, gxd_alloc_fn alloc, void* alloc_ctx,
+                   int64_t** out_probe_rows, int64_t** out_build_rows, int64_t* out_pairs, gx_stream_t stream);
+int gxd_join_destroy(gxd_join* table);
+
+/* groupby(keys).agg(sum, count) over all shards: local aggregate (gx_groupby_sum_count) -> hash-partition the partial
+ * (key, sum, count) rows -> exchange -> merge.  Every group ends on exactly one rank, keys ascending.
+ * key_dtype INT32 / INT64; val_dtype INT32 / INT64 (sums INT64) or FLOAT32 / FLOAT64 (sums FLOAT64). */
+int gxd_groupby_sum_count(gxd_comm* comm, int key_dtype, const void* keys, int val_dtype, const void* vals, int64_t n,
+                          int64_t max_groups, int force_exchange, gxd_alloc_fn alloc, void* alloc_ctx, void** out_keys,
+                          void** out_sums, int64_t** out_counts, int64_t* out_groups, gx_stream_t stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* CUDF_AMD_GXD_H */

@@ -17,7 +17,7 @@ def gx():
     import cudf_amd  # noqa: F401
     from cudf_amd import Column, ops, _lib
     yield Column, ops, _lib
-    _lib.lib.gx_join_set_partition_mode(1, 1)
+    _lib.lib.gx_join_set_partition_mode(1, 0)
 
 
 def _pairs(l, r):
@@ -39,34 +39,53 @@ def _inputs(rng, dtype, shape, nb, npr):
         pool = cand[part == 3][:200_000].astype(dtype)
         probe = pool[rng.integers(0, len(pool), npr)]
         build[: len(pool) // 2] = pool[::2]
+    elif shape == "edge_chains":     # long chains (60 equal build keys each) that start in the last slots of a sub-table
+        lg = 21                      # and of the table: tag windows that do not settle a row, full deferral queues
+        cand = np.arange(1, 6_000_000, dtype=np.uint64)
+        with np.errstate(over="ignore"):
+            slot = (cand * np.uint64(0x9E3779B97F4A7C15)) >> np.uint64(64 - lg)
+        edge = cand[(slot & np.uint64((1 << 17) - 1)) >= np.uint64((1 << 17) - 3)]
+        last = cand[slot >= np.uint64((1 << lg) - 2)]
+        hot = np.concatenate([edge[:40], last[:2], cand[1000:1040]]).astype(dtype)
+        build = np.concatenate([build[: nb - 60 * hot.size], np.repeat(hot, 60)])
+        rng.shuffle(build)
+        probe[::500] = hot[np.arange(probe[::500].size) % hot.size]
     return build, probe
 
 
-@pytest.mark.parametrize("dtype", ["int64", "int32"])
-@pytest.mark.parametrize("shape", ["uniform", "dup_build", "hot_key", "one_partition"])
-@pytest.mark.parametrize("early", [1, 0])
-def test_speculative_partition_probe_matches_oracle(gx, dtype, shape, early):
+CASES = [("int64", sh, md) for sh in ("uniform", "dup_build", "hot_key", "one_partition", "edge_chains") for md in (0, 2)] + \
+        [("int32", "uniform", 0), ("int32", "edge_chains", 0), ("int64", "uniform", 1), ("int64", "edge_chains", 3)]
+
+
+@pytest.mark.parametrize("dtype,shape,mode", CASES)
+def test_speculative_partition_probe_matches_oracle(gx, dtype, shape, mode):
+    """mode = the probe knobs: bit 0 rows requested at the top of a trip, bit 1 unsettled rows parked in the per-wave queue
+    instead of being finished in place (0 = the default kernel)."""
     Column, ops, _lib = gx
     rng = np.random.default_rng(1234)
-    nb, npr = 600_000, (1 << 22) + 1234          # table 2^21 slots -> 16 partitions
+    nb, npr = 600_000, (1 << 20) + 1234          # table 2^21 slots -> 16 partitions
     build, probe = _inputs(rng, dtype, shape, nb, npr)
     el, er = orc.inner_join(probe, build)
-    got = {}
-    for spec in (2, 0):                          # 2: the speculative path forced at this (small) size; 0: round-2 exact path
-        _lib.lib.gx_join_set_partition_mode(spec, early)
-        hj = ops.HashJoin(Column.from_numpy(build))
-        assert _lib.lib.gx_join_partition_bits(hj.key_size, hj.table_bytes) >= 3
-        l, r = hj.inner_join(Column.from_numpy(probe))
-        got[spec] = _pairs(l, r)
-        np.testing.assert_array_equal(got[spec][0], el)
-        np.testing.assert_array_equal(got[spec][1], er)
-        if shape in ("uniform", "hot_key"):      # left-outer form: unmatched rows pair with JoinNoMatch
-            pl, pr = hj.left_join(Column.from_numpy(probe))
-            wl, wr = orc.left_join([probe], [build])
-            a, b = _pairs(pl, pr), orc.canonical_pairs(wl, wr)
-            np.testing.assert_array_equal(a[0], b[0])
-            np.testing.assert_array_equal(a[1], b[1])
-    _lib.lib.gx_join_set_partition_mode(1, 1)
+    old_min = ops.HashJoin.PARTITIONED_MIN_ROWS
+    ops.HashJoin.PARTITIONED_MIN_ROWS = 1 << 20
+    try:
+        for spec in (2, 0):                      # 2: the speculative path forced at this (small) size; 0: round-2 exact path
+            _lib.lib.gx_join_set_partition_mode(spec, mode)
+            hj = ops.HashJoin(Column.from_numpy(build))
+            assert _lib.lib.gx_join_partition_bits(hj.key_size, hj.table_bytes) >= 3
+            l, r = hj.inner_join(Column.from_numpy(probe))
+            got = _pairs(l, r)
+            np.testing.assert_array_equal(got[0], el)
+            np.testing.assert_array_equal(got[1], er)
+            if spec == 2 and shape in ("uniform", "hot_key", "edge_chains"):  # left-outer form: unmatched rows pair with JoinNoMatch
+                pl, pr = hj.left_join(Column.from_numpy(probe))
+                wl, wr = orc.left_join([probe], [build])
+                a, b = _pairs(pl, pr), orc.canonical_pairs(wl, wr)
+                np.testing.assert_array_equal(a[0], b[0])
+                np.testing.assert_array_equal(a[1], b[1])
+    finally:
+        ops.HashJoin.PARTITIONED_MIN_ROWS = old_min
+        _lib.lib.gx_join_set_partition_mode(1, 0)
 
 
 def test_speculative_partition_probe_default_threshold(gx):
@@ -74,7 +93,7 @@ def test_speculative_partition_probe_default_threshold(gx):
     hot key (fallback) against the closed form."""
     import torch
     Column, ops, _lib = gx
-    _lib.lib.gx_join_set_partition_mode(1, 1)
+    _lib.lib.gx_join_set_partition_mode(1, 0)
     nb, n = 3_000_000, 30_000_000
     bk = Column.empty(np.int64, nb)
     bkt = bk.data[: nb * 8].view(torch.int64)
