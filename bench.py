@@ -136,6 +136,13 @@ def cpu_baseline_join(rows, pandas_rows):
         lp.merge(rp, on="k", how="inner")
         extra["pandas_merge_rows_per_s"] = m / (time.perf_counter() - t0)
         extra["pandas_rows"] = m
+        import pyarrow as pa
+        lt = pa.table({"k": probe[:m]})
+        rt = pa.table({"k": build, "r": np.arange(len(build))})
+        t0 = time.perf_counter()
+        lt.join(rt, keys="k", join_type="inner")          # pyarrow Table.join (Acero hash join, all host threads)
+        extra["pyarrow_table_join_rows_per_s"] = m / (time.perf_counter() - t0)
+        extra["pyarrow_threads"] = pa.cpu_count()
     except Exception as e:  # context only
         extra["pandas_error"] = repr(e)
     return {"value": n / dt, "unit": "rows/s", "cores": 1, "kind": "port",
@@ -162,6 +169,12 @@ def cpu_baseline_groupby(rows, pandas_rows):
         df.groupby("k", sort=False).agg(s=("v", "sum"), c=("v", "count"))
         extra["pandas_groupby_rows_per_s"] = m / (time.perf_counter() - t0)
         extra["pandas_rows"] = m
+        import pyarrow as pa
+        tb = pa.table({"k": k[:m], "v": v[:m]})
+        t0 = time.perf_counter()
+        tb.group_by("k").aggregate([("v", "sum"), ("v", "count")])   # pyarrow Table.group_by
+        extra["pyarrow_group_by_rows_per_s"] = m / (time.perf_counter() - t0)
+        extra["pyarrow_threads"] = pa.cpu_count()
     except Exception as e:  # context only
         extra["pandas_error"] = repr(e)
     return {"value": n / dt, "unit": "rows/s", "cores": 1, "kind": "port",

@@ -93,6 +93,7 @@ _PROTOS = {
     "gx_join_filter": (_i, [_i, _p, _p, _i64, _p, ctypes.c_size_t, _i, _i, _p, _p, _p, _sz, _p]),
     "gx_join_complement": (_i, [_p, _i64, _i64, _p, _p, _i64, _p, _p, _sz, _p]),
     "gx_groupby_set_algorithm": (None, [_i, _i]),
+    "gx_groupby_set_partition_mode": (None, [_i]),
     "gx_group_heads": (_i, [_i, _p, _p, _p, _i64, _i, _p, _p]),
     "gx_group_offsets": (_i, [_p, _i64, _p, _p, _p, _p, _p, _sz, _p]),
     "gx_segmented_reduce": (_i, [_i, _p, _p, _p, _p, _i64, _i, _p, _p, _p, _sz, _p]),
@@ -105,6 +106,7 @@ _PROTOS = {
     "gx_scan": (_i, [_i, _p, _p, _i64, _i, _i, _p, _p, _sz, _p]),
     "gx_fill_random": (_i, [_i, _p, _i64, ctypes.c_uint64, _i64, _i64, _p]),
     "gx_sequence_i32": (_i, [_p, _i64, ctypes.c_int32, _p]),
+    "gx_copy_bytes": (_i, [_p, _p, ctypes.c_size_t, _p]),
     "gx_checksum": (_i, [_i, _p, _i64, _i, _p, _p]),
 }
 

@@ -261,10 +261,11 @@ int partition_exchange(gxd_comm* c, int dtype, const void* keys, int64_t n, int 
       const char* sk = static_cast<const char*>(pk) + (c0 + so) * es;
       char* dk       = static_cast<char*>(rk) + rpos * es;
       if (r == c->rank) {  // my own group: a device-local copy on the exchange stream
-        if (sc) GXD_HIP(hipMemcpyAsync(dk, sk, (size_t)sc * es, hipMemcpyDeviceToDevice, c->xs));
+        // (a copy KERNEL: hipMemcpyAsync falls to the SDMA engines while other queues are busy -- 32 GB/s intra-device)
+        if (sc) GXD_GX(gx_copy_bytes(sk, dk, (size_t)sc * es, reinterpret_cast<gx_stream_t>(c->xs)));
         if (want_rows && sc)
-          GXD_HIP(hipMemcpyAsync(static_cast<int32_t*>(rr) + rpos, static_cast<const int32_t*>(prow) + c0 + so, (size_t)sc * 4,
-                                 hipMemcpyDeviceToDevice, c->xs));
+          GXD_GX(gx_copy_bytes(static_cast<const int32_t*>(prow) + c0 + so, static_cast<int32_t*>(rr) + rpos, (size_t)sc * 4,
+                               reinterpret_cast<gx_stream_t>(c->xs)));
       } else {
         if (sc) GXD_NCCL(ncclSend(sk, (size_t)sc * es, ncclInt8, r, c->comm, c->xs));
         if (rc) GXD_NCCL(ncclRecv(dk, (size_t)rc * es, ncclInt8, r, c->comm, c->xs));
@@ -666,7 +667,7 @@ int gxd_groupby_sum_count(gxd_comm* c, int key_dtype, const void* keys, int val_
   GXD_GX(c->arena.get(Arena::MISC_C, (size_t)max_groups * 4, &pc));
   GXD_GX(c->arena.get(Arena::CURSOR, 256, &ng));
   long long g = 0;
-  for (int attempt = 0; attempt < 2; ++attempt) {
+  for (;;) {
     GXD_HIP(hipMemsetAsync(ng, 0, 8, stream));
     if (n > 0)
       GXD_GX(with_tmp(c, Arena::TMP2, [&](void* t, size_t* b) {
@@ -675,8 +676,9 @@ int gxd_groupby_sum_count(gxd_comm* c, int key_dtype, const void* keys, int val_
       }));
     GXD_HIP(hipMemcpyAsync(&g, ng, 8, hipMemcpyDeviceToHost, stream));
     GXD_HIP(hipStreamSynchronize(stream));
-    if (g <= max_groups) break;
-    max_groups = g;  // more groups than the caller's bound: the count is exact now
+    if (g >= 0 && g <= max_groups) break;
+    if (max_groups >= n) return fail(GX_EOVERFLOW, "gxd_groupby_sum_count: group table overflow");
+    max_groups = std::min<int64_t>(n, max_groups * 8);  // more groups than the bound: the table reports overflow, not a count
     GXD_GX(c->arena.get(Arena::MISC_A, (size_t)max_groups * ks, &pk));
     GXD_GX(c->arena.get(Arena::MISC_B, (size_t)max_groups * 8, &ps));
     GXD_GX(c->arena.get(Arena::MISC_C, (size_t)max_groups * 4, &pc));
@@ -715,8 +717,8 @@ int gxd_groupby_sum_count(gxd_comm* c, int key_dtype, const void* keys, int val_
       const int64_t rcv = M[r * (W + 1) + c->rank + 1] - M[r * (W + 1) + c->rank];
       if (r == c->rank) {
         if (sc) {
-          GXD_HIP(hipMemcpyAsync(static_cast<char*>(rs) + rpos * 8, static_cast<const char*>(gs) + so * 8, (size_t)sc * 8, hipMemcpyDeviceToDevice, c->xs));
-          GXD_HIP(hipMemcpyAsync(static_cast<char*>(rc) + rpos * 8, static_cast<const char*>(gc) + so * 8, (size_t)sc * 8, hipMemcpyDeviceToDevice, c->xs));
+          GXD_GX(gx_copy_bytes(static_cast<const char*>(gs) + so * 8, static_cast<char*>(rs) + rpos * 8, (size_t)sc * 8, reinterpret_cast<gx_stream_t>(c->xs)));
+          GXD_GX(gx_copy_bytes(static_cast<const char*>(gc) + so * 8, static_cast<char*>(rc) + rpos * 8, (size_t)sc * 8, reinterpret_cast<gx_stream_t>(c->xs)));
         }
       } else {
         if (sc) {

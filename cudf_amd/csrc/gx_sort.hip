@@ -1334,9 +1334,10 @@ static HybridCfg hybrid_cfg(int64_t n, bool iota_payload, int algo)
 {
   HybridCfg c{false, 14, 8, HAS_VAL ? 10 : g_msd_kpt};
   if (sizeof(KeyT) != 8 || (HAS_VAL && !iota_payload) || algo != 0 || !g_hybrid || n < (1ll << 22)) return c;
-  // 8192-key cells (two local-sort workgroups per CU) for integer keys-only sorts while 2^17 cells suffice;
-  // floats and pairs sort packed (key bits, position) words through 16384-key cells as in round 1
-  const bool small_ok = !HAS_VAL && KIND != K_FLOAT;
+  // 8192-key cells (two local-sort workgroups per CU) + a 9-bit level 1 for INTEGER keys while 2^17 cells suffice -- keys only,
+  // and since round 3 pairs too (sorted_order: the packed (key bits, position) words need 13 position bits instead of 14);
+  // float keys keep the 16384-key cells of round 1
+  const bool small_ok = KIND != K_FLOAT;
   c.cl2 = (small_ok && g_cell != 16384 && (double)n / (double)(1 << 17) <= 0.955 * 8192.0) ? 13 : 14;
   if (g_cell == 8192 && small_ok) c.cl2 = 13;
   const double cell = (double)(1 << c.cl2);
@@ -1418,7 +1419,8 @@ int sort_impl(const void* keys_in, void* keys_out, const int32_t* vals_in, int32
       // hybrid MSD path: every kernel below is a no-op unless the device-side plan enables it
       constexpr size_t pay   = HAS_VAL ? 4 : 0;
       constexpr bool STABLE  = KIND == K_FLOAT || HAS_VAL;
-      constexpr bool SMALLOK = !HAS_VAL && KIND != K_FLOAT;  // 8192-key cells and the 9-bit level 1 exist for these
+      constexpr bool SMALLOK = KIND != K_FLOAT;  // 8192-key cells and the 9-bit level 1 exist for integer keys (keys only and pairs)
+      constexpr int SKPT     = HAS_VAL ? 10 : 16;  // keys per thread of their partition passes
       auto lds_msd = [&](int kpt, int nb) { return (size_t)BT * kpt * (sizeof(KeyT) + pay) + (size_t)((STABLE ? NW : 2) * nb + 2 * nb + 16 + 4) * 4; };
       auto lds_loc = [&](int cl2) { return ((size_t)sizeof(KeyT) << cl2) + (size_t)(((1 << cl2) / 16 / GX_WAVE) * BINS + 32 + 2 * BINS) * 4; };
       typedef void (*MsdK)(MsdArgs);
@@ -1437,7 +1439,7 @@ int sort_impl(const void* keys_in, void* keys_out, const int32_t* vals_in, int32
         GX_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(k_msd_pass<KeyT, KIND, HAS_VAL, 16, 4, 8>), hipFuncAttributeMaxDynamicSharedMemorySize, lds_mmax));
         GX_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(kloc), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_loc(14)));
         if constexpr (SMALLOK) {
-          GX_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(k_msd_pass<KeyT, KIND, HAS_VAL, 16, 4, 9>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_msd(16, NB2MAX)));
+          GX_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(k_msd_pass<KeyT, KIND, HAS_VAL, SKPT, 4, 9>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_msd(SKPT, NB2MAX)));
           GX_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(k_local_sort<KeyT, KIND, HAS_VAL, 13>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_loc(13)));
         }
         hattr_set = true;
@@ -1445,10 +1447,10 @@ int sort_impl(const void* keys_in, void* keys_out, const int32_t* vals_in, int32
       int kpt1 = hyb_kpt;
       if constexpr (SMALLOK) {
         if (hc.bits2 > 8) {
-          kmsd1 = (MsdK)k_msd_pass<KeyT, KIND, HAS_VAL, 16, 4, 9>;
-          kpt1  = 16;
+          kmsd1 = (MsdK)k_msd_pass<KeyT, KIND, HAS_VAL, SKPT, 4, 9>;
+          kpt1  = SKPT;
         }
-        if (g_lbw != 4 && hyb_kpt == 16) {  // A/B knob: predecessors examined per look-back round
+        if constexpr (!HAS_VAL) if (g_lbw != 4 && hyb_kpt == 16) {  // A/B knob: predecessors examined per look-back round
           static bool lattr_set = false;
           if (!lattr_set) {
             GX_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(k_msd_pass<KeyT, KIND, HAS_VAL, 16, 8, 8>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_msd(16, BINS)));

@@ -141,6 +141,40 @@ int gx_fill_random(int dtype, void* out, int64_t n, uint64_t seed, int64_t lo, i
   }
 }
 
+/* see gx.h */
+namespace gx {
+__global__ void __launch_bounds__(256) k_copy_bytes(const char* __restrict__ src, char* __restrict__ dst, size_t bytes)
+{
+  // 16-byte lanes over the aligned body, bytes at the ragged ends (src and dst share their alignment in the callers' use)
+  const size_t head = (16 - (reinterpret_cast<uintptr_t>(dst) & 15u)) & 15u;
+  const bool same   = ((reinterpret_cast<uintptr_t>(src) ^ reinterpret_cast<uintptr_t>(dst)) & 15u) == 0;
+  const size_t stride = (size_t)gridDim.x * 256;
+  const size_t tid    = (size_t)blockIdx.x * 256 + threadIdx.x;
+  if (!same || bytes < 64) {
+    for (size_t i = tid; i < bytes; i += stride) dst[i] = src[i];
+    return;
+  }
+  const size_t h = head < bytes ? head : bytes;
+  for (size_t i = tid; i < h; i += stride) dst[i] = src[i];
+  const size_t nvec = (bytes - h) / 16;
+  const uint4* s4   = reinterpret_cast<const uint4*>(src + h);
+  uint4* d4         = reinterpret_cast<uint4*>(dst + h);
+  for (size_t i = tid; i < nvec; i += stride) d4[i] = s4[i];
+  for (size_t i = h + nvec * 16 + tid; i < bytes; i += stride) dst[i] = src[i];
+}
+}  // namespace gx
+int gx_copy_bytes(const void* src, void* dst, size_t bytes, gx_stream_t s)
+{
+  if (bytes == 0) return 0;
+  if (!src || !dst) return GX_EINVAL;
+  size_t blocks = (bytes / 16 + 256 * 4 - 1) / (256 * 4);
+  if (blocks > 16384) blocks = 16384;
+  if (blocks < 1) blocks = 1;
+  hipLaunchKernelGGL(gx::k_copy_bytes, dim3((unsigned)blocks), dim3(256), 0, s, static_cast<const char*>(src), static_cast<char*>(dst), bytes);
+  GX_LAUNCH_CHECK();
+  return 0;
+}
+
 int gx_sequence_i32(int32_t* out, int64_t n, int32_t start, gx_stream_t s)
 {
   if (n < 0 || (n > 0 && !out)) return GX_EINVAL;

@@ -466,6 +466,10 @@ int gx_segment_ids(const int32_t* offsets, int64_t num_offsets, int64_t num_rows
  * table), 1 = global-atomic table only, 2 = partitioned for every n > 0.  nsplit: workgroups per
  * partition in the LDS aggregation kernel (1..16). */
 void gx_groupby_set_algorithm(int algo, int nsplit);
+/* A/B knob (process-wide) of the LDS-partitioned path: 1 (default) = the partition pass runs WITHOUT its histogram into padded
+ * (partition, XCD range) slots for n >= 2^22, with the exact histogram path as device-side fallback when a slot overflows
+ * (skewed keys); 0 = always the exact path; 2 = speculative for every n (tests). */
+void gx_groupby_set_partition_mode(int speculative);
 
 /* Result finalizers of cudf::groupby::aggregate: (a) validity bitmap of SUM / MEAN results from
  * COUNT_VALID -- a group without a valid value is null (src/groupby/hash/output_utils.cu:68-70);
@@ -515,6 +519,10 @@ int gx_bitmask_first_unset(const uint32_t* mask, int64_t nbits, int64_t* pos_dev
  * ------------------------------------------------------------------------------------------ */
 int gx_fill_random(int dtype, void* out, int64_t n, uint64_t seed, int64_t lo, int64_t hi,
                    gx_stream_t stream);
+/* device-to-device copy as a KERNEL on `stream` (16-byte lanes): what a rank does with the part of an exchange that stays
+ * on it.  hipMemcpyAsync picks the SDMA engines when other queues are busy -- 32 GB/s for an intra-device copy on this
+ * part, measured (profiles/r3_xp_distributed_single_rank.txt: 252 ms for 8 GB in chunks, 4 ms as one kernel). */
+int gx_copy_bytes(const void* src, void* dst, size_t bytes, gx_stream_t stream);
 /* iota: out[i] = start + i (int32) */
 int gx_sequence_i32(int32_t* out, int64_t n, int32_t start, gx_stream_t stream);
 /* order-independent 64-bit checksum of a column (sum and xor of splitmix64(element)) and a

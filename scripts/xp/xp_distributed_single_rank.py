@@ -39,7 +39,11 @@ sp = torch.sort(keys[:: max(1, n // 4096)])[0]
 splitters = sp[[len(sp) // 8 * i for i in range(1, 8)]].cpu().tolist()
 print(f"range partition into 8 (gx_partition_rows)  {timed(lambda: local.range_partition(keys, splitters)):8.2f} ms")
 print(f"hash partition into 8 of (key,row)          {timed(lambda: local.hash_partition_rows(keys, 8)):8.2f} ms")
-print(f"distributed_sort, 1 rank, exchange forced   {timed(lambda: D.distributed_sort(keys, local=local)):8.2f} ms")
+print(f"distributed_sort (round-2 python path)      {timed(lambda: D.distributed_sort(keys, local=local)):8.2f} ms")
+comm = D._gxd_comm(None)
+for ch in (1, 4, 8, 16):
+    print(f"gxd_sort forced, {ch:2d} chunks                   {timed(lambda: comm.sort(keys, chunks=ch, force_exchange=True)):8.2f} ms   (enqueue, count waits, total) = "
+          + ", ".join(f"{x:.2f}" for x in comm.last_timing()))
 del keys
 nb = n // 10
 bk = torch.randperm(nb, device="cuda") * 3 + 1
@@ -47,10 +51,22 @@ pk = as_t(ops.random_column(np.int64, n, seed=2, lo=0, hi=int(nb / 0.3)), torch.
 t0 = time.perf_counter()
 hj = D.DistributedHashJoin(bk, local=local)
 torch.cuda.synchronize()
-print(f"DistributedHashJoin build (1e8, forced)     {(time.perf_counter() - t0) * 1e3:8.2f} ms")
-print(f"DistributedHashJoin.inner_join (forced)     {timed(lambda: hj.inner_join(pk)):8.2f} ms")
-del hj, bk, pk
+print(f"DistributedHashJoin build (round-2 python)  {(time.perf_counter() - t0) * 1e3:8.2f} ms")
+print(f"DistributedHashJoin.inner_join (r2 python)  {timed(lambda: hj.inner_join(pk)):8.2f} ms")
+del hj
+from cudf_amd import gxd
+t0 = time.perf_counter()
+gj = gxd.HashJoin(comm, bk, force_exchange=True)
+torch.cuda.synchronize()
+print(f"gxd_join_build forced (1e8)                 {(time.perf_counter() - t0) * 1e3:8.2f} ms")
+for ch in (1, 4, 8, 16):
+    print(f"gxd_join_probe forced, {ch:2d} chunks             {timed(lambda: gj.inner_join(pk, chunks=ch)):8.2f} ms   (enqueue, count waits, total) = "
+          + ", ".join(f"{x:.2f}" for x in comm.last_timing()))
+gj.close()
+del bk, pk
 gk = as_t(ops.random_column(np.int32, n, seed=3, lo=0, hi=1_000_000), torch.int32)
 gv = as_t(ops.random_column(np.float64, n, seed=4), torch.float64)
-print(f"distributed_groupby_sum_count (forced)      {timed(lambda: D.distributed_groupby_sum_count(gk, gv, local=local)):8.2f} ms")
+print(f"distributed_groupby_sum_count (r2 python)   {timed(lambda: D.distributed_groupby_sum_count(gk, gv, local=local)):8.2f} ms")
+print(f"gxd_groupby_sum_count forced                {timed(lambda: comm.groupby_sum_count(gk, gv, max_groups=1 << 20, force_exchange=True)):8.2f} ms")
+D.close_communicators()
 dist.destroy_process_group()

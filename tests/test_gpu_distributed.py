@@ -22,6 +22,7 @@ def pg():
     D._FORCE_EXCHANGE = True
     yield D
     D._FORCE_EXCHANGE = False
+    D.close_communicators()
     dist.destroy_process_group()
 
 
@@ -130,3 +131,40 @@ def test_merge_sum_count_matches_numpy():
     np.testing.assert_array_equal(mk.to_numpy(), uk)
     np.testing.assert_array_equal(ms.to_numpy(), np.bincount(k, weights=s)[uk])
     np.testing.assert_array_equal(mc.to_numpy(), np.bincount(k, weights=c)[uk].astype(np.int64))
+
+
+def test_gxd_sharded_operators_chunked_forced_exchange(pg):
+    """The C++/RCCL product path (include/cudf_amd/gxd.h) at sizes where it CHUNKS: 6e6-row shards in several chunks, the
+    chunked partitioned probe against a 2^21-slot table, duplicate build keys that blow the first output-size guess, float and
+    32-bit sorts, chunk-relative row ids (gx_partition_rows_at / gx_join_probe_partitioned_at) and the chunk x rank segment table
+    (gx_gather_global_rows_dev)."""
+    import torch
+    from cudf_amd import gxd
+    D = pg
+    comm = D._gxd_comm(None)
+    rng = np.random.default_rng(77)
+    for v in (rng.integers(-2**62, 2**62, 6_000_011, dtype=np.int64), (rng.standard_normal(3_000_001) * 1e3).astype(np.float64),
+              rng.integers(-2**31, 2**31 - 1, 2_500_000).astype(np.int32), np.zeros(0, np.int64), np.arange(5, dtype=np.int64)[::-1].copy()):
+        out = comm.sort(torch.from_numpy(v).cuda(), chunks=4, force_exchange=True)
+        assert out.cpu().numpy().tobytes() == np.sort(v).tobytes()
+    nb, npr = 700_000, 6_000_013
+    build = rng.permutation(3 * nb)[:nb].astype(np.int64)
+    build[:90_000] = np.tile(build[100_000:130_000], 3)          # 30 000 build keys occur four times
+    probe = rng.integers(0, 4 * nb, npr).astype(np.int64)
+    probe[::3] = build[rng.integers(0, 30_000, len(probe[::3]))]  # a third of the probe rows hit them: pairs > rows
+    hj = gxd.HashJoin(comm, torch.from_numpy(build).cuda(), force_exchange=True)
+    el, er = orc.inner_join(probe, build)
+    assert len(el) > npr                                          # the first capacity guess (rows) is too small: the re-probe runs
+    for chunks in (5, 1):
+        l, r = hj.inner_join(torch.from_numpy(probe).cuda(), chunks=chunks)
+        a, b = orc.canonical_pairs(l.cpu().numpy(), r.cpu().numpy())
+        np.testing.assert_array_equal(a, el)
+        np.testing.assert_array_equal(b, er)
+    hj.close()
+    gk = rng.integers(0, 200_000, 4_000_000).astype(np.int64)
+    gv = rng.integers(0, 100, 4_000_000).astype(np.int32)
+    k, s, c = comm.groupby_sum_count(torch.from_numpy(gk).cuda(), torch.from_numpy(gv).cuda(), max_groups=1000, force_exchange=True)
+    uk = np.unique(gk)
+    np.testing.assert_array_equal(k.cpu().numpy(), uk)
+    np.testing.assert_array_equal(s.cpu().numpy(), np.bincount(gk, weights=gv)[uk].astype(np.int64))
+    np.testing.assert_array_equal(c.cpu().numpy(), np.bincount(gk)[uk])

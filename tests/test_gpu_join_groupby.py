@@ -412,3 +412,48 @@ def test_groupby_scan_matches_oracle(gx):
             np.testing.assert_array_equal(out[ev], eo[ev])
         else:
             np.testing.assert_allclose(out[ev], eo[ev], rtol=1e-12)
+
+
+@pytest.mark.parametrize("spec", [2, 0])
+@pytest.mark.parametrize("shape", ["uniform", "hot_key", "one_partition"])
+@pytest.mark.parametrize("nulls", [False, True])
+def test_groupby_speculative_partition_pass(gx, spec, shape, nulls):
+    """Round 3: the partition pass of the LDS-partitioned groupby runs without its histogram into padded (partition, XCD range)
+    slots (spec = 2 forces that at this size; by default it starts at 2^22 rows) and falls back ON THE DEVICE to the exact
+    histogram path when a slot overflows: uniform keys (speculation holds), one hot key and keys confined to one partition
+    (it must not), SUM / COUNT and MIN / MAX, with and without nulls -- all against the oracle."""
+    Column, ops = gx
+    from cudf_amd import _lib
+    rng = np.random.default_rng(5)
+    n = 1_300_003
+    keys = rng.integers(-40_000, 40_000, n).astype(np.int64)
+    if shape == "hot_key":
+        keys[rng.random(n) < 0.3] = 7
+    elif shape == "one_partition":  # keys whose partition hash agrees in its top 8 bits
+        cand = np.arange(1, 3_000_000, dtype=np.uint64)
+        with np.errstate(over="ignore"):
+            part = (cand * np.uint64(0x9E3779B97F4A7C15)) >> np.uint64(56)
+        pool = cand[part == 5][:3000].astype(np.int64)
+        keys = pool[rng.integers(0, len(pool), n)]
+    vals = rng.random(n) * 300.0 - 100.0
+    kv = (rng.random(n) > 0.04) if nulls else None
+    vv = (rng.random(n) > 0.2) if nulls else None
+    _lib.lib.gx_groupby_set_partition_mode(spec)
+    try:
+        kc, vc = Column.from_numpy(keys, kv), Column.from_numpy(vals, vv)
+        k, s, cv, ca = ops.groupby_sum_count(kc, vc)
+        o = np.argsort(k.to_numpy(), kind="stable")
+        ek, res = orc.groupby_agg(keys, vals, ["sum", "count_valid", "count_all", "min", "max"], kv, vv)
+        np.testing.assert_array_equal(k.to_numpy()[o], ek)
+        np.testing.assert_array_equal(cv.to_numpy()[o], res["count_valid"][0])
+        np.testing.assert_array_equal(ca.to_numpy()[o], res["count_all"][0])
+        ev = res["sum"][1]
+        assert np.all(orc.ulp_diff(s.to_numpy()[o][ev], res["sum"][0][ev]) <= 1)
+        k2, mn, mx, cv2 = ops.groupby_min_max(kc, vc)
+        o2 = np.argsort(k2.to_numpy(), kind="stable")
+        np.testing.assert_array_equal(k2.to_numpy()[o2], ek)
+        em = res["min"][1]
+        np.testing.assert_array_equal(mn.to_numpy()[o2][em], res["min"][0][em])
+        np.testing.assert_array_equal(mx.to_numpy()[o2][em], res["max"][0][em])
+    finally:
+        _lib.lib.gx_groupby_set_partition_mode(1)
