@@ -53,6 +53,7 @@ def parse():
                     help="sort knob: 0 onesweep/windowed look-back, 1 three-kernel, 2 onesweep/one-tile look-back")
     ap.add_argument("--gb-algo", type=int, default=0, help="groupby knob: 0 auto, 1 global table, 2 LDS-partitioned")
     ap.add_argument("--gb-split", type=int, default=1)
+    ap.add_argument("--gb-spec", type=int, default=1, help="groupby knob: 1 hist-free speculative partition pass (default), 0 exact histogram pass")
     ap.add_argument("--no-partitioned-join", action="store_true", help="join: probe the table directly")
     ap.add_argument("--join-probe-kernel", type=int, default=0, help="join knob: 0 pipelined tag probe, 1 round-1 tag probe")
     ap.add_argument("--join-scatter-tile", type=int, default=0, help="join knob: rows per scatter tile (0 = default)")
@@ -556,6 +557,7 @@ def bench_groupby(c):
     a, lib, L, ops, np, torch = c.args, c.lib, c.L, c.ops, c.np, c.torch
     n = c.n
     lib.gx_groupby_set_algorithm(a.gb_algo, a.gb_split)
+    lib.gx_groupby_set_partition_mode(a.gb_spec)
     gk = ops.random_column(np.int32, n, seed=7 + c.rank, lo=0, hi=1_000_000)
     gv = ops.random_column(np.float64, n, seed=8 + c.rank)
     if c.world > 1:
@@ -620,6 +622,7 @@ def bench_groupby_minmax(c):
     a, lib, L, ops, np, torch = c.args, c.lib, c.L, c.ops, c.np, c.torch
     n = c.n
     lib.gx_groupby_set_algorithm(a.gb_algo, a.gb_split)
+    lib.gx_groupby_set_partition_mode(a.gb_spec)
     gk = ops.random_column(np.int32, n, seed=7 + c.rank, lo=0, hi=1_000_000)
     gv = ops.random_column(np.float64, n, seed=8 + c.rank)
     mg = 1 << 20
@@ -830,7 +833,7 @@ def main():
             "metric": METRIC, "value": head["rows_per_s"], "unit": "rows/s", "n_gpus": c.world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": head["ms_per_step"], "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": head["dtype"], "data": "synthetic",
-            "config": {"workload": head["workload"], "rows_per_gpu": c.n, "algo": args.algo, "gb_algo": args.gb_algo,
+            "config": {"workload": head["workload"], "rows_per_gpu": c.n, "algo": args.algo, "gb_algo": args.gb_algo, "gb_spec": args.gb_spec,
                        "parallelism": (f"{c.world} ranks, row shards, one all-to-all exchange per step (RCCL over xGMI)"
                                        if c.world > 1 else "1 GPU")},
             "roofline": head["roofline"], "cpu_baseline": head["cpu_baseline"], "checked": head.get("checked"),

@@ -71,6 +71,7 @@ _PROTOS = {
     "gx_join_build_partitioned": (_i, [_i, _p, _i64, _p, ctypes.c_size_t, ctypes.c_double, _p, _sz, _p]),
     "gx_partition_rows": (_i, [_i, _p, _i64, _i, _i, _p, _p, _p, _p, _p, _sz, _p]),
     "gx_partition_rows_at": (_i, [_i, _p, _i64, ctypes.c_int32, _i, _i, _p, _p, _p, _p, _p, _sz, _p]),
+    "gx_partition_rows_spec_at": (_i, [_i, _p, _i64, ctypes.c_int32, _i, _i, _p, _i64, _p, _p, _p, _p, _sz, _p]),
     "gx_join_count_rows": (_i, [_i, _p, _p, _i64, _p, ctypes.c_size_t, ctypes.c_int32, _p, _p]),
     "gx_add_i32": (_i, [_p, _i64, ctypes.c_int32, _p]),
     "gx_join_partition_bits": (_i, [_i, ctypes.c_size_t]),

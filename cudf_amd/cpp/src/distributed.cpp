@@ -55,7 +55,7 @@ double now_ms()
 // grow-only device buffers, one per purpose, reused from call to call
 struct Arena {
   enum Slot { PART_KEYS, PART_ROWS, RECV_KEYS, RECV_ROWS, TMP, TMP2, OFFS, ALLOFFS, SAMPLE, ALLSAMPLE, PAIR_L, PAIR_R, CURSOR, MISC_A,
-              MISC_B, MISC_C, MISC_D, MISC_E, MISC_F, SEGTAB, NSLOTS };
+              MISC_B, MISC_C, MISC_D, MISC_E, MISC_F, SEGTAB, EXACT_KEYS, EXACT_ROWS, TMP3, CNT, NSLOTS };
   void* p[NSLOTS]      = {};
   size_t cap[NSLOTS]   = {};
   // at least `bytes`; the contents are NOT kept
@@ -126,6 +126,7 @@ struct gxd_join {
 namespace {
 
 constexpr int MAX_WORLD = 16;  // gx_partition_rows splits into <= 16 groups in one pass (PJ_MAX_SPLIT + 1)
+double g_slot_scale     = 0.0;  // gxd_test_set_slot_scale
 
 int elem_size(int dtype) { return gx_dtype_size(dtype); }
 
@@ -186,6 +187,8 @@ struct Exchange {
   int chunks    = 0;
   std::vector<long long> seg_counts;   // [chunks * world] rows received per (chunk, source rank), in buffer order
   std::vector<long long> chunk_start;  // [chunks + 1] first received row of each chunk
+  std::vector<long long> send_off, send_cnt;   // [chunks * world] where the rows for rank r sit in chunk k's partition output, how many
+  std::vector<const int32_t*> send_rows;       // [chunks] that chunk's row map (the permutation a payload column has to follow)
 };
 
 // Partition `keys` chunk by chunk into `world` destination groups (mode 0 hash / mode 1 range, gx_partition_rows_at), exchange
@@ -203,25 +206,37 @@ int partition_exchange(gxd_comm* c, int dtype, const void* keys, int64_t n, int 
   ex->chunks          = chunks;
   ex->seg_counts.assign((size_t)chunks * W, 0);
   ex->chunk_start.assign((size_t)chunks + 1, 0);
+  ex->send_off.assign((size_t)chunks * W, 0);
+  ex->send_cnt.assign((size_t)chunks * W, 0);
+  ex->send_rows.assign((size_t)chunks, nullptr);
   GXD_GX(ensure_events(c, chunks));
   GXD_GX(ensure_pinned(c, (size_t)W * (W + 1) + 64));
-  void *pk, *prow = nullptr, *offs, *alloffs, *tmp;
-  GXD_GX(c->arena.get(Arena::PART_KEYS, (size_t)std::max<int64_t>(n, 1) * es, &pk));
-  if (want_rows) GXD_GX(c->arena.get(Arena::PART_ROWS, (size_t)std::max<int64_t>(n, 1) * 4, &prow));
+  // Speculative partition passes (gx_partition_rows_spec_at): ONE read of the keys per chunk, group g of chunk k lands in the
+  // fixed slot (k * W + g) * cap; a chunk whose keys are skewed beyond the slot margin is partitioned again, exactly.
+  int64_t cap = W == 1 ? crows : crows / W + crows / (3 * W) + 4096;
+  if (g_slot_scale > 0) cap = (int64_t)((double)cap * g_slot_scale);  // tests: slots too small on purpose -> the exact re-partition runs
+  cap         = std::min<int64_t>((cap + 31) / 32 * 32, (crows + 31) / 32 * 32);
+  if (cap < 32) cap = 32;
+  const int64_t stride = cap * W;  // elements per chunk in the partition buffers
+  void *pk, *prow = nullptr, *offs, *alloffs, *tmp, *cnt;
+  GXD_GX(c->arena.get(Arena::PART_KEYS, (size_t)stride * chunks * es, &pk));
+  if (want_rows) GXD_GX(c->arena.get(Arena::PART_ROWS, (size_t)stride * chunks * 4, &prow));
   GXD_GX(c->arena.get(Arena::OFFS, sizeof(long long) * (size_t)chunks * (W + 1), &offs));
-  GXD_GX(c->arena.get(Arena::ALLOFFS, sizeof(long long) * (size_t)W * (W + 1), &alloffs));
+  GXD_GX(c->arena.get(Arena::ALLOFFS, sizeof(long long) * (size_t)W * W, &alloffs));
+  GXD_GX(c->arena.get(Arena::CNT, sizeof(long long) * (size_t)W, &cnt));
   size_t tb = 0;
-  GXD_GX(gx_partition_rows_at(dtype, keys, crows, 0, mode, W, splitters_host, pk, static_cast<int32_t*>(prow), static_cast<int64_t*>(offs),
-                              nullptr, &tb, stream));
+  GXD_GX(gx_partition_rows_spec_at(dtype, keys, crows, 0, mode, W, splitters_host, cap, pk, static_cast<int32_t*>(prow),
+                                   static_cast<int64_t*>(offs), nullptr, &tb, stream));
   GXD_GX(c->arena.get(Arena::TMP, tb ? tb : 1, &tmp));
   const double t0 = now_ms();
   // ---- every partition pass is enqueued before the first wait
   for (int k = 0; k < chunks; ++k) {
     const int64_t c0 = (int64_t)k * crows;
     const int64_t nc = std::min<int64_t>(crows, n - c0);
-    GXD_GX(gx_partition_rows_at(dtype, static_cast<const char*>(keys) + c0 * es, nc, (int32_t)c0, mode, W, splitters_host,
-                                static_cast<char*>(pk) + c0 * es, want_rows ? static_cast<int32_t*>(prow) + c0 : nullptr,
-                                static_cast<int64_t*>(offs) + (size_t)k * (W + 1), tmp, &tb, stream));
+    GXD_GX(gx_partition_rows_spec_at(dtype, static_cast<const char*>(keys) + c0 * es, nc, (int32_t)c0, mode, W, splitters_host, cap,
+                                     static_cast<char*>(pk) + (size_t)k * stride * es,
+                                     want_rows ? static_cast<int32_t*>(prow) + (size_t)k * stride : nullptr,
+                                     static_cast<int64_t*>(offs) + (size_t)k * (W + 1), tmp, &tb, stream));
     GXD_HIP(hipEventRecord(c->evP[k], stream));
   }
   c->ms[0] = now_ms() - t0;
@@ -236,15 +251,59 @@ int partition_exchange(gxd_comm* c, int dtype, const void* keys, int64_t n, int 
     recv_cap = std::min<int64_t>((int64_t)(c->arena.cap[Arena::RECV_KEYS] / es), want_rows ? (int64_t)(c->arena.cap[Arena::RECV_ROWS] / 4) : INT64_MAX);
   }
   double waited = 0;
+  std::vector<long long> soff(W), scnt(W);
   for (int k = 0; k < chunks; ++k) {
     const int64_t c0 = (int64_t)k * crows;
+    const int64_t nc = std::min<int64_t>(crows, n - c0);
     GXD_HIP(hipStreamWaitEvent(c->xs, c->evP[k], 0));
     const double w0 = now_ms();
-    GXD_GX(allgather_i64_host(c, static_cast<long long*>(offs) + (size_t)k * (W + 1), static_cast<long long*>(alloffs), W + 1, c->pinned));
+    // my fill counts of this chunk (and the overflow flag)
+    long long* H = c->pinned;
+    GXD_HIP(hipMemcpyAsync(H, static_cast<long long*>(offs) + (size_t)k * (W + 1), sizeof(long long) * (W + 1), hipMemcpyDeviceToHost, c->xs));
+    GXD_HIP(hipEventRecord(c->evQ, c->xs));
+    GXD_HIP(hipEventSynchronize(c->evQ));
+    const char* kbase    = static_cast<const char*>(pk) + (size_t)k * stride * es;
+    const int32_t* rbase = want_rows ? static_cast<const int32_t*>(prow) + (size_t)k * stride : nullptr;
+    if (H[W] != 0) {  // skewed beyond the margin: the exact two-pass partition of this chunk, on the exchange stream
+      void *ek, *er = nullptr, *t3, *eo;
+      GXD_GX(c->arena.get(Arena::EXACT_KEYS, (size_t)crows * es, &ek));
+      if (want_rows) GXD_GX(c->arena.get(Arena::EXACT_ROWS, (size_t)crows * 4, &er));
+      GXD_GX(c->arena.get(Arena::MISC_D, sizeof(long long) * (W + 1), &eo));
+      size_t tb3 = 0;
+      GXD_GX(gx_partition_rows_at(dtype, keys, crows, 0, mode, W, splitters_host, ek, static_cast<int32_t*>(er), static_cast<int64_t*>(eo), nullptr,
+                                  &tb3, reinterpret_cast<gx_stream_t>(c->xs)));
+      GXD_GX(c->arena.get(Arena::TMP3, tb3 ? tb3 : 1, &t3));
+      GXD_GX(gx_partition_rows_at(dtype, static_cast<const char*>(keys) + c0 * es, nc, (int32_t)c0, mode, W, splitters_host, ek,
+                                  static_cast<int32_t*>(er), static_cast<int64_t*>(eo), t3, &tb3, reinterpret_cast<gx_stream_t>(c->xs)));
+      GXD_HIP(hipMemcpyAsync(H, eo, sizeof(long long) * (W + 1), hipMemcpyDeviceToHost, c->xs));
+      GXD_HIP(hipEventRecord(c->evQ, c->xs));
+      GXD_HIP(hipEventSynchronize(c->evQ));
+      for (int r = 0; r < W; ++r) {
+        soff[r] = H[r];
+        scnt[r] = H[r + 1] - H[r];
+      }
+      kbase = static_cast<const char*>(ek);
+      rbase = static_cast<const int32_t*>(er);
+    } else {
+      for (int r = 0; r < W; ++r) {
+        soff[r] = (long long)r * cap;
+        scnt[r] = H[r];
+      }
+    }
+    for (int r = 0; r < W; ++r) {
+      ex->send_off[(size_t)k * W + r] = soff[r];
+      ex->send_cnt[(size_t)k * W + r] = scnt[r];
+    }
+    ex->send_rows[k] = rbase;
+    // everybody's counts: M[r * W + j] = rows rank r sends to rank j
+    for (int r = 0; r < W; ++r) H[r] = scnt[r];
+    GXD_HIP(hipMemcpyAsync(cnt, H, sizeof(long long) * W, hipMemcpyHostToDevice, c->xs));
+    GXD_HIP(hipStreamSynchronize(c->xs));  // H is reused right below
+    GXD_GX(allgather_i64_host(c, static_cast<long long*>(cnt), static_cast<long long*>(alloffs), W, c->pinned));
     waited += now_ms() - w0;
-    const long long* M = c->pinned;  // M[r * (W + 1) + j] = first row of rank r's group j in its chunk
+    const long long* M = c->pinned;
     int64_t rtotal     = 0;
-    for (int r = 0; r < W; ++r) rtotal += M[r * (W + 1) + c->rank + 1] - M[r * (W + 1) + c->rank];
+    for (int r = 0; r < W; ++r) rtotal += M[r * W + c->rank];
     if (rpos + rtotal > recv_cap) {  // (rare: a skewed split) grow, keeping what has arrived
       GXD_HIP(hipStreamSynchronize(c->xs));
       const int64_t want = rpos + rtotal + (rpos + rtotal) / 4;
@@ -255,22 +314,21 @@ int partition_exchange(gxd_comm* c, int dtype, const void* keys, int64_t n, int 
     ex->chunk_start[k] = rpos;
     if (W > 1) GXD_NCCL(ncclGroupStart());
     for (int r = 0; r < W; ++r) {
-      const int64_t so = M[c->rank * (W + 1) + r], sc = M[c->rank * (W + 1) + r + 1] - so;  // what I send to r
-      const int64_t rc = M[r * (W + 1) + c->rank + 1] - M[r * (W + 1) + c->rank];          // what r sends to me
+      const int64_t so = soff[r], sc = scnt[r];  // what I send to r
+      const int64_t rc = M[r * W + c->rank];     // what r sends to me
       ex->seg_counts[(size_t)k * W + r] = rc;
-      const char* sk = static_cast<const char*>(pk) + (c0 + so) * es;
+      const char* sk = kbase + so * es;
       char* dk       = static_cast<char*>(rk) + rpos * es;
       if (r == c->rank) {  // my own group: a device-local copy on the exchange stream
-        // (a copy KERNEL: hipMemcpyAsync falls to the SDMA engines while other queues are busy -- 32 GB/s intra-device)
+        // (a copy KERNEL: hipMemcpyAsync falls to the SDMA engines while other queues are busy)
         if (sc) GXD_GX(gx_copy_bytes(sk, dk, (size_t)sc * es, reinterpret_cast<gx_stream_t>(c->xs)));
         if (want_rows && sc)
-          GXD_GX(gx_copy_bytes(static_cast<const int32_t*>(prow) + c0 + so, static_cast<int32_t*>(rr) + rpos, (size_t)sc * 4,
-                               reinterpret_cast<gx_stream_t>(c->xs)));
+          GXD_GX(gx_copy_bytes(rbase + so, static_cast<int32_t*>(rr) + rpos, (size_t)sc * 4, reinterpret_cast<gx_stream_t>(c->xs)));
       } else {
         if (sc) GXD_NCCL(ncclSend(sk, (size_t)sc * es, ncclInt8, r, c->comm, c->xs));
         if (rc) GXD_NCCL(ncclRecv(dk, (size_t)rc * es, ncclInt8, r, c->comm, c->xs));
         if (want_rows) {
-          if (sc) GXD_NCCL(ncclSend(static_cast<const int32_t*>(prow) + c0 + so, (size_t)sc, ncclInt32, r, c->comm, c->xs));
+          if (sc) GXD_NCCL(ncclSend(rbase + so, (size_t)sc, ncclInt32, r, c->comm, c->xs));
           if (rc) GXD_NCCL(ncclRecv(static_cast<int32_t*>(rr) + rpos, (size_t)rc, ncclInt32, r, c->comm, c->xs));
         }
       }
@@ -372,6 +430,7 @@ int gxd_comm_destroy(gxd_comm* c)
   return 0;
 }
 
+void gxd_test_set_slot_scale(double scale) { g_slot_scale = scale; }
 int gxd_comm_rank(const gxd_comm* c) { return c ? c->rank : -1; }
 int gxd_comm_world(const gxd_comm* c) { return c ? c->world : -1; }
 int gxd_last_timing(const gxd_comm* c, double* ms3_host)
@@ -695,26 +754,34 @@ int gxd_groupby_sum_count(gxd_comm* c, int key_dtype, const void* keys, int val_
     GXD_HIP(hipStreamSynchronize(stream));
     Exchange ex;
     GXD_GX(partition_exchange(c, key_dtype, pk, g, 0, nullptr, true, 1, stream, &ex, nullptr));
-    // the (sum, count) payload rides the SAME split: gather by the partition's row map, then one more grouped exchange
+    // the (sum, count) payload rides the SAME split: per destination, gather by the partition's row map into a contiguous
+    // staging area, then one more grouped exchange with the counts of the key exchange
     void *gs, *gc;
     GXD_GX(c->arena.get(Arena::MISC_E, (size_t)std::max<long long>(g, 1) * 8, &gs));
     GXD_GX(c->arena.get(Arena::MISC_F, (size_t)std::max<long long>(g, 1) * 8, &gc));
-    if (g > 0) {
-      const int32_t* prow = static_cast<const int32_t*>(c->arena.p[Arena::PART_ROWS]);
-      GXD_GX(gx_gather(8, ps, nullptr, g, prow, g, 0, gs, nullptr, gstream));
-      GXD_GX(gx_gather(8, pc64, nullptr, g, prow, g, 0, gc, nullptr, gstream));
+    std::vector<long long> stage_off(W, 0);
+    {
+      long long run = 0;
+      for (int r = 0; r < W; ++r) {
+        stage_off[r]        = run;
+        const long long cnt = ex.send_cnt[r];
+        if (cnt > 0) {
+          const int32_t* map = ex.send_rows[0] + ex.send_off[r];
+          GXD_GX(gx_gather(8, ps, nullptr, g, map, cnt, 0, static_cast<char*>(gs) + run * 8, nullptr, gstream));
+          GXD_GX(gx_gather(8, pc64, nullptr, g, map, cnt, 0, static_cast<char*>(gc) + run * 8, nullptr, gstream));
+        }
+        run += cnt;
+      }
     }
     GXD_HIP(hipEventRecord(c->evP[0], stream));
     GXD_HIP(hipStreamWaitEvent(c->xs, c->evP[0], 0));
     GXD_GX(c->arena.get(Arena::PAIR_L, (size_t)std::max<int64_t>(ex.total, 1) * 8, &rs));
     GXD_GX(c->arena.get(Arena::PAIR_R, (size_t)std::max<int64_t>(ex.total, 1) * 8, &rc));
-    // the count matrix of the single chunk is still in pinned memory (partition_exchange left it there)
-    const long long* M = c->pinned;
     int64_t rpos = 0;
     if (W > 1) GXD_NCCL(ncclGroupStart());
     for (int r = 0; r < W; ++r) {
-      const int64_t so = M[c->rank * (W + 1) + r], sc = M[c->rank * (W + 1) + r + 1] - so;
-      const int64_t rcv = M[r * (W + 1) + c->rank + 1] - M[r * (W + 1) + c->rank];
+      const int64_t so = stage_off[r], sc = ex.send_cnt[r];
+      const int64_t rcv = ex.seg_counts[r];
       if (r == c->rank) {
         if (sc) {
           GXD_GX(gx_copy_bytes(static_cast<const char*>(gs) + so * 8, static_cast<char*>(rs) + rpos * 8, (size_t)sc * 8, reinterpret_cast<gx_stream_t>(c->xs)));

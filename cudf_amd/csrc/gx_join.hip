@@ -445,6 +445,7 @@ struct PjPlan {
   unsigned int chunk0[PJ_MAXP + 1];           // first probe chunk of each partition (partitions in list order)
   unsigned int list_chunk0[PJ_NR + 1];
   PjCounter ticket[PJ_NR];                    // chunk tickets per XCD list, each on its own line
+  alignas(128) unsigned int spec_overflow;    // speculative form of the scatter (gx_partition_rows_spec_at): a group outgrew its slot
 };
 
 __device__ __forceinline__ unsigned pj_xcc() { return __builtin_amdgcn_s_getreg(20 | (0 << 6) | (3 << 11)) & 7u; }
@@ -573,8 +574,10 @@ __global__ void __launch_bounds__(1024) k_pj_offsets(PjPlan* plan, int pbits, un
 template <typename K, int RPT, int BTt, typename F>
 __global__ void __launch_bounds__(BTt) k_pj_scatter(const K* __restrict__ keys, int64_t n, PjPlan* plan, int pbits,
                                                     int64_t rrows, K* __restrict__ pkeys, int32_t* __restrict__ pidx, F part_of,
-                                                    int32_t row0 = 0)
+                                                    int32_t row0 = 0, uint32_t spec_cap = 0)
 {
+  // spec_cap > 0 (gx_partition_rows_spec_at): no histogram ran -- group b owns the slot [b, b + 1) * spec_cap of the output, ONE
+  // fill counter per group (cursor[0][b], from zero); rows beyond a slot are dropped and flagged (the caller re-partitions)
   constexpr int TILE = BTt * RPT;
   extern __shared__ __attribute__((aligned(16))) char smem[];
   K* s_k                = reinterpret_cast<K*>(smem);                                  // TILE (reused for idx)
@@ -588,7 +591,7 @@ __global__ void __launch_bounds__(BTt) k_pj_scatter(const K* __restrict__ keys, 
   const unsigned tid  = threadIdx.x;
   const int64_t tile  = xcd_swizzle(blockIdx.x, gridDim.x);
   const int64_t base  = tile * TILE;
-  const int range     = (rrows > 0 && base / rrows < PJ_NR - 1) ? (int)(base / rrows) : PJ_NR - 1;
+  const int range     = spec_cap ? 0 : ((rrows > 0 && base / rrows < PJ_NR - 1) ? (int)(base / rrows) : PJ_NR - 1);
   const int nvalid    = (int)((n - base < (int64_t)TILE) ? (n - base) : (int64_t)TILE);
   for (int i = tid; i < P; i += BTt) s_cnt[i] = 0;
   if (tid == 0) s_carry = 0;
@@ -618,6 +621,10 @@ __global__ void __launch_bounds__(BTt) k_pj_scatter(const K* __restrict__ keys, 
       s_start[b] = st;
       unsigned long long g = 0;
       if (c) g = atomicAdd(&plan->cursor[range][b], (unsigned long long)c);
+      if (spec_cap) {
+        if (c && g + c > spec_cap) plan->spec_overflow = 1u;
+        g += (unsigned long long)b * spec_cap;
+      }
       s_delta[b] = (unsigned int)g - st;
     }
     __syncthreads();
@@ -639,7 +646,9 @@ __global__ void __launch_bounds__(BTt) k_pj_scatter(const K* __restrict__ keys, 
     if (i < nvalid) {
       const K k = s_k[i];
       obin[j]   = (unsigned short)part_of(k);
-      pkeys[(unsigned int)(s_delta[obin[j]] + (unsigned int)i)] = k;
+      const unsigned int p = s_delta[obin[j]] + (unsigned int)i;
+      if (spec_cap && p >= ((unsigned int)obin[j] + 1u) * spec_cap) obin[j] = 0xFFFFu;  // beyond the slot: dropped
+      else pkeys[p] = k;
     }
   }
   if (pidx == nullptr) return;  // keys only (range partition of a sort)
@@ -655,7 +664,7 @@ __global__ void __launch_bounds__(BTt) k_pj_scatter(const K* __restrict__ keys, 
 #pragma unroll
   for (int j = 0; j < RPT; ++j) {
     const int i = j * BTt + (int)tid;
-    if (i < nvalid) pidx[(unsigned int)(s_delta[obin[j]] + (unsigned int)i)] = s_i[i];
+    if (i < nvalid && obin[j] != 0xFFFFu) pidx[(unsigned int)(s_delta[obin[j]] + (unsigned int)i)] = s_i[i];
   }
 }
 
@@ -2292,7 +2301,7 @@ static int g_pj_defer = 0;        // round-3 probe: 1 = unsettled rows are parke
 // the partition pass shared by the partitioned probe and build (F = TableTop) and by gx_partition_rows
 template <typename K, typename F>
 int pj_partition_fn(const K* keys, int64_t n, int pbits, PjPlan* plan, K* pkeys, int32_t* pidx, unsigned int chunk_rows, hipStream_t s,
-                    F part_of, bool profile = false, int32_t row0 = 0)
+                    F part_of, bool profile = false, int32_t row0 = 0, uint32_t spec_cap = 0)
 {
   GX_HIP_TRY(hipMemsetAsync(plan, 0, sizeof(PjPlan), s));
   // tile: as many rows as the LDS holds next to the three P-entry arrays (160 KiB per CU)
@@ -2307,8 +2316,10 @@ int pj_partition_fn(const K* keys, int64_t n, int pbits, PjPlan* plan, K* pkeys,
   int64_t hb = div_up(n, 256 * 8 * 4 * PJ_NR);
   if (hb > 256) hb = 256;
   if (hb < 1) hb = 1;
-  hipLaunchKernelGGL((k_pj_hist<K, F>), dim3((unsigned)(hb * PJ_NR)), dim3(256), 0, s, keys, n, plan, pbits, rrows, part_of, (const unsigned int*)nullptr);
-  hipLaunchKernelGGL(k_pj_offsets, dim3(1), dim3(1024), 0, s, plan, pbits, chunk_rows, (const unsigned int*)nullptr);
+  if (!spec_cap) {  // (the speculative form has no histogram: fixed slots, fill counters from zero)
+    hipLaunchKernelGGL((k_pj_hist<K, F>), dim3((unsigned)(hb * PJ_NR)), dim3(256), 0, s, keys, n, plan, pbits, rrows, part_of, (const unsigned int*)nullptr);
+    hipLaunchKernelGGL(k_pj_offsets, dim3(1), dim3(1024), 0, s, plan, pbits, chunk_rows, (const unsigned int*)nullptr);
+  }
   if (profile) jprof_mark(1, s);
   const size_t lds = (size_t)tile_rows * sizeof(K) + ((size_t)12 << pbits);
   auto k4          = k_pj_scatter<K, 8, 512, F>;
@@ -2323,9 +2334,9 @@ int pj_partition_fn(const K* keys, int64_t n, int pbits, PjPlan* plan, K* pkeys,
     attr_set = true;
   }
   const unsigned grid = (unsigned)div_up(n, (int64_t)tile_rows);
-  if (tile_rows == 16384) hipLaunchKernelGGL(k16, dim3(grid), dim3(1024), lds, s, keys, n, plan, pbits, rrows, pkeys, pidx, part_of, row0);
-  else if (tile_rows == 8192) hipLaunchKernelGGL(k8, dim3(grid), dim3(512), lds, s, keys, n, plan, pbits, rrows, pkeys, pidx, part_of, row0);
-  else hipLaunchKernelGGL(k4, dim3(grid), dim3(512), lds, s, keys, n, plan, pbits, rrows, pkeys, pidx, part_of, row0);
+  if (tile_rows == 16384) hipLaunchKernelGGL(k16, dim3(grid), dim3(1024), lds, s, keys, n, plan, pbits, rrows, pkeys, pidx, part_of, row0, spec_cap);
+  else if (tile_rows == 8192) hipLaunchKernelGGL(k8, dim3(grid), dim3(512), lds, s, keys, n, plan, pbits, rrows, pkeys, pidx, part_of, row0, spec_cap);
+  else hipLaunchKernelGGL(k4, dim3(grid), dim3(512), lds, s, keys, n, plan, pbits, rrows, pkeys, pidx, part_of, row0, spec_cap);
   if (profile) jprof_mark(2, s);
   GX_LAUNCH_CHECK();
   return 0;
@@ -2342,10 +2353,19 @@ __global__ void k_pj_export_offsets(const PjPlan* plan, int nparts, long long* o
 {
   for (int i = threadIdx.x; i <= nparts; i += blockDim.x) out[i] = (long long)plan->offset[i];
 }
+// speculative form: rows per group (clamped to the slot), then the overflow flag
+__global__ void k_pj_export_fills(const PjPlan* plan, int nparts, uint32_t cap, long long* out)
+{
+  for (int i = threadIdx.x; i < nparts; i += blockDim.x) {
+    const unsigned long long f = plan->cursor[0][i];
+    out[i]                     = (long long)(f < cap ? f : cap);
+  }
+  if (threadIdx.x == 0) out[nparts] = (long long)plan->spec_overflow;
+}
 
 template <typename K>
 int partition_rows_hash(const void* keys, int64_t n, int pbits, int nparts, void* out_keys, int32_t* out_rows, int64_t* offsets,
-                        void* tmp, size_t* tmp_bytes, hipStream_t s, int32_t row0)
+                        void* tmp, size_t* tmp_bytes, hipStream_t s, int32_t row0, uint32_t spec_cap = 0)
 {
   Carver c(tmp);
   PjPlan* plan = c.take<PjPlan>(1);
@@ -2355,15 +2375,16 @@ int partition_rows_hash(const void* keys, int64_t n, int pbits, int nparts, void
   }
   if (*tmp_bytes < c.total()) return GX_ETMP;
   int rc = pj_partition_fn<K, AltHash<K>>(static_cast<const K*>(keys), n, pbits < 3 ? 3 : pbits, plan, static_cast<K*>(out_keys), out_rows,
-                                          PJ_CHUNK, s, AltHash<K>{pbits}, false, row0);
+                                          PJ_CHUNK, s, AltHash<K>{pbits}, false, row0, spec_cap);
   if (rc) return rc;
-  hipLaunchKernelGGL(k_pj_export_offsets, dim3(1), dim3(256), 0, s, plan, nparts, reinterpret_cast<long long*>(offsets));
+  if (spec_cap) hipLaunchKernelGGL(k_pj_export_fills, dim3(1), dim3(256), 0, s, plan, nparts, spec_cap, reinterpret_cast<long long*>(offsets));
+  else hipLaunchKernelGGL(k_pj_export_offsets, dim3(1), dim3(256), 0, s, plan, nparts, reinterpret_cast<long long*>(offsets));
   GX_LAUNCH_CHECK();
   return 0;
 }
 template <typename K, int KIND>
 int partition_rows_range(const void* keys, int64_t n, int nparts, const void* splitters_host, void* out_keys, int32_t* out_rows,
-                         int64_t* offsets, void* tmp, size_t* tmp_bytes, hipStream_t s, int32_t row0)
+                         int64_t* offsets, void* tmp, size_t* tmp_bytes, hipStream_t s, int32_t row0, uint32_t spec_cap = 0)
 {
   Carver c(tmp);
   PjPlan* plan = c.take<PjPlan>(1);
@@ -2379,9 +2400,10 @@ int partition_rows_range(const void* keys, int64_t n, int nparts, const void* sp
   int pbits = 3;
   while ((1 << pbits) < nparts) ++pbits;
   int rc = pj_partition_fn<K, RangeSplit<K, KIND>>(static_cast<const K*>(keys), n, pbits, plan, static_cast<K*>(out_keys), out_rows, PJ_CHUNK,
-                                                   s, f, false, row0);
+                                                   s, f, false, row0, spec_cap);
   if (rc) return rc;
-  hipLaunchKernelGGL(k_pj_export_offsets, dim3(1), dim3(256), 0, s, plan, nparts, reinterpret_cast<long long*>(offsets));
+  if (spec_cap) hipLaunchKernelGGL(k_pj_export_fills, dim3(1), dim3(256), 0, s, plan, nparts, spec_cap, reinterpret_cast<long long*>(offsets));
+  else hipLaunchKernelGGL(k_pj_export_offsets, dim3(1), dim3(256), 0, s, plan, nparts, reinterpret_cast<long long*>(offsets));
   GX_LAUNCH_CHECK();
   return 0;
 }
@@ -2761,6 +2783,15 @@ int gx_partition_rows(int key_dtype, const void* keys, int64_t n, int mode, int 
 int gx_partition_rows_at(int key_dtype, const void* keys, int64_t n, int32_t row0, int mode, int nparts, const void* splitters_host,
                          void* out_keys, int32_t* out_rows, int64_t* offsets_dev, void* tmp, size_t* tmp_bytes, gx_stream_t s)
 {
+  return gx_partition_rows_spec_at(key_dtype, keys, n, row0, mode, nparts, splitters_host, 0, out_keys, out_rows, offsets_dev, tmp, tmp_bytes, s);
+}
+
+int gx_partition_rows_spec_at(int key_dtype, const void* keys, int64_t n, int32_t row0, int mode, int nparts, const void* splitters_host,
+                              int64_t cap_rows, void* out_keys, int32_t* out_rows, int64_t* offsets_dev, void* tmp, size_t* tmp_bytes,
+                              gx_stream_t s)
+{
+  if (cap_rows < 0 || (int64_t)nparts * cap_rows > 0xFFFFFFFFll) return GX_EINVAL;
+  const uint32_t cap = (uint32_t)cap_rows;
   using namespace gx;
   using namespace gx::join;
   if (n < 0 || nparts < 1 || nparts > PJ_MAX_SPLIT + 1 || !tmp_bytes || (mode != 0 && mode != 1)) return GX_EINVAL;
@@ -2774,18 +2805,18 @@ int gx_partition_rows_at(int key_dtype, const void* keys, int64_t n, int32_t row
     int pbits = 0;
     while ((1 << pbits) < nparts) ++pbits;
     switch (gx_dtype_size(key_dtype)) {
-      case 8: return partition_rows_hash<uint64_t>(keys, n, pbits, nparts, out_keys, out_rows, offsets_dev, tmp, tmp_bytes, s, row0);
-      case 4: return partition_rows_hash<uint32_t>(keys, n, pbits, nparts, out_keys, out_rows, offsets_dev, tmp, tmp_bytes, s, row0);
+      case 8: return partition_rows_hash<uint64_t>(keys, n, pbits, nparts, out_keys, out_rows, offsets_dev, tmp, tmp_bytes, s, row0, cap);
+      case 4: return partition_rows_hash<uint32_t>(keys, n, pbits, nparts, out_keys, out_rows, offsets_dev, tmp, tmp_bytes, s, row0, cap);
       default: return GX_EDTYPE;
     }
   }
   switch (key_dtype) {
-    case GX_INT64: return partition_rows_range<uint64_t, K_SIGNED>(keys, n, nparts, splitters_host, out_keys, out_rows, offsets_dev, tmp, tmp_bytes, s, row0);
-    case GX_UINT64: return partition_rows_range<uint64_t, K_UNSIGNED>(keys, n, nparts, splitters_host, out_keys, out_rows, offsets_dev, tmp, tmp_bytes, s, row0);
-    case GX_FLOAT64: return partition_rows_range<uint64_t, K_FLOAT>(keys, n, nparts, splitters_host, out_keys, out_rows, offsets_dev, tmp, tmp_bytes, s, row0);
-    case GX_INT32: return partition_rows_range<uint32_t, K_SIGNED>(keys, n, nparts, splitters_host, out_keys, out_rows, offsets_dev, tmp, tmp_bytes, s, row0);
-    case GX_UINT32: return partition_rows_range<uint32_t, K_UNSIGNED>(keys, n, nparts, splitters_host, out_keys, out_rows, offsets_dev, tmp, tmp_bytes, s, row0);
-    case GX_FLOAT32: return partition_rows_range<uint32_t, K_FLOAT>(keys, n, nparts, splitters_host, out_keys, out_rows, offsets_dev, tmp, tmp_bytes, s, row0);
+    case GX_INT64: return partition_rows_range<uint64_t, K_SIGNED>(keys, n, nparts, splitters_host, out_keys, out_rows, offsets_dev, tmp, tmp_bytes, s, row0, cap);
+    case GX_UINT64: return partition_rows_range<uint64_t, K_UNSIGNED>(keys, n, nparts, splitters_host, out_keys, out_rows, offsets_dev, tmp, tmp_bytes, s, row0, cap);
+    case GX_FLOAT64: return partition_rows_range<uint64_t, K_FLOAT>(keys, n, nparts, splitters_host, out_keys, out_rows, offsets_dev, tmp, tmp_bytes, s, row0, cap);
+    case GX_INT32: return partition_rows_range<uint32_t, K_SIGNED>(keys, n, nparts, splitters_host, out_keys, out_rows, offsets_dev, tmp, tmp_bytes, s, row0, cap);
+    case GX_UINT32: return partition_rows_range<uint32_t, K_UNSIGNED>(keys, n, nparts, splitters_host, out_keys, out_rows, offsets_dev, tmp, tmp_bytes, s, row0, cap);
+    case GX_FLOAT32: return partition_rows_range<uint32_t, K_FLOAT>(keys, n, nparts, splitters_host, out_keys, out_rows, offsets_dev, tmp, tmp_bytes, s, row0, cap);
     default: return GX_EDTYPE;
   }
 }

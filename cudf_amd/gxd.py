@@ -31,6 +31,8 @@ _lib.gxd_sort.argtypes = [_p, _i, _p, _i64, _i, _i, _ALLOC, _p, ctypes.POINTER(_
 _lib.gxd_join_build.argtypes = [_p, _i, _p, _i64, _i, _p, ctypes.POINTER(_p)]
 _lib.gxd_join_probe.argtypes = [_p, _p, _i64, _i, _ALLOC, _p, ctypes.POINTER(_p), ctypes.POINTER(_p), ctypes.POINTER(_i64), _p]
 _lib.gxd_join_destroy.argtypes = [_p]
+_lib.gxd_test_set_slot_scale.argtypes = [ctypes.c_double]
+_lib.gxd_test_set_slot_scale.restype = None
 _lib.gxd_groupby_sum_count.argtypes = [_p, _i, _p, _i, _p, _i64, _i64, _i, _ALLOC, _p, ctypes.POINTER(_p), ctypes.POINTER(_p),
                                        ctypes.POINTER(_p), ctypes.POINTER(_i64), _p]
 
@@ -59,6 +61,11 @@ class _Results:
             if t.data_ptr() == ptr:
                 return t[: count * torch.empty(0, dtype=dtype).element_size()].view(dtype)
         raise RuntimeError("gxd: result pointer was not produced by the allocator")
+
+
+def set_slot_scale(scale: float):
+    """test hook: see gxd_test_set_slot_scale"""
+    _lib.gxd_test_set_slot_scale(float(scale))
 
 
 def _stream():

@@ -111,37 +111,8 @@ int gx_sort_status(const void* tmp, int* status_host, gx_stream_t stream);
  * C++ surface uses so that cudf::sort returns without a host round trip (reference: sort.cu:52-89 is asynchronous). */
 int gx_sort_status_async(const void* tmp, int* status_host_pinned, gx_stream_t stream);
 
-/* Tuning / A-B knob (process-wide): 0 = onesweep (decoupled look-back, 8-tile look-back window,
- * default), 1 = three-kernel passes (tile histogram + scan + scatter; no inter-workgroup
- * communication), 2 = onesweep with a one-tile-per-hop look-back (the textbook form; slower on
- * this chip, kept for A/B measurements). */
-void gx_sort_set_algorithm(int algo);
 
-/* Measurement hooks (bench.py's roofline leg): when enabled, every sort records HIP events on
- * the caller's stream around the histogram launch and around each pass's launch(es);
- * gx_sort_profile_read waits for the last sort and returns the durations in milliseconds
- * (pass_ms has room for 8 entries; skipped passes report the few microseconds of their early
- * exit). */
-int gx_sort_profile(int enable);
-int gx_sort_profile_read(float* hist_ms, float* pass_ms, int* npass);
-/* durations of the hybrid path's kernels of the last profiled sort, in milliseconds:
- * ms4 = {level-0 partition pass, level-1 partition pass, cell plan (one block), LDS local sort}.
- * GX_EINVAL when the last sort did not enqueue the hybrid path. */
-int gx_sort_profile_read_hybrid(float* ms4);
 
-/* Hybrid MSD path (64-bit keys, n >= 2^22): an up-front pass finds the varying bits and histograms the
- * level-0 digit (the 8 bits below the highest varying bit), two partition passes (8 + up to 9 bits), then one
- * kernel that sorts every cell of <= 8192 / 16384 keys on its remaining bits inside LDS (64 B/row of HBM
- * traffic instead of 136).  Enabled by default; the device falls back to the LSD passes by itself when a cell
- * does not fit (skewed keys).  0 disables it (A/B measurements). */
-void gx_sort_set_hybrid(int enable);
-/* A/B knob (process-wide): capacity of a local-sort cell of the hybrid path.  0 = auto (8192-key cells, two
- * workgroups per CU and a 9-bit second partition level, for integer keys-only sorts of up to ~1.02e9 rows;
- * 16384-key cells otherwise), 8192 / 16384 = force where the key kind allows it. */
-void gx_sort_set_cell(int keys);
-/* A/B knob (process-wide): predecessors a tile of the keys-only hybrid partition passes examines per look-back
- * round (4, 8, 16 = default). */
-void gx_sort_set_lookback(int window);
 /* info8_host (host, 8 x int32) = {hybrid attempted, hybrid used, d1, shift2, bits2, LDS passes,
  * largest cell, active LSD passes (-1 when the hybrid path produced the output)} of the last sort
  * that used `tmp`.  Synchronises `stream`. */
@@ -326,6 +297,13 @@ int gx_partition_rows(int key_dtype, const void* keys, int64_t n, int mode, int 
 int gx_partition_rows_at(int key_dtype, const void* keys, int64_t n, int32_t row_base, int mode, int nparts, const void* splitters_host,
                          void* out_keys, int32_t* out_rows, int64_t* offsets_dev, void* tmp, size_t* tmp_bytes,
                          gx_stream_t stream);
+/* The SPECULATIVE form (cap_rows > 0): no histogram pass.  Group g owns the fixed slot [g, g + 1) * cap_rows of out_keys /
+ * out_rows (which hold nparts * cap_rows elements); offsets_dev[g] receives the ROWS of group g (not a start), offsets_dev[nparts]
+ * is non-zero when some group outgrew its slot -- its surplus rows were dropped and the caller must partition this input again
+ * with the exact form.  What the sharded operators run per chunk before an exchange: one read of the keys instead of two. */
+int gx_partition_rows_spec_at(int key_dtype, const void* keys, int64_t n, int32_t row_base, int mode, int nparts, const void* splitters_host,
+                              int64_t cap_rows, void* out_keys, int32_t* out_rows, int64_t* offsets_dev, void* tmp, size_t* tmp_bytes,
+                              gx_stream_t stream);
 /* gx_join_probe_partitioned for a chunk of the probe side: the probe indices written are row_base + (index inside probe_keys);
  * pairs are appended at *cursor_dev (which the caller zeroes once, before the first chunk). */
 int gx_join_probe_partitioned_at(int key_size, const void* probe_keys, int64_t probe_rows, int32_t row_base, const void* table,
@@ -333,24 +311,6 @@ int gx_join_probe_partitioned_at(int key_size, const void* probe_keys, int64_t p
                                  int64_t capacity, int64_t* cursor_dev, void* tmp, size_t* tmp_bytes, gx_stream_t stream);
 /* log2 of the number of partitions the partitioned probe uses for this table; 0 = not partitionable */
 int gx_join_partition_bits(int key_size, size_t table_bytes);
-/* Measurement hooks (bench.py's roofline leg), like gx_sort_profile: when enabled, every partitioned probe
- * records HIP events on the caller's stream; gx_join_profile_read waits for the last one and returns
- * ms3 = {partition histogram + offsets, scatter of (key, row) into partitions, probe} in milliseconds. */
-int gx_join_profile(int enable);
-int gx_join_profile_read(float* ms3);
-/* A/B knob (process-wide): rows per workgroup tile of the partition scatter (4096, 8192, 16384; 0 = default:
- * the largest that fits the LDS next to the per-partition counters). */
-void gx_join_set_scatter_tile(int rows);
-/* A/B knob (process-wide): 0 = software-pipelined tag probe (default), 1 = the round-1 tag probe. */
-void gx_join_set_probe_kernel(int which);
-/* A/B knob (process-wide): speculative = 1 (default) partitions the probe rows WITHOUT a histogram pass into padded
- * (partition, XCD range) slots with a persistent scatter kernel, falling back on the device to the exact histogram
- * path when a slot overflows (skewed keys); 0 = always the exact path of round 2; 2 = speculative for every row count
- * (tests: by default inputs below 1.7e7 rows take the round-2 path).  early_loads bit 0 (default 0): the
- * pipelined probe requests a piece's rows at the top of a trip instead of at its end; bit 1 set: rows whose chain is not
- * settled by their first candidate slot are parked in a per-wave queue for one trip instead of being finished in place (A/B;
- * default 0: the queue measured slower once the tag window grew to 16 slots). */
-void gx_join_set_partition_mode(int speculative, int early_loads);
 
 /* out_build_idx[i] = the first build row whose key equals probe key i, or INT32_MIN (JoinNoMatch) --
  * the left join against DISTINCT build keys, in probe order and without an output reservation:
@@ -461,15 +421,6 @@ int gx_rank_from_groups(const int32_t* order, const int32_t* labels, const int32
  * segment [offsets[j], offsets[j+1]) get offsets[j+1]; rows outside every segment get unique ascending ids. */
 int gx_segment_ids(const int32_t* offsets, int64_t num_offsets, int64_t num_rows, int32_t* ids, gx_stream_t stream);
 
-/* Tuning / A-B knob (process-wide).  algo: 0 = auto (hash-partition rows into 256 LDS-sized
- * partitions and aggregate each in one workgroup's LDS when n >= 2^19, else the global-atomic
- * table), 1 = global-atomic table only, 2 = partitioned for every n > 0.  nsplit: workgroups per
- * partition in the LDS aggregation kernel (1..16). */
-void gx_groupby_set_algorithm(int algo, int nsplit);
-/* A/B knob (process-wide) of the LDS-partitioned path: 1 (default) = the partition pass runs WITHOUT its histogram into padded
- * (partition, XCD range) slots for n >= 2^22, with the exact histogram path as device-side fallback when a slot overflows
- * (skewed keys); 0 = always the exact path; 2 = speculative for every n (tests). */
-void gx_groupby_set_partition_mode(int speculative);
 
 /* Result finalizers of cudf::groupby::aggregate: (a) validity bitmap of SUM / MEAN results from
  * COUNT_VALID -- a group without a valid value is null (src/groupby/hash/output_utils.cu:68-70);

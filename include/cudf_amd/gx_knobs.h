@@ -1,0 +1,89 @@
+/*
+ * gx_knobs.h -- tuning knobs and measurement hooks of libcudf_amd.  NOT part of the drop-in boundary (gx.h): these set
+ * PROCESS-WIDE state that the entry points of gx.h read when they are called.  They exist for A/B measurements (bench.py,
+ * scripts/) and for tests that must force a code path (fallback algorithms, speculative passes at small sizes).  A production
+ * caller never calls them; calling one while another thread is inside a gx_* entry point is a data race by contract.
+ */
+#ifndef CUDF_AMD_GX_KNOBS_H
+#define CUDF_AMD_GX_KNOBS_H
+
+#include <cudf_amd/gx.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* Tuning / A-B knob (process-wide): 0 = onesweep (decoupled look-back, 8-tile look-back window,
+ * default), 1 = three-kernel passes (tile histogram + scan + scatter; no inter-workgroup
+ * communication), 2 = onesweep with a one-tile-per-hop look-back (the textbook form; slower on
+ * this chip, kept for A/B measurements). */
+void gx_sort_set_algorithm(int algo);
+
+/* Measurement hooks (bench.py's roofline leg): when enabled, every sort records HIP events on
+ * the caller's stream around the histogram launch and around each pass's launch(es);
+ * gx_sort_profile_read waits for the last sort and returns the durations in milliseconds
+ * (pass_ms has room for 8 entries; skipped passes report the few microseconds of their early
+ * exit). */
+int gx_sort_profile(int enable);
+
+int gx_sort_profile_read(float* hist_ms, float* pass_ms, int* npass);
+
+/* durations of the hybrid path's kernels of the last profiled sort, in milliseconds:
+ * ms4 = {level-0 partition pass, level-1 partition pass, cell plan (one block), LDS local sort}.
+ * GX_EINVAL when the last sort did not enqueue the hybrid path. */
+int gx_sort_profile_read_hybrid(float* ms4);
+
+/* Hybrid MSD path (64-bit keys, n >= 2^22): an up-front pass finds the varying bits and histograms the
+ * level-0 digit (the 8 bits below the highest varying bit), two partition passes (8 + up to 9 bits), then one
+ * kernel that sorts every cell of <= 8192 / 16384 keys on its remaining bits inside LDS (64 B/row of HBM
+ * traffic instead of 136).  Enabled by default; the device falls back to the LSD passes by itself when a cell
+ * does not fit (skewed keys).  0 disables it (A/B measurements). */
+void gx_sort_set_hybrid(int enable);
+
+/* A/B knob (process-wide): capacity of a local-sort cell of the hybrid path.  0 = auto (8192-key cells, two
+ * workgroups per CU and a 9-bit second partition level, for integer keys-only sorts of up to ~1.02e9 rows;
+ * 16384-key cells otherwise), 8192 / 16384 = force where the key kind allows it. */
+void gx_sort_set_cell(int keys);
+
+/* A/B knob (process-wide): predecessors a tile of the keys-only hybrid partition passes examines per look-back
+ * round (4, 8, 16 = default). */
+void gx_sort_set_lookback(int window);
+
+/* Measurement hooks (bench.py's roofline leg), like gx_sort_profile: when enabled, every partitioned probe
+ * records HIP events on the caller's stream; gx_join_profile_read waits for the last one and returns
+ * ms3 = {partition histogram + offsets, scatter of (key, row) into partitions, probe} in milliseconds. */
+int gx_join_profile(int enable);
+
+int gx_join_profile_read(float* ms3);
+
+/* A/B knob (process-wide): rows per workgroup tile of the partition scatter (4096, 8192, 16384; 0 = default:
+ * the largest that fits the LDS next to the per-partition counters). */
+void gx_join_set_scatter_tile(int rows);
+
+/* A/B knob (process-wide): 0 = software-pipelined tag probe (default), 1 = the round-1 tag probe. */
+void gx_join_set_probe_kernel(int which);
+
+/* A/B knob (process-wide): speculative = 1 (default) partitions the probe rows WITHOUT a histogram pass into padded
+ * (partition, XCD range) slots with a persistent scatter kernel, falling back on the device to the exact histogram
+ * path when a slot overflows (skewed keys); 0 = always the exact path of round 2; 2 = speculative for every row count
+ * (tests: by default inputs below 1.7e7 rows take the round-2 path).  early_loads bit 0 (default 0): the
+ * pipelined probe requests a piece's rows at the top of a trip instead of at its end; bit 1 set: rows whose chain is not
+ * settled by their first candidate slot are parked in a per-wave queue for one trip instead of being finished in place (A/B;
+ * default 0: the queue measured slower once the tag window grew to 16 slots). */
+void gx_join_set_partition_mode(int speculative, int early_loads);
+
+/* Tuning / A-B knob (process-wide).  algo: 0 = auto (hash-partition rows into 256 LDS-sized
+ * partitions and aggregate each in one workgroup's LDS when n >= 2^19, else the global-atomic
+ * table), 1 = global-atomic table only, 2 = partitioned for every n > 0.  nsplit: workgroups per
+ * partition in the LDS aggregation kernel (1..16). */
+void gx_groupby_set_algorithm(int algo, int nsplit);
+
+/* A/B knob (process-wide) of the LDS-partitioned path: 1 (default) = the partition pass runs WITHOUT its histogram into padded
+ * (partition, XCD range) slots for n >= 2^22, with the exact histogram path as device-side fallback when a slot overflows
+ * (skewed keys); 0 = always the exact path; 2 = speculative for every n (tests). */
+void gx_groupby_set_partition_mode(int speculative);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* CUDF_AMD_GX_KNOBS_H */

@@ -42,6 +42,9 @@ int gxd_comm_destroy(gxd_comm* comm);
 int gxd_comm_rank(const gxd_comm* comm);
 int gxd_comm_world(const gxd_comm* comm);
 const char* gxd_last_error(void);
+/* TEST HOOK: scales the slot capacity of the speculative partition passes (0 = default margin of 4/3).  A scale below 1 makes
+ * every chunk overflow its slots, so the exact re-partition path runs even on a single rank. */
+void gxd_test_set_slot_scale(double scale);
 /* milliseconds the last operator call of this communicator spent in: [0] partition kernels, [1] host waits for counts,
  * [2] whole call (host clock, the stream is synchronised at the end of every operator) */
 int gxd_last_timing(const gxd_comm* comm, double* ms3_host);

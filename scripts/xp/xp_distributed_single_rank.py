@@ -40,6 +40,7 @@ splitters = sp[[len(sp) // 8 * i for i in range(1, 8)]].cpu().tolist()
 print(f"range partition into 8 (gx_partition_rows)  {timed(lambda: local.range_partition(keys, splitters)):8.2f} ms")
 print(f"hash partition into 8 of (key,row)          {timed(lambda: local.hash_partition_rows(keys, 8)):8.2f} ms")
 print(f"distributed_sort (round-2 python path)      {timed(lambda: D.distributed_sort(keys, local=local)):8.2f} ms")
+torch.cuda.empty_cache()
 comm = D._gxd_comm(None)
 for ch in (1, 4, 8, 16):
     print(f"gxd_sort forced, {ch:2d} chunks                   {timed(lambda: comm.sort(keys, chunks=ch, force_exchange=True)):8.2f} ms   (enqueue, count waits, total) = "
@@ -54,6 +55,7 @@ torch.cuda.synchronize()
 print(f"DistributedHashJoin build (round-2 python)  {(time.perf_counter() - t0) * 1e3:8.2f} ms")
 print(f"DistributedHashJoin.inner_join (r2 python)  {timed(lambda: hj.inner_join(pk)):8.2f} ms")
 del hj
+torch.cuda.empty_cache()
 from cudf_amd import gxd
 t0 = time.perf_counter()
 gj = gxd.HashJoin(comm, bk, force_exchange=True)

@@ -8,6 +8,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 def _declared_symbols():
     text = open(os.path.join(ROOT, "include", "cudf_amd", "gx.h")).read()
+    text += open(os.path.join(ROOT, "include", "cudf_amd", "gx_knobs.h")).read()  # tuning / measurement hooks: a separate header
     text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
     return sorted(set(re.findall(r"\b(gx_[a-z0-9_]+)\s*\(", text)))
 

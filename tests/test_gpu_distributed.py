@@ -143,6 +143,23 @@ def test_gxd_sharded_operators_chunked_forced_exchange(pg):
     D = pg
     comm = D._gxd_comm(None)
     rng = np.random.default_rng(77)
+    # slots of the speculative partition passes shrunk below the chunk size: every chunk overflows and is re-partitioned exactly
+    gxd.set_slot_scale(0.4)
+    try:
+        v = rng.integers(-2**62, 2**62, 3_000_017, dtype=np.int64)
+        out = comm.sort(torch.from_numpy(v).cuda(), chunks=3, force_exchange=True)
+        assert out.cpu().numpy().tobytes() == np.sort(v).tobytes()
+        b2 = rng.permutation(900_000)[:400_000].astype(np.int64)
+        p2 = rng.integers(0, 1_200_000, 2_500_000).astype(np.int64)
+        hj2 = gxd.HashJoin(comm, torch.from_numpy(b2).cuda(), force_exchange=True)
+        l2, r2 = hj2.inner_join(torch.from_numpy(p2).cuda(), chunks=2)
+        a2, c2 = orc.canonical_pairs(l2.cpu().numpy(), r2.cpu().numpy())
+        e2l, e2r = orc.inner_join(p2, b2)
+        np.testing.assert_array_equal(a2, e2l)
+        np.testing.assert_array_equal(c2, e2r)
+        hj2.close()
+    finally:
+        gxd.set_slot_scale(0.0)
     for v in (rng.integers(-2**62, 2**62, 6_000_011, dtype=np.int64), (rng.standard_normal(3_000_001) * 1e3).astype(np.float64),
               rng.integers(-2**31, 2**31 - 1, 2_500_000).astype(np.int32), np.zeros(0, np.int64), np.arange(5, dtype=np.int64)[::-1].copy()):
         out = comm.sort(torch.from_numpy(v).cuda(), chunks=4, force_exchange=True)
@@ -168,3 +185,49 @@ def test_gxd_sharded_operators_chunked_forced_exchange(pg):
     np.testing.assert_array_equal(k.cpu().numpy(), uk)
     np.testing.assert_array_equal(s.cpu().numpy(), np.bincount(gk, weights=gv)[uk].astype(np.int64))
     np.testing.assert_array_equal(c.cpu().numpy(), np.bincount(gk)[uk])
+
+
+@pytest.mark.parametrize("mode", ["hash", "range"])
+def test_partition_rows_speculative_form(mode):
+    """gx_partition_rows_spec_at: the one-read partition pass of the sharded operators -- group g in the fixed slot
+    [g, g + 1) * cap, rows per group instead of starts, the overflow flag when a group outgrows its slot."""
+    import ctypes
+    import torch
+    import cudf_amd  # noqa: F401
+    from cudf_amd import Column, _lib as L
+    from cudf_amd.column import device_bytes, ptr, stream_ptr
+    rng = np.random.default_rng(12)
+    n, W = 3_000_017, 8
+    v = rng.integers(-2**62, 2**62, n, dtype=np.int64)
+    col = Column.from_numpy(v)
+    sp = np.sort(rng.choice(v, W - 1)).astype(np.int64)
+    spp = sp.ctypes.data_as(ctypes.c_void_p) if mode == "range" else None
+    # (random splitters make uneven groups: only a slot of n rows can never overflow in range mode)
+    for cap, expect_overflow in (((n + 31) // 32 * 32 if mode == "range" else n // W * 2, False), (n // W // 2 // 32 * 32, True)):
+        ok = Column.empty(np.int64, W * cap)
+        orow = Column.empty(np.int32, W * cap)
+        offs = torch.zeros(W + 1, dtype=torch.int64, device="cuda")
+        nb = ctypes.c_size_t(0)
+        args = lambda t: (col.gx, col.data_ptr, n, 1000, 1 if mode == "range" else 0, W, spp, cap, ok.data_ptr, orow.data_ptr, ptr(offs), t,
+                          ctypes.byref(nb), stream_ptr())
+        L.check(L.lib.gx_partition_rows_spec_at(*args(None)), "query")
+        tmp = device_bytes(nb.value)
+        L.check(L.lib.gx_partition_rows_spec_at(*args(ptr(tmp))), "partition")
+        f = offs.cpu().numpy()
+        assert bool(f[W]) == expect_overflow
+        if expect_overflow:
+            assert np.all(f[:W] <= cap)
+            continue
+        assert not bool(f[W])
+        assert int(f[:W].sum()) == n and np.all(f[:W] <= cap)
+        keys_out, rows_out = ok.to_numpy(), orow.to_numpy()
+        dest = np.searchsorted(sp, v, side="right") if mode == "range" else None
+        seen = np.zeros(n, bool)
+        for g in range(W):
+            r = rows_out[g * cap: g * cap + f[g]] - 1000         # row_base was 1000
+            assert np.all((r >= 0) & (r < n)) and not seen[r].any()
+            seen[r] = True
+            assert keys_out[g * cap: g * cap + f[g]].tobytes() == v[r].tobytes()
+            if mode == "range":
+                assert np.all(dest[r] == g)
+        assert seen.all()
