@@ -52,6 +52,10 @@ _PROTOS = {
     "gx_gather_global_rows": (_i, [_p, _i64, _p, _i64, _i, _p, _p, _p, _p]),
     "gx_gather_global_rows_dev": (_i, [_p, _i64, _p, _i64, _i, _p, _p, _p]),
     "gx_widen_i32_i64": (_i, [_p, _i64, _p, _p]),
+    "gx_decode_global_rows": (_i, [_p, _i64, _i, _p, _p, _p, _i, _p, _p]),
+    "gx_join_build_pl": (_i, [_i, _p, _p, _p, _i64, _p, ctypes.c_size_t, ctypes.c_double, _p]),
+    "gx_join_build_partitioned_pl": (_i, [_i, _p, _p, _i64, _p, ctypes.c_size_t, ctypes.c_double, _p, _sz, _p]),
+    "gx_join_probe_partitioned_pl": (_i, [_i, _p, _p, _i64, ctypes.c_int32, _p, ctypes.c_size_t, _i, _p, _p, _i64, _p, _p, _sz, _p]),
     "gx_bitmask_set": (_i, [_p, _i64, _i64, _i, _p]),
     "gx_bitmask_count": (_i, [_p, _i64, _i64, _p, _p]),
     "gx_bitmask_and": (_i, [ctypes.POINTER(_p), _i, _i64, _p, _p, _p]),

@@ -10,6 +10,8 @@
 //   host            : enqueues ALL partition passes first, then per chunk waits only for that chunk's count matrix
 //                     (a 64-entry D2H copy) -- the GPU is busy with the later chunks meanwhile.
 // Receive buffers, partition buffers and scratch are slots of a grow-only arena kept by the communicator object.
+#include <cstdio>
+#include <cstdlib>
 #include <cudf_amd/gxd.h>
 
 #include <hip/hip_runtime_api.h>
@@ -51,6 +53,25 @@ double now_ms()
 {
   return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count();
 }
+
+// GXD_TRACE=1: print where an operator call spends its host time (each mark synchronises the device first)
+struct Trace {
+  bool on;
+  double last;
+  const char* op;
+  explicit Trace(const char* o) : on(std::getenv("GXD_TRACE") != nullptr), last(0), op(o)
+  {
+    if (on) last = now_ms();
+  }
+  void mark(const char* what)
+  {
+    if (!on) return;
+    (void)hipDeviceSynchronize();
+    const double t = now_ms();
+    std::fprintf(stderr, "[gxd trace] %-16s %-28s %9.3f ms\n", op, what, t - last);
+    last = t;
+  }
+};
 
 // grow-only device buffers, one per purpose, reused from call to call
 struct Arena {
@@ -121,7 +142,17 @@ struct gxd_join {
   int64_t nrows = 0;
   std::vector<long long> seg_counts, seg_bases;  // per segment: rows, first global row of the source rank's shard
   void* segtab = nullptr;                          // device copy: [nseg + 1] starts | [nseg] bases
+  int enc_shift = 0;                               // > 0: the table slots hold (source rank << enc_shift) | row at the source --
+  void* bases_dev = nullptr;                       //      decoded by one streaming pass with these bases, no gather
 };
+
+// (rank << shift) | row fits an int32 >= 0 when shift = 31 - ceil(log2(world)) and row < 2^shift
+inline int code_shift(int world)
+{
+  int b = 0;
+  while ((1 << b) < world) ++b;
+  return 31 - b;
+}
 
 namespace {
 
@@ -162,8 +193,15 @@ int allgather_i64_host(gxd_comm* c, const long long* mine_dev, long long* all_de
   return 0;
 }
 
-// first global row of every rank's shard (exclusive scan of the shard sizes)
+// first global row of every rank's shard (exclusive scan of the shard sizes) and the largest shard: what chunk grids and row
+// encodings are derived from, so that every rank walks the same number of exchange rounds (one tiny all-gather)
+int shard_sizes(gxd_comm* c, int64_t n, std::vector<long long>& bases, int64_t* nmax);
 int shard_bases(gxd_comm* c, int64_t n, std::vector<long long>& bases)
+{
+  int64_t nmax;
+  return shard_sizes(c, n, bases, &nmax);
+}
+int shard_sizes(gxd_comm* c, int64_t n, std::vector<long long>& bases, int64_t* nmax)
 {
   void *d1, *d2;
   GXD_GX(c->arena.get(Arena::MISC_E, sizeof(long long), &d1));
@@ -174,11 +212,13 @@ int shard_bases(gxd_comm* c, int64_t n, std::vector<long long>& bases)
   GXD_HIP(hipStreamSynchronize(c->xs));  // `mine` is a stack variable
   GXD_GX(allgather_i64_host(c, static_cast<long long*>(d1), static_cast<long long*>(d2), 1, c->pinned));
   bases.assign(c->world, 0);
-  long long run = 0;
+  long long run = 0, mx = 0;
   for (int r = 0; r < c->world; ++r) {
     bases[r] = run;
     run += c->pinned[r];
+    mx = std::max(mx, c->pinned[r]);
   }
+  *nmax = mx;
   return 0;
 }
 
@@ -189,21 +229,34 @@ struct Exchange {
   std::vector<long long> chunk_start;  // [chunks + 1] first received row of each chunk
   std::vector<long long> send_off, send_cnt;   // [chunks * world] where the rows for rank r sit in chunk k's partition output, how many
   std::vector<const int32_t*> send_rows;       // [chunks] that chunk's row map (the permutation a payload column has to follow)
+  int64_t crows = 0;                           // rows per chunk -- the SAME on every rank (from the largest shard)
 };
+
+// how a row is identified on the wire (the int32 that travels next to its key)
+struct RowCode {
+  int shift = 0;       // 0: the row number inside the sender's shard.  > 0: (sender rank << shift) | row ...
+  bool in_chunk = false;  // ... counted inside the sender's CHUNK (probe side: chunk k of every rank starts at k * crows)
+};
+
 
 // Partition `keys` chunk by chunk into `world` destination groups (mode 0 hash / mode 1 range, gx_partition_rows_at), exchange
 // every chunk as soon as it is partitioned, and call on_chunk(c, first received row, rows) when the chunk's rows have been
 // POSTED on the exchange stream (evX is recorded behind them; the callee makes its stream wait for it).
-int partition_exchange(gxd_comm* c, int dtype, const void* keys, int64_t n, int mode, const void* splitters_host, bool want_rows,
-                       int chunks, hipStream_t stream, Exchange* ex, const std::function<int(int, int64_t, int64_t)>& on_chunk)
+int partition_exchange(gxd_comm* c, int dtype, const void* keys, int64_t n, int64_t nmax, int mode, const void* splitters_host,
+                       bool want_rows, int chunks, int64_t max_chunk_rows, RowCode code, hipStream_t stream, Exchange* ex,
+                       const std::function<int(int, int64_t, int64_t)>& on_chunk)
 {
   const int W  = c->world;
   const int es = elem_size(dtype);
+  // the chunk grid comes from the LARGEST shard, so it is the same on every rank (a rank with fewer rows has short or empty
+  // chunks): the grouped send / recv rounds below are collective
   if (chunks <= 0) chunks = 8;
-  if (n < (int64_t)chunks * (1 << 20)) chunks = (int)std::max<int64_t>(1, n >> 20);  // small shards: fewer, larger chunks
-  const int64_t crows = ((n + chunks - 1) / chunks + 16383) / 16384 * 16384;          // whole scatter tiles per chunk
-  chunks              = n > 0 ? (int)((n + crows - 1) / crows) : 1;
+  if (nmax < (int64_t)chunks * (1 << 20)) chunks = (int)std::max<int64_t>(1, nmax >> 20);  // small shards: fewer, larger chunks
+  if (max_chunk_rows > 0 && (nmax + chunks - 1) / chunks > max_chunk_rows - 16384) chunks = (int)((nmax + max_chunk_rows - 16385) / (max_chunk_rows - 16384));
+  const int64_t crows = std::max<int64_t>(16384, ((nmax + chunks - 1) / chunks + 16383) / 16384 * 16384);  // whole scatter tiles per chunk
+  chunks              = nmax > 0 ? (int)((nmax + crows - 1) / crows) : 1;
   ex->chunks          = chunks;
+  ex->crows           = crows;
   ex->seg_counts.assign((size_t)chunks * W, 0);
   ex->chunk_start.assign((size_t)chunks + 1, 0);
   ex->send_off.assign((size_t)chunks * W, 0);
@@ -230,10 +283,18 @@ int partition_exchange(gxd_comm* c, int dtype, const void* keys, int64_t n, int 
   GXD_GX(c->arena.get(Arena::TMP, tb ? tb : 1, &tmp));
   const double t0 = now_ms();
   // ---- every partition pass is enqueued before the first wait
+  auto chunk_rows = [&](int k, int64_t& c0) -> int64_t {
+    c0 = std::min<int64_t>((int64_t)k * crows, n);
+    return std::min<int64_t>(crows, n - c0);
+  };
+  auto row_base = [&](int64_t c0) -> int32_t {
+    if (code.shift == 0) return (int32_t)c0;
+    return (int32_t)(((uint32_t)c->rank << code.shift) + (uint32_t)(code.in_chunk ? 0 : c0));
+  };
   for (int k = 0; k < chunks; ++k) {
-    const int64_t c0 = (int64_t)k * crows;
-    const int64_t nc = std::min<int64_t>(crows, n - c0);
-    GXD_GX(gx_partition_rows_spec_at(dtype, static_cast<const char*>(keys) + c0 * es, nc, (int32_t)c0, mode, W, splitters_host, cap,
+    int64_t c0;
+    const int64_t nc = chunk_rows(k, c0);
+    GXD_GX(gx_partition_rows_spec_at(dtype, static_cast<const char*>(keys) + c0 * es, nc, row_base(c0), mode, W, splitters_host, cap,
                                      static_cast<char*>(pk) + (size_t)k * stride * es,
                                      want_rows ? static_cast<int32_t*>(prow) + (size_t)k * stride : nullptr,
                                      static_cast<int64_t*>(offs) + (size_t)k * (W + 1), tmp, &tb, stream));
@@ -253,8 +314,8 @@ int partition_exchange(gxd_comm* c, int dtype, const void* keys, int64_t n, int 
   double waited = 0;
   std::vector<long long> soff(W), scnt(W);
   for (int k = 0; k < chunks; ++k) {
-    const int64_t c0 = (int64_t)k * crows;
-    const int64_t nc = std::min<int64_t>(crows, n - c0);
+    int64_t c0;
+    const int64_t nc = chunk_rows(k, c0);
     GXD_HIP(hipStreamWaitEvent(c->xs, c->evP[k], 0));
     const double w0 = now_ms();
     // my fill counts of this chunk (and the overflow flag)
@@ -273,7 +334,7 @@ int partition_exchange(gxd_comm* c, int dtype, const void* keys, int64_t n, int 
       GXD_GX(gx_partition_rows_at(dtype, keys, crows, 0, mode, W, splitters_host, ek, static_cast<int32_t*>(er), static_cast<int64_t*>(eo), nullptr,
                                   &tb3, reinterpret_cast<gx_stream_t>(c->xs)));
       GXD_GX(c->arena.get(Arena::TMP3, tb3 ? tb3 : 1, &t3));
-      GXD_GX(gx_partition_rows_at(dtype, static_cast<const char*>(keys) + c0 * es, nc, (int32_t)c0, mode, W, splitters_host, ek,
+      GXD_GX(gx_partition_rows_at(dtype, static_cast<const char*>(keys) + c0 * es, nc, row_base(c0), mode, W, splitters_host, ek,
                                   static_cast<int32_t*>(er), static_cast<int64_t*>(eo), t3, &tb3, reinterpret_cast<gx_stream_t>(c->xs)));
       GXD_HIP(hipMemcpyAsync(H, eo, sizeof(long long) * (W + 1), hipMemcpyDeviceToHost, c->xs));
       GXD_HIP(hipEventRecord(c->evQ, c->xs));
@@ -449,6 +510,7 @@ int gxd_sort(gxd_comm* c, int dtype, const void* keys, int64_t n, int chunks, in
   if (es != 4 && es != 8) return GX_EDTYPE;
   hipStream_t stream = reinterpret_cast<hipStream_t>(gstream);
   const double t0    = now_ms();
+  Trace tr("gxd_sort");
   const int W        = c->world;
   *out_keys          = nullptr;
   *out_n             = 0;
@@ -492,18 +554,25 @@ int gxd_sort(gxd_comm* c, int dtype, const void* keys, int64_t n, int chunks, in
   GXD_HIP(hipMemcpyAsync(hs.data(), sorted, hs.size(), hipMemcpyDeviceToHost, c->xs));
   GXD_HIP(hipStreamSynchronize(c->xs));
   for (int r = 1; r < W; ++r) std::memcpy(&split[(size_t)(r - 1) * es], &hs[(size_t)r * S * es], es);
+  tr.mark("splitters");
   // ---- one range-partition pass per chunk, exchange, one local sort
   Exchange ex;
-  GXD_GX(partition_exchange(c, dtype, keys, n, 1, split.data(), false, chunks, stream, &ex, nullptr));
+  std::vector<long long> bases;
+  int64_t nmax = n;
+  GXD_GX(shard_sizes(c, n, bases, &nmax));
+  GXD_GX(partition_exchange(c, dtype, keys, n, nmax, 1, split.data(), false, chunks, 0, RowCode{}, stream, &ex, nullptr));
   GXD_HIP(hipStreamWaitEvent(stream, c->evX, 0));
+  tr.mark("partition + exchange");
   if (ex.total > 0) {
     void* out = alloc((size_t)ex.total * es, actx);
     if (!out) return fail(GX_EINVAL, "gxd_sort: allocator returned NULL");
+    tr.mark("result allocation");
     void* rk = c->arena.p[Arena::RECV_KEYS];
     GXD_GX(with_tmp(c, Arena::TMP2, [&](void* t, size_t* b) { return gx_sort_keys(dtype, rk, out, ex.total, 0, t, b, gstream); }));
     *out_keys = out;
   }
   GXD_HIP(hipStreamSynchronize(stream));
+  tr.mark("local sort");
   *out_n   = ex.total;
   c->ms[2] = now_ms() - t0;
   return 0;
@@ -517,20 +586,30 @@ int gxd_join_build(gxd_comm* c, int key_dtype, const void* build_keys, int64_t n
   if (ks != 4 && ks != 8) return GX_EDTYPE;
   hipStream_t stream = reinterpret_cast<hipStream_t>(gstream);
   const double t0    = now_ms();
+  Trace tr("gxd_join_build");
   auto* j            = new gxd_join;
   j->comm            = c;
   j->key_size        = ks;
   j->single          = c->world == 1 && !force_exchange;
   const void* tkeys  = build_keys;
+  const int32_t* tpl = nullptr;  // payload of the table slots (NULL: the row number)
   int64_t tn         = n;
   if (!j->single) {
     std::vector<long long> bases;
+    int64_t nmax = n;
     GXD_HIP(hipStreamSynchronize(stream));
-    GXD_GX(shard_bases(c, n, bases));
+    GXD_GX(shard_sizes(c, n, bases, &nmax));
+    // Rows travel -- and sit in the table slots -- as (source rank << shift) | row at the source whenever a shard fits the
+    // row field (2^28 rows at 8 ranks): the probe's pairs then decode in one streaming pass.  Larger build shards keep the
+    // position in the receive buffer in the slot and are translated by a gather (gx_gather_global_rows_dev).
+    const int sh = code_shift(c->world);
+    RowCode code;
+    if (nmax <= (1ll << sh)) code.shift = sh;
     Exchange ex;
-    GXD_GX(partition_exchange(c, key_dtype, build_keys, n, 0, nullptr, true, 4, stream, &ex, nullptr));
+    GXD_GX(partition_exchange(c, key_dtype, build_keys, n, nmax, 0, nullptr, true, 4, 0, code, stream, &ex, nullptr));
     GXD_HIP(hipStreamWaitEvent(stream, c->evX, 0));
     GXD_HIP(hipStreamSynchronize(stream));
+    tr.mark("partition + exchange");
     // the received rows stay with the table (the arena's receive buffers are reused by every probe)
     j->nrows = ex.total;
     GXD_HIP(hipMalloc(reinterpret_cast<void**>(&j->rows), (size_t)std::max<int64_t>(ex.total, 1) * 4));
@@ -542,19 +621,26 @@ int gxd_join_build(gxd_comm* c, int key_dtype, const void* build_keys, int64_t n
     for (size_t i = 0; i < ex.seg_counts.size(); ++i) j->seg_bases[i] = bases[i % c->world];
     GXD_HIP(hipMalloc(&j->segtab, (2 * j->seg_counts.size() + 1) * sizeof(long long)));
     GXD_GX(upload_segtab(c, j->seg_counts, j->seg_bases, j->segtab, stream));
+    GXD_HIP(hipMalloc(&j->bases_dev, sizeof(long long) * c->world));
+    GXD_HIP(hipMemcpy(j->bases_dev, bases.data(), sizeof(long long) * c->world, hipMemcpyHostToDevice));
+    j->enc_shift = code.shift;
     tkeys = j->keys_keep;
+    tpl   = code.shift ? j->rows : nullptr;
     tn    = ex.total;
   }
+  tr.mark("keep rows");
   j->table_bytes = gx_join_table_bytes(ks, tn, 0.5);
   GXD_HIP(hipMalloc(&j->table, j->table_bytes));
+  tr.mark("table allocation");
   if (tn >= (1 << 20) && gx_join_partition_bits(ks, j->table_bytes) > 0) {
     GXD_GX(with_tmp(c, Arena::TMP2, [&](void* t, size_t* b) {
-      return gx_join_build_partitioned(ks, tkeys, tn, j->table, j->table_bytes, 0.5, t, b, gstream);
+      return gx_join_build_partitioned_pl(ks, tkeys, tpl, tn, j->table, j->table_bytes, 0.5, t, b, gstream);
     }));
   } else {
-    GXD_GX(gx_join_build(ks, tkeys, nullptr, tn, j->table, j->table_bytes, 0.5, gstream));
+    GXD_GX(gx_join_build_pl(ks, tkeys, tpl, nullptr, tn, j->table, j->table_bytes, 0.5, gstream));
   }
   GXD_HIP(hipStreamSynchronize(stream));
+  tr.mark("table build");
   c->ms[2] = now_ms() - t0;
   *out     = j;
   return 0;
@@ -568,6 +654,7 @@ int gxd_join_destroy(gxd_join* j)
   if (j->rows) (void)hipFree(j->rows);
   if (j->keys_keep) (void)hipFree(j->keys_keep);
   if (j->segtab) (void)hipFree(j->segtab);
+  if (j->bases_dev) (void)hipFree(j->bases_dev);
   delete j;
   return 0;
 }
@@ -633,15 +720,26 @@ int gxd_join_probe(gxd_join* j, const void* probe_keys, int64_t n, int chunks, g
   }
 
   std::vector<long long> bases;
+  int64_t nmax = n;
   GXD_HIP(hipStreamSynchronize(stream));
-  GXD_GX(shard_bases(c, n, bases));
+  GXD_GX(shard_sizes(c, n, bases, &nmax));
+  // Probe rows travel as (source rank << shift) | row inside the sender's CHUNK; chunks are cut so that a chunk fits the row
+  // field.  The local partition pass carries that int32 along (payload form), the probe writes it into the pair array, and one
+  // streaming pass decodes it with the pair positions at which each received chunk's probe started -- no gather.  Tables too
+  // small for the partitioned probe take the plain probe + gather path (small inputs).
+  const int sh = code_shift(W);
+  RowCode code;
+  if (partitioned) {
+    code.shift    = sh;
+    code.in_chunk = true;
+  }
   Exchange ex;
   int64_t pair_cap = 0;
-  void *pl = nullptr, *pr = nullptr;
+  void *pl = nullptr, *pr = nullptr, *snap = nullptr;
+  GXD_GX(c->arena.get(Arena::MISC_C, sizeof(long long) * 1024, &snap));
   GXD_HIP(hipMemsetAsync(cur, 0, 8, stream));
   // a chunk is probed as soon as it has been posted: its probe overlaps the exchange of the later chunks
   auto on_chunk = [&](int k, int64_t first, int64_t rows) -> int {
-    (void)k;
     if (!partitioned) return 0;  // small tables: one direct probe of everything at the end
     const int64_t need = first + rows;
     if (need > pair_cap) {  // pairs <= probe rows unless build keys repeat (checked at the end)
@@ -651,10 +749,17 @@ int gxd_join_probe(gxd_join* j, const void* probe_keys, int64_t n, int chunks, g
       pair_cap = want;
     }
     GXD_HIP(hipStreamWaitEvent(stream, c->evX, 0));
-    const char* rk = static_cast<const char*>(c->arena.p[Arena::RECV_KEYS]);
-    return probe_into(rk + first * ks, rows, (int32_t)first, pl, pr, pair_cap);
+    GXD_HIP(hipMemcpyAsync(static_cast<long long*>(snap) + k, cur, 8, hipMemcpyDeviceToDevice, stream));  // pairs before this chunk
+    if (rows == 0) return 0;
+    const char* rk    = static_cast<const char*>(c->arena.p[Arena::RECV_KEYS]);
+    const int32_t* rr = static_cast<const int32_t*>(c->arena.p[Arena::RECV_ROWS]);
+    return with_tmp(c, Arena::TMP2, [&](void* t, size_t* b) {
+      return gx_join_probe_partitioned_pl(ks, rk + first * ks, rr + first, rows, 0, j->table, j->table_bytes, 0, static_cast<int32_t*>(pl),
+                                          static_cast<int32_t*>(pr), pair_cap, static_cast<int64_t*>(cur), t, b, gstream);
+    });
   };
-  GXD_GX(partition_exchange(c, key_dtype, probe_keys, n, 0, nullptr, true, chunks, stream, &ex, on_chunk));
+  GXD_GX(partition_exchange(c, key_dtype, probe_keys, n, nmax, 0, nullptr, true, chunks, partitioned ? (1ll << sh) : 0, code, stream, &ex, on_chunk));
+  if (ex.chunks + 1 > 1024) return fail(GX_EINVAL, "gxd_join_probe: more than 1023 chunks");
   GXD_HIP(hipStreamWaitEvent(stream, c->evX, 0));
   long long pairs = 0;
   if (!partitioned) {
@@ -669,10 +774,18 @@ int gxd_join_probe(gxd_join* j, const void* probe_keys, int64_t n, int chunks, g
     GXD_GX(c->arena.get(Arena::PAIR_L, (size_t)pair_cap * 4, &pl));
     GXD_GX(c->arena.get(Arena::PAIR_R, (size_t)pair_cap * 4, &pr));
     GXD_HIP(hipMemsetAsync(cur, 0, 8, stream));
-    const char* rk = static_cast<const char*>(c->arena.p[Arena::RECV_KEYS]);
+    const char* rk    = static_cast<const char*>(c->arena.p[Arena::RECV_KEYS]);
+    const int32_t* rr = static_cast<const int32_t*>(c->arena.p[Arena::RECV_ROWS]);
     if (partitioned) {
-      for (int k = 0; k < ex.chunks; ++k)
-        GXD_GX(probe_into(rk + ex.chunk_start[k] * ks, ex.chunk_start[k + 1] - ex.chunk_start[k], (int32_t)ex.chunk_start[k], pl, pr, pair_cap));
+      for (int k = 0; k < ex.chunks; ++k) {
+        const int64_t first = ex.chunk_start[k], rows = ex.chunk_start[k + 1] - ex.chunk_start[k];
+        GXD_HIP(hipMemcpyAsync(static_cast<long long*>(snap) + k, cur, 8, hipMemcpyDeviceToDevice, stream));
+        if (rows == 0) continue;
+        GXD_GX(with_tmp(c, Arena::TMP2, [&](void* t, size_t* b) {
+          return gx_join_probe_partitioned_pl(ks, rk + first * ks, rr + first, rows, 0, j->table, j->table_bytes, 0, static_cast<int32_t*>(pl),
+                                              static_cast<int32_t*>(pr), pair_cap, static_cast<int64_t*>(cur), t, b, gstream);
+        }));
+      }
     } else {
       GXD_GX(probe_into(rk, ex.total, 0, pl, pr, pair_cap));
     }
@@ -682,16 +795,34 @@ int gxd_join_probe(gxd_join* j, const void* probe_keys, int64_t n, int chunks, g
     auto* ol  = static_cast<int64_t*>(alloc((size_t)pairs * 8, actx));
     auto* orr = static_cast<int64_t*>(alloc((size_t)pairs * 8, actx));
     if (!ol || !orr) return fail(GX_EINVAL, "gxd_join_probe: allocator returned NULL");
-    // (position in the receive buffer) -> (int32 local row at its source) + (first global row of that source's shard)
-    std::vector<long long> segb(ex.seg_counts.size());
-    for (size_t i = 0; i < segb.size(); ++i) segb[i] = bases[i % W];
-    void* st;
-    GXD_GX(c->arena.get(Arena::SEGTAB, (2 * segb.size() + 1) * sizeof(long long), &st));
-    GXD_GX(upload_segtab(c, ex.seg_counts, segb, st, stream));
-    GXD_GX(gx_gather_global_rows_dev(static_cast<const int32_t*>(c->arena.p[Arena::RECV_ROWS]), ex.total, static_cast<const int32_t*>(pl), pairs,
-                                     (int)segb.size(), static_cast<const int64_t*>(st), ol, gstream));
-    GXD_GX(gx_gather_global_rows_dev(j->rows, j->nrows, static_cast<const int32_t*>(pr), pairs, (int)j->seg_counts.size(),
-                                     static_cast<const int64_t*>(j->segtab), orr, gstream));
+    if (partitioned) {
+      // probe side: (rank << sh | row in the sender's chunk) + chunk * crows + the sender's first global row
+      GXD_HIP(hipMemcpyAsync(static_cast<long long*>(snap) + ex.chunks, cur, 8, hipMemcpyDeviceToDevice, stream));
+      void *bd, *cr;
+      GXD_GX(c->arena.get(Arena::MISC_A, sizeof(long long) * W, &bd));
+      GXD_GX(c->arena.get(Arena::MISC_B, sizeof(long long) * W, &cr));
+      std::vector<long long> crv(W, ex.crows);
+      GXD_HIP(hipMemcpyAsync(bd, bases.data(), sizeof(long long) * W, hipMemcpyHostToDevice, stream));
+      GXD_HIP(hipMemcpyAsync(cr, crv.data(), sizeof(long long) * W, hipMemcpyHostToDevice, stream));
+      GXD_HIP(hipStreamSynchronize(stream));  // host vectors
+      GXD_GX(gx_decode_global_rows(static_cast<const int32_t*>(pl), pairs, sh, static_cast<const int64_t*>(bd), static_cast<const int64_t*>(cr),
+                                   static_cast<const int64_t*>(snap), ex.chunks, ol, gstream));
+    } else {
+      // (position in the receive buffer) -> (int32 local row at its source) + (first global row of that source's shard)
+      std::vector<long long> segb(ex.seg_counts.size());
+      for (size_t i = 0; i < segb.size(); ++i) segb[i] = bases[i % W];
+      void* st;
+      GXD_GX(c->arena.get(Arena::SEGTAB, (2 * segb.size() + 1) * sizeof(long long), &st));
+      GXD_GX(upload_segtab(c, ex.seg_counts, segb, st, stream));
+      GXD_GX(gx_gather_global_rows_dev(static_cast<const int32_t*>(c->arena.p[Arena::RECV_ROWS]), ex.total, static_cast<const int32_t*>(pl), pairs,
+                                       (int)segb.size(), static_cast<const int64_t*>(st), ol, gstream));
+    }
+    if (j->enc_shift)  // build side: the slots hold (rank << shift) | row at the source
+      GXD_GX(gx_decode_global_rows(static_cast<const int32_t*>(pr), pairs, j->enc_shift, static_cast<const int64_t*>(j->bases_dev), nullptr, nullptr, 0,
+                                   orr, gstream));
+    else
+      GXD_GX(gx_gather_global_rows_dev(j->rows, j->nrows, static_cast<const int32_t*>(pr), pairs, (int)j->seg_counts.size(),
+                                       static_cast<const int64_t*>(j->segtab), orr, gstream));
     *out_probe_rows = ol;
     *out_build_rows = orr;
   }
@@ -753,7 +884,11 @@ int gxd_groupby_sum_count(gxd_comm* c, int key_dtype, const void* keys, int val_
     // ---- hash-partition the partial rows, exchange keys + (sum, count) gathered into the same order
     GXD_HIP(hipStreamSynchronize(stream));
     Exchange ex;
-    GXD_GX(partition_exchange(c, key_dtype, pk, g, 0, nullptr, true, 1, stream, &ex, nullptr));
+    std::vector<long long> gb;
+    int64_t gmax = g;
+    GXD_GX(shard_sizes(c, g, gb, &gmax));
+    GXD_GX(partition_exchange(c, key_dtype, pk, g, std::max<int64_t>(gmax, 1 << 20) /* one chunk */, 0, nullptr, true, 1, 0, RowCode{}, stream, &ex,
+                              nullptr));
     // the (sum, count) payload rides the SAME split: per destination, gather by the partition's row map into a contiguous
     // staging area, then one more grouped exchange with the counts of the key exchange
     void *gs, *gc;

@@ -206,6 +206,30 @@ __global__ void __launch_bounds__(256) k_gather_global_rows_dev(const int32_t* _
     out[j] = (long long)rows[i] + base[lo];
   }
 }
+// Encoded global rows of the sharded join -> int64: enc = (source rank << shift) | row.  With `snap` (pair positions at which
+// the probe of each chunk started, nchunks + 1 entries) the row counts inside the SENDER's chunk: global = base[src] +
+// chunk * chunk_rows[src] + row; without it, global = base[src] + row.  Streaming: no gather, no random access.
+__global__ void __launch_bounds__(256) k_decode_global_rows(const int32_t* __restrict__ enc, int64_t n, int shift,
+                                                            const long long* __restrict__ bases, const long long* __restrict__ chunk_rows,
+                                                            const long long* __restrict__ snap, int nchunks, long long* __restrict__ out)
+{
+  const int64_t stride = (int64_t)gridDim.x * 256;
+  const uint32_t mask  = (1u << shift) - 1u;
+  for (int64_t j = (int64_t)blockIdx.x * 256 + threadIdx.x; j < n; j += stride) {
+    const uint32_t e = (uint32_t)enc[j];
+    const uint32_t s = e >> shift;
+    long long g      = bases[s] + (long long)(e & mask);
+    if (snap) {
+      int lo = 0, hi = nchunks;  // the chunk c with snap[c] <= j < snap[c + 1]
+      while (hi - lo > 1) {
+        const int mid = (lo + hi) >> 1;
+        if (snap[mid] <= j) lo = mid; else hi = mid;
+      }
+      g += (long long)lo * chunk_rows[s];
+    }
+    out[j] = g;
+  }
+}
 __global__ void __launch_bounds__(256) k_widen_i32_i64(const int32_t* __restrict__ in, int64_t n, long long* __restrict__ out)
 {
   const int64_t stride = (int64_t)gridDim.x * 256;
@@ -225,6 +249,21 @@ int gx_gather_global_rows_dev(const int32_t* rows, int64_t nrows, const int32_t*
   if (blocks > 16384) blocks = 16384;
   hipLaunchKernelGGL(gx::k_gather_global_rows_dev, dim3((unsigned)blocks), dim3(256), 0, s, rows, idx, n, nseg,
                      reinterpret_cast<const long long*>(segtab_dev), reinterpret_cast<long long*>(out));
+  GX_LAUNCH_CHECK();
+  return 0;
+}
+
+int gx_decode_global_rows(const int32_t* enc, int64_t n, int shift, const int64_t* bases_dev, const int64_t* chunk_rows_dev,
+                          const int64_t* snap_dev, int nchunks, int64_t* out, gx_stream_t s)
+{
+  if (n < 0 || shift < 1 || shift > 31 || !bases_dev || (snap_dev && (!chunk_rows_dev || nchunks < 1))) return GX_EINVAL;
+  if (n == 0) return 0;
+  if (!enc || !out) return GX_EINVAL;
+  int64_t blocks = gx::div_up(n, (int64_t)256 * 8);
+  if (blocks > 8192) blocks = 8192;
+  hipLaunchKernelGGL(gx::k_decode_global_rows, dim3((unsigned)blocks), dim3(256), 0, s, enc, n, shift, reinterpret_cast<const long long*>(bases_dev),
+                     reinterpret_cast<const long long*>(chunk_rows_dev), reinterpret_cast<const long long*>(snap_dev), nchunks,
+                     reinterpret_cast<long long*>(out));
   GX_LAUNCH_CHECK();
   return 0;
 }

@@ -120,8 +120,10 @@ static int launch_tags(void* table, uint32_t lg, hipStream_t s)
 
 template <typename K>
 __global__ void __launch_bounds__(JBT) k_build(const K* __restrict__ keys, const uint32_t* __restrict__ valid,
-                                               int64_t n, Slot<K>* slots, uint32_t log2cap)
+                                               int64_t n, Slot<K>* slots, uint32_t log2cap, const int32_t* __restrict__ payload = nullptr)
 {
+  // payload != NULL: the slot carries payload[i] (>= 0) instead of the row number i -- the sharded join stores an encoded
+  // global row there, so that its pairs need no gather afterwards
   const uint64_t mask  = (1ull << log2cap) - 1;
   const int64_t stride = (int64_t)gridDim.x * JBT;
   for (int64_t i = (int64_t)blockIdx.x * JBT + threadIdx.x; i < n; i += stride) {
@@ -129,7 +131,7 @@ __global__ void __launch_bounds__(JBT) k_build(const K* __restrict__ keys, const
     const K key = keys[i];
     uint64_t h  = slot_of<K>(key, log2cap);
     for (;;) {
-      const int32_t old = atomicCAS(&slots[h].row, EMPTY_ROW, (int32_t)i);
+      const int32_t old = atomicCAS(&slots[h].row, EMPTY_ROW, payload ? payload[i] : (int32_t)i);
       if (old == EMPTY_ROW) {
         slots[h].key = key;  // nobody reads keys before the build kernel has finished
         break;
@@ -574,8 +576,9 @@ __global__ void __launch_bounds__(1024) k_pj_offsets(PjPlan* plan, int pbits, un
 template <typename K, int RPT, int BTt, typename F>
 __global__ void __launch_bounds__(BTt) k_pj_scatter(const K* __restrict__ keys, int64_t n, PjPlan* plan, int pbits,
                                                     int64_t rrows, K* __restrict__ pkeys, int32_t* __restrict__ pidx, F part_of,
-                                                    int32_t row0 = 0, uint32_t spec_cap = 0)
+                                                    int32_t row0 = 0, uint32_t spec_cap = 0, const int32_t* __restrict__ payload = nullptr)
 {
+  // payload != NULL: a row travels with payload[row] instead of its row number
   // spec_cap > 0 (gx_partition_rows_spec_at): no histogram ran -- group b owns the slot [b, b + 1) * spec_cap of the output, ONE
   // fill counter per group (cursor[0][b], from zero); rows beyond a slot are dropped and flagged (the caller re-partitions)
   constexpr int TILE = BTt * RPT;
@@ -658,7 +661,7 @@ __global__ void __launch_bounds__(BTt) k_pj_scatter(const K* __restrict__ keys, 
 #pragma unroll
   for (int j = 0; j < RPT; ++j) {
     const int idx = j * BTt + (int)tid;
-    if (idx < nvalid) s_i[s_start[packed[j] >> 16] + (packed[j] & 0xFFFFu)] = (int32_t)(base + idx) + row0;
+    if (idx < nvalid) s_i[s_start[packed[j] >> 16] + (packed[j] & 0xFFFFu)] = payload ? payload[base + idx] : (int32_t)(base + idx) + row0;
   }
   __syncthreads();
 #pragma unroll
@@ -1581,7 +1584,8 @@ static inline uint32_t pj2_cap(int64_t n, int pbits)
 template <typename K, int RPT, int BTt, bool EXACT, typename F>
 __global__ void __launch_bounds__(BTt) k_pj2_scatter(const K* __restrict__ keys, int64_t n, Pj2Plan* plan2, PjPlan* plan, int pbits,
                                                      int64_t rrows, uint32_t cap, int64_t ntiles, K* __restrict__ pkeys,
-                                                     int32_t* __restrict__ pidx, F part_of, int32_t row0)
+                                                     int32_t* __restrict__ pidx, F part_of, int32_t row0,
+                                                     const int32_t* __restrict__ payload)
 {
   constexpr int TILE = BTt * RPT;
   extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -1708,7 +1712,7 @@ __global__ void __launch_bounds__(BTt) k_pj2_scatter(const K* __restrict__ keys,
     for (int j = 0; j < RPT; ++j) {
       const int idx        = j * BTt + (int)tid;
       const unsigned int l = (j & 1) ? lpos2[j / 2] >> 16 : lpos2[j / 2] & 0xFFFFu;
-      if (idx < nvalid) s_i[l] = (int32_t)(base + idx) + row0;
+      if (idx < nvalid) s_i[l] = payload ? payload[base + idx] : (int32_t)(base + idx) + row0;
     }
     __syncthreads();
 #pragma unroll
@@ -2301,7 +2305,7 @@ static int g_pj_defer = 0;        // round-3 probe: 1 = unsettled rows are parke
 // the partition pass shared by the partitioned probe and build (F = TableTop) and by gx_partition_rows
 template <typename K, typename F>
 int pj_partition_fn(const K* keys, int64_t n, int pbits, PjPlan* plan, K* pkeys, int32_t* pidx, unsigned int chunk_rows, hipStream_t s,
-                    F part_of, bool profile = false, int32_t row0 = 0, uint32_t spec_cap = 0)
+                    F part_of, bool profile = false, int32_t row0 = 0, uint32_t spec_cap = 0, const int32_t* payload = nullptr)
 {
   GX_HIP_TRY(hipMemsetAsync(plan, 0, sizeof(PjPlan), s));
   // tile: as many rows as the LDS holds next to the three P-entry arrays (160 KiB per CU)
@@ -2334,18 +2338,18 @@ int pj_partition_fn(const K* keys, int64_t n, int pbits, PjPlan* plan, K* pkeys,
     attr_set = true;
   }
   const unsigned grid = (unsigned)div_up(n, (int64_t)tile_rows);
-  if (tile_rows == 16384) hipLaunchKernelGGL(k16, dim3(grid), dim3(1024), lds, s, keys, n, plan, pbits, rrows, pkeys, pidx, part_of, row0, spec_cap);
-  else if (tile_rows == 8192) hipLaunchKernelGGL(k8, dim3(grid), dim3(512), lds, s, keys, n, plan, pbits, rrows, pkeys, pidx, part_of, row0, spec_cap);
-  else hipLaunchKernelGGL(k4, dim3(grid), dim3(512), lds, s, keys, n, plan, pbits, rrows, pkeys, pidx, part_of, row0, spec_cap);
+  if (tile_rows == 16384) hipLaunchKernelGGL(k16, dim3(grid), dim3(1024), lds, s, keys, n, plan, pbits, rrows, pkeys, pidx, part_of, row0, spec_cap, payload);
+  else if (tile_rows == 8192) hipLaunchKernelGGL(k8, dim3(grid), dim3(512), lds, s, keys, n, plan, pbits, rrows, pkeys, pidx, part_of, row0, spec_cap, payload);
+  else hipLaunchKernelGGL(k4, dim3(grid), dim3(512), lds, s, keys, n, plan, pbits, rrows, pkeys, pidx, part_of, row0, spec_cap, payload);
   if (profile) jprof_mark(2, s);
   GX_LAUNCH_CHECK();
   return 0;
 }
 template <typename K>
 int pj_partition(const K* keys, int64_t n, int pbits, PjPlan* plan, K* pkeys, int32_t* pidx, unsigned int chunk_rows, hipStream_t s,
-                 bool profile = false, int32_t row0 = 0)
+                 bool profile = false, int32_t row0 = 0, const int32_t* payload = nullptr)
 {
-  return pj_partition_fn<K, TableTop<K>>(keys, n, pbits, plan, pkeys, pidx, chunk_rows, s, TableTop<K>{pbits}, profile, row0);
+  return pj_partition_fn<K, TableTop<K>>(keys, n, pbits, plan, pkeys, pidx, chunk_rows, s, TableTop<K>{pbits}, profile, row0, 0u, payload);
 }
 
 // partition starts as int64, for the caller of gx_partition_rows
@@ -2430,7 +2434,8 @@ static bool pj2_applies(int64_t n, int pbits)
 }
 template <typename K>
 int probe_partitioned_impl2(const K* keys, int64_t n, const Slot<K>* slots, uint32_t lg, int pbits, int left_outer, int32_t* out_probe,
-                            int32_t* out_build, int64_t capacity, int64_t* cursor, void* tmp, size_t* tmp_bytes, hipStream_t s, int32_t row0)
+                            int32_t* out_build, int64_t capacity, int64_t* cursor, void* tmp, size_t* tmp_bytes, hipStream_t s, int32_t row0,
+                            const int32_t* payload)
 {
   constexpr int TILE   = 16384;
   const uint32_t cap   = pj2_cap(n, pbits);
@@ -2481,7 +2486,7 @@ int probe_partitioned_impl2(const K* keys, int64_t n, const Slot<K>* slots, uint
   GX_HIP_TRY(hipMemsetAsync(plan, 0, sizeof(PjPlan), s));
   jprof_mark(1, s);
   // ---- speculative pass
-  hipLaunchKernelGGL(kspec, dim3((unsigned)grid), dim3(1024), lds_s, s, keys, n, plan2, plan, pbits, rrows, cap, ntiles, pkeys, pidx, part_of, row0);
+  hipLaunchKernelGGL(kspec, dim3((unsigned)grid), dim3(1024), lds_s, s, keys, n, plan2, plan, pbits, rrows, cap, ntiles, pkeys, pidx, part_of, row0, payload);
   jprof_mark(2, s);
   hipLaunchKernelGGL(k_pj2_offsets, dim3(1), dim3(1024), 0, s, plan2, pbits, cap, (unsigned int)PP_ROWS);
   PieceTable pt{plan2->chunk0, plan2->list_chunk0, plan2->ticket, nullptr, plan2->fill, cap, PJ_NR};
@@ -2494,7 +2499,7 @@ int probe_partitioned_impl2(const K* keys, int64_t n, const Slot<K>* slots, uint
   if (hb < 1) hb = 1;
   hipLaunchKernelGGL((k_pj_hist<K, F>), dim3((unsigned)(hb * PJ_NR)), dim3(256), 0, s, keys, n, plan, pbits, rrows, part_of, &plan2->fallback);
   hipLaunchKernelGGL(k_pj_offsets, dim3(1), dim3(1024), 0, s, plan, pbits, (unsigned int)PP_ROWS, &plan2->fallback);
-  hipLaunchKernelGGL(kexact, dim3((unsigned)grid), dim3(1024), lds_s, s, keys, n, plan2, plan, pbits, rrows, cap, ntiles, pkeys, pidx, part_of, row0);
+  hipLaunchKernelGGL(kexact, dim3((unsigned)grid), dim3(1024), lds_s, s, keys, n, plan2, plan, pbits, rrows, cap, ntiles, pkeys, pidx, part_of, row0, payload);
   PieceTable pe{plan->chunk0, plan->list_chunk0, plan2->ticket_exact, plan->offset, nullptr, 0u, 1};
   hipLaunchKernelGGL(kprobe, dim3((unsigned)pgrid), dim3(PP_BT), lds_p, s, pkeys, pidx, pe, pbits, slots, lg, left_outer, out_probe, out_build,
                      capacity, cur);
@@ -2507,7 +2512,7 @@ int probe_partitioned_impl2(const K* keys, int64_t n, const Slot<K>* slots, uint
 template <typename K>
 int probe_partitioned_impl(const void* keys, int64_t n, const void* table, size_t table_bytes, uint32_t lg,
                            int left_outer, int32_t* out_probe, int32_t* out_build, int64_t capacity, int64_t* cursor,
-                           void* tmp, size_t* tmp_bytes, hipStream_t s, int32_t row0 = 0)
+                           void* tmp, size_t* tmp_bytes, hipStream_t s, int32_t row0 = 0, const int32_t* payload = nullptr)
 {
   const int pbits = pj_bits(lg, (int)sizeof(Slot<K>));
   if (pj2_applies<K>(n, pbits)) {
@@ -2517,7 +2522,7 @@ int probe_partitioned_impl(const void* keys, int64_t n, const void* table, size_
     }
     return probe_partitioned_impl2<K>(static_cast<const K*>(keys), n,
                                       reinterpret_cast<const Slot<K>*>(static_cast<const char*>(table) + sizeof(TableHeader)), lg, pbits,
-                                      left_outer, out_probe, out_build, capacity, cursor, tmp, tmp_bytes, s, row0);
+                                      left_outer, out_probe, out_build, capacity, cursor, tmp, tmp_bytes, s, row0, payload);
   }
   Carver c(tmp);
   PjPlan* plan   = c.take<PjPlan>(1);
@@ -2544,7 +2549,7 @@ int probe_partitioned_impl(const void* keys, int64_t n, const void* table, size_
     if (use_pipe) chunk_rows = PP_ROWS;  // the persistent probe takes tickets per 3840-row piece
   }
   {
-    int rc = pj_partition<K>(static_cast<const K*>(keys), n, pbits, plan, pkeys, pidx, chunk_rows, s, true, row0);
+    int rc = pj_partition<K>(static_cast<const K*>(keys), n, pbits, plan, pkeys, pidx, chunk_rows, s, true, row0, payload);
     if (rc) return rc;
   }
   const int64_t max_chunks = div_up(n, (int64_t)chunk_rows) + (1 << pbits);
@@ -2585,7 +2590,7 @@ int probe_partitioned_impl(const void* keys, int64_t n, const void* table, size_
 
 template <typename K>
 int build_partitioned_impl(const void* keys, int64_t n, void* table, size_t table_bytes, double load_factor, void* tmp,
-                           size_t* tmp_bytes, hipStream_t s)
+                           size_t* tmp_bytes, hipStream_t s, const int32_t* payload = nullptr)
 {
   const uint32_t lg = log2_capacity(n, load_factor);
   const int pbits   = pj_bits(lg, (int)sizeof(Slot<K>));
@@ -2604,7 +2609,7 @@ int build_partitioned_impl(const void* keys, int64_t n, void* table, size_t tabl
   char* base = static_cast<char*>(table);
   GX_HIP_TRY(hipMemsetAsync(base + sizeof(TableHeader), 0xFF, sizeof(Slot<K>) << lg, s));
   if (n == 0) return launch_tags<K>(table, lg, s);
-  int rc = pj_partition<K>(static_cast<const K*>(keys), n, pbits, plan, pkeys, pidx, PJ_CHUNK, s);
+  int rc = pj_partition<K>(static_cast<const K*>(keys), n, pbits, plan, pkeys, pidx, PJ_CHUNK, s, false, 0, payload);
   if (rc) return rc;
   const int64_t max_chunks = div_up(n, PJ_CHUNK) + (1 << pbits);
   hipLaunchKernelGGL((k_pj_build<K>), dim3((unsigned)max_chunks), dim3(PJ_BT), 0, s, pkeys, pidx, plan, pbits,
@@ -2615,7 +2620,7 @@ int build_partitioned_impl(const void* keys, int64_t n, void* table, size_t tabl
 
 template <typename K>
 int build_impl(const void* keys, const uint32_t* valid, int64_t n, void* table, size_t table_bytes,
-               double load_factor, hipStream_t s)
+               double load_factor, hipStream_t s, const int32_t* payload = nullptr)
 {
   const uint32_t lg = log2_capacity(n, load_factor);
   const size_t need = sizeof(TableHeader) + (sizeof(Slot<K>) << lg) + ((size_t)1 << lg) / 2;
@@ -2626,7 +2631,7 @@ int build_impl(const void* keys, const uint32_t* valid, int64_t n, void* table, 
     int64_t blocks = div_up(n, JBT * 4);
     if (blocks > 8192) blocks = 8192;
     hipLaunchKernelGGL((k_build<K>), dim3((unsigned)blocks), dim3(JBT), 0, s, static_cast<const K*>(keys), valid, n,
-                       reinterpret_cast<Slot<K>*>(base + sizeof(TableHeader)), lg);
+                       reinterpret_cast<Slot<K>*>(base + sizeof(TableHeader)), lg, payload);
     GX_LAUNCH_CHECK();
   }
   return launch_tags<K>(table, lg, s);
@@ -2665,9 +2670,14 @@ size_t gx_join_table_bytes(int key_size, int64_t build_rows, double load_factor)
 int gx_join_build(int key_size, const void* build_keys, const uint32_t* build_valid, int64_t build_rows,
                   void* table, size_t table_bytes, double load_factor, gx_stream_t s)
 {
+  return gx_join_build_pl(key_size, build_keys, nullptr, build_valid, build_rows, table, table_bytes, load_factor, s);
+}
+int gx_join_build_pl(int key_size, const void* build_keys, const int32_t* payload, const uint32_t* build_valid, int64_t build_rows,
+                     void* table, size_t table_bytes, double load_factor, gx_stream_t s)
+{
   if (build_rows < 0 || !table || (build_rows > 0 && !build_keys)) return GX_EINVAL;
-  if (key_size == 8) return gx::join::build_impl<uint64_t>(build_keys, build_valid, build_rows, table, table_bytes, load_factor, s);
-  if (key_size == 4) return gx::join::build_impl<uint32_t>(build_keys, build_valid, build_rows, table, table_bytes, load_factor, s);
+  if (key_size == 8) return gx::join::build_impl<uint64_t>(build_keys, build_valid, build_rows, table, table_bytes, load_factor, s, payload);
+  if (key_size == 4) return gx::join::build_impl<uint32_t>(build_keys, build_valid, build_rows, table, table_bytes, load_factor, s, payload);
   return GX_EDTYPE;
 }
 
@@ -2712,16 +2722,23 @@ int gx_join_probe_partitioned_at(int key_size, const void* probe_keys, int64_t p
                                  size_t table_bytes, int left_outer, int32_t* out_probe_idx, int32_t* out_build_idx,
                                  int64_t capacity, int64_t* cursor_dev, void* tmp, size_t* tmp_bytes, gx_stream_t s)
 {
+  return gx_join_probe_partitioned_pl(key_size, probe_keys, nullptr, probe_rows, row_base, table, table_bytes, left_outer, out_probe_idx,
+                                      out_build_idx, capacity, cursor_dev, tmp, tmp_bytes, s);
+}
+int gx_join_probe_partitioned_pl(int key_size, const void* probe_keys, const int32_t* payload, int64_t probe_rows, int32_t row_base,
+                                 const void* table, size_t table_bytes, int left_outer, int32_t* out_probe_idx, int32_t* out_build_idx,
+                                 int64_t capacity, int64_t* cursor_dev, void* tmp, size_t* tmp_bytes, gx_stream_t s)
+{
   if (probe_rows < 0 || capacity < 0 || !table || !tmp_bytes || (probe_rows > 0 && !probe_keys)) return GX_EINVAL;
   if (tmp && (!cursor_dev || (capacity > 0 && (!out_probe_idx || !out_build_idx)))) return GX_EINVAL;
   if (table_bytes <= sizeof(gx::join::TableHeader)) return GX_ETMP;
   const uint32_t lg = gx_join_log2_from_bytes(key_size, table_bytes);
   if (key_size == 8)
     return gx::join::probe_partitioned_impl<uint64_t>(probe_keys, probe_rows, table, table_bytes, lg, left_outer, out_probe_idx,
-                                                      out_build_idx, capacity, cursor_dev, tmp, tmp_bytes, s, row_base);
+                                                      out_build_idx, capacity, cursor_dev, tmp, tmp_bytes, s, row_base, payload);
   if (key_size == 4)
     return gx::join::probe_partitioned_impl<uint32_t>(probe_keys, probe_rows, table, table_bytes, lg, left_outer, out_probe_idx,
-                                                      out_build_idx, capacity, cursor_dev, tmp, tmp_bytes, s, row_base);
+                                                      out_build_idx, capacity, cursor_dev, tmp, tmp_bytes, s, row_base, payload);
   return GX_EDTYPE;
 }
 int gx_join_probe_partitioned(int key_size, const void* probe_keys, int64_t probe_rows, const void* table,
@@ -2900,9 +2917,14 @@ int gx_join_partition_bits(int key_size, size_t table_bytes)
 int gx_join_build_partitioned(int key_size, const void* build_keys, int64_t build_rows, void* table, size_t table_bytes,
                               double load_factor, void* tmp, size_t* tmp_bytes, gx_stream_t s)
 {
+  return gx_join_build_partitioned_pl(key_size, build_keys, nullptr, build_rows, table, table_bytes, load_factor, tmp, tmp_bytes, s);
+}
+int gx_join_build_partitioned_pl(int key_size, const void* build_keys, const int32_t* payload, int64_t build_rows, void* table,
+                                 size_t table_bytes, double load_factor, void* tmp, size_t* tmp_bytes, gx_stream_t s)
+{
   if (build_rows < 0 || !table || !tmp_bytes || (build_rows > 0 && !build_keys)) return GX_EINVAL;
-  if (key_size == 8) return gx::join::build_partitioned_impl<uint64_t>(build_keys, build_rows, table, table_bytes, load_factor, tmp, tmp_bytes, s);
-  if (key_size == 4) return gx::join::build_partitioned_impl<uint32_t>(build_keys, build_rows, table, table_bytes, load_factor, tmp, tmp_bytes, s);
+  if (key_size == 8) return gx::join::build_partitioned_impl<uint64_t>(build_keys, build_rows, table, table_bytes, load_factor, tmp, tmp_bytes, s, payload);
+  if (key_size == 4) return gx::join::build_partitioned_impl<uint32_t>(build_keys, build_rows, table, table_bytes, load_factor, tmp, tmp_bytes, s, payload);
   return GX_EDTYPE;
 }
 

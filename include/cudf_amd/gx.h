@@ -139,6 +139,12 @@ int gx_gather_global_rows(const int32_t* rows, int64_t nrows, const int32_t* idx
  * chunks x ranks segments): segtab_dev = [nseg + 1] int64 segment starts followed by [nseg] int64 bases. */
 int gx_gather_global_rows_dev(const int32_t* rows, int64_t nrows, const int32_t* idx, int64_t n, int nseg, const int64_t* segtab_dev,
                               int64_t* out, gx_stream_t stream);
+/* The sharded join's pairs without a gather: a row travels as enc = (source rank << shift) | row (the payload of the *_pl entry
+ * points below) and is decoded in one streaming pass: out[j] = bases_dev[src] + row, plus chunk(j) * chunk_rows_dev[src] when
+ * the row was counted inside its sender's CHUNK -- chunk(j) = the c with snap_dev[c] <= j < snap_dev[c + 1], snap_dev = the
+ * pair positions at which the probe of each received chunk started (nchunks + 1 device int64). */
+int gx_decode_global_rows(const int32_t* enc, int64_t n, int shift, const int64_t* bases_dev, const int64_t* chunk_rows_dev,
+                          const int64_t* snap_dev, int nchunks, int64_t* out, gx_stream_t stream);
 /* out[i] = in[i] as int64 (row indices / counts leaving the int32 world of cudf::size_type) */
 int gx_widen_i32_i64(const int32_t* in, int64_t n, int64_t* out, gx_stream_t stream);
 
@@ -308,6 +314,15 @@ int gx_partition_rows_spec_at(int key_dtype, const void* keys, int64_t n, int32_
  * pairs are appended at *cursor_dev (which the caller zeroes once, before the first chunk). */
 int gx_join_probe_partitioned_at(int key_size, const void* probe_keys, int64_t probe_rows, int32_t row_base, const void* table,
                                  size_t table_bytes, int left_outer, int32_t* out_probe_idx, int32_t* out_build_idx,
+                                 int64_t capacity, int64_t* cursor_dev, void* tmp, size_t* tmp_bytes, gx_stream_t stream);
+/* PAYLOAD forms: a build / probe row is represented by payload[i] (int32 >= 0) instead of its row number i -- what the table
+ * slots store and what the pair arrays receive.  The sharded join puts encoded global rows there (gx_decode_global_rows). */
+int gx_join_build_pl(int key_size, const void* build_keys, const int32_t* payload, const uint32_t* build_valid, int64_t build_rows,
+                     void* table, size_t table_bytes, double load_factor, gx_stream_t stream);
+int gx_join_build_partitioned_pl(int key_size, const void* build_keys, const int32_t* payload, int64_t build_rows, void* table,
+                                 size_t table_bytes, double load_factor, void* tmp, size_t* tmp_bytes, gx_stream_t stream);
+int gx_join_probe_partitioned_pl(int key_size, const void* probe_keys, const int32_t* payload, int64_t probe_rows, int32_t row_base,
+                                 const void* table, size_t table_bytes, int left_outer, int32_t* out_probe_idx, int32_t* out_build_idx,
                                  int64_t capacity, int64_t* cursor_dev, void* tmp, size_t* tmp_bytes, gx_stream_t stream);
 /* log2 of the number of partitions the partitioned probe uses for this table; 0 = not partitionable */
 int gx_join_partition_bits(int key_size, size_t table_bytes);

@@ -57,10 +57,14 @@ int gxd_last_timing(const gxd_comm* comm, double* ms3_host);
 int gxd_sort(gxd_comm* comm, int dtype, const void* keys, int64_t n, int chunks, int force_exchange, gxd_alloc_fn alloc,
              void* alloc_ctx, void** out_keys, int64_t* out_n, gx_stream_t stream);
 
-/* cudf::hash_join over sharded tables.  build: hash-partition this rank's build keys (key + int32 local row = 12 B/row on
+/* cudf::hash_join over sharded tables.  build: hash-partition this rank's build keys (key + int32 row code = 12 B/row on
  * the wire), exchange once, build the local table over what arrived.  probe: per chunk partition -> exchange -> local
  * partitioned probe; every pair comes back as (global probe row, global build row), global row = (first row of the owning
- * rank's shard) + local row.  key_dtype: an 8- or 4-byte numeric type (bit patterns are compared).  No nulls. */
+ * rank's shard) + local row.  The int32 that travels with a key is (source rank << s) | row, s = 31 - ceil(log2(world)):
+ * it rides through the receiver's partition pass and hash table as the payload and is turned into the global row by one
+ * streaming pass over the pair arrays (gx_decode_global_rows) -- no gather through the received row maps.  Probe rows are
+ * counted inside the sender's chunk (chunks are cut to fit the row field); a build shard of more than 2^s rows falls back
+ * to positions + gx_gather_global_rows_dev.  key_dtype: an 8- or 4-byte numeric type (bit patterns are compared).  No nulls. */
 int gxd_join_build(gxd_comm* comm, int key_dtype, const void* build_keys, int64_t n, int force_exchange, gx_stream_t stream,
                    gxd_join** out);
 int gxd_join_probe(gxd_join* table, const void* probe_keys, int64_t n, int chunks, gxd_alloc_fn alloc, void* alloc_ctx,
