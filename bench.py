@@ -63,6 +63,7 @@ def parse():
                     help="join: random = SURVEY 8d (build = distinct random 64-bit keys, probe = 30%% drawn from them + 70%% from a "
                          "disjoint random set); dense = round 2's arithmetic progressions 3i+1 (kept for comparison)")
     ap.add_argument("--no-hybrid", action="store_true", help="sort: disable the hybrid MSD path (LSD passes only)")
+    ap.add_argument("--no-cursor", action="store_true", help="sort: disable the cursor path (sampled plan + atomic-cursor partition levels); the look-back path runs")
     ap.add_argument("--sort-cell", type=int, default=0, help="sort knob: local-sort cell capacity (0 auto, 8192, 16384)")
     ap.add_argument("--sort-lbw", type=int, default=16, help="sort knob: predecessors per look-back round of the partition passes (4, 8, 16)")
     ap.add_argument("--key-range", type=int, nargs=2, default=None, metavar=("LO", "HI"),
@@ -284,6 +285,7 @@ def bench_sort(c, pairs=False):
     lib.gx_sort_set_hybrid(0 if a.no_hybrid else 1)
     lib.gx_sort_set_cell(a.sort_cell)
     lib.gx_sort_set_lookback(a.sort_lbw)
+    lib.gx_sort_set_cursor_path(0 if a.no_cursor else 1, 0.0)
     if a.key_range:
         keys = ops.random_column(np.int64, n, seed=42 + c.rank, lo=a.key_range[0], hi=a.key_range[1])
     else:
@@ -353,6 +355,10 @@ def bench_sort(c, pairs=False):
     info = (ctypes.c_int32 * 8)()
     lib.gx_sort_info(c.ptr(tmp), info, c.stream)
     sort_info = dict(zip(["hybrid_attempted", "hybrid_used", "shift0", "shift2", "bits2", "lds_passes", "max_cell", "lsd_passes"], list(info)))
+    cst = ctypes.c_int32(0)
+    lib.gx_sort_cursor_state(c.ptr(tmp), ctypes.byref(cst), c.stream)
+    sort_info["cursor_path_state"] = cst.value  # 3: sample-planned, atomic-cursor partition levels; 0 / 2: look-back path
+    cursor = cst.value == 3
     hist_ms = prof["hist_ms"] / nsteps_prof
     local_sort_ms = ms_per_step if c.world == 1 else hist_ms + (sum(prof["hyb"]) if prof["hyb_n"] else prof["pass_ms"])
     roofline = None
@@ -363,6 +369,10 @@ def bench_sort(c, pairs=False):
         names = ["k_msd_pass level 0 (8-bit partition, 8 XCD chains)",
                  f"k_msd_pass level 1 ({sort_info['bits2']}-bit partition inside buckets, padded cell slots)",
                  "k_plan2 (cell starts, one block)", "k_local_sort (LDS sort of the cells)"]
+        if cursor:
+            names[0] = "k_hf_scatter level 0 (8-bit partition into sampled (range, bin) slots, cursor atomics) + verdict"
+            names[1] = f"k_hf_scatter level 1 ({sort_info['bits2']}-bit partition of the regions into padded cell slots, cursor atomics)"
+        up_front = 0 if cursor else 8  # B/row of the up-front pass: the cursor path reads a 1/32 sample instead of the column
         bpr = [20, 24, 0, 24] if pairs else [16, 16, 0, 16]  # pairs carry a 4-B index
         dom = max(range(4), key=lambda i: ms[i])
         achieved = bpr[dom] * n / (ms[dom] * 1e-3) / 1e9
@@ -371,8 +381,8 @@ def bench_sort(c, pairs=False):
                     "avg_launch_ms": ms[dom], "launches_per_step": 1.0,
                     "kernels_ms": dict(zip(names, ms)), "kernels_GBps": {k: b * n / (m * 1e-3) / 1e9 for k, b, m in zip(names, bpr, ms) if b},
                     "hist_kernel_ms": hist_ms,
-                    "path_bytes_per_row": 8 + sum(bpr), "path_GBps": (8 + sum(bpr)) * n / (local_sort_ms * 1e-3) / 1e9,
-                    "path_frac": (8 + sum(bpr)) * n / (local_sort_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                    "path_bytes_per_row": up_front + sum(bpr), "path_GBps": (up_front + sum(bpr)) * n / (local_sort_ms * 1e-3) / 1e9,
+                    "path_frac": (up_front + sum(bpr)) * n / (local_sort_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
                     "whole_sort_model_GBps": model_bytes_row * n / (local_sort_ms * 1e-3) / 1e9,
                     "whole_sort_model_frac": model_bytes_row * n / (local_sort_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
                     "sort_info": sort_info}

@@ -44,7 +44,8 @@ constexpr int NRANGE     = 8;    // input ranges == XCDs: each gets its own look
 // Whether every cell fits is decided ON THE DEVICE (level 1 raises hy.overflow when a cell outgrows its slot,
 // k_plan2 checks the cell counts); when one does not (skewed keys) the remaining hybrid kernels turn into
 // no-ops and the LSD passes below run instead.
-constexpr int NB2MAX     = 512;  // level-1 bins (<= 9 bits)
+constexpr int NB2MAX     = 1024; // level-1 bins: row stride of the cell tables (cursor path: <= 10 bits)
+constexpr int NB9        = 512;  // bins of the 9-bit look-back level-1 pass
 
 struct HybridPlan {
   int32_t attempt;  // k_hy_plan: the hybrid path is being tried
@@ -66,6 +67,20 @@ struct HybridPlan {
   uint32_t hist0[BINS], gbin0[BINS];   // level-0 digit histogram of the whole column and its exclusive scan
   uint32_t rh0[NRANGE][BINS];          // range-resolved level-0 histogram
   uint32_t rhist[NRANGE][MAX_PASSES][BINS];  // range-resolved byte histograms (k_hist_all, LSD path)
+};
+
+// Round 3, the CURSOR path (integer keys, keys only): plan of the speculative passes, see k_hf_scatter
+struct FastPlan {
+  int32_t state;   // 0 not tried / given up before level 0; 1 planned from the sample; 2 failed the check after level 0
+                   // (the look-back path then runs from scratch); 3 verified (the look-back path is skipped)
+  int32_t fail;    // level 0: a slot outgrew its capacity
+  int32_t stride;  // the sample takes every stride-th 64-key chunk
+  uint32_t samp[NRANGE][BINS];              // sample histogram of the level-0 digit, per input range
+  uint32_t slot0[NRANGE][BINS];             // level-0 output: first key of slot (range, bin) ...
+  uint32_t cap0[NRANGE][BINS];              // ... and its capacity
+  uint32_t reg_tile0[BINS * NRANGE + 1];    // level 1: first tile of region q = bucket * NRANGE + range
+  uint32_t reg_start[BINS * NRANGE], reg_count[BINS * NRANGE];
+  alignas(128) uint32_t cur0[NRANGE][BINS];  // level-0 cursors = keys in slot (range, bin); atomics: lines of their own
 };
 
 // Every word that workgroups update with atomics lives on its own 128-B line, away from the
@@ -92,6 +107,7 @@ struct SortPlan {
   int32_t status;  // 0 ok, 3 hybrid bookkeeping mismatch (the LSD passes then produced the output); a look-back spin that times out traps
   HybridPlan hy;
   SortCounters cnt;
+  FastPlan hf;
 };
 
 // ------------------------------------------------------------------------------------------
@@ -163,6 +179,7 @@ __global__ void __launch_bounds__(BT) k_hy_hist(const KeyT* __restrict__ in, int
                                                 int64_t range_rows)
 {
   HybridPlan& hy = plan->hy;
+  if (plan->hf.state == 3) return;  // the cursor path has done levels 0 and 1
   if (!SPEC && !(hy.attempt && hy.need_hist)) return;
   const int shift      = SPEC ? (int)(8 * sizeof(KeyT) - 8) : hy.shift0;
   const int range      = blockIdx.x % NRANGE;
@@ -228,6 +245,20 @@ __global__ void __launch_bounds__(BT) k_hy_hist(const KeyT* __restrict__ in, int
   }
 }
 
+// digits of the local sort's stable LDS passes: the bytes below shift2 that vary somewhere in the column
+__device__ __forceinline__ void plan_local_digits(HybridPlan& hy, unsigned long long V, int shift2)
+{
+  int nl = 0;
+  for (int sft = 0; sft < shift2; sft += 8) {
+    const int bits = shift2 - sft < 8 ? shift2 - sft : 8;
+    if (bits == 8 && ((V >> sft) & 0xFFull) == 0) continue;  // constant byte: nothing to sort on
+    hy.lshift[nl] = sft;
+    hy.lbits[nl]  = bits;
+    ++nl;
+  }
+  hy.nlocal = nl;
+}
+
 // One block of 256 threads.  STAGE 0 (after k_hy_hist<SPEC>): digits from the varying-bit mask.  STAGE 1 (after
 // k_hy_hist<!SPEC>): level-0 histogram totals, bin bases per input range, level-0 segment tables.
 __global__ void __launch_bounds__(BINS) k_hy_plan(SortPlan* plan, int stage, int key_bits, int64_t n, int bits2, int cell_max,
@@ -236,6 +267,7 @@ __global__ void __launch_bounds__(BINS) k_hy_plan(SortPlan* plan, int stage, int
   __shared__ uint32_t s_tmp[BINS / GX_WAVE + 1];
   HybridPlan& hy = plan->hy;
   const int t    = threadIdx.x;
+  if (plan->hf.state == 3) return;  // the cursor path owns the plan
   if (stage == 0) {
     const unsigned long long V = hy.or_mask & hy.nor_mask;  // bits that differ somewhere in the column
     if (V == 0) {
@@ -263,15 +295,7 @@ __global__ void __launch_bounds__(BINS) k_hy_plan(SortPlan* plan, int stage, int
       hy.shift2    = shift2;
       hy.cell_max  = cell_max;
       hy.need_hist = spec_ok ? 0 : 1;
-      int nl       = 0;
-      for (int sft = 0; sft < shift2; sft += 8) {
-        const int bits = shift2 - sft < 8 ? shift2 - sft : 8;
-        if (bits == 8 && ((V >> sft) & 0xFFull) == 0) continue;  // constant byte: nothing to sort on
-        hy.lshift[nl] = sft;
-        hy.lbits[nl]  = bits;
-        ++nl;
-      }
-      hy.nlocal = nl;
+      plan_local_digits(hy, V, shift2);
     }
     return;
   }
@@ -714,7 +738,7 @@ __global__ void __launch_bounds__(BT, (KPT <= 8 ? 8 : (KPT <= 12 ? 6 : 4))) k_ms
   SortPlan* plan = a.plan;
   HybridPlan& hy = plan->hy;
   const int lvl  = a.level;
-  if (!hy.attempt) return;
+  if (!hy.attempt || plan->hf.state == 3) return;
   const KeyT* kin      = static_cast<const KeyT*>(a.in);
   KeyT* kout           = static_cast<KeyT*>(a.out);
   const uint32_t* vin  = a.vin;
@@ -925,10 +949,10 @@ __global__ void __launch_bounds__(BT, (KPT <= 8 ? 8 : (KPT <= 12 ? 6 : 4))) k_ms
 // order: a bucket starts at its histogram offset), largest cell; the bucket that finishes last gives the verdict:
 // the local sort runs iff no cell outgrew its slot and the cell sizes add up.
 __global__ void __launch_bounds__(GX_WAVE) k_plan2(SortPlan* plan, const uint32_t* __restrict__ cellcount,
-                                                   uint32_t* __restrict__ cellstart, int npass)
+                                                   uint32_t* __restrict__ cellstart, int npass, int cursor_path)
 {
   HybridPlan& hy = plan->hy;
-  if (!hy.attempt) return;
+  if (!hy.attempt || (plan->hf.state == 3) != (cursor_path != 0)) return;
   constexpr int PER    = NB2MAX / GX_WAVE;  // 8 consecutive cells per lane
   const int b          = blockIdx.x;
   const unsigned lane  = lane_id();
@@ -1044,7 +1068,7 @@ __global__ void __launch_bounds__((1 << CL2) / 16, 4) k_local_sort(const KeyT* i
                                                       const uint32_t* vin, uint32_t* __restrict__ vout,
                                                       KeyT desc_mask_in, SortPlan* plan,
                                                       const uint32_t* __restrict__ hist2, const uint32_t* __restrict__ base2,
-                                                      int exp = 0)
+                                                      int exp = 0, int cursor_path = 0)
 {
   // PAIRS = the packed-word mode: pairs, and float keys (whose -0.0 == +0.0 ties must keep input order
   // and whose original bits cannot be rebuilt from the sortable form)
@@ -1054,7 +1078,7 @@ __global__ void __launch_bounds__((1 << CL2) / 16, 4) k_local_sort(const KeyT* i
   constexpr int SB = CL2 - 6, NSB = 1 << SB;  // LDS split into NSB sub-buckets of ~64 keys
   constexpr bool CAN_PACK = HAS_VAL || KIND == K_FLOAT;
   HybridPlan& hy = plan->hy;
-  if (!hy.attempt || !hy.ok) return;
+  if (!hy.attempt || !hy.ok || (plan->hf.state == 3) != (cursor_path != 0)) return;
   const bool PAIRS     = CAN_PACK && (hy.shift2 + LS_POS_BITS <= 64);  // k_hy_plan never attempts pairs otherwise
   const KeyT desc_mask = desc_mask_in;
   const int pos_shift  = PAIRS ? LS_POS_BITS : 0;
@@ -1282,6 +1306,370 @@ __global__ void __launch_bounds__((1 << CL2) / 16, 4) k_local_sort(const KeyT* i
   }
 }
 
+
+// ------------------------------------------------------------------------------------------------------------------
+// Round 3: the CURSOR path of the hybrid sort -- integer keys, keys only (cudf::sort of one int64 / uint64 column, the
+// BASELINE config-2 workload).  Equal integer keys are indistinguishable, so neither partition level has to be stable
+// or deterministic in its order: a tile reserves its run in a bin's slot with ONE returning atomic on the bin's cursor
+// instead of waiting for its predecessor's prefix (k_msd_pass's decoupled look-back), tiles come from blockIdx (no
+// ticket), and nothing upstream needs the exact histogram any more:
+//   k_hf_sample<false>  OR / OR-of-complements over a 1/stride SAMPLE (every stride-th 64-key chunk)  -> digit positions
+//   k_hf_sample<true>   per-range histogram of the level-0 digit over the same sample                 -> slot capacities
+//   k_hf_scatter<0>     level 0 into padded (range, bin) slots of estimate + 8 sigma + seam allowance; it reads every
+//                       key anyway, so it also reduces the EXACT varying-bit masks and counts every slot
+//   k_hf_plan2          the verdict: the sample's top varying bit is the column's, no slot overflowed, the counts add up
+//                       -> bucket sizes, the local sort's digits (from the exact masks), the region table of level 1;
+//                       otherwise the plan is reset and the look-back path (k_hy_hist ... k_local_sort, enqueued behind
+//                       and skipped on success) sorts the column from scratch: no host round trip on either branch
+//   k_hf_scatter<1>     level 1: the (bucket, range) regions -> padded cell slots, cursor = the cell's size
+//   k_plan2, k_local_sort as on the look-back path.
+// HBM traffic 16 + 16 + 16 = 48 B/row (+ 2 x 8/stride for the sample) against 56 with the histogram read.  A 10-bit
+// level 1 (two bins per thread) keeps 8192-key cells up to 2^31 rows: the slow window of round 2, n in (1.02e9, 2.1e9],
+// where the 9-bit pass forced 16384-key cells at half occupancy, is gone for these keys.
+// ------------------------------------------------------------------------------------------------------------------
+constexpr int HF_CHUNK = GX_WAVE;  // keys per sample chunk: one 512-byte wave load
+
+template <typename KeyT, int KIND, bool HIST>
+__global__ void __launch_bounds__(256) k_hf_sample(const KeyT* __restrict__ in, int64_t n, KeyT desc_mask, SortPlan* plan, int stride,
+                                                   int64_t range_rows)
+{
+  HybridPlan& hy = plan->hy;
+  FastPlan& hf   = plan->hf;
+  if (HIST && hf.state != 1) return;
+  __shared__ uint32_t s_hist[HIST ? NRANGE * BINS : 1];
+  __shared__ unsigned long long s_red[2 * 4];
+  const unsigned tid = threadIdx.x, lane = lane_id();
+  if (HIST) {
+    for (int i = tid; i < NRANGE * BINS; i += 256) s_hist[i] = 0;
+    __syncthreads();
+  }
+  const int shift       = HIST ? hy.shift0 : 0;
+  const int64_t step    = (int64_t)stride * HF_CHUNK;
+  const int64_t nchunks = div_up(n, step);
+  const int64_t nw      = (int64_t)gridDim.x * 4;
+  constexpr int U       = 4;  // chunks in flight per wave
+  KeyT vor = 0, vnor = 0;
+  for (int64_t c0 = (int64_t)blockIdx.x * 4 + tid / GX_WAVE; c0 < nchunks; c0 += nw * U) {
+    KeyT raw[U];
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const int64_t row = (c0 + u * nw) * step + lane;
+      raw[u]            = (c0 + u * nw < nchunks && row < n) ? in[row] : KeyT(0);
+    }
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const int64_t row = (c0 + u * nw) * step + lane;
+      const bool live   = c0 + u * nw < nchunks && row < n;
+      const KeyT k      = to_sortable<KeyT, KIND>(raw[u], desc_mask);
+      if (!HIST) {
+        if (live) {
+          vor |= k;
+          vnor |= (KeyT)~k;
+        }
+      } else {
+        // a chunk never straddles two ranges (ranges are whole tiles, chunks start at multiples of 64)
+        const int64_t r64 = range_rows > 0 ? row / range_rows : (int64_t)(NRANGE - 1);
+        const int r       = r64 < NRANGE - 1 ? (int)r64 : NRANGE - 1;
+        (void)lds_rank(s_hist + r * BINS, (uint32_t)(k >> shift) & 0xFFu, live);
+      }
+    }
+  }
+  if (!HIST) {
+    const unsigned long long wo = wave_reduce((unsigned long long)vor, [](unsigned long long x, unsigned long long y) { return x | y; });
+    const unsigned long long wn = wave_reduce((unsigned long long)vnor, [](unsigned long long x, unsigned long long y) { return x | y; });
+    if (lane == 0) {
+      s_red[tid / GX_WAVE]     = wo;
+      s_red[4 + tid / GX_WAVE] = wn;
+    }
+    __syncthreads();
+    if (tid == 0) {
+      atomicOr(&hy.or_mask, s_red[0] | s_red[1] | s_red[2] | s_red[3]);
+      atomicOr(&hy.nor_mask, s_red[4] | s_red[5] | s_red[6] | s_red[7]);
+    }
+  } else {
+    __syncthreads();
+    for (int i = tid; i < NRANGE * BINS; i += 256) {
+      const uint32_t c = s_hist[i];
+      if (c) atomicAdd(&hf.samp[i / BINS][i % BINS], c);
+    }
+  }
+}
+
+// rows of input range r: ranges are whole tiles, the last one takes the remainder
+__device__ __forceinline__ int64_t hf_range_rows(int r, int64_t n, int64_t range_rows)
+{
+  const int64_t b = (int64_t)r * range_rows < n ? (int64_t)r * range_rows : n;
+  const int64_t e = (r == NRANGE - 1) ? n : (b + range_rows < n ? b + range_rows : n);
+  return e - b;
+}
+
+__device__ __forceinline__ void hf_give_up(SortPlan* plan, int state)
+{
+  // the look-back path starts from a clean plan
+  plan->hy.attempt  = 0;
+  plan->hy.or_mask  = 0;
+  plan->hy.nor_mask = 0;
+  plan->hy.overflow = 0;
+  plan->hf.state    = state;
+}
+
+// One block of 256 threads, three stages:
+//   0 (after the mask sample)  digit positions, as k_hy_plan's stage 0
+//   1 (after the histogram sample)  slot capacities and positions of level 0
+//   2 (after level 0)  the verdict + everything level 1, k_plan2 and the local sort need
+__global__ void __launch_bounds__(BINS) k_hf_plan(SortPlan* plan, int stage, int key_bits, int64_t n, int bits2, int cell_max, int stride,
+                                                  int64_t range_rows, int tile_rows, unsigned long long slot_rows, float margin)
+{
+  __shared__ uint32_t s_tmp[BINS / GX_WAVE + 1];
+  HybridPlan& hy = plan->hy;
+  FastPlan& hf   = plan->hf;
+  const int t    = threadIdx.x;
+  if (stage == 0) {
+    const unsigned long long V = hy.or_mask & hy.nor_mask;
+    const int top              = V ? 63 - __builtin_clzll(V) : 0;
+    const int shift0           = top - 7;
+    const int shift2           = shift0 - bits2;
+    if (V == 0 || shift2 < 8) {  // (all sampled keys equal) / too few bits below level 1: not this path
+      if (t == 0) hf_give_up(plan, 0);
+      return;
+    }
+    if (t == 0) {
+      hy.attempt   = 1;
+      hy.shift0    = shift0;
+      hy.bits2     = bits2;
+      hy.shift2    = shift2;
+      hy.cell_max  = cell_max;
+      hy.need_hist = 0;
+      hf.stride    = stride;
+      hf.state     = 1;
+    }
+    (void)key_bits;
+    return;
+  }
+  if (hf.state != 1) return;
+  if (stage == 1) {
+    // estimate of slot (range r, bin t) = sample count x (rows of the range / sampled rows of the range); capacity =
+    // estimate + `margin` standard deviations of that estimate + two sample steps (a bin that is one contiguous run of the
+    // input -- sorted or clustered keys -- is seen to within one step at either end) + a constant
+    uint32_t cap[NRANGE];
+    uint32_t sum = 0;
+    for (int r = 0; r < NRANGE; ++r) {
+      const uint32_t c = hf.samp[r][t];
+      uint32_t total;
+      (void)block_exclusive_scan<BINS>(c, 0u, SumOp(), s_tmp, &total);
+      const int64_t rows = hf_range_rows(r, n, range_rows);
+      const double scale = total ? (double)rows / (double)total : 0.0;
+      double cp          = (double)c * scale + (double)margin * scale * __builtin_sqrt((double)c + 1.0) + 2.0 * stride * HF_CHUNK + 64.0;
+      if (cp > (double)rows) cp = (double)rows;
+      if (cp < 0.0) cp = 0.0;
+      cap[r] = ((uint32_t)cp + 15u) & ~15u;  // slots start on 128-byte lines
+      sum += cap[r];
+    }
+    uint32_t total;
+    uint32_t run = block_exclusive_scan<BINS>(sum, 0u, SumOp(), s_tmp, &total);
+    if ((unsigned long long)total > slot_rows) {  // (cannot happen with the host's bound; checked all the same)
+      if (t == 0) hf_give_up(plan, 0);
+      return;
+    }
+    for (int r = 0; r < NRANGE; ++r) {  // the NRANGE slots of a bin are neighbours
+      hf.slot0[r][t] = run;
+      hf.cap0[r][t]  = cap[r];
+      run += cap[r];
+    }
+    if (t == 0) {  // level 0 reduces the EXACT masks into these
+      hy.or_mask  = 0;
+      hy.nor_mask = 0;
+    }
+    return;
+  }
+  // ---- stage 2
+  const unsigned long long V = hy.or_mask & hy.nor_mask;
+  uint32_t cnt[NRANGE];
+  uint32_t c   = 0;
+  int bad      = hf.fail != 0 || V == 0 || (63 - __builtin_clzll(V | 1ull)) != hy.shift0 + 7;
+  for (int r = 0; r < NRANGE; ++r) {
+    cnt[r] = hf.cur0[r][t];
+    if (cnt[r] > hf.cap0[r][t]) bad = 1;
+    c += cnt[r];
+  }
+  uint32_t total;
+  const uint32_t exc = block_exclusive_scan<BINS>(c, 0u, SumOp(), s_tmp, &total);
+  if ((int64_t)total != n) bad = 1;
+  if (__syncthreads_or(bad)) {
+    if (t == 0) hf_give_up(plan, 2);
+    return;
+  }
+  hy.hist0[t] = c;
+  hy.gbin0[t] = exc;
+  uint32_t tiles = 0;
+  for (int r = 0; r < NRANGE; ++r) tiles += (cnt[r] + (uint32_t)tile_rows - 1) / (uint32_t)tile_rows;
+  uint32_t ttotal;
+  uint32_t trun = block_exclusive_scan<BINS>(tiles, 0u, SumOp(), s_tmp, &ttotal);
+  for (int r = 0; r < NRANGE; ++r) {  // a tile never straddles two regions
+    const int q     = t * NRANGE + r;
+    hf.reg_tile0[q] = trun;
+    hf.reg_start[q] = hf.slot0[r][t];
+    hf.reg_count[q] = cnt[r];
+    trun += (cnt[r] + (uint32_t)tile_rows - 1) / (uint32_t)tile_rows;
+  }
+  if (t == 0) {
+    hf.reg_tile0[BINS * NRANGE] = ttotal;
+    plan_local_digits(hy, V, hy.shift2);
+    __threadfence();
+    hf.state = 3;
+  }
+}
+
+template <typename KeyT, int KIND, int LVL, int NBL>
+__global__ void __launch_bounds__(BT, 4) k_hf_scatter(const KeyT* __restrict__ in, KeyT* __restrict__ out, KeyT desc_mask, SortPlan* plan,
+                                                     uint32_t* __restrict__ cellcur, uint32_t cellcap, int64_t n)
+{
+  constexpr int KPT = 16, TILE = BT * KPT, NB = 1 << NBL, BPT = NB > BT ? NB / BT : 1;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  KeyT* s_keys      = reinterpret_cast<KeyT*>(smem);                                        // [TILE]
+  uint32_t* s_cnt   = reinterpret_cast<uint32_t*>(smem + (size_t)TILE * sizeof(KeyT));     // [NB] counts, then bin starts
+  uint32_t* s_delta = s_cnt + NB;                                                           // [NB] output position - position in the tile
+  uint32_t* s_limit = s_delta + NB;                                                         // [NB] end of the bin's slot
+  uint32_t* s_scan  = s_limit + NB;                                                         // [16]
+  uint32_t* s_misc  = s_scan + 16;                                                          // [4]
+  unsigned long long* s_red = reinterpret_cast<unsigned long long*>(s_misc + 4);           // [2 * NW] (level 0)
+  HybridPlan& hy = plan->hy;
+  FastPlan& hf   = plan->hf;
+  if (hf.state != (LVL == 0 ? 1 : 3)) return;
+  const unsigned tid = threadIdx.x;
+  const int64_t v    = xcd_swizzle((int64_t)blockIdx.x, (int64_t)gridDim.x);  // XCD x works on a contiguous eighth of the tiles
+  int64_t base;
+  int nvalid;
+  uint32_t seg;
+  if (LVL == 0) {
+    const int64_t per = (int64_t)gridDim.x / NRANGE;  // whole tiles per range (the last range takes the rest)
+    seg               = (per > 0 && v / per < NRANGE - 1) ? (uint32_t)(v / per) : (uint32_t)(NRANGE - 1);
+    base              = v * TILE;
+    nvalid            = (int)(n - base < (int64_t)TILE ? n - base : (int64_t)TILE);
+  } else {
+    if (v >= (int64_t)hf.reg_tile0[BINS * NRANGE]) return;
+    constexpr int QPT = BINS * NRANGE / BT;  // region table entries per thread
+#pragma unroll
+    for (int k = 0; k < QPT; ++k) {
+      const int q       = (int)tid * QPT + k;
+      const uint32_t lo = hf.reg_tile0[q], hi = hf.reg_tile0[q + 1];
+      if ((int64_t)lo <= v && v < (int64_t)hi) {
+        s_misc[0] = (uint32_t)q;
+        s_misc[1] = (uint32_t)(v - lo);
+      }
+    }
+    __syncthreads();
+    const uint32_t q  = s_misc[0];
+    const uint32_t jt = s_misc[1];
+    seg               = q / NRANGE;  // the level-0 bucket
+    base              = (int64_t)hf.reg_start[q] + (int64_t)jt * TILE;
+    const int64_t rem = (int64_t)hf.reg_count[q] - (int64_t)jt * TILE;
+    nvalid            = (int)(rem < (int64_t)TILE ? rem : (int64_t)TILE);
+  }
+  const int shift      = LVL == 0 ? hy.shift0 : hy.shift2;
+  const uint32_t dmask = LVL == 0 ? 0xFFu : ((1u << hy.bits2) - 1u);
+
+  KeyT key[KPT];
+  if (nvalid == TILE) {
+#pragma unroll
+    for (int j = 0; j < KPT; ++j) key[j] = in[base + j * BT + (int)tid];
+  } else {
+#pragma unroll
+    for (int j = 0; j < KPT; ++j) {
+      const int idx = j * BT + (int)tid;
+      key[j]        = in[base + (idx < nvalid ? idx : 0)];  // padding repeats the tile's first key: neutral for the masks below
+    }
+  }
+  for (int b = tid; b < NB; b += BT) s_cnt[b] = 0;
+  if (LVL == 0) {
+    // exact varying-bit masks of the column, on the raw keys: the sortable form of an integer is the key XOR a constant,
+    // so the set of bits that differ somewhere is the same
+    KeyT vor = key[0], vnor = (KeyT)~key[0];
+#pragma unroll
+    for (int j = 1; j < KPT; ++j) {
+      vor |= key[j];
+      vnor |= (KeyT)~key[j];
+    }
+    const unsigned long long wo = wave_reduce((unsigned long long)vor, [](unsigned long long x, unsigned long long y) { return x | y; });
+    const unsigned long long wn = wave_reduce((unsigned long long)vnor, [](unsigned long long x, unsigned long long y) { return x | y; });
+    if (lane_id() == 0) {
+      s_red[tid / GX_WAVE]      = wo;
+      s_red[NW + tid / GX_WAVE] = wn;
+    }
+  }
+  __syncthreads();
+  if (LVL == 0 && tid == 0) {  // atomics only while this workgroup still has a bit to add
+    unsigned long long o = 0, no = 0;
+    for (int k = 0; k < NW; ++k) {
+      o |= s_red[k];
+      no |= s_red[NW + k];
+    }
+    if (o & ~__hip_atomic_load(&hy.or_mask, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) atomicOr(&hy.or_mask, o);
+    if (no & ~__hip_atomic_load(&hy.nor_mask, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) atomicOr(&hy.nor_mask, no);
+  }
+  uint32_t packed[KPT];
+#pragma unroll
+  for (int j = 0; j < KPT; ++j) {
+    const bool live  = j * BT + (int)tid < nvalid;
+    const KeyT k     = to_sortable<KeyT, KIND>(key[j], desc_mask);
+    const uint32_t d = (uint32_t)(k >> shift) & dmask;
+    packed[j]        = (d << 16) | lds_rank(s_cnt, d, live);
+  }
+  __syncthreads();
+  // ---- one returning atomic per non-empty bin reserves the tile's run; the scan runs while it is in flight
+  uint32_t c[BPT], g[BPT], sbase[BPT], scap[BPT];
+  uint32_t csum = 0;
+#pragma unroll
+  for (int k = 0; k < BPT; ++k) {
+    const uint32_t bin = tid * BPT + k;
+    c[k] = g[k] = sbase[k] = scap[k] = 0;
+    if (bin < (uint32_t)NB) {
+      c[k] = s_cnt[bin];
+      if (LVL == 0) {
+        sbase[k] = hf.slot0[seg][bin];
+        scap[k]  = hf.cap0[seg][bin];
+        if (c[k]) g[k] = atomicAdd(&hf.cur0[seg][bin], c[k]);
+      } else if (bin <= dmask) {
+        sbase[k] = ((seg << hy.bits2) + bin) * cellcap;
+        scap[k]  = cellcap;
+        if (c[k]) g[k] = atomicAdd(&cellcur[seg * NB2MAX + bin], c[k]);
+      }
+      csum += c[k];
+    }
+  }
+  uint32_t st = block_exclusive_scan<BT>(csum, 0u, SumOp(), s_scan, (uint32_t*)nullptr);
+#pragma unroll
+  for (int k = 0; k < BPT; ++k) {
+    const uint32_t bin = tid * BPT + k;
+    if (bin < (uint32_t)NB) {
+      if (c[k] && g[k] + c[k] > scap[k]) {  // the surplus is dropped at the write-out; the fallback will sort the column
+        if (LVL == 0) hf.fail = 1;
+        else atomicExch(&hy.overflow, 1);
+      }
+      s_cnt[bin]   = st;
+      s_delta[bin] = sbase[k] + g[k] - st;
+      s_limit[bin] = sbase[k] + scap[k];
+      st += c[k];
+    }
+  }
+  __syncthreads();
+#pragma unroll
+  for (int j = 0; j < KPT; ++j) {
+    if (j * BT + (int)tid < nvalid) s_keys[s_cnt[packed[j] >> 16] + (packed[j] & 0xFFFFu)] = key[j];
+  }
+  __syncthreads();
+#pragma unroll
+  for (int j = 0; j < KPT; ++j) {
+    const int i = j * BT + (int)tid;
+    if (i < nvalid) {
+      const KeyT k       = s_keys[i];
+      const uint32_t d   = (uint32_t)(to_sortable<KeyT, KIND>(k, desc_mask) >> shift) & dmask;
+      const uint32_t dst = s_delta[d] + (uint32_t)i;
+      if (dst < s_limit[d]) out[dst] = k;
+    }
+  }
+}
+
 static int g_algorithm = 0;
 static int g_order_mode = 0;
 
@@ -1350,6 +1738,33 @@ static HybridCfg hybrid_cfg(int64_t n, bool iota_payload, int algo)
   return c;
 }
 
+// cursor path (integer keys, keys only): configuration, again a pure function of (n, kind, knobs)
+struct FastCfg {
+  bool on;
+  int bits2;         // level-1 bits (1..10), 8192-key cells
+  int stride;        // sample: every stride-th 64-key chunk
+  size_t slot_rows;  // keys the padded level-0 output holds
+};
+static int g_cursor          = 1;     // 0 disables the cursor path (A/B knob)
+static float g_cursor_margin = 8.0f;  // standard deviations of slack per level-0 slot (tests: < 0 forces the fallback)
+template <typename KeyT, int KIND, bool HAS_VAL>
+static FastCfg fast_cfg(int64_t n, int algo, bool hybrid_on)
+{
+  FastCfg f{false, 9, 32, 0};
+  if (sizeof(KeyT) != 8 || HAS_VAL || KIND == K_FLOAT || algo != 0 || !hybrid_on || !g_cursor || n < (1ll << 25)) return f;
+  int B = 9;
+  while (B < 18 && (double)n / (double)(1ull << B) > 0.955 * 8192.0) ++B;
+  if ((double)n / (double)(1ull << B) > 0.97 * 8192.0) return f;
+  f.bits2  = B - 8;
+  f.stride = n >= (1ll << 27) ? 32 : 8;
+  // sum of the slot capacities k_hf_plan hands out (Cauchy-Schwarz over the 2048 slots; the kernel checks it again)
+  const double m   = g_cursor_margin > 0 ? g_cursor_margin : 0.0;
+  const double dev = m * 1.25 * f.stride * __builtin_sqrt((double)(NRANGE * BINS) * ((double)n / f.stride + 2.0 * NRANGE * BINS));
+  f.slot_rows      = (size_t)((double)n * 1.002 + dev) + (size_t)(NRANGE * BINS) * (size_t)(2 * f.stride * HF_CHUNK + 64 + 16) + 65536;
+  f.on             = true;
+  return f;
+}
+
 template <typename KeyT, int KIND, bool HAS_VAL>
 int sort_impl(const void* keys_in, void* keys_out, const int32_t* vals_in, int32_t* vals_out, int64_t n,
               int descending, bool radix_nan_rule, void* tmp, size_t* tmp_bytes, hipStream_t stream)
@@ -1371,8 +1786,9 @@ int sort_impl(const void* keys_in, void* keys_out, const int32_t* vals_in, int32
   // tie-break the packed local sort relies on
   const HybridCfg hc    = hybrid_cfg<KeyT, KIND, HAS_VAL>(n, vals_in == nullptr, algo);
   const bool try_hybrid = hc.on;
+  const FastCfg fc      = fast_cfg<KeyT, KIND, HAS_VAL>(n, algo, hc.on);
   const int hyb_kpt     = hc.kpt;
-  const int nb1         = hc.bits2 > 8 ? NB2MAX : BINS;  // bins (and look-back granules per tile) of the level-1 pass
+  const int nb1         = hc.bits2 > 8 ? NB9 : BINS;  // bins (and look-back granules per tile) of the level-1 pass
   uint32_t* base1 = c.take<uint32_t>((size_t)NRANGE * NB2MAX);
   uint32_t* hist2 = try_hybrid ? c.take<uint32_t>((size_t)2 * BINS * NB2MAX) : nullptr;  // cell sizes | cell output positions
   uint32_t* base2 = try_hybrid ? hist2 + BINS * NB2MAX : nullptr;
@@ -1388,9 +1804,11 @@ int sort_impl(const void* keys_in, void* keys_out, const int32_t* vals_in, int32
   }
   // the level-1 pass writes every cell into its own slot of 1 << cl2 keys (no joint histogram pass): the
   // ping-pong scratch holds (256 << bits2) slots when that exceeds n
-  const size_t padded = try_hybrid ? ((size_t)BINS << hc.bits2) << hc.cl2 : 0;
+  size_t padded = try_hybrid ? ((size_t)BINS << hc.bits2) << hc.cl2 : 0;
+  if (fc.on && (((size_t)BINS << fc.bits2) << 13) > padded) padded = ((size_t)BINS << fc.bits2) << 13;
   const size_t nb_buf = padded > (size_t)n ? padded : (size_t)n;
   KeyT* kb_scratch = c.take<KeyT>(nb_buf);
+  KeyT* slot0_buf  = fc.on ? c.take<KeyT>(fc.slot_rows) : nullptr;  // cursor path: padded level-0 output
   KeyT* ka_scratch = keys_out ? nullptr : c.take<KeyT>((size_t)n);
   uint32_t* vb     = HAS_VAL ? c.take<uint32_t>(nb_buf) : nullptr;
   if (tmp == nullptr) {
@@ -1414,6 +1832,58 @@ int sort_impl(const void* keys_in, void* keys_out, const int32_t* vals_in, int32
   hblocks = div_up(hblocks, NRANGE) * NRANGE;  // block b serves input range b % NRANGE
   prof_mark(0, stream);
   g_prof.hybrid_marked = false;
+  bool cursor_marked = false;
+  if constexpr (sizeof(KeyT) == 8 && !HAS_VAL && KIND != K_FLOAT) {
+    if (fc.on) {
+      // cursor path: speculative plan from a sample, verified by level 0; on a miss everything below is a no-op and the
+      // look-back path further down sorts the column
+      constexpr int FT = BT * 16;
+      const int64_t ftiles  = div_up(n, (int64_t)FT);
+      const int64_t frange  = (ftiles / NRANGE) * FT;  // rows per input range (whole tiles; the last range takes the rest)
+      auto lds_hf = [&](int nb) { return (size_t)FT * sizeof(KeyT) + (size_t)(3 * nb + 16 + 4) * 4 + (size_t)2 * NW * 8; };
+      typedef void (*HfK)(const KeyT*, KeyT*, KeyT, SortPlan*, uint32_t*, uint32_t, int64_t);
+      HfK kf0 = k_hf_scatter<KeyT, KIND, 0, 8>;
+      HfK kf1 = fc.bits2 <= 8 ? (HfK)k_hf_scatter<KeyT, KIND, 1, 8> : (fc.bits2 == 9 ? (HfK)k_hf_scatter<KeyT, KIND, 1, 9> : (HfK)k_hf_scatter<KeyT, KIND, 1, 10>);
+      const int nbf = fc.bits2 <= 8 ? 256 : (1 << fc.bits2);
+      static bool fattr_set = false;
+      if (!fattr_set) {
+        GX_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(k_hf_scatter<KeyT, KIND, 0, 8>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_hf(256)));
+        GX_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(k_hf_scatter<KeyT, KIND, 1, 8>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_hf(256)));
+        GX_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(k_hf_scatter<KeyT, KIND, 1, 9>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_hf(512)));
+        GX_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(k_hf_scatter<KeyT, KIND, 1, 10>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_hf(1024)));
+        GX_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(k_local_sort<KeyT, KIND, HAS_VAL, 13>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                       (int)(((size_t)sizeof(KeyT) << 13) + (size_t)(((1 << 13) / 16 / GX_WAVE) * BINS + 32 + 2 * BINS) * 4)));
+        fattr_set = true;
+      }
+      const int64_t step = (int64_t)fc.stride * HF_CHUNK;
+      int64_t sblocks    = div_up(div_up(n, step), (int64_t)4 * 4);
+      if (sblocks > 2048) sblocks = 2048;
+      const KeyT* kin = static_cast<const KeyT*>(keys_in);
+      KeyT* bufA      = keys_out ? static_cast<KeyT*>(keys_out) : ka_scratch;
+      hipLaunchKernelGGL((k_hf_sample<KeyT, KIND, false>), dim3((unsigned)sblocks), dim3(256), 0, stream, kin, n, desc_mask, plan, fc.stride, frange);
+      hipLaunchKernelGGL(k_hf_plan, dim3(1), dim3(BINS), 0, stream, plan, 0, (int)(8 * sizeof(KeyT)), n, fc.bits2, 1 << 13, fc.stride, frange, FT,
+                         (unsigned long long)fc.slot_rows, g_cursor_margin);
+      hipLaunchKernelGGL((k_hf_sample<KeyT, KIND, true>), dim3((unsigned)sblocks), dim3(256), 0, stream, kin, n, desc_mask, plan, fc.stride, frange);
+      hipLaunchKernelGGL(k_hf_plan, dim3(1), dim3(BINS), 0, stream, plan, 1, (int)(8 * sizeof(KeyT)), n, fc.bits2, 1 << 13, fc.stride, frange, FT,
+                         (unsigned long long)fc.slot_rows, g_cursor_margin);
+      prof_mark(1, stream);
+      prof_mark_h(0, stream);
+      hipLaunchKernelGGL(kf0, dim3((unsigned)ftiles), dim3(BT), lds_hf(256), stream, kin, slot0_buf, desc_mask, plan, hist2, 1u << 13, n);
+      hipLaunchKernelGGL(k_hf_plan, dim3(1), dim3(BINS), 0, stream, plan, 2, (int)(8 * sizeof(KeyT)), n, fc.bits2, 1 << 13, fc.stride, frange, FT,
+                         (unsigned long long)fc.slot_rows, g_cursor_margin);
+      prof_mark_h(1, stream);
+      hipLaunchKernelGGL(kf1, dim3((unsigned)(ftiles + NRANGE * BINS)), dim3(BT), lds_hf(nbf), stream, slot0_buf, kb_scratch, desc_mask, plan, hist2, 1u << 13, n);
+      prof_mark_h(2, stream);
+      hipLaunchKernelGGL(k_plan2, dim3(BINS), dim3(GX_WAVE), 0, stream, plan, hist2, base2, NPASS, 1);
+      prof_mark_h(3, stream);
+      hipLaunchKernelGGL((k_local_sort<KeyT, KIND, HAS_VAL, 13>), dim3((unsigned)(BINS << fc.bits2)), dim3((1 << 13) / 16),
+                         ((size_t)sizeof(KeyT) << 13) + (size_t)(((1 << 13) / 16 / GX_WAVE) * BINS + 32 + 2 * BINS) * 4, stream, kb_scratch, bufA,
+                         (const uint32_t*)nullptr, (uint32_t*)nullptr, desc_mask, plan, hist2, base2, 0, 1);
+      prof_mark_h(4, stream);
+      g_prof.hybrid_marked = g_prof.enabled;
+      cursor_marked        = true;
+    }
+  }
   if constexpr (sizeof(KeyT) == 8) {
     if (try_hybrid) {
       // hybrid MSD path: every kernel below is a no-op unless the device-side plan enables it
@@ -1439,7 +1909,7 @@ int sort_impl(const void* keys_in, void* keys_out, const int32_t* vals_in, int32
         GX_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(k_msd_pass<KeyT, KIND, HAS_VAL, 16, 4, 8>), hipFuncAttributeMaxDynamicSharedMemorySize, lds_mmax));
         GX_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(kloc), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_loc(14)));
         if constexpr (SMALLOK) {
-          GX_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(k_msd_pass<KeyT, KIND, HAS_VAL, SKPT, 4, 9>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_msd(SKPT, NB2MAX)));
+          GX_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(k_msd_pass<KeyT, KIND, HAS_VAL, SKPT, 4, 9>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_msd(SKPT, NB9)));
           GX_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(k_local_sort<KeyT, KIND, HAS_VAL, 13>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_loc(13)));
         }
         hattr_set = true;
@@ -1455,8 +1925,8 @@ int sort_impl(const void* keys_in, void* keys_out, const int32_t* vals_in, int32
           if (!lattr_set) {
             GX_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(k_msd_pass<KeyT, KIND, HAS_VAL, 16, 8, 8>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_msd(16, BINS)));
             GX_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(k_msd_pass<KeyT, KIND, HAS_VAL, 16, 16, 8>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_msd(16, BINS)));
-            GX_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(k_msd_pass<KeyT, KIND, HAS_VAL, 16, 8, 9>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_msd(16, NB2MAX)));
-            GX_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(k_msd_pass<KeyT, KIND, HAS_VAL, 16, 16, 9>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_msd(16, NB2MAX)));
+            GX_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(k_msd_pass<KeyT, KIND, HAS_VAL, 16, 8, 9>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_msd(16, NB9)));
+            GX_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(k_msd_pass<KeyT, KIND, HAS_VAL, 16, 16, 9>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_msd(16, NB9)));
             lattr_set = true;
           }
           kmsd0 = g_lbw == 8 ? (MsdK)k_msd_pass<KeyT, KIND, HAS_VAL, 16, 8, 8> : (MsdK)k_msd_pass<KeyT, KIND, HAS_VAL, 16, 16, 8>;
@@ -1478,7 +1948,7 @@ int sort_impl(const void* keys_in, void* keys_out, const int32_t* vals_in, int32
                          static_cast<const KeyT*>(keys_in), n, desc_mask, plan, range_rows);
       hipLaunchKernelGGL(k_hy_plan, dim3(1), dim3(BINS), 0, stream, plan, 1, (int)(8 * sizeof(KeyT)), n, hc.bits2, 1 << hc.cl2,
                          HAS_VAL ? hc.cl2 : 0, range_rows, (int)msd_tile, base1);
-      prof_mark(1, stream);
+      if (!cursor_marked) prof_mark(1, stream);
       KeyT* bufA = keys_out ? static_cast<KeyT*>(keys_out) : ka_scratch;
       KeyT* bufB = kb_scratch;
       uint32_t* valA = reinterpret_cast<uint32_t*>(vals_out);
@@ -1497,29 +1967,29 @@ int sort_impl(const void* keys_in, void* keys_out, const int32_t* vals_in, int32
       m.exp       = 0;
       m.cellcount = hist2;
       m.cellcap   = 1u << hc.cl2;
-      prof_mark_h(0, stream);
+      if (!cursor_marked) prof_mark_h(0, stream);
       hipLaunchKernelGGL(kmsd0, dim3((unsigned)(msd_ntiles + NRANGE)), dim3(BT), lds_msd(hyb_kpt, BINS), stream, m);
-      prof_mark_h(1, stream);
+      if (!cursor_marked) prof_mark_h(1, stream);
       m.in    = bufA;
       m.out   = bufB;
       m.vin   = valA;
       m.vout  = valB;
       m.level = 1;
       hipLaunchKernelGGL(kmsd1, dim3((unsigned)(msd_ntiles + BINS + NRANGE)), dim3(BT), lds_msd(hyb_kpt, nb1), stream, m);
-      prof_mark_h(2, stream);
-      hipLaunchKernelGGL(k_plan2, dim3(BINS), dim3(GX_WAVE), 0, stream, plan, hist2, base2, NPASS);
-      prof_mark_h(3, stream);
+      if (!cursor_marked) prof_mark_h(2, stream);
+      hipLaunchKernelGGL(k_plan2, dim3(BINS), dim3(GX_WAVE), 0, stream, plan, hist2, base2, NPASS, 0);
+      if (!cursor_marked) prof_mark_h(3, stream);
       hipLaunchKernelGGL(kloc, dim3((unsigned)(BINS << hc.bits2)), dim3(ls_bt), lds_loc(hc.cl2), stream, bufB, bufA, valB, valA, desc_mask,
-                         plan, hist2, base2, m.exp);
-      prof_mark_h(4, stream);
-      g_prof.hybrid_marked = g_prof.enabled;
+                         plan, hist2, base2, m.exp, 0);
+      if (!cursor_marked) prof_mark_h(4, stream);
+      if (!cursor_marked) g_prof.hybrid_marked = g_prof.enabled;
     }
   }
   // LSD path: byte histograms + plan (no-ops when the hybrid path has sorted the column)
   hipLaunchKernelGGL((k_hist_all<KeyT, KIND>), dim3((unsigned)hblocks), dim3(BT), 0, stream,
                      static_cast<const KeyT*>(keys_in), n, desc_mask, plan, range_rows);
   hipLaunchKernelGGL(k_plan, dim3(1), dim3(BINS), 0, stream, plan, NPASS, n);
-  if (!try_hybrid) prof_mark(1, stream);
+  if (!try_hybrid && !cursor_marked) prof_mark(1, stream);
 
   PassArgs a;
   a.kbuf[0]   = const_cast<void*>(keys_in);
@@ -1742,6 +2212,21 @@ int gx_sort_profile_read_hybrid(float* ms4)
 }
 
 void gx_sort_set_hybrid(int enable) { gx::sort::g_hybrid = enable ? 1 : 0; }
+
+void gx_sort_set_cursor_path(int enable, float margin_sigmas)
+{
+  gx::sort::g_cursor        = enable ? 1 : 0;
+  gx::sort::g_cursor_margin = margin_sigmas == 0.0f ? 8.0f : margin_sigmas;
+}
+
+int gx_sort_cursor_state(const void* tmp, int32_t* state_host, gx_stream_t stream)
+{
+  if (!tmp || !state_host) return GX_EINVAL;
+  const auto* plan = static_cast<const gx::sort::SortPlan*>(tmp);
+  GX_HIP_TRY(hipMemcpyAsync(state_host, &plan->hf.state, sizeof(int32_t), hipMemcpyDeviceToHost, stream));
+  GX_HIP_TRY(hipStreamSynchronize(stream));
+  return 0;
+}
 
 void gx_sort_set_lookback(int window) { gx::sort::g_lbw = (window == 4 || window == 8) ? window : 16; }
 

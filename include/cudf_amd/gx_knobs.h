@@ -40,6 +40,17 @@ int gx_sort_profile_read_hybrid(float* ms4);
  * does not fit (skewed keys).  0 disables it (A/B measurements). */
 void gx_sort_set_hybrid(int enable);
 
+/* Cursor path of the hybrid sort (integer 64-bit keys, keys only, n >= 2^25; default on): the digit positions and
+ * the slot capacities of the first partition level come from a 1/32 SAMPLE, both partition levels reserve their output
+ * runs with one atomic per (tile, bin) instead of a look-back chain, and the first level -- which reads every key anyway --
+ * verifies the sample (exact varying-bit masks, slot counts).  On a miss the look-back path sorts the column; the device
+ * decides.  enable = 0 switches it off (A/B); margin_sigmas = slack per slot in standard deviations of the estimate
+ * (0 = default 8; a negative value makes every slot too small: TEST HOOK for the fallback). */
+void gx_sort_set_cursor_path(int enable, float margin_sigmas);
+/* 0 = not tried, 2 = tried and rejected by the device (the look-back path ran), 3 = the cursor path sorted the column.
+ * `tmp` is the scratch of that sort call; synchronises the stream. */
+int gx_sort_cursor_state(const void* tmp, int32_t* state_host, gx_stream_t stream);
+
 /* A/B knob (process-wide): capacity of a local-sort cell of the hybrid path.  0 = auto (8192-key cells, two
  * workgroups per CU and a 9-bit second partition level, for integer keys-only sorts of up to ~1.02e9 rows;
  * 16384-key cells otherwise), 8192 / 16384 = force where the key kind allows it. */

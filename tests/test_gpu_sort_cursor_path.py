@@ -1,0 +1,159 @@
+"""The CURSOR path of the hybrid radix sort (gx_sort.hip: k_hf_sample / k_hf_plan / k_hf_scatter; integer 64-bit keys,
+keys only, n >= 2^25): digit positions and slot capacities come from a SAMPLE, the first partition level verifies them.
+Every case is compared bit for bit with the plain-C oracle (oracle/oracle.c restates cub::DeviceRadixSort's contract as
+used by cudf::sort, cpp/src/sort/sort_radix.cu:66-117), and the test also pins WHICH path the device took: a sample that
+is representative must end in state 3 (cursor path sorted the column), a sample that is not must be caught by the device
+(state 2: the look-back path sorted it) -- never a wrong result.
+"""
+import ctypes
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+from oracle import c_oracle
+
+N = 40_000_000  # > 2^25: the smallest size class of the cursor path (sample stride 8)
+
+
+@pytest.fixture(scope="module")
+def gx():
+    import torch
+    assert torch.cuda.is_available()
+    import cudf_amd  # noqa: F401
+    from cudf_amd import Column, ops, _lib as L
+    yield Column, ops, L
+    L.lib.gx_sort_set_cursor_path(1, 0.0)
+
+
+def _sort_with_state(gx, v, descending=False):
+    """gx_sort_keys through the C ABI, returning (sorted numpy array, cursor-path state)"""
+    Column, ops, L = gx
+    col = Column.from_numpy(v)
+    out = Column.empty(v.dtype, v.size)
+    tmp = ops._run(L.lib.gx_sort_keys, col.gx, col.data_ptr, out.data_ptr, col.size, int(descending))
+    ops._check_sort_status(tmp)
+    st = ctypes.c_int32(-1)
+    L.check(L.lib.gx_sort_cursor_state(ops.ptr(tmp), ctypes.byref(st), ops.stream_ptr()), "gx_sort_cursor_state")
+    return out.to_numpy(), st.value
+
+
+def _keys(kind, rng):
+    if kind == "uniform":
+        return rng.integers(-2**63, 2**63 - 1, N, dtype=np.int64)
+    if kind == "narrow":  # the highest varying bit is not byte aligned, the top digit is not uniform (233 of 256 bins used)
+        return rng.integers(0, 1_000_000_000_000, N, dtype=np.int64)
+    if kind == "sorted":  # every range of the input sees a different eighth of the key space; bins are contiguous runs
+        return np.sort(rng.integers(-2**62, 2**62, N, dtype=np.int64))
+    if kind == "reversed":
+        return np.sort(rng.integers(-2**62, 2**62, N, dtype=np.int64))[::-1].copy()
+    if kind == "clustered":  # long runs of one key, run lengths around the sample step
+        runs = rng.integers(0, 2**40, N // 700 + 1, dtype=np.int64)
+        return np.repeat(runs, 700)[:N].copy()
+    if kind == "skewed":  # 90 % of the keys in one level-0 bin: slots of very different sizes
+        v = rng.integers(0, 2**48, N, dtype=np.int64)
+        hot = rng.random(N) < 0.9
+        v[hot] = (v[hot] & ((1 << 40) - 1)) | (37 << 40)
+        return v
+    if kind == "uint64":
+        return rng.integers(0, 2**64 - 1, N, dtype=np.uint64)
+    raise AssertionError(kind)
+
+
+@pytest.mark.parametrize("kind", ["uniform", "narrow", "sorted", "reversed", "clustered", "skewed"])
+@pytest.mark.parametrize("descending", [False, True])
+def test_cursor_path_matches_c_oracle(gx, kind, descending):
+    rng = np.random.default_rng(hash_seed(kind))
+    v = _keys(kind, rng)
+    got, state = _sort_with_state(gx, v, descending)
+    assert got.tobytes() == c_oracle.sort_i64(v, descending=descending).tobytes()
+    # representative samples: the device must have accepted the speculative plan (a silent fall-back would hide a
+    # broken capacity model behind a correct result)
+    assert state == 3, f"{kind}: the cursor path was rejected (state {state})"
+
+
+def hash_seed(s):
+    import zlib
+    return zlib.crc32(s.encode())
+
+
+def test_cursor_path_uint64(gx):
+    rng = np.random.default_rng(5)
+    v = _keys("uint64", rng)
+    got, state = _sort_with_state(gx, v)
+    assert got.tobytes() == np.sort(v).tobytes()
+    assert state == 3
+
+
+def test_sample_misses_the_top_bits_device_falls_back(gx):
+    """ONE key with high bits that no sampled chunk contains: the sample's digit positions are wrong for the column.
+    Level 0 reduces the exact masks, the verdict rejects the plan, the look-back path sorts from scratch."""
+    rng = np.random.default_rng(6)
+    v = rng.integers(0, 2**40, N, dtype=np.int64)
+    # the sample takes chunks [c * 8 * 64, c * 8 * 64 + 64): row 64 + 5 is never sampled
+    v[64 + 5] = 2**61 + 12345
+    v[N - 100] = -7  # and a negative one near the end (also outside the sampled chunks: (N - 100) % 512 >= 64)
+    assert (N - 100) % 512 >= 64
+    got, state = _sort_with_state(gx, v)
+    assert got.tobytes() == c_oracle.sort_i64(v).tobytes()
+    assert state == 2, f"the device accepted a plan built from an unrepresentative sample (state {state})"
+
+
+def test_slots_too_small_device_falls_back(gx):
+    """TEST HOOK: negative slack makes every level-0 slot smaller than its estimate -> overflow -> fallback"""
+    Column, ops, L = gx
+    rng = np.random.default_rng(7)
+    v = rng.integers(-2**63, 2**63 - 1, N, dtype=np.int64)
+    L.lib.gx_sort_set_cursor_path(1, -8.0)
+    try:
+        got, state = _sort_with_state(gx, v)
+    finally:
+        L.lib.gx_sort_set_cursor_path(1, 0.0)
+    assert got.tobytes() == c_oracle.sort_i64(v).tobytes()
+    assert state == 2
+
+
+def test_cursor_path_off_is_the_look_back_path(gx):
+    Column, ops, L = gx
+    rng = np.random.default_rng(8)
+    v = rng.integers(-2**63, 2**63 - 1, N, dtype=np.int64)
+    L.lib.gx_sort_set_cursor_path(0, 0.0)
+    try:
+        got, state = _sort_with_state(gx, v)
+    finally:
+        L.lib.gx_sort_set_cursor_path(1, 0.0)
+    assert got.tobytes() == c_oracle.sort_i64(v).tobytes()
+    assert state == 0
+
+
+def test_skewed_cells_fall_back_to_lsd(gx):
+    """keys that agree on everything the two partition levels look at: one cell would hold the whole column.  The cursor
+    path's level 1 raises the overflow flag, the LSD passes sort the column."""
+    rng = np.random.default_rng(9)
+    v = (rng.integers(0, 2**20, N, dtype=np.int64)) | (1 << 60) | (rng.integers(0, 2, N, dtype=np.int64) << 62)
+    got, state = _sort_with_state(gx, v)
+    assert got.tobytes() == c_oracle.sort_i64(v).tobytes()
+
+
+@pytest.mark.parametrize("n", [1_100_000_000])
+def test_window_above_1e9_rows_sorted_and_multiset_preserved(gx, n):
+    """n in (1.02e9, 2.1e9]: 8192-key cells need a 10-bit second level (two bins per thread in k_hf_scatter<1, 10>).
+    Too large for the CPU oracle in test time: sortedness + order-independent checksum (gx_checksum) of input vs output."""
+    Column, ops, L = gx
+    import torch
+    col = ops.random_column(np.int64, n, seed=77)
+    out = Column.empty(np.int64, n)
+    tmp = ops._run(L.lib.gx_sort_keys, col.gx, col.data_ptr, out.data_ptr, n, 0)
+    ops._check_sort_status(tmp)
+    st = ctypes.c_int32(-1)
+    L.check(L.lib.gx_sort_cursor_state(ops.ptr(tmp), ctypes.byref(st), ops.stream_ptr()), "gx_sort_cursor_state")
+    info = (ctypes.c_int32 * 8)()
+    L.lib.gx_sort_info(ops.ptr(tmp), info, ops.stream_ptr())
+    del tmp
+    cin, cout = ops.checksum(col), ops.checksum(out)
+    assert cout[2] == 0, "output not sorted"
+    assert cin[:2] == cout[:2], "multiset changed"
+    assert st.value == 3 and info[1] == 1 and info[4] == 10, (st.value, list(info))
+    t = out.data[: n * 8].view(torch.int64)
+    assert bool((t[1:] >= t[:-1]).all())
