@@ -72,9 +72,11 @@ struct HybridPlan {
 // Round 3, the CURSOR path (integer keys, keys only): plan of the speculative passes, see k_hf_scatter
 struct FastPlan {
   int32_t state;   // 0 not tried / given up before level 0; 1 planned from the sample; 2 failed the check after level 0
-                   // (the look-back path then runs from scratch); 3 verified (the look-back path is skipped)
+                   // (the look-back path then runs from scratch); 3 verified (the look-back path is skipped);
+                   // 4 the sample shows a key range too narrow for two partition levels: straight to the LSD passes
   int32_t fail;    // level 0: a slot outgrew its capacity
   int32_t stride;  // the sample takes every stride-th 64-key chunk
+  int32_t hist_ready;  // the first sample kernel's speculative top-byte histogram IS the level-0 digit's (full-range keys)
   uint32_t samp[NRANGE][BINS];              // sample histogram of the level-0 digit, per input range
   uint32_t slot0[NRANGE][BINS];             // level-0 output: first key of slot (range, bin) ...
   uint32_t cap0[NRANGE][BINS];              // ... and its capacity
@@ -179,7 +181,7 @@ __global__ void __launch_bounds__(BT) k_hy_hist(const KeyT* __restrict__ in, int
                                                 int64_t range_rows)
 {
   HybridPlan& hy = plan->hy;
-  if (plan->hf.state == 3) return;  // the cursor path has done levels 0 and 1
+  if (plan->hf.state >= 3) return;  // the cursor path has done levels 0 and 1 (3) / has ruled the hybrid path out (4)
   if (!SPEC && !(hy.attempt && hy.need_hist)) return;
   const int shift      = SPEC ? (int)(8 * sizeof(KeyT) - 8) : hy.shift0;
   const int range      = blockIdx.x % NRANGE;
@@ -267,7 +269,7 @@ __global__ void __launch_bounds__(BINS) k_hy_plan(SortPlan* plan, int stage, int
   __shared__ uint32_t s_tmp[BINS / GX_WAVE + 1];
   HybridPlan& hy = plan->hy;
   const int t    = threadIdx.x;
-  if (plan->hf.state == 3) return;  // the cursor path owns the plan
+  if (plan->hf.state >= 3) return;  // the cursor path owns the plan (3) / has ruled the hybrid path out (4: attempt stays 0)
   if (stage == 0) {
     const unsigned long long V = hy.or_mask & hy.nor_mask;  // bits that differ somewhere in the column
     if (V == 0) {
@@ -1335,19 +1337,19 @@ __global__ void __launch_bounds__(256) k_hf_sample(const KeyT* __restrict__ in, 
 {
   HybridPlan& hy = plan->hy;
   FastPlan& hf   = plan->hf;
-  if (HIST && hf.state != 1) return;
-  __shared__ uint32_t s_hist[HIST ? NRANGE * BINS : 1];
+  // HIST = false: the masks AND a speculative histogram of the TOP byte (the level-0 digit of any column whose top bit
+  // varies: full-range integers); HIST = true: the histogram of the digit k_hf_plan chose, only when that is another one
+  if (HIST && (hf.state != 1 || hf.hist_ready)) return;
+  __shared__ uint32_t s_hist[NRANGE * BINS];
   __shared__ unsigned long long s_red[2 * 4];
   const unsigned tid = threadIdx.x, lane = lane_id();
-  if (HIST) {
-    for (int i = tid; i < NRANGE * BINS; i += 256) s_hist[i] = 0;
-    __syncthreads();
-  }
-  const int shift       = HIST ? hy.shift0 : 0;
+  for (int i = tid; i < NRANGE * BINS; i += 256) s_hist[i] = 0;
+  __syncthreads();
+  const int shift       = HIST ? hy.shift0 : (int)(8 * sizeof(KeyT) - 8);
   const int64_t step    = (int64_t)stride * HF_CHUNK;
   const int64_t nchunks = div_up(n, step);
   const int64_t nw      = (int64_t)gridDim.x * 4;
-  constexpr int U       = 4;  // chunks in flight per wave
+  constexpr int U       = 8;  // chunks in flight per wave
   KeyT vor = 0, vnor = 0;
   for (int64_t c0 = (int64_t)blockIdx.x * 4 + tid / GX_WAVE; c0 < nchunks; c0 += nw * U) {
     KeyT raw[U];
@@ -1361,17 +1363,14 @@ __global__ void __launch_bounds__(256) k_hf_sample(const KeyT* __restrict__ in, 
       const int64_t row = (c0 + u * nw) * step + lane;
       const bool live   = c0 + u * nw < nchunks && row < n;
       const KeyT k      = to_sortable<KeyT, KIND>(raw[u], desc_mask);
-      if (!HIST) {
-        if (live) {
-          vor |= k;
-          vnor |= (KeyT)~k;
-        }
-      } else {
-        // a chunk never straddles two ranges (ranges are whole tiles, chunks start at multiples of 64)
-        const int64_t r64 = range_rows > 0 ? row / range_rows : (int64_t)(NRANGE - 1);
-        const int r       = r64 < NRANGE - 1 ? (int)r64 : NRANGE - 1;
-        (void)lds_rank(s_hist + r * BINS, (uint32_t)(k >> shift) & 0xFFu, live);
+      if (!HIST && live) {
+        vor |= k;
+        vnor |= (KeyT)~k;
       }
+      // a chunk never straddles two ranges (ranges are whole tiles, chunks start at multiples of 64)
+      const int64_t r64 = range_rows > 0 ? row / range_rows : (int64_t)(NRANGE - 1);
+      const int r       = r64 < NRANGE - 1 ? (int)r64 : NRANGE - 1;
+      (void)lds_rank(s_hist + r * BINS, (uint32_t)(k >> shift) & 0xFFu, live);
     }
   }
   if (!HIST) {
@@ -1386,12 +1385,11 @@ __global__ void __launch_bounds__(256) k_hf_sample(const KeyT* __restrict__ in, 
       atomicOr(&hy.or_mask, s_red[0] | s_red[1] | s_red[2] | s_red[3]);
       atomicOr(&hy.nor_mask, s_red[4] | s_red[5] | s_red[6] | s_red[7]);
     }
-  } else {
-    __syncthreads();
-    for (int i = tid; i < NRANGE * BINS; i += 256) {
-      const uint32_t c = s_hist[i];
-      if (c) atomicAdd(&hf.samp[i / BINS][i % BINS], c);
-    }
+  }
+  __syncthreads();
+  for (int i = tid; i < NRANGE * BINS; i += 256) {
+    const uint32_t c = s_hist[i];
+    if (c) atomicAdd(&hf.samp[i / BINS][i % BINS], c);
   }
 }
 
@@ -1429,11 +1427,19 @@ __global__ void __launch_bounds__(BINS) k_hf_plan(SortPlan* plan, int stage, int
     const int top              = V ? 63 - __builtin_clzll(V) : 0;
     const int shift0           = top - 7;
     const int shift2           = shift0 - bits2;
-    if (V == 0 || shift2 < 8) {  // (all sampled keys equal) / too few bits below level 1: not this path
-      if (t == 0) hf_give_up(plan, 0);
+    if (V == 0 || shift2 < 8) {
+      // all sampled keys equal: let the look-back path look at the whole column.  Too few varying bits below level 1 in
+      // the sample (narrow key ranges: the LSD passes are the right tool): state 4 also spares the look-back path's
+      // up-front read -- declining the hybrid path is always safe, the LSD passes sort anything
+      if (t == 0) hf_give_up(plan, V == 0 ? 0 : 4);
       return;
     }
+    const bool spec_ok = shift0 == key_bits - 8;
+    if (!spec_ok) {  // the speculative histogram is of the wrong digit: k_hf_sample<true> refills it
+      for (int r = 0; r < NRANGE; ++r) hf.samp[r][t] = 0;
+    }
     if (t == 0) {
+      hf.hist_ready = spec_ok ? 1 : 0;
       hy.attempt   = 1;
       hy.shift0    = shift0;
       hy.bits2     = bits2;
@@ -1443,7 +1449,6 @@ __global__ void __launch_bounds__(BINS) k_hf_plan(SortPlan* plan, int stage, int
       hf.stride    = stride;
       hf.state     = 1;
     }
-    (void)key_bits;
     return;
   }
   if (hf.state != 1) return;
@@ -1518,6 +1523,15 @@ __global__ void __launch_bounds__(BINS) k_hf_plan(SortPlan* plan, int stage, int
     __threadfence();
     hf.state = 3;
   }
+}
+
+// the look-back granules must start at zero for k_msd_pass / k_radix_pass -- which do not run when the cursor path has
+// sorted the column: then clearing half a gigabyte of status words is skipped too
+__global__ void __launch_bounds__(256) k_hf_clear_status(const SortPlan* plan, uint4* __restrict__ status, size_t n16)
+{
+  if (plan->hf.state == 3 && plan->hy.ok) return;
+  const size_t stride = (size_t)gridDim.x * 256;
+  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n16; i += stride) status[i] = uint4{0u, 0u, 0u, 0u};
 }
 
 template <typename KeyT, int KIND, int LVL, int NBL>
@@ -1821,7 +1835,7 @@ int sort_impl(const void* keys_in, void* keys_out, const int32_t* vals_in, int32
 
   GX_HIP_TRY(hipMemsetAsync(plan, 0, sizeof(SortPlan), stream));
   if (n == 0) return 0;
-  if (algo != 1) GX_HIP_TRY(hipMemsetAsync(status, 0, status_words * sizeof(unsigned long long), stream));
+  if (algo != 1 && !fc.on) GX_HIP_TRY(hipMemsetAsync(status, 0, status_words * sizeof(unsigned long long), stream));
   if (try_hybrid) GX_HIP_TRY(hipMemsetAsync(hist2, 0, (size_t)2 * BINS * NB2MAX * sizeof(uint32_t), stream));
   const int64_t range_rows = try_hybrid ? div_up(msd_ntiles, NRANGE) * msd_tile : div_up(ntiles, NRANGE) * TILE;
 
@@ -1882,6 +1896,7 @@ int sort_impl(const void* keys_in, void* keys_out, const int32_t* vals_in, int32
       prof_mark_h(4, stream);
       g_prof.hybrid_marked = g_prof.enabled;
       cursor_marked        = true;
+      hipLaunchKernelGGL(k_hf_clear_status, dim3(2048), dim3(256), 0, stream, plan, reinterpret_cast<uint4*>(status), status_words / 2);
     }
   }
   if constexpr (sizeof(KeyT) == 8) {

@@ -47,7 +47,8 @@ void gx_sort_set_hybrid(int enable);
  * decides.  enable = 0 switches it off (A/B); margin_sigmas = slack per slot in standard deviations of the estimate
  * (0 = default 8; a negative value makes every slot too small: TEST HOOK for the fallback). */
 void gx_sort_set_cursor_path(int enable, float margin_sigmas);
-/* 0 = not tried, 2 = tried and rejected by the device (the look-back path ran), 3 = the cursor path sorted the column.
+/* 0 = not tried, 2 = tried and rejected by the device (the look-back path ran), 3 = the cursor path sorted the column,
+ * 4 = the sample showed a key range too narrow for two partition levels (the LSD passes ran, no up-front read of the column).
  * `tmp` is the scratch of that sort call; synchronises the stream. */
 int gx_sort_cursor_state(const void* tmp, int32_t* state_host, gx_stream_t stream);
 

@@ -127,6 +127,16 @@ def test_cursor_path_off_is_the_look_back_path(gx):
     assert state == 0
 
 
+def test_narrow_key_range_goes_straight_to_the_lsd_passes(gx):
+    """the reference benchmark's own distribution (cpp/benchmarks/sort/sort.cpp: keys in [100, 10000]): two varying bytes,
+    nothing for two MSD levels to do -- the sample says so, and the look-back path's full up-front read is skipped too"""
+    rng = np.random.default_rng(10)
+    v = rng.integers(100, 10000, N, dtype=np.int64)
+    got, state = _sort_with_state(gx, v)
+    assert got.tobytes() == c_oracle.sort_i64(v).tobytes()
+    assert state == 4
+
+
 def test_skewed_cells_fall_back_to_lsd(gx):
     """keys that agree on everything the two partition levels look at: one cell would hold the whole column.  The cursor
     path's level 1 raises the overflow flag, the LSD passes sort the column."""
