@@ -53,6 +53,10 @@ def parse():
                     help="sort knob: 0 onesweep/windowed look-back, 1 three-kernel, 2 onesweep/one-tile look-back")
     ap.add_argument("--gb-algo", type=int, default=0, help="groupby knob: 0 auto, 1 global table, 2 LDS-partitioned")
     ap.add_argument("--gb-split", type=int, default=1)
+    ap.add_argument("--gb-keys", default="dense", choices=["dense", "random", "random64"],
+                    help="groupby: dense = int32 ids in [0, 1e6) (BASELINE config 4); random = the same ids through a 32-bit mixing bijection "
+                         "(sparse int32 keys: they hash like random numbers); random64 = int64 keys, ids through the splitmix64 finalizer")
+    ap.add_argument("--gb-pbits", type=int, default=9, help="groupby knob: 2^bits hash partitions (8 = round-2 layout, 9 = default)")
     ap.add_argument("--gb-spec", type=int, default=1, help="groupby knob: 1 hist-free speculative partition pass (default), 0 exact histogram pass")
     ap.add_argument("--no-partitioned-join", action="store_true", help="join: probe the table directly")
     ap.add_argument("--join-probe-kernel", type=int, default=0, help="join knob: 0 pipelined tag probe, 1 round-1 tag probe")
@@ -257,6 +261,14 @@ class Ctx:
         return col.data[: col.size * col.dtype.itemsize].view(dt)
 
 
+def lsr_mix64(j):
+    """splitmix64 finalizer on int64 tensors (a bijection of the 64-bit integers); logical shifts: mask off the sign extension"""
+    x = j
+    x = (x ^ ((x >> 30) & ((1 << 34) - 1))) * (-4658895280553007687)
+    x = (x ^ ((x >> 27) & ((1 << 37) - 1))) * (-7723592293110705685)
+    return x ^ ((x >> 31) & ((1 << 33) - 1))
+
+
 def pmc_traffic(roofline, n):
     """HBM bytes of the dominant kernel from the committed PMC passes (same command, 1e9 rows)"""
     if roofline is None or n != 1_000_000_000:
@@ -457,11 +469,6 @@ def bench_join(c):
         # random set of equal size.  The set is mix64(j), j in [0, 2 * nb_rows): mix64 (the splitmix64 finalizer) is a
         # bijection of the 64-bit integers, so the values are distinct and look random in every bit; j < nb_rows is the
         # build set, j >= nb_rows the disjoint one.
-        def lsr_mix64(j):  # logical shifts on int64 tensors: mask off the sign extension
-            x = j
-            x = (x ^ ((x >> 30) & ((1 << 34) - 1))) * (-4658895280553007687)
-            x = (x ^ ((x >> 27) & ((1 << 37) - 1))) * (-7723592293110705685)
-            return x ^ ((x >> 31) & ((1 << 33) - 1))
 
         bkt.copy_(lsr_mix64(torch.randperm(nb_rows, device="cuda") + (c.rank << 40)))
         pk = c.Column.empty(np.int64, n)
@@ -568,8 +575,25 @@ def bench_groupby(c):
     n = c.n
     lib.gx_groupby_set_algorithm(a.gb_algo, a.gb_split)
     lib.gx_groupby_set_partition_mode(a.gb_spec)
+    L.check(lib.gx_groupby_set_partition_bits(a.gb_pbits), "gx_groupby_set_partition_bits")
     gk = ops.random_column(np.int32, n, seed=7 + c.rank, lo=0, hi=1_000_000)
     gv = ops.random_column(np.float64, n, seed=8 + c.rank)
+    kdt, ktorch = np.int32, torch.int32
+    if a.gb_keys != "dense" and c.world == 1:
+        # sparse keys: the dense ids through a mixing BIJECTION (still exactly 1e6 groups, same group sizes), so the LDS tables
+        # see keys that hash like random numbers instead of the collision-free dense integers
+        ids = c.as_tensor(gk, torch.int32).to(torch.int64)
+        if a.gb_keys == "random":
+            x = ids & 0xFFFFFFFF
+            x = ((x ^ (x >> 16)) * 0x85EBCA6B) & 0xFFFFFFFF
+            x = ((x ^ (x >> 13)) * 0xC2B2AE35) & 0xFFFFFFFF
+            x = x ^ (x >> 16)
+            c.as_tensor(gk, torch.int32).copy_(torch.where(x >= 2**31, x - 2**32, x).to(torch.int32))
+        else:
+            kdt, ktorch = np.int64, torch.int64
+            gk = c.Column.empty(np.int64, n)
+            c.as_tensor(gk, torch.int64).copy_(lsr_mix64(ids))
+        del ids
     if c.world > 1:
         from cudf_amd import distributed as D
         local_ops = D.HipLocalOps()
@@ -584,7 +608,7 @@ def bench_groupby(c):
                 "rows": n, "ms_per_step": sec * 1e3, "rows_per_s": n * c.world / sec, "dtype": "f64", "roofline": None,
                 "cpu_baseline": None, "checked": "sum of counts == rows over all ranks"}
     mg = 1 << 20
-    ok, osum = c.Column.empty(np.int32, mg), c.Column.empty(np.float64, mg)
+    ok, osum = c.Column.empty(kdt, mg), c.Column.empty(np.float64, mg)
     ocv = c.Column.empty(np.int32, mg)
     ng = torch.zeros(1, dtype=torch.int64, device="cuda")
     nb = ctypes.c_size_t(0)
@@ -598,13 +622,14 @@ def bench_groupby(c):
     # ---- guard: counts add up to n, keys are distinct and in range, and sampled groups match a direct
     # device-side recomputation (count exact, f64 sum to 1e-11 relative: the kernel's own bar is 1 ulp)
     groups = int(ng.item())
-    kt = c.as_tensor(ok, torch.int32)[:groups]
+    kt = c.as_tensor(ok, ktorch)[:groups]
     st = c.as_tensor(osum, torch.float64)[:groups]
     ct = c.as_tensor(ocv, torch.int32)[:groups]
     assert int(ct.to(torch.int64).sum().item()) == n, "groupby: counts do not add up to the row count"
-    assert int(kt.min().item()) >= 0 and int(kt.max().item()) < 1_000_000, "groupby: key out of range"
+    if a.gb_keys == "dense":
+        assert int(kt.min().item()) >= 0 and int(kt.max().item()) < 1_000_000, "groupby: key out of range"
     assert int(torch.unique(kt).numel()) == groups, "groupby: duplicate group keys"
-    gkt, gvt = c.as_tensor(gk, torch.int32), c.as_tensor(gv, torch.float64)
+    gkt, gvt = c.as_tensor(gk, ktorch), c.as_tensor(gv, torch.float64)
     total_ref = float(gvt.sum().item())
     assert abs(float(st.sum().item()) - total_ref) <= 1e-9 * abs(total_ref), "groupby: sums do not add up"
     for gi in (0, groups // 3, groups - 1):
@@ -622,7 +647,8 @@ def bench_groupby(c):
     cpu = None
     if a.cpu and c.rank == 0:
         cpu = cpu_baseline_groupby(a.cpu_rows or 3e8, a.cpu_rows_pandas)
-    return {"workload": f"{n:.0e}-row groupby(int32 key, 1e6 groups).agg(float64 sum,count)", "rows": n,
+    kdesc = {"dense": "int32 key", "random": "sparse int32 key", "random64": "sparse int64 key"}[a.gb_keys]
+    return {"workload": f"{n:.0e}-row groupby({kdesc}, 1e6 groups).agg(float64 sum,count)", "rows": n,
             "ms_per_step": ms_per_step, "rows_per_s": n / sec, "dtype": "f64", "roofline": roofline, "cpu_baseline": cpu,
             "checked": "sum(count) == rows; distinct in-range keys; total and 3 sampled groups recomputed on the device"}
 
@@ -843,7 +869,7 @@ def main():
             "metric": METRIC, "value": head["rows_per_s"], "unit": "rows/s", "n_gpus": c.world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": head["ms_per_step"], "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": head["dtype"], "data": "synthetic",
-            "config": {"workload": head["workload"], "rows_per_gpu": c.n, "algo": args.algo, "gb_algo": args.gb_algo, "gb_spec": args.gb_spec,
+            "config": {"workload": head["workload"], "rows_per_gpu": c.n, "algo": args.algo, "gb_algo": args.gb_algo, "gb_spec": args.gb_spec, "gb_pbits": args.gb_pbits, "gb_keys": args.gb_keys,
                        "parallelism": (f"{c.world} ranks, row shards, one all-to-all exchange per step (RCCL over xGMI)"
                                        if c.world > 1 else "1 GPU")},
             "roofline": head["roofline"], "cpu_baseline": head["cpu_baseline"], "checked": head.get("checked"),

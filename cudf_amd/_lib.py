@@ -101,6 +101,7 @@ _PROTOS = {
     "gx_join_complement": (_i, [_p, _i64, _i64, _p, _p, _i64, _p, _p, _sz, _p]),
     "gx_groupby_set_algorithm": (None, [_i, _i]),
     "gx_groupby_set_partition_mode": (None, [_i]),
+    "gx_groupby_set_partition_bits": (_i, [_i]),
     "gx_group_heads": (_i, [_i, _p, _p, _p, _i64, _i, _p, _p]),
     "gx_group_offsets": (_i, [_p, _i64, _p, _p, _p, _p, _p, _sz, _p]),
     "gx_segmented_reduce": (_i, [_i, _p, _p, _p, _p, _i64, _i, _p, _p, _p, _sz, _p]),

@@ -129,6 +129,32 @@ struct gxd_comm {
   size_t pinned_elems = 0;
   Arena arena;
   double ms[3] = {0, 0, 0};
+  // Buffers of destroyed join tables, kept for the next build: hipFree / hipMalloc of multi-gigabyte blocks are
+  // device-synchronising and were seen to take SECONDS under a build / probe / destroy loop
+  // (profiles/r3_run14_alloc_probe.txt: 1.87 s for one 4.3 GB hipMalloc).  Released with the communicator.
+  std::vector<std::pair<void*, size_t>> pool;
+  int pool_get(size_t bytes, void** out)
+  {
+    int best = -1;
+    for (int i = 0; i < (int)pool.size(); ++i)
+      if (pool[i].second >= bytes && pool[i].second <= bytes + bytes / 4 + (1u << 20) && (best < 0 || pool[i].second < pool[best].second)) best = i;
+    if (best >= 0) {
+      *out = pool[best].first;
+      pool.erase(pool.begin() + best);
+      return 0;
+    }
+    hipError_t e = hipMalloc(out, bytes ? bytes : 1);
+    if (e != hipSuccess && !pool.empty()) {  // out of memory with cached buffers around: give them back and retry
+      for (auto& b : pool) (void)hipFree(b.first);
+      pool.clear();
+      e = hipMalloc(out, bytes ? bytes : 1);
+    }
+    return (int)e;
+  }
+  void pool_put(void* p, size_t bytes)
+  {
+    if (p) pool.emplace_back(p, bytes);
+  }
 };
 
 struct gxd_join {
@@ -142,6 +168,7 @@ struct gxd_join {
   int64_t nrows = 0;
   std::vector<long long> seg_counts, seg_bases;  // per segment: rows, first global row of the source rank's shard
   void* segtab = nullptr;                          // device copy: [nseg + 1] starts | [nseg] bases
+  size_t rows_bytes = 0, keys_bytes = 0;           // sizes of the pooled buffers (returned to the communicator's pool)
   int enc_shift = 0;                               // > 0: the table slots hold (source rank << enc_shift) | row at the source --
   void* bases_dev = nullptr;                       //      decoded by one streaming pass with these bases, no gather
 };
@@ -481,6 +508,8 @@ int gxd_comm_destroy(gxd_comm* c)
   if (!c) return 0;
   (void)hipDeviceSynchronize();
   c->arena.release();
+  for (auto& b : c->pool) (void)hipFree(b.first);
+  c->pool.clear();
   for (auto e : c->evP) (void)hipEventDestroy(e);
   if (c->evQ) (void)hipEventDestroy(c->evQ);
   if (c->evX) (void)hipEventDestroy(c->evX);
@@ -612,8 +641,10 @@ int gxd_join_build(gxd_comm* c, int key_dtype, const void* build_keys, int64_t n
     tr.mark("partition + exchange");
     // the received rows stay with the table (the arena's receive buffers are reused by every probe)
     j->nrows = ex.total;
-    GXD_HIP(hipMalloc(reinterpret_cast<void**>(&j->rows), (size_t)std::max<int64_t>(ex.total, 1) * 4));
-    GXD_HIP(hipMalloc(&j->keys_keep, (size_t)std::max<int64_t>(ex.total, 1) * ks));
+    j->rows_bytes = (size_t)std::max<int64_t>(ex.total, 1) * 4;
+    j->keys_bytes = (size_t)std::max<int64_t>(ex.total, 1) * ks;
+    GXD_HIP((hipError_t)c->pool_get(j->rows_bytes, reinterpret_cast<void**>(&j->rows)));
+    GXD_HIP((hipError_t)c->pool_get(j->keys_bytes, &j->keys_keep));
     GXD_HIP(hipMemcpy(j->rows, c->arena.p[Arena::RECV_ROWS], (size_t)ex.total * 4, hipMemcpyDeviceToDevice));
     GXD_HIP(hipMemcpy(j->keys_keep, c->arena.p[Arena::RECV_KEYS], (size_t)ex.total * ks, hipMemcpyDeviceToDevice));
     j->seg_counts = ex.seg_counts;
@@ -630,7 +661,7 @@ int gxd_join_build(gxd_comm* c, int key_dtype, const void* build_keys, int64_t n
   }
   tr.mark("keep rows");
   j->table_bytes = gx_join_table_bytes(ks, tn, 0.5);
-  GXD_HIP(hipMalloc(&j->table, j->table_bytes));
+  GXD_HIP((hipError_t)c->pool_get(j->table_bytes, &j->table));
   tr.mark("table allocation");
   if (tn >= (1 << 20) && gx_join_partition_bits(ks, j->table_bytes) > 0) {
     GXD_GX(with_tmp(c, Arena::TMP2, [&](void* t, size_t* b) {
@@ -650,9 +681,9 @@ int gxd_join_destroy(gxd_join* j)
 {
   if (!j) return 0;
   (void)hipDeviceSynchronize();
-  if (j->table) (void)hipFree(j->table);
-  if (j->rows) (void)hipFree(j->rows);
-  if (j->keys_keep) (void)hipFree(j->keys_keep);
+  j->comm->pool_put(j->table, j->table_bytes);
+  j->comm->pool_put(j->rows, j->rows_bytes);
+  j->comm->pool_put(j->keys_keep, j->keys_bytes);
   if (j->segtab) (void)hipFree(j->segtab);
   if (j->bases_dev) (void)hipFree(j->bases_dev);
   delete j;

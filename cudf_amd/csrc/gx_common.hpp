@@ -100,6 +100,32 @@ __device__ __forceinline__ void match_rank(uint32_t d, bool live, uint64_t activ
   count = (uint32_t)__builtin_popcount(m_lo) + (uint32_t)__builtin_popcount(m_hi);
 }
 
+// Rank of a key among the keys of its tile that go to the same bin, for FEW bins (<= 1 << NBITS, NBITS <= 4): the lanes of a
+// wave that share a bin are found with NBITS ballots, their leader reserves the whole group's ranks with ONE returning LDS
+// atomic and hands the base to the others through ds_bpermute.  With 1..16 bins the plain per-lane atomic serialises 4 to 64
+// lanes on one LDS address per instruction (the exchange partition of the sharded operators: 8 destination ranks).
+template <int NBITS>
+__device__ __forceinline__ uint32_t lds_rank_few(uint32_t* counters, uint32_t d, bool live)
+{
+  const uint64_t active = ballot(live);
+  uint32_t m_lo = (uint32_t)active, m_hi = (uint32_t)(active >> 32);
+#pragma unroll
+  for (int b = 0; b < NBITS; ++b) {
+    const int beta   = __builtin_amdgcn_sbfe(d, b, 1);  // 0 or -1
+    const uint64_t v = ballot(live && beta != 0);
+    m_lo             = __builtin_amdgcn_bitop3_b32(m_lo, (uint32_t)v, (uint32_t)beta, 0x90);
+    m_hi             = __builtin_amdgcn_bitop3_b32(m_hi, (uint32_t)(v >> 32), (uint32_t)beta, 0x90);
+  }
+  const uint32_t lower = __builtin_amdgcn_mbcnt_hi(m_hi, __builtin_amdgcn_mbcnt_lo(m_lo, 0u));
+  const uint32_t count = (uint32_t)__builtin_popcount(m_lo) + (uint32_t)__builtin_popcount(m_hi);
+  const uint64_t m     = ((uint64_t)m_hi << 32) | m_lo;
+  const int leader     = m ? __builtin_ctzll(m) : (int)lane_id();
+  uint32_t base        = 0;
+  if (live && lower == 0) base = atomicAdd(&counters[d], count);
+  base = (uint32_t)__builtin_amdgcn_ds_bpermute(leader << 2, (int)base);
+  return live ? base + lower : 0u;
+}
+
 __device__ __forceinline__ void match_rank8(uint32_t d, bool live, uint64_t active, uint32_t& lower, uint32_t& count)
 {
   match_rank<8>(d, live, active, lower, count);

@@ -182,7 +182,9 @@ __global__ void __launch_bounds__(GBT) k_compact(const unsigned long long* __res
 // sizeof(K)+sizeof(V), but every access is streaming; the global-atomic path above does ~4 random
 // memory-side atomics per row instead.
 // ------------------------------------------------------------------------------------------------
-constexpr int NPART  = 256;
+constexpr int NPART  = 512;          // MAXIMUM number of partitions (array sizes, launch bounds); 1 << d_gb_pbits are in use
+__device__ int d_gb_pbits = 9;       // partition bits in use (8 or 9): see gx_groupby_set_partition_bits
+static int g_gb_pbits     = 9;       // host mirror
 constexpr int PBT    = 512;          // scatter workgroup
 constexpr int PRPT   = 16;           // rows per thread -> 8192-row tiles
 constexpr int PTILE  = PBT * PRPT;
@@ -215,7 +217,7 @@ struct PartPlan {
 // work the same way).  Saves the 4 B/row histogram read: 0.7 of 8.3 ms at 1e9 rows, 42 -> 38 GB of HBM traffic.
 static inline uint32_t part_cap(int64_t n)
 {
-  const double mean = (double)n / (double)(NPART * NRANGE);
+  const double mean = (double)n / (double)((1 << g_gb_pbits) * NRANGE);
   const double cap  = mean + 8.0 * __builtin_sqrt(mean + 1.0) + 64.0;
   return (uint32_t)((((int64_t)cap + 31) / 32) * 32);
 }
@@ -235,8 +237,9 @@ __global__ void __launch_bounds__(256) k_part_hist(const K* __restrict__ keys, c
 {
   __shared__ uint32_t s_h[NPART];
   if (gated && plan->overflow == 0) return;  // the speculative pass held
-  s_h[threadIdx.x] = 0;
+  for (int i = threadIdx.x; i < NPART; i += 256) s_h[i] = 0;
   __syncthreads();
+  const int psh        = 64 - d_gb_pbits;
   const int r          = blockIdx.x % NRANGE;  // block b -> XCD b % 8 reads the rows it will scatter
   const int64_t jb     = blockIdx.x / NRANGE;
   const int64_t nb     = gridDim.x / NRANGE;
@@ -267,7 +270,7 @@ __global__ void __launch_bounds__(256) k_part_hist(const K* __restrict__ keys, c
         const int64_t i = i0 + (int64_t)u * 256 * V;
 #pragma unroll
         for (int e = 0; e < V; ++e)
-          if (i + e < rend && (!kvalid || bit_is_set(kvalid, i + e))) atomicAdd(&s_h[part_hash<K>(v[u].k[e]) >> 56], 1u);
+          if (i + e < rend && (!kvalid || bit_is_set(kvalid, i + e))) atomicAdd(&s_h[part_hash<K>(v[u].k[e]) >> psh], 1u);
       }
     }
   } else {
@@ -282,13 +285,15 @@ __global__ void __launch_bounds__(256) k_part_hist(const K* __restrict__ keys, c
 #pragma unroll
       for (int u = 0; u < U; ++u) {
         const int64_t i = i0 + (int64_t)u * 256;
-        if (i < rend && (!kvalid || bit_is_set(kvalid, i))) atomicAdd(&s_h[part_hash<K>(k[u]) >> 56], 1u);
+        if (i < rend && (!kvalid || bit_is_set(kvalid, i))) atomicAdd(&s_h[part_hash<K>(k[u]) >> psh], 1u);
       }
     }
   }
   __syncthreads();
-  const uint32_t c = s_h[threadIdx.x];
-  if (c) atomicAdd(&plan->count[nrange == 1 ? 0 : r][threadIdx.x], (unsigned long long)c);
+  for (int i = threadIdx.x; i < NPART; i += 256) {
+    const uint32_t c = s_h[i];
+    if (c) atomicAdd(&plan->count[nrange == 1 ? 0 : r][i], (unsigned long long)c);
+  }
 }
 
 __global__ void __launch_bounds__(NPART) k_part_offsets(PartPlan* plan, int gated = 0)
@@ -319,8 +324,7 @@ __global__ void __launch_bounds__(PBT) k_part_scatter(const K* __restrict__ keys
   constexpr int ESZ = sizeof(K) > sizeof(V) ? sizeof(K) : sizeof(V);
   extern __shared__ __attribute__((aligned(16))) char smem[];
   char* s_buf       = smem;                                             // PTILE * ESZ
-  uint8_t* s_bin    = reinterpret_cast<uint8_t*>(smem + (size_t)PTILE * ESZ);  // PTILE
-  uint8_t* s_flag   = s_bin + PTILE;                                    // PTILE (HAS_VV)
+  uint8_t* s_flag   = reinterpret_cast<uint8_t*>(smem + (size_t)PTILE * ESZ);  // PTILE (HAS_VV)
   uint32_t* s_cnt   = reinterpret_cast<uint32_t*>(s_flag + (HAS_VV ? PTILE : 0));  // NPART
   uint32_t* s_start = s_cnt + NPART;                                    // NPART
   unsigned long long* s_delta = reinterpret_cast<unsigned long long*>(s_start + NPART);  // NPART
@@ -328,6 +332,7 @@ __global__ void __launch_bounds__(PBT) k_part_scatter(const K* __restrict__ keys
   __shared__ uint32_t s_total;
 
   const unsigned tid = threadIdx.x;
+  const int psh      = 64 - d_gb_pbits;
   const int64_t tile = nrange == 1 ? (int64_t)blockIdx.x : xcd_swizzle(blockIdx.x, gridDim.x);
   const int64_t rper = range_tiles(n);
   const int range    = nrange == 1 ? 0 : ((rper > 0 && tile / rper < NRANGE - 1) ? (int)(tile / rper) : NRANGE - 1);
@@ -348,12 +353,11 @@ __global__ void __launch_bounds__(PBT) k_part_scatter(const K* __restrict__ keys
     vflag[j]        = HAS_VV ? (uint8_t)((idx < nvalid) && bit_is_set(vvalid, i)) : (uint8_t)1;
   }
   __syncthreads();
-  uint32_t rank[PRPT];
-  uint32_t part[PRPT];
+  uint32_t packed[PRPT];  // partition << 16 | rank inside (tile, partition)
 #pragma unroll
   for (int j = 0; j < PRPT; ++j) {
-    part[j] = (uint32_t)(part_hash<K>(key[j]) >> 56);
-    rank[j] = live[j] ? atomicAdd(&s_cnt[part[j]], 1u) : 0u;
+    const uint32_t part = (uint32_t)(part_hash<K>(key[j]) >> psh);
+    packed[j]           = (part << 16) | (live[j] ? atomicAdd(&s_cnt[part], 1u) : 0u);
   }
   __syncthreads();
   const uint32_t c  = (tid < NPART) ? s_cnt[tid] : 0u;
@@ -372,14 +376,37 @@ __global__ void __launch_bounds__(PBT) k_part_scatter(const K* __restrict__ keys
   if (tid == 0) s_total = total;
   __syncthreads();
   const int ntot = (int)s_total;
-  // ---- values (and flags, partition ids) through LDS
+  // ---- keys through LDS first: the partition of the element a thread writes out is recomputed from its key and kept
+  // in a register for the value pass (round 2 staged one byte per row in LDS; with 512 partitions that would be two,
+  // and the second workgroup per CU would no longer fit)
+  K* s_k = reinterpret_cast<K*>(s_buf);
+#pragma unroll
+  for (int j = 0; j < PRPT; ++j) {
+    if (live[j]) s_k[s_start[packed[j] >> 16] + (packed[j] & 0xFFFFu)] = key[j];
+  }
+  __syncthreads();
+  unsigned short obin[PRPT];
+#pragma unroll
+  for (int j = 0; j < PRPT; ++j) {
+    const int i = j * PBT + (int)tid;
+    obin[j]     = 0xFFFFu;
+    if (i < ntot) {
+      const K k                    = s_k[i];
+      const uint32_t b             = (uint32_t)(part_hash<K>(k) >> psh);
+      const unsigned long long dst = s_delta[b] + (unsigned long long)i;
+      if (cap && dst >= (unsigned long long)(b * NRANGE + range + 1) * cap) continue;  // beyond the slot
+      pkeys[dst] = k;
+      obin[j]    = (unsigned short)b;
+    }
+  }
+  __syncthreads();
+  // ---- values (and flags) through the same buffer
   V* s_v = reinterpret_cast<V*>(s_buf);
 #pragma unroll
   for (int j = 0; j < PRPT; ++j) {
     if (live[j]) {
-      const uint32_t pos = s_start[part[j]] + rank[j];
+      const uint32_t pos = s_start[packed[j] >> 16] + (packed[j] & 0xFFFFu);
       s_v[pos]           = val[j];
-      s_bin[pos]         = (uint8_t)part[j];
       if (HAS_VV) s_flag[pos] = vflag[j];
     }
   }
@@ -387,28 +414,10 @@ __global__ void __launch_bounds__(PBT) k_part_scatter(const K* __restrict__ keys
 #pragma unroll
   for (int j = 0; j < PRPT; ++j) {
     const int i = j * PBT + (int)tid;
-    if (i < ntot) {
-      const unsigned long long dst = s_delta[s_bin[i]] + (unsigned long long)i;
-      if (cap && dst >= (unsigned long long)(s_bin[i] * NRANGE + range + 1) * cap) continue;  // beyond the slot
+    if (obin[j] != 0xFFFFu) {
+      const unsigned long long dst = s_delta[obin[j]] + (unsigned long long)i;
       pvals[dst]                   = s_v[i];
       if (HAS_VV) pflags[dst] = s_flag[i];
-    }
-  }
-  __syncthreads();
-  // ---- keys through the same buffer
-  K* s_k = reinterpret_cast<K*>(s_buf);
-#pragma unroll
-  for (int j = 0; j < PRPT; ++j) {
-    if (live[j]) s_k[s_start[part[j]] + rank[j]] = key[j];
-  }
-  __syncthreads();
-#pragma unroll
-  for (int j = 0; j < PRPT; ++j) {
-    const int i = j * PBT + (int)tid;
-    if (i < ntot) {
-      const unsigned long long dst = s_delta[s_bin[i]] + (unsigned long long)i;
-      if (cap && dst >= (unsigned long long)(s_bin[i] * NRANGE + range + 1) * cap) continue;
-      pkeys[dst] = s_k[i];
     }
   }
 }
@@ -541,7 +550,7 @@ __global__ void __launch_bounds__(ABT) k_part_aggregate(const K* __restrict__ pk
         slot      = S;
         s_special = 1u;  // benign race: every writer stores 1
       } else {
-        uint32_t h = (uint32_t)(((part_hash<K>(key) >> 24) & 0xFFFFFFFFull) * (uint64_t)S >> 32);
+        uint32_t h = (uint32_t)(((part_hash<K>(key) >> (32 - d_gb_pbits)) & 0xFFFFFFFFull) * (uint64_t)S >> 32);
         for (int probes = 0; probes < S; ++probes) {
           K cur = l_key[h];
           if (cur == EMPTYK) {
@@ -610,7 +619,7 @@ static inline uint32_t log2_cap(int64_t max_groups)
 // (profiles/r2_xp_minmax_matrix.txt) -- and beyond 7/8 the rows spill to the global table one by one.
 static inline int lds_nsub(int64_t max_groups, int lds_slots)
 {
-  const double per_part = (double)(max_groups < 1 ? 1 : max_groups) / NPART;
+  const double per_part = (double)(max_groups < 1 ? 1 : max_groups) / (double)(1 << g_gb_pbits);
   int nsub = 1;
   while (nsub < 16 && per_part / nsub > 0.65 * lds_slots) nsub *= 2;
   return nsub;
@@ -626,7 +635,7 @@ static inline bool part_speculative(int64_t n) { return g_gb_nrange == NRANGE &&
 // elements of the partitioned arrays: the padded slots of the speculative pass, or n
 static inline size_t part_elems(int64_t n)
 {
-  const size_t padded = (size_t)NPART * NRANGE * part_cap(n);
+  const size_t padded = ((size_t)NRANGE << g_gb_pbits) * part_cap(n);
   return part_speculative(n) && padded > (size_t)n ? padded : (size_t)n;
 }
 // between the speculative and the exact pass: the fill counters become position cursors again (the exact k_part_offsets sets them)
@@ -646,7 +655,7 @@ int launch_partitioned(const K* keys, const uint32_t* kvalid, const V* vals, con
   if (hb > 256) hb = 256;
   if (hb < 1) hb = 1;
   constexpr int ESZ      = sizeof(K) > sizeof(V) ? sizeof(K) : sizeof(V);
-  constexpr size_t lds_s = (size_t)PTILE * ESZ + PTILE + (HAS_VV ? PTILE : 0) + NPART * 4 * 2 + NPART * 8 + 64;
+  constexpr size_t lds_s = (size_t)PTILE * ESZ + (HAS_VV ? PTILE : 0) + NPART * 4 * 2 + NPART * 8 + 64;
   auto ks                = k_part_scatter<K, V, HAS_VV>;
   constexpr int S        = lds_slots<K, HAS_VV>();
   constexpr size_t lds_a = (size_t)(S + 1) * 16 + (size_t)(S + 2) * sizeof(K) + (size_t)(S + 1) * 4 * (HAS_VV ? 2 : 1);
@@ -660,7 +669,7 @@ int launch_partitioned(const K* keys, const uint32_t* kvalid, const V* vals, con
   const int nsplit    = g_gb_nsplit;
   const int nsub      = lds_nsub(max_groups, S);
   const unsigned sgrd = (unsigned)div_up(n, PTILE);
-  const unsigned agrd = (unsigned)(NPART * nsplit * nsub);
+  const unsigned agrd = (unsigned)((1 << g_gb_pbits) * nsplit * nsub);
   const bool spec     = part_speculative(n);
   int gated           = 0;
   if (spec) {  // speculative pass: no histogram, padded slots (see PartPlan)
@@ -791,6 +800,14 @@ int gx_groupby_sum_count(int key_dtype, const void* keys, const uint32_t* keys_v
 }
 
 void gx_groupby_set_partition_mode(int speculative) { gx::gb::g_gb_spec = speculative == 2 ? 2 : (speculative ? 1 : 0); }
+
+int gx_groupby_set_partition_bits(int bits)
+{
+  const int v = bits == 8 ? 8 : 9;
+  GX_HIP_TRY(hipMemcpyToSymbol(HIP_SYMBOL(gx::gb::d_gb_pbits), &v, sizeof(int)));
+  gx::gb::g_gb_pbits = v;
+  return 0;
+}
 
 void gx_groupby_set_algorithm(int algo, int nsplit)
 {
@@ -1062,7 +1079,7 @@ __global__ void __launch_bounds__(ABT) k_part_minmax(const K* __restrict__ pkeys
         slot      = S;
         s_special = 1u;  // benign race: every writer stores 1
       } else {
-        uint32_t h = (uint32_t)(((part_hash<K>(key) >> 24) & 0xFFFFFFFFull) * (uint64_t)S >> 32);
+        uint32_t h = (uint32_t)(((part_hash<K>(key) >> (32 - d_gb_pbits)) & 0xFFFFFFFFull) * (uint64_t)S >> 32);
         for (int probes = 0; probes < S; ++probes) {
           K cur = l_key[h];
           if (cur == EMPTYK) {
@@ -1126,7 +1143,7 @@ int launch_partitioned_minmax(const K* keys, const uint32_t* kvalid, const V* va
   if (hb > 256) hb = 256;
   if (hb < 1) hb = 1;
   constexpr int ESZ      = sizeof(K) > sizeof(V) ? sizeof(K) : sizeof(V);
-  constexpr size_t lds_s = (size_t)PTILE * ESZ + PTILE + (HAS_VV ? PTILE : 0) + NPART * 4 * 2 + NPART * 8 + 64;
+  constexpr size_t lds_s = (size_t)PTILE * ESZ + (HAS_VV ? PTILE : 0) + NPART * 4 * 2 + NPART * 8 + 64;
   auto ks                = k_part_scatter<K, V, HAS_VV>;
   constexpr int S        = lds_slots_mm<K, HAS_VV>();
   constexpr size_t lds_a = (size_t)(S + 1) * 16 + (size_t)(S + 2) * sizeof(K) + (size_t)(S + 1) * 4;
@@ -1140,7 +1157,7 @@ int launch_partitioned_minmax(const K* keys, const uint32_t* kvalid, const V* va
   const int nsplit    = g_gb_nsplit;
   const int nsub      = lds_nsub(max_groups, S);
   const unsigned sgrd = (unsigned)div_up(n, PTILE);
-  const unsigned agrd = (unsigned)(NPART * nsplit * nsub);
+  const unsigned agrd = (unsigned)((1 << g_gb_pbits) * nsplit * nsub);
   const bool spec     = part_speculative(n);
   int gated           = 0;
   if (spec) {

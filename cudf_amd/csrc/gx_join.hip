@@ -610,7 +610,8 @@ __global__ void __launch_bounds__(BTt) k_pj_scatter(const K* __restrict__ keys, 
   for (int j = 0; j < RPT; ++j) {
     const int idx           = j * BTt + (int)tid;
     const unsigned int part = part_of(key[j]);
-    const unsigned int rank = (idx < nvalid) ? atomicAdd(&s_cnt[part], 1u) : 0u;
+    // few bins (the exchange partition: <= 16 destination ranks): wave-aggregated ranks, see lds_rank_few
+    const unsigned int rank = pbits <= 4 ? lds_rank_few<4>(s_cnt, part, idx < nvalid) : ((idx < nvalid) ? atomicAdd(&s_cnt[part], 1u) : 0u);
     packed[j]               = (part << 16) | rank;
   }
   __syncthreads();

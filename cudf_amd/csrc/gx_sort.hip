@@ -1015,8 +1015,9 @@ __global__ void __launch_bounds__(GX_WAVE) k_plan2(SortPlan* plan, const uint32_
 template <typename KeyT, int KIND, bool HAS_VAL, int CL2>
 __device__ __forceinline__ void pairs_write_out(KeyT* s_keys, const KeyT* __restrict__ in_cell, KeyT* __restrict__ out,
                                                 const uint32_t* __restrict__ vin_cell, uint32_t* __restrict__ vout,
-                                                int64_t start, uint32_t m, int shift2, KeyT desc_mask)
+                                                int64_t start, uint32_t m, int shift2, KeyT desc_mask, bool write_keys = true)
 {
+  // write_keys = false (sorted_order: only the permutation is asked for): the 8 B/row key write-back is skipped
   // in_cell / vin_cell point at the cell's slot; out / vout are indexed from `start`
   const KeyT* in      = in_cell - start;
   const uint32_t* vin = vin_cell ? vin_cell - start : nullptr;
@@ -1032,11 +1033,11 @@ __device__ __forceinline__ void pairs_write_out(KeyT* s_keys, const KeyT* __rest
     if ((uint32_t)i < m) {
       const KeyT wd = s_keys[i];
       pos[j]        = (uint32_t)wd & ((1u << LS_POS_BITS) - 1u);
-      if (KIND != K_FLOAT) out[start + i] = to_sortable<KeyT, KIND>(hi | ((wd >> LS_POS_BITS) & lowmask), desc_mask);
+      if (KIND != K_FLOAT && write_keys) out[start + i] = to_sortable<KeyT, KIND>(hi | ((wd >> LS_POS_BITS) & lowmask), desc_mask);
     }
   }
   __syncthreads();
-  if (KIND == K_FLOAT) {
+  if (KIND == K_FLOAT && write_keys) {
 #pragma unroll
     for (int j = 0; j < LS_KPT; ++j) {
       const int i = j * LS_BT + (int)tid;
@@ -1212,7 +1213,7 @@ __global__ void __launch_bounds__((1 << CL2) / 16, 4) k_local_sort(const KeyT* i
       }
       __syncthreads();
       if (PAIRS) {
-        pairs_write_out<KeyT, KIND, HAS_VAL, CL2>(s_keys, in + start, out, HAS_VAL ? vin + start : nullptr, vout, start, m, hy.shift2, desc_mask_in);
+        pairs_write_out<KeyT, KIND, HAS_VAL, CL2>(s_keys, in + start, out, HAS_VAL ? vin + start : nullptr, vout, start, m, hy.shift2, desc_mask_in, !(exp & 64));
         return;
       }
 #pragma unroll
@@ -1298,7 +1299,7 @@ __global__ void __launch_bounds__((1 << CL2) / 16, 4) k_local_sort(const KeyT* i
     return;
   }
   if (PAIRS) {
-    pairs_write_out<KeyT, KIND, HAS_VAL, CL2>(s_keys, in + start, out, HAS_VAL ? vin + start : nullptr, vout, start, m, hy.shift2, desc_mask_in);
+    pairs_write_out<KeyT, KIND, HAS_VAL, CL2>(s_keys, in + start, out, HAS_VAL ? vin + start : nullptr, vout, start, m, hy.shift2, desc_mask_in, !(exp & 64));
     return;
   }
 #pragma unroll
@@ -1979,7 +1980,7 @@ int sort_impl(const void* keys_in, void* keys_out, const int32_t* vals_in, int32
       m.out       = bufA;
       m.base      = base1;
       m.level     = 0;
-      m.exp       = 0;
+      m.exp       = (HAS_VAL && keys_out == nullptr) ? 64 : 0;  // bit 6: the caller wants the permutation only (sorted_order): no key write-back
       m.cellcount = hist2;
       m.cellcap   = 1u << hc.cl2;
       if (!cursor_marked) prof_mark_h(0, stream);

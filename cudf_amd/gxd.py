@@ -54,6 +54,12 @@ class _Results:
             return t.data_ptr()
         self.cb = _ALLOC(alloc)
 
+    def release(self):
+        """break the cycle self -> cb -> alloc closure -> self: without it the result buffers of every call stay alive
+        until the cyclic garbage collector runs (8 GB per 1e9-row sort: profiles/r3_run14_alloc_probe.txt)"""
+        self.bufs = []
+        self.cb = None
+
     def take(self, ptr, count: int, dtype: torch.dtype) -> torch.Tensor:
         if count == 0 or not ptr:
             return torch.empty(0, dtype=dtype, device="cuda")
@@ -117,19 +123,25 @@ class Communicator:
         keys = keys.contiguous()
         res = _Results()
         out, n = ctypes.c_void_p(), ctypes.c_int64()
-        _check(_lib.gxd_sort(self._h, gx_dtype(_np_dtype(keys)), keys.data_ptr(), keys.numel(), chunks, int(force_exchange), res.cb, None,
-                             ctypes.byref(out), ctypes.byref(n), _stream()), "gxd_sort")
-        return res.take(out.value, n.value, keys.dtype)
+        try:
+            _check(_lib.gxd_sort(self._h, gx_dtype(_np_dtype(keys)), keys.data_ptr(), keys.numel(), chunks, int(force_exchange), res.cb, None,
+                                 ctypes.byref(out), ctypes.byref(n), _stream()), "gxd_sort")
+            return res.take(out.value, n.value, keys.dtype)
+        finally:
+            res.release()
 
     def groupby_sum_count(self, keys: torch.Tensor, vals: torch.Tensor, max_groups: int = 0, force_exchange: bool = False):
         keys, vals = keys.contiguous(), vals.contiguous()
         res = _Results()
         ok, os_, oc, g = ctypes.c_void_p(), ctypes.c_void_p(), ctypes.c_void_p(), ctypes.c_int64()
-        _check(_lib.gxd_groupby_sum_count(self._h, gx_dtype(_np_dtype(keys)), keys.data_ptr(), gx_dtype(_np_dtype(vals)), vals.data_ptr(),
-                                          keys.numel(), max_groups, int(force_exchange), res.cb, None, ctypes.byref(ok), ctypes.byref(os_),
-                                          ctypes.byref(oc), ctypes.byref(g), _stream()), "gxd_groupby_sum_count")
-        sdt = torch.float64 if vals.dtype.is_floating_point else torch.int64
-        return res.take(ok.value, g.value, keys.dtype), res.take(os_.value, g.value, sdt), res.take(oc.value, g.value, torch.int64)
+        try:
+            _check(_lib.gxd_groupby_sum_count(self._h, gx_dtype(_np_dtype(keys)), keys.data_ptr(), gx_dtype(_np_dtype(vals)), vals.data_ptr(),
+                                              keys.numel(), max_groups, int(force_exchange), res.cb, None, ctypes.byref(ok), ctypes.byref(os_),
+                                              ctypes.byref(oc), ctypes.byref(g), _stream()), "gxd_groupby_sum_count")
+            sdt = torch.float64 if vals.dtype.is_floating_point else torch.int64
+            return res.take(ok.value, g.value, keys.dtype), res.take(os_.value, g.value, sdt), res.take(oc.value, g.value, torch.int64)
+        finally:
+            res.release()
 
 
 class HashJoin:
@@ -148,9 +160,12 @@ class HashJoin:
             raise TypeError("Mismatch in joining column data types")
         res = _Results()
         ol, orr, n = ctypes.c_void_p(), ctypes.c_void_p(), ctypes.c_int64()
-        _check(_lib.gxd_join_probe(self._h, probe_keys.data_ptr(), probe_keys.numel(), chunks, res.cb, None, ctypes.byref(ol), ctypes.byref(orr),
-                                   ctypes.byref(n), _stream()), "gxd_join_probe")
-        return res.take(ol.value, n.value, torch.int64), res.take(orr.value, n.value, torch.int64)
+        try:
+            _check(_lib.gxd_join_probe(self._h, probe_keys.data_ptr(), probe_keys.numel(), chunks, res.cb, None, ctypes.byref(ol), ctypes.byref(orr),
+                                       ctypes.byref(n), _stream()), "gxd_join_probe")
+            return res.take(ol.value, n.value, torch.int64), res.take(orr.value, n.value, torch.int64)
+        finally:
+            res.release()
 
     def close(self):
         if self._h:

@@ -95,6 +95,11 @@ void gx_groupby_set_algorithm(int algo, int nsplit);
  * (skewed keys); 0 = always the exact path; 2 = speculative for every n (tests). */
 void gx_groupby_set_partition_mode(int speculative);
 
+/* A/B knob (process-wide, synchronous): hash partitions of the LDS-partitioned groupby, 2^bits with bits = 8 or 9
+ * (default 9 since round 3: half as many groups per LDS table -- keys that hash like random numbers stay below 35 % load at
+ * 1e6 groups -- at the price of 16-row instead of 32-row runs in the scatter). */
+int gx_groupby_set_partition_bits(int bits);
+
 #ifdef __cplusplus
 }
 #endif

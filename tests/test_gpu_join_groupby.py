@@ -417,7 +417,8 @@ def test_groupby_scan_matches_oracle(gx):
 @pytest.mark.parametrize("spec", [2, 0])
 @pytest.mark.parametrize("shape", ["uniform", "hot_key", "one_partition"])
 @pytest.mark.parametrize("nulls", [False, True])
-def test_groupby_speculative_partition_pass(gx, spec, shape, nulls):
+@pytest.mark.parametrize("pbits", [9, 8])
+def test_groupby_speculative_partition_pass(gx, spec, shape, nulls, pbits):
     """Round 3: the partition pass of the LDS-partitioned groupby runs without its histogram into padded (partition, XCD range)
     slots (spec = 2 forces that at this size; by default it starts at 2^22 rows) and falls back ON THE DEVICE to the exact
     histogram path when a slot overflows: uniform keys (speculation holds), one hot key and keys confined to one partition
@@ -439,6 +440,7 @@ def test_groupby_speculative_partition_pass(gx, spec, shape, nulls):
     kv = (rng.random(n) > 0.04) if nulls else None
     vv = (rng.random(n) > 0.2) if nulls else None
     _lib.lib.gx_groupby_set_partition_mode(spec)
+    assert _lib.lib.gx_groupby_set_partition_bits(pbits) == 0  # 512 partitions (default since round 3) / the round-2 layout
     try:
         kc, vc = Column.from_numpy(keys, kv), Column.from_numpy(vals, vv)
         k, s, cv, ca = ops.groupby_sum_count(kc, vc)
@@ -457,3 +459,4 @@ def test_groupby_speculative_partition_pass(gx, spec, shape, nulls):
         np.testing.assert_array_equal(mx.to_numpy()[o2][em], res["max"][0][em])
     finally:
         _lib.lib.gx_groupby_set_partition_mode(1)
+        _lib.lib.gx_groupby_set_partition_bits(9)
