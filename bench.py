@@ -758,7 +758,7 @@ def bench_multikey(c, which):
             ref = float(tv[sel].sum().item())
             assert abs(float(c.as_tensor(sm, torch.float64)[gi].item()) - ref) <= 1e-11 * max(1.0, abs(ref))
         bpr = 16 + 8
-        kname = "gx_hash_rows64 + hash ids + LDS-partitioned groupby (2 x int64 keys)"
+        kname = "k_wide_scatter + k_wide_aggregate (one partition pass, rows compared in the LDS tables; 2 x int64 keys)"
         wl = f"{n:.0e}-row groupby(2 int64 key columns, 1e6 groups).agg(float64 sum,count)"
         checked = "sum(count) == rows; distinct key pairs; 3 sampled groups recomputed on the device"
     ach = bpr * n / sec / 1e9

@@ -69,6 +69,7 @@ _PROTOS = {
     "gx_join_count": (_i, [_i, _p, _p, _i64, _p, ctypes.c_size_t, _p, _p]),
     "gx_join_probe": (_i, [_i, _p, _p, _i64, _p, ctypes.c_size_t, _i, _p, _p, _i64, _p, _p]),
     "gx_groupby_sum_count": (_i, [_i, _p, _p, _i, _p, _p, _i64, _i64, _p, _p, _p, _p, _p, _p, _sz, _p]),
+    "gx_groupby_sum_count_wide": (_i, [_i, ctypes.POINTER(_p), _i, _p, _i64, _i64, ctypes.POINTER(_p), _p, _p, _p, _p, _sz, _p]),
     "gx_groupby_min_max": (_i, [_i, _p, _p, _i, _p, _p, _i64, _i64, _p, _p, _p, _p, _p, _p, _sz, _p]),
     "gx_valid_from_counts": (_i, [_p, _i64, _p, _p, _p]),
     "gx_mean_from_sum": (_i, [_i, _p, _p, _i64, _p, _p]),

@@ -1462,3 +1462,489 @@ int gx_groupby_arg_select(int val_dtype, const void* vals, const uint32_t* vals_
 }
 
 }  // extern "C"
+
+// ------------------------------------------------------------------------------------------------------------------
+// Round 3: groupby on SEVERAL key columns in one partition pass, rows compared inside the LDS table
+// (the reference hashes the row once and compares rows in its probe: primitive_row_operators.cuh:95-163, 247-268).
+// Round 2 reduced a multi-column key to ONE 8-byte word per row (packed values or a certified 64-bit row hash) and paid
+// for the certificate with one extra MIN/MAX groupby per key column (66 ms for 2 x int64 keys at 1e9 rows).  Here the W
+// key words of a row travel together:
+//   k_wide_scatter    one radix-partition pass on the top bits of the row hash; the hash column goes through LDS first so
+//                     that the partition of the element a thread writes out is known, then every key column and the value
+//                     column follow through the same 64 KiB buffer (columns are re-read per pass -- Infinity-Cache hits --
+//                     instead of being held in registers: W x 16 x 2 registers do not fit next to a second workgroup);
+//   k_wide_aggregate  one 1024-thread workgroup per partition: open addressing on a 32-bit tag {busy, 30 hash bits} claimed
+//                     by CAS, then the W key words are written and the tag is released; a row that meets an equal tag waits
+//                     for the release and compares the W words, so two different rows that share 30 tag bits -- or all 64
+//                     hash bits -- simply occupy two slots.  A partition's groups are complete (every row of a group hashes
+//                     to it), so they go straight to the output: no global table, no certificate.
+// Speculative padded slots as in the single-key path; a slot or LDS table that overflows, or more than max_groups groups,
+// is reported through *ngroups (-2 / -1) and the caller falls back to the round-2 path / retries with a larger bound.
+// No nulls (the host takes the round-2 path for nullable keys or values).
+// ------------------------------------------------------------------------------------------------------------------
+namespace gx {
+namespace gb {
+
+constexpr int WMAX = 4;
+struct WideCols {
+  const unsigned long long* k[WMAX];
+};
+struct WideOut {
+  unsigned long long* k[WMAX];
+};
+__device__ __forceinline__ unsigned long long wide_mix(unsigned long long h, unsigned long long k)
+{
+  h = (h ^ k) * 0xFF51AFD7ED558CCDull;
+  return h ^ (h >> 32);
+}
+__device__ __forceinline__ unsigned long long wide_fin(unsigned long long h)
+{
+  h *= 0xC4CEB9FE1A85EC53ull;
+  return h ^ (h >> 29);
+}
+
+struct WidePlan {
+  unsigned long long cursor[NRANGE][NPART];  // rows written to slot (partition, range)
+  uint32_t samp[NRANGE][NPART];               // sample histogram of the partition digit, per input range
+  uint32_t slot0[NRANGE][NPART];              // first row of slot (range, partition) in the partitioned arrays ...
+  uint32_t cap0[NRANGE][NPART];               // ... and its capacity
+  alignas(128) unsigned int overflow;         // a slot or an LDS table outgrew its capacity
+  alignas(128) unsigned long long ngroups;    // output cursor
+};
+
+// Slot capacities come from a SAMPLE of the rows (every stride-th 64-row chunk), as in the sort's cursor path: rows of one
+// group all go to one partition, so partition sizes carry the variance of the GROUP sizes -- 1e6 groups over 512 partitions
+// are uneven by +-2.3 %, far beyond the 8 sigma of row-level noise a fixed mean + margin allows (the first version of this
+// path overflowed on BASELINE-like inputs for exactly that reason); a sample sees the groups.
+template <int W>
+__global__ void __launch_bounds__(256) k_wide_sample(WideCols keys, int64_t n, WidePlan* plan, int stride, int64_t range_rows)
+{
+  __shared__ uint32_t s_hist[NRANGE * NPART];
+  const unsigned tid = threadIdx.x, lane = lane_id();
+  for (int i = tid; i < NRANGE * NPART; i += 256) s_hist[i] = 0;
+  __syncthreads();
+  const int psh         = 64 - d_gb_pbits;
+  const int64_t step    = (int64_t)stride * GX_WAVE;
+  const int64_t nchunks = div_up(n, step);
+  const int64_t nw      = (int64_t)gridDim.x * 4;
+  for (int64_t c = (int64_t)blockIdx.x * 4 + tid / GX_WAVE; c < nchunks; c += nw) {
+    const int64_t row = c * step + lane;
+    const bool live   = row < n;
+    unsigned long long x = 0x9E3779B97F4A7C15ull;
+#pragma unroll
+    for (int w = 0; w < W; ++w) x = wide_mix(x, keys.k[w][live ? row : 0]);
+    x = wide_fin(x);
+    const int64_t r64 = range_rows > 0 ? row / range_rows : (int64_t)(NRANGE - 1);
+    const int r       = r64 < NRANGE - 1 ? (int)r64 : NRANGE - 1;
+    (void)lds_rank(s_hist + r * NPART, (uint32_t)(x >> psh), live);
+  }
+  __syncthreads();
+  for (int i = tid; i < NRANGE * NPART; i += 256) {
+    const uint32_t c = s_hist[i];
+    if (c) atomicAdd(&plan->samp[i / NPART][i % NPART], c);
+  }
+}
+
+__global__ void __launch_bounds__(NPART) k_wide_plan(WidePlan* plan, int64_t n, int stride, int64_t range_rows, unsigned long long elems)
+{
+  __shared__ uint32_t s_tmp[NPART / GX_WAVE + 1];
+  const int t = threadIdx.x;
+  uint32_t cap[NRANGE];
+  uint32_t sum = 0;
+  for (int r = 0; r < NRANGE; ++r) {
+    const uint32_t c = plan->samp[r][t];
+    uint32_t total;
+    (void)block_exclusive_scan<NPART>(c, 0u, SumOp(), s_tmp, &total);
+    const int64_t b    = (int64_t)r * range_rows < n ? (int64_t)r * range_rows : n;
+    const int64_t e    = (r == NRANGE - 1) ? n : (b + range_rows < n ? b + range_rows : n);
+    const double rows  = (double)(e - b);
+    const double scale = total ? rows / (double)total : 0.0;
+    double cp          = (double)c * scale + 8.0 * scale * __builtin_sqrt((double)c + 1.0) + 2.0 * stride * GX_WAVE + 64.0;
+    if (cp > rows) cp = rows;
+    cap[r] = ((uint32_t)cp + 15u) & ~15u;
+    sum += cap[r];
+  }
+  uint32_t total;
+  uint32_t run = block_exclusive_scan<NPART>(sum, 0u, SumOp(), s_tmp, &total);
+  if ((unsigned long long)total > elems) {
+    if (t == 0) plan->overflow = 1u;
+    return;
+  }
+  for (int r = 0; r < NRANGE; ++r) {  // the NRANGE slots of a partition are neighbours
+    plan->slot0[r][t] = run;
+    plan->cap0[r][t]  = cap[r];
+    run += cap[r];
+  }
+}
+
+// rows the partitioned arrays must hold: n + the slack k_wide_plan hands out (Cauchy-Schwarz over the slots)
+static inline size_t wide_elems(int64_t n, int stride)
+{
+  const double slots = (double)NRANGE * (double)(1 << g_gb_pbits);
+  const double dev   = 8.0 * 1.25 * stride * __builtin_sqrt(slots * ((double)n / stride + 2.0 * slots));
+  return (size_t)((double)n * 1.002 + dev) + (size_t)slots * (size_t)(2 * stride * GX_WAVE + 64 + 16) + 65536;
+}
+static inline int wide_stride(int64_t n)
+{
+  int s = 1;
+  while (s < 32 && (n >> 22) >= 2 * s) s *= 2;
+  return s;
+}
+
+// 4096-row tiles (8 rows per thread): the W key words of a row stay in registers from the hash to their column pass, and
+// W x 8 x 2 VGPRs still leave room for the second workgroup per CU (16 rows per thread: 136 / 161 / 193 VGPRs for W = 2 / 3 / 4)
+constexpr int WRPT  = 8;
+constexpr int WTILE = PBT * WRPT;
+
+template <int W, typename V>
+__global__ void __launch_bounds__(PBT) k_wide_scatter(WideCols keys, const V* __restrict__ vals, int64_t n, WidePlan* plan, WideOut pkeys,
+                                                      V* __restrict__ pvals)
+{
+  if (plan->overflow != 0) return;  // (the plan's slots do not fit: cannot happen with the host's bound)
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  unsigned long long* s_w = reinterpret_cast<unsigned long long*>(smem);                      // WTILE words
+  uint32_t* s_cnt         = reinterpret_cast<uint32_t*>(smem + (size_t)WTILE * 8);           // NPART
+  uint32_t* s_start       = s_cnt + NPART;                                                    // NPART
+  unsigned long long* s_delta = reinterpret_cast<unsigned long long*>(s_start + NPART);      // NPART
+  unsigned long long* s_limit = s_delta + NPART;                                              // NPART: end of the partition's slot
+  uint32_t* s_scan        = reinterpret_cast<uint32_t*>(s_limit + NPART);                    // 16
+  __shared__ uint32_t s_total;
+  const unsigned tid = threadIdx.x;
+  const int psh      = 64 - d_gb_pbits;
+  const int64_t tile = xcd_swizzle(blockIdx.x, gridDim.x);
+  const int64_t rper = div_up(n, (int64_t)WTILE) / NRANGE;  // tiles per input range (the last range takes the rest)
+  const int range    = (rper > 0 && tile / rper < NRANGE - 1) ? (int)(tile / rper) : NRANGE - 1;
+  const int64_t base = tile * WTILE;
+  const int nvalid   = (int)((n - base < (int64_t)WTILE) ? (n - base) : (int64_t)WTILE);  // >= 1
+  if (tid < NPART) s_cnt[tid] = 0;
+  // ---- the row: W key words + value, loaded unconditionally (padding rows repeat the tile's last row and are never ranked)
+  unsigned long long k[W][WRPT];
+  V v[WRPT];
+#pragma unroll
+  for (int w = 0; w < W; ++w) {
+    const unsigned long long* kt = keys.k[w] + base;
+#pragma unroll
+    for (int j = 0; j < WRPT; ++j) {
+      const int idx = j * PBT + (int)tid;
+      k[w][j]       = kt[idx < nvalid ? idx : nvalid - 1];
+    }
+  }
+  {
+    const V* vt = vals + base;
+#pragma unroll
+    for (int j = 0; j < WRPT; ++j) {
+      const int idx = j * PBT + (int)tid;
+      v[j]          = vt[idx < nvalid ? idx : nvalid - 1];
+    }
+  }
+  __syncthreads();
+  unsigned long long h[WRPT];
+  uint32_t packed[WRPT];
+#pragma unroll
+  for (int j = 0; j < WRPT; ++j) {
+    unsigned long long x = 0x9E3779B97F4A7C15ull;
+#pragma unroll
+    for (int w = 0; w < W; ++w) x = wide_mix(x, k[w][j]);
+    h[j]                = wide_fin(x);
+    const uint32_t part = (uint32_t)(h[j] >> psh);
+    packed[j]           = (part << 16) | ((j * PBT + (int)tid < nvalid) ? atomicAdd(&s_cnt[part], 1u) : 0u);
+  }
+  __syncthreads();
+  const uint32_t c = (tid < NPART) ? s_cnt[tid] : 0u;
+  uint32_t total;
+  const uint32_t st = block_exclusive_scan<PBT>(c, 0u, SumOp(), s_scan, &total);
+  if (tid < NPART) {
+    s_start[tid]         = st;
+    unsigned long long g = 0;
+    if (c) g = atomicAdd(&plan->cursor[range][tid], (unsigned long long)c);
+    const uint32_t scap = plan->cap0[range][tid];
+    if (c && g + c > scap) plan->overflow = 1u;
+    const unsigned long long sb = plan->slot0[range][tid];
+    s_limit[tid] = sb + scap;
+    s_delta[tid] = sb + g - st;
+  }
+  if (tid == 0) s_total = total;
+  __syncthreads();
+  const int ntot = (int)s_total;
+  // ---- the hashes through LDS: the partition of every output position, kept in registers for all column passes
+#pragma unroll
+  for (int j = 0; j < WRPT; ++j) {
+    if (j * PBT + (int)tid < nvalid) s_w[s_start[packed[j] >> 16] + (packed[j] & 0xFFFFu)] = h[j];
+  }
+  __syncthreads();
+  unsigned short obin[WRPT];
+#pragma unroll
+  for (int j = 0; j < WRPT; ++j) {
+    const int i = j * PBT + (int)tid;
+    obin[j]     = 0xFFFFu;
+    if (i < ntot) {
+      const uint32_t b             = (uint32_t)(s_w[i] >> psh);
+      const unsigned long long dst = s_delta[b] + (unsigned long long)i;
+      if (dst < s_limit[b]) obin[j] = (unsigned short)b;  // else: beyond the slot (flagged)
+    }
+  }
+  // ---- key columns, then the values, through the same buffer
+#pragma unroll
+  for (int w = 0; w < W; ++w) {
+    __syncthreads();
+#pragma unroll
+    for (int j = 0; j < WRPT; ++j) {
+      if (j * PBT + (int)tid < nvalid) s_w[s_start[packed[j] >> 16] + (packed[j] & 0xFFFFu)] = k[w][j];
+    }
+    __syncthreads();
+#pragma unroll
+    for (int j = 0; j < WRPT; ++j) {
+      const int i = j * PBT + (int)tid;
+      if (obin[j] != 0xFFFFu) pkeys.k[w][s_delta[obin[j]] + (unsigned long long)i] = s_w[i];
+    }
+  }
+  __syncthreads();
+  V* s_v = reinterpret_cast<V*>(smem);
+#pragma unroll
+  for (int j = 0; j < WRPT; ++j) {
+    if (j * PBT + (int)tid < nvalid) s_v[s_start[packed[j] >> 16] + (packed[j] & 0xFFFFu)] = v[j];
+  }
+  __syncthreads();
+#pragma unroll
+  for (int j = 0; j < WRPT; ++j) {
+    const int i = j * PBT + (int)tid;
+    if (obin[j] != 0xFFFFu) pvals[s_delta[obin[j]] + (unsigned long long)i] = s_v[i];
+  }
+}
+
+template <int W>
+constexpr int wide_slots()
+{
+  return (LDS_BUDGET / (4 + 8 * W + 4 + 16)) / 256 * 256;
+}
+
+template <int W, typename V, bool IS_FLOAT>
+__global__ void __launch_bounds__(ABT) k_wide_aggregate(WideOut pkeys, const V* __restrict__ pvals, WidePlan* plan, int nsub,
+                                                        int64_t max_groups, WideOut out_keys, void* out_sum, int32_t* out_cv)
+{
+  if (plan->overflow != 0) return;
+  constexpr int S            = wide_slots<W>();
+  constexpr uint32_t MAXKEYS = (uint32_t)(S - S / 8);
+  constexpr uint32_t BUSY = 0x80000000u, LIVE = 0x40000000u;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  double* l_sum           = reinterpret_cast<double*>(smem);                       // S
+  double* l_comp          = l_sum + S;                                             // S
+  unsigned long long* l_k = reinterpret_cast<unsigned long long*>(l_comp + S);     // W x S
+  uint32_t* l_tag         = reinterpret_cast<uint32_t*>(l_k + (size_t)W * S);      // S
+  uint32_t* l_cv          = l_tag + S;                                             // S
+  __shared__ uint32_t s_nkeys;
+  __shared__ uint32_t s_scan[ABT / GX_WAVE + 1];
+  __shared__ unsigned long long s_base;
+  const unsigned tid = threadIdx.x;
+  for (int i = tid; i < S; i += ABT) {
+    l_sum[i]  = 0.0;
+    l_comp[i] = 0.0;
+    l_tag[i]  = 0u;
+    l_cv[i]   = 0u;
+  }
+  if (tid == 0) s_nkeys = 0;
+  __syncthreads();
+  const int sub  = (int)(blockIdx.x % (unsigned)nsub);
+  const int part = (int)(blockIdx.x / (unsigned)nsub);
+  const int pb   = d_gb_pbits;
+  constexpr int U = 4;
+  for (int rg = 0; rg < NRANGE; ++rg) {
+    const unsigned long long fill = plan->cursor[rg][part];
+    const unsigned long long cap  = plan->cap0[rg][part];
+    const unsigned long long p0   = plan->slot0[rg][part];
+    const unsigned long long p1   = p0 + (fill < cap ? fill : cap);
+    for (unsigned long long i0 = p0 + tid; i0 < p1; i0 += (unsigned long long)ABT * U) {
+      unsigned long long k[U][W];
+      V v[U];
+#pragma unroll
+      for (int u = 0; u < U; ++u) {
+        const unsigned long long i = i0 + (unsigned long long)u * ABT;
+        const bool in              = i < p1;
+#pragma unroll
+        for (int w = 0; w < W; ++w) k[u][w] = in ? pkeys.k[w][i] : 0ull;
+        v[u] = in ? pvals[i] : V(0);
+      }
+#pragma unroll
+      for (int u = 0; u < U; ++u) {
+        if (i0 + (unsigned long long)u * ABT >= p1) continue;
+        unsigned long long hh = 0x9E3779B97F4A7C15ull;
+#pragma unroll
+        for (int w = 0; w < W; ++w) hh = wide_mix(hh, k[u][w]);
+        hh = wide_fin(hh);
+        if (nsub > 1 && (int)((hh >> 16) & (unsigned long long)(nsub - 1)) != sub) continue;
+        const uint32_t want = ((uint32_t)hh & 0x3FFFFFFFu) | LIVE;  // released tag of this row's hash
+        uint32_t h          = (uint32_t)((((hh >> (32 - pb)) & 0xFFFFFFFFull) * (unsigned long long)S) >> 32);
+        int slot            = -1;
+        // NO exit edge between a successful claim and its release: a `break` there makes the claim block a loop exit, which
+        // the compiler lays out BEHIND the loop -- the owner lane would then sit at the loop's end with its tag still busy
+        // while lanes of its own wave spin on that tag inside the loop (seen as a hang in the first GPU run of this kernel)
+        bool searching = true;
+        for (int probes = 0; searching && probes < S; ++probes) {
+          uint32_t tag = __hip_atomic_load(&l_tag[h], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+          if (tag == 0u) {
+            if (s_nkeys >= MAXKEYS) {  // table (nearly) full: the caller falls back
+              searching = false;
+            } else {
+              tag = atomicCAS(&l_tag[h], 0u, want | BUSY);
+              if (tag == 0u) {  // claimed: write the row's key words, then release the tag
+#pragma unroll
+                for (int w = 0; w < W; ++w) l_k[(size_t)w * S + h] = k[u][w];
+                __hip_atomic_store(&l_tag[h], want, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
+                atomicAdd(&s_nkeys, 1u);
+                slot      = (int)h;
+                searching = false;
+                tag       = want;
+              }
+            }
+          }
+          if (searching && (tag & 0x7FFFFFFFu) == want) {
+            // same 30 hash bits: wait for the owner's key words (an owner in this wave released in the branch above, which
+            // every lane of the wave has left by now), then compare the row
+            while (tag & BUSY) {
+              __builtin_amdgcn_s_sleep(1);
+              tag = __hip_atomic_load(&l_tag[h], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP);
+            }
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+            bool same = true;
+#pragma unroll
+            for (int w = 0; w < W; ++w) same = same && (l_k[(size_t)w * S + h] == k[u][w]);
+            if (same) {
+              slot      = (int)h;
+              searching = false;
+            }
+          }
+          if (searching) h = (h + 1 == (uint32_t)S) ? 0u : h + 1;
+        }
+        if (slot < 0) {
+          plan->overflow = 1u;
+          continue;
+        }
+        LdsAcc<V, IS_FLOAT>::add(l_sum, l_comp, slot, v[u]);
+        atomicAdd(&l_cv[slot], 1u);
+      }
+    }
+  }
+  __syncthreads();
+  // ---- this workgroup's groups are complete: straight to the output
+  uint32_t mine = 0;
+  for (int i = tid; i < S; i += ABT) mine += l_tag[i] != 0u ? 1u : 0u;
+  uint32_t total;
+  const uint32_t before = block_exclusive_scan<ABT>(mine, 0u, SumOp(), s_scan, &total);
+  if (tid == 0) s_base = total ? atomicAdd(&plan->ngroups, (unsigned long long)total) : 0ull;
+  __syncthreads();
+  unsigned long long p = s_base + before;
+  for (int i = tid; i < S; i += ABT) {
+    if (l_tag[i] == 0u) continue;
+    if ((long long)p < max_groups) {
+#pragma unroll
+      for (int w = 0; w < W; ++w) out_keys.k[w][p] = l_k[(size_t)w * S + i];
+      if (IS_FLOAT) {
+        const double r = l_sum[i] + l_comp[i];
+        if (sizeof(V) == 4) static_cast<float*>(out_sum)[p] = (float)r; else static_cast<double*>(out_sum)[p] = r;
+      } else {
+        static_cast<long long*>(out_sum)[p] = reinterpret_cast<const long long*>(l_sum)[i];
+      }
+      out_cv[p] = (int32_t)l_cv[i];
+    }
+    ++p;
+  }
+}
+
+__global__ void k_wide_finish(const WidePlan* plan, int64_t max_groups, long long* ngroups)
+{
+  const long long g = (long long)plan->ngroups;
+  *ngroups          = plan->overflow ? -2ll : (g > max_groups ? -1ll : g);
+}
+
+template <int W, typename V, bool IS_FLOAT>
+int wide_impl(const void* const* key_cols, const void* vals, int64_t n, int64_t max_groups, void* const* out_key_cols, void* out_sum,
+              int32_t* out_cv, int64_t* ngroups, void* tmp, size_t* tmp_bytes, hipStream_t s)
+{
+  const int stride   = wide_stride(n);
+  const size_t elems = wide_elems(n, stride);
+  Carver c(tmp);
+  WidePlan* plan = c.take<WidePlan>(1);
+  WideOut pk{};
+  for (int w = 0; w < W; ++w) pk.k[w] = c.take<unsigned long long>(elems);
+  V* pv = c.take<V>(elems);
+  if (tmp == nullptr) {
+    *tmp_bytes = c.total();
+    return 0;
+  }
+  if (*tmp_bytes < c.total()) return GX_ETMP;
+  WideCols kc{};
+  WideOut ok{};
+  for (int w = 0; w < W; ++w) {
+    kc.k[w] = static_cast<const unsigned long long*>(key_cols[w]);
+    ok.k[w] = static_cast<unsigned long long*>(out_key_cols[w]);
+    if (n > 0 && !kc.k[w]) return GX_EINVAL;
+    if (max_groups > 0 && !ok.k[w]) return GX_EINVAL;
+  }
+  GX_HIP_TRY(hipMemsetAsync(plan, 0, sizeof(WidePlan), s));
+  if (n > 0) {
+    constexpr size_t lds_s = (size_t)WTILE * 8 + NPART * 4 * 2 + NPART * 8 * 2 + 64;
+    constexpr int S        = wide_slots<W>();
+    constexpr size_t lds_a = (size_t)S * (16 + 8 * W + 8);
+    auto ks                = k_wide_scatter<W, V>;
+    auto ka                = k_wide_aggregate<W, V, IS_FLOAT>;
+    static bool attr_set   = false;
+    if (!attr_set) {
+      GX_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(ks), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_s));
+      GX_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(ka), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_a));
+      attr_set = true;
+    }
+    // workgroups per partition: the groups one LDS table has to hold stay under half of its slots
+    const double per_part = (double)(max_groups < 1 ? 1 : max_groups) / (double)(1 << g_gb_pbits);
+    int nsub              = 1;
+    while (nsub < 16 && per_part / nsub > 0.5 * S) nsub *= 2;
+    const int64_t wtiles     = div_up(n, (int64_t)WTILE);
+    const int64_t range_rows = (wtiles / NRANGE) * WTILE;  // rows per input range (whole tiles; the last range takes the rest)
+    int64_t sblocks          = div_up(div_up(n, (int64_t)stride * GX_WAVE), (int64_t)4 * 8);
+    if (sblocks > 2048) sblocks = 2048;
+    if (sblocks < 1) sblocks = 1;
+    hipLaunchKernelGGL((k_wide_sample<W>), dim3((unsigned)sblocks), dim3(256), 0, s, kc, n, plan, stride, range_rows);
+    hipLaunchKernelGGL(k_wide_plan, dim3(1), dim3(NPART), 0, s, plan, n, stride, range_rows, (unsigned long long)elems);
+    hipLaunchKernelGGL(ks, dim3((unsigned)wtiles), dim3(PBT), lds_s, s, kc, static_cast<const V*>(vals), n, plan, pk, pv);
+    hipLaunchKernelGGL(ka, dim3((unsigned)((1 << g_gb_pbits) * nsub)), dim3(ABT), lds_a, s, pk, pv, plan, nsub, max_groups, ok, out_sum, out_cv);
+  }
+  hipLaunchKernelGGL(k_wide_finish, dim3(1), dim3(1), 0, s, plan, max_groups, reinterpret_cast<long long*>(ngroups));
+  GX_LAUNCH_CHECK();
+  return 0;
+}
+
+template <int W>
+int wide_dispatch_val(int val_dtype, const void* const* key_cols, const void* vals, int64_t n, int64_t max_groups, void* const* out_key_cols,
+                      void* out_sum, int32_t* out_cv, int64_t* ngroups, void* tmp, size_t* tmp_bytes, hipStream_t s)
+{
+  switch (val_dtype) {
+    case GX_INT32: return wide_impl<W, int32_t, false>(key_cols, vals, n, max_groups, out_key_cols, out_sum, out_cv, ngroups, tmp, tmp_bytes, s);
+    case GX_INT64: return wide_impl<W, int64_t, false>(key_cols, vals, n, max_groups, out_key_cols, out_sum, out_cv, ngroups, tmp, tmp_bytes, s);
+    case GX_FLOAT32: return wide_impl<W, float, true>(key_cols, vals, n, max_groups, out_key_cols, out_sum, out_cv, ngroups, tmp, tmp_bytes, s);
+    case GX_FLOAT64: return wide_impl<W, double, true>(key_cols, vals, n, max_groups, out_key_cols, out_sum, out_cv, ngroups, tmp, tmp_bytes, s);
+    default: return GX_EDTYPE;
+  }
+}
+
+}  // namespace gb
+}  // namespace gx
+
+extern "C" {
+
+int gx_groupby_sum_count_wide(int nkeys, const void* const* key_cols, int val_dtype, const void* vals, int64_t n, int64_t max_groups,
+                              void* const* out_key_cols, void* out_sum, int32_t* out_count, int64_t* ngroups_dev, void* tmp,
+                              size_t* tmp_bytes, gx_stream_t s)
+{
+  if (n < 0 || max_groups < 0 || !tmp_bytes || nkeys < 2 || nkeys > gx::gb::WMAX) return GX_EINVAL;
+  if (tmp && (!key_cols || !out_key_cols || !ngroups_dev || (n > 0 && !vals) || (max_groups > 0 && (!out_sum || !out_count)))) return GX_EINVAL;
+  static const void* const nulls[gx::gb::WMAX]  = {nullptr, nullptr, nullptr, nullptr};
+  static void* const nulls_out[gx::gb::WMAX]    = {nullptr, nullptr, nullptr, nullptr};
+  const void* const* kc = key_cols ? key_cols : nulls;
+  void* const* oc       = out_key_cols ? out_key_cols : nulls_out;
+  switch (nkeys) {
+    case 2: return gx::gb::wide_dispatch_val<2>(val_dtype, kc, vals, n, max_groups, oc, out_sum, out_count, ngroups_dev, tmp, tmp_bytes, s);
+    case 3: return gx::gb::wide_dispatch_val<3>(val_dtype, kc, vals, n, max_groups, oc, out_sum, out_count, ngroups_dev, tmp, tmp_bytes, s);
+    default: return gx::gb::wide_dispatch_val<4>(val_dtype, kc, vals, n, max_groups, oc, out_sum, out_count, ngroups_dev, tmp, tmp_bytes, s);
+  }
+}
+
+}  // extern "C"

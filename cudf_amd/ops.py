@@ -684,6 +684,60 @@ def groupby_sum_count(keys: Column, values: Column, max_groups_hint: int = 1 << 
     return ok, osum, ocv, oca
 
 
+WIDE_GROUPBY_MIN_ROWS = 1 << 18  # below: the partition pass is not worth its 4096 slots
+_SIGNED_OF_WIDTH = {1: torch.int8, 2: torch.int16, 4: torch.int32, 8: torch.int64}
+
+
+def _widen_i64(col: Column) -> Column:
+    """an integer column as 8-byte words (sign / zero extended): what gx_groupby_sum_count_wide compares"""
+    if col.dtype.itemsize == 8:
+        return Column(col.data, col.dtype, col.size)
+    # any injective map to 8-byte words will do (the words are only hashed and compared): view as the SIGNED type of the same
+    # width and sign-extend; narrowing back keeps the low bytes
+    t = col.data[: col.size * col.dtype.itemsize].view(_SIGNED_OF_WIDTH[col.dtype.itemsize])
+    out = Column.empty(np.int64, col.size)
+    out.data[: col.size * 8].view(torch.int64).copy_(t)
+    return out
+
+
+def _groupby_sum_count_wide(keys: Sequence[Column], values: Column, max_groups_hint: int = 1 << 20):
+    """groupby on 2..4 integer key columns in ONE partition pass with the rows compared inside the LDS tables
+    (gx_groupby_sum_count_wide).  None: not applicable / the device asked for the fallback."""
+    n = values.size
+    if not (2 <= len(keys) <= 4) or n < WIDE_GROUPBY_MIN_ROWS or values.has_nulls() or values.dtype.kind not in "if" or \
+            values.dtype.itemsize not in (4, 8) or any(k.has_nulls() or k.dtype.kind not in "iu" for k in keys):
+        return None
+    wide = [_widen_i64(k) for k in keys]
+    sum_dt = np.dtype(values.dtype if values.dtype.kind == "f" else np.int64)
+    max_groups = max(1, min(n, max_groups_hint))
+    kp = (ctypes.c_void_p * len(wide))(*[k.data_ptr.value or 0 for k in wide])
+    while True:
+        outs = [Column.empty(np.int64, max_groups) for _ in wide]
+        osum, ocv = Column.empty(sum_dt, max_groups), Column.empty(np.int32, max_groups)
+        op = (ctypes.c_void_p * len(outs))(*[o.data_ptr.value or 0 for o in outs])
+        ng = _dev_i64()
+        _run(_lib.gx_groupby_sum_count_wide, len(wide), kp, values.gx, values.data_ptr, n, max_groups, op, osum.data_ptr, ocv.data_ptr, ptr(ng))
+        g = int(ng.item())
+        if g == -2:
+            return None
+        if g >= 0:
+            break
+        if max_groups >= n:
+            raise RuntimeError("groupby table overflow")
+        max_groups = min(n, max_groups * 8)
+    kcols = []
+    for o, k in zip(outs, keys):
+        o.size = g
+        if k.dtype.itemsize == 8:
+            kcols.append(Column(o.data, k.dtype, g))
+        else:  # narrow the words back to the column's type
+            c = Column.empty(k.dtype, g)
+            c.data[: g * k.dtype.itemsize].view(_SIGNED_OF_WIDTH[k.dtype.itemsize]).copy_(o.data[: g * 8].view(torch.int64))
+            kcols.append(c)
+    osum.size = ocv.size = g
+    return kcols, osum, ocv, ocv
+
+
 def groupby_sum_count_tables(keys: Sequence[Column], values: Column, exact: bool = False):
     """groupby(keys = several columns).agg(SUM, COUNT_VALID, COUNT_ALL): the rows' 8-byte keys (RowKeys: packed values
     or row hash) go through the single-key hash groupby; the key columns come back from the distinct keys.
@@ -694,6 +748,10 @@ def groupby_sum_count_tables(keys: Sequence[Column], values: Column, exact: bool
         return [k], s, cv, ca
     if keys[0].size != values.size:
         raise RuntimeError("Size mismatch between request values and groupby keys.")
+    if not exact:
+        r = _groupby_sum_count_wide(keys, values)
+        if r is not None:
+            return r
     if not exact and len(keys) <= 8:
         rk = RowKeys(keys)
         hk, s, cv, ca = groupby_sum_count(rk.col, values)

@@ -366,6 +366,18 @@ int gx_groupby_sum_count(int key_dtype, const void* keys, const uint32_t* keys_v
                          int32_t* out_count_valid, int32_t* out_count_all, int64_t* ngroups_dev,
                          void* tmp, size_t* tmp_bytes, gx_stream_t stream);
 
+/* Groupby SUM + COUNT on SEVERAL key columns, rows compared inside the table (the reference hashes a row once and
+ * compares rows in its probe: include/cudf/detail/row_operator/primitive_row_operators.cuh:95-163, 247-268).
+ * key_cols: nkeys (2..4) HOST array of device pointers to columns of 8-byte words (int64 / uint64 columns as they are;
+ * narrower integer columns widened by the caller); out_key_cols: nkeys device columns of capacity max_groups that
+ * receive the groups' key words.  No nulls (nullable inputs take gx_hash_rows64 + gx_groupby_sum_count).  Groups come
+ * out in unspecified order.  *ngroups_dev: the group count; -1: more than max_groups groups (retry with a larger bound);
+ * -2: keys skewed beyond the partition slots / more groups per partition than an LDS table holds -- the caller takes the
+ * single-key path over row hashes instead (nothing usable was written). */
+int gx_groupby_sum_count_wide(int nkeys, const void* const* key_cols, int val_dtype, const void* vals, int64_t n,
+                              int64_t max_groups, void* const* out_key_cols, void* out_sum /* f64 or i64 */,
+                              int32_t* out_count, int64_t* ngroups_dev, void* tmp, size_t* tmp_bytes, gx_stream_t stream);
+
 /* Groupby MIN / MAX of one value column (src/groupby/hash/global_memory_aggregator.cuh:18-238):
  * same conventions as gx_groupby_sum_count; out_min / out_max have the VALUE dtype (either may be
  * NULL); a group without a valid value has count 0 and an unspecified min/max (the caller nulls it).
