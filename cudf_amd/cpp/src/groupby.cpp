@@ -5,6 +5,7 @@
 #include "row_encoding.hpp"
 #include "sort_helper.hpp"
 
+#include <optional>
 #include <cudf/column/column_factories.hpp>
 #include <cudf/copying.hpp>
 #include <cudf/groupby.hpp>
@@ -157,6 +158,76 @@ std::pair<std::unique_ptr<table>, std::vector<aggregation_result>> groupby::aggr
   }
 }
 
+std::optional<std::pair<std::unique_ptr<table>, std::vector<aggregation_result>>> groupby::wide_aggregate(
+  std::span<aggregation_request const> requests, rmm::cuda_stream_view stream, rmm::device_async_resource_ref mr)
+{
+  auto const n  = _keys.num_rows();
+  auto const nk = _keys.num_columns();
+  if (nk < 2 || nk > 4 || n < (size_type{1} << 18) || requests.size() != 1) return std::nullopt;
+  for (auto const& c : _keys)
+    if ((c.type().id() != type_id::INT64 && c.type().id() != type_id::UINT64) || c.has_nulls()) return std::nullopt;
+  auto const& req = requests[0];
+  auto const vt   = req.values.type().id();
+  if (req.values.has_nulls() || (vt != type_id::INT32 && vt != type_id::INT64 && vt != type_id::FLOAT32 && vt != type_id::FLOAT64))
+    return std::nullopt;
+  for (auto const& agg : req.aggregations)
+    if (agg->kind != aggregation::SUM && agg->kind != aggregation::COUNT_VALID && agg->kind != aggregation::COUNT_ALL &&
+        agg->kind != aggregation::MEAN)
+      return std::nullopt;
+  std::vector<void const*> kin(nk);
+  for (size_type i = 0; i < nk; ++i) kin[i] = detail::row0(_keys.column(i));
+  int64_t max_groups = std::max<int64_t>(1, std::min<int64_t>(n, int64_t{1} << 20));
+  rmm::device_buffer ng{sizeof(int64_t), stream};
+  for (;;) {
+    auto const g = static_cast<size_type>(max_groups);
+    std::vector<std::unique_ptr<column>> kout;
+    std::vector<void*> kptr(nk);
+    for (size_type i = 0; i < nk; ++i) {
+      kout.emplace_back(make_fixed_width_column(_keys.column(i).type(), g, mask_state::UNALLOCATED, stream, mr));
+      kptr[i] = kout.back()->mutable_view().head<void>();
+    }
+    auto sum = make_fixed_width_column(sum_type(req.values.type()), g, mask_state::UNALLOCATED, stream, mr);
+    auto cnt = make_fixed_width_column(data_type{type_id::INT32}, g, mask_state::UNALLOCATED, stream, mr);
+    detail::run_with_scratch(
+      [&](void* t, std::size_t* b) {
+        return gx_groupby_sum_count_wide(nk, kin.data(), detail::gx_type(req.values.type()), detail::row0(req.values), n, max_groups,
+                                         kptr.data(), sum->mutable_view().head<void>(), cnt->mutable_view().head<int32_t>(),
+                                         static_cast<int64_t*>(ng.data()), t, b, detail::gxs(stream));
+      },
+      "groupby aggregate (several key columns)", stream);
+    auto const groups = detail::read_i64(static_cast<int64_t const*>(ng.data()), stream);
+    if (groups == -2) return std::nullopt;  // skew / more groups per partition than an LDS table holds: the encoded path
+    if (groups >= 0) {
+      auto trim = [&](std::unique_ptr<column>& c) {
+        auto type     = c->type();
+        auto contents = c->release();
+        c = std::make_unique<column>(type, static_cast<size_type>(groups), std::move(*contents.data), rmm::device_buffer{}, 0);
+      };
+      for (auto& c : kout) trim(c);
+      trim(sum);
+      trim(cnt);
+      std::vector<aggregation_result> results(1);
+      for (auto const& agg : req.aggregations) {
+        switch (agg->kind) {
+          case aggregation::SUM: results[0].results.emplace_back(std::make_unique<column>(sum->view(), stream, mr)); break;
+          case aggregation::MEAN: {
+            auto c = make_fixed_width_column(data_type{type_id::FLOAT64}, static_cast<size_type>(groups), mask_state::UNALLOCATED, stream, mr);
+            detail::gx_check(gx_mean_from_sum(detail::gx_type(sum->type()), sum->view().head<void>(), cnt->view().head<int32_t>(), groups,
+                                              c->mutable_view().head<double>(), detail::gxs(stream)),
+                             "groupby mean");
+            results[0].results.emplace_back(std::move(c));
+            break;
+          }
+          default: results[0].results.emplace_back(std::make_unique<column>(cnt->view(), stream, mr)); break;  // COUNT_VALID == COUNT_ALL: no nulls
+        }
+      }
+      return std::make_pair(std::make_unique<table>(std::move(kout)), std::move(results));
+    }
+    CUDF_EXPECTS(max_groups < n, "groupby: group table overflow");
+    max_groups = std::min<int64_t>(n, max_groups * 8);
+  }
+}
+
 std::pair<std::unique_ptr<table>, std::vector<aggregation_result>> groupby::aggregate_impl(
   std::span<aggregation_request const> requests, bool exact_keys, rmm::cuda_stream_view stream, rmm::device_async_resource_ref mr)
 {
@@ -171,6 +242,11 @@ std::pair<std::unique_ptr<table>, std::vector<aggregation_result>> groupby::aggr
     for (auto const& agg : r.aggregations)
       sort_path = sort_path || agg->kind == aggregation::PRODUCT || agg->kind == aggregation::NTH_ELEMENT;
   if (sort_path && _keys.num_rows() > 0 && !requests.empty()) return sort_aggregate(requests, stream, mr);
+  // Several 8-byte integer key columns, one request of SUM / COUNT / MEAN, no nulls: ONE partition pass with the rows compared
+  // inside the LDS tables (gx_groupby_sum_count_wide) -- no row encoding, no certificate.  The device may decline (-2).
+  if (!exact_keys) {
+    if (auto r = wide_aggregate(requests, stream, mr)) return std::move(*r);
+  }
   // One 32/64-bit integer key column goes to the hash kernels as it is; anything else (several columns, floats,
   // narrow types) becomes ONE 8-byte row key first (detail::row_keys: the packed values, or a 64-bit row hash whose
   // result is certified against the key columns), and the key columns come back from the distinct row keys.

@@ -205,6 +205,13 @@ struct PartPlan {
   unsigned long long cursor[NRANGE][NPART];  // scatter cursors: exact pass = output positions (start at the region offset),
                                              // speculative pass = rows written to the (partition, range) slot so far
   unsigned long long offset[NPART + 1];      // partition starts (exact pass)
+  // speculative pass: slot (range, partition) of the partitioned arrays, sized from a SAMPLE of the rows (k_slot_sample /
+  // k_slot_plan below): rows of one group all go to one partition, so partition sizes carry the variance of the GROUP sizes
+  // -- 1e6 sparse keys over 512 partitions are uneven by +-2.3 %, far beyond the 8 sigma of row-level noise the fixed
+  // mean + margin slots of the first version allowed (every sparse-key input overflowed and paid for both passes)
+  uint32_t samp[NRANGE][NPART];
+  uint32_t slot0[NRANGE][NPART];
+  uint32_t cap0[NRANGE][NPART];
   alignas(128) unsigned int overflow;        // speculative pass: a slot outgrew its capacity -> the exact sequence runs
 };
 
@@ -328,7 +335,8 @@ __global__ void __launch_bounds__(PBT) k_part_scatter(const K* __restrict__ keys
   uint32_t* s_cnt   = reinterpret_cast<uint32_t*>(s_flag + (HAS_VV ? PTILE : 0));  // NPART
   uint32_t* s_start = s_cnt + NPART;                                    // NPART
   unsigned long long* s_delta = reinterpret_cast<unsigned long long*>(s_start + NPART);  // NPART
-  uint32_t* s_scan  = reinterpret_cast<uint32_t*>(s_delta + NPART);     // 16
+  unsigned long long* s_limit = s_delta + NPART;                        // NPART: end of the partition's slot (speculative pass)
+  uint32_t* s_scan  = reinterpret_cast<uint32_t*>(s_limit + NPART);     // 16
   __shared__ uint32_t s_total;
 
   const unsigned tid = threadIdx.x;
@@ -367,10 +375,14 @@ __global__ void __launch_bounds__(PBT) k_part_scatter(const K* __restrict__ keys
     s_start[tid] = st;
     unsigned long long g = 0;
     if (c) g = atomicAdd(&plan->cursor[range][tid], (unsigned long long)c);
+    unsigned long long lim = ~0ull;
     if (cap) {
-      if (c && g + c > cap) plan->overflow = 1u;  // the surplus is dropped at the write-out; the exact sequence will run
-      g += (unsigned long long)(tid * NRANGE + range) * cap;
+      const uint32_t scap = plan->cap0[range][tid];
+      if (c && g + c > scap) plan->overflow = 1u;  // the surplus is dropped at the write-out; the exact sequence will run
+      g += plan->slot0[range][tid];
+      lim = (unsigned long long)plan->slot0[range][tid] + scap;
     }
+    s_limit[tid] = lim;
     s_delta[tid] = g - st;
   }
   if (tid == 0) s_total = total;
@@ -394,7 +406,7 @@ __global__ void __launch_bounds__(PBT) k_part_scatter(const K* __restrict__ keys
       const K k                    = s_k[i];
       const uint32_t b             = (uint32_t)(part_hash<K>(k) >> psh);
       const unsigned long long dst = s_delta[b] + (unsigned long long)i;
-      if (cap && dst >= (unsigned long long)(b * NRANGE + range + 1) * cap) continue;  // beyond the slot
+      if (dst >= s_limit[b]) continue;  // beyond the slot
       pkeys[dst] = k;
       obin[j]    = (unsigned short)b;
     }
@@ -517,8 +529,9 @@ __global__ void __launch_bounds__(ABT) k_part_aggregate(const K* __restrict__ pk
   unsigned long long p0, p1;
   if (cap) {
     const unsigned long long fill = plan->cursor[rg][part];
-    p0 = (unsigned long long)(part * NRANGE + rg) * cap;
-    p1 = p0 + (fill < cap ? fill : (unsigned long long)cap);
+    const unsigned long long scap = plan->cap0[rg][part];
+    p0 = plan->slot0[rg][part];
+    p1 = p0 + (fill < scap ? fill : scap);
   } else {
     p0 = plan->offset[part];
     p1 = plan->offset[part + 1];
@@ -633,10 +646,81 @@ constexpr int64_t PART_MIN_ROWS = 1 << 19;
 // the speculative pass pays off once the slots are long enough for the 8-sigma margin to be small (>= ~2000 rows per slot)
 static inline bool part_speculative(int64_t n) { return g_gb_nrange == NRANGE && (g_gb_spec == 2 || (g_gb_spec == 1 && n >= (1 << 22))); }
 // elements of the partitioned arrays: the padded slots of the speculative pass, or n
-static inline size_t part_elems(int64_t n)
+static inline int slot_stride(int64_t n)  // the sample takes every stride-th 64-row chunk
 {
-  const size_t padded = ((size_t)NRANGE << g_gb_pbits) * part_cap(n);
-  return part_speculative(n) && padded > (size_t)n ? padded : (size_t)n;
+  int s = 1;
+  while (s < 32 && (n >> 22) >= 2 * s) s *= 2;
+  return s;
+}
+// rows the partitioned arrays must hold: n + the slack k_slot_plan hands out (Cauchy-Schwarz over the slots)
+static inline size_t slot_elems(int64_t n, int stride)
+{
+  const double slots = (double)NRANGE * (double)(1 << g_gb_pbits);
+  const double dev   = 8.0 * 1.25 * stride * __builtin_sqrt(slots * ((double)n / stride + 2.0 * slots));
+  return (size_t)((double)n * 1.002 + dev) + (size_t)slots * (size_t)(2 * stride * GX_WAVE + 64 + 16) + 65536;
+}
+static inline size_t part_elems(int64_t n) { return part_speculative(n) ? slot_elems(n, slot_stride(n)) : (size_t)n; }
+
+template <typename K>
+__global__ void __launch_bounds__(256) k_slot_sample(const K* __restrict__ keys, const uint32_t* __restrict__ kvalid, int64_t n, PartPlan* plan,
+                                                     int stride, int64_t range_rows)
+{
+  __shared__ uint32_t s_hist[NRANGE * NPART];
+  const unsigned tid = threadIdx.x, lane = lane_id();
+  for (int i = tid; i < NRANGE * NPART; i += 256) s_hist[i] = 0;
+  __syncthreads();
+  const int psh         = 64 - d_gb_pbits;
+  const int64_t step    = (int64_t)stride * GX_WAVE;
+  const int64_t nchunks = div_up(n, step);
+  const int64_t nw      = (int64_t)gridDim.x * 4;
+  for (int64_t c = (int64_t)blockIdx.x * 4 + tid / GX_WAVE; c < nchunks; c += nw) {
+    const int64_t row = c * step + lane;
+    const bool live   = row < n && (!kvalid || bit_is_set(kvalid, row));
+    const K k         = keys[row < n ? row : 0];
+    const int64_t r64 = range_rows > 0 ? row / range_rows : (int64_t)(NRANGE - 1);
+    const int r       = r64 < NRANGE - 1 ? (int)r64 : NRANGE - 1;
+    (void)lds_rank(s_hist + r * NPART, (uint32_t)(part_hash<K>(k) >> psh), live);
+  }
+  __syncthreads();
+  for (int i = tid; i < NRANGE * NPART; i += 256) {
+    const uint32_t c = s_hist[i];
+    if (c) atomicAdd(&plan->samp[i / NPART][i % NPART], c);
+  }
+}
+
+// one block of NPART threads: capacities = estimate + 8 sigma of the estimate + two sample steps + a constant, slots laid
+// out partition-major (the NRANGE slots of a partition are neighbours)
+template <typename Plan>
+__global__ void __launch_bounds__(NPART) k_slot_plan(Plan* plan, int64_t n, int stride, int64_t range_rows, unsigned long long elems)
+{
+  __shared__ uint32_t s_tmp[NPART / GX_WAVE + 1];
+  const int t = threadIdx.x;
+  uint32_t cap[NRANGE];
+  uint32_t sum = 0;
+  for (int r = 0; r < NRANGE; ++r) {
+    const uint32_t c = plan->samp[r][t];
+    uint32_t total;
+    (void)block_exclusive_scan<NPART>(c, 0u, SumOp(), s_tmp, &total);
+    const int64_t b    = (int64_t)r * range_rows < n ? (int64_t)r * range_rows : n;
+    const int64_t e    = (r == NRANGE - 1) ? n : (b + range_rows < n ? b + range_rows : n);
+    const double rows  = (double)(e - b);
+    const double scale = total ? rows / (double)total : 0.0;
+    double cp          = (double)c * scale + 8.0 * scale * __builtin_sqrt((double)c + 1.0) + 2.0 * stride * GX_WAVE + 64.0;
+    if (cp > rows) cp = rows;
+    cap[r] = ((uint32_t)cp + 15u) & ~15u;
+    sum += cap[r];
+  }
+  uint32_t total;
+  uint32_t run = block_exclusive_scan<NPART>(sum, 0u, SumOp(), s_tmp, &total);
+  if ((unsigned long long)total > elems) {
+    if (t == 0) plan->overflow = 1u;
+    return;
+  }
+  for (int r = 0; r < NRANGE; ++r) {
+    plan->slot0[r][t] = run;
+    plan->cap0[r][t]  = cap[r];
+    run += cap[r];
+  }
 }
 // between the speculative and the exact pass: the fill counters become position cursors again (the exact k_part_offsets sets them)
 __global__ void __launch_bounds__(NPART) k_part_reset_cursors(PartPlan* plan)
@@ -655,7 +739,7 @@ int launch_partitioned(const K* keys, const uint32_t* kvalid, const V* vals, con
   if (hb > 256) hb = 256;
   if (hb < 1) hb = 1;
   constexpr int ESZ      = sizeof(K) > sizeof(V) ? sizeof(K) : sizeof(V);
-  constexpr size_t lds_s = (size_t)PTILE * ESZ + (HAS_VV ? PTILE : 0) + NPART * 4 * 2 + NPART * 8 + 64;
+  constexpr size_t lds_s = (size_t)PTILE * ESZ + (HAS_VV ? PTILE : 0) + NPART * 4 * 2 + NPART * 8 * 2 + 64;
   auto ks                = k_part_scatter<K, V, HAS_VV>;
   constexpr int S        = lds_slots<K, HAS_VV>();
   constexpr size_t lds_a = (size_t)(S + 1) * 16 + (size_t)(S + 2) * sizeof(K) + (size_t)(S + 1) * 4 * (HAS_VV ? 2 : 1);
@@ -673,7 +757,13 @@ int launch_partitioned(const K* keys, const uint32_t* kvalid, const V* vals, con
   const bool spec     = part_speculative(n);
   int gated           = 0;
   if (spec) {  // speculative pass: no histogram, padded slots (see PartPlan)
-    const uint32_t cap = part_cap(n);
+    const uint32_t cap       = 1u;  // != 0: the speculative form (slot tables in the plan)
+    const int stride         = slot_stride(n);
+    const int64_t range_rows = range_tiles(n) * PTILE;
+    int64_t sblocks          = div_up(div_up(n, (int64_t)stride * GX_WAVE), (int64_t)4 * 8);
+    if (sblocks > 2048) sblocks = 2048;
+    hipLaunchKernelGGL((k_slot_sample<K>), dim3((unsigned)sblocks), dim3(256), 0, s, keys, kvalid, n, plan, stride, range_rows);
+    hipLaunchKernelGGL((k_slot_plan<PartPlan>), dim3(1), dim3(NPART), 0, s, plan, n, stride, range_rows, (unsigned long long)slot_elems(n, stride));
     hipLaunchKernelGGL(ks, dim3(sgrd), dim3(PBT), lds_s, s, keys, kvalid, vals, vvalid, n, plan, pkeys, pvals, pflags, NRANGE, cap, 0);
     hipLaunchKernelGGL(ka, dim3(agrd), dim3(ABT), lds_a, s, pkeys, pvals, pflags, plan, nsplit, nsub, table, lg, sum, comp, cv, ca, st, cap,
                        0);
@@ -1046,8 +1136,9 @@ __global__ void __launch_bounds__(ABT) k_part_minmax(const K* __restrict__ pkeys
   unsigned long long p0, p1;
   if (cap) {
     const unsigned long long fill = plan->cursor[rg][part];
-    p0 = (unsigned long long)(part * NRANGE + rg) * cap;
-    p1 = p0 + (fill < cap ? fill : (unsigned long long)cap);
+    const unsigned long long scap = plan->cap0[rg][part];
+    p0 = plan->slot0[rg][part];
+    p1 = p0 + (fill < scap ? fill : scap);
   } else {
     p0 = plan->offset[part];
     p1 = plan->offset[part + 1];
@@ -1143,7 +1234,7 @@ int launch_partitioned_minmax(const K* keys, const uint32_t* kvalid, const V* va
   if (hb > 256) hb = 256;
   if (hb < 1) hb = 1;
   constexpr int ESZ      = sizeof(K) > sizeof(V) ? sizeof(K) : sizeof(V);
-  constexpr size_t lds_s = (size_t)PTILE * ESZ + (HAS_VV ? PTILE : 0) + NPART * 4 * 2 + NPART * 8 + 64;
+  constexpr size_t lds_s = (size_t)PTILE * ESZ + (HAS_VV ? PTILE : 0) + NPART * 4 * 2 + NPART * 8 * 2 + 64;
   auto ks                = k_part_scatter<K, V, HAS_VV>;
   constexpr int S        = lds_slots_mm<K, HAS_VV>();
   constexpr size_t lds_a = (size_t)(S + 1) * 16 + (size_t)(S + 2) * sizeof(K) + (size_t)(S + 1) * 4;
@@ -1161,7 +1252,13 @@ int launch_partitioned_minmax(const K* keys, const uint32_t* kvalid, const V* va
   const bool spec     = part_speculative(n);
   int gated           = 0;
   if (spec) {
-    const uint32_t cap = part_cap(n);
+    const uint32_t cap       = 1u;  // != 0: the speculative form (slot tables in the plan)
+    const int stride         = slot_stride(n);
+    const int64_t range_rows = range_tiles(n) * PTILE;
+    int64_t sblocks          = div_up(div_up(n, (int64_t)stride * GX_WAVE), (int64_t)4 * 8);
+    if (sblocks > 2048) sblocks = 2048;
+    hipLaunchKernelGGL((k_slot_sample<K>), dim3((unsigned)sblocks), dim3(256), 0, s, keys, kvalid, n, plan, stride, range_rows);
+    hipLaunchKernelGGL((k_slot_plan<PartPlan>), dim3(1), dim3(NPART), 0, s, plan, n, stride, range_rows, (unsigned long long)slot_elems(n, stride));
     hipLaunchKernelGGL(ks, dim3(sgrd), dim3(PBT), lds_s, s, keys, kvalid, vals, vvalid, n, plan, pkeys, pvals, pflags, NRANGE, cap, 0);
     hipLaunchKernelGGL(ka, dim3(agrd), dim3(ABT), lds_a, s, pkeys, pvals, pflags, plan, nsplit, nsub, table, lg, mn, mx, cv, st, cap, 0);
     hipLaunchKernelGGL(k_part_reset_cursors, dim3(1), dim3(NPART), 0, s, plan);
@@ -1545,52 +1642,6 @@ __global__ void __launch_bounds__(256) k_wide_sample(WideCols keys, int64_t n, W
   }
 }
 
-__global__ void __launch_bounds__(NPART) k_wide_plan(WidePlan* plan, int64_t n, int stride, int64_t range_rows, unsigned long long elems)
-{
-  __shared__ uint32_t s_tmp[NPART / GX_WAVE + 1];
-  const int t = threadIdx.x;
-  uint32_t cap[NRANGE];
-  uint32_t sum = 0;
-  for (int r = 0; r < NRANGE; ++r) {
-    const uint32_t c = plan->samp[r][t];
-    uint32_t total;
-    (void)block_exclusive_scan<NPART>(c, 0u, SumOp(), s_tmp, &total);
-    const int64_t b    = (int64_t)r * range_rows < n ? (int64_t)r * range_rows : n;
-    const int64_t e    = (r == NRANGE - 1) ? n : (b + range_rows < n ? b + range_rows : n);
-    const double rows  = (double)(e - b);
-    const double scale = total ? rows / (double)total : 0.0;
-    double cp          = (double)c * scale + 8.0 * scale * __builtin_sqrt((double)c + 1.0) + 2.0 * stride * GX_WAVE + 64.0;
-    if (cp > rows) cp = rows;
-    cap[r] = ((uint32_t)cp + 15u) & ~15u;
-    sum += cap[r];
-  }
-  uint32_t total;
-  uint32_t run = block_exclusive_scan<NPART>(sum, 0u, SumOp(), s_tmp, &total);
-  if ((unsigned long long)total > elems) {
-    if (t == 0) plan->overflow = 1u;
-    return;
-  }
-  for (int r = 0; r < NRANGE; ++r) {  // the NRANGE slots of a partition are neighbours
-    plan->slot0[r][t] = run;
-    plan->cap0[r][t]  = cap[r];
-    run += cap[r];
-  }
-}
-
-// rows the partitioned arrays must hold: n + the slack k_wide_plan hands out (Cauchy-Schwarz over the slots)
-static inline size_t wide_elems(int64_t n, int stride)
-{
-  const double slots = (double)NRANGE * (double)(1 << g_gb_pbits);
-  const double dev   = 8.0 * 1.25 * stride * __builtin_sqrt(slots * ((double)n / stride + 2.0 * slots));
-  return (size_t)((double)n * 1.002 + dev) + (size_t)slots * (size_t)(2 * stride * GX_WAVE + 64 + 16) + 65536;
-}
-static inline int wide_stride(int64_t n)
-{
-  int s = 1;
-  while (s < 32 && (n >> 22) >= 2 * s) s *= 2;
-  return s;
-}
-
 // 4096-row tiles (8 rows per thread): the W key words of a row stay in registers from the hash to their column pass, and
 // W x 8 x 2 VGPRs still leave room for the second workgroup per CU (16 rows per thread: 136 / 161 / 193 VGPRs for W = 2 / 3 / 4)
 constexpr int WRPT  = 8;
@@ -1860,8 +1911,8 @@ template <int W, typename V, bool IS_FLOAT>
 int wide_impl(const void* const* key_cols, const void* vals, int64_t n, int64_t max_groups, void* const* out_key_cols, void* out_sum,
               int32_t* out_cv, int64_t* ngroups, void* tmp, size_t* tmp_bytes, hipStream_t s)
 {
-  const int stride   = wide_stride(n);
-  const size_t elems = wide_elems(n, stride);
+  const int stride   = slot_stride(n);
+  const size_t elems = slot_elems(n, stride);
   Carver c(tmp);
   WidePlan* plan = c.take<WidePlan>(1);
   WideOut pk{};
@@ -1903,7 +1954,7 @@ int wide_impl(const void* const* key_cols, const void* vals, int64_t n, int64_t 
     if (sblocks > 2048) sblocks = 2048;
     if (sblocks < 1) sblocks = 1;
     hipLaunchKernelGGL((k_wide_sample<W>), dim3((unsigned)sblocks), dim3(256), 0, s, kc, n, plan, stride, range_rows);
-    hipLaunchKernelGGL(k_wide_plan, dim3(1), dim3(NPART), 0, s, plan, n, stride, range_rows, (unsigned long long)elems);
+    hipLaunchKernelGGL((k_slot_plan<WidePlan>), dim3(1), dim3(NPART), 0, s, plan, n, stride, range_rows, (unsigned long long)elems);
     hipLaunchKernelGGL(ks, dim3((unsigned)wtiles), dim3(PBT), lds_s, s, kc, static_cast<const V*>(vals), n, plan, pk, pv);
     hipLaunchKernelGGL(ka, dim3((unsigned)((1 << g_gb_pbits) * nsub)), dim3(ABT), lds_a, s, pk, pv, plan, nsub, max_groups, ok, out_sum, out_cv);
   }

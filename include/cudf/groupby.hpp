@@ -12,6 +12,7 @@
 
 #include <functional>
 #include <memory>
+#include <optional>
 #include <span>
 #include <utility>
 #include <vector>
@@ -94,6 +95,10 @@ class groupby {
   sort_impl::sort_groupby_helper& helper();
 
   std::pair<std::unique_ptr<table>, std::vector<aggregation_result>> sort_aggregate(
+    std::span<aggregation_request const> requests, rmm::cuda_stream_view stream, rmm::device_async_resource_ref mr);
+  // several 8-byte integer key columns, one SUM / COUNT / MEAN request, no nulls: one partition pass, rows compared in the LDS
+  // tables (gx_groupby_sum_count_wide); nullopt = not applicable or declined by the device
+  std::optional<std::pair<std::unique_ptr<table>, std::vector<aggregation_result>>> wide_aggregate(
     std::span<aggregation_request const> requests, rmm::cuda_stream_view stream, rmm::device_async_resource_ref mr);
   // exact_keys: encode multi-column keys through dense ranks instead of 8-byte row keys (the retry after a hash collision)
   std::pair<std::unique_ptr<table>, std::vector<aggregation_result>> aggregate_impl(

@@ -2,6 +2,8 @@
 // cudf::hash_join, cudf::groupby::groupby, cudf::reduce, cudf::scan ...) with the literal vectors of
 // the reference's gtest suites (file:line cited per case).  No gtest in this image: a minimal
 // harness.  Needs a GPU; run by tests/test_gpu_cpp_api.py.
+#include <map>
+#include <tuple>
 #include <cudf/aggregation.hpp>
 #include <cudf/column/column_factories.hpp>
 #include <cudf/copying.hpp>
@@ -439,6 +441,47 @@ int main()
     std::sort(all.begin(), all.end());
     CHECK(all == whole);
   });
+  run("groupby on several int64 key columns at size: one partition pass, rows compared in the LDS tables (gx_groupby_sum_count_wide)", [] {
+    // 400 000 rows, keys (i % 371, (7 i) % 113, i % 3): 371 x 113 x 3 tuples, all of them hit; host-side reference in a map
+    size_type const n = 400000;
+    std::vector<int64_t> a(n), b(n), c3(n), v(n);
+    std::map<std::tuple<int64_t, int64_t, int64_t>, std::pair<int64_t, int32_t>> want;
+    for (size_type i = 0; i < n; ++i) {
+      a[i]  = i % 371 - 100;
+      b[i]  = (7LL * i) % 113;
+      c3[i] = (i % 3) * (int64_t{1} << 40);
+      v[i]  = (i * 31LL) % 1000 - 500;
+      auto& w = want[{a[i], b[i], c3[i]}];
+      w.first += v[i];
+      w.second += 1;
+    }
+    auto ka = make_col<int64_t>(a), kb = make_col<int64_t>(b), kc = make_col<int64_t>(c3), vals = make_col<int64_t>(v);
+    groupby::groupby gb{table_view{{ka->view(), kb->view(), kc->view()}}};
+    std::vector<groupby::aggregation_request> reqs(1);
+    reqs[0].values = vals->view();
+    reqs[0].aggregations.emplace_back(make_sum_aggregation<groupby_aggregation>());
+    reqs[0].aggregations.emplace_back(make_count_aggregation<groupby_aggregation>());
+    reqs[0].aggregations.emplace_back(make_mean_aggregation<groupby_aggregation>());
+    auto [k, res] = gb.aggregate(reqs);
+    CHECK(k->num_columns() == 3 && static_cast<std::size_t>(k->num_rows()) == want.size());
+    auto h0 = to_host<int64_t>(k->get_column(0).view()), h1 = to_host<int64_t>(k->get_column(1).view()),
+         h2 = to_host<int64_t>(k->get_column(2).view());
+    auto hs = to_host<int64_t>(res[0].results[0]->view());
+    auto hc = to_host<int32_t>(res[0].results[1]->view());
+    auto hm = to_host<double>(res[0].results[2]->view());
+    std::size_t seen = 0;
+    for (std::size_t g = 0; g < h0.size(); ++g) {
+      auto it = want.find({h0[g], h1[g], h2[g]});
+      CHECK(it != want.end());
+      CHECK(it->second.first == hs[g] && it->second.second == hc[g]);
+      CHECK(hm[g] == static_cast<double>(hs[g]) / hc[g]);
+      it->second.second = -1;  // every group exactly once
+      ++seen;
+    }
+    CHECK(seen == want.size());
+    for (auto const& e : want) CHECK(e.second.second == -1);
+  });
+
   run("multi-column join keys (join_tests.cpp:1163-1283,1421-1500: numeric key columns)", [] {
     auto l0 = make_col<int32_t>({3, 1, 2, 0, 2}), l1 = make_col<int32_t>({1, 1, 0, 4, 0});
     auto r0 = make_col<int32_t>({2, 2, 0, 4, 3}), r1 = make_col<int32_t>({1, 0, 1, 2, 1});
