@@ -45,6 +45,7 @@ _PROTOS = {
     "gx_sort_profile_read": (_i, [ctypes.POINTER(ctypes.c_float), ctypes.POINTER(ctypes.c_float), ctypes.POINTER(_i)]),
     "gx_sort_profile_read_hybrid": (_i, [ctypes.POINTER(ctypes.c_float)]),
     "gx_sort_set_hybrid": (None, [_i]),
+    "gx_sort_set_experiment": (None, [_i]),
     "gx_sort_set_cursor_path": (None, [_i, ctypes.c_float]),
     "gx_sort_cursor_state": (_i, [_p, ctypes.POINTER(ctypes.c_int32), _p]),
     "gx_sort_set_cell": (None, [_i]),

@@ -1761,6 +1761,7 @@ struct FastCfg {
   size_t slot_rows;  // keys the padded level-0 output holds
 };
 static int g_cursor          = 1;     // 0 disables the cursor path (A/B knob)
+static int g_exp             = 0;     // ablation bits of k_local_sort (measurement only: the result is NOT sorted under most of them)
 static float g_cursor_margin = 8.0f;  // standard deviations of slack per level-0 slot (tests: < 0 forces the fallback)
 template <typename KeyT, int KIND, bool HAS_VAL>
 static FastCfg fast_cfg(int64_t n, int algo, bool hybrid_on)
@@ -1893,7 +1894,7 @@ int sort_impl(const void* keys_in, void* keys_out, const int32_t* vals_in, int32
       prof_mark_h(3, stream);
       hipLaunchKernelGGL((k_local_sort<KeyT, KIND, HAS_VAL, 13>), dim3((unsigned)(BINS << fc.bits2)), dim3((1 << 13) / 16),
                          ((size_t)sizeof(KeyT) << 13) + (size_t)(((1 << 13) / 16 / GX_WAVE) * BINS + 32 + 2 * BINS) * 4, stream, kb_scratch, bufA,
-                         (const uint32_t*)nullptr, (uint32_t*)nullptr, desc_mask, plan, hist2, base2, 0, 1);
+                         (const uint32_t*)nullptr, (uint32_t*)nullptr, desc_mask, plan, hist2, base2, g_exp, 1);
       prof_mark_h(4, stream);
       g_prof.hybrid_marked = g_prof.enabled;
       cursor_marked        = true;
@@ -2228,6 +2229,8 @@ int gx_sort_profile_read_hybrid(float* ms4)
 }
 
 void gx_sort_set_hybrid(int enable) { gx::sort::g_hybrid = enable ? 1 : 0; }
+
+void gx_sort_set_experiment(int bits) { gx::sort::g_exp = bits & 0x3C; }
 
 void gx_sort_set_cursor_path(int enable, float margin_sigmas)
 {

@@ -40,6 +40,11 @@ int gx_sort_profile_read_hybrid(float* ms4);
  * does not fit (skewed keys).  0 disables it (A/B measurements). */
 void gx_sort_set_hybrid(int enable);
 
+/* MEASUREMENT ONLY (the output is not sorted under these): ablation bits of the cursor path's local sort -- 4 = skip the
+ * per-wave sub-bucket sorts, 8 = no LDS atomics in the sub-bucket split (positions instead of ranks), 16 = sorting networks
+ * instead of the counting split, 32 = reserved.  0 = production. */
+void gx_sort_set_experiment(int bits);
+
 /* Cursor path of the hybrid sort (integer 64-bit keys, keys only, n >= 2^25; default on): the digit positions and
  * the slot capacities of the first partition level come from a 1/32 SAMPLE, both partition levels reserve their output
  * runs with one atomic per (tile, bin) instead of a look-back chain, and the first level -- which reads every key anyway --
