@@ -552,6 +552,40 @@ __host__ __device__ __forceinline__ uint32_t hash_combine32(uint32_t lhs, uint32
   return lhs ^ (rhs + 0x9e3779b9u + (lhs << 6) + (lhs >> 2));
 }
 
+// ---- per-THREAD sorting networks over 16 registers (the local sort's window passes, gx_sort.hip k_local_sort).
+// sort16_regs: the 60-comparator, 10-layer network for 16 inputs (Green's; checked with the 0-1 principle over all 2^16
+// inputs, tests/test_kernel_formulas.py).  merge16_regs: Batcher's odd-even merge of two ascending runs v[0..7] and
+// v[8..15], 25 comparators.  Indices are compile-time constants, so the 16 keys never leave their registers.
+#define GX_CE(a, b)                          \
+  {                                          \
+    const bool s_ = v[b] < v[a];             \
+    const uint64_t lo_ = s_ ? v[b] : v[a];   \
+    v[b]               = s_ ? v[a] : v[b];   \
+    v[a]               = lo_;                \
+  }
+__device__ __forceinline__ void sort16_regs(uint64_t (&v)[16])
+{
+  GX_CE(0, 13); GX_CE(1, 12); GX_CE(2, 15); GX_CE(3, 14); GX_CE(4, 8); GX_CE(5, 6);
+  GX_CE(7, 11); GX_CE(9, 10); GX_CE(0, 5); GX_CE(1, 7); GX_CE(2, 9); GX_CE(3, 4);
+  GX_CE(6, 13); GX_CE(8, 14); GX_CE(10, 15); GX_CE(11, 12); GX_CE(0, 1); GX_CE(2, 3);
+  GX_CE(4, 5); GX_CE(6, 8); GX_CE(7, 9); GX_CE(10, 11); GX_CE(12, 13); GX_CE(14, 15);
+  GX_CE(0, 2); GX_CE(1, 3); GX_CE(4, 10); GX_CE(5, 11); GX_CE(6, 7); GX_CE(8, 9);
+  GX_CE(12, 14); GX_CE(13, 15); GX_CE(1, 2); GX_CE(3, 12); GX_CE(4, 6); GX_CE(5, 7);
+  GX_CE(8, 10); GX_CE(9, 11); GX_CE(13, 14); GX_CE(1, 4); GX_CE(2, 6); GX_CE(5, 8);
+  GX_CE(7, 10); GX_CE(9, 13); GX_CE(11, 14); GX_CE(2, 4); GX_CE(3, 6); GX_CE(9, 12);
+  GX_CE(11, 13); GX_CE(3, 5); GX_CE(6, 8); GX_CE(7, 9); GX_CE(10, 12); GX_CE(3, 4);
+  GX_CE(5, 6); GX_CE(7, 8); GX_CE(9, 10); GX_CE(11, 12); GX_CE(6, 7); GX_CE(8, 9);
+}
+__device__ __forceinline__ void merge16_regs(uint64_t (&v)[16])
+{
+  GX_CE(0, 8); GX_CE(1, 9); GX_CE(2, 10); GX_CE(3, 11); GX_CE(4, 12); GX_CE(5, 13);
+  GX_CE(6, 14); GX_CE(7, 15); GX_CE(4, 8); GX_CE(5, 9); GX_CE(6, 10); GX_CE(7, 11);
+  GX_CE(2, 4); GX_CE(3, 5); GX_CE(6, 8); GX_CE(7, 9); GX_CE(10, 12); GX_CE(11, 13);
+  GX_CE(1, 2); GX_CE(3, 4); GX_CE(5, 6); GX_CE(7, 8); GX_CE(9, 10); GX_CE(11, 12);
+  GX_CE(13, 14);
+}
+#undef GX_CE
+
 // XCD-aware tile mapping: the dispatcher is observed to place block b on XCD b % 8
 // (MI355X_MICROARCH.md, "Workgroup dispatch").  Give each XCD a contiguous range of tiles so
 // neighbouring tiles share an L2 (speed only; correctness never depends on it).

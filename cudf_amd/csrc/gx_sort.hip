@@ -67,6 +67,8 @@ struct HybridPlan {
   uint32_t hist0[BINS], gbin0[BINS];   // level-0 digit histogram of the whole column and its exclusive scan
   uint32_t rh0[NRANGE][BINS];          // range-resolved level-0 histogram
   uint32_t rhist[NRANGE][MAX_PASSES][BINS];  // range-resolved byte histograms (k_hist_all, LSD path)
+  alignas(128) uint32_t todo_count;          // k_local_place: cells left to k_local_sort (a line of its own: atomics)
+  uint32_t todo_pad[31];
 };
 
 // Round 3, the CURSOR path (integer keys, keys only): plan of the speculative passes, see k_hf_scatter
@@ -1015,8 +1017,10 @@ __global__ void __launch_bounds__(GX_WAVE) k_plan2(SortPlan* plan, const uint32_
 template <typename KeyT, int KIND, bool HAS_VAL, int CL2>
 __device__ __forceinline__ void pairs_write_out(KeyT* s_keys, const KeyT* __restrict__ in_cell, KeyT* __restrict__ out,
                                                 const uint32_t* __restrict__ vin_cell, uint32_t* __restrict__ vout,
-                                                int64_t start, uint32_t m, int shift2, KeyT desc_mask, bool write_keys = true)
+                                                int64_t start, uint32_t m, int shift2, KeyT desc_mask, bool write_keys = true,
+                                                bool padded = false)
 {
+  // padded: the sorted words sit at s_keys[i + (i >> 4)] (k_local_place's layout), not at s_keys[i]
   // write_keys = false (sorted_order: only the permutation is asked for): the 8 B/row key write-back is skipped
   // in_cell / vin_cell point at the cell's slot; out / vout are indexed from `start`
   const KeyT* in      = in_cell - start;
@@ -1031,7 +1035,7 @@ __device__ __forceinline__ void pairs_write_out(KeyT* s_keys, const KeyT* __rest
     const int i = j * LS_BT + (int)tid;
     pos[j]      = 0;
     if ((uint32_t)i < m) {
-      const KeyT wd = s_keys[i];
+      const KeyT wd = s_keys[padded ? i + (i >> 4) : i];
       pos[j]        = (uint32_t)wd & ((1u << LS_POS_BITS) - 1u);
       if (KIND != K_FLOAT && write_keys) out[start + i] = to_sortable<KeyT, KIND>(hi | ((wd >> LS_POS_BITS) & lowmask), desc_mask);
     }
@@ -1066,12 +1070,154 @@ __device__ __forceinline__ void pairs_write_out(KeyT* s_keys, const KeyT* __rest
   }
 }
 
+// ---- k_local_place (round 3, 8192-key cells; integer keys and packed (key bits, position) words): ONE counting pass on the
+// 13 bits below the level-1 digit puts every key within a few positions of where it belongs -- 8192 bins for <= 8192
+// keys, 0.93 keys per bin on uniform keys -- and two passes of per-THREAD networks over 16 registers finish the job:
+// thread t sorts positions [16t, 16t + 16) (60 comparators), then merges its upper half with the lower half of thread
+// t + 1 (25 comparators), i.e. sorts the window shifted by 8.  A bin of <= 9 keys lies inside an aligned or inside a
+// shifted window and bins are ordered among themselves, so the two passes together sort the cell.  A cell with a fuller
+// bin (duplicate keys, a cluster; 5e-8 per bin on uniform keys) is left alone and its number appended to `todo`:
+// k_local_sort, launched behind, sorts exactly those cells with its sub-bucket path.  The counters are BYTES (8 KiB for
+// 8192 bins): a returning add of 1 << 8 * (bin & 3) on the bin's word, the old byte is the key's rank inside its bin;
+// the add that sees 255 is about to carry into the neighbouring bin and raises the same flag.
+// Against k_local_sort's sub-bucket path: ~85 comparators and one counting pass per 16 keys with 16 independent keys per
+// lane in flight at every step, instead of 16 sub-buckets per wave taken two at a time through a chain of six dependent
+// LDS round trips each (2.7 of its 5.5 ms, profiles/r3_run21_local_sort_ablation.txt).
+// LDS: 8192 keys with one key of padding per 16 (a thread's window is 17 keys from its neighbour's: conflict-free
+// 8-byte accesses) + 8 KiB of counters + 512 bin-group bases + scan words = 78.1 KiB, two workgroups per CU.
+template <typename KeyT, int KIND, bool HAS_VAL>
+__device__ __forceinline__ bool place_applies(const HybridPlan& hy, int exp)
+{
+  if (KIND == K_FLOAT) return false;  // float keys take 16384-key cells
+  const int word_bits = hy.shift2 + (HAS_VAL ? 13 : 0);  // pairs always arrive packed (k_hy_plan's pos_bits rule)
+  return hy.nlocal > 0 && !(exp & (32 | 16 | 8 | 4)) && word_bits >= 13 && word_bits <= 64;
+}
+constexpr size_t place_lds_bytes() { return (size_t)(8192 + 512) * 8 + 8192 + 512 * 4 + 32 * 4; }
+
+template <typename KeyT, int KIND, bool HAS_VAL>
+__global__ void __launch_bounds__(512, 4) k_local_place(const KeyT* in, KeyT* __restrict__ out, const uint32_t* vin,
+                                                        uint32_t* __restrict__ vout, KeyT desc_mask, SortPlan* plan,
+                                                        const uint32_t* __restrict__ hist2, const uint32_t* __restrict__ base2,
+                                                        uint32_t* __restrict__ todo, int exp, int cursor_path)
+{
+  static_assert(sizeof(KeyT) == 8, "64-bit keys");
+  constexpr int CL2 = 13, LOCAL_MAX = 1 << CL2, LS_KPT = 16, LS_BT = LOCAL_MAX / LS_KPT, PB = 13, NPB = 1 << PB;
+  HybridPlan& hy = plan->hy;
+  if (!hy.attempt || !hy.ok || (plan->hf.state == 3) != (cursor_path != 0)) return;
+  if (!place_applies<KeyT, KIND, HAS_VAL>(hy, exp)) return;
+  const int bits2 = hy.bits2;
+  if (blockIdx.x >= ((unsigned)BINS << bits2)) return;
+  const uint32_t b  = blockIdx.x >> bits2;
+  const uint32_t d2 = blockIdx.x & ((1u << bits2) - 1u);
+  const uint32_t m  = hist2[b * NB2MAX + d2];
+  if (m == 0) return;
+  const int64_t start = base2[b * NB2MAX + d2];
+  in += (int64_t)blockIdx.x * LOCAL_MAX - start;  // the cell sits in its slot of the padded level-1 buffer
+  if (HAS_VAL) vin += (int64_t)blockIdx.x * LOCAL_MAX - start;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  KeyT* s_keys     = reinterpret_cast<KeyT*>(smem);                                                  // 8192 + 512
+  uint32_t* s_cnt8 = reinterpret_cast<uint32_t*>(smem + (size_t)(LOCAL_MAX + LOCAL_MAX / 16) * 8);  // NPB bytes
+  uint32_t* s_base = s_cnt8 + NPB / 4;                                                               // [LS_BT] first position of bin 16 t
+  uint32_t* s_scan = s_base + LS_BT;                                                                 // [32]
+  const unsigned tid  = threadIdx.x;
+  const unsigned lane = lane_id();
+  const int wbase     = (int)(tid / GX_WAVE) * (LS_KPT * GX_WAVE) + (int)lane;
+  const int shift2    = hy.shift2;
+  const int dshift    = shift2 + (HAS_VAL ? CL2 : 0) - PB;
+
+  reinterpret_cast<uint4*>(s_cnt8)[tid] = make_uint4(0u, 0u, 0u, 0u);
+  KeyT key[LS_KPT];
+#pragma unroll
+  for (int j = 0; j < LS_KPT; ++j) {
+    const int idx = wbase + j * GX_WAVE;
+    const KeyT k  = ((uint32_t)idx < m) ? in[start + idx] : KeyT(0);
+    const KeyT sk = to_sortable<KeyT, KIND>(k, desc_mask);
+    key[j]        = HAS_VAL ? (KeyT)(((sk & ((KeyT(1) << shift2) - KeyT(1))) << CL2) | (KeyT)idx) : sk;
+  }
+  __syncthreads();
+  uint32_t rk[LS_KPT / 4] = {0u, 0u, 0u, 0u};  // rank inside the bin, one byte per key
+  bool full = false;
+#pragma unroll
+  for (int j = 0; j < LS_KPT; ++j) {
+    const int idx = wbase + j * GX_WAVE;
+    if ((uint32_t)idx < m) {
+      const uint32_t bin = (uint32_t)(key[j] >> dshift) & (uint32_t)(NPB - 1);
+      const uint32_t sh8 = (bin & 3u) * 8u;
+      const uint32_t r   = (atomicAdd(&s_cnt8[bin >> 2], 1u << sh8) >> sh8) & 0xFFu;
+      full |= r == 0xFFu;
+      rk[j >> 2] |= r << (8 * (j & 3));
+    }
+  }
+  __syncthreads();
+  // bins 16 tid .. 16 tid + 15: byte-wise exclusive prefix inside the thread (x * 0x01010101 = inclusive prefix of the four
+  // bytes of a word while the sums stay below 256: 16 bins x <= 9 keys), then a block scan of the thread totals
+  const uint4 c4 = reinterpret_cast<uint4*>(s_cnt8)[tid];
+  auto ge10 = [](uint32_t x) { return ((((x & 0x7F7F7F7Fu) + 0x76767676u) | x) & 0x80808080u) != 0u; };
+  const bool crowded = ge10(c4.x) | ge10(c4.y) | ge10(c4.z) | ge10(c4.w);
+  if (__syncthreads_or(full || crowded)) {
+    if (tid == 0) todo[atomicAdd(&hy.todo_count, 1u)] = blockIdx.x;
+    return;
+  }
+  const uint32_t p0 = c4.x * 0x01010101u, p1 = c4.y * 0x01010101u, p2 = c4.z * 0x01010101u, p3 = c4.w * 0x01010101u;
+  const uint32_t t0 = p0 >> 24, t1 = t0 + (p1 >> 24), t2 = t1 + (p2 >> 24), t3 = t2 + (p3 >> 24);
+  uint4 e4;
+  e4.x = p0 - c4.x;
+  e4.y = p1 - c4.y + t0 * 0x01010101u;
+  e4.z = p2 - c4.z + t1 * 0x01010101u;
+  e4.w = p3 - c4.w + t2 * 0x01010101u;
+  const uint32_t first = block_exclusive_scan<LS_BT>(t3, 0u, SumOp(), s_scan, (uint32_t*)nullptr);
+  reinterpret_cast<uint4*>(s_cnt8)[tid] = e4;
+  s_base[tid]                           = first;
+  __syncthreads();
+  const uint8_t* s_off8 = reinterpret_cast<const uint8_t*>(s_cnt8);
+#pragma unroll
+  for (int j = 0; j < LS_KPT; ++j) {
+    const int idx = wbase + j * GX_WAVE;
+    if ((uint32_t)idx < m) {
+      const uint32_t bin = (uint32_t)(key[j] >> dshift) & (uint32_t)(NPB - 1);
+      const uint32_t pos = s_base[bin >> 4] + (uint32_t)s_off8[bin] + ((rk[j >> 2] >> (8 * (j & 3))) & 0xFFu);
+      s_keys[pos + (pos >> 4)] = key[j];
+    }
+  }
+  __syncthreads();
+  uint64_t v[16];
+  KeyT* mine = s_keys + 17 * tid;  // positions 16 tid .. 16 tid + 15
+#pragma unroll
+  for (int i = 0; i < 16; ++i) v[i] = (16u * tid + (uint32_t)i < m) ? (uint64_t)mine[i] : ~0ull;
+  sort16_regs(v);
+#pragma unroll
+  for (int i = 0; i < 8; ++i) mine[i] = (KeyT)v[i];  // the lower half: final for thread 0, merged by thread tid - 1 otherwise
+  __syncthreads();
+#pragma unroll
+  for (int i = 0; i < 8; ++i) {
+    v[i]     = v[8 + i];
+    v[8 + i] = (tid + 1 < (unsigned)LS_BT) ? (uint64_t)mine[17 + i] : ~0ull;
+  }
+  merge16_regs(v);
+#pragma unroll
+  for (int i = 0; i < 8; ++i) mine[8 + i] = (KeyT)v[i];
+  if (tid + 1 < (unsigned)LS_BT) {
+#pragma unroll
+    for (int i = 0; i < 8; ++i) mine[17 + i] = (KeyT)v[8 + i];
+  }
+  __syncthreads();
+  if (HAS_VAL) {
+    pairs_write_out<KeyT, KIND, HAS_VAL, CL2>(s_keys, in + start, out, vin + start, vout, start, m, shift2, desc_mask, !(exp & 64), true);
+    return;
+  }
+#pragma unroll
+  for (int j = 0; j < LS_KPT; ++j) {
+    const int i = j * LS_BT + (int)tid;
+    if ((uint32_t)i < m) out[start + i] = to_sortable<KeyT, KIND>(s_keys[i + (i >> 4)], desc_mask);  // an involution for integer kinds
+  }
+}
+
 template <typename KeyT, int KIND, bool HAS_VAL, int CL2>
 __global__ void __launch_bounds__((1 << CL2) / 16, 4) k_local_sort(const KeyT* in, KeyT* __restrict__ out,
                                                       const uint32_t* vin, uint32_t* __restrict__ vout,
                                                       KeyT desc_mask_in, SortPlan* plan,
                                                       const uint32_t* __restrict__ hist2, const uint32_t* __restrict__ base2,
-                                                      int exp = 0, int cursor_path = 0)
+                                                      int exp = 0, int cursor_path = 0, const uint32_t* __restrict__ todo = nullptr)
 {
   // PAIRS = the packed-word mode: pairs, and float keys (whose -0.0 == +0.0 ties must keep input order
   // and whose original bits cannot be rebuilt from the sortable form)
@@ -1093,13 +1239,21 @@ __global__ void __launch_bounds__((1 << CL2) / 16, 4) k_local_sort(const KeyT* i
   uint32_t* s_scan  = s_whist + LS_NW * BINS;                                                 // [32]
   const int bits2   = hy.bits2;
   if (blockIdx.x >= ((unsigned)BINS << bits2)) return;
-  const uint32_t b  = blockIdx.x >> bits2;
-  const uint32_t d2 = blockIdx.x & ((1u << bits2) - 1u);
+  // 8192-key cells: k_local_place has sorted every cell but the crowded ones, whose numbers it left in `todo`
+  uint32_t cell = blockIdx.x;
+  if constexpr (CL2 == 13 && KIND != K_FLOAT) {
+    if (todo != nullptr && place_applies<KeyT, KIND, HAS_VAL>(hy, exp)) {
+      if (cell >= hy.todo_count) return;
+      cell = todo[cell];
+    }
+  }
+  const uint32_t b  = cell >> bits2;
+  const uint32_t d2 = cell & ((1u << bits2) - 1u);
   const uint32_t m  = hist2[b * NB2MAX + d2];  // cell size (level-1 pass), output position (k_plan2)
   if (m == 0) return;
   const int64_t start = base2[b * NB2MAX + d2];
-  in += (int64_t)blockIdx.x * LOCAL_MAX - start;  // the cell sits in its slot of the padded level-1 buffer
-  if (HAS_VAL) vin += (int64_t)blockIdx.x * LOCAL_MAX - start;
+  in += (int64_t)cell * LOCAL_MAX - start;  // the cell sits in its slot of the padded level-1 buffer
+  if (HAS_VAL) vin += (int64_t)cell * LOCAL_MAX - start;
   const unsigned tid  = threadIdx.x;
   const unsigned lane = lane_id();
   const unsigned w    = tid / GX_WAVE;
@@ -1808,6 +1962,7 @@ int sort_impl(const void* keys_in, void* keys_out, const int32_t* vals_in, int32
   uint32_t* base1 = c.take<uint32_t>((size_t)NRANGE * NB2MAX);
   uint32_t* hist2 = try_hybrid ? c.take<uint32_t>((size_t)2 * BINS * NB2MAX) : nullptr;  // cell sizes | cell output positions
   uint32_t* base2 = try_hybrid ? hist2 + BINS * NB2MAX : nullptr;
+  uint32_t* todo  = try_hybrid ? c.take<uint32_t>((size_t)BINS * NB2MAX) : nullptr;  // cells k_local_place leaves to k_local_sort
   const int64_t msd_tile     = (int64_t)BT * hyb_kpt;  // tile of the hybrid partition passes
   const int64_t msd_ntiles   = n > 0 ? div_up(n, msd_tile) : 0;
   const int64_t status_tiles = (msd_ntiles > ntiles ? msd_ntiles : ntiles) + BINS + 2 * NRANGE;  // segment tails add at most one tile each
@@ -1869,6 +2024,8 @@ int sort_impl(const void* keys_in, void* keys_out, const int32_t* vals_in, int32
         GX_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(k_hf_scatter<KeyT, KIND, 1, 10>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_hf(1024)));
         GX_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(k_local_sort<KeyT, KIND, HAS_VAL, 13>), hipFuncAttributeMaxDynamicSharedMemorySize,
                                        (int)(((size_t)sizeof(KeyT) << 13) + (size_t)(((1 << 13) / 16 / GX_WAVE) * BINS + 32 + 2 * BINS) * 4)));
+        GX_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(k_local_place<KeyT, KIND, HAS_VAL>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                       (int)place_lds_bytes()));
         fattr_set = true;
       }
       const int64_t step = (int64_t)fc.stride * HF_CHUNK;
@@ -1892,9 +2049,11 @@ int sort_impl(const void* keys_in, void* keys_out, const int32_t* vals_in, int32
       prof_mark_h(2, stream);
       hipLaunchKernelGGL(k_plan2, dim3(BINS), dim3(GX_WAVE), 0, stream, plan, hist2, base2, NPASS, 1);
       prof_mark_h(3, stream);
+      hipLaunchKernelGGL((k_local_place<KeyT, KIND, HAS_VAL>), dim3((unsigned)(BINS << fc.bits2)), dim3((1 << 13) / 16), place_lds_bytes(), stream,
+                         kb_scratch, bufA, (const uint32_t*)nullptr, (uint32_t*)nullptr, desc_mask, plan, hist2, base2, todo, g_exp, 1);
       hipLaunchKernelGGL((k_local_sort<KeyT, KIND, HAS_VAL, 13>), dim3((unsigned)(BINS << fc.bits2)), dim3((1 << 13) / 16),
                          ((size_t)sizeof(KeyT) << 13) + (size_t)(((1 << 13) / 16 / GX_WAVE) * BINS + 32 + 2 * BINS) * 4, stream, kb_scratch, bufA,
-                         (const uint32_t*)nullptr, (uint32_t*)nullptr, desc_mask, plan, hist2, base2, g_exp, 1);
+                         (const uint32_t*)nullptr, (uint32_t*)nullptr, desc_mask, plan, hist2, base2, g_exp, 1, todo);
       prof_mark_h(4, stream);
       g_prof.hybrid_marked = g_prof.enabled;
       cursor_marked        = true;
@@ -1928,6 +2087,7 @@ int sort_impl(const void* keys_in, void* keys_out, const int32_t* vals_in, int32
         if constexpr (SMALLOK) {
           GX_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(k_msd_pass<KeyT, KIND, HAS_VAL, SKPT, 4, 9>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_msd(SKPT, NB9)));
           GX_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(k_local_sort<KeyT, KIND, HAS_VAL, 13>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_loc(13)));
+          GX_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(k_local_place<KeyT, KIND, HAS_VAL>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)place_lds_bytes()));
         }
         hattr_set = true;
       }
@@ -1981,7 +2141,8 @@ int sort_impl(const void* keys_in, void* keys_out, const int32_t* vals_in, int32
       m.out       = bufA;
       m.base      = base1;
       m.level     = 0;
-      m.exp       = (HAS_VAL && keys_out == nullptr) ? 64 : 0;  // bit 6: the caller wants the permutation only (sorted_order): no key write-back
+      m.exp       = ((HAS_VAL && keys_out == nullptr) ? 64 : 0) | (g_exp & 32);  // bit 6: the caller wants the permutation only (sorted_order): no key
+                                                                                  // write-back; bit 5 (knob): k_local_sort's sub-bucket path for every cell
       m.cellcount = hist2;
       m.cellcap   = 1u << hc.cl2;
       if (!cursor_marked) prof_mark_h(0, stream);
@@ -1996,8 +2157,16 @@ int sort_impl(const void* keys_in, void* keys_out, const int32_t* vals_in, int32
       if (!cursor_marked) prof_mark_h(2, stream);
       hipLaunchKernelGGL(k_plan2, dim3(BINS), dim3(GX_WAVE), 0, stream, plan, hist2, base2, NPASS, 0);
       if (!cursor_marked) prof_mark_h(3, stream);
+      bool placed = false;
+      if constexpr (SMALLOK) {
+        if (hc.cl2 == 13) {
+          hipLaunchKernelGGL((k_local_place<KeyT, KIND, HAS_VAL>), dim3((unsigned)(BINS << hc.bits2)), dim3(ls_bt), place_lds_bytes(), stream,
+                             (const KeyT*)bufB, bufA, (const uint32_t*)valB, valA, desc_mask, plan, hist2, base2, todo, m.exp, 0);
+          placed = true;
+        }
+      }
       hipLaunchKernelGGL(kloc, dim3((unsigned)(BINS << hc.bits2)), dim3(ls_bt), lds_loc(hc.cl2), stream, bufB, bufA, valB, valA, desc_mask,
-                         plan, hist2, base2, m.exp, 0);
+                         plan, hist2, base2, m.exp, 0, placed ? (const uint32_t*)todo : (const uint32_t*)nullptr);
       if (!cursor_marked) prof_mark_h(4, stream);
       if (!cursor_marked) g_prof.hybrid_marked = g_prof.enabled;
     }
@@ -2259,6 +2428,15 @@ int gx_sort_info(const void* tmp, int32_t* info8_host, gx_stream_t stream)
   GX_HIP_TRY(hipMemcpyAsync(info8_host, &plan->hy, 6 * sizeof(int32_t), hipMemcpyDeviceToHost, stream));
   GX_HIP_TRY(hipMemcpyAsync(info8_host + 6, &plan->hy.max_cell, sizeof(int32_t), hipMemcpyDeviceToHost, stream));
   GX_HIP_TRY(hipMemcpyAsync(info8_host + 7, &plan->num_active, sizeof(int32_t), hipMemcpyDeviceToHost, stream));
+  GX_HIP_TRY(hipStreamSynchronize(stream));
+  return 0;
+}
+
+int gx_sort_place_info(const void* tmp, int32_t* todo_cells_host, gx_stream_t stream)
+{
+  if (!tmp || !todo_cells_host) return GX_EINVAL;
+  const auto* plan = static_cast<const gx::sort::SortPlan*>(tmp);
+  GX_HIP_TRY(hipMemcpyAsync(todo_cells_host, &plan->hy.todo_count, sizeof(int32_t), hipMemcpyDeviceToHost, stream));
   GX_HIP_TRY(hipStreamSynchronize(stream));
   return 0;
 }

@@ -40,10 +40,15 @@ int gx_sort_profile_read_hybrid(float* ms4);
  * does not fit (skewed keys).  0 disables it (A/B measurements). */
 void gx_sort_set_hybrid(int enable);
 
-/* MEASUREMENT ONLY (the output is not sorted under these): ablation bits of the cursor path's local sort -- 4 = skip the
- * per-wave sub-bucket sorts, 8 = no LDS atomics in the sub-bucket split (positions instead of ranks), 16 = sorting networks
- * instead of the counting split, 32 = reserved.  0 = production. */
+/* Bits of the hybrid path's local sort.  MEASUREMENT ONLY (the output is not sorted under these): 4 = skip the per-wave
+ * sub-bucket sorts, 8 = no LDS atomics in the sub-bucket split (positions instead of ranks), 16 = sorting networks instead
+ * of the counting split.  A/B knob (the output IS sorted): 32 = every 8192-key cell takes k_local_sort's sub-bucket path,
+ * i.e. k_local_place (counting placement + per-thread window networks) is switched off.  0 = production. */
 void gx_sort_set_experiment(int bits);
+/* Cells of the last hybrid sort that used `tmp` which k_local_place found crowded (a bin of the 13-bit counting pass with
+ * more than 9 keys: duplicates, clusters) and left to k_local_sort; 0 when every cell was placed, or when k_local_place
+ * did not apply (16384-key cells, float keys, fewer than 13 key bits left, knob).  Synchronises `stream`. */
+int gx_sort_place_info(const void* tmp, int32_t* todo_cells_host, gx_stream_t stream);
 
 /* Cursor path of the hybrid sort (integer 64-bit keys, keys only, n >= 2^25; default on): the digit positions and
  * the slot capacities of the first partition level come from a 1/32 SAMPLE, both partition levels reserve their output

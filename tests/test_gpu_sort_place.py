@@ -1,0 +1,132 @@
+"""k_local_place (gx_sort.hip): the counting placement + per-thread window networks that sort the 8192-key cells of the
+hybrid radix sort (cudf::sort / sorted_order of one 64-bit integer column, n >= 2^22; replaces the cub::DeviceRadixSort
+passes of cpp/src/sort/sort_radix.cu:66-117 and sorted_order_radix.cu:83-94).  A cell whose 13-bit counting pass finds a
+bin with more than 9 keys is left to k_local_sort's sub-bucket path; the device decides per cell.  Every case is compared
+bit for bit with the oracle, and the test pins WHICH kernel sorted the cells (gx_sort_place_info = cells left to
+k_local_sort), so that a silent fall-back cannot hide a broken placement behind a correct result and vice versa.
+"""
+import ctypes
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+from oracle import c_oracle
+from oracle import cudf_oracle as orc
+
+
+@pytest.fixture(scope="module")
+def gx():
+    import torch
+    assert torch.cuda.is_available()
+    import cudf_amd  # noqa: F401
+    from cudf_amd import Column, ops, _lib as L
+    yield Column, ops, L
+    L.lib.gx_sort_set_experiment(0)
+
+
+def _sort(gx, v, descending=False):
+    """gx_sort_keys through the C ABI -> (sorted array, info8, cells left to k_local_sort)"""
+    Column, ops, L = gx
+    col = Column.from_numpy(v)
+    out = Column.empty(v.dtype, v.size)
+    tmp = ops._run(L.lib.gx_sort_keys, col.gx, col.data_ptr, out.data_ptr, col.size, int(descending))
+    ops._check_sort_status(tmp)
+    info = (ctypes.c_int32 * 8)()
+    L.check(L.lib.gx_sort_info(ops.ptr(tmp), info, ops.stream_ptr()), "gx_sort_info")
+    todo = ctypes.c_int32(-1)
+    L.check(L.lib.gx_sort_place_info(ops.ptr(tmp), ctypes.byref(todo), ops.stream_ptr()), "gx_sort_place_info")
+    return out.to_numpy(), list(info), todo.value
+
+
+def _order(gx, v, descending=False):
+    Column, ops, L = gx
+    return ops.sorted_order(Column.from_numpy(v), ascending=not descending).to_numpy()
+
+
+def _cells(info):
+    return 256 << info[4]
+
+
+@pytest.mark.parametrize("dtype", ["int64", "uint64"])
+@pytest.mark.parametrize("n", [(1 << 22) + 777, 20_000_003, 40_000_000])
+def test_uniform_keys_are_placed(gx, dtype, n):
+    """uniform keys: the cells go through the placement (a bin of 10 keys has probability 1e-9 .. 6e-8 depending on how full
+    the cells are, so at most a stray cell may be left to the sub-bucket path), both directions; n covers the look-back path
+    (< 2^25) and the cursor path"""
+    rng = np.random.default_rng(n % 1000)
+    info_t = np.iinfo(dtype)
+    v = rng.integers(info_t.min, info_t.max, n, dtype=dtype, endpoint=True)
+    for desc in (False, True):
+        got, info, todo = _sort(gx, v, desc)
+        exp = np.sort(v)[::-1] if desc else np.sort(v)
+        assert got.tobytes() == exp.tobytes(), (dtype, n, desc, info)
+        assert info[1] == 1, f"the hybrid path must have sorted the column: {info}"
+        assert 0 <= todo <= 2, f"{todo} of {_cells(info)} cells were left to the sub-bucket path"
+
+
+def test_crowded_cells_go_to_the_sub_bucket_path(gx):
+    """a few keys repeated 40 times each: exactly their cells are crowded -> k_local_sort sorts those, k_local_place the rest"""
+    rng = np.random.default_rng(3)
+    n = 30_000_000
+    v = rng.integers(-2**63, 2**63 - 1, n, dtype=np.int64)
+    hot = rng.choice(n, 25, replace=False)
+    for h in hot:
+        v[rng.choice(n, 40, replace=False)] = v[h]
+    got, info, todo = _sort(gx, v)
+    assert got.tobytes() == c_oracle.sort_i64(v).tobytes()
+    assert info[1] == 1 and 1 <= todo <= 25 + 2, (info, todo)
+    # every cell crowded: each key 20 times (cells of ~4900 keys +- 300: they still fit their slots)
+    n = 20_000_000
+    runs = rng.integers(-2**63, 2**63 - 1, n // 20, dtype=np.int64)
+    v = np.repeat(runs, 20)
+    rng.shuffle(v)
+    got, info, todo = _sort(gx, v, True)
+    assert got.tobytes() == c_oracle.sort_i64(v, descending=True).tobytes()
+    assert info[1] == 1 and todo > _cells(info) // 2, (info, todo)
+
+
+def test_knob_32_takes_the_sub_bucket_path_and_agrees(gx):
+    Column, ops, L = gx
+    rng = np.random.default_rng(4)
+    v = rng.integers(0, 2**64 - 1, 9_000_000, dtype=np.uint64)
+    L.lib.gx_sort_set_experiment(32)
+    try:
+        a, info_a, todo_a = _sort(gx, v)
+    finally:
+        L.lib.gx_sort_set_experiment(0)
+    b, info_b, todo_b = _sort(gx, v)
+    assert a.tobytes() == b.tobytes() == np.sort(v).tobytes()
+    assert info_a[1] == 1 and info_b[1] == 1 and todo_a == 0 and todo_b == 0
+
+
+@pytest.mark.parametrize("kind", ["unique", "ties", "heavy", "fewbits"])
+def test_sorted_order_through_the_placement(gx, kind):
+    """pairs: the packed (low key bits, position) words are distinct, so ties of the KEY do not crowd a bin unless ten of
+    them meet in one 13-bit bin of the word; tie order (stable) is checked against the oracle, both directions"""
+    rng = np.random.default_rng(11)
+    n = 12_000_000
+    if kind == "unique":
+        v = rng.integers(-2**63, 2**63 - 1, n, dtype=np.int64)
+    elif kind == "ties":  # every key about four times
+        v = rng.integers(-2**63, 2**63 - 1, n // 4, dtype=np.int64)[rng.integers(0, n // 4, n)]
+    elif kind == "heavy":  # 64 copies of each key: crowded bins -> sub-bucket path for most cells
+        v = rng.integers(-2**63, 2**63 - 1, n // 64, dtype=np.int64)[rng.integers(0, n // 64, n)]
+    else:  # 20 key bits over 1.2e7 rows: few bits left below the level-1 digit, the word's digit reaches into the position
+        v = rng.integers(0, 1 << 20, n, dtype=np.int64) << 30
+    for desc in (False, True):
+        got = _order(gx, v, desc)
+        np.testing.assert_array_equal(got, orc.sorted_order(v, None, not desc), err_msg=f"{kind} desc={desc}")
+
+
+@pytest.mark.parametrize("log2_cells", [12, 13])
+def test_placement_at_the_cell_capacity(gx, log2_cells):
+    """n just below the limit of a level-1 size class: cells 95 % full on average, some above 8000 keys (2^12 cells: the
+    look-back path, 2^13: the cursor path); a handful of crowded cells is expected (6e-8 per bin)"""
+    rng = np.random.default_rng(8)
+    n = int(0.95 * 8192 * (1 << log2_cells))
+    v = rng.integers(-2**63, 2**63 - 1, n, dtype=np.int64)
+    got, info, todo = _sort(gx, v)
+    assert got.tobytes() == c_oracle.sort_i64(v).tobytes()
+    assert info[1] == 1 and _cells(info) == 1 << log2_cells and 0 <= todo < 32 and info[6] > 7900, (info, todo)

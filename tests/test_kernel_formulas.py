@@ -626,3 +626,64 @@ def test_single_pass_lookback_scan_protocol_model():
                 hi[t] = (2, int(s["ex"] + agg[t]) >> 16)
                 got[t] = s["ex"]; s["done"] = True
         assert got == [int(x) for x in want], (trial, got, want.tolist())
+
+
+def _ce_list(name):
+    """The compare-exchange list of a per-thread register network, parsed from gx_common.hpp."""
+    import os
+    import re
+    src = open(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "cudf_amd", "csrc", "gx_common.hpp")).read()
+    body = re.search(r"void " + name + r"\(uint64_t \(&v\)\[16\]\)\s*\{(.*?)\n\}", src, re.S).group(1)
+    return [(int(a), int(b)) for a, b in re.findall(r"GX_CE\((\d+),\s*(\d+)\)", body)]
+
+
+def test_register_networks_of_the_placement_sort():
+    """k_local_place (gx_sort.hip): sort16_regs must sort every input (0-1 principle over all 2^16 inputs), merge16_regs must
+    merge any two ascending runs of 8; and the kernel's claim -- keys scattered to 13-bit bins of <= 9 keys each are sorted
+    by one pass over aligned 16-key windows and one over windows shifted by 8 -- on a model of a cell."""
+    s16, m16 = _ce_list("sort16_regs"), _ce_list("merge16_regs")
+    assert len(s16) == 60 and len(m16) == 25
+    bits = ((np.arange(1 << 16)[:, None] >> np.arange(16)[None, :]) & 1).astype(np.uint8)
+    for a, b in s16:
+        lo, hi = np.minimum(bits[:, a], bits[:, b]), np.maximum(bits[:, a], bits[:, b])
+        bits[:, a], bits[:, b] = lo, hi
+    assert (np.diff(bits.astype(np.int8), axis=1) >= 0).all()
+    runs = np.array([[0] * za + [1] * (8 - za) + [0] * zb + [1] * (8 - zb) for za in range(9) for zb in range(9)], dtype=np.uint8)
+    for a, b in m16:
+        lo, hi = np.minimum(runs[:, a], runs[:, b]), np.maximum(runs[:, a], runs[:, b])
+        runs[:, a], runs[:, b] = lo, hi
+    assert (np.diff(runs.astype(np.int8), axis=1) >= 0).all()
+
+    rng = np.random.default_rng(0)
+
+    def windows(keys, shift2):
+        m = len(keys)
+        bins = (keys >> np.uint64(shift2 - 13)).astype(np.int64)
+        assert np.bincount(bins, minlength=8192).max() <= 9
+        perm = rng.permutation(m)  # arrival order inside a bin is whatever the atomics return
+        cell = np.full(8192 + 16, np.uint64(2**64 - 1))
+        cell[:m] = keys[perm[np.argsort(bins[perm], kind="stable")]]
+        cell[:8192].reshape(512, 16).sort(axis=1)
+        cell[8:8200].reshape(512, 16).sort(axis=1)
+        return cell[:m]
+
+    for m in (1, 17, 4000, 7629, 8192):
+        keys = rng.integers(0, 1 << 47, m, dtype=np.uint64)
+        while np.bincount((keys >> np.uint64(34)).astype(np.int64), minlength=8192).max() > 9:
+            keys = rng.integers(0, 1 << 47, m, dtype=np.uint64)
+        np.testing.assert_array_equal(windows(keys, 47), np.sort(keys))
+    # every bin exactly 9 keys, bins straddling every window boundary
+    keys = (np.repeat(np.arange(910, dtype=np.uint64), 9) << np.uint64(34)) | rng.integers(0, 1 << 34, 8190, dtype=np.uint64)
+    np.testing.assert_array_equal(windows(keys, 47), np.sort(keys))
+    # the byte-counter arithmetic of the kernel: x * 0x01010101 is the inclusive prefix of the four bytes of x while sums < 256
+    c = rng.integers(0, 10, (1000, 4), dtype=np.uint32)
+    x = c[:, 0] | (c[:, 1] << 8) | (c[:, 2] << 16) | (c[:, 3] << 24)
+    p = (x.astype(np.uint64) * 0x01010101) & 0xFFFFFFFF
+    inc = np.cumsum(c, axis=1)
+    for k in range(4):
+        np.testing.assert_array_equal((p >> (8 * k)) & 0xFF, inc[:, k])
+    ge10 = ((((x & 0x7F7F7F7F) + 0x76767676) | x) & 0x80808080) != 0
+    assert not ge10.any()
+    y = x.copy(); y[::3] |= np.uint32(10) << (8 * rng.integers(0, 4, len(y[::3]), dtype=np.uint32))
+    ge10 = ((((y & 0x7F7F7F7F) + 0x76767676) | y) & 0x80808080) != 0
+    np.testing.assert_array_equal(ge10, ((y[:, None] >> (8 * np.arange(4, dtype=np.uint32))) & 0xFF).max(axis=1) >= 10)
