@@ -273,6 +273,17 @@ def pmc_traffic(roofline, n):
     """HBM bytes of the dominant kernel from the committed PMC passes (same command, 1e9 rows)"""
     if roofline is None or n != 1_000_000_000:
         return
+    key = roofline.get("traffic_key")
+    if key:  # round 3: kernels by base name, timed steps as groups (scripts/pmc_to_json.py)
+        try:
+            tr = json.load(open(os.path.join(ROOT, "profiles", "r3_pmc_traffic_1e9.json")))
+            e = tr.get("groups", {}).get(key) or tr["kernels"].get(key)
+            if e:
+                roofline["traffic"] = e["hbm_bytes_per_launch"]
+                roofline["traffic_source"] = tr["source"] + "; " + tr["correction"] + (f"; sum over {e['members']}" if "members" in e else "")
+                return
+        except (OSError, KeyError, ValueError):
+            pass
     for name in ("r2_pmc_traffic_1e9.json", "r1_pmc_traffic_1e9.json"):
         try:
             tr = json.load(open(os.path.join(ROOT, "profiles", name)))
@@ -378,18 +389,26 @@ def bench_sort(c, pairs=False):
         # hybrid MSD path: per-kernel algorithmic bytes: partition passes and the local sort read 8 +
         # write 8 B/row, the joint histogram reads 8 B/row
         ms = [x / prof["hyb_n"] for x in prof["hyb"]]
+        todo = ctypes.c_int32(-1)
+        lib.gx_sort_place_info(c.ptr(tmp), ctypes.byref(todo), c.stream)
+        sort_info["cells"] = 256 << sort_info["bits2"]
+        sort_info["cells_left_to_k_local_sort"] = todo.value  # crowded cells of k_local_place (a 13-bit bin with > 9 keys)
         names = ["k_msd_pass level 0 (8-bit partition, 8 XCD chains)",
                  f"k_msd_pass level 1 ({sort_info['bits2']}-bit partition inside buckets, padded cell slots)",
-                 "k_plan2 (cell starts, one block)", "k_local_sort (LDS sort of the cells)"]
+                 "k_plan2 (cell starts, one block)",
+                 "k_local_place + k_local_sort (LDS sort of the cells: counting placement + per-thread window networks; crowded cells: sub-bucket path)"
+                 if sort_info["max_cell"] <= 8192 else "k_local_sort (LDS sort of the cells)"]
+        tkeys = ["k_msd_pass level 0", "k_msd_pass level 1", "k_plan2", "sort local stage"]
         if cursor:
             names[0] = "k_hf_scatter level 0 (8-bit partition into sampled (range, bin) slots, cursor atomics) + verdict"
             names[1] = f"k_hf_scatter level 1 ({sort_info['bits2']}-bit partition of the regions into padded cell slots, cursor atomics)"
+            tkeys[0], tkeys[1] = "k_hf_scatter level 0", "k_hf_scatter level 1"
         up_front = 0 if cursor else 8  # B/row of the up-front pass: the cursor path reads a 1/32 sample instead of the column
         bpr = [20, 24, 0, 24] if pairs else [16, 16, 0, 16]  # pairs carry a 4-B index
         dom = max(range(4), key=lambda i: ms[i])
         achieved = bpr[dom] * n / (ms[dom] * 1e-3) / 1e9
         roofline = {"bound": "hbm", "kernel": names[dom], "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                    "frac": achieved / HBM_PEAK_GBS, "traffic": None, "algorithmic_bytes_per_launch": bpr[dom] * n,
+                    "frac": achieved / HBM_PEAK_GBS, "traffic": None, "traffic_key": tkeys[dom], "algorithmic_bytes_per_launch": bpr[dom] * n,
                     "avg_launch_ms": ms[dom], "launches_per_step": 1.0,
                     "kernels_ms": dict(zip(names, ms)), "kernels_GBps": {k: b * n / (m * 1e-3) / 1e9 for k, b, m in zip(names, bpr, ms) if b},
                     "hist_kernel_ms": hist_ms,
@@ -536,14 +555,20 @@ def bench_join(c):
     del lt, rt, rows, hit
     algb = 24 * n + 16 * matches   # 24 B/probe row + 16 B/match
     ach = algb / (ms_per_step * 1e-3) / 1e9
-    roofline = {"bound": "hbm", "kernel": "partitioned probe (k_pj_hist + k_pj_scatter + k_pj_probe_pipe)" if part_bits else "k_probe",
+    spec = bool(a.join_spec)
+    roofline = {"bound": "hbm",
+                "kernel": ("k_probe" if not part_bits else
+                           "partitioned probe (k_pj2_scatter + k_pj2_offsets + k_pj2_probe_pipe: hist-free speculative partition)" if spec else
+                           "partitioned probe (k_pj_hist + k_pj_scatter + k_pj_probe_pipe)"),
                 "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS, "traffic": None,
+                "traffic_key": None if not part_bits else ("join probe phase" if spec else "join probe phase (exact two-pass)"),
                 "algorithmic_bytes_per_launch": algb, "avg_launch_ms": ms_per_step, "matches": matches,
-                "model": "24 B/probe row + 16 B/match (SURVEY.md 8d); whole probe phase = 3 launches"}
+                "model": "24 B/probe row + 16 B/match (SURVEY.md 8d); whole probe phase = " + ("2 launches + a region-table kernel" if spec else "3 launches")}
     if kn[0]:
         ms = [x / kn[0] for x in kms]
-        names = ["k_pj_hist+k_pj_offsets (partition histogram)", "k_pj_scatter (partition (key,row) by table hash)",
-                 "k_pj_probe (tag probe of partition-resident sub-tables)"]
+        names = ["k_pj_hist+k_pj_offsets (partition histogram; a no-op on the speculative path)",
+                 ("k_pj2_scatter" if spec else "k_pj_scatter") + " (partition (key,row) by table hash)",
+                 ("k_pj2_probe_pipe" if spec else "k_pj_probe_pipe") + " (tag probe of partition-resident sub-tables)"]
         kb = [8 * n, 20 * n, 12 * n + 8 * matches]   # bytes each launch must move: keys | keys + (key,row) | (key,row) + pairs
         dom = max(range(3), key=lambda i: ms[i])
         roofline["kernels_ms"] = dict(zip(names, ms))
@@ -639,8 +664,11 @@ def bench_groupby(c):
         ref = float(gvt[sel].sum().item())
         assert abs(float(st[gi].item()) - ref) <= 1e-11 * max(1.0, abs(ref)), "groupby: sampled group sum differs"
     ach = 12 * n / (ms_per_step * 1e-3) / 1e9
-    roofline = {"bound": "hbm", "kernel": "k_part_hist + k_part_scatter + k_part_aggregate (LDS-partitioned groupby)",
+    roofline = {"bound": "hbm",
+                "kernel": ("k_slot_sample + k_part_scatter + k_part_aggregate (LDS-partitioned groupby, slots sized from a sample)" if a.gb_spec else
+                           "k_part_hist + k_part_scatter + k_part_aggregate (LDS-partitioned groupby)"),
                 "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS, "traffic": None,
+                "traffic_key": "groupby" if a.gb_spec else "groupby (exact two-pass)",
                 "algorithmic_bytes_per_launch": 12 * n, "avg_launch_ms": ms_per_step, "groups": groups,
                 "model": "12 B/row (4-B key + 8-B value read once; SURVEY.md 8d)"}
     pmc_traffic(roofline, n)
@@ -685,7 +713,7 @@ def bench_groupby_minmax(c):
         assert float(gvt[sel].min().item()) == float(mnt[gi].item()) and float(gvt[sel].max().item()) == float(mxt[gi].item()), \
             "groupby min/max: sampled group differs"
     ach = 12 * n / sec / 1e9
-    roofline = {"bound": "hbm", "kernel": "k_part_hist + k_part_scatter + k_part_minmax (LDS-partitioned groupby MIN/MAX)",
+    roofline = {"bound": "hbm", "traffic_key": "groupby_minmax", "kernel": "k_part_hist + k_part_scatter + k_part_minmax (LDS-partitioned groupby MIN/MAX)",
                 "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS, "traffic": None,
                 "algorithmic_bytes_per_launch": 12 * n, "avg_launch_ms": sec * 1e3, "groups": groups,
                 "model": "12 B/row (4-B key + 8-B value read once; SURVEY.md 8d)"}

@@ -18,6 +18,7 @@
 //     kernel + device scan + the same scatter kernel reading precomputed offsets.
 #include "gx_common.hpp"
 #include <cstdlib>
+#include <type_traits>
 #include "gx_scan.hpp"
 
 namespace gx {
@@ -733,8 +734,15 @@ __global__ void __launch_bounds__(BT, (KPT <= 8 ? 8 : (KPT <= 12 ? 6 : 4))) k_ms
   extern __shared__ __attribute__((aligned(16))) char smem[];
   KeyT* s_keys       = reinterpret_cast<KeyT*>(smem);
   uint32_t* s_vals   = reinterpret_cast<uint32_t*>(smem + (size_t)TILE * sizeof(KeyT));  // [TILE] (HAS_VAL)
-  uint32_t* s_whist  = s_vals + (HAS_VAL ? TILE : 0);                                    // [NW][NB]
-  uint32_t* s_gdelta = s_whist + WROWS * NB;                                             // [NB]
+  // stable ranking: per-wave counters [NW][NB]; unstable: {counts, bin starts} [2][NB].  The pairs' 9-bit pass keeps its
+  // counters in 16 bits (a tile holds 5120 rows): with 32-bit counters it needs 82 000 B of LDS, 160 B more than two
+  // workgroups per CU can share (level 1 of sorted_order: 8.7 -> 7.4 ms per 1e9 rows); everywhere else 16-bit counters
+  // measured slower (sub-dword LDS read-modify-write: level 0 of the pairs 6.15 -> 6.65 ms) and the pass fits twice anyway
+  constexpr bool HIST16 = STABLE && HAS_VAL && NBL == 9;
+  using HistT           = typename std::conditional<HIST16, uint16_t, uint32_t>::type;
+  uint32_t* s_whist  = s_vals + (HAS_VAL ? TILE : 0);
+  HistT* s_whist16   = reinterpret_cast<HistT*>(s_whist);
+  uint32_t* s_gdelta = s_whist + (HIST16 ? WROWS * NB / 2 : WROWS * NB);                 // [NB]
   uint32_t* s_limit  = s_gdelta + NB;                                                    // [NB] end of each bin's output slot
   uint32_t* s_scan   = s_limit + NB;                                                     // [16]
   uint32_t* s_misc   = s_scan + 16;                                                      // [4]
@@ -814,12 +822,12 @@ __global__ void __launch_bounds__(BT, (KPT <= 8 ? 8 : (KPT <= 12 ? 6 : 4))) k_ms
       val[j]        = (idx < nvalid) ? (vin ? vin[base + idx] : (uint32_t)(base + idx)) : 0u;
     }
   }
-  uint32_t* my_hist = s_whist + w * NB;
+  HistT* my_hist = s_whist16 + w * NB;
   uint32_t packed[KPT];
   uint32_t tile_count = 0;
   if (STABLE) {
 #pragma unroll
-    for (int k = 0; k < NB / GX_WAVE; ++k) my_hist[lane + k * GX_WAVE] = 0;
+    for (int k = 0; k < NB / ((HIST16 ? 2 : 1) * GX_WAVE); ++k) reinterpret_cast<uint32_t*>(my_hist)[lane + k * GX_WAVE] = 0;
 #pragma unroll
     for (int j = 0; j < KPT; ++j) {
       const int idx = wbase + j * GX_WAVE;
@@ -828,7 +836,7 @@ __global__ void __launch_bounds__(BT, (KPT <= 8 ? 8 : (KPT <= 12 ? 6 : 4))) k_ms
       uint32_t lower, cnt;
       match_rank<NBL>(d, true, ~0ull, lower, cnt);
       const uint32_t prev = my_hist[d];
-      if (lower == 0) my_hist[d] = prev + cnt;
+      if (lower == 0) my_hist[d] = (HistT)(prev + cnt);
       packed[j] = (d << 16) | (prev + lower);
     }
     __syncthreads();
@@ -836,8 +844,8 @@ __global__ void __launch_bounds__(BT, (KPT <= 8 ? 8 : (KPT <= 12 ? 6 : 4))) k_ms
       uint32_t sum = 0;
 #pragma unroll
       for (int w2 = 0; w2 < NW; ++w2) {
-        const uint32_t c       = s_whist[w2 * NB + tid];
-        s_whist[w2 * NB + tid] = sum;
+        const uint32_t c         = s_whist16[w2 * NB + tid];
+        s_whist16[w2 * NB + tid] = (HistT)sum;
         sum += c;
       }
       tile_count = sum;
@@ -864,7 +872,7 @@ __global__ void __launch_bounds__(BT, (KPT <= 8 ? 8 : (KPT <= 12 ? 6 : 4))) k_ms
   if (tid < NB) {
     if (STABLE) {
 #pragma unroll
-      for (int w2 = 0; w2 < NW; ++w2) s_whist[w2 * NB + tid] += bin_start;
+      for (int w2 = 0; w2 < NW; ++w2) s_whist16[w2 * NB + tid] = (HistT)(s_whist16[w2 * NB + tid] + bin_start);
     } else {
       s_whist[NB + tid] = bin_start;  // row 1: bin starts (row 0 holds the counts)
     }
@@ -875,7 +883,7 @@ __global__ void __launch_bounds__(BT, (KPT <= 8 ? 8 : (KPT <= 12 ? 6 : 4))) k_ms
   for (int j = 0; j < KPT; ++j) {
     const uint32_t d = packed[j] >> 16;
     if (STABLE) {
-      const uint32_t pos = my_hist[d] + (packed[j] & 0xFFFFu);
+      const uint32_t pos = (uint32_t)my_hist[d] + (packed[j] & 0xFFFFu);
       s_keys[pos]        = key[j];
       if (HAS_VAL) s_vals[pos] = val[j];
     } else if (wbase + j * GX_WAVE < nvalid) {
@@ -1070,41 +1078,45 @@ __device__ __forceinline__ void pairs_write_out(KeyT* s_keys, const KeyT* __rest
   }
 }
 
-// ---- k_local_place (round 3, 8192-key cells; integer keys and packed (key bits, position) words): ONE counting pass on the
-// 13 bits below the level-1 digit puts every key within a few positions of where it belongs -- 8192 bins for <= 8192
-// keys, 0.93 keys per bin on uniform keys -- and two passes of per-THREAD networks over 16 registers finish the job:
-// thread t sorts positions [16t, 16t + 16) (60 comparators), then merges its upper half with the lower half of thread
-// t + 1 (25 comparators), i.e. sorts the window shifted by 8.  A bin of <= 9 keys lies inside an aligned or inside a
-// shifted window and bins are ordered among themselves, so the two passes together sort the cell.  A cell with a fuller
-// bin (duplicate keys, a cluster; 5e-8 per bin on uniform keys) is left alone and its number appended to `todo`:
-// k_local_sort, launched behind, sorts exactly those cells with its sub-bucket path.  The counters are BYTES (8 KiB for
-// 8192 bins): a returning add of 1 << 8 * (bin & 3) on the bin's word, the old byte is the key's rank inside its bin;
-// the add that sees 255 is about to carry into the neighbouring bin and raises the same flag.
+// ---- k_local_place (round 3; integer keys and packed (key bits, position) words): ONE counting pass on the CL2 bits below
+// the level-1 digit puts every key within a few positions of where it belongs -- as many bins as the cell has key slots
+// (8192 or 16384), 0.93 keys per bin on uniform keys in full cells -- and two passes of per-THREAD networks over 16
+// registers finish the job: thread t sorts positions [16t, 16t + 16) (60 comparators), then merges its upper half with
+// the lower half of thread t + 1 (25 comparators), i.e. sorts the window shifted by 8.  A bin of <= 9 keys lies inside an
+// aligned or inside a shifted window and bins are ordered among themselves, so the two passes together sort the cell.  A
+// cell with a fuller bin (duplicate keys, a cluster; 6e-8 per bin on uniform keys) is left alone and its number appended
+// to `todo`: k_local_sort, launched behind, sorts exactly those cells with its sub-bucket path.  The counters are BYTES
+// (8 KiB for 8192 bins): a returning add of 1 << 8 * (bin & 3) on the bin's word, the old byte is the key's rank inside
+// its bin; the add that sees 255 is about to carry into the neighbouring bin and raises the same flag.
 // Against k_local_sort's sub-bucket path: ~85 comparators and one counting pass per 16 keys with 16 independent keys per
 // lane in flight at every step, instead of 16 sub-buckets per wave taken two at a time through a chain of six dependent
-// LDS round trips each (2.7 of its 5.5 ms, profiles/r3_run21_local_sort_ablation.txt).
-// LDS: 8192 keys with one key of padding per 16 (a thread's window is 17 keys from its neighbour's: conflict-free
-// 8-byte accesses) + 8 KiB of counters + 512 bin-group bases + scan words = 78.1 KiB, two workgroups per CU.
-template <typename KeyT, int KIND, bool HAS_VAL>
+// LDS round trips each (2.7 of its 5.5 ms, profiles/r3_run21_local_sort_ablation.txt): 5.6 -> 3.6 ms per 1e9 int64 keys,
+// 8.9 -> 5.1 ms for sorted_order's pairs (profiles/r3_run22_local_place_ab.txt), 54 VGPRs.
+// LDS: the keys with one key of padding per 16 (a thread's window is 17 keys from its neighbour's: conflict-free 8-byte
+// accesses) + one byte per bin + one bin-group base per thread + scan words = 78.1 KiB for 8192-key cells (two workgroups
+// per CU), 156.1 KiB for 16384-key cells (float keys, pairs above 1.02e9 rows: one workgroup per CU, as k_local_sort).
+template <typename KeyT, int KIND, bool HAS_VAL, int CL2>
 __device__ __forceinline__ bool place_applies(const HybridPlan& hy, int exp)
 {
-  if (KIND == K_FLOAT) return false;  // float keys take 16384-key cells
-  const int word_bits = hy.shift2 + (HAS_VAL ? 13 : 0);  // pairs always arrive packed (k_hy_plan's pos_bits rule)
-  return hy.nlocal > 0 && !(exp & (32 | 16 | 8 | 4)) && word_bits >= 13 && word_bits <= 64;
+  // packed words: pairs always (k_hy_plan's pos_bits rule), float keys when the position fits next to the key bits
+  constexpr bool PACKED = HAS_VAL || KIND == K_FLOAT;
+  const int word_bits   = hy.shift2 + (PACKED ? CL2 : 0);
+  return hy.nlocal > 0 && !(exp & (32 | 16 | 8 | 4)) && word_bits >= CL2 && word_bits <= 64;
 }
-constexpr size_t place_lds_bytes() { return (size_t)(8192 + 512) * 8 + 8192 + 512 * 4 + 32 * 4; }
+constexpr size_t place_lds_bytes(int cl2) { return (size_t)((1 << cl2) + (1 << cl2) / 16) * 8 + (size_t)(1 << cl2) + (size_t)((1 << cl2) / 16) * 4 + 32 * 4; }
 
-template <typename KeyT, int KIND, bool HAS_VAL>
-__global__ void __launch_bounds__(512, 4) k_local_place(const KeyT* in, KeyT* __restrict__ out, const uint32_t* vin,
-                                                        uint32_t* __restrict__ vout, KeyT desc_mask, SortPlan* plan,
-                                                        const uint32_t* __restrict__ hist2, const uint32_t* __restrict__ base2,
-                                                        uint32_t* __restrict__ todo, int exp, int cursor_path)
+template <typename KeyT, int KIND, bool HAS_VAL, int CL2>
+__global__ void __launch_bounds__((1 << CL2) / 16, 4) k_local_place(const KeyT* in, KeyT* __restrict__ out, const uint32_t* vin,
+                                                                    uint32_t* __restrict__ vout, KeyT desc_mask, SortPlan* plan,
+                                                                    const uint32_t* __restrict__ hist2, const uint32_t* __restrict__ base2,
+                                                                    uint32_t* __restrict__ todo, int exp, int cursor_path)
 {
   static_assert(sizeof(KeyT) == 8, "64-bit keys");
-  constexpr int CL2 = 13, LOCAL_MAX = 1 << CL2, LS_KPT = 16, LS_BT = LOCAL_MAX / LS_KPT, PB = 13, NPB = 1 << PB;
+  constexpr int LOCAL_MAX = 1 << CL2, LS_KPT = 16, LS_BT = LOCAL_MAX / LS_KPT, NPB = 1 << CL2;
+  constexpr bool PACKED = HAS_VAL || KIND == K_FLOAT;
   HybridPlan& hy = plan->hy;
   if (!hy.attempt || !hy.ok || (plan->hf.state == 3) != (cursor_path != 0)) return;
-  if (!place_applies<KeyT, KIND, HAS_VAL>(hy, exp)) return;
+  if (!place_applies<KeyT, KIND, HAS_VAL, CL2>(hy, exp)) return;
   const int bits2 = hy.bits2;
   if (blockIdx.x >= ((unsigned)BINS << bits2)) return;
   const uint32_t b  = blockIdx.x >> bits2;
@@ -1115,7 +1127,7 @@ __global__ void __launch_bounds__(512, 4) k_local_place(const KeyT* in, KeyT* __
   in += (int64_t)blockIdx.x * LOCAL_MAX - start;  // the cell sits in its slot of the padded level-1 buffer
   if (HAS_VAL) vin += (int64_t)blockIdx.x * LOCAL_MAX - start;
   extern __shared__ __attribute__((aligned(16))) char smem[];
-  KeyT* s_keys     = reinterpret_cast<KeyT*>(smem);                                                  // 8192 + 512
+  KeyT* s_keys     = reinterpret_cast<KeyT*>(smem);                                                  // LOCAL_MAX + LOCAL_MAX / 16
   uint32_t* s_cnt8 = reinterpret_cast<uint32_t*>(smem + (size_t)(LOCAL_MAX + LOCAL_MAX / 16) * 8);  // NPB bytes
   uint32_t* s_base = s_cnt8 + NPB / 4;                                                               // [LS_BT] first position of bin 16 t
   uint32_t* s_scan = s_base + LS_BT;                                                                 // [32]
@@ -1123,7 +1135,7 @@ __global__ void __launch_bounds__(512, 4) k_local_place(const KeyT* in, KeyT* __
   const unsigned lane = lane_id();
   const int wbase     = (int)(tid / GX_WAVE) * (LS_KPT * GX_WAVE) + (int)lane;
   const int shift2    = hy.shift2;
-  const int dshift    = shift2 + (HAS_VAL ? CL2 : 0) - PB;
+  const int dshift    = shift2 + (PACKED ? CL2 : 0) - CL2;
 
   reinterpret_cast<uint4*>(s_cnt8)[tid] = make_uint4(0u, 0u, 0u, 0u);
   KeyT key[LS_KPT];
@@ -1132,7 +1144,7 @@ __global__ void __launch_bounds__(512, 4) k_local_place(const KeyT* in, KeyT* __
     const int idx = wbase + j * GX_WAVE;
     const KeyT k  = ((uint32_t)idx < m) ? in[start + idx] : KeyT(0);
     const KeyT sk = to_sortable<KeyT, KIND>(k, desc_mask);
-    key[j]        = HAS_VAL ? (KeyT)(((sk & ((KeyT(1) << shift2) - KeyT(1))) << CL2) | (KeyT)idx) : sk;
+    key[j]        = PACKED ? (KeyT)(((sk & ((KeyT(1) << shift2) - KeyT(1))) << CL2) | (KeyT)idx) : sk;
   }
   __syncthreads();
   uint32_t rk[LS_KPT / 4] = {0u, 0u, 0u, 0u};  // rank inside the bin, one byte per key
@@ -1154,10 +1166,6 @@ __global__ void __launch_bounds__(512, 4) k_local_place(const KeyT* in, KeyT* __
   const uint4 c4 = reinterpret_cast<uint4*>(s_cnt8)[tid];
   auto ge10 = [](uint32_t x) { return ((((x & 0x7F7F7F7Fu) + 0x76767676u) | x) & 0x80808080u) != 0u; };
   const bool crowded = ge10(c4.x) | ge10(c4.y) | ge10(c4.z) | ge10(c4.w);
-  if (__syncthreads_or(full || crowded)) {
-    if (tid == 0) todo[atomicAdd(&hy.todo_count, 1u)] = blockIdx.x;
-    return;
-  }
   const uint32_t p0 = c4.x * 0x01010101u, p1 = c4.y * 0x01010101u, p2 = c4.z * 0x01010101u, p3 = c4.w * 0x01010101u;
   const uint32_t t0 = p0 >> 24, t1 = t0 + (p1 >> 24), t2 = t1 + (p2 >> 24), t3 = t2 + (p3 >> 24);
   uint4 e4;
@@ -1165,7 +1173,24 @@ __global__ void __launch_bounds__(512, 4) k_local_place(const KeyT* in, KeyT* __
   e4.y = p1 - c4.y + t0 * 0x01010101u;
   e4.z = p2 - c4.z + t1 * 0x01010101u;
   e4.w = p3 - c4.w + t2 * 0x01010101u;
-  const uint32_t first = block_exclusive_scan<LS_BT>(t3, 0u, SumOp(), s_scan, (uint32_t*)nullptr);
+  // block scan of the thread totals with ONE barrier: every wave publishes {its total, its crowded flag}, every thread adds
+  // up the waves before its own (broadcast reads) -- the verdict on the cell rides on the same barrier
+  constexpr int LS_NW = LS_BT / GX_WAVE;
+  const uint32_t inc  = wave_inclusive_scan(t3, SumOp());
+  const bool wbad     = ballot(full || crowded) != 0;
+  if (lane == GX_WAVE - 1) s_scan[tid / GX_WAVE] = inc | (wbad ? 0x80000000u : 0u);  // totals stay below 2^15
+  __syncthreads();
+  uint32_t first = inc - t3, anybad = 0;
+#pragma unroll
+  for (int i = 0; i < LS_NW; ++i) {
+    const uint32_t x = s_scan[i];
+    anybad |= x;
+    if ((unsigned)i < tid / GX_WAVE) first += x & 0x7FFFFFFFu;
+  }
+  if (anybad & 0x80000000u) {  // block-uniform
+    if (tid == 0) todo[atomicAdd(&hy.todo_count, 1u)] = blockIdx.x;
+    return;
+  }
   reinterpret_cast<uint4*>(s_cnt8)[tid] = e4;
   s_base[tid]                           = first;
   __syncthreads();
@@ -1180,29 +1205,37 @@ __global__ void __launch_bounds__(512, 4) k_local_place(const KeyT* in, KeyT* __
     }
   }
   __syncthreads();
+  // a wave whose 1024 positions all lie behind the cell's last key has nothing to sort (part-filled cells: n well below
+  // the size class's limit, 10-bit level 1); it only keeps the barriers
+  const bool busy = 16u * (tid & ~(unsigned)(GX_WAVE - 1)) < m;
   uint64_t v[16];
   KeyT* mine = s_keys + 17 * tid;  // positions 16 tid .. 16 tid + 15
+  if (busy) {
 #pragma unroll
-  for (int i = 0; i < 16; ++i) v[i] = (16u * tid + (uint32_t)i < m) ? (uint64_t)mine[i] : ~0ull;
-  sort16_regs(v);
+    for (int i = 0; i < 16; ++i) v[i] = (16u * tid + (uint32_t)i < m) ? (uint64_t)mine[i] : ~0ull;
+    sort16_regs(v);
 #pragma unroll
-  for (int i = 0; i < 8; ++i) mine[i] = (KeyT)v[i];  // the lower half: final for thread 0, merged by thread tid - 1 otherwise
-  __syncthreads();
-#pragma unroll
-  for (int i = 0; i < 8; ++i) {
-    v[i]     = v[8 + i];
-    v[8 + i] = (tid + 1 < (unsigned)LS_BT) ? (uint64_t)mine[17 + i] : ~0ull;
-  }
-  merge16_regs(v);
-#pragma unroll
-  for (int i = 0; i < 8; ++i) mine[8 + i] = (KeyT)v[i];
-  if (tid + 1 < (unsigned)LS_BT) {
-#pragma unroll
-    for (int i = 0; i < 8; ++i) mine[17 + i] = (KeyT)v[8 + i];
+    for (int i = 0; i < 8; ++i) mine[i] = (KeyT)v[i];  // the lower half: final for thread 0, merged by thread tid - 1 otherwise
   }
   __syncthreads();
-  if (HAS_VAL) {
-    pairs_write_out<KeyT, KIND, HAS_VAL, CL2>(s_keys, in + start, out, vin + start, vout, start, m, shift2, desc_mask, !(exp & 64), true);
+  if (busy) {
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      v[i]     = v[8 + i];
+      v[8 + i] = (16u * (tid + 1) + (uint32_t)i < m) ? (uint64_t)mine[17 + i] : ~0ull;  // m <= 16 LS_BT: never past the last thread
+    }
+    merge16_regs(v);
+#pragma unroll
+    for (int i = 0; i < 8; ++i) mine[8 + i] = (KeyT)v[i];
+    if (16u * (tid + 1) < m) {
+#pragma unroll
+      for (int i = 0; i < 8; ++i) mine[17 + i] = (KeyT)v[8 + i];
+    }
+  }
+  __syncthreads();
+  if (PACKED) {
+    pairs_write_out<KeyT, KIND, HAS_VAL, CL2>(s_keys, in + start, out, HAS_VAL ? vin + start : nullptr, vout, start, m, shift2, desc_mask, !(exp & 64),
+                                              true);
     return;
   }
 #pragma unroll
@@ -1239,13 +1272,11 @@ __global__ void __launch_bounds__((1 << CL2) / 16, 4) k_local_sort(const KeyT* i
   uint32_t* s_scan  = s_whist + LS_NW * BINS;                                                 // [32]
   const int bits2   = hy.bits2;
   if (blockIdx.x >= ((unsigned)BINS << bits2)) return;
-  // 8192-key cells: k_local_place has sorted every cell but the crowded ones, whose numbers it left in `todo`
+  // k_local_place has sorted every cell but the crowded ones, whose numbers it left in `todo`
   uint32_t cell = blockIdx.x;
-  if constexpr (CL2 == 13 && KIND != K_FLOAT) {
-    if (todo != nullptr && place_applies<KeyT, KIND, HAS_VAL>(hy, exp)) {
-      if (cell >= hy.todo_count) return;
-      cell = todo[cell];
-    }
+  if (todo != nullptr && place_applies<KeyT, KIND, HAS_VAL, CL2>(hy, exp)) {
+    if (cell >= hy.todo_count) return;
+    cell = todo[cell];
   }
   const uint32_t b  = cell >> bits2;
   const uint32_t d2 = cell & ((1u << bits2) - 1u);
@@ -2024,8 +2055,8 @@ int sort_impl(const void* keys_in, void* keys_out, const int32_t* vals_in, int32
         GX_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(k_hf_scatter<KeyT, KIND, 1, 10>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_hf(1024)));
         GX_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(k_local_sort<KeyT, KIND, HAS_VAL, 13>), hipFuncAttributeMaxDynamicSharedMemorySize,
                                        (int)(((size_t)sizeof(KeyT) << 13) + (size_t)(((1 << 13) / 16 / GX_WAVE) * BINS + 32 + 2 * BINS) * 4)));
-        GX_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(k_local_place<KeyT, KIND, HAS_VAL>), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                       (int)place_lds_bytes()));
+        GX_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(k_local_place<KeyT, KIND, HAS_VAL, 13>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                       (int)place_lds_bytes(13)));
         fattr_set = true;
       }
       const int64_t step = (int64_t)fc.stride * HF_CHUNK;
@@ -2049,7 +2080,7 @@ int sort_impl(const void* keys_in, void* keys_out, const int32_t* vals_in, int32
       prof_mark_h(2, stream);
       hipLaunchKernelGGL(k_plan2, dim3(BINS), dim3(GX_WAVE), 0, stream, plan, hist2, base2, NPASS, 1);
       prof_mark_h(3, stream);
-      hipLaunchKernelGGL((k_local_place<KeyT, KIND, HAS_VAL>), dim3((unsigned)(BINS << fc.bits2)), dim3((1 << 13) / 16), place_lds_bytes(), stream,
+      hipLaunchKernelGGL((k_local_place<KeyT, KIND, HAS_VAL, 13>), dim3((unsigned)(BINS << fc.bits2)), dim3((1 << 13) / 16), place_lds_bytes(13), stream,
                          kb_scratch, bufA, (const uint32_t*)nullptr, (uint32_t*)nullptr, desc_mask, plan, hist2, base2, todo, g_exp, 1);
       hipLaunchKernelGGL((k_local_sort<KeyT, KIND, HAS_VAL, 13>), dim3((unsigned)(BINS << fc.bits2)), dim3((1 << 13) / 16),
                          ((size_t)sizeof(KeyT) << 13) + (size_t)(((1 << 13) / 16 / GX_WAVE) * BINS + 32 + 2 * BINS) * 4, stream, kb_scratch, bufA,
@@ -2067,7 +2098,10 @@ int sort_impl(const void* keys_in, void* keys_out, const int32_t* vals_in, int32
       constexpr bool STABLE  = KIND == K_FLOAT || HAS_VAL;
       constexpr bool SMALLOK = KIND != K_FLOAT;  // 8192-key cells and the 9-bit level 1 exist for integer keys (keys only and pairs)
       constexpr int SKPT     = HAS_VAL ? 10 : 16;  // keys per thread of their partition passes
-      auto lds_msd = [&](int kpt, int nb) { return (size_t)BT * kpt * (sizeof(KeyT) + pay) + (size_t)((STABLE ? NW : 2) * nb + 2 * nb + 16 + 4) * 4; };
+      auto lds_msd = [&](int kpt, int nb) {  // the pairs' 9-bit pass: 16-bit per-wave counters (k_msd_pass, HIST16)
+        const int wrows = STABLE ? ((HAS_VAL && nb == NB9) ? NW / 2 : NW) : 2;
+        return (size_t)BT * kpt * (sizeof(KeyT) + pay) + (size_t)(wrows * nb + 2 * nb + 16 + 4) * 4;
+      };
       auto lds_loc = [&](int cl2) { return ((size_t)sizeof(KeyT) << cl2) + (size_t)(((1 << cl2) / 16 / GX_WAVE) * BINS + 32 + 2 * BINS) * 4; };
       typedef void (*MsdK)(MsdArgs);
       MsdK kmsd0 = HAS_VAL ? (MsdK)k_msd_pass<KeyT, KIND, HAS_VAL, 10, 4, 8>
@@ -2087,8 +2121,9 @@ int sort_impl(const void* keys_in, void* keys_out, const int32_t* vals_in, int32
         if constexpr (SMALLOK) {
           GX_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(k_msd_pass<KeyT, KIND, HAS_VAL, SKPT, 4, 9>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_msd(SKPT, NB9)));
           GX_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(k_local_sort<KeyT, KIND, HAS_VAL, 13>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_loc(13)));
-          GX_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(k_local_place<KeyT, KIND, HAS_VAL>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)place_lds_bytes()));
+          GX_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(k_local_place<KeyT, KIND, HAS_VAL, 13>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)place_lds_bytes(13)));
         }
+        GX_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(k_local_place<KeyT, KIND, HAS_VAL, 14>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)place_lds_bytes(14)));
         hattr_set = true;
       }
       int kpt1 = hyb_kpt;
@@ -2157,16 +2192,15 @@ int sort_impl(const void* keys_in, void* keys_out, const int32_t* vals_in, int32
       if (!cursor_marked) prof_mark_h(2, stream);
       hipLaunchKernelGGL(k_plan2, dim3(BINS), dim3(GX_WAVE), 0, stream, plan, hist2, base2, NPASS, 0);
       if (!cursor_marked) prof_mark_h(3, stream);
-      bool placed = false;
+      // the cells: k_local_place sorts all but the crowded ones, k_local_sort those (and every cell when the placement does not apply)
+      auto kplace = k_local_place<KeyT, KIND, HAS_VAL, 14>;
       if constexpr (SMALLOK) {
-        if (hc.cl2 == 13) {
-          hipLaunchKernelGGL((k_local_place<KeyT, KIND, HAS_VAL>), dim3((unsigned)(BINS << hc.bits2)), dim3(ls_bt), place_lds_bytes(), stream,
-                             (const KeyT*)bufB, bufA, (const uint32_t*)valB, valA, desc_mask, plan, hist2, base2, todo, m.exp, 0);
-          placed = true;
-        }
+        if (hc.cl2 == 13) kplace = k_local_place<KeyT, KIND, HAS_VAL, 13>;
       }
+      hipLaunchKernelGGL(kplace, dim3((unsigned)(BINS << hc.bits2)), dim3(ls_bt), place_lds_bytes(hc.cl2), stream, (const KeyT*)bufB, bufA,
+                         (const uint32_t*)valB, valA, desc_mask, plan, hist2, base2, todo, m.exp, 0);
       hipLaunchKernelGGL(kloc, dim3((unsigned)(BINS << hc.bits2)), dim3(ls_bt), lds_loc(hc.cl2), stream, bufB, bufA, valB, valA, desc_mask,
-                         plan, hist2, base2, m.exp, 0, placed ? (const uint32_t*)todo : (const uint32_t*)nullptr);
+                         plan, hist2, base2, m.exp, 0, (const uint32_t*)todo);
       if (!cursor_marked) prof_mark_h(4, stream);
       if (!cursor_marked) g_prof.hybrid_marked = g_prof.enabled;
     }

@@ -1,19 +1,44 @@
 """Turn the rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE CSVs of bench.py runs (1e9 rows, one step) into
-profiles/r2_pmc_traffic_1e9.json: HBM bytes per launch of every hot-path kernel, = (2 * FETCH_SIZE + WRITE_SIZE) * 1024
-(FETCH_SIZE counts 32-B... units of KB on gfx950 and under-reports by 2x: MI355X_MICROARCH.md, HBM / rocprofv3 section).
-Usage: pmc_to_json.py <dir with pmc_<workload>_{fetch,write}/...counter_collection.csv> <out.json>"""
+profiles/r<round>_pmc_traffic_1e9.json: HBM bytes per launch of every hot-path kernel, = (2 * FETCH_SIZE + WRITE_SIZE) * 1024
+(FETCH_SIZE is reported in KB on gfx950 and under-reports by 2x: MI355X_MICROARCH.md, HBM / rocprofv3 section).
+Round 3: kernels are keyed by their base name (k_hf_scatter / k_msd_pass with their level), and the steps bench.py times are
+summed into groups -- "sort local stage", "sort", "join probe phase", "groupby" -- whose names bench.py's roofline objects
+carry as `traffic_key`.
+Usage: pmc_to_json.py <dir with pmc_<workload>_{fetch_size,write_size}/...counter_collection.csv> <out.json> [source note]"""
 import csv
 import glob
 import json
 import os
+import re
 import sys
 
-GROUPS = {  # bench.py roofline["kernel"] prefix -> kernels whose traffic it sums (substring match)
-    "partitioned probe": ["k_pj_hist", "k_pj_offsets", "k_pj_scatter", "k_pj_probe_pipe"],
-    "k_part_hist + k_part_scatter + k_part_aggregate": ["k_part_hist", "k_part_offsets", "k_part_scatter", "k_part_aggregate"],
+GROUPS = {  # group -> (workload, base names whose LARGEST dispatch is summed)
+    "sort local stage": ("sort", ["k_local_place", "k_local_sort"]),
+    "sort": ("sort", ["k_hf_sample", "k_hf_plan", "k_hf_scatter level 0", "k_hf_scatter level 1", "k_hy_hist", "k_msd_pass level 0",
+                      "k_msd_pass level 1", "k_plan2", "k_local_place", "k_local_sort"]),
+    "join probe phase": ("join", ["k_pj2_scatter", "k_pj2_offsets", "k_pj2_probe_pipe"]),
+    "join probe phase (exact two-pass)": ("join", ["k_pj_hist", "k_pj_offsets", "k_pj_scatter", "k_pj_probe_pipe"]),
+    "groupby": ("groupby", ["k_slot_sample", "k_slot_plan", "k_part_reset_cursors", "k_part_scatter", "k_part_aggregate"]),
+    "groupby (exact two-pass)": ("groupby", ["k_part_hist", "k_part_offsets", "k_part_scatter", "k_part_aggregate"]),
+    "groupby_minmax": ("groupby_minmax", ["k_slot_sample", "k_slot_plan", "k_part_reset_cursors", "k_part_scatter", "k_part_minmax"]),
 }
-SINGLE = ["k_hy_hist", "k_msd_pass", "k_plan2", "k_local_sort", "k_pj_hist", "k_pj_scatter", "k_pj_probe_pipe", "k_pj_build",
-          "k_part_hist", "k_part_scatter", "k_part_aggregate", "k_part_minmax", "k_lookback_scan", "k_stream_reduce"]
+
+
+def base_name(kernel):
+    """gx::sort::k_hf_scatter<unsigned long, 1, 0, 8>(...) -> 'k_hf_scatter level 0'; None for kernels outside gx::"""
+    m = re.search(r"\bgx::(?:\w+::)*(k_\w+)", kernel)
+    if not m:
+        return None
+    name = m.group(1)
+    targs = re.search(re.escape(name) + r"<([^()]*?)>\(", kernel)
+    args = [a.strip() for a in targs.group(1).split(",")] if targs else []
+    if name == "k_hf_scatter" and len(args) >= 3:
+        return f"{name} level {args[2]}"
+    if name == "k_msd_pass" and args:
+        return f"{name} level {1 if args[-1] == '9' else 0}"  # level 1 of the 1e9-row sort is the 9-bit instantiation
+    if name == "k_hf_sample" and args:
+        return f"{name} {'histogram' if args[-1] == 'true' else 'masks'}"
+    return name
 
 
 def read(root, workload, counter):
@@ -27,48 +52,51 @@ def read(root, workload, counter):
     return out
 
 
-def main(root, out_path):
-    kernels = {}
-    for wl in ("sort", "join", "groupby", "scan", "reduce", "groupby_minmax"):
+def main(root, out_path, note):
+    kernels, per_wl = {}, {}
+    for wl in ("sort", "sorted_order", "join", "groupby", "scan", "reduce", "groupby_minmax"):
         fetch, write = read(root, wl, "fetch_size"), read(root, wl, "write_size")
         if not fetch and not write:
             continue
         per = {}
         for name in set(fetch) | set(write):
-            short = next((s for s in SINGLE if s in name), None)
+            short = base_name(name)
             if short is None:
                 continue
             f, w = fetch.get(name, []), write.get(name, [])
             m = min(len(f), len(w))
-            # the two passes launch the same sequence: pair the dispatches, keep the LARGEST one (the 1e9-row launch;
-            # the same kernel also runs on the 1e8-row build side, or as an early-exit no-op)
+            # the two passes launch the same sequence: pair the dispatches, keep the LARGEST one (the 1e9-row launch; the
+            # same kernel also runs on the 1e8-row build side, or as an early-exit no-op of a speculative branch)
             pairs = [(2 * a + b, a, b) for a, b in zip(f[:m], w[:m])]
             if not pairs:
                 continue
             tot, a, b = max(pairs)
-            tag = short
-            if short == "k_msd_pass":
-                tag = "k_msd_pass level 1" if ", 9>" in name else "k_msd_pass level 0"
-            if short == "k_hy_hist" and tot * 1024 < 1e9:
-                continue
             e = {"FETCH_SIZE_KB": a, "WRITE_SIZE_KB": b, "hbm_bytes_per_launch": tot * 1024, "dispatches_seen": m, "workload": wl}
-            if tag in per and per[tag]["hbm_bytes_per_launch"] >= e["hbm_bytes_per_launch"]:
+            if short in per and per[short]["hbm_bytes_per_launch"] >= e["hbm_bytes_per_launch"]:
                 continue
-            per[tag] = e
-        for tag, e in per.items():
-            kernels[tag if tag not in kernels else f"{tag} [{wl}]"] = e
-        for prefix, members in GROUPS.items():
-            have = [m for m in members if m in per]
-            if len(have) >= 3:
-                kernels[prefix] = {"hbm_bytes_per_launch": sum(per[m]["hbm_bytes_per_launch"] for m in have), "members": have,
-                                   "workload": wl, "note": "one step = one 1e9-row launch of each member"}
-    json.dump({"source": "rocprofv3 --kernel-trace --pmc FETCH_SIZE and --pmc WRITE_SIZE passes (separate runs) of "
-                         "python bench.py --workload <w> --rows 1e9 --steps 1 --warmup 0 (scripts/gpu_r2_run18.sh)",
-               "rows": 1000000000, "correction": "hbm_bytes = (2 * FETCH_SIZE + WRITE_SIZE) * 1024", "kernels": kernels},
-              open(out_path, "w"), indent=1)
-    for k, v in kernels.items():
-        print(f"{k:60s} {v['hbm_bytes_per_launch'] / 1e9:9.2f} GB/launch")
+            per[short] = e
+        per_wl[wl] = per
+        for short, e in per.items():
+            if e["hbm_bytes_per_launch"] >= 1e6:
+                kernels[short if short not in kernels else f"{short} [{wl}]"] = e
+    groups = {}
+    for g, (wl, members) in GROUPS.items():
+        per = per_wl.get(wl, {})
+        have = [m for m in members if any(k == m or k.startswith(m + " ") for k in per)]
+        if not have:
+            continue
+        tot = sum(e["hbm_bytes_per_launch"] for k, e in per.items() if any(k == m or k.startswith(m + " ") for m in members))
+        groups[g] = {"hbm_bytes_per_launch": tot, "members": have, "workload": wl,
+                     "note": "one step = the largest launch of each member (speculative branches that did not run contribute ~0)"}
+    json.dump({"source": note, "rows": 1000000000, "correction": "hbm_bytes = (2 * FETCH_SIZE + WRITE_SIZE) * 1024",
+               "kernels": kernels, "groups": groups}, open(out_path, "w"), indent=1)
+    for k, v in sorted(kernels.items(), key=lambda kv: -kv[1]["hbm_bytes_per_launch"]):
+        print(f"{k:60s} {v['hbm_bytes_per_launch'] / 1e9:9.2f} GB/launch  [{v['workload']}]")
+    for k, v in groups.items():
+        print(f"GROUP {k:54s} {v['hbm_bytes_per_launch'] / 1e9:9.2f} GB/step   {v['members']}")
 
 
 if __name__ == "__main__":
-    main(sys.argv[1], sys.argv[2])
+    main(sys.argv[1], sys.argv[2], sys.argv[3] if len(sys.argv) > 3 else
+         "rocprofv3 --kernel-trace --pmc FETCH_SIZE and --pmc WRITE_SIZE passes (separate runs) of python bench.py --workload <w> "
+         "--rows 1e9 --steps 1 --warmup 0")

@@ -11,8 +11,14 @@ from cudf_amd import Column, ops, _lib as L
 
 n = int(float(sys.argv[1])) if len(sys.argv) > 1 else 1_000_000_000
 which = sys.argv[2] if len(sys.argv) > 2 else "both"
-keys = ops.random_column(np.int64, n, seed=42)
+kind = sys.argv[3] if len(sys.argv) > 3 else "i64"  # f64: random BIT PATTERNS as float64 keys (16384-key cells, packed words)
 sp = ops.stream_ptr()
+if kind == "f64":
+    keys = Column.empty(np.float64, n)
+    L.check(L.lib.gx_fill_random(Column.empty(np.int64, 0).gx, keys.data_ptr, n, 42, 0, 0, sp), "fill")
+else:
+    keys = ops.random_column(np.int64, n, seed=42)
+KDT = np.float64 if kind == "f64" else np.int64
 
 
 def measure(name, call, tmp, out):
@@ -39,18 +45,18 @@ def measure(name, call, tmp, out):
         L.lib.gx_sort_cursor_state(ops.ptr(tmp), ctypes.byref(state), sp)
         sums[bits] = ops.checksum(out)
         m = np.mean(np.array(st), axis=0) if st else [float("nan")] * 4
-        print(f"{name:13s} n={n:.1e} exp={bits:2d} total {total:7.3f} ms | level0 {m[0]:5.2f} level1 {m[1]:5.2f} plan2 {m[2]:5.2f} local stage {m[3]:5.2f} ms | "
+        print(f"{name:16s} n={n:.1e} exp={bits:2d} total {total:7.3f} ms | level0 {m[0]:5.2f} level1 {m[1]:5.2f} plan2 {m[2]:5.2f} local stage {m[3]:5.2f} ms | "
               f"cursor state {state.value} cells left to k_local_sort {todo.value}", flush=True)
     L.lib.gx_sort_set_experiment(0)
     return sums
 
 
 if which in ("keys", "both"):
-    out = Column.empty(np.int64, n)
+    out = Column.empty(KDT, n)
     nb = ctypes.c_size_t(0)
     L.check(L.lib.gx_sort_keys(keys.gx, keys.data_ptr, out.data_ptr, n, 0, None, ctypes.byref(nb), sp), "query")
     tmp = ops.device_bytes(nb.value)
-    sums = measure("sort_keys", lambda: L.check(L.lib.gx_sort_keys(keys.gx, keys.data_ptr, out.data_ptr, n, 0, ops.ptr(tmp), ctypes.byref(nb), sp), "sort"), tmp, out)
+    sums = measure("sort_keys " + kind, lambda: L.check(L.lib.gx_sort_keys(keys.gx, keys.data_ptr, out.data_ptr, n, 0, ops.ptr(tmp), ctypes.byref(nb), sp), "sort"), tmp, out)
     assert sums[0] == sums[32] and sums[0][2] == 0 and sums[0][:2] == ops.checksum(keys)[:2], sums
     del tmp, out
 if which in ("order", "both"):
@@ -58,7 +64,7 @@ if which in ("order", "both"):
     nb = ctypes.c_size_t(0)
     L.check(L.lib.gx_sorted_order(keys.gx, keys.data_ptr, None, n, 0, 0, 1, out.data_ptr, None, ctypes.byref(nb), sp), "query")
     tmp = ops.device_bytes(nb.value)
-    sums = measure("sorted_order", lambda: L.check(L.lib.gx_sorted_order(keys.gx, keys.data_ptr, None, n, 0, 0, 1, out.data_ptr, ops.ptr(tmp), ctypes.byref(nb), sp), "order"), tmp, out)
+    sums = measure("sorted_order " + kind, lambda: L.check(L.lib.gx_sorted_order(keys.gx, keys.data_ptr, None, n, 0, 0, 1, out.data_ptr, ops.ptr(tmp), ctypes.byref(nb), sp), "order"), tmp, out)
     assert sums[0][:2] == sums[32][:2], sums
     srt = ops.gather(keys, out)
     assert ops.checksum(srt)[2] == 0

@@ -322,10 +322,10 @@ def test_hashed_row_keys_large_and_collision_fallback(gx, monkeypatch):
         l, r = ops.left_join_tables(L, R)
         assert l.size == len(el) + int(np.count_nonzero(~np.isin(np.arange(nl), el)))
 
-    def check_groupby():
+    def check_groupby(cols=None):
         vals = rng.integers(-1000, 1000, nl).astype(np.int64)
-        keys, s, cv, _ = ops.groupby_sum_count_tables(L, Column.from_numpy(vals))
-        ka, kb = keys[0].to_numpy(), keys[1].to_numpy()
+        keys, s, cv, _ = ops.groupby_sum_count_tables(cols or L, Column.from_numpy(vals))
+        ka, kb = keys[0].to_numpy(), keys[1].to_numpy().astype(np.int64)
         o = np.lexsort((kb, ka))
         packed = np.stack([la, lb], 1)
         uk, inv = np.unique(packed, axis=0, return_inverse=True)
@@ -353,8 +353,14 @@ def test_hashed_row_keys_large_and_collision_fallback(gx, monkeypatch):
     real = ops.rows_mismatch_count
     monkeypatch.setattr(ops, "rows_mismatch_count", lambda *a: (calls.append(1), real(*a) + 1)[1])
     check_join()
+    assert len(calls) >= 2
+    # integer key columns group in one partition pass with the rows compared inside the LDS tables (gx_groupby_sum_count_wide:
+    # no hash, no certificate); a float key column still goes through the certified row hash -- with the first answer
+    # "collision" the exact dense-rank path must give the same groups
     check_groupby()
-    assert len(calls) >= 3
+    before = len(calls)
+    check_groupby([L[0], Column.from_numpy(lb.astype(np.float64))])
+    assert len(calls) > before
 
 
 # ------------------------------------------------------------------------------------------------

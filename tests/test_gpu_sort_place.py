@@ -130,3 +130,21 @@ def test_placement_at_the_cell_capacity(gx, log2_cells):
     got, info, todo = _sort(gx, v)
     assert got.tobytes() == c_oracle.sort_i64(v).tobytes()
     assert info[1] == 1 and _cells(info) == 1 << log2_cells and 0 <= todo < 32 and info[6] > 7900, (info, todo)
+
+
+@pytest.mark.parametrize("n", [6_000_000, 20_000_000])
+def test_float64_keys_through_the_placement(gx, n):
+    """float keys travel as packed (sortable key bits, position) words in 16384-key cells: -0.0 / +0.0 ties and equal NaN
+    payload classes must keep input order, the original bits come back through the position (pairs_write_out)"""
+    rng = np.random.default_rng(n % 97)
+    v = rng.integers(-2**63, 2**63 - 1, n, dtype=np.int64).view(np.float64).copy()
+    v[::100_000] = 0.0   # a few hundred zeros of either sign; the random bit patterns bring n / 2048 NaNs (one cell)
+    v[1::100_000] = -0.0
+    for desc in (False, True):
+        got, info, todo = _sort(gx, v, desc)
+        assert got.tobytes() == orc.sort_keys(v, not desc).tobytes(), (n, desc, info)
+        assert info[1] == 1, info
+        # the zeros and the NaNs crowd their cells, the rest is placed
+        assert 0 <= todo <= 8, f"{todo} of {_cells(info)} cells were left to the sub-bucket path"
+    got = _order(gx, v)
+    np.testing.assert_array_equal(got, orc.sorted_order(v, None, True))
