@@ -1105,27 +1105,25 @@ __device__ __forceinline__ bool place_applies(const HybridPlan& hy, int exp)
 }
 constexpr size_t place_lds_bytes(int cl2) { return (size_t)((1 << cl2) + (1 << cl2) / 16) * 8 + (size_t)(1 << cl2) + (size_t)((1 << cl2) / 16) * 4 + 32 * 4; }
 
+// one cell of k_local_place (every thread of the workgroup calls it with the same cell; returns are block-uniform)
 template <typename KeyT, int KIND, bool HAS_VAL, int CL2>
-__global__ void __launch_bounds__((1 << CL2) / 16, 4) k_local_place(const KeyT* in, KeyT* __restrict__ out, const uint32_t* vin,
-                                                                    uint32_t* __restrict__ vout, KeyT desc_mask, SortPlan* plan,
-                                                                    const uint32_t* __restrict__ hist2, const uint32_t* __restrict__ base2,
-                                                                    uint32_t* __restrict__ todo, int exp, int cursor_path)
+__device__ __forceinline__ void local_place_cell(const uint32_t cell, const KeyT* in, KeyT* __restrict__ out, const uint32_t* vin,
+                                                 uint32_t* __restrict__ vout, KeyT desc_mask, SortPlan* plan,
+                                                 const uint32_t* __restrict__ hist2, const uint32_t* __restrict__ base2,
+                                                 uint32_t* __restrict__ todo, int exp)
 {
   static_assert(sizeof(KeyT) == 8, "64-bit keys");
   constexpr int LOCAL_MAX = 1 << CL2, LS_KPT = 16, LS_BT = LOCAL_MAX / LS_KPT, NPB = 1 << CL2;
   constexpr bool PACKED = HAS_VAL || KIND == K_FLOAT;
   HybridPlan& hy = plan->hy;
-  if (!hy.attempt || !hy.ok || (plan->hf.state == 3) != (cursor_path != 0)) return;
-  if (!place_applies<KeyT, KIND, HAS_VAL, CL2>(hy, exp)) return;
   const int bits2 = hy.bits2;
-  if (blockIdx.x >= ((unsigned)BINS << bits2)) return;
-  const uint32_t b  = blockIdx.x >> bits2;
-  const uint32_t d2 = blockIdx.x & ((1u << bits2) - 1u);
+  const uint32_t b  = cell >> bits2;
+  const uint32_t d2 = cell & ((1u << bits2) - 1u);
   const uint32_t m  = hist2[b * NB2MAX + d2];
   if (m == 0) return;
   const int64_t start = base2[b * NB2MAX + d2];
-  in += (int64_t)blockIdx.x * LOCAL_MAX - start;  // the cell sits in its slot of the padded level-1 buffer
-  if (HAS_VAL) vin += (int64_t)blockIdx.x * LOCAL_MAX - start;
+  in += (int64_t)cell * LOCAL_MAX - start;  // the cell sits in its slot of the padded level-1 buffer
+  if (HAS_VAL) vin += (int64_t)cell * LOCAL_MAX - start;
   extern __shared__ __attribute__((aligned(16))) char smem[];
   KeyT* s_keys     = reinterpret_cast<KeyT*>(smem);                                                  // LOCAL_MAX + LOCAL_MAX / 16
   uint32_t* s_cnt8 = reinterpret_cast<uint32_t*>(smem + (size_t)(LOCAL_MAX + LOCAL_MAX / 16) * 8);  // NPB bytes
@@ -1188,7 +1186,7 @@ __global__ void __launch_bounds__((1 << CL2) / 16, 4) k_local_place(const KeyT* 
     if ((unsigned)i < tid / GX_WAVE) first += x & 0x7FFFFFFFu;
   }
   if (anybad & 0x80000000u) {  // block-uniform
-    if (tid == 0) todo[atomicAdd(&hy.todo_count, 1u)] = blockIdx.x;
+    if (tid == 0) todo[atomicAdd(&hy.todo_count, 1u)] = cell;
     return;
   }
   reinterpret_cast<uint4*>(s_cnt8)[tid] = e4;
@@ -1245,12 +1243,30 @@ __global__ void __launch_bounds__((1 << CL2) / 16, 4) k_local_place(const KeyT* 
   }
 }
 
+// The workgroups walk the cells with a stride (gridDim.x = the number of cells: one cell each, the default; a smaller grid is
+// the persistent form, A/B knob gx_sort_set_place_grid).
 template <typename KeyT, int KIND, bool HAS_VAL, int CL2>
-__global__ void __launch_bounds__((1 << CL2) / 16, 4) k_local_sort(const KeyT* in, KeyT* __restrict__ out,
-                                                      const uint32_t* vin, uint32_t* __restrict__ vout,
-                                                      KeyT desc_mask_in, SortPlan* plan,
-                                                      const uint32_t* __restrict__ hist2, const uint32_t* __restrict__ base2,
-                                                      int exp = 0, int cursor_path = 0, const uint32_t* __restrict__ todo = nullptr)
+__global__ void __launch_bounds__((1 << CL2) / 16, 4) k_local_place(const KeyT* in, KeyT* __restrict__ out, const uint32_t* vin,
+                                                                    uint32_t* __restrict__ vout, KeyT desc_mask, SortPlan* plan,
+                                                                    const uint32_t* __restrict__ hist2, const uint32_t* __restrict__ base2,
+                                                                    uint32_t* __restrict__ todo, int exp, int cursor_path)
+{
+  HybridPlan& hy = plan->hy;
+  if (!hy.attempt || !hy.ok || (plan->hf.state == 3) != (cursor_path != 0)) return;
+  if (!place_applies<KeyT, KIND, HAS_VAL, CL2>(hy, exp)) return;
+  const uint32_t ncells = (uint32_t)BINS << hy.bits2;
+  for (uint32_t cell = blockIdx.x; cell < ncells; cell += gridDim.x) {
+    local_place_cell<KeyT, KIND, HAS_VAL, CL2>(cell, in, out, vin, vout, desc_mask, plan, hist2, base2, todo, exp);
+    __syncthreads();  // the next cell reuses the LDS
+  }
+}
+
+// One cell of k_local_sort (every thread of the workgroup calls it with the same cell; returns are block-uniform).
+template <typename KeyT, int KIND, bool HAS_VAL, int CL2>
+__device__ __forceinline__ void local_sort_cell(const uint32_t cell, const KeyT* in, KeyT* __restrict__ out,
+                                                const uint32_t* vin, uint32_t* __restrict__ vout,
+                                                KeyT desc_mask_in, SortPlan* plan,
+                                                const uint32_t* __restrict__ hist2, const uint32_t* __restrict__ base2, int exp)
 {
   // PAIRS = the packed-word mode: pairs, and float keys (whose -0.0 == +0.0 ties must keep input order
   // and whose original bits cannot be rebuilt from the sortable form)
@@ -1260,7 +1276,6 @@ __global__ void __launch_bounds__((1 << CL2) / 16, 4) k_local_sort(const KeyT* i
   constexpr int SB = CL2 - 6, NSB = 1 << SB;  // LDS split into NSB sub-buckets of ~64 keys
   constexpr bool CAN_PACK = HAS_VAL || KIND == K_FLOAT;
   HybridPlan& hy = plan->hy;
-  if (!hy.attempt || !hy.ok || (plan->hf.state == 3) != (cursor_path != 0)) return;
   const bool PAIRS     = CAN_PACK && (hy.shift2 + LS_POS_BITS <= 64);  // k_hy_plan never attempts pairs otherwise
   const KeyT desc_mask = desc_mask_in;
   const int pos_shift  = PAIRS ? LS_POS_BITS : 0;
@@ -1271,13 +1286,6 @@ __global__ void __launch_bounds__((1 << CL2) / 16, 4) k_local_sort(const KeyT* i
   uint32_t* s_whist = reinterpret_cast<uint32_t*>(smem + (size_t)LOCAL_MAX * sizeof(KeyT));   // [LS_NW][256]
   uint32_t* s_scan  = s_whist + LS_NW * BINS;                                                 // [32]
   const int bits2   = hy.bits2;
-  if (blockIdx.x >= ((unsigned)BINS << bits2)) return;
-  // k_local_place has sorted every cell but the crowded ones, whose numbers it left in `todo`
-  uint32_t cell = blockIdx.x;
-  if (todo != nullptr && place_applies<KeyT, KIND, HAS_VAL, CL2>(hy, exp)) {
-    if (cell >= hy.todo_count) return;
-    cell = todo[cell];
-  }
   const uint32_t b  = cell >> bits2;
   const uint32_t d2 = cell & ((1u << bits2) - 1u);
   const uint32_t m  = hist2[b * NB2MAX + d2];  // cell size (level-1 pass), output position (k_plan2)
@@ -1494,6 +1502,28 @@ __global__ void __launch_bounds__((1 << CL2) / 16, 4) k_local_sort(const KeyT* i
   }
 }
 
+
+// The cells of the hybrid path that k_local_place did not sort: all of them when the placement does not apply (fewer key
+// bits left than the counting pass takes, a packed word that does not fit, knob 32), otherwise the crowded cells whose
+// numbers it left in `todo`.  The grid is a fixed number of workgroups that walk the list with a stride: a launch that
+// finds nothing to do -- the common case behind k_local_place, and the look-back path's instance behind a cursor-path
+// sort -- costs a few microseconds instead of the ~0.1 ms that dispatching one workgroup per cell takes.
+template <typename KeyT, int KIND, bool HAS_VAL, int CL2>
+__global__ void __launch_bounds__((1 << CL2) / 16, 4) k_local_sort(const KeyT* in, KeyT* __restrict__ out,
+                                                      const uint32_t* vin, uint32_t* __restrict__ vout,
+                                                      KeyT desc_mask_in, SortPlan* plan,
+                                                      const uint32_t* __restrict__ hist2, const uint32_t* __restrict__ base2,
+                                                      int exp = 0, int cursor_path = 0, const uint32_t* __restrict__ todo = nullptr)
+{
+  HybridPlan& hy = plan->hy;
+  if (!hy.attempt || !hy.ok || (plan->hf.state == 3) != (cursor_path != 0)) return;
+  const bool listed    = todo != nullptr && place_applies<KeyT, KIND, HAS_VAL, CL2>(hy, exp);
+  const uint32_t count = listed ? hy.todo_count : ((uint32_t)BINS << hy.bits2);
+  for (uint32_t e = blockIdx.x; e < count; e += gridDim.x) {
+    local_sort_cell<KeyT, KIND, HAS_VAL, CL2>(listed ? todo[e] : e, in, out, vin, vout, desc_mask_in, plan, hist2, base2, exp);
+    __syncthreads();  // the next cell reuses the LDS
+  }
+}
 
 // ------------------------------------------------------------------------------------------------------------------
 // Round 3: the CURSOR path of the hybrid sort -- integer keys, keys only (cudf::sort of one int64 / uint64 column, the
@@ -1917,6 +1947,10 @@ struct HybridCfg {
   int kpt;    // keys per thread of the partition passes
 };
 static int g_cell = 0;  // A/B knob: 0 = auto, 8192 / 16384 = force the local-sort cell capacity
+// workgroups of k_local_sort: they walk the cells (or k_local_place's todo list) with a stride, see the kernel
+static inline unsigned local_sort_grid(int cells) { return (unsigned)(cells < 4096 ? cells : 4096); }
+static int g_place_grid = 0;  // A/B knob: workgroups of k_local_place; 0 = one per cell
+static inline unsigned local_place_grid(int cells) { return (unsigned)((g_place_grid > 0 && g_place_grid < cells) ? g_place_grid : cells); }
 template <typename KeyT, int KIND, bool HAS_VAL>
 static HybridCfg hybrid_cfg(int64_t n, bool iota_payload, int algo)
 {
@@ -2080,9 +2114,9 @@ int sort_impl(const void* keys_in, void* keys_out, const int32_t* vals_in, int32
       prof_mark_h(2, stream);
       hipLaunchKernelGGL(k_plan2, dim3(BINS), dim3(GX_WAVE), 0, stream, plan, hist2, base2, NPASS, 1);
       prof_mark_h(3, stream);
-      hipLaunchKernelGGL((k_local_place<KeyT, KIND, HAS_VAL, 13>), dim3((unsigned)(BINS << fc.bits2)), dim3((1 << 13) / 16), place_lds_bytes(13), stream,
+      hipLaunchKernelGGL((k_local_place<KeyT, KIND, HAS_VAL, 13>), dim3(local_place_grid(BINS << fc.bits2)), dim3((1 << 13) / 16), place_lds_bytes(13), stream,
                          kb_scratch, bufA, (const uint32_t*)nullptr, (uint32_t*)nullptr, desc_mask, plan, hist2, base2, todo, g_exp, 1);
-      hipLaunchKernelGGL((k_local_sort<KeyT, KIND, HAS_VAL, 13>), dim3((unsigned)(BINS << fc.bits2)), dim3((1 << 13) / 16),
+      hipLaunchKernelGGL((k_local_sort<KeyT, KIND, HAS_VAL, 13>), dim3(local_sort_grid(BINS << fc.bits2)), dim3((1 << 13) / 16),
                          ((size_t)sizeof(KeyT) << 13) + (size_t)(((1 << 13) / 16 / GX_WAVE) * BINS + 32 + 2 * BINS) * 4, stream, kb_scratch, bufA,
                          (const uint32_t*)nullptr, (uint32_t*)nullptr, desc_mask, plan, hist2, base2, g_exp, 1, todo);
       prof_mark_h(4, stream);
@@ -2197,9 +2231,9 @@ int sort_impl(const void* keys_in, void* keys_out, const int32_t* vals_in, int32
       if constexpr (SMALLOK) {
         if (hc.cl2 == 13) kplace = k_local_place<KeyT, KIND, HAS_VAL, 13>;
       }
-      hipLaunchKernelGGL(kplace, dim3((unsigned)(BINS << hc.bits2)), dim3(ls_bt), place_lds_bytes(hc.cl2), stream, (const KeyT*)bufB, bufA,
+      hipLaunchKernelGGL(kplace, dim3(local_place_grid(BINS << hc.bits2)), dim3(ls_bt), place_lds_bytes(hc.cl2), stream, (const KeyT*)bufB, bufA,
                          (const uint32_t*)valB, valA, desc_mask, plan, hist2, base2, todo, m.exp, 0);
-      hipLaunchKernelGGL(kloc, dim3((unsigned)(BINS << hc.bits2)), dim3(ls_bt), lds_loc(hc.cl2), stream, bufB, bufA, valB, valA, desc_mask,
+      hipLaunchKernelGGL(kloc, dim3(local_sort_grid(BINS << hc.bits2)), dim3(ls_bt), lds_loc(hc.cl2), stream, bufB, bufA, valB, valA, desc_mask,
                          plan, hist2, base2, m.exp, 0, (const uint32_t*)todo);
       if (!cursor_marked) prof_mark_h(4, stream);
       if (!cursor_marked) g_prof.hybrid_marked = g_prof.enabled;
@@ -2434,6 +2468,8 @@ int gx_sort_profile_read_hybrid(float* ms4)
 void gx_sort_set_hybrid(int enable) { gx::sort::g_hybrid = enable ? 1 : 0; }
 
 void gx_sort_set_experiment(int bits) { gx::sort::g_exp = bits & 0x3C; }
+
+void gx_sort_set_place_grid(int workgroups) { gx::sort::g_place_grid = workgroups > 0 ? workgroups : 0; }
 
 void gx_sort_set_cursor_path(int enable, float margin_sigmas)
 {

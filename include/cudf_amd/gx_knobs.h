@@ -45,6 +45,9 @@ void gx_sort_set_hybrid(int enable);
  * of the counting split.  A/B knob (the output IS sorted): 32 = every 8192-key cell takes k_local_sort's sub-bucket path,
  * i.e. k_local_place (counting placement + per-thread window networks) is switched off.  0 = production. */
 void gx_sort_set_experiment(int bits);
+/* A/B knob (process-wide): workgroups of k_local_place.  0 (default) = one per cell; otherwise that many workgroups walk the
+ * cells with a stride (persistent form). */
+void gx_sort_set_place_grid(int workgroups);
 /* Cells of the last hybrid sort that used `tmp` which k_local_place found crowded (a bin of the 13-bit counting pass with
  * more than 9 keys: duplicates, clusters) and left to k_local_sort; 0 when every cell was placed, or when k_local_place
  * did not apply (16384-key cells, float keys, fewer than 13 key bits left, knob).  Synchronises `stream`. */

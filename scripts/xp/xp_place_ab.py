@@ -13,6 +13,8 @@ n = int(float(sys.argv[1])) if len(sys.argv) > 1 else 1_000_000_000
 which = sys.argv[2] if len(sys.argv) > 2 else "both"
 kind = sys.argv[3] if len(sys.argv) > 3 else "i64"  # f64: random BIT PATTERNS as float64 keys (16384-key cells, packed words)
 sp = ops.stream_ptr()
+PLACE_GRID = int(os.environ.get("PLACE_GRID", "0"))  # workgroups of k_local_place (0 = one per cell)
+L.lib.gx_sort_set_place_grid(PLACE_GRID)
 if kind == "f64":
     keys = Column.empty(np.float64, n)
     L.check(L.lib.gx_fill_random(Column.empty(np.int64, 0).gx, keys.data_ptr, n, 42, 0, 0, sp), "fill")
@@ -45,7 +47,7 @@ def measure(name, call, tmp, out):
         L.lib.gx_sort_cursor_state(ops.ptr(tmp), ctypes.byref(state), sp)
         sums[bits] = ops.checksum(out)
         m = np.mean(np.array(st), axis=0) if st else [float("nan")] * 4
-        print(f"{name:16s} n={n:.1e} exp={bits:2d} total {total:7.3f} ms | level0 {m[0]:5.2f} level1 {m[1]:5.2f} plan2 {m[2]:5.2f} local stage {m[3]:5.2f} ms | "
+        print(f"{name:16s} place_grid={PLACE_GRID} n={n:.1e} exp={bits:2d} total {total:7.3f} ms | level0 {m[0]:5.2f} level1 {m[1]:5.2f} plan2 {m[2]:5.2f} local stage {m[3]:5.2f} ms | "
               f"cursor state {state.value} cells left to k_local_sort {todo.value}", flush=True)
     L.lib.gx_sort_set_experiment(0)
     return sums
