@@ -559,11 +559,12 @@ __host__ __device__ __forceinline__ uint32_t hash_combine32(uint32_t lhs, uint32
 #define GX_CE(a, b)                          \
   {                                          \
     const bool s_ = v[b] < v[a];             \
-    const uint64_t lo_ = s_ ? v[b] : v[a];   \
-    v[b]               = s_ ? v[a] : v[b];   \
-    v[a]               = lo_;                \
+    const T lo_   = s_ ? v[b] : v[a];        \
+    v[b]          = s_ ? v[a] : v[b];        \
+    v[a]          = lo_;                     \
   }
-__device__ __forceinline__ void sort16_regs(uint64_t (&v)[16])
+template <typename T>
+__device__ __forceinline__ void sort16_regs(T (&v)[16])
 {
   GX_CE(0, 13); GX_CE(1, 12); GX_CE(2, 15); GX_CE(3, 14); GX_CE(4, 8); GX_CE(5, 6);
   GX_CE(7, 11); GX_CE(9, 10); GX_CE(0, 5); GX_CE(1, 7); GX_CE(2, 9); GX_CE(3, 4);
@@ -576,7 +577,8 @@ __device__ __forceinline__ void sort16_regs(uint64_t (&v)[16])
   GX_CE(11, 13); GX_CE(3, 5); GX_CE(6, 8); GX_CE(7, 9); GX_CE(10, 12); GX_CE(3, 4);
   GX_CE(5, 6); GX_CE(7, 8); GX_CE(9, 10); GX_CE(11, 12); GX_CE(6, 7); GX_CE(8, 9);
 }
-__device__ __forceinline__ void merge16_regs(uint64_t (&v)[16])
+template <typename T>
+__device__ __forceinline__ void merge16_regs(T (&v)[16])
 {
   GX_CE(0, 8); GX_CE(1, 9); GX_CE(2, 10); GX_CE(3, 11); GX_CE(4, 12); GX_CE(5, 13);
   GX_CE(6, 14); GX_CE(7, 15); GX_CE(4, 8); GX_CE(5, 9); GX_CE(6, 10); GX_CE(7, 11);

@@ -1103,7 +1103,15 @@ __device__ __forceinline__ bool place_applies(const HybridPlan& hy, int exp)
   const int word_bits   = hy.shift2 + (PACKED ? CL2 : 0);
   return hy.nlocal > 0 && !(exp & (32 | 16 | 8 | 4)) && word_bits >= CL2 && word_bits <= 64;
 }
-constexpr size_t place_lds_bytes(int cl2) { return (size_t)((1 << cl2) + (1 << cl2) / 16) * 8 + (size_t)(1 << cl2) + (size_t)((1 << cl2) / 16) * 4 + 32 * 4; }
+// word of the cell sort: 8 bytes for 64-bit keys and for every packed (key bits, position) word; 32-bit integer keys travel as they are
+template <typename KeyT, int KIND, bool HAS_VAL>
+struct PlaceWord {
+  typedef typename std::conditional<sizeof(KeyT) == 8 || HAS_VAL || KIND == K_FLOAT, uint64_t, uint32_t>::type type;
+};
+constexpr size_t place_lds_bytes(int cl2, int word_bytes = 8)
+{
+  return (size_t)((1 << cl2) + (1 << cl2) / 16) * word_bytes + (size_t)(1 << cl2) + (size_t)((1 << cl2) / 16) * 4 + 32 * 4;
+}
 
 // one cell of k_local_place (every thread of the workgroup calls it with the same cell; returns are block-uniform)
 template <typename KeyT, int KIND, bool HAS_VAL, int CL2>
@@ -1112,9 +1120,10 @@ __device__ __forceinline__ void local_place_cell(const uint32_t cell, const KeyT
                                                  const uint32_t* __restrict__ hist2, const uint32_t* __restrict__ base2,
                                                  uint32_t* __restrict__ todo, int exp)
 {
-  static_assert(sizeof(KeyT) == 8, "64-bit keys");
   constexpr int LOCAL_MAX = 1 << CL2, LS_KPT = 16, LS_BT = LOCAL_MAX / LS_KPT, NPB = 1 << CL2;
   constexpr bool PACKED = HAS_VAL || KIND == K_FLOAT;
+  typedef typename PlaceWord<KeyT, KIND, HAS_VAL>::type WordT;  // what goes through LDS and the networks
+  static_assert(!PACKED || sizeof(KeyT) == 8, "packed words: 64-bit keys");
   HybridPlan& hy = plan->hy;
   const int bits2 = hy.bits2;
   const uint32_t b  = cell >> bits2;
@@ -1125,8 +1134,8 @@ __device__ __forceinline__ void local_place_cell(const uint32_t cell, const KeyT
   in += (int64_t)cell * LOCAL_MAX - start;  // the cell sits in its slot of the padded level-1 buffer
   if (HAS_VAL) vin += (int64_t)cell * LOCAL_MAX - start;
   extern __shared__ __attribute__((aligned(16))) char smem[];
-  KeyT* s_keys     = reinterpret_cast<KeyT*>(smem);                                                  // LOCAL_MAX + LOCAL_MAX / 16
-  uint32_t* s_cnt8 = reinterpret_cast<uint32_t*>(smem + (size_t)(LOCAL_MAX + LOCAL_MAX / 16) * 8);  // NPB bytes
+  WordT* s_keys    = reinterpret_cast<WordT*>(smem);                                                 // LOCAL_MAX + LOCAL_MAX / 16
+  uint32_t* s_cnt8 = reinterpret_cast<uint32_t*>(smem + (size_t)(LOCAL_MAX + LOCAL_MAX / 16) * sizeof(WordT));  // NPB bytes
   uint32_t* s_base = s_cnt8 + NPB / 4;                                                               // [LS_BT] first position of bin 16 t
   uint32_t* s_scan = s_base + LS_BT;                                                                 // [32]
   const unsigned tid  = threadIdx.x;
@@ -1136,13 +1145,14 @@ __device__ __forceinline__ void local_place_cell(const uint32_t cell, const KeyT
   const int dshift    = shift2 + (PACKED ? CL2 : 0) - CL2;
 
   reinterpret_cast<uint4*>(s_cnt8)[tid] = make_uint4(0u, 0u, 0u, 0u);
-  KeyT key[LS_KPT];
+  WordT key[LS_KPT];
 #pragma unroll
   for (int j = 0; j < LS_KPT; ++j) {
     const int idx = wbase + j * GX_WAVE;
     const KeyT k  = ((uint32_t)idx < m) ? in[start + idx] : KeyT(0);
     const KeyT sk = to_sortable<KeyT, KIND>(k, desc_mask);
-    key[j]        = PACKED ? (KeyT)(((sk & ((KeyT(1) << shift2) - KeyT(1))) << CL2) | (KeyT)idx) : sk;
+    if constexpr (PACKED) key[j] = (WordT)(((sk & ((KeyT(1) << shift2) - KeyT(1))) << CL2) | (KeyT)idx);
+    else key[j] = (WordT)sk;
   }
   __syncthreads();
   uint32_t rk[LS_KPT / 4] = {0u, 0u, 0u, 0u};  // rank inside the bin, one byte per key
@@ -1206,40 +1216,41 @@ __device__ __forceinline__ void local_place_cell(const uint32_t cell, const KeyT
   // a wave whose 1024 positions all lie behind the cell's last key has nothing to sort (part-filled cells: n well below
   // the size class's limit, 10-bit level 1); it only keeps the barriers
   const bool busy = 16u * (tid & ~(unsigned)(GX_WAVE - 1)) < m;
-  uint64_t v[16];
-  KeyT* mine = s_keys + 17 * tid;  // positions 16 tid .. 16 tid + 15
+  WordT v[16];
+  WordT* mine = s_keys + 17 * tid;  // positions 16 tid .. 16 tid + 15
   if (busy) {
 #pragma unroll
-    for (int i = 0; i < 16; ++i) v[i] = (16u * tid + (uint32_t)i < m) ? (uint64_t)mine[i] : ~0ull;
+    for (int i = 0; i < 16; ++i) v[i] = (16u * tid + (uint32_t)i < m) ? mine[i] : (WordT)~WordT(0);
     sort16_regs(v);
 #pragma unroll
-    for (int i = 0; i < 8; ++i) mine[i] = (KeyT)v[i];  // the lower half: final for thread 0, merged by thread tid - 1 otherwise
+    for (int i = 0; i < 8; ++i) mine[i] = v[i];  // the lower half: final for thread 0, merged by thread tid - 1 otherwise
   }
   __syncthreads();
   if (busy) {
 #pragma unroll
     for (int i = 0; i < 8; ++i) {
       v[i]     = v[8 + i];
-      v[8 + i] = (16u * (tid + 1) + (uint32_t)i < m) ? (uint64_t)mine[17 + i] : ~0ull;  // m <= 16 LS_BT: never past the last thread
+      v[8 + i] = (16u * (tid + 1) + (uint32_t)i < m) ? mine[17 + i] : (WordT)~WordT(0);  // m <= 16 LS_BT: never past the last thread
     }
     merge16_regs(v);
 #pragma unroll
-    for (int i = 0; i < 8; ++i) mine[8 + i] = (KeyT)v[i];
+    for (int i = 0; i < 8; ++i) mine[8 + i] = v[i];
     if (16u * (tid + 1) < m) {
 #pragma unroll
-      for (int i = 0; i < 8; ++i) mine[17 + i] = (KeyT)v[8 + i];
+      for (int i = 0; i < 8; ++i) mine[17 + i] = v[8 + i];
     }
   }
   __syncthreads();
-  if (PACKED) {
+  if constexpr (PACKED) {
     pairs_write_out<KeyT, KIND, HAS_VAL, CL2>(s_keys, in + start, out, HAS_VAL ? vin + start : nullptr, vout, start, m, shift2, desc_mask, !(exp & 64),
                                               true);
     return;
-  }
+  } else {
 #pragma unroll
-  for (int j = 0; j < LS_KPT; ++j) {
-    const int i = j * LS_BT + (int)tid;
-    if ((uint32_t)i < m) out[start + i] = to_sortable<KeyT, KIND>(s_keys[i + (i >> 4)], desc_mask);  // an involution for integer kinds
+    for (int j = 0; j < LS_KPT; ++j) {
+      const int i = j * LS_BT + (int)tid;
+      if ((uint32_t)i < m) out[start + i] = to_sortable<KeyT, KIND>((KeyT)s_keys[i + (i >> 4)], desc_mask);  // an involution for integer kinds
+    }
   }
 }
 
@@ -1253,7 +1264,7 @@ __global__ void __launch_bounds__((1 << CL2) / 16, 4) k_local_place(const KeyT* 
 {
   HybridPlan& hy = plan->hy;
   if (!hy.attempt || !hy.ok || (plan->hf.state == 3) != (cursor_path != 0)) return;
-  if (!place_applies<KeyT, KIND, HAS_VAL, CL2>(hy, exp)) return;
+  if (!place_applies<KeyT, KIND, HAS_VAL, CL2>(hy, exp)) return;  // k_local_sort, launched behind, takes every cell
   const uint32_t ncells = (uint32_t)BINS << hy.bits2;
   for (uint32_t cell = blockIdx.x; cell < ncells; cell += gridDim.x) {
     local_place_cell<KeyT, KIND, HAS_VAL, CL2>(cell, in, out, vin, vout, desc_mask, plan, hist2, base2, todo, exp);
@@ -1262,12 +1273,16 @@ __global__ void __launch_bounds__((1 << CL2) / 16, 4) k_local_place(const KeyT* 
 }
 
 // One cell of k_local_sort (every thread of the workgroup calls it with the same cell; returns are block-uniform).
-template <typename KeyT, int KIND, bool HAS_VAL, int CL2>
-__device__ __forceinline__ void local_sort_cell(const uint32_t cell, const KeyT* in, KeyT* __restrict__ out,
+// IoT: the column's element type when it is narrower than the word the cell is sorted on (32-bit integer keys: KeyT =
+// uint64_t words holding the SORTABLE form of the key, so that every transform below is the identity until the store).
+template <typename KeyT, int KIND, bool HAS_VAL, int CL2, typename IoT = KeyT>
+__device__ __forceinline__ void local_sort_cell(const uint32_t cell, const IoT* in, IoT* __restrict__ out,
                                                 const uint32_t* vin, uint32_t* __restrict__ vout,
                                                 KeyT desc_mask_in, SortPlan* plan,
                                                 const uint32_t* __restrict__ hist2, const uint32_t* __restrict__ base2, int exp)
 {
+  constexpr bool NARROW = !std::is_same<IoT, KeyT>::value;
+  static_assert(!NARROW || (!HAS_VAL && KIND != K_FLOAT && sizeof(KeyT) == 8), "narrow columns: integer keys only");
   // PAIRS = the packed-word mode: pairs, and float keys (whose -0.0 == +0.0 ties must keep input order
   // and whose original bits cannot be rebuilt from the sortable form)
   // (floats whose remaining bits do not leave room for the position keep plain keys and take the
@@ -1280,7 +1295,16 @@ __device__ __forceinline__ void local_sort_cell(const uint32_t cell, const KeyT*
   const KeyT desc_mask = desc_mask_in;
   const int pos_shift  = PAIRS ? LS_POS_BITS : 0;
   // sortable form of a register word: packed words already are, plain keys go through the transform
-  auto sortable = [&](KeyT x) -> KeyT { return PAIRS ? x : to_sortable<KeyT, KIND>(x, desc_mask); };
+  auto sortable = [&](KeyT x) -> KeyT { return (PAIRS || NARROW) ? x : to_sortable<KeyT, KIND>(x, desc_mask); };
+  // stores: `unsort` takes the sortable form of a key, `put` the form the registers hold (raw keys; sortable words when NARROW)
+  auto unsort = [&](KeyT x) -> IoT {
+    if constexpr (NARROW) return to_sortable<IoT, KIND>((IoT)x, (IoT)desc_mask);
+    else return to_sortable<KeyT, KIND>(x, desc_mask);
+  };
+  auto put = [&](KeyT x) -> IoT {
+    if constexpr (NARROW) return to_sortable<IoT, KIND>((IoT)x, (IoT)desc_mask);
+    else return x;
+  };
   extern __shared__ __attribute__((aligned(16))) char smem[];
   KeyT* s_keys      = reinterpret_cast<KeyT*>(smem);                                           // LOCAL_MAX
   uint32_t* s_whist = reinterpret_cast<uint32_t*>(smem + (size_t)LOCAL_MAX * sizeof(KeyT));   // [LS_NW][256]
@@ -1304,7 +1328,8 @@ __device__ __forceinline__ void local_sort_cell(const uint32_t cell, const KeyT*
 #pragma unroll
   for (int j = 0; j < LS_KPT; ++j) {
     const int idx = wbase + j * GX_WAVE;
-    key[j]        = ((uint32_t)idx < m) ? in[start + idx] : KeyT(0);
+    if constexpr (NARROW) key[j] = ((uint32_t)idx < m) ? (KeyT)to_sortable<IoT, KIND>(in[start + idx], (IoT)desc_mask) : KeyT(0);
+    else key[j] = ((uint32_t)idx < m) ? in[start + idx] : KeyT(0);
     if (PAIRS) {
       const KeyT sk = to_sortable<KeyT, KIND>(key[j], desc_mask_in);
       key[j]        = ((sk & ((KeyT(1) << hy.shift2) - KeyT(1))) << LS_POS_BITS) | (KeyT)idx;
@@ -1350,8 +1375,8 @@ __device__ __forceinline__ void local_sort_cell(const uint32_t cell, const KeyT*
           if (e0 < cnt) sub[e0] = (KeyT)k0;
           if (e1 < cnt) sub[e1] = (KeyT)k1;
         } else {
-          if (e0 < cnt) out[start + o + e0] = to_sortable<KeyT, KIND>((KeyT)k0, desc_mask);
-          if (e1 < cnt) out[start + o + e1] = to_sortable<KeyT, KIND>((KeyT)k1, desc_mask);
+          if (e0 < cnt) out[start + o + e0] = unsort((KeyT)k0);
+          if (e1 < cnt) out[start + o + e1] = unsort((KeyT)k1);
         }
       };
       // crowded bin (or too few bits left for a counting split): the in-register bitonic network
@@ -1361,7 +1386,7 @@ __device__ __forceinline__ void local_sort_cell(const uint32_t cell, const KeyT*
           k0 = lane < cnt ? (uint64_t)sub[lane] : ~0ull;
           wave_bitonic64(k0);
           if (lane < cnt) {
-            if (PAIRS) sub[lane] = (KeyT)k0; else out[start + o + lane] = to_sortable<KeyT, KIND>((KeyT)k0, desc_mask);
+            if (PAIRS) sub[lane] = (KeyT)k0; else out[start + o + lane] = unsort((KeyT)k0);
           }
         } else {
           k0 = (uint64_t)sub[lane];
@@ -1371,8 +1396,8 @@ __device__ __forceinline__ void local_sort_cell(const uint32_t cell, const KeyT*
             sub[lane] = (KeyT)k0;
             if (lane + 64 < cnt) sub[64 + lane] = (KeyT)k1;
           } else {
-            out[start + o + lane] = to_sortable<KeyT, KIND>((KeyT)k0, desc_mask);
-            if (lane + 64 < cnt) out[start + o + 64 + lane] = to_sortable<KeyT, KIND>((KeyT)k1, desc_mask);
+            out[start + o + lane] = unsort((KeyT)k0);
+            if (lane + 64 < cnt) out[start + o + 64 + lane] = unsort((KeyT)k1);
           }
         }
       };
@@ -1400,19 +1425,21 @@ __device__ __forceinline__ void local_sort_cell(const uint32_t cell, const KeyT*
       if (!PAIRS) {
         // sub-buckets of 0 or 1 keys were skipped by the loop above: they leave here
         if (!(exp & 4)) {
-          if (tid < NSB && s_cnt[tid] == 1) out[start + s_start[tid]] = to_sortable<KeyT, KIND>(s_keys[s_start[tid]], desc_mask);
+          if (tid < NSB && s_cnt[tid] == 1) out[start + s_start[tid]] = unsort(s_keys[s_start[tid]]);
           return;
         }
       }
       __syncthreads();
-      if (PAIRS) {
-        pairs_write_out<KeyT, KIND, HAS_VAL, CL2>(s_keys, in + start, out, HAS_VAL ? vin + start : nullptr, vout, start, m, hy.shift2, desc_mask_in, !(exp & 64));
-        return;
+      if constexpr (!NARROW) {
+        if (PAIRS) {
+          pairs_write_out<KeyT, KIND, HAS_VAL, CL2>(s_keys, in + start, out, HAS_VAL ? vin + start : nullptr, vout, start, m, hy.shift2, desc_mask_in, !(exp & 64));
+          return;
+        }
       }
 #pragma unroll
       for (int j = 0; j < LS_KPT; ++j) {
         const int i = j * LS_BT + (int)tid;
-        if ((uint32_t)i < m) out[start + i] = to_sortable<KeyT, KIND>(s_keys[i], desc_mask);  // integer kinds only
+        if ((uint32_t)i < m) out[start + i] = unsort(s_keys[i]);  // integer kinds only
       }
       return;
     }
@@ -1485,20 +1512,22 @@ __device__ __forceinline__ void local_sort_cell(const uint32_t cell, const KeyT*
           out[start + idx] = in[start + idx];
           if (HAS_VAL) vout[start + idx] = vin[start + idx];
         } else {
-          out[start + idx] = key[j];
+          out[start + idx] = put(key[j]);
         }
       }
     }
     return;
   }
-  if (PAIRS) {
-    pairs_write_out<KeyT, KIND, HAS_VAL, CL2>(s_keys, in + start, out, HAS_VAL ? vin + start : nullptr, vout, start, m, hy.shift2, desc_mask_in, !(exp & 64));
-    return;
+  if constexpr (!NARROW) {
+    if (PAIRS) {
+      pairs_write_out<KeyT, KIND, HAS_VAL, CL2>(s_keys, in + start, out, HAS_VAL ? vin + start : nullptr, vout, start, m, hy.shift2, desc_mask_in, !(exp & 64));
+      return;
+    }
   }
 #pragma unroll
   for (int j = 0; j < LS_KPT; ++j) {
     const int i = j * LS_BT + (int)tid;
-    if ((uint32_t)i < m) out[start + i] = s_keys[i];
+    if ((uint32_t)i < m) out[start + i] = put(s_keys[i]);
   }
 }
 
@@ -1508,8 +1537,8 @@ __device__ __forceinline__ void local_sort_cell(const uint32_t cell, const KeyT*
 // numbers it left in `todo`.  The grid is a fixed number of workgroups that walk the list with a stride: a launch that
 // finds nothing to do -- the common case behind k_local_place, and the look-back path's instance behind a cursor-path
 // sort -- costs a few microseconds instead of the ~0.1 ms that dispatching one workgroup per cell takes.
-template <typename KeyT, int KIND, bool HAS_VAL, int CL2>
-__global__ void __launch_bounds__((1 << CL2) / 16, 4) k_local_sort(const KeyT* in, KeyT* __restrict__ out,
+template <typename KeyT, int KIND, bool HAS_VAL, int CL2, typename IoT = KeyT>
+__global__ void __launch_bounds__((1 << CL2) / 16, 4) k_local_sort(const IoT* in, IoT* __restrict__ out,
                                                       const uint32_t* vin, uint32_t* __restrict__ vout,
                                                       KeyT desc_mask_in, SortPlan* plan,
                                                       const uint32_t* __restrict__ hist2, const uint32_t* __restrict__ base2,
@@ -1517,10 +1546,10 @@ __global__ void __launch_bounds__((1 << CL2) / 16, 4) k_local_sort(const KeyT* i
 {
   HybridPlan& hy = plan->hy;
   if (!hy.attempt || !hy.ok || (plan->hf.state == 3) != (cursor_path != 0)) return;
-  const bool listed    = todo != nullptr && place_applies<KeyT, KIND, HAS_VAL, CL2>(hy, exp);
+  const bool listed    = todo != nullptr && place_applies<IoT, KIND, HAS_VAL, CL2>(hy, exp);  // (as k_local_place decided: on the column's type)
   const uint32_t count = listed ? hy.todo_count : ((uint32_t)BINS << hy.bits2);
   for (uint32_t e = blockIdx.x; e < count; e += gridDim.x) {
-    local_sort_cell<KeyT, KIND, HAS_VAL, CL2>(listed ? todo[e] : e, in, out, vin, vout, desc_mask_in, plan, hist2, base2, exp);
+    local_sort_cell<KeyT, KIND, HAS_VAL, CL2, IoT>(listed ? todo[e] : e, in, out, vin, vout, desc_mask_in, plan, hist2, base2, exp);
     __syncthreads();  // the next cell reuses the LDS
   }
 }
@@ -1632,8 +1661,9 @@ __device__ __forceinline__ void hf_give_up(SortPlan* plan, int state)
 //   1 (after the histogram sample)  slot capacities and positions of level 0
 //   2 (after level 0)  the verdict + everything level 1, k_plan2 and the local sort need
 __global__ void __launch_bounds__(BINS) k_hf_plan(SortPlan* plan, int stage, int key_bits, int64_t n, int bits2, int cell_max, int stride,
-                                                  int64_t range_rows, int tile_rows, unsigned long long slot_rows, float margin)
+                                                  int64_t range_rows, int tile_rows, unsigned long long slot_rows, float margin, int min_shift2)
 {
+  // min_shift2: key bits that must be left below level 1 (8: k_local_sort's sub-bucket split)
   __shared__ uint32_t s_tmp[BINS / GX_WAVE + 1];
   HybridPlan& hy = plan->hy;
   FastPlan& hf   = plan->hf;
@@ -1643,7 +1673,7 @@ __global__ void __launch_bounds__(BINS) k_hf_plan(SortPlan* plan, int stage, int
     const int top              = V ? 63 - __builtin_clzll(V) : 0;
     const int shift0           = top - 7;
     const int shift2           = shift0 - bits2;
-    if (V == 0 || shift2 < 8) {
+    if (V == 0 || shift2 < min_shift2) {
       // all sampled keys equal: let the look-back path look at the whole column.  Too few varying bits below level 1 in
       // the sample (narrow key ranges: the LSD passes are the right tool): state 4 also spares the look-back path's
       // up-front read -- declining the hybrid path is always safe, the LSD passes sort anything
@@ -1750,11 +1780,18 @@ __global__ void __launch_bounds__(256) k_hf_clear_status(const SortPlan* plan, u
   for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n16; i += stride) status[i] = uint4{0u, 0u, 0u, 0u};
 }
 
+// keys per thread of k_hf_scatter: 16 x 8 bytes = 64 KiB per tile; 32-bit keys take 24 (48 KiB: 32 per thread spill registers)
+template <typename KeyT>
+constexpr int hf_kpt()
+{
+  return sizeof(KeyT) == 8 ? 16 : 24;
+}
+
 template <typename KeyT, int KIND, int LVL, int NBL>
 __global__ void __launch_bounds__(BT, 4) k_hf_scatter(const KeyT* __restrict__ in, KeyT* __restrict__ out, KeyT desc_mask, SortPlan* plan,
                                                      uint32_t* __restrict__ cellcur, uint32_t cellcap, int64_t n)
 {
-  constexpr int KPT = 16, TILE = BT * KPT, NB = 1 << NBL, BPT = NB > BT ? NB / BT : 1;
+  constexpr int KPT = hf_kpt<KeyT>(), TILE = BT * KPT, NB = 1 << NBL, BPT = NB > BT ? NB / BT : 1;
   extern __shared__ __attribute__((aligned(16))) char smem[];
   KeyT* s_keys      = reinterpret_cast<KeyT*>(smem);                                        // [TILE]
   uint32_t* s_cnt   = reinterpret_cast<uint32_t*>(smem + (size_t)TILE * sizeof(KeyT));     // [NB] counts, then bin starts
@@ -1837,13 +1874,22 @@ __global__ void __launch_bounds__(BT, 4) k_hf_scatter(const KeyT* __restrict__ i
     if (o & ~__hip_atomic_load(&hy.or_mask, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) atomicOr(&hy.or_mask, o);
     if (no & ~__hip_atomic_load(&hy.nor_mask, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) atomicOr(&hy.nor_mask, no);
   }
-  uint32_t packed[KPT];
+  // 64-bit keys: digit and rank of key j in one word; 32-bit keys (32 per thread): two 16-bit ranks per word, the digit is
+  // recomputed from the key at the scatter (registers: 32 keys + 32 words would spill)
+  constexpr bool RANK16 = sizeof(KeyT) == 4;
+  uint32_t packed[RANK16 ? KPT / 2 : KPT];
+  if constexpr (RANK16) {
+#pragma unroll
+    for (int j = 0; j < KPT / 2; ++j) packed[j] = 0;
+  }
 #pragma unroll
   for (int j = 0; j < KPT; ++j) {
     const bool live  = j * BT + (int)tid < nvalid;
     const KeyT k     = to_sortable<KeyT, KIND>(key[j], desc_mask);
     const uint32_t d = (uint32_t)(k >> shift) & dmask;
-    packed[j]        = (d << 16) | lds_rank(s_cnt, d, live);
+    const uint32_t r = lds_rank(s_cnt, d, live);
+    if constexpr (RANK16) packed[j >> 1] |= r << (16 * (j & 1));
+    else packed[j] = (d << 16) | r;
   }
   __syncthreads();
   // ---- one returning atomic per non-empty bin reserves the tile's run; the scan runs while it is in flight
@@ -1885,7 +1931,14 @@ __global__ void __launch_bounds__(BT, 4) k_hf_scatter(const KeyT* __restrict__ i
   __syncthreads();
 #pragma unroll
   for (int j = 0; j < KPT; ++j) {
-    if (j * BT + (int)tid < nvalid) s_keys[s_cnt[packed[j] >> 16] + (packed[j] & 0xFFFFu)] = key[j];
+    if (j * BT + (int)tid < nvalid) {
+      if constexpr (RANK16) {
+        const uint32_t d = (uint32_t)(to_sortable<KeyT, KIND>(key[j], desc_mask) >> shift) & dmask;
+        s_keys[s_cnt[d] + ((packed[j >> 1] >> (16 * (j & 1))) & 0xFFFFu)] = key[j];
+      } else {
+        s_keys[s_cnt[packed[j] >> 16] + (packed[j] & 0xFFFFu)] = key[j];
+      }
+    }
   }
   __syncthreads();
 #pragma unroll
@@ -1986,7 +2039,10 @@ template <typename KeyT, int KIND, bool HAS_VAL>
 static FastCfg fast_cfg(int64_t n, int algo, bool hybrid_on)
 {
   FastCfg f{false, 9, 32, 0};
-  if (sizeof(KeyT) != 8 || HAS_VAL || KIND == K_FLOAT || algo != 0 || !hybrid_on || !g_cursor || n < (1ll << 25)) return f;
+  // 64-bit keys: wherever the hybrid path applies; 32-bit integer keys (round 3): the same two partition levels, the cells sorted
+  // by k_local_place on 32-bit words, the LSD passes as the only fallback
+  if ((sizeof(KeyT) != 8 && sizeof(KeyT) != 4) || HAS_VAL || KIND == K_FLOAT || algo != 0 || !g_cursor || n < (1ll << 25)) return f;
+  if (sizeof(KeyT) == 8 ? !hybrid_on : !g_hybrid) return f;
   int B = 9;
   while (B < 18 && (double)n / (double)(1ull << B) > 0.955 * 8192.0) ++B;
   if ((double)n / (double)(1ull << B) > 0.97 * 8192.0) return f;
@@ -2025,9 +2081,10 @@ int sort_impl(const void* keys_in, void* keys_out, const int32_t* vals_in, int32
   const int hyb_kpt     = hc.kpt;
   const int nb1         = hc.bits2 > 8 ? NB9 : BINS;  // bins (and look-back granules per tile) of the level-1 pass
   uint32_t* base1 = c.take<uint32_t>((size_t)NRANGE * NB2MAX);
-  uint32_t* hist2 = try_hybrid ? c.take<uint32_t>((size_t)2 * BINS * NB2MAX) : nullptr;  // cell sizes | cell output positions
-  uint32_t* base2 = try_hybrid ? hist2 + BINS * NB2MAX : nullptr;
-  uint32_t* todo  = try_hybrid ? c.take<uint32_t>((size_t)BINS * NB2MAX) : nullptr;  // cells k_local_place leaves to k_local_sort
+  const bool cells = try_hybrid || fc.on;  // (the cursor path of 32-bit keys runs without the look-back hybrid)
+  uint32_t* hist2 = cells ? c.take<uint32_t>((size_t)2 * BINS * NB2MAX) : nullptr;  // cell sizes | cell output positions
+  uint32_t* base2 = cells ? hist2 + BINS * NB2MAX : nullptr;
+  uint32_t* todo  = cells ? c.take<uint32_t>((size_t)BINS * NB2MAX) : nullptr;  // cells k_local_place leaves to k_local_sort
   const int64_t msd_tile     = (int64_t)BT * hyb_kpt;  // tile of the hybrid partition passes
   const int64_t msd_ntiles   = n > 0 ? div_up(n, msd_tile) : 0;
   const int64_t status_tiles = (msd_ntiles > ntiles ? msd_ntiles : ntiles) + BINS + 2 * NRANGE;  // segment tails add at most one tile each
@@ -2058,7 +2115,7 @@ int sort_impl(const void* keys_in, void* keys_out, const int32_t* vals_in, int32
   GX_HIP_TRY(hipMemsetAsync(plan, 0, sizeof(SortPlan), stream));
   if (n == 0) return 0;
   if (algo != 1 && !fc.on) GX_HIP_TRY(hipMemsetAsync(status, 0, status_words * sizeof(unsigned long long), stream));
-  if (try_hybrid) GX_HIP_TRY(hipMemsetAsync(hist2, 0, (size_t)2 * BINS * NB2MAX * sizeof(uint32_t), stream));
+  if (cells) GX_HIP_TRY(hipMemsetAsync(hist2, 0, (size_t)2 * BINS * NB2MAX * sizeof(uint32_t), stream));
   const int64_t range_rows = try_hybrid ? div_up(msd_ntiles, NRANGE) * msd_tile : div_up(ntiles, NRANGE) * TILE;
 
   const KeyT desc_mask = descending ? KeyT(~KeyT(0)) : KeyT(0);
@@ -2069,11 +2126,13 @@ int sort_impl(const void* keys_in, void* keys_out, const int32_t* vals_in, int32
   prof_mark(0, stream);
   g_prof.hybrid_marked = false;
   bool cursor_marked = false;
-  if constexpr (sizeof(KeyT) == 8 && !HAS_VAL && KIND != K_FLOAT) {
+  if constexpr ((sizeof(KeyT) == 8 || sizeof(KeyT) == 4) && !HAS_VAL && KIND != K_FLOAT) {
     if (fc.on) {
       // cursor path: speculative plan from a sample, verified by level 0; on a miss everything below is a no-op and the
       // look-back path further down sorts the column
-      constexpr int FT = BT * 16;
+      constexpr int FT = BT * hf_kpt<KeyT>();  // k_hf_scatter's tile
+      constexpr int MIN_SHIFT2 = 8;  // key bits that must be left below level 1 (k_local_sort's sub-bucket split takes 7 + 1)
+      constexpr int WORD_BYTES = (int)sizeof(typename PlaceWord<KeyT, KIND, HAS_VAL>::type);
       const int64_t ftiles  = div_up(n, (int64_t)FT);
       const int64_t frange  = (ftiles / NRANGE) * FT;  // rows per input range (whole tiles; the last range takes the rest)
       auto lds_hf = [&](int nb) { return (size_t)FT * sizeof(KeyT) + (size_t)(3 * nb + 16 + 4) * 4 + (size_t)2 * NW * 8; };
@@ -2087,10 +2146,10 @@ int sort_impl(const void* keys_in, void* keys_out, const int32_t* vals_in, int32
         GX_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(k_hf_scatter<KeyT, KIND, 1, 8>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_hf(256)));
         GX_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(k_hf_scatter<KeyT, KIND, 1, 9>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_hf(512)));
         GX_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(k_hf_scatter<KeyT, KIND, 1, 10>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_hf(1024)));
-        GX_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(k_local_sort<KeyT, KIND, HAS_VAL, 13>), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                       (int)(((size_t)sizeof(KeyT) << 13) + (size_t)(((1 << 13) / 16 / GX_WAVE) * BINS + 32 + 2 * BINS) * 4)));
+        GX_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(k_local_sort<uint64_t, KIND, HAS_VAL, 13, KeyT>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                       (int)(((size_t)8 << 13) + (size_t)(((1 << 13) / 16 / GX_WAVE) * BINS + 32 + 2 * BINS) * 4)));
         GX_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(k_local_place<KeyT, KIND, HAS_VAL, 13>), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                       (int)place_lds_bytes(13)));
+                                       (int)place_lds_bytes(13, WORD_BYTES)));
         fattr_set = true;
       }
       const int64_t step = (int64_t)fc.stride * HF_CHUNK;
@@ -2100,25 +2159,27 @@ int sort_impl(const void* keys_in, void* keys_out, const int32_t* vals_in, int32
       KeyT* bufA      = keys_out ? static_cast<KeyT*>(keys_out) : ka_scratch;
       hipLaunchKernelGGL((k_hf_sample<KeyT, KIND, false>), dim3((unsigned)sblocks), dim3(256), 0, stream, kin, n, desc_mask, plan, fc.stride, frange);
       hipLaunchKernelGGL(k_hf_plan, dim3(1), dim3(BINS), 0, stream, plan, 0, (int)(8 * sizeof(KeyT)), n, fc.bits2, 1 << 13, fc.stride, frange, FT,
-                         (unsigned long long)fc.slot_rows, g_cursor_margin);
+                         (unsigned long long)fc.slot_rows, g_cursor_margin, MIN_SHIFT2);
       hipLaunchKernelGGL((k_hf_sample<KeyT, KIND, true>), dim3((unsigned)sblocks), dim3(256), 0, stream, kin, n, desc_mask, plan, fc.stride, frange);
       hipLaunchKernelGGL(k_hf_plan, dim3(1), dim3(BINS), 0, stream, plan, 1, (int)(8 * sizeof(KeyT)), n, fc.bits2, 1 << 13, fc.stride, frange, FT,
-                         (unsigned long long)fc.slot_rows, g_cursor_margin);
+                         (unsigned long long)fc.slot_rows, g_cursor_margin, MIN_SHIFT2);
       prof_mark(1, stream);
       prof_mark_h(0, stream);
       hipLaunchKernelGGL(kf0, dim3((unsigned)ftiles), dim3(BT), lds_hf(256), stream, kin, slot0_buf, desc_mask, plan, hist2, 1u << 13, n);
       hipLaunchKernelGGL(k_hf_plan, dim3(1), dim3(BINS), 0, stream, plan, 2, (int)(8 * sizeof(KeyT)), n, fc.bits2, 1 << 13, fc.stride, frange, FT,
-                         (unsigned long long)fc.slot_rows, g_cursor_margin);
+                         (unsigned long long)fc.slot_rows, g_cursor_margin, MIN_SHIFT2);
       prof_mark_h(1, stream);
       hipLaunchKernelGGL(kf1, dim3((unsigned)(ftiles + NRANGE * BINS)), dim3(BT), lds_hf(nbf), stream, slot0_buf, kb_scratch, desc_mask, plan, hist2, 1u << 13, n);
       prof_mark_h(2, stream);
       hipLaunchKernelGGL(k_plan2, dim3(BINS), dim3(GX_WAVE), 0, stream, plan, hist2, base2, NPASS, 1);
       prof_mark_h(3, stream);
-      hipLaunchKernelGGL((k_local_place<KeyT, KIND, HAS_VAL, 13>), dim3(local_place_grid(BINS << fc.bits2)), dim3((1 << 13) / 16), place_lds_bytes(13), stream,
-                         kb_scratch, bufA, (const uint32_t*)nullptr, (uint32_t*)nullptr, desc_mask, plan, hist2, base2, todo, g_exp, 1);
-      hipLaunchKernelGGL((k_local_sort<KeyT, KIND, HAS_VAL, 13>), dim3(local_sort_grid(BINS << fc.bits2)), dim3((1 << 13) / 16),
-                         ((size_t)sizeof(KeyT) << 13) + (size_t)(((1 << 13) / 16 / GX_WAVE) * BINS + 32 + 2 * BINS) * 4, stream, kb_scratch, bufA,
-                         (const uint32_t*)nullptr, (uint32_t*)nullptr, desc_mask, plan, hist2, base2, g_exp, 1, todo);
+      hipLaunchKernelGGL((k_local_place<KeyT, KIND, HAS_VAL, 13>), dim3(local_place_grid(BINS << fc.bits2)), dim3((1 << 13) / 16),
+                         place_lds_bytes(13, WORD_BYTES), stream, kb_scratch, bufA, (const uint32_t*)nullptr, (uint32_t*)nullptr, desc_mask, plan, hist2,
+                         base2, todo, g_exp, 1);
+      // the cells k_local_place left: 64-bit words (32-bit keys are widened to their sortable form on the way in)
+      hipLaunchKernelGGL((k_local_sort<uint64_t, KIND, HAS_VAL, 13, KeyT>), dim3(local_sort_grid(BINS << fc.bits2)), dim3((1 << 13) / 16),
+                         ((size_t)8 << 13) + (size_t)(((1 << 13) / 16 / GX_WAVE) * BINS + 32 + 2 * BINS) * 4, stream, (const KeyT*)kb_scratch, bufA,
+                         (const uint32_t*)nullptr, (uint32_t*)nullptr, (uint64_t)desc_mask, plan, hist2, base2, g_exp, 1, (const uint32_t*)todo);
       prof_mark_h(4, stream);
       g_prof.hybrid_marked = g_prof.enabled;
       cursor_marked        = true;
@@ -2262,7 +2323,7 @@ int sort_impl(const void* keys_in, void* keys_out, const int32_t* vals_in, int32
 
   constexpr size_t lds = pass_lds_bytes<KeyT, HAS_VAL, KPT>();
   auto kern_lb         = (algo == 2) ? k_radix_pass<KeyT, KIND, HAS_VAL, KPT, 1>
-                                       : (try_hybrid ? k_radix_pass<KeyT, KIND, HAS_VAL, KPT, 4, true> : k_radix_pass<KeyT, KIND, HAS_VAL, KPT, 4>);
+                                       : (cells ? k_radix_pass<KeyT, KIND, HAS_VAL, KPT, 4, true> : k_radix_pass<KeyT, KIND, HAS_VAL, KPT, 4>);
   auto kern_pre        = k_radix_pass<KeyT, KIND, HAS_VAL, KPT, 0>;
   static bool attr_set = false;  // per template instantiation
   if (!attr_set) {
@@ -2280,7 +2341,7 @@ int sort_impl(const void* keys_in, void* keys_out, const int32_t* vals_in, int32
     a.pass = pass;
     prof_mark(2 + 2 * pass, stream);
     if (algo != 1) {
-      const int64_t lb_grid = (try_hybrid && algo != 2) ? div_up(ntiles, PASS_TPB) : ntiles;
+      const int64_t lb_grid = (cells && algo != 2) ? div_up(ntiles, PASS_TPB) : ntiles;
       hipLaunchKernelGGL(kern_lb, dim3((unsigned)lb_grid), dim3(BT), lds, stream, a);
     } else {
       hipLaunchKernelGGL((k_tile_hist<KeyT, KIND, KPT>), dim3((unsigned)ntiles), dim3(BT), 0, stream, a, tile_hist);

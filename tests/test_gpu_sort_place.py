@@ -148,3 +148,79 @@ def test_float64_keys_through_the_placement(gx, n):
         assert 0 <= todo <= 8, f"{todo} of {_cells(info)} cells were left to the sub-bucket path"
     got = _order(gx, v)
     np.testing.assert_array_equal(got, orc.sorted_order(v, None, True))
+
+
+# ------------------------------------------------------------------------------------------------
+# 32-bit integer keys on the cursor path (n >= 2^25): two atomic-cursor partition levels + k_local_place on 32-bit words;
+# crowded cells (and every cell when fewer than 13 key bits are left) go to k_local_sort on widened words; key ranges too narrow
+# for two partition levels, rejected samples and overflowing cells to the LSD passes -- all decided on the device
+# ------------------------------------------------------------------------------------------------
+def _sort32(gx, v, descending=False):
+    Column, ops, L = gx
+    col = Column.from_numpy(v)
+    out = Column.empty(v.dtype, v.size)
+    tmp = ops._run(L.lib.gx_sort_keys, col.gx, col.data_ptr, out.data_ptr, col.size, int(descending))
+    ops._check_sort_status(tmp)
+    info = (ctypes.c_int32 * 8)()
+    L.check(L.lib.gx_sort_info(ops.ptr(tmp), info, ops.stream_ptr()), "gx_sort_info")
+    st = ctypes.c_int32(-1)
+    L.check(L.lib.gx_sort_cursor_state(ops.ptr(tmp), ctypes.byref(st), ops.stream_ptr()), "gx_sort_cursor_state")
+    todo = ctypes.c_int32(-1)
+    L.check(L.lib.gx_sort_place_info(ops.ptr(tmp), ctypes.byref(todo), ops.stream_ptr()), "gx_sort_place_info")
+    return out.to_numpy(), list(info), st.value, todo.value
+
+
+@pytest.mark.parametrize("dtype", ["int32", "uint32"])
+@pytest.mark.parametrize("n", [40_000_000, 130_000_000])
+def test_32bit_keys_uniform_take_the_cursor_path(gx, dtype, n):
+    rng = np.random.default_rng(n % 1013)
+    ii = np.iinfo(dtype)
+    v = rng.integers(ii.min, ii.max, n, dtype=dtype, endpoint=True)
+    for desc in (False, True):
+        got, info, state, todo = _sort32(gx, v, desc)
+        exp = np.sort(v)[::-1] if desc else np.sort(v)
+        assert got.tobytes() == exp.tobytes(), (dtype, n, desc, info, state)
+        assert state == 3 and info[1] == 1, f"uniform 32-bit keys must be sorted by the cursor path: state {state}, {info}"
+        assert 0 <= todo <= 3
+
+
+@pytest.mark.parametrize("kind", ["duplicates", "narrow", "very_narrow", "sorted", "skewed", "outlier", "multiples"])
+def test_32bit_keys_fallbacks_are_exact(gx, kind):
+    """inputs on which the 32-bit cursor path must take one of its fallbacks (or survive): bit-exact either way, and the
+    device's decision is pinned where it is deterministic"""
+    rng = np.random.default_rng(hash_seed32(kind))
+    n = 36_000_000
+    if kind == "duplicates":  # 200000 distinct values over the whole range, 180 copies each: every cell crowded -> k_local_sort
+        v = rng.integers(-2**31, 2**31 - 1, 200_000, dtype=np.int32)[rng.integers(0, 200_000, n)]
+    elif kind == "narrow":  # 22 varying bits: 9 left below level 1, fewer than the counting pass takes -> k_local_sort for every cell
+        v = rng.integers(0, 1 << 22, n, dtype=np.int32)
+    elif kind == "very_narrow":  # 16 varying bits: nothing for two partition levels to do -> state 4, LSD without an up-front read
+        v = rng.integers(0, 1 << 16, n, dtype=np.int32)
+    elif kind == "sorted":
+        v = np.sort(rng.integers(-2**31, 2**31 - 1, n, dtype=np.int32))
+    elif kind == "skewed":  # 80 % of the keys in one level-0 bin
+        v = rng.integers(-2**31, 2**31 - 1, n, dtype=np.int32)
+        hot = rng.random(n) < 0.8
+        v[hot] = (v[hot] & 0x00FFFFFF) | (37 << 24)
+    elif kind == "outlier":  # one unsampled row above the sampled range: the verdict of level 0 rejects the plan
+        v = rng.integers(0, 1 << 30, n, dtype=np.int32)
+        v[12345] = np.int32(2**31 - 1)
+    else:  # multiples of 2^20: nothing varies below level 1 beyond the cell digit
+        v = (rng.integers(0, 1 << 11, n, dtype=np.int32) << 20).astype(np.int32)
+    got, info, state, todo = _sort32(gx, v)
+    assert got.tobytes() == np.sort(v).tobytes(), (kind, info, state, todo)
+    if kind == "duplicates":
+        assert state == 3 and info[1] == 1 and todo > _cells(info) // 2, (info, state, todo)
+    if kind == "narrow":
+        assert state == 3 and info[1] == 1 and todo == 0, (info, state, todo)
+    if kind == "very_narrow":
+        assert state == 4 and info[1] == 0, (info, state)
+    if kind == "sorted":
+        assert state == 3 and info[1] == 1, (info, state)
+    got, info, state, todo = _sort32(gx, v, True)
+    assert got.tobytes() == np.sort(v)[::-1].tobytes(), (kind, "descending", info, state, todo)
+
+
+def hash_seed32(s):
+    import zlib
+    return zlib.crc32(s.encode()) + 32

@@ -633,7 +633,7 @@ def _ce_list(name):
     import os
     import re
     src = open(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "cudf_amd", "csrc", "gx_common.hpp")).read()
-    body = re.search(r"void " + name + r"\(uint64_t \(&v\)\[16\]\)\s*\{(.*?)\n\}", src, re.S).group(1)
+    body = re.search(r"void " + name + r"\(T \(&v\)\[16\]\)\s*\{(.*?)\n\}", src, re.S).group(1)
     return [(int(a), int(b)) for a, b in re.findall(r"GX_CE\((\d+),\s*(\d+)\)", body)]
 
 
