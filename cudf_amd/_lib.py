@@ -50,6 +50,7 @@ _PROTOS = {
     "gx_sort_cursor_state": (_i, [_p, ctypes.POINTER(ctypes.c_int32), _p]),
     "gx_sort_place_info": (_i, [_p, ctypes.POINTER(ctypes.c_int32), _p]),
     "gx_sort_set_place_grid": (None, [_i]),
+    "gx_sort_set_order_words": (None, [_i]),
     "gx_sort_set_cell": (None, [_i]),
     "gx_sort_set_lookback": (None, [_i]),
     "gx_sort_info": (_i, [_p, ctypes.POINTER(ctypes.c_int32), _p]),

@@ -1661,8 +1661,11 @@ __device__ __forceinline__ void hf_give_up(SortPlan* plan, int state)
 //   1 (after the histogram sample)  slot capacities and positions of level 0
 //   2 (after level 0)  the verdict + everything level 1, k_plan2 and the local sort need
 __global__ void __launch_bounds__(BINS) k_hf_plan(SortPlan* plan, int stage, int key_bits, int64_t n, int bits2, int cell_max, int stride,
-                                                  int64_t range_rows, int tile_rows, unsigned long long slot_rows, float margin, int min_shift2)
+                                                  int64_t range_rows, int tile_rows, unsigned long long slot_rows, float margin, int min_shift2,
+                                                  int bits2_max)
 {
+  // bits2_max: level-1 bits the launches behind are sized for (bits2 or bits2 + 1): stage 2 takes the extra bit when the EXACT
+  // level-0 histogram says the cells would not fit otherwise
   // min_shift2: key bits that must be left below level 1 (8: k_local_sort's sub-bucket split)
   __shared__ uint32_t s_tmp[BINS / GX_WAVE + 1];
   HybridPlan& hy = plan->hy;
@@ -1752,6 +1755,19 @@ __global__ void __launch_bounds__(BINS) k_hf_plan(SortPlan* plan, int stage, int
   }
   hy.hist0[t] = c;
   hy.gbin0[t] = exc;
+  // bits2 came from n alone, i.e. from buckets of n / 256 keys.  Keys whose range is not a power of two (ids below 1e12,
+  // timestamps: the top digit uses 233 of 256 bins) have fuller buckets, and at the upper end of a size class -- 1e9 rows sit at
+  // 93 % of one -- their cells overflow and the column falls back to the LSD passes (3x slower).  The exact histogram is here:
+  // take one more level-1 bit when the fullest bucket needs it (the launches behind are sized for it).
+  {
+    const uint32_t fit = (uint32_t)(0.97 * (double)cell_max);  // mean cell of the fullest bucket; a cell spreads 4.5 sigma = 5 % above it
+    const int more     = __syncthreads_or(((unsigned long long)c >> hy.bits2) > (unsigned long long)fit);
+    if (more && t == 0 && hy.bits2 < bits2_max && hy.shift2 - 1 >= min_shift2) {
+      hy.bits2 += 1;
+      hy.shift2 -= 1;
+    }
+    __syncthreads();
+  }
   uint32_t tiles = 0;
   for (int r = 0; r < NRANGE; ++r) tiles += (cnt[r] + (uint32_t)tile_rows - 1) / (uint32_t)tile_rows;
   uint32_t ttotal;
@@ -2029,6 +2045,7 @@ static HybridCfg hybrid_cfg(int64_t n, bool iota_payload, int algo)
 struct FastCfg {
   bool on;
   int bits2;         // level-1 bits (1..10), 8192-key cells
+  int bits2_max;     // ... or one more, decided on the device from the exact level-0 histogram (k_hf_plan stage 2)
   int stride;        // sample: every stride-th 64-key chunk
   size_t slot_rows;  // keys the padded level-0 output holds
 };
@@ -2038,7 +2055,7 @@ static float g_cursor_margin = 8.0f;  // standard deviations of slack per level-
 template <typename KeyT, int KIND, bool HAS_VAL>
 static FastCfg fast_cfg(int64_t n, int algo, bool hybrid_on)
 {
-  FastCfg f{false, 9, 32, 0};
+  FastCfg f{false, 9, 9, 32, 0};
   // 64-bit keys: wherever the hybrid path applies; 32-bit integer keys (round 3): the same two partition levels, the cells sorted
   // by k_local_place on 32-bit words, the LSD passes as the only fallback
   if ((sizeof(KeyT) != 8 && sizeof(KeyT) != 4) || HAS_VAL || KIND == K_FLOAT || algo != 0 || !g_cursor || n < (1ll << 25)) return f;
@@ -2047,6 +2064,7 @@ static FastCfg fast_cfg(int64_t n, int algo, bool hybrid_on)
   while (B < 18 && (double)n / (double)(1ull << B) > 0.955 * 8192.0) ++B;
   if ((double)n / (double)(1ull << B) > 0.97 * 8192.0) return f;
   f.bits2  = B - 8;
+  f.bits2_max = f.bits2 < 10 ? f.bits2 + 1 : 10;
   f.stride = n >= (1ll << 27) ? 32 : 8;
   // sum of the slot capacities k_hf_plan hands out (Cauchy-Schwarz over the 2048 slots; the kernel checks it again)
   const double m   = g_cursor_margin > 0 ? g_cursor_margin : 0.0;
@@ -2098,7 +2116,7 @@ int sort_impl(const void* keys_in, void* keys_out, const int32_t* vals_in, int32
   // the level-1 pass writes every cell into its own slot of 1 << cl2 keys (no joint histogram pass): the
   // ping-pong scratch holds (256 << bits2) slots when that exceeds n
   size_t padded = try_hybrid ? ((size_t)BINS << hc.bits2) << hc.cl2 : 0;
-  if (fc.on && (((size_t)BINS << fc.bits2) << 13) > padded) padded = ((size_t)BINS << fc.bits2) << 13;
+  if (fc.on && (((size_t)BINS << fc.bits2_max) << 13) > padded) padded = ((size_t)BINS << fc.bits2_max) << 13;
   const size_t nb_buf = padded > (size_t)n ? padded : (size_t)n;
   KeyT* kb_scratch = c.take<KeyT>(nb_buf);
   KeyT* slot0_buf  = fc.on ? c.take<KeyT>(fc.slot_rows) : nullptr;  // cursor path: padded level-0 output
@@ -2138,8 +2156,9 @@ int sort_impl(const void* keys_in, void* keys_out, const int32_t* vals_in, int32
       auto lds_hf = [&](int nb) { return (size_t)FT * sizeof(KeyT) + (size_t)(3 * nb + 16 + 4) * 4 + (size_t)2 * NW * 8; };
       typedef void (*HfK)(const KeyT*, KeyT*, KeyT, SortPlan*, uint32_t*, uint32_t, int64_t);
       HfK kf0 = k_hf_scatter<KeyT, KIND, 0, 8>;
-      HfK kf1 = fc.bits2 <= 8 ? (HfK)k_hf_scatter<KeyT, KIND, 1, 8> : (fc.bits2 == 9 ? (HfK)k_hf_scatter<KeyT, KIND, 1, 9> : (HfK)k_hf_scatter<KeyT, KIND, 1, 10>);
-      const int nbf = fc.bits2 <= 8 ? 256 : (1 << fc.bits2);
+      // (the level-1 kernel and the cell grids are sized for bits2_max: the device may take the extra bit)
+      HfK kf1 = fc.bits2_max <= 8 ? (HfK)k_hf_scatter<KeyT, KIND, 1, 8> : (fc.bits2_max == 9 ? (HfK)k_hf_scatter<KeyT, KIND, 1, 9> : (HfK)k_hf_scatter<KeyT, KIND, 1, 10>);
+      const int nbf = fc.bits2_max <= 8 ? 256 : (1 << fc.bits2_max);
       static bool fattr_set = false;
       if (!fattr_set) {
         GX_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(k_hf_scatter<KeyT, KIND, 0, 8>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_hf(256)));
@@ -2159,25 +2178,26 @@ int sort_impl(const void* keys_in, void* keys_out, const int32_t* vals_in, int32
       KeyT* bufA      = keys_out ? static_cast<KeyT*>(keys_out) : ka_scratch;
       hipLaunchKernelGGL((k_hf_sample<KeyT, KIND, false>), dim3((unsigned)sblocks), dim3(256), 0, stream, kin, n, desc_mask, plan, fc.stride, frange);
       hipLaunchKernelGGL(k_hf_plan, dim3(1), dim3(BINS), 0, stream, plan, 0, (int)(8 * sizeof(KeyT)), n, fc.bits2, 1 << 13, fc.stride, frange, FT,
-                         (unsigned long long)fc.slot_rows, g_cursor_margin, MIN_SHIFT2);
+                         (unsigned long long)fc.slot_rows, g_cursor_margin, MIN_SHIFT2, fc.bits2_max);
       hipLaunchKernelGGL((k_hf_sample<KeyT, KIND, true>), dim3((unsigned)sblocks), dim3(256), 0, stream, kin, n, desc_mask, plan, fc.stride, frange);
       hipLaunchKernelGGL(k_hf_plan, dim3(1), dim3(BINS), 0, stream, plan, 1, (int)(8 * sizeof(KeyT)), n, fc.bits2, 1 << 13, fc.stride, frange, FT,
-                         (unsigned long long)fc.slot_rows, g_cursor_margin, MIN_SHIFT2);
+                         (unsigned long long)fc.slot_rows, g_cursor_margin, MIN_SHIFT2, fc.bits2_max);
       prof_mark(1, stream);
       prof_mark_h(0, stream);
       hipLaunchKernelGGL(kf0, dim3((unsigned)ftiles), dim3(BT), lds_hf(256), stream, kin, slot0_buf, desc_mask, plan, hist2, 1u << 13, n);
       hipLaunchKernelGGL(k_hf_plan, dim3(1), dim3(BINS), 0, stream, plan, 2, (int)(8 * sizeof(KeyT)), n, fc.bits2, 1 << 13, fc.stride, frange, FT,
-                         (unsigned long long)fc.slot_rows, g_cursor_margin, MIN_SHIFT2);
+                         (unsigned long long)fc.slot_rows, g_cursor_margin, MIN_SHIFT2, fc.bits2_max);
       prof_mark_h(1, stream);
       hipLaunchKernelGGL(kf1, dim3((unsigned)(ftiles + NRANGE * BINS)), dim3(BT), lds_hf(nbf), stream, slot0_buf, kb_scratch, desc_mask, plan, hist2, 1u << 13, n);
       prof_mark_h(2, stream);
       hipLaunchKernelGGL(k_plan2, dim3(BINS), dim3(GX_WAVE), 0, stream, plan, hist2, base2, NPASS, 1);
       prof_mark_h(3, stream);
+      // (one workgroup per cell of the plan n suggests; when the device took the extra level-1 bit each of them walks two cells)
       hipLaunchKernelGGL((k_local_place<KeyT, KIND, HAS_VAL, 13>), dim3(local_place_grid(BINS << fc.bits2)), dim3((1 << 13) / 16),
                          place_lds_bytes(13, WORD_BYTES), stream, kb_scratch, bufA, (const uint32_t*)nullptr, (uint32_t*)nullptr, desc_mask, plan, hist2,
                          base2, todo, g_exp, 1);
       // the cells k_local_place left: 64-bit words (32-bit keys are widened to their sortable form on the way in)
-      hipLaunchKernelGGL((k_local_sort<uint64_t, KIND, HAS_VAL, 13, KeyT>), dim3(local_sort_grid(BINS << fc.bits2)), dim3((1 << 13) / 16),
+      hipLaunchKernelGGL((k_local_sort<uint64_t, KIND, HAS_VAL, 13, KeyT>), dim3(local_sort_grid(BINS << fc.bits2_max)), dim3((1 << 13) / 16),
                          ((size_t)8 << 13) + (size_t)(((1 << 13) / 16 / GX_WAVE) * BINS + 32 + 2 * BINS) * 4, stream, (const KeyT*)kb_scratch, bufA,
                          (const uint32_t*)nullptr, (uint32_t*)nullptr, (uint64_t)desc_mask, plan, hist2, base2, g_exp, 1, (const uint32_t*)todo);
       prof_mark_h(4, stream);
@@ -2447,6 +2467,65 @@ int sorted_order_nullable(int dtype, const void* keys, const uint32_t* valid, in
                         descending, false, sort_tmp, &sb, stream);
 }
 
+// ---- sorted_order of a 32-bit integer column as a KEYS-ONLY sort of 64-bit words (round 3) ------------------------------
+// (sortable key << rbits) | row, rbits = the bits of n - 1, is a distinct 64-bit word whose unsigned order is the stable order
+// of the pairs, so the cursor path of the 64-bit keys-only sort -- unstable, no look-back, k_local_place -- produces
+// cudf::sorted_order / stable_sorted_order (sorted_order_radix.cu:83-94) of an int32 / uint32 column: pack (12 B/row), sort
+// (48 B/row), unpack (12 B/row) instead of four stable LSD pair passes of 16 B/row each.  n >= 2^25, no nulls, the row payload
+// implicit.  The row sits directly below the key (no constant bits in between), so whatever digit window the sort's levels
+// and k_local_place's counting passes take, every bit in it varies: keys of a narrow range (dictionary codes, group ids) are
+// split further by the top bits of the row.
+template <typename K32, int KIND>
+__global__ void __launch_bounds__(256) k_pack_words(const K32* __restrict__ keys, int64_t n, K32 desc_mask, int rbits, uint64_t* __restrict__ words)
+{
+  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride)
+    words[i] = ((uint64_t)to_sortable<K32, KIND>(keys[i], desc_mask) << rbits) | (uint64_t)i;
+}
+__global__ void __launch_bounds__(256) k_unpack_rows(const uint64_t* __restrict__ words, int64_t n, int rbits, int32_t* __restrict__ rows)
+{
+  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  const uint64_t rmask = (1ull << rbits) - 1ull;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) rows[i] = (int32_t)(uint32_t)(words[i] & rmask);
+}
+// OFF by default (gx_sort_set_order_words): 1e9 well-spread int32 keys 22.2 -> 17.0 ms, but the sort's cells are cut by KEY bits
+// alone until its two levels are through, so keys with ~1000 rows each (1e6 distinct: group ids) overflow their cells and the
+// column falls back to eight LSD passes over the 64-bit words: 16-21 -> 55-59 ms (profiles/r3_run31_sorted_order_int32_words.txt).
+static int g_order_words = 0;
+static inline bool order_words32_applies(int dtype, int64_t n)
+{
+  return g_order_words && (dtype == GX_INT32 || dtype == GX_UINT32) && n >= (1ll << 25) && g_algorithm == 0 && g_hybrid && g_cursor;
+}
+template <typename K32, int KIND>
+int sorted_order_words32(const void* keys, int64_t n, int descending, int32_t* out, void* tmp, size_t* tmp_bytes, hipStream_t stream)
+{
+  size_t sort_bytes = 0;
+  int rc = sort_impl<uint64_t, K_UNSIGNED, false>(nullptr, nullptr, nullptr, nullptr, n, 0, false, nullptr, &sort_bytes, stream);
+  if (rc) return rc;
+  Carver c(tmp);
+  char* sort_tmp  = c.take<char>(sort_bytes);  // first: the plan header callers inspect (gx_sort_status / gx_sort_info) sits at tmp
+  uint64_t* w_in  = c.take<uint64_t>((size_t)n);
+  uint64_t* w_out = c.take<uint64_t>((size_t)n);
+  if (tmp == nullptr) {
+    *tmp_bytes = c.total();
+    return 0;
+  }
+  if (*tmp_bytes < c.total()) return GX_ETMP;
+  if (keys == nullptr || out == nullptr) return GX_EINVAL;
+  int64_t blocks = div_up(n, 256 * 8);
+  if (blocks > 8192) blocks = 8192;
+  int rbits = 1;
+  while (((int64_t)1 << rbits) < n) ++rbits;  // rows 0 .. n - 1 fit rbits <= 31 bits
+  hipLaunchKernelGGL((k_pack_words<K32, KIND>), dim3((unsigned)blocks), dim3(256), 0, stream, static_cast<const K32*>(keys), n,
+                     descending ? K32(~K32(0)) : K32(0), rbits, w_in);
+  size_t sb = sort_bytes;
+  rc = sort_impl<uint64_t, K_UNSIGNED, false>(w_in, w_out, nullptr, nullptr, n, 0, false, sort_tmp, &sb, stream);
+  if (rc) return rc;
+  hipLaunchKernelGGL(k_unpack_rows, dim3((unsigned)blocks), dim3(256), 0, stream, w_out, n, rbits, out);
+  GX_LAUNCH_CHECK();
+  return 0;
+}
+
 }  // namespace sort
 }  // namespace gx
 
@@ -2473,6 +2552,10 @@ int gx_sorted_order(int dtype, const void* keys, const uint32_t* valid, int64_t 
 {
   if (n < 0 || null_count < 0 || null_count > n || tmp_bytes == nullptr) return GX_EINVAL;
   if (valid == nullptr || null_count == 0) {
+    if (gx::sort::order_words32_applies(dtype, n)) {
+      return dtype == GX_INT32 ? gx::sort::sorted_order_words32<uint32_t, gx::K_SIGNED>(keys, n, descending, out_indices, tmp, tmp_bytes, stream)
+                               : gx::sort::sorted_order_words32<uint32_t, gx::K_UNSIGNED>(keys, n, descending, out_indices, tmp, tmp_bytes, stream);
+    }
     return gx::sort::dispatch<true>(dtype, keys, nullptr, nullptr, out_indices, n, descending, true, tmp,
                                     tmp_bytes, stream);
   }
@@ -2531,6 +2614,8 @@ void gx_sort_set_hybrid(int enable) { gx::sort::g_hybrid = enable ? 1 : 0; }
 void gx_sort_set_experiment(int bits) { gx::sort::g_exp = bits & 0x3C; }
 
 void gx_sort_set_place_grid(int workgroups) { gx::sort::g_place_grid = workgroups > 0 ? workgroups : 0; }
+
+void gx_sort_set_order_words(int enable) { gx::sort::g_order_words = enable ? 1 : 0; }
 
 void gx_sort_set_cursor_path(int enable, float margin_sigmas)
 {

@@ -48,6 +48,10 @@ void gx_sort_set_experiment(int bits);
 /* A/B knob (process-wide): workgroups of k_local_place.  0 (default) = one per cell; otherwise that many workgroups walk the
  * cells with a stride (persistent form). */
 void gx_sort_set_place_grid(int workgroups);
+/* EXPERIMENT (process-wide, default 0): gx_sorted_order of an int32 / uint32 column without nulls, n >= 2^25, as a keys-only sort
+ * of the 64-bit words (sortable key << bits(n - 1)) | row on the cursor path (pack, sort, unpack).  Faster for well-spread keys
+ * (1e9 rows: 22.2 -> 17.0 ms), much slower for keys with ~1000 rows each (cells overflow: 55-59 ms); see gx_sort.hip. */
+void gx_sort_set_order_words(int enable);
 /* Cells of the last hybrid sort that used `tmp` which k_local_place found crowded (a bin of the 13-bit counting pass with
  * more than 9 keys: duplicates, clusters) and left to k_local_sort; 0 when every cell was placed, or when k_local_place
  * did not apply (16384-key cells, float keys, fewer than 13 key bits left, knob).  Synchronises `stream`. */

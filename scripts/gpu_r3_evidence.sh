@@ -29,6 +29,11 @@ if [ "${2:-}" = "pmc" ]; then
   python scripts/pmc_to_json.py $O $O/r3_pmc_traffic_1e9.json "rocprofv3 --kernel-trace --pmc FETCH_SIZE and --pmc WRITE_SIZE passes (separate runs) of python bench.py --workload <w> --rows 1e9 --steps 1 --warmup 0 (scripts/gpu_r3_evidence.sh $R pmc)" | tee $O/r3_run${R}_pmc_traffic.txt
   find $O/pmc_* -name "*.csv" -size +1M -delete
 fi
+if [ "${3:-}" = "tests" ]; then
+  timeout 400 python -m pytest tests/test_gpu_cpp_parity.py tests/test_gpu_sort_place.py -m gpu -q -x -k "not 130000000 and not capacity and not float64" > $O/r3_run${R}_pytest.log 2>&1
+  echo "pytest exit $?" | tee -a $L
+  tail -4 $O/r3_run${R}_pytest.log | tee -a $L
+fi
 python - <<PY | tee -a $L
 import json
 for f in ('$O/r3_run${R}_bench_default.jsonl', '$O/r3_run${R}_bench_sorted_order.jsonl'):

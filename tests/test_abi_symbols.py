@@ -134,8 +134,10 @@ def test_scratch_queries_and_argument_checks_without_a_gpu():
     # the 1e9-row keys-only sort (no output buffer given): two key buffers worth of scratch, one of them padded to
     # 2^17 cell slots of 8192 keys (8.6 GB: what lets the level-1 pass run without a joint histogram), 512
     # eight-byte look-back granules per 8192-key tile (0.5 GB), and since round 3 the padded level-0 output of the
-    # cursor path (n + 8 % of slack for its 2048 sampled slots: 8.7 GB) -- not more
-    assert 24.5e9 < queries["gx_sort_keys"](10**9)[1] < 26.5e9
+    # cursor path (n + 8 % of slack for its 2048 sampled slots: 8.7 GB); the cell slots are sized for one level-1 bit more than
+    # n / 256 keys per bucket need (2^18 slots: + 8.6 GB), which the device takes when the exact histogram shows fuller buckets
+    # (key ranges that are not a power of two) -- not more
+    assert 33.0e9 < queries["gx_sort_keys"](10**9)[1] < 35.5e9
     assert q("gx_sort_keys", 99, None, None, 10, 0)[0] == -2                 # GX_EDTYPE
     assert q("gx_sort_keys", L.INT64, None, None, -1, 0)[0] == -1            # GX_EINVAL
     assert q("gx_sort_keys", L.INT64, None, None, 2**31, 0)[0] == -1         # more than size_type rows

@@ -24,6 +24,7 @@ def gx():
     from cudf_amd import Column, ops, _lib as L
     yield Column, ops, L
     L.lib.gx_sort_set_experiment(0)
+    L.lib.gx_sort_set_order_words(0)
 
 
 def _sort(gx, v, descending=False):
@@ -224,3 +225,55 @@ def test_32bit_keys_fallbacks_are_exact(gx, kind):
 def hash_seed32(s):
     import zlib
     return zlib.crc32(s.encode()) + 32
+
+
+@pytest.mark.parametrize("dtype", ["int32", "uint32"])
+@pytest.mark.parametrize("kind", ["wide", "ties", "few"])
+def test_sorted_order_of_32bit_keys_as_a_word_sort(gx, dtype, kind):
+    """n >= 2^25, no nulls: (sortable key << 32) | row goes through the unstable 64-bit keys-only sort -- the word order IS the
+    stable order of the pairs; checked against the oracle's stable order in both directions"""
+    Column, ops, L = gx
+    L.lib.gx_sort_set_order_words(1)  # an experiment, off by default (gx_knobs.h)
+    rng = np.random.default_rng(hash_seed32(kind + dtype))
+    n = 34_000_000
+    ii = np.iinfo(dtype)
+    if kind == "wide":
+        v = rng.integers(ii.min, ii.max, n, dtype=dtype, endpoint=True)
+    elif kind == "ties":  # ~35 rows per key
+        v = rng.integers(ii.min, ii.max, 1_000_000, dtype=dtype, endpoint=True)[rng.integers(0, 1_000_000, n)]
+    else:  # 1000 distinct keys in a narrow range: long runs of equal keys inside every cell
+        v = rng.integers(100, 1100, n).astype(dtype)
+    try:
+        for desc in (False, True):
+            got = _order(gx, v, desc)
+            np.testing.assert_array_equal(got, orc.sorted_order(v, None, not desc), err_msg=f"{dtype} {kind} desc={desc}")
+    finally:
+        L.lib.gx_sort_set_order_words(0)
+
+
+def _order_info(gx, v, descending=False):
+    """gx_sorted_order through the C ABI -> (permutation, info8, cells left to k_local_sort)"""
+    Column, ops, L = gx
+    col = Column.from_numpy(v)
+    out = Column.empty(np.int32, v.size)
+    tmp = ops._run(L.lib.gx_sorted_order, col.gx, col.data_ptr, None, col.size, 0, int(descending), 1, out.data_ptr)
+    ops._check_sort_status(tmp)
+    info = (ctypes.c_int32 * 8)()
+    L.check(L.lib.gx_sort_info(ops.ptr(tmp), info, ops.stream_ptr()), "gx_sort_info")
+    todo = ctypes.c_int32(-1)
+    L.check(L.lib.gx_sort_place_info(ops.ptr(tmp), ctypes.byref(todo), ops.stream_ptr()), "gx_sort_place_info")
+    return out.to_numpy(), list(info), todo.value
+
+
+@pytest.mark.parametrize("dtype", ["int64", "int32"])
+def test_fuller_buckets_take_one_more_level1_bit(gx, dtype):
+    """n at 95 % of a size class and keys in a range that is not a power of two (the top digit uses 160 of 256 bins): buckets are
+    1.6x fuller than n / 256, the cells would overflow -- the device sees it in the exact level-0 histogram and takes one more
+    level-1 bit instead of handing the column to the LSD passes"""
+    rng = np.random.default_rng(21)
+    n = int(0.95 * 8192 * (1 << 13))  # cursor path, 5 level-1 bits from n alone
+    hi = int(0.625 * 2**40) if dtype == "int64" else int(0.625 * 2**31)
+    v = rng.integers(0, hi, n, dtype=dtype)
+    got, info, todo = _sort(gx, v)
+    assert got.tobytes() == np.sort(v).tobytes()
+    assert info[1] == 1 and info[4] == 6 and 0 < info[6] <= 8192, f"expected the hybrid path with 6 level-1 bits: {info}"
