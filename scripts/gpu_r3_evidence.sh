@@ -30,7 +30,7 @@ if [ "${2:-}" = "pmc" ]; then
   find $O/pmc_* -name "*.csv" -size +1M -delete
 fi
 if [ "${3:-}" = "tests" ]; then
-  timeout 400 python -m pytest tests/test_gpu_cpp_parity.py tests/test_gpu_sort_place.py -m gpu -q -x -k "not 130000000 and not capacity and not float64" > $O/r3_run${R}_pytest.log 2>&1
+  timeout 400 python -m pytest tests/test_gpu_cpp_parity.py tests/test_gpu_sort_place.py -m gpu -q -x -k "not 70000000 and not capacity and not float64" > $O/r3_run${R}_pytest.log 2>&1
   echo "pytest exit $?" | tee -a $L
   tail -4 $O/r3_run${R}_pytest.log | tee -a $L
 fi

@@ -172,7 +172,7 @@ def _sort32(gx, v, descending=False):
 
 
 @pytest.mark.parametrize("dtype", ["int32", "uint32"])
-@pytest.mark.parametrize("n", [40_000_000, 130_000_000])
+@pytest.mark.parametrize("n", [40_000_000, 70_000_000])
 def test_32bit_keys_uniform_take_the_cursor_path(gx, dtype, n):
     rng = np.random.default_rng(n % 1013)
     ii = np.iinfo(dtype)
