@@ -687,3 +687,28 @@ def test_register_networks_of_the_placement_sort():
     y = x.copy(); y[::3] |= np.uint32(10) << (8 * rng.integers(0, 4, len(y[::3]), dtype=np.uint32))
     ge10 = ((((y & 0x7F7F7F7F) + 0x76767676) | y) & 0x80808080) != 0
     np.testing.assert_array_equal(ge10, ((y[:, None] >> (8 * np.arange(4, dtype=np.uint32))) & 0xFF).max(axis=1) >= 10)
+
+
+def test_pmc_kernel_names_and_groups():
+    """scripts/pmc_to_json.py: rocprofv3 kernel names -> the base names bench.py's `traffic_key`s refer to"""
+    import importlib.util
+    import os
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    spec = importlib.util.spec_from_file_location("pmc_to_json", os.path.join(root, "scripts", "pmc_to_json.py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    bn = mod.base_name
+    assert bn("void gx::sort::k_hf_scatter<unsigned long, 1, 0, 8>(unsigned long const*, unsigned long*)") == "k_hf_scatter level 0"
+    assert bn("void gx::sort::k_hf_scatter<unsigned long, 1, 1, 10>(unsigned long const*)") == "k_hf_scatter level 1"
+    assert bn("void gx::sort::k_local_place<unsigned long, 1, false, 13>(unsigned long const*)") == "k_local_place"
+    assert bn("void gx::sort::k_msd_pass<unsigned long, 1, true, 10, 4, 9>(gx::sort::MsdArgs)") == "k_msd_pass level 1"
+    assert bn("void gx::sort::k_msd_pass<unsigned long, 1, true, 10, 4, 8>(gx::sort::MsdArgs)") == "k_msd_pass level 0"
+    assert bn("gx::join::k_pj2_offsets(gx::join::Pj2Plan*, int, unsigned int, unsigned int)") == "k_pj2_offsets"
+    assert bn("void at::native::vectorized_elementwise_kernel<4>(int)") is None
+    # every traffic key bench.py uses resolves in the committed round-3 file
+    import json
+    tr = json.load(open(os.path.join(root, "profiles", "r3_pmc_traffic_1e9.json")))
+    for key in ("k_hf_scatter level 0", "k_hf_scatter level 1", "sort local stage", "join probe phase", "groupby"):
+        e = tr["groups"].get(key) or tr["kernels"].get(key)
+        assert e and e["hbm_bytes_per_launch"] > 1e9, key
+    assert 48e9 < tr["groups"]["sort"]["hbm_bytes_per_launch"] < 51e9
