@@ -227,8 +227,7 @@ def hash_seed32(s):
     return zlib.crc32(s.encode()) + 32
 
 
-@pytest.mark.parametrize("dtype", ["int32", "uint32"])
-@pytest.mark.parametrize("kind", ["wide", "ties", "few"])
+@pytest.mark.parametrize("dtype,kind", [("int32", "wide"), ("uint32", "ties"), ("int32", "few")])
 def test_sorted_order_of_32bit_keys_as_a_word_sort(gx, dtype, kind):
     """n >= 2^25, no nulls: (sortable key << 32) | row goes through the unstable 64-bit keys-only sort -- the word order IS the
     stable order of the pairs; checked against the oracle's stable order in both directions"""
