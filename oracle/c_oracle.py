@@ -26,6 +26,7 @@ def lib():
         L.orc_murmur3_u64_array.argtypes = [p, i64, ctypes.c_uint32, p]
         L.orc_sort_i64.argtypes = [p, p, p, i64, ctypes.c_int]
         L.orc_sorted_order_i64.argtypes = [p, p, i64, ctypes.c_int]
+        L.orc_sort_32.argtypes = [p, p, p, i64, ctypes.c_int, ctypes.c_int]
         L.orc_inner_join_i64.argtypes = [p, i64, p, i64, p, p, i64]
         L.orc_inner_join_i64.restype = i64
         L.orc_groupby_dense_sum_count.argtypes = [p, p, i64, ctypes.c_int32, p, p]
@@ -53,6 +54,16 @@ def sort_i64(values, descending=False):
     out = np.empty_like(v)
     tmp = np.empty_like(v)
     lib().orc_sort_i64(_ptr(v), _ptr(out), _ptr(tmp), len(v), int(descending))
+    return out
+
+
+def sort_32(values, descending=False):
+    """int32 / uint32 keys (the dtype decides the sign flip)"""
+    v = np.ascontiguousarray(values)
+    assert v.dtype in (np.int32, np.uint32)
+    out = np.empty_like(v)
+    tmp = np.empty_like(v)
+    lib().orc_sort_32(_ptr(v), _ptr(out), _ptr(tmp), len(v), int(v.dtype == np.int32), int(descending))
     return out
 
 

@@ -77,6 +77,31 @@ void orc_sort_i64(const int64_t* in, int64_t* out, int64_t* tmp, int64_t n, int 
   }
 }
 
+/* 32-bit integer keys: the same contract on four digit passes (cub::DeviceRadixSort::SortKeys over begin_bit = 0,
+ * end_bit = 32 as cudf::sort calls it for an INT32 / UINT32 column: cpp/src/sort/sort_radix.cu:66-78; the reference's own
+ * sort benchmark is typed on int32, cpp/benchmarks/sort/sort.cpp:51).  is_signed = 0: UINT32 (no sign flip). */
+static inline uint32_t flip_32(uint32_t v, int is_signed, int descending)
+{
+  uint32_t u = is_signed ? (v ^ 0x80000000u) : v;
+  return descending ? ~u : u;
+}
+void orc_sort_32(const uint32_t* in, uint32_t* out, uint32_t* tmp, int64_t n, int is_signed, int descending)
+{
+  const uint32_t* src = in;
+  uint32_t* bufs[2] = {tmp, out}; /* 4 passes: in->tmp->out->tmp->out */
+  for (int pass = 0; pass < 4; ++pass) {
+    uint32_t* dst = bufs[pass & 1];
+    int64_t hist[256];
+    memset(hist, 0, sizeof(hist));
+    const int shift = pass * 8;
+    for (int64_t i = 0; i < n; ++i) hist[(flip_32(src[i], is_signed, descending) >> shift) & 0xff]++;
+    int64_t sum = 0;
+    for (int b = 0; b < 256; ++b) { int64_t c = hist[b]; hist[b] = sum; sum += c; }
+    for (int64_t i = 0; i < n; ++i) dst[hist[(flip_32(src[i], is_signed, descending) >> shift) & 0xff]++] = src[i];
+    src = dst;
+  }
+}
+
 /* stable argsort (sorted_order): keys int64, out_idx int32; scratch: 2*n uint64 + n int32 */
 void orc_sorted_order_i64(const int64_t* in, int32_t* out_idx, int64_t n, int descending)
 {

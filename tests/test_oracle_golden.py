@@ -156,6 +156,13 @@ def test_c_oracle_matches_numpy_oracle():
     for desc in (False, True):
         assert c_oracle.sort_i64(v, desc).tobytes() == orc.sort_keys(v, not desc).tobytes()
         np.testing.assert_array_equal(c_oracle.sorted_order_i64(v, desc), orc.sorted_order(v, None, not desc))
+    for dt in (np.int32, np.uint32):  # the 32-bit keys of the cursor path's parity tests (tests/test_gpu_sort_place.py)
+        ii = np.iinfo(dt)
+        v32 = rng.integers(ii.min, ii.max, 100_003, dtype=dt, endpoint=True)
+        v32[::5] = v32[2]
+        v32[:4] = [ii.min, ii.max, 0, ii.max]
+        for desc in (False, True):
+            assert c_oracle.sort_32(v32, desc).tobytes() == orc.sort_keys(v32, not desc).tobytes()
     build = rng.permutation(20_000).astype(np.int64)[:5000] * 3
     probe = rng.integers(0, 60_000, 40_000).astype(np.int64)
     probe[:100] = build[:100]
