@@ -19,8 +19,11 @@
 
 #include <algorithm>
 #include <chrono>
+#include <condition_variable>
 #include <cstring>
 #include <functional>
+#include <memory>
+#include <mutex>
 #include <string>
 #include <vector>
 
@@ -76,7 +79,7 @@ struct Trace {
 // grow-only device buffers, one per purpose, reused from call to call
 struct Arena {
   enum Slot { PART_KEYS, PART_ROWS, RECV_KEYS, RECV_ROWS, TMP, TMP2, OFFS, ALLOFFS, SAMPLE, ALLSAMPLE, PAIR_L, PAIR_R, CURSOR, MISC_A,
-              MISC_B, MISC_C, MISC_D, MISC_E, MISC_F, SEGTAB, EXACT_KEYS, EXACT_ROWS, TMP3, CNT, NSLOTS };
+              MISC_B, MISC_C, MISC_D, MISC_E, MISC_F, SEGTAB, EXACT_KEYS, EXACT_ROWS, EXACT_OFFS, TMP3, CNT, NSLOTS };
   void* p[NSLOTS]      = {};
   size_t cap[NSLOTS]   = {};
   // at least `bytes`; the contents are NOT kept
@@ -117,10 +120,219 @@ struct Arena {
   }
 };
 
+
+// ---------------------------------------------------------------------------------------------------------------- transport
+// The two collectives the sharded operators need ("ncclAllGather of the count matrix, then all-to-all as grouped
+// ncclSend / ncclRecv pairs"), behind a seam so that the SAME operator code runs over
+//   * RCCL (one process per GPU, xGMI) -- the product transport, and
+//   * an in-process loopback fabric: W logical ranks = W communicators on ONE device, each driven by its own host thread,
+//     device-to-device copies standing in for the links (SURVEY.md 8e's prescription when only one GPU can be reached;
+//     tests/test_gpu_distributed_loopback.py).  Every r != rank branch, send offset and receive position of the operators
+//     executes under it exactly as it would over RCCL.
+// Semantics both keep: calls are stream-ordered on the stream passed in; a send buffer may be reused once the work behind the
+// call has completed on that stream; sends and receives between one pair of ranks match in posting order and must agree in size.
+struct Transport {
+  virtual ~Transport() = default;
+  virtual int allgather(const void* mine_dev, void* all_dev, size_t bytes_per_rank, hipStream_t s) = 0;
+  virtual int group_start()                                                                      = 0;
+  virtual int send(const void* p, size_t bytes, int peer, hipStream_t s)                          = 0;
+  virtual int recv(void* p, size_t bytes, int peer, hipStream_t s)                                = 0;
+  virtual int group_end(hipStream_t s)                                                            = 0;
+};
+
+struct RcclTransport final : Transport {
+  ncclComm_t comm = nullptr;
+  ~RcclTransport() override
+  {
+    if (comm) (void)ncclCommDestroy(comm);
+  }
+  int allgather(const void* mine, void* all, size_t bytes, hipStream_t s) override
+  {
+    GXD_NCCL(ncclAllGather(mine, all, bytes, ncclInt8, comm, s));
+    return 0;
+  }
+  int group_start() override
+  {
+    GXD_NCCL(ncclGroupStart());
+    return 0;
+  }
+  int send(const void* p, size_t bytes, int peer, hipStream_t s) override
+  {
+    GXD_NCCL(ncclSend(p, bytes, ncclInt8, peer, comm, s));
+    return 0;
+  }
+  int recv(void* p, size_t bytes, int peer, hipStream_t s) override
+  {
+    GXD_NCCL(ncclRecv(p, bytes, ncclInt8, peer, comm, s));
+    return 0;
+  }
+  int group_end(hipStream_t) override
+  {
+    GXD_NCCL(ncclGroupEnd());
+    return 0;
+  }
+};
+
+// What the W loopback ranks share.  A collective is three host barriers: (1) every rank has published its source pointers and
+// recorded `ready` on its stream -> peers make their streams wait for it and enqueue their copies, then record `done`;
+// (2) every `done` is recorded -> a rank's stream waits for all of them (its send buffers are free again, as after an RCCL
+// call); (3) every rank has issued those waits -> the events may be re-recorded by the next collective.  An event is always
+// recorded (host side) before anyone waits for it, so the work enqueued at any moment depends only on work enqueued earlier:
+// no cycle can form, whatever hardware queues the 2 W streams share.
+struct Fabric {
+  struct Msg {
+    const void* p;
+    size_t bytes;
+    int peer;
+  };
+  int W;
+  std::mutex m;
+  std::condition_variable cv;
+  int arrived       = 0;
+  unsigned long gen = 0;
+  bool broken       = false;  // a rank failed or timed out: every later barrier fails at once instead of hanging the others
+  std::vector<const void*> ag_src;
+  std::vector<std::vector<Msg>> sends;
+  std::vector<hipEvent_t> ready, done;
+  explicit Fabric(int w) : W(w), ag_src(w, nullptr), sends(w), ready(w, nullptr), done(w, nullptr) {}
+  ~Fabric()
+  {
+    for (auto e : ready)
+      if (e) (void)hipEventDestroy(e);
+    for (auto e : done)
+      if (e) (void)hipEventDestroy(e);
+  }
+  int init()
+  {
+    for (int r = 0; r < W; ++r) {
+      GXD_HIP(hipEventCreateWithFlags(&ready[r], hipEventDisableTiming));
+      GXD_HIP(hipEventCreateWithFlags(&done[r], hipEventDisableTiming));
+    }
+    return 0;
+  }
+  void abandon()
+  {
+    std::lock_guard<std::mutex> g(m);
+    broken = true;
+    cv.notify_all();
+  }
+  int barrier()
+  {
+    std::unique_lock<std::mutex> g(m);
+    if (broken) return fail(GX_EINTERNAL, "gxd loopback: a peer rank failed");
+    const unsigned long my = gen;
+    if (++arrived == W) {
+      arrived = 0;
+      ++gen;
+      cv.notify_all();
+      return 0;
+    }
+    const bool ok = cv.wait_for(g, std::chrono::seconds(120), [&] { return gen != my || broken; });
+    if (!ok || broken) {
+      broken = true;
+      cv.notify_all();
+      return fail(GX_EINTERNAL, ok ? "gxd loopback: a peer rank failed" : "gxd loopback: barrier timed out (a rank did not join the collective)");
+    }
+    return 0;
+  }
+};
+
+struct LoopbackTransport final : Transport {
+  std::shared_ptr<Fabric> f;
+  int rank = 0;
+  bool grouping = false;
+  std::vector<Fabric::Msg> my_recvs;
+  struct Bail {  // leaving a collective early (an error) must not leave the peers waiting at the barrier
+    Fabric* f;
+    bool armed = true;
+    ~Bail()
+    {
+      if (armed) f->abandon();
+    }
+  };
+  // after the copies of a collective are enqueued on `s`: done/wait/barrier tail shared by both collectives
+  int finish(hipStream_t s)
+  {
+    GXD_HIP(hipEventRecord(f->done[rank], s));
+    GXD_GX(f->barrier());
+    for (int r = 0; r < f->W; ++r)
+      if (r != rank) GXD_HIP(hipStreamWaitEvent(s, f->done[r], 0));
+    GXD_GX(f->barrier());
+    return 0;
+  }
+  int allgather(const void* mine, void* all, size_t bytes, hipStream_t s) override
+  {
+    Bail bail{f.get()};
+    f->ag_src[rank] = mine;
+    GXD_HIP(hipEventRecord(f->ready[rank], s));
+    GXD_GX(f->barrier());
+    for (int r = 0; r < f->W; ++r) {
+      if (r != rank) GXD_HIP(hipStreamWaitEvent(s, f->ready[r], 0));
+      if (bytes) GXD_HIP(hipMemcpyAsync(static_cast<char*>(all) + (size_t)r * bytes, f->ag_src[r], bytes, hipMemcpyDeviceToDevice, s));
+    }
+    GXD_GX(finish(s));
+    bail.armed = false;
+    return 0;
+  }
+  int group_start() override
+  {
+    grouping = true;
+    f->sends[rank].clear();
+    my_recvs.clear();
+    return 0;
+  }
+  int send(const void* p, size_t bytes, int peer, hipStream_t) override
+  {
+    if (!grouping || peer < 0 || peer >= f->W || peer == rank) return fail(GX_EINVAL, "gxd loopback: send outside a group / bad peer");
+    f->sends[rank].push_back({p, bytes, peer});
+    return 0;
+  }
+  int recv(void* p, size_t bytes, int peer, hipStream_t) override
+  {
+    if (!grouping || peer < 0 || peer >= f->W || peer == rank) return fail(GX_EINVAL, "gxd loopback: recv outside a group / bad peer");
+    my_recvs.push_back({p, bytes, peer});
+    return 0;
+  }
+  int group_end(hipStream_t s) override
+  {
+    Bail bail{f.get()};
+    grouping = false;
+    GXD_HIP(hipEventRecord(f->ready[rank], s));
+    GXD_GX(f->barrier());
+    std::vector<size_t> next(f->W, 0);  // per peer: its next unmatched send to me (posting order, as RCCL matches them)
+    std::vector<char> waited(f->W, 0);
+    for (const auto& rv : my_recvs) {
+      const auto& ps = f->sends[rv.peer];
+      size_t& i      = next[rv.peer];
+      while (i < ps.size() && ps[i].peer != rank) ++i;
+      if (i == ps.size()) return fail(GX_EINTERNAL, "gxd loopback: a receive has no matching send (rank " + std::to_string(rv.peer) + " -> " + std::to_string(rank) + ")");
+      if (ps[i].bytes != rv.bytes)
+        return fail(GX_EINTERNAL, "gxd loopback: send / receive sizes differ (rank " + std::to_string(rv.peer) + " -> " + std::to_string(rank) + ": " +
+                                    std::to_string(ps[i].bytes) + " vs " + std::to_string(rv.bytes) + " bytes)");
+      if (!waited[rv.peer]) {
+        GXD_HIP(hipStreamWaitEvent(s, f->ready[rv.peer], 0));
+        waited[rv.peer] = 1;
+      }
+      if (rv.bytes) GXD_HIP(hipMemcpyAsync(const_cast<void*>(rv.p), ps[i].p, rv.bytes, hipMemcpyDeviceToDevice, s));
+      ++i;
+    }
+    for (int r = 0; r < f->W; ++r) {  // a send nobody received would hang an RCCL group: report it
+      if (r == rank) continue;
+      const auto& ps = f->sends[r];
+      size_t i       = next[r];
+      while (i < ps.size() && ps[i].peer != rank) ++i;
+      if (i != ps.size()) return fail(GX_EINTERNAL, "gxd loopback: a send has no matching receive (rank " + std::to_string(r) + " -> " + std::to_string(rank) + ")");
+    }
+    GXD_GX(finish(s));
+    bail.armed = false;
+    return 0;
+  }
+};
+
 }  // namespace
 
 struct gxd_comm {
-  ncclComm_t comm = nullptr;
+  std::unique_ptr<Transport> tp;  // RCCL, or the loopback fabric (world == 1 without a peer: a one-rank fabric)
   int rank = 0, world = 1;
   hipStream_t xs = nullptr;  // exchange stream
   std::vector<hipEvent_t> evP;  // partition of chunk c done (caller's stream)
@@ -174,11 +386,13 @@ struct gxd_join {
 };
 
 // (rank << shift) | row fits an int32 >= 0 when shift = 31 - ceil(log2(world)) and row < 2^shift
+static int g_row_bits = 0;  // gxd_test_set_row_bits
 inline int code_shift(int world)
 {
   int b = 0;
   while ((1 << b) < world) ++b;
-  return 31 - b;
+  const int s = 31 - b;
+  return g_row_bits > 0 && g_row_bits < s ? g_row_bits : s;
 }
 
 namespace {
@@ -212,8 +426,7 @@ int ensure_pinned(gxd_comm* c, size_t elems)
 // all-gather of `count` int64 per rank (device -> device) followed by a copy to pinned host memory; waits for it.
 int allgather_i64_host(gxd_comm* c, const long long* mine_dev, long long* all_dev, int count, long long* host)
 {
-  if (c->world > 1) GXD_NCCL(ncclAllGather(mine_dev, all_dev, (size_t)count, ncclInt64, c->comm, c->xs));
-  else GXD_HIP(hipMemcpyAsync(all_dev, mine_dev, sizeof(long long) * count, hipMemcpyDeviceToDevice, c->xs));
+  GXD_GX(c->tp->allgather(mine_dev, all_dev, sizeof(long long) * (size_t)count, c->xs));
   GXD_HIP(hipMemcpyAsync(host, all_dev, sizeof(long long) * count * c->world, hipMemcpyDeviceToHost, c->xs));
   GXD_HIP(hipEventRecord(c->evQ, c->xs));
   GXD_HIP(hipEventSynchronize(c->evQ));
@@ -271,7 +484,7 @@ struct RowCode {
 // POSTED on the exchange stream (evX is recorded behind them; the callee makes its stream wait for it).
 int partition_exchange(gxd_comm* c, int dtype, const void* keys, int64_t n, int64_t nmax, int mode, const void* splitters_host,
                        bool want_rows, int chunks, int64_t max_chunk_rows, RowCode code, hipStream_t stream, Exchange* ex,
-                       const std::function<int(int, int64_t, int64_t)>& on_chunk)
+                       const std::function<int(int, int64_t, int64_t)>& on_chunk, int max_chunks = 0)
 {
   const int W  = c->world;
   const int es = elem_size(dtype);
@@ -282,6 +495,8 @@ int partition_exchange(gxd_comm* c, int dtype, const void* keys, int64_t n, int6
   if (max_chunk_rows > 0 && (nmax + chunks - 1) / chunks > max_chunk_rows - 16384) chunks = (int)((nmax + max_chunk_rows - 16385) / (max_chunk_rows - 16384));
   const int64_t crows = std::max<int64_t>(16384, ((nmax + chunks - 1) / chunks + 16383) / 16384 * 16384);  // whole scatter tiles per chunk
   chunks              = nmax > 0 ? (int)((nmax + crows - 1) / crows) : 1;
+  // (checked BEFORE anything is enqueued or on_chunk writes per-chunk state; nmax is common to all ranks, so all ranks agree)
+  if (max_chunks > 0 && chunks > max_chunks) return fail(GX_EINVAL, "gxd: the shard needs " + std::to_string(chunks) + " chunks, at most " + std::to_string(max_chunks) + " are supported");
   ex->chunks          = chunks;
   ex->crows           = crows;
   ex->seg_counts.assign((size_t)chunks * W, 0);
@@ -356,7 +571,7 @@ int partition_exchange(gxd_comm* c, int dtype, const void* keys, int64_t n, int6
       void *ek, *er = nullptr, *t3, *eo;
       GXD_GX(c->arena.get(Arena::EXACT_KEYS, (size_t)crows * es, &ek));
       if (want_rows) GXD_GX(c->arena.get(Arena::EXACT_ROWS, (size_t)crows * 4, &er));
-      GXD_GX(c->arena.get(Arena::MISC_D, sizeof(long long) * (W + 1), &eo));
+      GXD_GX(c->arena.get(Arena::EXACT_OFFS, sizeof(long long) * (W + 1), &eo));  // (a slot of its own: the callers keep data in MISC_*)
       size_t tb3 = 0;
       GXD_GX(gx_partition_rows_at(dtype, keys, crows, 0, mode, W, splitters_host, ek, static_cast<int32_t*>(er), static_cast<int64_t*>(eo), nullptr,
                                   &tb3, reinterpret_cast<gx_stream_t>(c->xs)));
@@ -400,7 +615,7 @@ int partition_exchange(gxd_comm* c, int dtype, const void* keys, int64_t n, int6
       recv_cap = want;
     }
     ex->chunk_start[k] = rpos;
-    if (W > 1) GXD_NCCL(ncclGroupStart());
+    GXD_GX(c->tp->group_start());
     for (int r = 0; r < W; ++r) {
       const int64_t so = soff[r], sc = scnt[r];  // what I send to r
       const int64_t rc = M[r * W + c->rank];     // what r sends to me
@@ -413,16 +628,16 @@ int partition_exchange(gxd_comm* c, int dtype, const void* keys, int64_t n, int6
         if (want_rows && sc)
           GXD_GX(gx_copy_bytes(rbase + so, static_cast<int32_t*>(rr) + rpos, (size_t)sc * 4, reinterpret_cast<gx_stream_t>(c->xs)));
       } else {
-        if (sc) GXD_NCCL(ncclSend(sk, (size_t)sc * es, ncclInt8, r, c->comm, c->xs));
-        if (rc) GXD_NCCL(ncclRecv(dk, (size_t)rc * es, ncclInt8, r, c->comm, c->xs));
+        if (sc) GXD_GX(c->tp->send(sk, (size_t)sc * es, r, c->xs));
+        if (rc) GXD_GX(c->tp->recv(dk, (size_t)rc * es, r, c->xs));
         if (want_rows) {
-          if (sc) GXD_NCCL(ncclSend(rbase + so, (size_t)sc, ncclInt32, r, c->comm, c->xs));
-          if (rc) GXD_NCCL(ncclRecv(static_cast<int32_t*>(rr) + rpos, (size_t)rc, ncclInt32, r, c->comm, c->xs));
+          if (sc) GXD_GX(c->tp->send(rbase + so, (size_t)sc * 4, r, c->xs));
+          if (rc) GXD_GX(c->tp->recv(static_cast<int32_t*>(rr) + rpos, (size_t)rc * 4, r, c->xs));
         }
       }
       rpos += rc;
     }
-    if (W > 1) GXD_NCCL(ncclGroupEnd());
+    GXD_GX(c->tp->group_end(c->xs));
     GXD_HIP(hipEventRecord(c->evX, c->xs));
     if (on_chunk) {
       int rc2 = on_chunk(k, ex->chunk_start[k], rpos - ex->chunk_start[k]);
@@ -464,6 +679,14 @@ int upload_segtab(gxd_comm* c, const std::vector<long long>& counts, const std::
   return 0;
 }
 
+int comm_resources(gxd_comm* c)
+{
+  GXD_HIP(hipStreamCreateWithFlags(&c->xs, hipStreamNonBlocking));
+  GXD_HIP(hipEventCreateWithFlags(&c->evQ, hipEventDisableTiming));
+  GXD_HIP(hipEventCreateWithFlags(&c->evX, hipEventDisableTiming));
+  return 0;
+}
+
 }  // namespace
 
 extern "C" {
@@ -484,22 +707,48 @@ int gxd_comm_create(const void* id128_host, int world, int rank, gxd_comm** out)
 {
   if (!id128_host || !out || world < 1 || rank < 0 || rank >= world) return GX_EINVAL;
   if (world > MAX_WORLD) return fail(GX_EINVAL, "gxd: at most 16 ranks (one partition pass splits into <= 16 groups)");
-  auto* c  = new gxd_comm;
+  auto c   = std::make_unique<gxd_comm>();
   c->rank  = rank;
   c->world = world;
-  ncclUniqueId id;
-  std::memcpy(&id, id128_host, sizeof(id));
   if (world > 1) {
-    ncclResult_t r = ncclCommInitRank(&c->comm, world, id, rank);
-    if (r != ncclSuccess) {
-      delete c;
-      return fail(GX_EINTERNAL, std::string("ncclCommInitRank: ") + ncclGetErrorString(r));
-    }
+    ncclUniqueId id;
+    std::memcpy(&id, id128_host, sizeof(id));
+    auto tp        = std::make_unique<RcclTransport>();
+    ncclResult_t r = ncclCommInitRank(&tp->comm, world, id, rank);
+    if (r != ncclSuccess) return fail(GX_EINTERNAL, std::string("ncclCommInitRank: ") + ncclGetErrorString(r));
+    c->tp = std::move(tp);
+  } else {  // one rank: the collectives are device-local copies (a one-rank fabric) -- no RCCL communicator is needed
+    auto f = std::make_shared<Fabric>(1);
+    GXD_GX(f->init());
+    auto tp  = std::make_unique<LoopbackTransport>();
+    tp->f    = std::move(f);
+    tp->rank = 0;
+    c->tp    = std::move(tp);
   }
-  GXD_HIP(hipStreamCreateWithFlags(&c->xs, hipStreamNonBlocking));
-  GXD_HIP(hipEventCreateWithFlags(&c->evQ, hipEventDisableTiming));
-  GXD_HIP(hipEventCreateWithFlags(&c->evX, hipEventDisableTiming));
-  *out = c;
+  GXD_GX(comm_resources(c.get()));
+  *out = c.release();
+  return 0;
+}
+
+int gxd_comm_create_loopback(int world, gxd_comm** out)
+{
+  if (!out || world < 1) return GX_EINVAL;
+  if (world > MAX_WORLD) return fail(GX_EINVAL, "gxd: at most 16 ranks (one partition pass splits into <= 16 groups)");
+  auto f = std::make_shared<Fabric>(world);
+  GXD_GX(f->init());
+  std::vector<std::unique_ptr<gxd_comm>> cs;
+  for (int r = 0; r < world; ++r) {
+    auto c   = std::make_unique<gxd_comm>();
+    c->rank  = r;
+    c->world = world;
+    auto tp  = std::make_unique<LoopbackTransport>();
+    tp->f    = f;
+    tp->rank = r;
+    c->tp    = std::move(tp);
+    GXD_GX(comm_resources(c.get()));
+    cs.push_back(std::move(c));
+  }
+  for (int r = 0; r < world; ++r) out[r] = cs[r].release();
   return 0;
 }
 
@@ -515,12 +764,12 @@ int gxd_comm_destroy(gxd_comm* c)
   if (c->evX) (void)hipEventDestroy(c->evX);
   if (c->pinned) (void)hipHostFree(c->pinned);
   if (c->xs) (void)hipStreamDestroy(c->xs);
-  if (c->comm) (void)ncclCommDestroy(c->comm);
-  delete c;
+  delete c;  // (the transport goes with it: ncclCommDestroy / the last rank's reference to the loopback fabric)
   return 0;
 }
 
 void gxd_test_set_slot_scale(double scale) { g_slot_scale = scale; }
+void gxd_test_set_row_bits(int bits) { g_row_bits = bits; }
 int gxd_comm_rank(const gxd_comm* c) { return c ? c->rank : -1; }
 int gxd_comm_world(const gxd_comm* c) { return c ? c->world : -1; }
 int gxd_last_timing(const gxd_comm* c, double* ms3_host)
@@ -574,8 +823,7 @@ int gxd_sort(gxd_comm* c, int dtype, const void* keys, int64_t n, int chunks, in
     }
     GXD_HIP(hipMemcpy(samp, h.data(), h.size(), hipMemcpyHostToDevice));
   }
-  if (W > 1) GXD_NCCL(ncclAllGather(samp, allsamp, (size_t)S * es, ncclInt8, c->comm, c->xs));
-  else GXD_HIP(hipMemcpyAsync(allsamp, samp, (size_t)S * es, hipMemcpyDeviceToDevice, c->xs));
+  GXD_GX(c->tp->allgather(samp, allsamp, (size_t)S * es, c->xs));
   GXD_GX(with_tmp(c, Arena::TMP2, [&](void* t, size_t* b) {
     return gx_sort_keys(dtype, allsamp, sorted, (int64_t)S * W, 0, t, b, reinterpret_cast<gx_stream_t>(c->xs));
   }));
@@ -645,8 +893,10 @@ int gxd_join_build(gxd_comm* c, int key_dtype, const void* build_keys, int64_t n
     j->keys_bytes = (size_t)std::max<int64_t>(ex.total, 1) * ks;
     GXD_HIP((hipError_t)c->pool_get(j->rows_bytes, reinterpret_cast<void**>(&j->rows)));
     GXD_HIP((hipError_t)c->pool_get(j->keys_bytes, &j->keys_keep));
-    GXD_HIP(hipMemcpy(j->rows, c->arena.p[Arena::RECV_ROWS], (size_t)ex.total * 4, hipMemcpyDeviceToDevice));
-    GXD_HIP(hipMemcpy(j->keys_keep, c->arena.p[Arena::RECV_KEYS], (size_t)ex.total * ks, hipMemcpyDeviceToDevice));
+    if (ex.total > 0) {  // (copy kernels on the caller's stream: nothing here touches the null stream)
+      GXD_GX(gx_copy_bytes(c->arena.p[Arena::RECV_ROWS], j->rows, (size_t)ex.total * 4, gstream));
+      GXD_GX(gx_copy_bytes(c->arena.p[Arena::RECV_KEYS], j->keys_keep, (size_t)ex.total * ks, gstream));
+    }
     j->seg_counts = ex.seg_counts;
     j->seg_bases.resize(ex.seg_counts.size());
     for (size_t i = 0; i < ex.seg_counts.size(); ++i) j->seg_bases[i] = bases[i % c->world];
@@ -789,8 +1039,8 @@ int gxd_join_probe(gxd_join* j, const void* probe_keys, int64_t n, int chunks, g
                                           static_cast<int32_t*>(pr), pair_cap, static_cast<int64_t*>(cur), t, b, gstream);
     });
   };
-  GXD_GX(partition_exchange(c, key_dtype, probe_keys, n, nmax, 0, nullptr, true, chunks, partitioned ? (1ll << sh) : 0, code, stream, &ex, on_chunk));
-  if (ex.chunks + 1 > 1024) return fail(GX_EINVAL, "gxd_join_probe: more than 1023 chunks");
+  GXD_GX(partition_exchange(c, key_dtype, probe_keys, n, nmax, 0, nullptr, true, chunks, partitioned ? (1ll << sh) : 0, code, stream, &ex, on_chunk,
+                            1023 /* snap[] holds 1024 pair positions */));
   GXD_HIP(hipStreamWaitEvent(stream, c->evX, 0));
   long long pairs = 0;
   if (!partitioned) {
@@ -944,7 +1194,7 @@ int gxd_groupby_sum_count(gxd_comm* c, int key_dtype, const void* keys, int val_
     GXD_GX(c->arena.get(Arena::PAIR_L, (size_t)std::max<int64_t>(ex.total, 1) * 8, &rs));
     GXD_GX(c->arena.get(Arena::PAIR_R, (size_t)std::max<int64_t>(ex.total, 1) * 8, &rc));
     int64_t rpos = 0;
-    if (W > 1) GXD_NCCL(ncclGroupStart());
+    GXD_GX(c->tp->group_start());
     for (int r = 0; r < W; ++r) {
       const int64_t so = stage_off[r], sc = ex.send_cnt[r];
       const int64_t rcv = ex.seg_counts[r];
@@ -955,17 +1205,17 @@ int gxd_groupby_sum_count(gxd_comm* c, int key_dtype, const void* keys, int val_
         }
       } else {
         if (sc) {
-          GXD_NCCL(ncclSend(static_cast<const char*>(gs) + so * 8, (size_t)sc * 8, ncclInt8, r, c->comm, c->xs));
-          GXD_NCCL(ncclSend(static_cast<const char*>(gc) + so * 8, (size_t)sc * 8, ncclInt8, r, c->comm, c->xs));
+          GXD_GX(c->tp->send(static_cast<const char*>(gs) + so * 8, (size_t)sc * 8, r, c->xs));
+          GXD_GX(c->tp->send(static_cast<const char*>(gc) + so * 8, (size_t)sc * 8, r, c->xs));
         }
         if (rcv) {
-          GXD_NCCL(ncclRecv(static_cast<char*>(rs) + rpos * 8, (size_t)rcv * 8, ncclInt8, r, c->comm, c->xs));
-          GXD_NCCL(ncclRecv(static_cast<char*>(rc) + rpos * 8, (size_t)rcv * 8, ncclInt8, r, c->comm, c->xs));
+          GXD_GX(c->tp->recv(static_cast<char*>(rs) + rpos * 8, (size_t)rcv * 8, r, c->xs));
+          GXD_GX(c->tp->recv(static_cast<char*>(rc) + rpos * 8, (size_t)rcv * 8, r, c->xs));
         }
       }
       rpos += rcv;
     }
-    if (W > 1) GXD_NCCL(ncclGroupEnd());
+    GXD_GX(c->tp->group_end(c->xs));
     GXD_HIP(hipEventRecord(c->evX, c->xs));
     GXD_HIP(hipStreamWaitEvent(stream, c->evX, 0));
     mk    = c->arena.p[Arena::RECV_KEYS];

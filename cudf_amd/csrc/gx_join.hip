@@ -465,10 +465,11 @@ struct TableTop {
 };
 template <typename K>
 struct AltHash {
-  int pbits;
+  unsigned int nparts;  // any count >= 1: the top 32 hash bits scaled into [0, nparts) -- for a power of two these ARE the top bits
   __device__ __forceinline__ unsigned int operator()(K key) const
   {
-    return pbits ? (unsigned int)(((uint64_t)key * 0xD6E8FEB86659FD93ull) >> (64 - pbits)) : 0u;
+    const uint32_t h = (uint32_t)(((uint64_t)key * 0xD6E8FEB86659FD93ull) >> 32);
+    return (unsigned int)(((uint64_t)h * nparts) >> 32);
   }
 };
 constexpr int PJ_MAX_SPLIT = 15;
@@ -2380,7 +2381,7 @@ int partition_rows_hash(const void* keys, int64_t n, int pbits, int nparts, void
   }
   if (*tmp_bytes < c.total()) return GX_ETMP;
   int rc = pj_partition_fn<K, AltHash<K>>(static_cast<const K*>(keys), n, pbits < 3 ? 3 : pbits, plan, static_cast<K*>(out_keys), out_rows,
-                                          PJ_CHUNK, s, AltHash<K>{pbits}, false, row0, spec_cap);
+                                          PJ_CHUNK, s, AltHash<K>{(unsigned int)nparts}, false, row0, spec_cap);
   if (rc) return rc;
   if (spec_cap) hipLaunchKernelGGL(k_pj_export_fills, dim3(1), dim3(256), 0, s, plan, nparts, spec_cap, reinterpret_cast<long long*>(offsets));
   else hipLaunchKernelGGL(k_pj_export_offsets, dim3(1), dim3(256), 0, s, plan, nparts, reinterpret_cast<long long*>(offsets));
@@ -2814,7 +2815,6 @@ int gx_partition_rows_spec_at(int key_dtype, const void* keys, int64_t n, int32_
   using namespace gx::join;
   if (n < 0 || nparts < 1 || nparts > PJ_MAX_SPLIT + 1 || !tmp_bytes || (mode != 0 && mode != 1)) return GX_EINVAL;
   if (tmp && (!offsets_dev || (n > 0 && (!keys || !out_keys)) || (mode == 1 && nparts > 1 && !splitters_host))) return GX_EINVAL;
-  if (mode == 0 && (nparts & (nparts - 1))) return GX_EINVAL;  // hash mode: a power of two ranks
   if (tmp && n == 0) {  // nothing to place: every partition is empty
     GX_HIP_TRY(hipMemsetAsync(offsets_dev, 0, sizeof(int64_t) * (size_t)(nparts + 1), (hipStream_t)s));
     return 0;

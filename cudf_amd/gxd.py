@@ -25,6 +25,7 @@ _p, _i, _i64 = ctypes.c_void_p, ctypes.c_int, ctypes.c_int64
 _lib.gxd_last_error.restype = ctypes.c_char_p
 _lib.gxd_unique_id.argtypes = [_p]
 _lib.gxd_comm_create.argtypes = [_p, _i, _i, ctypes.POINTER(_p)]
+_lib.gxd_comm_create_loopback.argtypes = [_i, ctypes.POINTER(_p)]
 _lib.gxd_comm_destroy.argtypes = [_p]
 _lib.gxd_last_timing.argtypes = [_p, ctypes.POINTER(ctypes.c_double)]
 _lib.gxd_sort.argtypes = [_p, _i, _p, _i64, _i, _i, _ALLOC, _p, ctypes.POINTER(_p), ctypes.POINTER(_i64), _p]
@@ -33,6 +34,8 @@ _lib.gxd_join_probe.argtypes = [_p, _p, _i64, _i, _ALLOC, _p, ctypes.POINTER(_p)
 _lib.gxd_join_destroy.argtypes = [_p]
 _lib.gxd_test_set_slot_scale.argtypes = [ctypes.c_double]
 _lib.gxd_test_set_slot_scale.restype = None
+_lib.gxd_test_set_row_bits.argtypes = [_i]
+_lib.gxd_test_set_row_bits.restype = None
 _lib.gxd_groupby_sum_count.argtypes = [_p, _i, _p, _i, _p, _i64, _i64, _i, _ALLOC, _p, ctypes.POINTER(_p), ctypes.POINTER(_p),
                                        ctypes.POINTER(_p), ctypes.POINTER(_i64), _p]
 
@@ -74,6 +77,11 @@ def set_slot_scale(scale: float):
     _lib.gxd_test_set_slot_scale(float(scale))
 
 
+def set_row_bits(bits: int):
+    """test hook: see gxd_test_set_row_bits"""
+    _lib.gxd_test_set_row_bits(int(bits))
+
+
 def _stream():
     return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
 
@@ -101,6 +109,19 @@ class Communicator:
             idbuf = (ctypes.c_char * 128).from_buffer_copy(bytes(t.cpu().numpy().tobytes()))
         self._h = ctypes.c_void_p()
         _check(_lib.gxd_comm_create(idbuf, self.world, self.rank, ctypes.byref(self._h)), "gxd_comm_create")
+
+    @classmethod
+    def loopback(cls, world: int) -> "List[Communicator]":
+        """`world` logical ranks on the current device (gxd_comm_create_loopback): device-to-device copies stand in for RCCL.
+        Each communicator must be driven by its own host thread on its own non-blocking stream -- see `run_ranks`."""
+        hs = (_p * world)()
+        _check(_lib.gxd_comm_create_loopback(world, hs), "gxd_comm_create_loopback")
+        out = []
+        for r in range(world):
+            c = cls.__new__(cls)
+            c.rank, c.world, c._h = r, world, ctypes.c_void_p(hs[r])
+            out.append(c)
+        return out
 
     def close(self):
         if self._h:
@@ -177,3 +198,34 @@ class HashJoin:
             self.close()
         except Exception:
             pass
+
+
+def run_ranks(comms: "List[Communicator]", fn):
+    """Drive the logical ranks of `Communicator.loopback`: one host thread and one (non-blocking) torch stream per rank, each
+    calling fn(rank, comm); returns the per-rank results in rank order, re-raises the first failure.  The sharded operators are
+    collective, so the ranks must run concurrently -- ctypes releases the GIL for the duration of every gxd_* call."""
+    import threading
+    dev = torch.cuda.current_device()
+    torch.cuda.synchronize()  # inputs made on the default stream are ready for every rank's stream
+    results: List[object] = [None] * len(comms)
+    errors: List[Optional[BaseException]] = [None] * len(comms)
+
+    def work(r):
+        try:
+            torch.cuda.set_device(dev)
+            s = torch.cuda.Stream()
+            with torch.cuda.stream(s):
+                results[r] = fn(r, comms[r])
+            s.synchronize()
+        except BaseException as e:  # noqa: BLE001 -- reported to the caller below
+            errors[r] = e
+
+    threads = [threading.Thread(target=work, args=(r,), name=f"gxd-rank-{r}") for r in range(len(comms))]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join()
+    for e in errors:
+        if e is not None:
+            raise e
+    return results

@@ -147,7 +147,7 @@ def hash_partition_map(key_cols: Sequence[Column], num_partitions: int, seed: in
 
 def partition_rows(col: Column, nparts: int, splitters: Optional[Sequence] = None, want_rows: bool = True):
     """One-pass partition of a key column into `nparts` groups (gx_partition_rows): by a hash that is independent of
-    the join table's slot bits (splitters None; nparts a power of two), or by range (nparts - 1 ascending splitters:
+    the join table's slot bits (splitters None; any nparts <= 16), or by range (nparts - 1 ascending splitters:
     destination = number of splitters <= key).  Returns (grouped keys, int32 row indices or None, nparts + 1 offsets).
     What a rank runs before the all-to-all of the distributed sort / join / groupby
     (cudf::hash_partition, cpp/src/partitioning/partitioning.cu:568-660)."""

@@ -290,8 +290,9 @@ int gx_add_i32(int32_t* data, int64_t n, int32_t value, gx_stream_t stream);
  * (optional) = their row indices, offsets_dev[nparts + 1] = group starts (device int64).  What a rank runs before the
  * all-to-all of the distributed operators (cudf::hash_partition, cpp/src/partitioning/partitioning.cu:568-660, feeding
  * the shuffle of cpp/libcudf_streaming/src/partition_utils.cpp:72-117):
- *   mode 0  destination = top bits of a multiplicative hash independent of the join table's slot bits (nparts a
- *           power of two); key_dtype any 4- or 8-byte type (bit patterns are hashed);
+ *   mode 0  destination = the top 32 bits of a multiplicative hash independent of the join table's slot bits, scaled into
+ *           [0, nparts) by a multiply-shift (any nparts; for a power of two these are the hash's top bits);
+ *           key_dtype any 4- or 8-byte type (bit patterns are hashed);
  *   mode 1  destination = number of splitters <= key in cudf sort order; splitters_host = nparts - 1 ascending keys
  *           of key_dtype in HOST memory (INT32/UINT32/FLOAT32/INT64/UINT64/FLOAT64).
  * cub-style scratch query. */

@@ -38,6 +38,13 @@ typedef void* (*gxd_alloc_fn)(size_t bytes, void* ctx);
 int gxd_unique_id(void* id128_host);
 /* ncclCommInitRank on the CURRENT device (collective over all `world` ranks) */
 int gxd_comm_create(const void* id128_host, int world, int rank, gxd_comm** out);
+/* `world` LOGICAL ranks on the CURRENT device: out[0 .. world) receive communicators that share an in-process loopback
+ * fabric -- device-to-device copies stand in for the xGMI links, the operators above run unchanged ("validate
+ * the partition/exchange logic with N logical ranks on one device").  Every communicator must be driven by a host thread of
+ * its own (the operators are collective: rank r's call returns only when its peers have made theirs) on a NON-BLOCKING stream
+ * of its own.  A rank that fails breaks the fabric: its peers' calls return GX_EINTERNAL instead of waiting for it.
+ * world <= 16 here and in gxd_comm_create; any world size (hash destinations are a multiply-shift of the hash, not a mask). */
+int gxd_comm_create_loopback(int world, gxd_comm** out);
 int gxd_comm_destroy(gxd_comm* comm);
 int gxd_comm_rank(const gxd_comm* comm);
 int gxd_comm_world(const gxd_comm* comm);
@@ -45,6 +52,10 @@ const char* gxd_last_error(void);
 /* TEST HOOK: scales the slot capacity of the speculative partition passes (0 = default margin of 4/3).  A scale below 1 makes
  * every chunk overflow its slots, so the exact re-partition path runs even on a single rank. */
 void gxd_test_set_slot_scale(double scale);
+/* TEST HOOK: narrows the row field of the (source rank << s) | row codes to `bits` (0 = the default s = 31 - ceil(log2(world))), so
+ * that shards of a few million rows already exceed it: build shards then take the documented positions + gather fallback and
+ * probe shards are cut into more chunks. */
+void gxd_test_set_row_bits(int bits);
 /* milliseconds the last operator call of this communicator spent in: [0] partition kernels, [1] host waits for counts,
  * [2] whole call (host clock, the stream is synchronised at the end of every operator) */
 int gxd_last_timing(const gxd_comm* comm, double* ms3_host);
