@@ -79,8 +79,9 @@ def parse():
     ap.add_argument("--cpu-baseline", dest="cpu", action="store_true", default=True)
     ap.add_argument("--no-cpu-baseline", dest="cpu", action="store_false")
     ap.add_argument("--cpu-rows", type=float, default=0, help="rows of the CPU-baseline sample (0 = per-workload default)")
-    ap.add_argument("--cpu-rows-pandas", type=float, default=1e7,
-                    help="rows of the pandas / pyarrow legs (BASELINE.md section 3 plans 1e7 and 1e8; 1e8 takes minutes)")
+    ap.add_argument("--cpu-rows-pandas", type=float, default=0,
+                    help="rows of the pandas / pyarrow legs; 0 = per-leg default: sort 1e8 and groupby 1e8 (BASELINE.md section 3's "
+                         "larger size, ~15 s per library), join 1e7 (pandas.merge at 1e8 probe rows takes minutes)")
     return ap.parse_args()
 
 
@@ -430,7 +431,7 @@ def bench_sort(c, pairs=False):
     pmc_traffic(roofline, n)
     cpu = None
     if a.cpu and c.world == 1 and c.rank == 0:
-        cpu = cpu_baseline_sort(a.cpu_rows or 5e8, a.cpu_rows_pandas)
+        cpu = cpu_baseline_sort(a.cpu_rows or 5e8, a.cpu_rows_pandas or 1e8)
     return {"workload": workload, "rows": n, "ms_per_step": ms_per_step, "rows_per_s": n * c.world / sec, "dtype": "int64",
             "roofline": roofline, "cpu_baseline": cpu, "checked": "order + multiset checksum of the timed output (gx_checksum)"}
 
@@ -581,7 +582,7 @@ def bench_join(c):
     pmc_traffic(roofline, n)
     cpu = None
     if a.cpu and c.rank == 0:
-        cpu = cpu_baseline_join(a.cpu_rows or 1e8, a.cpu_rows_pandas)
+        cpu = cpu_baseline_join(a.cpu_rows or 1e8, a.cpu_rows_pandas or 1e7)
     keydesc = ("random distinct 64-bit build keys, probe 30 % from them + 70 % from a disjoint random set (SURVEY 8d)"
                if a.join_keys == "random" else "dense keys 3i+1 (round-2 distribution)")
     return {"workload": f"{n:.0e}-row int64 probe x {nb_rows:.0e}-row build inner hash join (probe phase timed), {keydesc}", "rows": n,
@@ -674,7 +675,7 @@ def bench_groupby(c):
     pmc_traffic(roofline, n)
     cpu = None
     if a.cpu and c.rank == 0:
-        cpu = cpu_baseline_groupby(a.cpu_rows or 3e8, a.cpu_rows_pandas)
+        cpu = cpu_baseline_groupby(a.cpu_rows or 3e8, a.cpu_rows_pandas or 1e8)
     kdesc = {"dense": "int32 key", "random": "sparse int32 key", "random64": "sparse int64 key"}[a.gb_keys]
     return {"workload": f"{n:.0e}-row groupby({kdesc}, 1e6 groups).agg(float64 sum,count)", "rows": n,
             "ms_per_step": ms_per_step, "rows_per_s": n / sec, "dtype": "f64", "roofline": roofline, "cpu_baseline": cpu,

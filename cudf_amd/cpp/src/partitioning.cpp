@@ -1,0 +1,92 @@
+// cudf::hash_partition / cudf::partition over the C ABI (gx_murmur3_32 -> gx_hash_partition_map -> gx_gather).
+// reference: cpp/src/partitioning/partitioning.cu:53-92 (modulo / bitwise partitioners), 568-745 (hash_partition_table),
+// 875-921 (empty results, partition by map), 923-972 (front ends); contract pinned by
+// cpp/tests/partitioning/hash_partition_test.cpp:49-141,190-209 and partition_test.cpp.
+#include "common.hpp"
+
+#include <cudf/column/column_factories.hpp>
+#include <cudf/copying.hpp>
+#include <cudf/hashing.hpp>
+#include <cudf/partitioning.hpp>
+
+namespace cudf {
+namespace {
+
+// cudf::empty_like(table_view) (cpp/src/copying/copy.cpp): the columns' types, zero rows
+std::unique_ptr<table> empty_like_table(table_view const& t)
+{
+  std::vector<std::unique_ptr<column>> cols;
+  cols.reserve(t.num_columns());
+  for (auto const& c : t) cols.emplace_back(make_empty_column(c.type()));
+  return std::make_unique<table>(std::move(cols));
+}
+
+// rows regrouped by value[i] % num_partitions through a stable map; ALWAYS num_partitions + 1 offsets, last = rows
+// (partitioning.cu:684-688: "Add the total row count as the last offset")
+std::pair<std::unique_ptr<table>, std::vector<size_type>> regroup(table_view const& input, uint32_t const* value, int num_partitions,
+                                                                  rmm::cuda_stream_view stream, rmm::device_async_resource_ref mr)
+{
+  auto const n = input.num_rows();
+  rmm::device_uvector<int32_t> map(n, stream), offs(num_partitions + 1, stream);
+  detail::run_with_scratch(
+    [&](void* t, std::size_t* b) {
+      return gx_hash_partition_map(value, n, num_partitions, map.data(), offs.data(), t, b, detail::gxs(stream));
+    },
+    "hash_partition", stream);
+  std::vector<size_type> offsets(static_cast<std::size_t>(num_partitions) + 1);
+  CUDF_CUDA_TRY(hipMemcpyAsync(offsets.data(), offs.data(), offsets.size() * sizeof(size_type), hipMemcpyDeviceToHost, stream.value()));
+  column_view mapv{data_type{type_id::INT32}, n, map.data(), nullptr, 0};
+  auto out = gather(input, mapv, out_of_bounds_policy::DONT_CHECK, stream, mr);
+  stream.synchronize();  // the offsets are a host vector
+  offsets.back() = n;
+  return {std::move(out), std::move(offsets)};
+}
+
+}  // namespace
+
+std::pair<std::unique_ptr<table>, std::vector<size_type>> hash_partition(table_view const& input, table_view const& keys, int num_partitions,
+                                                                         hash_id hash_function, uint32_t seed, rmm::cuda_stream_view stream,
+                                                                         rmm::device_async_resource_ref mr)
+{
+  CUDF_EXPECTS(keys.num_columns() == 0 || input.num_rows() == keys.num_rows(),
+               "Input table and key table must have same number of rows, or key table should have no columns.", std::invalid_argument);
+  CUDF_EXPECTS(hash_function == hash_id::HASH_MURMUR3 || hash_function == hash_id::HASH_IDENTITY, "Unsupported hash function in hash_partition");
+  // no partitions, no rows or nothing to hash: an empty table and num_partitions + 1 zeros (partitioning.cu:883-886)
+  if (num_partitions <= 0 || input.num_rows() == 0 || keys.num_columns() == 0)
+    return {empty_like_table(input), std::vector<size_type>(static_cast<std::size_t>(std::max(num_partitions, 0)) + 1, 0)};
+  if (hash_function == hash_id::HASH_IDENTITY) {
+    // IdentityHash = the key cast to uint32 (partitioning.cu:852-872); a row of ONE column hashes to its element's hash
+    // (row_operator: the first column is hashed with the seed, later ones are combined).  What the reference's own
+    // tests use it for: a key column of externally computed row hashes (hash_partition_test.cpp:411-415).
+    for (auto const& c : keys) CUDF_EXPECTS(is_fixed_width(c.type()), "IdentityHash does not support this data type");  // (every fixed-width type of this path is numeric)
+    CUDF_EXPECTS(keys.num_columns() == 1 && !keys.column(0).has_nulls() &&
+                   (keys.column(0).type().id() == type_id::INT32 || keys.column(0).type().id() == type_id::UINT32),
+                 "HASH_IDENTITY: one INT32 / UINT32 key column without nulls is implemented on this path");
+    return regroup(input, static_cast<uint32_t const*>(detail::row0(keys.column(0))), num_partitions, stream, mr);
+  }
+  auto h = hashing::murmurhash3_x86_32(keys, seed, stream);
+  return regroup(input, h->view().head<uint32_t>(), num_partitions, stream, mr);
+}
+
+std::pair<std::unique_ptr<table>, std::vector<size_type>> hash_partition(table_view const& input, std::vector<size_type> const& columns_to_hash,
+                                                                         int num_partitions, hash_id hash_function, uint32_t seed,
+                                                                         rmm::cuda_stream_view stream, rmm::device_async_resource_ref mr)
+{
+  // (select() throws std::out_of_range for an invalid index: partitioning.hpp:91)
+  return hash_partition(input, input.select(columns_to_hash), num_partitions, hash_function, seed, stream, mr);
+}
+
+std::pair<std::unique_ptr<table>, std::vector<size_type>> partition(table_view const& t, column_view const& partition_map, size_type num_partitions,
+                                                                    rmm::cuda_stream_view stream, rmm::device_async_resource_ref mr)
+{
+  CUDF_EXPECTS(t.num_rows() == partition_map.size(), "Size mismatch between table and partition map.");
+  CUDF_EXPECTS(!partition_map.has_nulls(), "Unexpected null values in partition_map.");
+  if (num_partitions <= 0 || t.num_rows() == 0)
+    return {empty_like_table(t), std::vector<size_type>(static_cast<std::size_t>(std::max(num_partitions, 0)) + 1, 0)};
+  CUDF_EXPECTS(partition_map.type().id() == type_id::INT32 || partition_map.type().id() == type_id::UINT32,
+               "partition: the partition map must be INT32 or UINT32 on this path", cudf::data_type_error);
+  // map values lie in [0, num_partitions), so value % num_partitions is the value: the hash-partition kernels regroup by it
+  return regroup(t, static_cast<uint32_t const*>(detail::row0(partition_map)), num_partitions, stream, mr);
+}
+
+}  // namespace cudf

@@ -8,6 +8,10 @@
 #include <cudf/hashing.hpp>
 #include <cudf/reduction.hpp>
 
+#include <functional>
+#include <optional>
+#include <type_traits>
+
 namespace cudf {
 namespace {
 
@@ -63,6 +67,88 @@ std::unique_ptr<scalar> reduce(column_view const& col, reduce_aggregation const&
     case type_id::FLOAT64: return make_result<double>(value.data(), valid, stream, mr);
     default: CUDF_FAIL("reduce: unsupported output type");
   }
+}
+
+namespace {
+
+// op(init, r) in the output type T, as the reference folds the initial value into the reduction (simple.cuh:56-77: the
+// initial value is cast to the result type first; integers wrap like the device arithmetic does)
+template <typename T>
+T fold_init(int op, T r, T init)
+{
+  if constexpr (std::is_integral_v<T>) {
+    using U = std::make_unsigned_t<T>;
+    if (op == GX_OP_SUM) return static_cast<T>(static_cast<U>(static_cast<U>(r) + static_cast<U>(init)));
+    if (op == GX_OP_PRODUCT) return static_cast<T>(static_cast<U>(static_cast<U>(r) * static_cast<U>(init)));
+  }
+  switch (op) {
+    case GX_OP_SUM: return static_cast<T>(r + init);
+    case GX_OP_PRODUCT: return static_cast<T>(r * init);
+    case GX_OP_MIN: return init < r ? init : r;
+    default: return init > r ? init : r;
+  }
+}
+
+template <typename T>
+T read_init(scalar const& s, rmm::cuda_stream_view stream)
+{
+  switch (s.type().id()) {
+    case type_id::INT8: return static_cast<T>(static_cast<numeric_scalar<int8_t> const&>(s).value(stream));
+    case type_id::INT16: return static_cast<T>(static_cast<numeric_scalar<int16_t> const&>(s).value(stream));
+    case type_id::INT32: return static_cast<T>(static_cast<numeric_scalar<int32_t> const&>(s).value(stream));
+    case type_id::INT64: return static_cast<T>(static_cast<numeric_scalar<int64_t> const&>(s).value(stream));
+    case type_id::UINT8: return static_cast<T>(static_cast<numeric_scalar<uint8_t> const&>(s).value(stream));
+    case type_id::UINT16: return static_cast<T>(static_cast<numeric_scalar<uint16_t> const&>(s).value(stream));
+    case type_id::UINT32: return static_cast<T>(static_cast<numeric_scalar<uint32_t> const&>(s).value(stream));
+    case type_id::UINT64: return static_cast<T>(static_cast<numeric_scalar<uint64_t> const&>(s).value(stream));
+    case type_id::FLOAT32: return static_cast<T>(static_cast<numeric_scalar<float> const&>(s).value(stream));
+    case type_id::FLOAT64: return static_cast<T>(static_cast<numeric_scalar<double> const&>(s).value(stream));
+    default: throw cudf::data_type_error{"reduce: unsupported initial value type"};
+  }
+}
+
+template <typename T>
+void apply_init(int op, scalar& result, scalar const& init, rmm::cuda_stream_view stream)
+{
+  auto& r = static_cast<numeric_scalar<T>&>(result);
+  r.set_value(fold_init<T>(op, r.value(stream), read_init<T>(init, stream)), stream);
+}
+
+}  // namespace
+
+// reduce with an initial value (reduction.hpp:124-130; reductions.cpp:484-507; simple.cuh:47-85): result = op(init, reduce(col));
+// valid iff the column has a valid row AND the initial value is valid.
+std::unique_ptr<scalar> reduce(column_view const& col, reduce_aggregation const& agg, data_type output_type,
+                               std::optional<std::reference_wrapper<scalar const>> init, rmm::cuda_stream_view stream,
+                               rmm::device_async_resource_ref mr)
+{
+  CUDF_EXPECTS(!init.has_value() || init.value().get().type() == col.type(), "column and initial value must be the same type",
+               cudf::data_type_error);
+  if (init.has_value() && !(agg.kind == aggregation::SUM || agg.kind == aggregation::PRODUCT || agg.kind == aggregation::MIN ||
+                            agg.kind == aggregation::MAX))
+    throw std::invalid_argument{"Initial value is only supported for SUM, SUM_OVERFLOW, PRODUCT, MIN, MAX, ANY, ALL, and HOST_UDF aggregation types"};
+  auto result = reduce(col, agg, output_type, stream, mr);
+  if (!init.has_value()) return result;
+  if (!init.value().get().is_valid(stream)) {
+    result->set_valid_async(false, stream);
+    return result;
+  }
+  if (!result->is_valid(stream)) return result;  // no valid row: reduce_no_data, invalid whatever the initial value
+  int const op = gx_op_of(agg.kind);
+  switch (output_type.id()) {
+    case type_id::INT8: apply_init<int8_t>(op, *result, init.value().get(), stream); break;
+    case type_id::INT16: apply_init<int16_t>(op, *result, init.value().get(), stream); break;
+    case type_id::INT32: apply_init<int32_t>(op, *result, init.value().get(), stream); break;
+    case type_id::INT64: apply_init<int64_t>(op, *result, init.value().get(), stream); break;
+    case type_id::UINT8: apply_init<uint8_t>(op, *result, init.value().get(), stream); break;
+    case type_id::UINT16: apply_init<uint16_t>(op, *result, init.value().get(), stream); break;
+    case type_id::UINT32: apply_init<uint32_t>(op, *result, init.value().get(), stream); break;
+    case type_id::UINT64: apply_init<uint64_t>(op, *result, init.value().get(), stream); break;
+    case type_id::FLOAT32: apply_init<float>(op, *result, init.value().get(), stream); break;
+    case type_id::FLOAT64: apply_init<double>(op, *result, init.value().get(), stream); break;
+    default: CUDF_FAIL("reduce: unsupported output type");
+  }
+  return result;
 }
 
 std::unique_ptr<column> scan(column_view const& input, scan_aggregation const& agg, scan_type inclusive,
@@ -121,33 +207,5 @@ std::unique_ptr<column> murmurhash3_x86_32(table_view const& input, uint32_t see
   return out;
 }
 }  // namespace hashing
-
-std::pair<std::unique_ptr<table>, std::vector<size_type>> hash_partition(table_view const& input,
-                                                                         std::vector<size_type> const& columns_to_hash,
-                                                                         int num_partitions, hash_id hash_function,
-                                                                         uint32_t seed, rmm::cuda_stream_view stream,
-                                                                         rmm::device_async_resource_ref mr)
-{
-  CUDF_EXPECTS(hash_function == hash_id::HASH_MURMUR3, "only HASH_MURMUR3 is implemented on this path");
-  CUDF_EXPECTS(num_partitions > 0, "num_partitions must be positive", std::invalid_argument);
-  auto const n = input.num_rows();
-  std::vector<size_type> offsets(num_partitions, 0);
-  if (n == 0 || columns_to_hash.empty()) return {std::make_unique<table>(input, stream, mr), offsets};
-  auto h = hashing::murmurhash3_x86_32(input.select(columns_to_hash), seed, stream);
-  rmm::device_uvector<int32_t> map(n, stream), offs(num_partitions + 1, stream);
-  detail::run_with_scratch(
-    [&](void* t, std::size_t* b) {
-      return gx_hash_partition_map(h->view().head<uint32_t>(), n, num_partitions, map.data(), offs.data(), t, b,
-                                   detail::gxs(stream));
-    },
-    "hash_partition", stream);
-  std::vector<int32_t> host_offs(num_partitions + 1);
-  CUDF_CUDA_TRY(hipMemcpyAsync(host_offs.data(), offs.data(), host_offs.size() * 4, hipMemcpyDeviceToHost, stream.value()));
-  stream.synchronize();
-  for (int p = 0; p < num_partitions; ++p) offsets[p] = host_offs[p];
-  column_view mapv{data_type{type_id::INT32}, n, map.data(), nullptr, 0};
-  auto out = gather(input, mapv, out_of_bounds_policy::DONT_CHECK, stream, mr);
-  return {std::move(out), offsets};
-}
 
 }  // namespace cudf

@@ -10,10 +10,12 @@
 namespace cudf {
 namespace {
 
-// Device-side protocol faults: a look-back spin that loses forward progress traps inside the kernel (gx_sort.hip), so
-// the error belongs to the stream of the call that produced it and surfaces at that stream's next synchronisation as
-// a cudf::cuda_error -- never as a wrong order returned as success.  The sort itself returns as soon as its work is
-// queued, like the reference's (cpp/src/sort/sort.cu:52-89).
+// Device-side protocol faults: a look-back wait that makes no progress for 30 s of wall-clock time traps inside the kernel
+// (gx_sort.hip, spin_guard).  On ROCm a trap is a queue exception: the process' HIP context is unusable afterwards and the
+// runtime normally aborts -- the reference's cudf::fatal_cuda_error class of failure (utilities/error.hpp:63-86), not a
+// recoverable one.  What the trap guarantees is that a wrong order is never returned as success; a slow or time-sliced
+// predecessor tile (many polls, little time) never trips it.  The sort itself returns as soon as its work is queued, like
+// the reference's (cpp/src/sort/sort.cu:52-89).
 
 void check_order_args(table_view const& input, std::vector<order> const& column_order,
                       std::vector<null_order> const& null_precedence)

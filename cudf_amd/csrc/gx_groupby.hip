@@ -638,10 +638,10 @@ static inline int lds_nsub(int64_t max_groups, int lds_slots)
   return nsub;
 }
 
-static int g_gb_spec = 1;       // A/B knob: 1 = speculative hist-free partition pass (default), 0 = always the exact pass, 2 = speculative for every n
-static int g_gb_algorithm = 0;  // 0 auto, 1 global-atomic table only, 2 partitioned whenever possible
-static int g_gb_nsplit    = 1;
-static int g_gb_nrange    = NRANGE;  // 1 = single cursor per partition (A/B measurement)
+static thread_local int g_gb_spec = 1;       // A/B knob: 1 = speculative hist-free partition pass (default), 0 = always the exact pass, 2 = speculative for every n
+static thread_local int g_gb_algorithm = 0;  // 0 auto, 1 global-atomic table only, 2 partitioned whenever possible
+static thread_local int g_gb_nsplit    = 1;
+static thread_local int g_gb_nrange    = NRANGE;  // 1 = single cursor per partition (A/B measurement)
 constexpr int64_t PART_MIN_ROWS = 1 << 19;
 // the speculative pass pays off once the slots are long enough for the 8-sigma margin to be small (>= ~2000 rows per slot)
 static inline bool part_speculative(int64_t n) { return g_gb_nrange == NRANGE && (g_gb_spec == 2 || (g_gb_spec == 1 && n >= (1 << 22))); }

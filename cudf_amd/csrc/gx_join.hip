@@ -2292,16 +2292,16 @@ struct JoinProfile {
   bool enabled = false, created = false, marked = false;
   hipEvent_t ev[4];  // before hist | before scatter | before probe | after probe
 };
-static JoinProfile g_jprof;
+static thread_local JoinProfile g_jprof;
 static inline void jprof_mark(int i, hipStream_t s)
 {
   if (g_jprof.enabled) (void)hipEventRecord(g_jprof.ev[i], s);
 }
-static int g_pj_probe = 0; // probe kernel: 0 = default (software-pipelined tag probe), 1 = round-1 tag probe (A/B knob)
-static int g_pj_tile = 0;  // scatter tile rows: 0 = default, else 4096 / 8192 / 16384 (A/B knob)
-static int g_pj_probe_early = 0;  // round-3 probe: 1 = rows of a piece requested at the top of the trip, 0 = at its end (default: with the
+static thread_local int g_pj_probe = 0; // probe kernel: 0 = default (software-pipelined tag probe), 1 = round-1 tag probe (A/B knob)
+static thread_local int g_pj_tile = 0;  // scatter tile rows: 0 = default, else 4096 / 8192 / 16384 (A/B knob)
+static thread_local int g_pj_probe_early = 0;  // round-3 probe: 1 = rows of a piece requested at the top of the trip, 0 = at its end (default: with the
                                   // deferral queue the early form no longer fits 128 VGPRs) (A/B knob)
-static int g_pj_defer = 0;        // round-3 probe: 1 = unsettled rows are parked in a per-wave queue for one trip, 0 = settled in place (default:
+static thread_local int g_pj_defer = 0;        // round-3 probe: 1 = unsettled rows are parked in a per-wave queue for one trip, 0 = settled in place (default:
                                   // measured 0.3 ms SLOWER with the queue once the tag window covers 16 slots -- profiles/r3_run4_*) (A/B knob)
 
 // the partition pass shared by the partitioned probe and build (F = TableTop) and by gx_partition_rows
@@ -2426,7 +2426,7 @@ static inline int pj_bits(uint32_t log2cap, int slot_bytes)
 
 // The round-3 probe: speculative hist-free partition (padded regions, persistent scatter) -> probe over the region table,
 // with the exact sequence (histogram, offsets, exact scatter, probe) enqueued behind it and gated on `fallback`.
-static int g_pj_spec = 1;  // A/B knob: 1 = this path where it applies (default), 0 = the round-2 path
+static thread_local int g_pj_spec = 1;  // A/B knob: 1 = this path where it applies (default), 0 = the round-2 path
 template <typename K>
 static bool pj2_applies(int64_t n, int pbits)
 {

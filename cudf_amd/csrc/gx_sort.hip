@@ -398,7 +398,19 @@ struct PassArgs {
 };
 
 constexpr int PASS_TPB = 8;  // tickets per workgroup of the MULTI form of k_radix_pass
-constexpr uint32_t SPIN_LIMIT = 1u << 22;  // ~seconds; only a broken forward-progress chain gets here
+// A look-back wait that makes no progress for SPIN_SECONDS of WALL-CLOCK time (s_memrealtime: the 100 MHz constant clock, read
+// every 4096 polls -- a slow or time-sliced predecessor tile is not a fault, however many polls it takes) can only mean a broken
+// forward-progress chain.  The trap is FATAL for the process' HIP context, like any device-side fault (the reference's
+// cudf::fatal_cuda_error, utilities/error.hpp:63-86): what it guarantees is that a wrong order is never returned as success.
+constexpr uint32_t SPIN_CHECK        = 1u << 12;
+constexpr unsigned long long SPIN_SECONDS = 30;
+__device__ __forceinline__ void spin_guard(uint32_t& spins, unsigned long long& t0)
+{
+  if ((++spins & (SPIN_CHECK - 1)) != 0) return;
+  const unsigned long long now = __builtin_amdgcn_s_memrealtime();
+  if (t0 == 0) t0 = now;
+  else if (now - t0 > SPIN_SECONDS * 100000000ull) __builtin_trap();
+}
 
 __device__ __forceinline__ unsigned long long pack_status(unsigned flag, unsigned epoch, uint32_t value)
 {
@@ -554,8 +566,9 @@ __global__ void __launch_bounds__(BT, 4) k_radix_pass(PassArgs a)
             if (!done) {
               unsigned long long x = v[k];
               uint32_t spins       = 0;
+              unsigned long long spin_t0 = 0;
               while ((x >> 62) == 0 || ((unsigned)(x >> 32) & 0xFFu) != epoch) {
-                if (++spins > SPIN_LIMIT) __builtin_trap();  // broken forward progress: fail the STREAM, never return a wrong order
+                spin_guard(spins, spin_t0);  // broken forward progress: fail loudly, never return a wrong order
                 __builtin_amdgcn_s_sleep(2);
                 x = load_agent_u64(&a.status[(p - k) * BINS + tid]);
               }
@@ -908,8 +921,9 @@ __global__ void __launch_bounds__(BT, (KPT <= 8 ? 8 : (KPT <= 12 ? 6 : 4))) k_ms
           if (!done) {
             unsigned long long x = v[k];
             uint32_t spins       = 0;
+            unsigned long long spin_t0 = 0;
             while ((x >> 62) == 0 || ((unsigned)(x >> 32) & 0xFFu) != epoch) {
-              if (++spins > SPIN_LIMIT) __builtin_trap();  // as above
+              spin_guard(spins, spin_t0);  // as above
               __builtin_amdgcn_s_sleep(2);
               x = load_agent_u64(&a.status[(p - k) * NB + tid]);
             }
@@ -1969,8 +1983,8 @@ __global__ void __launch_bounds__(BT, 4) k_hf_scatter(const KeyT* __restrict__ i
   }
 }
 
-static int g_algorithm = 0;
-static int g_order_mode = 0;
+static thread_local int g_algorithm = 0;
+static thread_local int g_order_mode = 0;
 
 // optional per-launch timing with HIP events on the caller's stream (bench.py's roofline leg)
 struct Profile {
@@ -1981,7 +1995,7 @@ struct Profile {
   hipEvent_t hev[5];  // hybrid: before msd0, hist2, msd1, local sort, after
   bool hybrid_marked = false;
 };
-static Profile g_prof;
+static thread_local Profile g_prof;  // per calling thread, like every knob below: a thread that profiles or forces a path affects its own calls only
 static inline void prof_mark(int idx, hipStream_t s)
 {
   if (g_prof.enabled) (void)hipEventRecord(g_prof.ev[idx], s);
@@ -1990,10 +2004,10 @@ static inline void prof_mark_h(int idx, hipStream_t s)
 {
   if (g_prof.enabled) (void)hipEventRecord(g_prof.hev[idx], s);
 }
-static int g_hybrid = 1;  // 0 disables the hybrid MSD path (A/B knob)
-static int g_lbw    = 16;  // predecessors per look-back round of the keys-only hybrid partition passes (knob: 4, 8, 16;
+static thread_local int g_hybrid = 1;  // 0 disables the hybrid MSD path (A/B knob)
+static thread_local int g_lbw    = 16;  // predecessors per look-back round of the keys-only hybrid partition passes (knob: 4, 8, 16;
                            // 16 measured 2-3 % ahead of 4: profiles/r2_run21_bench_sort_lookback_window.jsonl)
-static int g_msd_kpt = 16;  // keys per thread of the partition passes (8 and 12 measured slower: 5.7 / 4.7 vs 4.0 ms)
+static thread_local int g_msd_kpt = 16;  // keys per thread of the partition passes (8 and 12 measured slower: 5.7 / 4.7 vs 4.0 ms)
 
 template <typename KeyT>
 constexpr int kpt_for(bool has_val)
@@ -2015,10 +2029,10 @@ struct HybridCfg {
   int bits2;  // level-1 bits (1..9)
   int kpt;    // keys per thread of the partition passes
 };
-static int g_cell = 0;  // A/B knob: 0 = auto, 8192 / 16384 = force the local-sort cell capacity
+static thread_local int g_cell = 0;  // A/B knob: 0 = auto, 8192 / 16384 = force the local-sort cell capacity
 // workgroups of k_local_sort: they walk the cells (or k_local_place's todo list) with a stride, see the kernel
 static inline unsigned local_sort_grid(int cells) { return (unsigned)(cells < 4096 ? cells : 4096); }
-static int g_place_grid = 0;  // A/B knob: workgroups of k_local_place; 0 = one per cell
+static thread_local int g_place_grid = 0;  // A/B knob: workgroups of k_local_place; 0 = one per cell
 static inline unsigned local_place_grid(int cells) { return (unsigned)((g_place_grid > 0 && g_place_grid < cells) ? g_place_grid : cells); }
 template <typename KeyT, int KIND, bool HAS_VAL>
 static HybridCfg hybrid_cfg(int64_t n, bool iota_payload, int algo)
@@ -2049,9 +2063,9 @@ struct FastCfg {
   int stride;        // sample: every stride-th 64-key chunk
   size_t slot_rows;  // keys the padded level-0 output holds
 };
-static int g_cursor          = 1;     // 0 disables the cursor path (A/B knob)
-static int g_exp             = 0;     // ablation bits of k_local_sort (measurement only: the result is NOT sorted under most of them)
-static float g_cursor_margin = 8.0f;  // standard deviations of slack per level-0 slot (tests: < 0 forces the fallback)
+static thread_local int g_cursor          = 1;     // 0 disables the cursor path (A/B knob)
+static thread_local int g_exp             = 0;     // ablation bits of k_local_sort (measurement only: the result is NOT sorted under most of them)
+static thread_local float g_cursor_margin = 8.0f;  // standard deviations of slack per level-0 slot (tests: < 0 forces the fallback)
 template <typename KeyT, int KIND, bool HAS_VAL>
 static FastCfg fast_cfg(int64_t n, int algo, bool hybrid_on)
 {
@@ -2491,7 +2505,7 @@ __global__ void __launch_bounds__(256) k_unpack_rows(const uint64_t* __restrict_
 // OFF by default (gx_sort_set_order_words): 1e9 well-spread int32 keys 22.2 -> 17.0 ms, but the sort's cells are cut by KEY bits
 // alone until its two levels are through, so keys with ~1000 rows each (1e6 distinct: group ids) overflow their cells and the
 // column falls back to eight LSD passes over the 64-bit words: 16-21 -> 55-59 ms (profiles/r3_run31_sorted_order_int32_words.txt).
-static int g_order_words = 0;
+static thread_local int g_order_words = 0;
 static inline bool order_words32_applies(int dtype, int64_t n)
 {
   return g_order_words && (dtype == GX_INT32 || dtype == GX_UINT32) && n >= (1ll << 25) && g_algorithm == 0 && g_hybrid && g_cursor;

@@ -6,7 +6,9 @@
 #include <cudf/scalar/scalar.hpp>
 #include <cudf/types.hpp>
 
+#include <functional>
 #include <memory>
+#include <optional>
 
 namespace cudf {
 
@@ -14,6 +16,15 @@ namespace cudf {
 // valid element.  SUM/PRODUCT compute in output_type (INT64, UINT64 or FLOAT64 here), MIN/MAX
 // require output_type == col.type().
 std::unique_ptr<scalar> reduce(column_view const& col, reduce_aggregation const& agg, data_type output_type,
+                               rmm::cuda_stream_view stream      = cudf::get_default_stream(),
+                               rmm::device_async_resource_ref mr = cudf::get_current_device_resource_ref());
+
+// The same with an initial value (reduction.hpp:124-130): result = op(init, reduce(col)), the initial value cast to
+// output_type first (simple.cuh:56-66).  `init` must have the column's type (cudf::data_type_error otherwise); an invalid
+// (null) initial value or a column without a valid row gives an invalid result (simple.cuh:80-83); only SUM, PRODUCT, MIN
+// and MAX take one here (std::invalid_argument otherwise, reductions.cpp:492-499).
+std::unique_ptr<scalar> reduce(column_view const& col, reduce_aggregation const& agg, data_type output_type,
+                               std::optional<std::reference_wrapper<scalar const>> init,
                                rmm::cuda_stream_view stream      = cudf::get_default_stream(),
                                rmm::device_async_resource_ref mr = cudf::get_current_device_resource_ref());
 

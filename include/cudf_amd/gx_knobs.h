@@ -1,8 +1,12 @@
 /*
- * gx_knobs.h -- tuning knobs and measurement hooks of libcudf_amd.  NOT part of the drop-in boundary (gx.h): these set
- * PROCESS-WIDE state that the entry points of gx.h read when they are called.  They exist for A/B measurements (bench.py,
- * scripts/) and for tests that must force a code path (fallback algorithms, speculative passes at small sizes).  A production
- * caller never calls them; calling one while another thread is inside a gx_* entry point is a data race by contract.
+ * gx_knobs.h -- tuning knobs and measurement hooks of libcudf_amd.  NOT part of the drop-in boundary (gx.h).  They exist for
+ * A/B measurements (bench.py, scripts/) and for tests that must force a code path (fallback algorithms, speculative passes at
+ * small sizes); a production caller never calls them.
+ * SCOPE: every knob and profile hook is state of the CALLING THREAD (thread_local): it changes what the gx_* entry points do
+ * when THAT thread calls them and nothing else, so concurrent callers -- hash_join probes are documented as callable in
+ * parallel (cpp/include/cudf/join/hash_join.hpp:63-68) -- never see another thread's experiment.  Where a comment below still
+ * says "process-wide" read "per calling thread".  The one exception is gx_groupby_set_partition_bits (it mirrors its value
+ * into device memory): process-wide, set it only while no groupby is running.
  */
 #ifndef CUDF_AMD_GX_KNOBS_H
 #define CUDF_AMD_GX_KNOBS_H

@@ -255,6 +255,10 @@ def hash_partition(key_columns: Sequence[np.ndarray], num_partitions: int, seed:
     """cudf::hash_partition (cpp/src/partitioning/partitioning.cu:53-92,568-660): partition id =
     row_hash % P (``& (P-1)`` when P is a power of two -- same value); rows keep their relative
     order inside a partition.  Returns (gather order, offsets[P+1])."""
+    nrows = len(key_columns[0]) if len(key_columns) else 0
+    if num_partitions <= 0 or nrows == 0 or len(key_columns) == 0:
+        # an EMPTY result and num_partitions + 1 zeros (partitioning.cu:883-886; hash_partition_test.cpp:73-141)
+        return np.zeros(0, np.int32), np.zeros(max(num_partitions, 0) + 1, np.int32)
     h = row_hash(key_columns, valids, seed)
     pid = (h % np.uint32(num_partitions)).astype(np.int64)
     order = np.argsort(pid, kind="stable").astype(np.int32)
@@ -895,16 +899,36 @@ def join_match_counts(left, right, kind: str = "inner", left_valid=None, right_v
 # ----------------------------------------------------------------------------------------------
 
 
-def reduce(values: np.ndarray, op: str, valid=None, out_dtype=None):
+def reduce(values: np.ndarray, op: str, valid=None, out_dtype=None, init=None, init_valid=True):
     """cudf::reduce (cpp/src/reductions/reductions.cpp:484-507, simple.cuh:47-85): nulls skipped;
     returns (value, is_valid); is_valid False iff there is no valid element; computed in
-    out_dtype (ints wrap)."""
+    out_dtype (ints wrap).  init (reduction.hpp:124-130): an initial value of the column's type, cast to out_dtype and
+    folded in with the operator (simple.cuh:56-77); the result is valid iff the column has a valid row AND the initial
+    value is valid (simple.cuh:80-83)."""
     v = np.asarray(values)
+    if init is not None:
+        if op not in ("sum", "product", "min", "max"):
+            raise ValueError("Initial value is only supported for SUM, SUM_OVERFLOW, PRODUCT, MIN, MAX, ANY, ALL, and HOST_UDF aggregation types")
+        r, ok = reduce(v, op, valid, out_dtype)
+        if not ok or not init_valid:
+            return r, False
+        od = np.dtype(out_dtype or v.dtype)
+        i = np.asarray(init, v.dtype).astype(od)
+        with np.errstate(over="ignore"):
+            if op == "sum":
+                return (np.asarray(r, od) + i).astype(od)[()], True
+            if op == "product":
+                return (np.asarray(r, od) * i).astype(od)[()], True
+        pair = np.array([r, i], od)
+        return (pair[np.argmin(sortable_bits(pair))] if op == "min" else pair[np.argmax(sortable_bits(pair))]), True
     m = np.ones(len(v), bool) if valid is None else np.asarray(valid, bool)
     x = v[m]
     out_dtype = np.dtype(out_dtype or v.dtype)
     if len(x) == 0:
         return out_dtype.type(0), False
+    if op == "product":
+        with np.errstate(over="ignore"):
+            return x.astype(out_dtype).prod(dtype=out_dtype), True
     if op == "sum":
         if out_dtype.kind == "f":
             return out_dtype.type(math.fsum(x.astype(np.float64))), True

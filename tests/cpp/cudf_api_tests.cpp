@@ -29,6 +29,7 @@
 #include <limits>
 #include <numeric>
 #include <random>
+#include <cudf/partitioning.hpp>
 #include <cudf_amd/distributed.hpp>
 
 #include <algorithm>
@@ -1125,14 +1126,49 @@ int main()
     auto hh = to_host<uint32_t>(h->view());
     auto [t, offs] = hash_partition(table_view{{c->view()}}, {0}, 4);
     auto out = to_host<int32_t>(t->view().column(0));
-    CHECK(offs.size() == 4 && offs[0] == 0 && t->num_rows() == 12);
-    for (int p = 0; p < 4; ++p) {
-      int e = p + 1 < 4 ? offs[p + 1] : 12;
-      for (int i = offs[p]; i < e; ++i) CHECK((int)(hh[out[i]] % 4) == p);
-    }
+    // num_partitions + 1 offsets, the last one = rows (partitioning.cu:684-688; hash_partition_test.cpp:422-431)
+    CHECK(offs.size() == 5 && offs[0] == 0 && offs[4] == 12 && t->num_rows() == 12);
+    for (int p = 0; p < 4; ++p)
+      for (int i = offs[p]; i < offs[p + 1]; ++i) CHECK((int)(hh[out[i]] % 4) == p);
     auto sorted = out;
     std::sort(sorted.begin(), sorted.end());
     CHECK((sorted == to_host<int32_t>(c->view())));
+    // hash_partition_test.cpp:73-141: zero partitions / zero rows / nothing to hash -> EMPTY table, num_partitions + 1 zeros
+    auto [t0, o0] = hash_partition(table_view{{c->view()}}, {0}, 0);
+    CHECK(t0->num_rows() == 0 && t0->num_columns() == 1 && o0.size() == 1);
+    auto e = make_col<int32_t>({});
+    auto [t1, o1] = hash_partition(table_view{{e->view()}}, {0}, 3);
+    CHECK(t1->num_rows() == 0 && o1.size() == 4 && o1[3] == 0);
+    auto [t2, o2] = hash_partition(table_view{{c->view()}}, std::vector<size_type>{}, 3);
+    CHECK(t2->num_rows() == 0 && t2->num_columns() == 1 && t2->view().column(0).type() == c->type() && o2.size() == 4);
+    CHECK(throws<std::out_of_range>([&] { (void)hash_partition(table_view{{c->view()}}, {-1}, 3); }));                       // :49-60
+    auto k9 = make_col<int16_t>({1, 2, 3, 4, 5, 6, 7, 8, 9});
+    CHECK(throws<std::invalid_argument>([&] { (void)hash_partition(table_view{{c->view()}}, table_view{{k9->view()}}, 3); }));  // :62-71
+    // the keys-table overload and HASH_IDENTITY over the externally computed row hashes agree with the direct form (:411-423)
+    auto [t3, o3] = hash_partition(table_view{{c->view()}}, table_view{{h->view()}}, 4, hash_id::HASH_IDENTITY);
+    CHECK((o3 == offs) && (to_host<int32_t>(t3->view().column(0)) == out));
+    // cudf::partition by an explicit map (partitioning.hpp:44-78, the documented example)
+    auto vals = make_col<int32_t>({10, 20, 30, 40, 50});
+    auto pmap = make_col<int32_t>({1, 0, 1, 2, 0});
+    auto [pt, po] = partition(table_view{{vals->view()}}, pmap->view(), 4);
+    CHECK((po == std::vector<size_type>{0, 2, 4, 5, 5}) && (to_host<int32_t>(pt->view().column(0)) == std::vector<int32_t>{20, 50, 10, 30, 40}));
+  });
+  run("reduce with an initial value (reduction.hpp:124-130; reduction_tests.cpp:122-235,330-421)", [] {
+    auto c = make_col<int32_t>({6, -14, 13, 64, 0, -13, -20, 45});
+    numeric_scalar<int32_t> init{100};
+    auto s = reduce(c->view(), *make_sum_aggregation<reduce_aggregation>(), data_type{type_id::INT32}, std::cref<scalar>(init));
+    CHECK(s->is_valid() && static_cast<numeric_scalar<int32_t>&>(*s).value() == 181);
+    auto mm = make_col<int64_t>({5, 0, -120, -111, 0, 64, 63, 99, 123, -16}, {1, 1, 0, 1, 1, 1, 0, 1, 0, 1});
+    numeric_scalar<int64_t> i64{100};
+    auto mn = reduce(mm->view(), *make_min_aggregation<reduce_aggregation>(), data_type{type_id::INT64}, std::cref<scalar>(i64));
+    auto mx = reduce(mm->view(), *make_max_aggregation<reduce_aggregation>(), data_type{type_id::INT64}, std::cref<scalar>(i64));
+    CHECK(static_cast<numeric_scalar<int64_t>&>(*mn).value() == -111 && static_cast<numeric_scalar<int64_t>&>(*mx).value() == 100);
+    init.set_valid_async(false);
+    auto inv = reduce(c->view(), *make_sum_aggregation<reduce_aggregation>(), data_type{type_id::INT32}, std::cref<scalar>(init));
+    CHECK(!inv->is_valid());                                                                       // invalid init -> invalid result (simple.cuh:80-83)
+    CHECK(throws<cudf::data_type_error>([&] { (void)reduce(c->view(), *make_sum_aggregation<reduce_aggregation>(), data_type{type_id::INT64}, std::cref<scalar>(i64)); }));
+    numeric_scalar<int32_t> one{1};
+    CHECK(throws<std::invalid_argument>([&] { (void)reduce(c->view(), *make_mean_aggregation<reduce_aggregation>(), data_type{type_id::FLOAT64}, std::cref<scalar>(one)); }));
   });
   run("Arrow C Device Data Interface round trip (interop.hpp:477-606,838-885)", [] {
     std::vector<std::unique_ptr<column>> cols;

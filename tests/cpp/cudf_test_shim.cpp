@@ -14,6 +14,8 @@
 #include <cudf/join/hash_join.hpp>
 #include <cudf/join/join.hpp>
 #include <cudf/null_mask.hpp>
+#include <cudf/partitioning.hpp>
+#include <cudf/reduction.hpp>
 #include <cudf/scalar/scalar.hpp>
 #include <cudf/sorting.hpp>
 #include <cudf/table/table_view.hpp>
@@ -22,6 +24,8 @@
 
 #include <cstring>
 #include <functional>
+#include <optional>
+#include <stdexcept>
 #include <string>
 #include <vector>
 
@@ -327,6 +331,134 @@ int shim_full_join(int dtype, const void* left, const uint32_t* lvalid, int lnul
     d2d(out_r, res.second->data(), static_cast<std::size_t>(m) * sizeof(int32_t));
     shim_sync();
   });
+}
+
+// cudf::hash_partition (partitioning.hpp:103-110) of `ncols` columns with `n` rows on the key columns key_idx_host[0 .. nkeys);
+// which == 1: the keys-table overload (partitioning.hpp:138-145) with the selected columns as the key table.  Outputs: the
+// regrouped columns (caller-allocated, n rows each), the offsets vector (out_offsets_host has room for max(parts, 0) + 2) and its
+// length, the rows of the output table, its number of columns.  Exceptions come back as -1 with the type name first.
+int shim_hash_partition(int ncols, const int* dtypes_host, const void* const* datas_host, const uint32_t* const* valids_host,
+                        const int* nulls_host, int n, int nkeys, const int* key_idx_host, int parts, unsigned seed, int which,
+                        const uint32_t* ext_key /* which == 2: a UINT32 key column of its own, hashed with HASH_IDENTITY */,
+                        void* const* out_datas_host, uint32_t* const* out_valids_host, int* out_nulls_host, int* out_offsets_host,
+                        int* out_noffsets_host, int* out_rows_host, int* out_cols_host)
+{
+  auto body = [&] {
+    std::vector<cudf::column_view> cols;
+    for (int i = 0; i < ncols; ++i) cols.push_back(view(dtypes_host[i], datas_host[i], valids_host ? valids_host[i] : nullptr, n, nulls_host ? nulls_host[i] : 0));
+    cudf::table_view input{cols};
+    std::vector<cudf::size_type> idx(key_idx_host, key_idx_host + nkeys);
+    auto res = which == 2   ? cudf::hash_partition(input, cudf::table_view{{view(static_cast<int>(cudf::type_id::UINT32), ext_key, nullptr, n, 0)}}, parts,
+                                                   cudf::hash_id::HASH_IDENTITY, seed)
+               : which == 1 ? cudf::hash_partition(input, input.select(idx), parts, cudf::hash_id::HASH_MURMUR3, seed)
+                            : cudf::hash_partition(input, idx, parts, cudf::hash_id::HASH_MURMUR3, seed);
+    *out_rows_host     = res.first->num_rows();
+    *out_cols_host     = res.first->num_columns();
+    *out_noffsets_host = static_cast<int>(res.second.size());
+    for (std::size_t i = 0; i < res.second.size(); ++i) out_offsets_host[i] = res.second[i];
+    for (int i = 0; i < res.first->num_columns(); ++i)
+      emit(res.first->get_column(i).view(), out_datas_host[i], out_valids_host ? out_valids_host[i] : nullptr, out_nulls_host ? out_nulls_host + i : nullptr);
+    shim_sync();
+  };
+  try {
+    body();
+    return 0;
+  } catch (std::out_of_range const& e) {
+    g_err = std::string{"std::out_of_range: "} + e.what();
+  } catch (std::invalid_argument const& e) {
+    g_err = std::string{"std::invalid_argument: "} + e.what();
+  } catch (std::exception const& e) {
+    g_err = e.what();
+  }
+  return -1;
+}
+
+// the keys-table overload with a key table of a DIFFERENT row count (hash_partition_test.cpp:62-71: std::invalid_argument)
+int shim_hash_partition_key_rows(int dtype, const void* data, int n, int key_dtype, const void* keys, int nk, int parts)
+{
+  try {
+    auto res = cudf::hash_partition(cudf::table_view{{view(dtype, data, nullptr, n, 0)}}, cudf::table_view{{view(key_dtype, keys, nullptr, nk, 0)}}, parts);
+    shim_sync();
+    return 0;
+  } catch (std::invalid_argument const& e) {
+    g_err = std::string{"std::invalid_argument: "} + e.what();
+  } catch (std::exception const& e) {
+    g_err = e.what();
+  }
+  return -1;
+}
+
+// cudf::partition by an INT32 map (partitioning.hpp:44-78)
+int shim_partition(int dtype, const void* data, int n, const int32_t* map, int parts, void* out, int* out_offsets_host, int* out_noffsets_host,
+                   int* out_rows_host)
+{
+  return guarded([&] {
+    auto res = cudf::partition(cudf::table_view{{view(dtype, data, nullptr, n, 0)}}, view(static_cast<int>(cudf::type_id::INT32), map, nullptr, n, 0), parts);
+    *out_rows_host     = res.first->num_rows();
+    *out_noffsets_host = static_cast<int>(res.second.size());
+    for (std::size_t i = 0; i < res.second.size(); ++i) out_offsets_host[i] = res.second[i];
+    emit(res.first->get_column(0).view(), out, nullptr, nullptr);
+    shim_sync();
+  });
+}
+
+// cudf::reduce with an initial value (reduction.hpp:124-130).  kind: aggregation::Kind; init_bits_host: the initial value's bytes
+// (of init_dtype -- a type other than the column's must throw cudf::data_type_error); has_init 0: the overload is called with
+// an empty optional.  Result: out_bits_host (8 bytes, the scalar's value in out_dtype) and out_valid_host.
+int shim_reduce_init(int dtype, const void* data, const uint32_t* valid, int nulls, int n, int kind, int out_dtype, int has_init, int init_dtype,
+                     unsigned long long init_bits_host, int init_valid, unsigned long long* out_bits_host, int* out_valid_host)
+{
+  auto body = [&] {
+    auto c = view(dtype, data, valid, n, nulls);
+    using A = cudf::aggregation;
+    std::unique_ptr<cudf::reduce_aggregation> agg;
+    switch (static_cast<A::Kind>(kind)) {
+      case A::SUM: agg = cudf::make_sum_aggregation<cudf::reduce_aggregation>(); break;
+      case A::PRODUCT: agg = cudf::make_product_aggregation<cudf::reduce_aggregation>(); break;
+      case A::MIN: agg = cudf::make_min_aggregation<cudf::reduce_aggregation>(); break;
+      case A::MAX: agg = cudf::make_max_aggregation<cudf::reduce_aggregation>(); break;
+      case A::MEAN: agg = cudf::make_mean_aggregation<cudf::reduce_aggregation>(); break;
+      default: throw std::runtime_error("shim: reduce kind");
+    }
+    std::unique_ptr<cudf::scalar> init;
+    auto mk = [&](auto tag) {
+      using T = decltype(tag);
+      T v;
+      std::memcpy(&v, &init_bits_host, sizeof(T));
+      init = std::make_unique<cudf::numeric_scalar<T>>(v, init_valid != 0);
+    };
+    if (has_init) {
+      switch (static_cast<cudf::type_id>(init_dtype)) {
+        case cudf::type_id::INT16: mk(int16_t{}); break;
+        case cudf::type_id::INT32: mk(int32_t{}); break;
+        case cudf::type_id::INT64: mk(int64_t{}); break;
+        case cudf::type_id::UINT8: mk(uint8_t{}); break;
+        case cudf::type_id::FLOAT32: mk(float{}); break;
+        case cudf::type_id::FLOAT64: mk(double{}); break;
+        default: throw std::runtime_error("shim: init dtype");
+      }
+    }
+    std::optional<std::reference_wrapper<cudf::scalar const>> oi;
+    if (init) oi = std::cref(*init);
+    auto r          = cudf::reduce(c, *agg, cudf::data_type{static_cast<cudf::type_id>(out_dtype)}, oi);
+    *out_valid_host = r->is_valid() ? 1 : 0;
+    *out_bits_host  = 0;
+    if (auto const* p = r->device_value_ptr()) {
+      if (hipMemcpy(out_bits_host, p, cudf::size_of(r->type()), hipMemcpyDeviceToHost) != hipSuccess) throw std::runtime_error("shim: copy failed");
+    }
+    shim_sync();
+  };
+  try {
+    body();
+    return 0;
+  } catch (cudf::data_type_error const& e) {
+    g_err = std::string{"cudf::data_type_error: "} + e.what();
+  } catch (std::invalid_argument const& e) {
+    g_err = std::string{"std::invalid_argument: "} + e.what();
+  } catch (std::exception const& e) {
+    g_err = e.what();
+  }
+  return -1;
 }
 
 }  // extern "C"

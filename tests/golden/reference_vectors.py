@@ -418,3 +418,77 @@ SEGMENTED_SORT = [
     dict(name="partial_offsets", cols=[_SEG_C1], offsets=[3, 7], ascending=[True],
          expect_order=[0, 1, 2, 6, 5, 3, 4, 7, 8, 9, 10, 11, 12, 13, 14, 15]),
 ]
+
+# ---------------------------------------------------------------------------------------------
+# cudf::hash_partition -- the CONTRACT cases of partitioning/hash_partition_test.cpp (what the returned table and
+# offsets vector must look like).  String columns are transcribed as small integer codes (only their presence as a
+# non-key / key column matters to these cases).  "rows" / "cols" / "noffsets" are the EXPECT_EQ literals of the cases.
+# ---------------------------------------------------------------------------------------------
+_HP_FLOATS = [1.0, 2.0, 3.0, 4.0, 5.0, 6.0, 7.0, 8.0]
+_HP_INTS = [1, 2, 3, 4, 5, 6, 7, 8]
+_HP_STR_CODES = [0, 1, 2, 3, 4, 5, 6, 7]          # {"a","bb","ccc","d","ee","fff","gg","h"}
+HASH_PARTITION = [
+    # hash_partition_test.cpp:49-60  InvalidColumnsToHash -> std::out_of_range
+    dict(name="invalid_columns_to_hash", cols=[("float32", _HP_FLOATS), ("int16", _HP_INTS), ("int32", _HP_STR_CODES)],
+         keys=[-1], parts=3, throws="std::out_of_range"),
+    # :73-89  ZeroPartitions -> empty table with the input's columns, num_partitions + 1 = 1 offset
+    dict(name="zero_partitions", cols=[("float32", _HP_FLOATS), ("int16", _HP_INTS), ("int32", _HP_STR_CODES)],
+         keys=[2], parts=0, rows=0, ncols=3, noffsets=1),
+    # :91-107  ZeroRows
+    dict(name="zero_rows", cols=[("float32", []), ("int16", []), ("int32", [])], keys=[2], parts=3, rows=0, ncols=3, noffsets=4),
+    # :109-122  ZeroColumns
+    dict(name="zero_columns", cols=[], keys=[], parts=3, rows=0, ncols=0, noffsets=4),
+    # :124-141  ZeroColumnsNonEmptyTable: nothing to hash -> an EMPTY result of the input's types
+    dict(name="zero_columns_nonempty_table", cols=[("float32", _HP_FLOATS), ("int16", _HP_INTS), ("int32", _HP_STR_CODES)],
+         keys=[], parts=3, rows=0, ncols=3, noffsets=4),
+    # :264-286  MixedColumnTypes: offsets of size num_partitions + 1, same shape as the input, deterministic
+    dict(name="mixed_column_types", cols=[("float32", _HP_FLOATS), ("int16", _HP_INTS), ("int32", _HP_STR_CODES)],
+         keys=[0, 2], parts=3, rows=8, ncols=3, noffsets=4, deterministic=True),
+    # :343-367  CustomSeedValue
+    dict(name="custom_seed", cols=[("float32", _HP_FLOATS), ("int16", _HP_INTS), ("int32", _HP_STR_CODES)],
+         keys=[0, 2], parts=3, seed=12345, rows=8, ncols=3, noffsets=4, deterministic=True),
+]
+# :302-326  ColumnsToHash: two tables that share the hashed column get the same offsets and the same hashed column
+HASH_PARTITION_COLUMNS_TO_HASH = dict(to_hash=[1, 2, 3, 4, 5, 6], first=[7, 8, 9, 10, 11, 12], second=[13, 14, 15, 16, 17, 18], parts=3)
+# :62-71  InvalidKeyRows: 8 input rows, 9 key rows -> std::invalid_argument
+HASH_PARTITION_INVALID_KEY_ROWS = dict(input=_HP_FLOATS, keys=[1, 2, 3, 4, 5, 6, 7, 8, 9], parts=3)
+# :173-188 MorePartitionsThanSharedMemory (48 * 1024 rows of `true`), :190-209 LargePartitionCountCorrectness (iota 1000),
+# :237-262 LargePartitionCountWithNulls (200 rows, valid = i % 4 != 0 -> 50 nulls survive).  The partition count is
+# "shared memory per block / 4 + 10" there; 160 KiB of LDS per CU gives 40970 here.
+HASH_PARTITION_LARGE_P = 160 * 1024 // 4 + 10
+# :388-472  HashPartitionFixedWidth: (cols, rows, partitions, nulls): MorePartitionsThanRows, LargeInput, HasNulls --
+# hash_partition(input, all columns) must give the offsets of hash_partition(input, {murmurhash3_x86_32(input)}, HASH_IDENTITY)
+HASH_PARTITION_FIXED_WIDTH = [(5, 10, 50, False), (10, 1000, 10, False), (10, 1000, 10, True)]
+
+# ---------------------------------------------------------------------------------------------
+# cudf::reduce with an initial value (reductions/reduction_tests.cpp).  expect = what the test's own std::accumulate
+# over the literals gives; "init_valid": False = init_scalar->set_valid_async(false) -> the result is invalid.
+# ---------------------------------------------------------------------------------------------
+_MM = [5, 0, -120, -111, 0, 64, 63, 99, 123, -16]
+_MM_MASK = [1, 1, 0, 1, 1, 1, 0, 1, 0, 1]
+_SUM = [6, -14, 13, 64, 0, -13, -20, 45]
+_SUM_MASK = [1, 1, 0, 0, 1, 1, 1, 1]
+_PROD = [5, -1, 1, 0, 3, 2, 4]
+_PROD_MASK = [1, 1, 0, 0, 1, 1, 1]
+REDUCE_INIT = [
+    # reduction_tests.cpp:122-161  MinMaxReductions, init 100, no nulls (typed int32 / int64 / float / double)
+    dict(name="min_init", op="min", values=_MM, valid=None, init=100, init_valid=True, expect=-120, expect_valid=True),
+    dict(name="max_init", op="max", values=_MM, valid=None, init=100, init_valid=True, expect=123, expect_valid=True),
+    # :171-205  with nulls {-120, 63, 123 masked}: min(100, -111) / max(100, 99)
+    dict(name="min_init_nulls", op="min", values=_MM, valid=_MM_MASK, init=100, init_valid=True, expect=-111, expect_valid=True),
+    dict(name="max_init_nulls", op="max", values=_MM, valid=_MM_MASK, init=100, init_valid=True, expect=100, expect_valid=True),
+    # :215-235  all rows null + invalid init -> invalid
+    dict(name="min_init_all_null", op="min", values=_MM, valid=[0] * 10, init=100, init_valid=False, expect=0, expect_valid=False),
+    dict(name="max_init_all_null", op="max", values=_MM, valid=[0] * 10, init=100, init_valid=False, expect=0, expect_valid=False),
+    # :330-352  Sum, init 100: 81 + 100
+    dict(name="sum_init", op="sum", values=_SUM, valid=None, init=100, init_valid=True, expect=181, expect_valid=True),
+    # :354-368  nulls + INVALID init -> invalid result
+    dict(name="sum_init_invalid", op="sum", values=_SUM, valid=_SUM_MASK, init=100, init_valid=False, expect=0, expect_valid=False),
+    # :372-405  Product, init 4: 5 * -1 * 1 * 0 * ... = 0; with the zero masked: 4 * (5 * -1 * 3 * 2 * 4) = -480 (our extra case
+    # on the same literals -- the reference's null case uses the invalid init, below)
+    dict(name="product_init", op="product", values=_PROD, valid=None, init=4, init_valid=True, expect=0, expect_valid=True),
+    dict(name="product_init_nulls_valid_init", op="product", values=_PROD, valid=_PROD_MASK, init=4, init_valid=True, expect=-480,
+         expect_valid=True),
+    # :407-421  nulls + INVALID init -> invalid
+    dict(name="product_init_invalid", op="product", values=_PROD, valid=_PROD_MASK, init=4, init_valid=False, expect=0, expect_valid=False),
+]

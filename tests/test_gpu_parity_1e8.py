@@ -34,6 +34,15 @@ def _mix(l, r):
         return int(x.sum(dtype=np.uint64)), int(np.bitwise_xor.reduce(x))
 
 
+def _splitmix(x):
+    """the finalizer of splitmix64 (a bijection of uint64): bench.py's join key set"""
+    with np.errstate(over="ignore"):
+        x = x + np.uint64(0x9E3779B97F4A7C15)
+        x = (x ^ (x >> np.uint64(30))) * np.uint64(0xBF58476D1CE4E5B9)
+        x = (x ^ (x >> np.uint64(27))) * np.uint64(0x94D049BB133111EB)
+        return x ^ (x >> np.uint64(31))
+
+
 def test_sort_1e8_matches_c_oracle(gx):
     Column, ops = gx
     rng = np.random.default_rng(42)
@@ -55,8 +64,12 @@ def test_join_1e8_x_4e7_matches_c_oracle(gx):
     from cudf_amd import _lib
     rng = np.random.default_rng(12345)
     nb = 40_000_000
-    build = (rng.permutation(nb).astype(np.int64) * 3 + 1)                       # distinct keys, shuffled
-    probe = rng.integers(0, int(nb / 0.3), N).astype(np.int64) * 3 + 1          # selectivity 0.3
+    # SURVEY 8(d) config 3 / bench.py's key set: a random 64-bit SET -- key(i) = splitmix64-finalizer(i), a bijection, so the
+    # build keys are distinct and hash like random numbers (collision chains, Poisson partition sizes); ids >= nb give the
+    # disjoint 70 % of the probe side.  (Round 2/3 used 3 * perm + 1 here: an arithmetic progression the table's
+    # multiplicative hash spreads perfectly -- VERDICT r3 weak 3.)
+    build = _splitmix(rng.permutation(nb).astype(np.uint64)).view(np.int64)     # distinct keys, shuffled
+    probe = _splitmix(rng.integers(0, int(nb / 0.3), N).astype(np.uint64)).view(np.int64)   # selectivity 0.3
     probe[::1000] = build[7]                                                     # a hot key
     hj = ops.HashJoin(Column.from_numpy(build))
     assert _lib.lib.gx_join_partition_bits(8, hj.table_bytes) >= 10, "the test must run P >= 1024 partitions"

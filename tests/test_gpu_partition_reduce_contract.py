@@ -1,0 +1,202 @@
+"""GPU: cudf::hash_partition / cudf::partition / cudf::reduce(init) through the C++ surface (libcudf.so via the test shim).
+
+The cases are the reference's own (cpp/tests/partitioning/hash_partition_test.cpp:49-472, cpp/tests/reductions/
+reduction_tests.cpp:122-421), transcribed as literals in tests/golden/reference_vectors.py: VERDICT r3 found that
+cudf::hash_partition returned P offsets where the reference returns P + 1 (partitioning.cu:684-688) because the C++ case had
+been written against the implementation; these are written against the reference."""
+import ctypes
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+from oracle import cudf_oracle as orc
+from tests.golden import reference_vectors as gv
+from tests.test_gpu_cpp_parity import Dev, Out, TID, shim  # noqa: F401  (the shim fixture and the device-column helpers)
+
+
+def _call_hash_partition(lib_call, cols, n, keys, parts, seed=0, which=0, ext_key=None, expect_fail=False, valids=None):
+    import ctypes as C
+    ncols = len(cols)
+    devs = [Dev(np.asarray(v, dt), None if valids is None else valids[i]) for i, (dt, v) in enumerate(cols)]
+    dts = (C.c_int * max(ncols, 1))(*[d.tid for d in devs])
+    dps = (C.c_void_p * max(ncols, 1))(*[d.p.value for d in devs])
+    vps = (C.c_void_p * max(ncols, 1))(*[(d.mp.value if d.mp is not None else None) for d in devs])
+    nls = (C.c_int * max(ncols, 1))(*[d.nulls for d in devs])
+    outs = [Out(d.dtype, max(n, 1), mask=True) for d in devs]
+    ops_ = (C.c_void_p * max(ncols, 1))(*[o.p.value for o in outs])
+    ovs = (C.c_void_p * max(ncols, 1))(*[o.mp.value for o in outs])
+    onl = (C.c_int * max(ncols, 1))()
+    kidx = (C.c_int * max(len(keys), 1))(*keys)
+    offs = (C.c_int * (max(parts, 0) + 2))()
+    noffs, rows, ocols = C.c_int(-1), C.c_int(-1), C.c_int(-1)
+    ek = Dev(np.asarray(ext_key, np.uint32)) if ext_key is not None else None
+    args = ("shim_hash_partition", ncols, dts, dps, vps, nls, n, len(keys), kidx, parts, C.c_uint(seed), which, ek.p if ek else None,
+            ops_, ovs, onl, offs, C.byref(noffs), C.byref(rows), C.byref(ocols))
+    if expect_fail:
+        with pytest.raises(AssertionError) as e:
+            lib_call(*args)
+        return str(e.value)
+    lib_call(*args)
+    return dict(offsets=np.array(offs[: noffs.value]), rows=rows.value, ncols=ocols.value,
+                cols=[o.get(rows.value) for o in outs[: ocols.value]], nulls=list(onl[: ocols.value]),
+                valid=[o.valid(rows.value) for o in outs[: ocols.value]])
+
+
+@pytest.mark.parametrize("case", gv.HASH_PARTITION, ids=lambda c: c["name"])
+def test_hash_partition_contract(shim, case):  # noqa: F811
+    n = len(case["cols"][0][1]) if case["cols"] else 0
+    if "throws" in case:
+        msg = _call_hash_partition(shim, case["cols"], n, case["keys"], case["parts"], expect_fail=True)
+        assert case["throws"] in msg
+        return
+    r = _call_hash_partition(shim, case["cols"], n, case["keys"], case["parts"], case.get("seed", 0))
+    assert len(r["offsets"]) == case["noffsets"]                 # num_partitions + 1, ALWAYS (partitioning.cu:684-688, 883-886)
+    assert r["rows"] == case["rows"] and r["ncols"] == case["ncols"]
+    assert r["offsets"][0] == 0 and r["offsets"][-1] == case["rows"] and np.all(np.diff(r["offsets"]) >= 0)
+    if case["rows"]:
+        cols = [np.asarray(v, dt) for dt, v in case["cols"]]
+        order, eoffs = orc.hash_partition([cols[i] for i in case["keys"]], case["parts"], case.get("seed", 0))
+        np.testing.assert_array_equal(r["offsets"], eoffs)
+        for got, c in zip(r["cols"], cols):                      # stable inside a partition: the oracle's gather order
+            assert got.tobytes() == c[order].tobytes()
+        if case.get("deterministic"):
+            r2 = _call_hash_partition(shim, case["cols"], n, case["keys"], case["parts"], case.get("seed", 0), which=1)
+            np.testing.assert_array_equal(r["offsets"], r2["offsets"])
+            for a, b in zip(r["cols"], r2["cols"]):
+                assert a.tobytes() == b.tobytes()
+
+
+def test_hash_partition_columns_to_hash_and_invalid_key_rows(shim):  # noqa: F811
+    c = gv.HASH_PARTITION_COLUMNS_TO_HASH
+    a = _call_hash_partition(shim, [("int32", c["to_hash"]), ("int32", c["first"])], 6, [0], c["parts"])
+    b = _call_hash_partition(shim, [("int32", c["to_hash"]), ("int32", c["second"])], 6, [0], c["parts"])
+    assert len(a["offsets"]) == c["parts"] + 1
+    np.testing.assert_array_equal(a["offsets"], b["offsets"])
+    np.testing.assert_array_equal(a["cols"][0], b["cols"][0])
+    np.testing.assert_array_equal(b["cols"][1] - a["cols"][1], 6)    # the payload columns followed the same permutation
+    k = gv.HASH_PARTITION_INVALID_KEY_ROWS
+    d, kk = Dev(np.asarray(k["input"], np.float32)), Dev(np.asarray(k["keys"], np.int16))
+    with pytest.raises(AssertionError, match="std::invalid_argument"):
+        shim("shim_hash_partition_key_rows", d.tid, d.p, d.n, kk.tid, kk.p, kk.n, k["parts"])
+
+
+def test_hash_partition_large_partition_counts(shim):  # noqa: F811
+    P = gv.HASH_PARTITION_LARGE_P
+    # :173-188 MorePartitionsThanSharedMemory: 48 Ki rows of `true`
+    n = 48 * 1024
+    r = _call_hash_partition(shim, [("uint8", np.ones(n, np.uint8))], n, [0], P)   # (BOOL8 and UINT8 hash one byte alike)
+    assert r["rows"] == n and len(r["offsets"]) == P + 1 and r["offsets"][-1] == n and r["offsets"][0] == 0
+    # :190-209 LargePartitionCountCorrectness: offsets monotone, output a permutation of the input
+    v = np.arange(1000, dtype=np.int32)
+    r = _call_hash_partition(shim, [("int32", v)], 1000, [0], P)
+    assert np.all(np.diff(r["offsets"]) >= 0) and r["offsets"][0] == 0 and r["offsets"][-1] == 1000 and len(r["offsets"]) == P + 1
+    np.testing.assert_array_equal(np.sort(r["cols"][0]), v)
+    order, eoffs = orc.hash_partition([v], P)
+    np.testing.assert_array_equal(r["offsets"], eoffs)
+    np.testing.assert_array_equal(r["cols"][0], v[order])
+    # :237-262 LargePartitionCountWithNulls: the null count survives the regrouping
+    w = np.arange(200, dtype=np.int32)
+    valid = (w % 4) != 0
+    r = _call_hash_partition(shim, [("int32", w), ("int64", w.astype(np.int64) * 3)], 200, [0], P, valids=[valid, valid])
+    assert r["rows"] == 200 and len(r["offsets"]) == P + 1 and r["offsets"][-1] == 200 and np.all(np.diff(r["offsets"]) >= 0)
+    assert r["nulls"] == [50, 50]
+    order, eoffs = orc.hash_partition([w], P, valids=[valid])
+    np.testing.assert_array_equal(r["offsets"], eoffs)
+    np.testing.assert_array_equal(r["valid"][0], valid[order])
+    np.testing.assert_array_equal(r["cols"][0][r["valid"][0]], w[order][valid[order]])
+
+
+@pytest.mark.parametrize("dtype", ["int8", "int32", "uint16", "int64", "float32", "float64"])
+@pytest.mark.parametrize("ncols,rows,parts,nulls", gv.HASH_PARTITION_FIXED_WIDTH)
+def test_hash_partition_fixed_width_matches_identity_of_row_hash(shim, dtype, ncols, rows, parts, nulls):  # noqa: F811
+    """hash_partition_test.cpp:388-472: hashing the columns directly == HASH_IDENTITY over the externally computed row hashes;
+    both equal the oracle's partition of the same rows."""
+    v = np.arange(rows).astype(dtype)
+    valid = (np.arange(rows) % 4) != 0 if nulls else None
+    cols = [(dtype, v)] * ncols
+    valids = [valid] * ncols if nulls else None
+    a = _call_hash_partition(shim, cols, rows, list(range(ncols)), parts, valids=valids)
+    h = orc.row_hash([v] * ncols, valids)
+    b = _call_hash_partition(shim, cols, rows, [], parts, which=2, ext_key=h, valids=valids)
+    assert len(a["offsets"]) == parts + 1 and a["offsets"][0] == 0 and a["offsets"][-1] == rows
+    np.testing.assert_array_equal(a["offsets"], b["offsets"])
+    order, eoffs = orc.hash_partition([v] * ncols, parts, valids=valids)
+    np.testing.assert_array_equal(a["offsets"], eoffs)
+    for got_a, got_b in zip(a["cols"], b["cols"]):
+        if nulls:
+            np.testing.assert_array_equal(a["valid"][0], valid[order])
+            m = valid[order]
+            assert got_a[m].tobytes() == v[order][m].tobytes() and got_b[m].tobytes() == got_a[m].tobytes()
+        else:
+            assert got_a.tobytes() == v[order].tobytes() and got_b.tobytes() == got_a.tobytes()
+
+
+def test_partition_by_map(shim):  # noqa: F811
+    """cudf::partition (partitioning.hpp:44-78; the docstring's example): num_partitions + 1 offsets, stable inside a partition"""
+    import ctypes as C
+    rng = np.random.default_rng(3)
+    for n, parts in ((0, 3), (12, 5), (100_003, 7), (1_000_000, 300)):
+        v = rng.integers(-2**40, 2**40, n, dtype=np.int64)
+        m = rng.integers(0, parts, n).astype(np.int32)
+        d, dm, out = Dev(v), Dev(m), Out(np.int64, max(n, 1))
+        offs = (C.c_int * (parts + 2))()
+        noffs, rows = C.c_int(), C.c_int()
+        shim("shim_partition", d.tid, d.p, n, dm.p, parts, out.p, offs, C.byref(noffs), C.byref(rows))
+        assert noffs.value == parts + 1 and rows.value == n
+        order = np.argsort(m, kind="stable")
+        np.testing.assert_array_equal(np.array(offs[: parts + 1]), np.concatenate([[0], np.cumsum(np.bincount(m, minlength=parts))]))
+        np.testing.assert_array_equal(out.get(n), v[order])
+
+
+_KIND = {"sum": 0, "product": 2, "min": 3, "max": 4, "mean": 10}   # cudf::aggregation::Kind (include/cudf/aggregation.hpp)
+
+
+def _reduce_init(shim_call, vals, mask, op, out_dtype, init, init_dtype, init_valid, has_init=True):
+    import ctypes as C
+    d = Dev(vals, mask)
+    bits = C.c_ulonglong(int(np.asarray([init], init_dtype).view(f"u{np.dtype(init_dtype).itemsize}")[0])) if has_init else C.c_ulonglong(0)
+    ob, ov = C.c_ulonglong(0), C.c_int(-1)
+    shim_call("shim_reduce_init", d.tid, d.p, d.mp, d.nulls, d.n, _KIND[op], TID[np.dtype(out_dtype)], 1 if has_init else 0, TID[np.dtype(init_dtype)],
+              bits, 1 if init_valid else 0, C.byref(ob), C.byref(ov))
+    val = np.asarray([ob.value], np.uint64).view(np.uint8)[: np.dtype(out_dtype).itemsize].view(out_dtype)[0]
+    return val, bool(ov.value)
+
+
+@pytest.mark.parametrize("dtype", ["int32", "int64", "float32", "float64"])
+@pytest.mark.parametrize("case", gv.REDUCE_INIT, ids=lambda c: c["name"])
+def test_reduce_init_reference_vectors(shim, case, dtype):  # noqa: F811
+    vals, mask = gv.col(case["values"], dtype, case["valid"])
+    got, ok = _reduce_init(shim, vals, mask, case["op"], dtype, case["init"], dtype, case["init_valid"])
+    assert ok == case["expect_valid"]
+    if ok:
+        assert got == case["expect"]
+        e, eok = orc.reduce(vals, case["op"], mask, None, init=case["init"], init_valid=case["init_valid"])
+        assert eok and got == e
+
+
+def test_reduce_init_contract_and_scale(shim):  # noqa: F811
+    rng = np.random.default_rng(11)
+    v = rng.integers(-1000, 1000, 3_000_017).astype(np.int32)
+    m = rng.random(len(v)) > 0.1
+    # int32 column summed in INT64 with an int32 initial value: the initial value is cast to the result type (simple.cuh:56-66)
+    got, ok = _reduce_init(shim, v, m, "sum", np.int64, 2**31 - 1, np.int32, True)
+    assert ok and got == int(v[m].astype(np.int64).sum()) + 2**31 - 1
+    got, ok = _reduce_init(shim, v, m, "min", np.int32, -5000, np.int32, True)
+    assert ok and got == -5000
+    got, ok = _reduce_init(shim, v, m, "max", np.int32, -5000, np.int32, True)
+    assert ok and got == int(v[m].max())
+    # no initial value through the same overload == the plain reduce
+    got, ok = _reduce_init(shim, v, m, "sum", np.int64, 0, np.int32, True, has_init=False)
+    assert ok and got == int(v[m].astype(np.int64).sum())
+    f = rng.standard_normal(1_000_003)
+    got, ok = _reduce_init(shim, f, None, "sum", np.float64, 0.5, np.float64, True)
+    e, _ = orc.reduce(f, "sum", None, np.float64, init=0.5)
+    assert ok and orc.ulp_diff(np.array([got]), np.array([e]))[0] <= 1
+    # an initial value of another type: cudf::data_type_error (reductions.cpp:488-490)
+    with pytest.raises(AssertionError, match="data_type_error"):
+        _reduce_init(shim, v, m, "sum", np.int64, 1, np.int64, True)
+    # MEAN takes no initial value: std::invalid_argument (reductions.cpp:492-499)
+    with pytest.raises(AssertionError, match="invalid_argument"):
+        _reduce_init(shim, v, m, "mean", np.float64, 1, np.int32, True)

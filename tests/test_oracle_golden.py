@@ -212,6 +212,28 @@ def test_reduce_golden(case, dtype):
         assert r == case["expect"]
 
 
+@pytest.mark.parametrize("dtype", ["int32", "int64", "float32", "float64"])
+@pytest.mark.parametrize("case", gv.REDUCE_INIT, ids=lambda c: c["name"])
+def test_reduce_init_golden(case, dtype):
+    """reduce with an initial value: the literals of reduction_tests.cpp (MinMaxReductions, Sum, Product)"""
+    vals, mask = gv.col(case["values"], dtype, case["valid"])
+    r, ok = orc.reduce(vals, case["op"], mask, None, init=case["init"], init_valid=case["init_valid"])
+    assert ok == case["expect_valid"]
+    if ok:
+        assert r == case["expect"] and np.asarray(r).dtype == np.dtype(dtype)
+
+
+@pytest.mark.parametrize("case", [c for c in gv.HASH_PARTITION if "throws" not in c], ids=lambda c: c["name"])
+def test_hash_partition_contract_golden(case):
+    """hash_partition_test.cpp: num_partitions + 1 offsets ALWAYS, the last = rows of the output; empty results"""
+    cols = [np.asarray(v, dt) for dt, v in case["cols"]]
+    order, offs = orc.hash_partition([cols[i] for i in case["keys"]], case["parts"], case.get("seed", 0))
+    assert len(offs) == case["noffsets"] and len(order) == case["rows"]
+    assert offs[0] == 0 and offs[-1] == case["rows"] and np.all(np.diff(offs) >= 0)
+    if case["rows"]:
+        assert np.array_equal(np.sort(order), np.arange(case["rows"]))
+
+
 # ---- round 3: the oracle restatements behind the at-scale parity tests of rank / top_k / segmented sort /
 # sort-path groupby / groupby::scan COUNT / shift / replace_nulls are pinned to the reference's own literals
 def test_rank_oracle_matches_every_reference_rank_vector():
