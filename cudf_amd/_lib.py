@@ -89,6 +89,7 @@ _PROTOS = {
     "gx_join_profile": (_i, [_i]),
     "gx_join_profile_read": (_i, [ctypes.POINTER(ctypes.c_float)]),
     "gx_join_set_scatter_tile": (None, [_i]),
+    "gx_join_set_build_kernel": (None, [_i]),
     "gx_join_set_probe_kernel": (None, [_i]),
     "gx_join_set_partition_mode": (None, [_i, _i]),
     "gx_bitmask_copy": (_i, [_p, _i64, _p, _i64, _i64, _p]),

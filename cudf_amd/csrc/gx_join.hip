@@ -1543,6 +1543,159 @@ __global__ void __launch_bounds__(PJ_BT) k_pj_build(const K* __restrict__ pkeys,
 }
 
 // ================================================================================================
+// Round 4: the sub-table build.  k_pj_build above claims slots with device-scope CAS on the table itself -- memory-side
+// atomics, one read-modify-write of a line per row (12.9 GB of HBM traffic for 1.6 GB of slots at 1e8 rows) -- and k_tags then
+// reads the whole table back (4.5 GB) to derive the tags.  But a slot's 4-bit tag is non-zero exactly when the slot is
+// occupied, so the TAGS are the occupancy map: one workgroup owns a sub-table (2^17 slots = one partition), keeps its 64 KiB
+// of tags in LDS, claims a slot with an LDS compare-and-swap on the tag word (first zero nibble at or behind the key's home,
+// SWAR over the 8 nibbles of a word), stores the 16-byte slot straight to its final place (nobody reads it back here) and
+// writes the finished tag block out in one coalesced run.  No global atomic, no table read.  A chain that runs off the end of
+// the sub-table (a few hundred rows per 1e8; everything for heavily repeated keys) is parked in a list and inserted afterwards
+// by k_bs_fixup with device-scope CAS on the GLOBAL tag words, starting at the first slot of the next sub-table -- every slot
+// from the key's home to the end of its own sub-table is occupied, so the linear-probe invariant holds.
+// ================================================================================================
+constexpr int BS_BT   = 512;
+constexpr int BS_LIST = 1 << 18;  // parked rows kept as positions; beyond that they are marked in place (row -> ~row)
+struct alignas(128) BuildFix {
+  unsigned int count;  // rows whose chain left their sub-table
+  unsigned int pad[31];
+  unsigned int list[BS_LIST];  // their positions in the partitioned arrays
+};
+
+template <typename K>
+__device__ __forceinline__ void store_slot(Slot<K>* s, K key, int32_t row);
+template <>
+__device__ __forceinline__ void store_slot<uint64_t>(Slot<uint64_t>* s, uint64_t key, int32_t row)
+{
+  *reinterpret_cast<uint4*>(s) = make_uint4((uint32_t)key, (uint32_t)(key >> 32), (uint32_t)row, 0u);
+}
+template <>
+__device__ __forceinline__ void store_slot<uint32_t>(Slot<uint32_t>* s, uint32_t key, int32_t row)
+{
+  *reinterpret_cast<uint2*>(s) = make_uint2(key, (uint32_t)row);
+}
+// LSB of every nibble of v that is zero, restricted to nibbles >= first
+__device__ __forceinline__ uint32_t zero_nibbles_from(uint32_t v, uint32_t first)
+{
+  const uint32_t any = v | (v >> 1) | (v >> 2) | (v >> 3);
+  return ~any & 0x11111111u & (0xFFFFFFFFu << (4u * first));
+}
+
+template <typename K>
+__global__ void __launch_bounds__(BS_BT) k_bs_build(const K* __restrict__ pkeys, int32_t* __restrict__ pidx, const PjPlan* __restrict__ plan,
+                                                    Slot<K>* __restrict__ slots, uint8_t* __restrict__ tags, uint32_t log2cap, BuildFix* fix)
+{
+  constexpr uint32_t SUB   = 1u << PJ_SUB_LOG2;
+  constexpr uint32_t WORDS = SUB / 8;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  uint32_t* s_tags = reinterpret_cast<uint32_t*>(smem);
+  const unsigned tid  = threadIdx.x;
+  const unsigned part = blockIdx.x;
+  for (uint32_t i = tid; i < WORDS / 4; i += BS_BT) reinterpret_cast<uint4*>(s_tags)[i] = make_uint4(0u, 0u, 0u, 0u);
+  __syncthreads();
+  const unsigned long long p0 = plan->offset[part], p1 = plan->offset[part + 1];
+  Slot<K>* sub = slots + ((size_t)part << PJ_SUB_LOG2);
+  constexpr int U = 4;
+  for (unsigned long long i0 = p0 + tid; i0 < p1; i0 += (unsigned long long)BS_BT * U) {
+    K key[U];
+    int32_t row[U];
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const unsigned long long i = i0 + (unsigned long long)u * BS_BT;
+      key[u] = i < p1 ? __builtin_nontemporal_load(&pkeys[i]) : K(0);
+      row[u] = i < p1 ? __builtin_nontemporal_load(&pidx[i]) : 0;
+    }
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const unsigned long long i = i0 + (unsigned long long)u * BS_BT;
+      if (i >= p1) continue;
+      const uint32_t t = tag_of<K>(key[u], log2cap);
+      uint32_t pos     = (uint32_t)slot_of<K>(key[u], log2cap) & (SUB - 1);
+      uint32_t w = pos >> 3, first = pos & 7u;
+      bool placed = false;
+      while (w < WORDS) {
+        uint32_t v = s_tags[w];
+        for (;;) {
+          const uint32_t z = zero_nibbles_from(v, first);
+          if (z == 0) break;
+          const uint32_t nib = (uint32_t)__builtin_ctz(z) >> 2;
+          const uint32_t old = atomicCAS(&s_tags[w], v, v | (t << (4u * nib)));
+          if (old == v) {
+            store_slot<K>(&sub[(w << 3) + nib], key[u], row[u]);
+            placed = true;
+            break;
+          }
+          v = old;
+        }
+        if (placed) break;
+        ++w;
+        first = 0;
+      }
+      if (!placed) {  // the chain ran off the end of this sub-table
+        const unsigned int e = atomicAdd(&fix->count, 1u);
+        if (e < (unsigned int)BS_LIST) fix->list[e] = (unsigned int)i;
+        else pidx[i] = ~row[u];  // (rows and payloads are >= 0)
+      }
+    }
+  }
+  __syncthreads();
+  uint4* out = reinterpret_cast<uint4*>(tags + ((size_t)part << (PJ_SUB_LOG2 - 1)));
+  for (uint32_t i = tid; i < WORDS / 4; i += BS_BT) out[i] = reinterpret_cast<const uint4*>(s_tags)[i];
+}
+
+// one parked row: claim the first free slot at or behind `start` through the GLOBAL tag words (device-scope CAS), write the slot
+template <typename K>
+__device__ __forceinline__ void bs_insert_global(K key, int32_t row, uint64_t start, Slot<K>* slots, uint32_t* tagw, uint32_t log2cap)
+{
+  const uint64_t mask = (1ull << log2cap) - 1;
+  const uint32_t t    = tag_of<K>(key, log2cap);
+  uint64_t pos        = start & mask;
+  for (;;) {
+    const uint64_t w = pos >> 3;
+    uint32_t v       = __hip_atomic_load(&tagw[w], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    uint32_t first   = (uint32_t)pos & 7u;
+    for (;;) {
+      const uint32_t z = zero_nibbles_from(v, first);
+      if (z == 0) break;
+      const uint32_t nib = (uint32_t)__builtin_ctz(z) >> 2;
+      const uint32_t old = atomicCAS(&tagw[w], v, v | (t << (4u * nib)));
+      if (old == v) {
+        store_slot<K>(&slots[(w << 3) + nib], key, row);
+        return;
+      }
+      v = old;
+    }
+    pos = ((w + 1) << 3) & mask;
+  }
+}
+template <typename K>
+__global__ void __launch_bounds__(256) k_bs_fixup(const K* __restrict__ pkeys, const int32_t* __restrict__ pidx, int64_t n, Slot<K>* slots,
+                                                  uint8_t* tags, uint32_t log2cap, const BuildFix* __restrict__ fix, int scan_all)
+{
+  const unsigned int cnt = fix->count;
+  if (cnt == 0 || (scan_all && cnt <= (unsigned int)BS_LIST)) return;
+  uint32_t* tagw       = reinterpret_cast<uint32_t*>(tags);
+  const int64_t stride = (int64_t)gridDim.x * 256;
+  const int64_t gid    = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  auto next_sub = [&](K key) { return ((slot_of<K>(key, log2cap) >> PJ_SUB_LOG2) + 1) << PJ_SUB_LOG2; };
+  if (!scan_all) {
+    const int64_t m = cnt < (unsigned int)BS_LIST ? cnt : BS_LIST;
+    for (int64_t e = gid; e < m; e += stride) {
+      const unsigned int i = fix->list[e];
+      const K key          = pkeys[i];
+      bs_insert_global<K>(key, pidx[i], next_sub(key), slots, tagw, log2cap);
+    }
+  } else {  // the list overflowed: the surplus rows were marked in place
+    for (int64_t i = gid; i < n; i += stride) {
+      const int32_t r = pidx[i];
+      if (r >= 0) continue;
+      const K key = pkeys[i];
+      bs_insert_global<K>(key, ~r, next_sub(key), slots, tagw, log2cap);
+    }
+  }
+}
+
+// ================================================================================================
 // Round 3: the partition pass without its histogram, persistent, and the probe over region tables.
 //
 // (1) No k_pj_hist.  Region e = partition * PJ_NR + range owns a fixed slot of `cap` rows in the partitioned arrays
@@ -2298,6 +2451,7 @@ static inline void jprof_mark(int i, hipStream_t s)
   if (g_jprof.enabled) (void)hipEventRecord(g_jprof.ev[i], s);
 }
 static thread_local int g_pj_probe = 0; // probe kernel: 0 = default (software-pipelined tag probe), 1 = round-1 tag probe (A/B knob)
+static thread_local int g_pj_build = 0; // partitioned build: 0 = sub-table build with the tags in LDS (round 4, default), 1 = round-2 kernel (global CAS + k_tags) (A/B knob)
 static thread_local int g_pj_tile = 0;  // scatter tile rows: 0 = default, else 4096 / 8192 / 16384 (A/B knob)
 static thread_local int g_pj_probe_early = 0;  // round-3 probe: 1 = rows of a piece requested at the top of the trip, 0 = at its end (default: with the
                                   // deferral queue the early form no longer fits 128 VGPRs) (A/B knob)
@@ -2600,6 +2754,7 @@ int build_partitioned_impl(const void* keys, int64_t n, void* table, size_t tabl
   PjPlan* plan  = c.take<PjPlan>(1);
   K* pkeys      = c.take<K>((size_t)n);
   int32_t* pidx = c.take<int32_t>((size_t)n);
+  BuildFix* fix = c.take<BuildFix>(1);
   if (!tmp) {
     *tmp_bytes = c.total();
     return 0;
@@ -2613,6 +2768,23 @@ int build_partitioned_impl(const void* keys, int64_t n, void* table, size_t tabl
   if (n == 0) return launch_tags<K>(table, lg, s);
   int rc = pj_partition<K>(static_cast<const K*>(keys), n, pbits, plan, pkeys, pidx, PJ_CHUNK, s, false, 0, payload);
   if (rc) return rc;
+  if (g_pj_build == 0 && (int)lg - pbits == PJ_SUB_LOG2) {  // one workgroup per sub-table: tags in LDS are the occupancy map
+    uint8_t* tags = reinterpret_cast<uint8_t*>(base + sizeof(TableHeader) + (sizeof(Slot<K>) << lg));
+    auto* slots   = reinterpret_cast<Slot<K>*>(base + sizeof(TableHeader));
+    GX_HIP_TRY(hipMemsetAsync(fix, 0, 128, s));
+    const size_t lds = (size_t)(1u << PJ_SUB_LOG2) / 2;
+    auto kb          = k_bs_build<K>;
+    static bool attr_set = false;  // per instantiation
+    if (!attr_set) {
+      GX_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(kb), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+      attr_set = true;
+    }
+    hipLaunchKernelGGL(kb, dim3(1u << pbits), dim3(BS_BT), lds, s, pkeys, pidx, plan, slots, tags, lg, fix);
+    hipLaunchKernelGGL((k_bs_fixup<K>), dim3(256), dim3(256), 0, s, pkeys, pidx, n, slots, tags, lg, fix, 0);
+    hipLaunchKernelGGL((k_bs_fixup<K>), dim3(1024), dim3(256), 0, s, pkeys, pidx, n, slots, tags, lg, fix, 1);
+    GX_LAUNCH_CHECK();
+    return 0;
+  }
   const int64_t max_chunks = div_up(n, PJ_CHUNK) + (1 << pbits);
   hipLaunchKernelGGL((k_pj_build<K>), dim3((unsigned)max_chunks), dim3(PJ_BT), 0, s, pkeys, pidx, plan, pbits,
                      reinterpret_cast<Slot<K>*>(base + sizeof(TableHeader)), lg);
@@ -2902,6 +3074,7 @@ void gx_join_set_partition_mode(int speculative, int early_loads)
   gx::join::g_pj_defer       = (early_loads & 2) ? 1 : 0;  // bit 1 of early_loads: park unsettled rows in the per-wave queue (A/B)
 }
 
+void gx_join_set_build_kernel(int which) { gx::join::g_pj_build = which == 1 ? 1 : 0; }
 void gx_join_set_scatter_tile(int rows)
 {
   gx::join::g_pj_tile = (rows == 4096 || rows == 8192 || rows == 16384) ? rows : 0;
