@@ -74,6 +74,7 @@ def parse():
     ap.add_argument("--key-range", type=int, nargs=2, default=None, metavar=("LO", "HI"),
                     help="sort: keys uniform in [LO, HI) instead of the full int64 range (the reference's own "
                          "benchmark distribution is 100 10001: benchmarks/sort/sort.cpp:24-26)")
+    ap.add_argument("--hot-copies", type=float, default=0, help="sort: this many rows carry ONE value (a hot value: zeros, a sentinel)")
     ap.add_argument("--through-cpp", action="store_true",
                     help="also time cudf::sort / hash_join::inner_join / groupby::aggregate through the C++ surface "
                          "(tests/cpp/cudf_api_bench, default pooled mr) and report the ratio to the C-ABI numbers")
@@ -315,6 +316,12 @@ def bench_sort(c, pairs=False):
         keys = ops.random_column(np.int64, n, seed=42 + c.rank, lo=a.key_range[0], hi=a.key_range[1])
     else:
         keys = ops.random_column(np.int64, n, seed=42 + c.rank)
+    if a.hot_copies:
+        # a HOT VALUE: `hot_copies` rows (every (n // hot_copies)-th, so every input range holds its share) carry one key -- the
+        # zeros / sentinel / default-id case that used to send the whole column to the LSD passes (VERDICT r3 "missing" 2)
+        kt = c.as_tensor(keys, c.torch.int64)
+        kt[:: max(1, n // int(a.hot_copies))] = 1234567890123
+        del kt
     out = c.Column.empty(np.int32 if pairs else np.int64, n)
     nb = ctypes.c_size_t(0)
     if pairs:
@@ -329,6 +336,8 @@ def bench_sort(c, pairs=False):
     workload = f"{n:.0e}-row int64 " + ("sorted_order (radix sort pairs, int32 payload)" if pairs else "radix sort (cudf::sort, keys only)")
     if a.key_range:
         workload += f", keys uniform in [{a.key_range[0]}, {a.key_range[1]})"
+    if a.hot_copies:
+        workload += f", {int(a.hot_copies):.0e} copies of one value"
 
     prof = {"pass_ms": 0.0, "hist_ms": 0.0, "launches": 0, "hyb": [0.0] * 4, "hyb_n": 0}
 
@@ -383,6 +392,9 @@ def bench_sort(c, pairs=False):
     cst = ctypes.c_int32(0)
     lib.gx_sort_cursor_state(c.ptr(tmp), ctypes.byref(cst), c.stream)
     sort_info["cursor_path_state"] = cst.value  # 3: sample-planned, atomic-cursor partition levels; 0 / 2: look-back path
+    bigi = (ctypes.c_int64 * 3)()
+    lib.gx_sort_big_info(c.ptr(tmp), bigi, c.stream)
+    sort_info["big_cells"] = {"sorted_through_x": int(bigi[0]), "cells": int(bigi[1]), "keys": int(bigi[2])}
     cursor = cst.value == 3
     hist_ms = prof["hist_ms"] / nsteps_prof
     local_sort_ms = ms_per_step if c.world == 1 else hist_ms + (sum(prof["hyb"]) if prof["hyb_n"] else prof["pass_ms"])

@@ -54,6 +54,7 @@ _PROTOS = {
     "gx_sort_set_cell": (None, [_i]),
     "gx_sort_set_lookback": (None, [_i]),
     "gx_sort_info": (_i, [_p, ctypes.POINTER(ctypes.c_int32), _p]),
+    "gx_sort_big_info": (_i, [_p, ctypes.POINTER(ctypes.c_int64), _p]),
     "gx_gather": (_i, [_i, _p, _p, _i64, _p, _i64, _i, _p, _p, _p]),
     "gx_gather_global_rows": (_i, [_p, _i64, _p, _i64, _i, _p, _p, _p, _p]),
     "gx_gather_global_rows_dev": (_i, [_p, _i64, _p, _i64, _i, _p, _p, _p]),

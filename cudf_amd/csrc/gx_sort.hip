@@ -70,6 +70,17 @@ struct HybridPlan {
   uint32_t rhist[NRANGE][MAX_PASSES][BINS];  // range-resolved byte histograms (k_hist_all, LSD path)
   alignas(128) uint32_t todo_count;          // k_local_place: cells left to k_local_sort (a line of its own: atomics)
   uint32_t todo_pad[31];
+  // Round 4, BIG cells of the cursor path: a cell that outgrew its slot (a hot value: 1e6 copies of one key land in ONE cell
+  // whatever the digits) costs that cell, not the column.  Its true size is known (the level-1 cursors count every key, also the
+  // dropped surplus), so every OTHER cell is sorted as usual; the big cells' keys are fetched again from the level-1 input
+  // (only the level-0 buckets that hold one are re-read), compacted into X, X is sorted by the LSD passes -- the same kernels
+  // as the whole-column fallback, run on X with a DEVICE-side length -- and copied into the cells' output ranges.
+  int32_t big;        // k_plan2: some cell outgrew its slot
+  int32_t lsd_mode;   // k_big_plan: 1 = the LSD passes sort X (kbufB, lsd_n keys) instead of the whole column
+  uint32_t nbig;      // big cells
+  uint32_t big_pad;
+  unsigned long long lsd_n;  // keys in X
+  uint32_t bigbucket[BINS];  // level-0 buckets that hold a big cell (the rescue pass re-reads only these)
 };
 
 // Round 3, the CURSOR path (integer keys, keys only): plan of the speculative passes, see k_hf_scatter
@@ -120,11 +131,16 @@ struct SortPlan {
 // ------------------------------------------------------------------------------------------
 template <typename KeyT, int KIND>
 __global__ void __launch_bounds__(BT) k_hist_all(const KeyT* __restrict__ in, int64_t n, KeyT desc_mask,
-                                                 SortPlan* plan, int64_t range_rows)
+                                                 SortPlan* plan, int64_t range_rows, const KeyT* __restrict__ inB = nullptr)
 {
   // block b histograms rows of input range b % NRANGE (range r = rows [r, r+1) * range_rows); k_plan
   // sums the ranges.  The hybrid's first partition pass runs one look-back chain per range.
-  if (plan->hy.ok) return;  // the hybrid path sorted the column: no LSD pass will run
+  if (plan->hy.ok && !plan->hy.lsd_mode) return;  // the hybrid path sorted the column: no LSD pass will run
+  if (plan->hy.lsd_mode) {  // the LSD passes sort X, the compacted big cells of the cursor path (HybridPlan::big)
+    in         = inB;
+    n          = (int64_t)plan->hy.lsd_n;
+    range_rows = div_up(div_up(n, (int64_t)NRANGE), (int64_t)GX_WAVE) * GX_WAVE;
+  }
   const int range      = blockIdx.x % NRANGE;
   const int64_t rbegin = (int64_t)range * range_rows < n ? (int64_t)range * range_rows : n;
   const int64_t rend   = (range == NRANGE - 1) ? n : (rbegin + range_rows < n ? rbegin + range_rows : n);
@@ -349,7 +365,8 @@ __global__ void __launch_bounds__(BINS) k_plan(SortPlan* plan, int npass, int64_
 {
   __shared__ uint32_t s_tmp[BINS / GX_WAVE + 1];
   __shared__ int s_skip[MAX_PASSES];
-  if (plan->hy.ok) return;  // the hybrid path sorted the column (k_plan2 marked every pass as skipped)
+  if (plan->hy.ok && !plan->hy.lsd_mode) return;  // the hybrid path sorted the column (k_plan2 marked every pass as skipped)
+  if (plan->hy.lsd_mode) n = (int64_t)plan->hy.lsd_n;
   const int t = threadIdx.x;
   for (int p = 0; p < npass; ++p) {
     uint32_t c = 0;
@@ -386,6 +403,7 @@ __global__ void __launch_bounds__(BINS) k_plan(SortPlan* plan, int npass, int64_
 // ------------------------------------------------------------------------------------------
 struct PassArgs {
   void* kbuf[3];
+  void* kbufB[3];     // the buffers of the X sort (HybridPlan::lsd_mode): X | work 1 (the sorted X ends here) | work 2
   uint32_t* vbuf[3];  // vbuf[0] may be null: iota
   SortPlan* plan;
   unsigned long long* status;  // [ntiles][256] look-back granules (algorithm 0)
@@ -443,8 +461,11 @@ __global__ void __launch_bounds__(BT, 4) k_radix_pass(PassArgs a)
   if (plan->pass_skip[pass]) return;  // constant digit: the pass would be the identity
   const int src_sel      = plan->pass_src[pass];
   const int dst_sel      = plan->pass_dst[pass];
-  const KeyT* kin        = static_cast<const KeyT*>(a.kbuf[src_sel]);
-  KeyT* kout             = static_cast<KeyT*>(a.kbuf[dst_sel]);
+  const bool mode_b      = plan->hy.lsd_mode != 0;  // X instead of the column, its length on the device
+  const int64_t a_n      = mode_b ? (int64_t)plan->hy.lsd_n : a.n;
+  const int64_t a_ntiles = mode_b ? div_up(a_n, (int64_t)(BT * KPT)) : a.ntiles;
+  const KeyT* kin        = static_cast<const KeyT*>(mode_b ? a.kbufB[src_sel] : a.kbuf[src_sel]);
+  KeyT* kout             = static_cast<KeyT*>(mode_b ? a.kbufB[dst_sel] : a.kbuf[dst_sel]);
   const uint32_t* vin    = HAS_VAL ? a.vbuf[src_sel] : nullptr;
   uint32_t* vout         = HAS_VAL ? a.vbuf[dst_sel] : nullptr;
   const KeyT desc_mask   = (KeyT)a.desc_mask;
@@ -454,13 +475,16 @@ __global__ void __launch_bounds__(BT, 4) k_radix_pass(PassArgs a)
   const unsigned w       = tid / GX_WAVE;
   const unsigned epoch   = (unsigned)pass + 1u;
 
+  // X mode: the grid is sized for the column, X is usually a sliver of it -- the surplus workgroups leave before they take a ticket
+  // (a ticket is a device-scope atomic on ONE word: 15 000 of them per pass cost more than sorting a small X)
+  if (mode_b && (int64_t)blockIdx.x * (MULTI ? PASS_TPB : 1) >= a_ntiles) return;
   for (int it = 0; it < (MULTI ? PASS_TPB : 1); ++it) {
   int64_t tile;
   if (LOOKBACK) {
     if (tid == 0) s_misc[0] = atomicAdd(&plan->cnt.tickets[pass].v, 1u);
     __syncthreads();
     tile = s_misc[0];
-    if (MULTI && tile >= a.ntiles) return;  // tickets only grow
+    if (tile >= a_ntiles) return;  // tickets only grow (MULTI; and the grid is sized for the column when X is sorted)
   } else if (a.order_mode == 2) {
     if (tid == 0) s_misc[0] = atomicAdd(&plan->cnt.tickets[pass].v, 1u);
     __syncthreads();
@@ -469,7 +493,7 @@ __global__ void __launch_bounds__(BT, 4) k_radix_pass(PassArgs a)
     tile = a.order_mode == 1 ? (int64_t)blockIdx.x : xcd_swizzle(blockIdx.x, gridDim.x);
   }
   const int64_t base = tile * TILE;
-  const int nvalid   = (int)((a.n - base < (int64_t)TILE) ? (a.n - base) : (int64_t)TILE);
+  const int nvalid   = (int)((a_n - base < (int64_t)TILE) ? (a_n - base) : (int64_t)TILE);
 
   // ---- load (wave-striped: wave w owns a contiguous run, lanes consecutive -> 512 B per load)
   KeyT key[KPT];
@@ -582,7 +606,7 @@ __global__ void __launch_bounds__(BT, 4) k_radix_pass(PassArgs a)
       }
       gbase = plan->gbin[pass][tid] + prefix;
     } else {
-      gbase = a.tile_off[(int64_t)tid * a.ntiles + tile];
+      gbase = a.tile_off[(int64_t)tid * a_ntiles + tile];
     }
     s_gdelta[tid] = gbase - bin_start;
   }
@@ -646,10 +670,12 @@ template <typename KeyT, bool HAS_VAL>
 __global__ void __launch_bounds__(256) k_finalize_copy(PassArgs a)
 {
   if (a.plan->num_active != 0) return;
-  const KeyT* kin      = static_cast<const KeyT*>(a.kbuf[0]);
-  KeyT* kout           = static_cast<KeyT*>(a.kbuf[1]);
+  const bool mode_b    = a.plan->hy.lsd_mode != 0;
+  const KeyT* kin      = static_cast<const KeyT*>(mode_b ? a.kbufB[0] : a.kbuf[0]);
+  KeyT* kout           = static_cast<KeyT*>(mode_b ? a.kbufB[1] : a.kbuf[1]);
+  const int64_t a_n    = mode_b ? (int64_t)a.plan->hy.lsd_n : a.n;
   const int64_t stride = (int64_t)gridDim.x * blockDim.x;
-  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < a.n; i += stride) {
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < a_n; i += stride) {
     kout[i] = kin[i];
     if (HAS_VAL) a.vbuf[1][i] = a.vbuf[0] ? a.vbuf[0][i] : (uint32_t)i;
   }
@@ -1009,12 +1035,16 @@ __global__ void __launch_bounds__(GX_WAVE) k_plan2(SortPlan* plan, const uint32_
     __threadfence();
     if (atomicAdd(&hy.plan2_done, 1u) == (uint32_t)BINS - 1u) {  // every bucket is in
       const int overflow     = atomicAdd(&hy.overflow, 0);
-      const int bad          = !overflow && atomicAdd(&hy.bad, 0);
+      // (cursor path: its level-1 cursors count every key, so the sizes add up with or without dropped keys)
+      const int bad          = (cursor_path || !overflow) && atomicAdd(&hy.bad, 0);
       const uint32_t maxcell = atomicMax(&hy.max_cell, 0u);
       if (bad) atomicExch(&plan->status, 3);
-      const int ok = (!bad && !overflow && maxcell <= (uint32_t)hy.cell_max) ? 1 : 0;
+      const int big = (overflow || maxcell > (uint32_t)hy.cell_max) ? 1 : 0;
+      // cursor path: big cells are handled on their own (k_big_plan decides); look-back path: they send the column to the LSD passes
+      const int ok = (!bad && (cursor_path || !big)) ? 1 : 0;
       hy.ok        = ok;
-      if (ok) {  // the LSD passes and the copy-only finalizer become no-ops
+      hy.big       = (ok && big) ? 1 : 0;
+      if (ok && !big) {  // the LSD passes and the copy-only finalizer become no-ops
         for (int p = 0; p < npass; ++p) plan->pass_skip[p] = 1;
         plan->num_active = -1;
       }
@@ -1143,7 +1173,7 @@ __device__ __forceinline__ void local_place_cell(const uint32_t cell, const KeyT
   const uint32_t b  = cell >> bits2;
   const uint32_t d2 = cell & ((1u << bits2) - 1u);
   const uint32_t m  = hist2[b * NB2MAX + d2];
-  if (m == 0) return;
+  if (m == 0 || m > (uint32_t)LOCAL_MAX) return;  // (a big cell -- cursor path only -- is sorted through X, see HybridPlan::big)
   const int64_t start = base2[b * NB2MAX + d2];
   in += (int64_t)cell * LOCAL_MAX - start;  // the cell sits in its slot of the padded level-1 buffer
   if (HAS_VAL) vin += (int64_t)cell * LOCAL_MAX - start;
@@ -1327,7 +1357,7 @@ __device__ __forceinline__ void local_sort_cell(const uint32_t cell, const IoT* 
   const uint32_t b  = cell >> bits2;
   const uint32_t d2 = cell & ((1u << bits2) - 1u);
   const uint32_t m  = hist2[b * NB2MAX + d2];  // cell size (level-1 pass), output position (k_plan2)
-  if (m == 0) return;
+  if (m == 0 || m > (uint32_t)LOCAL_MAX) return;  // (big cells: see HybridPlan::big)
   const int64_t start = base2[b * NB2MAX + d2];
   in += (int64_t)cell * LOCAL_MAX - start;  // the cell sits in its slot of the padded level-1 buffer
   if (HAS_VAL) vin += (int64_t)cell * LOCAL_MAX - start;
@@ -1805,9 +1835,83 @@ __global__ void __launch_bounds__(BINS) k_hf_plan(SortPlan* plan, int stage, int
 // sorted the column: then clearing half a gigabyte of status words is skipped too
 __global__ void __launch_bounds__(256) k_hf_clear_status(const SortPlan* plan, uint4* __restrict__ status, size_t n16)
 {
-  if (plan->hf.state == 3 && plan->hy.ok) return;
+  if (plan->hf.state == 3 && plan->hy.ok && !plan->hy.lsd_mode) return;  // (the X sort of the big cells runs the LSD passes too)
   const size_t stride = (size_t)gridDim.x * 256;
   for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n16; i += stride) status[i] = uint4{0u, 0u, 0u, 0u};
+}
+
+// Big cells of the cursor path (HybridPlan::big), one workgroup: the cells that outgrew their slot, in cell (= key) order ->
+// their first key in X (xoff), the list (cell, xoff) the copy-back searches, the level-0 buckets the rescue pass re-reads.
+// Too many keys for X (half the level-0 buffer: the LSD passes need two work areas) or too many cells for the list: the
+// whole-column LSD fallback runs, as it did for every overflow before round 4.
+constexpr int BIG_LIST = 1 << 16;
+__global__ void __launch_bounds__(1024) k_big_plan(SortPlan* plan, const uint32_t* __restrict__ cellcount, uint32_t* __restrict__ xoff,
+                                                   uint32_t* __restrict__ biglist, unsigned long long xcap)
+{
+  HybridPlan& hy = plan->hy;
+  if (plan->hf.state != 3 || !hy.ok || !hy.big) return;
+  __shared__ uint32_t s_tmp[1024 / GX_WAVE + 1];
+  const int bits2       = hy.bits2;
+  const uint32_t nb2    = 1u << bits2;
+  const uint32_t ncells = (uint32_t)BINS << bits2;
+  const uint32_t cap    = (uint32_t)hy.cell_max;
+  const uint32_t per    = (ncells + 1023u) / 1024u;
+  const uint32_t c0     = threadIdx.x * per;
+  uint32_t cnt = 0, keys = 0;
+  for (uint32_t c = c0; c < c0 + per && c < ncells; ++c) {
+    const uint32_t m = cellcount[(c >> bits2) * NB2MAX + (c & (nb2 - 1u))];
+    if (m > cap) {
+      ++cnt;
+      keys += m;
+    }
+  }
+  uint32_t nbig, xtotal;
+  uint32_t k      = block_exclusive_scan<1024>(cnt, 0u, SumOp(), s_tmp, &nbig);
+  uint32_t x      = block_exclusive_scan<1024>(keys, 0u, SumOp(), s_tmp, &xtotal);  // (n < 2^31: no overflow)
+  const bool fits = nbig <= (uint32_t)BIG_LIST && (unsigned long long)xtotal <= xcap;
+  if (!fits) {
+    if (threadIdx.x == 0) {
+      hy.ok  = 0;  // k_hist_all / k_plan / the LSD passes behind sort the column from scratch
+      hy.big = 0;
+    }
+    return;
+  }
+  for (uint32_t c = c0; c < c0 + per && c < ncells; ++c) {
+    const uint32_t idx = (c >> bits2) * NB2MAX + (c & (nb2 - 1u));
+    const uint32_t m   = cellcount[idx];
+    if (m > cap) {
+      xoff[idx]          = x;
+      biglist[2 * k]     = idx;
+      biglist[2 * k + 1] = x;
+      hy.bigbucket[c >> bits2] = 1u;
+      ++k;
+      x += m;
+    }
+  }
+  if (threadIdx.x == 0) {
+    hy.nbig     = nbig;
+    hy.lsd_n    = xtotal;
+    hy.lsd_mode = 1;
+  }
+}
+
+// behind the X sort: sorted X -> the output ranges of the big cells (cells are in key order, so is X)
+template <typename KeyT>
+__global__ void __launch_bounds__(256) k_big_distribute(const SortPlan* plan, const KeyT* __restrict__ xsorted, KeyT* __restrict__ out,
+                                                        const uint32_t* __restrict__ biglist, const uint32_t* __restrict__ cellstart)
+{
+  const HybridPlan& hy = plan->hy;
+  if (!(hy.ok && hy.lsd_mode)) return;
+  const uint32_t n = (uint32_t)hy.lsd_n, nbig = hy.nbig;
+  const uint32_t stride = gridDim.x * 256u;
+  for (uint32_t i = blockIdx.x * 256u + threadIdx.x; i < n; i += stride) {
+    uint32_t lo = 0, hi = nbig;  // the last list entry whose first key is <= i
+    while (hi - lo > 1) {
+      const uint32_t mid = (lo + hi) >> 1;
+      if (biglist[2 * mid + 1] <= i) lo = mid; else hi = mid;
+    }
+    out[cellstart[biglist[2 * lo]] + (i - biglist[2 * lo + 1])] = xsorted[i];
+  }
 }
 
 // keys per thread of k_hf_scatter: 16 x 8 bytes = 64 KiB per tile; 32-bit keys take 24 (48 KiB: 32 per thread spill registers)
@@ -1817,6 +1921,8 @@ constexpr int hf_kpt()
   return sizeof(KeyT) == 8 ? 16 : 24;
 }
 
+// LVL 2 (round 4) = the RESCUE pass of the big cells: level 1 once more over the level-0 buckets that hold a big cell, but
+// only the keys of big cells are written -- compacted into X at xoff[cell] (k_big_plan), cursors in `cellcur` + 2 * BINS * NB2MAX.
 template <typename KeyT, int KIND, int LVL, int NBL>
 __global__ void __launch_bounds__(BT, 4) k_hf_scatter(const KeyT* __restrict__ in, KeyT* __restrict__ out, KeyT desc_mask, SortPlan* plan,
                                                      uint32_t* __restrict__ cellcur, uint32_t cellcap, int64_t n)
@@ -1833,6 +1939,9 @@ __global__ void __launch_bounds__(BT, 4) k_hf_scatter(const KeyT* __restrict__ i
   HybridPlan& hy = plan->hy;
   FastPlan& hf   = plan->hf;
   if (hf.state != (LVL == 0 ? 1 : 3)) return;
+  if (LVL == 2 && !(hy.ok && hy.lsd_mode)) return;
+  const uint32_t* xoff = cellcur + 2 * BINS * NB2MAX;  // LVL 2: first key of a big cell in X ...
+  uint32_t* rescur     = cellcur + 3 * BINS * NB2MAX;  // ... and the rescue cursors (hist2 | base2 | xoff | rescur)
   const unsigned tid = threadIdx.x;
   const int64_t v    = xcd_swizzle((int64_t)blockIdx.x, (int64_t)gridDim.x);  // XCD x works on a contiguous eighth of the tiles
   int64_t base;
@@ -1859,6 +1968,7 @@ __global__ void __launch_bounds__(BT, 4) k_hf_scatter(const KeyT* __restrict__ i
     const uint32_t q  = s_misc[0];
     const uint32_t jt = s_misc[1];
     seg               = q / NRANGE;  // the level-0 bucket
+    if (LVL == 2 && !hy.bigbucket[seg]) return;  // (block-uniform: nothing of this bucket is needed again)
     base              = (int64_t)hf.reg_start[q] + (int64_t)jt * TILE;
     const int64_t rem = (int64_t)hf.reg_count[q] - (int64_t)jt * TILE;
     nvalid            = (int)(rem < (int64_t)TILE ? rem : (int64_t)TILE);
@@ -1924,21 +2034,32 @@ __global__ void __launch_bounds__(BT, 4) k_hf_scatter(const KeyT* __restrict__ i
   __syncthreads();
   // ---- one returning atomic per non-empty bin reserves the tile's run; the scan runs while it is in flight
   uint32_t c[BPT], g[BPT], sbase[BPT], scap[BPT];
+  bool skip[BPT];
   uint32_t csum = 0;
 #pragma unroll
   for (int k = 0; k < BPT; ++k) {
     const uint32_t bin = tid * BPT + k;
     c[k] = g[k] = sbase[k] = scap[k] = 0;
+    skip[k] = false;
     if (bin < (uint32_t)NB) {
       c[k] = s_cnt[bin];
       if (LVL == 0) {
         sbase[k] = hf.slot0[seg][bin];
         scap[k]  = hf.cap0[seg][bin];
         if (c[k]) g[k] = atomicAdd(&hf.cur0[seg][bin], c[k]);
-      } else if (bin <= dmask) {
+      } else if (LVL == 1 && bin <= dmask) {
         sbase[k] = ((seg << hy.bits2) + bin) * cellcap;
         scap[k]  = cellcap;
         if (c[k]) g[k] = atomicAdd(&cellcur[seg * NB2MAX + bin], c[k]);
+      } else if (LVL == 2 && bin <= dmask) {
+        const uint32_t total = cellcur[seg * NB2MAX + bin];  // the cell's true size (level 1 counted every key)
+        if (total > cellcap) {
+          sbase[k] = xoff[seg * NB2MAX + bin];
+          scap[k]  = total;
+          if (c[k]) g[k] = atomicAdd(&rescur[seg * NB2MAX + bin], c[k]);
+        } else {
+          skip[k] = true;  // not a big cell: its keys stay where level 1 put them (limit 0 below: nothing is written)
+        }
       }
       csum += c[k];
     }
@@ -1948,9 +2069,10 @@ __global__ void __launch_bounds__(BT, 4) k_hf_scatter(const KeyT* __restrict__ i
   for (int k = 0; k < BPT; ++k) {
     const uint32_t bin = tid * BPT + k;
     if (bin < (uint32_t)NB) {
-      if (c[k] && g[k] + c[k] > scap[k]) {  // the surplus is dropped at the write-out; the fallback will sort the column
+      if (c[k] && !skip[k] && g[k] + c[k] > scap[k]) {  // the surplus is dropped at the write-out; the fallback will sort the column
         if (LVL == 0) hf.fail = 1;
-        else atomicExch(&hy.overflow, 1);
+        else if (LVL == 1) atomicExch(&hy.overflow, 1);
+        else atomicExch(&hy.bad, 2);  // (cannot happen: the rescue writes exactly the keys level 1 counted)
       }
       s_cnt[bin]   = st;
       s_delta[bin] = sbase[k] + g[k] - st;
@@ -2114,9 +2236,12 @@ int sort_impl(const void* keys_in, void* keys_out, const int32_t* vals_in, int32
   const int nb1         = hc.bits2 > 8 ? NB9 : BINS;  // bins (and look-back granules per tile) of the level-1 pass
   uint32_t* base1 = c.take<uint32_t>((size_t)NRANGE * NB2MAX);
   const bool cells = try_hybrid || fc.on;  // (the cursor path of 32-bit keys runs without the look-back hybrid)
-  uint32_t* hist2 = cells ? c.take<uint32_t>((size_t)2 * BINS * NB2MAX) : nullptr;  // cell sizes | cell output positions
+  // cell sizes | cell output positions | (cursor path: big cells) first key in X | rescue cursors
+  uint32_t* hist2 = cells ? c.take<uint32_t>((size_t)4 * BINS * NB2MAX) : nullptr;
   uint32_t* base2 = cells ? hist2 + BINS * NB2MAX : nullptr;
+  uint32_t* xoff  = cells ? hist2 + 2 * BINS * NB2MAX : nullptr;
   uint32_t* todo  = cells ? c.take<uint32_t>((size_t)BINS * NB2MAX) : nullptr;  // cells k_local_place leaves to k_local_sort
+  uint32_t* biglist = fc.on ? c.take<uint32_t>((size_t)2 * BIG_LIST) : nullptr;  // big cells: (cell, first key in X)
   const int64_t msd_tile     = (int64_t)BT * hyb_kpt;  // tile of the hybrid partition passes
   const int64_t msd_ntiles   = n > 0 ? div_up(n, msd_tile) : 0;
   const int64_t status_tiles = (msd_ntiles > ntiles ? msd_ntiles : ntiles) + BINS + 2 * NRANGE;  // segment tails add at most one tile each
@@ -2147,7 +2272,7 @@ int sort_impl(const void* keys_in, void* keys_out, const int32_t* vals_in, int32
   GX_HIP_TRY(hipMemsetAsync(plan, 0, sizeof(SortPlan), stream));
   if (n == 0) return 0;
   if (algo != 1 && !fc.on) GX_HIP_TRY(hipMemsetAsync(status, 0, status_words * sizeof(unsigned long long), stream));
-  if (cells) GX_HIP_TRY(hipMemsetAsync(hist2, 0, (size_t)2 * BINS * NB2MAX * sizeof(uint32_t), stream));
+  if (cells) GX_HIP_TRY(hipMemsetAsync(hist2, 0, (size_t)4 * BINS * NB2MAX * sizeof(uint32_t), stream));
   const int64_t range_rows = try_hybrid ? div_up(msd_ntiles, NRANGE) * msd_tile : div_up(ntiles, NRANGE) * TILE;
 
   const KeyT desc_mask = descending ? KeyT(~KeyT(0)) : KeyT(0);
@@ -2172,9 +2297,13 @@ int sort_impl(const void* keys_in, void* keys_out, const int32_t* vals_in, int32
       HfK kf0 = k_hf_scatter<KeyT, KIND, 0, 8>;
       // (the level-1 kernel and the cell grids are sized for bits2_max: the device may take the extra bit)
       HfK kf1 = fc.bits2_max <= 8 ? (HfK)k_hf_scatter<KeyT, KIND, 1, 8> : (fc.bits2_max == 9 ? (HfK)k_hf_scatter<KeyT, KIND, 1, 9> : (HfK)k_hf_scatter<KeyT, KIND, 1, 10>);
+      HfK kf2 = fc.bits2_max <= 8 ? (HfK)k_hf_scatter<KeyT, KIND, 2, 8> : (fc.bits2_max == 9 ? (HfK)k_hf_scatter<KeyT, KIND, 2, 9> : (HfK)k_hf_scatter<KeyT, KIND, 2, 10>);
       const int nbf = fc.bits2_max <= 8 ? 256 : (1 << fc.bits2_max);
       static bool fattr_set = false;
       if (!fattr_set) {
+        GX_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(k_hf_scatter<KeyT, KIND, 2, 8>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_hf(256)));
+        GX_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(k_hf_scatter<KeyT, KIND, 2, 9>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_hf(512)));
+        GX_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(k_hf_scatter<KeyT, KIND, 2, 10>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_hf(1024)));
         GX_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(k_hf_scatter<KeyT, KIND, 0, 8>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_hf(256)));
         GX_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(k_hf_scatter<KeyT, KIND, 1, 8>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_hf(256)));
         GX_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(k_hf_scatter<KeyT, KIND, 1, 9>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_hf(512)));
@@ -2217,6 +2346,10 @@ int sort_impl(const void* keys_in, void* keys_out, const int32_t* vals_in, int32
       prof_mark_h(4, stream);
       g_prof.hybrid_marked = g_prof.enabled;
       cursor_marked        = true;
+      // big cells (a hot value): plan X, fetch their keys again from the level-1 input into X = the level-1 buffer (every other
+      // cell has left it by now); the LSD passes below then sort X between the two halves of the level-0 buffer
+      hipLaunchKernelGGL(k_big_plan, dim3(1), dim3(1024), 0, stream, plan, hist2, xoff, biglist, (unsigned long long)(fc.slot_rows / 2));
+      hipLaunchKernelGGL(kf2, dim3((unsigned)(ftiles + NRANGE * BINS)), dim3(BT), lds_hf(nbf), stream, slot0_buf, kb_scratch, desc_mask, plan, hist2, 1u << 13, n);
       hipLaunchKernelGGL(k_hf_clear_status, dim3(2048), dim3(256), 0, stream, plan, reinterpret_cast<uint4*>(status), status_words / 2);
     }
   }
@@ -2336,7 +2469,7 @@ int sort_impl(const void* keys_in, void* keys_out, const int32_t* vals_in, int32
   }
   // LSD path: byte histograms + plan (no-ops when the hybrid path has sorted the column)
   hipLaunchKernelGGL((k_hist_all<KeyT, KIND>), dim3((unsigned)hblocks), dim3(BT), 0, stream,
-                     static_cast<const KeyT*>(keys_in), n, desc_mask, plan, range_rows);
+                     static_cast<const KeyT*>(keys_in), n, desc_mask, plan, range_rows, (const KeyT*)kb_scratch);
   hipLaunchKernelGGL(k_plan, dim3(1), dim3(BINS), 0, stream, plan, NPASS, n);
   if (!try_hybrid && !cursor_marked) prof_mark(1, stream);
 
@@ -2344,6 +2477,9 @@ int sort_impl(const void* keys_in, void* keys_out, const int32_t* vals_in, int32
   a.kbuf[0]   = const_cast<void*>(keys_in);
   a.kbuf[1]   = keys_out ? keys_out : static_cast<void*>(ka_scratch);
   a.kbuf[2]   = kb_scratch;
+  a.kbufB[0]  = kb_scratch;                                              // X (HybridPlan::lsd_mode)
+  a.kbufB[1]  = slot0_buf;                                               // sorted X
+  a.kbufB[2]  = slot0_buf ? slot0_buf + fc.slot_rows / 2 : nullptr;
   a.vbuf[0]   = reinterpret_cast<uint32_t*>(const_cast<int32_t*>(vals_in));
   a.vbuf[1]   = reinterpret_cast<uint32_t*>(vals_out);
   a.vbuf[2]   = vb;
@@ -2391,6 +2527,9 @@ int sort_impl(const void* keys_in, void* keys_out, const int32_t* vals_in, int32
     int64_t blocks = div_up(n, 256 * 8);
     if (blocks > 4096) blocks = 4096;
     hipLaunchKernelGGL((k_finalize_copy<KeyT, HAS_VAL>), dim3((unsigned)blocks), dim3(256), 0, stream, a);
+    if (fc.on)
+      hipLaunchKernelGGL((k_big_distribute<KeyT>), dim3(2048), dim3(256), 0, stream, plan, (const KeyT*)slot0_buf,
+                         keys_out ? static_cast<KeyT*>(keys_out) : ka_scratch, (const uint32_t*)biglist, (const uint32_t*)base2);
     if (KIND == K_FLOAT && descending && radix_nan_rule && sizeof(KeyT) >= 4) {
       hipLaunchKernelGGL((k_reverse_nan_block<KeyT, HAS_VAL>), dim3(256), dim3(256), 0, stream,
                          static_cast<KeyT*>(a.kbuf[1]), a.vbuf[1], n);
@@ -2659,6 +2798,23 @@ int gx_sort_info(const void* tmp, int32_t* info8_host, gx_stream_t stream)
   GX_HIP_TRY(hipMemcpyAsync(info8_host + 6, &plan->hy.max_cell, sizeof(int32_t), hipMemcpyDeviceToHost, stream));
   GX_HIP_TRY(hipMemcpyAsync(info8_host + 7, &plan->num_active, sizeof(int32_t), hipMemcpyDeviceToHost, stream));
   GX_HIP_TRY(hipStreamSynchronize(stream));
+  return 0;
+}
+
+int gx_sort_big_info(const void* tmp, int64_t* info3_host, gx_stream_t stream)
+{
+  if (!tmp || !info3_host) return GX_EINVAL;
+  const auto* plan = static_cast<const gx::sort::SortPlan*>(tmp);
+  int32_t mode = 0;
+  uint32_t nbig = 0;
+  unsigned long long xn = 0;
+  GX_HIP_TRY(hipMemcpyAsync(&mode, &plan->hy.lsd_mode, sizeof(mode), hipMemcpyDeviceToHost, stream));
+  GX_HIP_TRY(hipMemcpyAsync(&nbig, &plan->hy.nbig, sizeof(nbig), hipMemcpyDeviceToHost, stream));
+  GX_HIP_TRY(hipMemcpyAsync(&xn, &plan->hy.lsd_n, sizeof(xn), hipMemcpyDeviceToHost, stream));
+  GX_HIP_TRY(hipStreamSynchronize(stream));
+  info3_host[0] = mode;
+  info3_host[1] = nbig;
+  info3_host[2] = (int64_t)xn;
   return 0;
 }
 

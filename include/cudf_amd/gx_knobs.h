@@ -61,6 +61,12 @@ void gx_sort_set_order_words(int enable);
  * did not apply (16384-key cells, float keys, fewer than 13 key bits left, knob).  Synchronises `stream`. */
 int gx_sort_place_info(const void* tmp, int32_t* todo_cells_host, gx_stream_t stream);
 
+/* Big cells of the last cursor-path sort that used `tmp` (round 4): info3 = {1 when cells that outgrew their slot -- a hot value --
+ * were sorted on their own (compacted into X, X sorted by the LSD passes, copied back) while every other cell took the fast
+ * path, 0 otherwise; number of such cells; keys in them}.  A column whose big cells hold more than half its keys still falls
+ * back to the whole-column LSD passes (mode 0, gx_sort_info's num_active > 0).  Synchronises `stream`. */
+int gx_sort_big_info(const void* tmp, int64_t* info3_host, gx_stream_t stream);
+
 /* Cursor path of the hybrid sort (integer 64-bit keys, keys only, n >= 2^25; default on): the digit positions and
  * the slot capacities of the first partition level come from a 1/32 SAMPLE, both partition levels reserve their output
  * runs with one atomic per (tile, bin) instead of a look-back chain, and the first level -- which reads every key anyway --
