@@ -1696,6 +1696,251 @@ __global__ void __launch_bounds__(256) k_bs_fixup(const K* __restrict__ pkeys, c
 }
 
 // ================================================================================================
+// Round 4b: the WINDOW build.  k_bs_build above stores every 16-byte slot straight into a 2 MiB sub-table that nothing keeps
+// cached: 1e8 partial-line writes into a table that a 4.3 GB memset has to fill with EMPTY first (3.65 + 0.8 of the 5.3 ms,
+// profiles/r4_run4_join_kernel_stats.txt).  Here the table is written ONCE, in full lines, and never pre-filled:
+//   k_bw_split  one workgroup per partition (sub-table): counts its rows per WINDOW (2^12 slots), then regroups them by window
+//               through LDS (tiles of 4096 rows: 128-row runs) into a second pair of arrays; window offsets go to `woffs`;
+//   k_bw_build  one workgroup per sub-table walks its 32 windows in order: the window's slots live in LDS (keys + rows, 48 KiB),
+//               rows claim them with an LDS compare-and-swap, the finished window leaves as 64 KiB of coalesced 16-byte stores
+//               (empty slots included) + 2 KiB of tags.  A chain that runs off the end of a window is CARRIED into the next one
+//               (a small LDS list, inserted first: every slot from the key's home to the window's end is occupied, so the
+//               linear-probe invariant holds); what does not fit the list, and what leaves the sub-table, is parked in a global
+//               list with the slot to resume at and inserted by k_bw_fixup through the global tag words, as before.
+// A parked list that overflows (hundreds of thousands of chains running off their windows: one key repeated without end)
+// raises `failed`: the round-2 kernels, enqueued behind and gated on it, then build the table from the level-1 partition.
+// ================================================================================================
+constexpr int BW_LOG2  = 12;                           // slots per window
+constexpr int BW_SLOTS = 1 << BW_LOG2;
+constexpr int BW_PER   = 1 << (PJ_SUB_LOG2 - BW_LOG2);  // windows per sub-table (32)
+constexpr int BW_BT    = 512;
+constexpr int BW_RPT   = 8;
+constexpr int BW_TILE  = BW_BT * BW_RPT;                // rows per split tile
+constexpr int BW_CARRY = 128;                           // rows carried from one window into the next through LDS
+constexpr int BW_LIST  = 1 << 18;                       // parked rows
+struct alignas(128) BuildFix2 {
+  unsigned int count;   // parked rows
+  unsigned int failed;  // the list overflowed: the gated round-2 kernels build the table
+  unsigned int pad[30];
+  uint4 list[BW_LIST];  // {key lo, key hi, row, slot to resume at}
+};
+
+template <typename K>
+__device__ __forceinline__ uint32_t bw_window(K key, uint32_t log2cap)
+{
+  return ((uint32_t)slot_of<K>(key, log2cap) >> BW_LOG2) & (uint32_t)(BW_PER - 1);
+}
+
+template <typename K>
+__global__ void __launch_bounds__(BW_BT) k_bw_split(const K* __restrict__ pkeys, const int32_t* __restrict__ pidx, const PjPlan* __restrict__ plan,
+                                                    K* __restrict__ wkeys, int32_t* __restrict__ widx, uint32_t* __restrict__ woffs, uint32_t log2cap)
+{
+  __shared__ K s_k[BW_TILE];
+  __shared__ int32_t s_i[BW_TILE];
+  __shared__ uint32_t s_tot[BW_PER], s_woff[BW_PER + 1], s_run[BW_PER], s_tc[BW_PER], s_start[BW_PER], s_delta[BW_PER];
+  const unsigned tid  = threadIdx.x;
+  const unsigned part = blockIdx.x;
+  const unsigned long long o0 = plan->offset[part], o1 = plan->offset[part + 1];
+  if (tid < BW_PER) {
+    s_tot[tid] = 0;
+    s_run[tid] = 0;
+  }
+  __syncthreads();
+  // ---- sweep A: rows per window
+  for (unsigned long long i0 = o0; i0 < o1; i0 += BW_TILE) {
+    K key[BW_RPT];
+#pragma unroll
+    for (int j = 0; j < BW_RPT; ++j) {
+      const unsigned long long i = i0 + (unsigned long long)j * BW_BT + tid;
+      key[j] = i < o1 ? pkeys[i] : K(0);
+    }
+#pragma unroll
+    for (int j = 0; j < BW_RPT; ++j) {
+      const unsigned long long i = i0 + (unsigned long long)j * BW_BT + tid;
+      (void)lds_rank_few<5>(s_tot, bw_window<K>(key[j], log2cap), i < o1);
+    }
+  }
+  __syncthreads();
+  if (tid < GX_WAVE) {  // one wave: exclusive scan of the 32 counts
+    const uint32_t c   = tid < BW_PER ? s_tot[tid] : 0u;
+    const uint32_t inc = wave_inclusive_sum_dpp(c);
+    if (tid < BW_PER) {
+      s_woff[tid] = inc - c;
+      woffs[(size_t)part * (BW_PER + 1) + tid] = inc - c;
+    }
+    if (tid == BW_PER - 1) {
+      s_woff[BW_PER] = inc;
+      woffs[(size_t)part * (BW_PER + 1) + BW_PER] = inc;
+    }
+  }
+  __syncthreads();
+  // ---- sweep B: regroup by window, tile by tile
+  for (unsigned long long i0 = o0; i0 < o1; i0 += BW_TILE) {
+    const int nvalid = (int)(o1 - i0 < (unsigned long long)BW_TILE ? o1 - i0 : (unsigned long long)BW_TILE);
+    if (tid < BW_PER) s_tc[tid] = 0;
+    K key[BW_RPT];
+    int32_t row[BW_RPT];
+#pragma unroll
+    for (int j = 0; j < BW_RPT; ++j) {
+      const int idx = j * BW_BT + (int)tid;
+      key[j] = idx < nvalid ? pkeys[i0 + idx] : K(0);
+      row[j] = idx < nvalid ? pidx[i0 + idx] : 0;
+    }
+    __syncthreads();
+    uint32_t packed[BW_RPT];
+#pragma unroll
+    for (int j = 0; j < BW_RPT; ++j) {
+      const int idx    = j * BW_BT + (int)tid;
+      const uint32_t w = bw_window<K>(key[j], log2cap);
+      packed[j]        = (w << 16) | lds_rank_few<5>(s_tc, w, idx < nvalid);
+    }
+    __syncthreads();
+    if (tid < GX_WAVE) {
+      const uint32_t c   = tid < BW_PER ? s_tc[tid] : 0u;
+      const uint32_t inc = wave_inclusive_sum_dpp(c);
+      if (tid < BW_PER) {
+        s_start[tid] = inc - c;
+        s_delta[tid] = s_woff[tid] + s_run[tid] - (inc - c);
+        s_run[tid] += c;
+      }
+    }
+    __syncthreads();
+#pragma unroll
+    for (int j = 0; j < BW_RPT; ++j) {
+      const int idx = j * BW_BT + (int)tid;
+      if (idx < nvalid) {
+        const uint32_t l = s_start[packed[j] >> 16] + (packed[j] & 0xFFFFu);
+        s_k[l]           = key[j];
+        s_i[l]           = row[j];
+      }
+    }
+    __syncthreads();
+#pragma unroll
+    for (int j = 0; j < BW_RPT; ++j) {
+      const int i = j * BW_BT + (int)tid;
+      if (i < nvalid) {
+        const K k          = s_k[i];
+        const uint32_t w   = bw_window<K>(k, log2cap);
+        const uint64_t dst = o0 + (uint64_t)(uint32_t)(s_delta[w] + (uint32_t)i);
+        wkeys[dst]         = k;
+        widx[dst]          = s_i[i];
+      }
+    }
+    __syncthreads();  // the next tile reuses the LDS
+  }
+}
+
+template <typename K>
+__global__ void __launch_bounds__(BW_BT) k_bw_build(const K* __restrict__ wkeys, const int32_t* __restrict__ widx, const PjPlan* __restrict__ plan,
+                                                    const uint32_t* __restrict__ woffs, Slot<K>* __restrict__ slots, uint8_t* __restrict__ tags,
+                                                    uint32_t log2cap, BuildFix2* fix)
+{
+  __shared__ K s_key[BW_SLOTS];
+  __shared__ int32_t s_row[BW_SLOTS];
+  __shared__ K s_ck[2][BW_CARRY];
+  __shared__ int32_t s_cr[2][BW_CARRY];
+  __shared__ uint32_t s_nc[2];
+  const unsigned tid  = threadIdx.x;
+  const unsigned part = blockIdx.x;
+  const unsigned long long o0 = plan->offset[part];
+  const uint32_t* wo  = woffs + (size_t)part * (BW_PER + 1);
+  Slot<K>* sub        = slots + ((size_t)part << PJ_SUB_LOG2);
+  uint32_t* tagw      = reinterpret_cast<uint32_t*>(tags) + ((size_t)part << (PJ_SUB_LOG2 - 3));
+  if (tid < 2) s_nc[tid] = 0;
+  // a row whose chain leaves the window (h == BW_SLOTS): into the LDS list of the next window, or parked with the slot to resume at
+  auto carry = [&](K key, int32_t row, int nxt, uint64_t resume) {
+    const uint32_t e = atomicAdd(&s_nc[nxt], 1u);
+    if (e < (uint32_t)BW_CARRY) {
+      s_ck[nxt][e] = key;
+      s_cr[nxt][e] = row;
+    } else {
+      const unsigned int g = atomicAdd(&fix->count, 1u);
+      if (g < (unsigned int)BW_LIST) fix->list[g] = make_uint4((uint32_t)(uint64_t)key, (uint32_t)((uint64_t)key >> 32), (uint32_t)row, (uint32_t)resume);
+      else fix->failed = 1u;
+    }
+  };
+  auto insert = [&](K key, int32_t row, uint32_t h, int nxt, uint64_t resume) {
+    for (;;) {
+      if (h >= (uint32_t)BW_SLOTS) {
+        carry(key, row, nxt, resume);
+        return;
+      }
+      if (atomicCAS(&s_row[h], EMPTY_ROW, row) == EMPTY_ROW) {
+        s_key[h] = key;
+        return;
+      }
+      ++h;
+    }
+  };
+  for (int w = 0; w < BW_PER; ++w) {
+    const int cur = w & 1, nxt = cur ^ 1;
+    const uint64_t resume = ((uint64_t)part << PJ_SUB_LOG2) + ((uint64_t)(w + 1) << BW_LOG2);  // first slot behind this window
+    for (int i = tid; i < BW_SLOTS; i += BW_BT) s_row[i] = EMPTY_ROW;
+    __syncthreads();  // (also: s_nc[cur] of the previous round is complete, s_nc[nxt] may be reset)
+    if (tid == 0) s_nc[nxt] = 0;
+    const uint32_t ncar = s_nc[cur] < (uint32_t)BW_CARRY ? s_nc[cur] : (uint32_t)BW_CARRY;
+    __syncthreads();
+    for (uint32_t e = tid; e < ncar; e += BW_BT) insert(s_ck[cur][e], s_cr[cur][e], 0u, nxt, resume);  // carried rows start at slot 0
+    const unsigned long long r0 = o0 + wo[w], r1 = o0 + wo[w + 1];
+    for (unsigned long long i = r0 + tid; i < r1; i += BW_BT) {
+      const K key = __builtin_nontemporal_load(&wkeys[i]);
+      insert(key, __builtin_nontemporal_load(&widx[i]), (uint32_t)slot_of<K>(key, log2cap) & (uint32_t)(BW_SLOTS - 1), nxt, resume);
+    }
+    __syncthreads();
+    // the finished window: 16-byte slots (empty ones as {0, EMPTY_ROW}) and one tag word per 8 slots
+    Slot<K>* out = sub + ((size_t)w << BW_LOG2);
+    for (int i = tid; i < BW_SLOTS; i += BW_BT) {
+      const int32_t r = s_row[i];
+      store_slot<K>(&out[i], r == EMPTY_ROW ? K(0) : s_key[i], r);
+    }
+    {
+      uint32_t word = 0;
+#pragma unroll
+      for (int k = 0; k < 8; ++k) {
+        const int i = (int)tid * 8 + k;
+        if (s_row[i] != EMPTY_ROW) word |= tag_of<K>(s_key[i], log2cap) << (4 * k);
+      }
+      tagw[((size_t)w << (BW_LOG2 - 3)) + tid] = word;  // BW_SLOTS / 8 == BW_BT words per window
+    }
+    __syncthreads();  // the next window reuses the LDS
+  }
+  // what the last window carried leaves the sub-table: parked, to resume at the first slot of the next one
+  {
+    const int last        = BW_PER & 1;
+    const uint32_t ncar   = s_nc[last] < (uint32_t)BW_CARRY ? s_nc[last] : (uint32_t)BW_CARRY;
+    const uint64_t resume = (uint64_t)(part + 1) << PJ_SUB_LOG2;
+    for (uint32_t e = tid; e < ncar; e += BW_BT) {
+      const unsigned int g = atomicAdd(&fix->count, 1u);
+      const K key          = s_ck[last][e];
+      if (g < (unsigned int)BW_LIST) fix->list[g] = make_uint4((uint32_t)(uint64_t)key, (uint32_t)((uint64_t)key >> 32), (uint32_t)s_cr[last][e], (uint32_t)resume);
+      else fix->failed = 1u;
+    }
+  }
+}
+static_assert(BW_SLOTS / 8 == BW_BT, "k_bw_build: one tag word per thread and window");
+
+template <typename K>
+__global__ void __launch_bounds__(256) k_bw_fixup(Slot<K>* slots, uint8_t* tags, uint32_t log2cap, const BuildFix2* __restrict__ fix)
+{
+  const unsigned int cnt = fix->count;
+  if (cnt == 0 || fix->failed) return;
+  uint32_t* tagw       = reinterpret_cast<uint32_t*>(tags);
+  const int64_t stride = (int64_t)gridDim.x * 256;
+  for (int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x; e < (int64_t)cnt; e += stride) {
+    const uint4 r = fix->list[e];
+    const K key   = (K)(((uint64_t)r.y << 32) | r.x);
+    bs_insert_global<K>(key, (int32_t)r.z, (uint64_t)r.w, slots, tagw, log2cap);
+  }
+}
+// the gated fallback needs an EMPTY table first (the window build never pre-fills it)
+__global__ void __launch_bounds__(256) k_bw_fill_empty(uint4* __restrict__ p, size_t n16, const unsigned int* __restrict__ gate)
+{
+  if (*gate == 0) return;
+  const size_t stride = (size_t)gridDim.x * 256;
+  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n16; i += stride) p[i] = make_uint4(0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu);
+}
+
+// ================================================================================================
 // Round 3: the partition pass without its histogram, persistent, and the probe over region tables.
 //
 // (1) No k_pj_hist.  Region e = partition * PJ_NR + range owns a fixed slot of `cap` rows in the partitioned arrays

@@ -81,6 +81,8 @@ struct HybridPlan {
   uint32_t big_pad;
   unsigned long long lsd_n;  // keys in X
   uint32_t bigbucket[BINS];  // level-0 buckets that hold a big cell (the rescue pass re-reads only these)
+  uint32_t bigcnt[BINS], bigkeys[BINS];    // k_plan2: big cells of bucket b, keys in them
+  uint32_t biglist0[BINS], bigx0[BINS];    // k_big_plan: first list entry / first X position of bucket b's big cells
 };
 
 // Round 3, the CURSOR path (integer keys, keys only): plan of the speculative passes, see k_hf_scatter
@@ -1029,6 +1031,22 @@ __global__ void __launch_bounds__(GX_WAVE) k_plan2(SortPlan* plan, const uint32_
   }
   const uint32_t total = shfl(inc, GX_WAVE - 1);
   mx                   = wave_reduce(mx, MaxOp());
+  if (cursor_path) {  // big cells of this bucket (cells that outgrew their slot: HybridPlan::big)
+    uint32_t bc = 0, bk = 0;
+#pragma unroll
+    for (int k = 0; k < PER; ++k) {
+      if (c[k] > (uint32_t)hy.cell_max) {
+        ++bc;
+        bk += c[k];
+      }
+    }
+    bc = wave_reduce(bc, SumOp());
+    bk = wave_reduce(bk, SumOp());
+    if (lane == 0) {
+      hy.bigcnt[b]  = bc;
+      hy.bigkeys[b] = bk;
+    }
+  }
   if (lane == 0) {
     atomicMax(&hy.max_cell, mx);
     if (total != count) atomicExch(&hy.bad, 1);
@@ -1804,8 +1822,12 @@ __global__ void __launch_bounds__(BINS) k_hf_plan(SortPlan* plan, int stage, int
   // 93 % of one -- their cells overflow and the column falls back to the LSD passes (3x slower).  The exact histogram is here:
   // take one more level-1 bit when the fullest bucket needs it (the launches behind are sized for it).
   {
-    const uint32_t fit = (uint32_t)(0.97 * (double)cell_max);  // mean cell of the fullest bucket; a cell spreads 4.5 sigma = 5 % above it
-    const int more     = __syncthreads_or(((unsigned long long)c >> hy.bits2) > (unsigned long long)fit);
+    // (round 4: at least FOUR buckets must be that full.  One hot value -- 1e6 copies of a key -- fills its bucket without filling
+    //  that bucket's ordinary cells; its one big cell is sorted on its own (HybridPlan::big), and the extra bit would have
+    //  halved every cell of the column for it: local stage 3.3 -> 4.8 ms, profiles/r4_run4_sort_hot1e6_kernel_stats.txt)
+    const uint32_t fit = (uint32_t)(0.97 * (double)cell_max);  // mean cell of a bucket; a cell spreads 4.5 sigma = 5 % above it
+    const int full     = ((unsigned long long)c >> hy.bits2) > (unsigned long long)fit ? 1 : 0;
+    const int more     = __syncthreads_count(full) >= 4;
     if (more && t == 0 && hy.bits2 < bits2_max && hy.shift2 - 1 >= min_shift2) {
       hy.bits2 += 1;
       hy.shift2 -= 1;
@@ -1845,53 +1867,64 @@ __global__ void __launch_bounds__(256) k_hf_clear_status(const SortPlan* plan, u
 // Too many keys for X (half the level-0 buffer: the LSD passes need two work areas) or too many cells for the list: the
 // whole-column LSD fallback runs, as it did for every overflow before round 4.
 constexpr int BIG_LIST = 1 << 16;
-__global__ void __launch_bounds__(1024) k_big_plan(SortPlan* plan, const uint32_t* __restrict__ cellcount, uint32_t* __restrict__ xoff,
-                                                   uint32_t* __restrict__ biglist, unsigned long long xcap)
+__global__ void __launch_bounds__(BINS) k_big_plan(SortPlan* plan, unsigned long long xcap)
 {
   HybridPlan& hy = plan->hy;
   if (plan->hf.state != 3 || !hy.ok || !hy.big) return;
-  __shared__ uint32_t s_tmp[1024 / GX_WAVE + 1];
-  const int bits2       = hy.bits2;
-  const uint32_t nb2    = 1u << bits2;
-  const uint32_t ncells = (uint32_t)BINS << bits2;
-  const uint32_t cap    = (uint32_t)hy.cell_max;
-  const uint32_t per    = (ncells + 1023u) / 1024u;
-  const uint32_t c0     = threadIdx.x * per;
-  uint32_t cnt = 0, keys = 0;
-  for (uint32_t c = c0; c < c0 + per && c < ncells; ++c) {
-    const uint32_t m = cellcount[(c >> bits2) * NB2MAX + (c & (nb2 - 1u))];
-    if (m > cap) {
-      ++cnt;
-      keys += m;
-    }
-  }
+  __shared__ uint32_t s_tmp[BINS / GX_WAVE + 1];
+  const int b = threadIdx.x;
   uint32_t nbig, xtotal;
-  uint32_t k      = block_exclusive_scan<1024>(cnt, 0u, SumOp(), s_tmp, &nbig);
-  uint32_t x      = block_exclusive_scan<1024>(keys, 0u, SumOp(), s_tmp, &xtotal);  // (n < 2^31: no overflow)
-  const bool fits = nbig <= (uint32_t)BIG_LIST && (unsigned long long)xtotal <= xcap;
-  if (!fits) {
-    if (threadIdx.x == 0) {
+  const uint32_t k0 = block_exclusive_scan<BINS>(hy.bigcnt[b], 0u, SumOp(), s_tmp, &nbig);
+  const uint32_t x0 = block_exclusive_scan<BINS>(hy.bigkeys[b], 0u, SumOp(), s_tmp, &xtotal);  // (n < 2^31: no overflow)
+  if (nbig == 0 || nbig > (uint32_t)BIG_LIST || (unsigned long long)xtotal > xcap) {
+    if (b == 0) {
       hy.ok  = 0;  // k_hist_all / k_plan / the LSD passes behind sort the column from scratch
       hy.big = 0;
     }
     return;
   }
-  for (uint32_t c = c0; c < c0 + per && c < ncells; ++c) {
-    const uint32_t idx = (c >> bits2) * NB2MAX + (c & (nb2 - 1u));
-    const uint32_t m   = cellcount[idx];
-    if (m > cap) {
-      xoff[idx]          = x;
-      biglist[2 * k]     = idx;
-      biglist[2 * k + 1] = x;
-      hy.bigbucket[c >> bits2] = 1u;
-      ++k;
-      x += m;
-    }
-  }
-  if (threadIdx.x == 0) {
+  hy.biglist0[b]  = k0;
+  hy.bigx0[b]     = x0;
+  hy.bigbucket[b] = hy.bigcnt[b] ? 1u : 0u;
+  if (b == 0) {
     hy.nbig     = nbig;
     hy.lsd_n    = xtotal;
     hy.lsd_mode = 1;
+  }
+}
+// one wave per level-0 bucket that holds a big cell: the cells' first keys in X and the list entries
+__global__ void __launch_bounds__(GX_WAVE) k_big_cells(const SortPlan* plan, const uint32_t* __restrict__ cellcount, uint32_t* __restrict__ xoff,
+                                                       uint32_t* __restrict__ biglist)
+{
+  const HybridPlan& hy = plan->hy;
+  const int b = blockIdx.x;
+  if (!(hy.ok && hy.lsd_mode) || !hy.bigbucket[b]) return;
+  constexpr int PER   = NB2MAX / GX_WAVE;
+  const unsigned lane = lane_id();
+  const int nb2       = 1 << hy.bits2;
+  const uint32_t cap  = (uint32_t)hy.cell_max;
+  uint32_t c[PER], cnt = 0, keys = 0;
+#pragma unroll
+  for (int k = 0; k < PER; ++k) {
+    const int d2 = (int)lane * PER + k;
+    c[k]         = d2 < nb2 ? cellcount[b * NB2MAX + d2] : 0u;
+    if (c[k] > cap) {
+      ++cnt;
+      keys += c[k];
+    }
+  }
+  uint32_t kk = hy.biglist0[b] + wave_inclusive_sum_dpp(cnt) - cnt;
+  uint32_t x  = hy.bigx0[b] + wave_inclusive_sum_dpp(keys) - keys;
+#pragma unroll
+  for (int k = 0; k < PER; ++k) {
+    if (c[k] > cap) {
+      const uint32_t idx  = (uint32_t)(b * NB2MAX + (int)lane * PER + k);
+      xoff[idx]           = x;
+      biglist[2 * kk]     = idx;
+      biglist[2 * kk + 1] = x;
+      ++kk;
+      x += c[k];
+    }
   }
 }
 
@@ -2348,7 +2381,8 @@ int sort_impl(const void* keys_in, void* keys_out, const int32_t* vals_in, int32
       cursor_marked        = true;
       // big cells (a hot value): plan X, fetch their keys again from the level-1 input into X = the level-1 buffer (every other
       // cell has left it by now); the LSD passes below then sort X between the two halves of the level-0 buffer
-      hipLaunchKernelGGL(k_big_plan, dim3(1), dim3(1024), 0, stream, plan, hist2, xoff, biglist, (unsigned long long)(fc.slot_rows / 2));
+      hipLaunchKernelGGL(k_big_plan, dim3(1), dim3(BINS), 0, stream, plan, (unsigned long long)(fc.slot_rows / 2));
+      hipLaunchKernelGGL(k_big_cells, dim3(BINS), dim3(GX_WAVE), 0, stream, (const SortPlan*)plan, (const uint32_t*)hist2, xoff, biglist);
       hipLaunchKernelGGL(kf2, dim3((unsigned)(ftiles + NRANGE * BINS)), dim3(BT), lds_hf(nbf), stream, slot0_buf, kb_scratch, desc_mask, plan, hist2, 1u << 13, n);
       hipLaunchKernelGGL(k_hf_clear_status, dim3(2048), dim3(256), 0, stream, plan, reinterpret_cast<uint4*>(status), status_words / 2);
     }
