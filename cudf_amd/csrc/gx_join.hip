@@ -91,8 +91,9 @@ __device__ __forceinline__ uint32_t tag_of(K key, uint32_t log2cap)
 }
 template <typename K>
 __global__ void __launch_bounds__(256) k_tags(const Slot<K>* __restrict__ slots, uint64_t cap, uint32_t log2cap,
-                                              uint8_t* __restrict__ tags)
+                                              uint8_t* __restrict__ tags, const unsigned int* __restrict__ gate = nullptr)
 {
+  if (gate && *gate == 0) return;  // the fallback behind the window build (k_bw_build) that was not needed
   const int64_t stride = (int64_t)gridDim.x * 256;
   for (int64_t b = (int64_t)blockIdx.x * 256 + threadIdx.x; b < (int64_t)(cap / 2); b += stride) {
     K k0, k1;
@@ -105,7 +106,7 @@ __global__ void __launch_bounds__(256) k_tags(const Slot<K>* __restrict__ slots,
   }
 }
 template <typename K>
-static int launch_tags(void* table, uint32_t lg, hipStream_t s)
+static int launch_tags(void* table, uint32_t lg, hipStream_t s, const unsigned int* gate = nullptr)
 {
   char* base     = static_cast<char*>(table);
   auto* slots    = reinterpret_cast<const Slot<K>*>(base + sizeof(TableHeader));
@@ -113,7 +114,7 @@ static int launch_tags(void* table, uint32_t lg, hipStream_t s)
   int64_t blocks = div_up((int64_t)((1ull << lg) / 2), 256 * 8);
   if (blocks > 4096) blocks = 4096;
   if (blocks < 1) blocks = 1;
-  hipLaunchKernelGGL((k_tags<K>), dim3((unsigned)blocks), dim3(256), 0, s, slots, 1ull << lg, lg, tags);
+  hipLaunchKernelGGL((k_tags<K>), dim3((unsigned)blocks), dim3(256), 0, s, slots, 1ull << lg, lg, tags, gate);
   GX_LAUNCH_CHECK();
   return 0;
 }
@@ -1481,8 +1482,10 @@ k_pj_probe_pipe(const K* __restrict__ pkeys, const int32_t* __restrict__ pidx, P
 // (k_build wrote 9.6 GB to HBM for 1.6 GB of slots at 1e8 rows).
 template <typename K>
 __global__ void __launch_bounds__(PJ_BT) k_pj_build(const K* __restrict__ pkeys, const int32_t* __restrict__ pidx,
-                                                    PjPlan* plan, int pbits, Slot<K>* __restrict__ slots, uint32_t log2cap)
+                                                    PjPlan* plan, int pbits, Slot<K>* __restrict__ slots, uint32_t log2cap,
+                                                    const unsigned int* __restrict__ gate = nullptr)
 {
+  if (gate && *gate == 0) return;
   constexpr int RPT = PJ_CHUNK / PJ_BT;
   __shared__ unsigned int s_misc[4];
   const int P         = 1 << pbits;
@@ -2696,7 +2699,8 @@ static inline void jprof_mark(int i, hipStream_t s)
   if (g_jprof.enabled) (void)hipEventRecord(g_jprof.ev[i], s);
 }
 static thread_local int g_pj_probe = 0; // probe kernel: 0 = default (software-pipelined tag probe), 1 = round-1 tag probe (A/B knob)
-static thread_local int g_pj_build = 0; // partitioned build: 0 = sub-table build with the tags in LDS (round 4, default), 1 = round-2 kernel (global CAS + k_tags) (A/B knob)
+static thread_local int g_pj_build = 0; // partitioned build: 0 = window build, table composed in LDS and written once (round 4b, default), 2 = sub-table build with
+                                        // the tags in LDS (round 4a), 1 = round-2 kernel (global CAS + k_tags) (A/B knob)
 static thread_local int g_pj_tile = 0;  // scatter tile rows: 0 = default, else 4096 / 8192 / 16384 (A/B knob)
 static thread_local int g_pj_probe_early = 0;  // round-3 probe: 1 = rows of a piece requested at the top of the trip, 0 = at its end (default: with the
                                   // deferral queue the early form no longer fits 128 VGPRs) (A/B knob)
@@ -3000,6 +3004,11 @@ int build_partitioned_impl(const void* keys, int64_t n, void* table, size_t tabl
   K* pkeys      = c.take<K>((size_t)n);
   int32_t* pidx = c.take<int32_t>((size_t)n);
   BuildFix* fix = c.take<BuildFix>(1);
+  const bool windows = g_pj_build == 0 && (int)lg - pbits == PJ_SUB_LOG2;  // the window build (round 4b)
+  K* wkeys        = windows ? c.take<K>((size_t)n) : nullptr;
+  int32_t* widx   = windows ? c.take<int32_t>((size_t)n) : nullptr;
+  uint32_t* woffs = windows ? c.take<uint32_t>(((size_t)1 << pbits) * (BW_PER + 1)) : nullptr;
+  BuildFix2* fix2 = windows ? c.take<BuildFix2>(1) : nullptr;
   if (!tmp) {
     *tmp_bytes = c.total();
     return 0;
@@ -3009,11 +3018,27 @@ int build_partitioned_impl(const void* keys, int64_t n, void* table, size_t tabl
   if (table_bytes < need) return GX_ETMP;
   if (pbits == 0) return GX_EINVAL;
   char* base = static_cast<char*>(table);
-  GX_HIP_TRY(hipMemsetAsync(base + sizeof(TableHeader), 0xFF, sizeof(Slot<K>) << lg, s));
+  if (!windows || n == 0) GX_HIP_TRY(hipMemsetAsync(base + sizeof(TableHeader), 0xFF, sizeof(Slot<K>) << lg, s));
   if (n == 0) return launch_tags<K>(table, lg, s);
   int rc = pj_partition<K>(static_cast<const K*>(keys), n, pbits, plan, pkeys, pidx, PJ_CHUNK, s, false, 0, payload);
   if (rc) return rc;
-  if (g_pj_build == 0 && (int)lg - pbits == PJ_SUB_LOG2) {  // one workgroup per sub-table: tags in LDS are the occupancy map
+  if (windows) {  // every window of the table is composed in LDS and written once, in full lines: no pre-fill, no global atomics
+    uint8_t* tags = reinterpret_cast<uint8_t*>(base + sizeof(TableHeader) + (sizeof(Slot<K>) << lg));
+    auto* slots   = reinterpret_cast<Slot<K>*>(base + sizeof(TableHeader));
+    GX_HIP_TRY(hipMemsetAsync(fix2, 0, 128, s));
+    hipLaunchKernelGGL((k_bw_split<K>), dim3(1u << pbits), dim3(BW_BT), 0, s, (const K*)pkeys, (const int32_t*)pidx, (const PjPlan*)plan, wkeys, widx, woffs, lg);
+    hipLaunchKernelGGL((k_bw_build<K>), dim3(1u << pbits), dim3(BW_BT), 0, s, (const K*)wkeys, (const int32_t*)widx, (const PjPlan*)plan, (const uint32_t*)woffs,
+                       slots, tags, lg, fix2);
+    hipLaunchKernelGGL((k_bw_fixup<K>), dim3(256), dim3(256), 0, s, slots, tags, lg, (const BuildFix2*)fix2);
+    // gated on fix2->failed (no-ops otherwise): the round-2 build from the level-1 partition
+    const unsigned int* gate = &fix2->failed;
+    hipLaunchKernelGGL(k_bw_fill_empty, dim3(2048), dim3(256), 0, s, reinterpret_cast<uint4*>(slots), (sizeof(Slot<K>) << lg) / 16, gate);
+    const int64_t max_chunks_f = div_up(n, PJ_CHUNK) + (1 << pbits);
+    hipLaunchKernelGGL((k_pj_build<K>), dim3((unsigned)max_chunks_f), dim3(PJ_BT), 0, s, pkeys, pidx, plan, pbits, slots, lg, gate);
+    GX_LAUNCH_CHECK();
+    return launch_tags<K>(table, lg, s, gate);
+  }
+  if (g_pj_build == 2 && (int)lg - pbits == PJ_SUB_LOG2) {  // one workgroup per sub-table: tags in LDS are the occupancy map
     uint8_t* tags = reinterpret_cast<uint8_t*>(base + sizeof(TableHeader) + (sizeof(Slot<K>) << lg));
     auto* slots   = reinterpret_cast<Slot<K>*>(base + sizeof(TableHeader));
     GX_HIP_TRY(hipMemsetAsync(fix, 0, 128, s));
@@ -3319,7 +3344,7 @@ void gx_join_set_partition_mode(int speculative, int early_loads)
   gx::join::g_pj_defer       = (early_loads & 2) ? 1 : 0;  // bit 1 of early_loads: park unsettled rows in the per-wave queue (A/B)
 }
 
-void gx_join_set_build_kernel(int which) { gx::join::g_pj_build = which == 1 ? 1 : 0; }
+void gx_join_set_build_kernel(int which) { gx::join::g_pj_build = (which == 1 || which == 2) ? which : 0; }
 void gx_join_set_scatter_tile(int rows)
 {
   gx::join::g_pj_tile = (rows == 4096 || rows == 8192 || rows == 16384) ? rows : 0;

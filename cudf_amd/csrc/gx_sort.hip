@@ -19,6 +19,7 @@
 #include "gx_common.hpp"
 #include <cstdlib>
 #include <type_traits>
+#include <vector>
 #include "gx_scan.hpp"
 
 namespace gx {
@@ -99,6 +100,17 @@ struct FastPlan {
   uint32_t reg_tile0[BINS * NRANGE + 1];    // level 1: first tile of region q = bucket * NRANGE + range
   uint32_t reg_start[BINS * NRANGE], reg_count[BINS * NRANGE];
   alignas(128) uint32_t cur0[NRANGE][BINS];  // level-0 cursors = keys in slot (range, bin); atomics: lines of their own
+  // The SHARDED sort (gx_sortx_*: the exchange sits between the two partition levels).  Sender: the digit positions come from
+  // masks the caller supplies (the OR over all ranks), so the verdict after level 0 does not compare the local top bit with them.
+  // Receiver: level 1 reads an EXTERNAL region table -- regions (bucket, source rank, input range) of the receive area, in
+  // bucket order -- instead of reg_* above.
+  uint32_t forced_masks;
+  uint32_t ext, nreg;
+  uint32_t slot_total;      // sender: rows of the level-0 buffer in use (end of the last slot)
+  uint32_t* x_tile0;        // [nreg + 1] first tile of region q (filled by k_hfx_plan)
+  const uint32_t* x_start;  // [nreg] first key of region q in the level-1 input
+  const uint32_t* x_count;  // [nreg]
+  const uint32_t* x_bucket; // [nreg] its level-0 bucket
 };
 
 // Every word that workgroups update with atomics lives on its own 128-B line, away from the
@@ -1795,6 +1807,7 @@ __global__ void __launch_bounds__(BINS) k_hf_plan(SortPlan* plan, int stage, int
     if (t == 0) {  // level 0 reduces the EXACT masks into these
       hy.or_mask  = 0;
       hy.nor_mask = 0;
+      hf.slot_total = total;
     }
     return;
   }
@@ -1802,7 +1815,8 @@ __global__ void __launch_bounds__(BINS) k_hf_plan(SortPlan* plan, int stage, int
   const unsigned long long V = hy.or_mask & hy.nor_mask;
   uint32_t cnt[NRANGE];
   uint32_t c   = 0;
-  int bad      = hf.fail != 0 || V == 0 || (63 - __builtin_clzll(V | 1ull)) != hy.shift0 + 7;
+  // (sharded sort: the digits come from the masks of ALL ranks; this rank's keys may well span fewer bits)
+  int bad      = hf.fail != 0 || (!hf.forced_masks && (V == 0 || (63 - __builtin_clzll(V | 1ull)) != hy.shift0 + 7));
   for (int r = 0; r < NRANGE; ++r) {
     cnt[r] = hf.cur0[r][t];
     if (cnt[r] > hf.cap0[r][t]) bad = 1;
@@ -1986,24 +2000,24 @@ __global__ void __launch_bounds__(BT, 4) k_hf_scatter(const KeyT* __restrict__ i
     base              = v * TILE;
     nvalid            = (int)(n - base < (int64_t)TILE ? n - base : (int64_t)TILE);
   } else {
-    if (v >= (int64_t)hf.reg_tile0[BINS * NRANGE]) return;
-    constexpr int QPT = BINS * NRANGE / BT;  // region table entries per thread
-#pragma unroll
-    for (int k = 0; k < QPT; ++k) {
-      const int q       = (int)tid * QPT + k;
-      const uint32_t lo = hf.reg_tile0[q], hi = hf.reg_tile0[q + 1];
+    const bool ext         = hf.ext != 0;  // the sharded sort's receive area (gx_sortx_finish)
+    const uint32_t nreg    = ext ? hf.nreg : (uint32_t)(BINS * NRANGE);
+    const uint32_t* rtile0 = ext ? hf.x_tile0 : hf.reg_tile0;
+    if (v >= (int64_t)rtile0[nreg]) return;
+    for (uint32_t q = tid; q < nreg; q += BT) {
+      const uint32_t lo = rtile0[q], hi = rtile0[q + 1];
       if ((int64_t)lo <= v && v < (int64_t)hi) {
-        s_misc[0] = (uint32_t)q;
+        s_misc[0] = q;
         s_misc[1] = (uint32_t)(v - lo);
       }
     }
     __syncthreads();
     const uint32_t q  = s_misc[0];
     const uint32_t jt = s_misc[1];
-    seg               = q / NRANGE;  // the level-0 bucket
+    seg               = ext ? hf.x_bucket[q] : q / NRANGE;  // the level-0 bucket
     if (LVL == 2 && !hy.bigbucket[seg]) return;  // (block-uniform: nothing of this bucket is needed again)
-    base              = (int64_t)hf.reg_start[q] + (int64_t)jt * TILE;
-    const int64_t rem = (int64_t)hf.reg_count[q] - (int64_t)jt * TILE;
+    base              = (int64_t)(ext ? hf.x_start[q] : hf.reg_start[q]) + (int64_t)jt * TILE;
+    const int64_t rem = (int64_t)(ext ? hf.x_count[q] : hf.reg_count[q]) - (int64_t)jt * TILE;
     nvalid            = (int)(rem < (int64_t)TILE ? rem : (int64_t)TILE);
   }
   const int shift      = LVL == 0 ? hy.shift0 : hy.shift2;
@@ -2573,6 +2587,289 @@ int sort_impl(const void* keys_in, void* keys_out, const int32_t* vals_in, int32
   return 0;
 }
 
+
+// ==================================================================================================================
+// The SHARDED sort's two halves (include/cudf_amd/gx.h gx_sortx_*): the exchange of a distributed sort
+// sits BETWEEN the cursor path's two partition levels.  Every rank runs level 0 on its shard with digit positions all ranks
+// agree on (the OR of everybody's varying-bit masks), whole level-0 bins are dealt to ranks in contiguous runs balanced by the
+// all-gathered histogram, a rank sends the span of its level-0 buffer that holds a peer's bins -- slots of (bin, input range),
+// padding included, ONE message per peer -- and the receiver runs level 1 + the cell sort over regions (bucket, source rank,
+// input range) of what arrived.  No separate range-partition pass on the sender, no level 0 on the receiver
+// (the reference's shape: sample -> boundaries -> shuffle -> local sort, cudf_polars collectives/sort.py).
+// ==================================================================================================================
+struct SortxCfg {
+  int bits2, bits2_max, stride;
+  size_t slot_rows;
+};
+static inline SortxCfg sortx_cfg(int64_t n)
+{
+  SortxCfg f{1, 2, 8, 0};
+  int B = 9;
+  while (B < 18 && (double)n / (double)(1ull << B) > 0.955 * 8192.0) ++B;
+  f.bits2     = B - 8;
+  f.bits2_max = f.bits2 < 10 ? f.bits2 + 1 : 10;
+  f.stride    = n >= (1ll << 27) ? 32 : 8;
+  const double dev = 8.0 * 1.25 * f.stride * __builtin_sqrt((double)(NRANGE * BINS) * ((double)n / f.stride + 2.0 * NRANGE * BINS));
+  f.slot_rows = (size_t)((double)n * 1.002 + dev) + (size_t)(NRANGE * BINS) * (size_t)(2 * f.stride * HF_CHUNK + 64 + 16) + 65536;
+  return f;
+}
+constexpr int SORTX_MAXREG = BINS * 16 * NRANGE;  // regions a receiver can see: every bin from 16 ranks x 8 input ranges
+
+// Receiver: one block, thread t = level-0 bucket t.  From the external region table (bucket-major; breg0[t] = first region of
+// bucket t) everything k_hf_plan's stage 2 leaves behind: bucket sizes and output bases, the level-1 digit (one more bit when
+// four buckets are that full), the tile numbering of the regions, the local sort's digits.
+__global__ void __launch_bounds__(BINS) k_hfx_plan(SortPlan* plan, long long n, int bits2, int bits2_max, int cell_max, int min_shift2, int tile_rows,
+                                                   unsigned long long or_mask, unsigned long long nor_mask, uint32_t nreg,
+                                                   const uint32_t* __restrict__ breg0, uint32_t* __restrict__ x_tile0,
+                                                   const uint32_t* __restrict__ x_start, const uint32_t* __restrict__ x_count,
+                                                   const uint32_t* __restrict__ x_bucket)
+{
+  __shared__ uint32_t s_tmp[BINS / GX_WAVE + 1];
+  HybridPlan& hy = plan->hy;
+  FastPlan& hf   = plan->hf;
+  const int t    = threadIdx.x;
+  const unsigned long long V = or_mask & nor_mask;
+  const int top    = V ? 63 - __builtin_clzll(V) : 0;
+  const int shift0 = top - 7;
+  uint32_t c = 0, tiles = 0;
+  for (uint32_t q = breg0[t]; q < breg0[t + 1]; ++q) {
+    c += x_count[q];
+    tiles += (x_count[q] + (uint32_t)tile_rows - 1) / (uint32_t)tile_rows;
+  }
+  uint32_t total, ttotal;
+  const uint32_t exc = block_exclusive_scan<BINS>(c, 0u, SumOp(), s_tmp, &total);
+  uint32_t trun      = block_exclusive_scan<BINS>(tiles, 0u, SumOp(), s_tmp, &ttotal);
+  const uint32_t fit = (uint32_t)(0.97 * (double)cell_max);
+  int b2             = bits2;
+  const int more     = __syncthreads_count(((unsigned long long)c >> bits2) > (unsigned long long)fit ? 1 : 0) >= 4;
+  if (more && b2 < bits2_max && shift0 - b2 - 1 >= min_shift2) ++b2;
+  const int shift2 = shift0 - b2;
+  if (V == 0 || shift2 < min_shift2 || (long long)total != n) return;  // state stays 0: gx_sortx_status reports the failure
+  hy.hist0[t] = c;
+  hy.gbin0[t] = exc;
+  for (uint32_t q = breg0[t]; q < breg0[t + 1]; ++q) {
+    x_tile0[q] = trun;
+    trun += (x_count[q] + (uint32_t)tile_rows - 1) / (uint32_t)tile_rows;
+  }
+  if (t == 0) {
+    x_tile0[nreg] = ttotal;
+    hy.attempt  = 1;
+    hy.shift0   = shift0;
+    hy.bits2    = b2;
+    hy.shift2   = shift2;
+    hy.cell_max = cell_max;
+    hy.or_mask  = or_mask;
+    hy.nor_mask = nor_mask;
+    plan_local_digits(hy, V, shift2);
+    hf.ext      = 1;
+    hf.nreg     = nreg;
+    hf.x_tile0  = x_tile0;
+    hf.x_start  = x_start;
+    hf.x_count  = x_count;
+    hf.x_bucket = x_bucket;
+    __threadfence();
+    hf.state = 3;
+  }
+}
+
+template <typename KeyT>
+struct SortxLayout {
+  SortPlan* plan;
+  uint32_t *hist2, *base2, *xoff, *todo, *biglist;
+  unsigned long long* status;
+  size_t status_words;
+  KeyT *cells, *level0;
+  size_t cells_rows, level0_rows;  // level0 = this rank's slots (slot_rows of its own n) followed by the receive area
+  uint32_t *x_tile0, *x_start, *x_count, *x_bucket, *breg0;
+  size_t total;
+};
+template <typename KeyT>
+static SortxLayout<KeyT> sortx_layout(void* tmp, int64_t n, int64_t recv_rows_max)
+{
+  SortxLayout<KeyT> L{};
+  Carver c(tmp);
+  const SortxCfg cs = sortx_cfg(n), cr = sortx_cfg(recv_rows_max);
+  L.plan          = c.take<SortPlan>(1);
+  L.hist2         = c.take<uint32_t>((size_t)4 * BINS * NB2MAX);
+  L.base2         = L.hist2 ? L.hist2 + BINS * NB2MAX : nullptr;
+  L.xoff          = L.hist2 ? L.hist2 + 2 * BINS * NB2MAX : nullptr;
+  L.todo          = c.take<uint32_t>((size_t)BINS * NB2MAX);
+  L.biglist       = c.take<uint32_t>((size_t)2 * BIG_LIST);
+  L.level0_rows   = cs.slot_rows + (size_t)recv_rows_max + 65536;
+  L.cells_rows    = ((size_t)BINS << cr.bits2_max) << 13;
+  const size_t xt = L.level0_rows / 2 / (size_t)(BT * 16) + BINS + 2 * NRANGE;  // tiles of the largest X the LSD passes may sort
+  L.status_words  = xt * BINS;
+  L.status        = c.take<unsigned long long>(L.status_words);
+  L.cells         = c.take<KeyT>(L.cells_rows);
+  L.level0        = c.take<KeyT>(L.level0_rows);
+  L.x_tile0       = c.take<uint32_t>((size_t)SORTX_MAXREG + 1);
+  L.x_start       = c.take<uint32_t>((size_t)SORTX_MAXREG);
+  L.x_count       = c.take<uint32_t>((size_t)SORTX_MAXREG);
+  L.x_bucket      = c.take<uint32_t>((size_t)SORTX_MAXREG);
+  L.breg0         = c.take<uint32_t>((size_t)BINS + 1);
+  L.total         = c.total();
+  return L;
+}
+
+// sender, step 1: varying-bit masks + speculative top-byte histogram of a sample of this rank's keys
+template <typename KeyT, int KIND>
+int sortx_sample(const void* keys, int64_t n, int64_t recv_rows_max, void* tmp, size_t* tmp_bytes, hipStream_t stream)
+{
+  auto L = sortx_layout<KeyT>(tmp, n, recv_rows_max);
+  if (!tmp) {
+    *tmp_bytes = L.total;
+    return 0;
+  }
+  if (*tmp_bytes < L.total) return GX_ETMP;
+  const SortxCfg cs = sortx_cfg(n);
+  GX_HIP_TRY(hipMemsetAsync(L.plan, 0, sizeof(SortPlan), stream));
+  GX_HIP_TRY(hipMemsetAsync(L.hist2, 0, (size_t)4 * BINS * NB2MAX * sizeof(uint32_t), stream));
+  if (n == 0) return 0;
+  constexpr int FT      = BT * hf_kpt<KeyT>();
+  const int64_t ftiles  = div_up(n, (int64_t)FT);
+  const int64_t frange  = (ftiles / NRANGE) * FT;
+  const int64_t step    = (int64_t)cs.stride * HF_CHUNK;
+  int64_t sblocks       = div_up(div_up(n, step), (int64_t)4 * 4);
+  if (sblocks > 2048) sblocks = 2048;
+  hipLaunchKernelGGL((k_hf_sample<KeyT, KIND, false>), dim3((unsigned)sblocks), dim3(256), 0, stream, static_cast<const KeyT*>(keys), n, KeyT(0), L.plan, cs.stride, frange);
+  GX_LAUNCH_CHECK();
+  return 0;
+}
+
+// sender, step 2: level 0 with the digit positions of masks2 = {OR, NOR} over ALL ranks (sortable form)
+template <typename KeyT, int KIND>
+int sortx_level0(const void* keys, int64_t n, int64_t recv_rows_max, const unsigned long long* masks2_host, int bits2_hint, void* tmp, hipStream_t stream)
+{
+  auto L = sortx_layout<KeyT>(tmp, n, recv_rows_max);
+  if (n == 0) return 0;
+  const SortxCfg cs = sortx_cfg(n);
+  constexpr int FT      = BT * hf_kpt<KeyT>();
+  constexpr int MIN_SHIFT2 = 8;
+  const int64_t ftiles  = div_up(n, (int64_t)FT);
+  const int64_t frange  = (ftiles / NRANGE) * FT;
+  const int64_t step    = (int64_t)cs.stride * HF_CHUNK;
+  int64_t sblocks       = div_up(div_up(n, step), (int64_t)4 * 4);
+  if (sblocks > 2048) sblocks = 2048;
+  const size_t lds0 = (size_t)FT * sizeof(KeyT) + (size_t)(3 * 256 + 16 + 4) * 4 + (size_t)2 * NW * 8;
+  static bool attr_set = false;  // per instantiation
+  if (!attr_set) {
+    GX_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(k_hf_scatter<KeyT, KIND, 0, 8>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds0));
+    attr_set = true;
+  }
+  // the masks of all ranks replace the sample's; forced_masks tells the verdict after level 0 not to compare the local top bit
+  GX_HIP_TRY(hipMemcpyAsync(&L.plan->hy.or_mask, masks2_host, 2 * sizeof(unsigned long long), hipMemcpyHostToDevice, stream));
+  const uint32_t one = 1;
+  GX_HIP_TRY(hipMemcpyAsync(&L.plan->hf.forced_masks, &one, sizeof(one), hipMemcpyHostToDevice, stream));
+  GX_HIP_TRY(hipStreamSynchronize(stream));  // (host sources)
+  const KeyT* kin = static_cast<const KeyT*>(keys);
+  // bits2 only decides whether enough key bits are left below level 1 (the receiver picks its own from what it receives)
+  hipLaunchKernelGGL(k_hf_plan, dim3(1), dim3(BINS), 0, stream, L.plan, 0, (int)(8 * sizeof(KeyT)), n, bits2_hint, 1 << 13, cs.stride, frange, FT,
+                     (unsigned long long)cs.slot_rows, 8.0f, MIN_SHIFT2, bits2_hint);
+  hipLaunchKernelGGL((k_hf_sample<KeyT, KIND, true>), dim3((unsigned)sblocks), dim3(256), 0, stream, kin, n, KeyT(0), L.plan, cs.stride, frange);
+  hipLaunchKernelGGL(k_hf_plan, dim3(1), dim3(BINS), 0, stream, L.plan, 1, (int)(8 * sizeof(KeyT)), n, bits2_hint, 1 << 13, cs.stride, frange, FT,
+                     (unsigned long long)cs.slot_rows, 8.0f, MIN_SHIFT2, bits2_hint);
+  hipLaunchKernelGGL((k_hf_scatter<KeyT, KIND, 0, 8>), dim3((unsigned)ftiles), dim3(BT), lds0, stream, kin, L.level0, KeyT(0), L.plan, L.hist2, 1u << 13, n);
+  hipLaunchKernelGGL(k_hf_plan, dim3(1), dim3(BINS), 0, stream, L.plan, 2, (int)(8 * sizeof(KeyT)), n, bits2_hint, 1 << 13, cs.stride, frange, FT,
+                     (unsigned long long)cs.slot_rows, 8.0f, MIN_SHIFT2, bits2_hint);
+  GX_LAUNCH_CHECK();
+  return 0;
+}
+
+// receiver: level 1 + cell sort over the regions of the level-0 area (own slots + what arrived), sorted keys to `out`
+template <typename KeyT, int KIND>
+int sortx_finish(int64_t n_send, int64_t recv_rows_max, int64_t n, const unsigned long long* masks2_host, const uint32_t* reg_start_host,
+                 const uint32_t* reg_count_host, const uint32_t* reg_bucket_host, int nreg, void* out, void* tmp, hipStream_t stream)
+{
+  auto L = sortx_layout<KeyT>(tmp, n_send, recv_rows_max);
+  if (nreg < 0 || nreg > SORTX_MAXREG || n > recv_rows_max + n_send) return GX_EINVAL;
+  // a fresh plan: the sender's is spent (its tables have been read by the caller)
+  GX_HIP_TRY(hipMemsetAsync(L.plan, 0, sizeof(SortPlan), stream));
+  GX_HIP_TRY(hipMemsetAsync(L.hist2, 0, (size_t)4 * BINS * NB2MAX * sizeof(uint32_t), stream));
+  if (n == 0) return 0;
+  const SortxCfg cr = sortx_cfg(n), cmax = sortx_cfg(recv_rows_max);
+  if (cr.bits2_max > cmax.bits2_max) return GX_EINVAL;
+  std::vector<uint32_t> breg0(BINS + 1, 0);
+  for (int q = 0; q < nreg; ++q) {
+    if (reg_bucket_host[q] >= (uint32_t)BINS || (q > 0 && reg_bucket_host[q] < reg_bucket_host[q - 1])) return GX_EINVAL;  // bucket-major
+    ++breg0[reg_bucket_host[q] + 1];
+  }
+  for (int b = 0; b < BINS; ++b) breg0[b + 1] += breg0[b];
+  GX_HIP_TRY(hipMemcpyAsync(L.x_start, reg_start_host, sizeof(uint32_t) * nreg, hipMemcpyHostToDevice, stream));
+  GX_HIP_TRY(hipMemcpyAsync(L.x_count, reg_count_host, sizeof(uint32_t) * nreg, hipMemcpyHostToDevice, stream));
+  GX_HIP_TRY(hipMemcpyAsync(L.x_bucket, reg_bucket_host, sizeof(uint32_t) * nreg, hipMemcpyHostToDevice, stream));
+  GX_HIP_TRY(hipMemcpyAsync(L.breg0, breg0.data(), sizeof(uint32_t) * (BINS + 1), hipMemcpyHostToDevice, stream));
+  GX_HIP_TRY(hipStreamSynchronize(stream));  // (host sources)
+  constexpr int FT         = BT * hf_kpt<KeyT>();
+  constexpr int MIN_SHIFT2 = 8;
+  constexpr int WORD_BYTES = (int)sizeof(typename PlaceWord<KeyT, KIND, false>::type);
+  auto lds_hf = [&](int nb) { return (size_t)FT * sizeof(KeyT) + (size_t)(3 * nb + 16 + 4) * 4 + (size_t)2 * NW * 8; };
+  typedef void (*HfK)(const KeyT*, KeyT*, KeyT, SortPlan*, uint32_t*, uint32_t, int64_t);
+  HfK kf1 = cr.bits2_max <= 8 ? (HfK)k_hf_scatter<KeyT, KIND, 1, 8> : (cr.bits2_max == 9 ? (HfK)k_hf_scatter<KeyT, KIND, 1, 9> : (HfK)k_hf_scatter<KeyT, KIND, 1, 10>);
+  HfK kf2 = cr.bits2_max <= 8 ? (HfK)k_hf_scatter<KeyT, KIND, 2, 8> : (cr.bits2_max == 9 ? (HfK)k_hf_scatter<KeyT, KIND, 2, 9> : (HfK)k_hf_scatter<KeyT, KIND, 2, 10>);
+  const int nbf = cr.bits2_max <= 8 ? 256 : (1 << cr.bits2_max);
+  const size_t lds_ls = ((size_t)8 << 13) + (size_t)(((1 << 13) / 16 / GX_WAVE) * BINS + 32 + 2 * BINS) * 4;
+  constexpr int KPT_L = kpt_for<KeyT>(false);
+  constexpr size_t lds_pass = pass_lds_bytes<KeyT, false, KPT_L>();
+  static bool attr_set = false;  // per instantiation
+  if (!attr_set) {
+    GX_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(k_hf_scatter<KeyT, KIND, 1, 8>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_hf(256)));
+    GX_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(k_hf_scatter<KeyT, KIND, 1, 9>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_hf(512)));
+    GX_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(k_hf_scatter<KeyT, KIND, 1, 10>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_hf(1024)));
+    GX_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(k_hf_scatter<KeyT, KIND, 2, 8>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_hf(256)));
+    GX_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(k_hf_scatter<KeyT, KIND, 2, 9>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_hf(512)));
+    GX_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(k_hf_scatter<KeyT, KIND, 2, 10>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_hf(1024)));
+    GX_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(k_local_sort<uint64_t, KIND, false, 13, KeyT>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_ls));
+    GX_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(k_local_place<KeyT, KIND, false, 13>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                   (int)place_lds_bytes(13, WORD_BYTES)));
+    GX_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(k_radix_pass<KeyT, KIND, false, KPT_L, 4, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_pass));
+    attr_set = true;
+  }
+  // tiles of the regions: one per FT keys + one tail per region
+  const int64_t l1_grid = div_up(n, (int64_t)FT) + nreg;
+  KeyT* bufA = static_cast<KeyT*>(out);
+  hipLaunchKernelGGL(k_hfx_plan, dim3(1), dim3(BINS), 0, stream, L.plan, (long long)n, cr.bits2, cr.bits2_max, 1 << 13, MIN_SHIFT2, FT, masks2_host[0], masks2_host[1],
+                     (uint32_t)nreg, (const uint32_t*)L.breg0, L.x_tile0, (const uint32_t*)L.x_start, (const uint32_t*)L.x_count, (const uint32_t*)L.x_bucket);
+  hipLaunchKernelGGL(kf1, dim3((unsigned)l1_grid), dim3(BT), lds_hf(nbf), stream, (const KeyT*)L.level0, L.cells, KeyT(0), L.plan, L.hist2, 1u << 13, n);
+  hipLaunchKernelGGL(k_plan2, dim3(BINS), dim3(GX_WAVE), 0, stream, L.plan, L.hist2, L.base2, (int)sizeof(KeyT), 1);
+  hipLaunchKernelGGL((k_local_place<KeyT, KIND, false, 13>), dim3(local_place_grid(BINS << cr.bits2)), dim3((1 << 13) / 16), place_lds_bytes(13, WORD_BYTES), stream,
+                     (const KeyT*)L.cells, bufA, (const uint32_t*)nullptr, (uint32_t*)nullptr, KeyT(0), L.plan, L.hist2, L.base2, L.todo, 0, 1);
+  hipLaunchKernelGGL((k_local_sort<uint64_t, KIND, false, 13, KeyT>), dim3(local_sort_grid(BINS << cr.bits2_max)), dim3((1 << 13) / 16), lds_ls, stream,
+                     (const KeyT*)L.cells, bufA, (const uint32_t*)nullptr, (uint32_t*)nullptr, (uint64_t)0, L.plan, L.hist2, L.base2, 0, 1, (const uint32_t*)L.todo);
+  // big cells: X in the cell buffer, the LSD passes between the two halves of the level-0 area (every region has been read by then)
+  const size_t xcap = L.level0_rows / 2;
+  hipLaunchKernelGGL(k_big_plan, dim3(1), dim3(BINS), 0, stream, L.plan, (unsigned long long)xcap);
+  hipLaunchKernelGGL(k_big_cells, dim3(BINS), dim3(GX_WAVE), 0, stream, (const SortPlan*)L.plan, (const uint32_t*)L.hist2, L.xoff, L.biglist);
+  hipLaunchKernelGGL(kf2, dim3((unsigned)l1_grid), dim3(BT), lds_hf(nbf), stream, (const KeyT*)L.level0, L.cells, KeyT(0), L.plan, L.hist2, 1u << 13, n);
+  hipLaunchKernelGGL(k_hf_clear_status, dim3(2048), dim3(256), 0, stream, L.plan, reinterpret_cast<uint4*>(L.status), L.status_words / 2);
+  int64_t hblocks = div_up(n, (int64_t)BT * 8);
+  if (hblocks > 2048) hblocks = 2048;
+  hblocks = div_up(hblocks, NRANGE) * NRANGE;
+  // (mode A -- the whole-column LSD fallback -- has no column to fall back to here: its length is 0, a failed plan is reported
+  //  by gx_sortx_status and the caller takes the range-partition path)
+  hipLaunchKernelGGL((k_hist_all<KeyT, KIND>), dim3((unsigned)hblocks), dim3(BT), 0, stream, (const KeyT*)L.cells, (int64_t)0, KeyT(0), L.plan, (int64_t)0, (const KeyT*)L.cells);
+  hipLaunchKernelGGL(k_plan, dim3(1), dim3(BINS), 0, stream, L.plan, (int)sizeof(KeyT), (int64_t)0);
+  PassArgs a{};
+  a.kbuf[0] = a.kbuf[1] = a.kbuf[2] = L.cells;
+  a.kbufB[0] = L.cells;
+  a.kbufB[1] = L.level0;
+  a.kbufB[2] = L.level0 + xcap;
+  a.plan      = L.plan;
+  a.status    = L.status;
+  a.n         = 0;
+  a.ntiles    = 0;
+  a.desc_mask = 0;
+  const int64_t xtiles = div_up((int64_t)(n < (int64_t)xcap ? n : (int64_t)xcap), (int64_t)(BT * KPT_L));
+  for (int pass = 0; pass < (int)sizeof(KeyT); ++pass) {
+    a.pass = pass;
+    hipLaunchKernelGGL((k_radix_pass<KeyT, KIND, false, KPT_L, 4, true>), dim3((unsigned)div_up(xtiles, (int64_t)PASS_TPB)), dim3(BT), lds_pass, stream, a);
+  }
+  hipLaunchKernelGGL((k_finalize_copy<KeyT, false>), dim3(1024), dim3(256), 0, stream, a);
+  hipLaunchKernelGGL((k_big_distribute<KeyT>), dim3(2048), dim3(256), 0, stream, (const SortPlan*)L.plan, (const KeyT*)L.level0, bufA, (const uint32_t*)L.biglist,
+                     (const uint32_t*)L.base2);
+  GX_LAUNCH_CHECK();
+  return 0;
+}
+
 template <bool HAS_VAL>
 int dispatch(int dtype, const void* keys_in, void* keys_out, const int32_t* vals_in, int32_t* vals_out,
              int64_t n, int descending, bool radix_nan_rule, void* tmp, size_t* tmp_bytes, hipStream_t s)
@@ -2717,6 +3014,103 @@ int sorted_order_words32(const void* keys, int64_t n, int descending, int32_t* o
 }  // namespace gx
 
 extern "C" {
+
+// ---- the sharded sort's halves (see gx.h)
+#define GX_SORTX_DISPATCH(CALL64S, CALL64U, CALL32S, CALL32U)  \
+  switch (dtype) {                                              \
+    case GX_INT64: return CALL64S;                              \
+    case GX_UINT64: return CALL64U;                             \
+    case GX_INT32: return CALL32S;                              \
+    case GX_UINT32: return CALL32U;                             \
+    default: return GX_EDTYPE;                                  \
+  }
+int gx_sortx_sample(int dtype, const void* keys, int64_t n, int64_t recv_rows_max, void* tmp, size_t* tmp_bytes, gx_stream_t s)
+{
+  using namespace gx::sort;
+  if (n < 0 || recv_rows_max < 0 || !tmp_bytes || n > 0x7FFFFFFFll || recv_rows_max > 0x7FFFFFFFll) return GX_EINVAL;
+  if (tmp && n > 0 && !keys) return GX_EINVAL;
+  hipStream_t st = (hipStream_t)s;
+  GX_SORTX_DISPATCH((sortx_sample<uint64_t, gx::K_SIGNED>(keys, n, recv_rows_max, tmp, tmp_bytes, st)),
+                    (sortx_sample<uint64_t, gx::K_UNSIGNED>(keys, n, recv_rows_max, tmp, tmp_bytes, st)),
+                    (sortx_sample<uint32_t, gx::K_SIGNED>(keys, n, recv_rows_max, tmp, tmp_bytes, st)),
+                    (sortx_sample<uint32_t, gx::K_UNSIGNED>(keys, n, recv_rows_max, tmp, tmp_bytes, st)))
+}
+int gx_sortx_masks(const void* tmp, uint64_t* masks2_host, gx_stream_t s)
+{
+  if (!tmp || !masks2_host) return GX_EINVAL;
+  const auto* plan = static_cast<const gx::sort::SortPlan*>(tmp);
+  GX_HIP_TRY(hipMemcpyAsync(masks2_host, &plan->hy.or_mask, 2 * sizeof(uint64_t), hipMemcpyDeviceToHost, (hipStream_t)s));
+  GX_HIP_TRY(hipStreamSynchronize((hipStream_t)s));
+  return 0;
+}
+int gx_sortx_level0(int dtype, const void* keys, int64_t n, int64_t recv_rows_max, const uint64_t* masks2_host, void* tmp, gx_stream_t s)
+{
+  using namespace gx::sort;
+  if (n < 0 || !tmp || !masks2_host || (n > 0 && !keys)) return GX_EINVAL;
+  hipStream_t st = (hipStream_t)s;
+  const int hint = sortx_cfg(recv_rows_max).bits2_max;
+  const auto* m  = reinterpret_cast<const unsigned long long*>(masks2_host);
+  GX_SORTX_DISPATCH((sortx_level0<uint64_t, gx::K_SIGNED>(keys, n, recv_rows_max, m, hint, tmp, st)),
+                    (sortx_level0<uint64_t, gx::K_UNSIGNED>(keys, n, recv_rows_max, m, hint, tmp, st)),
+                    (sortx_level0<uint32_t, gx::K_SIGNED>(keys, n, recv_rows_max, m, hint, tmp, st)),
+                    (sortx_level0<uint32_t, gx::K_UNSIGNED>(keys, n, recv_rows_max, m, hint, tmp, st)))
+}
+int gx_sortx_tables(const void* tmp, uint32_t* cur0_host, uint32_t* slot0_host, uint32_t* slot_total_host, int32_t* state_host, gx_stream_t s)
+{
+  using namespace gx::sort;
+  if (!tmp || !cur0_host || !slot0_host || !slot_total_host || !state_host) return GX_EINVAL;
+  const auto* plan = static_cast<const SortPlan*>(tmp);
+  hipStream_t st   = (hipStream_t)s;
+  GX_HIP_TRY(hipMemcpyAsync(cur0_host, &plan->hf.cur0[0][0], sizeof(uint32_t) * NRANGE * BINS, hipMemcpyDeviceToHost, st));
+  GX_HIP_TRY(hipMemcpyAsync(slot0_host, &plan->hf.slot0[0][0], sizeof(uint32_t) * NRANGE * BINS, hipMemcpyDeviceToHost, st));
+  GX_HIP_TRY(hipMemcpyAsync(slot_total_host, &plan->hf.slot_total, sizeof(uint32_t), hipMemcpyDeviceToHost, st));
+  GX_HIP_TRY(hipMemcpyAsync(state_host, &plan->hf.state, sizeof(int32_t), hipMemcpyDeviceToHost, st));
+  GX_HIP_TRY(hipStreamSynchronize(st));
+  return 0;
+}
+void* gx_sortx_level0_buffer(int dtype, void* tmp, int64_t n, int64_t recv_rows_max, int64_t* own_rows, int64_t* total_rows)
+{
+  using namespace gx::sort;
+  if (!tmp || n < 0 || recv_rows_max < 0) return nullptr;
+  if (dtype == GX_INT64 || dtype == GX_UINT64) {
+    auto L = sortx_layout<uint64_t>(tmp, n, recv_rows_max);
+    if (own_rows) *own_rows = (int64_t)sortx_cfg(n).slot_rows;
+    if (total_rows) *total_rows = (int64_t)L.level0_rows;
+    return L.level0;
+  }
+  if (dtype == GX_INT32 || dtype == GX_UINT32) {
+    auto L = sortx_layout<uint32_t>(tmp, n, recv_rows_max);
+    if (own_rows) *own_rows = (int64_t)sortx_cfg(n).slot_rows;
+    if (total_rows) *total_rows = (int64_t)L.level0_rows;
+    return L.level0;
+  }
+  return nullptr;
+}
+int gx_sortx_finish(int dtype, int64_t n_send, int64_t recv_rows_max, int64_t n, const uint64_t* masks2_host, const uint32_t* reg_start_host,
+                    const uint32_t* reg_count_host, const uint32_t* reg_bucket_host, int nreg, void* out, void* tmp, gx_stream_t s)
+{
+  using namespace gx::sort;
+  if (n < 0 || n_send < 0 || !tmp || !masks2_host || (nreg > 0 && (!reg_start_host || !reg_count_host || !reg_bucket_host)) || (n > 0 && !out)) return GX_EINVAL;
+  hipStream_t st = (hipStream_t)s;
+  const auto* m  = reinterpret_cast<const unsigned long long*>(masks2_host);
+  GX_SORTX_DISPATCH((sortx_finish<uint64_t, gx::K_SIGNED>(n_send, recv_rows_max, n, m, reg_start_host, reg_count_host, reg_bucket_host, nreg, out, tmp, st)),
+                    (sortx_finish<uint64_t, gx::K_UNSIGNED>(n_send, recv_rows_max, n, m, reg_start_host, reg_count_host, reg_bucket_host, nreg, out, tmp, st)),
+                    (sortx_finish<uint32_t, gx::K_SIGNED>(n_send, recv_rows_max, n, m, reg_start_host, reg_count_host, reg_bucket_host, nreg, out, tmp, st)),
+                    (sortx_finish<uint32_t, gx::K_UNSIGNED>(n_send, recv_rows_max, n, m, reg_start_host, reg_count_host, reg_bucket_host, nreg, out, tmp, st)))
+}
+int gx_sortx_status(const void* tmp, int32_t* ok_host, gx_stream_t s)
+{
+  if (!tmp || !ok_host) return GX_EINVAL;
+  const auto* plan = static_cast<const gx::sort::SortPlan*>(tmp);
+  int32_t state = 0, ok = 0, status = 0;
+  GX_HIP_TRY(hipMemcpyAsync(&state, &plan->hf.state, sizeof(int32_t), hipMemcpyDeviceToHost, (hipStream_t)s));
+  GX_HIP_TRY(hipMemcpyAsync(&ok, &plan->hy.ok, sizeof(int32_t), hipMemcpyDeviceToHost, (hipStream_t)s));
+  GX_HIP_TRY(hipMemcpyAsync(&status, &plan->status, sizeof(int32_t), hipMemcpyDeviceToHost, (hipStream_t)s));
+  GX_HIP_TRY(hipStreamSynchronize((hipStream_t)s));
+  *ok_host = (state == 3 && ok == 1 && status == 0) ? 1 : 0;
+  return 0;
+}
+#undef GX_SORTX_DISPATCH
 
 int gx_sort_keys(int dtype, const void* in, void* out, int64_t n, int descending, void* tmp,
                  size_t* tmp_bytes, gx_stream_t stream)

@@ -113,6 +113,33 @@ int gx_sort_status_async(const void* tmp, int* status_host_pinned, gx_stream_t s
 
 
 
+/* ------------------------------------------------------------------------------------------
+ * The two halves of the sort, for a SHARDED sort whose exchange sits between the sort's own two partition levels (gxd_sort;
+ * the reference's shape is sample -> boundaries -> shuffle -> local sort: python/cudf_polars/cudf_polars/streaming/
+ * actor_graph/collectives/sort.py, with cub::DeviceRadixSort as the local sort, cpp/src/sort/sort_radix.cu:52-161).
+ * INT64 / UINT64 / INT32 / UINT32 keys, ascending, keys only.  One scratch blob serves all calls of a sort: query its size with
+ * gx_sortx_sample(tmp = NULL); n = this rank's rows, recv_rows_max = the most rows it is prepared to receive.
+ *   gx_sortx_sample   varying-bit masks of a sample of the shard            -> gx_sortx_masks reads {OR, NOR} (sortable form)
+ *   gx_sortx_level0   level 0 (256 bins on the 8 bits below the highest bit that varies in masks2 = the OR over ALL ranks of
+ *                     what gx_sortx_masks returned) into padded (bin, input range) slots of the level-0 buffer
+ *   gx_sortx_tables   cur0[r * 256 + bin] = keys in slot (range r, bin), slot0[...] = its first key in the level-0 buffer (slots
+ *                     are laid out bin-major: the 8 slots of a bin are neighbours, bins ascend), slot_total = rows in use,
+ *                     state = 3 when level 0 succeeded (anything else: take another path)
+ *   gx_sortx_level0_buffer   the level-0 buffer: own_rows keys of this rank's slots, the rest (up to total_rows) is the
+ *                     receive area the caller fills with the spans its peers send
+ *   gx_sortx_finish   level 1 + cell sort over `nreg` regions {first key in the level-0 buffer, keys, level-0 bucket}, given in
+ *                     bucket order; n = their total; `out` receives the n sorted keys
+ *   gx_sortx_status   1 when the sorted output is valid (0: a device-side check failed -- take another path)
+ * masks, tables, status synchronise the stream (they return host values). */
+int gx_sortx_sample(int dtype, const void* keys, int64_t n, int64_t recv_rows_max, void* tmp, size_t* tmp_bytes, gx_stream_t stream);
+int gx_sortx_masks(const void* tmp, uint64_t* masks2_host, gx_stream_t stream);
+int gx_sortx_level0(int dtype, const void* keys, int64_t n, int64_t recv_rows_max, const uint64_t* masks2_host, void* tmp, gx_stream_t stream);
+int gx_sortx_tables(const void* tmp, uint32_t* cur0_host, uint32_t* slot0_host, uint32_t* slot_total_host, int32_t* state_host, gx_stream_t stream);
+void* gx_sortx_level0_buffer(int dtype, void* tmp, int64_t n, int64_t recv_rows_max, int64_t* own_rows, int64_t* total_rows);
+int gx_sortx_finish(int dtype, int64_t n_send, int64_t recv_rows_max, int64_t n, const uint64_t* masks2_host, const uint32_t* reg_start_host,
+                    const uint32_t* reg_count_host, const uint32_t* reg_bucket_host, int nreg, void* out, void* tmp, gx_stream_t stream);
+int gx_sortx_status(const void* tmp, int32_t* ok_host, gx_stream_t stream);
+
 /* info8_host (host, 8 x int32) = {hybrid attempted, hybrid used, d1, shift2, bits2, LDS passes,
  * largest cell, active LSD passes (-1 when the hybrid path produced the output)} of the last sort
  * that used `tmp`.  Synchronises `stream`. */

@@ -95,9 +95,10 @@ int gx_join_profile(int enable);
 
 int gx_join_profile_read(float* ms3);
 
-/* A/B knob: kernel of the partitioned build.  0 (default) = one workgroup per 2^17-slot sub-table, slots claimed through the 4-bit
- * tags held in LDS, no global atomics and no read-back of the table; 1 = the round-2 kernel (device-scope CAS on the table's
- * slots, then k_tags over the whole table). */
+/* A/B knob: kernel of the partitioned build.  0 (default) = the window build: the partition's rows regrouped by 2^12-slot window,
+ * every window composed in LDS and written once in full lines (no pre-fill of the table, no global atomics); 2 = one workgroup
+ * per 2^17-slot sub-table, slots claimed through the 4-bit tags held in LDS and stored one by one; 1 = the round-2 kernel
+ * (device-scope CAS on the table's slots, then k_tags over the whole table). */
 void gx_join_set_build_kernel(int which);
 /* A/B knob (process-wide): rows per workgroup tile of the partition scatter (4096, 8192, 16384; 0 = default:
  * the largest that fits the LDS next to the per-partition counters). */

@@ -57,10 +57,18 @@ print(f"DistributedHashJoin.inner_join (r2 python)  {timed(lambda: hj.inner_join
 del hj
 torch.cuda.empty_cache()
 from cudf_amd import gxd
-t0 = time.perf_counter()
-gj = gxd.HashJoin(comm, bk, force_exchange=True)
-torch.cuda.synchronize()
-print(f"gxd_join_build forced (1e8)                 {(time.perf_counter() - t0) * 1e3:8.2f} ms")
+# the FIRST build of a shape pays for its buffers: the communicator's arena grows (hipDeviceSynchronize + hipFree + hipMalloc per
+# slot: the partition / receive buffers sized for the 1e9-row sort above are released and re-made) and the 4.3 GB table, the kept
+# rows and keys come from hipMalloc -- the 1269.6 ms of profiles/r3_run36_single_rank_steps.txt was this one-off (a single
+# multi-gigabyte hipMalloc was measured at up to 1.87 s on these boxes: profiles/r3_run14_alloc_probe.txt).  Destroyed tables go
+# to the communicator's pool, so every later build of the shape allocates nothing: that is the number a pipeline sees.
+for label in ("first call (allocations)", "second call (pooled)    ", "third call (pooled)     "):
+    t0 = time.perf_counter()
+    gj = gxd.HashJoin(comm, bk, force_exchange=True)
+    torch.cuda.synchronize()
+    print(f"gxd_join_build forced (1e8), {label} {(time.perf_counter() - t0) * 1e3:8.2f} ms")
+    if not label.startswith("third"):
+        gj.close()
 for ch in (1, 4, 8, 16):
     print(f"gxd_join_probe forced, {ch:2d} chunks             {timed(lambda: gj.inner_join(pk, chunks=ch)):8.2f} ms   (enqueue, count waits, total) = "
           + ", ".join(f"{x:.2f}" for x in comm.last_timing()))

@@ -95,7 +95,7 @@ def test_loopback_sort(fabric, dtype, kind, chunks, slot_scale):
     ("even", 1, 0.0, 0, 2_600_000, 5_000_011),      # partitioned probe, (rank << s) | row decode on both sides
     ("skewed", 4, 0.0, 0, 2_600_000, 5_000_011),    # chunked probe overlapping the exchange
     ("empty", 2, 0.4, 0, 2_600_000, 4_000_003),     # one empty shard + every chunk's slots overflow -> exact re-partition
-    ("skewed", 1, 0.0, 20, 9_000_000, 6_000_011),   # row field of 2^20: build shards exceed it -> positions + gather fallback,
+    ("skewed", 1, 0.0, 20, 5_000_000, 4_000_011),   # row field of 2^20: build shards exceed it -> positions + gather fallback,
                                                      #   probe shards cut into several chunks by the row field
     ("even", 2, 0.0, 0, 40_000, 300_000),           # small tables: the plain probe + segment-table gather path
 ])
