@@ -55,6 +55,16 @@ _PROTOS = {
     "gx_sort_set_lookback": (None, [_i]),
     "gx_sort_info": (_i, [_p, ctypes.POINTER(ctypes.c_int32), _p]),
     "gx_sort_big_info": (_i, [_p, ctypes.POINTER(ctypes.c_int64), _p]),
+    # the sharded sort's halves (called from C++: cudf_amd/cpp/src/distributed.cpp; bound here for the ABI check and ad-hoc use)
+    "gx_sortx_sample": (_i, [_i, _p, _i64, _i64, _p, _sz, _p]),
+    "gx_sortx_masks": (_i, [_p, ctypes.POINTER(ctypes.c_uint64), _p]),
+    "gx_sortx_level0": (_i, [_i, _p, _i64, _i64, ctypes.POINTER(ctypes.c_uint64), _p, _p]),
+    "gx_sortx_tables": (_i, [_p, ctypes.POINTER(ctypes.c_uint32), ctypes.POINTER(ctypes.c_uint32), ctypes.POINTER(ctypes.c_uint32),
+                             ctypes.POINTER(ctypes.c_int32), _p]),
+    "gx_sortx_level0_buffer": (_p, [_i, _p, _i64, _i64, ctypes.POINTER(ctypes.c_int64), ctypes.POINTER(ctypes.c_int64)]),
+    "gx_sortx_finish": (_i, [_i, _i64, _i64, _i64, ctypes.POINTER(ctypes.c_uint64), ctypes.POINTER(ctypes.c_uint32), ctypes.POINTER(ctypes.c_uint32),
+                             ctypes.POINTER(ctypes.c_uint32), _i, _p, _p, _p]),
+    "gx_sortx_status": (_i, [_p, ctypes.POINTER(ctypes.c_int32), _p]),
     "gx_gather": (_i, [_i, _p, _p, _i64, _p, _i64, _i, _p, _p, _p]),
     "gx_gather_global_rows": (_i, [_p, _i64, _p, _i64, _i, _p, _p, _p, _p]),
     "gx_gather_global_rows_dev": (_i, [_p, _i64, _p, _i64, _i, _p, _p, _p]),

@@ -651,6 +651,8 @@ int partition_exchange(gxd_comm* c, int dtype, const void* keys, int64_t n, int6
 }
 
 template <typename F>
+int with_tmp(gxd_comm* c, int slot, F&& f);
+template <typename F>
 int with_tmp(gxd_comm* c, int slot, F&& f)
 {
   size_t b = 0;
@@ -676,6 +678,187 @@ int upload_segtab(gxd_comm* c, const std::vector<long long>& counts, const std::
   GXD_HIP(hipMemcpyAsync(dst, h.data(), h.size() * sizeof(long long), hipMemcpyHostToDevice, s));
   GXD_HIP(hipStreamSynchronize(s));  // `h` dies here
   (void)c;
+  return 0;
+}
+
+
+// ------------------------------------------------------------------------------------------------------------ sort, fused
+// The exchange BETWEEN the sort's two partition levels (gx.h gx_sortx_*).  Every rank runs level 0 on
+// its shard -- 256 bins on digit positions all ranks agree on -- whole bins are dealt to ranks in contiguous runs balanced by
+// the all-gathered level-0 histogram, a rank sends ONE span of its level-0 buffer per peer (the padded (bin, input range) slots
+// of the peer's bins, as they lie), and the receiver's level 1 + cell sort run over the regions of what arrived.  Against the
+// sample-sort path below this saves the range-partition pass on the sender (one full read + write of the shard) and level 0
+// on the receiver.  Collective decisions use all-gathered values only, so every rank takes the same branch; a rank whose
+// device-side checks fail reports it in the final status all-gather and ALL ranks take the sample-sort path instead.
+// Returns 0 (sorted), 1 (not applicable / a check failed: the caller runs the sample-sort path), or an error.
+int g_sort_mode = 0;  // gxd_test_set_sort_mode: 0 auto (fused for integer keys from 2^25 rows per rank), 1 never, 2 fused from 2^21 rows
+constexpr int SX_BINS = 256, SX_RANGES = 8;
+
+int sort_fused(gxd_comm* c, int dtype, const void* keys, int64_t n, gxd_alloc_fn alloc, void* actx, void** out_keys, int64_t* out_n,
+               hipStream_t stream, Trace& tr)
+{
+  const int W  = c->world;
+  const int es = elem_size(dtype);
+  if (g_sort_mode == 1 || !(dtype == GX_INT64 || dtype == GX_UINT64 || dtype == GX_INT32 || dtype == GX_UINT32)) return 1;
+  gx_stream_t gstream = reinterpret_cast<gx_stream_t>(stream);
+  std::vector<long long> bases;
+  int64_t nmax = n;
+  GXD_HIP(hipStreamSynchronize(stream));
+  GXD_GX(shard_sizes(c, n, bases, &nmax));
+  long long ntotal = 0;
+  for (int r = 0; r < W; ++r) ntotal += c->pinned[r];
+  const int64_t min_rows = g_sort_mode == 2 ? (1ll << 21) : (1ll << 25);
+  if (ntotal / W < min_rows || nmax > 0x60000000ll) return 1;
+  // a rank is prepared to receive 1.5 x the mean shard (level-0 bins are dealt by the exact histogram: the imbalance is at most
+  // one bin); beyond that -- one bin holding a large share of all keys -- the sample-sort path splits inside the bin
+  // (+ 2^22: the padding of small level-0 buffers -- two sample steps per slot -- is not proportional to the shard)
+  const int64_t recv_max = std::min<int64_t>((int64_t)(ntotal / W) * 3 / 2 + (1 << 22), 0x7FFF0000ll);
+  size_t tb = 0;
+  GXD_GX(gx_sortx_sample(dtype, nullptr, n, recv_max, nullptr, &tb, gstream));
+  void* tmp;
+  GXD_GX(c->arena.get(Arena::TMP2, tb, &tmp));
+  GXD_GX(gx_sortx_sample(dtype, keys, n, recv_max, tmp, &tb, gstream));
+  // ---- digit positions: the OR of every rank's varying-bit masks
+  constexpr int TAB = 2 * SX_RANGES * SX_BINS + 2;  // per rank: cur0 | slot0 | slot_total | state
+  void *d_mine, *d_all;
+  GXD_GX(c->arena.get(Arena::MISC_A, sizeof(long long) * TAB, &d_mine));
+  GXD_GX(c->arena.get(Arena::MISC_B, sizeof(long long) * TAB * W, &d_all));
+  GXD_GX(ensure_pinned(c, (size_t)TAB * W + 64));
+  uint64_t masks[2] = {0, 0};
+  if (n > 0) GXD_GX(gx_sortx_masks(tmp, masks, gstream));
+  GXD_HIP(hipMemcpyAsync(d_mine, masks, sizeof(masks), hipMemcpyHostToDevice, c->xs));
+  GXD_HIP(hipStreamSynchronize(c->xs));
+  GXD_GX(allgather_i64_host(c, static_cast<long long*>(d_mine), static_cast<long long*>(d_all), 2, c->pinned));
+  uint64_t gm[2] = {0, 0};
+  for (int r = 0; r < W; ++r) {
+    gm[0] |= (uint64_t)c->pinned[2 * r];
+    gm[1] |= (uint64_t)c->pinned[2 * r + 1];
+  }
+  if ((gm[0] & gm[1]) == 0) return 1;  // every key of every rank is the same value: nothing to partition on
+  tr.mark("sample + masks");
+  // ---- level 0, then everybody's slot tables
+  GXD_GX(gx_sortx_level0(dtype, keys, n, recv_max, gm, tmp, gstream));
+  std::vector<uint32_t> cur0(SX_RANGES * SX_BINS, 0), slot0(SX_RANGES * SX_BINS, 0);
+  uint32_t slot_total = 0;
+  int32_t state       = 3;
+  if (n > 0) GXD_GX(gx_sortx_tables(tmp, cur0.data(), slot0.data(), &slot_total, &state, gstream));
+  tr.mark("level 0");
+  {
+    std::vector<long long> mine(TAB);
+    for (int i = 0; i < SX_RANGES * SX_BINS; ++i) {
+      mine[i]                       = cur0[i];
+      mine[SX_RANGES * SX_BINS + i] = slot0[i];
+    }
+    mine[TAB - 2] = slot_total;
+    mine[TAB - 1] = state;
+    GXD_HIP(hipMemcpyAsync(d_mine, mine.data(), sizeof(long long) * TAB, hipMemcpyHostToDevice, c->xs));
+    GXD_HIP(hipStreamSynchronize(c->xs));
+  }
+  GXD_GX(allgather_i64_host(c, static_cast<long long*>(d_mine), static_cast<long long*>(d_all), TAB, c->pinned));
+  const long long* T = c->pinned;  // T[r * TAB + ...]
+  auto CUR  = [&](int r, int rg, int b) { return (uint32_t)T[(size_t)r * TAB + rg * SX_BINS + b]; };
+  auto SLOT = [&](int r, int rg, int b) { return (uint32_t)T[(size_t)r * TAB + SX_RANGES * SX_BINS + rg * SX_BINS + b]; };
+  auto STOT = [&](int r) { return (uint32_t)T[(size_t)r * TAB + TAB - 2]; };
+  for (int r = 0; r < W; ++r)
+    if (T[(size_t)r * TAB + TAB - 1] != 3) return 1;  // some rank's level 0 did not hold (its sample missed an outlier, ...)
+  // ---- whole bins to ranks, contiguous, balanced by the exact histogram
+  std::vector<long long> hist(SX_BINS, 0);
+  for (int b = 0; b < SX_BINS; ++b)
+    for (int r = 0; r < W; ++r)
+      for (int rg = 0; rg < SX_RANGES; ++rg) hist[b] += CUR(r, rg, b);
+  std::vector<int> b0(W + 1, SX_BINS);
+  {
+    long long run = 0;
+    int d         = 0;
+    b0[0]         = 0;
+    for (int b = 0; b < SX_BINS; ++b) {
+      // bin b goes to the rank whose share of the key space its midpoint falls into
+      const long long mid = run + hist[b] / 2;
+      int want            = (int)std::min<long long>(W - 1, ntotal > 0 ? mid * W / ntotal : 0);
+      while (d < want) b0[++d] = b;
+      run += hist[b];
+    }
+    while (d < W) b0[++d] = SX_BINS;
+  }
+  // span of rank r's level-0 buffer that holds the bins of rank d (slots are bin-major: the slots of a bin are neighbours)
+  auto span_lo = [&](int r, int d) { return b0[d] < SX_BINS ? SLOT(r, 0, b0[d]) : STOT(r); };
+  auto span_hi = [&](int r, int d) { return b0[d + 1] < SX_BINS ? SLOT(r, 0, b0[d + 1]) : STOT(r); };
+  for (int d = 0; d < W; ++d) {  // what rank d would have to receive: the same sum on every rank
+    long long rv = 0, rows = 0;
+    for (int r = 0; r < W; ++r) {
+      if (r != d) rv += (long long)span_hi(r, d) - span_lo(r, d);
+      for (int b = b0[d]; b < b0[d + 1]; ++b)
+        for (int rg = 0; rg < SX_RANGES; ++rg) rows += CUR(r, rg, b);
+    }
+    if (rv > recv_max || rows > recv_max) return 1;  // (rows: what rank d ends up with, its own bins included)
+  }
+  const int me = c->rank;
+  int64_t own_rows = 0, total_rows = 0;
+  char* level0 = static_cast<char*>(gx_sortx_level0_buffer(dtype, tmp, n, recv_max, &own_rows, &total_rows));
+  if (!level0) return fail(GX_EINTERNAL, "gxd_sort: gx_sortx_level0_buffer");
+  // ---- the exchange: one span per peer, received behind this rank's own slots
+  std::vector<long long> roff(W, 0);
+  {
+    long long off = own_rows;
+    for (int r = 0; r < W; ++r) {
+      roff[r] = off;
+      if (r != me) off += (long long)span_hi(r, me) - span_lo(r, me);
+    }
+    if (off > total_rows) return fail(GX_EINTERNAL, "gxd_sort: receive area too small (internal bound)");
+  }
+  GXD_GX(c->tp->group_start());
+  for (int r = 0; r < W; ++r) {
+    if (r == me) continue;
+    const long long slen = (long long)span_hi(me, r) - span_lo(me, r);
+    const long long rlen = (long long)span_hi(r, me) - span_lo(r, me);
+    if (slen > 0) GXD_GX(c->tp->send(level0 + (size_t)span_lo(me, r) * es, (size_t)slen * es, r, c->xs));
+    if (rlen > 0) GXD_GX(c->tp->recv(level0 + (size_t)roff[r] * es, (size_t)rlen * es, r, c->xs));
+  }
+  GXD_GX(c->tp->group_end(c->xs));
+  GXD_HIP(hipEventRecord(c->evX, c->xs));
+  GXD_HIP(hipStreamWaitEvent(stream, c->evX, 0));
+  tr.mark("exchange");
+  // ---- regions of my bins: (bucket, source rank, input range), in bucket order
+  std::vector<uint32_t> rs, rc, rb;
+  long long nrecv = 0;
+  for (int b = b0[me]; b < b0[me + 1]; ++b)
+    for (int r = 0; r < W; ++r)
+      for (int rg = 0; rg < SX_RANGES; ++rg) {
+        const uint32_t cnt = CUR(r, rg, b);
+        if (!cnt) continue;
+        const long long st = r == me ? (long long)SLOT(r, rg, b) : roff[r] + ((long long)SLOT(r, rg, b) - span_lo(r, me));
+        rs.push_back((uint32_t)st);
+        rc.push_back(cnt);
+        rb.push_back((uint32_t)b);
+        nrecv += cnt;
+      }
+  int ok = 1;
+  void* out = nullptr;
+  if (nrecv > 0) {
+    out = alloc((size_t)nrecv * es, actx);
+    if (!out) return fail(GX_EINVAL, "gxd_sort: allocator returned NULL");
+    const int frc = gx_sortx_finish(dtype, n, recv_max, nrecv, gm, rs.data(), rc.data(), rb.data(), (int)rs.size(), out, tmp, gstream);
+    if (frc == GX_EINVAL) ok = 0;  // (more regions than the table holds, ...): reported below, all ranks take the other path
+    else if (frc) return fail(frc, "gx_sortx_finish returned " + std::to_string(frc));
+    if (ok) {
+      int32_t sok = 0;
+      GXD_GX(gx_sortx_status(tmp, &sok, gstream));
+      ok = sok;
+    }
+  }
+  tr.mark("level 1 + cells");
+  // ---- everybody must have succeeded
+  {
+    long long mine = ok;
+    GXD_HIP(hipStreamSynchronize(stream));
+    GXD_HIP(hipMemcpyAsync(d_mine, &mine, sizeof(mine), hipMemcpyHostToDevice, c->xs));
+    GXD_HIP(hipStreamSynchronize(c->xs));
+    GXD_GX(allgather_i64_host(c, static_cast<long long*>(d_mine), static_cast<long long*>(d_all), 1, c->pinned));
+    for (int r = 0; r < W; ++r)
+      if (c->pinned[r] != 1) return 1;
+  }
+  *out_keys = out;
+  *out_n    = nrecv;
   return 0;
 }
 
@@ -770,6 +953,7 @@ int gxd_comm_destroy(gxd_comm* c)
 
 void gxd_test_set_slot_scale(double scale) { g_slot_scale = scale; }
 void gxd_test_set_row_bits(int bits) { g_row_bits = bits; }
+void gxd_test_set_sort_mode(int mode) { g_sort_mode = mode; }
 int gxd_comm_rank(const gxd_comm* c) { return c ? c->rank : -1; }
 int gxd_comm_world(const gxd_comm* c) { return c ? c->world : -1; }
 int gxd_last_timing(const gxd_comm* c, double* ms3_host)
@@ -802,6 +986,18 @@ int gxd_sort(gxd_comm* c, int dtype, const void* keys, int64_t n, int chunks, in
     *out_n    = n;
     c->ms[2]  = now_ms() - t0;
     return 0;
+  }
+  {  // the exchange between the sort's own two partition levels, where it applies (integer keys, large shards)
+    const int frc = sort_fused(c, dtype, keys, n, alloc, actx, out_keys, out_n, stream, tr);
+    if (frc == 0) {
+      GXD_HIP(hipStreamSynchronize(stream));
+      c->ms[2] = now_ms() - t0;
+      c->ms[0] = -1.0;  // (marks the fused path in gxd_last_timing: no separate partition pass)
+      return 0;
+    }
+    if (frc != 1) return frc;
+    *out_keys = nullptr;
+    *out_n    = 0;
   }
   // ---- splitters from an evenly strided sample of every shard (collectives/sort.py: sample -> allgather -> boundaries)
   constexpr int S = 1024;

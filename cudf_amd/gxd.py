@@ -36,6 +36,8 @@ _lib.gxd_test_set_slot_scale.argtypes = [ctypes.c_double]
 _lib.gxd_test_set_slot_scale.restype = None
 _lib.gxd_test_set_row_bits.argtypes = [_i]
 _lib.gxd_test_set_row_bits.restype = None
+_lib.gxd_test_set_sort_mode.argtypes = [_i]
+_lib.gxd_test_set_sort_mode.restype = None
 _lib.gxd_groupby_sum_count.argtypes = [_p, _i, _p, _i, _p, _i64, _i64, _i, _ALLOC, _p, ctypes.POINTER(_p), ctypes.POINTER(_p),
                                        ctypes.POINTER(_p), ctypes.POINTER(_i64), _p]
 
@@ -80,6 +82,11 @@ def set_slot_scale(scale: float):
 def set_row_bits(bits: int):
     """test hook: see gxd_test_set_row_bits"""
     _lib.gxd_test_set_row_bits(int(bits))
+
+
+def set_sort_mode(mode: int):
+    """test hook: see gxd_test_set_sort_mode"""
+    _lib.gxd_test_set_sort_mode(int(mode))
 
 
 def _stream():

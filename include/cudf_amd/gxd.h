@@ -56,13 +56,21 @@ void gxd_test_set_slot_scale(double scale);
  * that shards of a few million rows already exceed it: build shards then take the documented positions + gather fallback and
  * probe shards are cut into more chunks. */
 void gxd_test_set_row_bits(int bits);
+/* TEST HOOK: which path gxd_sort takes.  0 (default) = the exchange between the sort's two partition levels for INT32 / UINT32 /
+ * INT64 / UINT64 keys from 2^25 rows per rank on average, the sample-sort path otherwise; 1 = always the sample-sort path;
+ * 2 = the fused path from 2^21 rows per rank (so that tests reach it with small shards). */
+void gxd_test_set_sort_mode(int mode);
 /* milliseconds the last operator call of this communicator spent in: [0] partition kernels, [1] host waits for counts,
  * [2] whole call (host clock, the stream is synchronised at the end of every operator) */
 int gxd_last_timing(const gxd_comm* comm, double* ms3_host);
 
 /* Global sort of the concatenation of all ranks' shards: rank r receives the r-th range, sorted; the concatenation of the
- * results in rank order is sorted (sample sort: strided sample -> all-gather -> common splitters -> ONE range-partition
- * pass per chunk -> exchange -> ONE local sort).  dtype: a 4- or 8-byte numeric gx_dtype.  chunks <= 0: default (8).
+ * results in rank order is sorted.  Integer keys, large shards: the exchange sits BETWEEN the sort's two partition levels --
+ * every rank runs level 0 (256 bins on digit positions all ranks agree on), whole bins are dealt to ranks by the all-gathered
+ * histogram, ONE span of the level-0 buffer travels per peer, the receiver runs level 1 + the cell sort (gx.h gx_sortx_*).
+ * Otherwise (floats, small shards, a bin too heavy for one rank, a failed device-side check): sample sort -- strided sample ->
+ * all-gather -> common splitters -> ONE range-partition pass per chunk -> exchange -> ONE local sort.
+ * dtype: a 4- or 8-byte numeric gx_dtype.  chunks <= 0: default (8; sample-sort path only).
  * force_exchange != 0: take the exchange path even for world == 1 (measurements / tests).
  * *out_keys (alloc'ed, *out_n elements). */
 int gxd_sort(gxd_comm* comm, int dtype, const void* keys, int64_t n, int chunks, int force_exchange, gxd_alloc_fn alloc,

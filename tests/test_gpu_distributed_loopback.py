@@ -91,6 +91,58 @@ def test_loopback_sort(fabric, dtype, kind, chunks, slot_scale):
         assert sizes.max() < 2.5 * total / W, sizes       # the sampled splitters balance the ranges (duplicates aside)
 
 
+@pytest.mark.parametrize("dtype,kind,shape", [
+    ("int64", "even", "uniform"), ("int64", "skewed", "uniform"), ("int64", "empty", "hot_value"), ("int32", "skewed", "uniform"),
+    ("int64", "even", "narrow_range"), ("uint64", "skewed", "uniform"), ("int64", "even", "heavy_bin")])
+def test_loopback_sort_fused(fabric, dtype, kind, shape):
+    """gxd_sort with the exchange BETWEEN the sort's two partition levels (gx_sortx_*): level 0 on every rank with common digit
+    positions, whole level-0 bins dealt to ranks by the all-gathered histogram, one span per peer, level 1 + cell sort on the
+    receiver.  Bit-exact against the oracle on the concatenation; `hot_value` puts a big cell on one receiver (sorted through X),
+    `heavy_bin` one level-0 bin too heavy for a rank -- the collective decision falls back to the sample-sort path."""
+    import torch
+    from cudf_amd import gxd
+    W = len(fabric)
+    rng = np.random.default_rng(400 + W)
+    total = W * 2_300_000 + 12_345
+    if dtype == "int32":
+        v = rng.integers(-2**31, 2**31 - 1, total).astype(np.int32)
+    elif dtype == "uint64":
+        v = rng.integers(0, 2**64 - 1, total, dtype=np.uint64)
+    else:
+        v = rng.integers(-2**63, 2**63 - 1, total, dtype=np.int64)
+        if shape == "narrow_range":
+            v = rng.integers(0, 1_000_000_000_000, total, dtype=np.int64)       # the top digit uses 233 of 256 bins, not byte aligned
+        elif shape == "hot_value":
+            v[rng.choice(total, 300_000, replace=False)] = v[17]                # > 8192 copies of one key: a big cell
+        elif shape == "heavy_bin":
+            hot = rng.random(total) < 0.8
+            v[hot] = (v[hot] & np.int64((1 << 52) - 1)) | np.int64(37 << 52)     # 80 % of all keys inside one level-0 bin
+    sh = _shards(rng, total, W, kind)
+    tv = v.view(np.int64) if dtype == "uint64" else v
+    ins = [_cuda(tv[a:b]) for a, b in sh]
+    if dtype == "uint64":
+        pytest.skip("no uint64 tensors on this path; the unsigned kernels are covered through the C ABI tests")
+    gxd.set_sort_mode(2)                                                          # fused from 2^21 rows per rank
+    try:
+        def rank_fn(r, c):
+            out = c.sort(ins[r], force_exchange=True)
+            return out.cpu().numpy(), c.last_timing()[0]
+        outs = gxd.run_ranks(fabric, rank_fn)
+    finally:
+        gxd.set_sort_mode(0)
+    got = np.concatenate([o[0] for o in outs])
+    assert got.tobytes() == orc.sort_keys(v).tobytes()
+    fused = [o[1] == -1.0 for o in outs]
+    assert all(fused) or not any(fused)                                           # a collective decision
+    if shape == "heavy_bin" and W > 1:
+        assert not any(fused)
+    else:
+        assert all(fused)
+        sizes = np.array([len(o[0]) for o in outs])
+        if shape == "uniform":
+            assert sizes.max() < 1.3 * total / W + 70_000, sizes                  # whole bins: the imbalance is below one bin
+
+
 @pytest.mark.parametrize("kind,chunks,slot_scale,row_bits,nbuild,nprobe", [
     ("even", 1, 0.0, 0, 2_600_000, 5_000_011),      # partitioned probe, (rank << s) | row decode on both sides
     ("skewed", 4, 0.0, 0, 2_600_000, 5_000_011),    # chunked probe overlapping the exchange
