@@ -134,8 +134,9 @@ def test_loopback_sort_fused(fabric, dtype, kind, shape):
     assert got.tobytes() == orc.sort_keys(v).tobytes()
     fused = [o[1] == -1.0 for o in outs]
     assert all(fused) or not any(fused)                                           # a collective decision
-    if shape == "heavy_bin" and W > 1:
-        assert not any(fused)
+    if shape == "heavy_bin":
+        if W >= 8:
+            assert not any(fused)             # 80 % of 18 M keys do not fit one rank's receive area: the sample-sort path ran
     else:
         assert all(fused)
         sizes = np.array([len(o[0]) for o in outs])
