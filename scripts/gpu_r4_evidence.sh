@@ -1,0 +1,51 @@
+#!/bin/bash
+# round 4 evidence run: usage gpu_r4_evidence.sh <run number> [pmc]
+#   default bench line (with the CPU legs), rocprofv3 --kernel-trace --stats summary of the same command, sorted_order line;
+#   with "pmc": FETCH_SIZE / WRITE_SIZE passes (separate runs) of sort / join / groupby at 1e9 rows -> r4_pmc_traffic_1e9.json
+set -u
+ulimit -c 0
+export HSA_ENABLE_COREDUMP=0 AMD_LOG_LEVEL=0 TMPDIR=/tmp
+R=${1:-99}
+mkdir -p gpurun_out
+O=gpurun_out
+L=$O/r4_run$R.log
+: > $L
+( time timeout 900 python bench.py ) > $O/r4_run${R}_bench_default.jsonl 2>> $L
+timeout 300 python bench.py --workload sorted_order --no-cpu-baseline > $O/r4_run${R}_bench_sorted_order.jsonl 2>> $L
+(cd /tmp && timeout 600 rocprofv3 --kernel-trace --stats -d "$GRAFT_REPO_ROOT/$O/prof_default" -o default -- python "$GRAFT_REPO_ROOT/bench.py" --no-cpu-baseline) > $O/r4_run${R}_bench_under_rocprof.jsonl 2>> $L
+db=$(find $O/prof_default -name "*.db" | head -1)
+[ -n "$db" ] && python scripts/rocprof_summary.py "$db" "round 4 run $R: rocprofv3 --kernel-trace --stats -- python bench.py --no-cpu-baseline (sort + join + groupby, 5 steps + 2 warm-up each)" | head -60 | cut -c1-190 > $O/r4_run${R}_default_kernel_stats.txt
+find $O/prof_default -name "*.db" -delete
+if [ "${2:-}" = "pmc" ]; then
+  pmc() { # workload, counter
+    local wl=$1; local ctr=$2
+    local lc=$(echo $ctr | tr 'A-Z' 'a-z')
+    (cd /tmp && timeout 300 rocprofv3 --kernel-trace --pmc $ctr -d "$GRAFT_REPO_ROOT/$O/pmc_${wl}_${lc}" -o $wl --output-format csv -- python "$GRAFT_REPO_ROOT/bench.py" --workload $wl --rows 1e9 --steps 1 --warmup 0 --no-cpu-baseline) >> $L 2>&1
+  }
+  for wl in sort join groupby; do
+    pmc $wl FETCH_SIZE
+    pmc $wl WRITE_SIZE
+  done
+  python scripts/pmc_to_json.py $O $O/r4_pmc_traffic_1e9.json "rocprofv3 --kernel-trace --pmc FETCH_SIZE and --pmc WRITE_SIZE passes (separate runs) of python bench.py --workload <w> --rows 1e9 --steps 1 --warmup 0 (scripts/gpu_r4_evidence.sh $R pmc)" | tee $O/r4_run${R}_pmc_traffic.txt
+  find $O/pmc_* -name "*.csv" -size +1M -delete
+fi
+if [ "${3:-}" = "tests" ]; then
+  timeout 400 python -m pytest tests/test_gpu_cpp_parity.py tests/test_gpu_sort_place.py -m gpu -q -x -k "not 70000000 and not capacity and not float64" > $O/r4_run${R}_pytest.log 2>&1
+  echo "pytest exit $?" | tee -a $L
+  tail -4 $O/r4_run${R}_pytest.log | tee -a $L
+fi
+python - <<PY | tee -a $L
+import json
+for f in ('$O/r4_run${R}_bench_default.jsonl', '$O/r4_run${R}_bench_sorted_order.jsonl'):
+    for line in open(f):
+        try: d = json.loads(line)
+        except Exception: continue
+        r = d.get('roofline') or {}
+        print(d['config']['workload'][:60], round(d['ms_per_step'], 3), 'ms | frac', round(r.get('frac', 0), 3), '| path_frac', round(r.get('path_frac', 0), 3), {k[:22]: round(v, 2) for k, v in (r.get('kernels_ms') or {}).items()})
+        for k in ('join', 'groupby'):
+            if k in d:
+                rr = d[k].get('roofline') or {}
+                print('  ', k, round(d[k]['ms_per_step'], 3), 'ms | frac', round(rr.get('frac', 0), 3), {kk[:18]: round(v, 2) for kk, v in (rr.get('kernels_ms') or {}).items()})
+PY
+head -24 $O/r4_run${R}_default_kernel_stats.txt | cut -c1-170
+grep -E "real|Error|error|Traceback" $L | head

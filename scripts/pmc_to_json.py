@@ -12,11 +12,26 @@ import os
 import re
 import sys
 
+def csrc_sha16():
+    """first 16 hex digits of the sha256 over the kernel sources (cudf_amd/csrc/*.hip, *.hpp, sorted by name): bench.py attaches a
+    committed traffic figure to its roofline object only while the kernels it was measured on are the kernels it runs"""
+    import hashlib
+    root = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "cudf_amd", "csrc")
+    h = hashlib.sha256()
+    for f in sorted(os.listdir(root)):
+        if f.endswith(".hip") or f.endswith(".hpp"):
+            h.update(f.encode())
+            h.update(open(os.path.join(root, f), "rb").read())
+    return h.hexdigest()[:16]
+
+
 GROUPS = {  # group -> (workload, base names whose LARGEST dispatch is summed)
     "sort local stage": ("sort", ["k_local_place", "k_local_sort"]),
     "sort": ("sort", ["k_hf_sample", "k_hf_plan", "k_hf_scatter level 0", "k_hf_scatter level 1", "k_hy_hist", "k_msd_pass level 0",
                       "k_msd_pass level 1", "k_plan2", "k_local_place", "k_local_sort"]),
     "join probe phase": ("join", ["k_pj2_scatter", "k_pj2_offsets", "k_pj2_probe_pipe"]),
+    "join build": ("join", ["k_pj_hist", "k_pj_offsets", "k_pj_scatter", "k_bw_split", "k_bw_build", "k_bw_fixup"]),
+    "sorted_order": ("sorted_order", ["k_hy_hist", "k_msd_pass level 0", "k_msd_pass level 1", "k_plan2", "k_local_place", "k_local_sort"]),
     "join probe phase (exact two-pass)": ("join", ["k_pj_hist", "k_pj_offsets", "k_pj_scatter", "k_pj_probe_pipe"]),
     "groupby": ("groupby", ["k_slot_sample", "k_slot_plan", "k_part_reset_cursors", "k_part_scatter", "k_part_aggregate"]),
     "groupby (exact two-pass)": ("groupby", ["k_part_hist", "k_part_offsets", "k_part_scatter", "k_part_aggregate"]),
@@ -88,7 +103,7 @@ def main(root, out_path, note):
         tot = sum(e["hbm_bytes_per_launch"] for k, e in per.items() if any(k == m or k.startswith(m + " ") for m in members))
         groups[g] = {"hbm_bytes_per_launch": tot, "members": have, "workload": wl,
                      "note": "one step = the largest launch of each member (speculative branches that did not run contribute ~0)"}
-    json.dump({"source": note, "rows": 1000000000, "correction": "hbm_bytes = (2 * FETCH_SIZE + WRITE_SIZE) * 1024",
+    json.dump({"source": note, "rows": 1000000000, "csrc_sha16": csrc_sha16(), "correction": "hbm_bytes = (2 * FETCH_SIZE + WRITE_SIZE) * 1024",
                "kernels": kernels, "groups": groups}, open(out_path, "w"), indent=1)
     for k, v in sorted(kernels.items(), key=lambda kv: -kv[1]["hbm_bytes_per_launch"]):
         print(f"{k:60s} {v['hbm_bytes_per_launch'] / 1e9:9.2f} GB/launch  [{v['workload']}]")
