@@ -35,11 +35,22 @@ class communicator {
   ~communicator() { gxd_comm_destroy(_c); }
   communicator(communicator const&)            = delete;
   communicator& operator=(communicator const&) = delete;
+  // `world` LOGICAL ranks on the current device (gxd_comm_create_loopback): device-to-device copies stand in for the links.  Each
+  // communicator must be driven by a host thread of its own on a NON-BLOCKING stream of its own (the operators are collective).
+  static std::vector<std::unique_ptr<communicator>> loopback(int world)
+  {
+    std::vector<gxd_comm*> raw(static_cast<std::size_t>(world > 0 ? world : 0), nullptr);
+    CUDF_EXPECTS(world > 0 && gxd_comm_create_loopback(world, raw.data()) == 0, gxd_last_error());
+    std::vector<std::unique_ptr<communicator>> out;
+    for (auto* r : raw) out.emplace_back(std::unique_ptr<communicator>(new communicator(r)));
+    return out;
+  }
   [[nodiscard]] int rank() const { return gxd_comm_rank(_c); }
   [[nodiscard]] int world() const { return gxd_comm_world(_c); }
   [[nodiscard]] gxd_comm* get() const { return _c; }
 
  private:
+  explicit communicator(gxd_comm* c) : _c{c} {}
   gxd_comm* _c{nullptr};
 };
 

@@ -30,6 +30,8 @@
 #include <numeric>
 #include <random>
 #include <cudf/partitioning.hpp>
+
+#include <thread>
 #include <cudf_amd/distributed.hpp>
 
 #include <algorithm>
@@ -1365,6 +1367,77 @@ int main()
     bool good = true;
     for (int g = 0; g < 5000 && good; ++g) good = ok_[g] == g && os_[g] == ws[g] && oc_[g] == wc[g];  // keys ascending
     CHECK(good);
+  });
+
+  run("cudf_amd::distributed::sort / hash_join over 3 LOGICAL ranks on one device (loopback transport, one thread per rank)", [] {
+    namespace D = cudf_amd::distributed;
+    constexpr int W = 3;
+    auto comms = D::communicator::loopback(W);
+    CHECK((int)comms.size() == W && comms[2]->rank() == 2 && comms[0]->world() == W);
+    // shards of different sizes, one of them empty
+    std::vector<std::vector<int64_t>> shard(W), bshard(W), pshard(W);
+    std::vector<int64_t> all, ball, pall;
+    uint64_t x = 0x9E3779B97F4A7C15ull;
+    auto next = [&] { x ^= x << 13; x ^= x >> 7; x ^= x << 17; return x; };
+    const std::size_t sizes[W] = {1'500'003, 0, 700'001};
+    for (int r = 0; r < W; ++r)
+      for (std::size_t i = 0; i < sizes[r]; ++i) shard[r].push_back(static_cast<int64_t>(next()));
+    for (int r = 0; r < W; ++r) all.insert(all.end(), shard[r].begin(), shard[r].end());
+    for (std::size_t i = 0; i < 300'000; ++i) bshard[i % 2 ? 0 : 2].push_back(static_cast<int64_t>(i * 5 + 2));  // distinct build keys on ranks 0 and 2
+    for (int r = 0; r < W; ++r)
+      for (std::size_t i = 0; i < 400'000 + 100'000 * r; ++i) pshard[r].push_back(static_cast<int64_t>(next() % 2'000'000));
+    std::vector<std::vector<int64_t>> sorted(W), jl(W), jr(W);
+    std::vector<std::string> errs(W);
+    std::vector<std::thread> th;
+    for (int r = 0; r < W; ++r)
+      th.emplace_back([&, r] {
+        try {
+          hipStream_t s = nullptr;
+          if (hipStreamCreateWithFlags(&s, hipStreamNonBlocking) != hipSuccess) throw std::runtime_error("stream");
+          rmm::cuda_stream_view sv{s};
+          {  // (every column / buffer made on `s` goes back to the pool before the stream is destroyed)
+            auto kc  = make_col<int64_t>(shard[r]);
+            auto out = D::sort(kc->view(), *comms[r], true, sv);
+            sv.synchronize();
+            sorted[r] = to_host<int64_t>(out->view());
+            auto bc = make_col<int64_t>(bshard[r]);
+            auto pc = make_col<int64_t>(pshard[r]);
+            D::hash_join hj{bc->view(), *comms[r], true, sv};
+            auto [l, rr] = hj.inner_join(pc->view(), sv);
+            sv.synchronize();
+            jl[r] = to_host<int64_t>(l->view());
+            jr[r] = to_host<int64_t>(rr->view());
+          }
+          sv.synchronize();
+          (void)hipStreamDestroy(s);
+        } catch (std::exception const& e) {
+          errs[r] = e.what();
+        }
+      });
+    for (auto& t : th) t.join();
+    for (int r = 0; r < W; ++r) CHECK(errs[r].empty());
+    std::vector<int64_t> got;
+    for (int r = 0; r < W; ++r) got.insert(got.end(), sorted[r].begin(), sorted[r].end());
+    std::sort(all.begin(), all.end());
+    CHECK((got == all));  // rank order = key order
+    // pairs: (global probe row, global build row) -- global row = first row of the owning rank's shard + local row
+    for (int r = 0; r < W; ++r) {
+      ball.insert(ball.end(), bshard[r].begin(), bshard[r].end());
+      pall.insert(pall.end(), pshard[r].begin(), pshard[r].end());
+    }
+    std::size_t expect = 0, have = 0;
+    for (auto v : pall) expect += (v % 5 == 2 && v / 5 < 300'000) ? 1 : 0;
+    bool ok = true;
+    std::vector<uint8_t> hit(pall.size(), 0);
+    for (int r = 0; r < W; ++r) {
+      have += jl[r].size();
+      for (std::size_t i = 0; i < jl[r].size() && ok; ++i) {
+        ok = jl[r][i] >= 0 && jl[r][i] < (int64_t)pall.size() && jr[r][i] >= 0 && jr[r][i] < (int64_t)ball.size() && pall[jl[r][i]] == ball[jr[r][i]] &&
+             !hit[jl[r][i]];
+        if (ok) hit[jl[r][i]] = 1;
+      }
+    }
+    CHECK(ok && have == expect);
   });
 
   std::printf("%d run, %d failed\n", g_run, g_failed);
