@@ -56,7 +56,8 @@ def parse():
     ap.add_argument("--gb-keys", default="dense", choices=["dense", "random", "random64"],
                     help="groupby: dense = int32 ids in [0, 1e6) (BASELINE config 4); random = the same ids through a 32-bit mixing bijection "
                          "(sparse int32 keys: they hash like random numbers); random64 = int64 keys, ids through the splitmix64 finalizer")
-    ap.add_argument("--gb-pbits", type=int, default=9, help="groupby knob: 2^bits hash partitions (8 = round-2 layout, 9 = default)")
+    ap.add_argument("--gb-pbits", type=int, default=0, help="groupby knob: 2^bits hash partitions; 0 (default) = 512, and 256 chosen on the device for "
+                                                              "dense ids (round 4); 8 / 9 = fixed")
     ap.add_argument("--gb-spec", type=int, default=1, help="groupby knob: 1 hist-free speculative partition pass (default), 0 exact histogram pass")
     ap.add_argument("--no-partitioned-join", action="store_true", help="join: probe the table directly")
     ap.add_argument("--join-probe-kernel", type=int, default=0, help="join knob: 0 pipelined tag probe, 1 round-1 tag probe")

@@ -183,7 +183,7 @@ __global__ void __launch_bounds__(GBT) k_compact(const unsigned long long* __res
 // memory-side atomics per row instead.
 // ------------------------------------------------------------------------------------------------
 constexpr int NPART  = 512;          // MAXIMUM number of partitions (array sizes, launch bounds); 1 << d_gb_pbits are in use
-__device__ int d_gb_pbits = 9;       // partition bits in use (8 or 9): see gx_groupby_set_partition_bits
+__device__ int d_gb_pbits = 9;       // partition bits in use (8 or 9): see gx_groupby_set_partition_bits (a call's PartPlan may override it)
 static int g_gb_pbits     = 9;       // host mirror
 constexpr int PBT    = 512;          // scatter workgroup
 constexpr int PRPT   = 16;           // rows per thread -> 8192-row tiles
@@ -213,7 +213,16 @@ struct PartPlan {
   uint32_t slot0[NRANGE][NPART];
   uint32_t cap0[NRANGE][NPART];
   alignas(128) unsigned int overflow;        // speculative pass: a slot outgrew its capacity -> the exact sequence runs
+  // Round 4: the partition bits of THIS call (0: the process-wide d_gb_pbits).  k_slot_plan picks 8 for DENSE ids -- the sampled
+  // keys span no more than 2 x max_groups values: consecutive integers under the Fibonacci slot hash are a low-discrepancy
+  // sequence, an LDS table at 58 % load has next to no collisions, and 256 partitions give the scatter 32-row runs -- and 9
+  // otherwise (keys that hash like random numbers need the lower load of 512 tables: 12.7 vs 19.5 ms for sparse int32 keys,
+  // while dense keys run 9.53 vs 10.08 ms at 8 vs 9 bits; profiles/r4_run5_bench_groupby_pbits*.jsonl).
+  int pbits;
+  int auto_pbits;                            // host: let k_slot_plan choose
+  unsigned long long kmin, kmax;             // k_slot_sample: smallest / largest sampled key (order-preserving 64-bit form)
 };
+__device__ __forceinline__ int part_pbits(const PartPlan* plan) { return plan->pbits ? plan->pbits : d_gb_pbits; }
 
 // Round 3: no histogram pass in the common case.  Region (partition p, range r) owns a slot of `cap` rows at
 // (p * NRANGE + r) * cap of the partitioned arrays (cap = mean + 8 sigma of a uniform hash); the scatter adds a tile's
@@ -246,7 +255,7 @@ __global__ void __launch_bounds__(256) k_part_hist(const K* __restrict__ keys, c
   if (gated && plan->overflow == 0) return;  // the speculative pass held
   for (int i = threadIdx.x; i < NPART; i += 256) s_h[i] = 0;
   __syncthreads();
-  const int psh        = 64 - d_gb_pbits;
+  const int psh        = 64 - part_pbits(plan);
   const int r          = blockIdx.x % NRANGE;  // block b -> XCD b % 8 reads the rows it will scatter
   const int64_t jb     = blockIdx.x / NRANGE;
   const int64_t nb     = gridDim.x / NRANGE;
@@ -340,7 +349,7 @@ __global__ void __launch_bounds__(PBT) k_part_scatter(const K* __restrict__ keys
   __shared__ uint32_t s_total;
 
   const unsigned tid = threadIdx.x;
-  const int psh      = 64 - d_gb_pbits;
+  const int psh      = 64 - part_pbits(plan);
   const int64_t tile = nrange == 1 ? (int64_t)blockIdx.x : xcd_swizzle(blockIdx.x, gridDim.x);
   const int64_t rper = range_tiles(n);
   const int range    = nrange == 1 ? 0 : ((rper > 0 && tile / rper < NRANGE - 1) ? (int)(tile / rper) : NRANGE - 1);
@@ -486,10 +495,15 @@ __global__ void __launch_bounds__(ABT) k_part_aggregate(const K* __restrict__ pk
                                                         const uint8_t* __restrict__ pflags, const PartPlan* plan,
                                                         int nsplit, int nsub, unsigned long long* table, uint32_t log2cap,
                                                         double* sum, double* comp, uint32_t* cnt_valid,
-                                                        uint32_t* cnt_all, GbState* st, uint32_t cap = 0, int gated = 0)
+                                                        uint32_t* cnt_all, GbState* st, uint32_t cap = 0, int gated = 0, int nsub8 = 0)
 {
   // cap > 0: the speculative pass (skipped when a slot overflowed); cap == 0 && gated: the exact pass behind it
   if (cap ? plan->overflow != 0 : (gated && plan->overflow == 0)) return;
+  // the grid is sized for the process-wide partition bits; a call whose plan chose 8 (dense ids) uses nsub8 workgroups per
+  // partition and the surplus workgroups leave
+  const int pb = part_pbits(plan);
+  if (plan->pbits == 8 && nsub8 > 0) nsub = nsub8;
+  if (blockIdx.x >= (unsigned)((1 << pb) * nsplit * nsub)) return;
   constexpr int S     = lds_slots<K, HAS_VV>();
   constexpr K EMPTYK  = K(~K(0));   // rows with this key use the dedicated slot S
   extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -563,7 +577,7 @@ __global__ void __launch_bounds__(ABT) k_part_aggregate(const K* __restrict__ pk
         slot      = S;
         s_special = 1u;  // benign race: every writer stores 1
       } else {
-        uint32_t h = (uint32_t)(((part_hash<K>(key) >> (32 - d_gb_pbits)) & 0xFFFFFFFFull) * (uint64_t)S >> 32);
+        uint32_t h = (uint32_t)(((part_hash<K>(key) >> (32 - pb)) & 0xFFFFFFFFull) * (uint64_t)S >> 32);
         for (int probes = 0; probes < S; ++probes) {
           K cur = l_key[h];
           if (cur == EMPTYK) {
@@ -638,6 +652,7 @@ static inline int lds_nsub(int64_t max_groups, int lds_slots)
   return nsub;
 }
 
+static thread_local int g_gb_auto = 1;       // 1 = a call's plan may choose 8 partition bits for dense ids (PartPlan::pbits); gx_groupby_set_partition_bits(8 | 9) switches it off
 static thread_local int g_gb_spec = 1;       // A/B knob: 1 = speculative hist-free partition pass (default), 0 = always the exact pass, 2 = speculative for every n
 static thread_local int g_gb_algorithm = 0;  // 0 auto, 1 global-atomic table only, 2 partitioned whenever possible
 static thread_local int g_gb_nsplit    = 1;
@@ -669,10 +684,12 @@ __global__ void __launch_bounds__(256) k_slot_sample(const K* __restrict__ keys,
   const unsigned tid = threadIdx.x, lane = lane_id();
   for (int i = tid; i < NRANGE * NPART; i += 256) s_hist[i] = 0;
   __syncthreads();
-  const int psh         = 64 - d_gb_pbits;
+  const int psh         = 64 - d_gb_pbits;  // (the sample is always taken on the process-wide bits; k_slot_plan may fold it to 8)
   const int64_t step    = (int64_t)stride * GX_WAVE;
   const int64_t nchunks = div_up(n, step);
   const int64_t nw      = (int64_t)gridDim.x * 4;
+  unsigned long long kmin = ~0ull, kmax = 0ull;  // order-preserving form: sign bit flipped for signed keys
+  constexpr unsigned long long SIGN = std::is_signed<K>::value ? (1ull << (8 * sizeof(K) - 1)) : 0ull;
   for (int64_t c = (int64_t)blockIdx.x * 4 + tid / GX_WAVE; c < nchunks; c += nw) {
     const int64_t row = c * step + lane;
     const bool live   = row < n && (!kvalid || bit_is_set(kvalid, row));
@@ -680,6 +697,20 @@ __global__ void __launch_bounds__(256) k_slot_sample(const K* __restrict__ keys,
     const int64_t r64 = range_rows > 0 ? row / range_rows : (int64_t)(NRANGE - 1);
     const int r       = r64 < NRANGE - 1 ? (int)r64 : NRANGE - 1;
     (void)lds_rank(s_hist + r * NPART, (uint32_t)(part_hash<K>(k) >> psh), live);
+    if (live) {
+      typedef typename std::make_unsigned<K>::type UK;
+      const unsigned long long u = (unsigned long long)(UK)k ^ SIGN;
+      kmin = u < kmin ? u : kmin;
+      kmax = u > kmax ? u : kmax;
+    }
+  }
+  if (plan->auto_pbits) {
+    kmin = wave_reduce(kmin, MinOp());
+    kmax = wave_reduce(kmax, MaxOp());
+    if (lane == 0 && kmin <= kmax) {
+      atomicMin(&plan->kmin, kmin);
+      atomicMax(&plan->kmax, kmax);
+    }
   }
   __syncthreads();
   for (int i = tid; i < NRANGE * NPART; i += 256) {
@@ -691,10 +722,30 @@ __global__ void __launch_bounds__(256) k_slot_sample(const K* __restrict__ keys,
 // one block of NPART threads: capacities = estimate + 8 sigma of the estimate + two sample steps + a constant, slots laid
 // out partition-major (the NRANGE slots of a partition are neighbours)
 template <typename Plan>
-__global__ void __launch_bounds__(NPART) k_slot_plan(Plan* plan, int64_t n, int stride, int64_t range_rows, unsigned long long elems)
+__global__ void __launch_bounds__(NPART) k_slot_plan(Plan* plan, int64_t n, int stride, int64_t range_rows, unsigned long long elems,
+                                                     long long max_groups = 0)
 {
   __shared__ uint32_t s_tmp[NPART / GX_WAVE + 1];
   const int t = threadIdx.x;
+  if constexpr (std::is_same<Plan, PartPlan>::value) {
+    // dense ids (the sampled keys span at most 2 x max_groups values, from 0): 256 partitions -- the sample's 512 bins fold pairwise
+    // (partition = top bits of the hash) -- otherwise the process-wide bits.  See PartPlan::pbits.
+    if (plan->auto_pbits && d_gb_pbits == 9) {
+      // (max_groups must be a real bound -- a quarter of the rows at most: a caller that passes n says nothing about the key range)
+      const bool dense = max_groups > 0 && 4 * max_groups <= (long long)n && plan->kmax < 2ull * (unsigned long long)max_groups;
+      if (dense) {
+        uint32_t a[NRANGE], b[NRANGE];
+        for (int r = 0; r < NRANGE; ++r) {
+          a[r] = t < NPART / 2 ? plan->samp[r][2 * t] : 0u;
+          b[r] = t < NPART / 2 ? plan->samp[r][2 * t + 1] : 0u;
+        }
+        __syncthreads();
+        for (int r = 0; r < NRANGE; ++r) plan->samp[r][t] = a[r] + b[r];
+        __syncthreads();
+      }
+      if (t == 0) plan->pbits = dense ? 8 : 9;
+    }
+  }
   uint32_t cap[NRANGE];
   uint32_t sum = 0;
   for (int r = 0; r < NRANGE; ++r) {
@@ -752,8 +803,12 @@ int launch_partitioned(const K* keys, const uint32_t* kvalid, const V* vals, con
   }
   const int nsplit    = g_gb_nsplit;
   const int nsub      = lds_nsub(max_groups, S);
+  // the plan of a call may choose 8 bits (dense ids): workgroups per partition for that case; the grid covers both
+  int nsub8 = 1;
+  while (nsub8 < 16 && (double)(max_groups < 1 ? 1 : max_groups) / 256.0 / nsub8 > 0.65 * S) nsub8 *= 2;
   const unsigned sgrd = (unsigned)div_up(n, PTILE);
-  const unsigned agrd = (unsigned)((1 << g_gb_pbits) * nsplit * nsub);
+  unsigned agrd       = (unsigned)((1 << g_gb_pbits) * nsplit * nsub);
+  if (g_gb_auto && g_gb_pbits == 9 && (unsigned)(256 * nsplit * nsub8) > agrd) agrd = (unsigned)(256 * nsplit * nsub8);
   const bool spec     = part_speculative(n);
   int gated           = 0;
   if (spec) {  // speculative pass: no histogram, padded slots (see PartPlan)
@@ -762,11 +817,16 @@ int launch_partitioned(const K* keys, const uint32_t* kvalid, const V* vals, con
     const int64_t range_rows = range_tiles(n) * PTILE;
     int64_t sblocks          = div_up(div_up(n, (int64_t)stride * GX_WAVE), (int64_t)4 * 8);
     if (sblocks > 2048) sblocks = 2048;
+    if (g_gb_auto && g_gb_pbits == 9) {  // let k_slot_plan choose the partition bits of this call (PartPlan::pbits)
+      static const int one = 1;
+      GX_HIP_TRY(hipMemcpyAsync(&plan->auto_pbits, &one, sizeof(int), hipMemcpyHostToDevice, s));
+    }
     hipLaunchKernelGGL((k_slot_sample<K>), dim3((unsigned)sblocks), dim3(256), 0, s, keys, kvalid, n, plan, stride, range_rows);
-    hipLaunchKernelGGL((k_slot_plan<PartPlan>), dim3(1), dim3(NPART), 0, s, plan, n, stride, range_rows, (unsigned long long)slot_elems(n, stride));
+    hipLaunchKernelGGL((k_slot_plan<PartPlan>), dim3(1), dim3(NPART), 0, s, plan, n, stride, range_rows, (unsigned long long)slot_elems(n, stride),
+                       (long long)max_groups);
     hipLaunchKernelGGL(ks, dim3(sgrd), dim3(PBT), lds_s, s, keys, kvalid, vals, vvalid, n, plan, pkeys, pvals, pflags, NRANGE, cap, 0);
     hipLaunchKernelGGL(ka, dim3(agrd), dim3(ABT), lds_a, s, pkeys, pvals, pflags, plan, nsplit, nsub, table, lg, sum, comp, cv, ca, st, cap,
-                       0);
+                       0, nsub8);
     hipLaunchKernelGGL(k_part_reset_cursors, dim3(1), dim3(NPART), 0, s, plan);
     gated = 1;  // the exact sequence below runs only if a slot overflowed
   }
@@ -774,7 +834,7 @@ int launch_partitioned(const K* keys, const uint32_t* kvalid, const V* vals, con
   hipLaunchKernelGGL(k_part_offsets, dim3(1), dim3(NPART), 0, s, plan, gated);
   hipLaunchKernelGGL(ks, dim3(sgrd), dim3(PBT), lds_s, s, keys, kvalid, vals, vvalid, n, plan, pkeys, pvals, pflags, g_gb_nrange, 0u, gated);
   hipLaunchKernelGGL(ka, dim3(agrd), dim3(ABT), lds_a, s, pkeys, pvals, pflags, plan, nsplit, nsub, table, lg, sum, comp, cv, ca, st, 0u,
-                     gated);
+                     gated, nsub8);
   GX_LAUNCH_CHECK();
   return 0;
 }
@@ -893,6 +953,8 @@ void gx_groupby_set_partition_mode(int speculative) { gx::gb::g_gb_spec = specul
 
 int gx_groupby_set_partition_bits(int bits)
 {
+  // 0: 512 partitions process-wide, and the sum / count path picks 256 per call for dense ids (default); 8 / 9: fixed
+  gx::gb::g_gb_auto = bits == 0 ? 1 : 0;
   const int v = bits == 8 ? 8 : 9;
   GX_HIP_TRY(hipMemcpyToSymbol(HIP_SYMBOL(gx::gb::d_gb_pbits), &v, sizeof(int)));
   gx::gb::g_gb_pbits = v;

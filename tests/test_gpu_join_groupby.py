@@ -459,4 +459,35 @@ def test_groupby_speculative_partition_pass(gx, spec, shape, nulls, pbits):
         np.testing.assert_array_equal(mx.to_numpy()[o2][em], res["max"][0][em])
     finally:
         _lib.lib.gx_groupby_set_partition_mode(1)
-        _lib.lib.gx_groupby_set_partition_bits(9)
+        _lib.lib.gx_groupby_set_partition_bits(0)   # the default: 512 partitions, 256 chosen per call for dense ids
+
+
+@pytest.mark.parametrize("keys_kind", ["dense_ids", "sparse_ids", "dense_int32", "loose_bound"])
+def test_groupby_partition_bits_chosen_on_the_device(gx, keys_kind):
+    """Round 4: in the default mode k_slot_plan picks 256 partitions for DENSE ids (sampled keys below 2 x max_groups, max_groups a
+    real bound) and 512 otherwise; the sample's 512 bins fold pairwise, scatter / aggregate / the gated exact pass read the bits
+    from the call's plan.  Results against the oracle for ids that take the 8-bit layout, sparse ids that keep 9 bits, and a
+    max_groups that is no bound at all (no choice is made); one hot key on top makes a slot overflow, so the exact pass runs on
+    the plan's bits as well."""
+    Column, ops = gx
+    from cudf_amd import _lib
+    rng = np.random.default_rng(17)
+    n = 5_000_011                                        # >= 2^22: the speculative pass (and with it the sample) runs by default
+    ngroups = 200_000
+    if keys_kind == "sparse_ids":
+        ids = rng.integers(0, 2**62, ngroups, dtype=np.int64)
+        keys = ids[rng.integers(0, ngroups, n)]
+    elif keys_kind == "dense_int32":
+        keys = rng.integers(0, ngroups, n).astype(np.int32)
+    else:
+        keys = rng.integers(0, ngroups, n).astype(np.int64)
+    keys[rng.random(n) < 0.25] = keys[11]                # a hot key: its slot overflows -> the gated exact pass
+    vals = rng.integers(-1000, 1000, n).astype(np.float64)   # integer-valued: sums exact in any order
+    hint = n if keys_kind == "loose_bound" else 1 << 18
+    _lib.lib.gx_groupby_set_partition_bits(0)
+    k, s, cv, ca = ops.groupby_sum_count(Column.from_numpy(keys), Column.from_numpy(vals), max_groups_hint=hint)
+    o = np.argsort(k.to_numpy(), kind="stable")
+    ek, res = orc.groupby_agg(keys, vals, ["sum", "count_valid"])
+    np.testing.assert_array_equal(k.to_numpy()[o], ek)
+    np.testing.assert_array_equal(cv.to_numpy()[o], res["count_valid"][0])
+    np.testing.assert_array_equal(s.to_numpy()[o], res["sum"][0])
