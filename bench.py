@@ -265,6 +265,23 @@ class Ctx:
         return col.data[: col.size * col.dtype.itemsize].view(dt)
 
 
+def sharded_step(c, cpp_step, py_step):
+    """the step a multi-GPU line times: the C++ operators over RCCL; the torch.distributed implementation only if their first
+    call raises (decided collectively: every rank takes the same one)"""
+    ok = 1
+    try:
+        cpp_step()
+        c.torch.cuda.synchronize()
+    except Exception as e:  # noqa: BLE001
+        print(f"bench.py: C++ sharded operator failed on rank {c.rank} ({e!r})", file=sys.stderr)
+        ok = 0
+    t = c.torch.tensor([ok], device="cuda")
+    c.dist.all_reduce(t, op=c.dist.ReduceOp.MIN)
+    if int(t.item()) == 1:
+        return cpp_step, "C++ operators over RCCL"
+    return py_step, "torch.distributed fallback (the C++ operator's first call failed)"
+
+
 def lsr_mix64(j):
     """splitmix64 finalizer on int64 tensors (a bijection of the 64-bit integers); logical shifts: mask off the sign extension"""
     x = j
@@ -364,10 +381,13 @@ def bench_sort(c, pairs=False, cpu_leg=True):
 
     if c.world > 1:
         from cudf_amd import distributed as D
-        local_ops = D.HipLocalOps()
         dkeys = c.as_tensor(keys, c.torch.int64)
-        step = lambda: D.distributed_sort(dkeys, local=local_ops)
-        workload = f"{n:.0e}-row-per-GPU int64 distributed sort (splitters from a sample, range partition, all-to-all, one local sort)"
+        # CUDA tensors and no `local` object: the C++ operators over RCCL (cudf_amd/cpp/src/distributed.cpp, gxd_sort).  Should their
+        # first call fail on a box they have never seen (no multi-GPU hardware was available to any round), the torch.distributed
+        # implementation of round 2 takes over and the line says so.
+        step, sharded_impl = sharded_step(c, lambda: D.distributed_sort(dkeys), lambda: D.distributed_sort(dkeys, local=D.HipLocalOps()))
+        workload = (f"{n:.0e}-row-per-GPU int64 distributed sort (level 0 on every rank, level-0 bins dealt to ranks, one span per peer over "
+                    f"xGMI, level 1 + cell sort on the receiver) [{sharded_impl}]")
         sec = c.timed(step)
         res = step()
         assert bool((res[1:] >= res[:-1]).all()), "distributed sort: shard not sorted"
@@ -467,14 +487,17 @@ def bench_join(c):
     lib.gx_join_set_build_kernel(a.join_build_kernel)
     if c.world > 1:
         from cudf_amd import distributed as D
-        local_ops = D.HipLocalOps()
         torch.manual_seed(12345 + c.rank)
         dbk = (torch.randperm(nb_rows, device="cuda") + c.rank * nb_rows) * 3 + 1           # globally distinct build keys
         dpk = c.as_tensor(ops.random_column(np.int64, n, seed=67890 + c.rank, lo=0, hi=int(nb_rows * c.world / 0.3)), torch.int64) * 3 + 1
         # like the single-GPU line (and cudf::hash_join): the build side is exchanged and hashed ONCE, untimed;
         # a step = hash-partition the probe shard, all-to-all, probe the local table
         tb = time.perf_counter()
-        hj = D.DistributedHashJoin(dbk, local=local_ops)
+        try:
+            hj = D.DistributedHashJoin(dbk)         # the C++ operators over RCCL (gxd_join_build / gxd_join_probe)
+        except Exception as e:  # noqa: BLE001 -- see sharded_step
+            print(f"bench.py: C++ sharded join failed ({e!r}); torch.distributed implementation instead", file=sys.stderr)
+            hj = D.DistributedHashJoin(dbk, local=D.HipLocalOps())
         torch.cuda.synchronize()
         build_ms = (time.perf_counter() - tb) * 1e3
         step = lambda: hj.inner_join(dpk)
@@ -660,9 +683,9 @@ def bench_groupby(c):
         del ids
     if c.world > 1:
         from cudf_amd import distributed as D
-        local_ops = D.HipLocalOps()
         dgk, dgv = c.as_tensor(gk, torch.int32), c.as_tensor(gv, torch.float64)
-        step = lambda: D.distributed_groupby_sum_count(dgk, dgv, local=local_ops)
+        step, _ = sharded_step(c, lambda: D.distributed_groupby_sum_count(dgk, dgv),   # gxd_groupby_sum_count
+                               lambda: D.distributed_groupby_sum_count(dgk, dgv, local=D.HipLocalOps()))
         sec = c.timed(step)
         k, s, cnt = step()
         tot = cnt.sum().to(torch.int64)
@@ -969,6 +992,8 @@ def main():
                 r["traffic_GBps"] = r["traffic"] / (r["avg_launch_ms"] * 1e-3) / 1e9
         print(json.dumps(line), flush=True)
     if c.world > 1:
+        from cudf_amd import distributed as D
+        D.close_communicators()  # the RCCL communicators of the C++ operators, before the process group they were made with
         c.dist.destroy_process_group()
 
 
