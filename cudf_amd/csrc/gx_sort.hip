@@ -297,8 +297,13 @@ __device__ __forceinline__ void plan_local_digits(HybridPlan& hy, unsigned long 
 // One block of 256 threads.  STAGE 0 (after k_hy_hist<SPEC>): digits from the varying-bit mask.  STAGE 1 (after
 // k_hy_hist<!SPEC>): level-0 histogram totals, bin bases per input range, level-0 segment tables.
 __global__ void __launch_bounds__(BINS) k_hy_plan(SortPlan* plan, int stage, int key_bits, int64_t n, int bits2, int cell_max,
-                                                  int pos_bits, int64_t range_rows, int tile_rows, uint32_t* base1)
+                                                  int pos_bits, int64_t range_rows, int tile_rows, uint32_t* base1, int cell_alt = 0)
 {
+  // cell_alt (round 4; sorted_order's pairs): a larger cell capacity (16384) the launches behind are also prepared for.  bits2 comes
+  // from n alone; keys whose range is not a power of two have fuller buckets than n / 256, their 8192-key cells overflow and the
+  // column fell to the LSD pair passes (91 ms per 1e9 rows, profiles/r4_run8_bench_sorted_order_range1e12.jsonl).  Stage 1 has the
+  // exact level-0 histogram: when a bucket's mean cell would not fit it switches the whole sort to the larger cells (one
+  // workgroup per CU in the cell sort: slower than 8192-key cells, several times faster than the LSD passes).
   __shared__ uint32_t s_tmp[BINS / GX_WAVE + 1];
   HybridPlan& hy = plan->hy;
   const int t    = threadIdx.x;
@@ -340,6 +345,12 @@ __global__ void __launch_bounds__(BINS) k_hy_plan(SortPlan* plan, int stage, int
   const uint32_t exc = block_exclusive_scan<BINS>(c, 0u, SumOp(), s_tmp, (uint32_t*)nullptr);
   hy.hist0[t] = c;
   hy.gbin0[t] = exc;
+  if (cell_alt > cell_max) {
+    const int full = ((unsigned long long)c >> hy.bits2) > (unsigned long long)(0.97 * (double)cell_max) ? 1 : 0;
+    int alt_bits   = 0;
+    while ((1 << alt_bits) < cell_alt) ++alt_bits;
+    if (__syncthreads_or(full) && t == 0 && (pos_bits == 0 || hy.shift2 + alt_bits <= 64)) hy.cell_max = cell_alt;
+  }
   uint32_t run = exc;
   for (int r = 0; r < NRANGE; ++r) {  // level-0 output base of bin t for every input range
     base1[r * NB2MAX + t] = run;
@@ -984,10 +995,11 @@ __global__ void __launch_bounds__(BT, (KPT <= 8 ? 8 : (KPT <= 12 ? 6 : 4))) k_ms
       // cell sizes behind for k_plan2.  A cell that outgrows its slot (skewed keys) is cut off and flagged: the
       // LSD passes then sort the column instead.
       const bool live = tid < (1u << hy.bits2);
-      gb              = live ? ((seg << hy.bits2) + tid) * a.cellcap : 0u;
-      lim             = live ? gb + a.cellcap : 0u;
+      const uint32_t cellcap = (uint32_t)hy.cell_max;  // (the device may have chosen the larger cells: k_hy_plan stage 1)
+      gb              = live ? ((seg << hy.bits2) + tid) * cellcap : 0u;
+      lim             = live ? gb + cellcap : 0u;
       if (live) {
-        if (prefix + pub_count > a.cellcap) atomicExch(&hy.overflow, 1);
+        if (prefix + pub_count > (uint32_t)hy.cell_max) atomicExch(&hy.overflow, 1);
         if (gtile + 1 == hy.seg_tile0[1][seg + 1]) a.cellcount[seg * NB2MAX + tid] = prefix + pub_count;
       }
     }
@@ -1338,6 +1350,7 @@ __global__ void __launch_bounds__((1 << CL2) / 16, 4) k_local_place(const KeyT* 
 {
   HybridPlan& hy = plan->hy;
   if (!hy.attempt || !hy.ok || (plan->hf.state == 3) != (cursor_path != 0)) return;
+  if (hy.cell_max != (1 << CL2)) return;  // (both cell sizes are launched when the device may choose: see k_hy_plan's cell_alt)
   if (!place_applies<KeyT, KIND, HAS_VAL, CL2>(hy, exp)) return;  // k_local_sort, launched behind, takes every cell
   const uint32_t ncells = (uint32_t)BINS << hy.bits2;
   for (uint32_t cell = blockIdx.x; cell < ncells; cell += gridDim.x) {
@@ -1620,6 +1633,7 @@ __global__ void __launch_bounds__((1 << CL2) / 16, 4) k_local_sort(const IoT* in
 {
   HybridPlan& hy = plan->hy;
   if (!hy.attempt || !hy.ok || (plan->hf.state == 3) != (cursor_path != 0)) return;
+  if (hy.cell_max != (1 << CL2)) return;
   const bool listed    = todo != nullptr && place_applies<IoT, KIND, HAS_VAL, CL2>(hy, exp);  // (as k_local_place decided: on the column's type)
   const uint32_t count = listed ? hy.todo_count : ((uint32_t)BINS << hy.bits2);
   for (uint32_t e = blockIdx.x; e < count; e += gridDim.x) {
@@ -2197,6 +2211,7 @@ struct HybridCfg {
   int cl2;    // log2 of the local-sort cell capacity (13 or 14)
   int bits2;  // level-1 bits (1..9)
   int kpt;    // keys per thread of the partition passes
+  int cl2_alt;  // 14 when the device may switch a 13-bit plan to 16384-key cells (pairs: k_hy_plan's cell_alt), else 0
 };
 static thread_local int g_cell = 0;  // A/B knob: 0 = auto, 8192 / 16384 = force the local-sort cell capacity
 // workgroups of k_local_sort: they walk the cells (or k_local_place's todo list) with a stride, see the kernel
@@ -2206,7 +2221,7 @@ static inline unsigned local_place_grid(int cells) { return (unsigned)((g_place_
 template <typename KeyT, int KIND, bool HAS_VAL>
 static HybridCfg hybrid_cfg(int64_t n, bool iota_payload, int algo)
 {
-  HybridCfg c{false, 14, 8, HAS_VAL ? 10 : g_msd_kpt};
+  HybridCfg c{false, 14, 8, HAS_VAL ? 10 : g_msd_kpt, 0};
   if (sizeof(KeyT) != 8 || (HAS_VAL && !iota_payload) || algo != 0 || !g_hybrid || n < (1ll << 22)) return c;
   // 8192-key cells (two local-sort workgroups per CU) + a 9-bit level 1 for INTEGER keys while 2^17 cells suffice -- keys only,
   // and since round 3 pairs too (sorted_order: the packed (key bits, position) words need 13 position bits instead of 14);
@@ -2221,6 +2236,7 @@ static HybridCfg hybrid_cfg(int64_t n, bool iota_payload, int algo)
   if ((double)n / (double)(1ull << B) > 0.97 * cell) return c;  // cells would overflow: LSD passes
   c.bits2 = B - 8;
   c.on    = true;
+  if (HAS_VAL && c.cl2 == 13 && g_cell == 0) c.cl2_alt = 14;
   return c;
 }
 
@@ -2301,7 +2317,7 @@ int sort_impl(const void* keys_in, void* keys_out, const int32_t* vals_in, int32
   }
   // the level-1 pass writes every cell into its own slot of 1 << cl2 keys (no joint histogram pass): the
   // ping-pong scratch holds (256 << bits2) slots when that exceeds n
-  size_t padded = try_hybrid ? ((size_t)BINS << hc.bits2) << hc.cl2 : 0;
+  size_t padded = try_hybrid ? ((size_t)BINS << hc.bits2) << (hc.cl2_alt ? hc.cl2_alt : hc.cl2) : 0;
   if (fc.on && (((size_t)BINS << fc.bits2_max) << 13) > padded) padded = ((size_t)BINS << fc.bits2_max) << 13;
   const size_t nb_buf = padded > (size_t)n ? padded : (size_t)n;
   KeyT* kb_scratch = c.take<KeyT>(nb_buf);
@@ -2469,7 +2485,7 @@ int sort_impl(const void* keys_in, void* keys_out, const int32_t* vals_in, int32
       hipLaunchKernelGGL((k_hy_hist<KeyT, KIND, false>), dim3((unsigned)hblocks), dim3(BT), 0, stream,
                          static_cast<const KeyT*>(keys_in), n, desc_mask, plan, range_rows);
       hipLaunchKernelGGL(k_hy_plan, dim3(1), dim3(BINS), 0, stream, plan, 1, (int)(8 * sizeof(KeyT)), n, hc.bits2, 1 << hc.cl2,
-                         HAS_VAL ? hc.cl2 : 0, range_rows, (int)msd_tile, base1);
+                         HAS_VAL ? hc.cl2 : 0, range_rows, (int)msd_tile, base1, hc.cl2_alt ? (1 << hc.cl2_alt) : 0);
       if (!cursor_marked) prof_mark(1, stream);
       KeyT* bufA = keys_out ? static_cast<KeyT*>(keys_out) : ka_scratch;
       KeyT* bufB = kb_scratch;
@@ -2511,6 +2527,12 @@ int sort_impl(const void* keys_in, void* keys_out, const int32_t* vals_in, int32
                          (const uint32_t*)valB, valA, desc_mask, plan, hist2, base2, todo, m.exp, 0);
       hipLaunchKernelGGL(kloc, dim3(local_sort_grid(BINS << hc.bits2)), dim3(ls_bt), lds_loc(hc.cl2), stream, bufB, bufA, valB, valA, desc_mask,
                          plan, hist2, base2, m.exp, 0, (const uint32_t*)todo);
+      if (hc.cl2_alt == 14) {  // the cell sort on 16384-key cells, should k_hy_plan have switched to them (no-ops otherwise)
+        hipLaunchKernelGGL((k_local_place<KeyT, KIND, HAS_VAL, 14>), dim3(local_place_grid(BINS << hc.bits2)), dim3((1 << 14) / 16), place_lds_bytes(14), stream,
+                           (const KeyT*)bufB, bufA, (const uint32_t*)valB, valA, desc_mask, plan, hist2, base2, todo, m.exp, 0);
+        hipLaunchKernelGGL((k_local_sort<KeyT, KIND, HAS_VAL, 14>), dim3(local_sort_grid(BINS << hc.bits2)), dim3((1 << 14) / 16), lds_loc(14), stream, bufB, bufA,
+                           valB, valA, desc_mask, plan, hist2, base2, m.exp, 0, (const uint32_t*)todo);
+      }
       if (!cursor_marked) prof_mark_h(4, stream);
       if (!cursor_marked) g_prof.hybrid_marked = g_prof.enabled;
     }

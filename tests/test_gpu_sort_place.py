@@ -275,3 +275,36 @@ def test_fuller_buckets_take_one_more_level1_bit(gx, dtype):
     got, info, todo = _sort(gx, v)
     assert got.tobytes() == np.sort(v).tobytes()
     assert info[1] == 1 and info[4] == 6 and 0 < info[6] <= 8192, f"expected the hybrid path with 6 level-1 bits: {info}"
+
+
+def _order_info(gx, v, descending=False):
+    """gx_sorted_order through the C ABI -> (permutation, info8)"""
+    Column, ops, L = gx
+    col = Column.from_numpy(v)
+    out = Column.empty(np.int32, v.size)
+    tmp = ops._run(L.lib.gx_sorted_order, col.gx, col.data_ptr, None, col.size, 0, int(descending), 1, out.data_ptr)
+    ops._check_sort_status(tmp)
+    info = (ctypes.c_int32 * 8)()
+    L.check(L.lib.gx_sort_info(ops.ptr(tmp), info, ops.stream_ptr()), "gx_sort_info")
+    return out.to_numpy(), list(info)
+
+
+@pytest.mark.parametrize("desc", [False, True])
+def test_sorted_order_of_a_key_range_that_is_not_a_power_of_two_takes_wider_cells(gx, desc):
+    """Round 4 (DESIGN's measured 91 ms cliff at 1e9 rows): sorted_order of keys in [0, 1e12) at the top of a size
+    class.  The top digit uses 233 of 256 bins, so the buckets are 1.1x fuller than n / 256 and 8192-key cells overflow; the
+    look-back path of the pairs has no extra level-1 bit to take, but k_hy_plan's stage 1 sees the exact level-0 histogram and
+    switches the sort to 16384-key cells (both cell-sort instantiations are enqueued, one is a no-op).  Stable order bit-exact
+    against the oracle; the hybrid path must have produced it (no LSD pass), with cells above 8192 keys.  Full-range keys of the
+    same size from a power-of-two range keep the 8192-key cells."""
+    rng = np.random.default_rng(21)
+    n = 7_800_000                                            # n / 2^10 = 7617: 97 % of the 8192-key size class
+    v = rng.integers(0, 1_000_000_000_000, n, dtype=np.int64)
+    got, info = _order_info(gx, v, desc)
+    np.testing.assert_array_equal(got, orc.sorted_order(v, None, not desc))
+    assert info[1] == 1 and info[7] == -1                    # hybrid ok, every LSD pass skipped
+    assert 8192 < info[6] <= 16384                           # largest cell: only the wider cells hold it
+    w = rng.integers(0, 1 << 40, n, dtype=np.int64)            # a power-of-two range of the same width: every bin used, cells fit
+    got, info = _order_info(gx, w, desc)
+    np.testing.assert_array_equal(got, orc.sorted_order(w, None, not desc))
+    assert info[1] == 1 and info[6] <= 8192
