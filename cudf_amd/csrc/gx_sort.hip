@@ -84,7 +84,20 @@ struct HybridPlan {
   uint32_t bigbucket[BINS];  // level-0 buckets that hold a big cell (the rescue pass re-reads only these)
   uint32_t bigcnt[BINS], bigkeys[BINS];    // k_plan2: big cells of bucket b, keys in them
   uint32_t biglist0[BINS], bigx0[BINS];    // k_big_plan: first list entry / first X position of bucket b's big cells
+  // Round 4: PER-BUCKET cell slots.  Level 1 used to give every cell a slot of cell_max keys -- 2^17 x 8192 keys for a 1e9-row
+  // sort, twice that where the device may take one more level-1 bit or the larger cells: 17.2 of the sort's 34.4 GB of scratch.
+  // The plan kernels have the exact level-0 histogram, so bucket b's cells get ccap[b] = its mean cell + 6 sigma + 64 keys (a
+  // multiple of 16, at most cell_max) from cbase[b] on: the cell buffer shrinks to n + 640 (848) keys per cell.  ccap[b] == 0:
+  // the fixed layout (cell c at c * cell_max).
+  uint32_t cbase[BINS], ccap[BINS];
 };
+__device__ __forceinline__ uint32_t cell_cap(const HybridPlan& hy, uint32_t b) { return hy.ccap[b] ? hy.ccap[b] : (uint32_t)hy.cell_max; }
+__device__ __forceinline__ uint32_t cell_slot(const HybridPlan& hy, uint32_t b, uint32_t d2)
+{
+  return hy.ccap[b] ? hy.cbase[b] + d2 * hy.ccap[b] : ((b << hy.bits2) + d2) * (uint32_t)hy.cell_max;
+}
+// keys per cell beyond the bucket's mean cell that a slot holds: 6 sigma of a cell of cell_max keys + 64 + rounding (host bound)
+static inline size_t cell_slack(int cell_max) { return (size_t)(6.0 * __builtin_sqrt((double)cell_max)) + 64 + 16 + 2; }
 
 // Round 3, the CURSOR path (integer keys, keys only): plan of the speculative passes, see k_hf_scatter
 struct FastPlan {
@@ -280,6 +293,35 @@ __global__ void __launch_bounds__(BT) k_hy_hist(const KeyT* __restrict__ in, int
   }
 }
 
+// per-bucket cell slots (HybridPlan::ccap / cbase), cursor path: every thread of a BINS-thread block calls it with its bucket's
+// key count.  A bucket at the edge of the key range is only partly covered by keys (keys in [0, 1e12): the top bin is 83 % full),
+// its cells are as dense as its neighbours', so a bucket takes the LARGEST mean of itself and its two neighbours -- when the
+// total fits `budget` keys (the buffer the host made: n + slack per cell + n / 16); otherwise its own mean, which always fits.
+__device__ __forceinline__ void plan_cell_slots(HybridPlan& hy, uint32_t bucket_count, int bits2, int cell_max, uint32_t* s_tmp,
+                                                unsigned long long budget)
+{
+  __shared__ uint32_t s_mean[BINS];
+  const int t          = threadIdx.x;
+  const uint32_t mean  = (bucket_count >> bits2) + 1u;
+  s_mean[t]            = mean;
+  __syncthreads();
+  uint32_t m3 = mean;
+  if (t > 0 && s_mean[t - 1] > m3) m3 = s_mean[t - 1];
+  if (t < BINS - 1 && s_mean[t + 1] > m3) m3 = s_mean[t + 1];
+  auto cap_of = [&](uint32_t m) {
+    uint32_t cap = m + (uint32_t)(6.0f * __builtin_sqrtf((float)m)) + 64u;
+    cap          = (cap + 15u) & ~15u;
+    return cap > (uint32_t)cell_max ? (uint32_t)cell_max : cap;
+  };
+  const uint32_t cap_a = cap_of(m3), cap_b = cap_of(mean);
+  uint32_t total_a;
+  const uint32_t base_a = block_exclusive_scan<BINS>(cap_a << bits2, 0u, SumOp(), s_tmp, &total_a);
+  const uint32_t base_b = block_exclusive_scan<BINS>(cap_b << bits2, 0u, SumOp(), s_tmp, (uint32_t*)nullptr);
+  const bool smooth     = (unsigned long long)total_a <= budget;
+  hy.ccap[t]  = smooth ? cap_a : cap_b;
+  hy.cbase[t] = smooth ? base_a : base_b;
+}
+
 // digits of the local sort's stable LDS passes: the bytes below shift2 that vary somewhere in the column
 __device__ __forceinline__ void plan_local_digits(HybridPlan& hy, unsigned long long V, int shift2)
 {
@@ -351,6 +393,8 @@ __global__ void __launch_bounds__(BINS) k_hy_plan(SortPlan* plan, int stage, int
     while ((1 << alt_bits) < cell_alt) ++alt_bits;
     if (__syncthreads_or(full) && t == 0 && (pos_bits == 0 || hy.shift2 + alt_bits <= 64)) hy.cell_max = cell_alt;
   }
+  // (the look-back path keeps the fixed cell slots -- ccap stays 0: it has no rescue for a cell that outgrows its slot, and the
+  //  per-bucket capacities of the cursor path assume an even density inside a bucket, which float keys do not have)
   uint32_t run = exc;
   for (int r = 0; r < NRANGE; ++r) {  // level-0 output base of bin t for every input range
     base1[r * NB2MAX + t] = run;
@@ -995,11 +1039,11 @@ __global__ void __launch_bounds__(BT, (KPT <= 8 ? 8 : (KPT <= 12 ? 6 : 4))) k_ms
       // cell sizes behind for k_plan2.  A cell that outgrows its slot (skewed keys) is cut off and flagged: the
       // LSD passes then sort the column instead.
       const bool live = tid < (1u << hy.bits2);
-      const uint32_t cellcap = (uint32_t)hy.cell_max;  // (the device may have chosen the larger cells: k_hy_plan stage 1)
-      gb              = live ? ((seg << hy.bits2) + tid) * cellcap : 0u;
+      const uint32_t cellcap = cell_cap(hy, seg);  // (per bucket; the device may also have chosen the larger cells: k_hy_plan stage 1)
+      gb              = live ? cell_slot(hy, seg, tid) : 0u;
       lim             = live ? gb + cellcap : 0u;
       if (live) {
-        if (prefix + pub_count > (uint32_t)hy.cell_max) atomicExch(&hy.overflow, 1);
+        if (prefix + pub_count > cell_cap(hy, seg)) atomicExch(&hy.overflow, 1);
         if (gtile + 1 == hy.seg_tile0[1][seg + 1]) a.cellcount[seg * NB2MAX + tid] = prefix + pub_count;
       }
     }
@@ -1055,11 +1099,12 @@ __global__ void __launch_bounds__(GX_WAVE) k_plan2(SortPlan* plan, const uint32_
   }
   const uint32_t total = shfl(inc, GX_WAVE - 1);
   mx                   = wave_reduce(mx, MaxOp());
+  if (mx > cell_cap(hy, (uint32_t)b) && lane == 0) atomicExch(&hy.overflow, 1);  // (a cell above its bucket's slot capacity)
   if (cursor_path) {  // big cells of this bucket (cells that outgrew their slot: HybridPlan::big)
     uint32_t bc = 0, bk = 0;
 #pragma unroll
     for (int k = 0; k < PER; ++k) {
-      if (c[k] > (uint32_t)hy.cell_max) {
+      if (c[k] > cell_cap(hy, (uint32_t)b)) {
         ++bc;
         bk += c[k];
       }
@@ -1215,10 +1260,10 @@ __device__ __forceinline__ void local_place_cell(const uint32_t cell, const KeyT
   const uint32_t b  = cell >> bits2;
   const uint32_t d2 = cell & ((1u << bits2) - 1u);
   const uint32_t m  = hist2[b * NB2MAX + d2];
-  if (m == 0 || m > (uint32_t)LOCAL_MAX) return;  // (a big cell -- cursor path only -- is sorted through X, see HybridPlan::big)
+  if (m == 0 || m > cell_cap(hy, b)) return;  // (a big cell -- cursor path only -- is sorted through X, see HybridPlan::big)
   const int64_t start = base2[b * NB2MAX + d2];
-  in += (int64_t)cell * LOCAL_MAX - start;  // the cell sits in its slot of the padded level-1 buffer
-  if (HAS_VAL) vin += (int64_t)cell * LOCAL_MAX - start;
+  in += (int64_t)cell_slot(hy, b, d2) - start;  // the cell sits in its slot of the level-1 buffer
+  if (HAS_VAL) vin += (int64_t)cell_slot(hy, b, d2) - start;
   extern __shared__ __attribute__((aligned(16))) char smem[];
   WordT* s_keys    = reinterpret_cast<WordT*>(smem);                                                 // LOCAL_MAX + LOCAL_MAX / 16
   uint32_t* s_cnt8 = reinterpret_cast<uint32_t*>(smem + (size_t)(LOCAL_MAX + LOCAL_MAX / 16) * sizeof(WordT));  // NPB bytes
@@ -1400,10 +1445,10 @@ __device__ __forceinline__ void local_sort_cell(const uint32_t cell, const IoT* 
   const uint32_t b  = cell >> bits2;
   const uint32_t d2 = cell & ((1u << bits2) - 1u);
   const uint32_t m  = hist2[b * NB2MAX + d2];  // cell size (level-1 pass), output position (k_plan2)
-  if (m == 0 || m > (uint32_t)LOCAL_MAX) return;  // (big cells: see HybridPlan::big)
+  if (m == 0 || m > cell_cap(hy, b)) return;  // (big cells: see HybridPlan::big)
   const int64_t start = base2[b * NB2MAX + d2];
-  in += (int64_t)cell * LOCAL_MAX - start;  // the cell sits in its slot of the padded level-1 buffer
-  if (HAS_VAL) vin += (int64_t)cell * LOCAL_MAX - start;
+  in += (int64_t)cell_slot(hy, b, d2) - start;  // the cell sits in its slot of the level-1 buffer
+  if (HAS_VAL) vin += (int64_t)cell_slot(hy, b, d2) - start;
   const unsigned tid  = threadIdx.x;
   const unsigned lane = lane_id();
   const unsigned w    = tid / GX_WAVE;
@@ -1750,7 +1795,7 @@ __device__ __forceinline__ void hf_give_up(SortPlan* plan, int state)
 //   2 (after level 0)  the verdict + everything level 1, k_plan2 and the local sort need
 __global__ void __launch_bounds__(BINS) k_hf_plan(SortPlan* plan, int stage, int key_bits, int64_t n, int bits2, int cell_max, int stride,
                                                   int64_t range_rows, int tile_rows, unsigned long long slot_rows, float margin, int min_shift2,
-                                                  int bits2_max)
+                                                  int bits2_max, unsigned long long cell_budget = 0)
 {
   // bits2_max: level-1 bits the launches behind are sized for (bits2 or bits2 + 1): stage 2 takes the extra bit when the EXACT
   // level-0 histogram says the cells would not fit otherwise
@@ -1862,6 +1907,7 @@ __global__ void __launch_bounds__(BINS) k_hf_plan(SortPlan* plan, int stage, int
     }
     __syncthreads();
   }
+  plan_cell_slots(hy, c, hy.bits2, cell_max, s_tmp, cell_budget);
   uint32_t tiles = 0;
   for (int r = 0; r < NRANGE; ++r) tiles += (cnt[r] + (uint32_t)tile_rows - 1) / (uint32_t)tile_rows;
   uint32_t ttotal;
@@ -1930,7 +1976,7 @@ __global__ void __launch_bounds__(GX_WAVE) k_big_cells(const SortPlan* plan, con
   constexpr int PER   = NB2MAX / GX_WAVE;
   const unsigned lane = lane_id();
   const int nb2       = 1 << hy.bits2;
-  const uint32_t cap  = (uint32_t)hy.cell_max;
+  const uint32_t cap  = cell_cap(hy, (uint32_t)b);
   uint32_t c[PER], cnt = 0, keys = 0;
 #pragma unroll
   for (int k = 0; k < PER; ++k) {
@@ -2109,12 +2155,12 @@ __global__ void __launch_bounds__(BT, 4) k_hf_scatter(const KeyT* __restrict__ i
         scap[k]  = hf.cap0[seg][bin];
         if (c[k]) g[k] = atomicAdd(&hf.cur0[seg][bin], c[k]);
       } else if (LVL == 1 && bin <= dmask) {
-        sbase[k] = ((seg << hy.bits2) + bin) * cellcap;
-        scap[k]  = cellcap;
+        sbase[k] = cell_slot(hy, seg, bin);
+        scap[k]  = cell_cap(hy, seg);
         if (c[k]) g[k] = atomicAdd(&cellcur[seg * NB2MAX + bin], c[k]);
       } else if (LVL == 2 && bin <= dmask) {
         const uint32_t total = cellcur[seg * NB2MAX + bin];  // the cell's true size (level 1 counted every key)
-        if (total > cellcap) {
+        if (total > cell_cap(hy, seg)) {
           sbase[k] = xoff[seg * NB2MAX + bin];
           scap[k]  = total;
           if (c[k]) g[k] = atomicAdd(&rescur[seg * NB2MAX + bin], c[k]);
@@ -2292,9 +2338,15 @@ int sort_impl(const void* keys_in, void* keys_out, const int32_t* vals_in, int32
   uint32_t* partials         = nullptr;
   // hybrid MSD path: 64-bit keys; pairs only with the iota payload (sorted_order), whose value is the
   // tie-break the packed local sort relies on
-  const HybridCfg hc    = hybrid_cfg<KeyT, KIND, HAS_VAL>(n, vals_in == nullptr, algo);
+  HybridCfg hc     = hybrid_cfg<KeyT, KIND, HAS_VAL>(n, vals_in == nullptr, algo);
+  const FastCfg fc = fast_cfg<KeyT, KIND, HAS_VAL>(n, algo, hc.on);
+  // cell buffer of the cursor path: per-bucket slots (HybridPlan::ccap) -- n keys, 1/16 for the neighbour smoothing, the slack per cell
+  const size_t fc_cells = fc.on ? (size_t)n + (size_t)n / 16 + ((size_t)BINS << fc.bits2_max) * cell_slack(1 << 13) + 65536 : 0;
+  // the look-back path is the cursor path's first fallback (a sample that was not representative).  Up to 2^17 cells of 8192 keys
+  // (n <= 1.03e9) its FIXED cell slots are about the size of that buffer; above, it would switch to 16384-key slots (17.2 GB for
+  // 1.25e9 keys of 10 GB): there the LSD passes are the fallback, as for 32-bit keys, and the scratch stays proportional to n
+  if (fc.on && hc.on && hc.cl2 == 14 && (((size_t)BINS << hc.bits2) << 14) > fc_cells + (size_t)n / 4) hc.on = false;
   const bool try_hybrid = hc.on;
-  const FastCfg fc      = fast_cfg<KeyT, KIND, HAS_VAL>(n, algo, hc.on);
   const int hyb_kpt     = hc.kpt;
   const int nb1         = hc.bits2 > 8 ? NB9 : BINS;  // bins (and look-back granules per tile) of the level-1 pass
   uint32_t* base1 = c.take<uint32_t>((size_t)NRANGE * NB2MAX);
@@ -2315,10 +2367,12 @@ int sort_impl(const void* keys_in, void* keys_out, const int32_t* vals_in, int32
     tile_hist = c.take<uint32_t>((size_t)ntiles * BINS);
     partials  = c.take<uint32_t>(scan::partials_count(ntiles * BINS));
   }
-  // the level-1 pass writes every cell into its own slot of 1 << cl2 keys (no joint histogram pass): the
-  // ping-pong scratch holds (256 << bits2) slots when that exceeds n
+  // the level-1 pass writes every cell into its own slot (no joint histogram pass).  Round 4: slots are sized per bucket from the
+  // exact level-0 histogram (HybridPlan::ccap: the bucket's mean cell + 6 sigma + 64 keys), so the cell buffer holds n keys + that
+  // slack per cell instead of (256 << bits2) slots of the full cell capacity (8.6 / 17.2 GB -> 9.3 GB for the 1e9-row sort)
+  // (cursor path only: the look-back path -- floats, pairs, the cursor path's fallback -- keeps (256 << bits2) slots of the full capacity)
   size_t padded = try_hybrid ? ((size_t)BINS << hc.bits2) << (hc.cl2_alt ? hc.cl2_alt : hc.cl2) : 0;
-  if (fc.on && (((size_t)BINS << fc.bits2_max) << 13) > padded) padded = ((size_t)BINS << fc.bits2_max) << 13;
+  if (fc_cells > padded) padded = fc_cells;
   const size_t nb_buf = padded > (size_t)n ? padded : (size_t)n;
   KeyT* kb_scratch = c.take<KeyT>(nb_buf);
   KeyT* slot0_buf  = fc.on ? c.take<KeyT>(fc.slot_rows) : nullptr;  // cursor path: padded level-0 output
@@ -2392,7 +2446,7 @@ int sort_impl(const void* keys_in, void* keys_out, const int32_t* vals_in, int32
       prof_mark_h(0, stream);
       hipLaunchKernelGGL(kf0, dim3((unsigned)ftiles), dim3(BT), lds_hf(256), stream, kin, slot0_buf, desc_mask, plan, hist2, 1u << 13, n);
       hipLaunchKernelGGL(k_hf_plan, dim3(1), dim3(BINS), 0, stream, plan, 2, (int)(8 * sizeof(KeyT)), n, fc.bits2, 1 << 13, fc.stride, frange, FT,
-                         (unsigned long long)fc.slot_rows, g_cursor_margin, MIN_SHIFT2, fc.bits2_max);
+                         (unsigned long long)fc.slot_rows, g_cursor_margin, MIN_SHIFT2, fc.bits2_max, (unsigned long long)nb_buf);
       prof_mark_h(1, stream);
       hipLaunchKernelGGL(kf1, dim3((unsigned)(ftiles + NRANGE * BINS)), dim3(BT), lds_hf(nbf), stream, slot0_buf, kb_scratch, desc_mask, plan, hist2, 1u << 13, n);
       prof_mark_h(2, stream);
@@ -2644,7 +2698,7 @@ __global__ void __launch_bounds__(BINS) k_hfx_plan(SortPlan* plan, long long n, 
                                                    unsigned long long or_mask, unsigned long long nor_mask, uint32_t nreg,
                                                    const uint32_t* __restrict__ breg0, uint32_t* __restrict__ x_tile0,
                                                    const uint32_t* __restrict__ x_start, const uint32_t* __restrict__ x_count,
-                                                   const uint32_t* __restrict__ x_bucket)
+                                                   const uint32_t* __restrict__ x_bucket, unsigned long long cell_budget)
 {
   __shared__ uint32_t s_tmp[BINS / GX_WAVE + 1];
   HybridPlan& hy = plan->hy;
@@ -2669,6 +2723,7 @@ __global__ void __launch_bounds__(BINS) k_hfx_plan(SortPlan* plan, long long n, 
   if (V == 0 || shift2 < min_shift2 || (long long)total != n) return;  // state stays 0: gx_sortx_status reports the failure
   hy.hist0[t] = c;
   hy.gbin0[t] = exc;
+  plan_cell_slots(hy, c, b2, cell_max, s_tmp, cell_budget);
   for (uint32_t q = breg0[t]; q < breg0[t + 1]; ++q) {
     x_tile0[q] = trun;
     trun += (x_count[q] + (uint32_t)tile_rows - 1) / (uint32_t)tile_rows;
@@ -2718,7 +2773,7 @@ static SortxLayout<KeyT> sortx_layout(void* tmp, int64_t n, int64_t recv_rows_ma
   L.todo          = c.take<uint32_t>((size_t)BINS * NB2MAX);
   L.biglist       = c.take<uint32_t>((size_t)2 * BIG_LIST);
   L.level0_rows   = cs.slot_rows + (size_t)recv_rows_max + 65536;
-  L.cells_rows    = ((size_t)BINS << cr.bits2_max) << 13;
+  L.cells_rows    = (size_t)recv_rows_max + (size_t)recv_rows_max / 16 + ((size_t)BINS << cr.bits2_max) * cell_slack(1 << 13) + 65536;  // per-bucket cell slots (HybridPlan::ccap)
   const size_t xt = L.level0_rows / 2 / (size_t)(BT * 16) + BINS + 2 * NRANGE;  // tiles of the largest X the LSD passes may sort
   L.status_words  = xt * BINS;
   L.status        = c.take<unsigned long long>(L.status_words);
@@ -2850,7 +2905,8 @@ int sortx_finish(int64_t n_send, int64_t recv_rows_max, int64_t n, const unsigne
   const int64_t l1_grid = div_up(n, (int64_t)FT) + nreg;
   KeyT* bufA = static_cast<KeyT*>(out);
   hipLaunchKernelGGL(k_hfx_plan, dim3(1), dim3(BINS), 0, stream, L.plan, (long long)n, cr.bits2, cr.bits2_max, 1 << 13, MIN_SHIFT2, FT, masks2_host[0], masks2_host[1],
-                     (uint32_t)nreg, (const uint32_t*)L.breg0, L.x_tile0, (const uint32_t*)L.x_start, (const uint32_t*)L.x_count, (const uint32_t*)L.x_bucket);
+                     (uint32_t)nreg, (const uint32_t*)L.breg0, L.x_tile0, (const uint32_t*)L.x_start, (const uint32_t*)L.x_count, (const uint32_t*)L.x_bucket,
+                     (unsigned long long)L.cells_rows);
   hipLaunchKernelGGL(kf1, dim3((unsigned)l1_grid), dim3(BT), lds_hf(nbf), stream, (const KeyT*)L.level0, L.cells, KeyT(0), L.plan, L.hist2, 1u << 13, n);
   hipLaunchKernelGGL(k_plan2, dim3(BINS), dim3(GX_WAVE), 0, stream, L.plan, L.hist2, L.base2, (int)sizeof(KeyT), 1);
   hipLaunchKernelGGL((k_local_place<KeyT, KIND, false, 13>), dim3(local_place_grid(BINS << cr.bits2)), dim3((1 << 13) / 16), place_lds_bytes(13, WORD_BYTES), stream,
