@@ -69,6 +69,7 @@ struct HybridPlan {
   uint32_t hist0[BINS], gbin0[BINS];   // level-0 digit histogram of the whole column and its exclusive scan
   uint32_t rh0[NRANGE][BINS];          // range-resolved level-0 histogram
   uint32_t rhist[NRANGE][MAX_PASSES][BINS];  // range-resolved byte histograms (k_hist_all, LSD path)
+  unsigned long long fold_or;                // signed integer keys: OR of (key XOR its sign extension), see k_plan
   alignas(128) uint32_t todo_count;          // k_local_place: cells left to k_local_sort (a line of its own: atomics)
   uint32_t todo_pad[31];
   // Round 4, BIG cells of the cursor path: a cell that outgrew its slot (a hot value: 1e6 copies of one key land in ONE cell
@@ -173,9 +174,11 @@ __global__ void __launch_bounds__(BT) k_hist_all(const KeyT* __restrict__ in, in
   const int64_t rend   = (range == NRANGE - 1) ? n : (rbegin + range_rows < n ? rbegin + range_rows : n);
   constexpr int NPASS = sizeof(KeyT);
   __shared__ uint32_t s_hist[NPASS * BINS];
+  __shared__ unsigned long long s_fold[NW];
   for (int i = threadIdx.x; i < NPASS * BINS; i += BT) s_hist[i] = 0;
   __syncthreads();
   const unsigned lane  = lane_id();
+  KeyT fold            = 0;  // K_SIGNED: bits in which some key differs from its own sign extension
   constexpr int UNROLL = 4;  // independent loads in flight per lane (>= 32 KiB per CU at full occupancy)
   const int64_t stride = (int64_t)(gridDim.x / NRANGE) * BT * UNROLL;
   for (int64_t i0 = rbegin + (int64_t)(blockIdx.x / NRANGE) * BT * UNROLL + threadIdx.x; i0 < rend; i0 += stride) {
@@ -190,14 +193,19 @@ __global__ void __launch_bounds__(BT) k_hist_all(const KeyT* __restrict__ in, in
       const int64_t i = i0 + (int64_t)u * BT;
       if (i < rend) {
         const KeyT k          = to_sortable<KeyT, KIND>(raw[u], desc_mask);
+        if (KIND == K_SIGNED) fold |= (KeyT)(raw[u] ^ (KeyT)(KeyT(0) - (KeyT)(raw[u] >> (8 * sizeof(KeyT) - 1))));
         const uint64_t active = ballot(true);
         const int leader      = __builtin_ctzll(active);
 #pragma unroll
         for (int p = 0; p < NPASS; ++p) {
           const uint32_t d  = (uint32_t)(k >> (8 * p)) & 0xFFu;
           const uint32_t d0 = __builtin_amdgcn_readfirstlane(d);
-          if (ballot(d == d0) == active) {  // whole wave hits one bin: one add instead of 64 conflicts
+          const uint64_t same = ballot(d == d0);
+          if (same == active) {  // whole wave hits one bin: one add instead of 64 conflicts
             if ((int)lane == leader) atomicAdd(&s_hist[p * BINS + d0], (uint32_t)__builtin_popcountll(active));
+          } else if (__builtin_popcountll(same) >= 8) {  // a popular digit (skewed keys: 87 % of a Zipf column share their upper bytes)
+            if ((int)lane == leader) atomicAdd(&s_hist[p * BINS + d0], (uint32_t)__builtin_popcountll(same));
+            else if (d != d0) atomicAdd(&s_hist[p * BINS + d], 1u);
           } else {
             atomicAdd(&s_hist[p * BINS + d], 1u);
           }
@@ -205,7 +213,16 @@ __global__ void __launch_bounds__(BT) k_hist_all(const KeyT* __restrict__ in, in
       }
     }
   }
+  if (KIND == K_SIGNED) {
+    const unsigned long long wf = wave_reduce((unsigned long long)fold, [](unsigned long long x, unsigned long long y) { return x | y; });
+    if (lane == 0) s_fold[threadIdx.x / GX_WAVE] = wf;
+  }
   __syncthreads();
+  if (KIND == K_SIGNED && threadIdx.x == 0) {
+    unsigned long long f = 0;
+    for (int k = 0; k < NW; ++k) f |= s_fold[k];
+    if (f & ~__hip_atomic_load(&plan->hy.fold_or, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) atomicOr(&plan->hy.fold_or, f);
+  }
   for (int i = threadIdx.x; i < NPASS * BINS; i += BT) {
     const uint32_t c = s_hist[i];
     if (c) atomicAdd(&plan->hy.rhist[range][i / BINS][i % BINS], c);
@@ -395,6 +412,13 @@ __global__ void __launch_bounds__(BINS) k_hy_plan(SortPlan* plan, int stage, int
   }
   // (the look-back path keeps the fixed cell slots -- ccap stays 0: it has no rescue for a cell that outgrows its slot, and the
   //  per-bucket capacities of the cursor path assume an even density inside a bucket, which float keys do not have)
+  __syncthreads();
+  // a bucket with more keys than all of its cells hold overflows whatever its keys look like (keys spread around zero: two
+  // buckets of n / 2; bell-shaped or Zipf-like values): decline here, before the two partition passes are spent on it
+  if (__syncthreads_or((unsigned long long)c > ((unsigned long long)hy.cell_max << hy.bits2) ? 1 : 0)) {
+    if (t == 0) hy.attempt = 0;
+    return;
+  }
   uint32_t run = exc;
   for (int r = 0; r < NRANGE; ++r) {  // level-0 output base of bin t for every input range
     base1[r * NB2MAX + t] = run;
@@ -430,8 +454,14 @@ __global__ void __launch_bounds__(BINS) k_hy_plan(SortPlan* plan, int stage, int
 }
 
 // one block of 256 threads: plan of the LSD passes
-__global__ void __launch_bounds__(BINS) k_plan(SortPlan* plan, int npass, int64_t n)
+__global__ void __launch_bounds__(BINS) k_plan(SortPlan* plan, int npass, int64_t n, int signed_keys = 0)
 {
+  // signed_keys (round 4): integers spread around zero -- small signed values, differences, anything in [-a, b) -- have upper bytes
+  // that are pure SIGN EXTENSION: 0x00 for the non-negative keys, 0xFF for the negative ones.  Such a byte takes two values, so it
+  // is not trivial, yet it carries nothing the top byte does not: when every bit from position h up to the sign bit equals the
+  // key's sign (fold_or < 2^h, reduced by k_hist_all over exactly the keys being sorted), the stable passes over the bytes below
+  // h order the keys inside either sign class and the pass on the top byte -- also two values -- puts the classes in order.
+  // The passes on the bytes in between are skipped: keys in [-1000, 1000) take 3 passes instead of 8 (run 14: 57 ms per 1e9).
   __shared__ uint32_t s_tmp[BINS / GX_WAVE + 1];
   __shared__ int s_skip[MAX_PASSES];
   if (plan->hy.ok && !plan->hy.lsd_mode) return;  // the hybrid path sorted the column (k_plan2 marked every pass as skipped)
@@ -441,7 +471,12 @@ __global__ void __launch_bounds__(BINS) k_plan(SortPlan* plan, int npass, int64_
     uint32_t c = 0;
     for (int r = 0; r < NRANGE; ++r) c += plan->hy.rhist[r][p][t];
     plan->hist[p][t] = c;
-    const int triv   = __syncthreads_or(c == (uint32_t)n);
+    int triv         = __syncthreads_or(c == (uint32_t)n);
+    if (signed_keys && p < npass - 1) {
+      const unsigned long long f = plan->hy.fold_or;
+      const int h                = f ? 64 - __builtin_clzll(f) : 0;  // bits [h, sign) are copies of the sign in every key
+      if (8 * p >= h) triv = 1;
+    }
     uint32_t exc     = block_exclusive_scan<BINS>(c, 0u, SumOp(), s_tmp, (uint32_t*)nullptr);
     plan->gbin[p][t] = exc;
     if (t == 0) s_skip[p] = triv ? 1 : 0;
@@ -1858,6 +1893,28 @@ __global__ void __launch_bounds__(BINS) k_hf_plan(SortPlan* plan, int stage, int
       if (t == 0) hf_give_up(plan, 0);
       return;
     }
+    {
+      // Hopeless already by the sample?  A bucket of `est` keys has (1 << bits2_max) cells of cell_max keys; what does not fit
+      // them sits in cells that overflow (big cells), and big cells are sorted through X, which holds slot_rows / 2 keys.  When
+      // the sample puts more than three quarters of the column there (Zipf-like values: 97 % of the keys below 2^24; values
+      // spread around zero: two buckets of n / 2) the LSD passes will sort the column whatever level 0 finds: go there now
+      // (state 4 also spares the look-back path's attempt).  Run 14: such columns cost 56 - 240 ms, most of it in the levels.
+      double est = 0.0;
+      for (int r = 0; r < NRANGE; ++r) {
+        uint32_t tot_r;
+        (void)block_exclusive_scan<BINS>(hf.samp[r][t], 0u, SumOp(), s_tmp, &tot_r);
+        if (tot_r) est += (double)hf.samp[r][t] * ((double)hf_range_rows(r, n, range_rows) / (double)tot_r);
+      }
+      const double fits  = (double)((1ull << bits2_max) - 1ull) * (double)cell_max;
+      const double over  = est > fits + (double)cell_max ? est - fits : 0.0;
+      const uint32_t o32 = (uint32_t)(over < 4.0e9 ? over : 4.0e9);
+      uint32_t osum;
+      (void)block_exclusive_scan<BINS>(o32 >> 4, 0u, SumOp(), s_tmp, &osum);
+      if ((double)osum * 16.0 > 0.75 * (double)n) {
+        if (t == 0) hf_give_up(plan, 4);
+        return;
+      }
+    }
     for (int r = 0; r < NRANGE; ++r) {  // the NRANGE slots of a bin are neighbours
       hf.slot0[r][t] = run;
       hf.cap0[r][t]  = cap[r];
@@ -1906,6 +1963,20 @@ __global__ void __launch_bounds__(BINS) k_hf_plan(SortPlan* plan, int stage, int
       hy.shift2 -= 1;
     }
     __syncthreads();
+  }
+  {
+    // the same test on the EXACT level-0 histogram, against what X holds (k_big_plan: slot_rows / 2): a lower bound of the keys
+    // in big cells that does not fit X means the whole-column LSD fallback is certain -- level 1 (and, for such columns, its
+    // thousands of tiles that all bump the cursors of the same few cells: 205 ms for the Zipf-like column of run 15), the cell
+    // sort and the big-cell machinery are skipped
+    const unsigned long long fits = ((1ull << hy.bits2) - 1ull) * (unsigned long long)cell_max;
+    const uint32_t over           = (unsigned long long)c > fits + (unsigned long long)cell_max ? (uint32_t)((unsigned long long)c - fits) : 0u;
+    uint32_t osum;
+    (void)block_exclusive_scan<BINS>(over >> 4, 0u, SumOp(), s_tmp, &osum);
+    if ((unsigned long long)osum * 16ull > slot_rows / 2) {
+      if (t == 0) hf_give_up(plan, 4);
+      return;
+    }
   }
   plan_cell_slots(hy, c, hy.bits2, cell_max, s_tmp, cell_budget);
   uint32_t tiles = 0;
@@ -2594,7 +2665,7 @@ int sort_impl(const void* keys_in, void* keys_out, const int32_t* vals_in, int32
   // LSD path: byte histograms + plan (no-ops when the hybrid path has sorted the column)
   hipLaunchKernelGGL((k_hist_all<KeyT, KIND>), dim3((unsigned)hblocks), dim3(BT), 0, stream,
                      static_cast<const KeyT*>(keys_in), n, desc_mask, plan, range_rows, (const KeyT*)kb_scratch);
-  hipLaunchKernelGGL(k_plan, dim3(1), dim3(BINS), 0, stream, plan, NPASS, n);
+  hipLaunchKernelGGL(k_plan, dim3(1), dim3(BINS), 0, stream, plan, NPASS, n, KIND == K_SIGNED ? 1 : 0);
   if (!try_hybrid && !cursor_marked) prof_mark(1, stream);
 
   PassArgs a;
@@ -2925,7 +2996,7 @@ int sortx_finish(int64_t n_send, int64_t recv_rows_max, int64_t n, const unsigne
   // (mode A -- the whole-column LSD fallback -- has no column to fall back to here: its length is 0, a failed plan is reported
   //  by gx_sortx_status and the caller takes the range-partition path)
   hipLaunchKernelGGL((k_hist_all<KeyT, KIND>), dim3((unsigned)hblocks), dim3(BT), 0, stream, (const KeyT*)L.cells, (int64_t)0, KeyT(0), L.plan, (int64_t)0, (const KeyT*)L.cells);
-  hipLaunchKernelGGL(k_plan, dim3(1), dim3(BINS), 0, stream, L.plan, (int)sizeof(KeyT), (int64_t)0);
+  hipLaunchKernelGGL(k_plan, dim3(1), dim3(BINS), 0, stream, L.plan, (int)sizeof(KeyT), (int64_t)0, KIND == K_SIGNED ? 1 : 0);
   PassArgs a{};
   a.kbuf[0] = a.kbuf[1] = a.kbuf[2] = L.cells;
   a.kbufB[0] = L.cells;

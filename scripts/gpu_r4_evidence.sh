@@ -1,5 +1,5 @@
 #!/bin/bash
-# round 4 evidence run: usage gpu_r4_evidence.sh <run number> [pmc]
+# round 4 evidence run: usage gpu_r4_evidence.sh <run number> [pmc] [tests] [robust]
 #   default bench line (with the CPU legs), rocprofv3 --kernel-trace --stats summary of the same command, sorted_order line;
 #   with "pmc": FETCH_SIZE / WRITE_SIZE passes (separate runs) of sort / join / groupby at 1e9 rows -> r4_pmc_traffic_1e9.json
 set -u
@@ -33,6 +33,26 @@ if [ "${3:-}" = "tests" ]; then
   timeout 400 python -m pytest tests/test_gpu_cpp_parity.py tests/test_gpu_sort_place.py -m gpu -q -x -k "not 70000000 and not capacity and not float64" > $O/r4_run${R}_pytest.log 2>&1
   echo "pytest exit $?" | tee -a $L
   tail -4 $O/r4_run${R}_pytest.log | tee -a $L
+fi
+if [ "${4:-}" = "robust" ]; then
+  # value distributions the sort is NOT tuned for (cost must not depend on the distribution): measured, whatever they cost
+  rb() { local tag=$1; shift; timeout 300 python bench.py --workload sort --no-cpu-baseline --steps 3 --warmup 1 "$@" 2>> $L | tail -1 > $O/r4_run${R}_bench_sort_${tag}.jsonl; }
+  rb normal --key-dist normal
+  rb zipf --key-dist zipf
+  rb sorted --key-dist sorted
+  rb signed_range --key-range -1000000000000 1000000000000
+  rb range_100_10001 --key-range 100 10001
+  python - <<PY | tee $O/r4_run${R}_sort_robustness.txt
+import json, glob
+print("# round 4 run $R: python bench.py --workload sort --steps 3 on key distributions other than uniform 64-bit (1e9 int64 rows)")
+for f in sorted(glob.glob("$O/r4_run${R}_bench_sort_*.jsonl")):
+    try:
+        d = json.loads([l for l in open(f) if l.startswith("{")][-1])
+        si = (d.get("roofline") or {}).get("sort_info") or {}
+        print(f.split("_bench_sort_")[1][:-6], "|", d["config"]["workload"], "|", round(d["ms_per_step"], 3), "ms |", {k: si.get(k) for k in ("bits2", "max_cell", "lsd_passes", "cursor_path_state", "big_cells")})
+    except Exception as e:
+        print(f, "unreadable", e)
+PY
 fi
 python - <<PY | tee -a $L
 import json

@@ -201,7 +201,9 @@ def test_hybrid_msd_sort_matches_oracle(gx, dtype):
     got, info = _sort_info(ops, Column.from_numpy(v))
     assert got.tobytes() == orc.sort_keys(v, True).tobytes()
     assert info[1] == 1
-    # skew: a third of the keys in one narrow cluster -> one cell overflows -> device-side fallback
+    # skew: a third of the keys in one narrow cluster -> their level-0 bucket holds more keys than all of its cells -> device-side
+    # fallback.  Since round 4 the plan declines as soon as the exact level-0 histogram shows it (attempted = 0) instead of
+    # spending both partition passes on a cell that must overflow
     v = spread(6_000_000)
     if dtype == "float64":
         v[::3] = 1.0 + rng.random(len(v[::3])) * 1e-9
@@ -209,7 +211,7 @@ def test_hybrid_msd_sort_matches_oracle(gx, dtype):
         v[::3] = (rng.integers(0, 1 << 20, len(v[::3])) + (1 << 40)).astype(dtype)
     got, info = _sort_info(ops, Column.from_numpy(v))
     assert got.tobytes() == orc.sort_keys(v, True).tobytes()
-    assert info[0] == 1 and info[1] == 0 and info[6] > 16384, f"expected the LSD fallback: {info}"
+    assert info[0] == 0 and info[1] == 0 and info[7] > 0, f"expected the LSD fallback: {info}"
     # low-entropy keys (two active bytes): hybrid is not attempted
     v = _rand(dtype, 5_000_000, rng, True) if dtype != "float64" else np.floor(rng.random(5_000_000) * 50)
     got, info = _sort_info(ops, Column.from_numpy(v))
@@ -228,6 +230,27 @@ def test_hybrid_knob_off_uses_lsd(gx):
         _lib.lib.gx_sort_set_hybrid(1)
     assert got.tobytes() == np.sort(v).tobytes()
     assert info[0] == 0 and info[7] == 8
+
+
+@pytest.mark.parametrize("dtype,lo,hi,passes", [("int64", -1000, 1000, 3), ("int64", -(1 << 40), 1 << 40, 6), ("int64", -1, 1, 1),
+                                                 ("int32", -100, 100, 2), ("int32", -70_000, 70_000, 4), ("int16", -100, 100, 2),
+                                                 ("int64", 0, 1000, 2), ("int64", -3000, -1000, 2)])
+def test_sign_extension_bytes_are_not_sorted_on(gx, dtype, lo, hi, passes):
+    """Signed keys spread around zero: the bytes between the highest data bit and the top byte are copies of the sign (0x00 / 0xFF)
+    -- two values, so not a constant digit, yet the top byte already separates the signs.  k_hist_all reduces OR(key ^ sign
+    extension), k_plan skips those passes (round 4): [-1000, 1000) takes bytes 0, 1 and 7.  Bit-exact in both directions, and the
+    number of LSD passes is pinned; ranges on one side of zero keep taking their constant-byte skips."""
+    Column, ops = gx
+    rng = np.random.default_rng(79)
+    v = rng.integers(lo, hi, 3_000_001).astype(dtype)
+    v[5], v[77] = lo, hi - 1
+    for asc in (True, False):
+        got, info = _sort_info(ops, Column.from_numpy(v), asc)
+        assert got.tobytes() == orc.sort_keys(v, asc).tobytes(), (dtype, lo, hi, asc, info)
+        assert info[7] == passes, info
+    # the permutation (pairs passes) follows the same plan; ties keep their input order
+    order = ops.sorted_order(Column.from_numpy(v)).to_numpy()
+    np.testing.assert_array_equal(order, np.argsort(v, kind="stable").astype(np.int32))
 
 
 @pytest.mark.parametrize("dtype", ["int64", "float64", "uint64"])

@@ -51,7 +51,7 @@ def _keys(kind, rng):
     if kind == "clustered":  # long runs of one key, run lengths around the sample step
         runs = rng.integers(0, 2**40, N // 700 + 1, dtype=np.int64)
         return np.repeat(runs, 700)[:N].copy()
-    if kind == "skewed":  # 90 % of the keys in one level-0 bin: slots of very different sizes
+    if kind == "skewed":  # 90 % of the keys in one level-0 bin: slots of very different sizes; no cell of that bin can hold its share
         v = rng.integers(0, 2**48, N, dtype=np.int64)
         hot = rng.random(N) < 0.9
         v[hot] = (v[hot] & ((1 << 40) - 1)) | (37 << 40)
@@ -69,8 +69,11 @@ def test_cursor_path_matches_c_oracle(gx, kind, descending):
     got, state = _sort_with_state(gx, v, descending)
     assert got.tobytes() == c_oracle.sort_i64(v, descending=descending).tobytes()
     # representative samples: the device must have accepted the speculative plan (a silent fall-back would hide a
-    # broken capacity model behind a correct result)
-    assert state == 3, f"{kind}: the cursor path was rejected (state {state})"
+    # broken capacity model behind a correct result).  "skewed" is the exception since round 4: 36 M keys that differ only
+    # below the two partition levels sit in one bucket of 64 cells x 8192 keys -- the sample shows it, and the plan goes to the
+    # LSD passes at once (state 4) instead of spending both levels on cells that must overflow
+    want = 4 if kind == "skewed" else 3
+    assert state == want, f"{kind}: cursor path state {state}, expected {want}"
 
 
 def hash_seed(s):
