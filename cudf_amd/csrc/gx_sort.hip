@@ -70,6 +70,13 @@ struct HybridPlan {
   uint32_t rh0[NRANGE][BINS];          // range-resolved level-0 histogram
   uint32_t rhist[NRANGE][MAX_PASSES][BINS];  // range-resolved byte histograms (k_hist_all, LSD path)
   unsigned long long fold_or;                // signed integer keys: OR of (key XOR its sign extension), see k_plan
+  // SIGN FOLD of the level-0 digit (round 4; signed integer keys spread around zero): when every bit from position h up to the
+  // sign bit is a copy of the key's sign, the highest varying bit of the sortable key is the (flipped) sign and the 7 bits below
+  // it are constant inside either sign class -- level 0 would make TWO buckets.  With `fold` set the level-0 digit is
+  // (sign << 7) | bits [h - 7, h): shift0 = h - 7, level 1 and the cell sort take the bits below as before (all of them are
+  // below h; the bits in [h, sign) are equal inside a bucket because the sign is part of its digit).
+  int32_t fold;
+  unsigned long long fold_x;                 // OR of (key ^ sign extension): the sample's (k_hf_sample), then the EXACT one (level 0 / k_hy_hist)
   alignas(128) uint32_t todo_count;          // k_local_place: cells left to k_local_sort (a line of its own: atomics)
   uint32_t todo_pad[31];
   // Round 4, BIG cells of the cursor path: a cell that outgrew its slot (a hot value: 1e6 copies of one key land in ONE cell
@@ -153,6 +160,26 @@ struct SortPlan {
   SortCounters cnt;
   FastPlan hf;
 };
+
+// level-0 digit of a sortable key: ((k >> shift0) & dm) | ((k >> fsh) & fhi), where (dm, fsh, fhi) = (0xFF, 0, 0), or
+// (0x7F, width - 8, 0x80) under the sign fold (HybridPlan::fold)
+struct Digit0 {
+  int shift, fsh;
+  uint32_t dm, fhi;
+  template <typename KeyT>
+  __device__ __forceinline__ uint32_t operator()(KeyT k) const { return ((uint32_t)(k >> shift) & dm) | ((uint32_t)(k >> fsh) & fhi); }
+};
+__device__ __forceinline__ Digit0 digit0_of(const HybridPlan& hy, int key_bits)
+{
+  return hy.fold ? Digit0{hy.shift0, key_bits - 8, 0x7Fu, 0x80u} : Digit0{hy.shift0, 0, 0xFFu, 0u};
+}
+// (sign fold) bits [h, sign) of every key are copies of its sign: h from OR(key ^ sign extension); 0 = do not fold
+__device__ __forceinline__ int fold_height(unsigned long long fold_or, unsigned long long V, int key_bits)
+{
+  if (!((V >> (key_bits - 1)) & 1ull)) return 0;             // the sign does not vary: the plain masks say everything
+  const int h = fold_or ? 64 - __builtin_clzll(fold_or) : 0;
+  return (h >= 7 && h <= key_bits - 10) ? h : 0;              // >= 9 constant bits between the data and the sign, 7 bits of data for the digit
+}
 
 // ------------------------------------------------------------------------------------------
 // up-front histogram of every digit
@@ -246,7 +273,7 @@ __global__ void __launch_bounds__(BT) k_hy_hist(const KeyT* __restrict__ in, int
   HybridPlan& hy = plan->hy;
   if (plan->hf.state >= 3) return;  // the cursor path has done levels 0 and 1 (3) / has ruled the hybrid path out (4)
   if (!SPEC && !(hy.attempt && hy.need_hist)) return;
-  const int shift      = SPEC ? (int)(8 * sizeof(KeyT) - 8) : hy.shift0;
+  const Digit0 dig     = SPEC ? Digit0{(int)(8 * sizeof(KeyT) - 8), 0, 0xFFu, 0u} : digit0_of(hy, (int)(8 * sizeof(KeyT)));
   const int range      = blockIdx.x % NRANGE;
   const int64_t rbegin = (int64_t)range * range_rows < n ? (int64_t)range * range_rows : n;
   const int64_t rend   = (range == NRANGE - 1) ? n : (rbegin + range_rows < n ? rbegin + range_rows : n);
@@ -257,7 +284,7 @@ __global__ void __launch_bounds__(BT) k_hy_hist(const KeyT* __restrict__ in, int
   const unsigned lane  = lane_id();
   constexpr int UNROLL = 8;  // independent 8-byte loads in flight per lane
   const int64_t stride = (int64_t)(gridDim.x / NRANGE) * BT * UNROLL;
-  KeyT vor = 0, vnor = 0;
+  KeyT vor = 0, vnor = 0, vfold = 0;
   for (int64_t i0 = rbegin + (int64_t)(blockIdx.x / NRANGE) * BT * UNROLL + threadIdx.x; i0 < rend; i0 += stride) {
     KeyT raw[UNROLL];
 #pragma unroll
@@ -273,10 +300,11 @@ __global__ void __launch_bounds__(BT) k_hy_hist(const KeyT* __restrict__ in, int
         if (SPEC) {
           vor |= k;
           vnor |= (KeyT)~k;
+          if (KIND == K_SIGNED) vfold |= (KeyT)(raw[u] ^ (KeyT)(KeyT(0) - (KeyT)(raw[u] >> (8 * sizeof(KeyT) - 1))));
         }
         const uint64_t active = ballot(true);
         const int leader      = __builtin_ctzll(active);
-        const uint32_t d      = (uint32_t)(k >> shift) & 0xFFu;
+        const uint32_t d      = dig(k);
         const uint32_t d0     = __builtin_amdgcn_readfirstlane(d);
         if (ballot(d == d0) == active) {  // whole wave hits one bin: one add instead of 64 conflicts
           if ((int)lane == leader) atomicAdd(&s_hist[d0], (uint32_t)__builtin_popcountll(active));
@@ -303,6 +331,10 @@ __global__ void __launch_bounds__(BT) k_hy_hist(const KeyT* __restrict__ in, int
     }
     atomicOr(&hy.or_mask, o);
     atomicOr(&hy.nor_mask, no);
+  }
+  if (SPEC && KIND == K_SIGNED) {
+    const unsigned long long wf = wave_reduce((unsigned long long)vfold, [](unsigned long long x, unsigned long long y) { return x | y; });
+    if (lane == 0 && (wf & ~__hip_atomic_load(&hy.fold_x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT))) atomicOr(&hy.fold_x, wf);
   }
   for (int i = threadIdx.x; i < BINS; i += BT) {
     const uint32_t c = s_hist[i];
@@ -356,7 +388,8 @@ __device__ __forceinline__ void plan_local_digits(HybridPlan& hy, unsigned long 
 // One block of 256 threads.  STAGE 0 (after k_hy_hist<SPEC>): digits from the varying-bit mask.  STAGE 1 (after
 // k_hy_hist<!SPEC>): level-0 histogram totals, bin bases per input range, level-0 segment tables.
 __global__ void __launch_bounds__(BINS) k_hy_plan(SortPlan* plan, int stage, int key_bits, int64_t n, int bits2, int cell_max,
-                                                  int pos_bits, int64_t range_rows, int tile_rows, uint32_t* base1, int cell_alt = 0)
+                                                  int pos_bits, int64_t range_rows, int tile_rows, uint32_t* base1, int cell_alt = 0,
+                                                  int signed_keys = 0)
 {
   // cell_alt (round 4; sorted_order's pairs): a larger cell capacity (16384) the launches behind are also prepared for.  bits2 comes
   // from n alone; keys whose range is not a power of two have fuller buckets than n / 256, their 8192-key cells overflow and the
@@ -373,13 +406,14 @@ __global__ void __launch_bounds__(BINS) k_hy_plan(SortPlan* plan, int stage, int
       if (t == 0) hy.attempt = 0;
       return;
     }
-    const int top    = 63 - __builtin_clzll(V);
+    const int fh     = signed_keys ? fold_height(hy.fold_x, V, key_bits) : 0;  // (k_hy_hist<SPEC> read every key: exact)
+    const int top    = fh ? fh : 63 - __builtin_clzll(V);
     const int shift0 = top - 7;
     const int shift2 = shift0 - bits2;
     // the local sort splits a cell on >= 7 further bits in LDS; the packed (key bits, position) words of a pairs
     // sort must fit 64 bits (float keys-only sorts fall back to plain keys + stable LDS passes by themselves)
     const bool ok = shift2 >= 8 && (pos_bits == 0 || shift2 + pos_bits <= 64);
-    const bool spec_ok = shift0 == key_bits - 8;
+    const bool spec_ok = shift0 == key_bits - 8;  // (never under the sign fold: fh <= key_bits - 10)
     if (!ok) {
       if (t == 0) hy.attempt = 0;
       return;
@@ -390,6 +424,7 @@ __global__ void __launch_bounds__(BINS) k_hy_plan(SortPlan* plan, int stage, int
     if (t == 0) {
       hy.attempt   = 1;
       hy.shift0    = shift0;
+      hy.fold      = fh ? 1 : 0;
       hy.bits2     = bits2;
       hy.shift2    = shift2;
       hy.cell_max  = cell_max;
@@ -899,8 +934,8 @@ __global__ void __launch_bounds__(BT, (KPT <= 8 ? 8 : (KPT <= 12 ? 6 : 4))) k_ms
   const uint32_t* vin  = a.vin;
   uint32_t* vout       = a.vout;
   const KeyT desc_mask = (KeyT)a.desc_mask;
-  const int shift      = lvl == 0 ? hy.shift0 : hy.shift2;
   const uint32_t dmask = lvl == 0 ? 0xFFu : ((1u << hy.bits2) - 1u);
+  const Digit0 dig     = lvl == 0 ? digit0_of(hy, (int)(8 * sizeof(KeyT))) : Digit0{hy.shift2, 0, dmask, 0u};
   const int nseg       = lvl == 0 ? NRANGE : BINS;
   const unsigned tid   = threadIdx.x;
   const unsigned lane  = lane_id();
@@ -974,7 +1009,7 @@ __global__ void __launch_bounds__(BT, (KPT <= 8 ? 8 : (KPT <= 12 ? 6 : 4))) k_ms
 #pragma unroll
     for (int j = 0; j < KPT; ++j) {
       const int idx = wbase + j * GX_WAVE;
-      uint32_t d    = (uint32_t)(to_sortable<KeyT, KIND>(key[j], desc_mask) >> shift) & dmask;
+      uint32_t d    = dig(to_sortable<KeyT, KIND>(key[j], desc_mask));
       if (idx >= nvalid) d = NB - 1;  // padding sorts last (it is also last in input order)
       uint32_t lower, cnt;
       match_rank<NBL>(d, true, ~0ull, lower, cnt);
@@ -999,7 +1034,7 @@ __global__ void __launch_bounds__(BT, (KPT <= 8 ? 8 : (KPT <= 12 ? 6 : 4))) k_ms
 #pragma unroll
     for (int j = 0; j < KPT; ++j) {
       const int idx    = wbase + j * GX_WAVE;
-      const uint32_t d = (uint32_t)(to_sortable<KeyT, KIND>(key[j], desc_mask) >> shift) & dmask;
+      const uint32_t d = dig(to_sortable<KeyT, KIND>(key[j], desc_mask));
       const uint32_t r = lds_rank(s_whist, d, idx < nvalid);
       packed[j]        = (d << 16) | r;
     }
@@ -1078,7 +1113,8 @@ __global__ void __launch_bounds__(BT, (KPT <= 8 ? 8 : (KPT <= 12 ? 6 : 4))) k_ms
       gb              = live ? cell_slot(hy, seg, tid) : 0u;
       lim             = live ? gb + cellcap : 0u;
       if (live) {
-        if (prefix + pub_count > cell_cap(hy, seg)) atomicExch(&hy.overflow, 1);
+        if (prefix + pub_count > cell_cap(hy, seg) && !__hip_atomic_load(&hy.overflow, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT))
+          atomicExch(&hy.overflow, 1);  // (only while the flag is down: thousands of overflowing (tile, bin) pairs would queue on one word)
         if (gtile + 1 == hy.seg_tile0[1][seg + 1]) a.cellcount[seg * NB2MAX + tid] = prefix + pub_count;
       }
     }
@@ -1092,7 +1128,7 @@ __global__ void __launch_bounds__(BT, (KPT <= 8 ? 8 : (KPT <= 12 ? 6 : 4))) k_ms
     const int i = j * BT + (int)tid;
     if (i < nvalid) {
       const KeyT k       = s_keys[i];
-      const uint32_t d   = (uint32_t)(to_sortable<KeyT, KIND>(k, desc_mask) >> shift) & dmask;
+      const uint32_t d   = dig(to_sortable<KeyT, KIND>(k, desc_mask));
       const uint32_t dst = s_gdelta[d] + (uint32_t)i;
       if (dst < s_limit[d]) {
         kout[dst] = k;
@@ -1758,12 +1794,12 @@ __global__ void __launch_bounds__(256) k_hf_sample(const KeyT* __restrict__ in, 
   const unsigned tid = threadIdx.x, lane = lane_id();
   for (int i = tid; i < NRANGE * BINS; i += 256) s_hist[i] = 0;
   __syncthreads();
-  const int shift       = HIST ? hy.shift0 : (int)(8 * sizeof(KeyT) - 8);
+  const Digit0 dig      = HIST ? digit0_of(hy, (int)(8 * sizeof(KeyT))) : Digit0{(int)(8 * sizeof(KeyT) - 8), 0, 0xFFu, 0u};
   const int64_t step    = (int64_t)stride * HF_CHUNK;
   const int64_t nchunks = div_up(n, step);
   const int64_t nw      = (int64_t)gridDim.x * 4;
   constexpr int U       = 8;  // chunks in flight per wave
-  KeyT vor = 0, vnor = 0;
+  KeyT vor = 0, vnor = 0, vfold = 0;
   for (int64_t c0 = (int64_t)blockIdx.x * 4 + tid / GX_WAVE; c0 < nchunks; c0 += nw * U) {
     KeyT raw[U];
 #pragma unroll
@@ -1779,11 +1815,12 @@ __global__ void __launch_bounds__(256) k_hf_sample(const KeyT* __restrict__ in, 
       if (!HIST && live) {
         vor |= k;
         vnor |= (KeyT)~k;
+        if (KIND == K_SIGNED) vfold |= (KeyT)(raw[u] ^ (KeyT)(KeyT(0) - (KeyT)(raw[u] >> (8 * sizeof(KeyT) - 1))));
       }
       // a chunk never straddles two ranges (ranges are whole tiles, chunks start at multiples of 64)
       const int64_t r64 = range_rows > 0 ? row / range_rows : (int64_t)(NRANGE - 1);
       const int r       = r64 < NRANGE - 1 ? (int)r64 : NRANGE - 1;
-      (void)lds_rank(s_hist + r * BINS, (uint32_t)(k >> shift) & 0xFFu, live);
+      (void)lds_rank(s_hist + r * BINS, dig(k), live);
     }
   }
   if (!HIST) {
@@ -1797,6 +1834,10 @@ __global__ void __launch_bounds__(256) k_hf_sample(const KeyT* __restrict__ in, 
     if (tid == 0) {
       atomicOr(&hy.or_mask, s_red[0] | s_red[1] | s_red[2] | s_red[3]);
       atomicOr(&hy.nor_mask, s_red[4] | s_red[5] | s_red[6] | s_red[7]);
+    }
+    if (KIND == K_SIGNED) {
+      const unsigned long long wf = wave_reduce((unsigned long long)vfold, [](unsigned long long x, unsigned long long y) { return x | y; });
+      if (lane == 0 && wf) atomicOr(&hy.fold_x, wf);
     }
   }
   __syncthreads();
@@ -1821,6 +1862,8 @@ __device__ __forceinline__ void hf_give_up(SortPlan* plan, int state)
   plan->hy.or_mask  = 0;
   plan->hy.nor_mask = 0;
   plan->hy.overflow = 0;
+  plan->hy.fold     = 0;
+  plan->hy.fold_x   = 0;
   plan->hf.state    = state;
 }
 
@@ -1830,8 +1873,10 @@ __device__ __forceinline__ void hf_give_up(SortPlan* plan, int state)
 //   2 (after level 0)  the verdict + everything level 1, k_plan2 and the local sort need
 __global__ void __launch_bounds__(BINS) k_hf_plan(SortPlan* plan, int stage, int key_bits, int64_t n, int bits2, int cell_max, int stride,
                                                   int64_t range_rows, int tile_rows, unsigned long long slot_rows, float margin, int min_shift2,
-                                                  int bits2_max, unsigned long long cell_budget = 0)
+                                                  int bits2_max, unsigned long long cell_budget = 0, int signed_keys = 0)
 {
+  // signed_keys: the sign fold of the level-0 digit may be planned (HybridPlan::fold; never for the sharded sort, whose digit
+  // positions come from the masks of all ranks)
   // bits2_max: level-1 bits the launches behind are sized for (bits2 or bits2 + 1): stage 2 takes the extra bit when the EXACT
   // level-0 histogram says the cells would not fit otherwise
   // min_shift2: key bits that must be left below level 1 (8: k_local_sort's sub-bucket split)
@@ -1841,7 +1886,8 @@ __global__ void __launch_bounds__(BINS) k_hf_plan(SortPlan* plan, int stage, int
   const int t    = threadIdx.x;
   if (stage == 0) {
     const unsigned long long V = hy.or_mask & hy.nor_mask;
-    const int top              = V ? 63 - __builtin_clzll(V) : 0;
+    const int fh               = signed_keys ? fold_height(hy.fold_x, V, key_bits) : 0;  // (of the SAMPLE: level 0 reduces the exact one)
+    const int top              = fh ? fh : (V ? 63 - __builtin_clzll(V) : 0);
     const int shift0           = top - 7;
     const int shift2           = shift0 - bits2;
     if (V == 0 || shift2 < min_shift2) {
@@ -1858,6 +1904,7 @@ __global__ void __launch_bounds__(BINS) k_hf_plan(SortPlan* plan, int stage, int
     if (t == 0) {
       hf.hist_ready = spec_ok ? 1 : 0;
       hy.attempt   = 1;
+      hy.fold      = fh ? 1 : 0;
       hy.shift0    = shift0;
       hy.bits2     = bits2;
       hy.shift2    = shift2;
@@ -1905,8 +1952,10 @@ __global__ void __launch_bounds__(BINS) k_hf_plan(SortPlan* plan, int stage, int
         (void)block_exclusive_scan<BINS>(hf.samp[r][t], 0u, SumOp(), s_tmp, &tot_r);
         if (tot_r) est += (double)hf.samp[r][t] * ((double)hf_range_rows(r, n, range_rows) / (double)tot_r);
       }
+      // (a bucket with twice the keys its cells hold is overfull in every cell when its keys are spread at all -- bell-shaped
+      //  values -- and at least half of it is in big cells whatever they look like: counted whole)
       const double fits  = (double)((1ull << bits2_max) - 1ull) * (double)cell_max;
-      const double over  = est > fits + (double)cell_max ? est - fits : 0.0;
+      const double over  = est > 2.0 * (fits + (double)cell_max) ? est : (est > fits + (double)cell_max ? est - fits : 0.0);
       const uint32_t o32 = (uint32_t)(over < 4.0e9 ? over : 4.0e9);
       uint32_t osum;
       (void)block_exclusive_scan<BINS>(o32 >> 4, 0u, SumOp(), s_tmp, &osum);
@@ -1923,6 +1972,7 @@ __global__ void __launch_bounds__(BINS) k_hf_plan(SortPlan* plan, int stage, int
     if (t == 0) {  // level 0 reduces the EXACT masks into these
       hy.or_mask  = 0;
       hy.nor_mask = 0;
+      hy.fold_x   = 0;
       hf.slot_total = total;
     }
     return;
@@ -1932,7 +1982,10 @@ __global__ void __launch_bounds__(BINS) k_hf_plan(SortPlan* plan, int stage, int
   uint32_t cnt[NRANGE];
   uint32_t c   = 0;
   // (sharded sort: the digits come from the masks of ALL ranks; this rank's keys may well span fewer bits)
-  int bad      = hf.fail != 0 || (!hf.forced_masks && (V == 0 || (63 - __builtin_clzll(V | 1ull)) != hy.shift0 + 7));
+  // the digit positions came from the sample; the exact masks must agree: the top varying bit -- or, under the sign fold, the
+  // height of the data below the sign copies and a sign that does vary
+  const int top_exact = hy.fold ? (((V >> (key_bits - 1)) & 1ull) && hy.fold_x ? 64 - __builtin_clzll(hy.fold_x) : -1) : 63 - __builtin_clzll(V | 1ull);
+  int bad      = hf.fail != 0 || (!hf.forced_masks && (V == 0 || top_exact != hy.shift0 + 7));
   for (int r = 0; r < NRANGE; ++r) {
     cnt[r] = hf.cur0[r][t];
     if (cnt[r] > hf.cap0[r][t]) bad = 1;
@@ -1970,7 +2023,8 @@ __global__ void __launch_bounds__(BINS) k_hf_plan(SortPlan* plan, int stage, int
     // thousands of tiles that all bump the cursors of the same few cells: 205 ms for the Zipf-like column of run 15), the cell
     // sort and the big-cell machinery are skipped
     const unsigned long long fits = ((1ull << hy.bits2) - 1ull) * (unsigned long long)cell_max;
-    const uint32_t over           = (unsigned long long)c > fits + (unsigned long long)cell_max ? (uint32_t)((unsigned long long)c - fits) : 0u;
+    const unsigned long long full = fits + (unsigned long long)cell_max;
+    const uint32_t over           = (unsigned long long)c > 2ull * full ? c : ((unsigned long long)c > full ? (uint32_t)((unsigned long long)c - fits) : 0u);
     uint32_t osum;
     (void)block_exclusive_scan<BINS>(over >> 4, 0u, SumOp(), s_tmp, &osum);
     if ((unsigned long long)osum * 16ull > slot_rows / 2) {
@@ -2151,8 +2205,8 @@ __global__ void __launch_bounds__(BT, 4) k_hf_scatter(const KeyT* __restrict__ i
     const int64_t rem = (int64_t)(ext ? hf.x_count[q] : hf.reg_count[q]) - (int64_t)jt * TILE;
     nvalid            = (int)(rem < (int64_t)TILE ? rem : (int64_t)TILE);
   }
-  const int shift      = LVL == 0 ? hy.shift0 : hy.shift2;
   const uint32_t dmask = LVL == 0 ? 0xFFu : ((1u << hy.bits2) - 1u);
+  const Digit0 dig     = LVL == 0 ? digit0_of(hy, (int)(8 * sizeof(KeyT))) : Digit0{hy.shift2, 0, dmask, 0u};
 
   KeyT key[KPT];
   if (nvalid == TILE) {
@@ -2181,6 +2235,13 @@ __global__ void __launch_bounds__(BT, 4) k_hf_scatter(const KeyT* __restrict__ i
       s_red[tid / GX_WAVE]      = wo;
       s_red[NW + tid / GX_WAVE] = wn;
     }
+    if (KIND == K_SIGNED && hy.fold) {  // the sign fold is verified on the exact OR of (key ^ sign extension)
+      KeyT vf = 0;
+#pragma unroll
+      for (int j = 0; j < KPT; ++j) vf |= (KeyT)(key[j] ^ (KeyT)(KeyT(0) - (KeyT)(key[j] >> (8 * sizeof(KeyT) - 1))));
+      const unsigned long long wf = wave_reduce((unsigned long long)vf, [](unsigned long long x, unsigned long long y) { return x | y; });
+      if (lane_id() == 0 && (wf & ~__hip_atomic_load(&hy.fold_x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT))) atomicOr(&hy.fold_x, wf);
+    }
   }
   __syncthreads();
   if (LVL == 0 && tid == 0) {  // atomics only while this workgroup still has a bit to add
@@ -2204,7 +2265,7 @@ __global__ void __launch_bounds__(BT, 4) k_hf_scatter(const KeyT* __restrict__ i
   for (int j = 0; j < KPT; ++j) {
     const bool live  = j * BT + (int)tid < nvalid;
     const KeyT k     = to_sortable<KeyT, KIND>(key[j], desc_mask);
-    const uint32_t d = (uint32_t)(k >> shift) & dmask;
+    const uint32_t d = dig(k);
     const uint32_t r = lds_rank(s_cnt, d, live);
     if constexpr (RANK16) packed[j >> 1] |= r << (16 * (j & 1));
     else packed[j] = (d << 16) | r;
@@ -2243,27 +2304,33 @@ __global__ void __launch_bounds__(BT, 4) k_hf_scatter(const KeyT* __restrict__ i
     }
   }
   uint32_t st = block_exclusive_scan<BT>(csum, 0u, SumOp(), s_scan, (uint32_t*)nullptr);
+  bool spilled = false;
 #pragma unroll
   for (int k = 0; k < BPT; ++k) {
     const uint32_t bin = tid * BPT + k;
     if (bin < (uint32_t)NB) {
-      if (c[k] && !skip[k] && g[k] + c[k] > scap[k]) {  // the surplus is dropped at the write-out; the fallback will sort the column
-        if (LVL == 0) hf.fail = 1;
-        else if (LVL == 1) atomicExch(&hy.overflow, 1);
-        else atomicExch(&hy.bad, 2);  // (cannot happen: the rescue writes exactly the keys level 1 counted)
-      }
+      if (c[k] && !skip[k] && g[k] + c[k] > scap[k]) spilled = true;  // the surplus is dropped at the write-out
       s_cnt[bin]   = st;
       s_delta[bin] = sbase[k] + g[k] - st;
       s_limit[bin] = sbase[k] + scap[k];
       st += c[k];
     }
   }
+  // The flag is raised only while it is still down (a load, no read-modify-write): a column whose cells overflow by the million
+  // (bell-shaped or Zipf-like values) used to send an atomic per (tile, bin) to this ONE word -- 2.4e7 to 1.2e8 of them, 205 and
+  // 707 ms (profiles/r4_run15_sort_zipf_kernel_stats.txt, r4_run18_sort_robustness.txt).  Nothing is added for a tile without a spill.
+  if (spilled) {
+    if (LVL == 0) hf.fail = 1;
+    else if (LVL == 1) {
+      if (!__hip_atomic_load(&hy.overflow, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) atomicExch(&hy.overflow, 1);
+    } else atomicExch(&hy.bad, 2);  // (cannot happen: the rescue writes exactly the keys level 1 counted)
+  }
   __syncthreads();
 #pragma unroll
   for (int j = 0; j < KPT; ++j) {
     if (j * BT + (int)tid < nvalid) {
       if constexpr (RANK16) {
-        const uint32_t d = (uint32_t)(to_sortable<KeyT, KIND>(key[j], desc_mask) >> shift) & dmask;
+        const uint32_t d = dig(to_sortable<KeyT, KIND>(key[j], desc_mask));
         s_keys[s_cnt[d] + ((packed[j >> 1] >> (16 * (j & 1))) & 0xFFFFu)] = key[j];
       } else {
         s_keys[s_cnt[packed[j] >> 16] + (packed[j] & 0xFFFFu)] = key[j];
@@ -2276,7 +2343,7 @@ __global__ void __launch_bounds__(BT, 4) k_hf_scatter(const KeyT* __restrict__ i
     const int i = j * BT + (int)tid;
     if (i < nvalid) {
       const KeyT k       = s_keys[i];
-      const uint32_t d   = (uint32_t)(to_sortable<KeyT, KIND>(k, desc_mask) >> shift) & dmask;
+      const uint32_t d   = dig(to_sortable<KeyT, KIND>(k, desc_mask));
       const uint32_t dst = s_delta[d] + (uint32_t)i;
       if (dst < s_limit[d]) out[dst] = k;
     }
@@ -2509,7 +2576,7 @@ int sort_impl(const void* keys_in, void* keys_out, const int32_t* vals_in, int32
       KeyT* bufA      = keys_out ? static_cast<KeyT*>(keys_out) : ka_scratch;
       hipLaunchKernelGGL((k_hf_sample<KeyT, KIND, false>), dim3((unsigned)sblocks), dim3(256), 0, stream, kin, n, desc_mask, plan, fc.stride, frange);
       hipLaunchKernelGGL(k_hf_plan, dim3(1), dim3(BINS), 0, stream, plan, 0, (int)(8 * sizeof(KeyT)), n, fc.bits2, 1 << 13, fc.stride, frange, FT,
-                         (unsigned long long)fc.slot_rows, g_cursor_margin, MIN_SHIFT2, fc.bits2_max);
+                         (unsigned long long)fc.slot_rows, g_cursor_margin, MIN_SHIFT2, fc.bits2_max, 0ull, KIND == K_SIGNED ? 1 : 0);
       hipLaunchKernelGGL((k_hf_sample<KeyT, KIND, true>), dim3((unsigned)sblocks), dim3(256), 0, stream, kin, n, desc_mask, plan, fc.stride, frange);
       hipLaunchKernelGGL(k_hf_plan, dim3(1), dim3(BINS), 0, stream, plan, 1, (int)(8 * sizeof(KeyT)), n, fc.bits2, 1 << 13, fc.stride, frange, FT,
                          (unsigned long long)fc.slot_rows, g_cursor_margin, MIN_SHIFT2, fc.bits2_max);
@@ -2606,7 +2673,7 @@ int sort_impl(const void* keys_in, void* keys_out, const int32_t* vals_in, int32
       hipLaunchKernelGGL((k_hy_hist<KeyT, KIND, true>), dim3((unsigned)hblocks), dim3(BT), 0, stream,
                          static_cast<const KeyT*>(keys_in), n, desc_mask, plan, range_rows);
       hipLaunchKernelGGL(k_hy_plan, dim3(1), dim3(BINS), 0, stream, plan, 0, (int)(8 * sizeof(KeyT)), n, hc.bits2, 1 << hc.cl2,
-                         HAS_VAL ? hc.cl2 : 0, range_rows, (int)msd_tile, base1);
+                         HAS_VAL ? hc.cl2 : 0, range_rows, (int)msd_tile, base1, 0, KIND == K_SIGNED ? 1 : 0);
       hipLaunchKernelGGL((k_hy_hist<KeyT, KIND, false>), dim3((unsigned)hblocks), dim3(BT), 0, stream,
                          static_cast<const KeyT*>(keys_in), n, desc_mask, plan, range_rows);
       hipLaunchKernelGGL(k_hy_plan, dim3(1), dim3(BINS), 0, stream, plan, 1, (int)(8 * sizeof(KeyT)), n, hc.bits2, 1 << hc.cl2,
@@ -2809,6 +2876,7 @@ __global__ void __launch_bounds__(BINS) k_hfx_plan(SortPlan* plan, long long n, 
     hy.or_mask  = or_mask;
     hy.nor_mask = nor_mask;
     plan_local_digits(hy, V, shift2);
+    hy.fold     = 0;  // (the sharded sort's digits come from the masks of all ranks: no sign fold)
     hf.ext      = 1;
     hf.nreg     = nreg;
     hf.x_tile0  = x_tile0;

@@ -253,6 +253,23 @@ def test_sign_extension_bytes_are_not_sorted_on(gx, dtype, lo, hi, passes):
     np.testing.assert_array_equal(order, np.argsort(v, kind="stable").astype(np.int32))
 
 
+def test_look_back_path_takes_the_sign_fold(gx):
+    """6e6 int64 keys uniform in [-1e12, 1e12) (below the cursor path's 2^25 rows: the look-back path plans from the exact masks
+    of k_hy_hist): sign fold at height 40 -> shift0 33, every cell sorted in LDS; the permutation (pairs) takes the same plan"""
+    Column, ops = gx
+    rng = np.random.default_rng(80)
+    v = rng.integers(-10**12, 10**12, 6_000_000, dtype=np.int64)
+    v[::100_000] = v[7]                                  # ties: the order must be stable
+    for asc in (True, False):
+        got, info = _sort_info(ops, Column.from_numpy(v), asc)
+        assert got.tobytes() == orc.sort_keys(v, asc).tobytes()
+        assert info[0] == 1 and info[1] == 1 and info[2] == 33, info
+    order = ops.sorted_order(Column.from_numpy(v)).to_numpy()
+    np.testing.assert_array_equal(order, np.argsort(v, kind="stable").astype(np.int32))
+    order = ops.sorted_order(Column.from_numpy(v), ascending=False).to_numpy()
+    np.testing.assert_array_equal(order, orc.sorted_order(v, None, False).astype(np.int32))
+
+
 @pytest.mark.parametrize("dtype", ["int64", "float64", "uint64"])
 def test_hybrid_sorted_order_is_stable(gx, dtype):
     """sorted_order (key + iota payload) of >= 2^22 rows takes the hybrid path with the packed

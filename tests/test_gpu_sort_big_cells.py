@@ -118,21 +118,25 @@ def test_uniform_keys_have_no_big_cell(gx):
     assert state == 3 and big == [0, 0, 0] and info[1] == 1 and info[7] == -1   # k_plan2 marked every LSD pass as skipped
 
 
-@pytest.mark.parametrize("dist", ["zipf", "normal", "around_zero"])
-def test_value_distributions_the_levels_cannot_split_go_to_the_lsd_passes_at_once(gx, dist):
-    """Zipf-like values (floor(u^-5): 18 % of the rows are 1, 97 % below 2^24), bell-shaped values around zero and a uniform
-    range that crosses zero (both: the sign bit is the top digit -> two buckets of n / 2 whose keys agree on the next 20 bits)
-    put nearly every key into cells that must overflow.  Round 4 run 14 measured 56 - 240 ms per 1e9 rows for them (level 1:
-    every tile bumping the cursors of the same few cells); now the sample (stage 1) or the exact level-0 histogram (stage 2)
-    sees that more keys sit in big cells than X holds and the plan goes straight to the LSD passes: state 4, bit-exact."""
+@pytest.mark.parametrize("dist", ["zipf", "two_clusters", "normal"])
+def test_value_distributions_the_levels_cannot_split(gx, dist):
+    """Zipf-like values (floor(u^-5): 18 % of the rows are 1, 97 % below 2^24) and two narrow clusters far apart put nearly every
+    key into cells that must overflow.  Round 4 run 14 measured 56 - 240 ms per 1e9 rows for such columns (level 1: an atomic per
+    overflowing (tile, bin) on ONE flag word); now the sample (k_hf_plan stage 1) or the exact level-0 histogram (stage 2) sees
+    that more keys sit in big cells than X holds and the plan goes straight to the LSD passes: state 4, bit-exact.  Bell-shaped
+    values around zero take the sign fold; at 4e7 rows their central buckets are overfull, not hopeless: whichever way the device
+    decides (big cells through X, or the LSD passes), the result is bit-exact and the state is a decided one."""
     rng = np.random.default_rng(31)
     if dist == "zipf":
         v = np.minimum(np.floor(np.maximum(rng.random(N), 2.0 ** -53) ** -5.0), float(1 << 31)).astype(np.int64)
-    elif dist == "normal":
-        v = np.round(rng.standard_normal(N) * float(1 << 40)).astype(np.int64)
+    elif dist == "two_clusters":
+        v = rng.integers(0, 1 << 20, N, dtype=np.int64) + np.where(rng.random(N) < 0.5, np.int64(1) << 60, np.int64(0))
     else:
-        v = rng.integers(-10**12, 10**12, N, dtype=np.int64)
+        v = np.round(rng.standard_normal(N) * float(1 << 40)).astype(np.int64)
     for descending in (False, True):
         got, state, big, info = _sort(gx, v, descending)
         assert got.tobytes() == c_oracle.sort_i64(v, descending=descending).tobytes()
-        assert state == 4 and big[0] == 0 and info[1] == 0 and info[7] > 0, (state, big, info)
+        if dist == "normal":
+            assert state in (3, 4), (state, big, info)
+        else:
+            assert state == 4 and big[0] == 0 and info[1] == 0 and info[7] > 0, (state, big, info)
