@@ -964,7 +964,7 @@ def main():
     if wl in ("all", "sort", "sorted_order"):
         head = bench_sort(c, pairs=(wl == "sorted_order"))
         if wl == "all":
-            if c.world == 1:  # cudf::sorted_order, what the reference's sort benchmark times (cpp/benchmarks/sort/sort.cpp:16-61): its own block
+            if c.world == 1:  # cudf::sorted_order, what the reference's sort benchmark times (cpp/benchmarks/sort/sort.cpp:16-58): its own block
                 c.torch.cuda.empty_cache()
                 blocks["sorted_order"] = bench_sort(c, pairs=True, cpu_leg=False)
             c.torch.cuda.empty_cache()

@@ -2184,10 +2184,31 @@ __global__ void __launch_bounds__(BT, 4) k_hf_scatter(const KeyT* __restrict__ i
     seg               = (per > 0 && v / per < NRANGE - 1) ? (uint32_t)(v / per) : (uint32_t)(NRANGE - 1);
     base              = v * TILE;
     nvalid            = (int)(n - base < (int64_t)TILE ? n - base : (int64_t)TILE);
+  } else if (!hf.ext) {
+    // the column's own regions (bucket, input range): a table inside the plan, every address below is known at launch
+    if (v >= (int64_t)hf.reg_tile0[BINS * NRANGE]) return;
+    constexpr int QPT = BINS * NRANGE / BT;  // region table entries per thread
+#pragma unroll
+    for (int k = 0; k < QPT; ++k) {
+      const int q       = (int)tid * QPT + k;
+      const uint32_t lo = hf.reg_tile0[q], hi = hf.reg_tile0[q + 1];
+      if ((int64_t)lo <= v && v < (int64_t)hi) {
+        s_misc[0] = (uint32_t)q;
+        s_misc[1] = (uint32_t)(v - lo);
+      }
+    }
+    __syncthreads();
+    const uint32_t q  = s_misc[0];
+    const uint32_t jt = s_misc[1];
+    seg               = q / NRANGE;  // the level-0 bucket
+    if (LVL == 2 && !hy.bigbucket[seg]) return;  // (block-uniform: nothing of this bucket is needed again)
+    base              = (int64_t)hf.reg_start[q] + (int64_t)jt * TILE;
+    const int64_t rem = (int64_t)hf.reg_count[q] - (int64_t)jt * TILE;
+    nvalid            = (int)(rem < (int64_t)TILE ? rem : (int64_t)TILE);
   } else {
-    const bool ext         = hf.ext != 0;  // the sharded sort's receive area (gx_sortx_finish)
-    const uint32_t nreg    = ext ? hf.nreg : (uint32_t)(BINS * NRANGE);
-    const uint32_t* rtile0 = ext ? hf.x_tile0 : hf.reg_tile0;
+    // the sharded sort's receive area (gx_sortx_finish): regions (bucket, source rank, input range) in an external table
+    const uint32_t nreg    = hf.nreg;
+    const uint32_t* rtile0 = hf.x_tile0;
     if (v >= (int64_t)rtile0[nreg]) return;
     for (uint32_t q = tid; q < nreg; q += BT) {
       const uint32_t lo = rtile0[q], hi = rtile0[q + 1];
@@ -2199,14 +2220,18 @@ __global__ void __launch_bounds__(BT, 4) k_hf_scatter(const KeyT* __restrict__ i
     __syncthreads();
     const uint32_t q  = s_misc[0];
     const uint32_t jt = s_misc[1];
-    seg               = ext ? hf.x_bucket[q] : q / NRANGE;  // the level-0 bucket
+    seg               = hf.x_bucket[q];  // the level-0 bucket
     if (LVL == 2 && !hy.bigbucket[seg]) return;  // (block-uniform: nothing of this bucket is needed again)
-    base              = (int64_t)(ext ? hf.x_start[q] : hf.reg_start[q]) + (int64_t)jt * TILE;
-    const int64_t rem = (int64_t)(ext ? hf.x_count[q] : hf.reg_count[q]) - (int64_t)jt * TILE;
+    base              = (int64_t)hf.x_start[q] + (int64_t)jt * TILE;
+    const int64_t rem = (int64_t)hf.x_count[q] - (int64_t)jt * TILE;
     nvalid            = (int)(rem < (int64_t)TILE ? rem : (int64_t)TILE);
   }
   const uint32_t dmask = LVL == 0 ? 0xFFu : ((1u << hy.bits2) - 1u);
   const Digit0 dig     = LVL == 0 ? digit0_of(hy, (int)(8 * sizeof(KeyT))) : Digit0{hy.shift2, 0, dmask, 0u};
+  // the bucket's cell slots (HybridPlan::ccap / cbase), requested HERE: the two loads fly under the key loads and the ranking.
+  // Asked for where they are used, next to the cursor atomics, they held the atomics back by a round trip per tile
+  const uint32_t cap_s  = LVL >= 1 ? cell_cap(hy, seg) : 0u;
+  const uint32_t base_s = LVL >= 1 ? cell_slot(hy, seg, 0u) : 0u;
 
   KeyT key[KPT];
   if (nvalid == TILE) {
@@ -2287,12 +2312,12 @@ __global__ void __launch_bounds__(BT, 4) k_hf_scatter(const KeyT* __restrict__ i
         scap[k]  = hf.cap0[seg][bin];
         if (c[k]) g[k] = atomicAdd(&hf.cur0[seg][bin], c[k]);
       } else if (LVL == 1 && bin <= dmask) {
-        sbase[k] = cell_slot(hy, seg, bin);
-        scap[k]  = cell_cap(hy, seg);
+        sbase[k] = base_s + bin * cap_s;
+        scap[k]  = cap_s;
         if (c[k]) g[k] = atomicAdd(&cellcur[seg * NB2MAX + bin], c[k]);
       } else if (LVL == 2 && bin <= dmask) {
         const uint32_t total = cellcur[seg * NB2MAX + bin];  // the cell's true size (level 1 counted every key)
-        if (total > cell_cap(hy, seg)) {
+        if (total > cap_s) {
           sbase[k] = xoff[seg * NB2MAX + bin];
           scap[k]  = total;
           if (c[k]) g[k] = atomicAdd(&rescur[seg * NB2MAX + bin], c[k]);
