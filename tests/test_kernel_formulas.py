@@ -712,3 +712,63 @@ def test_pmc_kernel_names_and_groups():
         e = tr["groups"].get(key) or tr["kernels"].get(key)
         assert e and e["hbm_bytes_per_launch"] > 1e9, key
     assert 48e9 < tr["groups"]["sort"]["hbm_bytes_per_launch"] < 51e9
+
+
+def _sortable_i64(v, descending=False):
+    s = v.view(np.uint64) ^ np.uint64(1 << 63)
+    return ~s if descending else s
+
+
+def test_sign_fold_digit_and_lsd_skip_rule_models():
+    """gx_sort.hip round 4, two plan rules for signed keys spread around zero, restated in NumPy on the kernels' own bit formulas.
+    (1) fold_height / Digit0: with h = bit length of OR(key ^ sign extension), sorting by ((sign << 7) | bits [h-7, h) of the
+    sortable key, then the bits below h - 7) is sorting by the key -- the bits in [h, 63) are copies of the sign, equal inside a
+    bucket.  (2) k_plan: stable LSD passes over the bytes below h plus the TOP byte order the column; the bytes wholly inside
+    [h, 56) are skipped.  Both for ascending and descending sortable forms and for ranges on one side of zero."""
+    rng = np.random.default_rng(4)
+    for lo, hi in [(-10**12, 10**12), (-1000, 1000), (-(1 << 40), 1 << 33), (-5, 3 * 10**15), (0, 1000), (-3000, -1000), (-1, 1)]:
+        v = rng.integers(lo, hi, 20000, dtype=np.int64)
+        v[:2] = lo, hi - 1
+        fold_or = int(np.bitwise_or.reduce((v ^ (v >> 63)).view(np.uint64)))
+        h = fold_or.bit_length()
+        for desc in (False, True):
+            s = _sortable_i64(v, desc)
+            want = np.sort(v)[::-1] if desc else np.sort(v)
+            # (2) the LSD plan: passes on byte p unless it is constant or (p < 7 and 8p >= h)
+            order = np.arange(len(v))
+            passes = 0
+            for p in range(8):
+                d = ((s >> np.uint64(8 * p)) & np.uint64(0xFF)).astype(np.int64)
+                if len(np.unique(d)) == 1 or (p < 7 and 8 * p >= h):
+                    continue
+                order = order[np.argsort(d[order], kind="stable")]
+                passes += 1
+            np.testing.assert_array_equal(v[order], want)
+            assert passes <= (h + 7) // 8 + 1
+            # (1) the folded level-0 digit (planned only when the sign varies and 7 <= h <= 54)
+            sign_varies = (v < 0).any() and (v >= 0).any()
+            if sign_varies and 7 <= h <= 54:
+                d0 = ((s >> np.uint64(h - 7)) & np.uint64(0x7F)) | ((s >> np.uint64(56)) & np.uint64(0x80))
+                low = s & np.uint64((1 << (h - 7)) - 1)
+                order = np.lexsort((low, d0))
+                np.testing.assert_array_equal(v[order], want)
+                # every bucket's keys agree on every bit from h - 7 upwards: what the cell sort below relies on
+                top = s >> np.uint64(h - 7)
+                for b in np.unique(d0)[:8]:
+                    assert len(np.unique(top[d0 == b])) == 1
+
+
+def test_early_decline_estimate_is_a_lower_bound_times_two_at_most():
+    """k_hf_plan stage 2: keys of a bucket that must sit in overflowing cells.  With K cells of `cap` keys a bucket of c keys has at
+    least c - (K - 1) * cap keys in cells above capacity (everything else filled to the brim); the kernel counts the bucket whole
+    once c > 2 * K * cap, which overstates that bound by less than 2x.  Checked against a brute-force worst case."""
+    K, cap = 8, 100
+    for c in [0, 500, 800, 801, 950, 1600, 1601, 5000]:
+        fits, full = (K - 1) * cap, K * cap
+        over = c if c > 2 * full else (c - fits if c > full else 0)
+        # fewest keys in overflowing cells: fill K - 1 cells to exactly cap, the rest into the last one
+        rest = c - fits
+        brute = rest if rest > cap else 0
+        assert brute <= over or c <= full
+        if c > 2 * full:
+            assert over < 2 * brute
