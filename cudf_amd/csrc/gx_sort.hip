@@ -1334,11 +1334,15 @@ __device__ __forceinline__ void local_place_cell(const uint32_t cell, const KeyT
   const int bits2 = hy.bits2;
   const uint32_t b  = cell >> bits2;
   const uint32_t d2 = cell & ((1u << bits2) - 1u);
-  const uint32_t m  = hist2[b * NB2MAX + d2];
-  if (m == 0 || m > cell_cap(hy, b)) return;  // (a big cell -- cursor path only -- is sorted through X, see HybridPlan::big)
+  // (the cell's size, output position and slot are requested together: behind the size check the slot lookup would be a second
+  //  round trip before the first key load)
+  const uint32_t m    = hist2[b * NB2MAX + d2];
+  const uint32_t cap  = cell_cap(hy, b);
+  const uint32_t slot = cell_slot(hy, b, d2);
   const int64_t start = base2[b * NB2MAX + d2];
-  in += (int64_t)cell_slot(hy, b, d2) - start;  // the cell sits in its slot of the level-1 buffer
-  if (HAS_VAL) vin += (int64_t)cell_slot(hy, b, d2) - start;
+  if (m == 0 || m > cap) return;  // (a big cell -- cursor path only -- is sorted through X, see HybridPlan::big)
+  in += (int64_t)slot - start;  // the cell sits in its slot of the level-1 buffer
+  if (HAS_VAL) vin += (int64_t)slot - start;
   extern __shared__ __attribute__((aligned(16))) char smem[];
   WordT* s_keys    = reinterpret_cast<WordT*>(smem);                                                 // LOCAL_MAX + LOCAL_MAX / 16
   uint32_t* s_cnt8 = reinterpret_cast<uint32_t*>(smem + (size_t)(LOCAL_MAX + LOCAL_MAX / 16) * sizeof(WordT));  // NPB bytes
@@ -1519,11 +1523,13 @@ __device__ __forceinline__ void local_sort_cell(const uint32_t cell, const IoT* 
   const int bits2   = hy.bits2;
   const uint32_t b  = cell >> bits2;
   const uint32_t d2 = cell & ((1u << bits2) - 1u);
-  const uint32_t m  = hist2[b * NB2MAX + d2];  // cell size (level-1 pass), output position (k_plan2)
-  if (m == 0 || m > cell_cap(hy, b)) return;  // (big cells: see HybridPlan::big)
+  const uint32_t m    = hist2[b * NB2MAX + d2];  // cell size (level-1 pass), output position (k_plan2)
+  const uint32_t cap  = cell_cap(hy, b);
+  const uint32_t slot = cell_slot(hy, b, d2);
   const int64_t start = base2[b * NB2MAX + d2];
-  in += (int64_t)cell_slot(hy, b, d2) - start;  // the cell sits in its slot of the level-1 buffer
-  if (HAS_VAL) vin += (int64_t)cell_slot(hy, b, d2) - start;
+  if (m == 0 || m > cap) return;  // (big cells: see HybridPlan::big)
+  in += (int64_t)slot - start;  // the cell sits in its slot of the level-1 buffer
+  if (HAS_VAL) vin += (int64_t)slot - start;
   const unsigned tid  = threadIdx.x;
   const unsigned lane = lane_id();
   const unsigned w    = tid / GX_WAVE;
