@@ -1,4 +1,7 @@
 #!/bin/bash
+# NOTE: runs 24 and 25 used a temporary host-side knob (environment variable GX_SORT_LAYOUT, read in sort_impl) that moved the two
+# big buffers inside the scratch; it was removed again after these runs (no layout helped reproducibly).  Run 24 was this script
+# with the layout list `0 1 2 3 4 0`.  Kept as the record of what was measured: profiles/r4_run24_layout_ab.txt, r4_run25_layout_ab.txt
 # round 4, run 25 (EXPERIMENT): does the placement of the level-0 buffer and the cell buffer inside the scratch move level 0 / level 1?
 # (level 0 3.84 -> 3.6 ms and level 1 3.63 -> 3.97 ms with the commit that shrank the cell buffer; no kernel code of either changed)
 cd "$(dirname "$0")/.." || exit 1
