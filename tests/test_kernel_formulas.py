@@ -772,3 +772,39 @@ def test_early_decline_estimate_is_a_lower_bound_times_two_at_most():
         assert brute <= over or c <= full
         if c > 2 * full:
             assert over < 2 * brute
+
+
+def test_splitter_sort_model_orders_every_distribution():
+    """DESIGN.md section 8 row 1 (proposed, not built): the maps of the splitter sort are MONOTONE, so concatenating the sorted
+    cells in (bucket, cell) order is the sorted column -- executable statement of the plan next round's kernels have to keep:
+    bucket = upper_bound(splitters, key) with an equality bucket [v, v + 1) for a value that fills two sample quantiles;
+    cell = floor(rel * ncell / width) on rel = key - bucket_lo, exactly as a 64 x 64 -> 128-bit multiply-high computes it."""
+    import importlib.util
+    import os
+    spec = importlib.util.spec_from_file_location("xp_splitter_model", os.path.join(os.path.dirname(__file__), "..", "scripts", "xp", "xp_splitter_model.py"))
+    xp = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(xp)
+    rng = np.random.default_rng(3)
+    n = 1 << 17
+    for name, s in xp.distributions(n, rng):
+        samp = np.sort(s[rng.integers(0, n, 4096)])
+        q = samp[(np.arange(1, 256) * 4096) // 256]
+        vals, reps = np.unique(q, return_counts=True)
+        sp = np.unique(np.concatenate([vals, vals[reps >= 2] + np.uint64(1)]))
+        bucket = np.searchsorted(sp, s, side="right")
+        lo = np.concatenate([[s.min()], sp])
+        hi = np.concatenate([sp, [s.max() + np.uint64(1)]])
+        out = []
+        for b in range(len(sp) + 1):
+            kb = s[bucket == b]
+            if len(kb) == 0:
+                continue
+            width = int(hi[b]) - int(lo[b])
+            ncell = max(1, min(-(-len(kb) // 512), 1024, width))            # (512-key cells here: several cells per bucket at this n)
+            rel = [int(k) - int(lo[b]) for k in kb]
+            cell = np.array([(r * ncell) // width for r in rel])              # exact integer arithmetic = the multiply-high
+            assert cell.min() >= 0 and cell.max() < ncell, name
+            for k in range(ncell):
+                out.append(np.sort(kb[cell == k]))
+        got = np.concatenate(out)
+        np.testing.assert_array_equal(got, np.sort(s), err_msg=name)
