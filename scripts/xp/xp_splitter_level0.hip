@@ -1,8 +1,10 @@
 // xp_splitter_level0.hip -- micro-benchmark for DESIGN.md section 8 row 1 (the splitter sort's level 0).  Standalone: no dependency
 // on the library, NOT part of the product build.
 //
-// STATUS (end of round 4): written and cross-compiled for gfx950; NOT YET RUN -- the round's GPU minutes were spent.  First thing
-// to do with it:   hipcc --offload-arch=gfx950 -O3 -std=c++17 scripts/xp/xp_splitter_level0.hip -o /tmp/xp_split && /tmp/xp_split
+// STATUS (end of round 4): ran once, with the round's last GPU seconds (profiles/r4_run31_xp_splitter_level0.txt): correct on the
+// first execution (no key outside its bucket's range, histogram totals = n); plan 0.16-0.19 ms, histogram through the search
+// 6.6 ms, search + scatter 7.6-7.8 ms per 1e9 keys -- the 9-step LDS search is what has to get cheaper.
+//   hipcc --offload-arch=gfx950 -O3 -std=c++17 scripts/xp/xp_splitter_level0.hip -o /tmp/xp_split && /tmp/xp_split [n]
 // The CPU model of the same plan (bucket balance, equality buckets, cells above capacity on eleven distributions) is
 // scripts/xp/xp_splitter_model.py -> profiles/r4_model_splitter_sort.txt.
 //
