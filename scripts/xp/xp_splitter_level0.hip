@@ -3,7 +3,10 @@
 //
 // STATUS (end of round 4): ran once, with the round's last GPU seconds (profiles/r4_run31_xp_splitter_level0.txt): correct on the
 // first execution (no key outside its bucket's range, histogram totals = n); plan 0.16-0.19 ms, histogram through the search
-// 6.6 ms, search + scatter 7.6-7.8 ms per 1e9 keys -- the 9-step LDS search is what has to get cheaper.
+// 6.6 ms, search + scatter 7.6-7.8 ms per 1e9 keys.  Runs 32 / 33 (profiles/r4_run32_xp_splitter_level0.txt): SEARCH 1 -- a LUT of
+// 2048 key ranges + a scan of the sorted table -- histograms in 3.97 ms; the scatter below stays at 7.4 ms with either search: it
+// is bound by ITS placement (one cursor per bucket, all XCDs into all regions), not by the search.  Next: put the LUT search into
+// the product's k_hf_scatter<.., 0, ..> (per-(range, bin) slots) behind the plan's "uneven buckets" verdict.
 //   hipcc --offload-arch=gfx950 -O3 -std=c++17 scripts/xp/xp_splitter_level0.hip -o /tmp/xp_split && /tmp/xp_split [n]
 // The CPU model of the same plan (bucket balance, equality buckets, cells above capacity on eleven distributions) is
 // scripts/xp/xp_splitter_model.py -> profiles/r4_model_splitter_sort.txt.
@@ -39,6 +42,7 @@ constexpr int TILE   = BT * KPT;
 constexpr int NSAMP  = 16384;      // sample size: sorted by one workgroup
 constexpr int NLEAF  = 512;        // Eytzinger tree with 511 inner nodes -> up to 512 buckets
 constexpr uint64_t U64MAX = ~0ull;
+constexpr int NLUT   = 2048;       // SEARCH 1: first bucket of 2048 key ranges (uint16 each), then a short scan of the sorted table
 
 __device__ __forceinline__ uint64_t mix64(uint64_t x)
 {
@@ -94,7 +98,25 @@ struct Plan {
   unsigned long long start[NLEAF + 1];
   unsigned int cursor[NLEAF];
   unsigned long long violations;
+  // SEARCH 1 (run 32): lut[c] = number of splitters in cells below c, cells cut on rel = key - kmin either LINEARLY (rel >> lshift;
+  // even or bell-shaped densities) or LOGARITHMICALLY (exponent and 5 mantissa bits of rel; power-law densities): the planner
+  // takes the form whose fullest cell holds fewer splitters
+  uint64_t kmin;
+  uint32_t lut_log, lshift, lut_worst[2];
+  uint16_t lut[NLUT];
 };
+
+__device__ __forceinline__ uint32_t lut_cell(uint64_t rel, uint32_t lut_log, uint32_t lshift)
+{
+  if (lut_log) {
+    if (rel == 0) return 0;
+    const int e = 63 - __clzll((long long)rel);
+    const uint32_t m = e >= 5 ? (uint32_t)(rel >> (e - 5)) & 31u : (uint32_t)(rel << (5 - e)) & 31u;
+    return (uint32_t)e * 32u + m;
+  }
+  const uint64_t c = rel >> lshift;
+  return c < (uint64_t)(NLUT - 1) ? (uint32_t)c : (uint32_t)(NLUT - 1);
+}
 
 __global__ void __launch_bounds__(1024) k_sort_sample(uint64_t* __restrict__ samp, Plan* plan)
 {
@@ -163,6 +185,42 @@ __global__ void __launch_bounds__(1024) k_sort_sample(uint64_t* __restrict__ sam
     const int j = tid - (1 << l);
     plan->eyt[tid] = plan->table[(((2 * j + 1) << (8 - l)) - 1)];
   }
+  // ---- SEARCH 1: the LUT.  kmin / kmax of the SAMPLE (keys outside still find their bucket: the scan is exact, the LUT only a start)
+  __shared__ uint32_t s_idx[2][NLEAF];
+  __shared__ uint32_t s_worst[2];
+  const uint64_t kmin = s[0], kmax = s[NSAMP - 1];
+  uint32_t lshift = 0;
+  while (lshift < 63 && ((kmax - kmin) >> lshift) >= (uint64_t)NLUT) ++lshift;
+  const uint32_t nsp = s_total;
+  if (tid < 2) s_worst[tid] = 0;
+  __syncthreads();
+  for (int form = 0; form < 2; ++form) {
+    for (uint32_t i = tid; i < NLEAF; i += 1024) s_idx[form][i] = i < nsp ? lut_cell(plan->table[i] - kmin, (uint32_t)form, lshift) : 0xFFFFFFFFu;
+  }
+  __syncthreads();
+  uint32_t lo2[2][NLUT / 1024];
+  for (int form = 0; form < 2; ++form) {
+    for (int r = 0; r < NLUT / 1024; ++r) {
+      const uint32_t c = (uint32_t)tid + 1024u * r;
+      // splitters in cells below c = lower_bound(s_idx, c); in cell c: upper_bound - lower_bound
+      uint32_t a = 0, b = nsp;
+      while (a < b) { const uint32_t mid = (a + b) / 2; if (s_idx[form][mid] < c) a = mid + 1; else b = mid; }
+      uint32_t a2 = a, b2 = nsp;
+      while (a2 < b2) { const uint32_t mid = (a2 + b2) / 2; if (s_idx[form][mid] <= c) a2 = mid + 1; else b2 = mid; }
+      lo2[form][r] = a | (a2 == a ? 0x8000u : 0u);  // bit 15: no splitter inside this cell -> the bucket is known without the table
+      atomicMax(&s_worst[form], a2 - a);
+    }
+  }
+  __syncthreads();
+  const int pick = s_worst[1] < s_worst[0] ? 1 : 0;
+  for (int r = 0; r < NLUT / 1024; ++r) plan->lut[tid + 1024 * r] = (uint16_t)lo2[pick][r];
+  if (tid == 0) {
+    plan->kmin = kmin;
+    plan->lut_log = (uint32_t)pick;
+    plan->lshift = lshift;
+    plan->lut_worst[0] = s_worst[0];
+    plan->lut_worst[1] = s_worst[1];
+  }
 }
 
 // bucket = number of splitters <= key, by 9 branch-free steps over the BFS table in LDS (every level is contiguous: the lanes of a
@@ -176,21 +234,38 @@ __device__ __forceinline__ uint32_t bucket_of(const uint64_t* __restrict__ s_eyt
   return b < nsp ? b : nsp;
 }
 
-template <bool SCATTER>
+// SEARCH 1: start at the LUT's bucket, walk the sorted table while its splitters are <= key (exact for every key)
+__device__ __forceinline__ uint32_t bucket_lut(const uint64_t* __restrict__ s_tab, const uint16_t* __restrict__ s_lut, uint64_t key, uint32_t nsp,
+                                               uint64_t kmin, uint32_t lut_log, uint32_t lshift)
+{
+  const uint64_t rel = key >= kmin ? key - kmin : 0;
+  const uint32_t w   = s_lut[lut_cell(rel, lut_log, lshift)];
+  uint32_t b         = w & 0x7FFFu;
+  if (w & 0x8000u) return b;  // (run 33) a cell without a splitter: 88 % of the cells of a uniform column
+  while (b < nsp && s_tab[b] <= key) ++b;
+  return b;
+}
+
+template <bool SCATTER, int SEARCH>
 __global__ void __launch_bounds__(BT, 4) k_level0(const uint64_t* __restrict__ in, uint64_t* __restrict__ out, int64_t n, Plan* plan)
 {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   uint64_t* s_keys  = reinterpret_cast<uint64_t*>(smem);                                   // [TILE] (SCATTER)
-  uint64_t* s_eyt   = reinterpret_cast<uint64_t*>(smem + (SCATTER ? (size_t)TILE * 8 : 0));  // [NLEAF]
+  uint64_t* s_eyt   = reinterpret_cast<uint64_t*>(smem + (SCATTER ? (size_t)TILE * 8 : 0));  // [NLEAF]: BFS table (SEARCH 0) / sorted table (SEARCH 1)
   uint32_t* s_cnt   = reinterpret_cast<uint32_t*>(s_eyt + NLEAF);                          // [NLEAF] counts, then bin starts
   uint32_t* s_delta = s_cnt + NLEAF;                                                       // [NLEAF]
+  uint16_t* s_lut   = reinterpret_cast<uint16_t*>(s_delta + NLEAF);                        // [NLUT] (SEARCH 1)
   __shared__ uint32_t s_wsum[BT / WAVE + 1];
   const unsigned tid = threadIdx.x;
   const uint32_t nsp = plan->nsp;
+  const uint64_t kmin = plan->kmin;
+  const uint32_t lut_log = plan->lut_log, lshift = plan->lshift;
   for (int i = tid; i < NLEAF; i += BT) {
-    s_eyt[i] = plan->eyt[i];
+    s_eyt[i] = SEARCH == 0 ? plan->eyt[i] : plan->table[i];
     s_cnt[i] = 0;
   }
+  if (SEARCH == 1)
+    for (int i = tid; i < NLUT; i += BT) s_lut[i] = plan->lut[i];
   const int64_t base = (int64_t)blockIdx.x * TILE;
   const int nvalid   = (int)(n - base < (int64_t)TILE ? n - base : (int64_t)TILE);
   uint64_t key[KPT];
@@ -204,7 +279,7 @@ __global__ void __launch_bounds__(BT, 4) k_level0(const uint64_t* __restrict__ i
 #pragma unroll
   for (int j = 0; j < KPT; ++j) {
     const bool live  = j * BT + (int)tid < nvalid;
-    const uint32_t b = bucket_of(s_eyt, key[j], nsp);
+    const uint32_t b = SEARCH == 0 ? bucket_of(s_eyt, key[j], nsp) : bucket_lut(s_eyt, s_lut, key[j], nsp, kmin, lut_log, lshift);
     // (the product's lds_rank aggregates lanes that share a bucket; a plain returning atomic is enough for this measurement
     //  unless the column has heavy hitters -- distribution 2 will show that cost)
     const uint32_t r = live ? atomicAdd(&s_cnt[b], 1u) : 0u;
@@ -243,7 +318,7 @@ __global__ void __launch_bounds__(BT, 4) k_level0(const uint64_t* __restrict__ i
     const int i = j * BT + (int)tid;
     if (i < nvalid) {
       const uint64_t k = s_keys[i];
-      const uint32_t b = bucket_of(s_eyt, k, nsp);
+      const uint32_t b = SEARCH == 0 ? bucket_of(s_eyt, k, nsp) : bucket_lut(s_eyt, s_lut, k, nsp, kmin, lut_log, lshift);
       out[s_delta[b] + (uint32_t)i] = k;
     }
   }
@@ -299,8 +374,9 @@ int main(int argc, char** argv)
   HIP_TRY(hipEventCreate(&e0));
   HIP_TRY(hipEventCreate(&e1));
   HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(k_sort_sample), hipFuncAttributeMaxDynamicSharedMemorySize, NSAMP * 8));
-  const size_t lds_hist = (size_t)NLEAF * 8 + 2 * NLEAF * 4, lds_scat = (size_t)TILE * 8 + lds_hist;
-  HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(k_level0<true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_scat));
+  const size_t lds_hist = (size_t)NLEAF * 8 + 2 * NLEAF * 4 + NLUT * 2, lds_scat = (size_t)TILE * 8 + lds_hist;
+  HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(k_level0<true, 0>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_scat));
+  HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(k_level0<true, 1>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_scat));
   const unsigned tiles = (unsigned)((n + TILE - 1) / TILE);
   static const char* names[3] = {"uniform 64-bit", "bell-shaped around zero (sigma 2^40)", "Zipf-like floor(u^-5) <= 2^31"};
   for (int dist = 0; dist < 3; ++dist) {
@@ -325,15 +401,25 @@ int main(int argc, char** argv)
     }, 3);
     auto hist = [&] {
       HIP_TRY(hipMemsetAsync(plan->hist, 0, sizeof(plan->hist), 0));
-      hipLaunchKernelGGL(k_level0<false>, dim3(tiles), dim3(BT), lds_hist, 0, keys, out, n, plan);
+      hipLaunchKernelGGL((k_level0<false, 0>), dim3(tiles), dim3(BT), lds_hist, 0, keys, out, n, plan);
     };
-    const float t_hist = timed("histogram through the splitter search (8 B/row)", hist, 3);
+    const float t_hist = timed("histogram through the 9-step tree search (8 B/row)", hist, 3);
+    auto hist1 = [&] {
+      HIP_TRY(hipMemsetAsync(plan->hist, 0, sizeof(plan->hist), 0));
+      hipLaunchKernelGGL((k_level0<false, 1>), dim3(tiles), dim3(BT), lds_hist, 0, keys, out, n, plan);
+    };
+    timed("histogram through LUT + scan (8 B/row)", hist1, 3);
     hipLaunchKernelGGL(k_starts, dim3(1), dim3(64), 0, 0, plan);
     auto scat = [&] {
       HIP_TRY(hipMemsetAsync(plan->cursor, 0, sizeof(plan->cursor), 0));
-      hipLaunchKernelGGL(k_level0<true>, dim3(tiles), dim3(BT), lds_scat, 0, keys, out, n, plan);
+      hipLaunchKernelGGL((k_level0<true, 0>), dim3(tiles), dim3(BT), lds_scat, 0, keys, out, n, plan);
     };
-    const float t_scat = timed("level 0: search + scatter into bucket regions (16 B/row)", scat, 3);
+    const float t_scat = timed("level 0, tree search + scatter (16 B/row)", scat, 3);
+    auto scat1 = [&] {
+      HIP_TRY(hipMemsetAsync(plan->cursor, 0, sizeof(plan->cursor), 0));
+      hipLaunchKernelGGL((k_level0<true, 1>), dim3(tiles), dim3(BT), lds_scat, 0, keys, out, n, plan);
+    };
+    timed("level 0, LUT + scan + scatter (16 B/row)", scat1, 3);
     hipLaunchKernelGGL(k_check, dim3(4096), dim3(256), 0, 0, out, n, plan);
     Plan h;
     HIP_TRY(hipMemcpy(&h, plan, sizeof(Plan), hipMemcpyDeviceToHost));
@@ -348,7 +434,10 @@ int main(int argc, char** argv)
                 "keys outside their bucket's range: %llu\n",
                 h.nsp + 1, (double)mx / ((double)n / 256.0), 100.0 * (double)eq / (double)n, total, total == (unsigned long long)n ? "= n" : "!= n",
                 h.violations);
-    std::printf("  => %.2f TB/s (histogram), %.2f TB/s (level 0)\n", 8.0 * n / t_hist * 1e-9, 16.0 * n / t_scat * 1e-9);
+    std::printf("  LUT: %s cells, fullest cell holds %u splitters (linear form %u, logarithmic form %u)\n", h.lut_log ? "logarithmic" : "linear",
+                h.lut_worst[h.lut_log], h.lut_worst[0], h.lut_worst[1]);
+    std::printf("  => tree search: %.2f TB/s (histogram), %.2f TB/s (level 0); the check above is of the LUT form's output\n", 8.0 * n / t_hist * 1e-9,
+                16.0 * n / t_scat * 1e-9);
   }
   return 0;
 }
