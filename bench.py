@@ -80,6 +80,11 @@ def parse():
                     help="sort: distribution of the int64 keys.  normal = round(N(0, 1) * 2^40) (bell-shaped level-0 buckets); zipf = "
                          "floor(u^-5) clipped to 2^31 (the continuous form of Zipf(1.2): 18 %% of the rows carry the value 1); sorted = the "
                          "uniform keys, already in ascending order.  Robustness lines (VERDICT r3 next 3), not the headline")
+    ap.add_argument("--force-sharded", action="store_true",
+                    help="run the MULTI-GPU code path (pre-flight, sharded operators with the exchange forced, their guards) in a "
+                         "1-rank group on one GPU: what `--gpus N` executes, testable where only one device is visible")
+    ap.add_argument("--preflight-only", action="store_true", help="multi-GPU: run the oracle-checked pre-flight of the sharded operators, print its verdict as one JSON line, exit")
+    ap.add_argument("--preflight-timeout", type=float, default=90.0, help="multi-GPU: seconds the watchdog gives one pre-flight operator call")
     ap.add_argument("--through-cpp", action="store_true",
                     help="also time cudf::sort / hash_join::inner_join / groupby::aggregate through the C++ surface "
                          "(tests/cpp/cudf_api_bench, default pooled mr) and report the ratio to the C-ABI numbers")
@@ -228,8 +233,19 @@ class Ctx:
         self.world = int(os.environ.get("WORLD_SIZE", "1"))
         self.local = int(os.environ.get("LOCAL_RANK", "0"))
         torch.cuda.set_device(self.local)
-        if self.world > 1:
-            dist.init_process_group("nccl", device_id=torch.device("cuda", self.local))
+        self.sharded = self.world > 1 or args.force_sharded   # the multi-GPU code path (a 1-rank group under --force-sharded)
+        if self.sharded:
+            os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+            if "MASTER_PORT" not in os.environ:
+                with socket.socket() as so:
+                    so.bind(("127.0.0.1", 0))
+                    os.environ["MASTER_PORT"] = str(so.getsockname()[1])
+            dist.init_process_group("nccl", rank=self.rank, world_size=self.world, device_id=torch.device("cuda", self.local))
+            if args.force_sharded:
+                from cudf_amd import distributed as D
+                D._FORCE_EXCHANGE = True
+        self.preflight = None   # verdict of the pre-flight (multi-GPU): which sharded operators passed the oracle over this transport
+        self.beat = time.monotonic()
         from cudf_amd import Column, ops, _lib as L
         from cudf_amd.column import device_bytes, ptr, stream_ptr
         self.np, self.torch, self.dist = np, torch, dist
@@ -243,6 +259,7 @@ class Ctx:
         if self.world > 1:
             self.dist.barrier()
         self.torch.cuda.synchronize()
+        self.beat = time.monotonic()
 
     def timed(self, step, per_step=None, after_warmup=None):
         """W warm-ups, then exactly K steps between barriers; max over ranks.  Returns seconds per step."""
@@ -257,6 +274,7 @@ class Ctx:
             step()
             if per_step:
                 per_step()
+            self.beat = time.monotonic()
         self.barrier()
         dt = time.perf_counter() - t0
         if self.world > 1:
@@ -269,9 +287,200 @@ class Ctx:
         return col.data[: col.size * col.dtype.itemsize].view(dt)
 
 
-def sharded_step(c, cpp_step, py_step):
-    """the step a multi-GPU line times: the C++ operators over RCCL; the torch.distributed implementation only if their first
-    call raises (decided collectively: every rank takes the same one)"""
+def start_heartbeat_monitor(c, limit_s=600.0):
+    """Multi-GPU runs only: a daemon thread that ends the process when the main thread has made no progress for `limit_s` seconds
+    (a collective whose peer never arrived blocks for ever inside RCCL -- there is no timeout on that side).  The driver then sees
+    a failed run with the reason on stderr instead of a hang; torchrun takes the other ranks down with it."""
+    import threading
+
+    def watch():
+        while True:
+            time.sleep(5.0)
+            stale = time.monotonic() - c.beat
+            if stale > limit_s:
+                print(f"bench.py: rank {c.rank}: no progress for {stale:.0f} s (a collective that never completed?): giving up", file=sys.stderr, flush=True)
+                os._exit(5)
+    threading.Thread(target=watch, name="bench-heartbeat", daemon=True).start()
+
+
+def guarded(c, what, fn, timeout_s):
+    """fn() on a worker thread under a watchdog: (result, None) or (None, reason).  On a timeout the RCCL communicators of the C++
+    operators are ABORTED (gxd_comm_abort -> ncclCommAbort: the blocked call returns an error); a call that does not come back
+    even then ends the process -- a pre-flight can fail, it cannot hang."""
+    import threading
+    box = {}
+
+    def run():
+        try:
+            c.torch.cuda.set_device(c.local)
+            box["v"] = fn()
+            c.torch.cuda.synchronize()
+        except BaseException as e:  # noqa: BLE001 -- reported as the verdict
+            box["e"] = e
+    t = threading.Thread(target=run, name=f"preflight-{what}", daemon=True)
+    t.start()
+    t.join(timeout_s)
+    c.beat = time.monotonic()
+    if t.is_alive():
+        from cudf_amd import distributed as D
+        print(f"bench.py: rank {c.rank}: pre-flight {what}: no answer after {timeout_s:.0f} s -- aborting the communicator", file=sys.stderr, flush=True)
+        D.abort_communicators()
+        t.join(30.0)
+        if t.is_alive():
+            print(f"bench.py: rank {c.rank}: pre-flight {what}: still blocked after the abort: giving up", file=sys.stderr, flush=True)
+            os._exit(4)
+        return None, f"timeout after {timeout_s:.0f} s (communicator aborted)"
+    if "e" in box:
+        return None, repr(box["e"])
+    return box.get("v"), None
+
+
+def preflight(c):
+    """BEFORE any timed step of a multi-GPU line: every rank runs the SHIPPED sharded operators -- gxd_sort
+    on both of its paths, gxd_join_build + gxd_join_probe, gxd_groupby_sum_count: C++ over the RCCL transport -- on small seeded
+    shards of UNEVEN sizes (one of them empty from 3 ranks on), under a watchdog; the results travel to rank 0, which regenerates
+    every rank's input from its seed and compares with the CPU oracle on the concatenation (sort: bit-exact; join: the canonical
+    pair set in global rows; groupby: keys, counts, sums to 1e-12).  The verdict is broadcast: an operator that failed, or did not
+    answer, is timed through the torch.distributed implementation instead and the line says so.  The oracle is the checker here,
+    exactly as in tests/test_gpu_distributed_loopback.py; nothing it computes is timed."""
+    import numpy as np
+    torch, dist = c.torch, c.dist
+    from cudf_amd import distributed as D
+    from cudf_amd import gxd
+    W, rk = c.world, c.rank
+    t_start = time.perf_counter()
+    tmo = c.args.preflight_timeout
+
+    def shard_rows(total_per_rank, r):
+        if W >= 3 and r == 1:
+            return 0                                   # an EMPTY shard
+        return int(total_per_rank * (1 + (r % 3)) / 2)  # uneven: 0.5x / 1x / 1.5x
+
+    def gen(r):
+        rng = np.random.default_rng(9000 + r)
+        d = {}
+        d["sort_fused"] = rng.integers(-2**63, 2**63 - 1, shard_rows(4_000_000, r) if W > 1 else 2_600_000, dtype=np.int64)
+        f = rng.standard_normal(shard_rows(400_000, r)) * 1e6
+        f[::1013] = np.nan
+        f[5::997] = -0.0
+        d["sort_sample"] = f
+        d["build"] = (rng.permutation(1_500_000)[: shard_rows(200_000, r)].astype(np.int64) * W + r) * 7919   # globally distinct
+        d["probe"] = rng.integers(0, 1_500_000 * W, shard_rows(900_000, r)).astype(np.int64) * 7919
+        d["gk"] = rng.integers(0, 20_000, shard_rows(700_000, r)).astype(np.int32)
+        d["gv"] = rng.random(len(d["gk"]))
+        return d
+    mine = gen(rk)
+    dev = {k: torch.from_numpy(np.ascontiguousarray(v)).cuda() for k, v in mine.items()}
+    comm = D._gxd_comm(None)
+    res, why = {}, {}
+
+    def op_sort_fused():
+        gxd.set_sort_mode(2)        # the exchange between the sort's two partition levels from 2^21 rows per rank
+        try:
+            out = comm.sort(dev["sort_fused"], force_exchange=True)
+            return out.cpu().numpy(), comm.last_timing()[0] == -1.0
+        finally:
+            gxd.set_sort_mode(0)
+
+    def op_sort_sample():
+        return comm.sort(dev["sort_sample"], chunks=2, force_exchange=True).cpu().numpy()
+
+    def op_join():
+        hj = gxd.HashJoin(comm, dev["build"], force_exchange=True)
+        try:
+            l, r = hj.inner_join(dev["probe"], chunks=2)
+            return l.cpu().numpy(), r.cpu().numpy()
+        finally:
+            hj.close()
+
+    def op_groupby():
+        k, sm, cnt = comm.groupby_sum_count(dev["gk"], dev["gv"], force_exchange=True)
+        return k.cpu().numpy(), sm.cpu().numpy(), cnt.cpu().numpy()
+
+    alive = True
+    for name, fn in (("sort_fused", op_sort_fused), ("sort_sample", op_sort_sample), ("join", op_join), ("groupby", op_groupby)):
+        if not alive:
+            res[name], why[name] = None, "skipped: the communicator was aborted"
+            continue
+        res[name], why[name] = guarded(c, name, fn, tmo)
+        if why[name] and "abort" in why[name]:
+            alive = False
+    # ---- results to rank 0, oracle there
+    gathered = [None] * W if rk == 0 else None
+    dist.gather_object({"res": res, "why": why}, gathered, dst=0)
+    verdict = {}
+    if rk == 0:
+        from oracle import c_oracle
+        from oracle import cudf_oracle as orc
+        ins = [mine if r == 0 else gen(r) for r in range(W)]
+
+        def bases(key):
+            b, run = [], 0
+            for r in range(W):
+                b.append(run)
+                run += len(ins[r][key])
+            return b
+        for name in ("sort_fused", "sort_sample", "join", "groupby"):
+            bad = [f"rank {r}: {g['why'][name]}" for r, g in enumerate(gathered) if g["why"][name]]
+            if bad:
+                verdict[name] = "FAILED to run: " + "; ".join(bad)
+                continue
+            try:
+                if name == "sort_fused":
+                    got = np.concatenate([g["res"][name][0] for g in gathered])
+                    exp = c_oracle.sort_i64(np.concatenate([i["sort_fused"] for i in ins]))
+                    fused = [bool(g["res"][name][1]) for g in gathered]
+                    ok = got.tobytes() == exp.tobytes() and (all(fused) or not any(fused))
+                    verdict[name] = ("ok (fused path)" if all(fused) else "ok (collective fallback to the sample-sort path)") if ok else "MISMATCH vs oracle"
+                elif name == "sort_sample":
+                    got = np.concatenate([g["res"][name] for g in gathered])
+                    allin = np.concatenate([i["sort_sample"] for i in ins])
+                    exp = orc.sort_keys(allin)
+                    ok = np.array_equal(got, exp, equal_nan=True) and np.signbit(got[got == 0]).sum() == np.signbit(allin[allin == 0]).sum()
+                    verdict[name] = "ok" if ok else "MISMATCH vs oracle"
+                elif name == "join":
+                    l = np.concatenate([g["res"][name][0] for g in gathered])
+                    r_ = np.concatenate([g["res"][name][1] for g in gathered])
+                    el, er = c_oracle.inner_join_i64(np.concatenate([i["probe"] for i in ins]), np.concatenate([i["build"] for i in ins]))
+                    a = orc.canonical_pairs(l.astype(np.int64), r_.astype(np.int64))
+                    b = orc.canonical_pairs(el.astype(np.int64), er.astype(np.int64))
+                    ok = len(l) == len(el) and np.array_equal(a[0], b[0]) and np.array_equal(a[1], b[1])
+                    verdict[name] = f"ok ({len(l)} pairs in global rows)" if ok else f"MISMATCH vs oracle ({len(l)} pairs, oracle {len(el)})"
+                else:
+                    k = np.concatenate([g["res"][name][0] for g in gathered])
+                    sm = np.concatenate([g["res"][name][1] for g in gathered])
+                    cn = np.concatenate([g["res"][name][2] for g in gathered])
+                    o = np.argsort(k, kind="stable")
+                    gk = np.concatenate([i["gk"] for i in ins])
+                    gv = np.concatenate([i["gv"] for i in ins])
+                    uk = np.unique(gk)
+                    es, ec = np.bincount(gk, weights=gv)[uk], np.bincount(gk)[uk]
+                    ok = (np.array_equal(k[o], uk) and np.array_equal(cn[o], ec) and np.allclose(sm[o], es, rtol=1e-12, atol=0.0)
+                          and len(np.unique(k)) == len(k))
+                    verdict[name] = f"ok ({len(k)} groups, every group on one rank)" if ok else "MISMATCH vs oracle"
+            except Exception as e:  # noqa: BLE001 -- a checker failure is a failed check
+                verdict[name] = f"CHECK RAISED {e!r}"
+    box = [verdict]
+    dist.broadcast_object_list(box, src=0)
+    verdict = box[0]
+    verdict["transport"] = "RCCL (ncclAllGather + grouped ncclSend / ncclRecv)" if W > 1 else "one-rank loopback fabric (exchange forced)"
+    verdict["ranks"] = W
+    verdict["shards"] = "uneven (0.5x / 1x / 1.5x)" + (", rank 1 empty" if W >= 3 else "")
+    verdict["seconds"] = round(time.perf_counter() - t_start, 2)
+    verdict["communicator_alive"] = alive
+    c.beat = time.monotonic()
+    return verdict
+
+
+def sharded_step(c, op, cpp_step, py_step):
+    """the step a multi-GPU line times: the C++ operators over RCCL when the pre-flight verified them against the oracle on THIS
+    transport; otherwise -- or if their first full-size call raises (decided collectively: every rank takes the same one) -- the
+    torch.distributed implementation, and the line says which and why"""
+    pf = c.preflight or {}
+    names = {"sort": ("sort_fused", "sort_sample"), "join": ("join",), "groupby": ("groupby",)}[op]
+    failed = [f"{k}: {pf.get(k)}" for k in names if c.preflight is not None and not str(pf.get(k, "")).startswith("ok")]
+    if failed or (c.preflight is not None and not pf.get("communicator_alive", True)):
+        return py_step, "torch.distributed fallback (pre-flight of the C++ operator: " + ("; ".join(failed) or "communicator aborted") + ")"
     ok = 1
     try:
         cpp_step()
@@ -281,9 +490,29 @@ def sharded_step(c, cpp_step, py_step):
         ok = 0
     t = c.torch.tensor([ok], device="cuda")
     c.dist.all_reduce(t, op=c.dist.ReduceOp.MIN)
+    c.beat = time.monotonic()
     if int(t.item()) == 1:
-        return cpp_step, "C++ operators over RCCL"
+        return cpp_step, "C++ operators over RCCL" + (", pre-flight checked against the oracle" if c.preflight is not None else "")
     return py_step, "torch.distributed fallback (the C++ operator's first call failed)"
+
+
+def fetch_by_global_row(c, local_vals, grows, shard_rows):
+    """values[g] for global rows g = owner * shard_rows + local row, the values living on their owners: one all-to-all of the
+    requests, one of the answers (verification only; equal shard sizes)"""
+    from cudf_amd import distributed as D
+    torch = c.torch
+    W = c.world
+    owner = torch.div(grows, shard_rows, rounding_mode="floor")
+    order = torch.argsort(owner)
+    send = torch.bincount(owner, minlength=W).cpu().tolist()
+    recv = D.exchange_counts(send, grows.device) if W > 1 else list(send)
+    req_sorted = (grows - owner * shard_rows)[order]
+    req = D.all_to_all_rows(req_sorted, send, recv) if W > 1 else req_sorted
+    ans = local_vals[req]
+    back = D.all_to_all_rows(ans, recv, send) if W > 1 else ans
+    out = torch.empty_like(back)
+    out[order] = back
+    return out
 
 
 def lsr_mix64(j):
@@ -403,21 +632,34 @@ def bench_sort(c, pairs=False, cpu_leg=True):
                 prof["hyb"][i] += h4[i]
             prof["hyb_n"] += 1
 
-    if c.world > 1:
+    if c.sharded:
         from cudf_amd import distributed as D
         dkeys = c.as_tensor(keys, c.torch.int64)
-        # CUDA tensors and no `local` object: the C++ operators over RCCL (cudf_amd/cpp/src/distributed.cpp, gxd_sort).  Should their
-        # first call fail on a box they have never seen (no multi-GPU hardware was available to any round), the torch.distributed
-        # implementation of round 2 takes over and the line says so.
-        step, sharded_impl = sharded_step(c, lambda: D.distributed_sort(dkeys), lambda: D.distributed_sort(dkeys, local=D.HipLocalOps()))
+        # CUDA tensors and no `local` object: the C++ operators over RCCL (cudf_amd/cpp/src/distributed.cpp, gxd_sort), which the
+        # pre-flight has just checked against the oracle on this very transport; where it failed, or should the first full-size
+        # call raise, the torch.distributed implementation of round 2 takes over and the line says so.
+        step, sharded_impl = sharded_step(c, "sort", lambda: D.distributed_sort(dkeys), lambda: D.distributed_sort(dkeys, local=D.HipLocalOps()))
         workload = (f"{n:.0e}-row-per-GPU int64 distributed sort (level 0 on every rank, level-0 bins dealt to ranks, one span per peer over "
                     f"xGMI, level 1 + cell sort on the receiver) [{sharded_impl}]")
         sec = c.timed(step)
         res = step()
+        torch = c.torch
         assert bool((res[1:] >= res[:-1]).all()), "distributed sort: shard not sorted"
         tot = c.torch.tensor([res.numel()], device="cuda", dtype=c.torch.int64)
         c.dist.all_reduce(tot)
         assert int(tot.item()) == n * c.world, "distributed sort lost rows"
+        # shard r's largest key <= shard r + 1's smallest (empty shards carry neutral bounds)
+        big = torch.iinfo(torch.int64)
+        mm = torch.tensor([int(res[0].item()) if res.numel() else big.max, int(res[-1].item()) if res.numel() else big.min], device="cuda", dtype=torch.int64)
+        allmm = [torch.zeros_like(mm) for _ in range(c.world)]
+        c.dist.all_gather(allmm, mm)
+        hi = big.min
+        for t in allmm:
+            lo_r, hi_r = int(t[0].item()), int(t[1].item())
+            if lo_r <= hi_r:
+                assert lo_r >= hi, "distributed sort: shards overlap"
+                hi = hi_r
+        checked = "every rank's shard sorted; shard boundaries ordered over the ranks; row count over all ranks; see `preflight` for the oracle check of the same operators"
         del res
         # roofline of the dominant LOCAL kernel: one profiled single-GPU sort of this rank's shard, untimed
         lib.gx_sort_profile(1)
@@ -427,9 +669,36 @@ def bench_sort(c, pairs=False, cpu_leg=True):
     else:
         sec = c.timed(single_step, read_profile, after_warmup=lambda: lib.gx_sort_profile(1))
         nsteps_prof = a.steps
-        cin, cout = ops.checksum(keys), ops.checksum(out)
+        cin = ops.checksum(keys)
         if not pairs:
+            cout = ops.checksum(out)
             assert cout[2] == 0 and cin[:2] == cout[:2], "sort output invalid"
+            checked = "order + multiset checksum of the timed output (gx_checksum)"
+        else:
+            # cudf::sorted_order's timed output, checked at full size: (1) the int32 order is a PERMUTATION of
+            # [0, n) -- every row marked exactly once; (2) the keys gathered through it are in order and are the input's multiset
+            # (gx_checksum: sum, xor, sortedness violations); (3) ties keep the row order (stable: sorted_order_radix.cu:56-179)
+            torch = c.torch
+            ot = c.as_tensor(out, torch.int32)
+            assert int(ot.min().item()) >= 0 and int(ot.max().item()) < n, "sorted_order: row index out of range"
+            seen = torch.zeros(n, dtype=torch.int32, device="cuda")
+            CH = 1 << 27
+            for i in range(0, n, CH):
+                seen.index_add_(0, ot[i:i + CH].to(torch.int64), torch.ones(min(CH, n - i), dtype=torch.int32, device="cuda"))
+            assert int(seen.min().item()) == 1 and int(seen.max().item()) == 1, "sorted_order: the output is not a permutation of the rows"
+            del seen
+            gathered = ops.gather(keys, out)
+            cg = ops.checksum(gathered)
+            assert cg[2] == 0 and cin[:2] == cg[:2], "sorted_order: keys gathered through the order are not the sorted input"
+            gt = c.as_tensor(gathered, torch.int64)
+            for i in range(0, n - 1, CH):
+                m = min(CH, n - 1 - i)
+                eq = gt[i + 1:i + 1 + m] == gt[i:i + m]
+                assert bool((ot[i + 1:i + 1 + m][eq] > ot[i:i + m][eq]).all()), "sorted_order: equal keys are not in row order"
+            del gathered, gt, ot
+            torch.cuda.empty_cache()
+            checked = ("timed int32 order at full size: a permutation of [0, n); keys gathered through it: order + multiset checksum "
+                       "(gx_checksum) equal to the input's; equal keys in ascending row order")
         st = ctypes.c_int(0)
         lib.gx_sort_status(c.ptr(tmp), ctypes.byref(st), c.stream)
         assert st.value == 0, "look-back timed out"
@@ -446,7 +715,7 @@ def bench_sort(c, pairs=False, cpu_leg=True):
     sort_info["big_cells"] = {"sorted_through_x": int(bigi[0]), "cells": int(bigi[1]), "keys": int(bigi[2])}
     cursor = cst.value == 3
     hist_ms = prof["hist_ms"] / nsteps_prof
-    local_sort_ms = ms_per_step if c.world == 1 else hist_ms + (sum(prof["hyb"]) if prof["hyb_n"] else prof["pass_ms"])
+    local_sort_ms = ms_per_step if not c.sharded else hist_ms + (sum(prof["hyb"]) if prof["hyb_n"] else prof["pass_ms"])
     roofline = None
     if sort_info["hybrid_used"] and prof["hyb_n"]:
         # hybrid MSD path: per-kernel algorithmic bytes: partition passes and the local sort read 8 +
@@ -492,10 +761,10 @@ def bench_sort(c, pairs=False, cpu_leg=True):
                     "sort_info": sort_info}
     pmc_traffic(roofline, n)
     cpu = None
-    if a.cpu and cpu_leg and c.world == 1 and c.rank == 0:
+    if a.cpu and cpu_leg and not c.sharded and c.rank == 0:
         cpu = cpu_baseline_sort(a.cpu_rows or 5e8, a.cpu_rows_pandas or 1e8)
     return {"workload": workload, "rows": n, "ms_per_step": ms_per_step, "rows_per_s": n * c.world / sec, "dtype": "int64",
-            "roofline": roofline, "cpu_baseline": cpu, "checked": "order + multiset checksum of the timed output (gx_checksum)"}
+            "roofline": roofline, "cpu_baseline": cpu, "checked": checked}
 
 
 # ------------------------------------------------------------------------------------------------
@@ -509,34 +778,88 @@ def bench_join(c):
     lib.gx_join_set_probe_kernel(a.join_probe_kernel)
     lib.gx_join_set_scatter_tile(a.join_scatter_tile)
     lib.gx_join_set_build_kernel(a.join_build_kernel)
-    if c.world > 1:
+    if c.sharded:
         from cudf_amd import distributed as D
-        torch.manual_seed(12345 + c.rank)
-        dbk = (torch.randperm(nb_rows, device="cuda") + c.rank * nb_rows) * 3 + 1           # globally distinct build keys
-        dpk = c.as_tensor(ops.random_column(np.int64, n, seed=67890 + c.rank, lo=0, hi=int(nb_rows * c.world / 0.3)), torch.int64) * 3 + 1
+        W, rk = c.world, c.rank
+        if a.rows == 1e9 and W > 1:
+            n = 1_250_000_000        # BASELINE config 5: 1e10 probe rows over 8 GPUs = 1.25e9 per GPU (weak scaling: the same at every N > 1)
+            nb_rows = n // 10
+        # SURVEY 8d's key distribution, as on one GPU (no arithmetic progressions): build = random DISTINCT 64-bit
+        # keys, mix64(j + (rank << 40)) with j a random permutation of [0, nb_rows) -- a bijection, so distinct over all ranks;
+        # probe = 30 % hits drawn uniformly from the build keys of ALL ranks, 70 % from the disjoint set j >= nb_rows
+        torch.manual_seed(12345 + rk)
+        dbk = lsr_mix64(torch.randperm(nb_rows, device="cuda") + (rk << 40))
+        dpk = torch.empty(n, dtype=torch.int64, device="cuda")
+        hit_mask = torch.empty(n, dtype=torch.bool, device="cuda")
+        CH = 1 << 27
+        for s0 in range(0, n, CH):   # in pieces: a few 1-GB temporaries instead of 10-GB ones
+            m = min(CH, n - s0)
+            selt = c.as_tensor(ops.random_column(np.int64, m, seed=67890 + 131 * rk + (s0 >> 27), lo=0, hi=10), torch.int64)
+            jj = c.as_tensor(ops.random_column(np.int64, m, seed=424242 + 131 * rk + (s0 >> 27), lo=0, hi=nb_rows), torch.int64)
+            src = c.as_tensor(ops.random_column(np.int64, m, seed=515151 + 131 * rk + (s0 >> 27), lo=0, hi=W), torch.int64)
+            hit_mask[s0:s0 + m] = selt < 3
+            dpk[s0:s0 + m] = lsr_mix64(jj + (selt >= 3).to(torch.int64) * nb_rows + (src << 40))
+            del selt, jj, src
         # like the single-GPU line (and cudf::hash_join): the build side is exchanged and hashed ONCE, untimed;
         # a step = hash-partition the probe shard, all-to-all, probe the local table
+        use_cpp = c.preflight is None or (str(c.preflight.get("join", "")).startswith("ok") and c.preflight.get("communicator_alive", True))
         tb = time.perf_counter()
-        try:
-            hj = D.DistributedHashJoin(dbk)         # the C++ operators over RCCL (gxd_join_build / gxd_join_probe)
-        except Exception as e:  # noqa: BLE001 -- see sharded_step
-            print(f"bench.py: C++ sharded join failed ({e!r}); torch.distributed implementation instead", file=sys.stderr)
+        impl = "C++ operators over RCCL" + (", pre-flight checked against the oracle" if c.preflight is not None else "")
+        hj, ok = None, 1
+        if use_cpp:
+            try:
+                hj = D.DistributedHashJoin(dbk)         # gxd_join_build / gxd_join_probe
+                hj.inner_join(dpk[: 1 << 20])
+                torch.cuda.synchronize()
+            except Exception as e:  # noqa: BLE001 -- decided collectively below
+                print(f"bench.py: C++ sharded join failed on rank {rk} ({e!r})", file=sys.stderr)
+                ok = 0
+            t = torch.tensor([ok], device="cuda")
+            c.dist.all_reduce(t, op=c.dist.ReduceOp.MIN)
+            ok = int(t.item())
+        if not use_cpp or not ok:
+            impl = "torch.distributed fallback (" + ("pre-flight of the C++ operator: " + str((c.preflight or {}).get("join")) if not use_cpp
+                                                    else "the C++ operator's first call failed") + ")"
             hj = D.DistributedHashJoin(dbk, local=D.HipLocalOps())
         torch.cuda.synchronize()
+        c.beat = time.monotonic()
         build_ms = (time.perf_counter() - tb) * 1e3
         step = lambda: hj.inner_join(dpk)
         sec = c.timed(step)
         l, r = step()
+        # ---- guards on the (re-run) timed step: pair count = closed form; the probe rows that appear are exactly the hit rows of
+        # all ranks (sum and sum of squares of the global rows, wrapping); EVERY pair joins equal keys -- the probe key at the
+        # pair's global probe row and the build key at its global build row are fetched from their owners and compared
         tot = torch.tensor([l.numel()], device="cuda", dtype=torch.int64)
         c.dist.all_reduce(tot)
-        want = (dpk < 3 * nb_rows * c.world + 1).sum().to(torch.int64)
+        want = hit_mask.sum().to(torch.int64).reshape(1)
         c.dist.all_reduce(want)
-        assert int(tot.item()) == int(want.item()), "distributed join: wrong number of pairs"
-        return {"workload": f"{n:.0e}-row-per-GPU probe x {nb_rows:.0e}-row-per-GPU build distributed inner join "
-                            "(build side exchanged and hashed once; step = hash partition of the probe shard, all-to-all, local probe)",
+        assert int(tot.item()) == int(want.item()), f"distributed join: {int(tot.item())} pairs, closed form {int(want.item())}"
+        rows = torch.nonzero(hit_mask).flatten() + rk * n
+        sums = torch.stack([l.sum(), (l * l).sum(), rows.sum(), (rows * rows).sum()])
+        c.dist.all_reduce(sums)
+        assert int(sums[0].item()) == int(sums[2].item()) and int(sums[1].item()) == int(sums[3].item()), "distributed join: wrong set of probe rows"
+        del rows
+        checked = "pair count == closed form over all ranks; the global probe rows are exactly the hit rows (sum, sum of squares)"
+        try:
+            pkeys = fetch_by_global_row(c, dpk, l, n)
+            bkeys = fetch_by_global_row(c, dbk, r, nb_rows)
+            eq = torch.tensor([int((pkeys == bkeys).all().item())], device="cuda")
+            c.dist.all_reduce(eq, op=c.dist.ReduceOp.MIN)
+            assert int(eq.item()) == 1, "distributed join: a pair joins unequal keys"
+            checked += "; every pair joins equal keys (keys fetched from the owners of its global rows)"
+            del pkeys, bkeys
+        except AssertionError:
+            raise
+        except Exception as e:  # noqa: BLE001 -- the verification exchange itself failed: say so, keep the checks that ran
+            checked += f"; key equality per pair NOT checked ({e!r})"
+        c.beat = time.monotonic()
+        return {"workload": f"{n:.3g}-row-per-GPU probe x {nb_rows:.3g}-row-per-GPU build distributed inner join, random distinct 64-bit build keys, "
+                            f"probe 30 % hits over all ranks' keys (build side exchanged and hashed once; step = hash partition of the probe shard, "
+                            f"all-to-all, local probe) [{impl}]",
                 "rows": n, "ms_per_step": sec * 1e3, "rows_per_s": n * c.world / sec, "dtype": "int64", "roofline": None,
-                "cpu_baseline": None, "build_ms": build_ms, "partition_bits": None, "matches": int(tot.item()),
-                "checked": "pair count == closed form over all ranks"}
+                "cpu_baseline": None, "build_ms": build_ms, "partition_bits": None, "matches": int(tot.item()), "join_keys": "random",
+                "checked": checked}
     lib.gx_join_set_partition_mode(a.join_spec, a.join_early_loads)
     bk = c.Column.empty(np.int64, nb_rows)
     bkt = c.as_tensor(bk, torch.int64)
@@ -690,7 +1013,7 @@ def bench_groupby(c):
     gk = ops.random_column(np.int32, n, seed=7 + c.rank, lo=0, hi=1_000_000)
     gv = ops.random_column(np.float64, n, seed=8 + c.rank)
     kdt, ktorch = np.int32, torch.int32
-    if a.gb_keys != "dense" and c.world == 1:
+    if a.gb_keys != "dense" and not c.sharded:
         # sparse keys: the dense ids through a mixing BIJECTION (still exactly 1e6 groups, same group sizes), so the LDS tables
         # see keys that hash like random numbers instead of the collision-free dense integers
         ids = c.as_tensor(gk, torch.int32).to(torch.int64)
@@ -705,19 +1028,25 @@ def bench_groupby(c):
             gk = c.Column.empty(np.int64, n)
             c.as_tensor(gk, torch.int64).copy_(lsr_mix64(ids))
         del ids
-    if c.world > 1:
+    if c.sharded:
         from cudf_amd import distributed as D
         dgk, dgv = c.as_tensor(gk, torch.int32), c.as_tensor(gv, torch.float64)
-        step, _ = sharded_step(c, lambda: D.distributed_groupby_sum_count(dgk, dgv),   # gxd_groupby_sum_count
-                               lambda: D.distributed_groupby_sum_count(dgk, dgv, local=D.HipLocalOps()))
+        step, impl = sharded_step(c, "groupby", lambda: D.distributed_groupby_sum_count(dgk, dgv),   # gxd_groupby_sum_count
+                                  lambda: D.distributed_groupby_sum_count(dgk, dgv, local=D.HipLocalOps()))
         sec = c.timed(step)
         k, s, cnt = step()
-        tot = cnt.sum().to(torch.int64)
+        tot = cnt.sum().to(torch.int64).reshape(1)
         c.dist.all_reduce(tot)
         assert int(tot.item()) == n * c.world, "distributed groupby: counts do not add up"
-        return {"workload": f"{n:.0e}-row-per-GPU groupby(int32 key, 1e6 groups).agg(f64 sum,count), partials exchanged",
+        ng = torch.tensor([k.numel()], device="cuda", dtype=torch.int64)
+        c.dist.all_reduce(ng)
+        assert int(ng.item()) == 1_000_000 or n < 20_000_000, f"distributed groupby: {int(ng.item())} groups over all ranks"
+        tv = torch.stack([s.sum(), dgv.sum()])
+        c.dist.all_reduce(tv)
+        assert abs(float(tv[0].item()) - float(tv[1].item())) <= 1e-9 * abs(float(tv[1].item())), "distributed groupby: sums do not add up"
+        return {"workload": f"{n:.0e}-row-per-GPU groupby(int32 key, 1e6 groups).agg(f64 sum,count), partials exchanged [{impl}]",
                 "rows": n, "ms_per_step": sec * 1e3, "rows_per_s": n * c.world / sec, "dtype": "f64", "roofline": None,
-                "cpu_baseline": None, "checked": "sum of counts == rows over all ranks"}
+                "cpu_baseline": None, "checked": "sum of counts == rows, 1e6 groups and the total of the sums over all ranks (every group on one rank)"}
     mg = 1 << 20
     ok, osum = c.Column.empty(kdt, mg), c.Column.empty(np.float64, mg)
     ocv = c.Column.empty(np.int32, mg)
@@ -961,10 +1290,25 @@ def main():
         print(f"bench.py: note: --gpus {args.gpus} but the process group has {c.world} rank(s); n_gpus reports the group", file=sys.stderr)
     wl = args.workload
     blocks = {}
+    if c.sharded:
+        if c.world > 1:
+            start_heartbeat_monitor(c)
+        if wl in ("all", "sort", "join", "groupby") or args.preflight_only:
+            c.preflight = preflight(c)
+            if c.rank == 0:
+                print("bench.py: pre-flight of the sharded operators: " + json.dumps(c.preflight), file=sys.stderr, flush=True)
+        if args.preflight_only:
+            if c.rank == 0:
+                print(json.dumps({"preflight": c.preflight, "n_gpus": c.world}), flush=True)
+            from cudf_amd import distributed as D
+            D.close_communicators()
+            c.dist.destroy_process_group()
+            bad = [k for k in ("sort_fused", "sort_sample", "join", "groupby") if not str(c.preflight.get(k, "")).startswith("ok")]
+            sys.exit(1 if bad else 0)
     if wl in ("all", "sort", "sorted_order"):
         head = bench_sort(c, pairs=(wl == "sorted_order"))
         if wl == "all":
-            if c.world == 1:  # cudf::sorted_order, what the reference's sort benchmark times (cpp/benchmarks/sort/sort.cpp:16-58): its own block
+            if not c.sharded:  # cudf::sorted_order, what the reference's sort benchmark times (cpp/benchmarks/sort/sort.cpp:16-58): its own block
                 c.torch.cuda.empty_cache()
                 blocks["sorted_order"] = bench_sort(c, pairs=True, cpu_leg=False)
             c.torch.cuda.empty_cache()
@@ -988,9 +1332,11 @@ def main():
             "vs_baseline": None, "dtype": head["dtype"], "data": "synthetic",
             "config": {"workload": head["workload"], "rows_per_gpu": c.n, "algo": args.algo, "gb_algo": args.gb_algo, "gb_spec": args.gb_spec, "gb_pbits": args.gb_pbits, "gb_keys": args.gb_keys,
                        "parallelism": (f"{c.world} ranks, row shards, one all-to-all exchange per step (RCCL over xGMI)"
-                                       if c.world > 1 else "1 GPU")},
+                                       if c.world > 1 else ("1 GPU, the sharded operators with the exchange forced (--force-sharded)" if c.sharded else "1 GPU"))},
             "roofline": head["roofline"], "cpu_baseline": head["cpu_baseline"], "checked": head.get("checked"),
         }
+        if c.preflight is not None:
+            line["preflight"] = c.preflight   # the sharded operators against the oracle on this run's transport, before anything was timed
         for k in ("build_ms", "build_call_ms", "build_plus_probe_ms", "build_rows_per_s", "partition_bits", "matches", "join_keys", "partition_mode"):
             if k in head:
                 line["join_" + k if not k.startswith("join") else k] = head[k]
@@ -1001,7 +1347,7 @@ def main():
                           **({"build_ms": b["build_ms"], "build_call_ms": b.get("build_call_ms"), "build_plus_probe_ms": b.get("build_plus_probe_ms"),
                               "build_rows_per_s": b.get("build_rows_per_s"), "partition_bits": b["partition_bits"], "join_keys": b.get("join_keys"),
                               "partition_mode": b.get("partition_mode")} if "build_ms" in b else {})}
-        if args.through_cpp and c.world == 1:
+        if args.through_cpp and not c.sharded:
             line["through_cpp"] = through_cpp(args, c, head["ms_per_step"] if wl in ("all", "sort") else None,
                                               (blocks.get("join") or (head if wl == "join" else {})).get("ms_per_step"),
                                               (blocks.get("groupby") or (head if wl == "groupby" else {})).get("ms_per_step"))
@@ -1015,7 +1361,7 @@ def main():
             if r.get("traffic") and r.get("avg_launch_ms"):
                 r["traffic_GBps"] = r["traffic"] / (r["avg_launch_ms"] * 1e-3) / 1e9
         print(json.dumps(line), flush=True)
-    if c.world > 1:
+    if c.sharded:
         from cudf_amd import distributed as D
         D.close_communicators()  # the RCCL communicators of the C++ operators, before the process group they were made with
         c.dist.destroy_process_group()

@@ -18,6 +18,7 @@
 #include <rccl/rccl.h>
 
 #include <algorithm>
+#include <atomic>
 #include <chrono>
 #include <condition_variable>
 #include <cstring>
@@ -138,21 +139,28 @@ struct Transport {
   virtual int send(const void* p, size_t bytes, int peer, hipStream_t s)                          = 0;
   virtual int recv(void* p, size_t bytes, int peer, hipStream_t s)                                = 0;
   virtual int group_end(hipStream_t s)                                                            = 0;
+  // called from ANOTHER host thread while an operator of this communicator may be blocked inside a collective: make that
+  // call (and every later one) fail instead of waiting for a peer that will never come (gxd_comm_abort)
+  virtual void abort() = 0;
 };
 
 struct RcclTransport final : Transport {
   ncclComm_t comm = nullptr;
+  std::atomic<bool> aborted{false};
   ~RcclTransport() override
   {
-    if (comm) (void)ncclCommDestroy(comm);
+    if (comm && !aborted.load()) (void)ncclCommDestroy(comm);
   }
+  int dead() const { return aborted.load() ? fail(GX_EINTERNAL, "gxd: the communicator was aborted (gxd_comm_abort)") : 0; }
   int allgather(const void* mine, void* all, size_t bytes, hipStream_t s) override
   {
+    GXD_GX(dead());
     GXD_NCCL(ncclAllGather(mine, all, bytes, ncclInt8, comm, s));
     return 0;
   }
   int group_start() override
   {
+    GXD_GX(dead());
     GXD_NCCL(ncclGroupStart());
     return 0;
   }
@@ -170,6 +178,12 @@ struct RcclTransport final : Transport {
   {
     GXD_NCCL(ncclGroupEnd());
     return 0;
+  }
+  void abort() override
+  {
+    // ncclCommAbort: the kernels of in-flight collectives leave at their next poll of the abort flag, the stream drains, the
+    // thread blocked in hipStreamSynchronize behind them returns; the communicator is gone afterwards (no ncclCommDestroy)
+    if (!aborted.exchange(true) && comm) (void)ncclCommAbort(comm);
   }
 };
 
@@ -327,6 +341,7 @@ struct LoopbackTransport final : Transport {
     bail.armed = false;
     return 0;
   }
+  void abort() override { f->abandon(); }
 };
 
 }  // namespace
@@ -695,8 +710,10 @@ int g_sort_mode = 0;  // gxd_test_set_sort_mode: 0 auto (fused for integer keys 
 constexpr int SX_BINS = 256, SX_RANGES = 8;
 
 int sort_fused(gxd_comm* c, int dtype, const void* keys, int64_t n, gxd_alloc_fn alloc, void* actx, void** out_keys, int64_t* out_n,
-               hipStream_t stream, Trace& tr)
+               hipStream_t stream, Trace& tr, void** spare, size_t* spare_bytes)
 {
+  *spare       = nullptr;
+  *spare_bytes = 0;
   const int W  = c->world;
   const int es = elem_size(dtype);
   if (g_sort_mode == 1 || !(dtype == GX_INT64 || dtype == GX_UINT64 || dtype == GX_INT32 || dtype == GX_UINT32)) return 1;
@@ -832,30 +849,55 @@ int sort_fused(gxd_comm* c, int dtype, const void* keys, int64_t n, gxd_alloc_fn
         rb.push_back((uint32_t)b);
         nrecv += cnt;
       }
-  int ok = 1;
+  // From here on the exchange has been posted: a rank that left on its own would leave its peers blocked in the status
+  // all-gather below (for ever over RCCL, 120 s on the loopback fabric) -- ADVICE r4.  Every failure is therefore CARRIED to
+  // that all-gather: `ok` 0 = a device-side check failed (all ranks take the sample-sort path), `err` != 0 = a hard error
+  // (all ranks return an error together).
+  int ok = 1, err = 0;
+  std::string err_what;
   void* out = nullptr;
   if (nrecv > 0) {
     out = alloc((size_t)nrecv * es, actx);
-    if (!out) return fail(GX_EINVAL, "gxd_sort: allocator returned NULL");
-    const int frc = gx_sortx_finish(dtype, n, recv_max, nrecv, gm, rs.data(), rc.data(), rb.data(), (int)rs.size(), out, tmp, gstream);
-    if (frc == GX_EINVAL) ok = 0;  // (more regions than the table holds, ...): reported below, all ranks take the other path
-    else if (frc) return fail(frc, "gx_sortx_finish returned " + std::to_string(frc));
-    if (ok) {
-      int32_t sok = 0;
-      GXD_GX(gx_sortx_status(tmp, &sok, gstream));
-      ok = sok;
+    if (!out) {
+      err      = GX_EINVAL;
+      err_what = "gxd_sort: allocator returned NULL";
+    } else {
+      const int frc = gx_sortx_finish(dtype, n, recv_max, nrecv, gm, rs.data(), rc.data(), rb.data(), (int)rs.size(), out, tmp, gstream);
+      if (frc == GX_EINVAL) ok = 0;  // (more regions than the table holds, ...): reported below, all ranks take the other path
+      else if (frc) {
+        err      = frc;
+        err_what = "gx_sortx_finish returned " + std::to_string(frc);
+      }
+      if (ok && !err) {
+        int32_t sok   = 0;
+        const int src = gx_sortx_status(tmp, &sok, gstream);
+        if (src) {
+          err      = src;
+          err_what = "gx_sortx_status returned " + std::to_string(src);
+        }
+        ok = sok;
+      }
     }
   }
   tr.mark("level 1 + cells");
   // ---- everybody must have succeeded
   {
-    long long mine = ok;
-    GXD_HIP(hipStreamSynchronize(stream));
+    long long mine = err ? -(long long)(err > 0 ? err : -err) - 1 : ok;
+    if (hipStreamSynchronize(stream) != hipSuccess && !err) mine = -(long long)GX_EINTERNAL - 1;
     GXD_HIP(hipMemcpyAsync(d_mine, &mine, sizeof(mine), hipMemcpyHostToDevice, c->xs));
     GXD_HIP(hipStreamSynchronize(c->xs));
     GXD_GX(allgather_i64_host(c, static_cast<long long*>(d_mine), static_cast<long long*>(d_all), 1, c->pinned));
     for (int r = 0; r < W; ++r)
-      if (c->pinned[r] != 1) return 1;
+      if (c->pinned[r] < 0)
+        return fail(err ? err : GX_EINTERNAL, err ? err_what : "gxd_sort: the fused path failed on rank " + std::to_string(r));
+    for (int r = 0; r < W; ++r)
+      if (c->pinned[r] != 1) {
+        // the result buffer the allocator has already handed out is not dropped: the sample-sort path below uses it when its own
+        // result fits (same shard sizes: it usually does); otherwise it stays the caller's to reclaim like every allocator buffer
+        *spare       = out;
+        *spare_bytes = (size_t)nrecv * es;
+        return 1;
+      }
   }
   *out_keys = out;
   *out_n    = nrecv;
@@ -951,6 +993,13 @@ int gxd_comm_destroy(gxd_comm* c)
   return 0;
 }
 
+int gxd_comm_abort(gxd_comm* c)
+{
+  if (!c || !c->tp) return GX_EINVAL;
+  c->tp->abort();
+  return 0;
+}
+
 void gxd_test_set_slot_scale(double scale) { g_slot_scale = scale; }
 void gxd_test_set_row_bits(int bits) { g_row_bits = bits; }
 void gxd_test_set_sort_mode(int mode) { g_sort_mode = mode; }
@@ -987,8 +1036,10 @@ int gxd_sort(gxd_comm* c, int dtype, const void* keys, int64_t n, int chunks, in
     c->ms[2]  = now_ms() - t0;
     return 0;
   }
+  void* spare        = nullptr;  // a result buffer the fused attempt had already asked the allocator for (see sort_fused)
+  size_t spare_bytes = 0;
   {  // the exchange between the sort's own two partition levels, where it applies (integer keys, large shards)
-    const int frc = sort_fused(c, dtype, keys, n, alloc, actx, out_keys, out_n, stream, tr);
+    const int frc = sort_fused(c, dtype, keys, n, alloc, actx, out_keys, out_n, stream, tr, &spare, &spare_bytes);
     if (frc == 0) {
       GXD_HIP(hipStreamSynchronize(stream));
       c->ms[2] = now_ms() - t0;
@@ -1037,7 +1088,7 @@ int gxd_sort(gxd_comm* c, int dtype, const void* keys, int64_t n, int chunks, in
   GXD_HIP(hipStreamWaitEvent(stream, c->evX, 0));
   tr.mark("partition + exchange");
   if (ex.total > 0) {
-    void* out = alloc((size_t)ex.total * es, actx);
+    void* out = (spare && (size_t)ex.total * es <= spare_bytes) ? spare : alloc((size_t)ex.total * es, actx);
     if (!out) return fail(GX_EINVAL, "gxd_sort: allocator returned NULL");
     tr.mark("result allocation");
     void* rk = c->arena.p[Arena::RECV_KEYS];

@@ -126,6 +126,10 @@ struct FastPlan {
   // Receiver: level 1 reads an EXTERNAL region table -- regions (bucket, source rank, input range) of the receive area, in
   // bucket order -- instead of reg_* above.
   uint32_t forced_masks;
+  // (round 5) the masks that were forced, kept: level 0 reduces this rank's EXACT masks into hy.or_mask / nor_mask, and
+  // a key with a bit no rank's SAMPLE saw (one sentinel among ids, a rare odd key among evens) must fail the verdict -- its
+  // level-0 digit would be truncated and the receiver's cell sort would skip a byte it believes constant
+  unsigned long long forced_or, forced_nor;
   uint32_t ext, nreg;
   uint32_t slot_total;      // sender: rows of the level-0 buffer in use (end of the last slot)
   uint32_t* x_tile0;        // [nreg + 1] first tile of region q (filled by k_hfx_plan)
@@ -1996,6 +2000,11 @@ __global__ void __launch_bounds__(BINS) k_hf_plan(SortPlan* plan, int stage, int
   // height of the data below the sign copies and a sign that does vary
   const int top_exact = hy.fold ? (((V >> (key_bits - 1)) & 1ull) && hy.fold_x ? 64 - __builtin_clzll(hy.fold_x) : -1) : 63 - __builtin_clzll(V | 1ull);
   int bad      = hf.fail != 0 || (!hf.forced_masks && (V == 0 || top_exact != hy.shift0 + 7));
+  // sharded sort: a bit that varies among THIS rank's keys must vary in the all-gathered SAMPLE masks.  That is exact: a bit that
+  // varies over all ranks but in no sample has, on some rank, a key that differs in it from that rank's own samples (every rank
+  // with rows has at least one), i.e. it varies inside that rank.  (V is the same set on raw and on sortable keys -- they differ
+  // by a constant XOR -- so level 0's raw masks compare with the sample's sortable ones.)
+  if (hf.forced_masks && (V & ~(hf.forced_or & hf.forced_nor))) bad = 1;
   for (int r = 0; r < NRANGE; ++r) {
     cnt[r] = hf.cur0[r][t];
     if (cnt[r] > hf.cap0[r][t]) bad = 1;
@@ -3011,6 +3020,7 @@ int sortx_level0(const void* keys, int64_t n, int64_t recv_rows_max, const unsig
   GX_HIP_TRY(hipMemcpyAsync(&L.plan->hy.or_mask, masks2_host, 2 * sizeof(unsigned long long), hipMemcpyHostToDevice, stream));
   const uint32_t one = 1;
   GX_HIP_TRY(hipMemcpyAsync(&L.plan->hf.forced_masks, &one, sizeof(one), hipMemcpyHostToDevice, stream));
+  GX_HIP_TRY(hipMemcpyAsync(&L.plan->hf.forced_or, masks2_host, 2 * sizeof(unsigned long long), hipMemcpyHostToDevice, stream));
   GX_HIP_TRY(hipStreamSynchronize(stream));  // (host sources)
   const KeyT* kin = static_cast<const KeyT*>(keys);
   // bits2 only decides whether enough key bits are left below level 1 (the receiver picks its own from what it receives)

@@ -197,6 +197,13 @@ def close_communicators():
     _COMMS.clear()
 
 
+def abort_communicators():
+    """from a watchdog thread: make a sharded operator that is blocked inside a collective return an error (gxd_comm_abort ->
+    ncclCommAbort).  The communicators are unusable afterwards; close_communicators still releases their buffers."""
+    for c in list(_COMMS.values()):
+        c.abort()
+
+
 def _use_gxd(local, t: torch.Tensor) -> bool:
     return local is None and t.is_cuda
 

@@ -27,6 +27,7 @@ _lib.gxd_unique_id.argtypes = [_p]
 _lib.gxd_comm_create.argtypes = [_p, _i, _i, ctypes.POINTER(_p)]
 _lib.gxd_comm_create_loopback.argtypes = [_i, ctypes.POINTER(_p)]
 _lib.gxd_comm_destroy.argtypes = [_p]
+_lib.gxd_comm_abort.argtypes = [_p]
 _lib.gxd_last_timing.argtypes = [_p, ctypes.POINTER(ctypes.c_double)]
 _lib.gxd_sort.argtypes = [_p, _i, _p, _i64, _i, _i, _ALLOC, _p, ctypes.POINTER(_p), ctypes.POINTER(_i64), _p]
 _lib.gxd_join_build.argtypes = [_p, _i, _p, _i64, _i, _p, ctypes.POINTER(_p)]
@@ -134,6 +135,11 @@ class Communicator:
         if self._h:
             _lib.gxd_comm_destroy(self._h)
             self._h = ctypes.c_void_p()
+
+    def abort(self):
+        """gxd_comm_abort: callable from another thread while an operator of this communicator is blocked in a collective"""
+        if self._h:
+            _lib.gxd_comm_abort(self._h)
 
     def __del__(self):
         try:

@@ -46,6 +46,11 @@ int gxd_comm_create(const void* id128_host, int world, int rank, gxd_comm** out)
  * world <= 16 here and in gxd_comm_create; any world size (hash destinations are a multiply-shift of the hash, not a mask). */
 int gxd_comm_create_loopback(int world, gxd_comm** out);
 int gxd_comm_destroy(gxd_comm* comm);
+/* From ANOTHER host thread (a watchdog): make the operator call that is blocked inside a collective of `comm` -- a peer died,
+ * or never made its call -- return an error, and every later call fail at once.  RCCL: ncclCommAbort (the communicator is
+ * unusable afterwards; gxd_comm_destroy still releases the buffers); loopback fabric: the fabric is broken for all its ranks.
+ * The reference's analogue: rapidsmpf's communicator shutdown behind libcudf_streaming's shuffle (partition_utils.cpp:72-117). */
+int gxd_comm_abort(gxd_comm* comm);
 int gxd_comm_rank(const gxd_comm* comm);
 int gxd_comm_world(const gxd_comm* comm);
 const char* gxd_last_error(void);

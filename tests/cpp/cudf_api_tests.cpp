@@ -1440,6 +1440,88 @@ int main()
     CHECK(ok && have == expect);
   });
 
+  run("ONE cudf::hash_join probed from 4 host threads on 4 streams at once (hash_join.hpp:63-68: probes are const and thread-safe)", [] {
+    // build once on the default stream; every thread then probes the same object concurrently on a stream of its own: a large
+    // probe (>= 2^22 rows: the partitioned probe, scratch from the shared pooled mr), inner_join_size, a left join and a small
+    // probe (the direct kernel), each checked against the closed form of its own probe column
+    constexpr std::size_t NB = 3'000'000;
+    std::vector<int64_t> bk(NB);
+    for (std::size_t i = 0; i < NB; ++i) bk[i] = static_cast<int64_t>((i * 2654435761ull) % NB) * 5 + 2;  // distinct (a bijection mod NB... 2654435761 is odd, NB is not a power of two: checked below)
+    {
+      std::vector<uint8_t> seen(NB, 0);
+      bool distinct = true;
+      for (auto v : bk) {
+        auto j = static_cast<std::size_t>((v - 2) / 5);
+        if (seen[j]) distinct = false;
+        seen[j] = 1;
+      }
+      if (!distinct)
+        for (std::size_t i = 0; i < NB; ++i) bk[i] = static_cast<int64_t>(NB - 1 - i) * 5 + 2;
+    }
+    std::vector<int32_t> row_of(NB);
+    for (std::size_t i = 0; i < NB; ++i) row_of[static_cast<std::size_t>((bk[i] - 2) / 5)] = static_cast<int32_t>(i);
+    auto bc = make_col<int64_t>(bk);
+    get_default_stream().synchronize();
+    cudf::hash_join hj{table_view{{bc->view()}}, null_equality::EQUAL};
+    get_default_stream().synchronize();
+    constexpr int T = 4;
+    std::vector<std::string> errs(T);
+    std::vector<std::thread> th;
+    for (int t = 0; t < T; ++t)
+      th.emplace_back([&, t] {
+        try {
+          hipStream_t s = nullptr;
+          if (hipStreamCreateWithFlags(&s, hipStreamNonBlocking) != hipSuccess) throw std::runtime_error("stream");
+          rmm::cuda_stream_view sv{s};
+          {
+            uint64_t x = 0x9E3779B97F4A7C15ull * (t + 1);
+            auto next  = [&] { x ^= x << 13; x ^= x >> 7; x ^= x << 17; return x; };
+            const std::size_t np = 4'400'000 + 150'001 * t;
+            std::vector<int64_t> pk(np);
+            for (auto& v : pk) v = static_cast<int64_t>(next() % (5 * NB * 3));  // a third of the key space is populated at stride 5
+            std::size_t expect = 0;
+            for (auto v : pk) expect += (v % 5 == 2 && static_cast<std::size_t>(v / 5) < NB) ? 1 : 0;
+            rmm::device_buffer pd{pk.data(), np * sizeof(int64_t), sv};
+            column_view pc{data_type{type_id::INT64}, static_cast<size_type>(np), pd.data(), nullptr, 0};
+            table_view pt{{pc}};
+            for (int rep = 0; rep < 2; ++rep) {
+              auto [l, r] = hj.inner_join(pt, std::nullopt, sv);
+              sv.synchronize();
+              auto hl = to_host(*l);
+              auto hr = to_host(*r);
+              if (hl.size() != expect) throw std::runtime_error("inner_join: wrong number of pairs");
+              std::vector<uint8_t> hit(np, 0);
+              for (std::size_t i = 0; i < hl.size(); ++i) {
+                auto const v = pk[hl[i]];
+                if (hit[hl[i]] || v % 5 != 2 || row_of[static_cast<std::size_t>(v / 5)] != hr[i]) throw std::runtime_error("inner_join: wrong pair");
+                hit[hl[i]] = 1;
+              }
+              if (hj.inner_join_size(pt, sv) != expect) throw std::runtime_error("inner_join_size");
+            }
+            auto [ll, lr] = hj.left_join(pt, std::nullopt, sv);
+            sv.synchronize();
+            if (ll->size() != np) throw std::runtime_error("left_join: one row per probe row expected (distinct build keys)");
+            // the direct kernel on a slice of the same column
+            column_view small{data_type{type_id::INT64}, 100'000, pd.data(), nullptr, 0};
+            auto [sl, sr] = hj.inner_join(table_view{{small}}, std::nullopt, sv);
+            sv.synchronize();
+            std::size_t se = 0;
+            for (std::size_t i = 0; i < 100'000; ++i) se += (pk[i] % 5 == 2 && static_cast<std::size_t>(pk[i] / 5) < NB) ? 1 : 0;
+            if (sl->size() != se) throw std::runtime_error("small probe: wrong number of pairs");
+          }
+          sv.synchronize();
+          (void)hipStreamDestroy(s);
+        } catch (std::exception const& e) {
+          errs[t] = e.what();
+        }
+      });
+    for (auto& t : th) t.join();
+    for (int t = 0; t < T; ++t) {
+      if (!errs[t].empty()) std::printf("    thread %d: %s\n", t, errs[t].c_str());
+      CHECK(errs[t].empty());
+    }
+  });
+
   std::printf("%d run, %d failed\n", g_run, g_failed);
   return g_failed ? 1 : 0;
 }

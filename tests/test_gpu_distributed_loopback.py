@@ -101,12 +101,17 @@ def test_loopback_sort(fabric, dtype, kind, chunks, slot_scale):
 
 @pytest.mark.parametrize("dtype,kind,shape", [
     ("int64", "even", "uniform"), ("int64", "skewed", "uniform"), ("int64", "empty", "hot_value"), ("int32", "skewed", "uniform"),
-    ("int64", "even", "narrow_range"), ("int64", "even", "heavy_bin")])
+    ("int64", "even", "narrow_range"), ("int64", "even", "heavy_bin"), ("int64", "even", "outlier_high"), ("int64", "skewed", "outlier_low"),
+    ("int32", "even", "outlier_high")])
 def test_loopback_sort_fused(fabric, dtype, kind, shape):
     """gxd_sort with the exchange BETWEEN the sort's two partition levels (gx_sortx_*): level 0 on every rank with common digit
     positions, whole level-0 bins dealt to ranks by the all-gathered histogram, one span per peer, level 1 + cell sort on the
     receiver.  Bit-exact against the oracle on the concatenation; `hot_value` puts a big cell on one receiver (sorted through X),
-    `heavy_bin` one level-0 bin too heavy for a rank -- the collective decision falls back to the sample-sort path."""
+    `heavy_bin` one level-0 bin too heavy for a rank -- the collective decision falls back to the sample-sort path.
+    `outlier_high` / `outlier_low`: ONE key per rank with a bit no rank's SAMPLE saw -- a sentinel above ids
+    below 1e12, one odd key among even ones -- at a row the 1-in-8 / 1-in-32 chunk sample does not read.  The digit positions and
+    the receiver's skipped bytes come from the sampled masks; level 0's exact masks must expose the outlier and every rank must
+    take the sample-sort path (the fused path would truncate its level-0 digit / leave it unsorted inside its cell)."""
     import torch
     from cudf_amd import gxd
     W = len(fabric)
@@ -114,8 +119,14 @@ def test_loopback_sort_fused(fabric, dtype, kind, shape):
     total = W * 2_300_000 + 12_345
     if dtype == "int32":
         v = rng.integers(-2**31, 2**31 - 1, total).astype(np.int32)
+        if shape == "outlier_high":
+            v = rng.integers(0, 1 << 27, total).astype(np.int32)
     else:
         v = rng.integers(-2**63, 2**63 - 1, total, dtype=np.int64)
+        if shape == "outlier_high":
+            v = rng.integers(0, 1_000_000_000_000, total, dtype=np.int64)
+        elif shape == "outlier_low":
+            v &= np.int64(-2)                                                    # every key even
         if shape == "narrow_range":
             v = rng.integers(0, 1_000_000_000_000, total, dtype=np.int64)       # the top digit uses 233 of 256 bins, not byte aligned
         elif shape == "hot_value":
@@ -124,6 +135,10 @@ def test_loopback_sort_fused(fabric, dtype, kind, shape):
             hot = rng.random(total) < 0.8
             v[hot] = (v[hot] & np.int64((1 << 52) - 1)) | np.int64(37 << 52)     # 80 % of all keys inside one level-0 bin
     sh = _shards(rng, total, W, kind)
+    if shape.startswith("outlier"):
+        for a, b in sh[:: max(1, W - 1)]:    # first and last rank: row 100 of a shard lies in a chunk the sample skips (stride >= 8)
+            if b - a > 200:
+                v[a + 100] = (np.iinfo(v.dtype).max if a == 0 else -1) if shape == "outlier_high" else v[a + 100] | 1
     ins = [_cuda(v[a:b]) for a, b in sh]
     gxd.set_sort_mode(2)                                                          # fused from 2^21 rows per rank
     try:
@@ -137,7 +152,9 @@ def test_loopback_sort_fused(fabric, dtype, kind, shape):
     assert got.tobytes() == orc.sort_keys(v).tobytes()
     fused = [o[1] == -1.0 for o in outs]
     assert all(fused) or not any(fused)                                           # a collective decision
-    if shape == "heavy_bin":
+    if shape.startswith("outlier"):
+        assert not any(fused)                 # the exact masks of level 0 expose the unsampled bit: every rank falls back together
+    elif shape == "heavy_bin":
         if W >= 8:
             assert not any(fused)             # 80 % of 18 M keys do not fit one rank's receive area: the sample-sort path ran
     else:
