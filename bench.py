@@ -60,7 +60,7 @@ def parse():
                                                               "dense ids (round 4); 8 / 9 = fixed")
     ap.add_argument("--gb-spec", type=int, default=1, help="groupby knob: 1 hist-free speculative partition pass (default), 0 exact histogram pass")
     ap.add_argument("--no-partitioned-join", action="store_true", help="join: probe the table directly")
-    ap.add_argument("--join-probe-kernel", type=int, default=0, help="join knob: 0 pipelined tag probe, 1 round-1 tag probe")
+    ap.add_argument("--join-probe-kernel", type=int, default=0, help="join knob: 0 pipelined tag probe on LDS-resident tags (default), 1 round-1 tag probe, 2 / 3 L2-resident direct probe (4 / 2 rows per thread)")
     ap.add_argument("--join-scatter-tile", type=int, default=0, help="join knob: rows per scatter tile (0 = default)")
     ap.add_argument("--join-build-kernel", type=int, default=0, help="join knob: 0 sub-table build with the tags in LDS (default), 1 round-2 build (global CAS + k_tags)")
     ap.add_argument("--join-spec", type=int, default=1, help="join knob: 1 hist-free speculative partition (default), 0 round-2 path")
@@ -965,7 +965,8 @@ def bench_join(c):
     spec = bool(a.join_spec)
     roofline = {"bound": "hbm",
                 "kernel": ("k_probe" if not part_bits else
-                           "partitioned probe (k_pj2_scatter + k_pj2_offsets + k_pj2_probe_pipe: hist-free speculative partition)" if spec else
+                           ("partitioned probe (k_pj2_scatter + k_pj2_offsets + " + ("k_pj3_probe_direct" if a.join_probe_kernel in (2, 3) else "k_pj2_probe_pipe") +
+                            ": hist-free speculative partition)") if spec else
                            "partitioned probe (k_pj_hist + k_pj_scatter + k_pj_probe_pipe)"),
                 "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS, "traffic": None,
                 "traffic_key": None if not part_bits else ("join probe phase" if spec else "join probe phase (exact two-pass)"),
@@ -975,7 +976,8 @@ def bench_join(c):
         ms = [x / kn[0] for x in kms]
         names = ["k_pj_hist+k_pj_offsets (partition histogram; a no-op on the speculative path)",
                  ("k_pj2_scatter" if spec else "k_pj_scatter") + " (partition (key,row) by table hash)",
-                 ("k_pj2_probe_pipe" if spec else "k_pj_probe_pipe") + " (tag probe of partition-resident sub-tables)"]
+                 (("k_pj3_probe_direct (direct probe of L2-resident sub-tables, no tags)" if a.join_probe_kernel in (2, 3) else
+                   "k_pj2_probe_pipe (tag probe of partition-resident sub-tables)") if spec else "k_pj_probe_pipe (tag probe of partition-resident sub-tables)")]
         kb = [8 * n, 20 * n, 12 * n + 8 * matches]   # bytes each launch must move: keys | keys + (key,row) | (key,row) + pairs
         dom = max(range(3), key=lambda i: ms[i])
         roofline["kernels_ms"] = dict(zip(names, ms))
@@ -992,7 +994,7 @@ def bench_join(c):
     keydesc = ("random distinct 64-bit build keys, probe 30 % from them + 70 % from a disjoint random set (SURVEY 8d)"
                if a.join_keys == "random" else "dense keys 3i+1 (round-2 distribution)")
     return {"workload": f"{n:.0e}-row int64 probe x {nb_rows:.0e}-row build inner hash join (probe phase timed), {keydesc}", "rows": n,
-            "join_keys": a.join_keys, "partition_mode": {"speculative": a.join_spec, "early_loads": a.join_early_loads},
+            "join_keys": a.join_keys, "partition_mode": {"speculative": a.join_spec, "early_loads": a.join_early_loads, "probe_kernel": a.join_probe_kernel},
             "ms_per_step": ms_per_step, "rows_per_s": n / sec, "dtype": "int64", "build_ms": build_ms, "build_call_ms": build_call_ms,
             "build_plus_probe_ms": build_ms + ms_per_step,  # what the reference's own benchmark times (join_common.hpp:83-122)
             "build_rows_per_s": nb_rows / (build_ms * 1e-3),

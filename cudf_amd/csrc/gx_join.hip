@@ -2688,6 +2688,254 @@ k_pj2_probe_pipe(const K* __restrict__ pkeys, const int32_t* __restrict__ pidx, 
   }
 }
 
+// ================================================================================================
+// Round 5: the L2-RESIDENT direct probe (track B) -- selectable, gx_join_set_probe_kernel(2 | 3).
+//
+// k_pj2_probe_pipe keeps a sub-table's 4-bit tags in LDS so that only a tag match costs a slot read; that is ~128 VALU
+// instructions per row (SWAR scans of a 16-slot window, three pipeline stages of 64-bit keys) at ONE 16-wave gang per CU
+// (64 KiB of tags + 92 KiB of staging fill the LDS): half instruction issue, half exposed latency, 1.9 TB/s.  This kernel
+// asks the opposite question: the partition pass hands the pieces of XCD y's partitions to the workgroups of XCD y IN ORDER
+// (per-XCD ticket lists), so at any moment the 32 CUs of an XCD probe the same one or two 2-MiB sub-tables -- which the
+// XCD's 4-MiB L2 holds.  So: no tags, no LDS tables, no staging; every row reads its home slot straight from the L2 and walks
+// its chain there (1.3 - 1.8 slots at load 0.37, nearly always inside one 128-B line), ~45 VALU per row, and with the LDS
+// free the CU holds 24 - 32 waves instead of 16 to cover the ~200-cycle L2 latency.  Output positions: the single matches
+// of a piece are numbered through one LDS counter, ONE returning atomic per piece reserves their run, and the pairs wait in
+// registers for one iteration until that atomic has come back (the wave never waits for it); rows with duplicate build keys
+// (rare) reserve and write on their own.  Same PieceTable, same scatter, same fallback gating as k_pj2_probe_pipe.
+// ================================================================================================
+constexpr int PD_BT = 512;
+template <typename K, int R, int WPE>
+__global__ void __launch_bounds__(PD_BT, WPE)
+k_pj3_probe_direct(const K* __restrict__ pkeys, const int32_t* __restrict__ pidx, PieceTable pt, int pbits,
+                   const Slot<K>* __restrict__ slots, uint32_t log2cap, int left_outer, int32_t* __restrict__ out_probe,
+                   int32_t* __restrict__ out_build, int64_t capacity, unsigned long long* cursor)
+{
+  typedef typename SlotRaw<K>::type Raw;
+  __shared__ PpPiece s_piece[2];
+  __shared__ unsigned int s_cnt[2];
+  __shared__ unsigned long long s_base[2];
+  const unsigned tid  = threadIdx.x;
+  const unsigned lane = lane_id();
+  const unsigned w    = tid / GX_WAVE;
+  const int P         = 1 << pbits;
+  const int LISTP     = P / PJ_NR;
+  const uint32_t mask = log2cap >= 32 ? 0xFFFFFFFFu : ((1u << log2cap) - 1u);  // (rows are int32: a table has at most 2^32 slots)
+  // ---- wave 0 resolves pieces (the service wave's search of k_pj2_probe_pipe): ticket of the XCD's list, partition, region
+  const unsigned x0 = pj_xcc();
+  unsigned ylist    = 0;
+  auto take_piece = [&](PpPiece& pc) {
+    pc.valid = 0;
+    pc.c0 = pc.c1 = 0;
+    pc.part = 0;
+    unsigned int g = 0xFFFFFFFFu, y = 0;
+    if (lane == 0) {
+      while (ylist < PJ_NR) {
+        y                      = (x0 + ylist) % PJ_NR;
+        const unsigned int nch = pt.list_chunk0[y + 1] - pt.list_chunk0[y];
+        if (nch) {
+          const unsigned int t = atomicAdd(&pt.ticket[y].v, 1u);
+          if (t < nch) {
+            g = pt.list_chunk0[y] + t;
+            break;
+          }
+        }
+        ++ylist;
+      }
+    }
+    g     = (unsigned int)__builtin_amdgcn_readfirstlane((int)g);
+    y     = (unsigned int)__builtin_amdgcn_readfirstlane((int)y);
+    ylist = (unsigned int)__builtin_amdgcn_readfirstlane((int)ylist);
+    if (g == 0xFFFFFFFFu) return;
+    unsigned int part = 0;
+    bool hit = false;
+    for (int e = (int)lane; e < LISTP; e += GX_WAVE) {
+      const int p           = (int)y * LISTP + e;
+      const unsigned int lo = pt.chunk0[p * pt.nr], hi = pt.chunk0[(p + 1) * pt.nr];
+      if (lo <= g && g < hi) {
+        part = (unsigned int)p;
+        hit  = true;
+      }
+    }
+    uint64_t hb = ballot(hit);
+    part        = shfl(part, __builtin_ctzll(hb));
+    unsigned int reg = part * (unsigned int)pt.nr, loc = 0;
+    hit = false;
+    if ((int)lane < pt.nr) {
+      const unsigned int e  = part * (unsigned int)pt.nr + lane;
+      const unsigned int lo = pt.chunk0[e], hi = pt.chunk0[e + 1];
+      if (lo <= g && g < hi) {
+        reg = e;
+        loc = g - lo;
+        hit = true;
+      }
+    }
+    hb           = ballot(hit);
+    const int sr = __builtin_ctzll(hb);
+    reg          = shfl(reg, sr);
+    loc          = shfl(loc, sr);
+    unsigned long long r0, r1;
+    if (pt.start) {
+      r0 = pt.start[reg];
+      r1 = pt.start[reg + 1];
+    } else {
+      unsigned int c = pt.fill[reg];
+      c              = c < pt.cap ? c : pt.cap;
+      r0             = (unsigned long long)reg * pt.cap;
+      r1             = r0 + c;
+    }
+    constexpr unsigned long long ROWS = (unsigned long long)PD_BT * R;
+    pc.c0    = r0 + (unsigned long long)loc * ROWS;
+    pc.c1    = pc.c0 + ROWS < r1 ? pc.c0 + ROWS : r1;
+    pc.part  = part;
+    pc.valid = 1;
+  };
+  if (tid < 2) s_cnt[tid] = 0;
+  if (w == 0) {
+    PpPiece pc;
+    take_piece(pc);
+    if (lane == 0) s_piece[0] = pc;
+  }
+  __syncthreads();
+  // the single matches of the PREVIOUS piece: written one iteration late, when the piece's reservation has come back
+  int32_t h_idx[R], h_first[R];
+  uint32_t h_pos[R];
+  uint32_t h_live = 0;
+#pragma unroll
+  for (int j = 0; j < R; ++j) {
+    h_idx[j] = h_first[j] = 0;
+    h_pos[j] = 0;
+  }
+  unsigned long long pend = 0;  // thread 0: the returning atomic of the previous piece
+  for (int t = 0;; ++t) {
+    const PpPiece pc = s_piece[t & 1];
+    const bool valid = pc.valid != 0;  // block-uniform
+    K key[R];
+    int32_t idx[R];
+    uint32_t act = 0;
+    if (valid) {
+#pragma unroll
+      for (int j = 0; j < R; ++j) {
+        const unsigned long long i  = pc.c0 + (unsigned long long)(j * PD_BT) + tid;
+        const unsigned long long ic = i < pc.c1 ? i : pc.c0;
+        key[j] = __builtin_nontemporal_load(&pkeys[ic]);
+        idx[j] = __builtin_nontemporal_load(&pidx[ic]);
+        if (i < pc.c1) act |= 1u << j;
+      }
+    }
+    if (tid == 0) s_base[(t & 1) ^ 1] = pend;  // (read behind this iteration's barrier)
+    if (w == 0 && valid) {                     // the next piece resolves under this piece's loads
+      PpPiece nx;
+      take_piece(nx);
+      if (lane == 0) s_piece[(t + 1) & 1] = nx;
+    }
+    uint32_t m[R], pos[R];
+    int32_t first[R];
+    uint32_t live = 0;
+    if (valid) {
+      uint32_t sl[R];
+      Raw sv[R];
+#pragma unroll
+      for (int j = 0; j < R; ++j) {
+        m[j]     = 0;
+        first[j] = NO_MATCH;
+        sl[j]    = (uint32_t)slot_of<K>(key[j], log2cap);
+        sv[j]    = *reinterpret_cast<const Raw*>(&slots[sl[j]]);  // the home slot of every row, R loads in flight per lane
+      }
+      const uint32_t rows = act;
+      for (;;) {
+        uint32_t next = 0;
+#pragma unroll
+        for (int j = 0; j < R; ++j) {
+          if ((act >> j) & 1u) {
+            K k;
+            int32_t r;
+            unpack_slot(sv[j], k, r);
+            if (r != EMPTY_ROW) {
+              if (k == key[j]) {
+                if (m[j] == 0) first[j] = r;
+                ++m[j];
+              }
+              sl[j] = (sl[j] + 1u) & mask;
+              next |= 1u << j;
+            }
+          }
+        }
+        act = next;
+        if (act == 0) break;
+#pragma unroll
+        for (int j = 0; j < R; ++j)
+          if ((act >> j) & 1u) sv[j] = *reinterpret_cast<const Raw*>(&slots[sl[j]]);
+      }
+      // duplicate build keys: such a row reserves its own run and walks its chain again (the lines are L2 / L1 resident)
+#pragma unroll
+      for (int j = 0; j < R; ++j) {
+        if (left_outer && ((rows >> j) & 1u) && m[j] == 0) m[j] = 1;  // (row, JoinNoMatch): first[j] is NO_MATCH
+        if (m[j] > 1) {
+          unsigned long long gp = atomicAdd(cursor, (unsigned long long)m[j]);
+          uint32_t hh           = (uint32_t)slot_of<K>(key[j], log2cap);
+          for (;;) {
+            K k;
+            int32_t r;
+            load_slot<K>(&slots[hh], k, r);
+            if (r == EMPTY_ROW) break;
+            if (k == key[j]) {
+              if ((int64_t)gp < capacity) {
+                out_probe[gp] = idx[j];
+                out_build[gp] = r;
+              }
+              ++gp;
+            }
+            hh = (hh + 1u) & mask;
+          }
+          m[j] = 0;
+        }
+      }
+      // single matches: numbered inside the piece through one LDS counter
+      uint32_t tot = 0;
+#pragma unroll
+      for (int j = 0; j < R; ++j) {
+        const uint64_t bb = ballot(m[j] == 1);
+        pos[j]            = tot + (uint32_t)__builtin_popcountll(bb & lanemask_lt());
+        tot += (uint32_t)__builtin_popcountll(bb);
+        if (m[j] == 1) live |= 1u << j;
+      }
+      uint32_t woff = 0;
+      if (lane == 0 && tot) woff = atomicAdd(&s_cnt[t & 1], tot);
+      woff = (uint32_t)__builtin_amdgcn_readfirstlane((int)woff);
+#pragma unroll
+      for (int j = 0; j < R; ++j) pos[j] += woff;
+    }
+    __syncthreads();
+    // ---- the previous piece's pairs leave (its base sits in s_base); this piece's reservation is requested
+    {
+      const unsigned long long gb = s_base[(t & 1) ^ 1];
+#pragma unroll
+      for (int j = 0; j < R; ++j) {
+        if ((h_live >> j) & 1u) {
+          const unsigned long long gp = gb + h_pos[j];
+          if ((int64_t)gp < capacity) {
+            __builtin_nontemporal_store(h_idx[j], &out_probe[gp]);
+            __builtin_nontemporal_store(h_first[j], &out_build[gp]);
+          }
+        }
+      }
+    }
+    if (!valid) break;  // (block-uniform: the pipeline has drained)
+    if (tid == 0) {
+      const unsigned int c = s_cnt[t & 1];
+      pend                 = c ? atomicAdd(cursor, (unsigned long long)c) : 0ull;
+      s_cnt[t & 1]         = 0;  // next used two iterations from here, behind the next barrier
+    }
+    h_live = live;
+#pragma unroll
+    for (int j = 0; j < R; ++j) {
+      h_idx[j]   = idx[j];
+      h_first[j] = first[j];
+      h_pos[j]   = pos[j];
+    }
+  }
+}
+
 // optional per-kernel timing of the partitioned probe with HIP events on the caller's stream (bench.py)
 struct JoinProfile {
   bool enabled = false, created = false, marked = false;
@@ -2834,7 +3082,7 @@ template <typename K>
 static bool pj2_applies(int64_t n, int pbits)
 {
   const size_t lds = (size_t)16384 * sizeof(K) + ((size_t)8 << pbits) + 512;
-  return g_pj_spec && g_pj_probe == 0 && pbits >= 3 && pbits <= 12 && lds <= (size_t)160 * 1024 && n > 0 &&
+  return g_pj_spec && (g_pj_probe == 0 || g_pj_probe == 2 || g_pj_probe == 3) && pbits >= 3 && pbits <= 12 && lds <= (size_t)160 * 1024 && n > 0 &&
          (g_pj_spec == 2 || n > 4 * (int64_t)16384 * 256);  // 2: forced for any n (tests)
 }
 template <typename K>
@@ -2893,21 +3141,37 @@ int probe_partitioned_impl2(const K* keys, int64_t n, const Slot<K>* slots, uint
   // ---- speculative pass
   hipLaunchKernelGGL(kspec, dim3((unsigned)grid), dim3(1024), lds_s, s, keys, n, plan2, plan, pbits, rrows, cap, ntiles, pkeys, pidx, part_of, row0, payload);
   jprof_mark(2, s);
-  hipLaunchKernelGGL(k_pj2_offsets, dim3(1), dim3(1024), 0, s, plan2, pbits, cap, (unsigned int)PP_ROWS);
+  // the probe kernel: the LDS-tag gang probe, or (knob 2 / 3) the L2-resident direct probe with 4 / 2 rows per thread
+  const bool direct        = g_pj_probe == 2 || g_pj_probe == 3;
+  auto kdirect             = g_pj_probe == 3 ? k_pj3_probe_direct<K, 2, 8> : k_pj3_probe_direct<K, 4, 6>;
+  const unsigned piece_rows = direct ? (unsigned)PD_BT * (g_pj_probe == 3 ? 2u : 4u) : (unsigned)PP_ROWS;
+  static int direct_wgs[2] = {0, 0};  // resident workgroups per CU of the two instantiations (occupancy query, once)
+  if (direct && direct_wgs[g_pj_probe - 2] == 0) {
+    int nb = 0;
+    GX_HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, reinterpret_cast<const void*>(kdirect), PD_BT, 0));
+    direct_wgs[g_pj_probe - 2] = nb > 0 ? nb : 1;
+  }
+  auto launch_probe = [&](const PieceTable& t) {
+    if (direct) {
+      const int64_t g = (int64_t)(num_cus > 0 ? num_cus : 256) * direct_wgs[g_pj_probe - 2];
+      hipLaunchKernelGGL(kdirect, dim3((unsigned)g), dim3(PD_BT), 0, s, pkeys, pidx, t, pbits, slots, lg, left_outer, out_probe, out_build, capacity, cur);
+    } else {
+      const int64_t g = num_cus > 0 ? num_cus : 256;
+      hipLaunchKernelGGL(kprobe, dim3((unsigned)g), dim3(PP_BT), lds_p, s, pkeys, pidx, t, pbits, slots, lg, left_outer, out_probe, out_build, capacity, cur);
+    }
+  };
+  hipLaunchKernelGGL(k_pj2_offsets, dim3(1), dim3(1024), 0, s, plan2, pbits, cap, piece_rows);
   PieceTable pt{plan2->chunk0, plan2->list_chunk0, plan2->ticket, nullptr, plan2->fill, cap, PJ_NR};
-  int64_t pgrid = num_cus > 0 ? num_cus : 256;
-  hipLaunchKernelGGL(kprobe, dim3((unsigned)pgrid), dim3(PP_BT), lds_p, s, pkeys, pidx, pt, pbits, slots, lg, left_outer, out_probe, out_build,
-                     capacity, cur);
+  launch_probe(pt);
   // ---- exact sequence: every kernel returns at once unless plan2->fallback is set
   int64_t hb = div_up(n, 256 * 8 * 4 * PJ_NR);
   if (hb > 256) hb = 256;
   if (hb < 1) hb = 1;
   hipLaunchKernelGGL((k_pj_hist<K, F>), dim3((unsigned)(hb * PJ_NR)), dim3(256), 0, s, keys, n, plan, pbits, rrows, part_of, &plan2->fallback);
-  hipLaunchKernelGGL(k_pj_offsets, dim3(1), dim3(1024), 0, s, plan, pbits, (unsigned int)PP_ROWS, &plan2->fallback);
+  hipLaunchKernelGGL(k_pj_offsets, dim3(1), dim3(1024), 0, s, plan, pbits, piece_rows, &plan2->fallback);
   hipLaunchKernelGGL(kexact, dim3((unsigned)grid), dim3(1024), lds_s, s, keys, n, plan2, plan, pbits, rrows, cap, ntiles, pkeys, pidx, part_of, row0, payload);
   PieceTable pe{plan->chunk0, plan->list_chunk0, plan2->ticket_exact, plan->offset, nullptr, 0u, 1};
-  hipLaunchKernelGGL(kprobe, dim3((unsigned)pgrid), dim3(PP_BT), lds_p, s, pkeys, pidx, pe, pbits, slots, lg, left_outer, out_probe, out_build,
-                     capacity, cur);
+  launch_probe(pe);
   jprof_mark(3, s);
   g_jprof.marked = g_jprof.enabled;
   GX_LAUNCH_CHECK();
@@ -3336,7 +3600,7 @@ int gx_join_profile_read(float* ms3)
   return 0;
 }
 
-void gx_join_set_probe_kernel(int which) { gx::join::g_pj_probe = which == 1 ? 1 : 0; }
+void gx_join_set_probe_kernel(int which) { gx::join::g_pj_probe = (which >= 1 && which <= 3) ? which : 0; }
 void gx_join_set_partition_mode(int speculative, int early_loads)
 {
   gx::join::g_pj_spec        = speculative == 2 ? 2 : (speculative ? 1 : 0);

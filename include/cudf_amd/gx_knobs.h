@@ -104,7 +104,10 @@ void gx_join_set_build_kernel(int which);
  * the largest that fits the LDS next to the per-partition counters). */
 void gx_join_set_scatter_tile(int rows);
 
-/* A/B knob (process-wide): 0 = software-pipelined tag probe (default), 1 = the round-1 tag probe. */
+/* A/B knob (per calling thread): 0 = software-pipelined tag probe on LDS-resident 4-bit tags (default), 1 = the round-1 tag probe,
+ * 2 / 3 = the L2-resident DIRECT probe of round 5 (k_pj3_probe_direct, 4 / 2 rows per thread): no tags, no LDS tables -- the
+ * workgroups of an XCD take the pieces of the XCD's partitions in order, so the 2-MiB sub-table they all probe sits in the
+ * XCD's L2 and every row reads its home slot there. */
 void gx_join_set_probe_kernel(int which);
 
 /* A/B knob (process-wide): speculative = 1 (default) partitions the probe rows WITHOUT a histogram pass into padded

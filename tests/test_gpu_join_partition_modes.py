@@ -113,3 +113,40 @@ def test_speculative_partition_probe_default_threshold(gx):
         assert l.size == hitrows.numel()
         assert int(li.sum().item()) == int(hitrows.sum().item())
         assert int(torch.unique(li).numel()) == l.size
+
+
+@pytest.mark.parametrize("dtype,shape,kernel", [(dt, sh, k) for k in (2, 3) for dt, sh in
+                                                 (("int64", "uniform"), ("int64", "dup_build"), ("int64", "hot_key"), ("int64", "one_partition"),
+                                                  ("int64", "edge_chains"), ("int32", "uniform"), ("int32", "edge_chains"))])
+def test_l2_resident_direct_probe_matches_oracle(gx, dtype, shape, kernel):
+    """Round 5: k_pj3_probe_direct (gx_join_set_probe_kernel 2 / 3: 4 / 2 rows per thread) -- the same partition pass, the same
+    region table and fallback gating, but every row reads its home slot from the L2-resident sub-table and walks its chain there
+    (no tags).  Inner and left-outer pairs against the oracle on uniform keys, duplicate build keys (rows that reserve their own
+    output run), a hot key and one-partition inputs (slot overflow -> the gated exact sequence runs the same kernel over exact
+    partitions), and chains that cross a sub-table's end and the table's end (the walk wraps through `mask`)."""
+    Column, ops, _lib = gx
+    rng = np.random.default_rng(4321)
+    nb, npr = 600_000, (1 << 20) + 4321
+    build, probe = _inputs(rng, dtype, shape, nb, npr)
+    el, er = orc.inner_join(probe, build)
+    old_min = ops.HashJoin.PARTITIONED_MIN_ROWS
+    ops.HashJoin.PARTITIONED_MIN_ROWS = 1 << 20
+    try:
+        _lib.lib.gx_join_set_probe_kernel(kernel)
+        _lib.lib.gx_join_set_partition_mode(2, 0)
+        hj = ops.HashJoin(Column.from_numpy(build))
+        assert _lib.lib.gx_join_partition_bits(hj.key_size, hj.table_bytes) >= 3
+        l, r = hj.inner_join(Column.from_numpy(probe))
+        got = _pairs(l, r)
+        np.testing.assert_array_equal(got[0], el)
+        np.testing.assert_array_equal(got[1], er)
+        if shape in ("uniform", "hot_key", "edge_chains", "dup_build"):
+            pl, pr = hj.left_join(Column.from_numpy(probe))
+            wl, wr = orc.left_join([probe], [build])
+            a, b = _pairs(pl, pr), orc.canonical_pairs(wl, wr)
+            np.testing.assert_array_equal(a[0], b[0])
+            np.testing.assert_array_equal(a[1], b[1])
+    finally:
+        ops.HashJoin.PARTITIONED_MIN_ROWS = old_min
+        _lib.lib.gx_join_set_probe_kernel(0)
+        _lib.lib.gx_join_set_partition_mode(1, 0)
