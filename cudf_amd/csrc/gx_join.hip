@@ -2936,6 +2936,325 @@ k_pj3_probe_direct(const K* __restrict__ pkeys, const int32_t* __restrict__ pidx
   }
 }
 
+// ================================================================================================
+// Round 5, second form: the tag probe WITHOUT the software pipeline and WITHOUT the staging buffers (knob 4).
+//
+// Fresh counters of k_pj2_probe_pipe (profiles/r5_run1_pmc_sq_join_k0.txt): 571 VALU + 274 SALU wave-instructions per 256 rows,
+// the VALU pipes ~58 % busy, 61 % of the wave cycles waiting -- at FOUR waves per SIMD, because 64 KiB of tags + 92 KiB of pair
+// staging fill the LDS with one 16-wave gang.  The direct probe (k_pj3, above) showed that pairs need no staging: the single
+// matches of a piece are numbered through one LDS counter, one returning atomic reserves their run, and the pairs wait in
+// registers for one iteration.  Here the tags stay (they settle 9 of 10 misses without a slot read and bound every row's work:
+// the direct probe's waves ran 16 chain steps per trip for their slowest lane), the staging goes, a workgroup is 1024 threads
+// with 2 rows each in <= 64 registers, and TWO workgroups share a CU: 8 waves per SIMD cover the latencies the pipeline was
+// built to hide, and the two workgroups' barriers and tag reloads overlap.
+// ================================================================================================
+constexpr int PT_BT = 1024;
+template <typename K, int R, int WPE>
+__global__ void __launch_bounds__(PT_BT, WPE)
+k_pj4_probe_tags(const K* __restrict__ pkeys, const int32_t* __restrict__ pidx, PieceTable pt, int pbits,
+                 const Slot<K>* __restrict__ slots, uint32_t log2cap, int left_outer, int32_t* __restrict__ out_probe,
+                 int32_t* __restrict__ out_build, int64_t capacity, unsigned long long* cursor)
+{
+  typedef typename SlotRaw<K>::type Raw;
+  constexpr uint32_t SUB = 1u << PJ_SUB_LOG2;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const uint32_t* s_tagw = reinterpret_cast<const uint32_t*>(smem);  // 64 KiB of tags + the 32 tags that follow them
+  __shared__ PpPiece s_piece[2];
+  __shared__ unsigned int s_cnt[2];
+  __shared__ unsigned long long s_base[2];
+  const unsigned tid  = threadIdx.x;
+  const unsigned lane = lane_id();
+  const unsigned w    = tid / GX_WAVE;
+  const int P         = 1 << pbits;
+  const int LISTP     = P / PJ_NR;
+  const uint64_t mask = (1ull << log2cap) - 1;
+  const uint8_t* gtags = reinterpret_cast<const uint8_t*>(slots + (mask + 1));
+  const unsigned x0 = pj_xcc();
+  unsigned ylist    = 0;
+  auto take_piece = [&](PpPiece& pc) {  // wave 0: ticket of the XCD's list, partition, region (as k_pj2_probe_pipe's service wave)
+    pc.valid = 0;
+    pc.c0 = pc.c1 = 0;
+    pc.part = 0;
+    unsigned int g = 0xFFFFFFFFu, y = 0;
+    if (lane == 0) {
+      while (ylist < PJ_NR) {
+        y                      = (x0 + ylist) % PJ_NR;
+        const unsigned int nch = pt.list_chunk0[y + 1] - pt.list_chunk0[y];
+        if (nch) {
+          const unsigned int t = atomicAdd(&pt.ticket[y].v, 1u);
+          if (t < nch) {
+            g = pt.list_chunk0[y] + t;
+            break;
+          }
+        }
+        ++ylist;
+      }
+    }
+    g     = (unsigned int)__builtin_amdgcn_readfirstlane((int)g);
+    y     = (unsigned int)__builtin_amdgcn_readfirstlane((int)y);
+    ylist = (unsigned int)__builtin_amdgcn_readfirstlane((int)ylist);
+    if (g == 0xFFFFFFFFu) return;
+    unsigned int part = 0;
+    bool hit = false;
+    for (int e = (int)lane; e < LISTP; e += GX_WAVE) {
+      const int p           = (int)y * LISTP + e;
+      const unsigned int lo = pt.chunk0[p * pt.nr], hi = pt.chunk0[(p + 1) * pt.nr];
+      if (lo <= g && g < hi) {
+        part = (unsigned int)p;
+        hit  = true;
+      }
+    }
+    uint64_t hb = ballot(hit);
+    part        = shfl(part, __builtin_ctzll(hb));
+    unsigned int reg = part * (unsigned int)pt.nr, loc = 0;
+    hit = false;
+    if ((int)lane < pt.nr) {
+      const unsigned int e  = part * (unsigned int)pt.nr + lane;
+      const unsigned int lo = pt.chunk0[e], hi = pt.chunk0[e + 1];
+      if (lo <= g && g < hi) {
+        reg = e;
+        loc = g - lo;
+        hit = true;
+      }
+    }
+    hb           = ballot(hit);
+    const int sr = __builtin_ctzll(hb);
+    reg          = shfl(reg, sr);
+    loc          = shfl(loc, sr);
+    unsigned long long r0, r1;
+    if (pt.start) {
+      r0 = pt.start[reg];
+      r1 = pt.start[reg + 1];
+    } else {
+      unsigned int c = pt.fill[reg];
+      c              = c < pt.cap ? c : pt.cap;
+      r0             = (unsigned long long)reg * pt.cap;
+      r1             = r0 + c;
+    }
+    constexpr unsigned long long ROWS = (unsigned long long)PT_BT * R;
+    pc.c0    = r0 + (unsigned long long)loc * ROWS;
+    pc.c1    = pc.c0 + ROWS < r1 ? pc.c0 + ROWS : r1;
+    pc.part  = part;
+    pc.valid = 1;
+  };
+  if (tid < 2) s_cnt[tid] = 0;
+  if (w == 0) {
+    PpPiece pc;
+    take_piece(pc);
+    if (lane == 0) s_piece[0] = pc;
+  }
+  __syncthreads();
+  int32_t h_idx[R], h_first[R];
+  uint32_t h_pos[R];
+  uint32_t h_live = 0;
+#pragma unroll
+  for (int j = 0; j < R; ++j) {
+    h_idx[j] = h_first[j] = 0;
+    h_pos[j] = 0;
+  }
+  unsigned long long pend = 0;
+  uint32_t cur_part       = 0xFFFFFFFFu;  // the partition whose tags sit in LDS
+  for (int t = 0;; ++t) {
+    const PpPiece pc = s_piece[t & 1];
+    const bool valid = pc.valid != 0;  // block-uniform
+    K key[R];
+    int32_t idx[R];
+    uint32_t rows = 0;
+    if (valid) {
+#pragma unroll
+      for (int j = 0; j < R; ++j) {
+        const unsigned long long i  = pc.c0 + (unsigned long long)(j * PT_BT) + tid;
+        const unsigned long long ic = i < pc.c1 ? i : pc.c0;
+        key[j] = __builtin_nontemporal_load(&pkeys[ic]);
+        idx[j] = __builtin_nontemporal_load(&pidx[ic]);
+        if (i < pc.c1) rows |= 1u << j;
+      }
+    }
+    if (tid == 0) s_base[(t & 1) ^ 1] = pend;
+    if (w == 0 && valid) {
+      PpPiece nx;
+      take_piece(nx);
+      if (lane == 0) s_piece[(t + 1) & 1] = nx;
+    }
+    if (valid && pc.part != cur_part) {  // block-uniform: the tags of the piece's partition (every earlier reader passed the last barrier)
+      const uint4* src = reinterpret_cast<const uint4*>(gtags + (((uint64_t)pc.part << PJ_SUB_LOG2) >> 1));
+      uint4* dst       = reinterpret_cast<uint4*>(smem);
+      for (uint32_t i = tid; i < SUB / 2 / 16; i += PT_BT) dst[i] = src[i];
+      if (tid == 0) {  // the 32 tags behind the sub-table's own; behind the LAST sub-table the table wraps to slot 0
+        const bool last   = (((uint64_t)pc.part + 1) << PJ_SUB_LOG2) > mask;
+        dst[SUB / 2 / 16] = last ? *reinterpret_cast<const uint4*>(gtags) : src[SUB / 2 / 16];
+      }
+      cur_part = pc.part;
+      __syncthreads();
+    }
+    uint32_t m[R], pos[R];
+    int32_t first[R];
+    uint32_t live = 0;
+    if (valid) {
+      const uint64_t sub_base = (uint64_t)pc.part << PJ_SUB_LOG2;
+      uint32_t li[R];
+      uint64_t cand[R];
+      uint32_t ended = 0;
+      Raw sv[R];
+#pragma unroll
+      for (int j = 0; j < R; ++j) {
+        m[j]     = 0;
+        first[j] = NO_MATCH;
+        cand[j]  = 0;
+        li[j]    = 0;
+        if ((rows >> j) & 1u) {
+          const uint64_t prod = (uint64_t)key[j] * 0x9E3779B97F4A7C15ull;
+          li[j]               = (uint32_t)((prod >> (64 - log2cap)) - sub_base);
+          uint32_t tg         = (uint32_t)(prod >> (60 - log2cap)) & 15u;
+          tg                  = tg ? tg : 8u;
+          const uint32_t tagpat = tg * 0x11111111u;
+          const uint32_t w0 = s_tagw[li[j] >> 3], w1 = s_tagw[(li[j] >> 3) + 1], w2 = s_tagw[(li[j] >> 3) + 2];
+          const uint32_t sh = (li[j] & 7u) * 4u;
+          const uint32_t x0w = __builtin_amdgcn_alignbit(w1, w0, sh), x1w = __builtin_amdgcn_alignbit(w2, w1, sh);
+          const uint32_t y0 = x0w ^ tagpat, y1 = x1w ^ tagpat;
+          const uint32_t z0 = ~(((x0w & 0x77777777u) + 0x77777777u) | x0w) & 0x88888888u;  // empty slots
+          const uint32_t z1 = ~(((x1w & 0x77777777u) + 0x77777777u) | x1w) & 0x88888888u;
+          const uint32_t m0 = ~(((y0 & 0x77777777u) + 0x77777777u) | y0) & 0x88888888u;    // tag matches
+          const uint32_t m1 = ~(((y1 & 0x77777777u) + 0x77777777u) | y1) & 0x88888888u;
+          const uint32_t c0 = m0 & ((z0 & (0u - z0)) - 1u);                                 // ... below the first empty one
+          const uint32_t c1 = z0 ? 0u : (m1 & ((z1 & (0u - z1)) - 1u));
+          cand[j]           = (uint64_t)c0 | ((uint64_t)c1 << 32);
+          if (z0 | z1) ended |= 1u << j;
+        }
+      }
+#pragma unroll
+      for (int j = 0; j < R; ++j)  // the first candidate slot of every row that has one: R loads in flight per lane
+        if (cand[j]) sv[j] = *reinterpret_cast<const Raw*>(&slots[(sub_base + li[j] + ((uint32_t)__builtin_ctzll(cand[j]) >> 2)) & mask]);
+#pragma unroll
+      for (int j = 0; j < R; ++j) {
+        if (!((rows >> j) & 1u)) continue;
+        if (cand[j]) {
+          K sk;
+          int32_t sr;
+          unpack_slot(sv[j], sk, sr);
+          if (sk == key[j]) {  // a tagged slot is never empty
+            m[j]     = 1;
+            first[j] = sr;
+          }
+          cand[j] &= cand[j] - 1;
+        }
+        // rare: more tag candidates in the window (1 in ~25 rows), or a chain that runs past 16 slots (1e-5): finished in place
+        uint64_t cnd64 = cand[j];
+        uint64_t wb    = sub_base + li[j];
+        while (cnd64) {
+          K k;
+          int32_t r;
+          load_slot<K>(&slots[(wb + ((uint32_t)__builtin_ctzll(cnd64) >> 2)) & mask], k, r);
+          if (k == key[j]) {
+            if (m[j] == 0) first[j] = r;
+            ++m[j];
+          }
+          cnd64 &= cnd64 - 1;
+        }
+        if (!((ended >> j) & 1u)) {
+          const uint32_t tagpat = tag_of<K>(key[j], log2cap) * 0x11111111u;
+          const uint32_t* gtagw = reinterpret_cast<const uint32_t*>(gtags);
+          wb                    = (wb + 16) & mask;
+          bool done             = false;
+          while (!done) {  // further windows of 8 slots, tags from global memory
+            if (wb + 8 > mask) {  // the window would wrap around the table's end: walk the slots themselves
+              for (;;) {
+                K k;
+                int32_t r;
+                load_slot<K>(&slots[wb & mask], k, r);
+                if (r == EMPTY_ROW) break;
+                if (k == key[j]) {
+                  if (m[j] == 0) first[j] = r;
+                  ++m[j];
+                }
+                ++wb;
+              }
+              break;
+            }
+            uint32_t cnd = 0;
+            done         = scan_tags8_global(gtagw, (uint32_t)wb, tagpat, cnd);
+            while (cnd) {
+              K k;
+              int32_t r;
+              load_slot<K>(&slots[wb + ((uint32_t)__builtin_ctz(cnd) >> 2)], k, r);
+              if (k == key[j]) {
+                if (m[j] == 0) first[j] = r;
+                ++m[j];
+              }
+              cnd &= cnd - 1;
+            }
+            wb += 8;
+          }
+        }
+      }
+      // duplicate build keys: such a row reserves its own run and walks its chain again
+#pragma unroll
+      for (int j = 0; j < R; ++j) {
+        if (left_outer && ((rows >> j) & 1u) && m[j] == 0) m[j] = 1;  // (row, JoinNoMatch): first[j] is NO_MATCH
+        if (m[j] > 1) {
+          unsigned long long gp = atomicAdd(cursor, (unsigned long long)m[j]);
+          uint64_t hh           = slot_of<K>(key[j], log2cap);
+          for (;;) {
+            K k;
+            int32_t r;
+            load_slot<K>(&slots[hh], k, r);
+            if (r == EMPTY_ROW) break;
+            if (k == key[j]) {
+              if ((int64_t)gp < capacity) {
+                out_probe[gp] = idx[j];
+                out_build[gp] = r;
+              }
+              ++gp;
+            }
+            hh = (hh + 1) & mask;
+          }
+          m[j] = 0;
+        }
+      }
+      uint32_t tot = 0;
+#pragma unroll
+      for (int j = 0; j < R; ++j) {
+        const uint64_t bb = ballot(m[j] == 1);
+        pos[j]            = tot + (uint32_t)__builtin_popcountll(bb & lanemask_lt());
+        tot += (uint32_t)__builtin_popcountll(bb);
+        if (m[j] == 1) live |= 1u << j;
+      }
+      uint32_t woff = 0;
+      if (lane == 0 && tot) woff = atomicAdd(&s_cnt[t & 1], tot);
+      woff = (uint32_t)__builtin_amdgcn_readfirstlane((int)woff);
+#pragma unroll
+      for (int j = 0; j < R; ++j) pos[j] += woff;
+    }
+    __syncthreads();
+    {
+      const unsigned long long gb = s_base[(t & 1) ^ 1];
+#pragma unroll
+      for (int j = 0; j < R; ++j) {
+        if ((h_live >> j) & 1u) {
+          const unsigned long long gp = gb + h_pos[j];
+          if ((int64_t)gp < capacity) {
+            __builtin_nontemporal_store(h_idx[j], &out_probe[gp]);
+            __builtin_nontemporal_store(h_first[j], &out_build[gp]);
+          }
+        }
+      }
+    }
+    if (!valid) break;
+    if (tid == 0) {
+      const unsigned int c = s_cnt[t & 1];
+      pend                 = c ? atomicAdd(cursor, (unsigned long long)c) : 0ull;
+      s_cnt[t & 1]         = 0;
+    }
+    h_live = live;
+#pragma unroll
+    for (int j = 0; j < R; ++j) {
+      h_idx[j]   = idx[j];
+      h_first[j] = first[j];
+      h_pos[j]   = pos[j];
+    }
+  }
+}
+
 // optional per-kernel timing of the partitioned probe with HIP events on the caller's stream (bench.py)
 struct JoinProfile {
   bool enabled = false, created = false, marked = false;
@@ -3082,7 +3401,7 @@ template <typename K>
 static bool pj2_applies(int64_t n, int pbits)
 {
   const size_t lds = (size_t)16384 * sizeof(K) + ((size_t)8 << pbits) + 512;
-  return g_pj_spec && (g_pj_probe == 0 || g_pj_probe == 2 || g_pj_probe == 3) && pbits >= 3 && pbits <= 12 && lds <= (size_t)160 * 1024 && n > 0 &&
+  return g_pj_spec && g_pj_probe != 1 && pbits >= 3 && pbits <= 12 && lds <= (size_t)160 * 1024 && n > 0 &&
          (g_pj_spec == 2 || n > 4 * (int64_t)16384 * 256);  // 2: forced for any n (tests)
 }
 template <typename K>
@@ -3141,20 +3460,28 @@ int probe_partitioned_impl2(const K* keys, int64_t n, const Slot<K>* slots, uint
   // ---- speculative pass
   hipLaunchKernelGGL(kspec, dim3((unsigned)grid), dim3(1024), lds_s, s, keys, n, plan2, plan, pbits, rrows, cap, ntiles, pkeys, pidx, part_of, row0, payload);
   jprof_mark(2, s);
-  // the probe kernel: the LDS-tag gang probe, or (knob 2 / 3) the L2-resident direct probe with 4 / 2 rows per thread
-  const bool direct        = g_pj_probe == 2 || g_pj_probe == 3;
-  auto kdirect             = g_pj_probe == 3 ? k_pj3_probe_direct<K, 2, 8> : k_pj3_probe_direct<K, 4, 6>;
-  const unsigned piece_rows = direct ? (unsigned)PD_BT * (g_pj_probe == 3 ? 2u : 4u) : (unsigned)PP_ROWS;
-  static int direct_wgs[2] = {0, 0};  // resident workgroups per CU of the two instantiations (occupancy query, once)
-  if (direct && direct_wgs[g_pj_probe - 2] == 0) {
+  // the probe kernel: 0 the pipelined LDS-tag gang probe; 2 / 3 the L2-resident direct probe with 4 / 2 rows per thread (round 5,
+  // measured negative); 4 / 5 the tag probe in its occupancy form (round 5: no pipeline, no staging, two workgroups per CU), 2 / 4 rows
+  typedef void (*ProbeK)(const K*, const int32_t*, PieceTable, int, const Slot<K>*, uint32_t, int, int32_t*, int32_t*, int64_t, unsigned long long*);
+  const int pk        = g_pj_probe;
+  const bool alt      = pk >= 2;
+  ProbeK kalt         = pk == 2 ? (ProbeK)k_pj3_probe_direct<K, 4, 6> : pk == 3 ? (ProbeK)k_pj3_probe_direct<K, 2, 8>
+                        : pk == 4 ? (ProbeK)k_pj4_probe_tags<K, 2, 8> : (ProbeK)k_pj4_probe_tags<K, 4, 4>;
+  const unsigned alt_bt     = (pk == 2 || pk == 3) ? (unsigned)PD_BT : (unsigned)PT_BT;
+  const unsigned alt_rpt    = (pk == 2 || pk == 5) ? 4u : 2u;
+  const size_t alt_lds      = (pk == 4 || pk == 5) ? ((size_t)1 << (PJ_SUB_LOG2 - 1)) + PP_TAGPAD : 0;
+  const unsigned piece_rows = alt ? alt_bt * alt_rpt : (unsigned)PP_ROWS;
+  static int alt_wgs[4] = {0, 0, 0, 0};  // resident workgroups per CU of the alternative kernels (occupancy query, once each)
+  if (alt && alt_wgs[pk - 2] == 0) {
+    if (alt_lds) GX_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(kalt), hipFuncAttributeMaxDynamicSharedMemorySize, (int)alt_lds));
     int nb = 0;
-    GX_HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, reinterpret_cast<const void*>(kdirect), PD_BT, 0));
-    direct_wgs[g_pj_probe - 2] = nb > 0 ? nb : 1;
+    GX_HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, reinterpret_cast<const void*>(kalt), (int)alt_bt, alt_lds));
+    alt_wgs[pk - 2] = nb > 0 ? nb : 1;
   }
   auto launch_probe = [&](const PieceTable& t) {
-    if (direct) {
-      const int64_t g = (int64_t)(num_cus > 0 ? num_cus : 256) * direct_wgs[g_pj_probe - 2];
-      hipLaunchKernelGGL(kdirect, dim3((unsigned)g), dim3(PD_BT), 0, s, pkeys, pidx, t, pbits, slots, lg, left_outer, out_probe, out_build, capacity, cur);
+    if (alt) {
+      const int64_t g = (int64_t)(num_cus > 0 ? num_cus : 256) * alt_wgs[pk - 2];
+      hipLaunchKernelGGL(kalt, dim3((unsigned)g), dim3(alt_bt), alt_lds, s, pkeys, pidx, t, pbits, slots, lg, left_outer, out_probe, out_build, capacity, cur);
     } else {
       const int64_t g = num_cus > 0 ? num_cus : 256;
       hipLaunchKernelGGL(kprobe, dim3((unsigned)g), dim3(PP_BT), lds_p, s, pkeys, pidx, t, pbits, slots, lg, left_outer, out_probe, out_build, capacity, cur);
@@ -3600,7 +3927,7 @@ int gx_join_profile_read(float* ms3)
   return 0;
 }
 
-void gx_join_set_probe_kernel(int which) { gx::join::g_pj_probe = (which >= 1 && which <= 3) ? which : 0; }
+void gx_join_set_probe_kernel(int which) { gx::join::g_pj_probe = (which >= 1 && which <= 5) ? which : 0; }
 void gx_join_set_partition_mode(int speculative, int early_loads)
 {
   gx::join::g_pj_spec        = speculative == 2 ? 2 : (speculative ? 1 : 0);

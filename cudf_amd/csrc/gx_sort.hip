@@ -46,6 +46,7 @@ constexpr int NRANGE     = 8;    // input ranges == XCDs: each gets its own look
 // Whether every cell fits is decided ON THE DEVICE (level 1 raises hy.overflow when a cell outgrows its slot,
 // k_plan2 checks the cell counts); when one does not (skewed keys) the remaining hybrid kernels turn into
 // no-ops and the LSD passes below run instead.
+constexpr int CS_MAXBITS = 15;   // counting sort of narrow key ranges (k_cs_*): 32768 bins = 128 KiB of LDS counters, one 1024-thread workgroup per CU
 constexpr int NB2MAX     = 1024; // level-1 bins: row stride of the cell tables (cursor path: <= 10 bits)
 constexpr int NB9        = 512;  // bins of the 9-bit look-back level-1 pass
 
@@ -112,6 +113,12 @@ struct FastPlan {
   int32_t state;   // 0 not tried / given up before level 0; 1 planned from the sample; 2 failed the check after level 0
                    // (the look-back path then runs from scratch); 3 verified (the look-back path is skipped);
                    // 4 the sample shows a key range too narrow for two partition levels: straight to the LSD passes
+                   // 5 (round 5) the sample shows at most CS_MAXBITS varying low bits: COUNTING SORT (k_cs_*; a key outside that
+                   //   range, seen by the count's exact check, turns it into 4)
+  int32_t cs_bits;              // counting sort: the low bits that vary (bins = 1 << cs_bits)
+  uint32_t cs_fail;             // k_cs_count: a key differs from cs_base above cs_bits (the sample missed it)
+  uint32_t cs_groups;           // k_cs_scan: non-empty bins
+  unsigned long long cs_base;   // the bits all (sampled) keys share above cs_bits, sortable form
   int32_t fail;    // level 0: a slot outgrew its capacity
   int32_t stride;  // the sample takes every stride-th 64-key chunk
   int32_t hist_ready;  // the first sample kernel's speculative top-byte histogram IS the level-0 digit's (full-range keys)
@@ -1887,7 +1894,7 @@ __device__ __forceinline__ void hf_give_up(SortPlan* plan, int state)
 //   2 (after level 0)  the verdict + everything level 1, k_plan2 and the local sort need
 __global__ void __launch_bounds__(BINS) k_hf_plan(SortPlan* plan, int stage, int key_bits, int64_t n, int bits2, int cell_max, int stride,
                                                   int64_t range_rows, int tile_rows, unsigned long long slot_rows, float margin, int min_shift2,
-                                                  int bits2_max, unsigned long long cell_budget = 0, int signed_keys = 0)
+                                                  int bits2_max, unsigned long long cell_budget = 0, int signed_keys = 0, int allow_counting = 0)
 {
   // signed_keys: the sign fold of the level-0 digit may be planned (HybridPlan::fold; never for the sharded sort, whose digit
   // positions come from the masks of all ranks)
@@ -1908,7 +1915,19 @@ __global__ void __launch_bounds__(BINS) k_hf_plan(SortPlan* plan, int stage, int
       // all sampled keys equal: let the look-back path look at the whole column.  Too few varying bits below level 1 in
       // the sample (narrow key ranges: the LSD passes are the right tool): state 4 also spares the look-back path's
       // up-front read -- declining the hybrid path is always safe, the LSD passes sort anything
-      if (t == 0) hf_give_up(plan, V == 0 ? 0 : 4);
+      // Round 5: when ALL varying bits are the low CS_MAXBITS or fewer (ids in [100, 10001): the reference benchmark's own
+      // distribution, sort.cpp:24-26) keys-only sorting is a histogram + a fill -- state 5, k_cs_count / k_cs_scan / k_cs_fill.
+      // The count verifies the sample's claim on every key; an outlier sends the column to the LSD passes (state 4).
+      if (t == 0) {
+        const int cs_top = V ? 63 - __builtin_clzll(V) : 0;
+        const bool cs    = allow_counting && V != 0 && cs_top < CS_MAXBITS;
+        const unsigned long long ormask = hy.or_mask;
+        hf_give_up(plan, V == 0 ? 0 : (cs ? 5 : 4));
+        if (cs) {
+          hf.cs_bits = cs_top + 1;
+          hf.cs_base = ormask & ~((1ull << (cs_top + 1)) - 1ull);
+        }
+      }
       return;
     }
     const bool spec_ok = shift0 == key_bits - 8;
@@ -2071,11 +2090,170 @@ __global__ void __launch_bounds__(BINS) k_hf_plan(SortPlan* plan, int stage, int
   }
 }
 
+// ------------------------------------------------------------------------------------------
+// Round 5: COUNTING SORT of keys whose varying bits are the low CS_MAXBITS or fewer (FastPlan::state 5) -- keys only, so
+// the sorted column is fully described by how often each value occurs: one read of the column (a histogram in LDS), a
+// scan of <= 32768 counters, one write (every output tile looks up the value runs that cover it).  24 -> 16 B/row against
+// the two LSD passes such a column took (13.6 ms per 1e9 rows for the reference benchmark's [100, 10001) keys), and the
+// LSD plan's own 8 B/row histogram read is skipped as well.  cub::DeviceRadixSort behind cudf::sort has no such path
+// (cpp/src/sort/sort_radix.cu:52-161); the result is the same bytes.
+// ------------------------------------------------------------------------------------------
+constexpr int CS_BT      = 1024;
+constexpr int CS_TILE    = 4096;            // output elements per fill tile
+template <typename KeyT, int KIND>
+__global__ void __launch_bounds__(CS_BT) k_cs_count(const KeyT* __restrict__ in, int64_t n, KeyT desc_mask, SortPlan* plan, uint32_t* __restrict__ ghist)
+{
+  FastPlan& hf = plan->hf;
+  if (hf.state != 5) return;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  uint32_t* s_hist   = reinterpret_cast<uint32_t*>(smem);
+  const int bits     = hf.cs_bits;
+  const uint32_t nb  = 1u << bits;
+  const KeyT lowmask = (KeyT)(nb - 1u);
+  const KeyT base    = (KeyT)hf.cs_base;
+  for (uint32_t i = threadIdx.x; i < nb; i += CS_BT) s_hist[i] = 0;
+  __syncthreads();
+  constexpr int VEC = 16 / sizeof(KeyT);  // keys per 16-byte load
+  typedef KeyT VecT __attribute__((ext_vector_type(VEC)));
+  KeyT bad = 0;
+  auto count1 = [&](KeyT raw) {
+    const KeyT k = to_sortable<KeyT, KIND>(raw, desc_mask);
+    bad |= (KeyT)((k ^ base) & (KeyT)~lowmask);
+    atomicAdd(&s_hist[(uint32_t)(k & lowmask)], 1u);
+  };
+  // (a sliced column may start at any element: the keys before the first 16-byte boundary and behind the last one go one by one)
+  int64_t head = (int64_t)(((16u - (uint32_t)(reinterpret_cast<uintptr_t>(in) & 15u)) & 15u) / sizeof(KeyT));
+  if (head > n) head = n;
+  const int64_t nvec   = (n - head) / VEC;
+  const VecT* vin      = reinterpret_cast<const VecT*>(in + head);
+  const int64_t stride = (int64_t)gridDim.x * CS_BT;
+  constexpr int U = 4;  // independent 16-byte loads in flight per lane
+  int64_t i = (int64_t)blockIdx.x * CS_BT + threadIdx.x;
+  for (; i + (U - 1) * stride < nvec; i += U * stride) {
+    VecT v[U];
+#pragma unroll
+    for (int u = 0; u < U; ++u) v[u] = __builtin_nontemporal_load(&vin[i + u * stride]);
+#pragma unroll
+    for (int u = 0; u < U; ++u)
+#pragma unroll
+      for (int e = 0; e < VEC; ++e) count1(v[u][e]);
+  }
+  for (; i < nvec; i += stride) {
+    const VecT v = vin[i];
+#pragma unroll
+    for (int e = 0; e < VEC; ++e) count1(v[e]);
+  }
+  if (blockIdx.x == 0) {
+    const int64_t tail0 = head + nvec * VEC;
+    if ((int64_t)threadIdx.x < head) count1(in[threadIdx.x]);
+    if ((int64_t)threadIdx.x < n - tail0) count1(in[tail0 + threadIdx.x]);
+  }
+  if (__syncthreads_or(bad != 0)) {  // (also the barrier before the flush)
+    if (threadIdx.x == 0 && !__hip_atomic_load(&hf.cs_fail, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) atomicExch(&hf.cs_fail, 1u);
+  }
+  for (uint32_t b = threadIdx.x; b < nb; b += CS_BT) {
+    const uint32_t c = s_hist[b];
+    if (c) atomicAdd(&ghist[b], c);
+  }
+}
+
+// one workgroup: counts -> first output position of every NON-EMPTY value (nz_start[g], nz_val[g], g < groups; nz_start[groups] = n);
+// the verdict: every key inside the sampled range and the counts add up -> the LSD passes become no-ops; else state 4
+__global__ void __launch_bounds__(CS_BT) k_cs_scan(SortPlan* plan, const uint32_t* __restrict__ ghist, uint32_t* __restrict__ nz_start,
+                                                   uint32_t* __restrict__ nz_val, int64_t n, int npass)
+{
+  FastPlan& hf = plan->hf;
+  if (hf.state != 5) return;
+  __shared__ uint32_t s_tmp[CS_BT / GX_WAVE + 1];
+  const uint32_t nb  = 1u << hf.cs_bits;
+  const uint32_t per = (nb + CS_BT - 1) / CS_BT;  // consecutive bins per thread (<= 32)
+  const uint32_t b0  = threadIdx.x * per;
+  uint32_t sum = 0, cnt = 0;
+  for (uint32_t k = 0; k < per; ++k) {
+    const uint32_t b = b0 + k;
+    const uint32_t c = b < nb ? ghist[b] : 0u;
+    sum += c;
+    cnt += c ? 1u : 0u;
+  }
+  uint32_t total, groups;
+  uint32_t run = block_exclusive_scan<CS_BT>(sum, 0u, SumOp(), s_tmp, &total);
+  uint32_t g   = block_exclusive_scan<CS_BT>(cnt, 0u, SumOp(), s_tmp, &groups);
+  const bool good = (int64_t)total == n && hf.cs_fail == 0;
+  if (!good) {
+    if (threadIdx.x == 0) hf.state = 4;  // an outlier the sample did not see: the LSD passes sort the column
+    return;
+  }
+  for (uint32_t k = 0; k < per; ++k) {
+    const uint32_t b = b0 + k;
+    const uint32_t c = b < nb ? ghist[b] : 0u;
+    if (c) {
+      nz_start[g] = run;
+      nz_val[g]   = b;
+      ++g;
+      run += c;
+    }
+  }
+  if (threadIdx.x == 0) {
+    nz_start[groups] = total;
+    hf.cs_groups     = groups;
+    for (int p = 0; p < npass; ++p) plan->pass_skip[p] = 1;  // as k_plan2 does for a column the hybrid path has sorted
+    plan->num_active = -1;
+    __threadfence();
+    plan->hy.ok = 1;
+  }
+}
+
+// every tile of CS_TILE output keys: the value runs that cover it (a bisection of nz_start by wave 0), then one value per element
+template <typename KeyT, int KIND>
+__global__ void __launch_bounds__(256) k_cs_fill(KeyT* __restrict__ out, int64_t n, KeyT desc_mask, const SortPlan* plan,
+                                                 const uint32_t* __restrict__ nz_start, const uint32_t* __restrict__ nz_val)
+{
+  const FastPlan& hf = plan->hf;
+  if (hf.state != 5 || !plan->hy.ok) return;
+  __shared__ uint32_t s_start[CS_TILE + 2];
+  __shared__ uint32_t s_g[2];
+  const uint32_t groups = hf.cs_groups;
+  const KeyT base       = (KeyT)hf.cs_base;
+  const int64_t tiles   = div_up(n, (int64_t)CS_TILE);
+  for (int64_t tile = blockIdx.x; tile < tiles; tile += gridDim.x) {
+    const uint32_t lo = (uint32_t)(tile * CS_TILE);
+    const uint32_t hi = (uint32_t)((tile + 1) * CS_TILE < n ? (tile + 1) * CS_TILE : n);
+    if (threadIdx.x < 2) {  // last group whose start is <= position (lo | hi - 1)
+      const uint32_t pos = threadIdx.x == 0 ? lo : hi - 1;
+      uint32_t a = 0, b = groups;
+      while (b - a > 1) {
+        const uint32_t mid = (a + b) >> 1;
+        if (nz_start[mid] <= pos) a = mid; else b = mid;
+      }
+      s_g[threadIdx.x] = a;
+    }
+    __syncthreads();
+    const uint32_t g0 = s_g[0], g1 = s_g[1];
+    if (g0 == g1) {  // one value for the whole tile: the common case
+      const KeyT v = to_sortable<KeyT, KIND>((KeyT)(base | (KeyT)nz_val[g0]), desc_mask);
+      for (uint32_t i = lo + threadIdx.x; i < hi; i += 256) __builtin_nontemporal_store(v, &out[i]);
+    } else {  // g1 - g0 <= CS_TILE: every group holds at least one key
+      const uint32_t ng = g1 - g0 + 1;
+      for (uint32_t k = threadIdx.x; k < ng; k += 256) s_start[k] = nz_start[g0 + k];
+      __syncthreads();
+      for (uint32_t i = lo + threadIdx.x; i < hi; i += 256) {
+        uint32_t a = 0, b = ng;
+        while (b - a > 1) {
+          const uint32_t mid = (a + b) >> 1;
+          if (s_start[mid] <= i) a = mid; else b = mid;
+        }
+        __builtin_nontemporal_store(to_sortable<KeyT, KIND>((KeyT)(base | (KeyT)nz_val[g0 + a]), desc_mask), &out[i]);
+      }
+    }
+    __syncthreads();
+  }
+}
+
 // the look-back granules must start at zero for k_msd_pass / k_radix_pass -- which do not run when the cursor path has
 // sorted the column: then clearing half a gigabyte of status words is skipped too
 __global__ void __launch_bounds__(256) k_hf_clear_status(const SortPlan* plan, uint4* __restrict__ status, size_t n16)
 {
-  if (plan->hf.state == 3 && plan->hy.ok && !plan->hy.lsd_mode) return;  // (the X sort of the big cells runs the LSD passes too)
+  if ((plan->hf.state == 3 || plan->hf.state == 5) && plan->hy.ok && !plan->hy.lsd_mode) return;  // (the X sort of the big cells runs the LSD passes too)
   const size_t stride = (size_t)gridDim.x * 256;
   for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n16; i += stride) status[i] = uint4{0u, 0u, 0u, 0u};
 }
@@ -2477,6 +2655,7 @@ struct FastCfg {
   size_t slot_rows;  // keys the padded level-0 output holds
 };
 static thread_local int g_cursor          = 1;     // 0 disables the cursor path (A/B knob)
+static thread_local int g_counting        = 1;     // 0 disables the counting sort of narrow key ranges (A/B knob: the LSD passes run)
 static thread_local int g_exp             = 0;     // ablation bits of k_local_sort (measurement only: the result is NOT sorted under most of them)
 static thread_local float g_cursor_margin = 8.0f;  // standard deviations of slack per level-0 slot (tests: < 0 forces the fallback)
 template <typename KeyT, int KIND, bool HAS_VAL>
@@ -2620,7 +2799,20 @@ int sort_impl(const void* keys_in, void* keys_out, const int32_t* vals_in, int32
       KeyT* bufA      = keys_out ? static_cast<KeyT*>(keys_out) : ka_scratch;
       hipLaunchKernelGGL((k_hf_sample<KeyT, KIND, false>), dim3((unsigned)sblocks), dim3(256), 0, stream, kin, n, desc_mask, plan, fc.stride, frange);
       hipLaunchKernelGGL(k_hf_plan, dim3(1), dim3(BINS), 0, stream, plan, 0, (int)(8 * sizeof(KeyT)), n, fc.bits2, 1 << 13, fc.stride, frange, FT,
-                         (unsigned long long)fc.slot_rows, g_cursor_margin, MIN_SHIFT2, fc.bits2_max, 0ull, KIND == K_SIGNED ? 1 : 0);
+                         (unsigned long long)fc.slot_rows, g_cursor_margin, MIN_SHIFT2, fc.bits2_max, 0ull, KIND == K_SIGNED ? 1 : 0, g_counting);
+      {
+        // counting sort of a column whose varying bits are its low <= 15 (state 5; no-ops otherwise): histogram in LDS, scan, fill
+        // (counters | group starts | group values live in the cell tables, unused on this branch and zeroed above)
+        static bool cattr_set = false;
+        if (!cattr_set) {
+          GX_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(k_cs_count<KeyT, KIND>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)(4u << CS_MAXBITS)));
+          cattr_set = true;
+        }
+        hipLaunchKernelGGL((k_cs_count<KeyT, KIND>), dim3(256), dim3(CS_BT), (size_t)4 << CS_MAXBITS, stream, kin, n, desc_mask, plan, hist2);
+        hipLaunchKernelGGL(k_cs_scan, dim3(1), dim3(CS_BT), 0, stream, plan, (const uint32_t*)hist2, base2, xoff, n, NPASS);
+        hipLaunchKernelGGL((k_cs_fill<KeyT, KIND>), dim3(4096), dim3(256), 0, stream, bufA, n, desc_mask, (const SortPlan*)plan, (const uint32_t*)base2,
+                           (const uint32_t*)xoff);
+      }
       hipLaunchKernelGGL((k_hf_sample<KeyT, KIND, true>), dim3((unsigned)sblocks), dim3(256), 0, stream, kin, n, desc_mask, plan, fc.stride, frange);
       hipLaunchKernelGGL(k_hf_plan, dim3(1), dim3(BINS), 0, stream, plan, 1, (int)(8 * sizeof(KeyT)), n, fc.bits2, 1 << 13, fc.stride, frange, FT,
                          (unsigned long long)fc.slot_rows, g_cursor_margin, MIN_SHIFT2, fc.bits2_max);
@@ -3460,6 +3652,7 @@ void gx_sort_set_place_grid(int workgroups) { gx::sort::g_place_grid = workgroup
 
 void gx_sort_set_order_words(int enable) { gx::sort::g_order_words = enable ? 1 : 0; }
 
+void gx_sort_set_counting(int enable) { gx::sort::g_counting = enable ? 1 : 0; }
 void gx_sort_set_cursor_path(int enable, float margin_sigmas)
 {
   gx::sort::g_cursor        = enable ? 1 : 0;

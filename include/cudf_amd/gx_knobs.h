@@ -74,6 +74,9 @@ int gx_sort_big_info(const void* tmp, int64_t* info3_host, gx_stream_t stream);
  * decides.  enable = 0 switches it off (A/B); margin_sigmas = slack per slot in standard deviations of the estimate
  * (0 = default 8; a negative value makes every slot too small: TEST HOOK for the fallback). */
 void gx_sort_set_cursor_path(int enable, float margin_sigmas);
+/* A/B knob (per calling thread): 1 (default) = integer keys whose varying bits are their low 15 or fewer (sampled, then verified on
+ * every key) are sorted by a histogram + fill (the counting sort of round 5, FastPlan::state 5); 0 = the LSD passes, as before. */
+void gx_sort_set_counting(int enable);
 /* 0 = not tried, 2 = tried and rejected by the device (the look-back path ran), 3 = the cursor path sorted the column,
  * 4 = the sample showed a key range too narrow for two partition levels (the LSD passes ran, no up-front read of the column).
  * `tmp` is the scratch of that sort call; synchronises the stream. */

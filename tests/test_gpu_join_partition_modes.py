@@ -115,11 +115,13 @@ def test_speculative_partition_probe_default_threshold(gx):
         assert int(torch.unique(li).numel()) == l.size
 
 
-@pytest.mark.parametrize("dtype,shape,kernel", [(dt, sh, k) for k in (2, 3) for dt, sh in
+@pytest.mark.parametrize("dtype,shape,kernel", [(dt, sh, k) for k in (2, 3, 4, 5) for dt, sh in
                                                  (("int64", "uniform"), ("int64", "dup_build"), ("int64", "hot_key"), ("int64", "one_partition"),
                                                   ("int64", "edge_chains"), ("int32", "uniform"), ("int32", "edge_chains"))])
 def test_l2_resident_direct_probe_matches_oracle(gx, dtype, shape, kernel):
-    """Round 5: k_pj3_probe_direct (gx_join_set_probe_kernel 2 / 3: 4 / 2 rows per thread) -- the same partition pass, the same
+    """Round 5: the alternative probe kernels behind the same partition pass, region table and fallback gating.  4 / 5 =
+    k_pj4_probe_tags (the LDS-tag probe without pipeline and staging, 2 / 4 rows per thread): tag windows, in-place chain
+    continuation, wrap at the table's end, duplicate build keys.  2 / 3 = k_pj3_probe_direct (4 / 2 rows per thread) -- the same
     region table and fallback gating, but every row reads its home slot from the L2-resident sub-table and walks its chain there
     (no tags).  Inner and left-outer pairs against the oracle on uniform keys, duplicate build keys (rows that reserve their own
     output run), a hot key and one-partition inputs (slot overflow -> the gated exact sequence runs the same kernel over exact
