@@ -85,9 +85,11 @@ def parse():
                          "1-rank group on one GPU: what `--gpus N` executes, testable where only one device is visible")
     ap.add_argument("--preflight-only", action="store_true", help="multi-GPU: run the oracle-checked pre-flight of the sharded operators, print its verdict as one JSON line, exit")
     ap.add_argument("--preflight-timeout", type=float, default=90.0, help="multi-GPU: seconds the watchdog gives one pre-flight operator call")
-    ap.add_argument("--through-cpp", action="store_true",
-                    help="also time cudf::sort / hash_join::inner_join / groupby::aggregate through the C++ surface "
-                         "(tests/cpp/cudf_api_bench, default pooled mr) and report the ratio to the C-ABI numbers")
+    ap.add_argument("--through-cpp", dest="through_cpp", action="store_true", default=None,
+                    help="also time cudf::sort / sorted_order / hash_join::inner_join / groupby::aggregate through the C++ surface "
+                         "(tests/cpp/cudf_api_bench, default pooled mr) and report the ratio to the C-ABI numbers; default: on for "
+                         "--workload all on one GPU (the driver's line), off otherwise")
+    ap.add_argument("--no-through-cpp", dest="through_cpp", action="store_false")
     ap.add_argument("--cpu-baseline", dest="cpu", action="store_true", default=True)
     ap.add_argument("--no-cpu-baseline", dest="cpu", action="store_false")
     ap.add_argument("--cpu-rows", type=float, default=0, help="rows of the CPU-baseline sample (0 = per-workload default)")
@@ -1263,20 +1265,25 @@ def bench_stream(c, which):
             "dtype": "f64" if which == "reduce" else "int64", "roofline": roofline, "cpu_baseline": None, "checked": checked}
 
 
-def through_cpp(args, c, sort_ms, join_ms, groupby_ms):
+def through_cpp(args, c, sort_ms, order_ms, join_ms, groupby_ms):
     """What a caller of include/cudf/*.hpp pays (allocation through the pooled mr, result columns, the size read of
-    the join) next to the C-ABI numbers of this run.  The binary is built by __graft_entry__.build()."""
+    the join) next to the C-ABI numbers of this run: the same workloads through cudf::sort / cudf::sorted_order /
+    cudf::hash_join::inner_join / cudf::groupby::aggregate (cpp/include/cudf/sorting.hpp:103-108 and friends), in a
+    process of its own (tests/cpp/cudf_api_bench, built by __graft_entry__.build()), wall-clock per call."""
     import subprocess
     exe = os.path.join(ROOT, "tests", "cpp", "cudf_api_bench")
     if not os.path.exists(exe):
-        raise RuntimeError("tests/cpp/cudf_api_bench is missing: run `python __graft_entry__.py` (build) first")
+        return {"error": "tests/cpp/cudf_api_bench is missing: run `python __graft_entry__.py` (build) first"}
     c.torch.cuda.synchronize()
     c.torch.cuda.empty_cache()
-    out = subprocess.run([exe, str(c.n), str(args.steps), str(args.warmup)], check=True, capture_output=True, text=True,
-                         timeout=1200).stdout.strip().splitlines()[-1]
-    r = json.loads(out)
-    for k, ref in (("sort", sort_ms), ("join_probe", join_ms), ("groupby", groupby_ms)):
-        if ref:
+    try:
+        out = subprocess.run([exe, str(c.n), str(args.steps), str(args.warmup)], check=True, capture_output=True, text=True,
+                             timeout=600).stdout.strip().splitlines()[-1]
+        r = json.loads(out)
+    except Exception as e:  # noqa: BLE001 -- context, never the headline
+        return {"error": repr(e)}
+    for k, ref in (("sort", sort_ms), ("sorted_order", order_ms), ("join_probe", join_ms), ("groupby", groupby_ms)):
+        if ref and r.get(k + "_ms"):
             r[k + "_vs_c_abi"] = r[k + "_ms"] / ref
     r["note"] = ("wall-clock per call through the C++ API (allocation of outputs and scratch from the pooled mr included); "
                  "the C-ABI numbers beside it use caller-owned buffers")
@@ -1349,10 +1356,11 @@ def main():
                           **({"build_ms": b["build_ms"], "build_call_ms": b.get("build_call_ms"), "build_plus_probe_ms": b.get("build_plus_probe_ms"),
                               "build_rows_per_s": b.get("build_rows_per_s"), "partition_bits": b["partition_bits"], "join_keys": b.get("join_keys"),
                               "partition_mode": b.get("partition_mode")} if "build_ms" in b else {})}
-        if args.through_cpp and not c.sharded:
-            line["through_cpp"] = through_cpp(args, c, head["ms_per_step"] if wl in ("all", "sort") else None,
-                                              (blocks.get("join") or (head if wl == "join" else {})).get("ms_per_step"),
-                                              (blocks.get("groupby") or (head if wl == "groupby" else {})).get("ms_per_step"))
+        want_cpp = args.through_cpp if args.through_cpp is not None else (wl == "all" and c.n >= 100_000_000)
+        if want_cpp and not c.sharded:
+            blk = lambda name: (blocks.get(name) or (head if wl == name else {})).get("ms_per_step")
+            line["through_cpp"] = through_cpp(args, c, head["ms_per_step"] if wl in ("all", "sort") else None, blk("sorted_order"),
+                                              blk("join"), blk("groupby"))
         for r in [line.get("roofline")] + [line[k].get("roofline") for k in ("sorted_order", "join", "groupby") if k in line]:
             if not r:
                 continue

@@ -131,6 +131,7 @@ _PROTOS = {
     "gx_reduce": (_i, [_i, _p, _p, _i64, _i, _i, _p, _p, _p, _sz, _p]),
     "gx_scan": (_i, [_i, _p, _p, _i64, _i, _i, _p, _p, _sz, _p]),
     "gx_fill_random": (_i, [_i, _p, _i64, ctypes.c_uint64, _i64, _i64, _p]),
+    "gx_mix64_inplace": (_i, [_p, _i64, _p]),
     "gx_sequence_i32": (_i, [_p, _i64, ctypes.c_int32, _p]),
     "gx_copy_bytes": (_i, [_p, _p, ctypes.c_size_t, _p]),
     "gx_checksum": (_i, [_i, _p, _i64, _i, _p, _p]),

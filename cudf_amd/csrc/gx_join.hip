@@ -2949,7 +2949,13 @@ k_pj3_probe_direct(const K* __restrict__ pkeys, const int32_t* __restrict__ pidx
 // built to hide, and the two workgroups' barriers and tag reloads overlap.
 // ================================================================================================
 constexpr int PT_BT = 1024;
-template <typename K, int R, int WPE>
+constexpr int PT_PW = PT_BT / GX_WAVE - 1;  // 15 probe waves + the service wave
+// LDS_TAGS = false (knob 6 / 7): the tag windows are read from GLOBAL memory, i.e. from the XCD's L2 -- nothing is staged in LDS,
+// so the partition pass may cut the table into FEWER, larger sub-tables (2^20 slots: 512 KiB of tags, which the 4-MiB L2 holds
+// while the XCD's workgroups probe that partition): P = 256 instead of 2048 partitions means 64-row runs and an eighth of the
+// fill-counter atomics in k_pj2_scatter (the sort's level 0 moves 16 B/row at 4.4 TB/s with exactly that shape; the 2048-way
+// scatter reaches 3.1 - 3.3).  Slot reads then come from the Infinity Cache / HBM instead of the L2.
+template <typename K, int R, int WPE, bool LDS_TAGS>
 __global__ void __launch_bounds__(PT_BT, WPE)
 k_pj4_probe_tags(const K* __restrict__ pkeys, const int32_t* __restrict__ pidx, PieceTable pt, int pbits,
                  const Slot<K>* __restrict__ slots, uint32_t log2cap, int left_outer, int32_t* __restrict__ out_probe,
@@ -2957,11 +2963,13 @@ k_pj4_probe_tags(const K* __restrict__ pkeys, const int32_t* __restrict__ pidx, 
 {
   typedef typename SlotRaw<K>::type Raw;
   constexpr uint32_t SUB = 1u << PJ_SUB_LOG2;
+  constexpr int ROWS     = PT_PW * GX_WAVE * R;  // rows per piece
+  const int sub_log2     = (int)log2cap - pbits;  // slots per sub-table (LDS_TAGS: PJ_SUB_LOG2)
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const uint32_t* s_tagw = reinterpret_cast<const uint32_t*>(smem);  // 64 KiB of tags + the 32 tags that follow them
-  __shared__ PpPiece s_piece[2];
-  __shared__ unsigned int s_cnt[2];
-  __shared__ unsigned long long s_base[2];
+  __shared__ PpPiece s_piece[4];            // piece of iteration (t & 3), resolved two iterations ahead by the service wave
+  __shared__ unsigned int s_cnt[2];         // single matches of piece (t & 1)
+  __shared__ unsigned long long s_base[2];  // output position of piece (t & 1)
   const unsigned tid  = threadIdx.x;
   const unsigned lane = lane_id();
   const unsigned w    = tid / GX_WAVE;
@@ -2969,117 +2977,151 @@ k_pj4_probe_tags(const K* __restrict__ pkeys, const int32_t* __restrict__ pidx, 
   const int LISTP     = P / PJ_NR;
   const uint64_t mask = (1ull << log2cap) - 1;
   const uint8_t* gtags = reinterpret_cast<const uint8_t*>(slots + (mask + 1));
-  const unsigned x0 = pj_xcc();
-  unsigned ylist    = 0;
-  auto take_piece = [&](PpPiece& pc) {  // wave 0: ticket of the XCD's list, partition, region (as k_pj2_probe_pipe's service wave)
-    pc.valid = 0;
-    pc.c0 = pc.c1 = 0;
-    pc.part = 0;
-    unsigned int g = 0xFFFFFFFFu, y = 0;
-    if (lane == 0) {
-      while (ylist < PJ_NR) {
-        y                      = (x0 + ylist) % PJ_NR;
-        const unsigned int nch = pt.list_chunk0[y + 1] - pt.list_chunk0[y];
-        if (nch) {
-          const unsigned int t = atomicAdd(&pt.ticket[y].v, 1u);
-          if (t < nch) {
-            g = pt.list_chunk0[y] + t;
-            break;
-          }
-        }
-        ++ylist;
-      }
-    }
-    g     = (unsigned int)__builtin_amdgcn_readfirstlane((int)g);
-    y     = (unsigned int)__builtin_amdgcn_readfirstlane((int)y);
-    ylist = (unsigned int)__builtin_amdgcn_readfirstlane((int)ylist);
-    if (g == 0xFFFFFFFFu) return;
-    unsigned int part = 0;
-    bool hit = false;
-    for (int e = (int)lane; e < LISTP; e += GX_WAVE) {
-      const int p           = (int)y * LISTP + e;
-      const unsigned int lo = pt.chunk0[p * pt.nr], hi = pt.chunk0[(p + 1) * pt.nr];
-      if (lo <= g && g < hi) {
-        part = (unsigned int)p;
-        hit  = true;
-      }
-    }
-    uint64_t hb = ballot(hit);
-    part        = shfl(part, __builtin_ctzll(hb));
-    unsigned int reg = part * (unsigned int)pt.nr, loc = 0;
-    hit = false;
-    if ((int)lane < pt.nr) {
-      const unsigned int e  = part * (unsigned int)pt.nr + lane;
-      const unsigned int lo = pt.chunk0[e], hi = pt.chunk0[e + 1];
-      if (lo <= g && g < hi) {
-        reg = e;
-        loc = g - lo;
-        hit = true;
-      }
-    }
-    hb           = ballot(hit);
-    const int sr = __builtin_ctzll(hb);
-    reg          = shfl(reg, sr);
-    loc          = shfl(loc, sr);
-    unsigned long long r0, r1;
-    if (pt.start) {
-      r0 = pt.start[reg];
-      r1 = pt.start[reg + 1];
-    } else {
-      unsigned int c = pt.fill[reg];
-      c              = c < pt.cap ? c : pt.cap;
-      r0             = (unsigned long long)reg * pt.cap;
-      r1             = r0 + c;
-    }
-    constexpr unsigned long long ROWS = (unsigned long long)PT_BT * R;
-    pc.c0    = r0 + (unsigned long long)loc * ROWS;
-    pc.c1    = pc.c0 + ROWS < r1 ? pc.c0 + ROWS : r1;
-    pc.part  = part;
-    pc.valid = 1;
-  };
   if (tid < 2) s_cnt[tid] = 0;
-  if (w == 0) {
+
+  if (w == PT_PW) {
+    // ------------------------------------------------------------------ service wave: tickets, region search, reservations.
+    // Its global round trips (ticket atomic -> region table -> fill counter; the reservation atomic) run two iterations ahead of /
+    // one behind the probe waves and never sit between their barriers.
+    const unsigned x0 = pj_xcc();
+    unsigned ylist    = 0;
+    auto take_piece = [&](PpPiece& pc) {
+      pc.valid = 0;
+      pc.c0 = pc.c1 = 0;
+      pc.part = 0;
+      unsigned int g = 0xFFFFFFFFu, y = 0;
+      if (lane == 0) {
+        while (ylist < PJ_NR) {
+          y                      = (x0 + ylist) % PJ_NR;
+          const unsigned int nch = pt.list_chunk0[y + 1] - pt.list_chunk0[y];
+          if (nch) {
+            const unsigned int t = atomicAdd(&pt.ticket[y].v, 1u);
+            if (t < nch) {
+              g = pt.list_chunk0[y] + t;
+              break;
+            }
+          }
+          ++ylist;
+        }
+      }
+      g     = (unsigned int)__builtin_amdgcn_readfirstlane((int)g);
+      y     = (unsigned int)__builtin_amdgcn_readfirstlane((int)y);
+      ylist = (unsigned int)__builtin_amdgcn_readfirstlane((int)ylist);
+      if (g == 0xFFFFFFFFu) return;
+      unsigned int part = 0;
+      bool hit = false;
+      for (int e = (int)lane; e < LISTP; e += GX_WAVE) {
+        const int p           = (int)y * LISTP + e;
+        const unsigned int lo = pt.chunk0[p * pt.nr], hi = pt.chunk0[(p + 1) * pt.nr];
+        if (lo <= g && g < hi) {
+          part = (unsigned int)p;
+          hit  = true;
+        }
+      }
+      uint64_t hb = ballot(hit);
+      part        = shfl(part, __builtin_ctzll(hb));
+      unsigned int reg = part * (unsigned int)pt.nr, loc = 0;
+      hit = false;
+      if ((int)lane < pt.nr) {
+        const unsigned int e  = part * (unsigned int)pt.nr + lane;
+        const unsigned int lo = pt.chunk0[e], hi = pt.chunk0[e + 1];
+        if (lo <= g && g < hi) {
+          reg = e;
+          loc = g - lo;
+          hit = true;
+        }
+      }
+      hb           = ballot(hit);
+      const int sr = __builtin_ctzll(hb);
+      reg          = shfl(reg, sr);
+      loc          = shfl(loc, sr);
+      unsigned long long r0, r1;
+      if (pt.start) {
+        r0 = pt.start[reg];
+        r1 = pt.start[reg + 1];
+      } else {
+        unsigned int c = pt.fill[reg];
+        c              = c < pt.cap ? c : pt.cap;
+        r0             = (unsigned long long)reg * pt.cap;
+        r1             = r0 + c;
+      }
+      pc.c0    = r0 + (unsigned long long)loc * ROWS;
+      pc.c1    = pc.c0 + ROWS < r1 ? pc.c0 + ROWS : r1;
+      pc.part  = part;
+      pc.valid = 1;
+    };
     PpPiece pc;
     take_piece(pc);
     if (lane == 0) s_piece[0] = pc;
+    take_piece(pc);
+    if (lane == 0) s_piece[1] = pc;
+    __syncthreads();  // prologue barrier
+    unsigned long long pend = 0;
+    uint32_t cur_part       = 0xFFFFFFFFu;
+    for (int t = 0;; ++t) {
+      const PpPiece cur = s_piece[t & 3];
+      const bool valid  = cur.valid != 0;
+      if (lane == 0) s_base[(t & 1) ^ 1] = pend;  // the reservation of piece t - 1 (asked for behind last iteration's barrier)
+      if (valid) {
+        take_piece(pc);
+        if (lane == 0) s_piece[(t + 2) & 3] = pc;
+      }
+      if (LDS_TAGS && valid && cur.part != cur_part) {  // the probe waves reload their tags: same (block-uniform) test, same barrier
+        cur_part = cur.part;
+        __syncthreads();
+      }
+      __syncthreads();  // X(t): the counts of piece t are in
+      if (!valid) break;
+      if (lane == 0) {
+        const unsigned int c = s_cnt[t & 1];
+        pend                 = c ? atomicAdd(cursor, (unsigned long long)c) : 0ull;
+        s_cnt[t & 1]         = 0;  // next used two iterations from here, behind the next barrier
+      }
+    }
+    return;
   }
-  __syncthreads();
-  int32_t h_idx[R], h_first[R];
-  uint32_t h_pos[R];
-  uint32_t h_live = 0;
+
+  // ---------------------------------------------------------------------- probe waves
+  __syncthreads();  // prologue barrier: pieces 0 and 1 are resolved
+  int32_t h_idx[R], h_first[R];  // the single matches of the PREVIOUS piece: written when its reservation has come back
+  uint32_t h_live = 0, h_woff = 0;
+  K keyN[R];                     // rows of the NEXT piece, requested one iteration ahead
+  int32_t idxN[R];
 #pragma unroll
   for (int j = 0; j < R; ++j) {
     h_idx[j] = h_first[j] = 0;
-    h_pos[j] = 0;
+    keyN[j] = K(0);
+    idxN[j] = 0;
   }
-  unsigned long long pend = 0;
-  uint32_t cur_part       = 0xFFFFFFFFu;  // the partition whose tags sit in LDS
+  auto request_rows = [&](const PpPiece& pc) {
+    if (!pc.valid) return;
+#pragma unroll
+    for (int j = 0; j < R; ++j) {
+      const unsigned long long i  = pc.c0 + (unsigned long long)(j * PT_PW * GX_WAVE) + tid;
+      const unsigned long long ic = i < pc.c1 ? i : pc.c0;
+      keyN[j] = __builtin_nontemporal_load(&pkeys[ic]);
+      idxN[j] = __builtin_nontemporal_load(&pidx[ic]);
+    }
+  };
+  request_rows(s_piece[0]);
+  uint32_t cur_part = 0xFFFFFFFFu;  // the partition whose tags sit in LDS
   for (int t = 0;; ++t) {
-    const PpPiece pc = s_piece[t & 1];
+    const PpPiece pc = s_piece[t & 3];
     const bool valid = pc.valid != 0;  // block-uniform
     K key[R];
     int32_t idx[R];
     uint32_t rows = 0;
-    if (valid) {
 #pragma unroll
-      for (int j = 0; j < R; ++j) {
-        const unsigned long long i  = pc.c0 + (unsigned long long)(j * PT_BT) + tid;
-        const unsigned long long ic = i < pc.c1 ? i : pc.c0;
-        key[j] = __builtin_nontemporal_load(&pkeys[ic]);
-        idx[j] = __builtin_nontemporal_load(&pidx[ic]);
-        if (i < pc.c1) rows |= 1u << j;
-      }
+    for (int j = 0; j < R; ++j) {
+      key[j] = keyN[j];
+      idx[j] = idxN[j];
+      if (valid && pc.c0 + (unsigned long long)(j * PT_PW * GX_WAVE) + tid < pc.c1) rows |= 1u << j;
     }
-    if (tid == 0) s_base[(t & 1) ^ 1] = pend;
-    if (w == 0 && valid) {
-      PpPiece nx;
-      take_piece(nx);
-      if (lane == 0) s_piece[(t + 1) & 1] = nx;
-    }
-    if (valid && pc.part != cur_part) {  // block-uniform: the tags of the piece's partition (every earlier reader passed the last barrier)
+    if (valid) request_rows(s_piece[(t + 1) & 3]);  // (resolved by the service wave before the last barrier)
+    if (LDS_TAGS && valid && pc.part != cur_part) {  // block-uniform: the tags of the piece's partition (every earlier reader passed the last barrier)
       const uint4* src = reinterpret_cast<const uint4*>(gtags + (((uint64_t)pc.part << PJ_SUB_LOG2) >> 1));
       uint4* dst       = reinterpret_cast<uint4*>(smem);
-      for (uint32_t i = tid; i < SUB / 2 / 16; i += PT_BT) dst[i] = src[i];
+      for (uint32_t i = tid; i < SUB / 2 / 16; i += PT_PW * GX_WAVE) dst[i] = src[i];
       if (tid == 0) {  // the 32 tags behind the sub-table's own; behind the LAST sub-table the table wraps to slot 0
         const bool last   = (((uint64_t)pc.part + 1) << PJ_SUB_LOG2) > mask;
         dst[SUB / 2 / 16] = last ? *reinterpret_cast<const uint4*>(gtags) : src[SUB / 2 / 16];
@@ -3087,15 +3129,29 @@ k_pj4_probe_tags(const K* __restrict__ pkeys, const int32_t* __restrict__ pidx, 
       cur_part = pc.part;
       __syncthreads();
     }
-    uint32_t m[R], pos[R];
+    uint32_t m[R];
     int32_t first[R];
-    uint32_t live = 0;
+    uint32_t live = 0, woff = 0;
     if (valid) {
-      const uint64_t sub_base = (uint64_t)pc.part << PJ_SUB_LOG2;
+      const uint64_t sub_base = (uint64_t)pc.part << sub_log2;
+      const uint32_t* gtagw0  = reinterpret_cast<const uint32_t*>(gtags);
       uint32_t li[R];
       uint64_t cand[R];
-      uint32_t ended = 0;
+      uint32_t ended = 0, edge = 0;
       Raw sv[R];
+      uint32_t tw[LDS_TAGS ? 1 : R][3];
+      if (!LDS_TAGS) {  // the 16-slot tag windows of all R rows are requested together (three dwords each, from the L2)
+#pragma unroll
+        for (int j = 0; j < R; ++j) {
+          const uint64_t sl = ((uint64_t)key[j] * 0x9E3779B97F4A7C15ull) >> (64 - log2cap);
+          // (a window that would run past the table's last tag word is read from the table's start instead and its row takes the
+          //  slot walk below: 16 of 2^log2cap home slots)
+          const uint64_t wi = (sl >> 3) + 2 <= (mask >> 3) ? (sl >> 3) : 0;
+          tw[j][0] = gtagw0[wi];
+          tw[j][1] = gtagw0[wi + 1];
+          tw[j][2] = gtagw0[wi + 2];
+        }
+      }
 #pragma unroll
       for (int j = 0; j < R; ++j) {
         m[j]     = 0;
@@ -3108,7 +3164,16 @@ k_pj4_probe_tags(const K* __restrict__ pkeys, const int32_t* __restrict__ pidx, 
           uint32_t tg         = (uint32_t)(prod >> (60 - log2cap)) & 15u;
           tg                  = tg ? tg : 8u;
           const uint32_t tagpat = tg * 0x11111111u;
-          const uint32_t w0 = s_tagw[li[j] >> 3], w1 = s_tagw[(li[j] >> 3) + 1], w2 = s_tagw[(li[j] >> 3) + 2];
+          uint32_t w0, w1, w2;
+          if (LDS_TAGS) {
+            w0 = s_tagw[li[j] >> 3];
+            w1 = s_tagw[(li[j] >> 3) + 1];
+            w2 = s_tagw[(li[j] >> 3) + 2];
+          } else {
+            w0 = tw[LDS_TAGS ? 0 : j][0];
+            w1 = tw[LDS_TAGS ? 0 : j][1];
+            w2 = tw[LDS_TAGS ? 0 : j][2];
+          }
           const uint32_t sh = (li[j] & 7u) * 4u;
           const uint32_t x0w = __builtin_amdgcn_alignbit(w1, w0, sh), x1w = __builtin_amdgcn_alignbit(w2, w1, sh);
           const uint32_t y0 = x0w ^ tagpat, y1 = x1w ^ tagpat;
@@ -3120,6 +3185,11 @@ k_pj4_probe_tags(const K* __restrict__ pkeys, const int32_t* __restrict__ pidx, 
           const uint32_t c1 = z0 ? 0u : (m1 & ((z1 & (0u - z1)) - 1u));
           cand[j]           = (uint64_t)c0 | ((uint64_t)c1 << 32);
           if (z0 | z1) ended |= 1u << j;
+          if (!LDS_TAGS && ((sub_base + li[j]) >> 3) + 2 > (mask >> 3)) {  // the window was not the row's: no candidates, chain open
+            cand[j] = 0;
+            ended &= ~(1u << j);
+            edge |= 1u << j;
+          }
         }
       }
 #pragma unroll
@@ -3154,7 +3224,7 @@ k_pj4_probe_tags(const K* __restrict__ pkeys, const int32_t* __restrict__ pidx, 
         if (!((ended >> j) & 1u)) {
           const uint32_t tagpat = tag_of<K>(key[j], log2cap) * 0x11111111u;
           const uint32_t* gtagw = reinterpret_cast<const uint32_t*>(gtags);
-          wb                    = (wb + 16) & mask;
+          wb                    = ((edge >> j) & 1u) ? wb : ((wb + 16) & mask);  // (edge rows: nothing of the chain has been looked at)
           bool done             = false;
           while (!done) {  // further windows of 8 slots, tags from global memory
             if (wb + 8 > mask) {  // the window would wrap around the table's end: walk the slots themselves
@@ -3211,46 +3281,41 @@ k_pj4_probe_tags(const K* __restrict__ pkeys, const int32_t* __restrict__ pidx, 
           m[j] = 0;
         }
       }
+      // the wave's single matches: one LDS add hands out its run inside the piece
       uint32_t tot = 0;
 #pragma unroll
       for (int j = 0; j < R; ++j) {
-        const uint64_t bb = ballot(m[j] == 1);
-        pos[j]            = tot + (uint32_t)__builtin_popcountll(bb & lanemask_lt());
-        tot += (uint32_t)__builtin_popcountll(bb);
+        tot += (uint32_t)__builtin_popcountll(ballot(m[j] == 1));
         if (m[j] == 1) live |= 1u << j;
       }
-      uint32_t woff = 0;
       if (lane == 0 && tot) woff = atomicAdd(&s_cnt[t & 1], tot);
       woff = (uint32_t)__builtin_amdgcn_readfirstlane((int)woff);
-#pragma unroll
-      for (int j = 0; j < R; ++j) pos[j] += woff;
     }
-    __syncthreads();
+    __syncthreads();  // X(t)
     {
-      const unsigned long long gb = s_base[(t & 1) ^ 1];
+      // the previous piece's pairs leave: position = the piece's reservation + the wave's run + the lane's rank among the matches
+      const unsigned long long gb = s_base[(t & 1) ^ 1] + h_woff;
+      uint32_t run = 0;
 #pragma unroll
       for (int j = 0; j < R; ++j) {
+        const uint64_t bb = ballot((h_live >> j) & 1u);
         if ((h_live >> j) & 1u) {
-          const unsigned long long gp = gb + h_pos[j];
+          const unsigned long long gp = gb + run + (uint32_t)__builtin_popcountll(bb & lanemask_lt());
           if ((int64_t)gp < capacity) {
             __builtin_nontemporal_store(h_idx[j], &out_probe[gp]);
             __builtin_nontemporal_store(h_first[j], &out_build[gp]);
           }
         }
+        run += (uint32_t)__builtin_popcountll(bb);
       }
     }
     if (!valid) break;
-    if (tid == 0) {
-      const unsigned int c = s_cnt[t & 1];
-      pend                 = c ? atomicAdd(cursor, (unsigned long long)c) : 0ull;
-      s_cnt[t & 1]         = 0;
-    }
     h_live = live;
+    h_woff = woff;
 #pragma unroll
     for (int j = 0; j < R; ++j) {
       h_idx[j]   = idx[j];
       h_first[j] = first[j];
-      h_pos[j]   = pos[j];
     }
   }
 }
@@ -3460,18 +3525,20 @@ int probe_partitioned_impl2(const K* keys, int64_t n, const Slot<K>* slots, uint
   // ---- speculative pass
   hipLaunchKernelGGL(kspec, dim3((unsigned)grid), dim3(1024), lds_s, s, keys, n, plan2, plan, pbits, rrows, cap, ntiles, pkeys, pidx, part_of, row0, payload);
   jprof_mark(2, s);
+  // (6 / 7: the same kernel with the tag windows read from the L2 -- the partition pass then cuts 2^20-slot sub-tables, see pj_bits)
   // the probe kernel: 0 the pipelined LDS-tag gang probe; 2 / 3 the L2-resident direct probe with 4 / 2 rows per thread (round 5,
   // measured negative); 4 / 5 the tag probe in its occupancy form (round 5: no pipeline, no staging, two workgroups per CU), 2 / 4 rows
   typedef void (*ProbeK)(const K*, const int32_t*, PieceTable, int, const Slot<K>*, uint32_t, int, int32_t*, int32_t*, int64_t, unsigned long long*);
   const int pk        = g_pj_probe;
   const bool alt      = pk >= 2;
   ProbeK kalt         = pk == 2 ? (ProbeK)k_pj3_probe_direct<K, 4, 6> : pk == 3 ? (ProbeK)k_pj3_probe_direct<K, 2, 8>
-                        : pk == 4 ? (ProbeK)k_pj4_probe_tags<K, 2, 8> : (ProbeK)k_pj4_probe_tags<K, 4, 4>;
+                        : pk == 4 ? (ProbeK)k_pj4_probe_tags<K, 2, 8, true> : pk == 5 ? (ProbeK)k_pj4_probe_tags<K, 4, 4, true>
+                        : pk == 6 ? (ProbeK)k_pj4_probe_tags<K, 2, 8, false> : (ProbeK)k_pj4_probe_tags<K, 4, 4, false>;
   const unsigned alt_bt     = (pk == 2 || pk == 3) ? (unsigned)PD_BT : (unsigned)PT_BT;
-  const unsigned alt_rpt    = (pk == 2 || pk == 5) ? 4u : 2u;
-  const size_t alt_lds      = (pk == 4 || pk == 5) ? ((size_t)1 << (PJ_SUB_LOG2 - 1)) + PP_TAGPAD : 0;
-  const unsigned piece_rows = alt ? alt_bt * alt_rpt : (unsigned)PP_ROWS;
-  static int alt_wgs[4] = {0, 0, 0, 0};  // resident workgroups per CU of the alternative kernels (occupancy query, once each)
+  const unsigned alt_rpt    = (pk == 2 || pk == 5 || pk == 7) ? 4u : 2u;
+  const size_t alt_lds      = (pk == 4 || pk == 5) ? ((size_t)1 << (PJ_SUB_LOG2 - 1)) + PP_TAGPAD : 0;  // (6 / 7: no LDS tags)
+  const unsigned piece_rows = !alt ? (unsigned)PP_ROWS : (pk >= 4 ? (unsigned)(PT_PW * GX_WAVE) * alt_rpt : alt_bt * alt_rpt);
+  static int alt_wgs[6] = {0, 0, 0, 0, 0, 0};  // resident workgroups per CU of the alternative kernels (occupancy query, once each)
   if (alt && alt_wgs[pk - 2] == 0) {
     if (alt_lds) GX_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(kalt), hipFuncAttributeMaxDynamicSharedMemorySize, (int)alt_lds));
     int nb = 0;
@@ -3510,7 +3577,9 @@ int probe_partitioned_impl(const void* keys, int64_t n, const void* table, size_
                            int left_outer, int32_t* out_probe, int32_t* out_build, int64_t capacity, int64_t* cursor,
                            void* tmp, size_t* tmp_bytes, hipStream_t s, int32_t row0 = 0, const int32_t* payload = nullptr)
 {
-  const int pbits = pj_bits(lg, (int)sizeof(Slot<K>));
+  int pbits = pj_bits(lg, (int)sizeof(Slot<K>));
+  // knob 6 / 7 (the tag windows come from the L2, nothing is staged in LDS): 2^20-slot sub-tables -- an eighth of the partitions
+  if ((g_pj_probe == 6 || g_pj_probe == 7) && pbits >= 6) pbits -= 3;
   if (pj2_applies<K>(n, pbits)) {
     if (tmp) {
       const size_t need = sizeof(TableHeader) + (sizeof(Slot<K>) << lg) + ((size_t)1 << lg) / 2;
@@ -3927,7 +3996,7 @@ int gx_join_profile_read(float* ms3)
   return 0;
 }
 
-void gx_join_set_probe_kernel(int which) { gx::join::g_pj_probe = (which >= 1 && which <= 5) ? which : 0; }
+void gx_join_set_probe_kernel(int which) { gx::join::g_pj_probe = (which >= 1 && which <= 7) ? which : 0; }
 void gx_join_set_partition_mode(int speculative, int early_loads)
 {
   gx::join::g_pj_spec        = speculative == 2 ? 2 : (speculative ? 1 : 0);

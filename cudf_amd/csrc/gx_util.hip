@@ -44,6 +44,17 @@ __global__ void __launch_bounds__(256) k_fill_random(T* out, int64_t n, uint64_t
   }
 }
 
+__global__ void __launch_bounds__(256) k_mix64(uint64_t* data, int64_t n)
+{
+  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
+    uint64_t x = data[i];
+    x          = (x ^ (x >> 30)) * 0xBF58476D1CE4E5B9ull;
+    x          = (x ^ (x >> 27)) * 0x94D049BB133111EBull;
+    data[i]    = x ^ (x >> 31);
+  }
+}
+
 __global__ void __launch_bounds__(256) k_sequence_i32(int32_t* out, int64_t n, int32_t start)
 {
   const int64_t stride = (int64_t)gridDim.x * blockDim.x;
@@ -121,6 +132,17 @@ int fill_launch(void* out, int64_t n, uint64_t seed, int64_t lo, int64_t hi, int
 }  // namespace gx
 
 extern "C" {
+
+int gx_mix64_inplace(uint64_t* data, int64_t n, gx_stream_t s)
+{
+  if (n < 0 || (n > 0 && !data)) return GX_EINVAL;
+  if (n == 0) return 0;
+  int64_t blocks = (n + 256 * 8 - 1) / (256 * 8);
+  if (blocks > 8192) blocks = 8192;
+  hipLaunchKernelGGL(gx::k_mix64, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)s, data, n);
+  GX_LAUNCH_CHECK();
+  return 0;
+}
 
 int gx_fill_random(int dtype, void* out, int64_t n, uint64_t seed, int64_t lo, int64_t hi, gx_stream_t s)
 {

@@ -525,6 +525,10 @@ int gx_bitmask_first_unset(const uint32_t* mask, int64_t nbits, int64_t* pos_dev
  * ------------------------------------------------------------------------------------------ */
 int gx_fill_random(int dtype, void* out, int64_t n, uint64_t seed, int64_t lo, int64_t hi,
                    gx_stream_t stream);
+/* data[i] = mix64(data[i]) in place, mix64 = the splitmix64 FINALIZER (a bijection of the 64-bit integers): ids j in [0, m)
+ * become m distinct keys that look random in every bit -- the join benchmarks' key sets (distinct random build keys,
+ * a probe side that hits them with a chosen probability; cpp/benchmarks/join/generate_input_tables.cu:24-103). */
+int gx_mix64_inplace(uint64_t* data, int64_t n, gx_stream_t stream);
 /* device-to-device copy as a KERNEL on `stream` (16-byte lanes): what a rank does with the part of an exchange that stays
  * on it.  hipMemcpyAsync picks the SDMA engines when other queues are busy -- 32 GB/s for an intra-device copy on this
  * part, measured (profiles/r3_xp_distributed_single_rank.txt: 252 ms for 8 GB in chunks, 4 ms as one kernel). */

@@ -70,20 +70,35 @@ int main(int argc, char** argv)
     table_view tv{{keys->view()}};
     sort_ms = time_steps(warmup, steps, [&] { auto out = cudf::sort(tv); });
   }
-  // ---- hash_join: distinct build keys floor(10 p / 3) over a bijection p of [0, nbuild); probe uniform in
-  //      [0, nbuild / 0.3): a probe row finds a build key with probability 0.3
+  // ---- cudf::sorted_order of the same kind of column (what the reference's own sort benchmark times, benchmarks/sort/sort.cpp:16-58)
+  double order_ms = 0;
+  {
+    auto keys = random_column(type_id::INT64, rows, 43, 0, 0);
+    table_view tv{{keys->view()}};
+    order_ms = time_steps(warmup, steps, [&] { auto out = cudf::sorted_order(tv); });
+  }
+  // ---- hash_join on SURVEY 8d's key distribution, as bench.py's line: build = nbuild DISTINCT random 64-bit keys, mix64(p(i)) with
+  //      p a bijection of [0, nbuild) and mix64 the splitmix64 finalizer (a bijection of the 64-bit integers); probe = mix64(u), u
+  //      uniform in [0, nbuild / 0.3): a probe row finds a build key with probability 0.3, the rest are random keys outside the set
   double build_ms = 0, probe_ms = 0;
   std::size_t pairs = 0;
   {
+    auto mix64 = [](uint64_t x) {
+      x = (x ^ (x >> 30)) * 0xBF58476D1CE4E5B9ull;
+      x = (x ^ (x >> 27)) * 0x94D049BB133111EBull;
+      return x ^ (x >> 31);
+    };
     std::vector<int64_t> hb(static_cast<std::size_t>(nbuild));
     // i -> i * 2654435761 mod nbuild is a bijection whenever nbuild has no prime factor besides 2 and 5 (1e8 has none)
     for (std::size_t i = 0; i < hb.size(); ++i) {
       uint64_t const p = (static_cast<uint64_t>(i) * 2654435761ull) % static_cast<uint64_t>(nbuild);
-      hb[i]            = static_cast<int64_t>(p * 10 / 3);
+      hb[i]            = static_cast<int64_t>(mix64(p));
     }
     auto bk = make_fixed_width_column(data_type{type_id::INT64}, nbuild, mask_state::UNALLOCATED);
     HIP_OK(hipMemcpy(bk->mutable_view().head<void>(), hb.data(), hb.size() * 8, hipMemcpyHostToDevice));
     auto pk = random_column(type_id::INT64, rows, 67890, 0, static_cast<int64_t>(nbuild / 0.3));
+    if (gx_mix64_inplace(pk->mutable_view().head<uint64_t>(), rows, nullptr) != 0) std::exit(3);
+    HIP_OK(hipDeviceSynchronize());
     table_view bt{{bk->view()}}, pt{{pk->view()}};
     std::unique_ptr<hash_join> hj;
     {  // steady state: the loop below builds the new table while the old one is still alive, so the arena must hold two
@@ -128,10 +143,10 @@ int main(int argc, char** argv)
     });
   }
   std::printf(
-    "{\"rows\": %lld, \"build_rows\": %lld, \"steps\": %d, \"warmup\": %d, \"sort_ms\": %.4f, \"join_build_ms\": %.4f, "
+    "{\"rows\": %lld, \"build_rows\": %lld, \"steps\": %d, \"warmup\": %d, \"sort_ms\": %.4f, \"sorted_order_ms\": %.4f, \"join_build_ms\": %.4f, "
     "\"join_probe_ms\": %.4f, \"join_pairs\": %zu, \"groupby_ms\": %.4f, \"groups\": %lld, \"memory_resource\": \"%s\", "
     "\"driver_allocations\": %zu, \"cached_bytes\": %zu}\n",
-    (long long)rows, (long long)nbuild, steps, warmup, sort_ms, build_ms, probe_ms, pairs, groupby_ms, (long long)groups,
+    (long long)rows, (long long)nbuild, steps, warmup, sort_ms, order_ms, build_ms, probe_ms, pairs, groupby_ms, (long long)groups,
     pool ? "pool_memory_resource" : "other", pool ? pool->driver_allocations() : 0, pool ? pool->cached_bytes() : 0);
   return 0;
 }

@@ -115,7 +115,7 @@ def test_speculative_partition_probe_default_threshold(gx):
         assert int(torch.unique(li).numel()) == l.size
 
 
-@pytest.mark.parametrize("dtype,shape,kernel", [(dt, sh, k) for k in (2, 3, 4, 5) for dt, sh in
+@pytest.mark.parametrize("dtype,shape,kernel", [(dt, sh, k) for k in (2, 3, 4, 5, 6, 7) for dt, sh in
                                                  (("int64", "uniform"), ("int64", "dup_build"), ("int64", "hot_key"), ("int64", "one_partition"),
                                                   ("int64", "edge_chains"), ("int32", "uniform"), ("int32", "edge_chains"))])
 def test_l2_resident_direct_probe_matches_oracle(gx, dtype, shape, kernel):

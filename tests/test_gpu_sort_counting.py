@@ -34,7 +34,7 @@ def _sort_with_state(gx, v, descending=False, offset=0):
     col = Column.from_numpy(v)
     n = v.size - offset
     out = Column.empty(v.dtype, n)
-    tmp = ops._run(L.lib.gx_sort_keys, col.gx, col.data_ptr + offset * v.dtype.itemsize, out.data_ptr, n, int(descending))
+    tmp = ops._run(L.lib.gx_sort_keys, col.gx, ctypes.c_void_p(col.data_ptr.value + offset * v.dtype.itemsize), out.data_ptr, n, int(descending))
     ops._check_sort_status(tmp)
     st = ctypes.c_int32(-1)
     L.check(L.lib.gx_sort_cursor_state(ops.ptr(tmp), ctypes.byref(st), ops.stream_ptr()), "gx_sort_cursor_state")
