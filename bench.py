@@ -76,7 +76,7 @@ def parse():
                     help="sort: keys uniform in [LO, HI) instead of the full int64 range (the reference's own "
                          "benchmark distribution is 100 10001: benchmarks/sort/sort.cpp:24-26)")
     ap.add_argument("--hot-copies", type=float, default=0, help="sort: this many rows carry ONE value (a hot value: zeros, a sentinel)")
-    ap.add_argument("--key-dist", default="uniform", choices=["uniform", "normal", "zipf", "sorted"],
+    ap.add_argument("--key-dist", default="uniform", choices=["uniform", "normal", "zipf", "sorted", "lognormal", "clusters"],
                     help="sort: distribution of the int64 keys.  normal = round(N(0, 1) * 2^40) (bell-shaped level-0 buckets); zipf = "
                          "floor(u^-5) clipped to 2^31 (the continuous form of Zipf(1.2): 18 %% of the rows carry the value 1); sorted = the "
                          "uniform keys, already in ascending order.  Robustness lines (VERDICT r3 next 3), not the headline")
@@ -90,6 +90,11 @@ def parse():
                          "(tests/cpp/cudf_api_bench, default pooled mr) and report the ratio to the C-ABI numbers; default: on for "
                          "--workload all on one GPU (the driver's line), off otherwise")
     ap.add_argument("--no-through-cpp", dest="through_cpp", action="store_false")
+    ap.add_argument("--robustness", dest="robustness", action="store_true", default=None,
+                    help="sort the same 1e9 rows on other VALUE DISTRIBUTIONS (bell-shaped, lognormal, Zipf-like, two clusters, keys around zero, "
+                         "the reference benchmark's [100, 10001), a hot value) and report each time and its ratio to the uniform line; "
+                         "default: on for --workload all on one GPU (the driver's line)")
+    ap.add_argument("--no-robustness", dest="robustness", action="store_false")
     ap.add_argument("--cpu-baseline", dest="cpu", action="store_true", default=True)
     ap.add_argument("--no-cpu-baseline", dest="cpu", action="store_false")
     ap.add_argument("--cpu-rows", type=float, default=0, help="rows of the CPU-baseline sample (0 = per-workload default)")
@@ -585,6 +590,11 @@ def bench_sort(c, pairs=False, cpu_leg=True):
                 m = min(step, n - i)
                 if a.key_dist == "normal":
                     kt[i:i + m] = (torch.randn(m, generator=g, device="cuda", dtype=torch.float64) * float(1 << 40)).round_().to(torch.int64)
+                elif a.key_dist == "lognormal":   # round(exp(N(25, 3))): densities over many octaves
+                    kt[i:i + m] = torch.randn(m, generator=g, device="cuda", dtype=torch.float64).mul_(3.0).add_(25.0).exp_().round_().clamp_(max=9.0e18).to(torch.int64)
+                elif a.key_dist == "clusters":    # two far-apart clusters: -2^50 + N(0, 2^30) and 2^50 + N(0, 2^30)
+                    side = torch.rand(m, generator=g, device="cuda", dtype=torch.float64) < 0.5
+                    kt[i:i + m] = (torch.randn(m, generator=g, device="cuda", dtype=torch.float64) * float(1 << 30)).round_().to(torch.int64) + torch.where(side, -(1 << 50), 1 << 50)
                 else:
                     u = torch.rand(m, generator=g, device="cuda", dtype=torch.float64).clamp_(min=2.0 ** -53)
                     kt[i:i + m] = u.pow_(-5.0).clamp_(max=float(1 << 31)).floor_().to(torch.int64)
@@ -715,6 +725,9 @@ def bench_sort(c, pairs=False, cpu_leg=True):
     bigi = (ctypes.c_int64 * 3)()
     lib.gx_sort_big_info(c.ptr(tmp), bigi, c.stream)
     sort_info["big_cells"] = {"sorted_through_x": int(bigi[0]), "cells": int(bigi[1]), "keys": int(bigi[2])}
+    spi = (ctypes.c_int32 * 4)()
+    lib.gx_sort_split_info(c.ptr(tmp), spi, c.stream)
+    sort_info["splitters"] = {"on": int(spi[0]), "splitters": int(spi[1]), "equality_buckets": int(spi[2])}
     cursor = cst.value == 3
     hist_ms = prof["hist_ms"] / nsteps_prof
     local_sort_ms = ms_per_step if not c.sharded else hist_ms + (sum(prof["hyb"]) if prof["hyb_n"] else prof["pass_ms"])
@@ -1290,6 +1303,44 @@ def through_cpp(args, c, sort_ms, order_ms, join_ms, groupby_ms):
     return r
 
 
+def sort_robustness(c, uniform_ms):
+    """cudf::sort's cost must not depend on the VALUES (cub::DeviceRadixSort behind cpp/src/sort/sort_radix.cu:52-161 does not care;
+    the reference's own benchmark draws keys from [100, 10001): cpp/benchmarks/sort/sort.cpp:24-26).  The same 1e9-row int64 sort on
+    distributions the headline is not tuned for, 3 timed steps each, every output checked like the headline's; `ratio` is to the
+    uniform line of this run."""
+    import copy
+    a0 = c.args
+    cases = [("normal N(0, 2^40)", {"key_dist": "normal"}), ("lognormal exp(N(25, 3))", {"key_dist": "lognormal"}),
+             ("zipf-like floor(u^-5)", {"key_dist": "zipf"}), ("two clusters", {"key_dist": "clusters"}),
+             ("uniform in [-1e12, 1e12)", {"key_range": [-10**12, 10**12]}), ("uniform in [100, 10001)", {"key_range": [100, 10001]}),
+             ("1e8 copies of one value", {"hot_copies": 1e8}), ("already sorted", {"key_dist": "sorted"})]
+    out, worst = {}, None
+    for name, kw in cases:
+        a = copy.copy(a0)
+        a.steps, a.warmup, a.key_dist, a.key_range, a.hot_copies = 3, 1, "uniform", None, 0
+        for k, v in kw.items():
+            setattr(a, k, v)
+        c.args = a
+        try:
+            c.torch.cuda.empty_cache()
+            b = bench_sort(c, cpu_leg=False)
+            si = (b.get("roofline") or {}).get("sort_info") or {}
+            out[name] = {"ms_per_step": b["ms_per_step"], "ratio_to_uniform": b["ms_per_step"] / uniform_ms,
+                         "path": {"cursor_path_state": si.get("cursor_path_state"), "splitters": (si.get("splitters") or {}).get("on"),
+                                  "lsd_passes": si.get("lsd_passes"), "keys_through_big_cells": (si.get("big_cells") or {}).get("keys")}}
+            if worst is None or out[name]["ratio_to_uniform"] > worst[1]:
+                worst = (name, out[name]["ratio_to_uniform"])
+        except Exception as e:  # noqa: BLE001 -- a robustness line must not take the headline down; it says what happened
+            out[name] = {"error": repr(e)}
+        finally:
+            c.args = a0
+    return {"rows": c.n, "steps": 3, "warmup": 1, "uniform_ms": uniform_ms, "cases": out,
+            "worst": {"case": worst[0], "ratio_to_uniform": worst[1]} if worst else None,
+            "checked": "every case: order + multiset checksum of the timed output (gx_checksum), as the headline",
+            "state_legend": "cursor_path_state 3 = two partition levels + cell sort (splitters: level 0 cut on sample-chosen splitters), "
+                            "5 = counting sort of a narrow range, 4 / 2 = declined to the LSD passes / look-back path"}
+
+
 def main():
     args = parse()
     if args.gpus > 1 and "RANK" not in os.environ:
@@ -1356,6 +1407,9 @@ def main():
                           **({"build_ms": b["build_ms"], "build_call_ms": b.get("build_call_ms"), "build_plus_probe_ms": b.get("build_plus_probe_ms"),
                               "build_rows_per_s": b.get("build_rows_per_s"), "partition_bits": b["partition_bits"], "join_keys": b.get("join_keys"),
                               "partition_mode": b.get("partition_mode")} if "build_ms" in b else {})}
+        want_rb = args.robustness if args.robustness is not None else (wl == "all" and c.n >= 100_000_000)
+        if want_rb and not c.sharded and wl in ("all", "sort"):
+            line["sort_robustness"] = sort_robustness(c, head["ms_per_step"])
         want_cpp = args.through_cpp if args.through_cpp is not None else (wl == "all" and c.n >= 100_000_000)
         if want_cpp and not c.sharded:
             blk = lambda name: (blocks.get(name) or (head if wl == name else {})).get("ms_per_step")

@@ -126,7 +126,9 @@ std::unique_ptr<scalar> reduce(column_view const& col, reduce_aggregation const&
                cudf::data_type_error);
   if (init.has_value() && !(agg.kind == aggregation::SUM || agg.kind == aggregation::PRODUCT || agg.kind == aggregation::MIN ||
                             agg.kind == aggregation::MAX))
-    throw std::invalid_argument{"Initial value is only supported for SUM, SUM_OVERFLOW, PRODUCT, MIN, MAX, ANY, ALL, and HOST_UDF aggregation types"};
+    // (the reference also folds an initial value into SUM_WITH_OVERFLOW, ANY, ALL and HOST_UDF -- reductions.cpp:484-507; those
+    //  aggregations are not part of this hot path at all, with or without an initial value: INTEGRATION.md section 5)
+    throw std::invalid_argument{"Initial value is only supported for SUM, PRODUCT, MIN and MAX on this path (the reference's SUM_OVERFLOW, ANY, ALL and HOST_UDF reductions are not implemented here)"};
   auto result = reduce(col, agg, output_type, stream, mr);
   if (!init.has_value()) return result;
   if (!init.value().get().is_valid(stream)) {

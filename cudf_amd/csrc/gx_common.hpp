@@ -3,6 +3,8 @@
 #pragma once
 
 #include <hip/hip_runtime.h>
+
+#include <atomic>
 #include <stdint.h>
 
 #include "../../include/cudf_amd/gx.h"

@@ -795,7 +795,7 @@ int launch_partitioned(const K* keys, const uint32_t* kvalid, const V* vals, con
   constexpr int S        = lds_slots<K, HAS_VV>();
   constexpr size_t lds_a = (size_t)(S + 1) * 16 + (size_t)(S + 2) * sizeof(K) + (size_t)(S + 1) * 4 * (HAS_VV ? 2 : 1);
   auto ka                = k_part_aggregate<K, V, IS_FLOAT, HAS_VV>;
-  static bool attr_set   = false;
+  static std::atomic<bool> attr_set{false};
   if (!attr_set) {
     GX_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(ks), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_s));
     GX_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(ka), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_a));
@@ -1301,7 +1301,7 @@ int launch_partitioned_minmax(const K* keys, const uint32_t* kvalid, const V* va
   constexpr int S        = lds_slots_mm<K, HAS_VV>();
   constexpr size_t lds_a = (size_t)(S + 1) * 16 + (size_t)(S + 2) * sizeof(K) + (size_t)(S + 1) * 4;
   auto ka                = k_part_minmax<K, V, HAS_VV>;
-  static bool attr_set   = false;
+  static std::atomic<bool> attr_set{false};
   if (!attr_set) {
     GX_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(ks), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_s));
     GX_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(ka), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_a));
@@ -2000,7 +2000,7 @@ int wide_impl(const void* const* key_cols, const void* vals, int64_t n, int64_t 
     constexpr size_t lds_a = (size_t)S * (16 + 8 * W + 8);
     auto ks                = k_wide_scatter<W, V>;
     auto ka                = k_wide_aggregate<W, V, IS_FLOAT>;
-    static bool attr_set   = false;
+    static std::atomic<bool> attr_set{false};
     if (!attr_set) {
       GX_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(ks), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_s));
       GX_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(ka), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_a));

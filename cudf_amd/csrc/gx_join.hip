@@ -3366,7 +3366,7 @@ int pj_partition_fn(const K* keys, int64_t n, int pbits, PjPlan* plan, K* pkeys,
   auto k4          = k_pj_scatter<K, 8, 512, F>;
   auto k8          = k_pj_scatter<K, 16, 512, F>;
   auto k16         = k_pj_scatter<K, 16, 1024, F>;
-  static bool attr_set = false;  // per instantiation
+  static std::atomic<bool> attr_set{false};  // per instantiation
   if (!attr_set) {
     const int lds_max = 160 * 1024 - 256;
     GX_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(k4), hipFuncAttributeMaxDynamicSharedMemorySize, lds_max));
@@ -3496,7 +3496,7 @@ int probe_partitioned_impl2(const K* keys, int64_t n, const Slot<K>* slots, uint
                            : (g_pj_probe_early ? k_pj2_probe_pipe<K, true, false> : k_pj2_probe_pipe<K, false, false>);
   constexpr size_t lds_p = ((size_t)1 << (PJ_SUB_LOG2 - 1)) + PP_TAGPAD + (size_t)6 * PP_ROWS * sizeof(int32_t);
   const size_t lds_s     = (size_t)TILE * sizeof(K) + ((size_t)8 << pbits);
-  static bool attr_set   = false;  // per instantiation
+  static std::atomic<bool> attr_set{false};  // per instantiation
   static int num_cus     = 0;
   if (!attr_set) {
     const int lds_max = 160 * 1024 - 256;
@@ -3620,7 +3620,7 @@ int probe_partitioned_impl(const void* keys, int64_t n, const void* table, size_
   const int64_t max_chunks = div_up(n, (int64_t)chunk_rows) + (1 << pbits);
   if (use_pipe) {
     constexpr size_t lds_p = ((size_t)1 << (PJ_SUB_LOG2 - 1)) + (size_t)6 * PP_ROWS * sizeof(int32_t);
-    static bool pattr_set  = false;
+    static std::atomic<bool> pattr_set{false};
     static int num_cus     = 0;
     if (!pattr_set) {
       GX_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(k_pj_probe_pipe<K>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_p));
@@ -3636,7 +3636,7 @@ int probe_partitioned_impl(const void* keys, int64_t n, const void* table, size_
                        left_outer, out_probe, out_build, capacity, reinterpret_cast<unsigned long long*>(cursor));
   } else if (use_tags) {
     constexpr size_t lds_t = (size_t)1 << (PJ_SUB_LOG2 - 1);
-    static bool tattr_set  = false;
+    static std::atomic<bool> tattr_set{false};
     if (!tattr_set) {
       GX_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(k_pj_probe_tags<K>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_t));
       tattr_set = true;
@@ -3704,7 +3704,7 @@ int build_partitioned_impl(const void* keys, int64_t n, void* table, size_t tabl
     GX_HIP_TRY(hipMemsetAsync(fix, 0, 128, s));
     const size_t lds = (size_t)(1u << PJ_SUB_LOG2) / 2;
     auto kb          = k_bs_build<K>;
-    static bool attr_set = false;  // per instantiation
+    static std::atomic<bool> attr_set{false};  // per instantiation
     if (!attr_set) {
       GX_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(kb), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
       attr_set = true;

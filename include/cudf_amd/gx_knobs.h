@@ -7,6 +7,9 @@
  * parallel (cpp/include/cudf/join/hash_join.hpp:63-68) -- never see another thread's experiment.  Where a comment below still
  * says "process-wide" read "per calling thread".  The one exception is gx_groupby_set_partition_bits (it mirrors its value
  * into device memory): process-wide, set it only while no groupby is running.
+ * CONSEQUENCE for the multi-rank test drivers (cudf_amd/gxd.py run_ranks, communicator::loopback in C++): every logical rank runs
+ * on a host thread of its own, so a knob set on the test's main thread is NOT seen by the rank threads -- set it inside the
+ * per-rank function (the gxd_test_set_* hooks of gxd.h are process-wide for that reason).
  */
 #ifndef CUDF_AMD_GX_KNOBS_H
 #define CUDF_AMD_GX_KNOBS_H
@@ -77,6 +80,13 @@ void gx_sort_set_cursor_path(int enable, float margin_sigmas);
 /* A/B knob (per calling thread): 1 (default) = integer keys whose varying bits are their low 15 or fewer (sampled, then verified on
  * every key) are sorted by a histogram + fill (the counting sort of round 5, FastPlan::state 5); 0 = the LSD passes, as before. */
 void gx_sort_set_counting(int enable);
+/* A/B knob (per calling thread): 1 (default) = a 64-bit integer column whose level-0 buckets the sample shows to be too uneven for
+ * two levels of bit digits (bell-shaped, lognormal, Zipf-like, clustered values) is cut on sample-chosen SPLITTERS instead
+ * (round 5: k_sp_plan / k_sp_level0, equal-width cells inside a bucket, equality buckets for heavy values); 0 = such a column is
+ * declined to the LSD passes, as before. */
+void gx_sort_set_splitters(int enable);
+/* info4 = {splitter mode used, splitters, equality buckets, level-1 bits} of the last sort on this scratch (synchronises). */
+int gx_sort_split_info(const void* tmp, int32_t* info4_host, gx_stream_t stream);
 /* 0 = not tried, 2 = tried and rejected by the device (the look-back path ran), 3 = the cursor path sorted the column,
  * 4 = the sample showed a key range too narrow for two partition levels (the LSD passes ran, no up-front read of the column).
  * `tmp` is the scratch of that sort call; synchronises the stream. */

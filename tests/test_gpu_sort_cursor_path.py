@@ -69,11 +69,11 @@ def test_cursor_path_matches_c_oracle(gx, kind, descending):
     got, state = _sort_with_state(gx, v, descending)
     assert got.tobytes() == c_oracle.sort_i64(v, descending=descending).tobytes()
     # representative samples: the device must have accepted the speculative plan (a silent fall-back would hide a
-    # broken capacity model behind a correct result).  "skewed" is the exception since round 4: 36 M keys that differ only
-    # below the two partition levels sit in one bucket of 64 cells x 8192 keys -- the sample shows it, and the plan goes to the
-    # LSD passes at once (state 4) instead of spending both levels on cells that must overflow
-    want = 4 if kind == "skewed" else 3
-    assert state == want, f"{kind}: cursor path state {state}, expected {want}"
+    # broken capacity model behind a correct result).  "skewed" -- 36 M keys that differ only below the two partition levels sit in
+    # one bucket of 64 cells x 8192 keys -- was declined to the LSD passes by the sample in round 4 (state 4); since round 5 the
+    # sample's verdict switches level 0 to SPLITTERS and the cursor path sorts the column (state 3, tests/test_gpu_sort_splitters.py)
+    assert state == 3, f"{kind}: cursor path state {state}, expected 3"
+
 
 
 def hash_seed(s):
@@ -165,9 +165,15 @@ def test_cursor_path_off_is_the_look_back_path(gx):
 
 def test_narrow_key_range_goes_straight_to_the_lsd_passes(gx):
     """the reference benchmark's own distribution (cpp/benchmarks/sort/sort.cpp: keys in [100, 10000]): two varying bytes,
-    nothing for two MSD levels to do -- the sample says so, and the look-back path's full up-front read is skipped too"""
+    nothing for two MSD levels to do -- the sample says so, and the look-back path's full up-front read is skipped too.  Since
+    round 5 a range of <= 15 varying bits is COUNTED (state 5, tests/test_gpu_sort_counting.py); a wider narrow range -- 20 bits --
+    still goes to the LSD passes (state 4)"""
     rng = np.random.default_rng(10)
     v = rng.integers(100, 10000, N, dtype=np.int64)
+    got, state = _sort_with_state(gx, v)
+    assert got.tobytes() == c_oracle.sort_i64(v).tobytes()
+    assert state == 5
+    v = rng.integers(100, 1_000_000, N, dtype=np.int64)
     got, state = _sort_with_state(gx, v)
     assert got.tobytes() == c_oracle.sort_i64(v).tobytes()
     assert state == 4
