@@ -808,3 +808,65 @@ def test_splitter_sort_model_orders_every_distribution():
                 out.append(np.sort(kb[cell == k]))
         got = np.concatenate(out)
         np.testing.assert_array_equal(got, np.sort(s), err_msg=name)
+
+
+# ------------------------------------------------------------------------------------------------
+# Round 5: the fraction map of the sort's splitter mode (gx_sort.hip: k_sp_plan's per-bucket parameters, sp_frac, sp_cell, sp_fine)
+# ------------------------------------------------------------------------------------------------
+def _sp_params(w):
+    """what k_sp_plan stores for a bucket of `w` key values: (nsh, mlow) -- the range's last key, relative, becomes a 31-bit number with
+    bit 30 set; M = floor(2^63 / (that + 1)) lies in [2^32, 2^33) and mlow = M - 2^32"""
+    wm = w - 1
+    if wm == 0:
+        return 63, 0
+    wl = wm.bit_length()
+    nsh = wl - 31
+    wx = wm >> nsh if nsh >= 0 else wm << -nsh
+    assert (wx >> 30) == 1
+    M = (1 << 63) // (wx + 1)
+    assert (1 << 32) <= M < (1 << 33)
+    return nsh, M - (1 << 32)
+
+
+def _sp_frac(rel, w, nsh, mlow):
+    """sp_frac: position of key = lo + rel inside [lo, lo + w) as a 32-bit fraction (the device's integer arithmetic, width for width)"""
+    if rel >= w:
+        return 0xFFFFFFFF
+    x = (rel >> nsh) if nsh >= 0 else ((rel << -nsh) & 0xFFFFFFFF)
+    x &= 0xFFFFFFFF
+    p = x * mlow
+    f = ((x << 1) & 0xFFFFFFFF) + ((p >> 31) & 0xFFFFFFFF)
+    assert f < (1 << 32), "the sum must not wrap (x * M / 2^31 < 2^32)"
+    return f
+
+
+def test_splitter_fraction_map_is_monotone_and_bounded():
+    """two unordered partition levels and a cell sort on full keys need nothing of the cell map but MONOTONICITY (a key never lands in a
+    cell before a smaller key's) and cell < cells: checked on bucket widths from 1 to 2^64 - 1 and cell counts up to 1024"""
+    import random
+    rnd = random.Random(7)
+    widths = [1, 2, 3, 5, 1023, 1024, 1025, 65535, (1 << 31) - 1, 1 << 31, (1 << 31) + 1, (1 << 40) + 12345, (1 << 63) + 9, (1 << 64) - 1]
+    widths += [rnd.getrandbits(rnd.randrange(1, 65)) | 1 for _ in range(60)]
+    for w in widths:
+        nsh, mlow = _sp_params(w)
+        rels = sorted({0, w - 1, w // 2, w // 3} | {rnd.randrange(w) for _ in range(300)} | {min(w - 1, k) for k in range(40)})
+        fr = [_sp_frac(r, w, nsh, mlow) for r in rels]
+        assert all(a <= b for a, b in zip(fr, fr[1:])), w
+        assert _sp_frac(w, w, nsh, mlow) == 0xFFFFFFFF and fr[-1] <= 0xFFFFFFFF   # keys past the range clamp to its end
+        for nc in (1, 7, 512, 700, 1024):
+            cells = [(f * nc) >> 32 for f in fr]
+            assert all(a <= b for a, b in zip(cells, cells[1:])) and cells[-1] < nc
+            fine = [((f * nc) >> 19) for f in fr]                                   # cell * 8192 + the 13-bit counting digit
+            assert all(a <= b for a, b in zip(fine, fine[1:]))
+
+
+def test_splitter_narrow_bucket_has_one_value_per_cell():
+    """a NARROW bucket (no more values in its range than it has cell slots) is counted and filled instead of sorted: that needs the
+    cell map to be INJECTIVE on the bucket's values -- k_sp_fill inverts it by evaluating it on every value"""
+    for ncmax in (64, 256, 1024):
+        for w in list(range(2, 70)) + [ncmax - 1, ncmax, ncmax // 2 + 1, ncmax * 3 // 4]:
+            if w > ncmax:
+                continue
+            nsh, mlow = _sp_params(w)
+            cells = [(_sp_frac(r, w, nsh, mlow) * ncmax) >> 32 for r in range(w)]
+            assert len(set(cells)) == w and cells == sorted(cells) and cells[-1] < ncmax, (ncmax, w)
