@@ -76,6 +76,8 @@ def parse():
                     help="sort: keys uniform in [LO, HI) instead of the full int64 range (the reference's own "
                          "benchmark distribution is 100 10001: benchmarks/sort/sort.cpp:24-26)")
     ap.add_argument("--hot-copies", type=float, default=0, help="sort: this many rows carry ONE value (a hot value: zeros, a sentinel)")
+    ap.add_argument("--key-type", default="int64", choices=["int64", "float64"],
+                    help="sort: float64 = a FLOAT64 column, keys drawn as N(0, 1) (--key-dist normal, the default for floats) or U[0, 1) (--key-dist uniform)")
     ap.add_argument("--key-dist", default="uniform", choices=["uniform", "normal", "zipf", "sorted", "lognormal", "clusters"],
                     help="sort: distribution of the int64 keys.  normal = round(N(0, 1) * 2^40) (bell-shaped level-0 buckets); zipf = "
                          "floor(u^-5) clipped to 2^31 (the continuous form of Zipf(1.2): 18 %% of the rows carry the value 1); sorted = the "
@@ -578,7 +580,24 @@ def bench_sort(c, pairs=False, cpu_leg=True):
         keys = ops.random_column(np.int64, n, seed=42 + c.rank, lo=a.key_range[0], hi=a.key_range[1])
     else:
         keys = ops.random_column(np.int64, n, seed=42 + c.rank)
-    if a.key_dist != "uniform":
+    is_f64 = getattr(a, "key_type", "int64") == "float64" and not pairs
+    if is_f64:
+        # a FLOAT64 column of ordinary data: N(0, 1) (default) or U[0, 1) doubles -- no NaN, no -0.0
+        torch = c.torch
+        keys = c.Column.empty(np.float64, n)
+        ft = c.as_tensor(keys, torch.float64)
+        g = torch.Generator(device="cuda").manual_seed(42 + c.rank)
+        step = 1 << 27
+        for i in range(0, n, step):
+            m = min(step, n - i)
+            if a.key_dist == "uniform":
+                ft[i:i + m] = torch.rand(m, generator=g, device="cuda", dtype=torch.float64)
+            else:
+                ft[i:i + m] = torch.randn(m, generator=g, device="cuda", dtype=torch.float64)
+        ft[ft == 0] = 1.0
+        del ft
+        torch.cuda.synchronize()
+    elif a.key_dist != "uniform":
         torch = c.torch
         kt = c.as_tensor(keys, torch.int64)
         if a.key_dist == "sorted":
@@ -607,7 +626,7 @@ def bench_sort(c, pairs=False, cpu_leg=True):
         kt = c.as_tensor(keys, c.torch.int64)
         kt[:: max(1, n // int(a.hot_copies))] = 1234567890123
         del kt
-    out = c.Column.empty(np.int32 if pairs else np.int64, n)
+    out = c.Column.empty(np.int32 if pairs else (np.float64 if is_f64 else np.int64), n)
     nb = ctypes.c_size_t(0)
     if pairs:
         fn = lambda tmp, nbp: lib.gx_sorted_order(keys.gx, keys.data_ptr, None, n, 0, 0, 1, out.data_ptr, tmp, nbp, c.stream)
@@ -618,12 +637,14 @@ def bench_sort(c, pairs=False, cpu_leg=True):
     single_step = lambda: L.check(fn(c.ptr(tmp), ctypes.byref(nb)), "sort")
     bytes_per_row_pass = 24 if pairs else 16   # read key(+idx) + write key(+idx)
     model_bytes_row = 200 if pairs else 136    # 8-pass LSD model
-    workload = f"{n:.0e}-row int64 " + ("sorted_order (radix sort pairs, int32 payload)" if pairs else "radix sort (cudf::sort, keys only)")
+    workload = f"{n:.0e}-row " + ("float64 " if is_f64 else "int64 ") + ("sorted_order (radix sort pairs, int32 payload)" if pairs else "radix sort (cudf::sort, keys only)")
+    if is_f64:
+        workload += ", keys " + ("U[0, 1)" if a.key_dist == "uniform" else "N(0, 1)")
     if a.key_range:
         workload += f", keys uniform in [{a.key_range[0]}, {a.key_range[1]})"
     if a.hot_copies:
         workload += f", {int(a.hot_copies):.0e} copies of one value"
-    if a.key_dist != "uniform":
+    if a.key_dist != "uniform" and not is_f64:
         workload += f", {a.key_dist} keys"
 
     prof = {"pass_ms": 0.0, "hist_ms": 0.0, "launches": 0, "hyb": [0.0] * 4, "hyb_n": 0}
@@ -778,7 +799,7 @@ def bench_sort(c, pairs=False, cpu_leg=True):
     cpu = None
     if a.cpu and cpu_leg and not c.sharded and c.rank == 0:
         cpu = cpu_baseline_sort(a.cpu_rows or 5e8, a.cpu_rows_pandas or 1e8)
-    return {"workload": workload, "rows": n, "ms_per_step": ms_per_step, "rows_per_s": n * c.world / sec, "dtype": "int64",
+    return {"workload": workload, "rows": n, "ms_per_step": ms_per_step, "rows_per_s": n * c.world / sec, "dtype": "f64" if is_f64 else "int64",
             "roofline": roofline, "cpu_baseline": cpu, "checked": checked}
 
 
@@ -1313,11 +1334,12 @@ def sort_robustness(c, uniform_ms):
     cases = [("normal N(0, 2^40)", {"key_dist": "normal"}), ("lognormal exp(N(25, 3))", {"key_dist": "lognormal"}),
              ("zipf-like floor(u^-5)", {"key_dist": "zipf"}), ("two clusters", {"key_dist": "clusters"}),
              ("uniform in [-1e12, 1e12)", {"key_range": [-10**12, 10**12]}), ("uniform in [100, 10001)", {"key_range": [100, 10001]}),
-             ("1e8 copies of one value", {"hot_copies": 1e8}), ("already sorted", {"key_dist": "sorted"})]
+             ("1e8 copies of one value", {"hot_copies": 1e8}), ("already sorted", {"key_dist": "sorted"}),
+             ("float64 N(0, 1)", {"key_type": "float64", "key_dist": "normal"}), ("float64 U[0, 1)", {"key_type": "float64", "key_dist": "uniform"})]
     out, worst = {}, None
     for name, kw in cases:
         a = copy.copy(a0)
-        a.steps, a.warmup, a.key_dist, a.key_range, a.hot_copies = 3, 1, "uniform", None, 0
+        a.steps, a.warmup, a.key_dist, a.key_range, a.hot_copies, a.key_type = 3, 1, "uniform", None, 0, "int64"
         for k, v in kw.items():
             setattr(a, k, v)
         c.args = a

@@ -475,13 +475,17 @@ __device__ __forceinline__ unsigned wave_split_sort_x2(uint64_t* keysA, uint32_t
 //  signed: sign flip.  float: -0.0 -> +0.0, NaN -> all ones (after +Inf; all NaNs equivalent),
 //  then the IEEE total-order flip.  desc_mask (0 or ~0) reverses the order.  Equal sortable bits
 //  <=> equivalent under the row comparator (NaN == NaN, -0 == +0).
-enum KeyKind { K_UNSIGNED = 0, K_SIGNED = 1, K_FLOAT = 2 };
+//  K_FTOTAL (round 5): the IEEE total-order flip alone -- a BIJECTION (from_sortable below), which is the cudf order exactly on
+//  columns that hold no NaN and no -0.0 ("clean" float columns: the sort's unordered levels check every key and fall back).
+enum KeyKind { K_UNSIGNED = 0, K_SIGNED = 1, K_FLOAT = 2, K_FTOTAL = 3 };
 template <typename U, int KIND>
 __host__ __device__ __forceinline__ U to_sortable(U bits, U desc_mask)
 {
   constexpr U SIGN = U(U(1) << (sizeof(U) * 8 - 1));
   if (KIND == K_SIGNED) {
     bits ^= SIGN;
+  } else if (KIND == K_FTOTAL) {
+    bits ^= (bits & SIGN) ? U(~U(0)) : SIGN;
   } else if (KIND == K_FLOAT) {
     constexpr U EXP = (sizeof(U) == 8) ? U(0x7FF0000000000000ull) : U(0x7F800000u);
     const U mag     = bits & U(~SIGN);
@@ -493,6 +497,27 @@ __host__ __device__ __forceinline__ U to_sortable(U bits, U desc_mask)
     }
   }
   return bits ^ desc_mask;
+}
+
+// sortable form -> the key's own bits: the inverse of to_sortable for the kinds where it has one (integers: the transform is an
+// involution; K_FTOTAL: the flip undone).  K_FLOAT has none (-0.0 and NaN payloads are merged): its paths carry the original bits.
+template <typename U, int KIND>
+__host__ __device__ __forceinline__ U from_sortable(U s, U desc_mask)
+{
+  static_assert(KIND != K_FLOAT, "K_FLOAT's sortable form is not invertible");
+  constexpr U SIGN = U(U(1) << (sizeof(U) * 8 - 1));
+  s ^= desc_mask;
+  if (KIND == K_SIGNED) return U(s ^ SIGN);
+  if (KIND == K_FTOTAL) return (s & SIGN) ? U(s ^ SIGN) : U(~s);
+  return s;
+}
+// a float key that K_FTOTAL must not see: NaN (all of them sort last, in input order) or -0.0 (equivalent to +0.0)
+template <typename U>
+__host__ __device__ __forceinline__ bool float_unclean(U bits)
+{
+  constexpr U SIGN = U(U(1) << (sizeof(U) * 8 - 1));
+  constexpr U EXP  = (sizeof(U) == 8) ? U(0x7FF0000000000000ull) : U(0x7F800000u);
+  return (U)(bits & U(~SIGN)) > EXP || bits == SIGN;
 }
 
 // splitmix64: counter-based generator for synthetic data and checksums

@@ -1596,7 +1596,7 @@ __device__ __forceinline__ void local_place_cell(const uint32_t cell, const KeyT
 #pragma unroll
     for (int j = 0; j < LS_KPT; ++j) {
       const int i = j * LS_BT + (int)tid;
-      if ((uint32_t)i < m) out[start + i] = to_sortable<KeyT, KIND>((KeyT)s_keys[i + (i >> 4)], desc_mask);  // an involution for integer kinds
+      if ((uint32_t)i < m) out[start + i] = from_sortable<KeyT, KIND == K_FLOAT ? K_UNSIGNED : KIND>((KeyT)s_keys[i + (i >> 4)], desc_mask);  // (K_FLOAT never gets here: PACKED)
     }
   }
 }
@@ -1655,12 +1655,13 @@ __device__ __forceinline__ void local_sort_cell(const uint32_t cell, const IoT* 
   // sortable form of a register word: packed words already are, plain keys go through the transform
   auto sortable = [&](KeyT x) -> KeyT { return (PAIRS || NARROW) ? x : to_sortable<KeyT, KIND>(x, desc_mask); };
   // stores: `unsort` takes the sortable form of a key, `put` the form the registers hold (raw keys; sortable words when NARROW)
+  constexpr int IK = KIND == K_FLOAT ? K_UNSIGNED : KIND;  // (K_FLOAT keys never leave through unsort: they travel as packed words or raw)
   auto unsort = [&](KeyT x) -> IoT {
-    if constexpr (NARROW) return to_sortable<IoT, KIND>((IoT)x, (IoT)desc_mask);
-    else return to_sortable<KeyT, KIND>(x, desc_mask);
+    if constexpr (NARROW) return from_sortable<IoT, IK>((IoT)x, (IoT)desc_mask);
+    else return from_sortable<KeyT, IK>(x, desc_mask);
   };
   auto put = [&](KeyT x) -> IoT {
-    if constexpr (NARROW) return to_sortable<IoT, KIND>((IoT)x, (IoT)desc_mask);
+    if constexpr (NARROW) return from_sortable<IoT, IK>((IoT)x, (IoT)desc_mask);
     else return x;
   };
   extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -1808,7 +1809,10 @@ __device__ __forceinline__ void local_sort_cell(const uint32_t cell, const IoT* 
     }
     // undo the transform and fall through to the stable passes
 #pragma unroll
-    for (int j = 0; j < LS_KPT; ++j) key[j] = sortable(key[j]);
+    for (int j = 0; j < LS_KPT; ++j) {
+      if constexpr (NARROW) key[j] = key[j];  // (words that ARE the sortable form)
+      else key[j] = PAIRS ? key[j] : from_sortable<KeyT, IK>(key[j], desc_mask);
+    }
     __syncthreads();
   }
   for (int lp = 0; lp < nlocal; ++lp) {
@@ -1973,6 +1977,9 @@ __global__ void __launch_bounds__(256) k_hf_sample(const KeyT* __restrict__ in, 
       const bool live   = c0 + u * nw < nchunks && row < n;
       const KeyT k      = to_sortable<KeyT, KIND>(raw[u], desc_mask);
       if (!HIST && live) {
+        if constexpr (KIND == K_FTOTAL) {
+          if (float_unclean<KeyT>(raw[u])) hf.fail = 1;  // a NaN / -0.0 in the sample: stage 0 sends the column to the look-back path at once
+        }
         vor |= k;
         vnor |= (KeyT)~k;
         if (KIND == K_SIGNED) vfold |= (KeyT)(raw[u] ^ (KeyT)(KeyT(0) - (KeyT)(raw[u] >> (8 * sizeof(KeyT) - 1))));
@@ -2046,6 +2053,10 @@ __global__ void __launch_bounds__(BINS) k_hf_plan(SortPlan* plan, int stage, int
   FastPlan& hf   = plan->hf;
   const int t    = threadIdx.x;
   if (stage == 0) {
+    if (hf.fail) {  // (float keys) the sample holds a NaN or a -0.0: the look-back path -- stable -- sorts the column
+      if (t == 0) hf_give_up(plan, 0);
+      return;
+    }
     const unsigned long long V = hy.or_mask & hy.nor_mask;
     const int fh               = signed_keys ? fold_height(hy.fold_x, V, key_bits) : 0;  // (of the SAMPLE: level 0 reduces the exact one)
     const int top              = fh ? fh : (V ? 63 - __builtin_clzll(V) : 0);
@@ -2585,7 +2596,7 @@ __global__ void __launch_bounds__(256) k_sp_fill(uint64_t* __restrict__ out, uin
     __syncthreads();
     const uint32_t g0 = s_g[0], g1 = s_g[1];
     if (g0 == g1) {
-      const uint64_t v = to_sortable<uint64_t, KIND>(spc.lo + s_valj[g0], desc_mask);
+      const uint64_t v = from_sortable<uint64_t, KIND>(spc.lo + s_valj[g0], desc_mask);
       for (uint32_t i = lo + threadIdx.x; i < hi; i += 256) __builtin_nontemporal_store(v, &out[i]);
     } else {
       for (uint32_t i = lo + threadIdx.x; i < hi; i += 256) {
@@ -2594,7 +2605,7 @@ __global__ void __launch_bounds__(256) k_sp_fill(uint64_t* __restrict__ out, uin
           const uint32_t mid = (a + e) >> 1;
           if (s_start[mid] <= i) a = mid; else e = mid;
         }
-        __builtin_nontemporal_store(to_sortable<uint64_t, KIND>(spc.lo + s_valj[a], desc_mask), &out[i]);
+        __builtin_nontemporal_store(from_sortable<uint64_t, KIND>(spc.lo + s_valj[a], desc_mask), &out[i]);
       }
     }
     __syncthreads();
@@ -2740,7 +2751,7 @@ __global__ void __launch_bounds__(256) k_cs_fill(KeyT* __restrict__ out, int64_t
     __syncthreads();
     const uint32_t g0 = s_g[0], g1 = s_g[1];
     if (g0 == g1) {  // one value for the whole tile: the common case
-      const KeyT v = to_sortable<KeyT, KIND>((KeyT)(base | (KeyT)nz_val[g0]), desc_mask);
+      const KeyT v = from_sortable<KeyT, KIND>((KeyT)(base | (KeyT)nz_val[g0]), desc_mask);
       for (uint32_t i = lo + threadIdx.x; i < hi; i += 256) __builtin_nontemporal_store(v, &out[i]);
     } else {  // g1 - g0 <= CS_TILE: every group holds at least one key
       const uint32_t ng = g1 - g0 + 1;
@@ -2752,7 +2763,7 @@ __global__ void __launch_bounds__(256) k_cs_fill(KeyT* __restrict__ out, int64_t
           const uint32_t mid = (a + b) >> 1;
           if (s_start[mid] <= i) a = mid; else b = mid;
         }
-        __builtin_nontemporal_store(to_sortable<KeyT, KIND>((KeyT)(base | (KeyT)nz_val[g0 + a]), desc_mask), &out[i]);
+        __builtin_nontemporal_store(from_sortable<KeyT, KIND>((KeyT)(base | (KeyT)nz_val[g0 + a]), desc_mask), &out[i]);
       }
     }
     __syncthreads();
@@ -2997,14 +3008,25 @@ __global__ void __launch_bounds__(BT, 4) k_hf_scatter(const KeyT* __restrict__ i
     }
   }
   for (int b = tid; b < NB; b += BT) s_cnt[b] = 0;
+  if constexpr (LVL == 0 && KIND == K_FTOTAL) {  // float keys: every key is checked -- one NaN or -0.0 and the stable path sorts the column
+    bool unclean = false;
+#pragma unroll
+    for (int j = 0; j < KPT; ++j) unclean |= float_unclean<KeyT>(key[j]);
+    if (unclean) hf.fail = 1;
+  }
   if (LVL == 0) {
     // exact varying-bit masks of the column, on the raw keys: the sortable form of an integer is the key XOR a constant,
     // so the set of bits that differ somewhere is the same
-    KeyT vor = key[0], vnor = (KeyT)~key[0];
+    // (float keys, K_FTOTAL: the flip depends on the sign, so the masks are taken on the sortable form itself)
+    auto mform = [&](KeyT k) -> KeyT {
+      if constexpr (KIND == K_FTOTAL) return to_sortable<KeyT, KIND>(k, KeyT(0));
+      else return k;
+    };
+    KeyT vor = mform(key[0]), vnor = (KeyT)~mform(key[0]);
 #pragma unroll
     for (int j = 1; j < KPT; ++j) {
-      vor |= key[j];
-      vnor |= (KeyT)~key[j];
+      vor |= mform(key[j]);
+      vnor |= (KeyT)~mform(key[j]);
     }
     const unsigned long long wo = wave_reduce((unsigned long long)vor, [](unsigned long long x, unsigned long long y) { return x | y; });
     const unsigned long long wn = wave_reduce((unsigned long long)vnor, [](unsigned long long x, unsigned long long y) { return x | y; });
@@ -3182,12 +3204,22 @@ __global__ void __launch_bounds__(BT, 4) k_sp_level0(const uint64_t* __restrict_
     s_tab[b] = sp.tab[b];
   }
   for (int i = tid; i < SP_NLUT; i += BT) s_lut[i] = sp.lut[i];
+  if constexpr (KIND == K_FTOTAL) {  // float keys: one NaN or -0.0 and the stable path sorts the column (k_hf_plan stage 2 sees hf.fail)
+    bool unclean = false;
+#pragma unroll
+    for (int j = 0; j < KPT; ++j) unclean |= float_unclean<uint64_t>(key[j]);
+    if (unclean) hf.fail = 1;
+  }
   {  // exact varying-bit masks of the column (the LSD fallback and the stable passes of crowded cells skip constant bytes by them)
-    uint64_t vor = key[0], vnor = ~key[0];
+    auto mform = [&](uint64_t k) -> uint64_t {  // (float keys: the flip depends on the sign -- masks of the sortable form itself)
+      if constexpr (KIND == K_FTOTAL) return to_sortable<uint64_t, KIND>(k, 0ull);
+      else return k;
+    };
+    uint64_t vor = mform(key[0]), vnor = ~mform(key[0]);
 #pragma unroll
     for (int j = 1; j < KPT; ++j) {
-      vor |= key[j];
-      vnor |= ~key[j];
+      vor |= mform(key[j]);
+      vnor |= ~mform(key[j]);
     }
     const unsigned long long wo = wave_reduce((unsigned long long)vor, [](unsigned long long x, unsigned long long y) { return x | y; });
     const unsigned long long wn = wave_reduce((unsigned long long)vnor, [](unsigned long long x, unsigned long long y) { return x | y; });
@@ -3339,6 +3371,7 @@ struct FastCfg {
 };
 static thread_local int g_cursor          = 1;     // 0 disables the cursor path (A/B knob)
 static thread_local int g_counting        = 1;     // 0 disables the counting sort of narrow key ranges (A/B knob: the LSD passes run)
+static thread_local int g_float_cursor    = 1;     // 0: float64 keys stay on the look-back path (A/B knob)
 static thread_local int g_split           = 1;     // 0 disables the splitter mode of the cursor path (A/B knob: uneven columns are declined as before round 5)
 static thread_local int g_exp             = 0;     // ablation bits of k_local_sort (measurement only: the result is NOT sorted under most of them)
 static thread_local float g_cursor_margin = 8.0f;  // standard deviations of slack per level-0 slot (tests: < 0 forces the fallback)
@@ -3348,7 +3381,9 @@ static FastCfg fast_cfg(int64_t n, int algo, bool hybrid_on)
   FastCfg f{false, 9, 9, 32, 0};
   // 64-bit keys: wherever the hybrid path applies; 32-bit integer keys (round 3): the same two partition levels, the cells sorted
   // by k_local_place on 32-bit words, the LSD passes as the only fallback
-  if ((sizeof(KeyT) != 8 && sizeof(KeyT) != 4) || HAS_VAL || KIND == K_FLOAT || algo != 0 || !g_cursor || n < (1ll << 25)) return f;
+  // (round 5) float64 keys only: the cursor path runs on the total-order flip (K_FTOTAL) and verifies on every key that the column holds
+  // no NaN and no -0.0 -- the values on which an unordered sort and the reference's stable one could differ; else the look-back path
+  if ((sizeof(KeyT) != 8 && sizeof(KeyT) != 4) || HAS_VAL || (KIND == K_FLOAT && (sizeof(KeyT) != 8 || !g_float_cursor)) || algo != 0 || !g_cursor || n < (1ll << 25)) return f;
   if (sizeof(KeyT) == 8 ? !hybrid_on : !g_hybrid) return f;
   int B = 9;
   while (B < 18 && (double)n / (double)(1ull << B) > 0.955 * 8192.0) ++B;
@@ -3445,34 +3480,36 @@ int sort_impl(const void* keys_in, void* keys_out, const int32_t* vals_in, int32
   prof_mark(0, stream);
   g_prof.hybrid_marked = false;
   bool cursor_marked = false;
-  if constexpr ((sizeof(KeyT) == 8 || sizeof(KeyT) == 4) && !HAS_VAL && KIND != K_FLOAT) {
+  // CK: the key kind the cursor path's kernels are instantiated for -- float64 columns travel on the total-order flip (K_FTOTAL)
+  constexpr int CK = (KIND == K_FLOAT) ? (int)K_FTOTAL : KIND;
+  if constexpr ((sizeof(KeyT) == 8 || sizeof(KeyT) == 4) && !HAS_VAL && (KIND != K_FLOAT || sizeof(KeyT) == 8)) {
     if (fc.on) {
       // cursor path: speculative plan from a sample, verified by level 0; on a miss everything below is a no-op and the
       // look-back path further down sorts the column
       constexpr int FT = BT * hf_kpt<KeyT>();  // k_hf_scatter's tile
       constexpr int MIN_SHIFT2 = 8;  // key bits that must be left below level 1 (k_local_sort's sub-bucket split takes 7 + 1)
-      constexpr int WORD_BYTES = (int)sizeof(typename PlaceWord<KeyT, KIND, HAS_VAL>::type);
+      constexpr int WORD_BYTES = (int)sizeof(typename PlaceWord<KeyT, CK, HAS_VAL>::type);
       const int64_t ftiles  = div_up(n, (int64_t)FT);
       const int64_t frange  = (ftiles / NRANGE) * FT;  // rows per input range (whole tiles; the last range takes the rest)
       auto lds_hf = [&](int nb) { return (size_t)FT * sizeof(KeyT) + (size_t)(3 * nb + 16 + 4) * 4 + (size_t)2 * NW * 8; };
       typedef void (*HfK)(const KeyT*, KeyT*, KeyT, SortPlan*, uint32_t*, uint32_t, int64_t, KeyT*);
-      HfK kf0 = k_hf_scatter<KeyT, KIND, 0, 8>;
+      HfK kf0 = k_hf_scatter<KeyT, CK, 0, 8>;
       // (the level-1 kernel and the cell grids are sized for bits2_max: the device may take the extra bit)
-      HfK kf1 = fc.bits2_max <= 8 ? (HfK)k_hf_scatter<KeyT, KIND, 1, 8> : (fc.bits2_max == 9 ? (HfK)k_hf_scatter<KeyT, KIND, 1, 9> : (HfK)k_hf_scatter<KeyT, KIND, 1, 10>);
-      HfK kf2 = fc.bits2_max <= 8 ? (HfK)k_hf_scatter<KeyT, KIND, 2, 8> : (fc.bits2_max == 9 ? (HfK)k_hf_scatter<KeyT, KIND, 2, 9> : (HfK)k_hf_scatter<KeyT, KIND, 2, 10>);
+      HfK kf1 = fc.bits2_max <= 8 ? (HfK)k_hf_scatter<KeyT, CK, 1, 8> : (fc.bits2_max == 9 ? (HfK)k_hf_scatter<KeyT, CK, 1, 9> : (HfK)k_hf_scatter<KeyT, CK, 1, 10>);
+      HfK kf2 = fc.bits2_max <= 8 ? (HfK)k_hf_scatter<KeyT, CK, 2, 8> : (fc.bits2_max == 9 ? (HfK)k_hf_scatter<KeyT, CK, 2, 9> : (HfK)k_hf_scatter<KeyT, CK, 2, 10>);
       const int nbf = fc.bits2_max <= 8 ? 256 : (1 << fc.bits2_max);
       static std::atomic<bool> fattr_set{false};
       if (!fattr_set) {
-        GX_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(k_hf_scatter<KeyT, KIND, 2, 8>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_hf(256)));
-        GX_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(k_hf_scatter<KeyT, KIND, 2, 9>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_hf(512)));
-        GX_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(k_hf_scatter<KeyT, KIND, 2, 10>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_hf(1024)));
-        GX_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(k_hf_scatter<KeyT, KIND, 0, 8>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_hf(256)));
-        GX_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(k_hf_scatter<KeyT, KIND, 1, 8>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_hf(256)));
-        GX_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(k_hf_scatter<KeyT, KIND, 1, 9>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_hf(512)));
-        GX_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(k_hf_scatter<KeyT, KIND, 1, 10>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_hf(1024)));
-        GX_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(k_local_sort<uint64_t, KIND, HAS_VAL, 13, KeyT>), hipFuncAttributeMaxDynamicSharedMemorySize,
+        GX_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(k_hf_scatter<KeyT, CK, 2, 8>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_hf(256)));
+        GX_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(k_hf_scatter<KeyT, CK, 2, 9>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_hf(512)));
+        GX_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(k_hf_scatter<KeyT, CK, 2, 10>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_hf(1024)));
+        GX_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(k_hf_scatter<KeyT, CK, 0, 8>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_hf(256)));
+        GX_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(k_hf_scatter<KeyT, CK, 1, 8>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_hf(256)));
+        GX_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(k_hf_scatter<KeyT, CK, 1, 9>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_hf(512)));
+        GX_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(k_hf_scatter<KeyT, CK, 1, 10>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_hf(1024)));
+        GX_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(k_local_sort<uint64_t, CK, HAS_VAL, 13, KeyT>), hipFuncAttributeMaxDynamicSharedMemorySize,
                                        (int)(((size_t)8 << 13) + (size_t)(((1 << 13) / 16 / GX_WAVE) * BINS + 32 + 2 * BINS) * 4)));
-        GX_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(k_local_place<KeyT, KIND, HAS_VAL, 13>), hipFuncAttributeMaxDynamicSharedMemorySize,
+        GX_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(k_local_place<KeyT, CK, HAS_VAL, 13>), hipFuncAttributeMaxDynamicSharedMemorySize,
                                        (int)place_lds_bytes(13, WORD_BYTES)));
         fattr_set = true;
       }
@@ -3481,23 +3518,23 @@ int sort_impl(const void* keys_in, void* keys_out, const int32_t* vals_in, int32
       if (sblocks > 2048) sblocks = 2048;
       const KeyT* kin = static_cast<const KeyT*>(keys_in);
       KeyT* bufA      = keys_out ? static_cast<KeyT*>(keys_out) : ka_scratch;
-      hipLaunchKernelGGL((k_hf_sample<KeyT, KIND, false>), dim3((unsigned)sblocks), dim3(256), 0, stream, kin, n, desc_mask, plan, fc.stride, frange);
+      hipLaunchKernelGGL((k_hf_sample<KeyT, CK, false>), dim3((unsigned)sblocks), dim3(256), 0, stream, kin, n, desc_mask, plan, fc.stride, frange);
       hipLaunchKernelGGL(k_hf_plan, dim3(1), dim3(BINS), 0, stream, plan, 0, (int)(8 * sizeof(KeyT)), n, fc.bits2, 1 << 13, fc.stride, frange, FT,
-                         (unsigned long long)fc.slot_rows, g_cursor_margin, MIN_SHIFT2, fc.bits2_max, 0ull, KIND == K_SIGNED ? 1 : 0, g_counting);
+                         (unsigned long long)fc.slot_rows, g_cursor_margin, MIN_SHIFT2, fc.bits2_max, 0ull, CK == K_SIGNED ? 1 : 0, (KIND == K_FLOAT) ? 0 : g_counting);
       {
         // counting sort of a column whose varying bits are its low <= 15 (state 5; no-ops otherwise): histogram in LDS, scan, fill
         // (counters | group starts | group values live in the cell tables, unused on this branch and zeroed above)
         static std::atomic<bool> cattr_set{false};
         if (!cattr_set) {
-          GX_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(k_cs_count<KeyT, KIND>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)(4u << CS_MAXBITS)));
+          GX_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(k_cs_count<KeyT, CK>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)(4u << CS_MAXBITS)));
           cattr_set = true;
         }
-        hipLaunchKernelGGL((k_cs_count<KeyT, KIND>), dim3(256), dim3(CS_BT), (size_t)4 << CS_MAXBITS, stream, kin, n, desc_mask, plan, hist2);
+        hipLaunchKernelGGL((k_cs_count<KeyT, CK>), dim3(256), dim3(CS_BT), (size_t)4 << CS_MAXBITS, stream, kin, n, desc_mask, plan, hist2);
         hipLaunchKernelGGL(k_cs_scan, dim3(1), dim3(CS_BT), 0, stream, plan, (const uint32_t*)hist2, base2, xoff, n, NPASS);
-        hipLaunchKernelGGL((k_cs_fill<KeyT, KIND>), dim3(4096), dim3(256), 0, stream, bufA, n, desc_mask, (const SortPlan*)plan, (const uint32_t*)base2,
+        hipLaunchKernelGGL((k_cs_fill<KeyT, CK>), dim3(4096), dim3(256), 0, stream, bufA, n, desc_mask, (const SortPlan*)plan, (const uint32_t*)base2,
                            (const uint32_t*)xoff);
       }
-      hipLaunchKernelGGL((k_hf_sample<KeyT, KIND, true>), dim3((unsigned)sblocks), dim3(256), 0, stream, kin, n, desc_mask, plan, fc.stride, frange);
+      hipLaunchKernelGGL((k_hf_sample<KeyT, CK, true>), dim3((unsigned)sblocks), dim3(256), 0, stream, kin, n, desc_mask, plan, fc.stride, frange);
       const int allow_split = (sizeof(KeyT) == 8 && g_split) ? 1 : 0;
       hipLaunchKernelGGL(k_hf_plan, dim3(1), dim3(BINS), 0, stream, plan, 1, (int)(8 * sizeof(KeyT)), n, fc.bits2, 1 << 13, fc.stride, frange, FT,
                          (unsigned long long)fc.slot_rows, g_cursor_margin, MIN_SHIFT2, fc.bits2_max, 0ull, 0, 0, allow_split);
@@ -3508,14 +3545,14 @@ int sort_impl(const void* keys_in, void* keys_out, const int32_t* vals_in, int32
         if (allow_split) {
           static std::atomic<bool> sattr_set{false};
           if (!sattr_set) {
-            GX_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(k_sp_plan<KIND>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)(SP_NSAMP * 8)));
-            GX_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(k_sp_level0<KIND>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)sp_level0_lds()));
+            GX_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(k_sp_plan<CK>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)(SP_NSAMP * 8)));
+            GX_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(k_sp_level0<CK>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)sp_level0_lds()));
             sattr_set = true;
           }
           ftiles_s               = div_up(n, (int64_t)SP_TILE);
           const int64_t frange_s = (ftiles_s / NRANGE) * SP_TILE;
-          hipLaunchKernelGGL((k_sp_plan<KIND>), dim3(1), dim3(1024), (size_t)SP_NSAMP * 8, stream, kin, n, (uint64_t)desc_mask, plan, fc.bits2_max);
-          hipLaunchKernelGGL((k_sp_sample<KIND>), dim3((unsigned)sblocks), dim3(256), 0, stream, kin, n, (uint64_t)desc_mask, plan, fc.stride, frange_s);
+          hipLaunchKernelGGL((k_sp_plan<CK>), dim3(1), dim3(1024), (size_t)SP_NSAMP * 8, stream, kin, n, (uint64_t)desc_mask, plan, fc.bits2_max);
+          hipLaunchKernelGGL((k_sp_sample<CK>), dim3((unsigned)sblocks), dim3(256), 0, stream, kin, n, (uint64_t)desc_mask, plan, fc.stride, frange_s);
           hipLaunchKernelGGL(k_hf_plan, dim3(1), dim3(BINS), 0, stream, plan, 1, (int)(8 * sizeof(KeyT)), n, fc.bits2, 1 << 13, fc.stride, frange_s, FT,
                              (unsigned long long)fc.slot_rows, g_cursor_margin, MIN_SHIFT2, fc.bits2_max, 0ull, 0, 0, allow_split);
         }
@@ -3525,7 +3562,7 @@ int sort_impl(const void* keys_in, void* keys_out, const int32_t* vals_in, int32
       hipLaunchKernelGGL(kf0, dim3((unsigned)ftiles), dim3(BT), lds_hf(256), stream, kin, slot0_buf, desc_mask, plan, hist2, 1u << 13, n, (KeyT*)nullptr);
       if constexpr (sizeof(KeyT) == 8) {
         if (allow_split)
-          hipLaunchKernelGGL((k_sp_level0<KIND>), dim3((unsigned)ftiles_s), dim3(BT), sp_level0_lds(), stream, kin, slot0_buf, (uint64_t)desc_mask, plan, n);
+          hipLaunchKernelGGL((k_sp_level0<CK>), dim3((unsigned)ftiles_s), dim3(BT), sp_level0_lds(), stream, kin, slot0_buf, (uint64_t)desc_mask, plan, n);
       }
       hipLaunchKernelGGL(k_hf_plan, dim3(1), dim3(BINS), 0, stream, plan, 2, (int)(8 * sizeof(KeyT)), n, fc.bits2, 1 << 13, fc.stride, frange, FT,
                          (unsigned long long)fc.slot_rows, g_cursor_margin, MIN_SHIFT2, fc.bits2_max, (unsigned long long)nb_buf);
@@ -3536,14 +3573,14 @@ int sort_impl(const void* keys_in, void* keys_out, const int32_t* vals_in, int32
       prof_mark_h(3, stream);
       if constexpr (sizeof(KeyT) == 8) {
         if (allow_split)  // splitter mode: the narrow buckets (one value per cell) are filled from their cell starts
-          hipLaunchKernelGGL((k_sp_fill<KIND>), dim3(BINS, SP_FILL_Y), dim3(256), 0, stream, bufA, (uint64_t)desc_mask, (const SortPlan*)plan, (const uint32_t*)base2);
+          hipLaunchKernelGGL((k_sp_fill<CK>), dim3(BINS, SP_FILL_Y), dim3(256), 0, stream, bufA, (uint64_t)desc_mask, (const SortPlan*)plan, (const uint32_t*)base2);
       }
       // (one workgroup per cell of the plan n suggests; when the device took the extra level-1 bit each of them walks two cells)
-      hipLaunchKernelGGL((k_local_place<KeyT, KIND, HAS_VAL, 13>), dim3(local_place_grid(BINS << fc.bits2)), dim3((1 << 13) / 16),
+      hipLaunchKernelGGL((k_local_place<KeyT, CK, HAS_VAL, 13>), dim3(local_place_grid(BINS << fc.bits2)), dim3((1 << 13) / 16),
                          place_lds_bytes(13, WORD_BYTES), stream, kb_scratch, bufA, (const uint32_t*)nullptr, (uint32_t*)nullptr, desc_mask, plan, hist2,
                          base2, todo, g_exp, 1);
       // the cells k_local_place left: 64-bit words (32-bit keys are widened to their sortable form on the way in)
-      hipLaunchKernelGGL((k_local_sort<uint64_t, KIND, HAS_VAL, 13, KeyT>), dim3(local_sort_grid(BINS << fc.bits2_max)), dim3((1 << 13) / 16),
+      hipLaunchKernelGGL((k_local_sort<uint64_t, CK, HAS_VAL, 13, KeyT>), dim3(local_sort_grid(BINS << fc.bits2_max)), dim3((1 << 13) / 16),
                          ((size_t)8 << 13) + (size_t)(((1 << 13) / 16 / GX_WAVE) * BINS + 32 + 2 * BINS) * 4, stream, (const KeyT*)kb_scratch, bufA,
                          (const uint32_t*)nullptr, (uint32_t*)nullptr, (uint64_t)desc_mask, plan, hist2, base2, g_exp, 1, (const uint32_t*)todo);
       prof_mark_h(4, stream);
@@ -4366,6 +4403,7 @@ void gx_sort_set_order_words(int enable) { gx::sort::g_order_words = enable ? 1 
 
 void gx_sort_set_counting(int enable) { gx::sort::g_counting = enable ? 1 : 0; }
 void gx_sort_set_splitters(int enable) { gx::sort::g_split = enable ? 1 : 0; }
+void gx_sort_set_float_cursor(int enable) { gx::sort::g_float_cursor = enable ? 1 : 0; }
 int gx_sort_split_info(const void* tmp, int32_t* info4_host, gx_stream_t stream)
 {
   if (!tmp || !info4_host) return GX_EINVAL;

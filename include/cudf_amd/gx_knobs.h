@@ -85,6 +85,11 @@ void gx_sort_set_counting(int enable);
  * (round 5: k_sp_plan / k_sp_level0, equal-width cells inside a bucket, equality buckets for heavy values); 0 = such a column is
  * declined to the LSD passes, as before. */
 void gx_sort_set_splitters(int enable);
+/* A/B knob (per calling thread): 1 (default) = FLOAT64 keys-only sorts of >= 2^25 rows take the cursor path on the IEEE total-order
+ * flip; every key is checked, and a column with a NaN or a -0.0 -- where an unordered sort and the reference's stable radix sort of
+ * (isnan * (idx + 1), value) pairs (cpp/src/sort/sort_radix.cu:36-117) could differ -- is sorted by the stable look-back path
+ * instead (decided on the device); 0 = float keys always take the look-back path, as before round 5. */
+void gx_sort_set_float_cursor(int enable);
 /* info4 = {splitter mode used, splitters, equality buckets, level-1 bits} of the last sort on this scratch (synchronises). */
 int gx_sort_split_info(const void* tmp, int32_t* info4_host, gx_stream_t stream);
 /* 0 = not tried, 2 = tried and rejected by the device (the look-back path ran), 3 = the cursor path sorted the column,
