@@ -176,13 +176,17 @@ struct SortCounters {
 // ---------------------------------------------------------------------------------------------------------------------------
 constexpr int SP_NSAMP = 16384;  // sampled keys, sorted by one workgroup (128 KiB of LDS)
 constexpr int SP_NLUT  = 2048;
+constexpr int SP_NPIECE = 16;  // pieces of a bucket's range whose sampled masses shape the bucket's cell map (sp_warp)
+constexpr int SP_PSH    = 28;  // piece of a fraction = frac >> SP_PSH
 struct SplitPlan {
   int32_t req;             // k_hf_plan stage 1 asks for splitters
   int32_t on;              // k_sp_plan has built the tables: level 0 / level 1 / the cell sort use them
   uint32_t nsp;            // splitters in use; buckets = nsp + 1 <= BINS
   uint32_t neq;            // equality buckets
   unsigned long long kmin; // LUT origin (the sample's smallest key)
-  uint32_t lut_log, lshift;
+  uint32_t lut_log, lshift;      // LUT form: 0 linear in (key - kmin) >> lshift, 1 logarithmic, 2 (float keys) one linear half per sign (SpLutF)
+  unsigned long long f_nmin, f_pmin;  // form 2: the sample's smallest negative / smallest positive key (sortable form) ...
+  uint32_t f_nsh, f_psh;              // ... and the shifts that lay each sign's sampled range over SP_NLUT / 2 cells
   unsigned long long tab[BINS];  // sorted splitters (sortable form), padded with ~0
   unsigned long long lo[BINS];   // bucket b maps keys in [lo, lo + w) to [0, 1): its range, clamped to the sample's at either end
   unsigned long long w[BINS];
@@ -192,9 +196,15 @@ struct SplitPlan {
   uint32_t nc[BINS];             // cells of bucket b (k_hf_plan stage 2, from the EXACT level-0 histogram): about 7400 keys per cell whatever the
                                  // bucket's size -- a 16384-key sample balances the buckets to +- 12 %, and a power-of-two cell count sized for the
                                  // fullest bucket left every cell half empty (the cell sort costs a cell what it costs full: 5.4 against 3.3 ms)
-  uint32_t pf[BINS];             // k_sp_plan: peak / mean density inside the bucket x 256, from where the bucket's sampled keys have their median
-                                 // (a linear-density model): equal-width cells must be sized for the DENSE end -- power-law and bell tails
-                                 // vary 1.2 - 2 x across one bucket and 4 % / 1.5 % of such columns' keys overfilled the dense-end cells
+  uint32_t pf[BINS];             // k_hf_plan stage 1: fullest / mean cell of the bucket x 256 as far as the n / 32 sample can tell -- what is left
+                                 // of the density's slope INSIDE one piece of the warp (1.01 - 1.05 for smooth densities); cells and their slots
+                                 // are sized for it.  (Until run 12 the cells were equal-width slices sized by a peak factor taken from the
+                                 // median of ~68 sampled keys: 1.25 on average -- a quarter more cells than needed -- and still 1 - 2.5 % of a
+                                 // bell-shaped / float column's keys overfilled the dense-end cells: scripts/xp/xp_split_warp_model.py.)
+  uint32_t sub[BINS][SP_NPIECE]; // k_sp_sample: sampled keys per (bucket, sixteenth of the bucket's range)
+  uint2 wt[BINS][SP_NPIECE];     // k_hf_plan stage 1: the bucket's WARP -- piece j of the fraction maps linearly onto [x, x + y) with y proportional
+                                 // to the piece's sampled mass: a piecewise-linear estimate of the bucket's CDF, so that equal slices of the
+                                 // warped fraction (the cells, and the cell sort's counting bins) hold equal numbers of keys
   uint32_t nw[BINS];             // values in the bucket's TRUE range when that is what lo / w describe and it is small (<= 65535), else 0: with
                                  // nw <= cells per bucket every cell holds ONE value -- a NARROW bucket is counted and filled, never sorted
   uint16_t lut[SP_NLUT];         // splitters in LUT cells below c | 0x8000 when cell c holds none (the bucket is then known)
@@ -208,17 +218,25 @@ __device__ __forceinline__ SpCell sp_cell_of(const SplitPlan& sp, uint32_t b) { 
 // (bits2 = the level-1 bits the launches are sized for: 1 << bits2 cell slots per bucket)
 __device__ __forceinline__ bool sp_narrow(const SplitPlan& sp, uint32_t b, int bits2) { return sp.nw[b] != 0u && sp.nw[b] <= (1u << bits2) && !sp.eq[b]; }
 // cell of a key inside its bucket and, below it, the CL2-bit counting digit of the cell sort: both from frac * cells
-__device__ __forceinline__ uint32_t sp_cell(uint32_t frac, uint32_t nc) { return (uint32_t)(((unsigned long long)frac * nc) >> 32); }
+__device__ __forceinline__ uint32_t sp_cell(uint32_t frac, uint32_t nc) { return __umulhi(frac, nc); }
+// (one v_mul_hi_u32 each -- 32-bit multiplies run at a quarter of the VALU rate, and the 64-bit product these are written as costs two:
+//  (frac * nc) >> (32 - CL2) = mulhi(frac, nc << CL2) while nc << CL2 < 2^32 -- nc <= 1024, CL2 = 13)
 template <int CL2>
-__device__ __forceinline__ uint32_t sp_fine(uint32_t frac, uint32_t nc) { return (uint32_t)(((unsigned long long)frac * nc) >> (32 - CL2)) & ((1u << CL2) - 1u); }
+__device__ __forceinline__ uint32_t sp_fine(uint32_t frac, uint32_t nc) { return __umulhi(frac, nc << CL2) & ((1u << CL2) - 1u); }
+// the bucket's warp (SplitPlan::wt, staged in LDS by the caller): monotone -- piece j ends below x[j] + y[j] <= x[j + 1] -- and the
+// IDENTITY for the table {j << 28, 1 << 28} that narrow buckets get (their cell map must stay injective: k_sp_fill inverts it)
+__device__ __forceinline__ uint32_t sp_warp(uint32_t frac, const uint2* wt)
+{
+  const uint2 e = wt[frac >> SP_PSH];
+  return e.x + __umulhi(frac << (32 - SP_PSH), e.y);  // = ((frac & (2^28 - 1)) * e.y) >> 28
+}
 // position of a key inside its bucket's range as a 32-bit fraction; monotone; keys outside the range clamp to its ends
 __device__ __forceinline__ uint32_t sp_frac(const SpCell& c, unsigned long long key)
 {
   const unsigned long long rel = key > c.lo ? key - c.lo : 0ull;
   if (rel >= c.w) return 0xFFFFFFFFu;
-  const uint32_t x           = c.nsh >= 0 ? (uint32_t)(rel >> c.nsh) : (uint32_t)(rel << (-c.nsh));
-  const unsigned long long p = (unsigned long long)x * c.mlow;
-  return (x << 1) + (uint32_t)(p >> 31);
+  const uint32_t x = c.nsh >= 0 ? (uint32_t)(rel >> c.nsh) : (uint32_t)(rel << (-c.nsh));  // < 2^31
+  return (x << 1) + __umulhi(x << 1, c.mlow);                                                // = (x * mlow) >> 31
 }
 __device__ __forceinline__ uint32_t sp_lut_cell(unsigned long long rel, uint32_t lut_log, uint32_t lshift)
 {
@@ -231,15 +249,38 @@ __device__ __forceinline__ uint32_t sp_lut_cell(unsigned long long rel, uint32_t
   const unsigned long long c = rel >> lshift;
   return c < (unsigned long long)(SP_NLUT - 1) ? (uint32_t)c : (uint32_t)(SP_NLUT - 1);
 }
+// Form 2: TWO linear halves, cut at the widest gap between neighbouring splitters.  Float keys of both signs: the sortable forms of -x
+// and +x lie 2^63 apart with nothing between -tiny and +tiny, and one binade is 2^52 of 2^64 -- a linear LUT over the whole range gives
+// a binade two cells, the logarithmic one is no better: N(0, 1) doubles had 61 / 79 splitters in the fullest cell and 97 % / 50 % of the
+// keys paid a bisection (level 0: 7.3 ms against 5.1 for U[0, 1); 5.3 with this form, run 13).  Integer keys around two far-apart
+// centres: a cluster's 125 splitters in one cell of either form (level 0: 6.2 ms).  Each side of the gap gets half the cells, linear
+// over its own splitters' range.  (Run 12's four-segment form cost EVERY column 0.7 ms at level 0: eleven 64-bit parameters and a
+// 4-way select per key.  This one is two parameters and one compare, behind a block-uniform test of the form.)
+struct SpLutF {
+  unsigned long long nmin, pmin;  // origin of the lower half (the sample's smallest key) | first key of the upper half (the splitter above the gap)
+  uint32_t nsh, psh;
+};
+__device__ __forceinline__ SpLutF sp_lutf_of(const SplitPlan& sp) { return SpLutF{sp.f_nmin, sp.f_pmin, sp.f_nsh, sp.f_psh}; }
+template <int KIND>
+__device__ __forceinline__ uint32_t sp_lut_cell_k(unsigned long long key, unsigned long long kmin, uint32_t form, uint32_t lshift, const SpLutF& f)
+{
+  if (form == 2u) {
+    const bool pos             = key >= f.pmin;
+    const unsigned long long o = pos ? f.pmin : f.nmin;
+    const unsigned long long c = (key > o ? key - o : 0ull) >> (pos ? f.psh : f.nsh);
+    return (pos ? (uint32_t)(SP_NLUT / 2) : 0u) + (c < (unsigned long long)(SP_NLUT / 2 - 1) ? (uint32_t)c : (uint32_t)(SP_NLUT / 2 - 1));
+  }
+  return sp_lut_cell(key >= kmin ? key - kmin : 0ull, form, lshift);
+}
 // bucket = number of splitters <= key (exact for every key: the LUT only says where the search starts).  LUT word: bits 0-8 the
 // splitters in cells below, bits 9-14 the splitters INSIDE the cell (capped at 63), bit 15 "none inside" (the bucket is then known).
 // A few inside: a short scan; many (two far-apart clusters put a whole cluster's splitters into one cell of either LUT form:
 // 46 ms for level 0 in the first run): a bisection of that stretch of the sorted table.
+template <int KIND>
 __device__ __forceinline__ uint32_t sp_bucket(const unsigned long long* __restrict__ tab, const uint16_t* __restrict__ lut, unsigned long long key,
-                                              uint32_t nsp, unsigned long long kmin, uint32_t lut_log, uint32_t lshift)
+                                              uint32_t nsp, unsigned long long kmin, uint32_t lut_log, uint32_t lshift, const SpLutF& lf)
 {
-  const unsigned long long rel = key >= kmin ? key - kmin : 0ull;
-  const uint32_t wd            = lut[sp_lut_cell(rel, lut_log, lshift)];
+  const uint32_t wd            = lut[sp_lut_cell_k<KIND>(key, kmin, lut_log, lshift, lf)];
   uint32_t b                   = wd & 0x1FFu;
   if (wd & 0x8000u) return b;
   const uint32_t inside = (wd >> 9) & 63u;
@@ -456,10 +497,14 @@ __global__ void __launch_bounds__(BT) k_hy_hist(const KeyT* __restrict__ in, int
 // its cells are as dense as its neighbours', so a bucket takes the LARGEST mean of itself and its two neighbours -- when the
 // total fits `budget` keys (the buffer the host made: n + slack per cell + n / 16); otherwise its own mean, which always fits.
 __device__ __forceinline__ void plan_cell_slots(HybridPlan& hy, uint32_t bucket_count, int bits2, int cell_max, uint32_t* s_tmp,
-                                                unsigned long long budget, uint32_t ncells_given = 0u)
+                                                unsigned long long budget, uint32_t ncells_given = 0u, uint32_t true_count = 0xFFFFFFFFu)
 {
-  // ncells_given (splitter mode): the cells this bucket uses (SplitPlan::nc) when that is not all of the 1 << bits2 slots
+  // ncells_given (splitter mode): the cells this bucket uses (SplitPlan::nc) when that is not all of the 1 << bits2 slots;
+  // bucket_count is then the bucket's size x its fullest / mean cell (SplitPlan::pf) and true_count its size: slots sized for the
+  // fullest cell need not fit the buffer -- the third choice, slots for the mean cell, always does
   __shared__ uint32_t s_mean[BINS];
+  __shared__ unsigned long long s_tmp64[BINS / GX_WAVE + 1];
+  (void)s_tmp;
   const int t           = threadIdx.x;
   const uint32_t ncells = ncells_given ? ncells_given : (1u << bits2);
   const uint32_t mean   = bucket_count / ncells + 1u;
@@ -474,12 +519,22 @@ __device__ __forceinline__ void plan_cell_slots(HybridPlan& hy, uint32_t bucket_
     return cap > (uint32_t)cell_max ? (uint32_t)cell_max : cap;
   };
   const uint32_t cap_a = cap_of(m3), cap_b = cap_of(mean);
-  uint32_t total_a;
-  const uint32_t base_a = block_exclusive_scan<BINS>(cap_a * ncells, 0u, SumOp(), s_tmp, &total_a);
-  const uint32_t base_b = block_exclusive_scan<BINS>(cap_b * ncells, 0u, SumOp(), s_tmp, (uint32_t*)nullptr);
-  const bool smooth     = (unsigned long long)total_a <= budget;
-  hy.ccap[t]  = smooth ? cap_a : cap_b;
-  hy.cbase[t] = smooth ? base_a : base_b;
+  // (sums in 64 bits: a splitter-mode column of steep buckets can ask for more than 2^32 keys of slots)
+  unsigned long long total_a, total_b;
+  const unsigned long long base_a = block_exclusive_scan<BINS>((unsigned long long)cap_a * ncells, 0ull, SumOp(), s_tmp64, &total_a);
+  const unsigned long long base_b = block_exclusive_scan<BINS>((unsigned long long)cap_b * ncells, 0ull, SumOp(), s_tmp64, &total_b);
+  const bool smooth = total_a <= budget;
+  uint32_t cap = smooth ? cap_a : cap_b, base = (uint32_t)(smooth ? base_a : base_b);
+  if (true_count != 0xFFFFFFFFu) {  // block-uniform (splitter mode)
+    const uint32_t cap_c            = cap_of(true_count / ncells + 1u);
+    const unsigned long long base_c = block_exclusive_scan<BINS>((unsigned long long)cap_c * ncells, 0ull, SumOp(), s_tmp64, (unsigned long long*)nullptr);
+    if (!smooth && total_b > budget) {
+      cap  = cap_c;
+      base = (uint32_t)base_c;
+    }
+  }
+  hy.ccap[t]  = cap;
+  hy.cbase[t] = base;
 }
 
 // digits of the local sort's stable LDS passes: the bytes below shift2 that vary somewhere in the column
@@ -1479,12 +1534,16 @@ __device__ __forceinline__ void local_place_cell(const uint32_t cell, const KeyT
   // that follow the cell's own (equal-width sub-slices of the cell; monotone, which is all the placement needs)
   const SpCell spc    = SPLIT ? sp_cell_of(plan->sp, b) : SpCell{0ull, 1ull, 0u, 63};
   const uint32_t spnc = SPLIT ? plan->sp.nc[b] : 1u;
+  __shared__ uint2 s_wt[SPLIT ? SP_NPIECE : 1];  // the bucket's warp (read between the two barriers below; the next cell's write comes after both)
   auto bin_of         = [&](WordT wd) -> uint32_t {
-    if constexpr (SPLIT) return sp_fine<CL2>(sp_frac(spc, (unsigned long long)wd), spnc);
+    if constexpr (SPLIT) return sp_fine<CL2>(sp_warp(sp_frac(spc, (unsigned long long)wd), s_wt), spnc);
     else return (uint32_t)(wd >> dshift) & (uint32_t)(NPB - 1);
   };
 
   reinterpret_cast<uint4*>(s_cnt8)[tid] = make_uint4(0u, 0u, 0u, 0u);
+  if constexpr (SPLIT) {
+    if (tid < (unsigned)SP_NPIECE) s_wt[tid] = plan->sp.wt[b][tid];
+  }
   WordT key[LS_KPT];
 #pragma unroll
   for (int j = 0; j < LS_KPT; ++j) {
@@ -2172,6 +2231,54 @@ __global__ void __launch_bounds__(BINS) k_hf_plan(SortPlan* plan, int stage, int
       hf.cap0[r][t]  = cap[r];
       run += cap[r];
     }
+    if (sp.on) {
+      // splitter mode: the WARP of bucket t's cell map from the sampled masses of the sixteen pieces of its range (k_sp_sample: n / 32
+      // keys, ~7600 per piece of an ordinary bucket -- the masses are known to about 1 %).  Piece j maps onto a stretch of the warped
+      // fraction proportional to its mass (floored at 1/64 of an even share: keys the sample missed keep some resolution).
+      // Narrow buckets, equality buckets and buckets the sample hardly saw keep the identity.
+      uint32_t m[SP_NPIECE];
+      uint32_t M = 0;
+#pragma unroll
+      for (int j = 0; j < SP_NPIECE; ++j) {
+        m[j] = sp.sub[t][j];
+        M += m[j];
+      }
+      uint32_t pfx = 320;
+      if (sp.eq[t] || sp.w[t] <= 65535ull || M < 1024u) {
+#pragma unroll
+        for (int j = 0; j < SP_NPIECE; ++j) sp.wt[t][j] = make_uint2((uint32_t)j << SP_PSH, 1u << SP_PSH);
+      } else {
+        const uint32_t fl = M / (uint32_t)(SP_NPIECE * 64) + 1u;
+        double tot        = 0.0;
+#pragma unroll
+        for (int j = 0; j < SP_NPIECE; ++j) {
+          m[j] = m[j] < fl ? fl : m[j];
+          tot += (double)m[j];
+        }
+        uint32_t y  = 0;
+        double peak = 1.0;
+#pragma unroll
+        for (int j = 0; j < SP_NPIECE; ++j) {
+          uint32_t d = (uint32_t)((double)m[j] / tot * 4294967040.0);  // (the sixteen of them add up to less than 2^32 - 256 + 16)
+          d          = d < 1u ? 1u : d;
+          sp.wt[t][j] = make_uint2(y, d);
+          y += d;
+          // what the warp cannot follow: the slope of the density INSIDE a piece.  Density at the piece's two edges ~ the mean of the two
+          // pieces that meet there (extrapolated at the bucket's ends); the fullest cell of the piece is that much over the piece's mean
+          if (m[j] * 256u >= M) {  // (a piece that holds a couple of cells or more)
+            const double c  = (double)m[j];
+            const double el = j > 0 ? 0.5 * ((double)m[j - 1] + c) : c + 0.5 * (c - (double)m[j + 1]);
+            const double er = j < SP_NPIECE - 1 ? 0.5 * ((double)m[j + 1] + c) : c + 0.5 * (c - (double)m[j - 1]);
+            const double r  = (el > er ? el : er) / c;
+            peak            = r > peak ? r : peak;
+          }
+        }
+        peak += 0.02;  // (the masses' own noise)
+        peak = peak > 2.5 ? 2.5 : peak;
+        pfx  = (uint32_t)(peak * 256.0);
+      }
+      sp.pf[t] = pfx;
+    }
     if (t == 0) {  // level 0 reduces the EXACT masks into these
       hy.or_mask  = 0;
       hy.nor_mask = 0;
@@ -2216,7 +2323,7 @@ __global__ void __launch_bounds__(BINS) k_hf_plan(SortPlan* plan, int stage, int
     // every bucket gets as many of the 1 << bits2_max cell slots as its EXACT size asks for at ~7400 keys per cell (a narrow bucket:
     // all of them -- one value per cell); the tables and grids behind are indexed with bits2_max
     const uint32_t ncmax = 1u << bits2_max;
-    uint32_t nc          = (uint32_t)(((unsigned long long)cc * sp.pf[t] / 256ull + 7399ull) / 7400ull);  // sized for the bucket's dense end
+    uint32_t nc          = (uint32_t)(((unsigned long long)cc * sp.pf[t] / 256ull + 7399ull) / 7400ull);  // sized for the bucket's fullest cell
     nc                   = nc < 1u ? 1u : (nc > ncmax ? ncmax : nc);
     if (sp.nw[t] != 0u && sp.nw[t] <= ncmax && !sp.eq[t]) nc = ncmax;
     // a range of few values (<= 8 per cell slot): a cell holds a whole number of values, so with cells sized for the MEAN a cell of
@@ -2263,8 +2370,12 @@ __global__ void __launch_bounds__(BINS) k_hf_plan(SortPlan* plan, int stage, int
     }
   }
   // (splitter mode: a narrow bucket is only counted and an empty one holds nothing -- one cell's worth of slot space)
-  plan_cell_slots(hy, cc, hy.bits2, cell_max, s_tmp, cell_budget,
-                  sp.on ? ((cc == 0u || (sp.nw[t] != 0u && sp.nw[t] <= (1u << bits2_max) && !sp.eq[t])) ? 1u : sp.nc[t]) : 0u);
+  // (... and a slot holds the bucket's FULLEST cell -- pf x the mean: until run 12 the slots were sized for the mean, and the dense-end cells
+  //  of every bucket with pf > 1.08 overflowed them by construction: 1 - 2.5 % of the keys of bell-shaped / float columns went through X)
+  const unsigned long long cc_pf = (unsigned long long)cc * (sp.on ? sp.pf[t] : 256u) / 256ull;
+  const uint32_t cc_slots        = cc_pf < 0xFFFFFFFFull ? (uint32_t)cc_pf : 0xFFFFFFFFu;
+  plan_cell_slots(hy, cc_slots, hy.bits2, cell_max, s_tmp, cell_budget,
+                  sp.on ? ((cc == 0u || (sp.nw[t] != 0u && sp.nw[t] <= (1u << bits2_max) && !sp.eq[t])) ? 1u : sp.nc[t]) : 0u, sp.on ? cc : 0xFFFFFFFFu);
   uint32_t tiles = 0;
   for (int r = 0; r < NRANGE; ++r) tiles += (cnt[r] + (uint32_t)tile_rows - 1) / (uint32_t)tile_rows;
   uint32_t ttotal;
@@ -2300,8 +2411,8 @@ __global__ void __launch_bounds__(1024) k_sp_plan(const uint64_t* __restrict__ i
   unsigned long long* s = reinterpret_cast<unsigned long long*>(smem);  // [SP_NSAMP]
   __shared__ uint32_t s_wsum[1024 / GX_WAVE + 1];
   __shared__ uint32_t s_total;
-  __shared__ uint32_t s_idx[2][BINS];
-  __shared__ uint32_t s_worst[2];
+  __shared__ uint32_t s_idx[3][BINS];
+  __shared__ uint32_t s_worst[3];
   __shared__ unsigned long long s_tab[BINS];
   __shared__ uint32_t s_handled[BINS];
   const int tid = threadIdx.x;
@@ -2370,6 +2481,69 @@ __global__ void __launch_bounds__(1024) k_sp_plan(const uint64_t* __restrict__ i
     if (tid == 0) sp.req = -1;                  // stage 1's second launch then sends the column to the LSD passes, as before round 5
     return;
   }
+  // ---- GAP splitters.  A bucket whose sampled keys leave more than half of its extent empty in ONE gap straddles two clusters (int
+  // keys around two far-apart centres; float keys of both signs: nothing lies between -tiny and +tiny, 2^63 apart in sortable form).
+  // No map over its range can cut such a bucket into even cells -- its keys sit at the two ends (two clusters, run 13: 4 cells of 4.8e6
+  // keys through X; N(0, 1) doubles: 157 cells, 5e6 keys) -- so the gap gets a bucket of its own: two more splitters, at most twice.
+  {
+    __shared__ unsigned long long s_g64[1024 / GX_WAVE];
+    __shared__ uint32_t s_gwin[1024 / GX_WAVE];
+    __shared__ unsigned long long s_gv[2];
+    __shared__ uint32_t s_gt;
+    auto lower = [&](unsigned long long v) {  // first sample index whose key is >= v
+      int a = 0, e = SP_NSAMP;
+      while (a < e) {
+        const int mid = (a + e) >> 1;
+        if (s[mid] < v) a = mid + 1; else e = mid;
+      }
+      return a;
+    };
+    for (int round = 0; round < 2 && nsp + 2u <= (uint32_t)BINS - 1u; ++round) {  // (block-uniform)
+      unsigned long long g = 0ull, ga = 0ull, gb = 0ull;
+      if (tid <= (int)nsp) {
+        const unsigned long long tlo = tid == 0 ? 0ull : s_tab[tid - 1];
+        const int ia = tid == 0 ? 0 : lower(tlo), ib = tid == (int)nsp ? SP_NSAMP : lower(s_tab[tid]);
+        if (ib - ia >= 2) {
+          for (int i = ia; i + 1 < ib; ++i) {
+            const unsigned long long a = s[i], d = s[i + 1] - a;
+            if (d > g) {
+              g  = d;
+              ga = a;
+              gb = a + d;
+            }
+          }
+          if (g < (1ull << 20) || g <= (s[ib - 1] - s[ia]) / 2ull) g = 0ull;
+        }
+      }
+      const unsigned long long wg = wave_reduce(g, [](unsigned long long x, unsigned long long y) { return x > y ? x : y; });
+      if ((tid & (GX_WAVE - 1)) == 0) s_g64[tid / GX_WAVE] = wg;
+      __syncthreads();
+      unsigned long long gmax = 0ull;
+      for (int w = 0; w < 1024 / GX_WAVE; ++w) gmax = s_g64[w] > gmax ? s_g64[w] : gmax;
+      if (gmax == 0ull) break;  // (block-uniform)
+      const uint32_t cand = (g == gmax) ? (uint32_t)tid : 0xFFFFFFFFu;  // the first bucket that has it
+      const uint32_t wc   = wave_reduce(cand, [](uint32_t x, uint32_t y) { return x < y ? x : y; });
+      if ((tid & (GX_WAVE - 1)) == 0) s_gwin[tid / GX_WAVE] = wc;
+      __syncthreads();
+      uint32_t win = 0xFFFFFFFFu;
+      for (int w = 0; w < 1024 / GX_WAVE; ++w) win = s_gwin[w] < win ? s_gwin[w] : win;
+      if ((uint32_t)tid == win) {
+        s_gv[0] = ga + 1ull;
+        s_gv[1] = gb;
+        s_gt    = (uint32_t)tid;
+      }
+      const unsigned long long mine = tid < (int)nsp ? s_tab[tid] : ~0ull;
+      __syncthreads();
+      const uint32_t t = s_gt;  // both new splitters lie inside bucket t: the entries from t on move up by two
+      if (tid < (int)nsp && (uint32_t)tid >= t) s_tab[tid + 2] = mine;
+      if (tid == 0) {
+        s_tab[t]      = s_gv[0];
+        s_tab[t + 1u] = s_gv[1];
+      }
+      nsp += 2u;
+      __syncthreads();
+    }
+  }
   const unsigned long long kmin = s[0], kmax = s[SP_NSAMP - 1];
   // ---- per-bucket maps.  Bucket b holds the keys in [T(b - 1), T(b)) with T(-1) = 0 and T(nsp) = 2^64; the cell map of the first /
   // last bucket is laid over what the SAMPLE saw of it (keys beyond clamp to the end cells -- still monotone)
@@ -2396,29 +2570,7 @@ __global__ void __launch_bounds__(1024) k_sp_plan(const uint64_t* __restrict__ i
       const unsigned long long M = (1ull << 63) / ((unsigned long long)wx + 1ull);      // [2^32, 2^33)
       mlow                       = (uint32_t)(M - (1ull << 32));
     }
-    // density skew inside the bucket: the median of the sampled keys that fall into [lo, hi) sits at fraction f of the range; for a
-    // density that is linear across the bucket, peak / mean = (0.5 - f^2) / (f (1 - f)) with f the smaller of the two sides
-    uint32_t pfx = 256;
-    {
-      auto lower = [&](unsigned long long v) {  // first sample index whose key is >= v
-        int a = 0, e = SP_NSAMP;
-        while (a < e) {
-          const int mid = (a + e) >> 1;
-          if (s[mid] < v) a = mid + 1; else e = mid;
-        }
-        return a;
-      };
-      const int ia = lower(lo), ib = lastb ? SP_NSAMP : lower(hi);
-      if (ib - ia >= 8 && w >= 16ull) {
-        const unsigned long long med = s[(ia + ib) >> 1];
-        double f = (double)(med - lo) / (double)w;
-        f        = f > 0.5 ? 1.0 - f : f;
-        f        = f < 0.2 ? 0.2 : f;
-        const double peak = (0.5 - f * f) / (f * (1.0 - f)) + 0.1;  // + 0.1: the median of ~68 samples is known to +- 6 % of the mass
-        pfx = (uint32_t)(peak * 256.0);
-        pfx = pfx < 256u ? 256u : (pfx > 640u ? 640u : pfx);
-      }
-    }
+    const uint32_t pfx = 320;  // (k_hf_plan stage 1 measures it on the n / 32 sample; this is what a bucket without enough sampled keys keeps)
     // interior buckets map exactly their true range; the first / last one only when it is a single value
     const bool pure = (tid > 0 && !lastb) || eq;
     mynw            = pure && w <= 65535ull ? (uint32_t)w : 0u;
@@ -2470,16 +2622,35 @@ __global__ void __launch_bounds__(1024) k_sp_plan(const uint64_t* __restrict__ i
       return;
     }
   }
-  // ---- the LUT: cells cut on rel = key - kmin LINEARLY (even or bell-shaped densities) or LOGARITHMICALLY (power laws); the form whose
-  // fullest cell holds fewer splitters wins
-  uint32_t lshift = 0;
+  // ---- the LUT: cells cut on rel = key - kmin LINEARLY (even or bell-shaped densities) or LOGARITHMICALLY (power laws) or, for float keys
+  // of both signs, linearly per sign (SpLutF); the form whose fullest cell holds the fewest splitters wins (ties: the lower form)
+  constexpr int NF = 3;
+  uint32_t lshift  = 0;
   while (lshift < 63 && ((kmax - kmin) >> lshift) >= (unsigned long long)SP_NLUT) ++lshift;
-  if (tid < 2) s_worst[tid] = 0;
-  for (int form = 0; form < 2; ++form)
-    if (tid < BINS) s_idx[form][tid] = (uint32_t)tid < nsp ? sp_lut_cell(s_tab[tid] >= kmin ? s_tab[tid] - kmin : 0ull, (uint32_t)form, lshift) : 0xFFFFFFFFu;
+  SpLutF lf{0ull, 0ull, 0u, 0u};
+  const bool both = nsp >= 2u;
+  if (both) {  // (block-uniform) the widest gap between neighbouring splitters: every thread walks the table (<= 254 entries, broadcast reads)
+    uint32_t gi          = 0;
+    unsigned long long g = 0ull;
+    for (uint32_t i = 0; i + 1u < nsp; ++i) {
+      const unsigned long long d = s_tab[i + 1] - s_tab[i];
+      if (d > g) {
+        g  = d;
+        gi = i;
+      }
+    }
+    const unsigned long long alast = s_tab[gi] > kmin ? s_tab[gi] : kmin;
+    lf.nmin = kmin;
+    lf.pmin = s_tab[gi + 1];
+    while (lf.nsh < 63u && ((alast - kmin) >> lf.nsh) >= (unsigned long long)(SP_NLUT / 2)) ++lf.nsh;
+    while (lf.psh < 63u && kmax > lf.pmin && ((kmax - lf.pmin) >> lf.psh) >= (unsigned long long)(SP_NLUT / 2)) ++lf.psh;
+  }
+  if (tid < NF) s_worst[tid] = (tid == 2 && !both) ? 0xFFFFFFFFu : 0u;
+  for (int form = 0; form < NF; ++form)
+    if (tid < BINS) s_idx[form][tid] = (uint32_t)tid < nsp ? sp_lut_cell_k<KIND>(s_tab[tid], kmin, (uint32_t)form, lshift, lf) : 0xFFFFFFFFu;
   __syncthreads();
-  uint32_t lo2[2][SP_NLUT / 1024];
-  for (int form = 0; form < 2; ++form) {
+  uint32_t lo2[NF][SP_NLUT / 1024];
+  for (int form = 0; form < NF; ++form) {
     for (int r = 0; r < SP_NLUT / 1024; ++r) {
       const uint32_t c = (uint32_t)tid + 1024u * r;
       uint32_t a = 0, b = nsp;  // splitters in cells below c = lower_bound(s_idx, c)
@@ -2498,14 +2669,19 @@ __global__ void __launch_bounds__(1024) k_sp_plan(const uint64_t* __restrict__ i
     }
   }
   __syncthreads();
-  const int pick = s_worst[1] < s_worst[0] ? 1 : 0;
-  for (int r = 0; r < SP_NLUT / 1024; ++r) sp.lut[tid + 1024 * r] = (uint16_t)lo2[pick][r];
+  int pick = s_worst[1] < s_worst[0] ? 1 : 0;
+  if (s_worst[2] < s_worst[pick]) pick = 2;
+  for (int r = 0; r < SP_NLUT / 1024; ++r) sp.lut[tid + 1024 * r] = (uint16_t)(pick == 0 ? lo2[0][r] : (pick == 1 ? lo2[1][r] : lo2[NF - 1][r]));
   if (tid == 0) {
     sp.nsp     = nsp;
     sp.neq     = neq;
     sp.kmin    = kmin;
     sp.lut_log = (uint32_t)pick;
     sp.lshift  = lshift;
+    sp.f_nmin  = lf.nmin;
+    sp.f_pmin  = lf.pmin;
+    sp.f_nsh   = lf.nsh;
+    sp.f_psh   = lf.psh;
     plan->hy.fold = 0;  // (the sign fold is a property of the bit digit)
     __threadfence();
     sp.on = 1;
@@ -2522,13 +2698,23 @@ __global__ void __launch_bounds__(256) k_sp_sample(const uint64_t* __restrict__ 
   __shared__ uint32_t s_hist[NRANGE * BINS];
   __shared__ unsigned long long s_tab[BINS];
   __shared__ uint16_t s_lut[SP_NLUT];
+  __shared__ uint32_t s_sub[BINS * SP_NPIECE];  // sampled keys per (bucket, sixteenth of its range): the warp of the cell maps (stage 1)
+  __shared__ unsigned long long s_lo[BINS], s_w[BINS];
+  __shared__ uint32_t s_mlow[BINS];
+  __shared__ int32_t s_nsh[BINS];
   const unsigned tid = threadIdx.x, lane = lane_id();
   for (int i = tid; i < NRANGE * BINS; i += 256) s_hist[i] = 0;
-  s_tab[tid] = sp.tab[tid];
+  for (int i = tid; i < BINS * SP_NPIECE; i += 256) s_sub[i] = 0;
+  s_tab[tid]  = sp.tab[tid];
+  s_lo[tid]   = sp.lo[tid];
+  s_w[tid]    = sp.w[tid];
+  s_mlow[tid] = sp.mlow[tid];
+  s_nsh[tid]  = sp.nsh[tid];
   for (int i = tid; i < SP_NLUT; i += 256) s_lut[i] = sp.lut[i];
   __syncthreads();
   const uint32_t nsp = sp.nsp, lut_log = sp.lut_log, lshift = sp.lshift;
   const unsigned long long kmin = sp.kmin;
+  const SpLutF lf               = sp_lutf_of(sp);
   const int64_t step    = (int64_t)stride * HF_CHUNK;
   const int64_t nchunks = div_up(n, step);
   const int64_t nw      = (int64_t)gridDim.x * 4;
@@ -2547,13 +2733,19 @@ __global__ void __launch_bounds__(256) k_sp_sample(const uint64_t* __restrict__ 
       const uint64_t k  = to_sortable<uint64_t, KIND>(raw[u], desc_mask);
       const int64_t r64 = range_rows > 0 ? row / range_rows : (int64_t)(NRANGE - 1);
       const int r       = r64 < NRANGE - 1 ? (int)r64 : NRANGE - 1;
-      (void)lds_rank(s_hist + r * BINS, sp_bucket(s_tab, s_lut, k, nsp, kmin, lut_log, lshift), live);
+      const uint32_t b  = sp_bucket<KIND>(s_tab, s_lut, k, nsp, kmin, lut_log, lshift, lf);
+      (void)lds_rank(s_hist + r * BINS, b, live);
+      if (live) atomicAdd(&s_sub[b * SP_NPIECE + (sp_frac(SpCell{s_lo[b], s_w[b], s_mlow[b], s_nsh[b]}, k) >> SP_PSH)], 1u);
     }
   }
   __syncthreads();
   for (int i = tid; i < NRANGE * BINS; i += 256) {
     const uint32_t c = s_hist[i];
     if (c) atomicAdd(&hf.samp[i / BINS][i % BINS], c);
+  }
+  for (int i = tid; i < BINS * SP_NPIECE; i += 256) {
+    const uint32_t c = s_sub[i];
+    if (c) atomicAdd(&plan->sp.sub[i / SP_NPIECE][i % SP_NPIECE], c);
   }
 }
 
@@ -2887,6 +3079,7 @@ __global__ void __launch_bounds__(BT, 4) k_hf_scatter(const KeyT* __restrict__ i
   uint32_t* s_scan  = s_limit + NB;                                                         // [16]
   uint32_t* s_misc  = s_scan + 16;                                                          // [4]
   unsigned long long* s_red = reinterpret_cast<unsigned long long*>(s_misc + 4);           // [2 * NW] (level 0)
+  __shared__ uint2 s_wt[(LVL >= 1 && sizeof(KeyT) == 8) ? SP_NPIECE : 1];                  // splitter mode: the bucket's warp (sp_warp)
   HybridPlan& hy = plan->hy;
   FastPlan& hf   = plan->hf;
   if (hf.state != (LVL == 0 ? 1 : 3)) return;
@@ -2968,10 +3161,11 @@ __global__ void __launch_bounds__(BT, 4) k_hf_scatter(const KeyT* __restrict__ i
       return;
     }
     spc = sp_cell_of(plan->sp, seg);
+    if (tid < (unsigned)SP_NPIECE) s_wt[tid] = plan->sp.wt[seg][tid];  // (read behind the barrier that follows the clearing of s_cnt, on either path)
   }
   const uint32_t spnc = split ? plan->sp.nc[seg] : 1u;
   auto spdig          = [&](KeyT k) -> uint32_t {
-    if constexpr (sizeof(KeyT) == 8) return sp_cell(sp_frac(spc, (unsigned long long)k), spnc);
+    if constexpr (sizeof(KeyT) == 8) return sp_cell(sp_warp(sp_frac(spc, (unsigned long long)k), s_wt), spnc);
     else return dig(k);
   };
   if (split && sp_narrow(plan->sp, seg, hy.bits2)) {
@@ -3240,12 +3434,13 @@ __global__ void __launch_bounds__(BT, 4) k_sp_level0(const uint64_t* __restrict_
   }
   const uint32_t nsp = sp.nsp, lut_log = sp.lut_log, lshift = sp.lshift;
   const unsigned long long kmin = sp.kmin;
+  const SpLutF lf               = sp_lutf_of(sp);
   uint32_t packed[KPT];
 #pragma unroll
   for (int j = 0; j < KPT; ++j) {
     const bool live  = j * BT + (int)tid < nvalid;
     const uint64_t k = to_sortable<uint64_t, KIND>(key[j], desc_mask);
-    const uint32_t d = sp_bucket(s_tab, s_lut, k, nsp, kmin, lut_log, lshift);
+    const uint32_t d = sp_bucket<KIND>(s_tab, s_lut, k, nsp, kmin, lut_log, lshift, lf);
     const uint32_t r = lds_rank(s_cnt, d, live);
     packed[j]        = (d << 16) | r;
   }
@@ -3552,7 +3747,8 @@ int sort_impl(const void* keys_in, void* keys_out, const int32_t* vals_in, int32
           ftiles_s               = div_up(n, (int64_t)SP_TILE);
           const int64_t frange_s = (ftiles_s / NRANGE) * SP_TILE;
           hipLaunchKernelGGL((k_sp_plan<CK>), dim3(1), dim3(1024), (size_t)SP_NSAMP * 8, stream, kin, n, (uint64_t)desc_mask, plan, fc.bits2_max);
-          hipLaunchKernelGGL((k_sp_sample<CK>), dim3((unsigned)sblocks), dim3(256), 0, stream, kin, n, (uint64_t)desc_mask, plan, fc.stride, frange_s);
+          // (half the workgroups of k_hf_sample: each flushes 2048 + 4096 counters)
+          hipLaunchKernelGGL((k_sp_sample<CK>), dim3((unsigned)(sblocks > 1024 ? 1024 : sblocks)), dim3(256), 0, stream, kin, n, (uint64_t)desc_mask, plan, fc.stride, frange_s);
           hipLaunchKernelGGL(k_hf_plan, dim3(1), dim3(BINS), 0, stream, plan, 1, (int)(8 * sizeof(KeyT)), n, fc.bits2, 1 << 13, fc.stride, frange_s, FT,
                              (unsigned long long)fc.slot_rows, g_cursor_margin, MIN_SHIFT2, fc.bits2_max, 0ull, 0, 0, allow_split);
         }

@@ -870,3 +870,61 @@ def test_splitter_narrow_bucket_has_one_value_per_cell():
             nsh, mlow = _sp_params(w)
             cells = [(_sp_frac(r, w, nsh, mlow) * ncmax) >> 32 for r in range(w)]
             assert len(set(cells)) == w and cells == sorted(cells) and cells[-1] < ncmax, (ncmax, w)
+
+
+def _sp_warp_table(masses):
+    """k_hf_plan stage 1 (splitter mode): the sixteen (start, stretch) pairs of a bucket's warp from the sampled masses of its pieces"""
+    M = sum(masses)
+    fl = M // (16 * 64) + 1
+    m = [max(x, fl) for x in masses]
+    tot = float(sum(m))
+    y, tab = 0, []
+    for x in m:
+        d = max(1, int(float(x) / tot * 4294967040.0))
+        tab.append((y, d))
+        y += d
+    assert y < (1 << 32)
+    return tab
+
+
+def _sp_warp(frac, tab):
+    y0, d = tab[frac >> 28]
+    return y0 + (((frac & 0x0FFFFFFF) * d) >> 28)
+
+
+def test_splitter_warp_is_monotone_bounded_and_the_identity_for_narrow_buckets():
+    """sp_warp (gx_sort.hip): cells are equal slices of the WARPED fraction -- a piecewise-linear estimate of the bucket's CDF from the
+    n / 32 sample.  The levels need it monotone and below 2^32 for every table stage 1 can produce (any masses, zeros included); narrow
+    buckets need the identity table to reproduce the fraction bit for bit (k_sp_fill inverts the un-warped cell map)."""
+    import random
+    rnd = random.Random(11)
+    ident = [(j << 28, 1 << 28) for j in range(16)]
+    fracs = sorted({0, 1, 0x0FFFFFFF, 0x10000000, 0x7FFFFFFF, 0x80000000, 0xFFFFFFFE, 0xFFFFFFFF} | {rnd.getrandbits(32) for _ in range(2000)}
+                   | {(j << 28) + k for j in range(16) for k in (0, 1, 0x0FFFFFFF)})
+    assert all(_sp_warp(f, ident) == f for f in fracs)
+    shapes = [[7600] * 16, [0] * 15 + [100000], [100000] + [0] * 15, [1 << 27] * 16, [1] * 16, [0, 0, 5, 900000, 5, 0, 0, 0, 0, 0, 0, 3, 0, 0, 0, 1],
+              [int(7600 * 1.3 ** j) for j in range(16)], [int(7600 * 0.5 ** j) + 1 for j in range(16)]]
+    shapes += [[rnd.randrange(0, 1 << rnd.randrange(1, 28)) for _ in range(16)] for _ in range(40)]
+    for masses in shapes:
+        if sum(masses) == 0:
+            continue
+        tab = _sp_warp_table(masses)
+        assert all(tab[j][0] + tab[j][1] <= tab[j + 1][0] for j in range(15))          # piece j ends where piece j + 1 starts, or below
+        ys = [_sp_warp(f, tab) for f in fracs]
+        assert all(a <= b for a, b in zip(ys, ys[1:])), masses
+        assert ys[-1] < (1 << 32)
+        for nc in (1, 7, 539, 1024):
+            cells = [(y * nc) >> 32 for y in ys]
+            assert all(a <= b for a, b in zip(cells, cells[1:])) and cells[-1] < nc
+    # what it is for: a bucket whose density doubles from one end to the other -- cells cut on the warped fraction hold equal shares
+    masses = [int(100000 * (1 + j / 15.0)) for j in range(16)]
+    tab = _sp_warp_table(masses)
+    nc = 40
+    keys = [rnd.random() for _ in range(200000)]
+    keys = [((1 + 3 * u) ** 0.5 - 1) for u in keys]   # density ~ (1 + 2x)/2 on [0, 1): CDF (x + x^2) / 2 ... inverse of u = (x + x^2)/2 scaled
+    keys = [min(k, 0.999999999) for k in keys]
+    cnt = [0] * nc
+    for k in keys:
+        cnt[(_sp_warp(int(k * (1 << 32)), tab) * nc) >> 32] += 1
+    mean = len(keys) / nc
+    assert max(cnt) < 1.06 * mean and min(cnt) > 0.94 * mean, (max(cnt) / mean, min(cnt) / mean)
