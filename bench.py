@@ -60,6 +60,7 @@ def parse():
                                                               "dense ids (round 4); 8 / 9 = fixed")
     ap.add_argument("--gb-spec", type=int, default=1, help="groupby knob: 1 hist-free speculative partition pass (default), 0 exact histogram pass")
     ap.add_argument("--no-partitioned-join", action="store_true", help="join: probe the table directly")
+    ap.add_argument("--sort-splitters", type=int, default=1, help="sort knob: 0 no splitter mode (uneven columns go to the LSD passes), 1 default")
     ap.add_argument("--join-probe-kernel", type=int, default=0, help="join knob: 0 pipelined tag probe on LDS-resident tags (default), 1 round-1 tag probe, 2 / 3 L2-resident direct probe (4 / 2 rows per thread)")
     ap.add_argument("--join-scatter-tile", type=int, default=0, help="join knob: rows per scatter tile (0 = default)")
     ap.add_argument("--join-build-kernel", type=int, default=0, help="join knob: 0 sub-table build with the tags in LDS (default), 1 round-2 build (global CAS + k_tags)")
@@ -576,6 +577,7 @@ def bench_sort(c, pairs=False, cpu_leg=True):
     lib.gx_sort_set_cell(a.sort_cell)
     lib.gx_sort_set_lookback(a.sort_lbw)
     lib.gx_sort_set_cursor_path(0 if a.no_cursor else 1, 0.0)
+    lib.gx_sort_set_splitters(a.sort_splitters)
     if a.key_range:
         keys = ops.random_column(np.int64, n, seed=42 + c.rank, lo=a.key_range[0], hi=a.key_range[1])
     else:

@@ -184,6 +184,7 @@ struct SplitPlan {
   uint32_t nsp;            // splitters in use; buckets = nsp + 1 <= BINS
   uint32_t neq;            // equality buckets
   unsigned long long kmin; // LUT origin (the sample's smallest key)
+  uint32_t lut_steps;            // splitters in the fullest LUT cell of the chosen form
   uint32_t lut_log, lshift;      // LUT form: 0 linear in (key - kmin) >> lshift, 1 logarithmic, 2 (float keys) one linear half per sign (SpLutF)
   unsigned long long f_nmin, f_pmin;  // form 2: the sample's smallest negative / smallest positive key (sortable form) ...
   uint32_t f_nsh, f_psh;              // ... and the shifts that lay each sign's sampled range over SP_NLUT / 2 cells
@@ -212,7 +213,7 @@ struct SplitPlan {
 struct SpCell {
   unsigned long long lo, w;
   uint32_t mlow;
-  int nsh;
+  int nsh;  // (as planned: x = rel >> nsh, or rel << -nsh; sp_frac uses the one left shift 33 - nsh that does both)
 };
 __device__ __forceinline__ SpCell sp_cell_of(const SplitPlan& sp, uint32_t b) { return SpCell{sp.lo[b], sp.w[b], sp.mlow[b], sp.nsh[b]}; }
 // (bits2 = the level-1 bits the launches are sized for: 1 << bits2 cell slots per bucket)
@@ -235,8 +236,11 @@ __device__ __forceinline__ uint32_t sp_frac(const SpCell& c, unsigned long long 
 {
   const unsigned long long rel = key > c.lo ? key - c.lo : 0ull;
   if (rel >= c.w) return 0xFFFFFFFFu;
-  const uint32_t x = c.nsh >= 0 ? (uint32_t)(rel >> c.nsh) : (uint32_t)(rel << (-c.nsh));  // < 2^31
-  return (x << 1) + __umulhi(x << 1, c.mlow);                                                // = (x * mlow) >> 31
+  // x = rel >> nsh (nsh >= 0) or rel << -nsh: the range's last key becomes a 31-bit number with bit 30 set.  Both are
+  // (rel << (33 - nsh)) >> 33 -- rel < 2^(31 + nsh), so the left shift loses nothing -- i.e. the high word of ONE shift, halved
+  // (computing both shifts and selecting cost three 64-bit instructions per key; nsh = 63 marks a range of one value: x = 0)
+  const uint32_t x2 = c.nsh == 63 ? 0u : ((uint32_t)((rel << (33 - c.nsh)) >> 32) & ~1u);  // = x << 1
+  return x2 + __umulhi(x2, c.mlow);                                                          // = 2 x + (x * mlow) >> 31
 }
 __device__ __forceinline__ uint32_t sp_lut_cell(unsigned long long rel, uint32_t lut_log, uint32_t lshift)
 {
@@ -261,10 +265,12 @@ struct SpLutF {
   uint32_t nsh, psh;
 };
 __device__ __forceinline__ SpLutF sp_lutf_of(const SplitPlan& sp) { return SpLutF{sp.f_nmin, sp.f_pmin, sp.f_nsh, sp.f_psh}; }
-template <int KIND>
+// F2: 1 = the caller knows the form is 2, 0 = knows it is not (k_sp_level0 picks its ranking loop once per tile -- with the test inside
+// the loop, run 14, every split-mode column paid 0.1 - 0.15 ms for a form most of them do not use), -1 = look at `form`
+template <int KIND, int F2 = -1>
 __device__ __forceinline__ uint32_t sp_lut_cell_k(unsigned long long key, unsigned long long kmin, uint32_t form, uint32_t lshift, const SpLutF& f)
 {
-  if (form == 2u) {
+  if (F2 == 1 || (F2 < 0 && form == 2u)) {
     const bool pos             = key >= f.pmin;
     const unsigned long long o = pos ? f.pmin : f.nmin;
     const unsigned long long c = (key > o ? key - o : 0ull) >> (pos ? f.psh : f.nsh);
@@ -276,11 +282,11 @@ __device__ __forceinline__ uint32_t sp_lut_cell_k(unsigned long long key, unsign
 // splitters in cells below, bits 9-14 the splitters INSIDE the cell (capped at 63), bit 15 "none inside" (the bucket is then known).
 // A few inside: a short scan; many (two far-apart clusters put a whole cluster's splitters into one cell of either LUT form:
 // 46 ms for level 0 in the first run): a bisection of that stretch of the sorted table.
-template <int KIND>
+template <int KIND, int F2 = -1>
 __device__ __forceinline__ uint32_t sp_bucket(const unsigned long long* __restrict__ tab, const uint16_t* __restrict__ lut, unsigned long long key,
                                               uint32_t nsp, unsigned long long kmin, uint32_t lut_log, uint32_t lshift, const SpLutF& lf)
 {
-  const uint32_t wd            = lut[sp_lut_cell_k<KIND>(key, kmin, lut_log, lshift, lf)];
+  const uint32_t wd            = lut[sp_lut_cell_k<KIND, F2>(key, kmin, lut_log, lshift, lf)];
   uint32_t b                   = wd & 0x1FFu;
   if (wd & 0x8000u) return b;
   const uint32_t inside = (wd >> 9) & 63u;
@@ -1496,12 +1502,22 @@ constexpr size_t place_lds_bytes(int cl2, int word_bytes = 8)
   return (size_t)((1 << cl2) + (1 << cl2) / 16) * word_bytes + (size_t)(1 << cl2) + (size_t)((1 << cl2) / 16) * 4 + 32 * 4;
 }
 
+// what a cell's workgroup must know before its first key load: size, slot capacity, slot, output position
+struct CellMeta {
+  uint32_t m, cap, slot, start;
+};
+__device__ __forceinline__ CellMeta cell_meta(const HybridPlan& hy, const uint32_t* __restrict__ hist2, const uint32_t* __restrict__ base2, uint32_t cell)
+{
+  const uint32_t b = cell >> hy.bits2, d2 = cell & ((1u << hy.bits2) - 1u);
+  return CellMeta{hist2[b * NB2MAX + d2], cell_cap(hy, b), cell_slot(hy, b, d2), base2[b * NB2MAX + d2]};
+}
 // one cell of k_local_place (every thread of the workgroup calls it with the same cell; returns are block-uniform)
+// (pre: the cell's CellMeta when the caller has it already -- splitter mode asks for both of its slots' at once)
 template <typename KeyT, int KIND, bool HAS_VAL, int CL2, bool SPLIT = false>
 __device__ __forceinline__ void local_place_cell(const uint32_t cell, const KeyT* in, KeyT* __restrict__ out, const uint32_t* vin,
                                                  uint32_t* __restrict__ vout, KeyT desc_mask, SortPlan* plan,
                                                  const uint32_t* __restrict__ hist2, const uint32_t* __restrict__ base2,
-                                                 uint32_t* __restrict__ todo, int exp)
+                                                 uint32_t* __restrict__ todo, int exp, const CellMeta* pre = nullptr)
 {
   constexpr int LOCAL_MAX = 1 << CL2, LS_KPT = 16, LS_BT = LOCAL_MAX / LS_KPT, NPB = 1 << CL2;
   constexpr bool PACKED = HAS_VAL || KIND == K_FLOAT;
@@ -1513,10 +1529,10 @@ __device__ __forceinline__ void local_place_cell(const uint32_t cell, const KeyT
   const uint32_t d2 = cell & ((1u << bits2) - 1u);
   // (the cell's size, output position and slot are requested together: behind the size check the slot lookup would be a second
   //  round trip before the first key load)
-  const uint32_t m    = hist2[b * NB2MAX + d2];
-  const uint32_t cap  = cell_cap(hy, b);
-  const uint32_t slot = cell_slot(hy, b, d2);
-  const int64_t start = base2[b * NB2MAX + d2];
+  const uint32_t m    = pre ? pre->m : hist2[b * NB2MAX + d2];
+  const uint32_t cap  = pre ? pre->cap : cell_cap(hy, b);
+  const uint32_t slot = pre ? pre->slot : cell_slot(hy, b, d2);
+  const int64_t start = pre ? pre->start : base2[b * NB2MAX + d2];
   if (m == 0 || m > cap) return;  // (a big cell -- cursor path only -- is sorted through X, see HybridPlan::big)
   in += (int64_t)slot - start;  // the cell sits in its slot of the level-1 buffer
   if (HAS_VAL) vin += (int64_t)slot - start;
@@ -1676,8 +1692,30 @@ __global__ void __launch_bounds__((1 << CL2) / 16, 4) k_local_place(const KeyT* 
   constexpr bool CAN_SPLIT = sizeof(KeyT) == 8 && !HAS_VAL && KIND != K_FLOAT && CL2 == 13;
   if (CAN_SPLIT && cursor_path && plan->sp.on) {  // (block-uniform; an instantiation of its own: the bit-digit path is untouched)
     if constexpr (CAN_SPLIT) {
-      for (uint32_t cell = blockIdx.x; cell < ncells; cell += gridDim.x) {
-        local_place_cell<KeyT, KIND, HAS_VAL, CL2, true>(cell, in, out, vin, vout, desc_mask, plan, hist2, base2, todo, exp);
+      // a bucket uses the FIRST nc of its 1 << bits2 cell slots (about half of them: the grid is sized for half the slots), so the two
+      // slots of a workgroup must not be the same cell index of two buckets -- both used or both empty: until run 14 half the
+      // workgroups sorted two cells back to back and the other half none.  Every other round walks its group of slots backwards
+      // (slot ^ (slots per bucket - 1): a permutation inside the bucket, so every slot is still visited exactly once).
+      // The sizes / slots / positions of BOTH slots are requested before either is looked at: one of the two is empty as a rule, and
+      // finding that out cost the workgroup a round trip to memory of its own (run 16: 43 % more wave-cycles waiting than on bit
+      // digits, 1400 per wave -- the 0.9 ms this stage took longer in splitter mode).
+      const uint32_t flip = (1u << hy.bits2) - 1u;
+      const uint32_t c0 = blockIdx.x, c1 = blockIdx.x + gridDim.x;  // (c0 < ncells: the grid is never larger than the slots)
+      const bool two    = c1 < ncells;
+      const uint32_t s1 = two ? (c1 ^ flip) : c0;
+      const CellMeta m0 = cell_meta(hy, hist2, base2, c0);
+      const CellMeta m1 = cell_meta(hy, hist2, base2, s1);
+      if (m0.m != 0u) {  // (block-uniform)
+        local_place_cell<KeyT, KIND, HAS_VAL, CL2, true>(c0, in, out, vin, vout, desc_mask, plan, hist2, base2, todo, exp, &m0);
+        __syncthreads();
+      }
+      if (two && m1.m != 0u) {
+        local_place_cell<KeyT, KIND, HAS_VAL, CL2, true>(s1, in, out, vin, vout, desc_mask, plan, hist2, base2, todo, exp, &m1);
+        __syncthreads();
+      }
+      uint32_t round = 2;  // (a smaller grid -- the A/B knob gx_sort_set_place_grid -- walks on)
+      for (uint32_t cell = blockIdx.x + 2u * gridDim.x; cell < ncells && cell >= 2u * gridDim.x; cell += gridDim.x, ++round) {
+        local_place_cell<KeyT, KIND, HAS_VAL, CL2, true>((round & 1u) ? (cell ^ flip) : cell, in, out, vin, vout, desc_mask, plan, hist2, base2, todo, exp);
         __syncthreads();
       }
     }
@@ -2503,7 +2541,7 @@ __global__ void __launch_bounds__(1024) k_sp_plan(const uint64_t* __restrict__ i
       if (tid <= (int)nsp) {
         const unsigned long long tlo = tid == 0 ? 0ull : s_tab[tid - 1];
         const int ia = tid == 0 ? 0 : lower(tlo), ib = tid == (int)nsp ? SP_NSAMP : lower(s_tab[tid]);
-        if (ib - ia >= 2) {
+        if (ib - ia >= 24) {  // (a tail bucket of a handful of sampled keys has nothing but gaps)
           for (int i = ia; i + 1 < ib; ++i) {
             const unsigned long long a = s[i], d = s[i + 1] - a;
             if (d > g) {
@@ -2677,6 +2715,7 @@ __global__ void __launch_bounds__(1024) k_sp_plan(const uint64_t* __restrict__ i
     sp.neq     = neq;
     sp.kmin    = kmin;
     sp.lut_log = (uint32_t)pick;
+    sp.lut_steps = s_worst[pick];
     sp.lshift  = lshift;
     sp.f_nmin  = lf.nmin;
     sp.f_pmin  = lf.pmin;
@@ -3355,9 +3394,14 @@ __global__ void __launch_bounds__(BT, 4) k_hf_scatter(const KeyT* __restrict__ i
 // through the LDS reorder as one byte.  14 keys per thread (56 KiB of keys + 7 KiB of bucket bytes + 6 KiB of tables): two
 // workgroups per CU, as the bit-digit kernel.
 constexpr int SP_KPT  = 14;
+// (13 keys per thread -- 39.3 KiB of LDS, four workgroups per CU instead of three -- measured in run 15: 5.44 against 5.36 ms, no gain)
 constexpr int SP_TILE = BT * SP_KPT;
 constexpr size_t sp_level0_lds() { return (size_t)SP_TILE * 8 + (size_t)(3 * BINS + 16 + 4) * 4 + (size_t)2 * NW * 8 + (size_t)BINS * 8 + (size_t)SP_NLUT * 2 + (size_t)SP_TILE; }
-template <int KIND>
+// F2: the LUT form this instantiation searches with (1: form 2, SpLutF; 0: forms 0 / 1).  Both are launched, the one the plan did not
+// pick returns at once (~0.05 ms): with the form tested per key the unrolled ranking loop of EVERY split-mode column slowed by 0.15 ms
+// (run 14), and with two copies of the loop inside one kernel the compiler stopped interleaving the fourteen searches (70 instead
+// of 84 registers, level 0 4.9 -> 5.4 ms, run 15).
+template <int KIND, int F2>
 __global__ void __launch_bounds__(BT, 4) k_sp_level0(const uint64_t* __restrict__ in, uint64_t* __restrict__ out, uint64_t desc_mask, SortPlan* plan, int64_t n)
 {
   constexpr int KPT = SP_KPT, TILE = SP_TILE;
@@ -3376,6 +3420,7 @@ __global__ void __launch_bounds__(BT, 4) k_sp_level0(const uint64_t* __restrict_
   FastPlan& hf        = plan->hf;
   const SplitPlan& sp = plan->sp;
   if (hf.state != 1 || !sp.on || !hf.slots_ready) return;
+  if ((sp.lut_log == 2u) != (F2 == 1)) return;
   const unsigned tid = threadIdx.x;
   const int64_t v    = xcd_swizzle((int64_t)blockIdx.x, (int64_t)gridDim.x);
   const int64_t per  = (int64_t)gridDim.x / NRANGE;  // whole tiles per range (the last range takes the rest)
@@ -3437,12 +3482,42 @@ __global__ void __launch_bounds__(BT, 4) k_sp_level0(const uint64_t* __restrict_
   const SpLutF lf               = sp_lutf_of(sp);
   uint32_t packed[KPT];
 #pragma unroll
-  for (int j = 0; j < KPT; ++j) {
-    const bool live  = j * BT + (int)tid < nvalid;
-    const uint64_t k = to_sortable<uint64_t, KIND>(key[j], desc_mask);
-    const uint32_t d = sp_bucket<KIND>(s_tab, s_lut, k, nsp, kmin, lut_log, lshift, lf);
-    const uint32_t r = lds_rank(s_cnt, d, live);
-    packed[j]        = (d << 16) | r;
+  for (int j = 0; j < KPT; ++j) packed[j] = 0;
+  const uint32_t steps = sp.lut_steps;
+  if (steps <= 4u) {  // (block-uniform; the common case: the fullest LUT cell of a bell-shaped / lognormal / float column holds 1 - 2 splitters)
+    // the search WITHOUT branches: the LUT word names the first candidate, then `steps` times "one further if that splitter is <= key"
+    // (past the key's own LUT cell every splitter is larger: extra steps change nothing).  The per-key scan loop this replaces
+    // diverged, and its dependent LDS reads could not be interleaved over the thread's fourteen keys -- run 16: eight times the
+    // cycles waiting on LDS of the bit-digit kernel, 50 % more wave-cycles.
+#pragma unroll
+    for (int j = 0; j < KPT; ++j) {
+      const uint64_t k = to_sortable<uint64_t, KIND>(key[j], desc_mask);
+      packed[j]        = (uint32_t)s_lut[sp_lut_cell_k<KIND, F2>(k, kmin, lut_log, lshift, lf)] & 0x1FFu;
+    }
+    for (uint32_t st = 0; st < steps; ++st) {
+#pragma unroll
+      for (int j = 0; j < KPT; ++j) {
+        const uint64_t k  = to_sortable<uint64_t, KIND>(key[j], desc_mask);
+        const uint32_t bb = packed[j];
+        packed[j]         = bb + ((bb < nsp && s_tab[bb] <= k) ? 1u : 0u);
+      }
+    }
+#pragma unroll
+    for (int j = 0; j < KPT; ++j) {
+      const bool live  = j * BT + (int)tid < nvalid;
+      const uint32_t d = packed[j];
+      const uint32_t r = lds_rank(s_cnt, d, live);
+      packed[j]        = (d << 16) | r;
+    }
+  } else {
+#pragma unroll
+    for (int j = 0; j < KPT; ++j) {
+      const bool live  = j * BT + (int)tid < nvalid;
+      const uint64_t k = to_sortable<uint64_t, KIND>(key[j], desc_mask);
+      const uint32_t d = sp_bucket<KIND, F2>(s_tab, s_lut, k, nsp, kmin, lut_log, lshift, lf);
+      const uint32_t r = lds_rank(s_cnt, d, live);
+      packed[j]        = (d << 16) | r;
+    }
   }
   __syncthreads();
   // one returning atomic per non-empty bin reserves the tile's run; the scan runs while it is in flight
@@ -3741,7 +3816,8 @@ int sort_impl(const void* keys_in, void* keys_out, const int32_t* vals_in, int32
           static std::atomic<bool> sattr_set{false};
           if (!sattr_set) {
             GX_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(k_sp_plan<CK>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)(SP_NSAMP * 8)));
-            GX_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(k_sp_level0<CK>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)sp_level0_lds()));
+            GX_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(k_sp_level0<CK, 0>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)sp_level0_lds()));
+            GX_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(k_sp_level0<CK, 1>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)sp_level0_lds()));
             sattr_set = true;
           }
           ftiles_s               = div_up(n, (int64_t)SP_TILE);
@@ -3758,7 +3834,10 @@ int sort_impl(const void* keys_in, void* keys_out, const int32_t* vals_in, int32
       hipLaunchKernelGGL(kf0, dim3((unsigned)ftiles), dim3(BT), lds_hf(256), stream, kin, slot0_buf, desc_mask, plan, hist2, 1u << 13, n, (KeyT*)nullptr);
       if constexpr (sizeof(KeyT) == 8) {
         if (allow_split)
-          hipLaunchKernelGGL((k_sp_level0<CK>), dim3((unsigned)ftiles_s), dim3(BT), sp_level0_lds(), stream, kin, slot0_buf, (uint64_t)desc_mask, plan, n);
+        {
+          hipLaunchKernelGGL((k_sp_level0<CK, 0>), dim3((unsigned)ftiles_s), dim3(BT), sp_level0_lds(), stream, kin, slot0_buf, (uint64_t)desc_mask, plan, n);
+          hipLaunchKernelGGL((k_sp_level0<CK, 1>), dim3((unsigned)ftiles_s), dim3(BT), sp_level0_lds(), stream, kin, slot0_buf, (uint64_t)desc_mask, plan, n);
+        }
       }
       hipLaunchKernelGGL(k_hf_plan, dim3(1), dim3(BINS), 0, stream, plan, 2, (int)(8 * sizeof(KeyT)), n, fc.bits2, 1 << 13, fc.stride, frange, FT,
                          (unsigned long long)fc.slot_rows, g_cursor_margin, MIN_SHIFT2, fc.bits2_max, (unsigned long long)nb_buf);

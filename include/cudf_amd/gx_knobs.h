@@ -82,8 +82,8 @@ void gx_sort_set_cursor_path(int enable, float margin_sigmas);
 void gx_sort_set_counting(int enable);
 /* A/B knob (per calling thread): 1 (default) = a 64-bit integer column whose level-0 buckets the sample shows to be too uneven for
  * two levels of bit digits (bell-shaped, lognormal, Zipf-like, clustered values) is cut on sample-chosen SPLITTERS instead
- * (round 5: k_sp_plan / k_sp_level0, equal-width cells inside a bucket, equality buckets for heavy values); 0 = such a column is
- * declined to the LSD passes, as before. */
+ * (round 5: k_sp_plan / k_sp_level0, cells cut on a per-bucket warp of the key's position, equality buckets for heavy values); 0 = such a
+ * column is declined to the LSD passes, as before. */
 void gx_sort_set_splitters(int enable);
 /* A/B knob (per calling thread): 1 (default) = FLOAT64 keys-only sorts of >= 2^25 rows take the cursor path on the IEEE total-order
  * flip; every key is checked, and a column with a NaN or a -0.0 -- where an unordered sort and the reference's stable radix sort of
