@@ -50,6 +50,8 @@ _PROTOS = {
     "gx_sort_set_counting": (None, [_i]),
     "gx_sort_set_splitters": (None, [_i]),
     "gx_sort_set_float_cursor": (None, [_i]),
+    "gx_sort_set_spin_limit_ms": (None, [_i]),
+    "gx_sort_inject_lost_tile": (None, [ctypes.c_longlong]),
     "gx_sort_split_info": (_i, [_p, ctypes.POINTER(ctypes.c_int32), _p]),
     "gx_sort_cursor_state": (_i, [_p, ctypes.POINTER(ctypes.c_int32), _p]),
     "gx_sort_place_info": (_i, [_p, ctypes.POINTER(ctypes.c_int32), _p]),

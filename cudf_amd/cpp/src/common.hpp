@@ -53,6 +53,16 @@ rmm::device_buffer run_with_scratch(F&& f, char const* what, rmm::cuda_stream_vi
   return tmp;
 }
 
+// After a sort: the device-side status word of its scratch (gx_sort_status; synchronises the stream -- 4 bytes and a round trip,
+// ~0.3 % of a 1e9-row sort).  5 = a look-back wait was abandoned (gx_sort.hip spin_guard): the output is not sorted and the caller
+// gets cudf::logic_error instead of a dead process (until round 5 the kernel trapped).
+inline void check_sort_status(rmm::device_buffer const& tmp, char const* what, rmm::cuda_stream_view stream)
+{
+  int st = 0;
+  gx_check(gx_sort_status(tmp.data(), &st, gxs(stream)), what);
+  CUDF_EXPECTS(st != 5, "radix sort: a look-back wait made no progress and was abandoned (device-side fault); the result is not sorted");
+}
+
 // read one int64 from the device (synchronises the stream)
 inline int64_t read_i64(int64_t const* dev, rmm::cuda_stream_view stream)
 {

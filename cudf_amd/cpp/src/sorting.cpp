@@ -10,12 +10,13 @@
 namespace cudf {
 namespace {
 
-// Device-side protocol faults: a look-back wait that makes no progress for 30 s of wall-clock time traps inside the kernel
-// (gx_sort.hip, spin_guard).  On ROCm a trap is a queue exception: the process' HIP context is unusable afterwards and the
-// runtime normally aborts -- the reference's cudf::fatal_cuda_error class of failure (utilities/error.hpp:63-86), not a
-// recoverable one.  What the trap guarantees is that a wrong order is never returned as success; a slow or time-sliced
-// predecessor tile (many polls, little time) never trips it.  The sort itself returns as soon as its work is queued, like
-// the reference's (cpp/src/sort/sort.cu:52-89).
+// Device-side protocol faults: a look-back wait that makes no progress for 30 s of wall-clock time is ABANDONED inside the kernel
+// (gx_sort.hip, spin_guard): the scratch's status word becomes 5, every write stays inside the output, and the sort below reads
+// the word and throws cudf::logic_error -- the caller's process and HIP context survive (until round 5 the kernel trapped, which
+// on ROCm is a queue exception the process does not survive: the reference's cudf::fatal_cuda_error class of failure,
+// utilities/error.hpp:63-86).  A wrong order is never returned as success; a slow or time-sliced predecessor tile (many polls,
+// little time) never trips the guard.  The price is one 4-byte read-back per sort: the reference's sort returns as soon as its
+// work is queued (cpp/src/sort/sort.cu:52-89), this one after it has run.
 
 void check_order_args(table_view const& input, std::vector<order> const& column_order,
                       std::vector<null_order> const& null_precedence)
@@ -36,12 +37,13 @@ void column_sorted_order(column_view const& col, order ord, null_order nulls, in
   int const dtype       = detail::gx_type(col.type());
   int const descending  = ord == order::DESCENDING ? 1 : 0;
   int const null_before = nulls == null_order::BEFORE ? 1 : 0;
-  (void)detail::run_with_scratch(
+  auto const tmp = detail::run_with_scratch(
     [&](void* t, std::size_t* b) {
       return gx_sorted_order(dtype, detail::row0(col), mask, col.size(), mask ? col.null_count() : 0, descending,
                              null_before, out, t, b, detail::gxs(stream));
     },
     "sorted_order", stream);
+  if (col.size() > 0) detail::check_sort_status(tmp, "sorted_order", stream);
 }
 
 std::unique_ptr<column> gather_column(column_view const& src, int32_t const* map, size_type n, bool nullify,
@@ -160,12 +162,13 @@ std::unique_ptr<table> sort(table_view const& input, std::vector<order> const& c
       auto const& col = input.column(0);
     auto out        = make_fixed_width_column(col.type(), col.size(), mask_state::UNALLOCATED, stream, mr);
     int const desc  = (!column_order.empty() && column_order[0] == order::DESCENDING) ? 1 : 0;
-    (void)detail::run_with_scratch(
+    auto const tmp = detail::run_with_scratch(
       [&](void* t, std::size_t* b) {
         return gx_sort_keys(detail::gx_type(col.type()), detail::row0(col), out->mutable_view().head<void>(), col.size(),
                             desc, t, b, detail::gxs(stream));
       },
       "sort", stream);
+    detail::check_sort_status(tmp, "sort", stream);
     std::vector<std::unique_ptr<column>> cols;
     cols.emplace_back(std::move(out));
     return std::make_unique<table>(std::move(cols));

@@ -310,7 +310,8 @@ struct SortPlan {
   int32_t pass_src[MAX_PASSES];  // buffer selector: 0 = input, 1 = output (A), 2 = scratch (B)
   int32_t pass_dst[MAX_PASSES];
   int32_t num_active;
-  int32_t status;  // 0 ok, 3 hybrid bookkeeping mismatch (the LSD passes then produced the output); a look-back spin that times out traps
+  int32_t status;  // 0 ok, 3 hybrid bookkeeping mismatch (the LSD passes then produced the output), 5 (GX_SORT_SPIN_FAULT) a look-back wait
+                   // was abandoned (spin_guard): the output is NOT sorted; gx_sort_status reports it
   HybridPlan hy;
   SortCounters cnt;
   FastPlan hf;
@@ -724,21 +725,35 @@ struct PassArgs {
   int pass;
   int order_mode;  // experiment knob for the LBW == 0 kernel: 0 XCD-swizzled blockIdx, 1 plain blockIdx, 2 ticket
   uint64_t desc_mask;
+  unsigned long long spin_ticks = 0;  // look-back wait limit in 100 MHz ticks (0: SPIN_SECONDS)
+  long long inject_tile         = -1;  // TEST HOOK (gx_sort_inject_lost_tile): this tile never publishes its look-back granules
 };
 
 constexpr int PASS_TPB = 8;  // tickets per workgroup of the MULTI form of k_radix_pass
 // A look-back wait that makes no progress for SPIN_SECONDS of WALL-CLOCK time (s_memrealtime: the 100 MHz constant clock, read
 // every 4096 polls -- a slow or time-sliced predecessor tile is not a fault, however many polls it takes) can only mean a broken
-// forward-progress chain.  The trap is FATAL for the process' HIP context, like any device-side fault (the reference's
-// cudf::fatal_cuda_error, utilities/error.hpp:63-86): what it guarantees is that a wrong order is never returned as success.
+// forward-progress chain.  Until round 5 that ended in __builtin_trap(): fatal for the process' HIP context.  Now the wait is
+// ABANDONED: SortPlan::status becomes 5, the waiting bin takes what it has summed so far as its prefix -- never more than the
+// true prefix, so every write of the tile stays inside its bin's (or cell's) range: the output is wrong, nothing outside it is
+// touched -- and every other waiter that sees the flag gives up at its next check instead of sitting out its own 30 s.  The host
+// side reads the word (gx_sort_status) and reports the failure: a wrong order is still never returned as success, and the caller's
+// process survives (cudf::sort throws cudf::logic_error; the reference's analogue is a recoverable cudaError from cub,
+// utilities/error.hpp:63-86 draws that line).
 constexpr uint32_t SPIN_CHECK        = 1u << 12;
 constexpr unsigned long long SPIN_SECONDS = 30;
-__device__ __forceinline__ void spin_guard(uint32_t& spins, unsigned long long& t0)
+constexpr int32_t SPIN_FAULT = 5;  // SortPlan::status
+__device__ __forceinline__ bool spin_guard(uint32_t& spins, unsigned long long& t0, SortPlan* plan, unsigned long long limit_ticks)
 {
-  if ((++spins & (SPIN_CHECK - 1)) != 0) return;
+  if ((++spins & (SPIN_CHECK - 1)) != 0) return false;
+  if (__hip_atomic_load(&plan->status, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == SPIN_FAULT) return true;
   const unsigned long long now = __builtin_amdgcn_s_memrealtime();
-  if (t0 == 0) t0 = now;
-  else if (now - t0 > SPIN_SECONDS * 100000000ull) __builtin_trap();
+  if (t0 == 0) {
+    t0 = now;
+    return false;
+  }
+  if (now - t0 <= (limit_ticks ? limit_ticks : SPIN_SECONDS * 100000000ull)) return false;
+  __hip_atomic_store(&plan->status, SPIN_FAULT, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  return true;
 }
 
 __device__ __forceinline__ unsigned long long pack_status(unsigned flag, unsigned epoch, uint32_t value)
@@ -862,7 +877,7 @@ __global__ void __launch_bounds__(BT, 4) k_radix_pass(PassArgs a)
   uint32_t pub_count = tile_count;
   if (tid == BINS - 1) pub_count -= (uint32_t)(TILE - nvalid);  // padding is not data
   if (LOOKBACK && tid < BINS) {
-    store_agent_u64(&a.status[tile * BINS + tid], pack_status(tile == 0 ? 2u : 1u, epoch, pub_count));
+    if (tile != a.inject_tile) store_agent_u64(&a.status[tile * BINS + tid], pack_status(tile == 0 ? 2u : 1u, epoch, pub_count));
   }
   const uint32_t bin_start = block_exclusive_scan<BT>(tile_count, 0u, SumOp(), s_scan, (uint32_t*)nullptr);
   if (tid < BINS) {
@@ -903,7 +918,10 @@ __global__ void __launch_bounds__(BT, 4) k_radix_pass(PassArgs a)
               uint32_t spins       = 0;
               unsigned long long spin_t0 = 0;
               while ((x >> 62) == 0 || ((unsigned)(x >> 32) & 0xFFu) != epoch) {
-                spin_guard(spins, spin_t0);  // broken forward progress: fail loudly, never return a wrong order
+                if (spin_guard(spins, spin_t0, plan, a.spin_ticks)) {  // broken forward progress: flagged, never returned as a sorted column
+                  x = pack_status(2u, epoch, 0u);
+                  break;
+                }
                 __builtin_amdgcn_s_sleep(2);
                 x = load_agent_u64(&a.status[(p - k) * BINS + tid]);
               }
@@ -913,7 +931,7 @@ __global__ void __launch_bounds__(BT, 4) k_radix_pass(PassArgs a)
           }
           p -= LBW;
         }
-        store_agent_u64(&a.status[tile * BINS + tid], pack_status(2u, epoch, prefix + pub_count));
+        if (tile != a.inject_tile) store_agent_u64(&a.status[tile * BINS + tid], pack_status(2u, epoch, prefix + pub_count));
       }
       gbase = plan->gbin[pass][tid] + prefix;
     } else {
@@ -1046,6 +1064,8 @@ struct MsdArgs {
   int level;
   int exp;  // experiment bits (A/B knob of the XCD placement; 0 in production)
   uint64_t desc_mask;
+  unsigned long long spin_ticks = 0;  // as PassArgs
+  long long inject_tile         = -1;
 };
 
 // One stable partition pass of the hybrid sort: k_radix_pass's tile body (wave64 ballot ranking,
@@ -1220,7 +1240,7 @@ __global__ void __launch_bounds__(BT, (KPT <= 8 ? 8 : (KPT <= 12 ? 6 : 4))) k_ms
   uint32_t pub_count = tile_count;
   if (STABLE && tid == NB - 1) pub_count -= (uint32_t)(TILE - nvalid);
   if (tid < NB) {
-    store_agent_u64(&a.status[(int64_t)gtile * NB + tid], pack_status(jt == 0 ? 2u : 1u, epoch, pub_count));
+    if ((long long)gtile != a.inject_tile) store_agent_u64(&a.status[(int64_t)gtile * NB + tid], pack_status(jt == 0 ? 2u : 1u, epoch, pub_count));
   }
   const uint32_t bin_start = block_exclusive_scan<BT>(tile_count, 0u, SumOp(), s_scan, (uint32_t*)nullptr);
   if (tid < NB) {
@@ -1264,7 +1284,10 @@ __global__ void __launch_bounds__(BT, (KPT <= 8 ? 8 : (KPT <= 12 ? 6 : 4))) k_ms
             uint32_t spins       = 0;
             unsigned long long spin_t0 = 0;
             while ((x >> 62) == 0 || ((unsigned)(x >> 32) & 0xFFu) != epoch) {
-              spin_guard(spins, spin_t0);  // as above
+              if (spin_guard(spins, spin_t0, a.plan, a.spin_ticks)) {  // as above
+                x = pack_status(2u, epoch, 0u);
+                break;
+              }
               __builtin_amdgcn_s_sleep(2);
               x = load_agent_u64(&a.status[(p - k) * NB + tid]);
             }
@@ -1274,7 +1297,7 @@ __global__ void __launch_bounds__(BT, (KPT <= 8 ? 8 : (KPT <= 12 ? 6 : 4))) k_ms
         }
         p -= LBW;
       }
-      store_agent_u64(&a.status[(int64_t)gtile * NB + tid], pack_status(2u, epoch, prefix + pub_count));
+      if ((long long)gtile != a.inject_tile) store_agent_u64(&a.status[(int64_t)gtile * NB + tid], pack_status(2u, epoch, prefix + pub_count));
     }
     uint32_t gb, lim = 0xFFFFFFFFu;
     if (lvl == 0) {
@@ -1383,7 +1406,7 @@ __global__ void __launch_bounds__(GX_WAVE) k_plan2(SortPlan* plan, uint32_t* __r
       // (cursor path: its level-1 cursors count every key, so the sizes add up with or without dropped keys)
       const int bad          = (cursor_path || !overflow) && atomicAdd(&hy.bad, 0);
       const uint32_t maxcell = atomicMax(&hy.max_cell, 0u);
-      if (bad) atomicExch(&plan->status, 3);
+      if (bad) atomicCAS(&plan->status, 0, 3);  // (never over a spin fault)
       const int big = (overflow || maxcell > (uint32_t)hy.cell_max) ? 1 : 0;
       // cursor path: big cells are handled on their own (k_big_plan decides); look-back path: they send the column to the LSD passes
       const int ok = (!bad && (cursor_path || !big)) ? 1 : 0;
@@ -3639,6 +3662,8 @@ struct FastCfg {
   int stride;        // sample: every stride-th 64-key chunk
   size_t slot_rows;  // keys the padded level-0 output holds
 };
+static thread_local int g_spin_ms         = 0;     // look-back wait limit in ms (0: SPIN_SECONDS); tests shorten it
+static thread_local long long g_inject_tile = -1;  // TEST HOOK: the tile of every look-back pass that never publishes (-1: none)
 static thread_local int g_cursor          = 1;     // 0 disables the cursor path (A/B knob)
 static thread_local int g_counting        = 1;     // 0 disables the counting sort of narrow key ranges (A/B knob: the LSD passes run)
 static thread_local int g_float_cursor    = 1;     // 0: float64 keys stay on the look-back path (A/B knob)
@@ -3958,6 +3983,8 @@ int sort_impl(const void* keys_in, void* keys_out, const int32_t* vals_in, int32
                                                                                   // write-back; bit 5 (knob): k_local_sort's sub-bucket path for every cell
       m.cellcount = hist2;
       m.cellcap   = 1u << hc.cl2;
+      m.spin_ticks  = (unsigned long long)g_spin_ms * 100000ull;
+      m.inject_tile = g_inject_tile;
       if (!cursor_marked) prof_mark_h(0, stream);
       hipLaunchKernelGGL(kmsd0, dim3((unsigned)(msd_ntiles + NRANGE)), dim3(BT), lds_msd(hyb_kpt, BINS), stream, m);
       if (!cursor_marked) prof_mark_h(1, stream);
@@ -4012,6 +4039,8 @@ int sort_impl(const void* keys_in, void* keys_out, const int32_t* vals_in, int32
   a.ntiles    = ntiles;
   a.desc_mask = (uint64_t)desc_mask;
   a.order_mode = g_order_mode;
+  a.spin_ticks  = (unsigned long long)g_spin_ms * 100000ull;
+  a.inject_tile = g_inject_tile;
 
   constexpr size_t lds = pass_lds_bytes<KeyT, HAS_VAL, KPT>();
   auto kern_lb         = (algo == 2) ? k_radix_pass<KeyT, KIND, HAS_VAL, KPT, 1>
@@ -4679,6 +4708,8 @@ void gx_sort_set_order_words(int enable) { gx::sort::g_order_words = enable ? 1 
 void gx_sort_set_counting(int enable) { gx::sort::g_counting = enable ? 1 : 0; }
 void gx_sort_set_splitters(int enable) { gx::sort::g_split = enable ? 1 : 0; }
 void gx_sort_set_float_cursor(int enable) { gx::sort::g_float_cursor = enable ? 1 : 0; }
+void gx_sort_set_spin_limit_ms(int ms) { gx::sort::g_spin_ms = ms > 0 ? ms : 0; }
+void gx_sort_inject_lost_tile(long long tile) { gx::sort::g_inject_tile = tile >= 0 ? tile : -1; }
 int gx_sort_split_info(const void* tmp, int32_t* info4_host, gx_stream_t stream)
 {
   if (!tmp || !info4_host) return GX_EINVAL;

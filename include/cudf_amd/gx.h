@@ -103,8 +103,9 @@ int gx_sorted_order(int dtype, const void* keys, const uint32_t* valid, int64_t 
                     int descending, int nulls_before, int32_t* out_indices, void* tmp, size_t* tmp_bytes,
                     gx_stream_t stream);
 
-/* Copies the device-side status word of the last sort that used `tmp` to *status_host
- * (0 = ok).  Synchronises `stream`.  A non-zero status means a look-back spin timed out. */
+/* Copies the device-side status word of the last sort that used `tmp` to *status_host (0 = ok).  Synchronises `stream`.
+ * 5: a look-back wait made no progress for 30 s of wall-clock time (gx_sort_set_spin_limit_ms) and was abandoned -- the output is
+ * NOT sorted (every write stayed inside it); 3: a bookkeeping mismatch of the hybrid path, the LSD passes produced the output. */
 int gx_sort_status(const void* tmp, int* status_host, gx_stream_t stream);
 /* The same copy, queued on `stream` and NOT waited for: *status_host_pinned (host memory the device can write, e.g.
  * hipHostMalloc) holds the status once everything queued on `stream` so far has run.  The asynchronous form the

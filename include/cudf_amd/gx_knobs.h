@@ -90,6 +90,12 @@ void gx_sort_set_splitters(int enable);
  * (isnan * (idx + 1), value) pairs (cpp/src/sort/sort_radix.cu:36-117) could differ -- is sorted by the stable look-back path
  * instead (decided on the device); 0 = float keys always take the look-back path, as before round 5. */
 void gx_sort_set_float_cursor(int enable);
+/* (per calling thread) how long a look-back wait may make no progress before it is abandoned and the sort's status word becomes 5
+ * (gx_sort_status): milliseconds of wall-clock time, 0 = the default 30 s.  Tests shorten it. */
+void gx_sort_set_spin_limit_ms(int ms);
+/* TEST HOOK (per calling thread): tile `tile` of every look-back pass of the sorts this thread issues never publishes its granules --
+ * the lost-chain fault the guard exists for; -1 = none (default). */
+void gx_sort_inject_lost_tile(long long tile);
 /* info4 = {splitter mode used, splitters, equality buckets, level-1 bits} of the last sort on this scratch (synchronises). */
 int gx_sort_split_info(const void* tmp, int32_t* info4_host, gx_stream_t stream);
 /* 0 = not tried, 2 = tried and rejected by the device (the look-back path ran), 3 = the cursor path sorted the column,

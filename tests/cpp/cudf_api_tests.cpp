@@ -17,6 +17,7 @@
 #include <cudf/reduction.hpp>
 #include <cudf/sorting.hpp>
 #include <cudf_amd/gx.h>  // gx_sequence_i32: a device fill for the allocator test
+#include <cudf_amd/gx_knobs.h>  // the look-back fault hooks of the last case
 
 #include <execinfo.h>
 #include <signal.h>
@@ -1520,6 +1521,47 @@ int main()
       if (!errs[t].empty()) std::printf("    thread %d: %s\n", t, errs[t].c_str());
       CHECK(errs[t].empty());
     }
+  });
+
+  run("a lost look-back chain is an EXCEPTION, not a dead process (gx_sort.hip spin_guard; utilities/error.hpp:63-86 draws the line)", [] {
+    // TEST HOOK: tile 3 of every look-back pass never publishes its granules; the wait limit is cut from 30 s to 150 ms.  The
+    // successors' waits are abandoned, the scratch's status word says so, cudf::sorted_order / cudf::sort throw cudf::logic_error --
+    // and the same calls succeed right after, in the same process, on the same HIP context.
+    constexpr std::size_t N = 3'000'000;
+    std::vector<int64_t> k(N);
+    uint64_t x = 88172645463325252ull;
+    for (auto& v : k) { x ^= x << 13; x ^= x >> 7; x ^= x << 17; v = static_cast<int64_t>(x); }
+    auto c = make_col<int64_t>(k);
+    table_view t{{c->view()}};
+    gx_sort_set_spin_limit_ms(150);
+    gx_sort_inject_lost_tile(3);
+    bool threw_order = false, threw_sort = false;
+    try {
+      auto o = cudf::sorted_order(t);
+    } catch (cudf::logic_error const&) {
+      threw_order = true;
+    }
+    try {
+      auto o = cudf::sort(t);
+    } catch (cudf::logic_error const&) {
+      threw_sort = true;
+    }
+    gx_sort_inject_lost_tile(-1);
+    gx_sort_set_spin_limit_ms(0);
+    CHECK(threw_order);
+    CHECK(threw_sort);
+    auto o  = cudf::sorted_order(t);
+    auto so = cudf::sort(t);
+    get_default_stream().synchronize();
+    auto ho = to_host<int32_t>(o->view());
+    std::vector<int32_t> ref(N);
+    std::iota(ref.begin(), ref.end(), 0);
+    std::stable_sort(ref.begin(), ref.end(), [&](int32_t a, int32_t b) { return k[a] < k[b]; });
+    CHECK(std::equal(ref.begin(), ref.end(), ho.begin()));
+    std::vector<int64_t> hs(N);
+    CHECK(hipMemcpy(hs.data(), so->view().column(0).head<int64_t>(), N * sizeof(int64_t), hipMemcpyDeviceToHost) == hipSuccess);
+    std::sort(k.begin(), k.end());
+    CHECK(hs == k);
   });
 
   std::printf("%d run, %d failed\n", g_run, g_failed);
