@@ -175,7 +175,7 @@ struct SortCounters {
 //     that crowd a cell anyway go through the big-cell path (X + LSD passes) as before.
 // ---------------------------------------------------------------------------------------------------------------------------
 constexpr int SP_NSAMP = 16384;  // sampled keys, sorted by one workgroup (128 KiB of LDS)
-constexpr int SP_NLUT  = 2048;
+constexpr int SP_NLUT  = 4096;  // (2048 until run 19: U[0, 1) doubles -- half the splitters in one binade -- had 4 in the fullest cell: four search steps per key)
 constexpr int SP_NPIECE = 16;  // pieces of a bucket's range whose sampled masses shape the bucket's cell map (sp_warp)
 constexpr int SP_PSH    = 28;  // piece of a fraction = frac >> SP_PSH
 struct SplitPlan {
@@ -244,11 +244,11 @@ __device__ __forceinline__ uint32_t sp_frac(const SpCell& c, unsigned long long 
 }
 __device__ __forceinline__ uint32_t sp_lut_cell(unsigned long long rel, uint32_t lut_log, uint32_t lshift)
 {
-  if (lut_log) {  // exponent and 5 mantissa bits of rel: power-law densities
+  if (lut_log) {  // exponent and 6 mantissa bits of rel (64 x 64 = SP_NLUT cells): power-law densities
     if (rel == 0) return 0;
     const int e      = 63 - __builtin_clzll(rel);
-    const uint32_t m = e >= 5 ? (uint32_t)(rel >> (e - 5)) & 31u : (uint32_t)(rel << (5 - e)) & 31u;
-    return (uint32_t)e * 32u + m;
+    const uint32_t m = e >= 6 ? (uint32_t)(rel >> (e - 6)) & 63u : (uint32_t)(rel << (6 - e)) & 63u;
+    return (uint32_t)e * 64u + m;
   }
   const unsigned long long c = rel >> lshift;
   return c < (unsigned long long)(SP_NLUT - 1) ? (uint32_t)c : (uint32_t)(SP_NLUT - 1);
@@ -2324,12 +2324,16 @@ __global__ void __launch_bounds__(BINS) k_hf_plan(SortPlan* plan, int stage, int
           d          = d < 1u ? 1u : d;
           sp.wt[t][j] = make_uint2(y, d);
           y += d;
-          // what the warp cannot follow: the slope of the density INSIDE a piece.  Density at the piece's two edges ~ the mean of the two
-          // pieces that meet there (extrapolated at the bucket's ends); the fullest cell of the piece is that much over the piece's mean
+          // what the warp cannot follow: how the density varies INSIDE a piece.  It is taken to stay below the denser of the two
+          // neighbouring pieces' means (extrapolated at the bucket's ends): exact for a STEP inside the piece -- float keys: the density
+          // over the sortable form doubles at every power of two, and with the milder "mean of the two pieces that meet at an edge"
+          // of runs 13 - 19 every bucket that holds such a step overfilled a cell or two: N(0, 1) doubles 123 big cells, 1e6 keys
+          // -- and each of them has its whole bucket read again by the rescue pass (0.8 ms) -- and twice the slope for a smooth
+          // density (a bell-shaped tail: 1.04 instead of 1.02: 2 % more cells)
           if (m[j] * 256u >= M) {  // (a piece that holds a couple of cells or more)
             const double c  = (double)m[j];
-            const double el = j > 0 ? 0.5 * ((double)m[j - 1] + c) : c + 0.5 * (c - (double)m[j + 1]);
-            const double er = j < SP_NPIECE - 1 ? 0.5 * ((double)m[j + 1] + c) : c + 0.5 * (c - (double)m[j - 1]);
+            const double el = j > 0 ? (double)m[j - 1] : 2.0 * c - (double)m[j + 1];
+            const double er = j < SP_NPIECE - 1 ? (double)m[j + 1] : 2.0 * c - (double)m[j - 1];
             const double r  = (el > er ? el : er) / c;
             peak            = r > peak ? r : peak;
           }

@@ -18,7 +18,6 @@ rb normal --key-dist normal
 rb zipf --key-dist zipf
 rb lognormal --key-dist lognormal
 rb uniform
-rb uniform_1p25e9 --rows 1250000000
 python - $R <<'PY' | tee $O/r5_run${R}_sort_lines.txt
 import json, glob, sys
 R = sys.argv[1]
