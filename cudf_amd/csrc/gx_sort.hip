@@ -734,7 +734,8 @@ constexpr int PASS_TPB = 8;  // tickets per workgroup of the MULTI form of k_rad
 // every 4096 polls -- a slow or time-sliced predecessor tile is not a fault, however many polls it takes) can only mean a broken
 // forward-progress chain.  Until round 5 that ended in __builtin_trap(): fatal for the process' HIP context.  Now the wait is
 // ABANDONED: SortPlan::status becomes 5, the waiting bin takes what it has summed so far as its prefix -- never more than the
-// true prefix, so every write of the tile stays inside its bin's (or cell's) range: the output is wrong, nothing outside it is
+// true prefix, so every write of the tile stays inside its bin's (or cell's) range; the passes behind it do not run (k_radix_pass
+// checks the word first: THEIR bin bases would no longer match what they read); the output is wrong, nothing outside it is
 // touched -- and every other waiter that sees the flag gives up at its next check instead of sitting out its own 30 s.  The host
 // side reads the word (gx_sort_status) and reports the failure: a wrong order is still never returned as success, and the caller's
 // process survives (cudf::sort throws cudf::logic_error; the reference's analogue is a recoverable cudaError from cub,
@@ -785,6 +786,11 @@ __global__ void __launch_bounds__(BT, 4) k_radix_pass(PassArgs a)
   SortPlan* plan = a.plan;
   const int pass = a.pass;
   if (plan->pass_skip[pass]) return;  // constant digit: the pass would be the identity
+  // after an abandoned look-back wait (spin_guard) no further pass runs: the faulted pass kept its writes inside the bins -- its
+  // input was a permutation of the column, its prefixes were too small, never too large -- but its OUTPUT is not one any more (some
+  // keys twice, some missing), so the next pass's digit counts would no longer match the up-front histograms its bin bases come
+  // from, and its last bins would be written past the end of the buffer
+  if (__hip_atomic_load(&plan->status, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == SPIN_FAULT) return;
   const int src_sel      = plan->pass_src[pass];
   const int dst_sel      = plan->pass_dst[pass];
   const bool mode_b      = plan->hy.lsd_mode != 0;  // X instead of the column, its length on the device
@@ -802,9 +808,13 @@ __global__ void __launch_bounds__(BT, 4) k_radix_pass(PassArgs a)
   const unsigned epoch   = (unsigned)pass + 1u;
 
   // X mode: the grid is sized for the column, X is usually a sliver of it -- the surplus workgroups leave before they take a ticket
-  // (a ticket is a device-scope atomic on ONE word: 15 000 of them per pass cost more than sorting a small X)
-  if (mode_b && (int64_t)blockIdx.x * (MULTI ? PASS_TPB : 1) >= a_ntiles) return;
+  // (a ticket is a device-scope atomic on ONE word: 15 000 of them per pass cost more than sorting a small X).  And when X has no
+  // more tiles than the grid has workgroups, every workgroup takes ONE ticket: with PASS_TPB tiles handled back to back by the same
+  // few workgroups a pass over 43 tiles took 80 us -- eight passes 0.65 ms, for 2e5 keys (profiles/r5_prof_f64_uniform_kernel_stats.txt)
+  const bool one_each = MULTI && mode_b && a_ntiles <= (int64_t)gridDim.x;
+  if (mode_b && (int64_t)blockIdx.x * ((MULTI && !one_each) ? PASS_TPB : 1) >= a_ntiles) return;
   for (int it = 0; it < (MULTI ? PASS_TPB : 1); ++it) {
+  if (one_each && it > 0) return;  // (block-uniform)
   int64_t tile;
   if (LOOKBACK) {
     if (tid == 0) s_misc[0] = atomicAdd(&plan->cnt.tickets[pass].v, 1u);
