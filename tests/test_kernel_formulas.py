@@ -928,3 +928,125 @@ def test_splitter_warp_is_monotone_bounded_and_the_identity_for_narrow_buckets()
         cnt[(_sp_warp(int(k * (1 << 32)), tab) * nc) >> 32] += 1
     mean = len(keys) / nc
     assert max(cnt) < 1.06 * mean and min(cnt) > 0.94 * mean, (max(cnt) / mean, min(cnt) / mean)
+
+
+# ------------------------------------------------------------------------------------------------
+# Round 5: the splitter search of level 0 (gx_sort.hip: sp_lut_cell / sp_lut_cell_k, the LUT word, the branch-free steps) and
+# k_sp_plan's gap splitters
+# ------------------------------------------------------------------------------------------------
+_NLUT = 4096
+
+
+def _lut_cell(key, form, kmin, lshift, f):
+    """LUT cell of a sortable 64-bit key: form 0 linear in key - kmin, 1 logarithmic (exponent + 6 mantissa bits), 2 two linear halves
+    cut at f = (nmin, pmin, nsh, psh)"""
+    if form == 2:
+        nmin, pmin, nsh, psh = f
+        pos = key >= pmin
+        o = pmin if pos else nmin
+        c = ((key - o) if key > o else 0) >> (psh if pos else nsh)
+        return (_NLUT // 2 if pos else 0) + min(c, _NLUT // 2 - 1)
+    rel = key - kmin if key >= kmin else 0
+    if form == 1:
+        if rel == 0:
+            return 0
+        e = rel.bit_length() - 1
+        m = (rel >> (e - 6)) & 63 if e >= 6 else (rel << (6 - e)) & 63
+        return e * 64 + m
+    return min(rel >> lshift, _NLUT - 1)
+
+
+def _build_lut(tab, form, kmin, lshift, f):
+    """k_sp_plan: per LUT cell c the splitters in cells below c (bits 0-8) | the splitters inside it, capped at 63 (bits 9-14) | 0x8000
+    when it holds none; and the fullest cell's count (SplitPlan::lut_steps)"""
+    cells = [_lut_cell(t, form, kmin, lshift, f) for t in tab]
+    assert cells == sorted(cells), "the cell function must be monotone over the sorted table"
+    lut, worst = [], 0
+    import bisect
+    for c in range(_NLUT):
+        a = bisect.bisect_left(cells, c)
+        ins = bisect.bisect_right(cells, c) - a
+        worst = max(worst, ins)
+        lut.append(a | (min(ins, 63) << 9) | (0x8000 if ins == 0 else 0))
+    return lut, worst
+
+
+def _bucket_steps(tab, lut, key, steps, form, kmin, lshift, f):
+    """k_sp_level0's branch-free search: start at the LUT word's count, then `steps` times one further if that splitter is <= key"""
+    b = lut[_lut_cell(key, form, kmin, lshift, f)] & 0x1FF
+    for _ in range(steps):
+        if b < len(tab) and tab[b] <= key:
+            b += 1
+    return b
+
+
+def test_splitter_search_by_lut_and_fixed_steps_is_upper_bound_for_every_lut_form():
+    """bucket(key) = number of splitters <= key, for keys inside, between, below and above the sampled range, under all three LUT forms --
+    which needs nothing of a form but that its cell function is monotone; the fixed number of steps is the fullest cell's count"""
+    import bisect
+    import random
+    rnd = random.Random(23)
+    shapes = {
+        "bell": sorted({(1 << 63) + int(rnd.gauss(0, 2.0 ** 40)) for _ in range(250)}),
+        "power law": sorted({int((1.0 - rnd.random()) ** -5.0) + 1000 for _ in range(250)}),
+        "two clusters": sorted({(1 << 63) + s * (1 << 50) + int(rnd.gauss(0, 2.0 ** 30)) for _ in range(125) for s in (-1, 1)}),
+        "float64 N(0, 1)": None,
+    }
+    import struct
+    def fkey(x):
+        b = struct.unpack("<Q", struct.pack("<d", x))[0]
+        return (~b) & ((1 << 64) - 1) if b >> 63 else b | (1 << 63)
+    shapes["float64 N(0, 1)"] = sorted({fkey(rnd.gauss(0, 1)) for _ in range(250)})
+    for name, tab in shapes.items():
+        kmin = tab[0] - (tab[1] - tab[0]) // 3
+        kmax = tab[-1] + 5
+        lshift = 0
+        while ((kmax - kmin) >> lshift) >= _NLUT:
+            lshift += 1
+        gaps = [tab[i + 1] - tab[i] for i in range(len(tab) - 1)]
+        gi = gaps.index(max(gaps))
+        alast = max(tab[gi], kmin)
+        nsh = psh = 0
+        while ((alast - kmin) >> nsh) >= _NLUT // 2:
+            nsh += 1
+        while kmax > tab[gi + 1] and ((kmax - tab[gi + 1]) >> psh) >= _NLUT // 2:
+            psh += 1
+        f = (kmin, tab[gi + 1], nsh, psh)
+        keys = set(tab) | {t - 1 for t in tab} | {t + 1 for t in tab} | {0, 1, kmin, kmin - 1, kmax, (1 << 64) - 1, tab[gi] + gaps[gi] // 2}
+        keys |= {rnd.randrange(tab[0], tab[-1]) for _ in range(2000)}
+        worsts = []
+        for form in (0, 1, 2):
+            lut, worst = _build_lut(tab, form, kmin, lshift, f)
+            worsts.append(worst)
+            for k in keys:
+                if k < 0:
+                    continue
+                assert _bucket_steps(tab, lut, k, worst, form, kmin, lshift, f) == bisect.bisect_right(tab, k), (name, form, k)
+                assert _bucket_steps(tab, lut, k, worst + 2, form, kmin, lshift, f) == bisect.bisect_right(tab, k)   # extra steps change nothing
+        # what the forms are for: the form k_sp_plan picks (fewest splitters in the fullest cell) needs at most a handful of steps
+        assert min(worsts) <= 4, (name, worsts)
+        if name in ("two clusters", "float64 N(0, 1)"):
+            assert worsts[2] < worsts[0] and worsts[2] < worsts[1], (name, worsts)   # one linear half per cluster / per sign
+
+
+def test_gap_splitters_keep_the_table_sorted_and_isolate_the_gap():
+    """k_sp_plan's gap splitters: a bucket whose sampled keys leave more than half of its extent empty in one gap gets two more
+    splitters -- one past the key below the gap, one at the key above it -- so the gap becomes a bucket of its own"""
+    import bisect
+    samp = sorted([100 + i for i in range(40)] + [10 ** 9 + 3 * i for i in range(40)])      # one bucket's sampled keys: two clusters
+    tab = [50, 2 * 10 ** 9]                                                                   # the bucket is [50, 2e9)
+    ia, ib = bisect.bisect_left(samp, tab[0]), bisect.bisect_left(samp, tab[1])
+    assert ib - ia >= 24
+    gaps = [(samp[i + 1] - samp[i], i) for i in range(ia, ib - 1)]
+    g, i = max(gaps)
+    assert g >= (1 << 20) and g > (samp[ib - 1] - samp[ia]) // 2
+    v1, v2 = samp[i] + 1, samp[i + 1]
+    new = tab[:1] + [v1, v2] + tab[1:]
+    assert new == sorted(new) and len(set(new)) == len(new)
+    # every sampled key of the lower cluster is in [50, v1), every one of the upper in [v2, 2e9), none in the gap bucket [v1, v2)
+    b = [bisect.bisect_right(new, k) for k in samp]
+    assert set(b[:40]) == {1} and set(b[40:]) == {3}
+    # a smooth bucket (68 evenly spread keys) never qualifies: its widest gap is a few per cent of its extent
+    smooth = sorted({1000 + 977 * i * i % 100000 for i in range(68)})
+    gs = max(smooth[i + 1] - smooth[i] for i in range(len(smooth) - 1))
+    assert gs <= (smooth[-1] - smooth[0]) // 2
