@@ -40,6 +40,7 @@ _PROTOS = {
     "gx_sorted_order": (_i, [_i, _p, _p, _i64, _i64, _i, _i, _p, _p, _sz, _p]),
     "gx_sort_status": (_i, [_p, ctypes.POINTER(_i), _p]),
     "gx_sort_status_async": (_i, [_p, _p, _p]),
+    "gx_sort_set_fault_mode": (None, [_i]),
     "gx_sort_set_algorithm": (None, [_i]),
     "gx_sort_profile": (_i, [_i]),
     "gx_sort_profile_read": (_i, [ctypes.POINTER(ctypes.c_float), ctypes.POINTER(ctypes.c_float), ctypes.POINTER(_i)]),
@@ -106,6 +107,7 @@ _PROTOS = {
     "gx_join_profile": (_i, [_i]),
     "gx_join_profile_read": (_i, [ctypes.POINTER(ctypes.c_float)]),
     "gx_join_set_scatter_tile": (None, [_i]),
+    "gx_join_set_experiment": (None, [_i]),
     "gx_join_set_build_kernel": (None, [_i]),
     "gx_join_set_probe_kernel": (None, [_i]),
     "gx_join_set_partition_mode": (None, [_i, _i]),

@@ -53,15 +53,20 @@ rmm::device_buffer run_with_scratch(F&& f, char const* what, rmm::cuda_stream_vi
   return tmp;
 }
 
-// After a sort: the device-side status word of its scratch (gx_sort_status; synchronises the stream -- 4 bytes and a round trip,
-// ~0.3 % of a 1e9-row sort).  5 = a look-back wait was abandoned (gx_sort.hip spin_guard): the output is not sorted and the caller
-// gets cudf::logic_error instead of a dead process (until round 5 the kernel trapped).
-inline void check_sort_status(rmm::device_buffer const& tmp, char const* what, rmm::cuda_stream_view stream)
-{
-  int st = 0;
-  gx_check(gx_sort_status(tmp.data(), &st, gxs(stream)), what);
-  CUDF_EXPECTS(st != 5, "radix sort: a look-back wait made no progress and was abandoned (device-side fault); the result is not sorted");
-}
+// Sorts are stream-ordered (round 6): the device-side status word of a sort's scratch (5 = a look-back wait was
+// abandoned, gx_sort.hip spin_guard) is copied to pinned host memory BY THE STREAM behind the sort (post_sort_status: no wait) and
+// examined by a later call -- throw_pending_sort_faults at the entry of the next sort and at this layer's own synchronisation points,
+// cudf_amd::check_device_faults(stream) on demand (src/device_faults.cpp, include/cudf_amd/device_faults.hpp).  cudf::cuda_error, not
+// logic_error (a device runtime fault is not a caller error); only status 5 is a fault.  SortFaultMode opts the sorts issued
+// inside its scope into the recoverable form; every other caller of the C-ABI sorts keeps the trap.
+void post_sort_status(rmm::device_buffer const& tmp, rmm::cuda_stream_view stream);
+void throw_pending_sort_faults();
+struct SortFaultMode {
+  SortFaultMode() { gx_sort_set_fault_mode(1); }
+  ~SortFaultMode() { gx_sort_set_fault_mode(0); }
+  SortFaultMode(SortFaultMode const&)            = delete;
+  SortFaultMode& operator=(SortFaultMode const&) = delete;
+};
 
 // read one int64 from the device (synchronises the stream)
 inline int64_t read_i64(int64_t const* dev, rmm::cuda_stream_view stream)
@@ -69,6 +74,7 @@ inline int64_t read_i64(int64_t const* dev, rmm::cuda_stream_view stream)
   int64_t h = 0;
   CUDF_CUDA_TRY(hipMemcpyAsync(&h, dev, sizeof(h), hipMemcpyDeviceToHost, stream.value()));
   stream.synchronize();
+  throw_pending_sort_faults();  // a synchronisation point of this layer: sorts queued before it have run
   return h;
 }
 

@@ -15,6 +15,8 @@
 namespace cudf {
 namespace {
 
+double read_init_as_double(scalar const& s, rmm::cuda_stream_view stream);
+
 int gx_op_of(aggregation::Kind k)
 {
   switch (k) {
@@ -22,8 +24,108 @@ int gx_op_of(aggregation::Kind k)
     case aggregation::PRODUCT: return GX_OP_PRODUCT;
     case aggregation::MIN: return GX_OP_MIN;
     case aggregation::MAX: return GX_OP_MAX;
-    default: CUDF_FAIL("aggregation kind not implemented on this path (SUM, PRODUCT, MIN, MAX are)");
+    default: CUDF_FAIL("aggregation kind not implemented on this path (SUM, PRODUCT, MIN, MAX, MEAN, COUNT_VALID, COUNT_ALL, ANY, ALL are)");
   }
+}
+
+// a valid numeric scalar of a runtime type holding a host value (count.cpp:20-34: static_cast<T>(count))
+template <typename V>
+std::unique_ptr<scalar> host_scalar(data_type type, V v, bool valid, rmm::cuda_stream_view stream, rmm::device_async_resource_ref mr)
+{
+  switch (type.id()) {
+    case type_id::INT8: return std::make_unique<numeric_scalar<int8_t>>(static_cast<int8_t>(v), valid, stream, mr);
+    case type_id::INT16: return std::make_unique<numeric_scalar<int16_t>>(static_cast<int16_t>(v), valid, stream, mr);
+    case type_id::INT32: return std::make_unique<numeric_scalar<int32_t>>(static_cast<int32_t>(v), valid, stream, mr);
+    case type_id::INT64: return std::make_unique<numeric_scalar<int64_t>>(static_cast<int64_t>(v), valid, stream, mr);
+    case type_id::UINT8: return std::make_unique<numeric_scalar<uint8_t>>(static_cast<uint8_t>(v), valid, stream, mr);
+    case type_id::UINT16: return std::make_unique<numeric_scalar<uint16_t>>(static_cast<uint16_t>(v), valid, stream, mr);
+    case type_id::UINT32: return std::make_unique<numeric_scalar<uint32_t>>(static_cast<uint32_t>(v), valid, stream, mr);
+    case type_id::UINT64: return std::make_unique<numeric_scalar<uint64_t>>(static_cast<uint64_t>(v), valid, stream, mr);
+    case type_id::FLOAT32: return std::make_unique<numeric_scalar<float>>(static_cast<float>(v), valid, stream, mr);
+    case type_id::FLOAT64: return std::make_unique<numeric_scalar<double>>(static_cast<double>(v), valid, stream, mr);
+    case type_id::BOOL8: return std::make_unique<numeric_scalar<bool>>(v != V(0), valid, stream, mr);
+    default: CUDF_FAIL("reduce: unsupported output type");
+  }
+}
+
+bool is_arithmetic_id(type_id id)
+{
+  switch (id) {
+    case type_id::INT8: case type_id::INT16: case type_id::INT32: case type_id::INT64:
+    case type_id::UINT8: case type_id::UINT16: case type_id::UINT32: case type_id::UINT64:
+    case type_id::FLOAT32: case type_id::FLOAT64: case type_id::BOOL8: return true;
+    default: return false;
+  }
+}
+
+// one gx_reduce into a device scalar of `acc` type, read back (reduce ends in a host-visible scalar anyway: the reference's
+// compound and bool reductions return through a device_scalar too, reduction.cuh:63-81)
+template <typename T>
+T reduce_to_host(column_view const& col, int op, int acc_dtype, rmm::cuda_stream_view stream)
+{
+  rmm::device_buffer holder;
+  auto const* mask = col.has_nulls() ? detail::rebased_mask(col, holder, stream) : nullptr;
+  rmm::device_buffer value{16, stream};
+  detail::run_with_scratch(
+    [&](void* t, std::size_t* b) {
+      return gx_reduce(detail::gx_type(col.type()), detail::row0(col), mask, col.size(), op, acc_dtype, value.data(), nullptr, t, b,
+                       detail::gxs(stream));
+    },
+    "reduce", stream);
+  T h{};
+  CUDF_CUDA_TRY(hipMemcpyAsync(&h, value.data(), sizeof(T), hipMemcpyDeviceToHost, stream.value()));
+  CUDF_CUDA_TRY(hipStreamSynchronize(stream.value()));
+  return h;
+}
+
+// COUNT_VALID / COUNT_ALL (reductions/count.cpp:37-46): size - null_count (EXCLUDE) or size, as the output type; any numeric type but
+// bool; always valid, empty and all-null columns included (reductions.cpp:252-275: reduce_no_data == reduce)
+std::unique_ptr<scalar> reduce_count(column_view const& col, bool include_nulls, data_type output_type, rmm::cuda_stream_view stream,
+                                     rmm::device_async_resource_ref mr)
+{
+  if (!is_arithmetic_id(output_type.id()) || output_type.id() == type_id::BOOL8)
+    throw std::invalid_argument{"COUNT is not supported for boolean or non-numeric types"};
+  auto const count = col.size() - (include_nulls ? 0 : col.null_count());
+  return host_scalar<int64_t>(output_type, count, true, stream, mr);
+}
+
+// MEAN (reductions/mean.cu, compound.cuh:41-84, reduction_operators.cuh:256-275): sum of the valid elements / valid count in the
+// (floating) output type; no valid row -> an invalid scalar.  The sum is the double-double SUM of gx_reduce: within an ulp of the exact
+// quotient, where the reference's order of additions is cub's
+std::unique_ptr<scalar> reduce_mean(column_view const& col, data_type output_type, rmm::cuda_stream_view stream,
+                                    rmm::device_async_resource_ref mr)
+{
+  CUDF_EXPECTS(is_arithmetic_id(col.type().id()), "Reduction operator `mean` `var` `std` not supported for this type");
+  CUDF_EXPECTS(output_type.id() == type_id::FLOAT32 || output_type.id() == type_id::FLOAT64, "Unsupported output data type");
+  auto const valid_count = col.size() - col.null_count();
+  if (valid_count == 0) return host_scalar<double>(output_type, 0.0, false, stream, mr);
+  double const sum = reduce_to_host<double>(col, GX_OP_SUM, GX_FLOAT64, stream);
+  return host_scalar<double>(output_type, sum / static_cast<double>(valid_count), true, stream, mr);
+}
+
+// ANY / ALL (reductions/any.cu:79-95, all.cu; simple.cuh:47-85, 238-259): max / min over static_cast<bool>(x), nulls skipped, the
+// initial value cast to bool and folded in; BOOL8 output only.  No valid row: any = false, all = true, both VALID
+// (reductions.cpp:163-186) -- with or without an initial value, which reduce_no_data never looks at
+std::unique_ptr<scalar> reduce_any_all(column_view const& col, bool is_any, data_type output_type,
+                                       std::optional<std::reference_wrapper<scalar const>> init, rmm::cuda_stream_view stream,
+                                       rmm::device_async_resource_ref mr)
+{
+  CUDF_EXPECTS(output_type == data_type{type_id::BOOL8},
+               is_any ? "any() operation can be applied with output type `bool8` only" : "all() operation can be applied with output type `BOOL8` only");
+  auto const valid_count = col.size() - col.null_count();
+  if (valid_count == 0) return std::make_unique<numeric_scalar<bool>>(!is_any, true, stream, mr);
+  CUDF_EXPECTS(is_arithmetic_id(col.type().id()), "Reduction operator not supported for this type");
+  auto const nonzero = reduce_to_host<int64_t>(col, GX_OP_COUNT_NONZERO, GX_INT64, stream);
+  bool result        = is_any ? nonzero > 0 : nonzero == static_cast<int64_t>(valid_count);
+  bool valid         = true;
+  if (init.has_value()) {
+    if (!init.value().get().is_valid(stream)) valid = false;
+    else {
+      bool const iv = read_init_as_double(init.value().get(), stream) != 0.0;  // (NaN != 0: true, as static_cast<bool>)
+      result        = is_any ? (result || iv) : (result && iv);
+    }
+  }
+  return std::make_unique<numeric_scalar<bool>>(result, valid, stream, mr);
 }
 
 template <typename T>
@@ -40,6 +142,14 @@ std::unique_ptr<scalar> make_result(void const* dev_value, bool valid, rmm::cuda
 std::unique_ptr<scalar> reduce(column_view const& col, reduce_aggregation const& agg, data_type output_type,
                                rmm::cuda_stream_view stream, rmm::device_async_resource_ref mr)
 {
+  switch (agg.kind) {  // reductions.cpp:484-507 dispatches on (type, kind); these four are not cub reductions
+    case aggregation::COUNT_VALID: return reduce_count(col, false, output_type, stream, mr);
+    case aggregation::COUNT_ALL: return reduce_count(col, true, output_type, stream, mr);
+    case aggregation::MEAN: return reduce_mean(col, output_type, stream, mr);
+    case aggregation::ANY: return reduce_any_all(col, true, output_type, std::nullopt, stream, mr);
+    case aggregation::ALL: return reduce_any_all(col, false, output_type, std::nullopt, stream, mr);
+    default: break;
+  }
   int const op = gx_op_of(agg.kind);
   CUDF_EXPECTS(is_fixed_width(col.type()), "reduce: only fixed-width columns are supported on this path", cudf::data_type_error);
   if (op == GX_OP_MIN || op == GX_OP_MAX)
@@ -103,9 +213,12 @@ T read_init(scalar const& s, rmm::cuda_stream_view stream)
     case type_id::UINT64: return static_cast<T>(static_cast<numeric_scalar<uint64_t> const&>(s).value(stream));
     case type_id::FLOAT32: return static_cast<T>(static_cast<numeric_scalar<float> const&>(s).value(stream));
     case type_id::FLOAT64: return static_cast<T>(static_cast<numeric_scalar<double> const&>(s).value(stream));
+    case type_id::BOOL8: return static_cast<T>(static_cast<numeric_scalar<bool> const&>(s).value(stream));
     default: throw cudf::data_type_error{"reduce: unsupported initial value type"};
   }
 }
+
+double read_init_as_double(scalar const& s, rmm::cuda_stream_view stream) { return read_init<double>(s, stream); }
 
 template <typename T>
 void apply_init(int op, scalar& result, scalar const& init, rmm::cuda_stream_view stream)
@@ -125,10 +238,12 @@ std::unique_ptr<scalar> reduce(column_view const& col, reduce_aggregation const&
   CUDF_EXPECTS(!init.has_value() || init.value().get().type() == col.type(), "column and initial value must be the same type",
                cudf::data_type_error);
   if (init.has_value() && !(agg.kind == aggregation::SUM || agg.kind == aggregation::PRODUCT || agg.kind == aggregation::MIN ||
-                            agg.kind == aggregation::MAX))
-    // (the reference also folds an initial value into SUM_WITH_OVERFLOW, ANY, ALL and HOST_UDF -- reductions.cpp:484-507; those
+                            agg.kind == aggregation::MAX || agg.kind == aggregation::ANY || agg.kind == aggregation::ALL))
+    // (the reference also folds an initial value into SUM_WITH_OVERFLOW and HOST_UDF -- reductions.cpp:484-507; those two
     //  aggregations are not part of this hot path at all, with or without an initial value: INTEGRATION.md section 5)
-    throw std::invalid_argument{"Initial value is only supported for SUM, PRODUCT, MIN and MAX on this path (the reference's SUM_OVERFLOW, ANY, ALL and HOST_UDF reductions are not implemented here)"};
+    throw std::invalid_argument{"Initial value is only supported for SUM, PRODUCT, MIN, MAX, ANY and ALL on this path (the reference's SUM_OVERFLOW and HOST_UDF reductions are not implemented here)"};
+  if (agg.kind == aggregation::ANY || agg.kind == aggregation::ALL)
+    return reduce_any_all(col, agg.kind == aggregation::ANY, output_type, init, stream, mr);
   auto result = reduce(col, agg, output_type, stream, mr);
   if (!init.has_value()) return result;
   if (!init.value().get().is_valid(stream)) {

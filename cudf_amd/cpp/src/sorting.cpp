@@ -11,12 +11,12 @@ namespace cudf {
 namespace {
 
 // Device-side protocol faults: a look-back wait that makes no progress for 30 s of wall-clock time is ABANDONED inside the kernel
-// (gx_sort.hip, spin_guard): the scratch's status word becomes 5, every write stays inside the output, and the sort below reads
-// the word and throws cudf::logic_error -- the caller's process and HIP context survive (until round 5 the kernel trapped, which
-// on ROCm is a queue exception the process does not survive: the reference's cudf::fatal_cuda_error class of failure,
-// utilities/error.hpp:63-86).  A wrong order is never returned as success; a slow or time-sliced predecessor tile (many polls,
-// little time) never trips the guard.  The price is one 4-byte read-back per sort: the reference's sort returns as soon as its
-// work is queued (cpp/src/sort/sort.cu:52-89), this one after it has run.
+// (gx_sort.hip, spin_guard; opted into by SortFaultMode below -- other callers of the C-ABI sorts keep the trap): the scratch's status
+// word becomes 5 and every write stays inside the output.  Round 6: the sorts here stay STREAM-ORDERED like the reference's
+// (cpp/src/sort/sort.cu:52-89 returns once the work is queued) -- the word travels to pinned host memory behind the sort
+// (detail::post_sort_status) and the fault surfaces at the next sort call or at cudf_amd::check_device_faults(stream) as
+// cudf::cuda_error, the way a sticky device error reaches a caller of the reference (utilities/error.hpp:63-86).  Round 5 read the
+// word back after every sort: one host round trip per call, and callers pipelining sorts over several streams serialised on it.
 
 void check_order_args(table_view const& input, std::vector<order> const& column_order,
                       std::vector<null_order> const& null_precedence)
@@ -37,13 +37,14 @@ void column_sorted_order(column_view const& col, order ord, null_order nulls, in
   int const dtype       = detail::gx_type(col.type());
   int const descending  = ord == order::DESCENDING ? 1 : 0;
   int const null_before = nulls == null_order::BEFORE ? 1 : 0;
+  detail::SortFaultMode soft;
   auto const tmp = detail::run_with_scratch(
     [&](void* t, std::size_t* b) {
       return gx_sorted_order(dtype, detail::row0(col), mask, col.size(), mask ? col.null_count() : 0, descending,
                              null_before, out, t, b, detail::gxs(stream));
     },
     "sorted_order", stream);
-  if (col.size() > 0) detail::check_sort_status(tmp, "sorted_order", stream);
+  if (col.size() > 0 && !mask) detail::post_sort_status(tmp, stream);  // (nullable columns: the validity split's scratch has no plan header in front)
 }
 
 std::unique_ptr<column> gather_column(column_view const& src, int32_t const* map, size_type n, bool nullify,
@@ -68,6 +69,7 @@ std::unique_ptr<column> sorted_order_impl(table_view const& input, std::vector<o
                                           std::vector<null_order> const& null_precedence,
                                           rmm::cuda_stream_view stream, rmm::device_async_resource_ref mr)
 {
+  detail::throw_pending_sort_faults();  // an earlier sort's device-side fault surfaces here (non-blocking: completed sorts only)
   check_order_args(input, column_order, null_precedence);
   auto const n = input.num_rows();
   if (n == 0 || input.num_columns() == 0) return make_numeric_column(data_type{type_id::INT32}, 0, mask_state::UNALLOCATED, stream, mr);
@@ -155,6 +157,7 @@ std::unique_ptr<table> sort(table_view const& input, std::vector<order> const& c
                             std::vector<null_order> const& null_precedence, rmm::cuda_stream_view stream,
                             rmm::device_async_resource_ref mr)
 {
+  detail::throw_pending_sort_faults();
   check_order_args(input, column_order, null_precedence);
   // fast path of sort.cu:57-64: one fixed-width column without nulls -> keys-only radix sort
   if (input.num_columns() == 1 && !input.column(0).has_nulls() && is_fixed_width(input.column(0).type()) &&
@@ -162,13 +165,14 @@ std::unique_ptr<table> sort(table_view const& input, std::vector<order> const& c
       auto const& col = input.column(0);
     auto out        = make_fixed_width_column(col.type(), col.size(), mask_state::UNALLOCATED, stream, mr);
     int const desc  = (!column_order.empty() && column_order[0] == order::DESCENDING) ? 1 : 0;
+    detail::SortFaultMode soft;
     auto const tmp = detail::run_with_scratch(
       [&](void* t, std::size_t* b) {
         return gx_sort_keys(detail::gx_type(col.type()), detail::row0(col), out->mutable_view().head<void>(), col.size(),
                             desc, t, b, detail::gxs(stream));
       },
       "sort", stream);
-    detail::check_sort_status(tmp, "sort", stream);
+    detail::post_sort_status(tmp, stream);
     std::vector<std::unique_ptr<column>> cols;
     cols.emplace_back(std::move(out));
     return std::make_unique<table>(std::move(cols));

@@ -2133,6 +2133,191 @@ __global__ void __launch_bounds__(BTt) k_pj2_scatter(const K* __restrict__ keys,
   }
 }
 
+// Round 6: the partition pass writing 12-byte RECORDS {key, row} instead of a key array and a row array (gx_join_set_experiment
+// bit 0; 8-byte keys).
+//
+// k_pj2_scatter at P = 2048 leaves runs of 16384 / 2048 = 8 rows per (tile, partition): a 64-B key run and a 32-B row run at an
+// arbitrary 8- / 4-byte offset.  A wave's store instruction then touches 8 runs = ~11.5 128-B lines for its 64 keys and ~9.8 for
+// its 64 rows, where 64 contiguous keys + rows would touch 6; the 256-way form of the same kernel (64-row runs) moves the same
+// rows in 4.43 ms against 6.1 (profiles/r5_join_probe_ab.txt), i.e. the pass is bound by line transactions at the L2, not by
+// bytes.  One 96-B record run per (tile, partition) touches ~13.5 lines per 64 rows instead of ~21, and the probe reads a lane's
+// four rows as three 16-byte loads.  To have key AND row of a position at hand when it is written, the tile goes through LDS in
+// windows of 8192 positions (64 KiB of keys + 32 KiB of rows) instead of keys first, rows second; RPT = 24 keys per thread
+// (24576-row tiles, 12-row runs, three windows) costs 16 more registers and a third fewer fill-counter atomics.
+// FULL tiles only (ntiles = n / TILE): the ragged tail is a second launch on the last rows with `tail_base`.
+__device__ __forceinline__ void pj_opaque(uint64_t& k)
+{  // the compiler must not carry values derived from k across this point (it would keep the partition numbers live next to the keys)
+  uint32_t lo = (uint32_t)k, hi = (uint32_t)(k >> 32);
+  asm volatile("" : "+v"(lo), "+v"(hi));
+  k = ((uint64_t)hi << 32) | lo;
+}
+struct PjRec {  // one partitioned probe row
+  uint32_t klo, khi;
+  int32_t row;
+};
+template <int RPT, bool EXACT, bool TAIL, bool AOS, typename F>
+__global__ void __launch_bounds__(1024) k_pj2_scatter_rec(const uint64_t* __restrict__ keys, int64_t n, Pj2Plan* plan2, PjPlan* plan, int pbits,
+                                                          int64_t rrows, uint32_t cap, int64_t ntiles, int64_t tile0_row,
+                                                          PjRec* __restrict__ precs, F part_of, int32_t row0,
+                                                          const int32_t* __restrict__ payload, int32_t* __restrict__ soa_idx)
+{
+  typedef uint64_t K;
+  constexpr int BTt  = 1024;
+  constexpr int TILE = BTt * RPT;
+  constexpr int WIN  = 8192;            // tile positions per LDS window
+  constexpr int NWIN = (TILE + WIN - 1) / WIN;
+  constexpr int RPW  = WIN / BTt;       // positions a thread writes out per window
+  static_assert(TILE <= 65536 && TILE % WIN == 0, "tile positions travel as 16-bit halves; whole windows");
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  K* s_k                = reinterpret_cast<K*>(smem);                                             // WIN keys
+  int32_t* s_i          = reinterpret_cast<int32_t*>(smem + (size_t)WIN * sizeof(K));             // WIN rows
+  unsigned int* s_cd    = reinterpret_cast<unsigned int*>(smem + (size_t)WIN * (sizeof(K) + 4));  // P: counts, then global - tile position
+  unsigned int* s_start = s_cd + (1 << pbits);                                                    // P
+  __shared__ unsigned int s_scan[BTt / GX_WAVE + 1];
+  if (EXACT && plan2->fallback == 0) return;
+  const int P      = 1 << pbits;
+  unsigned tid     = threadIdx.x;
+  const int bpt    = P > BTt ? P / BTt : 1;
+  const int b0     = P > BTt ? (int)threadIdx.x * bpt : (int)threadIdx.x;
+  const bool owner = P > BTt || (int)threadIdx.x < P;
+
+  K key[RPT];
+  int64_t v = blockIdx.x;
+  if (v >= ntiles) return;
+  // TAIL: the tail launch -- ONE partial tile starting at row tile0_row (nvalid < TILE), always in the last range; otherwise every
+  // tile is full and the validity tests below fold away (hoisted out of the tile loop they cost 2 SGPRs per key, and spills)
+  auto locate = [&](int64_t vv, int64_t& b, int& nv, int& r) {
+    if (TAIL) {
+      b  = tile0_row;
+      nv = (int)(n - tile0_row);
+      r  = PJ_NR - 1;
+      return;
+    }
+    const int64_t tile = xcd_swizzle(vv, ntiles);
+    b                  = tile * TILE;
+    nv                 = TILE;
+    r                  = (rrows > 0 && b / rrows < PJ_NR - 1) ? (int)(b / rrows) : PJ_NR - 1;
+  };
+  auto load = [&](int64_t b, int nv) {
+#pragma unroll
+    for (int j = 0; j < RPT; ++j) {
+      const int idx = j * BTt + (int)tid;
+      key[j]        = __builtin_nontemporal_load(&keys[b + (idx < nv ? idx : 0)]);
+    }
+  };
+  int64_t base;
+  int range, nvalid_;
+  locate(v, base, nvalid_, range);
+  load(base, nvalid_);
+  for (;;) {
+    const int nvalid = TAIL ? nvalid_ : TILE;
+    asm volatile("" : "+v"(tid));  // per-iteration addresses are recomputed, not hoisted out of the tile loop and spilled (DESIGN, compiler note)
+    for (int i = tid; i < P; i += BTt) s_cd[i] = 0;
+    __syncthreads();
+    unsigned int lpos2[RPT / 2];  // rank inside (tile, partition), then the tile position: 16 bits each, two per register (0xFFFF: no row)
+#pragma unroll
+    for (int j = 0; j < RPT; ++j) {
+      const int idx           = j * BTt + (int)tid;
+      const unsigned int rank = idx < nvalid ? atomicAdd(&s_cd[part_of(key[j])], 1u) : 0xFFFFu;  // < TILE < 65535
+      if (j & 1) lpos2[j / 2] |= rank << 16; else lpos2[j / 2] = rank;
+    }
+#pragma unroll
+    for (int j = 0; j < RPT; ++j) pj_opaque(key[j]);
+    __syncthreads();
+    unsigned int c[4], g[4];
+    unsigned int sum = 0;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      c[k] = (owner && k < bpt) ? s_cd[b0 + k] : 0u;
+      g[k] = 0;
+      sum += c[k];
+    }
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      if (c[k]) {
+        if (EXACT) g[k] = (unsigned int)atomicAdd(&plan->cursor[range][b0 + k], (unsigned long long)c[k]);
+        else g[k] = atomicAdd(&plan2->fill[(b0 + k) * PJ_NR + range], c[k]);
+      }
+    }
+    unsigned int st = block_exclusive_scan<BTt>(sum, 0u, SumOp(), s_scan, (unsigned int*)nullptr);
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      if (owner && k < bpt) s_start[b0 + k] = st;
+      st += c[k];
+    }
+    __syncthreads();
+    // rank -> tile position (the partition is recomputed from the key: a multiply and a shift against RPT more live registers)
+#pragma unroll
+    for (int j = 0; j < RPT; ++j) {
+      const unsigned int h   = (j & 1) ? lpos2[j / 2] >> 16 : lpos2[j / 2] & 0xFFFFu;
+      const unsigned int add = h == 0xFFFFu ? 0u : s_start[part_of(key[j])];  // run start + rank < TILE: no carry out of a half
+      if (j & 1) lpos2[j / 2] += add << 16; else lpos2[j / 2] += add;
+    }
+    {  // (s_cd's counts were consumed above and nobody reads it again before the barrier behind the first window's keys)
+      unsigned int st2 = s_start[owner ? b0 : 0];
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        if (owner && k < bpt) {
+          unsigned int gb = g[k];
+          if (!EXACT) {
+            gb += (unsigned int)((b0 + k) * PJ_NR + range) * cap;
+            if (c[k] && g[k] + c[k] > cap) plan2->overflow = 1u;
+          }
+          s_cd[b0 + k] = gb - st2;
+        }
+        st2 += c[k];
+      }
+    }
+    const int64_t vn = v + gridDim.x;
+    int64_t nbase    = 0;
+    int nrange = 0, nnvalid = 0;
+    const bool more  = !TAIL && vn < ntiles;
+#pragma unroll
+    for (int q = 0; q < NWIN; ++q) {
+      asm volatile("" : "+v"(tid));
+      // ---- keys and rows of window q into LDS
+      const int32_t rowt = (int32_t)base + (int32_t)tid + row0;
+#pragma unroll
+      for (int j = 0; j < RPT; ++j) {
+        const unsigned int l = (j & 1) ? lpos2[j / 2] >> 16 : lpos2[j / 2] & 0xFFFFu;
+        if ((int)(l / WIN) == q) {  // (0xFFFF / WIN = 7 is no window)
+          s_k[l % WIN] = key[j];
+          s_i[l % WIN] = payload ? payload[base + j * BTt + (int)tid] : rowt + j * BTt;
+        }
+      }
+      if (q == NWIN - 1 && more) {  // the key registers are free: the next tile's keys land under the write-out
+        locate(vn, nbase, nnvalid, nrange);
+        load(nbase, nnvalid);
+      }
+      __syncthreads();
+#pragma unroll
+      for (int j = 0; j < RPW; ++j) {
+        const int i  = j * BTt + (int)tid;
+        const int gi = q * WIN + i;
+        if (gi < nvalid) {
+          const K k             = s_k[i];
+          const int32_t r       = s_i[i];
+          const unsigned int pt = part_of(k);
+          const unsigned int p  = s_cd[pt] + (unsigned int)gi;
+          if (EXACT || p < (unsigned int)(pt * PJ_NR + range + 1) * cap) {  // (a run that outgrew its slot is dropped: `overflow` is up)
+            if (AOS) precs[p] = PjRec{(uint32_t)k, (uint32_t)(k >> 32), r};
+            else {  // the same pass writing the two arrays of k_pj2_scatter (A/B: is it the record runs or the window structure that pays?)
+              reinterpret_cast<K*>(precs)[p] = k;
+              soa_idx[p]                     = r;
+            }
+          }
+        }
+      }
+      __syncthreads();  // the windows and s_cd are read until here
+    }
+    if (!more) break;
+    v       = vn;
+    base    = nbase;
+    range   = nrange;
+    nvalid_ = nnvalid;
+  }
+}
+
 // After the speculative scatter: piece numbering over the regions, or the verdict "fallback".  One block of 1024 threads,
 // each handling a run of consecutive regions.
 __global__ void __launch_bounds__(1024) k_pj2_offsets(Pj2Plan* plan2, int pbits, uint32_t cap, unsigned int piece_rows)
@@ -2182,6 +2367,11 @@ struct PieceTable {
   const unsigned int* fill;          // padded slots: rows in region e (clamped to cap)
   unsigned int cap;                  // padded slots: region e starts at e * cap
   int nr;                            // regions per partition: PJ_NR (padded slots) or 1 (exact partitions)
+  // round 6 (k_pj2_probe_pipe, padded slots only): fixedk > 0 = EVERY region is cut into fixedk = ceil(cap / piece rows) pieces, so a
+  // ticket t of list y IS (region, piece in region) = (t / fixedk, t % fixedk) -- no search through chunk0 -- and the service wave's
+  // ticket atomic and fill-counter read are issued one trip ahead of their use.  `gate` (plan2->fallback): non-zero = no piece at all.
+  unsigned int fixedk;
+  const unsigned int* gate;
 };
 
 // DEFER: a row whose chain is not settled by its first (preloaded) candidate slot -- another slot carries its tag, or the
@@ -2201,7 +2391,14 @@ struct alignas(8) PpDefer {
   uint32_t ended;  // the chain ends inside the window
   uint64_t cand;   // tag candidates still to look at (bit 4i + 3 = slot i of the window), lowest first
 };
-template <typename K, bool EARLY, bool DEFER>
+typedef uint32_t pj_u32x4 __attribute__((ext_vector_type(4)));
+typedef uint32_t pj_u32x3 __attribute__((ext_vector_type(3)));
+// REC (round 6): the probe rows are 12-byte records {key, row} (k_pj2_scatter_rec) behind `pkeys`: one 12-byte load per row instead of an
+// 8-byte and a 4-byte one.  (Measured and dropped: four CONSECUTIVE rows per lane as three 16-byte loads -- 16 bytes per lane at a 48-byte
+// stride touch every line of the wave's 3 KiB three times: probe 7.57 -> 8.8 ms, profiles/r6_run1_join_ab.txt.)
+// ABL (measurement only, WRONG results; gx_join_set_experiment bits 4-6): 1 = tag lookup kept, no slot is read; 2 = matches are found but
+// not staged / flushed; 3 = no tag lookup at all (rows streamed in, nothing else)
+template <typename K, bool EARLY, bool DEFER, bool REC = false, int ABL = 0>
 __global__ void __launch_bounds__(PP_BT)
 k_pj2_probe_pipe(const K* __restrict__ pkeys, const int32_t* __restrict__ pidx, PieceTable pt, int pbits,
                  const Slot<K>* __restrict__ slots, uint32_t log2cap, int left_outer, int32_t* __restrict__ out_probe,
@@ -2298,11 +2495,74 @@ k_pj2_probe_pipe(const K* __restrict__ pkeys, const int32_t* __restrict__ pidx, 
       pc.part  = part;
       pc.valid = 1;
     };
+    // Round 6: the PIPELINED take (pt.fixedk > 0).  take_piece above is a chain of four dependent global round trips -- ticket atomic,
+    // two searches through chunk0, the region's fill counter -- and the output reservation of the previous piece was waited for at the
+    // top of the same trip: five round trips per trip on ONE wave, with fifteen probe waves waiting for it at X(t).  Measured
+    // (profiles/r6_run2_join_ab.txt): with the slot reads, or the tag lookups, or both removed the kernel still takes 4.7 ms = 4.9 us
+    // per 3840-row trip; every form of the probe that shares this service wave landed at the same 7.5 ms in round 5.  Now a ticket IS
+    // its (region, piece): step C issues the ticket atomic, step B (next trip) turns it into a region and requests the fill counter,
+    // step A (the trip after) builds the piece -- each step consumes what was issued a whole trip earlier, and the reservation is
+    // read back behind them.  A list that runs out costs one empty piece (valid, no rows) while the next list's first ticket travels.
+    const unsigned fixedk  = pt.fixedk;
+    const bool gated       = fixedk && pt.gate && *pt.gate != 0;
+    unsigned int tk_raw    = 0, fill_raw = 0;  // lane 0: ticket / fill counter in flight
+    unsigned int tk_y      = 0, pe = 0, ploc = 0, last_part = 0;
+    bool tk_pend = false, fill_pend = false;
+    auto step_take = [&](PpPiece& pc) {
+      pc.valid = 1;  // an empty piece unless step A has a region
+      pc.c0 = pc.c1 = 0;
+      pc.part = last_part;
+      // ---- A: the fill counter requested last trip
+      if (fill_pend) {
+        unsigned int c = (unsigned int)__builtin_amdgcn_readfirstlane((int)fill_raw);
+        c              = c < pt.cap ? c : pt.cap;
+        const unsigned long long r0 = (unsigned long long)pe * pt.cap;
+        pc.c0     = r0 + (unsigned long long)ploc * PP_ROWS;
+        pc.c1     = pc.c0 + PP_ROWS < r0 + c ? pc.c0 + PP_ROWS : r0 + c;
+        if (pc.c1 < pc.c0) pc.c1 = pc.c0;  // the region ends before this piece
+        pc.part   = pe / (unsigned int)pt.nr;
+        last_part = pc.part;
+        fill_pend = false;
+      } else if (!tk_pend && ylist >= PJ_NR) {
+        pc.valid = 0;  // nothing in flight, no list left: the pipeline drains
+      }
+      // ---- B: the ticket requested last trip
+      if (tk_pend) {
+        const unsigned int tk  = (unsigned int)__builtin_amdgcn_readfirstlane((int)tk_raw);
+        const unsigned int nch = (unsigned int)LISTP * (unsigned int)pt.nr * fixedk;
+        tk_pend                = false;
+        if (tk < nch) {
+          pe        = tk_y * (unsigned int)LISTP * (unsigned int)pt.nr + tk / fixedk;
+          ploc      = tk % fixedk;
+          if (lane == 0) fill_raw = pt.fill[pe];
+          fill_pend = true;
+        } else {
+          ++ylist;  // this list is exhausted
+        }
+      }
+      // ---- C: the next ticket
+      if (ylist < PJ_NR && !gated) {
+        tk_y = (x0 + ylist) % PJ_NR;
+        if (lane == 0) tk_raw = atomicAdd(&pt.ticket[tk_y].v, 1u);
+        tk_pend = true;
+      } else {
+        ylist = PJ_NR;
+      }
+    };
     PpPiece pc;
-    take_piece(pc);
-    if (lane == 0) s_piece[0] = pc;
-    take_piece(pc);
-    if (lane == 0) s_piece[1] = pc;
+    if (fixedk) {
+      step_take(pc);  // (C)
+      step_take(pc);  // (B, C)
+      step_take(pc);
+      if (lane == 0) s_piece[0] = pc;
+      step_take(pc);
+      if (lane == 0) s_piece[1] = pc;
+    } else {
+      take_piece(pc);
+      if (lane == 0) s_piece[0] = pc;
+      take_piece(pc);
+      if (lane == 0) s_piece[1] = pc;
+    }
     __syncthreads();  // prologue barrier
     unsigned long long pending = 0;
     int done_at = -1;
@@ -2319,9 +2579,14 @@ k_pj2_probe_pipe(const K* __restrict__ pkeys, const int32_t* __restrict__ pidx, 
         }
       }
       if (done_at < 0 && !s_piece[t & 3].valid) done_at = t;  // same test as the probe waves make
-      if (lane == 0 && itf >= 0) s_base[(unsigned)itf % 3u] = pending;
-      take_piece(pc);
+      if (fixedk) {
+        step_take(pc);
+      } else {
+        if (lane == 0 && itf >= 0) s_base[(unsigned)itf % 3u] = pending;
+        take_piece(pc);
+      }
       if (lane == 0) s_piece[(t + 2) & 3] = pc;
+      if (fixedk && lane == 0 && itf >= 0) s_base[(unsigned)itf % 3u] = pending;  // (its atomic left behind X(t - 1): read back last)
       __syncthreads();  // X(t)
       if (done_at >= 0 && t >= done_at + (DEFER ? 4 : 3)) break;  // DEFER: rows parked in the last S3 are staged one trip later
       if (lane == 0) {
@@ -2530,6 +2795,10 @@ k_pj2_probe_pipe(const K* __restrict__ pkeys, const int32_t* __restrict__ pidx, 
         const K rkey       = j < PP_R ? kB[j < PP_R ? j : 0] : keyx;
         const int32_t ridx = j < PP_R ? iB[j < PP_R ? j : 0] : idxx;
         if (left_outer && live && m[j] == 0) m[j] = 1;  // (row, JoinNoMatch); first[j] is NO_MATCH
+        if (ABL == 2) {
+          asm volatile("" ::"v"(m[j]), "v"(first[j]));
+          m[j] = 0;
+        }
         uint32_t off, tot;
         if (ballot(m[j] > 1) == 0) {
           const uint64_t bb = ballot(m[j] == 1);
@@ -2623,7 +2892,7 @@ k_pj2_probe_pipe(const K* __restrict__ pkeys, const int32_t* __restrict__ pidx, 
           // the 16 tags of local slots [li, li + 16): three words, two funnel shifts.  A chain of the table (load <= 0.5)
           // that is not over after 16 slots is a 1e-5 event; after 8 it is not (3e-3 per row: one stalled wave per trip).
           const uint32_t tagpat = tg * 0x11111111u;
-          const uint32_t w0 = s_tagw[li[j] >> 3], w1 = s_tagw[(li[j] >> 3) + 1], w2 = s_tagw[(li[j] >> 3) + 2];
+          const uint32_t w0 = ABL == 3 ? li[j] : s_tagw[li[j] >> 3], w1 = ABL == 3 ? tg : s_tagw[(li[j] >> 3) + 1], w2 = ABL == 3 ? 0u : s_tagw[(li[j] >> 3) + 2];
           const uint32_t sh = (li[j] & 7u) * 4u;
           const uint32_t x0 = __builtin_amdgcn_alignbit(w1, w0, sh), x1 = __builtin_amdgcn_alignbit(w2, w1, sh);
           const uint32_t y0 = x0 ^ tagpat, y1 = x1 ^ tagpat;
@@ -2635,6 +2904,12 @@ k_pj2_probe_pipe(const K* __restrict__ pkeys, const int32_t* __restrict__ pidx, 
           const uint32_t c1 = z0 ? 0u : (m1 & ((z1 & (0u - z1)) - 1u));
           cand[j]           = (uint64_t)c0 | ((uint64_t)c1 << 32);
           if (z0 | z1) fl |= 1u << (4 + j);
+          if (ABL == 1 || ABL == 3) {
+            uint32_t a0 = c0, a1 = c1;
+            asm volatile("" ::"v"(a0), "v"(a1));
+            cand[j] = 0;
+            fl |= 1u << (4 + j);
+          }
         }
       }
 #pragma unroll
@@ -2650,7 +2925,19 @@ k_pj2_probe_pipe(const K* __restrict__ pkeys, const int32_t* __restrict__ pidx, 
       partA = pcur.part;
       cA0   = pcur.c0;
       cA1   = pcur.c1;
-      if (!EARLY) {
+      if constexpr (REC) {
+        static_assert(sizeof(K) == 8 && !EARLY, "record form: 8-byte keys, rows requested at the end of a trip");
+        const PjRec* recs           = reinterpret_cast<const PjRec*>(pkeys);
+        const unsigned long long pb = cA0 + (unsigned long long)w * (PP_R * GX_WAVE) + lane;
+#pragma unroll
+        for (int j = 0; j < PP_R; ++j) {  // one 12-byte load per row: a wave reads 768 contiguous bytes per instruction
+          const unsigned long long i  = pb + (unsigned long long)j * GX_WAVE;
+          const unsigned long long ic = i < cA1 ? i : cA0;
+          const pj_u32x3 r = __builtin_nontemporal_load(reinterpret_cast<const pj_u32x3*>(recs + ic));
+          kA[j] = ((uint64_t)r.y << 32) | r.x;
+          iA[j] = (int32_t)r.z;
+        }
+      } else if (!EARLY) {
         const unsigned long long pb = cA0 + (unsigned long long)w * (PP_R * GX_WAVE) + lane;
 #pragma unroll
         for (int j = 0; j < PP_R; ++j) {
@@ -3333,6 +3620,10 @@ static inline void jprof_mark(int i, hipStream_t s)
 static thread_local int g_pj_probe = 0; // probe kernel: 0 = default (software-pipelined tag probe), 1 = round-1 tag probe (A/B knob)
 static thread_local int g_pj_build = 0; // partitioned build: 0 = window build, table composed in LDS and written once (round 4b, default), 2 = sub-table build with
                                         // the tags in LDS (round 4a), 1 = round-2 kernel (global CAS + k_tags) (A/B knob)
+// round 6 (gx_join_set_experiment; default 5): bit 0 = the partition pass writes 12-byte {key, row} records (k_pj2_scatter_rec) and the probe
+// reads them (8-byte keys); bit 1 = with bit 0, 24576-row scatter tiles; bit 2 = pipelined service wave of k_pj2_probe_pipe on fixed
+// pieces per region; bit 3 = without bit 0, the windowed scatter writing key / row arrays (A/B); bits 4-6 = ablations (wrong results)
+static thread_local int g_pj_xp = 5;
 static thread_local int g_pj_tile = 0;  // scatter tile rows: 0 = default, else 4096 / 8192 / 16384 (A/B knob)
 static thread_local int g_pj_probe_early = 0;  // round-3 probe: 1 = rows of a piece requested at the top of the trip, 0 = at its end (default: with the
                                   // deferral queue the early form no longer fits 128 VGPRs) (A/B knob)
@@ -3474,15 +3765,19 @@ int probe_partitioned_impl2(const K* keys, int64_t n, const Slot<K>* slots, uint
                             int32_t* out_build, int64_t capacity, int64_t* cursor, void* tmp, size_t* tmp_bytes, hipStream_t s, int32_t row0,
                             const int32_t* payload)
 {
-  constexpr int TILE   = 16384;
+  // round 6 (gx_join_set_experiment bit 0; 8-byte keys): 12-byte record runs (k_pj2_scatter_rec) + the probe's record loads; bit 1: 24576-row tiles
+  const bool rec       = (g_pj_xp & 1) != 0 && sizeof(K) == 8 && !g_pj_defer && !g_pj_probe_early && g_pj_probe == 0;
+  const bool rec24     = rec && (g_pj_xp & 2) != 0;
+  const bool win_soa   = !rec && (g_pj_xp & 8) != 0 && sizeof(K) == 8;  // bit 3: the windowed scatter writing key and row ARRAYS (any probe kernel)
+  const int TILE       = rec24 ? 24576 : 16384;
   const uint32_t cap   = pj2_cap(n, pbits);
   const size_t nslots  = ((size_t)PJ_NR << pbits) * cap;
   const size_t nbuf    = nslots > (size_t)n ? nslots : (size_t)n;
   Carver c(tmp);
   Pj2Plan* plan2 = c.take<Pj2Plan>(1);
   PjPlan* plan   = c.take<PjPlan>(1);
-  K* pkeys       = c.take<K>(nbuf);
-  int32_t* pidx  = c.take<int32_t>(nbuf);
+  K* pkeys       = c.take<K>(nbuf);          // (record form: the 12-byte records occupy pkeys and pidx, which are carved back to back
+  int32_t* pidx  = c.take<int32_t>(nbuf);    //  -- 256-byte carving leaves pidx at or behind pkeys + 8 nbuf, so 12 nbuf bytes fit)
   if (!tmp) {
     *tmp_bytes = c.total();
     return 0;
@@ -3494,14 +3789,39 @@ int probe_partitioned_impl2(const K* keys, int64_t n, const Slot<K>* slots, uint
   auto kexact = k_pj2_scatter<K, 16, 1024, true, F>;
   auto kprobe = g_pj_defer ? (g_pj_probe_early ? k_pj2_probe_pipe<K, true, true> : k_pj2_probe_pipe<K, false, true>)
                            : (g_pj_probe_early ? k_pj2_probe_pipe<K, true, false> : k_pj2_probe_pipe<K, false, false>);
+  if constexpr (sizeof(K) == 8) {
+    if (rec) {
+      const int abl = (g_pj_xp >> 4) & 7;  // measurement only: the ablated kernels give WRONG results
+      kprobe        = abl == 1 ? k_pj2_probe_pipe<K, false, false, true, 1> : abl == 2 ? k_pj2_probe_pipe<K, false, false, true, 2>
+                      : abl == 3 ? k_pj2_probe_pipe<K, false, false, true, 3> : k_pj2_probe_pipe<K, false, false, true>;
+    }
+  }
   constexpr size_t lds_p = ((size_t)1 << (PJ_SUB_LOG2 - 1)) + PP_TAGPAD + (size_t)6 * PP_ROWS * sizeof(int32_t);
-  const size_t lds_s     = (size_t)TILE * sizeof(K) + ((size_t)8 << pbits);
+  const size_t lds_s     = (rec || win_soa) ? (size_t)8192 * 12 + ((size_t)8 << pbits) : (size_t)16384 * sizeof(K) + ((size_t)8 << pbits);
   static std::atomic<bool> attr_set{false};  // per instantiation
   static int num_cus     = 0;
   if (!attr_set) {
     const int lds_max = 160 * 1024 - 256;
     GX_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(kspec), hipFuncAttributeMaxDynamicSharedMemorySize, lds_max));
     GX_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(kexact), hipFuncAttributeMaxDynamicSharedMemorySize, lds_max));
+    if constexpr (sizeof(K) == 8) {
+      GX_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(k_pj2_scatter_rec<16, false, false, true, F>), hipFuncAttributeMaxDynamicSharedMemorySize, lds_max));
+      GX_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(k_pj2_scatter_rec<16, false, true, true, F>), hipFuncAttributeMaxDynamicSharedMemorySize, lds_max));
+      GX_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(k_pj2_scatter_rec<16, true, false, true, F>), hipFuncAttributeMaxDynamicSharedMemorySize, lds_max));
+      GX_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(k_pj2_scatter_rec<16, true, true, true, F>), hipFuncAttributeMaxDynamicSharedMemorySize, lds_max));
+      GX_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(k_pj2_scatter_rec<16, false, false, false, F>), hipFuncAttributeMaxDynamicSharedMemorySize, lds_max));
+      GX_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(k_pj2_scatter_rec<16, false, true, false, F>), hipFuncAttributeMaxDynamicSharedMemorySize, lds_max));
+      GX_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(k_pj2_scatter_rec<16, true, false, false, F>), hipFuncAttributeMaxDynamicSharedMemorySize, lds_max));
+      GX_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(k_pj2_scatter_rec<16, true, true, false, F>), hipFuncAttributeMaxDynamicSharedMemorySize, lds_max));
+      GX_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(k_pj2_scatter_rec<24, false, false, true, F>), hipFuncAttributeMaxDynamicSharedMemorySize, lds_max));
+      GX_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(k_pj2_scatter_rec<24, false, true, true, F>), hipFuncAttributeMaxDynamicSharedMemorySize, lds_max));
+      GX_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(k_pj2_scatter_rec<24, true, false, true, F>), hipFuncAttributeMaxDynamicSharedMemorySize, lds_max));
+      GX_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(k_pj2_scatter_rec<24, true, true, true, F>), hipFuncAttributeMaxDynamicSharedMemorySize, lds_max));
+      GX_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(k_pj2_probe_pipe<K, false, false, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_p));
+      GX_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(k_pj2_probe_pipe<K, false, false, true, 1>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_p));
+      GX_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(k_pj2_probe_pipe<K, false, false, true, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_p));
+      GX_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(k_pj2_probe_pipe<K, false, false, true, 3>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_p));
+    }
     GX_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(k_pj2_probe_pipe<K, true, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_p));
     GX_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(k_pj2_probe_pipe<K, false, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_p));
     GX_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(k_pj2_probe_pipe<K, true, false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_p));
@@ -3523,7 +3843,33 @@ int probe_partitioned_impl2(const K* keys, int64_t n, const Slot<K>* slots, uint
   GX_HIP_TRY(hipMemsetAsync(plan, 0, sizeof(PjPlan), s));
   jprof_mark(1, s);
   // ---- speculative pass
-  hipLaunchKernelGGL(kspec, dim3((unsigned)grid), dim3(1024), lds_s, s, keys, n, plan2, plan, pbits, rrows, cap, ntiles, pkeys, pidx, part_of, row0, payload);
+  // (record form: full tiles, then the ragged tail as one more workgroup)
+  const int64_t nfull = n / TILE;
+  auto launch_rec = [&](bool exact) {
+    if constexpr (sizeof(K) == 8) {
+      const uint64_t* k64 = reinterpret_cast<const uint64_t*>(keys);
+      PjRec* precs        = reinterpret_cast<PjRec*>(pkeys);
+      const unsigned gf   = (unsigned)(grid < nfull ? grid : nfull);
+      const int64_t tail0 = nfull * TILE;
+#define GX_PJ_REC(RPT_, EX_, AOS_)                                                                                                        \
+  do {                                                                                                                                    \
+    if (gf) hipLaunchKernelGGL((k_pj2_scatter_rec<RPT_, EX_, false, AOS_, F>), dim3(gf), dim3(1024), lds_s, s, k64, n, plan2, plan, pbits, \
+                               rrows, cap, nfull, (int64_t)0, precs, part_of, row0, payload, pidx);                                       \
+    if (tail0 < n) hipLaunchKernelGGL((k_pj2_scatter_rec<RPT_, EX_, true, AOS_, F>), dim3(1), dim3(1024), lds_s, s, k64, n, plan2, plan,   \
+                                      pbits, rrows, cap, (int64_t)1, tail0, precs, part_of, row0, payload, pidx);                         \
+  } while (0)
+      if (rec24) {
+        if (exact) GX_PJ_REC(24, true, true); else GX_PJ_REC(24, false, true);
+      } else if (rec) {
+        if (exact) GX_PJ_REC(16, true, true); else GX_PJ_REC(16, false, true);
+      } else {
+        if (exact) GX_PJ_REC(16, true, false); else GX_PJ_REC(16, false, false);
+      }
+#undef GX_PJ_REC
+    }
+  };
+  if (rec || win_soa) launch_rec(false);
+  else hipLaunchKernelGGL(kspec, dim3((unsigned)grid), dim3(1024), lds_s, s, keys, n, plan2, plan, pbits, rrows, cap, ntiles, pkeys, pidx, part_of, row0, payload);
   jprof_mark(2, s);
   // (6 / 7: the same kernel with the tag windows read from the L2 -- the partition pass then cuts 2^20-slot sub-tables, see pj_bits)
   // the probe kernel: 0 the pipelined LDS-tag gang probe; 2 / 3 the L2-resident direct probe with 4 / 2 rows per thread (round 5,
@@ -3555,7 +3901,11 @@ int probe_partitioned_impl2(const K* keys, int64_t n, const Slot<K>* slots, uint
     }
   };
   hipLaunchKernelGGL(k_pj2_offsets, dim3(1), dim3(1024), 0, s, plan2, pbits, cap, piece_rows);
-  PieceTable pt{plan2->chunk0, plan2->list_chunk0, plan2->ticket, nullptr, plan2->fill, cap, PJ_NR};
+  PieceTable pt{plan2->chunk0, plan2->list_chunk0, plan2->ticket, nullptr, plan2->fill, cap, PJ_NR, 0u, nullptr};
+  if ((g_pj_xp & 4) != 0 && !alt) {  // round 6: pipelined service wave on fixed pieces per region
+    pt.fixedk = (cap + piece_rows - 1) / piece_rows;
+    pt.gate   = &plan2->fallback;
+  }
   launch_probe(pt);
   // ---- exact sequence: every kernel returns at once unless plan2->fallback is set
   int64_t hb = div_up(n, 256 * 8 * 4 * PJ_NR);
@@ -3563,8 +3913,9 @@ int probe_partitioned_impl2(const K* keys, int64_t n, const Slot<K>* slots, uint
   if (hb < 1) hb = 1;
   hipLaunchKernelGGL((k_pj_hist<K, F>), dim3((unsigned)(hb * PJ_NR)), dim3(256), 0, s, keys, n, plan, pbits, rrows, part_of, &plan2->fallback);
   hipLaunchKernelGGL(k_pj_offsets, dim3(1), dim3(1024), 0, s, plan, pbits, piece_rows, &plan2->fallback);
-  hipLaunchKernelGGL(kexact, dim3((unsigned)grid), dim3(1024), lds_s, s, keys, n, plan2, plan, pbits, rrows, cap, ntiles, pkeys, pidx, part_of, row0, payload);
-  PieceTable pe{plan->chunk0, plan->list_chunk0, plan2->ticket_exact, plan->offset, nullptr, 0u, 1};
+  if (rec || win_soa) launch_rec(true);
+  else hipLaunchKernelGGL(kexact, dim3((unsigned)grid), dim3(1024), lds_s, s, keys, n, plan2, plan, pbits, rrows, cap, ntiles, pkeys, pidx, part_of, row0, payload);
+  PieceTable pe{plan->chunk0, plan->list_chunk0, plan2->ticket_exact, plan->offset, nullptr, 0u, 1, 0u, nullptr};
   launch_probe(pe);
   jprof_mark(3, s);
   g_jprof.marked = g_jprof.enabled;
@@ -4005,6 +4356,7 @@ void gx_join_set_partition_mode(int speculative, int early_loads)
 }
 
 void gx_join_set_build_kernel(int which) { gx::join::g_pj_build = (which == 1 || which == 2) ? which : 0; }
+void gx_join_set_experiment(int bits) { gx::join::g_pj_xp = bits; }
 void gx_join_set_scatter_tile(int rows)
 {
   gx::join::g_pj_tile = (rows == 4096 || rows == 8192 || rows == 16384) ? rows : 0;

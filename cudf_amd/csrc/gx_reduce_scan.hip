@@ -193,6 +193,36 @@ int reduce_typed(const void* in, const uint32_t* valid, int64_t n, AccT identity
   return 0;
 }
 
+// number of valid elements that are not zero (a NaN is not zero): what cudf::reduce ANY / ALL need -- the reference reduces
+// static_cast<bool>(x) with max / min (src/reductions/any.cu:79-95, all.cu) -- as ONE streaming pass whatever the input type
+template <typename InT>
+struct NonZeroLoader {
+  const InT* in;
+  const uint32_t* valid;
+  __device__ __forceinline__ uint64_t operator()(int64_t i) const
+  {
+    if (valid && !bit_is_set(valid, i)) return 0;
+    return in[i] != InT(0) ? 1ull : 0ull;
+  }
+};
+template <typename InT>
+int reduce_nonzero(const void* in, const uint32_t* valid, int64_t n, int out_dtype, void* out, void* tmp, size_t* tmp_bytes, hipStream_t s)
+{
+  Carver c(tmp);
+  uint64_t* partials = c.take<uint64_t>(scan::partials_count(n));
+  if (!tmp) {
+    *tmp_bytes = c.total();
+    return 0;
+  }
+  if (*tmp_bytes < c.total()) return GX_ETMP;
+  NonZeroLoader<InT> ld{static_cast<const InT*>(in), valid};
+  int rc = scan::device_reduce<uint64_t>(ld, n, uint64_t(0), SumOp(), partials, s);
+  if (rc) return rc;
+  hipLaunchKernelGGL((k_store_result<uint64_t>), dim3(1), dim3(1), 0, s, partials + scan::reduce_blocks(n), out_dtype, out);
+  GX_LAUNCH_CHECK();
+  return 0;
+}
+
 template <typename InT>
 int reduce_dd(const void* in, const uint32_t* valid, int64_t n, int out_dtype, void* out, void* tmp,
               size_t* tmp_bytes, hipStream_t s)
@@ -223,6 +253,7 @@ int reduce_int(const void* in, const uint32_t* valid, int64_t n, int op, int out
     case GX_OP_PRODUCT: return reduce_typed<InT, uint64_t>(in, valid, n, uint64_t(1), ProdOp(), out_dtype, out, tmp, tmp_bytes, s);
     case GX_OP_MIN: return reduce_typed<InT, W>(in, valid, n, Limits<W>::highest(), MinOp(), out_dtype, out, tmp, tmp_bytes, s);
     case GX_OP_MAX: return reduce_typed<InT, W>(in, valid, n, Limits<W>::lowest(), MaxOp(), out_dtype, out, tmp, tmp_bytes, s);
+    case GX_OP_COUNT_NONZERO: return reduce_nonzero<InT>(in, valid, n, out_dtype, out, tmp, tmp_bytes, s);
     default: return GX_EINVAL;
   }
 }
@@ -235,6 +266,7 @@ int reduce_float(const void* in, const uint32_t* valid, int64_t n, int op, int o
     case GX_OP_PRODUCT: return reduce_typed<InT, double>(in, valid, n, 1.0, ProdOp(), out_dtype, out, tmp, tmp_bytes, s);
     case GX_OP_MIN: return reduce_typed<InT, double>(in, valid, n, Limits<double>::highest(), MinOp(), out_dtype, out, tmp, tmp_bytes, s);
     case GX_OP_MAX: return reduce_typed<InT, double>(in, valid, n, Limits<double>::lowest(), MaxOp(), out_dtype, out, tmp, tmp_bytes, s);
+    case GX_OP_COUNT_NONZERO: return reduce_nonzero<InT>(in, valid, n, out_dtype, out, tmp, tmp_bytes, s);
     default: return GX_EINVAL;
   }
 }

@@ -743,6 +743,7 @@ constexpr int PASS_TPB = 8;  // tickets per workgroup of the MULTI form of k_rad
 constexpr uint32_t SPIN_CHECK        = 1u << 12;
 constexpr unsigned long long SPIN_SECONDS = 30;
 constexpr int32_t SPIN_FAULT = 5;  // SortPlan::status
+constexpr unsigned long long SPIN_SOFT_BIT = 1ull << 63;  // in the spin_ticks argument: abandon + report instead of trapping
 __device__ __forceinline__ bool spin_guard(uint32_t& spins, unsigned long long& t0, SortPlan* plan, unsigned long long limit_ticks)
 {
   if ((++spins & (SPIN_CHECK - 1)) != 0) return false;
@@ -752,8 +753,13 @@ __device__ __forceinline__ bool spin_guard(uint32_t& spins, unsigned long long& 
     t0 = now;
     return false;
   }
-  if (now - t0 <= (limit_ticks ? limit_ticks : SPIN_SECONDS * 100000000ull)) return false;
+  const unsigned long long limit = limit_ticks & ~SPIN_SOFT_BIT;
+  if (now - t0 <= (limit ? limit : SPIN_SECONDS * 100000000ull)) return false;
   __hip_atomic_store(&plan->status, SPIN_FAULT, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  // Round 6: the recoverable form is OPT-IN per call (gx_sort_set_fault_mode(1): the caller promises to read the
+  // status word -- cudf::sort / sorted_order and ops.py do).  Every other caller of the sorts -- hash partitioning, rank, the sharded
+  // operators -- never looks at the word, and a wrong order returned as success is worse than a dead process: they keep the trap.
+  if (!(limit_ticks & SPIN_SOFT_BIT)) __builtin_trap();
   return true;
 }
 
@@ -3676,6 +3682,7 @@ struct FastCfg {
   int stride;        // sample: every stride-th 64-key chunk
   size_t slot_rows;  // keys the padded level-0 output holds
 };
+static thread_local int g_soft_fault      = 0;     // 1: an abandoned look-back wait is REPORTED through the status word (the caller reads it); 0: it traps
 static thread_local int g_spin_ms         = 0;     // look-back wait limit in ms (0: SPIN_SECONDS); tests shorten it
 static thread_local long long g_inject_tile = -1;  // TEST HOOK: the tile of every look-back pass that never publishes (-1: none)
 static thread_local int g_cursor          = 1;     // 0 disables the cursor path (A/B knob)
@@ -3997,7 +4004,7 @@ int sort_impl(const void* keys_in, void* keys_out, const int32_t* vals_in, int32
                                                                                   // write-back; bit 5 (knob): k_local_sort's sub-bucket path for every cell
       m.cellcount = hist2;
       m.cellcap   = 1u << hc.cl2;
-      m.spin_ticks  = (unsigned long long)g_spin_ms * 100000ull;
+      m.spin_ticks  = (unsigned long long)g_spin_ms * 100000ull | (g_soft_fault ? SPIN_SOFT_BIT : 0ull);
       m.inject_tile = g_inject_tile;
       if (!cursor_marked) prof_mark_h(0, stream);
       hipLaunchKernelGGL(kmsd0, dim3((unsigned)(msd_ntiles + NRANGE)), dim3(BT), lds_msd(hyb_kpt, BINS), stream, m);
@@ -4053,7 +4060,7 @@ int sort_impl(const void* keys_in, void* keys_out, const int32_t* vals_in, int32
   a.ntiles    = ntiles;
   a.desc_mask = (uint64_t)desc_mask;
   a.order_mode = g_order_mode;
-  a.spin_ticks  = (unsigned long long)g_spin_ms * 100000ull;
+  a.spin_ticks  = (unsigned long long)g_spin_ms * 100000ull | (g_soft_fault ? SPIN_SOFT_BIT : 0ull);
   a.inject_tile = g_inject_tile;
 
   constexpr size_t lds = pass_lds_bytes<KeyT, HAS_VAL, KPT>();
@@ -4723,6 +4730,7 @@ void gx_sort_set_counting(int enable) { gx::sort::g_counting = enable ? 1 : 0; }
 void gx_sort_set_splitters(int enable) { gx::sort::g_split = enable ? 1 : 0; }
 void gx_sort_set_float_cursor(int enable) { gx::sort::g_float_cursor = enable ? 1 : 0; }
 void gx_sort_set_spin_limit_ms(int ms) { gx::sort::g_spin_ms = ms > 0 ? ms : 0; }
+void gx_sort_set_fault_mode(int soft) { gx::sort::g_soft_fault = soft ? 1 : 0; }
 void gx_sort_inject_lost_tile(long long tile) { gx::sort::g_inject_tile = tile >= 0 ? tile : -1; }
 int gx_sort_split_info(const void* tmp, int32_t* info4_host, gx_stream_t stream)
 {

@@ -38,11 +38,22 @@ def _run(fn, *args):
 
 
 def _check_sort_status(tmp: torch.Tensor):
-    """Fail loudly if the device-side look-back protocol reported a timeout (never expected)."""
+    """Fail loudly if the device-side look-back protocol reported a timeout (never expected).  Only status 5 is a fault -- 3 means a
+    bookkeeping mismatch of the hybrid path after which the LSD passes produced a correct output (include/cudf_amd/gx.h; the C++
+    face draws the same line, cudf_amd/cpp/src/device_faults.cpp)."""
     st = ctypes.c_int(0)
     L.check(_lib.gx_sort_status(ptr(tmp), ctypes.byref(st), stream_ptr()), "gx_sort_status")
-    if st.value != 0:
+    if st.value == 5:
         raise L.GxError(f"radix sort look-back timed out (status {st.value})")
+
+
+def _run_sort(fn, *args):
+    """a sort whose status word this caller reads: opt into the recoverable fault form for this call (default: the kernel traps)"""
+    _lib.gx_sort_set_fault_mode(1)
+    try:
+        return _run(fn, *args)
+    finally:
+        _lib.gx_sort_set_fault_mode(0)
 
 
 def _dev_i64(value: int = 0) -> torch.Tensor:
@@ -60,7 +71,7 @@ def sort(col: Column, ascending: bool = True, null_before: bool = True) -> Colum
         order = sorted_order(col, ascending, null_before)
         return gather(col, order)
     out = Column.empty(col.dtype, col.size)
-    tmp = _run(_lib.gx_sort_keys, col.gx, col.data_ptr, out.data_ptr, col.size, int(not ascending))
+    tmp = _run_sort(_lib.gx_sort_keys, col.gx, col.data_ptr, out.data_ptr, col.size, int(not ascending))
     _check_sort_status(tmp)
     return out
 
@@ -69,8 +80,8 @@ def sorted_order(col: Column, ascending: bool = True, null_before: bool = True) 
     """cudf::sorted_order == stable_sorted_order for one column (always stable here)."""
     out = Column.empty(np.int32, col.size)
     valid = col.mask_ptr if col.has_nulls() else None
-    tmp = _run(_lib.gx_sorted_order, col.gx, col.data_ptr, valid, col.size, col.null_count if valid else 0,
-               int(not ascending), int(null_before), out.data_ptr)
+    tmp = (_run if valid else _run_sort)(_lib.gx_sorted_order, col.gx, col.data_ptr, valid, col.size, col.null_count if valid else 0,
+                                         int(not ascending), int(null_before), out.data_ptr)
     if not valid:
         _check_sort_status(tmp)  # plan header sits at the start of the scratch on the radix path
     return out
@@ -309,17 +320,18 @@ class HashJoin:
         out = Column.empty(np.int32, left.size)
         if left.size == 0:
             return out
-        if self.build.size == 0:
-            out.data[: left.size * 4].view(torch.int32).fill_(-(2 ** 31))
-            return out
+        if self.build.size == 0:   # nothing to look up: JoinNoMatch everywhere (a host-built column: no kernel of ours or of torch's)
+            return Column.from_numpy(np.full(left.size, -(2 ** 31), np.int32))
         valid = left.mask_ptr if left.has_nulls() else None
         L.check(_lib.gx_join_lookup(self.key_size, left.data_ptr, valid, left.size, ptr(self.table), self.table_bytes,
                                     out.data_ptr, stream_ptr()), "gx_join_lookup")
         if self.nulls_equal and left.has_nulls() and self.build.has_nulls():
-            # null == null: every null left row matches the (single, keys are distinct) null build row
+            # null == null: every null left row matches the (single, keys are distinct) null build row.  A rare path, patched on the
+            # host like the C++ face does (cpp/src/join.cpp: the null x null pairs are composed on the host and copied)
             rv = int(np.nonzero(~self.build.valid_numpy())[0][0])
-            lv = torch.from_numpy(~left.valid_numpy()).cuda()
-            out.data[: left.size * 4].view(torch.int32)[lv] = rv
+            o = out.to_numpy()
+            o[~left.valid_numpy()] = rv
+            out = Column.from_numpy(o)
         return out
 
     def _filter(self, left: Column, anti: bool) -> Column:
@@ -329,7 +341,7 @@ class HashJoin:
             return out
         if self.build.size == 0:  # nothing can match
             if anti:
-                out.data[: left.size * 4].view(torch.int32).copy_(torch.arange(left.size, dtype=torch.int32, device="cuda"))
+                L.check(_lib.gx_sequence_i32(out.data_ptr, left.size, 0, stream_ptr()), "gx_sequence_i32")
             else:
                 out.size = 0
             return out
@@ -352,16 +364,23 @@ class HashJoin:
 
 def _append_null_cross(lo: Column, ro: Column, left: Column, right: Column):
     """null_equality::EQUAL for a single nullable key: every null left row matches every null
-    right row.  Rare path, assembled with torch index ops on the device."""
-    lv = torch.from_numpy(~left.valid_numpy()).cuda().nonzero().flatten().to(torch.int32)
-    rv = torch.from_numpy(~right.valid_numpy()).cuda().nonzero().flatten().to(torch.int32)
-    # the null left rows were emitted by nobody (probe skips them): add the cross product
-    cl = lv.repeat_interleave(len(rv))
-    cr = rv.repeat(len(lv))
-    a = torch.cat([lo.data[: lo.size * 4].view(torch.int32), cl])
-    b = torch.cat([ro.data[: ro.size * 4].view(torch.int32), cr])
-    n = a.numel()
-    return (Column(a.view(torch.uint8), np.int32, n), Column(b.view(torch.uint8), np.int32, n))
+    right row.  Rare path: the cross product is composed on the HOST from the two validity masks and copied behind the probe's
+    pairs -- what the C++ face does (cudf_amd/cpp/src/join.cpp, `cross`); no torch kernel takes part."""
+    lv = np.nonzero(~left.valid_numpy())[0].astype(np.int32)
+    rv = np.nonzero(~right.valid_numpy())[0].astype(np.int32)
+    cross = len(lv) * len(rv)
+    n = lo.size + cross
+    outs = []
+    for src, add in ((lo, np.repeat(lv, len(rv))), (ro, np.tile(rv, len(lv)))):
+        out = Column.empty(np.int32, n)
+        if lo.size:
+            L.check(_lib.gx_copy_bytes(src.data_ptr, out.data_ptr, lo.size * 4, stream_ptr()), "gx_copy_bytes")
+        if cross:
+            tail = Column.from_numpy(np.ascontiguousarray(add))
+            L.check(_lib.gx_copy_bytes(tail.data_ptr, ctypes.c_void_p(out.data.data_ptr() + lo.size * 4), cross * 4, stream_ptr()), "gx_copy_bytes")
+            torch.cuda.current_stream().synchronize()   # `tail` may be recycled once the copy has run
+        outs.append(out)
+    return outs[0], outs[1]
 
 
 def inner_join(left: Column, right: Column, nulls_equal: bool = True) -> Tuple[Column, Column]:

@@ -1,7 +1,7 @@
 // cudf/aggregation.hpp -- aggregation descriptors and their factories
 // (reference: cpp/include/cudf/aggregation.hpp:73-330).  The Kind enumerators keep the reference's
 // order so integer values stay interchangeable; the hot path implements SUM, PRODUCT, MIN, MAX, COUNT_VALID,
-// COUNT_ALL, MEAN, SUM_OF_SQUARES, M2, VARIANCE, STD, ARGMIN, ARGMAX and (sort path) NTH_ELEMENT; others throw
+// COUNT_ALL, MEAN, ANY and ALL (cudf::reduce), SUM_OF_SQUARES, M2, VARIANCE, STD, ARGMIN, ARGMAX and (sort path) NTH_ELEMENT; others throw
 // cudf::logic_error where they are used.
 #pragma once
 #include <cudf/types.hpp>
@@ -129,6 +129,11 @@ std::unique_ptr<Base> make_count_aggregation(null_policy null_handling = null_po
 }
 template <typename Base = aggregation>
 std::unique_ptr<Base> make_mean_aggregation() { return detail::make_simple<Base>(aggregation::MEAN); }
+// ANY / ALL reductions (aggregation.hpp:318-326 of the reference): cudf::reduce only, BOOL8 output
+template <typename Base = aggregation>
+std::unique_ptr<Base> make_any_aggregation() { return detail::make_simple<Base>(aggregation::ANY); }
+template <typename Base = aggregation>
+std::unique_ptr<Base> make_all_aggregation() { return detail::make_simple<Base>(aggregation::ALL); }
 // include/cudf/aggregation.hpp:335-375 of the reference: SUM_OF_SQUARES, M2, VARIANCE(ddof = 1), STD(ddof = 1)
 template <typename Base = aggregation>
 std::unique_ptr<Base> make_sum_of_squares_aggregation() { return detail::make_simple<Base>(aggregation::SUM_OF_SQUARES); }

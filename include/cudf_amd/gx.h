@@ -65,6 +65,7 @@ enum gx_op {
   GX_OP_MAX         = 3,
   GX_OP_COUNT_VALID = 4,
   GX_OP_COUNT_ALL   = 5,
+  GX_OP_COUNT_NONZERO = 6, /* gx_reduce only: valid elements != 0 (NaN counts); cudf::reduce ANY / ALL (reductions/any.cu, all.cu) */
   GX_OP_MEAN        = 10
 };
 
@@ -111,6 +112,10 @@ int gx_sort_status(const void* tmp, int* status_host, gx_stream_t stream);
  * hipHostMalloc) holds the status once everything queued on `stream` so far has run.  The asynchronous form the
  * C++ surface uses so that cudf::sort returns without a host round trip (reference: sort.cu:52-89 is asynchronous). */
 int gx_sort_status_async(const void* tmp, int* status_host_pinned, gx_stream_t stream);
+/* What an abandoned look-back wait does, for the sorts the CALLING THREAD issues from now on: 0 (default) = __builtin_trap -- loud, fatal
+ * for the process' HIP context: right for a caller that never reads the status word; 1 = the recoverable form: status 5, every write
+ * inside the output, the caller MUST read the word (gx_sort_status / gx_sort_status_async) before it trusts the result. */
+void gx_sort_set_fault_mode(int recoverable);
 
 
 
@@ -502,7 +507,8 @@ int gx_segmented_scan(int key_dtype, const void* sorted_keys, int val_dtype, con
  * Column reduce / scan.
  * gx_reduce replaces cub::DeviceReduce::Reduce at include/cudf/reduction/detail/reduction.cuh:
  * 46-83 (cudf::reduce SUM/MIN/MAX/PRODUCT; nulls skipped).  Result written to *out_dev in
- * `out_dtype` (GX_INT64, GX_UINT64 or GX_FLOAT64 for SUM/PRODUCT; in_dtype for MIN/MAX);
+ * `out_dtype` (GX_INT64, GX_UINT64 or GX_FLOAT64 for SUM/PRODUCT; in_dtype for MIN/MAX; an integer type for
+ * GX_OP_COUNT_NONZERO, the number of valid elements != 0 -- ANY = count > 0, ALL = count == valid count);
  * *valid_count_dev (device int64, optional) = number of valid inputs.
  * gx_scan replaces thrust::inclusive_scan / exclusive_scan at
  * src/reductions/scan/scan_inclusive.cu:76-89 and scan_exclusive.cu; output dtype == input

@@ -128,6 +128,15 @@ void gx_join_set_build_kernel(int which);
  * the largest that fits the LDS next to the per-partition counters). */
 void gx_join_set_scatter_tile(int rows);
 
+/* A/B knob (per calling thread; round 6; default 5 = bits 0 and 2): bit 0 = the partition pass of the partitioned probe writes 12-byte
+ * {key, row} RECORDS (one 96-B run per tile and partition instead of a 64-B key run and a 32-B row run: k_pj2_scatter_rec) and the
+ * pipelined probe reads them (8-byte keys, default probe kernel only); bit 1 = with bit 0: 24576-row scatter tiles (12-row runs);
+ * bit 2 = the pipelined probe's service wave takes tickets that ARE (region, piece) -- every region is cut into the same number of
+ * pieces -- and issues the ticket atomic and the fill-counter read one trip ahead of their use (0: the round-3 chain of four
+ * dependent round trips per piece); bit 3 = without bit 0: the windowed scatter writing key / row arrays (measured slower);
+ * bits 4-6 = ablations of the probe for measurements (WRONG results: 1 no slot reads, 2 no staging, 3 no tag lookups). */
+void gx_join_set_experiment(int bits);
+
 /* A/B knob (per calling thread): 0 = software-pipelined tag probe on LDS-resident 4-bit tags (default), 1 = the round-1 tag probe,
  * 2 / 3 = the L2-resident DIRECT probe of round 5 (k_pj3_probe_direct, 4 / 2 rows per thread): no tags, no LDS tables -- the
  * workgroups of an XCD take the pieces of the XCD's partitions in order, so the 2-MiB sub-table they all probe sits in the

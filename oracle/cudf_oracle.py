@@ -906,6 +906,33 @@ def reduce(values: np.ndarray, op: str, valid=None, out_dtype=None, init=None, i
     folded in with the operator (simple.cuh:56-77); the result is valid iff the column has a valid row AND the initial
     value is valid (simple.cuh:80-83)."""
     v = np.asarray(values)
+    if op in ("count_valid", "count_all"):
+        # reductions/count.cpp:37-46: size - null_count (EXCLUDE) or size, cast to the output type; ALWAYS valid -- also for an
+        # empty or all-null column (reductions.cpp:252-275: reduce_no_data is reduce); no initial value (reductions.cpp:492-499)
+        if init is not None:
+            raise ValueError("Initial value is only supported for SUM, SUM_OVERFLOW, PRODUCT, MIN, MAX, ANY, ALL, and HOST_UDF aggregation types")
+        od = np.dtype(out_dtype or np.int32)
+        if od.kind not in "iuf":
+            raise ValueError("COUNT is not supported for boolean or non-numeric types")
+        m = np.ones(len(v), bool) if valid is None else np.asarray(valid, bool)
+        return od.type(len(v) if op == "count_all" else int(m.sum())), True
+    if op in ("any", "all"):
+        # reductions/any.cu:79-95, all.cu, simple.cuh:47-85,238-259: max / min over static_cast<bool>(x), nulls skipped, BOOL8 out;
+        # no valid row: any = false / all = true and VALID, whatever the initial value (reductions.cpp:163-186); otherwise the
+        # initial value is cast to bool and folded in, and an invalid one invalidates the result (simple.cuh:80-83)
+        if out_dtype is not None and np.dtype(out_dtype) != np.dtype(bool):
+            raise ValueError("any() / all() operation can be applied with output type `bool8` only")
+        m = np.ones(len(v), bool) if valid is None else np.asarray(valid, bool)
+        x = v[m]
+        if len(x) == 0:
+            return np.bool_(op == "all"), True
+        r = bool((x != 0).any()) if op == "any" else bool((x != 0).all())
+        if init is not None:
+            if not init_valid:
+                return np.bool_(r), False
+            iv = bool(np.asarray(init, v.dtype) != 0)
+            r = (r or iv) if op == "any" else (r and iv)
+        return np.bool_(r), True
     if init is not None:
         if op not in ("sum", "product", "min", "max"):
             raise ValueError("Initial value is only supported for SUM, SUM_OVERFLOW, PRODUCT, MIN, MAX, ANY, ALL, and HOST_UDF aggregation types")
@@ -923,7 +950,10 @@ def reduce(values: np.ndarray, op: str, valid=None, out_dtype=None, init=None, i
         return (pair[np.argmin(sortable_bits(pair))] if op == "min" else pair[np.argmax(sortable_bits(pair))]), True
     m = np.ones(len(v), bool) if valid is None else np.asarray(valid, bool)
     x = v[m]
+    explicit_out = out_dtype is not None
     out_dtype = np.dtype(out_dtype or v.dtype)
+    if op == "mean" and explicit_out and out_dtype.kind != "f":
+        raise ValueError("Unsupported output data type")
     if len(x) == 0:
         return out_dtype.type(0), False
     if op == "product":
@@ -938,7 +968,13 @@ def reduce(values: np.ndarray, op: str, valid=None, out_dtype=None, init=None, i
     if op == "max":
         return x[np.argmax(sortable_bits(x))].astype(out_dtype), True
     if op == "mean":
-        return np.float64(math.fsum(x.astype(np.float64)) / len(x)), True
+        # reductions/mean.cu, compound.cuh:41-84, reduction_operators.cuh:256-275: sum / valid count in the floating OUTPUT type
+        # ("Unsupported output data type" otherwise); here the correctly rounded quotient of the exact sum
+        if not explicit_out:
+            out_dtype = np.dtype(np.float64)
+        if out_dtype.kind != "f":
+            raise ValueError("Unsupported output data type")
+        return out_dtype.type(math.fsum(x.astype(np.float64)) / len(x)), True
     raise ValueError(op)
 
 

@@ -17,6 +17,9 @@
 #include <cudf/reduction.hpp>
 #include <cudf/sorting.hpp>
 #include <cudf_amd/gx.h>  // gx_sequence_i32: a device fill for the allocator test
+#include <chrono>
+#include <cudf_amd/device_faults.hpp>
+#include <cudf_amd/gx.h>
 #include <cudf_amd/gx_knobs.h>  // the look-back fault hooks of the last case
 
 #include <execinfo.h>
@@ -1523,10 +1526,12 @@ int main()
     }
   });
 
-  run("a lost look-back chain is an EXCEPTION, not a dead process (gx_sort.hip spin_guard; utilities/error.hpp:63-86 draws the line)", [] {
+  run("a lost look-back chain is an EXCEPTION, not a dead process -- and the sorts stay stream-ordered (gx_sort.hip spin_guard; utilities/error.hpp:63-86)", [] {
     // TEST HOOK: tile 3 of every look-back pass never publishes its granules; the wait limit is cut from 30 s to 150 ms.  The
-    // successors' waits are abandoned, the scratch's status word says so, cudf::sorted_order / cudf::sort throw cudf::logic_error --
-    // and the same calls succeed right after, in the same process, on the same HIP context.
+    // successors' waits are abandoned and the scratch's status word says so.  Round 6: cudf::sorted_order / cudf::sort RETURN (their
+    // work is queued, as the reference's is: sort.cu:52-89); the fault surfaces as cudf::cuda_error at cudf_amd::check_device_faults
+    // (which waits for the stream) or at the next sort call once the faulting sort has run -- and the same calls succeed right after,
+    // in the same process, on the same HIP context.
     constexpr std::size_t N = 3'000'000;
     std::vector<int64_t> k(N);
     uint64_t x = 88172645463325252ull;
@@ -1535,24 +1540,32 @@ int main()
     table_view t{{c->view()}};
     gx_sort_set_spin_limit_ms(150);
     gx_sort_inject_lost_tile(3);
-    bool threw_order = false, threw_sort = false;
+    bool threw_order = false, threw_sort = false, returned_order = false, returned_sort = false;
     try {
-      auto o = cudf::sorted_order(t);
-    } catch (cudf::logic_error const&) {
-      threw_order = true;
+      auto o         = cudf::sorted_order(t);
+      returned_order = true;  // no throw from the call that queued the faulting work
+      cudf_amd::check_device_faults(get_default_stream());
+    } catch (cudf::cuda_error const& e) {
+      threw_order = e.error_code() == GX_EINTERNAL;
     }
     try {
-      auto o = cudf::sort(t);
-    } catch (cudf::logic_error const&) {
-      threw_sort = true;
+      auto o        = cudf::sort(t);
+      returned_sort = true;
+      get_default_stream().synchronize();
+      auto o2 = cudf::sort(t);  // the NEXT sort call reports the completed one's fault
+    } catch (cudf::cuda_error const& e) {
+      threw_sort = e.error_code() == GX_EINTERNAL;
     }
     gx_sort_inject_lost_tile(-1);
     gx_sort_set_spin_limit_ms(0);
+    CHECK(returned_order);
+    CHECK(returned_sort);
     CHECK(threw_order);
     CHECK(threw_sort);
+    try { cudf_amd::check_device_faults(get_default_stream()); } catch (cudf::cuda_error const&) {}  // (the second faulting sort of the block above, if it ran)
     auto o  = cudf::sorted_order(t);
     auto so = cudf::sort(t);
-    get_default_stream().synchronize();
+    cudf_amd::check_device_faults(get_default_stream());  // waits; nothing to report
     auto ho = to_host<int32_t>(o->view());
     std::vector<int32_t> ref(N);
     std::iota(ref.begin(), ref.end(), 0);
@@ -1562,6 +1575,50 @@ int main()
     CHECK(hipMemcpy(hs.data(), so->view().column(0).head<int64_t>(), N * sizeof(int64_t), hipMemcpyDeviceToHost) == hipSuccess);
     std::sort(k.begin(), k.end());
     CHECK(hs == k);
+  });
+
+  run("two sorts on two streams are queued back to back: cudf::sort does not wait for the device (sort.cu:52-89)", [] {
+    // 2^26 random int64 keys per stream (cursor path).  Both calls are issued from one host thread without any synchronisation in
+    // between; the host time of the two calls must be a fraction of the device time of the two sorts (round 5 read a status word
+    // back inside every call: issue time == device time), and both results must be sorted permutations of their inputs.
+    constexpr std::size_t N = std::size_t{1} << 26;
+    hipStream_t s1, s2;
+    CHECK(hipStreamCreateWithFlags(&s1, hipStreamNonBlocking) == hipSuccess);
+    CHECK(hipStreamCreateWithFlags(&s2, hipStreamNonBlocking) == hipSuccess);
+    std::vector<int64_t> k(N);
+    uint64_t x = 0x9E3779B97F4A7C15ull;
+    for (auto& v : k) { x ^= x << 13; x ^= x >> 7; x ^= x << 17; v = static_cast<int64_t>(x); }
+    auto a = make_col<int64_t>(k);
+    for (auto& v : k) v = ~v;
+    auto b = make_col<int64_t>(k);
+    table_view ta{{a->view()}}, tb{{b->view()}};
+    { auto w1 = cudf::sort(ta, {}, {}, s1); auto w2 = cudf::sort(tb, {}, {}, s2); }  // warm-up: arena blocks of both streams, module load
+    CHECK(hipDeviceSynchronize() == hipSuccess);
+    auto const t0 = std::chrono::steady_clock::now();
+    auto ra = cudf::sort(ta, {}, {}, s1);
+    auto rb = cudf::sort(tb, {}, {}, s2);
+    auto const t1 = std::chrono::steady_clock::now();
+    CHECK(hipStreamSynchronize(s1) == hipSuccess);
+    CHECK(hipStreamSynchronize(s2) == hipSuccess);
+    auto const t2 = std::chrono::steady_clock::now();
+    cudf_amd::poll_device_faults();
+    double const issue_ms = std::chrono::duration<double, std::milli>(t1 - t0).count();
+    double const total_ms = std::chrono::duration<double, std::milli>(t2 - t0).count();
+    std::printf("    issue of both calls %.3f ms, until both streams drained %.3f ms\n", issue_ms, total_ms);
+    CHECK(issue_ms < 0.6 * total_ms);
+    std::vector<int64_t> ha(N), hb(N);
+    CHECK(hipMemcpy(ha.data(), ra->view().column(0).head<int64_t>(), N * 8, hipMemcpyDeviceToHost) == hipSuccess);
+    CHECK(hipMemcpy(hb.data(), rb->view().column(0).head<int64_t>(), N * 8, hipMemcpyDeviceToHost) == hipSuccess);
+    CHECK(std::is_sorted(ha.begin(), ha.end()));
+    CHECK(std::is_sorted(hb.begin(), hb.end()));
+    uint64_t sa = 0, sb = 0, sk = 0;
+    for (std::size_t i = 0; i < N; ++i) { sa += static_cast<uint64_t>(ha[i]); sb += static_cast<uint64_t>(hb[i]); sk += static_cast<uint64_t>(k[i]); }
+    CHECK(sb == sk);                          // b's keys are the ones left in k
+    CHECK(sa == static_cast<uint64_t>(0) - sk - N);  // a = ~b element-wise: sum(~v) = -sum(v) - N
+    ra.reset();
+    rb.reset();
+    CHECK(hipStreamDestroy(s1) == hipSuccess);
+    CHECK(hipStreamDestroy(s2) == hipSuccess);
   });
 
   std::printf("%d run, %d failed\n", g_run, g_failed);

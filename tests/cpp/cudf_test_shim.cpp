@@ -418,6 +418,10 @@ int shim_reduce_init(int dtype, const void* data, const uint32_t* valid, int nul
       case A::MIN: agg = cudf::make_min_aggregation<cudf::reduce_aggregation>(); break;
       case A::MAX: agg = cudf::make_max_aggregation<cudf::reduce_aggregation>(); break;
       case A::MEAN: agg = cudf::make_mean_aggregation<cudf::reduce_aggregation>(); break;
+      case A::COUNT_VALID: agg = cudf::make_count_aggregation<cudf::reduce_aggregation>(cudf::null_policy::EXCLUDE); break;
+      case A::COUNT_ALL: agg = cudf::make_count_aggregation<cudf::reduce_aggregation>(cudf::null_policy::INCLUDE); break;
+      case A::ANY: agg = cudf::make_any_aggregation<cudf::reduce_aggregation>(); break;
+      case A::ALL: agg = cudf::make_all_aggregation<cudf::reduce_aggregation>(); break;
       default: throw std::runtime_error("shim: reduce kind");
     }
     std::unique_ptr<cudf::scalar> init;
@@ -429,6 +433,8 @@ int shim_reduce_init(int dtype, const void* data, const uint32_t* valid, int nul
     };
     if (has_init) {
       switch (static_cast<cudf::type_id>(init_dtype)) {
+        case cudf::type_id::INT8: mk(int8_t{}); break;
+        case cudf::type_id::BOOL8: mk(bool{}); break;
         case cudf::type_id::INT16: mk(int16_t{}); break;
         case cudf::type_id::INT32: mk(int32_t{}); break;
         case cudf::type_id::INT64: mk(int64_t{}); break;

@@ -295,6 +295,48 @@ REDUCE = [
     dict(name="sum_all_null", op="sum", values=[1, 2, 3], valid=[0, 0, 0], expect=0, expect_valid=False),
 ]
 
+# cudf::reduce MEAN / COUNT / ANY / ALL (round 6): literals of reductions/reduction_tests.cpp.  "dtypes": the types the reference's
+# typed test runs over; "out": the output type it asks for; init = None: no initial value.
+_AA_MASK = [1, 1, 0, 1]
+_MEAN = [-3, 2, 1, 0, 5, -3, -2, 28]
+_MEAN_MASK = [1, 1, 0, 1, 1, 1, 0, 1]
+_CNT = [1, -3, 1, 2, 0, 2, -4, 45]
+REDUCE_MORE = [
+    # :668-728  ReductionAnyAllTest.AnyAllTrueTrue (int32, float, bool): {1,1,1,1}, init true; then nulls {1,1,0,1} and an INVALID init
+    dict(name="any_true", op="any", dtypes=["int32", "float32", "bool"], out="bool", values=[1, 1, 1, 1], valid=None, init=None, init_valid=True, expect=True, expect_valid=True),
+    dict(name="all_true", op="all", dtypes=["int32", "float32", "bool"], out="bool", values=[1, 1, 1, 1], valid=None, init=None, init_valid=True, expect=True, expect_valid=True),
+    dict(name="any_true_init", op="any", dtypes=["int32", "float32", "bool"], out="bool", values=[1, 1, 1, 1], valid=None, init=1, init_valid=True, expect=True, expect_valid=True),
+    dict(name="all_true_init", op="all", dtypes=["int32", "float32", "bool"], out="bool", values=[1, 1, 1, 1], valid=None, init=1, init_valid=True, expect=True, expect_valid=True),
+    dict(name="any_true_nulls", op="any", dtypes=["int32", "float32", "bool"], out="bool", values=[1, 1, 1, 1], valid=_AA_MASK, init=None, init_valid=True, expect=True, expect_valid=True),
+    dict(name="all_true_nulls", op="all", dtypes=["int32", "float32", "bool"], out="bool", values=[1, 1, 1, 1], valid=_AA_MASK, init=None, init_valid=True, expect=True, expect_valid=True),
+    dict(name="any_true_nulls_invalid_init", op="any", dtypes=["int32", "float32", "bool"], out="bool", values=[1, 1, 1, 1], valid=_AA_MASK, init=1, init_valid=False, expect=True, expect_valid=False),
+    dict(name="all_true_nulls_invalid_init", op="all", dtypes=["int32", "float32", "bool"], out="bool", values=[1, 1, 1, 1], valid=_AA_MASK, init=1, init_valid=False, expect=True, expect_valid=False),
+    # :731-791  AnyAllFalseFalse: {0,0,0,0}, init false
+    dict(name="any_false", op="any", dtypes=["int32", "float32", "bool"], out="bool", values=[0, 0, 0, 0], valid=None, init=None, init_valid=True, expect=False, expect_valid=True),
+    dict(name="all_false", op="all", dtypes=["int32", "float32", "bool"], out="bool", values=[0, 0, 0, 0], valid=None, init=None, init_valid=True, expect=False, expect_valid=True),
+    dict(name="any_false_init", op="any", dtypes=["int32", "float32", "bool"], out="bool", values=[0, 0, 0, 0], valid=None, init=0, init_valid=True, expect=False, expect_valid=True),
+    dict(name="all_false_init", op="all", dtypes=["int32", "float32", "bool"], out="bool", values=[0, 0, 0, 0], valid=None, init=0, init_valid=True, expect=False, expect_valid=True),
+    dict(name="any_false_nulls", op="any", dtypes=["int32", "float32", "bool"], out="bool", values=[0, 0, 0, 0], valid=_AA_MASK, init=None, init_valid=True, expect=False, expect_valid=True),
+    dict(name="all_false_nulls", op="all", dtypes=["int32", "float32", "bool"], out="bool", values=[0, 0, 0, 0], valid=_AA_MASK, init=None, init_valid=True, expect=False, expect_valid=True),
+    dict(name="any_false_nulls_invalid_init", op="any", dtypes=["int32", "float32", "bool"], out="bool", values=[0, 0, 0, 0], valid=_AA_MASK, init=0, init_valid=False, expect=False, expect_valid=False),
+    # :1145-1178  ReductionEmptyTest.empty_column: an empty column and five all-null rows -> any = false, all = true, both VALID
+    dict(name="any_empty", op="any", dtypes=["int32"], out="bool", values=[], valid=None, init=None, init_valid=True, expect=False, expect_valid=True),
+    dict(name="all_empty", op="all", dtypes=["int32"], out="bool", values=[], valid=None, init=None, init_valid=True, expect=True, expect_valid=True),
+    dict(name="any_all_null", op="any", dtypes=["int32"], out="bool", values=[0] * 5, valid=[0] * 5, init=None, init_valid=True, expect=False, expect_valid=True),
+    dict(name="all_all_null", op="all", dtypes=["int32"], out="bool", values=[0] * 5, valid=[0] * 5, init=None, init_valid=True, expect=True, expect_valid=True),
+    # :1201-1208  COUNT (null_policy::INCLUDE) of the empty column = 0, of the five all-null rows = 5, both valid
+    dict(name="count_all_empty", op="count_all", dtypes=["int32"], out="int32", values=[], valid=None, init=None, init_valid=True, expect=0, expect_valid=True),
+    dict(name="count_all_all_null", op="count_all", dtypes=["int32"], out="int32", values=[0] * 5, valid=[0] * 5, init=None, init_valid=True, expect=5, expect_valid=True),
+    # :806-840  MultiStepReductionTest.Mean (int16, int32, float, double), FLOAT64 out: 28 / 8; nulls {1, -2 masked}: 29 / 6
+    dict(name="mean", op="mean", dtypes=["int16", "int32", "float32", "float64"], out="float64", values=_MEAN, valid=None, init=None, init_valid=True, expect=3.5, expect_valid=True),
+    dict(name="mean_nulls", op="mean", dtypes=["int16", "int32", "float32", "float64"], out="float64", values=_MEAN, valid=_MEAN_MASK, init=None, init_valid=True, expect=29 / 6, expect_valid=True),
+    # :1759-1785  ReductionTest.Count (typed over the numeric types), size_type out: 8 / 8; null_at(3): 8 / 7
+    dict(name="count_all", op="count_all", dtypes=["int8", "int32", "int64", "float32", "float64"], out="int32", values=_CNT, valid=None, init=None, init_valid=True, expect=8, expect_valid=True),
+    dict(name="count_valid", op="count_valid", dtypes=["int8", "int32", "int64", "float32", "float64"], out="int32", values=_CNT, valid=None, init=None, init_valid=True, expect=8, expect_valid=True),
+    dict(name="count_all_nulls", op="count_all", dtypes=["int8", "int32", "int64", "float32", "float64"], out="int32", values=_CNT, valid=[1, 1, 1, 0, 1, 1, 1, 1], init=None, init_valid=True, expect=8, expect_valid=True),
+    dict(name="count_valid_nulls", op="count_valid", dtypes=["int8", "int32", "int64", "float32", "float64"], out="int32", values=_CNT, valid=[1, 1, 1, 0, 1, 1, 1, 1], init=None, init_valid=True, expect=7, expect_valid=True),
+]
+
 # Published MurmurHash3_x86_32 known-answer vectors (Appleby's SMHasher reference implementation;
 # the reference delegates the body to cuco::murmurhash3_32,
 # include/cudf/hashing/detail/murmurhash3_x86_32.cuh:16,45).  (bytes, seed, digest)

@@ -149,3 +149,15 @@ def test_scratch_queries_and_argument_checks_without_a_gpu():
     assert q("gx_dense_rank", L.INT64, None, None, 10, 11, None, None, None)[0] == -1   # null_count > n
     assert lib.gx_pack_keys(0, None, None, 0, None, None) == -1
     assert lib.gx_join_table_bytes(3, 1000, 0.5) == 0
+
+
+def test_import_cudf_is_the_alias_of_cudf_amd():
+    """north_star: "the cudf.DataFrame Python wrapper so it is a drop-in" -- `import cudf` resolves to the alias package at the repo
+    root and names the same class; what is out of scope raises instead of pretending (no GPU needed: nothing is launched)."""
+    import cudf
+    import cudf_amd
+    assert cudf.DataFrame is cudf_amd.DataFrame and callable(cudf.from_pandas)
+    assert sorted(cudf.__all__) == ["DataFrame", "__version__", "from_pandas"]
+    import pytest
+    with pytest.raises(AttributeError):
+        cudf.Series  # noqa: B018

@@ -23,7 +23,8 @@ from oracle import cudf_oracle as orc
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 KIND = dict(sum=0, product=2, min=3, max=4, count_valid=5, count_all=6, nth=19)  # cudf::aggregation::Kind
 TID = {np.dtype("int8"): 1, np.dtype("int16"): 2, np.dtype("int32"): 3, np.dtype("int64"): 4, np.dtype("uint8"): 5,
-       np.dtype("uint16"): 6, np.dtype("uint32"): 7, np.dtype("uint64"): 8, np.dtype("float32"): 9, np.dtype("float64"): 10}
+       np.dtype("uint16"): 6, np.dtype("uint32"): 7, np.dtype("uint64"): 8, np.dtype("float32"): 9, np.dtype("float64"): 10,
+       np.dtype("bool"): 11}
 NPT = {v: k for k, v in TID.items()}
 
 

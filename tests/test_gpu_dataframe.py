@@ -9,8 +9,10 @@ pytestmark = pytest.mark.gpu
 
 @pytest.fixture(scope="module")
 def DF():
+    import cudf          # the name a user of the reference types: an alias package over cudf_amd (cudf/__init__.py)
     import cudf_amd
-    return cudf_amd.DataFrame
+    assert cudf.DataFrame is cudf_amd.DataFrame
+    return cudf.DataFrame
 
 
 def test_sort_values_single_and_multi_key(DF):
@@ -104,3 +106,14 @@ def test_groupby_on_two_keys_and_float_key_matches_pandas(DF):
         np.testing.assert_array_equal(got["v_max"], exp["v_max"])
         np.testing.assert_array_equal(got["w_sum"], exp["w_sum"])
         np.testing.assert_array_equal(got["w_count"], exp["w_count"])
+
+
+def test_import_cudf_from_pandas(DF):
+    """`import cudf; cudf.from_pandas(pdf).sort_values(...)` -- the reference's module-level entry point on this path."""
+    import cudf
+    import pandas as pd
+    pdf = pd.DataFrame({"k": np.array([3, 1, 2, 1], np.int64), "v": np.array([0.5, 1.5, 2.5, 3.5])})
+    got = cudf.from_pandas(pdf).sort_values("k").to_pandas()
+    pd.testing.assert_frame_equal(got, pdf.sort_values("k", kind="stable").reset_index(drop=True), check_dtype=False)
+    with pytest.raises(AttributeError):
+        cudf.read_parquet  # noqa: B018 -- out of scope: the alias does not pretend

