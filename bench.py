@@ -61,6 +61,7 @@ def parse():
                                                               "dense ids (round 4); 8 / 9 = fixed")
     ap.add_argument("--gb-spec", type=int, default=1, help="groupby knob: 1 hist-free speculative partition pass (default), 0 exact histogram pass")
     ap.add_argument("--no-partitioned-join", action="store_true", help="join: probe the table directly")
+    ap.add_argument("--sort-order-map", type=int, default=1, help="sorted_order knob (round 6): 1 keys-only sort of (rank, row) words for 64-bit columns (default), 0 the round-3 pairs path")
     ap.add_argument("--sort-splitters", type=int, default=1, help="sort knob: 0 no splitter mode (uneven columns go to the LSD passes), 1 default")
     ap.add_argument("--join-probe-kernel", type=int, default=0, help="join knob: 0 pipelined tag probe on LDS-resident tags (default), 1 round-1 tag probe, 2 / 3 L2-resident direct probe (4 / 2 rows per thread)")
     ap.add_argument("--join-scatter-tile", type=int, default=0, help="join knob: rows per scatter tile (0 = default)")
@@ -599,7 +600,7 @@ def bench_sort(c, pairs=False, cpu_leg=True):
         keys = ops.random_column(np.int64, n, seed=42 + c.rank, lo=a.key_range[0], hi=a.key_range[1])
     else:
         keys = ops.random_column(np.int64, n, seed=42 + c.rank)
-    is_f64 = getattr(a, "key_type", "int64") == "float64" and not pairs
+    is_f64 = getattr(a, "key_type", "int64") == "float64"
     if is_f64:
         # a FLOAT64 column of ordinary data: N(0, 1) (default) or U[0, 1) doubles -- no NaN, no -0.0
         torch = c.torch
@@ -654,9 +655,14 @@ def bench_sort(c, pairs=False, cpu_leg=True):
     L.check(fn(None, ctypes.byref(nb)), "size query")
     tmp = c.device_bytes(nb.value)
     single_step = lambda: L.check(fn(c.ptr(tmp), ctypes.byref(nb)), "sort")
-    bytes_per_row_pass = 24 if pairs else 16   # read key(+idx) + write key(+idx)
+    # round 6: sorted_order of a 64-bit column from 2^25 rows = a keys-only sort of (monotone rank << row bits | row) words + a pass
+    # that puts runs of equal ranks right (cudf_amd/csrc/gx_order.hip): its partition / cell kernels move keys-only 16 B/row
+    lib.gx_sort_set_order_map(getattr(a, "sort_order_map", 1))
+    order_map = bool(pairs and lib.gx_order_map_applies(keys.gx, n))
+    bytes_per_row_pass = 24 if (pairs and not order_map) else 16   # read key(+idx) + write key(+idx)
     model_bytes_row = 200 if pairs else 136    # 8-pass LSD model
-    workload = f"{n:.0e}-row " + ("float64 " if is_f64 else "int64 ") + ("sorted_order (radix sort pairs, int32 payload)" if pairs else "radix sort (cudf::sort, keys only)")
+    workload = f"{n:.0e}-row " + ("float64 " if is_f64 else "int64 ") + (("sorted_order (keys-only sort of (rank, row) words + run fix-up, int32 order out)" if order_map else
+                                                                          "sorted_order (radix sort pairs, int32 payload)") if pairs else "radix sort (cudf::sort, keys only)")
     if is_f64:
         workload += ", keys " + ("U[0, 1)" if a.key_dist == "uniform" else "N(0, 1)")
     if a.key_range:
@@ -742,7 +748,7 @@ def bench_sort(c, pairs=False, cpu_leg=True):
             gathered = ops.gather(keys, out)
             cg = ops.checksum(gathered)
             assert cg[2] == 0 and cin[:2] == cg[:2], "sorted_order: keys gathered through the order are not the sorted input"
-            gt = c.as_tensor(gathered, torch.int64)
+            gt = c.as_tensor(gathered, torch.int64)   # (float64 keys of the bench hold no NaN and no zero: equal bits == equal values)
             for i in range(0, n - 1, CH):
                 m = min(CH, n - 1 - i)
                 eq = gt[i + 1:i + 1 + m] == gt[i:i + m]
@@ -791,7 +797,9 @@ def bench_sort(c, pairs=False, cpu_leg=True):
             names[1] = f"k_hf_scatter level 1 ({sort_info['bits2']}-bit partition of the regions into padded cell slots, cursor atomics)"
             tkeys[0], tkeys[1] = "k_hf_scatter level 0", "k_hf_scatter level 1"
         up_front = 0 if cursor else 8  # B/row of the up-front pass: the cursor path reads a 1/32 sample instead of the column
-        bpr = [20, 24, 0, 24] if pairs else [16, 16, 0, 16]  # pairs carry a 4-B index
+        bpr = [20, 24, 0, 24] if (pairs and not order_map) else [16, 16, 0, 16]  # pairs carry a 4-B index (the word sort of round 6 moves 8-byte words)
+        if order_map:
+            up_front = 16 + 12  # the map pass (8 B key in, 8 B word out) and the finish pass (8 B word in, 4 B row out) around the word sort
         dom = max(range(4), key=lambda i: ms[i])
         achieved = bpr[dom] * n / (ms[dom] * 1e-3) / 1e9
         roofline = {"bound": "hbm", "kernel": names[dom], "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
@@ -804,6 +812,11 @@ def bench_sort(c, pairs=False, cpu_leg=True):
                     "whole_sort_model_GBps": model_bytes_row * n / (local_sort_ms * 1e-3) / 1e9,
                     "whole_sort_model_frac": model_bytes_row * n / (local_sort_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
                     "sort_info": sort_info}
+        if order_map:
+            omi = (ctypes.c_int32 * 5)()
+            lib.gx_sort_order_map_info(c.ptr(tmp), n, omi, c.stream)
+            roofline["order_map"] = {"long_runs": int(omi[0]), "row_bits": int(omi[2]), "rank_bits_in_bucket": int(omi[3]), "inexact_buckets": int(omi[4]),
+                                     "note": "the kernels above are those of the WORD sort (gx_sort_keys on uint64 words); map + finish = total - their sum"}
     elif prof["launches"]:
         avg_ms = prof["pass_ms"] / prof["launches"]
         achieved = bytes_per_row_pass * n / (avg_ms * 1e-3) / 1e9
@@ -1385,6 +1398,43 @@ def sort_robustness(c, uniform_ms):
                             "5 = counting sort of a narrow range, 4 / 2 = declined to the LSD passes / look-back path"}
 
 
+def sorted_order_robustness(c, uniform_ms):
+    """The same for cudf::sorted_order -- what sort_by_key, the sort-path groupby, multi-column sorts and DataFrame.sort_values sit on
+    (cub's SortPairs behind cpp/src/sort/sorted_order_radix.cu:56-179 costs the same on any distribution).  Every
+    output verified like the headline sorted_order run: a permutation, keys gathered through it sorted + multiset, ties in row order."""
+    import copy
+    a0 = c.args
+    cases = [("normal N(0, 2^40)", {"key_dist": "normal"}), ("lognormal exp(N(25, 3))", {"key_dist": "lognormal"}),
+             ("zipf-like floor(u^-5)", {"key_dist": "zipf"}), ("two clusters", {"key_dist": "clusters"}),
+             ("uniform in [-1e12, 1e12)", {"key_range": [-10**12, 10**12]}), ("uniform in [100, 10001)", {"key_range": [100, 10001]}),
+             ("1e8 copies of one value", {"hot_copies": 1e8}), ("already sorted", {"key_dist": "sorted"}),
+             ("float64 N(0, 1)", {"key_type": "float64", "key_dist": "normal"}), ("float64 U[0, 1)", {"key_type": "float64", "key_dist": "uniform"})]
+    out, worst = {}, None
+    for name, kw in cases:
+        a = copy.copy(a0)
+        a.steps, a.warmup, a.key_dist, a.key_range, a.hot_copies, a.key_type = 3, 1, "uniform", None, 0, "int64"
+        for k, v in kw.items():
+            setattr(a, k, v)
+        c.args = a
+        try:
+            c.torch.cuda.empty_cache()
+            b = bench_sort(c, pairs=True, cpu_leg=False)
+            r = b.get("roofline") or {}
+            si = r.get("sort_info") or {}
+            out[name] = {"ms_per_step": b["ms_per_step"], "ratio_to_uniform": b["ms_per_step"] / uniform_ms,
+                         "path": {"word_sort_cursor_path_state": si.get("cursor_path_state"), "splitters": (si.get("splitters") or {}).get("on"),
+                                  "lsd_passes": si.get("lsd_passes"), "order_map": r.get("order_map")}}
+            if worst is None or out[name]["ratio_to_uniform"] > worst[1]:
+                worst = (name, out[name]["ratio_to_uniform"])
+        except Exception as e:  # noqa: BLE001 -- a robustness line must not take the headline down; it says what happened
+            out[name] = {"error": repr(e)}
+        finally:
+            c.args = a0
+    return {"rows": c.n, "steps": 3, "warmup": 1, "uniform_ms": uniform_ms, "cases": out,
+            "worst": {"case": worst[0], "ratio_to_uniform": worst[1]} if worst else None,
+            "checked": "every case: the timed int32 order is a permutation of [0, n); keys gathered through it: order + multiset checksum; equal keys in row order"}
+
+
 def main():
     args = parse()
     if args.gpus > 1 and "RANK" not in os.environ:
@@ -1454,6 +1504,10 @@ def main():
         want_rb = args.robustness if args.robustness is not None else (wl == "all" and c.n >= 100_000_000)
         if want_rb and not c.sharded and wl in ("all", "sort"):
             line["sort_robustness"] = sort_robustness(c, head["ms_per_step"])
+            if "sorted_order" in line:
+                line["sorted_order_robustness"] = sorted_order_robustness(c, line["sorted_order"]["ms_per_step"])
+        if args.robustness and not c.sharded and wl == "sorted_order":
+            line["sorted_order_robustness"] = sorted_order_robustness(c, head["ms_per_step"])
         want_cpp = args.through_cpp if args.through_cpp is not None else (wl == "all" and c.n >= 100_000_000)
         if want_cpp and not c.sharded:
             blk = lambda name: (blocks.get(name) or (head if wl == name else {})).get("ms_per_step")

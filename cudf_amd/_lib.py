@@ -41,6 +41,9 @@ _PROTOS = {
     "gx_sort_status": (_i, [_p, ctypes.POINTER(_i), _p]),
     "gx_sort_status_async": (_i, [_p, _p, _p]),
     "gx_sort_set_fault_mode": (None, [_i]),
+    "gx_sort_set_order_map": (None, [_i]),
+    "gx_order_map_applies": (_i, [_i, _i64]),
+    "gx_sort_order_map_info": (_i, [_p, _i64, ctypes.POINTER(ctypes.c_int32), _p]),
     "gx_sort_set_algorithm": (None, [_i]),
     "gx_sort_profile": (_i, [_i]),
     "gx_sort_profile_read": (_i, [ctypes.POINTER(ctypes.c_float), ctypes.POINTER(ctypes.c_float), ctypes.POINTER(_i)]),

@@ -164,18 +164,22 @@ struct RcclTransport final : Transport {
     GXD_NCCL(ncclGroupStart());
     return 0;
   }
+  // (every entry checks the abort flag: a call racing gxd_comm_abort must not touch the aborted ncclComm -- ADVICE r5)
   int send(const void* p, size_t bytes, int peer, hipStream_t s) override
   {
+    GXD_GX(dead());
     GXD_NCCL(ncclSend(p, bytes, ncclInt8, peer, comm, s));
     return 0;
   }
   int recv(void* p, size_t bytes, int peer, hipStream_t s) override
   {
+    GXD_GX(dead());
     GXD_NCCL(ncclRecv(p, bytes, ncclInt8, peer, comm, s));
     return 0;
   }
   int group_end(hipStream_t) override
   {
+    GXD_GX(dead());
     GXD_NCCL(ncclGroupEnd());
     return 0;
   }
@@ -884,9 +888,12 @@ int sort_fused(gxd_comm* c, int dtype, const void* keys, int64_t n, gxd_alloc_fn
   {
     long long mine = err ? -(long long)(err > 0 ? err : -err) - 1 : ok;
     if (hipStreamSynchronize(stream) != hipSuccess && !err) mine = -(long long)GX_EINTERNAL - 1;
-    GXD_HIP(hipMemcpyAsync(d_mine, &mine, sizeof(mine), hipMemcpyHostToDevice, c->xs));
-    GXD_HIP(hipStreamSynchronize(c->xs));
+    // (these two HIP calls must not return early on this rank alone -- the peers would sit in the all-gather below: a failure here
+    //  is reported after the collective has been entered, with whatever `mine` made it to the device -- ADVICE r5)
+    const hipError_t e1 = hipMemcpyAsync(d_mine, &mine, sizeof(mine), hipMemcpyHostToDevice, c->xs);
+    const hipError_t e2 = hipStreamSynchronize(c->xs);
     GXD_GX(allgather_i64_host(c, static_cast<long long*>(d_mine), static_cast<long long*>(d_all), 1, c->pinned));
+    if (e1 != hipSuccess || e2 != hipSuccess) return fail(GX_EINTERNAL, "gxd_sort: publishing this rank's status failed (HIP error)");
     for (int r = 0; r < W; ++r)
       if (c->pinned[r] < 0)
         return fail(err ? err : GX_EINTERNAL, err ? err_what : "gxd_sort: the fused path failed on rank " + std::to_string(r));

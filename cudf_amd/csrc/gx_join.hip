@@ -3884,7 +3884,7 @@ int probe_partitioned_impl2(const K* keys, int64_t n, const Slot<K>* slots, uint
   const unsigned alt_rpt    = (pk == 2 || pk == 5 || pk == 7) ? 4u : 2u;
   const size_t alt_lds      = (pk == 4 || pk == 5) ? ((size_t)1 << (PJ_SUB_LOG2 - 1)) + PP_TAGPAD : 0;  // (6 / 7: no LDS tags)
   const unsigned piece_rows = !alt ? (unsigned)PP_ROWS : (pk >= 4 ? (unsigned)(PT_PW * GX_WAVE) * alt_rpt : alt_bt * alt_rpt);
-  static int alt_wgs[6] = {0, 0, 0, 0, 0, 0};  // resident workgroups per CU of the alternative kernels (occupancy query, once each)
+  static std::atomic<int> alt_wgs[6];  // resident workgroups per CU of the alternative kernels (occupancy query, once each; zero-initialised)
   if (alt && alt_wgs[pk - 2] == 0) {
     if (alt_lds) GX_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(kalt), hipFuncAttributeMaxDynamicSharedMemorySize, (int)alt_lds));
     int nb = 0;

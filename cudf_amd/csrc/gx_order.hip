@@ -1,0 +1,675 @@
+// gx_order.hip -- cudf::sorted_order of ONE 64-bit column as a KEYS-ONLY sort of 64-bit words (round 6).
+//
+// Replaces cub::DeviceRadixSort::SortPairs over (key copy, iota) at cpp/src/sort/sorted_order_radix.cu:56-179 (stable: :81), whose cost
+// does not depend on the value distribution.  Round 3-5's pairs path (gx_sort.hip: look-back levels on key BITS into fixed 8192 / 16384
+// key cells) sorts uniform keys in 21 ms per 1e9 rows and DECLINES every uneven column -- bell-shaped, lognormal, Zipf-like integers,
+// any real-valued float64 -- to 4-8 LSD pair passes: 65-93 ms.  The keys-only sort got its distribution insensitivity in round 5
+// (sample-chosen splitters, warped cells, big-cell rescue: 11-15 ms on anything); this file puts the argsort ON it:
+//
+//   word(i) = rank34(key_i) << ib | i          ib = bits(n - 1),  rank34 = a MONOTONE 64 - ib bit image of the key
+//
+// sorted ascending as plain uint64 keys.  Rows come out ordered by rank, ties of the rank by row -- which IS the stable order wherever
+// the rank separates distinct keys, and wherever it does not (two different keys, one rank) the rows sit in ONE run of equal ranks and a
+// last pass puts that run right by (key, row).
+//
+// The rank has to do two things at once: keep DISTINCT keys apart (else runs grow), and leave the words EVENLY dense at every scale the
+// word sort cuts on -- its cells are sized for 93 % full at 1e9 rows, and a first version that gave each of 4096 sample-quantile buckets
+// the same share of the rank space (Gamma(4) noise: +-50 % in true mass) overflowed its cells and fell to eight LSD passes: 94.8 ms
+// (profiles/r6_run8_*).  So:
+//   * 4096 buckets cut at every 4th of 16384 sorted sample keys (k_om_plan: one workgroup, bitonic sort in LDS);
+//   * their MASS is measured, not assumed: k_om_count looks every 32nd 64-key chunk up (3 % of the column, 0.25 B/row) and a bucket's
+//     share of the rank space is its share of that count (+-1 %) -- k_om_plan2: base_b, alloc_b;
+//   * inside a bucket of width W_b: alloc_b >= W_b ("lossless"): every key value owns F_b = alloc_b / W_b consecutive ranks and its rows
+//     are spread over them BY ROW NUMBER, rank = base_b + (key - lo_b) F_b + (row F_b >> ib) -- monotone in (key, row), distinct keys in
+//     disjoint intervals, and a value of 10^5 copies is 10^5 evenly spread words instead of one cell of the word sort (the reference
+//     benchmark's own keys in [100, 10001): cpp/benchmarks/sort/sort.cpp:24-26); alloc_b < W_b ("lossy"): rank = base_b + (key - lo_b) >> sh_b,
+//     distinct keys may share a rank -> the fix-up.  A value that fills several quantiles (consecutive equal splitters) gets a bucket of
+//     its own (the empty one in front of its successor's) with W = 1.
+// Uniform random 64-bit keys at 1e9 rows: every bucket is 2^52 wide against 2^22 ranks: lossy by 30 bits, 5.8 % of the rows share a rank
+// with a neighbour and have their keys fetched again (a 2- or 3-row insertion sort per run).  Runs beyond 16 rows go to a list and are
+// sorted per workgroup (LDS up to 4096 rows, a network in global scratch beyond: a density spike the samples cannot see -- slow, correct).
+//
+// Cost per 1e9 rows: plan 0.3 + map 16 B/row + word sort 48 B/row (11-15 ms) + finish 12 B/row + the runs' gathers; descending order and
+// float64 (NaN last and equal to each other, -0.0 == 0.0: to_sortable<K_FLOAT>) go through the same sortable form, ties by row in both
+// directions (sorted_order_radix.cu:81; sort_column_impl.cuh:35-57 for the NaN / zero rule).
+#include "gx_common.hpp"
+
+extern "C" size_t gx_sort_plan_bytes(void);  // gx_sort.hip: sizeof(SortPlan) -- the header at the start of a sort's scratch (status word inside)
+
+namespace gx {
+namespace order {
+
+constexpr int OM_S     = 16384;  // sample keys
+constexpr int OM_B     = 4096;   // buckets (one per 4 samples)
+constexpr int OM_LUT  = 16384;  // cells of the bucket look-up table over the splitters' range: the binary search starts inside one cell
+constexpr int OM_CSTRIDE = 32;  // k_om_count looks at every 32nd 64-key chunk
+constexpr int OM_SMALL = 16;     // runs of equal ranks up to this length are put right by the thread that finds them
+constexpr int OM_LDSRUN = 4096;  // ... up to this one by a workgroup in LDS
+constexpr int OM_FIN_WGS = 8192; // workgroups of the finish passes (each owns a contiguous range of the sorted words and a segment of the run list)
+
+struct alignas(256) OmPlan {
+  uint64_t lo[OM_B];      // first sortable key of bucket b (lo[0] = 0; buckets 0 and OM_B - 1 are catch-alls beyond the sample's reach)
+  uint64_t base[OM_B];    // first rank of bucket b
+  uint64_t mul[OM_B];     // M_b = alloc_b 2^64 / (W_b << lz_b): umulhi(d << lz_b, M_b) = floor(d alloc_b / W_b), d = key - lo_b
+  uint32_t meta[OM_B];    // lz_b (bits 0-5) | lossy (bit 8) | eq (bit 9: lo[b] is a repeated splitter -- rows with key == lo[b] belong to
+                          // bucket b - 1, which is empty otherwise and holds that one VALUE)
+  uint32_t cnt[OM_B];     // sampled rows per bucket (k_om_count)
+  uint16_t lut[OM_LUT + 8];  // lut[c] = bucket of the first key of cell c of [lo[1], lo[OM_B - 1]] (cells of 2^gsh keys); lut[OM_LUT] = OM_B - 1
+  int gsh;
+  uint64_t invn;          // floor((2^64 - 1) / n): row * invn = the row's position in [0, 1) as a 64-bit fraction
+  unsigned int nlong;     // entries of the long-run list
+  unsigned long long nan_count;  // float64 keys: NaN rows (k_om_map) -- a descending order has them first, in REVERSE row order
+  unsigned int long_overflow;
+  int ib, rb;
+  int nlossy;
+};
+struct LongRun {
+  unsigned int start, len;
+};
+
+__device__ __forceinline__ int bitlen64(uint64_t x) { return x ? 64 - __builtin_clzll(x) : 0; }
+
+// ---- 1. sample: OM_S keys at even strides, in sortable form
+template <int KIND>
+__global__ void __launch_bounds__(256) k_om_sample(const uint64_t* __restrict__ keys, int64_t n, uint64_t desc_mask, uint64_t* __restrict__ samp)
+{
+  const int j = blockIdx.x * 256 + threadIdx.x;
+  if (j >= OM_S) return;
+  const int64_t i = (int64_t)(((__int128)j * n) / OM_S);
+  samp[j]         = to_sortable<uint64_t, KIND>(keys[i < n ? i : n - 1], desc_mask);
+}
+
+// ---- 2. plan: sort the sample (bitonic, 128 KiB of LDS), cut 4096 buckets, size their shifts
+__global__ void __launch_bounds__(1024) k_om_plan(const uint64_t* __restrict__ samp, OmPlan* plan, int ib, int64_t n)
+{
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  uint64_t* s = reinterpret_cast<uint64_t*>(smem);
+  const int t = threadIdx.x;
+  for (int i = t; i < OM_S; i += 1024) s[i] = samp[i];
+  __syncthreads();
+  for (int k = 2; k <= OM_S; k <<= 1) {
+    for (int j = k >> 1; j > 0; j >>= 1) {
+      for (int i = t; i < OM_S; i += 1024) {
+        const int p = i ^ j;
+        if (p > i) {
+          const uint64_t a = s[i], b = s[p];
+          const bool up    = (i & k) == 0;
+          if ((a > b) == up) {
+            s[i] = b;
+            s[p] = a;
+          }
+        }
+      }
+      __syncthreads();
+    }
+  }
+  constexpr int SPB = OM_S / OM_B;  // samples per bucket
+  // bucket 0 = [0, ext_min) and bucket OM_B - 1 = (ext_max, 2^64) are CATCH-ALLS for keys beyond the sample's reach (the sample minimum /
+  // maximum pushed out by 16 times the extent of the end bucket): rare rows, one or two ranks, put right by the run pass.  Without them
+  // the end buckets ran to the ends of the key SPACE and a smooth tail's quarter million rows shared a handful of ranks.
+  auto lo_of = [&](int b) -> uint64_t {
+    if (b == 0) return 0ull;
+    if (b == 1) {
+      const uint64_t w = s[2 * SPB] - s[0];
+      const uint64_t e = w > (~0ull >> 4) ? ~0ull : w * 16;
+      return s[0] > e ? s[0] - e : 0ull;
+    }
+    if (b == OM_B - 1) {
+      const uint64_t top = s[OM_S - 1], w = top - s[(OM_B - 2) * SPB];
+      const uint64_t e   = w > (~0ull >> 4) ? ~0ull : w * 16 + 1;
+      return top >= ~0ull - e ? ~0ull : top + e + 1;
+    }
+    // a GAP bucket -- 64 times wider than its neighbours together: two clusters with nothing in between -- holds its rows at its two
+    // ends; mapped linearly, each end was one rank: two runs of 10^5 distinct keys for the long-run pass (55 ms for the two-cluster
+    // column of the robustness block).  Its boundaries move INWARD by 16 neighbour widths, so the neighbours take its rows and the
+    // gap itself becomes a (nearly) empty bucket.  Boundary b moves up when bucket b is a gap, down when bucket b - 1 is.
+    const uint64_t c0 = s[b * SPB];
+    auto raw = [&](int q) -> uint64_t { return s[q * SPB]; };
+    auto is_gap = [&](int q) -> bool {  // bucket q = [raw(q), raw(q + 1)), 2 <= q <= OM_B - 3
+      if (q < 2 || q > OM_B - 3) return false;
+      const uint64_t w = raw(q + 1) - raw(q), wl = raw(q) - raw(q - 1), wr = raw(q + 2) - raw(q + 1);
+      return (w >> 6) > wl && (w >> 6) > wr && (w >> 6) > wl + wr;
+    };
+    const bool gap_here = is_gap(b), gap_before = is_gap(b - 1);
+    if (gap_here && !gap_before) return c0 + 16 * (c0 - raw(b - 1)) + 1;      // (16 wl < w / 4: stays inside the bucket)
+    if (gap_before && !gap_here) return c0 - 16 * (raw(b + 1) - c0);          // (16 wr < w / 4)
+    return c0;
+  };
+  for (int b = t; b < OM_B; b += 1024) {
+    const uint64_t lo = lo_of(b);
+    plan->lo[b]   = lo;
+    plan->cnt[b]  = 0;
+    // a repeated splitter: the previous bucket [lo, lo) is empty -- it becomes the bucket of the VALUE lo (never a catch-all or its neighbour)
+    plan->meta[b] = (b >= 3 && b <= OM_B - 2 && lo_of(b - 1) == lo) ? 512u : 0u;
+  }
+  // look-up table: the bucket of the first key of each of 16384 equal cells of [lo[1], lo[OM_B - 1]]
+  {
+    const uint64_t l1 = lo_of(1), span = lo_of(OM_B - 1) - l1;
+    int gsh = bitlen64(span) - 14;
+    if (gsh < 0) gsh = 0;
+    for (int c = t; c <= OM_LUT; c += 1024) {
+      int b = OM_B - 1;
+      if (c < OM_LUT) {
+        const uint64_t off = (uint64_t)c << gsh;
+        if (off <= span) {
+          const uint64_t key = l1 + off;
+          b = 1;  // (key >= lo[1])
+          for (int step = OM_B / 2; step > 0; step >>= 1) {
+            const int q = b + step;
+            if (q < OM_B && lo_of(q) <= key) b = q;
+          }
+        }
+      }
+      plan->lut[c] = (uint16_t)b;
+    }
+    if (t == 0) plan->gsh = gsh;
+  }
+  if (t == 0) {
+    plan->invn          = ~0ull / (uint64_t)(n > 0 ? n : 1);
+    plan->nlong         = 0;
+    plan->nan_count     = 0;
+    plan->long_overflow = 0;
+    plan->ib            = ib;
+    plan->rb            = 64 - ib;
+    plan->nlossy        = 0;
+  }
+}
+
+// bucket of sortable key s: upper bound over lo[] -- the look-up table narrows it to the buckets that start inside the key's cell (one
+// or two for evenly spread keys: 12 dependent LDS reads per key were 8.2 of the first version's 39 ms), a binary search finishes; a key
+// that IS a repeated splitter goes to the (otherwise empty) bucket in front
+__device__ __forceinline__ int om_bucket(const uint64_t* __restrict__ lo, const uint16_t* __restrict__ lut, const uint32_t* __restrict__ meta, int gsh, uint64_t s)
+{
+  const uint64_t l1 = lo[1];
+  if (s < l1) return 0;
+  uint64_t c = (s - l1) >> gsh;
+  if (c > (uint64_t)(OM_LUT - 1)) c = OM_LUT - 1;
+  int bl = lut[c], bh = lut[c + 1];  // lo[bl] <= first key of the cell <= s; every bucket beyond bh starts behind the cell
+  if (c == (uint64_t)(OM_LUT - 1)) bh = OM_B - 1;
+  while (bl < bh) {
+    const int mid = (bl + bh + 1) >> 1;
+    if (lo[mid] <= s) bl = mid; else bh = mid - 1;
+  }
+  if ((meta[bl] & 512u) && s == lo[bl]) --bl;
+  return bl;
+}
+
+// ---- 2b. count: every 32nd 64-key chunk looked up -> sampled mass per bucket
+template <int KIND>
+__global__ void __launch_bounds__(256) k_om_count(const uint64_t* __restrict__ keys, int64_t n, uint64_t desc_mask, OmPlan* plan)
+{
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  uint64_t* s_lo  = reinterpret_cast<uint64_t*>(smem);
+  uint32_t* s_eq  = reinterpret_cast<uint32_t*>(smem + OM_B * 8);
+  uint32_t* s_cnt = s_eq + OM_B;
+  uint16_t* s_lut = reinterpret_cast<uint16_t*>(s_cnt + OM_B);
+  for (int i = threadIdx.x; i < OM_B; i += 256) {
+    s_lo[i]  = plan->lo[i];
+    s_eq[i]  = plan->meta[i];
+    s_cnt[i] = 0;
+  }
+  for (int i = threadIdx.x; i <= OM_LUT; i += 256) s_lut[i] = plan->lut[i];
+  __syncthreads();
+  const int gsh = plan->gsh;
+  const int64_t nchunks = (n + 63) / 64;
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  for (int64_t c = ((int64_t)blockIdx.x * 4 + w) * OM_CSTRIDE; c < nchunks; c += (int64_t)gridDim.x * 4 * OM_CSTRIDE) {
+    const int64_t i = c * 64 + lane;
+    if (i < n) atomicAdd(&s_cnt[om_bucket(s_lo, s_lut, s_eq, gsh, to_sortable<uint64_t, KIND>(keys[i], desc_mask))], 1u);
+  }
+  __syncthreads();
+  for (int i = threadIdx.x; i < OM_B; i += 256)
+    if (s_cnt[i]) atomicAdd(&plan->cnt[i], s_cnt[i]);
+}
+
+// ---- 2c. plan2: rank space per bucket in proportion to its sampled mass; per-bucket map
+__global__ void __launch_bounds__(1024) k_om_plan2(OmPlan* plan)
+{
+  __shared__ unsigned long long s_part[1024];
+  __shared__ unsigned int s_lossy;
+  const int t  = threadIdx.x;
+  const int rb = plan->rb;
+  if (t == 0) s_lossy = 0;
+  // total sampled mass
+  unsigned long long loc = 0;
+  for (int b = t * 4; b < t * 4 + 4; ++b) loc += plan->cnt[b];
+  s_part[t] = loc;
+  __syncthreads();
+  for (int o = 512; o > 0; o >>= 1) {
+    if (t < o) s_part[t] += s_part[t + o];
+    __syncthreads();
+  }
+  const unsigned long long total = s_part[0] ? s_part[0] : 1ull;
+  __syncthreads();
+  // every bucket: a floor of R / 2^20 ranks (a bucket the sample never hit may still hold rows), the rest in proportion
+  const unsigned long long R    = rb >= 64 ? ~0ull : (1ull << rb);
+  const unsigned long long rmin = R >> 20 ? R >> 20 : 1ull;
+  const unsigned long long rest = R - rmin * OM_B - OM_B;  // (- OM_B: the divisions below round down, the shares never add up to more)
+  unsigned long long al[4];
+  loc = 0;
+  for (int k = 0; k < 4; ++k) {
+    const unsigned long long c = plan->cnt[t * 4 + k];
+    al[k] = rmin + (unsigned long long)(((__uint128_t)c * rest) / total);
+    loc += al[k];
+  }
+  s_part[t] = loc;
+  __syncthreads();
+  // exclusive scan over the 1024 thread sums (one wave of work: 4096 buckets once per sort)
+  if (t == 0) {
+    unsigned long long run = 0;
+    for (int i = 0; i < 1024; ++i) {
+      const unsigned long long v = s_part[i];
+      s_part[i]                  = run;
+      run += v;
+    }
+  }
+  __syncthreads();
+  unsigned long long base = s_part[t];
+  for (int k = 0; k < 4; ++k) {
+    const int b = t * 4 + k;
+    const uint64_t lo = plan->lo[b];
+    // width of the bucket's key range: [lo, next lo); the bucket of a repeated splitter's VALUE (eq of b + 1) holds one value
+    uint64_t wm1;
+    if (b + 1 < OM_B) {
+      const uint64_t nx = plan->lo[b + 1];
+      wm1               = ((plan->meta[b + 1] & 512u) || nx <= lo) ? 0ull : nx - lo - 1;
+    } else {
+      wm1 = ~0ull - lo;
+    }
+    // M = alloc 2^64 / (W << lz) with W << lz in [2^63, 2^64]: umulhi(d << lz, M) = floor(d alloc / W) (to within the floor of M)
+    const int lz          = wm1 ? __builtin_clzll(wm1) : 63;
+    const __uint128_t wal = ((__uint128_t)wm1 + 1) << lz;
+    const uint64_t M      = (uint64_t)((((__uint128_t)al[k]) << 64) / wal);
+    // lossless: every key value owns >= 1 rank (alloc >= 2 W keeps the floors apart); lossy: distinct keys may share a rank
+    const bool lossy = al[k] < 2 * ((unsigned long long)wm1 + 1) || wm1 >= (1ull << 62) || b == 0 || b == OM_B - 1;  // (the end buckets clamp)
+    if (lossy) atomicAdd(&s_lossy, 1u);
+    plan->base[b] = base;
+    plan->mul[b]  = M;
+    plan->meta[b] = (plan->meta[b] & 512u) | (unsigned)lz | (lossy ? 256u : 0u);
+    base += al[k];
+  }
+  __syncthreads();
+  if (t == 0) plan->nlossy = (int)s_lossy;
+}
+
+// the rank of sortable key s in row `row`
+__device__ __forceinline__ uint64_t om_rank(const uint64_t* __restrict__ lo, const uint16_t* __restrict__ lut, const uint32_t* __restrict__ meta,
+                                            const uint64_t* __restrict__ base, const uint64_t* __restrict__ mul, int gsh, uint64_t s, uint64_t row, uint64_t invn)
+{
+  const int b       = om_bucket(lo, lut, meta, gsh, s);
+  const uint32_t mt = meta[b];
+  const int lz      = (int)(mt & 63u);
+  const uint64_t d  = s - lo[b];
+  const uint64_t M  = mul[b];
+  const uint64_t A  = __umul64hi(d << lz, M);
+  if (mt & 256u) return base[b] + A;                  // lossy: floor(d alloc / W)
+  // lossless: the value d owns [A, B); its rows are spread over them by row / n -- NOT row >> ib: 1e9 rows fill 93 % of 2^30, the rows
+  // of every value would crowd into the first 93 % of its ranks and the word sort's cells, sized for 93 % full, would overflow by the
+  // thousand (measured: keys in [100, 10001), 476 M of 1e9 rows through the big-cell rescue, 78.6 ms)
+  const uint64_t d1 = (d + 1) << lz;                  // ((W << lz) = 2^64 wraps to 0)
+  const uint64_t B  = d1 ? __umul64hi(d1, M) : M;     // (d + 1 = W and W << lz = 2^64: floor(W alloc / W) = alloc = M)
+  return base[b] + A + __umul64hi(row * invn, B - A);
+}
+
+// ---- 3. map: word(i) = rank << ib | i
+template <int KIND>
+__global__ void __launch_bounds__(1024) k_om_map(const uint64_t* __restrict__ keys, int64_t n, uint64_t desc_mask, OmPlan* __restrict__ plan,
+                                                 uint64_t* __restrict__ words)
+{
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  uint64_t* s_lo   = reinterpret_cast<uint64_t*>(smem);
+  uint64_t* s_base = s_lo + OM_B;
+  uint64_t* s_mul  = s_base + OM_B;
+  uint32_t* s_meta = reinterpret_cast<uint32_t*>(s_mul + OM_B);
+  uint16_t* s_lut  = reinterpret_cast<uint16_t*>(s_meta + OM_B);
+  for (int i = threadIdx.x; i < OM_B; i += 1024) {
+    s_lo[i]   = plan->lo[i];
+    s_base[i] = plan->base[i];
+    s_mul[i]  = plan->mul[i];
+    s_meta[i] = plan->meta[i];
+  }
+  for (int i = threadIdx.x; i <= OM_LUT; i += 1024) s_lut[i] = plan->lut[i];
+  __syncthreads();
+  const int gsh        = plan->gsh;
+  const int ib         = plan->ib;
+  const uint64_t invn  = plan->invn;
+  constexpr int U      = 4;
+  const int64_t stride = (int64_t)gridDim.x * 1024 * U;
+  unsigned int nans    = 0;
+  for (int64_t i0 = (int64_t)blockIdx.x * 1024 * U + threadIdx.x; i0 < n; i0 += stride) {
+    uint64_t k[U];
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const int64_t i = i0 + (int64_t)u * 1024;
+      k[u]            = i < n ? __builtin_nontemporal_load(&keys[i]) : 0ull;
+    }
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const int64_t i = i0 + (int64_t)u * 1024;
+      if (i < n) {
+        if (KIND == K_FLOAT && (k[u] & 0x7FFFFFFFFFFFFFFFull) > 0x7FF0000000000000ull) ++nans;
+        const uint64_t r = om_rank(s_lo, s_lut, s_meta, s_base, s_mul, gsh, to_sortable<uint64_t, KIND>(k[u], desc_mask), (uint64_t)i, invn);
+        __builtin_nontemporal_store((r << ib) | (uint64_t)i, &words[i]);
+      }
+    }
+  }
+  if (KIND == K_FLOAT) {  // (wave-uniform branch: a column without NaN costs one ballot per wave)
+    const unsigned int wsum = wave_reduce(nans, SumOp());
+    if (wsum && lane_id() == 0) atomicAdd(&plan->nan_count, (unsigned long long)wsum);
+  }
+}
+
+// float64, DESCENDING: the reference sorts the pair (isnan * (row + 1), value) downwards (cpp/src/sort/sorted_order_radix.cu:37-48), so the
+// NaN rows come first in REVERSE row order; the word sort leaves them first in row order: turn the block around
+__global__ void __launch_bounds__(256) k_om_reverse_nans(int32_t* __restrict__ out, const OmPlan* __restrict__ plan)
+{
+  const unsigned long long c = plan->nan_count;
+  for (unsigned long long i = (unsigned long long)blockIdx.x * 256 + threadIdx.x; i < c / 2; i += (unsigned long long)gridDim.x * 256) {
+    const int32_t a = out[i], b = out[c - 1 - i];
+    out[i]         = b;
+    out[c - 1 - i] = a;
+  }
+}
+
+// ---- 5. finish: rows out; runs of equal ranks in lossy buckets are put right by (key, row).
+// Two kernels.  A first version did both in one pass -- the thread that found a run's head fetched the run's keys and sorted them on the
+// spot -- and took ~25 ms per 1e9 rows: a wave sat out two or three DEPENDENT memory round trips (the run's words, then its keys, ~2 us
+// each under load) for the two or three heads among its 64 rows.  Now pass A only streams: every row's index goes out as it stands, the
+// heads of lossy runs are appended to the workgroup's OWN segment of a run list (an LDS counter: no global atomic); pass B gives every
+// listed run a thread of its own, so all lanes of all waves have a gather in flight.
+template <int KIND>
+__device__ __forceinline__ uint64_t om_key(const uint64_t* __restrict__ keys, uint32_t row, uint64_t desc_mask)
+{
+  return to_sortable<uint64_t, KIND>(keys[row], desc_mask);
+}
+
+struct RunSeg {  // per workgroup of pass A
+  unsigned int count, pad;
+};
+
+__global__ void __launch_bounds__(256) k_om_finish_a(const uint64_t* __restrict__ sorted, int64_t n, const OmPlan* __restrict__ plan, int32_t* __restrict__ out,
+                                                     unsigned int* __restrict__ heads, RunSeg* __restrict__ segs, int64_t chunk, unsigned int seg_cap)
+{
+  // pure streaming: one 8-byte load and one 4-byte store per row, the neighbours' ranks through wave shuffles (the wave's edge lanes
+  // load theirs), the heads of runs of equal ranks appended -- position only -- to the workgroup's own segment through an LDS counter
+  __shared__ unsigned int s_n;
+  if (threadIdx.x == 0) s_n = 0;
+  __syncthreads();
+  const int ib         = plan->ib;
+  const uint64_t imask = (1ull << ib) - 1;
+  const int64_t p0 = (int64_t)blockIdx.x * chunk, p1 = p0 + chunk < n ? p0 + chunk : n;  // (chunk is a multiple of 256: whole waves)
+  unsigned int* mine = heads + (size_t)blockIdx.x * seg_cap;
+  const unsigned lane = threadIdx.x & 63u;
+  for (int64_t pb = p0; pb < p1; pb += 256) {
+    const int64_t p  = pb + threadIdx.x;
+    const bool live  = p < p1;
+    const uint64_t w = live ? __builtin_nontemporal_load(&sorted[p]) : 0ull;
+    const uint64_t r = w >> ib;
+    uint64_t rp = __shfl_up(r, 1), rn = __shfl_down(r, 1);
+    if (lane == 0) rp = (live && p > 0) ? sorted[p - 1] >> ib : ~0ull;
+    if (lane == 63 || p + 1 >= p1) rn = (live && p + 1 < n) ? sorted[p + 1] >> ib : ~0ull;
+    if (!live) continue;
+    __builtin_nontemporal_store((int32_t)(w & imask), &out[p]);  // right unless the row sits in a run of a lossy bucket: pass B rewrites those
+    if (rp != r && rn == r && p + 1 < n) {                        // the head of a run
+      const unsigned int e = atomicAdd(&s_n, 1u);
+      if (e < seg_cap) mine[e] = (unsigned int)p;                 // (seg_cap = chunk / 2 + 1 runs of >= 2 rows: cannot overflow)
+    }
+  }
+  __syncthreads();
+  if (threadIdx.x == 0) segs[blockIdx.x].count = s_n < seg_cap ? s_n : seg_cap;
+}
+
+template <int KIND>
+__global__ void __launch_bounds__(256) k_om_finish_b(const uint64_t* __restrict__ sorted, int64_t n, const uint64_t* __restrict__ keys, uint64_t desc_mask,
+                                                     OmPlan* plan, int32_t* __restrict__ out, const unsigned int* __restrict__ heads,
+                                                     const RunSeg* __restrict__ segs, unsigned int seg_cap, LongRun* __restrict__ longlist, unsigned int long_cap)
+{
+  // one thread per run: is its bucket lossy (else equal ranks are equal keys, already in row order)?  its length, its keys, its order
+  __shared__ uint64_t s_bl[OM_B];  // first rank of bucket b | lossy << 63
+  const unsigned int cnt = segs[blockIdx.x].count;
+  if (cnt == 0) return;
+  for (int i = threadIdx.x; i < OM_B; i += 256) s_bl[i] = plan->base[i] | ((plan->meta[i] & 256u) ? (1ull << 63) : 0ull);
+  __syncthreads();
+  const int ib           = plan->ib;
+  const uint64_t imask   = (1ull << ib) - 1;
+  const uint64_t bmask   = ~(1ull << 63);
+  const unsigned int* mine = heads + (size_t)blockIdx.x * seg_cap;
+  for (unsigned int i = threadIdx.x; i < cnt; i += 256) {
+    const unsigned int p = mine[i];
+    const uint64_t w0 = sorted[p], w1 = sorted[p + 1];
+    const uint64_t r  = w0 >> ib;
+    int b = 0;
+#pragma unroll
+    for (int step = OM_B / 2; step > 0; step >>= 1)
+      if ((s_bl[b + step] & bmask) <= r) b += step;
+    if (!(s_bl[b] >> 63)) continue;
+    int64_t q = (int64_t)p + 2;
+    while (q < n && (sorted[q] >> ib) == r) ++q;
+    const unsigned int L = (unsigned int)(q - p);
+    if (L == 2) {  // the common case, without the private arrays
+      const uint32_t r0 = (uint32_t)(w0 & imask), r1 = (uint32_t)(w1 & imask);
+      const uint64_t k0 = om_key<KIND>(keys, r0, desc_mask), k1 = om_key<KIND>(keys, r1, desc_mask);
+      if (k1 < k0) {  // (equal keys: r0 < r1 already)
+        out[p]     = (int32_t)r1;
+        out[p + 1] = (int32_t)r0;
+      }
+    } else if (L <= (unsigned)OM_SMALL) {
+      uint64_t kk[OM_SMALL];
+      uint32_t rr[OM_SMALL];
+      for (unsigned int j = 0; j < L; ++j) {  // rows arrive in ascending row order: a stable insertion by key keeps it among equal keys
+        const uint32_t row = (uint32_t)(sorted[p + j] & imask);
+        const uint64_t key = om_key<KIND>(keys, row, desc_mask);
+        int m = (int)j;
+        while (m > 0 && kk[m - 1] > key) {
+          kk[m] = kk[m - 1];
+          rr[m] = rr[m - 1];
+          --m;
+        }
+        kk[m] = key;
+        rr[m] = row;
+      }
+      for (unsigned int j = 0; j < L; ++j) out[p + j] = (int32_t)rr[j];
+    } else {
+      const unsigned int e = atomicAdd(&plan->nlong, 1u);
+      if (e < long_cap) longlist[e] = LongRun{p, L};
+      else plan->long_overflow = 1u;  // cannot happen: long_cap = n / (OM_SMALL + 1) + 1 runs of more than OM_SMALL rows
+    }
+  }
+}
+
+// ---- 6. the long runs: one workgroup per run; (key, row) sorted by a network whose compare-exchanges all put the smaller element at the
+// lower index, so positions beyond the run's length behave as +infinity without being stored
+struct KR {
+  uint64_t key;
+  uint32_t row;
+};
+__device__ __forceinline__ bool kr_less(uint64_t ka, uint32_t ra, uint64_t kb, uint32_t rb) { return ka < kb || (ka == kb && ra < rb); }
+
+template <int KIND>
+__global__ void __launch_bounds__(1024) k_om_long(const uint64_t* __restrict__ sorted, const uint64_t* __restrict__ keys, uint64_t desc_mask,
+                                                  const OmPlan* __restrict__ plan, int32_t* __restrict__ out, const LongRun* __restrict__ longlist,
+                                                  unsigned int long_cap, uint64_t* __restrict__ gk, uint32_t* __restrict__ gr)
+{
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  uint64_t* s_k = reinterpret_cast<uint64_t*>(smem);                    // OM_LDSRUN keys
+  uint32_t* s_r = reinterpret_cast<uint32_t*>(smem + OM_LDSRUN * 8);    // OM_LDSRUN rows
+  const int ib  = plan->ib;
+  const uint64_t imask = (1ull << ib) - 1;
+  unsigned int nl = plan->nlong;
+  if (nl > long_cap) nl = long_cap;
+  for (unsigned int e = blockIdx.x; e < nl; e += gridDim.x) {
+    const unsigned int p0 = longlist[e].start, L = longlist[e].len;
+    unsigned int N = 1;
+    while (N < L) N <<= 1;
+    const bool in_lds = L <= (unsigned)OM_LDSRUN;
+    uint64_t* K = in_lds ? s_k : gk + p0;  // (global scratch: the run's own slice)
+    uint32_t* R = in_lds ? s_r : gr + p0;
+    for (unsigned int i = threadIdx.x; i < L; i += 1024) {
+      const uint32_t row = (uint32_t)(sorted[p0 + i] & imask);
+      K[i] = om_key<KIND>(keys, row, desc_mask);
+      R[i] = row;
+    }
+    __syncthreads();
+    for (unsigned int k = 2; k <= N; k <<= 1) {
+      for (unsigned int j = k >> 1; j > 0; j >>= 1) {
+        for (unsigned int i = threadIdx.x; i < N; i += 1024) {
+          // first stage of a merge: mirror inside the block of k; later stages: distance j.  Always (lower index) <= (higher index).
+          const unsigned int prt = (j == (k >> 1)) ? (i ^ (k - 1)) : (i ^ j);
+          if (prt > i && prt < L) {  // (i < prt < L; a partner beyond L is +infinity: no exchange)
+            const uint64_t ka = K[i], kb = K[prt];
+            const uint32_t ra = R[i], rb = R[prt];
+            if (kr_less(kb, rb, ka, ra)) {
+              K[i]   = kb;
+              R[i]   = rb;
+              K[prt] = ka;
+              R[prt] = ra;
+            }
+          }
+        }
+        __syncthreads();
+      }
+    }
+    for (unsigned int i = threadIdx.x; i < L; i += 1024) out[p0 + i] = (int32_t)R[i];
+    __syncthreads();
+  }
+}
+
+static inline size_t round256(size_t b) { return (b + 255) / 256 * 256; }
+static thread_local int g_order_map = 1;  // 1: 64-bit sorted_order from 2^25 rows goes through the word sort (default); 0: the round-3 pairs path
+
+struct Layout {
+  size_t inner_bytes;
+  char* inner;
+  OmPlan* plan;
+  uint64_t* samp;
+  uint64_t* words;
+  uint64_t* sorted;
+  size_t total;
+};
+
+static int layout(void* tmp, int64_t n, Layout& L)
+{
+  size_t inner = 0;
+  int rc       = gx_sort_keys(GX_UINT64, nullptr, nullptr, n, 0, nullptr, &inner, nullptr);
+  if (rc) return rc;
+  // the runs' scratch lives in the word sort's scratch, which is free by then, behind the plan header: per-workgroup run segments,
+  // their counts, the long-run list and its (key, row) slices
+  const size_t long_cap = (size_t)n / (OM_SMALL + 1) + 1;
+  const size_t lneed    = round256(gx_sort_plan_bytes()) + round256(((size_t)n / 2 + (size_t)OM_FIN_WGS * 2) * sizeof(unsigned int)) +
+                          round256((size_t)OM_FIN_WGS * sizeof(RunSeg)) + round256(long_cap * sizeof(LongRun)) + round256((size_t)n * 8) + round256((size_t)n * 4);
+  if (lneed > inner) inner = lneed;
+  Carver c(tmp);
+  L.inner       = c.take<char>(inner);  // FIRST: the word sort's plan header -- its status word -- is what gx_sort_status(tmp) reads
+  L.inner_bytes = inner;
+  L.plan        = c.take<OmPlan>(1);
+  L.samp        = c.take<uint64_t>(OM_S);
+  L.words       = c.take<uint64_t>((size_t)n);
+  L.sorted      = c.take<uint64_t>((size_t)n);
+  L.total       = c.total();
+  return 0;
+}
+
+template <int KIND>
+static int sorted_order_words(const void* keys, int64_t n, int descending, int32_t* out, void* tmp, size_t* tmp_bytes, hipStream_t s)
+{
+  Layout L;
+  int rc = layout(tmp, n, L);
+  if (rc) return rc;
+  if (!tmp) {
+    *tmp_bytes = L.total;
+    return 0;
+  }
+  if (*tmp_bytes < L.total) return GX_ETMP;
+  if (!keys || !out) return GX_EINVAL;
+  const uint64_t* k        = static_cast<const uint64_t*>(keys);
+  const uint64_t desc_mask = descending ? ~0ull : 0ull;
+  int ib                   = 1;
+  while (((int64_t)1 << ib) < n) ++ib;
+  static std::atomic<bool> attr_set{false};
+  static int num_cus = 0;
+  if (!attr_set) {
+    GX_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(k_om_plan), hipFuncAttributeMaxDynamicSharedMemorySize, OM_S * 8));
+    GX_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(k_om_map<KIND>), hipFuncAttributeMaxDynamicSharedMemorySize, OM_B * 28 + OM_LUT * 2 + 64));
+    GX_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(k_om_count<KIND>), hipFuncAttributeMaxDynamicSharedMemorySize, OM_B * 16 + OM_LUT * 2 + 64));
+    GX_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(k_om_long<KIND>), hipFuncAttributeMaxDynamicSharedMemorySize, OM_LDSRUN * 12));
+    int dev = 0;
+    GX_HIP_TRY(hipGetDevice(&dev));
+    GX_HIP_TRY(hipDeviceGetAttribute(&num_cus, hipDeviceAttributeMultiprocessorCount, dev));
+    attr_set = true;
+  }
+  const unsigned cus = (unsigned)(num_cus > 0 ? num_cus : 256);
+  hipLaunchKernelGGL((k_om_sample<KIND>), dim3(OM_S / 256), dim3(256), 0, s, k, n, desc_mask, L.samp);
+  hipLaunchKernelGGL(k_om_plan, dim3(1), dim3(1024), OM_S * 8, s, (const uint64_t*)L.samp, L.plan, ib, n);
+  hipLaunchKernelGGL((k_om_count<KIND>), dim3(cus), dim3(256), OM_B * 16 + OM_LUT * 2 + 64, s, k, n, desc_mask, L.plan);
+  hipLaunchKernelGGL(k_om_plan2, dim3(1), dim3(1024), 0, s, L.plan);
+  hipLaunchKernelGGL((k_om_map<KIND>), dim3(cus), dim3(1024), OM_B * 28 + OM_LUT * 2 + 64, s, k, n, desc_mask, L.plan, L.words);
+  size_t ib2 = L.inner_bytes;
+  rc         = gx_sort_keys(GX_UINT64, L.words, L.sorted, n, 0, L.inner, &ib2, s);
+  if (rc) return rc;
+  // (behind the word sort its scratch is dead: the long-run list and slices alias it, past the plan header whose status word stays)
+  char* lbase              = L.inner + round256(gx_sort_plan_bytes());
+  const size_t long_cap    = (size_t)n / (OM_SMALL + 1) + 1;
+  const int64_t chunk      = ((n + OM_FIN_WGS - 1) / OM_FIN_WGS + 255) / 256 * 256;  // rows per workgroup of the finish passes
+  const unsigned int seg_cap = (unsigned int)(chunk / 2 + 1);
+  unsigned int* heads      = reinterpret_cast<unsigned int*>(lbase);
+  RunSeg* segs             = reinterpret_cast<RunSeg*>(lbase + round256(((size_t)n / 2 + (size_t)OM_FIN_WGS * 2) * sizeof(unsigned int)));
+  LongRun* longlist        = reinterpret_cast<LongRun*>(reinterpret_cast<char*>(segs) + round256((size_t)OM_FIN_WGS * sizeof(RunSeg)));
+  uint64_t* gk             = reinterpret_cast<uint64_t*>(reinterpret_cast<char*>(longlist) + round256(long_cap * sizeof(LongRun)));
+  uint32_t* gr             = reinterpret_cast<uint32_t*>(reinterpret_cast<char*>(gk) + round256((size_t)n * 8));
+  hipLaunchKernelGGL(k_om_finish_a, dim3(OM_FIN_WGS), dim3(256), 0, s, (const uint64_t*)L.sorted, n, (const OmPlan*)L.plan, out, heads, segs, chunk, seg_cap);
+  hipLaunchKernelGGL((k_om_finish_b<KIND>), dim3(OM_FIN_WGS), dim3(256), 0, s, (const uint64_t*)L.sorted, n, k, desc_mask, L.plan, out, (const unsigned int*)heads,
+                     (const RunSeg*)segs, seg_cap, longlist, (unsigned int)long_cap);
+  hipLaunchKernelGGL((k_om_long<KIND>), dim3(cus), dim3(1024), OM_LDSRUN * 12, s, (const uint64_t*)L.sorted, k, desc_mask, (const OmPlan*)L.plan, out,
+                     (const LongRun*)longlist, (unsigned int)long_cap, gk, gr);
+  if (KIND == K_FLOAT && descending) hipLaunchKernelGGL(k_om_reverse_nans, dim3(cus), dim3(256), 0, s, out, (const OmPlan*)L.plan);
+  GX_LAUNCH_CHECK();
+  return 0;
+}
+
+}  // namespace order
+}  // namespace gx
+
+extern "C" {
+
+void gx_sort_set_order_map(int mode) { gx::order::g_order_map = mode ? 1 : 0; }
+
+// whether gx_sorted_order (no nulls) takes this path; the caller (gx_sort.hip) asks first
+int gx_order_map_applies(int dtype, int64_t n)
+{
+  return gx::order::g_order_map && n >= (1ll << 25) && n <= 0x7FFFFFFFll && (dtype == GX_INT64 || dtype == GX_UINT64 || dtype == GX_FLOAT64);
+}
+
+int gx_sorted_order_words(int dtype, const void* keys, int64_t n, int descending, int32_t* out, void* tmp, size_t* tmp_bytes, gx_stream_t s)
+{
+  using namespace gx::order;
+  if (n < 0 || !tmp_bytes) return GX_EINVAL;
+  hipStream_t st = (hipStream_t)s;
+  switch (dtype) {
+    case GX_INT64: return sorted_order_words<gx::K_SIGNED>(keys, n, descending, out, tmp, tmp_bytes, st);
+    case GX_UINT64: return sorted_order_words<gx::K_UNSIGNED>(keys, n, descending, out, tmp, tmp_bytes, st);
+    case GX_FLOAT64: return sorted_order_words<gx::K_FLOAT>(keys, n, descending, out, tmp, tmp_bytes, st);
+    default: return GX_EDTYPE;
+  }
+}
+
+// state of the last run that used `tmp`: info[0] = runs that went to the long list, [1] = list overflow (never), [2] = row bits, [3] = rank
+// bits, [4] = lossy buckets (rank space < key range: distinct keys may share a rank).  Synchronises.
+int gx_sort_order_map_info(const void* tmp, int64_t n, int32_t* info5_host, gx_stream_t s)
+{
+  using namespace gx::order;
+  if (!tmp || !info5_host) return GX_EINVAL;
+  Layout L;
+  int rc = layout(const_cast<void*>(tmp), n, L);
+  if (rc) return rc;
+  static thread_local OmPlan h;
+  GX_HIP_TRY(hipMemcpyAsync(&h, L.plan, sizeof(OmPlan), hipMemcpyDeviceToHost, (hipStream_t)s));
+  GX_HIP_TRY(hipStreamSynchronize((hipStream_t)s));
+  info5_host[0] = (int32_t)h.nlong;
+  info5_host[1] = (int32_t)h.long_overflow;
+  info5_host[2] = h.ib;
+  info5_host[3] = h.rb;
+  info5_host[4] = h.nlossy;
+  return 0;
+}
+
+}  // extern "C"

@@ -1738,7 +1738,9 @@ __global__ void __launch_bounds__((1 << CL2) / 16, 4) k_local_place(const KeyT* 
       // The sizes / slots / positions of BOTH slots are requested before either is looked at: one of the two is empty as a rule, and
       // finding that out cost the workgroup a round trip to memory of its own (run 16: 43 % more wave-cycles waiting than on bit
       // digits, 1400 per wave -- the 0.9 ms this stage took longer in splitter mode).
-      const uint32_t flip = (1u << hy.bits2) - 1u;
+      // (odd rounds visit cell ^ flip -- a permutation of the round's cells only when the grid is a whole number of buckets: the default
+      //  grid is; a grid from the A/B knob gx_sort_set_place_grid that is not walks linearly -- ADVICE r5: some cells twice, others never)
+      const uint32_t flip = (gridDim.x % (1u << hy.bits2)) == 0u ? (1u << hy.bits2) - 1u : 0u;
       const uint32_t c0 = blockIdx.x, c1 = blockIdx.x + gridDim.x;  // (c0 < ncells: the grid is never larger than the slots)
       const bool two    = c1 < ncells;
       const uint32_t s1 = two ? (c1 ^ flip) : c0;
@@ -4655,12 +4657,17 @@ int gx_sort_pairs(int key_dtype, const void* keys_in, void* keys_out, const int3
                                   tmp_bytes, stream);
 }
 
+int gx_order_map_applies(int dtype, int64_t n);                                                                                            // gx_order.hip
+int gx_sorted_order_words(int dtype, const void* keys, int64_t n, int descending, int32_t* out, void* tmp, size_t* tmp_bytes, gx_stream_t s);  // gx_order.hip
 int gx_sorted_order(int dtype, const void* keys, const uint32_t* valid, int64_t n, int64_t null_count,
                     int descending, int nulls_before, int32_t* out_indices, void* tmp, size_t* tmp_bytes,
                     gx_stream_t stream)
 {
   if (n < 0 || null_count < 0 || null_count > n || tmp_bytes == nullptr) return GX_EINVAL;
   if (valid == nullptr || null_count == 0) {
+    // round 6: 64-bit keys from 2^25 rows -- the argsort as a keys-only sort of (monotone rank, row) words (gx_order.hip): the cost of
+    // the keys-only paths on ANY value distribution instead of the look-back pairs levels that decline uneven columns to LSD passes
+    if (gx_order_map_applies(dtype, n)) return gx_sorted_order_words(dtype, keys, n, descending, out_indices, tmp, tmp_bytes, stream);
     if (gx::sort::order_words32_applies(dtype, n)) {
       return dtype == GX_INT32 ? gx::sort::sorted_order_words32<uint32_t, gx::K_SIGNED>(keys, n, descending, out_indices, tmp, tmp_bytes, stream)
                                : gx::sort::sorted_order_words32<uint32_t, gx::K_UNSIGNED>(keys, n, descending, out_indices, tmp, tmp_bytes, stream);
@@ -4804,6 +4811,8 @@ int gx_sort_place_info(const void* tmp, int32_t* todo_cells_host, gx_stream_t st
   GX_HIP_TRY(hipStreamSynchronize(stream));
   return 0;
 }
+
+size_t gx_sort_plan_bytes(void) { return sizeof(gx::sort::SortPlan); }
 
 int gx_sort_status(const void* tmp, int* status_host, gx_stream_t stream)
 {

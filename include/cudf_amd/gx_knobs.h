@@ -90,6 +90,14 @@ void gx_sort_set_splitters(int enable);
  * (isnan * (idx + 1), value) pairs (cpp/src/sort/sort_radix.cu:36-117) could differ -- is sorted by the stable look-back path
  * instead (decided on the device); 0 = float keys always take the look-back path, as before round 5. */
 void gx_sort_set_float_cursor(int enable);
+/* A/B knob (per calling thread; round 6): 1 (default) = gx_sorted_order of a 64-bit column without nulls, from 2^25 rows, is a KEYS-ONLY
+ * sort of (monotone rank << row bits | row) words + a pass that puts runs of equal ranks right by (key, row) (gx_order.hip): the cost of
+ * the keys-only paths on any value distribution; 0 = the round-3 pairs path (look-back levels on key bits; uneven columns -> LSD passes). */
+void gx_sort_set_order_map(int enable);
+/* Measurement / test hook: state of the last gx_sorted_order that took the word sort with this scratch and row count: info5 = {runs of
+ * more than 16 equal ranks (sorted by the long-run pass), long-run list overflow (always 0), row bits, rank bits inside a bucket, buckets
+ * whose rank drops key bits}.  Synchronises `stream`. */
+int gx_sort_order_map_info(const void* tmp, int64_t n, int32_t* info5_host, gx_stream_t stream);
 /* (per calling thread) how long a look-back wait may make no progress before it is abandoned and the sort's status word becomes 5
  * (gx_sort_status): milliseconds of wall-clock time, 0 = the default 30 s.  Tests shorten it. */
 void gx_sort_set_spin_limit_ms(int ms);
@@ -140,7 +148,10 @@ void gx_join_set_experiment(int bits);
 /* A/B knob (per calling thread): 0 = software-pipelined tag probe on LDS-resident 4-bit tags (default), 1 = the round-1 tag probe,
  * 2 / 3 = the L2-resident DIRECT probe of round 5 (k_pj3_probe_direct, 4 / 2 rows per thread): no tags, no LDS tables -- the
  * workgroups of an XCD take the pieces of the XCD's partitions in order, so the 2-MiB sub-table they all probe sits in the
- * XCD's L2 and every row reads its home slot there. */
+ * XCD's L2 and every row reads its home slot there; 4 / 5 = k_pj4_probe_tags, the LDS-tag probe without the software pipeline and the
+ * pair staging (2 rows per thread and two workgroups per CU / 4 rows and one); 6 / 7 = the same with the tag windows read from the L2
+ * instead of LDS -- these two ALSO change the partition count of the probe (2^20-slot sub-tables: an eighth of the partitions).
+ * All measured at parity or slower in round 5 (profiles/r5_join_probe_ab.txt); values outside 0-7 select 0. */
 void gx_join_set_probe_kernel(int which);
 
 /* A/B knob (process-wide): speculative = 1 (default) partitions the probe rows WITHOUT a histogram pass into padded

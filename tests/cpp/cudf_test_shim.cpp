@@ -461,6 +461,8 @@ int shim_reduce_init(int dtype, const void* data, const uint32_t* valid, int nul
     g_err = std::string{"cudf::data_type_error: "} + e.what();
   } catch (std::invalid_argument const& e) {
     g_err = std::string{"std::invalid_argument: "} + e.what();
+  } catch (cudf::logic_error const& e) {
+    g_err = std::string{"cudf::logic_error: "} + e.what();
   } catch (std::exception const& e) {
     g_err = e.what();
   }
