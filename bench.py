@@ -553,7 +553,7 @@ def lsr_mix64(j):
 
 def pmc_traffic(roofline, n):
     """HBM bytes of the step from the COMMITTED PMC passes (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate runs of this
-    command at 1e9 rows, scripts/gpu_r5_evidence.sh -> profiles/r5_pmc_traffic_1e9.json).  A constant read from a file cannot
+    command at 1e9 rows, scripts/gpu_r6.sh <tag> evidence -> profiles/r6_pmc_traffic_1e9.json).  A constant read from a file cannot
     notice a regression in the run it annotates, so it is attached only while it describes THESE kernels: the file records the
     sha256 of the kernel sources it was measured on; when the sources have changed since, `traffic` stays null and
     `traffic_note` says why.  `traffic_source` always names where a figure came from."""
@@ -567,18 +567,18 @@ def pmc_traffic(roofline, n):
     try:
         sys.path.insert(0, os.path.join(ROOT, "scripts"))
         from pmc_to_json import csrc_sha16
-        tr = json.load(open(os.path.join(ROOT, "profiles", "r5_pmc_traffic_1e9.json")))
+        tr = json.load(open(os.path.join(ROOT, "profiles", "r6_pmc_traffic_1e9.json")))
         if tr.get("csrc_sha16") != csrc_sha16():
-            roofline["traffic_note"] = ("profiles/r5_pmc_traffic_1e9.json was measured on other kernel sources (sha "
+            roofline["traffic_note"] = ("profiles/r6_pmc_traffic_1e9.json was measured on other kernel sources (sha "
                                         f"{tr.get('csrc_sha16')} != {csrc_sha16()}): not attached")
             return
         e = (tr.get("groups", {}).get(key) or tr["kernels"].get(key)) if key else None
         if e:
             roofline["traffic"] = e["hbm_bytes_per_launch"]
-            roofline["traffic_source"] = ("COMMITTED FILE profiles/r5_pmc_traffic_1e9.json, not measured in this run: " + tr["source"] + "; " +
+            roofline["traffic_source"] = ("COMMITTED FILE profiles/r6_pmc_traffic_1e9.json, not measured in this run: " + tr["source"] + "; " +
                                           tr["correction"] + (f"; sum over {e['members']}" if "members" in e else ""))
         else:
-            roofline["traffic_note"] = f"no entry {key!r} in profiles/r5_pmc_traffic_1e9.json"
+            roofline["traffic_note"] = f"no entry {key!r} in profiles/r6_pmc_traffic_1e9.json"
     except (OSError, KeyError, ValueError, ImportError) as ex:
         roofline["traffic_note"] = f"no committed PMC file for this build ({type(ex).__name__})"
 

@@ -2915,7 +2915,7 @@ k_pj2_probe_pipe(const K* __restrict__ pkeys, const int32_t* __restrict__ pidx, 
 #pragma unroll
       for (int j = 0; j < PP_R; ++j) {
         const Slot<K>* sp = cand[j] ? slots + ((sub_base + li[j] + ((uint32_t)__builtin_ctzll(cand[j]) >> 2)) & mask) : dummy;
-        sv[j]             = *reinterpret_cast<const Raw*>(sp);
+        sv[j]             = *reinterpret_cast<const Raw*>(sp);  // (measured and dropped: nontemporal slot reads -- the L1 does help: probe 7.55 -> 9.34 ms, profiles/r6_run16_join_ab.txt)
       }
     }
     // ---------------- S1(t): the piece that enters S2 next trip
@@ -3793,7 +3793,8 @@ int probe_partitioned_impl2(const K* keys, int64_t n, const Slot<K>* slots, uint
     if (rec) {
       const int abl = (g_pj_xp >> 4) & 7;  // measurement only: the ablated kernels give WRONG results
       kprobe        = abl == 1 ? k_pj2_probe_pipe<K, false, false, true, 1> : abl == 2 ? k_pj2_probe_pipe<K, false, false, true, 2>
-                      : abl == 3 ? k_pj2_probe_pipe<K, false, false, true, 3> : k_pj2_probe_pipe<K, false, false, true>;
+                      : abl == 3 ? k_pj2_probe_pipe<K, false, false, true, 3>
+                      : k_pj2_probe_pipe<K, false, false, true>;
     }
   }
   constexpr size_t lds_p = ((size_t)1 << (PJ_SUB_LOG2 - 1)) + PP_TAGPAD + (size_t)6 * PP_ROWS * sizeof(int32_t);

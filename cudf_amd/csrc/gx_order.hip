@@ -390,29 +390,45 @@ struct RunSeg {  // per workgroup of pass A
 __global__ void __launch_bounds__(256) k_om_finish_a(const uint64_t* __restrict__ sorted, int64_t n, const OmPlan* __restrict__ plan, int32_t* __restrict__ out,
                                                      unsigned int* __restrict__ heads, RunSeg* __restrict__ segs, int64_t chunk, unsigned int seg_cap)
 {
-  // pure streaming: one 8-byte load and one 4-byte store per row, the neighbours' ranks through wave shuffles (the wave's edge lanes
-  // load theirs), the heads of runs of equal ranks appended -- position only -- to the workgroup's own segment through an LDS counter
+  // pure streaming: 8 bytes in and 4 bytes out per row, the neighbours' ranks through wave shuffles (the wave's edge lanes load
+  // theirs), the heads of runs of equal ranks appended -- position only -- to the workgroup's own segment through an LDS counter
   __shared__ unsigned int s_n;
   if (threadIdx.x == 0) s_n = 0;
   __syncthreads();
   const int ib         = plan->ib;
   const uint64_t imask = (1ull << ib) - 1;
-  const int64_t p0 = (int64_t)blockIdx.x * chunk, p1 = p0 + chunk < n ? p0 + chunk : n;  // (chunk is a multiple of 256: whole waves)
+  const int64_t p0 = (int64_t)blockIdx.x * chunk, p1 = p0 + chunk < n ? p0 + chunk : n;  // (chunk is a multiple of 512: whole waves of pairs)
   unsigned int* mine = heads + (size_t)blockIdx.x * seg_cap;
   const unsigned lane = threadIdx.x & 63u;
-  for (int64_t pb = p0; pb < p1; pb += 256) {
-    const int64_t p  = pb + threadIdx.x;
-    const bool live  = p < p1;
-    const uint64_t w = live ? __builtin_nontemporal_load(&sorted[p]) : 0ull;
-    const uint64_t r = w >> ib;
-    uint64_t rp = __shfl_up(r, 1), rn = __shfl_down(r, 1);
-    if (lane == 0) rp = (live && p > 0) ? sorted[p - 1] >> ib : ~0ull;
-    if (lane == 63 || p + 1 >= p1) rn = (live && p + 1 < n) ? sorted[p + 1] >> ib : ~0ull;
-    if (!live) continue;
-    __builtin_nontemporal_store((int32_t)(w & imask), &out[p]);  // right unless the row sits in a run of a lossy bucket: pass B rewrites those
-    if (rp != r && rn == r && p + 1 < n) {                        // the head of a run
+  typedef uint64_t u64x2 __attribute__((ext_vector_type(2)));
+  typedef int32_t i32x2 __attribute__((ext_vector_type(2)));
+  // two consecutive words per thread: one 16-byte load, one 8-byte store (the sorted words start 256-byte aligned, p0 is a multiple of 512)
+  for (int64_t pb = p0; pb < p1; pb += 512) {
+    const int64_t p  = pb + 2 * (int64_t)threadIdx.x;
+    const bool live0 = p < p1, live1 = p + 1 < p1;
+    uint64_t w0 = 0, w1 = 0;
+    if (live1) {
+      const u64x2 v = __builtin_nontemporal_load(reinterpret_cast<const u64x2*>(sorted + p));
+      w0 = v.x;
+      w1 = v.y;
+    } else if (live0) {
+      w0 = sorted[p];
+    }
+    const uint64_t r0 = w0 >> ib, r1 = w1 >> ib;
+    uint64_t rp = __shfl_up(r1, 1), rn = __shfl_down(r0, 1);  // the previous lane's second word, the next lane's first
+    if (lane == 0) rp = (live0 && p > 0) ? sorted[p - 1] >> ib : ~0ull;
+    if (lane == 63 || p + 2 >= p1) rn = (live1 && p + 2 < n) ? sorted[p + 2] >> ib : ~0ull;
+    if (!live0) continue;
+    if (live1) __builtin_nontemporal_store(i32x2{(int32_t)(w0 & imask), (int32_t)(w1 & imask)}, reinterpret_cast<i32x2*>(out + p));
+    else out[p] = (int32_t)(w0 & imask);  // right unless the row sits in a run of a lossy bucket: pass B rewrites those
+    const bool n0 = live1 ? r1 == r0 : (p + 1 < n && (sorted[p + 1] >> ib) == r0);  // (live0 && !live1: the last row of the workgroup's range)
+    if (rp != r0 && n0) {  // word 0 heads a run
       const unsigned int e = atomicAdd(&s_n, 1u);
-      if (e < seg_cap) mine[e] = (unsigned int)p;                 // (seg_cap = chunk / 2 + 1 runs of >= 2 rows: cannot overflow)
+      if (e < seg_cap) mine[e] = (unsigned int)p;  // (seg_cap = chunk / 2 + 1 runs of >= 2 rows: cannot overflow)
+    }
+    if (live1 && r0 != r1 && rn == r1) {  // word 1 heads a run
+      const unsigned int e = atomicAdd(&s_n, 1u);
+      if (e < seg_cap) mine[e] = (unsigned int)(p + 1);
     }
   }
   __syncthreads();
@@ -609,7 +625,7 @@ static int sorted_order_words(const void* keys, int64_t n, int descending, int32
   // (behind the word sort its scratch is dead: the long-run list and slices alias it, past the plan header whose status word stays)
   char* lbase              = L.inner + round256(gx_sort_plan_bytes());
   const size_t long_cap    = (size_t)n / (OM_SMALL + 1) + 1;
-  const int64_t chunk      = ((n + OM_FIN_WGS - 1) / OM_FIN_WGS + 255) / 256 * 256;  // rows per workgroup of the finish passes
+  const int64_t chunk      = ((n + OM_FIN_WGS - 1) / OM_FIN_WGS + 511) / 512 * 512;  // rows per workgroup of the finish passes
   const unsigned int seg_cap = (unsigned int)(chunk / 2 + 1);
   unsigned int* heads      = reinterpret_cast<unsigned int*>(lbase);
   RunSeg* segs             = reinterpret_cast<RunSeg*>(lbase + round256(((size_t)n / 2 + (size_t)OM_FIN_WGS * 2) * sizeof(unsigned int)));

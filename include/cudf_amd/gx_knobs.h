@@ -98,6 +98,8 @@ void gx_sort_set_order_map(int enable);
  * more than 16 equal ranks (sorted by the long-run pass), long-run list overflow (always 0), row bits, rank bits inside a bucket, buckets
  * whose rank drops key bits}.  Synchronises `stream`. */
 int gx_sort_order_map_info(const void* tmp, int64_t n, int32_t* info5_host, gx_stream_t stream);
+/* 1 when gx_sorted_order of a column of `dtype` with n rows and no nulls takes the word sort (knob on, 64-bit dtype, 2^25 <= n < 2^31), else 0. */
+int gx_order_map_applies(int dtype, int64_t n);
 /* (per calling thread) how long a look-back wait may make no progress before it is abandoned and the sort's status word becomes 5
  * (gx_sort_status): milliseconds of wall-clock time, 0 = the default 30 s.  Tests shorten it. */
 void gx_sort_set_spin_limit_ms(int ms);

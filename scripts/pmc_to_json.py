@@ -29,9 +29,13 @@ GROUPS = {  # group -> (workload, base names whose LARGEST dispatch is summed)
     "sort local stage": ("sort", ["k_local_place", "k_local_sort"]),
     "sort": ("sort", ["k_hf_sample", "k_hf_plan", "k_hf_scatter level 0", "k_hf_scatter level 1", "k_hy_hist", "k_msd_pass level 0",
                       "k_msd_pass level 1", "k_plan2", "k_local_place", "k_local_sort"]),
-    "join probe phase": ("join", ["k_pj2_scatter", "k_pj2_offsets", "k_pj2_probe_pipe"]),
+    "join probe phase": ("join", ["k_pj2_scatter", "k_pj2_scatter_rec", "k_pj2_offsets", "k_pj2_probe_pipe"]),  # (round 6: the record-form scatter)
     "join build": ("join", ["k_pj_hist", "k_pj_offsets", "k_pj_scatter", "k_bw_split", "k_bw_build", "k_bw_fixup"]),
-    "sorted_order": ("sorted_order", ["k_hy_hist", "k_msd_pass level 0", "k_msd_pass level 1", "k_plan2", "k_local_place", "k_local_sort"]),
+    # round 6: the argsort is a keys-only word sort (gx_order.hip) -- its own kernels + the cursor path's; the round-3 pairs kernels stay listed
+    # for runs with --sort-order-map 0 (base names that did not run contribute nothing)
+    "sorted_order": ("sorted_order", ["k_om_sample", "k_om_plan", "k_om_count", "k_om_plan2", "k_om_map", "k_om_finish_a", "k_om_finish_b", "k_om_long",
+                                      "k_hf_sample", "k_hf_plan", "k_hf_scatter level 0", "k_hf_scatter level 1",
+                                      "k_hy_hist", "k_msd_pass level 0", "k_msd_pass level 1", "k_plan2", "k_local_place", "k_local_sort"]),
     "join probe phase (exact two-pass)": ("join", ["k_pj_hist", "k_pj_offsets", "k_pj_scatter", "k_pj_probe_pipe"]),
     "groupby": ("groupby", ["k_slot_sample", "k_slot_plan", "k_part_reset_cursors", "k_part_scatter", "k_part_aggregate"]),
     "groupby (exact two-pass)": ("groupby", ["k_part_hist", "k_part_offsets", "k_part_scatter", "k_part_aggregate"]),
