@@ -48,7 +48,10 @@ def parse():
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--workload", default="all",
-                    choices=["all", "sort", "sorted_order", "join", "groupby", "groupby_minmax", "join_multikey", "groupby_multikey", "reduce", "scan", "gather"])
+                    choices=["all", "sort", "sorted_order", "sorted_order_table", "sort_by_key", "join", "groupby", "groupby_minmax", "join_multikey", "groupby_multikey", "reduce", "scan", "gather"])
+    ap.add_argument("--table-keys", default="lowcard", choices=["lowcard", "random", "tiny"],
+                    help="sorted_order_table: lowcard = 1000 distinct leading values x random 64-bit second column (ties of the leading column by "
+                         "the million); random = random 64-bit leading column (no ties); tiny = 10 x 100 distinct values (whole tuples tie)")
     ap.add_argument("--rows", type=float, default=1e9)
     ap.add_argument("--algo", type=int, default=0,
                     help="sort knob: 0 onesweep/windowed look-back, 1 three-kernel, 2 onesweep/one-tile look-back")
@@ -83,10 +86,12 @@ def parse():
     ap.add_argument("--hot-copies", type=float, default=0, help="sort: this many rows carry ONE value (a hot value: zeros, a sentinel)")
     ap.add_argument("--key-type", default="int64", choices=["int64", "float64"],
                     help="sort: float64 = a FLOAT64 column, keys drawn as N(0, 1) (--key-dist normal, the default for floats) or U[0, 1) (--key-dist uniform)")
-    ap.add_argument("--key-dist", default="uniform", choices=["uniform", "normal", "zipf", "sorted", "lognormal", "clusters"],
+    ap.add_argument("--key-dist", default="uniform", choices=["uniform", "normal", "zipf", "sorted", "lognormal", "clusters", "dupids"],
                     help="sort: distribution of the int64 keys.  normal = round(N(0, 1) * 2^40) (bell-shaped level-0 buckets); zipf = "
                          "floor(u^-5) clipped to 2^31 (the continuous form of Zipf(1.2): 18 %% of the rows carry the value 1); sorted = the "
                          "uniform keys, already in ascending order.  Robustness lines (VERDICT r3 next 3), not the headline")
+    ap.add_argument("--key-copies", type=int, default=100, help="sort --key-dist dupids: rows per distinct id (ids = a 64-bit mixing bijection of [0, rows / copies): "
+                                                                "wide keys WITH duplicates, a foreign-key column of hashed ids)")
     ap.add_argument("--force-sharded", action="store_true",
                     help="run the MULTI-GPU code path (pre-flight, sharded operators with the exchange forced, their guards) in a "
                          "1-rank group on one GPU: what `--gpus N` executes, testable where only one device is visible")
@@ -622,6 +627,11 @@ def bench_sort(c, pairs=False, cpu_leg=True):
         kt = c.as_tensor(keys, torch.int64)
         if a.key_dist == "sorted":
             kt.copy_(torch.sort(kt).values)
+        elif a.key_dist == "dupids":
+            del kt
+            keys = ops.random_column(np.int64, n, seed=42 + c.rank, lo=0, hi=max(1, n // max(1, a.key_copies)))
+            kt = c.as_tensor(keys, torch.int64)
+            kt.mul_(-7046029254386353131)   # x * 0x9E3779B97F4A7C15 mod 2^64: distinct ids spread over the 64-bit range
         else:
             g = torch.Generator(device="cuda").manual_seed(42 + c.rank)
             step = 1 << 27
@@ -670,7 +680,7 @@ def bench_sort(c, pairs=False, cpu_leg=True):
     if a.hot_copies:
         workload += f", {int(a.hot_copies):.0e} copies of one value"
     if a.key_dist != "uniform" and not is_f64:
-        workload += f", {a.key_dist} keys"
+        workload += f", {a.key_dist} keys" + (f" ({a.key_copies} rows per id)" if a.key_dist == "dupids" else "")
 
     prof = {"pass_ms": 0.0, "hist_ms": 0.0, "launches": 0, "hyb": [0.0] * 4, "hyb_n": 0}
 
@@ -1285,6 +1295,92 @@ def bench_multikey(c, which):
             "cpu_baseline": None, "checked": checked}
 
 
+def bench_sort_table(c, which):
+    """cudf::sorted_order of a 2 x int64 table (VERDICT r5 next 5a: one word sort on a nested rank of the tuple, gx_sorted_order_table) and
+    cudf::sort_by_key of an 8-byte value column by one int64 key column (sorted_order + gather: src/sort/sort.cu:31-50).  Verified on the
+    device every run: the output is a permutation whose (key tuple, row) sequence is strictly increasing -- sortedness AND stability."""
+    a, lib, L, ops, np, torch = c.args, c.lib, c.L, c.ops, c.np, c.torch
+    n = c.n
+    import ctypes
+    if which == "sorted_order_table":
+        if a.table_keys == "lowcard":
+            k0 = ops.random_column(np.int64, n, seed=31, lo=0, hi=1000)
+            k1 = ops.random_column(np.int64, n, seed=32)
+            kd = "1000 distinct leading values x random 64-bit second column"
+        elif a.table_keys == "random":
+            k0 = ops.random_column(np.int64, n, seed=31)
+            k1 = ops.random_column(np.int64, n, seed=32, lo=0, hi=5)
+            kd = "random 64-bit leading column x 5 distinct values"
+        else:
+            k0 = ops.random_column(np.int64, n, seed=31, lo=0, hi=10)
+            k1 = ops.random_column(np.int64, n, seed=32, lo=0, hi=100)
+            kd = "10 x 100 distinct values"
+        out = c.Column.empty(np.int32, n)
+        dt = (ctypes.c_int * 2)(k0.gx, k1.gx)
+        dp = (ctypes.c_void_p * 2)(k0.data_ptr, k1.data_ptr)
+        de = (ctypes.c_int * 2)(0, 0)
+        nb = ctypes.c_size_t(0)
+        L.check(lib.gx_sorted_order_table(2, dt, dp, de, n, None, None, ctypes.byref(nb), c.stream), "query")
+        tmp = c.device_bytes(nb.value)
+
+        def step():
+            L.check(lib.gx_sorted_order_table(2, dt, dp, de, n, out.data_ptr, c.ptr(tmp), ctypes.byref(nb), c.stream), "gx_sorted_order_table")
+        sec = c.timed(step)
+        st = ctypes.c_int(0)
+        L.check(lib.gx_sort_status(c.ptr(tmp), ctypes.byref(st), c.stream), "status")
+        assert st.value != 5
+        info = (ctypes.c_int32 * 5)()
+        L.check(lib.gx_sort_order_map_info(c.ptr(tmp), n, info, c.stream), "info")
+        del tmp
+        torch.cuda.empty_cache()
+        o = c.as_tensor(out, torch.int32)
+        assert int(o.to(torch.int64).sum().item()) == n * (n - 1) // 2 and int(o.min().item()) == 0 and int(o.max().item()) == n - 1
+        # strictly increasing (k0, k1, row) along the output, checked in slices (the gathers are 8 GB each at 1e9 rows)
+        t0, t1 = c.as_tensor(k0, torch.int64), c.as_tensor(k1, torch.int64)
+        step_rows = 1 << 27
+        for lo in range(0, n, step_rows):
+            hi = min(n, lo + step_rows + 1)
+            idx = o[lo:hi].to(torch.int64)
+            x0, x1 = t0[idx], t1[idx]
+            ok = (x0[:-1] < x0[1:]) | ((x0[:-1] == x0[1:]) & ((x1[:-1] < x1[1:]) | ((x1[:-1] == x1[1:]) & (idx[:-1] < idx[1:]))))
+            assert bool(ok.all().item()), f"rows {lo}..{hi}: not in (key tuple, row) order"
+            del idx, x0, x1, ok
+        bpr = 16 + 4
+        kname = "gx_sorted_order_table (k_omt_map x 2 + keys-only word sort + k_om_finish_a + k_omt_finish_b)"
+        wl = f"{n:.0e}-row sorted_order of a 2 x int64 table, {kd} (one word sort on a nested rank + tuple fix-up of equal-rank runs)"
+        checked = "permutation (index sum, min, max); (k0, k1, row) strictly increasing along the whole output"
+        extra = {"long_runs": int(info[0]), "row_bits": int(info[2]), "rank_bits": int(info[3])}
+    else:
+        k = ops.random_column(np.int64, n, seed=41)
+        v = ops.random_column(np.int64, n, seed=42)
+        res = {}
+
+        def step():
+            res["out"] = ops.sort_by_key([v], k)[0]
+        sec = c.timed(step)
+        o = res["out"]
+        # the values arrive in key order: spot slices gathered back through a fresh order
+        order = ops.sorted_order(k)
+        ot, kt, vt = c.as_tensor(order, torch.int32), c.as_tensor(k, torch.int64), c.as_tensor(v, torch.int64)
+        got = c.as_tensor(o, torch.int64)
+        for lo in (0, n // 2, max(0, n - (1 << 24))):
+            idx = ot[lo:lo + (1 << 24)].to(torch.int64)
+            assert bool((got[lo:lo + (1 << 24)] == vt[idx]).all().item())
+            ks = kt[idx]
+            assert bool((ks[:-1] <= ks[1:]).all().item())
+        bpr = 8 + 8 + 8
+        kname = "gx_sorted_order (word sort) + gx_gather (8-byte rows through the order)"
+        wl = f"{n:.0e}-row sort_by_key (int64 keys, one int64 value column)"
+        checked = "3 slices of 2^24 rows: values == values[order], keys[order] non-decreasing"
+        extra = {}
+    ach = bpr * n / sec / 1e9
+    roofline = {"bound": "hbm", "kernel": kname, "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS,
+                "traffic": None, "algorithmic_bytes_per_launch": bpr * n, "avg_launch_ms": sec * 1e3,
+                "model": f"{bpr} B/row: the key (and value) columns read once, the result written once", **extra}
+    return {"workload": wl, "rows": n, "ms_per_step": sec * 1e3, "rows_per_s": n / sec, "dtype": "int64", "roofline": roofline,
+            "cpu_baseline": None, "checked": checked}
+
+
 # ------------------------------------------------------------------------------------------------
 # streaming primitives (SURVEY 8a rows a13-a15)
 # ------------------------------------------------------------------------------------------------
@@ -1477,6 +1573,8 @@ def main():
         head = bench_groupby_minmax(c)
     elif wl in ("join_multikey", "groupby_multikey"):
         head = bench_multikey(c, wl)
+    elif wl in ("sorted_order_table", "sort_by_key"):
+        head = bench_sort_table(c, wl)
     else:
         head = bench_stream(c, wl)
     if c.rank == 0:

@@ -38,6 +38,7 @@ _PROTOS = {
     "gx_sort_keys": (_i, [_i, _p, _p, _i64, _i, _p, _sz, _p]),
     "gx_sort_pairs": (_i, [_i, _p, _p, _p, _p, _i64, _i, _p, _sz, _p]),
     "gx_sorted_order": (_i, [_i, _p, _p, _i64, _i64, _i, _i, _p, _p, _sz, _p]),
+    "gx_sorted_order_table": (_i, [_i, _p, _p, _p, _i64, _p, _p, _sz, _p]),
     "gx_sort_status": (_i, [_p, ctypes.POINTER(_i), _p]),
     "gx_sort_status_async": (_i, [_p, _p, _p]),
     "gx_sort_set_fault_mode": (None, [_i]),

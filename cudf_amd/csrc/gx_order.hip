@@ -58,6 +58,7 @@ struct alignas(256) OmPlan {
   int gsh;
   uint64_t invn;          // floor((2^64 - 1) / n): row * invn = the row's position in [0, 1) as a 64-bit fraction
   unsigned int nlong;     // entries of the long-run list
+  unsigned int nwg;       // ... of which the workgroup pass has to sort (k_om_medium's list)
   unsigned long long nan_count;  // float64 keys: NaN rows (k_om_map) -- a descending order has them first, in REVERSE row order
   unsigned int long_overflow;
   int ib, rb;
@@ -167,6 +168,7 @@ __global__ void __launch_bounds__(1024) k_om_plan(const uint64_t* __restrict__ s
   if (t == 0) {
     plan->invn          = ~0ull / (uint64_t)(n > 0 ? n : 1);
     plan->nlong         = 0;
+    plan->nwg           = 0;
     plan->nan_count     = 0;
     plan->long_overflow = 0;
     plan->ib            = ib;
@@ -302,10 +304,11 @@ __device__ __forceinline__ uint64_t om_rank(const uint64_t* __restrict__ lo, con
   const uint64_t d  = s - lo[b];
   const uint64_t M  = mul[b];
   const uint64_t A  = __umul64hi(d << lz, M);
-  if (mt & 256u) return base[b] + A;                  // lossy: floor(d alloc / W)
-  // lossless: the value d owns [A, B); its rows are spread over them by row / n -- NOT row >> ib: 1e9 rows fill 93 % of 2^30, the rows
-  // of every value would crowd into the first 93 % of its ranks and the word sort's cells, sized for 93 % full, would overflow by the
-  // thousand (measured: keys in [100, 10001), 476 M of 1e9 rows through the big-cell rescue, 78.6 ms)
+  // The value d owns the ranks [A, B), B = floor((d + 1) alloc / W); its rows are spread over them by row / n -- NOT row >> ib: 1e9 rows
+  // fill 93 % of 2^30, the rows of every value would crowd into the first 93 % of its ranks and the word sort's cells, sized for 93 %
+  // full, would overflow by the thousand (measured: keys in [100, 10001), 476 M of 1e9 rows through the big-cell rescue, 78.6 ms).
+  // Lossless bucket: B - A >= 2.  Lossy bucket: B - A is 0 or 1 where the bucket is wider than its rank space (the value shares rank A
+  // with its neighbours: the run pass) -- the same formula, no branch.
   const uint64_t d1 = (d + 1) << lz;                  // ((W << lz) = 2^64 wraps to 0)
   const uint64_t B  = d1 ? __umul64hi(d1, M) : M;     // (d + 1 = W and W << lz = 2^64: floor(W alloc / W) = alloc = M)
   return base[b] + A + __umul64hi(row * invn, B - A);
@@ -377,12 +380,6 @@ __global__ void __launch_bounds__(256) k_om_reverse_nans(int32_t* __restrict__ o
 // each under load) for the two or three heads among its 64 rows.  Now pass A only streams: every row's index goes out as it stands, the
 // heads of lossy runs are appended to the workgroup's OWN segment of a run list (an LDS counter: no global atomic); pass B gives every
 // listed run a thread of its own, so all lanes of all waves have a gather in flight.
-template <int KIND>
-__device__ __forceinline__ uint64_t om_key(const uint64_t* __restrict__ keys, uint32_t row, uint64_t desc_mask)
-{
-  return to_sortable<uint64_t, KIND>(keys[row], desc_mask);
-}
-
 struct RunSeg {  // per workgroup of pass A
   unsigned int count, pad;
 };
@@ -435,17 +432,189 @@ __global__ void __launch_bounds__(256) k_om_finish_a(const uint64_t* __restrict_
   if (threadIdx.x == 0) segs[blockIdx.x].count = s_n < seg_cap ? s_n : seg_cap;
 }
 
-template <int KIND>
-__global__ void __launch_bounds__(256) k_om_finish_b(const uint64_t* __restrict__ sorted, int64_t n, const uint64_t* __restrict__ keys, uint64_t desc_mask,
-                                                     OmPlan* plan, int32_t* __restrict__ out, const unsigned int* __restrict__ heads,
-                                                     const RunSeg* __restrict__ segs, unsigned int seg_cap, LongRun* __restrict__ longlist, unsigned int long_cap)
+// =====================================================================================================================================
+// Several key columns (round 6).  cudf::sorted_order of a TABLE is a comparison sort under the lexicographic row
+// comparator (cpp/src/sort/sort_impl.cuh:61-93, sort.cu:31-50); rounds 1-5 ran it as LSD over the columns -- per extra column one
+// single-column argsort, one random 8-byte gather of the column through the order so far and one random 4-byte gather of that order:
+// ~90 ms for 2 x int64 at 1e9 rows.  Here the tuple goes through ONE word sort.  Column j has its own bucket plan P_j (the same
+// sample / count / plan kernels); the ranks nest from the last column to the first,
+//
+//   F_k = row / n                                   (a 64-bit fraction)
+//   F_j = base_j(b) + A_j(d) + floor(F_{j+1} (B_j(d) - A_j(d)))      -- column j's value owns the ranks [A, B) of P_j's 2^64, and the
+//                                                                       REST of the tuple says where inside them the row sits
+//   word = F_0 (computed in 64 - ib bits) << ib | row
+//
+// so F_j is monotone in (c_j, ..., c_{k-1}, row) and rows of equal leading values are ordered -- as far as the bits reach -- by the
+// columns behind.  What the bits do not resolve ends in runs of equal ranks, which the run pass puts right by comparing FULL tuples
+// (column values fetched on demand, ties by row: a stable order, which both cudf::sorted_order and stable_sorted_order accept).
+// One map pass per column (8 B/row fraction in, 8 B/row out, in place): 2 x int64 at 1e9 rows = the single-column cost + ~5 ms.
+// NaN: equal to each other and greater than every number in both directions (the comparator rule: row_operator/common_utils.cuh:157-169
+// -- NOT the reverse-row-order quirk of the single-column radix path).  Columns: 1-, 2-, 4- or 8-byte numerics without nulls.
+constexpr int OMT_MAXCOLS = 8;
+struct ColDesc {
+  const void* data;
+  uint64_t desc_mask;  // 0 or all ones at the column's width
+  int kind;            // KeyKind
+  int width;           // bytes
+};
+struct TableDesc {
+  ColDesc c[OMT_MAXCOLS];
+  int ncols;
+};
+
+template <typename U>
+__device__ __forceinline__ uint64_t col_sortable_w(const ColDesc& c, int64_t i)
 {
-  // one thread per run: is its bucket lossy (else equal ranks are equal keys, already in row order)?  its length, its keys, its order
-  __shared__ uint64_t s_bl[OM_B];  // first rank of bucket b | lossy << 63
+  const U b = static_cast<const U*>(c.data)[i];
+  const U m = (U)c.desc_mask;
+  if (c.kind == K_SIGNED) return (uint64_t)to_sortable<U, K_SIGNED>(b, m);
+  return (uint64_t)to_sortable<U, K_UNSIGNED>(b, m);
+}
+// the column's value in row i as a 64-bit unsigned key (narrow types zero-extended: the order is what matters)
+__device__ __forceinline__ uint64_t col_sortable(const ColDesc& c, int64_t i)
+{
+  switch (c.width) {
+    case 8:
+      if (c.kind == K_FLOAT) return to_sortable<uint64_t, K_FLOAT>(static_cast<const uint64_t*>(c.data)[i], c.desc_mask);
+      return col_sortable_w<uint64_t>(c, i);
+    case 4:
+      if (c.kind == K_FLOAT) return (uint64_t)to_sortable<uint32_t, K_FLOAT>(static_cast<const uint32_t*>(c.data)[i], (uint32_t)c.desc_mask);
+      return col_sortable_w<uint32_t>(c, i);
+    case 2: return col_sortable_w<uint16_t>(c, i);
+    default: return col_sortable_w<uint8_t>(c, i);
+  }
+}
+
+__global__ void __launch_bounds__(256) k_omt_sample(ColDesc c, int64_t n, uint64_t* __restrict__ samp)
+{
+  const int j = blockIdx.x * 256 + threadIdx.x;
+  if (j >= OM_S) return;
+  const int64_t i = (int64_t)(((__int128)j * n) / OM_S);
+  samp[j]         = col_sortable(c, i < n ? i : n - 1);
+}
+
+__global__ void __launch_bounds__(256) k_omt_count(ColDesc col, int64_t n, OmPlan* plan)
+{
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  uint64_t* s_lo  = reinterpret_cast<uint64_t*>(smem);
+  uint32_t* s_eq  = reinterpret_cast<uint32_t*>(smem + OM_B * 8);
+  uint32_t* s_cnt = s_eq + OM_B;
+  uint16_t* s_lut = reinterpret_cast<uint16_t*>(s_cnt + OM_B);
+  for (int i = threadIdx.x; i < OM_B; i += 256) {
+    s_lo[i]  = plan->lo[i];
+    s_eq[i]  = plan->meta[i];
+    s_cnt[i] = 0;
+  }
+  for (int i = threadIdx.x; i <= OM_LUT; i += 256) s_lut[i] = plan->lut[i];
+  __syncthreads();
+  const int gsh = plan->gsh;
+  const int64_t nchunks = (n + 63) / 64;
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  // (a short column: every chunk -- the stride only thins out what is plentiful)
+  const int64_t cstride = nchunks >= 64 * OM_CSTRIDE ? OM_CSTRIDE : 1;
+  for (int64_t c = ((int64_t)blockIdx.x * 4 + w) * cstride; c < nchunks; c += (int64_t)gridDim.x * 4 * cstride) {
+    const int64_t i = c * 64 + lane;
+    if (i < n) atomicAdd(&s_cnt[om_bucket(s_lo, s_lut, s_eq, gsh, col_sortable(col, i))], 1u);
+  }
+  __syncthreads();
+  for (int i = threadIdx.x; i < OM_B; i += 256)
+    if (s_cnt[i]) atomicAdd(&plan->cnt[i], s_cnt[i]);
+}
+
+// one column's level of the nested rank: io[i] = rank_j(c_j[i]; F = io[i] or row / n), the leading column's shifted up over the row
+__global__ void __launch_bounds__(1024) k_omt_map(ColDesc col, int64_t n, const OmPlan* __restrict__ plan, uint64_t* __restrict__ io, int innermost, int leading)
+{
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  uint64_t* s_lo   = reinterpret_cast<uint64_t*>(smem);
+  uint64_t* s_base = s_lo + OM_B;
+  uint64_t* s_mul  = s_base + OM_B;
+  uint32_t* s_meta = reinterpret_cast<uint32_t*>(s_mul + OM_B);
+  uint16_t* s_lut  = reinterpret_cast<uint16_t*>(s_meta + OM_B);
+  for (int i = threadIdx.x; i < OM_B; i += 1024) {
+    s_lo[i]   = plan->lo[i];
+    s_base[i] = plan->base[i];
+    s_mul[i]  = plan->mul[i];
+    s_meta[i] = plan->meta[i];
+  }
+  for (int i = threadIdx.x; i <= OM_LUT; i += 1024) s_lut[i] = plan->lut[i];
+  __syncthreads();
+  const int gsh        = plan->gsh;
+  const int ib         = plan->ib;  // (0 unless this is the leading column's plan)
+  const uint64_t invn  = plan->invn;
+  constexpr int U      = 4;
+  const int64_t stride = (int64_t)gridDim.x * 1024 * U;
+  for (int64_t i0 = (int64_t)blockIdx.x * 1024 * U + threadIdx.x; i0 < n; i0 += stride) {
+    uint64_t k[U], f[U];
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const int64_t i = i0 + (int64_t)u * 1024;
+      k[u]            = i < n ? col_sortable(col, i) : 0ull;
+      f[u]            = innermost ? (uint64_t)i * invn : (i < n ? __builtin_nontemporal_load(&io[i]) : 0ull);
+    }
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const int64_t i = i0 + (int64_t)u * 1024;
+      if (i < n) {
+        const int b       = om_bucket(s_lo, s_lut, s_meta, gsh, k[u]);
+        const int lz      = (int)(s_meta[b] & 63u);
+        const uint64_t d  = k[u] - s_lo[b];
+        const uint64_t M  = s_mul[b];
+        const uint64_t A  = __umul64hi(d << lz, M);
+        const uint64_t d1 = (d + 1) << lz;
+        const uint64_t B  = d1 ? __umul64hi(d1, M) : M;
+        const uint64_t r  = s_base[b] + A + __umul64hi(f[u], B - A);
+        __builtin_nontemporal_store(leading ? ((r << ib) | (uint64_t)i) : r, &io[i]);
+      }
+    }
+  }
+}
+
+// rows ra, rb agree in the leading column: which comes first?  the columns behind, then the row
+__device__ __forceinline__ bool tuple_rest_less(const TableDesc& t, uint32_t ra, uint32_t rb)
+{
+  for (int c = 1; c < t.ncols; ++c) {
+    const uint64_t a = col_sortable(t.c[c], ra), b = col_sortable(t.c[c], rb);
+    if (a != b) return a < b;
+  }
+  return ra < rb;
+}
+// ---- the run passes, for one key column (OneCol) or a tuple (Tuple).  A policy supplies the leading key of a row in sortable form and
+// the order of two rows whose leading keys agree.
+template <int KIND>
+struct OneCol {
+  const uint64_t* keys;
+  uint64_t desc_mask;
+  static constexpr bool kSkipLossless = true;  // a run inside a lossless bucket holds ONE key value: already in row order
+  __device__ __forceinline__ uint64_t key(uint32_t row) const { return to_sortable<uint64_t, KIND>(keys[row], desc_mask); }
+  __device__ __forceinline__ bool rest_less(uint32_t ra, uint32_t rb) const { return ra < rb; }
+};
+struct Tuple {
+  TableDesc t;
+  static constexpr bool kSkipLossless = false;  // equal ranks say nothing about the columns behind the first
+  __device__ __forceinline__ uint64_t key(uint32_t row) const { return col_sortable(t.c[0], row); }
+  __device__ __forceinline__ bool rest_less(uint32_t ra, uint32_t rb) const { return tuple_rest_less(t, ra, rb); }
+};
+template <class P>
+__device__ __forceinline__ bool kr_less(const P& pol, uint64_t ka, uint32_t ra, uint64_t kb, uint32_t rb)
+{
+  return ka < kb || (ka == kb && pol.rest_less(ra, rb));
+}
+
+constexpr unsigned int OM_WAVERUN = 128;  // listed runs up to this length are first LOOKED AT by one wave (two rows per lane): only those out of order go on
+
+// pass B: one thread per run head that pass A listed
+template <class P>
+__global__ void __launch_bounds__(256) k_om_finish_b(const uint64_t* __restrict__ sorted, int64_t n, P pol, OmPlan* plan, int32_t* __restrict__ out,
+                                                     const unsigned int* __restrict__ heads, const RunSeg* __restrict__ segs, unsigned int seg_cap,
+                                                     LongRun* __restrict__ longlist, unsigned int long_cap)
+{
+  __shared__ uint64_t s_bl[P::kSkipLossless ? OM_B : 1];  // first rank of bucket b | lossy << 63
   const unsigned int cnt = segs[blockIdx.x].count;
   if (cnt == 0) return;
-  for (int i = threadIdx.x; i < OM_B; i += 256) s_bl[i] = plan->base[i] | ((plan->meta[i] & 256u) ? (1ull << 63) : 0ull);
-  __syncthreads();
+  if (P::kSkipLossless) {
+    for (int i = threadIdx.x; i < OM_B; i += 256) s_bl[i] = plan->base[i] | ((plan->meta[i] & 256u) ? (1ull << 63) : 0ull);
+    __syncthreads();
+  }
   const int ib           = plan->ib;
   const uint64_t imask   = (1ull << ib) - 1;
   const uint64_t bmask   = ~(1ull << 63);
@@ -454,29 +623,54 @@ __global__ void __launch_bounds__(256) k_om_finish_b(const uint64_t* __restrict_
     const unsigned int p = mine[i];
     const uint64_t w0 = sorted[p], w1 = sorted[p + 1];
     const uint64_t r  = w0 >> ib;
-    int b = 0;
+    if (P::kSkipLossless) {
+      int b = 0;
 #pragma unroll
-    for (int step = OM_B / 2; step > 0; step >>= 1)
-      if ((s_bl[b + step] & bmask) <= r) b += step;
-    if (!(s_bl[b] >> 63)) continue;
+      for (int step = OM_B / 2; step > 0; step >>= 1)
+        if ((s_bl[b + step] & bmask) <= r) b += step;
+      if (!(s_bl[b] >> 63)) continue;
+    }
     int64_t q = (int64_t)p + 2;
     while (q < n && (sorted[q] >> ib) == r) ++q;
     const unsigned int L = (unsigned int)(q - p);
     if (L == 2) {  // the common case, without the private arrays
       const uint32_t r0 = (uint32_t)(w0 & imask), r1 = (uint32_t)(w1 & imask);
-      const uint64_t k0 = om_key<KIND>(keys, r0, desc_mask), k1 = om_key<KIND>(keys, r1, desc_mask);
-      if (k1 < k0) {  // (equal keys: r0 < r1 already)
+      const uint64_t k0 = pol.key(r0), k1 = pol.key(r1);
+      if (kr_less(pol, k1, r1, k0, r0)) {  // (one column, equal keys: r0 < r1 already)
         out[p]     = (int32_t)r1;
         out[p + 1] = (int32_t)r0;
       }
+    } else if (L <= 4u) {  // three or four rows (ids with a few rows each): all loads issued at once, a five-comparator network in registers
+      const bool four = L == 4u;
+      uint32_t rr[4] = {(uint32_t)(w0 & imask), (uint32_t)(w1 & imask), (uint32_t)(sorted[p + 2] & imask), four ? (uint32_t)(sorted[p + 3] & imask) : 0u};
+      uint64_t kk[4] = {pol.key(rr[0]), pol.key(rr[1]), pol.key(rr[2]), four ? pol.key(rr[3]) : 0ull};
+      auto cx = [&](int a, int b) {  // the smaller of (a, b) to a
+        if (kr_less(pol, kk[b], rr[b], kk[a], rr[a])) {
+          const uint64_t tk = kk[a];
+          const uint32_t tr = rr[a];
+          kk[a] = kk[b];
+          rr[a] = rr[b];
+          kk[b] = tk;
+          rr[b] = tr;
+        }
+      };
+      cx(0, 1);
+      if (four) cx(2, 3);
+      cx(0, 2);
+      if (four) cx(1, 3);
+      cx(1, 2);
+      out[p]     = (int32_t)rr[0];
+      out[p + 1] = (int32_t)rr[1];
+      out[p + 2] = (int32_t)rr[2];
+      if (four) out[p + 3] = (int32_t)rr[3];
     } else if (L <= (unsigned)OM_SMALL) {
       uint64_t kk[OM_SMALL];
       uint32_t rr[OM_SMALL];
-      for (unsigned int j = 0; j < L; ++j) {  // rows arrive in ascending row order: a stable insertion by key keeps it among equal keys
+      for (unsigned int j = 0; j < L; ++j) {  // rows arrive in ascending row order: a stable insertion keeps it among equal tuples
         const uint32_t row = (uint32_t)(sorted[p + j] & imask);
-        const uint64_t key = om_key<KIND>(keys, row, desc_mask);
+        const uint64_t key = pol.key(row);
         int m = (int)j;
-        while (m > 0 && kk[m - 1] > key) {
+        while (m > 0 && kr_less(pol, key, row, kk[m - 1], rr[m - 1])) {
           kk[m] = kk[m - 1];
           rr[m] = rr[m - 1];
           --m;
@@ -493,25 +687,57 @@ __global__ void __launch_bounds__(256) k_om_finish_b(const uint64_t* __restrict_
   }
 }
 
-// ---- 6. the long runs: one workgroup per run; (key, row) sorted by a network whose compare-exchanges all put the smaller element at the
-// lower index, so positions beyond the run's length behave as +infinity without being stored
-struct KR {
-  uint64_t key;
-  uint32_t row;
-};
-__device__ __forceinline__ bool kr_less(uint64_t ka, uint32_t ra, uint64_t kb, uint32_t rb) { return ka < kb || (ka == kb && ra < rb); }
+// ---- 6a. listed runs up to 128 rows: ONE WAVE looks at each -- two rows per lane, their keys fetched, neighbours compared through
+// shuffles.  A column of WIDE keys with DUPLICATES (a hundred rows per 64-bit id: the buckets are lossy, every id is one run of a
+// hundred equal keys) lists n / 100 runs that are all in order already; a workgroup and a sorting network for each took 0.5 s per 1e9
+// rows.  Runs found in order are done (pass A wrote their rows); the others -- and the runs beyond 128 rows -- go to the workgroup pass's list.
+template <class P>
+__global__ void __launch_bounds__(256) k_om_medium(const uint64_t* __restrict__ sorted, P pol, OmPlan* __restrict__ plan, const LongRun* __restrict__ longlist,
+                                                   unsigned int long_cap, LongRun* __restrict__ wglist)
+{
+  const int ib         = plan->ib;
+  const uint64_t imask = (1ull << ib) - 1;
+  unsigned int nl      = plan->nlong;
+  if (nl > long_cap) nl = long_cap;
+  const unsigned int lane = threadIdx.x & 63u;
+  const unsigned int wave = (blockIdx.x * 256u + threadIdx.x) >> 6, nwaves = gridDim.x * 4u;
+  for (unsigned int e = wave; e < nl; e += nwaves) {
+    const LongRun run = longlist[e];
+    const unsigned int p0 = run.start, L = run.len;
+    bool bad = L > OM_WAVERUN;  // (wave-uniform) too long to look at here: the workgroup pass checks it itself
+    if (!bad) {
+      const bool h0 = lane < L, h1 = lane + 64u < L;
+      const uint32_t r0 = h0 ? (uint32_t)(sorted[p0 + lane] & imask) : 0u, r1 = h1 ? (uint32_t)(sorted[p0 + 64u + lane] & imask) : 0u;
+      const uint64_t k0 = h0 ? pol.key(r0) : 0ull, k1 = h1 ? pol.key(r1) : 0ull;
+      uint64_t nk0 = __shfl_down(k0, 1), nk1 = __shfl_down(k1, 1);
+      uint32_t nr0 = __shfl_down(r0, 1), nr1 = __shfl_down(r1, 1);
+      const uint64_t fk1 = __shfl(k1, 0);
+      const uint32_t fr1 = __shfl(r1, 0);
+      if (lane == 63u) {
+        nk0 = fk1;
+        nr0 = fr1;
+      }
+      bool mine = false;
+      if (lane + 1u < L) mine = kr_less(pol, nk0, nr0, k0, r0);                         // element lane + 1 before element lane?
+      if (lane < 63u && lane + 65u < L) mine = mine || kr_less(pol, nk1, nr1, k1, r1);  // element lane + 65 before element lane + 64?
+      bad = ballot(mine) != 0ull;
+    }
+    if (bad && lane == 0u) wglist[atomicAdd(&plan->nwg, 1u)] = run;  // (at most nl <= long_cap entries)
+  }
+}
 
-template <int KIND>
-__global__ void __launch_bounds__(1024) k_om_long(const uint64_t* __restrict__ sorted, const uint64_t* __restrict__ keys, uint64_t desc_mask,
-                                                  const OmPlan* __restrict__ plan, int32_t* __restrict__ out, const LongRun* __restrict__ longlist,
-                                                  unsigned int long_cap, uint64_t* __restrict__ gk, uint32_t* __restrict__ gr)
+// ---- 6b. the workgroup list: one workgroup per run; (key, row) sorted by a network whose compare-exchanges all put the
+// smaller element at the lower index, so positions beyond the run's length behave as +infinity without being stored
+template <class P>
+__global__ void __launch_bounds__(1024) k_om_long(const uint64_t* __restrict__ sorted, P pol, const OmPlan* __restrict__ plan, int32_t* __restrict__ out,
+                                                  const LongRun* __restrict__ longlist, unsigned int long_cap, uint64_t* __restrict__ gk, uint32_t* __restrict__ gr)
 {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   uint64_t* s_k = reinterpret_cast<uint64_t*>(smem);                    // OM_LDSRUN keys
   uint32_t* s_r = reinterpret_cast<uint32_t*>(smem + OM_LDSRUN * 8);    // OM_LDSRUN rows
   const int ib  = plan->ib;
   const uint64_t imask = (1ull << ib) - 1;
-  unsigned int nl = plan->nlong;
+  unsigned int nl = plan->nwg;
   if (nl > long_cap) nl = long_cap;
   for (unsigned int e = blockIdx.x; e < nl; e += gridDim.x) {
     const unsigned int p0 = longlist[e].start, L = longlist[e].len;
@@ -522,30 +748,35 @@ __global__ void __launch_bounds__(1024) k_om_long(const uint64_t* __restrict__ s
     uint32_t* R = in_lds ? s_r : gr + p0;
     for (unsigned int i = threadIdx.x; i < L; i += 1024) {
       const uint32_t row = (uint32_t)(sorted[p0 + i] & imask);
-      K[i] = om_key<KIND>(keys, row, desc_mask);
+      K[i] = pol.key(row);
       R[i] = row;
     }
     __syncthreads();
-    for (unsigned int k = 2; k <= N; k <<= 1) {
-      for (unsigned int j = k >> 1; j > 0; j >>= 1) {
-        for (unsigned int i = threadIdx.x; i < N; i += 1024) {
-          // first stage of a merge: mirror inside the block of k; later stages: distance j.  Always (lower index) <= (higher index).
-          const unsigned int prt = (j == (k >> 1)) ? (i ^ (k - 1)) : (i ^ j);
-          if (prt > i && prt < L) {  // (i < prt < L; a partner beyond L is +infinity: no exchange)
-            const uint64_t ka = K[i], kb = K[prt];
-            const uint32_t ra = R[i], rb = R[prt];
-            if (kr_less(kb, rb, ka, ra)) {
-              K[i]   = kb;
-              R[i]   = rb;
-              K[prt] = ka;
-              R[prt] = ra;
+    // in order already (one value's rows, or rows whose keys rise with the row)?  then pass A's output stands
+    int bad = 0;
+    for (unsigned int i = threadIdx.x; i + 1 < L; i += 1024) bad |= kr_less(pol, K[i + 1], R[i + 1], K[i], R[i]) ? 1 : 0;
+    if (__syncthreads_or(bad)) {
+      for (unsigned int k = 2; k <= N; k <<= 1) {
+        for (unsigned int j = k >> 1; j > 0; j >>= 1) {
+          for (unsigned int i = threadIdx.x; i < N; i += 1024) {
+            // first stage of a merge: mirror inside the block of k; later stages: distance j.  Always (lower index) <= (higher index).
+            const unsigned int prt = (j == (k >> 1)) ? (i ^ (k - 1)) : (i ^ j);
+            if (prt > i && prt < L) {  // (i < prt < L; a partner beyond L is +infinity: no exchange)
+              const uint64_t ka = K[i], kb = K[prt];
+              const uint32_t ra = R[i], rb = R[prt];
+              if (kr_less(pol, kb, rb, ka, ra)) {
+                K[i]   = kb;
+                R[i]   = rb;
+                K[prt] = ka;
+                R[prt] = ra;
+              }
             }
           }
+          __syncthreads();
         }
-        __syncthreads();
       }
+      for (unsigned int i = threadIdx.x; i < L; i += 1024) out[p0 + i] = (int32_t)R[i];
     }
-    for (unsigned int i = threadIdx.x; i < L; i += 1024) out[p0 + i] = (int32_t)R[i];
     __syncthreads();
   }
 }
@@ -556,33 +787,72 @@ static thread_local int g_order_map = 1;  // 1: 64-bit sorted_order from 2^25 ro
 struct Layout {
   size_t inner_bytes;
   char* inner;
-  OmPlan* plan;
+  OmPlan* plan;  // nplans of them: [0] is the plan of the (leading) key column -- the one gx_sort_order_map_info reads
   uint64_t* samp;
   uint64_t* words;
   uint64_t* sorted;
   size_t total;
 };
 
-static int layout(void* tmp, int64_t n, Layout& L)
+// the finish passes' geometry: workgroups, rows per workgroup (whole waves of pairs), run-list entries per workgroup
+struct FinGeo {
+  unsigned int wgs, seg_cap;
+  int64_t chunk;
+  size_t long_cap;
+};
+static FinGeo fin_geometry(int64_t n)
+{
+  FinGeo g;
+  const int64_t want = (n + 511) / 512;
+  g.wgs      = (unsigned int)(want < OM_FIN_WGS ? (want > 0 ? want : 1) : OM_FIN_WGS);
+  g.chunk    = ((n + g.wgs - 1) / g.wgs + 511) / 512 * 512;
+  g.seg_cap  = (unsigned int)(g.chunk / 2 + 1);
+  g.long_cap = (size_t)n / (OM_SMALL + 1) + 1;
+  return g;
+}
+
+static int layout(void* tmp, int64_t n, Layout& L, int nplans = 1)
 {
   size_t inner = 0;
   int rc       = gx_sort_keys(GX_UINT64, nullptr, nullptr, n, 0, nullptr, &inner, nullptr);
   if (rc) return rc;
   // the runs' scratch lives in the word sort's scratch, which is free by then, behind the plan header: per-workgroup run segments,
   // their counts, the long-run list and its (key, row) slices
-  const size_t long_cap = (size_t)n / (OM_SMALL + 1) + 1;
-  const size_t lneed    = round256(gx_sort_plan_bytes()) + round256(((size_t)n / 2 + (size_t)OM_FIN_WGS * 2) * sizeof(unsigned int)) +
-                          round256((size_t)OM_FIN_WGS * sizeof(RunSeg)) + round256(long_cap * sizeof(LongRun)) + round256((size_t)n * 8) + round256((size_t)n * 4);
+  const FinGeo g     = fin_geometry(n);
+  const size_t lneed = round256(gx_sort_plan_bytes()) + round256((size_t)g.wgs * g.seg_cap * sizeof(unsigned int)) +
+                       round256((size_t)g.wgs * sizeof(RunSeg)) + 2 * round256(g.long_cap * sizeof(LongRun)) + round256((size_t)n * 8) + round256((size_t)n * 4);
   if (lneed > inner) inner = lneed;
   Carver c(tmp);
   L.inner       = c.take<char>(inner);  // FIRST: the word sort's plan header -- its status word -- is what gx_sort_status(tmp) reads
   L.inner_bytes = inner;
-  L.plan        = c.take<OmPlan>(1);
+  L.plan        = c.take<OmPlan>((size_t)nplans);
   L.samp        = c.take<uint64_t>(OM_S);
   L.words       = c.take<uint64_t>((size_t)n);
   L.sorted      = c.take<uint64_t>((size_t)n);
   L.total       = c.total();
   return 0;
+}
+
+// the run scratch inside the (dead) word-sort scratch
+struct RunScratch {
+  unsigned int* heads;
+  RunSeg* segs;
+  LongRun* longlist;
+  LongRun* wglist;
+  uint64_t* gk;
+  uint32_t* gr;
+};
+static RunScratch run_scratch(const Layout& L, const FinGeo& g, int64_t n)
+{
+  RunScratch r;
+  char* lbase = L.inner + round256(gx_sort_plan_bytes());
+  r.heads     = reinterpret_cast<unsigned int*>(lbase);
+  r.segs      = reinterpret_cast<RunSeg*>(lbase + round256((size_t)g.wgs * g.seg_cap * sizeof(unsigned int)));
+  r.longlist  = reinterpret_cast<LongRun*>(reinterpret_cast<char*>(r.segs) + round256((size_t)g.wgs * sizeof(RunSeg)));
+  r.wglist    = reinterpret_cast<LongRun*>(reinterpret_cast<char*>(r.longlist) + round256(g.long_cap * sizeof(LongRun)));
+  r.gk        = reinterpret_cast<uint64_t*>(reinterpret_cast<char*>(r.wglist) + round256(g.long_cap * sizeof(LongRun)));
+  r.gr        = reinterpret_cast<uint32_t*>(reinterpret_cast<char*>(r.gk) + round256((size_t)n * 8));
+  return r;
 }
 
 template <int KIND>
@@ -607,7 +877,7 @@ static int sorted_order_words(const void* keys, int64_t n, int descending, int32
     GX_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(k_om_plan), hipFuncAttributeMaxDynamicSharedMemorySize, OM_S * 8));
     GX_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(k_om_map<KIND>), hipFuncAttributeMaxDynamicSharedMemorySize, OM_B * 28 + OM_LUT * 2 + 64));
     GX_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(k_om_count<KIND>), hipFuncAttributeMaxDynamicSharedMemorySize, OM_B * 16 + OM_LUT * 2 + 64));
-    GX_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(k_om_long<KIND>), hipFuncAttributeMaxDynamicSharedMemorySize, OM_LDSRUN * 12));
+    GX_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(k_om_long<OneCol<KIND>>), hipFuncAttributeMaxDynamicSharedMemorySize, OM_LDSRUN * 12));
     int dev = 0;
     GX_HIP_TRY(hipGetDevice(&dev));
     GX_HIP_TRY(hipDeviceGetAttribute(&num_cus, hipDeviceAttributeMultiprocessorCount, dev));
@@ -623,21 +893,94 @@ static int sorted_order_words(const void* keys, int64_t n, int descending, int32
   rc         = gx_sort_keys(GX_UINT64, L.words, L.sorted, n, 0, L.inner, &ib2, s);
   if (rc) return rc;
   // (behind the word sort its scratch is dead: the long-run list and slices alias it, past the plan header whose status word stays)
-  char* lbase              = L.inner + round256(gx_sort_plan_bytes());
-  const size_t long_cap    = (size_t)n / (OM_SMALL + 1) + 1;
-  const int64_t chunk      = ((n + OM_FIN_WGS - 1) / OM_FIN_WGS + 511) / 512 * 512;  // rows per workgroup of the finish passes
-  const unsigned int seg_cap = (unsigned int)(chunk / 2 + 1);
-  unsigned int* heads      = reinterpret_cast<unsigned int*>(lbase);
-  RunSeg* segs             = reinterpret_cast<RunSeg*>(lbase + round256(((size_t)n / 2 + (size_t)OM_FIN_WGS * 2) * sizeof(unsigned int)));
-  LongRun* longlist        = reinterpret_cast<LongRun*>(reinterpret_cast<char*>(segs) + round256((size_t)OM_FIN_WGS * sizeof(RunSeg)));
-  uint64_t* gk             = reinterpret_cast<uint64_t*>(reinterpret_cast<char*>(longlist) + round256(long_cap * sizeof(LongRun)));
-  uint32_t* gr             = reinterpret_cast<uint32_t*>(reinterpret_cast<char*>(gk) + round256((size_t)n * 8));
-  hipLaunchKernelGGL(k_om_finish_a, dim3(OM_FIN_WGS), dim3(256), 0, s, (const uint64_t*)L.sorted, n, (const OmPlan*)L.plan, out, heads, segs, chunk, seg_cap);
-  hipLaunchKernelGGL((k_om_finish_b<KIND>), dim3(OM_FIN_WGS), dim3(256), 0, s, (const uint64_t*)L.sorted, n, k, desc_mask, L.plan, out, (const unsigned int*)heads,
-                     (const RunSeg*)segs, seg_cap, longlist, (unsigned int)long_cap);
-  hipLaunchKernelGGL((k_om_long<KIND>), dim3(cus), dim3(1024), OM_LDSRUN * 12, s, (const uint64_t*)L.sorted, k, desc_mask, (const OmPlan*)L.plan, out,
-                     (const LongRun*)longlist, (unsigned int)long_cap, gk, gr);
+  const FinGeo g     = fin_geometry(n);
+  const RunScratch R = run_scratch(L, g, n);
+  hipLaunchKernelGGL(k_om_finish_a, dim3(g.wgs), dim3(256), 0, s, (const uint64_t*)L.sorted, n, (const OmPlan*)L.plan, out, R.heads, R.segs, g.chunk, g.seg_cap);
+  const OneCol<KIND> pol{k, desc_mask};
+  hipLaunchKernelGGL((k_om_finish_b<OneCol<KIND>>), dim3(g.wgs), dim3(256), 0, s, (const uint64_t*)L.sorted, n, pol, L.plan, out, (const unsigned int*)R.heads,
+                     (const RunSeg*)R.segs, g.seg_cap, R.longlist, (unsigned int)g.long_cap);
+  hipLaunchKernelGGL((k_om_medium<OneCol<KIND>>), dim3(cus * 8), dim3(256), 0, s, (const uint64_t*)L.sorted, pol, L.plan, (const LongRun*)R.longlist, (unsigned int)g.long_cap, R.wglist);
+  hipLaunchKernelGGL((k_om_long<OneCol<KIND>>), dim3(cus), dim3(1024), OM_LDSRUN * 12, s, (const uint64_t*)L.sorted, pol, (const OmPlan*)L.plan, out,
+                     (const LongRun*)R.wglist, (unsigned int)g.long_cap, R.gk, R.gr);
   if (KIND == K_FLOAT && descending) hipLaunchKernelGGL(k_om_reverse_nans, dim3(cus), dim3(256), 0, s, out, (const OmPlan*)L.plan);
+  GX_LAUNCH_CHECK();
+  return 0;
+}
+
+static int col_desc(int dtype, const void* data, int descending, ColDesc& c)
+{
+  c.data = data;
+  switch (dtype) {
+    case GX_INT8: c.kind = K_SIGNED; c.width = 1; break;
+    case GX_INT16: c.kind = K_SIGNED; c.width = 2; break;
+    case GX_INT32: c.kind = K_SIGNED; c.width = 4; break;
+    case GX_INT64: c.kind = K_SIGNED; c.width = 8; break;
+    case GX_UINT8: case GX_BOOL8: c.kind = K_UNSIGNED; c.width = 1; break;
+    case GX_UINT16: c.kind = K_UNSIGNED; c.width = 2; break;
+    case GX_UINT32: c.kind = K_UNSIGNED; c.width = 4; break;
+    case GX_UINT64: c.kind = K_UNSIGNED; c.width = 8; break;
+    case GX_FLOAT32: c.kind = K_FLOAT; c.width = 4; break;
+    case GX_FLOAT64: c.kind = K_FLOAT; c.width = 8; break;
+    default: return GX_EDTYPE;
+  }
+  c.desc_mask = descending ? (c.width == 8 ? ~0ull : ((1ull << (8 * c.width)) - 1)) : 0ull;
+  return 0;
+}
+
+static int sorted_order_table(int ncols, const int* dtypes, const void* const* cols, const int* descending, int64_t n, int32_t* out, void* tmp,
+                              size_t* tmp_bytes, hipStream_t s)
+{
+  Layout L;
+  int rc = layout(tmp, n, L, ncols);
+  if (rc) return rc;
+  if (!tmp) {
+    *tmp_bytes = L.total;
+    return 0;
+  }
+  if (*tmp_bytes < L.total) return GX_ETMP;
+  if (!out || !dtypes || !cols) return GX_EINVAL;
+  TableDesc t;
+  t.ncols = ncols;
+  for (int c = 0; c < ncols; ++c) {
+    if (!cols[c]) return GX_EINVAL;
+    rc = col_desc(dtypes[c], cols[c], descending ? descending[c] : 0, t.c[c]);
+    if (rc) return rc;
+  }
+  int ib = 1;
+  while (((int64_t)1 << ib) < n) ++ib;
+  static std::atomic<bool> attr_set{false};
+  static int num_cus = 0;
+  if (!attr_set) {
+    GX_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(k_om_plan), hipFuncAttributeMaxDynamicSharedMemorySize, OM_S * 8));
+    GX_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(k_omt_map), hipFuncAttributeMaxDynamicSharedMemorySize, OM_B * 28 + OM_LUT * 2 + 64));
+    GX_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(k_omt_count), hipFuncAttributeMaxDynamicSharedMemorySize, OM_B * 16 + OM_LUT * 2 + 64));
+    GX_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(k_om_long<Tuple>), hipFuncAttributeMaxDynamicSharedMemorySize, OM_LDSRUN * 12));
+    int dev = 0;
+    GX_HIP_TRY(hipGetDevice(&dev));
+    GX_HIP_TRY(hipDeviceGetAttribute(&num_cus, hipDeviceAttributeMultiprocessorCount, dev));
+    attr_set = true;
+  }
+  const unsigned cus = (unsigned)(num_cus > 0 ? num_cus : 256);
+  for (int c = ncols - 1; c >= 0; --c) {  // from the last column to the leading one: each level reads the fraction the level behind it left
+    OmPlan* P = L.plan + c;
+    hipLaunchKernelGGL(k_omt_sample, dim3(OM_S / 256), dim3(256), 0, s, t.c[c], n, L.samp);
+    hipLaunchKernelGGL(k_om_plan, dim3(1), dim3(1024), OM_S * 8, s, (const uint64_t*)L.samp, P, c == 0 ? ib : 0, n);
+    hipLaunchKernelGGL(k_omt_count, dim3(cus), dim3(256), OM_B * 16 + OM_LUT * 2 + 64, s, t.c[c], n, P);
+    hipLaunchKernelGGL(k_om_plan2, dim3(1), dim3(1024), 0, s, P);
+    hipLaunchKernelGGL(k_omt_map, dim3(cus), dim3(1024), OM_B * 28 + OM_LUT * 2 + 64, s, t.c[c], n, (const OmPlan*)P, L.words, c == ncols - 1 ? 1 : 0, c == 0 ? 1 : 0);
+  }
+  size_t ib2 = L.inner_bytes;
+  rc         = gx_sort_keys(GX_UINT64, L.words, L.sorted, n, 0, L.inner, &ib2, s);
+  if (rc) return rc;
+  const FinGeo g     = fin_geometry(n);
+  const RunScratch R = run_scratch(L, g, n);
+  hipLaunchKernelGGL(k_om_finish_a, dim3(g.wgs), dim3(256), 0, s, (const uint64_t*)L.sorted, n, (const OmPlan*)L.plan, out, R.heads, R.segs, g.chunk, g.seg_cap);
+  const Tuple pol{t};
+  hipLaunchKernelGGL((k_om_finish_b<Tuple>), dim3(g.wgs), dim3(256), 0, s, (const uint64_t*)L.sorted, n, pol, L.plan, out, (const unsigned int*)R.heads,
+                     (const RunSeg*)R.segs, g.seg_cap, R.longlist, (unsigned int)g.long_cap);
+  hipLaunchKernelGGL((k_om_medium<Tuple>), dim3(cus * 8), dim3(256), 0, s, (const uint64_t*)L.sorted, pol, L.plan, (const LongRun*)R.longlist, (unsigned int)g.long_cap, R.wglist);
+  hipLaunchKernelGGL((k_om_long<Tuple>), dim3(cus), dim3(1024), OM_LDSRUN * 12, s, (const uint64_t*)L.sorted, pol, (const OmPlan*)L.plan, out, (const LongRun*)R.wglist,
+                     (unsigned int)g.long_cap, R.gk, R.gr);
   GX_LAUNCH_CHECK();
   return 0;
 }
@@ -666,6 +1009,18 @@ int gx_sorted_order_words(int dtype, const void* keys, int64_t n, int descending
     case GX_FLOAT64: return sorted_order_words<gx::K_FLOAT>(keys, n, descending, out, tmp, tmp_bytes, st);
     default: return GX_EDTYPE;
   }
+}
+
+// cudf::sorted_order / stable_sorted_order of a table of 1 <= ncols <= 8 numeric columns without nulls (see "Several key columns" above)
+int gx_sorted_order_table(int ncols, const int* dtypes, const void* const* cols, const int* descending, int64_t n, int32_t* out, void* tmp,
+                          size_t* tmp_bytes, gx_stream_t s)
+{
+  if (n < 0 || n > 0x7FFFFFFFll || !tmp_bytes || ncols < 1 || ncols > gx::order::OMT_MAXCOLS) return GX_EINVAL;
+  if (n == 0) {
+    if (!tmp) *tmp_bytes = 256;
+    return 0;
+  }
+  return gx::order::sorted_order_table(ncols, dtypes, cols, descending, n, out, tmp, tmp_bytes, (hipStream_t)s);
 }
 
 // state of the last run that used `tmp`: info[0] = runs that went to the long list, [1] = list overflow (never), [2] = row bits, [3] = rank

@@ -9,7 +9,7 @@ Every function here only validates, allocates (torch as the device allocator) an
 from __future__ import annotations
 
 import ctypes
-from typing import List, Optional, Sequence, Tuple
+from typing import List, Optional, Sequence, Tuple, Union
 
 import numpy as np
 import torch
@@ -88,6 +88,34 @@ def sorted_order(col: Column, ascending: bool = True, null_before: bool = True) 
 
 
 stable_sorted_order = sorted_order
+
+
+def sorted_order_table(cols: Sequence[Column], ascending: Union[bool, Sequence[bool]] = True) -> Column:
+    """cudf::sorted_order / stable_sorted_order of a table of numeric columns WITHOUT nulls (src/sort/sort_impl.cuh:61-93): the
+    lexicographic order of the rows, stable; NaN equivalent and greatest in every column.  One word sort on a nested rank of the tuple
+    (gx_sorted_order_table, cudf_amd/csrc/gx_order.hip) instead of one argsort + two random gathers per column."""
+    cols = list(cols)
+    if not 1 <= len(cols) <= 8:
+        raise ValueError("sorted_order_table: 1 to 8 key columns")
+    n = cols[0].size
+    asc = [ascending] * len(cols) if isinstance(ascending, bool) else list(ascending)
+    if len(asc) != len(cols):
+        raise ValueError("Mismatch between number of columns and column order.")  # sort_impl.cuh:43-46
+    for c in cols:
+        if c.size != n:
+            raise ValueError("sorted_order_table: columns of different lengths")
+        if c.has_nulls():
+            raise NotImplementedError("sorted_order_table: columns with nulls take the per-column path (DataFrame.sort_values)")
+    out = Column.empty(np.int32, n)
+    if n == 0:
+        return out
+    k = len(cols)
+    dtypes = (ctypes.c_int * k)(*[c.gx for c in cols])
+    datas = (ctypes.c_void_p * k)(*[c.data_ptr for c in cols])
+    desc = (ctypes.c_int * k)(*[int(not a) for a in asc])
+    tmp = _run_sort(_lib.gx_sorted_order_table, k, dtypes, datas, desc, n, out.data_ptr)
+    _check_sort_status(tmp)
+    return out
 
 
 def sort_by_key(values: Sequence[Column], keys: Column, ascending: bool = True,

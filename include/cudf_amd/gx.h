@@ -104,6 +104,15 @@ int gx_sorted_order(int dtype, const void* keys, const uint32_t* valid, int64_t 
                     int descending, int nulls_before, int32_t* out_indices, void* tmp, size_t* tmp_bytes,
                     gx_stream_t stream);
 
+/* cudf::sorted_order / stable_sorted_order of a TABLE of 1 <= ncols <= 8 numeric columns without nulls: replaces thrust::sort /
+ * thrust::stable_sort of the row indices under the lexicographic row comparator (src/sort/sort_impl.cuh:61-93; src/sort/sort.cu:22-50).
+ * cols[c] / dtypes[c] / descending[c] (NULL = all ascending) are HOST arrays of ncols entries; the columns are device buffers of n rows.
+ * Stable (ties of the whole tuple in row order); NaN equivalent to each other and greater than every number in both directions,
+ * -0.0 == +0.0 (include/cudf/detail/row_operator/common_utils.cuh:157-169).  One keys-only word sort on a nested rank of the tuple plus
+ * a pass over the runs of equal ranks (gx_order.hip); gx_sort_status(tmp) reports the word sort's status. */
+int gx_sorted_order_table(int ncols, const int* dtypes, const void* const* cols, const int* descending, int64_t n, int32_t* out_indices,
+                          void* tmp, size_t* tmp_bytes, gx_stream_t stream);
+
 /* Copies the device-side status word of the last sort that used `tmp` to *status_host (0 = ok).  Synchronises `stream`.
  * 5: a look-back wait made no progress for 30 s of wall-clock time (gx_sort_set_spin_limit_ms) and was abandoned -- the output is
  * NOT sorted (every write stayed inside it); 3: a bookkeeping mismatch of the hybrid path, the LSD passes produced the output. */

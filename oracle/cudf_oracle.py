@@ -121,6 +121,24 @@ def sort_keys(values: np.ndarray, ascending: bool = True) -> np.ndarray:
     return np.asarray(values)[sorted_order(values, None, ascending)]
 
 
+def sorted_order_table(cols: Sequence[np.ndarray], ascending=True) -> np.ndarray:
+    """cudf::stable_sorted_order of a TABLE of numeric columns without nulls -> int32 row indices: the row indices sorted (stably) under
+    the lexicographic row comparator (cpp/src/sort/sort_impl.cuh:61-93: thrust::stable_sort of the sequence with
+    row::lexicographic::self_comparator).  Per column the element order of the comparator path: NaN equivalent to each other and greater
+    than every number, -0.0 == +0.0 (cpp/include/cudf/detail/row_operator/common_utils.cuh:157-169), reversed as a whole for a
+    DESCENDING column (so NaN first) -- NOT the single-column radix path's reverse-row-order rule for NaN.  cudf::sorted_order (the
+    unstable entry point) may order tied rows any way; the product is stable, which satisfies both."""
+    cols = [np.asarray(c) for c in cols]
+    asc = [ascending] * len(cols) if isinstance(ascending, bool) else list(ascending)
+    assert len(asc) == len(cols) and len(cols) >= 1
+    keys = []
+    for c, a in zip(cols, asc):
+        b = sortable_bits(c)
+        keys.append(b if a else ~b)
+    # np.lexsort: the LAST key is the primary one; it is stable (equal tuples keep their input order)
+    return np.lexsort(tuple(reversed(keys))).astype(np.int32)
+
+
 def sort_by_key(values: Sequence[np.ndarray], keys: np.ndarray, key_valid=None, ascending=True,
                 null_before=True):
     """cudf::sort_by_key = gather(values, sorted_order(keys)) (cpp/src/sort/sort.cu:31-50)."""

@@ -158,6 +158,25 @@ int shim_segmented_sorted_order(int ncols, const int* dtypes_host, const void* c
   });
 }
 
+// cudf::sorted_order / stable_sorted_order of a key table (reference cpp/src/sort/sort_impl.cuh:31-95, sort.cu:22-29, stable_sort.cu)
+int shim_table_sorted_order(int ncols, const int* dtypes_host, const void* const* datas_host, const uint32_t* const* valids_host,
+                            const int* nulls_host, int n, const int* descending_host, const int* nulls_before_host, int stable, int32_t* out)
+{
+  return guarded([&] {
+    std::vector<cudf::column_view> cols;
+    std::vector<cudf::order> ord;
+    std::vector<cudf::null_order> prec;
+    for (int i = 0; i < ncols; ++i) {
+      cols.push_back(view(dtypes_host[i], datas_host[i], valids_host ? valids_host[i] : nullptr, n, nulls_host ? nulls_host[i] : 0));
+      ord.push_back(descending_host[i] ? cudf::order::DESCENDING : cudf::order::ASCENDING);
+      prec.push_back(nulls_before_host && !nulls_before_host[i] ? cudf::null_order::AFTER : cudf::null_order::BEFORE);
+    }
+    auto r = stable ? cudf::stable_sorted_order(cudf::table_view{cols}, ord, prec) : cudf::sorted_order(cudf::table_view{cols}, ord, prec);
+    emit(r->view(), out, nullptr, nullptr);
+    shim_sync();
+  });
+}
+
 // cudf::groupby::groupby(keys, null_policy, sorted).aggregate({values, {agg}}) with ONE key column.
 // force_sort != 0 adds an NTH_ELEMENT(0) aggregation to the request, the way the reference's tests force the
 // sort-based path (cpp/tests/groupby/groupby_test_util.hpp force_use_sort_impl).  out_* have room for n groups.

@@ -57,6 +57,15 @@ SORT = [
          expected=[5, 11, 0, 14, 7, 8, 6, 4, 10, 1, 2, 3, 9, 12, 13], compare="indices"),
 ]
 
+# several key columns (the reference's tables carry a strings column between the two numeric ones; its order {a, d, d, e, k} agrees
+# with the first numeric column's, so the numeric columns alone give the same expected order)
+SORT_TABLE = [
+    # sort/sort_test.cpp:148-175  Sort.WithAllValid: col1 ASC, col3 DESC
+    dict(name="table_all_valid", cols=[[5, 4, 3, 5, 8], [10, 40, 70, 5, 2]], ascending=[True, False], expected=[2, 1, 0, 3, 4]),
+    # sort/stable_sort_tests.cpp:150-171  StableSort.WithAllValid: rows 0 and 3 tie in every column -> input order
+    dict(name="table_all_valid_stable_tie", cols=[[5, 4, 3, 5, 8], [10, 40, 70, 10, 2]], ascending=[True, False], expected=[2, 1, 0, 3, 4]),
+]
+
 # ---------------------------------------------------------------------------------------------
 # hash join.  left/right: list of key columns (each a list, None = null element);
 # expected_rows: multiset of (left payload..., right payload...) rows of the reference's gold

@@ -128,6 +128,39 @@ def test_a_density_spike_the_sample_cannot_see_goes_through_the_long_run_list(gx
         assert info[0] >= 3 and info[1] == 0
 
 
+@pytest.mark.parametrize("copies", [3, 100, 3000])
+def test_wide_keys_with_duplicates(gx, copies):
+    """Random 64-bit ids, `copies` rows each (a foreign-key column of hashed ids): every bucket is lossy, every id is ONE run of equal
+    keys -- up to 16 rows the run pass's threads, beyond that the listed runs, which one WAVE each finds in order (k_om_medium: no
+    workgroup, no network; a first version gave each of the n / 100 runs a workgroup).  Also multiples of 2^20 (few far-apart values)."""
+    rng = np.random.default_rng(12 + copies)
+    ids = rng.integers(-2**63, 2**63 - 1, N // copies + 1, dtype=np.int64)
+    v = ids[rng.integers(0, ids.size, N)]
+    w = rng.integers(0, N // copies + 1, N, dtype=np.int64) << 20
+    for keys in (v, w):
+        for desc in (False, True):
+            got, info = _order(gx, keys, desc)
+            np.testing.assert_array_equal(got, c_oracle.sorted_order_i64(keys, descending=desc).astype(np.int32))
+            assert info[1] == 0 and (copies > 100 or info[4] > 3000), info   # (13 000 ids of 3000 rows: most buckets hold ONE id, lossless)
+            if copies == 100:
+                assert info[0] > 300_000, info   # the runs WERE listed
+
+
+def test_listed_runs_out_of_order_reach_the_workgroup_pass(gx):
+    """Runs of 17 - 128 DISTINCT keys under one rank (consecutive integers inside uniform 64-bit keys), rows shuffled: the wave pass marks
+    them, the workgroup pass sorts them"""
+    rng = np.random.default_rng(77)
+    v = rng.integers(-2**63, 2**63 - 1, N, dtype=np.int64)
+    for j in range(2000):
+        cnt = int(rng.integers(17, 129))
+        pos = rng.choice(N, cnt, replace=False)
+        v[pos] = int(rng.integers(-2**62, 2**62)) + rng.permutation(cnt)
+    for desc in (False, True):
+        got, info = _order(gx, v, desc)
+        np.testing.assert_array_equal(got, c_oracle.sorted_order_i64(v, descending=desc).astype(np.int32))
+        assert info[0] >= 1500 and info[1] == 0
+
+
 def test_knob_off_is_the_round3_pairs_path_and_agrees(gx):
     Column, ops, L = gx
     rng = np.random.default_rng(4)

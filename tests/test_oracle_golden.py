@@ -28,6 +28,18 @@ def test_sort_golden(case):
         assert out.tobytes() == vals[exp].tobytes()
 
 
+@pytest.mark.parametrize("case", gv.SORT_TABLE, ids=lambda c: c["name"])
+@pytest.mark.parametrize("dtype", ["int8", "int32", "int64", "uint16", "uint64", "float32", "float64"])
+def test_sort_table_golden(case, dtype):
+    cols = [np.array(c, dtype) for c in case["cols"]]
+    np.testing.assert_array_equal(orc.sorted_order_table(cols, case["ascending"]), np.array(case["expected"], np.int32))
+    # the lexicographic order is what LSD over the columns with the single-column oracle gives (no NaN here)
+    order = np.arange(len(cols[0]))
+    for c, a in reversed(list(zip(cols, case["ascending"]))):
+        order = order[orc.sorted_order(c[order], None, a)]
+    np.testing.assert_array_equal(order, case["expected"])
+
+
 def _cols(lists, dtype):
     cols, masks = [], []
     for c in lists:
