@@ -209,26 +209,58 @@ __global__ void __launch_bounds__(256) k_gather_global_rows_dev(const int32_t* _
 // Encoded global rows of the sharded join -> int64: enc = (source rank << shift) | row.  With `snap` (pair positions at which
 // the probe of each chunk started, nchunks + 1 entries) the row counts inside the SENDER's chunk: global = base[src] +
 // chunk * chunk_rows[src] + row; without it, global = base[src] + row.  Streaming: no gather, no random access.
+// (round 6: the chunk positions -- <= 1024 -- staged in LDS, two pairs per lane per access; one element per trip with the binary
+// search's loads from global memory behind each other took 0.8 - 1.7 ms per 3e8 pairs, twice per probe call)
+constexpr int DEC_MAXCH = 1024;
 __global__ void __launch_bounds__(256) k_decode_global_rows(const int32_t* __restrict__ enc, int64_t n, int shift,
                                                             const long long* __restrict__ bases, const long long* __restrict__ chunk_rows,
                                                             const long long* __restrict__ snap, int nchunks, long long* __restrict__ out)
 {
-  const int64_t stride = (int64_t)gridDim.x * 256;
-  const uint32_t mask  = (1u << shift) - 1u;
-  for (int64_t j = (int64_t)blockIdx.x * 256 + threadIdx.x; j < n; j += stride) {
-    const uint32_t e = (uint32_t)enc[j];
-    const uint32_t s = e >> shift;
-    long long g      = bases[s] + (long long)(e & mask);
-    if (snap) {
-      int lo = 0, hi = nchunks;  // the chunk c with snap[c] <= j < snap[c + 1]
-      while (hi - lo > 1) {
-        const int mid = (lo + hi) >> 1;
-        if (snap[mid] <= j) lo = mid; else hi = mid;
-      }
-      g += (long long)lo * chunk_rows[s];
+  __shared__ long long s_snap[DEC_MAXCH + 1];
+  if (snap)
+    for (int i = threadIdx.x; i <= nchunks; i += 256) s_snap[i] = snap[i];
+  __syncthreads();
+  const uint32_t mask = (1u << shift) - 1u;
+  auto chunk_of = [&](int64_t j) -> int {  // the chunk c with snap[c] <= j < snap[c + 1]
+    int lo = 0, hi = nchunks;
+    while (hi - lo > 1) {
+      const int mid = (lo + hi) >> 1;
+      if (s_snap[mid] <= j) lo = mid; else hi = mid;
     }
-    out[j] = g;
+    return lo;
+  };
+  auto decode = [&](uint32_t e, int c) -> long long {
+    const uint32_t s = e >> shift;
+    return bases[s] + (long long)(e & mask) + (snap ? (long long)c * chunk_rows[s] : 0ll);  // (<= 16 ranks: the tables stay in the L1)
+  };
+  // two pairs per lane per access: an 8-byte load and ONE 16-byte store, contiguous across the wave (four per lane as two 16-byte stores
+  // left every 64-byte line to two instructions: 2.0 ms per 3e8 pairs against 0.8), two such accesses in flight per trip
+  const int64_t nh     = n / 2;
+  const int64_t stride = (int64_t)gridDim.x * 256;
+  typedef int32_t i32x2 __attribute__((ext_vector_type(2)));
+  typedef long long i64x2 __attribute__((ext_vector_type(2)));
+  const bool aligned = ((reinterpret_cast<uintptr_t>(enc) & 7u) | (reinterpret_cast<uintptr_t>(out) & 15u)) == 0;
+  auto two = [&](int64_t h, i32x2 e) {
+    const int64_t j = h * 2;
+    int c0 = 0, c1 = 0;
+    if (snap) {
+      c0 = chunk_of(j);
+      c1 = j + 1 < s_snap[c0 + 1] ? c0 : chunk_of(j + 1);  // (c0 + 1 <= nchunks; snap[nchunks] = the number of pairs)
+    }
+    *reinterpret_cast<i64x2*>(out + j) = i64x2{decode((uint32_t)e.x, c0), decode((uint32_t)e.y, c1)};
+  };
+  if (aligned) {
+    for (int64_t h = (int64_t)blockIdx.x * 256 + threadIdx.x; h < nh; h += 2 * stride) {
+      const int64_t h2 = h + stride;
+      const i32x2 ea   = *reinterpret_cast<const i32x2*>(enc + h * 2);
+      const i32x2 eb   = h2 < nh ? *reinterpret_cast<const i32x2*>(enc + h2 * 2) : i32x2{0, 0};
+      two(h, ea);
+      if (h2 < nh) two(h2, eb);
+    }
   }
+  // the last pair of an odd count (or everything, for buffers that are not aligned)
+  for (int64_t j = (aligned ? nh * 2 : 0) + (int64_t)blockIdx.x * 256 + threadIdx.x; j < n; j += stride)
+    out[j] = decode((uint32_t)enc[j], snap ? chunk_of(j) : 0);
 }
 __global__ void __launch_bounds__(256) k_widen_i32_i64(const int32_t* __restrict__ in, int64_t n, long long* __restrict__ out)
 {
@@ -256,7 +288,7 @@ int gx_gather_global_rows_dev(const int32_t* rows, int64_t nrows, const int32_t*
 int gx_decode_global_rows(const int32_t* enc, int64_t n, int shift, const int64_t* bases_dev, const int64_t* chunk_rows_dev,
                           const int64_t* snap_dev, int nchunks, int64_t* out, gx_stream_t s)
 {
-  if (n < 0 || shift < 1 || shift > 31 || !bases_dev || (snap_dev && (!chunk_rows_dev || nchunks < 1))) return GX_EINVAL;
+  if (n < 0 || shift < 1 || shift > 31 || !bases_dev || (snap_dev && (!chunk_rows_dev || nchunks < 1 || nchunks > gx::DEC_MAXCH))) return GX_EINVAL;
   if (n == 0) return 0;
   if (!enc || !out) return GX_EINVAL;
   int64_t blocks = gx::div_up(n, (int64_t)256 * 8);

@@ -2155,7 +2155,7 @@ struct PjRec {  // one partitioned probe row
   uint32_t klo, khi;
   int32_t row;
 };
-template <int RPT, bool EXACT, bool TAIL, bool AOS, typename F>
+template <int RPT, bool EXACT, bool TAIL, bool AOS, bool PAY, typename F>
 __global__ void __launch_bounds__(1024) k_pj2_scatter_rec(const uint64_t* __restrict__ keys, int64_t n, Pj2Plan* plan2, PjPlan* plan, int pbits,
                                                           int64_t rrows, uint32_t cap, int64_t ntiles, int64_t tile0_row,
                                                           PjRec* __restrict__ precs, F part_of, int32_t row0,
@@ -2182,6 +2182,8 @@ __global__ void __launch_bounds__(1024) k_pj2_scatter_rec(const uint64_t* __rest
   const bool owner = P > BTt || (int)threadIdx.x < P;
 
   K key[RPT];
+  int32_t pay[PAY ? RPT : 1];  // PAY: the rows' payloads (the sharded probe's encoded source rows) travel with the keys -- fetched inside the
+                               // window loop, under a divergent test, their latency lay bare: 8.4 ms per 1e9 rows against 5.5 without payload
   int64_t v = blockIdx.x;
   if (v >= ntiles) return;
   // TAIL: the tail launch -- ONE partial tile starting at row tile0_row (nvalid < TILE), always in the last range; otherwise every
@@ -2203,6 +2205,7 @@ __global__ void __launch_bounds__(1024) k_pj2_scatter_rec(const uint64_t* __rest
     for (int j = 0; j < RPT; ++j) {
       const int idx = j * BTt + (int)tid;
       key[j]        = __builtin_nontemporal_load(&keys[b + (idx < nv ? idx : 0)]);
+      if (PAY) pay[j] = __builtin_nontemporal_load(&payload[b + (idx < nv ? idx : 0)]);
     }
   };
   int64_t base;
@@ -2282,7 +2285,7 @@ __global__ void __launch_bounds__(1024) k_pj2_scatter_rec(const uint64_t* __rest
         const unsigned int l = (j & 1) ? lpos2[j / 2] >> 16 : lpos2[j / 2] & 0xFFFFu;
         if ((int)(l / WIN) == q) {  // (0xFFFF / WIN = 7 is no window)
           s_k[l % WIN] = key[j];
-          s_i[l % WIN] = payload ? payload[base + j * BTt + (int)tid] : rowt + j * BTt;
+          s_i[l % WIN] = PAY ? pay[j] : rowt + j * BTt;
         }
       }
       if (q == NWIN - 1 && more) {  // the key registers are free: the next tile's keys land under the write-out
@@ -3806,18 +3809,30 @@ int probe_partitioned_impl2(const K* keys, int64_t n, const Slot<K>* slots, uint
     GX_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(kspec), hipFuncAttributeMaxDynamicSharedMemorySize, lds_max));
     GX_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(kexact), hipFuncAttributeMaxDynamicSharedMemorySize, lds_max));
     if constexpr (sizeof(K) == 8) {
-      GX_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(k_pj2_scatter_rec<16, false, false, true, F>), hipFuncAttributeMaxDynamicSharedMemorySize, lds_max));
-      GX_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(k_pj2_scatter_rec<16, false, true, true, F>), hipFuncAttributeMaxDynamicSharedMemorySize, lds_max));
-      GX_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(k_pj2_scatter_rec<16, true, false, true, F>), hipFuncAttributeMaxDynamicSharedMemorySize, lds_max));
-      GX_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(k_pj2_scatter_rec<16, true, true, true, F>), hipFuncAttributeMaxDynamicSharedMemorySize, lds_max));
-      GX_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(k_pj2_scatter_rec<16, false, false, false, F>), hipFuncAttributeMaxDynamicSharedMemorySize, lds_max));
-      GX_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(k_pj2_scatter_rec<16, false, true, false, F>), hipFuncAttributeMaxDynamicSharedMemorySize, lds_max));
-      GX_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(k_pj2_scatter_rec<16, true, false, false, F>), hipFuncAttributeMaxDynamicSharedMemorySize, lds_max));
-      GX_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(k_pj2_scatter_rec<16, true, true, false, F>), hipFuncAttributeMaxDynamicSharedMemorySize, lds_max));
-      GX_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(k_pj2_scatter_rec<24, false, false, true, F>), hipFuncAttributeMaxDynamicSharedMemorySize, lds_max));
-      GX_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(k_pj2_scatter_rec<24, false, true, true, F>), hipFuncAttributeMaxDynamicSharedMemorySize, lds_max));
-      GX_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(k_pj2_scatter_rec<24, true, false, true, F>), hipFuncAttributeMaxDynamicSharedMemorySize, lds_max));
-      GX_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(k_pj2_scatter_rec<24, true, true, true, F>), hipFuncAttributeMaxDynamicSharedMemorySize, lds_max));
+      GX_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(k_pj2_scatter_rec<16, false, false, true, false, F>), hipFuncAttributeMaxDynamicSharedMemorySize, lds_max));
+      GX_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(k_pj2_scatter_rec<16, false, false, true, true, F>), hipFuncAttributeMaxDynamicSharedMemorySize, lds_max));
+      GX_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(k_pj2_scatter_rec<16, false, true, true, false, F>), hipFuncAttributeMaxDynamicSharedMemorySize, lds_max));
+      GX_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(k_pj2_scatter_rec<16, false, true, true, true, F>), hipFuncAttributeMaxDynamicSharedMemorySize, lds_max));
+      GX_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(k_pj2_scatter_rec<16, true, false, true, false, F>), hipFuncAttributeMaxDynamicSharedMemorySize, lds_max));
+      GX_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(k_pj2_scatter_rec<16, true, false, true, true, F>), hipFuncAttributeMaxDynamicSharedMemorySize, lds_max));
+      GX_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(k_pj2_scatter_rec<16, true, true, true, false, F>), hipFuncAttributeMaxDynamicSharedMemorySize, lds_max));
+      GX_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(k_pj2_scatter_rec<16, true, true, true, true, F>), hipFuncAttributeMaxDynamicSharedMemorySize, lds_max));
+      GX_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(k_pj2_scatter_rec<16, false, false, false, false, F>), hipFuncAttributeMaxDynamicSharedMemorySize, lds_max));
+      GX_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(k_pj2_scatter_rec<16, false, false, false, true, F>), hipFuncAttributeMaxDynamicSharedMemorySize, lds_max));
+      GX_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(k_pj2_scatter_rec<16, false, true, false, false, F>), hipFuncAttributeMaxDynamicSharedMemorySize, lds_max));
+      GX_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(k_pj2_scatter_rec<16, false, true, false, true, F>), hipFuncAttributeMaxDynamicSharedMemorySize, lds_max));
+      GX_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(k_pj2_scatter_rec<16, true, false, false, false, F>), hipFuncAttributeMaxDynamicSharedMemorySize, lds_max));
+      GX_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(k_pj2_scatter_rec<16, true, false, false, true, F>), hipFuncAttributeMaxDynamicSharedMemorySize, lds_max));
+      GX_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(k_pj2_scatter_rec<16, true, true, false, false, F>), hipFuncAttributeMaxDynamicSharedMemorySize, lds_max));
+      GX_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(k_pj2_scatter_rec<16, true, true, false, true, F>), hipFuncAttributeMaxDynamicSharedMemorySize, lds_max));
+      GX_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(k_pj2_scatter_rec<24, false, false, true, false, F>), hipFuncAttributeMaxDynamicSharedMemorySize, lds_max));
+      GX_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(k_pj2_scatter_rec<24, false, false, true, true, F>), hipFuncAttributeMaxDynamicSharedMemorySize, lds_max));
+      GX_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(k_pj2_scatter_rec<24, false, true, true, false, F>), hipFuncAttributeMaxDynamicSharedMemorySize, lds_max));
+      GX_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(k_pj2_scatter_rec<24, false, true, true, true, F>), hipFuncAttributeMaxDynamicSharedMemorySize, lds_max));
+      GX_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(k_pj2_scatter_rec<24, true, false, true, false, F>), hipFuncAttributeMaxDynamicSharedMemorySize, lds_max));
+      GX_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(k_pj2_scatter_rec<24, true, false, true, true, F>), hipFuncAttributeMaxDynamicSharedMemorySize, lds_max));
+      GX_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(k_pj2_scatter_rec<24, true, true, true, false, F>), hipFuncAttributeMaxDynamicSharedMemorySize, lds_max));
+      GX_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(k_pj2_scatter_rec<24, true, true, true, true, F>), hipFuncAttributeMaxDynamicSharedMemorySize, lds_max));
       GX_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(k_pj2_probe_pipe<K, false, false, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_p));
       GX_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(k_pj2_probe_pipe<K, false, false, true, 1>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_p));
       GX_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(k_pj2_probe_pipe<K, false, false, true, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_p));
@@ -3835,6 +3850,7 @@ int probe_partitioned_impl2(const K* keys, int64_t n, const Slot<K>* slots, uint
   const int64_t ntiles = div_up(n, (int64_t)TILE);
   const int64_t rrows  = pj_range_rows(n, TILE);
   int64_t grid         = num_cus > 0 ? num_cus : 256;
+  if (((g_pj_xp >> 8) & 255) != 0) grid = ((g_pj_xp >> 8) & 255) * 4;  // measurement: bits 8-15 = workgroups of the partition pass / 4
   grid                 = grid / PJ_NR * PJ_NR;  // v % 8 must stay the XCD of a workgroup over its whole walk
   if (grid < PJ_NR) grid = PJ_NR;
   if (grid > ntiles) grid = ntiles;
@@ -3852,12 +3868,17 @@ int probe_partitioned_impl2(const K* keys, int64_t n, const Slot<K>* slots, uint
       PjRec* precs        = reinterpret_cast<PjRec*>(pkeys);
       const unsigned gf   = (unsigned)(grid < nfull ? grid : nfull);
       const int64_t tail0 = nfull * TILE;
-#define GX_PJ_REC(RPT_, EX_, AOS_)                                                                                                        \
-  do {                                                                                                                                    \
-    if (gf) hipLaunchKernelGGL((k_pj2_scatter_rec<RPT_, EX_, false, AOS_, F>), dim3(gf), dim3(1024), lds_s, s, k64, n, plan2, plan, pbits, \
-                               rrows, cap, nfull, (int64_t)0, precs, part_of, row0, payload, pidx);                                       \
-    if (tail0 < n) hipLaunchKernelGGL((k_pj2_scatter_rec<RPT_, EX_, true, AOS_, F>), dim3(1), dim3(1024), lds_s, s, k64, n, plan2, plan,   \
-                                      pbits, rrows, cap, (int64_t)1, tail0, precs, part_of, row0, payload, pidx);                         \
+#define GX_PJ_REC2(RPT_, EX_, AOS_, PAY_)                                                                                                       \
+  do {                                                                                                                                          \
+    if (gf) hipLaunchKernelGGL((k_pj2_scatter_rec<RPT_, EX_, false, AOS_, PAY_, F>), dim3(gf), dim3(1024), lds_s, s, k64, n, plan2, plan, pbits, \
+                               rrows, cap, nfull, (int64_t)0, precs, part_of, row0, payload, pidx);                                             \
+    if (tail0 < n) hipLaunchKernelGGL((k_pj2_scatter_rec<RPT_, EX_, true, AOS_, PAY_, F>), dim3(1), dim3(1024), lds_s, s, k64, n, plan2, plan,   \
+                                      pbits, rrows, cap, (int64_t)1, tail0, precs, part_of, row0, payload, pidx);                               \
+  } while (0)
+#define GX_PJ_REC(RPT_, EX_, AOS_)                              \
+  do {                                                          \
+    if (payload) GX_PJ_REC2(RPT_, EX_, AOS_, true);             \
+    else GX_PJ_REC2(RPT_, EX_, AOS_, false);                    \
   } while (0)
       if (rec24) {
         if (exact) GX_PJ_REC(24, true, true); else GX_PJ_REC(24, false, true);
@@ -3866,6 +3887,7 @@ int probe_partitioned_impl2(const K* keys, int64_t n, const Slot<K>* slots, uint
       } else {
         if (exact) GX_PJ_REC(16, true, false); else GX_PJ_REC(16, false, false);
       }
+#undef GX_PJ_REC2
 #undef GX_PJ_REC
     }
   };
@@ -3897,7 +3919,8 @@ int probe_partitioned_impl2(const K* keys, int64_t n, const Slot<K>* slots, uint
       const int64_t g = (int64_t)(num_cus > 0 ? num_cus : 256) * alt_wgs[pk - 2];
       hipLaunchKernelGGL(kalt, dim3((unsigned)g), dim3(alt_bt), alt_lds, s, pkeys, pidx, t, pbits, slots, lg, left_outer, out_probe, out_build, capacity, cur);
     } else {
-      const int64_t g = num_cus > 0 ? num_cus : 256;
+      int64_t g = num_cus > 0 ? num_cus : 256;
+      if (((g_pj_xp >> 16) & 255) != 0) g = ((g_pj_xp >> 16) & 255) * 4;  // measurement: bits 16-23 = workgroups of the probe / 4
       hipLaunchKernelGGL(kprobe, dim3((unsigned)g), dim3(PP_BT), lds_p, s, pkeys, pidx, t, pbits, slots, lg, left_outer, out_probe, out_build, capacity, cur);
     }
   };

@@ -600,7 +600,7 @@ __device__ __forceinline__ bool kr_less(const P& pol, uint64_t ka, uint32_t ra, 
   return ka < kb || (ka == kb && pol.rest_less(ra, rb));
 }
 
-constexpr unsigned int OM_WAVERUN = 128;  // listed runs up to this length are first LOOKED AT by one wave (two rows per lane): only those out of order go on
+constexpr unsigned int OM_WAVERUN = 128;  // listed runs up to this length belong to one wave (two rows per lane), longer ones to a workgroup
 
 // pass B: one thread per run head that pass A listed
 template <class P>
@@ -619,81 +619,117 @@ __global__ void __launch_bounds__(256) k_om_finish_b(const uint64_t* __restrict_
   const uint64_t imask   = (1ull << ib) - 1;
   const uint64_t bmask   = ~(1ull << 63);
   const unsigned int* mine = heads + (size_t)blockIdx.x * seg_cap;
-  for (unsigned int i = threadIdx.x; i < cnt; i += 256) {
-    const unsigned int p = mine[i];
-    const uint64_t w0 = sorted[p], w1 = sorted[p + 1];
-    const uint64_t r  = w0 >> ib;
-    if (P::kSkipLossless) {
-      int b = 0;
+  // Rounds of 256 heads.  Step 1, a thread per head: runs of 2 - 4 rows are put right on the spot (all loads issued at once, a network in
+  // registers), runs of 5 - 16 rows go to the round's list in LDS, longer ones to the global list.  Step 2, SIXTEEN LANES per listed run:
+  // a lane per row fetches its key, counts the rows of the run that come before it (16 shuffled compares) and writes its row there.
+  // (The first version kept step 2 in the thread -- an insertion sort over private arrays: dependent gathers one after the other and the
+  // arrays in scratch memory; ids of a dozen rows each, 8e7 such runs per 1e9 rows, took 99 ms in this kernel.)
+  __shared__ unsigned int s_mid[256];
+  __shared__ unsigned char s_midl[256];
+  __shared__ unsigned int s_nmid, s_nlong, s_lbase;
+  __shared__ LongRun s_long[256];
+  for (unsigned int base = 0; base < cnt; base += 256) {
+    if (threadIdx.x == 0) {
+      s_nmid  = 0;
+      s_nlong = 0;
+    }
+    __syncthreads();
+    const unsigned int i = base + threadIdx.x;
+    if (i < cnt) {
+      const unsigned int p = mine[i];
+      const uint64_t w0 = sorted[p], w1 = sorted[p + 1];
+      const uint64_t r  = w0 >> ib;
+      bool skip = false;
+      if (P::kSkipLossless) {
+        int b = 0;
 #pragma unroll
-      for (int step = OM_B / 2; step > 0; step >>= 1)
-        if ((s_bl[b + step] & bmask) <= r) b += step;
-      if (!(s_bl[b] >> 63)) continue;
-    }
-    int64_t q = (int64_t)p + 2;
-    while (q < n && (sorted[q] >> ib) == r) ++q;
-    const unsigned int L = (unsigned int)(q - p);
-    if (L == 2) {  // the common case, without the private arrays
-      const uint32_t r0 = (uint32_t)(w0 & imask), r1 = (uint32_t)(w1 & imask);
-      const uint64_t k0 = pol.key(r0), k1 = pol.key(r1);
-      if (kr_less(pol, k1, r1, k0, r0)) {  // (one column, equal keys: r0 < r1 already)
-        out[p]     = (int32_t)r1;
-        out[p + 1] = (int32_t)r0;
+        for (int step = OM_B / 2; step > 0; step >>= 1)
+          if ((s_bl[b + step] & bmask) <= r) b += step;
+        skip = !(s_bl[b] >> 63);
       }
-    } else if (L <= 4u) {  // three or four rows (ids with a few rows each): all loads issued at once, a five-comparator network in registers
-      const bool four = L == 4u;
-      uint32_t rr[4] = {(uint32_t)(w0 & imask), (uint32_t)(w1 & imask), (uint32_t)(sorted[p + 2] & imask), four ? (uint32_t)(sorted[p + 3] & imask) : 0u};
-      uint64_t kk[4] = {pol.key(rr[0]), pol.key(rr[1]), pol.key(rr[2]), four ? pol.key(rr[3]) : 0ull};
-      auto cx = [&](int a, int b) {  // the smaller of (a, b) to a
-        if (kr_less(pol, kk[b], rr[b], kk[a], rr[a])) {
-          const uint64_t tk = kk[a];
-          const uint32_t tr = rr[a];
-          kk[a] = kk[b];
-          rr[a] = rr[b];
-          kk[b] = tk;
-          rr[b] = tr;
+      if (!skip) {
+        int64_t q = (int64_t)p + 2;
+        while (q < n && (sorted[q] >> ib) == r) ++q;
+        const unsigned int L = (unsigned int)(q - p);
+        if (L == 2) {  // the common case
+          const uint32_t r0 = (uint32_t)(w0 & imask), r1 = (uint32_t)(w1 & imask);
+          const uint64_t k0 = pol.key(r0), k1 = pol.key(r1);
+          if (kr_less(pol, k1, r1, k0, r0)) {  // (one column, equal keys: r0 < r1 already)
+            out[p]     = (int32_t)r1;
+            out[p + 1] = (int32_t)r0;
+          }
+        } else if (L <= 4u) {
+          const bool four = L == 4u;
+          uint32_t rr[4] = {(uint32_t)(w0 & imask), (uint32_t)(w1 & imask), (uint32_t)(sorted[p + 2] & imask), four ? (uint32_t)(sorted[p + 3] & imask) : 0u};
+          uint64_t kk[4] = {pol.key(rr[0]), pol.key(rr[1]), pol.key(rr[2]), four ? pol.key(rr[3]) : 0ull};
+          auto cx = [&](int a, int b) {  // the smaller of (a, b) to a
+            if (kr_less(pol, kk[b], rr[b], kk[a], rr[a])) {
+              const uint64_t tk = kk[a];
+              const uint32_t tr = rr[a];
+              kk[a] = kk[b];
+              rr[a] = rr[b];
+              kk[b] = tk;
+              rr[b] = tr;
+            }
+          };
+          cx(0, 1);
+          if (four) cx(2, 3);
+          cx(0, 2);
+          if (four) cx(1, 3);
+          cx(1, 2);
+          out[p]     = (int32_t)rr[0];
+          out[p + 1] = (int32_t)rr[1];
+          out[p + 2] = (int32_t)rr[2];
+          if (four) out[p + 3] = (int32_t)rr[3];
+        } else if (L <= (unsigned)OM_SMALL) {
+          const unsigned int e = atomicAdd(&s_nmid, 1u);  // (at most 256 per round)
+          s_mid[e]  = p;
+          s_midl[e] = (unsigned char)L;
+        } else {
+          s_long[atomicAdd(&s_nlong, 1u)] = LongRun{p, L};  // (at most 256 per round)
         }
-      };
-      cx(0, 1);
-      if (four) cx(2, 3);
-      cx(0, 2);
-      if (four) cx(1, 3);
-      cx(1, 2);
-      out[p]     = (int32_t)rr[0];
-      out[p + 1] = (int32_t)rr[1];
-      out[p + 2] = (int32_t)rr[2];
-      if (four) out[p + 3] = (int32_t)rr[3];
-    } else if (L <= (unsigned)OM_SMALL) {
-      uint64_t kk[OM_SMALL];
-      uint32_t rr[OM_SMALL];
-      for (unsigned int j = 0; j < L; ++j) {  // rows arrive in ascending row order: a stable insertion keeps it among equal tuples
-        const uint32_t row = (uint32_t)(sorted[p + j] & imask);
-        const uint64_t key = pol.key(row);
-        int m = (int)j;
-        while (m > 0 && kr_less(pol, key, row, kk[m - 1], rr[m - 1])) {
-          kk[m] = kk[m - 1];
-          rr[m] = rr[m - 1];
-          --m;
-        }
-        kk[m] = key;
-        rr[m] = row;
       }
-      for (unsigned int j = 0; j < L; ++j) out[p + j] = (int32_t)rr[j];
-    } else {
-      const unsigned int e = atomicAdd(&plan->nlong, 1u);
-      if (e < long_cap) longlist[e] = LongRun{p, L};
-      else plan->long_overflow = 1u;  // cannot happen: long_cap = n / (OM_SMALL + 1) + 1 runs of more than OM_SMALL rows
     }
+    __syncthreads();
+    // the round's long runs: ONE reservation in the global list (a global atomic per run -- 1e7 runs of a hundred equal keys, all on one
+    // address at ~88 atomics / us -- was 114 ms of this kernel)
+    const unsigned int nlg = s_nlong;
+    if (nlg) {
+      if (threadIdx.x == 0) s_lbase = atomicAdd(&plan->nlong, nlg);
+      __syncthreads();
+      const unsigned int e = s_lbase + threadIdx.x;
+      if (threadIdx.x < nlg) {
+        if (e < long_cap) longlist[e] = s_long[threadIdx.x];
+        else plan->long_overflow = 1u;  // cannot happen: long_cap = n / (OM_SMALL + 1) + 1 runs of more than OM_SMALL rows
+      }
+    }
+    const unsigned int nmid = s_nmid;
+    const unsigned int j = threadIdx.x & 15u;
+    for (unsigned int e = threadIdx.x >> 4; e < nmid; e += 16) {
+      const unsigned int p = s_mid[e], L = s_midl[e];
+      const bool has     = j < L;
+      const uint32_t row = has ? (uint32_t)(sorted[p + j] & imask) : 0u;
+      const uint64_t key = has ? pol.key(row) : 0ull;
+      unsigned int pos   = 0;
+#pragma unroll
+      for (int t = 0; t < OM_SMALL; ++t) {
+        const uint64_t kt = __shfl(key, t, 16);
+        const uint32_t rt = __shfl(row, t, 16);
+        if (has && (unsigned)t < L && (unsigned)t != j && kr_less(pol, kt, rt, key, row)) ++pos;
+      }
+      if (has) out[p + pos] = (int32_t)row;
+    }
+    __syncthreads();  // (the next round resets the list)
   }
 }
 
 // ---- 6a. listed runs up to 128 rows: ONE WAVE looks at each -- two rows per lane, their keys fetched, neighbours compared through
 // shuffles.  A column of WIDE keys with DUPLICATES (a hundred rows per 64-bit id: the buckets are lossy, every id is one run of a
 // hundred equal keys) lists n / 100 runs that are all in order already; a workgroup and a sorting network for each took 0.5 s per 1e9
-// rows.  Runs found in order are done (pass A wrote their rows); the others -- and the runs beyond 128 rows -- go to the workgroup pass's list.
+// rows.  Runs found in order are done (pass A wrote their rows); the others are ranked inside the wave; runs beyond 128 rows go to the workgroup pass's list.
 template <class P>
 __global__ void __launch_bounds__(256) k_om_medium(const uint64_t* __restrict__ sorted, P pol, OmPlan* __restrict__ plan, const LongRun* __restrict__ longlist,
-                                                   unsigned int long_cap, LongRun* __restrict__ wglist)
+                                                   unsigned int long_cap, LongRun* __restrict__ wglist, int32_t* __restrict__ out)
 {
   const int ib         = plan->ib;
   const uint64_t imask = (1ull << ib) - 1;
@@ -704,8 +740,7 @@ __global__ void __launch_bounds__(256) k_om_medium(const uint64_t* __restrict__ 
   for (unsigned int e = wave; e < nl; e += nwaves) {
     const LongRun run = longlist[e];
     const unsigned int p0 = run.start, L = run.len;
-    bool bad = L > OM_WAVERUN;  // (wave-uniform) too long to look at here: the workgroup pass checks it itself
-    if (!bad) {
+    if (L <= OM_WAVERUN) {  // (wave-uniform; longer runs: the workgroup pass)
       const bool h0 = lane < L, h1 = lane + 64u < L;
       const uint32_t r0 = h0 ? (uint32_t)(sorted[p0 + lane] & imask) : 0u, r1 = h1 ? (uint32_t)(sorted[p0 + 64u + lane] & imask) : 0u;
       const uint64_t k0 = h0 ? pol.key(r0) : 0ull, k1 = h1 ? pol.key(r1) : 0ull;
@@ -720,9 +755,24 @@ __global__ void __launch_bounds__(256) k_om_medium(const uint64_t* __restrict__ 
       bool mine = false;
       if (lane + 1u < L) mine = kr_less(pol, nk0, nr0, k0, r0);                         // element lane + 1 before element lane?
       if (lane < 63u && lane + 65u < L) mine = mine || kr_less(pol, nk1, nr1, k1, r1);  // element lane + 65 before element lane + 64?
-      bad = ballot(mine) != 0ull;
+      if (ballot(mine) != 0ull) {
+        // out of order: every element counts the elements of the run that come before it (L broadcasts) and goes there
+        unsigned int pos0 = 0, pos1 = 0;
+        for (unsigned int t = 0; t < L; ++t) {
+          const unsigned int src = t & 63u;
+          const uint64_t ka = __shfl(k0, src), kb = __shfl(k1, src);
+          const uint32_t ra = __shfl(r0, src), rb = __shfl(r1, src);
+          const uint64_t kt = t < 64u ? ka : kb;
+          const uint32_t rt = t < 64u ? ra : rb;
+          if (h0 && t != lane && kr_less(pol, kt, rt, k0, r0)) ++pos0;
+          if (h1 && t != lane + 64u && kr_less(pol, kt, rt, k1, r1)) ++pos1;
+        }
+        if (h0) out[p0 + pos0] = (int32_t)r0;
+        if (h1) out[p0 + pos1] = (int32_t)r1;
+      }
+    } else if (lane == 0u) {
+      wglist[atomicAdd(&plan->nwg, 1u)] = run;  // (at most n / 129 entries)
     }
-    if (bad && lane == 0u) wglist[atomicAdd(&plan->nwg, 1u)] = run;  // (at most nl <= long_cap entries)
   }
 }
 
@@ -899,7 +949,7 @@ static int sorted_order_words(const void* keys, int64_t n, int descending, int32
   const OneCol<KIND> pol{k, desc_mask};
   hipLaunchKernelGGL((k_om_finish_b<OneCol<KIND>>), dim3(g.wgs), dim3(256), 0, s, (const uint64_t*)L.sorted, n, pol, L.plan, out, (const unsigned int*)R.heads,
                      (const RunSeg*)R.segs, g.seg_cap, R.longlist, (unsigned int)g.long_cap);
-  hipLaunchKernelGGL((k_om_medium<OneCol<KIND>>), dim3(cus * 8), dim3(256), 0, s, (const uint64_t*)L.sorted, pol, L.plan, (const LongRun*)R.longlist, (unsigned int)g.long_cap, R.wglist);
+  hipLaunchKernelGGL((k_om_medium<OneCol<KIND>>), dim3(cus * 8), dim3(256), 0, s, (const uint64_t*)L.sorted, pol, L.plan, (const LongRun*)R.longlist, (unsigned int)g.long_cap, R.wglist, out);
   hipLaunchKernelGGL((k_om_long<OneCol<KIND>>), dim3(cus), dim3(1024), OM_LDSRUN * 12, s, (const uint64_t*)L.sorted, pol, (const OmPlan*)L.plan, out,
                      (const LongRun*)R.wglist, (unsigned int)g.long_cap, R.gk, R.gr);
   if (KIND == K_FLOAT && descending) hipLaunchKernelGGL(k_om_reverse_nans, dim3(cus), dim3(256), 0, s, out, (const OmPlan*)L.plan);
@@ -978,7 +1028,7 @@ static int sorted_order_table(int ncols, const int* dtypes, const void* const* c
   const Tuple pol{t};
   hipLaunchKernelGGL((k_om_finish_b<Tuple>), dim3(g.wgs), dim3(256), 0, s, (const uint64_t*)L.sorted, n, pol, L.plan, out, (const unsigned int*)R.heads,
                      (const RunSeg*)R.segs, g.seg_cap, R.longlist, (unsigned int)g.long_cap);
-  hipLaunchKernelGGL((k_om_medium<Tuple>), dim3(cus * 8), dim3(256), 0, s, (const uint64_t*)L.sorted, pol, L.plan, (const LongRun*)R.longlist, (unsigned int)g.long_cap, R.wglist);
+  hipLaunchKernelGGL((k_om_medium<Tuple>), dim3(cus * 8), dim3(256), 0, s, (const uint64_t*)L.sorted, pol, L.plan, (const LongRun*)R.longlist, (unsigned int)g.long_cap, R.wglist, out);
   hipLaunchKernelGGL((k_om_long<Tuple>), dim3(cus), dim3(1024), OM_LDSRUN * 12, s, (const uint64_t*)L.sorted, pol, (const OmPlan*)L.plan, out, (const LongRun*)R.wglist,
                      (unsigned int)g.long_cap, R.gk, R.gr);
   GX_LAUNCH_CHECK();

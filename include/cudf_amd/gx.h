@@ -184,7 +184,7 @@ int gx_gather_global_rows_dev(const int32_t* rows, int64_t nrows, const int32_t*
 /* The sharded join's pairs without a gather: a row travels as enc = (source rank << shift) | row (the payload of the *_pl entry
  * points below) and is decoded in one streaming pass: out[j] = bases_dev[src] + row, plus chunk(j) * chunk_rows_dev[src] when
  * the row was counted inside its sender's CHUNK -- chunk(j) = the c with snap_dev[c] <= j < snap_dev[c + 1], snap_dev = the
- * pair positions at which the probe of each received chunk started (nchunks + 1 device int64). */
+ * pair positions at which the probe of each received chunk started (nchunks + 1 device int64; nchunks <= 1024). */
 int gx_decode_global_rows(const int32_t* enc, int64_t n, int shift, const int64_t* bases_dev, const int64_t* chunk_rows_dev,
                           const int64_t* snap_dev, int nchunks, int64_t* out, gx_stream_t stream);
 /* out[i] = in[i] as int64 (row indices / counts leaving the int32 world of cudf::size_type) */

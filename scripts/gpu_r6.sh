@@ -9,6 +9,7 @@
 #   bench:<workload>[:extra args]   bench.py --workload <w> --no-cpu-baseline <extra>
 #   default                         the driver-style default line (all legs)
 #   steps:<rows>                    scripts/xp/xp_gxd_steps.py <rows>  (forced-exchange single-rank steps of the sharded operators)
+#   profsteps:<rows>                rocprofv3 --kernel-trace --stats summary of scripts/xp/xp_gxd_steps.py <rows>
 #   xp:<file.hip>[:args]            hipcc + run a micro-benchmark under scripts/xp/
 #   prof:<workload>[:extra args]    rocprofv3 --kernel-trace --stats summary of bench.py --workload <w>
 #   pmcsq:<workload>[:extra args]   SQ counters (two passes) of bench.py --workload <w> --steps 1 --warmup 0
@@ -68,6 +69,12 @@ PY
     steps)
       timeout 900 python scripts/xp/xp_gxd_steps.py ${rest:-1e9} 2>&1 | grep -v "^\[W\|amdgpu.ids" > $O/r6_${TAG}_single_rank_steps_${rest:-1e9}.txt
       cat $O/r6_${TAG}_single_rank_steps_${rest:-1e9}.txt | tail -30 ;;
+    profsteps)
+      (cd /tmp && timeout 900 rocprofv3 --kernel-trace --stats -d "$ROOT/$O/prof_$TAG" -o p -- python "$ROOT/scripts/xp/xp_gxd_steps.py" ${rest:-1e9}) > $O/r6_${TAG}_steps_under_rocprof.txt 2>> $O/r6_${TAG}.log
+      db=$(find $O/prof_$TAG -name "*.db" | head -1)
+      [ -n "$db" ] && python scripts/rocprof_summary.py "$db" "round 6 $TAG: rocprofv3 --kernel-trace --stats -- python scripts/xp/xp_gxd_steps.py ${rest:-1e9}" | head -70 | cut -c1-190 > $O/r6_${TAG}_steps_kernel_stats.txt
+      find $O/prof_$TAG -name "*.db" -delete
+      head -50 $O/r6_${TAG}_steps_kernel_stats.txt ;;
     xp)
       src=${rest%%:*}; args=${rest#*:}; [ "$args" = "$rest" ] && args=""
       mkdir -p scripts/xp/bin

@@ -146,9 +146,9 @@ def test_wide_keys_with_duplicates(gx, copies):
                 assert info[0] > 300_000, info   # the runs WERE listed
 
 
-def test_listed_runs_out_of_order_reach_the_workgroup_pass(gx):
+def test_listed_runs_out_of_order_are_ranked_inside_a_wave(gx):
     """Runs of 17 - 128 DISTINCT keys under one rank (consecutive integers inside uniform 64-bit keys), rows shuffled: the wave pass marks
-    them, the workgroup pass sorts them"""
+    (k_om_medium) ranks them where it finds them"""
     rng = np.random.default_rng(77)
     v = rng.integers(-2**63, 2**63 - 1, N, dtype=np.int64)
     for j in range(2000):
