@@ -62,6 +62,7 @@ def parse():
                          "(sparse int32 keys: they hash like random numbers); random64 = int64 keys, ids through the splitmix64 finalizer")
     ap.add_argument("--gb-pbits", type=int, default=0, help="groupby knob: 2^bits hash partitions; 0 (default) = 512, and 256 chosen on the device for "
                                                               "dense ids (round 4); 8 / 9 = fixed")
+    ap.add_argument("--gb-dense", type=int, default=1, help="groupby knob (round 6): 1 dense ids by direct address -- id-range partitions, 10-byte (value, 16-bit remainder) rows, LDS table indexed by the remainder (default); 0 the hash path")
     ap.add_argument("--gb-spec", type=int, default=1, help="groupby knob: 1 hist-free speculative partition pass (default), 0 exact histogram pass")
     ap.add_argument("--no-partitioned-join", action="store_true", help="join: probe the table directly")
     ap.add_argument("--sort-order-map", type=int, default=1, help="sorted_order knob (round 6): 1 keys-only sort of (rank, row) words for 64-bit columns (default), 0 the round-3 pairs path")
@@ -1092,6 +1093,7 @@ def bench_groupby(c):
     n = c.n
     lib.gx_groupby_set_algorithm(a.gb_algo, a.gb_split)
     lib.gx_groupby_set_partition_mode(a.gb_spec)
+    lib.gx_groupby_set_dense(a.gb_dense)
     L.check(lib.gx_groupby_set_partition_bits(a.gb_pbits), "gx_groupby_set_partition_bits")
     gk = ops.random_column(np.int32, n, seed=7 + c.rank, lo=0, hi=1_000_000)
     gv = ops.random_column(np.float64, n, seed=8 + c.rank)
@@ -1142,6 +1144,9 @@ def bench_groupby(c):
     step = lambda: L.check(fn(c.ptr(tmp), ctypes.byref(nb)), "groupby")
     sec = c.timed(step)
     ms_per_step = sec * 1e3
+    pinfo = (ctypes.c_int32 * 4)()
+    L.check(lib.gx_groupby_plan_info(c.ptr(tmp), mg, pinfo, c.stream), "gx_groupby_plan_info")
+    dense_path = bool(pinfo[0]) and not pinfo[1]
     # ---- guard: counts add up to n, keys are distinct and in range, and sampled groups match a direct
     # device-side recomputation (count exact, f64 sum to 1e-11 relative: the kernel's own bar is 1 ulp)
     groups = int(ng.item())
@@ -1163,11 +1168,13 @@ def bench_groupby(c):
         assert abs(float(st[gi].item()) - ref) <= 1e-11 * max(1.0, abs(ref)), "groupby: sampled group sum differs"
     ach = 12 * n / (ms_per_step * 1e-3) / 1e9
     roofline = {"bound": "hbm",
-                "kernel": ("k_slot_sample + k_part_scatter + k_part_aggregate (LDS-partitioned groupby, slots sized from a sample)" if a.gb_spec else
+                "kernel": ("k_slot_sample + k_part_scatter<dense> + k_dense_aggregate (id-range partitions, 10-byte rows, LDS table indexed by the id's remainder)" if dense_path else
+                           "k_slot_sample + k_part_scatter + k_part_aggregate (LDS-partitioned groupby, slots sized from a sample)" if a.gb_spec else
                            "k_part_hist + k_part_scatter + k_part_aggregate (LDS-partitioned groupby)"),
                 "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS, "traffic": None,
                 "traffic_key": "groupby" if a.gb_spec else "groupby (exact two-pass)",
                 "algorithmic_bytes_per_launch": 12 * n, "avg_launch_ms": ms_per_step, "groups": groups,
+                "path": {"dense_direct_address": int(pinfo[0]), "fell_back_to_exact": int(pinfo[1]), "partition_bits": int(pinfo[2]), "ids_per_partition": int(pinfo[3])},
                 "model": "12 B/row (4-B key + 8-B value read once; SURVEY.md 8d)"}
     pmc_traffic(roofline, n)
     cpu = None

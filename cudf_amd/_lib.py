@@ -129,6 +129,8 @@ _PROTOS = {
     "gx_join_filter": (_i, [_i, _p, _p, _i64, _p, ctypes.c_size_t, _i, _i, _p, _p, _p, _sz, _p]),
     "gx_join_complement": (_i, [_p, _i64, _i64, _p, _p, _i64, _p, _p, _sz, _p]),
     "gx_groupby_set_algorithm": (None, [_i, _i]),
+    "gx_groupby_set_dense": (None, [_i]),
+    "gx_groupby_plan_info": (_i, [_p, _i64, _p, _p]),
     "gx_groupby_set_partition_mode": (None, [_i]),
     "gx_groupby_set_partition_bits": (_i, [_i]),
     "gx_group_heads": (_i, [_i, _p, _p, _p, _i64, _i, _p, _p]),

@@ -221,7 +221,19 @@ struct PartPlan {
   int pbits;
   int auto_pbits;                            // host: let k_slot_plan choose
   unsigned long long kmin, kmax;             // k_slot_sample: smallest / largest sampled key (order-preserving 64-bit form)
+  // Round 6: DENSE ids by DIRECT ADDRESS.  Where the sampled keys span few enough values, partition p is the id
+  // RANGE [dlo + p dG, dlo + (p + 1) dG) of 256, a row travels as its 8-byte value + the 16-bit remainder of its id inside the range
+  // (10 B/row instead of 12: 12 + 10 + 10 = 32 GB per 1e9 rows against 36), and the aggregate kernel's LDS table is indexed by that
+  // remainder -- no hashing, no probing, no key compare.  A key outside [dlo, dlo + 256 dG) (the sample missed it by more than the
+  // margin) raises `overflow` like a slot that outgrew its capacity: the exact (hash) sequence produces the result.
+  int dense_allowed;                         // host: this call may take the dense path (8-byte values, no value nulls, knob on)
+  int dense;                                 // k_slot_plan: taken
+  unsigned long long dlo;                    // first id of partition 0 (order-preserving 64-bit form)
+  unsigned long long dM;                     // floor(2^40 / dG) + 1: (d dM) >> 40 = d / dG for d < 2^21
+  uint32_t dG;                               // ids per partition (<= DD_GMAX)
 };
+constexpr uint32_t DD_GMAX = 7680;           // direct-address entries per workgroup: 20 B each (sum, compensation, count) in 150 KiB of LDS
+constexpr int DD_PARTS     = 256;
 __device__ __forceinline__ int part_pbits(const PartPlan* plan) { return plan->pbits ? plan->pbits : d_gb_pbits; }
 
 // Round 3: no histogram pass in the common case.  Region (partition p, range r) owns a slot of `cap` rows at
@@ -328,8 +340,8 @@ __global__ void __launch_bounds__(NPART) k_part_offsets(PartPlan* plan, int gate
   if (threadIdx.x == 0) plan->offset[NPART] = total;
 }
 
-template <typename K, typename V, bool HAS_VV>
-__global__ void __launch_bounds__(PBT) k_part_scatter(const K* __restrict__ keys, const uint32_t* __restrict__ kvalid,
+template <typename K, typename V, bool HAS_VV, bool DENSE = false>
+__global__ void __launch_bounds__(PBT, 2) k_part_scatter(const K* __restrict__ keys, const uint32_t* __restrict__ kvalid,
                                                       const V* __restrict__ vals, const uint32_t* __restrict__ vvalid,
                                                       int64_t n, PartPlan* plan, K* __restrict__ pkeys,
                                                       V* __restrict__ pvals, uint8_t* __restrict__ pflags, int nrange,
@@ -337,6 +349,27 @@ __global__ void __launch_bounds__(PBT) k_part_scatter(const K* __restrict__ keys
 {
   // cap > 0: speculative pass into padded slots; cap == 0: exact pass (gated: only after an overflow)
   if (gated && plan->overflow == 0) return;
+  // DENSE (speculative pass only): partitions are id ranges, a row's key travels as a 16-bit remainder (PartPlan::dense); the two
+  // instantiations are launched behind each other and the one the plan did not choose leaves
+  if (cap && (DENSE != (plan->dense != 0))) return;
+  typedef typename std::make_unsigned<K>::type UK;
+  constexpr unsigned long long SIGN = std::is_signed<K>::value ? (1ull << (8 * sizeof(K) - 1)) : 0ull;
+  const unsigned long long dlo  = DENSE ? plan->dlo : 0ull;
+  const uint32_t dG             = DENSE ? plan->dG : 1u;
+  const unsigned long long dlim = (unsigned long long)DD_PARTS * dG;
+  const float dinv              = 1.0f / (float)dG;
+  // (DENSE) the id-range partition of a key; `out`: the key lies outside the planned range.  d < 2^21 inside it: the quotient by a
+  // float multiply (exact to within one) and a correction, all in 32 bits -- the 64-bit magic multiply of the first version, twice per
+  // row, took the kernel from 123 to 140 registers and from two workgroups per CU to one (6.5 ms against 5.6)
+  auto dense_part = [&](K k, bool& out) -> uint32_t {
+    const unsigned long long d64 = ((unsigned long long)(UK)k ^ SIGN) - dlo;
+    out                          = d64 >= dlim;
+    const uint32_t d             = (uint32_t)d64;
+    uint32_t q                   = (uint32_t)((float)d * dinv);
+    const int32_t r              = (int32_t)(d - q * dG);
+    if (r < 0) q -= 1u; else if ((uint32_t)r >= dG) q += 1u;
+    return q;
+  };
   constexpr int ESZ = sizeof(K) > sizeof(V) ? sizeof(K) : sizeof(V);
   extern __shared__ __attribute__((aligned(16))) char smem[];
   char* s_buf       = smem;                                             // PTILE * ESZ
@@ -371,11 +404,24 @@ __global__ void __launch_bounds__(PBT) k_part_scatter(const K* __restrict__ keys
   }
   __syncthreads();
   uint32_t packed[PRPT];  // partition << 16 | rank inside (tile, partition)
+  bool outside = false;
 #pragma unroll
   for (int j = 0; j < PRPT; ++j) {
-    const uint32_t part = (uint32_t)(part_hash<K>(key[j]) >> psh);
-    packed[j]           = (part << 16) | (live[j] ? atomicAdd(&s_cnt[part], 1u) : 0u);
+    uint32_t part;
+    if (DENSE) {
+      bool out;
+      part = dense_part(key[j], out);
+      if (live[j] && out) {
+        outside = true;
+        live[j] = false;
+      }
+      if (!live[j]) part = 0u;
+    } else {
+      part = (uint32_t)(part_hash<K>(key[j]) >> psh);
+    }
+    packed[j] = (part << 16) | (live[j] ? atomicAdd(&s_cnt[part], 1u) : 0u);
   }
+  if (DENSE && outside) plan->overflow = 1u;  // a key the sample's range (+ margin) does not cover: the exact sequence will run
   __syncthreads();
   const uint32_t c  = (tid < NPART) ? s_cnt[tid] : 0u;
   uint32_t total;
@@ -401,9 +447,14 @@ __global__ void __launch_bounds__(PBT) k_part_scatter(const K* __restrict__ keys
   // in a register for the value pass (round 2 staged one byte per row in LDS; with 512 partitions that would be two,
   // and the second workgroup per CU would no longer fit)
   K* s_k = reinterpret_cast<K*>(s_buf);
+  uint32_t* s_code = reinterpret_cast<uint32_t*>(s_buf);  // DENSE: partition << 16 | remainder (ESZ >= 8 here: PTILE * 4 bytes fit)
 #pragma unroll
   for (int j = 0; j < PRPT; ++j) {
-    if (live[j]) s_k[s_start[packed[j] >> 16] + (packed[j] & 0xFFFFu)] = key[j];
+    if (live[j]) {
+      const uint32_t pos = s_start[packed[j] >> 16] + (packed[j] & 0xFFFFu);
+      if (DENSE) s_code[pos] = (packed[j] & 0xFFFF0000u) | (((uint32_t)((unsigned long long)(UK)key[j] ^ SIGN) - (uint32_t)dlo - (packed[j] >> 16) * dG) & 0xFFFFu);  // partition << 16 | remainder
+      else s_k[pos] = key[j];
+    }
   }
   __syncthreads();
   unsigned short obin[PRPT];
@@ -412,12 +463,21 @@ __global__ void __launch_bounds__(PBT) k_part_scatter(const K* __restrict__ keys
     const int i = j * PBT + (int)tid;
     obin[j]     = 0xFFFFu;
     if (i < ntot) {
-      const K k                    = s_k[i];
-      const uint32_t b             = (uint32_t)(part_hash<K>(k) >> psh);
-      const unsigned long long dst = s_delta[b] + (unsigned long long)i;
-      if (dst >= s_limit[b]) continue;  // beyond the slot
-      pkeys[dst] = k;
-      obin[j]    = (unsigned short)b;
+      if (DENSE) {
+        const uint32_t code          = s_code[i];
+        const uint32_t b             = code >> 16;
+        const unsigned long long dst = s_delta[b] + (unsigned long long)i;
+        if (dst >= s_limit[b]) continue;  // beyond the slot
+        reinterpret_cast<unsigned short*>(pkeys)[dst] = (unsigned short)code;
+        obin[j]                                       = (unsigned short)b;
+      } else {
+        const K k                    = s_k[i];
+        const uint32_t b             = (uint32_t)(part_hash<K>(k) >> psh);
+        const unsigned long long dst = s_delta[b] + (unsigned long long)i;
+        if (dst >= s_limit[b]) continue;  // beyond the slot
+        pkeys[dst] = k;
+        obin[j]    = (unsigned short)b;
+      }
     }
   }
   __syncthreads();
@@ -498,7 +558,7 @@ __global__ void __launch_bounds__(ABT) k_part_aggregate(const K* __restrict__ pk
                                                         uint32_t* cnt_all, GbState* st, uint32_t cap = 0, int gated = 0, int nsub8 = 0)
 {
   // cap > 0: the speculative pass (skipped when a slot overflowed); cap == 0 && gated: the exact pass behind it
-  if (cap ? plan->overflow != 0 : (gated && plan->overflow == 0)) return;
+  if (cap ? (plan->overflow != 0 || plan->dense != 0) : (gated && plan->overflow == 0)) return;  // (dense: k_dense_aggregate has the speculative pass)
   // the grid is sized for the process-wide partition bits; a call whose plan chose 8 (dense ids) uses nsub8 workgroups per
   // partition and the surplus workgroups leave
   const int pb = part_pbits(plan);
@@ -632,6 +692,85 @@ __global__ void __launch_bounds__(ABT) k_part_aggregate(const K* __restrict__ pk
   }
 }
 
+// Round 6: the aggregate of the DENSE path (PartPlan::dense).  One workgroup per id range; the LDS table is indexed by the row's 16-bit
+// remainder -- {sum, compensation, count} per id, no key, no probing; a row costs a 2-byte and an 8-byte load, one ds_add_rtn_f64 and
+// one ds_add_u32.  The groups leave through the same global table as the hash path's (find_or_insert), key = dlo + p dG + remainder.
+template <typename K, typename V, bool IS_FLOAT>
+__global__ void __launch_bounds__(ABT) k_dense_aggregate(const unsigned short* __restrict__ prem, const V* __restrict__ pvals, const PartPlan* plan,
+                                                         unsigned long long* table, uint32_t log2cap, double* sum, double* comp, uint32_t* cnt_valid,
+                                                         uint32_t* cnt_all, GbState* st)
+{
+  if (plan->overflow != 0 || plan->dense == 0) return;
+  const uint32_t G = plan->dG;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  double* l_sum  = reinterpret_cast<double*>(smem);          // G
+  double* l_comp = l_sum + DD_GMAX;                           // G
+  uint32_t* l_cv = reinterpret_cast<uint32_t*>(l_comp + DD_GMAX);  // G
+  const unsigned tid = threadIdx.x;
+  for (uint32_t i = tid; i < G; i += ABT) {
+    l_sum[i]  = 0.0;
+    l_comp[i] = 0.0;
+    l_cv[i]   = 0;
+  }
+  __syncthreads();
+  const int part  = (int)blockIdx.x;
+  constexpr int U = 8;
+  for (int rg = 0; rg < NRANGE; ++rg) {
+    const unsigned long long fill = plan->cursor[rg][part];
+    const unsigned long long scap = plan->cap0[rg][part];
+    const unsigned long long p0   = plan->slot0[rg][part];
+    const unsigned long long p1   = p0 + (fill < scap ? fill : scap);
+    // four consecutive rows per lane and access: an 8-byte load of remainders, two 16-byte loads of values (slots start at multiples of
+    // 16 rows); 2-byte loads -- 128 B per wave instruction -- left the pass at 3.2 TB/s
+    typedef unsigned short u16x4 __attribute__((ext_vector_type(4)));
+    typedef V v2 __attribute__((ext_vector_type(2)));
+    constexpr int Q = U / 4;
+    for (unsigned long long i0 = p0 + 4ull * tid; i0 < p1; i0 += 4ull * ABT * Q) {
+      u16x4 r[Q];
+      v2 va[Q], vb[Q];
+#pragma unroll
+      for (int u = 0; u < Q; ++u) {
+        const unsigned long long i = i0 + 4ull * ABT * u;
+        if (i + 3 < p1) {
+          r[u]  = *reinterpret_cast<const u16x4*>(prem + i);
+          va[u] = *reinterpret_cast<const v2*>(pvals + i);
+          vb[u] = *reinterpret_cast<const v2*>(pvals + i + 2);
+        } else {  // the slot's last rows
+          r[u]  = u16x4{i < p1 ? prem[i] : (unsigned short)0, i + 1 < p1 ? prem[i + 1] : (unsigned short)0, i + 2 < p1 ? prem[i + 2] : (unsigned short)0, (unsigned short)0};
+          va[u] = v2{i < p1 ? pvals[i] : V(0), i + 1 < p1 ? pvals[i + 1] : V(0)};
+          vb[u] = v2{i + 2 < p1 ? pvals[i + 2] : V(0), V(0)};
+        }
+      }
+#pragma unroll
+      for (int u = 0; u < Q; ++u) {
+        const unsigned long long i = i0 + 4ull * ABT * u;
+        const unsigned short rr[4] = {r[u].x, r[u].y, r[u].z, r[u].w};
+        const V vv[4]              = {va[u].x, va[u].y, vb[u].x, vb[u].y};
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          if (i + e >= p1) continue;
+          LdsAcc<V, IS_FLOAT>::add(l_sum, l_comp, (int)rr[e], vv[e]);
+          atomicAdd(&l_cv[rr[e]], 1u);
+        }
+      }
+    }
+  }
+  __syncthreads();
+  typedef typename std::make_unsigned<K>::type UK;
+  constexpr unsigned long long SIGN = std::is_signed<K>::value ? (1ull << (8 * sizeof(K) - 1)) : 0ull;
+  const unsigned long long first    = plan->dlo + (unsigned long long)part * G;
+  for (uint32_t i = tid; i < G; i += ABT) {
+    const uint32_t cv = l_cv[i];
+    if (!cv) continue;
+    const K key     = (K)(UK)((first + i) ^ SIGN);
+    const int64_t g = find_or_insert<K>(table, log2cap, key, st);
+    if (g < 0) continue;
+    if (cnt_all) atomicAdd(&cnt_all[g], cv);
+    atomicAdd(&cnt_valid[g], cv);
+    global_merge<IS_FLOAT>(sum, comp, g, l_sum[i], l_comp[i]);
+  }
+}
+
 static inline uint32_t log2_cap(int64_t max_groups)
 {
   uint32_t lg = 6;
@@ -657,6 +796,7 @@ static thread_local int g_gb_spec = 1;       // A/B knob: 1 = speculative hist-f
 static thread_local int g_gb_algorithm = 0;  // 0 auto, 1 global-atomic table only, 2 partitioned whenever possible
 static thread_local int g_gb_nsplit    = 1;
 static thread_local int g_gb_nrange    = NRANGE;  // 1 = single cursor per partition (A/B measurement)
+static thread_local int g_gb_dense     = 1;       // round 6: dense ids by direct address (PartPlan::dense); gx_groupby_set_dense(0) keeps the hash path
 constexpr int64_t PART_MIN_ROWS = 1 << 19;
 // the speculative pass pays off once the slots are long enough for the 8-sigma margin to be small (>= ~2000 rows per slot)
 static inline bool part_speculative(int64_t n) { return g_gb_nrange == NRANGE && (g_gb_spec == 2 || (g_gb_spec == 1 && n >= (1 << 22))); }
@@ -719,18 +859,77 @@ __global__ void __launch_bounds__(256) k_slot_sample(const K* __restrict__ keys,
   }
 }
 
+// DENSE path: the sample again, counted per (range, id-range partition) -- the slot capacities of the dense scatter
+template <typename K>
+__global__ void __launch_bounds__(256) k_dense_sample(const K* __restrict__ keys, const uint32_t* __restrict__ kvalid, int64_t n, PartPlan* plan, int stride,
+                                                      int64_t range_rows)
+{
+  if (plan->dense == 0) return;
+  __shared__ uint32_t s_hist[NRANGE * DD_PARTS];
+  const unsigned tid = threadIdx.x, lane = lane_id();
+  for (int i = tid; i < NRANGE * DD_PARTS; i += 256) s_hist[i] = 0;
+  __syncthreads();
+  typedef typename std::make_unsigned<K>::type UK;
+  constexpr unsigned long long SIGN = std::is_signed<K>::value ? (1ull << (8 * sizeof(K) - 1)) : 0ull;
+  const unsigned long long dlo = plan->dlo, dM = plan->dM;
+  const int64_t step    = (int64_t)stride * GX_WAVE;
+  const int64_t nchunks = div_up(n, step);
+  const int64_t nw      = (int64_t)gridDim.x * 4;
+  for (int64_t c = (int64_t)blockIdx.x * 4 + tid / GX_WAVE; c < nchunks; c += nw) {
+    const int64_t row = c * step + lane;
+    const bool live   = row < n && (!kvalid || bit_is_set(kvalid, row));
+    const K k         = keys[row < n ? row : 0];
+    const int64_t r64 = range_rows > 0 ? row / range_rows : (int64_t)(NRANGE - 1);
+    const int r       = r64 < NRANGE - 1 ? (int)r64 : NRANGE - 1;
+    const unsigned long long d = ((unsigned long long)(UK)k ^ SIGN) - dlo;  // (sampled rows lie inside the planned range)
+    uint32_t part     = (uint32_t)((d * dM) >> 40);
+    if (part >= (uint32_t)DD_PARTS) part = DD_PARTS - 1;
+    if (live) atomicAdd(&s_hist[r * DD_PARTS + part], 1u);
+  }
+  __syncthreads();
+  for (int i = tid; i < NRANGE * DD_PARTS; i += 256) {
+    const uint32_t c = s_hist[i];
+    if (c) atomicAdd(&plan->samp[i / DD_PARTS][i % DD_PARTS], c);
+  }
+}
+
 // one block of NPART threads: capacities = estimate + 8 sigma of the estimate + two sample steps + a constant, slots laid
 // out partition-major (the NRANGE slots of a partition are neighbours)
 template <typename Plan>
 __global__ void __launch_bounds__(NPART) k_slot_plan(Plan* plan, int64_t n, int stride, int64_t range_rows, unsigned long long elems,
-                                                     long long max_groups = 0)
+                                                     long long max_groups = 0, int dense_phase = 0)
 {
   __shared__ uint32_t s_tmp[NPART / GX_WAVE + 1];
   const int t = threadIdx.x;
   if constexpr (std::is_same<Plan, PartPlan>::value) {
+    // dense_phase 1: the second call, behind k_dense_sample -- capacities from the id-range counts (only if the first call chose the dense path)
+    if (dense_phase == 1 && plan->dense == 0) return;
+    if (dense_phase == 0 && plan->dense_allowed && plan->kmin <= plan->kmax) {
+      // ids by direct address (PartPlan::dense): the sampled range pushed out by 1/64 of its width + 64 at both ends (the sample sees
+      // one row in `stride`: the true extremes of evenly used ids lie a few ids outside it), cut into 256 ranges of dG ids
+      const unsigned long long w      = plan->kmax - plan->kmin;
+      const unsigned long long margin = w / 64 + 64;
+      const unsigned long long lo     = plan->kmin > margin ? plan->kmin - margin : 0ull;
+      const unsigned long long hi     = plan->kmax > ~0ull - margin ? ~0ull : plan->kmax + margin;
+      const unsigned long long span   = hi - lo;  // (+ 1 ids)
+      const bool fits = span / DD_PARTS < (unsigned long long)DD_GMAX && max_groups > 0 && 4 * max_groups <= (long long)n;
+      __syncthreads();
+      if (fits) {
+        for (int r = 0; r < NRANGE; ++r) plan->samp[r][t] = 0;  // counted again per id range (k_dense_sample)
+        if (t == 0) {
+          const uint32_t G = (uint32_t)(span / DD_PARTS) + 1u;
+          plan->dense      = 1;
+          plan->dlo        = lo;
+          plan->dG         = G;
+          plan->dM         = (1ull << 40) / G + 1ull;
+          plan->pbits      = 8;  // (the exact sequence, should it run, cuts 256 hash partitions)
+        }
+        return;
+      }
+    }
     // dense ids (the sampled keys span at most 2 x max_groups values, from 0): 256 partitions -- the sample's 512 bins fold pairwise
     // (partition = top bits of the hash) -- otherwise the process-wide bits.  See PartPlan::pbits.
-    if (plan->auto_pbits && d_gb_pbits == 9) {
+    if (dense_phase == 0 && plan->auto_pbits && d_gb_pbits == 9) {
       // (max_groups must be a real bound -- a quarter of the rows at most: a caller that passes n says nothing about the key range)
       const bool dense = max_groups > 0 && 4 * max_groups <= (long long)n && plan->kmax < 2ull * (unsigned long long)max_groups;
       if (dense) {
@@ -819,11 +1018,39 @@ int launch_partitioned(const K* keys, const uint32_t* kvalid, const V* vals, con
     if (sblocks > 2048) sblocks = 2048;
     if (g_gb_auto && g_gb_pbits == 9) {  // let k_slot_plan choose the partition bits of this call (PartPlan::pbits)
       static const int one = 1;
+      static const unsigned long long all_ones = ~0ull;
       GX_HIP_TRY(hipMemcpyAsync(&plan->auto_pbits, &one, sizeof(int), hipMemcpyHostToDevice, s));
+      GX_HIP_TRY(hipMemcpyAsync(&plan->kmin, &all_ones, sizeof(all_ones), hipMemcpyHostToDevice, s));  // (the plan was cleared: a minimum starts at the top)
+    }
+    // round 6: dense ids by direct address (PartPlan::dense) -- 8-byte values without nulls, keys of 4 or 8 bytes, knob on
+    constexpr bool dense_types = !HAS_VV && sizeof(V) == 8 && sizeof(K) >= 4 && std::is_integral<K>::value;
+    const bool dense_ok        = dense_types && g_gb_dense && g_gb_auto && g_gb_pbits == 9 && nsplit == 1;
+    if (dense_ok) {
+      static const int one = 1;
+      GX_HIP_TRY(hipMemcpyAsync(&plan->dense_allowed, &one, sizeof(int), hipMemcpyHostToDevice, s));
     }
     hipLaunchKernelGGL((k_slot_sample<K>), dim3((unsigned)sblocks), dim3(256), 0, s, keys, kvalid, n, plan, stride, range_rows);
     hipLaunchKernelGGL((k_slot_plan<PartPlan>), dim3(1), dim3(NPART), 0, s, plan, n, stride, range_rows, (unsigned long long)slot_elems(n, stride),
-                       (long long)max_groups);
+                       (long long)max_groups, 0);
+    if constexpr (dense_types) {
+      if (dense_ok) {  // every kernel of the path the plan did not choose leaves at once
+        constexpr size_t lds_d = (size_t)DD_GMAX * 20;
+        auto ksd               = k_part_scatter<K, V, false, true>;
+        auto kad               = k_dense_aggregate<K, V, IS_FLOAT>;
+        static std::atomic<bool> dattr{false};
+        if (!dattr) {
+          GX_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(ksd), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_s));
+          GX_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(kad), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_d));
+          dattr = true;
+        }
+        hipLaunchKernelGGL((k_dense_sample<K>), dim3((unsigned)sblocks), dim3(256), 0, s, keys, kvalid, n, plan, stride, range_rows);
+        hipLaunchKernelGGL((k_slot_plan<PartPlan>), dim3(1), dim3(NPART), 0, s, plan, n, stride, range_rows, (unsigned long long)slot_elems(n, stride),
+                           (long long)max_groups, 1);
+        hipLaunchKernelGGL(ksd, dim3(sgrd), dim3(PBT), lds_s, s, keys, kvalid, vals, vvalid, n, plan, pkeys, pvals, pflags, NRANGE, cap, 0);
+        hipLaunchKernelGGL(kad, dim3(DD_PARTS), dim3(ABT), lds_d, s, reinterpret_cast<const unsigned short*>(pkeys), (const V*)pvals, (const PartPlan*)plan, table, lg,
+                           sum, comp, cv, ca, st);
+      }
+    }
     hipLaunchKernelGGL(ks, dim3(sgrd), dim3(PBT), lds_s, s, keys, kvalid, vals, vvalid, n, plan, pkeys, pvals, pflags, NRANGE, cap, 0);
     hipLaunchKernelGGL(ka, dim3(agrd), dim3(ABT), lds_a, s, pkeys, pvals, pflags, plan, nsplit, nsub, table, lg, sum, comp, cv, ca, st, cap,
                        0, nsub8);
@@ -958,6 +1185,37 @@ int gx_groupby_set_partition_bits(int bits)
   const int v = bits == 8 ? 8 : 9;
   GX_HIP_TRY(hipMemcpyToSymbol(HIP_SYMBOL(gx::gb::d_gb_pbits), &v, sizeof(int)));
   gx::gb::g_gb_pbits = v;
+  return 0;
+}
+
+void gx_groupby_set_dense(int on) { gx::gb::g_gb_dense = on ? 1 : 0; }
+
+// which path the last gx_groupby_sum_count that used `tmp` (with this max_groups) took: info[0] = dense ids by direct address,
+// [1] = a slot overflowed / a key lay outside the planned id range (the exact sequence produced the result), [2] = partition bits of
+// the call's plan (0: process-wide), [3] = ids per partition of the dense path.  Synchronises.
+int gx_groupby_plan_info(const void* tmp, int64_t max_groups, int32_t* info4_host, gx_stream_t s)
+{
+  using namespace gx;
+  using namespace gx::gb;
+  if (!tmp || !info4_host) return GX_EINVAL;
+  const uint64_t cap = 1ull << log2_cap(max_groups);
+  Carver c(const_cast<void*>(tmp));
+  (void)c.take<GbState>(1);
+  (void)c.take<unsigned long long>(cap);
+  (void)c.take<double>(cap + 1);
+  (void)c.take<double>(cap + 1);
+  (void)c.take<uint32_t>(cap + 1);
+  (void)c.take<uint32_t>(cap + 1);
+  (void)c.take<uint32_t>(cap + 1);
+  (void)c.take<uint32_t>(scan::partials_count(cap + 1));
+  const PartPlan* plan = c.take<PartPlan>(1);
+  static thread_local PartPlan h;
+  GX_HIP_TRY(hipMemcpyAsync(&h, plan, sizeof(PartPlan), hipMemcpyDeviceToHost, (hipStream_t)s));
+  GX_HIP_TRY(hipStreamSynchronize((hipStream_t)s));
+  info4_host[0] = h.dense;
+  info4_host[1] = (int32_t)h.overflow;
+  info4_host[2] = h.pbits;
+  info4_host[3] = (int32_t)h.dG;
   return 0;
 }
 

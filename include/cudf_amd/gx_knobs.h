@@ -171,6 +171,16 @@ void gx_join_set_partition_mode(int speculative, int early_loads);
  * partition in the LDS aggregation kernel (1..16). */
 void gx_groupby_set_algorithm(int algo, int nsplit);
 
+/* A/B knob (calling thread; round 6): 1 (default) = gx_groupby_sum_count takes DENSE ids by direct address -- where the sampled keys span
+ * at most 256 x 7680 values (8-byte values without nulls, integer keys of 4 or 8 bytes, n >= 2^22, 4 max_groups <= n) a partition is an
+ * id range, a row travels as its value + a 16-bit remainder (10 B instead of 12) and the aggregate's LDS table is indexed by the
+ * remainder; a key outside the planned range falls back to the exact hash sequence on the device.  0 = the hash path of rounds 3 - 5. */
+void gx_groupby_set_dense(int on);
+/* Which path the last gx_groupby_sum_count that used `tmp` (called with this max_groups) took: info[0] = 1 dense ids by direct address,
+ * [1] = 1 a slot overflowed or a key lay outside the planned id range (the exact sequence produced the result), [2] = partition bits of
+ * the call's plan (0: process-wide), [3] = ids per partition of the dense path.  Synchronises `stream`. */
+int gx_groupby_plan_info(const void* tmp, int64_t max_groups, int32_t* info4_host, gx_stream_t stream);
+
 /* A/B knob (process-wide) of the LDS-partitioned path: 1 (default) = the partition pass runs WITHOUT its histogram into padded
  * (partition, XCD range) slots for n >= 2^22, with the exact histogram path as device-side fallback when a slot overflows
  * (skewed keys); 0 = always the exact path; 2 = speculative for every n (tests). */

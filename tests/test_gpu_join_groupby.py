@@ -491,3 +491,115 @@ def test_groupby_partition_bits_chosen_on_the_device(gx, keys_kind):
     np.testing.assert_array_equal(k.to_numpy()[o], ek)
     np.testing.assert_array_equal(cv.to_numpy()[o], res["count_valid"][0])
     np.testing.assert_array_equal(s.to_numpy()[o], res["sum"][0])
+
+
+def _plan_info(ops, L, tmp, max_groups):
+    import ctypes
+    info = (ctypes.c_int32 * 4)()
+    L.check(L.lib.gx_groupby_plan_info(ops.ptr(tmp), max_groups, info, ops.stream_ptr()), "gx_groupby_plan_info")
+    return list(info)
+
+
+def _groupby_raw(Column, ops, L, keys, vals, kv=None, max_groups=1 << 20):
+    """gx_groupby_sum_count through the C ABI with the scratch kept, so that the path the plan chose can be read back"""
+    from cudf_amd.ops import _run, _dev_i64
+    kc, vc = Column.from_numpy(keys, kv), Column.from_numpy(vals)
+    sum_dt = np.float64 if vals.dtype.kind == "f" else np.int64
+    ok, osum = Column.empty(keys.dtype, max_groups), Column.empty(sum_dt, max_groups)
+    ocv, oca = Column.empty(np.int32, max_groups), Column.empty(np.int32, max_groups)
+    ng = _dev_i64()
+    tmp = _run(L.lib.gx_groupby_sum_count, kc.gx, kc.data_ptr, kc.mask_ptr if kv is not None else None, vc.gx, vc.data_ptr, None, keys.size, max_groups,
+               ok.data_ptr, osum.data_ptr, ocv.data_ptr, oca.data_ptr, ops.ptr(ng))
+    g = int(ng.item())
+    assert 0 <= g <= max_groups
+    for c in (ok, osum, ocv, oca):
+        c.size = g
+    return ok.to_numpy(), osum.to_numpy(), ocv.to_numpy(), oca.to_numpy(), _plan_info(ops, L, tmp, max_groups)
+
+
+DENSE_CASES = ["int32_from_zero", "int64_negative_offset", "uint32_high", "zipf_sizes", "wide_span", "few_ids", "key_nulls", "int64_values"]
+
+
+@pytest.mark.parametrize("case", DENSE_CASES)
+def test_groupby_dense_ids_by_direct_address(gx, case):
+    """Round 6: dense ids take id-RANGE partitions, travel as (value, 16-bit remainder) and are aggregated in an LDS
+    table indexed by the remainder (PartPlan::dense).  Against the oracle, with the path read back: ids from zero (BASELINE config 4's
+    shape), a negative offset in int64, uint32 ids near 2^32, Zipf-like group sizes (uneven partitions: the slots come from the sample),
+    a span close to the 256 x 7680 limit, a handful of ids, null keys, int64 values (exact sums)."""
+    Column, ops = gx
+    from cudf_amd import _lib as L
+    rng = np.random.default_rng(abs(hash(case)) % 997)
+    n = 6_000_017
+    vals = rng.random(n) * 200.0 - 100.0
+    kv = None
+    if case == "int32_from_zero":
+        keys = rng.integers(0, 1_000_000, n).astype(np.int32)
+    elif case == "int64_negative_offset":
+        keys = rng.integers(-700_000, 300_000, n).astype(np.int64) - 5_000_000_000
+    elif case == "uint32_high":
+        keys = (rng.integers(0, 500_000, n) + (2**32 - 600_000)).astype(np.uint32)
+    elif case == "zipf_sizes":
+        u = np.maximum(rng.random(n), 1e-12)
+        keys = np.minimum(np.floor(u ** -1.2), 900_000).astype(np.int32)
+    elif case == "wide_span":
+        keys = (rng.integers(0, 950_000, n) * 2).astype(np.int64)          # span 1.9e6 of 1.966e6: ids per partition close to the limit
+    elif case == "few_ids":
+        keys = rng.integers(10, 17, n).astype(np.int32)
+    elif case == "key_nulls":
+        keys = rng.integers(0, 300_000, n).astype(np.int32)
+        kv = rng.random(n) > 0.05
+    else:
+        keys = rng.integers(0, 1_000_000, n).astype(np.int32)
+        vals = rng.integers(-2**40, 2**40, n).astype(np.int64)
+    k, s, cv, ca, info = _groupby_raw(Column, ops, L, keys, vals, kv)
+    assert info[0] == 1 and info[1] == 0, f"{case}: the dense path was not taken / fell back ({info})"
+    o = np.argsort(k, kind="stable")
+    ek, res = orc.groupby_agg(keys, vals, ["sum", "count_valid", "count_all"], kv, None)
+    np.testing.assert_array_equal(k[o], ek)
+    np.testing.assert_array_equal(cv[o], res["count_valid"][0])
+    np.testing.assert_array_equal(ca[o], res["count_all"][0])
+    if vals.dtype.kind == "f":
+        assert np.all(orc.ulp_diff(s[o], res["sum"][0]) <= 1)
+    else:
+        np.testing.assert_array_equal(s[o], res["sum"][0])
+
+
+@pytest.mark.parametrize("case", ["outliers_the_sample_misses", "span_too_wide", "knob_off", "value_nulls"])
+def test_groupby_dense_path_declines_or_falls_back(gx, case):
+    """keys OUTSIDE the planned id range (a few rows far away that the 1-in-`stride` sample does not see) raise the overflow flag in the
+    dense scatter and the exact hash sequence produces the result; a span beyond 256 x 7680 ids, the knob off, value nulls: the hash
+    path from the start.  Same results either way."""
+    Column, ops = gx
+    from cudf_amd import _lib as L
+    rng = np.random.default_rng(3)
+    n = 9_000_011 if case == "outliers_the_sample_misses" else 6_000_017   # (from 2^23 rows the sample takes every other 64-row chunk)
+    keys = rng.integers(0, 400_000, n).astype(np.int64)
+    vals = rng.integers(-1000, 1000, n).astype(np.float64)
+    vv = None
+    if case == "outliers_the_sample_misses":
+        pos = 64 + 128 * rng.integers(0, n // 128 - 1, 7) + rng.integers(0, 64, 7)   # rows 64 - 127 of a 128-row step: never sampled
+        keys[pos] = 9_000_000_000 + np.arange(7)
+    elif case == "span_too_wide":
+        keys = keys * 7
+    elif case == "value_nulls":
+        vv = rng.random(n) > 0.1
+    L.lib.gx_groupby_set_dense(0 if case == "knob_off" else 1)
+    try:
+        if vv is None:
+            k, s, cv, ca, info = _groupby_raw(Column, ops, L, keys, vals)
+            if case == "outliers_the_sample_misses":
+                assert info[0] == 1 and info[1] == 1, info     # planned dense, a row outside the range, the exact sequence ran
+            else:
+                assert info[0] == 0, info
+        else:
+            kk, ss, cvv, caa = ops.groupby_sum_count(Column.from_numpy(keys), Column.from_numpy(vals, vv))
+            k, s, cv, ca = kk.to_numpy(), ss.to_numpy(), cvv.to_numpy(), caa.to_numpy()
+    finally:
+        L.lib.gx_groupby_set_dense(1)
+    o = np.argsort(k, kind="stable")
+    ek, res = orc.groupby_agg(keys, vals, ["sum", "count_valid", "count_all"], None, vv)
+    np.testing.assert_array_equal(k[o], ek)
+    np.testing.assert_array_equal(cv[o], res["count_valid"][0])
+    np.testing.assert_array_equal(ca[o], res["count_all"][0])
+    ev = res["sum"][1] if vv is not None else np.ones(len(ek), bool)
+    np.testing.assert_array_equal(s[o][ev], res["sum"][0][ev])
