@@ -69,7 +69,7 @@ def parse():
     ap.add_argument("--sort-splitters", type=int, default=1, help="sort knob: 0 no splitter mode (uneven columns go to the LSD passes), 1 default")
     ap.add_argument("--join-probe-kernel", type=int, default=0, help="join knob: 0 pipelined tag probe on LDS-resident tags (default), 1 round-1 tag probe, 2 / 3 L2-resident direct probe (4 / 2 rows per thread)")
     ap.add_argument("--join-scatter-tile", type=int, default=0, help="join knob: rows per scatter tile (0 = default)")
-    ap.add_argument("--join-xp", type=int, default=5, help="join knob (round 6; default 5): bit 0 record-form partition pass (12-byte {key, row} runs), bit 1 24576-row scatter tiles, bit 2 pipelined service wave of the probe on fixed pieces per region; 0 = the round-5 kernels")
+    ap.add_argument("--join-xp", type=int, default=133, help="join knob (round 6; default 133): bit 0 record-form partition pass (12-byte {key, row} runs), bit 1 24576-row scatter tiles, bit 2 pipelined service wave of the probe on fixed pieces per region, bit 7 the probe with every load a trip ahead of its use + overflow list (k_pj2_probe_rare); 5 = the first round-6 cut, 0 = the round-5 kernels")
     ap.add_argument("--join-unchecked", action="store_true", help="join: skip the result guards (ablation knobs of --join-xp give wrong results by design); the line says UNCHECKED")
     ap.add_argument("--join-build-kernel", type=int, default=0, help="join knob: 0 sub-table build with the tags in LDS (default), 1 round-2 build (global CAS + k_tags)")
     ap.add_argument("--join-spec", type=int, default=1, help="join knob: 1 hist-free speculative partition (default), 0 round-2 path")

@@ -112,6 +112,7 @@ _PROTOS = {
     "gx_join_profile_read": (_i, [ctypes.POINTER(ctypes.c_float)]),
     "gx_join_set_scatter_tile": (None, [_i]),
     "gx_join_set_experiment": (None, [_i]),
+    "gx_join_set_overflow_slice": (None, [_i]),
     "gx_join_set_build_kernel": (None, [_i]),
     "gx_join_set_probe_kernel": (None, [_i]),
     "gx_join_set_partition_mode": (None, [_i, _i]),

@@ -2375,6 +2375,11 @@ struct PieceTable {
   // ticket atomic and fill-counter read are issued one trip ahead of their use.  `gate` (plan2->fallback): non-zero = no piece at all.
   unsigned int fixedk;
   const unsigned int* gate;
+  // round 6 (k_pj2_probe_pipe<LONG>): rows whose chain needs a dependent read are not settled inside the pipelined loop -- they go to the
+  // workgroup's slice of an overflow list (ovf + blockIdx.x * ovf_cap, ovf_count[blockIdx.x] rows) and k_pj2_probe_rare settles them
+  PjRec* ovf;
+  unsigned int ovf_cap;
+  unsigned int* ovf_count;
 };
 
 // DEFER: a row whose chain is not settled by its first (preloaded) candidate slot -- another slot carries its tag, or the
@@ -2401,7 +2406,18 @@ typedef uint32_t pj_u32x3 __attribute__((ext_vector_type(3)));
 // stride touch every line of the wave's 3 KiB three times: probe 7.57 -> 8.8 ms, profiles/r6_run1_join_ab.txt.)
 // ABL (measurement only, WRONG results; gx_join_set_experiment bits 4-6): 1 = tag lookup kept, no slot is read; 2 = matches are found but
 // not staged / flushed; 3 = no tag lookup at all (rows streamed in, nothing else)
-template <typename K, bool EARLY, bool DEFER, bool REC = false, int ABL = 0>
+// LONG (round 6, second cut; record form, tables of <= 2^28 slots): every load of the probe waves gets a WHOLE trip between its issue and
+// its first use.  Until now a trip ran S3 (compare the slots requested by last trip's S2) -> S2 (tags, request slots) -> S1 (request the
+// next rows) -> X(t): the slot reads had S1 + the barrier + the flush to arrive, and all fifteen waves of the gang stalled on them at the
+// top of S3 at the same time -- the L2's random reads (0.45 per row, 2.4 ms at the part's rate) added to the kernel instead of hiding
+// under its ~140 VALU instructions per row (measured: no slot reads 3.98 ms, full kernel 7.13).  Now a trip is
+//     request rows(t) -> S2(t-1): tags, request slots -> S3(t-2): compare the slots requested LAST trip -> X(t) -> flush(t-3)
+// with two register sets for the rows and two for the S2 -> S3 state, alternated by unrolling the trip loop twice (a copy between sets
+// would wait for the loads it copies).  The memory pipeline returns loads in order, so the rows are requested BEFORE the slots of the
+// same trip and S3 waits with both of them still in flight.  Also cheaper per row: record addresses as 32-bit offsets from a scalar
+// base, the hash's upper word only, ONE staging reservation per wave and trip instead of one per row, no per-row candidate masks
+// carried to S3 (a row with a second tag candidate or a chain beyond its 16-slot window -- ~1 % -- walks its chain from the home slot).
+template <typename K, bool EARLY, bool DEFER, bool REC = false, int ABL = 0, bool LONG = false>
 __global__ void __launch_bounds__(PP_BT)
 k_pj2_probe_pipe(const K* __restrict__ pkeys, const int32_t* __restrict__ pidx, PieceTable pt, int pbits,
                  const Slot<K>* __restrict__ slots, uint32_t log2cap, int left_outer, int32_t* __restrict__ out_probe,
@@ -2417,6 +2433,7 @@ k_pj2_probe_pipe(const K* __restrict__ pkeys, const int32_t* __restrict__ pidx, 
   __shared__ unsigned long long s_base[3];    // output position of staging buffer (it % 3)
   __shared__ PpPiece s_piece[4];              // piece of trip (t & 3), resolved two trips ahead by the service wave
   __shared__ PpDefer<K> s_defer[DEFER ? PP_PW * PP_Q : 1];  // per-wave queues of rows that need another slot
+  __shared__ unsigned int s_ovf;              // LONG: rows sent to the workgroup's overflow slice
   const int P         = 1 << pbits;
   const int LISTP     = P / PJ_NR;
   const uint64_t mask = (1ull << log2cap) - 1;
@@ -2426,6 +2443,7 @@ k_pj2_probe_pipe(const K* __restrict__ pkeys, const int32_t* __restrict__ pidx, 
   const uint8_t* gtags = reinterpret_cast<const uint8_t*>(slots + (mask + 1));
 
   if (tid < 8) s_cnt[tid] = 0;
+  if (tid == 0) s_ovf = 0;
 
   if (w == PP_PW) {
     // ------------------------------------------------------------------ service wave: tickets and reservations
@@ -2606,6 +2624,319 @@ k_pj2_probe_pipe(const K* __restrict__ pkeys, const int32_t* __restrict__ pidx, 
 
   // ---------------------------------------------------------------------- probe waves
   __syncthreads();  // prologue barrier: pieces 0 and 1 are resolved
+  if constexpr (LONG) {
+    static_assert(REC && sizeof(K) == 8 && !EARLY && !DEFER && (ABL == 0 || ABL == 4), "LONG: the record form of 8-byte keys");  // ABL 4 (measurement, WRONG results): no chain walks
+    struct RowSet {    // rows of a piece, in flight from the top of trip t to S2 of trip t + 1
+      pj_u32x3 r[PP_R];
+    };
+    struct SlotSet {   // S2 -> S3: the rows, the first candidate slot of each (in flight), per-row flags
+      uint32_t klo[PP_R], khi[PP_R];
+      int32_t idx[PP_R];
+      Raw sv[PP_R];
+      Raw sv2;         // the SECOND candidate slot of one of the lane's rows (~1 % of the rows have two tag candidates)
+      uint32_t fl;     // bit j: live row; bit 4 + j: it has a first candidate; bit 8 + j: its chain must be walked (S3, rare: ~1e-4);
+                       // bit 12: sv2 is the second candidate of row (fl >> 13) & 3
+      uint32_t valid;
+    };
+    RowSet R0, R1;
+    SlotSet M0, M1;
+    M0.fl = M1.fl = 0;
+    M0.valid = M1.valid = 0;
+#pragma unroll
+    for (int j = 0; j < PP_R; ++j) {
+      R0.r[j] = R1.r[j] = pj_u32x3{0u, 0u, 0u};
+      M0.klo[j] = M0.khi[j] = M1.klo[j] = M1.khi[j] = 0;
+      M0.idx[j] = M1.idx[j] = 0;
+      M0.sv[j] = M1.sv[j] = Raw{};
+    }
+    M0.sv2 = M1.sv2 = Raw{};
+    const PjRec* recs  = reinterpret_cast<const PjRec*>(pkeys);
+    const uint32_t woff = w * (PP_R * GX_WAVE) + lane;  // this thread's first row inside a piece
+    uint32_t partA = 0, cntA = 0, partC = 0;
+    bool validA = false, tags_loaded = false;
+    int done_at = -1;
+    // the whole chain of a row, from its home slot (rare rows only)
+    auto walk = [&](K key, uint32_t& mm, int32_t& ff) {
+      mm          = 0;
+      ff          = NO_MATCH;
+      uint64_t hh = slot_of<K>(key, log2cap);
+      for (;;) {
+        K k;
+        int32_t r;
+        load_slot<K>(&slots[hh], k, r);
+        if (r == EMPTY_ROW) break;
+        if (k == key) {
+          if (mm == 0) ff = r;
+          ++mm;
+        }
+        hh = (hh + 1) & mask;
+      }
+    };
+    auto trip = [&](const int t, RowSet& Rl, RowSet& Ru, SlotSet& Mn, SlotSet& Mo) __attribute__((always_inline)) -> bool {
+      // ---------------- rows of piece t: requested first, looked at by S2 of the next trip
+      const PpPiece pcur = s_piece[t & 3];
+      const uint32_t pvalid = (uint32_t)__builtin_amdgcn_readfirstlane((int)pcur.valid);
+      // (UNCONDITIONAL loads, here and in S2: a load under a wave-uniform `if` does not count as "issued after" for the compiler's
+      //  s_waitcnt placement -- it waits for the older loads as if the younger ones were not in flight.  A trip without a piece reads
+      //  row 0 of the records / slot 0 of the table and ignores them.)
+      uint32_t cntN = 0, partN = 0;
+      {
+        uint32_t c0l = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)pcur.c0);
+        uint32_t c0h = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(pcur.c0 >> 32));
+        cntN         = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(pcur.c1 - pcur.c0));
+        partN        = (uint32_t)__builtin_amdgcn_readfirstlane((int)pcur.part);
+        if (!pvalid) c0l = c0h = cntN = partN = 0;
+        const char* base = reinterpret_cast<const char*>(recs + (((unsigned long long)c0h << 32) | c0l));
+#pragma unroll
+        for (int j = 0; j < PP_R; ++j) {
+          const uint32_t o = woff + (uint32_t)j * GX_WAVE;
+          const uint32_t b = (o < cntN ? o : 0u) * (uint32_t)sizeof(PjRec);
+          Rl.r[j]          = __builtin_nontemporal_load(reinterpret_cast<const pj_u32x3*>(base + b));
+        }
+      }
+      // ---------------- tags of the partition S2 is about to probe
+      if (validA && (!tags_loaded || partA != partC)) {
+        const uint4* src = reinterpret_cast<const uint4*>(gtags + (((uint64_t)partA << PJ_SUB_LOG2) >> 1));
+        uint4* dst       = reinterpret_cast<uint4*>(smem);
+        for (uint32_t i = tid; i < SUB / 2 / 16; i += PP_PW * GX_WAVE) dst[i] = src[i];
+        if (tid == 0) {  // the 32 tags behind the sub-table's own; behind the LAST sub-table the table wraps to slot 0
+          const bool last = (((uint64_t)partA + 1) << PJ_SUB_LOG2) > mask;
+          dst[SUB / 2 / 16] = last ? *reinterpret_cast<const uint4*>(gtags) : src[SUB / 2 / 16];
+        }
+        partC       = partA;
+        tags_loaded = true;
+        __syncthreads();  // R(t)
+      }
+      // ---------------- S2(t-1): chain heads on the LDS tags, first candidate slot requested
+      Mn.fl    = 0;
+      Mn.valid = validA ? 1u : 0u;
+      {  // (cntA = 0 without a piece: no live row)
+        const uint32_t sub_lo   = partA << PJ_SUB_LOG2;                      // (log2cap <= 28: a slot number is 32 bits)
+        const bool last         = (((uint64_t)partA + 1) << PJ_SUB_LOG2) > mask;
+        const char* sbase       = reinterpret_cast<const char*>(slots + ((uint64_t)partA << PJ_SUB_LOG2));
+        const uint32_t sh_slot  = 32u - log2cap, sh_tag = 28u - log2cap;
+        uint32_t soff[PP_R];
+        uint32_t soff2 = 0;
+#pragma unroll
+        for (int j = 0; j < PP_R; ++j) {
+          // (a COPY the compiler cannot see through: the rows' registers are free for the next request from here on, and the copy is made
+          //  HERE, where the rows are needed anyway.  Left to itself the compiler keeps one value and rotates the register sets with
+          //  copies at the loop's back edge -- copies of registers whose loads are still in flight: a full wait every second trip.)
+          asm volatile("v_mov_b32 %0, %3\n\tv_mov_b32 %1, %4\n\tv_mov_b32 %2, %5"
+                       : "=&v"(Mn.klo[j]), "=&v"(Mn.khi[j]), "=&v"(Mn.idx[j])
+                       : "v"(Ru.r[j].x), "v"(Ru.r[j].y), "v"(Ru.r[j].z));
+          soff[j]   = 0;
+          if (woff + (uint32_t)j * GX_WAVE < cntA) {
+            const uint64_t key = ((uint64_t)Mn.khi[j] << 32) | Mn.klo[j];
+            const uint32_t hi  = (uint32_t)((key * 0x9E3779B97F4A7C15ull) >> 32);
+            const uint32_t li  = (hi >> sh_slot) - sub_lo;
+            uint32_t tg        = (hi >> sh_tag) & 15u;
+            tg                 = tg ? tg : 8u;
+            const uint32_t tagpat = tg * 0x11111111u;
+            const uint32_t w0 = s_tagw[li >> 3], w1 = s_tagw[(li >> 3) + 1], w2 = s_tagw[(li >> 3) + 2];
+            const uint32_t sh = (li & 7u) * 4u;
+            const uint32_t x0 = __builtin_amdgcn_alignbit(w1, w0, sh), x1 = __builtin_amdgcn_alignbit(w2, w1, sh);
+            const uint32_t y0 = x0 ^ tagpat, y1 = x1 ^ tagpat;
+            const uint32_t z0 = ~(((x0 & 0x77777777u) + 0x77777777u) | x0) & 0x88888888u;  // empty slots
+            const uint32_t z1 = ~(((x1 & 0x77777777u) + 0x77777777u) | x1) & 0x88888888u;
+            const uint32_t m0 = ~(((y0 & 0x77777777u) + 0x77777777u) | y0) & 0x88888888u;  // tag matches
+            const uint32_t m1 = ~(((y1 & 0x77777777u) + 0x77777777u) | y1) & 0x88888888u;
+            const uint32_t c0 = m0 & ((z0 & (0u - z0)) - 1u);                               // ... below the first empty one
+            const uint32_t c1 = z0 ? 0u : (m1 & ((z1 & (0u - z1)) - 1u));
+            const uint32_t nc = (uint32_t)__builtin_popcount(c0) + (uint32_t)__builtin_popcount(c1);
+            uint32_t f        = 1u << j;
+            if (nc) {
+              f |= 1u << (4 + j);
+              const uint32_t first = c0 ? ((uint32_t)__builtin_ctz(c0) >> 2) : 8u + ((uint32_t)__builtin_ctz(c1) >> 2);
+              soff[j]              = li + first;
+            }
+            // More than the first candidate.  A dependent read in S3 would wait for EVERY load in flight (they return in order),
+            // i.e. empty the pipeline this loop exists to keep full: 92 % of the wave-trips hold such a row.  So the common case --
+            // exactly two candidates, the chain ends inside the window, the lane's first such row of the trip -- gets its second
+            // slot requested here as well; what remains (~1e-4 of the rows) walks its chain in S3.
+            if (nc > 1 || (z0 | z1) == 0) {
+              if (nc == 2 && (z0 | z1) != 0 && !((Mn.fl >> 12) & 1u)) {
+                const uint32_t d0 = c0 & (c0 - 1u);                 // (c1:c0) without its lowest candidate
+                const uint32_t d1 = c0 ? c1 : (c1 & (c1 - 1u));
+                soff2 = li + (d0 ? ((uint32_t)__builtin_ctz(d0) >> 2) : 8u + ((uint32_t)__builtin_ctz(d1) >> 2));
+                f |= (1u << 12) | ((uint32_t)j << 13);
+              } else {
+                f |= 1u << (8 + j);
+              }
+            }
+            Mn.fl |= f;
+          }
+        }
+        if (!last) {
+#pragma unroll
+          for (int j = 0; j < PP_R; ++j) Mn.sv[j] = *reinterpret_cast<const Raw*>(sbase + soff[j] * (uint32_t)sizeof(Slot<K>));
+          Mn.sv2 = *reinterpret_cast<const Raw*>(sbase + soff2 * (uint32_t)sizeof(Slot<K>));
+        } else {  // the table's last sub-table: a window may wrap to slot 0
+#pragma unroll
+          for (int j = 0; j < PP_R; ++j) Mn.sv[j] = *reinterpret_cast<const Raw*>(&slots[((uint64_t)sub_lo + soff[j]) & mask]);
+          Mn.sv2 = *reinterpret_cast<const Raw*>(&slots[((uint64_t)sub_lo + soff2) & mask]);
+        }
+      }
+      // ---------------- S3(t-2): compare the slots requested last trip, stage the matches
+      const int it3 = t - 2;
+      {  // (Mo.fl = 0 without a piece)
+        const unsigned buf = (unsigned)(it3 + 3) % 3u;
+        uint32_t m[PP_R];
+        int32_t first[PP_R];
+        bool multi = false;
+#pragma unroll
+        for (int j = 0; j < PP_R; ++j) {
+          // (compared as two words: a 64-bit compare wants an aligned register pair, and the pair was put together by copies at the
+          //  loop's back edge -- of registers whose loads are still in flight)
+          const K key = ((uint64_t)Mo.khi[j] << 32) | Mo.klo[j];
+          m[j]        = ((Mo.fl >> (4 + j)) & 1u) && Mo.sv[j].x == Mo.klo[j] && Mo.sv[j].y == Mo.khi[j] ? 1u : 0u;
+          first[j]    = m[j] ? (int32_t)Mo.sv[j].z : NO_MATCH;
+          if (((Mo.fl & 0x7000u) == (0x1000u | ((uint32_t)j << 13))) & (Mo.sv2.x == Mo.klo[j]) & (Mo.sv2.y == Mo.khi[j])) {  // (no short cut: sv2 is LOOKED AT on every path)
+            if (m[j] == 0) first[j] = (int32_t)Mo.sv2.z;
+            ++m[j];
+          }
+          bool settled = true;
+          if (ABL != 4 && ((Mo.fl >> (8 + j)) & 1u)) {  // rare (~1e-3 of the rows): three or more candidates, a chain beyond the window, ...
+            // NOT walked here: a dependent read waits for every load in flight (this trip's rows and slots included) -- with these rows
+            // walked in place the kernel took 8.9 ms, without them 5.0 (profiles/r6_run36_join_ab.txt).  The row goes to the workgroup's
+            // slice of the overflow list (position from an LDS counter, a plain store) and k_pj2_probe_rare settles it afterwards.
+            const unsigned int op = pt.ovf ? atomicAdd(&s_ovf, 1u) : 0xFFFFFFFFu;
+            if (op < pt.ovf_cap) {
+              PjRec rr;
+              rr.klo = Mo.klo[j];
+              rr.khi = Mo.khi[j];
+              rr.row = Mo.idx[j];
+              pt.ovf[(size_t)blockIdx.x * pt.ovf_cap + op] = rr;
+              m[j]     = 0;
+              first[j] = NO_MATCH;
+              settled  = false;
+            } else {  // the slice is full (or there is none): in place
+              walk(key, m[j], first[j]);
+            }
+          }
+          if (left_outer && settled && ((Mo.fl >> j) & 1u) && m[j] == 0) m[j] = 1;  // (row, JoinNoMatch); first[j] is NO_MATCH
+          multi |= m[j] > 1;
+        }
+        if (ballot(multi) == 0) {  // the common case: at most one pair per row -- one reservation for the wave's four rows
+          uint64_t bb[PP_R];
+          uint32_t tot = 0;
+#pragma unroll
+          for (int j = 0; j < PP_R; ++j) {
+            bb[j] = ballot(m[j] != 0);
+            tot += (uint32_t)__builtin_popcountll(bb[j]);
+          }
+          if (tot) {
+            uint32_t wbase = 0;
+            if (lane == 0) wbase = atomicAdd(&s_cnt[(unsigned)it3 & 7u], tot);
+            wbase = (uint32_t)__builtin_amdgcn_readfirstlane((int)wbase);
+#pragma unroll
+            for (int j = 0; j < PP_R; ++j) {
+              const uint32_t pos = wbase + (uint32_t)__builtin_popcountll(bb[j] & lanemask_lt());
+              wbase += (uint32_t)__builtin_popcountll(bb[j]);
+              if (m[j]) {
+                if (pos < (uint32_t)PP_ROWS) {
+                  s_sidx[buf * PP_ROWS + pos]   = Mo.idx[j];
+                  s_sfirst[buf * PP_ROWS + pos] = first[j];
+                } else {  // staging full (another wave staged duplicates): reserve and write directly.  (an atomic store: an ordinary one is
+                          // merged with the LDS store of the other branch into ONE flat store through a selected pointer -- and a pending FLAT
+                          // access makes the compiler wait with vmcnt(0) for EVERY load of the kernel: no load stays in flight across a use)
+                  const unsigned long long gp = atomicAdd(cursor, 1ull);
+                  if ((int64_t)gp < capacity) {
+                    __hip_atomic_store(&out_probe[gp], (int32_t)(Mo.idx[j]), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    __hip_atomic_store(&out_build[gp], (int32_t)(first[j]), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                  }
+                }
+              }
+            }
+          }
+        } else {  // duplicate build keys somewhere in the wave: per-row reservations, chains walked again
+#pragma unroll
+          for (int j = 0; j < PP_R; ++j) {
+            if (ballot(m[j] != 0) == 0) continue;
+            const uint32_t sc  = wave_inclusive_scan(m[j], SumOp());
+            const uint32_t off = sc - m[j];
+            const uint32_t tot = shfl(sc, GX_WAVE - 1);
+            uint32_t wbase     = 0;
+            if (lane == 0) wbase = atomicAdd(&s_cnt[(unsigned)it3 & 7u], tot);
+            wbase = (uint32_t)__builtin_amdgcn_readfirstlane((int)wbase);
+            if (m[j] == 0) continue;
+            const uint32_t pos = wbase + off;
+            const K rkey       = ((uint64_t)Mo.khi[j] << 32) | Mo.klo[j];
+            const int32_t ridx = Mo.idx[j];
+            if (m[j] == 1) {
+              if (pos < (uint32_t)PP_ROWS) {
+                s_sidx[buf * PP_ROWS + pos]   = ridx;
+                s_sfirst[buf * PP_ROWS + pos] = first[j];
+              } else {
+                const unsigned long long gp = atomicAdd(cursor, 1ull);
+                if ((int64_t)gp < capacity) {
+                  __hip_atomic_store(&out_probe[gp], (int32_t)(ridx), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                  __hip_atomic_store(&out_build[gp], (int32_t)(first[j]), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                }
+              }
+            } else {
+              const uint32_t room   = pos < (uint32_t)PP_ROWS ? (uint32_t)PP_ROWS - pos : 0u;
+              const uint32_t staged = room < m[j] ? room : m[j];
+              unsigned long long gp = 0;
+              if (staged < m[j]) gp = atomicAdd(cursor, (unsigned long long)(m[j] - staged));
+              uint32_t seen = 0;
+              uint64_t hh   = slot_of<K>(rkey, log2cap);
+              for (;;) {
+                K k;
+                int32_t r;
+                load_slot<K>(&slots[hh], k, r);
+                if (r == EMPTY_ROW) break;
+                if (k == rkey) {
+                  if (seen < staged) {
+                    s_sidx[buf * PP_ROWS + pos + seen]   = ridx;
+                    s_sfirst[buf * PP_ROWS + pos + seen] = r;
+                  } else {
+                    if ((int64_t)gp < capacity) {
+                      __hip_atomic_store(&out_probe[gp], (int32_t)(ridx), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                      __hip_atomic_store(&out_build[gp], (int32_t)(r), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    }
+                    ++gp;
+                  }
+                  ++seen;
+                }
+                hh = (hh + 1) & mask;
+              }
+            }
+          }
+        }
+      }
+      // ---------------- the piece that enters S2 next trip
+      validA = pvalid != 0;
+      if (done_at < 0 && !validA) done_at = t;
+      partA = validA ? partN : partA;  // (an empty trip keeps the tags it has)
+      cntA  = cntN;
+      __syncthreads();  // X(t): staging of piece t-2 complete, s_base of piece t-3 visible
+      if (done_at >= 0 && t >= done_at + 3) return true;
+      // ---------------- flush of piece t-3: two coalesced streams
+      const int itf = t - 3;
+      if (itf >= 0) {
+        const unsigned buf          = (unsigned)itf % 3u;
+        unsigned int c              = s_cnt[(unsigned)itf & 7u];
+        c                           = c < (unsigned)PP_ROWS ? c : (unsigned)PP_ROWS;
+        const unsigned long long gb = s_base[buf];
+        for (unsigned int i = tid; i < c; i += PP_PW * GX_WAVE) {
+          const unsigned long long gp = gb + i;
+          if ((int64_t)gp < capacity) {
+            __builtin_nontemporal_store(s_sidx[buf * PP_ROWS + i], &out_probe[gp]);
+            __builtin_nontemporal_store(s_sfirst[buf * PP_ROWS + i], &out_build[gp]);
+          }
+        }
+      }
+      return false;
+    };
+    for (int t = 0;; t += 2) {
+      if (trip(t, R0, R1, M0, M1)) break;      // rows(t) -> R0; S2 reads R1 (rows t-1) -> M0; S3 reads M1 (piece t-2)
+      if (trip(t + 1, R1, R0, M1, M0)) break;
+    }
+    // (every S3 lies before the barrier the loop was left behind)
+    if (tid == 0 && pt.ovf_count) pt.ovf_count[blockIdx.x] = s_ovf < pt.ovf_cap ? s_ovf : pt.ovf_cap;
+    return;
+  }
   K kN[PP_R];                // EARLY: loads of trip t, issued at its top
   int32_t iN[PP_R];
   K kA[PP_R];                // S1 -> S2
@@ -2825,8 +3156,8 @@ k_pj2_probe_pipe(const K* __restrict__ pkeys, const int32_t* __restrict__ pidx, 
           } else {  // staging full (duplicate build keys): reserve and write directly
             const unsigned long long gp = atomicAdd(cursor, 1ull);
             if ((int64_t)gp < capacity) {
-              out_probe[gp] = ridx;
-              out_build[gp] = first[j];
+              __hip_atomic_store(&out_probe[gp], (int32_t)(ridx), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+              __hip_atomic_store(&out_build[gp], (int32_t)(first[j]), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             }
           }
         } else {  // duplicate build keys: walk the chain again (lines are cache-resident)
@@ -2847,8 +3178,8 @@ k_pj2_probe_pipe(const K* __restrict__ pkeys, const int32_t* __restrict__ pidx, 
                 s_sfirst[buf * PP_ROWS + pos + seen] = r;
               } else {
                 if ((int64_t)gp < capacity) {
-                  out_probe[gp] = ridx;
-                  out_build[gp] = r;
+                  __hip_atomic_store(&out_probe[gp], (int32_t)(ridx), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                  __hip_atomic_store(&out_build[gp], (int32_t)(r), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 }
                 ++gp;
               }
@@ -2973,6 +3304,94 @@ k_pj2_probe_pipe(const K* __restrict__ pkeys, const int32_t* __restrict__ pidx, 
       for (int j = 0; j < PP_R; ++j) {
         kA[j] = kN[j];
         iA[j] = iN[j];
+      }
+    }
+  }
+}
+
+// The rows k_pj2_probe_pipe<LONG> did not settle (PieceTable::ovf): workgroup b walks the chains of slice b from their home slots and
+// emits the pairs -- a count walk, ONE reservation per wave, a write walk.  ~1e-3 of the probe rows, read from wherever the table lies.
+constexpr unsigned int PR_SUB = 8;  // workgroups per slice
+constexpr int PR_U            = 4;  // rows per thread and round
+template <typename K>
+__global__ void __launch_bounds__(256) k_pj2_probe_rare(const PjRec* __restrict__ ovf, unsigned int ovf_cap, const unsigned int* __restrict__ ovf_count,
+                                                        const Slot<K>* __restrict__ slots, uint32_t log2cap, int left_outer,
+                                                        int32_t* __restrict__ out_probe, int32_t* __restrict__ out_build, int64_t capacity,
+                                                        unsigned long long* cursor)
+{
+  // PR_SUB workgroups per slice: the walks are chains of dependent reads from HBM -- what hides them is waves in flight
+  const uint64_t mask    = (1ull << log2cap) - 1;
+  const unsigned int sl  = blockIdx.x / PR_SUB, sub = blockIdx.x % PR_SUB;
+  const unsigned int cnt = ovf_count[sl];
+  const PjRec* mine      = ovf + (size_t)sl * ovf_cap;
+  // A chain is a run of adjacent 16-byte slots: FOUR slots are requested at once (one or two lines).  Each thread walks PR_U rows and keeps
+  // their match counts and first matches in registers; the workgroup then makes ONE reservation for all of them (with one returning atomic
+  // per wave and row -- 6e4 on the cursor's address inside 0.2 ms of work -- the kernel took 0.8 ms whatever its walks cost) and only rows
+  // with several matches (duplicate build keys) walk a second time.
+  auto walk4 = [&](K key, auto&& on_match) {
+    uint64_t hh = slot_of<K>(key, log2cap);
+    for (;;) {
+      K k[4];
+      int32_t br[4];
+#pragma unroll
+      for (int q = 0; q < 4; ++q) load_slot<K>(&slots[(hh + q) & mask], k[q], br[q]);
+      bool end = false;
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        if (!end && br[q] == EMPTY_ROW) end = true;
+        if (!end && k[q] == key) on_match(br[q]);
+      }
+      if (end) break;
+      hh = (hh + 4) & mask;
+    }
+  };
+  __shared__ unsigned long long s_tmp[256 / GX_WAVE];
+  __shared__ unsigned long long s_gbase;
+  for (unsigned int r0 = sub * (256u * PR_U); r0 < cnt; r0 += 256u * PR_U * PR_SUB) {  // (block-uniform)
+    PjRec rec[PR_U];
+    uint32_t m[PR_U];
+    int32_t first[PR_U];
+    unsigned long long mine_tot = 0;
+#pragma unroll
+    for (int u = 0; u < PR_U; ++u) {
+      const unsigned int i = r0 + (unsigned int)u * 256u + threadIdx.x;
+      m[u]     = 0;
+      first[u] = NO_MATCH;
+      rec[u]   = PjRec{0u, 0u, 0};
+      if (i < cnt) {
+        rec[u]      = mine[i];
+        const K key = (K)(((uint64_t)rec[u].khi << 32) | rec[u].klo);
+        walk4(key, [&](int32_t br) {
+          if (m[u] == 0) first[u] = br;
+          ++m[u];
+        });
+        if (left_outer && m[u] == 0) m[u] = 1;  // (row, JoinNoMatch)
+        mine_tot += m[u];
+      }
+    }
+    unsigned long long total = 0;
+    unsigned long long gp    = block_exclusive_scan<256>(mine_tot, 0ull, SumOp(), s_tmp, &total);
+    if (threadIdx.x == 0) s_gbase = total ? atomicAdd(cursor, total) : 0ull;
+    __syncthreads();
+    gp += s_gbase;
+    __syncthreads();  // (s_gbase is rewritten by the next round)
+#pragma unroll
+    for (int u = 0; u < PR_U; ++u) {
+      if (m[u] == 1) {
+        if ((int64_t)gp < capacity) {
+          out_probe[gp] = rec[u].row;
+          out_build[gp] = first[u];
+        }
+        ++gp;
+      } else if (m[u] > 1) {
+        const K key = (K)(((uint64_t)rec[u].khi << 32) | rec[u].klo);
+        walk4(key, [&](int32_t br) {
+          if ((int64_t)gp < capacity) {
+            out_probe[gp] = rec[u].row;
+            out_build[gp] = br;
+          }
+          ++gp;
+        });
       }
     }
   }
@@ -3623,10 +4042,11 @@ static inline void jprof_mark(int i, hipStream_t s)
 static thread_local int g_pj_probe = 0; // probe kernel: 0 = default (software-pipelined tag probe), 1 = round-1 tag probe (A/B knob)
 static thread_local int g_pj_build = 0; // partitioned build: 0 = window build, table composed in LDS and written once (round 4b, default), 2 = sub-table build with
                                         // the tags in LDS (round 4a), 1 = round-2 kernel (global CAS + k_tags) (A/B knob)
-// round 6 (gx_join_set_experiment; default 5): bit 0 = the partition pass writes 12-byte {key, row} records (k_pj2_scatter_rec) and the probe
+// round 6 (gx_join_set_experiment; default 133 = bits 0, 2, 7): bit 0 = the partition pass writes 12-byte {key, row} records (k_pj2_scatter_rec) and the probe
 // reads them (8-byte keys); bit 1 = with bit 0, 24576-row scatter tiles; bit 2 = pipelined service wave of k_pj2_probe_pipe on fixed
 // pieces per region; bit 3 = without bit 0, the windowed scatter writing key / row arrays (A/B); bits 4-6 = ablations (wrong results)
-static thread_local int g_pj_xp = 5;
+static thread_local int g_pj_xp = 133;
+static thread_local int g_pj_ovf_cap = 0;  // tests: rows per overflow slice of k_pj2_probe_pipe<LONG> (0 = n / 16 / 256)
 static thread_local int g_pj_tile = 0;  // scatter tile rows: 0 = default, else 4096 / 8192 / 16384 (A/B knob)
 static thread_local int g_pj_probe_early = 0;  // round-3 probe: 1 = rows of a piece requested at the top of the trip, 0 = at its end (default: with the
                                   // deferral queue the early form no longer fits 128 VGPRs) (A/B knob)
@@ -3781,6 +4201,16 @@ int probe_partitioned_impl2(const K* keys, int64_t n, const Slot<K>* slots, uint
   PjPlan* plan   = c.take<PjPlan>(1);
   K* pkeys       = c.take<K>(nbuf);          // (record form: the 12-byte records occupy pkeys and pidx, which are carved back to back
   int32_t* pidx  = c.take<int32_t>(nbuf);    //  -- 256-byte carving leaves pidx at or behind pkeys + 8 nbuf, so 12 nbuf bytes fit)
+  // bit 7 (k_pj2_probe_pipe<LONG>): the overflow list -- one slice per probe workgroup, n / 16 rows in all (rows that need a dependent
+  // read: 1e-3 of them with keys that hash like random numbers; a full slice sends its workgroup back to walking in place)
+  const bool longp        = rec && (g_pj_xp & 128) != 0 && ((g_pj_xp >> 4) & 7) == 0 && lg <= 28 && sizeof(K) == 8;
+  constexpr int OVF_WGS   = 1024;  // >= any probe grid
+  int64_t ovf_cap64       = n / 16 / 256;
+  if (ovf_cap64 < 64) ovf_cap64 = 64;
+  if (g_pj_ovf_cap > 0) ovf_cap64 = g_pj_ovf_cap;  // (tests: tiny slices)
+  const unsigned int ovf_cap = (unsigned int)ovf_cap64;
+  PjRec* ovf              = longp ? c.take<PjRec>((size_t)ovf_cap * 256) : nullptr;
+  unsigned int* ovf_count = longp ? c.take<unsigned int>(OVF_WGS) : nullptr;
   if (!tmp) {
     *tmp_bytes = c.total();
     return 0;
@@ -3798,6 +4228,8 @@ int probe_partitioned_impl2(const K* keys, int64_t n, const Slot<K>* slots, uint
       kprobe        = abl == 1 ? k_pj2_probe_pipe<K, false, false, true, 1> : abl == 2 ? k_pj2_probe_pipe<K, false, false, true, 2>
                       : abl == 3 ? k_pj2_probe_pipe<K, false, false, true, 3>
                       : k_pj2_probe_pipe<K, false, false, true>;
+      if ((g_pj_xp & 128) != 0 && abl == 0 && lg <= 28) kprobe = k_pj2_probe_pipe<K, false, false, true, 0, true>;  // bit 7: every load a trip ahead of its use
+      if ((g_pj_xp & 128) != 0 && abl == 4 && lg <= 28) kprobe = k_pj2_probe_pipe<K, false, false, true, 4, true>;
     }
   }
   constexpr size_t lds_p = ((size_t)1 << (PJ_SUB_LOG2 - 1)) + PP_TAGPAD + (size_t)6 * PP_ROWS * sizeof(int32_t);
@@ -3837,6 +4269,8 @@ int probe_partitioned_impl2(const K* keys, int64_t n, const Slot<K>* slots, uint
       GX_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(k_pj2_probe_pipe<K, false, false, true, 1>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_p));
       GX_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(k_pj2_probe_pipe<K, false, false, true, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_p));
       GX_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(k_pj2_probe_pipe<K, false, false, true, 3>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_p));
+      GX_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(k_pj2_probe_pipe<K, false, false, true, 0, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_p));
+      GX_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(k_pj2_probe_pipe<K, false, false, true, 4, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_p));
     }
     GX_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(k_pj2_probe_pipe<K, true, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_p));
     GX_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(k_pj2_probe_pipe<K, false, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_p));
@@ -3921,11 +4355,20 @@ int probe_partitioned_impl2(const K* keys, int64_t n, const Slot<K>* slots, uint
     } else {
       int64_t g = num_cus > 0 ? num_cus : 256;
       if (((g_pj_xp >> 16) & 255) != 0) g = ((g_pj_xp >> 16) & 255) * 4;  // measurement: bits 16-23 = workgroups of the probe / 4
+      if (g > 256 && longp) g = 256;  // (the overflow list has 256 slices)
       hipLaunchKernelGGL(kprobe, dim3((unsigned)g), dim3(PP_BT), lds_p, s, pkeys, pidx, t, pbits, slots, lg, left_outer, out_probe, out_build, capacity, cur);
+      if (t.ovf)
+        hipLaunchKernelGGL((k_pj2_probe_rare<K>), dim3((unsigned)g * PR_SUB), dim3(256), 0, s, t.ovf, t.ovf_cap, t.ovf_count, slots, lg, left_outer, out_probe, out_build,
+                           capacity, cur);
     }
   };
   hipLaunchKernelGGL(k_pj2_offsets, dim3(1), dim3(1024), 0, s, plan2, pbits, cap, piece_rows);
-  PieceTable pt{plan2->chunk0, plan2->list_chunk0, plan2->ticket, nullptr, plan2->fill, cap, PJ_NR, 0u, nullptr};
+  PieceTable pt{plan2->chunk0, plan2->list_chunk0, plan2->ticket, nullptr, plan2->fill, cap, PJ_NR, 0u, nullptr, nullptr, 0u, nullptr};
+  if (longp && !alt) {
+    pt.ovf       = ovf;
+    pt.ovf_cap   = ovf_cap;
+    pt.ovf_count = ovf_count;
+  }
   if ((g_pj_xp & 4) != 0 && !alt) {  // round 6: pipelined service wave on fixed pieces per region
     pt.fixedk = (cap + piece_rows - 1) / piece_rows;
     pt.gate   = &plan2->fallback;
@@ -3939,7 +4382,7 @@ int probe_partitioned_impl2(const K* keys, int64_t n, const Slot<K>* slots, uint
   hipLaunchKernelGGL(k_pj_offsets, dim3(1), dim3(1024), 0, s, plan, pbits, piece_rows, &plan2->fallback);
   if (rec || win_soa) launch_rec(true);
   else hipLaunchKernelGGL(kexact, dim3((unsigned)grid), dim3(1024), lds_s, s, keys, n, plan2, plan, pbits, rrows, cap, ntiles, pkeys, pidx, part_of, row0, payload);
-  PieceTable pe{plan->chunk0, plan->list_chunk0, plan2->ticket_exact, plan->offset, nullptr, 0u, 1, 0u, nullptr};
+  PieceTable pe{plan->chunk0, plan->list_chunk0, plan2->ticket_exact, plan->offset, nullptr, 0u, 1, 0u, nullptr, pt.ovf, pt.ovf_cap, pt.ovf_count};
   launch_probe(pe);
   jprof_mark(3, s);
   g_jprof.marked = g_jprof.enabled;
@@ -4381,6 +4824,7 @@ void gx_join_set_partition_mode(int speculative, int early_loads)
 
 void gx_join_set_build_kernel(int which) { gx::join::g_pj_build = (which == 1 || which == 2) ? which : 0; }
 void gx_join_set_experiment(int bits) { gx::join::g_pj_xp = bits; }
+void gx_join_set_overflow_slice(int rows) { gx::join::g_pj_ovf_cap = rows > 0 ? rows : 0; }
 void gx_join_set_scatter_tile(int rows)
 {
   gx::join::g_pj_tile = (rows == 4096 || rows == 8192 || rows == 16384) ? rows : 0;

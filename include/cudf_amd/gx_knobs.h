@@ -138,14 +138,21 @@ void gx_join_set_build_kernel(int which);
  * the largest that fits the LDS next to the per-partition counters). */
 void gx_join_set_scatter_tile(int rows);
 
-/* A/B knob (per calling thread; round 6; default 5 = bits 0 and 2): bit 0 = the partition pass of the partitioned probe writes 12-byte
+/* A/B knob (per calling thread; round 6; default 133 = bits 0, 2 and 7): bit 0 = the partition pass of the partitioned probe writes 12-byte
  * {key, row} RECORDS (one 96-B run per tile and partition instead of a 64-B key run and a 32-B row run: k_pj2_scatter_rec) and the
  * pipelined probe reads them (8-byte keys, default probe kernel only); bit 1 = with bit 0: 24576-row scatter tiles (12-row runs);
  * bit 2 = the pipelined probe's service wave takes tickets that ARE (region, piece) -- every region is cut into the same number of
  * pieces -- and issues the ticket atomic and the fill-counter read one trip ahead of their use (0: the round-3 chain of four
  * dependent round trips per piece); bit 3 = without bit 0: the windowed scatter writing key / row arrays (measured slower);
- * bits 4-6 = ablations of the probe for measurements (WRONG results: 1 no slot reads, 2 no staging, 3 no tag lookups). */
+ * bits 4-6 = ablations of the probe for measurements (WRONG results: 1 no slot reads, 2 no staging, 3 no tag lookups; with bit 7:
+ * 4 no chain walks); bit 7 (with bit 0, tables of <= 2^28 slots) = the probe with two register sets, every load requested a whole trip
+ * before its use, rows that need a dependent read deferred to an overflow list (k_pj2_probe_rare). */
 void gx_join_set_experiment(int bits);
+
+/* Tests (per calling thread): rows per workgroup slice of the overflow list of the probe selected by gx_join_set_experiment bit 7
+ * (k_pj2_probe_pipe<LONG>: every load a trip ahead of its use; rows that need a dependent read go to the list and are settled by
+ * k_pj2_probe_rare).  0 = the default, n / 16 / 256 rows; a full slice makes its workgroup walk such rows in place. */
+void gx_join_set_overflow_slice(int rows);
 
 /* A/B knob (per calling thread): 0 = software-pipelined tag probe on LDS-resident 4-bit tags (default), 1 = the round-1 tag probe,
  * 2 / 3 = the L2-resident DIRECT probe of round 5 (k_pj3_probe_direct, 4 / 2 rows per thread): no tags, no LDS tables -- the

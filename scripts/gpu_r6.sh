@@ -45,7 +45,7 @@ for step in "$@"; do
       echo "# round 6 $TAG: python bench.py --workload join --no-cpu-baseline --join-xp <xp> (1e9 probe x 1e8 build rows, random 64-bit keys); ms per step | scatter | probe" >> $out
       for xp in ${rest//,/ }; do
         early=""; case $xp in *e) early="--join-early-loads 1"; xp=${xp%e};; *d) early="--join-early-loads 2"; xp=${xp%d};; *b) early="--join-early-loads 3"; xp=${xp%b};; esac
-        unchk=""; [ $xp -ge 16 ] && unchk="--join-unchecked"
+        unchk=""; [ $(( (xp >> 4) & 7 )) -ne 0 ] && unchk="--join-unchecked"
         [ -n "$early" ] && echo -n "$early " | tee -a $out
         timeout 400 python bench.py --workload join --no-cpu-baseline --join-xp $xp $unchk $early > $O/r6_${TAG}_bench_join_xp$xp.jsonl 2>> $O/r6_${TAG}.log
         python - "$O/r6_${TAG}_bench_join_xp$xp.jsonl" $xp <<'PY' | tee -a $out

@@ -18,7 +18,7 @@ def gx():
     from cudf_amd import Column, ops, _lib
     yield Column, ops, _lib
     _lib.lib.gx_join_set_partition_mode(1, 0)
-    _lib.lib.gx_join_set_experiment(5)
+    _lib.lib.gx_join_set_experiment(133)
 
 
 def _pairs(l, r):
@@ -155,7 +155,7 @@ def test_l2_resident_direct_probe_matches_oracle(gx, dtype, shape, kernel):
         _lib.lib.gx_join_set_partition_mode(1, 0)
 
 
-@pytest.mark.parametrize("shape,xp", [(sh, xp) for xp in (0, 1, 3, 4, 5, 12) for sh in ("uniform", "dup_build", "hot_key", "one_partition", "edge_chains")])
+@pytest.mark.parametrize("shape,xp", [(sh, xp) for xp in (0, 1, 3, 4, 5, 12, 129, 133) for sh in ("uniform", "dup_build", "hot_key", "one_partition", "edge_chains")])
 def test_record_form_partition_probe_matches_oracle(gx, shape, xp):
     """Round 6: the partition pass writes 12-byte {key, row} records (k_pj2_scatter_rec: 16384- or, xp bit 1, 24576-row tiles
     through 8192-position LDS windows, the ragged tail as a second launch) and the pipelined probe reads a lane's four rows as
@@ -186,4 +186,40 @@ def test_record_form_partition_probe_matches_oracle(gx, shape, xp):
     finally:
         ops.HashJoin.PARTITIONED_MIN_ROWS = old_min
         _lib.lib.gx_join_set_partition_mode(1, 0)
-        _lib.lib.gx_join_set_experiment(5)
+        _lib.lib.gx_join_set_experiment(133)
+
+
+@pytest.mark.parametrize("shape,slice_rows", [(sh, sl) for sl in (0, 3) for sh in ("uniform", "dup_build", "hot_key", "edge_chains")])
+def test_long_probe_overflow_list_matches_oracle(gx, shape, slice_rows):
+    """Round 6, gx_join_set_experiment bit 7: k_pj2_probe_pipe<LONG> (two register sets, every load a trip ahead of its use) sends the
+    rows that need a dependent read -- three or more tag candidates, a chain beyond the 16-slot window, a lane's second two-candidate
+    row -- to its workgroup's overflow slice, and k_pj2_probe_rare walks them afterwards.  slice_rows = 3: the slices fill at once and the
+    rows are walked in place (the fallback).  dup_build / hot_key: duplicate build keys (several pairs per row, the re-walk staging);
+    inner and left-outer pairs against the oracle."""
+    Column, ops, _lib = gx
+    rng = np.random.default_rng(4242)
+    nb, npr = 700_000, (1 << 20) + 4321
+    build, probe = _inputs(rng, "int64", shape, nb, npr)
+    el, er = orc.inner_join(probe, build)
+    old_min = ops.HashJoin.PARTITIONED_MIN_ROWS
+    ops.HashJoin.PARTITIONED_MIN_ROWS = 1 << 20
+    try:
+        _lib.lib.gx_join_set_experiment(133)
+        _lib.lib.gx_join_set_overflow_slice(slice_rows)
+        _lib.lib.gx_join_set_partition_mode(2, 0)
+        hj = ops.HashJoin(Column.from_numpy(build))
+        for _ in range(2):  # the object is probed again: the overflow counters are rewritten by every launch
+            l, r = hj.inner_join(Column.from_numpy(probe))
+            got = _pairs(l, r)
+            np.testing.assert_array_equal(got[0], el)
+            np.testing.assert_array_equal(got[1], er)
+        pl, pr = hj.left_join(Column.from_numpy(probe))
+        wl, wr = orc.left_join([probe], [build])
+        a, b = _pairs(pl, pr), orc.canonical_pairs(wl, wr)
+        np.testing.assert_array_equal(a[0], b[0])
+        np.testing.assert_array_equal(a[1], b[1])
+    finally:
+        ops.HashJoin.PARTITIONED_MIN_ROWS = old_min
+        _lib.lib.gx_join_set_partition_mode(1, 0)
+        _lib.lib.gx_join_set_experiment(133)
+        _lib.lib.gx_join_set_overflow_slice(0)
