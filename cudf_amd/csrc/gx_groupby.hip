@@ -641,10 +641,13 @@ __global__ void __launch_bounds__(ABT) k_part_aggregate(const K* __restrict__ pk
         }
       }
       if (slot >= 0) {
-        if (HAS_VV) atomicAdd(&l_ca[slot], 1u);
+        // (workgroup scope: an ordinary atomicAdd here is merged with the one on the global counters of the other branch into ONE
+        //  flat_atomic_add through a selected pointer -- every row then pays a FLAT access, and a pending FLAT access makes the compiler
+        //  wait with vmcnt(0) lgkmcnt(0) for everything)
+        if (HAS_VV) __hip_atomic_fetch_add(&l_ca[slot], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
         if (fl) {
           LdsAcc<V, IS_FLOAT>::add(l_sum, l_comp, slot, val);
-          atomicAdd(&l_cv[slot], 1u);
+          __hip_atomic_fetch_add(&l_cv[slot], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
         }
       } else {
         const int64_t g = find_or_insert<K>(table, log2cap, key, st);
