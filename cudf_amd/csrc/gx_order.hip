@@ -384,9 +384,20 @@ struct RunSeg {  // per workgroup of pass A
   unsigned int count, pad;
 };
 
+// A listed head is its position; bit 31 = the run has EXACTLY two rows (seen in pass A whenever the word behind the run lies in the thread's
+// or its right neighbour's quad): pass B then needs neither the sorted words nor the probe for the run's end -- it reads the two rows pass A
+// wrote.  skip_lossless (one key column): runs inside a lossless bucket are not listed at all (one key value, already in row order).
+constexpr unsigned int OM_HEAD_L2 = 1u << 31;
 __global__ void __launch_bounds__(256) k_om_finish_a(const uint64_t* __restrict__ sorted, int64_t n, const OmPlan* __restrict__ plan, int32_t* __restrict__ out,
-                                                     unsigned int* __restrict__ heads, RunSeg* __restrict__ segs, int64_t chunk, unsigned int seg_cap)
+                                                     unsigned int* __restrict__ heads, RunSeg* __restrict__ segs, int64_t chunk, unsigned int seg_cap,
+                                                     int skip_lossless)
 {
+  __shared__ uint64_t s_bl[OM_B];  // first rank of bucket b | lossy << 63
+  // 0: every run is listed (no lossless bucket, or several key columns); 1: the head's bucket is looked up; 2: nothing is listed (every bucket lossless)
+  const int nlossy = plan->nlossy;
+  const int lmode  = !skip_lossless || nlossy == OM_B ? 0 : (nlossy == 0 ? 2 : 1);
+  if (lmode == 1)
+    for (int i = threadIdx.x; i < OM_B; i += 256) s_bl[i] = plan->base[i] | ((plan->meta[i] & 256u) ? (1ull << 63) : 0ull);
   // pure streaming: 8 bytes in and 4 bytes out per row, the neighbours' ranks through wave shuffles (the wave's edge lanes load
   // theirs), the heads of runs of equal ranks appended -- position only -- to the workgroup's own segment through an LDS counter
   __shared__ unsigned int s_n;
@@ -394,38 +405,77 @@ __global__ void __launch_bounds__(256) k_om_finish_a(const uint64_t* __restrict_
   __syncthreads();
   const int ib         = plan->ib;
   const uint64_t imask = (1ull << ib) - 1;
-  const int64_t p0 = (int64_t)blockIdx.x * chunk, p1 = p0 + chunk < n ? p0 + chunk : n;  // (chunk is a multiple of 512: whole waves of pairs)
+  const int64_t p0 = (int64_t)blockIdx.x * chunk, p1 = p0 + chunk < n ? p0 + chunk : n;  // (chunk is a multiple of 1024: whole waves of quads)
   unsigned int* mine = heads + (size_t)blockIdx.x * seg_cap;
   const unsigned lane = threadIdx.x & 63u;
   typedef uint64_t u64x2 __attribute__((ext_vector_type(2)));
-  typedef int32_t i32x2 __attribute__((ext_vector_type(2)));
-  // two consecutive words per thread: one 16-byte load, one 8-byte store (the sorted words start 256-byte aligned, p0 is a multiple of 512)
-  for (int64_t pb = p0; pb < p1; pb += 512) {
-    const int64_t p  = pb + 2 * (int64_t)threadIdx.x;
-    const bool live0 = p < p1, live1 = p + 1 < p1;
-    uint64_t w0 = 0, w1 = 0;
-    if (live1) {
-      const u64x2 v = __builtin_nontemporal_load(reinterpret_cast<const u64x2*>(sorted + p));
-      w0 = v.x;
-      w1 = v.y;
-    } else if (live0) {
-      w0 = sorted[p];
+  typedef int32_t i32x4 __attribute__((ext_vector_type(4)));
+  // FOUR consecutive words per thread: two 16-byte loads, one 16-byte store (the sorted words start 256-byte aligned, p0 is a multiple of
+  // 1024).  The edge lanes' neighbour words are requested together with the wave's own -- asked for where they are used, behind the
+  // shuffles, they were a second dependent round trip in every iteration (2 words per thread and that order: 4.0 ms per 1e9 rows).
+  for (int64_t pb = p0; pb < p1; pb += 1024) {
+    const int64_t p = pb + 4 * (int64_t)threadIdx.x;
+    uint64_t w[4]   = {0, 0, 0, 0};
+    uint64_t ep = ~0ull, en = ~0ull;  // the word before the thread's first / behind its last (edge lanes only)
+    const bool full = p + 3 < p1;
+    if (full) {
+      const u64x2 a = __builtin_nontemporal_load(reinterpret_cast<const u64x2*>(sorted + p));
+      const u64x2 c = __builtin_nontemporal_load(reinterpret_cast<const u64x2*>(sorted + p + 2));
+      w[0] = a.x;
+      w[1] = a.y;
+      w[2] = c.x;
+      w[3] = c.y;
+    } else {
+#pragma unroll
+      for (int k = 0; k < 4; ++k)
+        if (p + k < p1) w[k] = sorted[p + k];
     }
-    const uint64_t r0 = w0 >> ib, r1 = w1 >> ib;
-    uint64_t rp = __shfl_up(r1, 1), rn = __shfl_down(r0, 1);  // the previous lane's second word, the next lane's first
-    if (lane == 0) rp = (live0 && p > 0) ? sorted[p - 1] >> ib : ~0ull;
-    if (lane == 63 || p + 2 >= p1) rn = (live1 && p + 2 < n) ? sorted[p + 2] >> ib : ~0ull;
-    if (!live0) continue;
-    if (live1) __builtin_nontemporal_store(i32x2{(int32_t)(w0 & imask), (int32_t)(w1 & imask)}, reinterpret_cast<i32x2*>(out + p));
-    else out[p] = (int32_t)(w0 & imask);  // right unless the row sits in a run of a lossy bucket: pass B rewrites those
-    const bool n0 = live1 ? r1 == r0 : (p + 1 < n && (sorted[p + 1] >> ib) == r0);  // (live0 && !live1: the last row of the workgroup's range)
-    if (rp != r0 && n0) {  // word 0 heads a run
-      const unsigned int e = atomicAdd(&s_n, 1u);
-      if (e < seg_cap) mine[e] = (unsigned int)p;  // (seg_cap = chunk / 2 + 1 runs of >= 2 rows: cannot overflow)
+    const bool edge_n = lane == 63 || p + 4 >= p1;
+    if (lane == 0 && p < p1 && p > 0) ep = sorted[p - 1];
+    if (edge_n && p < p1) {  // the word behind the thread's last live one
+      const int64_t q = (p + 4 < p1 ? p + 4 : p1);
+      if (q < n) en = sorted[q];
     }
-    if (live1 && r0 != r1 && rn == r1) {  // word 1 heads a run
-      const unsigned int e = atomicAdd(&s_n, 1u);
-      if (e < seg_cap) mine[e] = (unsigned int)(p + 1);
+    uint64_t r[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) r[k] = w[k] >> ib;
+    uint64_t rp = __shfl_up(r[3], 1), rn = __shfl_down(r[0], 1);  // the previous lane's last word, the next lane's first
+    const uint64_t rn2 = __shfl_down(r[1], 1);                       // ... and its second
+    if (lane == 0) rp = ep == ~0ull ? ~0ull : ep >> ib;
+    if (edge_n) rn = en == ~0ull ? ~0ull : en >> ib;
+    if (p >= p1) continue;
+    if (full) {
+      __builtin_nontemporal_store(i32x4{(int32_t)(w[0] & imask), (int32_t)(w[1] & imask), (int32_t)(w[2] & imask), (int32_t)(w[3] & imask)},
+                                  reinterpret_cast<i32x4*>(out + p));
+    } else {
+#pragma unroll
+      for (int k = 0; k < 4; ++k)
+        if (p + k < p1) out[p + k] = (int32_t)(w[k] & imask);  // right unless the row sits in a run of a lossy bucket: pass B rewrites those
+    }
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      if (p + k >= p1) break;
+      const uint64_t prev = k == 0 ? rp : r[k - 1];
+      // the next rank: the thread's next live word, else the word behind the workgroup's range (en)
+      const uint64_t next = (k < 3 && p + k + 1 < p1) ? r[k + 1] : rn;
+      if (prev != r[k] && next == r[k]) {  // word k heads a run
+        if (lmode == 2) continue;
+        if (lmode == 1) {
+          int b = 0;
+#pragma unroll
+          for (int step = OM_B / 2; step > 0; step >>= 1)
+            if ((s_bl[b + step] & ~(1ull << 63)) <= r[k]) b += step;
+          if (!(s_bl[b] >> 63)) continue;
+        }
+        // the rank two words on, where this thread knows it (inside the workgroup's range, not across the wave's edge)
+        bool two = false;
+        if (p + k + 2 < p1) {
+          if (k <= 1) two = r[k + 2] != r[k];
+          else if (lane != 63) two = (k == 2 ? rn : rn2) != r[k];
+        }
+        const unsigned int e = atomicAdd(&s_n, 1u);
+        if (e < seg_cap) mine[e] = (unsigned int)(p + k) | (two ? OM_HEAD_L2 : 0u);  // (seg_cap = chunk / 2 + 1 runs of >= 2 rows: cannot overflow)
+      }
     }
   }
   __syncthreads();
@@ -635,8 +685,17 @@ __global__ void __launch_bounds__(256) k_om_finish_b(const uint64_t* __restrict_
     }
     __syncthreads();
     const unsigned int i = base + threadIdx.x;
-    if (i < cnt) {
-      const unsigned int p = mine[i];
+    const unsigned int hd = i < cnt ? mine[i] : 0u;
+    if (i < cnt && (hd & OM_HEAD_L2)) {  // two rows, a lossy bucket (pass A saw both): the rows as pass A wrote them, their keys, one compare
+      const unsigned int p = hd & ~OM_HEAD_L2;
+      const uint32_t r0 = (uint32_t)out[p], r1 = (uint32_t)out[p + 1];
+      const uint64_t k0 = pol.key(r0), k1 = pol.key(r1);
+      if (kr_less(pol, k1, r1, k0, r0)) {  // (one column, equal keys: r0 < r1 already)
+        out[p]     = (int32_t)r1;
+        out[p + 1] = (int32_t)r0;
+      }
+    } else if (i < cnt) {
+      const unsigned int p = hd;
       const uint64_t w0 = sorted[p], w1 = sorted[p + 1];
       const uint64_t r  = w0 >> ib;
       bool skip = false;
@@ -855,7 +914,7 @@ static FinGeo fin_geometry(int64_t n)
   FinGeo g;
   const int64_t want = (n + 511) / 512;
   g.wgs      = (unsigned int)(want < OM_FIN_WGS ? (want > 0 ? want : 1) : OM_FIN_WGS);
-  g.chunk    = ((n + g.wgs - 1) / g.wgs + 511) / 512 * 512;
+  g.chunk    = ((n + g.wgs - 1) / g.wgs + 1023) / 1024 * 1024;
   g.seg_cap  = (unsigned int)(g.chunk / 2 + 1);
   g.long_cap = (size_t)n / (OM_SMALL + 1) + 1;
   return g;
@@ -945,7 +1004,7 @@ static int sorted_order_words(const void* keys, int64_t n, int descending, int32
   // (behind the word sort its scratch is dead: the long-run list and slices alias it, past the plan header whose status word stays)
   const FinGeo g     = fin_geometry(n);
   const RunScratch R = run_scratch(L, g, n);
-  hipLaunchKernelGGL(k_om_finish_a, dim3(g.wgs), dim3(256), 0, s, (const uint64_t*)L.sorted, n, (const OmPlan*)L.plan, out, R.heads, R.segs, g.chunk, g.seg_cap);
+  hipLaunchKernelGGL(k_om_finish_a, dim3(g.wgs), dim3(256), 0, s, (const uint64_t*)L.sorted, n, (const OmPlan*)L.plan, out, R.heads, R.segs, g.chunk, g.seg_cap, 1);
   const OneCol<KIND> pol{k, desc_mask};
   hipLaunchKernelGGL((k_om_finish_b<OneCol<KIND>>), dim3(g.wgs), dim3(256), 0, s, (const uint64_t*)L.sorted, n, pol, L.plan, out, (const unsigned int*)R.heads,
                      (const RunSeg*)R.segs, g.seg_cap, R.longlist, (unsigned int)g.long_cap);
@@ -1024,7 +1083,7 @@ static int sorted_order_table(int ncols, const int* dtypes, const void* const* c
   if (rc) return rc;
   const FinGeo g     = fin_geometry(n);
   const RunScratch R = run_scratch(L, g, n);
-  hipLaunchKernelGGL(k_om_finish_a, dim3(g.wgs), dim3(256), 0, s, (const uint64_t*)L.sorted, n, (const OmPlan*)L.plan, out, R.heads, R.segs, g.chunk, g.seg_cap);
+  hipLaunchKernelGGL(k_om_finish_a, dim3(g.wgs), dim3(256), 0, s, (const uint64_t*)L.sorted, n, (const OmPlan*)L.plan, out, R.heads, R.segs, g.chunk, g.seg_cap, 0);
   const Tuple pol{t};
   hipLaunchKernelGGL((k_om_finish_b<Tuple>), dim3(g.wgs), dim3(256), 0, s, (const uint64_t*)L.sorted, n, pol, L.plan, out, (const unsigned int*)R.heads,
                      (const RunSeg*)R.segs, g.seg_cap, R.longlist, (unsigned int)g.long_cap);
