@@ -29,7 +29,7 @@ GROUPS = {  # group -> (workload, base names whose LARGEST dispatch is summed)
     "sort local stage": ("sort", ["k_local_place", "k_local_sort"]),
     "sort": ("sort", ["k_hf_sample", "k_hf_plan", "k_hf_scatter level 0", "k_hf_scatter level 1", "k_hy_hist", "k_msd_pass level 0",
                       "k_msd_pass level 1", "k_plan2", "k_local_place", "k_local_sort"]),
-    "join probe phase": ("join", ["k_pj2_scatter", "k_pj2_scatter_rec", "k_pj2_offsets", "k_pj2_probe_pipe"]),  # (round 6: the record-form scatter)
+    "join probe phase": ("join", ["k_pj2_scatter", "k_pj2_scatter_rec", "k_pj2_offsets", "k_pj2_probe_pipe", "k_pj2_probe_rare"]),  # (round 6: the record-form scatter)
     "join build": ("join", ["k_pj_hist", "k_pj_offsets", "k_pj_scatter", "k_bw_split", "k_bw_build", "k_bw_fixup"]),
     # round 6: the argsort is a keys-only word sort (gx_order.hip) -- its own kernels + the cursor path's; the round-3 pairs kernels stay listed
     # for runs with --sort-order-map 0 (base names that did not run contribute nothing)
@@ -37,7 +37,9 @@ GROUPS = {  # group -> (workload, base names whose LARGEST dispatch is summed)
                                       "k_hf_sample", "k_hf_plan", "k_hf_scatter level 0", "k_hf_scatter level 1",
                                       "k_hy_hist", "k_msd_pass level 0", "k_msd_pass level 1", "k_plan2", "k_local_place", "k_local_sort"]),
     "join probe phase (exact two-pass)": ("join", ["k_pj_hist", "k_pj_offsets", "k_pj_scatter", "k_pj_probe_pipe"]),
-    "groupby": ("groupby", ["k_slot_sample", "k_slot_plan", "k_part_reset_cursors", "k_part_scatter", "k_part_aggregate"]),
+    # (round 6: the dense-id path's kernels -- k_dense_* -- run INSTEAD of k_part_aggregate where the ids allow; both listed)
+    "groupby": ("groupby", ["k_slot_sample", "k_slot_plan", "k_part_reset_cursors", "k_part_scatter", "k_part_aggregate", "k_dense_sample", "k_dense_plan",
+                            "k_dense_aggregate", "k_compact", "k_chunk_scan", "k_chunk_reduce"]),
     "groupby (exact two-pass)": ("groupby", ["k_part_hist", "k_part_offsets", "k_part_scatter", "k_part_aggregate"]),
     "groupby_minmax": ("groupby_minmax", ["k_slot_sample", "k_slot_plan", "k_part_reset_cursors", "k_part_scatter", "k_part_minmax"]),
 }
