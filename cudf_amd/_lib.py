@@ -89,6 +89,7 @@ _PROTOS = {
     "gx_bitmask_and": (_i, [ctypes.POINTER(_p), _i, _i64, _p, _p, _p]),
     "gx_bitmask_first_unset": (_i, [_p, _i64, _p, _p]),
     "gx_murmur3_32": (_i, [_i, _p, _p, _i64, ctypes.c_uint32, _i, _p, _p]),
+    "gx_identity_hash_32": (_i, [_i, _p, _p, _i64, _i, _p, _p]),
     "gx_hash_partition_map": (_i, [_p, _i64, _i, _p, _p, _p, _sz, _p]),
     "gx_join_table_bytes": (ctypes.c_size_t, [_i, _i64, ctypes.c_double]),
     "gx_join_build": (_i, [_i, _p, _p, _i64, _p, ctypes.c_size_t, ctypes.c_double, _p]),

@@ -55,14 +55,20 @@ std::pair<std::unique_ptr<table>, std::vector<size_type>> hash_partition(table_v
   if (num_partitions <= 0 || input.num_rows() == 0 || keys.num_columns() == 0)
     return {empty_like_table(input), std::vector<size_type>(static_cast<std::size_t>(std::max(num_partitions, 0)) + 1, 0)};
   if (hash_function == hash_id::HASH_IDENTITY) {
-    // IdentityHash = the key cast to uint32 (partitioning.cu:852-872); a row of ONE column hashes to its element's hash
-    // (row_operator: the first column is hashed with the seed, later ones are combined).  What the reference's own
-    // tests use it for: a key column of externally computed row hashes (hash_partition_test.cpp:411-415).
-    for (auto const& c : keys) CUDF_EXPECTS(is_fixed_width(c.type()), "IdentityHash does not support this data type");  // (every fixed-width type of this path is numeric)
-    CUDF_EXPECTS(keys.num_columns() == 1 && !keys.column(0).has_nulls() &&
-                   (keys.column(0).type().id() == type_id::INT32 || keys.column(0).type().id() == type_id::UINT32),
-                 "HASH_IDENTITY: one INT32 / UINT32 key column without nulls is implemented on this path");
-    return regroup(input, static_cast<uint32_t const*>(detail::row0(keys.column(0))), num_partitions, stream, mr);
+    // IdentityHash<T> = static_cast<uint32_t>(element) for every numeric T (partitioning.cu:852-872, 885-889), rows folded like any
+    // row hash: the first column's element hash, later columns through hash_combine, a null element = UINT32_MAX
+    // (row_operator/hashing.cuh:118-134).  The seed is not used (IdentityHash(uint32_t) {}).  What the reference's own tests use it
+    // for: a key column of externally computed row hashes (hash_partition_test.cpp:411-415).
+    for (auto const& c : keys) CUDF_EXPECTS(is_numeric(c.type()), "IdentityHash does not support this data type");
+    rmm::device_uvector<uint32_t> h(input.num_rows(), stream);
+    for (size_type k = 0; k < keys.num_columns(); ++k) {
+      auto const& c = keys.column(k);
+      rmm::device_buffer holder;
+      auto const* mask = c.has_nulls() ? detail::rebased_mask(c, holder, stream) : nullptr;
+      detail::gx_check(gx_identity_hash_32(detail::gx_type(c.type()), detail::row0(c), mask, c.size(), k > 0 ? 1 : 0, h.data(), detail::gxs(stream)),
+                       "gx_identity_hash_32");
+    }
+    return regroup(input, h.data(), num_partitions, stream, mr);
   }
   auto h = hashing::murmurhash3_x86_32(keys, seed, stream);
   return regroup(input, h->view().head<uint32_t>(), num_partitions, stream, mr);
@@ -83,10 +89,17 @@ std::pair<std::unique_ptr<table>, std::vector<size_type>> partition(table_view c
   CUDF_EXPECTS(!partition_map.has_nulls(), "Unexpected null values in partition_map.");
   if (num_partitions <= 0 || t.num_rows() == 0)
     return {empty_like_table(t), std::vector<size_type>(static_cast<std::size_t>(std::max(num_partitions, 0)) + 1, 0)};
-  CUDF_EXPECTS(partition_map.type().id() == type_id::INT32 || partition_map.type().id() == type_id::UINT32,
-               "partition: the partition map must be INT32 or UINT32 on this path", cudf::data_type_error);
-  // map values lie in [0, num_partitions), so value % num_partitions is the value: the hash-partition kernels regroup by it
-  return regroup(t, static_cast<uint32_t const*>(detail::row0(partition_map)), num_partitions, stream, mr);
+  // any integral map type but bool (partitioning.cu:780-842: is_index_type, else "Unexpected, non-integral partition map.")
+  CUDF_EXPECTS(is_index_type(partition_map.type()), "Unexpected, non-integral partition map.");
+  // map values lie in [0, num_partitions) (partitioning.hpp:52-55), so value % num_partitions is the value: the hash-partition
+  // kernels regroup by the map's low 32 bits
+  if (partition_map.type().id() == type_id::INT32 || partition_map.type().id() == type_id::UINT32)
+    return regroup(t, static_cast<uint32_t const*>(detail::row0(partition_map)), num_partitions, stream, mr);
+  rmm::device_uvector<uint32_t> ids(t.num_rows(), stream);
+  detail::gx_check(gx_identity_hash_32(detail::gx_type(partition_map.type()), detail::row0(partition_map), nullptr, partition_map.size(), 0, ids.data(),
+                                       detail::gxs(stream)),
+                   "gx_identity_hash_32");
+  return regroup(t, ids.data(), num_partitions, stream, mr);
 }
 
 }  // namespace cudf

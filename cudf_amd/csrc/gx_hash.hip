@@ -8,6 +8,8 @@
 // stable radix pass over 1/2/4-byte partition ids with an iota payload (gx_sort_pairs).
 #include "gx_common.hpp"
 
+#include <type_traits>
+
 namespace gx {
 
 template <typename T>
@@ -66,6 +68,46 @@ int murmur_launch(const void* in, const uint32_t* valid, int64_t n, uint32_t see
   if (blocks > 4096) blocks = 4096;
   hipLaunchKernelGGL((k_murmur3<U, MODE>), dim3((unsigned)blocks), dim3(256), 0, s, static_cast<const U*>(in), valid,
                      n, seed, combine, out);
+  GX_LAUNCH_CHECK();
+  return 0;
+}
+
+// IdentityHash<T> of the reference (cpp/src/partitioning/partitioning.cu:852-872): the element cast to uint32 --
+// static_cast<uint32_t>(key) for every arithmetic T.  Integers: sign- or zero-extended, then the low 32 bits.  bool: 0 / 1.
+// Floating point: truncated toward zero; what C++ leaves undefined (NaN, values outside [0, 2^32)) is given the value the device's
+// conversion instruction gives it -- and the reference's: cvt.rzi.u32.f{32,64} and v_cvt_u32_f{32,64} both saturate, NaN -> 0 --
+// spelled out here so that the oracle can restate it.  Null element -> UINT32_MAX, column fold as in k_murmur3.
+template <typename T>
+__device__ __forceinline__ uint32_t identity_u32(T v)
+{
+  if constexpr (std::is_floating_point<T>::value) {
+    if (!(v > T(-1))) return 0u;  // NaN, and everything that truncates below zero
+    if (v >= T(4294967296.0)) return 0xFFFFFFFFu;
+    return (uint32_t)v;
+  } else if constexpr (std::is_same<T, bool>::value) {
+    return v ? 1u : 0u;
+  } else {
+    return (uint32_t)v;
+  }
+}
+template <typename T, bool IS_BOOL>
+__global__ void __launch_bounds__(256) k_identity_hash(const T* __restrict__ in, const uint32_t* __restrict__ valid, int64_t n, int combine,
+                                                       uint32_t* __restrict__ out)
+{
+  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
+    uint32_t h;
+    if (valid && !bit_is_set(valid, i)) h = 0xFFFFFFFFu;
+    else h = IS_BOOL ? (in[i] ? 1u : 0u) : identity_u32<T>(in[i]);
+    out[i] = combine ? hash_combine32(out[i], h) : h;
+  }
+}
+template <typename T, bool IS_BOOL = false>
+int identity_launch(const void* in, const uint32_t* valid, int64_t n, int combine, uint32_t* out, hipStream_t s)
+{
+  int64_t blocks = div_up(n, 256 * 8);
+  if (blocks > 4096) blocks = 4096;
+  hipLaunchKernelGGL((k_identity_hash<T, IS_BOOL>), dim3((unsigned)blocks), dim3(256), 0, s, static_cast<const T*>(in), valid, n, combine, out);
   GX_LAUNCH_CHECK();
   return 0;
 }
@@ -149,6 +191,27 @@ int gx_murmur3_32(int dtype, const void* in, const uint32_t* valid, int64_t n, u
     case GX_INT64:
     case GX_UINT64: return gx::murmur_launch<uint64_t, 0>(in, valid, n, seed, combine, out, s);
     case GX_FLOAT64: return gx::murmur_launch<uint64_t, 2>(in, valid, n, seed, combine, out, s);
+    default: return GX_EDTYPE;
+  }
+}
+
+int gx_identity_hash_32(int dtype, const void* in, const uint32_t* valid, int64_t n, int combine, uint32_t* out, gx_stream_t s)
+{
+  if (n < 0) return GX_EINVAL;
+  if (n == 0) return 0;
+  if (!in || !out) return GX_EINVAL;
+  switch (dtype) {
+    case GX_BOOL8: return gx::identity_launch<uint8_t, true>(in, valid, n, combine, out, s);
+    case GX_INT8: return gx::identity_launch<int8_t>(in, valid, n, combine, out, s);
+    case GX_UINT8: return gx::identity_launch<uint8_t>(in, valid, n, combine, out, s);
+    case GX_INT16: return gx::identity_launch<int16_t>(in, valid, n, combine, out, s);
+    case GX_UINT16: return gx::identity_launch<uint16_t>(in, valid, n, combine, out, s);
+    case GX_INT32: return gx::identity_launch<int32_t>(in, valid, n, combine, out, s);
+    case GX_UINT32: return gx::identity_launch<uint32_t>(in, valid, n, combine, out, s);
+    case GX_INT64: return gx::identity_launch<int64_t>(in, valid, n, combine, out, s);
+    case GX_UINT64: return gx::identity_launch<uint64_t>(in, valid, n, combine, out, s);
+    case GX_FLOAT32: return gx::identity_launch<float>(in, valid, n, combine, out, s);
+    case GX_FLOAT64: return gx::identity_launch<double>(in, valid, n, combine, out, s);
     default: return GX_EDTYPE;
   }
 }

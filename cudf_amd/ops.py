@@ -174,9 +174,23 @@ def murmurhash3_x86_32(cols: Sequence[Column], seed: int = 0) -> Column:
     return out
 
 
-def hash_partition_map(key_cols: Sequence[Column], num_partitions: int, seed: int = 0) -> Tuple[Column, np.ndarray]:
-    """cudf::hash_partition in index form: (gather map, offsets[num_partitions+1])."""
-    h = murmurhash3_x86_32(key_cols, seed)
+def identity_hash(cols: Sequence[Column]) -> Column:
+    """Row hash over IdentityHash (cudf::hash_partition(..., hash_id::HASH_IDENTITY), partitioning.cu:852-889): the element cast to
+    uint32, columns folded with hash_combine, null -> UINT32_MAX."""
+    n = cols[0].size
+    out = Column.empty(np.uint32, n)
+    for k, c in enumerate(cols):
+        L.check(_lib.gx_identity_hash_32(c.gx, c.data_ptr, c.mask_ptr if c.has_nulls() else None, n, int(k > 0), out.data_ptr, stream_ptr()),
+                "gx_identity_hash_32")
+    return out
+
+
+def hash_partition_map(key_cols: Sequence[Column], num_partitions: int, seed: int = 0, hash_function: str = "murmur3") -> Tuple[Column, np.ndarray]:
+    """cudf::hash_partition in index form: (gather map, offsets[num_partitions+1]).  hash_function: "murmur3" (HASH_MURMUR3) or
+    "identity" (HASH_IDENTITY)."""
+    if hash_function not in ("murmur3", "identity"):
+        raise ValueError("Unsupported hash function in hash_partition")
+    h = identity_hash(key_cols) if hash_function == "identity" else murmurhash3_x86_32(key_cols, seed)
     n = h.size
     out_map = Column.empty(np.int32, n)
     offs = torch.empty(num_partitions + 1, dtype=torch.int32, device="cuda")

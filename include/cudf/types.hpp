@@ -108,6 +108,12 @@ constexpr std::size_t size_of(data_type t)
 }
 constexpr bool is_fixed_width(data_type t) { return size_of(t) != 0; }
 constexpr bool is_floating_point(data_type t) { return t.id() == type_id::FLOAT32 || t.id() == type_id::FLOAT64; }
+// (the run-time forms of cudf/utilities/traits.hpp:173-219: numeric = integers, floating point, bool; index type = integral, not bool)
+constexpr bool is_index_type(data_type t)
+{
+  return static_cast<int>(t.id()) >= static_cast<int>(type_id::INT8) && static_cast<int>(t.id()) <= static_cast<int>(type_id::UINT64);
+}
+constexpr bool is_numeric(data_type t) { return is_index_type(t) || is_floating_point(t) || t.id() == type_id::BOOL8; }
 constexpr bool is_nested(data_type t) { return t.id() == type_id::LIST || t.id() == type_id::STRUCT; }
 
 template <typename T>

@@ -218,6 +218,13 @@ int gx_bitmask_and(const uint32_t* const* masks_host, int nmasks, int64_t nbits,
 int gx_murmur3_32(int dtype, const void* in, const uint32_t* valid, int64_t n, uint32_t seed,
                   int combine, uint32_t* out, gx_stream_t stream);
 
+/* IdentityHash<T> of cudf::hash_partition(..., hash_id::HASH_IDENTITY) (src/partitioning/partitioning.cu:852-872): the element
+ * cast to uint32 (static_cast<uint32_t>(key); floating point truncated toward zero, NaN / negative -> 0, >= 2^32 -> UINT32_MAX as
+ * the device conversion does), null -> UINT32_MAX, the same column fold as gx_murmur3_32 (combine).  Also what turns a
+ * cudf::partition map of any integral type (partitioning.cu:780-842, is_index_type) into the uint32 ids gx_hash_partition_map takes. */
+int gx_identity_hash_32(int dtype, const void* in, const uint32_t* valid, int64_t n, int combine,
+                        uint32_t* out, gx_stream_t stream);
+
 /* cudf::hash_partition (include/cudf/partitioning.hpp:103-110; src/partitioning/partitioning.cu:
  * 53-92,120-360,568-660) reduced to its index form: from row hashes, a stable gather map that
  * groups rows by partition (hash % num_partitions) plus num_partitions+1 int32 offsets.

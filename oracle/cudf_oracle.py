@@ -268,8 +268,56 @@ def row_hash(columns: Sequence[np.ndarray], valids: Optional[Sequence] = None, s
     return h
 
 
+def identity_hash32(values: np.ndarray, valid=None) -> np.ndarray:
+    """IdentityHash<T> (cpp/src/partitioning/partitioning.cu:852-872): ``static_cast<uint32_t>(key)`` for arithmetic T.  Integers
+    wrap to their low 32 bits (sign-extended first when signed); bool -> 0 / 1; floating point truncates toward zero, and where C++
+    leaves the cast undefined the device conversion (cvt.rzi.u32 / v_cvt_u32) decides: NaN and values <= -1 -> 0, >= 2**32 ->
+    UINT32_MAX.  A null element hashes to UINT32_MAX like in every row hasher (row_operator/hashing.cuh:52-66)."""
+    v = np.asarray(values)
+    if v.dtype.kind == "b":
+        out = v.astype(np.uint32)
+    elif v.dtype.kind in "iu":
+        out = (v.astype(np.int64 if v.dtype.kind == "i" else np.uint64).view(np.uint64) & _M32).astype(np.uint32)
+    elif v.dtype.kind == "f":
+        d = v.astype(np.float64)                                  # (exact for float32)
+        out = np.zeros(len(d), np.uint32)
+        big = d >= 4294967296.0
+        ok = (d > -1.0) & ~big                                     # (NaN compares false: stays 0)
+        out[ok] = np.trunc(d[ok]).astype(np.uint64).astype(np.uint32)
+        out[big] = np.uint32(0xFFFFFFFF)
+    else:
+        raise TypeError("IdentityHash does not support this data type")
+    if valid is not None:
+        out = np.where(np.asarray(valid, dtype=bool), out, np.uint32(0xFFFFFFFF))
+    return out
+
+
+def row_hash_identity(columns: Sequence[np.ndarray], valids: Optional[Sequence] = None) -> np.ndarray:
+    """The row hasher (row_operator/hashing.cuh:118-134) over IdentityHash: first column's element hash, the others folded with
+    hash_combine; the seed is ignored (``IdentityHash(uint32_t) {}``)."""
+    valids = valids or [None] * len(columns)
+    h = identity_hash32(columns[0], valids[0])
+    for c, m in zip(columns[1:], valids[1:]):
+        h = hash_combine(h, identity_hash32(c, m))
+    return h
+
+
+def partition_by_map(partition_map: np.ndarray, num_partitions: int) -> Tuple[np.ndarray, np.ndarray]:
+    """cudf::partition (cpp/src/partitioning/partitioning.cu:755-842): offsets = exclusive scan of the histogram of the map over
+    [0, num_partitions), num_partitions + 1 entries; the reference leaves the order of rows INSIDE a partition to its atomics
+    (partition_test.cpp:80-108 compares partitions as sets) -- this restatement keeps them in row order, the order the HIP path
+    produces.  Returns (gather order, offsets)."""
+    m = np.asarray(partition_map)
+    if num_partitions <= 0 or len(m) == 0:
+        return np.zeros(0, np.int32), np.zeros(max(num_partitions, 0) + 1, np.int32)
+    pid = m.astype(np.int64)
+    order = np.argsort(pid, kind="stable").astype(np.int32)
+    offsets = np.concatenate([[0], np.cumsum(np.bincount(pid, minlength=num_partitions))]).astype(np.int32)
+    return order, offsets
+
+
 def hash_partition(key_columns: Sequence[np.ndarray], num_partitions: int, seed: int = 0,
-                   valids=None) -> Tuple[np.ndarray, np.ndarray]:
+                   valids=None, hash_function: str = "murmur3") -> Tuple[np.ndarray, np.ndarray]:
     """cudf::hash_partition (cpp/src/partitioning/partitioning.cu:53-92,568-660): partition id =
     row_hash % P (``& (P-1)`` when P is a power of two -- same value); rows keep their relative
     order inside a partition.  Returns (gather order, offsets[P+1])."""
@@ -277,7 +325,7 @@ def hash_partition(key_columns: Sequence[np.ndarray], num_partitions: int, seed:
     if num_partitions <= 0 or nrows == 0 or len(key_columns) == 0:
         # an EMPTY result and num_partitions + 1 zeros (partitioning.cu:883-886; hash_partition_test.cpp:73-141)
         return np.zeros(0, np.int32), np.zeros(max(num_partitions, 0) + 1, np.int32)
-    h = row_hash(key_columns, valids, seed)
+    h = row_hash_identity(key_columns, valids) if hash_function == "identity" else row_hash(key_columns, valids, seed)
     pid = (h % np.uint32(num_partitions)).astype(np.int64)
     order = np.argsort(pid, kind="stable").astype(np.int32)
     counts = np.bincount(pid, minlength=num_partitions)

@@ -6,6 +6,7 @@
 #   suite                           the whole -m gpu suite
 #   cpp                             tests/cpp/cudf_api_tests through tests/test_cpp_api.py
 #   joinab:<xp,xp,...>              bench.py --workload join for each --join-xp value (A/B on one box)
+#   sortab:<dist,dist,...>          bench.py --workload sort --key-dist <d> on the tree's library, then on scripts/xp/bin/libcudf_amd_oldsort.so, then the tree's again
 #   bench:<workload>[:extra args]   bench.py --workload <w> --no-cpu-baseline <extra>
 #   default                         the driver-style default line (all legs)
 #   steps:<rows>                    scripts/xp/xp_gxd_steps.py <rows>  (forced-exchange single-rank steps of the sharded operators)
@@ -57,6 +58,26 @@ try:
 except Exception as e:
     print("xp", sys.argv[2], "| no line:", e)
 PY
+      done ;;
+    sortab)
+      # same-box A/B of two builds of the kernel library: the tree's, then scripts/xp/bin/libcudf_amd_oldsort.so (a build with another gx_sort.hip)
+      out=$O/r6_${TAG}_sort_ab.txt
+      echo "# round 6 $TAG: python bench.py --workload sort --no-cpu-baseline --no-robustness --no-through-cpp --key-dist <d>; ms per step, 1e9 int64 keys" >> $out
+      for variant in new old new2; do
+        [ $variant = old ] && { cp cudf_amd/libcudf_amd.so /tmp/libcudf_amd_new.so; cp scripts/xp/bin/libcudf_amd_oldsort.so cudf_amd/libcudf_amd.so; }
+        [ $variant = new2 ] && cp /tmp/libcudf_amd_new.so cudf_amd/libcudf_amd.so
+        for d in ${rest//,/ }; do
+          timeout 300 python bench.py --workload sort --no-cpu-baseline --no-robustness --no-through-cpp --key-dist $d > $O/r6_${TAG}_sortab_${variant}_$d.jsonl 2>> $O/r6_${TAG}.log
+          python - "$O/r6_${TAG}_sortab_${variant}_$d.jsonl" $variant $d <<'PY' | tee -a $out
+import json, sys
+try:
+    d = json.loads([l for l in open(sys.argv[1]) if l.startswith("{")][-1])
+    r = d.get("roofline") or {}
+    print(sys.argv[2], sys.argv[3], "|", round(d["ms_per_step"], 3), "ms |", {k[:22]: round(v, 3) for k, v in (r.get("kernels_ms") or {}).items()})
+except Exception as e:
+    print(sys.argv[2], sys.argv[3], "| no line:", e)
+PY
+        done
       done ;;
     bench)
       wl=${rest%%:*}; extra=${rest#*:}; [ "$extra" = "$rest" ] && extra=""

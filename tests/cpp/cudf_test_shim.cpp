@@ -369,6 +369,7 @@ int shim_hash_partition(int ncols, const int* dtypes_host, const void* const* da
     std::vector<cudf::size_type> idx(key_idx_host, key_idx_host + nkeys);
     auto res = which == 2   ? cudf::hash_partition(input, cudf::table_view{{view(static_cast<int>(cudf::type_id::UINT32), ext_key, nullptr, n, 0)}}, parts,
                                                    cudf::hash_id::HASH_IDENTITY, seed)
+               : which == 3 ? cudf::hash_partition(input, input.select(idx), parts, cudf::hash_id::HASH_IDENTITY, seed)  // (any numeric key table)
                : which == 1 ? cudf::hash_partition(input, input.select(idx), parts, cudf::hash_id::HASH_MURMUR3, seed)
                             : cudf::hash_partition(input, idx, parts, cudf::hash_id::HASH_MURMUR3, seed);
     *out_rows_host     = res.first->num_rows();
@@ -417,6 +418,20 @@ int shim_partition(int dtype, const void* data, int n, const int32_t* map, int p
     *out_noffsets_host = static_cast<int>(res.second.size());
     for (std::size_t i = 0; i < res.second.size(); ++i) out_offsets_host[i] = res.second[i];
     emit(res.first->get_column(0).view(), out, nullptr, nullptr);
+    shim_sync();
+  });
+}
+
+// cudf::partition by a map of ANY type (partitioning.cu:780-842: the integral types but bool; others throw cudf::logic_error)
+int shim_partition_typed(int dtype, const void* data, int n, int map_dtype, const void* map, const uint32_t* map_valid, int map_nulls, int map_rows, int parts,
+                         void* out, int* out_offsets_host, int* out_noffsets_host, int* out_rows_host)
+{
+  return guarded([&] {
+    auto res = cudf::partition(cudf::table_view{{view(dtype, data, nullptr, n, 0)}}, view(map_dtype, map, map_valid, map_rows, map_nulls), parts);
+    *out_rows_host     = res.first->num_rows();
+    *out_noffsets_host = static_cast<int>(res.second.size());
+    for (std::size_t i = 0; i < res.second.size(); ++i) out_offsets_host[i] = res.second[i];
+    if (res.first->num_rows() > 0) emit(res.first->get_column(0).view(), out, nullptr, nullptr);
     shim_sync();
   });
 }

@@ -511,6 +511,16 @@ HASH_PARTITION_LARGE_P = 160 * 1024 // 4 + 10
 # hash_partition(input, all columns) must give the offsets of hash_partition(input, {murmurhash3_x86_32(input)}, HASH_IDENTITY)
 HASH_PARTITION_FIXED_WIDTH = [(5, 10, 50, False), (10, 1000, 10, False), (10, 1000, 10, True)]
 
+# cudf::partition, partitioning/partition_test.cpp (typed over every fixed-width value type x every integral map type but bool,
+# :28-33).  The fixed-width column of each case; "expected" is the reference's expected table, compared per partition as a set
+# (:85-108 expect_equal_partitions).  :126-140 Identity, :171-189 Reverse, :191-209 SinglePartition, :211-232 EmptyPartitions.
+PARTITION_BY_MAP = [
+    dict(name="Identity", values=[0, 1, 2, 3, 4, 5], map=[0, 1, 2, 3, 4, 5], parts=6, offsets=[0, 1, 2, 3, 4, 5, 6], expected=[0, 1, 2, 3, 4, 5]),
+    dict(name="Reverse", values=[0, 1, 3, 7, 5, 13], map=[5, 4, 3, 2, 1, 0], parts=6, offsets=[0, 1, 2, 3, 4, 5, 6], expected=[13, 5, 7, 3, 1, 0]),
+    dict(name="SinglePartition", values=[0, 1, 3, 7, 5, 13], map=[0, 0, 0, 0, 0, 0], parts=1, offsets=[0, 6], expected=[13, 5, 7, 3, 1, 0]),
+    dict(name="EmptyPartitions", values=[0, 1, 3, 7, 5, 13], map=[2, 2, 0, 0, 4, 4], parts=5, offsets=[0, 2, 2, 4, 4, 6], expected=[3, 7, 0, 1, 5, 13]),
+]
+
 # ---------------------------------------------------------------------------------------------
 # cudf::reduce with an initial value (reductions/reduction_tests.cpp).  expect = what the test's own std::accumulate
 # over the literals gives; "init_valid": False = init_scalar->set_valid_async(false) -> the result is invalid.

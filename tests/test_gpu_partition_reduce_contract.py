@@ -150,6 +150,110 @@ def test_partition_by_map(shim):  # noqa: F811
         np.testing.assert_array_equal(out.get(n), v[order])
 
 
+# ---- cudf::partition over every integral map type (partition_test.cpp:28-33: CrossProduct<FixedWidthTypes, IntegralTypesNotBool>)
+_MAP_TYPES = ["int8", "int16", "int32", "int64", "uint8", "uint16", "uint32", "uint64"]
+
+
+def _partition_typed(shim_call, values, pmap, parts, map_valid=None, map_rows=None):
+    import ctypes as C
+    n = len(values)
+    d, dm, out = Dev(values), Dev(pmap, map_valid), Out(values.dtype, max(n, 1))
+    offs = (C.c_int * (max(parts, 0) + 2))()
+    noffs, rows = C.c_int(-1), C.c_int(-1)
+    shim_call("shim_partition_typed", d.tid, d.p, n, dm.tid, dm.p, dm.mp, dm.nulls, len(pmap) if map_rows is None else map_rows, parts, out.p, offs,
+              C.byref(noffs), C.byref(rows))
+    return np.array(offs[: noffs.value]), out.get(rows.value)
+
+
+@pytest.mark.parametrize("map_type", _MAP_TYPES)
+@pytest.mark.parametrize("value_type", ["int8", "uint32", "int64", "float32", "float64"])
+@pytest.mark.parametrize("case", gv.PARTITION_BY_MAP, ids=lambda c: c["name"])
+def test_partition_reference_vectors_every_map_type(shim, case, value_type, map_type):  # noqa: F811
+    """partition_test.cpp:126-232 (Identity, Reverse, SinglePartition, EmptyPartitions): the offsets are the reference's literal; the
+    rows of every partition are the reference's AS A SET (expect_equal_partitions sorts each side: the reference's order inside a
+    partition is left to its atomics) and, here, in row order (the oracle's stable form)."""
+    v = np.asarray(case["values"]).astype(value_type)
+    m = np.asarray(case["map"]).astype(map_type)
+    offs, got = _partition_typed(shim, v, m, case["parts"])
+    np.testing.assert_array_equal(offs, case["offsets"])
+    exp = np.asarray(case["expected"]).astype(value_type)
+    for a, b in zip(offs[:-1], offs[1:]):
+        np.testing.assert_array_equal(np.sort(got[a:b]), np.sort(exp[a:b]))
+    order, eoffs = orc.partition_by_map(m, case["parts"])
+    np.testing.assert_array_equal(offs, eoffs)
+    assert got.tobytes() == v[order].tobytes()
+
+
+@pytest.mark.parametrize("map_type", _MAP_TYPES)
+def test_partition_map_types_at_scale(shim, map_type):  # noqa: F811
+    rng = np.random.default_rng(11)
+    n = 300_007
+    parts = min(100, np.iinfo(map_type).max)   # (a map value must be < num_partitions: int8 holds 127)
+    v = rng.integers(-2**62, 2**62, n, dtype=np.int64)
+    m = rng.integers(0, parts, n).astype(map_type)
+    offs, got = _partition_typed(shim, v, m, parts)
+    order, eoffs = orc.partition_by_map(m, parts)
+    np.testing.assert_array_equal(offs, eoffs)
+    assert got.tobytes() == v[order].tobytes()
+
+
+def test_partition_contract_errors(shim):  # noqa: F811
+    """partition_test.cpp:39-78 (EmptyInputs, MapInputSizeMismatch, MapWithNullsThrows) and partitioning.cu:836-841: a map that is
+    not an index type -- floating point, bool -- is a cudf::logic_error"""
+    v = np.arange(6, dtype=np.int32)
+    offs, got = _partition_typed(shim, v[:0], np.zeros(0, np.int16), 5)
+    assert len(got) == 0 and list(offs) == [0] * 6
+    with pytest.raises(AssertionError, match="Size mismatch"):
+        _partition_typed(shim, v, np.zeros(5, np.int64), 3)
+    with pytest.raises(AssertionError, match="null"):
+        _partition_typed(shim, v, np.zeros(6, np.uint8), 3, map_valid=np.array([1, 1, 0, 1, 1, 1], bool))
+    for bad in (np.zeros(6, np.float32), np.zeros(6, np.float64), np.zeros(6, bool)):
+        with pytest.raises(AssertionError, match="non-integral"):
+            _partition_typed(shim, v, bad, 3)
+
+
+# ---- HASH_IDENTITY over any numeric key table (partitioning.cu:852-889)
+@pytest.mark.parametrize("dtype", ["bool", "int8", "uint8", "int16", "uint16", "int32", "uint32", "int64", "uint64", "float32", "float64"])
+@pytest.mark.parametrize("ncols,nulls", [(1, False), (1, True), (3, False), (2, True)])
+def test_hash_partition_identity_any_numeric_key(shim, dtype, ncols, nulls):  # noqa: F811
+    rng = np.random.default_rng(5)
+    rows, parts = 20_011, 13
+    if dtype == "bool":
+        v = rng.integers(0, 2, rows).astype(bool)
+    elif dtype.startswith("float"):
+        v = (rng.standard_normal(rows) * 1e6).astype(dtype)
+        v[:8] = np.array([np.nan, -0.0, 0.0, np.inf, -np.inf, 4294967295.5 if dtype == "float64" else 4294967040.0, 1e30, -0.75], dtype)
+    else:
+        ii = np.iinfo(dtype)
+        v = rng.integers(ii.min, ii.max, rows, dtype=dtype, endpoint=True)
+    cols = [(dtype, np.roll(v, k)) for k in range(ncols)]
+    valids = [((np.arange(rows) + k) % 5) != 0 for k in range(ncols)] if nulls else None
+    r = _call_hash_partition(shim, cols, rows, list(range(ncols)), parts, which=3, valids=valids)
+    order, eoffs = orc.hash_partition([c for _, c in cols], parts, valids=valids, hash_function="identity")
+    np.testing.assert_array_equal(r["offsets"], eoffs)
+    for k, (_, c) in enumerate(cols):
+        if nulls:
+            np.testing.assert_array_equal(r["valid"][k], valids[k][order])
+            m = valids[k][order]
+            assert r["cols"][k][m].tobytes() == c[order][m].tobytes()
+        else:
+            assert r["cols"][k].tobytes() == c[order].tobytes()
+
+
+def test_hash_partition_identity_contract(shim):  # noqa: F811
+    """the seed does not enter IdentityHash (partitioning.cu:857); an INT64 key column of externally computed hashes splits like the
+    UINT32 one of hash_partition_test.cpp:411-419 when its values fit 32 bits"""
+    rng = np.random.default_rng(6)
+    v = rng.integers(-2**31, 2**31, 5000, dtype=np.int64)
+    a = _call_hash_partition(shim, [("int64", v)], 5000, [0], 7, which=3, seed=0)
+    b = _call_hash_partition(shim, [("int64", v)], 5000, [0], 7, which=3, seed=12345)
+    np.testing.assert_array_equal(a["offsets"], b["offsets"])
+    assert a["cols"][0].tobytes() == b["cols"][0].tobytes()
+    c = _call_hash_partition(shim, [("int64", v)], 5000, [], 7, which=2, ext_key=(v & 0xFFFFFFFF).astype(np.uint32))
+    np.testing.assert_array_equal(a["offsets"], c["offsets"])
+    assert a["cols"][0].tobytes() == c["cols"][0].tobytes()
+
+
 _KIND = {"sum": 0, "product": 2, "min": 3, "max": 4, "count_valid": 5, "count_all": 6, "any": 7, "all": 8, "mean": 10}   # cudf::aggregation::Kind (include/cudf/aggregation.hpp)
 
 

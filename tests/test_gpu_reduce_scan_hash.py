@@ -134,6 +134,32 @@ def test_murmur3_matches_oracle(gx, dtype):
     np.testing.assert_array_equal(got, orc.row_hash([v, w]))
 
 
+@pytest.mark.parametrize("dtype", ["int8", "uint8", "int16", "uint16", "int32", "uint32", "int64", "uint64", "float32", "float64", "bool"])
+def test_identity_hash_matches_oracle(gx, dtype):
+    """gx_identity_hash_32 = IdentityHash<T> (partitioning.cu:852-872): the cast to uint32, bit-exact incl. what the device conversion
+    does outside C++'s defined range; the column fold and the null value of every row hasher"""
+    Column, ops = gx
+    rng = np.random.default_rng(17)
+    n = 10_007
+    if dtype == "bool":
+        v = rng.integers(0, 2, n).astype(bool)
+    elif np.dtype(dtype).kind == "f":
+        v = (rng.standard_normal(n) * 10.0 ** rng.integers(0, 12, n)).astype(dtype)
+        v[:10] = np.array([0.0, -0.0, np.nan, -np.nan, np.inf, -np.inf, 4294967296.0, 4294967040.0, -0.99, 0.99], dtype)
+    else:
+        v = _vals(dtype, n, rng)
+    valid = rng.random(n) > 0.2
+    got = ops.identity_hash([Column.from_numpy(v, valid)]).to_numpy()
+    np.testing.assert_array_equal(got, orc.identity_hash32(v, valid))
+    w = rng.integers(-2**40, 2**40, n).astype(np.int64)
+    got = ops.identity_hash([Column.from_numpy(v), Column.from_numpy(w, valid)]).to_numpy()
+    np.testing.assert_array_equal(got, orc.row_hash_identity([v, w], [None, valid]))
+    m, offs = ops.hash_partition_map([Column.from_numpy(v), Column.from_numpy(w)], 37, hash_function="identity")
+    eo, eoffs = orc.hash_partition([v, w], 37, hash_function="identity")
+    np.testing.assert_array_equal(offs, eoffs)
+    np.testing.assert_array_equal(m.to_numpy(), eo)
+
+
 @pytest.mark.parametrize("nparts", [1, 2, 3, 8, 200, 1000])
 def test_hash_partition_matches_oracle(gx, nparts):
     Column, ops = gx

@@ -272,6 +272,43 @@ def test_hash_partition_contract_golden(case):
         assert np.array_equal(np.sort(order), np.arange(case["rows"]))
 
 
+@pytest.mark.parametrize("map_type", ["int8", "int16", "int32", "int64", "uint8", "uint16", "uint32", "uint64"])
+@pytest.mark.parametrize("case", gv.PARTITION_BY_MAP, ids=lambda c: c["name"])
+def test_partition_by_map_oracle_matches_reference(case, map_type):
+    """partition_test.cpp:126-232: the literal offsets; every partition holds the reference's rows (compared as sets there)"""
+    v, m = np.asarray(case["values"], np.int64), np.asarray(case["map"]).astype(map_type)
+    order, offs = orc.partition_by_map(m, case["parts"])
+    np.testing.assert_array_equal(offs, case["offsets"])
+    exp = np.asarray(case["expected"], np.int64)
+    for a, b in zip(offs[:-1], offs[1:]):
+        np.testing.assert_array_equal(np.sort(v[order][a:b]), np.sort(exp[a:b]))
+    assert orc.partition_by_map(m[:0], 5)[1].tolist() == [0] * 6          # :39-54 EmptyInputs
+
+
+def test_identity_hash_oracle_is_the_cast_to_uint32():
+    """partitioning.cu:852-872 IdentityHash: static_cast<uint32_t>(key); hash_partition_test.cpp:411-431: HASH_IDENTITY over a
+    column of externally computed murmur hashes gives the offsets of hashing the columns directly"""
+    assert orc.identity_hash32(np.array([-1, 5, 2**40 + 3, -2**40], np.int64)).tolist() == [0xFFFFFFFF, 5, 3, 0]
+    assert orc.identity_hash32(np.array([-1, 127, -128], np.int8)).tolist() == [0xFFFFFFFF, 127, 0xFFFFFF80]
+    assert orc.identity_hash32(np.array([65535, 7], np.uint16)).tolist() == [65535, 7]
+    assert orc.identity_hash32(np.array([True, False])).tolist() == [1, 0]
+    assert orc.identity_hash32(np.array([3.99, -0.5, -0.0, 4294967295.0], np.float64)).tolist() == [3, 0, 0, 0xFFFFFFFF]
+    # outside what C++ defines: the device conversion saturates, NaN -> 0
+    assert orc.identity_hash32(np.array([np.nan, -7.0, 1e20, np.inf, -np.inf], np.float32)).tolist() == [0, 0, 0xFFFFFFFF, 0xFFFFFFFF, 0]
+    assert orc.identity_hash32(np.array([9, 9], np.int32), [True, False]).tolist() == [9, 0xFFFFFFFF]
+    rng = np.random.default_rng(2)
+    cols = [rng.integers(-1000, 1000, 1000).astype(np.int32), rng.random(1000)]
+    h = orc.row_hash(cols)
+    for parts in (1, 7, 64):
+        a = orc.hash_partition(cols, parts)
+        b = orc.hash_partition([h], parts, hash_function="identity")
+        np.testing.assert_array_equal(a[0], b[0])
+        np.testing.assert_array_equal(a[1], b[1])
+    two = orc.row_hash_identity([np.array([1, 2], np.int32), np.array([3, 4], np.int64)])
+    assert two.tolist() == [int(orc.hash_combine(np.array([1], np.uint32), np.array([3], np.uint32))[0]),
+                            int(orc.hash_combine(np.array([2], np.uint32), np.array([4], np.uint32))[0])]
+
+
 # ---- round 3: the oracle restatements behind the at-scale parity tests of rank / top_k / segmented sort /
 # sort-path groupby / groupby::scan COUNT / shift / replace_nulls are pinned to the reference's own literals
 def test_rank_oracle_matches_every_reference_rank_vector():
