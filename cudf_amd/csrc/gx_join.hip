@@ -1967,7 +1967,13 @@ __global__ void __launch_bounds__(256) k_bw_fill_empty(uint4* __restrict__ p, si
 //     deliver them: the old order left them the barrier, the flush and S3 (~1.5 us) and every trip stalled on them.
 // ================================================================================================
 struct alignas(128) Pj2Plan {
-  unsigned int fill[PJ_MAXP * PJ_NR];        // rows written to region e (device-scope atomics; nothing else on these lines)
+  unsigned int fill[PJ_MAXP * PJ_NR];        // rows written to region e = partition * PJ_NR + range
+  // The counters the partition pass bumps, RANGE-major: fillx[range * P + partition]; k_pj2_offsets copies them into fill[].  A range is
+  // walked by ONE XCD, so a line of fillx is touched by one L2 only.  With the atomics on fill[] itself -- the eight ranges' counters of
+  // a partition side by side, every line of counters bumped by all eight XCDs -- the lines travelled from L2 to L2: WRITE_SIZE of the
+  // pass 16.9 GB for 12 GB of records (profiles/r6_pmc_traffic_1e9.json at 387665f), where the sort's and the groupby's partition
+  // passes, whose cursors have always been range-major, write 1.03 - 1.05 x their bytes.
+  unsigned int fillx[PJ_MAXP * PJ_NR];
   unsigned int chunk0[PJ_MAXP * PJ_NR + 1];  // first probe piece of region e, regions in (partition, range) order
   unsigned int list_chunk0[PJ_NR + 1];       // first piece of XCD list y (partitions [y, y + 1) * P / PJ_NR)
   alignas(128) unsigned int overflow;        // a region outgrew its slot
@@ -1988,7 +1994,7 @@ template <typename K, int RPT, int BTt, bool EXACT, typename F>
 __global__ void __launch_bounds__(BTt) k_pj2_scatter(const K* __restrict__ keys, int64_t n, Pj2Plan* plan2, PjPlan* plan, int pbits,
                                                      int64_t rrows, uint32_t cap, int64_t ntiles, K* __restrict__ pkeys,
                                                      int32_t* __restrict__ pidx, F part_of, int32_t row0,
-                                                     const int32_t* __restrict__ payload)
+                                                     const int32_t* __restrict__ payload, int xmajor)
 {
   constexpr int TILE = BTt * RPT;
   extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -2048,7 +2054,7 @@ __global__ void __launch_bounds__(BTt) k_pj2_scatter(const K* __restrict__ keys,
     for (int k = 0; k < 4; ++k) {
       if (c[k]) {
         if (EXACT) g[k] = (unsigned int)atomicAdd(&plan->cursor[range][b0 + k], (unsigned long long)c[k]);
-        else g[k] = atomicAdd(&plan2->fill[(b0 + k) * PJ_NR + range], c[k]);
+        else g[k] = xmajor ? atomicAdd(&plan2->fillx[range * P + b0 + k], c[k]) : atomicAdd(&plan2->fill[(b0 + k) * PJ_NR + range], c[k]);
       }
     }
     unsigned int st = block_exclusive_scan<BTt>(sum, 0u, SumOp(), s_scan, (unsigned int*)nullptr);
@@ -2159,7 +2165,7 @@ template <int RPT, bool EXACT, bool TAIL, bool AOS, bool PAY, typename F>
 __global__ void __launch_bounds__(1024) k_pj2_scatter_rec(const uint64_t* __restrict__ keys, int64_t n, Pj2Plan* plan2, PjPlan* plan, int pbits,
                                                           int64_t rrows, uint32_t cap, int64_t ntiles, int64_t tile0_row,
                                                           PjRec* __restrict__ precs, F part_of, int32_t row0,
-                                                          const int32_t* __restrict__ payload, int32_t* __restrict__ soa_idx)
+                                                          const int32_t* __restrict__ payload, int32_t* __restrict__ soa_idx, int xmajor)
 {
   typedef uint64_t K;
   constexpr int BTt  = 1024;
@@ -2239,7 +2245,7 @@ __global__ void __launch_bounds__(1024) k_pj2_scatter_rec(const uint64_t* __rest
     for (int k = 0; k < 4; ++k) {
       if (c[k]) {
         if (EXACT) g[k] = (unsigned int)atomicAdd(&plan->cursor[range][b0 + k], (unsigned long long)c[k]);
-        else g[k] = atomicAdd(&plan2->fill[(b0 + k) * PJ_NR + range], c[k]);
+        else g[k] = xmajor ? atomicAdd(&plan2->fillx[range * P + b0 + k], c[k]) : atomicAdd(&plan2->fill[(b0 + k) * PJ_NR + range], c[k]);
       }
     }
     unsigned int st = block_exclusive_scan<BTt>(sum, 0u, SumOp(), s_scan, (unsigned int*)nullptr);
@@ -2323,12 +2329,17 @@ __global__ void __launch_bounds__(1024) k_pj2_scatter_rec(const uint64_t* __rest
 
 // After the speculative scatter: piece numbering over the regions, or the verdict "fallback".  One block of 1024 threads,
 // each handling a run of consecutive regions.
-__global__ void __launch_bounds__(1024) k_pj2_offsets(Pj2Plan* plan2, int pbits, uint32_t cap, unsigned int piece_rows)
+__global__ void __launch_bounds__(1024) k_pj2_offsets(Pj2Plan* plan2, int pbits, uint32_t cap, unsigned int piece_rows, int xmajor)
 {
   __shared__ unsigned int s_tmp[1024 / GX_WAVE + 1];
   const int E   = (1 << pbits) * PJ_NR;
   const int per = E > 1024 ? E / 1024 : 1;
   const int e0  = (int)threadIdx.x * per;
+  if (xmajor)  // the pass counted range-major (Pj2Plan::fillx): region order from here on; a thread reads only the entries it wrote
+    for (int k = 0; k < per; ++k) {
+      const int e = e0 + k;
+      if (e < E) plan2->fill[e] = plan2->fillx[(e % PJ_NR) * (E / PJ_NR) + e / PJ_NR];
+    }
   if (plan2->overflow) {  // chunk0 / list_chunk0 stay zero (the plan was cleared): the speculative probe takes no piece
     if (threadIdx.x == 0) plan2->fallback = 1u;
     return;
@@ -4283,6 +4294,7 @@ int probe_partitioned_impl2(const K* keys, int64_t n, const Slot<K>* slots, uint
   }
   const int64_t ntiles = div_up(n, (int64_t)TILE);
   const int64_t rrows  = pj_range_rows(n, TILE);
+  const int xmajor     = (g_pj_xp & (1 << 24)) ? 0 : 1;  // bit 24 (measurement): the fill-counter atomics on fill[] itself, as until round 6
   int64_t grid         = num_cus > 0 ? num_cus : 256;
   if (((g_pj_xp >> 8) & 255) != 0) grid = ((g_pj_xp >> 8) & 255) * 4;  // measurement: bits 8-15 = workgroups of the partition pass / 4
   grid                 = grid / PJ_NR * PJ_NR;  // v % 8 must stay the XCD of a workgroup over its whole walk
@@ -4305,9 +4317,9 @@ int probe_partitioned_impl2(const K* keys, int64_t n, const Slot<K>* slots, uint
 #define GX_PJ_REC2(RPT_, EX_, AOS_, PAY_)                                                                                                       \
   do {                                                                                                                                          \
     if (gf) hipLaunchKernelGGL((k_pj2_scatter_rec<RPT_, EX_, false, AOS_, PAY_, F>), dim3(gf), dim3(1024), lds_s, s, k64, n, plan2, plan, pbits, \
-                               rrows, cap, nfull, (int64_t)0, precs, part_of, row0, payload, pidx);                                             \
+                               rrows, cap, nfull, (int64_t)0, precs, part_of, row0, payload, pidx, xmajor);                                             \
     if (tail0 < n) hipLaunchKernelGGL((k_pj2_scatter_rec<RPT_, EX_, true, AOS_, PAY_, F>), dim3(1), dim3(1024), lds_s, s, k64, n, plan2, plan,   \
-                                      pbits, rrows, cap, (int64_t)1, tail0, precs, part_of, row0, payload, pidx);                               \
+                                      pbits, rrows, cap, (int64_t)1, tail0, precs, part_of, row0, payload, pidx, xmajor);                               \
   } while (0)
 #define GX_PJ_REC(RPT_, EX_, AOS_)                              \
   do {                                                          \
@@ -4326,7 +4338,7 @@ int probe_partitioned_impl2(const K* keys, int64_t n, const Slot<K>* slots, uint
     }
   };
   if (rec || win_soa) launch_rec(false);
-  else hipLaunchKernelGGL(kspec, dim3((unsigned)grid), dim3(1024), lds_s, s, keys, n, plan2, plan, pbits, rrows, cap, ntiles, pkeys, pidx, part_of, row0, payload);
+  else hipLaunchKernelGGL(kspec, dim3((unsigned)grid), dim3(1024), lds_s, s, keys, n, plan2, plan, pbits, rrows, cap, ntiles, pkeys, pidx, part_of, row0, payload, xmajor);
   jprof_mark(2, s);
   // (6 / 7: the same kernel with the tag windows read from the L2 -- the partition pass then cuts 2^20-slot sub-tables, see pj_bits)
   // the probe kernel: 0 the pipelined LDS-tag gang probe; 2 / 3 the L2-resident direct probe with 4 / 2 rows per thread (round 5,
@@ -4362,7 +4374,7 @@ int probe_partitioned_impl2(const K* keys, int64_t n, const Slot<K>* slots, uint
                            capacity, cur);
     }
   };
-  hipLaunchKernelGGL(k_pj2_offsets, dim3(1), dim3(1024), 0, s, plan2, pbits, cap, piece_rows);
+  hipLaunchKernelGGL(k_pj2_offsets, dim3(1), dim3(1024), 0, s, plan2, pbits, cap, piece_rows, xmajor);
   PieceTable pt{plan2->chunk0, plan2->list_chunk0, plan2->ticket, nullptr, plan2->fill, cap, PJ_NR, 0u, nullptr, nullptr, 0u, nullptr};
   if (longp && !alt) {
     pt.ovf       = ovf;
@@ -4381,7 +4393,7 @@ int probe_partitioned_impl2(const K* keys, int64_t n, const Slot<K>* slots, uint
   hipLaunchKernelGGL((k_pj_hist<K, F>), dim3((unsigned)(hb * PJ_NR)), dim3(256), 0, s, keys, n, plan, pbits, rrows, part_of, &plan2->fallback);
   hipLaunchKernelGGL(k_pj_offsets, dim3(1), dim3(1024), 0, s, plan, pbits, piece_rows, &plan2->fallback);
   if (rec || win_soa) launch_rec(true);
-  else hipLaunchKernelGGL(kexact, dim3((unsigned)grid), dim3(1024), lds_s, s, keys, n, plan2, plan, pbits, rrows, cap, ntiles, pkeys, pidx, part_of, row0, payload);
+  else hipLaunchKernelGGL(kexact, dim3((unsigned)grid), dim3(1024), lds_s, s, keys, n, plan2, plan, pbits, rrows, cap, ntiles, pkeys, pidx, part_of, row0, payload, xmajor);
   PieceTable pe{plan->chunk0, plan->list_chunk0, plan2->ticket_exact, plan->offset, nullptr, 0u, 1, 0u, nullptr, pt.ovf, pt.ovf_cap, pt.ovf_count};
   launch_probe(pe);
   jprof_mark(3, s);
