@@ -155,7 +155,7 @@ def test_l2_resident_direct_probe_matches_oracle(gx, dtype, shape, kernel):
         _lib.lib.gx_join_set_partition_mode(1, 0)
 
 
-@pytest.mark.parametrize("shape,xp", [(sh, xp) for xp in (0, 1, 3, 4, 5, 12, 129, 133) for sh in ("uniform", "dup_build", "hot_key", "one_partition", "edge_chains")])
+@pytest.mark.parametrize("shape,xp", [(sh, xp) for xp in (0, 1, 3, 4, 5, 12, 129, 133, 133 | (1 << 24), 4 | (1 << 24)) for sh in ("uniform", "dup_build", "hot_key", "one_partition", "edge_chains")])
 def test_record_form_partition_probe_matches_oracle(gx, shape, xp):
     """Round 6: the partition pass writes 12-byte {key, row} records (k_pj2_scatter_rec: 16384- or, xp bit 1, 24576-row tiles
     through 8192-position LDS windows, the ragged tail as a second launch) and the pipelined probe reads a lane's four rows as
