@@ -47,6 +47,7 @@ _PROTOS = {
     "gx_sort_order_map_info": (_i, [_p, _i64, ctypes.POINTER(ctypes.c_int32), _p]),
     "gx_sort_set_algorithm": (None, [_i]),
     "gx_sort_profile": (_i, [_i]),
+    "gx_sort_profile_slot": (_i, [_i]),
     "gx_sort_profile_read": (_i, [ctypes.POINTER(ctypes.c_float), ctypes.POINTER(ctypes.c_float), ctypes.POINTER(_i)]),
     "gx_sort_profile_read_hybrid": (_i, [ctypes.POINTER(ctypes.c_float)]),
     "gx_sort_set_hybrid": (None, [_i]),
@@ -110,6 +111,7 @@ _PROTOS = {
     "gx_add_i32": (_i, [_p, _i64, ctypes.c_int32, _p]),
     "gx_join_partition_bits": (_i, [_i, ctypes.c_size_t]),
     "gx_join_profile": (_i, [_i]),
+    "gx_join_profile_slot": (_i, [_i]),
     "gx_join_profile_read": (_i, [ctypes.POINTER(ctypes.c_float)]),
     "gx_join_set_scatter_tile": (None, [_i]),
     "gx_join_set_experiment": (None, [_i]),

@@ -4045,7 +4045,10 @@ struct JoinProfile {
   bool enabled = false, created = false, marked = false;
   hipEvent_t ev[4];  // before hist | before scatter | before probe | after probe
 };
-static thread_local JoinProfile g_jprof;
+constexpr int JPROF_SLOTS = 64;  // event slots, as gx_sort_profile_slot: K timed calls, K slots, read after the last one
+static thread_local JoinProfile g_jprofs[JPROF_SLOTS];
+static thread_local int g_jprof_slot = 0;
+#define g_jprof g_jprofs[g_jprof_slot]
 static inline void jprof_mark(int i, hipStream_t s)
 {
   if (g_jprof.enabled) (void)hipEventRecord(g_jprof.ev[i], s);
@@ -4808,18 +4811,26 @@ int gx_add_i32(int32_t* data, int64_t n, int32_t value, gx_stream_t s)
 
 int gx_join_profile(int enable)
 {
-  auto& p = gx::join::g_jprof;
-  if (enable && !p.created) {
-    for (auto& e : p.ev) GX_HIP_TRY(hipEventCreate(&e));
-    p.created = true;
+  for (auto& p : gx::join::g_jprofs) {
+    if (enable && !p.created) {
+      for (auto& e : p.ev) GX_HIP_TRY(hipEventCreate(&e));
+      p.created = true;
+    }
+    p.enabled = enable != 0;
   }
-  p.enabled = enable != 0;
+  return 0;
+}
+
+int gx_join_profile_slot(int slot)
+{
+  if (slot < 0 || slot >= gx::join::JPROF_SLOTS) return GX_EINVAL;
+  gx::join::g_jprof_slot = slot;
   return 0;
 }
 
 int gx_join_profile_read(float* ms3)
 {
-  auto& p = gx::join::g_jprof;
+  auto& p = gx::join::g_jprofs[gx::join::g_jprof_slot];
   if (!p.created || !p.marked || !ms3) return GX_EINVAL;
   GX_HIP_TRY(hipEventSynchronize(p.ev[3]));
   for (int i = 0; i < 3; ++i) GX_HIP_TRY(hipEventElapsedTime(&ms3[i], p.ev[i], p.ev[i + 1]));

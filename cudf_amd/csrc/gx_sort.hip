@@ -3609,19 +3609,27 @@ static thread_local int g_order_mode = 0;
 struct Profile {
   bool enabled = false;
   bool created = false;
+  int level    = 1;  // 1: every event; 2: only the two around the first partition level (hev[0], hev[1]) -- an event between two kernels costs
+                     // the stream ~15 us, and a sort records 23 of them (0.35 ms of an 11-ms sort): the timed steps of bench.py take level 2
   int npass    = 0;
   hipEvent_t ev[2 * MAX_PASSES + 2];
   hipEvent_t hev[5];  // hybrid: before msd0, hist2, msd1, local sort, after
   bool hybrid_marked = false;
 };
-static thread_local Profile g_prof;  // per calling thread, like every knob below: a thread that profiles or forces a path affects its own calls only
+// Event SLOTS (gx_sort_profile_slot): a caller that times K calls back to back gives each call its own events and reads them all
+// AFTER the K calls -- reading a call's events right behind it waits for the call and puts a host round trip between two timed steps
+// (bench.py until round 6: +0.3 ms per 11-ms step against the same step through the C++ API, which never profiled).
+constexpr int PROF_SLOTS = 64;
+static thread_local Profile g_profs[PROF_SLOTS];  // per calling thread, like every knob below: a thread that profiles or forces a path affects its own calls only
+static thread_local int g_prof_slot = 0;
+#define g_prof g_profs[g_prof_slot]
 static inline void prof_mark(int idx, hipStream_t s)
 {
-  if (g_prof.enabled) (void)hipEventRecord(g_prof.ev[idx], s);
+  if (g_prof.enabled && g_prof.level == 1) (void)hipEventRecord(g_prof.ev[idx], s);
 }
 static inline void prof_mark_h(int idx, hipStream_t s)
 {
-  if (g_prof.enabled) (void)hipEventRecord(g_prof.hev[idx], s);
+  if (g_prof.enabled && (g_prof.level == 1 || idx <= 1)) (void)hipEventRecord(g_prof.hev[idx], s);
 }
 static thread_local int g_hybrid = 1;  // 0 disables the hybrid MSD path (A/B knob)
 static thread_local int g_lbw    = 16;  // predecessors per look-back round of the keys-only hybrid partition passes (knob: 4, 8, 16;
@@ -4694,20 +4702,34 @@ void gx_sort_set_algorithm(int algo)
 
 int gx_sort_profile(int enable)
 {
-  auto& p = gx::sort::g_prof;
-  if (enable && !p.created) {
-    for (auto& e : p.ev) GX_HIP_TRY(hipEventCreate(&e));
-    for (auto& e : p.hev) GX_HIP_TRY(hipEventCreate(&e));
-    p.created = true;
+  for (auto& p : gx::sort::g_profs) {
+    if (enable && !p.created) {
+      for (auto& e : p.ev) GX_HIP_TRY(hipEventCreate(&e));
+      for (auto& e : p.hev) GX_HIP_TRY(hipEventCreate(&e));
+      p.created = true;
+    }
+    p.enabled = enable != 0;
+    p.level   = enable == 2 ? 2 : 1;
   }
-  p.enabled = enable != 0;
+  return 0;
+}
+
+int gx_sort_profile_slot(int slot)
+{
+  if (slot < 0 || slot >= gx::sort::PROF_SLOTS) return GX_EINVAL;
+  gx::sort::g_prof_slot = slot;
   return 0;
 }
 
 int gx_sort_profile_read(float* hist_ms, float* pass_ms, int* npass)
 {
-  auto& p = gx::sort::g_prof;
+  auto& p = gx::sort::g_profs[gx::sort::g_prof_slot];
   if (!p.created || !hist_ms || !pass_ms || !npass) return GX_EINVAL;
+  if (p.level == 2) {  // (none of these events was recorded)
+    *npass   = 0;
+    *hist_ms = 0.0f;
+    return 0;
+  }
   *npass = p.npass;
   GX_HIP_TRY(hipEventSynchronize(p.ev[3 + 2 * (p.npass - 1)]));
   GX_HIP_TRY(hipEventElapsedTime(hist_ms, p.ev[0], p.ev[1]));
@@ -4717,9 +4739,15 @@ int gx_sort_profile_read(float* hist_ms, float* pass_ms, int* npass)
 
 int gx_sort_profile_read_hybrid(float* ms4)
 {
-  auto& p = gx::sort::g_prof;
+  auto& p = gx::sort::g_profs[gx::sort::g_prof_slot];
   if (!p.created || !ms4) return GX_EINVAL;
   if (!p.hybrid_marked) return GX_EINVAL;
+  if (p.level == 2) {  // the first partition level only
+    GX_HIP_TRY(hipEventSynchronize(p.hev[1]));
+    GX_HIP_TRY(hipEventElapsedTime(&ms4[0], p.hev[0], p.hev[1]));
+    ms4[1] = ms4[2] = ms4[3] = 0.0f;
+    return 0;
+  }
   GX_HIP_TRY(hipEventSynchronize(p.hev[4]));
   for (int i = 0; i < 4; ++i) GX_HIP_TRY(hipEventElapsedTime(&ms4[i], p.hev[i], p.hev[i + 1]));
   return 0;

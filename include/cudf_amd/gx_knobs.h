@@ -30,10 +30,15 @@ void gx_sort_set_algorithm(int algo);
  * the caller's stream around the histogram launch and around each pass's launch(es);
  * gx_sort_profile_read waits for the last sort and returns the durations in milliseconds
  * (pass_ms has room for 8 entries; skipped passes report the few microseconds of their early
- * exit). */
+ * exit).  enable == 2: only the two events around the first partition level are recorded (an event
+ * between two kernels costs the stream ~15 us; a sort records 23): gx_sort_profile_read then reports no
+ * pass, gx_sort_profile_read_hybrid the first interval and zeros. */
 int gx_sort_profile(int enable);
 
 int gx_sort_profile_read(float* hist_ms, float* pass_ms, int* npass);
+/* Event slot (0..63, per calling thread) the following sorts record into and gx_sort_profile_read* read from: K timed calls take K
+ * slots and are read after the last one, so that no read-back sits between two timed calls. */
+int gx_sort_profile_slot(int slot);
 
 /* durations of the hybrid path's kernels of the last profiled sort, in milliseconds:
  * ms4 = {level-0 partition pass, level-1 partition pass, cell plan (one block), LDS local sort}.
@@ -128,6 +133,8 @@ void gx_sort_set_lookback(int window);
 int gx_join_profile(int enable);
 
 int gx_join_profile_read(float* ms3);
+/* Event slot (0..63, per calling thread), as gx_sort_profile_slot. */
+int gx_join_profile_slot(int slot);
 
 /* A/B knob: kernel of the partitioned build.  0 (default) = the window build: the partition's rows regrouped by 2^12-slot window,
  * every window composed in LDS and written once in full lines (no pre-fill of the table, no global atomics); 2 = one workgroup
