@@ -12,6 +12,7 @@
 #   steps:<rows>                    scripts/xp/xp_gxd_steps.py <rows>  (forced-exchange single-rank steps of the sharded operators)
 #   profsteps:<rows>                rocprofv3 --kernel-trace --stats summary of scripts/xp/xp_gxd_steps.py <rows>
 #   xp:<file.hip>[:args]            hipcc + run a micro-benchmark under scripts/xp/
+#   overlap[:log2 rows]             rocprofv3 --kernel-trace of scripts/xp/bin/xp_two_streams (two sorts on two streams) + scripts/overlap_summary.py
 #   prof:<workload>[:extra args]    rocprofv3 --kernel-trace --stats summary of bench.py --workload <w>
 #   pmcsq:<workload>[:extra args]   SQ counters (two passes) of bench.py --workload <w> --steps 1 --warmup 0
 #   evidence                        default line + sorted_order line + rocprof summary + FETCH/WRITE passes -> r6_pmc_traffic_1e9.json
@@ -102,6 +103,13 @@ PY
       b=scripts/xp/bin/$(basename $src .hip)
       [ -x $b ] || /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -o $b scripts/xp/$src
       timeout 600 $b $args 2>&1 | tee $O/r6_${TAG}_$(basename $src .hip).txt | tail -40 ;;
+    overlap)
+      # two cudf::sort calls on two streams under rocprofv3 --kernel-trace: do the kernels of the two streams run at the same time?
+      (cd /tmp && timeout 600 rocprofv3 --kernel-trace -d "$ROOT/$O/prof_$TAG" -o p -- "$ROOT/scripts/xp/bin/xp_two_streams" ${rest:-27}) > $O/r6_${TAG}_two_streams.txt 2>> $O/r6_${TAG}.log
+      db=$(find $O/prof_$TAG -name "*.db" | head -1)
+      [ -n "$db" ] && python scripts/overlap_summary.py "$db" "round 6 $TAG: rocprofv3 --kernel-trace -- scripts/xp/bin/xp_two_streams ${rest:-27} (two cudf::sort calls on two streams, 3 repetitions + one sort alone each)" | head -150 | cut -c1-170 >> $O/r6_${TAG}_two_streams.txt
+      find $O/prof_$TAG -name "*.db" -delete
+      head -60 $O/r6_${TAG}_two_streams.txt ;;
     prof)
       wl=${rest%%:*}; extra=${rest#*:}; [ "$extra" = "$rest" ] && extra=""
       (cd /tmp && timeout 600 rocprofv3 --kernel-trace --stats -d "$ROOT/$O/prof_$TAG" -o p -- python "$ROOT/bench.py" --workload $wl --no-cpu-baseline --no-robustness --no-through-cpp $extra) > $O/r6_${TAG}_bench_under_rocprof.jsonl 2>> $O/r6_${TAG}.log
