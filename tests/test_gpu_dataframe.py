@@ -30,6 +30,42 @@ def test_sort_values_single_and_multi_key(DF):
     pd.testing.assert_frame_equal(gdf.sort_values("b", na_position="first").to_pandas(), exp, check_dtype=False)
 
 
+def test_sort_values_several_keys_one_word_sort(DF):
+    """from 2^18 rows, numeric keys without nulls: DataFrame.sort_values orders the rows with ONE word sort on the tuple
+    (ops.sorted_order_table); pandas' stable sort is the oracle, mixed directions, a float key with NaN VALUES (not nulls), ties"""
+    import pandas as pd
+    import cudf_amd
+    from cudf_amd import dataframe as dfm
+    rng = np.random.default_rng(12)
+    n = 400_003
+    assert n >= dfm._TABLE_PATH_MIN_ROWS
+    a = rng.integers(0, 40, n).astype(np.int32)
+    b = rng.integers(-3, 3, n).astype(np.int8)
+    c = rng.integers(-2**50, 2**50, n)
+    f = np.round(rng.standard_normal(n), 1)
+    v = rng.random(n)
+    gdf = DF({"a": a, "b": b, "c": c, "f": f, "v": v})
+    pdf = pd.DataFrame({"a": a, "b": b, "c": c, "f": f, "v": v})
+    calls = []
+    orig = cudf_amd.ops.sorted_order_table
+    cudf_amd.ops.sorted_order_table = lambda cols, asc=True: (calls.append(len(cols)), orig(cols, asc))[1]
+    try:
+        for by, asc in [(["a", "b"], True), (["a", "b", "c"], [True, False, True]), (["b", "f", "a"], [False, True, False]), (["f", "c"], [False, False])]:
+            exp = pdf.sort_values(by, ascending=asc, kind="stable").reset_index(drop=True)
+            got = gdf.sort_values(by, ascending=asc).to_pandas()
+            pd.testing.assert_frame_equal(got, exp, check_dtype=False)
+    finally:
+        cudf_amd.ops.sorted_order_table = orig
+    assert calls == [2, 3, 3, 2]          # the table path was the one that ran
+    # NaN values are the greatest of their column in both directions (the reference's comparator, sort_impl.cuh:61-93)
+    f2 = f.copy()
+    f2[::101] = np.nan
+    g2 = DF({"a": a, "f": f2, "v": v})
+    got = g2.sort_values(["a", "f"], ascending=[True, True]).to_pandas()
+    exp = pd.DataFrame({"a": a, "f": f2, "v": v}).sort_values(["a", "f"], ascending=True, kind="stable", na_position="last").reset_index(drop=True)
+    pd.testing.assert_frame_equal(got, exp, check_dtype=False)
+
+
 @pytest.mark.parametrize("how", ["inner", "left"])
 def test_merge_matches_pandas(DF, how):
     import pandas as pd
