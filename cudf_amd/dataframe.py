@@ -3,7 +3,7 @@ to the methods that land on it): sort_values, merge, groupby(...).agg.
 
 reference: python/cudf/cudf/core/dataframe.py (sort_values -> core/_internals/sorting.py ->
 pylibcudf.sorting.sorted_order + gather; merge -> core/join/join.py -> pylibcudf.join.inner_join /
-left_join + gather; groupby(...).agg -> core/groupby/groupby.py -> pylibcudf.groupby.aggregate).
+left_join / full_join / left_semi_join / left_anti_join + gather; groupby(...).agg -> core/groupby/groupby.py -> pylibcudf.groupby.aggregate).
 Columns are fixed-width numeric; data moves host<->device only in from_pandas / to_pandas.
 """
 from __future__ import annotations
@@ -99,9 +99,11 @@ class DataFrame:
 
     def merge(self, right: "DataFrame", on: Union[str, Sequence[str]], how: str = "inner",
               suffixes=("_x", "_y")) -> "DataFrame":
-        """Equi-join on one or several key columns; how in {"inner", "left", "leftsemi", "leftanti"}.
-        Row order is unspecified for inner / left (as in cudf); leftsemi / leftanti keep the left order."""
-        if how not in ("inner", "left", "leftsemi", "leftanti"):
+        """Equi-join on one or several key columns; how in {"inner", "left", "right", "outer", "leftsemi", "leftanti"}
+        (python/cudf/cudf/core/dataframe.py `merge`; null keys match nothing, as pandas' NaN keys do not on this path).
+        Row order is unspecified for inner / left / right / outer (as in cudf); leftsemi / leftanti keep the left order.
+        Columns: the keys, then the left frame's other columns, then the right frame's (suffixes where names collide)."""
+        if how not in ("inner", "left", "right", "outer", "leftsemi", "leftanti"):
             raise NotImplementedError(f"merge(how={how!r}) is not on this path yet")
         on = [on] if isinstance(on, str) else list(on)
         lt, rt = [self._cols[k] for k in on], [right._cols[k] for k in on]
@@ -114,21 +116,45 @@ class DataFrame:
             return self._take(fn(lk, rk, nulls_equal=False))
         if how == "inner":
             li, ri = ops.inner_join_tables(lt, rt, nulls_equal=False)
-        else:
+        elif how == "left":
             li, ri = ops.left_join_tables(lt, rt, nulls_equal=False)
+        elif how == "right":   # the left join of the swapped frames: every right row appears, li = JoinNoMatch where it has no partner
+            ri, li = ops.left_join_tables(rt, lt, nulls_equal=False)
+        else:                  # outer: the left join's pairs, then (JoinNoMatch, r) for every right row without a partner
+            li, ri = ops.left_join_tables(lt, rt, nulls_equal=False)
+            n0 = li.size           # pairs of the left join; the unmatched right rows come behind them
+            li, ri = ops._append_unmatched_right(li, ri, len(right))
+        null_l, null_r = how in ("right", "outer"), how in ("left", "outer")
         out = DataFrame()
-        for k, c in zip(on, lt):
-            out._cols[k] = ops.gather(c, li)
+        for k, lc, rc in zip(on, lt, rt):
+            if how == "right":
+                out._cols[k] = ops.gather(rc, ri)
+            elif how == "outer":
+                # the key of a pair is the left row's where there is one, else the right row's: unmatched right rows sit BEHIND the
+                # left join's pairs (one per left row or match), so the column is two gathers side by side
+                head = ops.gather(lc, _head(li, n0))
+                tail = ops.gather(rc, _tail(ri, n0))
+                out._cols[k] = ops.concat_columns(head, tail)
+            else:
+                out._cols[k] = ops.gather(lc, li)
         for name, c in self._cols.items():
             if name not in on:
-                out._cols[name + (suffixes[0] if name in right._cols else "")] = ops.gather(c, li)
+                out._cols[name + (suffixes[0] if name in right._cols else "")] = ops.gather(c, li, nullify_out_of_bounds=null_l)
         for name, c in right._cols.items():
             if name not in on:
-                out._cols[name + (suffixes[1] if name in self._cols else "")] = ops.gather(c, ri, nullify_out_of_bounds=(how == "left"))
+                out._cols[name + (suffixes[1] if name in self._cols else "")] = ops.gather(c, ri, nullify_out_of_bounds=null_r)
         return out
 
     def groupby(self, by: Union[str, Sequence[str]]) -> "GroupBy":
         return GroupBy(self, by)
+
+
+def _head(col: Column, n: int) -> Column:
+    return ops._slice_rows(col, 0, n)
+
+
+def _tail(col: Column, n: int) -> Column:
+    return ops._slice_rows(col, n, col.size)
 
 
 def _valid_from_counts(counts: Column):

@@ -454,6 +454,27 @@ def left_join(left: Column, right: Column, nulls_equal: bool = True) -> Tuple[Co
     return HashJoin(right, nulls_equal).left_join(left)
 
 
+def _append_unmatched_right(lo: Column, ro: Column, right_rows: int) -> Tuple[Column, Column]:
+    """cudf::full_join's complement step (src/join/join_utils.cu:86-157; gx_join_complement): behind the left-join pairs, one
+    (JoinNoMatch, r) pair for every right row r that occurs in no pair.  Returns the grown pair arrays."""
+    n0 = lo.size
+    ol, orr = Column.empty(np.int32, n0 + right_rows), Column.empty(np.int32, n0 + right_rows)
+    if n0:
+        L.check(_lib.gx_copy_bytes(lo.data_ptr, ol.data_ptr, n0 * 4, stream_ptr()), "gx_copy_bytes")
+        L.check(_lib.gx_copy_bytes(ro.data_ptr, orr.data_ptr, n0 * 4, stream_ptr()), "gx_copy_bytes")
+    cur = _dev_i64(n0)
+    _run(_lib.gx_join_complement, ro.data_ptr, n0, right_rows, ol.data_ptr, orr.data_ptr, n0 + right_rows, ptr(cur))
+    ol.size = orr.size = int(cur.item())
+    return ol, orr
+
+
+def full_join(left: Column, right: Column, nulls_equal: bool = True) -> Tuple[Column, Column]:
+    """cudf::full_join (join.hpp:240-246; src/join/hash_join/hash_join.cu:168-199): the left join's pairs, then every right row without
+    a partner as (JoinNoMatch, r)."""
+    lo, ro = left_join(left, right, nulls_equal)
+    return _append_unmatched_right(lo, ro, right.size)
+
+
 # ------------------------------------------------------------------------------------------------
 # multi-column keys: rows -> one fixed-width key  (gx_pack_keys / gx_dense_rank; the reference compares
 # whole rows inside its hash tables: detail/row_operator/primitive_row_operators.cuh:207-274)
@@ -701,6 +722,12 @@ def left_join_tables(left: Sequence[Column], right: Sequence[Column], nulls_equa
         return res
     lk, rk = encode_rows([left, right], nulls_equal)
     return left_join(lk, rk, nulls_equal)
+
+
+def full_join_tables(left: Sequence[Column], right: Sequence[Column], nulls_equal: bool = True):
+    """cudf::full_join on key tables: the left join of the tables + the unmatched right rows"""
+    lo, ro = left_join_tables(left, right, nulls_equal)
+    return _append_unmatched_right(lo, ro, right[0].size)
 
 
 def groupby_keys_tables(keys: Sequence[Column]):

@@ -95,6 +95,46 @@ def test_groupby_agg_matches_pandas(DF):
     np.testing.assert_array_equal(got["w_sum"], exp["w_sum"])
 
 
+@pytest.mark.parametrize("nkeys", [1, 2])
+@pytest.mark.parametrize("how", ["right", "outer"])
+def test_right_and_outer_merge_match_pandas(DF, how, nkeys):
+    """merge(how="right" / "outer") (python/cudf/cudf/core/dataframe.py merge; cudf::left_join on the swapped frames / cudf::full_join):
+    pandas is the oracle; rows compared after sorting by every column (row order of a join is unspecified)"""
+    import pandas as pd
+    rng = np.random.default_rng(21 + nkeys)
+    nl, nr = 60_000, 9_000
+    left = pd.DataFrame({"k": rng.integers(0, 7000, nl), "j": rng.integers(0, 3, nl).astype(np.int32), "x": rng.random(nl)})
+    right = pd.DataFrame({"k": rng.integers(3000, 12000, nr), "j": rng.integers(0, 3, nr).astype(np.int32), "y": rng.integers(0, 100, nr).astype(np.int64)})
+    on = ["k", "j"][:nkeys]
+    if nkeys == 1:
+        left, right = left.drop(columns="j"), right.drop(columns="j")
+    exp = left.merge(right, on=on, how=how)
+    got = DF.from_pandas(left).merge(DF.from_pandas(right), on=on, how=how).to_pandas()
+    assert list(got.columns) == list(exp.columns) and len(got) == len(exp)
+    cols = list(exp.columns)
+    exp = exp.sort_values(cols).reset_index(drop=True)
+    got = got.sort_values(cols).reset_index(drop=True)
+    pd.testing.assert_frame_equal(got, exp, check_dtype=False)
+    assert got["x"].isna().sum() == exp["x"].isna().sum() > 0      # right rows without a partner really occur
+    if how == "outer":
+        assert got["y"].isna().sum() == exp["y"].isna().sum() > 0
+
+
+def test_full_join_pairs_match_oracle(DF):
+    """ops.full_join (cudf::full_join, join.hpp:240-246): the canonical pair set against the oracle, JoinNoMatch on either side"""
+    from cudf_amd import Column, ops
+    from oracle import cudf_oracle as orc
+    rng = np.random.default_rng(5)
+    l = rng.integers(0, 5000, 40_000).astype(np.int64)
+    r = rng.integers(2500, 9000, 7_000).astype(np.int64)
+    gl, gr = ops.full_join(Column.from_numpy(l), Column.from_numpy(r))
+    el, er = orc.full_join([l], [r])
+    a = orc.canonical_pairs(gl.to_numpy().astype(np.int64), gr.to_numpy().astype(np.int64))
+    b = orc.canonical_pairs(np.asarray(el, np.int64), np.asarray(er, np.int64))
+    np.testing.assert_array_equal(a[0], b[0])
+    np.testing.assert_array_equal(a[1], b[1])
+
+
 @pytest.mark.parametrize("how", ["inner", "left"])
 def test_merge_on_two_keys_matches_pandas(DF, how):
     import pandas as pd
