@@ -171,6 +171,43 @@ std::unique_ptr<column> stable_sorted_order(table_view const& input, std::vector
   return sorted_order_impl(input, column_order, null_precedence, stream, mr);
 }
 
+// cudf::is_sorted (src/sort/is_sorted.cu:27-86).  One integer column without nulls: one streaming pass that counts the adjacent pairs
+// out of order (gx_checksum's violation count: NaN the greatest value, as the sort's comparator has it).  Everything else -- several
+// columns, nulls -- through the STABLE argsort: the rows are in order exactly when that argsort is the identity (equal rows keep
+// their places in a stable sort, and any adjacent pair out of order moves), compared with an iota on the device.
+bool is_sorted(table_view const& in, std::vector<order> const& column_order, std::vector<null_order> const& null_precedence,
+               rmm::cuda_stream_view stream)
+{
+  if (in.num_columns() == 0 || in.num_rows() == 0) return true;
+  if (!column_order.empty())
+    CUDF_EXPECTS(static_cast<std::size_t>(in.num_columns()) == column_order.size(),
+                 "Number of columns in the table doesn't match the vector column_order's size .\n");
+  if (!null_precedence.empty())
+    CUDF_EXPECTS(static_cast<std::size_t>(in.num_columns()) == null_precedence.size(),
+                 "Number of columns in the table doesn't match the vector null_precedence's size .\n");
+  auto const n = in.num_rows();
+  // (integers only: the streaming pass orders floats by their bit image, where -0.0 < +0.0 and NaNs differ -- the comparator has them equal)
+  if (in.num_columns() == 1 && !in.column(0).has_nulls() && table_path_column(in.column(0)) && !is_floating_point(in.column(0).type())) {
+    auto const& c  = in.column(0);
+    int const desc = (!column_order.empty() && column_order[0] == order::DESCENDING) ? 1 : 0;
+    rmm::device_uvector<uint64_t> res(3, stream);
+    detail::gx_check(gx_checksum(detail::gx_type(c.type()), detail::row0(c), n, desc, res.data(), detail::gxs(stream)), "is_sorted");
+    uint64_t h[3] = {0, 0, 0};
+    CUDF_CUDA_TRY(hipMemcpyAsync(h, res.data(), sizeof(h), hipMemcpyDeviceToHost, stream.value()));
+    stream.synchronize();
+    return h[2] == 0;
+  }
+  auto const ord = stable_sorted_order(in, column_order, null_precedence, stream, cudf::get_current_device_resource_ref());
+  rmm::device_uvector<int32_t> iota(n, stream);
+  detail::gx_check(gx_sequence_i32(iota.data(), n, 0, detail::gxs(stream)), "is_sorted");
+  rmm::device_uvector<int64_t> bad(1, stream);
+  void const* l[1] = {ord->view().head<int32_t>()};
+  void const* r[1] = {iota.data()};
+  int const dt[1]  = {GX_INT32};
+  detail::gx_check(gx_rows_mismatch_count(1, l, r, dt, nullptr, nullptr, n, bad.data(), detail::gxs(stream)), "is_sorted");
+  return detail::read_i64(bad.data(), stream) == 0;
+}
+
 std::unique_ptr<table> sort_by_key(table_view const& values, table_view const& keys,
                                    std::vector<order> const& column_order,
                                    std::vector<null_order> const& null_precedence, rmm::cuda_stream_view stream,

@@ -24,6 +24,11 @@ std::unique_ptr<column> stable_sorted_order(table_view const& input, std::vector
                                             rmm::cuda_stream_view stream      = cudf::get_default_stream(),
                                             rmm::device_async_resource_ref mr = cudf::get_current_device_resource_ref());
 
+// whether the rows of `table` are in the given lexicographic order (cpp/include/cudf/sorting.hpp:83-86; src/sort/is_sorted.cu:27-86):
+// empty `column_order` = all ascending, empty `null_precedence` = nulls before; no columns or no rows -> true
+bool is_sorted(table_view const& table, std::vector<order> const& column_order, std::vector<null_order> const& null_precedence,
+               rmm::cuda_stream_view stream = cudf::get_default_stream());
+
 // new table with the rows of `input` in sorted order
 std::unique_ptr<table> sort(table_view const& input, std::vector<order> const& column_order = {},
                             std::vector<null_order> const& null_precedence = {},

@@ -1577,6 +1577,68 @@ int main()
     CHECK(hs == k);
   });
 
+  run("is_sorted (sorting.hpp:83-86; is_sorted_tests.cpp:273-466, the fixed-width numeric cases)", [] {
+    using O = cudf::order;
+    using N = cudf::null_order;
+    auto check_type = [](auto tag) {
+      using T = decltype(tag);
+      std::vector<T> asc = std::is_signed_v<T> ? std::vector<T>{std::numeric_limits<T>::lowest(), T(-100), T(-10), T(-1), T(0), T(1), T(10), T(100), std::numeric_limits<T>::max()}
+                                               : std::vector<T>{std::numeric_limits<T>::lowest(), T(0), T(1), T(10), T(100), std::numeric_limits<T>::max()};
+      std::vector<T> desc(asc.rbegin(), asc.rend());
+      auto a = make_col<T>(asc);
+      auto d = make_col<T>(desc);
+      CHECK(is_sorted(table_view{{a->view()}}, {O::ASCENDING}, {}));      // :299-311 Ascending
+      CHECK(!is_sorted(table_view{{d->view()}}, {O::ASCENDING}, {}));     // :313-326 AscendingFalse
+      CHECK(is_sorted(table_view{{d->view()}}, {O::DESCENDING}, {}));     // :328-340 Descending
+      CHECK(!is_sorted(table_view{{a->view()}}, {O::DESCENDING}, {}));    // :342-355 DescendingFalse
+      auto na = make_col<T>({T(0), T(0)}, {1, 0});                        // nulls_after  :73-77
+      auto nb = make_col<T>({T(0), T(0)}, {0, 1});                        // nulls_before :79-83
+      CHECK(is_sorted(table_view{{na->view()}}, {}, {N::AFTER}));         // :357-369
+      CHECK(!is_sorted(table_view{{nb->view()}}, {}, {N::AFTER}));        // :371-383
+      CHECK(is_sorted(table_view{{nb->view()}}, {}, {N::BEFORE}));        // :385-397
+      CHECK(!is_sorted(table_view{{na->view()}}, {}, {N::BEFORE}));       // :399-411
+      CHECK(throws<cudf::logic_error>([&] { (void)is_sorted(table_view{{a->view(), a->view()}}, {O::ASCENDING}, {}); }));             // :413-424 OrderArgsTooFew
+      CHECK(throws<cudf::logic_error>([&] { (void)is_sorted(table_view{{a->view()}}, {O::ASCENDING, O::ASCENDING}, {}); }));           // :426-436
+      CHECK(throws<cudf::logic_error>([&] { (void)is_sorted(table_view{{nb->view(), nb->view()}}, {}, {N::BEFORE}); }));               // :438-449
+      CHECK(throws<cudf::logic_error>([&] { (void)is_sorted(table_view{{nb->view()}}, {}, {N::BEFORE, N::BEFORE}); }));                // :451-461
+      auto e = make_col<T>({});
+      CHECK(is_sorted(table_view{{e->view(), e->view()}}, {O::ASCENDING, O::DESCENDING}, {}));   // :281-297 NoRows
+    };
+    check_type(int8_t{});
+    check_type(int32_t{});
+    check_type(int64_t{});
+    check_type(uint16_t{});
+    check_type(uint64_t{});
+    check_type(float{});
+    check_type(double{});
+    CHECK(is_sorted(table_view{std::vector<column_view>{}}, {}, {}));       // :273-279 NoColumns
+    // floats: -0.0 and +0.0 are equal, NaN is the greatest value and every NaN equals every other (the sort's comparator)
+    double const nan = std::numeric_limits<double>::quiet_NaN();
+    auto f = make_col<double>({-1.0, 0.0, -0.0, 0.0, 3.5, nan, -nan});
+    CHECK(is_sorted(table_view{{f->view()}}, {O::ASCENDING}, {}));
+    auto g = make_col<double>({-1.0, nan, 3.5});
+    CHECK(!is_sorted(table_view{{g->view()}}, {O::ASCENDING}, {}));
+    // two columns, mixed directions; then a tie in the first column broken the wrong way by the second
+    auto c1 = make_col<int32_t>({1, 1, 2, 2, 3});
+    auto c2 = make_col<int64_t>({9, 7, 5, 5, 0});
+    CHECK(is_sorted(table_view{{c1->view(), c2->view()}}, {O::ASCENDING, O::DESCENDING}, {}));
+    CHECK(!is_sorted(table_view{{c1->view(), c2->view()}}, {O::ASCENDING, O::ASCENDING}, {}));
+    // at size: a sorted column with ties; one pair swapped far inside
+    std::vector<int64_t> big(3'000'001);
+    for (std::size_t i = 0; i < big.size(); ++i) big[i] = static_cast<int64_t>(i / 3) - 500'000;
+    auto b1 = make_col<int64_t>(big);
+    CHECK(is_sorted(table_view{{b1->view()}}, {}, {}));
+    std::swap(big[2'000'000], big[2'000'003]);
+    auto b2 = make_col<int64_t>(big);
+    CHECK(!is_sorted(table_view{{b2->view()}}, {}, {}));
+    std::vector<int> valid(big.size(), 1);
+    valid[0] = valid[1] = 0;
+    std::swap(big[2'000'000], big[2'000'003]);
+    auto b3 = make_col<int64_t>(big, valid);
+    CHECK(is_sorted(table_view{{b3->view()}}, {}, {N::BEFORE}));
+    CHECK(!is_sorted(table_view{{b3->view()}}, {}, {N::AFTER}));
+  });
+
   run("two sorts on two streams are queued back to back: cudf::sort does not wait for the device (sort.cu:52-89)", [] {
     // 2^26 random int64 keys per stream (cursor path).  Both calls are issued from one host thread without any synchronisation in
     // between; the host time of the two calls must be a fraction of the device time of the two sorts (round 5 read a status word
