@@ -102,4 +102,31 @@ std::pair<std::unique_ptr<table>, std::vector<size_type>> partition(table_view c
   return regroup(t, ids.data(), num_partitions, stream, mr);
 }
 
+// cudf::round_robin_partition (src/partitioning/round_robin.cu:150-275): the reference computes the gather map in closed form; here
+// the partition ids (start_partition + i, taken modulo num_partitions by the regrouping kernels) go through the same stable regrouping
+// as cudf::partition -- rows of a partition in input order, as dealing cards leaves them
+std::pair<std::unique_ptr<table>, std::vector<size_type>> round_robin_partition(table_view const& input, size_type num_partitions,
+                                                                               size_type start_partition, rmm::cuda_stream_view stream,
+                                                                               rmm::device_async_resource_ref mr)
+{
+  CUDF_EXPECTS(num_partitions > 0, "Incorrect number of partitions. Must be greater than 0.");
+  CUDF_EXPECTS(start_partition < num_partitions, "Incorrect start_partition index. Must be less than number of partitions.");
+  CUDF_EXPECTS(start_partition >= 0, "Incorrect start_partition index. Must be positive.");
+  auto const n = input.num_rows();
+  if (n == 0) return {empty_like_table(input), std::vector<size_type>(static_cast<std::size_t>(num_partitions) + 1, 0)};
+  if (input.num_columns() == 0) {  // no column to move: the offsets alone (round_robin_test.cpp:32-42)
+    std::vector<size_type> offs(static_cast<std::size_t>(num_partitions) + 1, 0);
+    for (size_type p = 0; p < num_partitions; ++p) {
+      // rows i with (start + i) % P == p: i = (p - start) mod P, then every P-th
+      size_type const first = ((p - start_partition) % num_partitions + num_partitions) % num_partitions;
+      offs[p + 1]           = offs[p] + (first < n ? (n - first + num_partitions - 1) / num_partitions : 0);
+    }
+    return {std::make_unique<table>(input, stream, mr), std::move(offs)};
+  }
+  rmm::device_uvector<int32_t> ids(n, stream);
+  detail::gx_check(gx_sequence_i32(ids.data(), n, start_partition, detail::gxs(stream)), "round_robin_partition");
+  // (start_partition + i < 2^32: as uint32 the sum is exact even where the int32 wrapped)
+  return regroup(input, reinterpret_cast<uint32_t const*>(ids.data()), num_partitions, stream, mr);
+}
+
 }  // namespace cudf

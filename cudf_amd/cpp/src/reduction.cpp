@@ -305,6 +305,16 @@ std::unique_ptr<column> scan(column_view const& input, scan_aggregation const& a
   return out;
 }
 
+// cudf::minmax (src/reductions/minmax.cu:214-257): the reference folds (min, max) pairs in one pass; here the two reductions of the
+// hot path back to back -- the second reads what the first left in the Infinity Cache for columns up to its size
+std::pair<std::unique_ptr<scalar>, std::unique_ptr<scalar>> minmax(column_view const& col, rmm::cuda_stream_view stream,
+                                                                   rmm::device_async_resource_ref mr)
+{
+  auto lo = reduce(col, *make_min_aggregation<reduce_aggregation>(), col.type(), stream, mr);
+  auto hi = reduce(col, *make_max_aggregation<reduce_aggregation>(), col.type(), stream, mr);
+  return {std::move(lo), std::move(hi)};
+}
+
 namespace hashing {
 std::unique_ptr<column> murmurhash3_x86_32(table_view const& input, uint32_t seed, rmm::cuda_stream_view stream,
                                            rmm::device_async_resource_ref mr)

@@ -30,8 +30,9 @@ std::pair<std::unique_ptr<table>, std::vector<size_type>> partition(
 // % P otherwise (partitioning.cu:53-92, 620-665).  ALWAYS num_partitions + 1 offsets, the last one = number of output rows --
 // also for an empty input, no key columns or num_partitions == 0, which return empty_like(input) and zeros
 // (partitioning.cu:883-886; tests/partitioning/hash_partition_test.cpp:73-141).  An invalid column index throws
-// std::out_of_range (partitioning.hpp:91).  hash_function: HASH_MURMUR3, or HASH_IDENTITY over ONE INT32 / UINT32 key column
-// (a column of precomputed row hashes: hash_partition_test.cpp:411-415).
+// std::out_of_range (partitioning.hpp:91).  hash_function: HASH_MURMUR3, or HASH_IDENTITY over any numeric key table
+// (the element cast to uint32, partitioning.cu:852-889; the reference's own use: a column of precomputed row hashes,
+// hash_partition_test.cpp:411-415).
 std::pair<std::unique_ptr<table>, std::vector<size_type>> hash_partition(
   table_view const& input, std::vector<size_type> const& columns_to_hash, int num_partitions,
   hash_id hash_function = hash_id::HASH_MURMUR3, uint32_t seed = DEFAULT_HASH_SEED,
@@ -44,5 +45,12 @@ std::pair<std::unique_ptr<table>, std::vector<size_type>> hash_partition(
   table_view const& input, table_view const& keys, int num_partitions, hash_id hash_function = hash_id::HASH_MURMUR3,
   uint32_t seed = DEFAULT_HASH_SEED, rmm::cuda_stream_view stream = cudf::get_default_stream(),
   rmm::device_async_resource_ref mr = cudf::get_current_device_resource_ref());
+
+// Round-robin partitioning (partitioning.hpp:287-292; src/partitioning/round_robin.cu:150-275): row i goes to partition
+// (start_partition + i) % num_partitions, the rows of a partition keep their order; num_partitions + 1 offsets.  num_partitions <= 0,
+// start_partition outside [0, num_partitions) throw cudf::logic_error (round_robin.cu:160-166).
+std::pair<std::unique_ptr<table>, std::vector<size_type>> round_robin_partition(
+  table_view const& input, size_type num_partitions, size_type start_partition = 0,
+  rmm::cuda_stream_view stream = cudf::get_default_stream(), rmm::device_async_resource_ref mr = cudf::get_current_device_resource_ref());
 
 }  // namespace cudf

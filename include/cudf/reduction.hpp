@@ -9,6 +9,7 @@
 #include <functional>
 #include <memory>
 #include <optional>
+#include <utility>
 
 namespace cudf {
 
@@ -29,6 +30,12 @@ std::unique_ptr<scalar> reduce(column_view const& col, reduce_aggregation const&
                                std::optional<std::reference_wrapper<scalar const>> init,
                                rmm::cuda_stream_view stream      = cudf::get_default_stream(),
                                rmm::device_async_resource_ref mr = cudf::get_current_device_resource_ref());
+
+// minimum and maximum of a column in one call (reduction.hpp:247-250; src/reductions/minmax.cu): scalars of the column's type, nulls
+// skipped, both invalid when there is no valid element
+std::pair<std::unique_ptr<scalar>, std::unique_ptr<scalar>> minmax(
+  column_view const& col, rmm::cuda_stream_view stream = cudf::get_default_stream(),
+  rmm::device_async_resource_ref mr = cudf::get_current_device_resource_ref());
 
 // prefix SUM / MIN / MAX / PRODUCT; output type == input type (integers wrap).
 // null_policy::EXCLUDE: nulls are skipped and stay null; INCLUDE: the first null poisons the rest.

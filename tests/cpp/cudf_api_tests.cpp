@@ -1577,6 +1577,73 @@ int main()
     CHECK(hs == k);
   });
 
+  run("round_robin_partition: the nine documented examples (partitioning.hpp:183-275), errors (round_robin.cu:160-166); minmax (reduction_tests.cpp:122-243)", [] {
+    auto iota = [](int n) { std::vector<int32_t> v(n); std::iota(v.begin(), v.end(), 0); return v; };
+    struct Ex { int rows, parts, start; std::vector<int32_t> table; std::vector<size_type> offsets; };
+    std::vector<Ex> const ex = {
+      {13, 3, 0, {0, 3, 6, 9, 12, 1, 4, 7, 10, 2, 5, 8, 11}, {0, 5, 9, 13}},
+      {13, 3, 1, {2, 5, 8, 11, 0, 3, 6, 9, 12, 1, 4, 7, 10}, {0, 4, 9, 13}},
+      {11, 3, 0, {0, 3, 6, 9, 1, 4, 7, 10, 2, 5, 8}, {0, 4, 8, 11}},
+      {11, 3, 1, {2, 5, 8, 0, 3, 6, 9, 1, 4, 7, 10}, {0, 3, 7, 11}},
+      {11, 3, 2, {1, 4, 7, 10, 2, 5, 8, 0, 3, 6, 9}, {0, 4, 7, 11}},
+      {11, 15, 2, {0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 10}, {0, 0, 0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11, 11, 11}},
+      {11, 15, 10, {5, 6, 7, 8, 9, 10, 0, 1, 2, 3, 4}, {0, 1, 2, 3, 4, 5, 6, 6, 6, 6, 6, 7, 8, 9, 10, 11}},
+      {11, 15, 14, {1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 0}, {0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 10, 10, 10, 10, 11}},
+      {11, 11, 2, {9, 10, 0, 1, 2, 3, 4, 5, 6, 7, 8}, {0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11}},
+    };
+    for (auto const& e : ex) {
+      auto c = make_col<int32_t>(iota(e.rows));
+      std::vector<double> dv(e.rows);
+      for (int i = 0; i < e.rows; ++i) dv[i] = 0.5 * i;
+      auto d = make_col<double>(dv);
+      auto [t, offs] = round_robin_partition(table_view{{c->view(), d->view()}}, e.parts, e.start);
+      CHECK(offs == e.offsets);
+      CHECK(to_host<int32_t>(t->get_column(0).view()) == e.table);
+      auto hd = to_host<double>(t->get_column(1).view());
+      for (int i = 0; i < e.rows; ++i) CHECK(hd[i] == 0.5 * e.table[i]);
+    }
+    auto c = make_col<int32_t>(iota(5));
+    auto e0 = make_col<int32_t>({});
+    auto [te, oe] = round_robin_partition(table_view{{e0->view()}}, 5, 0);              // round_robin_test.cpp:44-55 EmptyInput
+    CHECK(te->num_rows() == 0 && oe.size() == 6);
+    CHECK(throws<cudf::logic_error>([&] { (void)round_robin_partition(table_view{{c->view()}}, 0, 0); }));
+    CHECK(throws<cudf::logic_error>([&] { (void)round_robin_partition(table_view{{c->view()}}, 3, 3); }));
+    CHECK(throws<cudf::logic_error>([&] { (void)round_robin_partition(table_view{{c->view()}}, 3, -1); }));
+    // at size: against the closed form
+    int const n = 1'000'003, P = 37, S = 11;
+    auto big = make_col<int32_t>(iota(n));
+    auto [tb, ob] = round_robin_partition(table_view{{big->view()}}, P, S);
+    auto hb = to_host<int32_t>(tb->get_column(0).view());
+    std::size_t pos = 0;
+    bool ok = ob.size() == static_cast<std::size_t>(P) + 1 && ob.back() == n;
+    for (int p = 0; p < P && ok; ++p) {
+      ok = ok && static_cast<std::size_t>(ob[p]) == pos;
+      for (int i = ((p - S) % P + P) % P; i < n; i += P) ok = ok && hb[pos++] == i;
+    }
+    CHECK(ok);
+    // minmax: reduction_tests.cpp:125-243 (values, the null mask of the test, an all-null column)
+    std::vector<int> iv{5, 0, -120, -111, 0, 64, 63, 99, 123, -16};
+    std::vector<int> valid{1, 1, 0, 1, 1, 1, 0, 1, 0, 1};
+    auto mm_check = [&](auto tag) {
+      using T = decltype(tag);
+      std::vector<T> v(iv.begin(), iv.end());
+      auto col = make_col<T>(v);
+      auto [lo, hi] = cudf::minmax(col->view());
+      CHECK(lo->is_valid() && hi->is_valid());
+      CHECK(static_cast<numeric_scalar<T>*>(lo.get())->value() == T(-120) && static_cast<numeric_scalar<T>*>(hi.get())->value() == T(123));
+      auto coln = make_col<T>(v, valid);
+      auto [ln, hn] = cudf::minmax(coln->view());
+      CHECK(static_cast<numeric_scalar<T>*>(ln.get())->value() == T(-111) && static_cast<numeric_scalar<T>*>(hn.get())->value() == T(99));
+      auto colz = make_col<T>(v, std::vector<int>(v.size(), 0));
+      auto [lz, hz] = cudf::minmax(colz->view());
+      CHECK(!lz->is_valid() && !hz->is_valid());
+    };
+    mm_check(int32_t{});
+    mm_check(int64_t{});
+    mm_check(double{});
+    mm_check(float{});
+  });
+
   run("is_sorted (sorting.hpp:83-86; is_sorted_tests.cpp:273-466, the fixed-width numeric cases)", [] {
     using O = cudf::order;
     using N = cudf::null_order;
