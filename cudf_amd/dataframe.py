@@ -204,6 +204,34 @@ class GroupBy:
     def __init__(self, df: DataFrame, by: Union[str, Sequence[str]]):
         self._df, self._by = df, ([by] if isinstance(by, str) else list(by))
 
+    def _all(self, fn: str) -> DataFrame:
+        """fn over every column that is not a key (python/cudf/cudf/core/groupby/groupby.py: GroupBy.sum / mean / ... = agg(fn))"""
+        vals = [c for c in self._df.columns if c not in self._by]
+        if not vals:
+            raise ValueError("groupby: no value columns to aggregate")
+        return self.agg({c: fn for c in vals})
+
+    def sum(self) -> DataFrame:
+        return self._all("sum")
+
+    def count(self) -> DataFrame:
+        return self._all("count")
+
+    def mean(self) -> DataFrame:
+        return self._all("mean")
+
+    def min(self) -> DataFrame:
+        return self._all("min")
+
+    def max(self) -> DataFrame:
+        return self._all("max")
+
+    def var(self) -> DataFrame:
+        return self._all("var")
+
+    def std(self) -> DataFrame:
+        return self._all("std")
+
     def agg(self, spec: Dict[str, Union[str, Sequence[str]]], _exact: bool = False) -> DataFrame:
         """{value column: "sum" | "count" | "mean" | "min" | "max" | "var" | "std" | [..]} -> one row per group, sorted by key
         (pandas' default sort=True).  Null keys are dropped (dropna=True), null values are skipped."""

@@ -184,6 +184,21 @@ def test_groupby_on_two_keys_and_float_key_matches_pandas(DF):
         np.testing.assert_array_equal(got["w_count"], exp["w_count"])
 
 
+def test_groupby_shorthands_match_pandas(DF):
+    """GroupBy.sum / count / mean / min / max / var / std over every value column (core/groupby/groupby.py)"""
+    import pandas as pd
+    rng = np.random.default_rng(31)
+    n = 150_000
+    pdf = pd.DataFrame({"k": rng.integers(0, 900, n).astype(np.int32), "x": rng.random(n), "y": rng.integers(-50, 50, n).astype(np.int64)})
+    g = DF.from_pandas(pdf).groupby("k")
+    p = pdf.groupby("k")
+    for fn in ("sum", "count", "mean", "min", "max", "var", "std"):
+        exp = getattr(p, fn)().reset_index()
+        got = getattr(g, fn)().to_pandas()
+        assert list(got.columns) == list(exp.columns)
+        pd.testing.assert_frame_equal(got, exp, check_dtype=False, rtol=1e-12, atol=1e-12)
+
+
 def test_import_cudf_from_pandas(DF):
     """`import cudf; cudf.from_pandas(pdf).sort_values(...)` -- the reference's module-level entry point on this path."""
     import cudf
